@@ -1,0 +1,126 @@
+"""ctypes binding of libfdhip.so (the C ABI in include/fdhip.h).
+
+This is the thin layer the north star asks for: Python host code reaches the HIP
+kernels through plain C entry points, the way pyop2/global_kernel.py:443-456 reaches
+its JIT-compiled wrapper through ``ctypes.CDLL``.  There is no CPU fallback: if the
+library (or a GPU) is missing, calls raise :class:`FDHipError`.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64,
+                    c_size_t, c_uint16, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfdhip.so")
+
+
+class FDHipError(RuntimeError):
+    """Raised for every non-zero status from libfdhip.so (cf. pyop2 CompilationError /
+    the reference's practice of surfacing failures as Python exceptions)."""
+
+
+_lib = None
+
+# name -> (restype, argtypes); must list EVERY symbol declared in include/fdhip.h
+SIGNATURES = {
+    "fd_version": (c_int, []),
+    "fd_last_error": (c_char_p, []),
+    "fd_device_count": (c_int, [POINTER(c_int)]),
+    "fd_set_device": (c_int, [c_int]),
+    "fd_device_info": (c_int, [c_int, c_char_p, c_size_t, POINTER(c_int), POINTER(c_size_t), POINTER(c_int)]),
+    "fd_malloc": (c_int, [POINTER(c_void_p), c_size_t]),
+    "fd_free": (c_int, [c_void_p]),
+    "fd_memset": (c_int, [c_void_p, c_int, c_size_t, c_void_p]),
+    "fd_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "fd_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "fd_memcpy_d2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "fd_stream_create": (c_int, [POINTER(c_void_p)]),
+    "fd_stream_destroy": (c_int, [c_void_p]),
+    "fd_stream_sync": (c_int, [c_void_p]),
+    "fd_device_sync": (c_int, []),
+    "fd_event_create": (c_int, [POINTER(c_void_p)]),
+    "fd_event_destroy": (c_int, [c_void_p]),
+    "fd_event_record": (c_int, [c_void_p, c_void_p]),
+    "fd_event_sync": (c_int, [c_void_p]),
+    "fd_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
+    "fd_kernel_load": (c_int, [c_char_p, c_char_p, POINTER(c_void_p)]),
+    "fd_kernel_builtin": (c_int, [c_char_p, POINTER(c_void_p)]),
+    "fd_kernel_free": (c_int, [c_void_p]),
+    "fd_kernel_launch": (c_int, [c_void_p, c_int32, c_int32, POINTER(c_void_p), c_int, c_int, c_int, c_int,
+                                 c_size_t, c_void_p]),
+    "fd_plan_create": (c_int, [c_void_p, c_int, c_int32, c_int32, c_int, c_void_p, POINTER(c_void_p)]),
+    "fd_plan_info": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int64)]),
+    "fd_plan_arrays": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
+    "fd_plan_free": (c_int, [c_void_p]),
+    "fd_csr_from_maps": (c_int, [c_int32, c_int32, c_int, c_int, POINTER(c_void_p), POINTER(c_void_p),
+                                 POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
+                                 POINTER(c_void_p), POINTER(c_void_p),
+                                 POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_void_p]),
+    "fd_csr_expand_blocks": (c_int, [c_int32, c_void_p, c_void_p, c_int, c_int, POINTER(c_void_p),
+                                     POINTER(c_void_p), c_void_p]),
+    "fd_csr_elem_offsets": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int, c_int, c_void_p, c_void_p]),
+    "fd_csr_set_diagonal": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_double, c_void_p]),
+    "fd_csr_zero_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_double, c_void_p]),
+    "fd_csr_spmv": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fd_halo_pack": (c_int, [c_void_p, c_int, c_void_p, c_int32, c_void_p, c_void_p]),
+    "fd_halo_unpack": (c_int, [c_void_p, c_int, c_void_p, c_int32, c_void_p, c_int, c_void_p]),
+    "fd_dat_set_rows": (c_int, [c_void_p, c_int, c_void_p, c_int32, c_double, c_void_p]),
+    "fd_dat_copy_rows": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int32, c_void_p]),
+}
+
+
+def load():
+    """dlopen libfdhip.so (after torch, so both share one HIP runtime) and type every symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FDHipError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "or `make -C firedrake_amd/csrc`")
+    try:
+        import torch  # noqa: F401  (loads libamdhip64 first; our NEEDED entry then binds to the same copy)
+    except Exception:
+        pass
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != 0:
+        msg = load().fd_last_error()
+        raise FDHipError(f"libfdhip status {status}: {msg.decode() if msg else '?'}")
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args))
+
+
+_gpu_ok = None
+
+
+def require_gpu():
+    """Fail loudly when there is no MI355X to run on (no CPU fallback anywhere)."""
+    global _gpu_ok
+    if _gpu_ok is None:
+        n = c_int(0)
+        try:
+            st = load().fd_device_count(byref(n))
+        except FDHipError:
+            raise
+        _gpu_ok = (st == 0 and n.value > 0)
+    if not _gpu_ok:
+        raise FDHipError("no HIP device visible: the firedrake_amd compute path needs an MI355X "
+                         "(there is deliberately no CPU fallback)")
+    return True
+
+
+def gpu_available():
+    try:
+        return require_gpu()
+    except FDHipError:
+        return False

@@ -1,0 +1,402 @@
+"""Wrapper code generation: GlobalKernel -> HIP kernel source for gfx950.
+
+This is the backend's counterpart of pyop2/codegen/builder.py (WrapperBuilder,
+DatPack/GlobalPack/MatPack) + pyop2/codegen/rep2loopy.py:409-593.  The reference turns
+the pack / call / unpack description into one sequential C loop per MPI rank; here the same
+description becomes a HIP kernel built from the hand-written device pieces in
+csrc/fd_wrapper.h.  Two shapes are emitted:
+
+``staged``  (the fast path; SURVEY.md 8a rows a2+a3)
+    one workgroup per block of iteration-set entities (fd_plan_*).  The distinct Dat rows
+    the block touches are gathered once -- coalesced over the block's sorted node list --
+    into LDS; one lane per entity reads its element pack from LDS through a uint16 local
+    map, calls the local kernel in registers, and reduces INC contributions in LDS
+    (ds_add_f64); the block then issues ONE global atomic per distinct node.
+    Eligible when every indirect Dat is READ or INC, not extruded, no subset.
+
+``direct``  (always available)
+    one lane per entity (x layer), gather/scatter straight from global memory with
+    hardware atomics.  Covers RW/WRITE/MIN/MAX through maps, subsets, extruded columns
+    (builder.py:94-124, 790-831), permuted maps (builder.py:144-176), integer Dats.
+
+Matrix arguments (MatPack, builder.py:520-625) are scattered into the device CSR with
+fp64 atomics, locating each entry either through the precomputed element->nonzero table
+(fd_csr_elem_offsets) or by row search; BC-masked lgmaps drop rows/cols exactly as PETSc
+drops negative indices (parloop.py:279-302).
+
+The kernel's parameter list starts with the reference's own positional list
+(builder.py:962-981): start, end, [layers], [subset_indices], one pointer per
+Dat/Global/Mat, one pointer per distinct Map; backend-private tables follow.
+"""
+from __future__ import annotations
+
+import re
+from dataclasses import dataclass, field
+from typing import List
+
+import numpy as np
+
+from .configuration import configuration
+from .kernel import (DatKernelArg, GlobalKernel, GlobalKernelArg, MatKernelArg, PassthroughKernelArg,
+                     PermutedMapKernelArg)
+from .op2types import (ALL, INC, MAX, MIN, ON_BOTTOM, ON_INTERIOR_FACETS, ON_TOP, READ, RW, WRITE)
+
+CTYPE = {np.dtype("float64"): "double", np.dtype("float32"): "float", np.dtype("int32"): "int",
+         np.dtype("uint32"): "unsigned int", np.dtype("int64"): "long long", np.dtype("uint64"): "unsigned long long"}
+
+STAGEABLE_INC = {np.dtype("float64"), np.dtype("float32"), np.dtype("int32"), np.dtype("uint32")}
+
+
+@dataclass
+class WrapperSource:
+    source: str
+    symbol: str
+    mode: str
+    layout: List[tuple]                                   # kernel parameters after (start, end)
+    nmaps: int
+    staged_maps: List[int] = field(default_factory=list)  # distinct-map indices that need a plan
+    lds_items: List[tuple] = field(default_factory=list)  # (map index, elements per node, itemsize)
+    layer_parallel: bool = True
+    block_threads: int = 256
+
+
+def _distinct_maps(gk: GlobalKernel):
+    """Distinct base maps in first-use order (global_kernel.py:309-314, parloop.py:210-212)."""
+    order, index = [], {}
+    for a in gk.arguments:
+        for m in getattr(a, "maps", ()):
+            base = m.base_map if isinstance(m, PermutedMapKernelArg) else m
+            if id(base) not in index:
+                index[id(base)] = len(order)
+                order.append(base)
+    return order, index
+
+
+def select_mode(gk: GlobalKernel) -> str:
+    want = configuration["mode"]
+    ok = staged_eligible(gk)
+    if want == "staged" and not ok:
+        raise ValueError("FDHIP_MODE=staged but this parloop is not eligible for the staged wrapper")
+    if want == "direct":
+        return "direct"
+    return "staged" if ok else "direct"
+
+
+def staged_eligible(gk: GlobalKernel) -> bool:
+    if gk._extruded or gk._subset:
+        return False
+    n_ind = 0
+    for a, la in zip(gk.arguments, gk.local_kernel.arguments):
+        if isinstance(a, DatKernelArg) and a.is_indirect:
+            n_ind += 1
+            if a.index is not None:
+                return False
+            if la.access == READ:
+                continue
+            if la.access == INC and la.dtype in STAGEABLE_INC:
+                continue
+            return False
+    return n_ind > 0
+
+
+def _hoist_includes(code: str):
+    inc = re.findall(r"^\s*#\s*include[^\n]*$", code, flags=re.M)
+    body = re.sub(r"^\s*#\s*include[^\n]*$", "", code, flags=re.M)
+    return inc, body
+
+
+def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
+    lk = gk.local_kernel
+    maps, map_index = _distinct_maps(gk)
+    staged = mode == "staged"
+    extruded = gk._extruded
+    region = gk._iteration_region
+    ih = extruded and region == ON_INTERIOR_FACETS
+    nf = 2 if ih else 1
+    threads = configuration["block_threads"]
+
+    params: List[str] = []
+    layout: List[tuple] = []
+
+    def P(decl, desc):
+        params.append(decl)
+        layout.append(desc)
+
+    if extruded:
+        P("const int *__restrict__ layers", ("layers",))
+    if gk._subset:
+        P("const int *__restrict__ subset_indices", ("subset",))
+
+    # ---- classify arguments
+    infos = []
+    for k, (a, la) in enumerate(zip(gk.arguments, lk.arguments)):
+        ct = CTYPE[np.dtype(la.dtype)]
+        info = {"k": k, "arg": a, "acc": la.access, "ct": ct, "dtype": np.dtype(la.dtype)}
+        if isinstance(a, DatKernelArg):
+            info["kind"] = "dat"
+            info["c"] = int(np.prod(a.dim))
+            if a.is_indirect:
+                m = a.map_
+                base = m.base_map if isinstance(m, PermutedMapKernelArg) else m
+                info["m"] = map_index[id(base)]
+                info["ar"] = base.arity
+                info["perm"] = tuple(m.permutation) if isinstance(m, PermutedMapKernelArg) else None
+                info["off"] = base.offset if extruded else None
+        elif isinstance(a, GlobalKernelArg):
+            info["kind"] = "global"
+            info["n"] = int(np.prod(a.dim))
+        elif isinstance(a, MatKernelArg):
+            info["kind"] = "mat"
+            (rdim, cdim) = a.dims
+            info["rbs"], info["cbs"] = int(np.prod(rdim)), int(np.prod(cdim))
+            rm, cm = a.maps
+            info["rm"], info["cm"] = map_index[id(rm)], map_index[id(cm)]
+            info["ar"], info["ac"] = rm.arity, cm.arity
+            info["roff"] = rm.offset if extruded else None
+            info["coff"] = cm.offset if extruded else None
+            if la.access not in (INC, WRITE):
+                raise ValueError("Mat arguments must be INC or WRITE")
+        elif isinstance(a, PassthroughKernelArg):
+            info["kind"] = "pass"
+        else:
+            raise TypeError(f"unsupported kernel argument {a!r}")
+        infos.append(info)
+
+    for info in infos:
+        k, ct = info["k"], info["ct"]
+        const = "const " if info["acc"] == READ and info["kind"] != "mat" else ""
+        P(f"{const}{ct} *__restrict__ arg{k}" if info["kind"] != "pass" else f"void *arg{k}", ("arg", k))
+    for mi in range(len(maps)):
+        P(f"const int *__restrict__ map{mi}", ("map", mi))
+
+    # ---- backend-private parameters
+    P("long long epb_", ("epb",))
+    staged_maps = []
+    lds_items = []
+    if staged:
+        for info in infos:
+            if info["kind"] == "dat" and "m" in info and info["m"] not in staged_maps:
+                staged_maps.append(info["m"])
+        for mi in staged_maps:
+            P(f"const int *__restrict__ p{mi}_blkoff", ("plan_blkoff", mi))
+            P(f"const int *__restrict__ p{mi}_list", ("plan_list", mi))
+            P(f"const unsigned short *__restrict__ p{mi}_lmap", ("plan_lmap", mi))
+            P(f"long long p{mi}_maxnd", ("plan_maxnd", mi))
+    use_table = {}
+    for info in infos:
+        if info["kind"] != "mat":
+            continue
+        k = info["k"]
+        table = (configuration["mat_scatter"] == "table") and not extruded
+        use_table[k] = table
+        if table:
+            P(f"const int *__restrict__ tab{k}", ("mat_table", k))
+            if info["rbs"] * info["cbs"] != 1:
+                P(f"const int *__restrict__ nrp{k}", ("mat_node_rowptr", k))
+        else:
+            P(f"const int *__restrict__ rp{k}", ("mat_rowptr", k))
+            P(f"const int *__restrict__ ci{k}", ("mat_colidx", k))
+        if info["arg"].lgmaps:
+            P(f"const int *__restrict__ rlg{k}", ("mat_row_lgmap", k))
+            P(f"const int *__restrict__ clg{k}", ("mat_col_lgmap", k))
+
+    # ---- static tables (offsets / permutations)
+    decls = []
+    for mi, m in enumerate(maps):
+        if extruded and m.offset is not None:
+            decls.append(f"__device__ static const int map{mi}_off[{m.arity}] = {{{', '.join(str(int(o)) for o in m.offset)}}};")
+
+    def node(mi, ar, i, off, perm=None, f="0", ent="e"):
+        ii = _permi(perm, i)
+        e = f"map{mi}[(size_t){ent}*{ar} + {ii}]"
+        if extruded and off is not None:
+            e = f"({e} + map{mi}_off[{i}]*(layer - layers[0] + {f}))"
+        return e
+
+    pre, pack, call_args, unpack, post = [], [], [], [], []
+    lds_decl, stage, flush = [], [], []
+
+    # LDS carving for staged args
+    if staged:
+        lds_decl.append("size_t fd_off = 0;")
+
+    for info in infos:
+        k, ct, acc = info["k"], info["ct"], info["acc"]
+        if info["kind"] == "pass":
+            call_args.append(f"arg{k}")
+        elif info["kind"] == "global":
+            n = info["n"]
+            if acc == READ:
+                call_args.append(f"const_cast<{ct} *>(arg{k})")
+                continue
+            ident = {INC: "0", WRITE: "0", RW: f"arg{k}[q]", MIN: f"arg{k}[q]", MAX: f"arg{k}[q]"}[acc]
+            pre.append(f"{ct} g{k}[{n}]; for (int q = 0; q < {n}; ++q) g{k}[q] = {ident};")
+            if acc == INC:
+                # private zeroed pack per entity then += (builder.py:292-319)
+                pack.append(f"{ct} t{k}[{n}]; for (int q = 0; q < {n}; ++q) t{k}[q] = 0;")
+                unpack.append(f"for (int q = 0; q < {n}; ++q) g{k}[q] += t{k}[q];")
+                call_args.append(f"t{k}")
+                op, at = "OpAdd", "atomic_add"
+            elif acc in (MIN, MAX):
+                call_args.append(f"g{k}")
+                op, at = ("OpMin", "atomic_min") if acc == MIN else ("OpMax", "atomic_max")
+            else:
+                raise ValueError("Global arguments may be READ, INC, MIN or MAX in a parloop")
+            post.append(f"for (int q = 0; q < {n}; ++q) {{ {ct} r = fdw::block_reduce<{ct}, fdw::{op}<{ct}>>(g{k}[q], ({ct} *)fd_red); "
+                        f"if (threadIdx.x == 0) fdw::{at}<{ct}>(&arg{k}[q], r); }}")
+        elif info["kind"] == "dat" and "m" not in info:
+            c = info["c"]
+            cast = f"const_cast<{ct} *>" if acc == READ else ""
+            call_args.append(f"{cast}(&arg{k}[(size_t)e*{c}])")
+        elif info["kind"] == "dat":
+            c, ar, mi = info["c"], info["ar"], info["m"]
+            perm, off = info["perm"], info["off"]
+            size = nf * ar * c
+            pack.append(f"{ct} t{k}[{size}];")
+            if staged:
+                lds_items.append((mi, c, info["dtype"].itemsize))
+                lds_decl.append(f"{ct} *s{k} = ({ct} *)(fd_lds + fd_off); fd_off += (((size_t)p{mi}_maxnd*{c}*sizeof({ct})) + 15) & ~(size_t)15;")
+                if acc == READ:
+                    stage.append((mi, f"for (int q = tid; q < nd{mi}*{c}; q += nthr) {{ const int i = q / {c}; "
+                                      f"s{k}[q] = arg{k}[(size_t)p{mi}_list[l0_{mi} + i]*{c} + (q - i*{c})]; }}"))
+                    pack.append(f"for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j) t{k}[i*{c}+j] = s{k}[lm{mi}[{_permi(perm, 'i')}]*{c} + j];")
+                else:  # INC
+                    stage.append((mi, f"for (int q = tid; q < nd{mi}*{c}; q += nthr) s{k}[q] = 0;"))
+                    pack.append(f"for (int q = 0; q < {size}; ++q) t{k}[q] = 0;")
+                    unpack.append(f"for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j) "
+                                  f"atomicAdd(&s{k}[lm{mi}[{_permi(perm, 'i')}]*{c} + j], t{k}[i*{c}+j]);")
+                    flush.append((mi, f"for (int q = tid; q < nd{mi}*{c}; q += nthr) {{ const int i = q / {c}; "
+                                      f"fdw::atomic_add<{ct}>(&arg{k}[(size_t)p{mi}_list[l0_{mi} + i]*{c} + (q - i*{c})], s{k}[q]); }}"))
+                call_args.append(f"t{k}")
+                continue
+            nexpr = node(mi, ar, "i", off, perm, "f")
+            loop = f"for (int f = 0; f < {nf}; ++f) for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j)"
+            if acc in (INC, WRITE):
+                pack.append(f"for (int q = 0; q < {size}; ++q) t{k}[q] = 0;")
+            else:
+                pack.append(f"{loop} t{k}[(f*{ar}+i)*{c}+j] = arg{k}[(size_t){nexpr}*{c} + j];")
+            call_args.append(f"t{k}")
+            lhs = f"arg{k}[(size_t){nexpr}*{c} + j]"
+            rhs = f"t{k}[(f*{ar}+i)*{c}+j]"
+            if acc == INC:
+                unpack.append(f"{loop} fdw::atomic_add<{ct}>(&{lhs}, {rhs});")
+            elif acc == MIN:
+                unpack.append(f"{loop} fdw::atomic_min<{ct}>(&{lhs}, {rhs});")
+            elif acc == MAX:
+                unpack.append(f"{loop} fdw::atomic_max<{ct}>(&{lhs}, {rhs});")
+            elif acc in (WRITE, RW):
+                unpack.append(f"{loop} {lhs} = {rhs};")
+        elif info["kind"] == "mat":
+            ar, ac, rbs, cbs = info["ar"], info["ac"], info["rbs"], info["cbs"]
+            rm, cm = info["rm"], info["cm"]
+            size = nf * ar * rbs * nf * ac * cbs
+            pack.append(f"double t{k}[{size}]; for (int q = 0; q < {size}; ++q) t{k}[q] = 0;")
+            call_args.append(f"t{k}")
+            store = (lambda p, v: f"fdw::atomic_add<double>(&arg{k}[{p}], {v});") if acc == INC else (lambda p, v: f"arg{k}[{p}] = {v};")
+            lg = info["arg"].lgmaps
+            unroll = info["arg"].unroll
+            nr_, nc_ = nf * ar, nf * ac
+            lines = [f"for (int fi = 0; fi < {nf}; ++fi) for (int i = 0; i < {ar}; ++i) {{",
+                     f"  const int rn = {node(rm, ar, 'i', info['roff'], None, 'fi')};",
+                     f"  for (int fj = 0; fj < {nf}; ++fj) for (int j = 0; j < {ac}; ++j) {{",
+                     f"    const int cn = {node(cm, ac, 'j', info['coff'], None, 'fj')};",
+                     "    if (rn < 0 || cn < 0) continue;"]
+            if lg and not unroll:
+                lines.append(f"    if (rlg{k}[rn] < 0 || clg{k}[cn] < 0) continue;")
+            if use_table[k]:
+                lines.append(f"    const int pn = tab{k}[((size_t)e*{ar} + i)*{ac} + j];")
+                lines.append("    if (pn < 0) continue;")
+                if rbs * cbs != 1:
+                    lines.append(f"    const int r0 = nrp{k}[rn], rl = nrp{k}[rn+1] - r0;")
+            for p in range(rbs):
+                for q in range(cbs):
+                    v = f"t{k}[((((size_t)(fi*{ar}+i)*{rbs} + {p})*{nc_}) + (fj*{ac}+j))*{cbs} + {q}]"
+                    guard = ""
+                    if lg and unroll:
+                        guard = f"if (rlg{k}[rn*{rbs}+{p}] >= 0 && clg{k}[cn*{cbs}+{q}] >= 0) "
+                    if use_table[k]:
+                        pos = "pn" if rbs * cbs == 1 else f"(size_t)r0*{rbs * cbs} + (size_t){p}*rl*{cbs} + (size_t)(pn - r0)*{cbs} + {q}"
+                        lines.append(f"    {guard}{{ {store(pos, v)} }}")
+                    else:
+                        lines.append(f"    {guard}{{ const int ps = fdw::csr_find(rp{k}, ci{k}, rn*{rbs}+{p}, cn*{cbs}+{q}); if (ps >= 0) {{ {store('ps', v)} }} }}")
+            lines += ["  }", "}"]
+            unpack.append("\n      ".join(lines))
+    if gk._pass_layer_arg:
+        call_args.append("layer")
+
+    includes, body = _hoist_includes(lk.code)
+    src = ['#include "fd_wrapper.h"', "#include <math.h>", *includes, *[f"#include <{h}>" for h in lk.headers],
+           "namespace fdk {", "#pragma clang force_cuda_host_device begin", body,
+           "#pragma clang force_cuda_host_device end", "}  // namespace fdk", *decls, ""]
+    sym = f"wrap_{lk.name}"
+    src.append(f'extern "C" __global__ __launch_bounds__({threads}) void {sym}(int start, int end, {", ".join(params)})')
+    src.append("{")
+    need_red = bool(post)
+    if need_red:
+        src.append("  __shared__ double fd_red[16];")
+    layer_parallel = True
+    if staged:
+        src += ["  extern __shared__ __align__(16) unsigned char fd_lds[];",
+                "  const int tid = threadIdx.x, nthr = blockDim.x;",
+                "  const int b = fdw::xcd_block(blockIdx.x, gridDim.x);",
+                "  const int epb = (int)epb_;",
+                "  const int e0 = start + b*epb;",
+                "  const int e1 = (e0 + epb < end) ? e0 + epb : end;"]
+        src += ["  " + s for s in lds_decl]
+        for mi in staged_maps:
+            src.append(f"  const int l0_{mi} = p{mi}_blkoff[b], nd{mi} = p{mi}_blkoff[b+1] - l0_{mi};")
+        src += ["  " + s for _, s in stage]
+        src.append("  __syncthreads();")
+        src += ["  " + s for s in pre]
+        src.append("  for (int e = e0 + tid; e < e1; e += nthr) {")
+        for mi in staged_maps:
+            ar = maps[mi].arity
+            src.append(f"    int lm{mi}[{ar}]; fdw::load_lmap<{ar}>(p{mi}_lmap + (size_t)(e - start)*{ar}, lm{mi});")
+        src += ["    " + s for s in pack]
+        src.append(f"    fdk::{lk.name}({', '.join(call_args)});")
+        src += ["    " + s for s in unpack]
+        src.append("  }")
+        if flush:
+            src.append("  __syncthreads();")
+            src += ["  " + s for _, s in flush]
+        src += ["  " + s for s in post]
+    else:
+        if extruded:
+            lo, hi = {ALL: ("layers[0]", "layers[1]-1"), ON_BOTTOM: ("layers[0]", "layers[0]+1"),
+                      ON_TOP: ("layers[1]-2", "layers[1]-1"),
+                      ON_INTERIOR_FACETS: ("layers[0]", "layers[1]-2")}[region]
+            src.append(f"  const int llo = {lo}, lhi = {hi};")
+            # a direct (map-less) Dat written on an extruded set is addressed by the BASE entity
+            # (parloop.py:494-497): all layers of a column hit the same row -> keep layers sequential
+            layer_parallel = not any(i["kind"] == "dat" and "m" not in i and i["acc"] != READ for i in infos)
+        src += ["  " + s for s in pre]
+        if extruded and layer_parallel:
+            src += ["  const long long nlay = lhi - llo;",
+                    "  const long long total = (long long)(end - start) * nlay;",
+                    "  for (long long it = blockIdx.x*(long long)blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x*blockDim.x) {",
+                    "    const int n = start + (int)(it / nlay);",
+                    "    const int layer = llo + (int)(it - (long long)(n - start)*nlay);"]
+        else:
+            src += ["  for (long long it = blockIdx.x*(long long)blockDim.x + threadIdx.x; it < (long long)(end - start); it += (long long)gridDim.x*blockDim.x) {",
+                    "    const int n = start + (int)it;"]
+        src.append("    const int e = " + ("subset_indices[n];" if gk._subset else "n;"))
+        if extruded and not layer_parallel:
+            src.append("    for (int layer = llo; layer < lhi; ++layer) {")
+        src += ["      " + s for s in pack]
+        src.append(f"      fdk::{lk.name}({', '.join(call_args)});")
+        src += ["      " + s for s in unpack]
+        if extruded and not layer_parallel:
+            src.append("    }")
+        src.append("  }")
+        src += ["  " + s for s in post]
+    src.append("}")
+    return WrapperSource("\n".join(src) + "\n", sym, mode, layout, len(maps), staged_maps, lds_items,
+                         layer_parallel, threads)
+
+
+def _permi(perm, i):
+    if perm is None:
+        return i
+    if len(perm) == 1:
+        return "0"
+    return "(" + " : ".join(f"{i} == {q} ? {p}" for q, p in enumerate(perm[:-1])) + f" : {perm[-1]})"

@@ -1,0 +1,74 @@
+"""hipcc JIT + on-disk cache for wrapper kernels.
+
+Mirror of pyop2/compilation.py:424-455 (``load``) and :527-611 (``make_so``): the
+generated source is hashed together with the compiler identity and flags, compiled once
+by a subprocess and cached on disk; later runs (and other ranks) just load the artefact.
+Here the artefact is a gfx950 code object (``hipcc --genco``) loaded through
+``fd_kernel_load`` (hipModuleLoad) instead of ``ctypes.CDLL``.
+"""
+import hashlib
+import os
+import subprocess
+import tempfile
+
+from .configuration import configuration
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+
+
+class CompilationError(RuntimeError):
+    """pyop2/compilation.py:587-607 analogue."""
+
+
+_version = None
+
+
+def compiler_version():
+    global _version
+    if _version is None:
+        try:
+            out = subprocess.run([configuration["hipcc"], "--version"], capture_output=True, text=True).stdout
+            _version = out.splitlines()[0] if out else "unknown"
+        except OSError:
+            _version = "missing"
+    return _version
+
+
+def flags():
+    f = [f"--offload-arch={configuration['arch']}", "-O3", "-std=c++17", "--genco", "-munsafe-fp-atomics",
+         "-fno-math-errno", f"-I{_CSRC}"]
+    if configuration["cflags"]:
+        f += configuration["cflags"].split()
+    return f
+
+
+def _wrapper_header_hash():
+    with open(os.path.join(_CSRC, "fd_wrapper.h"), "rb") as fh:
+        return hashlib.sha1(fh.read()).hexdigest()
+
+
+def compile_hip(source: str, name: str) -> str:
+    """Return the path of the cached code object for ``source`` (compiling it if needed)."""
+    cache = configuration["cache_dir"]
+    os.makedirs(cache, exist_ok=True)
+    fl = flags()
+    key = hashlib.sha1("\0".join([source, " ".join(fl[:-1]), compiler_version(), _wrapper_header_hash()]).encode()).hexdigest()[:20]
+    out = os.path.join(cache, f"{name}_{key}.hsaco")
+    if os.path.exists(out):
+        return out
+    src = os.path.join(cache, f"{name}_{key}.hip")
+    with open(src, "w") as fh:
+        fh.write(source)
+    fd, tmp = tempfile.mkstemp(suffix=".hsaco", dir=cache)
+    os.close(fd)
+    cmd = [configuration["hipcc"], *fl, "-o", tmp, src]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True)
+    except OSError as e:
+        os.unlink(tmp)
+        raise CompilationError(f"cannot run {configuration['hipcc']}: {e}")
+    if r.returncode != 0:
+        os.unlink(tmp)
+        raise CompilationError(f"hipcc failed for {src}:\n{' '.join(cmd)}\n{r.stderr}")
+    os.replace(tmp, out)      # atomic: concurrent ranks race benignly
+    return out

@@ -1,0 +1,26 @@
+"""Environment-backed configuration (mirror of pyop2/configuration.py:41-166)."""
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _env(name, default, conv=str):
+    v = os.environ.get(name)
+    return conv(v) if v is not None else default
+
+
+configuration = {
+    # hipcc analogue of PYOP2_CFLAGS / PYOP2_CACHE_DIR (pyop2/configuration.py:83-115)
+    "hipcc": _env("FDHIP_HIPCC", "/opt/rocm/bin/hipcc"),
+    "arch": _env("FDHIP_ARCH", "gfx950"),
+    "cflags": _env("FDHIP_CFLAGS", ""),
+    "cache_dir": _env("FDHIP_CACHE_DIR", os.path.join(_HERE, "_cache")),
+    "debug": _env("FDHIP_DEBUG", 0, int),
+    "type_check": _env("FDHIP_TYPE_CHECK", 1, int),
+    # wrapper generation
+    "mode": _env("FDHIP_MODE", "auto"),                 # auto | staged | direct
+    "block_threads": _env("FDHIP_BLOCK_THREADS", 256, int),
+    "ents_per_block": _env("FDHIP_ENTS_PER_BLOCK", 1024, int),
+    "lds_limit": _env("FDHIP_LDS_LIMIT", 64 * 1024, int),
+    "mat_scatter": _env("FDHIP_MAT_SCATTER", "table"),  # table | search
+}

@@ -1,0 +1,261 @@
+// fd_csr.hip -- device-side sparsity construction and CSR services (include/fdhip.h: fd_csr_*).
+//
+// Native replacement of pyop2/sparsity.pyx:105-159 (build_sparsity) and :162-389
+// (fill_with_zeros), which walk the maps calling MatSetValuesBlockedLocal on a PETSc
+// MATPREALLOCATOR.  Here: emit one 64-bit key (row<<32 | col) per candidate entry,
+// radix-sort, unique, and derive rowptr/colidx -- all on the GPU.  One-off per
+// function-space pair, excluded from the DoFs/s metric.
+#include "fd_common.h"
+#include <hipcub/hipcub.hpp>
+
+namespace {
+
+__global__ void emit_keys(const int32_t *__restrict__ rmap, const int32_t *__restrict__ cmap, int32_t nent,
+                          int ar, int ac, int nl, const int32_t *__restrict__ roff,
+                          const int32_t *__restrict__ coff, int32_t nrows, int32_t ncols,
+                          uint64_t *__restrict__ keys) {
+    const int64_t per = (int64_t)ar * ac;
+    const int64_t L = nl > 0 ? nl : 1;
+    const int64_t total = (int64_t)nent * L * per;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t e = t / (L * per);
+        int64_t rem = t - e * L * per;
+        int l = (int)(rem / per);
+        int ij = (int)(rem - l * per);
+        int i = ij / ac, j = ij - i * ac;
+        int r = rmap[e * ar + i];
+        int c = cmap[e * ac + j];
+        if (nl > 0) { if (r >= 0) r += roff[i] * l; if (c >= 0) c += coff[j] * l; }
+        uint64_t key = ~0ull;                       // sentinel: dropped (negative / out of range)
+        if (r >= 0 && r < nrows && c >= 0 && c < ncols) key = ((uint64_t)(uint32_t)r << 32) | (uint32_t)c;
+        keys[t] = key;
+    }
+}
+
+__global__ void emit_diag(int32_t n, uint64_t *__restrict__ keys) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+        keys[t] = ((uint64_t)(uint32_t)t << 32) | (uint32_t)t;
+}
+
+__global__ void keys_to_csr(const uint64_t *__restrict__ keys, int64_t nnz, int32_t nrows,
+                            int32_t *__restrict__ rowptr, int32_t *__restrict__ colidx) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t <= nnz; t += (int64_t)gridDim.x * blockDim.x) {
+        int32_t r = t < nnz ? (int32_t)(keys[t] >> 32) : nrows;
+        int32_t rp = t > 0 ? (int32_t)(keys[t - 1] >> 32) : -1;
+        for (int32_t rr = rp + 1; rr <= r; ++rr) rowptr[rr] = (int32_t)t;
+        if (t < nnz) colidx[t] = (int32_t)(keys[t] & 0xffffffffu);
+    }
+}
+
+__global__ void expand_rowptr(int32_t nnode, const int32_t *__restrict__ nrp, int rbs, int cbs,
+                              int32_t *__restrict__ rp) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t <= (int64_t)nnode * rbs;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        if (t == (int64_t)nnode * rbs) { rp[t] = nrp[nnode] * rbs * cbs; continue; }
+        int32_t r = (int32_t)(t / rbs), p = (int32_t)(t - (int64_t)r * rbs);
+        int32_t len = nrp[r + 1] - nrp[r];
+        rp[t] = nrp[r] * rbs * cbs + p * len * cbs;
+    }
+}
+
+__global__ void expand_colidx(int32_t nnode, const int32_t *__restrict__ nrp, const int32_t *__restrict__ nci,
+                              int rbs, int cbs, const int32_t *__restrict__ rp, int32_t *__restrict__ ci) {
+    // one thread per (node row, p): writes its row's len*cbs entries
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < (int64_t)nnode * rbs;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        int32_t r = (int32_t)(t / rbs);
+        int32_t o = rp[t];
+        for (int32_t q = nrp[r]; q < nrp[r + 1]; ++q)
+            for (int c = 0; c < cbs; ++c) ci[o++] = nci[q] * cbs + c;
+    }
+}
+
+__device__ inline int csr_find(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, int r, int c) {
+    int lo = rowptr[r], hi = rowptr[r + 1] - 1;
+    while (lo <= hi) {
+        int mid = (lo + hi) >> 1;
+        int v = colidx[mid];
+        if (v == c) return mid;
+        if (v < c) lo = mid + 1; else hi = mid - 1;
+    }
+    return -1;
+}
+
+__global__ void elem_offsets(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                             const int32_t *__restrict__ rmap, const int32_t *__restrict__ cmap, int32_t nent,
+                             int ar, int ac, int32_t *__restrict__ out) {
+    const int64_t per = (int64_t)ar * ac, total = nent * per;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t e = t / per;
+        int ij = (int)(t - e * per);
+        int i = ij / ac, j = ij - i * ac;
+        int r = rmap[e * ar + i], c = cmap[e * ac + j];
+        out[t] = (r >= 0 && c >= 0) ? csr_find(rowptr, colidx, r, c) : -1;
+    }
+}
+
+__global__ void set_diag(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, double *__restrict__ vals,
+                         const int32_t *__restrict__ rows, int32_t n, double v, int zero_row) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        int r = rows[t];
+        if (r < 0) continue;
+        if (zero_row) {
+            for (int q = rowptr[r]; q < rowptr[r + 1]; ++q) vals[q] = (colidx[q] == r) ? v : 0.0;
+        } else {
+            int q = csr_find(rowptr, colidx, r, r);
+            if (q >= 0) vals[q] = v;
+        }
+    }
+}
+
+__global__ void spmv(int32_t nrows, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                     const double *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y) {
+    // one wavefront per row
+    const int lane = threadIdx.x & 63;
+    for (int64_t r = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6; r < nrows;
+         r += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+        double acc = 0.0;
+        for (int q = rowptr[r] + lane; q < rowptr[r + 1]; q += 64) acc += vals[q] * x[colidx[q]];
+        for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
+        if (lane == 0) y[r] = acc;
+    }
+}
+
+inline int grid_for(int64_t n, int block = 256) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > 256 * 32) g = 256 * 32;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fd_csr_from_maps(int32_t nrows, int32_t ncols, int set_diag, int npairs,
+                     const int32_t *const *rmaps, const int32_t *const *cmaps, const int32_t *nent,
+                     const int32_t *rarity, const int32_t *carity, const int32_t *nlayers,
+                     const int32_t *const *roffs_h, const int32_t *const *coffs_h,
+                     int32_t **rowptr_out, int32_t **colidx_out, int64_t *nnz_out, fd_stream_t s_) {
+    hipStream_t s = fd::st(s_);
+    int64_t ncand = 0;
+    for (int k = 0; k < npairs; ++k) {
+        int64_t L = (nlayers && nlayers[k] > 0) ? nlayers[k] : 1;
+        ncand += (int64_t)nent[k] * L * rarity[k] * carity[k];
+    }
+    int32_t ndiag = set_diag ? (nrows < ncols ? nrows : ncols) : 0;
+    ncand += ndiag;
+    uint64_t *keys = nullptr, *keys2 = nullptr;
+    FD_HIP(hipMalloc(&keys, (size_t)(ncand + 1) * 8));
+    FD_HIP(hipMalloc(&keys2, (size_t)(ncand + 1) * 8));
+    int64_t off = 0;
+    if (ndiag) { hipLaunchKernelGGL(emit_diag, dim3(grid_for(ndiag)), dim3(256), 0, s, ndiag, keys); FD_CHECK_LAUNCH(); off = ndiag; }
+    for (int k = 0; k < npairs; ++k) {
+        int nl = (nlayers && nlayers[k] > 0) ? nlayers[k] : 0;
+        int64_t cnt = (int64_t)nent[k] * (nl ? nl : 1) * rarity[k] * carity[k];
+        if (cnt == 0) continue;
+        int32_t *roff = nullptr, *coff = nullptr;
+        if (nl) {
+            FD_HIP(hipMalloc(&roff, rarity[k] * 4)); FD_HIP(hipMalloc(&coff, carity[k] * 4));
+            FD_HIP(hipMemcpyAsync(roff, roffs_h[k], rarity[k] * 4, hipMemcpyHostToDevice, s));
+            FD_HIP(hipMemcpyAsync(coff, coffs_h[k], carity[k] * 4, hipMemcpyHostToDevice, s));
+        }
+        hipLaunchKernelGGL(emit_keys, dim3(grid_for(cnt)), dim3(256), 0, s, rmaps[k], cmaps[k], nent[k], rarity[k],
+                           carity[k], nl, roff, coff, nrows, ncols, keys + off);
+        FD_CHECK_LAUNCH();
+        if (nl) { FD_HIP(hipStreamSynchronize(s)); FD_HIP(hipFree(roff)); FD_HIP(hipFree(coff)); }
+        off += cnt;
+    }
+    // sort (only the bits that carry information: 32 + ceil(log2(nrows)))
+    int rbits = 1; while ((1ll << rbits) < nrows) ++rbits;
+    int end_bit = 64;   // the ~0 sentinel must sort last: keep all bits
+    (void)rbits;
+    size_t tmp_bytes = 0;
+    hipcub::DoubleBuffer<uint64_t> db(keys, keys2);
+    FD_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, db, (int64_t)ncand, 0, end_bit, s));
+    void *tmp = nullptr;
+    FD_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
+    FD_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, db, (int64_t)ncand, 0, end_bit, s));
+    uint64_t *sorted = db.Current();
+    uint64_t *other = (sorted == keys) ? keys2 : keys;
+    // unique
+    int64_t *nsel = nullptr;
+    FD_HIP(hipMalloc(&nsel, 8));
+    size_t tmp2_bytes = 0;
+    FD_HIP(hipcub::DeviceSelect::Unique(nullptr, tmp2_bytes, sorted, other, nsel, (int64_t)ncand, s));
+    if (tmp2_bytes > tmp_bytes) { FD_HIP(hipFree(tmp)); FD_HIP(hipMalloc(&tmp, tmp2_bytes)); tmp_bytes = tmp2_bytes; }
+    FD_HIP(hipcub::DeviceSelect::Unique(tmp, tmp2_bytes, sorted, other, nsel, (int64_t)ncand, s));
+    int64_t nu = 0;
+    FD_HIP(hipMemcpyAsync(&nu, nsel, 8, hipMemcpyDeviceToHost, s));
+    FD_HIP(hipStreamSynchronize(s));
+    // drop the sentinel (if any candidate was masked it is the last unique key)
+    if (nu > 0) {
+        uint64_t last;
+        FD_HIP(hipMemcpy(&last, other + nu - 1, 8, hipMemcpyDeviceToHost));
+        if (last == ~0ull) --nu;
+    }
+    if (nu > 2147483647ll) FD_FAIL("fd_csr_from_maps: nnz exceeds int32 (IntType)");
+    int32_t *rowptr = nullptr, *colidx = nullptr;
+    FD_HIP(hipMalloc(&rowptr, ((size_t)nrows + 1) * 4));
+    FD_HIP(hipMalloc(&colidx, (size_t)(nu > 0 ? nu : 1) * 4));
+    hipLaunchKernelGGL(keys_to_csr, dim3(grid_for(nu + 1)), dim3(256), 0, s, other, nu, nrows, rowptr, colidx);
+    FD_CHECK_LAUNCH();
+    FD_HIP(hipStreamSynchronize(s));
+    FD_HIP(hipFree(keys)); FD_HIP(hipFree(keys2)); FD_HIP(hipFree(tmp)); FD_HIP(hipFree(nsel));
+    *rowptr_out = rowptr; *colidx_out = colidx; *nnz_out = nu;
+    return 0;
+}
+
+int fd_csr_expand_blocks(int32_t nnode, const int32_t *nrp, const int32_t *nci, int rbs, int cbs,
+                         int32_t **rp_out, int32_t **ci_out, fd_stream_t s_) {
+    hipStream_t s = fd::st(s_);
+    int32_t nnz_node;
+    FD_HIP(hipMemcpy(&nnz_node, nrp + nnode, 4, hipMemcpyDeviceToHost));
+    int64_t nnz = (int64_t)nnz_node * rbs * cbs;
+    if (nnz > 2147483647ll) FD_FAIL("fd_csr_expand_blocks: nnz exceeds int32");
+    int32_t *rp = nullptr, *ci = nullptr;
+    FD_HIP(hipMalloc(&rp, ((size_t)nnode * rbs + 1) * 4));
+    FD_HIP(hipMalloc(&ci, (size_t)(nnz > 0 ? nnz : 1) * 4));
+    hipLaunchKernelGGL(expand_rowptr, dim3(grid_for((int64_t)nnode * rbs + 1)), dim3(256), 0, s, nnode, nrp, rbs, cbs, rp);
+    FD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(expand_colidx, dim3(grid_for((int64_t)nnode * rbs)), dim3(256), 0, s, nnode, nrp, nci, rbs, cbs, rp, ci);
+    FD_CHECK_LAUNCH();
+    *rp_out = rp; *ci_out = ci;
+    return 0;
+}
+
+int fd_csr_elem_offsets(const int32_t *rowptr, const int32_t *colidx, const int32_t *rmap, const int32_t *cmap,
+                        int32_t nent, int ar, int ac, int32_t *out, fd_stream_t s) {
+    if (nent <= 0) return 0;
+    hipLaunchKernelGGL(elem_offsets, dim3(grid_for((int64_t)nent * ar * ac)), dim3(256), 0, fd::st(s), rowptr, colidx,
+                       rmap, cmap, nent, ar, ac, out);
+    FD_CHECK_LAUNCH();
+    return 0;
+}
+
+int fd_csr_set_diagonal(const int32_t *rowptr, const int32_t *colidx, double *vals, const int32_t *rows, int32_t n,
+                        double v, fd_stream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(set_diag, dim3(grid_for(n)), dim3(256), 0, fd::st(s), rowptr, colidx, vals, rows, n, v, 0);
+    FD_CHECK_LAUNCH();
+    return 0;
+}
+
+int fd_csr_zero_rows(const int32_t *rowptr, const int32_t *colidx, double *vals, const int32_t *rows, int32_t n,
+                     double v, fd_stream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(set_diag, dim3(grid_for(n)), dim3(256), 0, fd::st(s), rowptr, colidx, vals, rows, n, v, 1);
+    FD_CHECK_LAUNCH();
+    return 0;
+}
+
+int fd_csr_spmv(int32_t nrows, const int32_t *rowptr, const int32_t *colidx, const double *vals, const double *x,
+                double *y, fd_stream_t s) {
+    if (nrows <= 0) return 0;
+    hipLaunchKernelGGL(spmv, dim3(grid_for((int64_t)nrows * 64)), dim3(256), 0, fd::st(s), nrows, rowptr, colidx, vals, x, y);
+    FD_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,116 @@
+// fd_runtime.hip -- runtime half of the C ABI (include/fdhip.h): device memory, streams,
+// events, and loading/launching the wrapper kernels that replace the JIT-compiled
+// `wrap_<kernel>` of pyop2/global_kernel.py:426-456.
+#include "fd_common.h"
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+namespace fd {
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+
+struct Builtin { const char *name; const void *fn; };
+static std::vector<Builtin> &registry() { static std::vector<Builtin> r; return r; }
+int register_builtin(const char *name, const void *fn) { registry().push_back({name, fn}); return 0; }
+}  // namespace fd
+
+struct fd_kernel_s {
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    const void *host_fn = nullptr;   // builtin (compiled into this library)
+    size_t max_lds_set = 0;
+};
+struct fd_event_s { hipEvent_t ev; };
+
+extern "C" {
+
+int fd_version(void) { return 100; }
+const char *fd_last_error(void) { return fd::g_err.c_str(); }
+
+int fd_device_count(int *n) { FD_HIP(hipGetDeviceCount(n)); return 0; }
+int fd_set_device(int device) { FD_HIP(hipSetDevice(device)); return 0; }
+
+int fd_device_info(int device, char *name, size_t name_len, int *cus, size_t *hbm, int *lds) {
+    hipDeviceProp_t p;
+    FD_HIP(hipGetDeviceProperties(&p, device));
+    if (name && name_len) { std::strncpy(name, p.gcnArchName, name_len - 1); name[name_len - 1] = 0; }
+    if (cus) *cus = p.multiProcessorCount;
+    if (hbm) *hbm = p.totalGlobalMem;
+    if (lds) *lds = (int)p.sharedMemPerBlock;
+    return 0;
+}
+
+int fd_malloc(void **ptr, size_t bytes) { FD_HIP(hipMalloc(ptr, bytes ? bytes : 8)); return 0; }
+int fd_free(void *ptr) { if (ptr) FD_HIP(hipFree(ptr)); return 0; }
+int fd_memset(void *p, int b, size_t n, fd_stream_t s) { if (n) FD_HIP(hipMemsetAsync(p, b, n, fd::st(s))); return 0; }
+int fd_memcpy_h2d(void *d, const void *s_, size_t n, fd_stream_t s) { if (n) FD_HIP(hipMemcpyAsync(d, s_, n, hipMemcpyHostToDevice, fd::st(s))); return 0; }
+int fd_memcpy_d2h(void *d, const void *s_, size_t n, fd_stream_t s) {
+    if (n) { FD_HIP(hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToHost, fd::st(s))); FD_HIP(hipStreamSynchronize(fd::st(s))); }
+    return 0;
+}
+int fd_memcpy_d2d(void *d, const void *s_, size_t n, fd_stream_t s) { if (n) FD_HIP(hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, fd::st(s))); return 0; }
+int fd_stream_create(fd_stream_t *s) { hipStream_t h; FD_HIP(hipStreamCreateWithFlags(&h, hipStreamNonBlocking)); *s = h; return 0; }
+int fd_stream_destroy(fd_stream_t s) { FD_HIP(hipStreamDestroy(fd::st(s))); return 0; }
+int fd_stream_sync(fd_stream_t s) { FD_HIP(hipStreamSynchronize(fd::st(s))); return 0; }
+int fd_device_sync(void) { FD_HIP(hipDeviceSynchronize()); return 0; }
+
+int fd_event_create(fd_event_t *e) { auto *p = new fd_event_s; hipError_t r = hipEventCreate(&p->ev); if (r != hipSuccess) { delete p; FD_HIP(r); } *e = p; return 0; }
+int fd_event_destroy(fd_event_t e) { if (e) { FD_HIP(hipEventDestroy(e->ev)); delete e; } return 0; }
+int fd_event_record(fd_event_t e, fd_stream_t s) { FD_HIP(hipEventRecord(e->ev, fd::st(s))); return 0; }
+int fd_event_sync(fd_event_t e) { FD_HIP(hipEventSynchronize(e->ev)); return 0; }
+int fd_event_elapsed_ms(fd_event_t a, fd_event_t b, float *ms) { FD_HIP(hipEventElapsedTime(ms, a->ev, b->ev)); return 0; }
+
+int fd_kernel_load(const char *path, const char *symbol, fd_kernel_t *out) {
+    auto *k = new fd_kernel_s;
+    hipError_t r = hipModuleLoad(&k->mod, path);
+    if (r != hipSuccess) { delete k; fd::set_error(std::string("hipModuleLoad(") + path + "): " + hipGetErrorString(r)); return (int)r; }
+    r = hipModuleGetFunction(&k->fn, k->mod, symbol);
+    if (r != hipSuccess) { (void)hipModuleUnload(k->mod); delete k; fd::set_error(std::string("symbol ") + symbol + " not in " + path + ": " + hipGetErrorString(r)); return (int)r; }
+    *out = k;
+    return 0;
+}
+
+int fd_kernel_builtin(const char *symbol, fd_kernel_t *out) {
+    for (auto &b : fd::registry())
+        if (std::strcmp(b.name, symbol) == 0) { auto *k = new fd_kernel_s; k->host_fn = b.fn; *out = k; return 0; }
+    FD_FAIL(std::string("no builtin wrapper kernel named ") + symbol);
+}
+
+int fd_kernel_free(fd_kernel_t k) {
+    if (!k) return 0;
+    if (k->mod) FD_HIP(hipModuleUnload(k->mod));
+    delete k;
+    return 0;
+}
+
+int fd_kernel_launch(fd_kernel_t k, int32_t start, int32_t end, const void *const *args, int nargs,
+                     int block_threads, int ents_per_block, int nblocks, size_t lds_bytes, fd_stream_t s) {
+    if (!k) FD_FAIL("fd_kernel_launch: null kernel");
+    if (end <= start) return 0;     // empty iteration range: nothing to do (builder.py:734-741)
+    if (block_threads <= 0 || block_threads > 1024) FD_FAIL("fd_kernel_launch: bad block size");
+    if (nblocks <= 0) {
+        if (ents_per_block <= 0) FD_FAIL("fd_kernel_launch: need ents_per_block or nblocks");
+        int64_t n = (int64_t)end - start;
+        nblocks = (int)((n + ents_per_block - 1) / ents_per_block);
+    }
+    void *params[64];
+    uint64_t vals[64];
+    if (nargs > 62) FD_FAIL("fd_kernel_launch: too many arguments");
+    params[0] = &start; params[1] = &end;
+    for (int i = 0; i < nargs; ++i) { vals[i] = (uint64_t)(uintptr_t)args[i]; params[2 + i] = &vals[i]; }
+    if (lds_bytes > 64 * 1024 && lds_bytes > k->max_lds_set) {
+        if (k->host_fn) FD_HIP(hipFuncSetAttribute(k->host_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        else FD_HIP(hipFuncSetAttribute((const void *)k->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        k->max_lds_set = lds_bytes;
+    }
+    if (k->host_fn) {
+        FD_HIP(hipLaunchKernel(k->host_fn, dim3(nblocks), dim3(block_threads), params, lds_bytes, fd::st(s)));
+    } else {
+        FD_HIP(hipModuleLaunchKernel(k->fn, nblocks, 1, 1, block_threads, 1, 1, (unsigned)lds_bytes, fd::st(s), params, nullptr));
+    }
+    return 0;
+}
+
+}  // extern "C"

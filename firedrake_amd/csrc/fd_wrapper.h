@@ -1,0 +1,119 @@
+// fd_wrapper.h -- device-side building blocks of the wrapper kernels.
+//
+// The reference generates, per parloop, a sequential C function
+//     int wrap_<kernel>(start, end, [layers], [subset], dats..., maps...)
+// (pyop2/codegen/builder.py:702-1008, rep2loopy.py:409-593) that packs element data,
+// calls the TSFC/loopy local kernel and unpacks (+=, min, max, =, MatSetValues).
+// On MI355X the same contract is a HIP kernel assembled from these pieces by
+// firedrake_amd/codegen.py (JIT) or instantiated ahead of time in fd_builtin.hip:
+//
+//   * one workgroup per block of iteration-set entities, one lane per entity
+//     (wave64: 64 elements per wavefront);
+//   * staged mode: the distinct Dat rows a block touches are gathered once, coalesced
+//     over the block's sorted node list, into LDS; element packs are read from LDS;
+//     INC contributions are reduced in LDS (ds_add_f64) and leave the CU as ONE global
+//     atomic per distinct node;
+//   * direct mode: thread-per-entity gather/scatter straight from global memory with
+//     hardware fp64 atomics -- the always-available fallback for exotic access modes
+//     (RW/WRITE/MIN/MAX through maps, subsets, extruded columns, integer Dats);
+//   * workgroups are renumbered so that consecutive blocks (which share nodes) land on
+//     the same XCD and hit in its 4 MiB L2.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef double PetscScalar;
+typedef double PetscReal;
+typedef int PetscInt;
+
+namespace fdw {
+
+// Hardware places workgroup b on XCD b % 8 (MI355X_MICROARCH: "block b runs on XCD b % 8").
+// Map it to a logical block id such that each XCD owns one contiguous range of blocks.
+// Bijection for any nb; used for speed only, never for correctness.
+__device__ __forceinline__ int xcd_block(int bid, int nb) {
+    const int q = nb >> 3, r = nb & 7;
+    const int x = bid & 7, k = bid >> 3;
+    return x * q + (x < r ? x : r) + k;
+}
+
+// ---- global atomics (compiled with -munsafe-fp-atomics => global_atomic_add_f64) ----
+template <class T> __device__ __forceinline__ void atomic_add(T *p, T v) { atomicAdd(p, v); }
+template <> __device__ __forceinline__ void atomic_add<long long>(long long *p, long long v) {
+    atomicAdd((unsigned long long *)p, (unsigned long long)v);
+}
+template <class T> __device__ __forceinline__ void atomic_min(T *p, T v) { atomicMin(p, v); }
+template <class T> __device__ __forceinline__ void atomic_max(T *p, T v) { atomicMax(p, v); }
+
+// ---- CSR position of (row, col): the per-call row search of MatSetValuesLocal ----
+__device__ __forceinline__ int csr_find(const int *__restrict__ rowptr, const int *__restrict__ colidx, int r, int c) {
+    int lo = rowptr[r], hi = rowptr[r + 1] - 1;
+    while (lo <= hi) {
+        int mid = (lo + hi) >> 1;
+        int v = colidx[mid];
+        if (v == c) return mid;
+        if (v < c) lo = mid + 1; else hi = mid - 1;
+    }
+    return -1;
+}
+
+// ---- block reductions for Global INC/MIN/MAX (GlobalPack, builder.py:292-319) ----
+template <class T> struct OpAdd { static __device__ __forceinline__ T f(T a, T b) { return a + b; } };
+template <class T> struct OpMin { static __device__ __forceinline__ T f(T a, T b) { return a < b ? a : b; } };
+template <class T> struct OpMax { static __device__ __forceinline__ T f(T a, T b) { return a > b ? a : b; } };
+
+template <class T, class Op> __device__ __forceinline__ T wave_reduce(T v) {
+    for (int d = 32; d > 0; d >>= 1) {
+        T o = __shfl_xor(v, d, 64);
+        v = Op::f(v, o);
+    }
+    return v;
+}
+
+// All threads of the block must call.  Result valid on thread 0.
+template <class T, class Op> __device__ __forceinline__ T block_reduce(T v, T *scratch /* >= 16 */) {
+    v = wave_reduce<T, Op>(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < nw; ++i) v = Op::f(v, scratch[i]);
+    }
+    return v;
+}
+
+// ---- packed local-map rows: ARITY uint16 per entity, read with the widest aligned loads ----
+template <int ARITY> __device__ __forceinline__ void load_lmap(const uint16_t *__restrict__ p, int (&out)[ARITY]) {
+    if constexpr ((ARITY * 2) % 16 == 0) {
+        const uint4 *q = reinterpret_cast<const uint4 *>(p);
+#pragma unroll
+        for (int k = 0; k < ARITY / 8; ++k) {
+            uint4 v = q[k];
+            out[8 * k + 0] = v.x & 0xffff; out[8 * k + 1] = v.x >> 16;
+            out[8 * k + 2] = v.y & 0xffff; out[8 * k + 3] = v.y >> 16;
+            out[8 * k + 4] = v.z & 0xffff; out[8 * k + 5] = v.z >> 16;
+            out[8 * k + 6] = v.w & 0xffff; out[8 * k + 7] = v.w >> 16;
+        }
+    } else if constexpr ((ARITY * 2) % 8 == 0) {
+        const uint2 *q = reinterpret_cast<const uint2 *>(p);
+#pragma unroll
+        for (int k = 0; k < ARITY / 4; ++k) {
+            uint2 v = q[k];
+            out[4 * k + 0] = v.x & 0xffff; out[4 * k + 1] = v.x >> 16;
+            out[4 * k + 2] = v.y & 0xffff; out[4 * k + 3] = v.y >> 16;
+        }
+    } else if constexpr ((ARITY * 2) % 4 == 0) {
+        const unsigned *q = reinterpret_cast<const unsigned *>(p);
+#pragma unroll
+        for (int k = 0; k < ARITY / 2; ++k) {
+            unsigned v = q[k];
+            out[2 * k] = v & 0xffff; out[2 * k + 1] = v >> 16;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < ARITY; ++k) out[k] = p[k];
+    }
+}
+
+}  // namespace fdw

@@ -1,0 +1,86 @@
+"""Device buffers: HBM allocations that stand in for the numpy buffers whose raw pointers the
+reference passes to its wrapper (pyop2/types/dat.py:94-96, map.py:57-59, glob.py:32-33)."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+class DeviceBuffer:
+    """An owned hipMalloc allocation (fd_malloc / fd_free)."""
+
+    def __init__(self, nbytes: int):
+        _lib.require_gpu()
+        p = ctypes.c_void_p()
+        _lib.call("fd_malloc", ctypes.byref(p), max(int(nbytes), 8))
+        self.ptr = p.value
+        self.nbytes = int(nbytes)
+        self._owned = True
+
+    @classmethod
+    def wrap(cls, ptr: int, nbytes: int, owner=None):
+        """Adopt device memory allocated inside libfdhip (released with fd_free on GC)."""
+        b = cls.__new__(cls)
+        b.ptr, b.nbytes, b._owned = ptr, int(nbytes), True
+        return b
+
+    @classmethod
+    def from_numpy(cls, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        b = cls(arr.nbytes)
+        b.upload(arr)
+        return b
+
+    def upload(self, arr: np.ndarray, stream=None):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= max(self.nbytes, 8)
+        if arr.nbytes:
+            _lib.call("fd_memcpy_h2d", self.ptr, arr.ctypes.data, arr.nbytes, stream)
+            _lib.call("fd_stream_sync", stream)   # host buffer may be a temporary
+
+    def download(self, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        if out.nbytes:
+            _lib.call("fd_memcpy_d2h", out.ctypes.data, self.ptr, out.nbytes, None)
+        return out
+
+    def zero(self, stream=None):
+        _lib.call("fd_memset", self.ptr, 0, self.nbytes, stream)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_owned", False) and self.ptr:
+                _lib.load().fd_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def synchronize():
+    _lib.call("fd_device_sync")
+
+
+class Event:
+    def __init__(self):
+        p = ctypes.c_void_p()
+        _lib.call("fd_event_create", ctypes.byref(p))
+        self.h = p.value
+
+    def record(self, stream=None):
+        _lib.call("fd_event_record", self.h, stream)
+
+    def sync(self):
+        _lib.call("fd_event_sync", self.h)
+
+    def elapsed_ms(self, later: "Event") -> float:
+        ms = ctypes.c_float()
+        _lib.call("fd_event_elapsed_ms", self.h, later.h, ctypes.byref(ms))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.h:
+                _lib.load().fd_event_destroy(self.h)
+        except Exception:
+            pass

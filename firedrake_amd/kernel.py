@@ -1,0 +1,242 @@
+"""Local kernels, global-kernel argument descriptors and the GlobalKernel itself.
+
+Mirror of pyop2/local_kernel.py:20-227 (CStringLocalKernel) and
+pyop2/global_kernel.py:27-456 (MapKernelArg ... GlobalKernel, compile_global_kernel).
+``GlobalKernel.__call__(comm, start, end, *args)`` keeps the reference's calling
+convention (global_kernel.py:327-335); what changes is what it compiles to: a HIP
+wrapper kernel for gfx950 (codegen.py) loaded through the C ABI (fd_kernel_load).
+"""
+from __future__ import annotations
+
+import ctypes
+import hashlib
+import re
+from dataclasses import dataclass, field
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from .op2types import Access, IterationRegion, ALL, READ, ScalarType
+
+
+# ---- local kernel ---------------------------------------------------------------------------
+@dataclass(frozen=True)
+class LocalKernelArg:            # pyop2/local_kernel.py:20-40
+    access: Access
+    dtype: np.dtype
+
+
+class CStringLocalKernel:
+    """A local kernel given as a C string (pyop2/local_kernel.py:177-207).  This is the
+    generic input of the backend: the same text is compiled by gcc for the CPU path of the
+    reference and by hipcc (as a __device__ function) here."""
+
+    def __init__(self, code, name, accesses=None, dtypes=None, *, flop_count=None, headers=(),
+                 requires_zeroed_output_arguments=False, cpp=False, **_ignored):
+        if not isinstance(code, str):
+            raise TypeError("C-string local kernels need `code` to be a str "
+                            "(loopy translation units are ingested through firedrake's TSFC bridge, see INTEGRATION.md)")
+        self.code = code
+        self.name = name
+        self.accesses = None if accesses is None else tuple(Access(a) for a in accesses)
+        self.dtypes = None if dtypes is None else tuple(np.dtype(d) for d in dtypes)
+        self.flop_count = flop_count
+        self.headers = tuple(headers)
+        self.requires_zeroed_output_arguments = requires_zeroed_output_arguments
+        self.cpp = cpp
+
+    @property
+    def arguments(self):
+        return tuple(LocalKernelArg(a, d) for a, d in zip(self.accesses, self.dtypes))
+
+    @property
+    def cache_key(self):
+        return hashlib.md5((self.code + self.name + repr(self.accesses) + repr(self.dtypes)
+                            + repr(self.requires_zeroed_output_arguments)).encode()).hexdigest()
+
+    def with_signature(self, accesses, dtypes):
+        return CStringLocalKernel(self.code, self.name, accesses, dtypes, flop_count=self.flop_count,
+                                  headers=self.headers,
+                                  requires_zeroed_output_arguments=self.requires_zeroed_output_arguments, cpp=self.cpp)
+
+
+def Kernel(code, name, **kwargs):
+    """pyop2/local_kernel.py:54-83 ``Kernel`` factory."""
+    return CStringLocalKernel(code, name, **kwargs)
+
+
+# ---- global kernel argument descriptors -----------------------------------------------------
+@dataclass(eq=False, frozen=True)
+class MapKernelArg:              # pyop2/global_kernel.py:27-52
+    arity: int
+    offset: Optional[Tuple[int, ...]] = None
+    offset_quotient: Optional[Tuple[int, ...]] = None
+
+    @property
+    def cache_key(self):
+        return type(self), self.arity, self.offset, self.offset_quotient
+
+
+@dataclass(eq=False, frozen=True)
+class PermutedMapKernelArg:      # pyop2/global_kernel.py:55-70
+    base_map: MapKernelArg
+    permutation: Tuple[int, ...]
+
+    @property
+    def arity(self):
+        return self.base_map.arity
+
+    @property
+    def offset(self):
+        return self.base_map.offset
+
+    @property
+    def cache_key(self):
+        return type(self), self.base_map.cache_key, tuple(self.permutation)
+
+
+@dataclass(frozen=True)
+class GlobalKernelArg:           # pyop2/global_kernel.py:92-108
+    dim: Tuple[int, ...]
+    double: bool = False
+
+    @property
+    def cache_key(self):
+        return type(self), self.dim
+
+    @property
+    def maps(self):
+        return ()
+
+
+@dataclass(frozen=True)
+class DatKernelArg:              # pyop2/global_kernel.py:111-152
+    dim: Tuple[int, ...]
+    map_: object = None
+    index: Optional[Tuple[int, ...]] = None
+
+    @property
+    def is_direct(self):
+        return self.map_ is None
+
+    @property
+    def is_indirect(self):
+        return not self.is_direct
+
+    @property
+    def cache_key(self):
+        return type(self), self.dim, None if self.map_ is None else self.map_.cache_key, self.index
+
+    @property
+    def maps(self):
+        return () if self.map_ is None else (self.map_,)
+
+
+@dataclass(frozen=True)
+class MatKernelArg:              # pyop2/global_kernel.py:155-180
+    dims: Tuple[Tuple[int, ...], Tuple[int, ...]]
+    maps: Tuple[object, object]
+    unroll: bool = False
+    lgmaps: bool = False          # backend extension: BC-masked lgmaps are passed (parloop.py:279-302)
+
+    @property
+    def cache_key(self):
+        return type(self), self.dims, tuple(m.cache_key for m in self.maps), self.unroll, self.lgmaps
+
+
+@dataclass(frozen=True)
+class PassthroughKernelArg:      # pyop2/global_kernel.py:245-252
+    @property
+    def cache_key(self):
+        return type(self)
+
+    @property
+    def maps(self):
+        return ()
+
+
+class GlobalKernel:
+    """pyop2/global_kernel.py:255-405."""
+
+    _cache = {}
+
+    def __init__(self, local_kernel, arguments, *, extruded=False, extruded_periodic=False,
+                 constant_layers=False, subset=False, iteration_region=None, pass_layer_arg=False):
+        if local_kernel.accesses is None or len(local_kernel.accesses) != len(arguments):
+            raise ValueError("Number of arguments passed to the local and global kernels do not match")
+        if pass_layer_arg and not extruded:
+            raise ValueError("Cannot request layer argument for non-extruded iteration")
+        if constant_layers and not extruded:
+            raise ValueError("Cannot request constant_layers argument for non-extruded iteration")
+        if extruded_periodic:
+            raise NotImplementedError("periodic extrusion is out of scope")
+        if extruded and not constant_layers:
+            raise NotImplementedError("variable-layer extrusion is out of scope (SURVEY.md 2.3)")
+        self.local_kernel = local_kernel
+        self.arguments = tuple(arguments)
+        self._extruded = extruded
+        self._constant_layers = constant_layers
+        self._subset = subset
+        self._iteration_region = IterationRegion(iteration_region) if iteration_region is not None else ALL
+        self._pass_layer_arg = pass_layer_arg
+        seen = {}
+        map_ids = []
+        for a in self.arguments:
+            for m in a.maps:
+                base = m.base_map if isinstance(m, PermutedMapKernelArg) else m
+                map_ids.append(seen.setdefault(id(base), len(seen)))
+        self.cache_key = (local_kernel.cache_key, *[a.cache_key for a in self.arguments], *map_ids,
+                          extruded, constant_layers, subset, int(self._iteration_region), pass_layer_arg)
+        self._compiled = {}
+
+    @property
+    def name(self):
+        return f"wrap_{self.local_kernel.name}"
+
+    def compile(self, mode=None):
+        """compile_global_kernel (global_kernel.py:426-456): codegen -> hipcc -> code object ->
+        fd_kernel_load.  Returns a :class:`CompiledWrapper`."""
+        from .codegen import generate_wrapper, select_mode
+        from .compilation import compile_hip
+        mode = mode or select_mode(self)
+        cw = self._compiled.get(mode)
+        if cw is None:
+            ck = (self.cache_key, mode)
+            cw = GlobalKernel._cache.get(ck)
+            if cw is None:
+                src = generate_wrapper(self, mode)
+                path = compile_hip(src.source, self.name)
+                cw = CompiledWrapper(src, path)
+                GlobalKernel._cache[ck] = cw
+            self._compiled[mode] = cw
+        return cw
+
+    def __call__(self, comm, start, end, *args, **launch):
+        """func(start, end, *arglist) -- global_kernel.py:327-335."""
+        cw = self.compile(launch.pop("mode", None))
+        cw.launch(start, end, args, **launch)
+
+
+class CompiledWrapper:
+    """A loaded wrapper kernel + the layout of its argument list."""
+
+    def __init__(self, src, hsaco_path):
+        self.src = src
+        self.path = hsaco_path
+        self._handle = None
+
+    @property
+    def handle(self):
+        if self._handle is None:
+            _lib.require_gpu()
+            h = ctypes.c_void_p()
+            _lib.call("fd_kernel_load", self.path.encode(), self.src.symbol.encode(), ctypes.byref(h))
+            self._handle = h.value
+        return self._handle
+
+    def launch(self, start, end, args, *, block_threads=256, ents_per_block=256, nblocks=-1, lds_bytes=0, stream=None):
+        n = len(args)
+        arr = (ctypes.c_void_p * max(n, 1))(*[ctypes.c_void_p(int(a) if a is not None else 0) for a in args])
+        _lib.call("fd_kernel_launch", self.handle, int(start), int(end), arr, n, int(block_threads),
+                  int(ents_per_block), int(nblocks), int(lds_bytes), stream)

@@ -1,0 +1,913 @@
+"""PyOP2-shaped data carriers with device (HBM) mirrors.
+
+Host-side mirror of pyop2/types/*.py, restricted to what the assembly hot path uses
+(SURVEY.md 2.1): Set/ExtrudedSet/Subset (set.py:18-543), DataSet (dataset.py:17-199),
+Dat (dat.py:27-711), Global (glob.py:21-480), Map/PermutedMap (map.py:17-470),
+Sparsity/Mat (mat.py:27-985).  Same names, argument meaning and error behaviour, so the
+tests in tests/ read like the reference's tests/pyop2/*.py.
+
+Every carrier keeps a numpy host copy (what users see through ``.data``) and a device
+mirror that the wrapper kernels read/write; validity flags decide when to copy
+(the reference's ``dat_version``/``halo_valid`` bookkeeping, dat.py:154-173, :622-678,
+extended by a host/device pair).
+"""
+from __future__ import annotations
+
+import ctypes
+import enum
+from contextlib import contextmanager
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .configuration import configuration
+from .device import DeviceBuffer
+
+IntType = np.dtype(np.int32)       # pyop2/datatypes.py:6-8 (32-bit PETSc indices)
+ScalarType = np.dtype(np.float64)  # tsfc/parameters.py:19
+RealType = ScalarType
+
+
+class Access(enum.IntEnum):        # pyop2/types/access.py:4-37
+    READ = 1
+    WRITE = 2
+    RW = 3
+    INC = 4
+    MIN = 5
+    MAX = 6
+
+
+READ, WRITE, RW, INC, MIN, MAX = (Access.READ, Access.WRITE, Access.RW, Access.INC, Access.MIN, Access.MAX)
+
+
+class IterationRegion(enum.IntEnum):
+    ON_BOTTOM = 1
+    ON_TOP = 2
+    ON_INTERIOR_FACETS = 3
+    ALL = 4
+
+
+ON_BOTTOM, ON_TOP, ON_INTERIOR_FACETS, ALL = (IterationRegion.ON_BOTTOM, IterationRegion.ON_TOP,
+                                              IterationRegion.ON_INTERIOR_FACETS, IterationRegion.ALL)
+
+
+# ---- exceptions (pyop2/exceptions.py) -------------------------------------------------
+class DataTypeError(TypeError):
+    pass
+
+
+class DataValueError(ValueError):
+    pass
+
+
+class MapValueError(ValueError):
+    pass
+
+
+class ModeValueError(ValueError):
+    pass
+
+
+class SetTypeError(TypeError):
+    pass
+
+
+class SizeTypeError(TypeError):
+    pass
+
+
+class SubsetIndexOutOfBounds(IndexError):
+    pass
+
+
+class DimTypeError(TypeError):
+    pass
+
+
+# ---- sets -----------------------------------------------------------------------------
+class Set:
+    """pyop2/types/set.py:18-121.  ``size`` is an int or the cumulative triple
+    ``(core, owned, total)`` (set.py:32-55): entities [0,core) touch no ghost data,
+    [core,owned) are owned but adjacent to ghosts, [owned,total) are ghosts that are
+    never executed (set.py:115-121)."""
+
+    _extruded = False
+    _extruded_periodic = False
+    _kernel_args_ = ()
+
+    def __init__(self, size, name=None, halo=None, comm=None):
+        if isinstance(size, (int, np.integer)):
+            size = [int(size)] * 3
+        size = [int(s) for s in size]
+        if len(size) != 3 or not (0 <= size[0] <= size[1] <= size[2]):
+            raise SizeTypeError(f"Set size must be an int or (core, owned, total) with core<=owned<=total, got {size}")
+        self._sizes = tuple(size)
+        self.name = name or f"set_{id(self):x}"
+        self.halo = halo
+        self.comm = comm
+
+    @property
+    def core_size(self):
+        return self._sizes[0]
+
+    @property
+    def size(self):
+        return self._sizes[1]
+
+    @property
+    def total_size(self):
+        return self._sizes[2]
+
+    @property
+    def sizes(self):
+        return self._sizes
+
+    @property
+    def core_part(self):          # set.py:115-117: (offset, size)
+        return (0, self.core_size)
+
+    @property
+    def owned_part(self):         # set.py:119-121
+        return (self.core_size, self.size - self.core_size)
+
+    @property
+    def superset(self):
+        return self
+
+    def __pow__(self, e):
+        return DataSet(self, dim=e)
+
+    def __len__(self):
+        return 1
+
+    def __iter__(self):
+        yield self
+
+    def __repr__(self):
+        return f"Set({self._sizes!r}, {self.name!r})"
+
+
+class ExtrudedSet(Set):
+    """Constant-layer extruded set (pyop2/types/set.py:307-393).  ``layers`` counts node
+    levels = cell layers + 1 (set.py:320-345); the kernel argument is [[0, layers]]
+    (set.py:342-345, 351-353)."""
+
+    _extruded = True
+
+    def __init__(self, parent, layers, extruded_periodic=False):
+        if isinstance(layers, (int, np.integer)):
+            if layers < 2:
+                raise SizeTypeError("Number of layers must be > 1 (not %s)." % layers)
+            self._layers_array = np.array([[0, int(layers)]], dtype=IntType)
+            self.constant_layers = True
+        else:
+            raise NotImplementedError("variable layers are out of scope (SURVEY.md 2.3: constant layers only)")
+        self._parent = parent
+        self._sizes = parent._sizes
+        self.name = parent.name + "_extruded"
+        self.halo = parent.halo
+        self.comm = parent.comm
+        self._extruded_periodic = extruded_periodic
+        self._dev_layers = None
+
+    @property
+    def parent(self):
+        return self._parent
+
+    @property
+    def layers(self):
+        return int(self._layers_array[0, 1])
+
+    @property
+    def layers_array(self):
+        return self._layers_array
+
+    def _layers_dev(self):
+        if self._dev_layers is None:
+            self._dev_layers = DeviceBuffer.from_numpy(self._layers_array)
+        return self._dev_layers.ptr
+
+
+class Subset(Set):
+    """pyop2/types/set.py:396-543: iterate only ``indices`` of ``superset``."""
+
+    def __init__(self, superset, indices):
+        if isinstance(superset, Subset):
+            indices = superset.indices[np.asarray(indices, dtype=IntType)]
+            superset = superset.superset
+        self._superset = superset
+        idx = np.unique(np.asarray(indices, dtype=IntType).reshape(-1))
+        if len(idx) and (idx[0] < 0 or idx[-1] >= superset.total_size):
+            raise SubsetIndexOutOfBounds("Out of bounds indices in Subset construction: [%d, %d) not [0, %d)" %
+                                         (idx[0], idx[-1], superset.total_size))
+        self._indices = idx
+        self._sizes = ((idx < superset.core_size).sum(), (idx < superset.size).sum(), len(idx))
+        self._sizes = tuple(int(s) for s in self._sizes)
+        self.name = superset.name + "_subset"
+        self.halo = superset.halo
+        self.comm = superset.comm
+        self._extruded = superset._extruded
+        self._dev_indices = None
+
+    @property
+    def superset(self):
+        return self._superset
+
+    @property
+    def indices(self):
+        return self._indices
+
+    @property
+    def layers_array(self):
+        return self._superset.layers_array
+
+    @property
+    def layers(self):
+        return self._superset.layers
+
+    def _layers_dev(self):
+        return self._superset._layers_dev()
+
+    def _indices_dev(self):
+        if self._dev_indices is None:
+            self._dev_indices = DeviceBuffer.from_numpy(self._indices)
+        return self._dev_indices.ptr
+
+
+class DataSet:
+    """pyop2/types/dataset.py:17-112: Set x dim."""
+
+    def __init__(self, iter_set, dim=1, name=None):
+        if isinstance(iter_set, DataSet):
+            dim = iter_set.dim
+            iter_set = iter_set.set
+        if isinstance(iter_set, Subset):
+            raise NotImplementedError("Deriving a DataSet from a Subset is unsupported")
+        if not isinstance(iter_set, Set):
+            raise SetTypeError(f"expected a Set, got {type(iter_set)}")
+        if isinstance(dim, (int, np.integer)):
+            dim = (int(dim),)
+        self._set = iter_set
+        self._dim = tuple(int(d) for d in dim)
+        self._cdim = int(np.prod(self._dim))
+        self.name = name or f"dset_{id(self):x}"
+
+    @property
+    def set(self):
+        return self._set
+
+    @property
+    def dim(self):
+        return self._dim
+
+    @property
+    def cdim(self):
+        return self._cdim
+
+    @property
+    def size(self):
+        return self._set.size
+
+    @property
+    def total_size(self):
+        return self._set.total_size
+
+    def __eq__(self, o):
+        return isinstance(o, DataSet) and o._set is self._set and o._dim == self._dim
+
+    def __hash__(self):
+        return hash((id(self._set), self._dim))
+
+
+def _as_dataset(x, dim=1):
+    if isinstance(x, DataSet):
+        return x
+    if isinstance(x, Set):
+        return DataSet(x, dim)
+    raise DataTypeError(f"expected Set or DataSet, got {type(x)}")
+
+
+# ---- host/device mirrored array ---------------------------------------------------------
+class _Mirrored:
+    """numpy host array + device mirror with validity flags."""
+
+    def _init_storage(self, host: np.ndarray):
+        self._host = np.ascontiguousarray(host)
+        self._dev: Optional[DeviceBuffer] = None
+        self._host_valid = True
+        self._dev_valid = False
+        self.dat_version = 0
+
+    def _to_host(self):
+        if not self._host_valid:
+            self._host = self._dev.download(self._host.dtype, self._host.shape)
+            self._host_valid = True
+        return self._host
+
+    def _dev_ptr(self, write: bool) -> int:
+        """Device pointer for a kernel; uploads if the host copy is newer."""
+        if self._dev is None:
+            self._dev = DeviceBuffer(self._host.nbytes)
+            self._dev_valid = False
+        if not self._dev_valid:
+            self._dev.upload(self._host)
+            self._dev_valid = True
+        if write:
+            self._host_valid = False
+            self.dat_version += 1
+        return self._dev.ptr
+
+    def _host_rw(self):
+        h = self._to_host()
+        self._dev_valid = False
+        self.dat_version += 1
+        return h
+
+
+class Dat(_Mirrored):
+    """pyop2/types/dat.py:27-711.  Shape (total_size, *dim), ghosts at the tail (dat.py:83)."""
+
+    def __init__(self, dataset, data=None, dtype=None, name=None):
+        if isinstance(dataset, Dat):
+            data = dataset.data_ro_with_halos.copy() if data is None else data
+            dtype = dataset.dtype if dtype is None else dtype
+            dataset = dataset.dataset
+        dataset = _as_dataset(dataset)
+        self._dataset = dataset
+        shape = (dataset.total_size,) + (() if dataset.dim == (1,) else dataset.dim)
+        if data is None:
+            dt = np.dtype(dtype) if dtype is not None else ScalarType
+            host = np.zeros(shape, dtype=dt)
+        else:
+            a = np.asarray(data, dtype=dtype)
+            dt = a.dtype if dtype is None else np.dtype(dtype)
+            try:
+                host = np.array(a, dtype=dt).reshape(shape)
+            except ValueError:
+                raise DataValueError("Invalid data: expected %d values, got %d!" % (int(np.prod(shape)), a.size))
+        self._init_storage(host)
+        self.name = name or f"dat_{id(self):x}"
+        self.halo_valid = True
+        self._halo_frozen = False
+        self._frozen_access_mode = None
+
+    # -- metadata
+    @property
+    def dataset(self):
+        return self._dataset
+
+    @property
+    def dim(self):
+        return self._dataset.dim
+
+    @property
+    def cdim(self):
+        return self._dataset.cdim
+
+    @property
+    def dtype(self):
+        return self._host.dtype
+
+    @property
+    def shape(self):
+        return self._host.shape
+
+    @property
+    def nbytes(self):
+        return self.dtype.itemsize * self.dataset.size * self.cdim
+
+    # -- data access (dat.py:134-250)
+    @property
+    def data(self):
+        self.halo_valid = False
+        return self._host_rw()[:self.dataset.size]
+
+    @property
+    def data_with_halos(self):
+        self.global_to_local_begin(RW)
+        self.global_to_local_end(RW)
+        self.halo_valid = False
+        return self._host_rw()
+
+    @property
+    def data_ro(self):
+        v = self._to_host()[:self.dataset.size].view()
+        v.setflags(write=False)
+        return v
+
+    @property
+    def data_ro_with_halos(self):
+        self.global_to_local_begin(READ)
+        self.global_to_local_end(READ)
+        v = self._to_host().view()
+        v.setflags(write=False)
+        return v
+
+    def zero(self, subset=None):      # dat.py:297-311
+        if subset is not None:
+            self._host_rw()[subset.indices] = 0
+            return
+        if self._dev is not None:
+            self._dev.zero()
+            self._dev_valid = True
+            self._host_valid = False
+            self.dat_version += 1
+        else:
+            self._host[...] = 0
+            self.dat_version += 1
+        self.halo_valid = True      # zero everywhere, halos included
+
+    def copy(self, other):
+        other._host_rw()[...] = self._to_host()
+        other.halo_valid = self.halo_valid
+
+    def assign(self, values):
+        self._host_rw()[...] = values
+
+    def __call__(self, access, path=None):
+        from .parloop import DatLegacyArg
+        if configuration["type_check"] and path is not None and path.toset != self.dataset.set:
+            raise MapValueError("To Set of Map does not match Set of Dat.")
+        return DatLegacyArg(self, path, access)
+
+    # -- halo state machine (dat.py:622-711)
+    def global_to_local_begin(self, access_mode):
+        halo = self.dataset.set.halo
+        if halo is None or self._halo_frozen:
+            return
+        if not self.halo_valid and access_mode in (READ, RW):
+            halo.global_to_local_begin(self, WRITE)
+        elif access_mode in (INC, MIN, MAX):
+            halo.fill_ghosts(self, access_mode)      # dat.py:631-636
+
+    def global_to_local_end(self, access_mode):
+        halo = self.dataset.set.halo
+        if halo is None or self._halo_frozen:
+            return
+        if not self.halo_valid and access_mode in (READ, RW):
+            halo.global_to_local_end(self, WRITE)
+            self.halo_valid = True
+        elif access_mode in (INC, MIN, MAX):
+            self.halo_valid = False
+
+    def local_to_global_begin(self, insert_mode):
+        halo = self.dataset.set.halo
+        if halo is None or self._halo_frozen:
+            return
+        halo.local_to_global_begin(self, insert_mode)
+
+    def local_to_global_end(self, insert_mode):
+        halo = self.dataset.set.halo
+        if halo is None or self._halo_frozen:
+            return
+        halo.local_to_global_end(self, insert_mode)
+        self.halo_valid = False
+
+    @contextmanager
+    def frozen_halo(self, access_mode):
+        """dat.py:680-711, 1245-1262: suppress per-parloop reverse exchanges; do ONE
+        local_to_global when the block exits (OneFormAssembler, assemble.py:1281-1286)."""
+        if self._halo_frozen:
+            yield
+            return
+        self.global_to_local_begin(access_mode)
+        self.global_to_local_end(access_mode)
+        self._halo_frozen = True
+        self._frozen_access_mode = access_mode
+        try:
+            yield
+        finally:
+            self._halo_frozen = False
+            self._frozen_access_mode = None
+            if access_mode in (INC, MIN, MAX):
+                self.local_to_global_begin(access_mode)
+                self.local_to_global_end(access_mode)
+
+    # -- small algebra used by the tests / assemble()
+    def norm(self):
+        return float(np.linalg.norm(self.data_ro))
+
+
+class Global(_Mirrored):
+    """pyop2/types/glob.py:21-480."""
+
+    def __init__(self, dim, data=None, dtype=None, name=None, comm=None):
+        if isinstance(dim, Global):
+            data, dtype, dim = dim.data_ro.copy(), dim.dtype, dim.dim
+        if isinstance(dim, (int, np.integer)):
+            dim = (int(dim),)
+        self._dim = tuple(dim)
+        n = int(np.prod(self._dim))
+        dt = np.dtype(dtype) if dtype is not None else (np.asarray(data).dtype if data is not None else ScalarType)
+        if data is None:
+            host = np.zeros(self._dim, dtype=dt)
+        else:
+            a = np.asarray(data, dtype=dt)
+            host = (np.full(self._dim, a, dtype=dt) if a.size == 1 and n != 1 else a.reshape(self._dim)).copy()
+        self._init_storage(host)
+        self.name = name or f"global_{id(self):x}"
+        self.comm = comm
+
+    @property
+    def dim(self):
+        return self._dim
+
+    @property
+    def cdim(self):
+        return int(np.prod(self._dim))
+
+    @property
+    def dtype(self):
+        return self._host.dtype
+
+    @property
+    def data(self):
+        return self._host_rw()
+
+    @data.setter
+    def data(self, value):
+        self._host_rw()[...] = value
+
+    @property
+    def data_ro(self):
+        v = self._to_host().view()
+        v.setflags(write=False)
+        return v
+
+    def zero(self):
+        self._host_rw()[...] = 0
+
+    def __call__(self, access, map_=None):
+        from .parloop import GlobalLegacyArg
+        return GlobalLegacyArg(self, access)
+
+
+Constant = Global
+
+
+# ---- maps --------------------------------------------------------------------------------
+class Map:
+    """pyop2/types/map.py:17-110: int array (iterset.total_size, arity) of IntType;
+    ``offset`` gives the extruded per-entry node stride (map.py:46-53)."""
+
+    VALUE_UNDEFINED = -1
+
+    def __init__(self, iterset, toset, arity, values=None, name=None, offset=None, offset_quotient=None):
+        if not isinstance(iterset, Set) or not isinstance(toset, Set):
+            raise SetTypeError("Map iterset/toset must be Sets")
+        self._iterset = iterset
+        self._toset = toset
+        self._arity = int(arity)
+        if values is None:
+            self._values = np.zeros((0, self._arity), dtype=IntType)
+        else:
+            v = np.asarray(values)
+            try:
+                self._values = np.ascontiguousarray(v.astype(IntType, copy=False).reshape(iterset.total_size, self._arity))
+            except ValueError:
+                raise DataValueError("Invalid data: expected %d values, got %d!" % (iterset.total_size * self._arity, v.size))
+        self.name = name or f"map_{id(self):x}"
+        self._offset = None if offset is None else tuple(int(o) for o in offset)
+        self._offset_quotient = offset_quotient
+        self._dev = None
+        self._plans = {}
+
+    iterset = property(lambda self: self._iterset)
+    toset = property(lambda self: self._toset)
+    arity = property(lambda self: self._arity)
+    offset = property(lambda self: self._offset)
+    offset_quotient = property(lambda self: self._offset_quotient)
+
+    @property
+    def values(self):
+        return self._values[:self.iterset.size]
+
+    @property
+    def values_with_halo(self):
+        return self._values
+
+    @property
+    def arities(self):
+        return (self._arity,)
+
+    def __len__(self):
+        return 1
+
+    def _base(self):
+        return self
+
+    def _dev_values(self):
+        if self._dev is None:
+            self._dev = DeviceBuffer.from_numpy(self._values)
+        return self._dev.ptr
+
+    def plan(self, start, end, epb):
+        """Cached block-localisation plan for [start, end) (include/fdhip.h: fd_plan_create)."""
+        key = (int(start), int(end), int(epb))
+        p = self._plans.get(key)
+        if p is None:
+            p = Plan(self, *key)
+            self._plans[key] = p
+        return p
+
+
+class PermutedMap(Map):
+    """pyop2/types/map.py:113-156: same values, entries visited as map[n][perm[i]]."""
+
+    def __init__(self, map_, permutation):
+        if not isinstance(map_, Map):
+            raise SetTypeError("PermutedMap needs a Map")
+        self.map_ = map_
+        self.permutation = np.asarray(permutation, dtype=IntType)
+        if sorted(self.permutation.tolist()) != list(range(map_.arity)):
+            raise DataValueError("permutation must be a permutation of range(arity)")
+        self.name = map_.name + "_perm"
+
+    def __getattr__(self, name):
+        return getattr(self.map_, name)
+
+    def _base(self):
+        return self.map_._base()
+
+
+class Plan:
+    """Python handle on an fd_plan_t."""
+
+    def __init__(self, map_: Map, start, end, epb):
+        h = ctypes.c_void_p()
+        _lib.call("fd_plan_create", map_._dev_values(), map_.arity, start, end, epb, None, ctypes.byref(h))
+        self.h = h.value
+        nb, mx, ll = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
+        _lib.call("fd_plan_info", self.h, ctypes.byref(nb), ctypes.byref(mx), ctypes.byref(ll))
+        self.nblocks, self.max_nd, self.list_len = nb.value, mx.value, ll.value
+        a, b, c = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.call("fd_plan_arrays", self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+        self.blkoff, self.list, self.lmap = a.value, b.value, c.value
+        self.start, self.end, self.epb, self.arity = start, end, epb, map_.arity
+
+    def download(self):
+        """(block_offsets, node_list, local_map) as numpy arrays -- for tests/diagnostics."""
+        blk = np.empty(self.nblocks + 1, dtype=np.int32)
+        lst = np.empty(self.list_len, dtype=np.int32)
+        lm = np.empty((self.end - self.start, self.arity), dtype=np.uint16)
+        for arr, p in ((blk, self.blkoff), (lst, self.list), (lm, self.lmap)):
+            if arr.nbytes:
+                _lib.call("fd_memcpy_d2h", arr.ctypes.data, p, arr.nbytes, None)
+        return blk, lst, lm
+
+    def __del__(self):
+        try:
+            if self.h:
+                _lib.load().fd_plan_free(self.h)
+        except Exception:
+            pass
+
+
+# ---- sparsity / matrix -------------------------------------------------------------------
+class Sparsity:
+    """pyop2/types/mat.py:27-291.  ``maps_and_regions`` = [(rmap, cmap, iteration_regions)];
+    the CSR pattern is built natively on the device (fd_csr_from_maps) instead of walking a
+    PETSc MATPREALLOCATOR (pyop2/sparsity.pyx:105-159)."""
+
+    def __init__(self, dsets, maps_and_regions, name=None, nest=None, block_sparse=None, diagonal_block=True):
+        if isinstance(dsets, (Set, DataSet)):
+            dsets = (dsets, dsets)
+        self._dsets = tuple(_as_dataset(d) for d in dsets)
+        norm = []
+        if isinstance(maps_and_regions, dict):
+            maps_and_regions = maps_and_regions.get((0, 0), [])
+        for entry in maps_and_regions:
+            if isinstance(entry, Map):
+                entry = (entry, entry, None)
+            r, c = entry[0], entry[1]
+            reg = entry[2] if len(entry) > 2 else None
+            if configuration["type_check"]:
+                if r.toset != self._dsets[0].set or c.toset != self._dsets[1].set:
+                    raise MapValueError("Map toset does not match the sparsity's DataSets")
+                if r.iterset.superset != c.iterset.superset:
+                    raise MapValueError("Iterset of both maps in a pair must be the same")
+            norm.append((r, c, tuple(reg) if reg else (ALL,)))
+        self._rcmaps = norm
+        self.name = name or f"sparsity_{id(self):x}"
+        self._has_diagonal = diagonal_block and self._dsets[0].set is self._dsets[1].set
+        self._built = False
+
+    dsets = property(lambda self: self._dsets)
+    rcmaps = property(lambda self: self._rcmaps)
+
+    @property
+    def dims(self):
+        return ((self._dsets[0].dim, self._dsets[1].dim),)
+
+    @property
+    def shape(self):
+        return (1, 1)
+
+    def _build(self):
+        if self._built:
+            return
+        _lib.require_gpu()
+        rset, cset = self._dsets
+        n = len(self._rcmaps)
+        VP = ctypes.c_void_p
+        rm, cm = (VP * n)(), (VP * n)()
+        ro, co = (VP * n)(), (VP * n)()
+        nent, ra, ca, nl = ((ctypes.c_int32 * n)() for _ in range(4))
+        keep = []
+        for k, (r, c, regions) in enumerate(self._rcmaps):
+            rm[k], cm[k] = r._base()._dev_values(), c._base()._dev_values()
+            it = r.iterset
+            nent[k] = it.size if not isinstance(it, Subset) else it.superset.size
+            ra[k], ca[k] = r.arity, c.arity
+            if it._extruded:
+                if tuple(regions) != (ALL,):
+                    raise NotImplementedError("sparsity over ON_BOTTOM/ON_TOP/ON_INTERIOR_FACETS regions")
+                nl[k] = it.layers - 1
+                o1 = np.asarray(r.offset, dtype=np.int32)
+                o2 = np.asarray(c.offset, dtype=np.int32)
+                keep += [o1, o2]
+                ro[k], co[k] = o1.ctypes.data, o2.ctypes.data
+            else:
+                nl[k] = 0
+        rp, ci, nnz = VP(), VP(), ctypes.c_int64()
+        _lib.call("fd_csr_from_maps", rset.set.total_size, cset.set.total_size, int(self._has_diagonal), n,
+                  rm, cm, nent, ra, ca, nl, ro, co, ctypes.byref(rp), ctypes.byref(ci), ctypes.byref(nnz), None)
+        self._node_rowptr = DeviceBuffer.wrap(rp.value, (rset.set.total_size + 1) * 4)
+        self._node_colidx = DeviceBuffer.wrap(ci.value, max(nnz.value, 1) * 4)
+        self._node_nnz = nnz.value
+        rbs, cbs = rset.cdim, cset.cdim
+        if rbs == 1 and cbs == 1:
+            self._rowptr, self._colidx, self._nnz = self._node_rowptr, self._node_colidx, nnz.value
+        else:
+            rp2, ci2 = VP(), VP()
+            _lib.call("fd_csr_expand_blocks", rset.set.total_size, rp.value, ci.value, rbs, cbs,
+                      ctypes.byref(rp2), ctypes.byref(ci2), None)
+            self._nnz = nnz.value * rbs * cbs
+            self._rowptr = DeviceBuffer.wrap(rp2.value, (rset.set.total_size * rbs + 1) * 4)
+            self._colidx = DeviceBuffer.wrap(ci2.value, max(self._nnz, 1) * 4)
+        self._built = True
+        self._elem_tables = {}
+
+    @property
+    def nrows(self):
+        return self._dsets[0].set.total_size * self._dsets[0].cdim
+
+    @property
+    def ncols(self):
+        return self._dsets[1].set.total_size * self._dsets[1].cdim
+
+    @property
+    def nz(self):
+        self._build()
+        return self._nnz
+
+    @property
+    def rowptr(self):
+        self._build()
+        return self._rowptr.download(np.int32, (self.nrows + 1,))
+
+    @property
+    def colidx(self):
+        self._build()
+        return self._colidx.download(np.int32, (self._nnz,))
+
+    @property
+    def nnz(self):
+        """Per node-row count of nonzeros (sparsity.nnz of the reference, mat.py:254-278)."""
+        self._build()
+        rp = self._node_rowptr.download(np.int32, (self._dsets[0].set.total_size + 1,))
+        return np.diff(rp)
+
+    def elem_table(self, rmap: Map, cmap: Map):
+        """Device table element -> nonzero position in the NODE pattern (fd_csr_elem_offsets)."""
+        self._build()
+        key = (id(rmap._base()), id(cmap._base()))
+        t = self._elem_tables.get(key)
+        if t is None:
+            nent = rmap._base().values_with_halo.shape[0]
+            t = DeviceBuffer(nent * rmap.arity * cmap.arity * 4)
+            _lib.call("fd_csr_elem_offsets", self._node_rowptr.ptr, self._node_colidx.ptr, rmap._base()._dev_values(),
+                      cmap._base()._dev_values(), nent, rmap.arity, cmap.arity, t.ptr, None)
+            self._elem_tables[key] = t
+        return t
+
+
+class Mat:
+    """pyop2/types/mat.py:607-985, as a device-resident scalar CSR ("aij")."""
+
+    def __init__(self, sparsity, dtype=None, name=None):
+        if not isinstance(sparsity, Sparsity):
+            raise DataTypeError("Mat needs a Sparsity")
+        self._sparsity = sparsity
+        self._dtype = np.dtype(dtype) if dtype is not None else ScalarType
+        if self._dtype != ScalarType:
+            raise DataTypeError("only float64 matrices are supported (ScalarType)")
+        self.name = name or f"mat_{id(self):x}"
+        self._vals = None
+        self.dat_version = 0
+
+    sparsity = property(lambda self: self._sparsity)
+    dtype = property(lambda self: self._dtype)
+
+    @property
+    def dims(self):
+        return self._sparsity.dims
+
+    @property
+    def nrows(self):
+        return self._sparsity.nrows
+
+    @property
+    def ncols(self):
+        return self._sparsity.ncols
+
+    @property
+    def nblock_rows(self):
+        return self._sparsity.dsets[0].set.size
+
+    @property
+    def nblock_cols(self):
+        return self._sparsity.dsets[1].set.size
+
+    def _values_dev(self):
+        if self._vals is None:
+            self._sparsity._build()
+            self._vals = DeviceBuffer(max(self._sparsity._nnz, 1) * 8)
+            self._vals.zero()       # fill_with_zeros, sparsity.pyx:162-389
+        return self._vals
+
+    def zero(self):                 # mat.py:851-855
+        self._values_dev().zero()
+        self.dat_version += 1
+
+    def assemble(self):             # mat.py:940-954: nothing is stashed off-process here
+        _lib.call("fd_device_sync")
+
+    def __call__(self, access, path, lgmaps=None, unroll_map=False):
+        from .parloop import MatLegacyArg
+        if access not in (WRITE, INC):
+            raise ModeValueError("Mat arguments must have access mode WRITE or INC")
+        rmap, cmap = path
+        if configuration["type_check"]:
+            if rmap.toset != self._sparsity.dsets[0].set or cmap.toset != self._sparsity.dsets[1].set:
+                raise MapValueError("Path maps do not match the Mat's DataSets")
+        return MatLegacyArg(self, (rmap, cmap), access, lgmaps)
+
+    # -- host views
+    def csr(self):
+        """(rowptr, colidx, values) numpy copies."""
+        sp = self._sparsity
+        vals = self._values_dev().download(np.float64, (sp._nnz,))
+        return sp.rowptr, sp.colidx, vals
+
+    def toscipy(self):
+        import scipy.sparse as ssp
+        rp, ci, v = self.csr()
+        return ssp.csr_matrix((v, ci, rp), shape=(self.nrows, self.ncols))
+
+    @property
+    def values(self):
+        """Dense copy of the owned block (mat.py:968-985)."""
+        nr = self.nblock_rows * self._sparsity.dsets[0].cdim
+        nc = self.nblock_cols * self._sparsity.dsets[1].cdim
+        return np.asarray(self.toscipy().todense())[:nr, :nc]
+
+    def _rows_dev(self, rows):
+        if isinstance(rows, Subset):
+            rows = rows.indices
+        return np.ascontiguousarray(np.asarray(rows, dtype=np.int32).reshape(-1))
+
+    def set_local_diagonal_entries(self, rows, diag_val=1.0, idx=None):   # mat.py:896-937
+        r = self._rows_dev(rows)
+        rbs = self._sparsity.dsets[0].cdim
+        if rbs > 1:
+            comps = range(rbs) if idx is None else [idx]
+            r = np.concatenate([r * rbs + c for c in comps]).astype(np.int32)
+        d = DeviceBuffer.from_numpy(r)
+        sp = self._sparsity
+        sp._build()
+        _lib.call("fd_csr_set_diagonal", sp._rowptr.ptr, sp._colidx.ptr,
+                  self._values_dev().ptr, d.ptr, len(r), float(diag_val), None)
+        _lib.call("fd_device_sync")
+        self.dat_version += 1
+
+    def zero_rows(self, rows, diag_val=1.0):                               # mat.py:857-891
+        r = self._rows_dev(rows)
+        rbs = self._sparsity.dsets[0].cdim
+        if rbs > 1:
+            r = np.concatenate([r * rbs + c for c in range(rbs)]).astype(np.int32)
+        sp = self._sparsity
+        sp._build()
+        d = DeviceBuffer.from_numpy(r)
+        _lib.call("fd_csr_zero_rows", sp._rowptr.ptr, sp._colidx.ptr, self._values_dev().ptr, d.ptr, len(r),
+                  float(diag_val), None)
+        _lib.call("fd_device_sync")
+        self.dat_version += 1
+
+    def mult(self, x: Dat, y: Dat):
+        """y = A x on the device (used for the A*x == action(a,x) identity)."""
+        sp = self._sparsity
+        sp._build()
+        _lib.call("fd_csr_spmv", self.nrows, sp._rowptr.ptr, sp._colidx.ptr, self._values_dev().ptr,
+                  x._dev_ptr(False), y._dev_ptr(True), None)

@@ -1,0 +1,414 @@
+"""Parloop execution: argument marshalling, halo protocol, launches.
+
+Mirror of pyop2/parloop.py:167-540 (Parloop) and :545-743 (legacy ``par_loop`` API).
+``Parloop.__call__`` keeps the reference's protocol (parloop.py:243-260):
+
+    halo begin -> compute(core part) -> halo end -> compute(owned part)
+               -> global reductions -> reverse halo exchange for INC/MIN/MAX Dats
+
+with the wrapper launched asynchronously on the device, so the RCCL exchange posted in
+``global_to_local_begin`` overlaps the core-entity kernel exactly where the reference
+overlaps MPI with ``_compute(core_part)``.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Any, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from .configuration import configuration
+from .device import DeviceBuffer
+from .kernel import (CStringLocalKernel, DatKernelArg, GlobalKernel, GlobalKernelArg, MapKernelArg, MatKernelArg,
+                     PermutedMapKernelArg)
+from .op2types import (ALL, INC, MAX, MIN, READ, RW, WRITE, Access, Dat, ExtrudedSet, Global, Map, MapValueError,
+                       Mat, PermutedMap, Set, SetTypeError, Subset)
+
+
+# ---- parloop arguments (pyop2/parloop.py:36-165) ----------------------------------------------
+@dataclass
+class GlobalParloopArg:
+    data: Global
+
+    @property
+    def maps(self):
+        return ()
+
+
+@dataclass
+class DatParloopArg:
+    data: Dat
+    map_: Optional[Map] = None
+
+    def __post_init__(self):
+        if self.map_ is not None and configuration["type_check"]:
+            m = self.map_
+            if m.iterset.total_size > 0 and len(m.values_with_halo) == 0:
+                raise MapValueError(f"{m} is not initialized")
+
+    @property
+    def maps(self):
+        return () if self.map_ is None else (self.map_,)
+
+
+@dataclass
+class MatParloopArg:
+    data: Mat
+    maps: Tuple[Map, Map]
+    lgmaps: Optional[Any] = None      # (row_lgmap, col_lgmap) int32 arrays, -1 = dropped (parloop.py:279-302)
+
+
+# ---- legacy args (pyop2/parloop.py:545-660): what dat(access, map) returns -------------------
+@dataclass
+class DatLegacyArg:
+    data: Dat
+    map_: Optional[Map]
+    access: Access
+
+    @property
+    def dtype(self):
+        return self.data.dtype
+
+    @property
+    def global_kernel_arg(self):
+        return DatKernelArg(self.data.dataset.dim, _map_kernel_arg(self.map_))
+
+    @property
+    def parloop_arg(self):
+        return DatParloopArg(self.data, self.map_)
+
+
+@dataclass
+class GlobalLegacyArg:
+    data: Global
+    access: Access
+
+    @property
+    def dtype(self):
+        return self.data.dtype
+
+    @property
+    def global_kernel_arg(self):
+        return GlobalKernelArg(self.data.dim)
+
+    @property
+    def parloop_arg(self):
+        return GlobalParloopArg(self.data)
+
+
+@dataclass
+class MatLegacyArg:
+    data: Mat
+    maps: Tuple[Map, Map]
+    access: Access
+    lgmaps: Optional[Any] = None
+
+    @property
+    def dtype(self):
+        return self.data.dtype
+
+    @property
+    def global_kernel_arg(self):
+        (rdim, cdim), = self.data.dims
+        return MatKernelArg((rdim, cdim), tuple(_map_kernel_arg(m) for m in self.maps), lgmaps=self.lgmaps is not None)
+
+    @property
+    def parloop_arg(self):
+        return MatParloopArg(self.data, self.maps, self.lgmaps)
+
+
+_mka_cache = {}
+
+
+def _map_kernel_arg(m):
+    """One MapKernelArg per base Map object, so GlobalKernel de-duplicates by identity."""
+    if m is None:
+        return None
+    base = m._base()
+    mk = _mka_cache.get(id(base))
+    if mk is None or mk[0] is not base:
+        mk = (base, MapKernelArg(base.arity, base.offset))
+        _mka_cache[id(base)] = mk
+    if isinstance(m, PermutedMap):
+        return PermutedMapKernelArg(mk[1], tuple(int(p) for p in m.permutation))
+    return mk[1]
+
+
+# ---- Parloop ------------------------------------------------------------------------------------
+class Parloop:
+    """pyop2/parloop.py:167-540."""
+
+    def __init__(self, global_knl: GlobalKernel, iterset: Set, arguments):
+        if len(global_knl.arguments) != len(arguments):
+            raise ValueError("You are trying to pass in a different number of arguments than the kernel is expecting")
+        for la, pa in zip(global_knl.local_kernel.arguments, arguments):
+            if not isinstance(pa, MatParloopArg) and hasattr(pa.data, "dtype") and np.dtype(la.dtype) != pa.data.dtype:
+                raise ValueError("Data types of the local kernel and the data carrier do not match")   # parloop.py:182-185
+        self.global_kernel = global_knl
+        self.iterset = iterset
+        self.arguments = list(arguments)
+        self._check_maps()
+        self._prepared = None
+        self._lgmap_dev = {}
+
+    local_kernel = property(lambda self: self.global_kernel.local_kernel)
+    accesses = property(lambda self: self.local_kernel.accesses)
+
+    def _check_maps(self):          # parloop.py:472-501
+        if not configuration["type_check"]:
+            return
+        it = self.iterset
+        for pa in self.arguments:
+            for m in getattr(pa, "maps", ()):
+                if m.iterset.superset is not it.superset and m.iterset is not it:
+                    if not (isinstance(it, ExtrudedSet) and m.iterset is it.parent):
+                        raise MapValueError("Iterset of arg doesn't match ParLoop iterset.")
+            if isinstance(pa, DatParloopArg) and pa.map_ is None:
+                ds = pa.data.dataset.set
+                base = it.parent if isinstance(it, ExtrudedSet) else it.superset
+                if ds is not it and ds is not base and ds is not getattr(base, "parent", None):
+                    raise SetTypeError("Iterset of direct arg doesn't match ParLoop iterset.")
+
+    # -- preparation: compile + choose launch geometry + build plans
+    def _prepare(self):
+        if self._prepared is not None:
+            return self._prepared
+        _lib.require_gpu()
+        cw = self.global_kernel.compile()
+        src = cw.src
+        maps = []
+        for pa in self.arguments:
+            for m in getattr(pa, "maps", ()):
+                if all(m._base() is not q for q in maps):
+                    maps.append(m._base())
+        assert len(maps) == src.nmaps
+        prep = {"cw": cw, "maps": maps}
+        if src.mode == "staged":
+            prep["parts"] = {}
+        self._prepared = prep
+        return prep
+
+    def _staged_geometry(self, start, end):
+        """Pick ents_per_block so that the block's staged rows fit the LDS budget; build plans."""
+        prep = self._prepared
+        key = (start, end)
+        geo = prep["parts"].get(key)
+        if geo is not None:
+            return geo
+        src = prep["cw"].src
+        maps = prep["maps"]
+        maxar = max(maps[mi].arity for mi in src.staged_maps)
+        epb = configuration["ents_per_block"]
+        while epb * maxar > 16384:
+            epb //= 2
+        limit = configuration["lds_limit"]
+        while True:
+            plans = {mi: maps[mi].plan(start, end, epb) for mi in src.staged_maps}
+            lds = sum(((plans[mi].max_nd * c * isz) + 15) // 16 * 16 for mi, c, isz in src.lds_items)
+            if lds <= limit or epb <= 64:
+                break
+            epb //= 2
+        if lds > 160 * 1024:
+            raise _lib.FDHipError("staged wrapper does not fit LDS even at 64 entities per block")
+        geo = {"epb": epb, "plans": plans, "lds": lds}
+        prep["parts"][key] = geo
+        return geo
+
+    # -- argument list in the kernel's parameter order
+    def _arglist(self, start, end):
+        prep = self._prepare()
+        src = prep["cw"].src
+        geo = self._staged_geometry(start, end) if src.mode == "staged" else None
+        out = []
+        for desc in src.layout:
+            kind = desc[0]
+            if kind == "layers":
+                out.append(self.iterset._layers_dev())
+            elif kind == "subset":
+                out.append(self.iterset._indices_dev())
+            elif kind == "arg":
+                pa = self.arguments[desc[1]]
+                acc = self.accesses[desc[1]]
+                if isinstance(pa, MatParloopArg):
+                    pa.data.dat_version += 1
+                    out.append(pa.data._values_dev().ptr)
+                else:
+                    out.append(pa.data._dev_ptr(write=acc != READ))
+            elif kind == "map":
+                out.append(prep["maps"][desc[1]]._dev_values())
+            elif kind == "epb":
+                out.append(geo["epb"] if geo else 0)
+            elif kind == "plan_blkoff":
+                out.append(geo["plans"][desc[1]].blkoff)
+            elif kind == "plan_list":
+                out.append(geo["plans"][desc[1]].list)
+            elif kind == "plan_lmap":
+                out.append(geo["plans"][desc[1]].lmap)
+            elif kind == "plan_maxnd":
+                out.append(geo["plans"][desc[1]].max_nd)
+            elif kind == "mat_table":
+                pa = self.arguments[desc[1]]
+                out.append(pa.data.sparsity.elem_table(*pa.maps).ptr)
+            elif kind == "mat_node_rowptr":
+                pa = self.arguments[desc[1]]
+                pa.data.sparsity._build()
+                out.append(pa.data.sparsity._node_rowptr.ptr)
+            elif kind == "mat_rowptr":
+                pa = self.arguments[desc[1]]
+                pa.data.sparsity._build()
+                out.append(pa.data.sparsity._rowptr.ptr)
+            elif kind == "mat_colidx":
+                pa = self.arguments[desc[1]]
+                pa.data.sparsity._build()
+                out.append(pa.data.sparsity._colidx.ptr)
+            elif kind in ("mat_row_lgmap", "mat_col_lgmap"):
+                pa = self.arguments[desc[1]]
+                lg = pa.lgmaps[0 if kind == "mat_row_lgmap" else 1]
+                out.append(self._lgmap(lg))
+            else:
+                raise AssertionError(kind)
+        return out, geo
+
+    def _lgmap(self, lg):
+        a = np.ascontiguousarray(lg, dtype=np.int32)
+        key = id(lg)
+        d = self._lgmap_dev.get(key)
+        if d is None or d[0] is not lg:
+            d = (lg, DeviceBuffer.from_numpy(a))
+            self._lgmap_dev[key] = d
+        return d[1].ptr
+
+    # -- execution (parloop.py:243-260)
+    def __call__(self):
+        self.compute()
+
+    def compute(self):
+        self.global_to_local_begin()
+        self._compute(self.iterset.core_part)
+        self.global_to_local_end()
+        self._compute(self.iterset.owned_part)
+        self.reduction_begin()
+        self.local_to_global_begin()
+        self.reduction_end()
+        self.local_to_global_end()
+        self.finalize_assembly()
+
+    def _compute(self, part):
+        offset, size = part
+        if size <= 0:
+            return
+        start, end = offset, offset + size
+        args, geo = self._arglist(start, end)
+        cw = self._prepared["cw"]
+        src = cw.src
+        threads = src.block_threads
+        if src.mode == "staged":
+            cw.launch(start, end, args, block_threads=threads, ents_per_block=geo["epb"], lds_bytes=geo["lds"])
+        else:
+            total = size
+            if self.iterset._extruded and src.layer_parallel:
+                total *= self._nlayers_iterated()
+            nblocks = max(1, (total + threads - 1) // threads)
+            cw.launch(start, end, args, block_threads=threads, ents_per_block=threads, nblocks=nblocks)
+
+    def _nlayers_iterated(self):
+        from .op2types import ON_BOTTOM, ON_TOP, ON_INTERIOR_FACETS
+        L = self.iterset.layers
+        reg = self.global_kernel._iteration_region
+        if reg in (ON_BOTTOM, ON_TOP):
+            return 1
+        if reg == ON_INTERIOR_FACETS:
+            return max(L - 2, 0)
+        return L - 1
+
+    # -- halo protocol (parloop.py:320-409)
+    def _indirect_dats(self):
+        for pa, acc in zip(self.arguments, self.accesses):
+            if isinstance(pa, DatParloopArg) and pa.map_ is not None:
+                yield pa.data, acc
+
+    def global_to_local_begin(self):
+        for d, acc in self._indirect_dats():
+            if acc != WRITE:
+                d.global_to_local_begin(acc)
+
+    def global_to_local_end(self):
+        for d, acc in self._indirect_dats():
+            if acc != WRITE:
+                d.global_to_local_end(acc)
+
+    def local_to_global_begin(self):
+        for d, acc in self._indirect_dats():
+            if acc in (INC, MIN, MAX):
+                d.local_to_global_begin(acc)
+
+    def local_to_global_end(self):
+        for d, acc in self._indirect_dats():
+            if acc in (INC, MIN, MAX):
+                d.local_to_global_end(acc)
+        for pa, acc in zip(self.arguments, self.accesses):
+            if isinstance(pa, DatParloopArg) and acc != READ:
+                if pa.data.dataset.set.halo is not None:
+                    pa.data.halo_valid = False
+
+    def reduction_begin(self):        # parloop.py:411-442 (MPI_Iallreduce of Globals)
+        pass
+
+    def reduction_end(self):
+        from .halo import allreduce_global
+        for pa, acc in zip(self.arguments, self.accesses):
+            if isinstance(pa, GlobalParloopArg) and acc in (INC, MIN, MAX):
+                allreduce_global(pa.data, acc, self.iterset.comm)
+
+    def finalize_assembly(self):
+        pass
+
+
+def parloop(knl, *args, **kwargs):
+    """pyop2/parloop.py:746-763."""
+    if isinstance(knl, GlobalKernel):
+        Parloop(knl, *args, **kwargs)()
+    else:
+        LegacyParloop(knl, *args, **kwargs)()
+
+
+class LegacyParloop(Parloop):
+    """pyop2/parloop.py:709-743: build the GlobalKernel from dat(access, map)-style args."""
+
+    def __init__(self, local_knl, iterset, *args, **kwargs):
+        if not isinstance(iterset, Set):
+            raise SetTypeError("Iteration set is of the wrong type")
+        for a in args:
+            if not isinstance(a, (DatLegacyArg, GlobalLegacyArg, MatLegacyArg)):
+                raise ValueError("par_loop arguments must be created by calling a Dat/Global/Mat with an access mode")
+        if local_knl.accesses is None:
+            local_knl = local_knl.with_signature([a.access for a in args], [a.dtype for a in args])
+        extruded = iterset._extruded
+        subset = isinstance(iterset, Subset)
+        gk = _global_kernel_cached(local_knl, args, extruded=extruded, constant_layers=extruded, subset=subset,
+                                   iteration_region=kwargs.get("iteration_region"),
+                                   pass_layer_arg=kwargs.get("pass_layer_arg", False))
+        super().__init__(gk, iterset, [a.parloop_arg for a in args])
+
+
+_gk_cache = {}
+
+
+def _global_kernel_cached(lk, args, **flags):
+    gargs = [a.global_kernel_arg for a in args]
+    gk = GlobalKernel(lk, gargs, **flags)
+    hit = _gk_cache.get(gk.cache_key)
+    if hit is not None:
+        return hit
+    _gk_cache[gk.cache_key] = gk
+    return gk
+
+
+def par_loop(kernel, iterset, *args, **kwargs):
+    """pyop2/parloop.py:746-763 ``par_loop``: build and run immediately."""
+    LegacyParloop(kernel, iterset, *args, **kwargs)()
+
+
+ParLoop = LegacyParloop

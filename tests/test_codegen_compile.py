@@ -1,0 +1,94 @@
+"""CPU: every wrapper shape the code generator can emit cross-compiles for gfx950 with hipcc
+(no GPU needed) -- the analogue of the reference's "does the generated C compile" guarantee
+(pyop2/compilation.py:527-611)."""
+import numpy as np
+import pytest
+
+from firedrake_amd import op2
+from firedrake_amd.codegen import generate_wrapper, staged_eligible
+from firedrake_amd.compilation import compile_hip
+import golden_kernels as gk
+
+
+def _mesh():
+    nodes, ele = op2.Set(4), op2.Set(2)
+    m = op2.Map(ele, nodes, 3, gk.ELEM_NODE)
+    return nodes, ele, m
+
+
+def _compile(pl, modes=("staged", "direct")):
+    out = []
+    for mode in modes:
+        if mode == "staged" and not staged_eligible(pl.global_kernel):
+            continue
+        src = generate_wrapper(pl.global_kernel, mode)
+        path = compile_hip(src.source, src.symbol + "_" + mode)
+        assert path.endswith(".hsaco")
+        out.append(mode)
+    return out
+
+
+def test_rhs_staged_and_direct():
+    nodes, ele, m = _mesh()
+    b, x, f = op2.Dat(nodes), op2.Dat(nodes ** 2, gk.COORDS), op2.Dat(nodes, gk.F)
+    pl = op2.LegacyParloop(op2.Kernel(gk.RHS_Q6, "rhs_q6"), ele, b(op2.INC, m), x(op2.READ, m), f(op2.READ, m))
+    assert _compile(pl) == ["staged", "direct"]
+
+
+@pytest.mark.parametrize("scatter", ["table", "search"])
+@pytest.mark.parametrize("cdim", [1, 2])
+def test_mat_wrappers(scatter, cdim, monkeypatch):
+    from firedrake_amd.configuration import configuration
+    monkeypatch.setitem(configuration, "mat_scatter", scatter)
+    nodes, ele, m = _mesh()
+    mat = op2.Mat(op2.Sparsity((nodes ** cdim, nodes ** cdim), [(m, m, None)]))
+    x = op2.Dat(nodes ** 2, gk.COORDS)
+    k = op2.Kernel(gk.MASS_AFFINE if cdim == 1 else gk.MASS_VEC_AFFINE, "mass_affine" if cdim == 1 else "mass_vec_affine")
+    lg = np.array([-1, 1, 2, 3], dtype=np.int32)
+    for lgmaps in (None, (lg, lg)):
+        pl = op2.LegacyParloop(k, ele, mat(op2.INC, (m, m), lgmaps=lgmaps), x(op2.READ, m))
+        assert _compile(pl) == ["staged", "direct"]
+
+
+def test_integer_minmax_global_subset_permuted():
+    it, ind = op2.Set(16), op2.Set(16)
+    idm = op2.Map(it, ind, 1, np.arange(16))
+    a, b = op2.Dat(ind, dtype=np.int32), op2.Dat(ind, dtype=np.int32)
+    _compile(op2.LegacyParloop(op2.Kernel("static void mx(int *a, int *b) { *a = *a < *b ? *b : *a; }", "mx"),
+                               it, a(op2.MAX, idm), b(op2.READ, idm)))
+    x = op2.Dat(ind, dtype=np.uint32)
+    g = op2.Global(1, 0, np.uint32)
+    _compile(op2.LegacyParloop(op2.Kernel("static void gi(unsigned int *x, unsigned int *inc) { (*x) = (*x) + 1; (*inc) += (*x); }", "gi"),
+                               it, x(op2.RW, idm), g(op2.INC)))
+    ss = op2.Subset(it, [1, 3, 5])
+    d = op2.Dat(ind)
+    _compile(op2.LegacyParloop(op2.Kernel("static void one(double *x) { *x += 1.0; }", "one"), ss, d(op2.INC, idm)))
+    m1 = op2.Map(op2.Set(1), op2.Set(4), 4, [1, 2, 3, 0])
+    m2 = op2.PermutedMap(m1, [3, 2, 0, 1])
+    d1, d2 = op2.Dat(m1.toset, dtype=np.int32), op2.Dat(m1.toset, dtype=np.int32)
+    _compile(op2.LegacyParloop(op2.Kernel("void cp(int *to, const int *from) { for (int i = 0; i < 4; i++) to[i] = from[i]; }", "cp"),
+                               m1.iterset, d2(op2.WRITE, m2), d1(op2.READ, m1)))
+
+
+def test_extruded_wrappers():
+    base = op2.Set(4)
+    ext = op2.ExtrudedSet(base, layers=5)
+    nodes = op2.Set(6 * 5)
+    cm = op2.Map(ext, nodes, 6, np.arange(24) % 25, offset=[1] * 6)
+    x = op2.Dat(nodes ** 2)
+    g = op2.Global(1, 0.0)
+    k = op2.Kernel("static void vol(double A[1], const double x[12]) { A[0] += x[0]; }", "vol")
+    for region in (None, op2.ON_BOTTOM, op2.ON_TOP):
+        pl = op2.LegacyParloop(k, ext, g(op2.INC), x(op2.READ, cm), iteration_region=region)
+        assert _compile(pl) == ["direct"]
+    k2 = op2.Kernel("static void volf(double A[1], const double x[24]) { A[0] += x[12]; }", "volf")
+    pl = op2.LegacyParloop(k2, ext, g(op2.INC), x(op2.READ, cm), iteration_region=op2.ON_INTERIOR_FACETS)
+    assert _compile(pl) == ["direct"]
+    d = op2.Dat(base)
+    pl = op2.LegacyParloop(op2.Kernel("static void k1(double *x) { *x += 1.0; }", "k1"), ext, d(op2.INC))
+    assert _compile(pl) == ["direct"]
+    f = op2.Dat(op2.Set(4 * 4))
+    fm = op2.Map(ext, f.dataset.set, 1, np.arange(4) * 4, offset=[1])
+    pl = op2.LegacyParloop(op2.Kernel("static void blah(double* x, int layer_arg){ x[0] = layer_arg; }", "blah"), ext,
+                           f(op2.WRITE, fm), pass_layer_arg=True)
+    assert _compile(pl) == ["direct"]

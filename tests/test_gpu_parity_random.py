@@ -1,0 +1,103 @@
+"""GPU parity at larger sizes: staged (LDS plan) wrapper vs direct wrapper vs oracle on
+seeded unstructured-looking inputs, plus the block-localisation plan against a numpy restatement."""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+from firedrake_amd import op2
+from firedrake_amd.configuration import configuration
+import golden_kernels as gk
+from helpers import oracle_run, structured_tri_mesh
+
+pytestmark = pytest.mark.gpu
+
+
+def _plan_ref(mapv, start, end, epb):
+    blk, lst, lm = [0], [], np.zeros((end - start, mapv.shape[1]), dtype=np.uint16)
+    for b0 in range(start, end, epb):
+        b1 = min(end, b0 + epb)
+        u, inv = np.unique(mapv[b0:b1].reshape(-1), return_inverse=True)
+        lst.append(u)
+        lm[b0 - start:b1 - start] = inv.reshape(b1 - b0, -1)
+        blk.append(blk[-1] + len(u))
+    return np.array(blk, np.int32), np.concatenate(lst).astype(np.int32), lm
+
+
+@pytest.mark.parametrize("arity,epb,n", [(3, 256, 5000), (4, 1024, 20000), (10, 512, 7001), (1, 64, 130), (8, 2048, 4096)])
+def test_plan_matches_numpy(arity, epb, n):
+    rng = np.random.default_rng(arity)
+    ntgt = max(n // 2, 4)
+    # locality like a mesh numbering: targets near the entity index, plus a few far ones
+    base = (np.arange(n)[:, None] * ntgt // n + rng.integers(0, 40, size=(n, arity))) % ntgt
+    it, to = op2.Set(n), op2.Set(ntgt)
+    m = op2.Map(it, to, arity, base.astype(np.int32))
+    for (s, e) in [(0, n), (17, n - 5)]:
+        p = m.plan(s, e, epb)
+        blk, lst, lm = p.download()
+        rblk, rlst, rlm = _plan_ref(m.values_with_halo, s, e, epb)
+        assert np.array_equal(blk, rblk) and np.array_equal(lst, rlst) and np.array_equal(lm, rlm)
+        assert p.max_nd == np.diff(rblk).max() and p.nblocks == len(rblk) - 1
+
+
+@pytest.mark.parametrize("nx,ny", [(7, 5), (64, 64), (200, 150)])
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_p1_mass_and_rhs_all_paths(nx, ny, shuffle, monkeypatch):
+    coords, cells = structured_tri_mesh(nx, ny, perturb=0.2)
+    rng = np.random.default_rng(3)
+    if shuffle:
+        cells = cells[rng.permutation(len(cells))]
+    nodes, ele = op2.Set(len(coords)), op2.Set(len(cells))
+    m = op2.Map(ele, nodes, 3, cells)
+    x = op2.Dat(nodes ** 2, coords)
+    f = op2.Dat(nodes, rng.standard_normal(len(coords)))
+    krhs, kmass = op2.Kernel(gk.RHS_Q6, "rhs_q6"), op2.Kernel(gk.MASS_Q6, "mass_q6")
+    ob = oracle_run(krhs, ele, op2.Dat(nodes)(op2.INC, m), x(op2.READ, m), f(op2.READ, m))[0]
+    sp = op2.Sparsity((nodes ** 1, nodes ** 1), [(m, m, None)])
+    ocsr = oracle_run(kmass, ele, op2.Mat(sp)(op2.INC, (m, m)), x(op2.READ, m))[0]
+    # sparsity identical to the oracle's restatement of sparsity.pyx
+    assert np.array_equal(sp.rowptr, ocsr.rowptr) and np.array_equal(sp.colidx, ocsr.colidx)
+    for mode in ("auto", "direct"):
+        for scatter in ("table", "search"):
+            monkeypatch.setitem(configuration, "mode", mode)
+            monkeypatch.setitem(configuration, "mat_scatter", scatter)
+            b = op2.Dat(nodes)
+            op2.par_loop(krhs, ele, b(op2.INC, m), x(op2.READ, m), f(op2.READ, m))
+            # tolerance: SURVEY.md Appendix D -- atomics reorder fp adds
+            assert_allclose(b.data, ob, rtol=0, atol=1e-12 * max(1.0, np.abs(ob).max()))
+            mat = op2.Mat(sp)
+            op2.par_loop(kmass, ele, mat(op2.INC, (m, m)), x(op2.READ, m))
+            _, _, v = mat.csr()
+            assert_allclose(v, ocsr.values, rtol=0, atol=1e-12 * np.abs(ocsr.values).max())
+    # identities the reference's regression tests use: sum(M) = |Omega| (test_assemble.py:60-73)
+    assert_allclose(v.sum(), 1.0, rtol=1e-6)
+    # A*x == action: M f vs rhs(f)  (test_matrix_free.py:97-123)
+    y = op2.Dat(nodes)
+    mat.mult(f, y)
+    assert_allclose(y.data, ob, rtol=0, atol=1e-9 * np.abs(ob).max())
+
+
+def test_repeated_launch_accumulates_and_versions():
+    coords, cells = structured_tri_mesh(20, 20)
+    nodes, ele = op2.Set(len(coords)), op2.Set(len(cells))
+    m = op2.Map(ele, nodes, 3, cells)
+    x, f, b = op2.Dat(nodes ** 2, coords), op2.Dat(nodes, np.ones(len(coords))), op2.Dat(nodes)
+    pl = op2.LegacyParloop(op2.Kernel(gk.RHS_AFFINE, "rhs_affine"), ele, b(op2.INC, m), x(op2.READ, m), f(op2.READ, m))
+    pl()
+    once = b.data_ro.copy()
+    pl()
+    assert_allclose(b.data_ro, 2 * once, rtol=1e-13)
+    f.data[:] = 2.0                     # host write must reach the device (dat_version staleness)
+    b.zero()
+    pl()
+    assert_allclose(b.data_ro, 2 * once, rtol=1e-13)
+    assert_allclose(b.data_ro.sum(), 2.0, rtol=1e-12)
+
+
+def test_empty_and_tiny_iteration_sets():
+    nodes, ele = op2.Set(4), op2.Set(0)
+    m = op2.Map(ele, nodes, 3, np.zeros((0, 3), np.int32))
+    b = op2.Dat(nodes)
+    x = op2.Dat(nodes ** 2)
+    op2.par_loop(op2.Kernel(gk.MASS_AFFINE.replace("mass_affine", "mass_e").replace("double A[9]", "double *A"), "mass_e"),
+                 ele, b(op2.INC, m), x(op2.READ, m))
+    assert np.all(b.data == 0)

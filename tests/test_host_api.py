@@ -1,0 +1,99 @@
+"""CPU: host-side logic of the PyOP2-shaped carriers (mirrors tests/pyop2/test_api.py behaviours
+that the hot path depends on)."""
+import numpy as np
+import pytest
+
+from firedrake_amd import op2
+
+
+def test_set_sizes_core_owned_total():
+    s = op2.Set((3, 5, 8))
+    assert (s.core_size, s.size, s.total_size) == (3, 5, 8)
+    assert s.core_part == (0, 3) and s.owned_part == (3, 2)   # pyop2/types/set.py:115-121
+    with pytest.raises(op2.SizeTypeError):
+        op2.Set((5, 3, 8))
+
+
+def test_dat_shape_and_halo_tail():
+    s = op2.Set((2, 4, 6))
+    d = op2.Dat(s ** 2, np.arange(12.0))
+    assert d.data.shape == (4, 2) and d.data_with_halos.shape == (6, 2)     # dat.py:83
+    assert d.cdim == 2 and d.dtype == np.float64
+    with pytest.raises(op2.DataValueError):
+        op2.Dat(s ** 2, np.arange(5.0))
+
+
+def test_map_validation():
+    it, to = op2.Set(3), op2.Set(4)
+    m = op2.Map(it, to, 2, [0, 1, 1, 2, 2, 3])
+    assert m.values.shape == (3, 2) and m.values.dtype == np.int32
+    with pytest.raises(op2.DataValueError):
+        op2.Map(it, to, 2, [0, 1, 2])
+    d = op2.Dat(op2.Set(4))
+    with pytest.raises(op2.MapValueError):       # test_indirect_loop.py:122-127
+        d(op2.READ, m)
+
+
+def test_mismatching_iterset_raises():
+    # tests/pyop2/test_indirect_loop.py:115-120
+    it, ind = op2.Set(8), op2.Set(8)
+    x = op2.Dat(ind, dtype=np.uint32)
+    with pytest.raises(op2.MapValueError):
+        op2.LegacyParloop(op2.Kernel("", "dummy"), it, x(op2.WRITE, op2.Map(op2.Set(8), ind, 1, np.arange(8))))
+
+
+def test_uninitialised_map_raises():
+    # tests/pyop2/test_indirect_loop.py:129-135
+    it, ind = op2.Set(8), op2.Set(8)
+    x = op2.Dat(ind, dtype=np.uint32)
+    with pytest.raises(op2.MapValueError):
+        op2.LegacyParloop(op2.Kernel("static void wo(unsigned int* x) { *x = 42; }", "wo"), it,
+                          x(op2.WRITE, op2.Map(it, ind, 1)))
+
+
+def test_mat_invalid_mode():
+    # tests/pyop2/test_matrices.py:575-580
+    nodes, ele = op2.Set(4), op2.Set(2)
+    m = op2.Map(ele, nodes, 3, [0, 1, 3, 2, 3, 1])
+    mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(m, m, None)]))
+    for mode in (op2.READ, op2.RW, op2.MAX, op2.MIN):
+        with pytest.raises(op2.ModeValueError):
+            mat(mode, (m, m))
+
+
+def test_subset_sizes_and_bounds():
+    s = op2.Set((2, 4, 6))
+    ss = op2.Subset(s, [5, 0, 3, 3])
+    assert list(ss.indices) == [0, 3, 5] and ss.sizes == (1, 2, 3)
+    with pytest.raises(op2.SubsetIndexOutOfBounds):
+        op2.Subset(s, [6])
+
+
+def test_extruded_set_layers():
+    s = op2.ExtrudedSet(op2.Set(5), layers=11)
+    assert s.layers == 11 and s.layers_array.tolist() == [[0, 11]]      # set.py:342-345
+    with pytest.raises(op2.SizeTypeError):
+        op2.ExtrudedSet(op2.Set(5), layers=1)
+
+
+def test_global_kernel_cache_key_dedups_maps():
+    nodes, ele = op2.Set(4), op2.Set(2)
+    m = op2.Map(ele, nodes, 3, [0, 1, 3, 2, 3, 1])
+    b, c = op2.Dat(nodes), op2.Dat(nodes ** 2)
+    k = op2.Kernel("static void k(double *b, const double *x) { b[0] += x[0]; }", "k")
+    p1 = op2.LegacyParloop(k, ele, b(op2.INC, m), c(op2.READ, m))
+    p2 = op2.LegacyParloop(k, ele, b(op2.INC, m), c(op2.READ, m))
+    assert p1.global_kernel is p2.global_kernel
+    from firedrake_amd.codegen import generate_wrapper
+    src = generate_wrapper(p1.global_kernel, "direct")
+    assert src.nmaps == 1     # one pointer per distinct Map (parloop.py:210-212)
+
+
+def test_wrong_dtype_rejected():
+    s = op2.Set(4)
+    d = op2.Dat(s, dtype=np.float64)
+    k = op2.Kernel("static void k(int *x) { x[0] = 1; }", "k", accesses=[op2.WRITE], dtypes=[np.int32])
+    from firedrake_amd.kernel import GlobalKernel, DatKernelArg
+    gk = GlobalKernel(k, [DatKernelArg((1,))])
+    with pytest.raises(ValueError):             # pyop2/parloop.py:182-185
+        op2.Parloop(gk, s, [op2.DatParloopArg(d)])
