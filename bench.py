@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""bench.py -- assembled DoFs/s (residual + Jacobian) of the MI355X finite-element assembly path.
+
+Workload (BASELINE.json configs[1], "C2"): Poisson CG1 on UnitCubeMesh(215^3) tets -- 59 630 250
+cells, 10 077 696 DoFs per GPU; one "step" = one Newton-step assembly = assemble(F) + assemble(J):
+zero the tensors, run the cell kernels (HIP wrapper kernels through the C ABI), exchange halos
+(N > 1), apply the boundary conditions.  Inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Weak scaling: every rank owns a 215-layer z-slab of a 215 x 215 x (215 N) cube grid.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(ncell, arity, nnode, gdim, ncoeff, nnz=None):
+    """every input array read once, every output written once (+ the zeroing pass)."""
+    if nnz is None:   # residual: map + coords + coefficients + output write + zeroing
+        return ncell * arity * 4 + nnode * gdim * 8 + ncoeff * nnode * 8 + nnode * 8 + nnode * 8
+    return ncell * arity * 4 + nnode * gdim * 8 + nnz * 8 + nnz * 8      # Jacobian: map + coords + values + zeroing
+
+
+def cpu_baseline(n_sample, degree, seconds_hint=20.0):
+    """Time the oracle (CPU restatement of the PyOP2 wrapper, compiled with the reference's own
+    flags) on a bounded sample of the same workload: an n_sample^3-cube mesh, 1 thread."""
+    import oracle
+    from oracle import ODat, OMat, READ, INC
+    from firedrake_amd import forms, mesh as fmesh
+    m = fmesh.UnitCubeMesh(n_sample, degrees=(degree,))
+    V, X = m.space(degree), m.coord_space
+    cm, xm = V.cell_node_map.values_with_halo, X.cell_node_map.values_with_halo
+    nn = V.node_set.total_size
+    coords = np.array(m.coordinates.data_ro_with_halos)
+    pts = V.node_points
+    u = np.sin(3 * pts[:, 0]) * np.cos(2 * pts[:, 1]) + 0.3 * pts[:, 2]
+    f = (1 + 8 * np.pi ** 2) * np.cos(2 * np.pi * pts[:, 0]) * np.cos(2 * np.pi * pts[:, 1])
+    r = np.zeros(nn)
+    kr, kj = forms.poisson_residual_kernel(3, degree), forms.poisson_jacobian_kernel(3, degree)
+    ncell = m.cell_set.size
+    t0 = time.perf_counter()
+    csr = oracle.build_sparsity(nn, nn, [(cm, cm)])
+    t_sparsity = time.perf_counter() - t0
+    fn_r, a_r, k1, _ = oracle.par_loop(kr.code, kr.name, 0, ncell, [ODat(r, INC, cm), ODat(coords, READ, xm), ODat(u, READ, cm), ODat(f, READ, cm)], return_fn=True)
+    fn_j, a_j, k2, cm_ = oracle.par_loop(kj.code, kj.name, 0, ncell, [OMat(csr, INC, cm, cm), ODat(coords, READ, xm)], return_fn=True)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        r[:] = 0
+        fn_r(*a_r)
+        t1 = time.perf_counter()
+        csr.values[:] = 0
+        fn_j(*a_j)
+        t2 = time.perf_counter()
+        ts.append((t2 - t0, t1 - t0, t2 - t1))
+    ts.sort()
+    tot, tr, tj = ts[len(ts) // 2]
+    return {"value": nn / tot, "unit": "DoFs/s", "cores": 1, "kind": "port",
+            "sample": f"Poisson CG{degree} on UnitCubeMesh({n_sample}) tets: {ncell} cells, {nn} DoFs, residual+Jacobian, "
+                      f"median of 3; oracle = CPU restatement of the PyOP2 wrapper, gcc -O3 -march=native -ffast-math, 1 thread",
+            "residual_dofs_per_s": nn / tr, "jacobian_dofs_per_s": nn / tj, "sparsity_build_s": t_sparsity}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=215, help="cubes per axis per GPU (215 -> ~10M DoF)")
+    ap.add_argument("--degree", type=int, default=1)
+    ap.add_argument("--cpu-sample", type=int, default=64, help="cube size of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-bcs", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from firedrake_amd import _lib, forms, mesh as fmesh
+    from firedrake_amd.device import Event
+    _lib.require_gpu()
+    _lib.call("fd_set_device", local_rank)
+
+    n = args.n
+    t0 = time.perf_counter()
+    mesh = fmesh.UnitCubeMesh((n, n, n * world), degrees=(args.degree,), rank=rank, nranks=world, perturb=0.1)
+    prob = forms.PoissonProblem(mesh, args.degree, bcs=not args.no_bcs)
+    t_mesh = time.perf_counter() - t0
+    V = prob.V
+    ndofs_global = V.global_dofs
+    ncell_local = mesh.cell_set.size
+    t0 = time.perf_counter()
+    mat, _ = prob.jacobian()
+    mat.sparsity._build()
+    nnz = mat.sparsity.nz
+    _lib.call("fd_device_sync")
+    t_sparsity = time.perf_counter() - t0
+
+    ev = [[Event() for _ in range(4)] for _ in range(args.steps)]
+
+    def step(k=None):
+        if k is not None:
+            ev[k][0].record()
+        prob.assemble_residual()
+        if k is not None:
+            ev[k][1].record()
+            ev[k][2].record()
+        prob.assemble_jacobian()
+        if k is not None:
+            ev[k][3].record()
+
+    def barrier():
+        _lib.call("fd_device_sync")
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    t_res = float(np.median([ev[k][0].elapsed_ms(ev[k][1]) for k in range(args.steps)]))
+    t_jac = float(np.median([ev[k][2].elapsed_ms(ev[k][3]) for k in range(args.steps)]))
+
+    if rank == 0:
+        arity = V.cell_node_map.arity
+        nnode_local = V.node_set.total_size
+        b_res = algorithmic_bytes(ncell_local, arity, nnode_local, 3, 2)
+        b_jac = algorithmic_bytes(ncell_local, arity, nnode_local, 3, 0, nnz)
+        roof_res = {"kernel": prob.res_loop.global_kernel.name, "bound": "hbm", "achieved": b_res / (t_res * 1e-3) / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "ms": t_res, "algorithmic_bytes": b_res}
+        roof_res["frac"] = roof_res["achieved"] / HBM_PEAK_GBS
+        roof_jac = {"kernel": prob.jacobian()[1].global_kernel.name, "bound": "hbm", "achieved": b_jac / (t_jac * 1e-3) / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "ms": t_jac, "algorithmic_bytes": b_jac}
+        roof_jac["frac"] = roof_jac["achieved"] / HBM_PEAK_GBS
+        dominant = roof_jac if t_jac >= t_res else roof_res
+        out = {
+            "metric": "assembled DoFs/sec (residual + Jacobian)",
+            "value": ndofs_global / (ms_per_step * 1e-3),
+            "unit": "DoFs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"Poisson CG{args.degree} residual+Jacobian on UnitCubeMesh({n},{n},{n * world}) tets "
+                                   f"(BASELINE.json configs[1]), z-slab per GPU",
+                       "cells_per_gpu": ncell_local, "dofs_global": ndofs_global, "nnz_per_gpu": int(nnz),
+                       "parallelism": f"domain-decomposition x{world}", "bcs": not args.no_bcs},
+            "residual_dofs_per_s": V.node_set.size * world / (t_res * 1e-3),
+            "jacobian_dofs_per_s": V.node_set.size * world / (t_jac * 1e-3),
+            "roofline": dominant, "roofline_residual": roof_res, "roofline_jacobian": roof_jac,
+            "setup_s": {"mesh": t_mesh, "sparsity_and_tables": t_sparsity},
+        }
+        if args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.degree)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

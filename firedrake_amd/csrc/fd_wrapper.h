@@ -25,6 +25,7 @@
 typedef double PetscScalar;
 typedef double PetscReal;
 typedef int PetscInt;
+#define restrict __restrict__   /* C99 keyword used by loopy/TSFC-generated C */
 
 namespace fdw {
 

@@ -1,0 +1,409 @@
+"""Hand-restated TSFC-equivalent local kernels for the benchmark forms (C strings).
+
+In Firedrake these kernels are produced per form by TSFC (tsfc/driver.py:57-182 ->
+tsfc/loopy.py:215-276) with the argument order of
+tsfc/kernel_interface/firedrake_loopy.py:408-522:  ``A, coords, w_0, w_1, ...`` -- output
+element tensor first (zeroed by the wrapper, tsfc_interface.py:330-331), then the coordinate
+field, then the coefficients in form order; constant tables are ``static const`` arrays
+(tsfc/loopy.py:237-244) and the affine Jacobian is unrolled (tsfc/fem.py:793-797).
+TSFC/UFL/FIAT cannot be imported in this environment, so the kernels for the
+five configurations are written out here in that shape.  They are ordinary C: the oracle
+compiles the same string with gcc, the backend with hipcc.
+
+Element-tensor parity with a real Firedrake install is *unpinned* (no reference test stores
+element tensors); tests/test_forms_identities.py validates them with the analytic identities
+the reference's regression tests rely on (constants in the stiffness null space, sum(M) = |Omega|,
+A*u = action(a, u), exactness on polynomial data).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import op2
+
+
+def _c(a):
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim == 0:
+        return repr(float(a))
+    return "{" + ", ".join(_c(x) for x in a) + "}"
+
+
+# ------------------------------------------------------------------------------------------
+# quadrature + tabulation on the reference simplex (what FIAT/FInAT provide: tsfc/fem.py:330-333, 711-735)
+# ------------------------------------------------------------------------------------------
+def gauss_jacobi_simplex(dim, degree):
+    """Collapsed (Stroud conical-product) Gauss-Jacobi rule exact for polynomials of ``degree``."""
+    from scipy.special import roots_jacobi
+    m = degree // 2 + 1
+    if dim == 2:
+        x0, w0 = roots_jacobi(m, 0, 0)
+        x1, w1 = roots_jacobi(m, 1, 0)
+        pts, wts = [], []
+        for a, wa in zip(x1, w1):
+            for b, wb in zip(x0, w0):
+                s = (1 + a) / 2
+                t = (1 - a) / 2 * (1 + b) / 2
+                pts.append((s, t))
+                wts.append(wa * wb / 8.0)
+        return np.array(pts), np.array(wts)
+    x0, w0 = roots_jacobi(m, 0, 0)
+    x1, w1 = roots_jacobi(m, 1, 0)
+    x2, w2 = roots_jacobi(m, 2, 0)
+    pts, wts = [], []
+    for a, wa in zip(x2, w2):
+        for b, wb in zip(x1, w1):
+            for c, wc in zip(x0, w0):
+                r = (1 + a) / 2
+                s = (1 - a) / 2 * (1 + b) / 2
+                t = (1 - a) / 2 * (1 - b) / 2 * (1 + c) / 2
+                pts.append((r, s, t))
+                wts.append(wa * wb * wc / 64.0)
+    return np.array(pts), np.array(wts)
+
+
+_TET_EDGES = [(2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1)]
+_TRI_EDGES = [(1, 2), (0, 2), (0, 1)]
+
+
+def tabulate_lagrange(dim, degree, pts):
+    """(phi[q][i], dphi[q][i][b]) of P1/P2 on the reference simplex; node order = vertices, then edges
+    in the UFC/FIAT edge order (matches mesh.py's cell-node maps)."""
+    pts = np.asarray(pts)
+    lam = np.concatenate([1 - pts.sum(axis=1, keepdims=True), pts], axis=1)        # (nq, dim+1)
+    dlam = np.concatenate([-np.ones((1, dim)), np.eye(dim)], axis=0)               # (dim+1, dim)
+    nq = len(pts)
+    if degree == 1:
+        return lam.copy(), np.broadcast_to(dlam, (nq, dim + 1, dim)).copy()
+    edges = _TET_EDGES if dim == 3 else _TRI_EDGES
+    nd = dim + 1 + len(edges)
+    phi = np.zeros((nq, nd))
+    dphi = np.zeros((nq, nd, dim))
+    for v in range(dim + 1):
+        phi[:, v] = lam[:, v] * (2 * lam[:, v] - 1)
+        dphi[:, v, :] = (4 * lam[:, v] - 1)[:, None] * dlam[v][None, :]
+    for e, (a, b) in enumerate(edges):
+        k = dim + 1 + e
+        phi[:, k] = 4 * lam[:, a] * lam[:, b]
+        dphi[:, k, :] = 4 * (lam[:, a][:, None] * dlam[b][None, :] + lam[:, b][:, None] * dlam[a][None, :])
+    return phi, dphi
+
+
+# ------------------------------------------------------------------------------------------
+# geometry preamble shared by the affine-simplex kernels
+# ------------------------------------------------------------------------------------------
+_GEOM = {
+    2: """
+  const double J00 = x[2] - x[0], J01 = x[4] - x[0];
+  const double J10 = x[3] - x[1], J11 = x[5] - x[1];
+  const double det = J00*J11 - J01*J10;
+  const double idet = 1.0 / det;
+  const double K[2][2] = {{ J11*idet, -J01*idet}, {-J10*idet,  J00*idet}};
+  const double adet = fabs(det);
+""",
+    3: """
+  const double J00 = x[3] - x[0], J01 = x[6] - x[0], J02 = x[9]  - x[0];
+  const double J10 = x[4] - x[1], J11 = x[7] - x[1], J12 = x[10] - x[1];
+  const double J20 = x[5] - x[2], J21 = x[8] - x[2], J22 = x[11] - x[2];
+  const double c00 = J11*J22 - J12*J21, c01 = J12*J20 - J10*J22, c02 = J10*J21 - J11*J20;
+  const double det = J00*c00 + J01*c01 + J02*c02;
+  const double idet = 1.0 / det;
+  const double K[3][3] = {
+    { c00*idet, (J02*J21 - J01*J22)*idet, (J01*J12 - J02*J11)*idet },
+    { c01*idet, (J00*J22 - J02*J20)*idet, (J02*J10 - J00*J12)*idet },
+    { c02*idet, (J01*J20 - J00*J21)*idet, (J00*J11 - J01*J10)*idet } };
+  const double adet = fabs(det);
+""",
+}
+
+
+def poisson_residual_kernel(dim, degree, name=None):
+    """F(u; v) = int grad(u).grad(v) - f v dx   (configs C1/C2/C5).
+    Arguments: A[nd], coords[(dim+1)*dim], u[nd], f[nd]."""
+    name = name or f"poisson_p{degree}_{'tet' if dim == 3 else 'tri'}_residual"
+    nv = dim + 1
+    if degree == 1:
+        # P1: gradients constant on the cell -> stiffness term outside the quadrature loop
+        qp, qw = gauss_jacobi_simplex(dim, 2)
+        phi, _ = tabulate_lagrange(dim, 1, qp)
+        nq = len(qw)
+        dl = np.concatenate([-np.ones((1, dim)), np.eye(dim)], axis=0)
+        body = f"""
+static void {name}(double *restrict A, const double *restrict x, const double *restrict u, const double *restrict f)
+{{
+  static const double DL[{nv}][{dim}] = {_c(dl)};
+  static const double PHI[{nq}][{nv}] = {_c(phi)};
+  static const double W[{nq}] = {_c(qw)};
+{_GEOM[dim]}
+  double g[{nv}][{dim}];
+  for (int i = 0; i < {nv}; ++i)
+    for (int a = 0; a < {dim}; ++a) {{
+      double s = 0.0;
+      for (int b = 0; b < {dim}; ++b) s += DL[i][b] * K[b][a];
+      g[i][a] = s;
+    }}
+  double gu[{dim}];
+  for (int a = 0; a < {dim}; ++a) {{
+    double s = 0.0;
+    for (int j = 0; j < {nv}; ++j) s += u[j] * g[j][a];
+    gu[a] = s;
+  }}
+  const double vol = adet * {1.0 / (2 if dim == 2 else 6)!r};
+  for (int i = 0; i < {nv}; ++i) {{
+    double s = 0.0;
+    for (int a = 0; a < {dim}; ++a) s += g[i][a] * gu[a];
+    A[i] += vol * s;
+  }}
+  for (int q = 0; q < {nq}; ++q) {{
+    double fq = 0.0;
+    for (int j = 0; j < {nv}; ++j) fq += f[j] * PHI[q][j];
+    const double wf = W[q] * adet * fq;
+    for (int i = 0; i < {nv}; ++i) A[i] -= wf * PHI[q][i];
+  }}
+}}
+"""
+        return op2.Kernel(body, name, flop_count=None)
+    # P2: two quadrature loops (degree 2 for the stiffness term, degree 4 for f*v)
+    qs, ws = gauss_jacobi_simplex(dim, 2 * (degree - 1))
+    _, dphs = tabulate_lagrange(dim, degree, qs)
+    qm, wm = gauss_jacobi_simplex(dim, 2 * degree)
+    phm, _ = tabulate_lagrange(dim, degree, qm)
+    nd = phm.shape[1]
+    body = f"""
+static void {name}(double *restrict A, const double *restrict x, const double *restrict u, const double *restrict f)
+{{
+  static const double DPHI[{len(ws)}][{nd}][{dim}] = {_c(dphs)};
+  static const double WS[{len(ws)}] = {_c(ws)};
+  static const double PHI[{len(wm)}][{nd}] = {_c(phm)};
+  static const double WM[{len(wm)}] = {_c(wm)};
+{_GEOM[dim]}
+  double G[{dim}][{dim}];              /* K K^T : reference-space metric */
+  for (int a = 0; a < {dim}; ++a)
+    for (int b = 0; b < {dim}; ++b) {{
+      double s = 0.0;
+      for (int c = 0; c < {dim}; ++c) s += K[a][c] * K[b][c];
+      G[a][b] = s * adet;
+    }}
+  for (int q = 0; q < {len(ws)}; ++q) {{
+    double gr[{dim}];
+    for (int b = 0; b < {dim}; ++b) {{
+      double s = 0.0;
+      for (int j = 0; j < {nd}; ++j) s += u[j] * DPHI[q][j][b];
+      gr[b] = s;
+    }}
+    double t[{dim}];
+    for (int a = 0; a < {dim}; ++a) {{
+      double s = 0.0;
+      for (int b = 0; b < {dim}; ++b) s += G[a][b] * gr[b];
+      t[a] = s * WS[q];
+    }}
+    for (int i = 0; i < {nd}; ++i) {{
+      double s = 0.0;
+      for (int a = 0; a < {dim}; ++a) s += DPHI[q][i][a] * t[a];
+      A[i] += s;
+    }}
+  }}
+  for (int q = 0; q < {len(wm)}; ++q) {{
+    double fq = 0.0;
+    for (int j = 0; j < {nd}; ++j) fq += f[j] * PHI[q][j];
+    const double wf = WM[q] * adet * fq;
+    for (int i = 0; i < {nd}; ++i) A[i] -= wf * PHI[q][i];
+  }}
+}}
+"""
+    return op2.Kernel(body, name)
+
+
+def poisson_jacobian_kernel(dim, degree, name=None):
+    """J(du, v) = int grad(du).grad(v) dx.  Arguments: A[nd*nd], coords."""
+    name = name or f"poisson_p{degree}_{'tet' if dim == 3 else 'tri'}_jacobian"
+    nv = dim + 1
+    if degree == 1:
+        dl = np.concatenate([-np.ones((1, dim)), np.eye(dim)], axis=0)
+        body = f"""
+static void {name}(double *restrict A, const double *restrict x)
+{{
+  static const double DL[{nv}][{dim}] = {_c(dl)};
+{_GEOM[dim]}
+  double g[{nv}][{dim}];
+  for (int i = 0; i < {nv}; ++i)
+    for (int a = 0; a < {dim}; ++a) {{
+      double s = 0.0;
+      for (int b = 0; b < {dim}; ++b) s += DL[i][b] * K[b][a];
+      g[i][a] = s;
+    }}
+  const double vol = adet * {1.0 / (2 if dim == 2 else 6)!r};
+  for (int i = 0; i < {nv}; ++i)
+    for (int j = 0; j < {nv}; ++j) {{
+      double s = 0.0;
+      for (int a = 0; a < {dim}; ++a) s += g[i][a] * g[j][a];
+      A[i*{nv} + j] += vol * s;
+    }}
+}}
+"""
+        return op2.Kernel(body, name)
+    qs, ws = gauss_jacobi_simplex(dim, 2 * (degree - 1))
+    _, dphs = tabulate_lagrange(dim, degree, qs)
+    nd = dphs.shape[1]
+    body = f"""
+static void {name}(double *restrict A, const double *restrict x)
+{{
+  static const double DPHI[{len(ws)}][{nd}][{dim}] = {_c(dphs)};
+  static const double WS[{len(ws)}] = {_c(ws)};
+{_GEOM[dim]}
+  double G[{dim}][{dim}];
+  for (int a = 0; a < {dim}; ++a)
+    for (int b = 0; b < {dim}; ++b) {{
+      double s = 0.0;
+      for (int c = 0; c < {dim}; ++c) s += K[a][c] * K[b][c];
+      G[a][b] = s * adet;
+    }}
+  for (int q = 0; q < {len(ws)}; ++q)
+    for (int i = 0; i < {nd}; ++i) {{
+      double t[{dim}];
+      for (int a = 0; a < {dim}; ++a) {{
+        double s = 0.0;
+        for (int b = 0; b < {dim}; ++b) s += G[a][b] * DPHI[q][i][b];
+        t[a] = s * WS[q];
+      }}
+      for (int j = 0; j < {nd}; ++j) {{
+        double s = 0.0;
+        for (int a = 0; a < {dim}; ++a) s += t[a] * DPHI[q][j][a];
+        A[i*{nd} + j] += s;
+      }}
+    }}
+}}
+"""
+    return op2.Kernel(body, name)
+
+
+def mass_kernel(dim, degree, name=None):
+    """a(u, v) = int u v dx.  Arguments: A[nd*nd], coords."""
+    name = name or f"mass_p{degree}_{'tet' if dim == 3 else 'tri'}"
+    qm, wm = gauss_jacobi_simplex(dim, 2 * degree)
+    phm, _ = tabulate_lagrange(dim, degree, qm)
+    nd = phm.shape[1]
+    body = f"""
+static void {name}(double *restrict A, const double *restrict x)
+{{
+  static const double PHI[{len(wm)}][{nd}] = {_c(phm)};
+  static const double WM[{len(wm)}] = {_c(wm)};
+{_GEOM[dim]}
+  for (int q = 0; q < {len(wm)}; ++q)
+    for (int i = 0; i < {nd}; ++i)
+      for (int j = 0; j < {nd}; ++j)
+        A[i*{nd} + j] += WM[q] * adet * PHI[q][i] * PHI[q][j];
+}}
+"""
+    return op2.Kernel(body, name)
+
+
+# ------------------------------------------------------------------------------------------
+# assemble()-shaped front end for these forms
+# ------------------------------------------------------------------------------------------
+class PoissonProblem:
+    """The Newton-step assembly of configs C1/C2/C5: residual F(u) and Jacobian J on a CG space.
+
+    Plays the role of OneFormAssembler / ExplicitMatrixAssembler (firedrake/assemble.py:1197-1293,
+    1344-1558): parloops are built once and cached, ``assemble_residual`` zeroes the tensor, runs
+    the cell parloop inside ``frozen_halo(INC)`` (assemble.py:1281-1286) and applies BCs
+    (assemble.py:1243-1267); ``assemble_jacobian`` zeroes the CSR, scatters with BC-masked lgmaps
+    (assemble.py:2075-2108) and sets the BC diagonal (assemble.py:1501-1507).
+    """
+
+    def __init__(self, mesh, degree=1, bcs=True, seed=0):
+        self.mesh = mesh
+        self.degree = degree
+        self.V = V = mesh.space(degree)
+        dim = mesh.gdim
+        rng = np.random.default_rng(seed + 17 * V.halo.rank if V.halo else seed)
+        pts = V.node_points
+        # deterministic fields: a smooth "state" plus the Helmholtz-test forcing (test_helmholtz.py:36-39)
+        uvals = np.sin(3 * pts[:, 0]) * np.cos(2 * pts[:, 1]) + (0.3 * pts[:, 2] if dim == 3 else 0.0)
+        fvals = (1 + 8 * np.pi ** 2) * np.cos(2 * np.pi * pts[:, 0]) * np.cos(2 * np.pi * pts[:, 1])
+        self.u = V.dat(1, uvals, "u")
+        self.f = V.dat(1, fvals, "f")
+        self.r = V.dat(1, None, "residual")
+        self.bc_nodes = V.boundary_nodes if bcs else np.zeros(0, dtype=np.int32)
+        self.bc_nodes = self.bc_nodes[self.bc_nodes < V.node_set.size]
+        self.kres = poisson_residual_kernel(dim, degree)
+        self.kjac = poisson_jacobian_kernel(dim, degree)
+        cm, xm = V.cell_node_map, mesh.coord_space.cell_node_map
+        self.res_loop = op2.LegacyParloop(self.kres, mesh.cell_set, self.r(op2.INC, cm), mesh.coordinates(op2.READ, xm),
+                                          self.u(op2.READ, cm), self.f(op2.READ, cm))
+        self._jac = None
+        self._bc_dev = None
+        del rng
+
+    # -- residual ---------------------------------------------------------------------
+    def _bc_rows(self):
+        if self._bc_dev is None:
+            from .device import DeviceBuffer
+            self._bc_dev = DeviceBuffer.from_numpy(np.ascontiguousarray(self.bc_nodes, dtype=np.int32))
+        return self._bc_dev
+
+    def assemble_residual(self):
+        import ctypes
+        from . import _lib
+        self.r.zero()                                   # a13: zeroing is part of every assemble
+        with self.r.frozen_halo(op2.INC):
+            self.res_loop()
+        if len(self.bc_nodes):                          # a14: bc.zero(tensor)  (bcs.py:192-221)
+            _lib.call("fd_dat_set_rows", self.r._dev_ptr(True), 1, self._bc_rows().ptr, len(self.bc_nodes),
+                      ctypes.c_double(0.0), None)
+        return self.r
+
+    # -- Jacobian ---------------------------------------------------------------------
+    def jacobian(self):
+        if self._jac is None:
+            V = self.V
+            cm, xm = V.cell_node_map, self.mesh.coord_space.cell_node_map
+            sp = op2.Sparsity((V.node_set ** 1, V.node_set ** 1), [(cm, cm, None)])
+            mat = op2.Mat(sp)
+            lg = None
+            if len(self.bc_nodes):
+                lgm = np.arange(V.node_set.total_size, dtype=np.int32)
+                lgm[self.bc_nodes] = -1                 # functionspaceimpl.py:913-926
+                lg = (lgm, lgm)
+            loop = op2.LegacyParloop(self.kjac, self.mesh.cell_set, mat(op2.INC, (cm, cm), lgmaps=lg),
+                                     self.mesh.coordinates(op2.READ, xm))
+            self._jac = (mat, loop)
+        return self._jac
+
+    def assemble_jacobian(self):
+        import ctypes
+        from . import _lib
+        mat, loop = self.jacobian()
+        mat.zero()
+        loop()
+        if len(self.bc_nodes):
+            sp = mat.sparsity
+            _lib.call("fd_csr_set_diagonal", sp._rowptr.ptr, sp._colidx.ptr, mat._values_dev().ptr, self._bc_rows().ptr,
+                      len(self.bc_nodes), ctypes.c_double(1.0), None)
+        return mat
+
+
+def precompile_all():
+    """Compile (hipcc, disk-cached) the wrappers of the benchmark forms so the code objects ship with the tree."""
+    from .codegen import generate_wrapper, staged_eligible
+    from .compilation import compile_hip
+    from .kernel import DatKernelArg, GlobalKernel, MapKernelArg, MatKernelArg
+    from .op2types import INC, READ
+    out = []
+    for dim, degree in ((2, 1), (3, 1), (3, 2)):
+        nd = {(2, 1): 3, (3, 1): 4, (3, 2): 10}[(dim, degree)]
+        cm = MapKernelArg(nd)
+        xm = cm if degree == 1 else MapKernelArg(dim + 1)
+        f64 = np.dtype("float64")
+        kres = poisson_residual_kernel(dim, degree).with_signature([INC, READ, READ, READ], [f64] * 4)
+        gk = GlobalKernel(kres, [DatKernelArg((1,), cm), DatKernelArg((dim,), xm), DatKernelArg((1,), cm), DatKernelArg((1,), cm)])
+        kjac = poisson_jacobian_kernel(dim, degree).with_signature([INC, READ], [f64] * 2)
+        for lg in (False, True):
+            gj = GlobalKernel(kjac, [MatKernelArg(((1,), (1,)), (cm, cm), lgmaps=lg), DatKernelArg((dim,), xm)])
+            for g in (gk, gj):
+                for mode in ("staged", "direct"):
+                    if mode == "staged" and not staged_eligible(g):
+                        continue
+                    src = generate_wrapper(g, mode)
+                    out.append(compile_hip(src.source, src.symbol))
+    return out

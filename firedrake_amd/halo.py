@@ -1,13 +1,190 @@
-"""Halo exchange over RCCL (torch.distributed) -- placeholder filled in by the multi-GPU milestone."""
+"""Halo exchange of shared DoFs as an RCCL neighbour all-to-all over xGMI.
+
+Concrete counterpart of firedrake/halo.py:87-172 (a PetscSF over DoFs, ``bcastBegin/End`` for
+owner->ghost with MPI.REPLACE and ``reduceBegin/End`` for ghost->owner with SUM/MIN/MAX) behind
+the abstract interface of pyop2/types/halo.py:4-56.  One process per GPU; the per-neighbour
+send/receive node lists come from the mesh partitioner (mesh.HaloLists).  A transfer is
+
+    pack kernel (fd_halo_pack) -> batched isend/irecv on the packed buffers (RCCL grouped
+    ncclSend/ncclRecv) -> unpack kernel (fd_halo_unpack: =, +=, min, max)
+
+``*_begin`` posts the transfers, ``*_end`` waits and unpacks, so the exchange overlaps the
+core-entity kernel exactly like the reference's begin/end split (pyop2/parloop.py:250-253).
+Messages are O(1 MB) per neighbour: latency-bound, hence one grouped
+send/recv per neighbour and no ring collective.
+
+For the CPU-only protocol tests (``gloo`` backend, world_size 2) the same class runs with
+host tensors when FDHIP_HALO_HOST=1 is set by the test: pack/unpack are then torch index ops.
+This is test plumbing for the rank protocol, never used when a GPU is present.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from .op2types import INC, MAX, MIN, READ, RW, WRITE
+
+_OPS = {WRITE: 0, INC: 1, MIN: 2, MAX: 3}
 
 
-def allreduce_global(glob, access, comm):
-    """parloop.py:411-442: all-reduce of INC/MIN/MAX Globals.  Single-rank: nothing to do."""
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def attach_halo(space):
+    """Give the node Set of ``space`` a Halo if the mesh is partitioned."""
+    h = space.halo
+    if h is None or h.nranks <= 1:
+        space.node_set.halo = None
+        return
+    space.node_set.halo = Halo(h)
+
+
+class Halo:
+    """pyop2/types/halo.py interface implemented over torch.distributed (backend nccl == RCCL)."""
+
+    def __init__(self, lists):
+        self.lists = lists
+        self.rank, self.nranks = lists.rank, lists.nranks
+        self.host_mode = os.environ.get("FDHIP_HALO_HOST", "0") == "1"
+        self._dev_idx = {}
+        self._pending = {}
+
+    # -- helpers
+    def _neighbours(self):
+        return sorted(set(self.lists.send) | set(self.lists.recv))
+
+    def _idx(self, kind, r):
+        key = (kind, r)
+        t = self._dev_idx.get(key)
+        if t is None:
+            import torch
+            arr = (self.lists.send if kind == "send" else self.lists.recv)[r]
+            t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int32))
+            if not self.host_mode:
+                t = t.cuda()
+            self._dev_idx[key] = t
+        return t
+
+    def _dat_tensor(self, dat, write):
+        """A torch view of the Dat's storage (device memory unless host_mode)."""
+        import torch
+        if self.host_mode:
+            h = dat._host_rw() if write else dat._to_host()
+            return torch.from_numpy(h.reshape(h.shape[0], -1))
+        raise RuntimeError("device tensors are addressed by raw pointer; see _pack/_unpack")
+
+    def _pack(self, dat, idx, cdim):
+        import torch
+        if self.host_mode:
+            return self._dat_tensor(dat, False)[idx.long()].contiguous()
+        from . import _lib
+        buf = torch.empty((idx.numel(), cdim), dtype=torch.float64, device="cuda")
+        _lib.call("fd_halo_pack", dat._dev_ptr(False), cdim, idx.data_ptr(), idx.numel(), buf.data_ptr(),
+                  torch.cuda.current_stream().cuda_stream)
+        return buf
+
+    def _unpack(self, dat, idx, cdim, buf, op):
+        import torch
+        if self.host_mode:
+            t = self._dat_tensor(dat, True)
+            li = idx.long()
+            if op == 0:
+                t[li] = buf
+            elif op == 1:
+                t[li] += buf
+            elif op == 2:
+                t[li] = torch.minimum(t[li], buf)
+            else:
+                t[li] = torch.maximum(t[li], buf)
+            return
+        from . import _lib
+        _lib.call("fd_halo_unpack", dat._dev_ptr(True), cdim, idx.data_ptr(), idx.numel(), buf.data_ptr(), op,
+                  torch.cuda.current_stream().cuda_stream)
+
+    def _exchange_begin(self, dat, send_kind, recv_kind, tag):
+        import torch
+        dist = _dist()
+        cdim = dat.cdim
+        if dat.dtype != np.float64:
+            raise TypeError("halo exchange is implemented for float64 Dats (ScalarType)")
+        ops, recvs, keep = [], [], []
+        if not self.host_mode:
+            torch.cuda.synchronize()     # wrapper kernels run on the null stream; make their writes visible
+        for r in self._neighbours():
+            sl = (self.lists.send if send_kind == "send" else self.lists.recv).get(r)
+            rl = (self.lists.send if recv_kind == "send" else self.lists.recv).get(r)
+            if sl is not None and len(sl):
+                sbuf = self._pack(dat, self._idx(send_kind, r), cdim)
+                keep.append(sbuf)
+                ops.append(dist.P2POp(dist.isend, sbuf, r))
+            if rl is not None and len(rl):
+                rbuf = torch.empty((len(rl), cdim), dtype=torch.float64, device="cpu" if self.host_mode else "cuda")
+                recvs.append((r, rbuf))
+                ops.append(dist.P2POp(dist.irecv, rbuf, r))
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        self._pending[(id(dat), tag)] = (reqs, recvs, keep)
+
+    def _exchange_end(self, dat, recv_kind, op, tag):
+        reqs, recvs, keep = self._pending.pop((id(dat), tag))
+        for q in reqs:
+            q.wait()
+        for r, rbuf in recvs:
+            self._unpack(dat, self._idx(recv_kind, r), dat.cdim, rbuf, op)
+        if not self.host_mode:
+            import torch
+            torch.cuda.synchronize()
+
+    # -- pyop2 Halo interface
+    def global_to_local_begin(self, dat, insert_mode):
+        """owner -> ghost broadcast (firedrake/halo.py:125-131)."""
+        self._exchange_begin(dat, "send", "recv", "g2l")
+
+    def global_to_local_end(self, dat, insert_mode):
+        self._exchange_end(dat, "recv", 0, "g2l")
+
+    def local_to_global_begin(self, dat, insert_mode):
+        """ghost -> owner reduction with SUM/MIN/MAX (firedrake/halo.py:141-172)."""
+        self._exchange_begin(dat, "recv", "send", "l2g")
+
+    def local_to_global_end(self, dat, insert_mode):
+        self._exchange_end(dat, "send", _OPS[insert_mode], "l2g")
+
+    def fill_ghosts(self, dat, access_mode):
+        """pyop2/types/dat.py:631-636: before an INC/MIN/MAX loop the ghost region is set to the
+        identity (0 / +max / -max) so the reverse reduction only carries this loop's contributions."""
+        val = {INC: 0.0, MIN: np.finfo(np.float64).max, MAX: np.finfo(np.float64).min}[access_mode]
+        n0, n1 = dat.dataset.size, dat.dataset.total_size
+        if n1 == n0:
+            return
+        if self.host_mode:
+            dat._host_rw()[n0:] = val
+            return
+        import ctypes
+        from . import _lib
+        from .device import DeviceBuffer
+        rows = getattr(self, "_ghost_rows", None)
+        if rows is None or rows[0] != (n0, n1):
+            rows = ((n0, n1), DeviceBuffer.from_numpy(np.arange(n0, n1, dtype=np.int32)))
+            self._ghost_rows = rows
+        _lib.call("fd_dat_set_rows", dat._dev_ptr(True), dat.cdim, rows[1].ptr, n1 - n0, ctypes.c_double(val), None)
+
+
+def allreduce_global(glob, access, comm=None):
+    """pyop2/parloop.py:411-442: MPI_Iallreduce of INC/MIN/MAX Globals -> RCCL all-reduce of a tiny buffer."""
     try:
-        import torch.distributed as dist
+        import torch
+        dist = _dist()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
-    except Exception:
+    except ImportError:
         return
-    from .multigpu import allreduce_global as _ar
-    _ar(glob, access)
+    op = {INC: dist.ReduceOp.SUM, MIN: dist.ReduceOp.MIN, MAX: dist.ReduceOp.MAX}[access]
+    host = glob._to_host()
+    t = torch.from_numpy(np.ascontiguousarray(host.reshape(-1)).copy())
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=op)
+    glob._host_rw()[...] = t.cpu().numpy().reshape(host.shape)

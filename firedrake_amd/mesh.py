@@ -1,0 +1,240 @@
+"""Synthetic structured meshes + function-space data in the layouts Firedrake produces.
+
+The reference obtains cell->node maps, core|owned|ghost entity classes and halo lists from
+PETSc DMPlex through firedrake/cython/dmcommon.pyx (get_cell_nodes :1481-1597,
+mark_entity_classes :2236-2323, plex_renumbering :2599-2729, create_halo_exchange_sf
+:3891-3964).  DMPlex is out of scope; for the benchmark configurations this
+module generates the *same layouts* directly:
+
+  * ``UnitSquareMesh`` triangles (utility_meshes.py:640-700, 802), ``UnitCubeMesh`` 6-tet Kuhn
+    split per cube (utility_meshes.py:1466-1495) -- same vertex-offset tables;
+  * entities ordered core | owned | ghost (pyop2/types/set.py:32-55), only [0,size) executed;
+  * nodes numbered in cell-traversal order inside each class (dmcommon.pyx:2688-2712) -- the
+    traversal here walks the grid tile by tile so consecutive cells share nodes in all three
+    directions (the reference gets its locality from an RCM cell order, mesh.py:1214-1228);
+  * CG1 / CG2 scalar and vector spaces that share one Map object (functionspacedata.py:497-520);
+  * z-slab partition across ranks with send/receive node lists per neighbour for the halo
+    (firedrake/halo.py:87-172).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from . import op2
+
+# vertex offsets (di, dj, dk) of cube corners v0..v7 and the Kuhn split (utility_meshes.py:1477-1495)
+_CORNER = np.array([(0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0), (0, 0, 1), (1, 0, 1), (0, 1, 1), (1, 1, 1)], dtype=np.int32)
+_TETS = np.array([(0, 1, 3, 7), (0, 1, 7, 5), (0, 5, 7, 4), (0, 3, 2, 7), (0, 6, 4, 7), (0, 2, 6, 7)], dtype=np.int32)
+# UFC/FIAT edge -> vertex pairs of the reference tetrahedron (entity_dofs order of CG2)
+_TET_EDGES = np.array([(2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1)], dtype=np.int32)
+_TRI_EDGES = np.array([(1, 2), (0, 2), (0, 1)], dtype=np.int32)
+
+
+@dataclass
+class HaloLists:
+    """Per-neighbour node index lists (local numbering).  ``send[r]`` are owned nodes that rank r
+    holds as ghosts, ``recv[r]`` are our ghosts owned by r, in matching order."""
+    rank: int = 0
+    nranks: int = 1
+    send: Dict[int, np.ndarray] = field(default_factory=dict)
+    recv: Dict[int, np.ndarray] = field(default_factory=dict)
+
+
+@dataclass
+class FunctionSpaceData:
+    """What firedrake/functionspacedata.py caches per (mesh, element): node Set, cell-node Map."""
+    degree: int
+    node_set: op2.Set
+    cell_node_map: op2.Map
+    node_points: np.ndarray          # (total_nodes, gdim) physical location of every node
+    halo: Optional[HaloLists] = None
+    boundary_nodes: Optional[np.ndarray] = None     # local indices of nodes on the domain boundary
+    global_dofs: int = 0
+
+    def dat(self, dim=1, data=None, name=None):
+        return op2.Dat(self.node_set ** dim if dim != 1 else self.node_set, data, np.float64, name)
+
+
+@dataclass
+class Mesh:
+    gdim: int
+    cell_set: op2.Set
+    coordinates: op2.Dat             # vector CG1 Dat
+    coord_space: FunctionSpaceData
+    spaces: Dict[int, FunctionSpaceData]
+    ncells_global: int
+    shape: Tuple[int, ...]
+
+    def space(self, degree):
+        return self.spaces[degree]
+
+
+def _tile_keys(ix, iy, iz, nx, ny, nz, tile):
+    """Sort key that walks a (nx,ny,nz) grid tile by tile, x fastest inside a tile."""
+    tx, ty, tz = tile
+    Tx, Ty = -(-nx // tx), -(-ny // ty)
+    t = ((iz // tz).astype(np.int64) * Ty + iy // ty) * Tx + ix // tx
+    loc = ((iz % tz) * ty + iy % ty) * tx + ix % tx
+    return t * (tx * ty * tz) + loc
+
+
+def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0, ghost_cells=True):
+    """Kuhn-split tetrahedral unit cube, z-slab partitioned.  ``tile`` = cubes per traversal tile."""
+    nx, ny, nz = (int(n),) * 3 if np.isscalar(n) else tuple(int(v) for v in n)
+    # ---- cube slab owned by this rank (+ one ghost cube layer each side)
+    k0 = (nz * rank) // nranks
+    k1 = (nz * (rank + 1)) // nranks
+    glo = k0 - 1 if (rank > 0 and ghost_cells) else k0
+    ghi = k1 + 1 if (rank < nranks - 1 and ghost_cells) else k1
+    kk, jj, ii = np.meshgrid(np.arange(glo, ghi, dtype=np.int32), np.arange(ny, dtype=np.int32),
+                             np.arange(nx, dtype=np.int32), indexing="ij")
+    ii, jj, kk = ii.ravel(), jj.ravel(), kk.ravel()
+    # class of each cube: 0 core, 1 owned (touches a ghost node plane), 2 ghost
+    ccls = np.zeros(ii.shape, dtype=np.int8)
+    if rank < nranks - 1:
+        ccls[kk == k1 - 1] = 1
+    ccls[(kk < k0) | (kk >= k1)] = 2
+    key = _tile_keys(ii, jj, kk - glo, nx, ny, ghi - glo, tile) + ccls.astype(np.int64) * (1 << 50)
+    order = np.argsort(key, kind="stable")
+    ii, jj, kk, ccls = ii[order], jj[order], kk[order], ccls[order]
+    ncube = len(ii)
+    sizes_c = tuple(int(6 * (ccls <= c).sum()) for c in (0, 1, 2))
+    cell_set = op2.Set(sizes_c, "cells")
+
+    def lattice_space(p):
+        """CG_p nodes live on the lattice of spacing 1/(p*n); CG2 edge nodes are vertex sums."""
+        Lx, Ly = p * nx + 1, p * ny + 1
+        zlo, zhi = p * glo, p * ghi            # lattice planes present locally: [zlo, zhi]
+        nzl = zhi - zlo + 1
+        # integer (doubled for p=2) coordinates of the 4 vertices of every cell
+        cx = (ii[:, None] + _CORNER[:, 0][None, :])            # (ncube, 8)
+        cy = (jj[:, None] + _CORNER[:, 1][None, :])
+        cz = (kk[:, None] + _CORNER[:, 2][None, :])
+        vx, vy, vz = cx[:, _TETS], cy[:, _TETS], cz[:, _TETS]  # (ncube, 6, 4)
+        if p == 1:
+            nxs, nys, nzs = vx, vy, vz
+        else:
+            ex = vx[..., _TET_EDGES[:, 0]] + vx[..., _TET_EDGES[:, 1]]
+            ey = vy[..., _TET_EDGES[:, 0]] + vy[..., _TET_EDGES[:, 1]]
+            ez = vz[..., _TET_EDGES[:, 0]] + vz[..., _TET_EDGES[:, 1]]
+            nxs = np.concatenate([2 * vx, ex], axis=-1)
+            nys = np.concatenate([2 * vy, ey], axis=-1)
+            nzs = np.concatenate([2 * vz, ez], axis=-1)
+        arity = nxs.shape[-1]
+        box = ((nzs - zlo).astype(np.int64) * Ly + nys) * Lx + nxs      # index inside the local lattice box
+        box = box.reshape(ncube * 6, arity)
+        # ---- number the lattice nodes of the box: class, then tile traversal order
+        zz, yy, xx = np.meshgrid(np.arange(zlo, zhi + 1, dtype=np.int32), np.arange(Ly, dtype=np.int32),
+                                 np.arange(Lx, dtype=np.int32), indexing="ij")
+        xx, yy, zz = xx.ravel(), yy.ravel(), zz.ravel()
+        own_lo, own_hi = p * k0, (p * k1 if rank < nranks - 1 else p * nz + 1)   # owned planes [own_lo, own_hi)
+        ncls = np.full(xx.shape, 2, dtype=np.int8)
+        owned = (zz >= own_lo) & (zz < own_hi)
+        ncls[owned] = 0
+        if rank < nranks - 1:
+            ncls[owned & (zz > p * (k1 - 1))] = 1      # owned, but read by cells that also read ghosts
+        tl = tuple(p * t for t in tile)
+        nkey = _tile_keys(np.minimum(xx, p * nx - 1), np.minimum(yy, p * ny - 1), np.minimum(zz - zlo, p * (ghi - glo) - 1),
+                          p * nx, p * ny, p * (ghi - glo), tl)
+        # tie-break inside a tile by the true coordinates so keys are unique
+        nkey = (nkey + ncls.astype(np.int64) * (1 << 50)) * 8 + ((zz - zlo) // (p * (ghi - glo))) * 4 + (yy // (p * ny)) * 2 + xx // (p * nx)
+        norder = np.argsort(nkey, kind="stable")
+        newnum = np.empty(len(norder), dtype=np.int32)
+        newnum[norder] = np.arange(len(norder), dtype=np.int32)
+        sizes_n = tuple(int((ncls <= c).sum()) for c in (0, 1, 2))
+        cmap = newnum[box]
+        h = 1.0 / (p * nx)
+        pts = np.stack([xx[norder] * h, yy[norder] * (1.0 / (p * ny)), zz[norder] * (1.0 / (p * nz))], axis=1)
+        bnd = np.nonzero((xx[norder] == 0) | (xx[norder] == p * nx) | (yy[norder] == 0) | (yy[norder] == p * ny)
+                         | (zz[norder] == 0) | (zz[norder] == p * nz))[0].astype(np.int32)
+        halo = HaloLists(rank, nranks)
+        zs = zz[norder]
+        lat = (yy[norder].astype(np.int64) * Lx + xx[norder])
+        if nranks > 1:
+            def plane_nodes(zplane):
+                idx = np.nonzero(zs == zplane)[0]
+                return idx[np.argsort(lat[idx], kind="stable")].astype(np.int32)
+            if rank < nranks - 1:
+                # planes [p*k1, zhi] are owned by rank+1: we receive them / send contributions back
+                halo.recv[rank + 1] = np.concatenate([plane_nodes(z) for z in range(p * k1, zhi + 1)])
+                # rank+1 holds our planes (p*(k1-1), p*k1) .. only if it has ghost cells below
+                if ghost_cells:
+                    halo.send[rank + 1] = np.concatenate([plane_nodes(z) for z in range(p * (k1 - 1), p * k1)])
+            if rank > 0:
+                # rank-1 reads our plane p*k0 (top of its last owned layer) and, with ghost cells, up to p*(k0+1)
+                top = p * (k0 + 1) if ghost_cells else p * k0
+                halo.send[rank - 1] = np.concatenate([plane_nodes(z) for z in range(p * k0, top + 1)])
+                if ghost_cells:
+                    halo.recv[rank - 1] = np.concatenate([plane_nodes(z) for z in range(zlo, p * k0)])
+        node_set = op2.Set(sizes_n, f"cg{p}_nodes")
+        m = op2.Map(cell_set, node_set, arity, cmap, f"cell_cg{p}")
+        return FunctionSpaceData(p, node_set, m, pts, halo, bnd, (p * nx + 1) * (p * ny + 1) * (p * nz + 1))
+
+    spaces = {}
+    for p in sorted(set(degrees) | {1}):
+        spaces[p] = lattice_space(p)
+    cs = spaces[1]
+    xyz = cs.node_points.copy()
+    if perturb:
+        hgrid = 1.0 / nx
+        inner = ((xyz > 1e-12) & (xyz < 1 - 1e-12)).all(axis=1)
+        d = perturb * hgrid * np.stack([np.sin(2 * np.pi * xyz[:, 1]) * np.sin(2 * np.pi * xyz[:, 2]),
+                                        np.sin(2 * np.pi * xyz[:, 0]) * np.sin(2 * np.pi * xyz[:, 2]),
+                                        np.sin(2 * np.pi * xyz[:, 0]) * np.sin(2 * np.pi * xyz[:, 1])], axis=1)
+        xyz[inner] += d[inner]
+    coords = op2.Dat(cs.node_set ** 3, xyz, np.float64, "coordinates")
+    from .halo import attach_halo
+    for sp in spaces.values():
+        attach_halo(sp)
+    return Mesh(3, cell_set, coords, cs, spaces, 6 * nx * ny * nz, (nx, ny, nz))
+
+
+def UnitSquareMesh(nx, ny, degrees=(1,), tile=(16, 16), perturb=0.0):
+    """Triangulated unit square, 2 triangles per square, "left" diagonal (utility_meshes.py:661-662)."""
+    jj, ii = np.meshgrid(np.arange(ny, dtype=np.int32), np.arange(nx, dtype=np.int32), indexing="ij")
+    ii, jj = ii.ravel(), jj.ravel()
+    key = _tile_keys(ii, jj, np.zeros_like(ii), nx, ny, 1, (tile[0], tile[1], 1))
+    order = np.argsort(key, kind="stable")
+    ii, jj = ii[order], jj[order]
+    nsq = len(ii)
+    cell_set = op2.Set(2 * nsq, "cells")
+    # corners a=(i,j) b=(i+1,j) c=(i,j+1) d=(i+1,j+1); "left" diagonal joins b-c
+    tri = np.array([[(0, 0), (1, 0), (0, 1)], [(1, 0), (1, 1), (0, 1)]], dtype=np.int32)   # (2, 3, 2)
+    vx = ii[:, None, None] + tri[None, :, :, 0]
+    vy = jj[:, None, None] + tri[None, :, :, 1]
+
+    def lattice_space(p):
+        Lx, Ly = p * nx + 1, p * ny + 1
+        if p == 1:
+            nxs, nys = vx, vy
+        else:
+            ex = vx[..., _TRI_EDGES[:, 0]] + vx[..., _TRI_EDGES[:, 1]]
+            ey = vy[..., _TRI_EDGES[:, 0]] + vy[..., _TRI_EDGES[:, 1]]
+            nxs, nys = np.concatenate([2 * vx, ex], -1), np.concatenate([2 * vy, ey], -1)
+        arity = nxs.shape[-1]
+        box = (nys.astype(np.int64) * Lx + nxs).reshape(nsq * 2, arity)
+        yy, xx = np.meshgrid(np.arange(Ly, dtype=np.int32), np.arange(Lx, dtype=np.int32), indexing="ij")
+        xx, yy = xx.ravel(), yy.ravel()
+        nkey = _tile_keys(np.minimum(xx, p * nx - 1), np.minimum(yy, p * ny - 1), np.zeros_like(xx), p * nx, p * ny, 1,
+                          (p * tile[0], p * tile[1], 1)) * 4 + (yy // (p * ny)) * 2 + xx // (p * nx)
+        norder = np.argsort(nkey, kind="stable")
+        newnum = np.empty(len(norder), dtype=np.int32)
+        newnum[norder] = np.arange(len(norder), dtype=np.int32)
+        pts = np.stack([xx[norder] / (p * nx), yy[norder] / (p * ny)], axis=1)
+        bnd = np.nonzero((xx[norder] == 0) | (xx[norder] == p * nx) | (yy[norder] == 0) | (yy[norder] == p * ny))[0].astype(np.int32)
+        node_set = op2.Set(len(norder), f"cg{p}_nodes")
+        return FunctionSpaceData(p, node_set, op2.Map(cell_set, node_set, arity, newnum[box], f"cell_cg{p}"), pts,
+                                 HaloLists(), bnd, Lx * Ly)
+
+    spaces = {p: lattice_space(p) for p in sorted(set(degrees) | {1})}
+    cs = spaces[1]
+    xy = cs.node_points.copy()
+    if perturb:
+        inner = ((xy > 1e-12) & (xy < 1 - 1e-12)).all(axis=1)
+        d = perturb / nx * np.stack([np.sin(2 * np.pi * xy[:, 1]), np.sin(2 * np.pi * xy[:, 0])], axis=1)
+        xy[inner] += d[inner]
+    coords = op2.Dat(cs.node_set ** 2, xy, np.float64, "coordinates")
+    return Mesh(2, cell_set, coords, cs, spaces, 2 * nx * ny, (nx, ny))

@@ -62,7 +62,8 @@ def structured_tri_mesh(nx, ny, seed=0, perturb=0.0):
     coords = np.stack([xs.ravel(), ys.ravel()], axis=1)
     if perturb:
         rng = np.random.default_rng(seed)
-        coords += perturb * rng.standard_normal(coords.shape) / max(nx, ny)
+        interior = ((coords > 1e-12) & (coords < 1 - 1e-12)).all(axis=1)      # keep |Omega| = 1
+        coords[interior] += perturb * rng.uniform(-1, 1, size=(interior.sum(), 2)) / max(nx, ny)
     cells = []
     for j in range(ny):
         for i in range(nx):

@@ -1,0 +1,135 @@
+"""CPU: the hand-restated TSFC-equivalent local kernels satisfy the analytic identities the
+reference's regression tests rely on (tests/firedrake/regression/test_assemble.py:60-73,
+test_poisson_strong_bcs.py:74-92, test_matrix_free.py:97-123) -- evaluated through the oracle --
+and the synthetic mesh generators produce the layouts of SURVEY.md Appendix C."""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+import oracle
+from oracle import ODat, OMat, READ, INC
+from firedrake_amd import forms, mesh as fmesh
+
+
+def _mesh(dim, n, degree, perturb=0.15):
+    if dim == 2:
+        return fmesh.UnitSquareMesh(n, n, degrees=(degree,), tile=(4, 4), perturb=perturb)
+    return fmesh.UnitCubeMesh(n, degrees=(degree,), tile=(2, 2, 2), perturb=perturb)
+
+
+def _assemble(m, degree):
+    V, X = m.space(degree), m.coord_space
+    cm, xm = V.cell_node_map.values_with_halo, X.cell_node_map.values_with_halo
+    nn = V.node_set.total_size
+    coords = np.array(m.coordinates.data_ro_with_halos)
+    K = oracle.build_sparsity(nn, nn, [(cm, cm)])
+    kj = forms.poisson_jacobian_kernel(m.gdim, degree)
+    oracle.par_loop(kj.code, kj.name, 0, m.cell_set.size, [OMat(K, INC, cm, cm), ODat(coords, READ, xm)])
+    M = oracle.build_sparsity(nn, nn, [(cm, cm)])
+    km = forms.mass_kernel(m.gdim, degree)
+    oracle.par_loop(km.code, km.name, 0, m.cell_set.size, [OMat(M, INC, cm, cm), ODat(coords, READ, xm)])
+    return V, cm, xm, coords, K.toscipy(), M.toscipy()
+
+
+@pytest.mark.parametrize("dim,degree,n", [(2, 1, 6), (2, 2, 5), (3, 1, 4), (3, 2, 3)])
+def test_stiffness_and_mass_identities(dim, degree, n):
+    m = _mesh(dim, n, degree)
+    V, cm, xm, coords, K, M = _assemble(m, degree)
+    nn = V.node_set.total_size
+    assert nn == V.global_dofs == (degree * n + 1) ** dim
+    amax = abs(K).max()
+    assert_allclose(K @ np.ones(nn), 0, atol=1e-12 * amax)          # constants in the null space
+    assert abs(K - K.T).max() <= 1e-13 * amax                       # symmetric
+    assert_allclose(M.sum(), 1.0, rtol=1e-12)                       # sum(M) = |Omega|
+    # residual with f = 0 equals K u  (A*x == action(a, x))
+    pts = V.node_points
+    u = np.sin(2 * pts[:, 0]) + pts[:, 1] ** 2
+    r = np.zeros(nn)
+    kr = forms.poisson_residual_kernel(dim, degree)
+    oracle.par_loop(kr.code, kr.name, 0, m.cell_set.size,
+                    [ODat(r, INC, cm), ODat(coords, READ, xm), ODat(u.copy(), READ, cm), ODat(np.zeros(nn), READ, cm)])
+    assert_allclose(r, K @ u, atol=1e-12 * max(1, abs(K @ u).max()))
+    # load term: F(0) = -M f
+    f = np.cos(pts[:, 0]) * (1 + pts[:, 1])
+    r2 = np.zeros(nn)
+    oracle.par_loop(kr.code, kr.name, 0, m.cell_set.size,
+                    [ODat(r2, INC, cm), ODat(coords, READ, xm), ODat(np.zeros(nn), READ, cm), ODat(f.copy(), READ, cm)])
+    assert_allclose(r2, -(M @ f), atol=1e-12)
+
+
+@pytest.mark.parametrize("dim,n", [(2, 6), (3, 3)])
+def test_p2_residual_vanishes_for_exact_quadratic_solution(dim, n):
+    """-lap(u) = f with u = x^2 (in P2), f = -2: interior residual rows are zero (cf. test_poisson_strong_bcs.py)."""
+    m = _mesh(dim, n, 2, perturb=0.0)
+    V, X = m.space(2), m.coord_space
+    cm, xm = V.cell_node_map.values_with_halo, X.cell_node_map.values_with_halo
+    nn = V.node_set.total_size
+    pts = V.node_points
+    r = np.zeros(nn)
+    kr = forms.poisson_residual_kernel(dim, 2)
+    oracle.par_loop(kr.code, kr.name, 0, m.cell_set.size,
+                    [ODat(r, INC, cm), ODat(np.array(m.coordinates.data_ro_with_halos), READ, xm),
+                     ODat(pts[:, 0] ** 2, READ, cm), ODat(np.full(nn, -2.0), READ, cm)])
+    interior = np.setdiff1d(np.arange(nn), V.boundary_nodes)
+    assert len(interior) > 0
+    assert_allclose(r[interior], 0, atol=1e-12)
+
+
+def test_unit_cube_mesh_layout():
+    n = 5
+    m = fmesh.UnitCubeMesh(n, degrees=(1, 2), tile=(2, 2, 2))
+    assert m.cell_set.size == 6 * n ** 3 == m.ncells_global
+    V1, V2 = m.space(1), m.space(2)
+    assert V1.node_set.size == (n + 1) ** 3 and V2.node_set.size == (2 * n + 1) ** 3
+    c = V1.cell_node_map.values
+    assert c.shape == (6 * n ** 3, 4) and c.min() == 0 and c.max() == (n + 1) ** 3 - 1
+    # every tet has volume 1/(6 n^3)
+    X = np.array(m.coordinates.data_ro)[c]
+    vol = np.abs(np.linalg.det(X[:, 1:] - X[:, :1])) / 6
+    assert_allclose(vol, 1 / (6 * n ** 3), rtol=1e-12)
+    # CG2: vertex dofs coincide with the CG1 points, edge dofs are midpoints (UFC edge order)
+    c2 = V2.cell_node_map.values
+    P2 = V2.node_points[c2]
+    assert_allclose(P2[:, :4], X, atol=1e-14)
+    for e, (a, b) in enumerate([(2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1)]):
+        assert_allclose(P2[:, 4 + e], 0.5 * (X[:, a] + X[:, b]), atol=1e-14)
+    # numbering locality: nodes of consecutive cells are close (cell-traversal numbering)
+    assert np.median(c.max(axis=1) - c.min(axis=1)) < 4 * (n + 1) ** 2
+    # nnz of the P1 operator: nV + 2 nE with nE = 7n^3 + 9n^2 + 3n (SURVEY.md 8 sizes)
+    sp = oracle.build_sparsity((n + 1) ** 3, (n + 1) ** 3, [(V1.cell_node_map.values, V1.cell_node_map.values)])
+    assert len(sp.colidx) == (n + 1) ** 3 + 2 * (7 * n ** 3 + 9 * n ** 2 + 3 * n)
+
+
+def test_unit_square_mesh_layout():
+    m = fmesh.UnitSquareMesh(64, 64)
+    V = m.space(1)
+    assert m.cell_set.size == 8192 and V.node_set.size == 4225              # config C1 sizes
+    cm = V.cell_node_map.values
+    sp = oracle.build_sparsity(4225, 4225, [(cm, cm)])
+    assert len(sp.colidx) == 29057                                           # nV + 2 nE
+    X = np.array(m.coordinates.data_ro)[cm]
+    e1, e2 = X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]
+    area = 0.5 * np.abs(e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0])
+    assert_allclose(area, 1 / 8192, rtol=1e-12)
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_partitioned_cube_halo_lists_are_consistent(nranks):
+    n = 6
+    parts = [fmesh.UnitCubeMesh(n, degrees=(1, 2), tile=(2, 2, 2), rank=r, nranks=nranks) for r in range(nranks)]
+    assert sum(p.cell_set.size for p in parts) == 6 * n ** 3
+    for deg in (1, 2):
+        assert sum(p.space(deg).node_set.size for p in parts) == (deg * n + 1) ** 3
+        for r, p in enumerate(parts):
+            V = p.space(deg)
+            for nb, recv in V.halo.recv.items():
+                send = parts[nb].space(deg).halo.send[r]
+                assert len(send) == len(recv)
+                # matching order: same physical points
+                assert_allclose(parts[nb].space(deg).node_points[send], V.node_points[recv], atol=1e-14)
+                assert recv.min() >= V.node_set.size            # ghosts live at the tail
+                assert send.max() < parts[nb].space(deg).node_set.size
+            # executed cells only reference local nodes; core cells reference no ghost
+            cm = V.cell_node_map.values_with_halo
+            assert cm[:p.cell_set.core_size].max() < V.node_set.size
+            assert cm.max() < V.node_set.total_size

@@ -1,0 +1,98 @@
+"""GPU parity of the benchmark forms (configs C1/C2/C5 shapes at oracle-friendly sizes): the HIP
+path (assemble-shaped front end, staged wrappers, device CSR, BC masking) against the oracle."""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+import oracle
+from oracle import ODat, OMat, READ, INC
+from firedrake_amd import forms, mesh as fmesh, op2
+from firedrake_amd.configuration import configuration
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_problem(prob, with_bcs):
+    m, deg = prob.mesh, prob.degree
+    V, X = prob.V, m.coord_space
+    cm, xm = V.cell_node_map.values_with_halo, X.cell_node_map.values_with_halo
+    nn = V.node_set.total_size
+    coords = np.array(m.coordinates.data_ro_with_halos)
+    r = np.zeros(nn)
+    oracle.par_loop(prob.kres.code, prob.kres.name, 0, m.cell_set.size,
+                    [ODat(r, INC, cm), ODat(coords, READ, xm), ODat(np.array(prob.u.data_ro_with_halos), READ, cm),
+                     ODat(np.array(prob.f.data_ro_with_halos), READ, cm)])
+    csr = oracle.build_sparsity(nn, nn, [(cm, cm)])
+    lg = None
+    if with_bcs:
+        lg = np.arange(nn, dtype=np.int32)
+        lg[prob.bc_nodes] = -1
+        r[prob.bc_nodes] = 0.0
+    oracle.par_loop(prob.kjac.code, prob.kjac.name, 0, m.cell_set.size,
+                    [OMat(csr, INC, cm, cm, row_lgmap=lg, col_lgmap=lg), ODat(coords, READ, xm)])
+    A = csr.toscipy().tolil()
+    if with_bcs:
+        for b in prob.bc_nodes:
+            A[b, b] = 1.0
+    return r, A.tocsr()
+
+
+@pytest.mark.parametrize("dim,degree,n", [(2, 1, 64), (3, 1, 12), (3, 2, 6), (2, 2, 16)])
+@pytest.mark.parametrize("bcs", [False, True])
+def test_poisson_residual_and_jacobian(dim, degree, n, bcs):
+    m = (fmesh.UnitSquareMesh(n, n, degrees=(degree,), perturb=0.1) if dim == 2
+         else fmesh.UnitCubeMesh(n, degrees=(degree,), tile=(4, 4, 2), perturb=0.1))
+    prob = forms.PoissonProblem(m, degree, bcs=bcs)
+    r = prob.assemble_residual()
+    mat = prob.assemble_jacobian()
+    ro, Ao = _oracle_problem(prob, bcs)
+    # stated fp64 tolerance: 1e-12 relative to the largest entry
+    assert_allclose(r.data_ro, ro, rtol=0, atol=1e-12 * max(1.0, np.abs(ro).max()))
+    A = mat.toscipy()
+    assert np.array_equal(A.indptr, Ao.indptr) and np.array_equal(A.indices, Ao.indices)
+    assert_allclose(A.data, Ao.data, rtol=0, atol=1e-12 * np.abs(Ao.data).max())
+    # second assembly into the same tensors gives the same answer (tensor reuse, assemble.py:1042-1047)
+    r2 = np.array(prob.assemble_residual().data_ro)
+    assert_allclose(r2, ro, rtol=0, atol=1e-12 * max(1.0, np.abs(ro).max()))
+    if not bcs:
+        # A*u - M f == F(u)  i.e. matrix-free action identity with the assembled operator
+        y = prob.V.dat()
+        mat.mult(prob.u, y)
+        f0 = forms.PoissonProblem(m, degree, bcs=False)
+        f0.u.assign(0.0)
+        load = np.array(f0.assemble_residual().data_ro)
+        assert_allclose(y.data_ro + load, ro, rtol=0, atol=1e-10 * max(1.0, np.abs(ro).max()))
+
+
+def test_c1_config_sizes_and_direct_mode(monkeypatch):
+    """BASELINE.json configs[0]: Poisson CG1 on UnitSquareMesh(64,64), both wrapper shapes."""
+    m = fmesh.UnitSquareMesh(64, 64)
+    for mode in ("auto", "direct"):
+        monkeypatch.setitem(configuration, "mode", mode)
+        prob = forms.PoissonProblem(m, 1, bcs=True)
+        r = prob.assemble_residual()
+        mat = prob.assemble_jacobian()
+        ro, Ao = _oracle_problem(prob, True)
+        assert mat.sparsity.nz == 29057
+        assert_allclose(r.data_ro, ro, rtol=0, atol=1e-12 * np.abs(ro).max())
+        assert_allclose(mat.toscipy().data, Ao.data, rtol=0, atol=1e-12 * np.abs(Ao.data).max())
+
+
+def test_medium_cube_properties():
+    """Size-independent properties at a size the oracle would take too long for: K*1 = 0, symmetry,
+    repeated assembly idempotent (zero + assemble)."""
+    m = fmesh.UnitCubeMesh(48, degrees=(1,), perturb=0.1)
+    prob = forms.PoissonProblem(m, 1, bcs=False)
+    mat = prob.assemble_jacobian()
+    A = mat.toscipy()
+    amax = np.abs(A.data).max()
+    assert np.abs(A @ np.ones(A.shape[0])).max() <= 1e-11 * amax
+    assert abs(A - A.T).max() <= 1e-12 * amax
+    A2 = prob.assemble_jacobian().toscipy()
+    assert_allclose(A2.data, A.data, rtol=0, atol=1e-12 * amax)
+    ones = prob.V.dat(1, np.ones(prob.V.node_set.total_size))
+    prob.u.assign(1.0)
+    prob.f.assign(0.0)
+    r = prob.assemble_residual()
+    assert np.abs(r.data_ro).max() <= 1e-11 * amax
+    del ones

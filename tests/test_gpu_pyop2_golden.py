@@ -41,7 +41,7 @@ def _mat(nodes, m, cdim=1):
     return op2.Mat(op2.Sparsity((nodes ** cdim, nodes ** cdim), [(m, m, None)]), np.float64)
 
 
-@pytest.mark.parametrize("src,name", [(gk.MASS_Q6, "mass_q6"), (gk.MASS_AFFINE, "mass_affine")])
+@pytest.mark.parametrize("src,name", [(gk.MASS_Q6, "mass_q6"), (gk.MASS_AFFINE, "mass_affine")], ids=["q6", "affine"])
 def test_assemble_mat(mesh, mode, scatter, src, name):
     nodes, ele, m = mesh
     mat = _mat(nodes, m)
@@ -179,7 +179,7 @@ def test_onecolor_wo_rw(iset):
 def test_indirect_inc(iset, mode):
     it, ind, unit, i2i, i2u = iset
     u = op2.Dat(unit, np.array([0], dtype=np.uint32), np.uint32)
-    op2.par_loop(op2.Kernel("static void inc(unsigned int* x) { (*x) = (*x) + 1; }", "inc_u"), it, u(op2.INC, i2u))
+    op2.par_loop(op2.Kernel("static void inc_u(unsigned int* x) { (*x) = (*x) + 1; }", "inc_u"), it, u(op2.INC, i2u))
     assert u.data[0] == NEL
 
 
@@ -260,7 +260,7 @@ def test_direct_loops():
     n = 1000
     s = op2.Set(n)
     x = op2.Dat(s, np.arange(n, dtype=np.uint32), np.uint32)
-    op2.par_loop(op2.Kernel("static void wo(unsigned int* x) { *x = 42; }", "wo_d"), s, x(op2.WRITE))
+    op2.par_loop(op2.Kernel("static void wo_d(unsigned int* x) { *x = 42; }", "wo_d"), s, x(op2.WRITE))
     assert all(x.data == 42)
     y = op2.Dat(s, np.arange(n, dtype=np.float64))
     g = op2.Global(1, 0.0)
@@ -347,7 +347,7 @@ def test_extruded_mat_and_interior_facets():
     m = op2.Map(ext, nodes, 4, vm, offset=[1, 1, 1, 1])
     mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(m, m, None)]))
     g = op2.Global(1, 1.0)
-    k = op2.Kernel("static void ones(double A[16], const double *g) { for (int i = 0; i < 16; ++i) A[i] += g[0] * (i + 1); }", "ones16")
+    k = op2.Kernel("static void ones16(double A[16], const double *g) { for (int i = 0; i < 16; ++i) A[i] += g[0] * (i + 1); }", "ones16")
     op2.par_loop(k, ext, mat(op2.INC, (m, m)), g(op2.READ))
     ocsr = oracle_run(k, ext, mat(op2.INC, (m, m)), g(op2.READ))[0]
     assert_allclose(mat.values, ocsr.todense(), rtol=1e-14)

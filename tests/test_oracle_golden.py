@@ -37,7 +37,7 @@ def test_sparsity_nnz():
     assert list(np.diff(s2.rowptr)) == [0, 3, 0, 3]
 
 
-@pytest.mark.parametrize("src,name", [(gk.MASS_Q6, "mass_q6"), (gk.MASS_AFFINE, "mass_affine")])
+@pytest.mark.parametrize("src,name", [(gk.MASS_Q6, "mass_q6"), (gk.MASS_AFFINE, "mass_affine")], ids=["q6", "affine"])
 def test_assemble_mat(src, name):
     csr = _mat()
     oracle.par_loop(src, name, 0, 2, [OMat(csr, INC, gk.ELEM_NODE, gk.ELEM_NODE),
