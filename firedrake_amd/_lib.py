@@ -52,6 +52,10 @@ SIGNATURES = {
     "fd_plan_info": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int64)]),
     "fd_plan_arrays": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
     "fd_plan_free": (c_int, [c_void_p]),
+    "fd_matplan_create": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
+    "fd_matplan_info": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int64)]),
+    "fd_matplan_arrays": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
+    "fd_matplan_free": (c_int, [c_void_p]),
     "fd_csr_from_maps": (c_int, [c_int32, c_int32, c_int, c_int, POINTER(c_void_p), POINTER(c_void_p),
                                  POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
                                  POINTER(c_void_p), POINTER(c_void_p),

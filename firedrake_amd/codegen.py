@@ -58,6 +58,8 @@ class WrapperSource:
     lds_items: List[tuple] = field(default_factory=list)  # (map index, elements per node, itemsize)
     layer_parallel: bool = True
     block_threads: int = 256
+    kbytes: int = 1
+    mat_staged: dict = field(default_factory=dict)
 
 
 def _distinct_maps(gk: GlobalKernel):
@@ -108,7 +110,8 @@ def _hoist_includes(code: str):
 def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     lk = gk.local_kernel
     maps, map_index = _distinct_maps(gk)
-    staged = mode == "staged"
+    staged = mode.startswith("staged")
+    ktype, kbytes = ("unsigned short", 2) if mode.endswith("_k16") else ("unsigned char", 1)
     extruded = gk._extruded
     region = gk._iteration_region
     ih = extruded and region == ON_INTERIOR_FACETS
@@ -173,10 +176,19 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     P("long long epb_", ("epb",))
     staged_maps = []
     lds_items = []
+    mat_staged = {}
+    for info in infos:
+        if info["kind"] == "mat":
+            mat_staged[info["k"]] = bool(staged and configuration["mat_staged"] and info["rbs"] * info["cbs"] == 1
+                                         and info["acc"] == INC and not info["arg"].unroll)
     if staged:
         for info in infos:
             if info["kind"] == "dat" and "m" in info and info["m"] not in staged_maps:
                 staged_maps.append(info["m"])
+            if info["kind"] == "mat" and mat_staged[info["k"]]:
+                for mi in (info["rm"], info["cm"]):
+                    if mi not in staged_maps:
+                        staged_maps.append(mi)
         for mi in staged_maps:
             P(f"const int *__restrict__ p{mi}_blkoff", ("plan_blkoff", mi))
             P(f"const int *__restrict__ p{mi}_list", ("plan_list", mi))
@@ -189,7 +201,13 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         k = info["k"]
         table = (configuration["mat_scatter"] == "table") and not extruded
         use_table[k] = table
-        if table:
+        if mat_staged[k]:
+            P(f"const int *__restrict__ mp{k}_off", ("matplan_off", k))
+            P(f"const int *__restrict__ mp{k}_gpos", ("matplan_gpos", k))
+            P(f"const int *__restrict__ mp{k}_lrp", ("matplan_lrp", k))
+            P(f"const {ktype} *__restrict__ mp{k}_k", ("matplan_kidx", k))
+            P(f"long long mp{k}_maxnnz", ("matplan_maxnnz", k))
+        elif table:
             P(f"const int *__restrict__ tab{k}", ("mat_table", k))
             if info["rbs"] * info["cbs"] != 1:
                 P(f"const int *__restrict__ nrp{k}", ("mat_node_rowptr", k))
@@ -214,7 +232,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         return e
 
     pre, pack, call_args, unpack, post = [], [], [], [], []
-    lds_decl, stage, flush = [], [], []
+    lds_decl, stage, flush, mat_stage_pre = [], [], [], []
 
     # LDS carving for staged args
     if staged:
@@ -254,7 +272,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             size = nf * ar * c
             pack.append(f"{ct} t{k}[{size}];")
             if staged:
-                lds_items.append((mi, c, info["dtype"].itemsize))
+                lds_items.append(("dat", mi, c, info["dtype"].itemsize))
                 lds_decl.append(f"{ct} *s{k} = ({ct} *)(fd_lds + fd_off); fd_off += (((size_t)p{mi}_maxnd*{c}*sizeof({ct})) + 15) & ~(size_t)15;")
                 if acc == READ:
                     stage.append((mi, f"for (int q = tid; q < nd{mi}*{c}; q += nthr) {{ const int i = q / {c}; "
@@ -292,8 +310,34 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             size = nf * ar * rbs * nf * ac * cbs
             pack.append(f"double t{k}[{size}]; for (int q = 0; q < {size}; ++q) t{k}[q] = 0;")
             call_args.append(f"t{k}")
-            store = (lambda p, v: f"fdw::atomic_add<double>(&arg{k}[{p}], {v});") if acc == INC else (lambda p, v: f"arg{k}[{p}] = {v};")
             lg = info["arg"].lgmaps
+            if mat_staged[k]:
+                lds_items.append(("mat", k, rm, cm, bool(lg)))
+                lds_decl.append(f"double *sm{k} = (double *)(fd_lds + fd_off); fd_off += (((size_t)mp{k}_maxnnz*8) + 15) & ~(size_t)15;")
+                lds_decl.append(f"int *slrp{k} = (int *)(fd_lds + fd_off); fd_off += (((size_t)(p{rm}_maxnd + 1)*4) + 15) & ~(size_t)15;")
+                mat_pre = [f"const int mo{k} = mp{k}_off[b], nnzb{k} = mp{k}_off[b+1] - mo{k};"]
+                stage.append((rm, f"for (int q = tid; q < nnzb{k}; q += nthr) sm{k}[q] = 0;"))
+                stage.append((rm, f"for (int q = tid; q <= nd{rm}; q += nthr) slrp{k}[q] = mp{k}_lrp[l0_{rm} + b + q];"))
+                if lg:
+                    lds_decl.append(f"unsigned char *smr{k} = fd_lds + fd_off; fd_off += ((size_t)p{rm}_maxnd + 15) & ~(size_t)15;")
+                    lds_decl.append(f"unsigned char *smc{k} = fd_lds + fd_off; fd_off += ((size_t)p{cm}_maxnd + 15) & ~(size_t)15;")
+                    stage.append((rm, f"for (int q = tid; q < nd{rm}; q += nthr) smr{k}[q] = rlg{k}[p{rm}_list[l0_{rm} + q]] < 0;"))
+                    stage.append((cm, f"for (int q = tid; q < nd{cm}; q += nthr) smc{k}[q] = clg{k}[p{cm}_list[l0_{cm} + q]] < 0;"))
+                mat_stage_pre.extend(mat_pre)
+                lines = [f"int kk{k}[{ar * ac}]; fdw::load_packed<{ktype}, {ar * ac}>(mp{k}_k + (size_t)(e - start)*{ar * ac}, kk{k});",
+                         f"for (int i = 0; i < {ar}; ++i) {{",
+                         f"  const int base = slrp{k}[lm{rm}[i]];"]
+                if lg:
+                    lines.append(f"  if (smr{k}[lm{rm}[i]]) continue;")
+                lines.append(f"  for (int j = 0; j < {ac}; ++j) {{")
+                if lg:
+                    lines.append(f"    if (smc{k}[lm{cm}[j]]) continue;")
+                lines += [f"    atomicAdd(&sm{k}[base + kk{k}[i*{ac} + j]], t{k}[i*{ac} + j]);", "  }", "}"]
+                unpack.append("\n    ".join(lines))
+                flush.append((rm, f"for (int q = tid; q < nnzb{k}; q += nthr) {{ const double v = sm{k}[q]; "
+                                  f"if (v != 0.0) fdw::atomic_add<double>(&arg{k}[mp{k}_gpos[mo{k} + q]], v); }}"))
+                continue
+            store = (lambda p, v: f"fdw::atomic_add<double>(&arg{k}[{p}], {v});") if acc == INC else (lambda p, v: f"arg{k}[{p}] = {v};")
             unroll = info["arg"].unroll
             nr_, nc_ = nf * ar, nf * ac
             lines = [f"for (int fi = 0; fi < {nf}; ++fi) for (int i = 0; i < {ar}; ++i) {{",
@@ -345,6 +389,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         src += ["  " + s for s in lds_decl]
         for mi in staged_maps:
             src.append(f"  const int l0_{mi} = p{mi}_blkoff[b], nd{mi} = p{mi}_blkoff[b+1] - l0_{mi};")
+        src += ["  " + s for s in mat_stage_pre]
         src += ["  " + s for _, s in stage]
         src.append("  __syncthreads();")
         src += ["  " + s for s in pre]
@@ -391,7 +436,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         src += ["  " + s for s in post]
     src.append("}")
     return WrapperSource("\n".join(src) + "\n", sym, mode, layout, len(maps), staged_maps, lds_items,
-                         layer_parallel, threads)
+                         layer_parallel, threads, kbytes, mat_staged)
 
 
 def _permi(perm, i):

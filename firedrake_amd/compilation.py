@@ -35,8 +35,13 @@ def compiler_version():
 
 
 def flags():
+    # The reference compiles its wrappers with -O3 -ffast-math (pyop2/compilation.py:345-349).  Here: the
+    # value-safe subset (no NaN/Inf/signed-zero bookkeeping, reassociation, contraction) so that 0*x and
+    # 1*x fold in unrolled tabulation loops, but NOT approximate functions: f64 division keeps the
+    # div_scale/div_fmas/div_fixup sequence (a bare v_rcp_f64 is not accurate to 1e-12).
     f = [f"--offload-arch={configuration['arch']}", "-O3", "-std=c++17", "--genco", "-munsafe-fp-atomics",
-         "-fno-math-errno", f"-I{_CSRC}"]
+         "-fno-math-errno", "-fno-signed-zeros", "-fno-honor-nans", "-fno-honor-infinities", "-fassociative-math",
+         "-fno-trapping-math", "-ffp-contract=fast", f"-I{_CSRC}"]
     if configuration["cflags"]:
         f += configuration["cflags"].split()
     return f

@@ -22,5 +22,6 @@ configuration = {
     "block_threads": _env("FDHIP_BLOCK_THREADS", 256, int),
     "ents_per_block": _env("FDHIP_ENTS_PER_BLOCK", 1024, int),
     "lds_limit": _env("FDHIP_LDS_LIMIT", 64 * 1024, int),
-    "mat_scatter": _env("FDHIP_MAT_SCATTER", "table"),  # table | search
+    "mat_scatter": _env("FDHIP_MAT_SCATTER", "table"),  # table | search (direct scatter flavours)
+    "mat_staged": _env("FDHIP_MAT_STAGED", 1, int),     # reduce element matrices in LDS (matrix plans)
 }

@@ -231,3 +231,212 @@ int fd_plan_free(fd_plan_t p) {
 }
 
 }  // extern "C"
+
+// =====================================================================================
+// Matrix plans: block-local sparsity for LDS-staged MatPack scatter (fd_matplan_*).
+//
+// For every plan block, the distinct (local row, local col) pairs touched by the block's
+// entities, sorted by (row, col) -- i.e. in CSR order -- with their global CSR position.
+// The staged wrapper accumulates the block's element matrices into an LDS array indexed by
+// this block-local numbering (ds_add_f64) and then issues one global atomic per distinct
+// nonzero of the block instead of one per element-matrix entry (MatSetValuesLocal with
+// ADD_VALUES, pyop2/codegen/builder.py:573-625, at block granularity).
+// =====================================================================================
+#include <hipcub/hipcub.hpp>
+
+struct fd_matplan_s {
+    int32_t nblocks = 0, max_nnz = 0, max_rowlen = 0, kbytes = 1;
+    int64_t total = 0;
+    int32_t *mb_off = nullptr;   // nblocks+1
+    int32_t *gpos = nullptr;     // total
+    int32_t *lrp = nullptr;      // sum_b (ndr_b + 1), block b starts at blkoff_r[b] + b
+    void *kidx = nullptr;        // (end-start)*ar*ac entries of kbytes each
+};
+
+namespace {
+
+__global__ void mp_emit_keys(const uint16_t *__restrict__ lmr, const uint16_t *__restrict__ lmc, int ar, int ac,
+                             int64_t nent, int epb, uint64_t *__restrict__ keys) {
+    const int64_t per = (int64_t)ar * ac, total = nent * per;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t e = t / per;
+        int ij = (int)(t - e * per);
+        int i = ij / ac, j = ij - i * ac;
+        uint64_t b = (uint64_t)(e / epb);
+        keys[t] = (b << 32) | ((uint64_t)lmr[e * ar + i] << 16) | (uint64_t)lmc[e * ac + j];
+    }
+}
+
+__global__ void mp_block_offsets(const uint64_t *__restrict__ keys, int64_t n, int32_t nblocks, int32_t *__restrict__ off,
+                                 int32_t *__restrict__ maxnnz) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t <= n; t += (int64_t)gridDim.x * blockDim.x) {
+        int32_t b = t < n ? (int32_t)(keys[t] >> 32) : nblocks;
+        int32_t bp = t > 0 ? (int32_t)(keys[t - 1] >> 32) : -1;
+        for (int32_t bb = bp + 1; bb <= b; ++bb) off[bb] = (int32_t)t;
+    }
+}
+
+__device__ inline int64_t lower_bound_u64(const uint64_t *__restrict__ a, int64_t lo, int64_t hi, uint64_t key) {
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// one workgroup per block: local row pointers, global positions, statistics
+__global__ void mp_rows_and_gpos(const uint64_t *__restrict__ keys, const int32_t *__restrict__ mb_off,
+                                 const int32_t *__restrict__ blkoff_r, const int32_t *__restrict__ list_r,
+                                 const int32_t *__restrict__ blkoff_c, const int32_t *__restrict__ list_c,
+                                 const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                                 int32_t *__restrict__ lrp, int32_t *__restrict__ gpos, int32_t *__restrict__ stats) {
+    const int64_t b = blockIdx.x;
+    const int64_t o0 = mb_off[b], o1 = mb_off[b + 1];
+    const int32_t r0 = blkoff_r[b], ndr = blkoff_r[b + 1] - r0, c0 = blkoff_c[b];
+    int32_t *mylrp = lrp + r0 + b;
+    for (int lr = threadIdx.x; lr <= ndr; lr += blockDim.x) {
+        uint64_t key = ((uint64_t)b << 32) | ((uint64_t)lr << 16);
+        mylrp[lr] = (int32_t)(lower_bound_u64(keys, o0, o1, key) - o0);
+    }
+    for (int64_t t = o0 + threadIdx.x; t < o1; t += blockDim.x) {
+        uint64_t k = keys[t];
+        int lr = (int)((k >> 16) & 0xffff), lc = (int)(k & 0xffff);
+        int r = list_r[r0 + lr], c = list_c[c0 + lc];
+        int lo = rowptr[r], hi = rowptr[r + 1] - 1, pos = -1;
+        while (lo <= hi) {
+            int mid = (lo + hi) >> 1;
+            int v = colidx[mid];
+            if (v == c) { pos = mid; break; }
+            if (v < c) lo = mid + 1; else hi = mid - 1;
+        }
+        if (pos < 0) atomicExch(&stats[2], 1);
+        gpos[t] = pos;
+    }
+    if (threadIdx.x == 0) atomicMax(&stats[0], (int32_t)(o1 - o0));
+    __syncthreads();
+    for (int lr = threadIdx.x; lr < ndr; lr += blockDim.x) atomicMax(&stats[1], mylrp[lr + 1] - mylrp[lr]);
+}
+
+template <class KT>
+__global__ void mp_kidx(const uint64_t *__restrict__ keys, const int32_t *__restrict__ mb_off,
+                        const int32_t *__restrict__ blkoff_r, const int32_t *__restrict__ lrp,
+                        const uint16_t *__restrict__ lmr, const uint16_t *__restrict__ lmc, int ar, int ac, int64_t nent,
+                        int epb, KT *__restrict__ kidx) {
+    const int64_t per = (int64_t)ar * ac, total = nent * per;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t e = t / per;
+        int ij = (int)(t - e * per);
+        int i = ij / ac, j = ij - i * ac;
+        int64_t b = e / epb;
+        int lr = lmr[e * ar + i], lc = lmc[e * ac + j];
+        uint64_t key = ((uint64_t)b << 32) | ((uint64_t)lr << 16) | (uint64_t)lc;
+        const int32_t *mylrp = lrp + blkoff_r[b] + b;
+        int64_t o0 = mb_off[b];
+        int64_t p = lower_bound_u64(keys, o0 + mylrp[lr], o0 + mylrp[lr + 1], key);
+        kidx[t] = (KT)(p - o0 - mylrp[lr]);
+    }
+}
+
+inline int mp_grid(int64_t n) { int64_t g = (n + 255) / 256; if (g < 1) g = 1; if (g > 256 * 64) g = 256 * 64; return (int)g; }
+
+}  // namespace
+
+extern "C" {
+
+int fd_matplan_create(fd_plan_t rp, fd_plan_t cp, const int32_t *rowptr, const int32_t *colidx, fd_stream_t s_,
+                      fd_matplan_t *out) {
+    hipStream_t s = fd::st(s_);
+    if (!rp || !cp) FD_FAIL("fd_matplan_create: null plan");
+    if (rp->start != cp->start || rp->end != cp->end || rp->epb != cp->epb)
+        FD_FAIL("fd_matplan_create: row and column plans must cover the same blocks");
+    auto *m = new fd_matplan_s;
+    m->nblocks = rp->nblocks;
+    const int64_t nent = (int64_t)rp->end - rp->start;
+    const int ar = rp->arity, ac = cp->arity;
+    const int64_t nkeys = nent * ar * ac;
+    if (m->nblocks == 0 || nkeys == 0) { *out = m; return 0; }
+    uint64_t *k1 = nullptr, *k2 = nullptr;
+    FD_HIP(hipMalloc(&k1, (size_t)nkeys * 8));
+    FD_HIP(hipMalloc(&k2, (size_t)nkeys * 8));
+    hipLaunchKernelGGL(mp_emit_keys, dim3(mp_grid(nkeys)), dim3(256), 0, s, rp->lmap, cp->lmap, ar, ac, nent, rp->epb, k1);
+    FD_CHECK_LAUNCH();
+    int bbits = 1; while ((1ll << bbits) < m->nblocks) ++bbits;
+    size_t tb = 0;
+    hipcub::DoubleBuffer<uint64_t> db(k1, k2);
+    FD_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, db, nkeys, 0, 32 + bbits, s));
+    void *tmp = nullptr;
+    FD_HIP(hipMalloc(&tmp, tb ? tb : 8));
+    FD_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, tb, db, nkeys, 0, 32 + bbits, s));
+    uint64_t *sorted = db.Current(), *uniq = (sorted == k1) ? k2 : k1;
+    int64_t *nsel = nullptr;
+    FD_HIP(hipMalloc(&nsel, 8));
+    size_t tb2 = 0;
+    FD_HIP(hipcub::DeviceSelect::Unique(nullptr, tb2, sorted, uniq, nsel, nkeys, s));
+    if (tb2 > tb) { FD_HIP(hipFree(tmp)); FD_HIP(hipMalloc(&tmp, tb2)); }
+    FD_HIP(hipcub::DeviceSelect::Unique(tmp, tb2, sorted, uniq, nsel, nkeys, s));
+    int64_t nu = 0;
+    FD_HIP(hipMemcpyAsync(&nu, nsel, 8, hipMemcpyDeviceToHost, s));
+    FD_HIP(hipStreamSynchronize(s));
+    if (nu > 2147483647ll) FD_FAIL("fd_matplan_create: too many block-local nonzeros for int32");
+    m->total = nu;
+    int32_t *stats = nullptr;
+    FD_HIP(hipMalloc(&stats, 16));
+    FD_HIP(hipMemsetAsync(stats, 0, 16, s));
+    FD_HIP(hipMalloc(&m->mb_off, ((size_t)m->nblocks + 1) * 4));
+    FD_HIP(hipMalloc(&m->gpos, (size_t)nu * 4));
+    FD_HIP(hipMalloc(&m->lrp, ((size_t)rp->list_len + m->nblocks) * 4));
+    hipLaunchKernelGGL(mp_block_offsets, dim3(mp_grid(nu + 1)), dim3(256), 0, s, uniq, nu, m->nblocks, m->mb_off, stats);
+    FD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(mp_rows_and_gpos, dim3(m->nblocks), dim3(256), 0, s, uniq, m->mb_off, rp->blkoff, rp->list, cp->blkoff,
+                       cp->list, rowptr, colidx, m->lrp, m->gpos, stats);
+    FD_CHECK_LAUNCH();
+    int32_t h[4];
+    FD_HIP(hipMemcpyAsync(h, stats, 16, hipMemcpyDeviceToHost, s));
+    FD_HIP(hipStreamSynchronize(s));
+    if (h[2]) FD_FAIL("fd_matplan_create: an element-matrix entry is not in the sparsity pattern");
+    m->max_nnz = h[0];
+    m->max_rowlen = h[1];
+    m->kbytes = m->max_rowlen <= 255 ? 1 : 2;
+    FD_HIP(hipMalloc(&m->kidx, (size_t)nkeys * m->kbytes));
+    if (m->kbytes == 1)
+        hipLaunchKernelGGL(mp_kidx<uint8_t>, dim3(mp_grid(nkeys)), dim3(256), 0, s, uniq, m->mb_off, rp->blkoff, m->lrp, rp->lmap,
+                           cp->lmap, ar, ac, nent, rp->epb, (uint8_t *)m->kidx);
+    else
+        hipLaunchKernelGGL(mp_kidx<uint16_t>, dim3(mp_grid(nkeys)), dim3(256), 0, s, uniq, m->mb_off, rp->blkoff, m->lrp, rp->lmap,
+                           cp->lmap, ar, ac, nent, rp->epb, (uint16_t *)m->kidx);
+    FD_CHECK_LAUNCH();
+    FD_HIP(hipStreamSynchronize(s));
+    FD_HIP(hipFree(k1)); FD_HIP(hipFree(k2)); FD_HIP(hipFree(tmp)); FD_HIP(hipFree(nsel)); FD_HIP(hipFree(stats));
+    *out = m;
+    return 0;
+}
+
+int fd_matplan_info(fd_matplan_t m, int32_t *max_nnz, int32_t *max_rowlen, int32_t *kbytes, int64_t *total) {
+    if (!m) FD_FAIL("fd_matplan_info: null plan");
+    if (max_nnz) *max_nnz = m->max_nnz;
+    if (max_rowlen) *max_rowlen = m->max_rowlen;
+    if (kbytes) *kbytes = m->kbytes;
+    if (total) *total = m->total;
+    return 0;
+}
+
+int fd_matplan_arrays(fd_matplan_t m, const int32_t **mb_off, const int32_t **gpos, const int32_t **lrp, const void **kidx) {
+    if (!m) FD_FAIL("fd_matplan_arrays: null plan");
+    if (mb_off) *mb_off = m->mb_off;
+    if (gpos) *gpos = m->gpos;
+    if (lrp) *lrp = m->lrp;
+    if (kidx) *kidx = m->kidx;
+    return 0;
+}
+
+int fd_matplan_free(fd_matplan_t m) {
+    if (!m) return 0;
+    if (m->mb_off) FD_HIP(hipFree(m->mb_off));
+    if (m->gpos) FD_HIP(hipFree(m->gpos));
+    if (m->lrp) FD_HIP(hipFree(m->lrp));
+    if (m->kidx) FD_HIP(hipFree(m->kidx));
+    delete m;
+    return 0;
+}
+
+}  // extern "C"

@@ -84,37 +84,51 @@ template <class T, class Op> __device__ __forceinline__ T block_reduce(T v, T *s
     return v;
 }
 
-// ---- packed local-map rows: ARITY uint16 per entity, read with the widest aligned loads ----
-template <int ARITY> __device__ __forceinline__ void load_lmap(const uint16_t *__restrict__ p, int (&out)[ARITY]) {
-    if constexpr ((ARITY * 2) % 16 == 0) {
+// ---- packed per-entity index rows (uint16 local maps, uint8/uint16 matrix offsets): N small
+// unsigned integers read with the widest loads the row size allows (rows are N*sizeof(T) apart).
+template <class T, int N> __device__ __forceinline__ void load_packed(const T *__restrict__ p, int (&out)[N]) {
+    constexpr int BYTES = N * (int)sizeof(T);
+    constexpr int PER = 4 / (int)sizeof(T);          // entries per 32-bit word
+    constexpr unsigned MASK = sizeof(T) == 1 ? 0xffu : 0xffffu;
+    constexpr int SH = 8 * (int)sizeof(T);
+    if constexpr (BYTES % 16 == 0) {
         const uint4 *q = reinterpret_cast<const uint4 *>(p);
 #pragma unroll
-        for (int k = 0; k < ARITY / 8; ++k) {
+        for (int k = 0; k < BYTES / 16; ++k) {
             uint4 v = q[k];
-            out[8 * k + 0] = v.x & 0xffff; out[8 * k + 1] = v.x >> 16;
-            out[8 * k + 2] = v.y & 0xffff; out[8 * k + 3] = v.y >> 16;
-            out[8 * k + 4] = v.z & 0xffff; out[8 * k + 5] = v.z >> 16;
-            out[8 * k + 6] = v.w & 0xffff; out[8 * k + 7] = v.w >> 16;
+            unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < PER; ++c) out[(4 * k + a) * PER + c] = (w[a] >> (SH * c)) & MASK;
         }
-    } else if constexpr ((ARITY * 2) % 8 == 0) {
+    } else if constexpr (BYTES % 8 == 0) {
         const uint2 *q = reinterpret_cast<const uint2 *>(p);
 #pragma unroll
-        for (int k = 0; k < ARITY / 4; ++k) {
+        for (int k = 0; k < BYTES / 8; ++k) {
             uint2 v = q[k];
-            out[4 * k + 0] = v.x & 0xffff; out[4 * k + 1] = v.x >> 16;
-            out[4 * k + 2] = v.y & 0xffff; out[4 * k + 3] = v.y >> 16;
+            unsigned w[2] = {v.x, v.y};
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < PER; ++c) out[(2 * k + a) * PER + c] = (w[a] >> (SH * c)) & MASK;
         }
-    } else if constexpr ((ARITY * 2) % 4 == 0) {
+    } else if constexpr (BYTES % 4 == 0) {
         const unsigned *q = reinterpret_cast<const unsigned *>(p);
 #pragma unroll
-        for (int k = 0; k < ARITY / 2; ++k) {
+        for (int k = 0; k < BYTES / 4; ++k) {
             unsigned v = q[k];
-            out[2 * k] = v & 0xffff; out[2 * k + 1] = v >> 16;
+#pragma unroll
+            for (int c = 0; c < PER; ++c) out[k * PER + c] = (v >> (SH * c)) & MASK;
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < ARITY; ++k) out[k] = p[k];
+        for (int k = 0; k < N; ++k) out[k] = p[k];
     }
+}
+
+template <int ARITY> __device__ __forceinline__ void load_lmap(const uint16_t *__restrict__ p, int (&out)[ARITY]) {
+    load_packed<uint16_t, ARITY>(p, out);
 }
 
 }  // namespace fdw

@@ -200,6 +200,8 @@ class GlobalKernel:
         from .codegen import generate_wrapper, select_mode
         from .compilation import compile_hip
         mode = mode or select_mode(self)
+        if mode == "auto":
+            mode = select_mode(self)
         cw = self._compiled.get(mode)
         if cw is None:
             ck = (self.cache_key, mode)

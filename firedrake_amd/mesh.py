@@ -81,6 +81,15 @@ def _tile_keys(ix, iy, iz, nx, ny, nz, tile):
     return t * (tx * ty * tz) + loc
 
 
+def _epb_for_tile(cells_per_tile, arity):
+    """Entities per plan block: a whole traversal tile (or a power-of-two fraction of one) so that plan
+    blocks coincide with the spatially compact tiles; at most 16384 map entries per block."""
+    epb = cells_per_tile
+    while epb * arity > 16384 and epb % 2 == 0:
+        epb //= 2
+    return epb
+
+
 def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0, ghost_cells=True):
     """Kuhn-split tetrahedral unit cube, z-slab partitioned.  ``tile`` = cubes per traversal tile."""
     nx, ny, nz = (int(n),) * 3 if np.isscalar(n) else tuple(int(v) for v in n)
@@ -171,6 +180,7 @@ def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0,
                     halo.recv[rank - 1] = np.concatenate([plane_nodes(z) for z in range(zlo, p * k0)])
         node_set = op2.Set(sizes_n, f"cg{p}_nodes")
         m = op2.Map(cell_set, node_set, arity, cmap, f"cell_cg{p}")
+        m.preferred_epb = _epb_for_tile(6 * tile[0] * tile[1] * tile[2], arity)
         return FunctionSpaceData(p, node_set, m, pts, halo, bnd, (p * nx + 1) * (p * ny + 1) * (p * nz + 1))
 
     spaces = {}
@@ -226,8 +236,9 @@ def UnitSquareMesh(nx, ny, degrees=(1,), tile=(16, 16), perturb=0.0):
         pts = np.stack([xx[norder] / (p * nx), yy[norder] / (p * ny)], axis=1)
         bnd = np.nonzero((xx[norder] == 0) | (xx[norder] == p * nx) | (yy[norder] == 0) | (yy[norder] == p * ny))[0].astype(np.int32)
         node_set = op2.Set(len(norder), f"cg{p}_nodes")
-        return FunctionSpaceData(p, node_set, op2.Map(cell_set, node_set, arity, newnum[box], f"cell_cg{p}"), pts,
-                                 HaloLists(), bnd, Lx * Ly)
+        m = op2.Map(cell_set, node_set, arity, newnum[box], f"cell_cg{p}")
+        m.preferred_epb = _epb_for_tile(2 * tile[0] * tile[1], arity)
+        return FunctionSpaceData(p, node_set, m, pts, HaloLists(), bnd, Lx * Ly)
 
     spaces = {p: lattice_space(p) for p in sorted(set(degrees) | {1})}
     cs = spaces[1]

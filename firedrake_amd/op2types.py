@@ -779,6 +779,16 @@ class Sparsity:
         rp = self._node_rowptr.download(np.int32, (self._dsets[0].set.total_size + 1,))
         return np.diff(rp)
 
+    def matplan(self, rowplan, colplan, maps):
+        """Cached block-local sparsity for the staged matrix scatter (fd_matplan_create)."""
+        self._build()
+        key = ("mp", id(maps[0]._base()), id(maps[1]._base()), rowplan.start, rowplan.end, rowplan.epb)
+        mp = self._elem_tables.get(key)
+        if mp is None:
+            mp = MatPlan(self, rowplan, colplan)
+            self._elem_tables[key] = mp
+        return mp
+
     def elem_table(self, rmap: Map, cmap: Map):
         """Device table element -> nonzero position in the NODE pattern (fd_csr_elem_offsets)."""
         self._build()
@@ -791,6 +801,30 @@ class Sparsity:
                       cmap._base()._dev_values(), nent, rmap.arity, cmap.arity, t.ptr, None)
             self._elem_tables[key] = t
         return t
+
+
+class MatPlan:
+    """Python handle on an fd_matplan_t."""
+
+    def __init__(self, sparsity, rowplan, colplan):
+        h = ctypes.c_void_p()
+        _lib.call("fd_matplan_create", rowplan.h, colplan.h, sparsity._node_rowptr.ptr, sparsity._node_colidx.ptr, None,
+                  ctypes.byref(h))
+        self.h = h.value
+        a, b, c, t = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
+        _lib.call("fd_matplan_info", self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(t))
+        self.max_nnz, self.max_rowlen, self.kbytes, self.total = a.value, b.value, c.value, t.value
+        p = [ctypes.c_void_p() for _ in range(4)]
+        _lib.call("fd_matplan_arrays", self.h, *[ctypes.byref(x) for x in p])
+        self.mb_off, self.gpos, self.lrp, self.kidx = (x.value for x in p)
+        self._plans = (rowplan, colplan)      # keep alive
+
+    def __del__(self):
+        try:
+            if self.h:
+                _lib.load().fd_matplan_free(self.h)
+        except Exception:
+            pass
 
 
 class Mat:

@@ -185,7 +185,7 @@ class Parloop:
                     maps.append(m._base())
         assert len(maps) == src.nmaps
         prep = {"cw": cw, "maps": maps}
-        if src.mode == "staged":
+        if src.mode.startswith("staged"):
             prep["parts"] = {}
         self._prepared = prep
         return prep
@@ -201,18 +201,36 @@ class Parloop:
         maps = prep["maps"]
         maxar = max(maps[mi].arity for mi in src.staged_maps)
         epb = configuration["ents_per_block"]
+        for pa in self.arguments:                      # a Map may carry a preferred block size (mesh tiles)
+            for m in getattr(pa, "maps", ()):
+                epb = getattr(m._base(), "preferred_epb", None) or epb
         while epb * maxar > 16384:
             epb //= 2
         limit = configuration["lds_limit"]
         while True:
             plans = {mi: maps[mi].plan(start, end, epb) for mi in src.staged_maps}
-            lds = sum(((plans[mi].max_nd * c * isz) + 15) // 16 * 16 for mi, c, isz in src.lds_items)
-            if lds <= limit or epb <= 64:
+            mplans = {}
+            lds = 0
+            for item in src.lds_items:
+                if item[0] == "dat":
+                    _, mi, c, isz = item
+                    lds += ((plans[mi].max_nd * c * isz) + 15) // 16 * 16
+                else:
+                    _, k, rm, cm, lg = item
+                    pa = self.arguments[k]
+                    mp = pa.data.sparsity.matplan(plans[rm], plans[cm], pa.maps)
+                    mplans[k] = mp
+                    lds += (mp.max_nnz * 8 + 15) // 16 * 16 + ((plans[rm].max_nd + 1) * 4 + 15) // 16 * 16
+                    if lg:
+                        lds += (plans[rm].max_nd + 15) // 16 * 16 + (plans[cm].max_nd + 15) // 16 * 16
+            if lds <= limit or epb <= 32:
                 break
-            epb //= 2
+            epb = max(32, epb // 2)
         if lds > 160 * 1024:
-            raise _lib.FDHipError("staged wrapper does not fit LDS even at 64 entities per block")
-        geo = {"epb": epb, "plans": plans, "lds": lds}
+            raise _lib.FDHipError("staged wrapper does not fit LDS even at 32 entities per block")
+        if any(mp.kbytes == 2 for mp in mplans.values()) and src.kbytes == 1:
+            prep["cw"] = self.global_kernel.compile("staged_k16")
+        geo = {"epb": epb, "plans": plans, "mplans": mplans, "lds": lds}
         prep["parts"][key] = geo
         return geo
 
@@ -220,7 +238,8 @@ class Parloop:
     def _arglist(self, start, end):
         prep = self._prepare()
         src = prep["cw"].src
-        geo = self._staged_geometry(start, end) if src.mode == "staged" else None
+        geo = self._staged_geometry(start, end) if src.mode.startswith("staged") else None
+        src = prep["cw"].src
         out = []
         for desc in src.layout:
             kind = desc[0]
@@ -248,6 +267,16 @@ class Parloop:
                 out.append(geo["plans"][desc[1]].lmap)
             elif kind == "plan_maxnd":
                 out.append(geo["plans"][desc[1]].max_nd)
+            elif kind == "matplan_off":
+                out.append(geo["mplans"][desc[1]].mb_off)
+            elif kind == "matplan_gpos":
+                out.append(geo["mplans"][desc[1]].gpos)
+            elif kind == "matplan_lrp":
+                out.append(geo["mplans"][desc[1]].lrp)
+            elif kind == "matplan_kidx":
+                out.append(geo["mplans"][desc[1]].kidx)
+            elif kind == "matplan_maxnnz":
+                out.append(geo["mplans"][desc[1]].max_nnz)
             elif kind == "mat_table":
                 pa = self.arguments[desc[1]]
                 out.append(pa.data.sparsity.elem_table(*pa.maps).ptr)
@@ -304,7 +333,7 @@ class Parloop:
         cw = self._prepared["cw"]
         src = cw.src
         threads = src.block_threads
-        if src.mode == "staged":
+        if src.mode.startswith("staged"):
             cw.launch(start, end, args, block_threads=threads, ents_per_block=geo["epb"], lds_bytes=geo["lds"])
         else:
             total = size

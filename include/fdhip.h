@@ -109,6 +109,22 @@ int fd_plan_arrays(fd_plan_t p, const int32_t **block_offsets, const int32_t **n
                    const uint16_t **local_map);
 int fd_plan_free(fd_plan_t p);
 
+/* Matrix plans: for every plan block, the distinct (row node, col node) pairs its entities touch, in
+ * CSR order, with their position in the global node CSR.  Lets the staged wrapper reduce the block's
+ * element matrices in LDS and issue ONE global atomic per distinct nonzero of the block -- the
+ * block-granular form of MatSetValuesLocal(..., ADD_VALUES) (pyop2/codegen/builder.py:573-625).
+ *   mb_off[nblocks+1]  offsets of the blocks' nonzero lists;   gpos[total]  global CSR positions
+ *   lrp                local row pointers, block b at lrp[blkoff_r[b] + b .. + ndr_b]
+ *   kidx               per (entity,i,j): offset inside its local row (uint8 if kbytes==1 else uint16) */
+typedef struct fd_matplan_s *fd_matplan_t;
+int fd_matplan_create(fd_plan_t row_plan, fd_plan_t col_plan, const int32_t *node_rowptr_dev,
+                      const int32_t *node_colidx_dev, fd_stream_t s, fd_matplan_t *out);
+int fd_matplan_info(fd_matplan_t m, int32_t *max_nnz_per_block, int32_t *max_row_len, int32_t *kbytes,
+                    int64_t *total);
+int fd_matplan_arrays(fd_matplan_t m, const int32_t **mb_off, const int32_t **gpos, const int32_t **lrp,
+                      const void **kidx);
+int fd_matplan_free(fd_matplan_t m);
+
 /* ------------------------------------------------------------ sparsity / CSR (a12)
  * Native replacement of pyop2/sparsity.pyx:105-159 (build_sparsity) + :162-389
  * (fill_with_zeros): union over (rowmap, colmap) pairs of the outer product of each
