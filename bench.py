@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--degree", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=64, help="cube size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-bcs", action="store_true")
+    ap.add_argument("--tile", type=str, default="8,4,4", help="cubes per traversal tile (= plan block)")
+    ap.add_argument("--only", choices=["both", "residual", "jacobian"], default="both", help="profiling aid: run one form only")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -101,7 +103,8 @@ def main():
 
     n = args.n
     t0 = time.perf_counter()
-    mesh = fmesh.UnitCubeMesh((n, n, n * world), degrees=(args.degree,), rank=rank, nranks=world, perturb=0.1)
+    mesh = fmesh.UnitCubeMesh((n, n, n * world), degrees=(args.degree,), rank=rank, nranks=world, perturb=0.1,
+                              tile=tuple(int(v) for v in args.tile.split(",")))
     prob = forms.PoissonProblem(mesh, args.degree, bcs=not args.no_bcs)
     t_mesh = time.perf_counter() - t0
     V = prob.V
@@ -119,11 +122,13 @@ def main():
     def step(k=None):
         if k is not None:
             ev[k][0].record()
-        prob.assemble_residual()
+        if args.only != "jacobian":
+            prob.assemble_residual()
         if k is not None:
             ev[k][1].record()
             ev[k][2].record()
-        prob.assemble_jacobian()
+        if args.only != "residual":
+            prob.assemble_jacobian()
         if k is not None:
             ev[k][3].record()
 

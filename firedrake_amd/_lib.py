@@ -49,10 +49,14 @@ SIGNATURES = {
     "fd_kernel_launch": (c_int, [c_void_p, c_int32, c_int32, POINTER(c_void_p), c_int, c_int, c_int, c_int,
                                  c_size_t, c_void_p]),
     "fd_plan_create": (c_int, [c_void_p, c_int, c_int32, c_int32, c_int, c_void_p, POINTER(c_void_p)]),
+    "fd_plan_create_blocks": (c_int, [c_void_p, c_int, c_void_p, c_int32, c_void_p, POINTER(c_void_p)]),
+    "fd_plan_block_starts": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int32)]),
     "fd_plan_info": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int64)]),
     "fd_plan_arrays": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
     "fd_plan_free": (c_int, [c_void_p]),
-    "fd_matplan_create": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
+    "fd_matplan_create": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, POINTER(c_void_p)]),
+    "fd_matplan_zero_list": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64), POINTER(c_int64)]),
+    "fd_csr_zero_entries": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "fd_matplan_info": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int64)]),
     "fd_matplan_arrays": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
     "fd_matplan_free": (c_int, [c_void_p]),

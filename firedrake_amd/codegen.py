@@ -173,7 +173,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         P(f"const int *__restrict__ map{mi}", ("map", mi))
 
     # ---- backend-private parameters
-    P("long long epb_", ("epb",))
+    P("const int *__restrict__ bstart_", ("bstart",))
     staged_maps = []
     lds_items = []
     mat_staged = {}
@@ -207,6 +207,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             P(f"const int *__restrict__ mp{k}_lrp", ("matplan_lrp", k))
             P(f"const {ktype} *__restrict__ mp{k}_k", ("matplan_kidx", k))
             P(f"long long mp{k}_maxnnz", ("matplan_maxnnz", k))
+            P(f"long long mp{k}_flags", ("matplan_flags", k))
         elif table:
             P(f"const int *__restrict__ tab{k}", ("mat_table", k))
             if info["rbs"] * info["cbs"] != 1:
@@ -324,8 +325,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
                     stage.append((rm, f"for (int q = tid; q < nd{rm}; q += nthr) smr{k}[q] = rlg{k}[p{rm}_list[l0_{rm} + q]] < 0;"))
                     stage.append((cm, f"for (int q = tid; q < nd{cm}; q += nthr) smc{k}[q] = clg{k}[p{cm}_list[l0_{cm} + q]] < 0;"))
                 mat_stage_pre.extend(mat_pre)
-                lines = [f"int kk{k}[{ar * ac}]; fdw::load_packed<{ktype}, {ar * ac}>(mp{k}_k + (size_t)(e - start)*{ar * ac}, kk{k});",
-                         f"for (int i = 0; i < {ar}; ++i) {{",
+                lines = [f"for (int i = 0; i < {ar}; ++i) {{",
                          f"  const int base = slrp{k}[lm{rm}[i]];"]
                 if lg:
                     lines.append(f"  if (smr{k}[lm{rm}[i]]) continue;")
@@ -334,8 +334,14 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
                     lines.append(f"    if (smc{k}[lm{cm}[j]]) continue;")
                 lines += [f"    atomicAdd(&sm{k}[base + kk{k}[i*{ac} + j]], t{k}[i*{ac} + j]);", "  }", "}"]
                 unpack.append("\n    ".join(lines))
-                flush.append((rm, f"for (int q = tid; q < nnzb{k}; q += nthr) {{ const double v = sm{k}[q]; "
-                                  f"if (v != 0.0) fdw::atomic_add<double>(&arg{k}[mp{k}_gpos[mo{k} + q]], v); }}"))
+                # exclusive entries (~pos < 0) need no atomic; with a pending Mat.zero() they are simply overwritten
+                if configuration["mat_exclusive"]:
+                    flush.append((rm, f"for (int q = tid; q < nnzb{k}; q += nthr) {{ const double v = sm{k}[q]; const int g = mp{k}_gpos[mo{k} + q]; "
+                                      f"if (g < 0) {{ if (mp{k}_flags & 1) arg{k}[~g] = v; else if (v != 0.0) arg{k}[~g] += v; }} "
+                                      f"else if (v != 0.0) fdw::atomic_add<double>(&arg{k}[g], v); }}"))
+                else:
+                    flush.append((rm, f"for (int q = tid; q < nnzb{k}; q += nthr) {{ const double v = sm{k}[q]; const int g = mp{k}_gpos[mo{k} + q]; "
+                                      f"if (v != 0.0) fdw::atomic_add<double>(&arg{k}[g < 0 ? ~g : g], v); }}"))
                 continue
             store = (lambda p, v: f"fdw::atomic_add<double>(&arg{k}[{p}], {v});") if acc == INC else (lambda p, v: f"arg{k}[{p}] = {v};")
             unroll = info["arg"].unroll
@@ -373,7 +379,8 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
            "namespace fdk {", "#pragma clang force_cuda_host_device begin", body,
            "#pragma clang force_cuda_host_device end", "}  // namespace fdk", *decls, ""]
     sym = f"wrap_{lk.name}"
-    src.append(f'extern "C" __global__ __launch_bounds__({threads}) void {sym}(int start, int end, {", ".join(params)})')
+    lb = f"{threads}, {configuration['min_waves']}" if configuration["min_waves"] else f"{threads}"
+    src.append(f'extern "C" __global__ __launch_bounds__({lb}) void {sym}(int start, int end, {", ".join(params)})')
     src.append("{")
     need_red = bool(post)
     if need_red:
@@ -383,9 +390,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         src += ["  extern __shared__ __align__(16) unsigned char fd_lds[];",
                 "  const int tid = threadIdx.x, nthr = blockDim.x;",
                 "  const int b = fdw::xcd_block(blockIdx.x, gridDim.x);",
-                "  const int epb = (int)epb_;",
-                "  const int e0 = start + b*epb;",
-                "  const int e1 = (e0 + epb < end) ? e0 + epb : end;"]
+                "  const int e0 = bstart_[b], e1 = bstart_[b+1];"]
         src += ["  " + s for s in lds_decl]
         for mi in staged_maps:
             src.append(f"  const int l0_{mi} = p{mi}_blkoff[b], nd{mi} = p{mi}_blkoff[b+1] - l0_{mi};")
@@ -393,15 +398,42 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         src += ["  " + s for _, s in stage]
         src.append("  __syncthreads();")
         src += ["  " + s for s in pre]
-        src.append("  for (int e = e0 + tid; e < e1; e += nthr) {")
+        # software pipeline: the packed index rows of the NEXT entity are requested before the current
+        # entity's local kernel runs, so their HBM latency hides under ~10^2 fp64 instructions
+        idx_loads = []      # (declaration of the register row, load statement template)
         for mi in staged_maps:
             ar = maps[mi].arity
-            src.append(f"    int lm{mi}[{ar}]; fdw::load_lmap<{ar}>(p{mi}_lmap + (size_t)(e - start)*{ar}, lm{mi});")
+            idx_loads.append((f"int lm{mi}[{ar}]", f"int nx_lm{mi}[{ar}]", f"lm{mi}", ar,
+                              f"fdw::load_lmap<{ar}>(p{mi}_lmap + (size_t)(EE - start)*{ar}, DST);"))
+        for info in infos:
+            if info["kind"] == "mat" and mat_staged[info["k"]]:
+                k, n = info["k"], info["ar"] * info["ac"]
+                idx_loads.append((f"int kk{k}[{n}]", f"int nx_kk{k}[{n}]", f"kk{k}", n,
+                                  f"fdw::load_packed<{ktype}, {n}>(mp{k}_k + (size_t)(EE - start)*{n}, DST);"))
+        pf = bool(configuration["prefetch"])
+        if pf:
+            for cur, nxt, name, n, ld in idx_loads:
+                src.append(f"  {cur}; {nxt};")
+            src.append("  if (e0 + tid < e1) {")
+            for cur, nxt, name, n, ld in idx_loads:
+                src.append("    " + ld.replace("EE", "(e0 + tid)").replace("DST", name))
+            src.append("  }")
+        src.append("  for (int e = e0 + tid; e < e1; e += nthr) {")
+        if pf:
+            src.append("    const int en = (e + nthr < e1) ? e + nthr : e;")
+            for cur, nxt, name, n, ld in idx_loads:
+                src.append("    " + ld.replace("EE", "en").replace("DST", "nx_" + name))
+        else:
+            for cur, nxt, name, n, ld in idx_loads:
+                src.append(f"    {cur}; " + ld.replace("EE", "e").replace("DST", name))
         src += ["    " + s for s in pack]
         src.append(f"    fdk::{lk.name}({', '.join(call_args)});")
         src += ["    " + s for s in unpack]
+        if pf:
+            for cur, nxt, name, n, ld in idx_loads:
+                src.append(f"    for (int q = 0; q < {n}; ++q) {name}[q] = nx_{name}[q];")
         src.append("  }")
-        if flush:
+        if flush and not configuration["debug_noflush"]:
             src.append("  __syncthreads();")
             src += ["  " + s for _, s in flush]
         src += ["  " + s for s in post]

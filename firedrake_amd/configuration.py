@@ -21,6 +21,11 @@ configuration = {
     "mode": _env("FDHIP_MODE", "auto"),                 # auto | staged | direct
     "block_threads": _env("FDHIP_BLOCK_THREADS", 256, int),
     "ents_per_block": _env("FDHIP_ENTS_PER_BLOCK", 1024, int),
+    "prefetch": _env("FDHIP_PREFETCH", 1, int),          # software-pipeline the packed index rows
+    "mat_exclusive": _env("FDHIP_MAT_EXCLUSIVE", 0, int),  # non-atomic writes + fused zero for block-exclusive nonzeros
+    "debug_noflush": _env("FDHIP_DEBUG_NOFLUSH", 0, int),  # experiment: skip the global flush (WRONG results)
+    "min_waves": _env("FDHIP_MIN_WAVES", 0, int),       # 2nd __launch_bounds__ argument (waves per SIMD), 0 = unset
+    "use_preferred_blocks": _env("FDHIP_PREFERRED_BLOCKS", 1, int),   # plan blocks = the producer's traversal tiles
     "lds_limit": _env("FDHIP_LDS_LIMIT", 64 * 1024, int),
     "mat_scatter": _env("FDHIP_MAT_SCATTER", "table"),  # table | search (direct scatter flavours)
     "mat_staged": _env("FDHIP_MAT_STAGED", 1, int),     # reduce element matrices in LDS (matrix plans)

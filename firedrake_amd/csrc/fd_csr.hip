@@ -109,6 +109,11 @@ __global__ void set_diag(const int32_t *__restrict__ rowptr, const int32_t *__re
     }
 }
 
+__global__ void zero_entries(double *__restrict__ vals, const int32_t *__restrict__ idx, int64_t n) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+        vals[idx[t]] = 0.0;
+}
+
 __global__ void spmv(int32_t nrows, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                      const double *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y) {
     // one wavefront per row
@@ -246,6 +251,13 @@ int fd_csr_zero_rows(const int32_t *rowptr, const int32_t *colidx, double *vals,
                      double v, fd_stream_t s) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(set_diag, dim3(grid_for(n)), dim3(256), 0, fd::st(s), rowptr, colidx, vals, rows, n, v, 1);
+    FD_CHECK_LAUNCH();
+    return 0;
+}
+
+int fd_csr_zero_entries(double *vals, const int32_t *idx, int64_t n, fd_stream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(zero_entries, dim3(grid_for(n)), dim3(256), 0, fd::st(s), vals, idx, n);
     FD_CHECK_LAUNCH();
     return 0;
 }

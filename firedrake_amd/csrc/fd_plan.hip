@@ -19,7 +19,8 @@ struct fd_plan_s {
     int32_t *blkoff = nullptr;   // nblocks+1
     int32_t *list = nullptr;     // list_len
     uint16_t *lmap = nullptr;    // (end-start)*arity
-    int arity = 0, epb = 0;
+    int32_t *bstart = nullptr;   // nblocks+1: first entity of every block (blocks may differ in size)
+    int arity = 0, epb = 0;      // epb = largest block
     int32_t start = 0, end = 0;
 };
 
@@ -74,15 +75,15 @@ __device__ inline int block_excl_scan(int v, int *total) {
 
 // mode 0: count distinct nodes per block; mode 1: write node list + local map
 __global__ __launch_bounds__(PT) void plan_pass(const int32_t *__restrict__ map, int arity, int32_t start,
-                                                int32_t end, int epb, int n2, int mode,
+                                                const int32_t *__restrict__ bstart, int n2, int mode,
                                                 int32_t *__restrict__ nuniq, const int32_t *__restrict__ blkoff,
                                                 int32_t *__restrict__ list, uint16_t *__restrict__ lmap,
                                                 int32_t *__restrict__ maxnd, int32_t *__restrict__ err) {
     extern __shared__ int s[];
     const int tid = threadIdx.x;
     const int64_t b = blockIdx.x;
-    const int64_t e0 = start + b * epb;
-    const int64_t e1 = (e0 + epb < end) ? e0 + epb : end;
+    const int64_t e0 = bstart[b];
+    const int64_t e1 = bstart[b + 1];
     const int cnt = (int)(e1 - e0) * arity;
     const int32_t *src = map + e0 * arity;
     for (int i = tid; i < n2; i += PT) {
@@ -137,6 +138,13 @@ __global__ __launch_bounds__(PT) void plan_pass(const int32_t *__restrict__ map,
     }
 }
 
+__global__ void plan_uniform_blocks(int32_t start, int32_t end, int epb, int32_t nblocks, int32_t *__restrict__ bstart) {
+    for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b <= nblocks; b += (int64_t)gridDim.x * blockDim.x) {
+        int64_t e = (int64_t)start + b * epb;
+        bstart[b] = (int32_t)(e < end ? e : end);
+    }
+}
+
 __global__ __launch_bounds__(PT) void plan_scan(const int32_t *__restrict__ in, int32_t *__restrict__ out, int n) {
     __shared__ int carry_s;
     if (threadIdx.x == 0) carry_s = 0;
@@ -159,6 +167,51 @@ __global__ __launch_bounds__(PT) void plan_scan(const int32_t *__restrict__ in, 
 
 extern "C" {
 
+static int plan_build(fd_plan_s *p, const int32_t *map_dev, hipStream_t s) {
+    const int arity = p->arity;
+    const int64_t n = (int64_t)p->end - p->start;
+    int n2 = PT;
+    while (n2 < p->epb * arity) n2 <<= 1;
+    size_t lds = (size_t)n2 * sizeof(int);
+    if (lds > 48 * 1024)
+        FD_HIP(hipFuncSetAttribute((const void *)plan_pass, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int32_t *nuniq = nullptr, *scal = nullptr;
+    FD_HIP(hipMalloc(&nuniq, (size_t)p->nblocks * 4));
+    FD_HIP(hipMalloc(&scal, 8));
+    FD_HIP(hipMemsetAsync(scal, 0, 8, s));
+    FD_HIP(hipMalloc(&p->blkoff, ((size_t)p->nblocks + 1) * 4));
+    hipLaunchKernelGGL(plan_pass, dim3(p->nblocks), dim3(PT), lds, s, map_dev, arity, p->start, p->bstart, n2, 0,
+                       nuniq, nullptr, nullptr, nullptr, scal, scal + 1);
+    FD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(plan_scan, dim3(1), dim3(PT), 0, s, nuniq, p->blkoff, p->nblocks);
+    FD_CHECK_LAUNCH();
+    int32_t h[2], total;
+    FD_HIP(hipMemcpyAsync(h, scal, 8, hipMemcpyDeviceToHost, s));
+    FD_HIP(hipMemcpyAsync(&total, p->blkoff + p->nblocks, 4, hipMemcpyDeviceToHost, s));
+    FD_HIP(hipStreamSynchronize(s));
+    if (h[1]) { (void)hipFree(nuniq); (void)hipFree(scal);
+                FD_FAIL("fd_plan_create: map has negative entries (VALUE_UNDEFINED); use the direct wrapper"); }
+    p->max_nd = h[0];
+    p->list_len = total;
+    FD_HIP(hipMalloc(&p->list, (size_t)(total > 0 ? total : 1) * 4));
+    FD_HIP(hipMalloc(&p->lmap, (size_t)n * arity * 2));
+    hipLaunchKernelGGL(plan_pass, dim3(p->nblocks), dim3(PT), lds, s, map_dev, arity, p->start, p->bstart, n2, 1,
+                       nuniq, p->blkoff, p->list, p->lmap, scal, scal + 1);
+    FD_CHECK_LAUNCH();
+    FD_HIP(hipStreamSynchronize(s));
+    FD_HIP(hipFree(nuniq));
+    FD_HIP(hipFree(scal));
+    return 0;
+}
+
+static void plan_release(fd_plan_s *p) {
+    if (p->blkoff) (void)hipFree(p->blkoff);
+    if (p->list) (void)hipFree(p->list);
+    if (p->lmap) (void)hipFree(p->lmap);
+    if (p->bstart) (void)hipFree(p->bstart);
+    delete p;
+}
+
 int fd_plan_create(const int32_t *map_dev, int arity, int32_t start, int32_t end, int epb,
                    fd_stream_t s_, fd_plan_t *out) {
     hipStream_t s = fd::st(s_);
@@ -169,39 +222,46 @@ int fd_plan_create(const int32_t *map_dev, int arity, int32_t start, int32_t end
     p->arity = arity; p->epb = epb; p->start = start; p->end = end;
     int64_t n = (int64_t)end - start;
     p->nblocks = (int32_t)((n + epb - 1) / epb);
+    FD_HIP(hipMalloc(&p->bstart, ((size_t)p->nblocks + 1) * 4));
+    hipLaunchKernelGGL(plan_uniform_blocks, dim3((p->nblocks + 256) / 256), dim3(256), 0, s, start, end, epb, p->nblocks, p->bstart);
+    FD_CHECK_LAUNCH();
     if (p->nblocks == 0) { *out = p; return 0; }
-    int n2 = PT;
-    while (n2 < epb * arity) n2 <<= 1;
-    size_t lds = (size_t)n2 * sizeof(int);
-    if (lds > 48 * 1024)
-        FD_HIP(hipFuncSetAttribute((const void *)plan_pass, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int32_t *nuniq = nullptr, *scal = nullptr;
-    FD_HIP(hipMalloc(&nuniq, (size_t)p->nblocks * 4));
-    FD_HIP(hipMalloc(&scal, 8));
-    FD_HIP(hipMemsetAsync(scal, 0, 8, s));
-    FD_HIP(hipMalloc(&p->blkoff, ((size_t)p->nblocks + 1) * 4));
-    hipLaunchKernelGGL(plan_pass, dim3(p->nblocks), dim3(PT), lds, s, map_dev, arity, start, end, epb, n2, 0,
-                       nuniq, nullptr, nullptr, nullptr, scal, scal + 1);
-    FD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(plan_scan, dim3(1), dim3(PT), 0, s, nuniq, p->blkoff, p->nblocks);
-    FD_CHECK_LAUNCH();
-    int32_t h[2], total;
-    FD_HIP(hipMemcpyAsync(h, scal, 8, hipMemcpyDeviceToHost, s));
-    FD_HIP(hipMemcpyAsync(&total, p->blkoff + p->nblocks, 4, hipMemcpyDeviceToHost, s));
-    FD_HIP(hipStreamSynchronize(s));
-    if (h[1]) { (void)hipFree(nuniq); (void)hipFree(scal); (void)hipFree(p->blkoff); delete p;
-                FD_FAIL("fd_plan_create: map has negative entries (VALUE_UNDEFINED); use the direct wrapper"); }
-    p->max_nd = h[0];
-    p->list_len = total;
-    FD_HIP(hipMalloc(&p->list, (size_t)(total > 0 ? total : 1) * 4));
-    FD_HIP(hipMalloc(&p->lmap, (size_t)n * arity * 2));
-    hipLaunchKernelGGL(plan_pass, dim3(p->nblocks), dim3(PT), lds, s, map_dev, arity, start, end, epb, n2, 1,
-                       nuniq, p->blkoff, p->list, p->lmap, scal, scal + 1);
-    FD_CHECK_LAUNCH();
-    FD_HIP(hipStreamSynchronize(s));
-    FD_HIP(hipFree(nuniq));
-    FD_HIP(hipFree(scal));
+    int rc = plan_build(p, map_dev, s);
+    if (rc) { plan_release(p); return rc; }
     *out = p;
+    return 0;
+}
+
+int fd_plan_create_blocks(const int32_t *map_dev, int arity, const int32_t *block_starts_host, int32_t nblocks,
+                          fd_stream_t s_, fd_plan_t *out) {
+    hipStream_t s = fd::st(s_);
+    if (arity <= 0 || nblocks < 0 || !block_starts_host) FD_FAIL("fd_plan_create_blocks: bad arguments");
+    auto *p = new fd_plan_s;
+    p->arity = arity; p->nblocks = nblocks;
+    p->start = block_starts_host[0]; p->end = block_starts_host[nblocks];
+    int mx = 0;
+    for (int32_t b = 0; b < nblocks; ++b) {
+        int d = block_starts_host[b + 1] - block_starts_host[b];
+        if (d < 0) { delete p; FD_FAIL("fd_plan_create_blocks: block starts must be non-decreasing"); }
+        if (d > mx) mx = d;
+    }
+    p->epb = mx > 0 ? mx : 1;
+    if ((int64_t)p->epb * arity > (int64_t)PT * MAXCHUNK) { delete p;
+        FD_FAIL("fd_plan_create_blocks: a block exceeds 16384 map entries"); }
+    FD_HIP(hipMalloc(&p->bstart, ((size_t)nblocks + 1) * 4));
+    FD_HIP(hipMemcpyAsync(p->bstart, block_starts_host, ((size_t)nblocks + 1) * 4, hipMemcpyHostToDevice, s));
+    FD_HIP(hipStreamSynchronize(s));
+    if (nblocks == 0 || p->end == p->start) { *out = p; return 0; }
+    int rc = plan_build(p, map_dev, s);
+    if (rc) { plan_release(p); return rc; }
+    *out = p;
+    return 0;
+}
+
+int fd_plan_block_starts(fd_plan_t p, const int32_t **block_starts, int32_t *max_ents_per_block) {
+    if (!p) FD_FAIL("fd_plan_block_starts: null plan");
+    if (block_starts) *block_starts = p->bstart;
+    if (max_ents_per_block) *max_ents_per_block = p->epb;
     return 0;
 }
 
@@ -223,10 +283,7 @@ int fd_plan_arrays(fd_plan_t p, const int32_t **blkoff, const int32_t **list, co
 
 int fd_plan_free(fd_plan_t p) {
     if (!p) return 0;
-    if (p->blkoff) FD_HIP(hipFree(p->blkoff));
-    if (p->list) FD_HIP(hipFree(p->list));
-    if (p->lmap) FD_HIP(hipFree(p->lmap));
-    delete p;
+    plan_release(p);
     return 0;
 }
 
@@ -251,18 +308,25 @@ struct fd_matplan_s {
     int32_t *gpos = nullptr;     // total
     int32_t *lrp = nullptr;      // sum_b (ndr_b + 1), block b starts at blkoff_r[b] + b
     void *kidx = nullptr;        // (end-start)*ar*ac entries of kbytes each
+    int32_t *zero_list = nullptr;  // CSR positions NOT written exclusively by one block (shared or untouched)
+    int64_t n_zero = 0, n_exclusive = 0;
 };
 
 namespace {
 
+__global__ void mp_ent_block(const int32_t *__restrict__ bstart, int32_t start, int32_t *__restrict__ eb) {
+    const int32_t b = blockIdx.x;
+    for (int32_t e = bstart[b] + threadIdx.x; e < bstart[b + 1]; e += blockDim.x) eb[e - start] = b;
+}
+
 __global__ void mp_emit_keys(const uint16_t *__restrict__ lmr, const uint16_t *__restrict__ lmc, int ar, int ac,
-                             int64_t nent, int epb, uint64_t *__restrict__ keys) {
+                             int64_t nent, const int32_t *__restrict__ eb, uint64_t *__restrict__ keys) {
     const int64_t per = (int64_t)ar * ac, total = nent * per;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         int64_t e = t / per;
         int ij = (int)(t - e * per);
         int i = ij / ac, j = ij - i * ac;
-        uint64_t b = (uint64_t)(e / epb);
+        uint64_t b = (uint64_t)eb[e];
         keys[t] = (b << 32) | ((uint64_t)lmr[e * ar + i] << 16) | (uint64_t)lmc[e * ac + j];
     }
 }
@@ -321,13 +385,13 @@ template <class KT>
 __global__ void mp_kidx(const uint64_t *__restrict__ keys, const int32_t *__restrict__ mb_off,
                         const int32_t *__restrict__ blkoff_r, const int32_t *__restrict__ lrp,
                         const uint16_t *__restrict__ lmr, const uint16_t *__restrict__ lmc, int ar, int ac, int64_t nent,
-                        int epb, KT *__restrict__ kidx) {
+                        const int32_t *__restrict__ eb, KT *__restrict__ kidx) {
     const int64_t per = (int64_t)ar * ac, total = nent * per;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         int64_t e = t / per;
         int ij = (int)(t - e * per);
         int i = ij / ac, j = ij - i * ac;
-        int64_t b = e / epb;
+        int64_t b = eb[e];
         int lr = lmr[e * ar + i], lc = lmc[e * ac + j];
         uint64_t key = ((uint64_t)b << 32) | ((uint64_t)lr << 16) | (uint64_t)lc;
         const int32_t *mylrp = lrp + blkoff_r[b] + b;
@@ -337,17 +401,35 @@ __global__ void mp_kidx(const uint64_t *__restrict__ keys, const int32_t *__rest
     }
 }
 
+__global__ void mp_count(const int32_t *__restrict__ gpos, int64_t n, int32_t *__restrict__ cnt) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+        atomicAdd(&cnt[gpos[t]], 1);
+}
+
+// exclusive entries (touched by exactly one block) are encoded as ~pos (negative)
+__global__ void mp_encode(int32_t *__restrict__ gpos, int64_t n, const int32_t *__restrict__ cnt) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        int32_t g = gpos[t];
+        if (cnt[g] == 1) gpos[t] = ~g;
+    }
+}
+
+__global__ void mp_flags(const int32_t *__restrict__ cnt, int64_t nnz, uint8_t *__restrict__ flags) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < nnz; t += (int64_t)gridDim.x * blockDim.x)
+        flags[t] = cnt[t] != 1;
+}
+
 inline int mp_grid(int64_t n) { int64_t g = (n + 255) / 256; if (g < 1) g = 1; if (g > 256 * 64) g = 256 * 64; return (int)g; }
 
 }  // namespace
 
 extern "C" {
 
-int fd_matplan_create(fd_plan_t rp, fd_plan_t cp, const int32_t *rowptr, const int32_t *colidx, fd_stream_t s_,
-                      fd_matplan_t *out) {
+int fd_matplan_create(fd_plan_t rp, fd_plan_t cp, const int32_t *rowptr, const int32_t *colidx, int64_t nnz,
+                      fd_stream_t s_, fd_matplan_t *out) {
     hipStream_t s = fd::st(s_);
     if (!rp || !cp) FD_FAIL("fd_matplan_create: null plan");
-    if (rp->start != cp->start || rp->end != cp->end || rp->epb != cp->epb)
+    if (rp->start != cp->start || rp->end != cp->end || rp->nblocks != cp->nblocks)
         FD_FAIL("fd_matplan_create: row and column plans must cover the same blocks");
     auto *m = new fd_matplan_s;
     m->nblocks = rp->nblocks;
@@ -358,7 +440,11 @@ int fd_matplan_create(fd_plan_t rp, fd_plan_t cp, const int32_t *rowptr, const i
     uint64_t *k1 = nullptr, *k2 = nullptr;
     FD_HIP(hipMalloc(&k1, (size_t)nkeys * 8));
     FD_HIP(hipMalloc(&k2, (size_t)nkeys * 8));
-    hipLaunchKernelGGL(mp_emit_keys, dim3(mp_grid(nkeys)), dim3(256), 0, s, rp->lmap, cp->lmap, ar, ac, nent, rp->epb, k1);
+    int32_t *eb = nullptr;
+    FD_HIP(hipMalloc(&eb, (size_t)nent * 4));
+    hipLaunchKernelGGL(mp_ent_block, dim3(m->nblocks), dim3(256), 0, s, rp->bstart, rp->start, eb);
+    FD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(mp_emit_keys, dim3(mp_grid(nkeys)), dim3(256), 0, s, rp->lmap, cp->lmap, ar, ac, nent, eb, k1);
     FD_CHECK_LAUNCH();
     int bbits = 1; while ((1ll << bbits) < m->nblocks) ++bbits;
     size_t tb = 0;
@@ -400,14 +486,51 @@ int fd_matplan_create(fd_plan_t rp, fd_plan_t cp, const int32_t *rowptr, const i
     FD_HIP(hipMalloc(&m->kidx, (size_t)nkeys * m->kbytes));
     if (m->kbytes == 1)
         hipLaunchKernelGGL(mp_kidx<uint8_t>, dim3(mp_grid(nkeys)), dim3(256), 0, s, uniq, m->mb_off, rp->blkoff, m->lrp, rp->lmap,
-                           cp->lmap, ar, ac, nent, rp->epb, (uint8_t *)m->kidx);
+                           cp->lmap, ar, ac, nent, eb, (uint8_t *)m->kidx);
     else
         hipLaunchKernelGGL(mp_kidx<uint16_t>, dim3(mp_grid(nkeys)), dim3(256), 0, s, uniq, m->mb_off, rp->blkoff, m->lrp, rp->lmap,
-                           cp->lmap, ar, ac, nent, rp->epb, (uint16_t *)m->kidx);
+                           cp->lmap, ar, ac, nent, eb, (uint16_t *)m->kidx);
     FD_CHECK_LAUNCH();
     FD_HIP(hipStreamSynchronize(s));
-    FD_HIP(hipFree(k1)); FD_HIP(hipFree(k2)); FD_HIP(hipFree(tmp)); FD_HIP(hipFree(nsel)); FD_HIP(hipFree(stats));
+    FD_HIP(hipFree(k1)); FD_HIP(hipFree(k2)); FD_HIP(hipFree(stats)); FD_HIP(hipFree(eb));
+    // exclusivity: a CSR position touched by exactly one block can be written without an atomic; everything
+    // else (shared between blocks, or not touched by this loop at all) is listed for the fused zeroing pass
+    if (nnz > 0) {
+        int32_t *cnt = nullptr;
+        uint8_t *flags = nullptr;
+        FD_HIP(hipMalloc(&cnt, (size_t)nnz * 4));
+        FD_HIP(hipMemsetAsync(cnt, 0, (size_t)nnz * 4, s));
+        FD_HIP(hipMalloc(&flags, (size_t)nnz));
+        hipLaunchKernelGGL(mp_count, dim3(mp_grid(nu)), dim3(256), 0, s, m->gpos, nu, cnt);
+        FD_CHECK_LAUNCH();
+        hipLaunchKernelGGL(mp_encode, dim3(mp_grid(nu)), dim3(256), 0, s, m->gpos, nu, cnt);
+        FD_CHECK_LAUNCH();
+        hipLaunchKernelGGL(mp_flags, dim3(mp_grid(nnz)), dim3(256), 0, s, cnt, nnz, flags);
+        FD_CHECK_LAUNCH();
+        FD_HIP(hipMalloc(&m->zero_list, (size_t)nnz * 4));
+        size_t tb3 = 0;
+        hipcub::CountingInputIterator<int32_t> it(0);
+        FD_HIP(hipcub::DeviceSelect::Flagged(nullptr, tb3, it, flags, m->zero_list, nsel, nnz, s));
+        FD_HIP(hipFree(tmp));
+        FD_HIP(hipMalloc(&tmp, tb3 ? tb3 : 8));
+        FD_HIP(hipcub::DeviceSelect::Flagged(tmp, tb3, it, flags, m->zero_list, nsel, nnz, s));
+        int64_t nz = 0;
+        FD_HIP(hipMemcpyAsync(&nz, nsel, 8, hipMemcpyDeviceToHost, s));
+        FD_HIP(hipStreamSynchronize(s));
+        m->n_zero = nz;
+        m->n_exclusive = nnz - nz;
+        FD_HIP(hipFree(cnt)); FD_HIP(hipFree(flags));
+    }
+    FD_HIP(hipFree(tmp)); FD_HIP(hipFree(nsel));
     *out = m;
+    return 0;
+}
+
+int fd_matplan_zero_list(fd_matplan_t m, const int32_t **zero_list, int64_t *n_zero, int64_t *n_exclusive) {
+    if (!m) FD_FAIL("fd_matplan_zero_list: null plan");
+    if (zero_list) *zero_list = m->zero_list;
+    if (n_zero) *n_zero = m->n_zero;
+    if (n_exclusive) *n_exclusive = m->n_exclusive;
     return 0;
 }
 
@@ -435,6 +558,7 @@ int fd_matplan_free(fd_matplan_t m) {
     if (m->gpos) FD_HIP(hipFree(m->gpos));
     if (m->lrp) FD_HIP(hipFree(m->lrp));
     if (m->kidx) FD_HIP(hipFree(m->kidx));
+    if (m->zero_list) FD_HIP(hipFree(m->zero_list));
     delete m;
     return 0;
 }

@@ -81,16 +81,19 @@ def _tile_keys(ix, iy, iz, nx, ny, nz, tile):
     return t * (tx * ty * tz) + loc
 
 
-def _epb_for_tile(cells_per_tile, arity):
-    """Entities per plan block: a whole traversal tile (or a power-of-two fraction of one) so that plan
-    blocks coincide with the spatially compact tiles; at most 16384 map entries per block."""
-    epb = cells_per_tile
-    while epb * arity > 16384 and epb % 2 == 0:
-        epb //= 2
-    return epb
+def _split_blocks(blocks, arity, max_entries=16384):
+    """Halve tiles whose map rows exceed the plan builder's per-block capacity."""
+    blocks = np.asarray(blocks, dtype=np.int64)
+    while True:
+        d = np.diff(blocks)
+        big = np.nonzero(d * arity > max_entries)[0]
+        if len(big) == 0:
+            return blocks.astype(np.int32)
+        mids = blocks[big] + d[big] // 2
+        blocks = np.sort(np.concatenate([blocks, mids]))
 
 
-def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0, ghost_cells=True):
+def UnitCubeMesh(n, degrees=(1,), tile=(8, 4, 4), rank=0, nranks=1, perturb=0.0, ghost_cells=True):
     """Kuhn-split tetrahedral unit cube, z-slab partitioned.  ``tile`` = cubes per traversal tile."""
     nx, ny, nz = (int(n),) * 3 if np.isscalar(n) else tuple(int(v) for v in n)
     # ---- cube slab owned by this rank (+ one ghost cube layer each side)
@@ -112,6 +115,10 @@ def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0,
     ncube = len(ii)
     sizes_c = tuple(int(6 * (ccls <= c).sum()) for c in (0, 1, 2))
     cell_set = op2.Set(sizes_c, "cells")
+    # traversal tiles = natural plan blocks: boundaries (in cells) where the tile (or the class) changes
+    tkey = key[order] // (tile[0] * tile[1] * tile[2])
+    cuts = np.nonzero(np.diff(tkey))[0] + 1
+    cell_blocks = (6 * np.concatenate([[0], cuts, [ncube]])).astype(np.int32)
 
     def lattice_space(p):
         """CG_p nodes live on the lattice of spacing 1/(p*n); CG2 edge nodes are vertex sums."""
@@ -180,7 +187,7 @@ def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0,
                     halo.recv[rank - 1] = np.concatenate([plane_nodes(z) for z in range(zlo, p * k0)])
         node_set = op2.Set(sizes_n, f"cg{p}_nodes")
         m = op2.Map(cell_set, node_set, arity, cmap, f"cell_cg{p}")
-        m.preferred_epb = _epb_for_tile(6 * tile[0] * tile[1] * tile[2], arity)
+        m.preferred_blocks = _split_blocks(cell_blocks, arity)
         return FunctionSpaceData(p, node_set, m, pts, halo, bnd, (p * nx + 1) * (p * ny + 1) * (p * nz + 1))
 
     spaces = {}
@@ -211,6 +218,9 @@ def UnitSquareMesh(nx, ny, degrees=(1,), tile=(16, 16), perturb=0.0):
     ii, jj = ii[order], jj[order]
     nsq = len(ii)
     cell_set = op2.Set(2 * nsq, "cells")
+    tkey = key[order] // (tile[0] * tile[1])
+    cuts = np.nonzero(np.diff(tkey))[0] + 1
+    cell_blocks = (2 * np.concatenate([[0], cuts, [nsq]])).astype(np.int32)
     # corners a=(i,j) b=(i+1,j) c=(i,j+1) d=(i+1,j+1); "left" diagonal joins b-c
     tri = np.array([[(0, 0), (1, 0), (0, 1)], [(1, 0), (1, 1), (0, 1)]], dtype=np.int32)   # (2, 3, 2)
     vx = ii[:, None, None] + tri[None, :, :, 0]
@@ -237,7 +247,7 @@ def UnitSquareMesh(nx, ny, degrees=(1,), tile=(16, 16), perturb=0.0):
         bnd = np.nonzero((xx[norder] == 0) | (xx[norder] == p * nx) | (yy[norder] == 0) | (yy[norder] == p * ny))[0].astype(np.int32)
         node_set = op2.Set(len(norder), f"cg{p}_nodes")
         m = op2.Map(cell_set, node_set, arity, newnum[box], f"cell_cg{p}")
-        m.preferred_epb = _epb_for_tile(2 * tile[0] * tile[1], arity)
+        m.preferred_blocks = _split_blocks(cell_blocks, arity)
         return FunctionSpaceData(p, node_set, m, pts, HaloLists(), bnd, Lx * Ly)
 
     spaces = {p: lattice_space(p) for p in sorted(set(degrees) | {1})}

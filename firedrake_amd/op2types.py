@@ -602,12 +602,13 @@ class Map:
             self._dev = DeviceBuffer.from_numpy(self._values)
         return self._dev.ptr
 
-    def plan(self, start, end, epb):
-        """Cached block-localisation plan for [start, end) (include/fdhip.h: fd_plan_create)."""
-        key = (int(start), int(end), int(epb))
+    def plan(self, start, end, epb, blocks=None):
+        """Cached block-localisation plan for [start, end) (include/fdhip.h: fd_plan_create[_blocks]).
+        ``blocks``: optional int32 array of block boundaries (entity offsets, first = start, last = end)."""
+        key = (int(start), int(end), int(epb) if blocks is None else ("blocks", len(blocks), int(np.asarray(blocks).sum() % 2147483647)))
         p = self._plans.get(key)
         if p is None:
-            p = Plan(self, *key)
+            p = Plan(self, int(start), int(end), int(epb), blocks)
             self._plans[key] = p
         return p
 
@@ -634,10 +635,18 @@ class PermutedMap(Map):
 class Plan:
     """Python handle on an fd_plan_t."""
 
-    def __init__(self, map_: Map, start, end, epb):
+    def __init__(self, map_: Map, start, end, epb, blocks=None):
         h = ctypes.c_void_p()
-        _lib.call("fd_plan_create", map_._dev_values(), map_.arity, start, end, epb, None, ctypes.byref(h))
+        if blocks is None:
+            _lib.call("fd_plan_create", map_._dev_values(), map_.arity, start, end, epb, None, ctypes.byref(h))
+        else:
+            bl = np.ascontiguousarray(blocks, dtype=np.int32)
+            assert bl[0] == start and bl[-1] == end
+            _lib.call("fd_plan_create_blocks", map_._dev_values(), map_.arity, bl.ctypes.data, len(bl) - 1, None, ctypes.byref(h))
         self.h = h.value
+        bs, me = ctypes.c_void_p(), ctypes.c_int32()
+        _lib.call("fd_plan_block_starts", self.h, ctypes.byref(bs), ctypes.byref(me))
+        self.bstart, epb = bs.value, me.value
         nb, mx, ll = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
         _lib.call("fd_plan_info", self.h, ctypes.byref(nb), ctypes.byref(mx), ctypes.byref(ll))
         self.nblocks, self.max_nd, self.list_len = nb.value, mx.value, ll.value
@@ -808,8 +817,8 @@ class MatPlan:
 
     def __init__(self, sparsity, rowplan, colplan):
         h = ctypes.c_void_p()
-        _lib.call("fd_matplan_create", rowplan.h, colplan.h, sparsity._node_rowptr.ptr, sparsity._node_colidx.ptr, None,
-                  ctypes.byref(h))
+        _lib.call("fd_matplan_create", rowplan.h, colplan.h, sparsity._node_rowptr.ptr, sparsity._node_colidx.ptr,
+                  sparsity._node_nnz, None, ctypes.byref(h))
         self.h = h.value
         a, b, c, t = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
         _lib.call("fd_matplan_info", self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(t))
@@ -817,6 +826,9 @@ class MatPlan:
         p = [ctypes.c_void_p() for _ in range(4)]
         _lib.call("fd_matplan_arrays", self.h, *[ctypes.byref(x) for x in p])
         self.mb_off, self.gpos, self.lrp, self.kidx = (x.value for x in p)
+        z, nz, nx = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64()
+        _lib.call("fd_matplan_zero_list", self.h, ctypes.byref(z), ctypes.byref(nz), ctypes.byref(nx))
+        self.zero_list, self.n_zero, self.n_exclusive = z.value, nz.value, nx.value
         self._plans = (rowplan, colplan)      # keep alive
 
     def __del__(self):
@@ -839,6 +851,7 @@ class Mat:
             raise DataTypeError("only float64 matrices are supported (ScalarType)")
         self.name = name or f"mat_{id(self):x}"
         self._vals = None
+        self._zero_pending = False
         self.dat_version = 0
 
     sparsity = property(lambda self: self._sparsity)
@@ -865,6 +878,15 @@ class Mat:
         return self._sparsity.dsets[1].set.size
 
     def _values_dev(self):
+        """Device values; performs a pending zero() first (anything but a fused staged assembly sees
+        the zeroed matrix)."""
+        v = self._values_raw()
+        if self._zero_pending:
+            v.zero()
+            self._zero_pending = False
+        return v
+
+    def _values_raw(self):
         if self._vals is None:
             self._sparsity._build()
             self._vals = DeviceBuffer(max(self._sparsity._nnz, 1) * 8)
@@ -872,7 +894,11 @@ class Mat:
         return self._vals
 
     def zero(self):                 # mat.py:851-855
-        self._values_dev().zero()
+        """Zero the matrix.  The memset is deferred: a staged assembly that follows overwrites the entries
+        each block owns exclusively and clears only the shared/untouched ones (fd_matplan_zero_list), which
+        fuses the zeroing pass into the assembly kernel.  Any other access flushes it."""
+        self._values_raw()
+        self._zero_pending = True
         self.dat_version += 1
 
     def assemble(self):             # mat.py:940-954: nothing is stashed off-process here

@@ -200,15 +200,10 @@ class Parloop:
         src = prep["cw"].src
         maps = prep["maps"]
         maxar = max(maps[mi].arity for mi in src.staged_maps)
-        epb = configuration["ents_per_block"]
-        for pa in self.arguments:                      # a Map may carry a preferred block size (mesh tiles)
-            for m in getattr(pa, "maps", ()):
-                epb = getattr(m._base(), "preferred_epb", None) or epb
-        while epb * maxar > 16384:
-            epb //= 2
         limit = configuration["lds_limit"]
-        while True:
-            plans = {mi: maps[mi].plan(start, end, epb) for mi in src.staged_maps}
+
+        def build(epb, blocks):
+            plans = {mi: maps[mi].plan(start, end, epb, blocks) for mi in src.staged_maps}
             mplans = {}
             lds = 0
             for item in src.lds_items:
@@ -223,14 +218,47 @@ class Parloop:
                     lds += (mp.max_nnz * 8 + 15) // 16 * 16 + ((plans[rm].max_nd + 1) * 4 + 15) // 16 * 16
                     if lg:
                         lds += (plans[rm].max_nd + 15) // 16 * 16 + (plans[cm].max_nd + 15) // 16 * 16
-            if lds <= limit or epb <= 32:
-                break
-            epb = max(32, epb // 2)
+            return plans, mplans, lds
+
+        # 1. block boundaries suggested by the data producer (mesh traversal tiles), if they fit
+        blocks = None
+        cand = [getattr(maps[mi], "preferred_blocks", None) for mi in src.staged_maps]
+        if configuration["use_preferred_blocks"] and all(c is not None for c in cand) and all(c is cand[0] or np.array_equal(c, cand[0]) for c in cand):
+            pb = np.asarray(cand[0])
+            i0, i1 = np.searchsorted(pb, start), np.searchsorted(pb, end)
+            if i0 < len(pb) and i1 < len(pb) and pb[i0] == start and pb[i1] == end and i1 > i0:
+                bl = pb[i0:i1 + 1].astype(np.int32)
+                if int(np.diff(bl).max()) * maxar <= 16384:
+                    blocks = bl
+        plans = None
+        if blocks is not None:
+            plans, mplans, lds = build(0, blocks)
+            epb = int(np.diff(blocks).max())
+            if lds > limit:
+                plans = None
+        if plans is None:
+            # 2. uniform blocks, halved until the staged rows fit the LDS budget
+            epb = configuration["ents_per_block"]
+            while epb * maxar > 16384:
+                epb //= 2
+            while True:
+                plans, mplans, lds = build(epb, None)
+                if lds <= limit or epb <= 32:
+                    break
+                epb = max(32, epb // 2)
         if lds > 160 * 1024:
             raise _lib.FDHipError("staged wrapper does not fit LDS even at 32 entities per block")
         if any(mp.kbytes == 2 for mp in mplans.values()) and src.kbytes == 1:
             prep["cw"] = self.global_kernel.compile("staged_k16")
         geo = {"epb": epb, "plans": plans, "mplans": mplans, "lds": lds}
+        if configuration["debug"]:
+            import sys
+            for mi, pl in plans.items():
+                print(f"[fdhip] {self.global_kernel.name} [{start},{end}) epb={epb} map{mi}: blocks={pl.nblocks} "
+                      f"max_nd={pl.max_nd} list_len={pl.list_len} lds={lds}", file=sys.stderr)
+            for k, mp in mplans.items():
+                print(f"[fdhip]   matplan arg{k}: block-nz total={mp.total} max_nnz={mp.max_nnz} max_rowlen={mp.max_rowlen} "
+                      f"kbytes={mp.kbytes} exclusive={mp.n_exclusive} zero_list={mp.n_zero}", file=sys.stderr)
         prep["parts"][key] = geo
         return geo
 
@@ -241,6 +269,7 @@ class Parloop:
         geo = self._staged_geometry(start, end) if src.mode.startswith("staged") else None
         src = prep["cw"].src
         out = []
+        fused_flags = {}
         for desc in src.layout:
             kind = desc[0]
             if kind == "layers":
@@ -252,13 +281,25 @@ class Parloop:
                 acc = self.accesses[desc[1]]
                 if isinstance(pa, MatParloopArg):
                     pa.data.dat_version += 1
-                    out.append(pa.data._values_dev().ptr)
+                    k = desc[1]
+                    fused = (geo is not None and k in geo["mplans"] and pa.data._zero_pending and configuration["mat_exclusive"]
+                             and pa.data.sparsity.dsets[0].cdim * pa.data.sparsity.dsets[1].cdim == 1)
+                    if fused:
+                        # consume the pending Mat.zero(): clear only what no block overwrites
+                        mp = geo["mplans"][k]
+                        vals = pa.data._values_raw()
+                        _lib.call("fd_csr_zero_entries", vals.ptr, mp.zero_list, mp.n_zero, None)
+                        pa.data._zero_pending = False
+                        fused_flags[k] = 1
+                        out.append(vals.ptr)
+                    else:
+                        out.append(pa.data._values_dev().ptr)
                 else:
                     out.append(pa.data._dev_ptr(write=acc != READ))
             elif kind == "map":
                 out.append(prep["maps"][desc[1]]._dev_values())
-            elif kind == "epb":
-                out.append(geo["epb"] if geo else 0)
+            elif kind == "bstart":
+                out.append(next(iter(geo["plans"].values())).bstart if geo else 0)
             elif kind == "plan_blkoff":
                 out.append(geo["plans"][desc[1]].blkoff)
             elif kind == "plan_list":
@@ -277,6 +318,8 @@ class Parloop:
                 out.append(geo["mplans"][desc[1]].kidx)
             elif kind == "matplan_maxnnz":
                 out.append(geo["mplans"][desc[1]].max_nnz)
+            elif kind == "matplan_flags":
+                out.append(fused_flags.get(desc[1], 0))
             elif kind == "mat_table":
                 pa = self.arguments[desc[1]]
                 out.append(pa.data.sparsity.elem_table(*pa.maps).ptr)
@@ -334,7 +377,8 @@ class Parloop:
         src = cw.src
         threads = src.block_threads
         if src.mode.startswith("staged"):
-            cw.launch(start, end, args, block_threads=threads, ents_per_block=geo["epb"], lds_bytes=geo["lds"])
+            nb = next(iter(geo["plans"].values())).nblocks
+            cw.launch(start, end, args, block_threads=threads, ents_per_block=geo["epb"], nblocks=nb, lds_bytes=geo["lds"])
         else:
             total = size
             if self.iterset._extruded and src.layer_parallel:

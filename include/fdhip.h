@@ -104,6 +104,11 @@ int fd_kernel_launch(fd_kernel_t k, int32_t start, int32_t end,
  */
 int fd_plan_create(const int32_t *map_dev, int arity, int32_t start, int32_t end,
                    int ents_per_block, fd_stream_t s, fd_plan_t *out);
+/* Same, with caller-chosen block boundaries (host array of nblocks+1 entity offsets, e.g. the mesh
+ * generator's traversal tiles): block b covers [block_starts[b], block_starts[b+1]). */
+int fd_plan_create_blocks(const int32_t *map_dev, int arity, const int32_t *block_starts_host,
+                          int32_t nblocks, fd_stream_t s, fd_plan_t *out);
+int fd_plan_block_starts(fd_plan_t p, const int32_t **block_starts_dev, int32_t *max_ents_per_block);
 int fd_plan_info(fd_plan_t p, int32_t *nblocks, int32_t *max_nodes_per_block, int64_t *list_len);
 int fd_plan_arrays(fd_plan_t p, const int32_t **block_offsets, const int32_t **node_list,
                    const uint16_t **local_map);
@@ -118,7 +123,12 @@ int fd_plan_free(fd_plan_t p);
  *   kidx               per (entity,i,j): offset inside its local row (uint8 if kbytes==1 else uint16) */
 typedef struct fd_matplan_s *fd_matplan_t;
 int fd_matplan_create(fd_plan_t row_plan, fd_plan_t col_plan, const int32_t *node_rowptr_dev,
-                      const int32_t *node_colidx_dev, fd_stream_t s, fd_matplan_t *out);
+                      const int32_t *node_colidx_dev, int64_t nnz, fd_stream_t s, fd_matplan_t *out);
+/* gpos entries that exactly one block touches are stored as ~pos (negative): the wrapper writes them
+ * without an atomic.  zero_list = all other CSR positions (shared between blocks, or never touched by
+ * this loop): with a pending Mat.zero() (mat.py:851-855) only those need clearing before the loop --
+ * exclusive entries are overwritten -- which fuses the zeroing pass into assembly. */
+int fd_matplan_zero_list(fd_matplan_t m, const int32_t **zero_list, int64_t *n_zero, int64_t *n_exclusive);
 int fd_matplan_info(fd_matplan_t m, int32_t *max_nnz_per_block, int32_t *max_row_len, int32_t *kbytes,
                     int64_t *total);
 int fd_matplan_arrays(fd_matplan_t m, const int32_t **mb_off, const int32_t **gpos, const int32_t **lrp,
@@ -153,6 +163,8 @@ int fd_csr_set_diagonal(const int32_t *rowptr_dev, const int32_t *colidx_dev, do
                         const int32_t *rows_dev, int32_t nrows_sel, double value, fd_stream_t s);
 int fd_csr_zero_rows(const int32_t *rowptr_dev, const int32_t *colidx_dev, double *vals_dev,
                      const int32_t *rows_dev, int32_t nrows_sel, double value, fd_stream_t s);
+/* vals[idx[k]] = 0 for k < n (the fused zeroing pass of the staged matrix scatter) */
+int fd_csr_zero_entries(double *vals_dev, const int32_t *idx_dev, int64_t n, fd_stream_t s);
 /* y = A x  (parity identity  A*x == action(a, x), tests/firedrake/regression/test_matrix_free.py:97-123) */
 int fd_csr_spmv(int32_t nrows, const int32_t *rowptr_dev, const int32_t *colidx_dev,
                 const double *vals_dev, const double *x_dev, double *y_dev, fd_stream_t s);

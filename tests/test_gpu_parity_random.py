@@ -39,6 +39,23 @@ def test_plan_matches_numpy(arity, epb, n):
         assert p.max_nd == np.diff(rblk).max() and p.nblocks == len(rblk) - 1
 
 
+def test_plan_with_explicit_blocks():
+    rng = np.random.default_rng(5)
+    n, arity = 3000, 4
+    it, to = op2.Set(n), op2.Set(900)
+    m = op2.Map(it, to, arity, ((np.arange(n)[:, None] * 900 // n + rng.integers(0, 30, size=(n, arity))) % 900).astype(np.int32))
+    cuts = np.sort(rng.choice(np.arange(1, n), size=17, replace=False))
+    blocks = np.concatenate([[0], cuts, [n]]).astype(np.int32)
+    p = m.plan(0, n, 0, blocks)
+    blk, lst, lm = p.download()
+    off = 0
+    for b in range(len(blocks) - 1):
+        u, inv = np.unique(m.values[blocks[b]:blocks[b + 1]].reshape(-1), return_inverse=True)
+        assert np.array_equal(lst[blk[b]:blk[b + 1]], u)
+        assert np.array_equal(lm[blocks[b]:blocks[b + 1]].reshape(-1), inv)
+    assert p.nblocks == len(blocks) - 1
+
+
 @pytest.mark.parametrize("nx,ny", [(7, 5), (64, 64), (200, 150)])
 @pytest.mark.parametrize("shuffle", [False, True])
 def test_p1_mass_and_rhs_all_paths(nx, ny, shuffle, monkeypatch):

@@ -1,0 +1,12 @@
+#!/bin/bash
+# tools/pmc.sh <tag> <bench args...> -- rocprofv3 PMC passes (own runs, no tracing domains) + kernel trace.
+# Results land in gpurun_out/<tag>_*.  HBM bytes follow MI355X_MICROARCH.md: FETCH_SIZE/WRITE_SIZE in separate passes.
+TAG=$1; shift
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_trace -o t -- python $R/bench.py "$@" > $R/gpurun_out/${TAG}_trace.log 2>&1
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAVES SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_ATOMIC_sum TCC_ATOMIC_sum"; do
+  name=$(echo $set | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/${TAG}_pmc_$name -o p -- python $R/bench.py "$@" > $R/gpurun_out/${TAG}_pmc_$name.log 2>&1
+done
+cd $R
