@@ -18,6 +18,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL across processes)
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -94,7 +96,6 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from firedrake_amd import _lib, forms, mesh as fmesh
     from firedrake_amd.device import Event
@@ -123,6 +124,8 @@ def main():
         if k is not None:
             ev[k][0].record()
         if args.only != "jacobian":
+            if world > 1:
+                prob.u.halo_valid = False      # a Newton step changes u: its ghost copies are refreshed every step
             prob.assemble_residual()
         if k is not None:
             ev[k][1].record()

@@ -361,12 +361,20 @@ class PoissonProblem:
             sp = op2.Sparsity((V.node_set ** 1, V.node_set ** 1), [(cm, cm, None)])
             mat = op2.Mat(sp)
             lg = None
-            if len(self.bc_nodes):
-                lgm = np.arange(V.node_set.total_size, dtype=np.int32)
-                lgm[self.bc_nodes] = -1                 # functionspaceimpl.py:913-926
-                lg = (lgm, lgm)
+            partitioned = V.node_set.total_size > V.node_set.size
+            if len(self.bc_nodes) or partitioned:
+                rlg = np.arange(V.node_set.total_size, dtype=np.int32)
+                clg = rlg.copy()
+                rlg[self.bc_nodes] = -1                 # functionspaceimpl.py:913-926
+                clg[self.bc_nodes] = -1
+                if partitioned:
+                    rlg[V.node_set.size:] = -1          # rows owned elsewhere are assembled by their owner
+                    gb = V.boundary_nodes[V.boundary_nodes >= V.node_set.size]
+                    clg[gb] = -1                        # BC columns on ghost nodes are dropped too
+                lg = (rlg, clg)
             loop = op2.LegacyParloop(self.kjac, self.mesh.cell_set, mat(op2.INC, (cm, cm), lgmaps=lg),
                                      self.mesh.coordinates(op2.READ, xm))
+            loop.compute_ghost = partitioned
             self._jac = (mat, loop)
         return self._jac
 

@@ -33,6 +33,14 @@ def _dist():
     return dist
 
 
+def world_size():
+    try:
+        dist = _dist()
+        return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    except ImportError:
+        return 1
+
+
 def attach_halo(space):
     """Give the node Set of ``space`` a Halo if the mesh is partitioned."""
     h = space.halo

@@ -99,8 +99,13 @@ def UnitCubeMesh(n, degrees=(1,), tile=(8, 4, 4), rank=0, nranks=1, perturb=0.0,
     # ---- cube slab owned by this rank (+ one ghost cube layer each side)
     k0 = (nz * rank) // nranks
     k1 = (nz * (rank + 1)) // nranks
+    # ghost cells: the cube layer BELOW the slab.  Its cells touch our lowest owned node plane; executing
+    # them redundantly lets every rank assemble complete matrix rows for the nodes it owns
+    # (owner-computes-rows, SURVEY.md 8e option 1) instead of shipping off-process rows the way
+    # MatAssemblyBegin/End does (pyop2/types/mat.py:940-954).  Nothing above the slab is needed: the
+    # top node plane is a ghost plane read by our own last cell layer.
     glo = k0 - 1 if (rank > 0 and ghost_cells) else k0
-    ghi = k1 + 1 if (rank < nranks - 1 and ghost_cells) else k1
+    ghi = k1
     kk, jj, ii = np.meshgrid(np.arange(glo, ghi, dtype=np.int32), np.arange(ny, dtype=np.int32),
                              np.arange(nx, dtype=np.int32), indexing="ij")
     ii, jj, kk = ii.ravel(), jj.ravel(), kk.ravel()
@@ -151,7 +156,7 @@ def UnitCubeMesh(n, degrees=(1,), tile=(8, 4, 4), rank=0, nranks=1, perturb=0.0,
         owned = (zz >= own_lo) & (zz < own_hi)
         ncls[owned] = 0
         if rank < nranks - 1:
-            ncls[owned & (zz > p * (k1 - 1))] = 1      # owned, but read by cells that also read ghosts
+            ncls[owned & (zz >= p * (k1 - 1))] = 1     # owned, but read by cells that also read ghosts
         tl = tuple(p * t for t in tile)
         nkey = _tile_keys(np.minimum(xx, p * nx - 1), np.minimum(yy, p * ny - 1), np.minimum(zz - zlo, p * (ghi - glo) - 1),
                           p * nx, p * ny, p * (ghi - glo), tl)
@@ -174,15 +179,14 @@ def UnitCubeMesh(n, degrees=(1,), tile=(8, 4, 4), rank=0, nranks=1, perturb=0.0,
                 idx = np.nonzero(zs == zplane)[0]
                 return idx[np.argsort(lat[idx], kind="stable")].astype(np.int32)
             if rank < nranks - 1:
-                # planes [p*k1, zhi] are owned by rank+1: we receive them / send contributions back
-                halo.recv[rank + 1] = np.concatenate([plane_nodes(z) for z in range(p * k1, zhi + 1)])
-                # rank+1 holds our planes (p*(k1-1), p*k1) .. only if it has ghost cells below
+                # plane p*k1 is owned by rank+1: we receive it / send our contributions to it back
+                halo.recv[rank + 1] = plane_nodes(p * k1)
+                # rank+1 holds our planes [p*(k1-1), p*k1) as the nodes of its ghost cell layer
                 if ghost_cells:
                     halo.send[rank + 1] = np.concatenate([plane_nodes(z) for z in range(p * (k1 - 1), p * k1)])
             if rank > 0:
-                # rank-1 reads our plane p*k0 (top of its last owned layer) and, with ghost cells, up to p*(k0+1)
-                top = p * (k0 + 1) if ghost_cells else p * k0
-                halo.send[rank - 1] = np.concatenate([plane_nodes(z) for z in range(p * k0, top + 1)])
+                # rank-1 reads our plane p*k0 (top of its last owned cell layer)
+                halo.send[rank - 1] = plane_nodes(p * k0)
                 if ghost_cells:
                     halo.recv[rank - 1] = np.concatenate([plane_nodes(z) for z in range(zlo, p * k0)])
         node_set = op2.Set(sizes_n, f"cg{p}_nodes")

@@ -152,6 +152,10 @@ class Parloop:
         self._check_maps()
         self._prepared = None
         self._lgmap_dev = {}
+        # owner-computes-rows matrix assembly on a partitioned mesh: also execute the ghost entities
+        # [size, total_size) (their non-owned rows are masked by the lgmaps)
+        self.compute_ghost = False
+        self._glob_saved = {}
 
     local_kernel = property(lambda self: self.global_kernel.local_kernel)
     accesses = property(lambda self: self.local_kernel.accesses)
@@ -357,10 +361,13 @@ class Parloop:
         self.compute()
 
     def compute(self):
+        self._zero_global_temporaries()
         self.global_to_local_begin()
         self._compute(self.iterset.core_part)
         self.global_to_local_end()
         self._compute(self.iterset.owned_part)
+        if self.compute_ghost:
+            self._compute((self.iterset.size, self.iterset.total_size - self.iterset.size))
         self.reduction_begin()
         self.local_to_global_begin()
         self.reduction_end()
@@ -426,14 +433,28 @@ class Parloop:
                 if pa.data.dataset.set.halo is not None:
                     pa.data.halo_valid = False
 
+    def _zero_global_temporaries(self):
+        """pyop2/parloop.py:274-277, 516-532: with more than one rank an INC Global accumulates this loop's
+        contributions in a zeroed temporary; the all-reduced temporary is then added to the Global."""
+        from .halo import world_size
+        self._glob_saved = {}
+        if world_size() == 1:
+            return
+        for k, (pa, acc) in enumerate(zip(self.arguments, self.accesses)):
+            if isinstance(pa, GlobalParloopArg) and acc == INC:
+                self._glob_saved[k] = np.array(pa.data.data_ro, copy=True)
+                pa.data.data[...] = 0
+
     def reduction_begin(self):        # parloop.py:411-442 (MPI_Iallreduce of Globals)
         pass
 
     def reduction_end(self):
         from .halo import allreduce_global
-        for pa, acc in zip(self.arguments, self.accesses):
+        for k, (pa, acc) in enumerate(zip(self.arguments, self.accesses)):
             if isinstance(pa, GlobalParloopArg) and acc in (INC, MIN, MAX):
                 allreduce_global(pa.data, acc, self.iterset.comm)
+                if k in self._glob_saved:
+                    pa.data.data[...] += self._glob_saved[k]
 
     def finalize_assembly(self):
         pass
