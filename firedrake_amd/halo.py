@@ -119,6 +119,9 @@ class Halo:
         if dat.dtype != np.float64:
             raise TypeError("halo exchange is implemented for float64 Dats (ScalarType)")
         ops, recvs, keep = [], [], []
+        # device buffers go straight to RCCL; under a non-NCCL backend (gloo: debugging / the one-GPU
+        # two-rank test) the packed buffers are bounced through the host
+        via_host = (not self.host_mode) and dist.get_backend() != "nccl"
         if not self.host_mode:
             torch.cuda.synchronize()     # wrapper kernels run on the null stream; make their writes visible
         for r in self._neighbours():
@@ -126,10 +129,12 @@ class Halo:
             rl = (self.lists.send if recv_kind == "send" else self.lists.recv).get(r)
             if sl is not None and len(sl):
                 sbuf = self._pack(dat, self._idx(send_kind, r), cdim)
+                if via_host:
+                    sbuf = sbuf.cpu()
                 keep.append(sbuf)
                 ops.append(dist.P2POp(dist.isend, sbuf, r))
             if rl is not None and len(rl):
-                rbuf = torch.empty((len(rl), cdim), dtype=torch.float64, device="cpu" if self.host_mode else "cuda")
+                rbuf = torch.empty((len(rl), cdim), dtype=torch.float64, device="cpu" if (self.host_mode or via_host) else "cuda")
                 recvs.append((r, rbuf))
                 ops.append(dist.P2POp(dist.irecv, rbuf, r))
         reqs = dist.batch_isend_irecv(ops) if ops else []
@@ -140,6 +145,8 @@ class Halo:
         for q in reqs:
             q.wait()
         for r, rbuf in recvs:
+            if not self.host_mode and rbuf.device.type == "cpu":
+                rbuf = rbuf.cuda()
             self._unpack(dat, self._idx(recv_kind, r), dat.cdim, rbuf, op)
         if not self.host_mode:
             import torch

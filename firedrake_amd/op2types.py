@@ -727,7 +727,10 @@ class Sparsity:
         for k, (r, c, regions) in enumerate(self._rcmaps):
             rm[k], cm[k] = r._base()._dev_values(), c._base()._dev_values()
             it = r.iterset
-            nent[k] = it.size if not isinstance(it, Subset) else it.superset.size
+            # The reference walks the owned entities only (sparsity.pyx: set_size = iterset.size) and lets
+            # PETSc stash off-process rows; with owner-computes-rows the ghost entities contribute to owned
+            # rows too, so the pattern is built over owned + ghost entities.
+            nent[k] = it.total_size if not isinstance(it, Subset) else it.superset.total_size
             ra[k], ca[k] = r.arity, c.arity
             if it._extruded:
                 if tuple(regions) != (ALL,):

@@ -35,5 +35,27 @@ def test_partitioned_assembly_protocol(world, n):
             raise
         outs.append(out)
     for r, (p, out) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0, f"rank {r} failed:\n{out[-3000:]}"
+        assert p.returncode == 0, f"rank {r} failed:\n" + "\n=====\n".join(o[-2500:] for o in outs)
+        assert f"rank {r}/{world} ok" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,degree", [(2, 6, 1), (3, 6, 2)])
+def test_partitioned_assembly_on_one_gpu(world, n, degree):
+    """Production device path (HIP wrappers, device pack/unpack, owner-computes-rows) with W ranks sharing
+    cuda:0; only the wire (gloo instead of RCCL) differs from the multi-GPU run."""
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_worker_gpu.py"), str(r), str(world), str(port), str(n), str(degree)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n" + "\n=====\n".join(o[-2500:] for o in outs)
         assert f"rank {r}/{world} ok" in out
