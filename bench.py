@@ -75,6 +75,45 @@ def cpu_baseline(n_sample, degree, seconds_hint=20.0):
             "residual_dofs_per_s": nn / tr, "jacobian_dofs_per_s": nn / tj, "sparsity_build_s": t_sparsity}
 
 
+FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD datasheet; tools/microbench.hip measures 77.7 TFLOP/s with v_mfma_f64_16x16x4_f64
+
+
+def run_c3(args):
+    """BASELINE.json configs[2]: Helmholtz Q4 on an extruded hex mesh, stiffness+mass matrix by fp64 MFMA."""
+    from firedrake_amd import _lib, forms, mesh as fmesh
+    from firedrake_amd.device import Event
+    _lib.require_gpu()
+    n = args.n if args.n != 215 else 32
+    m = fmesh.make_extruded_hex_mesh(n, n, 4, perturb=0.1)
+    prob = forms.HelmholtzQ4Problem(m)
+    for _ in range(args.warmup):
+        prob.assemble_jacobian()
+    _lib.call("fd_device_sync")
+    ev = [(Event(), Event()) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        prob.assemble_jacobian()
+        ev[k][1].record()
+    _lib.call("fd_device_sync")
+    elapsed = time.perf_counter() - t0
+    ms = float(np.median([a.elapsed_ms(b) for a, b in ev]))
+    ncell = m.ncells
+    ndofs = m.node_set.size
+    flops = prob.ALGO_FLOPS_PER_CELL * ncell
+    out = {"metric": "assembled DoFs/sec (Jacobian)", "value": ndofs / (elapsed / args.steps), "unit": "DoFs/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"Helmholtz Q4 stiffness+mass on ExtrudedMesh(UnitSquareMesh({n},{n},quadrilateral), {n}) "
+                                  f"(BASELINE.json configs[2])", "cells": ncell, "dofs": ndofs, "nnz": int(prob.sparsity.nz)},
+           "roofline": {"kernel": "wrap_helmholtz_q4_hex_jacobian", "bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12,
+                        "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                        "traffic": None, "ms": ms, "algorithmic_flops": flops,
+                        "issued_mfma_flops": prob.FLOPS_PER_CELL * ncell},
+           "cpu_baseline": None}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,7 +125,11 @@ def main():
     ap.add_argument("--no-bcs", action="store_true")
     ap.add_argument("--tile", type=str, default="8,4,4", help="cubes per traversal tile (= plan block)")
     ap.add_argument("--only", choices=["both", "residual", "jacobian"], default="both", help="profiling aid: run one form only")
+    ap.add_argument("--workload", choices=["c2", "c3"], default="c2", help="c2 = headline config (default); c3 = Q4 hex MFMA")
     args = ap.parse_args()
+    if args.workload == "c3":
+        import torch  # noqa: F401
+        return run_c3(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -66,7 +66,8 @@ SIGNATURES = {
                                  POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_void_p]),
     "fd_csr_expand_blocks": (c_int, [c_int32, c_void_p, c_void_p, c_int, c_int, POINTER(c_void_p),
                                      POINTER(c_void_p), c_void_p]),
-    "fd_csr_elem_offsets": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int, c_int, c_void_p, c_void_p]),
+    "fd_csr_elem_offsets": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int, c_int, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_void_p]),
     "fd_csr_set_diagonal": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_double, c_void_p]),
     "fd_csr_zero_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_double, c_void_p]),
     "fd_csr_spmv": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -84,13 +84,17 @@ __device__ inline int csr_find(const int32_t *__restrict__ rowptr, const int32_t
 
 __global__ void elem_offsets(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                              const int32_t *__restrict__ rmap, const int32_t *__restrict__ cmap, int32_t nent,
-                             int ar, int ac, int32_t *__restrict__ out) {
-    const int64_t per = (int64_t)ar * ac, total = nent * per;
+                             int ar, int ac, int nl, const int32_t *__restrict__ roff, const int32_t *__restrict__ coff,
+                             int32_t *__restrict__ out) {
+    const int64_t per = (int64_t)ar * ac, L = nl > 0 ? nl : 1, total = (int64_t)nent * L * per;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        int64_t e = t / per;
-        int ij = (int)(t - e * per);
+        int64_t el = t / per;
+        int64_t e = el / L;
+        int l = (int)(el - e * L);
+        int ij = (int)(t - el * per);
         int i = ij / ac, j = ij - i * ac;
         int r = rmap[e * ar + i], c = cmap[e * ac + j];
+        if (nl > 0) { if (r >= 0) r += roff[i] * l; if (c >= 0) c += coff[j] * l; }
         out[t] = (r >= 0 && c >= 0) ? csr_find(rowptr, colidx, r, c) : -1;
     }
 }
@@ -231,11 +235,22 @@ int fd_csr_expand_blocks(int32_t nnode, const int32_t *nrp, const int32_t *nci, 
 }
 
 int fd_csr_elem_offsets(const int32_t *rowptr, const int32_t *colidx, const int32_t *rmap, const int32_t *cmap,
-                        int32_t nent, int ar, int ac, int32_t *out, fd_stream_t s) {
+                        int32_t nent, int ar, int ac, int nlayers, const int32_t *roff_host, const int32_t *coff_host,
+                        int32_t *out, fd_stream_t s_) {
     if (nent <= 0) return 0;
-    hipLaunchKernelGGL(elem_offsets, dim3(grid_for((int64_t)nent * ar * ac)), dim3(256), 0, fd::st(s), rowptr, colidx,
-                       rmap, cmap, nent, ar, ac, out);
+    hipStream_t s = fd::st(s_);
+    int32_t *roff = nullptr, *coff = nullptr;
+    if (nlayers > 0) {
+        if (!roff_host || !coff_host) FD_FAIL("fd_csr_elem_offsets: extruded tables need the map offsets");
+        FD_HIP(hipMalloc(&roff, ar * 4)); FD_HIP(hipMalloc(&coff, ac * 4));
+        FD_HIP(hipMemcpyAsync(roff, roff_host, ar * 4, hipMemcpyHostToDevice, s));
+        FD_HIP(hipMemcpyAsync(coff, coff_host, ac * 4, hipMemcpyHostToDevice, s));
+    }
+    int64_t total = (int64_t)nent * (nlayers > 0 ? nlayers : 1) * ar * ac;
+    hipLaunchKernelGGL(elem_offsets, dim3(grid_for(total)), dim3(256), 0, s, rowptr, colidx,
+                       rmap, cmap, nent, ar, ac, nlayers, roff, coff, out);
     FD_CHECK_LAUNCH();
+    if (nlayers > 0) { FD_HIP(hipStreamSynchronize(s)); FD_HIP(hipFree(roff)); FD_HIP(hipFree(coff)); }
     return 0;
 }
 

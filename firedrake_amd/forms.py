@@ -415,3 +415,123 @@ def precompile_all():
                     src = generate_wrapper(g, mode)
                     out.append(compile_hip(src.source, src.symbol))
     return out
+
+
+# ------------------------------------------------------------------------------------------
+# Config C3: Helmholtz on Q4 hexahedra (extruded) -- dense quadrature contraction, fp64 MFMA kernel
+# ------------------------------------------------------------------------------------------
+def q4_tables(degree=4, nq=5):
+    """1-D tables of CG_k on GLL nodes at Gauss-Legendre points: (L[q][i], DL[q][i], points, weights) on [0,1]."""
+    from numpy.polynomial import legendre as leg
+    k = degree
+    # GLL nodes: endpoints and roots of P'_k
+    cP = np.zeros(k + 1)
+    cP[k] = 1.0
+    nodes = np.concatenate([[-1.0], np.sort(leg.legroots(leg.legder(cP))), [1.0]])
+    nodes = 0.5 * (nodes + 1.0)
+    x, w = leg.leggauss(nq)
+    x, w = 0.5 * (x + 1.0), 0.5 * w
+    L = np.zeros((nq, k + 1))
+    DL = np.zeros((nq, k + 1))
+    for i in range(k + 1):
+        others = [nodes[m] for m in range(k + 1) if m != i]
+        denom = np.prod([nodes[i] - o for o in others])
+        for q in range(nq):
+            L[q, i] = np.prod([x[q] - o for o in others]) / denom
+            DL[q, i] = sum(np.prod([x[q] - o for mm, o in enumerate(others) if mm != m]) for m in range(k)) / denom
+    return L, DL, x, w
+
+
+def helmholtz_q4_hex_jacobian_kernel(name="helmholtz_q4_hex_jacobian"):
+    """a(u, v) = int grad(u).grad(v) + u v dx on a trilinear hexahedron with Q4 basis, 5x5x5 Gauss points
+    (dx(degree=8)).  Arguments: A[125*125], coords[8*3] (Q1 vertices, index a*4 + b*2 + c).
+    Dense formulation (what the MFMA kernel computes); used as the oracle's local kernel."""
+    L, DL, qp, qw = q4_tables()
+    body = f"""
+static void {name}(double *restrict A, const double *restrict x)
+{{
+  static const double L[5][5] = {_c(L)};
+  static const double DL[5][5] = {_c(DL)};
+  static const double QP[5] = {_c(qp)};
+  static const double QW[5] = {_c(qw)};
+  for (int q1 = 0; q1 < 5; ++q1) for (int q2 = 0; q2 < 5; ++q2) for (int q3 = 0; q3 < 5; ++q3) {{
+    const double t[3] = {{QP[q1], QP[q2], QP[q3]}};
+    double J[3][3] = {{{{0,0,0}},{{0,0,0}},{{0,0,0}}}};
+    for (int v = 0; v < 8; ++v) {{
+      const int a = v >> 2, b = (v >> 1) & 1, c = v & 1;
+      const double Na = a ? t[0] : 1.0 - t[0], Nb = b ? t[1] : 1.0 - t[1], Nc = c ? t[2] : 1.0 - t[2];
+      const double da = a ? 1.0 : -1.0, db = b ? 1.0 : -1.0, dc = c ? 1.0 : -1.0;
+      const double g[3] = {{da*Nb*Nc, Na*db*Nc, Na*Nb*dc}};
+      for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) J[r][s] += x[3*v + r] * g[s];
+    }}
+    const double c00 = J[1][1]*J[2][2] - J[1][2]*J[2][1], c01 = J[1][2]*J[2][0] - J[1][0]*J[2][2], c02 = J[1][0]*J[2][1] - J[1][1]*J[2][0];
+    const double det = J[0][0]*c00 + J[0][1]*c01 + J[0][2]*c02, id = 1.0 / det;
+    const double K[3][3] = {{
+      {{ c00*id, (J[0][2]*J[2][1] - J[0][1]*J[2][2])*id, (J[0][1]*J[1][2] - J[0][2]*J[1][1])*id }},
+      {{ c01*id, (J[0][0]*J[2][2] - J[0][2]*J[2][0])*id, (J[0][2]*J[1][0] - J[0][0]*J[1][2])*id }},
+      {{ c02*id, (J[0][1]*J[2][0] - J[0][0]*J[2][1])*id, (J[0][0]*J[1][1] - J[0][1]*J[1][0])*id }} }};
+    const double w = QW[q1]*QW[q2]*QW[q3]*fabs(det);
+    double G[3][3];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b)
+      G[a][b] = w * (K[a][0]*K[b][0] + K[a][1]*K[b][1] + K[a][2]*K[b][2]);
+    double ph[125], dp[125][3];
+    for (int i1 = 0; i1 < 5; ++i1) for (int i2 = 0; i2 < 5; ++i2) for (int i3 = 0; i3 < 5; ++i3) {{
+      const int i = (i1*5 + i2)*5 + i3;
+      ph[i] = L[q1][i1]*L[q2][i2]*L[q3][i3];
+      dp[i][0] = DL[q1][i1]*L[q2][i2]*L[q3][i3];
+      dp[i][1] = L[q1][i1]*DL[q2][i2]*L[q3][i3];
+      dp[i][2] = L[q1][i1]*L[q2][i2]*DL[q3][i3];
+    }}
+    for (int i = 0; i < 125; ++i) {{
+      const double t0 = G[0][0]*dp[i][0] + G[0][1]*dp[i][1] + G[0][2]*dp[i][2];
+      const double t1 = G[1][0]*dp[i][0] + G[1][1]*dp[i][1] + G[1][2]*dp[i][2];
+      const double t2 = G[2][0]*dp[i][0] + G[2][1]*dp[i][1] + G[2][2]*dp[i][2];
+      const double tm = w * ph[i];
+      for (int j = 0; j < 125; ++j)
+        A[i*125 + j] += t0*dp[j][0] + t1*dp[j][1] + t2*dp[j][2] + tm*ph[j];
+    }}
+  }}
+}}
+"""
+    return op2.Kernel(body, name)
+
+
+class HelmholtzQ4Problem:
+    """Config C3: assemble the Q4 Helmholtz operator on an extruded hex mesh with the fp64-MFMA kernel
+    ``wrap_helmholtz_q4_hex_jacobian`` (csrc/fd_builtin.hip), reached through fd_kernel_builtin /
+    fd_kernel_launch with the reference's extruded argument order (start, end, layers, mat, coords, maps)."""
+
+    FLOPS_PER_CELL = 2.0 * 128 * 128 * 4 * 125          # MFMA work issued (padded 128x128 tiles)
+    ALGO_FLOPS_PER_CELL = 2.0 * 125 * 125 * 125 * 4     # SURVEY.md 8(d): 15.6 MFLOP/cell
+
+    def __init__(self, hexmesh):
+        import ctypes
+        from . import _lib
+        from .device import DeviceBuffer
+        self.mesh = m = hexmesh
+        assert m.degree == 4
+        cm, xm = m.cell_node_map, m.coord_map
+        self.sparsity = op2.Sparsity((m.node_set ** 1, m.node_set ** 1), [(cm, cm, None)])
+        self.mat = op2.Mat(self.sparsity)
+        L, DL, qp, qw = q4_tables()
+        self.tables = DeviceBuffer.from_numpy(np.concatenate([L.ravel(), DL.ravel(), qp, qw]))
+        h = ctypes.c_void_p()
+        _lib.call("fd_kernel_builtin", b"wrap_helmholtz_q4_hex_jacobian", ctypes.byref(h))
+        self.kernel = h.value
+        self._elemtab = None
+
+    def assemble_jacobian(self):
+        import ctypes
+        from . import _lib
+        m = self.mesh
+        if self._elemtab is None:
+            self._elemtab = self.sparsity.elem_table(m.cell_node_map, m.cell_node_map, nlayers=m.layers)
+        self.mat.zero()
+        vals = self.mat._values_dev()
+        args = [m.cell_set._layers_dev(), vals.ptr, m.coordinates._dev_ptr(False), m.cell_node_map._dev_values(),
+                m.coord_map._dev_values(), self._elemtab.ptr, self.tables.ptr]
+        arr = (ctypes.c_void_p * len(args))(*[ctypes.c_void_p(a) for a in args])
+        ncol = m.base_set.size
+        _lib.call("fd_kernel_launch", self.kernel, 0, ncol, arr, len(args), 256, 1, ncol * m.layers, 0, None)
+        self.mat.dat_version += 1
+        return self.mat

@@ -263,3 +263,94 @@ def UnitSquareMesh(nx, ny, degrees=(1,), tile=(16, 16), perturb=0.0):
         xy[inner] += d[inner]
     coords = op2.Dat(cs.node_set ** 2, xy, np.float64, "coordinates")
     return Mesh(2, cell_set, coords, cs, spaces, 2 * nx * ny, (nx, ny))
+
+
+# ------------------------------------------------------------------------------------------
+# extruded hexahedra: ExtrudedMesh(UnitSquareMesh(n, n, quadrilateral=True), layers)  (config C3)
+# ------------------------------------------------------------------------------------------
+@dataclass
+class ExtrudedHexMesh:
+    """Column-structured hex mesh with Q_k = CG_k (x) CG_k (x) CG_k nodes (firedrake/mesh.py:3466,
+    extrusion_utils.py:342-367).  Maps hold the BOTTOM cell of each column; node = map + offset*layer
+    (pyop2/codegen/builder.py:94-124) with offset = k for every entry of Q_k and 1 for the Q1 coordinates.
+    Nodes of one vertical line are contiguous (firedrake numbers column DoFs consecutively, mesh.py:1932-1950).
+    Local DoF order inside a cell: (a, b, c) -> (a*(k+1) + b)*(k+1) + c, c along the extrusion direction."""
+    n: int
+    layers: int            # cell layers
+    degree: int
+    base_set: op2.Set
+    cell_set: op2.ExtrudedSet
+    node_set: op2.Set
+    cell_node_map: op2.Map
+    coord_node_set: op2.Set
+    coord_map: op2.Map
+    coordinates: op2.Dat
+    node_points: np.ndarray
+
+    @property
+    def ncells(self):
+        return self.base_set.size * self.layers
+
+
+def _gll_nodes(k):
+    """Gauss-Lobatto-Legendre points on [0, 1] (k+1 of them): the nodes of CG_k on an interval."""
+    if k == 1:
+        return np.array([0.0, 1.0])
+    from numpy.polynomial import legendre as leg
+    c = np.zeros(k + 1)
+    c[k] = 1.0
+    return 0.5 * (np.concatenate([[-1.0], np.sort(leg.legroots(leg.legder(c))), [1.0]]) + 1.0)
+
+
+def make_extruded_hex_mesh(n, layers=None, degree=4, tile=(4, 4), perturb=0.1):
+    layers = layers or n
+    k = degree
+    jj, ii = np.meshgrid(np.arange(n, dtype=np.int32), np.arange(n, dtype=np.int32), indexing="ij")
+    ii, jj = ii.ravel(), jj.ravel()
+    order = np.argsort(_tile_keys(ii, jj, np.zeros_like(ii), n, n, 1, (tile[0], tile[1], 1)), kind="stable")
+    ii, jj = ii[order], jj[order]
+    ncol = len(ii)
+    base = op2.Set(ncol, "base_cells")
+    ext = op2.ExtrudedSet(base, layers=layers + 1)
+
+    def space(p):
+        Lb = p * n + 1                      # base lattice points per axis
+        nz = p * layers + 1                 # nodes per vertical line
+        yy, xx = np.meshgrid(np.arange(Lb, dtype=np.int32), np.arange(Lb, dtype=np.int32), indexing="ij")
+        xx, yy = xx.ravel(), yy.ravel()
+        key = _tile_keys(np.minimum(xx, p * n - 1), np.minimum(yy, p * n - 1), np.zeros_like(xx), p * n, p * n, 1,
+                         (p * tile[0], p * tile[1], 1)) * 4 + (yy // (p * n)) * 2 + xx // (p * n)
+        border = np.argsort(key, kind="stable")
+        bnum = np.empty(len(border), dtype=np.int64)
+        bnum[border] = np.arange(len(border))
+        a, b, c = np.meshgrid(np.arange(p + 1), np.arange(p + 1), np.arange(p + 1), indexing="ij")
+        a, b, c = a.ravel(), b.ravel(), c.ravel()
+        bx = p * ii[:, None] + a[None, :]
+        by = p * jj[:, None] + b[None, :]
+        cmap = (bnum[by.astype(np.int64) * Lb + bx] * nz + c[None, :]).astype(np.int32)
+        nset = op2.Set(Lb * Lb * nz, f"q{p}_nodes")
+        m = op2.Map(ext, nset, (p + 1) ** 3, cmap, f"cell_q{p}", offset=[p] * (p + 1) ** 3)
+        # physical points of the nodes: CG_p on an interval has its nodes at the GLL points of each cell
+        gll = _gll_nodes(p)
+
+        def lat2x(lat, ncell):
+            cell = np.minimum(lat // p, ncell - 1)
+            return (cell + gll[lat - cell * p]) / ncell
+        bxy = np.stack([lat2x(xx[border], n), lat2x(yy[border], n)], axis=1)
+        pts = np.empty((Lb * Lb * nz, 3))
+        pts[:, :2] = np.repeat(bxy, nz, axis=0)
+        pts[:, 2] = np.tile(lat2x(np.arange(nz), layers), Lb * Lb)
+        return nset, m, pts
+
+    nset, cmap, pts = space(k)
+    cset, xmap, xpts = space(1)
+    xyz = xpts.copy()
+    if perturb:
+        h = 1.0 / n
+        inner = ((xyz > 1e-12) & (xyz < 1 - 1e-12)).all(axis=1)
+        d = perturb * h * np.stack([np.sin(2 * np.pi * xyz[:, 1]) * np.sin(2 * np.pi * xyz[:, 2]),
+                                    np.sin(2 * np.pi * xyz[:, 0]) * np.sin(2 * np.pi * xyz[:, 2]),
+                                    np.sin(2 * np.pi * xyz[:, 0]) * np.sin(2 * np.pi * xyz[:, 1])], axis=1)
+        xyz[inner] += d[inner]
+    coords = op2.Dat(cset ** 3, xyz, np.float64, "coordinates")
+    return ExtrudedHexMesh(n, layers, k, base, ext, nset, cmap, cset, xmap, coords, pts)

@@ -801,16 +801,21 @@ class Sparsity:
             self._elem_tables[key] = mp
         return mp
 
-    def elem_table(self, rmap: Map, cmap: Map):
-        """Device table element -> nonzero position in the NODE pattern (fd_csr_elem_offsets)."""
+    def elem_table(self, rmap: Map, cmap: Map, nlayers=0):
+        """Device table element (x layer) -> nonzero position in the NODE pattern (fd_csr_elem_offsets)."""
         self._build()
-        key = (id(rmap._base()), id(cmap._base()))
+        key = (id(rmap._base()), id(cmap._base()), nlayers)
         t = self._elem_tables.get(key)
         if t is None:
             nent = rmap._base().values_with_halo.shape[0]
-            t = DeviceBuffer(nent * rmap.arity * cmap.arity * 4)
+            t = DeviceBuffer(nent * max(nlayers, 1) * rmap.arity * cmap.arity * 4)
+            ro = co = None
+            if nlayers:
+                ro = np.asarray(rmap.offset, dtype=np.int32)
+                co = np.asarray(cmap.offset, dtype=np.int32)
             _lib.call("fd_csr_elem_offsets", self._node_rowptr.ptr, self._node_colidx.ptr, rmap._base()._dev_values(),
-                      cmap._base()._dev_values(), nent, rmap.arity, cmap.arity, t.ptr, None)
+                      cmap._base()._dev_values(), nent, rmap.arity, cmap.arity, nlayers,
+                      None if ro is None else ro.ctypes.data, None if co is None else co.ctypes.data, t.ptr, None)
             self._elem_tables[key] = t
         return t
 

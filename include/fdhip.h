@@ -152,12 +152,14 @@ int fd_csr_from_maps(int32_t nrow_nodes, int32_t ncol_nodes, int set_diag, int n
 /* node pattern -> scalar (aij) pattern for DataSet dims (rbs, cbs) (mat.py:254-278) */
 int fd_csr_expand_blocks(int32_t nrow_nodes, const int32_t *rowptr_dev, const int32_t *colidx_dev,
                          int rbs, int cbs, int32_t **rowptr_out, int32_t **colidx_out, fd_stream_t s);
-/* element -> nonzero table: out[(e*ar+i)*ac+j] = position of (rmap[e][i], cmap[e][j]) in the
- * node CSR, or -1.  Replaces the per-call row search inside MatSetValuesLocal
+/* element -> nonzero table: out[((e*nl+l)*ar+i)*ac+j] = position of (rmap[e][i]+roff[i]*l,
+ * cmap[e][j]+coff[j]*l) in the node CSR, or -1 (nlayers = 0: non-extruded, nl = 1).  Replaces the per-call row search inside MatSetValuesLocal
  * (pyop2/codegen/builder.py:573-625). */
 int fd_csr_elem_offsets(const int32_t *rowptr_dev, const int32_t *colidx_dev,
                         const int32_t *rmap_dev, const int32_t *cmap_dev,
-                        int32_t nent, int rarity, int carity, int32_t *out_dev, fd_stream_t s);
+                        int32_t nent, int rarity, int carity,
+                        int nlayers, const int32_t *roffsets_host, const int32_t *coffsets_host,
+                        int32_t *out_dev, fd_stream_t s);
 /* Mat.set_local_diagonal_entries (mat.py:896-937) and Mat.zero_rows (mat.py:857-891) */
 int fd_csr_set_diagonal(const int32_t *rowptr_dev, const int32_t *colidx_dev, double *vals_dev,
                         const int32_t *rows_dev, int32_t nrows_sel, double value, fd_stream_t s);
