@@ -56,7 +56,7 @@ __device__ __forceinline__ void inv3(const double J[3][3], double K[3][3], doubl
 
 // tables: L[5][5] (value of 1-D basis i at Gauss point q: L[q*5+i]), DL[5][5], QP[5], QW[5]  (60 doubles)
 // args after (start, end): layers, values, coords, map_q4 (unused: positions come from elemtab), map_q1, elemtab, tables
-extern "C" __global__ __launch_bounds__(256, 2)
+extern "C" __global__ __launch_bounds__(256, 1)
 void wrap_helmholtz_q4_hex_jacobian(int start, int end, const int *__restrict__ layers, double *__restrict__ vals,
                                     const double *__restrict__ coords, const int *__restrict__ map_q4,
                                     const int *__restrict__ map_q1, const int *__restrict__ elemtab,

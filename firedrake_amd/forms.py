@@ -535,3 +535,151 @@ class HelmholtzQ4Problem:
         _lib.call("fd_kernel_launch", self.kernel, 0, ncol, arr, len(args), 256, 1, ncol * m.layers, 0, None)
         self.mat.dat_version += 1
         return self.mat
+
+
+# ------------------------------------------------------------------------------------------
+# Config C4: DG advection (demos/DG_advection/DG_advection.py.rst, form L1) -- cell + ds + dS kernels
+# ------------------------------------------------------------------------------------------
+_QUAD_GEOM = """
+  /* bilinear geometry at reference point (s, t): vertex v = a*2 + b at (a, b) */
+  #define FD_QGEOM(xc, s, t) \\
+    const double N[4] = {(1-(s))*(1-(t)), (1-(s))*(t), (s)*(1-(t)), (s)*(t)}; \\
+    const double dNs[4] = {-(1-(t)), -(t), (1-(t)), (t)}; \\
+    const double dNt[4] = {-(1-(s)), (1-(s)), -(s), (s)}; \\
+    double J00 = 0, J01 = 0, J10 = 0, J11 = 0; \\
+    for (int v = 0; v < 4; ++v) { J00 += xc[2*v]*dNs[v]; J01 += xc[2*v]*dNt[v]; J10 += xc[2*v+1]*dNs[v]; J11 += xc[2*v+1]*dNt[v]; } \\
+    const double det = J00*J11 - J01*J10, idet = 1.0/det; \\
+    const double K00 = J11*idet, K01 = -J01*idet, K10 = -J10*idet, K11 = J00*idet;
+"""
+
+
+def dg_advection_kernels(nq=3):
+    """(cell, exterior-facet, interior-facet) kernels of
+        L1 = dtc*( q div(phi u) dx - [u.n<0] phi u.n q_in ds - [u.n>0] phi u.n q ds
+                   - (phi('+') - phi('-'))*(un('+') q('+') - un('-') q('-')) dS ),   un = (u.n + |u.n|)/2
+    with the TSFC argument order  A, coords, coefficients in form order (q, u), constants (dtc, q_in),
+    facet numbers (firedrake_loopy.py:432-522).  DQ1 basis = bilinear shape functions, vertex a*2+b."""
+    from numpy.polynomial import legendre as leg
+    x, w = leg.leggauss(nq)
+    x, w = 0.5 * (x + 1.0), 0.5 * w
+    tab = f"static const double QP[{nq}] = {_c(x)}; static const double QW[{nq}] = {_c(w)};"
+    cell = f"""
+{_QUAD_GEOM}
+static void dg_adv_cell(double *restrict A, const double *restrict xc, const double *restrict qd, const double *restrict ud,
+                        const double *restrict dtc)
+{{
+  {tab}
+  for (int a = 0; a < {nq}; ++a) for (int b = 0; b < {nq}; ++b) {{
+    const double s = QP[a], t = QP[b];
+    FD_QGEOM(xc, s, t)
+    double qq = 0, u0 = 0, u1 = 0, divu = 0;
+    double gx[4], gy[4];
+    for (int v = 0; v < 4; ++v) {{
+      gx[v] = dNs[v]*K00 + dNt[v]*K10;  gy[v] = dNs[v]*K01 + dNt[v]*K11;
+      qq += qd[v]*N[v]; u0 += ud[2*v]*N[v]; u1 += ud[2*v+1]*N[v];
+      divu += ud[2*v]*gx[v] + ud[2*v+1]*gy[v];
+    }}
+    const double wq = QW[a]*QW[b]*fabs(det)*dtc[0]*qq;
+    for (int i = 0; i < 4; ++i) A[i] += wq * (gx[i]*u0 + gy[i]*u1 + N[i]*divu);
+  }}
+}}
+"""
+    facet_pt = """
+    /* reference point of facet f at parameter p, outward reference normal (n0, n1), tangent axis */
+    const double s = (f == 0) ? 0.0 : (f == 1) ? 1.0 : p;
+    const double t = (f == 2) ? 0.0 : (f == 3) ? 1.0 : p;
+    const double rn0 = (f == 0) ? -1.0 : (f == 1) ? 1.0 : 0.0;
+    const double rn1 = (f == 2) ? -1.0 : (f == 3) ? 1.0 : 0.0;
+"""
+    ext = f"""
+{_QUAD_GEOM}
+static void dg_adv_ext(double *restrict A, const double *restrict xc, const double *restrict qd, const double *restrict ud,
+                       const double *restrict dtc, const double *restrict qin, const unsigned int *restrict facet)
+{{
+  {tab}
+  const unsigned int f = facet[0];
+  for (int a = 0; a < {nq}; ++a) {{
+    const double p = QP[a];
+{facet_pt}
+    FD_QGEOM(xc, s, t)
+    double nx = K00*rn0 + K10*rn1, ny = K01*rn0 + K11*rn1;
+    const double nn = sqrt(nx*nx + ny*ny); nx /= nn; ny /= nn;
+    const double tx = (f < 2) ? J01 : J00, ty = (f < 2) ? J11 : J10;
+    const double ds = sqrt(tx*tx + ty*ty);
+    double qq = 0, u0 = 0, u1 = 0;
+    for (int v = 0; v < 4; ++v) {{ qq += qd[v]*N[v]; u0 += ud[2*v]*N[v]; u1 += ud[2*v+1]*N[v]; }}
+    const double udn = u0*nx + u1*ny;
+    const double flux = (udn < 0.0) ? udn*qin[0] : ((udn > 0.0) ? udn*qq : 0.0);
+    const double wq = -dtc[0]*QW[a]*ds*flux;
+    for (int i = 0; i < 4; ++i) A[i] += wq * N[i];
+  }}
+}}
+"""
+    intf = f"""
+{_QUAD_GEOM}
+static void dg_adv_int(double *restrict A, const double *restrict xc, const double *restrict qd, const double *restrict ud,
+                       const double *restrict dtc, const unsigned int *restrict facet)
+{{
+  {tab}
+  for (int a = 0; a < {nq}; ++a) {{
+    const double p = QP[a];
+    double Np[4], Nm[4], nx, ny, ds;
+    {{ const unsigned int f = facet[0];
+{facet_pt}
+      FD_QGEOM(xc, s, t)
+      nx = K00*rn0 + K10*rn1; ny = K01*rn0 + K11*rn1;
+      const double nn = sqrt(nx*nx + ny*ny); nx /= nn; ny /= nn;
+      const double tx = (f < 2) ? J01 : J00, ty = (f < 2) ? J11 : J10;
+      ds = sqrt(tx*tx + ty*ty);
+      for (int v = 0; v < 4; ++v) Np[v] = N[v]; }}
+    {{ const unsigned int f = facet[1];
+{facet_pt}
+      const double N[4] = {{(1-s)*(1-t), (1-s)*t, s*(1-t), s*t}};
+      (void)rn0; (void)rn1;
+      for (int v = 0; v < 4; ++v) Nm[v] = N[v]; }}
+    double qp = 0, qm = 0, u0 = 0, u1 = 0;
+    for (int v = 0; v < 4; ++v) {{ qp += qd[v]*Np[v]; qm += qd[4+v]*Nm[v]; u0 += ud[2*v]*Np[v]; u1 += ud[2*v+1]*Np[v]; }}
+    const double udn = u0*nx + u1*ny;
+    const double unp = 0.5*(udn + fabs(udn)), unm = 0.5*(-udn + fabs(udn));
+    const double wq = -dtc[0]*QW[a]*ds*(unp*qp - unm*qm);
+    for (int i = 0; i < 4; ++i) {{ A[i] += wq*Np[i]; A[4+i] -= wq*Nm[i]; }}
+  }}
+}}
+"""
+    return op2.Kernel(cell, "dg_adv_cell"), op2.Kernel(ext, "dg_adv_ext"), op2.Kernel(intf, "dg_adv_int")
+
+
+class DGAdvectionProblem:
+    """RHS assembly of the DG-advection demo: one 1-form with cell + exterior-facet + interior-facet
+    integrals = three parloops into the same Dat inside frozen_halo(INC) (assemble.py:1281-1286;
+    SURVEY.md 3.3).  The interior-facet loop has arity-8 maps and a direct (2,)-uint32 facet-number Dat."""
+
+    def __init__(self, qmesh, dt=None):
+        import math
+        self.mesh = m = qmesh
+        pts = m.dq_points
+        xq1 = np.array(m.coordinates.data_ro)
+        self.u = op2.Dat(m.q1_set ** 2, np.stack([0.5 - xq1[:, 1], xq1[:, 0] - 0.5], axis=1), np.float64, "velocity")
+        r_bell = np.minimum(np.sqrt((pts[:, 0] - 0.25) ** 2 + (pts[:, 1] - 0.5) ** 2) / 0.15, 1.0)
+        r_cone = np.minimum(np.sqrt((pts[:, 0] - 0.5) ** 2 + (pts[:, 1] - 0.25) ** 2) / 0.15, 1.0)
+        self.q = op2.Dat(m.dq_set, 1.0 + 0.25 * (1 + np.cos(math.pi * r_bell)) + 1.0 - r_cone, np.float64, "q")
+        self.L = op2.Dat(m.dq_set, None, np.float64, "L1")
+        self.dtc = op2.Global(1, dt if dt is not None else 2 * math.pi / 600.0, np.float64, "dtc")
+        self.q_in = op2.Global(1, 1.0, np.float64, "q_in")
+        kc, ke, ki = dg_advection_kernels()
+        L, q, u, x = self.L, self.q, self.u, m.coordinates
+        self.loops = [
+            op2.LegacyParloop(kc, m.cell_set, L(op2.INC, m.cell_dq), x(op2.READ, m.cell_q1), q(op2.READ, m.cell_dq),
+                              u(op2.READ, m.cell_q1), self.dtc(op2.READ)),
+            op2.LegacyParloop(ke, m.ext_facet_set, L(op2.INC, m.ext_dq), x(op2.READ, m.ext_q1), q(op2.READ, m.ext_dq),
+                              u(op2.READ, m.ext_q1), self.dtc(op2.READ), self.q_in(op2.READ), m.ext_local_facet(op2.READ)),
+            op2.LegacyParloop(ki, m.int_facet_set, L(op2.INC, m.int_dq), x(op2.READ, m.int_q1), q(op2.READ, m.int_dq),
+                              u(op2.READ, m.int_q1), self.dtc(op2.READ), m.int_local_facet(op2.READ)),
+        ]
+
+    def assemble_rhs(self):
+        self.L.zero()
+        with self.L.frozen_halo(op2.INC):
+            for loop in self.loops:
+                loop()
+        return self.L

@@ -354,3 +354,91 @@ def make_extruded_hex_mesh(n, layers=None, degree=4, tile=(4, 4), perturb=0.1):
         xyz[inner] += d[inner]
     coords = op2.Dat(cset ** 3, xyz, np.float64, "coordinates")
     return ExtrudedHexMesh(n, layers, k, base, ext, nset, cmap, cset, xmap, coords, pts)
+
+
+# ------------------------------------------------------------------------------------------
+# quadrilateral mesh with facet sets: UnitSquareMesh(n, n, quadrilateral=True)  (config C4, DG advection)
+# ------------------------------------------------------------------------------------------
+@dataclass
+class QuadMesh:
+    """Cells, interior/exterior facet sets and the maps the DG-advection demo needs.
+
+    * DQ1: 4 DoFs per cell, dof = 4*cell + (a*2 + b)  (discontinuous: no sharing);
+    * Q1 (vector CG1: coordinates and velocity): vertex nodes, cell vertex order (a, b) -> a*2 + b;
+    * interior_facet maps have arity 2*ndof: [cell0 dofs..., cell1 dofs...] ('+' then '-',
+      firedrake/functionspaceimpl.py:814-829, dmcommon.pyx:1660-1674);
+    * ``local_facet_dat``: uint32 (nfacets, 2) / (nfacets, 1): local facet number inside each adjacent
+      cell (firedrake/mesh.py:196-201); reference-quad facets: 0: xi=0, 1: xi=1, 2: eta=0, 3: eta=1.
+    """
+    n: int
+    cell_set: op2.Set
+    int_facet_set: op2.Set
+    ext_facet_set: op2.Set
+    dq_set: op2.Set
+    q1_set: op2.Set
+    cell_dq: op2.Map
+    cell_q1: op2.Map
+    int_dq: op2.Map
+    int_q1: op2.Map
+    ext_dq: op2.Map
+    ext_q1: op2.Map
+    int_local_facet: op2.Dat
+    ext_local_facet: op2.Dat
+    coordinates: op2.Dat
+    dq_points: np.ndarray
+
+
+def make_quad_mesh(n, tile=(16, 16), perturb=0.0):
+    jj, ii = np.meshgrid(np.arange(n, dtype=np.int32), np.arange(n, dtype=np.int32), indexing="ij")
+    ii, jj = ii.ravel(), jj.ravel()
+    ckey = _tile_keys(ii, jj, np.zeros_like(ii), n, n, 1, (tile[0], tile[1], 1))
+    order = np.argsort(ckey, kind="stable")
+    ii, jj = ii[order], jj[order]
+    ncell = n * n
+    cellnum = np.empty(ncell, dtype=np.int64)
+    cellnum[jj.astype(np.int64) * n + ii] = np.arange(ncell)
+    cells, dq, q1n = op2.Set(ncell, "cells"), op2.Set(4 * ncell, "dq1_nodes"), op2.Set((n + 1) ** 2, "q1_nodes")
+    # vertices numbered in tile order as well
+    yy, xx = np.meshgrid(np.arange(n + 1, dtype=np.int32), np.arange(n + 1, dtype=np.int32), indexing="ij")
+    xx, yy = xx.ravel(), yy.ravel()
+    vkey = _tile_keys(np.minimum(xx, n - 1), np.minimum(yy, n - 1), np.zeros_like(xx), n, n, 1, (tile[0], tile[1], 1)) * 4 + (yy // n) * 2 + xx // n
+    vorder = np.argsort(vkey, kind="stable")
+    vnum = np.empty(len(vorder), dtype=np.int64)
+    vnum[vorder] = np.arange(len(vorder))
+    ab = np.array([(0, 0), (0, 1), (1, 0), (1, 1)], dtype=np.int32)       # vertex a*2+b -> (a, b)
+    cq1 = vnum[(jj[:, None] + ab[None, :, 1]).astype(np.int64) * (n + 1) + ii[:, None] + ab[None, :, 0]].astype(np.int32)
+    cdq = (4 * np.arange(ncell, dtype=np.int64)[:, None] + np.arange(4)[None, :]).astype(np.int32)
+    xy = np.stack([xx[vorder] / n, yy[vorder] / n], axis=1).astype(np.float64)
+    if perturb:
+        inner = ((xy > 1e-12) & (xy < 1 - 1e-12)).all(axis=1)
+        d = perturb / n * np.stack([np.sin(2 * np.pi * xy[:, 1]), np.sin(2 * np.pi * xy[:, 0])], axis=1)
+        xy[inner] += d[inner]
+    # interior facets: vertical (between (i,j) and (i+1,j)): + facet 1, - facet 0; horizontal: + facet 3, - facet 2
+    iv, jv = np.meshgrid(np.arange(n - 1), np.arange(n), indexing="xy")
+    c0v, c1v = cellnum[jv.ravel() * n + iv.ravel()], cellnum[jv.ravel() * n + iv.ravel() + 1]
+    ih, jh = np.meshgrid(np.arange(n), np.arange(n - 1), indexing="xy")
+    c0h, c1h = cellnum[jh.ravel() * n + ih.ravel()], cellnum[(jh.ravel() + 1) * n + ih.ravel()]
+    c0 = np.concatenate([c0v, c0h]); c1 = np.concatenate([c1v, c1h])
+    lf = np.concatenate([np.tile([1, 0], (len(c0v), 1)), np.tile([3, 2], (len(c0h), 1))]).astype(np.uint32)
+    forder = np.argsort(np.minimum(c0, c1), kind="stable")            # facets follow the cell traversal
+    c0, c1, lf = c0[forder], c1[forder], lf[forder]
+    ifs = op2.Set(len(c0), "interior_facets")
+    # exterior facets
+    ec, ef = [], []
+    for (sel_i, sel_j, f) in ((0, None, 0), (n - 1, None, 1), (None, 0, 2), (None, n - 1, 3)):
+        for t in range(n):
+            i, j = (sel_i, t) if sel_i is not None else (t, sel_j)
+            ec.append(cellnum[j * n + i]); ef.append(f)
+    ec, ef = np.array(ec), np.array(ef, dtype=np.uint32)
+    eorder = np.argsort(ec, kind="stable")
+    ec, ef = ec[eorder], ef[eorder]
+    efs = op2.Set(len(ec), "exterior_facets")
+    dq_pts = xy[cq1].reshape(-1, 2)
+    return QuadMesh(n, cells, ifs, efs, dq, q1n,
+                    op2.Map(cells, dq, 4, cdq, "cell_dq1"), op2.Map(cells, q1n, 4, cq1, "cell_q1"),
+                    op2.Map(ifs, dq, 8, np.concatenate([cdq[c0], cdq[c1]], axis=1), "ifacet_dq1"),
+                    op2.Map(ifs, q1n, 8, np.concatenate([cq1[c0], cq1[c1]], axis=1), "ifacet_q1"),
+                    op2.Map(efs, dq, 4, cdq[ec], "efacet_dq1"), op2.Map(efs, q1n, 4, cq1[ec], "efacet_q1"),
+                    op2.Dat(ifs ** 2, lf, np.uint32, "interior_local_facet"),
+                    op2.Dat(efs ** 1, ef.reshape(-1, 1), np.uint32, "exterior_local_facet"),
+                    op2.Dat(q1n ** 2, xy, np.float64, "coordinates"), dq_pts)
