@@ -1,0 +1,56 @@
+// tools/microbench_lds.hip -- LDS fp64 gather / atomic-add / plain RMW rates with register-resident random indices
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+template <int MODE>   // 0: ds_add_f64 (no return)  1: gather ds_read_b64  2: plain read+add+write  3: ds_add_f32  4: u64 int atomic add
+__global__ __launch_bounds__(256) void k(double *out, int iters, int span) {
+    extern __shared__ double s[];
+    for (int i = threadIdx.x; i < span; i += blockDim.x) s[i] = 0;
+    __syncthreads();
+    unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u;
+    int idx[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { h = h * 1664525u + 1013904223u; idx[q] = (h >> 8) % span; }
+    double acc = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            if (MODE == 0) atomicAdd(&s[idx[q]], 1.0);
+            else if (MODE == 1) acc += s[idx[q]];
+            else if (MODE == 2) s[idx[q]] += 1.0;
+            else if (MODE == 3) atomicAdd(((float *)s) + idx[q], 1.0f);
+            else atomicAdd(((unsigned long long *)s) + idx[q], 1ull);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) idx[q] = (idx[q] + 17) < span ? idx[q] + 17 : idx[q] + 17 - span;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && (s[0] == -1.0 || acc == -1.0)) out[0] = s[1] + acc;
+}
+
+template <int MODE> void run(const char *name, int span) {
+    double *out; CK(hipMalloc(&out, 64));
+    int iters = 256, grid = 256 * 8;
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), span * 8, 0, out, iters, span); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), span * 8, 0, out, iters, span);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    double ops = (double)grid * 256 * iters * 16;
+    printf("%-28s span %5d : %.3f ms  %.0f Gop/s chip  (%.2f lanes/clk/CU @2.1GHz)\n", name, span, ms, ops / ms / 1e6, ops / ms / 1e6 / 256 / 2.1);
+    CK(hipFree(out));
+}
+
+int main() {
+    for (int span : {512, 2048, 5472}) {
+        run<0>("ds_add_f64 (atomic)", span);
+        run<1>("ds_read_b64 gather", span);
+        run<2>("plain read+add+write f64", span);
+        run<3>("ds_add_f32 (atomic)", span);
+        run<4>("ds_add_u64 (atomic)", span);
+    }
+    return 0;
+}
