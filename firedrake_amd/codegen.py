@@ -81,6 +81,8 @@ def select_mode(gk: GlobalKernel) -> str:
         raise ValueError("FDHIP_MODE=staged but this parloop is not eligible for the staged wrapper")
     if want == "direct":
         return "direct"
+    if ok and configuration["mat_ocr"] and ocr_eligible(gk):
+        return "ocr"
     return "staged" if ok else "direct"
 
 
@@ -101,6 +103,23 @@ def staged_eligible(gk: GlobalKernel) -> bool:
     return n_ind > 0
 
 
+def ocr_eligible(gk: GlobalKernel) -> bool:
+    """Owner-computes-rows matrix assembly: the loop's only output is ONE scalar-block Mat with INC access
+    (entities are visited redundantly, so no other argument may be modified)."""
+    if not staged_eligible(gk):
+        return False
+    nmat = 0
+    for a, la in zip(gk.arguments, gk.local_kernel.arguments):
+        if isinstance(a, MatKernelArg):
+            (rdim, cdim) = a.dims
+            if la.access != INC or a.unroll or int(np.prod(rdim)) * int(np.prod(cdim)) != 1:
+                return False
+            nmat += 1
+        elif la.access != READ:
+            return False
+    return nmat == 1
+
+
 def _hoist_includes(code: str):
     inc = re.findall(r"^\s*#\s*include[^\n]*$", code, flags=re.M)
     body = re.sub(r"^\s*#\s*include[^\n]*$", "", code, flags=re.M)
@@ -110,7 +129,8 @@ def _hoist_includes(code: str):
 def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     lk = gk.local_kernel
     maps, map_index = _distinct_maps(gk)
-    staged = mode.startswith("staged")
+    ocr = mode.startswith("ocr")
+    staged = mode.startswith("staged") or ocr
     ktype, kbytes = ("unsigned short", 2) if mode.endswith("_k16") else ("unsigned char", 1)
     extruded = gk._extruded
     region = gk._iteration_region
@@ -174,18 +194,20 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
 
     # ---- backend-private parameters
     P("const int *__restrict__ bstart_", ("bstart",))
+    if ocr:
+        P("const int *__restrict__ inst_ent_", ("ocr_inst_ent",))
     staged_maps = []
     lds_items = []
     mat_staged = {}
     for info in infos:
         if info["kind"] == "mat":
-            mat_staged[info["k"]] = bool(staged and configuration["mat_staged"] and info["rbs"] * info["cbs"] == 1
+            mat_staged[info["k"]] = bool(staged and not ocr and configuration["mat_staged"] and info["rbs"] * info["cbs"] == 1
                                          and info["acc"] == INC and not info["arg"].unroll)
     if staged:
         for info in infos:
             if info["kind"] == "dat" and "m" in info and info["m"] not in staged_maps:
                 staged_maps.append(info["m"])
-            if info["kind"] == "mat" and mat_staged[info["k"]]:
+            if info["kind"] == "mat" and (mat_staged[info["k"]] or ocr):
                 for mi in (info["rm"], info["cm"]):
                     if mi not in staged_maps:
                         staged_maps.append(mi)
@@ -201,7 +223,14 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         k = info["k"]
         table = (configuration["mat_scatter"] == "table") and not extruded
         use_table[k] = table
-        if mat_staged[k]:
+        if ocr:
+            P(f"const int *__restrict__ oc{k}_rblk", ("ocr_rblk", k))
+            P(f"const int *__restrict__ oc{k}_rowptr", ("ocr_rowptr", k))
+            P(f"const {ktype} *__restrict__ oc{k}_k", ("ocr_kidx", k))
+            P(f"long long oc{k}_maxnnz", ("ocr_maxnnz", k))
+            P(f"long long oc{k}_maxnown", ("ocr_maxnown", k))
+            P(f"long long oc{k}_flags", ("ocr_flags", k))
+        elif mat_staged[k]:
             P(f"const int *__restrict__ mp{k}_off", ("matplan_off", k))
             P(f"const int *__restrict__ mp{k}_gpos", ("matplan_gpos", k))
             P(f"const int *__restrict__ mp{k}_lrp", ("matplan_lrp", k))
@@ -312,6 +341,34 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             pack.append(f"double t{k}[{size}]; for (int q = 0; q < {size}; ++q) t{k}[q] = 0;")
             call_args.append(f"t{k}")
             lg = info["arg"].lgmaps
+            if ocr:
+                lds_items.append(("ocr", k, rm, cm, bool(lg)))
+                lds_decl.append(f"double *sm{k} = (double *)(fd_lds + fd_off); fd_off += (((size_t)oc{k}_maxnnz*8) + 15) & ~(size_t)15;")
+                lds_decl.append(f"int *slrp{k} = (int *)(fd_lds + fd_off); fd_off += (((size_t)(oc{k}_maxnown + 1)*4) + 15) & ~(size_t)15;")
+                lds_decl.append(f"int *slrow{k} = (int *)(fd_lds + fd_off); fd_off += (((size_t)p{rm}_maxnd*4) + 15) & ~(size_t)15;")
+                mat_stage_pre.extend([f"const int n0_{k} = oc{k}_rblk[b], nown{k} = oc{k}_rblk[b+1] - n0_{k};",
+                                      f"const int r0_{k} = oc{k}_rowptr[n0_{k}], nnzb{k} = oc{k}_rowptr[n0_{k} + nown{k}] - r0_{k};"])
+                stage.append((rm, f"for (int q = tid; q < nnzb{k}; q += nthr) sm{k}[q] = 0;"))
+                stage.append((rm, f"for (int q = tid; q <= nown{k}; q += nthr) slrp{k}[q] = oc{k}_rowptr[n0_{k} + q] - r0_{k};"))
+                rowmask = f" && rlg{k}[g] >= 0" if lg else ""
+                stage.append((rm, f"for (int q = tid; q < nd{rm}; q += nthr) {{ const int g = p{rm}_list[l0_{rm} + q]; "
+                                  f"slrow{k}[q] = (g >= n0_{k} && g < n0_{k} + nown{k}{rowmask}) ? g - n0_{k} : -1; }}"))
+                if lg:
+                    lds_decl.append(f"unsigned char *smc{k} = fd_lds + fd_off; fd_off += ((size_t)p{cm}_maxnd + 15) & ~(size_t)15;")
+                    stage.append((cm, f"for (int q = tid; q < nd{cm}; q += nthr) smc{k}[q] = clg{k}[p{cm}_list[l0_{cm} + q]] < 0;"))
+                lines = [f"for (int i = 0; i < {ar}; ++i) {{",
+                         f"  const int lr = slrow{k}[lm{rm}[i]];",
+                         "  if (lr < 0) continue;          /* row owned by another block (or BC-masked) */",
+                         f"  const int base = slrp{k}[lr];",
+                         f"  for (int j = 0; j < {ac}; ++j) {{"]
+                if lg:
+                    lines.append(f"    if (smc{k}[lm{cm}[j]]) continue;")
+                lines += [f"    atomicAdd(&sm{k}[base + kk{k}[i*{ac} + j]], t{k}[i*{ac} + j]);", "  }", "}"]
+                unpack.append("\n    ".join(lines))
+                # complete rows, contiguous in the CSR value array: plain coalesced stores
+                flush.append((rm, f"if (oc{k}_flags & 1) {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)r0_{k} + q] = sm{k}[q]; }} "
+                                  f"else {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)r0_{k} + q] += sm{k}[q]; }}"))
+                continue
             if mat_staged[k]:
                 lds_items.append(("mat", k, rm, cm, bool(lg)))
                 lds_decl.append(f"double *sm{k} = (double *)(fd_lds + fd_off); fd_off += (((size_t)mp{k}_maxnnz*8) + 15) & ~(size_t)15;")
@@ -400,38 +457,49 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         src += ["  " + s for s in pre]
         # software pipeline: the packed index rows of the NEXT entity are requested before the current
         # entity's local kernel runs, so their HBM latency hides under ~10^2 fp64 instructions
-        idx_loads = []      # (declaration of the register row, load statement template)
+        idx_loads = []      # (register row, its prefetch twin, name, length, load template: II = iteration index, EE = entity)
         for mi in staged_maps:
             ar = maps[mi].arity
             idx_loads.append((f"int lm{mi}[{ar}]", f"int nx_lm{mi}[{ar}]", f"lm{mi}", ar,
-                              f"fdw::load_lmap<{ar}>(p{mi}_lmap + (size_t)(EE - start)*{ar}, DST);"))
+                              f"fdw::load_lmap<{ar}>(p{mi}_lmap + (size_t)(II - start)*{ar}, DST);"))
         for info in infos:
             if info["kind"] == "mat" and mat_staged[info["k"]]:
                 k, n = info["k"], info["ar"] * info["ac"]
                 idx_loads.append((f"int kk{k}[{n}]", f"int nx_kk{k}[{n}]", f"kk{k}", n,
-                                  f"fdw::load_packed<{ktype}, {n}>(mp{k}_k + (size_t)(EE - start)*{n}, DST);"))
+                                  f"fdw::load_packed<{ktype}, {n}>(mp{k}_k + (size_t)(II - start)*{n}, DST);"))
+            if info["kind"] == "mat" and ocr:
+                k, n = info["k"], info["ar"] * info["ac"]
+                idx_loads.append((f"int kk{k}[{n}]", f"int nx_kk{k}[{n}]", f"kk{k}", n,
+                                  f"fdw::load_packed<{ktype}, {n}>(oc{k}_k + (size_t)(EE)*{n}, DST);"))
         pf = bool(configuration["prefetch"])
+        ent_of = (lambda ii: f"inst_ent_[{ii}]") if ocr else (lambda ii: ii)
         if pf:
             for cur, nxt, name, n, ld in idx_loads:
                 src.append(f"  {cur}; {nxt};")
+            src.append("  int e_cur = 0;")
             src.append("  if (e0 + tid < e1) {")
+            src.append(f"    e_cur = {ent_of('e0 + tid')};")
             for cur, nxt, name, n, ld in idx_loads:
-                src.append("    " + ld.replace("EE", "(e0 + tid)").replace("DST", name))
+                src.append("    " + ld.replace("II", "(e0 + tid)").replace("EE", "e_cur").replace("DST", name))
             src.append("  }")
-        src.append("  for (int e = e0 + tid; e < e1; e += nthr) {")
+        src.append("  for (int it = e0 + tid; it < e1; it += nthr) {")
         if pf:
-            src.append("    const int en = (e + nthr < e1) ? e + nthr : e;")
+            src.append("    const int e = e_cur;")
+            src.append("    const int itn = (it + nthr < e1) ? it + nthr : it;")
+            src.append(f"    const int e_nx = {ent_of('itn')};")
             for cur, nxt, name, n, ld in idx_loads:
-                src.append("    " + ld.replace("EE", "en").replace("DST", "nx_" + name))
+                src.append("    " + ld.replace("II", "itn").replace("EE", "e_nx").replace("DST", "nx_" + name))
         else:
+            src.append(f"    const int e = {ent_of('it')};")
             for cur, nxt, name, n, ld in idx_loads:
-                src.append(f"    {cur}; " + ld.replace("EE", "e").replace("DST", name))
+                src.append(f"    {cur}; " + ld.replace("II", "it").replace("EE", "e").replace("DST", name))
         src += ["    " + s for s in pack]
         src.append(f"    fdk::{lk.name}({', '.join(call_args)});")
         src += ["    " + s for s in unpack]
         if pf:
             for cur, nxt, name, n, ld in idx_loads:
                 src.append(f"    for (int q = 0; q < {n}; ++q) {name}[q] = nx_{name}[q];")
+            src.append("    e_cur = e_nx;")
         src.append("  }")
         if flush and not configuration["debug_noflush"]:
             src.append("  __syncthreads();")

@@ -22,6 +22,8 @@ configuration = {
     "block_threads": _env("FDHIP_BLOCK_THREADS", 256, int),
     "ents_per_block": _env("FDHIP_ENTS_PER_BLOCK", 1024, int),
     "prefetch": _env("FDHIP_PREFETCH", 1, int),          # software-pipeline the packed index rows
+    "mat_ocr": _env("FDHIP_MAT_OCR", 1, int),             # owner-computes-rows matrix assembly (no global atomics)
+    "ocr_nnz_per_block": _env("FDHIP_OCR_NNZ", 2048, int),  # row-block size (CSR entries) when the producer gives no hint
     "mat_exclusive": _env("FDHIP_MAT_EXCLUSIVE", 0, int),  # non-atomic writes + fused zero for block-exclusive nonzeros
     "debug_noflush": _env("FDHIP_DEBUG_NOFLUSH", 0, int),  # experiment: skip the global flush (WRONG results)
     "min_waves": _env("FDHIP_MIN_WAVES", 0, int),       # 2nd __launch_bounds__ argument (waves per SIMD), 0 = unset

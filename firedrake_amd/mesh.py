@@ -192,6 +192,9 @@ def UnitCubeMesh(n, degrees=(1,), tile=(8, 4, 4), rank=0, nranks=1, perturb=0.0,
         node_set = op2.Set(sizes_n, f"cg{p}_nodes")
         m = op2.Map(cell_set, node_set, arity, cmap, f"cell_cg{p}")
         m.preferred_blocks = _split_blocks(cell_blocks, arity)
+        # node ranges of the traversal tiles (row blocks for owner-computes-rows matrix assembly)
+        ntile = (nkey[norder] // 8) // (tl[0] * tl[1] * tl[2])
+        m.preferred_node_blocks = np.concatenate([[0], np.nonzero(np.diff(ntile))[0] + 1, [len(norder)]]).astype(np.int32)
         return FunctionSpaceData(p, node_set, m, pts, halo, bnd, (p * nx + 1) * (p * ny + 1) * (p * nz + 1))
 
     spaces = {}

@@ -635,14 +635,20 @@ class PermutedMap(Map):
 class Plan:
     """Python handle on an fd_plan_t."""
 
-    def __init__(self, map_: Map, start, end, epb, blocks=None):
+    def __init__(self, map_, start, end, epb, blocks=None, arity=None):
+        """``map_``: a Map, or a raw device pointer to an int32 (n, arity) array (then pass ``arity``)."""
         h = ctypes.c_void_p()
+        if isinstance(map_, Map):
+            dev, arity = map_._dev_values(), map_.arity
+        else:
+            dev = int(map_)
+        self.arity = arity
         if blocks is None:
-            _lib.call("fd_plan_create", map_._dev_values(), map_.arity, start, end, epb, None, ctypes.byref(h))
+            _lib.call("fd_plan_create", dev, arity, start, end, epb, None, ctypes.byref(h))
         else:
             bl = np.ascontiguousarray(blocks, dtype=np.int32)
             assert bl[0] == start and bl[-1] == end
-            _lib.call("fd_plan_create_blocks", map_._dev_values(), map_.arity, bl.ctypes.data, len(bl) - 1, None, ctypes.byref(h))
+            _lib.call("fd_plan_create_blocks", dev, arity, bl.ctypes.data, len(bl) - 1, None, ctypes.byref(h))
         self.h = h.value
         bs, me = ctypes.c_void_p(), ctypes.c_int32()
         _lib.call("fd_plan_block_starts", self.h, ctypes.byref(bs), ctypes.byref(me))
@@ -653,7 +659,7 @@ class Plan:
         a, b, c = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
         _lib.call("fd_plan_arrays", self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
         self.blkoff, self.list, self.lmap = a.value, b.value, c.value
-        self.start, self.end, self.epb, self.arity = start, end, epb, map_.arity
+        self.start, self.end, self.epb = start, end, epb
 
     def download(self):
         """(block_offsets, node_list, local_map) as numpy arrays -- for tests/diagnostics."""
@@ -818,6 +824,52 @@ class Sparsity:
                       None if ro is None else ro.ctypes.data, None if co is None else co.ctypes.data, t.ptr, None)
             self._elem_tables[key] = t
         return t
+
+
+class OcrPlan:
+    """Owner-computes-rows plan (fd_ocrplan_*): row-node blocks, their entity instances, the per-instance
+    copies of the staged maps with their node plans, and the per-entity row-offset table."""
+
+    def __init__(self, sparsity, rmap: Map, cmap: Map, staged_maps, start, end, row_blocks):
+        self.row_blocks = rb = np.ascontiguousarray(row_blocks, dtype=np.int32)
+        nb = len(rb) - 1
+        h = ctypes.c_void_p()
+        _lib.call("fd_ocrplan_create", rmap._base()._dev_values(), rmap.arity, int(start), int(end), rb.ctypes.data, nb, None,
+                  ctypes.byref(h))
+        self.h = h.value
+        ni, mi = ctypes.c_int64(), ctypes.c_int32()
+        _lib.call("fd_ocrplan_info", self.h, ctypes.byref(ni), ctypes.byref(mi))
+        self.ninst, self.max_inst, self.nblocks = ni.value, mi.value, nb
+        p = [ctypes.c_void_p() for _ in range(4)]
+        _lib.call("fd_ocrplan_arrays", self.h, *[ctypes.byref(x) for x in p])
+        self.inst_off, inst_off_host, self.inst_ent, self.rblk = (x.value for x in p)
+        self.inst_off_host = np.ctypeslib.as_array(ctypes.cast(inst_off_host, ctypes.POINTER(ctypes.c_int32)), shape=(nb + 1,)).copy()
+        # per-instance copies of the staged maps + their node plans over the instance blocks
+        self.plans, self._imaps = {}, {}
+        for key, m in staged_maps.items():
+            imap = DeviceBuffer(max(self.ninst, 1) * m.arity * 4)
+            _lib.call("fd_gather_rows", m._base()._dev_values(), m.arity, self.inst_ent, self.ninst, imap.ptr, None)
+            self._imaps[key] = imap
+            self.plans[key] = Plan(imap.ptr, 0, int(self.ninst), 0, self.inst_off_host, arity=m.arity)
+        # geometry of the row blocks
+        rp = sparsity._node_rowptr.download(np.int32, (sparsity.dsets[0].set.total_size + 1,))
+        self.rows_end = int(rb[-1])
+        self.vals_end = int(rp[rb[-1]])
+        self.max_nnz = int(np.diff(rp[rb]).max()) if nb else 0
+        self.max_nown = int(np.diff(rb).max()) if nb else 0
+        maxlen = int(np.diff(rp).max()) if len(rp) > 1 else 0
+        self.kbytes = 1 if maxlen <= 254 else 2
+        nent = rmap._base().values_with_halo.shape[0]
+        self.kidx = DeviceBuffer(max(nent, 1) * rmap.arity * cmap.arity * self.kbytes)
+        _lib.call("fd_csr_elem_row_offsets", sparsity._node_rowptr.ptr, sparsity._node_colidx.ptr, rmap._base()._dev_values(),
+                  cmap._base()._dev_values(), nent, rmap.arity, cmap.arity, self.kbytes, self.kidx.ptr, None)
+
+    def __del__(self):
+        try:
+            if self.h:
+                _lib.load().fd_ocrplan_free(self.h)
+        except Exception:
+            pass
 
 
 class MatPlan:

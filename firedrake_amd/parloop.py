@@ -189,7 +189,7 @@ class Parloop:
                     maps.append(m._base())
         assert len(maps) == src.nmaps
         prep = {"cw": cw, "maps": maps}
-        if src.mode.startswith("staged"):
+        if src.mode.startswith("staged") or src.mode.startswith("ocr"):
             prep["parts"] = {}
         self._prepared = prep
         return prep
@@ -362,6 +362,15 @@ class Parloop:
 
     def compute(self):
         self._zero_global_temporaries()
+        if self._prepare()["cw"].src.mode.startswith("ocr"):
+            # owner-computes-rows: one launch over the row blocks; entities are visited through the instance
+            # lists, so there is no core/owned split to overlap the halo exchange with
+            self.global_to_local_begin()
+            self.global_to_local_end()
+            self._compute_ocr()
+            self.reduction_begin()
+            self.reduction_end()
+            return
         self.global_to_local_begin()
         self._compute(self.iterset.core_part)
         self.global_to_local_end()
@@ -392,6 +401,134 @@ class Parloop:
                 total *= self._nlayers_iterated()
             nblocks = max(1, (total + threads - 1) // threads)
             cw.launch(start, end, args, block_threads=threads, ents_per_block=threads, nblocks=nblocks)
+
+    # -- owner-computes-rows ---------------------------------------------------------------------------
+    def _ocr_geometry(self):
+        prep = self._prepared
+        geo = prep["parts"].get("ocr")
+        if geo is not None:
+            return geo
+        from .op2types import OcrPlan
+        src = prep["cw"].src
+        maps = prep["maps"]
+        (k, pa), = [(k, a) for k, a in enumerate(self.arguments) if isinstance(a, MatParloopArg)]
+        rmap, cmap = pa.maps
+        sp = pa.data.sparsity
+        sp._build()
+        nrows = rmap.toset.size                                   # owned rows only
+        end = self.iterset.total_size if self.compute_ghost else self.iterset.size
+        rp = sp._node_rowptr.download(np.int32, (rmap.toset.total_size + 1,))
+        limit = configuration["lds_limit"]
+        hint = getattr(rmap._base(), "preferred_node_blocks", None)
+        if hint is not None and configuration["use_preferred_blocks"]:
+            rb = np.asarray(hint, dtype=np.int64)
+            rb = np.unique(np.concatenate([rb[rb < nrows], [0, nrows]]))
+        else:
+            cap = configuration["ocr_nnz_per_block"]
+            targets = np.arange(0, int(rp[nrows]) + cap, cap)
+            rb = np.unique(np.concatenate([np.searchsorted(rp[:nrows + 1], targets, side="left"), [0, nrows]]))
+            rb = rb[rb <= nrows]
+        staged = {mi: maps[mi] for mi in src.staged_maps}
+        maxar = max(m.arity for m in staged.values())
+        for _ in range(12):
+            # split row blocks until the LDS rows and the instance lists fit
+            op = OcrPlan(sp, rmap, cmap, staged, 0, end, rb)
+            lds = 0
+            for item in src.lds_items:
+                if item[0] == "dat":
+                    _, mi, c, isz = item
+                    lds += ((op.plans[mi].max_nd * c * isz) + 15) // 16 * 16
+                else:
+                    _, kk, rm, cmi, lg = item
+                    lds += (op.max_nnz * 8 + 15) // 16 * 16 + ((op.max_nown + 1) * 4 + 15) // 16 * 16
+                    lds += (op.plans[rm].max_nd * 4 + 15) // 16 * 16
+                    if lg:
+                        lds += (op.plans[cmi].max_nd + 15) // 16 * 16
+            if lds <= limit and op.max_inst * maxar <= 16384:
+                break
+            d = np.diff(rb)
+            nn = np.diff(rp[rb])
+            ni = np.diff(op.inst_off_host)
+            big = (nn > 0.7 * nn.max()) | (ni * maxar > 16384) if lds > limit else (ni * maxar > 16384)
+            big &= d > 1
+            if not big.any():
+                break
+            rb = np.unique(np.concatenate([rb, (rb[:-1] + d // 2)[big]]))
+        if lds > 160 * 1024 or op.max_inst * maxar > 16384:
+            raise _lib.FDHipError("owner-computes-rows plan does not fit (LDS or instance list); set FDHIP_MAT_OCR=0")
+        if op.kbytes == 2 and src.kbytes == 1:
+            prep["cw"] = self.global_kernel.compile("ocr_k16")
+        geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz}
+        prep["parts"]["ocr"] = geo
+        if configuration["debug"]:
+            import sys
+            print(f"[fdhip] {self.global_kernel.name} OCR: row blocks={op.nblocks} instances={op.ninst} "
+                  f"(x{op.ninst / max(end, 1):.2f} entities) max_inst={op.max_inst} max_nnz={op.max_nnz} max_nown={op.max_nown} "
+                  f"lds={lds} kbytes={op.kbytes}", file=sys.stderr)
+        return geo
+
+    def _compute_ocr(self):
+        geo = self._ocr_geometry()
+        prep = self._prepared
+        cw = prep["cw"]
+        src = cw.src
+        op = geo["ocr"]
+        if op.nblocks == 0 or op.ninst == 0:
+            return
+        out = []
+        for desc in src.layout:
+            kind = desc[0]
+            if kind == "arg":
+                pa = self.arguments[desc[1]]
+                if isinstance(pa, MatParloopArg):
+                    mat = pa.data
+                    mat.dat_version += 1
+                    vals = mat._values_raw()
+                    flag = 0
+                    if mat._zero_pending:
+                        # rows outside the blocks (ghost rows) are the only part the loop does not overwrite
+                        tail = (geo["nnz"] - op.vals_end) * 8
+                        if tail > 0:
+                            _lib.call("fd_memset", vals.ptr + op.vals_end * 8, 0, tail, None)
+                        mat._zero_pending = False
+                        flag = 1
+                    self._ocr_flag = flag
+                    out.append(vals.ptr)
+                else:
+                    out.append(pa.data._dev_ptr(write=False))
+            elif kind == "map":
+                out.append(prep["maps"][desc[1]]._dev_values())
+            elif kind == "bstart":
+                out.append(op.inst_off)
+            elif kind == "ocr_inst_ent":
+                out.append(op.inst_ent)
+            elif kind == "plan_blkoff":
+                out.append(op.plans[desc[1]].blkoff)
+            elif kind == "plan_list":
+                out.append(op.plans[desc[1]].list)
+            elif kind == "plan_lmap":
+                out.append(op.plans[desc[1]].lmap)
+            elif kind == "plan_maxnd":
+                out.append(op.plans[desc[1]].max_nd)
+            elif kind == "ocr_rblk":
+                out.append(op.rblk)
+            elif kind == "ocr_rowptr":
+                out.append(self.arguments[desc[1]].data.sparsity._node_rowptr.ptr)
+            elif kind == "ocr_kidx":
+                out.append(op.kidx.ptr)
+            elif kind == "ocr_maxnnz":
+                out.append(op.max_nnz)
+            elif kind == "ocr_maxnown":
+                out.append(op.max_nown)
+            elif kind == "ocr_flags":
+                out.append(self._ocr_flag)
+            elif kind in ("mat_row_lgmap", "mat_col_lgmap"):
+                pa = self.arguments[desc[1]]
+                out.append(self._lgmap(pa.lgmaps[0 if kind == "mat_row_lgmap" else 1]))
+            else:
+                raise AssertionError(kind)
+        cw.launch(0, op.ninst, out, block_threads=src.block_threads, ents_per_block=op.max_inst, nblocks=op.nblocks,
+                  lds_bytes=geo["lds"])
 
     def _nlayers_iterated(self):
         from .op2types import ON_BOTTOM, ON_TOP, ON_INTERIOR_FACETS

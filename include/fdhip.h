@@ -135,6 +135,28 @@ int fd_matplan_arrays(fd_matplan_t m, const int32_t **mb_off, const int32_t **gp
                       const void **kidx);
 int fd_matplan_free(fd_matplan_t m);
 
+/* Owner-computes-rows plans: matrix assembly without global atomics.  Row nodes are cut into contiguous
+ * blocks [row_block_starts[b], row_block_starts[b+1]); block b visits every entity of [start,end) that touches
+ * one of its rows ("instances"; border entities are visited by several blocks) and so produces COMPLETE rows,
+ * which are contiguous in the CSR value array and are written with plain coalesced stores -- no atomics, and a
+ * pending Mat.zero() costs nothing.  Block-granular form of SURVEY.md 8e option 1; replaces
+ * MatSetValuesLocal(ADD_VALUES) + MatAssemblyBegin/End (builder.py:573-625, mat.py:940-954).
+ *   inst_off[nblocks+1], inst_entity[ninst]: the instances of every block (device; inst_off also on the host)
+ * fd_gather_rows builds the per-instance copy of a Map (dst[k] = src[idx[k]]) that fd_plan_create_blocks
+ * then localises; fd_csr_elem_row_offsets gives, per entity (i,j), the offset of column cmap[e][j] inside
+ * CSR row rmap[e][i] (uint8/uint16; all-ones = entry absent). */
+typedef struct fd_ocrplan_s *fd_ocrplan_t;
+int fd_ocrplan_create(const int32_t *rmap_dev, int rarity, int32_t start, int32_t end,
+                      const int32_t *row_block_starts_host, int32_t nblocks, fd_stream_t s, fd_ocrplan_t *out);
+int fd_ocrplan_info(fd_ocrplan_t p, int64_t *ninst, int32_t *max_inst_per_block);
+int fd_ocrplan_arrays(fd_ocrplan_t p, const int32_t **inst_off_dev, const int32_t **inst_off_host,
+                      const int32_t **inst_entity_dev, const int32_t **row_block_starts_dev);
+int fd_ocrplan_free(fd_ocrplan_t p);
+int fd_gather_rows(const int32_t *src_dev, int arity, const int32_t *idx_dev, int64_t n, int32_t *dst_dev, fd_stream_t s);
+int fd_csr_elem_row_offsets(const int32_t *rowptr_dev, const int32_t *colidx_dev, const int32_t *rmap_dev,
+                            const int32_t *cmap_dev, int32_t nent, int rarity, int carity, int kbytes,
+                            void *out_dev, fd_stream_t s);
+
 /* ------------------------------------------------------------ sparsity / CSR (a12)
  * Native replacement of pyop2/sparsity.pyx:105-159 (build_sparsity) + :162-389
  * (fill_with_zeros): union over (rowmap, colmap) pairs of the outer product of each

@@ -39,7 +39,9 @@ def _oracle_problem(prob, with_bcs):
 
 @pytest.mark.parametrize("dim,degree,n", [(2, 1, 64), (3, 1, 12), (3, 2, 6), (2, 2, 16)])
 @pytest.mark.parametrize("bcs", [False, True])
-def test_poisson_residual_and_jacobian(dim, degree, n, bcs):
+@pytest.mark.parametrize("ocr", [1, 0])
+def test_poisson_residual_and_jacobian(dim, degree, n, bcs, ocr, monkeypatch):
+    monkeypatch.setitem(configuration, "mat_ocr", ocr)
     m = (fmesh.UnitSquareMesh(n, n, degrees=(degree,), perturb=0.1) if dim == 2
          else fmesh.UnitCubeMesh(n, degrees=(degree,), tile=(4, 4, 2), perturb=0.1))
     prob = forms.PoissonProblem(m, degree, bcs=bcs)

@@ -73,10 +73,11 @@ def test_p1_mass_and_rhs_all_paths(nx, ny, shuffle, monkeypatch):
     ocsr = oracle_run(kmass, ele, op2.Mat(sp)(op2.INC, (m, m)), x(op2.READ, m))[0]
     # sparsity identical to the oracle's restatement of sparsity.pyx
     assert np.array_equal(sp.rowptr, ocsr.rowptr) and np.array_equal(sp.colidx, ocsr.colidx)
-    for mode in ("auto", "direct"):
-        for scatter in ("table", "search"):
+    for mode, scatter, ocr in (("auto", "table", 1), ("auto", "table", 0), ("auto", "search", 0), ("direct", "table", 0), ("direct", "search", 0)):
+        if True:
             monkeypatch.setitem(configuration, "mode", mode)
             monkeypatch.setitem(configuration, "mat_scatter", scatter)
+            monkeypatch.setitem(configuration, "mat_ocr", ocr)
             b = op2.Dat(nodes)
             op2.par_loop(krhs, ele, b(op2.INC, m), x(op2.READ, m), f(op2.READ, m))
             # tolerance: SURVEY.md Appendix D -- atomics reorder fp adds
