@@ -344,25 +344,29 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             if ocr:
                 lds_items.append(("ocr", k, rm, cm, bool(lg)))
                 lds_decl.append(f"double *sm{k} = (double *)(fd_lds + fd_off); fd_off += (((size_t)oc{k}_maxnnz*8) + 15) & ~(size_t)15;")
-                lds_decl.append(f"int *slrp{k} = (int *)(fd_lds + fd_off); fd_off += (((size_t)(oc{k}_maxnown + 1)*4) + 15) & ~(size_t)15;")
-                lds_decl.append(f"int *slrow{k} = (int *)(fd_lds + fd_off); fd_off += (((size_t)p{rm}_maxnd*4) + 15) & ~(size_t)15;")
+                # one LDS word per gathered node: bits 0..29 = 1 + offset of the node's row inside the block's
+                # accumulator (0 = row not owned here or BC-masked), bit 31 = column is BC-masked
+                lds_decl.append(f"unsigned int *srow{k} = (unsigned int *)(fd_lds + fd_off); fd_off += (((size_t)p{rm}_maxnd*4) + 15) & ~(size_t)15;")
+                if cm != rm:
+                    lds_decl.append(f"unsigned char *smc{k} = fd_lds + fd_off; fd_off += ((size_t)p{cm}_maxnd + 15) & ~(size_t)15;")
                 mat_stage_pre.extend([f"const int n0_{k} = oc{k}_rblk[b], nown{k} = oc{k}_rblk[b+1] - n0_{k};",
                                       f"const int r0_{k} = oc{k}_rowptr[n0_{k}], nnzb{k} = oc{k}_rowptr[n0_{k} + nown{k}] - r0_{k};"])
                 stage.append((rm, f"for (int q = tid; q < nnzb{k}; q += nthr) sm{k}[q] = 0;"))
-                stage.append((rm, f"for (int q = tid; q <= nown{k}; q += nthr) slrp{k}[q] = oc{k}_rowptr[n0_{k} + q] - r0_{k};"))
                 rowmask = f" && rlg{k}[g] >= 0" if lg else ""
+                colbit = (f" | ((clg{k}[g] < 0) ? 0x80000000u : 0u)" if (lg and cm == rm) else "")
                 stage.append((rm, f"for (int q = tid; q < nd{rm}; q += nthr) {{ const int g = p{rm}_list[l0_{rm} + q]; "
-                                  f"slrow{k}[q] = (g >= n0_{k} && g < n0_{k} + nown{k}{rowmask}) ? g - n0_{k} : -1; }}"))
-                if lg:
-                    lds_decl.append(f"unsigned char *smc{k} = fd_lds + fd_off; fd_off += ((size_t)p{cm}_maxnd + 15) & ~(size_t)15;")
+                                  f"srow{k}[q] = ((g >= n0_{k} && g < n0_{k} + nown{k}{rowmask}) ? (unsigned)(oc{k}_rowptr[g] - r0_{k} + 1) : 0u){colbit}; }}"))
+                if lg and cm != rm:
                     stage.append((cm, f"for (int q = tid; q < nd{cm}; q += nthr) smc{k}[q] = clg{k}[p{cm}_list[l0_{cm} + q]] < 0;"))
-                lines = [f"for (int i = 0; i < {ar}; ++i) {{",
-                         f"  const int lr = slrow{k}[lm{rm}[i]];",
-                         "  if (lr < 0) continue;          /* row owned by another block (or BC-masked) */",
-                         f"  const int base = slrp{k}[lr];",
-                         f"  for (int j = 0; j < {ac}; ++j) {{"]
+                lines = [f"unsigned int rw{k}[{ar}];", f"for (int i = 0; i < {ar}; ++i) rw{k}[i] = srow{k}[lm{rm}[i]];"]
+                if lg and cm != rm:
+                    lines += [f"bool cmk{k}[{ac}];", f"for (int j = 0; j < {ac}; ++j) cmk{k}[j] = smc{k}[lm{cm}[j]];"]
+                lines += [f"for (int i = 0; i < {ar}; ++i) {{",
+                          f"  const int base = (int)(rw{k}[i] & 0x3fffffffu) - 1;",
+                          "  if (base < 0) continue;          /* row owned by another block (or BC-masked) */",
+                          f"  for (int j = 0; j < {ac}; ++j) {{"]
                 if lg:
-                    lines.append(f"    if (smc{k}[lm{cm}[j]]) continue;")
+                    lines.append(f"    if ({'cmk%d[j]' % k if cm != rm else '(rw%d[j] >> 31)' % k}) continue;")
                 lines += [f"    atomicAdd(&sm{k}[base + kk{k}[i*{ac} + j]], t{k}[i*{ac} + j]);", "  }", "}"]
                 unpack.append("\n    ".join(lines))
                 # complete rows, contiguous in the CSR value array: plain coalesced stores

@@ -619,6 +619,27 @@ __global__ void ocr_split(const uint64_t *__restrict__ keys, int64_t n, int32_t 
     }
 }
 
+// Within every block, reorder the instances by a multiplicative permutation i -> (i*P) mod n so that the
+// lanes of a wavefront work on entities ~P apart: neighbouring entities share nodes, and lanes that add into
+// the SAME LDS accumulator in one ds_add_f64 are serialised by the hardware.
+__global__ void ocr_interleave(const int32_t *__restrict__ off, const int32_t *__restrict__ in, int32_t *__restrict__ out, int stride) {
+    const int b = blockIdx.x;
+    const int o = off[b], n = off[b + 1] - o;
+    __shared__ int P;
+    if (threadIdx.x == 0) {
+        int p = stride;
+        for (;; ++p) {
+            int a = p, c = n;
+            while (c) { int t = a % c; a = c; c = t; }
+            if (a == 1 || n <= 1) break;
+        }
+        P = p;
+    }
+    __syncthreads();
+    const long long pp = P;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) out[o + j] = in[o + (int)((j * pp) % n)];
+}
+
 __global__ void gather_rows_k(const int32_t *__restrict__ src, int arity, const int32_t *__restrict__ idx, int64_t n,
                               int32_t *__restrict__ dst) {
     const int64_t total = n * arity;
@@ -659,7 +680,7 @@ __global__ void row_offsets_k(const int32_t *__restrict__ rowptr, const int32_t 
 extern "C" {
 
 int fd_ocrplan_create(const int32_t *rmap_dev, int ar, int32_t start, int32_t end,
-                      const int32_t *row_block_starts_host, int32_t nblocks, fd_stream_t s_, fd_ocrplan_t *out) {
+                      const int32_t *row_block_starts_host, int32_t nblocks, int interleave, fd_stream_t s_, fd_ocrplan_t *out) {
     hipStream_t s = fd::st(s_);
     if (ar <= 0 || nblocks < 0 || end < start || !row_block_starts_host) FD_FAIL("fd_ocrplan_create: bad arguments");
     auto *p = new fd_ocrplan_s;
@@ -705,6 +726,15 @@ int fd_ocrplan_create(const int32_t *rmap_dev, int ar, int32_t start, int32_t en
     FD_HIP(hipMalloc(&p->inst_ent, (size_t)(nu > 0 ? nu : 1) * 4));
     hipLaunchKernelGGL(ocr_split, dim3(mp_grid(nu + 1)), dim3(256), 0, s, uniq, nu, nblocks, p->inst_off, p->inst_ent);
     FD_CHECK_LAUNCH();
+    if (interleave > 1 && nu > 0) {
+        int32_t *perm = nullptr;
+        FD_HIP(hipMalloc(&perm, (size_t)nu * 4));
+        hipLaunchKernelGGL(ocr_interleave, dim3(nblocks), dim3(256), 0, s, p->inst_off, p->inst_ent, perm, interleave);
+        FD_CHECK_LAUNCH();
+        FD_HIP(hipStreamSynchronize(s));
+        FD_HIP(hipFree(p->inst_ent));
+        p->inst_ent = perm;
+    }
     FD_HIP(hipMemcpyAsync(p->inst_off_host, p->inst_off, ((size_t)nblocks + 1) * 4, hipMemcpyDeviceToHost, s));
     FD_HIP(hipStreamSynchronize(s));
     for (int32_t b = 0; b < nblocks; ++b) {

@@ -834,8 +834,8 @@ class OcrPlan:
         self.row_blocks = rb = np.ascontiguousarray(row_blocks, dtype=np.int32)
         nb = len(rb) - 1
         h = ctypes.c_void_p()
-        _lib.call("fd_ocrplan_create", rmap._base()._dev_values(), rmap.arity, int(start), int(end), rb.ctypes.data, nb, None,
-                  ctypes.byref(h))
+        _lib.call("fd_ocrplan_create", rmap._base()._dev_values(), rmap.arity, int(start), int(end), rb.ctypes.data, nb,
+                  int(configuration["ocr_interleave"]), None, ctypes.byref(h))
         self.h = h.value
         ni, mi = ctypes.c_int64(), ctypes.c_int32()
         _lib.call("fd_ocrplan_info", self.h, ctypes.byref(ni), ctypes.byref(mi))

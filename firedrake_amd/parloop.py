@@ -232,6 +232,13 @@ class Parloop:
             i0, i1 = np.searchsorted(pb, start), np.searchsorted(pb, end)
             if i0 < len(pb) and i1 < len(pb) and pb[i0] == start and pb[i1] == end and i1 > i0:
                 bl = pb[i0:i1 + 1].astype(np.int32)
+                mrg = max(1, int(configuration["block_merge"]))
+                while mrg > 1:
+                    cand_bl = np.unique(np.concatenate([bl[::mrg], bl[-1:]]))
+                    if int(np.diff(cand_bl).max()) * maxar <= 16384:
+                        bl = cand_bl
+                        break
+                    mrg -= 1
                 if int(np.diff(bl).max()) * maxar <= 16384:
                     blocks = bl
         plans = None
@@ -440,9 +447,8 @@ class Parloop:
                     lds += ((op.plans[mi].max_nd * c * isz) + 15) // 16 * 16
                 else:
                     _, kk, rm, cmi, lg = item
-                    lds += (op.max_nnz * 8 + 15) // 16 * 16 + ((op.max_nown + 1) * 4 + 15) // 16 * 16
-                    lds += (op.plans[rm].max_nd * 4 + 15) // 16 * 16
-                    if lg:
+                    lds += (op.max_nnz * 8 + 15) // 16 * 16 + (op.plans[rm].max_nd * 4 + 15) // 16 * 16
+                    if cmi != rm:
                         lds += (op.plans[cmi].max_nd + 15) // 16 * 16
             if lds <= limit and op.max_inst * maxar <= 16384:
                 break

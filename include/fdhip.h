@@ -147,7 +147,8 @@ int fd_matplan_free(fd_matplan_t m);
  * CSR row rmap[e][i] (uint8/uint16; all-ones = entry absent). */
 typedef struct fd_ocrplan_s *fd_ocrplan_t;
 int fd_ocrplan_create(const int32_t *rmap_dev, int rarity, int32_t start, int32_t end,
-                      const int32_t *row_block_starts_host, int32_t nblocks, fd_stream_t s, fd_ocrplan_t *out);
+                      const int32_t *row_block_starts_host, int32_t nblocks, int interleave,
+                      fd_stream_t s, fd_ocrplan_t *out);   /* interleave > 1: spread neighbouring entities over lanes */
 int fd_ocrplan_info(fd_ocrplan_t p, int64_t *ninst, int32_t *max_inst_per_block);
 int fd_ocrplan_arrays(fd_ocrplan_t p, const int32_t **inst_off_dev, const int32_t **inst_off_host,
                       const int32_t **inst_entity_dev, const int32_t **row_block_starts_dev);
