@@ -62,6 +62,19 @@ def gauss_jacobi_simplex(dim, degree):
     return np.array(pts), np.array(wts)
 
 
+def simplex_rule(dim, degree):
+    """Quadrature on the reference simplex the way FIAT's default scheme picks it (tsfc/fem.py:330-333 ->
+    FIAT create_quadrature): the minimal symmetric rules for degree <= 2, collapsed Gauss-Jacobi above."""
+    if degree <= 1:
+        return np.full((1, dim), 1.0 / (dim + 1)), np.array([1.0 / (2 if dim == 2 else 6)])
+    if degree == 2 and dim == 2:
+        return np.array([[1 / 6, 1 / 6], [2 / 3, 1 / 6], [1 / 6, 2 / 3]]), np.full(3, 1.0 / 6.0)
+    if degree == 2 and dim == 3:
+        a, b = 0.5854101966249685, 0.1381966011250105
+        return np.array([[b, b, b], [a, b, b], [b, a, b], [b, b, a]]), np.full(4, 1.0 / 24.0)
+    return gauss_jacobi_simplex(dim, degree)
+
+
 _TET_EDGES = [(2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1)]
 _TRI_EDGES = [(1, 2), (0, 2), (0, 1)]
 
@@ -124,7 +137,7 @@ def poisson_residual_kernel(dim, degree, name=None):
     nv = dim + 1
     if degree == 1:
         # P1: gradients constant on the cell -> stiffness term outside the quadrature loop
-        qp, qw = gauss_jacobi_simplex(dim, 2)
+        qp, qw = simplex_rule(dim, 2)
         phi, _ = tabulate_lagrange(dim, 1, qp)
         nq = len(qw)
         dl = np.concatenate([-np.ones((1, dim)), np.eye(dim)], axis=0)
@@ -164,9 +177,9 @@ static void {name}(double *restrict A, const double *restrict x, const double *r
 """
         return op2.Kernel(body, name, flop_count=None)
     # P2: two quadrature loops (degree 2 for the stiffness term, degree 4 for f*v)
-    qs, ws = gauss_jacobi_simplex(dim, 2 * (degree - 1))
+    qs, ws = simplex_rule(dim, 2 * (degree - 1))
     _, dphs = tabulate_lagrange(dim, degree, qs)
-    qm, wm = gauss_jacobi_simplex(dim, 2 * degree)
+    qm, wm = simplex_rule(dim, 2 * degree)
     phm, _ = tabulate_lagrange(dim, degree, qm)
     nd = phm.shape[1]
     body = f"""
@@ -242,7 +255,7 @@ static void {name}(double *restrict A, const double *restrict x)
 }}
 """
         return op2.Kernel(body, name)
-    qs, ws = gauss_jacobi_simplex(dim, 2 * (degree - 1))
+    qs, ws = simplex_rule(dim, 2 * (degree - 1))
     _, dphs = tabulate_lagrange(dim, degree, qs)
     nd = dphs.shape[1]
     body = f"""
@@ -280,7 +293,7 @@ static void {name}(double *restrict A, const double *restrict x)
 def mass_kernel(dim, degree, name=None):
     """a(u, v) = int u v dx.  Arguments: A[nd*nd], coords."""
     name = name or f"mass_p{degree}_{'tet' if dim == 3 else 'tri'}"
-    qm, wm = gauss_jacobi_simplex(dim, 2 * degree)
+    qm, wm = simplex_rule(dim, 2 * degree)
     phm, _ = tabulate_lagrange(dim, degree, qm)
     nd = phm.shape[1]
     body = f"""
@@ -409,8 +422,11 @@ def precompile_all():
         for lg in (False, True):
             gj = GlobalKernel(kjac, [MatKernelArg(((1,), (1,)), (cm, cm), lgmaps=lg), DatKernelArg((dim,), xm)])
             for g in (gk, gj):
-                for mode in ("staged", "direct"):
+                from .codegen import ocr_eligible
+                for mode in ("staged", "direct", "ocr"):
                     if mode == "staged" and not staged_eligible(g):
+                        continue
+                    if mode == "ocr" and not ocr_eligible(g):
                         continue
                     src = generate_wrapper(g, mode)
                     out.append(compile_hip(src.source, src.symbol))

@@ -21,7 +21,10 @@ __global__ __launch_bounds__(256) void k(double *out, int iters, int span) {
             else if (MODE == 1) acc += s[idx[q]];
             else if (MODE == 2) s[idx[q]] += 1.0;
             else if (MODE == 3) atomicAdd(((float *)s) + idx[q], 1.0f);
-            else atomicAdd(((unsigned long long *)s) + idx[q], 1ull);
+            else if (MODE == 4) atomicAdd(((unsigned long long *)s) + idx[q], 1ull);
+            else if (MODE == 5) { double2 v = *(const double2 *)&s[idx[q] & ~1]; acc += v.x + v.y; }
+            else if (MODE == 6) { const double *r = &s[(idx[q] % (span / 6)) * 6]; double2 a = *(const double2 *)r, b = *(const double2 *)(r + 2), c = *(const double2 *)(r + 4); acc += a.x + a.y + b.x + b.y + c.x; (void)c.y; }
+            else { const double *r = &s[(idx[q] % (span / 5)) * 5]; acc += r[0] + r[1] + r[2] + r[3] + r[4]; }
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) idx[q] = (idx[q] + 17) < span ? idx[q] + 17 : idx[q] + 17 - span;
@@ -51,6 +54,9 @@ int main() {
         run<2>("plain read+add+write f64", span);
         run<3>("ds_add_f32 (atomic)", span);
         run<4>("ds_add_u64 (atomic)", span);
+        run<5>("ds_read_b128 gather", span);
+        run<6>("record 48B: 3x b128", span);
+        run<7>("record 40B: 5x b64", span);
     }
     return 0;
 }
