@@ -137,6 +137,8 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     ih = extruded and region == ON_INTERIOR_FACETS
     nf = 2 if ih else 1
     threads = configuration["block_threads"]
+    if mode.startswith("ocr") and configuration["ocr_block_threads"]:
+        threads = configuration["ocr_block_threads"]
 
     params: List[str] = []
     layout: List[tuple] = []

@@ -24,6 +24,7 @@ configuration = {
     "prefetch": _env("FDHIP_PREFETCH", 1, int),          # software-pipeline the packed index rows
     "mat_ocr": _env("FDHIP_MAT_OCR", 1, int),             # owner-computes-rows matrix assembly (no global atomics)
     "ocr_nnz_per_block": _env("FDHIP_OCR_NNZ", 2048, int),  # row-block size (CSR entries) when the producer gives no hint
+    "ocr_block_threads": _env("FDHIP_OCR_BLOCK_THREADS", 0, int),  # 0 = same as block_threads
     "ocr_interleave": _env("FDHIP_OCR_INTERLEAVE", 1, int),  # lane <-> instance stride inside a block (1 = none)
     "mat_exclusive": _env("FDHIP_MAT_EXCLUSIVE", 0, int),  # non-atomic writes + fused zero for block-exclusive nonzeros
     "debug_noflush": _env("FDHIP_DEBUG_NOFLUSH", 0, int),  # experiment: skip the global flush (WRONG results)
