@@ -55,24 +55,39 @@ def cpu_baseline(n_sample, degree, seconds_hint=20.0):
     t0 = time.perf_counter()
     csr = oracle.build_sparsity(nn, nn, [(cm, cm)])
     t_sparsity = time.perf_counter() - t0
-    fn_r, a_r, k1, _ = oracle.par_loop(kr.code, kr.name, 0, ncell, [ODat(r, INC, cm), ODat(coords, READ, xm), ODat(u, READ, cm), ODat(f, READ, cm)], return_fn=True)
-    fn_j, a_j, k2, cm_ = oracle.par_loop(kj.code, kj.name, 0, ncell, [OMat(csr, INC, cm, cm), ODat(coords, READ, xm)], return_fn=True)
-    ts = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        r[:] = 0
-        fn_r(*a_r)
-        t1 = time.perf_counter()
-        csr.values[:] = 0
-        fn_j(*a_j)
-        t2 = time.perf_counter()
-        ts.append((t2 - t0, t1 - t0, t2 - t1))
-    ts.sort()
-    tot, tr, tj = ts[len(ts) // 2]
-    return {"value": nn / tot, "unit": "DoFs/s", "cores": 1, "kind": "port",
+    def timed(threads):
+        fn_r, a_r, k1, _ = oracle.par_loop(kr.code, kr.name, 0, ncell, [ODat(r, INC, cm), ODat(coords, READ, xm), ODat(u, READ, cm), ODat(f, READ, cm)],
+                                           return_fn=True, threads=threads)
+        fn_j, a_j, k2, cm_ = oracle.par_loop(kj.code, kj.name, 0, ncell, [OMat(csr, INC, cm, cm), ODat(coords, READ, xm)],
+                                             return_fn=True, threads=threads)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            r[:] = 0
+            fn_r(*a_r)
+            t1 = time.perf_counter()
+            csr.values[:] = 0
+            fn_j(*a_j)
+            t2 = time.perf_counter()
+            ts.append((t2 - t0, t1 - t0, t2 - t1))
+        ts.sort()
+        return ts[len(ts) // 2]
+
+    tot1, tr1, tj1 = timed(False)
+    cores = os.cpu_count() or 1
+    totN, trN, tjN = timed(True)          # OpenMP over cells, atomic scatter: the shared-memory analogue of N ranks
+    multi = {"value": nn / totN, "cores": cores, "residual_dofs_per_s": nn / trN, "jacobian_dofs_per_s": nn / tjN,
+             "note": "OpenMP over contiguous cell ranges, thread-private residual vectors summed afterwards, atomic CSR adds "
+                     "(shared-memory analogue of N ranks)"}
+    single = {"value": nn / tot1, "cores": 1, "residual_dofs_per_s": nn / tr1, "jacobian_dofs_per_s": nn / tj1,
+              "note": "1 thread = what one MPI rank of the reference executes"}
+    best = multi if multi["value"] >= single["value"] else single
+    return {"value": best["value"], "unit": "DoFs/s", "cores": best["cores"], "kind": "port",
             "sample": f"Poisson CG{degree} on UnitCubeMesh({n_sample}) tets: {ncell} cells, {nn} DoFs, residual+Jacobian, "
-                      f"median of 3; oracle = CPU restatement of the PyOP2 wrapper, gcc -O3 -march=native -ffast-math, 1 thread",
-            "residual_dofs_per_s": nn / tr, "jacobian_dofs_per_s": nn / tj, "sparsity_build_s": t_sparsity}
+                      f"median of 5; oracle = CPU restatement of the PyOP2 wrapper (not the reference binary), "
+                      f"gcc -O3 -march=native -ffast-math; the faster of 1 thread and {cores} OpenMP threads is reported",
+            "residual_dofs_per_s": best["residual_dofs_per_s"], "jacobian_dofs_per_s": best["jacobian_dofs_per_s"],
+            "single_thread": single, "all_host_threads": multi, "sparsity_build_s": t_sparsity}
 
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD datasheet; tools/microbench.hip measures 77.7 TFLOP/s with v_mfma_f64_16x16x4_f64
@@ -121,7 +136,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=215, help="cubes per axis per GPU (215 -> ~10M DoF)")
     ap.add_argument("--degree", type=int, default=1)
-    ap.add_argument("--cpu-sample", type=int, default=64, help="cube size of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=128, help="cube size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-bcs", action="store_true")
     ap.add_argument("--tile", type=str, default="8,4,4", help="cubes per traversal tile (= plan block)")
     ap.add_argument("--only", choices=["both", "residual", "jacobian"], default="both", help="profiling aid: run one form only")

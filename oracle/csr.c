@@ -147,7 +147,13 @@ static inline void add_scalar(oracle_mat *A, int row, int col, double v, int ins
         int mid = (lo + hi) >> 1;
         int c = A->colidx[mid];
         if (c == col) {
-            if (insert) A->vals[mid] = v; else A->vals[mid] += v;
+            if (insert) A->vals[mid] = v;
+            else {
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+                A->vals[mid] += v;
+            }
             return;
         }
         if (c < col) lo = mid + 1; else hi = mid - 1;

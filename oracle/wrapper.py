@@ -144,7 +144,7 @@ int oracle_MatSetValuesLocal(oracle_mat *A, int nr, const int *rows, int nc, con
 
 
 def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
-                     extruded=False, iteration_region=ALL, pass_layer_arg=False):
+                     extruded=False, iteration_region=ALL, pass_layer_arg=False, threads=False):
     """Emit the C wrapper (restating SURVEY.md Appendix A)."""
     sig = ["int start", "int end"]
     if extruded:
@@ -173,6 +173,7 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
         return e
 
     decls = []
+    priv = []       # (arg index, ctype, length): INC Dats that get thread-private copies under OpenMP
     for k, a in enumerate(args):
         if isinstance(a, ODat):
             ct = _CTYPES[a.data.dtype]
@@ -199,6 +200,9 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
             if a.access != READ:
                 lhs = f"arg{k}[(size_t)({node_expr(mn, ar, 'i', a.offset, a.perm, 'f')})*{c} + j]"
                 rhs = f"t{k}[(f*{ar}+i)*{c}+j]"
+                if threads and a.access == INC:
+                    lhs = lhs.replace(f"arg{k}[", f"priv{k}[", 1)
+                    priv.append((k, ct, a.data.size))
                 op = {INC: f"{lhs} += {rhs};",
                       MIN: f"{lhs} = {lhs} < {rhs} ? {lhs} : {rhs};",
                       MAX: f"{lhs} = {lhs} > {rhs} ? {lhs} : {rhs};",
@@ -255,9 +259,17 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
     if pass_layer_arg:
         body_call.append("layer")
 
-    lines = [_PREAMBLE, kernel_src, *decls, f"int wrap_{kernel_name}({', '.join(sig)})", "{",
-             "  for (int n = start; n < end; ++n) {",
-             "    int e = " + ("subset_indices[n];" if subset else "n;")]
+    lines = [_PREAMBLE, "#include <stdlib.h>", kernel_src, *decls, f"int wrap_{kernel_name}({', '.join(sig)})", "{"]
+    if threads:
+        # shared-memory analogue of rank-local assembly + local_to_global SUM (pyop2/types/dat.py:659-678):
+        # contiguous entity ranges per thread, private output vectors summed afterwards
+        lines.append('  _Pragma("omp parallel")')
+        lines.append("  {")
+        for k, ct, n in priv:
+            lines.append(f"  {ct} *priv{k} = ({ct} *)calloc({n}, sizeof({ct}));")
+        lines.append('  _Pragma("omp for schedule(static)")')
+    lines += ["  for (int n = start; n < end; ++n) {",
+              "    int e = " + ("subset_indices[n];" if subset else "n;")]
     if extruded:
         lo, hi = {ALL: ("layers[0]", "layers[1]-1"),
                   ON_BOTTOM: ("layers[0]", "layers[0]+1"),
@@ -269,18 +281,26 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
     lines += ["      " + s for s in body_unpack]
     if extruded:
         lines.append("    }")
-    lines += ["  }", "  return 0;", "}"]
+    lines.append("  }")
+    if threads:
+        for k, ct, n in priv:
+            lines.append('  _Pragma("omp critical")')
+            lines.append(f"  for (long q = 0; q < {n}; ++q) arg{k}[q] += priv{k}[q];")
+            lines.append(f"  free(priv{k});")
+        lines.append("  }")
+    lines += ["  return 0;", "}"]
     return "\n".join(lines), [m for m, _ in maps]
 
 
 def par_loop(kernel_src: str, kernel_name: str, start: int, end: int, args, *,
              subset: Optional[np.ndarray] = None, layers: Optional[Tuple[int, int]] = None,
-             iteration_region=ALL, pass_layer_arg=False, cflags=None, return_fn=False):
+             iteration_region=ALL, pass_layer_arg=False, cflags=None, return_fn=False, threads=False):
     """Generate + compile + run the wrapper over [start, end).  Arrays are modified in place."""
     code, maps = generate_wrapper(kernel_src, kernel_name, args, subset=subset is not None,
                                   extruded=layers is not None, iteration_region=iteration_region,
-                                  pass_layer_arg=pass_layer_arg)
-    lib = compile_c(code, "wrap_" + kernel_name, extra_sources=[os.path.join(_HERE, "csr.c")], cflags=cflags)
+                                  pass_layer_arg=pass_layer_arg, threads=threads)
+    lib = compile_c(code, "wrap_" + kernel_name + ("_omp" if threads else ""), extra_sources=[os.path.join(_HERE, "csr.c")],
+                    cflags=cflags, threads=threads)
     fn = getattr(lib, "wrap_" + kernel_name)
     cargs = [ctypes.c_int(start), ctypes.c_int(end)]
     keep = []
