@@ -264,6 +264,8 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         return e
 
     pre, pack, call_args, unpack, post = [], [], [], [], []
+    node_actions = {}    # per staged map: [(load statements, LDS store statements)] templated on I_U / G_U
+    pack_gather = []     # staged READ gathers (arg, ctype, size, template) -- software-pipelined one entity ahead
     lds_decl, stage, flush, mat_stage_pre = [], [], [], []
 
     # LDS carving for staged args
@@ -302,14 +304,20 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             c, ar, mi = info["c"], info["ar"], info["m"]
             perm, off = info["perm"], info["off"]
             size = nf * ar * c
-            pack.append(f"{ct} t{k}[{size}];")
+            if not (staged and acc == READ and configuration["pipeline_packs"] and configuration["prefetch"]):
+                pack.append(f"{ct} t{k}[{size}];")
             if staged:
                 lds_items.append(("dat", mi, c, info["dtype"].itemsize))
                 lds_decl.append(f"{ct} *s{k} = ({ct} *)(fd_lds + fd_off); fd_off += (((size_t)p{mi}_maxnd*{c}*sizeof({ct})) + 15) & ~(size_t)15;")
                 if acc == READ:
-                    stage.append((mi, f"for (int q = tid; q < nd{mi}*{c}; q += nthr) {{ const int i = q / {c}; "
-                                      f"s{k}[q] = arg{k}[(size_t)p{mi}_list[l0_{mi} + i]*{c} + (q - i*{c})]; }}"))
-                    pack.append(f"for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j) t{k}[i*{c}+j] = s{k}[lm{mi}[{_permi(perm, 'i')}]*{c} + j];")
+                    node_actions.setdefault(mi, []).append(
+                        ([f"{ct} v{k}_U[{c}];", f"for (int j = 0; j < {c}; ++j) v{k}_U[j] = arg{k}[(size_t)G_U*{c} + j];"],
+                         [f"for (int j = 0; j < {c}; ++j) s{k}[I_U*{c} + j] = v{k}_U[j];"]))
+                    g = f"for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j) TT{k}[i*{c}+j] = s{k}[LM{mi}[{_permi(perm, 'i')}]*{c} + j];"
+                    if configuration["pipeline_packs"] and configuration["prefetch"]:
+                        pack_gather.append((k, ct, size, g))
+                    else:
+                        pack.append(g.replace(f"TT{k}", f"t{k}").replace(f"LM{mi}", f"lm{mi}"))
                 else:  # INC
                     stage.append((mi, f"for (int q = tid; q < nd{mi}*{c}; q += nthr) s{k}[q] = 0;"))
                     pack.append(f"for (int q = 0; q < {size}; ++q) t{k}[q] = 0;")
@@ -356,10 +364,11 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
                 stage.append((rm, f"for (int q = tid; q < nnzb{k}; q += nthr) sm{k}[q] = 0;"))
                 rowmask = f" && rlg{k}[g] >= 0" if lg else ""
                 colbit = (f" | ((clg{k}[g] < 0) ? 0x80000000u : 0u)" if (lg and cm == rm) else "")
-                stage.append((rm, f"for (int q = tid; q < nd{rm}; q += nthr) {{ const int g = p{rm}_list[l0_{rm} + q]; "
-                                  f"srow{k}[q] = ((g >= n0_{k} && g < n0_{k} + nown{k}{rowmask}) ? (unsigned)(oc{k}_rowptr[g] - r0_{k} + 1) : 0u){colbit}; }}"))
+                node_actions.setdefault(rm, []).append(
+                    ([f"const int g = G_U; const unsigned w{k}_U = ((g >= n0_{k} && g < n0_{k} + nown{k}{rowmask}) ? (unsigned)(oc{k}_rowptr[g] - r0_{k} + 1) : 0u){colbit};".replace("const int g = G_U; ", "").replace("(g ", "(G_U ").replace(" g ", " G_U ").replace("[g]", "[G_U]")],
+                     [f"srow{k}[I_U] = w{k}_U;"]))
                 if lg and cm != rm:
-                    stage.append((cm, f"for (int q = tid; q < nd{cm}; q += nthr) smc{k}[q] = clg{k}[p{cm}_list[l0_{cm} + q]] < 0;"))
+                    node_actions.setdefault(cm, []).append(([f"const bool m{k}_U = clg{k}[G_U] < 0;"], [f"smc{k}[I_U] = m{k}_U;"]))
                 lines = [f"unsigned int rw{k}[{ar}];", f"for (int i = 0; i < {ar}; ++i) rw{k}[i] = srow{k}[lm{rm}[i]];"]
                 if lg and cm != rm:
                     lines += [f"bool cmk{k}[{ac}];", f"for (int j = 0; j < {ac}; ++j) cmk{k}[j] = smc{k}[lm{cm}[j]];"]
@@ -454,11 +463,31 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
                 "  const int tid = threadIdx.x, nthr = blockDim.x;",
                 "  const int b = fdw::xcd_block(blockIdx.x, gridDim.x);",
                 "  const int e0 = bstart_[b], e1 = bstart_[b+1];"]
+        if configuration["stagger"]:
+            src.append(f"  if (blockIdx.x < 2048 && ((blockIdx.x >> 3) & 1)) {{ for (int w = 0; w < {int(configuration['stagger'])}; ++w) __builtin_amdgcn_s_sleep(127); }}")
         src += ["  " + s for s in lds_decl]
         for mi in staged_maps:
             src.append(f"  const int l0_{mi} = p{mi}_blkoff[b], nd{mi} = p{mi}_blkoff[b+1] - l0_{mi};")
         src += ["  " + s for s in mat_stage_pre]
         src += ["  " + s for _, s in stage]
+        # node-major staging, two nodes per lane and trip: both node-list entries are requested first, then all the
+        # rows that depend on them -- two dependent memory round trips per trip instead of one pair per value
+        UNR = max(1, int(configuration["stage_unroll"]))
+        for mi, acts in node_actions.items():
+            src.append(f"  for (int ia = tid; ia < nd{mi}; ia += {UNR}*nthr) {{")
+            for u in range(UNR):
+                src.append(f"    const int i_{u} = (ia + {u}*nthr < nd{mi}) ? ia + {u}*nthr : ia;")
+            for u in range(UNR):
+                src.append(f"    const int g_{u} = p{mi}_list[l0_{mi} + i_{u}];")
+            for u in range(UNR):
+                for loads, stores in acts:
+                    for l in loads:
+                        src.append("    " + l.replace("_U", f"_{u}").replace("G_" + str(u), f"g_{u}").replace("I_" + str(u), f"i_{u}"))
+            for u in range(UNR):
+                for loads, stores in acts:
+                    for l in stores:
+                        src.append("    " + l.replace("_U", f"_{u}").replace("G_" + str(u), f"g_{u}").replace("I_" + str(u), f"i_{u}"))
+            src.append("  }")
         src.append("  __syncthreads();")
         src += ["  " + s for s in pre]
         # software pipeline: the packed index rows of the NEXT entity are requested before the current
@@ -479,20 +508,44 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
                                   f"fdw::load_packed<{ktype}, {n}>(oc{k}_k + (size_t)(EE)*{n}, DST);"))
         pf = bool(configuration["prefetch"])
         ent_of = (lambda ii: f"inst_ent_[{ii}]") if ocr else (lambda ii: ii)
+        def gathers(tprefix, lmprefix):
+            out = []
+            for k, ct, size, g in pack_gather:
+                t = re.sub(r"TT(\d+)", lambda m: f"{tprefix}{m.group(1)}", g)
+                out.append(re.sub(r"LM(\d+)", lambda m: f"{lmprefix}{m.group(1)}", t))
+            return out
+        pp = pf and bool(pack_gather)       # two-deep pipeline: indices two entities ahead, LDS gathers one ahead
         if pf:
             for cur, nxt, name, n, ld in idx_loads:
-                src.append(f"  {cur}; {nxt};")
-            src.append("  int e_cur = 0;")
+                src.append(f"  {cur}; {nxt};" + (f" int nn_{name}[{n}];" if pp else ""))
+            for k, ct, size, g in pack_gather:
+                src.append(f"  {ct} t{k}[{size}], tn{k}[{size}];")
+            src.append("  int e_cur = 0, e_nx = 0;")
             src.append("  if (e0 + tid < e1) {")
             src.append(f"    e_cur = {ent_of('e0 + tid')};")
             for cur, nxt, name, n, ld in idx_loads:
                 src.append("    " + ld.replace("II", "(e0 + tid)").replace("EE", "e_cur").replace("DST", name))
+            if pp:
+                src.append("    const int it1 = (e0 + tid + nthr < e1) ? e0 + tid + nthr : e0 + tid;")
+                src.append(f"    e_nx = {ent_of('it1')};")
+                for cur, nxt, name, n, ld in idx_loads:
+                    src.append("    " + ld.replace("II", "it1").replace("EE", "e_nx").replace("DST", "nx_" + name))
+            src += ["    " + g for g in gathers("t", "lm")]
             src.append("  }")
-        src.append("  for (int it = e0 + tid; it < e1; it += nthr) {")
-        if pf:
+        src.append("  for (int it = e0 + tid; it < e1; it += nthr) {" if not configuration["debug_noloop"] else "  for (int it = e1; it < e1; it += nthr) {")
+        if pp:
+            src.append("    const int e = e_cur;")
+            src.append("    const int it2 = (it + 2*nthr < e1) ? it + 2*nthr : it;")
+            src.append(f"    const int e_nn = {ent_of('it2')};")
+            for cur, nxt, name, n, ld in idx_loads:
+                src.append("    " + ld.replace("II", "it2").replace("EE", "e_nn").replace("DST", "nn_" + name))
+            # LDS gathers for the NEXT entity are issued before this entity's local kernel: ds_read latency and
+            # LDS-pipe time overlap the ~10^2 fp64 VALU instructions of the kernel inside the same wavefront
+            src += ["    " + g for g in gathers("tn", "nx_lm")]
+        elif pf:
             src.append("    const int e = e_cur;")
             src.append("    const int itn = (it + nthr < e1) ? it + nthr : it;")
-            src.append(f"    const int e_nx = {ent_of('itn')};")
+            src.append(f"    e_nx = {ent_of('itn')};")
             for cur, nxt, name, n, ld in idx_loads:
                 src.append("    " + ld.replace("II", "itn").replace("EE", "e_nx").replace("DST", "nx_" + name))
         else:
@@ -505,7 +558,11 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         if pf:
             for cur, nxt, name, n, ld in idx_loads:
                 src.append(f"    for (int q = 0; q < {n}; ++q) {name}[q] = nx_{name}[q];")
-            src.append("    e_cur = e_nx;")
+                if pp:
+                    src.append(f"    for (int q = 0; q < {n}; ++q) nx_{name}[q] = nn_{name}[q];")
+            for k, ct, size, g in pack_gather:
+                src.append(f"    for (int q = 0; q < {size}; ++q) t{k}[q] = tn{k}[q];")
+            src.append("    e_cur = e_nx;" + (" e_nx = e_nn;" if pp else ""))
         src.append("  }")
         if flush and not configuration["debug_noflush"]:
             src.append("  __syncthreads();")
