@@ -310,10 +310,12 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
                 lds_items.append(("dat", mi, c, info["dtype"].itemsize))
                 lds_decl.append(f"{ct} *s{k} = ({ct} *)(fd_lds + fd_off); fd_off += (((size_t)p{mi}_maxnd*{c}*sizeof({ct})) + 15) & ~(size_t)15;")
                 if acc == READ:
+                    soa = bool(configuration["lds_soa"]) and c > 1
                     node_actions.setdefault(mi, []).append(
                         ([f"{ct} v{k}_U[{c}];", f"for (int j = 0; j < {c}; ++j) v{k}_U[j] = arg{k}[(size_t)G_U*{c} + j];"],
-                         [f"for (int j = 0; j < {c}; ++j) s{k}[I_U*{c} + j] = v{k}_U[j];"]))
-                    g = f"for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j) TT{k}[i*{c}+j] = s{k}[LM{mi}[{_permi(perm, 'i')}]*{c} + j];"
+                         [f"for (int j = 0; j < {c}; ++j) s{k}[{'j*(int)p%d_maxnd + I_U' % mi if soa else 'I_U*%d + j' % c}] = v{k}_U[j];"]))
+                    idx = f"j*(int)p{mi}_maxnd + LM{mi}[{_permi(perm, 'i')}]" if soa else f"LM{mi}[{_permi(perm, 'i')}]*{c} + j"
+                    g = f"for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j) TT{k}[i*{c}+j] = s{k}[{idx}];"
                     if configuration["pipeline_packs"] and configuration["prefetch"]:
                         pack_gather.append((k, ct, size, g))
                     else:

@@ -24,6 +24,7 @@ configuration = {
     "pipeline_packs": _env("FDHIP_PIPELINE_PACKS", 0, int),  # gather the next entity's packs from LDS one iteration ahead
     "stage_unroll": _env("FDHIP_STAGE_UNROLL", 1, int),   # nodes staged per lane per trip (memory-level parallelism)
     "stagger": _env("FDHIP_STAGGER", 0, int),             # experiment: delay (x ~4 us) for every other workgroup of the first dispatch wave
+    "lds_soa": _env("FDHIP_LDS_SOA", 1, int),             # component-major LDS layout for staged vector Dats
     "prefetch": _env("FDHIP_PREFETCH", 1, int),          # software-pipeline the packed index rows
     "mat_ocr": _env("FDHIP_MAT_OCR", 1, int),             # owner-computes-rows matrix assembly (no global atomics)
     "ocr_nnz_per_block": _env("FDHIP_OCR_NNZ", 2048, int),  # row-block size (CSR entries) when the producer gives no hint
