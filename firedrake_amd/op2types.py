@@ -632,6 +632,37 @@ class PermutedMap(Map):
         return self.map_._base()
 
 
+class ComposedMap(Map):
+    """pyop2/types/map.py:206-270: ``local[i] = global[maps_[0][maps_[1][maps_[2][...]]][i]]`` with the inner maps of
+    arity 1.  The reference indexes through the chain inside the generated wrapper (builder.py:179-198); here the
+    chain is composed once on the host into an ordinary (iterset, arity) table -- a lossless re-encoding, so the
+    wrapper kernels see a plain Map.  Undefined (negative) intermediate entries give a row of VALUE_UNDEFINED."""
+
+    def __init__(self, *maps_, name=None):
+        flat = []
+        for m in maps_:
+            if not isinstance(m, Map):
+                raise TypeError("All maps must be Map instances")
+            flat.extend(m.maps_ if isinstance(m, ComposedMap) else [m])
+        for tomap, frommap in zip(flat[:-1], flat[1:]):
+            if tomap.iterset.superset is not frommap.toset.superset and tomap.iterset is not frommap.toset:
+                raise MapValueError("tomap.iterset must match frommap.toset")
+            if frommap.arity != 1:
+                raise MapValueError("frommap.arity must be 1")
+        self.maps_ = tuple(flat)
+        first = flat[0]
+        rows = first.values_with_halo
+        if isinstance(first, PermutedMap):
+            rows = first.map_.values_with_halo[:, first.permutation]
+        idx = None
+        for m in reversed(flat[1:]):
+            v = m.values_with_halo[:, 0]
+            idx = v if idx is None else np.where(idx >= 0, v[np.maximum(idx, 0)], -1)
+        vals = np.where((idx >= 0)[:, None], rows[np.maximum(idx, 0)], self.VALUE_UNDEFINED).astype(IntType)
+        super().__init__(flat[-1].iterset, first.toset, first.arity, vals, name or f"cmap_{id(self):x}",
+                         offset=first.offset)
+
+
 class Plan:
     """Python handle on an fd_plan_t."""
 

@@ -362,3 +362,42 @@ def test_extruded_mat_and_interior_facets():
         op2.par_loop(kb, ext, d2(op2.INC, m), iteration_region=reg)
         o2 = oracle_run(kb, ext, op2.Dat(nodes)(op2.INC, m), iteration_region=reg)[0]
         assert_allclose(d2.data, o2)
+
+
+# ---- composed maps (tests/pyop2/test_indirect_loop.py:320-380) ------------------------------------
+@pytest.mark.parametrize("permuted", ["none", "pre"])
+def test_composed_map_two_maps(permuted):
+    setB, nodesetB = op2.Set(3), op2.Set(6)
+    datB = op2.Dat(op2.DataSet(nodesetB, 1), dtype=np.float64)
+    mapB = op2.Map(setB, nodesetB, 2, values=[[0, 1], [2, 3], [4, 5]])
+    setA, nodesetA = op2.Set(5), op2.Set(8)
+    datA = op2.Dat(op2.DataSet(nodesetA, 1), np.array([.0, .1, .2, .3, .4, .5, .6, .7]))
+    mapA0 = op2.Map(setA, nodesetA, 2, values=[[0, 1], [2, 3], [4, 5], [6, 7], [0, 1]])
+    if permuted == "pre":
+        mapA0 = op2.PermutedMap(mapA0, [1, 0])
+    mapA = op2.ComposedMap(mapA0, op2.Map(setB, setA, 1, values=[3, 1, 2]))
+    k = op2.Kernel("void copy2(double *to, const double * restrict from) { for (int i = 0; i < 2; ++i) { to[i] = from[i]; } }", "copy2")
+    op2.par_loop(k, setB, datB(op2.WRITE, mapB), datA(op2.READ, mapA))
+    expect = [.6, .7, .2, .3, .4, .5] if permuted == "none" else [.7, .6, .3, .2, .5, .4]
+    assert (datB.data == np.array(expect)).all()
+
+
+@pytest.mark.parametrize("nested", ["none", "first", "last"])
+@pytest.mark.parametrize("subset", [False, True])
+def test_composed_map_three_maps(nested, subset):
+    setC, nodesetC = op2.Set(2), op2.Set(4)
+    datC = op2.Dat(op2.DataSet(nodesetC, 1), dtype=np.float64)
+    mapC = op2.Map(setC, nodesetC, 2, values=[[0, 1], [2, 3]])
+    setB, setA, nodesetA = op2.Set(3), op2.Set(5), op2.Set(8)
+    datA = op2.Dat(op2.DataSet(nodesetA, 1), np.array([.0, .1, .2, .3, .4, .5, .6, .7]))
+    mapA0 = op2.Map(setA, nodesetA, 2, values=[[0, 1], [2, 3], [4, 5], [6, 7], [0, 1]])
+    mapA1 = op2.Map(setB, setA, 1, values=[3, 1, 2])
+    mapA2 = op2.Map(setC, setB, 1, values=[2, 0])
+    mapA = {"none": lambda: op2.ComposedMap(mapA0, mapA1, mapA2),
+            "first": lambda: op2.ComposedMap(op2.ComposedMap(mapA0, mapA1), mapA2),
+            "last": lambda: op2.ComposedMap(mapA0, op2.ComposedMap(mapA1, mapA2))}[nested]()
+    k = op2.Kernel("void copy2(double *to, const double * restrict from) { for (int i = 0; i < 2; ++i) { to[i] = from[i]; } }", "copy2")
+    it = op2.Subset(setC, np.array([1], dtype=np.int32)) if subset else setC
+    op2.par_loop(k, it, datC(op2.WRITE, mapC), datA(op2.READ, mapA))
+    expect = [.0, .0, .6, .7] if subset else [.4, .5, .6, .7]
+    assert (datC.data == np.array(expect)).all()

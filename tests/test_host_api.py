@@ -97,3 +97,18 @@ def test_wrong_dtype_rejected():
     gk = GlobalKernel(k, [DatKernelArg((1,))])
     with pytest.raises(ValueError):             # pyop2/parloop.py:182-185
         op2.Parloop(gk, s, [op2.DatParloopArg(d)])
+
+
+def test_composed_map_tables():
+    # tests/pyop2/test_indirect_loop.py:320-380 (expected gathers .6,.7,.2,.3,.4,.5 / .4,.5,.6,.7)
+    setB, setA, nodesetA, setC = op2.Set(3), op2.Set(5), op2.Set(8), op2.Set(2)
+    mapA0 = op2.Map(setA, nodesetA, 2, values=[[0, 1], [2, 3], [4, 5], [6, 7], [0, 1]])
+    mapA1 = op2.Map(setB, setA, 1, values=[3, 1, 2])
+    mapA2 = op2.Map(setC, setB, 1, values=[2, 0])
+    assert op2.ComposedMap(mapA0, mapA1).values.tolist() == [[6, 7], [2, 3], [4, 5]]
+    assert op2.ComposedMap(op2.PermutedMap(mapA0, [1, 0]), mapA1).values.tolist() == [[7, 6], [3, 2], [5, 4]]
+    for m in (op2.ComposedMap(mapA0, mapA1, mapA2), op2.ComposedMap(op2.ComposedMap(mapA0, mapA1), mapA2),
+              op2.ComposedMap(mapA0, op2.ComposedMap(mapA1, mapA2))):
+        assert m.values.tolist() == [[4, 5], [6, 7]] and m.iterset is setC and m.toset is nodesetA
+    with pytest.raises(op2.MapValueError):
+        op2.ComposedMap(mapA0, mapA0)          # inner maps must have arity 1 / matching sets
