@@ -129,6 +129,42 @@ def run_c3(args):
     print(json.dumps(out))
 
 
+def run_c1(args):
+    """BASELINE.json configs[0]: Poisson CG1 on UnitSquareMesh(64,64) -- launch-bound on a GPU; eager vs hipGraph replay."""
+    from firedrake_amd import _lib, forms, mesh as fmesh
+    from firedrake_amd.graph import CapturedStep
+    _lib.require_gpu()
+    prob = forms.PoissonProblem(fmesh.UnitSquareMesh(64, 64, perturb=0.1), 1, bcs=True)
+
+    def step():
+        prob.assemble_residual()
+        prob.assemble_jacobian()
+
+    for _ in range(max(args.warmup, 2)):
+        step()
+    _lib.call("fd_device_sync")
+    n = max(args.steps, 200)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    _lib.call("fd_device_sync")
+    eager = (time.perf_counter() - t0) / n
+    g = CapturedStep(step)
+    g(); g.sync()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        g()
+    g.sync()
+    graph = (time.perf_counter() - t0) / n
+    nd = prob.V.node_set.size
+    print(json.dumps({"metric": "assembled DoFs/sec (residual + Jacobian)", "value": nd / graph, "unit": "DoFs/s", "n_gpus": 1,
+                      "steps": n, "warmup": args.warmup, "ms_per_step": graph * 1e3, "higher_is_better": True, "scaling": "weak",
+                      "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                      "config": {"workload": "Poisson CG1 residual+Jacobian on UnitSquareMesh(64,64) (BASELINE.json configs[0]), hipGraph replay",
+                                 "cells": 8192, "dofs": nd},
+                      "eager_ms_per_step": eager * 1e3, "graph_ms_per_step": graph * 1e3, "roofline": None, "cpu_baseline": None}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,11 +176,15 @@ def main():
     ap.add_argument("--no-bcs", action="store_true")
     ap.add_argument("--tile", type=str, default="8,4,4", help="cubes per traversal tile (= plan block)")
     ap.add_argument("--only", choices=["both", "residual", "jacobian"], default="both", help="profiling aid: run one form only")
-    ap.add_argument("--workload", choices=["c2", "c3"], default="c2", help="c2 = headline config (default); c3 = Q4 hex MFMA")
+    ap.add_argument("--workload", choices=["c1", "c2", "c3"], default="c2",
+                    help="c2 = headline config (default); c1 = launch-bound 64x64 square (eager vs hipGraph); c3 = Q4 hex MFMA")
     args = ap.parse_args()
     if args.workload == "c3":
         import torch  # noqa: F401
         return run_c3(args)
+    if args.workload == "c1":
+        import torch  # noqa: F401
+        return run_c1(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -43,6 +43,11 @@ SIGNATURES = {
     "fd_event_record": (c_int, [c_void_p, c_void_p]),
     "fd_event_sync": (c_int, [c_void_p]),
     "fd_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
+    "fd_graph_begin": (c_int, [POINTER(c_void_p)]),
+    "fd_graph_end": (c_int, [c_void_p]),
+    "fd_graph_launch": (c_int, [c_void_p, c_void_p]),
+    "fd_graph_sync": (c_int, [c_void_p]),
+    "fd_graph_free": (c_int, [c_void_p]),
     "fd_kernel_load": (c_int, [c_char_p, c_char_p, POINTER(c_void_p)]),
     "fd_kernel_builtin": (c_int, [c_char_p, POINTER(c_void_p)]),
     "fd_kernel_free": (c_int, [c_void_p]),

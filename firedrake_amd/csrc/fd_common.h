@@ -8,7 +8,10 @@
 
 namespace fd {
 void set_error(const std::string &msg);
-inline hipStream_t st(fd_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+// A NULL stream argument means "the library's default stream": the HIP null stream, or the capturing
+// stream while a hipGraph of an assembly step is being recorded (fd_graph_begin).
+hipStream_t default_stream();
+inline hipStream_t st(fd_stream_t s) { return s ? reinterpret_cast<hipStream_t>(s) : default_stream(); }
 }  // namespace fd
 
 #define FD_HIP(call)                                                                   \

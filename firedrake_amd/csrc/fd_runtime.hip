@@ -8,6 +8,8 @@
 #include <vector>
 
 namespace fd {
+static hipStream_t g_default_stream = nullptr;
+hipStream_t default_stream() { return g_default_stream; }
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
 
@@ -23,6 +25,7 @@ struct fd_kernel_s {
     size_t max_lds_set = 0;
 };
 struct fd_event_s { hipEvent_t ev; };
+struct fd_graph_s { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; hipStream_t stream = nullptr; };
 
 extern "C" {
 
@@ -61,6 +64,49 @@ int fd_event_destroy(fd_event_t e) { if (e) { FD_HIP(hipEventDestroy(e->ev)); de
 int fd_event_record(fd_event_t e, fd_stream_t s) { FD_HIP(hipEventRecord(e->ev, fd::st(s))); return 0; }
 int fd_event_sync(fd_event_t e) { FD_HIP(hipEventSynchronize(e->ev)); return 0; }
 int fd_event_elapsed_ms(fd_event_t a, fd_event_t b, float *ms) { FD_HIP(hipEventElapsedTime(ms, a->ev, b->ev)); return 0; }
+
+// ---- hipGraph capture of a launch-bound assembly step (small meshes: Python + launch overhead dominates,
+// SURVEY.md 7 hard part (f)).  Between begin and end every libfdhip call that takes a NULL stream records
+// into the graph instead of executing.
+int fd_graph_begin(fd_graph_t *out) {
+    auto *g = new fd_graph_s;
+    hipError_t r = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+    if (r != hipSuccess) { delete g; FD_HIP(r); }
+    r = hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal);
+    if (r != hipSuccess) { (void)hipStreamDestroy(g->stream); delete g; FD_HIP(r); }
+    fd::g_default_stream = g->stream;
+    *out = g;
+    return 0;
+}
+
+int fd_graph_end(fd_graph_t g) {
+    fd::g_default_stream = nullptr;
+    if (!g) FD_FAIL("fd_graph_end: null graph");
+    FD_HIP(hipStreamEndCapture(g->stream, &g->graph));
+    FD_HIP(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0));
+    return 0;
+}
+
+int fd_graph_launch(fd_graph_t g, fd_stream_t s) {
+    if (!g || !g->exec) FD_FAIL("fd_graph_launch: graph not instantiated");
+    FD_HIP(hipGraphLaunch(g->exec, s ? fd::st(s) : g->stream));
+    return 0;
+}
+
+int fd_graph_sync(fd_graph_t g) {
+    if (!g) FD_FAIL("fd_graph_sync: null graph");
+    FD_HIP(hipStreamSynchronize(g->stream));
+    return 0;
+}
+
+int fd_graph_free(fd_graph_t g) {
+    if (!g) return 0;
+    if (g->exec) FD_HIP(hipGraphExecDestroy(g->exec));
+    if (g->graph) FD_HIP(hipGraphDestroy(g->graph));
+    if (g->stream) FD_HIP(hipStreamDestroy(g->stream));
+    delete g;
+    return 0;
+}
 
 int fd_kernel_load(const char *path, const char *symbol, fd_kernel_t *out) {
     auto *k = new fd_kernel_s;

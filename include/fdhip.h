@@ -62,6 +62,17 @@ int fd_event_record(fd_event_t e, fd_stream_t s);
 int fd_event_sync(fd_event_t e);
 int fd_event_elapsed_ms(fd_event_t start, fd_event_t stop, float *ms);
 
+/* hipGraph capture of one assembly step.  Between fd_graph_begin and fd_graph_end every entry point called with
+ * a NULL stream records into the graph instead of executing; fd_graph_launch then replays the whole step
+ * (zeroing, wrapper kernels, BC fix-up) with one host call.  For launch-bound problem sizes (config C1), where
+ * the reference pays Python + ctypes overhead per parloop (pyop2/parloop.py:203-232). */
+typedef struct fd_graph_s *fd_graph_t;
+int fd_graph_begin(fd_graph_t *out);
+int fd_graph_end(fd_graph_t g);
+int fd_graph_launch(fd_graph_t g, fd_stream_t s);   /* s = NULL: the graph's own stream */
+int fd_graph_sync(fd_graph_t g);
+int fd_graph_free(fd_graph_t g);
+
 /* ------------------------------------------------- wrapper kernels (the hot loop)
  * Replaces  compilation.load(...) -> ctypes.CDLL -> wrap_<kernel>  of
  * pyop2/global_kernel.py:426-456 / pyop2/compilation.py:424-455.
