@@ -29,11 +29,12 @@ FD_REGISTER(wrap_fd_axpy);
 // G_q = w_q |J| J^-1 J^-T, m_q = w_q |J| (cell dependent).  K = 4 per quadrature point is exactly the K of
 // v_mfma_f64_16x16x4_f64: one MFMA updates a 16x16 tile of A_e with one quadrature point.
 //
-// One workgroup (4 wavefronts) per cell; wavefront w owns the row panel i in [32w, 32w+32) of the (padded
-// 128 x 128) element matrix: 2 x 8 tiles = 128 accumulator registers.  Per quadrature point a lane builds
-// 2 A-operands ((W Phi)^T for its two row tiles) and 8 B-operands (Phi for the eight column tiles) from
-// LDS-resident 1-D tables and the per-cell W (7 doubles/point, precomputed by the whole workgroup), then
-// issues 16 MFMAs.  Finally each lane scatters its 64 accumulator values with fp64 atomics through the
+// Two workgroups (4 wavefronts each) per cell; wavefront w of half h owns the 16-row panel i in
+// [16(4h+w), 16(4h+w)+16) of the (padded 128 x 128) element matrix: 1 x 8 tiles = 64 accumulator registers, so
+// three wavefronts fit per SIMD and one wavefront's operand preparation / scatter overlaps another's MFMAs.
+// Per quadrature point a lane builds 1 A-operand ((W Phi)^T for its row tile) and 8 B-operands (Phi for the eight
+// column tiles) from LDS-resident 1-D tables and the per-cell W (7 doubles/point, computed by the workgroup),
+// then issues 8 MFMAs.  Finally each lane scatters its 32 accumulator values with fp64 atomics through the
 // element->nonzero table (MatSetValuesLocal ADD_VALUES of the 125 x 125 block, builder.py:573-625).
 // Roofline: fp64 MFMA; 2*128*128*4*125 = 16.4 MFLOP per cell.
 // =====================================================================================
@@ -56,7 +57,7 @@ __device__ __forceinline__ void inv3(const double J[3][3], double K[3][3], doubl
 
 // tables: L[5][5] (value of 1-D basis i at Gauss point q: L[q*5+i]), DL[5][5], QP[5], QW[5]  (60 doubles)
 // args after (start, end): layers, values, coords, map_q4 (unused: positions come from elemtab), map_q1, elemtab, tables
-extern "C" __global__ __launch_bounds__(256, 1)
+extern "C" __global__ __launch_bounds__(256, 3)
 void wrap_helmholtz_q4_hex_jacobian(int start, int end, const int *__restrict__ layers, double *__restrict__ vals,
                                     const double *__restrict__ coords, const int *__restrict__ map_q4,
                                     const int *__restrict__ map_q1, const int *__restrict__ elemtab,
@@ -66,8 +67,9 @@ void wrap_helmholtz_q4_hex_jacobian(int start, int end, const int *__restrict__ 
     __shared__ double sW[125][8];          // G00 G01 G02 G11 G12 G22 m pad
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nl = layers[1] - 1 - layers[0];
-    const int col = start + blockIdx.x / nl;
-    const int layer = layers[0] + blockIdx.x % nl;
+    const int cellid = blockIdx.x >> 1, half = blockIdx.x & 1;
+    const int col = start + cellid / nl;
+    const int layer = layers[0] + cellid % nl;
     if (col >= end) return;
     if (tid < 25) { sL[tid] = tables[tid]; sDL[tid] = tables[25 + tid]; }
     if (tid < 5) { sQP[tid] = tables[50 + tid]; sQW[tid] = tables[55 + tid]; }
@@ -108,13 +110,13 @@ void wrap_helmholtz_q4_hex_jacobian(int start, int end, const int *__restrict__ 
     __syncthreads();
     // ---- lane roles
     const int r16 = lane & 15, kk = lane >> 4;             // row/col inside a tile, MFMA k index (channel)
-    int i1[2], i2[2], i3[2]; bool iv[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int i = (2 * wave + t) * 16 + r16;
-        iv[t] = i < Q4_ND;
-        const int ic = iv[t] ? i : 0;
-        i1[t] = ic / 25; i2[t] = (ic / 5) % 5; i3[t] = ic % 5;
+    const int itile = half * 4 + wave;
+    int i1, i2, i3; bool iv;
+    {
+        const int i = itile * 16 + r16;
+        iv = i < Q4_ND;
+        const int ic = iv ? i : 0;
+        i1 = ic / 25; i2 = (ic / 5) % 5; i3 = ic % 5;
     }
     int j1[8], j2[8], j3[8]; bool jv[8];
 #pragma unroll
@@ -128,41 +130,33 @@ void wrap_helmholtz_q4_hex_jacobian(int start, int end, const int *__restrict__ 
     const double *tabx = kk == 0 ? sDL : sL, *taby = kk == 1 ? sDL : sL, *tabz = kk == 2 ? sDL : sL;
     // index of W_q entries forming row kk of G: (kk,0) (kk,1) (kk,2)
     const int g0 = kk == 0 ? 0 : (kk == 1 ? 1 : 2), g1 = kk == 0 ? 1 : (kk == 1 ? 3 : 4), g2 = kk == 0 ? 2 : (kk == 1 ? 4 : 5);
-    fd_d4 acc[2][8];
+    fd_d4 acc[8];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b) acc[a][b] = fd_d4{0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < 8; ++b) acc[b] = fd_d4{0.0, 0.0, 0.0, 0.0};
 
+#pragma unroll 1
     for (int q1 = 0; q1 < Q4_NQ1; ++q1) {
+#pragma unroll 1
         for (int q2 = 0; q2 < Q4_NQ1; ++q2) {
             double bxy[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) bxy[t] = jv[t] ? tabx[q1 * 5 + j1[t]] * taby[q2 * 5 + j2[t]] : 0.0;
-            double ax[2], ay[2], axy[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const double lx = sL[q1 * 5 + i1[t]], dx = sDL[q1 * 5 + i1[t]];
-                const double ly = sL[q2 * 5 + i2[t]], dy = sDL[q2 * 5 + i2[t]];
-                ax[t] = iv[t] ? dx * ly : 0.0;      // d/dxi1 part
-                ay[t] = iv[t] ? lx * dy : 0.0;      // d/dxi2 part
-                axy[t] = iv[t] ? lx * ly : 0.0;     // value in (xi1, xi2)
-            }
+            const double lx = sL[q1 * 5 + i1], dx = sDL[q1 * 5 + i1];
+            const double ly = sL[q2 * 5 + i2], dy = sDL[q2 * 5 + i2];
+            const double ax = iv ? dx * ly : 0.0;      // d/dxi1 part
+            const double ay = iv ? lx * dy : 0.0;      // d/dxi2 part
+            const double axy = iv ? lx * ly : 0.0;     // value in (xi1, xi2)
+#pragma unroll 1
             for (int q3 = 0; q3 < Q4_NQ1; ++q3) {
                 const int q = (q1 * 5 + q2) * 5 + q3;
                 const double w0 = sW[q][g0], w1 = sW[q][g1], w2 = sW[q][g2], wm = sW[q][6];
-                double aop[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const double lz = sL[q3 * 5 + i3[t]], dz = sDL[q3 * 5 + i3[t]];
-                    const double d0 = ax[t] * lz, d1 = ay[t] * lz, d2 = axy[t] * dz, ph = axy[t] * lz;
-                    aop[t] = kk < 3 ? (w0 * d0 + w1 * d1 + w2 * d2) : wm * ph;
-                }
+                const double lz = sL[q3 * 5 + i3], dz = sDL[q3 * 5 + i3];
+                const double d0 = ax * lz, d1 = ay * lz, d2 = axy * dz, ph = axy * lz;
+                const double aop = kk < 3 ? (w0 * d0 + w1 * d1 + w2 * d2) : wm * ph;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     const double bop = bxy[t] * tabz[q3 * 5 + j3[t]];
-                    acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[0], bop, acc[0][t], 0, 0, 0);
-                    acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[1], bop, acc[1][t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc[t], 0, 0, 0);
                 }
             }
         }
@@ -170,18 +164,15 @@ void wrap_helmholtz_q4_hex_jacobian(int start, int end, const int *__restrict__ 
     // ---- scatter: C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4*reg
     const int *tab = elemtab + ((size_t)(col - start) * nl + (layer - layers[0])) * (Q4_ND * Q4_ND);
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+    for (int g = 0; g < 4; ++g) {
+        const int i = itile * 16 + kk + 4 * g;
+        if (i >= Q4_ND) continue;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int i = (2 * wave + a) * 16 + kk + 4 * g;
-            if (i >= Q4_ND) continue;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int j = t * 16 + r16;
-                if (j >= Q4_ND) continue;
-                const int pos = tab[i * Q4_ND + j];
-                if (pos >= 0) atomicAdd(&vals[pos], acc[a][t][g]);
-            }
+        for (int t = 0; t < 8; ++t) {
+            const int j = t * 16 + r16;
+            if (j >= Q4_ND) continue;
+            const int pos = tab[i * Q4_ND + j];
+            if (pos >= 0) atomicAdd(&vals[pos], acc[t][g]);
         }
     }
 }

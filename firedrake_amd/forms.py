@@ -548,7 +548,8 @@ class HelmholtzQ4Problem:
                 m.coord_map._dev_values(), self._elemtab.ptr, self.tables.ptr]
         arr = (ctypes.c_void_p * len(args))(*[ctypes.c_void_p(a) for a in args])
         ncol = m.base_set.size
-        _lib.call("fd_kernel_launch", self.kernel, 0, ncol, arr, len(args), 256, 1, ncol * m.layers, 0, None)
+        # two workgroups per cell (each owns 64 of the 128 padded rows of the element matrix)
+        _lib.call("fd_kernel_launch", self.kernel, 0, ncol, arr, len(args), 256, 1, 2 * ncol * m.layers, 0, None)
         self.mat.dat_version += 1
         return self.mat
 
