@@ -600,6 +600,8 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         src.append("  }")
         src += ["  " + s for s in post]
     src.append("}")
+    if configuration["debug_noatomic"]:
+        src = [re.sub(r"atomicAdd\(&(s[m]?\d+\[[^;]*?\]), (t\d+\[[^;]*?\])\);", r"\1 = \2;", l) for l in src]
     return WrapperSource("\n".join(src) + "\n", sym, mode, layout, len(maps), staged_maps, lds_items,
                          layer_parallel, threads, kbytes, mat_staged)
 

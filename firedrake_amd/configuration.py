@@ -31,6 +31,7 @@ configuration = {
     "ocr_block_threads": _env("FDHIP_OCR_BLOCK_THREADS", 0, int),  # 0 = same as block_threads
     "ocr_interleave": _env("FDHIP_OCR_INTERLEAVE", 1, int),  # lane <-> instance stride inside a block (1 = none)
     "mat_exclusive": _env("FDHIP_MAT_EXCLUSIVE", 0, int),  # non-atomic writes + fused zero for block-exclusive nonzeros
+    "debug_noatomic": _env("FDHIP_DEBUG_NOATOMIC", 0, int),  # experiment: plain LDS store instead of ds_add (WRONG results)
     "debug_noloop": _env("FDHIP_DEBUG_NOLOOP", 0, int),    # experiment: skip the entity loop (WRONG results)
     "debug_noflush": _env("FDHIP_DEBUG_NOFLUSH", 0, int),  # experiment: skip the global flush (WRONG results)
     "min_waves": _env("FDHIP_MIN_WAVES", 0, int),       # 2nd __launch_bounds__ argument (waves per SIMD), 0 = unset
