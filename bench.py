@@ -293,7 +293,7 @@ def main():
             "roofline": dominant, "roofline_residual": roof_res, "roofline_jacobian": roof_jac,
             "setup_s": {"mesh": t_mesh, "sparsity_and_tables": t_sparsity},
         }
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:       # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.degree)
         else:
             out["cpu_baseline"] = None

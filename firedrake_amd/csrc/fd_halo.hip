@@ -55,6 +55,11 @@ __global__ void copy_rows(double *__restrict__ dst, const double *__restrict__ s
     }
 }
 
+__global__ void axpby_k(double *__restrict__ y, double a, const double *__restrict__ x, double b, int64_t n) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+        y[t] = a * x[t] + b * y[t];
+}
+
 inline int grid_for(int64_t n) { int64_t g = (n + 255) / 256; if (g < 1) g = 1; if (g > 8192) g = 8192; return (int)g; }
 
 }  // namespace
@@ -79,6 +84,13 @@ int fd_halo_unpack(double *dat, int cdim, const int32_t *idx, int32_t n, const d
 int fd_dat_set_rows(double *dat, int cdim, const int32_t *rows, int32_t n, double v, fd_stream_t s) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(set_rows, dim3(grid_for((int64_t)n * cdim)), dim3(256), 0, fd::st(s), dat, cdim, rows, n, v);
+    FD_CHECK_LAUNCH();
+    return 0;
+}
+
+int fd_dat_axpby(double *y, double a, const double *x, double b, int64_t n, fd_stream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(axpby_k, dim3(grid_for(n)), dim3(256), 0, fd::st(s), y, a, x, b, n);
     FD_CHECK_LAUNCH();
     return 0;
 }

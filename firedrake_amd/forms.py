@@ -700,3 +700,103 @@ class DGAdvectionProblem:
             for loop in self.loops:
                 loop()
         return self.L
+
+
+def dg_mass_solve_kernel(nq=2):
+    """dq = M_e^{-1} L_e on one DQ1 cell (the DG mass matrix is block diagonal, so the demo's
+    ``LinearVariationalSolver(a, L)`` with bjacobi/ilu is an exact cell-local solve).
+    Arguments: dq[4] (WRITE), coords[8], L[4]."""
+    from numpy.polynomial import legendre as leg
+    x, w = leg.leggauss(nq)
+    x, w = 0.5 * (x + 1.0), 0.5 * w
+    body = f"""
+{_QUAD_GEOM}
+static void dg_mass_solve(double *restrict dq, const double *restrict xc, const double *restrict L)
+{{
+  static const double QP[{nq}] = {_c(x)}; static const double QW[{nq}] = {_c(w)};
+  double M[4][5];
+  for (int i = 0; i < 4; ++i) {{ for (int j = 0; j < 4; ++j) M[i][j] = 0.0; M[i][4] = L[i]; }}
+  for (int a = 0; a < {nq}; ++a) for (int b = 0; b < {nq}; ++b) {{
+    const double s = QP[a], t = QP[b];
+    FD_QGEOM(xc, s, t)
+    const double wq = QW[a]*QW[b]*fabs(det);
+    (void)K00; (void)K01; (void)K10; (void)K11;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) M[i][j] += wq*N[i]*N[j];
+  }}
+  for (int c = 0; c < 4; ++c) {{                 /* Gauss-Jordan on the SPD 4x4 block */
+    const double ip = 1.0 / M[c][c];
+    for (int j = c; j < 5; ++j) M[c][j] *= ip;
+    for (int r = 0; r < 4; ++r) if (r != c) {{
+      const double fct = M[r][c];
+      for (int j = c; j < 5; ++j) M[r][j] -= fct*M[c][j];
+    }}
+  }}
+  for (int i = 0; i < 4; ++i) dq[i] = M[i][4];
+}}
+"""
+    return op2.Kernel(body, "dg_mass_solve")
+
+
+def dg_integrals_kernel(nq=3):
+    """Zero-forms of the regression test (tests/firedrake/regression/test_dg_advection.py:60-72):
+    g[0] += int q dx, g[1] += int q^2 dx.  Arguments: g[2] (Global INC), coords[8], q[4]."""
+    from numpy.polynomial import legendre as leg
+    x, w = leg.leggauss(nq)
+    x, w = 0.5 * (x + 1.0), 0.5 * w
+    body = f"""
+{_QUAD_GEOM}
+static void dg_integrals(double *restrict g, const double *restrict xc, const double *restrict qd)
+{{
+  static const double QP[{nq}] = {_c(x)}; static const double QW[{nq}] = {_c(w)};
+  for (int a = 0; a < {nq}; ++a) for (int b = 0; b < {nq}; ++b) {{
+    const double s = QP[a], t = QP[b];
+    FD_QGEOM(xc, s, t)
+    (void)K00; (void)K01; (void)K10; (void)K11;
+    double qq = 0.0;
+    for (int v = 0; v < 4; ++v) qq += qd[v]*N[v];
+    const double wq = QW[a]*QW[b]*fabs(det);
+    g[0] += wq*qq; g[1] += wq*qq*qq;
+  }}
+}}
+"""
+    return op2.Kernel(body, "dg_integrals")
+
+
+class DGAdvectionStepper:
+    """The demo's three-stage SSP Runge-Kutta loop (demos/DG_advection/DG_advection.py.rst), entirely on the
+    device: RHS assembly (three parloops), block-diagonal mass solve (one parloop with an indirect WRITE),
+    stage combinations with fd_dat_axpby."""
+
+    def __init__(self, qmesh, dt=None):
+        self.prob = p = DGAdvectionProblem(qmesh, dt)
+        m = qmesh
+        self.dq = op2.Dat(m.dq_set, None, np.float64, "dq")
+        self.q0 = op2.Dat(m.dq_set, None, np.float64, "q_n")
+        self.solve_loop = op2.LegacyParloop(dg_mass_solve_kernel(), m.cell_set, self.dq(op2.WRITE, m.cell_dq),
+                                            m.coordinates(op2.READ, m.cell_q1), p.L(op2.READ, m.cell_dq))
+        self.g = op2.Global(2, [0.0, 0.0], np.float64, "integrals")
+        self.int_loop = op2.LegacyParloop(dg_integrals_kernel(), m.cell_set, self.g(op2.INC), m.coordinates(op2.READ, m.cell_q1),
+                                          p.q(op2.READ, m.cell_dq))
+
+    def _solve(self):
+        self.prob.assemble_rhs()       # L(q)
+        self.solve_loop()              # dq = M^{-1} L
+
+    def step(self):
+        q, q0, dq = self.prob.q, self.q0, self.dq
+        q0.assign_dat(q)
+        self._solve()
+        q.axpby(1.0, dq, 1.0)                              # q1 = q + dq
+        self._solve()
+        q.axpby(0.25, dq, 0.25)                            # q2 = 0.75 q_n + 0.25 (q1 + dq)
+        q.axpby(0.75, q0, 1.0)
+        self._solve()
+        q.axpby(2.0 / 3.0, dq, 2.0 / 3.0)                  # q_{n+1} = 1/3 q_n + 2/3 (q2 + dq)
+        q.axpby(1.0 / 3.0, q0, 1.0)
+
+    def integrals(self):
+        """(int q dx, ||q||_L2)"""
+        self.g.data[...] = 0.0
+        self.int_loop()
+        v = self.g.data_ro
+        return float(v[0]), float(np.sqrt(v[1]))

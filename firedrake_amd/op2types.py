@@ -484,7 +484,20 @@ class Dat(_Mirrored):
                 self.local_to_global_begin(access_mode)
                 self.local_to_global_end(access_mode)
 
-    # -- small algebra used by the tests / assemble()
+    # -- pointwise algebra on the device (pyop2/types/dat.py:354-620): keeps coefficient updates next to the
+    #    assemblies (Newton / Runge-Kutta loops) instead of round-tripping through the host
+    def axpby(self, a, x: "Dat", b=1.0):
+        """self = a*x + b*self  (all rows, halos included)."""
+        if x.dataset.total_size != self.dataset.total_size or x.cdim != self.cdim or self.dtype != ScalarType:
+            raise DataValueError("axpby needs two float64 Dats of the same shape")
+        n = self.dataset.total_size * self.cdim
+        _lib.call("fd_dat_axpby", self._dev_ptr(True), ctypes.c_double(a), x._dev_ptr(False), ctypes.c_double(b), n, None)
+        self.halo_valid = self.halo_valid and x.halo_valid
+        return self
+
+    def assign_dat(self, x: "Dat"):
+        return self.axpby(1.0, x, 0.0)
+
     def norm(self):
         return float(np.linalg.norm(self.data_ro))
 

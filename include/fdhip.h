@@ -220,6 +220,9 @@ int fd_halo_unpack(double *dat_dev, int cdim, const int32_t *idx_dev, int32_t n,
  * bc.zero / bc.apply on a residual (firedrake/bcs.py:192-221, 404-457). */
 int fd_dat_set_rows(double *dat_dev, int cdim, const int32_t *rows_dev, int32_t n,
                     double value, fd_stream_t s);
+/* y = a*x + b*y over n doubles: Dat.assign / axpy kept on the device between assemblies
+ * (pyop2/types/dat.py:354-620; firedrake/assign.py), e.g. the Runge-Kutta stages of the DG-advection demo. */
+int fd_dat_axpby(double *y_dev, double a, const double *x_dev, double b, int64_t n, fd_stream_t s);
 int fd_dat_copy_rows(double *dst_dev, const double *src_dev, int cdim, const int32_t *rows_dev,
                      int32_t n, fd_stream_t s);
 
