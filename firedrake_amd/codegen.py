@@ -465,8 +465,6 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
                 "  const int tid = threadIdx.x, nthr = blockDim.x;",
                 "  const int b = fdw::xcd_block(blockIdx.x, gridDim.x);",
                 "  const int e0 = bstart_[b], e1 = bstart_[b+1];"]
-        if configuration["stagger"]:
-            src.append(f"  if (blockIdx.x < 2048 && ((blockIdx.x >> 3) & 1)) {{ for (int w = 0; w < {int(configuration['stagger'])}; ++w) __builtin_amdgcn_s_sleep(127); }}")
         src += ["  " + s for s in lds_decl]
         for mi in staged_maps:
             src.append(f"  const int l0_{mi} = p{mi}_blkoff[b], nd{mi} = p{mi}_blkoff[b+1] - l0_{mi};")
@@ -534,7 +532,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
                     src.append("    " + ld.replace("II", "it1").replace("EE", "e_nx").replace("DST", "nx_" + name))
             src += ["    " + g for g in gathers("t", "lm")]
             src.append("  }")
-        src.append("  for (int it = e0 + tid; it < e1; it += nthr) {" if not configuration["debug_noloop"] else "  for (int it = e1; it < e1; it += nthr) {")
+        src.append("  for (int it = e0 + tid; it < e1; it += nthr) {")
         if pp:
             src.append("    const int e = e_cur;")
             src.append("    const int it2 = (it + 2*nthr < e1) ? it + 2*nthr : it;")
@@ -566,7 +564,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
                 src.append(f"    for (int q = 0; q < {size}; ++q) t{k}[q] = tn{k}[q];")
             src.append("    e_cur = e_nx;" + (" e_nx = e_nn;" if pp else ""))
         src.append("  }")
-        if flush and not configuration["debug_noflush"]:
+        if flush:
             src.append("  __syncthreads();")
             src += ["  " + s for _, s in flush]
         src += ["  " + s for s in post]
@@ -600,8 +598,6 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         src.append("  }")
         src += ["  " + s for s in post]
     src.append("}")
-    if configuration["debug_noatomic"]:
-        src = [re.sub(r"atomicAdd\(&(s[m]?\d+\[[^;]*?\]), (t\d+\[[^;]*?\])\);", r"\1 = \2;", l) for l in src]
     return WrapperSource("\n".join(src) + "\n", sym, mode, layout, len(maps), staged_maps, lds_items,
                          layer_parallel, threads, kbytes, mat_staged)
 

@@ -23,7 +23,6 @@ configuration = {
     "ents_per_block": _env("FDHIP_ENTS_PER_BLOCK", 1024, int),
     "pipeline_packs": _env("FDHIP_PIPELINE_PACKS", 0, int),  # gather the next entity's packs from LDS one iteration ahead
     "stage_unroll": _env("FDHIP_STAGE_UNROLL", 1, int),   # nodes staged per lane per trip (memory-level parallelism)
-    "stagger": _env("FDHIP_STAGGER", 0, int),             # experiment: delay (x ~4 us) for every other workgroup of the first dispatch wave
     "lds_soa": _env("FDHIP_LDS_SOA", 1, int),             # component-major LDS layout for staged vector Dats
     "prefetch": _env("FDHIP_PREFETCH", 1, int),          # software-pipeline the packed index rows
     "mat_ocr": _env("FDHIP_MAT_OCR", 1, int),             # owner-computes-rows matrix assembly (no global atomics)
@@ -31,9 +30,6 @@ configuration = {
     "ocr_block_threads": _env("FDHIP_OCR_BLOCK_THREADS", 0, int),  # 0 = same as block_threads
     "ocr_interleave": _env("FDHIP_OCR_INTERLEAVE", 1, int),  # lane <-> instance stride inside a block (1 = none)
     "mat_exclusive": _env("FDHIP_MAT_EXCLUSIVE", 0, int),  # non-atomic writes + fused zero for block-exclusive nonzeros
-    "debug_noatomic": _env("FDHIP_DEBUG_NOATOMIC", 0, int),  # experiment: plain LDS store instead of ds_add (WRONG results)
-    "debug_noloop": _env("FDHIP_DEBUG_NOLOOP", 0, int),    # experiment: skip the entity loop (WRONG results)
-    "debug_noflush": _env("FDHIP_DEBUG_NOFLUSH", 0, int),  # experiment: skip the global flush (WRONG results)
     "min_waves": _env("FDHIP_MIN_WAVES", 0, int),       # 2nd __launch_bounds__ argument (waves per SIMD), 0 = unset
     "block_merge": _env("FDHIP_BLOCK_MERGE", 2, int),     # staged loops: fuse this many consecutive producer tiles into one plan block
     "use_preferred_blocks": _env("FDHIP_PREFERRED_BLOCKS", 1, int),   # plan blocks = the producer's traversal tiles
