@@ -121,3 +121,40 @@ def test_c1_step_as_hipgraph():
     prob.r._host_valid = False                  # device copy is authoritative after the replay
     assert_allclose(prob.r.data_ro, ro, rtol=0, atol=1e-12 * np.abs(ro).max())
     assert_allclose(prob.jacobian()[0].toscipy().data, Ao.data, rtol=0, atol=1e-12 * np.abs(Ao.data).max())
+
+
+def test_c2_full_size_properties():
+    """BASELINE.json configs[1] at full size (59.6 M tets, 10.08 M DoFs, nnz 150 M): size-independent properties of the
+    assembled tensors instead of the oracle -- constants in the null space, symmetry (x'Ay = y'Ax), residual of a
+    constant state with f = 0 vanishes, F(u) = A u - M f linearity, second assembly idempotent."""
+    n = 215
+    m = fmesh.UnitCubeMesh(n, degrees=(1,), perturb=0.1)
+    prob = forms.PoissonProblem(m, 1, bcs=False)
+    V = prob.V
+    assert V.node_set.size == 10077696 and m.cell_set.size == 59630250
+    mat = prob.assemble_jacobian()
+    assert mat.sparsity.nz == 150048286                      # SURVEY.md 8 sizes
+    nn = V.node_set.size
+    ones = V.dat(1, np.ones(nn))
+    y = V.dat()
+    mat.mult(ones, y)
+    rp, ci, v = mat.csr()
+    amax = np.abs(v).max()
+    assert np.abs(y.data_ro).max() <= 1e-10 * amax
+    rng = np.random.default_rng(0)
+    a, b = rng.standard_normal(nn), rng.standard_normal(nn)
+    da, db, ta, tb = V.dat(1, a), V.dat(1, b), V.dat(), V.dat()
+    mat.mult(da, ta)
+    mat.mult(db, tb)
+    lhs, rhs = float(b @ ta.data_ro), float(a @ tb.data_ro)
+    assert abs(lhs - rhs) <= 1e-10 * max(abs(lhs), abs(rhs))
+    # residual: F(u) with f = 0 equals A u
+    prob.f.assign(0.0)
+    r = np.array(prob.assemble_residual().data_ro)
+    mat.mult(prob.u, y)
+    assert np.abs(r - y.data_ro).max() <= 1e-10 * max(1.0, np.abs(r).max())
+    prob.u.assign(3.25)
+    r0 = prob.assemble_residual().data_ro
+    assert np.abs(r0).max() <= 1e-10 * amax
+    v2 = prob.assemble_jacobian().csr()[2]
+    assert np.abs(v2 - v).max() <= 1e-12 * amax

