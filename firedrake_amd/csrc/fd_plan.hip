@@ -27,7 +27,7 @@ struct fd_plan_s {
 namespace {
 
 constexpr int PT = 1024;       // threads per plan-builder workgroup
-constexpr int MAXCHUNK = 16;   // PT * MAXCHUNK = 16384 map entries per block at most
+constexpr int MAXCHUNK = 32;   // PT * MAXCHUNK = 32768 map entries per block at most (128 KiB of LDS for the sort)
 
 __device__ inline void bitonic_sort_lds(int *s, int n2) {
     const int tid = threadIdx.x;
@@ -217,7 +217,7 @@ int fd_plan_create(const int32_t *map_dev, int arity, int32_t start, int32_t end
     hipStream_t s = fd::st(s_);
     if (arity <= 0 || epb <= 0 || end < start) FD_FAIL("fd_plan_create: bad arguments");
     if ((int64_t)epb * arity > (int64_t)PT * MAXCHUNK)
-        FD_FAIL("fd_plan_create: ents_per_block*arity exceeds 16384 map entries per block");
+        FD_FAIL("fd_plan_create: ents_per_block*arity exceeds 32768 map entries per block");
     auto *p = new fd_plan_s;
     p->arity = arity; p->epb = epb; p->start = start; p->end = end;
     int64_t n = (int64_t)end - start;
@@ -247,7 +247,7 @@ int fd_plan_create_blocks(const int32_t *map_dev, int arity, const int32_t *bloc
     }
     p->epb = mx > 0 ? mx : 1;
     if ((int64_t)p->epb * arity > (int64_t)PT * MAXCHUNK) { delete p;
-        FD_FAIL("fd_plan_create_blocks: a block exceeds 16384 map entries"); }
+        FD_FAIL("fd_plan_create_blocks: a block exceeds 32768 map entries"); }
     FD_HIP(hipMalloc(&p->bstart, ((size_t)nblocks + 1) * 4));
     FD_HIP(hipMemcpyAsync(p->bstart, block_starts_host, ((size_t)nblocks + 1) * 4, hipMemcpyHostToDevice, s));
     FD_HIP(hipStreamSynchronize(s));

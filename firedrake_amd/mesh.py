@@ -81,7 +81,7 @@ def _tile_keys(ix, iy, iz, nx, ny, nz, tile):
     return t * (tx * ty * tz) + loc
 
 
-def _split_blocks(blocks, arity, max_entries=16384):
+def _split_blocks(blocks, arity, max_entries=32768):
     """Halve tiles whose map rows exceed the plan builder's per-block capacity."""
     blocks = np.asarray(blocks, dtype=np.int64)
     while True:

@@ -235,11 +235,11 @@ class Parloop:
                 mrg = max(1, int(configuration["block_merge"]))
                 while mrg > 1:
                     cand_bl = np.unique(np.concatenate([bl[::mrg], bl[-1:]]))
-                    if int(np.diff(cand_bl).max()) * maxar <= 16384:
+                    if int(np.diff(cand_bl).max()) * maxar <= 32768:
                         bl = cand_bl
                         break
                     mrg -= 1
-                if int(np.diff(bl).max()) * maxar <= 16384:
+                if int(np.diff(bl).max()) * maxar <= 32768:
                     blocks = bl
         plans = None
         if blocks is not None:
@@ -250,7 +250,7 @@ class Parloop:
         if plans is None:
             # 2. uniform blocks, halved until the staged rows fit the LDS budget
             epb = configuration["ents_per_block"]
-            while epb * maxar > 16384:
+            while epb * maxar > 32768:
                 epb //= 2
             while True:
                 plans, mplans, lds = build(epb, None)
@@ -439,7 +439,14 @@ class Parloop:
         maxar = max(m.arity for m in staged.values())
         for _ in range(12):
             # split row blocks until the LDS rows and the instance lists fit
-            op = OcrPlan(sp, rmap, cmap, staged, 0, end, rb)
+            try:
+                op = OcrPlan(sp, rmap, cmap, staged, 0, end, rb)
+            except _lib.FDHipError as exc:
+                if "map entries" not in str(exc):
+                    raise
+                d = np.diff(rb)                                    # an instance list is too long: halve every wide block
+                rb = np.unique(np.concatenate([rb, (rb[:-1] + d // 2)[d > 1]]))
+                continue
             lds = 0
             for item in src.lds_items:
                 if item[0] == "dat":
@@ -450,17 +457,17 @@ class Parloop:
                     lds += (op.max_nnz * 8 + 15) // 16 * 16 + (op.plans[rm].max_nd * 4 + 15) // 16 * 16
                     if cmi != rm:
                         lds += (op.plans[cmi].max_nd + 15) // 16 * 16
-            if lds <= limit and op.max_inst * maxar <= 16384:
+            if lds <= limit and op.max_inst * maxar <= 32768:
                 break
             d = np.diff(rb)
             nn = np.diff(rp[rb])
             ni = np.diff(op.inst_off_host)
-            big = (nn > 0.7 * nn.max()) | (ni * maxar > 16384) if lds > limit else (ni * maxar > 16384)
+            big = (nn > 0.7 * nn.max()) | (ni * maxar > 32768) if lds > limit else (ni * maxar > 32768)
             big &= d > 1
             if not big.any():
                 break
             rb = np.unique(np.concatenate([rb, (rb[:-1] + d // 2)[big]]))
-        if lds > 160 * 1024 or op.max_inst * maxar > 16384:
+        if lds > 160 * 1024 or op.max_inst * maxar > 32768:
             raise _lib.FDHipError("owner-computes-rows plan does not fit (LDS or instance list); set FDHIP_MAT_OCR=0")
         if op.kbytes == 2 and src.kbytes == 1:
             prep["cw"] = self.global_kernel.compile("ocr_k16")
