@@ -170,7 +170,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=215, help="cubes per axis per GPU (215 -> ~10M DoF)")
+    ap.add_argument("--n", "--size", dest="n", type=int, default=215, help="cubes per axis per GPU (215 -> ~10M DoF)")
     ap.add_argument("--degree", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=128, help="cube size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-bcs", action="store_true")
@@ -190,11 +190,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
+    # test knobs (one-GPU rehearsal of the N > 1 path): FDHIP_FORCE_DEVICE pins every rank to one device and
+    # FDHIP_DIST_BACKEND=gloo carries the halo buffers through the host instead of RCCL
+    if os.environ.get("FDHIP_FORCE_DEVICE") is not None:
+        local_rank = int(os.environ["FDHIP_FORCE_DEVICE"])
+    backend = os.environ.get("FDHIP_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     from firedrake_amd import _lib, forms, mesh as fmesh
     from firedrake_amd.device import Event
     _lib.require_gpu()
@@ -248,7 +256,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
