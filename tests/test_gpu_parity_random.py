@@ -119,3 +119,41 @@ def test_empty_and_tiny_iteration_sets():
     op2.par_loop(op2.Kernel(gk.MASS_AFFINE.replace("mass_affine", "mass_e").replace("double A[9]", "double *A"), "mass_e"),
                  ele, b(op2.INC, m), x(op2.READ, m))
     assert np.all(b.data == 0)
+
+
+@pytest.mark.parametrize("dtype,ctype", [(np.float32, "float"), (np.int32, "int"), (np.uint32, "unsigned int"), (np.float64, "double")])
+@pytest.mark.parametrize("mode", ["auto", "direct"])
+def test_staged_inc_other_dtypes_and_high_arity(dtype, ctype, mode, monkeypatch):
+    """INC through a map for every stageable dtype, arity 27 (a Q2-hexahedron-sized map), vector cdim 2."""
+    monkeypatch.setitem(configuration, "mode", mode)
+    rng = np.random.default_rng(7)
+    n, ntgt, ar = 3000, 800, 27
+    vals = ((np.arange(n)[:, None] * ntgt // n + rng.integers(0, 60, size=(n, ar))) % ntgt).astype(np.int32)
+    it, to = op2.Set(n), op2.Set(ntgt)
+    m = op2.Map(it, to, ar, vals)
+    src = op2.Dat(to ** 2, rng.integers(1, 5, size=(ntgt, 2)).astype(dtype), dtype)
+    out = op2.Dat(to ** 2, dtype=dtype)
+    k = op2.Kernel(f"static void acc27({ctype} *o, const {ctype} *s) {{ for (int i = 0; i < 27; ++i) {{ o[2*i] += s[2*i+1]; o[2*i+1] += ({ctype})(i % 3); }} }}",
+                   f"acc27_{np.dtype(dtype).name}".replace("acc27_", "acc27"))
+    k = op2.Kernel(k.code.replace("acc27(", f"acc27_{np.dtype(dtype).name}("), f"acc27_{np.dtype(dtype).name}")
+    op2.par_loop(k, it, out(op2.INC, m), src(op2.READ, m))
+    ref = oracle_run(k, it, op2.Dat(to ** 2, dtype=dtype)(op2.INC, m), src(op2.READ, m))[0]
+    if np.issubdtype(dtype, np.integer):
+        assert np.array_equal(out.data_ro, ref)                  # integer work is bit-exact
+    else:
+        assert_allclose(out.data_ro, ref, rtol=1e-5 if dtype == np.float32 else 1e-13)
+
+
+def test_plan_with_empty_and_single_entity_blocks():
+    rng = np.random.default_rng(11)
+    n = 700
+    it, to = op2.Set(n), op2.Set(300)
+    m = op2.Map(it, to, 3, rng.integers(0, 300, size=(n, 3)).astype(np.int32))
+    blocks = np.array([0, 0, 1, 1, 250, 250, 699, 700, 700], dtype=np.int32)     # empty, single-entity and large blocks
+    p = m.plan(0, n, 0, blocks)
+    blk, lst, lm = p.download()
+    for b in range(len(blocks) - 1):
+        rows = m.values[blocks[b]:blocks[b + 1]]
+        u, inv = (np.unique(rows.reshape(-1), return_inverse=True) if len(rows) else (np.zeros(0, np.int32), np.zeros(0, np.int64)))
+        assert np.array_equal(lst[blk[b]:blk[b + 1]], u)
+        assert np.array_equal(lm[blocks[b]:blocks[b + 1]].reshape(-1), inv)
