@@ -60,6 +60,7 @@ class WrapperSource:
     block_threads: int = 256
     kbytes: int = 1
     mat_staged: dict = field(default_factory=dict)
+    lane_threads: int = 0                                  # >0: plans must be in lane order for this many lanes
 
 
 def _distinct_maps(gk: GlobalKernel):
@@ -196,6 +197,9 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
 
     # ---- backend-private parameters
     P("const int *__restrict__ bstart_", ("bstart",))
+    if staged:
+        # log2 of the number of lane-private replicas of every LDS accumulator (see "replicated accumulators" below)
+        P("long long fd_rsh_", ("rep_shift",))
     if ocr:
         P("const int *__restrict__ inst_ent_", ("ocr_inst_ent",))
     staged_maps = []
@@ -307,8 +311,9 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             if not (staged and acc == READ and configuration["pipeline_packs"] and configuration["prefetch"]):
                 pack.append(f"{ct} t{k}[{size}];")
             if staged:
-                lds_items.append(("dat", mi, c, info["dtype"].itemsize))
-                lds_decl.append(f"{ct} *s{k} = ({ct} *)(fd_lds + fd_off); fd_off += (((size_t)p{mi}_maxnd*{c}*sizeof({ct})) + 15) & ~(size_t)15;")
+                lds_items.append(("dat", mi, c, info["dtype"].itemsize, acc != READ))
+                rsh = " << fd_rsh" if acc != READ else ""
+                lds_decl.append(f"{ct} *s{k} = ({ct} *)(fd_lds + fd_off); fd_off += ((((size_t)p{mi}_maxnd*{c}*sizeof({ct})){rsh}) + 15) & ~(size_t)15;")
                 if acc == READ:
                     soa = bool(configuration["lds_soa"]) and c > 1
                     node_actions.setdefault(mi, []).append(
@@ -321,12 +326,17 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
                     else:
                         pack.append(g.replace(f"TT{k}", f"t{k}").replace(f"LM{mi}", f"lm{mi}"))
                 else:  # INC
-                    stage.append((mi, f"for (int q = tid; q < nd{mi}*{c}; q += nthr) s{k}[q] = 0;"))
+                    # replicated accumulators: every accumulator has 2^fd_rsh copies, interleaved so that copy r of
+                    # consecutive accumulators sits in banks r, r + R, ...; a lane adds into copy (lane mod R).
+                    # Neighbouring entities (consecutive lanes) that share a node no longer hit one address in the
+                    # same ds_add, and distinct nodes collide on a bank R times less often.
+                    stage.append((mi, f"for (int q = tid; q < (nd{mi}*{c}) << fd_rsh; q += nthr) s{k}[q] = 0;"))
                     pack.append(f"for (int q = 0; q < {size}; ++q) t{k}[q] = 0;")
                     unpack.append(f"for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j) "
-                                  f"atomicAdd(&s{k}[lm{mi}[{_permi(perm, 'i')}]*{c} + j], t{k}[i*{c}+j]);")
+                                  f"atomicAdd(&s{k}[((lm{mi}[{_permi(perm, 'i')}]*{c} + j) << fd_rsh) + fd_r], t{k}[i*{c}+j]);")
                     flush.append((mi, f"for (int q = tid; q < nd{mi}*{c}; q += nthr) {{ const int i = q / {c}; "
-                                      f"fdw::atomic_add<{ct}>(&arg{k}[(size_t)p{mi}_list[l0_{mi} + i]*{c} + (q - i*{c})], s{k}[q]); }}"))
+                                      f"fdw::atomic_add<{ct}>(&arg{k}[(size_t)p{mi}_list[l0_{mi} + i]*{c} + (q - i*{c})], "
+                                      f"fdw::rep_sum<{ct}>(s{k}, q, fd_rsh)); }}"))
                 call_args.append(f"t{k}")
                 continue
             nexpr = node(mi, ar, "i", off, perm, "f")
@@ -355,7 +365,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             lg = info["arg"].lgmaps
             if ocr:
                 lds_items.append(("ocr", k, rm, cm, bool(lg)))
-                lds_decl.append(f"double *sm{k} = (double *)(fd_lds + fd_off); fd_off += (((size_t)oc{k}_maxnnz*8) + 15) & ~(size_t)15;")
+                lds_decl.append(f"double *sm{k} = (double *)(fd_lds + fd_off); fd_off += ((((size_t)oc{k}_maxnnz*8) << fd_rsh) + 15) & ~(size_t)15;")
                 # one LDS word per gathered node: bits 0..29 = 1 + offset of the node's row inside the block's
                 # accumulator (0 = row not owned here or BC-masked), bit 31 = column is BC-masked
                 lds_decl.append(f"unsigned int *srow{k} = (unsigned int *)(fd_lds + fd_off); fd_off += (((size_t)p{rm}_maxnd*4) + 15) & ~(size_t)15;")
@@ -363,7 +373,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
                     lds_decl.append(f"unsigned char *smc{k} = fd_lds + fd_off; fd_off += ((size_t)p{cm}_maxnd + 15) & ~(size_t)15;")
                 mat_stage_pre.extend([f"const int n0_{k} = oc{k}_rblk[b], nown{k} = oc{k}_rblk[b+1] - n0_{k};",
                                       f"const int r0_{k} = oc{k}_rowptr[n0_{k}], nnzb{k} = oc{k}_rowptr[n0_{k} + nown{k}] - r0_{k};"])
-                stage.append((rm, f"for (int q = tid; q < nnzb{k}; q += nthr) sm{k}[q] = 0;"))
+                stage.append((rm, f"for (int q = tid; q < nnzb{k} << fd_rsh; q += nthr) sm{k}[q] = 0;"))
                 rowmask = f" && rlg{k}[g] >= 0" if lg else ""
                 colbit = (f" | ((clg{k}[g] < 0) ? 0x80000000u : 0u)" if (lg and cm == rm) else "")
                 node_actions.setdefault(rm, []).append(
@@ -380,18 +390,18 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
                           f"  for (int j = 0; j < {ac}; ++j) {{"]
                 if lg:
                     lines.append(f"    if ({'cmk%d[j]' % k if cm != rm else '(rw%d[j] >> 31)' % k}) continue;")
-                lines += [f"    atomicAdd(&sm{k}[base + kk{k}[i*{ac} + j]], t{k}[i*{ac} + j]);", "  }", "}"]
+                lines += [f"    atomicAdd(&sm{k}[((base + kk{k}[i*{ac} + j]) << fd_rsh) + fd_r], t{k}[i*{ac} + j]);", "  }", "}"]
                 unpack.append("\n    ".join(lines))
                 # complete rows, contiguous in the CSR value array: plain coalesced stores
-                flush.append((rm, f"if (oc{k}_flags & 1) {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)r0_{k} + q] = sm{k}[q]; }} "
-                                  f"else {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)r0_{k} + q] += sm{k}[q]; }}"))
+                flush.append((rm, f"if (oc{k}_flags & 1) {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)r0_{k} + q] = fdw::rep_sum<double>(sm{k}, q, fd_rsh); }} "
+                                  f"else {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)r0_{k} + q] += fdw::rep_sum<double>(sm{k}, q, fd_rsh); }}"))
                 continue
             if mat_staged[k]:
                 lds_items.append(("mat", k, rm, cm, bool(lg)))
-                lds_decl.append(f"double *sm{k} = (double *)(fd_lds + fd_off); fd_off += (((size_t)mp{k}_maxnnz*8) + 15) & ~(size_t)15;")
+                lds_decl.append(f"double *sm{k} = (double *)(fd_lds + fd_off); fd_off += ((((size_t)mp{k}_maxnnz*8) << fd_rsh) + 15) & ~(size_t)15;")
                 lds_decl.append(f"int *slrp{k} = (int *)(fd_lds + fd_off); fd_off += (((size_t)(p{rm}_maxnd + 1)*4) + 15) & ~(size_t)15;")
                 mat_pre = [f"const int mo{k} = mp{k}_off[b], nnzb{k} = mp{k}_off[b+1] - mo{k};"]
-                stage.append((rm, f"for (int q = tid; q < nnzb{k}; q += nthr) sm{k}[q] = 0;"))
+                stage.append((rm, f"for (int q = tid; q < nnzb{k} << fd_rsh; q += nthr) sm{k}[q] = 0;"))
                 stage.append((rm, f"for (int q = tid; q <= nd{rm}; q += nthr) slrp{k}[q] = mp{k}_lrp[l0_{rm} + b + q];"))
                 if lg:
                     lds_decl.append(f"unsigned char *smr{k} = fd_lds + fd_off; fd_off += ((size_t)p{rm}_maxnd + 15) & ~(size_t)15;")
@@ -406,15 +416,15 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
                 lines.append(f"  for (int j = 0; j < {ac}; ++j) {{")
                 if lg:
                     lines.append(f"    if (smc{k}[lm{cm}[j]]) continue;")
-                lines += [f"    atomicAdd(&sm{k}[base + kk{k}[i*{ac} + j]], t{k}[i*{ac} + j]);", "  }", "}"]
+                lines += [f"    atomicAdd(&sm{k}[((base + kk{k}[i*{ac} + j]) << fd_rsh) + fd_r], t{k}[i*{ac} + j]);", "  }", "}"]
                 unpack.append("\n    ".join(lines))
                 # exclusive entries (~pos < 0) need no atomic; with a pending Mat.zero() they are simply overwritten
                 if configuration["mat_exclusive"]:
-                    flush.append((rm, f"for (int q = tid; q < nnzb{k}; q += nthr) {{ const double v = sm{k}[q]; const int g = mp{k}_gpos[mo{k} + q]; "
+                    flush.append((rm, f"for (int q = tid; q < nnzb{k}; q += nthr) {{ const double v = fdw::rep_sum<double>(sm{k}, q, fd_rsh); const int g = mp{k}_gpos[mo{k} + q]; "
                                       f"if (g < 0) {{ if (mp{k}_flags & 1) arg{k}[~g] = v; else if (v != 0.0) arg{k}[~g] += v; }} "
                                       f"else if (v != 0.0) fdw::atomic_add<double>(&arg{k}[g], v); }}"))
                 else:
-                    flush.append((rm, f"for (int q = tid; q < nnzb{k}; q += nthr) {{ const double v = sm{k}[q]; const int g = mp{k}_gpos[mo{k} + q]; "
+                    flush.append((rm, f"for (int q = tid; q < nnzb{k}; q += nthr) {{ const double v = fdw::rep_sum<double>(sm{k}, q, fd_rsh); const int g = mp{k}_gpos[mo{k} + q]; "
                                       f"if (v != 0.0) fdw::atomic_add<double>(&arg{k}[g < 0 ? ~g : g], v); }}"))
                 continue
             store = (lambda p, v: f"fdw::atomic_add<double>(&arg{k}[{p}], {v});") if acc == INC else (lambda p, v: f"arg{k}[{p}] = {v};")
@@ -463,6 +473,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     if staged:
         src += ["  extern __shared__ __align__(16) unsigned char fd_lds[];",
                 "  const int tid = threadIdx.x, nthr = blockDim.x;",
+                "  const int fd_rsh = (int)fd_rsh_, fd_r = tid & ((1 << fd_rsh) - 1);",
                 "  const int b = fdw::xcd_block(blockIdx.x, gridDim.x);",
                 "  const int e0 = bstart_[b], e1 = bstart_[b+1];"]
         src += ["  " + s for s in lds_decl]
@@ -490,6 +501,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             src.append("  }")
         src.append("  __syncthreads();")
         src += ["  " + s for s in pre]
+        src += ["  const int fd_first = e0 + tid, fd_step = nthr, fd_last = e1;"]
         # software pipeline: the packed index rows of the NEXT entity are requested before the current
         # entity's local kernel runs, so their HBM latency hides under ~10^2 fp64 instructions
         idx_loads = []      # (register row, its prefetch twin, name, length, load template: II = iteration index, EE = entity)
@@ -507,7 +519,18 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
                 idx_loads.append((f"int kk{k}[{n}]", f"int nx_kk{k}[{n}]", f"kk{k}", n,
                                   f"fdw::load_packed<{ktype}, {n}>(oc{k}_k + (size_t)(EE)*{n}, DST);"))
         pf = bool(configuration["prefetch"])
-        ent_of = (lambda ii: f"inst_ent_[{ii}]") if ocr else (lambda ii: ii)
+        # lane order (fd_plan_set_lane_order): slot k*nthr + t of a block holds the k-th entity of lane t's contiguous
+        # run, so the lanes of one trip work on entities that are far apart (no shared nodes -> no serialised LDS
+        # atomics) while their index rows stay coalesced.  OCR instance lists are stored in that order already.
+        lane_threads = threads if configuration["lane_strided"] else 0
+        if ocr:
+            ent_of = lambda ii: f"inst_ent_[{ii}]"
+        elif lane_threads:
+            src += [f"  const int fd_q = (e1 - e0) / {threads}, fd_rem = (e1 - e0) - fd_q*{threads};",
+                    "  const int fd_ebase = e0 + tid*fd_q + (tid < fd_rem ? tid : fd_rem);"]
+            ent_of = lambda ii: f"(fd_ebase + ({ii} - e0) / {threads})"
+        else:
+            ent_of = lambda ii: ii
         def gathers(tprefix, lmprefix):
             out = []
             for k, ct, size, g in pack_gather:
@@ -521,21 +544,21 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             for k, ct, size, g in pack_gather:
                 src.append(f"  {ct} t{k}[{size}], tn{k}[{size}];")
             src.append("  int e_cur = 0, e_nx = 0;")
-            src.append("  if (e0 + tid < e1) {")
-            src.append(f"    e_cur = {ent_of('e0 + tid')};")
+            src.append("  if (fd_first < fd_last) {")
+            src.append(f"    e_cur = {ent_of('fd_first')};")
             for cur, nxt, name, n, ld in idx_loads:
-                src.append("    " + ld.replace("II", "(e0 + tid)").replace("EE", "e_cur").replace("DST", name))
+                src.append("    " + ld.replace("II", "fd_first").replace("EE", "e_cur").replace("DST", name))
             if pp:
-                src.append("    const int it1 = (e0 + tid + nthr < e1) ? e0 + tid + nthr : e0 + tid;")
+                src.append("    const int it1 = (fd_first + fd_step < fd_last) ? fd_first + fd_step : fd_first;")
                 src.append(f"    e_nx = {ent_of('it1')};")
                 for cur, nxt, name, n, ld in idx_loads:
                     src.append("    " + ld.replace("II", "it1").replace("EE", "e_nx").replace("DST", "nx_" + name))
             src += ["    " + g for g in gathers("t", "lm")]
             src.append("  }")
-        src.append("  for (int it = e0 + tid; it < e1; it += nthr) {")
+        src.append("  for (int it = fd_first; it < fd_last; it += fd_step) {")
         if pp:
             src.append("    const int e = e_cur;")
-            src.append("    const int it2 = (it + 2*nthr < e1) ? it + 2*nthr : it;")
+            src.append("    const int it2 = (it + 2*fd_step < fd_last) ? it + 2*fd_step : it;")
             src.append(f"    const int e_nn = {ent_of('it2')};")
             for cur, nxt, name, n, ld in idx_loads:
                 src.append("    " + ld.replace("II", "it2").replace("EE", "e_nn").replace("DST", "nn_" + name))
@@ -544,7 +567,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             src += ["    " + g for g in gathers("tn", "nx_lm")]
         elif pf:
             src.append("    const int e = e_cur;")
-            src.append("    const int itn = (it + nthr < e1) ? it + nthr : it;")
+            src.append("    const int itn = (it + fd_step < fd_last) ? it + fd_step : it;")
             src.append(f"    e_nx = {ent_of('itn')};")
             for cur, nxt, name, n, ld in idx_loads:
                 src.append("    " + ld.replace("II", "itn").replace("EE", "e_nx").replace("DST", "nx_" + name))
@@ -599,7 +622,8 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         src += ["  " + s for s in post]
     src.append("}")
     return WrapperSource("\n".join(src) + "\n", sym, mode, layout, len(maps), staged_maps, lds_items,
-                         layer_parallel, threads, kbytes, mat_staged)
+                         layer_parallel, threads, kbytes, mat_staged,
+                         (threads if (staged and configuration["lane_strided"]) else 0))
 
 
 def _permi(perm, i):

@@ -23,6 +23,10 @@ configuration = {
     "ents_per_block": _env("FDHIP_ENTS_PER_BLOCK", 1024, int),
     "pipeline_packs": _env("FDHIP_PIPELINE_PACKS", 0, int),  # gather the next entity's packs from LDS one iteration ahead
     "stage_unroll": _env("FDHIP_STAGE_UNROLL", 1, int),   # nodes staged per lane per trip (memory-level parallelism)
+    "lds_replicas": _env("FDHIP_LDS_REPLICAS", 1, int),   # lane-private copies of staged Dat accumulators (power of two)
+    "ocr_replicas": _env("FDHIP_OCR_REPLICAS", 1, int),   # the same for block matrix accumulators
+    "lane_strided": _env("FDHIP_LANE_STRIDED", 1, int),   # lane t handles a contiguous run of the block's entities
+    "lane_strided": _env("FDHIP_LANE_STRIDED", 1, int),   # plans in lane order (fd_plan_set_lane_order)
     "lds_soa": _env("FDHIP_LDS_SOA", 1, int),             # component-major LDS layout for staged vector Dats
     "prefetch": _env("FDHIP_PREFETCH", 1, int),          # software-pipeline the packed index rows
     "mat_ocr": _env("FDHIP_MAT_OCR", 1, int),             # owner-computes-rows matrix assembly (no global atomics)

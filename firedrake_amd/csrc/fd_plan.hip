@@ -22,6 +22,7 @@ struct fd_plan_s {
     int32_t *bstart = nullptr;   // nblocks+1: first entity of every block (blocks may differ in size)
     int arity = 0, epb = 0;      // epb = largest block
     int32_t start = 0, end = 0;
+    int lane_threads = 0;        // >0: lmap rows are stored in lane order (fd_plan_set_lane_order)
 };
 
 namespace {
@@ -135,6 +136,29 @@ __global__ __launch_bounds__(PT) void plan_pass(const int32_t *__restrict__ map,
             if (m < v) lo = mid + 1; else hi = mid - 1;
         }
         dst[i] = (uint16_t)r;
+    }
+}
+
+// Lane order for T lanes: a block of n entities is cut into T contiguous runs (lane t owns run t; the first
+// n%T runs are one longer), and the k-th entity of run t is stored at slot k*T + t.  A wavefront that walks the
+// slots with stride T therefore handles, in one trip, entities ~n/T apart -- entities that are neighbours in the
+// (locality-preserving) numbering, and so share nodes, no longer meet in one LDS atomic -- while every lane's
+// index rows stay coalesced.  slot_of_entity is the inverse used by the builders.
+__device__ __forceinline__ int lane_slot_of_entity(int c, int n, int T) {
+    const int q = n / T, rem = n - q * T;
+    int t, k;
+    if (c < rem * (q + 1)) { t = c / (q + 1); k = c - t * (q + 1); }
+    else { const int c2 = c - rem * (q + 1); const int d = c2 / q; t = rem + d; k = c2 - d * q; }
+    return k * T + t;
+}
+
+__global__ void plan_lane_order(const int32_t *__restrict__ bstart, int arity, int32_t start, int T,
+                                const uint16_t *__restrict__ in, uint16_t *__restrict__ out) {
+    const int e0 = bstart[blockIdx.x], n = bstart[blockIdx.x + 1] - e0;
+    const size_t base = (size_t)(e0 - start) * arity;
+    for (int i = threadIdx.x; i < n * arity; i += blockDim.x) {
+        const int c = i / arity, a = i - c * arity;
+        out[base + (size_t)lane_slot_of_entity(c, n, T) * arity + a] = in[base + i];
     }
 }
 
@@ -255,6 +279,23 @@ int fd_plan_create_blocks(const int32_t *map_dev, int arity, const int32_t *bloc
     int rc = plan_build(p, map_dev, s);
     if (rc) { plan_release(p); return rc; }
     *out = p;
+    return 0;
+}
+
+int fd_plan_set_lane_order(fd_plan_t p, int lane_threads, fd_stream_t s_) {
+    if (!p || lane_threads <= 0) FD_FAIL("fd_plan_set_lane_order: bad arguments");
+    if (p->lane_threads) FD_FAIL("fd_plan_set_lane_order: the plan is already in lane order");
+    p->lane_threads = lane_threads;
+    const int64_t n = (int64_t)p->end - p->start;
+    if (p->nblocks == 0 || n == 0) return 0;
+    hipStream_t s = fd::st(s_);
+    uint16_t *tmp = nullptr;
+    FD_HIP(hipMalloc(&tmp, (size_t)n * p->arity * 2));
+    hipLaunchKernelGGL(plan_lane_order, dim3(p->nblocks), dim3(256), 0, s, p->bstart, p->arity, p->start, lane_threads, p->lmap, tmp);
+    FD_CHECK_LAUNCH();
+    FD_HIP(hipStreamSynchronize(s));
+    FD_HIP(hipFree(p->lmap));
+    p->lmap = tmp;
     return 0;
 }
 
@@ -640,6 +681,11 @@ __global__ void ocr_interleave(const int32_t *__restrict__ off, const int32_t *_
     for (int j = threadIdx.x; j < n; j += blockDim.x) out[o + j] = in[o + (int)((j * pp) % n)];
 }
 
+__global__ void ocr_lane_order(const int32_t *__restrict__ off, const int32_t *__restrict__ in, int32_t *__restrict__ out, int T) {
+    const int o = off[blockIdx.x], n = off[blockIdx.x + 1] - o;
+    for (int c = threadIdx.x; c < n; c += blockDim.x) out[o + lane_slot_of_entity(c, n, T)] = in[o + c];
+}
+
 __global__ void gather_rows_k(const int32_t *__restrict__ src, int arity, const int32_t *__restrict__ idx, int64_t n,
                               int32_t *__restrict__ dst) {
     const int64_t total = n * arity;
@@ -726,10 +772,13 @@ int fd_ocrplan_create(const int32_t *rmap_dev, int ar, int32_t start, int32_t en
     FD_HIP(hipMalloc(&p->inst_ent, (size_t)(nu > 0 ? nu : 1) * 4));
     hipLaunchKernelGGL(ocr_split, dim3(mp_grid(nu + 1)), dim3(256), 0, s, uniq, nu, nblocks, p->inst_off, p->inst_ent);
     FD_CHECK_LAUNCH();
-    if (interleave > 1 && nu > 0) {
+    if ((interleave > 1 || interleave < 0) && nu > 0) {
         int32_t *perm = nullptr;
         FD_HIP(hipMalloc(&perm, (size_t)nu * 4));
-        hipLaunchKernelGGL(ocr_interleave, dim3(nblocks), dim3(256), 0, s, p->inst_off, p->inst_ent, perm, interleave);
+        if (interleave > 1)
+            hipLaunchKernelGGL(ocr_interleave, dim3(nblocks), dim3(256), 0, s, p->inst_off, p->inst_ent, perm, interleave);
+        else
+            hipLaunchKernelGGL(ocr_lane_order, dim3(nblocks), dim3(256), 0, s, p->inst_off, p->inst_ent, perm, -interleave);
         FD_CHECK_LAUNCH();
         FD_HIP(hipStreamSynchronize(s));
         FD_HIP(hipFree(p->inst_ent));

@@ -84,6 +84,17 @@ template <class T, class Op> __device__ __forceinline__ T block_reduce(T v, T *s
     return v;
 }
 
+// ---- replicated LDS accumulators: accumulator q has R = 2^rsh copies at s[q*R .. q*R + R-1].
+// Sum of the copies; consecutive lanes start at rotated copies so the R reads of a wavefront spread over the banks.
+template <class T> __device__ __forceinline__ T rep_sum(const T *s, int q, int rsh) {
+    if (rsh == 0) return s[q];
+    const int R = 1 << rsh, rot = (rsh < 5) ? (q >> (5 - rsh)) : q;
+    const T *p = s + ((size_t)q << rsh);
+    T v = 0;
+    for (int r = 0; r < R; ++r) v += p[(r + rot) & (R - 1)];
+    return v;
+}
+
 // ---- packed per-entity index rows (uint16 local maps, uint8/uint16 matrix offsets): N small
 // unsigned integers read with the widest loads the row size allows (rows are N*sizeof(T) apart).
 template <class T, int N> __device__ __forceinline__ void load_packed(const T *__restrict__ p, int (&out)[N]) {

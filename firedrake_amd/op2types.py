@@ -615,13 +615,14 @@ class Map:
             self._dev = DeviceBuffer.from_numpy(self._values)
         return self._dev.ptr
 
-    def plan(self, start, end, epb, blocks=None):
+    def plan(self, start, end, epb, blocks=None, lane_threads=0):
         """Cached block-localisation plan for [start, end) (include/fdhip.h: fd_plan_create[_blocks]).
         ``blocks``: optional int32 array of block boundaries (entity offsets, first = start, last = end)."""
-        key = (int(start), int(end), int(epb) if blocks is None else ("blocks", len(blocks), int(np.asarray(blocks).sum() % 2147483647)))
+        key = (int(start), int(end), int(epb) if blocks is None else ("blocks", len(blocks), int(np.asarray(blocks).sum() % 2147483647)),
+               int(lane_threads))
         p = self._plans.get(key)
         if p is None:
-            p = Plan(self, int(start), int(end), int(epb), blocks)
+            p = Plan(self, int(start), int(end), int(epb), blocks, lane_threads=lane_threads)
             self._plans[key] = p
         return p
 
@@ -679,8 +680,9 @@ class ComposedMap(Map):
 class Plan:
     """Python handle on an fd_plan_t."""
 
-    def __init__(self, map_, start, end, epb, blocks=None, arity=None):
-        """``map_``: a Map, or a raw device pointer to an int32 (n, arity) array (then pass ``arity``)."""
+    def __init__(self, map_, start, end, epb, blocks=None, arity=None, lane_threads=0):
+        """``map_``: a Map, or a raw device pointer to an int32 (n, arity) array (then pass ``arity``).
+        ``lane_threads`` > 0: local-map rows in lane order (include/fdhip.h: fd_plan_set_lane_order)."""
         h = ctypes.c_void_p()
         if isinstance(map_, Map):
             dev, arity = map_._dev_values(), map_.arity
@@ -694,6 +696,9 @@ class Plan:
             assert bl[0] == start and bl[-1] == end
             _lib.call("fd_plan_create_blocks", dev, arity, bl.ctypes.data, len(bl) - 1, None, ctypes.byref(h))
         self.h = h.value
+        self.lane_threads = int(lane_threads)
+        if self.lane_threads > 0:
+            _lib.call("fd_plan_set_lane_order", self.h, self.lane_threads, None)
         bs, me = ctypes.c_void_p(), ctypes.c_int32()
         _lib.call("fd_plan_block_starts", self.h, ctypes.byref(bs), ctypes.byref(me))
         self.bstart, epb = bs.value, me.value
@@ -874,12 +879,12 @@ class OcrPlan:
     """Owner-computes-rows plan (fd_ocrplan_*): row-node blocks, their entity instances, the per-instance
     copies of the staged maps with their node plans, and the per-entity row-offset table."""
 
-    def __init__(self, sparsity, rmap: Map, cmap: Map, staged_maps, start, end, row_blocks):
+    def __init__(self, sparsity, rmap: Map, cmap: Map, staged_maps, start, end, row_blocks, lane_threads=0):
         self.row_blocks = rb = np.ascontiguousarray(row_blocks, dtype=np.int32)
         nb = len(rb) - 1
         h = ctypes.c_void_p()
         _lib.call("fd_ocrplan_create", rmap._base()._dev_values(), rmap.arity, int(start), int(end), rb.ctypes.data, nb,
-                  int(configuration["ocr_interleave"]), None, ctypes.byref(h))
+                  -int(lane_threads) if lane_threads > 0 else int(configuration["ocr_interleave"]), None, ctypes.byref(h))
         self.h = h.value
         ni, mi = ctypes.c_int64(), ctypes.c_int32()
         _lib.call("fd_ocrplan_info", self.h, ctypes.byref(ni), ctypes.byref(mi))

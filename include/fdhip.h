@@ -119,6 +119,14 @@ int fd_plan_create(const int32_t *map_dev, int arity, int32_t start, int32_t end
  * generator's traversal tiles): block b covers [block_starts[b], block_starts[b+1]). */
 int fd_plan_create_blocks(const int32_t *map_dev, int arity, const int32_t *block_starts_host,
                           int32_t nblocks, fd_stream_t s, fd_plan_t *out);
+/* Re-store the plan's local-map rows in LANE ORDER for workgroups of `lane_threads` lanes: a block of n
+ * entities is cut into lane_threads contiguous runs (the first n %% lane_threads one longer) and the k-th entity
+ * of run t goes to slot k*lane_threads + t.  A wrapper that walks the slots with stride lane_threads then has
+ * the lanes of one trip on entities ~n/lane_threads apart (entities adjacent in a locality-preserving numbering
+ * share nodes, and lanes adding into one LDS accumulator in the same ds_add are serialised), with coalesced
+ * index rows.  Execution order inside a block is free for INC semantics (pyop2/codegen/builder.py:338-429 only
+ * fixes what is accumulated, not when).  Call once, before fd_matplan_create. */
+int fd_plan_set_lane_order(fd_plan_t p, int lane_threads, fd_stream_t s);
 int fd_plan_block_starts(fd_plan_t p, const int32_t **block_starts_dev, int32_t *max_ents_per_block);
 int fd_plan_info(fd_plan_t p, int32_t *nblocks, int32_t *max_nodes_per_block, int64_t *list_len);
 int fd_plan_arrays(fd_plan_t p, const int32_t **block_offsets, const int32_t **node_list,
@@ -159,7 +167,9 @@ int fd_matplan_free(fd_matplan_t m);
 typedef struct fd_ocrplan_s *fd_ocrplan_t;
 int fd_ocrplan_create(const int32_t *rmap_dev, int rarity, int32_t start, int32_t end,
                       const int32_t *row_block_starts_host, int32_t nblocks, int interleave,
-                      fd_stream_t s, fd_ocrplan_t *out);   /* interleave > 1: spread neighbouring entities over lanes */
+                      fd_stream_t s, fd_ocrplan_t *out);   /* interleave > 1: multiplicative permutation of every instance list;
+                                                             * interleave < 0: lane order for -interleave lanes (see
+                                                             * fd_plan_set_lane_order) */
 int fd_ocrplan_info(fd_ocrplan_t p, int64_t *ninst, int32_t *max_inst_per_block);
 int fd_ocrplan_arrays(fd_ocrplan_t p, const int32_t **inst_off_dev, const int32_t **inst_off_host,
                       const int32_t **inst_entity_dev, const int32_t **row_block_starts_dev);
