@@ -174,7 +174,7 @@ def main():
     ap.add_argument("--degree", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=128, help="cube size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-bcs", action="store_true")
-    ap.add_argument("--tile", type=str, default="8,4,4", help="cubes per traversal tile (= plan block)")
+    ap.add_argument("--tile", type=str, default="8,8,4", help="cubes per traversal tile (= plan block)")
     ap.add_argument("--only", choices=["both", "residual", "jacobian"], default="both", help="profiling aid: run one form only")
     ap.add_argument("--workload", choices=["c1", "c2", "c3"], default="c2",
                     help="c2 = headline config (default); c1 = launch-bound 64x64 square (eager vs hipGraph); c3 = Q4 hex MFMA")
@@ -278,7 +278,7 @@ def main():
         # profiles/r1f_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) KB, MI355X_MICROARCH.md HBM section); only
         # valid for the default workload it was collected on
         tpath = os.path.join(ROOT, "profiles", "r1f_traffic.json")
-        if os.path.exists(tpath) and n == 215 and args.degree == 1 and world == 1 and args.tile == "8,4,4":
+        if os.path.exists(tpath) and n == 215 and args.degree == 1 and world == 1 and args.tile == "8,8,4":
             tr = json.load(open(tpath))
             for roof in (roof_res, roof_jac):
                 t = tr.get(roof["kernel"], {}).get("hbm_bytes_per_launch")

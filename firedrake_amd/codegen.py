@@ -61,6 +61,7 @@ class WrapperSource:
     kbytes: int = 1
     mat_staged: dict = field(default_factory=dict)
     lane_threads: int = 0                                  # >0: plans must be in lane order for this many lanes
+    rep_shift: int = 0                                     # log2(replicas of every LDS accumulator)
 
 
 def _distinct_maps(gk: GlobalKernel):
@@ -138,8 +139,17 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     ih = extruded and region == ON_INTERIOR_FACETS
     nf = 2 if ih else 1
     threads = configuration["block_threads"]
-    if mode.startswith("ocr") and configuration["ocr_block_threads"]:
-        threads = configuration["ocr_block_threads"]
+    if mode.startswith("ocr"):
+        if configuration["ocr_block_threads"]:
+            threads = configuration["ocr_block_threads"]
+        else:
+            # small element matrices leave registers to spare: wider workgroups amortise the per-block staging and
+            # flush phases; large ones (P2: 10x10 doubles per lane) need the full register budget of 256-lane groups
+            entries = max(int(np.prod(a.dims[0])) * int(np.prod(a.dims[1])) * a.maps[0].arity * a.maps[1].arity
+                          for a in gk.arguments if isinstance(a, MatKernelArg))
+            threads = 512 if entries <= 32 else threads
+    has_mat = any(isinstance(a, MatKernelArg) for a in gk.arguments)
+    rep_shift = max(1, min(32, int(configuration["ocr_replicas" if has_mat else "lds_replicas"]))).bit_length() - 1
 
     params: List[str] = []
     layout: List[tuple] = []
@@ -197,9 +207,6 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
 
     # ---- backend-private parameters
     P("const int *__restrict__ bstart_", ("bstart",))
-    if staged:
-        # log2 of the number of lane-private replicas of every LDS accumulator (see "replicated accumulators" below)
-        P("long long fd_rsh_", ("rep_shift",))
     if ocr:
         P("const int *__restrict__ inst_ent_", ("ocr_inst_ent",))
     staged_maps = []
@@ -388,9 +395,12 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
                           f"  const int base = (int)(rw{k}[i] & 0x3fffffffu) - 1;",
                           "  if (base < 0) continue;          /* row owned by another block (or BC-masked) */",
                           f"  for (int j = 0; j < {ac}; ++j) {{"]
+                # a BC-masked column adds 0.0 to its (existing) position instead of branching around the atomic:
+                # the value array is unchanged either way, and the scatter stays one branch per row
+                val = f"t{k}[i*{ac} + j]"
                 if lg:
-                    lines.append(f"    if ({'cmk%d[j]' % k if cm != rm else '(rw%d[j] >> 31)' % k}) continue;")
-                lines += [f"    atomicAdd(&sm{k}[((base + kk{k}[i*{ac} + j]) << fd_rsh) + fd_r], t{k}[i*{ac} + j]);", "  }", "}"]
+                    val = f"(({'cmk%d[j]' % k if cm != rm else '(rw%d[j] >> 31)' % k}) ? 0.0 : {val})"
+                lines += [f"    atomicAdd(&sm{k}[((base + kk{k}[i*{ac} + j]) << fd_rsh) + fd_r], {val});", "  }", "}"]
                 unpack.append("\n    ".join(lines))
                 # complete rows, contiguous in the CSR value array: plain coalesced stores
                 flush.append((rm, f"if (oc{k}_flags & 1) {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)r0_{k} + q] = fdw::rep_sum<double>(sm{k}, q, fd_rsh); }} "
@@ -473,7 +483,8 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     if staged:
         src += ["  extern __shared__ __align__(16) unsigned char fd_lds[];",
                 "  const int tid = threadIdx.x, nthr = blockDim.x;",
-                "  const int fd_rsh = (int)fd_rsh_, fd_r = tid & ((1 << fd_rsh) - 1);",
+                # log2 of the number of lane-private replicas of every LDS accumulator ("replicated accumulators" above)
+                f"  constexpr int fd_rsh = {rep_shift}; const int fd_r = tid & ((1 << fd_rsh) - 1);",
                 "  const int b = fdw::xcd_block(blockIdx.x, gridDim.x);",
                 "  const int e0 = bstart_[b], e1 = bstart_[b+1];"]
         src += ["  " + s for s in lds_decl]
@@ -517,7 +528,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             if info["kind"] == "mat" and ocr:
                 k, n = info["k"], info["ar"] * info["ac"]
                 idx_loads.append((f"int kk{k}[{n}]", f"int nx_kk{k}[{n}]", f"kk{k}", n,
-                                  f"fdw::load_packed<{ktype}, {n}>(oc{k}_k + (size_t)(EE)*{n}, DST);"))
+                                  f"fdw::load_packed<{ktype}, {n}>(oc{k}_k + (size_t)(II - start)*{n}, DST);"))
         pf = bool(configuration["prefetch"])
         # lane order (fd_plan_set_lane_order): slot k*nthr + t of a block holds the k-th entity of lane t's contiguous
         # run, so the lanes of one trip work on entities that are far apart (no shared nodes -> no serialised LDS
@@ -623,7 +634,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     src.append("}")
     return WrapperSource("\n".join(src) + "\n", sym, mode, layout, len(maps), staged_maps, lds_items,
                          layer_parallel, threads, kbytes, mat_staged,
-                         (threads if (staged and configuration["lane_strided"]) else 0))
+                         (threads if (staged and configuration["lane_strided"]) else 0), rep_shift)
 
 
 def _permi(perm, i):

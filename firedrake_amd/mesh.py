@@ -93,7 +93,7 @@ def _split_blocks(blocks, arity, max_entries=32768):
         blocks = np.sort(np.concatenate([blocks, mids]))
 
 
-def UnitCubeMesh(n, degrees=(1,), tile=(8, 4, 4), rank=0, nranks=1, perturb=0.0, ghost_cells=True):
+def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0, ghost_cells=True):
     """Kuhn-split tetrahedral unit cube, z-slab partitioned.  ``tile`` = cubes per traversal tile."""
     nx, ny, nz = (int(n),) * 3 if np.isscalar(n) else tuple(int(v) for v in n)
     # ---- cube slab owned by this rank (+ one ghost cube layer each side)

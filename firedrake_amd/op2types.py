@@ -908,10 +908,20 @@ class OcrPlan:
         self.max_nown = int(np.diff(rb).max()) if nb else 0
         maxlen = int(np.diff(rp).max()) if len(rp) > 1 else 0
         self.kbytes = 1 if maxlen <= 254 else 2
-        nent = rmap._base().values_with_halo.shape[0]
-        self.kidx = DeviceBuffer(max(nent, 1) * rmap.arity * cmap.arity * self.kbytes)
-        _lib.call("fd_csr_elem_row_offsets", sparsity._node_rowptr.ptr, sparsity._node_colidx.ptr, rmap._base()._dev_values(),
-                  cmap._base()._dev_values(), nent, rmap.arity, cmap.arity, self.kbytes, self.kidx.ptr, None)
+        # per-INSTANCE row-offset table (position of every (i, j) entry inside its CSR row), stored in instance order:
+        # the wrapper streams it coalesced next to the local maps instead of gathering 16-byte rows by entity id
+        def imap_of(m):
+            for key, mm in staged_maps.items():
+                if mm._base() is m._base():
+                    return self._imaps[key]
+            buf = DeviceBuffer(max(self.ninst, 1) * m.arity * 4)
+            _lib.call("fd_gather_rows", m._base()._dev_values(), m.arity, self.inst_ent, self.ninst, buf.ptr, None)
+            return buf
+        self.kidx = DeviceBuffer(max(self.ninst, 1) * rmap.arity * cmap.arity * self.kbytes)
+        if self.ninst:
+            ir, ic = imap_of(rmap), imap_of(cmap)
+            _lib.call("fd_csr_elem_row_offsets", sparsity._node_rowptr.ptr, sparsity._node_colidx.ptr, ir.ptr, ic.ptr,
+                      int(self.ninst), rmap.arity, cmap.arity, self.kbytes, self.kidx.ptr, None)
 
     def __del__(self):
         try:

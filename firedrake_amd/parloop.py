@@ -122,12 +122,6 @@ class MatLegacyArg:
 _mka_cache = {}
 
 
-def _rep_shift(replicas):
-    """log2 of the accumulator replica count (rounded down to a power of two, at most 32)."""
-    r = max(1, min(32, int(replicas)))
-    return r.bit_length() - 1
-
-
 def _map_kernel_arg(m):
     """One MapKernelArg per base Map object, so GlobalKernel de-duplicates by identity."""
     if m is None:
@@ -212,8 +206,6 @@ class Parloop:
         maxar = max(maps[mi].arity for mi in src.staged_maps)
         limit = configuration["lds_limit"]
 
-        has_mat = any(item[0] != "dat" for item in src.lds_items)
-        rsh_max = _rep_shift(configuration["ocr_replicas" if has_mat else "lds_replicas"])
 
         def lds_bytes(plans, mplans, rsh):
             lds = 0
@@ -237,12 +229,7 @@ class Parloop:
                     _, k, rm, cm, lg = item
                     pa = self.arguments[k]
                     mplans[k] = pa.data.sparsity.matplan(plans[rm], plans[cm], pa.maps)
-            # as many accumulator replicas as the LDS budget allows
-            rsh = rsh_max
-            while rsh > 0 and lds_bytes(plans, mplans, rsh) > limit:
-                rsh -= 1
-            self._rsh_tmp = rsh
-            return plans, mplans, lds_bytes(plans, mplans, rsh)
+            return plans, mplans, lds_bytes(plans, mplans, src.rep_shift)
 
         # 1. block boundaries suggested by the data producer (mesh traversal tiles), if they fit
         blocks = None
@@ -281,12 +268,12 @@ class Parloop:
             raise _lib.FDHipError("staged wrapper does not fit LDS even at 32 entities per block")
         if any(mp.kbytes == 2 for mp in mplans.values()) and src.kbytes == 1:
             prep["cw"] = self.global_kernel.compile("staged_k16")
-        geo = {"epb": epb, "plans": plans, "mplans": mplans, "lds": lds, "rsh": self._rsh_tmp}
+        geo = {"epb": epb, "plans": plans, "mplans": mplans, "lds": lds}
         if configuration["debug"]:
             import sys
             for mi, pl in plans.items():
                 print(f"[fdhip] {self.global_kernel.name} [{start},{end}) epb={epb} map{mi}: blocks={pl.nblocks} "
-                      f"max_nd={pl.max_nd} list_len={pl.list_len} lds={lds} replicas={1 << geo['rsh']}", file=sys.stderr)
+                      f"max_nd={pl.max_nd} list_len={pl.list_len} lds={lds} replicas={1 << src.rep_shift}", file=sys.stderr)
             for k, mp in mplans.items():
                 print(f"[fdhip]   matplan arg{k}: block-nz total={mp.total} max_nnz={mp.max_nnz} max_rowlen={mp.max_rowlen} "
                       f"kbytes={mp.kbytes} exclusive={mp.n_exclusive} zero_list={mp.n_zero}", file=sys.stderr)
@@ -331,8 +318,6 @@ class Parloop:
                 out.append(prep["maps"][desc[1]]._dev_values())
             elif kind == "bstart":
                 out.append(next(iter(geo["plans"].values())).bstart if geo else 0)
-            elif kind == "rep_shift":
-                out.append(geo["rsh"])
             elif kind == "plan_blkoff":
                 out.append(geo["plans"][desc[1]].blkoff)
             elif kind == "plan_list":
@@ -481,10 +466,7 @@ class Parloop:
                         if cmi != rm:
                             lds += (op.plans[cmi].max_nd + 15) // 16 * 16
                 return lds
-            rsh = _rep_shift(configuration["ocr_replicas"])
-            while rsh > 0 and lds_bytes(rsh) > limit:
-                rsh -= 1
-            lds = lds_bytes(rsh)
+            lds = lds_bytes(src.rep_shift)
             if lds <= limit and op.max_inst * maxar <= 32768:
                 break
             d = np.diff(rb)
@@ -499,13 +481,13 @@ class Parloop:
             raise _lib.FDHipError("owner-computes-rows plan does not fit (LDS or instance list); set FDHIP_MAT_OCR=0")
         if op.kbytes == 2 and src.kbytes == 1:
             prep["cw"] = self.global_kernel.compile("ocr_k16")
-        geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz, "rsh": rsh}
+        geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz}
         prep["parts"]["ocr"] = geo
         if configuration["debug"]:
             import sys
             print(f"[fdhip] {self.global_kernel.name} OCR: row blocks={op.nblocks} instances={op.ninst} "
                   f"(x{op.ninst / max(end, 1):.2f} entities) max_inst={op.max_inst} max_nnz={op.max_nnz} max_nown={op.max_nown} "
-                  f"lds={lds} replicas={1 << rsh} kbytes={op.kbytes}", file=sys.stderr)
+                  f"lds={lds} replicas={1 << src.rep_shift} kbytes={op.kbytes}", file=sys.stderr)
         return geo
 
     def _compute_ocr(self):
@@ -541,8 +523,6 @@ class Parloop:
                 out.append(prep["maps"][desc[1]]._dev_values())
             elif kind == "bstart":
                 out.append(op.inst_off)
-            elif kind == "rep_shift":
-                out.append(geo["rsh"])
             elif kind == "ocr_inst_ent":
                 out.append(op.inst_ent)
             elif kind == "plan_blkoff":
