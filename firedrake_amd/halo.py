@@ -122,8 +122,13 @@ class Halo:
         # device buffers go straight to RCCL; under a non-NCCL backend (gloo: debugging / the one-GPU
         # two-rank test) the packed buffers are bounced through the host
         via_host = (not self.host_mode) and dist.get_backend() != "nccl"
-        if not self.host_mode:
-            torch.cuda.synchronize()     # wrapper kernels run on the null stream; make their writes visible
+        # Wrapper kernels and the pack/unpack kernels run on the null stream, which is also torch's current stream:
+        # ProcessGroupNCCL orders its own stream after it (event record/wait) and work.wait() orders it back, so the
+        # RCCL path needs no host-side synchronisation and the host keeps queueing ahead.  The host-bounce path
+        # (non-NCCL backends) synchronises through .cpu(); FDHIP_HALO_SYNC=1 restores full device syncs everywhere.
+        self._sync = (not self.host_mode) and (via_host or os.environ.get("FDHIP_HALO_SYNC", "0") == "1")
+        if self._sync:
+            torch.cuda.synchronize()
         for r in self._neighbours():
             sl = (self.lists.send if send_kind == "send" else self.lists.recv).get(r)
             rl = (self.lists.send if recv_kind == "send" else self.lists.recv).get(r)
@@ -148,7 +153,7 @@ class Halo:
             if not self.host_mode and rbuf.device.type == "cpu":
                 rbuf = rbuf.cuda()
             self._unpack(dat, self._idx(recv_kind, r), dat.cdim, rbuf, op)
-        if not self.host_mode:
+        if getattr(self, "_sync", False):
             import torch
             torch.cuda.synchronize()
 

@@ -5,14 +5,20 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 template <int MODE>   // 0: ds_add_f64 (no return)  1: gather ds_read_b64  2: plain read+add+write  3: ds_add_f32  4: u64 int atomic add
-__global__ __launch_bounds__(256) void k(double *out, int iters, int span) {
+__global__ __launch_bounds__(256) void k(double *out, int iters, int span, int pat) {
     extern __shared__ double s[];
     for (int i = threadIdx.x; i < span; i += blockDim.x) s[i] = 0;
     __syncthreads();
     unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u;
     int idx[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { h = h * 1664525u + 1013904223u; idx[q] = (h >> 8) % span; }
+    for (int q = 0; q < 16; ++q) {
+        h = h * 1664525u + 1013904223u;
+        // pat 0: random; 1: lane-consecutive (conflict-free); 2: groups of 6 consecutive lanes share one address;
+        // 3: lane-consecutive with stride 15 (CSR rows of 15 doubles, same column)
+        idx[q] = pat == 0 ? (h >> 8) % span : pat == 1 ? (threadIdx.x + q * 256) % span
+               : pat == 2 ? (threadIdx.x / 6 + q * 64) % span : (threadIdx.x * 15 + q) % span;
+    }
     double acc = 0;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -33,17 +39,17 @@ __global__ __launch_bounds__(256) void k(double *out, int iters, int span) {
     if (threadIdx.x == 0 && (s[0] == -1.0 || acc == -1.0)) out[0] = s[1] + acc;
 }
 
-template <int MODE> void run(const char *name, int span) {
+template <int MODE> void run(const char *name, int span, int pat = 0) {
     double *out; CK(hipMalloc(&out, 64));
     int iters = 256, grid = 256 * 8;
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), span * 8, 0, out, iters, span); CK(hipDeviceSynchronize());
+    hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), span * 8, 0, out, iters, span, pat); CK(hipDeviceSynchronize());
     CK(hipEventRecord(a));
-    hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), span * 8, 0, out, iters, span);
+    hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), span * 8, 0, out, iters, span, pat);
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b));
     double ops = (double)grid * 256 * iters * 16;
-    printf("%-28s span %5d : %.3f ms  %.0f Gop/s chip  (%.2f lanes/clk/CU @2.1GHz)\n", name, span, ms, ops / ms / 1e6, ops / ms / 1e6 / 256 / 2.1);
+    printf("%-28s pat %d span %5d : %.3f ms  %.0f Gop/s chip  (%.2f lanes/clk/CU @2.1GHz)\n", name, pat, span, ms, ops / ms / 1e6, ops / ms / 1e6 / 256 / 2.1);
     CK(hipFree(out));
 }
 
@@ -57,6 +63,11 @@ int main() {
         run<5>("ds_read_b128 gather", span);
         run<6>("record 48B: 3x b128", span);
         run<7>("record 40B: 5x b64", span);
+    }
+    for (int pat : {1, 2, 3}) {
+        run<0>("ds_add_f64 (atomic)", 4096, pat);
+        run<1>("ds_read_b64 gather", 4096, pat);
+        run<2>("plain read+add+write f64", 4096, pat);
     }
     return 0;
 }
