@@ -381,15 +381,18 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
                 mat_stage_pre.extend([f"const int n0_{k} = oc{k}_rblk[b], nown{k} = oc{k}_rblk[b+1] - n0_{k};",
                                       f"const int r0_{k} = oc{k}_rowptr[n0_{k}], nnzb{k} = oc{k}_rowptr[n0_{k} + nown{k}] - r0_{k};"])
                 stage.append((rm, f"for (int q = tid; q < nnzb{k} << fd_rsh; q += nthr) sm{k}[q] = 0;"))
+                # "_nm" variants leave the column masking to a post-pass (Parloop._compute_ocr: when the matrix is
+                # assembled from zero, dropping BC columns == clearing fd_csr_masked_entries afterwards)
+                colmask = bool(lg) and "_nm" not in mode
                 rowmask = f" && rlg{k}[g] >= 0" if lg else ""
-                colbit = (f" | ((clg{k}[g] < 0) ? 0x80000000u : 0u)" if (lg and cm == rm) else "")
+                colbit = (f" | ((clg{k}[g] < 0) ? 0x80000000u : 0u)" if (colmask and cm == rm) else "")
                 node_actions.setdefault(rm, []).append(
                     ([f"const int g = G_U; const unsigned w{k}_U = ((g >= n0_{k} && g < n0_{k} + nown{k}{rowmask}) ? (unsigned)(oc{k}_rowptr[g] - r0_{k} + 1) : 0u){colbit};".replace("const int g = G_U; ", "").replace("(g ", "(G_U ").replace(" g ", " G_U ").replace("[g]", "[G_U]")],
                      [f"srow{k}[I_U] = w{k}_U;"]))
-                if lg and cm != rm:
+                if colmask and cm != rm:
                     node_actions.setdefault(cm, []).append(([f"const bool m{k}_U = clg{k}[G_U] < 0;"], [f"smc{k}[I_U] = m{k}_U;"]))
                 lines = [f"unsigned int rw{k}[{ar}];", f"for (int i = 0; i < {ar}; ++i) rw{k}[i] = srow{k}[lm{rm}[i]];"]
-                if lg and cm != rm:
+                if colmask and cm != rm:
                     lines += [f"bool cmk{k}[{ac}];", f"for (int j = 0; j < {ac}; ++j) cmk{k}[j] = smc{k}[lm{cm}[j]];"]
                 lines += [f"for (int i = 0; i < {ar}; ++i) {{",
                           f"  const int base = (int)(rw{k}[i] & 0x3fffffffu) - 1;",
@@ -398,7 +401,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
                 # a BC-masked column adds 0.0 to its (existing) position instead of branching around the atomic:
                 # the value array is unchanged either way, and the scatter stays one branch per row
                 val = f"t{k}[i*{ac} + j]"
-                if lg:
+                if colmask:
                     val = f"(({'cmk%d[j]' % k if cm != rm else '(rw%d[j] >> 31)' % k}) ? 0.0 : {val})"
                 lines += [f"    atomicAdd(&sm{k}[((base + kk{k}[i*{ac} + j]) << fd_rsh) + fd_r], {val});", "  }", "}"]
                 unpack.append("\n    ".join(lines))

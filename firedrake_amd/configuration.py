@@ -25,7 +25,7 @@ configuration = {
     "stage_unroll": _env("FDHIP_STAGE_UNROLL", 1, int),   # nodes staged per lane per trip (memory-level parallelism)
     "lds_replicas": _env("FDHIP_LDS_REPLICAS", 1, int),   # lane-private copies of staged Dat accumulators (power of two)
     "ocr_replicas": _env("FDHIP_OCR_REPLICAS", 1, int),   # the same for block matrix accumulators
-    "lane_strided": _env("FDHIP_LANE_STRIDED", 1, int),   # lane t handles a contiguous run of the block's entities
+    "ocr_post_mask": _env("FDHIP_OCR_POST_MASK", 0, int),  # fused-zero OCR assembly: clear BC columns after the loop
     "lane_strided": _env("FDHIP_LANE_STRIDED", 1, int),   # plans in lane order (fd_plan_set_lane_order)
     "lds_soa": _env("FDHIP_LDS_SOA", 1, int),             # component-major LDS layout for staged vector Dats
     "prefetch": _env("FDHIP_PREFETCH", 1, int),          # software-pipeline the packed index rows

@@ -152,6 +152,7 @@ class Parloop:
         self._check_maps()
         self._prepared = None
         self._lgmap_dev = {}
+        self._masked = {}
         # owner-computes-rows matrix assembly on a partitioned mesh: also execute the ghost entities
         # [size, total_size) (their non-owned rows are masked by the lgmaps)
         self.compute_ghost = False
@@ -498,7 +499,16 @@ class Parloop:
         op = geo["ocr"]
         if op.nblocks == 0 or op.ninst == 0:
             return
+        # A matrix assembled from zero: BC-masked COLUMNS need no test per inserted entry -- insert everything and
+        # clear the masked positions afterwards (fd_csr_masked_entries, built once per lgmap).  Rows stay masked
+        # in the kernel (that only skips work).
+        mpa = self.arguments[geo["k"]]
+        post_mask = bool(mpa.lgmaps is not None and mpa.data._zero_pending and configuration["ocr_post_mask"])
+        if post_mask:
+            cw = self.global_kernel.compile("ocr_nm" + ("_k16" if src.kbytes == 2 else ""))
+            assert cw.src.layout == src.layout
         out = []
+        post_vals = None
         for desc in src.layout:
             kind = desc[0]
             if kind == "arg":
@@ -507,6 +517,7 @@ class Parloop:
                     mat = pa.data
                     mat.dat_version += 1
                     vals = mat._values_raw()
+                    post_vals = vals
                     flag = 0
                     if mat._zero_pending:
                         # rows outside the blocks (ghost rows) are the only part the loop does not overwrite
@@ -552,6 +563,24 @@ class Parloop:
                 raise AssertionError(kind)
         cw.launch(0, op.ninst, out, block_threads=src.block_threads, ents_per_block=op.max_inst, nblocks=op.nblocks,
                   lds_bytes=geo["lds"])
+        if post_mask:
+            lst, n = self._masked_entries(mpa)
+            if n:
+                _lib.call("fd_csr_zero_entries", post_vals.ptr, lst, n, None)
+
+    def _masked_entries(self, pa):
+        """(device list, length) of the CSR positions whose column ``pa``'s column lgmap masks; cached per lgmap."""
+        clg = pa.lgmaps[1]
+        hit = self._masked.get(id(clg))
+        if hit is None or hit[0] is not clg:
+            sp = pa.data.sparsity
+            sp._build()
+            lst, n = ctypes.c_void_p(), ctypes.c_int64()
+            _lib.call("fd_csr_masked_entries", sp._node_colidx.ptr, sp._node_nnz, self._lgmap(clg), ctypes.byref(lst),
+                      ctypes.byref(n), None)
+            hit = (clg, DeviceBuffer.wrap(lst.value, n.value * 4) if lst.value else None, n.value)
+            self._masked[id(clg)] = hit
+        return (hit[1].ptr if hit[1] is not None else None), hit[2]
 
     def _nlayers_iterated(self):
         from .op2types import ON_BOTTOM, ON_TOP, ON_INTERIOR_FACETS

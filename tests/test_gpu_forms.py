@@ -66,6 +66,29 @@ def test_poisson_residual_and_jacobian(dim, degree, n, bcs, ocr, monkeypatch):
         assert_allclose(y.data_ro + load, ro, rtol=0, atol=1e-10 * max(1.0, np.abs(ro).max()))
 
 
+@pytest.mark.parametrize("post_mask", [1, 0])
+def test_bc_column_masking_fused_and_accumulating(post_mask, monkeypatch):
+    """Owner-computes-rows with BC lgmaps: (i) assembled from zero -> columns cleared by the post-pass
+    (fd_csr_masked_entries) or masked in the kernel, same matrix; (ii) a second loop WITHOUT Mat.zero()
+    accumulates (MatSetValuesLocal ADD_VALUES, builder.py:573-625) and must mask inside the kernel: exactly
+    twice the dropped-column matrix, BC diagonal untouched by the loop."""
+    monkeypatch.setitem(configuration, "ocr_post_mask", post_mask)
+    m = fmesh.UnitCubeMesh(10, degrees=(1,), tile=(4, 4, 2), perturb=0.1)
+    prob = forms.PoissonProblem(m, 1, bcs=True)
+    _, Ao = _oracle_problem(prob, True)
+    A1 = prob.assemble_jacobian().toscipy()
+    assert_allclose(A1.data, Ao.data, rtol=0, atol=1e-12 * np.abs(Ao.data).max())
+    mat, loop = prob.jacobian()
+    loop()                                   # no zero(): accumulate a second copy of the masked operator
+    A2 = mat.toscipy()
+    bc = np.zeros(prob.V.node_set.total_size, dtype=bool)
+    bc[prob.bc_nodes] = True
+    rows = np.repeat(np.arange(A2.shape[0]), np.diff(A2.indptr))
+    masked = bc[rows] | bc[A2.indices]
+    expect = np.where(masked, A1.data, 2.0 * A1.data)     # masked entries: diagonal 1 / zeros stay as they were
+    assert_allclose(A2.data, expect, rtol=0, atol=1e-12 * np.abs(Ao.data).max())
+
+
 def test_c1_config_sizes_and_direct_mode(monkeypatch):
     """BASELINE.json configs[0]: Poisson CG1 on UnitSquareMesh(64,64), both wrapper shapes."""
     m = fmesh.UnitSquareMesh(64, 64)
