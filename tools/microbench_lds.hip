@@ -17,7 +17,11 @@ __global__ __launch_bounds__(256) void k(double *out, int iters, int span, int p
         // pat 0: random; 1: lane-consecutive (conflict-free); 2: groups of 6 consecutive lanes share one address;
         // 3: lane-consecutive with stride 15 (CSR rows of 15 doubles, same column)
         idx[q] = pat == 0 ? (h >> 8) % span : pat == 1 ? (threadIdx.x + q * 256) % span
-               : pat == 2 ? (threadIdx.x / 6 + q * 64) % span : (threadIdx.x * 15 + q) % span;
+               : pat == 2 ? (threadIdx.x / 6 + q * 64) % span : pat == 3 ? (threadIdx.x * 15 + q) % span
+               // 4/5/6: lanes l and l+16 / l+8 / l+32 hit the same BANK at different addresses (conflict window probe)
+               : pat == 4 ? ((threadIdx.x & 15) + 32 * ((threadIdx.x >> 4) + 16 * q)) % span
+               : pat == 5 ? ((threadIdx.x & 7) + 32 * ((threadIdx.x >> 3) + 32 * q)) % span
+               : ((threadIdx.x & 31) + 32 * ((threadIdx.x >> 5) + 8 * q)) % span;
     }
     double acc = 0;
     for (int it = 0; it < iters; ++it) {
@@ -64,7 +68,7 @@ int main() {
         run<6>("record 48B: 3x b128", span);
         run<7>("record 40B: 5x b64", span);
     }
-    for (int pat : {1, 2, 3}) {
+    for (int pat : {1, 2, 3, 4, 5, 6}) {
         run<0>("ds_add_f64 (atomic)", 4096, pat);
         run<1>("ds_read_b64 gather", 4096, pat);
         run<2>("plain read+add+write f64", 4096, pat);
