@@ -62,6 +62,7 @@ class WrapperSource:
     mat_staged: dict = field(default_factory=dict)
     lane_threads: int = 0                                  # >0: plans must be in lane order for this many lanes
     rep_shift: int = 0                                     # log2(replicas of every LDS accumulator)
+    ocr_lds_limit: int = 0                                 # LDS budget of an OCR row block (0 = configuration["lds_limit"])
 
 
 def _distinct_maps(gk: GlobalKernel):
@@ -139,15 +140,22 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     ih = extruded and region == ON_INTERIOR_FACETS
     nf = 2 if ih else 1
     threads = configuration["block_threads"]
+    if not threads:
+        # staged loops over high-arity maps (P2: 10 nodes per cell, ~2600 nodes per block) stage and flush several
+        # nodes per lane: 512-lane groups halve those phases (P2 residual 0.48 -> 0.37 ms); P1 is best at 256
+        threads = 512 if (mode.startswith("staged") and max((m.arity for m in maps), default=0) >= 8) else 256
     if mode.startswith("ocr"):
         if configuration["ocr_block_threads"]:
             threads = configuration["ocr_block_threads"]
         else:
-            # small element matrices leave registers to spare: wider workgroups amortise the per-block staging and
-            # flush phases; large ones (P2: 10x10 doubles per lane) need the full register budget of 256-lane groups
-            entries = max(int(np.prod(a.dims[0])) * int(np.prod(a.dims[1])) * a.maps[0].arity * a.maps[1].arity
-                          for a in gk.arguments if isinstance(a, MatKernelArg))
-            threads = 512 if entries <= 32 else threads
+            threads = 512     # 8 wavefronts amortise the per-block staging and flush phases (256 VGPRs per lane still fit)
+        # Large element matrices (P2 tets: 10x10) have long rows, so a 64 KiB row block owns few rows and most of its
+        # instances are border entities computed again by the neighbours.  Give such loops the whole CU's LDS:
+        # one 512-lane group per CU, ~2x the rows per block (P2 Jacobian 2.57 -> 1.87 ms).  Small element matrices
+        # (P1: 4x4) do better with three 47 KiB groups per CU overlapping their phases.
+        entries = max(int(np.prod(a.dims[0])) * int(np.prod(a.dims[1])) * a.maps[0].arity * a.maps[1].arity
+                      for a in gk.arguments if isinstance(a, MatKernelArg))
+        ocr_lds_limit = configuration["ocr_lds_limit"] or (159 * 1024 if entries > 32 else 0)
     has_mat = any(isinstance(a, MatKernelArg) for a in gk.arguments)
     rep_shift = max(1, min(32, int(configuration["ocr_replicas" if has_mat else "lds_replicas"]))).bit_length() - 1
 
@@ -637,7 +645,8 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     src.append("}")
     return WrapperSource("\n".join(src) + "\n", sym, mode, layout, len(maps), staged_maps, lds_items,
                          layer_parallel, threads, kbytes, mat_staged,
-                         (threads if (staged and configuration["lane_strided"]) else 0), rep_shift)
+                         (threads if (staged and configuration["lane_strided"]) else 0), rep_shift,
+                         ocr_lds_limit if ocr else 0)
 
 
 def _permi(perm, i):

@@ -19,12 +19,13 @@ configuration = {
     "type_check": _env("FDHIP_TYPE_CHECK", 1, int),
     # wrapper generation
     "mode": _env("FDHIP_MODE", "auto"),                 # auto | staged | direct
-    "block_threads": _env("FDHIP_BLOCK_THREADS", 256, int),
+    "block_threads": _env("FDHIP_BLOCK_THREADS", 0, int),
     "ents_per_block": _env("FDHIP_ENTS_PER_BLOCK", 1024, int),
     "pipeline_packs": _env("FDHIP_PIPELINE_PACKS", 0, int),  # gather the next entity's packs from LDS one iteration ahead
     "stage_unroll": _env("FDHIP_STAGE_UNROLL", 1, int),   # nodes staged per lane per trip (memory-level parallelism)
     "lds_replicas": _env("FDHIP_LDS_REPLICAS", 1, int),   # lane-private copies of staged Dat accumulators (power of two)
     "ocr_replicas": _env("FDHIP_OCR_REPLICAS", 1, int),   # the same for block matrix accumulators
+    "ocr_lds_limit": _env("FDHIP_OCR_LDS_LIMIT", 0, int),  # 0 = auto (whole CU for large element matrices)
     "ocr_post_mask": _env("FDHIP_OCR_POST_MASK", 0, int),  # fused-zero OCR assembly: clear BC columns after the loop
     "lane_strided": _env("FDHIP_LANE_STRIDED", 1, int),   # plans in lane order (fd_plan_set_lane_order)
     "lds_soa": _env("FDHIP_LDS_SOA", 1, int),             # component-major LDS layout for staged vector Dats

@@ -433,7 +433,7 @@ class Parloop:
         nrows = rmap.toset.size                                   # owned rows only
         end = self.iterset.total_size if self.compute_ghost else self.iterset.size
         rp = sp._node_rowptr.download(np.int32, (rmap.toset.total_size + 1,))
-        limit = configuration["lds_limit"]
+        limit = src.ocr_lds_limit or configuration["lds_limit"]
         hint = getattr(rmap._base(), "preferred_node_blocks", None)
         if hint is not None and configuration["use_preferred_blocks"]:
             rb = np.asarray(hint, dtype=np.int64)
