@@ -165,6 +165,53 @@ def run_c1(args):
                       "eager_ms_per_step": eager * 1e3, "graph_ms_per_step": graph * 1e3, "roofline": None, "cpu_baseline": None}))
 
 
+def run_c4(args):
+    """BASELINE.json configs[3]: DG_advection demo, DQ1 on quadrilaterals -- the 1-form L1 (cell + exterior-facet +
+    interior-facet integrals, upwind flux) assembled matrix-free: three parloops INC-ing one Dat (C4)."""
+    from firedrake_amd import _lib, forms, mesh as fmesh
+    from firedrake_amd.device import Event
+    _lib.require_gpu()
+    n = args.n if args.n != 215 else 2048
+    m = fmesh.make_quad_mesh(n, perturb=0.1)
+    prob = forms.DGAdvectionProblem(m)
+    for _ in range(max(args.warmup, 1)):
+        prob.assemble_rhs()
+    _lib.call("fd_device_sync")
+    names = [lp.global_kernel.name for lp in prob.loops]
+    ev = [[Event() for _ in range(len(prob.loops) + 1)] for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        # same sequence as DGAdvectionProblem.assemble_rhs, with an event between the three loops
+        prob.L.zero()
+        with prob.L.frozen_halo(forms.op2.INC):
+            ev[k][0].record()
+            for i, loop in enumerate(prob.loops):
+                loop()
+                ev[k][i + 1].record()
+    _lib.call("fd_device_sync")
+    elapsed = time.perf_counter() - t0
+    per = [float(np.median([ev[k][i].elapsed_ms(ev[k][i + 1]) for k in range(args.steps)])) for i in range(len(prob.loops))]
+    ncell, nint, next_ = m.cell_set.size, m.int_facet_set.size, m.ext_facet_set.size
+    ndq, nq1 = m.dq_set.size, m.q1_set.size
+    # algorithmic bytes per loop (SURVEY.md 8d): maps + direct facet numbers + every node array once; the INC output is
+    # written once by the first loop (+ the zeroing pass) and read+written by the loops that accumulate on top of it
+    node_in = nq1 * (16 + 16) + ndq * 8
+    b_cell = ncell * (4 + 4) * 4 + node_in + ndq * 8 + ndq * 8
+    b_ext = next_ * ((4 + 4) * 4 + 4 + 4 * (16 + 16) + 4 * (8 + 16))     # boundary cells only: per-facet rows, no reuse
+    b_int = nint * ((8 + 8) * 4 + 8) + node_in + ndq * 16
+    roofs = []
+    for name, ms, nbytes in zip(names, per, (b_cell, b_ext, b_int)):
+        roofs.append({"kernel": name, "bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "ms": ms, "algorithmic_bytes": nbytes})
+    dominant = max(roofs, key=lambda r: r["ms"])
+    print(json.dumps({"metric": "assembled DoFs/sec (DG advection RHS action)", "value": ndq / (elapsed / args.steps), "unit": "DoFs/s",
+                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                      "config": {"workload": f"DG_advection demo 1-form L1, DQ1 on {n}x{n} quadrilaterals (BASELINE.json configs[3])",
+                                 "cells": ncell, "dofs": ndq, "interior_facets": nint, "exterior_facets": next_},
+                      "roofline": dominant, "roofline_per_loop": roofs, "cpu_baseline": None}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,8 +223,9 @@ def main():
     ap.add_argument("--no-bcs", action="store_true")
     ap.add_argument("--tile", type=str, default="8,8,4", help="cubes per traversal tile (= plan block)")
     ap.add_argument("--only", choices=["both", "residual", "jacobian"], default="both", help="profiling aid: run one form only")
-    ap.add_argument("--workload", choices=["c1", "c2", "c3"], default="c2",
-                    help="c2 = headline config (default); c1 = launch-bound 64x64 square (eager vs hipGraph); c3 = Q4 hex MFMA")
+    ap.add_argument("--workload", choices=["c1", "c2", "c3", "c4"], default="c2",
+                    help="c2 = headline config (default); c1 = launch-bound 64x64 square (eager vs hipGraph); c3 = Q4 hex MFMA; "
+                         "c4 = DG advection RHS action")
     args = ap.parse_args()
     if args.workload == "c3":
         import torch  # noqa: F401
@@ -185,6 +233,9 @@ def main():
     if args.workload == "c1":
         import torch  # noqa: F401
         return run_c1(args)
+    if args.workload == "c4":
+        import torch  # noqa: F401
+        return run_c4(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
