@@ -33,7 +33,9 @@ configuration = {
     "mat_ocr": _env("FDHIP_MAT_OCR", 1, int),             # owner-computes-rows matrix assembly (no global atomics)
     "ocr_nnz_per_block": _env("FDHIP_OCR_NNZ", 2048, int),  # row-block size (CSR entries) when the producer gives no hint
     "ocr_block_threads": _env("FDHIP_OCR_BLOCK_THREADS", 0, int),  # 0 = auto: 512 for small element matrices, else block_threads
-    "ocr_interleave": _env("FDHIP_OCR_INTERLEAVE", 1, int),  # lane <-> instance stride inside a block (1 = none)
+    # order of the instances inside an owner-computes-rows block: "lane" (fd_plan_set_lane_order), "stencil"
+    # (sorted by owned-row signature), "natural" (entity order) or an integer > 1 (multiplicative permutation)
+    "ocr_order": _env("FDHIP_OCR_ORDER", "stencil"),
     "mat_exclusive": _env("FDHIP_MAT_EXCLUSIVE", 0, int),  # non-atomic writes + fused zero for block-exclusive nonzeros
     "min_waves": _env("FDHIP_MIN_WAVES", 0, int),       # 2nd __launch_bounds__ argument (waves per SIMD), 0 = unset
     "block_merge": _env("FDHIP_BLOCK_MERGE", 1, int),     # staged loops: fuse this many consecutive producer tiles into one plan block

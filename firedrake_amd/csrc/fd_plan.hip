@@ -686,6 +686,38 @@ __global__ void ocr_lane_order(const int32_t *__restrict__ off, const int32_t *_
     for (int c = threadIdx.x; c < n; c += blockDim.x) out[o + lane_slot_of_entity(c, n, T)] = in[o + c];
 }
 
+// Stencil order: sort the instances of every block by (signature, first owned row), where the signature hashes which
+// of the entity's rows the block owns and the offsets of all its row nodes from the first owned one.  Instances with
+// equal signatures are the "same kind of entity at another place" (a tet type of the structured cube split, in the
+// same position relative to the tile border): consecutive ones touch consecutive rows, so the 16 lanes of an LDS
+// conflict window add into distinct banks, and no two of them share an accumulator in one instruction.
+__global__ void ocr_stencil_keys(const int32_t *__restrict__ rmap, int ar, const int32_t *__restrict__ inst_off,
+                                 const int32_t *__restrict__ inst_ent, const int32_t *__restrict__ rblk, int32_t nblocks,
+                                 int64_t ninst, uint64_t *__restrict__ keys) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < ninst; t += (int64_t)gridDim.x * blockDim.x) {
+        int lo = 0, hi = nblocks - 1;                      // block of instance t: largest b with inst_off[b] <= t
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (inst_off[mid] <= t) lo = mid; else hi = mid - 1;
+        }
+        const int32_t n0 = rblk[lo], n1 = rblk[lo + 1];
+        const int32_t *row = rmap + (int64_t)inst_ent[t] * ar;
+        int32_t first = -1;
+        for (int i = 0; i < ar; ++i) { int32_t r = row[i]; if (first < 0 && r >= n0 && r < n1) first = r; }
+        uint32_t h = 2166136261u;
+        for (int i = 0; i < ar; ++i) {
+            int32_t r = row[i];
+            uint32_t own = (r >= n0 && r < n1) ? 1u : 0u;
+            uint32_t d = (uint32_t)(r - first);
+            h = (h ^ own) * 16777619u;
+            h = (h ^ (d & 0xffffu)) * 16777619u;
+            h = (h ^ (d >> 16)) * 16777619u;
+        }
+        h ^= h >> 16;
+        keys[t] = ((uint64_t)(uint32_t)lo << 32) | ((uint64_t)(h & 0xffffu) << 16) | (uint64_t)((uint32_t)(first - n0) & 0xffffu);
+    }
+}
+
 __global__ void gather_rows_k(const int32_t *__restrict__ src, int arity, const int32_t *__restrict__ idx, int64_t n,
                               int32_t *__restrict__ dst) {
     const int64_t total = n * arity;
@@ -772,6 +804,28 @@ int fd_ocrplan_create(const int32_t *rmap_dev, int ar, int32_t start, int32_t en
     FD_HIP(hipMalloc(&p->inst_ent, (size_t)(nu > 0 ? nu : 1) * 4));
     hipLaunchKernelGGL(ocr_split, dim3(mp_grid(nu + 1)), dim3(256), 0, s, uniq, nu, nblocks, p->inst_off, p->inst_ent);
     FD_CHECK_LAUNCH();
+    if (interleave == 1 && nu > 0) {
+        // stencil order: (block | signature | first owned row) keys, one stable radix sort of (key, entity) pairs
+        uint64_t *ka = nullptr, *kb = nullptr;
+        int32_t *vb = nullptr;
+        FD_HIP(hipMalloc(&ka, (size_t)nu * 8));
+        FD_HIP(hipMalloc(&kb, (size_t)nu * 8));
+        FD_HIP(hipMalloc(&vb, (size_t)nu * 4));
+        hipLaunchKernelGGL(ocr_stencil_keys, dim3(mp_grid(nu)), dim3(256), 0, s, rmap_dev, ar, p->inst_off, p->inst_ent, p->rblk,
+                           nblocks, nu, ka);
+        FD_CHECK_LAUNCH();
+        hipcub::DoubleBuffer<uint64_t> dk(ka, kb);
+        hipcub::DoubleBuffer<int32_t> dv(p->inst_ent, vb);
+        size_t tb3 = 0;
+        FD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb3, dk, dv, (int)nu, 0, 64, s));
+        void *tmp3 = nullptr;
+        FD_HIP(hipMalloc(&tmp3, tb3 ? tb3 : 8));
+        FD_HIP(hipcub::DeviceRadixSort::SortPairs(tmp3, tb3, dk, dv, (int)nu, 0, 64, s));
+        FD_HIP(hipStreamSynchronize(s));
+        int32_t *sorted_ent = dv.Current(), *other = (sorted_ent == p->inst_ent) ? vb : p->inst_ent;
+        p->inst_ent = sorted_ent;
+        FD_HIP(hipFree(other)); FD_HIP(hipFree(ka)); FD_HIP(hipFree(kb)); FD_HIP(hipFree(tmp3));
+    }
     if ((interleave > 1 || interleave < 0) && nu > 0) {
         int32_t *perm = nullptr;
         FD_HIP(hipMalloc(&perm, (size_t)nu * 4));

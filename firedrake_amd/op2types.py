@@ -884,7 +884,7 @@ class OcrPlan:
         nb = len(rb) - 1
         h = ctypes.c_void_p()
         _lib.call("fd_ocrplan_create", rmap._base()._dev_values(), rmap.arity, int(start), int(end), rb.ctypes.data, nb,
-                  -int(lane_threads) if lane_threads > 0 else int(configuration["ocr_interleave"]), None, ctypes.byref(h))
+                  self._order_code(lane_threads), None, ctypes.byref(h))
         self.h = h.value
         ni, mi = ctypes.c_int64(), ctypes.c_int32()
         _lib.call("fd_ocrplan_info", self.h, ctypes.byref(ni), ctypes.byref(mi))
@@ -922,6 +922,18 @@ class OcrPlan:
             ir, ic = imap_of(rmap), imap_of(cmap)
             _lib.call("fd_csr_elem_row_offsets", sparsity._node_rowptr.ptr, sparsity._node_colidx.ptr, ir.ptr, ic.ptr,
                       int(self.ninst), rmap.arity, cmap.arity, self.kbytes, self.kidx.ptr, None)
+
+    @staticmethod
+    def _order_code(lane_threads):
+        """fd_ocrplan_create's ``interleave`` argument for configuration["ocr_order"]."""
+        order = str(configuration["ocr_order"])
+        if order == "stencil":
+            return 1
+        if order == "natural":
+            return 0
+        if order == "lane":
+            return -int(lane_threads) if lane_threads > 0 else 0
+        return int(order)
 
     def __del__(self):
         try:

@@ -167,7 +167,10 @@ int fd_matplan_free(fd_matplan_t m);
 typedef struct fd_ocrplan_s *fd_ocrplan_t;
 int fd_ocrplan_create(const int32_t *rmap_dev, int rarity, int32_t start, int32_t end,
                       const int32_t *row_block_starts_host, int32_t nblocks, int interleave,
-                      fd_stream_t s, fd_ocrplan_t *out);   /* interleave > 1: multiplicative permutation of every instance list;
+                      fd_stream_t s, fd_ocrplan_t *out);   /* interleave == 1: stencil order (instances of a block sorted by
+                                                             * which rows they own + node offsets, then by first owned
+                                                             * row: conflict-free LDS atomics on structured pieces);
+                                                             * interleave > 1: multiplicative permutation of every instance list;
                                                              * interleave < 0: lane order for -interleave lanes (see
                                                              * fd_plan_set_lane_order) */
 int fd_ocrplan_info(fd_ocrplan_t p, int64_t *ninst, int32_t *max_inst_per_block);
