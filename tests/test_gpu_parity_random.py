@@ -56,6 +56,66 @@ def test_plan_with_explicit_blocks():
     assert p.nblocks == len(blocks) - 1
 
 
+def _lane_slot_to_entity(n, T):
+    """numpy restatement of the lane order (include/fdhip.h: fd_plan_set_lane_order): slot k*T + t holds the k-th
+    entity of lane t's contiguous run; the first n % T runs are one longer."""
+    q, rem = divmod(n, T)
+    ent = np.full(n, -1, dtype=np.int64)
+    for t in range(T):
+        cnt = q + 1 if t < rem else q
+        first = t * q + min(t, rem)
+        for k in range(cnt):
+            ent[k * T + t] = first + k
+    assert (ent >= 0).all() and len(set(ent.tolist())) == n
+    return ent
+
+
+@pytest.mark.parametrize("T", [64, 256, 512])
+def test_plan_lane_order_is_the_documented_permutation(T):
+    rng = np.random.default_rng(T)
+    n, arity = 5003, 4
+    it, to = op2.Set(n), op2.Set(1500)
+    m = op2.Map(it, to, arity, ((np.arange(n)[:, None] * 1500 // n + rng.integers(0, 30, size=(n, arity))) % 1500).astype(np.int32))
+    cuts = np.sort(rng.choice(np.arange(1, n), size=9, replace=False))
+    blocks = np.concatenate([[0], cuts, [cuts[-1]], [n]]).astype(np.int32)       # includes an empty block
+    p0 = m.plan(0, n, 0, blocks)
+    p1 = m.plan(0, n, 0, blocks, lane_threads=T)
+    assert p1 is not p0
+    blk0, lst0, lm0 = p0.download()
+    blk1, lst1, lm1 = p1.download()
+    assert np.array_equal(blk0, blk1) and np.array_equal(lst0, lst1)          # node lists unchanged
+    for b in range(len(blocks) - 1):
+        e0, e1 = blocks[b], blocks[b + 1]
+        if e1 > e0:
+            ent = _lane_slot_to_entity(e1 - e0, T)
+            assert np.array_equal(lm1[e0:e1], lm0[e0:e1][ent])
+
+
+@pytest.mark.parametrize("order", ["stencil", "lane", "natural", "37"])
+def test_ocr_instance_orders_are_permutations(order, monkeypatch):
+    """Every instance order of an owner-computes-rows plan lists, per row block, exactly the entities that touch
+    the block's rows (once each); only their order differs."""
+    from firedrake_amd import mesh as fmesh
+    from firedrake_amd.op2types import OcrPlan
+    monkeypatch.setitem(configuration, "ocr_order", order)
+    m = fmesh.UnitCubeMesh(6, degrees=(1,), tile=(4, 2, 2), perturb=0.1)
+    V = m.space(1)
+    cm = V.cell_node_map
+    sp = op2.Sparsity((V.node_set ** 1, V.node_set ** 1), [(cm, cm, None)])
+    sp._build()
+    nrows = V.node_set.size
+    rb = np.unique(np.concatenate([np.arange(0, nrows, 37), [nrows]])).astype(np.int32)
+    op = OcrPlan(sp, cm, cm, {0: cm}, 0, m.cell_set.size, rb, lane_threads=128)
+    ent = np.empty(op.ninst, dtype=np.int32)
+    from firedrake_amd import _lib
+    _lib.call("fd_memcpy_d2h", ent.ctypes.data, op.inst_ent, ent.nbytes, None)
+    vals = cm.values_with_halo
+    for b in range(len(rb) - 1):
+        got = np.sort(ent[op.inst_off_host[b]:op.inst_off_host[b + 1]])
+        touch = ((vals[:m.cell_set.size] >= rb[b]) & (vals[:m.cell_set.size] < rb[b + 1])).any(axis=1)
+        assert np.array_equal(got, np.nonzero(touch)[0])
+
+
 @pytest.mark.parametrize("nx,ny", [(7, 5), (64, 64), (200, 150)])
 @pytest.mark.parametrize("shuffle", [False, True])
 def test_p1_mass_and_rhs_all_paths(nx, ny, shuffle, monkeypatch):
