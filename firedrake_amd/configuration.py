@@ -25,6 +25,7 @@ configuration = {
     "stage_unroll": _env("FDHIP_STAGE_UNROLL", 1, int),   # nodes staged per lane per trip (memory-level parallelism)
     "lds_replicas": _env("FDHIP_LDS_REPLICAS", 1, int),   # lane-private copies of staged Dat accumulators (power of two)
     "ocr_replicas": _env("FDHIP_OCR_REPLICAS", 1, int),   # the same for block matrix accumulators
+    "ocr_pack": _env("FDHIP_OCR_PACK", 1, int),            # bank-aware greedy packing of the instance lists (fd_ocrplan_pack)
     "ocr_lds_limit": _env("FDHIP_OCR_LDS_LIMIT", 0, int),  # 0 = auto (whole CU for large element matrices)
     "ocr_post_mask": _env("FDHIP_OCR_POST_MASK", 0, int),  # fused-zero OCR assembly: clear BC columns after the loop
     "lane_strided": _env("FDHIP_LANE_STRIDED", 1, int),   # plans in lane order (fd_plan_set_lane_order)

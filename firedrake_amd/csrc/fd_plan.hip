@@ -718,6 +718,105 @@ __global__ void ocr_stencil_keys(const int32_t *__restrict__ rmap, int ar, const
     }
 }
 
+
+// ---- bank-aware packing of the instances of a row block --------------------------------------------------------
+// The wrapper's lanes walk the instance slots in order, so the 16 lanes of an LDS conflict window (64-bit LDS
+// operations are processed 16 lanes at a time; tools/microbench_lds.hip) are 16 consecutive slots.  Per slot the
+// kernel issues, for each row vertex i, gathers at local node index lm[i] (32 eight-byte banks: bank = lm & 31; equal
+// addresses broadcast) and, for each owned row i and column j, a ds_add_f64 at (row base + position); the fp64 atomic
+// path resolves only 16 banks (measured: stride-2 doubles already halve its rate, profiles/r1i_microbench_lds.txt):
+// bank = that & 15, and equal addresses serialise too.  A greedy list scheduler fills the windows one slot at a time: among the next CAND
+// unplaced instances (in stencil order) it takes the one that adds the fewest bank collisions to the current
+// window, ties to the earliest.  One wavefront per block; lane l scores candidate l.
+constexpr int PACK_MAXSIG = 32;      // ar + ar*ac signature bytes per instance at most
+constexpr int PACK_CAND = 128;
+
+__global__ __launch_bounds__(64) void ocr_pack_k(const int32_t *__restrict__ inst_off, const int32_t *__restrict__ ent_in,
+                                                 int32_t *__restrict__ ent_out, const int32_t *__restrict__ imap_r,
+                                                 const uint16_t *__restrict__ lmap, const unsigned char *__restrict__ kidx8,
+                                                 const unsigned short *__restrict__ kidx16, int ar, int ac,
+                                                 const int32_t *__restrict__ rblk, const int32_t *__restrict__ rowptr,
+                                                 int maxn, int window, int cand) {
+    extern __shared__ unsigned char pk_lds[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int o = inst_off[b], n = inst_off[b + 1] - o;
+    if (n <= window || n > maxn) {                       // nothing to gain / does not fit: keep the order
+        for (int q = lane; q < n; q += 64) ent_out[o + q] = ent_in[o + q];
+        return;
+    }
+    const int ns = ar + ar * ac;
+    unsigned char *sig = pk_lds;                                          // n * ns bank bytes (0xff = no access)
+    unsigned short *gaddr = (unsigned short *)(pk_lds + (((size_t)maxn * ns + 15) & ~(size_t)15));   // n * ar local node ids
+    unsigned short *pool = gaddr + (size_t)maxn * ar;                     // n slots: unplaced instances in order
+    unsigned int *amask = (unsigned int *)(pool + ((maxn + 7) & ~7));     // ar*ac bank masks of the current window
+    unsigned short *gown = (unsigned short *)(amask + PACK_MAXSIG);       // ar * 32: address held by a gather bank
+    const int32_t n0 = rblk[b], n1 = rblk[b + 1];
+    const int32_t r0 = rowptr[n0];
+    for (int q = lane; q < n; q += 64) {
+        const int64_t t = (int64_t)o + q;
+        for (int i = 0; i < ar; ++i) {
+            const unsigned short l = lmap[t * ar + i];
+            gaddr[q * ar + i] = l;
+            sig[q * ns + i] = (unsigned char)(l & 31);
+            const int32_t g = imap_r[t * ar + i];
+            const bool own = g >= n0 && g < n1;
+            const int base = own ? rowptr[g] - r0 : 0;
+            for (int j = 0; j < ac; ++j) {
+                const int k = kidx8 ? (int)kidx8[t * ar * ac + i * ac + j] : (int)kidx16[t * ar * ac + i * ac + j];
+                sig[q * ns + ar + i * ac + j] = own ? (unsigned char)((base + k) & 15) : (unsigned char)0xff;
+            }
+        }
+        pool[q] = (unsigned short)q;
+    }
+    __syncthreads();
+    int head = 0;
+    for (int p = 0; p < n; ++p) {
+        if (p % window == 0) {
+            for (int q = lane; q < ar * ac; q += 64) amask[q] = 0u;
+            for (int q = lane; q < ar * 32; q += 64) gown[q] = 0xffffu;
+            __syncthreads();
+        }
+        const int ncand = (n - head) < cand ? (n - head) : cand;
+        int best = 0x7fffffff, bl = 0x7fffffff;          // best (cost, candidate index) seen by this lane
+        for (int c = lane; c < ncand; c += 64) {
+            const int inst = pool[head + c];
+            int cost = 0;
+            const unsigned char *s = sig + (size_t)inst * ns;
+            for (int i = 0; i < ar; ++i) {
+                const unsigned short held = gown[i * 32 + s[i]];
+                if (held != 0xffffu && held != gaddr[inst * ar + i]) cost += 3;      // one extra pass per component
+            }
+            for (int q = 0; q < ar * ac; ++q) {
+                const unsigned char bk = s[ar + q];
+                if (bk != 0xff && (amask[q] >> bk & 1u)) cost += 1;
+            }
+            if (cost < best) { best = cost; bl = c; }
+        }
+        // argmin over the wavefront, ties to the earliest candidate (keeps the incoming order where it is conflict-free)
+        for (int d = 32; d > 0; d >>= 1) {
+            const int oc = __shfl_xor(best, d, 64), ol = __shfl_xor(bl, d, 64);
+            if (oc < best || (oc == best && ol < bl)) { best = oc; bl = ol; }
+        }
+        const int chosen = pool[head + bl];
+        __syncthreads();
+        // remove pool[head + bl]: shift the earlier candidates up by one (highest first), advance head
+        for (int base = ((bl - 1) / 64) * 64; base >= 0 && bl > 0; base -= 64) {
+            const int c = base + lane;
+            unsigned short keep = 0;
+            if (c < bl) keep = pool[head + c];
+            __syncthreads();
+            if (c < bl) pool[head + c + 1] = keep;
+            __syncthreads();
+        }
+        if (lane == 0) ent_out[o + p] = ent_in[o + chosen];
+        const unsigned char *s = sig + (size_t)chosen * ns;
+        for (int q = lane; q < ar * ac; q += 64) { const unsigned char bk = s[ar + q]; if (bk != 0xff) amask[q] |= 1u << bk; }
+        if (lane < ar) { if (gown[lane * 32 + s[lane]] == 0xffffu) gown[lane * 32 + s[lane]] = gaddr[chosen * ar + lane]; }
+        ++head;
+        __syncthreads();
+    }
+}
+
 __global__ void gather_rows_k(const int32_t *__restrict__ src, int arity, const int32_t *__restrict__ idx, int64_t n,
                               int32_t *__restrict__ dst) {
     const int64_t total = n * arity;
@@ -846,6 +945,40 @@ int fd_ocrplan_create(const int32_t *rmap_dev, int ar, int32_t start, int32_t en
     }
     FD_HIP(hipFree(k1)); FD_HIP(hipFree(k2)); FD_HIP(hipFree(tmp)); FD_HIP(hipFree(nsel));
     *out = p;
+    return 0;
+}
+
+int fd_ocrplan_pack(fd_ocrplan_t p, const int32_t *imap_r_dev, const uint16_t *lmap_dev, int ar, const void *kidx_dev, int kbytes,
+                    int ac, const int32_t *node_rowptr_dev, fd_stream_t s_) {
+    if (!p || !imap_r_dev || !lmap_dev || !kidx_dev || !node_rowptr_dev || ar <= 0 || ac <= 0 || (kbytes != 1 && kbytes != 2))
+        FD_FAIL("fd_ocrplan_pack: bad arguments");
+    if (p->nblocks == 0 || p->ninst == 0) return 0;
+    const int ns = ar + ar * ac;
+    if (ns > PACK_MAXSIG) return 0;                     // large element matrices: keep the incoming order
+    hipStream_t s = fd::st(s_);
+    const int window = 16;
+    int cand = PACK_CAND;
+    if (const char *e = getenv("FDHIP_PACK_CAND")) cand = atoi(e) > 0 ? atoi(e) : PACK_CAND;
+    // per block in LDS: ns bank bytes + ar local ids + one pool slot per instance, + the window state
+    const size_t fixed = PACK_MAXSIG * 4 + (size_t)ar * 32 * 2 + 64;
+    int maxn = p->max_inst;
+    const size_t per = (size_t)ns + (size_t)ar * 2 + 2;
+    const size_t budget = 150 * 1024;
+    if ((size_t)maxn * per + fixed > budget) maxn = (int)((budget - fixed) / per);
+    maxn &= ~7;
+    if (maxn < 64) return 0;
+    const size_t lds = (((size_t)maxn * ns + 15) & ~(size_t)15) + (size_t)maxn * ar * 2 + (size_t)((maxn + 7) & ~7) * 2 + fixed;
+    if (lds > 48 * 1024)
+        FD_HIP(hipFuncSetAttribute((const void *)ocr_pack_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int32_t *out = nullptr;
+    FD_HIP(hipMalloc(&out, (size_t)p->ninst * 4));
+    hipLaunchKernelGGL(ocr_pack_k, dim3(p->nblocks), dim3(64), lds, s, p->inst_off, p->inst_ent, out, imap_r_dev, lmap_dev,
+                       kbytes == 1 ? (const unsigned char *)kidx_dev : nullptr,
+                       kbytes == 2 ? (const unsigned short *)kidx_dev : nullptr, ar, ac, p->rblk, node_rowptr_dev, maxn, window, cand);
+    FD_CHECK_LAUNCH();
+    FD_HIP(hipStreamSynchronize(s));
+    FD_HIP(hipFree(p->inst_ent));
+    p->inst_ent = out;
     return 0;
 }
 

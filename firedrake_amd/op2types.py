@@ -893,13 +893,6 @@ class OcrPlan:
         _lib.call("fd_ocrplan_arrays", self.h, *[ctypes.byref(x) for x in p])
         self.inst_off, inst_off_host, self.inst_ent, self.rblk = (x.value for x in p)
         self.inst_off_host = np.ctypeslib.as_array(ctypes.cast(inst_off_host, ctypes.POINTER(ctypes.c_int32)), shape=(nb + 1,)).copy()
-        # per-instance copies of the staged maps + their node plans over the instance blocks
-        self.plans, self._imaps = {}, {}
-        for key, m in staged_maps.items():
-            imap = DeviceBuffer(max(self.ninst, 1) * m.arity * 4)
-            _lib.call("fd_gather_rows", m._base()._dev_values(), m.arity, self.inst_ent, self.ninst, imap.ptr, None)
-            self._imaps[key] = imap
-            self.plans[key] = Plan(imap.ptr, 0, int(self.ninst), 0, self.inst_off_host, arity=m.arity)
         # geometry of the row blocks
         rp = sparsity._node_rowptr.download(np.int32, (sparsity.dsets[0].set.total_size + 1,))
         self.rows_end = int(rb[-1])
@@ -908,18 +901,41 @@ class OcrPlan:
         self.max_nown = int(np.diff(rb).max()) if nb else 0
         maxlen = int(np.diff(rp).max()) if len(rp) > 1 else 0
         self.kbytes = 1 if maxlen <= 254 else 2
-        # per-INSTANCE row-offset table (position of every (i, j) entry inside its CSR row), stored in instance order:
-        # the wrapper streams it coalesced next to the local maps instead of gathering 16-byte rows by entity id
-        def imap_of(m):
-            for key, mm in staged_maps.items():
-                if mm._base() is m._base():
-                    return self._imaps[key]
-            buf = DeviceBuffer(max(self.ninst, 1) * m.arity * 4)
-            _lib.call("fd_gather_rows", m._base()._dev_values(), m.arity, self.inst_ent, self.ninst, buf.ptr, None)
-            return buf
+        self._build_tables(sparsity, rmap, cmap, staged_maps)
+        if configuration["ocr_pack"] and self.ninst and rmap.arity * (1 + cmap.arity) <= 32:
+            # bank-aware packing needs the tables of the current order; the tables are then rebuilt for the packed order
+            ir, rkey = self._imap_of(rmap, staged_maps)
+            lm = self.plans[rkey].lmap if rkey is not None else Plan(ir.ptr, 0, int(self.ninst), 0, self.inst_off_host,
+                                                                     arity=rmap.arity).lmap
+            _lib.call("fd_ocrplan_pack", self.h, ir.ptr, lm, rmap.arity, self.kidx.ptr, self.kbytes, cmap.arity,
+                      sparsity._node_rowptr.ptr, None)
+            p = [ctypes.c_void_p() for _ in range(4)]
+            _lib.call("fd_ocrplan_arrays", self.h, *[ctypes.byref(x) for x in p])
+            self.inst_ent = p[2].value
+            self._build_tables(sparsity, rmap, cmap, staged_maps)
+
+    def _imap_of(self, m, staged_maps):
+        """(per-instance copy of Map ``m``, its key among the staged maps or None)."""
+        for key, mm in staged_maps.items():
+            if mm._base() is m._base():
+                return self._imaps[key], key
+        buf = DeviceBuffer(max(self.ninst, 1) * m.arity * 4)
+        _lib.call("fd_gather_rows", m._base()._dev_values(), m.arity, self.inst_ent, self.ninst, buf.ptr, None)
+        return buf, None
+
+    def _build_tables(self, sparsity, rmap, cmap, staged_maps):
+        """Per-instance copies of the staged maps with their node plans over the instance blocks, and the per-INSTANCE
+        row-offset table (position of every (i, j) entry inside its CSR row) in instance order: the wrapper streams it
+        coalesced next to the local maps instead of gathering 16-byte rows by entity id."""
+        self.plans, self._imaps = {}, {}
+        for key, m in staged_maps.items():
+            imap = DeviceBuffer(max(self.ninst, 1) * m.arity * 4)
+            _lib.call("fd_gather_rows", m._base()._dev_values(), m.arity, self.inst_ent, self.ninst, imap.ptr, None)
+            self._imaps[key] = imap
+            self.plans[key] = Plan(imap.ptr, 0, int(self.ninst), 0, self.inst_off_host, arity=m.arity)
         self.kidx = DeviceBuffer(max(self.ninst, 1) * rmap.arity * cmap.arity * self.kbytes)
         if self.ninst:
-            ir, ic = imap_of(rmap), imap_of(cmap)
+            ir, ic = self._imap_of(rmap, staged_maps)[0], self._imap_of(cmap, staged_maps)[0]
             _lib.call("fd_csr_elem_row_offsets", sparsity._node_rowptr.ptr, sparsity._node_colidx.ptr, ir.ptr, ic.ptr,
                       int(self.ninst), rmap.arity, cmap.arity, self.kbytes, self.kidx.ptr, None)
 

@@ -21,7 +21,9 @@ __global__ __launch_bounds__(256) void k(double *out, int iters, int span, int p
                // 4/5/6: lanes l and l+16 / l+8 / l+32 hit the same BANK at different addresses (conflict window probe)
                : pat == 4 ? ((threadIdx.x & 15) + 32 * ((threadIdx.x >> 4) + 16 * q)) % span
                : pat == 5 ? ((threadIdx.x & 7) + 32 * ((threadIdx.x >> 3) + 32 * q)) % span
-               : ((threadIdx.x & 31) + 32 * ((threadIdx.x >> 5) + 8 * q)) % span;
+               : pat == 6 ? ((threadIdx.x & 31) + 32 * ((threadIdx.x >> 5) + 8 * q)) % span
+               // 100+s: lane l of every 16-lane window accesses (l & 15) * s (+ window and q offsets that keep the bank): bank function probe
+               : (((threadIdx.x & 15) * (pat - 100)) + 1024 * (threadIdx.x >> 4) % 3072 + 32 * q) % span;
     }
     double acc = 0;
     for (int it = 0; it < iters; ++it) {
@@ -72,6 +74,10 @@ int main() {
         run<0>("ds_add_f64 (atomic)", 4096, pat);
         run<1>("ds_read_b64 gather", 4096, pat);
         run<2>("plain read+add+write f64", 4096, pat);
+    }
+    for (int st : {1, 2, 3, 4, 8, 16, 32, 64}) {
+        run<0>("ds_add_f64 stride", 4096, 100 + st);
+        run<1>("ds_read_b64 stride", 4096, 100 + st);
     }
     return 0;
 }
