@@ -728,7 +728,7 @@ __global__ void ocr_stencil_keys(const int32_t *__restrict__ rmap, int ar, const
 // bank = that & 15, and equal addresses serialise too.  A greedy list scheduler fills the windows one slot at a time: among the next CAND
 // unplaced instances (in stencil order) it takes the one that adds the fewest bank collisions to the current
 // window, ties to the earliest.  One wavefront per block; lane l scores candidate l.
-constexpr int PACK_MAXSIG = 32;      // ar + ar*ac signature bytes per instance at most
+constexpr int PACK_MAXSIG = 128;     // ar + ar*ac signature bytes per instance at most
 constexpr int PACK_CAND = 128;
 
 __global__ __launch_bounds__(64) void ocr_pack_k(const int32_t *__restrict__ inst_off, const int32_t *__restrict__ ent_in,

@@ -902,7 +902,7 @@ class OcrPlan:
         maxlen = int(np.diff(rp).max()) if len(rp) > 1 else 0
         self.kbytes = 1 if maxlen <= 254 else 2
         self._build_tables(sparsity, rmap, cmap, staged_maps)
-        if configuration["ocr_pack"] and self.ninst and rmap.arity * (1 + cmap.arity) <= 32:
+        if configuration["ocr_pack"] and self.ninst and rmap.arity * (1 + cmap.arity) <= 128:
             # bank-aware packing needs the tables of the current order; the tables are then rebuilt for the packed order
             ir, rkey = self._imap_of(rmap, staged_maps)
             lm = self.plans[rkey].lmap if rkey is not None else Plan(ir.ptr, 0, int(self.ninst), 0, self.inst_off_host,

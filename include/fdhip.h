@@ -177,7 +177,7 @@ int fd_ocrplan_create(const int32_t *rmap_dev, int rarity, int32_t start, int32_
  * (global node ids), local-map rows and row-offset table built for the CURRENT instance order, a greedy list scheduler
  * reorders the instances of every block so that the 16 consecutive slots of an LDS conflict window touch distinct
  * LDS banks in the wrapper's gathers and ds_add_f64 scatter wherever the block allows it.  The caller rebuilds the
- * per-instance tables for the new order afterwards.  No-op for element matrices with ar + ar*ac > 32. */
+ * per-instance tables for the new order afterwards.  No-op for element matrices with ar + ar*ac > 128. */
 int fd_ocrplan_pack(fd_ocrplan_t p, const int32_t *imap_rows_dev, const uint16_t *lmap_dev, int ar,
                     const void *kidx_dev, int kbytes, int ac, const int32_t *node_rowptr_dev, fd_stream_t s);
 int fd_ocrplan_info(fd_ocrplan_t p, int64_t *ninst, int32_t *max_inst_per_block);
