@@ -136,6 +136,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     staged = mode.startswith("staged") or ocr
     ktype, kbytes = ("unsigned short", 2) if mode.endswith("_k16") else ("unsigned char", 1)
     extruded = gk._extruded
+    periodic = bool(extruded and gk._extruded_periodic)
     region = gk._iteration_region
     ih = extruded and region == ON_INTERIOR_FACETS
     nf = 2 if ih else 1
@@ -274,12 +275,23 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     for mi, m in enumerate(maps):
         if extruded and m.offset is not None:
             decls.append(f"__device__ static const int map{mi}_off[{m.arity}] = {{{', '.join(str(int(o)) for o in m.offset)}}};")
+            if periodic and m.offset_quotient is not None:
+                decls.append(f"__device__ static const int map{mi}_quot[{m.arity}] = {{{', '.join(str(int(o)) for o in m.offset_quotient)}}};")
 
     def node(mi, ar, i, off, perm=None, f="0", ent="e"):
         ii = _permi(perm, i)
         e = f"map{mi}[(size_t){ent}*{ar} + {ii}]"
         if extruded and off is not None:
-            e = f"({e} + map{mi}_off[{i}]*(layer - layers[0] + {f}))"
+            # a permuted map permutes its offsets (and quotients) with its values (builder.py:160-169)
+            rel = f"(layer - layers[0] + {f})"
+            if periodic:
+                # builder.py:101-123: the layer offset wraps around the column of fd_nl cell layers
+                if maps[mi].offset_quotient is None:
+                    rel = f"fdw::wrap_layer({rel}, fd_nl)"
+                else:
+                    rel = (f"(fdw::wrap_layer({rel} + map{mi}_quot[{ii}], fd_nl) - "
+                           f"fdw::wrap_layer(map{mi}_quot[{ii}], fd_nl))")
+            e = f"({e} + map{mi}_off[{ii}]*{rel})"
         return e
 
     pre, pack, call_args, unpack, post = [], [], [], [], []
@@ -617,8 +629,11 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         if extruded:
             lo, hi = {ALL: ("layers[0]", "layers[1]-1"), ON_BOTTOM: ("layers[0]", "layers[0]+1"),
                       ON_TOP: ("layers[1]-2", "layers[1]-1"),
-                      ON_INTERIOR_FACETS: ("layers[0]", "layers[1]-2")}[region]
+                      # periodic columns have one more interior facet: between the top and the bottom cell (builder.py:806-809)
+                      ON_INTERIOR_FACETS: ("layers[0]", "layers[1]-1" if periodic else "layers[1]-2")}[region]
             src.append(f"  const int llo = {lo}, lhi = {hi};")
+            if periodic:
+                src.append("  const int fd_nl = layers[1] - 1 - layers[0];")
             # a direct (map-less) Dat written on an extruded set is addressed by the BASE entity
             # (parloop.py:494-497): all layers of a column hit the same row -> keep layers sequential
             layer_parallel = not any(i["kind"] == "dat" and "m" not in i and i["acc"] != READ for i in infos)

@@ -10,23 +10,34 @@
 
 namespace {
 
+// One candidate key per (entity, layer, stacked cell x row entry, stacked cell x col entry).  nf = 2 for the
+// ON_INTERIOR_FACETS region (two vertically stacked cells per facet, sparsity.pyx:298-303); layers l0 .. l0+nli-1 of
+// the nl cell layers are visited (sparsity.pyx:331-346).  Node of entry i in layer l (sparsity.pyx:357-368):
+//   map[e][i % arity] + off[i % arity] * ((l + i / arity + quot) % nl - quot % nl)      (quot = 0 unless periodic)
 __global__ void emit_keys(const int32_t *__restrict__ rmap, const int32_t *__restrict__ cmap, int32_t nent,
-                          int ar, int ac, int nl, const int32_t *__restrict__ roff,
-                          const int32_t *__restrict__ coff, int32_t nrows, int32_t ncols,
+                          int ar, int ac, int nl, int l0, int nli, int nf, const int32_t *__restrict__ roff,
+                          const int32_t *__restrict__ coff, const int32_t *__restrict__ rquot,
+                          const int32_t *__restrict__ cquot, int32_t nrows, int32_t ncols,
                           uint64_t *__restrict__ keys) {
-    const int64_t per = (int64_t)ar * ac;
-    const int64_t L = nl > 0 ? nl : 1;
+    const int nr = nf * ar, nc = nf * ac;
+    const int64_t per = (int64_t)nr * nc;
+    const int64_t L = nl > 0 ? nli : 1;
     const int64_t total = (int64_t)nent * L * per;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
          t += (int64_t)gridDim.x * blockDim.x) {
         int64_t e = t / (L * per);
         int64_t rem = t - e * L * per;
-        int l = (int)(rem / per);
-        int ij = (int)(rem - l * per);
-        int i = ij / ac, j = ij - i * ac;
-        int r = rmap[e * ar + i];
-        int c = cmap[e * ac + j];
-        if (nl > 0) { if (r >= 0) r += roff[i] * l; if (c >= 0) c += coff[j] * l; }
+        int l = l0 + (int)(rem / per);
+        int ij = (int)(rem % per);
+        int i = ij / nc, j = ij - i * nc;
+        const int ki = i / ar, ii = i - ki * ar, kj = j / ac, jj = j - kj * ac;
+        int r = rmap[e * ar + ii];
+        int c = cmap[e * ac + jj];
+        if (nl > 0) {
+            const int qr = rquot ? rquot[ii] : 0, qc = cquot ? cquot[jj] : 0;
+            if (r >= 0) r += roff[ii] * ((l + ki + qr) % nl - qr % nl);
+            if (c >= 0) c += coff[jj] * ((l + kj + qc) % nl - qc % nl);
+        }
         uint64_t key = ~0ull;                       // sentinel: dropped (negative / out of range)
         if (r >= 0 && r < nrows && c >= 0 && c < ncols) key = ((uint64_t)(uint32_t)r << 32) | (uint32_t)c;
         keys[t] = key;
@@ -153,16 +164,31 @@ inline int grid_for(int64_t n, int block = 256) {
 
 extern "C" {
 
-int fd_csr_from_maps(int32_t nrows, int32_t ncols, int set_diag, int npairs,
-                     const int32_t *const *rmaps, const int32_t *const *cmaps, const int32_t *nent,
-                     const int32_t *rarity, const int32_t *carity, const int32_t *nlayers,
-                     const int32_t *const *roffs_h, const int32_t *const *coffs_h,
-                     int32_t **rowptr_out, int32_t **colidx_out, int64_t *nnz_out, fd_stream_t s_) {
+// layers visited and stacked cells of one (pair, region): sparsity.pyx:291-305, 331-346
+static void pair_layers(int nl, int region, int periodic, int *l0, int *nli, int *nf) {
+    *l0 = 0; *nli = nl > 0 ? nl : 1; *nf = 1;
+    if (nl <= 0) return;
+    if (region == FD_ON_BOTTOM) *nli = 1;
+    else if (region == FD_ON_TOP) { *l0 = nl - 1; *nli = 1; }
+    else if (region == FD_ON_INTERIOR_FACETS) { *nf = 2; *nli = periodic ? nl : nl - 1; }
+}
+
+int fd_csr_from_maps_ex(int32_t nrows, int32_t ncols, int set_diag, int npairs,
+                        const int32_t *const *rmaps, const int32_t *const *cmaps, const int32_t *nent,
+                        const int32_t *rarity, const int32_t *carity, const int32_t *nlayers,
+                        const int32_t *const *roffs_h, const int32_t *const *coffs_h,
+                        const int32_t *region, const int32_t *periodic,
+                        const int32_t *const *rquots_h, const int32_t *const *cquots_h,
+                        int32_t **rowptr_out, int32_t **colidx_out, int64_t *nnz_out, fd_stream_t s_) {
     hipStream_t s = fd::st(s_);
     int64_t ncand = 0;
     for (int k = 0; k < npairs; ++k) {
-        int64_t L = (nlayers && nlayers[k] > 0) ? nlayers[k] : 1;
-        ncand += (int64_t)nent[k] * L * rarity[k] * carity[k];
+        int nl = (nlayers && nlayers[k] > 0) ? nlayers[k] : 0, l0, nli, nf;
+        if (nl && region && region[k] != FD_ALL && region[k] != FD_ON_BOTTOM && region[k] != FD_ON_TOP &&
+            region[k] != FD_ON_INTERIOR_FACETS) FD_FAIL("fd_csr_from_maps_ex: unknown iteration region");
+        pair_layers(nl, region ? region[k] : FD_ALL, periodic ? periodic[k] : 0, &l0, &nli, &nf);
+        if (nli < 0) nli = 0;
+        ncand += (int64_t)nent[k] * nli * nf * rarity[k] * nf * carity[k];
     }
     int32_t ndiag = set_diag ? (nrows < ncols ? nrows : ncols) : 0;
     ncand += ndiag;
@@ -172,19 +198,34 @@ int fd_csr_from_maps(int32_t nrows, int32_t ncols, int set_diag, int npairs,
     int64_t off = 0;
     if (ndiag) { hipLaunchKernelGGL(emit_diag, dim3(grid_for(ndiag)), dim3(256), 0, s, ndiag, keys); FD_CHECK_LAUNCH(); off = ndiag; }
     for (int k = 0; k < npairs; ++k) {
-        int nl = (nlayers && nlayers[k] > 0) ? nlayers[k] : 0;
-        int64_t cnt = (int64_t)nent[k] * (nl ? nl : 1) * rarity[k] * carity[k];
+        int nl = (nlayers && nlayers[k] > 0) ? nlayers[k] : 0, l0, nli, nf;
+        pair_layers(nl, region ? region[k] : FD_ALL, periodic ? periodic[k] : 0, &l0, &nli, &nf);
+        if (nli < 0) nli = 0;
+        int64_t cnt = (int64_t)nent[k] * nli * nf * rarity[k] * nf * carity[k];
         if (cnt == 0) continue;
-        int32_t *roff = nullptr, *coff = nullptr;
+        int32_t *roff = nullptr, *coff = nullptr, *rq = nullptr, *cq = nullptr;
         if (nl) {
+            if (!roffs_h || !coffs_h || !roffs_h[k] || !coffs_h[k]) FD_FAIL("fd_csr_from_maps_ex: extruded pairs need the map offsets");
             FD_HIP(hipMalloc(&roff, rarity[k] * 4)); FD_HIP(hipMalloc(&coff, carity[k] * 4));
             FD_HIP(hipMemcpyAsync(roff, roffs_h[k], rarity[k] * 4, hipMemcpyHostToDevice, s));
             FD_HIP(hipMemcpyAsync(coff, coffs_h[k], carity[k] * 4, hipMemcpyHostToDevice, s));
+            if (rquots_h && rquots_h[k]) {
+                FD_HIP(hipMalloc(&rq, rarity[k] * 4));
+                FD_HIP(hipMemcpyAsync(rq, rquots_h[k], rarity[k] * 4, hipMemcpyHostToDevice, s));
+            }
+            if (cquots_h && cquots_h[k]) {
+                FD_HIP(hipMalloc(&cq, carity[k] * 4));
+                FD_HIP(hipMemcpyAsync(cq, cquots_h[k], carity[k] * 4, hipMemcpyHostToDevice, s));
+            }
         }
         hipLaunchKernelGGL(emit_keys, dim3(grid_for(cnt)), dim3(256), 0, s, rmaps[k], cmaps[k], nent[k], rarity[k],
-                           carity[k], nl, roff, coff, nrows, ncols, keys + off);
+                           carity[k], nl, l0, nli, nf, roff, coff, rq, cq, nrows, ncols, keys + off);
         FD_CHECK_LAUNCH();
-        if (nl) { FD_HIP(hipStreamSynchronize(s)); FD_HIP(hipFree(roff)); FD_HIP(hipFree(coff)); }
+        if (nl) {
+            FD_HIP(hipStreamSynchronize(s)); FD_HIP(hipFree(roff)); FD_HIP(hipFree(coff));
+            if (rq) FD_HIP(hipFree(rq));
+            if (cq) FD_HIP(hipFree(cq));
+        }
         off += cnt;
     }
     // sort (only the bits that carry information: 32 + ceil(log2(nrows)))
@@ -225,6 +266,15 @@ int fd_csr_from_maps(int32_t nrows, int32_t ncols, int set_diag, int npairs,
     FD_HIP(hipFree(keys)); FD_HIP(hipFree(keys2)); FD_HIP(hipFree(tmp)); FD_HIP(hipFree(nsel));
     *rowptr_out = rowptr; *colidx_out = colidx; *nnz_out = nu;
     return 0;
+}
+
+int fd_csr_from_maps(int32_t nrows, int32_t ncols, int set_diag, int npairs,
+                     const int32_t *const *rmaps, const int32_t *const *cmaps, const int32_t *nent,
+                     const int32_t *rarity, const int32_t *carity, const int32_t *nlayers,
+                     const int32_t *const *roffs_h, const int32_t *const *coffs_h,
+                     int32_t **rowptr_out, int32_t **colidx_out, int64_t *nnz_out, fd_stream_t s) {
+    return fd_csr_from_maps_ex(nrows, ncols, set_diag, npairs, rmaps, cmaps, nent, rarity, carity, nlayers, roffs_h,
+                               coffs_h, nullptr, nullptr, nullptr, nullptr, rowptr_out, colidx_out, nnz_out, s);
 }
 
 int fd_csr_expand_blocks(int32_t nnode, const int32_t *nrp, const int32_t *nci, int rbs, int cbs,

@@ -46,6 +46,10 @@ template <> __device__ __forceinline__ void atomic_add<long long>(long long *p, 
 template <class T> __device__ __forceinline__ void atomic_min(T *p, T v) { atomicMin(p, v); }
 template <class T> __device__ __forceinline__ void atomic_max(T *p, T v) { atomicMax(p, v); }
 
+// ---- periodic extrusion: layer offset modulo the number of cell layers (pyop2/codegen/builder.py:101-123; the
+// reference's ad hoc _Remainder subtracts once, which is the same for every offset it can produce when nl >= 2)
+__device__ __forceinline__ int wrap_layer(int a, int nl) { return a % nl; }
+
 // ---- CSR position of (row, col): the per-call row search of MatSetValuesLocal ----
 __device__ __forceinline__ int csr_find(const int *__restrict__ rowptr, const int *__restrict__ colidx, int r, int c) {
     int lo = rowptr[r], hi = rowptr[r + 1] - 1;

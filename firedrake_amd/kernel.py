@@ -169,13 +169,14 @@ class GlobalKernel:
             raise ValueError("Cannot request layer argument for non-extruded iteration")
         if constant_layers and not extruded:
             raise ValueError("Cannot request constant_layers argument for non-extruded iteration")
-        if extruded_periodic:
-            raise NotImplementedError("periodic extrusion is out of scope")
+        if extruded_periodic and not extruded:
+            raise ValueError("Cannot request extruded_periodic for non-extruded iteration")
         if extruded and not constant_layers:
             raise NotImplementedError("variable-layer extrusion is out of scope (SURVEY.md 2.3)")
         self.local_kernel = local_kernel
         self.arguments = tuple(arguments)
         self._extruded = extruded
+        self._extruded_periodic = bool(extruded_periodic)
         self._constant_layers = constant_layers
         self._subset = subset
         self._iteration_region = IterationRegion(iteration_region) if iteration_region is not None else ALL
@@ -187,7 +188,8 @@ class GlobalKernel:
                 base = m.base_map if isinstance(m, PermutedMapKernelArg) else m
                 map_ids.append(seen.setdefault(id(base), len(seen)))
         self.cache_key = (local_kernel.cache_key, *[a.cache_key for a in self.arguments], *map_ids,
-                          extruded, constant_layers, subset, int(self._iteration_region), pass_layer_arg)
+                          extruded, constant_layers, subset, int(self._iteration_region), pass_layer_arg,
+                          *((True,) if extruded_periodic else ()))
         self._compiled = {}
 
     @property

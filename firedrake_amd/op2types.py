@@ -208,6 +208,7 @@ class Subset(Set):
         self.halo = superset.halo
         self.comm = superset.comm
         self._extruded = superset._extruded
+        self._extruded_periodic = superset._extruded_periodic
         self._dev_indices = None
 
     @property
@@ -582,7 +583,12 @@ class Map:
                 raise DataValueError("Invalid data: expected %d values, got %d!" % (iterset.total_size * self._arity, v.size))
         self.name = name or f"map_{id(self):x}"
         self._offset = None if offset is None else tuple(int(o) for o in offset)
-        self._offset_quotient = offset_quotient
+        if offset_quotient is None or len(offset_quotient) == 0:        # map.py:50-53
+            self._offset_quotient = None
+        else:
+            if len(offset_quotient) != self._arity:
+                raise DataValueError("offset_quotient must have one entry per map entry")
+            self._offset_quotient = tuple(int(o) for o in offset_quotient)
         self._dev = None
         self._plans = {}
 
@@ -773,13 +779,22 @@ class Sparsity:
             return
         _lib.require_gpu()
         rset, cset = self._dsets
-        n = len(self._rcmaps)
+        # one pattern contribution per (map pair, iteration region): sparsity.pyx:291-305
+        pairs = [(r, c, reg) for (r, c, regions) in self._rcmaps
+                 for reg in (regions if r.iterset._extruded else (ALL,))]
+        n = len(pairs)
         VP = ctypes.c_void_p
         rm, cm = (VP * n)(), (VP * n)()
-        ro, co = (VP * n)(), (VP * n)()
-        nent, ra, ca, nl = ((ctypes.c_int32 * n)() for _ in range(4))
+        ro, co, rq, cq = (VP * n)(), (VP * n)(), (VP * n)(), (VP * n)()
+        nent, ra, ca, nl, region, periodic = ((ctypes.c_int32 * n)() for _ in range(6))
         keep = []
-        for k, (r, c, regions) in enumerate(self._rcmaps):
+
+        def host_ints(x):
+            a = np.asarray(x, dtype=np.int32)
+            keep.append(a)
+            return a.ctypes.data
+
+        for k, (r, c, reg) in enumerate(pairs):
             rm[k], cm[k] = r._base()._dev_values(), c._base()._dev_values()
             it = r.iterset
             # The reference walks the owned entities only (sparsity.pyx: set_size = iterset.size) and lets
@@ -787,19 +802,23 @@ class Sparsity:
             # rows too, so the pattern is built over owned + ghost entities.
             nent[k] = it.total_size if not isinstance(it, Subset) else it.superset.total_size
             ra[k], ca[k] = r.arity, c.arity
+            region[k] = int(reg)
             if it._extruded:
-                if tuple(regions) != (ALL,):
-                    raise NotImplementedError("sparsity over ON_BOTTOM/ON_TOP/ON_INTERIOR_FACETS regions")
                 nl[k] = it.layers - 1
-                o1 = np.asarray(r.offset, dtype=np.int32)
-                o2 = np.asarray(c.offset, dtype=np.int32)
-                keep += [o1, o2]
-                ro[k], co[k] = o1.ctypes.data, o2.ctypes.data
+                if r.offset is None or c.offset is None:
+                    raise MapValueError("maps of an extruded iteration set need offsets to build a sparsity")
+                ro[k], co[k] = host_ints(r.offset), host_ints(c.offset)
+                periodic[k] = int(bool(it._extruded_periodic))
+                if r.offset_quotient is not None:
+                    rq[k] = host_ints(r.offset_quotient)
+                if c.offset_quotient is not None:
+                    cq[k] = host_ints(c.offset_quotient)
             else:
                 nl[k] = 0
         rp, ci, nnz = VP(), VP(), ctypes.c_int64()
-        _lib.call("fd_csr_from_maps", rset.set.total_size, cset.set.total_size, int(self._has_diagonal), n,
-                  rm, cm, nent, ra, ca, nl, ro, co, ctypes.byref(rp), ctypes.byref(ci), ctypes.byref(nnz), None)
+        _lib.call("fd_csr_from_maps_ex", rset.set.total_size, cset.set.total_size, int(self._has_diagonal), n,
+                  rm, cm, nent, ra, ca, nl, ro, co, region, periodic, rq, cq,
+                  ctypes.byref(rp), ctypes.byref(ci), ctypes.byref(nnz), None)
         self._node_rowptr = DeviceBuffer.wrap(rp.value, (rset.set.total_size + 1) * 4)
         self._node_colidx = DeviceBuffer.wrap(ci.value, max(nnz.value, 1) * 4)
         self._node_nnz = nnz.value
@@ -1059,7 +1078,7 @@ class Mat:
         if configuration["type_check"]:
             if rmap.toset != self._sparsity.dsets[0].set or cmap.toset != self._sparsity.dsets[1].set:
                 raise MapValueError("Path maps do not match the Mat's DataSets")
-        return MatLegacyArg(self, (rmap, cmap), access, lgmaps)
+        return MatLegacyArg(self, (rmap, cmap), access, lgmaps, bool(unroll_map))
 
     # -- host views
     def csr(self):

@@ -104,6 +104,7 @@ class MatLegacyArg:
     maps: Tuple[Map, Map]
     access: Access
     lgmaps: Optional[Any] = None
+    unroll_map: bool = False          # MatSetValuesLocal on dof indices; lgmaps are then per dof (mat.py:700-716)
 
     @property
     def dtype(self):
@@ -112,7 +113,8 @@ class MatLegacyArg:
     @property
     def global_kernel_arg(self):
         (rdim, cdim), = self.data.dims
-        return MatKernelArg((rdim, cdim), tuple(_map_kernel_arg(m) for m in self.maps), lgmaps=self.lgmaps is not None)
+        return MatKernelArg((rdim, cdim), tuple(_map_kernel_arg(m) for m in self.maps), unroll=bool(self.unroll_map),
+                            lgmaps=self.lgmaps is not None)
 
     @property
     def parloop_arg(self):
@@ -122,6 +124,10 @@ class MatLegacyArg:
 _mka_cache = {}
 
 
+def _tuple_or_none(x):
+    return None if x is None else tuple(int(v) for v in x)
+
+
 def _map_kernel_arg(m):
     """One MapKernelArg per base Map object, so GlobalKernel de-duplicates by identity."""
     if m is None:
@@ -129,7 +135,7 @@ def _map_kernel_arg(m):
     base = m._base()
     mk = _mka_cache.get(id(base))
     if mk is None or mk[0] is not base:
-        mk = (base, MapKernelArg(base.arity, base.offset))
+        mk = (base, MapKernelArg(base.arity, base.offset, _tuple_or_none(base.offset_quotient)))
         _mka_cache[id(base)] = mk
     if isinstance(m, PermutedMap):
         return PermutedMapKernelArg(mk[1], tuple(int(p) for p in m.permutation))
@@ -589,7 +595,7 @@ class Parloop:
         if reg in (ON_BOTTOM, ON_TOP):
             return 1
         if reg == ON_INTERIOR_FACETS:
-            return max(L - 2, 0)
+            return max(L - 1 if self.global_kernel._extruded_periodic else L - 2, 0)
         return L - 1
 
     # -- halo protocol (parloop.py:320-409)
@@ -671,6 +677,7 @@ class LegacyParloop(Parloop):
         extruded = iterset._extruded
         subset = isinstance(iterset, Subset)
         gk = _global_kernel_cached(local_knl, args, extruded=extruded, constant_layers=extruded, subset=subset,
+                                   extruded_periodic=bool(extruded and iterset._extruded_periodic),
                                    iteration_region=kwargs.get("iteration_region"),
                                    pass_layer_arg=kwargs.get("pass_layer_arg", False))
         super().__init__(gk, iterset, [a.parloop_arg for a in args])

@@ -203,6 +203,23 @@ int fd_csr_from_maps(int32_t nrow_nodes, int32_t ncol_nodes, int set_diag, int n
                      const int32_t *nlayers, const int32_t *const *roffsets_host,
                      const int32_t *const *coffsets_host,
                      int32_t **rowptr_dev, int32_t **colidx_dev, int64_t *nnz, fd_stream_t s);
+/* The same with the rest of fill_with_zeros' extruded cases: `region[k]` is the iteration region of pair k
+ * (FD_ON_BOTTOM / FD_ON_TOP / FD_ON_INTERIOR_FACETS / FD_ALL, the values of pyop2's IterationRegion; sparsity.pyx:291-305,
+ * 331-346 -- interior facets couple two stacked cells), `periodic[k]` marks periodic extrusion (sparsity.pyx:273, 343-346)
+ * and `rquot_host[k]` / `cquot_host[k]` are the maps' offset quotients (sparsity.pyx:309-312, 357-368):
+ *   node = map[e][i % arity] + offset[i % arity] * ((layer + i / arity + quot) % nlayers - quot % nlayers).
+ * region, periodic and the quotient arrays (or single quotients) may be NULL = FD_ALL / not periodic / 0. */
+#define FD_ON_BOTTOM 1
+#define FD_ON_TOP 2
+#define FD_ON_INTERIOR_FACETS 3
+#define FD_ALL 4
+int fd_csr_from_maps_ex(int32_t nrow_nodes, int32_t ncol_nodes, int set_diag, int npairs,
+                        const int32_t *const *rmaps_dev, const int32_t *const *cmaps_dev,
+                        const int32_t *nent, const int32_t *rarity, const int32_t *carity,
+                        const int32_t *nlayers, const int32_t *const *roffsets_host,
+                        const int32_t *const *coffsets_host, const int32_t *region, const int32_t *periodic,
+                        const int32_t *const *rquot_host, const int32_t *const *cquot_host,
+                        int32_t **rowptr_dev, int32_t **colidx_dev, int64_t *nnz, fd_stream_t s);
 /* node pattern -> scalar (aij) pattern for DataSet dims (rbs, cbs) (mat.py:254-278) */
 int fd_csr_expand_blocks(int32_t nrow_nodes, const int32_t *rowptr_dev, const int32_t *colidx_dev,
                          int rbs, int cbs, int32_t **rowptr_out, int32_t **colidx_out, fd_stream_t s);

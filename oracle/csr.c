@@ -50,27 +50,71 @@ static int cmp_int(const void *a, const void *b)
  * Build the block (node) sparsity from npairs (rmap, cmap) pairs.
  *   rmaps[k], cmaps[k] : (nent[k], rarity[k]) / (nent[k], carity[k]) int32, row-major
  *   nlayers[k]         : 0 for a non-extruded iteration set, else number of
- *                        cell layers; node = map + offset*layer (builder.py:94-124)
+ *                        cell layers (constant layers, bottom = 0)
  *   roffs[k], coffs[k] : per-map-entry extruded offsets (NULL when nlayers==0)
+ *   region[k]          : iteration region of the pair, oracle numbering ALL=1, ON_BOTTOM=2, ON_TOP=3,
+ *                        ON_INTERIOR_FACETS=4 (sparsity.pyx:291-305, 331-346); NULL = ALL everywhere
+ *   periodic[k]        : periodic extrusion (sparsity.pyx:273, 343-346); NULL = none
+ *   rquot[k], cquot[k] : offset quotients (sparsity.pyx:309-312) or NULL (= 0)
+ * Node of entry i (k-th cell of an interior facet: k = i / arity) in layer l, sparsity.pyx:357-368:
+ *   map[e][i % arity] + off[i % arity] * ((l + k + quot) % num_layers - quot % num_layers)
+ * which for standard extrusion (quot = 0, l + k < num_layers) is map + off*(l + k).
  * Output: rowptr (malloc'ed, nrows+1) and colidx (malloc'ed); returns nnz.
  * Node-level pattern; the caller expands by (rbs, cbs).
  */
-long oracle_build_node_sparsity(int nrows, int ncols, int set_diag, int npairs,
-                                const int **rmaps, const int **cmaps,
-                                const int *nent, const int *rarity, const int *carity,
-                                const int *nlayers, const int **roffs, const int **coffs,
-                                int **rowptr_out, int **colidx_out)
+typedef struct {
+    const int *rmap, *cmap, *roff, *coff, *rquot, *cquot;
+    int nent, ar, ac, nl, region, periodic;
+} oracle_pair;
+
+static int pair_node(const int *map, const int *off, const int *quot, int arity, int nl, int e, int i, int l)
 {
+    int k = i / arity, irem = i % arity;
+    int v = map[(size_t)e * arity + irem];
+    if (nl > 0) {
+        int q = quot ? quot[irem] : 0;
+        v += off[irem] * ((l + k + q) % nl - q % nl);
+    }
+    return v;
+}
+
+/* layer range and number of stacked cells of a pair (sparsity.pyx:331-346) */
+static void pair_layers(const oracle_pair *p, int *l0, int *l1, int *nf)
+{
+    *nf = 1;
+    if (p->nl <= 0) { *l0 = 0; *l1 = 1; return; }
+    *l0 = 0; *l1 = p->nl;
+    if (p->region == 2) *l1 = 1;
+    else if (p->region == 3) *l0 = p->nl - 1;
+    else if (p->region == 4) { *nf = 2; if (!p->periodic) *l1 = p->nl - 1; }
+}
+
+long oracle_build_node_sparsity_ex(int nrows, int ncols, int set_diag, int npairs,
+                                   const int **rmaps, const int **cmaps,
+                                   const int *nent, const int *rarity, const int *carity,
+                                   const int *nlayers, const int **roffs, const int **coffs,
+                                   const int *region, const int *periodic,
+                                   const int **rquots, const int **cquots,
+                                   int **rowptr_out, int **colidx_out)
+{
+    oracle_pair *P = (oracle_pair *)calloc((size_t)(npairs > 0 ? npairs : 1), sizeof(oracle_pair));
+    for (int k = 0; k < npairs; ++k) {
+        P[k].rmap = rmaps[k]; P[k].cmap = cmaps[k]; P[k].nent = nent[k]; P[k].ar = rarity[k]; P[k].ac = carity[k];
+        P[k].nl = nlayers[k] > 0 ? nlayers[k] : 0;
+        P[k].roff = P[k].nl ? roffs[k] : NULL; P[k].coff = P[k].nl ? coffs[k] : NULL;
+        P[k].region = region ? region[k] : 1; P[k].periodic = periodic ? periodic[k] : 0;
+        P[k].rquot = rquots ? rquots[k] : NULL; P[k].cquot = cquots ? cquots[k] : NULL;
+    }
     long *cnt = (long *)calloc((size_t)nrows + 1, sizeof(long));
     for (int k = 0; k < npairs; ++k) {
-        int L = nlayers[k] > 0 ? nlayers[k] : 1;
-        for (int e = 0; e < nent[k]; ++e)
-            for (int l = 0; l < L; ++l)
-                for (int i = 0; i < rarity[k]; ++i) {
-                    int r = rmaps[k][(size_t)e * rarity[k] + i];
-                    if (nlayers[k] > 0) r += roffs[k][i] * l;
+        int l0, l1, nf;
+        pair_layers(&P[k], &l0, &l1, &nf);
+        for (int e = 0; e < P[k].nent; ++e)
+            for (int l = l0; l < l1; ++l)
+                for (int i = 0; i < nf * P[k].ar; ++i) {
+                    int r = pair_node(P[k].rmap, P[k].roff, P[k].rquot, P[k].ar, P[k].nl, e, i, l);
                     if (r < 0 || r >= nrows) continue;
-                    cnt[r + 1] += carity[k];
+                    cnt[r + 1] += nf * P[k].ac;
                 }
     }
     if (set_diag)
@@ -78,25 +122,23 @@ long oracle_build_node_sparsity(int nrows, int ncols, int set_diag, int npairs,
     for (int r = 0; r < nrows; ++r) cnt[r + 1] += cnt[r];
     long ncand = cnt[nrows];
     int *cand = (int *)malloc((size_t)(ncand > 0 ? ncand : 1) * sizeof(int));
-    long *fill = (long *)malloc((size_t)nrows * sizeof(long));
+    long *fill = (long *)malloc((size_t)(nrows > 0 ? nrows : 1) * sizeof(long));
     for (int r = 0; r < nrows; ++r) fill[r] = cnt[r];
     if (set_diag)
         for (int r = 0; r < nrows && r < ncols; ++r) cand[fill[r]++] = r;
     for (int k = 0; k < npairs; ++k) {
-        int L = nlayers[k] > 0 ? nlayers[k] : 1;
-        for (int e = 0; e < nent[k]; ++e)
-            for (int l = 0; l < L; ++l)
-                for (int i = 0; i < rarity[k]; ++i) {
-                    int r = rmaps[k][(size_t)e * rarity[k] + i];
-                    if (nlayers[k] > 0) r += roffs[k][i] * l;
+        int l0, l1, nf;
+        pair_layers(&P[k], &l0, &l1, &nf);
+        for (int e = 0; e < P[k].nent; ++e)
+            for (int l = l0; l < l1; ++l)
+                for (int i = 0; i < nf * P[k].ar; ++i) {
+                    int r = pair_node(P[k].rmap, P[k].roff, P[k].rquot, P[k].ar, P[k].nl, e, i, l);
                     if (r < 0 || r >= nrows) continue;
-                    for (int j = 0; j < carity[k]; ++j) {
-                        int c = cmaps[k][(size_t)e * carity[k] + j];
-                        if (nlayers[k] > 0) c += coffs[k][j] * l;
-                        cand[fill[r]++] = c;   /* negative cols filtered below */
-                    }
+                    for (int j = 0; j < nf * P[k].ac; ++j)   /* negative cols filtered below */
+                        cand[fill[r]++] = pair_node(P[k].cmap, P[k].coff, P[k].cquot, P[k].ac, P[k].nl, e, j, l);
                 }
     }
+    free(P);
     int *rowptr = (int *)malloc(((size_t)nrows + 1) * sizeof(int));
     long nnz = 0;
     rowptr[0] = 0;
@@ -119,6 +161,17 @@ long oracle_build_node_sparsity(int nrows, int ncols, int set_diag, int npairs,
     *rowptr_out = rowptr;
     *colidx_out = colidx;
     return nnz;
+}
+
+/* iteration region ALL, standard extrusion */
+long oracle_build_node_sparsity(int nrows, int ncols, int set_diag, int npairs,
+                                const int **rmaps, const int **cmaps,
+                                const int *nent, const int *rarity, const int *carity,
+                                const int *nlayers, const int **roffs, const int **coffs,
+                                int **rowptr_out, int **colidx_out)
+{
+    return oracle_build_node_sparsity_ex(nrows, ncols, set_diag, npairs, rmaps, cmaps, nent, rarity, carity,
+                                         nlayers, roffs, coffs, NULL, NULL, NULL, NULL, rowptr_out, colidx_out);
 }
 
 void oracle_free(void *p) { free(p); }
@@ -184,15 +237,21 @@ int oracle_MatSetValuesBlockedLocal(oracle_mat *A, int nr, const int *rows,
     return 0;
 }
 
-/* Unrolled variant: rows/cols are scalar dof indices (builder.py:579-581). */
+/* Unrolled variant: rows/cols are scalar dof indices (builder.py:579-581); the lgmaps are then indexed
+ * by dof (component-wise boundary conditions mask single dofs of a node). */
 int oracle_MatSetValuesLocal(oracle_mat *A, int nr, const int *rows,
                              int nc, const int *cols, const double *vals, int insert)
 {
-    for (int i = 0; i < nr; ++i)
+    for (int i = 0; i < nr; ++i) {
+        int r = rows[i];
+        if (r >= 0 && A->row_lgmap) r = A->row_lgmap[r];
         for (int j = 0; j < nc; ++j) {
-            if (rows[i] < 0 || cols[j] < 0) { A->dropped++; continue; }
-            add_scalar(A, rows[i], cols[j], vals[(size_t)i * nc + j], insert);
+            int c = cols[j];
+            if (c >= 0 && A->col_lgmap) c = A->col_lgmap[c];
+            if (r < 0 || c < 0) { A->dropped++; continue; }
+            add_scalar(A, r, c, vals[(size_t)i * nc + j], insert);
         }
+    }
     return 0;
 }
 

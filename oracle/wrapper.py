@@ -14,6 +14,10 @@ Follows (file:line relative to /root/reference):
   * Global pack/unpack ........... pyop2/codegen/builder.py:262-319
   * Mat pack/unpack .............. pyop2/codegen/builder.py:550-625  (zero-init, MatSetValues[Blocked]Local)
   * permuted map ................. pyop2/codegen/builder.py:144-176
+  * periodic extrusion ........... pyop2/codegen/builder.py:101-123 (offset wraps with the ad hoc _Remainder,
+                                   builder.py:26-29; offset_quotient), :806-809 (interior facets run one layer more)
+  * mixed Dat / Mat packs ........ pyop2/codegen/builder.py:432-518 (MixedDatPack: parts concatenated at flat offsets),
+                                   :628-699 (MixedMatPack: sub-blocks of one element tensor, one MatSetValues per block)
   * compile flags ................ pyop2/compilation.py:341-363 (gcc -O3 -march=native -ffast-math -fPIC -std=gnu11)
 
 The generated C is compiled with the reference's own flags and driven through
@@ -51,6 +55,7 @@ class ODat:
     map: Optional[np.ndarray] = None      # (nent, arity) int32, or None = direct
     offset: Optional[Sequence[int]] = None  # extruded offsets per map entry
     perm: Optional[Sequence[int]] = None    # PermutedMap permutation
+    offset_quotient: Optional[Sequence[int]] = None   # periodic extrusion (map.py:46-53)
 
     @property
     def cdim(self):
@@ -97,6 +102,24 @@ class OMat:
     col_lgmap: Optional[np.ndarray] = None
     unroll: bool = False                      # MatSetValuesLocal with dof indices
     stats: dict = field(default_factory=dict)
+    roffset_quotient: Optional[Sequence[int]] = None
+    coffset_quotient: Optional[Sequence[int]] = None
+
+
+@dataclass
+class OMixedDat:
+    """MixedDat argument: ``parts`` are ODats (each with its own map); the local kernel sees ONE flat pack
+    in which part p occupies [offset_p, offset_p + nf*arity_p*cdim_p) (builder.py:432-518)."""
+    parts: Sequence[ODat]
+    access: int
+
+
+@dataclass
+class OMixedMat:
+    """MixedMat argument: ``blocks[i][j]`` are OMats; the local kernel sees one (sum rows) x (sum cols) element
+    tensor whose sub-blocks are inserted block by block (builder.py:628-699)."""
+    blocks: Sequence[Sequence[OMat]]
+    access: int
 
 
 class _CMat(ctypes.Structure):
@@ -144,7 +167,8 @@ int oracle_MatSetValuesLocal(oracle_mat *A, int nr, const int *rows, int nc, con
 
 
 def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
-                     extruded=False, iteration_region=ALL, pass_layer_arg=False, threads=False):
+                     extruded=False, iteration_region=ALL, pass_layer_arg=False, threads=False,
+                     periodic=False):
     """Emit the C wrapper (restating SURVEY.md Appendix A)."""
     sig = ["int start", "int end"]
     if extruded:
@@ -164,16 +188,90 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
 
     ih = extruded and iteration_region == ON_INTERIOR_FACETS
     nf = 2 if ih else 1
+    decls = []
 
-    def node_expr(mname, arity, i, offset, perm, f="0"):
+    def declare(line):
+        if line not in decls:
+            decls.append(line)
+
+    def table(name, vals):
+        declare(f"static const int {name}[{len(vals)}] = {{{', '.join(str(int(o)) for o in vals)}}};")
+
+    def node_expr(mname, arity, i, offset, perm, f="0", quotient=None):
+        """map[e][perm[i]] + offset[i]*(layer - bottom + f), wrapped for periodic columns (builder.py:80-128)."""
         ii = f"{mname}_perm[{i}]" if perm is not None else i
         e = f"{mname}[(size_t)e*{arity} + {ii}]"
         if extruded and offset is not None:
-            e += f" + {mname}_off[{i}]*(layer - layers[0] + {f})"
+            table(f"{mname}_off", offset)
+            rel = f"(layer - layers[0] + {f})"
+            if periodic:
+                # builder.py:108-120: _Remainder(a, b) = a < b ? a : a - b (builder.py:26-29), num_layers = top - bottom
+                if quotient is None:
+                    rel = f"ORACLE_REM({rel}, (layers[1] - 1 - layers[0]))"
+                else:
+                    table(f"{mname}_quot", quotient)
+                    rel = (f"(ORACLE_REM(({rel} + {mname}_quot[{ii}]), (layers[1] - 1 - layers[0])) - "
+                           f"ORACLE_REM({mname}_quot[{ii}], (layers[1] - 1 - layers[0])))")
+            # a permuted map permutes its offsets (and quotients) with its values (builder.py:160-169)
+            e += f" + {mname}_off[{ii}]*{rel}"
         return e
 
-    decls = []
-    priv = []       # (arg index, ctype, length): INC Dats that get thread-private copies under OpenMP
+    priv = []       # (arg name, ctype, length): INC Dats that get thread-private copies under OpenMP
+
+    def emit_dat(an, a, access, tname, toff):
+        """Pack/unpack of one (part of a) Dat into ``tname`` at flat offset ``toff``; returns the pack length."""
+        ct = _CTYPES[a.data.dtype]
+        c = a.cdim
+        mn = map_name(a.map)
+        ar = a.map.shape[1]
+        if a.perm is not None:
+            table(f"{mn}_perm", a.perm)
+        n = nf * ar * c
+        nexpr = node_expr(mn, ar, 'i', a.offset, a.perm, 'f', a.offset_quotient)
+        loop = f"for (int f = 0; f < {nf}; ++f) for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j)"
+        tt = f"{tname}[{toff} + (f*{ar}+i)*{c}+j]"
+        if access in (INC, WRITE):
+            body_pack.append(f"for (int q = 0; q < {n}; ++q) {tname}[{toff} + q] = 0;")
+        else:
+            body_pack.append(f"{loop} {tt} = {an}[(size_t)({nexpr})*{c} + j];")
+        if access != READ:
+            lhs = f"{an}[(size_t)({nexpr})*{c} + j]"
+            if threads and access == INC:
+                lhs = lhs.replace(f"{an}[", f"priv_{an}[", 1)
+                priv.append((an, ct, a.data.size))
+            op = {INC: f"{lhs} += {tt};",
+                  MIN: f"{lhs} = {lhs} < {tt} ? {lhs} : {tt};",
+                  MAX: f"{lhs} = {lhs} > {tt} ? {lhs} : {tt};",
+                  WRITE: f"{lhs} = {tt};", RW: f"{lhs} = {tt};"}[access]
+            body_unpack.append(f"{loop} {op}")
+        return n
+
+    def mat_shape(a):
+        return nf * a.rmap.shape[1] * a.csr.rbs, nf * a.cmap.shape[1] * a.csr.cbs
+
+    def emit_mat(an, a, access, tname):
+        """MatSetValues[Blocked]Local of the dense pack ``tname`` (builder.py:573-625)."""
+        rn, cn = map_name(a.rmap), map_name(a.cmap)
+        ar, ac = a.rmap.shape[1], a.cmap.shape[1]
+        rbs, cbs = a.csr.rbs, a.csr.cbs
+        ins = 1 if access == WRITE else 0
+        body_unpack.append(f"int r_{an}[{nf * ar}], c_{an}[{nf * ac}];")
+        body_unpack.append(
+            f"for (int f = 0; f < {nf}; ++f) for (int i = 0; i < {ar}; ++i) r_{an}[f*{ar}+i] = "
+            f"{node_expr(rn, ar, 'i', a.roffset, None, 'f', a.roffset_quotient)};")
+        body_unpack.append(
+            f"for (int f = 0; f < {nf}; ++f) for (int i = 0; i < {ac}; ++i) c_{an}[f*{ac}+i] = "
+            f"{node_expr(cn, ac, 'i', a.coffset, None, 'f', a.coffset_quotient)};")
+        if a.unroll:
+            body_unpack.append(f"int ru_{an}[{nf * ar * rbs}], cu_{an}[{nf * ac * cbs}];")
+            body_unpack.append(f"for (int i = 0; i < {nf * ar}; ++i) for (int p = 0; p < {rbs}; ++p) "
+                               f"ru_{an}[i*{rbs}+p] = r_{an}[i] < 0 ? -1 : r_{an}[i]*{rbs}+p;")
+            body_unpack.append(f"for (int i = 0; i < {nf * ac}; ++i) for (int p = 0; p < {cbs}; ++p) "
+                               f"cu_{an}[i*{cbs}+p] = c_{an}[i] < 0 ? -1 : c_{an}[i]*{cbs}+p;")
+            body_unpack.append(f"oracle_MatSetValuesLocal({an}, {nf * ar * rbs}, ru_{an}, {nf * ac * cbs}, cu_{an}, {tname}, {ins});")
+        else:
+            body_unpack.append(f"oracle_MatSetValuesBlockedLocal({an}, {nf * ar}, r_{an}, {nf * ac}, c_{an}, {tname}, {ins});")
+
     for k, a in enumerate(args):
         if isinstance(a, ODat):
             ct = _CTYPES[a.data.dtype]
@@ -183,32 +281,19 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
                 # direct: pointer straight into the Dat (builder.py:387-396)
                 body_call.append(f"&arg{k}[(size_t)e*{c}]")
                 continue
-            mn = map_name(a.map)
-            ar = a.map.shape[1]
-            if a.offset is not None:
-                decls.append(f"static const int {mn}_off[{ar}] = {{{', '.join(str(int(o)) for o in a.offset)}}};")
-            if a.perm is not None:
-                decls.append(f"static const int {mn}_perm[{ar}] = {{{', '.join(str(int(o)) for o in a.perm)}}};")
-            body_pack.append(f"{ct} t{k}[{nf * ar * c}];")
-            if a.access in (INC, WRITE):
-                body_pack.append(f"for (int q = 0; q < {nf * ar * c}; ++q) t{k}[q] = 0;")
-            else:
-                body_pack.append(
-                    f"for (int f = 0; f < {nf}; ++f) for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j) "
-                    f"t{k}[(f*{ar}+i)*{c}+j] = arg{k}[(size_t)({node_expr(mn, ar, 'i', a.offset, a.perm, 'f')})*{c} + j];")
+            body_pack.append(f"{ct} t{k}[{nf * a.map.shape[1] * c}];")
+            emit_dat(f"arg{k}", a, a.access, f"t{k}", 0)
             body_call.append(f"t{k}")
-            if a.access != READ:
-                lhs = f"arg{k}[(size_t)({node_expr(mn, ar, 'i', a.offset, a.perm, 'f')})*{c} + j]"
-                rhs = f"t{k}[(f*{ar}+i)*{c}+j]"
-                if threads and a.access == INC:
-                    lhs = lhs.replace(f"arg{k}[", f"priv{k}[", 1)
-                    priv.append((k, ct, a.data.size))
-                op = {INC: f"{lhs} += {rhs};",
-                      MIN: f"{lhs} = {lhs} < {rhs} ? {lhs} : {rhs};",
-                      MAX: f"{lhs} = {lhs} > {rhs} ? {lhs} : {rhs};",
-                      WRITE: f"{lhs} = {rhs};", RW: f"{lhs} = {rhs};"}[a.access]
-                body_unpack.append(
-                    f"for (int f = 0; f < {nf}; ++f) for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j) {op}")
+        elif isinstance(a, OMixedDat):
+            # one flat pack, the parts at consecutive offsets (builder.py:439-475); one pointer per part
+            ct = _CTYPES[a.parts[0].data.dtype]
+            total = sum(nf * p.map.shape[1] * p.cdim for p in a.parts)
+            body_pack.append(f"{ct} t{k}[{total}];")
+            off = 0
+            for pi, p in enumerate(a.parts):
+                sig.append(f"{ct} *arg{k}_{pi}")
+                off += emit_dat(f"arg{k}_{pi}", p, a.access, f"t{k}", off)
+            body_call.append(f"t{k}")
         elif isinstance(a, OGlobal):
             ct = _CTYPES[a.data.dtype]
             sig.append(f"{ct} *arg{k}")
@@ -227,31 +312,29 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
                 body_unpack.append(f"for (int q = 0; q < {n}; ++q) {op}")
         elif isinstance(a, OMat):
             sig.append(f"oracle_mat *arg{k}")
-            rn, cn = map_name(a.rmap), map_name(a.cmap)
-            ar, ac = a.rmap.shape[1], a.cmap.shape[1]
-            rbs, cbs = a.csr.rbs, a.csr.cbs
-            if a.roffset is not None:
-                decls.append(f"static const int {rn}_off[{ar}] = {{{', '.join(str(int(o)) for o in a.roffset)}}};")
-            if a.coffset is not None and cn != rn:
-                decls.append(f"static const int {cn}_off[{ac}] = {{{', '.join(str(int(o)) for o in a.coffset)}}};")
-            size = nf * ar * rbs * nf * ac * cbs
-            body_pack.append(f"double t{k}[{size}]; for (int q = 0; q < {size}; ++q) t{k}[q] = 0;")
+            nr, nc = mat_shape(a)
+            body_pack.append(f"double t{k}[{nr * nc}]; for (int q = 0; q < {nr * nc}; ++q) t{k}[q] = 0;")
             body_call.append(f"t{k}")
-            ins = 1 if a.access == WRITE else 0
-            body_unpack.append(f"int r{k}[{nf * ar}], c{k}[{nf * ac}];")
-            body_unpack.append(
-                f"for (int f = 0; f < {nf}; ++f) for (int i = 0; i < {ar}; ++i) r{k}[f*{ar}+i] = {node_expr(rn, ar, 'i', a.roffset, None, 'f')};")
-            body_unpack.append(
-                f"for (int f = 0; f < {nf}; ++f) for (int i = 0; i < {ac}; ++i) c{k}[f*{ac}+i] = {node_expr(cn, ac, 'i', a.coffset, None, 'f')};")
-            if a.unroll:
-                body_unpack.append(f"int ru{k}[{nf * ar * rbs}], cu{k}[{nf * ac * cbs}];")
-                body_unpack.append(f"for (int i = 0; i < {nf * ar}; ++i) for (int p = 0; p < {rbs}; ++p) "
-                                   f"ru{k}[i*{rbs}+p] = r{k}[i] < 0 ? -1 : r{k}[i]*{rbs}+p;")
-                body_unpack.append(f"for (int i = 0; i < {nf * ac}; ++i) for (int p = 0; p < {cbs}; ++p) "
-                                   f"cu{k}[i*{cbs}+p] = c{k}[i] < 0 ? -1 : c{k}[i]*{cbs}+p;")
-                body_unpack.append(f"oracle_MatSetValuesLocal(arg{k}, {nf * ar * rbs}, ru{k}, {nf * ac * cbs}, cu{k}, t{k}, {ins});")
-            else:
-                body_unpack.append(f"oracle_MatSetValuesBlockedLocal(arg{k}, {nf * ar}, r{k}, {nf * ac}, c{k}, t{k}, {ins});")
+            emit_mat(f"arg{k}", a, a.access, f"t{k}")
+        elif isinstance(a, OMixedMat):
+            # one (R x C) element tensor; block (i, j) is copied out of it and inserted on its own (builder.py:667-699)
+            R = sum(mat_shape(row[0])[0] for row in a.blocks)
+            C = sum(mat_shape(b)[1] for b in a.blocks[0])
+            body_pack.append(f"double t{k}[{R * C}]; for (int q = 0; q < {R * C}; ++q) t{k}[q] = 0;")
+            body_call.append(f"t{k}")
+            ro = 0
+            for bi, row in enumerate(a.blocks):
+                co = 0
+                for bj, blk in enumerate(row):
+                    an = f"arg{k}_{bi}_{bj}"
+                    sig.append(f"oracle_mat *{an}")
+                    nr, nc = mat_shape(blk)
+                    body_unpack.append(f"double t_{an}[{nr * nc}];")
+                    body_unpack.append(f"for (int i = 0; i < {nr}; ++i) for (int j = 0; j < {nc}; ++j) "
+                                       f"t_{an}[i*{nc}+j] = t{k}[({ro}+i)*{C} + {co}+j];")
+                    emit_mat(an, blk, a.access, f"t_{an}")
+                    co += nc
+                ro += mat_shape(row[0])[0]
         else:
             raise TypeError(a)
     for _, nm in maps:
@@ -259,22 +342,24 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
     if pass_layer_arg:
         body_call.append("layer")
 
-    lines = [_PREAMBLE, "#include <stdlib.h>", kernel_src, *decls, f"int wrap_{kernel_name}({', '.join(sig)})", "{"]
+    lines = [_PREAMBLE, "#include <stdlib.h>", "#define ORACLE_REM(a, b) ((a) < (b) ? (a) : (a) - (b))",
+             kernel_src, *decls, f"int wrap_{kernel_name}({', '.join(sig)})", "{"]
     if threads:
         # shared-memory analogue of rank-local assembly + local_to_global SUM (pyop2/types/dat.py:659-678):
         # contiguous entity ranges per thread, private output vectors summed afterwards
         lines.append('  _Pragma("omp parallel")')
         lines.append("  {")
-        for k, ct, n in priv:
-            lines.append(f"  {ct} *priv{k} = ({ct} *)calloc({n}, sizeof({ct}));")
+        for an, ct, n in priv:
+            lines.append(f"  {ct} *priv_{an} = ({ct} *)calloc({n}, sizeof({ct}));")
         lines.append('  _Pragma("omp for schedule(static)")')
     lines += ["  for (int n = start; n < end; ++n) {",
               "    int e = " + ("subset_indices[n];" if subset else "n;")]
     if extruded:
+        # builder.py:790-812; periodic columns have one more interior facet (between the top and the bottom cell)
         lo, hi = {ALL: ("layers[0]", "layers[1]-1"),
                   ON_BOTTOM: ("layers[0]", "layers[0]+1"),
                   ON_TOP: ("layers[1]-2", "layers[1]-1"),
-                  ON_INTERIOR_FACETS: ("layers[0]", "layers[1]-2")}[iteration_region]
+                  ON_INTERIOR_FACETS: ("layers[0]", "layers[1]-1" if periodic else "layers[1]-2")}[iteration_region]
         lines.append(f"    for (int layer = {lo}; layer < {hi}; ++layer) {{")
     lines += ["      " + s for s in body_pack]
     lines.append(f"      {kernel_name}({', '.join(body_call)});")
@@ -283,10 +368,10 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
         lines.append("    }")
     lines.append("  }")
     if threads:
-        for k, ct, n in priv:
+        for an, ct, n in priv:
             lines.append('  _Pragma("omp critical")')
-            lines.append(f"  for (long q = 0; q < {n}; ++q) arg{k}[q] += priv{k}[q];")
-            lines.append(f"  free(priv{k});")
+            lines.append(f"  for (long q = 0; q < {n}; ++q) {an}[q] += priv_{an}[q];")
+            lines.append(f"  free(priv_{an});")
         lines.append("  }")
     lines += ["  return 0;", "}"]
     return "\n".join(lines), [m for m, _ in maps]
@@ -294,11 +379,12 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
 
 def par_loop(kernel_src: str, kernel_name: str, start: int, end: int, args, *,
              subset: Optional[np.ndarray] = None, layers: Optional[Tuple[int, int]] = None,
-             iteration_region=ALL, pass_layer_arg=False, cflags=None, return_fn=False, threads=False):
+             iteration_region=ALL, pass_layer_arg=False, cflags=None, return_fn=False, threads=False,
+             periodic=False):
     """Generate + compile + run the wrapper over [start, end).  Arrays are modified in place."""
     code, maps = generate_wrapper(kernel_src, kernel_name, args, subset=subset is not None,
                                   extruded=layers is not None, iteration_region=iteration_region,
-                                  pass_layer_arg=pass_layer_arg, threads=threads)
+                                  pass_layer_arg=pass_layer_arg, threads=threads, periodic=periodic)
     lib = compile_c(code, "wrap_" + kernel_name + ("_omp" if threads else ""), extra_sources=[os.path.join(_HERE, "csr.c")],
                     cflags=cflags, threads=threads)
     fn = getattr(lib, "wrap_" + kernel_name)
@@ -313,17 +399,29 @@ def par_loop(kernel_src: str, kernel_name: str, start: int, end: int, args, *,
         keep.append(sa)
         cargs.append(sa.ctypes.data_as(ctypes.c_void_p))
     cmats = []
+
+    def add_mat(a):
+        cm = _CMat(a.csr.nrows, a.csr.ncols, a.csr.rbs, a.csr.cbs,
+                   a.csr.rowptr.ctypes.data, a.csr.colidx.ctypes.data, a.csr.values.ctypes.data,
+                   a.row_lgmap.ctypes.data if a.row_lgmap is not None else None,
+                   a.col_lgmap.ctypes.data if a.col_lgmap is not None else None, 0, 0)
+        cmats.append((a, cm))
+        cargs.append(ctypes.byref(cm))
+
     for a in args:
         if isinstance(a, (ODat, OGlobal)):
             assert a.data.flags.c_contiguous
             cargs.append(a.data.ctypes.data_as(ctypes.c_void_p))
+        elif isinstance(a, OMixedDat):
+            for p in a.parts:
+                assert p.data.flags.c_contiguous
+                cargs.append(p.data.ctypes.data_as(ctypes.c_void_p))
+        elif isinstance(a, OMixedMat):
+            for row in a.blocks:
+                for blk in row:
+                    add_mat(blk)
         else:
-            cm = _CMat(a.csr.nrows, a.csr.ncols, a.csr.rbs, a.csr.cbs,
-                       a.csr.rowptr.ctypes.data, a.csr.colidx.ctypes.data, a.csr.values.ctypes.data,
-                       a.row_lgmap.ctypes.data if a.row_lgmap is not None else None,
-                       a.col_lgmap.ctypes.data if a.col_lgmap is not None else None, 0, 0)
-            cmats.append((a, cm))
-            cargs.append(ctypes.byref(cm))
+            add_mat(a)
     for m in maps:
         assert m.dtype == np.int32 and m.flags.c_contiguous, "maps must be contiguous int32"
         cargs.append(m.ctypes.data_as(ctypes.c_void_p))
@@ -351,30 +449,45 @@ def _csrlib():
 
 
 def build_sparsity(nrow_nodes: int, ncol_nodes: int, pairs, rbs=1, cbs=1, set_diag=True) -> OracleCSR:
-    """pairs: list of (rmap, cmap) or (rmap, cmap, nlayers, roffset, coffset)."""
+    """pairs: list of (rmap, cmap) or (rmap, cmap, nlayers, roffset, coffset[, rquotient, cquotient, periodic[, region]])
+    -- ``region`` in the oracle's numbering (ALL = 1 ...); one entry per (map pair, iteration region)."""
     lib = _csrlib()
     n = len(pairs)
     P = ctypes.POINTER(ctypes.c_int)
-    rm = (P * n)(); cmm = (P * n)(); ro = (P * n)(); co = (P * n)()
+    rm = (P * n)(); cmm = (P * n)(); ro = (P * n)(); co = (P * n)(); rq = (P * n)(); cq = (P * n)()
     nent = (ctypes.c_int * n)(); ra = (ctypes.c_int * n)(); ca = (ctypes.c_int * n)(); nl = (ctypes.c_int * n)()
+    reg = (ctypes.c_int * n)(); per = (ctypes.c_int * n)()
     keep = []
+
+    def arr(x):
+        x = np.ascontiguousarray(x, dtype=np.int32)
+        keep.append(x)
+        return x.ctypes.data_as(P)
+
     for k, p in enumerate(pairs):
         r, c = np.ascontiguousarray(p[0], dtype=np.int32), np.ascontiguousarray(p[1], dtype=np.int32)
         keep += [r, c]
         rm[k] = r.ctypes.data_as(P); cmm[k] = c.ctypes.data_as(P)
         nent[k] = r.shape[0]; ra[k] = r.shape[1]; ca[k] = c.shape[1]
+        reg[k], per[k] = ALL, 0
         if len(p) > 2 and p[2]:
             nl[k] = int(p[2])
-            o1 = np.asarray(p[3], dtype=np.int32); o2 = np.asarray(p[4], dtype=np.int32)
-            keep += [o1, o2]
-            ro[k] = o1.ctypes.data_as(P); co[k] = o2.ctypes.data_as(P)
+            ro[k] = arr(p[3]); co[k] = arr(p[4])
+            if len(p) > 5 and p[5] is not None:
+                rq[k] = arr(p[5])
+            if len(p) > 6 and p[6] is not None:
+                cq[k] = arr(p[6])
+            if len(p) > 7:
+                per[k] = int(bool(p[7]))
+            if len(p) > 8 and p[8] is not None:
+                reg[k] = int(p[8])
         else:
             nl[k] = 0
     rp = P(); ci = P()
-    lib.oracle_build_node_sparsity.restype = ctypes.c_long
-    nnz = lib.oracle_build_node_sparsity(nrow_nodes, ncol_nodes, int(set_diag and nrow_nodes == ncol_nodes or set_diag),
-                                         n, rm, cmm, nent, ra, ca, nl, ro, co,
-                                         ctypes.byref(rp), ctypes.byref(ci))
+    lib.oracle_build_node_sparsity_ex.restype = ctypes.c_long
+    nnz = lib.oracle_build_node_sparsity_ex(nrow_nodes, ncol_nodes, int(bool(set_diag)),
+                                            n, rm, cmm, nent, ra, ca, nl, ro, co, reg, per, rq, cq,
+                                            ctypes.byref(rp), ctypes.byref(ci))
     nrowptr = np.ctypeslib.as_array(rp, shape=(nrow_nodes + 1,)).copy()
     ncolidx = np.ctypeslib.as_array(ci, shape=(max(nnz, 1),))[:nnz].copy()
     lib.oracle_free(rp); lib.oracle_free(ci)

@@ -1,0 +1,168 @@
+"""CPU: the DIRECT-mode wrappers emitted by firedrake_amd/codegen.py, compiled for the host against the
+one-lane stand-in header (tests/hostsim/) and compared with the oracle.  Checks the generator's indexing
+logic (maps, extruded offsets, iteration regions, subsets, permuted maps, lgmap masking, CSR search)
+without a GPU; the -m gpu suite checks the same loops through the HIP build."""
+import numpy as np
+import pytest
+
+from firedrake_amd import op2
+import golden_kernels as gk
+from helpers import oracle_run, structured_tri_mesh
+from hostsim import run_direct
+
+
+def _check(kernel, iterset, *args, **kw):
+    pl = op2.LegacyParloop(kernel, iterset, *args, **kw)
+    got = run_direct(pl)
+    ref = oracle_run(kernel, iterset, *args, **kw)
+    for g, r in zip(got, ref):
+        if hasattr(r, "values"):
+            assert np.array_equal(g.rowptr, r.rowptr) and np.array_equal(g.colidx, r.colidx)
+            g, r = g.values, r.values
+        if r.dtype.kind == "f":
+            assert np.abs(g - r).max() <= 1e-12 * max(1.0, np.abs(r).max())
+        else:
+            assert np.array_equal(g, r)
+    return got
+
+
+def test_rhs_and_mass_triangles():
+    coords, cells = structured_tri_mesh(5, 4, perturb=0.2)
+    nodes, ele = op2.Set(len(coords)), op2.Set(len(cells))
+    m = op2.Map(ele, nodes, 3, cells)
+    x = op2.Dat(nodes ** 2, coords)
+    f = op2.Dat(nodes, np.random.default_rng(1).standard_normal(len(coords)))
+    b = op2.Dat(nodes)
+    _check(op2.Kernel(gk.RHS_Q6, "rhs_q6"), ele, b(op2.INC, m), x(op2.READ, m), f(op2.READ, m))
+    mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(m, m, None)]))
+    lg = np.arange(len(coords), dtype=np.int32)
+    lg[[0, 3, 7]] = -1
+    for lgmaps in (None, (lg, lg)):
+        _check(op2.Kernel(gk.MASS_Q6, "mass_q6"), ele, mat(op2.INC, (m, m), lgmaps=lgmaps), x(op2.READ, m))
+
+
+def test_vector_mass_unrolled_and_blocked():
+    coords, cells = structured_tri_mesh(3, 3)
+    nodes, ele = op2.Set(len(coords)), op2.Set(len(cells))
+    m = op2.Map(ele, nodes, 3, cells)
+    x = op2.Dat(nodes ** 2, coords)
+    mat = op2.Mat(op2.Sparsity((nodes ** 2, nodes ** 2), [(m, m, None)]))
+    _check(op2.Kernel(gk.MASS_VEC_AFFINE, "mass_vec_affine"), ele, mat(op2.INC, (m, m)), x(op2.READ, m))
+
+
+def test_minmax_rw_subset_permuted_global():
+    rng = np.random.default_rng(3)
+    it, ind = op2.Set(40), op2.Set(17)
+    mp = op2.Map(it, ind, 2, rng.integers(0, 17, size=(40, 2)))
+    a = op2.Dat(ind, rng.integers(-50, 50, size=17), dtype=np.int32)
+    b = op2.Dat(it, rng.integers(-50, 50, size=40), dtype=np.int32)
+    _check(op2.Kernel("static void mx(int *a, int *b) { for (int i = 0; i < 2; ++i) a[i] = a[i] < *b ? *b : a[i]; }", "mx"),
+           it, a(op2.MAX, mp), b(op2.READ))
+    g = op2.Global(1, 0.0)
+    d = op2.Dat(ind, rng.standard_normal(17))
+    ss = op2.Subset(it, [1, 3, 5, 8, 13, 21, 34])
+    _check(op2.Kernel("static void sm(double *g, double *d) { g[0] += d[0] - 2*d[1]; }", "sm"), ss, g(op2.INC), d(op2.READ, mp))
+    m1 = op2.Map(op2.Set(5), op2.Set(20), 4, rng.permutation(20).reshape(5, 4))
+    m2 = op2.PermutedMap(m1, [3, 2, 0, 1])
+    d1 = op2.Dat(m1.toset, rng.integers(0, 99, size=20), dtype=np.int32)
+    d2 = op2.Dat(m1.toset, dtype=np.int32)
+    _check(op2.Kernel("void cp(int *to, const int *from) { for (int i = 0; i < 4; i++) to[i] = from[i]; }", "cp"),
+           m1.iterset, d2(op2.WRITE, m2), d1(op2.READ, m1))
+
+
+@pytest.mark.parametrize("region", [None, op2.ON_BOTTOM, op2.ON_TOP, op2.ON_INTERIOR_FACETS])
+def test_extruded_columns(region):
+    rng = np.random.default_rng(5)
+    nbase, L = 6, 5                     # 6 base cells, 5 node layers -> 4 cell layers
+    base = op2.Set(nbase)
+    ext = op2.ExtrudedSet(base, layers=L)
+    nv = 8                               # base vertices; P1xP1 prism-like: 3 base vertices x 2 per cell
+    nodes = op2.Set(nv * L)
+    tri = np.array([rng.choice(nv, 3, replace=False) for _ in range(nbase)])
+    vals = np.concatenate([tri * L, tri * L + 1], axis=1).astype(np.int32)      # bottom + top vertex of layer 0
+    cm = op2.Map(ext, nodes, 6, vals, offset=[1] * 6)
+    x = op2.Dat(nodes ** 2, rng.standard_normal((nv * L, 2)))
+    out = op2.Dat(nodes)
+    nf = 2 if region == op2.ON_INTERIOR_FACETS else 1
+    k = op2.Kernel("static void kk(double *o, const double *x) { for (int i = 0; i < %d; ++i) o[i] += x[2*i] + 0.5*x[2*i+1]; }" % (6 * nf), "kk")
+    _check(k, ext, out(op2.INC, cm), x(op2.READ, cm), iteration_region=region)
+    mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(cm, cm, None)]))
+    n = 6 * nf
+    km = op2.Kernel("static void km(double *A, const double *x) { for (int i = 0; i < %d; ++i) for (int j = 0; j < %d; ++j) A[i*%d+j] += x[2*i]*x[2*j+1]; }" % (n, n, n), "km")
+    if region in (None,):
+        _check(km, ext, mat(op2.INC, (cm, cm)), x(op2.READ, cm), iteration_region=region)
+
+
+def _periodic_column_mesh(rng, nbase=5, ncl=4, nv=7):
+    """A periodic column mesh: ``ncl`` cell layers, ``ncl`` node levels (the top level IS the bottom level).
+    P1 x P1 prisms: 3 base vertices x {lower, upper}; the upper vertices of the top cell wrap to level 0, which is
+    what offset_quotient = 1 on the upper entries expresses (map.py:46-53, builder.py:108-120)."""
+    base = op2.Set(nbase)
+    ext = op2.ExtrudedSet(base, layers=ncl + 1, extruded_periodic=True)
+    nodes = op2.Set(nv * ncl)
+    tri = np.array([rng.choice(nv, 3, replace=False) for _ in range(nbase)])
+    # entries 0..2: lower vertices (level 0 of the column), 3..5: upper vertices (level 1)
+    vals = np.concatenate([tri * ncl, tri * ncl + 1], axis=1).astype(np.int32)
+    cm = op2.Map(ext, nodes, 6, vals, offset=[1] * 6, offset_quotient=[0, 0, 0, 1, 1, 1])
+    return base, ext, nodes, cm
+
+
+@pytest.mark.parametrize("region", [None, op2.ON_BOTTOM, op2.ON_TOP, op2.ON_INTERIOR_FACETS])
+def test_periodic_extrusion(region):
+    rng = np.random.default_rng(11)
+    ncl = 4
+    base, ext, nodes, cm = _periodic_column_mesh(rng, ncl=ncl)
+    x = op2.Dat(nodes ** 2, rng.standard_normal((nodes.size, 2)))
+    out = op2.Dat(nodes)
+    nf = 2 if region == op2.ON_INTERIOR_FACETS else 1
+    k = op2.Kernel("static void kp(double *o, const double *x) { for (int i = 0; i < %d; ++i) o[i] += (i+1)*x[2*i] + 0.5*x[2*i+1]; }" % (6 * nf), "kp")
+    got = _check(k, ext, out(op2.INC, cm), x(op2.READ, cm), iteration_region=region)
+    # independent numpy restatement: the top cell's upper vertices are the column's level-0 vertices
+    exp = np.zeros(nodes.size)
+    xv = x.data_ro
+    lay = {None: range(ncl), op2.ON_BOTTOM: [0], op2.ON_TOP: [ncl - 1], op2.ON_INTERIOR_FACETS: range(ncl)}[region]
+    for e in range(base.size):
+        for l in lay:
+            for f in range(nf):
+                for i in range(6):
+                    lev = (l + f + (1 if i >= 3 else 0)) % ncl
+                    n = (cm.values[e, i] // ncl) * ncl + lev
+                    q = f * 6 + i
+                    exp[n] += (q + 1) * xv[n, 0] + 0.5 * xv[n, 1]
+    assert np.abs(got[0] - exp).max() < 1e-12
+    # matrix + sparsity over the same region
+    n = 6 * nf
+    mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(cm, cm, [region] if region is not None else None)]))
+    km = op2.Kernel("static void kpm(double *A, const double *x) { for (int i = 0; i < %d; ++i) for (int j = 0; j < %d; ++j) A[i*%d+j] += x[2*i]*x[2*j+1]; }" % (n, n, n), "kpm")
+    _check(km, ext, mat(op2.INC, (cm, cm)), x(op2.READ, cm), iteration_region=region)
+
+
+def test_periodic_without_quotient_and_subset():
+    """offset_quotient None: every entry wraps like (layer + k) % nl (builder.py:109-112)."""
+    rng = np.random.default_rng(12)
+    ncl = 3
+    base = op2.Set(6)
+    ext = op2.ExtrudedSet(base, layers=ncl + 1, extruded_periodic=True)
+    dg = op2.Set(6 * ncl)
+    cm = op2.Map(ext, dg, 1, np.arange(6) * ncl, offset=[1])
+    d = op2.Dat(dg, rng.standard_normal(6 * ncl))
+    g = op2.Global(1, 0.0)
+    k = op2.Kernel("static void ks(double *g, const double *d) { g[0] += d[0] - 3*d[1]; }", "ks")
+    _check(k, ext, g(op2.INC), d(op2.READ, cm), iteration_region=op2.ON_INTERIOR_FACETS)
+    ss = op2.Subset(ext, [0, 2, 5])
+    _check(k, ss, g(op2.INC), d(op2.READ, cm), iteration_region=op2.ON_INTERIOR_FACETS)
+
+
+def test_extruded_interior_facet_sparsity_regions():
+    rng = np.random.default_rng(13)
+    nbase, L, nv = 4, 4, 6
+    base = op2.Set(nbase)
+    ext = op2.ExtrudedSet(base, layers=L)
+    nodes = op2.Set(nv * L)
+    tri = np.array([rng.choice(nv, 3, replace=False) for _ in range(nbase)])
+    vals = np.concatenate([tri * L, tri * L + 1], axis=1).astype(np.int32)
+    cm = op2.Map(ext, nodes, 6, vals, offset=[1] * 6)
+    x = op2.Dat(nodes ** 2, rng.standard_normal((nv * L, 2)))
+    mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(cm, cm, [op2.ALL, op2.ON_INTERIOR_FACETS])]))
+    km = op2.Kernel("static void kif(double *A, const double *x) { for (int i = 0; i < 12; ++i) for (int j = 0; j < 12; ++j) A[i*12+j] += x[2*i]*x[2*j+1]; }", "kif")
+    _check(km, ext, mat(op2.INC, (cm, cm)), x(op2.READ, cm), iteration_region=op2.ON_INTERIOR_FACETS)
