@@ -106,10 +106,11 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise FDHipError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                          "or `make -C firedrake_amd/csrc`")
-    try:
-        import torch  # noqa: F401  (loads libamdhip64 first; our NEEDED entry then binds to the same copy)
-    except Exception:
-        pass
+    if os.environ.get("FDHIP_SKIP_TORCH", "0") != "1":      # single-process runs that never touch torch.distributed
+        try:
+            import torch  # noqa: F401  (loads libamdhip64 first; our NEEDED entry then binds to the same copy)
+        except Exception:
+            pass
     lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

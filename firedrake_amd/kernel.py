@@ -19,6 +19,9 @@ import numpy as np
 from . import _lib
 from .op2types import Access, IterationRegion, ALL, READ, ScalarType
 
+_C_TYPE = {np.dtype("float64"): "double", np.dtype("float32"): "float", np.dtype("int32"): "int",
+           np.dtype("uint32"): "unsigned int", np.dtype("int64"): "long long", np.dtype("uint64"): "unsigned long long"}
+
 
 # ---- local kernel ---------------------------------------------------------------------------
 @dataclass(frozen=True)
@@ -146,6 +149,45 @@ class MatKernelArg:              # pyop2/global_kernel.py:155-180
 
 
 @dataclass(frozen=True)
+class MixedDatKernelArg:         # pyop2/global_kernel.py:183-219
+    arguments: Tuple[DatKernelArg, ...]
+
+    def __iter__(self):
+        return iter(self.arguments)
+
+    def __len__(self):
+        return len(self.arguments)
+
+    @property
+    def cache_key(self):
+        return (type(self),) + tuple(a.cache_key for a in self.arguments)
+
+    @property
+    def maps(self):
+        return tuple(m for a in self.arguments for m in a.maps)
+
+
+@dataclass(frozen=True)
+class MixedMatKernelArg:         # pyop2/global_kernel.py:222-252
+    arguments: Tuple[MatKernelArg, ...]
+    shape: Tuple[int, int]
+
+    def __iter__(self):
+        return iter(self.arguments)
+
+    def __len__(self):
+        return len(self.arguments)
+
+    @property
+    def cache_key(self):
+        return (type(self), self.shape) + tuple(a.cache_key for a in self.arguments)
+
+    @property
+    def maps(self):
+        return tuple(m for a in self.arguments for m in a.maps)
+
+
+@dataclass(frozen=True)
 class PassthroughKernelArg:      # pyop2/global_kernel.py:245-252
     @property
     def cache_key(self):
@@ -196,9 +238,81 @@ class GlobalKernel:
     def name(self):
         return f"wrap_{self.local_kernel.name}"
 
+    @property
+    def is_mixed(self):
+        return any(isinstance(a, (MixedDatKernelArg, MixedMatKernelArg)) for a in self.arguments)
+
+    def flattened(self):
+        """The same loop with every Mixed argument split into its parts -- what the reference's builder does when it
+        emits one pointer per part (builder.py:872-893, 904-916).  The local kernel keeps seeing ONE concatenated pack
+        per mixed argument: an adaptor with the original name gathers the parts' packs into it before the call and
+        copies them back afterwards (MixedDatPack, builder.py:432-518), resp. cuts the mixed element tensor into its
+        blocks (MixedMatPack, builder.py:628-699).  The adaptor is inlined by hipcc; the packs stay in registers."""
+        if not self.is_mixed:
+            return self
+        if getattr(self, "_flat", None) is None:
+            nf = 2 if (self._extruded and self._iteration_region == IterationRegion.ON_INTERIOR_FACETS) else 1
+            lk = self.local_kernel
+            inner = lk.name + "__mixed"
+            flat_args, accesses, dtypes, params, pre, call, post = [], [], [], [], [], [], []
+            for k, (a, la) in enumerate(zip(self.arguments, lk.arguments)):
+                ct = _C_TYPE[np.dtype(la.dtype)]
+                if isinstance(a, MixedDatKernelArg):
+                    sizes = []
+                    for pa in a:
+                        if pa.map_ is None:
+                            raise NotImplementedError("direct (map-less) MixedDat arguments")        # as builder.py:441
+                        sizes.append(nf * pa.map_.arity * int(np.prod(pa.dim)))
+                    pre.append(f"{ct} m{k}[{sum(sizes)}];")
+                    off = 0
+                    for p_, (pa, n) in enumerate(zip(a, sizes)):
+                        flat_args.append(pa); accesses.append(la.access); dtypes.append(la.dtype)
+                        params.append(f"{ct} *a{k}_{p_}")
+                        pre.append(f"for (int q = 0; q < {n}; ++q) m{k}[{off} + q] = a{k}_{p_}[q];")
+                        if la.access != READ:
+                            post.append(f"for (int q = 0; q < {n}; ++q) a{k}_{p_}[q] = m{k}[{off} + q];")
+                        off += n
+                    call.append(f"m{k}")
+                elif isinstance(a, MixedMatKernelArg):
+                    nr, nc = a.shape
+                    blocks = [a.arguments[i * nc:(i + 1) * nc] for i in range(nr)]
+                    rows = [nf * row[0].maps[0].arity * int(np.prod(row[0].dims[0])) for row in blocks]
+                    cols = [nf * b.maps[1].arity * int(np.prod(b.dims[1])) for b in blocks[0]]
+                    R, C = sum(rows), sum(cols)
+                    pre.append(f"{ct} m{k}[{R * C}]; for (int q = 0; q < {R * C}; ++q) m{k}[q] = 0;")
+                    ro = 0
+                    for i, row in enumerate(blocks):
+                        co = 0
+                        for j, b in enumerate(row):
+                            flat_args.append(b); accesses.append(la.access); dtypes.append(la.dtype)
+                            params.append(f"{ct} *a{k}_{i}_{j}")
+                            post.append(f"for (int i = 0; i < {rows[i]}; ++i) for (int j = 0; j < {cols[j]}; ++j) "
+                                        f"a{k}_{i}_{j}[i*{cols[j]} + j] = m{k}[({ro} + i)*{C} + {co} + j];")
+                            co += cols[j]
+                        ro += rows[i]
+                    call.append(f"m{k}")
+                else:
+                    flat_args.append(a); accesses.append(la.access); dtypes.append(la.dtype)
+                    params.append(f"{ct} *a{k}")
+                    call.append(f"a{k}")
+            if self._pass_layer_arg:
+                params.append("int layer")
+                call.append("layer")
+            body = "\n  ".join(pre + [f"{inner}({', '.join(call)});"] + post)
+            code = (f"#define {lk.name} {inner}\n{lk.code}\n#undef {lk.name}\n"
+                    f"static inline void {lk.name}({', '.join(params)})\n{{\n  {body}\n}}\n")
+            flk = CStringLocalKernel(code, lk.name, accesses, dtypes, flop_count=lk.flop_count, headers=lk.headers,
+                                     requires_zeroed_output_arguments=lk.requires_zeroed_output_arguments, cpp=lk.cpp)
+            self._flat = GlobalKernel(flk, flat_args, extruded=self._extruded, extruded_periodic=self._extruded_periodic,
+                                      constant_layers=self._constant_layers, subset=self._subset,
+                                      iteration_region=self._iteration_region, pass_layer_arg=self._pass_layer_arg)
+        return self._flat
+
     def compile(self, mode=None):
         """compile_global_kernel (global_kernel.py:426-456): codegen -> hipcc -> code object ->
         fd_kernel_load.  Returns a :class:`CompiledWrapper`."""
+        if self.is_mixed:
+            return self.flattened().compile(mode)
         from .codegen import generate_wrapper, select_mode
         from .compilation import compile_hip
         mode = mode or select_mode(self)

@@ -274,6 +274,17 @@ class DataSet:
     def total_size(self):
         return self._set.total_size
 
+    def __iter__(self):            # dataset.py:95-103: a DataSet is a one-member bag of itself
+        yield self
+
+    def __len__(self):
+        return 1
+
+    def __getitem__(self, idx):
+        if idx != 0:
+            raise IndexError("Can only extract component 0 from a DataSet")
+        return self
+
     def __eq__(self, o):
         return isinstance(o, DataSet) and o._set is self._set and o._dim == self._dim
 
@@ -287,6 +298,54 @@ def _as_dataset(x, dim=1):
     if isinstance(x, Set):
         return DataSet(x, dim)
     raise DataTypeError(f"expected Set or DataSet, got {type(x)}")
+
+
+class MixedDataSet:
+    """pyop2/types/dataset.py:295-450: a bag of DataSets, built from a MixedSet (with dims) or from an iterable of
+    Sets / DataSets."""
+
+    def __init__(self, arg, dims=None):
+        if isinstance(arg, MixedDataSet):
+            dsets = arg.split
+        elif dims is not None:
+            sets = arg.split if isinstance(arg, MixedSet) else tuple(arg)
+            dims = (dims,) * len(sets) if isinstance(dims, (int, np.integer)) else tuple(dims)
+            if len(sets) != len(dims):
+                raise ValueError("Got MixedSet of %d Sets but %s dims" % (len(sets), len(dims)))
+            dsets = tuple(s ** d for s, d in zip(sets, dims))
+        else:
+            dsets = tuple(x if isinstance(x, DataSet) else _as_dataset(x) for x in arg)
+        if not dsets:
+            raise DataTypeError("MixedDataSet needs at least one DataSet")
+        self._dsets = dsets
+        self.comm = dsets[0].set.comm
+
+    split = property(lambda self: self._dsets)
+    dim = property(lambda self: tuple(d.dim for d in self._dsets))
+    cdim = property(lambda self: sum(d.cdim for d in self._dsets))
+    name = property(lambda self: "_".join(d.name for d in self._dsets))
+
+    @property
+    def set(self):
+        return MixedSet(d.set for d in self._dsets)
+
+    def __getitem__(self, idx):
+        return self._dsets[idx]
+
+    def __iter__(self):
+        return iter(self._dsets)
+
+    def __len__(self):
+        return len(self._dsets)
+
+    def __eq__(self, o):
+        return isinstance(o, MixedDataSet) and self._dsets == o._dsets
+
+    def __hash__(self):
+        return hash(self._dsets)
+
+    def __repr__(self):
+        return f"MixedDataSet({self._dsets!r})"
 
 
 # ---- host/device mirrored array ---------------------------------------------------------
@@ -407,7 +466,11 @@ class Dat(_Mirrored):
 
     def zero(self, subset=None):      # dat.py:297-311
         if subset is not None:
-            self._host_rw()[subset.indices] = 0
+            if subset.superset != self.dataset.set:
+                raise MapValueError("The subset and dataset are incompatible")
+            # bc.zero(r) (firedrake/bcs.py:192-221): a direct loop over the subset's owned entities
+            from .parloop import par_loop
+            par_loop(self._kernel("zero"), subset, self(WRITE))
             return
         if self._dev is not None:
             self._dev.zero()
@@ -419,9 +482,20 @@ class Dat(_Mirrored):
             self.dat_version += 1
         self.halo_valid = True      # zero everywhere, halos included
 
-    def copy(self, other):
-        other._host_rw()[...] = self._to_host()
-        other.halo_valid = self.halo_valid
+    def copy(self, other, subset=None):           # dat.py:313-336
+        if other is self:
+            return
+        if subset is None:
+            if self._dev is not None and self._dev_valid and _lib.gpu_available() and self._host.nbytes == other._host.nbytes:
+                _lib.call("fd_memcpy_d2d", other._dev_ptr(True), self._dev_ptr(False), self._host.nbytes, None)
+            else:
+                other._host_rw()[...] = self._to_host()
+            other.halo_valid = self.halo_valid
+            return
+        if subset.superset != self.dataset.set:
+            raise MapValueError("The subset and dataset are incompatible")
+        from .parloop import par_loop
+        par_loop(self._kernel("copy"), subset, self(READ), other(WRITE))
 
     def assign(self, values):
         self._host_rw()[...] = values
@@ -499,8 +573,306 @@ class Dat(_Mirrored):
     def assign_dat(self, x: "Dat"):
         return self.axpby(1.0, x, 0.0)
 
+    # -- the reference's Dat arithmetic (pyop2/types/dat.py:354-620): every operation is a DIRECT parloop over the
+    #    Dat's own set with a tiny generated kernel (binop_*/iop_*/inner/neg, dat.py:354-470).  Same here: the kernels
+    #    are C strings, the loops run through the direct wrapper on the device, so a Newton / Runge-Kutta / Krylov
+    #    update never leaves HBM.
+    _OPS = {"add": "+", "sub": "-", "mul": "*", "div": "/"}
+
+    def _check_shape(self, other):                # dat.py:349-352
+        if other.dataset.dim != self.dataset.dim:
+            raise ValueError("Mismatched shapes in operands %s and %s" % (self.dataset.dim, other.dataset.dim))
+
+    @staticmethod
+    def _ctype(dt):
+        from .codegen import CTYPE
+        return CTYPE[np.dtype(dt)]
+
+    def _kernel(self, kind, op=None, globalp=False, other_is_self=False, odtype=None):
+        from .kernel import Kernel
+        c, ct = self.cdim, self._ctype(self.dtype)
+        oct_ = self._ctype(odtype) if odtype is not None else ct
+        rhs = "other[0]" if globalp else ("self[i]" if other_is_self else "other[i]")
+        loop = f"for (int i = 0; i < {c}; ++i)"
+        if kind == "binop":      # dat.py:354-383
+            name = f"binop_{op}"
+            code = f"static void {name}(const {ct} *self, const {oct_} *other, {ct} *ret) {{ {loop} ret[i] = self[i] {self._OPS[op]} {rhs}; }}"
+        elif kind == "iop":      # dat.py:401-436
+            name = f"iop_{op}"
+            args = f"{ct} *self" + ("" if other_is_self else f", const {oct_} *other")
+            code = f"static void {name}({args}) {{ {loop} self[i] = self[i] {self._OPS[op]} {rhs}; }}"
+        elif kind == "inner":    # dat.py:454-476
+            name = "inner"
+            code = f"static void inner(const {ct} *self, const {oct_} *other, {ct} *ret) {{ {loop} ret[0] = ret[0] + self[i]*other[i]; }}"
+        elif kind == "neg":      # dat.py:560-582
+            name = "neg"
+            code = f"static void neg({ct} *other, const {ct} *self) {{ {loop} other[i] = -self[i]; }}"
+        elif kind == "axpy":
+            name = "axpy"
+            code = f"static void axpy({ct} *self, const {ct} *alpha, const {oct_} *other) {{ {loop} self[i] = alpha[0]*other[i] + self[i]; }}"
+        elif kind == "copy":
+            name = "copy"
+            code = f"static void copy(const {ct} *self, {ct} *other) {{ {loop} other[i] = self[i]; }}"
+        elif kind == "zero":
+            name = "zero"
+            code = f"static void zero({ct} *self) {{ {loop} self[i] = 0; }}"
+        else:
+            raise ValueError(kind)
+        # unique per signature: the wrapper cache is keyed by kernel text + name
+        return Kernel(code, name)
+
+    def _op(self, other, op):                     # dat.py:385-399
+        from .parloop import par_loop
+        ret = Dat(self.dataset, None, self.dtype)
+        if np.isscalar(other):
+            other = Global(1, data=other)
+            globalp = True
+        else:
+            self._check_shape(other)
+            globalp = False
+        par_loop(self._kernel("binop", op, globalp, odtype=other.dtype), self.dataset.set,
+                 self(READ), other(READ), ret(WRITE))
+        return ret
+
+    def _iop(self, other, op):                    # dat.py:438-452
+        from .parloop import par_loop
+        globalp = False
+        if np.isscalar(other):
+            other = Global(1, data=other)
+            globalp = True
+        elif isinstance(other, Global):
+            globalp = True
+        elif other is not self:
+            self._check_shape(other)
+        args = [self(INC)]
+        if other is not self:
+            args.append(other(READ))
+        par_loop(self._kernel("iop", op, globalp, other is self, odtype=other.dtype), self.dataset.set, *args)
+        return self
+
+    def inner(self, other):                       # dat.py:478-492
+        """Inner product of the flattened owned data with ``other``."""
+        from .parloop import par_loop
+        self._check_shape(other)
+        ret = Global(1, data=0, dtype=self.dtype)
+        par_loop(self._kernel("inner", odtype=other.dtype), self.dataset.set, self(READ), other(READ), ret(INC))
+        return ret.data_ro[0]
+
+    @property
+    def norm(self):                               # dat.py:494-503
+        """L2 norm of the flattened owned data."""
+        from math import sqrt
+        return sqrt(self.inner(self).real)
+
+    def axpy(self, alpha, other):                 # dat.py:527-546: self = alpha*other + self
+        from .parloop import par_loop
+        self._check_shape(other)
+        if not np.isscalar(alpha):
+            raise TypeError("alpha must be a scalar")
+        a = Global(1, data=alpha, dtype=self.dtype)
+        par_loop(self._kernel("axpy", odtype=other.dtype), self.dataset.set, self(INC), a(READ), other(READ))
+
+    def maxpy(self, scalar, x):                   # dat.py:505-525
+        if len(scalar) != len(x):
+            raise ValueError("scalar and x must have the same length")
+        for alpha_i, x_i in zip(scalar, x):
+            self.axpy(alpha_i, x_i)
+
+    def __pos__(self):
+        return Dat(self)
+
+    def __neg__(self):                            # dat.py:584-590
+        from .parloop import par_loop
+        neg = Dat(self.dataset, dtype=self.dtype)
+        par_loop(self._kernel("neg"), self.dataset.set, neg(WRITE), self(READ))
+        return neg
+
+    def __add__(self, other):
+        return self._op(other, "add")
+
+    def __radd__(self, other):
+        return self + other
+
+    def __sub__(self, other):
+        return self._op(other, "sub")
+
+    def __rsub__(self, other):                    # dat.py:596-603
+        ret = -self
+        ret += other
+        return ret
+
+    def __mul__(self, other):
+        return self._op(other, "mul")
+
+    def __rmul__(self, other):
+        return self.__mul__(other)
+
+    def __truediv__(self, other):
+        return self._op(other, "div")
+
+    __div__ = __truediv__
+
+    def __iadd__(self, other):
+        return self._iop(other, "add")
+
+    def __isub__(self, other):
+        return self._iop(other, "sub")
+
+    def __imul__(self, other):
+        return self._iop(other, "mul")
+
+    def __itruediv__(self, other):
+        return self._iop(other, "div")
+
+    __idiv__ = __itruediv__
+
+
+class MixedDat:
+    """pyop2/types/dat.py:861-1243: a bag of Dats (the coefficient vector of a mixed function space).  Built from a
+    MixedDataSet / MixedSet / iterable of (Data)Sets, or from an iterable of Dats."""
+
+    def __init__(self, mdset_or_dats):
+        if isinstance(mdset_or_dats, MixedDat):
+            self._dats = tuple(Dat(d) for d in mdset_or_dats)
+        else:
+            self._dats = tuple(d if isinstance(d, Dat) else Dat(d) for d in mdset_or_dats)
+        if not self._dats:
+            raise DataValueError("MixedDat needs at least one Dat")
+        if not all(d.dtype == self._dats[0].dtype for d in self._dats):
+            raise DataValueError("MixedDat with different dtypes is not supported")
+        self.comm = self._dats[0].dataset.set.comm
+
+    split = property(lambda self: self._dats)
+    dtype = property(lambda self: self._dats[0].dtype)
+    dat_version = property(lambda self: sum(d.dat_version for d in self._dats))
+    data = property(lambda self: tuple(d.data for d in self._dats))
+    data_ro = property(lambda self: tuple(d.data_ro for d in self._dats))
+    data_with_halos = property(lambda self: tuple(d.data_with_halos for d in self._dats))
+    data_ro_with_halos = property(lambda self: tuple(d.data_ro_with_halos for d in self._dats))
+    nbytes = property(lambda self: sum(d.nbytes for d in self._dats))
+
+    @property
+    def dataset(self):
+        return MixedDataSet(tuple(d.dataset for d in self._dats))
+
+    @property
+    def halo_valid(self):
+        return all(d.halo_valid for d in self._dats)
+
+    @halo_valid.setter
+    def halo_valid(self, val):
+        for d in self._dats:
+            d.halo_valid = val
+
+    def __getitem__(self, idx):
+        return self._dats[idx]
+
+    def __iter__(self):
+        return iter(self._dats)
+
+    def __len__(self):
+        return len(self._dats)
+
+    def __call__(self, access, path=None):
+        from .parloop import MixedDatLegacyArg
+        return MixedDatLegacyArg(self, path, access)
+
+    def zero(self, subset=None):      # dat.py:1028-1036
+        if subset is not None:
+            raise NotImplementedError("Subsets of mixed sets not implemented")
+        for d in self._dats:
+            d.zero()
+
+    def copy(self, other, subset=None):
+        if subset is not None:
+            raise NotImplementedError("MixedDat.copy with a Subset is not supported")
+        for s_, o in zip(self, other):
+            s_.copy(o)
+
+    def global_to_local_begin(self, access_mode):
+        for d in self._dats:
+            d.global_to_local_begin(access_mode)
+
+    def global_to_local_end(self, access_mode):
+        for d in self._dats:
+            d.global_to_local_end(access_mode)
+
+    def local_to_global_begin(self, insert_mode):
+        for d in self._dats:
+            d.local_to_global_begin(insert_mode)
+
+    def local_to_global_end(self, insert_mode):
+        for d in self._dats:
+            d.local_to_global_end(insert_mode)
+
+    def __repr__(self):
+        return f"MixedDat({self._dats!r})"
+
+    # -- arithmetic: component-wise (dat.py:1090-1198)
+    def inner(self, other):
+        return sum(s_.inner(o) for s_, o in zip(self, other))
+
+    @property
     def norm(self):
-        return float(np.linalg.norm(self.data_ro))
+        from math import sqrt
+        return sqrt(self.inner(self).real)
+
+    def axpy(self, alpha, other):
+        for s_, o in zip(self, other):
+            s_.axpy(alpha, o)
+
+    def _op(self, other, op):
+        if np.isscalar(other):
+            return MixedDat([getattr(s_, op)(other) for s_ in self])
+        return MixedDat([getattr(s_, op)(o) for s_, o in zip(self, other)])
+
+    def _iop(self, other, op):
+        if np.isscalar(other):
+            for s_ in self:
+                getattr(s_, op)(other)
+        else:
+            for s_, o in zip(self, other):
+                getattr(s_, op)(o)
+        return self
+
+    def __pos__(self):
+        return MixedDat([+d for d in self])
+
+    def __neg__(self):
+        return MixedDat([-d for d in self])
+
+    def __add__(self, other):
+        return self._op(other, "__add__")
+
+    def __radd__(self, other):
+        return self._op(other, "__radd__")
+
+    def __sub__(self, other):
+        return self._op(other, "__sub__")
+
+    def __rsub__(self, other):
+        return self._op(other, "__rsub__")
+
+    def __mul__(self, other):
+        return self._op(other, "__mul__")
+
+    def __rmul__(self, other):
+        return self._op(other, "__rmul__")
+
+    def __truediv__(self, other):
+        return self._op(other, "__truediv__")
+
+    def __iadd__(self, other):
+        return self._iop(other, "__iadd__")
+
+    def __isub__(self, other):
+        return self._iop(other, "__isub__")
+
+    def __imul__(self, other):
+        return self._iop(other, "__imul__")
+
+    def __itruediv__(self, other):
+        return self._iop(other, "__itruediv__")
 
 
 class Global(_Mirrored):
@@ -558,6 +930,49 @@ class Global(_Mirrored):
 
 
 Constant = Global
+
+
+class MixedSet:
+    """pyop2/types/set.py:546-660: an ordered bag of Sets (the node sets of a mixed function space)."""
+
+    def __init__(self, sets):
+        sets = tuple(sets.split if isinstance(sets, MixedSet) else sets)
+        if not sets or not all(isinstance(s, Set) for s in sets):
+            raise SetTypeError("MixedSet needs an iterable of Sets")
+        if len({s._extruded for s in sets}) != 1:
+            raise AssertionError("All components of a MixedSet must have the same extrusion")      # set.py:552-556
+        self._sets = sets
+        self.comm = sets[0].comm
+        self.name = "_".join(s.name for s in sets)
+
+    split = property(lambda self: self._sets)
+    _extruded = property(lambda self: self._sets[0]._extruded)
+    core_size = property(lambda self: sum(s.core_size for s in self._sets))
+    size = property(lambda self: sum(s.size for s in self._sets))
+    total_size = property(lambda self: sum(s.total_size for s in self._sets))
+    sizes = property(lambda self: (self.core_size, self.size, self.total_size))
+    superset = property(lambda self: self)
+
+    def __getitem__(self, idx):
+        return self._sets[idx]
+
+    def __iter__(self):
+        return iter(self._sets)
+
+    def __len__(self):
+        return len(self._sets)
+
+    def __pow__(self, e):
+        return MixedDataSet(self._sets, e)
+
+    def __eq__(self, o):
+        return isinstance(o, MixedSet) and len(o) == len(self) and all(a is b for a, b in zip(self, o))
+
+    def __hash__(self):
+        return hash(tuple(id(s) for s in self._sets))
+
+    def __repr__(self):
+        return f"MixedSet({self._sets!r})"
 
 
 # ---- maps --------------------------------------------------------------------------------
@@ -683,6 +1098,45 @@ class ComposedMap(Map):
                          offset=first.offset)
 
 
+class MixedMap:
+    """pyop2/types/map.py:330-470: one Map per component of a mixed space, all on the same iteration set
+    (entries may be None for components an argument does not touch)."""
+
+    def __init__(self, maps):
+        maps = tuple(maps.split if isinstance(maps, MixedMap) else maps)
+        if not maps or not all(m is None or isinstance(m, Map) for m in maps):
+            raise TypeError("MixedMap needs an iterable of Maps")
+        present = [m for m in maps if m is not None]
+        if not present:
+            raise TypeError("Don't know how to make a MixedMap of no Maps")
+        if any(m.iterset is not present[0].iterset for m in present):
+            raise MapValueError("All maps in a MixedMap need to share the same iterset")       # map.py:378-385
+        self._maps = maps
+
+    split = property(lambda self: self._maps)
+    iterset = property(lambda self: next(m for m in self._maps if m is not None).iterset)
+    toset = property(lambda self: MixedSet(tuple(m.toset for m in self._maps)))
+    arity = property(lambda self: sum(m.arity for m in self._maps))
+    arities = property(lambda self: tuple(m.arity for m in self._maps))
+    values = property(lambda self: tuple(m.values for m in self._maps))
+    values_with_halo = property(lambda self: tuple(m.values_with_halo for m in self._maps))
+    offset = property(lambda self: tuple(0 if m is None else m.offset for m in self._maps))
+    offset_quotient = property(lambda self: tuple(0 if m is None else m.offset_quotient for m in self._maps))
+    name = property(lambda self: "_".join(m.name for m in self._maps if m is not None))
+
+    def __iter__(self):
+        return iter(self._maps)
+
+    def __len__(self):
+        return len(self._maps)
+
+    def __getitem__(self, idx):
+        return self._maps[idx]
+
+    def __repr__(self):
+        return f"MixedMap({self._maps!r})"
+
+
 class Plan:
     """Python handle on an fd_plan_t."""
 
@@ -741,13 +1195,38 @@ class Sparsity:
     PETSc MATPREALLOCATOR (pyop2/sparsity.pyx:105-159)."""
 
     def __init__(self, dsets, maps_and_regions, name=None, nest=None, block_sparse=None, diagonal_block=True):
-        if isinstance(dsets, (Set, DataSet)):
+        if isinstance(dsets, (Set, DataSet, MixedSet, MixedDataSet)):
             dsets = (dsets, dsets)
+        if len(dsets) != 2:
+            raise RuntimeError(f"dsets must be a tuple of two DataSets: got {dsets}")
+        dsets = tuple(MixedDataSet(d) if isinstance(d, MixedSet) else d for d in dsets)
+        self.name = name or f"sparsity_{id(self):x}"
+        self._built = False
+        if isinstance(maps_and_regions, (list, tuple)):
+            maps_and_regions = {(0, 0): maps_and_regions}          # short-hand for a single block (mat.py:125-127)
+        elif not isinstance(maps_and_regions, dict):
+            raise TypeError(f"maps_and_regions must be dict or Sequence: got {type(maps_and_regions)}")
+        for (i, j) in maps_and_regions:
+            if i >= len(dsets[0]) or j >= len(dsets[1]):
+                raise RuntimeError(f"(i, j) must be < {(len(dsets[0]), len(dsets[1]))}: got {(i, j)}")
+        if any(isinstance(d, MixedDataSet) for d in dsets):
+            # mixed spaces: one Sparsity per block, each built on its own (mat.py:87-99, MATNEST)
+            if nest is False:
+                raise NotImplementedError("monolithic (nest=False) sparsities over mixed sets are out of scope")
+            self._dsets = dsets
+            self._nested = True
+            same = dsets[0] is dsets[1] or dsets[0] == dsets[1]
+            self._blocks = [[Sparsity((rds, cds), list(maps_and_regions.get((i, j), ())), block_sparse=block_sparse,
+                                      diagonal_block=(same and i == j))
+                             for j, cds in enumerate(dsets[1])] for i, rds in enumerate(dsets[0])]
+            self._rcmaps = []
+            self._has_diagonal = False
+            return
+        self._nested = False
+        self._blocks = [[self]]
         self._dsets = tuple(_as_dataset(d) for d in dsets)
         norm = []
-        if isinstance(maps_and_regions, dict):
-            maps_and_regions = maps_and_regions.get((0, 0), [])
-        for entry in maps_and_regions:
+        for entry in maps_and_regions.get((0, 0), ()):
             if isinstance(entry, Map):
                 entry = (entry, entry, None)
             r, c = entry[0], entry[1]
@@ -757,25 +1236,41 @@ class Sparsity:
                     raise MapValueError("Map toset does not match the sparsity's DataSets")
                 if r.iterset.superset != c.iterset.superset:
                     raise MapValueError("Iterset of both maps in a pair must be the same")
-            norm.append((r, c, tuple(reg) if reg else (ALL,)))
+            norm.append((r, c, tuple(sorted(reg)) if reg else (ALL,)))
         self._rcmaps = norm
-        self.name = name or f"sparsity_{id(self):x}"
         self._has_diagonal = diagonal_block and self._dsets[0].set is self._dsets[1].set
-        self._built = False
+
+    def __getitem__(self, idx):        # mat.py:180-187
+        try:
+            i, j = idx
+            return self._blocks[i][j]
+        except TypeError:
+            return self._blocks[idx]
+
+    def __iter__(self):                # blocks in row-major order (mat.py:216-220)
+        for row in self._blocks:
+            yield from row
+
+    nested = property(lambda self: self._nested)
 
     dsets = property(lambda self: self._dsets)
     rcmaps = property(lambda self: self._rcmaps)
 
     @property
     def dims(self):
-        return ((self._dsets[0].dim, self._dsets[1].dim),)
+        return tuple(tuple((r.dim, c.dim) for c in self._dsets[1]) for r in self._dsets[0])
 
     @property
     def shape(self):
-        return (1, 1)
+        return (len(self._dsets[0]), len(self._dsets[1]))
 
     def _build(self):
         if self._built:
+            return
+        if self._nested:
+            for blk in self:
+                blk._build()
+            self._built = True
             return
         _lib.require_gpu()
         rset, cset = self._dsets
@@ -1019,9 +1514,23 @@ class Mat:
         self._vals = None
         self._zero_pending = False
         self.dat_version = 0
+        # mixed spaces: one Mat per block of the nested sparsity (MATNEST, mat.py:741-768)
+        self._blocks = ([[Mat(sparsity[i, j], dtype, f"{self.name}_{i}_{j}") for j in range(sparsity.shape[1])]
+                         for i in range(sparsity.shape[0])] if sparsity.nested else [[self]])
 
     sparsity = property(lambda self: self._sparsity)
     dtype = property(lambda self: self._dtype)
+
+    def __getitem__(self, idx):        # mat.py:663-672
+        try:
+            i, j = idx
+            return self._blocks[i][j]
+        except TypeError:
+            return self._blocks[idx]
+
+    def __iter__(self):                # blocks in row-major order (mat.py:674-677)
+        for row in self._blocks:
+            yield from row
 
     @property
     def dims(self):
@@ -1060,6 +1569,13 @@ class Mat:
         return self._vals
 
     def zero(self):                 # mat.py:851-855
+        if self._sparsity.nested:
+            for blk in self:
+                blk.zero()
+            return
+        self._zero()
+
+    def _zero(self):
         """Zero the matrix.  The memset is deferred: a staged assembly that follows overwrites the entries
         each block owns exclusively and clears only the shared/untouched ones (fd_matplan_zero_list), which
         fuses the zeroing pass into the assembly kernel.  Any other access flushes it."""
@@ -1071,10 +1587,12 @@ class Mat:
         _lib.call("fd_device_sync")
 
     def __call__(self, access, path, lgmaps=None, unroll_map=False):
-        from .parloop import MatLegacyArg
+        from .parloop import MatLegacyArg, MixedMatLegacyArg
         if access not in (WRITE, INC):
             raise ModeValueError("Mat arguments must have access mode WRITE or INC")
         rmap, cmap = path
+        if self._sparsity.nested:
+            return MixedMatLegacyArg(self, (rmap, cmap), access, lgmaps, bool(unroll_map))
         if configuration["type_check"]:
             if rmap.toset != self._sparsity.dsets[0].set or cmap.toset != self._sparsity.dsets[1].set:
                 raise MapValueError("Path maps do not match the Mat's DataSets")

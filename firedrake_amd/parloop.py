@@ -22,9 +22,9 @@ from . import _lib
 from .configuration import configuration
 from .device import DeviceBuffer
 from .kernel import (CStringLocalKernel, DatKernelArg, GlobalKernel, GlobalKernelArg, MapKernelArg, MatKernelArg,
-                     PermutedMapKernelArg)
+                     MixedDatKernelArg, MixedMatKernelArg, PermutedMapKernelArg)
 from .op2types import (ALL, INC, MAX, MIN, READ, RW, WRITE, Access, Dat, ExtrudedSet, Global, Map, MapValueError,
-                       Mat, PermutedMap, Set, SetTypeError, Subset)
+                       Mat, MixedDat, MixedMap, PermutedMap, Set, SetTypeError, Subset)
 
 
 # ---- parloop arguments (pyop2/parloop.py:36-165) ----------------------------------------------
@@ -58,6 +58,37 @@ class MatParloopArg:
     data: Mat
     maps: Tuple[Map, Map]
     lgmaps: Optional[Any] = None      # (row_lgmap, col_lgmap) int32 arrays, -1 = dropped (parloop.py:279-302)
+
+
+@dataclass
+class MixedDatParloopArg:            # pyop2/parloop.py:97-118
+    data: MixedDat
+    map_: MixedMap
+
+    @property
+    def maps(self):
+        return tuple(m for m in self.map_.split if m is not None)
+
+    @property
+    def split(self):
+        return [DatParloopArg(d, m) for d, m in zip(self.data.split, self.map_.split)]
+
+
+@dataclass
+class MixedMatParloopArg:            # pyop2/parloop.py:137-152
+    data: Mat
+    maps: Tuple[MixedMap, MixedMap]
+    lgmaps: Optional[Any] = None      # one (row_lgmap, col_lgmap) pair per block, row-major (parloop.py:286-291)
+
+    @property
+    def split(self):
+        rmaps, cmaps = self.maps
+        out = []
+        for i, rm in enumerate(rmaps):
+            for j, cm in enumerate(cmaps):
+                lg = None if self.lgmaps is None else self.lgmaps[i * len(cmaps) + j]
+                out.append(MatParloopArg(self.data[i, j], (rm, cm), lg))
+        return out
 
 
 # ---- legacy args (pyop2/parloop.py:545-660): what dat(access, map) returns -------------------
@@ -112,13 +143,77 @@ class MatLegacyArg:
 
     @property
     def global_kernel_arg(self):
-        (rdim, cdim), = self.data.dims
+        ((rdim, cdim),), = self.data.dims
         return MatKernelArg((rdim, cdim), tuple(_map_kernel_arg(m) for m in self.maps), unroll=bool(self.unroll_map),
                             lgmaps=self.lgmaps is not None)
 
     @property
     def parloop_arg(self):
         return MatParloopArg(self.data, self.maps, self.lgmaps)
+
+
+@dataclass
+class MixedDatLegacyArg:             # pyop2/parloop.py:618-641
+    data: MixedDat
+    map_: MixedMap
+    access: Access
+
+    def __post_init__(self):
+        if not isinstance(self.map_, MixedMap) or len(self.map_) != len(self.data):
+            raise MapValueError("a MixedDat is accessed through a MixedMap with one Map per component")
+
+    @property
+    def dtype(self):
+        return self.data.dtype
+
+    @property
+    def split(self):
+        return [DatLegacyArg(d, m, self.access) for d, m in zip(self.data.split, self.map_.split)]
+
+    @property
+    def global_kernel_arg(self):
+        return MixedDatKernelArg(tuple(a.global_kernel_arg for a in self.split))
+
+    @property
+    def parloop_arg(self):
+        return MixedDatParloopArg(self.data, self.map_)
+
+
+@dataclass
+class MixedMatLegacyArg:             # pyop2/parloop.py:679-706
+    data: Mat
+    maps: Tuple[MixedMap, MixedMap]
+    access: Access
+    lgmaps: Optional[Any] = None
+    unroll_map: bool = False
+
+    def __post_init__(self):
+        shape = self.data.sparsity.shape
+        if not all(isinstance(m, MixedMap) for m in self.maps) or (len(self.maps[0]), len(self.maps[1])) != shape:
+            raise MapValueError("a mixed Mat is accessed through a pair of MixedMaps matching its block shape")
+        if self.lgmaps is not None and len(self.lgmaps) != shape[0] * shape[1]:
+            raise ValueError("lgmaps of a mixed Mat: one (row, col) pair per block, in row-major order")
+
+    @property
+    def dtype(self):
+        return self.data.dtype
+
+    @property
+    def split(self):
+        """Rows of per-block legacy arguments."""
+        rmaps, cmaps = self.maps
+        return [[MatLegacyArg(self.data[i, j], (rm, cm), self.access,
+                              None if self.lgmaps is None else self.lgmaps[i * len(cmaps) + j], self.unroll_map)
+                 for j, cm in enumerate(cmaps)] for i, rm in enumerate(rmaps)]
+
+    @property
+    def global_kernel_arg(self):
+        return MixedMatKernelArg(tuple(b.global_kernel_arg for row in self.split for b in row),
+                                 self.data.sparsity.shape)
+
+    @property
+    def parloop_arg(self):
+        return MixedMatParloopArg(self.data, self.maps, self.lgmaps)
 
 
 _mka_cache = {}
@@ -149,6 +244,13 @@ class Parloop:
     def __init__(self, global_knl: GlobalKernel, iterset: Set, arguments):
         if len(global_knl.arguments) != len(arguments):
             raise ValueError("You are trying to pass in a different number of arguments than the kernel is expecting")
+        if global_knl.is_mixed:
+            # Mixed arguments are split into their parts (one pointer per part, builder.py:872-916); the flattened
+            # kernel's adaptor presents the concatenated packs to the local kernel (GlobalKernel.flattened)
+            global_knl = global_knl.flattened()
+            arguments = [q for pa in arguments
+                         for q in (pa.split if isinstance(pa, (MixedDatParloopArg, MixedMatParloopArg)) else [pa])]
+            assert len(global_knl.arguments) == len(arguments)
         for la, pa in zip(global_knl.local_kernel.arguments, arguments):
             if not isinstance(pa, MatParloopArg) and hasattr(pa.data, "dtype") and np.dtype(la.dtype) != pa.data.dtype:
                 raise ValueError("Data types of the local kernel and the data carrier do not match")   # parloop.py:182-185
@@ -670,7 +772,7 @@ class LegacyParloop(Parloop):
         if not isinstance(iterset, Set):
             raise SetTypeError("Iteration set is of the wrong type")
         for a in args:
-            if not isinstance(a, (DatLegacyArg, GlobalLegacyArg, MatLegacyArg)):
+            if not isinstance(a, (DatLegacyArg, GlobalLegacyArg, MatLegacyArg, MixedDatLegacyArg, MixedMatLegacyArg)):
                 raise ValueError("par_loop arguments must be created by calling a Dat/Global/Mat with an access mode")
         if local_knl.accesses is None:
             local_knl = local_knl.with_signature([a.access for a in args], [a.dtype for a in args])

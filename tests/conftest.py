@@ -15,8 +15,8 @@ def pytest_configure(config):
 
 def pytest_collection_modifyitems(config, items):
     try:
-        import torch
-        has_gpu = torch.cuda.is_available()
+        from firedrake_amd import _lib
+        has_gpu = bool(_lib.gpu_available())          # HIP device count through libfdhip.so (the product's own check)
     except Exception:
         has_gpu = False
     if has_gpu:

@@ -92,3 +92,35 @@ def test_extruded_wrappers():
     pl = op2.LegacyParloop(op2.Kernel("static void blah(double* x, int layer_arg){ x[0] = layer_arg; }", "blah"), ext,
                            f(op2.WRITE, fm), pass_layer_arg=True)
     assert _compile(pl) == ["direct"]
+
+
+def test_mixed_wrappers_compile():
+    """Mixed arguments are flattened to per-part arguments + an adaptor local kernel (GlobalKernel.flattened)."""
+    from mixed_cases import ADDONE_MAT, ADDONE_RHS_VEC, mixed_kernels, reference_mixed_fixture, velocity_pressure_space
+    mset, mdat, mvdat, mmap, msparsity = reference_mixed_fixture()
+    mat = op2.Mat(msparsity)
+    pl = op2.LegacyParloop(op2.Kernel(ADDONE_MAT, "addone_mat"), mmap.iterset, mat(op2.INC, (mmap, mmap)), mdat(op2.READ, mmap))
+    assert len(pl.arguments) == 6 and not pl.global_kernel.is_mixed
+    assert _compile(pl) == ["staged", "direct"]
+    dat = op2.MixedDat(mset ** 2)
+    pl = op2.LegacyParloop(op2.Kernel(ADDONE_RHS_VEC, "addone_rhs_vec"), mmap.iterset, dat(op2.INC, mmap), mvdat(op2.READ, mmap))
+    assert _compile(pl) == ["staged", "direct"]
+    ele, ms, mm, x, vmap = velocity_pressure_space(3, 3, 2)
+    mds = op2.MixedDataSet(ms, (2, 1))
+    sp = op2.Sparsity((mds, mds), {(i, j): [(rm, cm, None)] for i, rm in enumerate(mm) for j, cm in enumerate(mm)})
+    jac, res = mixed_kernels(2)
+    lgv, lgp = np.arange(ms[0].total_size, dtype=np.int32), np.arange(ms[1].total_size, dtype=np.int32)
+    for lgmaps in (None, [(lgv, lgv), (lgv, lgp), (lgp, lgv), (lgp, lgp)]):
+        pl = op2.LegacyParloop(jac, ele, op2.Mat(sp)(op2.INC, (mm, mm), lgmaps=lgmaps), x(op2.READ, vmap))
+        assert _compile(pl) == ["staged", "direct"]
+
+
+def test_periodic_extruded_wrappers_compile():
+    from mixed_cases import periodic_column_mesh
+    base, ext, nodes, cm = periodic_column_mesh(np.random.default_rng(0))
+    x, out = op2.Dat(nodes ** 2), op2.Dat(nodes)
+    for region, nf in ((None, 1), (op2.ON_INTERIOR_FACETS, 2)):
+        k = op2.Kernel("static void kp(double *o, const double *x) { for (int i = 0; i < %d; ++i) o[i] += x[2*i]; }" % (6 * nf), "kp")
+        pl = op2.LegacyParloop(k, ext, out(op2.INC, cm), x(op2.READ, cm), iteration_region=region)
+        assert pl.global_kernel._extruded_periodic
+        assert _compile(pl) == ["direct"]

@@ -1,0 +1,154 @@
+"""GPU parity for mixed spaces and periodic extrusion.
+
+Mixed: tests/pyop2/test_matrices.py:858-937 (TestMixedMatrices) with the reference's data, kernels and expected
+blocks, plus a (P1^d x P0) velocity-pressure pair on a triangle mesh against the oracle's native mixed packs
+(pyop2/codegen/builder.py:432-518, 628-699).  Periodic extrusion: pyop2/codegen/builder.py:101-123, 806-809 and
+pyop2/sparsity.pyx:343-368 against the oracle.  Every loop runs through the HIP backend and the C ABI."""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+from firedrake_amd import op2
+from firedrake_amd.configuration import configuration
+from helpers import oracle_run
+from mixed_cases import (ADDONE_MAT, ADDONE_RHS, ADDONE_RHS_VEC, LL, OD, mixed_kernels, periodic_column_mesh, rdata,
+                         reference_mixed_fixture, velocity_pressure_space)
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+@pytest.fixture(params=["auto", "direct"])
+def mode(request, monkeypatch):
+    monkeypatch.setitem(configuration, "mode", request.param)
+    return request.param
+
+
+def _close(got, ref):
+    assert np.abs(got - ref).max() <= TOL * max(1.0, np.abs(ref).max())
+
+
+def test_assemble_mixed_mat(mode):
+    mset, mdat, mvdat, mmap, msparsity = reference_mixed_fixture()
+    mat = op2.Mat(msparsity)
+    k = op2.Kernel(ADDONE_MAT, "addone_mat")
+    op2.par_loop(k, mmap.iterset, mat(op2.INC, (mmap, mmap)), mdat(op2.READ, mmap))
+    mat.assemble()
+    eps = 1.e-12
+    assert_allclose(mat[0, 0].values, np.diag([1.0, 4.0, 9.0]), eps)
+    assert_allclose(mat[0, 1].values, OD, eps)
+    assert_allclose(mat[1, 0].values, OD.T, eps)
+    assert_allclose(mat[1, 1].values, LL, eps)
+    # a second accumulation doubles every block (INC semantics across launches)
+    op2.par_loop(k, mmap.iterset, mat(op2.INC, (mmap, mmap)), mdat(op2.READ, mmap))
+    assert_allclose(mat[1, 1].values, 2 * LL, eps)
+    mat.zero()
+    assert_allclose(mat[0, 1].values, 0 * OD, eps)
+
+
+def test_assemble_mixed_rhs(mode):
+    mset, mdat, mvdat, mmap, msparsity = reference_mixed_fixture()
+    dat = op2.MixedDat(mset)
+    op2.par_loop(op2.Kernel(ADDONE_RHS, "addone_rhs"), mmap.iterset, dat(op2.INC, mmap), mdat(op2.READ, mmap))
+    eps = 1.e-12
+    assert_allclose(dat[0].data_ro, rdata(3), eps)
+    assert_allclose(dat[1].data_ro, [1.0, 4.0, 6.0, 4.0], eps)
+
+
+def test_assemble_mixed_rhs_vector(mode):
+    mset, mdat, mvdat, mmap, msparsity = reference_mixed_fixture()
+    dat = op2.MixedDat(mset ** 2)
+    op2.par_loop(op2.Kernel(ADDONE_RHS_VEC, "addone_rhs_vec"), mmap.iterset, dat(op2.INC, mmap), mvdat(op2.READ, mmap))
+    eps = 1.e-12
+    assert_allclose(dat[0].data_ro, np.kron(list(zip(rdata(3))), np.ones(2)), eps)
+    assert_allclose(dat[1].data_ro, np.kron(list(zip([1.0, 4.0, 6.0, 4.0])), np.ones(2)), eps)
+
+
+@pytest.mark.parametrize("vdim", [1, 2])
+@pytest.mark.parametrize("n", [6, 40])
+def test_mixed_velocity_pressure(mode, vdim, n):
+    ele, mset, mmap, x, vmap = velocity_pressure_space(n, n - 1, vdim)
+    mds = op2.MixedDataSet(mset, (vdim, 1))
+    sp = op2.Sparsity((mds, mds), {(i, j): [(rm, cm, None)] for i, rm in enumerate(mmap) for j, cm in enumerate(mmap)})
+    mat = op2.Mat(sp)
+    jac, res = mixed_kernels(vdim)
+    lgv = np.arange(mset[0].total_size, dtype=np.int32)
+    lgv[::7] = -1
+    lgp = np.arange(mset[1].total_size, dtype=np.int32)
+    for lgmaps in (None, [(lgv, lgv), (lgv, lgp), (lgp, lgv), (lgp, lgp)]):
+        mat.zero()
+        args = (mat(op2.INC, (mmap, mmap), lgmaps=lgmaps), x(op2.READ, vmap))
+        op2.par_loop(jac, ele, *args)
+        ref = oracle_run(jac, ele, *args)[0]
+        for i in range(2):
+            for j in range(2):
+                rp, ci, v = mat[i, j].csr()
+                assert np.array_equal(rp, ref[i][j].rowptr) and np.array_equal(ci, ref[i][j].colidx)
+                _close(v, ref[i][j].values)
+    rng = np.random.default_rng(4)
+    w = op2.MixedDat([op2.Dat(ds, rng.standard_normal((ds.total_size,) + (() if ds.cdim == 1 else ds.dim))) for ds in mds])
+    b = op2.MixedDat(mds)
+    op2.par_loop(res, ele, b(op2.INC, mmap), x(op2.READ, vmap), w(op2.READ, mmap))
+    ref = oracle_run(res, ele, op2.MixedDat(mds)(op2.INC, mmap), x(op2.READ, vmap), w(op2.READ, mmap))[0]
+    for got, r in zip(b.data_ro, ref):
+        _close(got, r)
+
+
+@pytest.mark.parametrize("region", [None, op2.ON_BOTTOM, op2.ON_TOP, op2.ON_INTERIOR_FACETS])
+def test_periodic_extrusion(region):
+    rng = np.random.default_rng(11)
+    ncl = 5
+    base, ext, nodes, cm = periodic_column_mesh(rng, nbase=300, ncl=ncl, nv=200)
+    x = op2.Dat(nodes ** 2, rng.standard_normal((nodes.size, 2)))
+    out = op2.Dat(nodes)
+    nf = 2 if region == op2.ON_INTERIOR_FACETS else 1
+    k = op2.Kernel("static void kp(double *o, const double *x) { for (int i = 0; i < %d; ++i) o[i] += (i+1)*x[2*i] + 0.5*x[2*i+1]; }" % (6 * nf), "kp%d" % nf)
+    op2.par_loop(k, ext, out(op2.INC, cm), x(op2.READ, cm), iteration_region=region)
+    ref = oracle_run(k, ext, op2.Dat(nodes)(op2.INC, cm), x(op2.READ, cm), iteration_region=region)[0]
+    _close(out.data_ro, ref)
+    n = 6 * nf
+    mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(cm, cm, [region] if region is not None else None)]))
+    km = op2.Kernel("static void kpm(double *A, const double *x) { for (int i = 0; i < %d; ++i) for (int j = 0; j < %d; ++j) A[i*%d+j] += x[2*i]*x[2*j+1]; }" % (n, n, n), "kpm%d" % nf)
+    args = (mat(op2.INC, (cm, cm)), x(op2.READ, cm))
+    op2.par_loop(km, ext, *args, iteration_region=region)
+    ocsr = oracle_run(km, ext, *args, iteration_region=region)[0]
+    rp, ci, v = mat.csr()
+    assert np.array_equal(rp, ocsr.rowptr) and np.array_equal(ci, ocsr.colidx)
+    _close(v, ocsr.values)
+
+
+def test_periodic_without_quotient_and_subset():
+    rng = np.random.default_rng(12)
+    ncl = 3
+    base = op2.Set(600)
+    ext = op2.ExtrudedSet(base, layers=ncl + 1, extruded_periodic=True)
+    dg = op2.Set(600 * ncl)
+    cm = op2.Map(ext, dg, 1, np.arange(600) * ncl, offset=[1])
+    d = op2.Dat(dg, rng.standard_normal(600 * ncl))
+    k = op2.Kernel("static void ks(double *g, const double *d) { g[0] += d[0] - 3*d[1]; }", "ks")
+    for it in (ext, op2.Subset(ext, np.arange(0, 600, 7))):
+        g = op2.Global(1, 0.0)
+        op2.par_loop(k, it, g(op2.INC), d(op2.READ, cm), iteration_region=op2.ON_INTERIOR_FACETS)
+        ref = oracle_run(k, it, op2.Global(1, 0.0)(op2.INC), d(op2.READ, cm), iteration_region=op2.ON_INTERIOR_FACETS)[0]
+        assert abs(g.data_ro[0] - ref[0]) <= 1e-11 * max(1.0, abs(ref[0]))
+
+
+def test_extruded_sparsity_over_regions():
+    """A pattern built from ALL + ON_INTERIOR_FACETS pairs (sparsity.pyx:291-346) holds the facet couplings."""
+    rng = np.random.default_rng(13)
+    nbase, L, nv = 50, 4, 40
+    base = op2.Set(nbase)
+    ext = op2.ExtrudedSet(base, layers=L)
+    nodes = op2.Set(nv * L)
+    tri = np.array([rng.choice(nv, 3, replace=False) for _ in range(nbase)])
+    vals = np.concatenate([tri * L, tri * L + 1], axis=1).astype(np.int32)
+    cm = op2.Map(ext, nodes, 6, vals, offset=[1] * 6)
+    x = op2.Dat(nodes ** 2, rng.standard_normal((nv * L, 2)))
+    mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(cm, cm, [op2.ALL, op2.ON_INTERIOR_FACETS])]))
+    km = op2.Kernel("static void kif(double *A, const double *x) { for (int i = 0; i < 12; ++i) for (int j = 0; j < 12; ++j) A[i*12+j] += x[2*i]*x[2*j+1]; }", "kif")
+    args = (mat(op2.INC, (cm, cm)), x(op2.READ, cm))
+    op2.par_loop(km, ext, *args, iteration_region=op2.ON_INTERIOR_FACETS)
+    ocsr = oracle_run(km, ext, *args, iteration_region=op2.ON_INTERIOR_FACETS)[0]
+    rp, ci, v = mat.csr()
+    assert np.array_equal(rp, ocsr.rowptr) and np.array_equal(ci, ocsr.colidx)
+    _close(v, ocsr.values)

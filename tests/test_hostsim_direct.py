@@ -9,6 +9,7 @@ from firedrake_amd import op2
 import golden_kernels as gk
 from helpers import oracle_run, structured_tri_mesh
 from hostsim import run_direct
+from mixed_cases import periodic_column_mesh
 
 
 def _check(kernel, iterset, *args, **kw):
@@ -93,25 +94,11 @@ def test_extruded_columns(region):
         _check(km, ext, mat(op2.INC, (cm, cm)), x(op2.READ, cm), iteration_region=region)
 
 
-def _periodic_column_mesh(rng, nbase=5, ncl=4, nv=7):
-    """A periodic column mesh: ``ncl`` cell layers, ``ncl`` node levels (the top level IS the bottom level).
-    P1 x P1 prisms: 3 base vertices x {lower, upper}; the upper vertices of the top cell wrap to level 0, which is
-    what offset_quotient = 1 on the upper entries expresses (map.py:46-53, builder.py:108-120)."""
-    base = op2.Set(nbase)
-    ext = op2.ExtrudedSet(base, layers=ncl + 1, extruded_periodic=True)
-    nodes = op2.Set(nv * ncl)
-    tri = np.array([rng.choice(nv, 3, replace=False) for _ in range(nbase)])
-    # entries 0..2: lower vertices (level 0 of the column), 3..5: upper vertices (level 1)
-    vals = np.concatenate([tri * ncl, tri * ncl + 1], axis=1).astype(np.int32)
-    cm = op2.Map(ext, nodes, 6, vals, offset=[1] * 6, offset_quotient=[0, 0, 0, 1, 1, 1])
-    return base, ext, nodes, cm
-
-
 @pytest.mark.parametrize("region", [None, op2.ON_BOTTOM, op2.ON_TOP, op2.ON_INTERIOR_FACETS])
 def test_periodic_extrusion(region):
     rng = np.random.default_rng(11)
     ncl = 4
-    base, ext, nodes, cm = _periodic_column_mesh(rng, ncl=ncl)
+    base, ext, nodes, cm = periodic_column_mesh(rng, ncl=ncl)
     x = op2.Dat(nodes ** 2, rng.standard_normal((nodes.size, 2)))
     out = op2.Dat(nodes)
     nf = 2 if region == op2.ON_INTERIOR_FACETS else 1
@@ -166,3 +153,73 @@ def test_extruded_interior_facet_sparsity_regions():
     mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(cm, cm, [op2.ALL, op2.ON_INTERIOR_FACETS])]))
     km = op2.Kernel("static void kif(double *A, const double *x) { for (int i = 0; i < 12; ++i) for (int j = 0; j < 12; ++j) A[i*12+j] += x[2*i]*x[2*j+1]; }", "kif")
     _check(km, ext, mat(op2.INC, (cm, cm)), x(op2.READ, cm), iteration_region=op2.ON_INTERIOR_FACETS)
+
+
+# ---- mixed spaces: the flattened loop (GlobalKernel.flattened) through the direct wrapper -------------------------
+def _check_mixed(kernel, iterset, *args, **kw):
+    """Host-sim result of the flattened loop against the oracle's native mixed packs."""
+    pl = op2.LegacyParloop(kernel, iterset, *args, **kw)
+    flat = iter(run_direct(pl))
+    ref = oracle_run(kernel, iterset, *args, **kw)
+    out = []
+    for r in ref:
+        if isinstance(r, list) and r and isinstance(r[0], list):          # MixedMat: rows of OracleCSR
+            got = [[next(flat) for _ in row] for row in r]
+            for grow, rrow in zip(got, r):
+                for g, q in zip(grow, rrow):
+                    assert np.array_equal(g.rowptr, q.rowptr) and np.array_equal(g.colidx, q.colidx)
+                    assert np.abs(g.values - q.values).max() <= 1e-12 * max(1.0, np.abs(q.values).max())
+        elif isinstance(r, list):                                          # MixedDat: list of arrays
+            got = [next(flat) for _ in r]
+            for g, q in zip(got, r):
+                assert np.abs(g - q).max() <= 1e-12 * max(1.0, np.abs(q).max())
+        else:
+            got = next(flat)
+            if hasattr(r, "values"):
+                assert np.abs(got.values - r.values).max() <= 1e-12 * max(1.0, np.abs(r.values).max())
+            else:
+                assert np.abs(got - r).max() <= 1e-12 * max(1.0, np.abs(r).max())
+        out.append(got)
+    return out
+
+
+def test_mixed_reference_goldens():
+    """tests/pyop2/test_matrices.py:858-937 (TestMixedMatrices): data, kernels and expected blocks of the reference."""
+    from mixed_cases import (ADDONE_MAT, ADDONE_RHS, ADDONE_RHS_VEC, LL, OD, rdata, reference_mixed_fixture)
+    mset, mdat, mvdat, mmap, msparsity = reference_mixed_fixture()
+    mat = op2.Mat(msparsity)
+    got, _ = _check_mixed(op2.Kernel(ADDONE_MAT, "addone_mat"), mmap.iterset, mat(op2.INC, (mmap, mmap)), mdat(op2.READ, mmap))
+    eps = 1e-12
+    np.testing.assert_allclose(got[0][0].todense(), np.diag([1.0, 4.0, 9.0]), eps)
+    np.testing.assert_allclose(got[0][1].todense(), OD, eps)
+    np.testing.assert_allclose(got[1][0].todense(), OD.T, eps)
+    np.testing.assert_allclose(got[1][1].todense(), LL, eps)
+    dat = op2.MixedDat(mset)
+    got, _ = _check_mixed(op2.Kernel(ADDONE_RHS, "addone_rhs"), mmap.iterset, dat(op2.INC, mmap), mdat(op2.READ, mmap))
+    np.testing.assert_allclose(got[0], rdata(3), eps)
+    np.testing.assert_allclose(got[1], [1.0, 4.0, 6.0, 4.0], eps)
+    vdat = op2.MixedDat(mset ** 2)
+    got, _ = _check_mixed(op2.Kernel(ADDONE_RHS_VEC, "addone_rhs_vec"), mmap.iterset, vdat(op2.INC, mmap), mvdat(op2.READ, mmap))
+    np.testing.assert_allclose(got[0], np.kron(list(zip(rdata(3))), np.ones(2)), eps)
+    np.testing.assert_allclose(got[1], np.kron(list(zip([1.0, 4.0, 6.0, 4.0])), np.ones(2)), eps)
+
+
+@pytest.mark.parametrize("vdim", [1, 2])
+def test_mixed_velocity_pressure(vdim):
+    from mixed_cases import mixed_kernels, velocity_pressure_space
+    ele, mset, mmap, x, vmap = velocity_pressure_space(4, 3, vdim)
+    mds = op2.MixedDataSet(mset, (vdim, 1))
+    sp = op2.Sparsity((mds, mds), {(i, j): [(rm, cm, None)] for i, rm in enumerate(mmap) for j, cm in enumerate(mmap)})
+    mat = op2.Mat(sp)
+    jac, res = mixed_kernels(vdim)
+    _check_mixed(jac, ele, mat(op2.INC, (mmap, mmap)), x(op2.READ, vmap))
+    rng = np.random.default_rng(4)
+    w = op2.MixedDat([op2.Dat(ds, rng.standard_normal((ds.total_size,) + (() if ds.cdim == 1 else ds.dim))) for ds in mds])
+    b = op2.MixedDat(mds)
+    _check_mixed(res, ele, b(op2.INC, mmap), x(op2.READ, vmap), w(op2.READ, mmap))
+    # boundary conditions on the velocity block: masked lgmaps, one (row, col) pair per block
+    lgv = np.arange(mset[0].total_size, dtype=np.int32)
+    lgv[[0, 2, 5]] = -1
+    lgp = np.arange(mset[1].total_size, dtype=np.int32)
+    lgmaps = [(lgv, lgv), (lgv, lgp), (lgp, lgv), (lgp, lgp)]
+    _check_mixed(jac, ele, mat(op2.INC, (mmap, mmap), lgmaps=lgmaps), x(op2.READ, vmap))
