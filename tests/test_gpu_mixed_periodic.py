@@ -102,13 +102,13 @@ def test_periodic_extrusion(region):
     x = op2.Dat(nodes ** 2, rng.standard_normal((nodes.size, 2)))
     out = op2.Dat(nodes)
     nf = 2 if region == op2.ON_INTERIOR_FACETS else 1
-    k = op2.Kernel("static void kp(double *o, const double *x) { for (int i = 0; i < %d; ++i) o[i] += (i+1)*x[2*i] + 0.5*x[2*i+1]; }" % (6 * nf), "kp%d" % nf)
+    k = op2.Kernel("static void kp%d(double *o, const double *x) { for (int i = 0; i < %d; ++i) o[i] += (i+1)*x[2*i] + 0.5*x[2*i+1]; }" % (nf, 6 * nf), "kp%d" % nf)
     op2.par_loop(k, ext, out(op2.INC, cm), x(op2.READ, cm), iteration_region=region)
     ref = oracle_run(k, ext, op2.Dat(nodes)(op2.INC, cm), x(op2.READ, cm), iteration_region=region)[0]
     _close(out.data_ro, ref)
     n = 6 * nf
     mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(cm, cm, [region] if region is not None else None)]))
-    km = op2.Kernel("static void kpm(double *A, const double *x) { for (int i = 0; i < %d; ++i) for (int j = 0; j < %d; ++j) A[i*%d+j] += x[2*i]*x[2*j+1]; }" % (n, n, n), "kpm%d" % nf)
+    km = op2.Kernel("static void kpm%d(double *A, const double *x) { for (int i = 0; i < %d; ++i) for (int j = 0; j < %d; ++j) A[i*%d+j] += x[2*i]*x[2*j+1]; }" % (nf, n, n, n), "kpm%d" % nf)
     args = (mat(op2.INC, (cm, cm)), x(op2.READ, cm))
     op2.par_loop(km, ext, *args, iteration_region=region)
     ocsr = oracle_run(km, ext, *args, iteration_region=region)[0]

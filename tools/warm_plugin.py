@@ -1,0 +1,45 @@
+"""Warm the wrapper code-object cache (firedrake_amd/_cache) WITHOUT a GPU.
+
+hipcc cross-compiles gfx950 here, and the cache key (source, flags, compiler, fd_wrapper.h) is the same on the GPU
+box, so every kernel compiled now is a kernel the box does not have to compile inside its GPU-minutes.  This pytest
+plugin runs the -m gpu tests "dry": the device layer is stubbed out, every Parloop only selects its mode, generates
+its wrapper and compiles it, and assertions are disabled (run under `python -O`).  Test outcomes are meaningless in
+this mode -- only the cache side effect matters.
+
+    PYTHONPATH=tools python -O -m pytest tests -m gpu -q -n 8 -p warm_plugin -p no:cacheprovider
+"""
+import numpy as np
+
+
+def pytest_configure(config):
+    import numpy.testing as npt
+    from firedrake_amd import _lib, device, parloop
+    from firedrake_amd.codegen import generate_wrapper, select_mode
+    from firedrake_amd.compilation import compile_hip
+
+    _lib.require_gpu = lambda: True
+    _lib.gpu_available = lambda: True
+    _lib.call = lambda name, *a: None
+
+    def init(self, nbytes):
+        self.ptr, self.nbytes, self._owned = 1, int(nbytes), False
+    device.DeviceBuffer.__init__ = init
+    device.DeviceBuffer.wrap = classmethod(lambda cls, ptr, nbytes, owner=None: cls(nbytes))
+    device.DeviceBuffer.upload = lambda self, arr, stream=None: None
+    device.DeviceBuffer.download = lambda self, dtype, shape: np.zeros(shape, dtype=dtype)
+    device.DeviceBuffer.zero = lambda self, stream=None: None
+    device.DeviceBuffer.__del__ = lambda self: None
+
+    def compute(self):
+        gk = self.global_kernel
+        mode = select_mode(gk)
+        modes = [mode]
+        if mode == "ocr":
+            modes.append("staged")          # fallback when a plan does not fit
+        for m in modes:
+            src = generate_wrapper(gk, m)
+            compile_hip(src.source, gk.name)
+    parloop.Parloop.compute = compute
+
+    for name in ("assert_allclose", "assert_array_equal", "assert_equal", "assert_almost_equal", "assert_array_almost_equal"):
+        setattr(npt, name, lambda *a, **k: None)
