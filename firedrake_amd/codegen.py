@@ -124,6 +124,8 @@ def ocr_eligible(gk: GlobalKernel) -> bool:
 
 
 def _hoist_includes(code: str):
+    from .kernel import strip_host_only_includes
+    code = strip_host_only_includes(code)
     inc = re.findall(r"^\s*#\s*include[^\n]*$", code, flags=re.M)
     body = re.sub(r"^\s*#\s*include[^\n]*$", "", code, flags=re.M)
     return inc, body

@@ -682,6 +682,7 @@ class DGAdvectionProblem:
         r_bell = np.minimum(np.sqrt((pts[:, 0] - 0.25) ** 2 + (pts[:, 1] - 0.5) ** 2) / 0.15, 1.0)
         r_cone = np.minimum(np.sqrt((pts[:, 0] - 0.5) ** 2 + (pts[:, 1] - 0.25) ** 2) / 0.15, 1.0)
         self.q = op2.Dat(m.dq_set, 1.0 + 0.25 * (1 + np.cos(math.pi * r_bell)) + 1.0 - r_cone, np.float64, "q")
+        self._interp = None
         self.L = op2.Dat(m.dq_set, None, np.float64, "L1")
         self.dtc = op2.Global(1, dt if dt is not None else 2 * math.pi / 600.0, np.float64, "dtc")
         self.q_in = op2.Global(1, 1.0, np.float64, "q_in")
@@ -702,6 +703,29 @@ class DGAdvectionProblem:
             for loop in self.loops:
                 loop()
         return self.L
+
+    # the demo's own statements ``u = Function(W).interpolate(velocity)`` and ``q = Function(V).interpolate(1.0 + bell +
+    # cone + slot_cyl)`` (demos/DG_advection/DG_advection.py.rst:128-156) as dual-evaluation parloops on the device
+    DEMO_VELOCITY = ("0.5 - X[1]", "X[0] - 0.5")
+    DEMO_INITIAL_CONDITION = (
+        "1.0 + 0.25*(1.0 + cos(M_PI*fmin(sqrt(pow(X[0] - 0.25, 2) + pow(X[1] - 0.5, 2))/0.15, 1.0)))"
+        " + (1.0 - fmin(sqrt(pow(X[0] - 0.5, 2) + pow(X[1] - 0.25, 2))/0.15, 1.0))"
+        " + ((sqrt(pow(X[0] - 0.5, 2) + pow(X[1] - 0.75, 2)) < 0.15)"
+        " ? (((X[0] > 0.475 && X[0] < 0.525) && X[1] < 0.85) ? 0.0 : 1.0) : 0.0)",)
+
+    def interpolate_demo_fields(self):
+        """Set ``u`` and ``q`` to the demo's velocity and bell + cone + slotted-cylinder state on the device."""
+        from .interpolation import QUAD_VERTEX_POINTS, Interpolator, Space, q1_quad
+        m = self.mesh
+        if self._interp is None:
+            xs = Space(m.cell_q1, QUAD_VERTEX_POINTS, q1_quad, 2)
+            self._interp = (
+                Interpolator(self.DEMO_VELOCITY, Space(m.cell_q1, QUAD_VERTEX_POINTS, q1_quad, 2), m.coordinates, xs,
+                             name="interpolate_velocity"),
+                Interpolator(self.DEMO_INITIAL_CONDITION, Space(m.cell_dq, QUAD_VERTEX_POINTS, q1_quad, 1), m.coordinates, xs,
+                             name="interpolate_q0"))
+        self._interp[0].interpolate(self.u)
+        self._interp[1].interpolate(self.q)
 
 
 def dg_mass_solve_kernel(nq=2):

@@ -38,8 +38,7 @@ class CStringLocalKernel:
     def __init__(self, code, name, accesses=None, dtypes=None, *, flop_count=None, headers=(),
                  requires_zeroed_output_arguments=False, cpp=False, **_ignored):
         if not isinstance(code, str):
-            raise TypeError("C-string local kernels need `code` to be a str "
-                            "(loopy translation units are ingested through firedrake's TSFC bridge, see INTEGRATION.md)")
+            raise TypeError("C-string local kernels need `code` to be a str (loopy kernels: LoopyLocalKernel)")
         self.code = code
         self.name = name
         self.accesses = None if accesses is None else tuple(Access(a) for a in accesses)
@@ -64,9 +63,55 @@ class CStringLocalKernel:
                                   requires_zeroed_output_arguments=self.requires_zeroed_output_arguments, cpp=self.cpp)
 
 
+# Includes that only make sense on the host side of the reference: PETSc's umbrella header (the types the wrappers
+# use -- PetscScalar, PetscInt -- are typedef'd in csrc/fd_wrapper.h) and C99 <complex.h>, which loopy's C target
+# emits unconditionally (pyop2/codegen/rep2loopy.py:565) but real-valued kernels never use.
+_HOST_ONLY_INCLUDE = re.compile(r"^[ \t]*#[ \t]*include[ \t]*[<\"](petsc[a-z]*\.h|complex\.h)[>\"][ \t]*$", flags=re.M)
+
+
+def strip_host_only_includes(code: str) -> str:
+    return _HOST_ONLY_INCLUDE.sub("", code)
+
+
+class LoopyLocalKernel(CStringLocalKernel):
+    """pyop2/local_kernel.py:210-227: a local kernel given as a loopy ``LoopKernel``/``TranslationUnit`` -- what TSFC
+    hands to PyOP2 (tsfc/loopy.py:216-283).  It is lowered ONCE on the host to C with ``lp.generate_code_v2``, exactly
+    the text the reference compiles with gcc (global_kernel.py:408-423), and that text is compiled as a ``__device__``
+    function: loopy's C dialect (``__restrict__`` pointers, ``int32_t`` loop counters, ``double const t0[...] = {...}``
+    tabulation tables, ``static inline`` helper preambles) is valid HIP device code as it stands; only the host-only
+    includes are dropped.  Register allocation of the temporaries and constant-table placement are hipcc's job.
+    Needs the ``loopy`` package (absent from this image -- see ``loopy_c_kernel`` for text produced elsewhere)."""
+
+    def __init__(self, code, name, accesses=None, dtypes=None, **kwargs):
+        try:
+            import loopy as lp
+        except ImportError as exc:                         # pragma: no cover - loopy is not installed here
+            raise ImportError("LoopyLocalKernel needs the 'loopy' package to lower the kernel to C; pass the generated "
+                              "C text to loopy_c_kernel() instead") from exc
+        self.loopy_code = code
+        if dtypes is None:                                 # local_kernel.py:217-227
+            knl = code.callables_table[name].subkernel if hasattr(code, "callables_table") else code
+            dtypes = tuple(a.dtype.numpy_dtype if hasattr(a.dtype, "numpy_dtype") else a.dtype
+                           for a in knl.args if isinstance(a, lp.ArrayArg))
+        text = lp.generate_code_v2(code).device_code()
+        super().__init__(text, name, accesses, dtypes, **kwargs)
+
+
+def loopy_c_kernel(code: str, name: str, accesses=None, dtypes=None, **kwargs):
+    """A local kernel from C text that loopy generated elsewhere (``lp.generate_code_v2(knl).device_code()``), e.g.
+    captured from a Firedrake installation.  TSFC kernels accumulate into zeroed output tensors
+    (tsfc/loopy.py:335-348, tsfc_interface.py:330-331), hence ``requires_zeroed_output_arguments`` defaults to True."""
+    kwargs.setdefault("requires_zeroed_output_arguments", True)
+    return CStringLocalKernel(code, name, accesses, dtypes, **kwargs)
+
+
 def Kernel(code, name, **kwargs):
-    """pyop2/local_kernel.py:54-83 ``Kernel`` factory."""
-    return CStringLocalKernel(code, name, **kwargs)
+    """pyop2/local_kernel.py:54-83 ``Kernel`` factory: C strings and loopy kernels."""
+    if isinstance(code, str):
+        return CStringLocalKernel(code, name, **kwargs)
+    if type(code).__name__ in ("LoopKernel", "TranslationUnit") or hasattr(code, "callables_table"):
+        return LoopyLocalKernel(code, name, **kwargs)
+    raise TypeError("code argument is the wrong type: expected a C string or a loopy kernel")
 
 
 # ---- global kernel argument descriptors -----------------------------------------------------

@@ -6,7 +6,7 @@ from .op2types import (Set, ExtrudedSet, Subset, MixedSet, DataSet, MixedDataSet
                        READ, WRITE, RW, INC, MIN, MAX, ON_BOTTOM, ON_TOP, ON_INTERIOR_FACETS, ALL,
                        IntType, ScalarType, MapValueError, ModeValueError, DataValueError, DataTypeError,
                        SetTypeError, SizeTypeError, SubsetIndexOutOfBounds)
-from .kernel import (Kernel, CStringLocalKernel, GlobalKernel, GlobalKernelArg, DatKernelArg,  # noqa: F401
+from .kernel import (Kernel, CStringLocalKernel, LoopyLocalKernel, loopy_c_kernel, GlobalKernel, GlobalKernelArg, DatKernelArg,  # noqa: F401
                      MatKernelArg, MapKernelArg, PermutedMapKernelArg, MixedDatKernelArg, MixedMatKernelArg,
                      PassthroughKernelArg)
 from .parloop import (Parloop, ParLoop, LegacyParloop, parloop, par_loop, DatParloopArg,  # noqa: F401

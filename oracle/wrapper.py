@@ -28,6 +28,7 @@ from __future__ import annotations
 import ctypes
 import hashlib
 import os
+import re
 import subprocess
 from dataclasses import dataclass, field
 from typing import Optional, Sequence, Tuple
@@ -342,6 +343,8 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
     if pass_layer_arg:
         body_call.append("layer")
 
+    # PETSc's header is not available to the oracle; the three typedefs the wrappers use are in _PREAMBLE
+    kernel_src = re.sub(r'^[ \t]*#[ \t]*include[ \t]*[<"]petsc[a-z]*\.h[>"][ \t]*$', "", kernel_src, flags=re.M)
     lines = [_PREAMBLE, "#include <stdlib.h>", "#define ORACLE_REM(a, b) ((a) < (b) ? (a) : (a) - (b))",
              kernel_src, *decls, f"int wrap_{kernel_name}({', '.join(sig)})", "{"]
     if threads:
