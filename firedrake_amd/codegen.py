@@ -134,6 +134,12 @@ def _hoist_includes(code: str):
 def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     lk = gk.local_kernel
     maps, map_index = _distinct_maps(gk)
+    full_mode = mode
+    # "<mode>_s<S0>x<S1>...": compile-time node strides of the staged maps (in staged_maps order), see lds_stride()
+    sm_ = re.search(r"_s(\d+(?:x\d+)*)$", mode)
+    strides = [int(v) for v in sm_.group(1).split("x")] if sm_ else None
+    if sm_:
+        mode = mode[:sm_.start()]
     ocr = mode.startswith("ocr")
     staged = mode.startswith("staged") or ocr
     ktype, kbytes = ("unsigned short", 2) if mode.endswith("_k16") else ("unsigned char", 1)
@@ -300,6 +306,10 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     node_actions = {}    # per staged map: [(load statements, LDS store statements)] templated on I_U / G_U
     pack_gather = []     # staged READ gathers (arg, ctype, size, template) -- software-pipelined one entity ahead
     lds_decl, stage, flush, mat_stage_pre = [], [], [], []
+    # LDS carve-up order: staged Dat rows, then the per-node matrix tables (sizes fixed by the node strides), then the
+    # matrix accumulators (sized by the block's nonzero count, known only at run time) -- with compile-time strides
+    # every array then starts at a compile-time offset
+    lds_tail_const, lds_tail_var = [], []
 
     # LDS carving for staged args
     if staged:
@@ -394,12 +404,12 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             lg = info["arg"].lgmaps
             if ocr:
                 lds_items.append(("ocr", k, rm, cm, bool(lg)))
-                lds_decl.append(f"double *sm{k} = (double *)(fd_lds + fd_off); fd_off += ((((size_t)oc{k}_maxnnz*8) << fd_rsh) + 15) & ~(size_t)15;")
+                lds_tail_var.append(f"double *sm{k} = (double *)(fd_lds + fd_off); fd_off += ((((size_t)oc{k}_maxnnz*8) << fd_rsh) + 15) & ~(size_t)15;")
                 # one LDS word per gathered node: bits 0..29 = 1 + offset of the node's row inside the block's
                 # accumulator (0 = row not owned here or BC-masked), bit 31 = column is BC-masked
-                lds_decl.append(f"unsigned int *srow{k} = (unsigned int *)(fd_lds + fd_off); fd_off += (((size_t)p{rm}_maxnd*4) + 15) & ~(size_t)15;")
+                lds_tail_const.append(f"unsigned int *srow{k} = (unsigned int *)(fd_lds + fd_off); fd_off += (((size_t)p{rm}_maxnd*4) + 15) & ~(size_t)15;")
                 if cm != rm:
-                    lds_decl.append(f"unsigned char *smc{k} = fd_lds + fd_off; fd_off += ((size_t)p{cm}_maxnd + 15) & ~(size_t)15;")
+                    lds_tail_const.append(f"unsigned char *smc{k} = fd_lds + fd_off; fd_off += ((size_t)p{cm}_maxnd + 15) & ~(size_t)15;")
                 mat_stage_pre.extend([f"const int n0_{k} = oc{k}_rblk[b], nown{k} = oc{k}_rblk[b+1] - n0_{k};",
                                       f"const int r0_{k} = oc{k}_rowptr[n0_{k}], nnzb{k} = oc{k}_rowptr[n0_{k} + nown{k}] - r0_{k};"])
                 stage.append((rm, f"for (int q = tid; q < nnzb{k} << fd_rsh; q += nthr) sm{k}[q] = 0;"))
@@ -433,14 +443,14 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
                 continue
             if mat_staged[k]:
                 lds_items.append(("mat", k, rm, cm, bool(lg)))
-                lds_decl.append(f"double *sm{k} = (double *)(fd_lds + fd_off); fd_off += ((((size_t)mp{k}_maxnnz*8) << fd_rsh) + 15) & ~(size_t)15;")
-                lds_decl.append(f"int *slrp{k} = (int *)(fd_lds + fd_off); fd_off += (((size_t)(p{rm}_maxnd + 1)*4) + 15) & ~(size_t)15;")
+                lds_tail_var.append(f"double *sm{k} = (double *)(fd_lds + fd_off); fd_off += ((((size_t)mp{k}_maxnnz*8) << fd_rsh) + 15) & ~(size_t)15;")
+                lds_tail_const.append(f"int *slrp{k} = (int *)(fd_lds + fd_off); fd_off += (((size_t)(p{rm}_maxnd + 1)*4) + 15) & ~(size_t)15;")
                 mat_pre = [f"const int mo{k} = mp{k}_off[b], nnzb{k} = mp{k}_off[b+1] - mo{k};"]
                 stage.append((rm, f"for (int q = tid; q < nnzb{k} << fd_rsh; q += nthr) sm{k}[q] = 0;"))
                 stage.append((rm, f"for (int q = tid; q <= nd{rm}; q += nthr) slrp{k}[q] = mp{k}_lrp[l0_{rm} + b + q];"))
                 if lg:
-                    lds_decl.append(f"unsigned char *smr{k} = fd_lds + fd_off; fd_off += ((size_t)p{rm}_maxnd + 15) & ~(size_t)15;")
-                    lds_decl.append(f"unsigned char *smc{k} = fd_lds + fd_off; fd_off += ((size_t)p{cm}_maxnd + 15) & ~(size_t)15;")
+                    lds_tail_const.append(f"unsigned char *smr{k} = fd_lds + fd_off; fd_off += ((size_t)p{rm}_maxnd + 15) & ~(size_t)15;")
+                    lds_tail_const.append(f"unsigned char *smc{k} = fd_lds + fd_off; fd_off += ((size_t)p{cm}_maxnd + 15) & ~(size_t)15;")
                     stage.append((rm, f"for (int q = tid; q < nd{rm}; q += nthr) smr{k}[q] = rlg{k}[p{rm}_list[l0_{rm} + q]] < 0;"))
                     stage.append((cm, f"for (int q = tid; q < nd{cm}; q += nthr) smc{k}[q] = clg{k}[p{cm}_list[l0_{cm} + q]] < 0;"))
                 mat_stage_pre.extend(mat_pre)
@@ -512,7 +522,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
                 f"  constexpr int fd_rsh = {rep_shift}; const int fd_r = tid & ((1 << fd_rsh) - 1);",
                 "  const int b = fdw::xcd_block(blockIdx.x, gridDim.x);",
                 "  const int e0 = bstart_[b], e1 = bstart_[b+1];"]
-        src += ["  " + s for s in lds_decl]
+        src += ["  " + s for s in lds_decl + lds_tail_const + lds_tail_var]
         for mi in staged_maps:
             src.append(f"  const int l0_{mi} = p{mi}_blkoff[b], nd{mi} = p{mi}_blkoff[b+1] - l0_{mi};")
         src += ["  " + s for s in mat_stage_pre]
@@ -660,10 +670,37 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         src.append("  }")
         src += ["  " + s for s in post]
     src.append("}")
-    return WrapperSource("\n".join(src) + "\n", sym, mode, layout, len(maps), staged_maps, lds_items,
+    if strides is not None:
+        if len(strides) != len(staged_maps):
+            raise ValueError("one compile-time stride per staged map")
+        sig = next(i for i, l in enumerate(src) if l.startswith('extern "C" __global__'))
+        for mi, S in zip(staged_maps, strides):
+            pat = re.compile(r"\bp%d_maxnd\b" % mi)
+            src[sig + 1:] = [pat.sub("((long long)%d)" % S, l) for l in src[sig + 1:]]
+    return WrapperSource("\n".join(src) + "\n", sym, full_mode, layout, len(maps), staged_maps, lds_items,
                          layer_parallel, threads, kbytes, mat_staged,
                          (threads if (staged and configuration["lane_strided"]) else 0), rep_shift,
                          ocr_lds_limit if ocr else 0)
+
+
+def lds_stride(max_nd: int, ocr: bool = False) -> int:
+    """Node stride of a staged LDS array: the block maximum, rounded up to a multiple of FDHIP_LDS_CONST_STRIDE
+    (FDHIP_OCR_CONST_STRIDE for owner-computes-rows loops) when the stride is compiled in; 0 = run-time stride, 1 = exact,
+    64 makes component offsets multiples of 512 bytes so that pairs of accesses fuse into ds_read2st64_b64 -- at the price
+    of a larger LDS footprint, which costs a resident workgroup per CU on the P1 residual (measured: slower)."""
+    g = int(configuration["ocr_const_stride" if ocr else "lds_const_stride"])
+    if g <= 0:
+        return int(max_nd)
+    return -(-int(max_nd) // g) * g
+
+
+def mode_variant(base: str, kbytes: int, max_nds) -> str:
+    """Name of the wrapper variant for a launch geometry: base mode [+ _k16] [+ _s<strides>]."""
+    m = base + ("_k16" if kbytes == 2 else "")
+    ocr = base.startswith("ocr")
+    if int(configuration["ocr_const_stride" if ocr else "lds_const_stride"]) > 0 and max_nds:
+        m += "_s" + "x".join(str(lds_stride(n, ocr)) for n in max_nds)
+    return m
 
 
 def _permi(perm, i):

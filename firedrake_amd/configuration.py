@@ -29,6 +29,11 @@ configuration = {
     "ocr_lds_limit": _env("FDHIP_OCR_LDS_LIMIT", 0, int),  # 0 = auto (whole CU for large element matrices)
     "ocr_post_mask": _env("FDHIP_OCR_POST_MASK", 0, int),  # fused-zero OCR assembly: clear BC columns after the loop
     "lane_strided": _env("FDHIP_LANE_STRIDED", 1, int),   # plans in lane order (fd_plan_set_lane_order)
+    # staged rows addressed with a COMPILE-TIME node stride (max nodes per block rounded up to a multiple of this value;
+    # 0 = run-time stride): the LDS offsets of all staged arrays fold into ds_read/ds_add immediates instead of one
+    # v_add_u32 per access
+    "lds_const_stride": _env("FDHIP_LDS_CONST_STRIDE", 1, int),     # staged loops: P1 residual 0.43 -> 0.41 ms
+    "ocr_const_stride": _env("FDHIP_OCR_CONST_STRIDE", 0, int),     # owner-computes-rows loops: measured 2 % slower
     "lds_soa": _env("FDHIP_LDS_SOA", 1, int),             # component-major LDS layout for staged vector Dats
     "prefetch": _env("FDHIP_PREFETCH", 1, int),          # software-pipeline the packed index rows
     "mat_ocr": _env("FDHIP_MAT_OCR", 1, int),             # owner-computes-rows matrix assembly (no global atomics)

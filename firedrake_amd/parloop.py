@@ -316,18 +316,21 @@ class Parloop:
         limit = configuration["lds_limit"]
 
 
+        from .codegen import lds_stride, mode_variant
+
         def lds_bytes(plans, mplans, rsh):
             lds = 0
+            nd = {mi: lds_stride(p.max_nd) for mi, p in plans.items()}
             for item in src.lds_items:
                 if item[0] == "dat":
                     _, mi, c, isz, accum = item
-                    lds += (((plans[mi].max_nd * c * isz) << (rsh if accum else 0)) + 15) // 16 * 16
+                    lds += (((nd[mi] * c * isz) << (rsh if accum else 0)) + 15) // 16 * 16
                 else:
                     _, k, rm, cm, lg = item
                     mp = mplans[k]
-                    lds += ((mp.max_nnz * 8 << rsh) + 15) // 16 * 16 + ((plans[rm].max_nd + 1) * 4 + 15) // 16 * 16
+                    lds += ((mp.max_nnz * 8 << rsh) + 15) // 16 * 16 + ((nd[rm] + 1) * 4 + 15) // 16 * 16
                     if lg:
-                        lds += (plans[rm].max_nd + 15) // 16 * 16 + (plans[cm].max_nd + 15) // 16 * 16
+                        lds += (nd[rm] + 15) // 16 * 16 + (nd[cm] + 15) // 16 * 16
             return lds
 
         def build(epb, blocks):
@@ -375,9 +378,12 @@ class Parloop:
                 epb = max(32, epb // 2)
         if lds > 160 * 1024:
             raise _lib.FDHipError("staged wrapper does not fit LDS even at 32 entities per block")
-        if any(mp.kbytes == 2 for mp in mplans.values()) and src.kbytes == 1:
-            prep["cw"] = self.global_kernel.compile("staged_k16")
-        geo = {"epb": epb, "plans": plans, "mplans": mplans, "lds": lds}
+        kb = 2 if any(mp.kbytes == 2 for mp in mplans.values()) else 1
+        variant = mode_variant("staged", kb, [plans[mi].max_nd for mi in src.staged_maps])
+        # geometry-specific variant (16-bit matrix offsets, compile-time LDS strides); same parameter layout
+        cw = prep["cw"] if variant == src.mode else self.global_kernel.compile(variant)
+        assert cw.src.layout == src.layout
+        geo = {"epb": epb, "plans": plans, "mplans": mplans, "lds": lds, "cw": cw}
         if configuration["debug"]:
             import sys
             for mi, pl in plans.items():
@@ -512,7 +518,7 @@ class Parloop:
             return
         start, end = offset, offset + size
         args, geo = self._arglist(start, end)
-        cw = self._prepared["cw"]
+        cw = geo["cw"] if geo is not None else self._prepared["cw"]
         src = cw.src
         threads = src.block_threads
         if src.mode.startswith("staged"):
@@ -532,6 +538,7 @@ class Parloop:
         if geo is not None:
             return geo
         from .op2types import OcrPlan
+        from .codegen import lds_stride, mode_variant
         src = prep["cw"].src
         maps = prep["maps"]
         (k, pa), = [(k, a) for k, a in enumerate(self.arguments) if isinstance(a, MatParloopArg)]
@@ -565,15 +572,16 @@ class Parloop:
                 continue
             def lds_bytes(rsh):
                 lds = 0
+                nd = {mi: lds_stride(p.max_nd, ocr=True) for mi, p in op.plans.items()}
                 for item in src.lds_items:
                     if item[0] == "dat":
                         _, mi, c, isz, accum = item
-                        lds += (((op.plans[mi].max_nd * c * isz) << (rsh if accum else 0)) + 15) // 16 * 16
+                        lds += (((nd[mi] * c * isz) << (rsh if accum else 0)) + 15) // 16 * 16
                     else:
                         _, kk, rm, cmi, lg = item
-                        lds += ((op.max_nnz * 8 << rsh) + 15) // 16 * 16 + (op.plans[rm].max_nd * 4 + 15) // 16 * 16
+                        lds += ((op.max_nnz * 8 << rsh) + 15) // 16 * 16 + (nd[rm] * 4 + 15) // 16 * 16
                         if cmi != rm:
-                            lds += (op.plans[cmi].max_nd + 15) // 16 * 16
+                            lds += (nd[cmi] + 15) // 16 * 16
                 return lds
             lds = lds_bytes(src.rep_shift)
             if lds <= limit and op.max_inst * maxar <= 32768:
@@ -588,9 +596,11 @@ class Parloop:
             rb = np.unique(np.concatenate([rb, (rb[:-1] + d // 2)[big]]))
         if lds > 160 * 1024 or op.max_inst * maxar > 32768:
             raise _lib.FDHipError("owner-computes-rows plan does not fit (LDS or instance list); set FDHIP_MAT_OCR=0")
-        if op.kbytes == 2 and src.kbytes == 1:
-            prep["cw"] = self.global_kernel.compile("ocr_k16")
-        geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz}
+        nds = [op.plans[mi].max_nd for mi in src.staged_maps]
+        variant = mode_variant("ocr", op.kbytes, nds)
+        geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz,
+               "cw": prep["cw"] if variant == src.mode else self.global_kernel.compile(variant),
+               "variant_nm": mode_variant("ocr_nm", op.kbytes, nds)}
         prep["parts"]["ocr"] = geo
         if configuration["debug"]:
             import sys
@@ -602,7 +612,7 @@ class Parloop:
     def _compute_ocr(self):
         geo = self._ocr_geometry()
         prep = self._prepared
-        cw = prep["cw"]
+        cw = geo["cw"]
         src = cw.src
         op = geo["ocr"]
         if op.nblocks == 0 or op.ninst == 0:
@@ -613,7 +623,7 @@ class Parloop:
         mpa = self.arguments[geo["k"]]
         post_mask = bool(mpa.lgmaps is not None and mpa.data._zero_pending and configuration["ocr_post_mask"])
         if post_mask:
-            cw = self.global_kernel.compile("ocr_nm" + ("_k16" if src.kbytes == 2 else ""))
+            cw = self.global_kernel.compile(geo["variant_nm"])
             assert cw.src.layout == src.layout
         out = []
         post_vals = None
