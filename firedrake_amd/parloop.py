@@ -282,7 +282,7 @@ class Parloop:
                 ds = pa.data.dataset.set
                 base = it.parent if isinstance(it, ExtrudedSet) else it.superset
                 if ds is not it and ds is not base and ds is not getattr(base, "parent", None):
-                    raise SetTypeError("Iterset of direct arg doesn't match ParLoop iterset.")
+                    raise MapValueError("Iterset of direct arg does not match parloop iterset")     # parloop.py:494-497
 
     # -- preparation: compile + choose launch geometry + build plans
     def _prepare(self):
