@@ -42,7 +42,7 @@ from .kernel import (DatKernelArg, GlobalKernel, GlobalKernelArg, MatKernelArg, 
 from .op2types import (ALL, INC, MAX, MIN, ON_BOTTOM, ON_INTERIOR_FACETS, ON_TOP, READ, RW, WRITE)
 
 CTYPE = {np.dtype("float64"): "double", np.dtype("float32"): "float", np.dtype("int32"): "int",
-         np.dtype("uint32"): "unsigned int", np.dtype("int64"): "long long", np.dtype("uint64"): "unsigned long long"}
+         np.dtype("uint32"): "unsigned int", np.dtype("int64"): "int64_t", np.dtype("uint64"): "uint64_t"}
 
 STAGEABLE_INC = {np.dtype("float64"), np.dtype("float32"), np.dtype("int32"), np.dtype("uint32")}
 

@@ -45,6 +45,22 @@ template <> __device__ __forceinline__ void atomic_add<long long>(long long *p, 
 }
 template <class T> __device__ __forceinline__ void atomic_min(T *p, T v) { atomicMin(p, v); }
 template <class T> __device__ __forceinline__ void atomic_max(T *p, T v) { atomicMax(p, v); }
+// int64_t / uint64_t are `long` / `unsigned long` on this ABI; HIP's 64-bit integer atomics are declared for the
+// `long long` spellings, which have the same representation
+template <> __device__ __forceinline__ void atomic_add<long>(long *p, long v) {
+    atomicAdd((unsigned long long *)p, (unsigned long long)v);
+}
+template <> __device__ __forceinline__ void atomic_add<unsigned long>(unsigned long *p, unsigned long v) {
+    atomicAdd((unsigned long long *)p, (unsigned long long)v);
+}
+template <> __device__ __forceinline__ void atomic_min<long>(long *p, long v) { atomicMin((long long *)p, (long long)v); }
+template <> __device__ __forceinline__ void atomic_max<long>(long *p, long v) { atomicMax((long long *)p, (long long)v); }
+template <> __device__ __forceinline__ void atomic_min<unsigned long>(unsigned long *p, unsigned long v) {
+    atomicMin((unsigned long long *)p, (unsigned long long)v);
+}
+template <> __device__ __forceinline__ void atomic_max<unsigned long>(unsigned long *p, unsigned long v) {
+    atomicMax((unsigned long long *)p, (unsigned long long)v);
+}
 
 // ---- periodic extrusion: layer offset modulo the number of cell layers (pyop2/codegen/builder.py:101-123; the
 // reference's ad hoc _Remainder subtracts once, which is the same for every offset it can produce when nl >= 2)

@@ -20,7 +20,7 @@ from . import _lib
 from .op2types import Access, IterationRegion, ALL, READ, ScalarType
 
 _C_TYPE = {np.dtype("float64"): "double", np.dtype("float32"): "float", np.dtype("int32"): "int",
-           np.dtype("uint32"): "unsigned int", np.dtype("int64"): "long long", np.dtype("uint64"): "unsigned long long"}
+           np.dtype("uint32"): "unsigned int", np.dtype("int64"): "int64_t", np.dtype("uint64"): "uint64_t"}
 
 
 # ---- local kernel ---------------------------------------------------------------------------
@@ -39,6 +39,9 @@ class CStringLocalKernel:
                  requires_zeroed_output_arguments=False, cpp=False, **_ignored):
         if not isinstance(code, str):
             raise TypeError("C-string local kernels need `code` to be a str (loopy kernels: LoopyLocalKernel)")
+        if not isinstance(name, str):
+            from .exceptions import NameTypeError
+            raise NameTypeError("Kernel name must be a string")        # local_kernel.py:99 (validate_type)
         self.code = code
         self.name = name
         self.accesses = None if accesses is None else tuple(Access(a) for a in accesses)
@@ -51,6 +54,12 @@ class CStringLocalKernel:
     @property
     def arguments(self):
         return tuple(LocalKernelArg(a, d) for a, d in zip(self.accesses, self.dtypes))
+
+    def __str__(self):                     # local_kernel.py:172-176
+        return f"OP2 Kernel: {self.name}"
+
+    def __repr__(self):
+        return 'Kernel("""%s""", %r)' % (self.code, self.name)
 
     @property
     def cache_key(self):

@@ -53,36 +53,14 @@ ON_BOTTOM, ON_TOP, ON_INTERIOR_FACETS, ALL = (IterationRegion.ON_BOTTOM, Iterati
 
 
 # ---- exceptions (pyop2/exceptions.py) -------------------------------------------------
-class DataTypeError(TypeError):
-    pass
+from .exceptions import (ArityTypeError, DataSetTypeError, DataTypeError, DataValueError, DatTypeError, DimTypeError,  # noqa: E402,F401
+                         IndexTypeError, IndexValueError, MapTypeError, MapValueError, MatTypeError, ModeValueError,
+                         NameTypeError, SetTypeError, SizeTypeError, SparsityTypeError, SubsetIndexOutOfBounds)
 
 
-class DataValueError(ValueError):
-    pass
-
-
-class MapValueError(ValueError):
-    pass
-
-
-class ModeValueError(ValueError):
-    pass
-
-
-class SetTypeError(TypeError):
-    pass
-
-
-class SizeTypeError(TypeError):
-    pass
-
-
-class SubsetIndexOutOfBounds(IndexError):
-    pass
-
-
-class DimTypeError(TypeError):
-    pass
+def _check_name(name):
+    if name is not None and not isinstance(name, str):
+        raise NameTypeError(f"name must be a string, got {type(name)}")
 
 
 # ---- sets -----------------------------------------------------------------------------
@@ -97,13 +75,17 @@ class Set:
     _kernel_args_ = ()
 
     def __init__(self, size, name=None, halo=None, comm=None):
+        _check_name(name)
         if isinstance(size, (int, np.integer)):
             size = [int(size)] * 3
-        size = [int(s) for s in size]
-        if len(size) != 3 or not (0 <= size[0] <= size[1] <= size[2]):
+        try:
+            size = [int(s) for s in size]
+        except (TypeError, ValueError):
+            raise SizeTypeError(f"Set size must be an int or a (core, owned, total) triple, got {size!r}")
+        if isinstance(size, str) or len(size) != 3 or not (0 <= size[0] <= size[1] <= size[2]):
             raise SizeTypeError(f"Set size must be an int or (core, owned, total) with core<=owned<=total, got {size}")
         self._sizes = tuple(size)
-        self.name = name or f"set_{id(self):x}"
+        self.name = name or f"set_#x{id(self):x}"
         self.halo = halo
         self.comm = comm
 
@@ -144,6 +126,37 @@ class Set:
     def __iter__(self):
         yield self
 
+    def __getitem__(self, idx):           # set.py:155-159
+        if idx != 0:
+            raise IndexTypeError("Can only extract component 0 from %r" % self)
+        return self
+
+    # set.py:143-149: Sets compare by sizes and name (default names are unique per object)
+    def __hash__(self):
+        return hash((type(self).__name__, self._sizes, self.name))
+
+    def __eq__(self, other):
+        return isinstance(other, Set) and not isinstance(other, (ExtrudedSet, Subset)) and type(self) is type(other) \
+            and self._sizes == other._sizes and self.name == other.name
+
+    def __ne__(self, other):
+        return not self == other
+
+    def __contains__(self, dset):         # set.py:183-189
+        return isinstance(dset, DataSet) and dset.set is self
+
+    def __call__(self, *indices):         # set.py:170-181: set(i, j, ...) -> Subset
+        if len(indices) == 1:
+            indices = indices[0]
+            if np.isscalar(indices):
+                indices = [indices]
+        return Subset(self, indices)
+
+    layers = property(lambda self: 1)     # set.py:197-199
+
+    def __str__(self):
+        return "OP2 Set: %s with size %s" % (self.name, self.size)
+
     def __repr__(self):
         return f"Set({self._sizes!r}, {self.name!r})"
 
@@ -156,6 +169,8 @@ class ExtrudedSet(Set):
     _extruded = True
 
     def __init__(self, parent, layers, extruded_periodic=False):
+        if not isinstance(parent, Set):
+            raise TypeError("ExtrudedSet needs a parent Set")          # set.py:325 (validate_type)
         if isinstance(layers, (int, np.integer)):
             if layers < 2:
                 raise SizeTypeError("Number of layers must be > 1 (not %s)." % layers)
@@ -175,6 +190,20 @@ class ExtrudedSet(Set):
     def parent(self):
         return self._parent
 
+    def __contains__(self, set_):         # set.py:368-369
+        return set_ is self._parent
+
+    def __eq__(self, other):
+        return self is other
+
+    __hash__ = object.__hash__
+
+    def __str__(self):
+        return "OP2 ExtrudedSet: %s with size %s (%s layers)" % (self.name, self.size, self._layers_array)
+
+    def __repr__(self):
+        return "ExtrudedSet(%r, %r)" % (self._parent, self.layers)
+
     @property
     def layers(self):
         return int(self._layers_array[0, 1])
@@ -193,6 +222,8 @@ class Subset(Set):
     """pyop2/types/set.py:396-543: iterate only ``indices`` of ``superset``."""
 
     def __init__(self, superset, indices):
+        if not isinstance(superset, Set):
+            raise TypeError("Subset needs a Set")                      # set.py:407 (validate_type)
         if isinstance(superset, Subset):
             indices = superset.indices[np.asarray(indices, dtype=IntType)]
             superset = superset.superset
@@ -220,6 +251,28 @@ class Subset(Set):
         return self._indices
 
     @property
+    def owned_indices(self):              # set.py:485-490
+        return self._indices[self._indices < self._superset.size]
+
+    def __eq__(self, other):
+        return self is other
+
+    __hash__ = object.__hash__
+
+    def __call__(self, *indices):         # set.py:462-473: a Subset of a Subset
+        if len(indices) == 1:
+            indices = indices[0]
+            if np.isscalar(indices):
+                indices = [indices]
+        return Subset(self, indices)
+
+    def __str__(self):
+        return "OP2 Subset: %s with sizes %s" % (self.name, self._sizes)
+
+    def __repr__(self):
+        return "Subset(%r, %r)" % (self._superset, self._indices)
+
+    @property
     def layers_array(self):
         return self._superset.layers_array
 
@@ -239,7 +292,8 @@ class Subset(Set):
 class DataSet:
     """pyop2/types/dataset.py:17-112: Set x dim."""
 
-    def __init__(self, iter_set, dim=1, name=None):
+    def __init__(self, iter_set, dim=1, name=None, apply_local_global_filter=False):
+        _check_name(name)
         if isinstance(iter_set, DataSet):
             dim = iter_set.dim
             iter_set = iter_set.set
@@ -249,10 +303,16 @@ class DataSet:
             raise SetTypeError(f"expected a Set, got {type(iter_set)}")
         if isinstance(dim, (int, np.integer)):
             dim = (int(dim),)
+        try:                                                       # dataset.py:27 (validate_type DimTypeError)
+            if isinstance(dim, str) or not all(isinstance(d, (int, np.integer)) for d in dim):
+                raise TypeError
+            self._dim = tuple(int(d) for d in dim)
+        except TypeError:
+            raise DimTypeError(f"dim must be an int or a tuple of ints, got {dim!r}")
         self._set = iter_set
-        self._dim = tuple(int(d) for d in dim)
         self._cdim = int(np.prod(self._dim))
-        self.name = name or f"dset_{id(self):x}"
+        self.name = name or f"dset_#x{id(self):x}"
+        self._apply_local_global_filter = apply_local_global_filter
 
     @property
     def set(self):
@@ -288,8 +348,20 @@ class DataSet:
     def __eq__(self, o):
         return isinstance(o, DataSet) and o._set is self._set and o._dim == self._dim
 
+    def __ne__(self, o):
+        return not self == o
+
     def __hash__(self):
         return hash((id(self._set), self._dim))
+
+    def __contains__(self, dat):           # dataset.py:109-111
+        return getattr(dat, "dataset", None) == self
+
+    def __str__(self):
+        return "OP2 DataSet: %s on set %s, with dim %s, %s" % (self.name, self._set, self._dim, self._apply_local_global_filter)
+
+    def __repr__(self):
+        return "DataSet(%r, %r, %r, %r)" % (self._set, self._dim, self.name, self._apply_local_global_filter)
 
 
 def _as_dataset(x, dim=1):
@@ -297,7 +369,7 @@ def _as_dataset(x, dim=1):
         return x
     if isinstance(x, Set):
         return DataSet(x, dim)
-    raise DataTypeError(f"expected Set or DataSet, got {type(x)}")
+    raise DataSetTypeError(f"expected Set or DataSet, got {type(x)}")
 
 
 class MixedDataSet:
@@ -307,23 +379,28 @@ class MixedDataSet:
     def __init__(self, arg, dims=None):
         if isinstance(arg, MixedDataSet):
             dsets = arg.split
+        elif isinstance(arg, str):
+            raise DataSetTypeError("MixedDataSet needs a MixedSet or an iterable of Sets / DataSets")
         elif dims is not None:
+            # dataset.py:364-374: a MixedSet / iterable of Sets with a scalar dim or one dim per Set
             sets = arg.split if isinstance(arg, MixedSet) else tuple(arg)
+            if not all(isinstance(s_, Set) for s_ in sets):
+                raise TypeError("with dims given, the first argument must be a MixedSet or an iterable of Sets")
             dims = (dims,) * len(sets) if isinstance(dims, (int, np.integer)) else tuple(dims)
             if len(sets) != len(dims):
                 raise ValueError("Got MixedSet of %d Sets but %s dims" % (len(sets), len(dims)))
-            dsets = tuple(s ** d for s, d in zip(sets, dims))
+            dsets = tuple(s_ ** d for s_, d in zip(sets, dims))
         else:
             dsets = tuple(x if isinstance(x, DataSet) else _as_dataset(x) for x in arg)
         if not dsets:
-            raise DataTypeError("MixedDataSet needs at least one DataSet")
+            raise DataSetTypeError("MixedDataSet needs at least one DataSet")
         self._dsets = dsets
         self.comm = dsets[0].set.comm
 
     split = property(lambda self: self._dsets)
     dim = property(lambda self: tuple(d.dim for d in self._dsets))
     cdim = property(lambda self: sum(d.cdim for d in self._dsets))
-    name = property(lambda self: "_".join(d.name for d in self._dsets))
+    name = property(lambda self: tuple(d.name for d in self._dsets))          # dataset.py:409-412
 
     @property
     def set(self):
@@ -341,11 +418,17 @@ class MixedDataSet:
     def __eq__(self, o):
         return isinstance(o, MixedDataSet) and self._dsets == o._dsets
 
+    def __ne__(self, o):
+        return not self == o
+
     def __hash__(self):
         return hash(self._dsets)
 
+    def __str__(self):
+        return "OP2 MixedDataSet composed of DataSets: %s" % (self._dsets,)
+
     def __repr__(self):
-        return f"MixedDataSet({self._dsets!r})"
+        return "MixedDataSet(%r)" % (self._dsets,)
 
 
 # ---- host/device mirrored array ---------------------------------------------------------
@@ -389,6 +472,7 @@ class Dat(_Mirrored):
     """pyop2/types/dat.py:27-711.  Shape (total_size, *dim), ghosts at the tail (dat.py:83)."""
 
     def __init__(self, dataset, data=None, dtype=None, name=None):
+        _check_name(name)
         if isinstance(dataset, Dat):
             data = dataset.data_ro_with_halos.copy() if data is None else data
             dtype = dataset.dtype if dtype is None else dtype
@@ -396,6 +480,11 @@ class Dat(_Mirrored):
         dataset = _as_dataset(dataset)
         self._dataset = dataset
         shape = (dataset.total_size,) + (() if dataset.dim == (1,) else dataset.dim)
+        if dtype is not None:
+            try:
+                dtype = np.dtype(dtype)
+            except TypeError:
+                raise DataTypeError("Invalid data type: %s" % (dtype,))          # utils.verify_reshape
         if data is None:
             dt = np.dtype(dtype) if dtype is not None else ScalarType
             host = np.zeros(shape, dtype=dt)
@@ -407,10 +496,40 @@ class Dat(_Mirrored):
             except ValueError:
                 raise DataValueError("Invalid data: expected %d values, got %d!" % (int(np.prod(shape)), a.size))
         self._init_storage(host)
-        self.name = name or f"dat_{id(self):x}"
+        self.name = name or f"dat_#x{id(self):x}"
         self.halo_valid = True
         self._halo_frozen = False
         self._frozen_access_mode = None
+
+    # -- container protocol (dat.py:113-122, 333-347): a Dat is a one-member bag of itself
+    def __getitem__(self, idx):
+        if idx != 0:
+            raise IndexValueError("Can only extract component 0 from %r" % self)
+        return self
+
+    @property
+    def split(self):
+        return (self,)
+
+    def __iter__(self):
+        yield self
+
+    def __len__(self):
+        return 1
+
+    def __str__(self):
+        return "OP2 Dat: %s on (%s) with datatype %s" % (self.name, self._dataset, self.dtype.name)
+
+    def __repr__(self):
+        return "Dat(%r, None, %r, %r)" % (self._dataset, self.dtype, self.name)
+
+    @property
+    def _is_allocated(self):               # dat.py:141-143: device storage is created on first use
+        return self._dev is not None
+
+    @property
+    def _data(self):
+        return self._host
 
     # -- metadata
     @property
@@ -732,6 +851,8 @@ class MixedDat:
     MixedDataSet / MixedSet / iterable of (Data)Sets, or from an iterable of Dats."""
 
     def __init__(self, mdset_or_dats):
+        if isinstance(mdset_or_dats, str):
+            raise DataSetTypeError("MixedDat needs a MixedDataSet, a MixedSet or an iterable of Dats / (Data)Sets")
         if isinstance(mdset_or_dats, MixedDat):
             self._dats = tuple(Dat(d) for d in mdset_or_dats)
         else:
@@ -744,6 +865,8 @@ class MixedDat:
 
     split = property(lambda self: self._dats)
     dtype = property(lambda self: self._dats[0].dtype)
+    dim = property(lambda self: self.dataset.dim)
+    cdim = property(lambda self: self.dataset.cdim)
     dat_version = property(lambda self: sum(d.dat_version for d in self._dats))
     data = property(lambda self: tuple(d.data for d in self._dats))
     data_ro = property(lambda self: tuple(d.data_ro for d in self._dats))
@@ -805,8 +928,21 @@ class MixedDat:
         for d in self._dats:
             d.local_to_global_end(insert_mode)
 
+    def __hash__(self):
+        return hash(self._dats)
+
+    def __eq__(self, other):               # dat.py:1074-1082
+        return type(self) is type(other) and all(a is b for a, b in zip(self._dats, other._dats)) \
+            and len(self._dats) == len(other._dats)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    def __str__(self):
+        return "OP2 MixedDat composed of Dats: %s" % (self._dats,)
+
     def __repr__(self):
-        return f"MixedDat({self._dats!r})"
+        return "MixedDat(%r)" % (self._dats,)
 
     # -- arithmetic: component-wise (dat.py:1090-1198)
     def inner(self, other):
@@ -879,20 +1015,32 @@ class Global(_Mirrored):
     """pyop2/types/glob.py:21-480."""
 
     def __init__(self, dim, data=None, dtype=None, name=None, comm=None):
+        _check_name(name)
         if isinstance(dim, Global):
             data, dtype, dim = dim.data_ro.copy(), dim.dtype, dim.dim
         if isinstance(dim, (int, np.integer)):
             dim = (int(dim),)
-        self._dim = tuple(dim)
+        try:                                                       # glob.py:29 (as_tuple(dim, int))
+            if isinstance(dim, str) or not all(isinstance(d, (int, np.integer)) for d in dim):
+                raise TypeError
+            self._dim = tuple(int(d) for d in dim)
+        except TypeError:
+            raise DimTypeError(f"Global dim must be an int or a tuple of ints, got {dim!r}")
         n = int(np.prod(self._dim))
-        dt = np.dtype(dtype) if dtype is not None else (np.asarray(data).dtype if data is not None else ScalarType)
-        if data is None:
-            host = np.zeros(self._dim, dtype=dt)
-        else:
-            a = np.asarray(data, dtype=dt)
-            host = (np.full(self._dim, a, dtype=dt) if a.size == 1 and n != 1 else a.reshape(self._dim)).copy()
+        try:                                                       # utils.verify_reshape: bad dtype / values / length
+            dt = np.dtype(dtype) if dtype is not None else (np.asarray(data).dtype if data is not None else ScalarType)
+            if data is None:
+                host = np.zeros(self._dim, dtype=dt)
+            else:
+                a = np.asarray(data, dtype=dt)
+                if a.size == 1 and n != 1:
+                    host = np.full(self._dim, a, dtype=dt)
+                else:
+                    host = a.reshape(self._dim).copy()
+        except (TypeError, ValueError):
+            raise DataValueError("Invalid data for a Global of dim %s: %r" % (self._dim, data))
         self._init_storage(host)
-        self.name = name or f"global_{id(self):x}"
+        self.name = name or f"global_#x{id(self):x}"
         self.comm = comm
 
     @property
@@ -912,8 +1060,14 @@ class Global(_Mirrored):
         return self._host_rw()
 
     @data.setter
-    def data(self, value):
-        self._host_rw()[...] = value
+    def data(self, value):                 # glob.py:160-163 (verify_reshape: wrong length -> DataValueError)
+        try:
+            v = np.asarray(value, dtype=self.dtype)
+            if v.size != 1 and v.size != self._host.size:
+                raise ValueError
+            self._host_rw()[...] = v.reshape(self._host.shape) if v.size == self._host.size else v
+        except (TypeError, ValueError):
+            raise DataValueError("Invalid data: expected %d values, got %r" % (self._host.size, value))
 
     @property
     def data_ro(self):
@@ -924,9 +1078,35 @@ class Global(_Mirrored):
     def zero(self):
         self._host_rw()[...] = 0
 
+    _modes = (READ, INC, MIN, MAX)            # glob.py:91
+
     def __call__(self, access, map_=None):
         from .parloop import GlobalLegacyArg
+        if access not in self._modes:
+            raise ModeValueError("Global arguments may be accessed with READ, INC, MIN or MAX")
+        assert map_ is None
         return GlobalLegacyArg(self, access)
+
+    # glob.py:100-125, 292-298: a Global is a one-member bag of itself
+    def __getitem__(self, idx):
+        if idx != 0:
+            raise IndexValueError("Can only extract component 0 from %r" % self)
+        return self
+
+    split = property(lambda self: (self,))
+    shape = property(lambda self: self._dim)
+
+    def __iter__(self):
+        yield self
+
+    def __len__(self):
+        return 1
+
+    def __str__(self):
+        return "OP2 Global Argument: %s with dim %s and value %s" % (self.name, self._dim, self._to_host())
+
+    def __repr__(self):
+        return "Global(%r, %r, %r, %r)" % (self._dim, self._to_host(), self.dtype, self.name)
 
 
 Constant = Global
@@ -938,14 +1118,23 @@ class MixedSet:
     def __init__(self, sets):
         sets = tuple(sets.split if isinstance(sets, MixedSet) else sets)
         if not sets or not all(isinstance(s, Set) for s in sets):
-            raise SetTypeError("MixedSet needs an iterable of Sets")
+            raise SetTypeError("All sets of a MixedSet must be of type Set")
         if len({s._extruded for s in sets}) != 1:
             raise AssertionError("All components of a MixedSet must have the same extrusion")      # set.py:552-556
+        if len({s.layers for s in sets}) != 1:
+            raise AssertionError("All components of a MixedSet must have the same number of layers")
         self._sets = sets
         self.comm = sets[0].comm
-        self.name = "_".join(s.name for s in sets)
 
     split = property(lambda self: self._sets)
+    name = property(lambda self: tuple(s.name for s in self._sets))          # set.py:619-622
+    layers = property(lambda self: self._sets[0].layers)                      # set.py:639-642
+
+    @property
+    def halo(self):                        # set.py:624-628
+        halos = tuple(s.halo for s in self._sets)
+        return halos if any(halos) else None
+
     _extruded = property(lambda self: self._sets[0]._extruded)
     core_size = property(lambda self: sum(s.core_size for s in self._sets))
     size = property(lambda self: sum(s.size for s in self._sets))
@@ -966,13 +1155,19 @@ class MixedSet:
         return MixedDataSet(self._sets, e)
 
     def __eq__(self, o):
-        return isinstance(o, MixedSet) and len(o) == len(self) and all(a is b for a, b in zip(self, o))
+        return type(self) is type(o) and self._sets == o._sets
+
+    def __ne__(self, o):
+        return not self == o
 
     def __hash__(self):
-        return hash(tuple(id(s) for s in self._sets))
+        return hash(self._sets)
+
+    def __str__(self):
+        return "OP2 MixedSet composed of Sets: %s" % (self._sets,)
 
     def __repr__(self):
-        return f"MixedSet({self._sets!r})"
+        return "MixedSet(%r)" % (self._sets,)
 
 
 # ---- maps --------------------------------------------------------------------------------
@@ -985,18 +1180,21 @@ class Map:
     def __init__(self, iterset, toset, arity, values=None, name=None, offset=None, offset_quotient=None):
         if not isinstance(iterset, Set) or not isinstance(toset, Set):
             raise SetTypeError("Map iterset/toset must be Sets")
+        if not isinstance(arity, (int, np.integer)) or isinstance(arity, bool):
+            raise ArityTypeError("Map arity must be an int")          # map.py:34 (validate_type)
+        _check_name(name)
         self._iterset = iterset
         self._toset = toset
         self._arity = int(arity)
         if values is None:
             self._values = np.zeros((0, self._arity), dtype=IntType)
         else:
-            v = np.asarray(values)
             try:
+                v = np.asarray(values)
                 self._values = np.ascontiguousarray(v.astype(IntType, copy=False).reshape(iterset.total_size, self._arity))
-            except ValueError:
-                raise DataValueError("Invalid data: expected %d values, got %d!" % (iterset.total_size * self._arity, v.size))
-        self.name = name or f"map_{id(self):x}"
+            except (TypeError, ValueError):
+                raise DataValueError("Invalid data: expected %d integer values, got %r" % (iterset.total_size * self._arity, values))
+        self.name = name or f"map_#x{id(self):x}"
         self._offset = None if offset is None else tuple(int(o) for o in offset)
         if offset_quotient is None or len(offset_quotient) == 0:        # map.py:50-53
             self._offset_quotient = None
@@ -1025,8 +1223,29 @@ class Map:
     def arities(self):
         return (self._arity,)
 
+    arange = property(lambda self: (0, self._arity))      # map.py:115-118
+    split = property(lambda self: (self,))
+
     def __len__(self):
         return 1
+
+    def __iter__(self):
+        yield self
+
+    def __getitem__(self, idx):
+        if idx != 0:
+            raise IndexValueError("Can only extract component 0 from %r" % self)
+        return self
+
+    def __le__(self, o):                   # map.py:160-162
+        return self == o
+
+    def __str__(self):
+        return "OP2 Map: %s from (%s) to (%s) with arity %s" % (self.name, self._iterset, self._toset, self._arity)
+
+    def __repr__(self):
+        return "Map(%r, %r, %r, None, %r, %r, %r)" % (self._iterset, self._toset, self._arity, self.name, self._offset,
+                                                      self._offset_quotient)
 
     def _base(self):
         return self
@@ -1103,9 +1322,11 @@ class MixedMap:
     (entries may be None for components an argument does not touch)."""
 
     def __init__(self, maps):
+        if isinstance(maps, str):
+            raise MapTypeError("MixedMap needs an iterable of Maps")
         maps = tuple(maps.split if isinstance(maps, MixedMap) else maps)
         if not maps or not all(m is None or isinstance(m, Map) for m in maps):
-            raise TypeError("MixedMap needs an iterable of Maps")
+            raise MapTypeError("MixedMap needs an iterable of Maps")
         present = [m for m in maps if m is not None]
         if not present:
             raise TypeError("Don't know how to make a MixedMap of no Maps")
@@ -1122,7 +1343,23 @@ class MixedMap:
     values_with_halo = property(lambda self: tuple(m.values_with_halo for m in self._maps))
     offset = property(lambda self: tuple(0 if m is None else m.offset for m in self._maps))
     offset_quotient = property(lambda self: tuple(0 if m is None else m.offset_quotient for m in self._maps))
-    name = property(lambda self: "_".join(m.name for m in self._maps if m is not None))
+    name = property(lambda self: tuple(m.name for m in self._maps))            # map.py:434-437
+    arange = property(lambda self: (0,) + tuple(np.cumsum(self.arities)))      # map.py:411-414
+
+    def __eq__(self, o):
+        return type(self) is type(o) and len(o) == len(self) and all(a is b for a, b in zip(self._maps, o._maps))
+
+    def __ne__(self, o):
+        return not self == o
+
+    def __hash__(self):
+        return hash(tuple(id(m) for m in self._maps))
+
+    def __le__(self, o):                   # map.py:458-460
+        return self == o or all(m <= om for m, om in zip(self, o))
+
+    def __str__(self):
+        return "OP2 MixedMap composed of Maps: %s" % (self._maps,)
 
     def __iter__(self):
         return iter(self._maps)
@@ -1134,7 +1371,7 @@ class MixedMap:
         return self._maps[idx]
 
     def __repr__(self):
-        return f"MixedMap({self._maps!r})"
+        return "MixedMap(%r)" % (self._maps,)
 
 
 class Plan:
@@ -1199,46 +1436,79 @@ class Sparsity:
             dsets = (dsets, dsets)
         if len(dsets) != 2:
             raise RuntimeError(f"dsets must be a tuple of two DataSets: got {dsets}")
-        dsets = tuple(MixedDataSet(d) if isinstance(d, MixedSet) else d for d in dsets)
-        self.name = name or f"sparsity_{id(self):x}"
+        dsets = tuple(MixedDataSet(d) if isinstance(d, MixedSet) else (DataSet(d) if isinstance(d, Set) else d)
+                      for d in dsets)
+        for d in dsets:
+            if not isinstance(d, (DataSet, MixedDataSet)):
+                raise DataSetTypeError("All data sets must be of type DataSet, not type %r" % type(d))     # mat.py:119-121
+        _check_name(name)
+        self.name = name or f"sparsity_#x{id(self):x}"
         self._built = False
+        self._block_sparse = block_sparse
+        self._diagonal_block = diagonal_block
         if isinstance(maps_and_regions, (list, tuple)):
             maps_and_regions = {(0, 0): maps_and_regions}          # short-hand for a single block (mat.py:125-127)
         elif not isinstance(maps_and_regions, dict):
             raise TypeError(f"maps_and_regions must be dict or Sequence: got {type(maps_and_regions)}")
-        for (i, j) in maps_and_regions:
+        # mat.py:128-160: validate, de-duplicate and order the (rmap, cmap, regions) triples of every block
+        processed = {(i, j): () for i in range(len(dsets[0])) for j in range(len(dsets[1]))}
+        for (i, j), val in maps_and_regions.items():
             if i >= len(dsets[0]) or j >= len(dsets[1]):
                 raise RuntimeError(f"(i, j) must be < {(len(dsets[0]), len(dsets[1]))}: got {(i, j)}")
+            seen = []
+            for entry in val:
+                if isinstance(entry, Map):
+                    entry = (entry, entry, None)
+                rmap, cmap = entry[0], entry[1]
+                regions = entry[2] if len(entry) > 2 else None
+                for m in (rmap, cmap):
+                    if not isinstance(m, Map):
+                        raise MapTypeError("All maps must be of type map, not type %r" % type(m))
+                    if not isinstance(m, ComposedMap) and len(m.values_with_halo) == 0 and m.iterset.total_size > 0:
+                        raise MapValueError("Unpopulated map values when trying to build sparsity.")
+                if rmap.toset is not dsets[0][i].set or cmap.toset is not dsets[1][j].set:
+                    raise RuntimeError("Map toset must be the same as DataSet set")
+                if rmap.iterset.superset is not cmap.iterset.superset:
+                    raise RuntimeError("Iterset of both maps in a pair must be the same")
+                regions = (ALL,) if regions is None else tuple(sorted(regions))
+                if not any(t[0] is rmap and t[1] is cmap and t[2] == regions for t in seen):
+                    seen.append((rmap, cmap, regions))
+            # a deterministic order whatever the order the pairs were given in
+            processed[(i, j)] = tuple(sorted(seen, key=lambda t: (t[0].name, t[1].name, tuple(int(r) for r in t[2]))))
+        self._maps_and_regions = dict(sorted(processed.items()))
+        self._dsets = dsets
         if any(isinstance(d, MixedDataSet) for d in dsets):
             # mixed spaces: one Sparsity per block, each built on its own (mat.py:87-99, MATNEST)
             if nest is False:
                 raise NotImplementedError("monolithic (nest=False) sparsities over mixed sets are out of scope")
-            self._dsets = dsets
             self._nested = True
             same = dsets[0] is dsets[1] or dsets[0] == dsets[1]
-            self._blocks = [[Sparsity((rds, cds), list(maps_and_regions.get((i, j), ())), block_sparse=block_sparse,
+            self._blocks = [[Sparsity((rds, cds), list(self._maps_and_regions[(i, j)]), block_sparse=block_sparse,
                                       diagonal_block=(same and i == j))
                              for j, cds in enumerate(dsets[1])] for i, rds in enumerate(dsets[0])]
-            self._rcmaps = []
+            self._pairs = []
             self._has_diagonal = False
             return
         self._nested = False
         self._blocks = [[self]]
-        self._dsets = tuple(_as_dataset(d) for d in dsets)
-        norm = []
-        for entry in maps_and_regions.get((0, 0), ()):
-            if isinstance(entry, Map):
-                entry = (entry, entry, None)
-            r, c = entry[0], entry[1]
-            reg = entry[2] if len(entry) > 2 else None
-            if configuration["type_check"]:
-                if r.toset != self._dsets[0].set or c.toset != self._dsets[1].set:
-                    raise MapValueError("Map toset does not match the sparsity's DataSets")
-                if r.iterset.superset != c.iterset.superset:
-                    raise MapValueError("Iterset of both maps in a pair must be the same")
-            norm.append((r, c, tuple(sorted(reg)) if reg else (ALL,)))
-        self._rcmaps = norm
+        self._pairs = list(self._maps_and_regions[(0, 0)])
         self._has_diagonal = diagonal_block and self._dsets[0].set is self._dsets[1].set
+
+    @property
+    def rcmaps(self):                  # mat.py:195-197
+        return {key: [(r, c) for r, c, _ in val] for key, val in self._maps_and_regions.items()}
+
+    @property
+    def iteration_regions(self):       # mat.py:199-201
+        return {key: [reg for _, _, reg in val] for key, val in self._maps_and_regions.items()}
+
+    def __str__(self):
+        return "OP2 Sparsity: dsets %s, maps_and_regions %s, name %s, nested %s, block_sparse %s, diagonal_block %s" % \
+            (self._dsets, self._maps_and_regions, self.name, self._nested, self._block_sparse, self._diagonal_block)
+
+    def __repr__(self):
+        return "Sparsity(%r, %r, name=%r, nested=%r, block_sparse=%r, diagonal_block=%r)" % \
+            (self.dsets, self._maps_and_regions, self.name, self._nested, self._block_sparse, self._diagonal_block)
 
     def __getitem__(self, idx):        # mat.py:180-187
         try:
@@ -1254,11 +1524,10 @@ class Sparsity:
     nested = property(lambda self: self._nested)
 
     dsets = property(lambda self: self._dsets)
-    rcmaps = property(lambda self: self._rcmaps)
 
     @property
-    def dims(self):
-        return tuple(tuple((r.dim, c.dim) for c in self._dsets[1]) for r in self._dsets[0])
+    def dims(self):                    # mat.py:203-212: (rows per row-set entry, cols per col-set entry) of every block
+        return tuple(tuple((r.cdim, c.cdim) for c in self._dsets[1]) for r in self._dsets[0])
 
     @property
     def shape(self):
@@ -1275,7 +1544,7 @@ class Sparsity:
         _lib.require_gpu()
         rset, cset = self._dsets
         # one pattern contribution per (map pair, iteration region): sparsity.pyx:291-305
-        pairs = [(r, c, reg) for (r, c, regions) in self._rcmaps
+        pairs = [(r, c, reg) for (r, c, regions) in self._pairs
                  for reg in (regions if r.iterset._extruded else (ALL,))]
         n = len(pairs)
         VP = ctypes.c_void_p
@@ -1505,12 +1774,13 @@ class Mat:
 
     def __init__(self, sparsity, dtype=None, name=None):
         if not isinstance(sparsity, Sparsity):
-            raise DataTypeError("Mat needs a Sparsity")
+            raise SparsityTypeError("Mat needs a Sparsity")
+        _check_name(name)
         self._sparsity = sparsity
         self._dtype = np.dtype(dtype) if dtype is not None else ScalarType
         if self._dtype != ScalarType:
             raise DataTypeError("only float64 matrices are supported (ScalarType)")
-        self.name = name or f"mat_{id(self):x}"
+        self.name = name or f"mat_#x{id(self):x}"
         self._vals = None
         self._zero_pending = False
         self.dat_version = 0
@@ -1531,6 +1801,12 @@ class Mat:
     def __iter__(self):                # blocks in row-major order (mat.py:674-677)
         for row in self._blocks:
             yield from row
+
+    def __str__(self):
+        return "OP2 Mat: %s, sparsity (%s), datatype %s" % (self.name, self._sparsity, self._dtype.name)
+
+    def __repr__(self):
+        return "Mat(%r, %r, %r)" % (self._sparsity, self._dtype, self.name)
 
     @property
     def dims(self):

@@ -258,6 +258,7 @@ class Parloop:
         self.iterset = iterset
         self.arguments = list(arguments)
         self._check_maps()
+        self._check_frozen_access_modes()
         self._prepared = None
         self._lgmap_dev = {}
         self._masked = {}
@@ -283,6 +284,12 @@ class Parloop:
                 base = it.parent if isinstance(it, ExtrudedSet) else it.superset
                 if ds is not it and ds is not base and ds is not getattr(base, "parent", None):
                     raise MapValueError("Iterset of direct arg does not match parloop iterset")     # parloop.py:494-497
+
+    def _check_frozen_access_modes(self):          # parloop.py:503-513
+        for la, pa in zip(self.global_kernel.local_kernel.arguments, self.arguments):
+            d = pa.data
+            if isinstance(d, Dat) and d._halo_frozen and d._frozen_access_mode != la.access:
+                raise RuntimeError("Dats with frozen halos must always be accessed with the same access mode")
 
     # -- preparation: compile + choose launch geometry + build plans
     def _prepare(self):
@@ -779,6 +786,9 @@ class LegacyParloop(Parloop):
     """pyop2/parloop.py:709-743: build the GlobalKernel from dat(access, map)-style args."""
 
     def __init__(self, local_knl, iterset, *args, **kwargs):
+        if not isinstance(local_knl, CStringLocalKernel):
+            from .exceptions import KernelTypeError
+            raise KernelTypeError("par_loop needs a Kernel")             # parloop.py:752-756
         if not isinstance(iterset, Set):
             raise SetTypeError("Iteration set is of the wrong type")
         for a in args:

@@ -14,7 +14,7 @@ def oracle_pattern(sp):
     """The CSR pattern of Sparsity ``sp`` built by the oracle (one contribution per map pair and iteration region)."""
     rds, cds = sp.dsets
     pairs = []
-    for r, c, regions in sp.rcmaps:
+    for r, c, regions in sp._pairs:
         it = r.iterset
         if it._extruded:
             for reg in regions:
