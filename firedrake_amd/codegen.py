@@ -131,7 +131,7 @@ def _hoist_includes(code: str):
     return inc, body
 
 
-def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
+def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> WrapperSource:
     lk = gk.local_kernel
     maps, map_index = _distinct_maps(gk)
     full_mode = mode
@@ -508,7 +508,8 @@ def generate_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
            "namespace fdk {", "#pragma clang force_cuda_host_device begin", body,
            "#pragma clang force_cuda_host_device end", "}  // namespace fdk", *decls, ""]
     sym = f"wrap_{lk.name}"
-    lb = f"{threads}, {configuration['min_waves']}" if configuration["min_waves"] else f"{threads}"
+    min_waves = min_waves or configuration["min_waves"]
+    lb = f"{threads}, {min_waves}" if min_waves else f"{threads}"
     src.append(f'extern "C" __global__ __launch_bounds__({lb}) void {sym}(int start, int end, {", ".join(params)})')
     src.append("{")
     need_red = bool(post)

@@ -7,7 +7,9 @@ Here the artefact is a gfx950 code object (``hipcc --genco``) loaded through
 ``fd_kernel_load`` (hipModuleLoad) instead of ``ctypes.CDLL``.
 """
 import hashlib
+import json
 import os
+import re
 import subprocess
 import tempfile
 
@@ -66,7 +68,9 @@ def compile_hip(source: str, name: str) -> str:
         fh.write(source)
     fd, tmp = tempfile.mkstemp(suffix=".hsaco", dir=cache)
     os.close(fd)
-    cmd = [configuration["hipcc"], *fl, "-o", tmp, src]
+    # -Rpass-analysis=kernel-resource-usage: the register / scratch / occupancy figures of the wrapper kernel, kept in a
+    # sidecar file next to the code object (kernel_resources) for the occupancy-directed variant choice in kernel.py
+    cmd = [configuration["hipcc"], *fl, "-Rpass-analysis=kernel-resource-usage", "-o", tmp, src]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True)
     except OSError as e:
@@ -75,5 +79,37 @@ def compile_hip(source: str, name: str) -> str:
     if r.returncode != 0:
         os.unlink(tmp)
         raise CompilationError(f"hipcc failed for {src}:\n{' '.join(cmd)}\n{r.stderr}")
+    res = _parse_resources(r.stderr)
+    if res:
+        with open(out + ".res.json.tmp", "w") as fh:
+            json.dump(res, fh)
+        os.replace(out + ".res.json.tmp", out + ".res.json")
     os.replace(tmp, out)      # atomic: concurrent ranks race benignly
     return out
+
+
+_RES_KEYS = {"VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch", "Occupancy [waves/SIMD]": "occupancy",
+             "VGPRs Spill": "vgpr_spill", "LDS Size [bytes/block]": "static_lds"}
+
+
+def _parse_resources(stderr: str):
+    """{kernel name: {vgprs, scratch, occupancy, ...}} from hipcc's kernel-resource-usage remarks."""
+    out, cur = {}, None
+    for line in stderr.splitlines():
+        m = re.search(r"remark:\s+Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z \[\]/]+): (\d+)", line)
+        if m and cur is not None and m.group(1).strip() in _RES_KEYS:
+            cur[_RES_KEYS[m.group(1).strip()]] = int(m.group(2))
+    return out
+
+
+def kernel_resources(path: str, symbol: str):
+    """Resource usage of ``symbol`` in the cached code object ``path`` (None when it was compiled without remarks)."""
+    try:
+        with open(path + ".res.json") as fh:
+            return json.load(fh).get(symbol)
+    except (OSError, ValueError):
+        return None

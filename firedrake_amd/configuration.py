@@ -44,6 +44,10 @@ configuration = {
     "ocr_order": _env("FDHIP_OCR_ORDER", "stencil"),
     "mat_exclusive": _env("FDHIP_MAT_EXCLUSIVE", 0, int),  # non-atomic writes + fused zero for block-exclusive nonzeros
     "min_waves": _env("FDHIP_MIN_WAVES", 0, int),       # 2nd __launch_bounds__ argument (waves per SIMD), 0 = unset
+    # occupancy-directed variants: a staged/OCR wrapper whose register count leaves room for one more resident workgroup
+    # per CU is recompiled with the matching __launch_bounds__ and kept if that costs at most this many bytes of scratch
+    # per lane (-1 = off).  DG-advection interior-facet loop: 172 -> 128 VGPRs, 12 B scratch, 0.50 -> 0.32 ms
+    "auto_occupancy_scratch": _env("FDHIP_AUTO_OCCUPANCY_SCRATCH", 16, int),
     "block_merge": _env("FDHIP_BLOCK_MERGE", 1, int),     # staged loops: fuse this many consecutive producer tiles into one plan block
     "use_preferred_blocks": _env("FDHIP_PREFERRED_BLOCKS", 1, int),   # plan blocks = the producer's traversal tiles
     "lds_limit": _env("FDHIP_LDS_LIMIT", 64 * 1024, int),

@@ -379,10 +379,36 @@ class GlobalKernel:
             if cw is None:
                 src = generate_wrapper(self, mode)
                 path = compile_hip(src.source, self.name)
+                src, path = self._occupancy_variant(mode, src, path)
                 cw = CompiledWrapper(src, path)
                 GlobalKernel._cache[ck] = cw
             self._compiled[mode] = cw
         return cw
+
+    def _occupancy_variant(self, mode, src, path):
+        """Workgroups of T lanes put T/256 wavefronts on every SIMD, so the resident wavefronts per SIMD go up in steps
+        of T/256.  If the wrapper's register count is what stops the next step, recompile it with
+        ``__launch_bounds__(T, next step)`` and keep the variant when the registers it gives up cost (almost) no
+        scratch; otherwise keep the original.  Decided from hipcc's own resource report, once per JIT compilation."""
+        from .codegen import generate_wrapper
+        from .compilation import compile_hip, kernel_resources
+        from .configuration import configuration
+        limit = configuration["auto_occupancy_scratch"]
+        if limit < 0 or configuration["min_waves"] or not (mode.startswith("staged") or mode.startswith("ocr")):
+            return src, path
+        res = kernel_resources(path, src.symbol)
+        if not res or "occupancy" not in res:
+            return src, path
+        step = max(1, src.block_threads // 256)
+        target = (res["occupancy"] // step + 1) * step
+        if target > 8 or res.get("vgprs", 0) <= 512 // target:
+            return src, path            # already at the hardware limit / not limited by registers
+        src2 = generate_wrapper(self, mode, min_waves=target)
+        path2 = compile_hip(src2.source, self.name)
+        res2 = kernel_resources(path2, src2.symbol)
+        if res2 and res2.get("occupancy", 0) >= target and res2.get("scratch", 1 << 30) <= limit:
+            return src2, path2
+        return src, path
 
     def __call__(self, comm, start, end, *args, **launch):
         """func(start, end, *arglist) -- global_kernel.py:327-335."""

@@ -37,8 +37,7 @@ def pytest_configure(config):
         if mode == "ocr":
             modes.append("staged")          # fallback when a plan does not fit
         for m in modes:
-            src = generate_wrapper(gk, m)
-            compile_hip(src.source, gk.name)
+            gk.compile(m)                   # codegen + hipcc + the occupancy-directed variant choice
     parloop.Parloop.compute = compute
 
     for name in ("assert_allclose", "assert_array_equal", "assert_equal", "assert_almost_equal", "assert_array_almost_equal"):
