@@ -81,7 +81,7 @@ SIGNATURES = {
     "fd_csr_from_maps_ex": (c_int, [c_int32, c_int32, c_int, c_int, POINTER(c_void_p), POINTER(c_void_p),
                                     POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
                                     POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32), POINTER(c_int32),
-                                    POINTER(c_void_p), POINTER(c_void_p),
+                                    POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                     POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_void_p]),
     "fd_csr_expand_blocks": (c_int, [c_int32, c_void_p, c_void_p, c_int, c_int, POINTER(c_void_p),
                                      POINTER(c_void_p), c_void_p]),

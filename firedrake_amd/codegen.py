@@ -145,6 +145,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
     ktype, kbytes = ("unsigned short", 2) if mode.endswith("_k16") else ("unsigned char", 1)
     extruded = gk._extruded
     periodic = bool(extruded and gk._extruded_periodic)
+    varlay = bool(extruded and not gk._constant_layers)      # per-entity [bottom, top) rows (set.py:326-337)
     region = gk._iteration_region
     ih = extruded and region == ON_INTERIOR_FACETS
     nf = 2 if ih else 1
@@ -291,7 +292,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         e = f"map{mi}[(size_t){ent}*{ar} + {ii}]"
         if extruded and off is not None:
             # a permuted map permutes its offsets (and quotients) with its values (builder.py:160-169)
-            rel = f"(layer - layers[0] + {f})"
+            rel = f"(layer - lay[0] + {f})"
             if periodic:
                 # builder.py:101-123: the layer offset wraps around the column of fd_nl cell layers
                 if maps[mi].offset_quotient is None:
@@ -640,16 +641,21 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         src += ["  " + s for s in post]
     else:
         if extruded:
-            lo, hi = {ALL: ("layers[0]", "layers[1]-1"), ON_BOTTOM: ("layers[0]", "layers[0]+1"),
-                      ON_TOP: ("layers[1]-2", "layers[1]-1"),
+            lo, hi = {ALL: ("lay[0]", "lay[1]-1"), ON_BOTTOM: ("lay[0]", "lay[0]+1"),
+                      ON_TOP: ("lay[1]-2", "lay[1]-1"),
                       # periodic columns have one more interior facet: between the top and the bottom cell (builder.py:806-809)
-                      ON_INTERIOR_FACETS: ("layers[0]", "layers[1]-1" if periodic else "layers[1]-2")}[region]
-            src.append(f"  const int llo = {lo}, lhi = {hi};")
+                      ON_INTERIOR_FACETS: ("lay[0]", "lay[1]-1" if periodic else "lay[1]-2")}[region]
+            bounds = [f"const int llo = {lo}, lhi = {hi};"]
             if periodic:
-                src.append("  const int fd_nl = layers[1] - 1 - layers[0];")
+                bounds.append("const int fd_nl = lay[1] - 1 - lay[0];")
+            if not varlay:
+                # constant layers: one [bottom, top) row for every entity (set.py:342-345)
+                src.append("  const int *__restrict__ lay = layers;")
+                src += ["  " + b for b in bounds]
             # a direct (map-less) Dat written on an extruded set is addressed by the BASE entity
-            # (parloop.py:494-497): all layers of a column hit the same row -> keep layers sequential
-            layer_parallel = not any(i["kind"] == "dat" and "m" not in i and i["acc"] != READ for i in infos)
+            # (parloop.py:494-497): all layers of a column hit the same row -> keep layers sequential.
+            # Variable layers: every column has its own range -> one lane walks its column (builder.py:754-831)
+            layer_parallel = not varlay and not any(i["kind"] == "dat" and "m" not in i and i["acc"] != READ for i in infos)
         src += ["  " + s for s in pre]
         if extruded and layer_parallel:
             src += ["  const long long nlay = lhi - llo;",
@@ -661,6 +667,10 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             src += ["  for (long long it = blockIdx.x*(long long)blockDim.x + threadIdx.x; it < (long long)(end - start); it += (long long)gridDim.x*blockDim.x) {",
                     "    const int n = start + (int)it;"]
         src.append("    const int e = " + ("subset_indices[n];" if gk._subset else "n;"))
+        if varlay:
+            # the layers array belongs to the superset: indexed by the entity, not by the position in a subset
+            src.append("    const int *__restrict__ lay = layers + 2*(size_t)e;")
+            src += ["    " + b for b in bounds]
         if extruded and not layer_parallel:
             src.append("    for (int layer = llo; layer < lhi; ++layer) {")
         src += ["      " + s for s in pack]

@@ -14,11 +14,13 @@ namespace {
 // ON_INTERIOR_FACETS region (two vertically stacked cells per facet, sparsity.pyx:298-303); layers l0 .. l0+nli-1 of
 // the nl cell layers are visited (sparsity.pyx:331-346).  Node of entry i in layer l (sparsity.pyx:357-368):
 //   map[e][i % arity] + off[i % arity] * ((l + i / arity + quot) % nl - quot % nl)      (quot = 0 unless periodic)
+// Variable layers (`layers` = per-entity [bottom, top) rows, set.py:326-337): every entity gets nli = the longest
+// column's slots; slots outside its own layer range emit the dropped-key sentinel.
 __global__ void emit_keys(const int32_t *__restrict__ rmap, const int32_t *__restrict__ cmap, int32_t nent,
                           int ar, int ac, int nl, int l0, int nli, int nf, const int32_t *__restrict__ roff,
                           const int32_t *__restrict__ coff, const int32_t *__restrict__ rquot,
-                          const int32_t *__restrict__ cquot, int32_t nrows, int32_t ncols,
-                          uint64_t *__restrict__ keys) {
+                          const int32_t *__restrict__ cquot, const int32_t *__restrict__ layers, int region,
+                          int32_t nrows, int32_t ncols, uint64_t *__restrict__ keys) {
     const int nr = nf * ar, nc = nf * ac;
     const int64_t per = (int64_t)nr * nc;
     const int64_t L = nl > 0 ? nli : 1;
@@ -33,13 +35,21 @@ __global__ void emit_keys(const int32_t *__restrict__ rmap, const int32_t *__res
         const int ki = i / ar, ii = i - ki * ar, kj = j / ac, jj = j - kj * ac;
         int r = rmap[e * ar + ii];
         int c = cmap[e * ac + jj];
+        bool live = true;
         if (nl > 0) {
+            int nle = nl;
+            if (layers) {       // this column's cell layers and the part of them the region visits (sparsity.pyx:331-346)
+                nle = layers[2 * e + 1] - 1 - layers[2 * e];
+                const int lo = region == FD_ON_TOP ? nle - 1 : 0;
+                const int hi = region == FD_ON_BOTTOM ? 1 : (region == FD_ON_INTERIOR_FACETS ? nle - 1 : nle);
+                live = l >= lo && l < hi;
+            }
             const int qr = rquot ? rquot[ii] : 0, qc = cquot ? cquot[jj] : 0;
-            if (r >= 0) r += roff[ii] * ((l + ki + qr) % nl - qr % nl);
-            if (c >= 0) c += coff[jj] * ((l + kj + qc) % nl - qc % nl);
+            if (live && r >= 0) r += roff[ii] * ((l + ki + qr) % nle - qr % nle);
+            if (live && c >= 0) c += coff[jj] * ((l + kj + qc) % nle - qc % nle);
         }
-        uint64_t key = ~0ull;                       // sentinel: dropped (negative / out of range)
-        if (r >= 0 && r < nrows && c >= 0 && c < ncols) key = ((uint64_t)(uint32_t)r << 32) | (uint32_t)c;
+        uint64_t key = ~0ull;                       // sentinel: dropped (negative / out of range / no such layer)
+        if (live && r >= 0 && r < nrows && c >= 0 && c < ncols) key = ((uint64_t)(uint32_t)r << 32) | (uint32_t)c;
         keys[t] = key;
     }
 }
@@ -179,6 +189,7 @@ int fd_csr_from_maps_ex(int32_t nrows, int32_t ncols, int set_diag, int npairs,
                         const int32_t *const *roffs_h, const int32_t *const *coffs_h,
                         const int32_t *region, const int32_t *periodic,
                         const int32_t *const *rquots_h, const int32_t *const *cquots_h,
+                        const int32_t *const *layers_dev,
                         int32_t **rowptr_out, int32_t **colidx_out, int64_t *nnz_out, fd_stream_t s_) {
     hipStream_t s = fd::st(s_);
     int64_t ncand = 0;
@@ -187,6 +198,10 @@ int fd_csr_from_maps_ex(int32_t nrows, int32_t ncols, int set_diag, int npairs,
         if (nl && region && region[k] != FD_ALL && region[k] != FD_ON_BOTTOM && region[k] != FD_ON_TOP &&
             region[k] != FD_ON_INTERIOR_FACETS) FD_FAIL("fd_csr_from_maps_ex: unknown iteration region");
         pair_layers(nl, region ? region[k] : FD_ALL, periodic ? periodic[k] : 0, &l0, &nli, &nf);
+        if (layers_dev && layers_dev[k]) {          // variable layers: nlayers[k] = the longest column, all slots enumerated
+            if (periodic && periodic[k]) FD_FAIL("fd_csr_from_maps_ex: periodic extrusion needs constant layers");
+            l0 = 0; nli = nl;
+        }
         if (nli < 0) nli = 0;
         ncand += (int64_t)nent[k] * nli * nf * rarity[k] * nf * carity[k];
     }
@@ -200,6 +215,8 @@ int fd_csr_from_maps_ex(int32_t nrows, int32_t ncols, int set_diag, int npairs,
     for (int k = 0; k < npairs; ++k) {
         int nl = (nlayers && nlayers[k] > 0) ? nlayers[k] : 0, l0, nli, nf;
         pair_layers(nl, region ? region[k] : FD_ALL, periodic ? periodic[k] : 0, &l0, &nli, &nf);
+        const int32_t *lay = (layers_dev && layers_dev[k]) ? layers_dev[k] : nullptr;
+        if (lay) { l0 = 0; nli = nl; }
         if (nli < 0) nli = 0;
         int64_t cnt = (int64_t)nent[k] * nli * nf * rarity[k] * nf * carity[k];
         if (cnt == 0) continue;
@@ -219,7 +236,8 @@ int fd_csr_from_maps_ex(int32_t nrows, int32_t ncols, int set_diag, int npairs,
             }
         }
         hipLaunchKernelGGL(emit_keys, dim3(grid_for(cnt)), dim3(256), 0, s, rmaps[k], cmaps[k], nent[k], rarity[k],
-                           carity[k], nl, l0, nli, nf, roff, coff, rq, cq, nrows, ncols, keys + off);
+                           carity[k], nl, l0, nli, nf, roff, coff, rq, cq, lay, region ? region[k] : FD_ALL, nrows, ncols,
+                           keys + off);
         FD_CHECK_LAUNCH();
         if (nl) {
             FD_HIP(hipStreamSynchronize(s)); FD_HIP(hipFree(roff)); FD_HIP(hipFree(coff));
@@ -274,7 +292,7 @@ int fd_csr_from_maps(int32_t nrows, int32_t ncols, int set_diag, int npairs,
                      const int32_t *const *roffs_h, const int32_t *const *coffs_h,
                      int32_t **rowptr_out, int32_t **colidx_out, int64_t *nnz_out, fd_stream_t s) {
     return fd_csr_from_maps_ex(nrows, ncols, set_diag, npairs, rmaps, cmaps, nent, rarity, carity, nlayers, roffs_h,
-                               coffs_h, nullptr, nullptr, nullptr, nullptr, rowptr_out, colidx_out, nnz_out, s);
+                               coffs_h, nullptr, nullptr, nullptr, nullptr, nullptr, rowptr_out, colidx_out, nnz_out, s);
 }
 
 int fd_csr_expand_blocks(int32_t nnode, const int32_t *nrp, const int32_t *nci, int rbs, int cbs,

@@ -267,8 +267,6 @@ class GlobalKernel:
             raise ValueError("Cannot request constant_layers argument for non-extruded iteration")
         if extruded_periodic and not extruded:
             raise ValueError("Cannot request extruded_periodic for non-extruded iteration")
-        if extruded and not constant_layers:
-            raise NotImplementedError("variable-layer extrusion is out of scope (SURVEY.md 2.3)")
         self.local_kernel = local_kernel
         self.arguments = tuple(arguments)
         self._extruded = extruded

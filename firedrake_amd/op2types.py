@@ -206,7 +206,18 @@ class ExtrudedSet(Set):
             self._layers_array = np.array([[0, int(layers)]], dtype=IntType)
             self.constant_layers = True
         else:
-            raise NotImplementedError("variable layers are out of scope (SURVEY.md 2.3: constant layers only)")
+            # set.py:326-337: one [bottom, top) row of node levels per entity of the parent set
+            try:
+                arr = np.ascontiguousarray(np.asarray(layers, dtype=IntType).reshape(parent.total_size, 2))
+            except (TypeError, ValueError):
+                raise SizeTypeError(f"Specifying layers per entity, but provided {np.shape(layers)}, "
+                                    f"needed ({parent.total_size}, 2)")
+            if arr.size and arr.min() < 0:
+                raise SizeTypeError("Bottom of layers must be >= 0")
+            if (arr[:, 1] - arr[:, 0] < 1).any():
+                raise SizeTypeError("Number of layers must be >= 0")
+            self._layers_array = arr
+            self.constant_layers = False
         self._parent = parent
         self._sizes = parent._sizes
         self.name = parent.name + "_extruded"
@@ -231,10 +242,12 @@ class ExtrudedSet(Set):
         return "OP2 ExtrudedSet: %s with size %s (%s layers)" % (self.name, self.size, self._layers_array)
 
     def __repr__(self):
-        return "ExtrudedSet(%r, %r)" % (self._parent, self.layers)
+        return "ExtrudedSet(%r, %r)" % (self._parent, self.layers if self.constant_layers else self._layers_array)
 
     @property
-    def layers(self):
+    def layers(self):                      # set.py:383-389
+        if not self.constant_layers:
+            raise ValueError("No single layer, use layers_array attribute")
         return int(self._layers_array[0, 1])
 
     @property
@@ -269,6 +282,7 @@ class Subset(Set):
         self.comm = superset.comm
         self._extruded = superset._extruded
         self._extruded_periodic = superset._extruded_periodic
+        self.constant_layers = getattr(superset, "constant_layers", True)
         self._dev_indices = None
 
     @property
@@ -1614,7 +1628,7 @@ class Sparsity:
         n = len(pairs)
         VP = ctypes.c_void_p
         rm, cm = (VP * n)(), (VP * n)()
-        ro, co, rq, cq = (VP * n)(), (VP * n)(), (VP * n)(), (VP * n)()
+        ro, co, rq, cq, lay = (VP * n)(), (VP * n)(), (VP * n)(), (VP * n)(), (VP * n)()
         nent, ra, ca, nl, region, periodic = ((ctypes.c_int32 * n)() for _ in range(6))
         keep = []
 
@@ -1633,7 +1647,12 @@ class Sparsity:
             ra[k], ca[k] = r.arity, c.arity
             region[k] = int(reg)
             if it._extruded:
-                nl[k] = it.layers - 1
+                if it.constant_layers:
+                    nl[k] = it.layers - 1
+                else:
+                    la = it.layers_array                       # per-entity [bottom, top): the longest column sets the slots
+                    nl[k] = int((la[:, 1] - 1 - la[:, 0]).max()) if len(la) else 0
+                    lay[k] = it._layers_dev()
                 if r.offset is None or c.offset is None:
                     raise MapValueError("maps of an extruded iteration set need offsets to build a sparsity")
                 ro[k], co[k] = host_ints(r.offset), host_ints(c.offset)
@@ -1646,7 +1665,7 @@ class Sparsity:
                 nl[k] = 0
         rp, ci, nnz = VP(), VP(), ctypes.c_int64()
         _lib.call("fd_csr_from_maps_ex", rset.set.total_size, cset.set.total_size, int(self._has_diagonal), n,
-                  rm, cm, nent, ra, ca, nl, ro, co, region, periodic, rq, cq,
+                  rm, cm, nent, ra, ca, nl, ro, co, region, periodic, rq, cq, lay,
                   ctypes.byref(rp), ctypes.byref(ci), ctypes.byref(nnz), None)
         self._node_rowptr = DeviceBuffer.wrap(rp.value, (rset.set.total_size + 1) * 4)
         self._node_colidx = DeviceBuffer.wrap(ci.value, max(nnz.value, 1) * 4)

@@ -798,7 +798,8 @@ class LegacyParloop(Parloop):
             local_knl = local_knl.with_signature([a.access for a in args], [a.dtype for a in args])
         extruded = iterset._extruded
         subset = isinstance(iterset, Subset)
-        gk = _global_kernel_cached(local_knl, args, extruded=extruded, constant_layers=extruded, subset=subset,
+        gk = _global_kernel_cached(local_knl, args, extruded=extruded,
+                                   constant_layers=bool(extruded and iterset.constant_layers), subset=subset,
                                    extruded_periodic=bool(extruded and iterset._extruded_periodic),
                                    iteration_region=kwargs.get("iteration_region"),
                                    pass_layer_arg=kwargs.get("pass_layer_arg", False))

@@ -208,7 +208,10 @@ int fd_csr_from_maps(int32_t nrow_nodes, int32_t ncol_nodes, int set_diag, int n
  * 331-346 -- interior facets couple two stacked cells), `periodic[k]` marks periodic extrusion (sparsity.pyx:273, 343-346)
  * and `rquot_host[k]` / `cquot_host[k]` are the maps' offset quotients (sparsity.pyx:309-312, 357-368):
  *   node = map[e][i % arity] + offset[i % arity] * ((layer + i / arity + quot) % nlayers - quot % nlayers).
- * region, periodic and the quotient arrays (or single quotients) may be NULL = FD_ALL / not periodic / 0. */
+ * region, periodic and the quotient arrays (or single quotients) may be NULL = FD_ALL / not periodic / 0.
+ * Variable layers (pyop2/types/set.py:326-337, sparsity.pyx:325-330): `layers_dev[k]` is the device (nent, 2) array of
+ * per-entity [bottom, top) node levels and nlayers[k] the largest number of cell layers of any entity; NULL (array or
+ * entry) = constant layers. */
 #define FD_ON_BOTTOM 1
 #define FD_ON_TOP 2
 #define FD_ON_INTERIOR_FACETS 3
@@ -219,6 +222,7 @@ int fd_csr_from_maps_ex(int32_t nrow_nodes, int32_t ncol_nodes, int set_diag, in
                         const int32_t *nlayers, const int32_t *const *roffsets_host,
                         const int32_t *const *coffsets_host, const int32_t *region, const int32_t *periodic,
                         const int32_t *const *rquot_host, const int32_t *const *cquot_host,
+                        const int32_t *const *layers_dev,
                         int32_t **rowptr_dev, int32_t **colidx_dev, int64_t *nnz, fd_stream_t s);
 /* node pattern -> scalar (aij) pattern for DataSet dims (rbs, cbs) (mat.py:254-278) */
 int fd_csr_expand_blocks(int32_t nrow_nodes, const int32_t *rowptr_dev, const int32_t *colidx_dev,

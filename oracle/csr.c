@@ -64,6 +64,7 @@ static int cmp_int(const void *a, const void *b)
  */
 typedef struct {
     const int *rmap, *cmap, *roff, *coff, *rquot, *cquot;
+    const int *layers;      /* variable layers: (nent, 2) [bottom, top) node levels per entity, else NULL */
     int nent, ar, ac, nl, region, periodic;
 } oracle_pair;
 
@@ -78,15 +79,20 @@ static int pair_node(const int *map, const int *off, const int *quot, int arity,
     return v;
 }
 
-/* layer range and number of stacked cells of a pair (sparsity.pyx:331-346) */
-static void pair_layers(const oracle_pair *p, int *l0, int *l1, int *nf)
+/* layer range (relative to the entity's bottom layer) and number of stacked cells of entity e of a pair
+ * (sparsity.pyx:325-346).  Node offsets are taken relative to the entity's own bottom layer, which is what the
+ * generated wrapper uses (builder.py:101-103); sparsity.pyx uses the absolute layer modulo num_layers, which
+ * enumerates the same set for the ALL region. */
+static void pair_layers(const oracle_pair *p, int e, int *l0, int *l1, int *nf, int *nle)
 {
     *nf = 1;
-    if (p->nl <= 0) { *l0 = 0; *l1 = 1; return; }
-    *l0 = 0; *l1 = p->nl;
+    if (p->nl <= 0) { *l0 = 0; *l1 = 1; *nle = 0; return; }
+    int nl = p->layers ? p->layers[2 * e + 1] - 1 - p->layers[2 * e] : p->nl;
+    *nle = nl;
+    *l0 = 0; *l1 = nl;
     if (p->region == 2) *l1 = 1;
-    else if (p->region == 3) *l0 = p->nl - 1;
-    else if (p->region == 4) { *nf = 2; if (!p->periodic) *l1 = p->nl - 1; }
+    else if (p->region == 3) *l0 = nl - 1;
+    else if (p->region == 4) { *nf = 2; if (!p->periodic) *l1 = nl - 1; }
 }
 
 long oracle_build_node_sparsity_ex(int nrows, int ncols, int set_diag, int npairs,
@@ -94,7 +100,7 @@ long oracle_build_node_sparsity_ex(int nrows, int ncols, int set_diag, int npair
                                    const int *nent, const int *rarity, const int *carity,
                                    const int *nlayers, const int **roffs, const int **coffs,
                                    const int *region, const int *periodic,
-                                   const int **rquots, const int **cquots,
+                                   const int **rquots, const int **cquots, const int **layers,
                                    int **rowptr_out, int **colidx_out)
 {
     oracle_pair *P = (oracle_pair *)calloc((size_t)(npairs > 0 ? npairs : 1), sizeof(oracle_pair));
@@ -104,18 +110,20 @@ long oracle_build_node_sparsity_ex(int nrows, int ncols, int set_diag, int npair
         P[k].roff = P[k].nl ? roffs[k] : NULL; P[k].coff = P[k].nl ? coffs[k] : NULL;
         P[k].region = region ? region[k] : 1; P[k].periodic = periodic ? periodic[k] : 0;
         P[k].rquot = rquots ? rquots[k] : NULL; P[k].cquot = cquots ? cquots[k] : NULL;
+        P[k].layers = layers ? layers[k] : NULL;
     }
     long *cnt = (long *)calloc((size_t)nrows + 1, sizeof(long));
     for (int k = 0; k < npairs; ++k) {
-        int l0, l1, nf;
-        pair_layers(&P[k], &l0, &l1, &nf);
-        for (int e = 0; e < P[k].nent; ++e)
+        for (int e = 0; e < P[k].nent; ++e) {
+            int l0, l1, nf, nle;
+            pair_layers(&P[k], e, &l0, &l1, &nf, &nle);
             for (int l = l0; l < l1; ++l)
                 for (int i = 0; i < nf * P[k].ar; ++i) {
-                    int r = pair_node(P[k].rmap, P[k].roff, P[k].rquot, P[k].ar, P[k].nl, e, i, l);
+                    int r = pair_node(P[k].rmap, P[k].roff, P[k].rquot, P[k].ar, nle, e, i, l);
                     if (r < 0 || r >= nrows) continue;
                     cnt[r + 1] += nf * P[k].ac;
                 }
+        }
     }
     if (set_diag)
         for (int r = 0; r < nrows && r < ncols; ++r) cnt[r + 1] += 1;
@@ -127,16 +135,17 @@ long oracle_build_node_sparsity_ex(int nrows, int ncols, int set_diag, int npair
     if (set_diag)
         for (int r = 0; r < nrows && r < ncols; ++r) cand[fill[r]++] = r;
     for (int k = 0; k < npairs; ++k) {
-        int l0, l1, nf;
-        pair_layers(&P[k], &l0, &l1, &nf);
-        for (int e = 0; e < P[k].nent; ++e)
+        for (int e = 0; e < P[k].nent; ++e) {
+            int l0, l1, nf, nle;
+            pair_layers(&P[k], e, &l0, &l1, &nf, &nle);
             for (int l = l0; l < l1; ++l)
                 for (int i = 0; i < nf * P[k].ar; ++i) {
-                    int r = pair_node(P[k].rmap, P[k].roff, P[k].rquot, P[k].ar, P[k].nl, e, i, l);
+                    int r = pair_node(P[k].rmap, P[k].roff, P[k].rquot, P[k].ar, nle, e, i, l);
                     if (r < 0 || r >= nrows) continue;
                     for (int j = 0; j < nf * P[k].ac; ++j)   /* negative cols filtered below */
-                        cand[fill[r]++] = pair_node(P[k].cmap, P[k].coff, P[k].cquot, P[k].ac, P[k].nl, e, j, l);
+                        cand[fill[r]++] = pair_node(P[k].cmap, P[k].coff, P[k].cquot, P[k].ac, nle, e, j, l);
                 }
+        }
     }
     free(P);
     int *rowptr = (int *)malloc(((size_t)nrows + 1) * sizeof(int));
@@ -171,7 +180,7 @@ long oracle_build_node_sparsity(int nrows, int ncols, int set_diag, int npairs,
                                 int **rowptr_out, int **colidx_out)
 {
     return oracle_build_node_sparsity_ex(nrows, ncols, set_diag, npairs, rmaps, cmaps, nent, rarity, carity,
-                                         nlayers, roffs, coffs, NULL, NULL, NULL, NULL, rowptr_out, colidx_out);
+                                         nlayers, roffs, coffs, NULL, NULL, NULL, NULL, NULL, rowptr_out, colidx_out);
 }
 
 void oracle_free(void *p) { free(p); }

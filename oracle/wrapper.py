@@ -169,7 +169,7 @@ int oracle_MatSetValuesLocal(oracle_mat *A, int nr, const int *rows, int nc, con
 
 def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
                      extruded=False, iteration_region=ALL, pass_layer_arg=False, threads=False,
-                     periodic=False):
+                     periodic=False, constant_layers=True):
     """Emit the C wrapper (restating SURVEY.md Appendix A)."""
     sig = ["int start", "int end"]
     if extruded:
@@ -204,15 +204,15 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
         e = f"{mname}[(size_t)e*{arity} + {ii}]"
         if extruded and offset is not None:
             table(f"{mname}_off", offset)
-            rel = f"(layer - layers[0] + {f})"
+            rel = f"(layer - lay[0] + {f})"
             if periodic:
                 # builder.py:108-120: _Remainder(a, b) = a < b ? a : a - b (builder.py:26-29), num_layers = top - bottom
                 if quotient is None:
-                    rel = f"ORACLE_REM({rel}, (layers[1] - 1 - layers[0]))"
+                    rel = f"ORACLE_REM({rel}, (lay[1] - 1 - lay[0]))"
                 else:
                     table(f"{mname}_quot", quotient)
-                    rel = (f"(ORACLE_REM(({rel} + {mname}_quot[{ii}]), (layers[1] - 1 - layers[0])) - "
-                           f"ORACLE_REM({mname}_quot[{ii}], (layers[1] - 1 - layers[0])))")
+                    rel = (f"(ORACLE_REM(({rel} + {mname}_quot[{ii}]), (lay[1] - 1 - lay[0])) - "
+                           f"ORACLE_REM({mname}_quot[{ii}], (lay[1] - 1 - lay[0])))")
             # a permuted map permutes its offsets (and quotients) with its values (builder.py:160-169)
             e += f" + {mname}_off[{ii}]*{rel}"
         return e
@@ -359,10 +359,13 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
               "    int e = " + ("subset_indices[n];" if subset else "n;")]
     if extruded:
         # builder.py:790-812; periodic columns have one more interior facet (between the top and the bottom cell)
-        lo, hi = {ALL: ("layers[0]", "layers[1]-1"),
-                  ON_BOTTOM: ("layers[0]", "layers[0]+1"),
-                  ON_TOP: ("layers[1]-2", "layers[1]-1"),
-                  ON_INTERIOR_FACETS: ("layers[0]", "layers[1]-1" if periodic else "layers[1]-2")}[iteration_region]
+        lo, hi = {ALL: ("lay[0]", "lay[1]-1"),
+                  ON_BOTTOM: ("lay[0]", "lay[0]+1"),
+                  ON_TOP: ("lay[1]-2", "lay[1]-1"),
+                  ON_INTERIOR_FACETS: ("lay[0]", "lay[1]-1" if periodic else "lay[1]-2")}[iteration_region]
+        # builder.py:754-760, 834-838: one [bottom, top) row for all entities (constant layers) or one per entity,
+        # indexed by the entity itself (for a Subset: the superset's entity, set.py:434-436)
+        lines.append("    const int *lay = layers" + ("" if constant_layers else " + 2*(size_t)e") + ";")
         lines.append(f"    for (int layer = {lo}; layer < {hi}; ++layer) {{")
     lines += ["      " + s for s in body_pack]
     lines.append(f"      {kernel_name}({', '.join(body_call)});")
@@ -384,17 +387,20 @@ def par_loop(kernel_src: str, kernel_name: str, start: int, end: int, args, *,
              subset: Optional[np.ndarray] = None, layers: Optional[Tuple[int, int]] = None,
              iteration_region=ALL, pass_layer_arg=False, cflags=None, return_fn=False, threads=False,
              periodic=False):
-    """Generate + compile + run the wrapper over [start, end).  Arrays are modified in place."""
+    """Generate + compile + run the wrapper over [start, end).  Arrays are modified in place.
+    ``layers``: (bottom, top) for constant layers or an (nentities, 2) array for variable layers."""
+    constant_layers = layers is None or np.ndim(layers) == 1
     code, maps = generate_wrapper(kernel_src, kernel_name, args, subset=subset is not None,
                                   extruded=layers is not None, iteration_region=iteration_region,
-                                  pass_layer_arg=pass_layer_arg, threads=threads, periodic=periodic)
+                                  pass_layer_arg=pass_layer_arg, threads=threads, periodic=periodic,
+                                  constant_layers=constant_layers)
     lib = compile_c(code, "wrap_" + kernel_name + ("_omp" if threads else ""), extra_sources=[os.path.join(_HERE, "csr.c")],
                     cflags=cflags, threads=threads)
     fn = getattr(lib, "wrap_" + kernel_name)
     cargs = [ctypes.c_int(start), ctypes.c_int(end)]
     keep = []
     if layers is not None:
-        la = np.asarray(layers, dtype=np.int32)
+        la = np.ascontiguousarray(layers, dtype=np.int32)
         keep.append(la)
         cargs.append(la.ctypes.data_as(ctypes.c_void_p))
     if subset is not None:
@@ -453,11 +459,12 @@ def _csrlib():
 
 def build_sparsity(nrow_nodes: int, ncol_nodes: int, pairs, rbs=1, cbs=1, set_diag=True) -> OracleCSR:
     """pairs: list of (rmap, cmap) or (rmap, cmap, nlayers, roffset, coffset[, rquotient, cquotient, periodic[, region]])
-    -- ``region`` in the oracle's numbering (ALL = 1 ...); one entry per (map pair, iteration region)."""
+    -- ``region`` in the oracle's numbering (ALL = 1 ...); one entry per (map pair, iteration region).  ``nlayers`` is
+    the number of cell layers (constant layers) or the (nentities, 2) array of [bottom, top) node levels."""
     lib = _csrlib()
     n = len(pairs)
     P = ctypes.POINTER(ctypes.c_int)
-    rm = (P * n)(); cmm = (P * n)(); ro = (P * n)(); co = (P * n)(); rq = (P * n)(); cq = (P * n)()
+    rm = (P * n)(); cmm = (P * n)(); ro = (P * n)(); co = (P * n)(); rq = (P * n)(); cq = (P * n)(); lay = (P * n)()
     nent = (ctypes.c_int * n)(); ra = (ctypes.c_int * n)(); ca = (ctypes.c_int * n)(); nl = (ctypes.c_int * n)()
     reg = (ctypes.c_int * n)(); per = (ctypes.c_int * n)()
     keep = []
@@ -473,8 +480,13 @@ def build_sparsity(nrow_nodes: int, ncol_nodes: int, pairs, rbs=1, cbs=1, set_di
         rm[k] = r.ctypes.data_as(P); cmm[k] = c.ctypes.data_as(P)
         nent[k] = r.shape[0]; ra[k] = r.shape[1]; ca[k] = c.shape[1]
         reg[k], per[k] = ALL, 0
-        if len(p) > 2 and p[2]:
-            nl[k] = int(p[2])
+        if len(p) > 2 and p[2] is not None and np.size(p[2]) and np.any(p[2]):
+            if np.ndim(p[2]) == 2:                      # variable layers
+                la = np.ascontiguousarray(p[2], dtype=np.int32)
+                lay[k] = arr(la)
+                nl[k] = int((la[:, 1] - 1 - la[:, 0]).max())
+            else:
+                nl[k] = int(p[2])
             ro[k] = arr(p[3]); co[k] = arr(p[4])
             if len(p) > 5 and p[5] is not None:
                 rq[k] = arr(p[5])
@@ -489,7 +501,7 @@ def build_sparsity(nrow_nodes: int, ncol_nodes: int, pairs, rbs=1, cbs=1, set_di
     rp = P(); ci = P()
     lib.oracle_build_node_sparsity_ex.restype = ctypes.c_long
     nnz = lib.oracle_build_node_sparsity_ex(nrow_nodes, ncol_nodes, int(bool(set_diag)),
-                                            n, rm, cmm, nent, ra, ca, nl, ro, co, reg, per, rq, cq,
+                                            n, rm, cmm, nent, ra, ca, nl, ro, co, reg, per, rq, cq, lay,
                                             ctypes.byref(rp), ctypes.byref(ci))
     nrowptr = np.ctypeslib.as_array(rp, shape=(nrow_nodes + 1,)).copy()
     ncolidx = np.ctypeslib.as_array(ci, shape=(max(nnz, 1),))[:nnz].copy()

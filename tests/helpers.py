@@ -18,7 +18,8 @@ def oracle_pattern(sp):
         it = r.iterset
         if it._extruded:
             for reg in regions:
-                pairs.append((r.values_with_halo, c.values_with_halo, it.layers - 1, r.offset, c.offset,
+                nl = it.layers - 1 if it.constant_layers else np.asarray(it.layers_array, dtype=np.int32)
+                pairs.append((r.values_with_halo, c.values_with_halo, nl, r.offset, c.offset,
                               r.offset_quotient, c.offset_quotient, bool(it._extruded_periodic), _REGION[reg]))
         else:
             pairs.append((r.values_with_halo, c.values_with_halo))
@@ -81,7 +82,10 @@ def oracle_run(kernel, iterset, *args, iteration_region=None, pass_layer_arg=Fal
             oargs.append(om)
             outs.append(csr)
     subset = iterset.indices if isinstance(iterset, op2.Subset) else None
-    layers = tuple(int(x) for x in iterset.layers_array[0]) if iterset._extruded else None
+    layers = None
+    if iterset._extruded:
+        la = iterset.layers_array
+        layers = tuple(int(x) for x in la[0]) if iterset.constant_layers else np.asarray(la, dtype=np.int32)
     oracle.par_loop(kernel.code, kernel.name, 0, iterset.size, oargs, subset=subset, layers=layers,
                     iteration_region=_REGION[iteration_region], pass_layer_arg=pass_layer_arg,
                     periodic=bool(iterset._extruded and iterset._extruded_periodic))

@@ -152,3 +152,40 @@ def test_extruded_sparsity_over_regions():
     rp, ci, v = mat.csr()
     assert np.array_equal(rp, ocsr.rowptr) and np.array_equal(ci, ocsr.colidx)
     _close(v, ocsr.values)
+
+
+@pytest.mark.parametrize("region", [None, op2.ON_BOTTOM, op2.ON_TOP, op2.ON_INTERIOR_FACETS])
+def test_variable_layers(region):
+    """Columns with their own [bottom, top) layer ranges (pyop2/types/set.py:326-337; builder.py:754-838;
+    sparsity.pyx:325-346): vector and matrix assembly, the device-built sparsity and a Subset, against the oracle."""
+    rng = np.random.default_rng(21)
+    nbase, nv, maxl = 500, 260, 7
+    bottom = rng.integers(0, 3, size=nbase)
+    layers = np.stack([bottom, bottom + rng.integers(2, maxl, size=nbase)], axis=1).astype(np.int32)
+    base = op2.Set(nbase)
+    ext = op2.ExtrudedSet(base, layers)
+    L = maxl + 3
+    nodes = op2.Set(nv * L)
+    tri = np.array([rng.choice(nv, 3, replace=False) for _ in range(nbase)])
+    cm = op2.Map(ext, nodes, 6, np.concatenate([tri * L, tri * L + 1], axis=1).astype(np.int32), offset=[1] * 6)
+    x = op2.Dat(nodes ** 2, rng.standard_normal((nodes.size, 2)))
+    nf = 2 if region == op2.ON_INTERIOR_FACETS else 1
+    k = op2.Kernel("static void kv%d(double *o, const double *x) { for (int i = 0; i < %d; ++i) o[i] += (i+1)*x[2*i] + 0.5*x[2*i+1]; }" % (nf, 6 * nf), "kv%d" % nf)
+    for it in (ext, op2.Subset(ext, np.arange(1, nbase, 3))):
+        out = op2.Dat(nodes)
+        op2.par_loop(k, it, out(op2.INC, cm), x(op2.READ, cm), iteration_region=region)
+        ref = oracle_run(k, it, op2.Dat(nodes)(op2.INC, cm), x(op2.READ, cm), iteration_region=region)[0]
+        _close(out.data_ro, ref)
+    n = 6 * nf
+    mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(cm, cm, [region] if region is not None else None)]))
+    km = op2.Kernel("static void kvm%d(double *A, const double *x) { for (int i = 0; i < %d; ++i) for (int j = 0; j < %d; ++j) A[i*%d+j] += x[2*i]*x[2*j+1] + 1.0; }" % (nf, n, n, n), "kvm%d" % nf)
+    args = (mat(op2.INC, (cm, cm)), x(op2.READ, cm))
+    op2.par_loop(km, ext, *args, iteration_region=region)
+    ocsr = oracle_run(km, ext, *args, iteration_region=region)[0]
+    rp, ci, v = mat.csr()
+    assert np.array_equal(rp, ocsr.rowptr) and np.array_equal(ci, ocsr.colidx)
+    _close(v, ocsr.values)
+    g = op2.Global(1, 0.0)                                       # layer argument: sum of the visited layer numbers
+    kl = op2.Kernel("static void kl(double *g, int layer) { g[0] += layer; }", "kl")
+    op2.par_loop(kl, ext, g(op2.INC), pass_layer_arg=True)
+    assert g.data_ro[0] == sum(sum(range(b, t - 1)) for b, t in layers)

@@ -223,3 +223,78 @@ def test_mixed_velocity_pressure(vdim):
     lgp = np.arange(mset[1].total_size, dtype=np.int32)
     lgmaps = [(lgv, lgv), (lgv, lgp), (lgp, lgv), (lgp, lgp)]
     _check_mixed(jac, ele, mat(op2.INC, (mmap, mmap), lgmaps=lgmaps), x(op2.READ, vmap))
+
+
+# ---- variable layers (pyop2/types/set.py:326-337, codegen/builder.py:754-838) ---------------------------------------
+def _variable_layer_columns(rng, nbase=7, nv=9, maxl=6):
+    """Columns with their own [bottom, top) node levels; DoFs of a column are numbered from ITS bottom cell, so the
+    map entry of a cell points at the cell's own bottom layer (layer - bottom = 0 there)."""
+    bottom = rng.integers(0, 3, size=nbase)
+    top = bottom + rng.integers(2, maxl, size=nbase)            # at least one cell per column
+    layers = np.stack([bottom, top], axis=1).astype(np.int32)
+    base = op2.Set(nbase)
+    ext = op2.ExtrudedSet(base, layers)
+    L = maxl + 3
+    nodes = op2.Set(nv * L)
+    tri = np.array([rng.choice(nv, 3, replace=False) for _ in range(nbase)])
+    vals = np.concatenate([tri * L, tri * L + 1], axis=1).astype(np.int32)
+    return base, ext, nodes, op2.Map(ext, nodes, 6, vals, offset=[1] * 6), layers, L
+
+
+@pytest.mark.parametrize("region", [None, op2.ON_BOTTOM, op2.ON_TOP, op2.ON_INTERIOR_FACETS])
+def test_variable_layers(region):
+    rng = np.random.default_rng(21)
+    base, ext, nodes, cm, layers, L = _variable_layer_columns(rng)
+    assert not ext.constant_layers
+    with pytest.raises(ValueError):
+        ext.layers
+    x = op2.Dat(nodes ** 2, rng.standard_normal((nodes.size, 2)))
+    out = op2.Dat(nodes)
+    nf = 2 if region == op2.ON_INTERIOR_FACETS else 1
+    k = op2.Kernel("static void kv(double *o, const double *x) { for (int i = 0; i < %d; ++i) o[i] += (i+1)*x[2*i] + 0.5*x[2*i+1]; }" % (6 * nf), "kv")
+    got = _check(k, ext, out(op2.INC, cm), x(op2.READ, cm), iteration_region=region)
+    exp = np.zeros(nodes.size)                                   # independent numpy restatement
+    xv = x.data_ro
+    for e in range(base.size):
+        b, t = layers[e]
+        ncl = t - 1 - b
+        lay = {None: range(ncl), op2.ON_BOTTOM: range(0, 1), op2.ON_TOP: range(ncl - 1, ncl),
+               op2.ON_INTERIOR_FACETS: range(ncl - 1)}[region]
+        for l in lay:
+            for f in range(nf):
+                for i in range(6):
+                    n = cm.values[e, i] + (l + f)
+                    exp[n] += (f * 6 + i + 1) * xv[n, 0] + 0.5 * xv[n, 1]
+    assert np.abs(got[0] - exp).max() < 1e-12
+    # layer argument and subsets: the layers array is indexed by the entity, not by the position in the subset
+    lay_out = op2.Dat(nodes, dtype=np.float64)
+    kl = op2.Kernel("static void kl(double *o, int layer) { for (int i = 0; i < 6; ++i) o[i] = layer; }", "kl")
+    ss = op2.Subset(ext, [1, 4, 5])
+    got = _check(kl, ss, lay_out(op2.WRITE, cm), pass_layer_arg=True)
+    for e in (1, 4, 5):
+        b, t = layers[e]
+        assert got[0][cm.values[e, 3] + (t - 2 - b)] == t - 2          # upper nodes of the top cell carry its layer
+
+
+@pytest.mark.parametrize("region", [None, op2.ON_BOTTOM, op2.ON_TOP, op2.ON_INTERIOR_FACETS])
+def test_variable_layers_matrix(region):
+    """Matrix assembly + sparsity over columns with their own layer ranges (sparsity.pyx:325-346)."""
+    rng = np.random.default_rng(22)
+    base, ext, nodes, cm, layers, L = _variable_layer_columns(rng)
+    x = op2.Dat(nodes ** 2, rng.standard_normal((nodes.size, 2)))
+    n = 6 * (2 if region == op2.ON_INTERIOR_FACETS else 1)
+    mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(cm, cm, [region] if region is not None else None)]))
+    km = op2.Kernel("static void kvm(double *A, const double *x) { for (int i = 0; i < %d; ++i) for (int j = 0; j < %d; ++j) A[i*%d+j] += x[2*i]*x[2*j+1] + 1.0; }" % (n, n, n), "kvm")
+    got = _check(km, ext, mat(op2.INC, (cm, cm)), x(op2.READ, cm), iteration_region=region)[0]
+    # the pattern holds the always-allocated diagonal plus exactly the rows some cell of the region inserts into
+    rows = set()
+    for e in range(base.size):
+        b, t = layers[e]
+        ncl = t - 1 - b
+        lay = {None: range(ncl), op2.ON_BOTTOM: range(0, 1), op2.ON_TOP: range(ncl - 1, ncl),
+               op2.ON_INTERIOR_FACETS: range(ncl - 1)}[region]
+        nf = 2 if region == op2.ON_INTERIOR_FACETS else 1
+        for l in lay:
+            rows.update(int(cm.values[e, i] + l + f) for f in range(nf) for i in range(6))
+    touched = {r for r in range(got.nrows) if got.rowptr[r + 1] - got.rowptr[r] > 1}
+    assert touched == rows
