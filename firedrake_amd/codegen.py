@@ -189,6 +189,9 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         if isinstance(a, DatKernelArg):
             info["kind"] = "dat"
             info["c"] = int(np.prod(a.dim))
+            # DatView (dat.py:714-805, builder.py:347-349): the kernel sees ONE component of every node; `vi` is its flat
+            # position inside the node's row, the row stride stays the parent's
+            info["vi"] = None if a.index is None else int(np.ravel_multi_index(tuple(a.index), tuple(a.dim)))
             if a.is_indirect:
                 m = a.map_
                 base = m.base_map if isinstance(m, PermutedMapKernelArg) else m
@@ -343,7 +346,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         elif info["kind"] == "dat" and "m" not in info:
             c = info["c"]
             cast = f"const_cast<{ct} *>" if acc == READ else ""
-            call_args.append(f"{cast}(&arg{k}[(size_t)e*{c}])")
+            call_args.append(f"{cast}(&arg{k}[(size_t)e*{c}" + (f" + {info['vi']}" if info["vi"] is not None else "") + "])")
         elif info["kind"] == "dat":
             c, ar, mi = info["c"], info["ar"], info["m"]
             perm, off = info["perm"], info["off"]
@@ -380,14 +383,22 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 call_args.append(f"t{k}")
                 continue
             nexpr = node(mi, ar, "i", off, perm, "f")
-            loop = f"for (int f = 0; f < {nf}; ++f) for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j)"
-            if acc in (INC, WRITE):
-                pack.append(f"for (int q = 0; q < {size}; ++q) t{k}[q] = 0;")
+            if info["vi"] is not None:
+                # a view packs one value per node: t[f][i] <-> dat[node][vi]
+                loop = f"for (int f = 0; f < {nf}; ++f) for (int i = 0; i < {ar}; ++i)"
+                lhs = f"arg{k}[(size_t){nexpr}*{c} + {info['vi']}]"
+                rhs = f"t{k}[f*{ar}+i]"
+                vsize = nf * ar
             else:
-                pack.append(f"{loop} t{k}[(f*{ar}+i)*{c}+j] = arg{k}[(size_t){nexpr}*{c} + j];")
+                loop = f"for (int f = 0; f < {nf}; ++f) for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j)"
+                lhs = f"arg{k}[(size_t){nexpr}*{c} + j]"
+                rhs = f"t{k}[(f*{ar}+i)*{c}+j]"
+                vsize = size
+            if acc in (INC, WRITE):
+                pack.append(f"for (int q = 0; q < {vsize}; ++q) t{k}[q] = 0;")
+            else:
+                pack.append(f"{loop} {rhs} = {lhs};")
             call_args.append(f"t{k}")
-            lhs = f"arg{k}[(size_t){nexpr}*{c} + j]"
-            rhs = f"t{k}[(f*{ar}+i)*{c}+j]"
             if acc == INC:
                 unpack.append(f"{loop} fdw::atomic_add<{ct}>(&{lhs}, {rhs});")
             elif acc == MIN:

@@ -1,6 +1,6 @@
 """The PyOP2-compatible API surface of the MI355X backend (mirror of pyop2/op2.py:42-69)."""
 from .configuration import configuration  # noqa: F401
-from .op2types import (Set, ExtrudedSet, Subset, MixedSet, DataSet, MixedDataSet, Dat, MixedDat, Global, Constant,  # noqa: F401
+from .op2types import (Set, ExtrudedSet, Subset, MixedSet, DataSet, MixedDataSet, Dat, DatView, MixedDat, Global, Constant,  # noqa: F401
                        Map, PermutedMap, ComposedMap, MixedMap,
                        Sparsity, Mat, Access, IterationRegion,
                        READ, WRITE, RW, INC, MIN, MAX, ON_BOTTOM, ON_TOP, ON_INTERIOR_FACETS, ALL,

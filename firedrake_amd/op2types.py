@@ -925,6 +925,76 @@ class Dat(_Mirrored):
     __idiv__ = __itruediv__
 
 
+class DatView(Dat):
+    """pyop2/types/dat.py:714-805: a Dat that shows ONE component of a vector/tensor-valued Dat.  It shares the parent's
+    storage (host and device) and version / halo state; a kernel sees a single value per node."""
+
+    def __init__(self, dat, index):
+        index = (index,) if isinstance(index, (int, np.integer)) else tuple(index)
+        if len(index) != len(dat.dim) or not all(0 <= i < d for i, d in zip(index, dat.dim)):
+            raise IndexValueError("Can't create DatView with index %s for Dat with shape %s" % (index, dat.dim))
+        self.index = tuple(int(i) for i in index)
+        self._idx = (slice(None), *self.index)
+        self._parent = dat
+        self._dataset = dat.dataset
+        self.name = "view[%s](%s)" % (self.index, dat.name)
+        self._halo_frozen = False
+        self._frozen_access_mode = None
+
+    # shared storage and state
+    _host = property(lambda self: self._parent._host)
+    _dev = property(lambda self: self._parent._dev)
+    _host_valid = property(lambda self: self._parent._host_valid)
+    _dev_valid = property(lambda self: self._parent._dev_valid)
+    dat_version = property(lambda self: self._parent.dat_version)
+    dtype = property(lambda self: self._parent.dtype)
+    cdim = property(lambda self: 1)
+    dim = property(lambda self: (1,))
+    shape = property(lambda self: (self._dataset.total_size,))
+
+    @property
+    def halo_valid(self):
+        return self._parent.halo_valid
+
+    @halo_valid.setter
+    def halo_valid(self, value):
+        self._parent.halo_valid = value
+
+    def _to_host(self):
+        return self._parent._to_host()
+
+    def _host_rw(self):
+        return self._parent._host_rw()
+
+    def _dev_ptr(self, write):
+        return self._parent._dev_ptr(write)
+
+    data = property(lambda self: self._parent.data[self._idx])
+    data_ro = property(lambda self: self._parent.data_ro[self._idx])
+    data_with_halos = property(lambda self: self._parent.data_with_halos[self._idx])
+    data_ro_with_halos = property(lambda self: self._parent.data_ro_with_halos[self._idx])
+    _data = property(lambda self: self._parent._host[self._idx])
+
+    def zero(self, subset=None):               # dat.py:297-311 on the view's slice
+        if subset is not None:
+            return Dat.zero(self, subset)
+        if self._parent._dev is not None and self._parent._dev_valid and _lib.gpu_available():
+            from .parloop import par_loop
+            par_loop(self._kernel("zero"), self._dataset.set, self(WRITE))
+            if self._dataset.set.total_size > self._dataset.set.size:     # ghosts too: "zero everywhere"
+                self._parent._host_rw()[(slice(self._dataset.size, None), *self.index)] = 0
+        else:
+            self._parent._host_rw()[self._idx] = 0
+            self._parent.dat_version += 1
+        self.halo_valid = True
+
+    def __call__(self, access, path=None):
+        from .parloop import DatLegacyArg
+        if configuration["type_check"] and path is not None and path.toset != self._dataset.set:
+            raise MapValueError("To Set of Map does not match Set of Dat.")
+        return DatLegacyArg(self, path, access)
+
+
 class MixedDat:
     """pyop2/types/dat.py:861-1243: a bag of Dats (the coefficient vector of a mixed function space).  Built from a
     MixedDataSet / MixedSet / iterable of (Data)Sets, or from an iterable of Dats."""

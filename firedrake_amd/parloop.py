@@ -104,7 +104,8 @@ class DatLegacyArg:
 
     @property
     def global_kernel_arg(self):
-        return DatKernelArg(self.data.dataset.dim, _map_kernel_arg(self.map_))
+        # a DatView passes its parent's row shape and the component it shows (parloop.py:595-601)
+        return DatKernelArg(self.data.dataset.dim, _map_kernel_arg(self.map_), getattr(self.data, "index", None))
 
     @property
     def parloop_arg(self):

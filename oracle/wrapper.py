@@ -57,6 +57,7 @@ class ODat:
     offset: Optional[Sequence[int]] = None  # extruded offsets per map entry
     perm: Optional[Sequence[int]] = None    # PermutedMap permutation
     offset_quotient: Optional[Sequence[int]] = None   # periodic extrusion (map.py:46-53)
+    view_index: Optional[int] = None      # DatView: flat position of the one component the kernel sees (dat.py:714-805)
 
     @property
     def cdim(self):
@@ -227,16 +228,24 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
         ar = a.map.shape[1]
         if a.perm is not None:
             table(f"{mn}_perm", a.perm)
-        n = nf * ar * c
         nexpr = node_expr(mn, ar, 'i', a.offset, a.perm, 'f', a.offset_quotient)
-        loop = f"for (int f = 0; f < {nf}; ++f) for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j)"
-        tt = f"{tname}[{toff} + (f*{ar}+i)*{c}+j]"
+        if a.view_index is not None:
+            # builder.py:347-349, 365-367: a view packs one value per node, taken at the fixed component
+            n = nf * ar
+            loop = f"for (int f = 0; f < {nf}; ++f) for (int i = 0; i < {ar}; ++i)"
+            tt = f"{tname}[{toff} + f*{ar}+i]"
+            comp = str(int(a.view_index))
+        else:
+            n = nf * ar * c
+            loop = f"for (int f = 0; f < {nf}; ++f) for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j)"
+            tt = f"{tname}[{toff} + (f*{ar}+i)*{c}+j]"
+            comp = "j"
         if access in (INC, WRITE):
             body_pack.append(f"for (int q = 0; q < {n}; ++q) {tname}[{toff} + q] = 0;")
         else:
-            body_pack.append(f"{loop} {tt} = {an}[(size_t)({nexpr})*{c} + j];")
+            body_pack.append(f"{loop} {tt} = {an}[(size_t)({nexpr})*{c} + {comp}];")
         if access != READ:
-            lhs = f"{an}[(size_t)({nexpr})*{c} + j]"
+            lhs = f"{an}[(size_t)({nexpr})*{c} + {comp}]"
             if threads and access == INC:
                 lhs = lhs.replace(f"{an}[", f"priv_{an}[", 1)
                 priv.append((an, ct, a.data.size))
@@ -280,7 +289,7 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
             c = a.cdim
             if a.map is None:
                 # direct: pointer straight into the Dat (builder.py:387-396)
-                body_call.append(f"&arg{k}[(size_t)e*{c}]")
+                body_call.append(f"&arg{k}[(size_t)e*{c}" + (f" + {a.view_index}" if a.view_index is not None else "") + "]")
                 continue
             body_pack.append(f"{ct} t{k}[{nf * a.map.shape[1] * c}];")
             emit_dat(f"arg{k}", a, a.access, f"t{k}", 0)

@@ -28,7 +28,13 @@ def oracle_pattern(sp):
 
 
 def _odat(a, access, iterset):
-    data = np.array(a.data.data_ro_with_halos, copy=True)
+    view = None
+    if isinstance(a.data, op2.DatView):          # the oracle gets the parent's rows and the component to look at
+        parent = a.data._parent
+        data = np.array(parent.data_ro_with_halos, copy=True)
+        view = int(np.ravel_multi_index(a.data.index, parent.dim))
+    else:
+        data = np.array(a.data.data_ro_with_halos, copy=True)
     m = a.map_
     perm = mv = off = quot = None
     if m is not None:
@@ -37,7 +43,7 @@ def _odat(a, access, iterset):
         mv = m._base().values_with_halo
         off = m.offset if iterset._extruded else None
         quot = m.offset_quotient if iterset._extruded else None
-    return oracle.ODat(data, int(access), mv, offset=off, perm=perm, offset_quotient=quot), data
+    return oracle.ODat(data, int(access), mv, offset=off, perm=perm, offset_quotient=quot, view_index=view), data
 
 
 def _omat(mat, maps, lgmaps, access, iterset, unroll=False):

@@ -79,7 +79,7 @@ def run_direct(pl, part=None):
                 outs[desc[1]] = csr
                 cargs.append(ctypes.c_void_p(csr.values.ctypes.data))
             elif isinstance(pa, (DatParloopArg, GlobalParloopArg)):
-                host = pa.data._host if pa.data._host_valid else pa.data._to_host()
+                host = pa.data._host if pa.data._host_valid else pa.data._to_host()     # a DatView: its parent's rows
                 a = np.array(host, copy=True)
                 outs[desc[1]] = a
                 cargs.append(ctypes.c_void_p(a.ctypes.data))

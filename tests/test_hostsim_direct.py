@@ -298,3 +298,56 @@ def test_variable_layers_matrix(region):
             rows.update(int(cm.values[e, i] + l + f) for f in range(nf) for i in range(6))
     touched = {r for r in range(got.nrows) if got.rowptr[r + 1] - got.rowptr[r] > 1}
     assert touched == rows
+
+
+# ---- DatView (pyop2/types/dat.py:714-805; tests/pyop2/test_dats.py:286-340) ------------------------------------------
+def test_dat_view_host_semantics():
+    s = op2.Set(5)
+    vdat = op2.Dat(op2.DataSet(s, 2), np.zeros(2 * 5), dtype=op2.ScalarType)
+    vdat.data[:, 0] = 3
+    vdat.data[:, 1] = 4
+    comp = op2.DatView(vdat, 1)
+    comp.data[:] = 7
+    assert not vdat.halo_valid and not comp.halo_valid
+    assert all(comp.data == 7) and all(vdat.data[:, 0] == 3) and all(vdat.data[:, 1] == 7)
+    comp.zero()
+    assert vdat.halo_valid and comp.halo_valid
+    assert all(comp.data == 0) and all(vdat.data[:, 0] == 3) and all(vdat.data[:, 1] == 0)
+    v2 = op2.Dat(op2.DataSet(s, 2), np.zeros(2 * 5), dtype=op2.ScalarType)
+    c2 = op2.DatView(v2, 1)
+    assert v2.halo_valid and c2.halo_valid and v2.dat_version == 0 and c2.dat_version == 0
+    c2.data_ro_with_halos
+    assert v2.halo_valid and c2.halo_valid and v2.dat_version == 0
+    c2.data_with_halos                                      # marks the parent's halo dirty and bumps its version
+    assert not v2.halo_valid and not c2.halo_valid and v2.dat_version == 1 and c2.dat_version == 1
+    assert c2.cdim == 1 and c2.dim == (1,) and c2.shape == (5,)
+    from firedrake_amd import exceptions
+    with pytest.raises(exceptions.IndexValueError):
+        op2.DatView(v2, 2)
+
+
+def test_dat_view_in_parloops():
+    rng = np.random.default_rng(31)
+    coords, cells = structured_tri_mesh(4, 3)
+    nodes, ele = op2.Set(len(coords)), op2.Set(len(cells))
+    m = op2.Map(ele, nodes, 3, cells)
+    v = op2.Dat(nodes ** 3, rng.standard_normal((len(coords), 3)))
+    out = op2.Dat(nodes ** 2, rng.standard_normal((len(coords), 2)))
+    # READ one component, INC into one component of another Dat
+    k = op2.Kernel("static void kvw(double *o, const double *a) { for (int i = 0; i < 3; ++i) o[i] += 2.0*a[i] + i; }", "kvw")
+    got = _check(k, ele, op2.DatView(out, 1)(op2.INC, m), op2.DatView(v, 2)(op2.READ, m))
+    exp = out.data_ro.copy()
+    for c in cells:
+        for i in range(3):
+            exp[c[i], 1] += 2.0 * v.data_ro[c[i], 2] + i
+    assert np.abs(got[0] - exp).max() < 1e-13 and np.array_equal(got[0][:, 0], out.data_ro[:, 0])
+    # direct loop over the nodes on a view: the kernel sees one value per node
+    kd = op2.Kernel("static void kd(double *x, const double *y) { x[0] = 3.0*y[0]; }", "kd")
+    got = _check(kd, nodes, op2.DatView(out, 0)(op2.WRITE), op2.DatView(v, 1)(op2.READ))
+    assert np.allclose(got[0][:, 0], 3.0 * v.data_ro[:, 1]) and np.array_equal(got[0][:, 1], out.data_ro[:, 1])
+    # a tensor-valued Dat: index (1, 0) of a (2, 2) row
+    t = op2.Dat(nodes ** (2, 2), rng.standard_normal((len(coords), 2, 2)))
+    g = op2.Global(1, 0.0)
+    ks = op2.Kernel("static void ks(double *g, const double *a) { g[0] += a[0] + a[1] + a[2]; }", "ks")
+    got = _check(ks, ele, g(op2.INC), op2.DatView(t, (1, 0))(op2.READ, m))
+    assert abs(got[0][0] - t.data_ro[:, 1, 0][cells].sum()) < 1e-12

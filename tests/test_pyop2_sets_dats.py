@@ -312,3 +312,28 @@ def test_extruded_write_and_rw(par_loop):
     # concurrent cells may both see a shared node at 0 and both write 1: the outcome is the sequential one
     par_loop(op2.Kernel(kernel_inc, "inc"), ext, dat_c(op2.RW, cmap), coords(op2.READ, cmap))
     assert dat_c.data.sum() == nodes.size * 2
+
+
+# ---- DatView (pyop2/types/dat.py:714-805, tests/pyop2/test_dats.py:286-340) -------------------------------------------
+@pytest.mark.gpu
+def test_dat_view_on_device():
+    rng = np.random.default_rng(31)
+    s = op2.Set(2000)
+    it = op2.Set(3000)
+    m = op2.Map(it, s, 2, rng.integers(0, 2000, size=(3000, 2)))
+    v = op2.Dat(s ** 3, rng.standard_normal((2000, 3)))
+    out = op2.Dat(s ** 2, rng.standard_normal((2000, 2)))
+    V, O = v.data_ro.copy(), out.data_ro.copy()
+    k = op2.Kernel("static void kvw(double *o, const double *a) { for (int i = 0; i < 2; ++i) o[i] += 2.0*a[i] + i; }", "kvw")
+    op2.par_loop(k, it, op2.DatView(out, 1)(op2.INC, m), op2.DatView(v, 2)(op2.READ, m))
+    exp = O.copy()
+    np.add.at(exp[:, 1], m.values[:, 0], 2.0 * V[m.values[:, 0], 2])
+    np.add.at(exp[:, 1], m.values[:, 1], 2.0 * V[m.values[:, 1], 2] + 1)
+    assert np.abs(out.data_ro - exp).max() < 1e-12 and np.array_equal(out.data_ro[:, 0], O[:, 0])
+    comp = op2.DatView(out, 0)
+    comp.zero()                                                  # one component zeroed on the device, the other untouched
+    assert (out.data_ro[:, 0] == 0).all() and np.abs(out.data_ro[:, 1] - exp[:, 1]).max() < 1e-12
+    kd = op2.Kernel("static void kd(double *x, const double *y) { x[0] = 3.0*y[0]; }", "kd")
+    op2.par_loop(kd, s, comp(op2.WRITE), op2.DatView(v, 1)(op2.READ))
+    assert np.allclose(out.data_ro[:, 0], 3.0 * V[:, 1])
+    assert comp.dat_version == out.dat_version
