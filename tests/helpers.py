@@ -98,6 +98,68 @@ def oracle_run(kernel, iterset, *args, iteration_region=None, pass_layer_arg=Fal
     return outs
 
 
+def plan_ref(mapv, start, end, epb):
+    """numpy restatement of the block-localisation plan (include/fdhip.h: fd_plan_create): per block of ``epb``
+    entities the sorted distinct nodes and, per entity, the positions of its nodes in that list."""
+    blk, lst, lm = [0], [], np.zeros((end - start, mapv.shape[1]), dtype=np.uint16)
+    for b0 in range(start, end, epb):
+        b1 = min(end, b0 + epb)
+        u, inv = np.unique(mapv[b0:b1].reshape(-1), return_inverse=True)
+        lst.append(u)
+        lm[b0 - start:b1 - start] = inv.reshape(b1 - b0, -1)
+        blk.append(blk[-1] + len(u))
+    return np.array(blk, np.int32), np.concatenate(lst).astype(np.int32) if lst else np.zeros(0, np.int32), lm
+
+
+def plan_ref_blocks(mapv, blocks):
+    """plan_ref over explicit block boundaries ``blocks`` (slot offsets, first = 0, last = len(mapv))."""
+    blk, lst, lm = [0], [], np.zeros((len(mapv), mapv.shape[1]), dtype=np.uint16)
+    for b in range(len(blocks) - 1):
+        b0, b1 = int(blocks[b]), int(blocks[b + 1])
+        u, inv = np.unique(mapv[b0:b1].reshape(-1), return_inverse=True)
+        lst.append(u)
+        lm[b0:b1] = inv.reshape(b1 - b0, -1)
+        blk.append(blk[-1] + len(u))
+    return (np.array(blk, np.int32), np.concatenate(lst).astype(np.int32) if lst else np.zeros(0, np.int32), lm)
+
+
+def ocr_plan_ref(rmapv, cmapv, nent, row_blocks, rowptr, colidx):
+    """numpy restatement of the owner-computes-rows plan (include/fdhip.h: fd_ocrplan_create in natural order +
+    fd_csr_elem_row_offsets): per block of row nodes the entities that touch one of its rows (*instances*, in entity
+    order), and per instance the position of every (i, j) entry inside its CSR row."""
+    inst_off, inst_ent = [0], []
+    for b in range(len(row_blocks) - 1):
+        hit = ((rmapv[:nent] >= row_blocks[b]) & (rmapv[:nent] < row_blocks[b + 1])).any(axis=1)
+        inst_ent.append(np.nonzero(hit)[0])
+        inst_off.append(inst_off[-1] + int(hit.sum()))
+    inst_ent = np.concatenate(inst_ent).astype(np.int32) if inst_ent else np.zeros(0, np.int32)
+    ar, ac = rmapv.shape[1], cmapv.shape[1]
+    kidx = np.zeros((len(inst_ent), ar * ac), dtype=np.uint8)
+    for s_, e in enumerate(inst_ent):
+        for i in range(ar):
+            r = rmapv[e, i]
+            row = colidx[rowptr[r]:rowptr[r + 1]]
+            for j in range(ac):
+                pos = int(np.searchsorted(row, cmapv[e, j]))
+                assert pos < len(row) and row[pos] == cmapv[e, j] and pos < 255
+                kidx[s_, i * ac + j] = pos
+    return np.array(inst_off, np.int32), inst_ent, kidx
+
+
+def lane_slot_to_entity(n, T):
+    """numpy restatement of the lane order (include/fdhip.h: fd_plan_set_lane_order): slot k*T + t holds the k-th
+    entity of lane t's contiguous run; the first n % T runs are one longer."""
+    q, rem = divmod(n, T)
+    ent = np.full(n, -1, dtype=np.int64)
+    for t in range(T):
+        cnt = q + 1 if t < rem else q
+        first = t * q + min(t, rem)
+        for k in range(cnt):
+            ent[k * T + t] = first + k
+    assert (ent >= 0).all() and len(set(ent.tolist())) == n
+    return ent
+
+
 def structured_tri_mesh(nx, ny, seed=0, perturb=0.0):
     """P1 triangles on a grid: (coords (nv,2), cells (nc,3) int32)."""
     xs, ys = np.meshgrid(np.linspace(0, 1, nx + 1), np.linspace(0, 1, ny + 1), indexing="xy")

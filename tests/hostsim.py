@@ -39,6 +39,184 @@ def _compile(source, name):
     return ctypes.CDLL(so)
 
 
+def _compile_mt(source, name):
+    os.makedirs(_BUILD, exist_ok=True)
+    key = hashlib.sha1(source.encode()).hexdigest()[:16]
+    so = os.path.join(_BUILD, f"{name}_mt_{key}.so")
+    if not os.path.exists(so):
+        src = os.path.join(_BUILD, f"{name}_mt_{key}.cpp")
+        with open(src, "w") as f:
+            f.write(source)
+        cmd = ["g++", "-O1", "-fPIC", "-shared", "-std=gnu++20", "-pthread", "-w", "-I", os.path.join(_HERE, "hostsim", "mt"),
+               "-o", so + ".tmp", src, "-lm"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hostsim (mt) compile failed:\n" + r.stderr[-4000:])
+        os.replace(so + ".tmp", so)
+    return ctypes.CDLL(so)
+
+
+def run_staged(pl, epb=48):
+    """Execute Parloop ``pl`` (Dat / Global arguments only) with the STAGED wrapper on the host: one OS thread per
+    lane, workgroups one after the other, real barriers and atomics (tests/hostsim/mt/fd_wrapper.h).  The
+    block-localisation plans come from the numpy restatement in helpers.py (itself checked against the device's
+    plans by the -m gpu suite), stored in lane order like the device's.  Returns COPIES like run_direct."""
+    import re
+    from firedrake_amd.codegen import mode_variant, staged_eligible
+    from helpers import lane_slot_to_entity, plan_ref
+    gk = pl.global_kernel
+    assert staged_eligible(gk) and not any(isinstance(pa, MatParloopArg) for pa in pl.arguments)
+    start, end = 0, pl.iterset.size
+    maps = []
+    for pa in pl.arguments:
+        for m in getattr(pa, "maps", ()):
+            if all(m._base() is not q for q in maps):
+                maps.append(m._base())
+    base = generate_wrapper(gk, "staged")
+    T = base.block_threads
+    plans = {}
+    for mi in base.staged_maps:
+        blk, lst, lm = plan_ref(np.asarray(maps[mi].values_with_halo), start, end, epb)
+        if base.lane_threads:                                   # lane order: slot k*T + t <- k-th entity of lane t's run
+            for b0 in range(start, end, epb):
+                b1 = min(end, b0 + epb)
+                lm[b0 - start:b1 - start] = lm[b0 - start:b1 - start][lane_slot_to_entity(b1 - b0, T)]
+        plans[mi] = (blk, lst, np.ascontiguousarray(lm), int(np.diff(blk).max()) if len(blk) > 1 else 0)
+    bstart = np.array(list(range(start, end, epb)) + [end], dtype=np.int32)
+    nblocks = len(bstart) - 1
+    src = generate_wrapper(gk, mode_variant("staged", 1, [plans[mi][3] for mi in base.staged_maps]))
+    text = src.source.replace("extern __shared__ __align__(16) unsigned char fd_lds[];", "unsigned char *fd_lds = fd_sim::lds;")
+    # driver: the kernel's own parameter list, run as nblocks workgroups of T lanes
+    sig = re.search(r'extern "C" __global__[^\n]*void %s\((.*)\)\n' % src.symbol, text).group(1)
+    names = [p.split()[-1].lstrip("*") for p in sig.split(", ")]
+    text += ('\nextern "C" void sim_run(int fd_nblocks, int fd_nthreads, %s)\n{\n  fd_sim::run(fd_nblocks, fd_nthreads, [&] { %s(%s); });\n}\n'
+             % (sig, src.symbol, ", ".join(names)))
+    lib = _compile_mt(text, src.symbol)
+    lib.sim_run.restype = None
+    outs, keep = {}, []
+
+    def ptr(a):
+        a = np.ascontiguousarray(a)
+        keep.append(a)
+        return ctypes.c_void_p(a.ctypes.data)
+
+    cargs = [ctypes.c_int(nblocks), ctypes.c_int(T), ctypes.c_int(start), ctypes.c_int(end)]
+    for desc in src.layout:
+        kind = desc[0]
+        if kind == "arg":
+            pa = pl.arguments[desc[1]]
+            host = pa.data._host if pa.data._host_valid else pa.data._to_host()
+            a = np.array(host, copy=True)
+            outs[desc[1]] = a
+            cargs.append(ctypes.c_void_p(a.ctypes.data))
+        elif kind == "map":
+            cargs.append(ptr(np.asarray(maps[desc[1]].values_with_halo, dtype=np.int32)))
+        elif kind == "bstart":
+            cargs.append(ptr(bstart))
+        elif kind == "plan_blkoff":
+            cargs.append(ptr(plans[desc[1]][0]))
+        elif kind == "plan_list":
+            cargs.append(ptr(plans[desc[1]][1]))
+        elif kind == "plan_lmap":
+            cargs.append(ptr(plans[desc[1]][2]))
+        elif kind == "plan_maxnd":
+            cargs.append(ctypes.c_longlong(plans[desc[1]][3]))
+        else:
+            raise AssertionError(f"hostsim (staged) cannot provide {kind}")
+    lib.sim_run(*cargs)
+    return [outs.get(k) for k in range(len(pl.arguments))]
+
+
+def run_ocr(pl, rows_per_block=24, zero_pending=True):
+    """Execute a matrix-assembly Parloop ``pl`` with the OWNER-COMPUTES-ROWS wrapper on the host (one OS thread per
+    lane, tests/hostsim/mt/fd_wrapper.h).  The plan tables come from the numpy restatements in helpers.py; the CSR
+    pattern from the oracle.  Returns the OracleCSR holding the assembled values."""
+    import re
+    from firedrake_amd.codegen import mode_variant, ocr_eligible
+    from helpers import ocr_plan_ref, plan_ref_blocks
+    gk = pl.global_kernel
+    assert ocr_eligible(gk)
+    (k, mpa), = [(k, pa) for k, pa in enumerate(pl.arguments) if isinstance(pa, MatParloopArg)]
+    maps = []
+    for pa in pl.arguments:
+        for m in getattr(pa, "maps", ()):
+            if all(m._base() is not q for q in maps):
+                maps.append(m._base())
+    base = generate_wrapper(gk, "ocr")
+    T = base.block_threads
+    csr = oracle_pattern(mpa.data.sparsity)
+    rmap, cmap = (m._base() for m in mpa.maps)
+    nent = pl.iterset.size
+    nrows = rmap.toset.size
+    rb = np.array(list(range(0, nrows, rows_per_block)) + [nrows], dtype=np.int32)
+    inst_off, inst_ent, kidx = ocr_plan_ref(np.asarray(rmap.values_with_halo), np.asarray(cmap.values_with_halo), nent, rb,
+                                            csr.rowptr, csr.colidx)
+    plans = {}
+    for mi in base.staged_maps:
+        blk, lst, lm = plan_ref_blocks(np.asarray(maps[mi].values_with_halo)[inst_ent], inst_off)
+        plans[mi] = (blk, lst, np.ascontiguousarray(lm), int(np.diff(blk).max()) if len(blk) > 1 else 0)
+    max_nnz = int(np.diff(csr.rowptr[rb]).max())
+    src = generate_wrapper(gk, mode_variant("ocr", 1, [plans[mi][3] for mi in base.staged_maps]))
+    text = src.source.replace("extern __shared__ __align__(16) unsigned char fd_lds[];", "unsigned char *fd_lds = fd_sim::lds;")
+    sig = re.search(r'extern "C" __global__[^\n]*void %s\((.*)\)\n' % src.symbol, text).group(1)
+    names = [p.split()[-1].lstrip("*") for p in sig.split(", ")]
+    text += ('\nextern "C" void sim_run(int fd_nblocks, int fd_nthreads, %s)\n{\n  fd_sim::run(fd_nblocks, fd_nthreads, [&] { %s(%s); });\n}\n'
+             % (sig, src.symbol, ", ".join(names)))
+    lib = _compile_mt(text, src.symbol)
+    lib.sim_run.restype = None
+    keep = []
+
+    def ptr(a):
+        a = np.ascontiguousarray(a)
+        keep.append(a)
+        return ctypes.c_void_p(a.ctypes.data)
+
+    if not zero_pending:
+        csr.values[...] = 1.0                     # accumulate on top of existing values
+    cargs = [ctypes.c_int(len(rb) - 1), ctypes.c_int(T), ctypes.c_int(0), ctypes.c_int(len(inst_ent))]
+    for desc in src.layout:
+        kind = desc[0]
+        if kind == "arg":
+            pa = pl.arguments[desc[1]]
+            if isinstance(pa, MatParloopArg):
+                cargs.append(ctypes.c_void_p(csr.values.ctypes.data))
+            else:
+                host = pa.data._host if pa.data._host_valid else pa.data._to_host()
+                cargs.append(ptr(np.array(host, copy=True)))
+        elif kind == "map":
+            cargs.append(ptr(np.asarray(maps[desc[1]].values_with_halo, dtype=np.int32)))
+        elif kind == "bstart":
+            cargs.append(ptr(inst_off))
+        elif kind == "ocr_inst_ent":
+            cargs.append(ptr(inst_ent))
+        elif kind == "plan_blkoff":
+            cargs.append(ptr(plans[desc[1]][0]))
+        elif kind == "plan_list":
+            cargs.append(ptr(plans[desc[1]][1]))
+        elif kind == "plan_lmap":
+            cargs.append(ptr(plans[desc[1]][2]))
+        elif kind == "plan_maxnd":
+            cargs.append(ctypes.c_longlong(plans[desc[1]][3]))
+        elif kind == "ocr_rblk":
+            cargs.append(ptr(rb))
+        elif kind == "ocr_rowptr":
+            cargs.append(ptr(csr.rowptr))
+        elif kind == "ocr_kidx":
+            cargs.append(ptr(kidx))
+        elif kind == "ocr_maxnnz":
+            cargs.append(ctypes.c_longlong(max_nnz))
+        elif kind == "ocr_maxnown":
+            cargs.append(ctypes.c_longlong(int(np.diff(rb).max())))
+        elif kind == "ocr_flags":
+            cargs.append(ctypes.c_longlong(1 if zero_pending else 0))
+        elif kind in ("mat_row_lgmap", "mat_col_lgmap"):
+            cargs.append(ptr(np.asarray(mpa.lgmaps[0 if kind == "mat_row_lgmap" else 1], dtype=np.int32)))
+        else:
+            raise AssertionError(f"hostsim (ocr) cannot provide {kind}")
+    lib.sim_run(*cargs)
+    return csr
+
+
 def run_direct(pl, part=None):
     """Execute Parloop ``pl`` over ``part`` = (offset, size) (default: all owned entities) with the direct
     wrapper on the host.  Returns one array per argument: COPIES of Dat/Global data after the loop, or an

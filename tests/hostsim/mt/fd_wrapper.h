@@ -1,0 +1,125 @@
+// tests/hostsim/mt/fd_wrapper.h -- TEST INFRASTRUCTURE ONLY (never shipped, never on the product path).
+//
+// Multi-threaded host stand-in for firedrake_amd/csrc/fd_wrapper.h: lets g++ compile a STAGED wrapper kernel emitted
+// by firedrake_amd/codegen.py and execute it with one OS thread per lane of a workgroup (workgroups one after the
+// other).  __syncthreads() is a real barrier, LDS is a shared buffer, LDS/global atomics are CAS loops -- so the
+// staging phase, the lane-ordered main loop, the LDS reduction and the flush run with the same structure (and the
+// same races to get right) as on the device.  tests/hostsim.py drives it to check the staged code path against the
+// oracle on machines without a GPU.  The device helpers below are restated as plain C++ (same contracts as the real
+// header); nothing under firedrake_amd/ can reach this file.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <math.h>
+#include <barrier>
+#include <functional>
+#include <thread>
+#include <type_traits>
+#include <vector>
+
+#define __device__
+#define __global__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static            /* static LDS arrays: one copy shared by all lanes (workgroups run one at a time) */
+#define __align__(x)
+#define restrict __restrict__
+
+typedef double PetscScalar;
+typedef double PetscReal;
+typedef int PetscInt;
+
+struct fd_sim_dim3 { int x, y, z; };
+static thread_local fd_sim_dim3 threadIdx = {0, 0, 0}, blockIdx = {0, 0, 0};
+static fd_sim_dim3 blockDim = {1, 1, 1}, gridDim = {1, 1, 1};
+
+namespace fd_sim {
+static std::barrier<> *bar = nullptr;
+alignas(16) static unsigned char lds[160 * 1024];        // dynamic LDS of the running workgroup
+static double red_scratch[2048];
+
+// run `body` as `nblocks` workgroups of `nthreads` lanes: every OS thread is one lane and walks the workgroups in order
+inline void run(int nblocks, int nthreads, const std::function<void()> &body) {
+    blockDim.x = nthreads; gridDim.x = nblocks;
+    std::barrier<> b(nthreads);
+    bar = &b;
+    std::vector<std::thread> ts;
+    for (int t = 0; t < nthreads; ++t)
+        ts.emplace_back([&, t] {
+            threadIdx.x = t;
+            for (int blk = 0; blk < nblocks; ++blk) {
+                blockIdx.x = blk;
+                body();
+                bar->arrive_and_wait();                    // the next workgroup reuses the LDS buffer
+            }
+        });
+    for (auto &t : ts) t.join();
+    bar = nullptr;
+}
+
+template <class T, class F> inline void cas_update(T *p, F f) {
+    typedef typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type U;
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "32- or 64-bit atomics");
+    U o = __atomic_load_n((U *)p, __ATOMIC_RELAXED);
+    for (;;) {
+        T old;
+        __builtin_memcpy(&old, &o, sizeof(T));
+        const T neu = f(old);
+        U n;
+        __builtin_memcpy(&n, &neu, sizeof(T));
+        if (__atomic_compare_exchange_n((U *)p, &o, n, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) return;
+    }
+}
+}  // namespace fd_sim
+
+static inline void __syncthreads() { fd_sim::bar->arrive_and_wait(); }
+template <class T> inline T atomicAdd(T *p, T v) { fd_sim::cas_update(p, [v](T o) { return o + v; }); return v; }
+
+namespace fdw {
+inline int xcd_block(int bid, int nb) {
+    const int q = nb >> 3, r = nb & 7;
+    const int x = bid & 7, k = bid >> 3;
+    return x * q + (x < r ? x : r) + k;
+}
+template <class T> inline void atomic_add(T *p, T v) { fd_sim::cas_update(p, [v](T o) { return o + v; }); }
+template <class T> inline void atomic_min(T *p, T v) { fd_sim::cas_update(p, [v](T o) { return v < o ? v : o; }); }
+template <class T> inline void atomic_max(T *p, T v) { fd_sim::cas_update(p, [v](T o) { return v > o ? v : o; }); }
+inline int wrap_layer(int a, int nl) { return a % nl; }
+
+inline int csr_find(const int *rowptr, const int *colidx, int r, int c) {
+    for (int q = rowptr[r]; q < rowptr[r + 1]; ++q)
+        if (colidx[q] == c) return q;
+    return -1;
+}
+
+template <class T> struct OpAdd { static T f(T a, T b) { return a + b; } };
+template <class T> struct OpMin { static T f(T a, T b) { return a < b ? a : b; } };
+template <class T> struct OpMax { static T f(T a, T b) { return a > b ? a : b; } };
+
+// all lanes call; result valid on lane 0 (same contract as the device version)
+template <class T, class Op> inline T block_reduce(T v, T *) {
+    T *s = (T *)fd_sim::red_scratch;
+    __syncthreads();
+    s[threadIdx.x] = v;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int i = 1; i < blockDim.x; ++i) v = Op::f(v, s[i]);
+    __syncthreads();
+    return v;
+}
+
+template <class T> inline T rep_sum(const T *s, int q, int rsh) {
+    if (rsh == 0) return s[q];
+    const int R = 1 << rsh;
+    const T *p = s + ((size_t)q << rsh);
+    T v = 0;
+    for (int r = 0; r < R; ++r) v += p[r];
+    return v;
+}
+
+template <class T, int N> inline void load_packed(const T *p, int (&out)[N]) {
+    for (int k = 0; k < N; ++k) out[k] = p[k];
+}
+template <int ARITY> inline void load_lmap(const uint16_t *p, int (&out)[ARITY]) { load_packed<uint16_t, ARITY>(p, out); }
+}  // namespace fdw

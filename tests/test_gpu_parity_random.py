@@ -7,20 +7,9 @@ from numpy.testing import assert_allclose
 from firedrake_amd import op2
 from firedrake_amd.configuration import configuration
 import golden_kernels as gk
-from helpers import oracle_run, structured_tri_mesh
+from helpers import lane_slot_to_entity as _lane_slot_to_entity, oracle_run, plan_ref as _plan_ref, structured_tri_mesh
 
 pytestmark = pytest.mark.gpu
-
-
-def _plan_ref(mapv, start, end, epb):
-    blk, lst, lm = [0], [], np.zeros((end - start, mapv.shape[1]), dtype=np.uint16)
-    for b0 in range(start, end, epb):
-        b1 = min(end, b0 + epb)
-        u, inv = np.unique(mapv[b0:b1].reshape(-1), return_inverse=True)
-        lst.append(u)
-        lm[b0 - start:b1 - start] = inv.reshape(b1 - b0, -1)
-        blk.append(blk[-1] + len(u))
-    return np.array(blk, np.int32), np.concatenate(lst).astype(np.int32), lm
 
 
 @pytest.mark.parametrize("arity,epb,n", [(3, 256, 5000), (4, 1024, 20000), (10, 512, 7001), (1, 64, 130), (8, 2048, 4096)])
@@ -54,20 +43,6 @@ def test_plan_with_explicit_blocks():
         assert np.array_equal(lst[blk[b]:blk[b + 1]], u)
         assert np.array_equal(lm[blocks[b]:blocks[b + 1]].reshape(-1), inv)
     assert p.nblocks == len(blocks) - 1
-
-
-def _lane_slot_to_entity(n, T):
-    """numpy restatement of the lane order (include/fdhip.h: fd_plan_set_lane_order): slot k*T + t holds the k-th
-    entity of lane t's contiguous run; the first n % T runs are one longer."""
-    q, rem = divmod(n, T)
-    ent = np.full(n, -1, dtype=np.int64)
-    for t in range(T):
-        cnt = q + 1 if t < rem else q
-        first = t * q + min(t, rem)
-        for k in range(cnt):
-            ent[k * T + t] = first + k
-    assert (ent >= 0).all() and len(set(ent.tolist())) == n
-    return ent
 
 
 @pytest.mark.parametrize("T", [64, 256, 512])
@@ -114,6 +89,31 @@ def test_ocr_instance_orders_are_permutations(order, monkeypatch):
         got = np.sort(ent[op.inst_off_host[b]:op.inst_off_host[b + 1]])
         touch = ((vals[:m.cell_set.size] >= rb[b]) & (vals[:m.cell_set.size] < rb[b + 1])).any(axis=1)
         assert np.array_equal(got, np.nonzero(touch)[0])
+
+
+def test_ocr_plan_matches_numpy_restatement(monkeypatch):
+    """The numpy restatement the host-sim of the owner-computes-rows wrapper runs on (helpers.ocr_plan_ref) equals the
+    device's plan in natural order: instance offsets, instance lists and the per-instance row-offset table."""
+    from firedrake_amd import _lib, mesh as fmesh
+    from firedrake_amd.op2types import OcrPlan
+    from helpers import ocr_plan_ref
+    monkeypatch.setitem(configuration, "ocr_order", "natural")
+    monkeypatch.setitem(configuration, "ocr_pack", 0)
+    m = fmesh.UnitCubeMesh(5, degrees=(1,), tile=(4, 2, 2), perturb=0.1)
+    V = m.space(1)
+    cm = V.cell_node_map
+    sp = op2.Sparsity((V.node_set ** 1, V.node_set ** 1), [(cm, cm, None)])
+    sp._build()
+    nrows = V.node_set.size
+    rb = np.unique(np.concatenate([np.arange(0, nrows, 29), [nrows]])).astype(np.int32)
+    op = OcrPlan(sp, cm, cm, {0: cm}, 0, m.cell_set.size, rb, lane_threads=0)
+    inst_off, inst_ent, kidx = ocr_plan_ref(cm.values_with_halo, cm.values_with_halo, m.cell_set.size, rb, sp.rowptr, sp.colidx)
+    assert np.array_equal(op.inst_off_host, inst_off)
+    ent = np.empty(op.ninst, dtype=np.int32)
+    _lib.call("fd_memcpy_d2h", ent.ctypes.data, op.inst_ent, ent.nbytes, None)
+    assert np.array_equal(ent, inst_ent)
+    assert op.kbytes == 1
+    assert np.array_equal(op.kidx.download(np.uint8, kidx.shape), kidx)
 
 
 @pytest.mark.parametrize("nx,ny", [(7, 5), (64, 64), (200, 150)])

@@ -351,3 +351,72 @@ def test_dat_view_in_parloops():
     ks = op2.Kernel("static void ks(double *g, const double *a) { g[0] += a[0] + a[1] + a[2]; }", "ks")
     got = _check(ks, ele, g(op2.INC), op2.DatView(t, (1, 0))(op2.READ, m))
     assert abs(got[0][0] - t.data_ro[:, 1, 0][cells].sum()) < 1e-12
+
+
+# ---- the STAGED wrapper (LDS staging, lane order, LDS reduction, flush) with one OS thread per lane ---------------------
+@pytest.mark.parametrize("lane_strided", [1, 0])
+def test_staged_wrapper_residuals_on_host(lane_strided, monkeypatch):
+    """The hot residual path: staged wrappers of the P1 right-hand side (golden kernel) and of the benchmark's Poisson
+    residuals (P1 and P2, compile-time LDS strides) against the oracle, on a mesh that spans several plan blocks."""
+    from firedrake_amd import forms
+    from firedrake_amd.configuration import configuration
+    from hostsim import run_staged
+    monkeypatch.setitem(configuration, "lane_strided", lane_strided)
+    coords, cells = structured_tri_mesh(9, 8, perturb=0.2)
+    nodes, ele = op2.Set(len(coords)), op2.Set(len(cells))
+    m = op2.Map(ele, nodes, 3, cells)
+    x = op2.Dat(nodes ** 2, coords)
+    f = op2.Dat(nodes, np.random.default_rng(1).standard_normal(len(coords)))
+    k = op2.Kernel(gk.RHS_Q6, "rhs_q6")
+    args = (op2.Dat(nodes)(op2.INC, m), x(op2.READ, m), f(op2.READ, m))
+    got = run_staged(op2.LegacyParloop(k, ele, *args), epb=40)[0]
+    ref = oracle_run(k, ele, *args)[0]
+    assert np.abs(got - ref).max() <= 1e-13 * max(1.0, np.abs(ref).max())
+    u = op2.Dat(nodes, np.random.default_rng(2).standard_normal(len(coords)))
+    kr = forms.poisson_residual_kernel(2, 1)
+    args = (op2.Dat(nodes)(op2.INC, m), x(op2.READ, m), u(op2.READ, m), f(op2.READ, m))
+    got = run_staged(op2.LegacyParloop(kr, ele, *args), epb=33)[0]
+    ref = oracle_run(kr, ele, *args)[0]
+    assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+
+
+def test_staged_wrapper_p2_tets_and_global_reduction_on_host():
+    from firedrake_amd import forms, mesh as fmesh
+    from hostsim import run_staged
+    mesh = fmesh.UnitCubeMesh(3, degrees=(1, 2), perturb=0.1)
+    prob = forms.PoissonProblem(mesh, 2, bcs=False)
+    pl = prob.res_loop                                             # arity-10 map + arity-4 coordinate map, 512 lanes
+    got = run_staged(pl, epb=70)
+    ref_args = [pa.data(acc, pa.map_) for pa, acc in zip(pl.arguments, pl.accesses)]
+    ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *ref_args)[0]
+    assert np.abs(got[0] - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    # an indirect READ with a Global INC (block reduction) in the staged shape
+    cm = mesh.space(1).cell_node_map
+    d = mesh.space(1).dat(data=np.random.default_rng(3).standard_normal(mesh.space(1).node_set.total_size))
+    g = op2.Global(1, 0.0)
+    kg = op2.Kernel("static void kg(double *g, const double *d) { g[0] += d[0] - 2*d[1] + d[2]*d[3]; }", "kg")
+    got = run_staged(op2.LegacyParloop(kg, mesh.cell_set, g(op2.INC), d(op2.READ, cm)), epb=50)[0]
+    ref = oracle_run(kg, mesh.cell_set, op2.Global(1, 0.0)(op2.INC), d(op2.READ, cm))[0]
+    assert abs(got[0] - ref[0]) <= 1e-11 * max(1.0, abs(ref[0]))
+
+
+@pytest.mark.parametrize("bcs", [False, True])
+def test_owner_computes_rows_wrapper_on_host(bcs):
+    """The hot Jacobian path: the owner-computes-rows wrapper (instance lists, per-instance row-offset table, LDS row
+    accumulators, complete-row flush, BC masking through the lgmaps) of the benchmark's P1 and P2 Poisson Jacobians
+    against the oracle's MatSetValuesLocal."""
+    from firedrake_amd import forms, mesh as fmesh
+    from hostsim import run_ocr
+    mesh = fmesh.UnitCubeMesh(3, degrees=(1, 2), perturb=0.1)
+    for degree in (1, 2):
+        prob = forms.PoissonProblem(mesh, degree, bcs=bcs)
+        mat, pl = prob.jacobian()
+        mpa = pl.arguments[0]
+        got = run_ocr(pl, rows_per_block=17 if degree == 1 else 40)
+        args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
+        ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
+        assert np.array_equal(got.rowptr, ref.rowptr) and np.array_equal(got.colidx, ref.colidx)
+        assert np.abs(got.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
+        if degree == 1:                              # accumulate into existing values (no pending Mat.zero())
+            got2 = run_ocr(pl, rows_per_block=17, zero_pending=False)
+            assert np.abs(got2.values - (ref.values + 1.0)).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
