@@ -328,14 +328,15 @@ def main():
         # HBM bytes per launch from the rocprofv3 PMC passes of this same command (tools/pmc.sh ->
         # profiles/r1i_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) KB, MI355X_MICROARCH.md HBM section); only
         # valid for the default workload it was collected on
-        tpath = os.path.join(ROOT, "profiles", "r1i_traffic.json")
-        if os.path.exists(tpath) and n == 215 and args.degree == 1 and world == 1 and args.tile == "8,8,4":
-            tr = json.load(open(tpath))
+        tname = next((t for t in ("r1j_traffic.json", "r1i_traffic.json")
+                      if os.path.exists(os.path.join(ROOT, "profiles", t))), None)
+        if tname and n == 215 and args.degree == 1 and world == 1 and args.tile == "8,8,4":
+            tr = json.load(open(os.path.join(ROOT, "profiles", tname)))
             for roof in (roof_res, roof_jac):
                 t = tr.get(roof["kernel"], {}).get("hbm_bytes_per_launch")
                 if t:
                     roof["traffic"] = t
-                    roof["traffic_source"] = "profiles/r1i_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes)"
+                    roof["traffic_source"] = f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes)"
         dominant = roof_jac if t_jac >= t_res else roof_res
         out = {
             "metric": "assembled DoFs/sec (residual + Jacobian)",
