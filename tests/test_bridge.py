@@ -97,3 +97,28 @@ def test_function_level_seam_builds_the_direct_wrapper():
     if not _lib.gpu_available():
         with pytest.raises(_lib.FDHipError):                 # no device, no fallback
             func(0, 2, 0, 0, 0, 0)
+
+
+@pytest.mark.gpu
+def test_function_level_seam_on_device():
+    """func(start, end, *arglist) with device pointers in the reference's positional order."""
+    from firedrake_amd.device import DeviceBuffer
+    rng = np.random.default_rng(0)
+    nn, ne = 500, 900
+    cells = rng.integers(0, nn, size=(ne, 3)).astype(np.int32)
+    x, f = rng.standard_normal((nn, 2)), rng.standard_normal(nn)
+    m = MapKernelArg(arity=3)
+    lk = CStringLocalKernel(code=RHS, name="rhs", accesses=(4, 1, 1), dtypes=(np.float64,) * 3)
+    gk = GlobalKernel(local_kernel=lk, arguments=[DatKernelArg(dim=(), map_=m), DatKernelArg(dim=(2,), map_=m),
+                                                  DatKernelArg(dim=(1,), map_=m)])
+    func = bridge.compile_global_kernel_hip(gk)
+    b_d, x_d, f_d, m_d = (DeviceBuffer.from_numpy(a) for a in (np.zeros(nn), x, f, cells))
+    func(0, ne, b_d.ptr, x_d.ptr, f_d.ptr, m_d.ptr)
+    func(0, ne // 2, b_d.ptr, x_d.ptr, f_d.ptr, m_d.ptr)            # a second, partial range accumulates
+    exp = np.zeros(nn)
+    for rng_ in (range(ne), range(ne // 2)):
+        for e in rng_:
+            for i in range(3):
+                exp[cells[e, i]] += x[cells[e, i], 0] * f[cells[e, i]]
+    got = b_d.download(np.float64, (nn,))
+    assert np.abs(got - exp).max() < 1e-12 * max(1.0, np.abs(exp).max())
