@@ -103,3 +103,20 @@ def test_dg_advection_time_loop_conserves_mass_and_is_l2_stable():
                     [ODat(dq, oracle.WRITE, m.cell_dq.values), ODat(np.array(m.coordinates.data_ro), READ, m.cell_q1.values),
                      ODat(L, READ, m.cell_dq.values)])
     assert_allclose(st.dq.data_ro, dq, rtol=0, atol=1e-11 * np.abs(dq).max())
+
+
+@pytest.mark.parametrize("lane_strided", [1, 0])
+def test_dg_rhs_staged_wrappers_on_host(lane_strided, monkeypatch):
+    """The three staged wrappers of the demo's RHS (cell, exterior-facet and interior-facet loops: arity-8 maps, a
+    direct uint32 facet-number Dat addressed through the lane-order entity formula, READ Globals) executed by the
+    multi-threaded host-sim, chained like assemble_rhs, against the oracle."""
+    from hostsim import run_staged
+    monkeypatch.setitem(configuration, "lane_strided", lane_strided)
+    m = fmesh.make_quad_mesh(9, tile=(4, 4), perturb=0.15)
+    prob = forms.DGAdvectionProblem(m)
+    L = np.zeros(m.dq_set.total_size)
+    for loop, epb in zip(prob.loops, (30, 16, 70)):
+        prob.L._host_rw()[...] = L                       # the loops accumulate into the same Dat
+        L = run_staged(loop, epb=epb)[0]
+    ref = _oracle_rhs(prob)
+    assert np.abs(L - ref).max() <= 1e-12 * np.abs(ref).max()

@@ -420,3 +420,30 @@ def test_owner_computes_rows_wrapper_on_host(bcs):
         if degree == 1:                              # accumulate into existing values (no pending Mat.zero())
             got2 = run_ocr(pl, rows_per_block=17, zero_pending=False)
             assert np.abs(got2.values - (ref.values + 1.0)).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
+
+
+def test_staged_wrapper_mixed_and_other_dtypes_on_host():
+    """Staged wrappers beyond fp64 scalars: a flattened mixed residual (two maps, vector block) and INC into
+    float32 / int32 / uint32 Dats with arity 27 and cdim 2 (LDS atomics of every staged dtype)."""
+    from hostsim import run_staged
+    from mixed_cases import mixed_kernels, velocity_pressure_space
+    ele, mset, mmap, x, vmap = velocity_pressure_space(6, 5, 2)
+    mds = op2.MixedDataSet(mset, (2, 1))
+    rng = np.random.default_rng(4)
+    w = op2.MixedDat([op2.Dat(ds, rng.standard_normal((ds.total_size,) + (() if ds.cdim == 1 else ds.dim))) for ds in mds])
+    b = op2.MixedDat(mds)
+    _, res = mixed_kernels(2)
+    pl = op2.LegacyParloop(res, ele, b(op2.INC, mmap), x(op2.READ, vmap), w(op2.READ, mmap))
+    got = run_staged(pl, epb=25)
+    ref = oracle_run(res, ele, op2.MixedDat(mds)(op2.INC, mmap), x(op2.READ, vmap), w(op2.READ, mmap))[0]
+    for g, r in zip(got[:2], ref):
+        assert np.abs(g - r).max() <= 1e-12 * max(1.0, np.abs(r).max())
+    it, tgt = op2.Set(300), op2.Set(90)
+    m27 = op2.Map(it, tgt, 27, rng.integers(0, 90, size=(300, 27)))
+    for dt, ct in ((np.float32, "float"), (np.int32, "int"), (np.uint32, "unsigned int")):
+        src = op2.Dat(it, rng.integers(1, 9, size=300), dtype=dt)
+        acc = op2.Dat(tgt ** 2, dtype=dt)
+        k = op2.Kernel("static void acc27(%s *a, const %s *s) { for (int i = 0; i < 27; ++i) { a[2*i] += s[0]; a[2*i+1] += 2*s[0]; } }" % (ct, ct), "acc27")
+        got = run_staged(op2.LegacyParloop(k, it, acc(op2.INC, m27), src(op2.READ)), epb=64)[0]
+        ref = oracle_run(k, it, op2.Dat(tgt ** 2, dtype=dt)(op2.INC, m27), src(op2.READ))[0]
+        assert np.array_equal(got, ref)
