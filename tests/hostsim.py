@@ -1,10 +1,13 @@
-"""TEST INFRASTRUCTURE ONLY: run a DIRECT-mode wrapper emitted by firedrake_amd/codegen.py on the host.
+"""TEST INFRASTRUCTURE ONLY: run the wrappers emitted by firedrake_amd/codegen.py on the host.
 
-The generated HIP source is compiled by g++ against tests/hostsim/fd_wrapper.h (a sequential one-lane
-stand-in for csrc/fd_wrapper.h) and called with host pointers in the kernel's own parameter order
-(``WrapperSource.layout``).  This checks the code generator's indexing logic -- maps, extruded offsets,
-layer bounds, subsets, lgmap masking, CSR search -- against the oracle where no GPU is available.  It is
-not a fallback: nothing under firedrake_amd/ can reach it, and the product path still raises without a GPU.
+``run_direct``: the generated HIP source of a DIRECT-mode wrapper is compiled by g++ against
+tests/hostsim/fd_wrapper.h (a sequential one-lane stand-in for csrc/fd_wrapper.h) and called with host pointers in
+the kernel's own parameter order (``WrapperSource.layout``): maps, extruded offsets, layer bounds, subsets, lgmap
+masking, CSR search.  ``run_staged`` / ``run_ocr``: STAGED and OWNER-COMPUTES-ROWS wrappers compiled against
+tests/hostsim/mt/fd_wrapper.h and executed with one OS thread per lane (real barriers, a shared LDS buffer, CAS
+atomics), on plan tables built by the numpy restatements in helpers.py.  Everything is compared with the oracle by the
+callers.  This is not a fallback: nothing under firedrake_amd/ can reach it, and the product path still raises
+without a GPU.
 """
 import ctypes
 import hashlib

@@ -5,8 +5,7 @@ import numpy as np
 import pytest
 
 from firedrake_amd import mesh as fmesh, op2
-from firedrake_amd.interpolation import (QUAD_VERTEX_POINTS, Interpolator, Space, q1_quad, simplex_lagrange,
-                                         simplex_node_points)
+from firedrake_amd.interpolation import Interpolator, Space, simplex_lagrange, simplex_node_points
 from helpers import oracle_run
 
 
