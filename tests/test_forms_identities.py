@@ -133,3 +133,47 @@ def test_partitioned_cube_halo_lists_are_consistent(nranks):
             cm = V.cell_node_map.values_with_halo
             assert cm[:p.cell_set.core_size].max() < V.node_set.size
             assert cm.max() < V.node_set.total_size
+
+
+def _element_tensor(kernel, nd, coords):
+    """One call of a local kernel on a single element, through the oracle's wrapper (a one-cell mesh)."""
+    nv = len(coords)
+    cm = np.arange(nd, dtype=np.int32).reshape(1, nd)
+    xm = np.arange(nv, dtype=np.int32).reshape(1, nv)
+    A = oracle.build_sparsity(nd, nd, [(cm, cm)])
+    oracle.par_loop(kernel.code, kernel.name, 0, 1, [OMat(A, INC, cm, cm), ODat(np.ascontiguousarray(coords, dtype=float), READ, xm)])
+    return A.todense()
+
+
+def test_p1_element_tensors_are_the_textbook_ones():
+    """Known answers for the hand-restated local kernels (no reference test stores element tensors -- SURVEY.md 8c): the
+    P1 stiffness and mass matrices of the unit right triangle / tetrahedron, and their affine scaling laws."""
+    tri = np.array([[0, 0], [1, 0], [0, 1]], dtype=float)
+    tet = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], dtype=float)
+    K2 = _element_tensor(forms.poisson_jacobian_kernel(2, 1), 3, tri)
+    assert_allclose(K2, 0.5 * np.array([[2, -1, -1], [-1, 1, 0], [-1, 0, 1]]), atol=1e-15)
+    M2 = _element_tensor(forms.mass_kernel(2, 1), 3, tri)
+    assert_allclose(M2, (np.ones((3, 3)) + np.eye(3)) / 24.0, atol=1e-15)
+    K3 = _element_tensor(forms.poisson_jacobian_kernel(3, 1), 4, tet)
+    assert_allclose(K3, np.array([[3, -1, -1, -1], [-1, 1, 0, 0], [-1, 0, 1, 0], [-1, 0, 0, 1]]) / 6.0, atol=1e-15)
+    M3 = _element_tensor(forms.mass_kernel(3, 1), 4, tet)
+    assert_allclose(M3, (np.ones((4, 4)) + np.eye(4)) / 120.0, atol=1e-15)
+    # x -> s*x: mass scales with s^d, stiffness with s^(d-2); a rotation leaves both unchanged
+    s = 0.37
+    assert_allclose(_element_tensor(forms.mass_kernel(3, 1), 4, s * tet), s ** 3 * M3, rtol=1e-13)
+    assert_allclose(_element_tensor(forms.poisson_jacobian_kernel(3, 1), 4, s * tet), s * K3, rtol=1e-13)
+    assert_allclose(_element_tensor(forms.poisson_jacobian_kernel(2, 1), 3, s * tri), K2, rtol=1e-13)
+    th = 0.7
+    R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    assert_allclose(_element_tensor(forms.poisson_jacobian_kernel(2, 1), 3, tri @ R.T + 3.0), K2, atol=1e-14)
+
+
+def test_p2_element_mass_matrix_is_the_textbook_one():
+    """P2 on the unit right triangle (vertices, then the edges opposite to them -- FIAT's order): the classical
+    (1/360) mass matrix; vertices couple to their two adjacent edges with 0 and to the opposite edge with -4."""
+    tri = np.array([[0, 0], [1, 0], [0, 1]], dtype=float)
+    M = _element_tensor(forms.mass_kernel(2, 2), 6, tri) * 360.0
+    vv = np.array([[6, -1, -1], [-1, 6, -1], [-1, -1, 6]])
+    ee = np.array([[32, 16, 16], [16, 32, 16], [16, 16, 32]])
+    ve = np.array([[-4, 0, 0], [0, -4, 0], [0, 0, -4]])                 # vertex i vs the edge opposite to vertex i
+    assert_allclose(M, np.block([[vv, ve], [ve.T, ee]]), atol=1e-12)
