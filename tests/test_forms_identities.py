@@ -177,3 +177,31 @@ def test_p2_element_mass_matrix_is_the_textbook_one():
     ee = np.array([[32, 16, 16], [16, 32, 16], [16, 16, 32]])
     ve = np.array([[-4, 0, 0], [0, -4, 0], [0, 0, -4]])                 # vertex i vs the edge opposite to vertex i
     assert_allclose(M, np.block([[vv, ve], [ve.T, ee]]), atol=1e-12)
+
+
+def test_q4_hex_element_matrix_is_the_kronecker_product_of_exact_1d_matrices():
+    """Known answer for the C3 local kernel (which the fp64-MFMA kernel is compared with on the GPU): on the box
+    [0,a]x[0,b]x[0,c] the Q4 Helmholtz matrix is K1(a) (x) M1(b) (x) M1(c) + M1 (x) K1 (x) M1 + M1 (x) M1 (x) K1 +
+    M1 (x) M1 (x) M1, with the 1-D CG4 mass / stiffness matrices on GLL nodes integrated EXACTLY here by polynomial
+    algebra (independent of the kernel's quadrature tables; 5 Gauss points integrate degree 8 exactly)."""
+    from numpy.polynomial import polynomial as P
+    nodes = fmesh._gll_nodes(4)
+    basis = []
+    for i in range(5):
+        p = np.array([1.0])
+        for m in range(5):
+            if m != i:
+                p = P.polymul(p, np.array([-nodes[m], 1.0]) / (nodes[i] - nodes[m]))
+        basis.append(p)
+
+    def integ(p):
+        q = P.polyint(p)
+        return P.polyval(1.0, q) - P.polyval(0.0, q)
+    M1 = np.array([[integ(P.polymul(bi, bj)) for bj in basis] for bi in basis])
+    K1 = np.array([[integ(P.polymul(P.polyder(bi), P.polyder(bj))) for bj in basis] for bi in basis])
+    a, b, c = 0.7, 1.3, 0.45
+    exact = (np.kron(np.kron(K1 / a, M1 * b), M1 * c) + np.kron(np.kron(M1 * a, K1 / b), M1 * c)
+             + np.kron(np.kron(M1 * a, M1 * b), K1 / c) + np.kron(np.kron(M1 * a, M1 * b), M1 * c))
+    verts = np.array([[x * a, y * b, z * c] for x in (0, 1) for y in (0, 1) for z in (0, 1)], dtype=float)   # v = 4x+2y+z
+    A = _element_tensor(forms.helmholtz_q4_hex_jacobian_kernel(), 125, verts)
+    assert_allclose(A, exact, atol=1e-12 * np.abs(exact).max())
