@@ -120,3 +120,26 @@ def test_dg_rhs_staged_wrappers_on_host(lane_strided, monkeypatch):
         L = run_staged(loop, epb=epb)[0]
     ref = _oracle_rhs(prob)
     assert np.abs(L - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_dg_cell_and_facet_kernels_known_answers():
+    """Known answers on the unit square cell with u = (1, 0), q = 1 (vertex a*2 + b at (a, b)):
+    cell term dt * int u.grad(phi_i) = dt * (-1/2, -1/2, 1/2, 1/2); the exterior facets at x = 1 (outflow, facet 1)
+    give -dt * int phi_i q u.n = -dt * (0, 0, 1/2, 1/2), at x = 0 (inflow of q_in, facet 0) +dt * q_in * (1/2, 1/2, 0, 0),
+    and the facets y = 0, 1 (u.n = 0) nothing -- the upwind form of demos/DG_advection/DG_advection.py.rst."""
+    kc, ke, _ = forms.dg_advection_kernels()
+    xc = np.array([[0.0, 0.0], [0.0, 1.0], [1.0, 0.0], [1.0, 1.0]])
+    q, u = np.ones(4), np.tile([1.0, 0.0], (4, 1))
+    ident = np.arange(4, dtype=np.int32).reshape(1, 4)
+    dt = 0.125
+    L = np.zeros(4)
+    oracle.par_loop(kc.code, kc.name, 0, 1, [ODat(L, INC, ident), ODat(xc.copy(), READ, ident), ODat(q.copy(), READ, ident),
+                                             ODat(u.copy(), READ, ident), OGlobal(np.array([dt]), READ)])
+    assert_allclose(L, dt * np.array([-0.5, -0.5, 0.5, 0.5]), atol=1e-15)
+    expect = {0: 0.75 * dt * np.array([0.5, 0.5, 0, 0]), 1: -dt * np.array([0, 0, 0.5, 0.5]), 2: np.zeros(4), 3: np.zeros(4)}
+    for f, exp in expect.items():
+        L = np.zeros(4)
+        oracle.par_loop(ke.code, ke.name, 0, 1, [ODat(L, INC, ident), ODat(xc.copy(), READ, ident), ODat(q.copy(), READ, ident),
+                                                 ODat(u.copy(), READ, ident), OGlobal(np.array([dt]), READ),
+                                                 OGlobal(np.array([0.75]), READ), ODat(np.array([[f]], dtype=np.uint32), READ)])
+        assert_allclose(L, exp, atol=1e-15)
