@@ -143,3 +143,23 @@ def test_dg_cell_and_facet_kernels_known_answers():
                                                  ODat(u.copy(), READ, ident), OGlobal(np.array([dt]), READ),
                                                  OGlobal(np.array([0.75]), READ), ODat(np.array([[f]], dtype=np.uint32), READ)])
         assert_allclose(L, exp, atol=1e-15)
+
+
+def test_dg_interior_facet_kernel_known_answer():
+    """Two unit cells side by side, u = (1, 0): the facet x = 1 is facet 1 of the '+' cell and facet 0 of the '-' cell;
+    upwinding takes q('+'): -dt * int (phi('+') - phi('-')) * q('+') dS = dt * (0, 0, -q/2, -q/2 | q/2, q/2, 0, 0)."""
+    ki = forms.dg_advection_kernels()[2]
+    xc = np.array([[0, 0], [0, 1], [1, 0], [1, 1], [1, 0], [1, 1], [2, 0], [2, 1]], dtype=float)
+    ident = np.arange(8, dtype=np.int32).reshape(1, 8)
+    q = np.array([3.0] * 4 + [7.0] * 4)                       # q('+') = 3, q('-') = 7 (not used: it is downwind)
+    u = np.tile([1.0, 0.0], (8, 1))
+    dt = 0.25
+    L = np.zeros(8)
+    oracle.par_loop(ki.code, ki.name, 0, 1, [ODat(L, INC, ident), ODat(xc, READ, ident), ODat(q, READ, ident), ODat(u, READ, ident),
+                                             OGlobal(np.array([dt]), READ), ODat(np.array([[1, 0]], dtype=np.uint32), READ)])
+    assert_allclose(L, dt * 3.0 * np.array([0, 0, -0.5, -0.5, 0.5, 0.5, 0, 0]), atol=1e-15)
+    # reversed flow: the '-' cell is upwind
+    L = np.zeros(8)
+    oracle.par_loop(ki.code, ki.name, 0, 1, [ODat(L, INC, ident), ODat(xc, READ, ident), ODat(q, READ, ident), ODat(-u, READ, ident),
+                                             OGlobal(np.array([dt]), READ), ODat(np.array([[1, 0]], dtype=np.uint32), READ)])
+    assert_allclose(L, dt * 7.0 * np.array([0, 0, 0.5, 0.5, -0.5, -0.5, 0, 0]), atol=1e-15)
