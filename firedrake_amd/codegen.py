@@ -61,7 +61,6 @@ class WrapperSource:
     kbytes: int = 1
     mat_staged: dict = field(default_factory=dict)
     lane_threads: int = 0                                  # >0: plans must be in lane order for this many lanes
-    rep_shift: int = 0                                     # log2(replicas of every LDS accumulator)
     ocr_lds_limit: int = 0                                 # LDS budget of an OCR row block (0 = configuration["lds_limit"])
 
 
@@ -166,8 +165,6 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         entries = max(int(np.prod(a.dims[0])) * int(np.prod(a.dims[1])) * a.maps[0].arity * a.maps[1].arity
                       for a in gk.arguments if isinstance(a, MatKernelArg))
         ocr_lds_limit = configuration["ocr_lds_limit"] or (159 * 1024 if entries > 32 else 0)
-    has_mat = any(isinstance(a, MatKernelArg) for a in gk.arguments)
-    rep_shift = max(1, min(32, int(configuration["ocr_replicas" if has_mat else "lds_replicas"]))).bit_length() - 1
 
     params: List[str] = []
     layout: List[tuple] = []
@@ -308,7 +305,6 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
 
     pre, pack, call_args, unpack, post = [], [], [], [], []
     node_actions = {}    # per staged map: [(load statements, LDS store statements)] templated on I_U / G_U
-    pack_gather = []     # staged READ gathers (arg, ctype, size, template) -- software-pipelined one entity ahead
     lds_decl, stage, flush, mat_stage_pre = [], [], [], []
     # LDS carve-up order: staged Dat rows, then the per-node matrix tables (sizes fixed by the node strides), then the
     # matrix accumulators (sized by the block's nonzero count, known only at run time) -- with compile-time strides
@@ -351,35 +347,25 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             c, ar, mi = info["c"], info["ar"], info["m"]
             perm, off = info["perm"], info["off"]
             size = nf * ar * c
-            if not (staged and acc == READ and configuration["pipeline_packs"] and configuration["prefetch"]):
-                pack.append(f"{ct} t{k}[{size}];")
+            pack.append(f"{ct} t{k}[{size}];")
             if staged:
                 lds_items.append(("dat", mi, c, info["dtype"].itemsize, acc != READ))
-                rsh = " << fd_rsh" if acc != READ else ""
-                lds_decl.append(f"{ct} *s{k} = ({ct} *)(fd_lds + fd_off); fd_off += ((((size_t)p{mi}_maxnd*{c}*sizeof({ct})){rsh}) + 15) & ~(size_t)15;")
+                lds_decl.append(f"{ct} *s{k} = ({ct} *)(fd_lds + fd_off); fd_off += (((size_t)p{mi}_maxnd*{c}*sizeof({ct})) + 15) & ~(size_t)15;")
                 if acc == READ:
                     soa = bool(configuration["lds_soa"]) and c > 1
                     node_actions.setdefault(mi, []).append(
                         ([f"{ct} v{k}_U[{c}];", f"for (int j = 0; j < {c}; ++j) v{k}_U[j] = arg{k}[(size_t)G_U*{c} + j];"],
                          [f"for (int j = 0; j < {c}; ++j) s{k}[{'j*(int)p%d_maxnd + I_U' % mi if soa else 'I_U*%d + j' % c}] = v{k}_U[j];"]))
-                    idx = f"j*(int)p{mi}_maxnd + LM{mi}[{_permi(perm, 'i')}]" if soa else f"LM{mi}[{_permi(perm, 'i')}]*{c} + j"
-                    g = f"for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j) TT{k}[i*{c}+j] = s{k}[{idx}];"
-                    if configuration["pipeline_packs"] and configuration["prefetch"]:
-                        pack_gather.append((k, ct, size, g))
-                    else:
-                        pack.append(g.replace(f"TT{k}", f"t{k}").replace(f"LM{mi}", f"lm{mi}"))
+                    idx = f"j*(int)p{mi}_maxnd + lm{mi}[{_permi(perm, 'i')}]" if soa else f"lm{mi}[{_permi(perm, 'i')}]*{c} + j"
+                    pack.append(f"for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j) t{k}[i*{c}+j] = s{k}[{idx}];")
                 else:  # INC
-                    # replicated accumulators: every accumulator has 2^fd_rsh copies, interleaved so that copy r of
-                    # consecutive accumulators sits in banks r, r + R, ...; a lane adds into copy (lane mod R).
-                    # Neighbouring entities (consecutive lanes) that share a node no longer hit one address in the
-                    # same ds_add, and distinct nodes collide on a bank R times less often.
-                    stage.append((mi, f"for (int q = tid; q < (nd{mi}*{c}) << fd_rsh; q += nthr) s{k}[q] = 0;"))
+                    stage.append((mi, f"for (int q = tid; q < nd{mi}*{c}; q += nthr) s{k}[q] = 0;"))
                     pack.append(f"for (int q = 0; q < {size}; ++q) t{k}[q] = 0;")
                     unpack.append(f"for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j) "
-                                  f"atomicAdd(&s{k}[((lm{mi}[{_permi(perm, 'i')}]*{c} + j) << fd_rsh) + fd_r], t{k}[i*{c}+j]);")
+                                  f"atomicAdd(&s{k}[lm{mi}[{_permi(perm, 'i')}]*{c} + j], t{k}[i*{c}+j]);")
                     flush.append((mi, f"for (int q = tid; q < nd{mi}*{c}; q += nthr) {{ const int i = q / {c}; "
                                       f"fdw::atomic_add<{ct}>(&arg{k}[(size_t)p{mi}_list[l0_{mi} + i]*{c} + (q - i*{c})], "
-                                      f"fdw::rep_sum<{ct}>(s{k}, q, fd_rsh)); }}"))
+                                      f"s{k}[q]); }}"))
                 call_args.append(f"t{k}")
                 continue
             nexpr = node(mi, ar, "i", off, perm, "f")
@@ -416,7 +402,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             lg = info["arg"].lgmaps
             if ocr:
                 lds_items.append(("ocr", k, rm, cm, bool(lg)))
-                lds_tail_var.append(f"double *sm{k} = (double *)(fd_lds + fd_off); fd_off += ((((size_t)oc{k}_maxnnz*8) << fd_rsh) + 15) & ~(size_t)15;")
+                lds_tail_var.append(f"double *sm{k} = (double *)(fd_lds + fd_off); fd_off += (((size_t)oc{k}_maxnnz*8) + 15) & ~(size_t)15;")
                 # one LDS word per gathered node: bits 0..29 = 1 + offset of the node's row inside the block's
                 # accumulator (0 = row not owned here or BC-masked), bit 31 = column is BC-masked
                 lds_tail_const.append(f"unsigned int *srow{k} = (unsigned int *)(fd_lds + fd_off); fd_off += (((size_t)p{rm}_maxnd*4) + 15) & ~(size_t)15;")
@@ -424,10 +410,8 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                     lds_tail_const.append(f"unsigned char *smc{k} = fd_lds + fd_off; fd_off += ((size_t)p{cm}_maxnd + 15) & ~(size_t)15;")
                 mat_stage_pre.extend([f"const int n0_{k} = oc{k}_rblk[b], nown{k} = oc{k}_rblk[b+1] - n0_{k};",
                                       f"const int r0_{k} = oc{k}_rowptr[n0_{k}], nnzb{k} = oc{k}_rowptr[n0_{k} + nown{k}] - r0_{k};"])
-                stage.append((rm, f"for (int q = tid; q < nnzb{k} << fd_rsh; q += nthr) sm{k}[q] = 0;"))
-                # "_nm" variants leave the column masking to a post-pass (Parloop._compute_ocr: when the matrix is
-                # assembled from zero, dropping BC columns == clearing fd_csr_masked_entries afterwards)
-                colmask = bool(lg) and "_nm" not in mode
+                stage.append((rm, f"for (int q = tid; q < nnzb{k}; q += nthr) sm{k}[q] = 0;"))
+                colmask = bool(lg)
                 rowmask = f" && rlg{k}[g] >= 0" if lg else ""
                 colbit = (f" | ((clg{k}[g] < 0) ? 0x80000000u : 0u)" if (colmask and cm == rm) else "")
                 node_actions.setdefault(rm, []).append(
@@ -447,18 +431,18 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 val = f"t{k}[i*{ac} + j]"
                 if colmask:
                     val = f"(({'cmk%d[j]' % k if cm != rm else '(rw%d[j] >> 31)' % k}) ? 0.0 : {val})"
-                lines += [f"    atomicAdd(&sm{k}[((base + kk{k}[i*{ac} + j]) << fd_rsh) + fd_r], {val});", "  }", "}"]
+                lines += [f"    atomicAdd(&sm{k}[base + kk{k}[i*{ac} + j]], {val});", "  }", "}"]
                 unpack.append("\n    ".join(lines))
                 # complete rows, contiguous in the CSR value array: plain coalesced stores
-                flush.append((rm, f"if (oc{k}_flags & 1) {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)r0_{k} + q] = fdw::rep_sum<double>(sm{k}, q, fd_rsh); }} "
-                                  f"else {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)r0_{k} + q] += fdw::rep_sum<double>(sm{k}, q, fd_rsh); }}"))
+                flush.append((rm, f"if (oc{k}_flags & 1) {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)r0_{k} + q] = sm{k}[q]; }} "
+                                  f"else {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)r0_{k} + q] += sm{k}[q]; }}"))
                 continue
             if mat_staged[k]:
                 lds_items.append(("mat", k, rm, cm, bool(lg)))
-                lds_tail_var.append(f"double *sm{k} = (double *)(fd_lds + fd_off); fd_off += ((((size_t)mp{k}_maxnnz*8) << fd_rsh) + 15) & ~(size_t)15;")
+                lds_tail_var.append(f"double *sm{k} = (double *)(fd_lds + fd_off); fd_off += (((size_t)mp{k}_maxnnz*8) + 15) & ~(size_t)15;")
                 lds_tail_const.append(f"int *slrp{k} = (int *)(fd_lds + fd_off); fd_off += (((size_t)(p{rm}_maxnd + 1)*4) + 15) & ~(size_t)15;")
                 mat_pre = [f"const int mo{k} = mp{k}_off[b], nnzb{k} = mp{k}_off[b+1] - mo{k};"]
-                stage.append((rm, f"for (int q = tid; q < nnzb{k} << fd_rsh; q += nthr) sm{k}[q] = 0;"))
+                stage.append((rm, f"for (int q = tid; q < nnzb{k}; q += nthr) sm{k}[q] = 0;"))
                 stage.append((rm, f"for (int q = tid; q <= nd{rm}; q += nthr) slrp{k}[q] = mp{k}_lrp[l0_{rm} + b + q];"))
                 if lg:
                     lds_tail_const.append(f"unsigned char *smr{k} = fd_lds + fd_off; fd_off += ((size_t)p{rm}_maxnd + 15) & ~(size_t)15;")
@@ -473,16 +457,11 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 lines.append(f"  for (int j = 0; j < {ac}; ++j) {{")
                 if lg:
                     lines.append(f"    if (smc{k}[lm{cm}[j]]) continue;")
-                lines += [f"    atomicAdd(&sm{k}[((base + kk{k}[i*{ac} + j]) << fd_rsh) + fd_r], t{k}[i*{ac} + j]);", "  }", "}"]
+                lines += [f"    atomicAdd(&sm{k}[base + kk{k}[i*{ac} + j]], t{k}[i*{ac} + j]);", "  }", "}"]
                 unpack.append("\n    ".join(lines))
-                # exclusive entries (~pos < 0) need no atomic; with a pending Mat.zero() they are simply overwritten
-                if configuration["mat_exclusive"]:
-                    flush.append((rm, f"for (int q = tid; q < nnzb{k}; q += nthr) {{ const double v = fdw::rep_sum<double>(sm{k}, q, fd_rsh); const int g = mp{k}_gpos[mo{k} + q]; "
-                                      f"if (g < 0) {{ if (mp{k}_flags & 1) arg{k}[~g] = v; else if (v != 0.0) arg{k}[~g] += v; }} "
-                                      f"else if (v != 0.0) fdw::atomic_add<double>(&arg{k}[g], v); }}"))
-                else:
-                    flush.append((rm, f"for (int q = tid; q < nnzb{k}; q += nthr) {{ const double v = fdw::rep_sum<double>(sm{k}, q, fd_rsh); const int g = mp{k}_gpos[mo{k} + q]; "
-                                      f"if (v != 0.0) fdw::atomic_add<double>(&arg{k}[g < 0 ? ~g : g], v); }}"))
+                # gpos < 0 marks an entry no other block touches (~gpos is its position); both kinds are added atomically
+                flush.append((rm, f"for (int q = tid; q < nnzb{k}; q += nthr) {{ const double v = sm{k}[q]; const int g = mp{k}_gpos[mo{k} + q]; "
+                                  f"if (v != 0.0) fdw::atomic_add<double>(&arg{k}[g < 0 ? ~g : g], v); }}"))
                 continue
             store = (lambda p, v: f"fdw::atomic_add<double>(&arg{k}[{p}], {v});") if acc == INC else (lambda p, v: f"arg{k}[{p}] = {v};")
             unroll = info["arg"].unroll
@@ -531,8 +510,6 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
     if staged:
         src += ["  extern __shared__ __align__(16) unsigned char fd_lds[];",
                 "  const int tid = threadIdx.x, nthr = blockDim.x;",
-                # log2 of the number of lane-private replicas of every LDS accumulator ("replicated accumulators" above)
-                f"  constexpr int fd_rsh = {rep_shift}; const int fd_r = tid & ((1 << fd_rsh) - 1);",
                 "  const int b = fdw::xcd_block(blockIdx.x, gridDim.x);",
                 "  const int e0 = bstart_[b], e1 = bstart_[b+1];"]
         src += ["  " + s for s in lds_decl + lds_tail_const + lds_tail_var]
@@ -540,23 +517,14 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             src.append(f"  const int l0_{mi} = p{mi}_blkoff[b], nd{mi} = p{mi}_blkoff[b+1] - l0_{mi};")
         src += ["  " + s for s in mat_stage_pre]
         src += ["  " + s for _, s in stage]
-        # node-major staging, two nodes per lane and trip: both node-list entries are requested first, then all the
-        # rows that depend on them -- two dependent memory round trips per trip instead of one pair per value
-        UNR = max(1, int(configuration["stage_unroll"]))
+        # node-major staging: the node-list entry is requested first, then all the rows that depend on it
         for mi, acts in node_actions.items():
-            src.append(f"  for (int ia = tid; ia < nd{mi}; ia += {UNR}*nthr) {{")
-            for u in range(UNR):
-                src.append(f"    const int i_{u} = (ia + {u}*nthr < nd{mi}) ? ia + {u}*nthr : ia;")
-            for u in range(UNR):
-                src.append(f"    const int g_{u} = p{mi}_list[l0_{mi} + i_{u}];")
-            for u in range(UNR):
-                for loads, stores in acts:
-                    for l in loads:
-                        src.append("    " + l.replace("_U", f"_{u}").replace("G_" + str(u), f"g_{u}").replace("I_" + str(u), f"i_{u}"))
-            for u in range(UNR):
-                for loads, stores in acts:
-                    for l in stores:
-                        src.append("    " + l.replace("_U", f"_{u}").replace("G_" + str(u), f"g_{u}").replace("I_" + str(u), f"i_{u}"))
+            src.append(f"  for (int i_0 = tid; i_0 < nd{mi}; i_0 += nthr) {{")
+            src.append(f"    const int g_0 = p{mi}_list[l0_{mi} + i_0];")
+            for part in (0, 1):
+                for act in acts:
+                    for l in act[part]:
+                        src.append("    " + l.replace("_U", "_0").replace("G_0", "g_0").replace("I_0", "i_0"))
             src.append("  }")
         src.append("  __syncthreads();")
         src += ["  " + s for s in pre]
@@ -590,41 +558,17 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             ent_of = lambda ii: f"(fd_ebase + ({ii} - e0) / {threads})"
         else:
             ent_of = lambda ii: ii
-        def gathers(tprefix, lmprefix):
-            out = []
-            for k, ct, size, g in pack_gather:
-                t = re.sub(r"TT(\d+)", lambda m: f"{tprefix}{m.group(1)}", g)
-                out.append(re.sub(r"LM(\d+)", lambda m: f"{lmprefix}{m.group(1)}", t))
-            return out
-        pp = pf and bool(pack_gather)       # two-deep pipeline: indices two entities ahead, LDS gathers one ahead
         if pf:
             for cur, nxt, name, n, ld in idx_loads:
-                src.append(f"  {cur}; {nxt};" + (f" int nn_{name}[{n}];" if pp else ""))
-            for k, ct, size, g in pack_gather:
-                src.append(f"  {ct} t{k}[{size}], tn{k}[{size}];")
+                src.append(f"  {cur}; {nxt};")
             src.append("  int e_cur = 0, e_nx = 0;")
             src.append("  if (fd_first < fd_last) {")
             src.append(f"    e_cur = {ent_of('fd_first')};")
             for cur, nxt, name, n, ld in idx_loads:
                 src.append("    " + ld.replace("II", "fd_first").replace("EE", "e_cur").replace("DST", name))
-            if pp:
-                src.append("    const int it1 = (fd_first + fd_step < fd_last) ? fd_first + fd_step : fd_first;")
-                src.append(f"    e_nx = {ent_of('it1')};")
-                for cur, nxt, name, n, ld in idx_loads:
-                    src.append("    " + ld.replace("II", "it1").replace("EE", "e_nx").replace("DST", "nx_" + name))
-            src += ["    " + g for g in gathers("t", "lm")]
             src.append("  }")
         src.append("  for (int it = fd_first; it < fd_last; it += fd_step) {")
-        if pp:
-            src.append("    const int e = e_cur;")
-            src.append("    const int it2 = (it + 2*fd_step < fd_last) ? it + 2*fd_step : it;")
-            src.append(f"    const int e_nn = {ent_of('it2')};")
-            for cur, nxt, name, n, ld in idx_loads:
-                src.append("    " + ld.replace("II", "it2").replace("EE", "e_nn").replace("DST", "nn_" + name))
-            # LDS gathers for the NEXT entity are issued before this entity's local kernel: ds_read latency and
-            # LDS-pipe time overlap the ~10^2 fp64 VALU instructions of the kernel inside the same wavefront
-            src += ["    " + g for g in gathers("tn", "nx_lm")]
-        elif pf:
+        if pf:
             src.append("    const int e = e_cur;")
             src.append("    const int itn = (it + fd_step < fd_last) ? it + fd_step : it;")
             src.append(f"    e_nx = {ent_of('itn')};")
@@ -640,11 +584,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         if pf:
             for cur, nxt, name, n, ld in idx_loads:
                 src.append(f"    for (int q = 0; q < {n}; ++q) {name}[q] = nx_{name}[q];")
-                if pp:
-                    src.append(f"    for (int q = 0; q < {n}; ++q) nx_{name}[q] = nn_{name}[q];")
-            for k, ct, size, g in pack_gather:
-                src.append(f"    for (int q = 0; q < {size}; ++q) t{k}[q] = tn{k}[q];")
-            src.append("    e_cur = e_nx;" + (" e_nx = e_nn;" if pp else ""))
+            src.append("    e_cur = e_nx;")
         src.append("  }")
         if flush:
             src.append("  __syncthreads();")
@@ -701,7 +641,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             src[sig + 1:] = [pat.sub("((long long)%d)" % S, l) for l in src[sig + 1:]]
     return WrapperSource("\n".join(src) + "\n", sym, full_mode, layout, len(maps), staged_maps, lds_items,
                          layer_parallel, threads, kbytes, mat_staged,
-                         (threads if (staged and configuration["lane_strided"]) else 0), rep_shift,
+                         (threads if (staged and configuration["lane_strided"]) else 0),
                          ocr_lds_limit if ocr else 0)
 
 

@@ -21,13 +21,8 @@ configuration = {
     "mode": _env("FDHIP_MODE", "auto"),                 # auto | staged | direct
     "block_threads": _env("FDHIP_BLOCK_THREADS", 0, int),
     "ents_per_block": _env("FDHIP_ENTS_PER_BLOCK", 1024, int),
-    "pipeline_packs": _env("FDHIP_PIPELINE_PACKS", 0, int),  # gather the next entity's packs from LDS one iteration ahead
-    "stage_unroll": _env("FDHIP_STAGE_UNROLL", 1, int),   # nodes staged per lane per trip (memory-level parallelism)
-    "lds_replicas": _env("FDHIP_LDS_REPLICAS", 1, int),   # lane-private copies of staged Dat accumulators (power of two)
-    "ocr_replicas": _env("FDHIP_OCR_REPLICAS", 1, int),   # the same for block matrix accumulators
     "ocr_pack": _env("FDHIP_OCR_PACK", 1, int),            # bank-aware greedy packing of the instance lists (fd_ocrplan_pack)
     "ocr_lds_limit": _env("FDHIP_OCR_LDS_LIMIT", 0, int),  # 0 = auto (whole CU for large element matrices)
-    "ocr_post_mask": _env("FDHIP_OCR_POST_MASK", 0, int),  # fused-zero OCR assembly: clear BC columns after the loop
     "lane_strided": _env("FDHIP_LANE_STRIDED", 1, int),   # plans in lane order (fd_plan_set_lane_order)
     # staged rows addressed with a COMPILE-TIME node stride (max nodes per block rounded up to a multiple of this value;
     # 0 = run-time stride): the LDS offsets of all staged arrays fold into ds_read/ds_add immediates instead of one
@@ -40,15 +35,13 @@ configuration = {
     "ocr_nnz_per_block": _env("FDHIP_OCR_NNZ", 2048, int),  # row-block size (CSR entries) when the producer gives no hint
     "ocr_block_threads": _env("FDHIP_OCR_BLOCK_THREADS", 0, int),  # 0 = auto: 512 for small element matrices, else block_threads
     # order of the instances inside an owner-computes-rows block: "lane" (fd_plan_set_lane_order), "stencil"
-    # (sorted by owned-row signature), "natural" (entity order) or an integer > 1 (multiplicative permutation)
+    # (sorted by owned-row signature) or "natural" (entity order)
     "ocr_order": _env("FDHIP_OCR_ORDER", "stencil"),
-    "mat_exclusive": _env("FDHIP_MAT_EXCLUSIVE", 0, int),  # non-atomic writes + fused zero for block-exclusive nonzeros
     "min_waves": _env("FDHIP_MIN_WAVES", 0, int),       # 2nd __launch_bounds__ argument (waves per SIMD), 0 = unset
     # occupancy-directed variants: a staged/OCR wrapper whose register count leaves room for one more resident workgroup
     # per CU is recompiled with the matching __launch_bounds__ and kept if that costs at most this many bytes of scratch
     # per lane (-1 = off).  DG-advection interior-facet loop: 172 -> 128 VGPRs, 12 B scratch, 0.50 -> 0.32 ms
     "auto_occupancy_scratch": _env("FDHIP_AUTO_OCCUPANCY_SCRATCH", 16, int),
-    "block_merge": _env("FDHIP_BLOCK_MERGE", 1, int),     # staged loops: fuse this many consecutive producer tiles into one plan block
     "use_preferred_blocks": _env("FDHIP_PREFERRED_BLOCKS", 1, int),   # plan blocks = the producer's traversal tiles
     "lds_limit": _env("FDHIP_LDS_LIMIT", 64 * 1024, int),
     "mat_scatter": _env("FDHIP_MAT_SCATTER", "table"),  # table | search (direct scatter flavours)

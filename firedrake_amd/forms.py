@@ -423,12 +423,10 @@ def precompile_all():
             gj = GlobalKernel(kjac, [MatKernelArg(((1,), (1,)), (cm, cm), lgmaps=lg), DatKernelArg((dim,), xm)])
             for g in (gk, gj):
                 from .codegen import ocr_eligible
-                for mode in ("staged", "direct", "ocr", "ocr_nm"):
+                for mode in ("staged", "direct", "ocr"):
                     if mode == "staged" and not staged_eligible(g):
                         continue
                     if mode.startswith("ocr") and not ocr_eligible(g):
-                        continue
-                    if mode == "ocr_nm" and not lg:
                         continue
                     src = generate_wrapper(g, mode)
                     out.append(compile_hip(src.source, src.symbol))

@@ -154,34 +154,18 @@ class Set:
 
     layers = property(lambda self: 1)     # set.py:197-199
 
-    # -- set algebra between a Set and itself / its Subsets (set.py:201-232)
-    def _check_operands(self, other):
-        if type(other) is Set:
-            if other is not self:
-                raise ValueError("Unable to perform set operations between two unrelated sets: %s and %s." % (self, other))
-        elif type(other) is Subset:
-            if self is not other._superset:
-                raise TypeError("Superset mismatch: self (%s) != other._superset (%s)" % (self, other._superset))
-        else:
-            raise TypeError("Unable to perform set operations between `Set` and %s." % (type(other),))
-
+    # -- set algebra between a Set and itself / its Subsets: see _set_algebra below
     def intersection(self, other):
-        self._check_operands(other)
-        return other
+        return _set_algebra(self, other, "and")
 
     def union(self, other):
-        self._check_operands(other)
-        return self
+        return _set_algebra(self, other, "or")
 
     def difference(self, other):
-        self._check_operands(other)
-        if other is self:
-            return Subset(self, [])
-        return Subset(self, np.setdiff1d(np.arange(self.total_size, dtype=IntType), other._indices))
+        return _set_algebra(self, other, "andnot")
 
     def symmetric_difference(self, other):
-        self._check_operands(other)
-        return self.difference(other)
+        return _set_algebra(self, other, "xor")
 
     def __str__(self):
         return "OP2 Set: %s with size %s" % (self.name, self.size)
@@ -302,41 +286,10 @@ class Subset(Set):
 
     __hash__ = object.__hash__
 
-    # -- set algebra (set.py:498-543)
-    def _check_operands(self, other):
-        if type(other) is Set:
-            if other is not self._superset:
-                raise TypeError("Superset mismatch: self._superset (%s) != other (%s)" % (self._superset, other))
-        elif type(other) is Subset:
-            if self._superset is not other._superset:
-                raise TypeError("Unable to perform set operation between subsets of mismatching supersets (%s != %s)"
-                                % (self._superset, other._superset))
-        else:
-            raise TypeError("Unable to perform set operations between `Subset` and %s." % (type(other),))
-
-    def intersection(self, other):
-        self._check_operands(other)
-        if other is self._superset:
-            return self
-        return Subset(self._superset, np.intersect1d(self._indices, other._indices))
-
-    def union(self, other):
-        self._check_operands(other)
-        if other is self._superset:
-            return other
-        return Subset(self._superset, np.union1d(self._indices, other._indices))
-
-    def difference(self, other):
-        self._check_operands(other)
-        if other is self._superset:
-            return Subset(other, [])
-        return Subset(self._superset, np.setdiff1d(self._indices, other._indices))
-
-    def symmetric_difference(self, other):
-        self._check_operands(other)
-        if other is self._superset:
-            return other.symmetric_difference(self)
-        return Subset(self._superset, np.setxor1d(self._indices, other._indices))
+    intersection = Set.intersection      # membership-mask algebra shared with Set (_set_algebra)
+    union = Set.union
+    difference = Set.difference
+    symmetric_difference = Set.symmetric_difference
 
     def __call__(self, *indices):         # set.py:462-473: a Subset of a Subset
         if len(indices) == 1:
@@ -366,6 +319,34 @@ class Subset(Set):
         if self._dev_indices is None:
             self._dev_indices = DeviceBuffer.from_numpy(self._indices)
         return self._dev_indices.ptr
+
+
+def _set_algebra(lhs, rhs, op):
+    """Set operations among a Set and its Subsets (the semantics of pyop2/types/set.py:201-232, 498-543), computed on
+    membership masks over the common superset.  A result that covers the whole superset is the superset itself, anything
+    else a Subset of it; operands that do not share a superset are a TypeError (two unrelated plain Sets: ValueError)."""
+    for x in (lhs, rhs):
+        if type(x) not in (Set, Subset):
+            raise TypeError(f"set operations are defined between a Set and its Subsets, not {type(x)}")
+    root = lhs.superset
+    if rhs.superset is not root:
+        if type(lhs) is Set and type(rhs) is Set:
+            raise ValueError(f"{lhs} and {rhs} are unrelated sets")
+        raise TypeError(f"{lhs} and {rhs} do not share a superset")
+
+    def mask(x):
+        m = np.zeros(root.total_size, dtype=bool)
+        m[x._indices if type(x) is Subset else slice(None)] = True
+        return m
+
+    a, b = mask(lhs), mask(rhs)
+    out = {"and": a & b, "or": a | b, "andnot": a & ~b, "xor": a ^ b}[op]
+    if out.all() and root.total_size > 0:
+        return root
+    for x in (lhs, rhs):                         # hand an operand back unchanged when it already is the answer
+        if type(x) is Subset and np.array_equal(out, mask(x)):
+            return x
+    return Subset(root, np.nonzero(out)[0].astype(IntType))
 
 
 class DataSet:
@@ -1886,7 +1867,7 @@ class OcrPlan:
             return 0
         if order == "lane":
             return -int(lane_threads) if lane_threads > 0 else 0
-        return int(order)
+        raise ValueError("FDHIP_OCR_ORDER must be stencil, lane or natural")
 
     def __del__(self):
         try:

@@ -262,7 +262,6 @@ class Parloop:
         self._check_frozen_access_modes()
         self._prepared = None
         self._lgmap_dev = {}
-        self._masked = {}
         # owner-computes-rows matrix assembly on a partitioned mesh: also execute the ghost entities
         # [size, total_size) (their non-owned rows are masked by the lgmaps)
         self.compute_ghost = False
@@ -326,17 +325,17 @@ class Parloop:
 
         from .codegen import lds_stride, mode_variant
 
-        def lds_bytes(plans, mplans, rsh):
+        def lds_bytes(plans, mplans):
             lds = 0
             nd = {mi: lds_stride(p.max_nd) for mi, p in plans.items()}
             for item in src.lds_items:
                 if item[0] == "dat":
                     _, mi, c, isz, accum = item
-                    lds += (((nd[mi] * c * isz) << (rsh if accum else 0)) + 15) // 16 * 16
+                    lds += ((nd[mi] * c * isz) + 15) // 16 * 16
                 else:
                     _, k, rm, cm, lg = item
                     mp = mplans[k]
-                    lds += ((mp.max_nnz * 8 << rsh) + 15) // 16 * 16 + ((nd[rm] + 1) * 4 + 15) // 16 * 16
+                    lds += ((mp.max_nnz * 8) + 15) // 16 * 16 + ((nd[rm] + 1) * 4 + 15) // 16 * 16
                     if lg:
                         lds += (nd[rm] + 15) // 16 * 16 + (nd[cm] + 15) // 16 * 16
             return lds
@@ -349,7 +348,7 @@ class Parloop:
                     _, k, rm, cm, lg = item
                     pa = self.arguments[k]
                     mplans[k] = pa.data.sparsity.matplan(plans[rm], plans[cm], pa.maps)
-            return plans, mplans, lds_bytes(plans, mplans, src.rep_shift)
+            return plans, mplans, lds_bytes(plans, mplans)
 
         # 1. block boundaries suggested by the data producer (mesh traversal tiles), if they fit
         blocks = None
@@ -359,13 +358,6 @@ class Parloop:
             i0, i1 = np.searchsorted(pb, start), np.searchsorted(pb, end)
             if i0 < len(pb) and i1 < len(pb) and pb[i0] == start and pb[i1] == end and i1 > i0:
                 bl = pb[i0:i1 + 1].astype(np.int32)
-                mrg = max(1, int(configuration["block_merge"]))
-                while mrg > 1:
-                    cand_bl = np.unique(np.concatenate([bl[::mrg], bl[-1:]]))
-                    if int(np.diff(cand_bl).max()) * maxar <= 32768:
-                        bl = cand_bl
-                        break
-                    mrg -= 1
                 if int(np.diff(bl).max()) * maxar <= 32768:
                     blocks = bl
         plans = None
@@ -396,7 +388,7 @@ class Parloop:
             import sys
             for mi, pl in plans.items():
                 print(f"[fdhip] {self.global_kernel.name} [{start},{end}) epb={epb} map{mi}: blocks={pl.nblocks} "
-                      f"max_nd={pl.max_nd} list_len={pl.list_len} lds={lds} replicas={1 << src.rep_shift}", file=sys.stderr)
+                      f"max_nd={pl.max_nd} list_len={pl.list_len} lds={lds}", file=sys.stderr)
             for k, mp in mplans.items():
                 print(f"[fdhip]   matplan arg{k}: block-nz total={mp.total} max_nnz={mp.max_nnz} max_rowlen={mp.max_rowlen} "
                       f"kbytes={mp.kbytes} exclusive={mp.n_exclusive} zero_list={mp.n_zero}", file=sys.stderr)
@@ -410,7 +402,6 @@ class Parloop:
         geo = self._staged_geometry(start, end) if src.mode.startswith("staged") else None
         src = prep["cw"].src
         out = []
-        fused_flags = {}
         for desc in src.layout:
             kind = desc[0]
             if kind == "layers":
@@ -422,19 +413,7 @@ class Parloop:
                 acc = self.accesses[desc[1]]
                 if isinstance(pa, MatParloopArg):
                     pa.data.dat_version += 1
-                    k = desc[1]
-                    fused = (geo is not None and k in geo["mplans"] and pa.data._zero_pending and configuration["mat_exclusive"]
-                             and pa.data.sparsity.dsets[0].cdim * pa.data.sparsity.dsets[1].cdim == 1)
-                    if fused:
-                        # consume the pending Mat.zero(): clear only what no block overwrites
-                        mp = geo["mplans"][k]
-                        vals = pa.data._values_raw()
-                        _lib.call("fd_csr_zero_entries", vals.ptr, mp.zero_list, mp.n_zero, None)
-                        pa.data._zero_pending = False
-                        fused_flags[k] = 1
-                        out.append(vals.ptr)
-                    else:
-                        out.append(pa.data._values_dev().ptr)
+                    out.append(pa.data._values_dev().ptr)
                 else:
                     out.append(pa.data._dev_ptr(write=acc != READ))
             elif kind == "map":
@@ -460,7 +439,7 @@ class Parloop:
             elif kind == "matplan_maxnnz":
                 out.append(geo["mplans"][desc[1]].max_nnz)
             elif kind == "matplan_flags":
-                out.append(fused_flags.get(desc[1], 0))
+                out.append(0)
             elif kind == "mat_table":
                 pa = self.arguments[desc[1]]
                 out.append(pa.data.sparsity.elem_table(*pa.maps).ptr)
@@ -578,20 +557,20 @@ class Parloop:
                 d = np.diff(rb)                                    # an instance list is too long: halve every wide block
                 rb = np.unique(np.concatenate([rb, (rb[:-1] + d // 2)[d > 1]]))
                 continue
-            def lds_bytes(rsh):
+            def lds_bytes():
                 lds = 0
                 nd = {mi: lds_stride(p.max_nd, ocr=True) for mi, p in op.plans.items()}
                 for item in src.lds_items:
                     if item[0] == "dat":
                         _, mi, c, isz, accum = item
-                        lds += (((nd[mi] * c * isz) << (rsh if accum else 0)) + 15) // 16 * 16
+                        lds += ((nd[mi] * c * isz) + 15) // 16 * 16
                     else:
                         _, kk, rm, cmi, lg = item
-                        lds += ((op.max_nnz * 8 << rsh) + 15) // 16 * 16 + (nd[rm] * 4 + 15) // 16 * 16
+                        lds += ((op.max_nnz * 8) + 15) // 16 * 16 + (nd[rm] * 4 + 15) // 16 * 16
                         if cmi != rm:
                             lds += (nd[cmi] + 15) // 16 * 16
                 return lds
-            lds = lds_bytes(src.rep_shift)
+            lds = lds_bytes()
             if lds <= limit and op.max_inst * maxar <= 32768:
                 break
             d = np.diff(rb)
@@ -607,14 +586,13 @@ class Parloop:
         nds = [op.plans[mi].max_nd for mi in src.staged_maps]
         variant = mode_variant("ocr", op.kbytes, nds)
         geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz,
-               "cw": prep["cw"] if variant == src.mode else self.global_kernel.compile(variant),
-               "variant_nm": mode_variant("ocr_nm", op.kbytes, nds)}
+               "cw": prep["cw"] if variant == src.mode else self.global_kernel.compile(variant)}
         prep["parts"]["ocr"] = geo
         if configuration["debug"]:
             import sys
             print(f"[fdhip] {self.global_kernel.name} OCR: row blocks={op.nblocks} instances={op.ninst} "
                   f"(x{op.ninst / max(end, 1):.2f} entities) max_inst={op.max_inst} max_nnz={op.max_nnz} max_nown={op.max_nown} "
-                  f"lds={lds} replicas={1 << src.rep_shift} kbytes={op.kbytes}", file=sys.stderr)
+                  f"lds={lds} kbytes={op.kbytes}", file=sys.stderr)
         return geo
 
     def _compute_ocr(self):
@@ -625,16 +603,7 @@ class Parloop:
         op = geo["ocr"]
         if op.nblocks == 0 or op.ninst == 0:
             return
-        # A matrix assembled from zero: BC-masked COLUMNS need no test per inserted entry -- insert everything and
-        # clear the masked positions afterwards (fd_csr_masked_entries, built once per lgmap).  Rows stay masked
-        # in the kernel (that only skips work).
-        mpa = self.arguments[geo["k"]]
-        post_mask = bool(mpa.lgmaps is not None and mpa.data._zero_pending and configuration["ocr_post_mask"])
-        if post_mask:
-            cw = self.global_kernel.compile(geo["variant_nm"])
-            assert cw.src.layout == src.layout
         out = []
-        post_vals = None
         for desc in src.layout:
             kind = desc[0]
             if kind == "arg":
@@ -643,7 +612,6 @@ class Parloop:
                     mat = pa.data
                     mat.dat_version += 1
                     vals = mat._values_raw()
-                    post_vals = vals
                     flag = 0
                     if mat._zero_pending:
                         # rows outside the blocks (ghost rows) are the only part the loop does not overwrite
@@ -689,24 +657,6 @@ class Parloop:
                 raise AssertionError(kind)
         cw.launch(0, op.ninst, out, block_threads=src.block_threads, ents_per_block=op.max_inst, nblocks=op.nblocks,
                   lds_bytes=geo["lds"])
-        if post_mask:
-            lst, n = self._masked_entries(mpa)
-            if n:
-                _lib.call("fd_csr_zero_entries", post_vals.ptr, lst, n, None)
-
-    def _masked_entries(self, pa):
-        """(device list, length) of the CSR positions whose column ``pa``'s column lgmap masks; cached per lgmap."""
-        clg = pa.lgmaps[1]
-        hit = self._masked.get(id(clg))
-        if hit is None or hit[0] is not clg:
-            sp = pa.data.sparsity
-            sp._build()
-            lst, n = ctypes.c_void_p(), ctypes.c_int64()
-            _lib.call("fd_csr_masked_entries", sp._node_colidx.ptr, sp._node_nnz, self._lgmap(clg), ctypes.byref(lst),
-                      ctypes.byref(n), None)
-            hit = (clg, DeviceBuffer.wrap(lst.value, n.value * 4) if lst.value else None, n.value)
-            self._masked[id(clg)] = hit
-        return (hit[1].ptr if hit[1] is not None else None), hit[2]
 
     def _nlayers_iterated(self):
         from .op2types import ON_BOTTOM, ON_TOP, ON_INTERIOR_FACETS

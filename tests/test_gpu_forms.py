@@ -66,13 +66,10 @@ def test_poisson_residual_and_jacobian(dim, degree, n, bcs, ocr, monkeypatch):
         assert_allclose(y.data_ro + load, ro, rtol=0, atol=1e-10 * max(1.0, np.abs(ro).max()))
 
 
-@pytest.mark.parametrize("post_mask", [1, 0])
-def test_bc_column_masking_fused_and_accumulating(post_mask, monkeypatch):
-    """Owner-computes-rows with BC lgmaps: (i) assembled from zero -> columns cleared by the post-pass
-    (fd_csr_masked_entries) or masked in the kernel, same matrix; (ii) a second loop WITHOUT Mat.zero()
-    accumulates (MatSetValuesLocal ADD_VALUES, builder.py:573-625) and must mask inside the kernel: exactly
-    twice the dropped-column matrix, BC diagonal untouched by the loop."""
-    monkeypatch.setitem(configuration, "ocr_post_mask", post_mask)
+def test_bc_column_masking_fused_and_accumulating():
+    """Owner-computes-rows with BC lgmaps: (i) assembled from zero (pending Mat.zero() fused into the loop) -> columns
+    masked in the kernel; (ii) a second loop WITHOUT Mat.zero() accumulates (MatSetValuesLocal ADD_VALUES,
+    builder.py:573-625): exactly twice the dropped-column matrix, BC diagonal untouched by the loop."""
     m = fmesh.UnitCubeMesh(10, degrees=(1,), tile=(4, 4, 2), perturb=0.1)
     prob = forms.PoissonProblem(m, 1, bcs=True)
     _, Ao = _oracle_problem(prob, True)
