@@ -93,6 +93,8 @@ def staged_eligible(gk: GlobalKernel) -> bool:
         return False
     n_ind = 0
     for a, la in zip(gk.arguments, gk.local_kernel.arguments):
+        if isinstance(a, MatKernelArg) and any(isinstance(m, PermutedMapKernelArg) for m in a.maps):
+            return False          # matrix plans / row-offset tables are built on the base maps
         if isinstance(a, DatKernelArg) and a.is_indirect:
             n_ind += 1
             if a.index is not None:
@@ -133,6 +135,8 @@ def _hoist_includes(code: str):
 def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> WrapperSource:
     lk = gk.local_kernel
     maps, map_index = _distinct_maps(gk)
+    # requires_zeroed_output_arguments: MIN/MAX packs start from zero like INC/WRITE ones (builder.py:276-279, 368-371)
+    also_zero = (MIN, MAX) if lk.requires_zeroed_output_arguments else ()
     full_mode = mode
     # "<mode>_s<S0>x<S1>...": compile-time node strides of the staged maps (in staged_maps order), see lds_stride()
     sm_ = re.search(r"_s(\d+(?:x\d+)*)$", mode)
@@ -204,6 +208,10 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             (rdim, cdim) = a.dims
             info["rbs"], info["cbs"] = int(np.prod(rdim)), int(np.prod(cdim))
             rm, cm = a.maps
+            info["rperm"] = tuple(rm.permutation) if isinstance(rm, PermutedMapKernelArg) else None
+            info["cperm"] = tuple(cm.permutation) if isinstance(cm, PermutedMapKernelArg) else None
+            rm = rm.base_map if isinstance(rm, PermutedMapKernelArg) else rm
+            cm = cm.base_map if isinstance(cm, PermutedMapKernelArg) else cm
             info["rm"], info["cm"] = map_index[id(rm)], map_index[id(cm)]
             info["ar"], info["ac"] = rm.arity, cm.arity
             info["roff"] = rm.offset if extruded else None
@@ -252,7 +260,8 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         if info["kind"] != "mat":
             continue
         k = info["k"]
-        table = (configuration["mat_scatter"] == "table") and not extruded
+        # (the element->nonzero table is built on the base maps: a Mat reached through PermutedMaps searches its rows)
+        table = (configuration["mat_scatter"] == "table") and not extruded and info["rperm"] is None and info["cperm"] is None
         use_table[k] = table
         if ocr:
             P(f"const int *__restrict__ oc{k}_rblk", ("ocr_rblk", k))
@@ -333,8 +342,14 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 call_args.append(f"t{k}")
                 op, at = "OpAdd", "atomic_add"
             elif acc in (MIN, MAX):
-                call_args.append(f"g{k}")
                 op, at = ("OpMin", "atomic_min") if acc == MIN else ("OpMax", "atomic_max")
+                if acc in also_zero:
+                    # the kernel sees a zeroed pack per entity, combined into the running value afterwards
+                    pack.append(f"{ct} t{k}[{n}]; for (int q = 0; q < {n}; ++q) t{k}[q] = 0;")
+                    unpack.append(f"for (int q = 0; q < {n}; ++q) g{k}[q] = fdw::{op}<{ct}>::f(g{k}[q], t{k}[q]);")
+                    call_args.append(f"t{k}")
+                else:
+                    call_args.append(f"g{k}")
             else:
                 raise ValueError("Global arguments may be READ, INC, MIN or MAX in a parloop")
             post.append(f"for (int q = 0; q < {n}; ++q) {{ {ct} r = fdw::block_reduce<{ct}, fdw::{op}<{ct}>>(g{k}[q], ({ct} *)fd_red); "
@@ -380,7 +395,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 lhs = f"arg{k}[(size_t){nexpr}*{c} + j]"
                 rhs = f"t{k}[(f*{ar}+i)*{c}+j]"
                 vsize = size
-            if acc in (INC, WRITE):
+            if acc in (INC, WRITE) + also_zero:
                 pack.append(f"for (int q = 0; q < {vsize}; ++q) t{k}[q] = 0;")
             else:
                 pack.append(f"{loop} {rhs} = {lhs};")
@@ -467,9 +482,9 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             unroll = info["arg"].unroll
             nr_, nc_ = nf * ar, nf * ac
             lines = [f"for (int fi = 0; fi < {nf}; ++fi) for (int i = 0; i < {ar}; ++i) {{",
-                     f"  const int rn = {node(rm, ar, 'i', info['roff'], None, 'fi')};",
+                     f"  const int rn = {node(rm, ar, 'i', info['roff'], info['rperm'], 'fi')};",
                      f"  for (int fj = 0; fj < {nf}; ++fj) for (int j = 0; j < {ac}; ++j) {{",
-                     f"    const int cn = {node(cm, ac, 'j', info['coff'], None, 'fj')};",
+                     f"    const int cn = {node(cm, ac, 'j', info['coff'], info['cperm'], 'fj')};",
                      "    if (rn < 0 || cn < 0) continue;"]
             if lg and not unroll:
                 lines.append(f"    if (rlg{k}[rn] < 0 || clg{k}[cn] < 0) continue;")

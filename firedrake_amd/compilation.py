@@ -59,13 +59,19 @@ def compile_hip(source: str, name: str) -> str:
     cache = configuration["cache_dir"]
     os.makedirs(cache, exist_ok=True)
     fl = flags()
-    key = hashlib.sha1("\0".join([source, " ".join(fl[:-1]), compiler_version(), _wrapper_header_hash()]).encode()).hexdigest()[:20]
+    # every flag except the include path of this installation (the header's CONTENT is hashed instead)
+    keyed = [f for f in fl if f != f"-I{_CSRC}"]
+    key = hashlib.sha1("\0".join([source, " ".join(keyed), compiler_version(), _wrapper_header_hash()]).encode()).hexdigest()[:20]
     out = os.path.join(cache, f"{name}_{key}.hsaco")
     if os.path.exists(out):
         return out
+    # the source goes to a unique temporary name and is renamed into place (pyop2/compilation.py:560-575): ranks that
+    # miss the cache together never truncate a file another rank's hipcc is reading
     src = os.path.join(cache, f"{name}_{key}.hip")
-    with open(src, "w") as fh:
+    fd, tmpsrc = tempfile.mkstemp(suffix=".hip", dir=cache)
+    with os.fdopen(fd, "w") as fh:
         fh.write(source)
+    os.replace(tmpsrc, src)
     fd, tmp = tempfile.mkstemp(suffix=".hsaco", dir=cache)
     os.close(fd)
     # -Rpass-analysis=kernel-resource-usage: the register / scratch / occupancy figures of the wrapper kernel, kept in a

@@ -63,8 +63,8 @@ class CStringLocalKernel:
 
     @property
     def cache_key(self):
-        return hashlib.md5((self.code + self.name + repr(self.accesses) + repr(self.dtypes)
-                            + repr(self.requires_zeroed_output_arguments)).encode()).hexdigest()
+        return hashlib.md5((self.code + self.name + repr(self.accesses) + repr(self.dtypes) + repr(self.headers)
+                            + repr(self.cpp) + repr(self.requires_zeroed_output_arguments)).encode()).hexdigest()
 
     def with_signature(self, accesses, dtypes):
         return CStringLocalKernel(self.code, self.name, accesses, dtypes, flop_count=self.flop_count,

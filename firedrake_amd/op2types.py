@@ -497,33 +497,63 @@ class _Mirrored:
 
     def _init_storage(self, host: np.ndarray):
         self._host = np.ascontiguousarray(host)
+        if not self._host.flags.owndata or not self._host.flags.writeable:
+            self._host = np.array(self._host)                 # the ONE buffer every handed-out view aliases
         self._dev: Optional[DeviceBuffer] = None
         self._host_valid = True
         self._dev_valid = False
+        self._rw_handed = False
         self.dat_version = 0
+
+    # Host/device coherence.  The reference has ONE buffer: every array ``dat.data`` ever returned aliases it, and code
+    # that holds such a view across parloops keeps working (pyop2/types/dat.py:145-204).  Here the host buffer
+    # ``_host`` is allocated once and never rebound -- downloads go INTO it, so views stay attached -- and the views
+    # handed out are plain ndarray views whose ``base`` collapses to ``_host``: while any of them is alive the
+    # reference count of ``_host`` says so.  Once a WRITABLE view has been handed out and views are still alive, the
+    # host may be written at any moment without this class hearing of it; the Dat is then kept coherent the expensive
+    # way: uploaded again before every device use, downloaded again after every device write (Parloop calls
+    # ``_after_device_write``).  When the last view dies the Dat returns to lazy mirroring.
+    def _views_alive(self) -> bool:
+        import sys
+        return sys.getrefcount(self._host) > 2               # our attribute + getrefcount's argument
 
     def _to_host(self):
         if not self._host_valid:
-            self._host = self._dev.download(self._host.dtype, self._host.shape)
+            if self._host.nbytes:
+                _lib.call("fd_memcpy_d2h", self._host.ctypes.data, self._dev.ptr, self._host.nbytes, None)
             self._host_valid = True
         return self._host
 
     def _dev_ptr(self, write: bool) -> int:
-        """Device pointer for a kernel; uploads if the host copy is newer."""
+        """Device pointer for a kernel; uploads if the host copy is newer (or may be: see above)."""
         if self._dev is None:
             self._dev = DeviceBuffer(self._host.nbytes)
             self._dev_valid = False
+        if self._rw_handed and self._host_valid and self._dev_valid:
+            if self._views_alive():
+                self._dev_valid = False                       # a live writable view: assume it was written
+            else:
+                self._rw_handed = False
         if not self._dev_valid:
-            self._dev.upload(self._host)
+            self._dev.upload(self._to_host())
             self._dev_valid = True
         if write:
             self._host_valid = False
             self.dat_version += 1
         return self._dev.ptr
 
+    def _after_device_write(self):
+        """Called once the kernels that wrote this carrier are queued: keep live writable views current."""
+        if self._rw_handed and not self._host_valid:
+            if self._views_alive():
+                self._to_host()
+            else:
+                self._rw_handed = False
+
     def _host_rw(self):
         h = self._to_host()
         self._dev_valid = False
+        self._rw_handed = True
         self.dat_version += 1
         return h
 

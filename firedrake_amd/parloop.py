@@ -498,6 +498,9 @@ class Parloop:
         self.reduction_end()
         self.local_to_global_end()
         self.finalize_assembly()
+        for pa, acc in zip(self.arguments, self.accesses):
+            if acc != READ and hasattr(pa.data, "_after_device_write"):
+                pa.data._after_device_write()      # live writable host views stay current (op2types._Mirrored)
 
     def _compute(self, part):
         offset, size = part
@@ -670,8 +673,15 @@ class Parloop:
 
     # -- halo protocol (parloop.py:320-409)
     def _indirect_dats(self):
+        """(Dat, access) of the indirectly accessed Dats, each data carrier once (the reference's ``seen`` sets,
+        pyop2/parloop.py:343-352, 393-403): one exchange per distinct Dat and direction."""
+        seen = set()
         for pa, acc in zip(self.arguments, self.accesses):
             if isinstance(pa, DatParloopArg) and pa.map_ is not None:
+                d = getattr(pa.data, "_parent", pa.data)          # a DatView exchanges its parent's storage
+                if id(d) in seen:
+                    continue
+                seen.add(id(d))
                 yield pa.data, acc
 
     def global_to_local_begin(self):

@@ -9,7 +9,7 @@ Follows (file:line relative to /root/reference):
   * subset indirection ........... pyop2/codegen/builder.py:744-752
   * layer loop + iteration regions pyop2/codegen/builder.py:790-831
   * extruded node addressing ..... pyop2/codegen/builder.py:80-128  (map + offset*(layer-bottom+k))
-  * Dat pack/unpack .............. pyop2/codegen/builder.py:352-429  (INC/WRITE zero-init; READ/RW/MIN/MAX gather;
+  * Dat pack/unpack .............. pyop2/codegen/builder.py:352-429  (INC/WRITE zero-init, MIN/MAX too when the kernel requires zeroed outputs; READ/RW/MIN/MAX gather;
                                    unpack += / min / max / =)
   * Global pack/unpack ........... pyop2/codegen/builder.py:262-319
   * Mat pack/unpack .............. pyop2/codegen/builder.py:550-625  (zero-init, MatSetValues[Blocked]Local)
@@ -106,6 +106,8 @@ class OMat:
     stats: dict = field(default_factory=dict)
     roffset_quotient: Optional[Sequence[int]] = None
     coffset_quotient: Optional[Sequence[int]] = None
+    rperm: Optional[Sequence[int]] = None     # PermutedMap on the row / column side (builder.py:144-176: the MatPack
+    cperm: Optional[Sequence[int]] = None     # indexes through the map's indexed(), which applies the permutation)
 
 
 @dataclass
@@ -170,8 +172,11 @@ int oracle_MatSetValuesLocal(oracle_mat *A, int nr, const int *rows, int nc, con
 
 def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
                      extruded=False, iteration_region=ALL, pass_layer_arg=False, threads=False,
-                     periodic=False, constant_layers=True):
-    """Emit the C wrapper (restating SURVEY.md Appendix A)."""
+                     periodic=False, constant_layers=True, init_with_zero=False):
+    """Emit the C wrapper (restating SURVEY.md Appendix A).  ``init_with_zero`` = the local kernel's
+    ``requires_zeroed_output_arguments``: MIN/MAX packs (Dat and Global) then start from zero instead of the current
+    values (builder.py:276-279, 368-371; passed down at builder.py:855, 871)."""
+    also_zero = (MIN, MAX) if init_with_zero else ()
     sig = ["int start", "int end"]
     if extruded:
         sig.append("const int *layers")
@@ -201,7 +206,11 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
 
     def node_expr(mname, arity, i, offset, perm, f="0", quotient=None):
         """map[e][perm[i]] + offset[i]*(layer - bottom + f), wrapped for periodic columns (builder.py:80-128)."""
-        ii = f"{mname}_perm[{i}]" if perm is not None else i
+        ii = i
+        if perm is not None:                      # one table per distinct permutation of this map
+            pname = f"{mname}_perm_" + "_".join(str(int(q)) for q in perm)
+            table(pname, perm)
+            ii = f"{pname}[{i}]"
         e = f"{mname}[(size_t)e*{arity} + {ii}]"
         if extruded and offset is not None:
             table(f"{mname}_off", offset)
@@ -226,8 +235,6 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
         c = a.cdim
         mn = map_name(a.map)
         ar = a.map.shape[1]
-        if a.perm is not None:
-            table(f"{mn}_perm", a.perm)
         nexpr = node_expr(mn, ar, 'i', a.offset, a.perm, 'f', a.offset_quotient)
         if a.view_index is not None:
             # builder.py:347-349, 365-367: a view packs one value per node, taken at the fixed component
@@ -240,7 +247,7 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
             loop = f"for (int f = 0; f < {nf}; ++f) for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j)"
             tt = f"{tname}[{toff} + (f*{ar}+i)*{c}+j]"
             comp = "j"
-        if access in (INC, WRITE):
+        if access in (INC, WRITE) + also_zero:
             body_pack.append(f"for (int q = 0; q < {n}; ++q) {tname}[{toff} + q] = 0;")
         else:
             body_pack.append(f"{loop} {tt} = {an}[(size_t)({nexpr})*{c} + {comp}];")
@@ -268,10 +275,10 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
         body_unpack.append(f"int r_{an}[{nf * ar}], c_{an}[{nf * ac}];")
         body_unpack.append(
             f"for (int f = 0; f < {nf}; ++f) for (int i = 0; i < {ar}; ++i) r_{an}[f*{ar}+i] = "
-            f"{node_expr(rn, ar, 'i', a.roffset, None, 'f', a.roffset_quotient)};")
+            f"{node_expr(rn, ar, 'i', a.roffset, a.rperm, 'f', a.roffset_quotient)};")
         body_unpack.append(
             f"for (int f = 0; f < {nf}; ++f) for (int i = 0; i < {ac}; ++i) c_{an}[f*{ac}+i] = "
-            f"{node_expr(cn, ac, 'i', a.coffset, None, 'f', a.coffset_quotient)};")
+            f"{node_expr(cn, ac, 'i', a.coffset, a.cperm, 'f', a.coffset_quotient)};")
         if a.unroll:
             body_unpack.append(f"int ru_{an}[{nf * ar * rbs}], cu_{an}[{nf * ac * cbs}];")
             body_unpack.append(f"for (int i = 0; i < {nf * ar}; ++i) for (int p = 0; p < {rbs}; ++p) "
@@ -313,6 +320,8 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
             else:
                 # private accumulator then combine (builder.py:292-319)
                 init = {INC: "0", MIN: f"arg{k}[q]", MAX: f"arg{k}[q]", WRITE: "0", RW: f"arg{k}[q]"}[a.access]
+                if a.access in also_zero:
+                    init = "0"
                 body_pack.append(f"{ct} t{k}[{n}]; for (int q = 0; q < {n}; ++q) t{k}[q] = {init};")
                 body_call.append(f"t{k}")
                 op = {INC: f"arg{k}[q] += t{k}[q];",
@@ -395,14 +404,14 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
 def par_loop(kernel_src: str, kernel_name: str, start: int, end: int, args, *,
              subset: Optional[np.ndarray] = None, layers: Optional[Tuple[int, int]] = None,
              iteration_region=ALL, pass_layer_arg=False, cflags=None, return_fn=False, threads=False,
-             periodic=False):
+             periodic=False, init_with_zero=False):
     """Generate + compile + run the wrapper over [start, end).  Arrays are modified in place.
     ``layers``: (bottom, top) for constant layers or an (nentities, 2) array for variable layers."""
     constant_layers = layers is None or np.ndim(layers) == 1
     code, maps = generate_wrapper(kernel_src, kernel_name, args, subset=subset is not None,
                                   extruded=layers is not None, iteration_region=iteration_region,
                                   pass_layer_arg=pass_layer_arg, threads=threads, periodic=periodic,
-                                  constant_layers=constant_layers)
+                                  constant_layers=constant_layers, init_with_zero=init_with_zero)
     lib = compile_c(code, "wrap_" + kernel_name + ("_omp" if threads else ""), extra_sources=[os.path.join(_HERE, "csr.c")],
                     cflags=cflags, threads=threads)
     fn = getattr(lib, "wrap_" + kernel_name)

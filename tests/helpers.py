@@ -57,7 +57,9 @@ def _omat(mat, maps, lgmaps, access, iterset, unroll=False):
                        col_lgmap=None if lg[1] is None else np.ascontiguousarray(lg[1], dtype=np.int32),
                        unroll=unroll,
                        roffset_quotient=rm.offset_quotient if ext else None,
-                       coffset_quotient=cm.offset_quotient if ext else None), csr
+                       coffset_quotient=cm.offset_quotient if ext else None,
+                       rperm=list(rm.permutation) if isinstance(rm, op2.PermutedMap) else None,
+                       cperm=list(cm.permutation) if isinstance(cm, op2.PermutedMap) else None), csr
 
 
 def oracle_run(kernel, iterset, *args, iteration_region=None, pass_layer_arg=False):
@@ -94,7 +96,8 @@ def oracle_run(kernel, iterset, *args, iteration_region=None, pass_layer_arg=Fal
         layers = tuple(int(x) for x in la[0]) if iterset.constant_layers else np.asarray(la, dtype=np.int32)
     oracle.par_loop(kernel.code, kernel.name, 0, iterset.size, oargs, subset=subset, layers=layers,
                     iteration_region=_REGION[iteration_region], pass_layer_arg=pass_layer_arg,
-                    periodic=bool(iterset._extruded and iterset._extruded_periodic))
+                    periodic=bool(iterset._extruded and iterset._extruded_periodic),
+                    init_with_zero=bool(getattr(kernel, "requires_zeroed_output_arguments", False)))
     return outs
 
 

@@ -447,3 +447,38 @@ def test_staged_wrapper_mixed_and_other_dtypes_on_host():
         got = run_staged(op2.LegacyParloop(k, it, acc(op2.INC, m27), src(op2.READ)), epb=64)[0]
         ref = oracle_run(k, it, op2.Dat(tgt ** 2, dtype=dt)(op2.INC, m27), src(op2.READ))[0]
         assert np.array_equal(got, ref)
+
+
+def test_zeroed_output_arguments_for_min_max():
+    """requires_zeroed_output_arguments: MIN/MAX packs (Dat through a map, and Global) start from ZERO, not from the
+    current values (pyop2/codegen/builder.py:276-279, 368-371, 855, 871).  The kernel below only ever raises its pack to
+    the entity value when that beats what the pack holds: with gathered packs a large current value survives, with
+    zeroed packs the result is max(current, max over entities of max(0, b))."""
+    rng = np.random.default_rng(8)
+    it, ind = op2.Set(30), op2.Set(11)
+    mp = op2.Map(it, ind, 2, rng.integers(0, 11, size=(30, 2)))
+    b = op2.Dat(it, rng.standard_normal(30))
+    code = "static void mz(double *a, double *g, const double *b) { for (int i = 0; i < 2; ++i) a[i] = a[i] < *b ? *b : a[i]; g[0] = g[0] < *b ? *b : g[0]; }"
+    for zeroed in (False, True):
+        a = op2.Dat(ind, np.full(11, -5.0))
+        g = op2.Global(1, -7.0)
+        k = op2.Kernel(code, "mz", requires_zeroed_output_arguments=zeroed)
+        got = _check(k, it, a(op2.MAX, mp), g(op2.MAX), b(op2.READ))
+        bm = max(0.0, b.data_ro.max()) if zeroed else b.data_ro.max()
+        assert got[1][0] == max(-7.0, bm)
+        if zeroed:
+            assert (got[0] >= 0.0).all()          # every touched node saw a zeroed pack (all 11 nodes are touched)
+
+
+def test_mat_through_permuted_maps():
+    """A Mat accessed through PermutedMaps: rows/columns are map[e][perm[i]] (MatPack goes through the map's indexed(),
+    builder.py:144-176, 573-625)."""
+    coords, cells = structured_tri_mesh(4, 3, perturb=0.2)
+    nodes, ele = op2.Set(len(coords)), op2.Set(len(cells))
+    m = op2.Map(ele, nodes, 3, cells)
+    pr, pc = op2.PermutedMap(m, [2, 0, 1]), op2.PermutedMap(m, [1, 2, 0])
+    x = op2.Dat(nodes ** 2, coords)
+    mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(m, m, None)]))
+    km = op2.Kernel("static void kpm(double *A, const double *x) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) "
+                    "A[i*3+j] += (i+1)*x[2*i] + 10*(j+1)*x[2*j+1]; }", "kpm")
+    _check(km, ele, mat(op2.INC, (pr, pc)), x(op2.READ, m))
