@@ -28,16 +28,20 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def algorithmic_bytes(ncell, arity, nnode, gdim, ncoeff, nnz=None):
-    """every input array read once, every output written once (+ the zeroing pass)."""
-    if nnz is None:   # residual: map + coords + coefficients + output write + zeroing
-        return ncell * arity * 4 + nnode * gdim * 8 + ncoeff * nnode * 8 + nnode * 8 + nnode * 8
-    return ncell * arity * 4 + nnode * gdim * 8 + nnz * 8 + nnz * 8      # Jacobian: map + coords + values + zeroing
+def algorithmic_bytes(ncell, arity, nnode, gdim, ncoeff, nnz=None, zeroing=False):
+    """every input array read once, every output written once.  ``zeroing`` adds the separate zeroing
+    pass of a13 -- counted only where a separate pass is actually executed inside the bracket the time comes from
+    (the owner-computes-rows Jacobian has none: it overwrites complete rows)."""
+    if nnz is None:   # residual kernel: map + coords + coefficients + output
+        return ncell * arity * 4 + nnode * gdim * 8 + ncoeff * nnode * 8 + nnode * 8 + (nnode * 8 if zeroing else 0)
+    return ncell * arity * 4 + nnode * gdim * 8 + nnz * 8 + (nnz * 8 if zeroing else 0)      # Jacobian: map + coords + values
 
 
-def cpu_baseline(n_sample, degree, seconds_hint=20.0):
-    """Time the oracle (CPU restatement of the PyOP2 wrapper, compiled with the reference's own
-    flags) on a bounded sample of the same workload: an n_sample^3-cube mesh, 1 thread."""
+def cpu_baseline(n_sample, degree, reps=10):
+    """Time the oracle (CPU restatement of the PyOP2 wrapper, compiled with the reference's own flags) on a bounded
+    sample of the same workload: an n_sample^3-cube mesh.  Headline = 1 thread (what one MPI rank of the reference
+    executes).  Beside it: all host threads, node-partitioned (each thread owns a contiguous node range and runs the
+    cells touching it, dropping foreign rows -- the shared-memory analogue of N ranks with a ghost-cell layer)."""
     import oracle
     from oracle import ODat, OMat, READ, INC
     from firedrake_amd import forms, mesh as fmesh
@@ -55,13 +59,18 @@ def cpu_baseline(n_sample, degree, seconds_hint=20.0):
     t0 = time.perf_counter()
     csr = oracle.build_sparsity(nn, nn, [(cm, cm)])
     t_sparsity = time.perf_counter() - t0
-    def timed(threads):
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+    def timed(threads, nrep):
+        kw = {}
+        if threads:
+            kw = {"threads": "owner", "owner_partition": oracle.make_owner_partition(cm, ncell, nn, cores)}
         fn_r, a_r, k1, _ = oracle.par_loop(kr.code, kr.name, 0, ncell, [ODat(r, INC, cm), ODat(coords, READ, xm), ODat(u, READ, cm), ODat(f, READ, cm)],
-                                           return_fn=True, threads=threads)
+                                           return_fn=True, **kw)
         fn_j, a_j, k2, cm_ = oracle.par_loop(kj.code, kj.name, 0, ncell, [OMat(csr, INC, cm, cm), ODat(coords, READ, xm)],
-                                             return_fn=True, threads=threads)
+                                             return_fn=True, **kw)
         ts = []
-        for _ in range(5):
+        for _ in range(nrep + 1):          # first repetition = warm-up (page faults, thread pool), dropped
             t0 = time.perf_counter()
             r[:] = 0
             fn_r(*a_r)
@@ -70,24 +79,20 @@ def cpu_baseline(n_sample, degree, seconds_hint=20.0):
             fn_j(*a_j)
             t2 = time.perf_counter()
             ts.append((t2 - t0, t1 - t0, t2 - t1))
-        ts.sort()
+        ts = sorted(ts[1:])
         return ts[len(ts) // 2]
 
-    tot1, tr1, tj1 = timed(False)
-    cores = os.cpu_count() or 1
-    totN, trN, tjN = timed(True)          # OpenMP over cells, atomic scatter: the shared-memory analogue of N ranks
+    tot1, tr1, tj1 = timed(False, reps)
+    totN, trN, tjN = timed(True, reps)
     multi = {"value": nn / totN, "cores": cores, "residual_dofs_per_s": nn / trN, "jacobian_dofs_per_s": nn / tjN,
-             "note": "OpenMP over contiguous cell ranges, thread-private residual vectors summed afterwards, atomic CSR adds "
-                     "(shared-memory analogue of N ranks)"}
-    single = {"value": nn / tot1, "cores": 1, "residual_dofs_per_s": nn / tr1, "jacobian_dofs_per_s": nn / tj1,
-              "note": "1 thread = what one MPI rank of the reference executes"}
-    best = multi if multi["value"] >= single["value"] else single
-    return {"value": best["value"], "unit": "DoFs/s", "cores": best["cores"], "kind": "port",
+             "note": "OpenMP, one thread per contiguous node range running the cells that touch it (owned + ghost cells), "
+                     "foreign rows dropped: no atomics, no private vectors (shared-memory analogue of N MPI ranks)"}
+    return {"value": nn / tot1, "unit": "DoFs/s", "cores": 1, "kind": "port",
             "sample": f"Poisson CG{degree} on UnitCubeMesh({n_sample}) tets: {ncell} cells, {nn} DoFs, residual+Jacobian, "
-                      f"median of 5; oracle = CPU restatement of the PyOP2 wrapper (not the reference binary), "
-                      f"gcc -O3 -march=native -ffast-math; the faster of 1 thread and {cores} OpenMP threads is reported",
-            "residual_dofs_per_s": best["residual_dofs_per_s"], "jacobian_dofs_per_s": best["jacobian_dofs_per_s"],
-            "single_thread": single, "all_host_threads": multi, "sparsity_build_s": t_sparsity}
+                      f"median of {reps} warm repetitions; oracle = CPU restatement of the PyOP2 wrapper (not the reference "
+                      f"binary), gcc -O3 -march=native -ffast-math; 1 thread = what one MPI rank of the reference executes",
+            "residual_dofs_per_s": nn / tr1, "jacobian_dofs_per_s": nn / tj1,
+            "all_host_threads": multi, "sparsity_build_s": t_sparsity}
 
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD datasheet; tools/microbench.hip measures 77.7 TFLOP/s with v_mfma_f64_16x16x4_f64
@@ -212,20 +217,195 @@ def run_c4(args):
                       "roofline": dominant, "roofline_per_loop": roofs, "cpu_baseline": None}))
 
 
+CALIB = (("wrap_fd_calib_read2", 2), ("wrap_fd_calib_read4", 4), ("wrap_fd_calib_read8", 8), ("wrap_fd_calib_read16", 16),
+         ("wrap_fd_calib_gather8", 8), ("wrap_fd_calib_write8", 8), ("wrap_fd_calib_atomic8", 8))
+
+
+def run_calibration():
+    """Launch the PMC calibration kernels (csrc/fd_builtin.hip) on 1 GiB buffers: known byte counts in the access widths
+    of the wrapper kernels.  Only useful under rocprofv3 --pmc (bench.py --inner-pmc)."""
+    import ctypes
+    from firedrake_amd import _lib
+    from firedrake_amd.device import DeviceBuffer
+    nbytes = 1 << 30
+    src, dst, sink = DeviceBuffer(nbytes), DeviceBuffer(nbytes), DeviceBuffer(8 * 65536)
+    src.zero(); dst.zero()
+    ngather = nbytes // 8
+    idx = DeviceBuffer.from_numpy(np.random.default_rng(0).permutation(ngather).astype(np.int32))
+    for name, width in CALIB:
+        h = ctypes.c_void_p()
+        _lib.call("fd_kernel_builtin", name.encode(), ctypes.byref(h))
+        n = nbytes // width
+        if name.endswith("gather8"):
+            ptrs = [src.ptr, idx.ptr, sink.ptr]
+        elif name.endswith("write8") or name.endswith("atomic8"):
+            ptrs = [dst.ptr]
+        else:
+            ptrs = [src.ptr, sink.ptr]
+        arr = (ctypes.c_void_p * len(ptrs))(*[ctypes.c_void_p(q) for q in ptrs])
+        for _ in range(2):
+            _lib.call("fd_kernel_launch", h.value, 0, n, arr, len(ptrs), 256, 0, 16384, 0, None)
+    _lib.call("fd_device_sync")
+
+
+def collect_traffic(argv_tail, kernels):
+    """HBM bytes per launch of ``kernels`` from rocprofv3 PMC passes of THIS command, run as child processes after the
+    timed region: FETCH_SIZE and WRITE_SIZE in separate passes with --kernel-trace only (MI355X_MICROARCH.md, HBM and PMC
+    sections).  The child also runs the calibration kernels, so the same CSVs hold the counter-to-byte factors of this
+    session for 2/4/8/16-byte streaming reads, 8-byte gathers, 8-byte writes and fp64 atomics."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, {"error": "rocprofv3 not found"}
+    mean = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix=f"fd_pmc_{counter}_", dir="/tmp")
+        cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+               sys.executable, os.path.join(ROOT, "bench.py"), "--inner-pmc", *argv_tail]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+        except (OSError, subprocess.TimeoutExpired) as exc:
+            return None, {"error": f"{counter} pass: {exc}"}
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return None, {"error": f"{counter} pass failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}"}
+        acc = {}
+        for fcsv in files:
+            with open(fcsv) as fh:
+                for row in csv.DictReader(fh):
+                    if row.get("Counter_Name") == counter:
+                        acc.setdefault(row["Kernel_Name"].split("(")[0].strip(), []).append(float(row["Counter_Value"]))
+        for k, v in acc.items():
+            mean.setdefault(k, {})[counter] = sum(v) / len(v)
+        shutil.rmtree(d, ignore_errors=True)
+    calib = {}
+    gib = float(1 << 30)
+    for name, width in CALIB:
+        c = mean.get(name)
+        if c:
+            moved = gib * (1.5 if name.endswith("gather8") else 1.0)        # the gather also streams its 4-byte index array
+            calib[name[len("wrap_fd_calib_"):]] = {
+                "known_read_bytes": 0.0 if ("write" in name or "atomic" in name) else moved,
+                "known_write_bytes": gib if ("write" in name or "atomic" in name) else 0.0,
+                "FETCH_SIZE_kb": c.get("FETCH_SIZE"), "WRITE_SIZE_kb": c.get("WRITE_SIZE")}
+    out = {}
+    for k in kernels:
+        c = mean.get(k)
+        if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            # guide formula: FETCH_SIZE counts 64 B per 128-B request on gfx950 -> doubled; WRITE_SIZE as reported
+            out[k] = {"hbm_bytes_per_launch": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0,
+                      "FETCH_SIZE_kb": c["FETCH_SIZE"], "WRITE_SIZE_kb": c["WRITE_SIZE"]}
+    return out, {"calibration": calib, "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes of this command"}
+
+
+def measure(prob, args, world, dist, backend, torch):
+    """Warm-up (first call timed on its own: JIT load + plan construction), then EXACTLY args.steps timed steps."""
+    from firedrake_amd import _lib
+    from firedrake_amd.device import Event
+
+    def sync():
+        _lib.call("fd_device_sync")
+
+    def barrier():
+        sync()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    first = {}
+    do_res, do_jac = args.only != "jacobian", args.only != "residual"
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        if do_res:
+            if world > 1:
+                prob.u.halo_valid = False      # a Newton step changes u: its ghost copies are refreshed every step
+            prob.assemble_residual(events=None if ev is None else (ev[1], ev[2]))
+        if ev is not None:
+            ev[3].record()
+        if do_jac:
+            prob.assemble_jacobian(events=None if ev is None else (ev[4], ev[5]))
+        if ev is not None:
+            ev[6].record()
+
+    # first call of each form on its own: code-object load + plan construction (one-off, SURVEY.md 8 a12)
+    sync()
+    t0 = time.perf_counter()
+    if do_res:
+        prob.assemble_residual()
+    sync()
+    first["plans_residual_first_call"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    if do_jac:
+        prob.assemble_jacobian()
+    sync()
+    first["plans_jacobian_first_call"] = time.perf_counter() - t0
+    for _ in range(max(args.warmup - 1, 0)):
+        step()
+    ev = [[Event() for _ in range(7)] for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(ev[k])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    med = lambda i, j: float(np.median([ev[k][i].elapsed_ms(ev[k][j]) for k in range(args.steps)]))
+    return {"ms_per_step": elapsed / args.steps * 1e3, "first": first,
+            "res_kernel_ms": med(1, 2) if do_res else None, "jac_kernel_ms": med(4, 5) if do_jac else None,
+            "res_assemble_ms": med(0, 3), "jac_assemble_ms": med(3, 6)}
+
+
+def exchange_only_ms(prob, reps, torch):
+    """Halo traffic of one step on its own (SURVEY.md 8e deliverable): forward exchange of u, reverse exchange of r."""
+    from firedrake_amd import _lib, op2
+    halo = prob.V.node_set.halo
+    if halo is None:
+        return None
+    _lib.call("fd_device_sync")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        prob.u.halo_valid = False
+        prob.u.global_to_local_begin(op2.READ)
+        prob.u.global_to_local_end(op2.READ)
+        prob.r.local_to_global_begin(op2.INC)
+        prob.r.local_to_global_end(op2.INC)
+    _lib.call("fd_device_sync")
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", "--size", dest="n", type=int, default=215, help="cubes per axis per GPU (215 -> ~10M DoF)")
-    ap.add_argument("--degree", type=int, default=1)
+    ap.add_argument("--n", "--size", dest="n", type=int, default=0, help="cubes per axis per GPU (default 215 -> ~10M CG1 DoF; c5: 107)")
+    ap.add_argument("--degree", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=128, help="cube size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-bcs", action="store_true")
     ap.add_argument("--tile", type=str, default="8,8,4", help="cubes per traversal tile (= plan block)")
+    ap.add_argument("--numbering", choices=["tiled", "lexicographic", "random"], default="tiled",
+                    help="entity numbering of the headline measurement (SURVEY.md 8d)")
+    ap.add_argument("--variants", type=str, default="lexicographic,random",
+                    help="further numberings measured after the headline one at N=1 (no producer hints); '' = none")
+    ap.add_argument("--traffic", choices=["auto", "off"], default="auto",
+                    help="auto: rocprofv3 PMC passes of this command (child processes) fill roofline.traffic at N=1")
+    ap.add_argument("--inner-pmc", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--only", choices=["both", "residual", "jacobian"], default="both", help="profiling aid: run one form only")
-    ap.add_argument("--workload", choices=["c1", "c2", "c3", "c4"], default="c2",
+    ap.add_argument("--workload", choices=["c1", "c2", "c3", "c4", "c5"], default="c2",
                     help="c2 = headline config (default); c1 = launch-bound 64x64 square (eager vs hipGraph); c3 = Q4 hex MFMA; "
-                         "c4 = DG advection RHS action")
+                         "c4 = DG advection RHS action; c5 = Poisson CG2, ~10M DoF per GPU (the multi-GPU config)")
     args = ap.parse_args()
     if args.workload == "c3":
         import torch  # noqa: F401
@@ -236,6 +416,11 @@ def main():
     if args.workload == "c4":
         import torch  # noqa: F401
         return run_c4(args)
+    if args.workload == "c5":
+        args.degree = args.degree or 2
+        args.n = args.n or 107
+    args.degree = args.degree or 1
+    args.n = args.n or 215
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -255,106 +440,106 @@ def main():
         else:
             dist.init_process_group(backend)
     from firedrake_amd import _lib, forms, mesh as fmesh
-    from firedrake_amd.device import Event
     _lib.require_gpu()
     _lib.call("fd_set_device", local_rank)
 
     n = args.n
-    t0 = time.perf_counter()
-    mesh = fmesh.UnitCubeMesh((n, n, n * world), degrees=(args.degree,), rank=rank, nranks=world, perturb=0.1,
-                              tile=tuple(int(v) for v in args.tile.split(",")))
-    prob = forms.PoissonProblem(mesh, args.degree, bcs=not args.no_bcs)
-    t_mesh = time.perf_counter() - t0
+    tile = tuple(int(v) for v in args.tile.split(","))
+
+    def build(numbering):
+        t0 = time.perf_counter()
+        mesh = fmesh.UnitCubeMesh((n, n, n * world), degrees=(args.degree,), rank=rank, nranks=world, perturb=0.1, tile=tile,
+                                  numbering=numbering)
+        prob = forms.PoissonProblem(mesh, args.degree, bcs=not args.no_bcs)
+        t_mesh = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        mat, _ = prob.jacobian()
+        mat.sparsity._build()
+        _lib.call("fd_device_sync")
+        return mesh, prob, {"mesh": t_mesh, "sparsity": time.perf_counter() - t0}
+
+    mesh, prob, setup = build(args.numbering)
     V = prob.V
     ndofs_global = V.global_dofs
     ncell_local = mesh.cell_set.size
-    t0 = time.perf_counter()
-    mat, _ = prob.jacobian()
-    mat.sparsity._build()
-    nnz = mat.sparsity.nz
-    _lib.call("fd_device_sync")
-    t_sparsity = time.perf_counter() - t0
-
-    ev = [[Event() for _ in range(4)] for _ in range(args.steps)]
-
-    def step(k=None):
-        if k is not None:
-            ev[k][0].record()
-        if args.only != "jacobian":
-            if world > 1:
-                prob.u.halo_valid = False      # a Newton step changes u: its ghost copies are refreshed every step
-            prob.assemble_residual()
-        if k is not None:
-            ev[k][1].record()
-            ev[k][2].record()
-        if args.only != "residual":
-            prob.assemble_jacobian()
-        if k is not None:
-            ev[k][3].record()
-
-    def barrier():
-        _lib.call("fd_device_sync")
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = elapsed / args.steps * 1e3
-    t_res = float(np.median([ev[k][0].elapsed_ms(ev[k][1]) for k in range(args.steps)]))
-    t_jac = float(np.median([ev[k][2].elapsed_ms(ev[k][3]) for k in range(args.steps)]))
+    nnz = prob.jacobian()[0].sparsity.nz
+    res = measure(prob, args, world, dist, backend, torch)
+    setup.update(res["first"])
+    if args.inner_pmc:
+        run_calibration()
+        return
+    exch = exchange_only_ms(prob, max(args.steps, 5), torch) if world > 1 else None
 
     if rank == 0:
         arity = V.cell_node_map.arity
         nnode_local = V.node_set.total_size
-        b_res = algorithmic_bytes(ncell_local, arity, nnode_local, 3, 2)
-        b_jac = algorithmic_bytes(ncell_local, arity, nnode_local, 3, 0, nnz)
-        roof_res = {"kernel": prob.res_loop.global_kernel.name, "bound": "hbm", "achieved": b_res / (t_res * 1e-3) / 1e9,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "ms": t_res, "algorithmic_bytes": b_res}
-        roof_res["frac"] = roof_res["achieved"] / HBM_PEAK_GBS
-        roof_jac = {"kernel": prob.jacobian()[1].global_kernel.name, "bound": "hbm", "achieved": b_jac / (t_jac * 1e-3) / 1e9,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "ms": t_jac, "algorithmic_bytes": b_jac}
-        roof_jac["frac"] = roof_jac["achieved"] / HBM_PEAK_GBS
-        # HBM bytes per launch from the rocprofv3 PMC passes of this same command (tools/pmc.sh ->
-        # profiles/r1i_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) KB, MI355X_MICROARCH.md HBM section); only
-        # valid for the default workload it was collected on
-        tname = next((t for t in ("r1j_traffic.json", "r1i_traffic.json")
-                      if os.path.exists(os.path.join(ROOT, "profiles", t))), None)
-        if tname and n == 215 and args.degree == 1 and world == 1 and args.tile == "8,8,4":
-            tr = json.load(open(os.path.join(ROOT, "profiles", tname)))
-            for roof in (roof_res, roof_jac):
-                t = tr.get(roof["kernel"], {}).get("hbm_bytes_per_launch")
-                if t:
-                    roof["traffic"] = t
-                    roof["traffic_source"] = f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes)"
-        dominant = roof_jac if t_jac >= t_res else roof_res
+        kres, kjac = prob.res_loop.global_kernel.name, prob.jacobian()[1].global_kernel.name
+        jac_ocr = prob.jacobian()[1]._prepared["cw"].src.mode.startswith("ocr") if prob.jacobian()[1]._prepared else False
+
+        def roof(kernel, ms, nbytes, **extra):
+            d = {"kernel": kernel, "bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "ms": ms, "algorithmic_bytes": nbytes}
+            d.update(extra)
+            return d
+
+        roof_res = roof_jac = None
+        if res["res_kernel_ms"]:
+            # the wrapper kernel alone: map + coords + 2 coefficients + the output, against the kernel's own duration
+            b = algorithmic_bytes(ncell_local, arity, nnode_local, 3, 2)
+            roof_res = roof(kres, res["res_kernel_ms"], b, assemble_ms=res["res_assemble_ms"],
+                            note="kernel-only bytes and time; assemble_ms adds the zeroing pass (a13) and the BC fix-up (a14)")
+        if res["jac_kernel_ms"]:
+            # owner-computes-rows writes complete rows and performs NO zeroing pass: strict bytes = map + coords + values.
+            # frac_with_zeroing credits the nnz*8 zeroing traffic SURVEY.md 8(d) lists for the reference's two-pass scheme.
+            b = algorithmic_bytes(ncell_local, arity, nnode_local, 3, 0, nnz, zeroing=not jac_ocr)
+            bz = algorithmic_bytes(ncell_local, arity, nnode_local, 3, 0, nnz, zeroing=True)
+            roof_jac = roof(kjac, res["jac_kernel_ms"], b, assemble_ms=res["jac_assemble_ms"],
+                            frac_with_zeroing=bz / (res["jac_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            note="kernel-only; strict bytes (no credit for the zeroing pass the kernel makes unnecessary)")
+        roofs = [r for r in (roof_res, roof_jac) if r]
+        dominant = max(roofs, key=lambda r: r["ms"])
+        traffic_meta = None
+        if args.traffic == "auto" and world == 1:
+            tail = ["--steps", "3", "--warmup", "1", "--cpu-sample", "0", "--n", str(n), "--degree", str(args.degree),
+                    "--tile", args.tile, "--numbering", args.numbering, "--only", args.only, "--traffic", "off", "--variants", ""]
+            if args.no_bcs:
+                tail.append("--no-bcs")
+            tr, traffic_meta = collect_traffic(tail, [r["kernel"] for r in roofs])
+            for r in roofs:
+                if tr and r["kernel"] in tr:
+                    r["traffic"] = tr[r["kernel"]]["hbm_bytes_per_launch"]
+                    r["traffic_counters_kb"] = {"FETCH_SIZE": tr[r["kernel"]]["FETCH_SIZE_kb"], "WRITE_SIZE": tr[r["kernel"]]["WRITE_SIZE_kb"]}
         out = {
             "metric": "assembled DoFs/sec (residual + Jacobian)",
-            "value": ndofs_global / (ms_per_step * 1e-3),
+            "value": ndofs_global / (res["ms_per_step"] * 1e-3),
             "unit": "DoFs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"Poisson CG{args.degree} residual+Jacobian on UnitCubeMesh({n},{n},{n * world}) tets "
-                                   f"(BASELINE.json configs[1]), z-slab per GPU",
+                                   f"(BASELINE.json configs[{1 if args.degree == 1 else 4}]), z-slab per GPU",
                        "cells_per_gpu": ncell_local, "dofs_global": ndofs_global, "nnz_per_gpu": int(nnz),
-                       "parallelism": f"domain-decomposition x{world}", "bcs": not args.no_bcs},
-            "residual_dofs_per_s": V.node_set.size * world / (t_res * 1e-3),
-            "jacobian_dofs_per_s": V.node_set.size * world / (t_jac * 1e-3),
+                       "parallelism": f"domain-decomposition x{world}", "bcs": not args.no_bcs, "numbering": args.numbering},
+            "residual_dofs_per_s": ndofs_global / (res["res_assemble_ms"] * 1e-3) if roof_res else None,
+            "jacobian_dofs_per_s": ndofs_global / (res["jac_assemble_ms"] * 1e-3) if roof_jac else None,
             "roofline": dominant, "roofline_residual": roof_res, "roofline_jacobian": roof_jac,
-            "setup_s": {"mesh": t_mesh, "sparsity_and_tables": t_sparsity},
+            "traffic_meta": traffic_meta,
+            "setup_s": setup,
+            "exchange_ms": exch,
         }
+    # further numberings (no producer hints): locality dependence of the same step, N = 1 only
+    if world == 1 and args.variants:
+        for nb in [v for v in args.variants.split(",") if v and v != args.numbering]:
+            del prob, mesh
+            import gc
+            gc.collect()
+            mesh, prob, st = build(nb)
+            r2 = measure(prob, args, world, dist, backend, torch)
+            out[f"value_{nb}_numbering"] = ndofs_global / (r2["ms_per_step"] * 1e-3)
+            out[f"detail_{nb}_numbering"] = {"ms_per_step": r2["ms_per_step"], "residual_kernel_ms": r2["res_kernel_ms"],
+                                             "jacobian_kernel_ms": r2["jac_kernel_ms"], "setup_s": {**st, **r2["first"]}}
+    if rank == 0:
         if args.cpu_sample > 0 and world == 1:       # reported baseline: rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.degree)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample if args.degree == 1 else min(args.cpu_sample, 64), args.degree)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -355,12 +355,18 @@ class PoissonProblem:
             self._bc_dev = DeviceBuffer.from_numpy(np.ascontiguousarray(self.bc_nodes, dtype=np.int32))
         return self._bc_dev
 
-    def assemble_residual(self):
+    def assemble_residual(self, events=None):
+        """``events``: optional (before, after) device events recorded around the cell parloop alone (bench.py's
+        per-kernel roofline; the zeroing pass and the BC fix-up stay outside that bracket)."""
         import ctypes
         from . import _lib
         self.r.zero()                                   # a13: zeroing is part of every assemble
         with self.r.frozen_halo(op2.INC):
+            if events:
+                events[0].record()
             self.res_loop()
+            if events:
+                events[1].record()
         if len(self.bc_nodes):                          # a14: bc.zero(tensor)  (bcs.py:192-221)
             _lib.call("fd_dat_set_rows", self.r._dev_ptr(True), 1, self._bc_rows().ptr, len(self.bc_nodes),
                       ctypes.c_double(0.0), None)
@@ -391,12 +397,16 @@ class PoissonProblem:
             self._jac = (mat, loop)
         return self._jac
 
-    def assemble_jacobian(self):
+    def assemble_jacobian(self, events=None):
         import ctypes
         from . import _lib
         mat, loop = self.jacobian()
         mat.zero()
+        if events:
+            events[0].record()
         loop()
+        if events:
+            events[1].record()
         if len(self.bc_nodes):
             sp = mat.sparsity
             _lib.call("fd_csr_set_diagonal", sp._rowptr.ptr, sp._colidx.ptr, mat._values_dev().ptr, self._bc_rows().ptr,

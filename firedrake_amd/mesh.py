@@ -93,9 +93,26 @@ def _split_blocks(blocks, arity, max_entries=32768):
         blocks = np.sort(np.concatenate([blocks, mids]))
 
 
-def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0, ghost_cells=True):
-    """Kuhn-split tetrahedral unit cube, z-slab partitioned.  ``tile`` = cubes per traversal tile."""
+NUMBERINGS = ("tiled", "lexicographic", "random")
+
+
+def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0, ghost_cells=True, numbering="tiled",
+                 seed=0):
+    """Kuhn-split tetrahedral unit cube, z-slab partitioned.  ``tile`` = cubes per traversal tile.
+
+    ``numbering`` (SURVEY.md 8d asks for a locality-dependence variant of every measurement):
+      * ``"tiled"``          cells walk the grid tile by tile, nodes are numbered tile by tile, and the Maps carry the
+                             tile boundaries as producer hints (``preferred_blocks`` / ``preferred_node_blocks``);
+      * ``"lexicographic"``  cells in plain x-fastest order inside each class, nodes numbered in order of first
+                             appearance while walking the cells' closures -- the rule of dmcommon.pyx:2688-2712 applied
+                             to an un-tiled cell order -- and NO hints: what a DMPlex-produced mesh looks like to the backend;
+      * ``"random"``         cells and nodes randomly permuted inside each class (seeded), no hints: the worst case.
+    """
+    if numbering not in NUMBERINGS:
+        raise ValueError(f"numbering must be one of {NUMBERINGS}")
     nx, ny, nz = (int(n),) * 3 if np.isscalar(n) else tuple(int(v) for v in n)
+    if numbering != "tiled":
+        tile = (nx, ny, nz)          # one tile = plain lexicographic traversal
     # ---- cube slab owned by this rank (+ one ghost cube layer each side)
     k0 = (nz * rank) // nranks
     k1 = (nz * (rank + 1)) // nranks
@@ -115,6 +132,8 @@ def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0,
         ccls[kk == k1 - 1] = 1
     ccls[(kk < k0) | (kk >= k1)] = 2
     key = _tile_keys(ii, jj, kk - glo, nx, ny, ghi - glo, tile) + ccls.astype(np.int64) * (1 << 50)
+    if numbering == "random":
+        key = np.random.default_rng(seed + 1000 * rank).permutation(len(ii)).astype(np.int64) + ccls.astype(np.int64) * (1 << 50)
     order = np.argsort(key, kind="stable")
     ii, jj, kk, ccls = ii[order], jj[order], kk[order], ccls[order]
     ncube = len(ii)
@@ -162,6 +181,17 @@ def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0,
                           p * nx, p * ny, p * (ghi - glo), tl)
         # tie-break inside a tile by the true coordinates so keys are unique
         nkey = (nkey + ncls.astype(np.int64) * (1 << 50)) * 8 + ((zz - zlo) // (p * (ghi - glo))) * 4 + (yy // (p * ny)) * 2 + xx // (p * nx)
+        if numbering == "lexicographic":
+            # first appearance in the cell traversal (vertices of a cell before its edge nodes, as the closure walk
+            # of dmcommon.pyx:2688-2712 meets them); lattice points no local cell touches keep the grid order, last
+            first = np.full(len(xx), np.iinfo(np.int64).max, dtype=np.int64)
+            flat = box.reshape(-1)
+            # first occurrence of every node: assign positions in REVERSE order, the last write (= earliest position) stays
+            first[flat[::-1]] = np.arange(len(flat) - 1, -1, -1, dtype=np.int64)
+            nkey = ncls.astype(np.int64) * (1 << 50) + np.minimum(first, (1 << 49))
+            nkey = nkey * 2                        # keep "key // 8 // tile volume" below meaningful only for "tiled"
+        elif numbering == "random":
+            nkey = ncls.astype(np.int64) * (1 << 50) + np.random.default_rng(seed + 7 + 1000 * rank + p).permutation(len(xx))
         norder = np.argsort(nkey, kind="stable")
         newnum = np.empty(len(norder), dtype=np.int32)
         newnum[norder] = np.arange(len(norder), dtype=np.int32)
@@ -191,10 +221,11 @@ def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0,
                     halo.recv[rank - 1] = np.concatenate([plane_nodes(z) for z in range(zlo, p * k0)])
         node_set = op2.Set(sizes_n, f"cg{p}_nodes")
         m = op2.Map(cell_set, node_set, arity, cmap, f"cell_cg{p}")
-        m.preferred_blocks = _split_blocks(cell_blocks, arity)
-        # node ranges of the traversal tiles (row blocks for owner-computes-rows matrix assembly)
-        ntile = (nkey[norder] // 8) // (tl[0] * tl[1] * tl[2])
-        m.preferred_node_blocks = np.concatenate([[0], np.nonzero(np.diff(ntile))[0] + 1, [len(norder)]]).astype(np.int32)
+        if numbering == "tiled":
+            m.preferred_blocks = _split_blocks(cell_blocks, arity)
+            # node ranges of the traversal tiles (row blocks for owner-computes-rows matrix assembly)
+            ntile = (nkey[norder] // 8) // (tl[0] * tl[1] * tl[2])
+            m.preferred_node_blocks = np.concatenate([[0], np.nonzero(np.diff(ntile))[0] + 1, [len(norder)]]).astype(np.int32)
         return FunctionSpaceData(p, node_set, m, pts, halo, bnd, (p * nx + 1) * (p * ny + 1) * (p * nz + 1))
 
     spaces = {}

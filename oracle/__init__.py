@@ -14,6 +14,6 @@ kernels* for the five configs are "parity unpinned" at the element-tensor level
 here -- SURVEY.md 8c); they are validated by the analytic identities the
 reference's regression tests use.
 """
-from .wrapper import (ODat, OGlobal, OMat, OMixedDat, OMixedMat, OracleCSR, par_loop, build_sparsity,  # noqa: F401
+from .wrapper import (ODat, OGlobal, OMat, OMixedDat, OMixedMat, OracleCSR, par_loop, build_sparsity, make_owner_partition,  # noqa: F401
                       READ, WRITE, RW, INC, MIN, MAX, ALL, ON_BOTTOM, ON_TOP,
                       ON_INTERIOR_FACETS, generate_wrapper, compile_c)

@@ -201,6 +201,13 @@ void oracle_expand_blocks(int nnode_rows, const int *nrowptr, const int *ncolidx
 }
 
 /* ---- insertion --------------------------------------------------------- */
+/* the dropped-entry statistic is kept by the sequential build only: under OpenMP every thread would hammer one counter */
+#ifdef _OPENMP
+#define ORACLE_COUNT_DROPPED(A) ((void)0)
+#else
+#define ORACLE_COUNT_DROPPED(A) ((A)->dropped++)
+#endif
+
 
 static inline void add_scalar(oracle_mat *A, int row, int col, double v, int insert)
 {
@@ -237,7 +244,7 @@ int oracle_MatSetValuesBlockedLocal(oracle_mat *A, int nr, const int *rows,
                 int cn = cols[j];
                 if (cn >= 0 && A->col_lgmap) cn = A->col_lgmap[cn];
                 for (int q = 0; q < cbs; ++q) {
-                    if (rn < 0 || cn < 0) { A->dropped++; continue; }
+                    if (rn < 0 || cn < 0) { ORACLE_COUNT_DROPPED(A); continue; }
                     double v = vals[(((size_t)i * rbs + p) * nc + j) * cbs + q];
                     add_scalar(A, rn * rbs + p, cn * cbs + q, v, insert);
                 }
@@ -257,7 +264,7 @@ int oracle_MatSetValuesLocal(oracle_mat *A, int nr, const int *rows,
         for (int j = 0; j < nc; ++j) {
             int c = cols[j];
             if (c >= 0 && A->col_lgmap) c = A->col_lgmap[c];
-            if (r < 0 || c < 0) { A->dropped++; continue; }
+            if (r < 0 || c < 0) { ORACLE_COUNT_DROPPED(A); continue; }
             add_scalar(A, r, c, vals[(size_t)i * nc + j], insert);
         }
     }

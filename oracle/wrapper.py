@@ -177,6 +177,11 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
     ``requires_zeroed_output_arguments``: MIN/MAX packs (Dat and Global) then start from zero instead of the current
     values (builder.py:276-279, 368-371; passed down at builder.py:855, 871)."""
     also_zero = (MIN, MAX) if init_with_zero else ()
+    # threads == "owner": the shared-memory analogue of N MPI ranks of the reference.  Thread t owns the node range
+    # [trange[t], trange[t+1]) of the output's node set and executes the cells that touch it (tcells, the rank-local cell
+    # set including its ghost-cell layer); contributions to nodes/rows outside the range are dropped, exactly like the
+    # off-process rows a rank of the owner-computes partition never assembles.  No atomics, no private vectors.
+    owner = threads == "owner"
     sig = ["int start", "int end"]
     if extruded:
         sig.append("const int *layers")
@@ -253,13 +258,17 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
             body_pack.append(f"{loop} {tt} = {an}[(size_t)({nexpr})*{c} + {comp}];")
         if access != READ:
             lhs = f"{an}[(size_t)({nexpr})*{c} + {comp}]"
-            if threads and access == INC:
+            if threads and not owner and access == INC:
                 lhs = lhs.replace(f"{an}[", f"priv_{an}[", 1)
                 priv.append((an, ct, a.data.size))
             op = {INC: f"{lhs} += {tt};",
                   MIN: f"{lhs} = {lhs} < {tt} ? {lhs} : {tt};",
                   MAX: f"{lhs} = {lhs} > {tt} ? {lhs} : {tt};",
                   WRITE: f"{lhs} = {tt};", RW: f"{lhs} = {tt};"}[access]
+            if owner:
+                if access != INC:
+                    raise ValueError("owner-partitioned threading supports INC outputs only")
+                op = f"{{ const int nd_ = {nexpr}; if (nd_ >= own_lo && nd_ < own_hi) {op} }}"
             body_unpack.append(f"{loop} {op}")
         return n
 
@@ -279,6 +288,8 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
         body_unpack.append(
             f"for (int f = 0; f < {nf}; ++f) for (int i = 0; i < {ac}; ++i) c_{an}[f*{ac}+i] = "
             f"{node_expr(cn, ac, 'i', a.coffset, a.cperm, 'f', a.coffset_quotient)};")
+        if owner:
+            body_unpack.append(f"for (int i = 0; i < {nf * ar}; ++i) if (r_{an}[i] < own_lo || r_{an}[i] >= own_hi) r_{an}[i] = -1;")
         if a.unroll:
             body_unpack.append(f"int ru_{an}[{nf * ar * rbs}], cu_{an}[{nf * ac * cbs}];")
             body_unpack.append(f"for (int i = 0; i < {nf * ar}; ++i) for (int p = 0; p < {rbs}; ++p) "
@@ -358,6 +369,8 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
             raise TypeError(a)
     for _, nm in maps:
         sig.append(f"const int *{nm}")
+    if owner:
+        sig += ["int nthreads_", "const int *trange", "const int *tcell_off", "const int *tcells"]
     if pass_layer_arg:
         body_call.append("layer")
 
@@ -365,7 +378,13 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
     kernel_src = re.sub(r'^[ \t]*#[ \t]*include[ \t]*[<"]petsc[a-z]*\.h[>"][ \t]*$', "", kernel_src, flags=re.M)
     lines = [_PREAMBLE, "#include <stdlib.h>", "#define ORACLE_REM(a, b) ((a) < (b) ? (a) : (a) - (b))",
              kernel_src, *decls, f"int wrap_{kernel_name}({', '.join(sig)})", "{"]
-    if threads:
+    if owner:
+        lines += ['  _Pragma("omp parallel for schedule(static, 1) num_threads(nthreads_)")',
+                  "  for (int th_ = 0; th_ < nthreads_; ++th_) {",
+                  "  const int own_lo = trange[th_], own_hi = trange[th_ + 1];",
+                  "  for (int n = tcell_off[th_]; n < tcell_off[th_ + 1]; ++n) {",
+                  "    int e = tcells[n];"]
+    elif threads:
         # shared-memory analogue of rank-local assembly + local_to_global SUM (pyop2/types/dat.py:659-678):
         # contiguous entity ranges per thread, private output vectors summed afterwards
         lines.append('  _Pragma("omp parallel")')
@@ -373,8 +392,9 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
         for an, ct, n in priv:
             lines.append(f"  {ct} *priv_{an} = ({ct} *)calloc({n}, sizeof({ct}));")
         lines.append('  _Pragma("omp for schedule(static)")')
-    lines += ["  for (int n = start; n < end; ++n) {",
-              "    int e = " + ("subset_indices[n];" if subset else "n;")]
+    if not owner:
+        lines += ["  for (int n = start; n < end; ++n) {",
+                  "    int e = " + ("subset_indices[n];" if subset else "n;")]
     if extruded:
         # builder.py:790-812; periodic columns have one more interior facet (between the top and the bottom cell)
         lo, hi = {ALL: ("lay[0]", "lay[1]-1"),
@@ -391,7 +411,9 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
     if extruded:
         lines.append("    }")
     lines.append("  }")
-    if threads:
+    if owner:
+        lines.append("  }")
+    elif threads:
         for an, ct, n in priv:
             lines.append('  _Pragma("omp critical")')
             lines.append(f"  for (long q = 0; q < {n}; ++q) {an}[q] += priv_{an}[q];")
@@ -404,15 +426,17 @@ def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,
 def par_loop(kernel_src: str, kernel_name: str, start: int, end: int, args, *,
              subset: Optional[np.ndarray] = None, layers: Optional[Tuple[int, int]] = None,
              iteration_region=ALL, pass_layer_arg=False, cflags=None, return_fn=False, threads=False,
-             periodic=False, init_with_zero=False):
+             periodic=False, init_with_zero=False, owner_partition=None):
     """Generate + compile + run the wrapper over [start, end).  Arrays are modified in place.
-    ``layers``: (bottom, top) for constant layers or an (nentities, 2) array for variable layers."""
+    ``layers``: (bottom, top) for constant layers or an (nentities, 2) array for variable layers.
+    ``threads="owner"`` with ``owner_partition=(trange, tcell_off, tcells)`` (see make_owner_partition()): node-partitioned
+    OpenMP execution, one thread per node range."""
     constant_layers = layers is None or np.ndim(layers) == 1
     code, maps = generate_wrapper(kernel_src, kernel_name, args, subset=subset is not None,
                                   extruded=layers is not None, iteration_region=iteration_region,
                                   pass_layer_arg=pass_layer_arg, threads=threads, periodic=periodic,
                                   constant_layers=constant_layers, init_with_zero=init_with_zero)
-    lib = compile_c(code, "wrap_" + kernel_name + ("_omp" if threads else ""), extra_sources=[os.path.join(_HERE, "csr.c")],
+    lib = compile_c(code, "wrap_" + kernel_name + ("_own" if threads == "owner" else "_omp" if threads else ""), extra_sources=[os.path.join(_HERE, "csr.c")],
                     cflags=cflags, threads=threads)
     fn = getattr(lib, "wrap_" + kernel_name)
     cargs = [ctypes.c_int(start), ctypes.c_int(end)]
@@ -452,6 +476,11 @@ def par_loop(kernel_src: str, kernel_name: str, start: int, end: int, args, *,
     for m in maps:
         assert m.dtype == np.int32 and m.flags.c_contiguous, "maps must be contiguous int32"
         cargs.append(m.ctypes.data_as(ctypes.c_void_p))
+    if threads == "owner":
+        trange, tcell_off, tcells = (np.ascontiguousarray(x, dtype=np.int32) for x in owner_partition)
+        keep += [trange, tcell_off, tcells]
+        cargs.append(ctypes.c_int(len(trange) - 1))
+        cargs += [x.ctypes.data_as(ctypes.c_void_p) for x in (trange, tcell_off, tcells)]
     fn.restype = ctypes.c_int
     if return_fn:
         return fn, cargs, keep, cmats
@@ -461,6 +490,30 @@ def par_loop(kernel_src: str, kernel_name: str, start: int, end: int, args, *,
         if cm.missing:
             raise RuntimeError(f"{cm.missing} matrix entries outside the sparsity")
     return None
+
+
+def make_owner_partition(mapv: np.ndarray, ncell: int, nnode: int, nthreads: int):
+    """(trange, tcell_off, tcells) for ``threads="owner"``: thread t owns nodes [trange[t], trange[t+1]) and runs the
+    cells of [0, ncell) that touch one of them -- the analogue of one MPI rank's owned + ghost cells
+    (firedrake/mesh.py:1131-1179 with the vertex-adjacent overlap of SURVEY.md 8e option 1)."""
+    trange = (np.arange(nthreads + 1, dtype=np.int64) * nnode // nthreads).astype(np.int32)
+    owner_of = np.searchsorted(trange, mapv[:ncell], side="right") - 1            # (ncell, arity)
+    lo, hi = owner_of.min(axis=1), owner_of.max(axis=1)
+    lists = []
+    if (hi - lo).max() <= 1:
+        # cells straddle at most two neighbouring ranges (contiguous partitions of a locality-preserving numbering)
+        ids = np.arange(ncell, dtype=np.int32)
+        both = hi > lo
+        owner_t = np.concatenate([lo, hi[both]])
+        cell = np.concatenate([ids, ids[both]])
+    else:
+        pairs = np.unique(np.stack([owner_of.reshape(-1), np.repeat(np.arange(ncell), mapv.shape[1])], axis=1), axis=0)
+        owner_t, cell = pairs[:, 0], pairs[:, 1].astype(np.int32)
+    order = np.argsort(owner_t, kind="stable")
+    tcells = cell[order].astype(np.int32)
+    tcell_off = np.concatenate([[0], np.cumsum(np.bincount(owner_t, minlength=nthreads))]).astype(np.int32)
+    del lists
+    return trange, tcell_off, tcells
 
 
 _csr_lib = None

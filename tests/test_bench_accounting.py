@@ -1,6 +1,6 @@
 """CPU: the byte accounting behind ``roofline.achieved`` in bench.py is the one SURVEY.md 8(d) defines (every input array
-read once, every output written once, plus the zeroing pass) -- pinned to the figures quoted there for config C2 --
-and the C2 mesh sizes are the ones the scope table states."""
+read once, every output written once; the zeroing pass only where a separate pass exists) -- pinned to the figures quoted
+there for config C2 -- and the C2 mesh sizes are the ones the scope table states."""
 import importlib.util
 import os
 
@@ -20,13 +20,38 @@ def test_c2_algorithmic_bytes_match_the_scope_table():
     ncell, nnode = 6 * N ** 3, (N + 1) ** 3
     nnz = nnode + 2 * (7 * N ** 3 + 9 * N ** 2 + 3 * N)          # vertices + 2 * edges
     assert (ncell, nnode, nnz) == (59630250, 10077696, 150048286)
-    # residual with ONE coefficient: map 954 MB + coords 242 MB + u 81 MB + output 81 MB + zeroing 81 MB = 1.44 GB
+    # residual with ONE coefficient: map 954 MB + coords 242 MB + u 81 MB + output 81 MB = 1.36 GB (+ zeroing 81 MB = 1.44 GB)
     r1 = b.algorithmic_bytes(ncell, 4, nnode, 3, 1)
-    assert abs(r1 - 1.44e9) < 0.01e9
-    assert r1 == ncell * 16 + nnode * 24 + nnode * 8 + 2 * nnode * 8
-    # the benchmark's residual reads two coefficients (u and f): + 81 MB
-    assert b.algorithmic_bytes(ncell, 4, nnode, 3, 2) == r1 + nnode * 8 == 1518434976
-    # Jacobian: map + coords + values + zeroing = 954 MB + 242 MB + 1.20 GB + 1.20 GB = 3.60 GB
+    assert abs(r1 - 1.36e9) < 0.01e9 and r1 == ncell * 16 + nnode * 24 + nnode * 8 + nnode * 8
+    assert abs(b.algorithmic_bytes(ncell, 4, nnode, 3, 1, zeroing=True) - 1.44e9) < 0.01e9
+    # the benchmark's residual kernel reads two coefficients (u and f): + 81 MB; the memset is outside the kernel bracket
+    assert b.algorithmic_bytes(ncell, 4, nnode, 3, 2) == r1 + nnode * 8 == 1437813408
+    # Jacobian, strict (owner-computes-rows: complete rows are written once, no zeroing pass): 954 MB + 242 MB + 1.20 GB
     j = b.algorithmic_bytes(ncell, 4, nnode, 3, 0, nnz)
-    assert j == 3596721280 and abs(j - 3.60e9) < 0.01e9
+    assert j == 2396334992 and abs(j - 2.396e9) < 0.001e9
+    # with the reference's separate zeroing pass: 3.60 GB
+    assert b.algorithmic_bytes(ncell, 4, nnode, 3, 0, nnz, zeroing=True) == 3596721280
     assert b.HBM_PEAK_GBS == 8000.0
+
+
+def test_cpu_baseline_owner_partition_matches_serial():
+    """The node-partitioned OpenMP mode behind cpu_baseline.all_host_threads assembles exactly what one thread does."""
+    import numpy as np
+    import oracle
+    from oracle import ODat, OMat, READ, INC
+    from firedrake_amd import forms, mesh as fmesh
+    m = fmesh.UnitCubeMesh(9, degrees=(1,), perturb=0.1, tile=(4, 4, 2))
+    V = m.space(1)
+    cm, nn, nc = V.cell_node_map.values_with_halo, V.node_set.total_size, m.cell_set.size
+    coords = np.array(m.coordinates.data_ro_with_halos)
+    u, f = np.sin(3 * V.node_points[:, 0]), np.cos(V.node_points[:, 1])
+    kr, kj = forms.poisson_residual_kernel(3, 1), forms.poisson_jacobian_kernel(3, 1)
+    out = []
+    for kw in ({}, {"threads": "owner", "owner_partition": oracle.make_owner_partition(cm, nc, nn, 5)}):
+        csr = oracle.build_sparsity(nn, nn, [(cm, cm)])
+        r = np.zeros(nn)
+        oracle.par_loop(kr.code, kr.name, 0, nc, [ODat(r, INC, cm), ODat(coords, READ, cm), ODat(u, READ, cm), ODat(f, READ, cm)], **kw)
+        oracle.par_loop(kj.code, kj.name, 0, nc, [OMat(csr, INC, cm, cm), ODat(coords, READ, cm)], **kw)
+        out.append((r, csr.values.copy()))
+    assert np.abs(out[0][0] - out[1][0]).max() <= 1e-13 * np.abs(out[0][0]).max()
+    assert np.abs(out[0][1] - out[1][1]).max() <= 1e-13 * np.abs(out[0][1]).max()
