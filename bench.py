@@ -84,7 +84,15 @@ def cpu_baseline(n_sample, degree, reps=10):
 
     tot1, tr1, tj1 = timed(False, reps)
     totN, trN, tjN = timed(True, reps)
-    multi = {"value": nn / totN, "cores": cores, "residual_dofs_per_s": nn / trN, "jacobian_dofs_per_s": nn / tjN,
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:          # "max 100000" or "<quota> <period>": CPU time the container may use
+            q = fh.read().split()
+            quota = None if q[0] == "max" else float(q[0]) / float(q[1])
+    except (OSError, ValueError, IndexError):
+        pass
+    multi = {"value": nn / totN, "cores": cores, "cgroup_cpu_quota_cores": quota,
+             "residual_dofs_per_s": nn / trN, "jacobian_dofs_per_s": nn / tjN,
              "note": "OpenMP, one thread per contiguous node range running the cells that touch it (owned + ghost cells), "
                      "foreign rows dropped: no atomics, no private vectors (shared-memory analogue of N MPI ranks)"}
     return {"value": nn / tot1, "unit": "DoFs/s", "cores": 1, "kind": "port",

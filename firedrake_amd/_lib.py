@@ -53,6 +53,21 @@ SIGNATURES = {
     "fd_kernel_free": (c_int, [c_void_p]),
     "fd_kernel_launch": (c_int, [c_void_p, c_int32, c_int32, POINTER(c_void_p), c_int, c_int, c_int, c_int,
                                  c_size_t, c_void_p]),
+    "fd_comm_available": (c_int, []),
+    "fd_comm_unique_id": (c_int, [c_void_p]),
+    "fd_comm_create": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    "fd_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+    "fd_comm_free": (c_int, [c_void_p]),
+    "fd_comm_allreduce": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "fd_halo_create": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
+    "fd_halo_free": (c_int, [c_void_p]),
+    "fd_halo_g2l_begin": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "fd_halo_g2l_end": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "fd_halo_l2g_begin": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "fd_halo_l2g_end": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "fd_halo_wire_buffers": (c_int, [c_void_p, c_void_p, c_int, POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p),
+                                     POINTER(c_int64)]),
+    "fd_dat_fill_range": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "fd_plan_create": (c_int, [c_void_p, c_int, c_int32, c_int32, c_int, c_void_p, POINTER(c_void_p)]),
     "fd_plan_create_blocks": (c_int, [c_void_p, c_int, c_void_p, c_int32, c_void_p, POINTER(c_void_p)]),
     "fd_ocrplan_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -8,13 +8,13 @@ and ``pyop2/local_kernel.py:86-227`` define -- which is also what makes the tran
 
 * **function level** (this module): ``compile_global_kernel_hip(kernel, comm)`` replaces
   ``pyop2.global_kernel.compile_global_kernel`` (global_kernel.py:426-456).  The returned callable takes the reference's
-  positional list -- ``start, end, [layers], [subset], one pointer per Dat/Global, one per distinct Map`` -- with DEVICE
-  pointers (the carriers' ``_kernel_args_`` patched as INTEGRATION.md shows) and launches the *direct* wrapper, which
-  needs nothing but that list.  Matrix arguments are PETSc ``Mat`` handles in the reference's list and have no meaning
-  on the device: loops with Mat arguments, and the staged / owner-computes-rows fast paths (which need the
-  backend-private plan tables), go through
+  positional list -- ``start, end, [layers], [subset], one pointer per Dat/Global/Mat, one per distinct Map`` -- with
+  DEVICE pointers (the carriers' ``_kernel_args_`` patched as INTEGRATION.md shows; a Mat slot carries the handle of a
+  ``DeviceMat``, the device CSR that stands where the PETSc ``Mat`` handle stood) and runs the same staged /
+  owner-computes-rows / direct wrappers the native Parloop picks: the backend-private plan tables are resolved inside
+  ``func``, keyed on the Map pointers, the Mat handle and the iteration range, and cached across calls.
 * **Parloop level**: ``firedrake_amd.parloop.Parloop`` is the worked replacement of ``pyop2.parloop.Parloop`` (same
-  protocol, ``_arglist`` appends the private tables); ``as_fd_global_kernel`` is what it needs from PyOP2's side.
+  protocol, halo exchanges included); ``as_fd_global_kernel`` is what it needs from PyOP2's side.
 """
 from __future__ import annotations
 
@@ -105,25 +105,263 @@ def as_fd_global_kernel(gk):
                           pass_layer_arg=bool(getattr(gk, "_pass_layer_arg", False)))
 
 
+# ---- the function-level seam ------------------------------------------------------------------------------------------
+# The reference's call is ``func(start, end, *arglist)`` with raw pointers taken from the carriers' ``_kernel_args_``
+# (pyop2/parloop.py:203-232, global_kernel.py:327-335): Dat -> data pointer (dat.py:94-96), Map -> values pointer
+# (map.py:57-59), Global -> data pointer (glob.py:32-33), ExtrudedSet -> layers pointer (set.py:351-353), Subset ->
+# indices pointer (set.py:434-436), Mat -> the PETSc ``Mat`` handle (mat.py:621-623).  The replacement receives DEVICE
+# pointers in the same slots; in a Mat slot it receives the handle of a ``DeviceMat`` (below): the device CSR the
+# carrier-side patch created for that matrix.  Everything backend-private -- block-localisation plans keyed on the Map
+# pointer and the iteration range, owner-computes-rows plans keyed on (Mat handle, Map pointers, range), element->nonzero
+# tables -- is resolved INSIDE ``func`` and cached, so the reference's Parloop needs no change beyond the carrier patches.
+
+_device_mats = {}
+_device_maps = {}
+
+
+class DeviceMat:
+    """Device CSR behind a PyOP2 ``Mat`` (the ``handle`` is what the patched ``Mat._kernel_args_`` returns).
+
+    ``rowptr/colidx/values`` are device pointers of the scalar ("aij") pattern; ``nrows_owned`` = rows this rank
+    assembles (the row Set's ``size``; the CSR holds ``nrows`` >= that).  ``set_lgmaps`` mirrors the lgmap swap the
+    reference performs around the wrapper call for boundary conditions (pyop2/parloop.py:279-314): device int32 arrays
+    with -1 for dropped rows/columns, or None.  ``zero()`` is ``Mat.zero()`` (mat.py:851-855): deferred, an
+    owner-computes-rows assembly that follows overwrites complete rows instead of memset + add."""
+
+    _next = [1]
+
+    def __init__(self, rowptr, colidx, values, nrows, nnz, nrows_owned=None, ncols=None, rbs=1, cbs=1):
+        from .device import DeviceBuffer
+        self.handle = (DeviceMat._next[0] << 4) | 0xD            # never a plausible device address
+        DeviceMat._next[0] += 1
+        self.nrows, self.ncols, self.nnz = int(nrows), int(ncols if ncols is not None else nrows), int(nnz)
+        self.nrows_owned = int(nrows if nrows_owned is None else nrows_owned)
+        self.rbs, self.cbs = int(rbs), int(cbs)
+        wrap = lambda p, n: DeviceBuffer.wrap(int(p), int(n), owned=False)       # noqa: E731
+        self.rowptr, self.colidx, self.values = wrap(rowptr, (self.nrows + 1) * 4), wrap(colidx, max(nnz, 1) * 4), wrap(values, max(nnz, 1) * 8)
+        self.lgmaps = None
+        self._carriers = {}
+        self._zero_requested = False
+        _device_mats[self.handle] = self
+
+    def set_lgmaps(self, row_ptr, col_ptr):
+        if (row_ptr is None) != (col_ptr is None):
+            raise ValueError("set_lgmaps: give both the row and the column lgmap (identity = arange), or neither")
+        self.lgmaps = None if row_ptr is None else (_RawIntArray(row_ptr), _RawIntArray(col_ptr))
+
+    def zero(self):
+        self._zero_requested = True
+
+    def free(self):
+        _device_mats.pop(self.handle, None)
+
+
+def register_map(ptr, nent_total, arity, toset_sizes, iterset_sizes=None, preferred_blocks=None, preferred_node_blocks=None):
+    """Optional: tell the backend what it cannot read off a bare Map pointer -- the (core, owned, total) sizes of the Set
+    the Map points into (needed when a Mat is assembled through it: only owned rows are assembled here), the number of
+    map rows, and the producer's block hints.  Unregistered maps work for Dat-only loops."""
+    _device_maps[int(ptr)] = {"nent": int(nent_total), "arity": int(arity), "toset": tuple(int(v) for v in np.atleast_1d(toset_sizes)),
+                              "iterset": None if iterset_sizes is None else tuple(int(v) for v in np.atleast_1d(iterset_sizes)),
+                              "pb": preferred_blocks, "pnb": preferred_node_blocks}
+
+
+class _RawIntArray:
+    """A device int32 array known only by its pointer (Parloop._lgmap accepts objects with ``_fd_dev_ptr``)."""
+
+    def __init__(self, ptr):
+        self._fd_dev_ptr = int(ptr) if ptr is not None else 0
+
+
+class _Shape:
+    """Stands in for a host array nobody may read: only ``shape``/``len`` are known."""
+
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+    def __len__(self):
+        return self.shape[0]
+
+
+def _borrowed_carriers(fd, arglist, start, end):
+    """Carriers of this backend (Set/Map/Dat/Global/Sparsity/Mat) that BORROW the device memory behind ``arglist``."""
+    from . import op2
+    from .device import DeviceBuffer
+    from .parloop import DatParloopArg, GlobalParloopArg, MatParloopArg
+    from .op2types import Dat, Global, Map, Mat, Sparsity
+    it = iter(arglist)
+    layers_ptr = next(it) if fd._extruded else None
+    subset_ptr = next(it) if fd._subset else None
+    arg_ptrs = [next(it) for _ in fd.arguments]
+    from .codegen import _distinct_maps
+    mkas, mindex = _distinct_maps(fd)
+    map_ptrs = [next(it) for _ in mkas]
+    if fd._extruded or fd._subset:
+        raise NotImplementedError("function-level seam: extruded / subset loops keep the direct wrapper")
+    iter_total = max([_device_maps.get(int(p), {}).get("nent", 0) for p in map_ptrs] + [int(end)])
+    iterset = op2.Set((int(end), int(end), iter_total) if iter_total > end else int(end), "seam_iterset")
+    tosets, maps = {}, []
+    for mka, ptr in zip(mkas, map_ptrs):
+        info = _device_maps.get(int(ptr))
+        sizes = info["toset"] if info else None
+        m = Map.__new__(Map)
+        m._iterset, m._arity, m.name = iterset, mka.arity, f"seam_map_{int(ptr):x}"
+        m._toset = tosets.setdefault(sizes, op2.Set(sizes if sizes and len(sizes) == 3 else (sizes[0] if sizes else 1), "seam_toset")) if sizes else None
+        m._values = _Shape((iter_total, mka.arity))
+        m._offset, m._offset_quotient, m._plans = mka.offset, mka.offset_quotient, {}
+        m._dev = DeviceBuffer.wrap(int(ptr), iter_total * mka.arity * 4, owned=False)
+        if info and info["pb"] is not None:
+            m.preferred_blocks = info["pb"]
+        if info and info["pnb"] is not None:
+            m.preferred_node_blocks = info["pnb"]
+        maps.append(m)
+
+    def map_of(mka):
+        if mka is None:
+            return None
+        base = mka.base_map if isinstance(mka, K.PermutedMapKernelArg) else mka
+        m = maps[mindex[id(base)]]
+        return op2.PermutedMap(m, mka.permutation) if isinstance(mka, K.PermutedMapKernelArg) else m
+
+    pargs = []
+    for a, la, ptr in zip(fd.arguments, fd.local_kernel.arguments, arg_ptrs):
+        if isinstance(a, K.DatKernelArg):
+            m = map_of(a.map_)
+            d = _BorrowedDat(int(ptr), a.dim, la.dtype)
+            pargs.append(DatParloopArg(d, m))
+        elif isinstance(a, K.GlobalKernelArg):
+            pargs.append(GlobalParloopArg(_BorrowedDat(int(ptr), a.dim, la.dtype)))
+        elif isinstance(a, K.MatKernelArg):
+            dm = _device_mats.get(int(ptr))
+            if dm is None:
+                raise ValueError("a Mat slot must hold the handle of a bridge.DeviceMat")
+            rm, cm = (map_of(x) for x in a.maps)
+            for m in (rm, cm):
+                if m._base()._toset is None:
+                    raise ValueError("maps a Mat is assembled through must be registered (bridge.register_map): the owned row count is needed")
+            key = (id(rm._base()), id(cm._base()))
+            mat = dm._carriers.get(key)
+            if mat is None:
+                sp = Sparsity.__new__(Sparsity)
+                sp._nested, sp._blocks, sp._built, sp._elem_tables = False, [[sp]], True, {}
+                sp._dsets = (op2.DataSet(rm.toset, dm.rbs), op2.DataSet(cm.toset, dm.cbs))
+                sp._pairs, sp._has_diagonal, sp.name = [], True, "seam_sparsity"
+                if dm.rbs * dm.cbs != 1:
+                    raise NotImplementedError("function-level seam: vector-valued matrix blocks")
+                sp._node_rowptr = sp._rowptr = dm.rowptr
+                sp._node_colidx = sp._colidx = dm.colidx
+                sp._node_nnz = sp._nnz = dm.nnz
+                mat = Mat.__new__(Mat)
+                mat._sparsity, mat._dtype, mat.name, mat._vals = sp, np.dtype("float64"), "seam_mat", dm.values
+                mat._zero_pending, mat.dat_version, mat._blocks = False, 0, [[mat]]
+                mat._fd_device_mat = dm
+                dm._carriers[key] = mat
+            pargs.append(MatParloopArg(mat, (rm, cm), dm.lgmaps))
+        else:
+            raise NotImplementedError(f"function-level seam: {type(a).__name__}")
+    return iterset, pargs
+
+
+class _BorrowedDat:
+    """A Dat/Global whose storage is somebody else's device memory: the wrapper only ever asks for the pointer."""
+
+    def __init__(self, ptr, dim, dtype):
+        self._ptr, self.dim, self.dtype = ptr, tuple(dim), np.dtype(dtype)
+        self.cdim = int(np.prod(dim))
+        self._halo_frozen, self.halo_valid, self.dat_version = False, True, 0
+
+    class _NoHalo:
+        halo = None
+    dataset = type("DS", (), {"set": _NoHalo(), "size": 0, "total_size": 0})()
+
+    def _dev_ptr(self, write):
+        return self._ptr
+
+    def global_to_local_begin(self, *_):      # the reference's Parloop performs the exchanges around func
+        pass
+
+    global_to_local_end = local_to_global_begin = local_to_global_end = global_to_local_begin
+
+
 def compile_global_kernel_hip(kernel, comm=None):
-    """Replacement for ``pyop2.global_kernel.compile_global_kernel``: same cache role, same returned signature
-    ``func(start, end, *arglist)``.  See the module docstring for what the function-level seam covers."""
+    """Replacement for ``pyop2.global_kernel.compile_global_kernel`` (global_kernel.py:426-456): same cache role, same
+    returned signature ``func(start, end, *arglist)``, and the SAME wrapper shapes the native Parloop uses -- staged
+    (LDS gather / reduction) for Dat loops, owner-computes-rows for matrix loops, direct otherwise.  ``arglist`` holds
+    device pointers in the reference's positional order; a Mat slot holds a ``DeviceMat.handle``."""
+    from .codegen import select_mode
+    from .parloop import Parloop
     fd = as_fd_global_kernel(kernel)
     if fd.is_mixed:
         fd = fd.flattened()
-    if any(isinstance(a, K.MatKernelArg) for a in fd.arguments):
-        raise NotImplementedError("loops with Mat arguments need the Parloop-level integration "
-                                  "(firedrake_amd.parloop.Parloop): a PETSc Mat handle means nothing on the device")
-    cw = fd.compile("direct")
-    nref = sum(1 for d in cw.src.layout if d[0] in ("layers", "subset", "arg", "map"))
-    threads = cw.src.block_threads
+    mode = select_mode(fd)
+    nlead = (1 if fd._extruded else 0) + (1 if fd._subset else 0)
+    nref = nlead + len(fd.arguments)
+    from .codegen import _distinct_maps
+    nref += len(_distinct_maps(fd)[0])
+    loops = {}
+    has_mat = any(isinstance(a, K.MatKernelArg) for a in fd.arguments)
+    # the descriptor does not say whether BC-masked lgmaps will be swapped in around a call (pyop2/parloop.py:279-314
+    # does that on the PETSc Mat): the wrapper variant with lgmap parameters is built on first need
+    variants = {False: fd}
+
+    def variant(with_lgmaps):
+        if with_lgmaps not in variants:
+            import dataclasses
+            args = [dataclasses.replace(a, lgmaps=True) if isinstance(a, K.MatKernelArg) else a for a in fd.arguments]
+            variants[True] = K.GlobalKernel(fd.local_kernel, args, extruded=fd._extruded, extruded_periodic=fd._extruded_periodic,
+                                            constant_layers=fd._constant_layers, subset=fd._subset,
+                                            iteration_region=fd._iteration_region, pass_layer_arg=fd._pass_layer_arg)
+        return variants[with_lgmaps]
 
     def func(start, end, *arglist):
         if len(arglist) != nref:
             raise ValueError(f"{fd.name}: expected {nref} arguments after (start, end), got {len(arglist)}")
-        args = list(arglist) + [0] * (len(cw.src.layout) - nref)           # backend-private slots unused by `direct`
-        n = max(int(end) - int(start), 0)
-        cw.launch(start, end, args, block_threads=threads, ents_per_block=threads,
-                  nblocks=max(1, min((n + threads - 1) // threads, 256 * 32)))
-    func.wrapper = cw
+        start, end = int(start), int(end)
+        if mode == "direct" and not has_mat:
+            # needs nothing but the reference's own list
+            cw = fd.compile("direct")
+            args = list(arglist) + [0] * (len(cw.src.layout) - nref)
+            threads, n = cw.src.block_threads, max(end - start, 0)
+            if fd._extruded:
+                raise NotImplementedError("function-level seam: extruded loops need the layer count (Parloop level)")
+            cw.launch(start, end, args, block_threads=threads, ents_per_block=threads,
+                      nblocks=max(1, min((n + threads - 1) // threads, 256 * 32)))
+            return 0
+        with_lg = False
+        if has_mat:
+            for a, ptr in zip(fd.arguments, arglist[nlead:]):
+                if isinstance(a, K.MatKernelArg):
+                    dm = _device_mats.get(int(ptr))
+                    if dm is None:
+                        raise ValueError("a Mat slot must hold the handle of a bridge.DeviceMat")
+                    with_lg = with_lg or dm.lgmaps is not None
+        key = (with_lg,) + tuple(int(a) if a is not None else 0 for a in arglist)
+        pl = loops.get(key)
+        if pl is None:
+            from .configuration import configuration
+            gk = variant(with_lg)
+            iterset, pargs = _borrowed_carriers(gk, arglist, start, end)
+            old = configuration["type_check"]
+            configuration["type_check"] = 0          # the carriers are pointer shells: nothing to check against
+            try:
+                pl = Parloop(gk, iterset, pargs)
+            finally:
+                configuration["type_check"] = old
+            loops[key] = pl
+        if end <= start:
+            return 0
+        for pa in pl.arguments:
+            dm = getattr(getattr(pa, "data", None), "_fd_device_mat", None)
+            if dm is not None:
+                pa.lgmaps = dm.lgmaps                # the lgmap swap of pyop2/parloop.py:279-314 happens per call
+                if dm._zero_requested:               # Mat.zero() since the last assembly: consumed by this launch
+                    pa.data._zero_pending = True
+                    dm._zero_requested = False
+        if pl._prepare()["cw"].src.mode.startswith("ocr"):
+            pl._compute_ocr(start, end)
+        else:
+            pl._compute((start, end - start))
+        return 0
+    func.global_kernel = fd
+    func.mode = mode
+    func.loops = loops
     return func

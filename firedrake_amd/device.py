@@ -19,10 +19,11 @@ class DeviceBuffer:
         self._owned = True
 
     @classmethod
-    def wrap(cls, ptr: int, nbytes: int, owner=None):
-        """Adopt device memory allocated inside libfdhip (released with fd_free on GC)."""
+    def wrap(cls, ptr: int, nbytes: int, owner=None, owned=True):
+        """Adopt device memory allocated inside libfdhip (released with fd_free on GC), or -- ``owned=False`` --
+        borrow memory that belongs to somebody else (the function-level seam, bridge.py)."""
         b = cls.__new__(cls)
-        b.ptr, b.nbytes, b._owned = ptr, int(nbytes), True
+        b.ptr, b.nbytes, b._owned = ptr, int(nbytes), bool(owned)
         return b
 
     @classmethod

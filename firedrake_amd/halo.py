@@ -1,24 +1,27 @@
-"""Halo exchange of shared DoFs as an RCCL neighbour all-to-all over xGMI.
+"""Halo exchange of shared DoFs as an RCCL neighbour all-to-all over xGMI, driven through the C ABI.
 
-Concrete counterpart of firedrake/halo.py:87-172 (a PetscSF over DoFs, ``bcastBegin/End`` for
-owner->ghost with MPI.REPLACE and ``reduceBegin/End`` for ghost->owner with SUM/MIN/MAX) behind
-the abstract interface of pyop2/types/halo.py:4-56.  One process per GPU; the per-neighbour
-send/receive node lists come from the mesh partitioner (mesh.HaloLists).  A transfer is
+Concrete counterpart of firedrake/halo.py:87-172 (a PetscSF over DoFs, ``bcastBegin/End`` for owner->ghost with
+MPI.REPLACE and ``reduceBegin/End`` for ghost->owner with SUM/MIN/MAX) behind the abstract interface of
+pyop2/types/halo.py:4-56.  One process per GPU; the per-neighbour send/receive node lists come from the mesh partitioner
+(mesh.HaloLists).  The exchange itself lives in libfdhip.so (csrc/fd_comm.hip: ``fd_halo_create`` /
+``fd_halo_{g2l,l2g}_{begin,end}``): device-resident index lists, persistent packed buffers, pack kernel -> ONE grouped
+``ncclSend``/``ncclRecv`` exchange on a side stream -> unpack kernel (=, +=, min, max), ordered by events so the host
+never waits and the transfer overlaps the core-entity kernel exactly where the reference overlaps MPI with
+``_compute(core_part)`` (pyop2/parloop.py:250-253).  Messages are O(1 MB) per neighbour: latency-bound,
+hence one grouped exchange per Dat and no ring collective.
 
-    pack kernel (fd_halo_pack) -> batched isend/irecv on the packed buffers (RCCL grouped
-    ncclSend/ncclRecv) -> unpack kernel (fd_halo_unpack: =, +=, min, max)
+Wire selection (``Halo.wire``):
 
-``*_begin`` posts the transfers, ``*_end`` waits and unpacks, so the exchange overlaps the
-core-entity kernel exactly like the reference's begin/end split (pyop2/parloop.py:250-253).
-Messages are O(1 MB) per neighbour: latency-bound, hence one grouped
-send/recv per neighbour and no ring collective.
-
-For the CPU-only protocol tests (``gloo`` backend, world_size 2) the same class runs with
-host tensors when FDHIP_HALO_HOST=1 is set by the test: pack/unpack are then torch index ops.
-This is test plumbing for the rank protocol, never used when a GPU is present.
+``rccl``   the library's own communicator (``fd_comm_create`` = ncclCommInitRank; the 128-byte id is broadcast through
+           ``torch.distributed``, which is only the process launcher/rendezvous here).  Default whenever
+           ``torch.distributed`` runs with the ``nccl`` backend.
+``host``   non-NCCL backends (gloo: the CPU-launched multi-rank tests, ranks sharing one GPU): the same C-ABI pack /
+           unpack and persistent device buffers, the packed rows bounced through host tensors.
+``hostsim`` FDHIP_HALO_HOST=1: no device at all -- torch index ops on the host arrays; protocol tests on CPU-only machines.
 """
 from __future__ import annotations
 
+import ctypes
 import os
 
 import numpy as np
@@ -26,6 +29,8 @@ import numpy as np
 from .op2types import INC, MAX, MIN, READ, RW, WRITE
 
 _OPS = {WRITE: 0, INC: 1, MIN: 2, MAX: 3}
+DTYPE_CODE = {np.dtype("float64"): 0, np.dtype("float32"): 1, np.dtype("int32"): 2, np.dtype("uint32"): 3,
+              np.dtype("int64"): 4, np.dtype("uint64"): 5}
 
 
 def _dist():
@@ -50,55 +55,204 @@ def attach_halo(space):
     space.node_set.halo = Halo(h)
 
 
+# ---- the process-wide RCCL communicator of the library ---------------------------------------------------------------
+_comm = {"handle": None, "tried": False, "why": None}
+
+
+def communicator():
+    """The library's RCCL communicator over all ranks (created on first use, collectively), or None when the wire is
+    not RCCL (non-NCCL torch backend, FDHIP_HALO_WIRE=host, or librccl.so missing -- the reason is kept in
+    ``communicator_status()``)."""
+    if _comm["tried"]:
+        return _comm["handle"]
+    _comm["tried"] = True
+    dist = _dist()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        _comm["why"] = "single process"
+        return None
+    want = os.environ.get("FDHIP_HALO_WIRE", "auto")
+    if want == "host" or (want == "auto" and dist.get_backend() != "nccl"):
+        _comm["why"] = f"wire=host (torch.distributed backend {dist.get_backend()})"
+        return None
+    from . import _lib
+    lib = _lib.load()
+    rank, nranks = dist.get_rank(), dist.get_world_size()
+    ok = bool(lib.fd_comm_available())
+    # every rank must take the same branch: agree on availability first
+    flags = [None] * nranks
+    dist.all_gather_object(flags, ok)
+    if not all(flags):
+        _comm["why"] = "librccl.so could not be bound on every rank: " + (lib.fd_last_error() or b"").decode()
+        return None
+    uid = (ctypes.c_ubyte * 128)()
+    if rank == 0:
+        _lib.call("fd_comm_unique_id", uid)
+    box = [bytes(uid)]
+    dist.broadcast_object_list(box, src=0)
+    buf = (ctypes.c_ubyte * 128).from_buffer_copy(box[0])
+    h = ctypes.c_void_p()
+    _lib.call("fd_comm_create", buf, rank, nranks, ctypes.byref(h))
+    _comm["handle"], _comm["why"] = h.value, "rccl"
+    return h.value
+
+
+def communicator_status():
+    return _comm["why"]
+
+
 class Halo:
-    """pyop2/types/halo.py interface implemented over torch.distributed (backend nccl == RCCL)."""
+    """pyop2/types/halo.py interface over the C-ABI exchange."""
 
     def __init__(self, lists):
         self.lists = lists
         self.rank, self.nranks = lists.rank, lists.nranks
         self.host_mode = os.environ.get("FDHIP_HALO_HOST", "0") == "1"
-        self._dev_idx = {}
+        self._h = None
+        self._host_idx = {}
         self._pending = {}
 
     # -- helpers
     def _neighbours(self):
         return sorted(set(self.lists.send) | set(self.lists.recv))
 
+    def _lists(self, r):
+        e = np.zeros(0, dtype=np.int32)
+        return (np.ascontiguousarray(self.lists.send.get(r, e), dtype=np.int32),
+                np.ascontiguousarray(self.lists.recv.get(r, e), dtype=np.int32))
+
+    @property
+    def wire(self):
+        if self.host_mode:
+            return "hostsim"
+        self._handle()
+        return "rccl" if self._comm else "host"
+
+    def _handle(self):
+        """fd_halo_t of this Halo (created on first use; collective when the wire is RCCL)."""
+        if self._h is None:
+            from . import _lib
+            self._comm = communicator()
+            nb = self._neighbours()
+            self._nb = nb
+            pairs = [self._lists(r) for r in nb]
+            n = len(nb)
+            peers = (ctypes.c_int32 * max(n, 1))(*nb)
+            sp = (ctypes.c_void_p * max(n, 1))(*[p[0].ctypes.data for p in pairs])
+            rp = (ctypes.c_void_p * max(n, 1))(*[p[1].ctypes.data for p in pairs])
+            ns = (ctypes.c_int32 * max(n, 1))(*[len(p[0]) for p in pairs])
+            nr = (ctypes.c_int32 * max(n, 1))(*[len(p[1]) for p in pairs])
+            h = ctypes.c_void_p()
+            _lib.call("fd_halo_create", self._comm, n, peers, sp, ns, rp, nr, ctypes.byref(h))
+            self._h = h.value
+            self._nsend = [len(p[0]) for p in pairs]
+            self._nrecv = [len(p[1]) for p in pairs]
+        return self._h
+
+    def __del__(self):
+        try:
+            if self._h:
+                from . import _lib
+                _lib.load().fd_halo_free(self._h)
+        except Exception:
+            pass
+
+    @staticmethod
+    def _code(dat):
+        try:
+            return DTYPE_CODE[np.dtype(dat.dtype)]
+        except KeyError:
+            raise TypeError(f"halo exchange is not implemented for Dats of type {dat.dtype}")
+
+    # -- device exchange through the C ABI
+    def _begin(self, dat, direction, op):
+        from . import _lib
+        h, code = self._handle(), self._code(dat)
+        ptr = dat._dev_ptr(False)                              # begin only reads the Dat
+        if direction == 0:
+            _lib.call("fd_halo_g2l_begin", h, ptr, dat.cdim, code, None)
+        else:
+            _lib.call("fd_halo_l2g_begin", h, ptr, dat.cdim, code, op, None)
+        if self._comm:
+            return
+        # external wire: bounce the packed rows through the host (gloo and friends)
+        import torch
+        dist = _dist()
+        sb, rb, ns, nr = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64()
+        _lib.call("fd_halo_wire_buffers", h, ptr, direction, ctypes.byref(sb), ctypes.byref(ns), ctypes.byref(rb), ctypes.byref(nr))
+        row = dat.cdim * np.dtype(dat.dtype).itemsize
+        out_counts = self._nsend if direction == 0 else self._nrecv
+        in_counts = self._nrecv if direction == 0 else self._nsend
+        sendh = np.empty(ns.value * row, dtype=np.uint8)
+        if sendh.nbytes:
+            _lib.call("fd_memcpy_d2h", sendh.ctypes.data, sb.value, sendh.nbytes, None)     # synchronises the pack
+        recvh = np.empty(nr.value * row, dtype=np.uint8)
+        ops, so, ro = [], 0, 0
+        for r, no, ni in zip(self._nb, out_counts, in_counts):
+            if no:
+                ops.append(dist.P2POp(dist.isend, torch.from_numpy(sendh[so * row:(so + no) * row]), r))
+            if ni:
+                ops.append(dist.P2POp(dist.irecv, torch.from_numpy(recvh[ro * row:(ro + ni) * row]), r))
+            so += no
+            ro += ni
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        self._pending[(id(dat), direction)] = (reqs, sendh, recvh, rb.value)
+
+    def _end(self, dat, direction, op):
+        from . import _lib
+        h, code = self._handle(), self._code(dat)
+        if not self._comm:
+            reqs, sendh, recvh, rbuf = self._pending.pop((id(dat), direction))
+            for q in reqs:
+                q.wait()
+            if recvh.nbytes:
+                _lib.call("fd_memcpy_h2d", rbuf, recvh.ctypes.data, recvh.nbytes, None)
+                _lib.call("fd_stream_sync", None)
+        ptr = dat._dev_ptr(True)
+        if direction == 0:
+            _lib.call("fd_halo_g2l_end", h, ptr, dat.cdim, code, None)
+        else:
+            _lib.call("fd_halo_l2g_end", h, ptr, dat.cdim, code, op, None)
+
+    # -- host-only protocol simulation (FDHIP_HALO_HOST=1: CPU machines, the oracle as "kernel")
     def _idx(self, kind, r):
+        import torch
         key = (kind, r)
-        t = self._dev_idx.get(key)
+        t = self._host_idx.get(key)
         if t is None:
-            import torch
             arr = (self.lists.send if kind == "send" else self.lists.recv)[r]
-            t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int32))
-            if not self.host_mode:
-                t = t.cuda()
-            self._dev_idx[key] = t
+            t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int64))
+            self._host_idx[key] = t
         return t
 
-    def _dat_tensor(self, dat, write):
-        """A torch view of the Dat's storage (device memory unless host_mode)."""
+    def _host_begin(self, dat, send_kind, recv_kind, tag):
         import torch
-        if self.host_mode:
-            h = dat._host_rw() if write else dat._to_host()
-            return torch.from_numpy(h.reshape(h.shape[0], -1))
-        raise RuntimeError("device tensors are addressed by raw pointer; see _pack/_unpack")
+        dist = _dist()
+        ops, recvs, keep = [], [], []
+        hview = dat._to_host()
+        t = torch.from_numpy(hview.reshape(hview.shape[0], -1))
+        for r in self._neighbours():
+            sl = (self.lists.send if send_kind == "send" else self.lists.recv).get(r)
+            rl = (self.lists.send if recv_kind == "send" else self.lists.recv).get(r)
+            if sl is not None and len(sl):
+                sbuf = t[self._idx(send_kind, r)].contiguous()
+                keep.append(sbuf)
+                ops.append(dist.P2POp(dist.isend, sbuf, r))
+            if rl is not None and len(rl):
+                rbuf = torch.empty((len(rl), t.shape[1]), dtype=t.dtype)
+                recvs.append((r, rbuf))
+                ops.append(dist.P2POp(dist.irecv, rbuf, r))
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        self._pending[(id(dat), tag)] = (reqs, recvs, keep)
 
-    def _pack(self, dat, idx, cdim):
+    def _host_end(self, dat, recv_kind, op, tag):
         import torch
-        if self.host_mode:
-            return self._dat_tensor(dat, False)[idx.long()].contiguous()
-        from . import _lib
-        buf = torch.empty((idx.numel(), cdim), dtype=torch.float64, device="cuda")
-        _lib.call("fd_halo_pack", dat._dev_ptr(False), cdim, idx.data_ptr(), idx.numel(), buf.data_ptr(),
-                  torch.cuda.current_stream().cuda_stream)
-        return buf
-
-    def _unpack(self, dat, idx, cdim, buf, op):
-        import torch
-        if self.host_mode:
-            t = self._dat_tensor(dat, True)
-            li = idx.long()
+        reqs, recvs, keep = self._pending.pop((id(dat), tag))
+        for q in reqs:
+            q.wait()
+        hview = dat._host_rw()
+        t = torch.from_numpy(hview.reshape(hview.shape[0], -1))
+        for r, buf in recvs:
+            li = self._idx(recv_kind, r)
             if op == 0:
                 t[li] = buf
             elif op == 1:
@@ -107,104 +261,71 @@ class Halo:
                 t[li] = torch.minimum(t[li], buf)
             else:
                 t[li] = torch.maximum(t[li], buf)
-            return
-        from . import _lib
-        _lib.call("fd_halo_unpack", dat._dev_ptr(True), cdim, idx.data_ptr(), idx.numel(), buf.data_ptr(), op,
-                  torch.cuda.current_stream().cuda_stream)
-
-    def _exchange_begin(self, dat, send_kind, recv_kind, tag):
-        import torch
-        dist = _dist()
-        cdim = dat.cdim
-        if dat.dtype != np.float64:
-            raise TypeError("halo exchange is implemented for float64 Dats (ScalarType)")
-        ops, recvs, keep = [], [], []
-        # device buffers go straight to RCCL; under a non-NCCL backend (gloo: debugging / the one-GPU
-        # two-rank test) the packed buffers are bounced through the host
-        via_host = (not self.host_mode) and dist.get_backend() != "nccl"
-        # Wrapper kernels and the pack/unpack kernels run on the null stream, which is also torch's current stream:
-        # ProcessGroupNCCL orders its own stream after it (event record/wait) and work.wait() orders it back, so the
-        # RCCL path needs no host-side synchronisation and the host keeps queueing ahead.  The host-bounce path
-        # (non-NCCL backends) synchronises through .cpu(); FDHIP_HALO_SYNC=1 restores full device syncs everywhere.
-        self._sync = (not self.host_mode) and (via_host or os.environ.get("FDHIP_HALO_SYNC", "0") == "1")
-        if self._sync:
-            torch.cuda.synchronize()
-        for r in self._neighbours():
-            sl = (self.lists.send if send_kind == "send" else self.lists.recv).get(r)
-            rl = (self.lists.send if recv_kind == "send" else self.lists.recv).get(r)
-            if sl is not None and len(sl):
-                sbuf = self._pack(dat, self._idx(send_kind, r), cdim)
-                if via_host:
-                    sbuf = sbuf.cpu()
-                keep.append(sbuf)
-                ops.append(dist.P2POp(dist.isend, sbuf, r))
-            if rl is not None and len(rl):
-                rbuf = torch.empty((len(rl), cdim), dtype=torch.float64, device="cpu" if (self.host_mode or via_host) else "cuda")
-                recvs.append((r, rbuf))
-                ops.append(dist.P2POp(dist.irecv, rbuf, r))
-        reqs = dist.batch_isend_irecv(ops) if ops else []
-        self._pending[(id(dat), tag)] = (reqs, recvs, keep)
-
-    def _exchange_end(self, dat, recv_kind, op, tag):
-        reqs, recvs, keep = self._pending.pop((id(dat), tag))
-        for q in reqs:
-            q.wait()
-        for r, rbuf in recvs:
-            if not self.host_mode and rbuf.device.type == "cpu":
-                rbuf = rbuf.cuda()
-            self._unpack(dat, self._idx(recv_kind, r), dat.cdim, rbuf, op)
-        if getattr(self, "_sync", False):
-            import torch
-            torch.cuda.synchronize()
 
     # -- pyop2 Halo interface
     def global_to_local_begin(self, dat, insert_mode):
         """owner -> ghost broadcast (firedrake/halo.py:125-131)."""
-        self._exchange_begin(dat, "send", "recv", "g2l")
+        if self.host_mode:
+            return self._host_begin(dat, "send", "recv", "g2l")
+        self._begin(dat, 0, 0)
 
     def global_to_local_end(self, dat, insert_mode):
-        self._exchange_end(dat, "recv", 0, "g2l")
+        if self.host_mode:
+            return self._host_end(dat, "recv", 0, "g2l")
+        self._end(dat, 0, 0)
 
     def local_to_global_begin(self, dat, insert_mode):
         """ghost -> owner reduction with SUM/MIN/MAX (firedrake/halo.py:141-172)."""
-        self._exchange_begin(dat, "recv", "send", "l2g")
+        if self.host_mode:
+            return self._host_begin(dat, "recv", "send", "l2g")
+        self._begin(dat, 1, _OPS[insert_mode])
 
     def local_to_global_end(self, dat, insert_mode):
-        self._exchange_end(dat, "send", _OPS[insert_mode], "l2g")
+        if self.host_mode:
+            return self._host_end(dat, "send", _OPS[insert_mode], "l2g")
+        self._end(dat, 1, _OPS[insert_mode])
 
     def fill_ghosts(self, dat, access_mode):
-        """pyop2/types/dat.py:631-636: before an INC/MIN/MAX loop the ghost region is set to the
-        identity (0 / +max / -max) so the reverse reduction only carries this loop's contributions."""
-        val = {INC: 0.0, MIN: np.finfo(np.float64).max, MAX: np.finfo(np.float64).min}[access_mode]
+        """pyop2/types/dat.py:631-636: before an INC/MIN/MAX loop the ghost region is set to the identity of the
+        access mode (0 / largest / lowest value OF THE DAT'S DTYPE, ``dtype_limits``) so the reverse reduction only
+        carries this loop's contributions."""
         n0, n1 = dat.dataset.size, dat.dataset.total_size
         if n1 == n0:
             return
+        dt = np.dtype(dat.dtype)
         if self.host_mode:
-            dat._host_rw()[n0:] = val
+            lim = np.finfo(dt) if dt.kind == "f" else np.iinfo(dt)
+            dat._host_rw()[n0:] = {INC: 0, MIN: lim.max, MAX: lim.min}[access_mode]
             return
-        import ctypes
         from . import _lib
-        from .device import DeviceBuffer
-        rows = getattr(self, "_ghost_rows", None)
-        if rows is None or rows[0] != (n0, n1):
-            rows = ((n0, n1), DeviceBuffer.from_numpy(np.arange(n0, n1, dtype=np.int32)))
-            self._ghost_rows = rows
-        _lib.call("fd_dat_set_rows", dat._dev_ptr(True), dat.cdim, rows[1].ptr, n1 - n0, ctypes.c_double(val), None)
+        code = self._code(dat)                                 # raises before any memory is touched
+        kind = {INC: 0, MIN: 1, MAX: 2}[access_mode]
+        _lib.call("fd_dat_fill_range", dat._dev_ptr(True), n0 * dat.cdim, (n1 - n0) * dat.cdim, code, kind, None)
 
 
 def allreduce_global(glob, access, comm=None):
-    """pyop2/parloop.py:411-442: MPI_Iallreduce of INC/MIN/MAX Globals -> RCCL all-reduce of a tiny buffer."""
+    """pyop2/parloop.py:411-442: MPI_Iallreduce of INC/MIN/MAX Globals.  With the RCCL wire the reduction runs on the
+    Global's device buffer (``fd_comm_allreduce``, stream ordered, no host round trip); otherwise through
+    ``torch.distributed`` on the host copy."""
     try:
-        import torch
         dist = _dist()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
     except ImportError:
         return
-    op = {INC: dist.ReduceOp.SUM, MIN: dist.ReduceOp.MIN, MAX: dist.ReduceOp.MAX}[access]
+    op = {INC: 1, MIN: 2, MAX: 3}[access]
+    hostsim = os.environ.get("FDHIP_HALO_HOST", "0") == "1"
+    c = None if hostsim else communicator()
+    code = DTYPE_CODE.get(np.dtype(glob.dtype))
+    if c and code is not None:
+        from . import _lib
+        _lib.call("fd_comm_allreduce", c, glob._dev_ptr(True), int(np.prod(glob._host.shape)), code, op, None)
+        return
+    import torch
+    rop = {1: dist.ReduceOp.SUM, 2: dist.ReduceOp.MIN, 3: dist.ReduceOp.MAX}[op]
     host = glob._to_host()
     t = torch.from_numpy(np.ascontiguousarray(host.reshape(-1)).copy())
     if dist.get_backend() == "nccl":
         t = t.cuda()
-    dist.all_reduce(t, op=op)
+    dist.all_reduce(t, op=rop)
     glob._host_rw()[...] = t.cpu().numpy().reshape(host.shape)

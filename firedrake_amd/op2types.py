@@ -980,6 +980,9 @@ class DatView(Dat):
     def _dev_ptr(self, write):
         return self._parent._dev_ptr(write)
 
+    def _after_device_write(self):
+        self._parent._after_device_write()
+
     data = property(lambda self: self._parent.data[self._idx])
     data_ro = property(lambda self: self._parent.data_ro[self._idx])
     data_with_halos = property(lambda self: self._parent.data_with_halos[self._idx])

@@ -464,6 +464,8 @@ class Parloop:
         return out, geo
 
     def _lgmap(self, lg):
+        if hasattr(lg, "_fd_dev_ptr"):           # already on the device (bridge.DeviceMat.set_lgmaps)
+            return lg._fd_dev_ptr
         a = np.ascontiguousarray(lg, dtype=np.int32)
         key = id(lg)
         d = self._lgmap_dev.get(key)
@@ -522,9 +524,13 @@ class Parloop:
             cw.launch(start, end, args, block_threads=threads, ents_per_block=threads, nblocks=nblocks)
 
     # -- owner-computes-rows ---------------------------------------------------------------------------
-    def _ocr_geometry(self):
+    def _ocr_geometry(self, start=0, end=None):
+        """Owner-computes-rows plan over the entities [start, end) (default: every entity the loop executes)."""
         prep = self._prepared
-        geo = prep["parts"].get("ocr")
+        if end is None:
+            end = self.iterset.total_size if self.compute_ghost else self.iterset.size
+        gkey = ("ocr", int(start), int(end))
+        geo = prep["parts"].get(gkey)
         if geo is not None:
             return geo
         from .op2types import OcrPlan
@@ -536,7 +542,6 @@ class Parloop:
         sp = pa.data.sparsity
         sp._build()
         nrows = rmap.toset.size                                   # owned rows only
-        end = self.iterset.total_size if self.compute_ghost else self.iterset.size
         rp = sp._node_rowptr.download(np.int32, (rmap.toset.total_size + 1,))
         limit = src.ocr_lds_limit or configuration["lds_limit"]
         hint = getattr(rmap._base(), "preferred_node_blocks", None)
@@ -553,7 +558,7 @@ class Parloop:
         for _ in range(12):
             # split row blocks until the LDS rows and the instance lists fit
             try:
-                op = OcrPlan(sp, rmap, cmap, staged, 0, end, rb, lane_threads=src.lane_threads)
+                op = OcrPlan(sp, rmap, cmap, staged, start, end, rb, lane_threads=src.lane_threads)
             except _lib.FDHipError as exc:
                 if "map entries" not in str(exc):
                     raise
@@ -590,16 +595,16 @@ class Parloop:
         variant = mode_variant("ocr", op.kbytes, nds)
         geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz,
                "cw": prep["cw"] if variant == src.mode else self.global_kernel.compile(variant)}
-        prep["parts"]["ocr"] = geo
+        prep["parts"][gkey] = geo
         if configuration["debug"]:
             import sys
-            print(f"[fdhip] {self.global_kernel.name} OCR: row blocks={op.nblocks} instances={op.ninst} "
-                  f"(x{op.ninst / max(end, 1):.2f} entities) max_inst={op.max_inst} max_nnz={op.max_nnz} max_nown={op.max_nown} "
+            print(f"[fdhip] {self.global_kernel.name} OCR [{start},{end}): row blocks={op.nblocks} instances={op.ninst} "
+                  f"(x{op.ninst / max(end - start, 1):.2f} entities) max_inst={op.max_inst} max_nnz={op.max_nnz} max_nown={op.max_nown} "
                   f"lds={lds} kbytes={op.kbytes}", file=sys.stderr)
         return geo
 
-    def _compute_ocr(self):
-        geo = self._ocr_geometry()
+    def _compute_ocr(self, start=0, end=None):
+        geo = self._ocr_geometry(start, end)
         prep = self._prepared
         cw = geo["cw"]
         src = cw.src

@@ -256,14 +256,52 @@ int fd_csr_spmv(int32_t nrows, const int32_t *rowptr_dev, const int32_t *colidx_
 
 /* -------------------------------------------------------------- halo pack / unpack
  * Device side of firedrake/halo.py:125-172 (PetscSF bcast owner->ghost with REPLACE,
- * reduce ghost->owner with SUM/MIN/MAX).  The wire transfer itself is RCCL
- * (torch.distributed send/recv on the packed buffers).
+ * reduce ghost->owner with SUM/MIN/MAX): the bare fp64 pack/unpack kernels (the full exchange, any dtype, is
+ * fd_halo_create / fd_halo_*_begin / fd_halo_*_end below).
  *   op: 0 = REPLACE, 1 = SUM, 2 = MIN, 3 = MAX      (fp64 rows of `cdim` values)
  */
 int fd_halo_pack(const double *dat_dev, int cdim, const int32_t *idx_dev, int32_t n,
                  double *buf_dev, fd_stream_t s);
 int fd_halo_unpack(double *dat_dev, int cdim, const int32_t *idx_dev, int32_t n,
                    const double *buf_dev, int op, fd_stream_t s);
+
+/* ------------------------------------------------- halo exchange + Global reductions over RCCL
+ * firedrake/halo.py:87-172 (PetscSF bcast owner->ghost with MPI.REPLACE, reduce ghost->owner with SUM/MIN/MAX behind
+ * pyop2/types/halo.py:4-56) and pyop2/parloop.py:411-442 (MPI_Iallreduce of INC/MIN/MAX Globals), one process per
+ * GPU.  A communicator wraps ncclCommInitRank (librccl.so is bound at run time); rank 0 obtains the 128-byte id with
+ * fd_comm_unique_id and the host side broadcasts it.  A halo holds the per-neighbour node lists (local numbering,
+ * matching order on both sides: send[k] = owned nodes neighbour k keeps as ghosts, recv[k] = our ghosts it owns),
+ * persistent packed buffers and the side stream the grouped ncclSend/ncclRecv exchange runs on:
+ *     g2l (forward)  owner -> ghost, REPLACE       pyop2/types/dat.py:622-658  (global_to_local_begin/end)
+ *     l2g (reverse)  ghost -> owner, op            pyop2/types/dat.py:659-678  (local_to_global_begin/end)
+ * *_begin queues pack + transfer and returns; *_end makes the compute stream wait for the transfer and queues the
+ * unpack, so whatever is launched on `s` in between overlaps the exchange (parloop.py:250-253).  Several Dats may be
+ * in flight at once (one begin/end pair per Dat and direction).
+ *   dtype: FD_F64 .. FD_U64;  op: 0 = REPLACE (forward only), 1 = SUM, 2 = MIN, 3 = MAX.
+ * A halo created with comm == NULL packs/unpacks only: the caller moves the packed rows itself between begin and end
+ * (fd_halo_wire_buffers) -- the host-bounce wire of the gloo-launched tests. */
+enum { FD_F64 = 0, FD_F32 = 1, FD_I32 = 2, FD_U32 = 3, FD_I64 = 4, FD_U64 = 5 };
+typedef struct fd_comm_s *fd_comm_t;
+typedef struct fd_halo_s *fd_halo_t;
+int fd_comm_available(void);                          /* 1 if librccl.so could be bound, else 0 (reason: fd_last_error) */
+int fd_comm_unique_id(unsigned char *id128);
+int fd_comm_create(const unsigned char *id128, int rank, int nranks, fd_comm_t *out);   /* collective over all ranks */
+int fd_comm_info(fd_comm_t c, int *rank, int *nranks);
+int fd_comm_free(fd_comm_t c);
+int fd_comm_allreduce(fd_comm_t c, void *buf_dev, int64_t count, int dtype, int op, fd_stream_t s);   /* in place */
+int fd_halo_create(fd_comm_t comm, int nneigh, const int32_t *peer_ranks,
+                   const int32_t *const *send_idx_host, const int32_t *nsend,
+                   const int32_t *const *recv_idx_host, const int32_t *nrecv, fd_halo_t *out);
+int fd_halo_free(fd_halo_t h);
+int fd_halo_g2l_begin(fd_halo_t h, void *dat_dev, int cdim, int dtype, fd_stream_t s);
+int fd_halo_g2l_end(fd_halo_t h, void *dat_dev, int cdim, int dtype, fd_stream_t s);
+int fd_halo_l2g_begin(fd_halo_t h, void *dat_dev, int cdim, int dtype, int op, fd_stream_t s);
+int fd_halo_l2g_end(fd_halo_t h, void *dat_dev, int cdim, int dtype, int op, fd_stream_t s);
+int fd_halo_wire_buffers(fd_halo_t h, const void *dat_dev, int dir, void **send_buf, int64_t *send_rows,
+                         void **recv_buf, int64_t *recv_rows);   /* dir: 0 = g2l, 1 = l2g */
+/* identity of an access mode over a contiguous element range: kind 0 = zero (INC), 1 = largest (MIN), 2 = lowest (MAX)
+ * value of the dtype -- the ghost-region fill of pyop2/types/dat.py:631-636 for any Dat dtype */
+int fd_dat_fill_range(void *dat_dev, int64_t first_elem, int64_t count, int dtype, int kind, fd_stream_t s);
 
 /* ------------------------------------------------- pointwise helpers (a13, a14)
  * bc.zero / bc.apply on a residual (firedrake/bcs.py:192-221, 404-457). */

@@ -75,28 +75,31 @@ def test_flags_permuted_maps_views_and_mixed():
         bridge.as_fd_global_kernel(GlobalKernel(local_kernel=lk, arguments=[types.SimpleNamespace()] * 3))
 
 
-def test_function_level_seam_rejects_mat_arguments():
-    m = MapKernelArg(arity=3)
-    lk = CStringLocalKernel(code="static void k(double *A) {}", name="k", accesses=(4,), dtypes=(np.float64,))
-    gk = GlobalKernel(local_kernel=lk, arguments=[MatKernelArg(dims=((1, 1),), maps=(m, m))])
-    assert bridge.as_fd_global_kernel(gk).arguments[0].dims == (1, 1)
-    with pytest.raises(NotImplementedError):
-        bridge.compile_global_kernel_hip(gk)
-
-
-def test_function_level_seam_builds_the_direct_wrapper():
+def test_function_level_seam_selects_the_fast_paths():
+    """The seam picks the same wrapper shapes as the native Parloop: staged for indirect Dat loops, owner-computes-rows
+    for a scalar INC matrix; a Mat slot must hold a DeviceMat handle."""
     from firedrake_amd import _lib
     m = MapKernelArg(arity=3)
-    lk = CStringLocalKernel(code=RHS, name="rhs", accesses=(4, 1, 1), dtypes=(np.float64,) * 3)
-    gk = GlobalKernel(local_kernel=lk, arguments=[DatKernelArg(dim=(), map_=m), DatKernelArg(dim=(2,), map_=m),
-                                                  DatKernelArg(dim=(1,), map_=m)])
+    lk = CStringLocalKernel(code="static void k(double *A, const double *x) {}", name="k", accesses=(4, 1), dtypes=(np.float64,) * 2)
+    gk = GlobalKernel(local_kernel=lk, arguments=[MatKernelArg(dims=((1, 1),), maps=(m, m)), DatKernelArg(dim=(2,), map_=m)])
+    assert bridge.as_fd_global_kernel(gk).arguments[0].dims == (1, 1)
     func = bridge.compile_global_kernel_hip(gk)
-    assert func.wrapper.src.mode == "direct" and func.wrapper.path.endswith(".hsaco")
+    assert func.mode == "ocr"
     with pytest.raises(ValueError):
-        func(0, 2, 1, 2)                                     # three Dat pointers + one map pointer are expected
+        func(0, 2, 1, 2)                                     # Mat handle + Dat pointer + one map pointer are expected
+    with pytest.raises(ValueError):
+        func(0, 2, 12345, 0, 0)                              # not a DeviceMat handle
+    lk2 = CStringLocalKernel(code=RHS, name="rhs", accesses=(4, 1, 1), dtypes=(np.float64,) * 3)
+    gk2 = GlobalKernel(local_kernel=lk2, arguments=[DatKernelArg(dim=(), map_=m), DatKernelArg(dim=(2,), map_=m),
+                                                    DatKernelArg(dim=(1,), map_=m)])
+    func2 = bridge.compile_global_kernel_hip(gk2)
+    assert func2.mode == "staged"
     if not _lib.gpu_available():
         with pytest.raises(_lib.FDHipError):                 # no device, no fallback
-            func(0, 2, 0, 0, 0, 0)
+            func2(0, 2, 0, 0, 0, 0)
+    direct = GlobalKernel(local_kernel=CStringLocalKernel(code="static void d(double *a) { a[0] = 1.0; }", name="d", accesses=(2,),
+                                                          dtypes=(np.float64,)), arguments=[DatKernelArg(dim=(1,))])
+    assert bridge.compile_global_kernel_hip(direct).mode == "direct"
 
 
 @pytest.mark.gpu
@@ -112,6 +115,7 @@ def test_function_level_seam_on_device():
     gk = GlobalKernel(local_kernel=lk, arguments=[DatKernelArg(dim=(), map_=m), DatKernelArg(dim=(2,), map_=m),
                                                   DatKernelArg(dim=(1,), map_=m)])
     func = bridge.compile_global_kernel_hip(gk)
+    assert func.mode == "staged"
     b_d, x_d, f_d, m_d = (DeviceBuffer.from_numpy(a) for a in (np.zeros(nn), x, f, cells))
     func(0, ne, b_d.ptr, x_d.ptr, f_d.ptr, m_d.ptr)
     func(0, ne // 2, b_d.ptr, x_d.ptr, f_d.ptr, m_d.ptr)            # a second, partial range accumulates
@@ -122,3 +126,67 @@ def test_function_level_seam_on_device():
                 exp[cells[e, i]] += x[cells[e, i], 0] * f[cells[e, i]]
     got = b_d.download(np.float64, (nn,))
     assert np.abs(got - exp).max() < 1e-12 * max(1.0, np.abs(exp).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bcs", [False, True])
+def test_c1_residual_and_jacobian_through_func_only(bcs):
+    """BASELINE.json configs[0] (Poisson CG1 on UnitSquareMesh(64, 64)) assembled through ``func(start, end, *arglist)``
+    ALONE -- device pointers in the reference's positional order, a DeviceMat handle in the Mat slot, BC lgmaps swapped
+    in like pyop2/parloop.py:279-314 -- on the staged and owner-computes-rows wrappers, against the oracle."""
+    import oracle
+    from oracle import ODat, OMat, READ, INC
+    from firedrake_amd import forms, mesh as fmesh
+    from firedrake_amd.device import DeviceBuffer
+    msh = fmesh.UnitSquareMesh(64, 64, perturb=0.1)
+    V = msh.space(1)
+    cells = np.ascontiguousarray(V.cell_node_map.values_with_halo)
+    nn, ne = V.node_set.total_size, msh.cell_set.size
+    x = np.array(msh.coordinates.data_ro)
+    rng = np.random.default_rng(1)
+    u, f = rng.standard_normal(nn), rng.standard_normal(nn)
+    kr, kj = forms.poisson_residual_kernel(2, 1), forms.poisson_jacobian_kernel(2, 1)
+    m = MapKernelArg(arity=3)
+    gres = GlobalKernel(local_kernel=CStringLocalKernel(code=kr.code, name=kr.name, accesses=(4, 1, 1, 1), dtypes=(np.float64,) * 4),
+                        arguments=[DatKernelArg(dim=(1,), map_=m), DatKernelArg(dim=(2,), map_=m), DatKernelArg(dim=(1,), map_=m),
+                                   DatKernelArg(dim=(1,), map_=m)])
+    gjac = GlobalKernel(local_kernel=CStringLocalKernel(code=kj.code, name=kj.name, accesses=(4, 1), dtypes=(np.float64,) * 2),
+                        arguments=[MatKernelArg(dims=((1, 1),), maps=(m, m)), DatKernelArg(dim=(2,), map_=m)])
+    fres, fjac = bridge.compile_global_kernel_hip(gres), bridge.compile_global_kernel_hip(gjac)
+    assert (fres.mode, fjac.mode) == ("staged", "ocr")
+    # what the patched carriers would hold: device mirrors of the Map, the Dats and the matrix
+    m_d, x_d, u_d, f_d, r_d = (DeviceBuffer.from_numpy(a) for a in (cells, x, u, f, np.zeros(nn)))
+    bridge.register_map(m_d.ptr, ne, 3, toset_sizes=(nn, nn, nn))
+    sp = op2.Sparsity((V.node_set ** 1, V.node_set ** 1), [(V.cell_node_map, V.cell_node_map, None)])
+    sp._build()
+    vals = DeviceBuffer(sp.nz * 8)
+    vals.upload(np.full(sp.nz, 7.0))                                   # stale values: Mat.zero() must clear them
+    dm = bridge.DeviceMat(sp._rowptr.ptr, sp._colidx.ptr, vals.ptr, nn, sp.nz)
+    bc = V.boundary_nodes
+    lg = np.arange(nn, dtype=np.int32)
+    if bcs:
+        lg[bc] = -1
+        lg_d = DeviceBuffer.from_numpy(lg)
+        dm.set_lgmaps(lg_d.ptr, lg_d.ptr)
+    # residual: core part then (empty) owned part, exactly the reference's two calls (parloop.py:250-253)
+    fres(0, ne, r_d.ptr, x_d.ptr, u_d.ptr, f_d.ptr, m_d.ptr)
+    fres(ne, ne, r_d.ptr, x_d.ptr, u_d.ptr, f_d.ptr, m_d.ptr)
+    dm.zero()
+    fjac(0, ne, dm.handle, x_d.ptr, m_d.ptr)
+    fjac(ne, ne, dm.handle, x_d.ptr, m_d.ptr)
+    ro = np.zeros(nn)
+    oracle.par_loop(kr.code, kr.name, 0, ne, [ODat(ro, INC, cells), ODat(x, READ, cells), ODat(u, READ, cells), ODat(f, READ, cells)])
+    csr = oracle.build_sparsity(nn, nn, [(cells, cells)])
+    olg = lg if bcs else None
+    oracle.par_loop(kj.code, kj.name, 0, ne, [OMat(csr, INC, cells, cells, row_lgmap=olg, col_lgmap=olg), ODat(x, READ, cells)])
+    r = r_d.download(np.float64, (nn,))
+    v = vals.download(np.float64, (sp.nz,))
+    assert np.array_equal(sp.rowptr, csr.rowptr) and np.array_equal(sp.colidx, csr.colidx)
+    assert np.abs(r - ro).max() <= 1e-12 * max(1.0, np.abs(ro).max())
+    assert np.abs(v - csr.values).max() <= 1e-12 * np.abs(csr.values).max()
+    # a second assembly WITHOUT Mat.zero() accumulates (MatSetValuesLocal ADD_VALUES)
+    fjac(0, ne, dm.handle, x_d.ptr, m_d.ptr)
+    v2 = vals.download(np.float64, (sp.nz,))
+    assert np.abs(v2 - 2.0 * csr.values).max() <= 1e-12 * np.abs(csr.values).max()
+    assert len(fjac.loops) == 1 and len(fres.loops) == 1                # plans resolved once, cached on the argument list
+    dm.free()

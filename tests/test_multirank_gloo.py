@@ -59,3 +59,32 @@ def test_partitioned_assembly_on_one_gpu(world, n, degree):
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n" + "\n=====\n".join(o[-2500:] for o in outs)
         assert f"rank {r}/{world} ok" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,degree", [(2, 6, 1), (2, 6, 2)])
+def test_partitioned_assembly_over_rccl(world, n, degree):
+    """The real wire: one GPU per rank, backend nccl (= RCCL), halos through fd_halo_* / ncclSend / ncclRecv and Globals
+    through ncclAllReduce (csrc/fd_comm.hip).  Needs >= 2 devices: skipped on a one-GPU box, exercised by the
+    driver's multi-GPU node."""
+    from firedrake_amd import _lib
+    import ctypes
+    ndev = ctypes.c_int()
+    _lib.call("fd_device_count", ctypes.byref(ndev))
+    if ndev.value < world:
+        pytest.skip(f"needs {world} GPUs, found {ndev.value}")
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_worker_gpu.py"), str(r), str(world), str(port), str(n), str(degree), "nccl"],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n" + "\n=====\n".join(o[-2500:] for o in outs)
+        assert f"rank {r}/{world} ok" in out
