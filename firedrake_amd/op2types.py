@@ -1830,12 +1830,24 @@ class OcrPlan:
     """Owner-computes-rows plan (fd_ocrplan_*): row-node blocks, their entity instances, the per-instance
     copies of the staged maps with their node plans, and the per-entity row-offset table."""
 
-    def __init__(self, sparsity, rmap: Map, cmap: Map, staged_maps, start, end, row_blocks, lane_threads=0):
+    def __init__(self, sparsity, rmap: Map, cmap: Map, staged_maps, start, end, row_blocks, lane_threads=0, chains=None):
+        """``chains``: optional block indices (first 0, last nblocks) cutting the row blocks into chains for the
+        sliding-window variant (fd_ocrplan_create_chained); ``window``/``nchains``/``chain_off`` describe the result."""
         self.row_blocks = rb = np.ascontiguousarray(row_blocks, dtype=np.int32)
         nb = len(rb) - 1
         h = ctypes.c_void_p()
-        _lib.call("fd_ocrplan_create", rmap._base()._dev_values(), rmap.arity, int(start), int(end), rb.ctypes.data, nb,
-                  self._order_code(lane_threads), None, ctypes.byref(h))
+        self.nchains, self.window, self.chain_off = 0, 1, None
+        if chains is not None and nb > 0:
+            ch = np.ascontiguousarray(chains, dtype=np.int32)
+            _lib.call("fd_ocrplan_create_chained", rmap._base()._dev_values(), rmap.arity, int(start), int(end), rb.ctypes.data, nb,
+                      ch.ctypes.data, len(ch) - 1, self._order_code(lane_threads), None, ctypes.byref(h))
+            nc, w, co = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_void_p()
+            _lib.call("fd_ocrplan_chain_info", h.value, ctypes.byref(nc), ctypes.byref(w), ctypes.byref(co))
+            self.nchains, self.window, self.chain_off = nc.value, w.value, co.value
+            self.chains = ch
+        else:
+            _lib.call("fd_ocrplan_create", rmap._base()._dev_values(), rmap.arity, int(start), int(end), rb.ctypes.data, nb,
+                      self._order_code(lane_threads), None, ctypes.byref(h))
         self.h = h.value
         ni, mi = ctypes.c_int64(), ctypes.c_int32()
         _lib.call("fd_ocrplan_info", self.h, ctypes.byref(ni), ctypes.byref(mi))

@@ -545,8 +545,13 @@ class Parloop:
         rp = sp._node_rowptr.download(np.int32, (rmap.toset.total_size + 1,))
         limit = src.ocr_lds_limit or configuration["lds_limit"]
         hint = getattr(rmap._base(), "preferred_node_blocks", None)
+        chain_hint = getattr(rmap._base(), "preferred_node_chains", None)
+        chain_rows = None
         if hint is not None and configuration["use_preferred_blocks"]:
             rb = np.asarray(hint, dtype=np.int64)
+            if chain_hint is not None and configuration["ocr_chains"]:
+                chain_rows = rb[np.asarray(chain_hint, dtype=np.int64)]       # first row of every chain
+                chain_rows = np.unique(np.concatenate([chain_rows[chain_rows < nrows], [0, nrows]]))
             rb = np.unique(np.concatenate([rb[rb < nrows], [0, nrows]]))
         else:
             cap = configuration["ocr_nnz_per_block"]
@@ -555,30 +560,39 @@ class Parloop:
             rb = rb[rb <= nrows]
         staged = {mi: maps[mi] for mi in src.staged_maps}
         maxar = max(m.arity for m in staged.values())
-        for _ in range(12):
+
+        def lds_bytes(op):
+            lds = 0
+            nd = {mi: lds_stride(p.max_nd, ocr=True) for mi, p in op.plans.items()}
+            for item in src.lds_items:
+                if item[0] == "dat":
+                    _, mi, c, isz, accum = item
+                    lds += ((nd[mi] * c * isz) + 15) // 16 * 16
+                else:
+                    _, kk, rm, cmi, lg = item
+                    lds += ((op.max_nnz * 8 * op.window) + 15) // 16 * 16 + (nd[rm] * 4 + 15) // 16 * 16
+                    if cmi != rm:
+                        lds += (nd[cmi] + 15) // 16 * 16
+            return lds
+
+        for attempt in range(14):
             # split row blocks until the LDS rows and the instance lists fit
+            chains = None
+            if chain_rows is not None:
+                chains = np.searchsorted(rb, chain_rows).astype(np.int32)     # chain boundaries are row-block boundaries
             try:
-                op = OcrPlan(sp, rmap, cmap, staged, start, end, rb, lane_threads=src.lane_threads)
+                op = OcrPlan(sp, rmap, cmap, staged, start, end, rb, lane_threads=src.lane_threads, chains=chains)
             except _lib.FDHipError as exc:
                 if "map entries" not in str(exc):
                     raise
                 d = np.diff(rb)                                    # an instance list is too long: halve every wide block
                 rb = np.unique(np.concatenate([rb, (rb[:-1] + d // 2)[d > 1]]))
                 continue
-            def lds_bytes():
-                lds = 0
-                nd = {mi: lds_stride(p.max_nd, ocr=True) for mi, p in op.plans.items()}
-                for item in src.lds_items:
-                    if item[0] == "dat":
-                        _, mi, c, isz, accum = item
-                        lds += ((nd[mi] * c * isz) + 15) // 16 * 16
-                    else:
-                        _, kk, rm, cmi, lg = item
-                        lds += ((op.max_nnz * 8) + 15) // 16 * 16 + (nd[rm] * 4 + 15) // 16 * 16
-                        if cmi != rm:
-                            lds += (nd[cmi] + 15) // 16 * 16
-                return lds
-            lds = lds_bytes()
+            lds = lds_bytes(op)
+            if op.nchains and (op.window > 4 or lds > limit):
+                # the blocks of a chain couple further than neighbours (or the window does not fit): plain row blocks
+                chain_rows = None
+                continue
             if lds <= limit and op.max_inst * maxar <= 32768:
                 break
             d = np.diff(rb)
@@ -592,13 +606,13 @@ class Parloop:
         if lds > 160 * 1024 or op.max_inst * maxar > 32768:
             raise _lib.FDHipError("owner-computes-rows plan does not fit (LDS or instance list); set FDHIP_MAT_OCR=0")
         nds = [op.plans[mi].max_nd for mi in src.staged_maps]
-        variant = mode_variant("ocr", op.kbytes, nds)
+        variant = mode_variant(f"ocrc{op.window}" if op.nchains else "ocr", op.kbytes, nds)
         geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz,
                "cw": prep["cw"] if variant == src.mode else self.global_kernel.compile(variant)}
         prep["parts"][gkey] = geo
         if configuration["debug"]:
             import sys
-            print(f"[fdhip] {self.global_kernel.name} OCR [{start},{end}): row blocks={op.nblocks} instances={op.ninst} "
+            print(f"[fdhip] {self.global_kernel.name} OCR [{start},{end}): chains={op.nchains} window={op.window} row blocks={op.nblocks} instances={op.ninst} "
                   f"(x{op.ninst / max(end - start, 1):.2f} entities) max_inst={op.max_inst} max_nnz={op.max_nnz} max_nown={op.max_nown} "
                   f"lds={lds} kbytes={op.kbytes}", file=sys.stderr)
         return geo
@@ -658,13 +672,15 @@ class Parloop:
                 out.append(op.max_nown)
             elif kind == "ocr_flags":
                 out.append(self._ocr_flag)
+            elif kind == "ocr_chain":
+                out.append(op.chain_off)
             elif kind in ("mat_row_lgmap", "mat_col_lgmap"):
                 pa = self.arguments[desc[1]]
                 out.append(self._lgmap(pa.lgmaps[0 if kind == "mat_row_lgmap" else 1]))
             else:
                 raise AssertionError(kind)
-        cw.launch(0, op.ninst, out, block_threads=src.block_threads, ents_per_block=op.max_inst, nblocks=op.nblocks,
-                  lds_bytes=geo["lds"])
+        cw.launch(0, op.ninst, out, block_threads=src.block_threads, ents_per_block=op.max_inst,
+                  nblocks=op.nchains if op.nchains else op.nblocks, lds_bytes=geo["lds"])
 
     def _nlayers_iterated(self):
         from .op2types import ON_BOTTOM, ON_TOP, ON_INTERIOR_FACETS

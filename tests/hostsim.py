@@ -130,7 +130,7 @@ def run_staged(pl, epb=48):
     return [outs.get(k) for k in range(len(pl.arguments))]
 
 
-def run_ocr(pl, rows_per_block=24, zero_pending=True):
+def run_ocr(pl, rows_per_block=24, zero_pending=True, blocks_per_chain=0):
     """Execute a matrix-assembly Parloop ``pl`` with the OWNER-COMPUTES-ROWS wrapper on the host (one OS thread per
     lane, tests/hostsim/mt/fd_wrapper.h).  The plan tables come from the numpy restatements in helpers.py; the CSR
     pattern from the oracle.  Returns the OracleCSR holding the assembled values."""
@@ -152,14 +152,22 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True):
     nent = pl.iterset.size
     nrows = rmap.toset.size
     rb = np.array(list(range(0, nrows, rows_per_block)) + [nrows], dtype=np.int32)
-    inst_off, inst_ent, kidx = ocr_plan_ref(np.asarray(rmap.values_with_halo), np.asarray(cmap.values_with_halo), nent, rb,
-                                            csr.rowptr, csr.colidx)
+    chains, W = None, 0
+    if blocks_per_chain:
+        # sliding-window variant: chains of consecutive row blocks (fd_ocrplan_create_chained)
+        nb_ = len(rb) - 1
+        chains = np.array(list(range(0, nb_, blocks_per_chain)) + [nb_], dtype=np.int32)
+        inst_off, inst_ent, kidx, W = ocr_plan_ref(np.asarray(rmap.values_with_halo), np.asarray(cmap.values_with_halo), nent, rb,
+                                                   csr.rowptr, csr.colidx, chains=chains)
+    else:
+        inst_off, inst_ent, kidx = ocr_plan_ref(np.asarray(rmap.values_with_halo), np.asarray(cmap.values_with_halo), nent, rb,
+                                                csr.rowptr, csr.colidx)
     plans = {}
     for mi in base.staged_maps:
         blk, lst, lm = plan_ref_blocks(np.asarray(maps[mi].values_with_halo)[inst_ent], inst_off)
         plans[mi] = (blk, lst, np.ascontiguousarray(lm), int(np.diff(blk).max()) if len(blk) > 1 else 0)
     max_nnz = int(np.diff(csr.rowptr[rb]).max())
-    src = generate_wrapper(gk, mode_variant("ocr", 1, [plans[mi][3] for mi in base.staged_maps]))
+    src = generate_wrapper(gk, mode_variant(f"ocrc{W}" if chains is not None else "ocr", 1, [plans[mi][3] for mi in base.staged_maps]))
     text = src.source.replace("extern __shared__ __align__(16) unsigned char fd_lds[];", "unsigned char *fd_lds = fd_sim::lds;")
     sig = re.search(r'extern "C" __global__[^\n]*void %s\((.*)\)\n' % src.symbol, text).group(1)
     names = [p.split()[-1].lstrip("*") for p in sig.split(", ")]
@@ -176,7 +184,8 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True):
 
     if not zero_pending:
         csr.values[...] = 1.0                     # accumulate on top of existing values
-    cargs = [ctypes.c_int(len(rb) - 1), ctypes.c_int(T), ctypes.c_int(0), ctypes.c_int(len(inst_ent))]
+    cargs = [ctypes.c_int(len(chains) - 1 if chains is not None else len(rb) - 1), ctypes.c_int(T), ctypes.c_int(0),
+             ctypes.c_int(len(inst_ent))]
     for desc in src.layout:
         kind = desc[0]
         if kind == "arg":
@@ -212,6 +221,8 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True):
             cargs.append(ctypes.c_longlong(int(np.diff(rb).max())))
         elif kind == "ocr_flags":
             cargs.append(ctypes.c_longlong(1 if zero_pending else 0))
+        elif kind == "ocr_chain":
+            cargs.append(ptr(chains))
         elif kind in ("mat_row_lgmap", "mat_col_lgmap"):
             cargs.append(ptr(np.asarray(mpa.lgmaps[0 if kind == "mat_row_lgmap" else 1], dtype=np.int32)))
         else:

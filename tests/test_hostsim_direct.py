@@ -482,3 +482,26 @@ def test_mat_through_permuted_maps():
     km = op2.Kernel("static void kpm(double *A, const double *x) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) "
                     "A[i*3+j] += (i+1)*x[2*i] + 10*(j+1)*x[2*j+1]; }", "kpm")
     _check(km, ele, mat(op2.INC, (pr, pc)), x(op2.READ, m))
+
+
+@pytest.mark.parametrize("bcs", [False, True])
+@pytest.mark.parametrize("numbering", ["tiled", "sweep"])
+def test_chained_owner_computes_rows_wrapper_on_host(bcs, numbering):
+    """Sliding-window owner-computes-rows (fd_ocrplan_create_chained + the "ocrc<W>" wrapper): a workgroup walks the row
+    blocks of a chain, keeps the accumulators of the last W blocks in LDS, visits an entity once per chain.  Arbitrary
+    chains over arbitrary row blocks (large window) and the sweep numbering's x-planes (window 2 / 3) against the oracle,
+    including accumulation into existing values."""
+    from firedrake_amd import forms, mesh as fmesh
+    from hostsim import run_ocr
+    mesh = fmesh.UnitCubeMesh(4, degrees=(1, 2), perturb=0.1, numbering=numbering, tile=(4, 2, 2))
+    for degree, rpb, bpc in ((1, 5, 3), (1, 25, 4), (2, 27, 3)):
+        prob = forms.PoissonProblem(mesh, degree, bcs=bcs)
+        mat, pl = prob.jacobian()
+        mpa = pl.arguments[0]
+        got = run_ocr(pl, rows_per_block=rpb, blocks_per_chain=bpc)
+        args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
+        ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
+        assert np.abs(got.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
+        if degree == 1:
+            got2 = run_ocr(pl, rows_per_block=rpb, zero_pending=False, blocks_per_chain=bpc)
+            assert np.abs(got2.values - (ref.values + 1.0)).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
