@@ -106,39 +106,65 @@ def cpu_baseline(n_sample, degree, reps=10):
 FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD datasheet; tools/microbench.hip measures 77.7 TFLOP/s with v_mfma_f64_16x16x4_f64
 
 
-def run_c3(args):
-    """BASELINE.json configs[2]: Helmholtz Q4 on an extruded hex mesh, stiffness+mass matrix by fp64 MFMA."""
+def measure_c3(n, steps, warmup):
+    """BASELINE.json configs[2]: Helmholtz Q4 on an extruded hex mesh through ordinary parloops -- the stiffness+mass
+    matrix on the fp64 matrix cores (tp_matrix wrapper) and the sum-factorised operator action (tp_action).  Reports the
+    kernel alone AND the whole assemble (zeroing pass + kernel [+ BC diagonal]) against the fp64 MFMA peak."""
     from firedrake_amd import _lib, forms, mesh as fmesh
     from firedrake_amd.device import Event
-    _lib.require_gpu()
-    n = args.n if args.n != 215 else 32
     m = fmesh.make_extruded_hex_mesh(n, n, 4, perturb=0.1)
-    prob = forms.HelmholtzQ4Problem(m)
-    for _ in range(args.warmup):
-        prob.assemble_jacobian()
-    _lib.call("fd_device_sync")
-    ev = [(Event(), Event()) for _ in range(args.steps)]
+    prob = forms.HelmholtzQ4Problem(m, bcs=True)
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()
+    prob.assemble_jacobian()
+    prob.assemble_action()
+    _lib.call("fd_device_sync")
+    first = time.perf_counter() - t0
+    for _ in range(max(warmup - 1, 0)):
         prob.assemble_jacobian()
-        ev[k][1].record()
+        prob.assemble_action()
+    _lib.call("fd_device_sync")
+    ev = [[Event() for _ in range(7)] for _ in range(steps)]
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ev[k][0].record()
+        prob.assemble_jacobian(events=(ev[k][1], ev[k][2]))
+        ev[k][3].record()
+        prob.assemble_action(events=(ev[k][4], ev[k][5]))
+        ev[k][6].record()
     _lib.call("fd_device_sync")
     elapsed = time.perf_counter() - t0
-    ms = float(np.median([a.elapsed_ms(b) for a, b in ev]))
-    ncell = m.ncells
-    ndofs = m.node_set.size
+    med = lambda i, j: float(np.median([ev[k][i].elapsed_ms(ev[k][j]) for k in range(steps)]))
+    ncell, ndofs, nnz = m.ncells, m.node_set.size, int(prob.sparsity.nz)
     flops = prob.ALGO_FLOPS_PER_CELL * ncell
-    out = {"metric": "assembled DoFs/sec (Jacobian)", "value": ndofs / (elapsed / args.steps), "unit": "DoFs/s", "n_gpus": 1,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": f"Helmholtz Q4 stiffness+mass on ExtrudedMesh(UnitSquareMesh({n},{n},quadrilateral), {n}) "
-                                  f"(BASELINE.json configs[2])", "cells": ncell, "dofs": ndofs, "nnz": int(prob.sparsity.nz)},
-           "roofline": {"kernel": "wrap_helmholtz_q4_hex_jacobian", "bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12,
-                        "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-                        "traffic": None, "ms": ms, "algorithmic_flops": flops,
-                        "issued_mfma_flops": prob.FLOPS_PER_CELL * ncell},
-           "cpu_baseline": None}
+    k_ms, a_ms = med(1, 2), med(0, 3)
+    act_k_ms, act_a_ms = med(4, 5), med(3, 6)
+    tf = lambda ms: flops / (ms * 1e-3) / 1e12
+    # action: map (one 125-entry row per COLUMN) + Q1 coordinates + u read + y written (+ zeroing pass at assemble level)
+    ncol = m.base_set.size
+    act_bytes = ncol * 125 * 4 + ncol * 8 * 4 + m.coord_node_set.size * 24 + ndofs * 8 + ndofs * 8
+    return {"config": {"workload": f"Helmholtz Q4 stiffness+mass on ExtrudedMesh(UnitSquareMesh({n},{n},quadrilateral), {n}) "
+                                   f"(BASELINE.json configs[2]), Dirichlet BCs", "cells": ncell, "dofs": ndofs, "nnz": nnz},
+            "jacobian_dofs_per_s": ndofs / (a_ms * 1e-3), "action_dofs_per_s": ndofs / (act_a_ms * 1e-3),
+            "ms_per_step": elapsed / steps * 1e3, "first_call_s": first,
+            "roofline": {"kernel": "wrap_helmholtz_q4_hex_jacobian", "bound": "mfma", "achieved": tf(k_ms), "peak": FP64_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": tf(k_ms) / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "ms": k_ms,
+                         "algorithmic_flops": flops, "issued_mfma_flops": prob.FLOPS_PER_CELL * ncell,
+                         "assemble_ms": a_ms, "frac_assemble": tf(a_ms) / FP64_MFMA_PEAK_TFLOPS,
+                         "note": "assemble = zeroing pass over the CSR values + MFMA kernel incl. its atomic scatter + BC diagonal"},
+            "roofline_action": {"kernel": "wrap_helmholtz_q4_hex_action", "bound": "hbm", "achieved": act_bytes / (act_k_ms * 1e-3) / 1e9,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": act_bytes / (act_k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "traffic": None, "ms": act_k_ms, "algorithmic_bytes": act_bytes, "assemble_ms": act_a_ms}}
+
+
+def run_c3(args):
+    from firedrake_amd import _lib
+    _lib.require_gpu()
+    r = measure_c3(args.n if args.n else 32, args.steps, args.warmup)
+    out = {"metric": "assembled DoFs/sec (Jacobian)", "value": r["jacobian_dofs_per_s"], "unit": "DoFs/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": r["config"],
+           "action_dofs_per_s": r["action_dofs_per_s"], "roofline": r["roofline"], "roofline_action": r["roofline_action"],
+           "first_call_s": r["first_call_s"], "cpu_baseline": None}
     print(json.dumps(out))
 
 
@@ -184,7 +210,7 @@ def run_c4(args):
     from firedrake_amd import _lib, forms, mesh as fmesh
     from firedrake_amd.device import Event
     _lib.require_gpu()
-    n = args.n if args.n != 215 else 2048
+    n = args.n if args.n else 2048
     m = fmesh.make_quad_mesh(n, perturb=0.1)
     prob = forms.DGAdvectionProblem(m)
     for _ in range(max(args.warmup, 1)):
@@ -403,13 +429,15 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=128, help="cube size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-bcs", action="store_true")
     ap.add_argument("--tile", type=str, default="8,8,4", help="cubes per traversal tile (= plan block)")
-    ap.add_argument("--numbering", choices=["tiled", "lexicographic", "random"], default="tiled",
+    ap.add_argument("--numbering", choices=["tiled", "sweep", "lexicographic", "random"], default="tiled",
                     help="entity numbering of the headline measurement (SURVEY.md 8d)")
     ap.add_argument("--variants", type=str, default="lexicographic,random",
                     help="further numberings measured after the headline one at N=1 (no producer hints); '' = none")
     ap.add_argument("--traffic", choices=["auto", "off"], default="auto",
                     help="auto: rocprofv3 PMC passes of this command (child processes) fill roofline.traffic at N=1")
     ap.add_argument("--inner-pmc", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-secondary", dest="secondary", action="store_false",
+                    help="skip the config-C3 (Q4 hex, fp64 MFMA) section appended to the default line at N=1")
     ap.add_argument("--only", choices=["both", "residual", "jacobian"], default="both", help="profiling aid: run one form only")
     ap.add_argument("--workload", choices=["c1", "c2", "c3", "c4", "c5"], default="c2",
                     help="c2 = headline config (default); c1 = launch-bound 64x64 square (eager vs hipGraph); c3 = Q4 hex MFMA; "
@@ -509,7 +537,8 @@ def main():
         traffic_meta = None
         if args.traffic == "auto" and world == 1:
             tail = ["--steps", "3", "--warmup", "1", "--cpu-sample", "0", "--n", str(n), "--degree", str(args.degree),
-                    "--tile", args.tile, "--numbering", args.numbering, "--only", args.only, "--traffic", "off", "--variants", ""]
+                    "--tile", args.tile, "--numbering", args.numbering, "--only", args.only, "--traffic", "off", "--variants", "",
+                    "--no-secondary"]
             if args.no_bcs:
                 tail.append("--no-bcs")
             tr, traffic_meta = collect_traffic(tail, [r["kernel"] for r in roofs])
@@ -545,6 +574,15 @@ def main():
             out[f"value_{nb}_numbering"] = ndofs_global / (r2["ms_per_step"] * 1e-3)
             out[f"detail_{nb}_numbering"] = {"ms_per_step": r2["ms_per_step"], "residual_kernel_ms": r2["res_kernel_ms"],
                                              "jacobian_kernel_ms": r2["jac_kernel_ms"], "setup_s": {**st, **r2["first"]}}
+    if rank == 0 and world == 1 and args.secondary and args.workload == "c2" and args.only == "both":
+        # north_star's second numeric target (fp64 MFMA fraction on the Q4 hex config), measured in the same driver run
+        del prob, mesh
+        import gc
+        gc.collect()
+        try:
+            out["secondary_c3"] = measure_c3(32, max(3, args.steps // 2), 2)
+        except Exception as exc:                      # the headline line must not die with a secondary measurement
+            out["secondary_c3"] = {"error": repr(exc)}
     if rank == 0:
         if args.cpu_sample > 0 and world == 1:       # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample if args.degree == 1 else min(args.cpu_sample, 64), args.degree)

@@ -37,7 +37,7 @@ from typing import List
 import numpy as np
 
 from .configuration import configuration
-from .kernel import (DatKernelArg, GlobalKernel, GlobalKernelArg, MatKernelArg, PassthroughKernelArg,
+from .kernel import (DatKernelArg, GlobalKernel, GlobalKernelArg, MapKernelArg, MatKernelArg, PassthroughKernelArg,
                      PermutedMapKernelArg)
 from .op2types import (ALL, INC, MAX, MIN, ON_BOTTOM, ON_INTERIOR_FACETS, ON_TOP, READ, RW, WRITE)
 
@@ -76,8 +76,82 @@ def _distinct_maps(gk: GlobalKernel):
     return order, index
 
 
+def tensor_eligible(gk: GlobalKernel):
+    """'matrix' / 'action' when the loop can take the tensor-product wrappers of csrc/fd_tensor.h: a
+    TensorProductLocalKernel of degree 4 with 5 Gauss points per axis over an extruded set with constant layers, the
+    whole column (iteration region ALL), no subset, and the argument shapes
+        matrix:  Mat INC (scalar block, both maps the 125-node Q4 map)  +  coordinates READ (dim 3, 8-node Q1 map)
+        action:  Dat INC (scalar, Q4 map)  +  coordinates READ  +  Dat READ (scalar, the same Q4 map)."""
+    tp = getattr(gk.local_kernel, "tp", None)
+    if not tp or not configuration["tensor_wrappers"] or (tp["degree"], tp["nq"]) != (4, 5):
+        return None
+    if not gk._extruded or not gk._constant_layers or gk._subset or gk._extruded_periodic or gk._iteration_region != ALL or gk._pass_layer_arg:
+        return None
+    args, las = gk.arguments, gk.local_kernel.arguments
+    f64 = np.dtype("float64")
+
+    def plain(m, arity, off):
+        return isinstance(m, MapKernelArg) and m.arity == arity and m.offset is not None and tuple(m.offset) == (off,) * arity
+
+    def coords_ok(a, la):
+        return isinstance(a, DatKernelArg) and a.index is None and la.access == READ and la.dtype == f64 and tuple(a.dim) == (3,) \
+            and plain(a.map_, 8, 1)
+
+    if tp["kind"] == "matrix" and len(args) == 2:
+        a, la = args[0], las[0]
+        if isinstance(a, MatKernelArg) and la.access == INC and not a.unroll and a.maps[0] is a.maps[1] and plain(a.maps[0], 125, 4) \
+                and int(np.prod(a.dims[0])) * int(np.prod(a.dims[1])) == 1 and coords_ok(args[1], las[1]):
+            return "matrix"
+    if tp["kind"] == "action" and len(args) == 3:
+        y, u = args[0], args[2]
+        if all(isinstance(d, DatKernelArg) and d.index is None and int(np.prod(d.dim)) == 1 for d in (y, u)) \
+                and las[0].access == INC and las[2].access == READ and las[0].dtype == f64 and las[2].dtype == f64 \
+                and y.map_ is u.map_ and plain(y.map_, 125, 4) and coords_ok(args[1], las[1]):
+            return "action"
+    return None
+
+
+def generate_tensor_wrapper(gk: GlobalKernel) -> WrapperSource:
+    """The wrapper of a tensor-product loop: the reference's positional list for an extruded loop (start, end, layers, one
+    pointer per argument, one per distinct Map, builder.py:962-981), then the backend-private tables, around the device
+    templates of csrc/fd_tensor.h with the kernel's weight callback inlined."""
+    kind = tensor_eligible(gk)
+    lk = gk.local_kernel
+    sym = f"wrap_{lk.name}"
+    wname = f"{lk.name}_weights"
+    layout = [("layers",)]
+    head = ['#include "fd_tensor.h"', "#include <math.h>", "namespace fdk {", "#pragma clang force_cuda_host_device begin",
+            lk.tp["weights_code"], "#pragma clang force_cuda_host_device end", "}  // namespace fdk", ""]
+    call_w = f"[](const double J[3][3], const double X[3], double wq, double W[16]) {{ fdk::{wname}(J, X, wq, W); }}"
+    if kind == "matrix":
+        lg = bool(gk.arguments[0].lgmaps)
+        layout += [("arg", 0), ("arg", 1), ("map", 0), ("map", 1), ("mat_rowptr", 0), ("tp_offtab", 0)]
+        params = ["const int *__restrict__ layers", "double *__restrict__ arg0", "const double *__restrict__ arg1",
+                  "const int *__restrict__ map0", "const int *__restrict__ map1", "const int *__restrict__ rp0",
+                  "const unsigned short *__restrict__ tpo0"]
+        if lg:
+            layout += [("mat_row_lgmap", 0), ("mat_col_lgmap", 0)]
+            params += ["const int *__restrict__ rlg0", "const int *__restrict__ clg0"]
+        layout.append(("tp_tables",))
+        params.append("const double *__restrict__ tptab")
+        body = (f"  fdt::hex_q4_matrix(start, end, layers, arg0, arg1, map0, map1, rp0, tpo0, "
+                f"{'rlg0, clg0' if lg else 'nullptr, nullptr'}, tptab, {call_w});")
+        threads, bounds = 256, "256, 3"
+    else:
+        layout += [("arg", 0), ("arg", 1), ("arg", 2), ("map", 0), ("map", 1), ("tp_tables",)]
+        params = ["const int *__restrict__ layers", "double *__restrict__ arg0", "const double *__restrict__ arg1",
+                  "const double *__restrict__ arg2", "const int *__restrict__ map0", "const int *__restrict__ map1",
+                  "const double *__restrict__ tptab"]
+        body = f"  fdt::hex_q4_action(start, end, layers, arg0, arg1, arg2, map0, map1, tptab, {call_w});"
+        threads, bounds = 128, "128"
+    src = head + [f'extern "C" __global__ __launch_bounds__({bounds}) void {sym}(int start, int end, {", ".join(params)})', "{", body, "}"]
+    return WrapperSource("\n".join(src) + "\n", sym, "tp_" + kind, layout, 2, block_threads=threads)
+
+
 def select_mode(gk: GlobalKernel) -> str:
     want = configuration["mode"]
+    if want != "direct" and tensor_eligible(gk):
+        return "tp_" + tensor_eligible(gk)
     ok = staged_eligible(gk)
     if want == "staged" and not ok:
         raise ValueError("FDHIP_MODE=staged but this parloop is not eligible for the staged wrapper")
@@ -89,8 +163,21 @@ def select_mode(gk: GlobalKernel) -> str:
 
 
 def staged_eligible(gk: GlobalKernel) -> bool:
+    """Staged wrapper (LDS gather / reduction over block-localisation plans).  Subsets and extruded sets qualify too: the
+    plan is then built on a DERIVED map over the virtual iteration space -- the map rows of the subset's entities, resp.
+    one row ``map + offset*layer`` per (column, layer) cell (builder.py:94-124 folded into the table once) -- so the kernel
+    itself addresses nothing but local indices; only direct arguments need the base entity.  Restrictions: Dat-only
+    loops, constant layers, no periodic wrap, regions ALL / ON_BOTTOM / ON_TOP, and no direct Dat written on an extruded
+    set (all layers of a column share its row: parloop.py:494-497)."""
     if gk._extruded or gk._subset:
-        return False
+        if any(isinstance(a, MatKernelArg) for a in gk.arguments):
+            return False
+        if gk._extruded:
+            if not gk._constant_layers or gk._extruded_periodic or gk._iteration_region == ON_INTERIOR_FACETS:
+                return False
+            if any(isinstance(a, DatKernelArg) and not a.is_indirect and la.access != READ
+                   for a, la in zip(gk.arguments, gk.local_kernel.arguments)):
+                return False
     n_ind = 0
     for a, la in zip(gk.arguments, gk.local_kernel.arguments):
         if isinstance(a, MatKernelArg) and any(isinstance(m, PermutedMapKernelArg) for m in a.maps):
@@ -133,6 +220,8 @@ def _hoist_includes(code: str):
 
 
 def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> WrapperSource:
+    if mode.startswith("tp_"):
+        return generate_tensor_wrapper(gk)
     lk = gk.local_kernel
     maps, map_index = _distinct_maps(gk)
     # requires_zeroed_output_arguments: MIN/MAX packs start from zero like INC/WRITE ones (builder.py:276-279, 368-371)
@@ -600,6 +689,12 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         # run, so the lanes of one trip work on entities that are far apart (no shared nodes -> no serialised LDS
         # atomics) while their index rows stay coalesced.  OCR instance lists are stored in that order already.
         lane_threads = threads if configuration["lane_strided"] else 0
+        virt = (extruded or gk._subset) and not ocr
+        if virt:
+            if extruded:
+                lo, hi = {ALL: ("layers[0]", "layers[1]-1"), ON_BOTTOM: ("layers[0]", "layers[0]+1"),
+                          ON_TOP: ("layers[1]-2", "layers[1]-1")}[region]
+                src.append(f"  const int fd_llo = {lo}, fd_nlit = ({hi}) - fd_llo;")
         if ocr:
             ent_of = lambda ii: f"inst_ent_[{ii}]"
         elif lane_threads:
@@ -618,14 +713,30 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 src.append("    " + ld.replace("II", "fd_first").replace("EE", "e_cur").replace("DST", name))
             src.append("  }")
         src.append("  for (int it = fd_first; it < fd_last; it += fd_step) {")
-        if pf:
+
+        def decode(v):
+            """virtual id (position in the subset x layer) -> base entity ``e`` (+ ``layer``)"""
+            out = []
+            if extruded:
+                out.append(f"    const int fd_col = ({v}) / fd_nlit; const int layer = fd_llo + (({v}) - fd_col*fd_nlit);")
+                out.append("    const int e = " + ("subset_indices[fd_col];" if gk._subset else "fd_col;"))
+            else:
+                out.append(f"    const int e = subset_indices[{v}];")
+            return out
+        if pf and virt:
+            src += decode("e_cur")
+        elif pf:
             src.append("    const int e = e_cur;")
             src.append("    const int itn = (it + fd_step < fd_last) ? it + fd_step : it;")
             src.append(f"    e_nx = {ent_of('itn')};")
             for cur, nxt, name, n, ld in idx_loads:
                 src.append("    " + ld.replace("II", "itn").replace("EE", "e_nx").replace("DST", "nx_" + name))
         else:
-            src.append(f"    const int e = {ent_of('it')};")
+            if virt:
+                src.append(f"    const int fd_v = {ent_of('it')};")
+                src += decode("fd_v")
+            else:
+                src.append(f"    const int e = {ent_of('it')};")
             for cur, nxt, name, n, ld in idx_loads:
                 src.append(f"    {cur}; " + ld.replace("II", "it").replace("EE", "e").replace("DST", name))
         src += ["    " + s for s in pack]

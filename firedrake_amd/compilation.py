@@ -50,8 +50,11 @@ def flags():
 
 
 def _wrapper_header_hash():
-    with open(os.path.join(_CSRC, "fd_wrapper.h"), "rb") as fh:
-        return hashlib.sha1(fh.read()).hexdigest()
+    h = hashlib.sha1()
+    for name in ("fd_wrapper.h", "fd_tensor.h"):
+        with open(os.path.join(_CSRC, name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def compile_hip(source: str, name: str) -> str:

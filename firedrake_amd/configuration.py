@@ -31,6 +31,7 @@ configuration = {
     "ocr_const_stride": _env("FDHIP_OCR_CONST_STRIDE", 0, int),     # owner-computes-rows loops: measured 2 % slower
     "lds_soa": _env("FDHIP_LDS_SOA", 1, int),             # component-major LDS layout for staged vector Dats
     "prefetch": _env("FDHIP_PREFETCH", 1, int),          # software-pipeline the packed index rows
+    "tensor_wrappers": _env("FDHIP_TENSOR_WRAPPERS", 1, int),   # MFMA matrix / sum-factorised action for TensorProductLocalKernels
     "mat_ocr": _env("FDHIP_MAT_OCR", 1, int),             # owner-computes-rows matrix assembly (no global atomics)
     "ocr_chains": _env("FDHIP_OCR_CHAINS", 1, int),       # sliding-window owner-computes-rows over the producer's block chains
     "ocr_nnz_per_block": _env("FDHIP_OCR_NNZ", 2048, int),  # row-block size (CSR entries) when the producer gives no hint

@@ -448,24 +448,8 @@ def precompile_all():
 # ------------------------------------------------------------------------------------------
 def q4_tables(degree=4, nq=5):
     """1-D tables of CG_k on GLL nodes at Gauss-Legendre points: (L[q][i], DL[q][i], points, weights) on [0,1]."""
-    from numpy.polynomial import legendre as leg
-    k = degree
-    # GLL nodes: endpoints and roots of P'_k
-    cP = np.zeros(k + 1)
-    cP[k] = 1.0
-    nodes = np.concatenate([[-1.0], np.sort(leg.legroots(leg.legder(cP))), [1.0]])
-    nodes = 0.5 * (nodes + 1.0)
-    x, w = leg.leggauss(nq)
-    x, w = 0.5 * (x + 1.0), 0.5 * w
-    L = np.zeros((nq, k + 1))
-    DL = np.zeros((nq, k + 1))
-    for i in range(k + 1):
-        others = [nodes[m] for m in range(k + 1) if m != i]
-        denom = np.prod([nodes[i] - o for o in others])
-        for q in range(nq):
-            L[q, i] = np.prod([x[q] - o for o in others]) / denom
-            DL[q, i] = sum(np.prod([x[q] - o for mm, o in enumerate(others) if mm != m]) for m in range(k)) / denom
-    return L, DL, x, w
+    from .tensor import gll_gauss_tables
+    return gll_gauss_tables(degree, nq)
 
 
 def helmholtz_q4_hex_jacobian_kernel(name="helmholtz_q4_hex_jacobian"):
@@ -519,49 +503,97 @@ static void {name}(double *restrict A, const double *restrict x)
   }}
 }}
 """
-    return op2.Kernel(body, name)
+    from .kernel import TensorProductLocalKernel
+    from .tensor import HELMHOLTZ_WEIGHTS
+    return TensorProductLocalKernel(body, name, kind="matrix", degree=4, nq=5, weights_code=HELMHOLTZ_WEIGHTS.replace("NAME", name))
+
+
+def helmholtz_q4_hex_action_kernel(name="helmholtz_q4_hex_action"):
+    """y += A_e(coords) u: the action of the same bilinear form on a coefficient (the matrix-free operator application of
+    tests/firedrake/regression/test_matrix_free.py, and the Q4 "residual/action" of SURVEY.md 8d).  Arguments: y[125],
+    coords[24], u[125].  The C text is the dense definition (element matrix times element vector) the oracle executes; the
+    backend evaluates it sum-factorised from the descriptor (csrc/fd_tensor.h: hex_q4_action)."""
+    from .kernel import TensorProductLocalKernel
+    from .tensor import HELMHOLTZ_WEIGHTS
+    jac = helmholtz_q4_hex_jacobian_kernel(name + "_matrix")
+    body = jac.code + f"""
+static void {name}(double *restrict y, const double *restrict x, const double *restrict u)
+{{
+  static double A[125*125];
+  for (int q = 0; q < 125*125; ++q) A[q] = 0.0;
+  {name}_matrix(A, x);
+  for (int i = 0; i < 125; ++i) {{
+    double s = 0.0;
+    for (int j = 0; j < 125; ++j) s += A[i*125 + j] * u[j];
+    y[i] += s;
+  }}
+}}
+"""
+    return TensorProductLocalKernel(body, name, kind="action", degree=4, nq=5, weights_code=HELMHOLTZ_WEIGHTS.replace("NAME", name))
 
 
 class HelmholtzQ4Problem:
-    """Config C3: assemble the Q4 Helmholtz operator on an extruded hex mesh with the fp64-MFMA kernel
-    ``wrap_helmholtz_q4_hex_jacobian`` (csrc/fd_builtin.hip), reached through fd_kernel_builtin /
-    fd_kernel_launch with the reference's extruded argument order (start, end, layers, mat, coords, maps)."""
+    """Config C3: the Q4 Helmholtz operator on an extruded hex mesh, assembled and applied through ordinary parloops
+    (``op2.LegacyParloop`` with a Mat / Dat argument over the extruded cell set, optional BC lgmaps) whose local kernels
+    are TensorProductLocalKernels: ``GlobalKernel.compile`` picks the fp64-MFMA matrix wrapper and the sum-factorised
+    action wrapper of csrc/fd_tensor.h.  Plays ExplicitMatrixAssembler / OneFormAssembler like PoissonProblem."""
 
     FLOPS_PER_CELL = 2.0 * 128 * 128 * 4 * 125          # MFMA work issued (padded 128x128 tiles)
     ALGO_FLOPS_PER_CELL = 2.0 * 125 * 125 * 125 * 4     # SURVEY.md 8(d): 15.6 MFLOP/cell
 
-    def __init__(self, hexmesh):
-        import ctypes
-        from . import _lib
-        from .device import DeviceBuffer
+    def __init__(self, hexmesh, bcs=False):
         self.mesh = m = hexmesh
         assert m.degree == 4
         cm, xm = m.cell_node_map, m.coord_map
         self.sparsity = op2.Sparsity((m.node_set ** 1, m.node_set ** 1), [(cm, cm, None)])
         self.mat = op2.Mat(self.sparsity)
-        L, DL, qp, qw = q4_tables()
-        self.tables = DeviceBuffer.from_numpy(np.concatenate([L.ravel(), DL.ravel(), qp, qw]))
-        h = ctypes.c_void_p()
-        _lib.call("fd_kernel_builtin", b"wrap_helmholtz_q4_hex_jacobian", ctypes.byref(h))
-        self.kernel = h.value
-        self._elemtab = None
+        pts = m.node_points
+        bnd = np.nonzero(((pts < 1e-12) | (pts > 1 - 1e-12)).any(axis=1))[0].astype(np.int32)
+        self.bc_nodes = bnd if bcs else np.zeros(0, dtype=np.int32)
+        lg = None
+        if len(self.bc_nodes):
+            rlg = np.arange(m.node_set.total_size, dtype=np.int32)
+            rlg[self.bc_nodes] = -1
+            lg = (rlg, rlg.copy())
+        self.kjac, self.kact = helmholtz_q4_hex_jacobian_kernel(), helmholtz_q4_hex_action_kernel()
+        self.jac_loop = op2.LegacyParloop(self.kjac, m.cell_set, self.mat(op2.INC, (cm, cm), lgmaps=lg), m.coordinates(op2.READ, xm))
+        self.u = op2.Dat(m.node_set, np.sin(3 * pts[:, 0]) * np.cos(2 * pts[:, 1]) + 0.3 * pts[:, 2], np.float64, "u")
+        self.y = op2.Dat(m.node_set, None, np.float64, "y")
+        self.act_loop = op2.LegacyParloop(self.kact, m.cell_set, self.y(op2.INC, cm), m.coordinates(op2.READ, xm), self.u(op2.READ, cm))
+        self._bc_dev = None
 
-    def assemble_jacobian(self):
+    def _bc_rows(self):
+        if self._bc_dev is None:
+            from .device import DeviceBuffer
+            self._bc_dev = DeviceBuffer.from_numpy(np.ascontiguousarray(self.bc_nodes, dtype=np.int32))
+        return self._bc_dev
+
+    def assemble_jacobian(self, events=None):
         import ctypes
         from . import _lib
-        m = self.mesh
-        if self._elemtab is None:
-            self._elemtab = self.sparsity.elem_table(m.cell_node_map, m.cell_node_map, nlayers=m.layers)
-        self.mat.zero()
-        vals = self.mat._values_dev()
-        args = [m.cell_set._layers_dev(), vals.ptr, m.coordinates._dev_ptr(False), m.cell_node_map._dev_values(),
-                m.coord_map._dev_values(), self._elemtab.ptr, self.tables.ptr]
-        arr = (ctypes.c_void_p * len(args))(*[ctypes.c_void_p(a) for a in args])
-        ncol = m.base_set.size
-        # two workgroups per cell (each owns 64 of the 128 padded rows of the element matrix)
-        _lib.call("fd_kernel_launch", self.kernel, 0, ncol, arr, len(args), 256, 1, 2 * ncol * m.layers, 0, None)
-        self.mat.dat_version += 1
+        self.mat.zero()                       # a13: part of every assemble (the scatter adds into zeroed values)
+        if events:
+            self.mat._values_dev()            # perform the memset outside the kernel bracket
+            events[0].record()
+        self.jac_loop()
+        if events:
+            events[1].record()
+        if len(self.bc_nodes):
+            sp = self.sparsity
+            _lib.call("fd_csr_set_diagonal", sp._rowptr.ptr, sp._colidx.ptr, self.mat._values_dev().ptr, self._bc_rows().ptr,
+                      len(self.bc_nodes), ctypes.c_double(1.0), None)
         return self.mat
+
+    def assemble_action(self, events=None):
+        """y = A u  (zero + one INC parloop inside frozen_halo, like a 1-form assembly)."""
+        self.y.zero()
+        with self.y.frozen_halo(op2.INC):
+            if events:
+                events[0].record()
+            self.act_loop()
+            if events:
+                events[1].record()
+        return self.y
 
 
 # ------------------------------------------------------------------------------------------

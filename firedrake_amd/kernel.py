@@ -114,6 +114,40 @@ def loopy_c_kernel(code: str, name: str, accesses=None, dtypes=None, **kwargs):
     return CStringLocalKernel(code, name, accesses, dtypes, **kwargs)
 
 
+class TensorProductLocalKernel(CStringLocalKernel):
+    """A local kernel on a tensor-product (hexahedral Q_k) element whose element tensor is a quadrature contraction with a
+    per-point 4 x 4 weight:
+
+        matrix:  A_e = sum_q Phi_q^T W_q Phi_q              action:  y_e = sum_q Phi_q^T W_q (Phi_q u_e)
+
+    ``Phi_q`` = (d/dxi_1, d/dxi_2, d/dxi_3, value) of the (degree+1)^3 basis functions at the nq^3 Gauss points, ``W_q``
+    what ``weights_code`` computes from the cell geometry.  TSFC hands PyOP2 a sum-factorised scalar kernel for such forms
+    (tsfc/spectral.py:157-191); ``code`` plays that role here -- an ordinary C kernel with the TSFC argument order
+    (A, coords[, u]) that the oracle and the direct wrapper execute -- and the descriptor fields let the backend build
+    the element tensor where it belongs on this chip: the matrix as a dense contraction on the fp64 matrix cores, the action
+    sum-factorised out of LDS (csrc/fd_tensor.h).  ``weights_code`` defines
+
+        static inline void <name>_weights(const double J[3][3], const double X[3], double wq, double W[16])
+
+    (J[r][s] = dx_r/dxi_s at the point, X the physical point, wq the quadrature weight; W row-major, W[l*4+k] couples
+    component l of the test side with component k of the trial side).  Only (degree, nq) = (4, 5) is instantiated."""
+
+    def __init__(self, code, name, accesses=None, dtypes=None, *, kind, degree, nq, weights_code, **kwargs):
+        if kind not in ("matrix", "action"):
+            raise ValueError("TensorProductLocalKernel kind must be 'matrix' or 'action'")
+        kwargs.setdefault("requires_zeroed_output_arguments", True)
+        super().__init__(code, name, accesses, dtypes, **kwargs)
+        self.tp = {"kind": kind, "degree": int(degree), "nq": int(nq), "weights_code": weights_code}
+
+    @property
+    def cache_key(self):
+        return hashlib.md5((CStringLocalKernel.cache_key.fget(self) + repr(sorted(self.tp.items()))).encode()).hexdigest()
+
+    def with_signature(self, accesses, dtypes):
+        return TensorProductLocalKernel(self.code, self.name, accesses, dtypes, flop_count=self.flop_count, headers=self.headers,
+                                        requires_zeroed_output_arguments=self.requires_zeroed_output_arguments, cpp=self.cpp, **self.tp)
+
+
 def Kernel(code, name, **kwargs):
     """pyop2/local_kernel.py:54-83 ``Kernel`` factory: C strings and loopy kernels."""
     if isinstance(code, str):

@@ -459,9 +459,51 @@ class Parloop:
                 pa = self.arguments[desc[1]]
                 lg = pa.lgmaps[0 if kind == "mat_row_lgmap" else 1]
                 out.append(self._lgmap(lg))
+            elif kind == "tp_offtab":
+                out.append(self._tp_offtab(desc[1]).ptr)
+            elif kind == "tp_tables":
+                out.append(self._tp_tables().ptr)
             else:
                 raise AssertionError(kind)
         return out, geo
+
+    # -- tensor-product wrappers (csrc/fd_tensor.h) ------------------------------------------------------------------
+    def _tp_tables(self):
+        """1-D tabulation of the element (values and derivatives of the CG_k GLL basis at the Gauss points, points,
+        weights) on the device -- what FInAT hands TSFC as constant tables (tsfc/fem.py:711-735)."""
+        t = self._prepared.get("tp_tables")
+        if t is None:
+            from .tensor import gll_gauss_tables
+            tp = self.global_kernel.local_kernel.tp
+            L, DL, qp, qw = gll_gauss_tables(tp["degree"], tp["nq"])
+            t = DeviceBuffer.from_numpy(np.concatenate([L.ravel(), DL.ravel(), qp, qw]))
+            self._prepared["tp_tables"] = t
+        return t
+
+    def _tp_offtab(self, k):
+        """uint16 [ncol][3][nd*nd]: position of every element-matrix entry inside its CSR row for the bottom, an interior
+        and the top cell of every column.  The interior cells of an extruded column are translates of each other (node =
+        map + offset*layer for rows and columns alike), so one table serves them all: 3 x nd^2 x 2 B per COLUMN instead
+        of nd^2 x 4 B per cell."""
+        tabs = self._prepared.setdefault("tp_offtab", {})
+        t = tabs.get(k)
+        if t is None:
+            pa = self.arguments[k]
+            m = pa.maps[0]._base()
+            sp = pa.data.sparsity
+            sp._build()
+            nl = self.iterset.layers - 1
+            ncol = m.values_with_halo.shape[0]
+            nd = m.arity
+            off = np.asarray(m.offset, dtype=np.int32)
+            lay = np.array([0, min(1, nl - 1), nl - 1], dtype=np.int32)
+            rows = (np.asarray(m.values_with_halo, dtype=np.int32)[:, None, :] + off[None, None, :] * lay[None, :, None])
+            rows_d = DeviceBuffer.from_numpy(np.ascontiguousarray(rows.reshape(ncol * 3, nd)))
+            t = DeviceBuffer(ncol * 3 * nd * nd * 2)
+            _lib.call("fd_csr_elem_row_offsets", sp._node_rowptr.ptr, sp._node_colidx.ptr, rows_d.ptr, rows_d.ptr, ncol * 3, nd, nd,
+                      2, t.ptr, None)
+            tabs[k] = t
+        return t
 
     def _lgmap(self, lg):
         if hasattr(lg, "_fd_dev_ptr"):           # already on the device (bridge.DeviceMat.set_lgmaps)
@@ -516,6 +558,11 @@ class Parloop:
         if src.mode.startswith("staged"):
             nb = next(iter(geo["plans"].values())).nblocks
             cw.launch(start, end, args, block_threads=threads, ents_per_block=geo["epb"], nblocks=nb, lds_bytes=geo["lds"])
+        elif src.mode.startswith("tp_"):
+            # one (action) or two (matrix: the halves of the padded 128-row element matrix) workgroups per cell
+            ncell = size * (self.iterset.layers - 1)
+            cw.launch(start, end, args, block_threads=threads, ents_per_block=1,
+                      nblocks=ncell * (2 if src.mode == "tp_matrix" else 1))
         else:
             total = size
             if self.iterset._extruded and src.layer_parallel:

@@ -1,0 +1,55 @@
+"""Tensor-product (hexahedral Q_k) elements: 1-D tabulations and the kernel descriptor the backend turns into the
+matrix-core / sum-factorised wrappers of csrc/fd_tensor.h.
+
+In Firedrake these tables come from FInAT/FIAT (tsfc/fem.py:711-735: ``ctx.basis_evaluation``; Q_k = CG_k (x) CG_k (x)
+CG_k with GLL nodes, Gauss-Legendre quadrature from ``dx(degree=...)``, tsfc/fem.py:330-333); neither package is
+available here, so the 1-D Lagrange tabulation is computed directly."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def gll_nodes(k):
+    """Gauss-Lobatto-Legendre points on [0, 1] (k+1 of them): the nodes of CG_k on an interval."""
+    if k == 1:
+        return np.array([0.0, 1.0])
+    from numpy.polynomial import legendre as leg
+    c = np.zeros(k + 1)
+    c[k] = 1.0
+    return 0.5 * (np.concatenate([[-1.0], np.sort(leg.legroots(leg.legder(c))), [1.0]]) + 1.0)
+
+
+def gll_gauss_tables(degree=4, nq=5):
+    """(L[q][i], DL[q][i], points, weights): values and derivatives of the CG_degree Lagrange basis on the GLL nodes at
+    the nq Gauss-Legendre points of [0, 1]."""
+    from numpy.polynomial import legendre as leg
+    k = degree
+    nodes = gll_nodes(k)
+    x, w = leg.leggauss(nq)
+    x, w = 0.5 * (x + 1.0), 0.5 * w
+    L = np.zeros((nq, k + 1))
+    DL = np.zeros((nq, k + 1))
+    for i in range(k + 1):
+        others = [nodes[m] for m in range(k + 1) if m != i]
+        denom = np.prod([nodes[i] - o for o in others])
+        for q in range(nq):
+            L[q, i] = np.prod([x[q] - o for o in others]) / denom
+            DL[q, i] = sum(np.prod([x[q] - o for mm, o in enumerate(others) if mm != m]) for m in range(k)) / denom
+    return L, DL, x, w
+
+
+# the Helmholtz point weight: a(u, v) = int grad(u).grad(v) + u v dx  ->  W = [ w|J| K K^T  0 ; 0  w|J| ],  K = J^-1
+HELMHOLTZ_WEIGHTS = """
+static inline void NAME_weights(const double J[3][3], const double X[3], double wq, double W[16])
+{
+  double K[3][3], det;
+  fdt::inv3(J, K, det);
+  const double w = wq * fabs(det);
+  for (int a = 0; a < 3; ++a) {
+    for (int b = 0; b < 3; ++b) W[a*4 + b] = w * (K[a][0]*K[b][0] + K[a][1]*K[b][1] + K[a][2]*K[b][2]);
+    W[a*4 + 3] = 0.0; W[12 + a] = 0.0;
+  }
+  W[15] = w;
+  (void)X;
+}
+"""

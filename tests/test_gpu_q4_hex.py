@@ -9,16 +9,37 @@ from oracle import ODat, OMat, READ, INC
 from firedrake_amd import forms, mesh as fmesh
 
 
-def _oracle_matrix(m):
+def _oracle_matrix(m, bc_nodes=None):
+    """Dense Q4 kernel through the oracle's extruded wrapper; BC rows/columns dropped through the lgmaps and the unit
+    diagonal set afterwards, as assemble.py:1501-1507 / 2075-2108 do."""
     cm, xm = m.cell_node_map.values_with_halo, m.coord_map.values_with_halo
     nn = m.node_set.total_size
     csr = oracle.build_sparsity(nn, nn, [(cm, cm, m.layers, m.cell_node_map.offset, m.cell_node_map.offset)])
     k = forms.helmholtz_q4_hex_jacobian_kernel()
+    lg = None
+    if bc_nodes is not None and len(bc_nodes):
+        lg = np.arange(nn, dtype=np.int32)
+        lg[bc_nodes] = -1
     oracle.par_loop(k.code, k.name, 0, m.base_set.size,
-                    [OMat(csr, INC, cm, cm, roffset=m.cell_node_map.offset, coffset=m.cell_node_map.offset),
+                    [OMat(csr, INC, cm, cm, roffset=m.cell_node_map.offset, coffset=m.cell_node_map.offset, row_lgmap=lg, col_lgmap=lg),
                      ODat(np.array(m.coordinates.data_ro_with_halos), READ, xm, offset=m.coord_map.offset)],
                     layers=(0, m.layers + 1))
+    if lg is not None:
+        rp, ci = csr.rowptr, csr.colidx
+        for b in bc_nodes:
+            csr.values[rp[b] + np.searchsorted(ci[rp[b]:rp[b + 1]], b)] = 1.0
     return csr
+
+
+def _oracle_action(m, u):
+    cm, xm = m.cell_node_map.values_with_halo, m.coord_map.values_with_halo
+    y = np.zeros(m.node_set.total_size)
+    k = forms.helmholtz_q4_hex_action_kernel()
+    oracle.par_loop(k.code, k.name, 0, m.base_set.size,
+                    [ODat(y, INC, cm, offset=m.cell_node_map.offset),
+                     ODat(np.array(m.coordinates.data_ro_with_halos), READ, xm, offset=m.coord_map.offset),
+                     ODat(np.array(u), READ, cm, offset=m.cell_node_map.offset)], layers=(0, m.layers + 1))
+    return y
 
 
 def test_q4_tables_and_oracle_kernel_identities():
@@ -42,18 +63,97 @@ def test_q4_tables_and_oracle_kernel_identities():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,layers", [(2, 2), (3, 2), (2, 5)])
-def test_q4_mfma_matches_oracle(n, layers):
+@pytest.mark.parametrize("n,layers", [(2, 2), (3, 2), (2, 5), (3, 1), (8, 8)])
+@pytest.mark.parametrize("bcs", [False, True])
+def test_q4_mfma_matches_oracle(n, layers, bcs):
+    """The Q4 matrix through an ordinary parloop (Mat INC over the extruded cell set, BC lgmaps): GlobalKernel.compile
+    selects the fp64-MFMA wrapper from the TensorProductLocalKernel descriptor; the oracle runs the kernel's dense C text."""
     m = fmesh.make_extruded_hex_mesh(n, layers, 4, perturb=0.1)
-    prob = forms.HelmholtzQ4Problem(m)
+    prob = forms.HelmholtzQ4Problem(m, bcs=bcs)
+    assert prob.jac_loop._prepare()["cw"].src.mode == "tp_matrix"
     mat = prob.assemble_jacobian()
-    ref = _oracle_matrix(m)
+    ref = _oracle_matrix(m, prob.bc_nodes)
     rp, ci, v = mat.csr()
     assert np.array_equal(rp, ref.rowptr) and np.array_equal(ci, ref.colidx)
     # SURVEY.md Appendix D: 1e-11 * max|A| for Q4 (different contraction order under MFMA)
     assert_allclose(v, ref.values, rtol=0, atol=1e-11 * np.abs(ref.values).max())
     v2 = prob.assemble_jacobian().csr()[2]
     assert_allclose(v2, ref.values, rtol=0, atol=1e-11 * np.abs(ref.values).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,layers", [(2, 2), (3, 4), (8, 8)])
+def test_q4_action_matches_oracle_and_the_assembled_matrix(n, layers):
+    """y = A u by the sum-factorised action wrapper (tp_action) against the oracle's dense element-matrix-times-vector,
+    and against the MFMA-assembled matrix applied with the device SpMV (A*x == action(a, x), test_matrix_free.py:97-123)."""
+    from firedrake_amd import op2
+    m = fmesh.make_extruded_hex_mesh(n, layers, 4, perturb=0.1)
+    prob = forms.HelmholtzQ4Problem(m)
+    assert prob.act_loop._prepare()["cw"].src.mode == "tp_action"
+    y = np.array(prob.assemble_action().data_ro)
+    ref = _oracle_action(m, prob.u.data_ro)
+    assert_allclose(y, ref, rtol=0, atol=1e-11 * np.abs(ref).max())
+    y2 = np.array(prob.assemble_action().data_ro)                   # tensor reuse: zero + INC again
+    assert_allclose(y2, ref, rtol=0, atol=1e-11 * np.abs(ref).max())
+    mat = prob.assemble_jacobian()
+    t = op2.Dat(m.node_set)
+    mat.mult(prob.u, t)
+    assert_allclose(t.data_ro, y, rtol=0, atol=1e-11 * np.abs(ref).max())
+
+
+@pytest.mark.gpu
+def test_q4_direct_wrapper_fallback(monkeypatch):
+    """FDHIP_TENSOR_WRAPPERS=0: the same parloops run the kernel's C text through the generic direct wrapper."""
+    from firedrake_amd.configuration import configuration
+    monkeypatch.setitem(configuration, "tensor_wrappers", 0)
+    m = fmesh.make_extruded_hex_mesh(2, 2, 4, perturb=0.1)
+    prob = forms.HelmholtzQ4Problem(m, bcs=True)
+    assert prob.jac_loop._prepare()["cw"].src.mode == "direct"
+    v = prob.assemble_jacobian().csr()[2]
+    ref = _oracle_matrix(m, prob.bc_nodes)
+    assert_allclose(v, ref.values, rtol=0, atol=1e-11 * np.abs(ref.values).max())
+
+
+@pytest.mark.gpu
+def test_q4_full_size_sampled_rows_against_oracle():
+    """BASELINE.json configs[2] at n = 32 (32768 cells): the rows of the 27 cell-interior DoFs of a cell receive
+    contributions from that cell alone, so they equal the corresponding rows of its element matrix -- checked against
+    the oracle's dense kernel for 256 random cells (bottom, interior and top layers included), with BCs in place."""
+    from test_forms_identities import _element_tensor
+    n = 32
+    m = fmesh.make_extruded_hex_mesh(n, n, 4, perturb=0.1)
+    prob = forms.HelmholtzQ4Problem(m, bcs=True)
+    mat = prob.assemble_jacobian()
+    sp = mat.sparsity
+    rp = sp.rowptr
+    rng = np.random.default_rng(5)
+    cols_ = np.concatenate([rng.integers(0, m.base_set.size, 250), [0, 1, m.base_set.size - 1, 5, 7, 9]])
+    lays = np.concatenate([rng.integers(0, n, 250), [0, n - 1, 0, n - 1, 1, n - 2]])
+    cm, xm = m.cell_node_map.values_with_halo, m.coord_map.values_with_halo
+    coords = np.array(m.coordinates.data_ro_with_halos)
+    interior = [(a * 5 + b) * 5 + c for a in (1, 2, 3) for b in (1, 2, 3) for c in (1, 2, 3)]
+    from firedrake_amd import _lib
+    bc = np.zeros(m.node_set.total_size, dtype=bool)
+    bc[prob.bc_nodes] = True
+    worst = 0.0
+    for col, lay in zip(cols_, lays):
+        nodes = cm[col] + 4 * lay
+        verts = coords[xm[col] + lay]
+        Ae = _element_tensor(prob.kjac, 125, verts).reshape(125, 125)
+        scale = np.abs(Ae).max()
+        for i in interior:
+            r = nodes[i]
+            assert not bc[r]
+            n0, n1 = int(rp[r]), int(rp[r + 1])
+            cidx = np.empty(n1 - n0, dtype=np.int32)
+            vals = np.empty(n1 - n0)
+            _lib.call("fd_memcpy_d2h", cidx.ctypes.data, sp._colidx.ptr + 4 * n0, cidx.nbytes, None)
+            _lib.call("fd_memcpy_d2h", vals.ctypes.data, mat._values_dev().ptr + 8 * n0, vals.nbytes, None)
+            assert np.array_equal(np.sort(nodes), cidx)                # an interior DoF couples to its own cell only
+            expect = np.where(bc[nodes], 0.0, Ae[i])                   # BC columns dropped
+            got = vals[np.searchsorted(cidx, nodes)]
+            worst = max(worst, np.abs(got - expect).max() / scale)
+    assert worst <= 1e-11
 
 
 @pytest.mark.gpu
