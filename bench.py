@@ -429,7 +429,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=128, help="cube size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-bcs", action="store_true")
     ap.add_argument("--tile", type=str, default="8,8,4", help="cubes per traversal tile (= plan block)")
-    ap.add_argument("--numbering", choices=["tiled", "sweep", "lexicographic", "random"], default="tiled",
+    ap.add_argument("--numbering", choices=["tiled", "lexicographic", "random"], default="tiled",
                     help="entity numbering of the headline measurement (SURVEY.md 8d)")
     ap.add_argument("--variants", type=str, default="lexicographic,random",
                     help="further numberings measured after the headline one at N=1 (no producer hints); '' = none")

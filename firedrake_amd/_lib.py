@@ -70,9 +70,6 @@ SIGNATURES = {
     "fd_dat_fill_range": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "fd_plan_create": (c_int, [c_void_p, c_int, c_int32, c_int32, c_int, c_void_p, POINTER(c_void_p)]),
     "fd_plan_create_blocks": (c_int, [c_void_p, c_int, c_void_p, c_int32, c_void_p, POINTER(c_void_p)]),
-    "fd_ocrplan_create_chained": (c_int, [c_void_p, c_int, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int, c_void_p,
-                                          POINTER(c_void_p)]),
-    "fd_ocrplan_chain_info": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_void_p)]),
     "fd_ocrplan_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "fd_plan_set_lane_order": (c_int, [c_void_p, c_int, c_void_p]),
     "fd_plan_block_starts": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int32)]),

@@ -233,10 +233,6 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
     if sm_:
         mode = mode[:sm_.start()]
     ocr = mode.startswith("ocr")
-    # "ocrc<W>": chained owner-computes-rows -- a workgroup walks the row blocks of one chain and keeps the accumulators of
-    # the last W blocks in LDS (fd_ocrplan_create_chained); W is compiled in (slot = block % W)
-    cm_ = re.match(r"ocrc(\d+)", mode)
-    chained = int(cm_.group(1)) if cm_ else 0
     staged = mode.startswith("staged") or ocr
     ktype, kbytes = ("unsigned short", 2) if mode.endswith("_k16") else ("unsigned char", 1)
     extruded = gk._extruded
@@ -363,8 +359,6 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             P(f"long long oc{k}_maxnnz", ("ocr_maxnnz", k))
             P(f"long long oc{k}_maxnown", ("ocr_maxnown", k))
             P(f"long long oc{k}_flags", ("ocr_flags", k))
-            if chained:
-                P(f"const int *__restrict__ oc{k}_chain", ("ocr_chain", k))
         elif mat_staged[k]:
             P(f"const int *__restrict__ mp{k}_off", ("matplan_off", k))
             P(f"const int *__restrict__ mp{k}_gpos", ("matplan_gpos", k))
@@ -512,28 +506,19 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             lg = info["arg"].lgmaps
             if ocr:
                 lds_items.append(("ocr", k, rm, cm, bool(lg)))
-                lds_tail_var.append(f"double *sm{k} = (double *)(fd_lds + fd_off); fd_off += (((size_t)oc{k}_maxnnz*8*{max(chained, 1)}) + 15) & ~(size_t)15;")
+                lds_tail_var.append(f"double *sm{k} = (double *)(fd_lds + fd_off); fd_off += (((size_t)oc{k}_maxnnz*8) + 15) & ~(size_t)15;")
                 # one LDS word per gathered node: bits 0..29 = 1 + offset of the node's row inside the block's
                 # accumulator (0 = row not owned here or BC-masked), bit 31 = column is BC-masked
                 lds_tail_const.append(f"unsigned int *srow{k} = (unsigned int *)(fd_lds + fd_off); fd_off += (((size_t)p{rm}_maxnd*4) + 15) & ~(size_t)15;")
                 if cm != rm:
                     lds_tail_const.append(f"unsigned char *smc{k} = fd_lds + fd_off; fd_off += ((size_t)p{cm}_maxnd + 15) & ~(size_t)15;")
-                if chained:
-                    # live window of row blocks [wlo, b]; block s accumulates in slot s % W at sm + slot*maxnnz
-                    mat_stage_pre.extend([f"const int wlo{k} = (b - {chained - 1} > fd_b0) ? b - {chained - 1} : fd_b0;",
-                                          f"const int n0_{k} = oc{k}_rblk[wlo{k}], nown{k} = oc{k}_rblk[b+1] - n0_{k};"])
-                    ocr_chain_k = k
-                else:
-                    mat_stage_pre.extend([f"const int n0_{k} = oc{k}_rblk[b], nown{k} = oc{k}_rblk[b+1] - n0_{k};",
-                                          f"const int r0_{k} = oc{k}_rowptr[n0_{k}], nnzb{k} = oc{k}_rowptr[n0_{k} + nown{k}] - r0_{k};"])
-                    stage.append((rm, f"for (int q = tid; q < nnzb{k}; q += nthr) sm{k}[q] = 0;"))
+                mat_stage_pre.extend([f"const int n0_{k} = oc{k}_rblk[b], nown{k} = oc{k}_rblk[b+1] - n0_{k};",
+                                      f"const int r0_{k} = oc{k}_rowptr[n0_{k}], nnzb{k} = oc{k}_rowptr[n0_{k} + nown{k}] - r0_{k};"])
+                stage.append((rm, f"for (int q = tid; q < nnzb{k}; q += nthr) sm{k}[q] = 0;"))
                 colmask = bool(lg)
                 rowmask = f" && rlg{k}[g] >= 0" if lg else ""
                 colbit = (f" | ((clg{k}[g] < 0) ? 0x80000000u : 0u)" if (colmask and cm == rm) else "")
-                if chained:
-                    rowpos = f"fdw::chain_row_pos<{chained}>(oc{k}_rblk, oc{k}_rowptr, g, wlo{k}, b, (int)oc{k}_maxnnz)"
-                else:
-                    rowpos = f"(unsigned)(oc{k}_rowptr[g] - r0_{k} + 1)"
+                rowpos = f"(unsigned)(oc{k}_rowptr[g] - r0_{k} + 1)"
                 node_actions.setdefault(rm, []).append(
                     ([f"const int g = G_U; const unsigned w{k}_U = ((g >= n0_{k} && g < n0_{k} + nown{k}{rowmask}) ? {rowpos} : 0u){colbit};".replace("const int g = G_U; ", "").replace("(g ", "(G_U ").replace(" g ", " G_U ").replace(" g,", " G_U,").replace("[g]", "[G_U]")],
                      [f"srow{k}[I_U] = w{k}_U;"]))
@@ -554,14 +539,6 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 lines += [f"    atomicAdd(&sm{k}[base + kk{k}[i*{ac} + j]], {val});", "  }", "}"]
                 unpack.append("\n    ".join(lines))
                 # complete rows, contiguous in the CSR value array: plain coalesced stores
-                if chained:
-                    # block b - W + 1 can no longer be touched: write its rows and clear its slot for block b + 1; the last
-                    # step of the chain writes everything still in the window
-                    flush.append((rm, f"for (int f = (b == fd_b1 - 1) ? wlo{k} : b - {chained - 1}; f >= fd_b0 && f <= ((b == fd_b1 - 1) ? b : b - {chained - 1}); ++f) {{ "
-                                      f"const int fr0 = oc{k}_rowptr[oc{k}_rblk[f]], fnn = oc{k}_rowptr[oc{k}_rblk[f+1]] - fr0; double *fs = sm{k} + (size_t)(f % {chained})*oc{k}_maxnnz; "
-                                      f"if (oc{k}_flags & 1) {{ for (int q = tid; q < fnn; q += nthr) {{ arg{k}[(size_t)fr0 + q] = fs[q]; fs[q] = 0; }} }} "
-                                      f"else {{ for (int q = tid; q < fnn; q += nthr) {{ arg{k}[(size_t)fr0 + q] += fs[q]; fs[q] = 0; }} }} }}"))
-                    continue
                 flush.append((rm, f"if (oc{k}_flags & 1) {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)r0_{k} + q] = sm{k}[q]; }} "
                                   f"else {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)r0_{k} + q] += sm{k}[q]; }}"))
                 continue
@@ -638,19 +615,9 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
     if staged:
         src += ["  extern __shared__ __align__(16) unsigned char fd_lds[];",
                 "  const int tid = threadIdx.x, nthr = blockDim.x;"]
-        if chained:
-            # one workgroup per CHAIN of row blocks; the accumulator window survives from block to block
-            src += [f"  const int fd_c = fdw::xcd_block(blockIdx.x, gridDim.x);",
-                    f"  const int fd_b0 = oc{ocr_chain_k}_chain[fd_c], fd_b1 = oc{ocr_chain_k}_chain[fd_c+1];"]
-            src += ["  " + s for s in lds_decl + lds_tail_const + lds_tail_var]
-            src += [f"  for (int q = tid; q < (int)oc{ocr_chain_k}_maxnnz*{chained}; q += nthr) sm{ocr_chain_k}[q] = 0;"]
-            src += ["  " + s for s in pre]
-            src += ["  for (int b = fd_b0; b < fd_b1; ++b) {",
-                    "  const int e0 = bstart_[b], e1 = bstart_[b+1];"]
-        else:
-            src += ["  const int b = fdw::xcd_block(blockIdx.x, gridDim.x);",
-                    "  const int e0 = bstart_[b], e1 = bstart_[b+1];"]
-            src += ["  " + s for s in lds_decl + lds_tail_const + lds_tail_var]
+        src += ["  const int b = fdw::xcd_block(blockIdx.x, gridDim.x);",
+                "  const int e0 = bstart_[b], e1 = bstart_[b+1];"]
+        src += ["  " + s for s in lds_decl + lds_tail_const + lds_tail_var]
         for mi in staged_maps:
             src.append(f"  const int l0_{mi} = p{mi}_blkoff[b], nd{mi} = p{mi}_blkoff[b+1] - l0_{mi};")
         src += ["  " + s for s in mat_stage_pre]
@@ -665,8 +632,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                         src.append("    " + l.replace("_U", "_0").replace("G_0", "g_0").replace("I_0", "i_0"))
             src.append("  }")
         src.append("  __syncthreads();")
-        if not chained:
-            src += ["  " + s for s in pre]
+        src += ["  " + s for s in pre]
         src += ["  const int fd_first = e0 + tid, fd_step = nthr, fd_last = e1;"]
         # software pipeline: the packed index rows of the NEXT entity are requested before the current
         # entity's local kernel runs, so their HBM latency hides under ~10^2 fp64 instructions
@@ -750,8 +716,6 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         if flush:
             src.append("  __syncthreads();")
             src += ["  " + s for _, s in flush]
-        if chained:
-            src.append("  }")
         src += ["  " + s for s in post]
     else:
         if extruded:

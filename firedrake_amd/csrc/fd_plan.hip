@@ -12,8 +12,6 @@
 // re-encoding of Map.values (pyop2/types/map.py:32-45) restricted to [start,end).
 #include "fd_common.h"
 #include <climits>
-#include <algorithm>
-#include <vector>
 
 struct fd_plan_s {
     int32_t nblocks = 0, max_nd = 0;
@@ -626,11 +624,6 @@ struct fd_ocrplan_s {
     int32_t *inst_off_host = nullptr;
     int32_t *inst_ent = nullptr;     // ninst (device): entity of every instance
     int32_t *rblk = nullptr;         // nblocks+1 (device): first row node of every block
-    // chained (sliding-window) plans: consecutive blocks form chains; a workgroup walks the blocks of one chain in order
-    // and keeps the accumulators of the last `window` blocks in LDS.  Unchained plans: nchains == 0, window == 1.
-    int32_t nchains = 0, window = 1;
-    int32_t *chain_off = nullptr;    // nchains+1 (device): first block of every chain
-    int32_t *chain_first = nullptr;  // nblocks (device): first block of the chain a block belongs to
 };
 
 namespace {
@@ -654,31 +647,6 @@ __global__ void ocr_emit(const int32_t *__restrict__ rmap, int ar, int32_t start
         int32_t r = rmap[e * ar + (t % ar)];
         int32_t b = r >= 0 ? block_of_node(rblk, nblocks, r) : -1;
         keys[t] = b >= 0 ? (((uint64_t)b << 32) | (uint64_t)(uint32_t)e) : ~0ull;
-    }
-}
-
-// Chained plans: an entity is an instance of the LAST block of a chain it touches (per chain): when the workgroup reaches
-// that block, every earlier block the entity adds into is still inside the accumulator window.  window = the largest
-// (last - first + 1) over all (entity, chain) pairs.
-__global__ void ocr_emit_chained(const int32_t *__restrict__ rmap, int ar, int32_t start, int32_t end,
-                                 const int32_t *__restrict__ rblk, int32_t nblocks, const int32_t *__restrict__ chain_first,
-                                 uint64_t *__restrict__ keys, int32_t *__restrict__ window) {
-    const int64_t total = ((int64_t)end - start) * ar;
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t e = start + t / ar;
-        const int32_t *row = rmap + e * ar;
-        const int32_t r = row[t % ar];
-        const int32_t b = r >= 0 ? block_of_node(rblk, nblocks, r) : -1;
-        if (b < 0) { keys[t] = ~0ull; continue; }
-        const int32_t c = chain_first[b];
-        int32_t hi = b;
-        for (int j = 0; j < ar; ++j) {
-            const int32_t rj = row[j];
-            const int32_t bj = rj >= 0 ? block_of_node(rblk, nblocks, rj) : -1;
-            if (bj > hi && chain_first[bj] == c) hi = bj;
-        }
-        if (hi - b + 1 > 1) atomicMax(window, hi - b + 1);
-        keys[t] = ((uint64_t)hi << 32) | (uint64_t)(uint32_t)e;
     }
 }
 
@@ -725,17 +693,14 @@ __global__ void ocr_lane_order(const int32_t *__restrict__ off, const int32_t *_
 // conflict window add into distinct banks, and no two of them share an accumulator in one instruction.
 __global__ void ocr_stencil_keys(const int32_t *__restrict__ rmap, int ar, const int32_t *__restrict__ inst_off,
                                  const int32_t *__restrict__ inst_ent, const int32_t *__restrict__ rblk, int32_t nblocks,
-                                 int64_t ninst, uint64_t *__restrict__ keys, const int32_t *__restrict__ chain_first, int window) {
+                                 int64_t ninst, uint64_t *__restrict__ keys) {
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < ninst; t += (int64_t)gridDim.x * blockDim.x) {
         int lo = 0, hi = nblocks - 1;                      // block of instance t: largest b with inst_off[b] <= t
         while (lo < hi) {
             int mid = (lo + hi + 1) >> 1;
             if (inst_off[mid] <= t) lo = mid; else hi = mid - 1;
         }
-        // rows this instance may add into: its block, or (chained plans) the window of live blocks ending at it
-        int wlo = lo;
-        if (chain_first) { wlo = lo - window + 1; if (wlo < chain_first[lo]) wlo = chain_first[lo]; }
-        const int32_t n0 = rblk[wlo], n1 = rblk[lo + 1];
+        const int32_t n0 = rblk[lo], n1 = rblk[lo + 1];
         const int32_t *row = rmap + (int64_t)inst_ent[t] * ar;
         int32_t first = -1;
         for (int i = 0; i < ar; ++i) { int32_t r = row[i]; if (first < 0 && r >= n0 && r < n1) first = r; }
@@ -771,8 +736,7 @@ __global__ __launch_bounds__(64) void ocr_pack_k(const int32_t *__restrict__ ins
                                                  const uint16_t *__restrict__ lmap, const unsigned char *__restrict__ kidx8,
                                                  const unsigned short *__restrict__ kidx16, int ar, int ac,
                                                  const int32_t *__restrict__ rblk, const int32_t *__restrict__ rowptr,
-                                                 int maxn, int window, int cand, const int32_t *__restrict__ chain_first,
-                                                 int acc_window, int slot_nnz) {
+                                                 int maxn, int window, int cand) {
     extern __shared__ unsigned char pk_lds[];
     const int b = blockIdx.x, lane = threadIdx.x;
     const int o = inst_off[b], n = inst_off[b + 1] - o;
@@ -786,9 +750,8 @@ __global__ __launch_bounds__(64) void ocr_pack_k(const int32_t *__restrict__ ins
     unsigned short *pool = gaddr + (size_t)maxn * ar;                     // n slots: unplaced instances in order
     unsigned int *amask = (unsigned int *)(pool + ((maxn + 7) & ~7));     // ar*ac bank masks of the current window
     unsigned short *gown = (unsigned short *)(amask + PACK_MAXSIG);       // ar * 32: address held by a gather bank
-    int wlo = b;
-    if (chain_first) { wlo = b - acc_window + 1; if (wlo < chain_first[b]) wlo = chain_first[b]; }
-    const int32_t n0 = rblk[wlo], n1 = rblk[b + 1];
+    const int32_t n0 = rblk[b], n1 = rblk[b + 1];
+    const int32_t r0 = rowptr[n0];
     for (int q = lane; q < n; q += 64) {
         const int64_t t = (int64_t)o + q;
         for (int i = 0; i < ar; ++i) {
@@ -797,14 +760,7 @@ __global__ __launch_bounds__(64) void ocr_pack_k(const int32_t *__restrict__ ins
             sig[q * ns + i] = (unsigned char)(l & 31);
             const int32_t g = imap_r[t * ar + i];
             const bool own = g >= n0 && g < n1;
-            // LDS position of the row's first entry: offset inside its block's accumulator slot (chained plans keep
-            // `acc_window` slots of slot_nnz entries, block s in slot s % acc_window)
-            int base = 0;
-            if (own) {
-                int sb = b;
-                while (sb > wlo && g < rblk[sb]) --sb;
-                base = (chain_first ? (sb % acc_window) * slot_nnz : 0) + rowptr[g] - rowptr[rblk[sb]];
-            }
+            const int base = own ? rowptr[g] - r0 : 0;
             for (int j = 0; j < ac; ++j) {
                 const int k = kidx8 ? (int)kidx8[t * ar * ac + i * ac + j] : (int)kidx16[t * ar * ac + i * ac + j];
                 sig[q * ns + ar + i * ac + j] = own ? (unsigned char)((base + k) & 15) : (unsigned char)0xff;
@@ -900,55 +856,12 @@ __global__ void row_offsets_k(const int32_t *__restrict__ rowptr, const int32_t 
 
 extern "C" {
 
-static int ocrplan_build(const int32_t *rmap_dev, int ar, int32_t start, int32_t end, const int32_t *row_block_starts_host,
-                         int32_t nblocks, const int32_t *chain_starts_host, int32_t nchains, int interleave, fd_stream_t s_,
-                         fd_ocrplan_t *out);
-
 int fd_ocrplan_create(const int32_t *rmap_dev, int ar, int32_t start, int32_t end,
                       const int32_t *row_block_starts_host, int32_t nblocks, int interleave, fd_stream_t s_, fd_ocrplan_t *out) {
-    return ocrplan_build(rmap_dev, ar, start, end, row_block_starts_host, nblocks, nullptr, 0, interleave, s_, out);
-}
-
-int fd_ocrplan_create_chained(const int32_t *rmap_dev, int ar, int32_t start, int32_t end,
-                              const int32_t *row_block_starts_host, int32_t nblocks,
-                              const int32_t *chain_starts_host, int32_t nchains, int interleave, fd_stream_t s_, fd_ocrplan_t *out) {
-    if (!chain_starts_host || nchains < 0) FD_FAIL("fd_ocrplan_create_chained: bad arguments");
-    if (nchains > 0 && (chain_starts_host[0] != 0 || chain_starts_host[nchains] != nblocks))
-        FD_FAIL("fd_ocrplan_create_chained: the chains must cover the blocks (first 0, last nblocks)");
-    for (int32_t c = 0; c < nchains; ++c)
-        if (chain_starts_host[c + 1] <= chain_starts_host[c]) FD_FAIL("fd_ocrplan_create_chained: empty chain");
-    return ocrplan_build(rmap_dev, ar, start, end, row_block_starts_host, nblocks, chain_starts_host, nchains, interleave, s_, out);
-}
-
-int fd_ocrplan_chain_info(fd_ocrplan_t p, int32_t *nchains, int32_t *window, const int32_t **chain_off_dev) {
-    if (!p) FD_FAIL("fd_ocrplan_chain_info: null plan");
-    if (nchains) *nchains = p->nchains;
-    if (window) *window = p->window;
-    if (chain_off_dev) *chain_off_dev = p->chain_off;
-    return 0;
-}
-
-static int ocrplan_build(const int32_t *rmap_dev, int ar, int32_t start, int32_t end, const int32_t *row_block_starts_host,
-                         int32_t nblocks, const int32_t *chain_starts_host, int32_t nchains, int interleave, fd_stream_t s_,
-                         fd_ocrplan_t *out) {
     hipStream_t s = fd::st(s_);
     if (ar <= 0 || nblocks < 0 || end < start || !row_block_starts_host) FD_FAIL("fd_ocrplan_create: bad arguments");
     auto *p = new fd_ocrplan_s;
     p->nblocks = nblocks;
-    int32_t *window_dev = nullptr;
-    if (nchains > 0) {
-        p->nchains = nchains;
-        std::vector<int32_t> cf((size_t)nblocks);
-        for (int32_t c = 0; c < nchains; ++c)
-            for (int32_t b = chain_starts_host[c]; b < chain_starts_host[c + 1]; ++b) cf[b] = chain_starts_host[c];
-        FD_HIP(hipMalloc(&p->chain_off, ((size_t)nchains + 1) * 4));
-        FD_HIP(hipMemcpy(p->chain_off, chain_starts_host, ((size_t)nchains + 1) * 4, hipMemcpyHostToDevice));
-        FD_HIP(hipMalloc(&p->chain_first, (size_t)std::max(nblocks, 1) * 4));
-        if (nblocks) FD_HIP(hipMemcpy(p->chain_first, cf.data(), (size_t)nblocks * 4, hipMemcpyHostToDevice));
-        FD_HIP(hipMalloc(&window_dev, 4));
-        int32_t one = 1;
-        FD_HIP(hipMemcpy(window_dev, &one, 4, hipMemcpyHostToDevice));
-    }
     FD_HIP(hipMalloc(&p->rblk, ((size_t)nblocks + 1) * 4));
     FD_HIP(hipMemcpyAsync(p->rblk, row_block_starts_host, ((size_t)nblocks + 1) * 4, hipMemcpyHostToDevice, s));
     FD_HIP(hipMalloc(&p->inst_off, ((size_t)nblocks + 1) * 4));
@@ -962,17 +875,8 @@ static int ocrplan_build(const int32_t *rmap_dev, int ar, int32_t start, int32_t
     uint64_t *k1 = nullptr, *k2 = nullptr;
     FD_HIP(hipMalloc(&k1, (size_t)nkeys * 8));
     FD_HIP(hipMalloc(&k2, (size_t)nkeys * 8));
-    if (nchains > 0)
-        hipLaunchKernelGGL(ocr_emit_chained, dim3(mp_grid(nkeys)), dim3(256), 0, s, rmap_dev, ar, start, end, p->rblk, nblocks,
-                           p->chain_first, k1, window_dev);
-    else
-        hipLaunchKernelGGL(ocr_emit, dim3(mp_grid(nkeys)), dim3(256), 0, s, rmap_dev, ar, start, end, p->rblk, nblocks, k1);
+    hipLaunchKernelGGL(ocr_emit, dim3(mp_grid(nkeys)), dim3(256), 0, s, rmap_dev, ar, start, end, p->rblk, nblocks, k1);
     FD_CHECK_LAUNCH();
-    if (nchains > 0) {
-        FD_HIP(hipMemcpyAsync(&p->window, window_dev, 4, hipMemcpyDeviceToHost, s));
-        FD_HIP(hipStreamSynchronize(s));
-        FD_HIP(hipFree(window_dev));
-    }
     size_t tb = 0;
     hipcub::DoubleBuffer<uint64_t> db(k1, k2);
     FD_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, db, nkeys, 0, 64, s));
@@ -1007,7 +911,7 @@ static int ocrplan_build(const int32_t *rmap_dev, int ar, int32_t start, int32_t
         FD_HIP(hipMalloc(&kb, (size_t)nu * 8));
         FD_HIP(hipMalloc(&vb, (size_t)nu * 4));
         hipLaunchKernelGGL(ocr_stencil_keys, dim3(mp_grid(nu)), dim3(256), 0, s, rmap_dev, ar, p->inst_off, p->inst_ent, p->rblk,
-                           nblocks, nu, ka, p->chain_first, p->window);
+                           nblocks, nu, ka);
         FD_CHECK_LAUNCH();
         hipcub::DoubleBuffer<uint64_t> dk(ka, kb);
         hipcub::DoubleBuffer<int32_t> dv(p->inst_ent, vb);
@@ -1068,19 +972,9 @@ int fd_ocrplan_pack(fd_ocrplan_t p, const int32_t *imap_r_dev, const uint16_t *l
         FD_HIP(hipFuncSetAttribute((const void *)ocr_pack_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int32_t *out = nullptr;
     FD_HIP(hipMalloc(&out, (size_t)p->ninst * 4));
-    int slot_nnz = 0;
-    if (p->nchains) {
-        // accumulator slot size of a chained plan = the largest block in CSR entries (the wrapper uses the same figure)
-        std::vector<int32_t> rb((size_t)p->nblocks + 1), rp((size_t)p->nblocks + 1);
-        FD_HIP(hipMemcpy(rb.data(), p->rblk, rb.size() * 4, hipMemcpyDeviceToHost));
-        for (int32_t b = 0; b <= p->nblocks; ++b)
-            FD_HIP(hipMemcpy(&rp[b], node_rowptr_dev + rb[b], 4, hipMemcpyDeviceToHost));
-        for (int32_t b = 0; b < p->nblocks; ++b) slot_nnz = std::max(slot_nnz, rp[b + 1] - rp[b]);
-    }
     hipLaunchKernelGGL(ocr_pack_k, dim3(p->nblocks), dim3(64), lds, s, p->inst_off, p->inst_ent, out, imap_r_dev, lmap_dev,
                        kbytes == 1 ? (const unsigned char *)kidx_dev : nullptr,
-                       kbytes == 2 ? (const unsigned short *)kidx_dev : nullptr, ar, ac, p->rblk, node_rowptr_dev, maxn, window, cand,
-                       p->chain_first, p->window, slot_nnz);
+                       kbytes == 2 ? (const unsigned short *)kidx_dev : nullptr, ar, ac, p->rblk, node_rowptr_dev, maxn, window, cand);
     FD_CHECK_LAUNCH();
     FD_HIP(hipStreamSynchronize(s));
     FD_HIP(hipFree(p->inst_ent));
@@ -1110,8 +1004,6 @@ int fd_ocrplan_free(fd_ocrplan_t p) {
     if (p->inst_off) FD_HIP(hipFree(p->inst_off));
     if (p->inst_ent) FD_HIP(hipFree(p->inst_ent));
     if (p->rblk) FD_HIP(hipFree(p->rblk));
-    if (p->chain_off) FD_HIP(hipFree(p->chain_off));
-    if (p->chain_first) FD_HIP(hipFree(p->chain_first));
     free(p->inst_off_host);
     delete p;
     return 0;

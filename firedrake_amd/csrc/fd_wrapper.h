@@ -115,17 +115,6 @@ template <class T> __device__ __forceinline__ T rep_sum(const T *s, int q, int r
     return v;
 }
 
-// ---- chained owner-computes-rows: 1 + LDS position of the first entry of row g, which lies in one of the live row blocks
-// [wlo, b] of the chain; block s keeps its rows in accumulator slot s % W (slot = maxnnz entries), in CSR order.
-template <int W> __device__ __forceinline__ unsigned chain_row_pos(const int *__restrict__ rblk, const int *__restrict__ rowptr,
-                                                                   int g, int wlo, int b, int maxnnz) {
-    int s = b;
-#pragma unroll
-    for (int k = 1; k < W; ++k)
-        if (s > wlo && g < rblk[s]) --s;
-    return (unsigned)((s % W) * maxnnz + rowptr[g] - rowptr[rblk[s]] + 1);
-}
-
 // ---- packed per-entity index rows (uint16 local maps, uint8/uint16 matrix offsets): N small
 // unsigned integers read with the widest loads the row size allows (rows are N*sizeof(T) apart).
 template <class T, int N> __device__ __forceinline__ void load_packed(const T *__restrict__ p, int (&out)[N]) {

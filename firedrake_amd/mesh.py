@@ -72,15 +72,12 @@ class Mesh:
         return self.spaces[degree]
 
 
-def _tile_keys(ix, iy, iz, nx, ny, nz, tile, xslow=False):
-    """Sort key that walks a (nx,ny,nz) grid tile by tile, x fastest inside a tile (``xslow``: x-plane by x-plane)."""
+def _tile_keys(ix, iy, iz, nx, ny, nz, tile):
+    """Sort key that walks a (nx,ny,nz) grid tile by tile, x fastest inside a tile."""
     tx, ty, tz = tile
     Tx, Ty = -(-nx // tx), -(-ny // ty)
     t = ((iz // tz).astype(np.int64) * Ty + iy // ty) * Tx + ix // tx
-    if xslow:
-        loc = ((ix % tx) * tz + iz % tz) * ty + iy % ty
-    else:
-        loc = ((iz % tz) * ty + iy % ty) * tx + ix % tx
+    loc = ((iz % tz) * ty + iy % ty) * tx + ix % tx
     return t * (tx * ty * tz) + loc
 
 
@@ -96,7 +93,7 @@ def _split_blocks(blocks, arity, max_entries=32768):
         blocks = np.sort(np.concatenate([blocks, mids]))
 
 
-NUMBERINGS = ("tiled", "sweep", "lexicographic", "random")
+NUMBERINGS = ("tiled", "lexicographic", "random")
 
 
 def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0, ghost_cells=True, numbering="tiled",
@@ -106,10 +103,6 @@ def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0,
     ``numbering`` (SURVEY.md 8d asks for a locality-dependence variant of every measurement):
       * ``"tiled"``          cells walk the grid tile by tile, nodes are numbered tile by tile, and the Maps carry the
                              tile boundaries as producer hints (``preferred_blocks`` / ``preferred_node_blocks``);
-      * ``"sweep"``          tiles again, but walked x-plane by x-plane inside a tile: the node planes of a tile are
-                             consecutive row ranges that couple only to their neighbours, which is what the sliding-window
-                             owner-computes-rows assembly wants (hints: ``preferred_node_blocks`` = planes,
-                             ``preferred_node_chains`` = tiles);
       * ``"lexicographic"``  cells in plain x-fastest order inside each class, nodes numbered in order of first
                              appearance while walking the cells' closures -- the rule of dmcommon.pyx:2688-2712 applied
                              to an un-tiled cell order -- and NO hints: what a DMPlex-produced mesh looks like to the backend;
@@ -118,9 +111,8 @@ def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0,
     if numbering not in NUMBERINGS:
         raise ValueError(f"numbering must be one of {NUMBERINGS}")
     nx, ny, nz = (int(n),) * 3 if np.isscalar(n) else tuple(int(v) for v in n)
-    if numbering not in ("tiled", "sweep"):
+    if numbering != "tiled":
         tile = (nx, ny, nz)          # one tile = plain lexicographic traversal
-    xslow = numbering == "sweep"
     # ---- cube slab owned by this rank (+ one ghost cube layer each side)
     k0 = (nz * rank) // nranks
     k1 = (nz * (rank + 1)) // nranks
@@ -139,7 +131,7 @@ def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0,
     if rank < nranks - 1:
         ccls[kk == k1 - 1] = 1
     ccls[(kk < k0) | (kk >= k1)] = 2
-    key = _tile_keys(ii, jj, kk - glo, nx, ny, ghi - glo, tile, xslow) + ccls.astype(np.int64) * (1 << 50)
+    key = _tile_keys(ii, jj, kk - glo, nx, ny, ghi - glo, tile) + ccls.astype(np.int64) * (1 << 50)
     if numbering == "random":
         key = np.random.default_rng(seed + 1000 * rank).permutation(len(ii)).astype(np.int64) + ccls.astype(np.int64) * (1 << 50)
     order = np.argsort(key, kind="stable")
@@ -148,12 +140,7 @@ def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0,
     sizes_c = tuple(int(6 * (ccls <= c).sum()) for c in (0, 1, 2))
     cell_set = op2.Set(sizes_c, "cells")
     # traversal tiles = natural plan blocks: boundaries (in cells) where the tile (or the class) changes
-    if xslow:
-        # staged-loop blocks: a few x-layers of a tile (the layers' node planes fit the LDS budget, see lattice_space)
-        lay = max(1, min(tile[0], 49152 // (48 * (tile[1] + 1) * (tile[2] + 1)) - 1, 8192 // (6 * tile[1] * tile[2])))
-        tkey = key[order] // (tile[1] * tile[2] * lay)
-    else:
-        tkey = key[order] // (tile[0] * tile[1] * tile[2])
+    tkey = key[order] // (tile[0] * tile[1] * tile[2])
     cuts = np.nonzero(np.diff(tkey))[0] + 1
     cell_blocks = (6 * np.concatenate([[0], cuts, [ncube]])).astype(np.int32)
 
@@ -191,22 +178,9 @@ def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0,
             ncls[owned & (zz >= p * (k1 - 1))] = 1     # owned, but read by cells that also read ghosts
         tl = tuple(p * t for t in tile)
         nkey = _tile_keys(np.minimum(xx, p * nx - 1), np.minimum(yy, p * ny - 1), np.minimum(zz - zlo, p * (ghi - glo) - 1),
-                          p * nx, p * ny, p * (ghi - glo), tl, xslow)
+                          p * nx, p * ny, p * (ghi - glo), tl)
         # tie-break inside a tile by the true coordinates so keys are unique
-        if xslow:
-            # sweep: x-plane-major inside the tile with the TRUE local coordinates (the lattice planes on the upper domain
-            # faces are one extra plane / row / column of the last tile), so every x-plane is one contiguous range
-            cx_, cy_, cz_ = np.minimum(xx, p * nx - 1), np.minimum(yy, p * ny - 1), np.minimum(zz - zlo, p * (ghi - glo) - 1)
-            Tx, Ty = -(-(p * nx) // tl[0]), -(-(p * ny) // tl[1])
-            tix, tiy, tiz = cx_ // tl[0], cy_ // tl[1], cz_ // tl[2]
-            tno = (tiz.astype(np.int64) * Ty + tiy) * Tx + tix
-            lx, ly, lz = xx - tix * tl[0], yy - tiy * tl[1], (zz - zlo) - tiz * tl[2]
-            loc = (lx.astype(np.int64) * (tl[2] + 1) + lz) * (tl[1] + 1) + ly
-            nkey = tno * ((tl[0] + 1) * (tl[1] + 1) * (tl[2] + 1)) + loc
-            ntile_sweep = tno
-            nkey = (nkey + ncls.astype(np.int64) * (1 << 50)) * 8
-        else:
-            nkey = (nkey + ncls.astype(np.int64) * (1 << 50)) * 8 + ((zz - zlo) // (p * (ghi - glo))) * 4 + (yy // (p * ny)) * 2 + xx // (p * nx)
+        nkey = (nkey + ncls.astype(np.int64) * (1 << 50)) * 8 + ((zz - zlo) // (p * (ghi - glo))) * 4 + (yy // (p * ny)) * 2 + xx // (p * nx)
         if numbering == "lexicographic":
             # first appearance in the cell traversal (vertices of a cell before its edge nodes, as the closure walk
             # of dmcommon.pyx:2688-2712 meets them); lattice points no local cell touches keep the grid order, last
@@ -247,20 +221,11 @@ def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0,
                     halo.recv[rank - 1] = np.concatenate([plane_nodes(z) for z in range(zlo, p * k0)])
         node_set = op2.Set(sizes_n, f"cg{p}_nodes")
         m = op2.Map(cell_set, node_set, arity, cmap, f"cell_cg{p}")
-        if numbering in ("tiled", "sweep"):
+        if numbering == "tiled":
             m.preferred_blocks = _split_blocks(cell_blocks, arity)
             # node ranges of the traversal tiles (row blocks for owner-computes-rows matrix assembly)
-            ntile = ntile_sweep[norder] if xslow else (nkey[norder] // 8) // (tl[0] * tl[1] * tl[2])
-            if xslow:
-                # sub-blocks = the x-planes of every tile (class changes cut too), chains = the tiles
-                xs = xx[norder]
-                cut = np.nonzero((np.diff(ntile) != 0) | (np.diff(xs) != 0) | (np.diff(ncls[norder]) != 0))[0] + 1
-                nb = np.concatenate([[0], cut, [len(norder)]]).astype(np.int32)
-                m.preferred_node_blocks = nb
-                chain_id = ntile[nb[:-1]] * 4 + ncls[norder][nb[:-1]]
-                m.preferred_node_chains = np.concatenate([[0], np.nonzero(np.diff(chain_id))[0] + 1, [len(nb) - 1]]).astype(np.int32)
-            else:
-                m.preferred_node_blocks = np.concatenate([[0], np.nonzero(np.diff(ntile))[0] + 1, [len(norder)]]).astype(np.int32)
+            ntile = (nkey[norder] // 8) // (tl[0] * tl[1] * tl[2])
+            m.preferred_node_blocks = np.concatenate([[0], np.nonzero(np.diff(ntile))[0] + 1, [len(norder)]]).astype(np.int32)
         return FunctionSpaceData(p, node_set, m, pts, halo, bnd, (p * nx + 1) * (p * ny + 1) * (p * nz + 1))
 
     spaces = {}

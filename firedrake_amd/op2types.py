@@ -1418,6 +1418,20 @@ class Map:
             self._dev = DeviceBuffer.from_numpy(self._values)
         return self._dev.ptr
 
+    def derived(self, key, build):
+        """A non-extruded, unsubsetted Map over a VIRTUAL iteration space derived from this one -- the rows of a Subset's
+        entities, or one row ``map + offset*layer`` per (column, layer) cell of an extruded set -- built once by
+        ``build()`` (an (n, arity) int32 array) and cached: what the staged wrapper's plans are made of on subsets and
+        extruded sets (codegen.staged_eligible)."""
+        d = self._derived.get(key) if hasattr(self, "_derived") else None
+        if d is None:
+            if not hasattr(self, "_derived"):
+                self._derived = {}
+            vals = np.ascontiguousarray(build(), dtype=IntType)
+            d = Map(Set(len(vals), "virtual_" + self.iterset.name), self.toset, self.arity, vals, self.name + "_derived")
+            self._derived[key] = d
+        return d
+
     def plan(self, start, end, epb, blocks=None, lane_threads=0):
         """Cached block-localisation plan for [start, end) (include/fdhip.h: fd_plan_create[_blocks]).
         ``blocks``: optional int32 array of block boundaries (entity offsets, first = start, last = end)."""
@@ -1830,24 +1844,12 @@ class OcrPlan:
     """Owner-computes-rows plan (fd_ocrplan_*): row-node blocks, their entity instances, the per-instance
     copies of the staged maps with their node plans, and the per-entity row-offset table."""
 
-    def __init__(self, sparsity, rmap: Map, cmap: Map, staged_maps, start, end, row_blocks, lane_threads=0, chains=None):
-        """``chains``: optional block indices (first 0, last nblocks) cutting the row blocks into chains for the
-        sliding-window variant (fd_ocrplan_create_chained); ``window``/``nchains``/``chain_off`` describe the result."""
+    def __init__(self, sparsity, rmap: Map, cmap: Map, staged_maps, start, end, row_blocks, lane_threads=0):
         self.row_blocks = rb = np.ascontiguousarray(row_blocks, dtype=np.int32)
         nb = len(rb) - 1
         h = ctypes.c_void_p()
-        self.nchains, self.window, self.chain_off = 0, 1, None
-        if chains is not None and nb > 0:
-            ch = np.ascontiguousarray(chains, dtype=np.int32)
-            _lib.call("fd_ocrplan_create_chained", rmap._base()._dev_values(), rmap.arity, int(start), int(end), rb.ctypes.data, nb,
-                      ch.ctypes.data, len(ch) - 1, self._order_code(lane_threads), None, ctypes.byref(h))
-            nc, w, co = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_void_p()
-            _lib.call("fd_ocrplan_chain_info", h.value, ctypes.byref(nc), ctypes.byref(w), ctypes.byref(co))
-            self.nchains, self.window, self.chain_off = nc.value, w.value, co.value
-            self.chains = ch
-        else:
-            _lib.call("fd_ocrplan_create", rmap._base()._dev_values(), rmap.arity, int(start), int(end), rb.ctypes.data, nb,
-                      self._order_code(lane_threads), None, ctypes.byref(h))
+        _lib.call("fd_ocrplan_create", rmap._base()._dev_values(), rmap.arity, int(start), int(end), rb.ctypes.data, nb,
+                  self._order_code(lane_threads), None, ctypes.byref(h))
         self.h = h.value
         ni, mi = ctypes.c_int64(), ctypes.c_int32()
         _lib.call("fd_ocrplan_info", self.h, ctypes.byref(ni), ctypes.byref(mi))

@@ -318,7 +318,7 @@ class Parloop:
         if geo is not None:
             return geo
         src = prep["cw"].src
-        maps = prep["maps"]
+        maps = [self._plan_map(m) for m in prep["maps"]]
         maxar = max(maps[mi].arity for mi in src.staged_maps)
         limit = configuration["lds_limit"]
 
@@ -394,6 +394,48 @@ class Parloop:
                       f"kbytes={mp.kbytes} exclusive={mp.n_exclusive} zero_list={mp.n_zero}", file=sys.stderr)
         prep["parts"][key] = geo
         return geo
+
+    # -- virtual iteration space of staged loops over subsets / extruded sets
+    def _virtual(self, staged=None):
+        """(layers per entity iterated, first layer) when the staged wrapper runs over a virtual space, else None."""
+        gk = self.global_kernel
+        if staged is None:
+            staged = self._prepared["cw"].src.mode.startswith("staged")
+        if not (gk._extruded or gk._subset) or not staged:
+            return None
+        if not gk._extruded:
+            return (1, 0)
+        from .op2types import ON_BOTTOM, ON_TOP
+        bottom, top = (int(v) for v in self.iterset.layers_array[0])
+        reg = gk._iteration_region
+        if reg == ON_BOTTOM:
+            return (1, bottom)
+        if reg == ON_TOP:
+            return (1, top - 2)
+        return (top - 1 - bottom, bottom)
+
+    def _plan_map(self, m, staged=None):
+        """The Map the block-localisation plans of this loop are built on: ``m`` itself, or its derived map over the
+        virtual iteration space (subset position x layer)."""
+        v = self._virtual(staged)
+        if v is None:
+            return m
+        nlit, llo = v
+        it = self.iterset
+        sub = it.indices if isinstance(it, Subset) else None
+        bottom = int(it.layers_array[0][0]) if self.global_kernel._extruded else 0
+        key = ("virtual", None if sub is None else id(it), nlit, llo)
+
+        def build():
+            rows = np.asarray(m.values_with_halo)
+            if sub is not None:
+                rows = rows[sub]
+            if self.global_kernel._extruded:
+                off = np.asarray(m.offset, dtype=np.int64)
+                lay = np.arange(llo - bottom, llo - bottom + nlit, dtype=np.int64)
+                rows = (rows[:, None, :] + off[None, None, :] * lay[None, :, None]).reshape(-1, m.arity)
+            return rows
+        return m.derived(key, build)
 
     # -- argument list in the kernel's parameter order
     def _arglist(self, start, end):
@@ -551,6 +593,10 @@ class Parloop:
         if size <= 0:
             return
         start, end = offset, offset + size
+        self._prepare()
+        v = self._virtual()
+        if v is not None:
+            start, end = start * v[0], end * v[0]       # positions in the virtual (entity x layer) space
         args, geo = self._arglist(start, end)
         cw = geo["cw"] if geo is not None else self._prepared["cw"]
         src = cw.src
@@ -592,13 +638,8 @@ class Parloop:
         rp = sp._node_rowptr.download(np.int32, (rmap.toset.total_size + 1,))
         limit = src.ocr_lds_limit or configuration["lds_limit"]
         hint = getattr(rmap._base(), "preferred_node_blocks", None)
-        chain_hint = getattr(rmap._base(), "preferred_node_chains", None)
-        chain_rows = None
         if hint is not None and configuration["use_preferred_blocks"]:
             rb = np.asarray(hint, dtype=np.int64)
-            if chain_hint is not None and configuration["ocr_chains"]:
-                chain_rows = rb[np.asarray(chain_hint, dtype=np.int64)]       # first row of every chain
-                chain_rows = np.unique(np.concatenate([chain_rows[chain_rows < nrows], [0, nrows]]))
             rb = np.unique(np.concatenate([rb[rb < nrows], [0, nrows]]))
         else:
             cap = configuration["ocr_nnz_per_block"]
@@ -617,18 +658,15 @@ class Parloop:
                     lds += ((nd[mi] * c * isz) + 15) // 16 * 16
                 else:
                     _, kk, rm, cmi, lg = item
-                    lds += ((op.max_nnz * 8 * op.window) + 15) // 16 * 16 + (nd[rm] * 4 + 15) // 16 * 16
+                    lds += ((op.max_nnz * 8) + 15) // 16 * 16 + (nd[rm] * 4 + 15) // 16 * 16
                     if cmi != rm:
                         lds += (nd[cmi] + 15) // 16 * 16
             return lds
 
         for attempt in range(14):
             # split row blocks until the LDS rows and the instance lists fit
-            chains = None
-            if chain_rows is not None:
-                chains = np.searchsorted(rb, chain_rows).astype(np.int32)     # chain boundaries are row-block boundaries
             try:
-                op = OcrPlan(sp, rmap, cmap, staged, start, end, rb, lane_threads=src.lane_threads, chains=chains)
+                op = OcrPlan(sp, rmap, cmap, staged, start, end, rb, lane_threads=src.lane_threads)
             except _lib.FDHipError as exc:
                 if "map entries" not in str(exc):
                     raise
@@ -636,10 +674,6 @@ class Parloop:
                 rb = np.unique(np.concatenate([rb, (rb[:-1] + d // 2)[d > 1]]))
                 continue
             lds = lds_bytes(op)
-            if op.nchains and (op.window > 4 or lds > limit):
-                # the blocks of a chain couple further than neighbours (or the window does not fit): plain row blocks
-                chain_rows = None
-                continue
             if lds <= limit and op.max_inst * maxar <= 32768:
                 break
             d = np.diff(rb)
@@ -653,13 +687,13 @@ class Parloop:
         if lds > 160 * 1024 or op.max_inst * maxar > 32768:
             raise _lib.FDHipError("owner-computes-rows plan does not fit (LDS or instance list); set FDHIP_MAT_OCR=0")
         nds = [op.plans[mi].max_nd for mi in src.staged_maps]
-        variant = mode_variant(f"ocrc{op.window}" if op.nchains else "ocr", op.kbytes, nds)
+        variant = mode_variant("ocr", op.kbytes, nds)
         geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz,
                "cw": prep["cw"] if variant == src.mode else self.global_kernel.compile(variant)}
         prep["parts"][gkey] = geo
         if configuration["debug"]:
             import sys
-            print(f"[fdhip] {self.global_kernel.name} OCR [{start},{end}): chains={op.nchains} window={op.window} row blocks={op.nblocks} instances={op.ninst} "
+            print(f"[fdhip] {self.global_kernel.name} OCR [{start},{end}): row blocks={op.nblocks} instances={op.ninst} "
                   f"(x{op.ninst / max(end - start, 1):.2f} entities) max_inst={op.max_inst} max_nnz={op.max_nnz} max_nown={op.max_nown} "
                   f"lds={lds} kbytes={op.kbytes}", file=sys.stderr)
         return geo
@@ -719,15 +753,13 @@ class Parloop:
                 out.append(op.max_nown)
             elif kind == "ocr_flags":
                 out.append(self._ocr_flag)
-            elif kind == "ocr_chain":
-                out.append(op.chain_off)
             elif kind in ("mat_row_lgmap", "mat_col_lgmap"):
                 pa = self.arguments[desc[1]]
                 out.append(self._lgmap(pa.lgmaps[0 if kind == "mat_row_lgmap" else 1]))
             else:
                 raise AssertionError(kind)
-        cw.launch(0, op.ninst, out, block_threads=src.block_threads, ents_per_block=op.max_inst,
-                  nblocks=op.nchains if op.nchains else op.nblocks, lds_bytes=geo["lds"])
+        cw.launch(0, op.ninst, out, block_threads=src.block_threads, ents_per_block=op.max_inst, nblocks=op.nblocks,
+                  lds_bytes=geo["lds"])
 
     def _nlayers_iterated(self):
         from .op2types import ON_BOTTOM, ON_TOP, ON_INTERIOR_FACETS

@@ -178,17 +178,6 @@ int fd_ocrplan_create(const int32_t *rmap_dev, int rarity, int32_t start, int32_
  * reorders the instances of every block so that the 16 consecutive slots of an LDS conflict window touch distinct
  * LDS banks in the wrapper's gathers and ds_add_f64 scatter wherever the block allows it.  The caller rebuilds the
  * per-instance tables for the new order afterwards.  No-op for element matrices with ar + ar*ac > 128. */
-/* Chained (sliding-window) variant: consecutive row blocks form chains (chain_starts: nchains+1 block indices, first 0,
- * last nblocks).  ONE workgroup walks the blocks of a chain in order and keeps the accumulators of the last `window`
- * blocks in LDS, so an entity that straddles neighbouring blocks of a chain is visited once (as an instance of the LAST
- * block of the chain it touches) instead of once per block: for x-plane blocks of a (y, z) tile the redundancy of
- * owner-computes-rows drops from (tx+1)(ty+1)(tz+1)/(tx ty tz) to (ty+1)(tz+1)/(ty tz).  window = the largest number of
- * consecutive blocks an entity spans (computed here); block b may be flushed once block b + window - 1 is done. */
-int fd_ocrplan_create_chained(const int32_t *rmap_dev, int rarity, int32_t start, int32_t end,
-                              const int32_t *row_block_starts_host, int32_t nblocks,
-                              const int32_t *chain_starts_host, int32_t nchains, int interleave,
-                              fd_stream_t s, fd_ocrplan_t *out);
-int fd_ocrplan_chain_info(fd_ocrplan_t p, int32_t *nchains, int32_t *window, const int32_t **chain_off_dev);
 int fd_ocrplan_pack(fd_ocrplan_t p, const int32_t *imap_rows_dev, const uint16_t *lmap_dev, int ar,
                     const void *kidx_dev, int kbytes, int ac, const int32_t *node_rowptr_dev, fd_stream_t s);
 int fd_ocrplan_info(fd_ocrplan_t p, int64_t *ninst, int32_t *max_inst_per_block);

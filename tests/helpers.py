@@ -129,33 +129,12 @@ def plan_ref_blocks(mapv, blocks):
     return (np.array(blk, np.int32), np.concatenate(lst).astype(np.int32) if lst else np.zeros(0, np.int32), lm)
 
 
-def ocr_plan_ref(rmapv, cmapv, nent, row_blocks, rowptr, colidx, chains=None):
-    """numpy restatement of the owner-computes-rows plan (include/fdhip.h: fd_ocrplan_create[_chained] in natural order +
+def ocr_plan_ref(rmapv, cmapv, nent, row_blocks, rowptr, colidx):
+    """numpy restatement of the owner-computes-rows plan (include/fdhip.h: fd_ocrplan_create in natural order +
     fd_csr_elem_row_offsets): per block of row nodes the entities that touch one of its rows (*instances*, in entity
-    order), and per instance the position of every (i, j) entry inside its CSR row.  With ``chains`` (block indices
-    cutting the blocks into chains) an entity is an instance of the LAST block it touches in every chain it touches;
-    returns the window (largest last - first + 1) as a fourth value then."""
+    order), and per instance the position of every (i, j) entry inside its CSR row."""
     inst_off, inst_ent = [0], []
-    window = 1
-    if chains is not None:
-        blk = np.searchsorted(row_blocks, rmapv[:nent], side="right") - 1          # block of every map entry
-        blk[(rmapv[:nent] < row_blocks[0]) | (rmapv[:nent] >= row_blocks[-1])] = -1
-        chain = np.where(blk >= 0, np.searchsorted(chains, np.maximum(blk, 0), side="right") - 1, -1)
-        last = {}
-        for c in range(len(chains) - 1):
-            inc = chain == c
-            hi = np.where(inc, blk, -1).max(axis=1)
-            lo = np.where(inc, blk, 1 << 30).min(axis=1)
-            ok = hi >= 0
-            if ok.any():
-                window = max(window, int((hi - lo)[ok].max()) + 1)
-            for e in np.nonzero(ok)[0]:
-                last.setdefault(int(hi[e]), []).append(int(e))
-        for b in range(len(row_blocks) - 1):
-            ents = np.array(sorted(last.get(b, [])), dtype=np.int64)
-            inst_ent.append(ents)
-            inst_off.append(inst_off[-1] + len(ents))
-    for b in range(len(row_blocks) - 1 if chains is None else 0):
+    for b in range(len(row_blocks) - 1):
         hit = ((rmapv[:nent] >= row_blocks[b]) & (rmapv[:nent] < row_blocks[b + 1])).any(axis=1)
         inst_ent.append(np.nonzero(hit)[0])
         inst_off.append(inst_off[-1] + int(hit.sum()))
@@ -170,8 +149,6 @@ def ocr_plan_ref(rmapv, cmapv, nent, row_blocks, rowptr, colidx, chains=None):
                 pos = int(np.searchsorted(row, cmapv[e, j]))
                 assert pos < len(row) and row[pos] == cmapv[e, j] and pos < 255
                 kidx[s_, i * ac + j] = pos
-    if chains is not None:
-        return np.array(inst_off, np.int32), inst_ent, kidx, window
     return np.array(inst_off, np.int32), inst_ent, kidx
 
 

@@ -69,12 +69,15 @@ def run_staged(pl, epb=48):
     from helpers import lane_slot_to_entity, plan_ref
     gk = pl.global_kernel
     assert staged_eligible(gk) and not any(isinstance(pa, MatParloopArg) for pa in pl.arguments)
-    start, end = 0, pl.iterset.size
-    maps = []
+    # subsets / extruded sets: the plans live on derived maps over the virtual (position x layer) space
+    virt = pl._virtual(staged=True)
+    start, end = 0, pl.iterset.size * (virt[0] if virt else 1)
+    maps, base_maps = [], []
     for pa in pl.arguments:
         for m in getattr(pa, "maps", ()):
-            if all(m._base() is not q for q in maps):
-                maps.append(m._base())
+            if all(m._base() is not q for q in base_maps):
+                base_maps.append(m._base())
+                maps.append(pl._plan_map(m._base(), staged=True))
     base = generate_wrapper(gk, "staged")
     T = base.block_threads
     plans = {}
@@ -106,14 +109,18 @@ def run_staged(pl, epb=48):
     cargs = [ctypes.c_int(nblocks), ctypes.c_int(T), ctypes.c_int(start), ctypes.c_int(end)]
     for desc in src.layout:
         kind = desc[0]
-        if kind == "arg":
+        if kind == "layers":
+            cargs.append(ptr(np.asarray(pl.iterset.layers_array, dtype=np.int32)))
+        elif kind == "subset":
+            cargs.append(ptr(np.asarray(pl.iterset.indices, dtype=np.int32)))
+        elif kind == "arg":
             pa = pl.arguments[desc[1]]
             host = pa.data._host if pa.data._host_valid else pa.data._to_host()
             a = np.array(host, copy=True)
             outs[desc[1]] = a
             cargs.append(ctypes.c_void_p(a.ctypes.data))
         elif kind == "map":
-            cargs.append(ptr(np.asarray(maps[desc[1]].values_with_halo, dtype=np.int32)))
+            cargs.append(ptr(np.asarray(base_maps[desc[1]].values_with_halo, dtype=np.int32)))
         elif kind == "bstart":
             cargs.append(ptr(bstart))
         elif kind == "plan_blkoff":
@@ -130,7 +137,7 @@ def run_staged(pl, epb=48):
     return [outs.get(k) for k in range(len(pl.arguments))]
 
 
-def run_ocr(pl, rows_per_block=24, zero_pending=True, blocks_per_chain=0):
+def run_ocr(pl, rows_per_block=24, zero_pending=True):
     """Execute a matrix-assembly Parloop ``pl`` with the OWNER-COMPUTES-ROWS wrapper on the host (one OS thread per
     lane, tests/hostsim/mt/fd_wrapper.h).  The plan tables come from the numpy restatements in helpers.py; the CSR
     pattern from the oracle.  Returns the OracleCSR holding the assembled values."""
@@ -152,22 +159,14 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, blocks_per_chain=0):
     nent = pl.iterset.size
     nrows = rmap.toset.size
     rb = np.array(list(range(0, nrows, rows_per_block)) + [nrows], dtype=np.int32)
-    chains, W = None, 0
-    if blocks_per_chain:
-        # sliding-window variant: chains of consecutive row blocks (fd_ocrplan_create_chained)
-        nb_ = len(rb) - 1
-        chains = np.array(list(range(0, nb_, blocks_per_chain)) + [nb_], dtype=np.int32)
-        inst_off, inst_ent, kidx, W = ocr_plan_ref(np.asarray(rmap.values_with_halo), np.asarray(cmap.values_with_halo), nent, rb,
-                                                   csr.rowptr, csr.colidx, chains=chains)
-    else:
-        inst_off, inst_ent, kidx = ocr_plan_ref(np.asarray(rmap.values_with_halo), np.asarray(cmap.values_with_halo), nent, rb,
-                                                csr.rowptr, csr.colidx)
+    inst_off, inst_ent, kidx = ocr_plan_ref(np.asarray(rmap.values_with_halo), np.asarray(cmap.values_with_halo), nent, rb,
+                                            csr.rowptr, csr.colidx)
     plans = {}
     for mi in base.staged_maps:
         blk, lst, lm = plan_ref_blocks(np.asarray(maps[mi].values_with_halo)[inst_ent], inst_off)
         plans[mi] = (blk, lst, np.ascontiguousarray(lm), int(np.diff(blk).max()) if len(blk) > 1 else 0)
     max_nnz = int(np.diff(csr.rowptr[rb]).max())
-    src = generate_wrapper(gk, mode_variant(f"ocrc{W}" if chains is not None else "ocr", 1, [plans[mi][3] for mi in base.staged_maps]))
+    src = generate_wrapper(gk, mode_variant("ocr", 1, [plans[mi][3] for mi in base.staged_maps]))
     text = src.source.replace("extern __shared__ __align__(16) unsigned char fd_lds[];", "unsigned char *fd_lds = fd_sim::lds;")
     sig = re.search(r'extern "C" __global__[^\n]*void %s\((.*)\)\n' % src.symbol, text).group(1)
     names = [p.split()[-1].lstrip("*") for p in sig.split(", ")]
@@ -184,8 +183,7 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, blocks_per_chain=0):
 
     if not zero_pending:
         csr.values[...] = 1.0                     # accumulate on top of existing values
-    cargs = [ctypes.c_int(len(chains) - 1 if chains is not None else len(rb) - 1), ctypes.c_int(T), ctypes.c_int(0),
-             ctypes.c_int(len(inst_ent))]
+    cargs = [ctypes.c_int(len(rb) - 1), ctypes.c_int(T), ctypes.c_int(0), ctypes.c_int(len(inst_ent))]
     for desc in src.layout:
         kind = desc[0]
         if kind == "arg":
@@ -221,8 +219,6 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, blocks_per_chain=0):
             cargs.append(ctypes.c_longlong(int(np.diff(rb).max())))
         elif kind == "ocr_flags":
             cargs.append(ctypes.c_longlong(1 if zero_pending else 0))
-        elif kind == "ocr_chain":
-            cargs.append(ptr(chains))
         elif kind in ("mat_row_lgmap", "mat_col_lgmap"):
             cargs.append(ptr(np.asarray(mpa.lgmaps[0 if kind == "mat_row_lgmap" else 1], dtype=np.int32)))
         else:

@@ -118,12 +118,6 @@ template <class T> inline T rep_sum(const T *s, int q, int rsh) {
     return v;
 }
 
-template <int W> inline unsigned chain_row_pos(const int *rblk, const int *rowptr, int g, int wlo, int b, int maxnnz) {
-    int s = b;
-    while (s > wlo && g < rblk[s]) --s;
-    return (unsigned)((s % W) * maxnnz + rowptr[g] - rowptr[rblk[s]] + 1);
-}
-
 template <class T, int N> inline void load_packed(const T *p, int (&out)[N]) {
     for (int k = 0; k < N; ++k) out[k] = p[k];
 }

@@ -80,7 +80,7 @@ def test_extruded_wrappers():
     k = op2.Kernel("static void vol(double A[1], const double x[12]) { A[0] += x[0]; }", "vol")
     for region in (None, op2.ON_BOTTOM, op2.ON_TOP):
         pl = op2.LegacyParloop(k, ext, g(op2.INC), x(op2.READ, cm), iteration_region=region)
-        assert _compile(pl) == ["direct"]
+        assert _compile(pl) == ["staged", "direct"]        # staged over the (column, layer) cells through a derived map
     k2 = op2.Kernel("static void volf(double A[1], const double x[24]) { A[0] += x[12]; }", "volf")
     pl = op2.LegacyParloop(k2, ext, g(op2.INC), x(op2.READ, cm), iteration_region=op2.ON_INTERIOR_FACETS)
     assert _compile(pl) == ["direct"]

@@ -116,68 +116,6 @@ def test_ocr_plan_matches_numpy_restatement(monkeypatch):
     assert np.array_equal(op.kidx.download(np.uint8, kidx.shape), kidx)
 
 
-@pytest.mark.parametrize("numbering,rows,bpc", [("tiled", 29, 3), ("sweep", 0, 0), ("random", 13, 5)])
-def test_chained_ocr_plan_matches_numpy_restatement(numbering, rows, bpc, monkeypatch):
-    """fd_ocrplan_create_chained against helpers.ocr_plan_ref(chains=...): an entity is an instance of the LAST block it
-    touches in every chain it touches; the window is the largest number of consecutive blocks an entity spans."""
-    from firedrake_amd import _lib, mesh as fmesh
-    from firedrake_amd.op2types import OcrPlan
-    from helpers import ocr_plan_ref
-    monkeypatch.setitem(configuration, "ocr_order", "natural")
-    monkeypatch.setitem(configuration, "ocr_pack", 0)
-    m = fmesh.UnitCubeMesh(6, degrees=(1,), tile=(3, 2, 2), perturb=0.1, numbering=numbering)
-    V = m.space(1)
-    cm = V.cell_node_map
-    sp = op2.Sparsity((V.node_set ** 1, V.node_set ** 1), [(cm, cm, None)])
-    sp._build()
-    nrows = V.node_set.size
-    if rows:
-        rb = np.unique(np.concatenate([np.arange(0, nrows, rows), [nrows]])).astype(np.int32)
-        chains = np.array(list(range(0, len(rb) - 1, bpc)) + [len(rb) - 1], dtype=np.int32)
-    else:
-        rb, chains = cm.preferred_node_blocks, cm.preferred_node_chains
-    op = OcrPlan(sp, cm, cm, {0: cm}, 0, m.cell_set.size, rb, lane_threads=0, chains=chains)
-    inst_off, inst_ent, kidx, window = ocr_plan_ref(cm.values_with_halo, cm.values_with_halo, m.cell_set.size, rb, sp.rowptr,
-                                                    sp.colidx, chains=chains)
-    assert op.nchains == len(chains) - 1 and op.window == window
-    if numbering == "sweep":
-        assert window == 2                     # x-planes couple to their neighbours only
-    assert np.array_equal(op.inst_off_host, inst_off)
-    ent = np.empty(op.ninst, dtype=np.int32)
-    _lib.call("fd_memcpy_d2h", ent.ctypes.data, op.inst_ent, ent.nbytes, None)
-    assert np.array_equal(ent, inst_ent)
-    assert np.array_equal(op.kidx.download(np.uint8, kidx.shape), kidx)
-    ch = np.empty(op.nchains + 1, dtype=np.int32)
-    _lib.call("fd_memcpy_d2h", ch.ctypes.data, op.chain_off, ch.nbytes, None)
-    assert np.array_equal(ch, chains)
-
-
-@pytest.mark.parametrize("degree,n,tile", [(1, 12, (6, 4, 4)), (2, 6, (3, 2, 2)), (1, 20, (27, 16, 8))])
-@pytest.mark.parametrize("bcs", [False, True])
-def test_sweep_numbering_chained_jacobian_matches_oracle(degree, n, tile, bcs, monkeypatch):
-    """End to end: PoissonProblem on the sweep numbering takes the chained owner-computes-rows wrapper (stencil order,
-    bank-aware packing on) and reproduces the oracle; a second loop without Mat.zero() accumulates."""
-    from firedrake_amd import forms, mesh as fmesh
-    from test_gpu_forms import _oracle_problem
-    m = fmesh.UnitCubeMesh(n, degrees=(degree,), tile=tile, perturb=0.1, numbering="sweep")
-    prob = forms.PoissonProblem(m, degree, bcs=bcs)
-    r = prob.assemble_residual()
-    A = prob.assemble_jacobian().toscipy()
-    mat, loop = prob.jacobian()
-    geo = loop._ocr_geometry()
-    assert geo["ocr"].nchains > 0 and geo["cw"].src.mode.startswith("ocrc")
-    ro, Ao = _oracle_problem(prob, bcs)
-    assert np.abs(r.data_ro - ro).max() <= 1e-12 * max(1.0, np.abs(ro).max())
-    assert np.array_equal(A.indptr, Ao.indptr) and np.array_equal(A.indices, Ao.indices)
-    assert np.abs(A.data - Ao.data).max() <= 1e-12 * np.abs(Ao.data).max()
-    A2 = prob.assemble_jacobian().toscipy()
-    assert np.abs(A2.data - Ao.data).max() <= 1e-12 * np.abs(Ao.data).max()
-    if not bcs:
-        loop()                                   # no zero(): accumulate
-        A3 = mat.toscipy()
-        assert np.abs(A3.data - 2.0 * Ao.data).max() <= 1e-12 * np.abs(Ao.data).max()
-
-
 @pytest.mark.parametrize("nx,ny", [(7, 5), (64, 64), (200, 150)])
 @pytest.mark.parametrize("shuffle", [False, True])
 def test_p1_mass_and_rhs_all_paths(nx, ny, shuffle, monkeypatch):

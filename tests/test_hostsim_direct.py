@@ -484,24 +484,38 @@ def test_mat_through_permuted_maps():
     _check(km, ele, mat(op2.INC, (pr, pc)), x(op2.READ, m))
 
 
-@pytest.mark.parametrize("bcs", [False, True])
-@pytest.mark.parametrize("numbering", ["tiled", "sweep"])
-def test_chained_owner_computes_rows_wrapper_on_host(bcs, numbering):
-    """Sliding-window owner-computes-rows (fd_ocrplan_create_chained + the "ocrc<W>" wrapper): a workgroup walks the row
-    blocks of a chain, keeps the accumulators of the last W blocks in LDS, visits an entity once per chain.  Arbitrary
-    chains over arbitrary row blocks (large window) and the sweep numbering's x-planes (window 2 / 3) against the oracle,
-    including accumulation into existing values."""
-    from firedrake_amd import forms, mesh as fmesh
-    from hostsim import run_ocr
-    mesh = fmesh.UnitCubeMesh(4, degrees=(1, 2), perturb=0.1, numbering=numbering, tile=(4, 2, 2))
-    for degree, rpb, bpc in ((1, 5, 3), (1, 25, 4), (2, 27, 3)):
-        prob = forms.PoissonProblem(mesh, degree, bcs=bcs)
-        mat, pl = prob.jacobian()
-        mpa = pl.arguments[0]
-        got = run_ocr(pl, rows_per_block=rpb, blocks_per_chain=bpc)
-        args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
-        ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
-        assert np.abs(got.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
-        if degree == 1:
-            got2 = run_ocr(pl, rows_per_block=rpb, zero_pending=False, blocks_per_chain=bpc)
-            assert np.abs(got2.values - (ref.values + 1.0)).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
+@pytest.mark.parametrize("region", [None, op2.ON_BOTTOM, op2.ON_TOP])
+def test_staged_wrapper_on_extruded_columns_and_subsets_on_host(region):
+    """The staged wrapper over a virtual iteration space: (column, layer) cells of an extruded set -- plans on the derived
+    map ``map + offset*layer`` -- also under a Subset of the columns, with a direct (base-entity) READ argument and the
+    layer argument; and a plain Subset of a non-extruded set.  Against the oracle."""
+    from hostsim import run_staged
+    rng = np.random.default_rng(21)
+    nbase, L, nv = 7, 6, 9
+    base = op2.Set(nbase)
+    ext = op2.ExtrudedSet(base, layers=L)
+    nodes = op2.Set(nv * L)
+    tri = np.array([rng.choice(nv, 3, replace=False) for _ in range(nbase)])
+    cm = op2.Map(ext, nodes, 6, np.concatenate([tri * L, tri * L + 1], axis=1).astype(np.int32), offset=[1] * 6)
+    x = op2.Dat(nodes ** 2, rng.standard_normal((nv * L, 2)))
+    w = op2.Dat(base, rng.standard_normal(nbase))                       # direct: addressed by the BASE entity (parloop.py:494-497)
+    out = op2.Dat(nodes)
+    k = op2.Kernel("static void ks(double *o, const double *x, const double *w, int layer) "
+                   "{ for (int i = 0; i < 6; ++i) o[i] += (1 + layer) * w[0] * (x[2*i] + 0.5*x[2*i+1]); }", "ks")
+    for iterset in (ext, op2.Subset(ext, [5, 1, 3, 6])):
+        args = (out(op2.INC, cm), x(op2.READ, cm), w(op2.READ))
+        pl = op2.LegacyParloop(k, iterset, *args, iteration_region=region, pass_layer_arg=True)
+        got = run_staged(pl, epb=5)[0]
+        ref = oracle_run(k, iterset, *args, iteration_region=region, pass_layer_arg=True)[0]
+        assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    if region is None:
+        it, ind = op2.Set(50), op2.Set(19)
+        mp = op2.Map(it, ind, 3, rng.integers(0, 19, size=(50, 3)))
+        d, o2 = op2.Dat(ind, rng.standard_normal(19)), op2.Dat(ind)
+        ws = op2.Dat(it, rng.standard_normal(50))
+        ss = op2.Subset(it, [40, 3, 17, 18, 19, 2, 44, 45, 9])
+        k2 = op2.Kernel("static void k2(double *o, const double *d, const double *w) { for (int i = 0; i < 3; ++i) o[i] += w[0]*d[(i+1)%3]; }", "k2")
+        pl = op2.LegacyParloop(k2, ss, o2(op2.INC, mp), d(op2.READ, mp), ws(op2.READ))
+        got = run_staged(pl, epb=4)[0]
+        ref = oracle_run(k2, ss, o2(op2.INC, mp), d(op2.READ, mp), ws(op2.READ))[0]
+        assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
