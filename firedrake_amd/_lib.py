@@ -49,6 +49,7 @@ SIGNATURES = {
     "fd_graph_sync": (c_int, [c_void_p]),
     "fd_graph_free": (c_int, [c_void_p]),
     "fd_kernel_load": (c_int, [c_char_p, c_char_p, POINTER(c_void_p)]),
+    "fd_kernel_create": (c_int, [c_char_p, c_char_p, c_char_p, c_char_p, POINTER(c_void_p)]),
     "fd_kernel_builtin": (c_int, [c_char_p, POINTER(c_void_p)]),
     "fd_kernel_free": (c_int, [c_void_p]),
     "fd_kernel_launch": (c_int, [c_void_p, c_int32, c_int32, POINTER(c_void_p), c_int, c_int, c_int, c_int,

@@ -90,9 +90,10 @@ def compile_hip(source: str, name: str) -> str:
         raise CompilationError(f"hipcc failed for {src}:\n{' '.join(cmd)}\n{r.stderr}")
     res = _parse_resources(r.stderr)
     if res:
-        with open(out + ".res.json.tmp", "w") as fh:
+        fd, rtmp = tempfile.mkstemp(suffix=".res.json", dir=cache)      # unique per process: ranks compiling the same
+        with os.fdopen(fd, "w") as fh:                                  # kernel at the same time never share a temporary
             json.dump(res, fh)
-        os.replace(out + ".res.json.tmp", out + ".res.json")
+        os.replace(rtmp, out + ".res.json")
     os.replace(tmp, out)      # atomic: concurrent ranks race benignly
     return out
 

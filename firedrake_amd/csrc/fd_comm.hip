@@ -335,7 +335,8 @@ int fd_halo_create(fd_comm_t comm, int nneigh, const int32_t *peers, const int32
     h->comm = comm;
     std::vector<int32_t> sall, rall;
     for (int k = 0; k < nneigh; ++k) {
-        if (comm && (peers[k] < 0 || peers[k] >= comm->nranks || peers[k] == comm->rank)) { delete h; FD_FAIL("fd_halo_create: bad neighbour rank"); }
+        // a rank may be its own neighbour (a periodic direction that is not partitioned): ncclSend/ncclRecv to self inside the group
+        if (comm && (peers[k] < 0 || peers[k] >= comm->nranks)) { delete h; FD_FAIL("fd_halo_create: bad neighbour rank"); }
         h->peer.push_back(peers[k]);
         h->nsend.push_back(nsend[k]); h->nrecv.push_back(nrecv[k]);
         h->soff.push_back((int64_t)sall.size()); h->roff.push_back((int64_t)rall.size());

@@ -3,6 +3,9 @@
 // `wrap_<kernel>` of pyop2/global_kernel.py:426-456.
 #include "fd_common.h"
 #include <cstring>
+#include <cstdlib>
+#include <dlfcn.h>
+#include <unistd.h>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -116,6 +119,57 @@ int fd_kernel_load(const char *path, const char *symbol, fd_kernel_t *out) {
     if (r != hipSuccess) { (void)hipModuleUnload(k->mod); delete k; fd::set_error(std::string("symbol ") + symbol + " not in " + path + ": " + hipGetErrorString(r)); return (int)r; }
     *out = k;
     return 0;
+}
+
+// JIT from wrapper source inside the library (for hosts that do not want to shell out themselves): the counterpart of
+// compilation.load() -> make_so() (pyop2/compilation.py:424-455, 527-611): hash (source, flags, compiler) -> cached code
+// object under cache_dir, else hipcc --genco into a temporary name + rename (concurrent ranks race benignly), then load.
+static uint64_t fnv1a(const std::string &s, uint64_t h = 1469598103934665603ull) {
+    for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+    return h;
+}
+
+int fd_kernel_create(const char *wrapper_src, const char *symbol, const char *cache_dir, const char *extra_flags, fd_kernel_t *out) {
+    if (!wrapper_src || !symbol || !cache_dir || !out) FD_FAIL("fd_kernel_create: bad arguments");
+    const char *hipcc = getenv("FDHIP_HIPCC");
+    if (!hipcc) hipcc = "/opt/rocm/bin/hipcc";
+    const char *arch = getenv("FDHIP_ARCH");
+    if (!arch) arch = "gfx950";
+    // the device headers (fd_wrapper.h, fd_tensor.h) live next to this library: <dir of libfdhip.so>/csrc
+    Dl_info info;
+    std::string inc;
+    if (dladdr((const void *)&fd_kernel_create, &info) && info.dli_fname) {
+        std::string lib(info.dli_fname);
+        size_t p = lib.find_last_of('/');
+        inc = (p == std::string::npos ? std::string(".") : lib.substr(0, p)) + "/csrc";
+    }
+    const std::string flags = std::string("--offload-arch=") + arch + " -O3 -std=c++17 --genco -munsafe-fp-atomics -fno-math-errno "
+        "-fno-signed-zeros -fno-honor-nans -fno-honor-infinities -fassociative-math -fno-trapping-math -ffp-contract=fast " +
+        (extra_flags ? extra_flags : "");
+    char key[32];
+    snprintf(key, sizeof key, "%016llx", (unsigned long long)fnv1a(flags, fnv1a(wrapper_src)));
+    const std::string base = std::string(cache_dir) + "/" + symbol + "_c" + key;
+    const std::string obj = base + ".hsaco";
+    if (access(obj.c_str(), R_OK) != 0) {
+        const std::string tmp = base + "." + std::to_string((long)getpid()) + ".tmp";
+        const std::string src = tmp + ".hip";
+        FILE *f = fopen(src.c_str(), "w");
+        if (!f) FD_FAIL("fd_kernel_create: cannot write " + src);
+        fputs(wrapper_src, f);
+        fclose(f);
+        const std::string log = tmp + ".log";
+        const std::string cmd = std::string(hipcc) + " " + flags + " -I'" + inc + "' -o '" + tmp + ".hsaco' '" + src + "' > '" + log + "' 2>&1";
+        const int rc = system(cmd.c_str());
+        if (rc != 0) {
+            std::string msg = "fd_kernel_create: hipcc failed (" + cmd + ")";
+            if (FILE *lf = fopen(log.c_str(), "r")) { char buf[2048]; size_t n = fread(buf, 1, sizeof buf - 1, lf); buf[n] = 0; fclose(lf); msg += std::string("\n") + buf; }
+            unlink(src.c_str()); unlink(log.c_str()); unlink((tmp + ".hsaco").c_str());
+            FD_FAIL(msg);
+        }
+        unlink(src.c_str()); unlink(log.c_str());
+        if (rename((tmp + ".hsaco").c_str(), obj.c_str()) != 0) FD_FAIL("fd_kernel_create: cannot move the code object into the cache");
+    }
+    return fd_kernel_load(obj.c_str(), symbol, out);
 }
 
 int fd_kernel_builtin(const char *symbol, fd_kernel_t *out) {

@@ -93,6 +93,11 @@ int fd_graph_free(fd_graph_t g);
  *     lds_bytes       dynamic LDS for the staged (plan) wrappers, else 0
  */
 int fd_kernel_load(const char *hsaco_path, const char *symbol, fd_kernel_t *out);
+/* JIT inside the library: compile wrapper source (what codegen emits) with hipcc --genco into cache_dir, keyed by
+ * (source, flags) like compilation.load()/make_so() (pyop2/compilation.py:424-455, 527-611), then load `symbol`.
+ * FDHIP_HIPCC / FDHIP_ARCH select the compiler / target; extra_flags may be NULL. */
+int fd_kernel_create(const char *wrapper_src, const char *symbol, const char *cache_dir, const char *extra_flags,
+                     fd_kernel_t *out);
 int fd_kernel_builtin(const char *symbol, fd_kernel_t *out);
 int fd_kernel_free(fd_kernel_t k);
 int fd_kernel_launch(fd_kernel_t k, int32_t start, int32_t end,
