@@ -233,6 +233,12 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
     if sm_:
         mode = mode[:sm_.start()]
     ocr = mode.startswith("ocr")
+    # "stagedo": staged over a backend-derived entity ORDER (fd_locality_order): slot -> entity through fd_order_, plans on
+    # the map rows gathered in that order (Parloop._staged_geometry, un-hinted maps)
+    ordered = mode.startswith("stagedo")
+    # "ocrp": owner-computes-rows over row POSITIONS of a backend-derived row order (fd_first_touch_order): a block's rows
+    # are a set of CSR rows -- accumulated contiguously in LDS, flushed row by row
+    ocrp = mode.startswith("ocrp")
     staged = mode.startswith("staged") or ocr
     ktype, kbytes = ("unsigned short", 2) if mode.endswith("_k16") else ("unsigned char", 1)
     extruded = gk._extruded
@@ -324,6 +330,8 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
     P("const int *__restrict__ bstart_", ("bstart",))
     if ocr:
         P("const int *__restrict__ inst_ent_", ("ocr_inst_ent",))
+    if ordered:
+        P("const int *__restrict__ fd_order_", ("order",))
     staged_maps = []
     lds_items = []
     mat_staged = {}
@@ -359,6 +367,11 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             P(f"long long oc{k}_maxnnz", ("ocr_maxnnz", k))
             P(f"long long oc{k}_maxnown", ("ocr_maxnown", k))
             P(f"long long oc{k}_flags", ("ocr_flags", k))
+            if ocrp:
+                P(f"const int *__restrict__ oc{k}_pinv", ("ocr_pinv", k))
+                P(f"const int *__restrict__ oc{k}_prowptr", ("ocr_prowptr", k))
+                P(f"const int *__restrict__ oc{k}_plist", ("ocr_plist", k))
+                P(f"long long oc{k}_npos", ("ocr_npos", k))
         elif mat_staged[k]:
             P(f"const int *__restrict__ mp{k}_off", ("matplan_off", k))
             P(f"const int *__restrict__ mp{k}_gpos", ("matplan_gpos", k))
@@ -512,16 +525,22 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 lds_tail_const.append(f"unsigned int *srow{k} = (unsigned int *)(fd_lds + fd_off); fd_off += (((size_t)p{rm}_maxnd*4) + 15) & ~(size_t)15;")
                 if cm != rm:
                     lds_tail_const.append(f"unsigned char *smc{k} = fd_lds + fd_off; fd_off += ((size_t)p{cm}_maxnd + 15) & ~(size_t)15;")
+                rp_ = f"oc{k}_prowptr" if ocrp else f"oc{k}_rowptr"       # row starts in the order the blocks are cut in
                 mat_stage_pre.extend([f"const int n0_{k} = oc{k}_rblk[b], nown{k} = oc{k}_rblk[b+1] - n0_{k};",
-                                      f"const int r0_{k} = oc{k}_rowptr[n0_{k}], nnzb{k} = oc{k}_rowptr[n0_{k} + nown{k}] - r0_{k};"])
+                                      f"const int r0_{k} = {rp_}[n0_{k}], nnzb{k} = {rp_}[n0_{k} + nown{k}] - r0_{k};"])
                 stage.append((rm, f"for (int q = tid; q < nnzb{k}; q += nthr) sm{k}[q] = 0;"))
                 colmask = bool(lg)
                 rowmask = f" && rlg{k}[g] >= 0" if lg else ""
                 colbit = (f" | ((clg{k}[g] < 0) ? 0x80000000u : 0u)" if (colmask and cm == rm) else "")
-                rowpos = f"(unsigned)(oc{k}_rowptr[g] - r0_{k} + 1)"
-                node_actions.setdefault(rm, []).append(
-                    ([f"const int g = G_U; const unsigned w{k}_U = ((g >= n0_{k} && g < n0_{k} + nown{k}{rowmask}) ? {rowpos} : 0u){colbit};".replace("const int g = G_U; ", "").replace("(g ", "(G_U ").replace(" g ", " G_U ").replace(" g,", " G_U,").replace("[g]", "[G_U]")],
-                     [f"srow{k}[I_U] = w{k}_U;"]))
+                if ocrp:
+                    # the node's row position decides ownership and the accumulator offset
+                    loads = [f"const int p{k}_U = (G_U < (int)oc{k}_npos) ? oc{k}_pinv[G_U] : -1;",
+                             f"const unsigned w{k}_U = ((p{k}_U >= n0_{k} && p{k}_U < n0_{k} + nown{k}{rowmask.replace('[g]', '[G_U]')}) ? "
+                             f"(unsigned)(oc{k}_prowptr[p{k}_U] - r0_{k} + 1) : 0u){colbit.replace('[g]', '[G_U]')};"]
+                else:
+                    rowpos = f"(unsigned)(oc{k}_rowptr[g] - r0_{k} + 1)"
+                    loads = [f"const int g = G_U; const unsigned w{k}_U = ((g >= n0_{k} && g < n0_{k} + nown{k}{rowmask}) ? {rowpos} : 0u){colbit};".replace("const int g = G_U; ", "").replace("(g ", "(G_U ").replace(" g ", " G_U ").replace(" g,", " G_U,").replace("[g]", "[G_U]")]
+                node_actions.setdefault(rm, []).append((loads, [f"srow{k}[I_U] = w{k}_U;"]))
                 if colmask and cm != rm:
                     node_actions.setdefault(cm, []).append(([f"const bool m{k}_U = clg{k}[G_U] < 0;"], [f"smc{k}[I_U] = m{k}_U;"]))
                 lines = [f"unsigned int rw{k}[{ar}];", f"for (int i = 0; i < {ar}; ++i) rw{k}[i] = srow{k}[lm{rm}[i]];"]
@@ -538,6 +557,14 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                     val = f"(({'cmk%d[j]' % k if cm != rm else '(rw%d[j] >> 31)' % k}) ? 0.0 : {val})"
                 lines += [f"    atomicAdd(&sm{k}[base + kk{k}[i*{ac} + j]], {val});", "  }", "}"]
                 unpack.append("\n    ".join(lines))
+                if ocrp:
+                    # complete rows again, but a SET of CSR rows: 16 lanes per row, four rows per wavefront step
+                    flush.append((rm, f"for (int fr = tid >> 4; fr < nown{k}; fr += nthr >> 4) {{ const int fp = n0_{k} + fr; "
+                                      f"const int fs = oc{k}_prowptr[fp] - r0_{k}, fl = oc{k}_prowptr[fp+1] - oc{k}_prowptr[fp]; "
+                                      f"const size_t fd_ = (size_t)oc{k}_rowptr[oc{k}_plist[fp]]; "
+                                      f"if (oc{k}_flags & 1) {{ for (int q = tid & 15; q < fl; q += 16) arg{k}[fd_ + q] = sm{k}[fs + q]; }} "
+                                      f"else {{ for (int q = tid & 15; q < fl; q += 16) arg{k}[fd_ + q] += sm{k}[fs + q]; }} }}"))
+                    continue
                 # complete rows, contiguous in the CSR value array: plain coalesced stores
                 flush.append((rm, f"if (oc{k}_flags & 1) {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)r0_{k} + q] = sm{k}[q]; }} "
                                   f"else {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)r0_{k} + q] += sm{k}[q]; }}"))
@@ -655,7 +682,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         # run, so the lanes of one trip work on entities that are far apart (no shared nodes -> no serialised LDS
         # atomics) while their index rows stay coalesced.  OCR instance lists are stored in that order already.
         lane_threads = threads if configuration["lane_strided"] else 0
-        virt = (extruded or gk._subset) and not ocr
+        virt = (extruded or gk._subset or ordered) and not ocr
         if virt:
             if extruded:
                 lo, hi = {ALL: ("layers[0]", "layers[1]-1"), ON_BOTTOM: ("layers[0]", "layers[0]+1"),
@@ -686,8 +713,10 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             if extruded:
                 out.append(f"    const int fd_col = ({v}) / fd_nlit; const int layer = fd_llo + (({v}) - fd_col*fd_nlit);")
                 out.append("    const int e = " + ("subset_indices[fd_col];" if gk._subset else "fd_col;"))
-            else:
+            elif gk._subset:
                 out.append(f"    const int e = subset_indices[{v}];")
+            else:
+                out.append(f"    const int e = fd_order_[{v}];")
             return out
         if pf and virt:
             src += decode("e_cur")

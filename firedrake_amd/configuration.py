@@ -33,6 +33,7 @@ configuration = {
     "prefetch": _env("FDHIP_PREFETCH", 1, int),          # software-pipeline the packed index rows
     "tensor_wrappers": _env("FDHIP_TENSOR_WRAPPERS", 1, int),   # MFMA matrix / sum-factorised action for TensorProductLocalKernels
     "mat_ocr": _env("FDHIP_MAT_OCR", 1, int),             # owner-computes-rows matrix assembly (no global atomics)
+    "ocr_nnz_per_block_ordered": _env("FDHIP_OCR_NNZ_ORDERED", 3840, int),   # the same under a backend-derived row order
     "ocr_nnz_per_block": _env("FDHIP_OCR_NNZ", 2048, int),  # row-block size (CSR entries) when the producer gives no hint
     "ocr_block_threads": _env("FDHIP_OCR_BLOCK_THREADS", 0, int),  # 0 = auto: 512 for small element matrices, else block_threads
     # order of the instances inside an owner-computes-rows block: "lane" (fd_plan_set_lane_order), "stencil"
@@ -43,6 +44,10 @@ configuration = {
     # per CU is recompiled with the matching __launch_bounds__ and kept if that costs at most this many bytes of scratch
     # per lane (-1 = off).  DG-advection interior-facet loop: 172 -> 128 VGPRs, 12 B scratch, 0.50 -> 0.32 ms
     "auto_occupancy_scratch": _env("FDHIP_AUTO_OCCUPANCY_SCRATCH", 16, int),
+    # maps without producer hints: derive the entity order of staged loops from the loop's position field (Morton order of
+    # the entity centroids) instead of cutting the caller's order into uniform blocks
+    "locality_order": _env("FDHIP_LOCALITY_ORDER", 1, int),
+    "locality_min_entities": _env("FDHIP_LOCALITY_MIN", 8192, int),
     "use_preferred_blocks": _env("FDHIP_PREFERRED_BLOCKS", 1, int),   # plan blocks = the producer's traversal tiles
     "lds_limit": _env("FDHIP_LDS_LIMIT", 64 * 1024, int),
     "mat_scatter": _env("FDHIP_MAT_SCATTER", "table"),  # table | search (direct scatter flavours)

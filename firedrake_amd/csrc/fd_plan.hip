@@ -624,9 +624,20 @@ struct fd_ocrplan_s {
     int32_t *inst_off_host = nullptr;
     int32_t *inst_ent = nullptr;     // ninst (device): entity of every instance
     int32_t *rblk = nullptr;         // nblocks+1 (device): first row node of every block
+    // optional backend-derived row order (fd_first_touch_order): the blocks are then ranges of row POSITIONS;
+    // pinv[node] = position for node < npos (borrowed, caller keeps it alive), prowptr = CSR row starts in position order
+    const int32_t *pinv = nullptr;
+    const int32_t *prowptr = nullptr;
+    int32_t npos = 0;
 };
 
 namespace {
+
+// row position of a node under an optional row order (identity when pinv == nullptr; -1 = not an owned row)
+__device__ __forceinline__ int32_t row_position(const int32_t *__restrict__ pinv, int32_t npos, int32_t node) {
+    if (!pinv) return node;
+    return (node >= 0 && node < npos) ? pinv[node] : -1;
+}
 
 __device__ inline int32_t block_of_node(const int32_t *__restrict__ rblk, int32_t nblocks, int32_t node) {
     // largest b with rblk[b] <= node ; node outside [rblk[0], rblk[nblocks]) -> -1
@@ -640,11 +651,12 @@ __device__ inline int32_t block_of_node(const int32_t *__restrict__ rblk, int32_
 }
 
 __global__ void ocr_emit(const int32_t *__restrict__ rmap, int ar, int32_t start, int32_t end,
-                         const int32_t *__restrict__ rblk, int32_t nblocks, uint64_t *__restrict__ keys) {
+                         const int32_t *__restrict__ rblk, int32_t nblocks, uint64_t *__restrict__ keys,
+                         const int32_t *__restrict__ pinv, int32_t npos) {
     const int64_t total = ((int64_t)end - start) * ar;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         int64_t e = start + t / ar;
-        int32_t r = rmap[e * ar + (t % ar)];
+        int32_t r = row_position(pinv, npos, rmap[e * ar + (t % ar)]);
         int32_t b = r >= 0 ? block_of_node(rblk, nblocks, r) : -1;
         keys[t] = b >= 0 ? (((uint64_t)b << 32) | (uint64_t)(uint32_t)e) : ~0ull;
     }
@@ -693,7 +705,7 @@ __global__ void ocr_lane_order(const int32_t *__restrict__ off, const int32_t *_
 // conflict window add into distinct banks, and no two of them share an accumulator in one instruction.
 __global__ void ocr_stencil_keys(const int32_t *__restrict__ rmap, int ar, const int32_t *__restrict__ inst_off,
                                  const int32_t *__restrict__ inst_ent, const int32_t *__restrict__ rblk, int32_t nblocks,
-                                 int64_t ninst, uint64_t *__restrict__ keys) {
+                                 int64_t ninst, uint64_t *__restrict__ keys, const int32_t *__restrict__ pinv, int32_t npos) {
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < ninst; t += (int64_t)gridDim.x * blockDim.x) {
         int lo = 0, hi = nblocks - 1;                      // block of instance t: largest b with inst_off[b] <= t
         while (lo < hi) {
@@ -703,10 +715,10 @@ __global__ void ocr_stencil_keys(const int32_t *__restrict__ rmap, int ar, const
         const int32_t n0 = rblk[lo], n1 = rblk[lo + 1];
         const int32_t *row = rmap + (int64_t)inst_ent[t] * ar;
         int32_t first = -1;
-        for (int i = 0; i < ar; ++i) { int32_t r = row[i]; if (first < 0 && r >= n0 && r < n1) first = r; }
+        for (int i = 0; i < ar; ++i) { int32_t r = row_position(pinv, npos, row[i]); if (first < 0 && r >= n0 && r < n1) first = r; }
         uint32_t h = 2166136261u;
         for (int i = 0; i < ar; ++i) {
-            int32_t r = row[i];
+            int32_t r = row_position(pinv, npos, row[i]);
             uint32_t own = (r >= n0 && r < n1) ? 1u : 0u;
             uint32_t d = (uint32_t)(r - first);
             h = (h ^ own) * 16777619u;
@@ -736,7 +748,7 @@ __global__ __launch_bounds__(64) void ocr_pack_k(const int32_t *__restrict__ ins
                                                  const uint16_t *__restrict__ lmap, const unsigned char *__restrict__ kidx8,
                                                  const unsigned short *__restrict__ kidx16, int ar, int ac,
                                                  const int32_t *__restrict__ rblk, const int32_t *__restrict__ rowptr,
-                                                 int maxn, int window, int cand) {
+                                                 int maxn, int window, int cand, const int32_t *__restrict__ pinv, int32_t npos) {
     extern __shared__ unsigned char pk_lds[];
     const int b = blockIdx.x, lane = threadIdx.x;
     const int o = inst_off[b], n = inst_off[b + 1] - o;
@@ -758,7 +770,7 @@ __global__ __launch_bounds__(64) void ocr_pack_k(const int32_t *__restrict__ ins
             const unsigned short l = lmap[t * ar + i];
             gaddr[q * ar + i] = l;
             sig[q * ns + i] = (unsigned char)(l & 31);
-            const int32_t g = imap_r[t * ar + i];
+            const int32_t g = row_position(pinv, npos, imap_r[t * ar + i]);     // (rowptr = row starts in the same order)
             const bool own = g >= n0 && g < n1;
             const int base = own ? rowptr[g] - r0 : 0;
             for (int j = 0; j < ac; ++j) {
@@ -856,12 +868,30 @@ __global__ void row_offsets_k(const int32_t *__restrict__ rowptr, const int32_t 
 
 extern "C" {
 
+static int ocrplan_build(const int32_t *rmap_dev, int ar, int32_t start, int32_t end, const int32_t *row_block_starts_host,
+                         int32_t nblocks, int interleave, const int32_t *pinv_dev, int32_t npos, const int32_t *prowptr_dev,
+                         fd_stream_t s_, fd_ocrplan_t *out);
+
 int fd_ocrplan_create(const int32_t *rmap_dev, int ar, int32_t start, int32_t end,
                       const int32_t *row_block_starts_host, int32_t nblocks, int interleave, fd_stream_t s_, fd_ocrplan_t *out) {
+    return ocrplan_build(rmap_dev, ar, start, end, row_block_starts_host, nblocks, interleave, nullptr, 0, nullptr, s_, out);
+}
+
+int fd_ocrplan_create_ordered(const int32_t *rmap_dev, int ar, int32_t start, int32_t end,
+                              const int32_t *pos_block_starts_host, int32_t nblocks, int interleave,
+                              const int32_t *pinv_dev, int32_t npos, const int32_t *prowptr_dev, fd_stream_t s_, fd_ocrplan_t *out) {
+    if (!pinv_dev || !prowptr_dev || npos < 0) FD_FAIL("fd_ocrplan_create_ordered: bad arguments");
+    return ocrplan_build(rmap_dev, ar, start, end, pos_block_starts_host, nblocks, interleave, pinv_dev, npos, prowptr_dev, s_, out);
+}
+
+static int ocrplan_build(const int32_t *rmap_dev, int ar, int32_t start, int32_t end, const int32_t *row_block_starts_host,
+                         int32_t nblocks, int interleave, const int32_t *pinv_dev, int32_t npos, const int32_t *prowptr_dev,
+                         fd_stream_t s_, fd_ocrplan_t *out) {
     hipStream_t s = fd::st(s_);
     if (ar <= 0 || nblocks < 0 || end < start || !row_block_starts_host) FD_FAIL("fd_ocrplan_create: bad arguments");
     auto *p = new fd_ocrplan_s;
     p->nblocks = nblocks;
+    p->pinv = pinv_dev; p->npos = npos; p->prowptr = prowptr_dev;
     FD_HIP(hipMalloc(&p->rblk, ((size_t)nblocks + 1) * 4));
     FD_HIP(hipMemcpyAsync(p->rblk, row_block_starts_host, ((size_t)nblocks + 1) * 4, hipMemcpyHostToDevice, s));
     FD_HIP(hipMalloc(&p->inst_off, ((size_t)nblocks + 1) * 4));
@@ -875,7 +905,7 @@ int fd_ocrplan_create(const int32_t *rmap_dev, int ar, int32_t start, int32_t en
     uint64_t *k1 = nullptr, *k2 = nullptr;
     FD_HIP(hipMalloc(&k1, (size_t)nkeys * 8));
     FD_HIP(hipMalloc(&k2, (size_t)nkeys * 8));
-    hipLaunchKernelGGL(ocr_emit, dim3(mp_grid(nkeys)), dim3(256), 0, s, rmap_dev, ar, start, end, p->rblk, nblocks, k1);
+    hipLaunchKernelGGL(ocr_emit, dim3(mp_grid(nkeys)), dim3(256), 0, s, rmap_dev, ar, start, end, p->rblk, nblocks, k1, p->pinv, p->npos);
     FD_CHECK_LAUNCH();
     size_t tb = 0;
     hipcub::DoubleBuffer<uint64_t> db(k1, k2);
@@ -911,7 +941,7 @@ int fd_ocrplan_create(const int32_t *rmap_dev, int ar, int32_t start, int32_t en
         FD_HIP(hipMalloc(&kb, (size_t)nu * 8));
         FD_HIP(hipMalloc(&vb, (size_t)nu * 4));
         hipLaunchKernelGGL(ocr_stencil_keys, dim3(mp_grid(nu)), dim3(256), 0, s, rmap_dev, ar, p->inst_off, p->inst_ent, p->rblk,
-                           nblocks, nu, ka);
+                           nblocks, nu, ka, p->pinv, p->npos);
         FD_CHECK_LAUNCH();
         hipcub::DoubleBuffer<uint64_t> dk(ka, kb);
         hipcub::DoubleBuffer<int32_t> dv(p->inst_ent, vb);
@@ -974,7 +1004,8 @@ int fd_ocrplan_pack(fd_ocrplan_t p, const int32_t *imap_r_dev, const uint16_t *l
     FD_HIP(hipMalloc(&out, (size_t)p->ninst * 4));
     hipLaunchKernelGGL(ocr_pack_k, dim3(p->nblocks), dim3(64), lds, s, p->inst_off, p->inst_ent, out, imap_r_dev, lmap_dev,
                        kbytes == 1 ? (const unsigned char *)kidx_dev : nullptr,
-                       kbytes == 2 ? (const unsigned short *)kidx_dev : nullptr, ar, ac, p->rblk, node_rowptr_dev, maxn, window, cand);
+                       kbytes == 2 ? (const unsigned short *)kidx_dev : nullptr, ar, ac, p->rblk,
+                       p->prowptr ? p->prowptr : node_rowptr_dev, maxn, window, cand, p->pinv, p->npos);
     FD_CHECK_LAUNCH();
     FD_HIP(hipStreamSynchronize(s));
     FD_HIP(hipFree(p->inst_ent));

@@ -1333,6 +1333,16 @@ class MixedSet:
         return "MixedSet(%r)" % (self._sets,)
 
 
+class _ShapeOnly:
+    """Stands in for the host values of a Map that exists on the device only."""
+
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+    def __len__(self):
+        return self.shape[0]
+
+
 # ---- maps --------------------------------------------------------------------------------
 class Map:
     """pyop2/types/map.py:17-110: int array (iterset.total_size, arity) of IntType;
@@ -1429,6 +1439,21 @@ class Map:
                 self._derived = {}
             vals = np.ascontiguousarray(build(), dtype=IntType)
             d = Map(Set(len(vals), "virtual_" + self.iterset.name), self.toset, self.arity, vals, self.name + "_derived")
+            self._derived[key] = d
+        return d
+
+    def derived_dev(self, key, nrows, build_dev):
+        """Like ``derived`` for rows gathered ON THE DEVICE (``build_dev()`` returns a DeviceBuffer of nrows x arity int32):
+        the derived Map has no host values."""
+        if not hasattr(self, "_derived"):
+            self._derived = {}
+        d = self._derived.get(key)
+        if d is None:
+            d = Map.__new__(Map)
+            d._iterset, d._toset, d._arity = Set(int(nrows), "ordered_" + self.iterset.name), self.toset, self.arity
+            d._values = _ShapeOnly((int(nrows), self.arity))
+            d.name, d._offset, d._offset_quotient, d._plans = self.name + "_ordered", None, None, {}
+            d._dev = build_dev()
             self._derived[key] = d
         return d
 
@@ -1814,7 +1839,7 @@ class Sparsity:
     def matplan(self, rowplan, colplan, maps):
         """Cached block-local sparsity for the staged matrix scatter (fd_matplan_create)."""
         self._build()
-        key = ("mp", id(maps[0]._base()), id(maps[1]._base()), rowplan.start, rowplan.end, rowplan.epb)
+        key = ("mp", id(maps[0]._base()), id(maps[1]._base()), id(rowplan), id(colplan))
         mp = self._elem_tables.get(key)
         if mp is None:
             mp = MatPlan(self, rowplan, colplan)
@@ -1844,12 +1869,19 @@ class OcrPlan:
     """Owner-computes-rows plan (fd_ocrplan_*): row-node blocks, their entity instances, the per-instance
     copies of the staged maps with their node plans, and the per-entity row-offset table."""
 
-    def __init__(self, sparsity, rmap: Map, cmap: Map, staged_maps, start, end, row_blocks, lane_threads=0):
+    def __init__(self, sparsity, rmap: Map, cmap: Map, staged_maps, start, end, row_blocks, lane_threads=0, row_order=None):
+        """``row_order``: optional ``RowOrder`` (backend-derived row positions); ``row_blocks`` are then ranges of row
+        positions and the wrapper flushes row by row ("ocrp")."""
         self.row_blocks = rb = np.ascontiguousarray(row_blocks, dtype=np.int32)
         nb = len(rb) - 1
         h = ctypes.c_void_p()
-        _lib.call("fd_ocrplan_create", rmap._base()._dev_values(), rmap.arity, int(start), int(end), rb.ctypes.data, nb,
-                  self._order_code(lane_threads), None, ctypes.byref(h))
+        self.row_order = row_order
+        if row_order is not None:
+            _lib.call("fd_ocrplan_create_ordered", rmap._base()._dev_values(), rmap.arity, int(start), int(end), rb.ctypes.data, nb,
+                      self._order_code(lane_threads), row_order.pinv.ptr, row_order.npos, row_order.prowptr.ptr, None, ctypes.byref(h))
+        else:
+            _lib.call("fd_ocrplan_create", rmap._base()._dev_values(), rmap.arity, int(start), int(end), rb.ctypes.data, nb,
+                      self._order_code(lane_threads), None, ctypes.byref(h))
         self.h = h.value
         ni, mi = ctypes.c_int64(), ctypes.c_int32()
         _lib.call("fd_ocrplan_info", self.h, ctypes.byref(ni), ctypes.byref(mi))
@@ -1861,8 +1893,11 @@ class OcrPlan:
         # geometry of the row blocks
         rp = sparsity._node_rowptr.download(np.int32, (sparsity.dsets[0].set.total_size + 1,))
         self.rows_end = int(rb[-1])
-        self.vals_end = int(rp[rb[-1]])
-        self.max_nnz = int(np.diff(rp[rb]).max()) if nb else 0
+        self.vals_end = int(rp[rb[-1]])              # (positions cover exactly the rows [0, npos): same end either way)
+        if row_order is not None:
+            self.max_nnz = int(np.diff(row_order.prowptr_host[rb]).max()) if nb else 0
+        else:
+            self.max_nnz = int(np.diff(rp[rb]).max()) if nb else 0
         self.max_nown = int(np.diff(rb).max()) if nb else 0
         maxlen = int(np.diff(rp).max()) if len(rp) > 1 else 0
         self.kbytes = 1 if maxlen <= 254 else 2
@@ -1922,6 +1957,22 @@ class OcrPlan:
                 _lib.load().fd_ocrplan_free(self.h)
         except Exception:
             pass
+
+
+class RowOrder:
+    """A backend-derived order of the rows [0, npos) of a sparsity: ``plist[p]`` = p-th row, ``pinv[row]`` = its position,
+    ``prowptr`` = CSR row starts in that order (device + host copy).  Built from an entity order by the first-touch rule
+    (fd_first_touch_order)."""
+
+    def __init__(self, rmap: Map, order: "DeviceBuffer", n, npos, node_rowptr_host):
+        self.npos = int(npos)
+        self.pinv, self.plist = DeviceBuffer(max(npos, 1) * 4), DeviceBuffer(max(npos, 1) * 4)
+        _lib.call("fd_first_touch_order", rmap._base()._dev_values(), rmap.arity, order.ptr, int(n), self.npos, self.pinv.ptr,
+                  self.plist.ptr, None)
+        plist = self.plist.download(np.int32, (self.npos,))
+        rowlen = np.diff(np.asarray(node_rowptr_host, dtype=np.int64))[:self.npos]
+        self.prowptr_host = np.concatenate([[0], np.cumsum(rowlen[plist])]).astype(np.int32)
+        self.prowptr = DeviceBuffer.from_numpy(self.prowptr_host)
 
 
 class MatPlan:

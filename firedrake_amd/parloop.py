@@ -238,6 +238,11 @@ def _map_kernel_arg(m):
     return mk[1]
 
 
+class PlanDoesNotFit(_lib.FDHipError):
+    """A staged / owner-computes-rows plan exceeds the LDS or the plan builder's per-block capacity: the Parloop demotes
+    the loop to the next wrapper shape (ocr -> staged -> direct) before anything is launched."""
+
+
 # ---- Parloop ------------------------------------------------------------------------------------
 class Parloop:
     """pyop2/parloop.py:167-540."""
@@ -296,7 +301,7 @@ class Parloop:
         if self._prepared is not None:
             return self._prepared
         _lib.require_gpu()
-        cw = self.global_kernel.compile()
+        cw = self.global_kernel.compile(getattr(self, "_forced_mode", None))
         src = cw.src
         maps = []
         for pa in self.arguments:
@@ -340,8 +345,10 @@ class Parloop:
                         lds += (nd[rm] + 15) // 16 * 16 + (nd[cm] + 15) // 16 * 16
             return lds
 
+        pstart, pend, order = start, end, None
+
         def build(epb, blocks):
-            plans = {mi: maps[mi].plan(start, end, epb, blocks, lane_threads=src.lane_threads) for mi in src.staged_maps}
+            plans = {mi: maps[mi].plan(pstart, pend, epb, blocks, lane_threads=src.lane_threads) for mi in src.staged_maps}
             mplans = {}
             for item in src.lds_items:
                 if item[0] != "dat":
@@ -367,7 +374,16 @@ class Parloop:
             if lds > limit:
                 plans = None
         if plans is None:
-            # 2. uniform blocks, halved until the staged rows fit the LDS budget
+            # 2. no usable producer hints: derive a locality order of the entities from the loop's position field (Morton
+            #    key of the entity centroids, fd_locality_order) and plan over the map rows gathered in that order
+            order = self._locality_order(start, end)
+            if order is not None:
+                n = end - start
+                okey = ("order", start, end, order.ptr)
+                maps = [m.derived_dev(okey, n, (lambda m=m: self._gather_rows(m, order, n))) if mi in src.staged_maps else m
+                        for mi, m in enumerate(maps)]
+                pstart, pend = 0, n
+            # 3. uniform blocks (of the derived order, or of the caller's), halved until the staged rows fit the LDS budget
             epb = configuration["ents_per_block"]
             while epb * maxar > 32768:
                 epb //= 2
@@ -377,13 +393,14 @@ class Parloop:
                     break
                 epb = max(32, epb // 2)
         if lds > 160 * 1024:
-            raise _lib.FDHipError("staged wrapper does not fit LDS even at 32 entities per block")
+            raise PlanDoesNotFit("staged wrapper does not fit LDS even at 32 entities per block")
         kb = 2 if any(mp.kbytes == 2 for mp in mplans.values()) else 1
-        variant = mode_variant("staged", kb, [plans[mi].max_nd for mi in src.staged_maps])
-        # geometry-specific variant (16-bit matrix offsets, compile-time LDS strides); same parameter layout
+        variant = mode_variant("stagedo" if order is not None else "staged", kb, [plans[mi].max_nd for mi in src.staged_maps])
+        # geometry-specific variant (16-bit matrix offsets, compile-time LDS strides, entity order); same parameter layout
+        # up to the order table
         cw = prep["cw"] if variant == src.mode else self.global_kernel.compile(variant)
-        assert cw.src.layout == src.layout
-        geo = {"epb": epb, "plans": plans, "mplans": mplans, "lds": lds, "cw": cw}
+        assert [d for d in cw.src.layout if d[0] != "order"] == [d for d in src.layout if d[0] != "order"]
+        geo = {"epb": epb, "plans": plans, "mplans": mplans, "lds": lds, "cw": cw, "order": order, "range": (pstart, pend)}
         if configuration["debug"]:
             import sys
             for mi, pl in plans.items():
@@ -437,12 +454,49 @@ class Parloop:
             return rows
         return m.derived(key, build)
 
+    # -- backend-derived locality (un-hinted maps)
+    def _position_arg(self):
+        """The loop's position field: the first fp64 Dat of 2 or 3 components READ through a map -- the coordinate argument
+        of a TSFC kernel (tsfc/kernel_interface/firedrake_loopy.py:432-522).  None if the loop has none."""
+        for pa, acc in zip(self.arguments, self.accesses):
+            if (isinstance(pa, DatParloopArg) and pa.map_ is not None and acc == READ and not isinstance(pa.map_, PermutedMap)
+                    and np.dtype(pa.data.dtype) == np.float64 and pa.data.cdim in (2, 3) and getattr(pa.data, "index", None) is None):
+                return pa
+        return None
+
+    def _locality_order(self, start, end):
+        """Device buffer with the entities of [start, end) in locality order, or None when the loop keeps the caller's
+        order (switched off, tiny range, virtual iteration space, no position field)."""
+        n = end - start
+        if not configuration["locality_order"] or n < configuration["locality_min_entities"] or self._virtual() is not None:
+            return None
+        pa = self._position_arg()
+        if pa is None:
+            return None
+        cache = pa.map_._base().__dict__.setdefault("_locality_orders", {})
+        key = (start, end, id(pa.data), pa.data.dat_version)
+        buf = cache.get(key)
+        if buf is None:
+            buf = DeviceBuffer(n * 4)
+            _lib.call("fd_locality_order", pa.map_._base()._dev_values(), pa.map_.arity, int(start), int(end),
+                      pa.data._dev_ptr(False), pa.data.cdim, buf.ptr, None)
+            cache.clear()                      # one order per map and range: a moved mesh replaces it
+            cache[key] = buf
+        return buf
+
+    @staticmethod
+    def _gather_rows(m, order, n):
+        buf = DeviceBuffer(max(n, 1) * m.arity * 4)
+        _lib.call("fd_gather_rows", m._dev_values(), m.arity, order.ptr, n, buf.ptr, None)
+        return buf
+
     # -- argument list in the kernel's parameter order
     def _arglist(self, start, end):
         prep = self._prepare()
         src = prep["cw"].src
         geo = self._staged_geometry(start, end) if src.mode.startswith("staged") else None
-        src = prep["cw"].src
+        if geo is not None:
+            src = geo["cw"].src
         out = []
         for desc in src.layout:
             kind = desc[0]
@@ -462,6 +516,8 @@ class Parloop:
                 out.append(prep["maps"][desc[1]]._dev_values())
             elif kind == "bstart":
                 out.append(next(iter(geo["plans"].values())).bstart if geo else 0)
+            elif kind == "order":
+                out.append(geo["order"].ptr)
             elif kind == "plan_blkoff":
                 out.append(geo["plans"][desc[1]].blkoff)
             elif kind == "plan_list":
@@ -562,8 +618,36 @@ class Parloop:
     def __call__(self):
         self.compute()
 
+    def _parts(self):
+        parts = [self.iterset.core_part, self.iterset.owned_part]
+        if self.compute_ghost:
+            parts.append((self.iterset.size, self.iterset.total_size - self.iterset.size))
+        return [p for p in parts if p[1] > 0]
+
+    def _ensure_geometry(self):
+        """Build every plan this loop needs BEFORE anything is launched; a plan that does not fit demotes the loop to the
+        next wrapper shape (owner-computes-rows -> staged matrix plans -> direct) instead of failing half way."""
+        for _ in range(3):
+            mode = self._prepare()["cw"].src.mode
+            try:
+                if mode.startswith("ocr"):
+                    self._ocr_geometry()
+                elif mode.startswith("staged"):
+                    v = self._virtual()
+                    for off, size in self._parts():
+                        k = v[0] if v else 1
+                        self._staged_geometry(off * k, (off + size) * k)
+                return
+            except PlanDoesNotFit as exc:
+                nxt = "staged" if mode.startswith("ocr") else "direct"
+                if configuration["debug"]:
+                    import sys
+                    print(f"[fdhip] {self.global_kernel.name}: {exc}; falling back to the {nxt} wrapper", file=sys.stderr)
+                self._forced_mode, self._prepared = nxt, None
+
     def compute(self):
         self._zero_global_temporaries()
+        self._ensure_geometry()
         if self._prepare()["cw"].src.mode.startswith("ocr"):
             # owner-computes-rows: one launch over the row blocks; entities are visited through the instance
             # lists, so there is no core/owned split to overlap the halo exchange with
@@ -603,7 +687,8 @@ class Parloop:
         threads = src.block_threads
         if src.mode.startswith("staged"):
             nb = next(iter(geo["plans"].values())).nblocks
-            cw.launch(start, end, args, block_threads=threads, ents_per_block=geo["epb"], nblocks=nb, lds_bytes=geo["lds"])
+            ps, pe = geo["range"]               # plan coordinates: [start, end), or [0, n) of the derived entity order
+            cw.launch(ps, pe, args, block_threads=threads, ents_per_block=geo["epb"], nblocks=nb, lds_bytes=geo["lds"])
         elif src.mode.startswith("tp_"):
             # one (action) or two (matrix: the halves of the padded 128-row element matrix) workgroups per cell
             ncell = size * (self.iterset.layers - 1)
@@ -638,13 +723,23 @@ class Parloop:
         rp = sp._node_rowptr.download(np.int32, (rmap.toset.total_size + 1,))
         limit = src.ocr_lds_limit or configuration["lds_limit"]
         hint = getattr(rmap._base(), "preferred_node_blocks", None)
+        row_order = None
         if hint is not None and configuration["use_preferred_blocks"]:
             rb = np.asarray(hint, dtype=np.int64)
             rb = np.unique(np.concatenate([rb[rb < nrows], [0, nrows]]))
         else:
+            # no producer hints: a backend-derived row order (first touch under the locality order of the entities) when
+            # the loop has a position field, else the caller's row order; blocks = greedy ranges of ~cap CSR entries
+            order = self._locality_order(start, end)
+            prp = rp[:nrows + 1]
             cap = configuration["ocr_nnz_per_block"]
-            targets = np.arange(0, int(rp[nrows]) + cap, cap)
-            rb = np.unique(np.concatenate([np.searchsorted(rp[:nrows + 1], targets, side="left"), [0, nrows]]))
+            if order is not None:
+                from .op2types import RowOrder
+                row_order = RowOrder(rmap, order, end - start, nrows, rp)
+                prp = row_order.prowptr_host
+                cap = configuration["ocr_nnz_per_block_ordered"]
+            targets = np.arange(0, int(prp[nrows]) + cap, cap)
+            rb = np.unique(np.concatenate([np.searchsorted(prp[:nrows + 1], targets, side="left"), [0, nrows]]))
             rb = rb[rb <= nrows]
         staged = {mi: maps[mi] for mi in src.staged_maps}
         maxar = max(m.arity for m in staged.values())
@@ -666,7 +761,7 @@ class Parloop:
         for attempt in range(14):
             # split row blocks until the LDS rows and the instance lists fit
             try:
-                op = OcrPlan(sp, rmap, cmap, staged, start, end, rb, lane_threads=src.lane_threads)
+                op = OcrPlan(sp, rmap, cmap, staged, start, end, rb, lane_threads=src.lane_threads, row_order=row_order)
             except _lib.FDHipError as exc:
                 if "map entries" not in str(exc):
                     raise
@@ -677,7 +772,7 @@ class Parloop:
             if lds <= limit and op.max_inst * maxar <= 32768:
                 break
             d = np.diff(rb)
-            nn = np.diff(rp[rb])
+            nn = np.diff((row_order.prowptr_host if row_order is not None else rp)[rb])
             ni = np.diff(op.inst_off_host)
             big = (nn > 0.7 * nn.max()) | (ni * maxar > 32768) if lds > limit else (ni * maxar > 32768)
             big &= d > 1
@@ -685,11 +780,11 @@ class Parloop:
                 break
             rb = np.unique(np.concatenate([rb, (rb[:-1] + d // 2)[big]]))
         if lds > 160 * 1024 or op.max_inst * maxar > 32768:
-            raise _lib.FDHipError("owner-computes-rows plan does not fit (LDS or instance list); set FDHIP_MAT_OCR=0")
+            raise PlanDoesNotFit("owner-computes-rows plan does not fit (LDS or instance list)")
         nds = [op.plans[mi].max_nd for mi in src.staged_maps]
-        variant = mode_variant("ocr", op.kbytes, nds)
+        variant = mode_variant("ocrp" if row_order is not None else "ocr", op.kbytes, nds)
         geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz,
-               "cw": prep["cw"] if variant == src.mode else self.global_kernel.compile(variant)}
+               "cw": prep["cw"] if variant == src.mode else self.global_kernel.compile(variant), "row_order": row_order}
         prep["parts"][gkey] = geo
         if configuration["debug"]:
             import sys
@@ -753,6 +848,14 @@ class Parloop:
                 out.append(op.max_nown)
             elif kind == "ocr_flags":
                 out.append(self._ocr_flag)
+            elif kind == "ocr_pinv":
+                out.append(geo["row_order"].pinv.ptr)
+            elif kind == "ocr_prowptr":
+                out.append(geo["row_order"].prowptr.ptr)
+            elif kind == "ocr_plist":
+                out.append(geo["row_order"].plist.ptr)
+            elif kind == "ocr_npos":
+                out.append(geo["row_order"].npos)
             elif kind in ("mat_row_lgmap", "mat_col_lgmap"):
                 pa = self.arguments[desc[1]]
                 out.append(self._lgmap(pa.lgmaps[0 if kind == "mat_row_lgmap" else 1]))

@@ -183,6 +183,13 @@ int fd_ocrplan_create(const int32_t *rmap_dev, int rarity, int32_t start, int32_
  * reorders the instances of every block so that the 16 consecutive slots of an LDS conflict window touch distinct
  * LDS banks in the wrapper's gathers and ds_add_f64 scatter wherever the block allows it.  The caller rebuilds the
  * per-instance tables for the new order afterwards.  No-op for element matrices with ar + ar*ac > 128. */
+/* Row blocks as ranges of row POSITIONS under a backend-derived row order (fd_first_touch_order): pinv[node] = position
+ * for node < npos, prowptr[p] = CSR row start of the p-th row in that order (npos + 1 entries).  The CSR itself keeps
+ * the caller's numbering; a block's rows are then a set of CSR rows, flushed row by row.  The tables are borrowed. */
+int fd_ocrplan_create_ordered(const int32_t *rmap_dev, int rarity, int32_t start, int32_t end,
+                              const int32_t *pos_block_starts_host, int32_t nblocks, int interleave,
+                              const int32_t *pinv_dev, int32_t npos, const int32_t *prowptr_dev,
+                              fd_stream_t s, fd_ocrplan_t *out);
 int fd_ocrplan_pack(fd_ocrplan_t p, const int32_t *imap_rows_dev, const uint16_t *lmap_dev, int ar,
                     const void *kidx_dev, int kbytes, int ac, const int32_t *node_rowptr_dev, fd_stream_t s);
 int fd_ocrplan_info(fd_ocrplan_t p, int64_t *ninst, int32_t *max_inst_per_block);
@@ -269,6 +276,20 @@ int fd_halo_pack(const double *dat_dev, int cdim, const int32_t *idx_dev, int32_
                  double *buf_dev, fd_stream_t s);
 int fd_halo_unpack(double *dat_dev, int cdim, const int32_t *idx_dev, int32_t n,
                    const double *buf_dev, int op, fd_stream_t s);
+
+/* ------------------------------------------------- backend-derived locality orders
+ * The reference's locality comes from DMPlex (RCM cell order + first-touch DoF numbering, firedrake/mesh.py:1214-1228,
+ * firedrake/cython/dmcommon.pyx:2599-2729); execution order is free under the wrapper's semantics
+ * (pyop2/codegen/builder.py:734-741), so when the producer gives no block hints the backend derives its own:
+ *   fd_locality_order     entity ids of [start, end) sorted by the Morton key of the centroid of their nodes in the
+ *                         position field `pos` (pdim doubles per node): the coordinate argument of a TSFC kernel
+ *   fd_first_touch_order  the first-touch rule applied to that entity order: plist[p] = p-th node of [0, nnodes),
+ *                         pinv[node] = p; nodes no entity touches come last
+ * Private re-encodings: Dats, Maps and the CSR keep the caller's numbering. */
+int fd_locality_order(const int32_t *map_dev, int arity, int32_t start, int32_t end, const double *pos_dev, int pdim,
+                      int32_t *order_dev, fd_stream_t s);
+int fd_first_touch_order(const int32_t *map_dev, int arity, const int32_t *order_dev, int64_t n, int32_t nnodes,
+                         int32_t *pinv_dev, int32_t *plist_dev, fd_stream_t s);
 
 /* ------------------------------------------------- halo exchange + Global reductions over RCCL
  * firedrake/halo.py:87-172 (PetscSF bcast owner->ghost with MPI.REPLACE, reduce ghost->owner with SUM/MIN/MAX behind

@@ -129,13 +129,31 @@ def plan_ref_blocks(mapv, blocks):
     return (np.array(blk, np.int32), np.concatenate(lst).astype(np.int32) if lst else np.zeros(0, np.int32), lm)
 
 
-def ocr_plan_ref(rmapv, cmapv, nent, row_blocks, rowptr, colidx):
+def first_touch_ref(mapv, order, nnodes):
+    """numpy restatement of fd_first_touch_order: rows [0, nnodes) sorted by (rank of the first entity of ``order`` touching
+    them, node id); untouched rows last.  Returns (plist, pinv)."""
+    rank = np.full(nnodes, np.iinfo(np.uint32).max, dtype=np.uint64)
+    rows = np.asarray(mapv)[np.asarray(order)]
+    for r in range(len(rows) - 1, -1, -1):
+        for g in rows[r]:
+            if 0 <= g < nnodes:
+                rank[g] = r
+    plist = np.lexsort((np.arange(nnodes), rank)).astype(np.int32)
+    pinv = np.empty(nnodes, dtype=np.int32)
+    pinv[plist] = np.arange(nnodes, dtype=np.int32)
+    return plist, pinv
+
+
+def ocr_plan_ref(rmapv, cmapv, nent, row_blocks, rowptr, colidx, pinv=None):
     """numpy restatement of the owner-computes-rows plan (include/fdhip.h: fd_ocrplan_create in natural order +
     fd_csr_elem_row_offsets): per block of row nodes the entities that touch one of its rows (*instances*, in entity
     order), and per instance the position of every (i, j) entry inside its CSR row."""
     inst_off, inst_ent = [0], []
+    rows_of = rmapv[:nent]
+    if pinv is not None:                 # blocks are ranges of row POSITIONS (fd_ocrplan_create_ordered)
+        rows_of = np.where((rows_of >= 0) & (rows_of < len(pinv)), np.asarray(pinv)[np.clip(rows_of, 0, len(pinv) - 1)], -1)
     for b in range(len(row_blocks) - 1):
-        hit = ((rmapv[:nent] >= row_blocks[b]) & (rmapv[:nent] < row_blocks[b + 1])).any(axis=1)
+        hit = ((rows_of >= row_blocks[b]) & (rows_of < row_blocks[b + 1])).any(axis=1)
         inst_ent.append(np.nonzero(hit)[0])
         inst_off.append(inst_off[-1] + int(hit.sum()))
     inst_ent = np.concatenate(inst_ent).astype(np.int32) if inst_ent else np.zeros(0, np.int32)
@@ -181,3 +199,25 @@ def structured_tri_mesh(nx, ny, seed=0, perturb=0.0):
             b, c, d = a + 1, a + nx + 1, a + nx + 2
             cells += [(a, b, c), (b, d, c)]
     return coords, np.asarray(cells, dtype=np.int32)
+
+
+def locality_order_ref(mapv, start, end, pos):
+    """numpy restatement of fd_locality_order: entity ids of [start, end) sorted (stably) by the Morton key of the centroid
+    of their nodes, 16 bits per axis over the bounding box of the referenced positions.  Returns (order, keys)."""
+    rows = np.asarray(mapv[start:end])
+    pdim = pos.shape[1]
+    P = pos[rows]                                         # (n, arity, pdim)
+    lo, hi = P.reshape(-1, pdim).min(axis=0), P.reshape(-1, pdim).max(axis=0)
+    acc = np.zeros((len(rows), pdim))
+    for i in range(rows.shape[1]):                        # same summation order as the device loop
+        acc += P[:, i, :]
+    c = acc / rows.shape[1]
+    w = hi - lo
+    u = np.where(w > 0, (c - lo) / np.where(w > 0, w, 1.0), 0.0)
+    q = (np.clip(u, 0.0, 1.0) * 65535.0).astype(np.uint64)
+    keys = np.zeros(len(rows), dtype=np.uint64)
+    for k in range(pdim):
+        for i in range(16):
+            keys |= ((q[:, k] >> np.uint64(i)) & np.uint64(1)) << np.uint64(i * pdim + k)
+    order = (start + np.argsort(keys, kind="stable")).astype(np.int32)
+    return order, keys

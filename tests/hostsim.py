@@ -59,7 +59,7 @@ def _compile_mt(source, name):
     return ctypes.CDLL(so)
 
 
-def run_staged(pl, epb=48):
+def run_staged(pl, epb=48, order=None):
     """Execute Parloop ``pl`` (Dat / Global arguments only) with the STAGED wrapper on the host: one OS thread per
     lane, workgroups one after the other, real barriers and atomics (tests/hostsim/mt/fd_wrapper.h).  The
     block-localisation plans come from the numpy restatement in helpers.py (itself checked against the device's
@@ -78,11 +78,14 @@ def run_staged(pl, epb=48):
             if all(m._base() is not q for q in base_maps):
                 base_maps.append(m._base())
                 maps.append(pl._plan_map(m._base(), staged=True))
-    base = generate_wrapper(gk, "staged")
+    base = generate_wrapper(gk, "stagedo" if order is not None else "staged")
     T = base.block_threads
     plans = {}
     for mi in base.staged_maps:
-        blk, lst, lm = plan_ref(np.asarray(maps[mi].values_with_halo), start, end, epb)
+        rows = np.asarray(maps[mi].values_with_halo)
+        if order is not None:                                   # "stagedo": plans over the rows gathered in the entity order
+            rows = rows[np.asarray(order)]
+        blk, lst, lm = plan_ref(rows, start, end, epb)
         if base.lane_threads:                                   # lane order: slot k*T + t <- k-th entity of lane t's run
             for b0 in range(start, end, epb):
                 b1 = min(end, b0 + epb)
@@ -90,7 +93,7 @@ def run_staged(pl, epb=48):
         plans[mi] = (blk, lst, np.ascontiguousarray(lm), int(np.diff(blk).max()) if len(blk) > 1 else 0)
     bstart = np.array(list(range(start, end, epb)) + [end], dtype=np.int32)
     nblocks = len(bstart) - 1
-    src = generate_wrapper(gk, mode_variant("staged", 1, [plans[mi][3] for mi in base.staged_maps]))
+    src = generate_wrapper(gk, mode_variant("stagedo" if order is not None else "staged", 1, [plans[mi][3] for mi in base.staged_maps]))
     text = src.source.replace("extern __shared__ __align__(16) unsigned char fd_lds[];", "unsigned char *fd_lds = fd_sim::lds;")
     # driver: the kernel's own parameter list, run as nblocks workgroups of T lanes
     sig = re.search(r'extern "C" __global__[^\n]*void %s\((.*)\)\n' % src.symbol, text).group(1)
@@ -123,6 +126,8 @@ def run_staged(pl, epb=48):
             cargs.append(ptr(np.asarray(base_maps[desc[1]].values_with_halo, dtype=np.int32)))
         elif kind == "bstart":
             cargs.append(ptr(bstart))
+        elif kind == "order":
+            cargs.append(ptr(np.asarray(order, dtype=np.int32)))
         elif kind == "plan_blkoff":
             cargs.append(ptr(plans[desc[1]][0]))
         elif kind == "plan_list":
@@ -137,13 +142,13 @@ def run_staged(pl, epb=48):
     return [outs.get(k) for k in range(len(pl.arguments))]
 
 
-def run_ocr(pl, rows_per_block=24, zero_pending=True):
+def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None):
     """Execute a matrix-assembly Parloop ``pl`` with the OWNER-COMPUTES-ROWS wrapper on the host (one OS thread per
     lane, tests/hostsim/mt/fd_wrapper.h).  The plan tables come from the numpy restatements in helpers.py; the CSR
     pattern from the oracle.  Returns the OracleCSR holding the assembled values."""
     import re
     from firedrake_amd.codegen import mode_variant, ocr_eligible
-    from helpers import ocr_plan_ref, plan_ref_blocks
+    from helpers import first_touch_ref, ocr_plan_ref, plan_ref_blocks
     gk = pl.global_kernel
     assert ocr_eligible(gk)
     (k, mpa), = [(k, pa) for k, pa in enumerate(pl.arguments) if isinstance(pa, MatParloopArg)]
@@ -159,14 +164,19 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True):
     nent = pl.iterset.size
     nrows = rmap.toset.size
     rb = np.array(list(range(0, nrows, rows_per_block)) + [nrows], dtype=np.int32)
+    plist = pinv = prowptr = None
+    if order is not None:
+        # "ocrp": row blocks are ranges of row positions under the first-touch order of the entity order
+        plist, pinv = first_touch_ref(np.asarray(rmap.values_with_halo), order, nrows)
+        prowptr = np.concatenate([[0], np.cumsum(np.diff(csr.rowptr)[:nrows][plist])]).astype(np.int32)
     inst_off, inst_ent, kidx = ocr_plan_ref(np.asarray(rmap.values_with_halo), np.asarray(cmap.values_with_halo), nent, rb,
-                                            csr.rowptr, csr.colidx)
+                                            csr.rowptr, csr.colidx, pinv=pinv)
     plans = {}
     for mi in base.staged_maps:
         blk, lst, lm = plan_ref_blocks(np.asarray(maps[mi].values_with_halo)[inst_ent], inst_off)
         plans[mi] = (blk, lst, np.ascontiguousarray(lm), int(np.diff(blk).max()) if len(blk) > 1 else 0)
-    max_nnz = int(np.diff(csr.rowptr[rb]).max())
-    src = generate_wrapper(gk, mode_variant("ocr", 1, [plans[mi][3] for mi in base.staged_maps]))
+    max_nnz = int(np.diff((prowptr if order is not None else csr.rowptr)[rb]).max())
+    src = generate_wrapper(gk, mode_variant("ocrp" if order is not None else "ocr", 1, [plans[mi][3] for mi in base.staged_maps]))
     text = src.source.replace("extern __shared__ __align__(16) unsigned char fd_lds[];", "unsigned char *fd_lds = fd_sim::lds;")
     sig = re.search(r'extern "C" __global__[^\n]*void %s\((.*)\)\n' % src.symbol, text).group(1)
     names = [p.split()[-1].lstrip("*") for p in sig.split(", ")]
@@ -219,6 +229,14 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True):
             cargs.append(ctypes.c_longlong(int(np.diff(rb).max())))
         elif kind == "ocr_flags":
             cargs.append(ctypes.c_longlong(1 if zero_pending else 0))
+        elif kind == "ocr_pinv":
+            cargs.append(ptr(pinv))
+        elif kind == "ocr_prowptr":
+            cargs.append(ptr(prowptr))
+        elif kind == "ocr_plist":
+            cargs.append(ptr(plist))
+        elif kind == "ocr_npos":
+            cargs.append(ctypes.c_longlong(nrows))
         elif kind in ("mat_row_lgmap", "mat_col_lgmap"):
             cargs.append(ptr(np.asarray(mpa.lgmaps[0 if kind == "mat_row_lgmap" else 1], dtype=np.int32)))
         else:

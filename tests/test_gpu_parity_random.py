@@ -217,3 +217,77 @@ def test_plan_with_empty_and_single_entity_blocks():
         u, inv = (np.unique(rows.reshape(-1), return_inverse=True) if len(rows) else (np.zeros(0, np.int32), np.zeros(0, np.int64)))
         assert np.array_equal(lst[blk[b]:blk[b + 1]], u)
         assert np.array_equal(lm[blocks[b]:blocks[b + 1]].reshape(-1), inv)
+
+
+@pytest.mark.parametrize("numbering", ["lexicographic", "random"])
+def test_locality_order_matches_numpy_and_drives_the_staged_wrapper(numbering, monkeypatch):
+    """fd_locality_order against helpers.locality_order_ref (identical Morton keys, a permutation of the range), the
+    first-touch row order derived from it, and the un-hinted residual taking the "stagedo" wrapper end to end."""
+    from firedrake_amd import _lib, forms, mesh as fmesh
+    from firedrake_amd.device import DeviceBuffer
+    from helpers import locality_order_ref
+    monkeypatch.setitem(configuration, "locality_min_entities", 64)
+    m = fmesh.UnitCubeMesh(9, degrees=(1,), perturb=0.1, numbering=numbering)
+    V = m.space(1)
+    cm = V.cell_node_map
+    n = m.cell_set.size
+    pos = np.array(m.coordinates.data_ro)
+    order_ref, keys = locality_order_ref(cm.values_with_halo, 0, n, pos)
+    buf = DeviceBuffer(n * 4)
+    _lib.call("fd_locality_order", cm._dev_values(), 4, 0, n, m.coordinates._dev_ptr(False), 3, buf.ptr, None)
+    order = buf.download(np.int32, (n,))
+    assert sorted(order.tolist()) == list(range(n))
+    assert np.array_equal(keys[order], keys[order_ref])            # same key sequence (ties may be ordered alike or not)
+    # first-touch rows under that order
+    nn = V.node_set.size
+    pinv, plist = DeviceBuffer(nn * 4), DeviceBuffer(nn * 4)
+    _lib.call("fd_first_touch_order", cm._dev_values(), 4, buf.ptr, n, nn, pinv.ptr, plist.ptr, None)
+    pl, pi = plist.download(np.int32, (nn,)), pinv.download(np.int32, (nn,))
+    assert np.array_equal(pi[pl], np.arange(nn)) and sorted(pl.tolist()) == list(range(nn))
+    first = np.full(nn, np.iinfo(np.int64).max)
+    flat = cm.values_with_halo[order].reshape(-1)
+    first[flat[::-1]] = np.arange(len(flat) - 1, -1, -1) // 4
+    assert (np.diff(first[pl]) >= 0).all()                          # rows sorted by the rank of the first cell touching them
+    prob = forms.PoissonProblem(m, 1, bcs=True)
+    r = prob.assemble_residual()
+    assert prob.res_loop._staged_geometry(0, n)["cw"].src.mode.startswith("stagedo")
+    from test_gpu_forms import _oracle_problem
+    ro, Ao = _oracle_problem(prob, True)
+    assert np.abs(r.data_ro - ro).max() <= 1e-12 * max(1.0, np.abs(ro).max())
+    A = prob.assemble_jacobian().toscipy()
+    geo = prob.jacobian()[1]._ocr_geometry()
+    assert geo["cw"].src.mode.startswith("ocrp") and geo["row_order"] is not None
+    assert np.abs(A.data - Ao.data).max() <= 1e-12 * np.abs(Ao.data).max()
+    mat, loop = prob.jacobian()
+    A2 = prob.assemble_jacobian().toscipy()                         # plans reused, pending zero fused
+    assert np.abs(A2.data - Ao.data).max() <= 1e-12 * np.abs(Ao.data).max()
+
+
+def test_ordered_ocr_plan_matches_numpy_restatement(monkeypatch):
+    """fd_ocrplan_create_ordered (row blocks = ranges of row positions) against helpers.ocr_plan_ref(pinv=...) in natural
+    instance order, with the row order built by fd_first_touch_order from a numpy-made entity order."""
+    from firedrake_amd import _lib, mesh as fmesh
+    from firedrake_amd.device import DeviceBuffer
+    from firedrake_amd.op2types import OcrPlan, RowOrder
+    from helpers import first_touch_ref, locality_order_ref, ocr_plan_ref
+    monkeypatch.setitem(configuration, "ocr_order", "natural")
+    monkeypatch.setitem(configuration, "ocr_pack", 0)
+    m = fmesh.UnitCubeMesh(6, degrees=(1,), perturb=0.1, numbering="random")
+    V = m.space(1)
+    cm = V.cell_node_map
+    sp = op2.Sparsity((V.node_set ** 1, V.node_set ** 1), [(cm, cm, None)])
+    sp._build()
+    n, nrows = m.cell_set.size, V.node_set.size
+    order, _ = locality_order_ref(cm.values_with_halo, 0, n, np.array(m.coordinates.data_ro))
+    obuf = DeviceBuffer.from_numpy(order)
+    ro = RowOrder(cm, obuf, n, nrows, sp.rowptr)
+    plist, pinv = first_touch_ref(cm.values_with_halo, order, nrows)
+    assert np.array_equal(ro.plist.download(np.int32, (nrows,)), plist) and np.array_equal(ro.pinv.download(np.int32, (nrows,)), pinv)
+    rb = np.unique(np.concatenate([np.arange(0, nrows, 31), [nrows]])).astype(np.int32)
+    op = OcrPlan(sp, cm, cm, {0: cm}, 0, n, rb, lane_threads=0, row_order=ro)
+    inst_off, inst_ent, kidx = ocr_plan_ref(cm.values_with_halo, cm.values_with_halo, n, rb, sp.rowptr, sp.colidx, pinv=pinv)
+    assert np.array_equal(op.inst_off_host, inst_off)
+    ent = np.empty(op.ninst, dtype=np.int32)
+    _lib.call("fd_memcpy_d2h", ent.ctypes.data, op.inst_ent, ent.nbytes, None)
+    assert np.array_equal(ent, inst_ent)
+    assert np.array_equal(op.kidx.download(np.uint8, kidx.shape), kidx)

@@ -70,3 +70,34 @@ def test_held_host_views_stay_coherent():
     del v, gv, ro
     op2.par_loop(inc, s, d(op2.RW))
     assert not d._rw_handed                      # last view gone: back to lazy mirroring
+
+
+def test_plan_that_does_not_fit_demotes_the_wrapper(monkeypatch):
+    """A plan that exceeds LDS / builder capacity must not fail the loop: ocr -> staged (matrix plans) -> direct, decided
+    before anything is launched (Parloop._ensure_geometry); results unchanged."""
+    from firedrake_amd import forms, mesh as fmesh
+    from firedrake_amd.parloop import Parloop, PlanDoesNotFit
+    from test_gpu_forms import _oracle_problem
+    m = fmesh.UnitCubeMesh(8, degrees=(1,), tile=(4, 4, 2), perturb=0.1)
+    prob = forms.PoissonProblem(m, 1, bcs=True)
+    ro, Ao = _oracle_problem(prob, True)
+    real_ocr, real_staged = Parloop._ocr_geometry, Parloop._staged_geometry
+
+    def no_ocr(self, *a, **k):
+        raise PlanDoesNotFit("test: owner-computes-rows plan does not fit")
+    monkeypatch.setattr(Parloop, "_ocr_geometry", no_ocr)
+    A = prob.assemble_jacobian().toscipy()
+    assert prob.jacobian()[1]._prepared["cw"].src.mode.startswith("staged")
+    assert np.abs(A.data - Ao.data).max() <= 1e-12 * np.abs(Ao.data).max()
+
+    def no_staged(self, *a, **k):
+        raise PlanDoesNotFit("test: staged plan does not fit")
+    monkeypatch.setattr(Parloop, "_staged_geometry", no_staged)
+    prob2 = forms.PoissonProblem(m, 1, bcs=True)
+    r = prob2.assemble_residual()
+    A2 = prob2.assemble_jacobian().toscipy()
+    assert prob2.res_loop._prepared["cw"].src.mode == "direct" and prob2.jacobian()[1]._prepared["cw"].src.mode == "direct"
+    assert np.abs(r.data_ro - ro).max() <= 1e-12 * max(1.0, np.abs(ro).max())
+    assert np.abs(A2.data - Ao.data).max() <= 1e-12 * np.abs(Ao.data).max()
+    monkeypatch.setattr(Parloop, "_ocr_geometry", real_ocr)
+    monkeypatch.setattr(Parloop, "_staged_geometry", real_staged)

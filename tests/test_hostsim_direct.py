@@ -519,3 +519,55 @@ def test_staged_wrapper_on_extruded_columns_and_subsets_on_host(region):
         got = run_staged(pl, epb=4)[0]
         ref = oracle_run(k2, ss, o2(op2.INC, mp), d(op2.READ, mp), ws(op2.READ))[0]
         assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("numbering", ["lexicographic", "random"])
+def test_staged_wrapper_over_a_locality_order_on_host(numbering):
+    """"stagedo": the staged wrapper over a backend-derived entity order (Morton order of the cell centroids,
+    helpers.locality_order_ref = numpy restatement of fd_locality_order) -- plans on the gathered map rows, slot -> entity
+    through fd_order_ for the direct argument.  The benchmark's P1 residual plus a direct READ Dat, against the oracle."""
+    from firedrake_amd import forms, mesh as fmesh
+    from helpers import locality_order_ref
+    from hostsim import run_staged
+    mesh = fmesh.UnitCubeMesh(5, degrees=(1,), perturb=0.1, numbering=numbering)
+    V = mesh.space(1)
+    cm = V.cell_node_map
+    order, keys = locality_order_ref(cm.values_with_halo, 0, mesh.cell_set.size, np.array(mesh.coordinates.data_ro))
+    assert sorted(order.tolist()) == list(range(mesh.cell_set.size)) and (np.diff(keys[order]) >= 0).all()
+    prob = forms.PoissonProblem(mesh, 1, bcs=False)
+    got = run_staged(prob.res_loop, epb=40, order=order)[0]
+    ref = oracle_run(prob.kres, mesh.cell_set, prob.r(op2.INC, cm), mesh.coordinates(op2.READ, cm), prob.u(op2.READ, cm),
+                     prob.f(op2.READ, cm))[0]
+    assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    w = op2.Dat(mesh.cell_set, np.random.default_rng(2).standard_normal(mesh.cell_set.total_size))
+    out = op2.Dat(V.node_set)
+    k = op2.Kernel("static void kw(double *o, const double *x, const double *w) { for (int i = 0; i < 4; ++i) o[i] += w[0]*x[3*i+1]; }", "kw")
+    pl = op2.LegacyParloop(k, mesh.cell_set, out(op2.INC, cm), mesh.coordinates(op2.READ, cm), w(op2.READ))
+    got = run_staged(pl, epb=33, order=order)[0]
+    ref = oracle_run(k, mesh.cell_set, out(op2.INC, cm), mesh.coordinates(op2.READ, cm), w(op2.READ))[0]
+    assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("bcs", [False, True])
+@pytest.mark.parametrize("numbering", ["lexicographic", "random"])
+def test_owner_computes_rows_over_a_row_order_on_host(bcs, numbering):
+    """"ocrp": owner-computes-rows whose row blocks are ranges of row POSITIONS under a backend-derived row order (first
+    touch under the Morton order of the cells): ownership and accumulator offsets through pinv / prowptr, complete rows
+    flushed row by row.  P1 and P2 Jacobians against the oracle, including accumulation into existing values."""
+    from firedrake_amd import forms, mesh as fmesh
+    from helpers import locality_order_ref
+    from hostsim import run_ocr
+    mesh = fmesh.UnitCubeMesh(4, degrees=(1, 2), perturb=0.1, numbering=numbering)
+    pos = np.array(mesh.coordinates.data_ro)
+    order, _ = locality_order_ref(mesh.coord_space.cell_node_map.values_with_halo, 0, mesh.cell_set.size, pos)
+    for degree, rpb in ((1, 19), (2, 45)):
+        prob = forms.PoissonProblem(mesh, degree, bcs=bcs)
+        mat, pl = prob.jacobian()
+        mpa = pl.arguments[0]
+        got = run_ocr(pl, rows_per_block=rpb, order=order)
+        args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
+        ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
+        assert np.abs(got.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
+        if degree == 1:
+            got2 = run_ocr(pl, rows_per_block=rpb, zero_pending=False, order=order)
+            assert np.abs(got2.values - (ref.values + 1.0)).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
