@@ -718,10 +718,11 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             else:
                 out.append(f"    const int e = fd_order_[{v}];")
             return out
-        if pf and virt:
-            src += decode("e_cur")
-        elif pf:
-            src.append("    const int e = e_cur;")
+        if pf:
+            if virt:
+                src += decode("e_cur")
+            else:
+                src.append("    const int e = e_cur;")
             src.append("    const int itn = (it + fd_step < fd_last) ? it + fd_step : it;")
             src.append(f"    e_nx = {ent_of('itn')};")
             for cur, nxt, name, n, ld in idx_loads:

@@ -491,7 +491,7 @@ def test_staged_wrapper_on_extruded_columns_and_subsets_on_host(region):
     layer argument; and a plain Subset of a non-extruded set.  Against the oracle."""
     from hostsim import run_staged
     rng = np.random.default_rng(21)
-    nbase, L, nv = 7, 6, 9
+    nbase, L, nv = 70, 6, 30                    # 350 cells per sweep: more than the 256 lanes of a workgroup
     base = op2.Set(nbase)
     ext = op2.ExtrudedSet(base, layers=L)
     nodes = op2.Set(nv * L)
@@ -502,21 +502,21 @@ def test_staged_wrapper_on_extruded_columns_and_subsets_on_host(region):
     out = op2.Dat(nodes)
     k = op2.Kernel("static void ks(double *o, const double *x, const double *w, int layer) "
                    "{ for (int i = 0; i < 6; ++i) o[i] += (1 + layer) * w[0] * (x[2*i] + 0.5*x[2*i+1]); }", "ks")
-    for iterset in (ext, op2.Subset(ext, [5, 1, 3, 6])):
+    for iterset, epb in ((ext, 330), (op2.Subset(ext, [5, 1, 3, 6] + list(range(10, 70))), 300), (ext, 5)):
         args = (out(op2.INC, cm), x(op2.READ, cm), w(op2.READ))
         pl = op2.LegacyParloop(k, iterset, *args, iteration_region=region, pass_layer_arg=True)
-        got = run_staged(pl, epb=5)[0]
+        got = run_staged(pl, epb=epb)[0]
         ref = oracle_run(k, iterset, *args, iteration_region=region, pass_layer_arg=True)[0]
         assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
     if region is None:
-        it, ind = op2.Set(50), op2.Set(19)
-        mp = op2.Map(it, ind, 3, rng.integers(0, 19, size=(50, 3)))
-        d, o2 = op2.Dat(ind, rng.standard_normal(19)), op2.Dat(ind)
-        ws = op2.Dat(it, rng.standard_normal(50))
-        ss = op2.Subset(it, [40, 3, 17, 18, 19, 2, 44, 45, 9])
+        it, ind = op2.Set(900), op2.Set(190)
+        mp = op2.Map(it, ind, 3, rng.integers(0, 190, size=(900, 3)))
+        d, o2 = op2.Dat(ind, rng.standard_normal(190)), op2.Dat(ind)
+        ws = op2.Dat(it, rng.standard_normal(900))
+        ss = op2.Subset(it, rng.choice(900, 700, replace=False))
         k2 = op2.Kernel("static void k2(double *o, const double *d, const double *w) { for (int i = 0; i < 3; ++i) o[i] += w[0]*d[(i+1)%3]; }", "k2")
         pl = op2.LegacyParloop(k2, ss, o2(op2.INC, mp), d(op2.READ, mp), ws(op2.READ))
-        got = run_staged(pl, epb=4)[0]
+        got = run_staged(pl, epb=640)[0]
         ref = oracle_run(k2, ss, o2(op2.INC, mp), d(op2.READ, mp), ws(op2.READ))[0]
         assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
 
@@ -535,7 +535,7 @@ def test_staged_wrapper_over_a_locality_order_on_host(numbering):
     order, keys = locality_order_ref(cm.values_with_halo, 0, mesh.cell_set.size, np.array(mesh.coordinates.data_ro))
     assert sorted(order.tolist()) == list(range(mesh.cell_set.size)) and (np.diff(keys[order]) >= 0).all()
     prob = forms.PoissonProblem(mesh, 1, bcs=False)
-    got = run_staged(prob.res_loop, epb=40, order=order)[0]
+    got = run_staged(prob.res_loop, epb=600, order=order)[0]         # > 256 lanes: lanes iterate (index-row prefetch path)
     ref = oracle_run(prob.kres, mesh.cell_set, prob.r(op2.INC, cm), mesh.coordinates(op2.READ, cm), prob.u(op2.READ, cm),
                      prob.f(op2.READ, cm))[0]
     assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
@@ -543,7 +543,7 @@ def test_staged_wrapper_over_a_locality_order_on_host(numbering):
     out = op2.Dat(V.node_set)
     k = op2.Kernel("static void kw(double *o, const double *x, const double *w) { for (int i = 0; i < 4; ++i) o[i] += w[0]*x[3*i+1]; }", "kw")
     pl = op2.LegacyParloop(k, mesh.cell_set, out(op2.INC, cm), mesh.coordinates(op2.READ, cm), w(op2.READ))
-    got = run_staged(pl, epb=33, order=order)[0]
+    got = run_staged(pl, epb=700, order=order)[0]
     ref = oracle_run(k, mesh.cell_set, out(op2.INC, cm), mesh.coordinates(op2.READ, cm), w(op2.READ))[0]
     assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
 
