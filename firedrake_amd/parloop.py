@@ -374,24 +374,38 @@ class Parloop:
             if lds > limit:
                 plans = None
         if plans is None:
-            # 2. no usable producer hints: derive a locality order of the entities from the loop's position field (Morton
-            #    key of the entity centroids, fd_locality_order) and plan over the map rows gathered in that order
-            order = self._locality_order(start, end)
-            if order is not None:
+            def uniform():
+                # uniform blocks, halved until the staged rows fit the LDS budget
+                epb = configuration["ents_per_block"]
+                while epb * maxar > 32768:
+                    epb //= 2
+                while True:
+                    plans, mplans, lds = build(epb, None)
+                    if lds <= limit or epb <= 32:
+                        return epb, plans, mplans, lds
+                    epb = max(32, epb // 2)
+
+            # 2. no usable producer hints: uniform blocks of the caller's order ...
+            epb, plans, mplans, lds = uniform()
+            # 3. ... or of a backend-derived locality order of the entities (Morton key of the entity centroids in the loop's
+            #    position field, fd_locality_order; plans over the map rows gathered in that order) -- kept when its blocks
+            #    touch clearly fewer distinct nodes (the staged traffic) than the caller's order does
+            cand_order = self._locality_order(start, end)
+            if cand_order is not None:
                 n = end - start
-                okey = ("order", start, end, order.ptr)
-                maps = [m.derived_dev(okey, n, (lambda m=m: self._gather_rows(m, order, n))) if mi in src.staged_maps else m
-                        for mi, m in enumerate(maps)]
+                okey = ("order", start, end, cand_order.ptr)
+                base_maps, base = maps, (epb, plans, mplans, lds)
+                maps = [m.derived_dev(okey, n, (lambda m=m: self._gather_rows(m, cand_order, n))) if mi in src.staged_maps else m
+                        for mi, m in enumerate(base_maps)]
                 pstart, pend = 0, n
-            # 3. uniform blocks (of the derived order, or of the caller's), halved until the staged rows fit the LDS budget
-            epb = configuration["ents_per_block"]
-            while epb * maxar > 32768:
-                epb //= 2
-            while True:
-                plans, mplans, lds = build(epb, None)
-                if lds <= limit or epb <= 32:
-                    break
-                epb = max(32, epb // 2)
+                cand = uniform()
+                touched = lambda pl: sum(p.list_len for p in pl.values())          # noqa: E731
+                if touched(cand[1]) < 0.9 * touched(base[1]):
+                    order = cand_order
+                    epb, plans, mplans, lds = cand
+                else:
+                    maps, pstart, pend = base_maps, start, end
+                    epb, plans, mplans, lds = base
         if lds > 160 * 1024:
             raise PlanDoesNotFit("staged wrapper does not fit LDS even at 32 entities per block")
         kb = 2 if any(mp.kbytes == 2 for mp in mplans.values()) else 1

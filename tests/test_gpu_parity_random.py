@@ -250,7 +250,9 @@ def test_locality_order_matches_numpy_and_drives_the_staged_wrapper(numbering, m
     assert (np.diff(first[pl]) >= 0).all()                          # rows sorted by the rank of the first cell touching them
     prob = forms.PoissonProblem(m, 1, bcs=True)
     r = prob.assemble_residual()
-    assert prob.res_loop._staged_geometry(0, n)["cw"].src.mode.startswith("stagedo")
+    mode = prob.res_loop._staged_geometry(0, n)["cw"].src.mode
+    if numbering == "random":            # (a numbering with locality keeps the caller's order unless the derived one wins clearly)
+        assert mode.startswith("stagedo")
     from test_gpu_forms import _oracle_problem
     ro, Ao = _oracle_problem(prob, True)
     assert np.abs(r.data_ro - ro).max() <= 1e-12 * max(1.0, np.abs(ro).max())
