@@ -54,10 +54,8 @@ SIGNATURES = {
     "fd_kernel_free": (c_int, [c_void_p]),
     "fd_kernel_launch": (c_int, [c_void_p, c_int32, c_int32, POINTER(c_void_p), c_int, c_int, c_int, c_int,
                                  c_size_t, c_void_p]),
-    "fd_locality_order": (c_int, [c_void_p, c_int, c_int32, c_int32, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
-    "fd_first_touch_order": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "fd_locality_blocks": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int32, POINTER(c_void_p), POINTER(c_int32), c_void_p]),
-    "fd_host_free": (c_int, [c_void_p]),
+    "fd_locality_order": (c_int, [c_void_p, c_int, c_int32, c_int32, c_void_p, c_int, c_void_p, c_void_p]),
+    "fd_first_touch_order": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "fd_comm_available": (c_int, []),
     "fd_comm_unique_id": (c_int, [c_void_p]),
     "fd_comm_create": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),

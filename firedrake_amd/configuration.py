@@ -46,7 +46,6 @@ configuration = {
     "auto_occupancy_scratch": _env("FDHIP_AUTO_OCCUPANCY_SCRATCH", 16, int),
     # maps without producer hints: derive the entity order of staged loops from the loop's position field (Morton order of
     # the entity centroids) instead of cutting the caller's order into uniform blocks
-    "ents_per_block_ordered": _env("FDHIP_ENTS_PER_BLOCK_ORDERED", 2048, int),   # largest Morton box (entities) of a derived order
     "locality_order": _env("FDHIP_LOCALITY_ORDER", 1, int),
     "locality_min_entities": _env("FDHIP_LOCALITY_MIN", 8192, int),
     "use_preferred_blocks": _env("FDHIP_PREFERRED_BLOCKS", 1, int),   # plan blocks = the producer's traversal tiles

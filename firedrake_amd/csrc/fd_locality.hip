@@ -88,36 +88,7 @@ __global__ void ft_invert(const int32_t *__restrict__ plist, int32_t nnodes, int
         pinv[plist[p]] = (int32_t)p;
 }
 
-__global__ void ft_rank_of_position(const int32_t *__restrict__ plist, const uint32_t *__restrict__ node_key, int32_t nnodes,
-                                    int32_t *__restrict__ prank) {
-    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < nnodes; p += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t r = node_key[plist[p]];
-        prank[p] = r == 0xffffffffu ? -1 : (int32_t)r;
-    }
-}
-
-// ---- blocks aligned to Morton boxes: element i carries key keys[idx ? idx[i] : i]; a boundary sits where the key prefix
-// (key >> shift) changes (elements with idx < 0 form their own trailing runs)
-__device__ __forceinline__ uint64_t lb_prefix(const uint64_t *__restrict__ keys, const int32_t *__restrict__ idx, int64_t i, int shift) {
-    if (!idx) return keys[i] >> shift;
-    const int32_t r = idx[i];
-    return r < 0 ? ~0ull : (keys[r] >> shift);
-}
-
-__global__ void lb_flags(const uint64_t *__restrict__ keys, const int32_t *__restrict__ idx, int64_t n, int shift,
-                         unsigned char *__restrict__ flag) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        flag[i] = (i == 0 || lb_prefix(keys, idx, i, shift) != lb_prefix(keys, idx, i - 1, shift)) ? 1 : 0;
-}
-
-__global__ void lb_max_run(const int32_t *__restrict__ starts, int64_t nb, int64_t n, int32_t *__restrict__ mx) {
-    for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b < nb; b += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t e = (b + 1 < nb) ? starts[b + 1] : n;
-        atomicMax(mx, (int32_t)(e - starts[b]));
-    }
-}
-
-template <class K, class V> int sort_pairs(K *keys, V *vals, int64_t n, int end_bit, hipStream_t s, K *keys_out = nullptr) {
+template <class K, class V> int sort_pairs(K *keys, V *vals, int64_t n, int end_bit, hipStream_t s) {
     K *k2 = nullptr; V *v2 = nullptr; void *tmp = nullptr;
     FD_HIP(hipMalloc(&k2, (size_t)n * sizeof(K)));
     FD_HIP(hipMalloc(&v2, (size_t)n * sizeof(V)));
@@ -129,7 +100,6 @@ template <class K, class V> int sort_pairs(K *keys, V *vals, int64_t n, int end_
     FD_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, dk, dv, n, 0, end_bit, s));
     FD_HIP(hipStreamSynchronize(s));
     if (dv.Current() != vals) FD_HIP(hipMemcpy(vals, dv.Current(), (size_t)n * sizeof(V), hipMemcpyDeviceToDevice));
-    if (keys_out) FD_HIP(hipMemcpy(keys_out, dk.Current(), (size_t)n * sizeof(K), hipMemcpyDeviceToDevice));
     FD_HIP(hipFree(k2)); FD_HIP(hipFree(v2)); FD_HIP(hipFree(tmp));
     return 0;
 }
@@ -139,7 +109,7 @@ template <class K, class V> int sort_pairs(K *keys, V *vals, int64_t n, int end_
 extern "C" {
 
 int fd_locality_order(const int32_t *map_dev, int arity, int32_t start, int32_t end, const double *pos_dev, int pdim,
-                      int32_t *order_dev, uint64_t *keys_out_dev, fd_stream_t s_) {
+                      int32_t *order_dev, fd_stream_t s_) {
     if (!map_dev || !pos_dev || !order_dev || arity <= 0 || end < start || pdim < 1 || pdim > 3)
         FD_FAIL("fd_locality_order: bad arguments");
     const int64_t n = (int64_t)end - start;
@@ -155,13 +125,13 @@ int fd_locality_order(const int32_t *map_dev, int arity, int32_t start, int32_t 
     FD_HIP(hipMalloc(&keys, (size_t)n * 8));
     hipLaunchKernelGGL(lo_keys, dim3(lo_grid(n)), dim3(256), 0, s, map_dev, arity, (int64_t)start, n, pos_dev, pdim, box, keys, order_dev);
     FD_CHECK_LAUNCH();
-    int rc = sort_pairs<uint64_t, int32_t>(keys, order_dev, n, 16 * pdim, s, keys_out_dev);
+    int rc = sort_pairs<uint64_t, int32_t>(keys, order_dev, n, 16 * pdim, s);
     (void)hipFree(box); (void)hipFree(keys);
     return rc;
 }
 
 int fd_first_touch_order(const int32_t *map_dev, int arity, const int32_t *order_dev, int64_t n, int32_t nnodes,
-                         int32_t *pinv_dev, int32_t *plist_dev, int32_t *prank_out_dev, fd_stream_t s_) {
+                         int32_t *pinv_dev, int32_t *plist_dev, fd_stream_t s_) {
     if (!map_dev || !order_dev || !pinv_dev || !plist_dev || arity <= 0 || n < 0 || nnodes < 0)
         FD_FAIL("fd_first_touch_order: bad arguments");
     if (nnodes == 0) return 0;
@@ -179,8 +149,6 @@ int fd_first_touch_order(const int32_t *map_dev, int arity, const int32_t *order
     FD_CHECK_LAUNCH();
     int rc = sort_pairs<uint64_t, int32_t>(keys, plist_dev, (int64_t)nnodes, 64, s);
     if (!rc) {
-        if (prank_out_dev)      // rank of the first entity touching the p-th row (-1: untouched)
-            hipLaunchKernelGGL(ft_rank_of_position, dim3(lo_grid(nnodes)), dim3(256), 0, s, plist_dev, nk, nnodes, prank_out_dev);
         hipLaunchKernelGGL(ft_invert, dim3(lo_grid(nnodes)), dim3(256), 0, s, plist_dev, nnodes, pinv_dev);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { fd::set_error(hipGetErrorString(e)); rc = (int)e; }
@@ -189,55 +157,5 @@ int fd_first_touch_order(const int32_t *map_dev, int arity, const int32_t *order
     (void)hipFree(nk); (void)hipFree(keys);
     return rc;
 }
-
-// Cut a sequence of n elements, sorted by Morton key, into blocks aligned to Morton boxes: the coarsest octree level at
-// which no box holds more than max_run elements.  starts_host_out: malloc'ed nblocks + 1 offsets (first 0, last n); the
-// caller frees it with fd_host_free.
-int fd_locality_blocks(const uint64_t *keys_sorted_dev, const int32_t *index_dev, int64_t n, int pdim, int32_t max_run,
-                       int32_t **starts_host_out, int32_t *nblocks_out, fd_stream_t s_) {
-    if (!keys_sorted_dev || !starts_host_out || !nblocks_out || n < 0 || pdim < 1 || pdim > 3 || max_run < 1)
-        FD_FAIL("fd_locality_blocks: bad arguments");
-    if (n > 2147483647ll) FD_FAIL("fd_locality_blocks: too many elements");
-    hipStream_t s = fd::st(s_);
-    if (n == 0) {
-        *starts_host_out = (int32_t *)malloc(4); (*starts_host_out)[0] = 0; *nblocks_out = 0;
-        return 0;
-    }
-    unsigned char *flag = nullptr;
-    int32_t *starts = nullptr, *nsel = nullptr, *mx = nullptr;
-    void *tmp = nullptr;
-    FD_HIP(hipMalloc(&flag, (size_t)n));
-    FD_HIP(hipMalloc(&starts, (size_t)n * 4));
-    FD_HIP(hipMalloc(&nsel, 4));
-    FD_HIP(hipMalloc(&mx, 4));
-    size_t tb = 0;
-    hipcub::CountingInputIterator<int32_t> iota(0);
-    FD_HIP(hipcub::DeviceSelect::Flagged(nullptr, tb, iota, flag, starts, nsel, (int)n, s));
-    FD_HIP(hipMalloc(&tmp, tb ? tb : 8));
-    int32_t nb = 0;
-    for (int level = 1; level <= 17; ++level) {
-        const int shift = level <= 16 ? pdim * (16 - level) : 0;
-        hipLaunchKernelGGL(lb_flags, dim3(lo_grid(n)), dim3(256), 0, s, keys_sorted_dev, index_dev, n, shift, flag);
-        FD_CHECK_LAUNCH();
-        FD_HIP(hipcub::DeviceSelect::Flagged(tmp, tb, iota, flag, starts, nsel, (int)n, s));
-        FD_HIP(hipMemsetAsync(mx, 0, 4, s));
-        FD_HIP(hipMemcpyAsync(&nb, nsel, 4, hipMemcpyDeviceToHost, s));
-        FD_HIP(hipStreamSynchronize(s));
-        hipLaunchKernelGGL(lb_max_run, dim3(lo_grid(nb)), dim3(256), 0, s, starts, (int64_t)nb, n, mx);
-        FD_CHECK_LAUNCH();
-        int32_t m = 0;
-        FD_HIP(hipMemcpyAsync(&m, mx, 4, hipMemcpyDeviceToHost, s));
-        FD_HIP(hipStreamSynchronize(s));
-        if (m <= max_run || level == 17) break;       // finest level: equal keys cannot be separated (caller splits if needed)
-    }
-    int32_t *out = (int32_t *)malloc(((size_t)nb + 1) * 4);
-    FD_HIP(hipMemcpy(out, starts, (size_t)nb * 4, hipMemcpyDeviceToHost));
-    out[nb] = (int32_t)n;
-    *starts_host_out = out; *nblocks_out = nb;
-    (void)hipFree(flag); (void)hipFree(starts); (void)hipFree(nsel); (void)hipFree(mx); (void)hipFree(tmp);
-    return 0;
-}
-
-int fd_host_free(void *p) { free(p); return 0; }
 
 }  // extern "C"

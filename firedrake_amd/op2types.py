@@ -1966,9 +1966,9 @@ class RowOrder:
 
     def __init__(self, rmap: Map, order: "DeviceBuffer", n, npos, node_rowptr_host):
         self.npos = int(npos)
-        self.pinv, self.plist, self.prank = (DeviceBuffer(max(npos, 1) * 4) for _ in range(3))
+        self.pinv, self.plist = DeviceBuffer(max(npos, 1) * 4), DeviceBuffer(max(npos, 1) * 4)
         _lib.call("fd_first_touch_order", rmap._base()._dev_values(), rmap.arity, order.ptr, int(n), self.npos, self.pinv.ptr,
-                  self.plist.ptr, self.prank.ptr, None)
+                  self.plist.ptr, None)
         plist = self.plist.download(np.int32, (self.npos,))
         rowlen = np.diff(np.asarray(node_rowptr_host, dtype=np.int64))[:self.npos]
         self.prowptr_host = np.concatenate([[0], np.cumsum(rowlen[plist])]).astype(np.int32)

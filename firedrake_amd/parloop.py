@@ -398,19 +398,7 @@ class Parloop:
                 maps = [m.derived_dev(okey, n, (lambda m=m: self._gather_rows(m, cand_order, n))) if mi in src.staged_maps else m
                         for mi, m in enumerate(base_maps)]
                 pstart, pend = 0, n
-                # blocks = Morton boxes (cubes of entities, not arbitrary runs of the curve) holding at most `cap` entities
-                cap = min(configuration["ents_per_block_ordered"], 32768 // maxar)
-                cand = None
-                while cap >= 64:
-                    bl = self._locality_blocks(cand_order, n, cap)
-                    if int(np.diff(bl).max()) * maxar <= 32768:
-                        pl_, mp_, lds_ = build(0, bl)
-                        if lds_ <= limit:
-                            cand = (int(np.diff(bl).max()), pl_, mp_, lds_)
-                            break
-                    cap //= 2
-                if cand is None:
-                    cand = uniform()
+                cand = uniform()
                 touched = lambda pl: sum(p.list_len for p in pl.values())          # noqa: E731
                 if touched(cand[1]) < 0.9 * touched(base[1]):
                     order = cand_order
@@ -504,25 +492,11 @@ class Parloop:
         buf = cache.get(key)
         if buf is None:
             buf = DeviceBuffer(n * 4)
-            buf.keys = DeviceBuffer(n * 8)     # the sorted Morton keys: block cuts aligned to Morton boxes (_locality_blocks)
-            buf.pdim = pa.data.cdim
             _lib.call("fd_locality_order", pa.map_._base()._dev_values(), pa.map_.arity, int(start), int(end),
-                      pa.data._dev_ptr(False), pa.data.cdim, buf.ptr, buf.keys.ptr, None)
+                      pa.data._dev_ptr(False), pa.data.cdim, buf.ptr, None)
             cache.clear()                      # one order per map and range: a moved mesh replaces it
             cache[key] = buf
         return buf
-
-    @staticmethod
-    def _locality_blocks(order, n, max_run, index=None):
-        """Block boundaries (offsets into the ordered sequence, first 0, last n) aligned to Morton boxes: the coarsest
-        octree level whose boxes hold at most ``max_run`` elements (fd_locality_blocks).  ``index``: optional device
-        int32[n] giving, per element, the entity rank whose key it carries (rows: the first entity touching them)."""
-        import ctypes
-        out, nb = ctypes.c_void_p(), ctypes.c_int32()
-        _lib.call("fd_locality_blocks", order.keys.ptr, index, int(n), order.pdim, int(max_run), ctypes.byref(out), ctypes.byref(nb), None)
-        arr = np.ctypeslib.as_array(ctypes.cast(out.value, ctypes.POINTER(ctypes.c_int32)), shape=(nb.value + 1,)).copy()
-        _lib.call("fd_host_free", out)
-        return arr
 
     @staticmethod
     def _gather_rows(m, order, n):
@@ -773,19 +747,14 @@ class Parloop:
             order = self._locality_order(start, end)
             prp = rp[:nrows + 1]
             cap = configuration["ocr_nnz_per_block"]
-            rb = None
             if order is not None:
                 from .op2types import RowOrder
                 row_order = RowOrder(rmap, order, end - start, nrows, rp)
                 prp = row_order.prowptr_host
                 cap = configuration["ocr_nnz_per_block_ordered"]
-                # rows of one Morton box of entities (the box of the first entity touching the row) form a block
-                rows_cap = max(16, int(cap * nrows / max(int(prp[nrows]), 1)))
-                rb = self._locality_blocks(order, nrows, rows_cap, index=row_order.prank.ptr).astype(np.int64)
-            if rb is None:
-                targets = np.arange(0, int(prp[nrows]) + cap, cap)
-                rb = np.unique(np.concatenate([np.searchsorted(prp[:nrows + 1], targets, side="left"), [0, nrows]]))
-                rb = rb[rb <= nrows]
+            targets = np.arange(0, int(prp[nrows]) + cap, cap)
+            rb = np.unique(np.concatenate([np.searchsorted(prp[:nrows + 1], targets, side="left"), [0, nrows]]))
+            rb = rb[rb <= nrows]
         staged = {mi: maps[mi] for mi in src.staged_maps}
         maxar = max(m.arity for m in staged.values())
 

@@ -287,17 +287,9 @@ int fd_halo_unpack(double *dat_dev, int cdim, const int32_t *idx_dev, int32_t n,
  *                         pinv[node] = p; nodes no entity touches come last
  * Private re-encodings: Dats, Maps and the CSR keep the caller's numbering. */
 int fd_locality_order(const int32_t *map_dev, int arity, int32_t start, int32_t end, const double *pos_dev, int pdim,
-                      int32_t *order_dev, uint64_t *sorted_keys_out_dev /* n keys, may be NULL */, fd_stream_t s);
+                      int32_t *order_dev, fd_stream_t s);
 int fd_first_touch_order(const int32_t *map_dev, int arity, const int32_t *order_dev, int64_t n, int32_t nnodes,
-                         int32_t *pinv_dev, int32_t *plist_dev,
-                         int32_t *prank_out_dev /* rank of the first entity touching the p-th row, -1 = none; may be NULL */,
-                         fd_stream_t s);
-/* Blocks aligned to Morton boxes: cut n elements (element i has key keys[index ? index[i] : i]; sorted by key) where the
- * key prefix changes, at the coarsest octree level whose boxes hold at most max_run elements each -- cubes of entities /
- * rows instead of arbitrary runs of the curve.  starts_host_out: nblocks + 1 offsets, released with fd_host_free. */
-int fd_locality_blocks(const uint64_t *keys_sorted_dev, const int32_t *index_dev, int64_t n, int pdim, int32_t max_run,
-                       int32_t **starts_host_out, int32_t *nblocks_out, fd_stream_t s);
-int fd_host_free(void *p);
+                         int32_t *pinv_dev, int32_t *plist_dev, fd_stream_t s);
 
 /* ------------------------------------------------- halo exchange + Global reductions over RCCL
  * firedrake/halo.py:87-172 (PetscSF bcast owner->ghost with MPI.REPLACE, reduce ghost->owner with SUM/MIN/MAX behind

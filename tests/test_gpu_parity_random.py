@@ -234,34 +234,20 @@ def test_locality_order_matches_numpy_and_drives_the_staged_wrapper(numbering, m
     pos = np.array(m.coordinates.data_ro)
     order_ref, keys = locality_order_ref(cm.values_with_halo, 0, n, pos)
     buf = DeviceBuffer(n * 4)
-    kbuf = DeviceBuffer(n * 8)
-    _lib.call("fd_locality_order", cm._dev_values(), 4, 0, n, m.coordinates._dev_ptr(False), 3, buf.ptr, kbuf.ptr, None)
+    _lib.call("fd_locality_order", cm._dev_values(), 4, 0, n, m.coordinates._dev_ptr(False), 3, buf.ptr, None)
     order = buf.download(np.int32, (n,))
-    assert np.array_equal(kbuf.download(np.uint64, (n,)), keys[order_ref])
-    # blocks aligned to Morton boxes: the coarsest level whose boxes hold at most 200 cells
-    import ctypes
-    out, nb = ctypes.c_void_p(), ctypes.c_int32()
-    _lib.call("fd_locality_blocks", kbuf.ptr, None, n, 3, 200, ctypes.byref(out), ctypes.byref(nb), None)
-    bl = np.ctypeslib.as_array(ctypes.cast(out.value, ctypes.POINTER(ctypes.c_int32)), shape=(nb.value + 1,)).copy()
-    _lib.call("fd_host_free", out)
-    sk = keys[order_ref]
-    level = next(l for l in range(1, 17) if max(np.diff(np.concatenate([[0], np.nonzero(np.diff(sk >> np.uint64(3 * (16 - l))))[0] + 1, [n]]))) <= 200)
-    expect = np.concatenate([[0], np.nonzero(np.diff(sk >> np.uint64(3 * (16 - level))))[0] + 1, [n]])
-    assert np.array_equal(bl, expect) and np.diff(bl).max() <= 200
     assert sorted(order.tolist()) == list(range(n))
     assert np.array_equal(keys[order], keys[order_ref])            # same key sequence (ties may be ordered alike or not)
     # first-touch rows under that order
     nn = V.node_set.size
     pinv, plist = DeviceBuffer(nn * 4), DeviceBuffer(nn * 4)
-    prank = DeviceBuffer(nn * 4)
-    _lib.call("fd_first_touch_order", cm._dev_values(), 4, buf.ptr, n, nn, pinv.ptr, plist.ptr, prank.ptr, None)
+    _lib.call("fd_first_touch_order", cm._dev_values(), 4, buf.ptr, n, nn, pinv.ptr, plist.ptr, None)
     pl, pi = plist.download(np.int32, (nn,)), pinv.download(np.int32, (nn,))
     assert np.array_equal(pi[pl], np.arange(nn)) and sorted(pl.tolist()) == list(range(nn))
     first = np.full(nn, np.iinfo(np.int64).max)
     flat = cm.values_with_halo[order].reshape(-1)
     first[flat[::-1]] = np.arange(len(flat) - 1, -1, -1) // 4
     assert (np.diff(first[pl]) >= 0).all()                          # rows sorted by the rank of the first cell touching them
-    assert np.array_equal(prank.download(np.int32, (nn,)), first[pl])
     prob = forms.PoissonProblem(m, 1, bcs=True)
     r = prob.assemble_residual()
     mode = prob.res_loop._staged_geometry(0, n)["cw"].src.mode

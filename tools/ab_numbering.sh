@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/ab_numbering.sh -- un-hinted numberings: backend-derived locality (FDHIP_LOCALITY_ORDER=1) vs the caller's order cut
-# into uniform blocks (=0), and the block caps of the derived orders.  Output: gpurun_out/ab_numbering.txt
+# into uniform blocks (=0).  Output: gpurun_out/ab_numbering.txt
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 OUT=gpurun_out/ab_numbering.txt
@@ -16,8 +16,9 @@ print('step_ms', round(d['ms_per_step'], 4), 'res_ms', round(d['roofline_residua
   grep -i "error\|Traceback" gpurun_out/ab_numbering.err | tail -3 >> $OUT
 }
 run lexicographic "FDHIP_LOCALITY_ORDER=1"
-run random "FDHIP_LOCALITY_ORDER=1"
-run lexicographic "FDHIP_LOCALITY_ORDER=1 FDHIP_ENTS_PER_BLOCK_ORDERED=4096"
-run lexicographic "FDHIP_LOCALITY_ORDER=1 FDHIP_OCR_NNZ_ORDERED=8000"
 run lexicographic "FDHIP_LOCALITY_ORDER=0"
+run random "FDHIP_LOCALITY_ORDER=1"
+run random "FDHIP_LOCALITY_ORDER=0"
+run lexicographic "FDHIP_LOCALITY_ORDER=1 FDHIP_OCR_NNZ_ORDERED=2048"
+run lexicographic "FDHIP_LOCALITY_ORDER=1 FDHIP_OCR_NNZ_ORDERED=3000"
 cat $OUT
