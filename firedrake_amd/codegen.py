@@ -370,7 +370,8 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             if ocrp:
                 P(f"const int *__restrict__ oc{k}_pinv", ("ocr_pinv", k))
                 P(f"const int *__restrict__ oc{k}_prowptr", ("ocr_prowptr", k))
-                P(f"const int *__restrict__ oc{k}_plist", ("ocr_plist", k))
+                P(f"const int *__restrict__ oc{k}_nstart", ("ocr_nstart", k))
+                P(f"const int *__restrict__ oc{k}_gstart", ("ocr_gstart", k))
                 P(f"long long oc{k}_npos", ("ocr_npos", k))
         elif mat_staged[k]:
             P(f"const int *__restrict__ mp{k}_off", ("matplan_off", k))
@@ -536,7 +537,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                     # the node's row position decides ownership and the accumulator offset
                     loads = [f"const int p{k}_U = (G_U < (int)oc{k}_npos) ? oc{k}_pinv[G_U] : -1;",
                              f"const unsigned w{k}_U = ((p{k}_U >= n0_{k} && p{k}_U < n0_{k} + nown{k}{rowmask.replace('[g]', '[G_U]')}) ? "
-                             f"(unsigned)(oc{k}_prowptr[p{k}_U] - r0_{k} + 1) : 0u){colbit.replace('[g]', '[G_U]')};"]
+                             f"(unsigned)(oc{k}_nstart[G_U] - r0_{k} + 1) : 0u){colbit.replace('[g]', '[G_U]')};"]
                 else:
                     rowpos = f"(unsigned)(oc{k}_rowptr[g] - r0_{k} + 1)"
                     loads = [f"const int g = G_U; const unsigned w{k}_U = ((g >= n0_{k} && g < n0_{k} + nown{k}{rowmask}) ? {rowpos} : 0u){colbit};".replace("const int g = G_U; ", "").replace("(g ", "(G_U ").replace(" g ", " G_U ").replace(" g,", " G_U,").replace("[g]", "[G_U]")]
@@ -561,7 +562,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                     # complete rows again, but a SET of CSR rows: 16 lanes per row, four rows per wavefront step
                     flush.append((rm, f"for (int fr = tid >> 4; fr < nown{k}; fr += nthr >> 4) {{ const int fp = n0_{k} + fr; "
                                       f"const int fs = oc{k}_prowptr[fp] - r0_{k}, fl = oc{k}_prowptr[fp+1] - oc{k}_prowptr[fp]; "
-                                      f"const size_t fd_ = (size_t)oc{k}_rowptr[oc{k}_plist[fp]]; "
+                                      f"const size_t fd_ = (size_t)oc{k}_gstart[fp]; "
                                       f"if (oc{k}_flags & 1) {{ for (int q = tid & 15; q < fl; q += 16) arg{k}[fd_ + q] = sm{k}[fs + q]; }} "
                                       f"else {{ for (int q = tid & 15; q < fl; q += 16) arg{k}[fd_ + q] += sm{k}[fs + q]; }} }}"))
                     continue

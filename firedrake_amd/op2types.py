@@ -1970,9 +1970,16 @@ class RowOrder:
         _lib.call("fd_first_touch_order", rmap._base()._dev_values(), rmap.arity, order.ptr, int(n), self.npos, self.pinv.ptr,
                   self.plist.ptr, None)
         plist = self.plist.download(np.int32, (self.npos,))
-        rowlen = np.diff(np.asarray(node_rowptr_host, dtype=np.int64))[:self.npos]
+        rp = np.asarray(node_rowptr_host, dtype=np.int64)
+        rowlen = np.diff(rp)[:self.npos]
         self.prowptr_host = np.concatenate([[0], np.cumsum(rowlen[plist])]).astype(np.int32)
         self.prowptr = DeviceBuffer.from_numpy(self.prowptr_host)
+        # the two lookups the wrapper needs, flattened so that neither is a dependent chain of loads:
+        # nstart[node] = prowptr[pinv[node]] (accumulator offset of a row, by NODE), gstart[p] = rowptr[plist[p]] (CSR start, by POSITION)
+        nstart = np.zeros(max(self.npos, 1), dtype=np.int32)
+        nstart[plist] = self.prowptr_host[:-1]
+        self.nstart = DeviceBuffer.from_numpy(nstart)
+        self.gstart = DeviceBuffer.from_numpy(np.ascontiguousarray(rp[plist], dtype=np.int32) if self.npos else np.zeros(1, np.int32))
 
 
 class MatPlan:

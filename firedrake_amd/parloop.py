@@ -866,8 +866,10 @@ class Parloop:
                 out.append(geo["row_order"].pinv.ptr)
             elif kind == "ocr_prowptr":
                 out.append(geo["row_order"].prowptr.ptr)
-            elif kind == "ocr_plist":
-                out.append(geo["row_order"].plist.ptr)
+            elif kind == "ocr_nstart":
+                out.append(geo["row_order"].nstart.ptr)
+            elif kind == "ocr_gstart":
+                out.append(geo["row_order"].gstart.ptr)
             elif kind == "ocr_npos":
                 out.append(geo["row_order"].npos)
             elif kind in ("mat_row_lgmap", "mat_col_lgmap"):

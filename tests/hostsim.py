@@ -233,8 +233,12 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None):
             cargs.append(ptr(pinv))
         elif kind == "ocr_prowptr":
             cargs.append(ptr(prowptr))
-        elif kind == "ocr_plist":
-            cargs.append(ptr(plist))
+        elif kind == "ocr_nstart":
+            ns = np.zeros(max(nrows, 1), dtype=np.int32)
+            ns[plist] = prowptr[:-1]
+            cargs.append(ptr(ns))
+        elif kind == "ocr_gstart":
+            cargs.append(ptr(np.ascontiguousarray(csr.rowptr[plist], dtype=np.int32)))
         elif kind == "ocr_npos":
             cargs.append(ctypes.c_longlong(nrows))
         elif kind in ("mat_row_lgmap", "mat_col_lgmap"):

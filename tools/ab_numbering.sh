@@ -16,9 +16,7 @@ print('step_ms', round(d['ms_per_step'], 4), 'res_ms', round(d['roofline_residua
   grep -i "error\|Traceback" gpurun_out/ab_numbering.err | tail -3 >> $OUT
 }
 run lexicographic "FDHIP_LOCALITY_ORDER=1"
-run lexicographic "FDHIP_LOCALITY_ORDER=0"
 run random "FDHIP_LOCALITY_ORDER=1"
+run lexicographic "FDHIP_LOCALITY_ORDER=0"
 run random "FDHIP_LOCALITY_ORDER=0"
-run lexicographic "FDHIP_LOCALITY_ORDER=1 FDHIP_OCR_NNZ_ORDERED=2048"
-run lexicographic "FDHIP_LOCALITY_ORDER=1 FDHIP_OCR_NNZ_ORDERED=3000"
 cat $OUT
