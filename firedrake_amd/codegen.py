@@ -158,7 +158,7 @@ def select_mode(gk: GlobalKernel) -> str:
     if want == "direct":
         return "direct"
     if ok and configuration["mat_ocr"] and ocr_eligible(gk):
-        return "ocr"
+        return "ocrs" if sliced_eligible(gk) else "ocr"
     return "staged" if ok else "direct"
 
 
@@ -211,6 +211,17 @@ def ocr_eligible(gk: GlobalKernel) -> bool:
     return nmat == 1
 
 
+def sliced_eligible(gk: GlobalKernel) -> bool:
+    """Row-sliced owner-computes-rows (generate_sliced_wrapper): an owner-computes-rows loop whose row map has at least
+    ``ocr_sliced_min_arity`` entries -- the size from which one row of the element matrix costs much less than the whole
+    (P2 tets: 10 rows; measured on the P2 stiffness kernel: 233 fp64 instructions for one row against 599 for all ten, i.e.
+    the rows share little beyond the geometry, while an unsliced row block recomputes whole entities x2.2-3.4)."""
+    if not configuration["ocr_sliced"] or not ocr_eligible(gk):
+        return False
+    (a,) = [a for a in gk.arguments if isinstance(a, MatKernelArg)]
+    return configuration["ocr_sliced_min_arity"] <= a.maps[0].arity <= 255
+
+
 def _hoist_includes(code: str):
     from .kernel import strip_host_only_includes
     code = strip_host_only_includes(code)
@@ -222,6 +233,8 @@ def _hoist_includes(code: str):
 def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> WrapperSource:
     if mode.startswith("tp_"):
         return generate_tensor_wrapper(gk)
+    if mode.startswith("ocrs"):
+        return generate_sliced_wrapper(gk, mode)
     lk = gk.local_kernel
     maps, map_index = _distinct_maps(gk)
     # requires_zeroed_output_arguments: MIN/MAX packs start from zero like INC/WRITE ones (builder.py:276-279, 368-371)
@@ -801,6 +814,203 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                          layer_parallel, threads, kbytes, mat_staged,
                          (threads if (staged and configuration["lane_strided"]) else 0),
                          ocr_lds_limit if ocr else 0)
+
+
+def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
+    """Row-sliced owner-computes-rows wrapper (modes "ocrs" / "ocrsp" [+ _k16] [+ _s<strides>]).
+
+    Same contract as the owner-computes-rows wrapper -- complete CSR rows accumulated in LDS, stored without global atomics,
+    MatSetValuesLocal semantics for negative indices (builder.py:573-625) -- but the unit of work is (entity, local row i)
+    (fd_ocrplan_create_sliced): the local kernel is inlined once per i inside a ``switch`` on the wavefront's row index, and
+    only row i of its output is read, so every instantiation keeps just the arithmetic that row needs.  The lgmaps do not
+    appear: they are folded into the per-instance tables (slot = 0xffff / position = all-ones for dropped rows / columns),
+    one table set per pair of lgmaps (fd_ocrplan_sliced_tables).  "ocrsp": the row blocks are ranges of row POSITIONS of a
+    backend-derived row order, flushed row by row like "ocrp"."""
+    lk = gk.local_kernel
+    maps, map_index = _distinct_maps(gk)
+    full_mode = mode
+    sm_ = re.search(r"_s(\d+(?:x\d+)*)$", mode)
+    strides = [int(v) for v in sm_.group(1).split("x")] if sm_ else None
+    if sm_:
+        mode = mode[:sm_.start()]
+    ordered = mode.startswith("ocrsp")
+    ktype, kbytes = ("unsigned short", 2) if mode.endswith("_k16") else ("unsigned char", 1)
+    skip = "0xffffu" if kbytes == 2 else "0xffu"
+    threads = configuration["ocrs_block_threads"]
+    params: List[str] = []
+    layout: List[tuple] = []
+
+    def P(decl, desc):
+        params.append(decl)
+        layout.append(desc)
+
+    infos = []
+    for k, (a, la) in enumerate(zip(gk.arguments, lk.arguments)):
+        info = {"k": k, "arg": a, "acc": la.access, "ct": CTYPE[np.dtype(la.dtype)], "dtype": np.dtype(la.dtype)}
+        if isinstance(a, MatKernelArg):
+            info["kind"] = "mat"
+            info["ar"], info["ac"] = a.maps[0].arity, a.maps[1].arity
+        elif isinstance(a, DatKernelArg):
+            info["kind"] = "dat"
+            info["c"] = int(np.prod(a.dim))
+            if a.is_indirect:
+                m = a.map_
+                base = m.base_map if isinstance(m, PermutedMapKernelArg) else m
+                info["m"], info["ar"] = map_index[id(base)], base.arity
+                info["perm"] = tuple(m.permutation) if isinstance(m, PermutedMapKernelArg) else None
+        elif isinstance(a, GlobalKernelArg):
+            info["kind"] = "global"
+        elif isinstance(a, PassthroughKernelArg):
+            info["kind"] = "pass"
+        else:
+            raise TypeError(f"unsupported kernel argument {a!r}")
+        infos.append(info)
+    (mat,) = [i for i in infos if i["kind"] == "mat"]
+    K, AR, AC = mat["k"], mat["ar"], mat["ac"]
+
+    for info in infos:
+        k, ct = info["k"], info["ct"]
+        const = "const " if info["kind"] != "mat" else ""
+        P(f"{const}{ct} *__restrict__ arg{k}" if info["kind"] != "pass" else f"void *arg{k}", ("arg", k))
+    for mi in range(len(maps)):
+        P(f"const int *__restrict__ map{mi}", ("map", mi))
+    P("const int *__restrict__ bstart_", ("bstart",))
+    P("const int *__restrict__ inst_ent_", ("ocr_inst_ent",))
+    P("const unsigned char *__restrict__ chunk_role_", ("ocrs_chunk_role",))
+    staged_maps = []
+    for info in infos:
+        if info["kind"] == "dat" and "m" in info and info["m"] not in staged_maps:
+            staged_maps.append(info["m"])
+    for mi in staged_maps:
+        P(f"const int *__restrict__ p{mi}_blkoff", ("plan_blkoff", mi))
+        P(f"const int *__restrict__ p{mi}_list", ("plan_list", mi))
+        P(f"const unsigned short *__restrict__ p{mi}_lmap", ("plan_lmap", mi))
+        P(f"long long p{mi}_maxnd", ("plan_maxnd", mi))
+    P(f"const int *__restrict__ oc{K}_rblk", ("ocr_rblk", K))
+    P(f"const int *__restrict__ oc{K}_rowptr", ("ocr_prowptr" if ordered else "ocr_rowptr", K))
+    if ordered:
+        P(f"const int *__restrict__ oc{K}_gstart", ("ocr_gstart", K))
+    P(f"const unsigned short *__restrict__ oc{K}_slot", ("ocrs_slot", K))
+    P(f"const {ktype} *__restrict__ oc{K}_k", ("ocrs_kk", K))
+    P(f"long long oc{K}_maxnnz", ("ocr_maxnnz", K))
+    P(f"long long oc{K}_flags", ("ocr_flags", K))
+
+    lds_decl, lds_items, stage_nodes, pack, call_args = ["size_t fd_off = 0;"], [], {}, [], []
+    for info in infos:
+        k, ct = info["k"], info["ct"]
+        if info["kind"] == "pass":
+            call_args.append(f"arg{k}")
+        elif info["kind"] == "global":
+            call_args.append(f"const_cast<{ct} *>(arg{k})")
+        elif info["kind"] == "mat":
+            call_args.append(f"t{k}")
+        elif "m" not in info:
+            vi = info["arg"].index
+            off = "" if vi is None else f" + {int(np.ravel_multi_index(tuple(vi), tuple(info['arg'].dim)))}"
+            call_args.append(f"const_cast<{ct} *>(&arg{k}[(size_t)e*{info['c']}{off}])")
+        else:
+            c, ar, mi, perm = info["c"], info["ar"], info["m"], info["perm"]
+            soa = bool(configuration["lds_soa"]) and c > 1
+            lds_items.append(("dat", mi, c, info["dtype"].itemsize, False))
+            lds_decl.append(f"{ct} *s{k} = ({ct} *)(fd_lds + fd_off); fd_off += (((size_t)p{mi}_maxnd*{c}*sizeof({ct})) + 15) & ~(size_t)15;")
+            stage_nodes.setdefault(mi, []).append(
+                ([f"{ct} v{k}[{c}];", f"for (int j = 0; j < {c}; ++j) v{k}[j] = arg{k}[(size_t)g*{c} + j];"],
+                 [f"for (int j = 0; j < {c}; ++j) s{k}[{'j*(int)p%d_maxnd + i' % mi if soa else 'i*%d + j' % c}] = v{k}[j];"]))
+            idx = f"j*(int)p{mi}_maxnd + lm{mi}[{_permi(perm, 'i')}]" if soa else f"lm{mi}[{_permi(perm, 'i')}]*{c} + j"
+            pack.append(f"{ct} t{k}[{ar * c}];")
+            pack.append(f"for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j) t{k}[i*{c}+j] = s{k}[{idx}];")
+            call_args.append(f"t{k}")
+    lds_items.append(("ocrs", K))
+    lds_decl.append(f"double *sm{K} = (double *)(fd_lds + fd_off); fd_off += (((size_t)oc{K}_maxnnz*8) + 15) & ~(size_t)15;")
+
+    includes, body = _hoist_includes(lk.code)
+    sym = f"wrap_{lk.name}"
+    src = ['#include "fd_wrapper.h"', "#include <math.h>", *includes, *[f"#include <{h}>" for h in lk.headers],
+           "namespace fdk {", "#pragma clang force_cuda_host_device begin", body,
+           "#pragma clang force_cuda_host_device end", "}  // namespace fdk", "",
+           f'extern "C" __global__ __launch_bounds__({threads}) void {sym}(int start, int end, {", ".join(params)})', "{",
+           "  extern __shared__ __align__(16) unsigned char fd_lds[];",
+           "  const int tid = threadIdx.x, nthr = blockDim.x;",
+           "  const int b = fdw::xcd_block(blockIdx.x, gridDim.x);",
+           "  const int e0 = bstart_[b], e1 = bstart_[b+1];"]
+    src += ["  " + s for s in lds_decl]
+    for mi in staged_maps:
+        src.append(f"  const int l0_{mi} = p{mi}_blkoff[b], nd{mi} = p{mi}_blkoff[b+1] - l0_{mi};")
+    src += [f"  const int n0 = oc{K}_rblk[b], nown = oc{K}_rblk[b+1] - n0;",
+            f"  const int r0 = oc{K}_rowptr[n0], nnzb = oc{K}_rowptr[n0 + nown] - r0;",
+            f"  for (int q = tid; q < nnzb; q += nthr) sm{K}[q] = 0;"]
+    for mi, acts in stage_nodes.items():
+        src.append(f"  for (int i = tid; i < nd{mi}; i += nthr) {{")
+        src.append(f"    const int g = p{mi}_list[l0_{mi} + i];")
+        for part in (0, 1):
+            for act in acts:
+                src += ["    " + l for l in act[part]]
+        src.append("  }")
+    src.append("  __syncthreads();")
+    # every 64 consecutive slots hold one local row index, and e0 / nthr are multiples of 64: the index is wave-uniform.
+    # Software pipeline like the unsliced wrappers: the index rows of the lane's NEXT instance are requested before the
+    # current one's local kernel runs (a trip is only ~300 instructions, far less than an HBM round trip).
+    need_e = any(i["kind"] == "dat" and "m" not in i for i in infos)
+    rows = [(f"lm{mi}", maps[mi].arity, f"fdw::load_lmap<{maps[mi].arity}>(p{mi}_lmap + (size_t)(II - start)*{maps[mi].arity}, DST);")
+            for mi in staged_maps]
+    rows.append(("kk", AC, f"fdw::load_packed<{ktype}, {AC}>(oc{K}_k + (size_t)(II - start)*{AC}, DST);"))
+    scal = [("role", "(int)chunk_role_[(II - start) >> 6]"), ("slot", f"(int)oc{K}_slot[II - start]")]
+    if need_e:
+        scal.append(("e", "inst_ent_[II - start]"))
+    pf = bool(configuration["prefetch"])
+
+    def loads(ii, prefix):
+        out = [f"{prefix}{n} = {ex.replace('II', ii)};" for n, ex in scal]
+        out += [ld.replace("II", ii).replace("DST", prefix + n) for n, _, ld in rows]
+        return out
+    for n, ln, _ in rows:
+        src.append(f"  int {n}[{ln}];" + (f" int nx_{n}[{ln}];" if pf else ""))
+    src.append("  int " + ", ".join(f"{n} = 0" + (f", nx_{n} = 0" if pf else "") for n, _ in scal) + ";")
+    if pf:
+        src.append("  if (e0 + tid < e1) {")
+        src += ["    " + l for l in loads("(e0 + tid)", "")]
+        src.append("  }")
+    src.append("  for (int it = e0 + tid; it < e1; it += nthr) {")
+    if pf:
+        src.append("    const int itn = (it + nthr < e1) ? it + nthr : it;")
+        src += ["    " + l for l in loads("itn", "nx_")]
+    else:
+        src += ["    " + l for l in loads("it", "")]
+    src += ["    " + s for s in pack]
+    src.append("    switch (fdw::wave_uniform(role)) {")
+    for r in range(AR):
+        src += [f"    case {r}: {{",
+                f"      double t{K}[{AR * AC}]; for (int q = 0; q < {AR * AC}; ++q) t{K}[q] = 0;",
+                f"      fdk::{lk.name}({', '.join(call_args)});",
+                # (dropped contributions branch around the ds_add_f64; sending them to per-lane dump words instead measured 5 % slower)
+                "      if (slot != 0xffff) {",
+                f"        for (int j = 0; j < {AC}; ++j) if (kk[j] != {skip}) atomicAdd(&sm{K}[slot + kk[j]], t{K}[{r * AC} + j]);",
+                "      }",
+                "    } break;"]
+    src += ["    default: break;", "    }"]
+    if pf:
+        for n, ln, _ in rows:
+            src.append(f"    for (int q = 0; q < {ln}; ++q) {n}[q] = nx_{n}[q];")
+        src.append("    " + " ".join(f"{n} = nx_{n};" for n, _ in scal))
+    src += ["  }", "  __syncthreads();"]
+    if ordered:
+        src.append(f"  for (int fr = tid >> 4; fr < nown; fr += nthr >> 4) {{ const int fp = n0 + fr; "
+                   f"const int fs = oc{K}_rowptr[fp] - r0, fl = oc{K}_rowptr[fp+1] - oc{K}_rowptr[fp]; "
+                   f"const size_t fd_ = (size_t)oc{K}_gstart[fp]; "
+                   f"if (oc{K}_flags & 1) {{ for (int q = tid & 15; q < fl; q += 16) arg{K}[fd_ + q] = sm{K}[fs + q]; }} "
+                   f"else {{ for (int q = tid & 15; q < fl; q += 16) arg{K}[fd_ + q] += sm{K}[fs + q]; }} }}")
+    else:
+        src.append(f"  if (oc{K}_flags & 1) {{ for (int q = tid; q < nnzb; q += nthr) arg{K}[(size_t)r0 + q] = sm{K}[q]; }} "
+                   f"else {{ for (int q = tid; q < nnzb; q += nthr) arg{K}[(size_t)r0 + q] += sm{K}[q]; }}")
+    src.append("}")
+    if strides is not None:
+        if len(strides) != len(staged_maps):
+            raise ValueError("one compile-time stride per staged map")
+        sig = next(i for i, l in enumerate(src) if l.startswith('extern "C" __global__'))
+        for mi, S in zip(staged_maps, strides):
+            pat = re.compile(r"\bp%d_maxnd\b" % mi)
+            src[sig + 1:] = [pat.sub("((long long)%d)" % S, l) for l in src[sig + 1:]]
+    return WrapperSource("\n".join(src) + "\n", sym, full_mode, layout, len(maps), staged_maps, lds_items, True, threads, kbytes)
 
 
 def lds_stride(max_nd: int, ocr: bool = False) -> int:

@@ -35,6 +35,13 @@ configuration = {
     "mat_ocr": _env("FDHIP_MAT_OCR", 1, int),             # owner-computes-rows matrix assembly (no global atomics)
     "ocr_nnz_per_block_ordered": _env("FDHIP_OCR_NNZ_ORDERED", 3840, int),   # the same under a backend-derived row order
     "ocr_nnz_per_block": _env("FDHIP_OCR_NNZ", 2048, int),  # row-block size (CSR entries) when the producer gives no hint
+    # row-sliced owner-computes-rows (codegen.generate_sliced_wrapper): instances are (entity, local row), the local kernel is
+    # instantiated once per row; pays when the rows of the element matrix dominate its shared (geometry) part
+    "ocr_sliced": _env("FDHIP_OCR_SLICED", 1, int),
+    "ocr_sliced_min_arity": _env("FDHIP_OCR_SLICED_MIN_ARITY", 8, int),
+    "ocrs_nnz_per_block": _env("FDHIP_OCRS_NNZ", 4096, int),     # accumulator entries per row block (x8 bytes of LDS)
+    "ocrs_block_threads": _env("FDHIP_OCRS_BLOCK_THREADS", 256, int),
+    "ocrs_interleave": _env("FDHIP_OCRS_INTERLEAVE", 7, int),    # > 1: stride permutation of the instances of every (block, row index) group
     "ocr_block_threads": _env("FDHIP_OCR_BLOCK_THREADS", 0, int),  # 0 = auto: 512 for small element matrices, else block_threads
     # order of the instances inside an owner-computes-rows block: "lane" (fd_plan_set_lane_order), "stencil"
     # (sorted by owned-row signature) or "natural" (entity order)

@@ -629,6 +629,12 @@ struct fd_ocrplan_s {
     const int32_t *pinv = nullptr;
     const int32_t *prowptr = nullptr;
     int32_t npos = 0;
+    // row-sliced plans (fd_ocrplan_create_sliced): an instance is (entity, local row); the lists are padded so that every
+    // 64 consecutive slots hold ONE local row index (chunk_role), valid[t] = 0 marks the padding slots
+    uint8_t *chunk_role = nullptr;
+    uint8_t *valid = nullptr;
+    int64_t nreal = 0;
+    int sliced_ar = 0;
 };
 
 namespace {
@@ -864,6 +870,128 @@ __global__ void row_offsets_k(const int32_t *__restrict__ rowptr, const int32_t 
     }
 }
 
+// ---- row-sliced owner-computes-rows (fd_ocrplan_create_sliced) --------------------------------------------------
+// Large element matrices (P2 tets: 10x10, 28-entry rows) leave a 64 KiB row block ~250 rows, i.e. a brick of ~30
+// vertices: most entities touching it are border entities computed again by the neighbouring blocks (x2.2-3.4), and
+// the 100 accumulator registers per lane cap the occupancy.  The sliced form makes the unit of work (entity, local
+// row i): the wrapper instantiates the local kernel once per i and uses row i of its output only, so the compiler
+// strips the other rows' arithmetic from that instantiation.  Every instance is then useful whatever the block size
+// (only the entity's geometry is recomputed per row), blocks can be small (several resident per CU), and the lane
+// needs ~60 registers.  The instances of a block are grouped by i and every group is padded to whole wavefronts, so
+// a wavefront executes exactly one instantiation.
+__global__ void ocrs_emit(const int32_t *__restrict__ rmap, int ar, int32_t start, int32_t end, const int32_t *__restrict__ rblk,
+                          int32_t nblocks, uint64_t *__restrict__ keys, const int32_t *__restrict__ pinv, int32_t npos) {
+    const int64_t total = ((int64_t)end - start) * ar;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = start + t / ar;
+        const int i = (int)(t % ar);
+        const int32_t r = row_position(pinv, npos, rmap[e * ar + i]);
+        const int32_t b = r >= 0 ? block_of_node(rblk, nblocks, r) : -1;
+        keys[t] = b >= 0 ? (((uint64_t)b << 39) | ((uint64_t)i << 31) | (uint64_t)(uint32_t)e) : ~0ull;
+    }
+}
+
+// segment (block, role) boundaries of the sorted keys: sstart/send per dense segment id b*ar + role; nvalid = number of real keys
+__global__ void ocrs_bounds(const uint64_t *__restrict__ keys, int64_t n, int ar, int32_t *__restrict__ sstart, int32_t *__restrict__ send,
+                            int64_t *__restrict__ nvalid) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = keys[t];
+        if (k == ~0ull) continue;
+        const uint64_t seg = k >> 31;
+        const int64_t id = (int64_t)(seg >> 8) * ar + (int64_t)(seg & 255u);
+        if (t == 0 || (keys[t - 1] >> 31) != seg) sstart[id] = (int32_t)t;
+        if (t + 1 == n || keys[t + 1] == ~0ull || (keys[t + 1] >> 31) != seg) send[id] = (int32_t)(t + 1);
+        if (t + 1 == n || keys[t + 1] == ~0ull) *nvalid = t + 1;
+    }
+}
+
+__global__ void ocrs_padded_counts(const int32_t *__restrict__ sstart, const int32_t *__restrict__ send, int64_t nseg, int64_t *__restrict__ pc) {
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q <= nseg; q += (int64_t)gridDim.x * blockDim.x)
+        pc[q] = q < nseg ? (((int64_t)(send[q] - sstart[q]) + 63) & ~(int64_t)63) : 0;
+}
+
+// one thread per segment: copy the entities, pad with the last one (valid = 0), name the role of every 64-slot chunk
+// interleave > 1: the real instances of a group are stored in the order j -> (j*P) mod cnt, P = the smallest integer >= interleave
+// coprime with cnt -- neighbouring entities share rows and columns, and lanes that add into the SAME accumulator in one
+// ds_add_f64 are serialised
+__global__ void ocrs_fill(const uint64_t *__restrict__ keys, const int32_t *__restrict__ sstart, const int32_t *__restrict__ send,
+                          const int64_t *__restrict__ pstart, int64_t nseg, int ar, int32_t *__restrict__ ent, uint8_t *__restrict__ valid,
+                          uint8_t *__restrict__ chunk_role, int interleave) {
+    // 64 lanes per segment
+    const int lane = threadIdx.x & 63;
+    for (int64_t q = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6; q < nseg; q += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+        const int32_t s0 = sstart[q], cnt = send[q] - s0;
+        if (cnt <= 0) continue;
+        const int64_t o = pstart[q];
+        const int32_t pc = (cnt + 63) & ~63;
+        const int32_t last = (int32_t)(keys[s0 + cnt - 1] & 0x7fffffffu);
+        long long P = 1;
+        if (interleave > 1 && cnt > 1) {
+            for (P = interleave;; ++P) {
+                long long a = P, c = cnt;
+                while (c) { long long t = a % c; a = c; c = t; }
+                if (a == 1) break;
+            }
+        }
+        for (int32_t j = lane; j < pc; j += 64) {
+            ent[o + j] = j < cnt ? (int32_t)(keys[s0 + (int32_t)((j * P) % cnt)] & 0x7fffffffu) : last;
+            valid[o + j] = j < cnt ? 1 : 0;
+            if ((j & 63) == 0) chunk_role[(o + j) >> 6] = (uint8_t)(q % ar);
+        }
+    }
+}
+
+__global__ void ocrs_block_offsets(const int64_t *__restrict__ pstart, int32_t nblocks, int ar, int32_t *__restrict__ off) {
+    for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b <= nblocks; b += (int64_t)gridDim.x * blockDim.x)
+        off[b] = (int32_t)pstart[b * ar];
+}
+
+// per-instance tables of a sliced plan for one pair of lgmaps: slot[t] = offset of the instance's row inside the block's
+// accumulator (0xffff: padding slot, or row dropped by the row lgmap), kk[t][j] = position of column cmap[e][j] inside that
+// CSR row (all-ones: negative map entry, or column dropped by the column lgmap -- MatSetValuesLocal ignores negative indices)
+template <class KT>
+__global__ void ocrs_tables_k(const int32_t *__restrict__ inst_off, int32_t nblocks, const int32_t *__restrict__ ent,
+                              const uint8_t *__restrict__ valid, const uint8_t *__restrict__ chunk_role, int64_t ninst,
+                              const int32_t *__restrict__ rmap, int ar, const int32_t *__restrict__ cmap, int ac,
+                              const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                              const int32_t *__restrict__ acc_by_node, const int32_t *__restrict__ acc_by_pos,
+                              const int32_t *__restrict__ rblk, const int32_t *__restrict__ rlg, const int32_t *__restrict__ clg,
+                              uint16_t *__restrict__ slot, KT *__restrict__ kk, int32_t *__restrict__ err) {
+    const KT SKIP = (KT)~(KT)0;
+    const int64_t total = ninst * ac;
+    for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u < total; u += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = u / ac;
+        const int j = (int)(u - t * ac);
+        const int role = chunk_role[t >> 6];
+        const int32_t e = ent[t];
+        const int32_t r = rmap[(int64_t)e * ar + role];
+        const bool live = valid[t] && r >= 0 && !(rlg && rlg[r] < 0);
+        if (j == 0) {
+            uint16_t sl = 0xffffu;
+            if (live) {
+                int lo = 0, hi = nblocks - 1;                  // block of instance t: largest b with inst_off[b] <= t
+                while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (inst_off[mid] <= t) lo = mid; else hi = mid - 1; }
+                const int32_t d = acc_by_node[r] - acc_by_pos[rblk[lo]];
+                if (d < 0 || d >= 0xffff) atomicExch(err, 2); else sl = (uint16_t)d;
+            }
+            slot[t] = sl;
+        }
+        KT v = SKIP;
+        const int32_t c = cmap[(int64_t)e * ac + j];
+        if (live && c >= 0 && !(clg && clg[c] < 0)) {
+            int lo = rowptr[r], hi = rowptr[r + 1] - 1, pos = -1;
+            while (lo <= hi) {
+                int mid = (lo + hi) >> 1;
+                int cv = colidx[mid];
+                if (cv == c) { pos = mid; break; }
+                if (cv < c) lo = mid + 1; else hi = mid - 1;
+            }
+            if (pos >= 0) v = (KT)(pos - rowptr[r]); else atomicExch(err, 1);
+        }
+        kk[u] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1035,8 +1163,126 @@ int fd_ocrplan_free(fd_ocrplan_t p) {
     if (p->inst_off) FD_HIP(hipFree(p->inst_off));
     if (p->inst_ent) FD_HIP(hipFree(p->inst_ent));
     if (p->rblk) FD_HIP(hipFree(p->rblk));
+    if (p->chunk_role) FD_HIP(hipFree(p->chunk_role));
+    if (p->valid) FD_HIP(hipFree(p->valid));
     free(p->inst_off_host);
     delete p;
+    return 0;
+}
+
+int fd_ocrplan_create_sliced(const int32_t *rmap_dev, int ar, int32_t start, int32_t end, const int32_t *block_starts_host,
+                             int32_t nblocks, const int32_t *pinv_dev, int32_t npos, int interleave, fd_stream_t s_, fd_ocrplan_t *out) {
+    hipStream_t s = fd::st(s_);
+    if (!rmap_dev || !out || ar <= 0 || ar > 255 || nblocks < 0 || nblocks >= (1 << 24) || end < start || !block_starts_host)
+        FD_FAIL("fd_ocrplan_create_sliced: bad arguments");
+    auto *p = new fd_ocrplan_s;
+    p->nblocks = nblocks;
+    p->pinv = pinv_dev; p->npos = npos; p->sliced_ar = ar;
+    FD_HIP(hipMalloc(&p->rblk, ((size_t)nblocks + 1) * 4));
+    FD_HIP(hipMemcpyAsync(p->rblk, block_starts_host, ((size_t)nblocks + 1) * 4, hipMemcpyHostToDevice, s));
+    FD_HIP(hipMalloc(&p->inst_off, ((size_t)nblocks + 1) * 4));
+    p->inst_off_host = (int32_t *)calloc((size_t)nblocks + 1, 4);
+    const int64_t nkeys = ((int64_t)end - start) * ar;
+    if (nblocks == 0 || nkeys == 0) {
+        FD_HIP(hipMemsetAsync(p->inst_off, 0, ((size_t)nblocks + 1) * 4, s));
+        *out = p; return 0;
+    }
+    if (nkeys > 2147483647ll) FD_FAIL("fd_ocrplan_create_sliced: too many (entity, row) pairs");
+    uint64_t *k1 = nullptr, *k2 = nullptr;
+    FD_HIP(hipMalloc(&k1, (size_t)nkeys * 8));
+    FD_HIP(hipMalloc(&k2, (size_t)nkeys * 8));
+    hipLaunchKernelGGL(ocrs_emit, dim3(mp_grid(nkeys)), dim3(256), 0, s, rmap_dev, ar, start, end, p->rblk, nblocks, k1, p->pinv, p->npos);
+    FD_CHECK_LAUNCH();
+    size_t tb = 0;
+    hipcub::DoubleBuffer<uint64_t> db(k1, k2);
+    FD_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, db, nkeys, 0, 64, s));
+    void *tmp = nullptr;
+    FD_HIP(hipMalloc(&tmp, tb ? tb : 8));
+    FD_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, tb, db, nkeys, 0, 64, s));
+    const uint64_t *sorted = db.Current();
+    const int64_t nseg = (int64_t)nblocks * ar;
+    int32_t *sstart = nullptr, *send = nullptr;
+    int64_t *pc = nullptr, *pstart = nullptr, *nvalid = nullptr;
+    FD_HIP(hipMalloc(&sstart, (size_t)nseg * 4));
+    FD_HIP(hipMalloc(&send, (size_t)nseg * 4));
+    FD_HIP(hipMalloc(&pc, (size_t)(nseg + 1) * 8));
+    FD_HIP(hipMalloc(&pstart, (size_t)(nseg + 1) * 8));
+    FD_HIP(hipMalloc(&nvalid, 8));
+    FD_HIP(hipMemsetAsync(sstart, 0, (size_t)nseg * 4, s));
+    FD_HIP(hipMemsetAsync(send, 0, (size_t)nseg * 4, s));
+    FD_HIP(hipMemsetAsync(nvalid, 0, 8, s));
+    hipLaunchKernelGGL(ocrs_bounds, dim3(mp_grid(nkeys)), dim3(256), 0, s, sorted, nkeys, ar, sstart, send, nvalid);
+    FD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ocrs_padded_counts, dim3(mp_grid(nseg + 1)), dim3(256), 0, s, sstart, send, nseg, pc);
+    FD_CHECK_LAUNCH();
+    size_t tb2 = 0;
+    FD_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, pc, pstart, (int)(nseg + 1), s));
+    if (tb2 > tb) { FD_HIP(hipFree(tmp)); FD_HIP(hipMalloc(&tmp, tb2)); }
+    FD_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb2, pc, pstart, (int)(nseg + 1), s));
+    int64_t np_ = 0, nv = 0;
+    FD_HIP(hipMemcpyAsync(&np_, pstart + nseg, 8, hipMemcpyDeviceToHost, s));
+    FD_HIP(hipMemcpyAsync(&nv, nvalid, 8, hipMemcpyDeviceToHost, s));
+    FD_HIP(hipStreamSynchronize(s));
+    if (np_ > 2147483647ll) FD_FAIL("fd_ocrplan_create_sliced: too many instances");
+    p->ninst = np_; p->nreal = nv;
+    FD_HIP(hipMalloc(&p->inst_ent, (size_t)(np_ > 0 ? np_ : 1) * 4));
+    FD_HIP(hipMalloc(&p->valid, (size_t)(np_ > 0 ? np_ : 1)));
+    FD_HIP(hipMalloc(&p->chunk_role, (size_t)(np_ / 64 + 1)));
+    if (np_ > 0) {
+        hipLaunchKernelGGL(ocrs_fill, dim3(mp_grid(nseg * 64)), dim3(256), 0, s, sorted, sstart, send, pstart, nseg, ar, p->inst_ent,
+                           p->valid, p->chunk_role, interleave);
+        FD_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(ocrs_block_offsets, dim3(mp_grid((int64_t)nblocks + 1)), dim3(256), 0, s, pstart, nblocks, ar, p->inst_off);
+    FD_CHECK_LAUNCH();
+    FD_HIP(hipMemcpyAsync(p->inst_off_host, p->inst_off, ((size_t)nblocks + 1) * 4, hipMemcpyDeviceToHost, s));
+    FD_HIP(hipStreamSynchronize(s));
+    for (int32_t b = 0; b < nblocks; ++b) {
+        int d = p->inst_off_host[b + 1] - p->inst_off_host[b];
+        if (d > p->max_inst) p->max_inst = d;
+    }
+    FD_HIP(hipFree(k1)); FD_HIP(hipFree(k2)); FD_HIP(hipFree(tmp)); FD_HIP(hipFree(sstart)); FD_HIP(hipFree(send));
+    FD_HIP(hipFree(pc)); FD_HIP(hipFree(pstart)); FD_HIP(hipFree(nvalid));
+    *out = p;
+    return 0;
+}
+
+int fd_ocrplan_sliced_arrays(fd_ocrplan_t p, const uint8_t **chunk_role_dev, const uint8_t **valid_dev, int64_t *nreal) {
+    if (!p || !p->sliced_ar) FD_FAIL("fd_ocrplan_sliced_arrays: not a sliced plan");
+    if (chunk_role_dev) *chunk_role_dev = p->chunk_role;
+    if (valid_dev) *valid_dev = p->valid;
+    if (nreal) *nreal = p->nreal;
+    return 0;
+}
+
+int fd_ocrplan_sliced_tables(fd_ocrplan_t p, const int32_t *rmap_dev, const int32_t *cmap_dev, int ac, const int32_t *rowptr_dev,
+                             const int32_t *colidx_dev, const int32_t *acc_by_node_dev, const int32_t *acc_by_pos_dev,
+                             const int32_t *row_lgmap_dev, const int32_t *col_lgmap_dev, int kbytes, uint16_t *slot_out_dev,
+                             void *kk_out_dev, fd_stream_t s_) {
+    if (!p || !p->sliced_ar || !rmap_dev || !cmap_dev || ac <= 0 || !rowptr_dev || !colidx_dev || !acc_by_node_dev || !acc_by_pos_dev ||
+        !slot_out_dev || !kk_out_dev || (kbytes != 1 && kbytes != 2))
+        FD_FAIL("fd_ocrplan_sliced_tables: bad arguments");
+    if (p->ninst == 0) return 0;
+    hipStream_t s = fd::st(s_);
+    int32_t *err = nullptr;
+    FD_HIP(hipMalloc(&err, 4));
+    FD_HIP(hipMemsetAsync(err, 0, 4, s));
+    const int64_t total = p->ninst * ac;
+    if (kbytes == 1)
+        hipLaunchKernelGGL(ocrs_tables_k<uint8_t>, dim3(mp_grid(total)), dim3(256), 0, s, p->inst_off, p->nblocks, p->inst_ent, p->valid,
+                           p->chunk_role, p->ninst, rmap_dev, p->sliced_ar, cmap_dev, ac, rowptr_dev, colidx_dev, acc_by_node_dev,
+                           acc_by_pos_dev, p->rblk, row_lgmap_dev, col_lgmap_dev, slot_out_dev, (uint8_t *)kk_out_dev, err);
+    else
+        hipLaunchKernelGGL(ocrs_tables_k<uint16_t>, dim3(mp_grid(total)), dim3(256), 0, s, p->inst_off, p->nblocks, p->inst_ent, p->valid,
+                           p->chunk_role, p->ninst, rmap_dev, p->sliced_ar, cmap_dev, ac, rowptr_dev, colidx_dev, acc_by_node_dev,
+                           acc_by_pos_dev, p->rblk, row_lgmap_dev, col_lgmap_dev, slot_out_dev, (uint16_t *)kk_out_dev, err);
+    FD_CHECK_LAUNCH();
+    int32_t h = 0;
+    FD_HIP(hipMemcpyAsync(&h, err, 4, hipMemcpyDeviceToHost, s));
+    FD_HIP(hipStreamSynchronize(s));
+    FD_HIP(hipFree(err));
+    if (h == 1) FD_FAIL("fd_ocrplan_sliced_tables: an element-matrix entry is not in the sparsity pattern");
+    if (h == 2) FD_FAIL("fd_ocrplan_sliced_tables: a row block holds more than 65534 matrix entries");
     return 0;
 }
 

@@ -38,6 +38,10 @@ __device__ __forceinline__ int xcd_block(int bid, int nb) {
     return x * q + (x < r ? x : r) + k;
 }
 
+// A value the caller knows to be equal in all lanes of the wavefront (the row index of a sliced instance chunk): moving it
+// to a scalar register turns the switch on it into scalar branches -- no divergence bookkeeping, one instantiation executed.
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 // ---- global atomics (compiled with -munsafe-fp-atomics => global_atomic_add_f64) ----
 template <class T> __device__ __forceinline__ void atomic_add(T *p, T v) { atomicAdd(p, v); }
 template <> __device__ __forceinline__ void atomic_add<long long>(long long *p, long long v) {

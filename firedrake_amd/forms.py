@@ -432,11 +432,13 @@ def precompile_all():
         for lg in (False, True):
             gj = GlobalKernel(kjac, [MatKernelArg(((1,), (1,)), (cm, cm), lgmaps=lg), DatKernelArg((dim,), xm)])
             for g in (gk, gj):
-                from .codegen import ocr_eligible
-                for mode in ("staged", "direct", "ocr"):
+                from .codegen import ocr_eligible, sliced_eligible
+                for mode in ("staged", "direct", "ocr", "ocrs"):
                     if mode == "staged" and not staged_eligible(g):
                         continue
                     if mode.startswith("ocr") and not ocr_eligible(g):
+                        continue
+                    if mode == "ocrs" and not sliced_eligible(g):
                         continue
                     src = generate_wrapper(g, mode)
                     out.append(compile_hip(src.source, src.symbol))

@@ -426,8 +426,8 @@ class GlobalKernel:
         from .compilation import compile_hip, kernel_resources
         from .configuration import configuration
         limit = configuration["auto_occupancy_scratch"]
-        if limit < 0 or configuration["min_waves"] or not (mode.startswith("staged") or mode.startswith("ocr")):
-            return src, path
+        if limit < 0 or configuration["min_waves"] or not (mode.startswith("staged") or mode.startswith("ocr")) or mode.startswith("ocrs"):
+            return src, path            # (row-sliced loops are LDS-limited: ~90 registers per lane)
         res = kernel_resources(path, src.symbol)
         if not res or "occupancy" not in res:
             return src, path

@@ -1959,6 +1959,79 @@ class OcrPlan:
             pass
 
 
+class SlicedOcrPlan:
+    """Row-sliced owner-computes-rows plan (fd_ocrplan_create_sliced): instances are (entity, local row), grouped by local
+    row inside every row block and padded to whole wavefronts.  ``plans`` = node plans of the staged READ maps over the
+    (padded) instance blocks; ``tables(rlg, clg)`` = the per-instance accumulator slots / column positions for one pair of
+    lgmaps, built on first use and kept for the last few pairs (a BC set is assembled many times)."""
+
+    MAX_TABLE_SETS = 3
+
+    def __init__(self, sparsity, rmap: Map, cmap: Map, staged_maps, start, end, row_blocks, row_order=None):
+        self.row_blocks = rb = np.ascontiguousarray(row_blocks, dtype=np.int32)
+        nb = len(rb) - 1
+        self.row_order = row_order
+        self._sp, self._rmap, self._cmap = sparsity, rmap._base(), cmap._base()
+        h = ctypes.c_void_p()
+        _lib.call("fd_ocrplan_create_sliced", self._rmap._dev_values(), rmap.arity, int(start), int(end), rb.ctypes.data, nb,
+                  row_order.pinv.ptr if row_order is not None else None, row_order.npos if row_order is not None else 0,
+                  int(configuration["ocrs_interleave"]), None, ctypes.byref(h))
+        self.h = h.value
+        ni, mi = ctypes.c_int64(), ctypes.c_int32()
+        _lib.call("fd_ocrplan_info", self.h, ctypes.byref(ni), ctypes.byref(mi))
+        self.ninst, self.max_inst, self.nblocks = ni.value, mi.value, nb
+        p = [ctypes.c_void_p() for _ in range(4)]
+        _lib.call("fd_ocrplan_arrays", self.h, *[ctypes.byref(x) for x in p])
+        self.inst_off, inst_off_host, self.inst_ent, self.rblk = (x.value for x in p)
+        self.inst_off_host = np.ctypeslib.as_array(ctypes.cast(inst_off_host, ctypes.POINTER(ctypes.c_int32)), shape=(nb + 1,)).copy()
+        cr, va, nr = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64()
+        _lib.call("fd_ocrplan_sliced_arrays", self.h, ctypes.byref(cr), ctypes.byref(va), ctypes.byref(nr))
+        self.chunk_role, self.valid, self.nreal = cr.value, va.value, nr.value
+        rp = sparsity._node_rowptr.download(np.int32, (sparsity.dsets[0].set.total_size + 1,))
+        self.rows_end = int(rb[-1])
+        self.vals_end = int(rp[rb[-1]])
+        acc = row_order.prowptr_host if row_order is not None else rp
+        self.max_nnz = int(np.diff(acc[rb]).max()) if nb else 0
+        self.max_nown = int(np.diff(rb).max()) if nb else 0
+        maxlen = int(np.diff(rp).max()) if len(rp) > 1 else 0
+        self.kbytes = 1 if maxlen <= 254 else 2
+        self.plans, self._imaps = {}, {}
+        for key, m in staged_maps.items():
+            imap = DeviceBuffer(max(self.ninst, 1) * m.arity * 4)
+            _lib.call("fd_gather_rows", m._base()._dev_values(), m.arity, self.inst_ent, self.ninst, imap.ptr, None)
+            self._imaps[key] = imap
+            self.plans[key] = Plan(imap.ptr, 0, int(self.ninst), 0, self.inst_off_host, arity=m.arity)
+        self._tables = {}
+
+    def tables(self, rlg, clg, lgmap_ptr):
+        """(slot buffer, column-position buffer) for the lgmap objects ``rlg`` / ``clg`` (None = no masking);
+        ``lgmap_ptr(obj)`` gives the device pointer of an lgmap.  Keyed by object identity (lgmaps are immutable, like the
+        reference's PETSc LGMaps); the entry keeps the objects alive so that an id cannot be recycled."""
+        key = (id(rlg), id(clg))
+        t = self._tables.pop(key, None)
+        if t is None:
+            slot = DeviceBuffer(max(self.ninst, 1) * 2)
+            kk = DeviceBuffer(max(self.ninst, 1) * self._cmap.arity * self.kbytes)
+            sp, ro = self._sp, self.row_order
+            _lib.call("fd_ocrplan_sliced_tables", self.h, self._rmap._dev_values(), self._cmap._dev_values(), self._cmap.arity,
+                      sp._node_rowptr.ptr, sp._node_colidx.ptr, ro.nstart.ptr if ro is not None else sp._node_rowptr.ptr,
+                      ro.prowptr.ptr if ro is not None else sp._node_rowptr.ptr,
+                      lgmap_ptr(rlg) if rlg is not None else None, lgmap_ptr(clg) if clg is not None else None,
+                      self.kbytes, slot.ptr, kk.ptr, None)
+            t = (slot, kk, rlg, clg)
+            while len(self._tables) >= self.MAX_TABLE_SETS:
+                self._tables.pop(next(iter(self._tables)))
+        self._tables[key] = t                       # most recently used last
+        return t[0], t[1]
+
+    def __del__(self):
+        try:
+            if self.h:
+                _lib.load().fd_ocrplan_free(self.h)
+        except Exception:
+            pass
+
+
 class RowOrder:
     """A backend-derived order of the rows [0, npos) of a sparsity: ``plist[p]`` = p-th row, ``pinv[row]`` = its position,
     ``prowptr`` = CSR row starts in that order (device + host copy).  Built from an entity order by the first-touch rule

@@ -728,6 +728,8 @@ class Parloop:
         from .op2types import OcrPlan
         from .codegen import lds_stride, mode_variant
         src = prep["cw"].src
+        if src.mode.startswith("ocrs"):
+            return self._ocrs_geometry(start, end, gkey)
         maps = prep["maps"]
         (k, pa), = [(k, a) for k, a in enumerate(self.arguments) if isinstance(a, MatParloopArg)]
         rmap, cmap = pa.maps
@@ -807,6 +809,65 @@ class Parloop:
                   f"lds={lds} kbytes={op.kbytes}", file=sys.stderr)
         return geo
 
+    def _ocrs_geometry(self, start, end, gkey):
+        """Row-sliced owner-computes-rows plan (codegen.generate_sliced_wrapper): no instance is redundant, so the row blocks
+        are sized for occupancy alone -- ranges of ~``ocrs_nnz_per_block`` accumulator entries of the caller's row order
+        (producer hints present: that order is compact already) or of the backend-derived one."""
+        from .op2types import RowOrder, SlicedOcrPlan
+        from .codegen import lds_stride, mode_variant
+        prep = self._prepared
+        src = prep["cw"].src
+        maps = prep["maps"]
+        (k, pa), = [(k, a) for k, a in enumerate(self.arguments) if isinstance(a, MatParloopArg)]
+        rmap, cmap = pa.maps
+        sp = pa.data.sparsity
+        sp._build()
+        nrows = rmap.toset.size
+        rp = sp._node_rowptr.download(np.int32, (rmap.toset.total_size + 1,))
+        row_order = None
+        prp = rp[:nrows + 1]
+        hint = getattr(rmap._base(), "preferred_node_blocks", None)
+        if hint is None or not configuration["use_preferred_blocks"]:
+            order = self._locality_order(start, end)
+            if order is not None:
+                row_order = RowOrder(rmap, order, end - start, nrows, rp)
+                prp = row_order.prowptr_host
+        cap = max(int(configuration["ocrs_nnz_per_block"]), int(np.diff(prp).max()) if nrows else 1)
+        staged = {mi: maps[mi] for mi in src.staged_maps}
+        limit = configuration["lds_limit"]
+        for attempt in range(8):
+            targets = np.arange(0, int(prp[nrows]) + cap, cap)
+            rb = np.unique(np.concatenate([np.searchsorted(prp[:nrows + 1], targets, side="left"), [0, nrows]]))
+            rb = rb[rb <= nrows]
+            try:
+                op = SlicedOcrPlan(sp, rmap, cmap, staged, start, end, rb, row_order=row_order)
+            except _lib.FDHipError as exc:
+                if "map entries" not in str(exc):
+                    raise
+                cap //= 2
+                continue
+            lds = ((op.max_nnz * 8) + 15) // 16 * 16
+            for item in src.lds_items:
+                if item[0] == "dat":
+                    _, mi, c, isz, _ = item
+                    lds += ((lds_stride(op.plans[mi].max_nd, ocr=True) * c * isz) + 15) // 16 * 16
+            if lds <= limit and op.max_nnz < 0xffff:
+                break
+            cap //= 2
+        else:
+            raise PlanDoesNotFit("row-sliced owner-computes-rows plan does not fit")
+        nds = [op.plans[mi].max_nd for mi in src.staged_maps]
+        variant = mode_variant("ocrsp" if row_order is not None else "ocrs", op.kbytes, nds)
+        geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz,
+               "cw": prep["cw"] if variant == src.mode else self.global_kernel.compile(variant), "row_order": row_order}
+        prep["parts"][gkey] = geo
+        if configuration["debug"]:
+            import sys
+            print(f"[fdhip] {self.global_kernel.name} OCR row-sliced [{start},{end}): row blocks={op.nblocks} instances={op.nreal} "
+                  f"(+{op.ninst - op.nreal} padding, x{op.nreal / max((end - start) * rmap.arity, 1):.2f} of the map entries) "
+                  f"max_inst={op.max_inst} max_nnz={op.max_nnz} max_nown={op.max_nown} lds={lds} kbytes={op.kbytes}", file=sys.stderr)
+        return geo
+
     def _compute_ocr(self, start=0, end=None):
         geo = self._ocr_geometry(start, end)
         prep = self._prepared
@@ -856,6 +917,12 @@ class Parloop:
                 out.append(self.arguments[desc[1]].data.sparsity._node_rowptr.ptr)
             elif kind == "ocr_kidx":
                 out.append(op.kidx.ptr)
+            elif kind == "ocrs_chunk_role":
+                out.append(op.chunk_role)
+            elif kind in ("ocrs_slot", "ocrs_kk"):
+                lg = self.arguments[desc[1]].lgmaps
+                tabs = op.tables(lg[0] if lg else None, lg[1] if lg else None, self._lgmap)
+                out.append(tabs[0 if kind == "ocrs_slot" else 1].ptr)
             elif kind == "ocr_maxnnz":
                 out.append(op.max_nnz)
             elif kind == "ocr_maxnown":

@@ -196,6 +196,26 @@ int fd_ocrplan_info(fd_ocrplan_t p, int64_t *ninst, int32_t *max_inst_per_block)
 int fd_ocrplan_arrays(fd_ocrplan_t p, const int32_t **inst_off_dev, const int32_t **inst_off_host,
                       const int32_t **inst_entity_dev, const int32_t **row_block_starts_dev);
 int fd_ocrplan_free(fd_ocrplan_t p);
+/* Row-sliced owner-computes-rows plans (large element matrices): an instance is (entity, local row i) for every row-map
+ * entry that falls into a row block -- the wrapper instantiates the local kernel once per i and keeps row i of its
+ * output, so no instance is redundant whatever the block size.  The instance list of a block is grouped by i and each
+ * group is padded to a multiple of 64 slots (one wavefront = one i): fd_ocrplan_info reports the PADDED count,
+ * fd_ocrplan_arrays the padded offsets / entities (padding repeats a real entity), fd_ocrplan_sliced_arrays the local
+ * row index of every 64-slot chunk, the per-slot validity bytes and the number of real instances.  pinv_dev (nullable)
+ * = row order as in fd_ocrplan_create_ordered.  fd_ocrplan_sliced_tables fills, for ONE pair of lgmaps (nullable), the
+ * per-instance accumulator slot of the row (0xffff = padding or row dropped: negative map entry / negative row lgmap,
+ * MatSetValuesLocal semantics, builder.py:573-625) and the positions of the entity's columns inside that CSR row
+ * (all-ones = dropped); acc_by_node[r] - acc_by_pos[block start] is the row's offset in the block accumulator
+ * (node_rowptr twice for the caller's row order; nstart / prowptr of a RowOrder otherwise). */
+int fd_ocrplan_create_sliced(const int32_t *rmap_dev, int rarity, int32_t start, int32_t end,
+                             const int32_t *block_starts_host, int32_t nblocks, const int32_t *pinv_dev, int32_t npos,
+                             int interleave, fd_stream_t s, fd_ocrplan_t *out);   /* interleave > 1: the instances of a group
+                             * in the order j -> (j*P) mod count, P = smallest integer >= interleave coprime with count */
+int fd_ocrplan_sliced_arrays(fd_ocrplan_t p, const uint8_t **chunk_role_dev, const uint8_t **valid_dev, int64_t *nreal);
+int fd_ocrplan_sliced_tables(fd_ocrplan_t p, const int32_t *rmap_dev, const int32_t *cmap_dev, int carity,
+                             const int32_t *rowptr_dev, const int32_t *colidx_dev, const int32_t *acc_by_node_dev,
+                             const int32_t *acc_by_pos_dev, const int32_t *row_lgmap_dev, const int32_t *col_lgmap_dev,
+                             int kbytes, uint16_t *slot_out_dev, void *kk_out_dev, fd_stream_t s);
 int fd_gather_rows(const int32_t *src_dev, int arity, const int32_t *idx_dev, int64_t n, int32_t *dst_dev, fd_stream_t s);
 int fd_csr_elem_row_offsets(const int32_t *rowptr_dev, const int32_t *colidx_dev, const int32_t *rmap_dev,
                             const int32_t *cmap_dev, int32_t nent, int rarity, int carity, int kbytes,

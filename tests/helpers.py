@@ -170,6 +170,55 @@ def ocr_plan_ref(rmapv, cmapv, nent, row_blocks, rowptr, colidx, pinv=None):
     return np.array(inst_off, np.int32), inst_ent, kidx
 
 
+def ocrs_plan_ref(rmapv, cmapv, start, end, row_blocks, rowptr, colidx, acc_by_node, acc_by_pos, pinv=None, rlg=None, clg=None,
+                  interleave=0):
+    """numpy restatement of the row-sliced plan (include/fdhip.h: fd_ocrplan_create_sliced + fd_ocrplan_sliced_tables):
+    instances (entity, local row i) for every row-map entry inside a row block, per block grouped by i (entity order inside
+    a group), every group padded to a multiple of 64 slots with copies of its last entity.  Returns (padded inst_off,
+    inst_ent, chunk_role, valid, slot, kk)."""
+    ar, ac = rmapv.shape[1], cmapv.shape[1]
+    rows = np.asarray(rmapv)[start:end]
+    pos = rows
+    if pinv is not None:
+        pos = np.where((rows >= 0) & (rows < len(pinv)), np.asarray(pinv)[np.clip(rows, 0, len(pinv) - 1)], -1)
+    inst_off, ent, role, valid = [0], [], [], []
+    for b in range(len(row_blocks) - 1):
+        n = 0
+        for i in range(ar):
+            es = start + np.nonzero((pos[:, i] >= row_blocks[b]) & (pos[:, i] < row_blocks[b + 1]))[0]
+            if len(es) == 0:
+                continue
+            last = es[-1]                                   # the padding repeats the last entity of the group in entity order
+            if interleave > 1 and len(es) > 1:
+                P = next(q for q in range(interleave, interleave + len(es) + 2) if np.gcd(q, len(es)) == 1)
+                es = es[(np.arange(len(es)) * P) % len(es)]
+            pad = -len(es) % 64
+            ent += [es, np.full(pad, last)]
+            valid += [np.ones(len(es), np.uint8), np.zeros(pad, np.uint8)]
+            role += [np.full((len(es) + pad) // 64, i, np.uint8)]
+            n += len(es) + pad
+        inst_off.append(inst_off[-1] + n)
+    cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)
+    ent, role, valid = cat(ent, np.int32), cat(role, np.uint8), cat(valid, np.uint8)
+    slot = np.full(len(ent), 0xffff, dtype=np.uint16)
+    kk = np.full((len(ent), ac), 0xff, dtype=np.uint8)
+    blk = np.searchsorted(np.asarray(inst_off), np.arange(len(ent)), side="right") - 1
+    for t, e in enumerate(ent):
+        r = rmapv[e, role[t // 64]]
+        if not valid[t] or r < 0 or (rlg is not None and rlg[r] < 0):
+            continue
+        slot[t] = acc_by_node[r] - acc_by_pos[row_blocks[blk[t]]]
+        row = colidx[rowptr[r]:rowptr[r + 1]]
+        for j in range(ac):
+            c = cmapv[e, j]
+            if c < 0 or (clg is not None and clg[c] < 0):
+                continue
+            q = int(np.searchsorted(row, c))
+            assert q < len(row) and row[q] == c and q < 255
+            kk[t, j] = q
+    return np.array(inst_off, np.int32), ent, role, valid, slot, kk
+
+
 def lane_slot_to_entity(n, T):
     """numpy restatement of the lane order (include/fdhip.h: fd_plan_set_lane_order): slot k*T + t holds the k-th
     entity of lane t's contiguous run; the first n % T runs are one longer."""

@@ -249,6 +249,109 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None):
     return csr
 
 
+def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None):
+    """Execute a matrix-assembly Parloop ``pl`` with the ROW-SLICED owner-computes-rows wrapper on the host (one OS thread
+    per lane).  Plan tables from helpers.ocrs_plan_ref, CSR pattern from the oracle.  Returns the OracleCSR."""
+    import re
+    from firedrake_amd.codegen import mode_variant, ocr_eligible
+    from helpers import first_touch_ref, ocrs_plan_ref, plan_ref_blocks
+    gk = pl.global_kernel
+    assert ocr_eligible(gk)
+    (k, mpa), = [(k, pa) for k, pa in enumerate(pl.arguments) if isinstance(pa, MatParloopArg)]
+    maps = []
+    for pa in pl.arguments:
+        for m in getattr(pa, "maps", ()):
+            if all(m._base() is not q for q in maps):
+                maps.append(m._base())
+    base = generate_wrapper(gk, "ocrs")
+    T = base.block_threads
+    csr = oracle_pattern(mpa.data.sparsity)
+    rmap, cmap = (m._base() for m in mpa.maps)
+    nent = pl.iterset.size
+    nrows = rmap.toset.size
+    plist = pinv = None
+    acc = csr.rowptr
+    acc_by_node = csr.rowptr
+    if order is not None:
+        plist, pinv = first_touch_ref(np.asarray(rmap.values_with_halo), order, nrows)
+        acc = np.concatenate([[0], np.cumsum(np.diff(csr.rowptr)[:nrows][plist])]).astype(np.int32)
+        acc_by_node = np.zeros(max(nrows, 1), dtype=np.int32)
+        acc_by_node[plist] = acc[:-1]
+    targets = np.arange(0, int(acc[nrows]) + nnz_per_block, nnz_per_block)
+    rb = np.unique(np.concatenate([np.searchsorted(acc[:nrows + 1], targets, side="left"), [0, nrows]]))
+    rb = rb[rb <= nrows].astype(np.int32)
+    lg = mpa.lgmaps
+    inst_off, inst_ent, chunk_role, valid, slot, kk = ocrs_plan_ref(
+        np.asarray(rmap.values_with_halo), np.asarray(cmap.values_with_halo), 0, nent, rb, csr.rowptr, csr.colidx, acc_by_node, acc,
+        pinv=pinv, rlg=None if lg is None else np.asarray(lg[0]), clg=None if lg is None else np.asarray(lg[1]))
+    plans = {}
+    for mi in base.staged_maps:
+        blk, lst, lm = plan_ref_blocks(np.asarray(maps[mi].values_with_halo)[inst_ent], inst_off)
+        plans[mi] = (blk, lst, np.ascontiguousarray(lm), int(np.diff(blk).max()) if len(blk) > 1 else 0)
+    max_nnz = int(np.diff(acc[rb]).max())
+    src = generate_wrapper(gk, mode_variant("ocrsp" if order is not None else "ocrs", 1, [plans[mi][3] for mi in base.staged_maps]))
+    text = src.source.replace("extern __shared__ __align__(16) unsigned char fd_lds[];", "unsigned char *fd_lds = fd_sim::lds;")
+    sig = re.search(r'extern "C" __global__[^\n]*void %s\((.*)\)\n' % src.symbol, text).group(1)
+    names = [p.split()[-1].lstrip("*") for p in sig.split(", ")]
+    text += ('\nextern "C" void sim_run(int fd_nblocks, int fd_nthreads, %s)\n{\n  fd_sim::run(fd_nblocks, fd_nthreads, [&] { %s(%s); });\n}\n'
+             % (sig, src.symbol, ", ".join(names)))
+    lib = _compile_mt(text, src.symbol)
+    lib.sim_run.restype = None
+    keep = []
+
+    def ptr(a):
+        a = np.ascontiguousarray(a)
+        keep.append(a)
+        return ctypes.c_void_p(a.ctypes.data)
+
+    if not zero_pending:
+        csr.values[...] = 1.0
+    cargs = [ctypes.c_int(len(rb) - 1), ctypes.c_int(T), ctypes.c_int(0), ctypes.c_int(len(inst_ent))]
+    for desc in src.layout:
+        kind = desc[0]
+        if kind == "arg":
+            pa = pl.arguments[desc[1]]
+            if isinstance(pa, MatParloopArg):
+                cargs.append(ctypes.c_void_p(csr.values.ctypes.data))
+            else:
+                host = pa.data._host if pa.data._host_valid else pa.data._to_host()
+                cargs.append(ptr(np.array(host, copy=True)))
+        elif kind == "map":
+            cargs.append(ptr(np.asarray(maps[desc[1]].values_with_halo, dtype=np.int32)))
+        elif kind == "bstart":
+            cargs.append(ptr(inst_off))
+        elif kind == "ocr_inst_ent":
+            cargs.append(ptr(inst_ent))
+        elif kind == "ocrs_chunk_role":
+            cargs.append(ptr(chunk_role))
+        elif kind == "plan_blkoff":
+            cargs.append(ptr(plans[desc[1]][0]))
+        elif kind == "plan_list":
+            cargs.append(ptr(plans[desc[1]][1]))
+        elif kind == "plan_lmap":
+            cargs.append(ptr(plans[desc[1]][2]))
+        elif kind == "plan_maxnd":
+            cargs.append(ctypes.c_longlong(plans[desc[1]][3]))
+        elif kind == "ocr_rblk":
+            cargs.append(ptr(rb))
+        elif kind in ("ocr_rowptr", "ocr_prowptr"):
+            cargs.append(ptr(np.ascontiguousarray(acc, dtype=np.int32)))
+        elif kind == "ocr_gstart":
+            cargs.append(ptr(np.ascontiguousarray(csr.rowptr[plist], dtype=np.int32)))
+        elif kind == "ocrs_slot":
+            cargs.append(ptr(slot))
+        elif kind == "ocrs_kk":
+            cargs.append(ptr(kk))
+        elif kind == "ocr_maxnnz":
+            cargs.append(ctypes.c_longlong(max_nnz))
+        elif kind == "ocr_flags":
+            cargs.append(ctypes.c_longlong(1 if zero_pending else 0))
+        else:
+            raise AssertionError(f"hostsim (ocrs) cannot provide {kind}")
+    lib.sim_run(*cargs)
+    return csr
+
+
 def run_direct(pl, part=None):
     """Execute Parloop ``pl`` over ``part`` = (offset, size) (default: all owned entities) with the direct
     wrapper on the host.  Returns one array per argument: COPIES of Dat/Global data after the loop, or an

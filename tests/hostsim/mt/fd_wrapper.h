@@ -82,6 +82,7 @@ inline int xcd_block(int bid, int nb) {
     const int x = bid & 7, k = bid >> 3;
     return x * q + (x < r ? x : r) + k;
 }
+inline int wave_uniform(int v) { return v; }
 template <class T> inline void atomic_add(T *p, T v) { fd_sim::cas_update(p, [v](T o) { return o + v; }); }
 template <class T> inline void atomic_min(T *p, T v) { fd_sim::cas_update(p, [v](T o) { return v < o ? v : o; }); }
 template <class T> inline void atomic_max(T *p, T v) { fd_sim::cas_update(p, [v](T o) { return v > o ? v : o; }); }

@@ -124,3 +124,24 @@ def test_periodic_extruded_wrappers_compile():
         pl = op2.LegacyParloop(k, ext, out(op2.INC, cm), x(op2.READ, cm), iteration_region=region)
         assert pl.global_kernel._extruded_periodic
         assert _compile(pl) == ["direct"]
+
+
+def test_row_sliced_wrappers():
+    """The row-sliced owner-computes-rows wrappers ("ocrs": contiguous flush, "ocrsp": row-by-row flush under a row order,
+    8- and 16-bit column positions) cross-compile, each instantiation of the local kernel without scratch."""
+    from firedrake_amd import forms
+    from firedrake_amd.codegen import select_mode
+    from firedrake_amd.compilation import kernel_resources
+    nodes, ele, vs = op2.Set(40), op2.Set(2), op2.Set(8)
+    cm, xm = op2.Map(ele, nodes, 10, np.arange(20)), op2.Map(ele, vs, 4, np.arange(8))
+    mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(cm, cm, None)]))
+    x = op2.Dat(vs ** 3)
+    lg = np.arange(40, dtype=np.int32)
+    pl = op2.LegacyParloop(forms.poisson_jacobian_kernel(3, 2), ele, mat(op2.INC, (cm, cm), lgmaps=(lg, lg)), x(op2.READ, xm))
+    assert select_mode(pl.global_kernel) == "ocrs"
+    for mode in ("ocrs", "ocrsp", "ocrs_k16", "ocrsp_s448"):
+        src = generate_wrapper(pl.global_kernel, mode)
+        assert "rlg" not in src.source and src.source.count("fdk::poisson_p2_tet_jacobian(") == 10
+        path = compile_hip(src.source, src.symbol + "_" + mode)
+        res = kernel_resources(path, src.symbol)
+        assert res and res.get("scratch", 0) == 0 and res.get("vgprs", 999) <= 128

@@ -1,0 +1,144 @@
+"""GPU: the row-sliced owner-computes-rows path (codegen.generate_sliced_wrapper, fd_ocrplan_create_sliced) -- selected for
+matrix loops whose row map has >= 8 entries (P2 tetrahedra: 10).  Plan arrays against the numpy restatement, assembled
+matrices against the oracle's MatSetValuesLocal (builder.py:573-625) and against the unsliced wrapper, lgmap pairs swapped
+between calls like the reference does per assemble (parloop.py:279-314)."""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+from firedrake_amd import forms, mesh as fmesh, op2
+from firedrake_amd.configuration import configuration
+from helpers import oracle_run
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_jac(prob, pl, mat):
+    mpa = pl.arguments[0]
+    args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
+    return oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
+
+
+@pytest.mark.parametrize("ordered,interleave", [(False, 0), (True, 0), (False, 7)])
+def test_sliced_plan_matches_numpy_restatement(ordered, interleave, monkeypatch):
+    from firedrake_amd import _lib
+    from firedrake_amd.device import DeviceBuffer
+    from firedrake_amd.op2types import RowOrder, SlicedOcrPlan
+    from helpers import first_touch_ref, locality_order_ref, ocrs_plan_ref
+    monkeypatch.setitem(configuration, "ocrs_interleave", interleave)
+    m = fmesh.UnitCubeMesh(4, degrees=(2,), perturb=0.1, numbering="random" if ordered else "tiled")
+    V = m.space(2)
+    cm = V.cell_node_map
+    sp = op2.Sparsity((V.node_set ** 1, V.node_set ** 1), [(cm, cm, None)])
+    sp._build()
+    n, nrows = m.cell_set.size, V.node_set.size
+    rp = np.asarray(sp.rowptr)
+    ro, pinv, acc_node, acc_pos = None, None, rp, rp
+    if ordered:
+        order, _ = locality_order_ref(m.coord_space.cell_node_map.values_with_halo, 0, n, np.array(m.coordinates.data_ro))
+        ro = RowOrder(cm, DeviceBuffer.from_numpy(order), n, nrows, rp)
+        plist, pinv = first_touch_ref(cm.values_with_halo, order, nrows)
+        acc_pos = np.concatenate([[0], np.cumsum(np.diff(rp)[:nrows][plist])]).astype(np.int32)
+        acc_node = np.zeros(nrows, dtype=np.int32)
+        acc_node[plist] = acc_pos[:-1]
+    rb = np.unique(np.concatenate([np.arange(0, nrows, 37), [nrows]])).astype(np.int32)
+    op = SlicedOcrPlan(sp, cm, cm, {}, 0, n, rb, row_order=ro)
+    rng = np.random.default_rng(5)
+    rlg = np.arange(V.node_set.total_size, dtype=np.int32)
+    rlg[rng.choice(nrows, nrows // 7, replace=False)] = -1
+    clg = np.arange(V.node_set.total_size, dtype=np.int32)
+    clg[rng.choice(nrows, nrows // 5, replace=False)] = -1
+    for lgs in ((None, None), (rlg, clg)):
+        inst_off, ent, role, valid, slot, kk = ocrs_plan_ref(np.asarray(cm.values_with_halo), np.asarray(cm.values_with_halo), 0, n, rb,
+                                                            rp, np.asarray(sp.colidx), acc_node, acc_pos, pinv=pinv, rlg=lgs[0], clg=lgs[1], interleave=interleave)
+        assert np.array_equal(op.inst_off_host, inst_off) and op.ninst == len(ent) and op.nreal == int(valid.sum())
+        assert op.nreal == int(((np.asarray(cm.values_with_halo)[:n] < nrows)).sum())      # every (entity, owned row) pair exactly once
+
+        def down(ptr, dt, shape):
+            a = np.empty(shape, dtype=dt)
+            _lib.call("fd_memcpy_d2h", a.ctypes.data, ptr, a.nbytes, None)
+            return a
+        assert np.array_equal(down(op.inst_ent, np.int32, (op.ninst,)), ent)
+        assert np.array_equal(down(op.chunk_role, np.uint8, (op.ninst // 64,)), role)
+        assert np.array_equal(down(op.valid, np.uint8, (op.ninst,)), valid)
+        keep = []
+        s_, k_ = op.tables(lgs[0], lgs[1], lambda a: keep.append(DeviceBuffer.from_numpy(a)) or keep[-1].ptr)
+        assert np.array_equal(s_.download(np.uint16, (op.ninst,)), slot)
+        assert np.array_equal(k_.download(np.uint8, kk.shape), kk)
+
+
+@pytest.mark.parametrize("numbering", ["tiled", "lexicographic", "random"])
+@pytest.mark.parametrize("bcs", [False, True])
+def test_p2_jacobian_sliced_against_oracle_and_unsliced(numbering, bcs, monkeypatch):
+    monkeypatch.setitem(configuration, "locality_min_entities", 0)
+    m = fmesh.UnitCubeMesh(7, degrees=(2,), tile=(4, 4, 2), perturb=0.1, numbering=numbering)
+    prob = forms.PoissonProblem(m, 2, bcs=bcs)
+    mat, pl = prob.jacobian()
+    pl._ensure_geometry()
+    assert pl._prepare()["cw"].src.mode.startswith("ocrs")
+    geo = pl._ocr_geometry()
+    assert geo["cw"].src.mode.startswith("ocrsp" if numbering != "tiled" else "ocrs")
+    mat.zero()
+    pl()
+    ref = _oracle_jac(prob, pl, mat)
+    rp, ci, v = mat.csr()
+    assert np.array_equal(rp, ref.rowptr) and np.array_equal(ci, ref.colidx)
+    assert_allclose(v, ref.values, rtol=0, atol=1e-12 * np.abs(ref.values).max())
+    pl()                                                  # no zero(): ADD_VALUES on top of the first assembly
+    assert_allclose(mat.csr()[2], 2.0 * ref.values, rtol=0, atol=2e-12 * np.abs(ref.values).max())
+    # the unsliced owner-computes-rows wrapper on the same problem
+    monkeypatch.setitem(configuration, "ocr_sliced", 0)
+    prob2 = forms.PoissonProblem(m, 2, bcs=bcs)
+    mat2, pl2 = prob2.jacobian()
+    mat2.zero()
+    pl2()
+    assert not pl2._prepare()["cw"].src.mode.startswith("ocrs")
+    assert_allclose(mat2.csr()[2], v, rtol=0, atol=1e-12 * np.abs(ref.values).max())
+
+
+def test_lgmap_pairs_swap_between_calls():
+    """One Parloop, three lgmap pairs in turn (the reference swaps the Mat's lgmaps per call): each pair gets its own slot /
+    column-position tables, earlier pairs are reused, results match the oracle with that pair."""
+    m = fmesh.UnitCubeMesh(5, degrees=(2,), tile=(4, 4, 2), perturb=0.1)
+    prob = forms.PoissonProblem(m, 2, bcs=True)
+    mat, pl = prob.jacobian()
+    mpa = pl.arguments[0]
+    nn = prob.V.node_set.total_size
+    rng = np.random.default_rng(11)
+    pairs = [mpa.lgmaps]
+    for frac in (9, 4):
+        lg = np.arange(nn, dtype=np.int32)
+        lg[rng.choice(nn, nn // frac, replace=False)] = -1
+        pairs.append((lg, np.arange(nn, dtype=np.int32)))
+    for lgs in pairs + pairs[:1]:
+        mpa.lgmaps = lgs
+        mat.zero()
+        pl()
+        ref = _oracle_jac(prob, pl, mat)
+        assert_allclose(mat.csr()[2], ref.values, rtol=0, atol=1e-12 * np.abs(ref.values).max())
+    assert len(pl._ocr_geometry()["ocr"]._tables) == 3
+
+
+def test_sliced_with_direct_and_global_read_arguments():
+    """A high-arity matrix loop whose kernel also reads a direct (cell-wise) Dat and a Global: both reach every
+    instantiation unchanged."""
+    m = fmesh.UnitCubeMesh(4, degrees=(2,), tile=(4, 4, 2), perturb=0.1)
+    V = m.space(2)
+    cm, xm = V.cell_node_map, m.coord_space.cell_node_map
+    sp = op2.Sparsity((V.node_set ** 1, V.node_set ** 1), [(cm, cm, None)])
+    mat = op2.Mat(sp)
+    w = op2.Dat(m.cell_set, np.random.default_rng(2).uniform(0.5, 1.5, m.cell_set.total_size), np.float64)
+    g = op2.Global(2, [0.25, -1.5], np.float64)
+    k = op2.Kernel("""
+static void wk(double *A, const double *x, const double *w, const double *g)
+{
+  const double d = (x[3] - x[0]) * (x[7] - x[1]) + x[11] * g[0];
+  for (int i = 0; i < 10; ++i)
+    for (int j = 0; j < 10; ++j)
+      A[i*10 + j] += w[0] * (d + g[1] * (i + 1)) * (1.0 + 0.125 * j) + (i == j ? x[2] : 0.0);
+}""", "wk")
+    pl = op2.LegacyParloop(k, m.cell_set, mat(op2.INC, (cm, cm)), m.coordinates(op2.READ, xm), w(op2.READ), g(op2.READ))
+    pl()
+    assert pl._prepare()["cw"].src.mode.startswith("ocrs")
+    ref = oracle_run(k, m.cell_set, mat(op2.INC, (cm, cm)), m.coordinates(op2.READ, xm), w(op2.READ), g(op2.READ))[0]
+    assert_allclose(mat.csr()[2], ref.values, rtol=0, atol=1e-12 * np.abs(ref.values).max())

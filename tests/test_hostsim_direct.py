@@ -571,3 +571,34 @@ def test_owner_computes_rows_over_a_row_order_on_host(bcs, numbering):
         if degree == 1:
             got2 = run_ocr(pl, rows_per_block=rpb, zero_pending=False, order=order)
             assert np.abs(got2.values - (ref.values + 1.0)).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
+
+
+@pytest.mark.parametrize("bcs", [False, True])
+@pytest.mark.parametrize("numbering", ["tiled", "random"])
+def test_row_sliced_owner_computes_rows_on_host(bcs, numbering):
+    """"ocrs" / "ocrsp": the row-sliced owner-computes-rows wrapper -- instances (entity, local row) grouped by local row and
+    padded to whole wavefronts, one instantiation of the local kernel per row index, lgmaps folded into the per-instance
+    slot / column-position tables, complete rows flushed contiguously (caller's row order) or row by row (backend-derived
+    order).  P2 (the shape it is selected for) and P1 Jacobians against the oracle's MatSetValuesLocal, several trips per
+    lane, plus accumulation into existing values."""
+    from firedrake_amd import forms, mesh as fmesh
+    from firedrake_amd.codegen import select_mode
+    from helpers import locality_order_ref
+    from hostsim import run_ocrs
+    mesh = fmesh.UnitCubeMesh(3, degrees=(1, 2), perturb=0.1, numbering=numbering)
+    order = None
+    if numbering == "random":
+        pos = np.array(mesh.coordinates.data_ro)
+        order, _ = locality_order_ref(mesh.coord_space.cell_node_map.values_with_halo, 0, mesh.cell_set.size, pos)
+    for degree, cap in ((2, 700), (2, 96), (1, 150)):
+        prob = forms.PoissonProblem(mesh, degree, bcs=bcs)
+        mat, pl = prob.jacobian()
+        assert select_mode(pl.global_kernel) == ("ocrs" if degree == 2 else "ocr")
+        mpa = pl.arguments[0]
+        got = run_ocrs(pl, nnz_per_block=cap, order=order)
+        args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
+        ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
+        assert np.abs(got.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
+        if cap == 96:
+            got2 = run_ocrs(pl, nnz_per_block=cap, zero_pending=False, order=order)
+            assert np.abs(got2.values - (ref.values + 1.0)).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
