@@ -14,10 +14,8 @@ print('step_ms', round(d['ms_per_step'], 4), 'res_ms', round(d['roofline_residua
   grep "OCR" gpurun_out/ab_sliced.err | tail -1 >> $OUT
   grep -i "error\|Traceback" gpurun_out/ab_sliced.err | tail -3 >> $OUT
 }
-run c5 tiled "FDHIP_OCRS_INTERLEAVE=7"
-run c5 tiled "FDHIP_OCRS_INTERLEAVE=7 FDHIP_OCRS_DUMP_SLOTS=1"
-run c5 tiled "FDHIP_OCRS_INTERLEAVE=3"
-run c5 tiled "FDHIP_OCRS_INTERLEAVE=5 FDHIP_OCRS_DUMP_SLOTS=1"
-run c5 tiled "FDHIP_OCRS_INTERLEAVE=7 FDHIP_OCRS_DUMP_SLOTS=1 FDHIP_OCRS_NNZ=3584"
-run c5 tiled "FDHIP_OCRS_INTERLEAVE=7 FDHIP_OCRS_DUMP_SLOTS=1 FDHIP_OCRS_NNZ=4608"
+run c5 tiled "A=1"
+run c5 tiled "FDHIP_OCRS_BLOCK_THREADS=320"
+run c5 tiled "FDHIP_OCRS_BLOCK_THREADS=192 FDHIP_OCRS_NNZ=3072"
+run c5 tiled "FDHIP_OCRS_NNZ=4480"
 cat $OUT
