@@ -51,7 +51,7 @@ def flags():
 
 def _wrapper_header_hash():
     h = hashlib.sha1()
-    for name in ("fd_wrapper.h", "fd_tensor.h"):
+    for name in ("fd_wrapper.h", "fd_tensor.h", "fd_callables.h"):
         with open(os.path.join(_CSRC, name), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()

@@ -167,3 +167,5 @@ template <int ARITY> __device__ __forceinline__ void load_lmap(const uint16_t *_
 }
 
 }  // namespace fdw
+
+#include "fd_callables.h"

@@ -167,7 +167,8 @@ typedef int PetscInt;
 typedef struct oracle_mat oracle_mat;
 int oracle_MatSetValuesBlockedLocal(oracle_mat *A, int nr, const int *rows, int nc, const int *cols, const double *vals, int insert);
 int oracle_MatSetValuesLocal(oracle_mat *A, int nr, const int *rows, int nc, const int *cols, const double *vals, int insert);
-"""
+#include "%s"
+""" % os.path.join(os.path.dirname(os.path.abspath(__file__)), "callables.h")
 
 
 def generate_wrapper(kernel_src: str, kernel_name: str, args, *, subset=False,

@@ -44,3 +44,5 @@ template <class T> struct OpMin { static T f(T a, T b) { return a < b ? a : b; }
 template <class T> struct OpMax { static T f(T a, T b) { return a > b ? a : b; } };
 template <class T, class Op> inline T block_reduce(T v, T *) { return v; }
 }  // namespace fdw
+
+#include "../../oracle/callables.h"

@@ -124,3 +124,5 @@ template <class T, int N> inline void load_packed(const T *p, int (&out)[N]) {
 }
 template <int ARITY> inline void load_lmap(const uint16_t *p, int (&out)[ARITY]) { load_packed<uint16_t, ARITY>(p, out); }
 }  // namespace fdw
+
+#include "../../../oracle/callables.h"
