@@ -142,3 +142,31 @@ static void wk(double *A, const double *x, const double *w, const double *g)
     assert pl._prepare()["cw"].src.mode.startswith("ocrs")
     ref = oracle_run(k, m.cell_set, mat(op2.INC, (cm, cm)), m.coordinates(op2.READ, xm), w(op2.READ), g(op2.READ))[0]
     assert_allclose(mat.csr()[2], ref.values, rtol=0, atol=1e-12 * np.abs(ref.values).max())
+
+
+def test_long_rows_take_16_bit_column_positions():
+    """A hub node shared by 300 eight-node cells: its CSR row has 2101 entries, so the column positions no longer fit a
+    byte ("ocrs_k16") and the hub's block is cut to that one long row."""
+    ncell, ar = 300, 8
+    nn = 1 + ncell * (ar - 1)
+    nodes, cells = op2.Set(nn), op2.Set(ncell)
+    mv = np.zeros((ncell, ar), dtype=np.int32)
+    mv[:, 1:] = 1 + np.arange(ncell * (ar - 1)).reshape(ncell, ar - 1)
+    rng = np.random.default_rng(4)
+    mv = np.stack([rng.permutation(r) for r in mv])              # the hub sits at a different local index in every cell
+    m = op2.Map(cells, nodes, ar, mv)
+    pos = op2.Dat(nodes ** 2, rng.uniform(0, 1, (nn, 2)), np.float64)
+    mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(m, m, None)]))
+    k = op2.Kernel("""
+static void hub(double *A, const double *x)
+{
+  for (int i = 0; i < 8; ++i)
+    for (int j = 0; j < 8; ++j)
+      A[i*8 + j] += (1.0 + i) * x[2*j] - 0.5 * j * x[2*i + 1];
+}""", "hub")
+    pl = op2.LegacyParloop(k, cells, mat(op2.INC, (m, m)), pos(op2.READ, m))
+    pl()
+    geo = pl._ocr_geometry()
+    assert geo["cw"].src.mode.startswith("ocrs") and "_k16" in geo["cw"].src.mode and geo["ocr"].max_nnz >= 2101
+    ref = oracle_run(k, cells, mat(op2.INC, (m, m)), pos(op2.READ, m))[0]
+    assert_allclose(mat.csr()[2], ref.values, rtol=0, atol=1e-12 * np.abs(ref.values).max())
