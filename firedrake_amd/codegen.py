@@ -62,6 +62,7 @@ class WrapperSource:
     mat_staged: dict = field(default_factory=dict)
     lane_threads: int = 0                                  # >0: plans must be in lane order for this many lanes
     ocr_lds_limit: int = 0                                 # LDS budget of an OCR row block (0 = configuration["lds_limit"])
+    extra_flags: tuple = ()                                # per-kernel hipcc flags chosen at JIT time (kernel.GlobalKernel.compile)
 
 
 def _distinct_maps(gk: GlobalKernel):
@@ -157,8 +158,10 @@ def select_mode(gk: GlobalKernel) -> str:
         raise ValueError("FDHIP_MODE=staged but this parloop is not eligible for the staged wrapper")
     if want == "direct":
         return "direct"
+    if ok and configuration["mat_ocr"] and sliced_eligible(gk):
+        return "ocrs"
     if ok and configuration["mat_ocr"] and ocr_eligible(gk):
-        return "ocrs" if sliced_eligible(gk) else "ocr"
+        return "ocr"
     return "staged" if ok else "direct"
 
 
@@ -194,32 +197,40 @@ def staged_eligible(gk: GlobalKernel) -> bool:
     return n_ind > 0
 
 
-def ocr_eligible(gk: GlobalKernel) -> bool:
-    """Owner-computes-rows matrix assembly: the loop's only output is ONE scalar-block Mat with INC access
-    (entities are visited redundantly, so no other argument may be modified)."""
+def _ocr_shape(gk: GlobalKernel):
+    """The Mat argument of a loop that can assemble by owner-computes-rows -- its only output is ONE Mat with INC access,
+    addressed per node (no ``unroll``), everything else READ (entities are visited redundantly, so nothing else may be
+    modified) -- or None."""
     if not staged_eligible(gk):
-        return False
-    nmat = 0
+        return None
+    mats = []
     for a, la in zip(gk.arguments, gk.local_kernel.arguments):
         if isinstance(a, MatKernelArg):
-            (rdim, cdim) = a.dims
-            if la.access != INC or a.unroll or int(np.prod(rdim)) * int(np.prod(cdim)) != 1:
-                return False
-            nmat += 1
+            if la.access != INC or a.unroll:
+                return None
+            mats.append(a)
         elif la.access != READ:
-            return False
-    return nmat == 1
+            return None
+    return mats[0] if len(mats) == 1 else None
+
+
+def ocr_eligible(gk: GlobalKernel) -> bool:
+    """Owner-computes-rows matrix assembly with whole-entity instances: scalar blocks only."""
+    a = _ocr_shape(gk)
+    return a is not None and int(np.prod(a.dims[0])) * int(np.prod(a.dims[1])) == 1
 
 
 def sliced_eligible(gk: GlobalKernel) -> bool:
-    """Row-sliced owner-computes-rows (generate_sliced_wrapper): an owner-computes-rows loop whose row map has at least
-    ``ocr_sliced_min_arity`` entries -- the size from which one row of the element matrix costs much less than the whole
-    (P2 tets: 10 rows; measured on the P2 stiffness kernel: 233 fp64 instructions for one row against 599 for all ten, i.e.
-    the rows share little beyond the geometry, while an unsliced row block recomputes whole entities x2.2-3.4)."""
-    if not configuration["ocr_sliced"] or not ocr_eligible(gk):
+    """Row-sliced owner-computes-rows (generate_sliced_wrapper): an owner-computes-rows loop whose element matrix has at
+    least ``ocr_sliced_min_arity`` scalar rows (row-map arity x row block size) -- the size from which one node's rows cost
+    much less than the whole (P2 tets: 10 rows; measured on the P2 stiffness kernel: 233 fp64 instructions for one row
+    against 599 for all ten, i.e. the rows share little beyond the geometry, while an unsliced row block recomputes whole
+    entities x2.2-3.4).  Vector-valued blocks (MatSetValuesBlockedLocal, builder.py:573-625) are sliced per NODE: an
+    instance owns the ``rbs`` scalar rows of one node."""
+    a = _ocr_shape(gk) if configuration["ocr_sliced"] else None
+    if a is None:
         return False
-    (a,) = [a for a in gk.arguments if isinstance(a, MatKernelArg)]
-    return configuration["ocr_sliced_min_arity"] <= a.maps[0].arity <= 255
+    return a.maps[0].arity <= 255 and a.maps[0].arity * int(np.prod(a.dims[0])) >= configuration["ocr_sliced_min_arity"]
 
 
 def _hoist_includes(code: str):
@@ -850,6 +861,7 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         if isinstance(a, MatKernelArg):
             info["kind"] = "mat"
             info["ar"], info["ac"] = a.maps[0].arity, a.maps[1].arity
+            info["rbs"], info["cbs"] = int(np.prod(a.dims[0])), int(np.prod(a.dims[1]))
         elif isinstance(a, DatKernelArg):
             info["kind"] = "dat"
             info["c"] = int(np.prod(a.dim))
@@ -866,7 +878,8 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             raise TypeError(f"unsupported kernel argument {a!r}")
         infos.append(info)
     (mat,) = [i for i in infos if i["kind"] == "mat"]
-    K, AR, AC = mat["k"], mat["ar"], mat["ac"]
+    K, AR, AC, RB, CB = mat["k"], mat["ar"], mat["ac"], mat["rbs"], mat["cbs"]
+    B = RB * CB            # scalars per (row node, column node) pair; node row r holds its rbs scalar rows back to back
 
     for info in infos:
         k, ct = info["k"], info["ct"]
@@ -891,6 +904,8 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     if ordered:
         P(f"const int *__restrict__ oc{K}_gstart", ("ocr_gstart", K))
     P(f"const unsigned short *__restrict__ oc{K}_slot", ("ocrs_slot", K))
+    if B > 1:
+        P(f"const unsigned short *__restrict__ oc{K}_rowlen", ("ocrs_rowlen", K))
     P(f"const {ktype} *__restrict__ oc{K}_k", ("ocrs_kk", K))
     P(f"long long oc{K}_maxnnz", ("ocr_maxnnz", K))
     P(f"long long oc{K}_flags", ("ocr_flags", K))
@@ -920,8 +935,8 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             pack.append(f"{ct} t{k}[{ar * c}];")
             pack.append(f"for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j) t{k}[i*{c}+j] = s{k}[{idx}];")
             call_args.append(f"t{k}")
-    lds_items.append(("ocrs", K))
-    lds_decl.append(f"double *sm{K} = (double *)(fd_lds + fd_off); fd_off += (((size_t)oc{K}_maxnnz*8) + 15) & ~(size_t)15;")
+    lds_items.append(("ocrs", K, B))
+    lds_decl.append(f"double *sm{K} = (double *)(fd_lds + fd_off); fd_off += (((size_t)oc{K}_maxnnz*{B}*8) + 15) & ~(size_t)15;")
 
     includes, body = _hoist_includes(lk.code)
     sym = f"wrap_{lk.name}"
@@ -937,7 +952,7 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     for mi in staged_maps:
         src.append(f"  const int l0_{mi} = p{mi}_blkoff[b], nd{mi} = p{mi}_blkoff[b+1] - l0_{mi};")
     src += [f"  const int n0 = oc{K}_rblk[b], nown = oc{K}_rblk[b+1] - n0;",
-            f"  const int r0 = oc{K}_rowptr[n0], nnzb = oc{K}_rowptr[n0 + nown] - r0;",
+            f"  const int r0 = oc{K}_rowptr[n0], nnzb = (oc{K}_rowptr[n0 + nown] - r0)*{B};",
             f"  for (int q = tid; q < nnzb; q += nthr) sm{K}[q] = 0;"]
     for mi, acts in stage_nodes.items():
         src.append(f"  for (int i = tid; i < nd{mi}; i += nthr) {{")
@@ -955,6 +970,8 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             for mi in staged_maps]
     rows.append(("kk", AC, f"fdw::load_packed<{ktype}, {AC}>(oc{K}_k + (size_t)(II - start)*{AC}, DST);"))
     scal = [("role", "(int)chunk_role_[(II - start) >> 6]"), ("slot", f"(int)oc{K}_slot[II - start]")]
+    if B > 1:
+        scal.append(("rlen", f"(int)oc{K}_rowlen[II - start]"))
     if need_e:
         scal.append(("e", "inst_ent_[II - start]"))
     pf = bool(configuration["prefetch"])
@@ -978,14 +995,20 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         src += ["    " + l for l in loads("it", "")]
     src += ["    " + s for s in pack]
     src.append("    switch (fdw::wave_uniform(role)) {")
+    NT = AR * RB * AC * CB
     for r in range(AR):
+        # element tensor t[(i*rbs + p)][(j*cbs + q)] (builder.py:573-625); CSR: scalar row (node, p) starts at
+        # node_rowptr[node]*B + p*rowlen*cbs, column (k-th node of the row, q) sits at k*cbs + q
+        if B == 1:
+            scatter = [f"        for (int j = 0; j < {AC}; ++j) if (kk[j] != {skip}) atomicAdd(&sm{K}[slot + kk[j]], t{K}[{r * AC} + j]);"]
+        else:
+            scatter = [f"        for (int p = 0; p < {RB}; ++p) for (int j = 0; j < {AC}; ++j) if (kk[j] != {skip}) for (int q = 0; q < {CB}; ++q)",
+                       f"          atomicAdd(&sm{K}[slot*{B} + (p*rlen + kk[j])*{CB} + q], t{K}[(({r * RB} + p)*{AC} + j)*{CB} + q]);"]
         src += [f"    case {r}: {{",
-                f"      double t{K}[{AR * AC}]; for (int q = 0; q < {AR * AC}; ++q) t{K}[q] = 0;",
+                f"      double t{K}[{NT}]; for (int q = 0; q < {NT}; ++q) t{K}[q] = 0;",
                 f"      fdk::{lk.name}({', '.join(call_args)});",
                 # (dropped contributions branch around the ds_add_f64; sending them to per-lane dump words instead measured 5 % slower)
-                "      if (slot != 0xffff) {",
-                f"        for (int j = 0; j < {AC}; ++j) if (kk[j] != {skip}) atomicAdd(&sm{K}[slot + kk[j]], t{K}[{r * AC} + j]);",
-                "      }",
+                "      if (slot != 0xffff) {", *scatter, "      }",
                 "    } break;"]
     src += ["    default: break;", "    }"]
     if pf:
@@ -995,13 +1018,13 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     src += ["  }", "  __syncthreads();"]
     if ordered:
         src.append(f"  for (int fr = tid >> 4; fr < nown; fr += nthr >> 4) {{ const int fp = n0 + fr; "
-                   f"const int fs = oc{K}_rowptr[fp] - r0, fl = oc{K}_rowptr[fp+1] - oc{K}_rowptr[fp]; "
-                   f"const size_t fd_ = (size_t)oc{K}_gstart[fp]; "
+                   f"const int fs = (oc{K}_rowptr[fp] - r0)*{B}, fl = (oc{K}_rowptr[fp+1] - oc{K}_rowptr[fp])*{B}; "
+                   f"const size_t fd_ = (size_t)oc{K}_gstart[fp]*{B}; "
                    f"if (oc{K}_flags & 1) {{ for (int q = tid & 15; q < fl; q += 16) arg{K}[fd_ + q] = sm{K}[fs + q]; }} "
                    f"else {{ for (int q = tid & 15; q < fl; q += 16) arg{K}[fd_ + q] += sm{K}[fs + q]; }} }}")
     else:
-        src.append(f"  if (oc{K}_flags & 1) {{ for (int q = tid; q < nnzb; q += nthr) arg{K}[(size_t)r0 + q] = sm{K}[q]; }} "
-                   f"else {{ for (int q = tid; q < nnzb; q += nthr) arg{K}[(size_t)r0 + q] += sm{K}[q]; }}")
+        src.append(f"  if (oc{K}_flags & 1) {{ for (int q = tid; q < nnzb; q += nthr) arg{K}[(size_t)r0*{B} + q] = sm{K}[q]; }} "
+                   f"else {{ for (int q = tid; q < nnzb; q += nthr) arg{K}[(size_t)r0*{B} + q] += sm{K}[q]; }}")
     src.append("}")
     if strides is not None:
         if len(strides) != len(staged_maps):

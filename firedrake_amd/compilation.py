@@ -57,11 +57,12 @@ def _wrapper_header_hash():
     return h.hexdigest()
 
 
-def compile_hip(source: str, name: str) -> str:
-    """Return the path of the cached code object for ``source`` (compiling it if needed)."""
+def compile_hip(source: str, name: str, extra_flags=()) -> str:
+    """Return the path of the cached code object for ``source`` (compiling it if needed).  ``extra_flags``: further hipcc
+    arguments for this kernel only (part of the cache key)."""
     cache = configuration["cache_dir"]
     os.makedirs(cache, exist_ok=True)
-    fl = flags()
+    fl = flags() + list(extra_flags)
     # every flag except the include path of this installation (the header's CONTENT is hashed instead)
     keyed = [f for f in fl if f != f"-I{_CSRC}"]
     key = hashlib.sha1("\0".join([source, " ".join(keyed), compiler_version(), _wrapper_header_hash()]).encode()).hexdigest()[:20]

@@ -46,6 +46,9 @@ configuration = {
     # order of the instances inside an owner-computes-rows block: "lane" (fd_plan_set_lane_order), "stencil"
     # (sorted by owned-row signature) or "natural" (entity order)
     "ocr_order": _env("FDHIP_OCR_ORDER", "stencil"),
+    # a wrapper that comes out of hipcc with scratch memory is recompiled with this LLVM -unroll-threshold (0 = never) and the
+    # result kept if the scratch shrinks: element tensors must end up in registers (kernel.GlobalKernel._unrolled_variant)
+    "unroll_retry_threshold": _env("FDHIP_UNROLL_RETRY", 30000, int),
     "min_waves": _env("FDHIP_MIN_WAVES", 0, int),       # 2nd __launch_bounds__ argument (waves per SIMD), 0 = unset
     # occupancy-directed variants: a staged/OCR wrapper whose register count leaves room for one more resident workgroup
     # per CU is recompiled with the matching __launch_bounds__ and kept if that costs at most this many bytes of scratch

@@ -956,7 +956,7 @@ __global__ void ocrs_tables_k(const int32_t *__restrict__ inst_off, int32_t nblo
                               const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                               const int32_t *__restrict__ acc_by_node, const int32_t *__restrict__ acc_by_pos,
                               const int32_t *__restrict__ rblk, const int32_t *__restrict__ rlg, const int32_t *__restrict__ clg,
-                              uint16_t *__restrict__ slot, KT *__restrict__ kk, int32_t *__restrict__ err) {
+                              uint16_t *__restrict__ slot, uint16_t *__restrict__ rowlen, KT *__restrict__ kk, int32_t *__restrict__ err) {
     const KT SKIP = (KT)~(KT)0;
     const int64_t total = ninst * ac;
     for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u < total; u += (int64_t)gridDim.x * blockDim.x) {
@@ -975,6 +975,11 @@ __global__ void ocrs_tables_k(const int32_t *__restrict__ inst_off, int32_t nblo
                 if (d < 0 || d >= 0xffff) atomicExch(err, 2); else sl = (uint16_t)d;
             }
             slot[t] = sl;
+            if (rowlen) {
+                const int32_t rl = r >= 0 ? rowptr[r + 1] - rowptr[r] : 0;
+                if (rl > 0xffff) atomicExch(err, 2);
+                rowlen[t] = (uint16_t)rl;
+            }
         }
         KT v = SKIP;
         const int32_t c = cmap[(int64_t)e * ac + j];
@@ -1258,7 +1263,7 @@ int fd_ocrplan_sliced_arrays(fd_ocrplan_t p, const uint8_t **chunk_role_dev, con
 int fd_ocrplan_sliced_tables(fd_ocrplan_t p, const int32_t *rmap_dev, const int32_t *cmap_dev, int ac, const int32_t *rowptr_dev,
                              const int32_t *colidx_dev, const int32_t *acc_by_node_dev, const int32_t *acc_by_pos_dev,
                              const int32_t *row_lgmap_dev, const int32_t *col_lgmap_dev, int kbytes, uint16_t *slot_out_dev,
-                             void *kk_out_dev, fd_stream_t s_) {
+                             uint16_t *rowlen_out_dev, void *kk_out_dev, fd_stream_t s_) {
     if (!p || !p->sliced_ar || !rmap_dev || !cmap_dev || ac <= 0 || !rowptr_dev || !colidx_dev || !acc_by_node_dev || !acc_by_pos_dev ||
         !slot_out_dev || !kk_out_dev || (kbytes != 1 && kbytes != 2))
         FD_FAIL("fd_ocrplan_sliced_tables: bad arguments");
@@ -1271,11 +1276,11 @@ int fd_ocrplan_sliced_tables(fd_ocrplan_t p, const int32_t *rmap_dev, const int3
     if (kbytes == 1)
         hipLaunchKernelGGL(ocrs_tables_k<uint8_t>, dim3(mp_grid(total)), dim3(256), 0, s, p->inst_off, p->nblocks, p->inst_ent, p->valid,
                            p->chunk_role, p->ninst, rmap_dev, p->sliced_ar, cmap_dev, ac, rowptr_dev, colidx_dev, acc_by_node_dev,
-                           acc_by_pos_dev, p->rblk, row_lgmap_dev, col_lgmap_dev, slot_out_dev, (uint8_t *)kk_out_dev, err);
+                           acc_by_pos_dev, p->rblk, row_lgmap_dev, col_lgmap_dev, slot_out_dev, rowlen_out_dev, (uint8_t *)kk_out_dev, err);
     else
         hipLaunchKernelGGL(ocrs_tables_k<uint16_t>, dim3(mp_grid(total)), dim3(256), 0, s, p->inst_off, p->nblocks, p->inst_ent, p->valid,
                            p->chunk_role, p->ninst, rmap_dev, p->sliced_ar, cmap_dev, ac, rowptr_dev, colidx_dev, acc_by_node_dev,
-                           acc_by_pos_dev, p->rblk, row_lgmap_dev, col_lgmap_dev, slot_out_dev, (uint16_t *)kk_out_dev, err);
+                           acc_by_pos_dev, p->rblk, row_lgmap_dev, col_lgmap_dev, slot_out_dev, rowlen_out_dev, (uint16_t *)kk_out_dev, err);
     FD_CHECK_LAUNCH();
     int32_t h = 0;
     FD_HIP(hipMemcpyAsync(&h, err, 4, hipMemcpyDeviceToHost, s));

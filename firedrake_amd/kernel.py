@@ -411,11 +411,33 @@ class GlobalKernel:
             if cw is None:
                 src = generate_wrapper(self, mode)
                 path = compile_hip(src.source, self.name)
+                path = self._unrolled_variant(src, path)
                 src, path = self._occupancy_variant(mode, src, path)
                 cw = CompiledWrapper(src, path)
                 GlobalKernel._cache[ck] = cw
             self._compiled[mode] = cw
         return cw
+
+    def _unrolled_variant(self, src, path):
+        """The wrappers keep the element tensor and the packs in registers, which needs every loop of the local kernel fully
+        unrolled (constant indices); LLVM's default threshold gives up on larger nests -- a 12x12 vector-P1 element matrix
+        written as four nested loops already stays in scratch memory and runs 20x slower.  So when hipcc reports scratch,
+        the wrapper is compiled once more with a high ``-unroll-threshold`` and that code object is kept if its scratch is
+        smaller (genuine register spills are not cured by unrolling; then the first one stays).  The flag is recorded on
+        the source so that later variants of this wrapper are built the same way."""
+        from .compilation import compile_hip, kernel_resources
+        from .configuration import configuration
+        thr = configuration["unroll_retry_threshold"]
+        res = kernel_resources(path, src.symbol)
+        if thr <= 0 or not res or res.get("scratch", 0) <= 0:
+            return path
+        extra = ("-mllvm", f"-unroll-threshold={thr}")
+        path2 = compile_hip(src.source, self.name, extra)
+        res2 = kernel_resources(path2, src.symbol)
+        if res2 and res2.get("scratch", 1 << 30) < res["scratch"]:
+            src.extra_flags = extra
+            return path2
+        return path
 
     def _occupancy_variant(self, mode, src, path):
         """Workgroups of T lanes put T/256 wavefronts on every SIMD, so the resident wavefronts per SIMD go up in steps
@@ -436,7 +458,8 @@ class GlobalKernel:
         if target > 8 or res.get("vgprs", 0) <= 512 // target:
             return src, path            # already at the hardware limit / not limited by registers
         src2 = generate_wrapper(self, mode, min_waves=target)
-        path2 = compile_hip(src2.source, self.name)
+        src2.extra_flags = src.extra_flags
+        path2 = compile_hip(src2.source, self.name, src.extra_flags)
         res2 = kernel_resources(path2, src2.symbol)
         if res2 and res2.get("occupancy", 0) >= target and res2.get("scratch", 1 << 30) <= limit:
             return src2, path2

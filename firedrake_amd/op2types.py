@@ -1972,6 +1972,7 @@ class SlicedOcrPlan:
         nb = len(rb) - 1
         self.row_order = row_order
         self._sp, self._rmap, self._cmap = sparsity, rmap._base(), cmap._base()
+        self.block = int(sparsity.dsets[0].cdim) * int(sparsity.dsets[1].cdim)     # scalars per (row node, column node) pair
         h = ctypes.c_void_p()
         _lib.call("fd_ocrplan_create_sliced", self._rmap._dev_values(), rmap.arity, int(start), int(end), rb.ctypes.data, nb,
                   row_order.pinv.ptr if row_order is not None else None, row_order.npos if row_order is not None else 0,
@@ -1989,7 +1990,7 @@ class SlicedOcrPlan:
         self.chunk_role, self.valid, self.nreal = cr.value, va.value, nr.value
         rp = sparsity._node_rowptr.download(np.int32, (sparsity.dsets[0].set.total_size + 1,))
         self.rows_end = int(rb[-1])
-        self.vals_end = int(rp[rb[-1]])
+        self.vals_end = int(rp[rb[-1]]) * self.block
         acc = row_order.prowptr_host if row_order is not None else rp
         self.max_nnz = int(np.diff(acc[rb]).max()) if nb else 0
         self.max_nown = int(np.diff(rb).max()) if nb else 0
@@ -2004,7 +2005,7 @@ class SlicedOcrPlan:
         self._tables = {}
 
     def tables(self, rlg, clg, lgmap_ptr):
-        """(slot buffer, column-position buffer) for the lgmap objects ``rlg`` / ``clg`` (None = no masking);
+        """(slot buffer, column-position buffer, row-length buffer or None) for the lgmap objects ``rlg`` / ``clg`` (None = no masking);
         ``lgmap_ptr(obj)`` gives the device pointer of an lgmap.  Keyed by object identity (lgmaps are immutable, like the
         reference's PETSc LGMaps); the entry keeps the objects alive so that an id cannot be recycled."""
         key = (id(rlg), id(clg))
@@ -2012,17 +2013,18 @@ class SlicedOcrPlan:
         if t is None:
             slot = DeviceBuffer(max(self.ninst, 1) * 2)
             kk = DeviceBuffer(max(self.ninst, 1) * self._cmap.arity * self.kbytes)
+            rlen = DeviceBuffer(max(self.ninst, 1) * 2) if self.block > 1 else None
             sp, ro = self._sp, self.row_order
             _lib.call("fd_ocrplan_sliced_tables", self.h, self._rmap._dev_values(), self._cmap._dev_values(), self._cmap.arity,
                       sp._node_rowptr.ptr, sp._node_colidx.ptr, ro.nstart.ptr if ro is not None else sp._node_rowptr.ptr,
                       ro.prowptr.ptr if ro is not None else sp._node_rowptr.ptr,
                       lgmap_ptr(rlg) if rlg is not None else None, lgmap_ptr(clg) if clg is not None else None,
-                      self.kbytes, slot.ptr, kk.ptr, None)
-            t = (slot, kk, rlg, clg)
+                      self.kbytes, slot.ptr, rlen.ptr if rlen is not None else None, kk.ptr, None)
+            t = (slot, kk, rlen, rlg, clg)
             while len(self._tables) >= self.MAX_TABLE_SETS:
                 self._tables.pop(next(iter(self._tables)))
         self._tables[key] = t                       # most recently used last
-        return t[0], t[1]
+        return t[0], t[1], t[2]
 
     def __del__(self):
         try:

@@ -832,7 +832,8 @@ class Parloop:
             if order is not None:
                 row_order = RowOrder(rmap, order, end - start, nrows, rp)
                 prp = row_order.prowptr_host
-        cap = max(int(configuration["ocrs_nnz_per_block"]), int(np.diff(prp).max()) if nrows else 1)
+        B = int(sp.dsets[0].cdim) * int(sp.dsets[1].cdim)
+        cap = max(int(configuration["ocrs_nnz_per_block"]) // B, int(np.diff(prp).max()) if nrows else 1)
         staged = {mi: maps[mi] for mi in src.staged_maps}
         limit = configuration["lds_limit"]
         for attempt in range(8):
@@ -846,7 +847,7 @@ class Parloop:
                     raise
                 cap //= 2
                 continue
-            lds = ((op.max_nnz * 8) + 15) // 16 * 16
+            lds = ((op.max_nnz * B * 8) + 15) // 16 * 16
             for item in src.lds_items:
                 if item[0] == "dat":
                     _, mi, c, isz, _ = item
@@ -919,10 +920,10 @@ class Parloop:
                 out.append(op.kidx.ptr)
             elif kind == "ocrs_chunk_role":
                 out.append(op.chunk_role)
-            elif kind in ("ocrs_slot", "ocrs_kk"):
+            elif kind in ("ocrs_slot", "ocrs_kk", "ocrs_rowlen"):
                 lg = self.arguments[desc[1]].lgmaps
                 tabs = op.tables(lg[0] if lg else None, lg[1] if lg else None, self._lgmap)
-                out.append(tabs[0 if kind == "ocrs_slot" else 1].ptr)
+                out.append(tabs[{"ocrs_slot": 0, "ocrs_kk": 1, "ocrs_rowlen": 2}[kind]].ptr)
             elif kind == "ocr_maxnnz":
                 out.append(op.max_nnz)
             elif kind == "ocr_maxnown":

@@ -215,7 +215,8 @@ int fd_ocrplan_sliced_arrays(fd_ocrplan_t p, const uint8_t **chunk_role_dev, con
 int fd_ocrplan_sliced_tables(fd_ocrplan_t p, const int32_t *rmap_dev, const int32_t *cmap_dev, int carity,
                              const int32_t *rowptr_dev, const int32_t *colidx_dev, const int32_t *acc_by_node_dev,
                              const int32_t *acc_by_pos_dev, const int32_t *row_lgmap_dev, const int32_t *col_lgmap_dev,
-                             int kbytes, uint16_t *slot_out_dev, void *kk_out_dev, fd_stream_t s);
+                             int kbytes, uint16_t *slot_out_dev, uint16_t *rowlen_out_dev /* nullable: entries of the
+                             instance's CSR node row, needed to address vector-valued blocks */, void *kk_out_dev, fd_stream_t s);
 int fd_gather_rows(const int32_t *src_dev, int arity, const int32_t *idx_dev, int64_t n, int32_t *dst_dev, fd_stream_t s);
 int fd_csr_elem_row_offsets(const int32_t *rowptr_dev, const int32_t *colidx_dev, const int32_t *rmap_dev,
                             const int32_t *cmap_dev, int32_t nent, int rarity, int carity, int kbytes,

@@ -175,7 +175,7 @@ def ocrs_plan_ref(rmapv, cmapv, start, end, row_blocks, rowptr, colidx, acc_by_n
     """numpy restatement of the row-sliced plan (include/fdhip.h: fd_ocrplan_create_sliced + fd_ocrplan_sliced_tables):
     instances (entity, local row i) for every row-map entry inside a row block, per block grouped by i (entity order inside
     a group), every group padded to a multiple of 64 slots with copies of its last entity.  Returns (padded inst_off,
-    inst_ent, chunk_role, valid, slot, kk)."""
+    inst_ent, chunk_role, valid, slot, kk, rowlen)."""
     ar, ac = rmapv.shape[1], cmapv.shape[1]
     rows = np.asarray(rmapv)[start:end]
     pos = rows
@@ -202,9 +202,12 @@ def ocrs_plan_ref(rmapv, cmapv, start, end, row_blocks, rowptr, colidx, acc_by_n
     ent, role, valid = cat(ent, np.int32), cat(role, np.uint8), cat(valid, np.uint8)
     slot = np.full(len(ent), 0xffff, dtype=np.uint16)
     kk = np.full((len(ent), ac), 0xff, dtype=np.uint8)
+    rowlen = np.zeros(len(ent), dtype=np.uint16)
     blk = np.searchsorted(np.asarray(inst_off), np.arange(len(ent)), side="right") - 1
     for t, e in enumerate(ent):
         r = rmapv[e, role[t // 64]]
+        if r >= 0:
+            rowlen[t] = rowptr[r + 1] - rowptr[r]
         if not valid[t] or r < 0 or (rlg is not None and rlg[r] < 0):
             continue
         slot[t] = acc_by_node[r] - acc_by_pos[row_blocks[blk[t]]]
@@ -216,7 +219,7 @@ def ocrs_plan_ref(rmapv, cmapv, start, end, row_blocks, rowptr, colidx, acc_by_n
             q = int(np.searchsorted(row, c))
             assert q < len(row) and row[q] == c and q < 255
             kk[t, j] = q
-    return np.array(inst_off, np.int32), ent, role, valid, slot, kk
+    return np.array(inst_off, np.int32), ent, role, valid, slot, kk, rowlen
 
 
 def lane_slot_to_entity(n, T):

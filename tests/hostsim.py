@@ -253,10 +253,10 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None):
     """Execute a matrix-assembly Parloop ``pl`` with the ROW-SLICED owner-computes-rows wrapper on the host (one OS thread
     per lane).  Plan tables from helpers.ocrs_plan_ref, CSR pattern from the oracle.  Returns the OracleCSR."""
     import re
-    from firedrake_amd.codegen import mode_variant, ocr_eligible
+    from firedrake_amd.codegen import _ocr_shape, mode_variant
     from helpers import first_touch_ref, ocrs_plan_ref, plan_ref_blocks
     gk = pl.global_kernel
-    assert ocr_eligible(gk)
+    assert _ocr_shape(gk) is not None
     (k, mpa), = [(k, pa) for k, pa in enumerate(pl.arguments) if isinstance(pa, MatParloopArg)]
     maps = []
     for pa in pl.arguments:
@@ -265,24 +265,31 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None):
                 maps.append(m._base())
     base = generate_wrapper(gk, "ocrs")
     T = base.block_threads
-    csr = oracle_pattern(mpa.data.sparsity)
+    csr = oracle_pattern(mpa.data.sparsity)             # scalar CSR the values live in (blocks expanded)
+    sp = mpa.data.sparsity
+    B = sp.dsets[0].cdim * sp.dsets[1].cdim
+    ncsr = csr
+    if B > 1:                                             # the plan works on the NODE pattern
+        import oracle
+        ncsr = oracle.build_sparsity(sp.dsets[0].set.total_size, sp.dsets[1].set.total_size,
+                                     [(r.values_with_halo, c.values_with_halo) for r, c, _ in sp._pairs], set_diag=sp._has_diagonal)
     rmap, cmap = (m._base() for m in mpa.maps)
     nent = pl.iterset.size
     nrows = rmap.toset.size
     plist = pinv = None
-    acc = csr.rowptr
-    acc_by_node = csr.rowptr
+    acc = ncsr.rowptr
+    acc_by_node = ncsr.rowptr
     if order is not None:
         plist, pinv = first_touch_ref(np.asarray(rmap.values_with_halo), order, nrows)
-        acc = np.concatenate([[0], np.cumsum(np.diff(csr.rowptr)[:nrows][plist])]).astype(np.int32)
+        acc = np.concatenate([[0], np.cumsum(np.diff(ncsr.rowptr)[:nrows][plist])]).astype(np.int32)
         acc_by_node = np.zeros(max(nrows, 1), dtype=np.int32)
         acc_by_node[plist] = acc[:-1]
     targets = np.arange(0, int(acc[nrows]) + nnz_per_block, nnz_per_block)
     rb = np.unique(np.concatenate([np.searchsorted(acc[:nrows + 1], targets, side="left"), [0, nrows]]))
     rb = rb[rb <= nrows].astype(np.int32)
     lg = mpa.lgmaps
-    inst_off, inst_ent, chunk_role, valid, slot, kk = ocrs_plan_ref(
-        np.asarray(rmap.values_with_halo), np.asarray(cmap.values_with_halo), 0, nent, rb, csr.rowptr, csr.colidx, acc_by_node, acc,
+    inst_off, inst_ent, chunk_role, valid, slot, kk, rowlen = ocrs_plan_ref(
+        np.asarray(rmap.values_with_halo), np.asarray(cmap.values_with_halo), 0, nent, rb, ncsr.rowptr, ncsr.colidx, acc_by_node, acc,
         pinv=pinv, rlg=None if lg is None else np.asarray(lg[0]), clg=None if lg is None else np.asarray(lg[1]))
     plans = {}
     for mi in base.staged_maps:
@@ -337,9 +344,11 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None):
         elif kind in ("ocr_rowptr", "ocr_prowptr"):
             cargs.append(ptr(np.ascontiguousarray(acc, dtype=np.int32)))
         elif kind == "ocr_gstart":
-            cargs.append(ptr(np.ascontiguousarray(csr.rowptr[plist], dtype=np.int32)))
+            cargs.append(ptr(np.ascontiguousarray(ncsr.rowptr[plist], dtype=np.int32)))
         elif kind == "ocrs_slot":
             cargs.append(ptr(slot))
+        elif kind == "ocrs_rowlen":
+            cargs.append(ptr(rowlen))
         elif kind == "ocrs_kk":
             cargs.append(ptr(kk))
         elif kind == "ocr_maxnnz":

@@ -82,3 +82,34 @@ def periodic_column_mesh(rng, nbase=5, ncl=4, nv=7):
     vals = np.concatenate([tri * ncl, tri * ncl + 1], axis=1).astype(np.int32)
     cm = op2.Map(ext, nodes, 6, vals, offset=[1] * 6, offset_quotient=[0, 0, 0, 1, 1, 1])
     return base, ext, nodes, cm
+
+
+def vector_p1_elasticity_kernel(dim=3):
+    """Element matrix of  int eps(u):eps(v) + div(u) div(v) dx  on vector P1 simplices, laid out [i][p][j][q] like the MatPack
+    of a VectorFunctionSpace (pyop2/codegen/builder.py:538-548): rows (node i, component p), columns (node j, component q)."""
+    from firedrake_amd import op2
+    from firedrake_amd.forms import _GEOM
+    nv = dim + 1
+    fact = 2 if dim == 2 else 6
+    body = f"""
+static void vec_elasticity(double *restrict A, const double *restrict x)
+{{
+{_GEOM[dim]}
+  double g[{nv}][{dim}];
+  for (int a = 0; a < {dim}; ++a) {{
+    double s = 0.0;
+    for (int i = 1; i < {nv}; ++i) {{ g[i][a] = K[i-1][a]; s -= K[i-1][a]; }}
+    g[0][a] = s;
+  }}
+  const double vol = adet / {fact}.0;
+  for (int i = 0; i < {nv}; ++i)
+    for (int p = 0; p < {dim}; ++p)
+      for (int j = 0; j < {nv}; ++j)
+        for (int q = 0; q < {dim}; ++q) {{
+          double gg = 0.0;
+          for (int a = 0; a < {dim}; ++a) gg += g[i][a] * g[j][a];
+          A[((i*{dim} + p)*{nv} + j)*{dim} + q] += vol * (0.5 * ((p == q) ? gg : 0.0) + 0.5 * g[i][q] * g[j][p] + g[i][p] * g[j][q]);
+        }}
+}}
+"""
+    return op2.Kernel(body, "vec_elasticity")

@@ -145,3 +145,31 @@ def test_row_sliced_wrappers():
         path = compile_hip(src.source, src.symbol + "_" + mode)
         res = kernel_resources(path, src.symbol)
         assert res and res.get("scratch", 0) == 0 and res.get("vgprs", 999) <= 128
+
+
+def test_scratch_directed_unrolling(monkeypatch):
+    """A 12x12 element matrix written as four nested loops is not fully unrolled at LLVM's default threshold: the element
+    tensor stays in scratch memory.  GlobalKernel.compile notices hipcc's scratch report and rebuilds the wrapper with a
+    high -unroll-threshold; the flag sticks to the wrapper source."""
+    from firedrake_amd.compilation import kernel_resources
+    from firedrake_amd.configuration import configuration
+    from mixed_cases import vector_p1_elasticity_kernel
+    nodes, ele = op2.Set(40), op2.Set(2)
+    cm = op2.Map(ele, nodes, 4, np.arange(8))
+    x = op2.Dat(nodes ** 3)
+
+    def build():
+        mat = op2.Mat(op2.Sparsity((nodes ** 3, nodes ** 3), [(cm, cm, None)]))
+        k = vector_p1_elasticity_kernel(3)
+        gk_ = op2.LegacyParloop(k, ele, mat(op2.INC, (cm, cm)), x(op2.READ, cm)).global_kernel
+        gk_._compiled.clear()                 # (GlobalKernels are cached per local kernel + argument shapes)
+        return gk_
+    monkeypatch.setitem(configuration, "unroll_retry_threshold", 0)
+    from firedrake_amd.kernel import GlobalKernel
+    monkeypatch.setattr(GlobalKernel, "_cache", {})
+    cw0 = build().compile("ocrs")
+    assert kernel_resources(cw0.path, cw0.src.symbol)["scratch"] > 0 and cw0.src.extra_flags == ()
+    monkeypatch.setitem(configuration, "unroll_retry_threshold", 30000)
+    monkeypatch.setattr(GlobalKernel, "_cache", {})
+    cw1 = build().compile("ocrs")
+    assert kernel_resources(cw1.path, cw1.src.symbol)["scratch"] == 0 and "-unroll-threshold=30000" in cw1.src.extra_flags

@@ -49,7 +49,7 @@ def test_sliced_plan_matches_numpy_restatement(ordered, interleave, monkeypatch)
     clg = np.arange(V.node_set.total_size, dtype=np.int32)
     clg[rng.choice(nrows, nrows // 5, replace=False)] = -1
     for lgs in ((None, None), (rlg, clg)):
-        inst_off, ent, role, valid, slot, kk = ocrs_plan_ref(np.asarray(cm.values_with_halo), np.asarray(cm.values_with_halo), 0, n, rb,
+        inst_off, ent, role, valid, slot, kk, _ = ocrs_plan_ref(np.asarray(cm.values_with_halo), np.asarray(cm.values_with_halo), 0, n, rb,
                                                             rp, np.asarray(sp.colidx), acc_node, acc_pos, pinv=pinv, rlg=lgs[0], clg=lgs[1], interleave=interleave)
         assert np.array_equal(op.inst_off_host, inst_off) and op.ninst == len(ent) and op.nreal == int(valid.sum())
         assert op.nreal == int(((np.asarray(cm.values_with_halo)[:n] < nrows)).sum())      # every (entity, owned row) pair exactly once
@@ -62,7 +62,7 @@ def test_sliced_plan_matches_numpy_restatement(ordered, interleave, monkeypatch)
         assert np.array_equal(down(op.chunk_role, np.uint8, (op.ninst // 64,)), role)
         assert np.array_equal(down(op.valid, np.uint8, (op.ninst,)), valid)
         keep = []
-        s_, k_ = op.tables(lgs[0], lgs[1], lambda a: keep.append(DeviceBuffer.from_numpy(a)) or keep[-1].ptr)
+        s_, k_, _ = op.tables(lgs[0], lgs[1], lambda a: keep.append(DeviceBuffer.from_numpy(a)) or keep[-1].ptr)
         assert np.array_equal(s_.download(np.uint16, (op.ninst,)), slot)
         assert np.array_equal(k_.download(np.uint8, kk.shape), kk)
 
@@ -170,3 +170,53 @@ static void hub(double *A, const double *x)
     assert geo["cw"].src.mode.startswith("ocrs") and "_k16" in geo["cw"].src.mode and geo["ocr"].max_nnz >= 2101
     ref = oracle_run(k, cells, mat(op2.INC, (m, m)), pos(op2.READ, m))[0]
     assert_allclose(mat.csr()[2], ref.values, rtol=0, atol=1e-12 * np.abs(ref.values).max())
+
+
+@pytest.mark.parametrize("numbering", ["tiled", "lexicographic"])
+def test_vector_valued_blocks_against_oracle(numbering, monkeypatch):
+    """MatSetValuesBlockedLocal (builder.py:573-625): vector P1 on tetrahedra -- 12x12 element matrices in 3x3 blocks -- takes
+    the row-sliced wrapper (an instance owns the three scalar rows of one node), with block lgmaps, a second accumulating
+    call, and against the direct wrapper's global atomics."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from mixed_cases import vector_p1_elasticity_kernel
+    monkeypatch.setitem(configuration, "locality_min_entities", 0)
+    mesh = fmesh.UnitCubeMesh(9, degrees=(1,), tile=(4, 4, 2), perturb=0.1, numbering=numbering)
+    V = mesh.space(1)
+    cm = V.cell_node_map
+    sp = op2.Sparsity((V.node_set ** 3, V.node_set ** 3), [(cm, cm, None)])
+    lgv = np.arange(V.node_set.total_size, dtype=np.int32)
+    lgv[np.random.default_rng(1).choice(V.node_set.size, V.node_set.size // 6, replace=False)] = -1
+    k = vector_p1_elasticity_kernel(3)
+    mat = op2.Mat(sp)
+    pl = op2.LegacyParloop(k, mesh.cell_set, mat(op2.INC, (cm, cm), lgmaps=(lgv, lgv)), mesh.coordinates(op2.READ, cm))
+    pl()
+    geo = pl._ocr_geometry()
+    assert geo["cw"].src.mode.startswith("ocrsp" if numbering != "tiled" else "ocrs") and geo["ocr"].block == 9
+    ref = oracle_run(k, mesh.cell_set, mat(op2.INC, (cm, cm), lgmaps=(lgv, lgv)), mesh.coordinates(op2.READ, cm))[0]
+    rp, ci, v = mat.csr()
+    assert np.array_equal(rp, ref.rowptr) and np.array_equal(ci, ref.colidx)
+    assert_allclose(v, ref.values, rtol=0, atol=1e-12 * np.abs(ref.values).max())
+    pl()
+    assert_allclose(mat.csr()[2], 2.0 * ref.values, rtol=0, atol=2e-12 * np.abs(ref.values).max())
+    monkeypatch.setitem(configuration, "mat_ocr", 0)
+    mat2 = op2.Mat(sp)
+    pl2 = op2.LegacyParloop(k, mesh.cell_set, mat2(op2.INC, (cm, cm), lgmaps=(lgv, lgv)), mesh.coordinates(op2.READ, cm))
+    pl2()
+    assert not pl2._prepare()["cw"].src.mode.startswith("ocr")
+    assert_allclose(mat2.csr()[2], ref.values, rtol=0, atol=1e-12 * np.abs(ref.values).max())
+
+
+def test_reference_vector_matrix_golden_through_the_sliced_wrapper(monkeypatch):
+    """The reference's own expected vector-valued mass matrix (tests/pyop2/test_matrices.py, lifted into
+    tests/golden/pyop2_matrices.json) with the row-sliced wrapper forced onto its 6x6 element matrices."""
+    import golden_kernels as gk
+    monkeypatch.setitem(configuration, "ocr_sliced_min_arity", 1)
+    nodes, ele = op2.Set(4), op2.Set(2)
+    m = op2.Map(ele, nodes, 3, gk.ELEM_NODE)
+    mat = op2.Mat(op2.Sparsity((nodes ** 2, nodes ** 2), [(m, m, None)]))
+    x = op2.Dat(nodes ** 2, gk.COORDS)
+    pl = op2.LegacyParloop(op2.Kernel(gk.MASS_VEC_AFFINE, "mass_vec_affine"), ele, mat(op2.INC, (m, m)), x(op2.READ, m))
+    pl()
+    assert pl._prepare()["cw"].src.mode.startswith("ocrs")
+    assert_allclose(mat.values, np.array(gk.GOLD["expected_vector_matrix"]), rtol=1e-6, atol=1e-8)

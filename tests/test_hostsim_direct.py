@@ -602,3 +602,35 @@ def test_row_sliced_owner_computes_rows_on_host(bcs, numbering):
         if cap == 96:
             got2 = run_ocrs(pl, nnz_per_block=cap, zero_pending=False, order=order)
             assert np.abs(got2.values - (ref.values + 1.0)).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
+
+
+@pytest.mark.parametrize("numbering,bcs", [("tiled", False), ("tiled", True), ("random", True)])
+def test_row_sliced_vector_valued_blocks_on_host(numbering, bcs):
+    """MatSetValuesBlockedLocal through the row-sliced wrapper: vector P1 on tetrahedra (12x12 element matrices, 3x3 blocks;
+    an instance owns the three scalar rows of one node, addressed through the node row's length), block lgmaps, contiguous
+    and row-by-row flush."""
+    from firedrake_amd import mesh as fmesh
+    from firedrake_amd.codegen import select_mode
+    from helpers import locality_order_ref
+    from hostsim import run_ocrs
+    from mixed_cases import vector_p1_elasticity_kernel
+    mesh = fmesh.UnitCubeMesh(3, degrees=(1,), perturb=0.1, numbering=numbering)
+    V = mesh.space(1)
+    cm = V.cell_node_map
+    mat = op2.Mat(op2.Sparsity((V.node_set ** 3, V.node_set ** 3), [(cm, cm, None)]))
+    lg = None
+    if bcs:
+        lgv = np.arange(V.node_set.total_size, dtype=np.int32)
+        lgv[np.random.default_rng(1).choice(V.node_set.size, V.node_set.size // 6, replace=False)] = -1
+        lg = (lgv, lgv)
+    k = vector_p1_elasticity_kernel(3)
+    pl = op2.LegacyParloop(k, mesh.cell_set, mat(op2.INC, (cm, cm), lgmaps=lg), mesh.coordinates(op2.READ, cm))
+    assert select_mode(pl.global_kernel) == "ocrs"
+    order = None
+    if numbering == "random":
+        order, _ = locality_order_ref(cm.values_with_halo, 0, mesh.cell_set.size, np.array(mesh.coordinates.data_ro))
+    ref = oracle_run(k, mesh.cell_set, mat(op2.INC, (cm, cm), lgmaps=lg), mesh.coordinates(op2.READ, cm))[0]
+    for zero_pending in (True, False):
+        got = run_ocrs(pl, nnz_per_block=60, zero_pending=zero_pending, order=order)
+        assert np.array_equal(got.rowptr, ref.rowptr) and np.array_equal(got.colidx, ref.colidx)
+        assert np.abs(got.values - (ref.values + (0.0 if zero_pending else 1.0))).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
