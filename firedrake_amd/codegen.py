@@ -158,14 +158,14 @@ def select_mode(gk: GlobalKernel) -> str:
         raise ValueError("FDHIP_MODE=staged but this parloop is not eligible for the staged wrapper")
     if want == "direct":
         return "direct"
-    if ok and configuration["mat_ocr"] and sliced_eligible(gk):
+    if configuration["mat_ocr"] and sliced_eligible(gk):
         return "ocrs"
     if ok and configuration["mat_ocr"] and ocr_eligible(gk):
         return "ocr"
     return "staged" if ok else "direct"
 
 
-def staged_eligible(gk: GlobalKernel) -> bool:
+def staged_eligible(gk: GlobalKernel, mats_on_virtual: bool = False, need_indirect_dat: bool = True) -> bool:
     """Staged wrapper (LDS gather / reduction over block-localisation plans).  Subsets and extruded sets qualify too: the
     plan is then built on a DERIVED map over the virtual iteration space -- the map rows of the subset's entities, resp.
     one row ``map + offset*layer`` per (column, layer) cell (builder.py:94-124 folded into the table once) -- so the kernel
@@ -173,8 +173,8 @@ def staged_eligible(gk: GlobalKernel) -> bool:
     loops, constant layers, no periodic wrap, regions ALL / ON_BOTTOM / ON_TOP, and no direct Dat written on an extruded
     set (all layers of a column share its row: parloop.py:494-497)."""
     if gk._extruded or gk._subset:
-        if any(isinstance(a, MatKernelArg) for a in gk.arguments):
-            return False
+        if any(isinstance(a, MatKernelArg) for a in gk.arguments) and not mats_on_virtual:
+            return False          # (matrix loops over virtual spaces: row-sliced owner-computes-rows only, sliced_eligible)
         if gk._extruded:
             if not gk._constant_layers or gk._extruded_periodic or gk._iteration_region == ON_INTERIOR_FACETS:
                 return False
@@ -194,15 +194,15 @@ def staged_eligible(gk: GlobalKernel) -> bool:
             if la.access == INC and la.dtype in STAGEABLE_INC:
                 continue
             return False
-    return n_ind > 0
+    return n_ind > 0 or not need_indirect_dat
 
 
-def _ocr_shape(gk: GlobalKernel):
+def _ocr_shape(gk: GlobalKernel, mats_on_virtual: bool = False):
     """The Mat argument of a loop that can assemble by owner-computes-rows -- its only output is ONE Mat with INC access,
     addressed per node (no ``unroll``), everything else READ (entities are visited redundantly, so nothing else may be
     modified) -- or None."""
-    if not staged_eligible(gk):
-        return None
+    if not staged_eligible(gk, mats_on_virtual, need_indirect_dat=not mats_on_virtual):
+        return None                 # (the sliced wrapper -- the only caller with mats_on_virtual -- needs no staged Dat)
     mats = []
     for a, la in zip(gk.arguments, gk.local_kernel.arguments):
         if isinstance(a, MatKernelArg):
@@ -227,10 +227,20 @@ def sliced_eligible(gk: GlobalKernel) -> bool:
     against 599 for all ten, i.e. the rows share little beyond the geometry, while an unsliced row block recomputes whole
     entities x2.2-3.4).  Vector-valued blocks (MatSetValuesBlockedLocal, builder.py:573-625) are sliced per NODE: an
     instance owns the ``rbs`` scalar rows of one node."""
-    a = _ocr_shape(gk) if configuration["ocr_sliced"] else None
+    a = _ocr_shape(gk, mats_on_virtual=True) if configuration["ocr_sliced"] else None
     if a is None:
         return False
-    return a.maps[0].arity <= 255 and a.maps[0].arity * int(np.prod(a.dims[0])) >= configuration["ocr_sliced_min_arity"]
+    # the local kernel is inlined once per row-map entry and must unroll completely in each copy: bounded element matrices
+    # only (Q2 hexahedra 27x27 and vector P2 tetrahedra 30x30 qualify; the 125x125 of Q4 has its own wrapper, else direct)
+    entries = a.maps[0].arity * a.maps[1].arity * int(np.prod(a.dims[0])) * int(np.prod(a.dims[1]))
+    if a.maps[0].arity > configuration["ocr_sliced_max_arity"] or entries > configuration["ocr_sliced_max_entries"]:
+        return False
+    if gk._extruded or gk._subset:
+        # virtual iteration spaces (subset rows, (column, layer) cells; constant layers, regions ALL / ON_BOTTOM / ON_TOP, see
+        # staged_eligible): the plans are built on derived maps, and the only other matrix path there scatters with global
+        # atomics -- sliced whatever the size of the element matrix
+        return True
+    return a.maps[0].arity * int(np.prod(a.dims[0])) >= configuration["ocr_sliced_min_arity"]
 
 
 def _hoist_includes(code: str):
@@ -855,6 +865,14 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         params.append(decl)
         layout.append(desc)
 
+    # virtual iteration spaces (subset / extruded): the instance's entity id is a position in the (subset x layer) space,
+    # decoded only for direct arguments and the layer argument (every map row is a row of a derived map)
+    extruded = bool(gk._extruded)
+    if extruded:
+        P("const int *__restrict__ layers", ("layers",))
+    if gk._subset:
+        P("const int *__restrict__ subset_indices", ("subset",))
+
     infos = []
     for k, (a, la) in enumerate(zip(gk.arguments, lk.arguments)):
         info = {"k": k, "arg": a, "acc": la.access, "ct": CTYPE[np.dtype(la.dtype)], "dtype": np.dtype(la.dtype)}
@@ -935,6 +953,8 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             pack.append(f"{ct} t{k}[{ar * c}];")
             pack.append(f"for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j) t{k}[i*{c}+j] = s{k}[{idx}];")
             call_args.append(f"t{k}")
+    if gk._pass_layer_arg:
+        call_args.append("layer")
     lds_items.append(("ocrs", K, B))
     lds_decl.append(f"double *sm{K} = (double *)(fd_lds + fd_off); fd_off += (((size_t)oc{K}_maxnnz*{B}*8) + 15) & ~(size_t)15;")
 
@@ -962,18 +982,22 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
                 src += ["    " + l for l in act[part]]
         src.append("  }")
     src.append("  __syncthreads();")
+    if extruded:
+        lo, hi = {ALL: ("layers[0]", "layers[1]-1"), ON_BOTTOM: ("layers[0]", "layers[0]+1"), ON_TOP: ("layers[1]-2", "layers[1]-1")}[gk._iteration_region]
+        src.append(f"  const int fd_llo = {lo}, fd_nlit = ({hi}) - fd_llo;")
     # every 64 consecutive slots hold one local row index, and e0 / nthr are multiples of 64: the index is wave-uniform.
     # Software pipeline like the unsliced wrappers: the index rows of the lane's NEXT instance are requested before the
     # current one's local kernel runs (a trip is only ~300 instructions, far less than an HBM round trip).
-    need_e = any(i["kind"] == "dat" and "m" not in i for i in infos)
+    need_e = any(i["kind"] == "dat" and "m" not in i for i in infos) or bool(gk._pass_layer_arg)
     rows = [(f"lm{mi}", maps[mi].arity, f"fdw::load_lmap<{maps[mi].arity}>(p{mi}_lmap + (size_t)(II - start)*{maps[mi].arity}, DST);")
             for mi in staged_maps]
     rows.append(("kk", AC, f"fdw::load_packed<{ktype}, {AC}>(oc{K}_k + (size_t)(II - start)*{AC}, DST);"))
     scal = [("role", "(int)chunk_role_[(II - start) >> 6]"), ("slot", f"(int)oc{K}_slot[II - start]")]
     if B > 1:
         scal.append(("rlen", f"(int)oc{K}_rowlen[II - start]"))
+    virt = extruded or bool(gk._subset)
     if need_e:
-        scal.append(("e", "inst_ent_[II - start]"))
+        scal.append(("fd_v" if virt else "e", "inst_ent_[II - start]"))
     pf = bool(configuration["prefetch"])
 
     def loads(ii, prefix):
@@ -993,6 +1017,12 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         src += ["    " + l for l in loads("itn", "nx_")]
     else:
         src += ["    " + l for l in loads("it", "")]
+    if need_e and virt:
+        if extruded:
+            src += ["    const int fd_col = fd_v / fd_nlit; const int layer = fd_llo + (fd_v - fd_col*fd_nlit);",
+                    "    const int e = " + ("subset_indices[fd_col];" if gk._subset else "fd_col;")]
+        else:
+            src.append("    const int e = subset_indices[fd_v];")
     src += ["    " + s for s in pack]
     src.append("    switch (fdw::wave_uniform(role)) {")
     NT = AR * RB * AC * CB

@@ -39,6 +39,8 @@ configuration = {
     # instantiated once per row; pays when the rows of the element matrix dominate its shared (geometry) part
     "ocr_sliced": _env("FDHIP_OCR_SLICED", 1, int),
     "ocr_sliced_min_arity": _env("FDHIP_OCR_SLICED_MIN_ARITY", 8, int),
+    "ocr_sliced_max_arity": _env("FDHIP_OCR_SLICED_MAX_ARITY", 32, int),
+    "ocr_sliced_max_entries": _env("FDHIP_OCR_SLICED_MAX_ENTRIES", 1024, int),
     "ocrs_nnz_per_block": _env("FDHIP_OCRS_NNZ", 4096, int),     # accumulator entries per row block (x8 bytes of LDS)
     "ocrs_block_threads": _env("FDHIP_OCRS_BLOCK_THREADS", 256, int),
     "ocrs_interleave": _env("FDHIP_OCRS_INTERLEAVE", 7, int),    # > 1: stride permutation of the instances of every (block, row index) group
@@ -49,6 +51,7 @@ configuration = {
     # a wrapper that comes out of hipcc with scratch memory is recompiled with this LLVM -unroll-threshold (0 = never) and the
     # result kept if the scratch shrinks: element tensors must end up in registers (kernel.GlobalKernel._unrolled_variant)
     "unroll_retry_threshold": _env("FDHIP_UNROLL_RETRY", 30000, int),
+    "unroll_retry_max_scratch": _env("FDHIP_UNROLL_RETRY_MAX_SCRATCH", 8192, int),   # bytes per lane; beyond: too large for registers anyway
     "min_waves": _env("FDHIP_MIN_WAVES", 0, int),       # 2nd __launch_bounds__ argument (waves per SIMD), 0 = unset
     # occupancy-directed variants: a staged/OCR wrapper whose register count leaves room for one more resident workgroup
     # per CU is recompiled with the matching __launch_bounds__ and kept if that costs at most this many bytes of scratch

@@ -429,8 +429,8 @@ class GlobalKernel:
         from .configuration import configuration
         thr = configuration["unroll_retry_threshold"]
         res = kernel_resources(path, src.symbol)
-        if thr <= 0 or not res or res.get("scratch", 0) <= 0:
-            return path
+        if thr <= 0 or not res or not (0 < res.get("scratch", 0) <= configuration["unroll_retry_max_scratch"]):
+            return path                 # (a register file holds 2 KB per lane: far larger tensors stay where they are)
         extra = ("-mllvm", f"-unroll-threshold={thr}")
         path2 = compile_hip(src.source, self.name, extra)
         res2 = kernel_resources(path2, src.symbol)

@@ -431,7 +431,8 @@ class Parloop:
         """(layers per entity iterated, first layer) when the staged wrapper runs over a virtual space, else None."""
         gk = self.global_kernel
         if staged is None:
-            staged = self._prepared["cw"].src.mode.startswith("staged")
+            mode = self._prepared["cw"].src.mode
+            staged = mode.startswith("staged") or mode.startswith("ocrs")
         if not (gk._extruded or gk._subset) or not staged:
             return None
         if not gk._extruded:
@@ -817,9 +818,13 @@ class Parloop:
         from .codegen import lds_stride, mode_variant
         prep = self._prepared
         src = prep["cw"].src
-        maps = prep["maps"]
+        # subsets / extruded sets: every map is replaced by its derived map over the virtual (position x layer) space
+        maps = {mi: self._plan_map(m._base(), staged=True) for mi, m in enumerate(prep["maps"])}
+        v = self._virtual(staged=True)
+        if v is not None:
+            start, end = start * v[0], end * v[0]               # positions in the virtual space
         (k, pa), = [(k, a) for k, a in enumerate(self.arguments) if isinstance(a, MatParloopArg)]
-        rmap, cmap = pa.maps
+        rmap, cmap = (self._plan_map(m._base(), staged=True) for m in pa.maps)
         sp = pa.data.sparsity
         sp._build()
         nrows = rmap.toset.size
@@ -880,7 +885,11 @@ class Parloop:
         out = []
         for desc in src.layout:
             kind = desc[0]
-            if kind == "arg":
+            if kind == "layers":
+                out.append(self.iterset._layers_dev())
+            elif kind == "subset":
+                out.append(self.iterset._indices_dev())
+            elif kind == "arg":
                 pa = self.arguments[desc[1]]
                 if isinstance(pa, MatParloopArg):
                     mat = pa.data

@@ -256,13 +256,16 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None):
     from firedrake_amd.codegen import _ocr_shape, mode_variant
     from helpers import first_touch_ref, ocrs_plan_ref, plan_ref_blocks
     gk = pl.global_kernel
-    assert _ocr_shape(gk) is not None
+    assert _ocr_shape(gk, mats_on_virtual=True) is not None
     (k, mpa), = [(k, pa) for k, pa in enumerate(pl.arguments) if isinstance(pa, MatParloopArg)]
-    maps = []
+    # subsets / extruded sets: the plan lives on the derived maps over the virtual (position x layer) space
+    virt = pl._virtual(staged=True)
+    base_maps, maps = [], []
     for pa in pl.arguments:
         for m in getattr(pa, "maps", ()):
-            if all(m._base() is not q for q in maps):
-                maps.append(m._base())
+            if all(m._base() is not q for q in base_maps):
+                base_maps.append(m._base())
+                maps.append(pl._plan_map(m._base(), staged=True))
     base = generate_wrapper(gk, "ocrs")
     T = base.block_threads
     csr = oracle_pattern(mpa.data.sparsity)             # scalar CSR the values live in (blocks expanded)
@@ -273,8 +276,9 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None):
         import oracle
         ncsr = oracle.build_sparsity(sp.dsets[0].set.total_size, sp.dsets[1].set.total_size,
                                      [(r.values_with_halo, c.values_with_halo) for r, c, _ in sp._pairs], set_diag=sp._has_diagonal)
-    rmap, cmap = (m._base() for m in mpa.maps)
-    nent = pl.iterset.size
+        assert not pl.iterset._extruded
+    rmap, cmap = (pl._plan_map(m._base(), staged=True) for m in mpa.maps)
+    nent = pl.iterset.size * (virt[0] if virt else 1)
     nrows = rmap.toset.size
     plist = pinv = None
     acc = ncsr.rowptr
@@ -316,7 +320,11 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None):
     cargs = [ctypes.c_int(len(rb) - 1), ctypes.c_int(T), ctypes.c_int(0), ctypes.c_int(len(inst_ent))]
     for desc in src.layout:
         kind = desc[0]
-        if kind == "arg":
+        if kind == "layers":
+            cargs.append(ptr(np.asarray(pl.iterset.layers_array, dtype=np.int32)))
+        elif kind == "subset":
+            cargs.append(ptr(np.asarray(pl.iterset.indices, dtype=np.int32)))
+        elif kind == "arg":
             pa = pl.arguments[desc[1]]
             if isinstance(pa, MatParloopArg):
                 cargs.append(ctypes.c_void_p(csr.values.ctypes.data))
@@ -324,7 +332,7 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None):
                 host = pa.data._host if pa.data._host_valid else pa.data._to_host()
                 cargs.append(ptr(np.array(host, copy=True)))
         elif kind == "map":
-            cargs.append(ptr(np.asarray(maps[desc[1]].values_with_halo, dtype=np.int32)))
+            cargs.append(ptr(np.asarray(base_maps[desc[1]].values_with_halo, dtype=np.int32)))
         elif kind == "bstart":
             cargs.append(ptr(inst_off))
         elif kind == "ocr_inst_ent":

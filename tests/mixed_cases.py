@@ -113,3 +113,42 @@ static void vec_elasticity(double *restrict A, const double *restrict x)
 }}
 """
     return op2.Kernel(body, "vec_elasticity")
+
+
+def q1_hex_helmholtz_kernel():
+    """a(u, v) = int grad(u).grad(v) + u v dx on a trilinear hexahedron, Q1 basis, 2x2x2 Gauss points.  Arguments: A[8*8],
+    coords[8*3]; vertex index a*4 + b*2 + c like firedrake_amd.mesh.make_extruded_hex_mesh (c along the extrusion)."""
+    from firedrake_amd import op2
+    body = """
+static void q1_helmholtz(double *restrict A, const double *restrict x)
+{
+  static const double QP[2] = {0.21132486540518713, 0.7886751345948129};
+  for (int q1 = 0; q1 < 2; ++q1) for (int q2 = 0; q2 < 2; ++q2) for (int q3 = 0; q3 < 2; ++q3) {
+    const double t[3] = {QP[q1], QP[q2], QP[q3]};
+    double N[8], dN[8][3], J[3][3] = {{0,0,0},{0,0,0},{0,0,0}};
+    for (int v = 0; v < 8; ++v) {
+      const int a = v >> 2, b = (v >> 1) & 1, c = v & 1;
+      const double Na = a ? t[0] : 1.0 - t[0], Nb = b ? t[1] : 1.0 - t[1], Nc = c ? t[2] : 1.0 - t[2];
+      const double da = a ? 1.0 : -1.0, db = b ? 1.0 : -1.0, dc = c ? 1.0 : -1.0;
+      N[v] = Na*Nb*Nc; dN[v][0] = da*Nb*Nc; dN[v][1] = Na*db*Nc; dN[v][2] = Na*Nb*dc;
+      for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) J[r][s] += x[3*v + r] * dN[v][s];
+    }
+    const double c00 = J[1][1]*J[2][2] - J[1][2]*J[2][1], c01 = J[1][2]*J[2][0] - J[1][0]*J[2][2], c02 = J[1][0]*J[2][1] - J[1][1]*J[2][0];
+    const double det = J[0][0]*c00 + J[0][1]*c01 + J[0][2]*c02, id = 1.0 / det;
+    const double K[3][3] = {
+      { c00*id, (J[0][2]*J[2][1] - J[0][1]*J[2][2])*id, (J[0][1]*J[1][2] - J[0][2]*J[1][1])*id },
+      { c01*id, (J[0][0]*J[2][2] - J[0][2]*J[2][0])*id, (J[0][2]*J[1][0] - J[0][0]*J[1][2])*id },
+      { c02*id, (J[0][1]*J[2][0] - J[0][0]*J[2][1])*id, (J[0][0]*J[1][1] - J[0][1]*J[1][0])*id } };
+    const double w = 0.125 * fabs(det);
+    double g[8][3];
+    for (int v = 0; v < 8; ++v) for (int r = 0; r < 3; ++r) {
+      double s = 0.0;
+      for (int a = 0; a < 3; ++a) s += dN[v][a] * K[a][r];
+      g[v][r] = s;
+    }
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 8; ++j)
+      A[i*8 + j] += w * (g[i][0]*g[j][0] + g[i][1]*g[j][1] + g[i][2]*g[j][2] + N[i]*N[j]);
+  }
+}
+"""
+    return op2.Kernel(body, "q1_helmholtz")

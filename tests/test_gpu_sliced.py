@@ -220,3 +220,29 @@ def test_reference_vector_matrix_golden_through_the_sliced_wrapper(monkeypatch):
     pl()
     assert pl._prepare()["cw"].src.mode.startswith("ocrs")
     assert_allclose(mat.values, np.array(gk.GOLD["expected_vector_matrix"]), rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize("region", [None, "bottom"])
+def test_matrix_over_an_extruded_set_against_oracle_and_direct(region, monkeypatch):
+    """Extruded matrix assembly (node = map + offset*layer, builder.py:94-124) through the row-sliced wrapper over the derived
+    (column, layer) map: Q1 Helmholtz on a perturbed hex column mesh, against the oracle and the direct wrapper."""
+    from mixed_cases import q1_hex_helmholtz_kernel
+    m = fmesh.make_extruded_hex_mesh(12, 9, degree=1)
+    cm, xm = m.cell_node_map, m.coord_map
+    sp = op2.Sparsity((m.node_set ** 1, m.node_set ** 1), [(cm, cm, None)])
+    k = q1_hex_helmholtz_kernel()
+    kw = {"iteration_region": op2.ON_BOTTOM} if region else {}
+    mat = op2.Mat(sp)
+    pl = op2.LegacyParloop(k, m.cell_set, mat(op2.INC, (cm, cm)), m.coordinates(op2.READ, xm), **kw)
+    pl()
+    assert pl._prepare()["cw"].src.mode.startswith("ocrs")
+    ref = oracle_run(k, m.cell_set, mat(op2.INC, (cm, cm)), m.coordinates(op2.READ, xm), **kw)[0]
+    rp, ci, v = mat.csr()
+    assert np.array_equal(rp, ref.rowptr) and np.array_equal(ci, ref.colidx)
+    assert_allclose(v, ref.values, rtol=0, atol=1e-12 * np.abs(ref.values).max())
+    monkeypatch.setitem(configuration, "mat_ocr", 0)
+    mat2 = op2.Mat(sp)
+    pl2 = op2.LegacyParloop(k, m.cell_set, mat2(op2.INC, (cm, cm)), m.coordinates(op2.READ, xm), **kw)
+    pl2()
+    assert pl2._prepare()["cw"].src.mode == "direct"
+    assert_allclose(mat2.csr()[2], ref.values, rtol=0, atol=1e-12 * np.abs(ref.values).max())

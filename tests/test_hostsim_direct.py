@@ -634,3 +634,41 @@ def test_row_sliced_vector_valued_blocks_on_host(numbering, bcs):
         got = run_ocrs(pl, nnz_per_block=60, zero_pending=zero_pending, order=order)
         assert np.array_equal(got.rowptr, ref.rowptr) and np.array_equal(got.colidx, ref.colidx)
         assert np.abs(got.values - (ref.values + (0.0 if zero_pending else 1.0))).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
+
+
+@pytest.mark.parametrize("region", ["all", "bottom", "top"])
+@pytest.mark.parametrize("subset", [False, True])
+def test_row_sliced_matrix_over_extruded_sets_and_subsets_on_host(region, subset):
+    """Matrix loops over virtual iteration spaces take the row-sliced wrapper whatever their size: the plans are built on the
+    derived maps (one row ``map + offset*layer`` per (column, layer) cell, resp. the subset's rows), the virtual id is
+    decoded for the direct argument (base entity, parloop.py:494-497) and the layer argument only.  P1 prisms (arity 6) with
+    a coordinate field, a cell-wise coefficient and pass_layer_arg, against the oracle."""
+    from firedrake_amd.codegen import select_mode
+    from hostsim import run_ocrs
+    nb, layers = 7, 6
+    rng = np.random.default_rng(8)
+    base = op2.Set(nb)
+    ext = op2.ExtrudedSet(base, layers=layers)
+    nodes = op2.Set((nb + 2) * layers)
+    vm = np.array([[i * layers, i * layers + 1, (i + 1) * layers, (i + 1) * layers + 1, (i + 2) * layers, (i + 2) * layers + 1]
+                   for i in range(nb)], dtype=np.int32)
+    m = op2.Map(ext, nodes, 6, vm, offset=[1] * 6)
+    it = op2.Subset(ext, [0, 2, 3, 6]) if subset else ext
+    x = op2.Dat(nodes ** 2, rng.uniform(0, 1, (nodes.total_size, 2)), np.float64)
+    w = op2.Dat(ext, rng.uniform(1, 2, nb), np.float64)
+    mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(m, m, None)]))
+    k = op2.Kernel("""
+static void prism(double *A, const double *x, const double *w, int layer)
+{
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j)
+      A[i*6 + j] += w[0] * (x[2*i] + 2.0 * x[2*j + 1]) + 0.25 * layer + (i == j ? 1.0 : 0.0);
+}""", "prism")
+    reg = {"all": None, "bottom": op2.ON_BOTTOM, "top": op2.ON_TOP}[region]
+    kw = dict(iteration_region=reg, pass_layer_arg=True)
+    pl = op2.LegacyParloop(k, it, mat(op2.INC, (m, m)), x(op2.READ, m), w(op2.READ), **kw)
+    assert select_mode(pl.global_kernel) == "ocrs"
+    got = run_ocrs(pl, nnz_per_block=150)
+    ref = oracle_run(k, it, mat(op2.INC, (m, m)), x(op2.READ, m), w(op2.READ), **kw)[0]
+    assert np.array_equal(got.rowptr, ref.rowptr) and np.array_equal(got.colidx, ref.colidx)
+    assert np.abs(got.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
