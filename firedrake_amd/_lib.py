@@ -96,7 +96,7 @@ SIGNATURES = {
                                          POINTER(c_void_p)]),
     "fd_ocrplan_sliced_arrays": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64)]),
     "fd_ocrplan_sliced_tables": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                         c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                         c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "fd_gather_rows": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     "fd_csr_elem_row_offsets": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int, c_int, c_int, c_void_p, c_void_p]),
     "fd_csr_from_maps": (c_int, [c_int32, c_int32, c_int, c_int, POINTER(c_void_p), POINTER(c_void_p),

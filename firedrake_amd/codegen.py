@@ -197,16 +197,16 @@ def staged_eligible(gk: GlobalKernel, mats_on_virtual: bool = False, need_indire
     return n_ind > 0 or not need_indirect_dat
 
 
-def _ocr_shape(gk: GlobalKernel, mats_on_virtual: bool = False):
-    """The Mat argument of a loop that can assemble by owner-computes-rows -- its only output is ONE Mat with INC access,
-    addressed per node (no ``unroll``), everything else READ (entities are visited redundantly, so nothing else may be
-    modified) -- or None."""
+def _ocr_shape(gk: GlobalKernel, mats_on_virtual: bool = False, allow_unroll: bool = False):
+    """The Mat argument of a loop that can assemble by owner-computes-rows -- its only output is ONE Mat with INC access
+    (addressed per node unless ``allow_unroll``), everything else READ (entities are visited redundantly, so nothing else
+    may be modified) -- or None."""
     if not staged_eligible(gk, mats_on_virtual, need_indirect_dat=not mats_on_virtual):
         return None                 # (the sliced wrapper -- the only caller with mats_on_virtual -- needs no staged Dat)
     mats = []
     for a, la in zip(gk.arguments, gk.local_kernel.arguments):
         if isinstance(a, MatKernelArg):
-            if la.access != INC or a.unroll:
+            if la.access != INC or (a.unroll and not allow_unroll):
                 return None
             mats.append(a)
         elif la.access != READ:
@@ -227,9 +227,11 @@ def sliced_eligible(gk: GlobalKernel) -> bool:
     against 599 for all ten, i.e. the rows share little beyond the geometry, while an unsliced row block recomputes whole
     entities x2.2-3.4).  Vector-valued blocks (MatSetValuesBlockedLocal, builder.py:573-625) are sliced per NODE: an
     instance owns the ``rbs`` scalar rows of one node."""
-    a = _ocr_shape(gk, mats_on_virtual=True) if configuration["ocr_sliced"] else None
+    a = _ocr_shape(gk, mats_on_virtual=True, allow_unroll=True) if configuration["ocr_sliced"] else None
     if a is None:
         return False
+    if a.unroll and (int(np.prod(a.dims[0])) > 8 or a.maps[1].arity * int(np.prod(a.dims[1])) > 64):
+        return False          # per-dof lgmaps (MatSetValuesLocal on dof indices) travel as an 8-bit row and a 64-bit column mask
     # the local kernel is inlined once per row-map entry and must unroll completely in each copy: bounded element matrices
     # only (Q2 hexahedra 27x27 and vector P2 tetrahedra 30x30 qualify; the 125x125 of Q4 has its own wrapper, else direct)
     entries = a.maps[0].arity * a.maps[1].arity * int(np.prod(a.dims[0])) * int(np.prod(a.dims[1]))
@@ -924,6 +926,12 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     P(f"const unsigned short *__restrict__ oc{K}_slot", ("ocrs_slot", K))
     if B > 1:
         P(f"const unsigned short *__restrict__ oc{K}_rowlen", ("ocrs_rowlen", K))
+    # ``unroll``: MatSetValuesLocal on dof indices with per-dof lgmaps (mat.py:700-716, parloop.py:279-314 -- component-wise
+    # boundary conditions on vector spaces): which of the node's scalar rows / of the entity's scalar columns survive
+    dofmask = bool(mat["arg"].unroll and mat["arg"].lgmaps)
+    if dofmask:
+        P(f"const unsigned char *__restrict__ oc{K}_rmask", ("ocrs_rmask", K))
+        P(f"const unsigned long long *__restrict__ oc{K}_cmask", ("ocrs_cmask", K))
     P(f"const {ktype} *__restrict__ oc{K}_k", ("ocrs_kk", K))
     P(f"long long oc{K}_maxnnz", ("ocr_maxnnz", K))
     P(f"long long oc{K}_flags", ("ocr_flags", K))
@@ -995,6 +1003,8 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     scal = [("role", "(int)chunk_role_[(II - start) >> 6]"), ("slot", f"(int)oc{K}_slot[II - start]")]
     if B > 1:
         scal.append(("rlen", f"(int)oc{K}_rowlen[II - start]"))
+    if dofmask:
+        scal.append(("rmask", f"(int)oc{K}_rmask[II - start]"))
     virt = extruded or bool(gk._subset)
     if need_e:
         scal.append(("fd_v" if virt else "e", "inst_ent_[II - start]"))
@@ -1007,16 +1017,24 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     for n, ln, _ in rows:
         src.append(f"  int {n}[{ln}];" + (f" int nx_{n}[{ln}];" if pf else ""))
     src.append("  int " + ", ".join(f"{n} = 0" + (f", nx_{n} = 0" if pf else "") for n, _ in scal) + ";")
+    if dofmask:
+        src.append("  unsigned long long cmask = 0" + (", nx_cmask = 0;" if pf else ";"))
     if pf:
         src.append("  if (e0 + tid < e1) {")
         src += ["    " + l for l in loads("(e0 + tid)", "")]
+        if dofmask:
+            src.append(f"    cmask = oc{K}_cmask[(e0 + tid) - start];")
         src.append("  }")
     src.append("  for (int it = e0 + tid; it < e1; it += nthr) {")
     if pf:
         src.append("    const int itn = (it + nthr < e1) ? it + nthr : it;")
         src += ["    " + l for l in loads("itn", "nx_")]
+        if dofmask:
+            src.append(f"    nx_cmask = oc{K}_cmask[itn - start];")
     else:
         src += ["    " + l for l in loads("it", "")]
+        if dofmask:
+            src.append(f"    cmask = oc{K}_cmask[it - start];")
     if need_e and virt:
         if extruded:
             src += ["    const int fd_col = fd_v / fd_nlit; const int layer = fd_llo + (fd_v - fd_col*fd_nlit);",
@@ -1029,10 +1047,13 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     for r in range(AR):
         # element tensor t[(i*rbs + p)][(j*cbs + q)] (builder.py:573-625); CSR: scalar row (node, p) starts at
         # node_rowptr[node]*B + p*rowlen*cbs, column (k-th node of the row, q) sits at k*cbs + q
+        rg = "if ((rmask >> p) & 1) " if dofmask else ""
+        cg = f"if ((cmask >> (j*{CB} + q)) & 1ull) " if dofmask else ""
         if B == 1:
-            scatter = [f"        for (int j = 0; j < {AC}; ++j) if (kk[j] != {skip}) atomicAdd(&sm{K}[slot + kk[j]], t{K}[{r * AC} + j]);"]
+            scatter = [f"        for (int p = 0; p < 1; ++p) {rg}for (int j = 0; j < {AC}; ++j) if (kk[j] != {skip}) for (int q = 0; q < 1; ++q) {cg}"
+                       f"atomicAdd(&sm{K}[slot + kk[j]], t{K}[{r * AC} + j]);"]
         else:
-            scatter = [f"        for (int p = 0; p < {RB}; ++p) for (int j = 0; j < {AC}; ++j) if (kk[j] != {skip}) for (int q = 0; q < {CB}; ++q)",
+            scatter = [f"        for (int p = 0; p < {RB}; ++p) {rg}for (int j = 0; j < {AC}; ++j) if (kk[j] != {skip}) for (int q = 0; q < {CB}; ++q) {cg}",
                        f"          atomicAdd(&sm{K}[slot*{B} + (p*rlen + kk[j])*{CB} + q], t{K}[(({r * RB} + p)*{AC} + j)*{CB} + q]);"]
         src += [f"    case {r}: {{",
                 f"      double t{K}[{NT}]; for (int q = 0; q < {NT}; ++q) t{K}[q] = 0;",
@@ -1044,7 +1065,7 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     if pf:
         for n, ln, _ in rows:
             src.append(f"    for (int q = 0; q < {ln}; ++q) {n}[q] = nx_{n}[q];")
-        src.append("    " + " ".join(f"{n} = nx_{n};" for n, _ in scal))
+        src.append("    " + " ".join(f"{n} = nx_{n};" for n, _ in scal) + (" cmask = nx_cmask;" if dofmask else ""))
     src += ["  }", "  __syncthreads();"]
     if ordered:
         src.append(f"  for (int fr = tid >> 4; fr < nown; fr += nthr >> 4) {{ const int fp = n0 + fr; "

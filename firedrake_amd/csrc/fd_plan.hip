@@ -956,7 +956,10 @@ __global__ void ocrs_tables_k(const int32_t *__restrict__ inst_off, int32_t nblo
                               const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                               const int32_t *__restrict__ acc_by_node, const int32_t *__restrict__ acc_by_pos,
                               const int32_t *__restrict__ rblk, const int32_t *__restrict__ rlg, const int32_t *__restrict__ clg,
-                              uint16_t *__restrict__ slot, uint16_t *__restrict__ rowlen, KT *__restrict__ kk, int32_t *__restrict__ err) {
+                              uint16_t *__restrict__ slot, uint16_t *__restrict__ rowlen, KT *__restrict__ kk, int32_t *__restrict__ err,
+                              int rbs, int cbs, uint8_t *__restrict__ rmask, unsigned long long *__restrict__ cmask) {
+    // rmask != nullptr: per-DOF lgmaps (``unroll``): rlg / clg are indexed by node*bs + component; a node row (column) is
+    // dropped as a whole only when all its components are, the per-component bits go to rmask[t] / cmask[t]
     const KT SKIP = (KT)~(KT)0;
     const int64_t total = ninst * ac;
     for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u < total; u += (int64_t)gridDim.x * blockDim.x) {
@@ -965,7 +968,19 @@ __global__ void ocrs_tables_k(const int32_t *__restrict__ inst_off, int32_t nblo
         const int role = chunk_role[t >> 6];
         const int32_t e = ent[t];
         const int32_t r = rmap[(int64_t)e * ar + role];
-        const bool live = valid[t] && r >= 0 && !(rlg && rlg[r] < 0);
+        unsigned rm = 0;
+        if (rmask && r >= 0) { for (int p = 0; p < rbs; ++p) if (!rlg || rlg[(int64_t)r * rbs + p] >= 0) rm |= 1u << p; }
+        const bool live = valid[t] && r >= 0 && (rmask ? rm != 0 : !(rlg && rlg[r] < 0));
+        if (rmask && j == 0) {
+            rmask[t] = live ? (uint8_t)rm : (uint8_t)0;
+            unsigned long long cmk = 0;
+            for (int jj = 0; jj < ac; ++jj) {
+                const int32_t cc = cmap[(int64_t)e * ac + jj];
+                for (int q = 0; q < cbs; ++q)
+                    if (cc >= 0 && (!clg || clg[(int64_t)cc * cbs + q] >= 0)) cmk |= 1ull << (jj * cbs + q);
+            }
+            cmask[t] = live ? cmk : 0ull;
+        }
         if (j == 0) {
             uint16_t sl = 0xffffu;
             if (live) {
@@ -983,7 +998,7 @@ __global__ void ocrs_tables_k(const int32_t *__restrict__ inst_off, int32_t nblo
         }
         KT v = SKIP;
         const int32_t c = cmap[(int64_t)e * ac + j];
-        if (live && c >= 0 && !(clg && clg[c] < 0)) {
+        if (live && c >= 0 && (rmask || !(clg && clg[c] < 0))) {
             int lo = rowptr[r], hi = rowptr[r + 1] - 1, pos = -1;
             while (lo <= hi) {
                 int mid = (lo + hi) >> 1;
@@ -1263,10 +1278,13 @@ int fd_ocrplan_sliced_arrays(fd_ocrplan_t p, const uint8_t **chunk_role_dev, con
 int fd_ocrplan_sliced_tables(fd_ocrplan_t p, const int32_t *rmap_dev, const int32_t *cmap_dev, int ac, const int32_t *rowptr_dev,
                              const int32_t *colidx_dev, const int32_t *acc_by_node_dev, const int32_t *acc_by_pos_dev,
                              const int32_t *row_lgmap_dev, const int32_t *col_lgmap_dev, int kbytes, uint16_t *slot_out_dev,
-                             uint16_t *rowlen_out_dev, void *kk_out_dev, fd_stream_t s_) {
+                             uint16_t *rowlen_out_dev, void *kk_out_dev, int rbs, int cbs, uint8_t *rowmask_out_dev,
+                             uint64_t *colmask_out_dev, fd_stream_t s_) {
     if (!p || !p->sliced_ar || !rmap_dev || !cmap_dev || ac <= 0 || !rowptr_dev || !colidx_dev || !acc_by_node_dev || !acc_by_pos_dev ||
         !slot_out_dev || !kk_out_dev || (kbytes != 1 && kbytes != 2))
         FD_FAIL("fd_ocrplan_sliced_tables: bad arguments");
+    if ((rowmask_out_dev != nullptr) != (colmask_out_dev != nullptr) || (rowmask_out_dev && (rbs < 1 || rbs > 8 || cbs < 1 || ac * cbs > 64)))
+        FD_FAIL("fd_ocrplan_sliced_tables: per-dof masks need both outputs, rbs <= 8 and carity*cbs <= 64");
     if (p->ninst == 0) return 0;
     hipStream_t s = fd::st(s_);
     int32_t *err = nullptr;
@@ -1276,11 +1294,13 @@ int fd_ocrplan_sliced_tables(fd_ocrplan_t p, const int32_t *rmap_dev, const int3
     if (kbytes == 1)
         hipLaunchKernelGGL(ocrs_tables_k<uint8_t>, dim3(mp_grid(total)), dim3(256), 0, s, p->inst_off, p->nblocks, p->inst_ent, p->valid,
                            p->chunk_role, p->ninst, rmap_dev, p->sliced_ar, cmap_dev, ac, rowptr_dev, colidx_dev, acc_by_node_dev,
-                           acc_by_pos_dev, p->rblk, row_lgmap_dev, col_lgmap_dev, slot_out_dev, rowlen_out_dev, (uint8_t *)kk_out_dev, err);
+                           acc_by_pos_dev, p->rblk, row_lgmap_dev, col_lgmap_dev, slot_out_dev, rowlen_out_dev, (uint8_t *)kk_out_dev, err,
+                           rbs, cbs, rowmask_out_dev, (unsigned long long *)colmask_out_dev);
     else
         hipLaunchKernelGGL(ocrs_tables_k<uint16_t>, dim3(mp_grid(total)), dim3(256), 0, s, p->inst_off, p->nblocks, p->inst_ent, p->valid,
                            p->chunk_role, p->ninst, rmap_dev, p->sliced_ar, cmap_dev, ac, rowptr_dev, colidx_dev, acc_by_node_dev,
-                           acc_by_pos_dev, p->rblk, row_lgmap_dev, col_lgmap_dev, slot_out_dev, rowlen_out_dev, (uint16_t *)kk_out_dev, err);
+                           acc_by_pos_dev, p->rblk, row_lgmap_dev, col_lgmap_dev, slot_out_dev, rowlen_out_dev, (uint16_t *)kk_out_dev, err,
+                           rbs, cbs, rowmask_out_dev, (unsigned long long *)colmask_out_dev);
     FD_CHECK_LAUNCH();
     int32_t h = 0;
     FD_HIP(hipMemcpyAsync(&h, err, 4, hipMemcpyDeviceToHost, s));

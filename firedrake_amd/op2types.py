@@ -2004,27 +2004,31 @@ class SlicedOcrPlan:
             self.plans[key] = Plan(imap.ptr, 0, int(self.ninst), 0, self.inst_off_host, arity=m.arity)
         self._tables = {}
 
-    def tables(self, rlg, clg, lgmap_ptr):
-        """(slot buffer, column-position buffer, row-length buffer or None) for the lgmap objects ``rlg`` / ``clg`` (None = no masking);
+    def tables(self, rlg, clg, lgmap_ptr, per_dof=False):
+        """(slot, column positions, row lengths or None, row masks or None, column masks or None) for the lgmap objects ``rlg`` /
+        ``clg`` (None = no masking); ``per_dof``: the lgmaps are indexed by node*bs + component (``unroll``) and the last two are built;
         ``lgmap_ptr(obj)`` gives the device pointer of an lgmap.  Keyed by object identity (lgmaps are immutable, like the
         reference's PETSc LGMaps); the entry keeps the objects alive so that an id cannot be recycled."""
-        key = (id(rlg), id(clg))
+        key = (id(rlg), id(clg), bool(per_dof))
         t = self._tables.pop(key, None)
         if t is None:
             slot = DeviceBuffer(max(self.ninst, 1) * 2)
             kk = DeviceBuffer(max(self.ninst, 1) * self._cmap.arity * self.kbytes)
             rlen = DeviceBuffer(max(self.ninst, 1) * 2) if self.block > 1 else None
+            rmask = DeviceBuffer(max(self.ninst, 1)) if per_dof else None
+            cmask = DeviceBuffer(max(self.ninst, 1) * 8) if per_dof else None
             sp, ro = self._sp, self.row_order
             _lib.call("fd_ocrplan_sliced_tables", self.h, self._rmap._dev_values(), self._cmap._dev_values(), self._cmap.arity,
                       sp._node_rowptr.ptr, sp._node_colidx.ptr, ro.nstart.ptr if ro is not None else sp._node_rowptr.ptr,
                       ro.prowptr.ptr if ro is not None else sp._node_rowptr.ptr,
                       lgmap_ptr(rlg) if rlg is not None else None, lgmap_ptr(clg) if clg is not None else None,
-                      self.kbytes, slot.ptr, rlen.ptr if rlen is not None else None, kk.ptr, None)
-            t = (slot, kk, rlen, rlg, clg)
+                      self.kbytes, slot.ptr, rlen.ptr if rlen is not None else None, kk.ptr,
+                      int(sp.dsets[0].cdim), int(sp.dsets[1].cdim), rmask.ptr if per_dof else None, cmask.ptr if per_dof else None, None)
+            t = (slot, kk, rlen, rmask, cmask, rlg, clg)
             while len(self._tables) >= self.MAX_TABLE_SETS:
                 self._tables.pop(next(iter(self._tables)))
         self._tables[key] = t                       # most recently used last
-        return t[0], t[1], t[2]
+        return t[:5]
 
     def __del__(self):
         try:

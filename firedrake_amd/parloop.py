@@ -929,10 +929,11 @@ class Parloop:
                 out.append(op.kidx.ptr)
             elif kind == "ocrs_chunk_role":
                 out.append(op.chunk_role)
-            elif kind in ("ocrs_slot", "ocrs_kk", "ocrs_rowlen"):
+            elif kind in ("ocrs_slot", "ocrs_kk", "ocrs_rowlen", "ocrs_rmask", "ocrs_cmask"):
                 lg = self.arguments[desc[1]].lgmaps
-                tabs = op.tables(lg[0] if lg else None, lg[1] if lg else None, self._lgmap)
-                out.append(tabs[{"ocrs_slot": 0, "ocrs_kk": 1, "ocrs_rowlen": 2}[kind]].ptr)
+                per_dof = bool(lg) and bool(self.global_kernel.arguments[desc[1]].unroll)
+                tabs = op.tables(lg[0] if lg else None, lg[1] if lg else None, self._lgmap, per_dof=per_dof)
+                out.append(tabs[{"ocrs_slot": 0, "ocrs_kk": 1, "ocrs_rowlen": 2, "ocrs_rmask": 3, "ocrs_cmask": 4}[kind]].ptr)
             elif kind == "ocr_maxnnz":
                 out.append(op.max_nnz)
             elif kind == "ocr_maxnown":

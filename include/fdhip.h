@@ -216,7 +216,10 @@ int fd_ocrplan_sliced_tables(fd_ocrplan_t p, const int32_t *rmap_dev, const int3
                              const int32_t *rowptr_dev, const int32_t *colidx_dev, const int32_t *acc_by_node_dev,
                              const int32_t *acc_by_pos_dev, const int32_t *row_lgmap_dev, const int32_t *col_lgmap_dev,
                              int kbytes, uint16_t *slot_out_dev, uint16_t *rowlen_out_dev /* nullable: entries of the
-                             instance's CSR node row, needed to address vector-valued blocks */, void *kk_out_dev, fd_stream_t s);
+                             instance's CSR node row, needed to address vector-valued blocks */, void *kk_out_dev,
+                             int rbs, int cbs, uint8_t *rowmask_out_dev, uint64_t *colmask_out_dev /* both nullable; given:
+                             the lgmaps are per DOF (node*bs + component; MatSetValuesLocal on dof indices, mat.py:700-716):
+                             bit p of rowmask / bit j*cbs+q of colmask = that scalar row / column survives */, fd_stream_t s);
 int fd_gather_rows(const int32_t *src_dev, int arity, const int32_t *idx_dev, int64_t n, int32_t *dst_dev, fd_stream_t s);
 int fd_csr_elem_row_offsets(const int32_t *rowptr_dev, const int32_t *colidx_dev, const int32_t *rmap_dev,
                             const int32_t *cmap_dev, int32_t nent, int rarity, int carity, int kbytes,

@@ -171,11 +171,12 @@ def ocr_plan_ref(rmapv, cmapv, nent, row_blocks, rowptr, colidx, pinv=None):
 
 
 def ocrs_plan_ref(rmapv, cmapv, start, end, row_blocks, rowptr, colidx, acc_by_node, acc_by_pos, pinv=None, rlg=None, clg=None,
-                  interleave=0):
+                  interleave=0, per_dof=None):
     """numpy restatement of the row-sliced plan (include/fdhip.h: fd_ocrplan_create_sliced + fd_ocrplan_sliced_tables):
     instances (entity, local row i) for every row-map entry inside a row block, per block grouped by i (entity order inside
     a group), every group padded to a multiple of 64 slots with copies of its last entity.  Returns (padded inst_off,
-    inst_ent, chunk_role, valid, slot, kk, rowlen)."""
+    inst_ent, chunk_role, valid, slot, kk, rowlen).  ``per_dof=(rbs, cbs)``: the lgmaps are per DOF (``unroll``); the result
+    gains the row masks (uint8) and column masks (uint64)."""
     ar, ac = rmapv.shape[1], cmapv.shape[1]
     rows = np.asarray(rmapv)[start:end]
     pos = rows
@@ -203,22 +204,33 @@ def ocrs_plan_ref(rmapv, cmapv, start, end, row_blocks, rowptr, colidx, acc_by_n
     slot = np.full(len(ent), 0xffff, dtype=np.uint16)
     kk = np.full((len(ent), ac), 0xff, dtype=np.uint8)
     rowlen = np.zeros(len(ent), dtype=np.uint16)
+    rmask, cmask = np.zeros(len(ent), dtype=np.uint8), np.zeros(len(ent), dtype=np.uint64)
     blk = np.searchsorted(np.asarray(inst_off), np.arange(len(ent)), side="right") - 1
     for t, e in enumerate(ent):
         r = rmapv[e, role[t // 64]]
         if r >= 0:
             rowlen[t] = rowptr[r + 1] - rowptr[r]
-        if not valid[t] or r < 0 or (rlg is not None and rlg[r] < 0):
+        if per_dof is not None:
+            rbs, cbs = per_dof
+            rm = sum(1 << p for p in range(rbs) if r >= 0 and (rlg is None or rlg[r * rbs + p] >= 0))
+            if not valid[t] or r < 0 or rm == 0:
+                continue
+            rmask[t] = rm
+            cmask[t] = np.uint64(sum(1 << (j * cbs + q) for j in range(ac) for q in range(cbs)
+                                     if cmapv[e, j] >= 0 and (clg is None or clg[cmapv[e, j] * cbs + q] >= 0)))
+        elif not valid[t] or r < 0 or (rlg is not None and rlg[r] < 0):
             continue
         slot[t] = acc_by_node[r] - acc_by_pos[row_blocks[blk[t]]]
         row = colidx[rowptr[r]:rowptr[r + 1]]
         for j in range(ac):
             c = cmapv[e, j]
-            if c < 0 or (clg is not None and clg[c] < 0):
+            if c < 0 or (per_dof is None and clg is not None and clg[c] < 0):
                 continue
             q = int(np.searchsorted(row, c))
             assert q < len(row) and row[q] == c and q < 255
             kk[t, j] = q
+    if per_dof is not None:
+        return np.array(inst_off, np.int32), ent, role, valid, slot, kk, rowlen, rmask, cmask
     return np.array(inst_off, np.int32), ent, role, valid, slot, kk, rowlen
 
 

@@ -256,7 +256,7 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None):
     from firedrake_amd.codegen import _ocr_shape, mode_variant
     from helpers import first_touch_ref, ocrs_plan_ref, plan_ref_blocks
     gk = pl.global_kernel
-    assert _ocr_shape(gk, mats_on_virtual=True) is not None
+    assert _ocr_shape(gk, mats_on_virtual=True, allow_unroll=True) is not None
     (k, mpa), = [(k, pa) for k, pa in enumerate(pl.arguments) if isinstance(pa, MatParloopArg)]
     # subsets / extruded sets: the plan lives on the derived maps over the virtual (position x layer) space
     virt = pl._virtual(staged=True)
@@ -292,9 +292,11 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None):
     rb = np.unique(np.concatenate([np.searchsorted(acc[:nrows + 1], targets, side="left"), [0, nrows]]))
     rb = rb[rb <= nrows].astype(np.int32)
     lg = mpa.lgmaps
-    inst_off, inst_ent, chunk_role, valid, slot, kk, rowlen = ocrs_plan_ref(
+    per_dof = (sp.dsets[0].cdim, sp.dsets[1].cdim) if (lg is not None and gk.arguments[k].unroll) else None
+    res = ocrs_plan_ref(
         np.asarray(rmap.values_with_halo), np.asarray(cmap.values_with_halo), 0, nent, rb, ncsr.rowptr, ncsr.colidx, acc_by_node, acc,
-        pinv=pinv, rlg=None if lg is None else np.asarray(lg[0]), clg=None if lg is None else np.asarray(lg[1]))
+        pinv=pinv, rlg=None if lg is None else np.asarray(lg[0]), clg=None if lg is None else np.asarray(lg[1]), per_dof=per_dof)
+    inst_off, inst_ent, chunk_role, valid, slot, kk, rowlen = res[:7]
     plans = {}
     for mi in base.staged_maps:
         blk, lst, lm = plan_ref_blocks(np.asarray(maps[mi].values_with_halo)[inst_ent], inst_off)
@@ -357,6 +359,10 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None):
             cargs.append(ptr(slot))
         elif kind == "ocrs_rowlen":
             cargs.append(ptr(rowlen))
+        elif kind == "ocrs_rmask":
+            cargs.append(ptr(res[7]))
+        elif kind == "ocrs_cmask":
+            cargs.append(ptr(res[8]))
         elif kind == "ocrs_kk":
             cargs.append(ptr(kk))
         elif kind == "ocr_maxnnz":

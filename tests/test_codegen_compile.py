@@ -173,3 +173,33 @@ def test_scratch_directed_unrolling(monkeypatch):
     monkeypatch.setattr(GlobalKernel, "_cache", {})
     cw1 = build().compile("ocrs")
     assert kernel_resources(cw1.path, cw1.src.symbol)["scratch"] == 0 and "-unroll-threshold=30000" in cw1.src.extra_flags
+
+
+def test_row_sliced_variants_for_blocks_dof_masks_and_virtual_spaces():
+    """The sliced wrapper's other shapes cross-compile without scratch: vector-valued blocks (row length table), per-dof
+    lgmaps (row / column bit masks), and a matrix loop over an extruded subset with a direct argument and the layer argument."""
+    from firedrake_amd.codegen import select_mode
+    from firedrake_amd.compilation import kernel_resources
+    from mixed_cases import vector_p1_elasticity_kernel
+    nodes, ele = op2.Set(40), op2.Set(2)
+    cm = op2.Map(ele, nodes, 4, np.arange(8))
+    x = op2.Dat(nodes ** 3)
+    lg = np.arange(120, dtype=np.int32)
+    for unroll in (False, True):
+        mat = op2.Mat(op2.Sparsity((nodes ** 3, nodes ** 3), [(cm, cm, None)]))
+        pl = op2.LegacyParloop(vector_p1_elasticity_kernel(3), ele, mat(op2.INC, (cm, cm), lgmaps=(lg, lg), unroll_map=unroll), x(op2.READ, cm))
+        assert select_mode(pl.global_kernel) == "ocrs"
+        cw = pl.global_kernel.compile("ocrsp")
+        assert ("_rmask" in cw.src.source) == unroll and "_rowlen" in cw.src.source
+        assert kernel_resources(cw.path, cw.src.symbol)["scratch"] == 0
+    base = op2.Set(4)
+    ext = op2.ExtrudedSet(base, layers=5)
+    en = op2.Set(6 * 5)
+    em = op2.Map(ext, en, 6, np.arange(24) % 25, offset=[1] * 6)
+    emat = op2.Mat(op2.Sparsity((en ** 1, en ** 1), [(em, em, None)]))
+    w = op2.Dat(ext)
+    k = op2.Kernel("static void pk(double *A, const double *w, int layer) { for (int i = 0; i < 36; ++i) A[i] += w[0] + layer; }", "pk")
+    pl = op2.LegacyParloop(k, op2.Subset(ext, [0, 2]), emat(op2.INC, (em, em)), w(op2.READ), pass_layer_arg=True)
+    assert select_mode(pl.global_kernel) == "ocrs"
+    cw = pl.global_kernel.compile("ocrs")
+    assert "subset_indices[fd_col]" in cw.src.source and kernel_resources(cw.path, cw.src.symbol)["scratch"] == 0

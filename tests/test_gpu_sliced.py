@@ -62,7 +62,7 @@ def test_sliced_plan_matches_numpy_restatement(ordered, interleave, monkeypatch)
         assert np.array_equal(down(op.chunk_role, np.uint8, (op.ninst // 64,)), role)
         assert np.array_equal(down(op.valid, np.uint8, (op.ninst,)), valid)
         keep = []
-        s_, k_, _ = op.tables(lgs[0], lgs[1], lambda a: keep.append(DeviceBuffer.from_numpy(a)) or keep[-1].ptr)
+        s_, k_, *_ = op.tables(lgs[0], lgs[1], lambda a: keep.append(DeviceBuffer.from_numpy(a)) or keep[-1].ptr)
         assert np.array_equal(s_.download(np.uint16, (op.ninst,)), slot)
         assert np.array_equal(k_.download(np.uint8, kk.shape), kk)
 
@@ -246,3 +246,39 @@ def test_matrix_over_an_extruded_set_against_oracle_and_direct(region, monkeypat
     pl2()
     assert pl2._prepare()["cw"].src.mode == "direct"
     assert_allclose(mat2.csr()[2], ref.values, rtol=0, atol=1e-12 * np.abs(ref.values).max())
+
+
+def test_per_dof_lgmaps_against_oracle():
+    """``unroll_map`` (MatSetValuesLocal on dof indices, mat.py:700-716): component-wise Dirichlet conditions on a vector
+    space travel as per-instance row / column bit masks; against the oracle, and the masks against the numpy restatement."""
+    from helpers import ocrs_plan_ref
+    from mixed_cases import vector_p1_elasticity_kernel
+    mesh = fmesh.UnitCubeMesh(8, degrees=(1,), tile=(4, 4, 2), perturb=0.1)
+    V = mesh.space(1)
+    cm = V.cell_node_map
+    sp = op2.Sparsity((V.node_set ** 3, V.node_set ** 3), [(cm, cm, None)])
+    mat = op2.Mat(sp)
+    rng = np.random.default_rng(6)
+    nn = V.node_set.total_size
+    rlg, clg = np.arange(3 * nn, dtype=np.int32), np.arange(3 * nn, dtype=np.int32)
+    fx, fz = rng.choice(nn, nn // 4, replace=False), rng.choice(nn, nn // 5, replace=False)
+    rlg[3 * fx] = -1
+    rlg[3 * fz + 2] = -1
+    clg[3 * fx] = -1
+    clg[3 * rng.choice(nn, nn // 7, replace=False) + 1] = -1
+    k = vector_p1_elasticity_kernel(3)
+    args = lambda: (mat(op2.INC, (cm, cm), lgmaps=(rlg, clg), unroll_map=True), mesh.coordinates(op2.READ, cm))
+    pl = op2.LegacyParloop(k, mesh.cell_set, *args())
+    pl()
+    assert pl._prepare()["cw"].src.mode.startswith("ocrs")
+    ref = oracle_run(k, mesh.cell_set, *args())[0]
+    assert_allclose(mat.csr()[2], ref.values, rtol=0, atol=1e-12 * np.abs(ref.values).max())
+    op = pl._ocr_geometry()["ocr"]
+    tabs = op.tables(rlg, clg, pl._lgmap, per_dof=True)
+    nrp = np.asarray(sp._node_rowptr.download(np.int32, (nn + 1,)))
+    nci = np.asarray(sp._node_colidx.download(np.int32, (sp._node_nnz,)))
+    res = ocrs_plan_ref(np.asarray(cm.values_with_halo), np.asarray(cm.values_with_halo), 0, mesh.cell_set.size, op.row_blocks, nrp, nci, nrp, nrp,
+                        rlg=rlg, clg=clg, interleave=configuration["ocrs_interleave"], per_dof=(3, 3))
+    assert np.array_equal(tabs[0].download(np.uint16, (op.ninst,)), res[4])
+    assert np.array_equal(tabs[3].download(np.uint8, (op.ninst,)), res[7])
+    assert np.array_equal(tabs[4].download(np.uint64, (op.ninst,)), res[8])

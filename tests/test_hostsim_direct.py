@@ -672,3 +672,38 @@ static void prism(double *A, const double *x, const double *w, int layer)
     ref = oracle_run(k, it, mat(op2.INC, (m, m)), x(op2.READ, m), w(op2.READ), **kw)[0]
     assert np.array_equal(got.rowptr, ref.rowptr) and np.array_equal(got.colidx, ref.colidx)
     assert np.abs(got.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
+
+
+@pytest.mark.parametrize("numbering", ["tiled", "random"])
+def test_row_sliced_per_dof_lgmaps_on_host(numbering):
+    """``unroll_map``: MatSetValuesLocal on dof indices with per-dof lgmaps (mat.py:700-716) -- component-wise Dirichlet
+    conditions on a vector space: the x-component fixed on some nodes, the z-component on others.  The sliced wrapper carries
+    them as an 8-bit row mask and a 64-bit column mask per instance."""
+    from firedrake_amd import mesh as fmesh
+    from firedrake_amd.codegen import select_mode
+    from helpers import locality_order_ref
+    from hostsim import run_ocrs
+    from mixed_cases import vector_p1_elasticity_kernel
+    mesh = fmesh.UnitCubeMesh(3, degrees=(1,), perturb=0.1, numbering=numbering)
+    V = mesh.space(1)
+    cm = V.cell_node_map
+    mat = op2.Mat(op2.Sparsity((V.node_set ** 3, V.node_set ** 3), [(cm, cm, None)]))
+    rng = np.random.default_rng(6)
+    nn = V.node_set.total_size
+    rlg, clg = np.arange(3 * nn, dtype=np.int32), np.arange(3 * nn, dtype=np.int32)
+    fixed_x, fixed_z = rng.choice(nn, nn // 4, replace=False), rng.choice(nn, nn // 5, replace=False)
+    rlg[3 * fixed_x] = -1
+    rlg[3 * fixed_z + 2] = -1
+    clg[3 * fixed_x] = -1
+    clg[3 * rng.choice(nn, nn // 7, replace=False) + 1] = -1
+    k = vector_p1_elasticity_kernel(3)
+    args = lambda: (mat(op2.INC, (cm, cm), lgmaps=(rlg, clg), unroll_map=True), mesh.coordinates(op2.READ, cm))
+    pl = op2.LegacyParloop(k, mesh.cell_set, *args())
+    assert select_mode(pl.global_kernel) == "ocrs"
+    order = None
+    if numbering == "random":
+        order, _ = locality_order_ref(cm.values_with_halo, 0, mesh.cell_set.size, np.array(mesh.coordinates.data_ro))
+    ref = oracle_run(k, mesh.cell_set, *args())[0]
+    got = run_ocrs(pl, nnz_per_block=60, order=order)
+    assert np.abs(got.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
+    assert np.count_nonzero(ref.values == 0.0) > 0.05 * len(ref.values)         # the masks dropped something
