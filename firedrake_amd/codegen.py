@@ -160,7 +160,7 @@ def select_mode(gk: GlobalKernel) -> str:
         return "direct"
     if configuration["mat_ocr"] and sliced_eligible(gk):
         return "ocrs"
-    if ok and configuration["mat_ocr"] and ocr_eligible(gk):
+    if configuration["mat_ocr"] and ocr_eligible(gk):
         return "ocr"
     return "staged" if ok else "direct"
 
@@ -215,8 +215,9 @@ def _ocr_shape(gk: GlobalKernel, mats_on_virtual: bool = False, allow_unroll: bo
 
 
 def ocr_eligible(gk: GlobalKernel) -> bool:
-    """Owner-computes-rows matrix assembly with whole-entity instances: scalar blocks only."""
-    a = _ocr_shape(gk)
+    """Owner-computes-rows matrix assembly with whole-entity instances: scalar blocks, per-node lgmaps; also over subsets and
+    extruded sets (constant layers, regions ALL / ON_BOTTOM / ON_TOP: the plans are built on derived maps)."""
+    a = _ocr_shape(gk, mats_on_virtual=True)
     return a is not None and int(np.prod(a.dims[0])) * int(np.prod(a.dims[1])) == 1
 
 
@@ -225,7 +226,8 @@ def sliced_eligible(gk: GlobalKernel) -> bool:
     least ``ocr_sliced_min_arity`` scalar rows (row-map arity x row block size) -- the size from which one node's rows cost
     much less than the whole (P2 tets: 10 rows; measured on the P2 stiffness kernel: 233 fp64 instructions for one row
     against 599 for all ten, i.e. the rows share little beyond the geometry, while an unsliced row block recomputes whole
-    entities x2.2-3.4).  Vector-valued blocks (MatSetValuesBlockedLocal, builder.py:573-625) are sliced per NODE: an
+    entities x2.2-3.4).  The threshold is a proxy: what slicing repeats per row is the part of the kernel all rows share, so
+    kernels that evaluate the geometry at every quadrature point (Q1 hexahedra: 8 rows, 8 points) are better off whole.  Vector-valued blocks (MatSetValuesBlockedLocal, builder.py:573-625) are sliced per NODE: an
     instance owns the ``rbs`` scalar rows of one node."""
     a = _ocr_shape(gk, mats_on_virtual=True, allow_unroll=True) if configuration["ocr_sliced"] else None
     if a is None:
@@ -237,10 +239,9 @@ def sliced_eligible(gk: GlobalKernel) -> bool:
     entries = a.maps[0].arity * a.maps[1].arity * int(np.prod(a.dims[0])) * int(np.prod(a.dims[1]))
     if a.maps[0].arity > configuration["ocr_sliced_max_arity"] or entries > configuration["ocr_sliced_max_entries"]:
         return False
-    if gk._extruded or gk._subset:
-        # virtual iteration spaces (subset rows, (column, layer) cells; constant layers, regions ALL / ON_BOTTOM / ON_TOP, see
-        # staged_eligible): the plans are built on derived maps, and the only other matrix path there scatters with global
-        # atomics -- sliced whatever the size of the element matrix
+    if not ocr_eligible(gk):
+        # vector-valued blocks, per-dof lgmaps: whole-entity instances do not cover them, and the only other path scatters
+        # every entry with a global atomic -- sliced whatever the size of the element matrix
         return True
     return a.maps[0].arity * int(np.prod(a.dims[0])) >= configuration["ocr_sliced_min_arity"]
 
@@ -719,7 +720,10 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         # run, so the lanes of one trip work on entities that are far apart (no shared nodes -> no serialised LDS
         # atomics) while their index rows stay coalesced.  OCR instance lists are stored in that order already.
         lane_threads = threads if configuration["lane_strided"] else 0
-        virt = (extruded or gk._subset or ordered) and not ocr
+        # virtual iteration spaces: positions in a subset / (column, layer) cells / a derived entity order; the staged and the
+        # owner-computes-rows wrappers address everything through plans built on derived maps and decode the position only for
+        # direct arguments and the layer argument
+        virt = bool(extruded or gk._subset or ordered)
         if virt:
             if extruded:
                 lo, hi = {ALL: ("layers[0]", "layers[1]-1"), ON_BOTTOM: ("layers[0]", "layers[0]+1"),

@@ -432,7 +432,7 @@ class Parloop:
         gk = self.global_kernel
         if staged is None:
             mode = self._prepared["cw"].src.mode
-            staged = mode.startswith("staged") or mode.startswith("ocrs")
+            staged = mode.startswith("staged") or mode.startswith("ocr")
         if not (gk._extruded or gk._subset) or not staged:
             return None
         if not gk._extruded:
@@ -654,7 +654,8 @@ class Parloop:
                         self._staged_geometry(off * k, (off + size) * k)
                 return
             except PlanDoesNotFit as exc:
-                nxt = "staged" if mode.startswith("ocr") else "direct"
+                from .codegen import staged_eligible
+                nxt = "staged" if (mode.startswith("ocr") and staged_eligible(self.global_kernel)) else "direct"
                 if configuration["debug"]:
                     import sys
                     print(f"[fdhip] {self.global_kernel.name}: {exc}; falling back to the {nxt} wrapper", file=sys.stderr)
@@ -731,9 +732,13 @@ class Parloop:
         src = prep["cw"].src
         if src.mode.startswith("ocrs"):
             return self._ocrs_geometry(start, end, gkey)
-        maps = prep["maps"]
+        # subsets / extruded sets: every map is replaced by its derived map over the virtual (position x layer) space
+        maps = [self._plan_map(m._base(), staged=True) for m in prep["maps"]]
+        v = self._virtual(staged=True)
+        if v is not None:
+            start, end = start * v[0], end * v[0]
         (k, pa), = [(k, a) for k, a in enumerate(self.arguments) if isinstance(a, MatParloopArg)]
-        rmap, cmap = pa.maps
+        rmap, cmap = (self._plan_map(m._base(), staged=True) for m in pa.maps)
         sp = pa.data.sparsity
         sp._build()
         nrows = rmap.toset.size                                   # owned rows only

@@ -152,16 +152,19 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None):
     gk = pl.global_kernel
     assert ocr_eligible(gk)
     (k, mpa), = [(k, pa) for k, pa in enumerate(pl.arguments) if isinstance(pa, MatParloopArg)]
-    maps = []
+    # subsets / extruded sets: the plan lives on the derived maps over the virtual (position x layer) space
+    virt = pl._virtual(staged=True)
+    base_maps, maps = [], []
     for pa in pl.arguments:
         for m in getattr(pa, "maps", ()):
-            if all(m._base() is not q for q in maps):
-                maps.append(m._base())
+            if all(m._base() is not q for q in base_maps):
+                base_maps.append(m._base())
+                maps.append(pl._plan_map(m._base(), staged=True))
     base = generate_wrapper(gk, "ocr")
     T = base.block_threads
     csr = oracle_pattern(mpa.data.sparsity)
-    rmap, cmap = (m._base() for m in mpa.maps)
-    nent = pl.iterset.size
+    rmap, cmap = (pl._plan_map(m._base(), staged=True) for m in mpa.maps)
+    nent = pl.iterset.size * (virt[0] if virt else 1)
     nrows = rmap.toset.size
     rb = np.array(list(range(0, nrows, rows_per_block)) + [nrows], dtype=np.int32)
     plist = pinv = prowptr = None
@@ -196,7 +199,11 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None):
     cargs = [ctypes.c_int(len(rb) - 1), ctypes.c_int(T), ctypes.c_int(0), ctypes.c_int(len(inst_ent))]
     for desc in src.layout:
         kind = desc[0]
-        if kind == "arg":
+        if kind == "layers":
+            cargs.append(ptr(np.asarray(pl.iterset.layers_array, dtype=np.int32)))
+        elif kind == "subset":
+            cargs.append(ptr(np.asarray(pl.iterset.indices, dtype=np.int32)))
+        elif kind == "arg":
             pa = pl.arguments[desc[1]]
             if isinstance(pa, MatParloopArg):
                 cargs.append(ctypes.c_void_p(csr.values.ctypes.data))
@@ -204,7 +211,7 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None):
                 host = pa.data._host if pa.data._host_valid else pa.data._to_host()
                 cargs.append(ptr(np.array(host, copy=True)))
         elif kind == "map":
-            cargs.append(ptr(np.asarray(maps[desc[1]].values_with_halo, dtype=np.int32)))
+            cargs.append(ptr(np.asarray(base_maps[desc[1]].values_with_halo, dtype=np.int32)))
         elif kind == "bstart":
             cargs.append(ptr(inst_off))
         elif kind == "ocr_inst_ent":

@@ -200,6 +200,7 @@ def test_row_sliced_variants_for_blocks_dof_masks_and_virtual_spaces():
     w = op2.Dat(ext)
     k = op2.Kernel("static void pk(double *A, const double *w, int layer) { for (int i = 0; i < 36; ++i) A[i] += w[0] + layer; }", "pk")
     pl = op2.LegacyParloop(k, op2.Subset(ext, [0, 2]), emat(op2.INC, (em, em)), w(op2.READ), pass_layer_arg=True)
-    assert select_mode(pl.global_kernel) == "ocrs"
-    cw = pl.global_kernel.compile("ocrs")
-    assert "subset_indices[fd_col]" in cw.src.source and kernel_resources(cw.path, cw.src.symbol)["scratch"] == 0
+    assert select_mode(pl.global_kernel) == "ocr"             # 6 rows: whole-entity instances; both shapes exist on virtual spaces
+    for mode in ("ocrs", "ocr"):
+        cw = pl.global_kernel.compile(mode)
+        assert "subset_indices[fd_col]" in cw.src.source and kernel_resources(cw.path, cw.src.symbol)["scratch"] == 0

@@ -144,9 +144,10 @@ static void wk(double *A, const double *x, const double *w, const double *g)
     assert_allclose(mat.csr()[2], ref.values, rtol=0, atol=1e-12 * np.abs(ref.values).max())
 
 
-def test_long_rows_take_16_bit_column_positions():
+def test_long_rows_take_16_bit_column_positions(monkeypatch):
     """A hub node shared by 300 eight-node cells: its CSR row has 2101 entries, so the column positions no longer fit a
     byte ("ocrs_k16") and the hub's block is cut to that one long row."""
+    monkeypatch.setitem(configuration, "ocr_sliced_min_arity", 8)
     ncell, ar = 300, 8
     nn = 1 + ncell * (ar - 1)
     nodes, cells = op2.Set(nn), op2.Set(ncell)
@@ -223,10 +224,13 @@ def test_reference_vector_matrix_golden_through_the_sliced_wrapper(monkeypatch):
 
 
 @pytest.mark.parametrize("region", [None, "bottom"])
-def test_matrix_over_an_extruded_set_against_oracle_and_direct(region, monkeypatch):
-    """Extruded matrix assembly (node = map + offset*layer, builder.py:94-124) through the row-sliced wrapper over the derived
-    (column, layer) map: Q1 Helmholtz on a perturbed hex column mesh, against the oracle and the direct wrapper."""
+@pytest.mark.parametrize("sliced", [False, True])
+def test_matrix_over_an_extruded_set_against_oracle_and_direct(region, sliced, monkeypatch):
+    """Extruded matrix assembly (node = map + offset*layer, builder.py:94-124) through both owner-computes-rows wrappers over
+    the derived (column, layer) map: Q1 Helmholtz on a perturbed hex column mesh (8 rows: whole-entity instances by default,
+    row-sliced when the threshold is lowered), against the oracle and the direct wrapper."""
     from mixed_cases import q1_hex_helmholtz_kernel
+    monkeypatch.setitem(configuration, "ocr_sliced_min_arity", 8 if sliced else 10)
     m = fmesh.make_extruded_hex_mesh(12, 9, degree=1)
     cm, xm = m.cell_node_map, m.coord_map
     sp = op2.Sparsity((m.node_set ** 1, m.node_set ** 1), [(cm, cm, None)])
@@ -235,7 +239,7 @@ def test_matrix_over_an_extruded_set_against_oracle_and_direct(region, monkeypat
     mat = op2.Mat(sp)
     pl = op2.LegacyParloop(k, m.cell_set, mat(op2.INC, (cm, cm)), m.coordinates(op2.READ, xm), **kw)
     pl()
-    assert pl._prepare()["cw"].src.mode.startswith("ocrs")
+    assert pl._prepare()["cw"].src.mode.startswith("ocrs") == sliced and pl._prepare()["cw"].src.mode.startswith("ocr")
     ref = oracle_run(k, m.cell_set, mat(op2.INC, (cm, cm)), m.coordinates(op2.READ, xm), **kw)[0]
     rp, ci, v = mat.csr()
     assert np.array_equal(rp, ref.rowptr) and np.array_equal(ci, ref.colidx)

@@ -639,10 +639,11 @@ def test_row_sliced_vector_valued_blocks_on_host(numbering, bcs):
 @pytest.mark.parametrize("region", ["all", "bottom", "top"])
 @pytest.mark.parametrize("subset", [False, True])
 def test_row_sliced_matrix_over_extruded_sets_and_subsets_on_host(region, subset):
-    """Matrix loops over virtual iteration spaces take the row-sliced wrapper whatever their size: the plans are built on the
-    derived maps (one row ``map + offset*layer`` per (column, layer) cell, resp. the subset's rows), the virtual id is
-    decoded for the direct argument (base entity, parloop.py:494-497) and the layer argument only.  P1 prisms (arity 6) with
-    a coordinate field, a cell-wise coefficient and pass_layer_arg, against the oracle."""
+    """Matrix loops over virtual iteration spaces through both owner-computes-rows wrappers (whole-entity and row-sliced
+    instances): the plans are built on the derived maps (one row ``map + offset*layer`` per (column, layer) cell, resp. the
+    subset's rows), the virtual id is decoded for the direct argument (base entity, parloop.py:494-497) and the layer
+    argument only.  P1 prisms (arity 6) with a coordinate field, a cell-wise coefficient and pass_layer_arg, against the
+    oracle."""
     from firedrake_amd.codegen import select_mode
     from hostsim import run_ocrs
     nb, layers = 7, 6
@@ -667,11 +668,12 @@ static void prism(double *A, const double *x, const double *w, int layer)
     reg = {"all": None, "bottom": op2.ON_BOTTOM, "top": op2.ON_TOP}[region]
     kw = dict(iteration_region=reg, pass_layer_arg=True)
     pl = op2.LegacyParloop(k, it, mat(op2.INC, (m, m)), x(op2.READ, m), w(op2.READ), **kw)
-    assert select_mode(pl.global_kernel) == "ocrs"
-    got = run_ocrs(pl, nnz_per_block=150)
+    assert select_mode(pl.global_kernel) == "ocr"            # 6 rows: whole-entity instances, also on a virtual space
     ref = oracle_run(k, it, mat(op2.INC, (m, m)), x(op2.READ, m), w(op2.READ), **kw)[0]
-    assert np.array_equal(got.rowptr, ref.rowptr) and np.array_equal(got.colidx, ref.colidx)
-    assert np.abs(got.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
+    from hostsim import run_ocr
+    for got in (run_ocrs(pl, nnz_per_block=150), run_ocr(pl, rows_per_block=9)):
+        assert np.array_equal(got.rowptr, ref.rowptr) and np.array_equal(got.colidx, ref.colidx)
+        assert np.abs(got.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
 
 
 @pytest.mark.parametrize("numbering", ["tiled", "random"])
