@@ -218,7 +218,9 @@ def ocr_eligible(gk: GlobalKernel) -> bool:
     """Owner-computes-rows matrix assembly with whole-entity instances: scalar blocks, per-node lgmaps; also over subsets and
     extruded sets (constant layers, regions ALL / ON_BOTTOM / ON_TOP: the plans are built on derived maps)."""
     a = _ocr_shape(gk, mats_on_virtual=True)
-    return a is not None and int(np.prod(a.dims[0])) * int(np.prod(a.dims[1])) == 1
+    # (the element tensor and its row-offset table live in registers: bounded element matrices only)
+    return a is not None and int(np.prod(a.dims[0])) * int(np.prod(a.dims[1])) == 1 \
+        and a.maps[0].arity * a.maps[1].arity <= configuration["ocr_sliced_max_entries"]
 
 
 def sliced_eligible(gk: GlobalKernel) -> bool:
@@ -226,8 +228,9 @@ def sliced_eligible(gk: GlobalKernel) -> bool:
     least ``ocr_sliced_min_arity`` scalar rows (row-map arity x row block size) -- the size from which one node's rows cost
     much less than the whole (P2 tets: 10 rows; measured on the P2 stiffness kernel: 233 fp64 instructions for one row
     against 599 for all ten, i.e. the rows share little beyond the geometry, while an unsliced row block recomputes whole
-    entities x2.2-3.4).  The threshold is a proxy: what slicing repeats per row is the part of the kernel all rows share, so
-    kernels that evaluate the geometry at every quadrature point (Q1 hexahedra: 8 rows, 8 points) are better off whole.  Vector-valued blocks (MatSetValuesBlockedLocal, builder.py:573-625) are sliced per NODE: an
+    entities x2.2-3.4).  The threshold is a proxy for "the rows dominate what they share"; measured: P1 tets (4 rows) 2.09 ms
+    sliced against 1.03 whole, Q1 hexahedra with the geometry at 8 Gauss points (8 rows) 1.98 against 2.69, P2 tets (10
+    rows) 1.10 against 1.98.  Vector-valued blocks (MatSetValuesBlockedLocal, builder.py:573-625) are sliced per NODE: an
     instance owns the ``rbs`` scalar rows of one node."""
     a = _ocr_shape(gk, mats_on_virtual=True, allow_unroll=True) if configuration["ocr_sliced"] else None
     if a is None:

@@ -38,7 +38,7 @@ configuration = {
     # row-sliced owner-computes-rows (codegen.generate_sliced_wrapper): instances are (entity, local row), the local kernel is
     # instantiated once per row; pays when the rows of the element matrix dominate its shared (geometry) part
     "ocr_sliced": _env("FDHIP_OCR_SLICED", 1, int),
-    "ocr_sliced_min_arity": _env("FDHIP_OCR_SLICED_MIN_ARITY", 10, int),
+    "ocr_sliced_min_arity": _env("FDHIP_OCR_SLICED_MIN_ARITY", 8, int),
     "ocr_sliced_max_arity": _env("FDHIP_OCR_SLICED_MAX_ARITY", 32, int),
     "ocr_sliced_max_entries": _env("FDHIP_OCR_SLICED_MAX_ENTRIES", 1024, int),
     "ocrs_nnz_per_block": _env("FDHIP_OCRS_NNZ", 4096, int),     # accumulator entries per row block (x8 bytes of LDS)

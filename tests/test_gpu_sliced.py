@@ -227,8 +227,8 @@ def test_reference_vector_matrix_golden_through_the_sliced_wrapper(monkeypatch):
 @pytest.mark.parametrize("sliced", [False, True])
 def test_matrix_over_an_extruded_set_against_oracle_and_direct(region, sliced, monkeypatch):
     """Extruded matrix assembly (node = map + offset*layer, builder.py:94-124) through both owner-computes-rows wrappers over
-    the derived (column, layer) map: Q1 Helmholtz on a perturbed hex column mesh (8 rows: whole-entity instances by default,
-    row-sliced when the threshold is lowered), against the oracle and the direct wrapper."""
+    the derived (column, layer) map: Q1 Helmholtz on a perturbed hex column mesh (8 rows: row-sliced by default, whole-entity
+    instances when the threshold is raised), against the oracle and the direct wrapper."""
     from mixed_cases import q1_hex_helmholtz_kernel
     monkeypatch.setitem(configuration, "ocr_sliced_min_arity", 8 if sliced else 10)
     m = fmesh.make_extruded_hex_mesh(12, 9, degree=1)
