@@ -144,10 +144,13 @@ class DeviceMat:
         self._zero_requested = False
         _device_mats[self.handle] = self
 
-    def set_lgmaps(self, row_ptr, col_ptr):
+    def set_lgmaps(self, row_ptr, col_ptr, token=None):
+        """Install the (row, column) lgmap pair of the next calls (pyop2/parloop.py:279-314 swaps them per assemble).  The
+        row-sliced wrapper folds a pair into per-instance tables cached by (pointer, ``token``): lgmaps are immutable in the
+        reference (PETSc LGMaps); if a device array is ever REWRITTEN in place, pass a new ``token`` with it."""
         if (row_ptr is None) != (col_ptr is None):
             raise ValueError("set_lgmaps: give both the row and the column lgmap (identity = arange), or neither")
-        self.lgmaps = None if row_ptr is None else (_RawIntArray(row_ptr), _RawIntArray(col_ptr))
+        self.lgmaps = None if row_ptr is None else (_RawIntArray(row_ptr, token), _RawIntArray(col_ptr, token))
 
     def zero(self):
         self._zero_requested = True
@@ -168,8 +171,9 @@ def register_map(ptr, nent_total, arity, toset_sizes, iterset_sizes=None, prefer
 class _RawIntArray:
     """A device int32 array known only by its pointer (Parloop._lgmap accepts objects with ``_fd_dev_ptr``)."""
 
-    def __init__(self, ptr):
+    def __init__(self, ptr, token=None):
         self._fd_dev_ptr = int(ptr) if ptr is not None else 0
+        self._fd_token = token
 
 
 class _Shape:

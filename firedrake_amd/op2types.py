@@ -2009,7 +2009,11 @@ class SlicedOcrPlan:
         ``clg`` (None = no masking); ``per_dof``: the lgmaps are indexed by node*bs + component (``unroll``) and the last two are built;
         ``lgmap_ptr(obj)`` gives the device pointer of an lgmap.  Keyed by object identity (lgmaps are immutable, like the
         reference's PETSc LGMaps); the entry keeps the objects alive so that an id cannot be recycled."""
-        key = (id(rlg), id(clg), bool(per_dof))
+        def ident(o):
+            # host arrays: object identity (the entry keeps them alive); device arrays known by pointer (bridge.DeviceMat.
+            # set_lgmaps makes a new wrapper per call, like the reference swaps lgmaps per assemble): pointer + caller's token
+            return ("dev", o._fd_dev_ptr, getattr(o, "_fd_token", None)) if hasattr(o, "_fd_dev_ptr") else id(o)
+        key = (ident(rlg), ident(clg), bool(per_dof))
         t = self._tables.pop(key, None)
         if t is None:
             slot = DeviceBuffer(max(self.ninst, 1) * 2)

@@ -190,3 +190,50 @@ def test_c1_residual_and_jacobian_through_func_only(bcs):
     assert np.abs(v2 - 2.0 * csr.values).max() <= 1e-12 * np.abs(csr.values).max()
     assert len(fjac.loops) == 1 and len(fres.loops) == 1                # plans resolved once, cached on the argument list
     dm.free()
+
+
+@pytest.mark.gpu
+def test_p2_jacobian_through_func_takes_the_sliced_wrapper():
+    """The same seam with a 10x10 element matrix: ``func`` resolves to the row-sliced owner-computes-rows wrapper, whose
+    kernel has no lgmap parameters -- the pair installed with DeviceMat.set_lgmaps selects the per-instance tables, and
+    swapping the pair between calls (pyop2/parloop.py:279-314) switches them."""
+    import oracle
+    from oracle import ODat, OMat, READ, INC
+    from firedrake_amd import forms, mesh as fmesh
+    from firedrake_amd.device import DeviceBuffer
+    msh = fmesh.UnitCubeMesh(5, degrees=(2,), tile=(4, 4, 2), perturb=0.1)
+    V, X = msh.space(2), msh.coord_space
+    cells, xcells = np.ascontiguousarray(V.cell_node_map.values_with_halo), np.ascontiguousarray(X.cell_node_map.values_with_halo)
+    nn, nx, ne = V.node_set.total_size, X.node_set.total_size, msh.cell_set.size
+    x = np.array(msh.coordinates.data_ro)
+    kj = forms.poisson_jacobian_kernel(3, 2)
+    m, xm = MapKernelArg(arity=10), MapKernelArg(arity=4)
+    gjac = GlobalKernel(local_kernel=CStringLocalKernel(code=kj.code, name=kj.name, accesses=(4, 1), dtypes=(np.float64,) * 2),
+                        arguments=[MatKernelArg(dims=((1, 1),), maps=(m, m)), DatKernelArg(dim=(3,), map_=xm)])
+    fjac = bridge.compile_global_kernel_hip(gjac)
+    assert fjac.mode == "ocrs"
+    m_d, xm_d, x_d = (DeviceBuffer.from_numpy(a) for a in (cells, xcells, x))
+    bridge.register_map(m_d.ptr, ne, 10, toset_sizes=(nn, nn, nn))
+    bridge.register_map(xm_d.ptr, ne, 4, toset_sizes=(nx, nx, nx))
+    sp = op2.Sparsity((V.node_set ** 1, V.node_set ** 1), [(V.cell_node_map, V.cell_node_map, None)])
+    sp._build()
+    vals = DeviceBuffer(sp.nz * 8)
+    dm = bridge.DeviceMat(sp._rowptr.ptr, sp._colidx.ptr, vals.ptr, nn, sp.nz)
+    csr = oracle.build_sparsity(nn, nn, [(cells, cells)])
+    rng = np.random.default_rng(2)
+    pairs = []
+    for frac in (5, 3):
+        lg = np.arange(nn, dtype=np.int32)
+        lg[rng.choice(nn, nn // frac, replace=False)] = -1
+        pairs.append((lg, DeviceBuffer.from_numpy(lg)))
+    for lg, lg_d in pairs + pairs[:1] + pairs[:1]:
+        dm.set_lgmaps(lg_d.ptr, lg_d.ptr)                 # a fresh pair object per call, as the reference does per assemble
+        dm.zero()
+        fjac(0, ne, dm.handle, x_d.ptr, m_d.ptr, xm_d.ptr)
+        csr.values[:] = 0.0
+        oracle.par_loop(kj.code, kj.name, 0, ne, [OMat(csr, INC, cells, cells, row_lgmap=lg, col_lgmap=lg), ODat(x, READ, xcells)])
+        v = vals.download(np.float64, (sp.nz,))
+        assert np.abs(v - csr.values).max() <= 1e-12 * np.abs(csr.values).max()
+    (loop,) = fjac.loops.values() if isinstance(fjac.loops, dict) else fjac.loops
+    assert len(loop._ocr_geometry(0, ne)["ocr"]._tables) == 2          # one table set per distinct pair, reused by pointer
+    dm.free()
