@@ -297,10 +297,11 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             threads = configuration["ocr_block_threads"]
         else:
             threads = 512     # 8 wavefronts amortise the per-block staging and flush phases (256 VGPRs per lane still fit)
-        # Large element matrices (P2 tets: 10x10) have long rows, so a 64 KiB row block owns few rows and most of its
-        # instances are border entities computed again by the neighbours.  Give such loops the whole CU's LDS:
-        # one 512-lane group per CU, ~2x the rows per block (P2 Jacobian 2.57 -> 1.87 ms).  Small element matrices
-        # (P1: 4x4) do better with three 47 KiB groups per CU overlapping their phases.
+        # Larger element matrices kept whole (5..7 rows, or FDHIP_OCR_SLICED=0) have long rows, so a 64 KiB row block owns few
+        # rows and most of its instances are border entities computed again by the neighbours.  Give such loops the whole
+        # CU's LDS: one 512-lane group per CU, ~2x the rows per block (P2 Jacobian unsliced: 2.57 -> 1.87 ms; sliced it
+        # takes 1.1 ms, generate_sliced_wrapper).  Small element matrices (P1: 4x4) do better with three 47 KiB groups
+        # per CU overlapping their phases.
         entries = max(int(np.prod(a.dims[0])) * int(np.prod(a.dims[1])) * a.maps[0].arity * a.maps[1].arity
                       for a in gk.arguments if isinstance(a, MatKernelArg))
         ocr_lds_limit = configuration["ocr_lds_limit"] or (159 * 1024 if entries > 32 else 0)
