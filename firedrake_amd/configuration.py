@@ -44,7 +44,7 @@ configuration = {
     "ocrs_nnz_per_block": _env("FDHIP_OCRS_NNZ", 4096, int),     # accumulator entries per row block (x8 bytes of LDS)
     "ocrs_block_threads": _env("FDHIP_OCRS_BLOCK_THREADS", 256, int),
     # cut the row blocks of a sliced plan where the per-row-index instance groups pad least (parloop.balanced_row_cuts; host-side,
-    # needs the map's host values).  Off until measured on hardware: offline it removes ~half of the padding lanes on the C5 mesh
+    # needs the map's host values).  Off: measured on C5 it removes 20-40 % of the padding lanes and is 4 % SLOWER (profiles/r2t, run r3e)
     "ocrs_balanced_cuts": _env("FDHIP_OCRS_BALANCED_CUTS", 0, int),
     "ocrs_interleave": _env("FDHIP_OCRS_INTERLEAVE", 7, int),    # > 1: stride permutation of the instances of every (block, row index) group
     "ocr_block_threads": _env("FDHIP_OCR_BLOCK_THREADS", 0, int),  # 0 = auto: 512 for small element matrices, else block_threads

@@ -14,8 +14,7 @@ print('step_ms', round(d['ms_per_step'], 4), 'res_ms', round(d['roofline_residua
   grep "OCR" gpurun_out/ab_sliced.err | tail -1 >> $OUT
   grep -i "error\|Traceback" gpurun_out/ab_sliced.err | tail -3 >> $OUT
 }
-run c5 tiled "A=1"
-run c5 tiled "FDHIP_OCRS_BLOCK_THREADS=320"
-run c5 tiled "FDHIP_OCRS_BLOCK_THREADS=192 FDHIP_OCRS_NNZ=3072"
-run c5 tiled "FDHIP_OCRS_NNZ=4480"
+run c5 tiled "FDHIP_OCRS_BALANCED_CUTS=1"
+run c5 tiled "FDHIP_OCRS_BALANCED_CUTS=1 FDHIP_OCRS_NNZ=4608"
+run c5 tiled "FDHIP_OCRS_BALANCED_CUTS=0"
 cat $OUT
