@@ -14,7 +14,17 @@ print('step_ms', round(d['ms_per_step'], 4), 'res_ms', round(d['roofline_residua
   grep "OCR" gpurun_out/ab_sliced.err | tail -1 >> $OUT
   grep -i "error\|Traceback" gpurun_out/ab_sliced.err | tail -3 >> $OUT
 }
-run c5 tiled "FDHIP_OCRS_BALANCED_CUTS=1"
-run c5 tiled "FDHIP_OCRS_BALANCED_CUTS=1 FDHIP_OCRS_NNZ=4608"
-run c5 tiled "FDHIP_OCRS_BALANCED_CUTS=0"
+# (the runs behind profiles/r2t_ab_sliced_ocr.txt; comment in what is needed)
+run c5 tiled "FDHIP_OCR_SLICED=1"
+run c5 tiled "FDHIP_OCR_SLICED=0"
+run c5 lexicographic "FDHIP_OCR_SLICED=1"
+run c5 lexicographic "FDHIP_OCR_SLICED=0"
+run c5 random "FDHIP_OCR_SLICED=1"
+# run c5 tiled "FDHIP_PREFETCH=0"
+# run c5 tiled "FDHIP_OCRS_INTERLEAVE=0"
+# run c5 tiled "FDHIP_OCRS_NNZ=2048"
+# run c5 tiled "FDHIP_OCRS_NNZ=6144"
+# run c5 tiled "FDHIP_OCRS_BLOCK_THREADS=512"
+# run c5 tiled "FDHIP_OCRS_BALANCED_CUTS=1"
+# run c2 tiled "FDHIP_OCR_SLICED_MIN_ARITY=4"
 cat $OUT
