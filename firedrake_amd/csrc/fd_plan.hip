@@ -1207,7 +1207,7 @@ int fd_ocrplan_create_sliced(const int32_t *rmap_dev, int ar, int32_t start, int
         FD_HIP(hipMemsetAsync(p->inst_off, 0, ((size_t)nblocks + 1) * 4, s));
         *out = p; return 0;
     }
-    if (nkeys > 2147483647ll) FD_FAIL("fd_ocrplan_create_sliced: too many (entity, row) pairs");
+    if (nkeys > 2147483647ll || (int64_t)nblocks * ar >= 2147483647ll) FD_FAIL("fd_ocrplan_create_sliced: too many (entity, row) pairs");
     uint64_t *k1 = nullptr, *k2 = nullptr;
     FD_HIP(hipMalloc(&k1, (size_t)nkeys * 8));
     FD_HIP(hipMalloc(&k2, (size_t)nkeys * 8));

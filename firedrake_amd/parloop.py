@@ -886,6 +886,8 @@ class Parloop:
             try:
                 op = SlicedOcrPlan(sp, rmap, cmap, staged, start, end, rb, row_order=row_order)
             except _lib.FDHipError as exc:
+                if "too many" in str(exc):
+                    raise PlanDoesNotFit(str(exc))          # 32-bit instance indices: the loop falls back (staged / direct)
                 if "map entries" not in str(exc):
                     raise
                 cap //= 2
