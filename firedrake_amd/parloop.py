@@ -508,21 +508,24 @@ class Parloop:
                 return pa
         return None
 
-    def _locality_order(self, start, end):
+    def _locality_order(self, start, end, virtual=False):
         """Device buffer with the entities of [start, end) in locality order, or None when the loop keeps the caller's
-        order (switched off, tiny range, virtual iteration space, no position field)."""
+        order (switched off, tiny range, no position field).  ``virtual``: [start, end) are positions of the virtual
+        iteration space (owner-computes-rows loops over subsets / extruded sets, which need the order only to derive a row
+        order); staged loops over virtual spaces keep the caller's order."""
         n = end - start
-        if not configuration["locality_order"] or n < configuration["locality_min_entities"] or self._virtual() is not None:
+        if not configuration["locality_order"] or n < configuration["locality_min_entities"] or (self._virtual() is not None and not virtual):
             return None
         pa = self._position_arg()
         if pa is None:
             return None
-        cache = pa.map_._base().__dict__.setdefault("_locality_orders", {})
+        pmap = self._plan_map(pa.map_._base(), staged=True) if virtual else pa.map_._base()
+        cache = pmap.__dict__.setdefault("_locality_orders", {})
         key = (start, end, id(pa.data), pa.data.dat_version)
         buf = cache.get(key)
         if buf is None:
             buf = DeviceBuffer(n * 4)
-            _lib.call("fd_locality_order", pa.map_._base()._dev_values(), pa.map_.arity, int(start), int(end),
+            _lib.call("fd_locality_order", pmap._dev_values(), pa.map_.arity, int(start), int(end),
                       pa.data._dev_ptr(False), pa.data.cdim, buf.ptr, None)
             cache.clear()                      # one order per map and range: a moved mesh replaces it
             cache[key] = buf
@@ -781,7 +784,7 @@ class Parloop:
         else:
             # no producer hints: a backend-derived row order (first touch under the locality order of the entities) when
             # the loop has a position field, else the caller's row order; blocks = greedy ranges of ~cap CSR entries
-            order = self._locality_order(start, end)
+            order = self._locality_order(start, end, virtual=v is not None)
             prp = rp[:nrows + 1]
             cap = configuration["ocr_nnz_per_block"]
             if order is not None:
@@ -867,7 +870,8 @@ class Parloop:
         prp = rp[:nrows + 1]
         hint = getattr(rmap._base(), "preferred_node_blocks", None)
         if hint is None or not configuration["use_preferred_blocks"]:
-            order = self._locality_order(start, end)
+            # (virtual spaces too: an extruded numbering is column-major, so ranges of ITS rows are vertical pencils)
+            order = self._locality_order(start, end, virtual=v is not None)
             if order is not None:
                 row_order = RowOrder(rmap, order, end - start, nrows, rp)
                 prp = row_order.prowptr_host

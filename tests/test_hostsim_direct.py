@@ -671,7 +671,13 @@ static void prism(double *A, const double *x, const double *w, int layer)
     assert select_mode(pl.global_kernel) == "ocr"            # 6 rows: whole-entity instances, also on a virtual space
     ref = oracle_run(k, it, mat(op2.INC, (m, m)), x(op2.READ, m), w(op2.READ), **kw)[0]
     from hostsim import run_ocr
-    for got in (run_ocrs(pl, nnz_per_block=150), run_ocr(pl, rows_per_block=9)):
+    from helpers import locality_order_ref
+    # a backend-derived row order on the virtual space (Morton order of the (column, layer) cells -> first touch): what the
+    # Parloop uses for un-hinted extruded maps, whose own row ranges are vertical pencils
+    vrows = np.asarray(pl._plan_map(m, staged=True).values_with_halo)
+    order, _ = locality_order_ref(vrows, 0, len(vrows), np.array(x.data_ro))
+    for got in (run_ocrs(pl, nnz_per_block=150), run_ocr(pl, rows_per_block=9), run_ocrs(pl, nnz_per_block=150, order=order),
+                run_ocr(pl, rows_per_block=9, order=order)):
         assert np.array_equal(got.rowptr, ref.rowptr) and np.array_equal(got.colidx, ref.colidx)
         assert np.abs(got.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
 
