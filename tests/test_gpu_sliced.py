@@ -224,13 +224,15 @@ def test_reference_vector_matrix_golden_through_the_sliced_wrapper(monkeypatch):
 
 
 @pytest.mark.parametrize("region", [None, "bottom"])
-@pytest.mark.parametrize("sliced", [False, True])
-def test_matrix_over_an_extruded_set_against_oracle_and_direct(region, sliced, monkeypatch):
+@pytest.mark.parametrize("sliced,ordered", [(False, False), (True, False), (False, True), (True, True)])
+def test_matrix_over_an_extruded_set_against_oracle_and_direct(region, sliced, ordered, monkeypatch):
     """Extruded matrix assembly (node = map + offset*layer, builder.py:94-124) through both owner-computes-rows wrappers over
     the derived (column, layer) map: Q1 Helmholtz on a perturbed hex column mesh (8 rows: row-sliced by default, whole-entity
     instances when the threshold is raised), against the oracle and the direct wrapper."""
     from mixed_cases import q1_hex_helmholtz_kernel
     monkeypatch.setitem(configuration, "ocr_sliced_min_arity", 8 if sliced else 10)
+    # ordered: the backend-derived row order on the virtual space (meshes this small keep the caller's rows by default)
+    monkeypatch.setitem(configuration, "locality_min_entities", 0 if ordered else 1 << 30)
     m = fmesh.make_extruded_hex_mesh(12, 9, degree=1)
     cm, xm = m.cell_node_map, m.coord_map
     sp = op2.Sparsity((m.node_set ** 1, m.node_set ** 1), [(cm, cm, None)])
@@ -240,6 +242,7 @@ def test_matrix_over_an_extruded_set_against_oracle_and_direct(region, sliced, m
     pl = op2.LegacyParloop(k, m.cell_set, mat(op2.INC, (cm, cm)), m.coordinates(op2.READ, xm), **kw)
     pl()
     assert pl._prepare()["cw"].src.mode.startswith("ocrs") == sliced and pl._prepare()["cw"].src.mode.startswith("ocr")
+    assert (pl._ocr_geometry()["row_order"] is not None) == ordered
     ref = oracle_run(k, m.cell_set, mat(op2.INC, (cm, cm)), m.coordinates(op2.READ, xm), **kw)[0]
     rp, ci, v = mat.csr()
     assert np.array_equal(rp, ref.rowptr) and np.array_equal(ci, ref.colidx)
