@@ -379,7 +379,8 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
     for info in infos:
         if info["kind"] == "mat":
             mat_staged[info["k"]] = bool(staged and not ocr and configuration["mat_staged"] and info["rbs"] * info["cbs"] == 1
-                                         and info["acc"] == INC and not info["arg"].unroll)
+                                         and info["acc"] == INC and not info["arg"].unroll
+                                         and info["ar"] * info["ac"] <= configuration["ocr_sliced_max_entries"])
     if staged:
         for info in infos:
             if info["kind"] == "dat" and "m" in info and info["m"] not in staged_maps:

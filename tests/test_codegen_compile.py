@@ -204,3 +204,39 @@ def test_row_sliced_variants_for_blocks_dof_masks_and_virtual_spaces():
     for mode in ("ocrs", "ocr"):
         cw = pl.global_kernel.compile(mode)
         assert "subset_indices[fd_col]" in cw.src.source and kernel_resources(cw.path, cw.src.symbol)["scratch"] == 0
+
+
+def test_wrapper_shape_selection_table():
+    """Which wrapper a matrix loop gets (codegen.select_mode): whole-entity owner-computes-rows for small scalar element
+    matrices, row-sliced from 8 scalar rows and for every vector-valued / per-dof-lgmap matrix, both also over subsets and
+    extruded sets; the direct wrapper for what neither covers (periodic or interior-facet extrusion, oversized element
+    matrices, a second output)."""
+    from firedrake_amd.codegen import select_mode
+    from firedrake_amd.configuration import configuration
+    assert configuration["ocr_sliced_min_arity"] == 8
+    nodes, ele = op2.Set(64), op2.Set(2)
+    x = op2.Dat(nodes ** 3)
+    lg = np.arange(64, dtype=np.int32)
+
+    def mode(ar, dim=1, iterset=ele, unroll=False, extra=(), **kw):
+        m = op2.Map(iterset if not isinstance(iterset, op2.Subset) else iterset.superset, nodes, ar, np.arange(2 * ar) % 64,
+                    **({"offset": [1] * ar} if getattr(iterset, "_extruded", False) else {}))
+        mat = op2.Mat(op2.Sparsity((nodes ** dim, nodes ** dim), [(m, m, None)]))
+        n = ar * dim
+        k = op2.Kernel(f"static void k{n}(double *A, const double *x) {{ for (int i = 0; i < {n * n}; ++i) A[i] += x[0]; }}", f"k{n}")
+        lgs = (np.arange(64 * dim, dtype=np.int32),) * 2 if unroll else (lg, lg)
+        pl = op2.LegacyParloop(k, iterset, mat(op2.INC, (m, m), lgmaps=lgs, unroll_map=unroll), x(op2.READ, m), *extra, **kw)
+        return select_mode(pl.global_kernel)
+    assert mode(4) == "ocr" and mode(6) == "ocr"                      # P1 tets, P2 triangles
+    assert mode(8) == "ocrs" and mode(10) == "ocrs"                   # Q1 hexahedra, P2 tets
+    assert mode(3, dim=2) == "ocrs" and mode(4, dim=3) == "ocrs"      # vector-valued blocks: sliced whatever the size
+    assert mode(4, dim=3, unroll=True) == "ocrs"                      # per-dof lgmaps
+    assert mode(40) == "staged"                                       # 1600 entries: beyond the register budget of both (the staged
+    #                                                                   wrapper then scatters the matrix entry by entry)
+    ext = op2.ExtrudedSet(op2.Set(2), layers=4)
+    assert mode(6, iterset=ext) == "ocr" and mode(8, iterset=ext) == "ocrs"
+    assert mode(6, iterset=ext, iteration_region=op2.ON_INTERIOR_FACETS) == "direct"
+    assert mode(6, iterset=op2.Subset(ele, [1])) == "ocr"
+    out = op2.Dat(nodes)
+    m4 = op2.Map(ele, nodes, 4, np.arange(8))
+    assert mode(4, extra=(out(op2.INC, m4),)) in ("staged", "direct")  # a second output: no redundant instances
