@@ -352,6 +352,7 @@ class Parloop:
         if geo is not None:
             return geo
         src = prep["cw"].src
+        self._reject_negative_mat_maps()
         maps = [self._plan_map(m) for m in prep["maps"]]
         maxar = max(maps[mi].arity for mi in src.staged_maps)
         limit = configuration["lds_limit"]
@@ -454,6 +455,24 @@ class Parloop:
                       f"kbytes={mp.kbytes} exclusive={mp.n_exclusive} zero_list={mp.n_zero}", file=sys.stderr)
         prep["parts"][key] = geo
         return geo
+
+    def _reject_negative_mat_maps(self):
+        """MatSetValuesLocal ignores negative indices (builder.py:573-625), so the maps of a Mat argument may hold -1 entries
+        (composed maps with undefined intermediate entries).  The direct and the row-sliced wrappers honour that; block
+        localisation plans and whole-entity instance tables do not -- such loops are demoted (checked on the host values,
+        once per map; maps known only by a device pointer are trusted)."""
+        for pa in self.arguments:
+            if not isinstance(pa, MatParloopArg):
+                continue
+            for m in pa.maps:
+                b = m._base()
+                neg = b.__dict__.get("_has_negative")
+                if neg is None:
+                    v = getattr(b, "_values", None)
+                    neg = bool(isinstance(v, np.ndarray) and v.size and int(v.min()) < 0)
+                    b.__dict__["_has_negative"] = neg
+                if neg:
+                    raise PlanDoesNotFit("negative entries in the map of a Mat argument")
 
     # -- virtual iteration space of staged loops over subsets / extruded sets
     def _virtual(self, staged=None):
@@ -764,6 +783,7 @@ class Parloop:
         src = prep["cw"].src
         if src.mode.startswith("ocrs"):
             return self._ocrs_geometry(start, end, gkey)
+        self._reject_negative_mat_maps()
         # subsets / extruded sets: every map is replaced by its derived map over the virtual (position x layer) space
         maps = [self._plan_map(m._base(), staged=True) for m in prep["maps"]]
         v = self._virtual(staged=True)

@@ -289,3 +289,30 @@ def test_per_dof_lgmaps_against_oracle():
     assert np.array_equal(tabs[0].download(np.uint16, (op.ninst,)), res[4])
     assert np.array_equal(tabs[3].download(np.uint8, (op.ninst,)), res[7])
     assert np.array_equal(tabs[4].download(np.uint64, (op.ninst,)), res[8])
+
+
+@pytest.mark.parametrize("ar", [10, 4])
+def test_negative_entries_in_matrix_maps(ar):
+    """MatSetValuesLocal ignores negative indices (builder.py:573-625): a matrix map with -1 entries runs through the
+    row-sliced wrapper (rows never instantiated, columns never positioned) when its element matrix is large enough, and is
+    demoted to the direct wrapper otherwise (whole-entity instance tables and block plans do not take such maps)."""
+    rng = np.random.default_rng(12)
+    nn, ne = 900, 700
+    mv = np.stack([rng.choice(nn, ar, replace=False) for _ in range(ne)]).astype(np.int32)
+    mv[rng.random(mv.shape) < 0.15] = -1
+    nodes, ele = op2.Set(nn), op2.Set(ne)
+    m = op2.Map(ele, nodes, ar, mv)
+    xs = op2.Dat(ele ** 2, rng.uniform(0, 1, (ne, 2)), np.float64)
+    mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(m, m, None)]))
+    k = op2.Kernel(f"""
+static void neg{ar}(double *A, const double *w)
+{{
+  for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {ar}; ++j) A[i*{ar} + j] += w[0] * (i + 1) + w[1] * j;
+}}""", f"neg{ar}")
+    pl = op2.LegacyParloop(k, ele, mat(op2.INC, (m, m)), xs(op2.READ))
+    pl()
+    assert pl._prepare()["cw"].src.mode.startswith("ocrs" if ar == 10 else "direct")
+    ref = oracle_run(k, ele, mat(op2.INC, (m, m)), xs(op2.READ))[0]
+    rp, ci, v = mat.csr()
+    assert np.array_equal(rp, ref.rowptr) and np.array_equal(ci, ref.colidx)
+    assert_allclose(v, ref.values, rtol=0, atol=1e-12 * np.abs(ref.values).max())

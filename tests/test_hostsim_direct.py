@@ -715,3 +715,31 @@ def test_row_sliced_per_dof_lgmaps_on_host(numbering):
     got = run_ocrs(pl, nnz_per_block=60, order=order)
     assert np.abs(got.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
     assert np.count_nonzero(ref.values == 0.0) > 0.05 * len(ref.values)         # the masks dropped something
+
+
+def test_row_sliced_instances_with_negative_map_entries_on_host():
+    """Negative map entries (MatSetValuesLocal ignores negative indices, builder.py:573-625; composed maps with undefined
+    intermediate entries): the row is never an instance, the column never a position.  (Whole-entity instances and block
+    plans do not take such maps: Parloop._reject_negative_mat_maps demotes those loops to the direct wrapper.)"""
+    from hostsim import run_direct, run_ocrs
+    rng = np.random.default_rng(12)
+    nn, ne, ar = 90, 70, 10
+    mv = np.stack([rng.choice(nn, ar, replace=False) for _ in range(ne)]).astype(np.int32)
+    mv[rng.random(mv.shape) < 0.15] = -1
+    nodes, ele = op2.Set(nn), op2.Set(ne)
+    m = op2.Map(ele, nodes, ar, mv)
+    xs = op2.Dat(ele ** 2, rng.uniform(0, 1, (ne, 2)), np.float64)
+    mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(m, m, None)]))
+    k = op2.Kernel("""
+static void neg(double *A, const double *w)
+{
+  for (int i = 0; i < 10; ++i) for (int j = 0; j < 10; ++j) A[i*10 + j] += w[0] * (i + 1) + w[1] * j;
+}""", "neg")
+    pl = op2.LegacyParloop(k, ele, mat(op2.INC, (m, m)), xs(op2.READ))
+    ref = oracle_run(k, ele, mat(op2.INC, (m, m)), xs(op2.READ))[0]
+    for got in (run_ocrs(pl, nnz_per_block=200), run_direct(pl)[0]):
+        assert np.array_equal(got.rowptr, ref.rowptr) and np.array_equal(got.colidx, ref.colidx)
+        assert np.abs(got.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
+    from firedrake_amd.parloop import PlanDoesNotFit
+    with pytest.raises(PlanDoesNotFit):
+        pl._reject_negative_mat_maps()
