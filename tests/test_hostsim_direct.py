@@ -743,3 +743,28 @@ static void neg(double *A, const double *w)
     from firedrake_amd.parloop import PlanDoesNotFit
     with pytest.raises(PlanDoesNotFit):
         pl._reject_negative_mat_maps()
+
+
+def test_rectangular_matrix_through_both_owner_computes_rows_shapes_on_host():
+    """An off-diagonal block of a mixed operator: P2 rows x P1 columns on tetrahedra (10 x 4 element matrices, different
+    row and column sets), with a column lgmap -- row-sliced and whole-entity instances against the oracle."""
+    from firedrake_amd import mesh as fmesh
+    from hostsim import run_ocr, run_ocrs
+    mesh = fmesh.UnitCubeMesh(3, degrees=(1, 2), perturb=0.1)
+    V2, V1 = mesh.space(2), mesh.space(1)
+    rm, cm = V2.cell_node_map, V1.cell_node_map
+    mat = op2.Mat(op2.Sparsity((V2.node_set ** 1, V1.node_set ** 1), [(rm, cm, None)]))
+    rlg = np.arange(V2.node_set.total_size, dtype=np.int32)
+    clg = np.arange(V1.node_set.total_size, dtype=np.int32)
+    clg[np.random.default_rng(3).choice(len(clg), len(clg) // 5, replace=False)] = -1
+    k = op2.Kernel("""
+static void rect(double *A, const double *x)
+{
+  for (int i = 0; i < 10; ++i) for (int j = 0; j < 4; ++j) A[i*4 + j] += (1.0 + i) * x[3*j] - 0.5 * (j + 1) * x[3*(i % 4) + 2];
+}""", "rect")
+    args = lambda: (mat(op2.INC, (rm, cm), lgmaps=(rlg, clg)), mesh.coordinates(op2.READ, cm))
+    pl = op2.LegacyParloop(k, mesh.cell_set, *args())
+    ref = oracle_run(k, mesh.cell_set, *args())[0]
+    for got in (run_ocrs(pl, nnz_per_block=120), run_ocr(pl, rows_per_block=23)):
+        assert np.array_equal(got.rowptr, ref.rowptr) and np.array_equal(got.colidx, ref.colidx)
+        assert np.abs(got.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
