@@ -768,3 +768,49 @@ static void rect(double *A, const double *x)
     for got in (run_ocrs(pl, nnz_per_block=120), run_ocr(pl, rows_per_block=23)):
         assert np.array_equal(got.rowptr, ref.rowptr) and np.array_equal(got.colidx, ref.colidx)
         assert np.abs(got.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_owner_computes_rows_shapes_on_random_loops(seed):
+    """Randomised matrix loops through the row-sliced wrapper (and the whole-entity one where it applies) against the oracle:
+    random arities, rectangular row / column maps on different sets, duplicate nodes inside an entity, block sizes, per-node
+    or per-dof lgmaps, a direct and a mapped read-only argument, contiguous or row-ordered blocks, fresh or accumulating."""
+    from hostsim import run_ocr, run_ocrs
+    rng = np.random.default_rng(100 + seed)
+    ar, ac = int(rng.integers(1, 9)), int(rng.integers(1, 7))
+    rbs, cbs = (int(rng.integers(1, 4)), int(rng.integers(1, 3))) if seed % 3 == 0 else (1, 1)
+    nr, nc, ne = int(rng.integers(20, 120)), int(rng.integers(15, 90)), int(rng.integers(40, 260))
+    rows, cols, ele = op2.Set(nr), op2.Set(nc), op2.Set(ne)
+    rm = op2.Map(ele, rows, ar, rng.integers(0, nr, (ne, ar)).astype(np.int32))          # duplicates inside a row allowed
+    cm = op2.Map(ele, cols, ac, rng.integers(0, nc, (ne, ac)).astype(np.int32))
+    w = op2.Dat(ele ** 2, rng.uniform(0.5, 1.5, (ne, 2)), np.float64)
+    y = op2.Dat(cols ** 2, rng.uniform(-1, 1, (nc, 2)), np.float64)
+    mat = op2.Mat(op2.Sparsity((rows ** rbs, cols ** cbs), [(rm, cm, None)]))
+    R, C = ar * rbs, ac * cbs
+    k = op2.Kernel(f"""
+static void rnd{seed}(double *A, const double *w, const double *y)
+{{
+  for (int i = 0; i < {R}; ++i)
+    for (int j = 0; j < {C}; ++j)
+      A[i*{C} + j] += w[0] * (1.0 + i) + w[1] * y[2*(j / {cbs}) + (i & 1)] * (j + 1);
+}}""", f"rnd{seed}")
+    unroll = bool(seed % 4 == 1) and rbs <= 8 and C <= 64
+    lgs = None
+    if seed % 2 == 0 or unroll:
+        nrd, ncd = (nr * rbs, nc * cbs) if unroll else (nr, nc)
+        rlg, clg = np.arange(nrd, dtype=np.int32), np.arange(ncd, dtype=np.int32)
+        rlg[rng.random(nrd) < 0.2] = -1
+        clg[rng.random(ncd) < 0.25] = -1
+        lgs = (rlg, clg)
+    args = lambda: (mat(op2.INC, (rm, cm), lgmaps=lgs, unroll_map=unroll), w(op2.READ), y(op2.READ, cm))
+    pl = op2.LegacyParloop(k, ele, *args())
+    ref = oracle_run(k, ele, *args())[0]
+    order = rng.permutation(ne).astype(np.int32) if seed % 5 == 2 else None
+    zero = bool(seed % 3 != 1)
+    tol = 1e-12 * (1.0 + np.abs(ref.values).max())
+    got = run_ocrs(pl, nnz_per_block=int(rng.integers(30, 400)), zero_pending=zero, order=order)
+    assert np.array_equal(got.rowptr, ref.rowptr) and np.array_equal(got.colidx, ref.colidx)
+    assert np.abs(got.values - (ref.values + (0.0 if zero else 1.0))).max() <= tol
+    if rbs * cbs == 1 and not unroll:
+        got = run_ocr(pl, rows_per_block=int(rng.integers(3, 40)), zero_pending=zero, order=order)
+        assert np.abs(got.values - (ref.values + (0.0 if zero else 1.0))).max() <= tol
