@@ -191,7 +191,7 @@ def _borrowed_carriers(fd, arglist, start, end):
     from . import op2
     from .device import DeviceBuffer
     from .parloop import DatParloopArg, GlobalParloopArg, MatParloopArg
-    from .op2types import Dat, Global, Map, Mat, Sparsity
+    from .op2types import Map, Mat, Sparsity
     it = iter(arglist)
     layers_ptr = next(it) if fd._extruded else None
     subset_ptr = next(it) if fd._subset else None

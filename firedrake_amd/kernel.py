@@ -11,13 +11,13 @@ from __future__ import annotations
 import ctypes
 import hashlib
 import re
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Optional, Tuple
 
 import numpy as np
 
 from . import _lib
-from .op2types import Access, IterationRegion, ALL, READ, ScalarType
+from .op2types import Access, IterationRegion, ALL, READ
 
 _C_TYPE = {np.dtype("float64"): "double", np.dtype("float32"): "float", np.dtype("int32"): "int",
            np.dtype("uint32"): "unsigned int", np.dtype("int64"): "int64_t", np.dtype("uint64"): "uint64_t"}

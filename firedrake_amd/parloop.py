@@ -12,7 +12,6 @@ overlaps MPI with ``_compute(core_part)``.
 """
 from __future__ import annotations
 
-import ctypes
 from dataclasses import dataclass
 from typing import Any, Optional, Tuple
 
@@ -23,7 +22,7 @@ from .configuration import configuration
 from .device import DeviceBuffer
 from .kernel import (CStringLocalKernel, DatKernelArg, GlobalKernel, GlobalKernelArg, MapKernelArg, MatKernelArg,
                      MixedDatKernelArg, MixedMatKernelArg, PermutedMapKernelArg)
-from .op2types import (ALL, INC, MAX, MIN, READ, RW, WRITE, Access, Dat, ExtrudedSet, Global, Map, MapValueError,
+from .op2types import (INC, MAX, MIN, READ, WRITE, Access, Dat, ExtrudedSet, Global, Map, MapValueError,
                        Mat, MixedDat, MixedMap, PermutedMap, Set, SetTypeError, Subset)
 
 
