@@ -19,6 +19,7 @@
 #include "fd_common.h"
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -91,7 +92,11 @@ template <class T> __global__ void pack_rows_t(const T *__restrict__ dat, int cd
     }
 }
 
-// the index lists of one exchange never repeat a node, so the combine needs no atomics
+// One launch covers index lists that never repeat a node: the concatenated RECV lists of a forward exchange (a ghost has
+// one owner), or ONE neighbour's SEND list of a reverse exchange.  An owned node shared with several neighbours (a slab
+// one cell thick, the edges and corners of a block partition) appears once per neighbour in the concatenated SEND list,
+// so exchange_end() launches the reverse combine neighbour by neighbour -- stream order serialises the += / min / max on
+// such a node (the old per-neighbour PetscSF reduce of firedrake/halo.py:141-172 has the same semantics).
 template <class T> __global__ void unpack_rows_t(T *__restrict__ dat, int cdim, const int32_t *__restrict__ idx, int64_t n,
                                                  const T *__restrict__ buf, int op) {
     const int64_t total = n * cdim;
@@ -158,6 +163,7 @@ struct fd_halo_s {
     std::vector<int64_t> nsend, nrecv, soff, roff;     // rows per neighbour and their offsets in the concatenated lists
     int32_t *send_idx = nullptr, *recv_idx = nullptr;  // concatenated per-neighbour lists on the device
     int64_t tsend = 0, trecv = 0;
+    bool send_disjoint = true;                         // no owned node is sent to two neighbours: one reverse-combine launch
     std::vector<fd_halo_slot> slots;
 };
 
@@ -220,15 +226,24 @@ int exchange_begin(fd_halo_t h, void *dat, int cdim, int dtype, int dir, fd_stre
     FD_HIP(hipStreamWaitEvent(cs, sl->packed, 0));
     const auto &no = dir == 0 ? h->nsend : h->nrecv, &ni = dir == 0 ? h->nrecv : h->nsend;
     const auto &oo = dir == 0 ? h->soff : h->roff, &io = dir == 0 ? h->roff : h->soff;
-    FD_NCCL(R->GroupStart());
-    for (size_t k = 0; k < h->peer.size(); ++k) {
+    // a failure inside the group must still close it and release the slot, or every later exchange of this Dat would
+    // find the NCCL group open and the slot "in flight"
+    ncclResult_t bad = R->GroupStart();
+    const bool opened = bad == ncclSuccess;
+    for (size_t k = 0; opened && bad == ncclSuccess && k < h->peer.size(); ++k) {
         if (no[k] > 0)
-            FD_NCCL(R->Send((const char *)sl->sbuf + (size_t)oo[k] * row, (size_t)no[k] * cdim, NCCL_TYPE[dtype], h->peer[k], h->comm->comm, cs));
-        if (ni[k] > 0)
-            FD_NCCL(R->Recv((char *)sl->rbuf + (size_t)io[k] * row, (size_t)ni[k] * cdim, NCCL_TYPE[dtype], h->peer[k], h->comm->comm, cs));
+            bad = R->Send((const char *)sl->sbuf + (size_t)oo[k] * row, (size_t)no[k] * cdim, NCCL_TYPE[dtype], h->peer[k], h->comm->comm, cs);
+        if (bad == ncclSuccess && ni[k] > 0)
+            bad = R->Recv((char *)sl->rbuf + (size_t)io[k] * row, (size_t)ni[k] * cdim, NCCL_TYPE[dtype], h->peer[k], h->comm->comm, cs);
     }
-    FD_NCCL(R->GroupEnd());
-    FD_HIP(hipEventRecord(sl->done, cs));
+    if (opened) { const ncclResult_t e = R->GroupEnd(); if (bad == ncclSuccess) bad = e; }
+    if (bad != ncclSuccess) {
+        sl->key = nullptr;
+        fd::set_error(std::string("RCCL neighbour exchange failed: ") + R->GetErrorString(bad));
+        return -2;
+    }
+    hipError_t he = hipEventRecord(sl->done, cs);
+    if (he != hipSuccess) { sl->key = nullptr; FD_HIP(he); }
     return 0;
 }
 
@@ -244,9 +259,19 @@ int exchange_end(fd_halo_t h, void *dat, int cdim, int dtype, int dir, int op, f
     const int32_t *iidx = dir == 0 ? h->recv_idx : h->send_idx;
     int rc = 0;
     if (nin > 0) {
+        const size_t row = (size_t)cdim * ITEMSIZE[dtype];
         rc = by_dtype(dtype, [&](auto *tag) {
             using T = std::remove_pointer_t<decltype(tag)>;
-            hipLaunchKernelGGL(unpack_rows_t<T>, dim3(grid_for(nin * cdim)), dim3(256), 0, s, (T *)dat, cdim, iidx, nin, (const T *)sl->rbuf, op);
+            if (dir == 0 || h->peer.size() <= 1 || h->send_disjoint) {
+                hipLaunchKernelGGL(unpack_rows_t<T>, dim3(grid_for(nin * cdim)), dim3(256), 0, s, (T *)dat, cdim, iidx, nin, (const T *)sl->rbuf, op);
+                return 0;
+            }
+            for (size_t k = 0; k < h->peer.size(); ++k) {       // reverse combine, one neighbour after the other
+                const int64_t n = h->nsend[k];
+                if (n > 0)
+                    hipLaunchKernelGGL(unpack_rows_t<T>, dim3(grid_for(n * cdim)), dim3(256), 0, s, (T *)dat, cdim, iidx + h->soff[k], n,
+                                       (const T *)((const char *)sl->rbuf + (size_t)h->soff[k] * row), op);
+            }
             return 0;
         });
         if (!rc) { hipError_t e = hipGetLastError(); if (e != hipSuccess) { fd::set_error(hipGetErrorString(e)); rc = (int)e; } }
@@ -344,6 +369,19 @@ int fd_halo_create(fd_comm_t comm, int nneigh, const int32_t *peers, const int32
         rall.insert(rall.end(), recv_idx_host[k], recv_idx_host[k] + nrecv[k]);
     }
     h->tsend = (int64_t)sall.size(); h->trecv = (int64_t)rall.size();
+    {   // validate what the kernels rely on: a list never repeats a node; ghosts have one owner; shared owned nodes are noted
+        std::vector<int32_t> t(rall);
+        std::sort(t.begin(), t.end());
+        if (std::adjacent_find(t.begin(), t.end()) != t.end()) { delete h; FD_FAIL("fd_halo_create: a ghost node appears in two receive lists"); }
+        for (int k = 0; k < nneigh; ++k) {
+            t.assign(send_idx_host[k], send_idx_host[k] + nsend[k]);
+            std::sort(t.begin(), t.end());
+            if (std::adjacent_find(t.begin(), t.end()) != t.end()) { delete h; FD_FAIL("fd_halo_create: a send list repeats a node"); }
+        }
+        t = sall;
+        std::sort(t.begin(), t.end());
+        h->send_disjoint = std::adjacent_find(t.begin(), t.end()) == t.end();
+    }
     hipError_t e = hipMalloc((void **)&h->send_idx, std::max<size_t>(sall.size() * 4, 8));
     if (e == hipSuccess) e = hipMalloc((void **)&h->recv_idx, std::max<size_t>(rall.size() * 4, 8));
     if (e == hipSuccess && !sall.empty()) e = hipMemcpy(h->send_idx, sall.data(), sall.size() * 4, hipMemcpyHostToDevice);

@@ -17,7 +17,8 @@ Wire selection (``Halo.wire``):
            ``torch.distributed`` runs with the ``nccl`` backend.
 ``host``   non-NCCL backends (gloo: the CPU-launched multi-rank tests, ranks sharing one GPU): the same C-ABI pack /
            unpack and persistent device buffers, the packed rows bounced through host tensors.
-``hostsim`` FDHIP_HALO_HOST=1: no device at all -- torch index ops on the host arrays; protocol tests on CPU-only machines.
+(The CPU-only protocol tests replace this class by a host restatement of the exchange, tests/host_halo.py, installed
+through ``set_halo_factory`` -- nothing in this module runs without a device.)
 """
 from __future__ import annotations
 
@@ -26,7 +27,7 @@ import os
 
 import numpy as np
 
-from .op2types import INC, MAX, MIN, READ, RW, WRITE
+from .op2types import INC, MAX, MIN, WRITE
 
 _OPS = {WRITE: 0, INC: 1, MIN: 2, MAX: 3}
 DTYPE_CODE = {np.dtype("float64"): 0, np.dtype("float32"): 1, np.dtype("int32"): 2, np.dtype("uint32"): 3,
@@ -52,7 +53,16 @@ def attach_halo(space):
     if h is None or h.nranks <= 1:
         space.node_set.halo = None
         return
-    space.node_set.halo = Halo(h)
+    space.node_set.halo = _factory["halo"](h)
+
+
+_factory = {"halo": None}
+
+
+def set_halo_factory(cls):
+    """Install the class ``attach_halo`` instantiates (default: ``Halo``).  Test hook: the CPU-only multi-rank protocol
+    tests plug in a host restatement of the exchange (tests/host_halo.py)."""
+    _factory["halo"] = cls or Halo
 
 
 # ---- the process-wide RCCL communicator of the library ---------------------------------------------------------------
@@ -85,10 +95,18 @@ def communicator():
         _comm["why"] = "librccl.so could not be bound on every rank: " + (lib.fd_last_error() or b"").decode()
         return None
     uid = (ctypes.c_ubyte * 128)()
+    box = [None]
     if rank == 0:
-        _lib.call("fd_comm_unique_id", uid)
-    box = [bytes(uid)]
+        # a failure on rank 0 is broadcast too: every rank must leave this collective the same way
+        try:
+            _lib.call("fd_comm_unique_id", uid)
+            box = [bytes(uid)]
+        except _lib.FDHipError as exc:
+            box = [str(exc)]
     dist.broadcast_object_list(box, src=0)
+    if not isinstance(box[0], bytes):
+        _comm["why"] = f"ncclGetUniqueId failed on rank 0: {box[0]}"
+        raise _lib.FDHipError(_comm["why"])
     buf = (ctypes.c_ubyte * 128).from_buffer_copy(box[0])
     h = ctypes.c_void_p()
     _lib.call("fd_comm_create", buf, rank, nranks, ctypes.byref(h))
@@ -106,7 +124,6 @@ class Halo:
     def __init__(self, lists):
         self.lists = lists
         self.rank, self.nranks = lists.rank, lists.nranks
-        self.host_mode = os.environ.get("FDHIP_HALO_HOST", "0") == "1"
         self._h = None
         self._host_idx = {}
         self._pending = {}
@@ -122,8 +139,6 @@ class Halo:
 
     @property
     def wire(self):
-        if self.host_mode:
-            return "hostsim"
         self._handle()
         return "rccl" if self._comm else "host"
 
@@ -213,76 +228,19 @@ class Halo:
         else:
             _lib.call("fd_halo_l2g_end", h, ptr, dat.cdim, code, op, None)
 
-    # -- host-only protocol simulation (FDHIP_HALO_HOST=1: CPU machines, the oracle as "kernel")
-    def _idx(self, kind, r):
-        import torch
-        key = (kind, r)
-        t = self._host_idx.get(key)
-        if t is None:
-            arr = (self.lists.send if kind == "send" else self.lists.recv)[r]
-            t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int64))
-            self._host_idx[key] = t
-        return t
-
-    def _host_begin(self, dat, send_kind, recv_kind, tag):
-        import torch
-        dist = _dist()
-        ops, recvs, keep = [], [], []
-        hview = dat._to_host()
-        t = torch.from_numpy(hview.reshape(hview.shape[0], -1))
-        for r in self._neighbours():
-            sl = (self.lists.send if send_kind == "send" else self.lists.recv).get(r)
-            rl = (self.lists.send if recv_kind == "send" else self.lists.recv).get(r)
-            if sl is not None and len(sl):
-                sbuf = t[self._idx(send_kind, r)].contiguous()
-                keep.append(sbuf)
-                ops.append(dist.P2POp(dist.isend, sbuf, r))
-            if rl is not None and len(rl):
-                rbuf = torch.empty((len(rl), t.shape[1]), dtype=t.dtype)
-                recvs.append((r, rbuf))
-                ops.append(dist.P2POp(dist.irecv, rbuf, r))
-        reqs = dist.batch_isend_irecv(ops) if ops else []
-        self._pending[(id(dat), tag)] = (reqs, recvs, keep)
-
-    def _host_end(self, dat, recv_kind, op, tag):
-        import torch
-        reqs, recvs, keep = self._pending.pop((id(dat), tag))
-        for q in reqs:
-            q.wait()
-        hview = dat._host_rw()
-        t = torch.from_numpy(hview.reshape(hview.shape[0], -1))
-        for r, buf in recvs:
-            li = self._idx(recv_kind, r)
-            if op == 0:
-                t[li] = buf
-            elif op == 1:
-                t[li] += buf
-            elif op == 2:
-                t[li] = torch.minimum(t[li], buf)
-            else:
-                t[li] = torch.maximum(t[li], buf)
-
     # -- pyop2 Halo interface
     def global_to_local_begin(self, dat, insert_mode):
         """owner -> ghost broadcast (firedrake/halo.py:125-131)."""
-        if self.host_mode:
-            return self._host_begin(dat, "send", "recv", "g2l")
         self._begin(dat, 0, 0)
 
     def global_to_local_end(self, dat, insert_mode):
-        if self.host_mode:
-            return self._host_end(dat, "recv", 0, "g2l")
         self._end(dat, 0, 0)
 
     def local_to_global_begin(self, dat, insert_mode):
         """ghost -> owner reduction with SUM/MIN/MAX (firedrake/halo.py:141-172)."""
-        if self.host_mode:
-            return self._host_begin(dat, "recv", "send", "l2g")
         self._begin(dat, 1, _OPS[insert_mode])
 
     def local_to_global_end(self, dat, insert_mode):
-        if self.host_mode:
-            return self._host_end(dat, "send", _OPS[insert_mode], "l2g")
         self._end(dat, 1, _OPS[insert_mode])
 
     def fill_ghosts(self, dat, access_mode):
@@ -291,11 +249,6 @@ class Halo:
         carries this loop's contributions."""
         n0, n1 = dat.dataset.size, dat.dataset.total_size
         if n1 == n0:
-            return
-        dt = np.dtype(dat.dtype)
-        if self.host_mode:
-            lim = np.finfo(dt) if dt.kind == "f" else np.iinfo(dt)
-            dat._host_rw()[n0:] = {INC: 0, MIN: lim.max, MAX: lim.min}[access_mode]
             return
         from . import _lib
         code = self._code(dat)                                 # raises before any memory is touched
@@ -314,8 +267,7 @@ def allreduce_global(glob, access, comm=None):
     except ImportError:
         return
     op = {INC: 1, MIN: 2, MAX: 3}[access]
-    hostsim = os.environ.get("FDHIP_HALO_HOST", "0") == "1"
-    c = None if hostsim else communicator()
+    c = communicator()
     code = DTYPE_CODE.get(np.dtype(glob.dtype))
     if c and code is not None:
         from . import _lib
@@ -329,3 +281,6 @@ def allreduce_global(glob, access, comm=None):
         t = t.cuda()
     dist.all_reduce(t, op=rop)
     glob._host_rw()[...] = t.cpu().numpy().reshape(host.shape)
+
+
+_factory["halo"] = Halo

@@ -67,6 +67,7 @@ class Mesh:
     spaces: Dict[int, FunctionSpaceData]
     ncells_global: int
     shape: Tuple[int, ...]
+    partition: Tuple[int, ...] = (1, 1, 1)
 
     def space(self, degree):
         return self.spaces[degree]
@@ -96,9 +97,35 @@ def _split_blocks(blocks, arity, max_entries=32768):
 NUMBERINGS = ("tiled", "lexicographic", "random")
 
 
+def partition_grid(nranks, shape=None):
+    """Process grid (px, py, pz) of a box partition of the cube.  Default: z-slabs (1, 1, nranks) -- two neighbours per
+    rank, one message each way; ``shape="blocks"`` factorises nranks into the most cubic grid (8 -> 2 x 2 x 2: smaller
+    surface, up to 26 neighbours).  SURVEY.md 8e names both."""
+    if shape is None or shape == "slabs":
+        return (1, 1, int(nranks))
+    if shape == "blocks":
+        best = None
+        for px in range(1, nranks + 1):
+            if nranks % px:
+                continue
+            for py in range(1, nranks // px + 1):
+                if (nranks // px) % py:
+                    continue
+                pz = nranks // px // py
+                cand = (max(px, py, pz) - min(px, py, pz), px + py + pz, (px, py, pz))
+                if px <= py <= pz and (best is None or cand < best):
+                    best = cand
+        return best[2]
+    g = tuple(int(v) for v in shape)
+    if len(g) != 3 or g[0] * g[1] * g[2] != nranks:
+        raise ValueError(f"partition {shape!r} does not multiply to {nranks} ranks")
+    return g
+
+
 def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0, ghost_cells=True, numbering="tiled",
-                 seed=0):
-    """Kuhn-split tetrahedral unit cube, z-slab partitioned.  ``tile`` = cubes per traversal tile.
+                 seed=0, partition=None):
+    """Kuhn-split tetrahedral unit cube, box-partitioned over ``nranks`` ranks (``partition``: "slabs" = z-slabs, the
+    default; "blocks"; or an explicit (px, py, pz) grid).  ``tile`` = cubes per traversal tile.
 
     ``numbering`` (SURVEY.md 8d asks for a locality-dependence variant of every measurement):
       * ``"tiled"``          cells walk the grid tile by tile, nodes are numbered tile by tile, and the Maps carry the
@@ -107,31 +134,48 @@ def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0,
                              appearance while walking the cells' closures -- the rule of dmcommon.pyx:2688-2712 applied
                              to an un-tiled cell order -- and NO hints: what a DMPlex-produced mesh looks like to the backend;
       * ``"random"``         cells and nodes randomly permuted inside each class (seeded), no hints: the worst case.
+
+    Partition layout (firedrake/mesh.py:1131-1179 marks the same classes on a DMPlex): a rank owns the cubes of its box
+    and the lattice nodes on [lo, hi) of every axis (the domain's last plane goes to the last rank of the axis); cubes
+    touching a plane owned by the next rank are "owned" (non-core); with ``ghost_cells`` the local mesh also carries one
+    ghost cube layer on the LOW side of every partitioned axis -- the cells that touch the lowest owned node planes --
+    so every rank can assemble complete matrix rows for the nodes it owns (owner-computes-rows, SURVEY.md 8e option 1)
+    instead of shipping off-process rows the way MatAssemblyBegin/End does (pyop2/types/mat.py:940-954).  Nothing is
+    needed on the high side: those node planes are ghosts read by the rank's own last cube layer.
     """
     if numbering not in NUMBERINGS:
         raise ValueError(f"numbering must be one of {NUMBERINGS}")
     nx, ny, nz = (int(n),) * 3 if np.isscalar(n) else tuple(int(v) for v in n)
+    ndim = (nx, ny, nz)
+    pgrid = partition_grid(nranks, partition)
+    if any(pg > nd for pg, nd in zip(pgrid, ndim)):
+        raise ValueError(f"partition {pgrid} has more ranks than cubes along an axis of {ndim}")
+    rc = (rank % pgrid[0], (rank // pgrid[0]) % pgrid[1], rank // (pgrid[0] * pgrid[1]))       # (rx, ry, rz)
+
+    def cube_range(q):
+        """own cubes [lo, hi) of every axis for the rank at grid position q"""
+        return tuple(((ndim[d] * q[d]) // pgrid[d], (ndim[d] * (q[d] + 1)) // pgrid[d]) for d in range(3))
+
+    own = cube_range(rc)
+    last = tuple(rc[d] == pgrid[d] - 1 for d in range(3))
+    # local cubes: the own box + one ghost layer on the low side of every axis that has a lower neighbour
+    glo = tuple(own[d][0] - 1 if (rc[d] > 0 and ghost_cells) else own[d][0] for d in range(3))
+    ghi = tuple(own[d][1] for d in range(3))
+    ldim = tuple(ghi[d] - glo[d] for d in range(3))
     if numbering != "tiled":
-        tile = (nx, ny, nz)          # one tile = plain lexicographic traversal
-    # ---- cube slab owned by this rank (+ one ghost cube layer each side)
-    k0 = (nz * rank) // nranks
-    k1 = (nz * (rank + 1)) // nranks
-    # ghost cells: the cube layer BELOW the slab.  Its cells touch our lowest owned node plane; executing
-    # them redundantly lets every rank assemble complete matrix rows for the nodes it owns
-    # (owner-computes-rows, SURVEY.md 8e option 1) instead of shipping off-process rows the way
-    # MatAssemblyBegin/End does (pyop2/types/mat.py:940-954).  Nothing above the slab is needed: the
-    # top node plane is a ghost plane read by our own last cell layer.
-    glo = k0 - 1 if (rank > 0 and ghost_cells) else k0
-    ghi = k1
-    kk, jj, ii = np.meshgrid(np.arange(glo, ghi, dtype=np.int32), np.arange(ny, dtype=np.int32),
-                             np.arange(nx, dtype=np.int32), indexing="ij")
+        tile = ldim                  # one tile = plain lexicographic traversal
+    kk, jj, ii = np.meshgrid(np.arange(glo[2], ghi[2], dtype=np.int32), np.arange(glo[1], ghi[1], dtype=np.int32),
+                             np.arange(glo[0], ghi[0], dtype=np.int32), indexing="ij")
     ii, jj, kk = ii.ravel(), jj.ravel(), kk.ravel()
-    # class of each cube: 0 core, 1 owned (touches a ghost node plane), 2 ghost
+    cijk = (ii, jj, kk)
+    # class of each cube: 0 core, 1 owned (touches a node plane owned by the next rank of an axis), 2 ghost
     ccls = np.zeros(ii.shape, dtype=np.int8)
-    if rank < nranks - 1:
-        ccls[kk == k1 - 1] = 1
-    ccls[(kk < k0) | (kk >= k1)] = 2
-    key = _tile_keys(ii, jj, kk - glo, nx, ny, ghi - glo, tile) + ccls.astype(np.int64) * (1 << 50)
+    for d in range(3):
+        if not last[d]:
+            ccls[cijk[d] == own[d][1] - 1] = 1
+    for d in range(3):
+        ccls[cijk[d] < own[d][0]] = 2
+    key = _tile_keys(ii - glo[0], jj - glo[1], kk - glo[2], ldim[0], ldim[1], ldim[2], tile) + ccls.astype(np.int64) * (1 << 50)
     if numbering == "random":
         key = np.random.default_rng(seed + 1000 * rank).permutation(len(ii)).astype(np.int64) + ccls.astype(np.int64) * (1 << 50)
     order = np.argsort(key, kind="stable")
@@ -144,11 +188,18 @@ def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0,
     cuts = np.nonzero(np.diff(tkey))[0] + 1
     cell_blocks = (6 * np.concatenate([[0], cuts, [ncube]])).astype(np.int32)
 
+    def node_boxes(p, q):
+        """(owned, local) lattice-node boxes [lo, hi) per axis of the rank at grid position q, spacing 1/(p*n)"""
+        o = cube_range(q)
+        owned = tuple((p * o[d][0], p * o[d][1] if q[d] < pgrid[d] - 1 else p * ndim[d] + 1) for d in range(3))
+        local = tuple((p * (o[d][0] - 1 if (q[d] > 0 and ghost_cells) else o[d][0]), p * o[d][1] + 1) for d in range(3))
+        return owned, local
+
     def lattice_space(p):
         """CG_p nodes live on the lattice of spacing 1/(p*n); CG2 edge nodes are vertex sums."""
-        Lx, Ly = p * nx + 1, p * ny + 1
-        zlo, zhi = p * glo, p * ghi            # lattice planes present locally: [zlo, zhi]
-        nzl = zhi - zlo + 1
+        (oown, oloc) = node_boxes(p, rc)
+        lo = tuple(b[0] for b in oloc)
+        L = tuple(b[1] - b[0] for b in oloc)           # local lattice planes per axis
         # integer (doubled for p=2) coordinates of the 4 vertices of every cell
         cx = (ii[:, None] + _CORNER[:, 0][None, :])            # (ncube, 8)
         cy = (jj[:, None] + _CORNER[:, 1][None, :])
@@ -164,23 +215,29 @@ def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0,
             nys = np.concatenate([2 * vy, ey], axis=-1)
             nzs = np.concatenate([2 * vz, ez], axis=-1)
         arity = nxs.shape[-1]
-        box = ((nzs - zlo).astype(np.int64) * Ly + nys) * Lx + nxs      # index inside the local lattice box
-        box = box.reshape(ncube * 6, arity)
+
+        def box_index(x, y, z):
+            """index of global lattice point (x, y, z) inside the local lattice box"""
+            return ((np.asarray(z, dtype=np.int64) - lo[2]) * L[1] + (y - lo[1])) * L[0] + (x - lo[0])
+        box = box_index(nxs, nys, nzs).reshape(ncube * 6, arity)
         # ---- number the lattice nodes of the box: class, then tile traversal order
-        zz, yy, xx = np.meshgrid(np.arange(zlo, zhi + 1, dtype=np.int32), np.arange(Ly, dtype=np.int32),
-                                 np.arange(Lx, dtype=np.int32), indexing="ij")
+        zz, yy, xx = np.meshgrid(np.arange(oloc[2][0], oloc[2][1], dtype=np.int32), np.arange(oloc[1][0], oloc[1][1], dtype=np.int32),
+                                 np.arange(oloc[0][0], oloc[0][1], dtype=np.int32), indexing="ij")
         xx, yy, zz = xx.ravel(), yy.ravel(), zz.ravel()
-        own_lo, own_hi = p * k0, (p * k1 if rank < nranks - 1 else p * nz + 1)   # owned planes [own_lo, own_hi)
-        ncls = np.full(xx.shape, 2, dtype=np.int8)
-        owned = (zz >= own_lo) & (zz < own_hi)
-        ncls[owned] = 0
-        if rank < nranks - 1:
-            ncls[owned & (zz >= p * (k1 - 1))] = 1     # owned, but read by cells that also read ghosts
+        xyz_ = (xx, yy, zz)
+        ncls = np.zeros(xx.shape, dtype=np.int8)
+        for d in range(3):
+            if not last[d]:
+                ncls[xyz_[d] >= p * (own[d][1] - 1)] = 1       # owned, but read by cells that also read ghosts
+        for d in range(3):
+            ncls[(xyz_[d] < oown[d][0]) | (xyz_[d] >= oown[d][1])] = 2
         tl = tuple(p * t for t in tile)
-        nkey = _tile_keys(np.minimum(xx, p * nx - 1), np.minimum(yy, p * ny - 1), np.minimum(zz - zlo, p * (ghi - glo) - 1),
-                          p * nx, p * ny, p * (ghi - glo), tl)
+        lp = tuple(p * v for v in ldim)                          # lattice cells per axis of the local box
+        rel = tuple(xyz_[d] - lo[d] for d in range(3))
+        nkey = _tile_keys(np.minimum(rel[0], lp[0] - 1), np.minimum(rel[1], lp[1] - 1), np.minimum(rel[2], lp[2] - 1),
+                          lp[0], lp[1], lp[2], tl)
         # tie-break inside a tile by the true coordinates so keys are unique
-        nkey = (nkey + ncls.astype(np.int64) * (1 << 50)) * 8 + ((zz - zlo) // (p * (ghi - glo))) * 4 + (yy // (p * ny)) * 2 + xx // (p * nx)
+        nkey = (nkey + ncls.astype(np.int64) * (1 << 50)) * 8 + (rel[2] // lp[2]) * 4 + (rel[1] // lp[1]) * 2 + rel[0] // lp[0]
         if numbering == "lexicographic":
             # first appearance in the cell traversal (vertices of a cell before its edge nodes, as the closure walk
             # of dmcommon.pyx:2688-2712 meets them); lattice points no local cell touches keep the grid order, last
@@ -197,28 +254,33 @@ def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0,
         newnum[norder] = np.arange(len(norder), dtype=np.int32)
         sizes_n = tuple(int((ncls <= c).sum()) for c in (0, 1, 2))
         cmap = newnum[box]
-        h = 1.0 / (p * nx)
-        pts = np.stack([xx[norder] * h, yy[norder] * (1.0 / (p * ny)), zz[norder] * (1.0 / (p * nz))], axis=1)
+        pts = np.stack([xx[norder] * (1.0 / (p * nx)), yy[norder] * (1.0 / (p * ny)), zz[norder] * (1.0 / (p * nz))], axis=1)
         bnd = np.nonzero((xx[norder] == 0) | (xx[norder] == p * nx) | (yy[norder] == 0) | (yy[norder] == p * ny)
                          | (zz[norder] == 0) | (zz[norder] == p * nz))[0].astype(np.int32)
         halo = HaloLists(rank, nranks)
-        zs = zz[norder]
-        lat = (yy[norder].astype(np.int64) * Lx + xx[norder])
         if nranks > 1:
-            def plane_nodes(zplane):
-                idx = np.nonzero(zs == zplane)[0]
-                return idx[np.argsort(lat[idx], kind="stable")].astype(np.int32)
-            if rank < nranks - 1:
-                # plane p*k1 is owned by rank+1: we receive it / send our contributions to it back
-                halo.recv[rank + 1] = plane_nodes(p * k1)
-                # rank+1 holds our planes [p*(k1-1), p*k1) as the nodes of its ghost cell layer
-                if ghost_cells:
-                    halo.send[rank + 1] = np.concatenate([plane_nodes(z) for z in range(p * (k1 - 1), p * k1)])
-            if rank > 0:
-                # rank-1 reads our plane p*k0 (top of its last owned cell layer)
-                halo.send[rank - 1] = plane_nodes(p * k0)
-                if ghost_cells:
-                    halo.recv[rank - 1] = np.concatenate([plane_nodes(z) for z in range(zlo, p * k0)])
+            def box_nodes(a, b):
+                """local numbers of the lattice points in the intersection of boxes a and b, in global (z, y, x) order --
+                the same order on both sides of the exchange"""
+                r = [(max(a[d][0], b[d][0]), min(a[d][1], b[d][1])) for d in range(3)]
+                if any(hi <= lo_ for lo_, hi in r):
+                    return None
+                z, y, x = np.meshgrid(*[np.arange(r[d][0], r[d][1], dtype=np.int64) for d in (2, 1, 0)], indexing="ij")
+                return newnum[box_index(x.ravel(), y.ravel(), z.ravel())]
+            for qz in range(max(rc[2] - 1, 0), min(rc[2] + 2, pgrid[2])):
+                for qy in range(max(rc[1] - 1, 0), min(rc[1] + 2, pgrid[1])):
+                    for qx in range(max(rc[0] - 1, 0), min(rc[0] + 2, pgrid[0])):
+                        q = (qx, qy, qz)
+                        if q == rc:
+                            continue
+                        qrank = (qz * pgrid[1] + qy) * pgrid[0] + qx
+                        qown, qloc = node_boxes(p, q)
+                        snd = box_nodes(oown, qloc)        # owned here, present (as ghosts) on q
+                        rcv = box_nodes(qown, oloc)        # owned by q, ghosts here
+                        if snd is not None:
+                            halo.send[qrank] = snd
+                        if rcv is not None:
+                            halo.recv[qrank] = rcv
         node_set = op2.Set(sizes_n, f"cg{p}_nodes")
         m = op2.Map(cell_set, node_set, arity, cmap, f"cell_cg{p}")
         if numbering == "tiled":
@@ -244,7 +306,9 @@ def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0,
     from .halo import attach_halo
     for sp in spaces.values():
         attach_halo(sp)
-    return Mesh(3, cell_set, coords, cs, spaces, 6 * nx * ny * nz, (nx, ny, nz))
+    mesh = Mesh(3, cell_set, coords, cs, spaces, 6 * nx * ny * nz, (nx, ny, nz))
+    mesh.partition = pgrid
+    return mesh
 
 
 def UnitSquareMesh(nx, ny, degrees=(1,), tile=(16, 16), perturb=0.0):

@@ -290,17 +290,6 @@ int fd_csr_masked_entries(const int32_t *colidx_dev, int64_t nnz, const int32_t 
 int fd_csr_spmv(int32_t nrows, const int32_t *rowptr_dev, const int32_t *colidx_dev,
                 const double *vals_dev, const double *x_dev, double *y_dev, fd_stream_t s);
 
-/* -------------------------------------------------------------- halo pack / unpack
- * Device side of firedrake/halo.py:125-172 (PetscSF bcast owner->ghost with REPLACE,
- * reduce ghost->owner with SUM/MIN/MAX): the bare fp64 pack/unpack kernels (the full exchange, any dtype, is
- * fd_halo_create / fd_halo_*_begin / fd_halo_*_end below).
- *   op: 0 = REPLACE, 1 = SUM, 2 = MIN, 3 = MAX      (fp64 rows of `cdim` values)
- */
-int fd_halo_pack(const double *dat_dev, int cdim, const int32_t *idx_dev, int32_t n,
-                 double *buf_dev, fd_stream_t s);
-int fd_halo_unpack(double *dat_dev, int cdim, const int32_t *idx_dev, int32_t n,
-                   const double *buf_dev, int op, fd_stream_t s);
-
 /* ------------------------------------------------- backend-derived locality orders
  * The reference's locality comes from DMPlex (RCM cell order + first-touch DoF numbering, firedrake/mesh.py:1214-1228,
  * firedrake/cython/dmcommon.pyx:2599-2729); execution order is free under the wrapper's semantics

@@ -16,17 +16,19 @@ def point_key(pts):
     return [tuple(int(v) for v in np.round(p * 1e6)) for p in pts]
 
 
-def main(rank, world, port, n):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FDHIP_HALO_HOST="1")
+def main(rank, world, port, n, partition=None):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import oracle
     from oracle import ODat, OMat, READ, INC
     from firedrake_amd import forms, mesh as fmesh, op2
-    from firedrake_amd.halo import allreduce_global
+    from firedrake_amd.halo import allreduce_global, set_halo_factory
+    from host_halo import HostHalo
+    set_halo_factory(HostHalo)
 
     serial = fmesh.UnitCubeMesh(n, degrees=(1, 2), tile=(2, 2, 2), perturb=0.1)
-    part = fmesh.UnitCubeMesh(n, degrees=(1, 2), tile=(2, 2, 2), perturb=0.1, rank=rank, nranks=world)
+    part = fmesh.UnitCubeMesh(n, degrees=(1, 2), tile=(2, 2, 2), perturb=0.1, rank=rank, nranks=world, partition=partition)
     fn = lambda p: np.sin(3 * p[:, 0]) * np.cos(2 * p[:, 1]) + 0.3 * p[:, 2]          # noqa: E731
     for deg in (1, 2):
         Vs, V = serial.space(deg), part.space(deg)
@@ -94,4 +96,4 @@ def main(rank, world, port, n):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
+    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), *sys.argv[5:6])

@@ -14,7 +14,7 @@ def point_key(pts):
     return [tuple(int(v) for v in np.round(p * 1e6)) for p in pts]
 
 
-def main(rank, world, port, n, degree, backend="gloo"):
+def main(rank, world, port, n, degree, backend="gloo", partition=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
@@ -30,7 +30,7 @@ def main(rank, world, port, n, degree, backend="gloo"):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     from firedrake_amd import forms, mesh as fmesh, op2
     serial = forms.PoissonProblem(fmesh.UnitCubeMesh(n, degrees=(degree,), tile=(2, 2, 2), perturb=0.1), degree, bcs=True)
-    part = forms.PoissonProblem(fmesh.UnitCubeMesh(n, degrees=(degree,), tile=(2, 2, 2), perturb=0.1, rank=rank, nranks=world),
+    part = forms.PoissonProblem(fmesh.UnitCubeMesh(n, degrees=(degree,), tile=(2, 2, 2), perturb=0.1, rank=rank, nranks=world, partition=partition),
                                 degree, bcs=True)
     rs = np.array(serial.assemble_residual().data_ro)
     As = serial.assemble_jacobian().toscipy().tocsr()
@@ -66,4 +66,4 @@ def main(rank, world, port, n, degree, backend="gloo"):
 
 
 if __name__ == "__main__":
-    main(*[int(a) for a in sys.argv[1:6]], *sys.argv[6:7])
+    main(*[int(a) for a in sys.argv[1:6]], *sys.argv[6:8])

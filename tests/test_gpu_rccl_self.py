@@ -110,3 +110,54 @@ def test_allreduce_and_ghost_fill(comm):
             _lib.call("fd_dat_fill_range", buf.ptr, 10, 20, DT[np.dtype(dtype)], kind, None)
             got = buf.download(dtype, (40,))
             assert (got[:10] == 3).all() and (got[30:] == 3).all() and (got[10:30] == np.array(val).astype(dtype)).all()
+
+
+def _halo_multi(comm, pairs):
+    """halo with several neighbour entries (all of them this rank): pairs = [(send, recv), ...]"""
+    pairs = [tuple(np.ascontiguousarray(a, dtype=np.int32) for a in pr) for pr in pairs]
+    n = len(pairs)
+    peers = (ctypes.c_int32 * n)(*([0] * n))
+    sp = (ctypes.c_void_p * n)(*[p[0].ctypes.data for p in pairs])
+    rp = (ctypes.c_void_p * n)(*[p[1].ctypes.data for p in pairs])
+    ns = (ctypes.c_int32 * n)(*[len(p[0]) for p in pairs])
+    nr = (ctypes.c_int32 * n)(*[len(p[1]) for p in pairs])
+    h = ctypes.c_void_p()
+    _lib.call("fd_halo_create", comm, n, peers, sp, ns, rp, nr, ctypes.byref(h))
+    return h.value
+
+
+@pytest.mark.parametrize("op", [1, 2, 3])
+def test_owned_nodes_shared_with_several_neighbours(comm, op):
+    """An owned node that two (here: three) neighbours hold as a ghost -- the plane of a slab one cell thick, the edges and
+    corners of a block partition -- receives one contribution per neighbour in the reverse exchange; all of them must land
+    (a single non-atomic launch over the concatenated send lists lost some)."""
+    rng = np.random.default_rng(5)
+    n, nh = 40000, 6000
+    shared = rng.permutation(n // 2)[:nh]                         # owned nodes every "neighbour" keeps a ghost copy of
+    ghosts = [n // 2 + k * nh + np.arange(nh) for k in range(3)]  # three disjoint ghost sets
+    h = _halo_multi(comm, [(shared, g) for g in ghosts])
+    a = rng.standard_normal((n, 2))
+    d = DeviceBuffer.from_numpy(a)
+    for rep in range(3):
+        cur = d.download(np.float64, a.shape)
+        _lib.call("fd_halo_l2g_begin", h, d.ptr, 2, 0, op, None)
+        _lib.call("fd_halo_l2g_end", h, d.ptr, 2, 0, op, None)
+        exp = cur.copy()
+        for g in ghosts:
+            exp[shared] = {1: np.add, 2: np.minimum, 3: np.maximum}[op](exp[shared], cur[g])
+        got = d.download(np.float64, a.shape)
+        assert np.allclose(got, exp, rtol=0, atol=1e-13), np.abs(got - exp).max()
+    # forward: every ghost copy receives its owner's value
+    _lib.call("fd_halo_g2l_begin", h, d.ptr, 2, 0, None)
+    _lib.call("fd_halo_g2l_end", h, d.ptr, 2, 0, None)
+    got = d.download(np.float64, a.shape)
+    for g in ghosts:
+        assert np.array_equal(got[g], got[shared])
+    _lib.call("fd_halo_free", h)
+
+
+def test_halo_create_rejects_lists_the_kernels_cannot_handle(comm):
+    with pytest.raises(_lib.FDHipError, match="two receive lists"):
+        _halo_multi(comm, [([1, 2], [10, 11]), ([3, 4], [11, 12])])       # a ghost with two owners
+    with pytest.raises(_lib.FDHipError, match="repeats a node"):
+        _halo_multi(comm, [([1, 1], [10, 11])])

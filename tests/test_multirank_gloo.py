@@ -20,10 +20,12 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,n", [(2, 4), (3, 6)])
-def test_partitioned_assembly_protocol(world, n):
+# slabs two cubes thick; slabs ONE cube thick (an owned plane is then shared with both neighbours: the reverse exchange
+# combines two contributions into one node); 1 x 2 x 2 and 2 x 2 x 2 blocks (edge and corner nodes with 3 / 7 neighbours)
+@pytest.mark.parametrize("world,n,partition", [(2, 4, "slabs"), (3, 6, "slabs"), (3, 3, "slabs"), (4, 4, "blocks"), (8, 4, "blocks")])
+def test_partitioned_assembly_protocol(world, n, partition):
     port = _free_port()
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_worker.py"), str(r), str(world), str(port), str(n)],
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_worker.py"), str(r), str(world), str(port), str(n), partition],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     for p in procs:
@@ -40,12 +42,13 @@ def test_partitioned_assembly_protocol(world, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,n,degree", [(2, 6, 1), (3, 6, 2)])
-def test_partitioned_assembly_on_one_gpu(world, n, degree):
+@pytest.mark.parametrize("world,n,degree,partition", [(2, 6, 1, "slabs"), (3, 6, 2, "slabs"), (3, 3, 1, "slabs"), (4, 4, 2, "blocks"),
+                                                      (8, 4, 1, "blocks")])
+def test_partitioned_assembly_on_one_gpu(world, n, degree, partition):
     """Production device path (HIP wrappers, device pack/unpack, owner-computes-rows) with W ranks sharing
     cuda:0; only the wire (gloo instead of RCCL) differs from the multi-GPU run."""
     port = _free_port()
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_worker_gpu.py"), str(r), str(world), str(port), str(n), str(degree)],
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_worker_gpu.py"), str(r), str(world), str(port), str(n), str(degree), "gloo", partition],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     for p in procs:
@@ -62,8 +65,8 @@ def test_partitioned_assembly_on_one_gpu(world, n, degree):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,n,degree", [(2, 6, 1), (2, 6, 2)])
-def test_partitioned_assembly_over_rccl(world, n, degree):
+@pytest.mark.parametrize("world,n,degree,partition", [(2, 6, 1, "slabs"), (2, 6, 2, "slabs"), (4, 4, 1, "blocks"), (8, 4, 2, "blocks")])
+def test_partitioned_assembly_over_rccl(world, n, degree, partition):
     """The real wire: one GPU per rank, backend nccl (= RCCL), halos through fd_halo_* / ncclSend / ncclRecv and Globals
     through ncclAllReduce (csrc/fd_comm.hip).  Needs >= 2 devices: skipped on a one-GPU box, exercised by the
     driver's multi-GPU node."""
@@ -74,7 +77,7 @@ def test_partitioned_assembly_over_rccl(world, n, degree):
     if ndev.value < world:
         pytest.skip(f"needs {world} GPUs, found {ndev.value}")
     port = _free_port()
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_worker_gpu.py"), str(r), str(world), str(port), str(n), str(degree), "nccl"],
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_worker_gpu.py"), str(r), str(world), str(port), str(n), str(degree), "nccl", partition],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     for p in procs:
