@@ -7,10 +7,14 @@ zero the tensors, run the cell kernels (HIP wrapper kernels through the C ABI), 
 (N > 1), apply the boundary conditions.  Inputs are resident in HBM before the timed region.
 
     python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus N ...                      # starts the N ranks itself (one process per GPU, RCCL over xGMI)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Weak scaling: every rank owns a 215-layer z-slab of a 215 x 215 x (215 N) cube grid.
-Prints ONE JSON line on rank 0.
+Headline line, every N: weak scaling of C2 -- each rank owns a 215^3 block of cubes (z-slabs: a 215 x 215 x 215N grid).
+At N > 1 the same line carries ``strong_c5``: BASELINE.json configs[4] as written -- Poisson CG2 on the 215^3 cube,
+80 062 991 DoFs, split over the N ranks -- and ``multi_gpu``: ranks of the RCCL communicator, exchange time, per-rank
+kernel times, exchange/kernel overlap.  ``--workload c5`` runs configs[4] alone (N = 1: the whole cube on one GPU).
+--gpus N with fewer than N visible devices FAILS.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -419,74 +423,72 @@ def exchange_only_ms(prob, reps, torch):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", "--size", dest="n", type=int, default=0, help="cubes per axis per GPU (default 215 -> ~10M CG1 DoF; c5: 107)")
-    ap.add_argument("--degree", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=128, help="cube size of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--no-bcs", action="store_true")
-    ap.add_argument("--tile", type=str, default="8,8,4", help="cubes per traversal tile (= plan block)")
-    ap.add_argument("--numbering", choices=["tiled", "lexicographic", "random"], default="tiled",
-                    help="entity numbering of the headline measurement (SURVEY.md 8d)")
-    ap.add_argument("--variants", type=str, default="lexicographic,random",
-                    help="further numberings measured after the headline one at N=1 (no producer hints); '' = none")
-    ap.add_argument("--traffic", choices=["auto", "off"], default="auto",
-                    help="auto: rocprofv3 PMC passes of this command (child processes) fill roofline.traffic at N=1")
-    ap.add_argument("--inner-pmc", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--no-secondary", dest="secondary", action="store_false",
-                    help="skip the config-C3 (Q4 hex, fp64 MFMA) section appended to the default line at N=1")
-    ap.add_argument("--only", choices=["both", "residual", "jacobian"], default="both", help="profiling aid: run one form only")
-    ap.add_argument("--workload", choices=["c1", "c2", "c3", "c4", "c5"], default="c2",
-                    help="c2 = headline config (default); c1 = launch-bound 64x64 square (eager vs hipGraph); c3 = Q4 hex MFMA; "
-                         "c4 = DG advection RHS action; c5 = Poisson CG2, ~10M DoF per GPU (the multi-GPU config)")
-    args = ap.parse_args()
-    if args.workload == "c3":
-        import torch  # noqa: F401
-        return run_c3(args)
-    if args.workload == "c1":
-        import torch  # noqa: F401
-        return run_c1(args)
-    if args.workload == "c4":
-        import torch  # noqa: F401
-        return run_c4(args)
-    if args.workload == "c5":
-        args.degree = args.degree or 2
-        args.n = args.n or 107
-    args.degree = args.degree or 1
-    args.n = args.n or 215
+def self_launch(args):
+    """``python bench.py --gpus N`` with no launcher environment: start the N ranks here -- one process per GPU, the same
+    environment ``torch.distributed.run`` would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), rendezvous on
+    127.0.0.1 -- pass rank 0's JSON line through and fail if any rank fails."""
+    import socket
+    import subprocess
+    n = args.gpus
+    check_devices(n)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FDHIP_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for q in list(pending):
+                code = q.poll()
+                if code is None:
+                    continue
+                pending.remove(q)
+                if code != 0:
+                    rc = rc or code
+                    for o in pending:           # a dead rank leaves the others in a collective: stop them (exact PIDs)
+                        o.kill()
+            time.sleep(0.05)
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    if rc:
+        raise SystemExit(f"bench.py: a rank failed (exit code {rc})")
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch
-    # test knobs (one-GPU rehearsal of the N > 1 path): FDHIP_FORCE_DEVICE pins every rank to one device and
-    # FDHIP_DIST_BACKEND=gloo carries the halo buffers through the host instead of RCCL
-    if os.environ.get("FDHIP_FORCE_DEVICE") is not None:
-        local_rank = int(os.environ["FDHIP_FORCE_DEVICE"])
-    backend = os.environ.get("FDHIP_DIST_BACKEND", "nccl")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-    from firedrake_amd import _lib, forms, mesh as fmesh
+
+def check_devices(n):
+    """--gpus N needs N visible devices: fail loudly instead of measuring something else.  FDHIP_FORCE_DEVICE (the
+    one-GPU rehearsal of the N > 1 path used by the tests: every rank on one device, gloo wire) lifts the check."""
+    import ctypes
+    from firedrake_amd import _lib
     _lib.require_gpu()
-    _lib.call("fd_set_device", local_rank)
+    ndev = ctypes.c_int()
+    _lib.call("fd_device_count", ctypes.byref(ndev))
+    if ndev.value < n and os.environ.get("FDHIP_FORCE_DEVICE") is None:
+        raise SystemExit(f"bench.py: --gpus {n} but only {ndev.value} HIP device(s) visible; refusing to run a different "
+                         f"configuration (set FDHIP_FORCE_DEVICE=0 FDHIP_DIST_BACKEND=gloo for the one-device rehearsal)")
+    return ndev.value
 
-    n = args.n
+
+def poisson_line(args, ctx, degree, shape, scaling, label, numbering, variants, traffic):
+    """Measure residual + Jacobian assembly of Poisson CG<degree> on UnitCubeMesh(shape) box-partitioned over the ranks and
+    return rank 0's result dict (None on the other ranks)."""
+    from firedrake_amd import _lib, forms, mesh as fmesh
+    rank, world, dist, backend, torch = ctx["rank"], ctx["world"], ctx["dist"], ctx["backend"], ctx["torch"]
     tile = tuple(int(v) for v in args.tile.split(","))
 
-    def build(numbering):
+    def build(nb):
         t0 = time.perf_counter()
-        mesh = fmesh.UnitCubeMesh((n, n, n * world), degrees=(args.degree,), rank=rank, nranks=world, perturb=0.1, tile=tile,
-                                  numbering=numbering)
-        prob = forms.PoissonProblem(mesh, args.degree, bcs=not args.no_bcs)
+        mesh = fmesh.UnitCubeMesh(shape, degrees=(degree,), rank=rank, nranks=world, perturb=0.1, tile=tile, numbering=nb,
+                                  partition=args.partition)
+        prob = forms.PoissonProblem(mesh, degree, bcs=not args.no_bcs)
         t_mesh = time.perf_counter() - t0
         t0 = time.perf_counter()
         mat, _ = prob.jacobian()
@@ -494,7 +496,7 @@ def main():
         _lib.call("fd_device_sync")
         return mesh, prob, {"mesh": t_mesh, "sparsity": time.perf_counter() - t0}
 
-    mesh, prob, setup = build(args.numbering)
+    mesh, prob, setup = build(numbering)
     V = prob.V
     ndofs_global = V.global_dofs
     ncell_local = mesh.cell_set.size
@@ -502,10 +504,11 @@ def main():
     res = measure(prob, args, world, dist, backend, torch)
     setup.update(res["first"])
     if args.inner_pmc:
-        run_calibration()
-        return
-    exch = exchange_only_ms(prob, max(args.steps, 5), torch) if world > 1 else None
-
+        return None
+    multi = None
+    if world > 1:
+        multi = multi_gpu_detail(prob, args, res, ctx)
+    out = None
     if rank == 0:
         arity = V.cell_node_map.arity
         nnode_local = V.node_set.total_size
@@ -523,7 +526,8 @@ def main():
             # the wrapper kernel alone: map + coords + 2 coefficients + the output, against the kernel's own duration
             b = algorithmic_bytes(ncell_local, arity, nnode_local, 3, 2)
             roof_res = roof(kres, res["res_kernel_ms"], b, assemble_ms=res["res_assemble_ms"],
-                            note="kernel-only bytes and time; assemble_ms adds the zeroing pass (a13) and the BC fix-up (a14)")
+                            note="kernel-only bytes and time; assemble_ms adds the zeroing pass (a13) and the BC fix-up (a14)"
+                                 + ("; at N > 1 the bracket also holds the forward halo exchange (see multi_gpu.residual_kernel_only_ms)" if world > 1 else ""))
         if res["jac_kernel_ms"]:
             # owner-computes-rows writes complete rows and performs NO zeroing pass: strict bytes = map + coords + values.
             # frac_with_zeroing credits the nnz*8 zeroing traffic SURVEY.md 8(d) lists for the reference's two-pass scheme.
@@ -535,10 +539,10 @@ def main():
         roofs = [r for r in (roof_res, roof_jac) if r]
         dominant = max(roofs, key=lambda r: r["ms"])
         traffic_meta = None
-        if args.traffic == "auto" and world == 1:
-            tail = ["--steps", "3", "--warmup", "1", "--cpu-sample", "0", "--n", str(n), "--degree", str(args.degree),
-                    "--tile", args.tile, "--numbering", args.numbering, "--only", args.only, "--traffic", "off", "--variants", "",
-                    "--no-secondary"]
+        if traffic and world == 1:
+            tail = ["--steps", "3", "--warmup", "1", "--cpu-sample", "0", "--n", str(shape[0]), "--degree", str(degree),
+                    "--tile", args.tile, "--numbering", numbering, "--only", args.only, "--traffic", "off", "--variants", "",
+                    "--no-secondary", "--workload", "c2"]
             if args.no_bcs:
                 tail.append("--no-bcs")
             tr, traffic_meta = collect_traffic(tail, [r["kernel"] for r in roofs])
@@ -546,26 +550,30 @@ def main():
                 if tr and r["kernel"] in tr:
                     r["traffic"] = tr[r["kernel"]]["hbm_bytes_per_launch"]
                     r["traffic_counters_kb"] = {"FETCH_SIZE": tr[r["kernel"]]["FETCH_SIZE_kb"], "WRITE_SIZE": tr[r["kernel"]]["WRITE_SIZE_kb"]}
+        n_gpus = multi["n_gpus"] if multi else 1
         out = {
             "metric": "assembled DoFs/sec (residual + Jacobian)",
             "value": ndofs_global / (res["ms_per_step"] * 1e-3),
-            "unit": "DoFs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "unit": "DoFs/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"Poisson CG{args.degree} residual+Jacobian on UnitCubeMesh({n},{n},{n * world}) tets "
-                                   f"(BASELINE.json configs[{1 if args.degree == 1 else 4}]), z-slab per GPU",
+            "config": {"workload": f"Poisson CG{degree} residual+Jacobian on UnitCubeMesh({shape[0]},{shape[1]},{shape[2]}) tets "
+                                   f"({label}), partition {'x'.join(str(v) for v in mesh.partition)}",
                        "cells_per_gpu": ncell_local, "dofs_global": ndofs_global, "nnz_per_gpu": int(nnz),
-                       "parallelism": f"domain-decomposition x{world}", "bcs": not args.no_bcs, "numbering": args.numbering},
+                       "parallelism": f"domain-decomposition x{world}", "bcs": not args.no_bcs, "numbering": numbering},
             "residual_dofs_per_s": ndofs_global / (res["res_assemble_ms"] * 1e-3) if roof_res else None,
             "jacobian_dofs_per_s": ndofs_global / (res["jac_assemble_ms"] * 1e-3) if roof_jac else None,
             "roofline": dominant, "roofline_residual": roof_res, "roofline_jacobian": roof_jac,
             "traffic_meta": traffic_meta,
             "setup_s": setup,
-            "exchange_ms": exch,
+            "steps_to_amortise_setup": (setup.get("plans_residual_first_call", 0) + setup.get("plans_jacobian_first_call", 0) + setup["sparsity"])
+                                       / (res["ms_per_step"] * 1e-3),
+            "exchange_ms": multi["exchange_ms"] if multi else None,
+            "multi_gpu": multi,
         }
     # further numberings (no producer hints): locality dependence of the same step, N = 1 only
-    if world == 1 and args.variants:
-        for nb in [v for v in args.variants.split(",") if v and v != args.numbering]:
+    if world == 1 and variants:
+        for nb in [v for v in variants.split(",") if v and v != numbering]:
             del prob, mesh
             import gc
             gc.collect()
@@ -574,21 +582,167 @@ def main():
             out[f"value_{nb}_numbering"] = ndofs_global / (r2["ms_per_step"] * 1e-3)
             out[f"detail_{nb}_numbering"] = {"ms_per_step": r2["ms_per_step"], "residual_kernel_ms": r2["res_kernel_ms"],
                                              "jacobian_kernel_ms": r2["jac_kernel_ms"], "setup_s": {**st, **r2["first"]}}
+    del prob, mesh
+    import gc
+    gc.collect()
+    return out
+
+
+def multi_gpu_detail(prob, args, res, ctx):
+    """N > 1 (SURVEY.md 8e deliverables): ranks of the library's own communicator, the wire in use, the halo traffic of one
+    step on its own, per-rank kernel times, and how much of the exchange the core-entity kernel hides (parloop.py:250-253)."""
+    from firedrake_amd import _lib, halo as fhalo
+    from firedrake_amd.device import Event
+    import ctypes
+    rank, world, dist, torch = ctx["rank"], ctx["world"], ctx["dist"], ctx["torch"]
+    h = prob.V.node_set.halo
+    wire = h.wire if h is not None else None
+    n_comm = world
+    comm = fhalo.communicator()
+    if comm:
+        r_, n_ = ctypes.c_int(), ctypes.c_int()
+        _lib.call("fd_comm_info", comm, ctypes.byref(r_), ctypes.byref(n_))
+        n_comm = n_.value
+    exch = exchange_only_ms(prob, max(args.steps, 5), torch)
+    # the residual's kernels on their own: halos kept valid, so no exchange inside the bracket
+    reps = max(args.steps, 5)
+    ev = [(Event(), Event()) for _ in range(reps)]
+    for k in range(reps):
+        prob.u.halo_valid = True
+        prob.r._halo_frozen, prob.r._frozen_access_mode = True, prob.res_loop.accesses[0]
+        try:
+            ev[k][0].record()
+            prob.res_loop()
+            ev[k][1].record()
+        finally:
+            prob.r._halo_frozen, prob.r._frozen_access_mode = False, None
+    _lib.call("fd_device_sync")
+    k_only = float(np.median([a.elapsed_ms(b) for a, b in ev]))
+    mine = {"rank": rank, "residual_kernel_only_ms": k_only, "residual_with_exchange_ms": res["res_kernel_ms"],
+            "jacobian_kernel_ms": res["jac_kernel_ms"], "exchange_ms": exch,
+            "halo_rows": {"send": int(sum(len(v) for v in h.lists.send.values())), "recv": int(sum(len(v) for v in h.lists.recv.values())),
+                          "neighbours": len(set(h.lists.send) | set(h.lists.recv))} if h is not None else None}
+    allr = [None] * world
+    dist.all_gather_object(allr, mine)
+    if rank != 0:
+        return None
+    kmax = max(r["residual_kernel_only_ms"] for r in allr)
+    emax = max(r["exchange_ms"] or 0.0 for r in allr)
+    wmax = max(r["residual_with_exchange_ms"] or 0.0 for r in allr)
+    # bracket = forward exchange + kernels + reverse exchange; exchange_ms = forward + reverse on their own
+    hidden = max(0.0, min(emax, kmax + emax - wmax))
+    return {"n_gpus": n_comm, "wire": wire, "communicator": fhalo.communicator_status(), "exchange_ms": emax,
+            "residual_kernel_only_ms": kmax, "residual_with_exchange_ms": wmax, "exchange_hidden_ms": hidden,
+            "exchange_hidden_frac": hidden / emax if emax > 0 else None, "per_rank": allr}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", "--size", dest="n", type=int, default=0,
+                    help="cubes per axis (c2: per GPU, default 215 -> ~10M CG1 DoF per GPU; c5: of the WHOLE cube, default 215)")
+    ap.add_argument("--n5", type=int, default=0, help="cubes per axis of the strong-scaling C5 cube appended at N > 1 (default 215)")
+    ap.add_argument("--degree", type=int, default=0)
+    ap.add_argument("--cpu-sample", type=int, default=128, help="cube size of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-bcs", action="store_true")
+    ap.add_argument("--tile", type=str, default="8,8,4", help="cubes per traversal tile (= plan block)")
+    ap.add_argument("--numbering", choices=["tiled", "lexicographic", "random"], default="tiled",
+                    help="entity numbering of the headline measurement (SURVEY.md 8d)")
+    ap.add_argument("--variants", type=str, default="lexicographic,random",
+                    help="further numberings measured after the headline one at N=1 (no producer hints); '' = none")
+    ap.add_argument("--partition", choices=["slabs", "blocks"], default="slabs",
+                    help="N > 1: z-slabs (2 neighbours) or the most cubic process grid (8 -> 2x2x2), SURVEY.md 8e")
+    ap.add_argument("--traffic", choices=["auto", "off"], default="auto",
+                    help="auto: rocprofv3 PMC passes of this command (child processes) fill roofline.traffic at N=1")
+    ap.add_argument("--inner-pmc", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-secondary", dest="secondary", action="store_false",
+                    help="skip the secondary sections: config C3 (Q4 hex, fp64 MFMA) at N=1, config C5 (strong scaling) at N>1")
+    ap.add_argument("--only", choices=["both", "residual", "jacobian"], default="both", help="profiling aid: run one form only")
+    ap.add_argument("--workload", choices=["c1", "c2", "c3", "c4", "c5"], default="c2",
+                    help="c2 = headline config (default; weak scaling: one 215^3 cube per GPU); c1 = launch-bound 64x64 square "
+                         "(eager vs hipGraph); c3 = Q4 hex MFMA; c4 = DG advection RHS action; c5 = BASELINE configs[4] as written: "
+                         "Poisson CG2 on the 215^3 cube, 80 062 991 DoFs, split over the N GPUs (strong scaling)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.workload in ("c1", "c3", "c4"):
+        if args.gpus != 1:
+            raise SystemExit(f"--workload {args.workload} is a single-GPU configuration")
+        import torch  # noqa: F401
+        return {"c1": run_c1, "c3": run_c3, "c4": run_c4}[args.workload](args)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return self_launch(args)           # no launcher: start the ranks ourselves
+    world = int(env_world) if env_world is not None else 1
+    if args.gpus not in (1, world):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={world}")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    # test knobs (one-GPU rehearsal of the N > 1 path): FDHIP_FORCE_DEVICE pins every rank to one device and
+    # FDHIP_DIST_BACKEND=gloo carries the halo buffers through the host instead of RCCL
+    if os.environ.get("FDHIP_FORCE_DEVICE") is not None:
+        local_rank = int(os.environ["FDHIP_FORCE_DEVICE"])
+    backend = os.environ.get("FDHIP_DIST_BACKEND", "nccl")
+    check_devices(world)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    from firedrake_amd import _lib
+    _lib.require_gpu()
+    _lib.call("fd_set_device", local_rank)
+    ctx = {"rank": rank, "world": world, "dist": dist, "backend": backend, "torch": torch}
+    from firedrake_amd.mesh import partition_grid
+    pg = partition_grid(world, args.partition)
+
+    if args.workload == "c5":
+        # BASELINE configs[4] as written: ONE cube, split over the ranks -> strong scaling
+        n = args.n or 215
+        degree = args.degree or 2
+        out = poisson_line(args, ctx, degree, (n, n, n), "strong", "BASELINE.json configs[4]" + ("" if n == 215 and degree == 2 else ", reduced"),
+                           args.numbering, "", False)
+    else:
+        n = args.n or 215
+        degree = args.degree or 1
+        shape = (n * pg[0], n * pg[1], n * pg[2])        # weak scaling: every rank owns an n^3 cube of cubes
+        out = poisson_line(args, ctx, degree, shape, "weak", "BASELINE.json configs[1] per GPU" if degree == 1 else f"CG{degree}, weak",
+                           args.numbering, args.variants, args.traffic == "auto")
+    if args.inner_pmc:
+        run_calibration()
+        return
+    if args.secondary and args.workload == "c2" and args.only == "both" and world > 1:
+        # BASELINE configs[4] in the same run: the 215^3 CG2 cube split over the same ranks (strong scaling)
+        try:
+            n5 = args.n5 or 215
+            c5 = poisson_line(args, ctx, 2, (n5, n5, n5), "strong", "BASELINE.json configs[4]" + ("" if n5 == 215 else ", reduced"),
+                              args.numbering, "", False)
+            if rank == 0:
+                out["strong_c5"] = c5
+        except Exception as exc:
+            if rank == 0:
+                out["strong_c5"] = {"error": repr(exc)}
+            raise
     if rank == 0 and world == 1 and args.secondary and args.workload == "c2" and args.only == "both":
         # north_star's second numeric target (fp64 MFMA fraction on the Q4 hex config), measured in the same driver run
-        del prob, mesh
-        import gc
-        gc.collect()
         try:
             out["secondary_c3"] = measure_c3(32, max(3, args.steps // 2), 2)
         except Exception as exc:                      # the headline line must not die with a secondary measurement
             out["secondary_c3"] = {"error": repr(exc)}
     if rank == 0:
         if args.cpu_sample > 0 and world == 1:       # reported baseline: rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample if args.degree == 1 else min(args.cpu_sample, 64), args.degree)
+            ns = args.cpu_sample if degree == 1 else min(args.cpu_sample, 64)
+            out["cpu_baseline"] = cpu_baseline(ns, degree)
+            out["config"]["cpu_baseline_sample"] = f"{ns}^3 cubes (not the {n}^3 workload), see cpu_baseline.sample"
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

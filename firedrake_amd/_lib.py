@@ -115,6 +115,7 @@ SIGNATURES = {
     "fd_csr_set_diagonal": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_double, c_void_p]),
     "fd_csr_zero_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_double, c_void_p]),
     "fd_csr_spmv": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fd_csr_get_diagonal": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fd_dat_set_rows": (c_int, [c_void_p, c_int, c_void_p, c_int32, c_double, c_void_p]),
     "fd_dat_axpby": (c_int, [c_void_p, c_double, c_void_p, c_double, c_int64, c_void_p]),
     "fd_dat_copy_rows": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int32, c_void_p]),

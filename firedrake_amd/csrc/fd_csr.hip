@@ -150,6 +150,16 @@ __global__ void masked_entries(const int32_t *__restrict__ colidx, int64_t nnz, 
     }
 }
 
+__global__ void get_diag(int32_t nrows, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                         const double *__restrict__ vals, double *__restrict__ diag) {
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
+        int lo = rowptr[r], hi = rowptr[r + 1];          // columns are sorted: binary search for the diagonal
+        const int end = hi;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (colidx[mid] < (int32_t)r) lo = mid + 1; else hi = mid; }
+        diag[r] = (lo < end && colidx[lo] == (int32_t)r) ? vals[lo] : 0.0;
+    }
+}
+
 __global__ void spmv(int32_t nrows, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                      const double *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y) {
     // one wavefront per row
@@ -381,6 +391,13 @@ int fd_csr_masked_entries(const int32_t *colidx, int64_t nnz, const int32_t *col
 int fd_csr_zero_entries(double *vals, const int32_t *idx, int64_t n, fd_stream_t s) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(zero_entries, dim3(grid_for(n)), dim3(256), 0, fd::st(s), vals, idx, n);
+    FD_CHECK_LAUNCH();
+    return 0;
+}
+
+int fd_csr_get_diagonal(int32_t nrows, const int32_t *rowptr, const int32_t *colidx, const double *vals, double *diag, fd_stream_t s) {
+    if (nrows <= 0) return 0;
+    hipLaunchKernelGGL(get_diag, dim3(grid_for(nrows)), dim3(256), 0, fd::st(s), nrows, rowptr, colidx, vals, diag);
     FD_CHECK_LAUNCH();
     return 0;
 }

@@ -311,6 +311,45 @@ static void {name}(double *restrict A, const double *restrict x)
     return op2.Kernel(body, name)
 
 
+def helmholtz_kernel(dim, degree, name=None):
+    """a(u, v) = int grad(u).grad(v) + u v dx in ONE local kernel, the way TSFC emits a form with two terms under one
+    measure (tests/firedrake/regression/test_helmholtz.py:44): the stiffness and the mass quadrature loops of
+    poisson_jacobian_kernel / mass_kernel, one after the other.  Arguments: A[nd*nd], coords."""
+    name = name or f"helmholtz_p{degree}_{'tet' if dim == 3 else 'tri'}"
+    kj, km = poisson_jacobian_kernel(dim, degree, name + "_stiffness"), mass_kernel(dim, degree, name + "_mass")
+    body = kj.code + km.code + f"""
+static void {name}(double *restrict A, const double *restrict x)
+{{
+  {name}_stiffness(A, x);
+  {name}_mass(A, x);
+}}
+"""
+    return op2.Kernel(body, name)
+
+
+def rhs_kernel(dim, degree, name=None):
+    """L(v) = int f v dx with f in the same space (test_helmholtz.py:45).  Arguments: b[nd], coords, f[nd]."""
+    name = name or f"rhs_p{degree}_{'tet' if dim == 3 else 'tri'}"
+    qm, wm = simplex_rule(dim, 2 * degree)
+    phm, _ = tabulate_lagrange(dim, degree, qm)
+    nd = phm.shape[1]
+    body = f"""
+static void {name}(double *restrict b, const double *restrict x, const double *restrict f)
+{{
+  static const double PHI[{len(wm)}][{nd}] = {_c(phm)};
+  static const double WM[{len(wm)}] = {_c(wm)};
+{_GEOM[dim]}
+  for (int q = 0; q < {len(wm)}; ++q) {{
+    double fq = 0.0;
+    for (int j = 0; j < {nd}; ++j) fq += f[j] * PHI[q][j];
+    const double wf = WM[q] * adet * fq;
+    for (int i = 0; i < {nd}; ++i) b[i] += wf * PHI[q][i];
+  }}
+}}
+"""
+    return op2.Kernel(body, name)
+
+
 # ------------------------------------------------------------------------------------------
 # assemble()-shaped front end for these forms
 # ------------------------------------------------------------------------------------------
@@ -324,7 +363,9 @@ class PoissonProblem:
     (assemble.py:2075-2108) and sets the BC diagonal (assemble.py:1501-1507).
     """
 
-    def __init__(self, mesh, degree=1, bcs=True, seed=0):
+    def __init__(self, mesh, degree=1, bcs=True, seed=0, bc_nodes=None):
+        """``bcs``: Dirichlet conditions on the whole boundary; ``bc_nodes`` (local node numbers) restricts them to a part of
+        it, like ``DirichletBC(V, g, sub_domain)`` (bcs.py:245-330)."""
         self.mesh = mesh
         self.degree = degree
         self.V = V = mesh.space(degree)
@@ -337,7 +378,8 @@ class PoissonProblem:
         self.u = V.dat(1, uvals, "u")
         self.f = V.dat(1, fvals, "f")
         self.r = V.dat(1, None, "residual")
-        self.bc_nodes = V.boundary_nodes if bcs else np.zeros(0, dtype=np.int32)
+        self.bc_nodes = (V.boundary_nodes if bc_nodes is None else np.asarray(bc_nodes, dtype=np.int32)) if bcs else np.zeros(0, dtype=np.int32)
+        self._bc_all = self.bc_nodes                          # incl. ghost nodes: their columns are masked too
         self.bc_nodes = self.bc_nodes[self.bc_nodes < V.node_set.size]
         self.kres = poisson_residual_kernel(dim, degree)
         self.kjac = poisson_jacobian_kernel(dim, degree)
@@ -388,7 +430,7 @@ class PoissonProblem:
                 clg[self.bc_nodes] = -1
                 if partitioned:
                     rlg[V.node_set.size:] = -1          # rows owned elsewhere are assembled by their owner
-                    gb = V.boundary_nodes[V.boundary_nodes >= V.node_set.size]
+                    gb = self._bc_all[self._bc_all >= V.node_set.size]
                     clg[gb] = -1                        # BC columns on ghost nodes are dropped too
                 lg = (rlg, clg)
             loop = op2.LegacyParloop(self.kjac, self.mesh.cell_set, mat(op2.INC, (cm, cm), lgmaps=lg),
@@ -454,9 +496,10 @@ def q4_tables(degree=4, nq=5):
     return gll_gauss_tables(degree, nq)
 
 
-def helmholtz_q4_hex_jacobian_kernel(name="helmholtz_q4_hex_jacobian"):
-    """a(u, v) = int grad(u).grad(v) + u v dx on a trilinear hexahedron with Q4 basis, 5x5x5 Gauss points
-    (dx(degree=8)).  Arguments: A[125*125], coords[8*3] (Q1 vertices, index a*4 + b*2 + c).
+def helmholtz_q4_hex_jacobian_kernel(name="helmholtz_q4_hex_jacobian", alpha=1.0, beta=1.0):
+    """a(u, v) = int alpha grad(u).grad(v) + beta u v dx on a trilinear hexahedron with Q4 basis, 5x5x5 Gauss points
+    (dx(degree=8)); alpha = beta = 1 is the Helmholtz operator of config C3, (0, 1) the mass form.
+    Arguments: A[125*125], coords[8*3] (Q1 vertices, index a*4 + b*2 + c).
     Dense formulation (what the MFMA kernel computes); used as the oracle's local kernel."""
     L, DL, qp, qw = q4_tables()
     body = f"""
@@ -500,24 +543,24 @@ static void {name}(double *restrict A, const double *restrict x)
       const double t2 = G[2][0]*dp[i][0] + G[2][1]*dp[i][1] + G[2][2]*dp[i][2];
       const double tm = w * ph[i];
       for (int j = 0; j < 125; ++j)
-        A[i*125 + j] += t0*dp[j][0] + t1*dp[j][1] + t2*dp[j][2] + tm*ph[j];
+        A[i*125 + j] += {float(alpha)!r}*(t0*dp[j][0] + t1*dp[j][1] + t2*dp[j][2]) + {float(beta)!r}*tm*ph[j];
     }}
   }}
 }}
 """
     from .kernel import TensorProductLocalKernel
-    from .tensor import HELMHOLTZ_WEIGHTS
-    return TensorProductLocalKernel(body, name, kind="matrix", degree=4, nq=5, weights_code=HELMHOLTZ_WEIGHTS.replace("NAME", name))
+    from .tensor import second_order_weights
+    return TensorProductLocalKernel(body, name, kind="matrix", degree=4, nq=5, weights_code=second_order_weights(name, alpha, beta))
 
 
-def helmholtz_q4_hex_action_kernel(name="helmholtz_q4_hex_action"):
+def helmholtz_q4_hex_action_kernel(name="helmholtz_q4_hex_action", alpha=1.0, beta=1.0):
     """y += A_e(coords) u: the action of the same bilinear form on a coefficient (the matrix-free operator application of
     tests/firedrake/regression/test_matrix_free.py, and the Q4 "residual/action" of SURVEY.md 8d).  Arguments: y[125],
     coords[24], u[125].  The C text is the dense definition (element matrix times element vector) the oracle executes; the
     backend evaluates it sum-factorised from the descriptor (csrc/fd_tensor.h: hex_q4_action)."""
     from .kernel import TensorProductLocalKernel
-    from .tensor import HELMHOLTZ_WEIGHTS
-    jac = helmholtz_q4_hex_jacobian_kernel(name + "_matrix")
+    from .tensor import second_order_weights
+    jac = helmholtz_q4_hex_jacobian_kernel(name + "_matrix", alpha, beta)
     body = jac.code + f"""
 static void {name}(double *restrict y, const double *restrict x, const double *restrict u)
 {{
@@ -531,7 +574,7 @@ static void {name}(double *restrict y, const double *restrict x, const double *r
   }}
 }}
 """
-    return TensorProductLocalKernel(body, name, kind="action", degree=4, nq=5, weights_code=HELMHOLTZ_WEIGHTS.replace("NAME", name))
+    return TensorProductLocalKernel(body, name, kind="action", degree=4, nq=5, weights_code=second_order_weights(name, alpha, beta))
 
 
 class HelmholtzQ4Problem:

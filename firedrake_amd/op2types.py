@@ -2248,6 +2248,12 @@ class Mat:
         _lib.call("fd_device_sync")
         self.dat_version += 1
 
+    def get_diagonal(self, d: Dat):
+        """d = diag(A) on the device (MatGetDiagonal)."""
+        sp = self._sparsity
+        sp._build()
+        _lib.call("fd_csr_get_diagonal", self.nrows, sp._rowptr.ptr, sp._colidx.ptr, self._values_dev().ptr, d._dev_ptr(True), None)
+
     def mult(self, x: Dat, y: Dat):
         """y = A x on the device (used for the A*x == action(a,x) identity)."""
         sp = self._sparsity

@@ -53,3 +53,10 @@ static inline void NAME_weights(const double J[3][3], const double X[3], double 
   (void)X;
 }
 """
+
+
+def second_order_weights(name, alpha=1.0, beta=1.0):
+    """``weights_code`` of a(u, v) = int alpha grad(u).grad(v) + beta u v dx: W = w|J| [ alpha K K^T  0 ; 0  beta ]."""
+    return (HELMHOLTZ_WEIGHTS.replace("NAME", name)
+            .replace("W[a*4 + b] = w * (", f"W[a*4 + b] = {float(alpha)!r} * w * (")
+            .replace("W[15] = w;", f"W[15] = {float(beta)!r} * w;"))

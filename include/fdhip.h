@@ -289,6 +289,11 @@ int fd_csr_masked_entries(const int32_t *colidx_dev, int64_t nnz, const int32_t 
 /* y = A x  (parity identity  A*x == action(a, x), tests/firedrake/regression/test_matrix_free.py:97-123) */
 int fd_csr_spmv(int32_t nrows, const int32_t *rowptr_dev, const int32_t *colidx_dev,
                 const double *vals_dev, const double *x_dev, double *y_dev, fd_stream_t s);
+/* diag[r] = A[r][r] (0 where the pattern has no diagonal entry): MatGetDiagonal, what a Jacobi-preconditioned Krylov solve
+ * of the assembled operator needs (the reference's regression tests solve with PETSc: tests/firedrake/regression/
+ * test_helmholtz.py:50; here only the parity tests do, tests/test_reference_thresholds.py) */
+int fd_csr_get_diagonal(int32_t nrows, const int32_t *rowptr_dev, const int32_t *colidx_dev,
+                        const double *vals_dev, double *diag_dev, fd_stream_t s);
 
 /* ------------------------------------------------- backend-derived locality orders
  * The reference's locality comes from DMPlex (RCM cell order + first-touch DoF numbering, firedrake/mesh.py:1214-1228,
