@@ -83,8 +83,6 @@ SIGNATURES = {
     "fd_plan_free": (c_int, [c_void_p]),
     "fd_matplan_create": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, POINTER(c_void_p)]),
     "fd_matplan_zero_list": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64), POINTER(c_int64)]),
-    "fd_csr_zero_entries": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
-    "fd_csr_masked_entries": (c_int, [c_void_p, c_int64, c_void_p, POINTER(c_void_p), POINTER(c_int64), c_void_p]),
     "fd_matplan_info": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int64)]),
     "fd_matplan_arrays": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
     "fd_matplan_free": (c_int, [c_void_p]),

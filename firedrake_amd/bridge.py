@@ -46,10 +46,27 @@ def _map_arg(m, memo):
     elif n == "PermutedMapKernelArg":
         out = K.PermutedMapKernelArg(_map_arg(m.base_map, memo), tuple(int(p) for p in m.permutation))
     elif n == "ComposedMapKernelArg":
-        raise NotImplementedError("ComposedMapKernelArg: compose the maps on the host (op2.ComposedMap does) and pass "
-                                  "the composed table as an ordinary map")
+        # global_kernel.py:73-90, types/map.py:206-270: local[i] = global[maps_[0][maps_[1][...]]][i], inner maps of arity 1.
+        # The reference indexes through the chain inside the wrapper (builder.py:179-198) and passes one pointer per
+        # constituent; here the chain is composed ONCE on the device into an ordinary table (``_composed_table``): the
+        # wrapper sees a plain map, ``func`` consumes the constituents' pointers.
+        chain = []
+        for b in m.base_maps:
+            chain.extend(getattr(b, "base_maps", None) or [b]) if _name(b) == "ComposedMapKernelArg" else chain.append(b)
+        if any(_name(b) != "MapKernelArg" for b in chain):
+            raise NotImplementedError("ComposedMapKernelArg over permuted maps")
+        if any(int(b.arity) != 1 for b in chain[1:]):
+            raise ValueError("ComposedMapKernelArg: every map but the first must have arity 1 (types/map.py:246-247)")
+        first = chain[0]
+        out = K.MapKernelArg(int(first.arity), _tuple(getattr(first, "offset", None)), _tuple(getattr(first, "offset_quotient", None)))
+        memo.setdefault("composed", {})[id(out)] = tuple(chain)
+        for b in chain:
+            memo.setdefault("leaves", {}).setdefault(id(b), b)
     else:
         raise TypeError(f"unknown map kernel argument {n}")
+    if n == "MapKernelArg":
+        memo.setdefault("leaves", {}).setdefault(id(m), m)
+        memo.setdefault("leaf_of", {})[id(out)] = m
     memo[id(m)] = out
     return out
 
@@ -85,9 +102,44 @@ def as_fd_local_kernel(lk):
               cpp=bool(getattr(lk, "cpp", False)))
     accesses = tuple(Access(int(a)) for a in lk.accesses)
     dtypes = tuple(np.dtype(d) for d in lk.dtypes)
+    tp = getattr(lk, "fdhip_tensor", None)
+    if tp is not None:
+        # a tensor-product form the Firedrake-side patch recognised (tsfc_interface.py attaches the
+        # descriptor next to the TSFC kernel it wraps): same C text, plus what the matrix-core wrappers need
+        code = lk.code if isinstance(lk.code, str) else K.LoopyLocalKernel(lk.code, lk.name, accesses, dtypes, **kw).code
+        return tensor_product_local_kernel(code, lk.name, accesses, dtypes, tp, **kw)
     if isinstance(lk.code, str):
         return K.CStringLocalKernel(lk.code, lk.name, accesses, dtypes, **kw)
     return K.LoopyLocalKernel(lk.code, lk.name, accesses, dtypes, **kw)      # lowered with lp.generate_code_v2
+
+
+def tensor_form_info(cell, family, degree, quadrature_degree, terms, kind):
+    """The descriptor a Firedrake-side patch attaches to the pyop2 local kernel of a tensor-product form
+    (``kernel.fdhip_tensor = tensor_form_info(...)``).  Everything in it is form data Firedrake holds
+    when it builds the kernel (firedrake/tsfc_interface.py:84-140):
+
+    ``cell``, ``family``, ``degree``   ``V.ufl_element()``: cellname, family and degree of the (test = trial) space
+    ``quadrature_degree``              the integral's ``metadata["quadrature_degree"]`` / TSFC's estimate (tsfc/driver.py)
+    ``terms``                          the integrand as a sum of second-order terms with constant coefficients:
+                                       ``{"stiffness": alpha, "mass": beta}`` for alpha*inner(grad u, grad v) + beta*inner(u, v)
+    ``kind``                           "matrix" for a 2-form, "action" for action(a, u) / a 1-form linear in one coefficient
+
+    Returns None when the form is not one the tensor wrappers cover (the loop then takes the ordinary wrappers)."""
+    nq = int(quadrature_degree) // 2 + 1                   # Gauss-Legendre points per axis exact for that degree
+    ok = (cell in ("hexahedron", "quadrilateral * interval", "TensorProductCell(quadrilateral, interval)") and family in ("Q", "CG", "Lagrange")
+          and int(degree) == 4 and nq == 5 and kind in ("matrix", "action") and set(terms) <= {"stiffness", "mass"})
+    if not ok:
+        return None
+    return {"kind": kind, "degree": int(degree), "nq": nq, "alpha": float(terms.get("stiffness", 0.0)), "beta": float(terms.get("mass", 0.0))}
+
+
+def tensor_product_local_kernel(code, name, accesses, dtypes, info, **kw):
+    """TensorProductLocalKernel from the TSFC kernel text and a ``tensor_form_info`` descriptor: the per-point weight
+    callback of alpha*inner(grad u, grad v) + beta*inner(u, v) is W = w|J| [alpha K K^T, 0; 0, beta] (tensor.py)."""
+    from .tensor import second_order_weights
+    kw.setdefault("requires_zeroed_output_arguments", True)
+    return K.TensorProductLocalKernel(code, name, accesses, dtypes, kind=info["kind"], degree=info["degree"], nq=info["nq"],
+                                      weights_code=second_order_weights(name, info["alpha"], info["beta"]), **kw)
 
 
 def as_fd_global_kernel(gk):
@@ -96,6 +148,14 @@ def as_fd_global_kernel(gk):
     memo = {}
     args = [_kernel_arg(a, memo) for a in gk.arguments]
     region = getattr(gk, "_iteration_region", None)
+    fd = _global_kernel(gk, args, region)
+    # how the reference's map pointers (one per distinct LEAF map, parloop.py:203-212) feed this kernel's maps
+    fd._seam_maps = {"leaves": list(memo.get("leaves", {}).values()), "leaf_of": memo.get("leaf_of", {}),
+                     "composed": memo.get("composed", {})}
+    return fd
+
+
+def _global_kernel(gk, args, region):
     return K.GlobalKernel(as_fd_local_kernel(gk.local_kernel), args,
                           extruded=bool(getattr(gk, "_extruded", False)),
                           extruded_periodic=bool(getattr(gk, "_extruded_periodic", False)),
@@ -123,7 +183,11 @@ class DeviceMat:
     """Device CSR behind a PyOP2 ``Mat`` (the ``handle`` is what the patched ``Mat._kernel_args_`` returns).
 
     ``rowptr/colidx/values`` are device pointers of the scalar ("aij") pattern; ``nrows_owned`` = rows this rank
-    assembles (the row Set's ``size``; the CSR holds ``nrows`` >= that).  ``set_lgmaps`` mirrors the lgmap swap the
+    assembles (the row Set's ``size``; the CSR holds ``nrows`` >= that).  Vector-valued spaces (``rbs * cbs > 1``,
+    MatSetValuesBlockedLocal, builder.py:573-625): ``rowptr/colidx`` describe the NODE pattern (``nrows`` node rows, ``nnz``
+    node entries) and ``values`` holds the scalar CSR of the block-expanded matrix (``nnz * rbs * cbs`` doubles, scalar row
+    ``node * rbs + p`` = the node row's entries expanded by ``cbs``, columns ascending) -- what a PETSc (S)AIJ matrix on a
+    vector space stores; the expanded index arrays are derived here (fd_csr_expand_blocks).  ``set_lgmaps`` mirrors the lgmap swap the
     reference performs around the wrapper call for boundary conditions (pyop2/parloop.py:279-314): device int32 arrays
     with -1 for dropped rows/columns, or None.  ``zero()`` is ``Mat.zero()`` (mat.py:851-855): deferred, an
     owner-computes-rows assembly that follows overwrites complete rows instead of memset + add."""
@@ -138,7 +202,9 @@ class DeviceMat:
         self.nrows_owned = int(nrows if nrows_owned is None else nrows_owned)
         self.rbs, self.cbs = int(rbs), int(cbs)
         wrap = lambda p, n: DeviceBuffer.wrap(int(p), int(n), owned=False)       # noqa: E731
-        self.rowptr, self.colidx, self.values = wrap(rowptr, (self.nrows + 1) * 4), wrap(colidx, max(nnz, 1) * 4), wrap(values, max(nnz, 1) * 8)
+        self.rowptr, self.colidx = wrap(rowptr, (self.nrows + 1) * 4), wrap(colidx, max(nnz, 1) * 4)
+        self.values = wrap(values, max(nnz, 1) * 8 * self.rbs * self.cbs)
+        self._scalar = None
         self.lgmaps = None
         self._carriers = {}
         self._zero_requested = False
@@ -155,17 +221,92 @@ class DeviceMat:
     def zero(self):
         self._zero_requested = True
 
+    def scalar_pattern(self):
+        """(rowptr, colidx, nnz) of the scalar CSR the values are laid out in."""
+        if self.rbs * self.cbs == 1:
+            return self.rowptr, self.colidx, self.nnz
+        if self._scalar is None:
+            import ctypes
+            from . import _lib
+            from .device import DeviceBuffer
+            rp2, ci2 = ctypes.c_void_p(), ctypes.c_void_p()
+            _lib.call("fd_csr_expand_blocks", self.nrows, self.rowptr.ptr, self.colidx.ptr, self.rbs, self.cbs,
+                      ctypes.byref(rp2), ctypes.byref(ci2), None)
+            n2 = self.nnz * self.rbs * self.cbs
+            self._scalar = (DeviceBuffer.wrap(rp2.value, (self.nrows * self.rbs + 1) * 4), DeviceBuffer.wrap(ci2.value, max(n2, 1) * 4), n2)
+        return self._scalar
+
     def free(self):
         _device_mats.pop(self.handle, None)
 
 
-def register_map(ptr, nent_total, arity, toset_sizes, iterset_sizes=None, preferred_blocks=None, preferred_node_blocks=None):
+def register_map(ptr, nent_total, arity, toset_sizes, iterset_sizes=None, preferred_blocks=None, preferred_node_blocks=None,
+                 values=None):
     """Optional: tell the backend what it cannot read off a bare Map pointer -- the (core, owned, total) sizes of the Set
     the Map points into (needed when a Mat is assembled through it: only owned rows are assembled here), the number of
-    map rows, and the producer's block hints.  Unregistered maps work for Dat-only loops."""
+    map rows, the producer's block hints, and -- for loops over subsets / extruded sets, whose plans live on DERIVED maps
+    (one row per subset entity, resp. per (column, layer) cell) -- the host values the PyOP2 Map carries anyway
+    (``Map.values_with_halo``; without them the table is downloaded once).  Unregistered maps work for Dat-only loops
+    over plain sets."""
     _device_maps[int(ptr)] = {"nent": int(nent_total), "arity": int(arity), "toset": tuple(int(v) for v in np.atleast_1d(toset_sizes)),
                               "iterset": None if iterset_sizes is None else tuple(int(v) for v in np.atleast_1d(iterset_sizes)),
-                              "pb": preferred_blocks, "pnb": preferred_node_blocks}
+                              "pb": preferred_blocks, "pnb": preferred_node_blocks,
+                              "values": None if values is None else np.ascontiguousarray(values, dtype=np.int32)}
+
+
+def unregister_map(ptr):
+    """Forget a Map pointer (the carrier freed its buffer): drops the registration and every cached loop, plan and composed
+    table keyed on the address, so a later allocation at the same address starts clean."""
+    ptr = int(ptr)
+    _device_maps.pop(ptr, None)
+    for k in [k for k in _host_ints_cache if k[0] == ptr]:
+        _host_ints_cache.pop(k)
+    for k in [k for k in _composed if ptr in k]:
+        _composed.pop(k)
+    for f in list(_seam_funcs):
+        for k in [k for k in f.loops if ptr in k]:
+            f.loops.pop(k)
+
+
+_host_ints_cache = {}
+_composed = {}
+_seam_funcs = []
+
+
+def _host_ints(ptr, n, shape=None):
+    """int32 values behind a device pointer the host needs ONCE per pointer (layers, subset indices, map rows of loops over
+    virtual iteration spaces): in PyOP2 these live in host arrays of the carriers; the seam only sees their addresses."""
+    from . import _lib
+    key = (int(ptr), int(n))
+    a = _host_ints_cache.get(key)
+    if a is None:
+        a = np.empty(int(n), dtype=np.int32)
+        if n:
+            _lib.call("fd_memcpy_d2h", a.ctypes.data, int(ptr), a.nbytes, None)
+            _lib.call("fd_stream_sync", None)
+        _host_ints_cache[key] = a
+    return a if shape is None else a.reshape(shape)
+
+
+def _composed_table(ptrs, arity0, n):
+    """Device table of a ComposedMap (types/map.py:206-270) from its constituents' pointers: the arity-1 chain is followed
+    with row gathers (negative = undefined entries propagate), then the first map's rows are gathered."""
+    from . import _lib
+    from .device import DeviceBuffer
+    key = tuple(int(p) for p in ptrs) + (int(n),)
+    t = _composed.get(key)
+    if t is None:
+        cur, keep = int(ptrs[-1]), []
+        for p in reversed(ptrs[1:-1]):
+            nxt = DeviceBuffer(max(n, 1) * 4)
+            _lib.call("fd_gather_rows", int(p), 1, cur, n, nxt.ptr, None)
+            keep.append(nxt)
+            cur = nxt.ptr
+        t = DeviceBuffer(max(n, 1) * arity0 * 4)
+        _lib.call("fd_gather_rows", int(ptrs[0]), arity0, cur, n, t.ptr, None)
+        _lib.call("fd_stream_sync", None)
+        _composed[key] = t
+    return t
 
 
 class _RawIntArray:
@@ -187,7 +328,8 @@ class _Shape:
 
 
 def _borrowed_carriers(fd, arglist, start, end):
-    """Carriers of this backend (Set/Map/Dat/Global/Sparsity/Mat) that BORROW the device memory behind ``arglist``."""
+    """Carriers of this backend (Set/Map/Dat/Global/Sparsity/Mat) that BORROW the device memory behind ``arglist`` (this
+    kernel's positional list: composed maps already resolved to one table each)."""
     from . import op2
     from .device import DeviceBuffer
     from .parloop import DatParloopArg, GlobalParloopArg, MatParloopArg
@@ -199,20 +341,40 @@ def _borrowed_carriers(fd, arglist, start, end):
     from .codegen import _distinct_maps
     mkas, mindex = _distinct_maps(fd)
     map_ptrs = [next(it) for _ in mkas]
-    if fd._extruded or fd._subset:
-        raise NotImplementedError("function-level seam: extruded / subset loops keep the direct wrapper")
-    iter_total = max([_device_maps.get(int(p), {}).get("nent", 0) for p in map_ptrs] + [int(end)])
-    iterset = op2.Set((int(end), int(end), iter_total) if iter_total > end else int(end), "seam_iterset")
+    virtual = bool(fd._extruded or fd._subset)
+    infos = [_device_maps.get(int(p)) for p in map_ptrs]
+    if virtual and any(i is None for i in infos):
+        raise ValueError("function-level seam: the maps of a loop over a subset / an extruded set must be registered "
+                         "(bridge.register_map: the row count of the table is needed)")
+    iter_total = max([i["nent"] for i in infos if i] + ([0] if virtual else [int(end)]))
+    sizes = next((i["iterset"] for i in infos if i and i["iterset"]), None)
+    if sizes is None:
+        sizes = (iter_total,) * 3 if virtual else ((int(end), int(end), iter_total) if iter_total > end else (int(end),) * 3)
+    base = op2.Set(tuple(sizes), "seam_iterset")
+    iterset = base
+    if fd._extruded:
+        # the layers argument (set.py:351-353): [[bottom, top)] once, or one row per base entity
+        lay = _host_ints(layers_ptr, 2) if fd._constant_layers else _host_ints(layers_ptr, 2 * base.total_size, (base.total_size, 2))
+        if fd._constant_layers and int(lay[0]) != 0:
+            raise NotImplementedError("function-level seam: constant layers start at 0 (set.py:342-345)")
+        iterset = op2.ExtrudedSet(base, int(lay[1]) if fd._constant_layers else lay, extruded_periodic=fd._extruded_periodic)
+    if fd._subset:
+        iterset = op2.Subset(iterset, _host_ints(subset_ptr, int(end)))
     tosets, maps = {}, []
-    for mka, ptr in zip(mkas, map_ptrs):
-        info = _device_maps.get(int(ptr))
+    for mka, ptr, info in zip(mkas, map_ptrs, infos):
         sizes = info["toset"] if info else None
         m = Map.__new__(Map)
-        m._iterset, m._arity, m.name = iterset, mka.arity, f"seam_map_{int(ptr):x}"
+        m._iterset, m._arity, m.name = (iterset.superset if fd._subset else iterset), mka.arity, f"seam_map_{int(ptr):x}"
         m._toset = tosets.setdefault(sizes, op2.Set(sizes if sizes and len(sizes) == 3 else (sizes[0] if sizes else 1), "seam_toset")) if sizes else None
-        m._values = _Shape((iter_total, mka.arity))
+        if virtual:
+            # plans of loops over virtual spaces are built on derived maps: the host needs the rows (Parloop._plan_map)
+            vals = info["values"] if info["values"] is not None else _host_ints(ptr, info["nent"] * mka.arity)
+            m._values = np.asarray(vals, dtype=np.int32).reshape(info["nent"], mka.arity)
+        else:
+            m._values = _Shape((iter_total, mka.arity))
         m._offset, m._offset_quotient, m._plans = mka.offset, mka.offset_quotient, {}
-        m._dev = DeviceBuffer.wrap(int(ptr), iter_total * mka.arity * 4, owned=False)
+        nrows = info["nent"] if info else iter_total
+        m._dev = DeviceBuffer.wrap(int(ptr), nrows * mka.arity * 4, owned=False)
         if info and info["pb"] is not None:
             m.preferred_blocks = info["pb"]
         if info and info["pnb"] is not None:
@@ -249,11 +411,8 @@ def _borrowed_carriers(fd, arglist, start, end):
                 sp._nested, sp._blocks, sp._built, sp._elem_tables = False, [[sp]], True, {}
                 sp._dsets = (op2.DataSet(rm.toset, dm.rbs), op2.DataSet(cm.toset, dm.cbs))
                 sp._pairs, sp._has_diagonal, sp.name = [], True, "seam_sparsity"
-                if dm.rbs * dm.cbs != 1:
-                    raise NotImplementedError("function-level seam: vector-valued matrix blocks")
-                sp._node_rowptr = sp._rowptr = dm.rowptr
-                sp._node_colidx = sp._colidx = dm.colidx
-                sp._node_nnz = sp._nnz = dm.nnz
+                sp._node_rowptr, sp._node_colidx, sp._node_nnz = dm.rowptr, dm.colidx, dm.nnz
+                sp._rowptr, sp._colidx, sp._nnz = dm.scalar_pattern()
                 mat = Mat.__new__(Mat)
                 mat._sparsity, mat._dtype, mat.name, mat._vals = sp, np.dtype("float64"), "seam_mat", dm.values
                 mat._zero_pending, mat.dat_version, mat._blocks = False, 0, [[mat]]
@@ -294,13 +453,42 @@ def compile_global_kernel_hip(kernel, comm=None):
     from .codegen import select_mode
     from .parloop import Parloop
     fd = as_fd_global_kernel(kernel)
+    seam = fd._seam_maps
     if fd.is_mixed:
         fd = fd.flattened()
     mode = select_mode(fd)
     nlead = (1 if fd._extruded else 0) + (1 if fd._subset else 0)
-    nref = nlead + len(fd.arguments)
     from .codegen import _distinct_maps
-    nref += len(_distinct_maps(fd)[0])
+    fd_maps = _distinct_maps(fd)[0]
+    nhead = nlead + len(fd.arguments)
+    # the reference passes one pointer per distinct LEAF map (parloop.py:203-212; a ComposedMap contributes its
+    # constituents); this kernel's maps are those leaves or composed tables built from them
+    leaves = seam["leaves"]
+    leaf_pos = {id(l): i for i, l in enumerate(leaves)}
+    nref = nhead + len(leaves)
+    virtual = bool(fd._extruded or fd._subset)
+
+    def own_arglist(arglist):
+        """the reference's positional list -> this kernel's (composed maps resolved to their device tables)"""
+        if not seam["composed"]:
+            return list(arglist)
+        ptrs = arglist[nhead:]
+        out = list(arglist[:nhead])
+        for mk in fd_maps:
+            chain = seam["composed"].get(id(mk))
+            if chain is None:
+                out.append(ptrs[leaf_pos[id(seam["leaf_of"][id(mk)])]])
+                continue
+            cp = [ptrs[leaf_pos[id(b)]] for b in chain]
+            info = _device_maps.get(int(cp[-1]))
+            if info is None:
+                raise ValueError("function-level seam: the innermost map of a ComposedMap must be registered (its row count is needed)")
+            t = _composed_table(cp, mk.arity, info["nent"])
+            if int(t.ptr) not in _device_maps:
+                first = _device_maps.get(int(cp[0]))
+                register_map(t.ptr, info["nent"], mk.arity, first["toset"] if first else (1,), info["iterset"])
+            out.append(t.ptr)
+        return out
     loops = {}
     has_mat = any(isinstance(a, K.MatKernelArg) for a in fd.arguments)
     # the descriptor does not say whether BC-masked lgmaps will be swapped in around a call (pyop2/parloop.py:279-314
@@ -320,13 +508,13 @@ def compile_global_kernel_hip(kernel, comm=None):
         if len(arglist) != nref:
             raise ValueError(f"{fd.name}: expected {nref} arguments after (start, end), got {len(arglist)}")
         start, end = int(start), int(end)
-        if mode == "direct" and not has_mat:
+        ref_arglist = arglist                        # cache keys use the reference's pointers (unregister_map finds them)
+        arglist = own_arglist(arglist)
+        if mode == "direct" and not has_mat and not virtual:
             # needs nothing but the reference's own list
             cw = fd.compile("direct")
-            args = list(arglist) + [0] * (len(cw.src.layout) - nref)
+            args = list(arglist) + [0] * (len(cw.src.layout) - len(arglist))
             threads, n = cw.src.block_threads, max(end - start, 0)
-            if fd._extruded:
-                raise NotImplementedError("function-level seam: extruded loops need the layer count (Parloop level)")
             cw.launch(start, end, args, block_threads=threads, ents_per_block=threads,
                       nblocks=max(1, min((n + threads - 1) // threads, 256 * 32)))
             return 0
@@ -338,7 +526,7 @@ def compile_global_kernel_hip(kernel, comm=None):
                     if dm is None:
                         raise ValueError("a Mat slot must hold the handle of a bridge.DeviceMat")
                     with_lg = with_lg or dm.lgmaps is not None
-        key = (with_lg,) + tuple(int(a) if a is not None else 0 for a in arglist)
+        key = (with_lg,) + tuple(int(a) if a is not None else 0 for a in ref_arglist)
         pl = loops.get(key)
         if pl is None:
             from .configuration import configuration
@@ -368,4 +556,5 @@ def compile_global_kernel_hip(kernel, comm=None):
     func.global_kernel = fd
     func.mode = mode
     func.loops = loops
+    _seam_funcs.append(func)
     return func

@@ -572,6 +572,9 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 mat_stage_pre.extend([f"const int n0_{k} = oc{k}_rblk[b], nown{k} = oc{k}_rblk[b+1] - n0_{k};",
                                       f"const int r0_{k} = {rp_}[n0_{k}], nnzb{k} = {rp_}[n0_{k} + nown{k}] - r0_{k};"])
                 stage.append((rm, f"for (int q = tid; q < nnzb{k}; q += nthr) sm{k}[q] = 0;"))
+                # column masking (BC columns, pyop2/parloop.py:279-302) stays in the loop: a masked contribution adds 0.0.  Moving
+                # it to the row flush (one bit per CSR entry) removes 48 VALU instructions per instance and is NOT faster --
+                # the kernel is bound by the LDS pipe (profiles/r3b_ab_colmask.txt: 0.968 vs 0.952 ms tiled, 1.31 vs 1.19 un-hinted)
                 colmask = bool(lg)
                 rowmask = f" && rlg{k}[g] >= 0" if lg else ""
                 colbit = (f" | ((clg{k}[g] < 0) ? 0x80000000u : 0u)" if (colmask and cm == rm) else "")

@@ -134,22 +134,6 @@ __global__ void set_diag(const int32_t *__restrict__ rowptr, const int32_t *__re
     }
 }
 
-__global__ void zero_entries(double *__restrict__ vals, const int32_t *__restrict__ idx, int64_t n) {
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
-        vals[idx[t]] = 0.0;
-}
-
-// positions of the CSR entries whose column is masked by the column lgmap (order irrelevant)
-__global__ void masked_entries(const int32_t *__restrict__ colidx, int64_t nnz, const int32_t *__restrict__ clg,
-                               unsigned long long *__restrict__ cnt, int32_t *__restrict__ list) {
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < nnz; t += (int64_t)gridDim.x * blockDim.x) {
-        if (clg[colidx[t]] < 0) {
-            unsigned long long pos = atomicAdd(cnt, 1ull);
-            if (list) list[pos] = (int32_t)t;
-        }
-    }
-}
-
 __global__ void get_diag(int32_t nrows, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                          const double *__restrict__ vals, double *__restrict__ diag) {
     for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
@@ -355,42 +339,6 @@ int fd_csr_zero_rows(const int32_t *rowptr, const int32_t *colidx, double *vals,
                      double v, fd_stream_t s) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(set_diag, dim3(grid_for(n)), dim3(256), 0, fd::st(s), rowptr, colidx, vals, rows, n, v, 1);
-    FD_CHECK_LAUNCH();
-    return 0;
-}
-
-int fd_csr_masked_entries(const int32_t *colidx, int64_t nnz, const int32_t *col_lgmap, int32_t **list_out,
-                          int64_t *n_out, fd_stream_t s_) {
-    if (!list_out || !n_out) FD_FAIL("fd_csr_masked_entries: null output");
-    *list_out = nullptr; *n_out = 0;
-    if (nnz <= 0) return 0;
-    if (nnz > 2147483647ll) FD_FAIL("fd_csr_masked_entries: more than 2^31-1 nonzeros");
-    hipStream_t s = fd::st(s_);
-    unsigned long long *cnt = nullptr;
-    FD_HIP(hipMalloc(&cnt, 8));
-    FD_HIP(hipMemsetAsync(cnt, 0, 8, s));
-    hipLaunchKernelGGL(masked_entries, dim3(grid_for(nnz)), dim3(256), 0, s, colidx, nnz, col_lgmap, cnt, (int32_t *)nullptr);
-    FD_CHECK_LAUNCH();
-    unsigned long long h = 0;
-    FD_HIP(hipMemcpyAsync(&h, cnt, 8, hipMemcpyDeviceToHost, s));
-    FD_HIP(hipStreamSynchronize(s));
-    if (h > 0) {
-        int32_t *list = nullptr;
-        FD_HIP(hipMalloc(&list, (size_t)h * 4));
-        FD_HIP(hipMemsetAsync(cnt, 0, 8, s));
-        hipLaunchKernelGGL(masked_entries, dim3(grid_for(nnz)), dim3(256), 0, s, colidx, nnz, col_lgmap, cnt, list);
-        FD_CHECK_LAUNCH();
-        FD_HIP(hipStreamSynchronize(s));
-        *list_out = list;
-    }
-    *n_out = (int64_t)h;
-    FD_HIP(hipFree(cnt));
-    return 0;
-}
-
-int fd_csr_zero_entries(double *vals, const int32_t *idx, int64_t n, fd_stream_t s) {
-    if (n <= 0) return 0;
-    hipLaunchKernelGGL(zero_entries, dim3(grid_for(n)), dim3(256), 0, fd::st(s), vals, idx, n);
     FD_CHECK_LAUNCH();
     return 0;
 }

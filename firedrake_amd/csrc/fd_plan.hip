@@ -840,7 +840,8 @@ __global__ void gather_rows_k(const int32_t *__restrict__ src, int arity, const 
     const int64_t total = n * arity;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         int64_t k = t / arity;
-        dst[t] = src[(int64_t)idx[k] * arity + (t - k * arity)];
+        const int32_t r = idx[k];                        // a negative (undefined) index gives an undefined row
+        dst[t] = r < 0 ? -1 : src[(int64_t)r * arity + (t - k * arity)];
     }
 }
 

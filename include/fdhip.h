@@ -276,16 +276,6 @@ int fd_csr_set_diagonal(const int32_t *rowptr_dev, const int32_t *colidx_dev, do
                         const int32_t *rows_dev, int32_t nrows_sel, double value, fd_stream_t s);
 int fd_csr_zero_rows(const int32_t *rowptr_dev, const int32_t *colidx_dev, double *vals_dev,
                      const int32_t *rows_dev, int32_t nrows_sel, double value, fd_stream_t s);
-/* vals[idx[k]] = 0 for k < n (the fused zeroing pass of the staged matrix scatter) */
-int fd_csr_zero_entries(double *vals_dev, const int32_t *idx_dev, int64_t n, fd_stream_t s);
-/* Positions (into colidx / the value array) of the entries whose COLUMN the column lgmap masks (col_lgmap[col] < 0):
- * the entries MatSetValuesLocal drops for boundary-condition columns (pyop2/parloop.py:279-302,
- * firedrake/functionspaceimpl.py:913-926).  When a matrix is assembled from zero, dropping them during insertion
- * equals inserting everything and clearing this list afterwards (fd_csr_zero_entries); the owner-computes-rows
- * wrapper uses that to keep per-entry masking out of its inner loop.  *list_dev_out is allocated here (release it
- * with fd_free); order of the list is unspecified. */
-int fd_csr_masked_entries(const int32_t *colidx_dev, int64_t nnz, const int32_t *col_lgmap_dev,
-                          int32_t **list_dev_out, int64_t *n_out, fd_stream_t s);
 /* y = A x  (parity identity  A*x == action(a, x), tests/firedrake/regression/test_matrix_free.py:97-123) */
 int fd_csr_spmv(int32_t nrows, const int32_t *rowptr_dev, const int32_t *colidx_dev,
                 const double *vals_dev, const double *x_dev, double *y_dev, fd_stream_t s);

@@ -237,3 +237,211 @@ def test_p2_jacobian_through_func_takes_the_sliced_wrapper():
     (loop,) = fjac.loops.values() if isinstance(fjac.loops, dict) else fjac.loops
     assert len(loop._ocr_geometry(0, ne)["ocr"]._tables) == 2          # one table set per distinct pair, reused by pointer
     dm.free()
+
+
+# ---- round 3: composed maps, subsets, extruded sets, tensor-product forms and vector blocks through the seam ---------------
+ComposedMapKernelArg = _cls("ComposedMapKernelArg")
+
+
+def test_composed_map_translates_to_one_table_fed_by_the_constituents_pointers():
+    """global_kernel.py:73-90 / types/map.py:206-270: the wrapper sees ONE map of the first constituent's arity; the
+    reference's arglist carries one pointer per distinct leaf, in first-use order (parloop.py:203-212)."""
+    cell_node, facet_cell = MapKernelArg(arity=3), MapKernelArg(arity=1)
+    comp = ComposedMapKernelArg(base_maps=(cell_node, facet_cell))
+    lk = CStringLocalKernel(code="static void k(double *b, const double *f) { for (int i = 0; i < 3; ++i) b[i] += f[0]; }", name="k",
+                            accesses=(4, 1), dtypes=(np.float64,) * 2)
+    gk = GlobalKernel(local_kernel=lk, arguments=[DatKernelArg(dim=(1,), map_=comp), DatKernelArg(dim=(1,), map_=facet_cell)])
+    fd = bridge.as_fd_global_kernel(gk)
+    assert fd.arguments[0].map_.arity == 3 and fd.arguments[1].map_.arity == 1
+    assert fd._seam_maps["leaves"] == [cell_node, facet_cell]
+    assert list(fd._seam_maps["composed"].values()) == [(cell_node, facet_cell)]
+    with pytest.raises(ValueError):
+        bridge.as_fd_global_kernel(GlobalKernel(local_kernel=lk, arguments=[
+            DatKernelArg(dim=(1,), map_=ComposedMapKernelArg(base_maps=(facet_cell, cell_node))), DatKernelArg(dim=(1,), map_=facet_cell)]))
+
+
+def test_tensor_form_descriptor_selects_the_matrix_core_wrapper():
+    """the Firedrake-side patch attaches ``fdhip_tensor`` (form data it holds in tsfc_interface.py) to the
+    local kernel; the translated kernel is a TensorProductLocalKernel and the loop takes the tp_matrix wrapper."""
+    from firedrake_amd import forms
+    from firedrake_amd.codegen import select_mode
+    info = bridge.tensor_form_info("hexahedron", "Q", 4, 8, {"stiffness": 1.0, "mass": 1.0}, "matrix")
+    assert info == {"kind": "matrix", "degree": 4, "nq": 5, "alpha": 1.0, "beta": 1.0}
+    assert bridge.tensor_form_info("hexahedron", "Q", 3, 8, {"stiffness": 1.0}, "matrix") is None          # only Q4 / 5 points
+    assert bridge.tensor_form_info("tetrahedron", "CG", 4, 8, {"stiffness": 1.0}, "matrix") is None
+    assert bridge.tensor_form_info("hexahedron", "Q", 4, 8, {"advection": 1.0}, "matrix") is None
+    dense = forms.helmholtz_q4_hex_jacobian_kernel()
+    q4, q1 = MapKernelArg(arity=125, offset=(4,) * 125), MapKernelArg(arity=8, offset=(1,) * 8)
+    lk = CStringLocalKernel(code=dense.code, name=dense.name, accesses=(4, 1), dtypes=(np.float64,) * 2, requires_zeroed_output_arguments=True)
+    plain = GlobalKernel(local_kernel=lk, arguments=[MatKernelArg(dims=((1, 1),), maps=(q4, q4)), DatKernelArg(dim=(3,), map_=q1)],
+                         _extruded=True, _constant_layers=True)
+    assert select_mode(bridge.as_fd_global_kernel(plain)) == "direct"        # 125 x 125 without the descriptor: private tensor
+    lk.fdhip_tensor = info
+    fd = bridge.as_fd_global_kernel(plain)
+    assert select_mode(fd) == "tp_matrix" and fd.local_kernel.tp["weights_code"] == dense.tp["weights_code"]
+
+
+def _dev(*arrays):
+    from firedrake_amd.device import DeviceBuffer
+    return [DeviceBuffer.from_numpy(np.ascontiguousarray(a)) for a in arrays]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("undefined", [False, True])
+def test_composed_map_through_func(undefined):
+    """A Dat accessed through ComposedMap(cell_node, facet_cell): ``func`` receives both constituents' pointers and builds
+    the composed table on the device.  With undefined (negative) intermediate entries the composed rows are undefined and
+    the loop runs over the active entities only -- a Subset, as types/map.py:289-301 prescribes."""
+    rng = np.random.default_rng(3)
+    nn, nc, nf = 300, 500, 800
+    cell_node = rng.integers(0, nn, size=(nc, 3)).astype(np.int32)
+    facet_cell = rng.integers(0, nc, size=(nf, 1)).astype(np.int32)
+    if undefined:
+        facet_cell[::17, 0] = -1
+    f = rng.standard_normal(nf)
+    a, b = MapKernelArg(arity=3), MapKernelArg(arity=1)
+    code = "static void k(double *y, const double *f) { for (int i = 0; i < 3; ++i) y[i] += f[0]; }"
+    gk = GlobalKernel(local_kernel=CStringLocalKernel(code=code, name="k", accesses=(4, 1), dtypes=(np.float64,) * 2), _subset=undefined,
+                      arguments=[DatKernelArg(dim=(1,), map_=ComposedMapKernelArg(base_maps=(a, b))), DatKernelArg(dim=(1,))])
+    func = bridge.compile_global_kernel_hip(gk)
+    y_d, f_d, a_d, b_d = _dev(np.zeros(nn), f, cell_node, facet_cell)
+    bridge.register_map(a_d.ptr, nc, 3, toset_sizes=(nn,) * 3)
+    bridge.register_map(b_d.ptr, nf, 1, toset_sizes=(nc,) * 3)
+    active = np.nonzero(facet_cell[:, 0] >= 0)[0].astype(np.int32)
+    if undefined:
+        (idx_d,) = _dev(active)
+        func(0, len(active), idx_d.ptr, y_d.ptr, f_d.ptr, a_d.ptr, b_d.ptr)
+    else:
+        func(0, nf, y_d.ptr, f_d.ptr, a_d.ptr, b_d.ptr)
+    exp = np.zeros(nn)
+    for e in active:
+        for i in range(3):
+            exp[cell_node[facet_cell[e, 0], i]] += f[e]
+    got = y_d.download(np.float64, (nn,))
+    assert np.abs(got - exp).max() <= 1e-12 * max(1.0, np.abs(exp).max())
+    bridge.unregister_map(a_d.ptr)
+    bridge.unregister_map(b_d.ptr)
+    assert not func.loops
+
+
+@pytest.mark.gpu
+def test_dg_ds_subset_loop_through_func():
+    """Config C4's exterior-facet integral over a ``ds(subdomain)`` Subset (a direct uint32 facet-number Dat addressed by
+    the base entity, READ Globals) through ``func(start, end, subset, *args, *maps)`` against the oracle."""
+    from firedrake_amd import forms, mesh as fmesh
+    from helpers import oracle_run
+    m = fmesh.make_quad_mesh(24, perturb=0.1)
+    prob = forms.DGAdvectionProblem(m)
+    _, ke, _ = forms.dg_advection_kernels()
+    ec = np.asarray(m.ext_dq.values_with_halo)[:, 0] // 4
+    side = np.nonzero(m.dq_points.reshape(-1, 4, 2)[ec][:, :, 0].min(axis=1) < 0.5 / 24)[0].astype(np.int32)    # facets of cells at x ~ 0
+    sub = op2.Subset(m.ext_facet_set, side)
+    L = op2.Dat(m.dq_set)
+    args = (L(op2.INC, m.ext_dq), m.coordinates(op2.READ, m.ext_q1), prob.q(op2.READ, m.ext_dq), prob.u(op2.READ, m.ext_q1),
+            prob.dtc(op2.READ), prob.q_in(op2.READ), m.ext_local_facet(op2.READ))
+    ref = oracle_run(ke, sub, *args)[0]
+    dq, q1 = MapKernelArg(arity=4), MapKernelArg(arity=4)
+    lk = CStringLocalKernel(code=ke.code, name=ke.name, accesses=(4, 1, 1, 1, 1, 1, 1), dtypes=(np.float64,) * 6 + (np.uint32,))
+    gk = GlobalKernel(local_kernel=lk, _subset=True,
+                      arguments=[DatKernelArg(dim=(1,), map_=dq), DatKernelArg(dim=(2,), map_=q1), DatKernelArg(dim=(1,), map_=dq),
+                                 DatKernelArg(dim=(2,), map_=q1), GlobalKernelArg(dim=(1,)), GlobalKernelArg(dim=(1,)), DatKernelArg(dim=(1,))])
+    func = bridge.compile_global_kernel_hip(gk)
+    nd, nv, nf = m.dq_set.total_size, m.q1_set.total_size, m.ext_facet_set.total_size
+    L_d, x_d, q_d, u_d, dt_d, qin_d, lf_d, dq_d, q1_d, idx_d = _dev(
+        np.zeros(nd), np.array(m.coordinates.data_ro), np.array(prob.q.data_ro), np.array(prob.u.data_ro), np.array(prob.dtc.data_ro),
+        np.array(prob.q_in.data_ro), np.array(m.ext_local_facet.data_ro), np.asarray(m.ext_dq.values_with_halo),
+        np.asarray(m.ext_q1.values_with_halo), sub.indices.astype(np.int32))
+    bridge.register_map(dq_d.ptr, nf, 4, toset_sizes=(nd,) * 3, values=np.asarray(m.ext_dq.values_with_halo))
+    bridge.register_map(q1_d.ptr, nf, 4, toset_sizes=(nv,) * 3)                 # values are downloaded once when not given
+    func(0, len(sub.indices), idx_d.ptr, L_d.ptr, x_d.ptr, q_d.ptr, u_d.ptr, dt_d.ptr, qin_d.ptr, lf_d.ptr, dq_d.ptr, q1_d.ptr)
+    got = L_d.download(np.float64, (nd,))
+    assert np.abs(ref).max() > 0 and np.abs(got - ref.reshape(-1)).max() <= 1e-12 * np.abs(ref).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bcs", [False, True])
+def test_q4_jacobian_and_action_through_func(bcs):
+    """Config C3 through the seam alone: ``func(start, end, layers, mat, coords, map_q4, map_q1)`` over the extruded set,
+    the local kernel translated from a stand-in carrying the TSFC-shaped C text plus the ``fdhip_tensor`` descriptor -> the
+    fp64-MFMA matrix wrapper and the sum-factorised action wrapper, BC lgmaps swapped in, against the oracle."""
+    from firedrake_amd import forms, mesh as fmesh
+    from helpers import oracle_run
+    n = 3
+    m = fmesh.make_extruded_hex_mesh(n, n, 4, perturb=0.1)
+    cm, xm = m.cell_node_map, m.coord_map
+    nn, nx, ncol = m.node_set.total_size, m.coord_node_set.total_size, m.base_set.size
+    sp = op2.Sparsity((m.node_set ** 1, m.node_set ** 1), [(cm, cm, None)])
+    mat = op2.Mat(sp)
+    lg = None
+    if bcs:
+        pts = m.node_points
+        rlg = np.arange(nn, dtype=np.int32)
+        rlg[np.nonzero(((pts < 1e-12) | (pts > 1 - 1e-12)).any(axis=1))[0]] = -1
+        lg = (rlg, rlg.copy())
+    kj, ka = forms.helmholtz_q4_hex_jacobian_kernel(), forms.helmholtz_q4_hex_action_kernel()
+    ref = oracle_run(kj, m.cell_set, mat(op2.INC, (cm, cm), lgmaps=lg), m.coordinates(op2.READ, xm))[0]
+    u = np.random.default_rng(4).standard_normal(nn)
+    refy = oracle_run(ka, m.cell_set, op2.Dat(m.node_set)(op2.INC, cm), m.coordinates(op2.READ, xm), op2.Dat(m.node_set, u)(op2.READ, cm))[0]
+    q4, q1 = MapKernelArg(arity=125, offset=(4,) * 125), MapKernelArg(arity=8, offset=(1,) * 8)
+    lkj = CStringLocalKernel(code=kj.code, name=kj.name, accesses=(4, 1), dtypes=(np.float64,) * 2, requires_zeroed_output_arguments=True)
+    lkj.fdhip_tensor = bridge.tensor_form_info("hexahedron", "Q", 4, 8, {"stiffness": 1.0, "mass": 1.0}, "matrix")
+    lka = CStringLocalKernel(code=ka.code, name=ka.name, accesses=(4, 1, 1), dtypes=(np.float64,) * 3, requires_zeroed_output_arguments=True)
+    lka.fdhip_tensor = bridge.tensor_form_info("hexahedron", "Q", 4, 8, {"stiffness": 1.0, "mass": 1.0}, "action")
+    flags = dict(_extruded=True, _constant_layers=True)
+    fj = bridge.compile_global_kernel_hip(GlobalKernel(local_kernel=lkj, arguments=[MatKernelArg(dims=((1, 1),), maps=(q4, q4)),
+                                                                                 DatKernelArg(dim=(3,), map_=q1)], **flags))
+    fa = bridge.compile_global_kernel_hip(GlobalKernel(local_kernel=lka, arguments=[DatKernelArg(dim=(1,), map_=q4), DatKernelArg(dim=(3,), map_=q1),
+                                                                                 DatKernelArg(dim=(1,), map_=q4)], **flags))
+    assert (fj.mode, fa.mode) == ("tp_matrix", "tp_action")
+    sp._build()
+    from firedrake_amd.device import DeviceBuffer
+    vals = DeviceBuffer(sp.nz * 8)
+    vals.upload(np.zeros(sp.nz))
+    dm = bridge.DeviceMat(sp._rowptr.ptr, sp._colidx.ptr, vals.ptr, nn, sp.nz)
+    lay_d, x_d, q4_d, q1_d, y_d, u_d = _dev(np.asarray(m.cell_set.layers_array, dtype=np.int32), np.array(m.coordinates.data_ro),
+                                           np.asarray(cm.values_with_halo), np.asarray(xm.values_with_halo), np.zeros(nn), u)
+    bridge.register_map(q4_d.ptr, ncol, 125, toset_sizes=(nn,) * 3, values=np.asarray(cm.values_with_halo))
+    bridge.register_map(q1_d.ptr, ncol, 8, toset_sizes=(nx,) * 3, values=np.asarray(xm.values_with_halo))
+    if bcs:
+        (lg_d,) = _dev(lg[0])
+        dm.set_lgmaps(lg_d.ptr, lg_d.ptr)
+    fj(0, ncol, lay_d.ptr, dm.handle, x_d.ptr, q4_d.ptr, q1_d.ptr)
+    v = vals.download(np.float64, (sp.nz,))
+    assert np.abs(v - ref.values).max() <= 1e-11 * np.abs(ref.values).max()
+    fa(0, ncol, lay_d.ptr, y_d.ptr, x_d.ptr, u_d.ptr, q4_d.ptr, q1_d.ptr)
+    y = y_d.download(np.float64, (nn,))
+    assert np.abs(y - refy).max() <= 1e-11 * np.abs(refy).max()
+    dm.free()
+
+
+@pytest.mark.gpu
+def test_vector_valued_blocks_through_func():
+    """MatSetValuesBlockedLocal (builder.py:573-625) through the seam: vector P1 on tetrahedra, 3 x 3 blocks; the DeviceMat is
+    described by its NODE pattern and holds the block-expanded scalar CSR values."""
+    from firedrake_amd import mesh as fmesh
+    from firedrake_amd.device import DeviceBuffer
+    from helpers import oracle_run
+    from mixed_cases import vector_p1_elasticity_kernel
+    msh = fmesh.UnitCubeMesh(4, perturb=0.1)
+    V = msh.space(1)
+    cm = V.cell_node_map
+    sp = op2.Sparsity((V.node_set ** 3, V.node_set ** 3), [(cm, cm, None)])
+    mat = op2.Mat(sp)
+    k = vector_p1_elasticity_kernel(3)
+    ref = oracle_run(k, msh.cell_set, mat(op2.INC, (cm, cm)), msh.coordinates(op2.READ, cm))[0]
+    sp._build()
+    nn, ne = V.node_set.total_size, msh.cell_set.size
+    vals = DeviceBuffer(sp.nz * 8)
+    dm = bridge.DeviceMat(sp._node_rowptr.ptr, sp._node_colidx.ptr, vals.ptr, nn, sp._node_nnz, rbs=3, cbs=3)
+    m = MapKernelArg(arity=4)
+    gk = GlobalKernel(local_kernel=CStringLocalKernel(code=k.code, name=k.name, accesses=(4, 1), dtypes=(np.float64,) * 2),
+                      arguments=[MatKernelArg(dims=((3, 3),), maps=(m, m)), DatKernelArg(dim=(3,), map_=m)])
+    func = bridge.compile_global_kernel_hip(gk)
+    assert func.mode == "ocrs"
+    m_d, x_d = _dev(np.asarray(cm.values_with_halo), np.array(msh.coordinates.data_ro))
+    bridge.register_map(m_d.ptr, ne, 4, toset_sizes=(nn,) * 3)
+    dm.zero()
+    func(0, ne, dm.handle, x_d.ptr, m_d.ptr)
+    v = vals.download(np.float64, (sp.nz,))
+    assert np.abs(v - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
+    dm.free()
