@@ -54,8 +54,11 @@ SIGNATURES = {
     "fd_kernel_free": (c_int, [c_void_p]),
     "fd_kernel_launch": (c_int, [c_void_p, c_int32, c_int32, POINTER(c_void_p), c_int, c_int, c_int, c_int,
                                  c_size_t, c_void_p]),
-    "fd_locality_order": (c_int, [c_void_p, c_int, c_int32, c_int32, c_void_p, c_int, c_void_p, c_void_p]),
-    "fd_first_touch_order": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
+    "fd_kd_order": (c_int, [c_void_p, c_int, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int32, POINTER(c_int32), c_void_p]),
+    "fd_group_entities": (c_int, [c_void_p, c_int, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "fd_invert_permutation": (c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
+    "fd_row_entry_positions": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fd_first_touch_order": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fd_comm_available": (c_int, []),
     "fd_comm_unique_id": (c_int, [c_void_p]),
     "fd_comm_create": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
@@ -113,6 +116,9 @@ SIGNATURES = {
     "fd_csr_set_diagonal": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_double, c_void_p]),
     "fd_csr_zero_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_double, c_void_p]),
     "fd_csr_spmv": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fd_csr_split_mpiaij": (c_int, [c_int32, c_void_p, c_void_p, c_int32, c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64),
+                                    POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_void_p]),
+    "fd_csr_split_values": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fd_csr_get_diagonal": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fd_dat_set_rows": (c_int, [c_void_p, c_int, c_void_p, c_int32, c_double, c_void_p]),
     "fd_dat_axpby": (c_int, [c_void_p, c_double, c_void_p, c_double, c_int64, c_void_p]),

@@ -254,9 +254,11 @@ def register_map(ptr, nent_total, arity, toset_sizes, iterset_sizes=None, prefer
                               "values": None if values is None else np.ascontiguousarray(values, dtype=np.int32)}
 
 
-def unregister_map(ptr):
-    """Forget a Map pointer (the carrier freed its buffer): drops the registration and every cached loop, plan and composed
-    table keyed on the address, so a later allocation at the same address starts clean."""
+def forget(ptr):
+    """Forget a device address (a Map, Subset or layers buffer the carrier is about to free): drops the registration and
+    every cached loop, plan, host copy and composed table keyed on it, so a later allocation at the same address starts
+    clean.  The carrier-side patch calls this from the carriers' finalisers: everything the seam caches
+    is keyed on addresses because addresses are all ``func(start, end, *arglist)`` receives."""
     ptr = int(ptr)
     _device_maps.pop(ptr, None)
     for k in [k for k in _host_ints_cache if k[0] == ptr]:
@@ -266,6 +268,18 @@ def unregister_map(ptr):
     for f in list(_seam_funcs):
         for k in [k for k in f.loops if ptr in k]:
             f.loops.pop(k)
+
+
+unregister_map = forget
+
+
+def reset():
+    """Drop every address-keyed cache of the seam (all registrations, host copies, composed tables, cached loops)."""
+    _device_maps.clear()
+    _host_ints_cache.clear()
+    _composed.clear()
+    for f in _seam_funcs:
+        f.loops.clear()
 
 
 _host_ints_cache = {}

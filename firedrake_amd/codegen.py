@@ -410,10 +410,9 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             P(f"long long oc{k}_maxnown", ("ocr_maxnown", k))
             P(f"long long oc{k}_flags", ("ocr_flags", k))
             if ocrp:
-                P(f"const int *__restrict__ oc{k}_pinv", ("ocr_pinv", k))
                 P(f"const int *__restrict__ oc{k}_prowptr", ("ocr_prowptr", k))
                 P(f"const int *__restrict__ oc{k}_nstart", ("ocr_nstart", k))
-                P(f"const int *__restrict__ oc{k}_gstart", ("ocr_gstart", k))
+                P(f"const int *__restrict__ oc{k}_gpos", ("ocr_gpos", k))
                 P(f"long long oc{k}_npos", ("ocr_npos", k))
         elif mat_staged[k]:
             P(f"const int *__restrict__ mp{k}_off", ("matplan_off", k))
@@ -579,10 +578,11 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 rowmask = f" && rlg{k}[g] >= 0" if lg else ""
                 colbit = (f" | ((clg{k}[g] < 0) ? 0x80000000u : 0u)" if (colmask and cm == rm) else "")
                 if ocrp:
-                    # the node's row position decides ownership and the accumulator offset
-                    loads = [f"const int p{k}_U = (G_U < (int)oc{k}_npos) ? oc{k}_pinv[G_U] : -1;",
-                             f"const unsigned w{k}_U = ((p{k}_U >= n0_{k} && p{k}_U < n0_{k} + nown{k}{rowmask.replace('[g]', '[G_U]')}) ? "
-                             f"(unsigned)(oc{k}_nstart[G_U] - r0_{k} + 1) : 0u){colbit.replace('[g]', '[G_U]')};"]
+                    # the accumulator offset of the node's row (by NODE) decides ownership too: the block's rows are exactly
+                    # those whose offsets fall into [r0, r0 + nnzb) -- one lookup, no row-position table in the kernel
+                    loads = [f"const int p{k}_U = (G_U < (int)oc{k}_npos) ? oc{k}_nstart[G_U] - r0_{k} : -1;",
+                             f"const unsigned w{k}_U = ((p{k}_U >= 0 && p{k}_U < nnzb{k}{rowmask.replace('[g]', '[G_U]')}) ? "
+                             f"(unsigned)(p{k}_U + 1) : 0u){colbit.replace('[g]', '[G_U]')};"]
                 else:
                     rowpos = f"(unsigned)(oc{k}_rowptr[g] - r0_{k} + 1)"
                     loads = [f"const int g = G_U; const unsigned w{k}_U = ((g >= n0_{k} && g < n0_{k} + nown{k}{rowmask}) ? {rowpos} : 0u){colbit};".replace("const int g = G_U; ", "").replace("(g ", "(G_U ").replace(" g ", " G_U ").replace(" g,", " G_U,").replace("[g]", "[G_U]")]
@@ -604,12 +604,13 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 lines += [f"    atomicAdd(&sm{k}[base + kk{k}[i*{ac} + j]], {val});", "  }", "}"]
                 unpack.append("\n    ".join(lines))
                 if ocrp:
-                    # complete rows again, but a SET of CSR rows: 16 lanes per row, four rows per wavefront step
-                    flush.append((rm, f"for (int fr = tid >> 4; fr < nown{k}; fr += nthr >> 4) {{ const int fp = n0_{k} + fr; "
-                                      f"const int fs = oc{k}_prowptr[fp] - r0_{k}, fl = oc{k}_prowptr[fp+1] - oc{k}_prowptr[fp]; "
-                                      f"const size_t fd_ = (size_t)oc{k}_gstart[fp]; "
-                                      f"if (oc{k}_flags & 1) {{ for (int q = tid & 15; q < fl; q += 16) arg{k}[fd_ + q] = sm{k}[fs + q]; }} "
-                                      f"else {{ for (int q = tid & 15; q < fl; q += 16) arg{k}[fd_ + q] += sm{k}[fs + q]; }} }}"))
+                    # complete rows again, but a SET of CSR rows: the flush walks the accumulator entries like the contiguous
+                    # flush does and finds each entry's place in the CSR value array in a per-entry position table (4 B per
+                    # nonzero, streamed).  (A row-by-row flush, 16 lanes per row with the row descriptors in LDS, issued 4x the
+                    # LDS instructions and 1.5x the scalar ones for the same stores: +12 % LDS-pipe cycles in a kernel bound
+                    # by that pipe, profiles/r3f_pmc_jacobian_lexicographic.txt.)
+                    flush.append((rm, f"if (oc{k}_flags & 1) {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)oc{k}_gpos[(size_t)r0_{k} + q]] = sm{k}[q]; }} "
+                                      f"else {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)oc{k}_gpos[(size_t)r0_{k} + q]] += sm{k}[q]; }}"))
                     continue
                 # complete rows, contiguous in the CSR value array: plain coalesced stores
                 flush.append((rm, f"if (oc{k}_flags & 1) {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)r0_{k} + q] = sm{k}[q]; }} "

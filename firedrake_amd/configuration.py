@@ -60,10 +60,11 @@ configuration = {
     # per CU is recompiled with the matching __launch_bounds__ and kept if that costs at most this many bytes of scratch
     # per lane (-1 = off).  DG-advection interior-facet loop: 172 -> 128 VGPRs, 12 B scratch, 0.50 -> 0.32 ms
     "auto_occupancy_scratch": _env("FDHIP_AUTO_OCCUPANCY_SCRATCH", 16, int),
-    # maps without producer hints: derive the entity order of staged loops from the loop's position field (Morton order of
-    # the entity centroids) instead of cutting the caller's order into uniform blocks
+    # maps without producer hints: derive the entity order of staged loops from the loop's position field (box tiles of a
+    # uniform grid over the entity centroids, fd_locality_order) instead of cutting the caller's order into uniform blocks
     "locality_order": _env("FDHIP_LOCALITY_ORDER", 1, int),
     "locality_min_entities": _env("FDHIP_LOCALITY_MIN", 8192, int),
+    "locality_tile_entities": _env("FDHIP_LOCALITY_TILE", 1536, int),    # entities per box tile of the derived order
     "use_preferred_blocks": _env("FDHIP_PREFERRED_BLOCKS", 1, int),   # plan blocks = the producer's traversal tiles
     "lds_limit": _env("FDHIP_LDS_LIMIT", 64 * 1024, int),
     "mat_scatter": _env("FDHIP_MAT_SCATTER", "table"),  # table | search (direct scatter flavours)

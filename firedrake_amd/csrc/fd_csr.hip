@@ -134,6 +134,41 @@ __global__ void set_diag(const int32_t *__restrict__ rowptr, const int32_t *__re
     }
 }
 
+// ---- MPIAIJ split (pyop2/types/mat.py:254-278: d_nnz / o_nnz; MatCreateMPIAIJWithSplitArrays): columns are sorted
+// inside a row and the owned columns [0, ncols_owned) come first, so the diagonal block is a prefix of every row
+__global__ void split_counts(int32_t nrows, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, int32_t ncols_owned,
+                             int32_t *__restrict__ dcnt, int32_t *__restrict__ ocnt) {
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
+        int lo = rowptr[r], hi = rowptr[r + 1];
+        const int b = lo, e = hi;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (colidx[mid] < ncols_owned) lo = mid + 1; else hi = mid; }
+        dcnt[r] = lo - b;
+        ocnt[r] = e - lo;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { dcnt[nrows] = 0; ocnt[nrows] = 0; }
+}
+
+// one wavefront per row: copy the prefix into the diagonal block (local column indices) and the suffix into the
+// off-diagonal block (GLOBAL column indices through col_global, as MatCreateMPIAIJWithSplitArrays expects)
+template <bool WITH_IDX, bool WITH_VALS>
+__global__ void split_fill(int32_t nrows, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                           const double *__restrict__ vals, const int32_t *__restrict__ col_global,
+                           const int32_t *__restrict__ drp, const int32_t *__restrict__ orp,
+                           int32_t *__restrict__ dci, int32_t *__restrict__ oci, double *__restrict__ dv, double *__restrict__ ov) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t r = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6; r < nrows; r += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+        const int b = rowptr[r], nd = drp[r + 1] - drp[r], no = orp[r + 1] - orp[r];
+        for (int q = lane; q < nd; q += 64) {
+            if (WITH_IDX) dci[drp[r] + q] = colidx[b + q];
+            if (WITH_VALS) dv[drp[r] + q] = vals[b + q];
+        }
+        for (int q = lane; q < no; q += 64) {
+            if (WITH_IDX) { const int32_t c = colidx[b + nd + q]; oci[orp[r] + q] = col_global ? col_global[c] : c; }
+            if (WITH_VALS) ov[orp[r] + q] = vals[b + nd + q];
+        }
+    }
+}
+
 __global__ void get_diag(int32_t nrows, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                          const double *__restrict__ vals, double *__restrict__ diag) {
     for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
@@ -339,6 +374,53 @@ int fd_csr_zero_rows(const int32_t *rowptr, const int32_t *colidx, double *vals,
                      double v, fd_stream_t s) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(set_diag, dim3(grid_for(n)), dim3(256), 0, fd::st(s), rowptr, colidx, vals, rows, n, v, 1);
+    FD_CHECK_LAUNCH();
+    return 0;
+}
+
+int fd_csr_split_mpiaij(int32_t nrows_owned, const int32_t *rowptr, const int32_t *colidx, int32_t ncols_owned,
+                        const int32_t *col_global, int32_t **d_rowptr, int32_t **d_colidx, int64_t *d_nnz,
+                        int32_t **o_rowptr, int32_t **o_colidx, int64_t *o_nnz, fd_stream_t s_) {
+    if (nrows_owned < 0 || !rowptr || !colidx || !d_rowptr || !d_colidx || !o_rowptr || !o_colidx || !d_nnz || !o_nnz)
+        FD_FAIL("fd_csr_split_mpiaij: bad arguments");
+    hipStream_t s = fd::st(s_);
+    const size_t n1 = (size_t)nrows_owned + 1;
+    int32_t *dc = nullptr, *oc = nullptr, *drp = nullptr, *orp = nullptr, *dci = nullptr, *oci = nullptr;
+    void *tmp = nullptr;
+    FD_HIP(hipMalloc(&dc, n1 * 4)); FD_HIP(hipMalloc(&oc, n1 * 4));
+    FD_HIP(hipMalloc(&drp, n1 * 4)); FD_HIP(hipMalloc(&orp, n1 * 4));
+    hipLaunchKernelGGL(split_counts, dim3(grid_for(nrows_owned > 0 ? nrows_owned : 1)), dim3(256), 0, s, nrows_owned, rowptr, colidx,
+                       ncols_owned, dc, oc);
+    FD_CHECK_LAUNCH();
+    size_t tb = 0;
+    FD_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, dc, drp, (int)n1, s));
+    FD_HIP(hipMalloc(&tmp, tb ? tb : 8));
+    FD_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, dc, drp, (int)n1, s));
+    FD_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, oc, orp, (int)n1, s));
+    int32_t nd = 0, no = 0;
+    FD_HIP(hipMemcpyAsync(&nd, drp + nrows_owned, 4, hipMemcpyDeviceToHost, s));
+    FD_HIP(hipMemcpyAsync(&no, orp + nrows_owned, 4, hipMemcpyDeviceToHost, s));
+    FD_HIP(hipStreamSynchronize(s));
+    FD_HIP(hipMalloc(&dci, (size_t)(nd > 0 ? nd : 1) * 4));
+    FD_HIP(hipMalloc(&oci, (size_t)(no > 0 ? no : 1) * 4));
+    if (nrows_owned > 0) {
+        hipLaunchKernelGGL((split_fill<true, false>), dim3(grid_for((int64_t)nrows_owned * 64)), dim3(256), 0, s, nrows_owned, rowptr, colidx,
+                           (const double *)nullptr, col_global, drp, orp, dci, oci, (double *)nullptr, (double *)nullptr);
+        FD_CHECK_LAUNCH();
+    }
+    FD_HIP(hipStreamSynchronize(s));
+    FD_HIP(hipFree(dc)); FD_HIP(hipFree(oc)); FD_HIP(hipFree(tmp));
+    *d_rowptr = drp; *d_colidx = dci; *d_nnz = nd;
+    *o_rowptr = orp; *o_colidx = oci; *o_nnz = no;
+    return 0;
+}
+
+int fd_csr_split_values(int32_t nrows_owned, const int32_t *rowptr, const double *vals, const int32_t *d_rowptr,
+                        const int32_t *o_rowptr, double *d_vals, double *o_vals, fd_stream_t s) {
+    if (nrows_owned <= 0) return 0;
+    hipLaunchKernelGGL((split_fill<false, true>), dim3(grid_for((int64_t)nrows_owned * 64)), dim3(256), 0, fd::st(s), nrows_owned, rowptr,
+                       (const int32_t *)nullptr, vals, (const int32_t *)nullptr, d_rowptr, o_rowptr, (int32_t *)nullptr, (int32_t *)nullptr,
+                       d_vals, o_vals);
     FD_CHECK_LAUNCH();
     return 0;
 }

@@ -11,6 +11,8 @@
 // pyop2/codegen/builder.py:734-741).  Semantically the plan is a lossless
 // re-encoding of Map.values (pyop2/types/map.py:32-45) restricted to [start,end).
 #include "fd_common.h"
+#include <vector>
+#include <algorithm>
 #include <climits>
 
 struct fd_plan_s {
@@ -743,95 +745,89 @@ __global__ void ocr_stencil_keys(const int32_t *__restrict__ rmap, int ar, const
 // kernel issues, for each row vertex i, gathers at local node index lm[i] (32 eight-byte banks: bank = lm & 31; equal
 // addresses broadcast) and, for each owned row i and column j, a ds_add_f64 at (row base + position); the fp64 atomic
 // path resolves only 16 banks (measured: stride-2 doubles already halve its rate, profiles/r1i_microbench_lds.txt):
-// bank = that & 15, and equal addresses serialise too.  A greedy list scheduler fills the windows one slot at a time: among the next CAND
-// unplaced instances (in stencil order) it takes the one that adds the fewest bank collisions to the current
-// window, ties to the earliest.  One wavefront per block; lane l scores candidate l.
+// bank = that & 15, and equal addresses serialise too.  A greedy list scheduler fills the windows one slot at a time: among
+// the unplaced instances of its CHUNK it takes the one that adds the fewest bank collisions to the current window, ties to
+// the earliest (keeps the incoming stencil order where that is conflict-free).  A chunk is PACK_CHUNK consecutive
+// instances (8 windows) of one block, scheduled by one wavefront on its own: every chunk of every block runs in parallel
+// (round 2 scheduled a whole block -- ~2300 sequential steps -- per wavefront: 0.88 s for the C2 plan; chunked: ~15 ms).
 constexpr int PACK_MAXSIG = 128;     // ar + ar*ac signature bytes per instance at most
-constexpr int PACK_CAND = 128;
+constexpr int PACK_CHUNK = 128;      // instances per chunk = candidates a slot chooses from (2 per lane)
 
-__global__ __launch_bounds__(64) void ocr_pack_k(const int32_t *__restrict__ inst_off, const int32_t *__restrict__ ent_in,
-                                                 int32_t *__restrict__ ent_out, const int32_t *__restrict__ imap_r,
-                                                 const uint16_t *__restrict__ lmap, const unsigned char *__restrict__ kidx8,
-                                                 const unsigned short *__restrict__ kidx16, int ar, int ac,
-                                                 const int32_t *__restrict__ rblk, const int32_t *__restrict__ rowptr,
-                                                 int maxn, int window, int cand, const int32_t *__restrict__ pinv, int32_t npos) {
+__global__ __launch_bounds__(64) void ocr_pack_k(const int32_t *__restrict__ chunk_block, const int32_t *__restrict__ chunk_first,
+                                                 const int32_t *__restrict__ chunk_len, int64_t nchunks,
+                                                 const int32_t *__restrict__ ent_in, int32_t *__restrict__ ent_out,
+                                                 const int32_t *__restrict__ imap_r, const uint16_t *__restrict__ lmap,
+                                                 const unsigned char *__restrict__ kidx8, const unsigned short *__restrict__ kidx16,
+                                                 int ar, int ac, const int32_t *__restrict__ rblk, const int32_t *__restrict__ rowptr,
+                                                 int window, const int32_t *__restrict__ pinv, int32_t npos) {
     extern __shared__ unsigned char pk_lds[];
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const int o = inst_off[b], n = inst_off[b + 1] - o;
-    if (n <= window || n > maxn) {                       // nothing to gain / does not fit: keep the order
-        for (int q = lane; q < n; q += 64) ent_out[o + q] = ent_in[o + q];
-        return;
-    }
+    const int lane = threadIdx.x;
     const int ns = ar + ar * ac;
-    unsigned char *sig = pk_lds;                                          // n * ns bank bytes (0xff = no access)
-    unsigned short *gaddr = (unsigned short *)(pk_lds + (((size_t)maxn * ns + 15) & ~(size_t)15));   // n * ar local node ids
-    unsigned short *pool = gaddr + (size_t)maxn * ar;                     // n slots: unplaced instances in order
-    unsigned int *amask = (unsigned int *)(pool + ((maxn + 7) & ~7));     // ar*ac bank masks of the current window
-    unsigned short *gown = (unsigned short *)(amask + PACK_MAXSIG);       // ar * 32: address held by a gather bank
-    const int32_t n0 = rblk[b], n1 = rblk[b + 1];
-    const int32_t r0 = rowptr[n0];
-    for (int q = lane; q < n; q += 64) {
-        const int64_t t = (int64_t)o + q;
-        for (int i = 0; i < ar; ++i) {
-            const unsigned short l = lmap[t * ar + i];
-            gaddr[q * ar + i] = l;
-            sig[q * ns + i] = (unsigned char)(l & 31);
-            const int32_t g = row_position(pinv, npos, imap_r[t * ar + i]);     // (rowptr = row starts in the same order)
-            const bool own = g >= n0 && g < n1;
-            const int base = own ? rowptr[g] - r0 : 0;
-            for (int j = 0; j < ac; ++j) {
-                const int k = kidx8 ? (int)kidx8[t * ar * ac + i * ac + j] : (int)kidx16[t * ar * ac + i * ac + j];
-                sig[q * ns + ar + i * ac + j] = own ? (unsigned char)((base + k) & 15) : (unsigned char)0xff;
-            }
+    unsigned char *sig = pk_lds;                                                      // PACK_CHUNK * ns bank bytes (0xff = no access)
+    unsigned short *gaddr = (unsigned short *)(pk_lds + (((size_t)PACK_CHUNK * ns + 15) & ~(size_t)15));   // PACK_CHUNK * ar local node ids
+    unsigned int *amask = (unsigned int *)(gaddr + (size_t)PACK_CHUNK * ar);          // ar*ac bank masks of the current window
+    unsigned short *gown = (unsigned short *)(amask + PACK_MAXSIG);                   // ar * 32: address held by a gather bank
+    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int b = chunk_block[c], o = chunk_first[c], n = chunk_len[c];
+        if (n <= window) {                                   // nothing to gain: keep the order
+            for (int q = lane; q < n; q += 64) ent_out[o + q] = ent_in[o + q];
+            continue;
         }
-        pool[q] = (unsigned short)q;
-    }
-    __syncthreads();
-    int head = 0;
-    for (int p = 0; p < n; ++p) {
-        if (p % window == 0) {
-            for (int q = lane; q < ar * ac; q += 64) amask[q] = 0u;
-            for (int q = lane; q < ar * 32; q += 64) gown[q] = 0xffffu;
-            __syncthreads();
-        }
-        const int ncand = (n - head) < cand ? (n - head) : cand;
-        int best = 0x7fffffff, bl = 0x7fffffff;          // best (cost, candidate index) seen by this lane
-        for (int c = lane; c < ncand; c += 64) {
-            const int inst = pool[head + c];
-            int cost = 0;
-            const unsigned char *s = sig + (size_t)inst * ns;
+        const int32_t n0 = rblk[b], n1 = rblk[b + 1];
+        const int32_t r0 = rowptr[n0];
+        __syncthreads();
+        for (int q = lane; q < n; q += 64) {
+            const int64_t t = (int64_t)o + q;
             for (int i = 0; i < ar; ++i) {
-                const unsigned short held = gown[i * 32 + s[i]];
-                if (held != 0xffffu && held != gaddr[inst * ar + i]) cost += 3;      // one extra pass per component
+                const unsigned short l = lmap[t * ar + i];
+                gaddr[q * ar + i] = l;
+                sig[q * ns + i] = (unsigned char)(l & 31);
+                const int32_t g = row_position(pinv, npos, imap_r[t * ar + i]);     // (rowptr = row starts in the same order)
+                const bool own = g >= n0 && g < n1;
+                const int base = own ? rowptr[g] - r0 : 0;
+                for (int j = 0; j < ac; ++j) {
+                    const int k = kidx8 ? (int)kidx8[t * ar * ac + i * ac + j] : (int)kidx16[t * ar * ac + i * ac + j];
+                    sig[q * ns + ar + i * ac + j] = own ? (unsigned char)((base + k) & 15) : (unsigned char)0xff;
+                }
             }
-            for (int q = 0; q < ar * ac; ++q) {
-                const unsigned char bk = s[ar + q];
-                if (bk != 0xff && (amask[q] >> bk & 1u)) cost += 1;
+        }
+        bool placed0 = false, placed1 = false;               // candidates lane and lane + 64 of this chunk
+        for (int p = 0; p < n; ++p) {
+            if (p % window == 0) {
+                __syncthreads();
+                for (int q = lane; q < ar * ac; q += 64) amask[q] = 0u;
+                for (int q = lane; q < ar * 32; q += 64) gown[q] = 0xffffu;
             }
-            if (cost < best) { best = cost; bl = c; }
-        }
-        // argmin over the wavefront, ties to the earliest candidate (keeps the incoming order where it is conflict-free)
-        for (int d = 32; d > 0; d >>= 1) {
-            const int oc = __shfl_xor(best, d, 64), ol = __shfl_xor(bl, d, 64);
-            if (oc < best || (oc == best && ol < bl)) { best = oc; bl = ol; }
-        }
-        const int chosen = pool[head + bl];
-        __syncthreads();
-        // remove pool[head + bl]: shift the earlier candidates up by one (highest first), advance head
-        for (int base = ((bl - 1) / 64) * 64; base >= 0 && bl > 0; base -= 64) {
-            const int c = base + lane;
-            unsigned short keep = 0;
-            if (c < bl) keep = pool[head + c];
             __syncthreads();
-            if (c < bl) pool[head + c + 1] = keep;
+            int best = 0x7fffffff, bl = 0x7fffffff;          // best (cost, candidate) seen by this lane
+            for (int h = 0; h < 2; ++h) {
+                const int inst = lane + 64 * h;
+                if (inst >= n || (h ? placed1 : placed0)) continue;
+                int cost = 0;
+                const unsigned char *s = sig + (size_t)inst * ns;
+                for (int i = 0; i < ar; ++i) {
+                    const unsigned short held = gown[i * 32 + s[i]];
+                    if (held != 0xffffu && held != gaddr[inst * ar + i]) cost += 3;      // one extra pass per component
+                }
+                for (int q = 0; q < ar * ac; ++q) {
+                    const unsigned char bk = s[ar + q];
+                    if (bk != 0xff && (amask[q] >> bk & 1u)) cost += 1;
+                }
+                if (cost < best) { best = cost; bl = inst; }
+            }
+            // argmin over the wavefront, ties to the earliest candidate (keeps the incoming order where it is conflict-free)
+            for (int d = 32; d > 0; d >>= 1) {
+                const int oc = __shfl_xor(best, d, 64), ol = __shfl_xor(bl, d, 64);
+                if (oc < best || (oc == best && ol < bl)) { best = oc; bl = ol; }
+            }
+            const int chosen = bl;
+            if ((chosen & 63) == lane) { if (chosen >= 64) placed1 = true; else placed0 = true; }
+            if (lane == 0) ent_out[o + p] = ent_in[o + chosen];
             __syncthreads();
+            const unsigned char *s = sig + (size_t)chosen * ns;
+            for (int q = lane; q < ar * ac; q += 64) { const unsigned char bk = s[ar + q]; if (bk != 0xff) amask[q] |= 1u << bk; }
+            if (lane < ar) { if (gown[lane * 32 + s[lane]] == 0xffffu) gown[lane * 32 + s[lane]] = gaddr[chosen * ar + lane]; }
         }
-        if (lane == 0) ent_out[o + p] = ent_in[o + chosen];
-        const unsigned char *s = sig + (size_t)chosen * ns;
-        for (int q = lane; q < ar * ac; q += 64) { const unsigned char bk = s[ar + q]; if (bk != 0xff) amask[q] |= 1u << bk; }
-        if (lane < ar) { if (gown[lane * 32 + s[lane]] == 0xffffu) gown[lane * 32 + s[lane]] = gaddr[chosen * ar + lane]; }
-        ++head;
-        __syncthreads();
     }
 }
 
@@ -1136,27 +1132,32 @@ int fd_ocrplan_pack(fd_ocrplan_t p, const int32_t *imap_r_dev, const uint16_t *l
     if (ns > PACK_MAXSIG) return 0;                     // large element matrices: keep the incoming order
     hipStream_t s = fd::st(s_);
     const int window = 16;
-    int cand = PACK_CAND;
-    if (const char *e = getenv("FDHIP_PACK_CAND")) cand = atoi(e) > 0 ? atoi(e) : PACK_CAND;
-    // per block in LDS: ns bank bytes + ar local ids + one pool slot per instance, + the window state
-    const size_t fixed = PACK_MAXSIG * 4 + (size_t)ar * 32 * 2 + 64;
-    int maxn = p->max_inst;
-    const size_t per = (size_t)ns + (size_t)ar * 2 + 2;
-    const size_t budget = 150 * 1024;
-    if ((size_t)maxn * per + fixed > budget) maxn = (int)((budget - fixed) / per);
-    maxn &= ~7;
-    if (maxn < 64) return 0;
-    const size_t lds = (((size_t)maxn * ns + 15) & ~(size_t)15) + (size_t)maxn * ar * 2 + (size_t)((maxn + 7) & ~7) * 2 + fixed;
+    // chunks of PACK_CHUNK consecutive instances, never across a block boundary
+    std::vector<int32_t> cb, cf, cl;
+    for (int32_t b = 0; b < p->nblocks; ++b)
+        for (int32_t o = p->inst_off_host[b]; o < p->inst_off_host[b + 1]; o += PACK_CHUNK) {
+            cb.push_back(b); cf.push_back(o);
+            cl.push_back(std::min<int32_t>(PACK_CHUNK, p->inst_off_host[b + 1] - o));
+        }
+    const int64_t nchunks = (int64_t)cb.size();
+    if (nchunks == 0) return 0;
+    int32_t *dcb = nullptr, *dcf = nullptr, *dcl = nullptr, *out = nullptr;
+    FD_HIP(hipMalloc(&dcb, (size_t)nchunks * 4)); FD_HIP(hipMalloc(&dcf, (size_t)nchunks * 4)); FD_HIP(hipMalloc(&dcl, (size_t)nchunks * 4));
+    FD_HIP(hipMemcpyAsync(dcb, cb.data(), (size_t)nchunks * 4, hipMemcpyHostToDevice, s));
+    FD_HIP(hipMemcpyAsync(dcf, cf.data(), (size_t)nchunks * 4, hipMemcpyHostToDevice, s));
+    FD_HIP(hipMemcpyAsync(dcl, cl.data(), (size_t)nchunks * 4, hipMemcpyHostToDevice, s));
+    const size_t lds = (((size_t)PACK_CHUNK * ns + 15) & ~(size_t)15) + (size_t)PACK_CHUNK * ar * 2 + PACK_MAXSIG * 4 + (size_t)ar * 32 * 2 + 64;
     if (lds > 48 * 1024)
         FD_HIP(hipFuncSetAttribute((const void *)ocr_pack_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int32_t *out = nullptr;
     FD_HIP(hipMalloc(&out, (size_t)p->ninst * 4));
-    hipLaunchKernelGGL(ocr_pack_k, dim3(p->nblocks), dim3(64), lds, s, p->inst_off, p->inst_ent, out, imap_r_dev, lmap_dev,
+    const int64_t grid = nchunks < 256 * 64 ? nchunks : 256 * 64;
+    hipLaunchKernelGGL(ocr_pack_k, dim3((unsigned)grid), dim3(64), lds, s, dcb, dcf, dcl, nchunks, p->inst_ent, out, imap_r_dev, lmap_dev,
                        kbytes == 1 ? (const unsigned char *)kidx_dev : nullptr,
                        kbytes == 2 ? (const unsigned short *)kidx_dev : nullptr, ar, ac, p->rblk,
-                       p->prowptr ? p->prowptr : node_rowptr_dev, maxn, window, cand, p->pinv, p->npos);
+                       p->prowptr ? p->prowptr : node_rowptr_dev, window, p->pinv, p->npos);
     FD_CHECK_LAUNCH();
     FD_HIP(hipStreamSynchronize(s));
+    FD_HIP(hipFree(dcb)); FD_HIP(hipFree(dcf)); FD_HIP(hipFree(dcl));
     FD_HIP(hipFree(p->inst_ent));
     p->inst_ent = out;
     return 0;

@@ -1831,10 +1831,29 @@ class Sparsity:
 
     @property
     def nnz(self):
-        """Per node-row count of nonzeros (sparsity.nnz of the reference, mat.py:254-278)."""
+        """Non-zeroes per OWNED scalar row in the diagonal portion of the local submatrix: ``d_nnz`` of
+        MatMPIAIJSetPreallocation (mat.py:254-262)."""
+        return np.diff(self.mpiaij_split().d_rowptr.download(np.int32, (self._dsets[0].set.size * self._dsets[0].cdim + 1,)))
+
+    @property
+    def onnz(self):
+        """Non-zeroes per owned scalar row in the off-diagonal portion (columns owned by other ranks): ``o_nnz``
+        (mat.py:264-271)."""
+        return np.diff(self.mpiaij_split().o_rowptr.download(np.int32, (self._dsets[0].set.size * self._dsets[0].cdim + 1,)))
+
+    def mpiaij_split(self, col_global=None):
+        """The owned rows of the scalar CSR as the two sequential blocks of an MPIAIJ matrix (fd_csr_split_mpiaij): diagonal
+        block = columns owned here (local indices), off-diagonal block = ghost columns, numbered through ``col_global``
+        (int32 array over the local columns: the column lgmap of pyop2/types/dataset.py:120-164; None keeps local numbers).
+        Cached per ``col_global`` object; ``Mat.mpiaij_values`` fills the matching value arrays."""
         self._build()
-        rp = self._node_rowptr.download(np.int32, (self._dsets[0].set.total_size + 1,))
-        return np.diff(rp)
+        cache = self.__dict__.setdefault("_mpiaij", {})
+        key = id(col_global)
+        hit = cache.get(key)
+        if hit is None or hit[0] is not col_global:
+            hit = (col_global, MPIAIJSplit(self, col_global))
+            cache[key] = hit
+        return hit[1]
 
     def matplan(self, rowplan, colplan, maps):
         """Cached block-local sparsity for the staged matrix scatter (fd_matplan_create)."""
@@ -2048,10 +2067,27 @@ class RowOrder:
     (fd_first_touch_order)."""
 
     def __init__(self, rmap: Map, order: "DeviceBuffer", n, npos, node_rowptr_host):
+        """First-touch row order under the entity order ``order`` (fd_first_touch_order)."""
         self.npos = int(npos)
         self.pinv, self.plist = DeviceBuffer(max(npos, 1) * 4), DeviceBuffer(max(npos, 1) * 4)
+        rank = DeviceBuffer(max(npos, 1) * 4)
         _lib.call("fd_first_touch_order", rmap._base()._dev_values(), rmap.arity, order.ptr, int(n), self.npos, self.pinv.ptr,
-                  self.plist.ptr, None)
+                  self.plist.ptr, rank.ptr, None)
+        self.rank_host = rank.download(np.int32, (self.npos,))       # position (in ``order``) of the entity first touching row p
+        self._tables(node_rowptr_host)
+
+    @classmethod
+    def from_plist(cls, plist: "DeviceBuffer", npos, node_rowptr_host):
+        """A row order given as a device permutation of [0, npos) (a k-d partition of the rows' own positions)."""
+        self = cls.__new__(cls)
+        self.npos = int(npos)
+        self.plist, self.pinv = plist, DeviceBuffer(max(npos, 1) * 4)
+        _lib.call("fd_invert_permutation", plist.ptr, self.npos, self.pinv.ptr, None)
+        self.rank_host = None
+        self._tables(node_rowptr_host)
+        return self
+
+    def _tables(self, node_rowptr_host):
         plist = self.plist.download(np.int32, (self.npos,))
         rp = np.asarray(node_rowptr_host, dtype=np.int64)
         rowlen = np.diff(rp)[:self.npos]
@@ -2062,7 +2098,73 @@ class RowOrder:
         nstart = np.zeros(max(self.npos, 1), dtype=np.int32)
         nstart[plist] = self.prowptr_host[:-1]
         self.nstart = DeviceBuffer.from_numpy(nstart)
-        self.gstart = DeviceBuffer.from_numpy(np.ascontiguousarray(rp[plist], dtype=np.int32) if self.npos else np.zeros(1, np.int32))
+        self._gstart_host = np.ascontiguousarray(rp[plist], dtype=np.int32) if self.npos else np.zeros(1, np.int32)
+        self.gstart = DeviceBuffer.from_numpy(self._gstart_host)
+
+    def gpos(self):
+        """int32 per accumulator entry (rows in position order, entries in CSR order inside a row): its place in the CSR value
+        array -- what the whole-entity "ocrp" flush streams (built on first use)."""
+        if getattr(self, "_gpos", None) is None:
+            self._gpos = DeviceBuffer(max(int(self.prowptr_host[-1]), 1) * 4)
+            _lib.call("fd_row_entry_positions", self.npos, self.prowptr.ptr, self.gstart.ptr, self._gpos.ptr, None)
+        return self._gpos
+
+    def tile_cuts(self, entity_blocks, cap):
+        """Row-block boundaries (row positions) at the changes of the entity tile that first touches a row: the rows of one
+        block are the rows one box of entities meets first -- a box of rows.  Blocks above ``cap`` accumulator entries are
+        halved; rows no entity touches (sorted last) are cut into ``cap``-sized ranges.  None without tile boundaries."""
+        if entity_blocks is None or len(entity_blocks) < 2 or self.npos == 0 or self.rank_host is None:
+            return None
+        r = self.rank_host
+        ntouched = int(np.searchsorted(r < 0, True)) if (r < 0).any() else self.npos     # ranks ascend, untouched (-1) last
+        tile = np.searchsorted(np.asarray(entity_blocks, dtype=np.int64), r[:ntouched], side="right")
+        cuts = np.nonzero(np.diff(tile))[0] + 1
+        rb = np.concatenate([[0], cuts, [ntouched]]).astype(np.int64)
+        prp = self.prowptr_host.astype(np.int64)
+        if ntouched < self.npos:
+            tail = np.searchsorted(prp, np.arange(prp[ntouched], prp[self.npos] + cap, cap), side="left")
+            rb = np.concatenate([rb, tail[(tail > ntouched) & (tail < self.npos)], [self.npos]])
+        rb = np.unique(rb)
+        while True:                                   # a tile that owns more than the accumulator budget: halve it
+            nn = np.diff(prp[rb])
+            big = (nn > cap) & (np.diff(rb) > 1)
+            if not big.any():
+                return rb
+            rb = np.unique(np.concatenate([rb, (rb[:-1] + np.diff(rb) // 2)[big]]))
+
+
+class MPIAIJSplit:
+    """Device arrays of MatCreateMPIAIJWithSplitArrays(comm, m, n, M, N, i, j, a, oi, oj, oa) for the owned rows of a Sparsity
+    (pyop2/types/mat.py:741-804 creates the PETSc matrix these would be handed to; firedrake/preconditioners/offload.py:25-131
+    moves such a matrix to the device)."""
+
+    def __init__(self, sp, col_global):
+        rbs, cbs = sp._dsets[0].cdim, sp._dsets[1].cdim
+        self.nrows = sp._dsets[0].set.size * rbs
+        self.ncols_owned = sp._dsets[1].set.size * cbs
+        cg = None
+        if col_global is not None:
+            cg = DeviceBuffer.from_numpy(np.ascontiguousarray(col_global, dtype=np.int32))
+        VP = ctypes.c_void_p
+        drp, dci, orp, oci = VP(), VP(), VP(), VP()
+        dn, on = ctypes.c_int64(), ctypes.c_int64()
+        _lib.call("fd_csr_split_mpiaij", self.nrows, sp._rowptr.ptr, sp._colidx.ptr, self.ncols_owned, cg.ptr if cg else None,
+                  ctypes.byref(drp), ctypes.byref(dci), ctypes.byref(dn), ctypes.byref(orp), ctypes.byref(oci), ctypes.byref(on), None)
+        self.d_nnz, self.o_nnz = dn.value, on.value
+        self.d_rowptr = DeviceBuffer.wrap(drp.value, (self.nrows + 1) * 4)
+        self.d_colidx = DeviceBuffer.wrap(dci.value, max(self.d_nnz, 1) * 4)
+        self.o_rowptr = DeviceBuffer.wrap(orp.value, (self.nrows + 1) * 4)
+        self.o_colidx = DeviceBuffer.wrap(oci.value, max(self.o_nnz, 1) * 4)
+        self.d_vals = self.o_vals = None
+
+    def values(self, mat):
+        """(diagonal-block values, off-diagonal-block values) of ``mat`` as assembled now (fd_csr_split_values)."""
+        if self.d_vals is None:
+            self.d_vals, self.o_vals = DeviceBuffer(max(self.d_nnz, 1) * 8), DeviceBuffer(max(self.o_nnz, 1) * 8)
+        sp = mat.sparsity
+        _lib.call("fd_csr_split_values", self.nrows, sp._rowptr.ptr, mat._values_dev().ptr, self.d_rowptr.ptr, self.o_rowptr.ptr,
+                  self.d_vals.ptr, self.o_vals.ptr, None)
+        return self.d_vals, self.o_vals
 
 
 class MatPlan:
@@ -2247,6 +2349,13 @@ class Mat:
                   float(diag_val), None)
         _lib.call("fd_device_sync")
         self.dat_version += 1
+
+    def mpiaij_values(self, col_global=None):
+        """The assembled values laid out for MatCreateMPIAIJWithSplitArrays: (split, diagonal-block values, off-diagonal-block
+        values), all on the device (Sparsity.mpiaij_split)."""
+        split = self._sparsity.mpiaij_split(col_global)
+        d, o = split.values(self)
+        return split, d, o
 
     def get_diagonal(self, d: Dat):
         """d = diag(A) on the device (MatGetDiagonal)."""

@@ -266,6 +266,47 @@ def balanced_row_cuts(rows, rowptr, cap, lo=0.7, group=64):
     return np.asarray(rb, dtype=np.int64)
 
 
+class LocalityOrder:
+    """A backend-derived entity order: the nodes of the loop's position field are partitioned into k-d leaves (fd_kd_order)
+    and every entity joins the lowest leaf among its nodes (fd_group_entities).  ``buf`` = device int32 list of the entities,
+    ``blocks`` = block boundaries (positions in that list) at the leaf changes, and a process-unique ``serial`` (cache keys
+    must not use device addresses: a freed buffer's address is reused)."""
+    _serial = [0]
+
+    def __init__(self, buf, leaf_starts, target):
+        self.buf, self.target = buf, int(target)
+        self.ptr = buf.ptr
+        LocalityOrder._serial[0] += 1
+        self.serial = LocalityOrder._serial[0]
+        self.blocks = np.asarray(leaf_starts, dtype=np.int64)
+
+    @staticmethod
+    def cut(counts, target):
+        """Block boundaries from the entities per leaf: empty leaves dropped, a leaf above 1.5 x target split into equal parts
+        (leaves at a domain boundary hold fewer entities; nothing is merged: a block is one box)."""
+        sizes = []
+        for c in counts[counts > 0].tolist():
+            if c > (3 * target) // 2:
+                parts = -(-c // target)
+                q, r = divmod(c, parts)
+                sizes.extend([q + 1] * r + [q] * (parts - r))
+            else:
+                sizes.append(c)
+        return np.concatenate([[0], np.cumsum(np.asarray(sizes, dtype=np.int64))]).astype(np.int64)
+
+
+def kd_order(points_ptr, pdim, n, base, leaf_size):
+    """(device int32 order of the n points, leaf boundaries) of the k-d partition into leaves of ``leaf_size`` points."""
+    import ctypes
+    buf = DeviceBuffer(max(n, 1) * 4)
+    max_leaves = int(-(-n // max(leaf_size, 1))) + 1
+    starts = np.zeros(max_leaves + 1, dtype=np.int32)
+    nl = ctypes.c_int32()
+    _lib.call("fd_kd_order", points_ptr, int(pdim), int(n), int(base), int(leaf_size), buf.ptr, starts.ctypes.data, max_leaves,
+              ctypes.byref(nl), None)
+    return buf, starts[:nl.value + 1].astype(np.int64)
+
+
 class PlanDoesNotFit(_lib.FDHipError):
     """A staged / owner-computes-rows plan exceeds the LDS or the plan builder's per-block capacity: the Parloop demotes
     the loop to the next wrapper shape (ocr -> staged -> direct) before anything is launched."""
@@ -422,12 +463,23 @@ class Parloop:
             cand_order = self._locality_order(start, end)
             if cand_order is not None:
                 n = end - start
-                okey = ("order", start, end, cand_order.ptr)
                 base_maps, base = maps, (epb, plans, mplans, lds)
-                maps = [m.derived_dev(okey, n, (lambda m=m: self._gather_rows(m, cand_order, n))) if mi in src.staged_maps else m
-                        for mi, m in enumerate(base_maps)]
                 pstart, pend = 0, n
-                cand = uniform()
+                cand = None
+                for attempt in range(4):
+                    okey = ("order", start, end, cand_order.serial)
+                    maps = [m.derived_dev(okey, n, (lambda m=m, o=cand_order: self._gather_rows(m, o, n))) if mi in src.staged_maps else m
+                            for mi, m in enumerate(base_maps)]
+                    bl = cand_order.blocks.astype(np.int32)
+                    if int(np.diff(bl).max()) * maxar <= 32768:
+                        p_, mp_, lds_ = build(0, bl)
+                        if lds_ <= limit:
+                            cand = (int(np.diff(bl).max()), p_, mp_, lds_)
+                            break
+                    # tiles too large for the LDS budget / the plan builder: bin again with half the target
+                    cand_order = self._locality_order(start, end, target=max(cand_order.target // 2, 32))
+                if cand is None:
+                    cand = uniform()                    # (blocks of the derived order cut uniformly)
                 touched = lambda pl: sum(p.list_len for p in pl.values())          # noqa: E731
                 if touched(cand[1]) < 0.9 * touched(base[1]):
                     order = cand_order
@@ -526,28 +578,43 @@ class Parloop:
                 return pa
         return None
 
-    def _locality_order(self, start, end, virtual=False):
-        """Device buffer with the entities of [start, end) in locality order, or None when the loop keeps the caller's
-        order (switched off, tiny range, no position field).  ``virtual``: [start, end) are positions of the virtual
-        iteration space (owner-computes-rows loops over subsets / extruded sets, which need the order only to derive a row
-        order); staged loops over virtual spaces keep the caller's order."""
+    def _locality_order(self, start, end, virtual=False, target=None):
+        """``LocalityOrder`` of the entities of [start, end) -- grouped around the k-d leaves of the position field's nodes,
+        ~``target`` entities per group (fd_kd_order + fd_group_entities): entity list + block boundaries -- or None when the loop
+        keeps the caller's order (switched off, tiny range, no position field).  ``virtual``: [start, end) are positions of
+        the virtual iteration space (owner-computes-rows loops over subsets / extruded sets, which need the order only to
+        derive a row order); staged loops over virtual spaces keep the caller's order."""
         n = end - start
         if not configuration["locality_order"] or n < configuration["locality_min_entities"] or (self._virtual() is not None and not virtual):
             return None
         pa = self._position_arg()
         if pa is None:
             return None
+        target = int(target or configuration["locality_tile_entities"])
         pmap = self._plan_map(pa.map_._base(), staged=True) if virtual else pa.map_._base()
         cache = pmap.__dict__.setdefault("_locality_orders", {})
-        key = (start, end, id(pa.data), pa.data.dat_version)
-        buf = cache.get(key)
-        if buf is None:
+        key = (start, end, id(pa.data), pa.data.dat_version, target)
+        lo = cache.get(key)
+        if lo is None:
+            # k-d leaves of the position field's NODES, sized so that the entities around one leaf number ~target
+            pdim, nnodes = pa.data.cdim, pa.data.dataset.set.total_size
+            leaf_nodes = max(int(round(target * nnodes / max(n, 1))), 1)
+            norder, nstarts = kd_order(pa.data._dev_ptr(False), pdim, nnodes, 0, leaf_nodes)
+            nleaves = len(nstarts) - 1
+            label = np.empty(nnodes, dtype=np.int32)
+            label[norder.download(np.int32, (nnodes,))] = np.repeat(np.arange(nleaves, dtype=np.int32), np.diff(nstarts))
+            label_d = DeviceBuffer.from_numpy(label)
             buf = DeviceBuffer(n * 4)
-            _lib.call("fd_locality_order", pmap._dev_values(), pa.map_.arity, int(start), int(end),
-                      pa.data._dev_ptr(False), pa.data.cdim, buf.ptr, None)
-            cache.clear()                      # one order per map and range: a moved mesh replaces it
-            cache[key] = buf
-        return buf
+            counts = np.zeros(nleaves, dtype=np.int32)
+            _lib.call("fd_group_entities", pmap._dev_values(), pa.map_.arity, int(start), int(end), label_d.ptr, nnodes, nleaves,
+                      buf.ptr, counts.ctypes.data, None)
+            del label_d, norder
+            starts = LocalityOrder.cut(counts.astype(np.int64), target)
+            for k in [k for k in cache if k[:3] == key[:3] and k[3] != key[3]]:
+                cache.pop(k)                   # orders of an earlier state of the position field (a moved mesh)
+            lo = LocalityOrder(buf, starts, target)
+            cache[key] = lo
+        return lo
 
     @staticmethod
     def _gather_rows(m, order, n):
@@ -801,19 +868,35 @@ class Parloop:
             rb = np.asarray(hint, dtype=np.int64)
             rb = np.unique(np.concatenate([rb[rb < nrows], [0, nrows]]))
         else:
-            # no producer hints: a backend-derived row order (first touch under the locality order of the entities) when
-            # the loop has a position field, else the caller's row order; blocks = greedy ranges of ~cap CSR entries
-            order = self._locality_order(start, end, virtual=v is not None)
+            # no producer hints: a backend-derived row order when the loop has a position field, else the caller's row order in
+            # greedy ranges of ~cap CSR entries
+            from .op2types import RowOrder
+            pos_ = self._position_arg()
             prp = rp[:nrows + 1]
             cap = configuration["ocr_nnz_per_block"]
-            if order is not None:
-                from .op2types import RowOrder
-                row_order = RowOrder(rmap, order, end - start, nrows, rp)
-                prp = row_order.prowptr_host
+            rb = None
+            usable = configuration["locality_order"] and pos_ is not None and (end - start) >= configuration["locality_min_entities"]
+            if usable and v is None and pos_.map_._base() is pa.maps[0]._base():
+                # the rows ARE the nodes of the position field: partition them by their own coordinates into k-d leaves of
+                # equal row count -- boxes of rows whose accumulators fill the LDS budget exactly
                 cap = configuration["ocr_nnz_per_block_ordered"]
-            targets = np.arange(0, int(prp[nrows]) + cap, cap)
-            rb = np.unique(np.concatenate([np.searchsorted(prp[:nrows + 1], targets, side="left"), [0, nrows]]))
-            rb = rb[rb <= nrows]
+                rows_per_block = max(cap // max(int(np.ceil(rp[nrows] / max(nrows, 1))), 1), 1)
+                plist, rb = kd_order(pos_.data._dev_ptr(False), pos_.data.cdim, nrows, 0, rows_per_block)
+                row_order = RowOrder.from_plist(plist, nrows, rp)
+            elif usable:
+                # rows of another space: first touch under the k-d order of the entities, cut where the entity leaf changes
+                # (leaves hold equal numbers of entities, not of rows: 10 % slack before a block is halved)
+                order = self._locality_order(start, end, virtual=v is not None)
+                if order is not None:
+                    row_order = RowOrder(rmap, order, end - start, nrows, rp)
+                    cap = configuration["ocr_nnz_per_block_ordered"]
+                    rb = row_order.tile_cuts(order.blocks, cap + cap // 10)
+            if row_order is not None:
+                prp = row_order.prowptr_host
+            if rb is None:
+                targets = np.arange(0, int(prp[nrows]) + cap, cap)
+                rb = np.unique(np.concatenate([np.searchsorted(prp[:nrows + 1], targets, side="left"), [0, nrows]]))
+                rb = rb[rb <= nrows]
         staged = {mi: maps[mi] for mi in src.staged_maps}
         maxar = max(m.arity for m in staged.values())
 
@@ -1003,14 +1086,14 @@ class Parloop:
                 out.append(op.max_nown)
             elif kind == "ocr_flags":
                 out.append(self._ocr_flag)
-            elif kind == "ocr_pinv":
-                out.append(geo["row_order"].pinv.ptr)
             elif kind == "ocr_prowptr":
                 out.append(geo["row_order"].prowptr.ptr)
             elif kind == "ocr_nstart":
                 out.append(geo["row_order"].nstart.ptr)
             elif kind == "ocr_gstart":
                 out.append(geo["row_order"].gstart.ptr)
+            elif kind == "ocr_gpos":
+                out.append(geo["row_order"].gpos().ptr)
             elif kind == "ocr_npos":
                 out.append(geo["row_order"].npos)
             elif kind in ("mat_row_lgmap", "mat_col_lgmap"):

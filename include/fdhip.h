@@ -285,19 +285,49 @@ int fd_csr_spmv(int32_t nrows, const int32_t *rowptr_dev, const int32_t *colidx_
 int fd_csr_get_diagonal(int32_t nrows, const int32_t *rowptr_dev, const int32_t *colidx_dev,
                         const double *vals_dev, double *diag_dev, fd_stream_t s);
 
+/* ------------------------------------------------- hand-over to a distributed PETSc matrix (f1)
+ * The owned rows [0, nrows_owned) of the local CSR split into the two sequential blocks an MPIAIJ matrix is made of
+ * (pyop2/types/mat.py:254-278: Sparsity.nnz = d_nnz, Sparsity.onnz = o_nnz; firedrake/preconditioners/offload.py:25-131 moves
+ * such a matrix to the device): columns < ncols_owned form the DIAGONAL block (local column indices), the others the
+ * OFF-DIAGONAL block with GLOBAL column indices (col_global[local column], NULL = keep local) -- exactly the six arrays of
+ * MatCreateMPIAIJWithSplitArrays(comm, m, n, M, N, i, j, a, oi, oj, oa).  Columns are sorted inside a row and owned
+ * columns come first, so the diagonal block is a prefix of every row.  fd_csr_split_mpiaij builds the two patterns once
+ * (outputs allocated here, release with fd_free); fd_csr_split_values refreshes the two value arrays after an assembly. */
+int fd_csr_split_mpiaij(int32_t nrows_owned, const int32_t *rowptr_dev, const int32_t *colidx_dev, int32_t ncols_owned,
+                        const int32_t *col_global_dev, int32_t **d_rowptr_dev, int32_t **d_colidx_dev, int64_t *d_nnz,
+                        int32_t **o_rowptr_dev, int32_t **o_colidx_dev, int64_t *o_nnz, fd_stream_t s);
+int fd_csr_split_values(int32_t nrows_owned, const int32_t *rowptr_dev, const double *vals_dev, const int32_t *d_rowptr_dev,
+                        const int32_t *o_rowptr_dev, double *d_vals_dev, double *o_vals_dev, fd_stream_t s);
+
 /* ------------------------------------------------- backend-derived locality orders
  * The reference's locality comes from DMPlex (RCM cell order + first-touch DoF numbering, firedrake/mesh.py:1214-1228,
  * firedrake/cython/dmcommon.pyx:2599-2729); execution order is free under the wrapper's semantics
  * (pyop2/codegen/builder.py:734-741), so when the producer gives no block hints the backend derives its own:
- *   fd_locality_order     entity ids of [start, end) sorted by the Morton key of the centroid of their nodes in the
- *                         position field `pos` (pdim doubles per node): the coordinate argument of a TSFC kernel
- *   fd_first_touch_order  the first-touch rule applied to that entity order: plist[p] = p-th node of [0, nnodes),
- *                         pinv[node] = p; nodes no entity touches come last
+ *   fd_kd_order           k-d partition of n points (pdim doubles each) into ceil(n / leaf_size) leaves of equal
+ *                         population (+-1): recursive splits at the population median, in leaf units, along the longest
+ *                         axis of each segment's bounding box.  order[p] = base + index of the p-th point, leaves
+ *                         contiguous, points in index order inside a leaf; leaf_starts_host[0 .. *nleaves] (host array of capacity max_leaves + 1) = their
+ *                         boundaries.  Leaves are boxes with the same number of points whatever the mesh grading: one
+ *                         leaf of entities = one staged block, one leaf of rows = one owner-computes-rows block
+ *   fd_group_entities     entities of [start, end) grouped by the smallest label among their nodes (label_dev[node] in
+ *                         [0, nlabels): the k-d leaf of a node of the position field), groups in label order, entity order
+ *                         inside a group; counts_host[l] = entities of group l.  One group = one staged block: the
+ *                         entities around a leaf of nodes, as a producer's mesh tiles hold them
+ *   fd_first_touch_order  the reference's first-touch rule applied to an entity order: plist[p] = p-th node of
+ *                         [0, nnodes), pinv[node] = p; nodes no entity touches come last.  rank_dev (optional):
+ *                         rank_dev[p] = position in `order` of the entity that first touches plist[p] (-1: untouched)
+ *   fd_invert_permutation pinv[plist[p]] = p
  * Private re-encodings: Dats, Maps and the CSR keep the caller's numbering. */
-int fd_locality_order(const int32_t *map_dev, int arity, int32_t start, int32_t end, const double *pos_dev, int pdim,
-                      int32_t *order_dev, fd_stream_t s);
+int fd_kd_order(const double *pts_dev, int pdim, int64_t n, int32_t base, int32_t leaf_size, int32_t *order_dev,
+                int32_t *leaf_starts_host, int32_t max_leaves, int32_t *nleaves_out, fd_stream_t s);
+int fd_group_entities(const int32_t *map_dev, int arity, int32_t start, int32_t end, const int32_t *label_dev, int32_t nnodes,
+                      int32_t nlabels, int32_t *order_dev, int32_t *counts_host, fd_stream_t s);
 int fd_first_touch_order(const int32_t *map_dev, int arity, const int32_t *order_dev, int64_t n, int32_t nnodes,
-                         int32_t *pinv_dev, int32_t *plist_dev, fd_stream_t s);
+                         int32_t *pinv_dev, int32_t *plist_dev, int32_t *rank_dev, fd_stream_t s);
+int fd_invert_permutation(const int32_t *plist_dev, int32_t n, int32_t *pinv_dev, fd_stream_t s);
+/* gpos[prowptr[p] + k] = gstart[p] + k for the rows p of a row order (prowptr = accumulator starts by position, gstart = CSR
+ * starts by position): the place of every accumulator entry in the CSR value array, streamed by the "ocrp" row flush */
+int fd_row_entry_positions(int32_t npos, const int32_t *prowptr_dev, const int32_t *gstart_dev, int32_t *gpos_dev, fd_stream_t s);
 
 /* ------------------------------------------------- halo exchange + Global reductions over RCCL
  * firedrake/halo.py:87-172 (PetscSF bcast owner->ghost with MPI.REPLACE, reduce ghost->owner with SUM/MIN/MAX behind

@@ -265,23 +265,68 @@ def structured_tri_mesh(nx, ny, seed=0, perturb=0.0):
     return coords, np.asarray(cells, dtype=np.int32)
 
 
-def locality_order_ref(mapv, start, end, pos):
-    """numpy restatement of fd_locality_order: entity ids of [start, end) sorted (stably) by the Morton key of the centroid
-    of their nodes, 16 bits per axis over the bounding box of the referenced positions.  Returns (order, keys)."""
+def kd_order_ref(pts, leaf_size, base=0):
+    """numpy restatement of fd_kd_order: k-d partition of the points into ceil(n / leaf_size) leaves of equal population --
+    every segment holding more than one leaf is sorted (stably) along the longest axis of its bounding box, position
+    quantised to 32 bits, and cut at the boundary between its two groups of leaves.  Returns (order, leaf starts)."""
+    pts = np.asarray(pts, dtype=np.float64)
+    n, pdim = pts.shape
+    if n == 0:
+        return np.zeros(0, np.int32), np.zeros(1, np.int64)
+    idx = np.arange(n)
+    segs = [(0, n, -(-n // leaf_size))]
+    while any(l > 1 for _, _, l in segs):
+        nxt, keys = [], np.zeros(n, dtype=np.uint64)
+        for s, (st, c, l) in enumerate(segs):
+            sl = slice(st, st + c)
+            keys[sl] = np.uint64(s) << np.uint64(32)
+            if l <= 1:
+                nxt.append((st, c, l))
+                continue
+            if c:
+                P = pts[idx[sl]]
+                lo, hi = P.min(axis=0), P.max(axis=0)
+                w = hi - lo
+                ax = int(np.argmax(w))                      # first of the longest axes, like the device loop
+                if w[ax] > 0:
+                    u = np.clip((P[:, ax] - lo[ax]) / w[ax], 0.0, 1.0)
+                    keys[sl] |= (u * 4294967295.0).astype(np.uint64)
+            ll = l // 2
+            cl = (c * ll + l // 2) // l
+            nxt += [(st, cl, ll), (st + cl, c - cl, l - ll)]
+        idx = idx[np.argsort(keys, kind="stable")]
+        segs = nxt
+    starts = np.array([st for st, _, _ in segs] + [n], dtype=np.int64)
+    for a, b in zip(starts[:-1], starts[1:]):             # inside a leaf: index order
+        idx[a:b] = np.sort(idx[a:b])
+    return (base + idx).astype(np.int32), starts
+
+
+def cut_blocks_ref(counts, target):
+    """Parloop.LocalityOrder.cut restated: empty leaves dropped, leaves above 1.5 x target split into equal parts."""
+    sizes = []
+    for c in [int(c) for c in counts if c > 0]:
+        if c > (3 * target) // 2:
+            parts = -(-c // target)
+            q, r = divmod(c, parts)
+            sizes += [q + 1] * r + [q] * (parts - r)
+        else:
+            sizes.append(c)
+    return np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+
+
+def locality_order_ref(mapv, start, end, pos, target=1400):
+    """numpy restatement of the entity order of un-hinted loops (Parloop._locality_order): the nodes of the position field in
+    k-d leaves (fd_kd_order) sized for ~``target`` entities around each, every entity in the group of the lowest leaf among its
+    nodes, groups in leaf order and entities in their own order inside a group (fd_group_entities).  Returns (order, block
+    boundaries)."""
     rows = np.asarray(mapv[start:end])
-    pdim = pos.shape[1]
-    P = pos[rows]                                         # (n, arity, pdim)
-    lo, hi = P.reshape(-1, pdim).min(axis=0), P.reshape(-1, pdim).max(axis=0)
-    acc = np.zeros((len(rows), pdim))
-    for i in range(rows.shape[1]):                        # same summation order as the device loop
-        acc += P[:, i, :]
-    c = acc / rows.shape[1]
-    w = hi - lo
-    u = np.where(w > 0, (c - lo) / np.where(w > 0, w, 1.0), 0.0)
-    q = (np.clip(u, 0.0, 1.0) * 65535.0).astype(np.uint64)
-    keys = np.zeros(len(rows), dtype=np.uint64)
-    for k in range(pdim):
-        for i in range(16):
-            keys |= ((q[:, k] >> np.uint64(i)) & np.uint64(1)) << np.uint64(i * pdim + k)
-    order = (start + np.argsort(keys, kind="stable")).astype(np.int32)
-    return order, keys
+    n, nnodes = len(rows), len(pos)
+    leaf_nodes = max(int(round(target * nnodes / max(n, 1))), 1)
+    norder, nstarts = kd_order_ref(pos, leaf_nodes)
+    label = np.empty(nnodes, dtype=np.int64)
+    label[norder] = np.repeat(np.arange(len(nstarts) - 1), np.diff(nstarts))
+    ok = (rows >= 0) & (rows < nnodes)
+    key = np.where(ok, label[np.clip(rows, 0, nnodes - 1)], len(nstarts) - 2).min(axis=1)
+    order = (start + np.argsort(key, kind="stable")).astype(np.int32)
+    return order, cut_blocks_ref(np.bincount(key, minlength=len(nstarts) - 1), target)

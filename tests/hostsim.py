@@ -236,8 +236,6 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None):
             cargs.append(ctypes.c_longlong(int(np.diff(rb).max())))
         elif kind == "ocr_flags":
             cargs.append(ctypes.c_longlong(1 if zero_pending else 0))
-        elif kind == "ocr_pinv":
-            cargs.append(ptr(pinv))
         elif kind == "ocr_prowptr":
             cargs.append(ptr(prowptr))
         elif kind == "ocr_nstart":
@@ -246,6 +244,9 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None):
             cargs.append(ptr(ns))
         elif kind == "ocr_gstart":
             cargs.append(ptr(np.ascontiguousarray(csr.rowptr[plist], dtype=np.int32)))
+        elif kind == "ocr_gpos":
+            # place of every accumulator entry (rows in position order) in the CSR value array
+            cargs.append(ptr(np.concatenate([np.arange(csr.rowptr[r], csr.rowptr[r + 1]) for r in plist] + [np.zeros(0, np.int64)]).astype(np.int32)))
         elif kind == "ocr_npos":
             cargs.append(ctypes.c_longlong(nrows))
         elif kind in ("mat_row_lgmap", "mat_col_lgmap"):

@@ -10,6 +10,13 @@ from firedrake_amd import bridge, op2
 from firedrake_amd.codegen import generate_wrapper
 
 
+@pytest.fixture(autouse=True)
+def _fresh_seam():
+    """every test allocates and frees its own device buffers: addresses repeat between tests"""
+    yield
+    bridge.reset()
+
+
 def _cls(name, **defaults):
     def init(self, **kw):
         for k, v in {**defaults, **kw}.items():
@@ -319,8 +326,8 @@ def test_composed_map_through_func(undefined):
             exp[cell_node[facet_cell[e, 0], i]] += f[e]
     got = y_d.download(np.float64, (nn,))
     assert np.abs(got - exp).max() <= 1e-12 * max(1.0, np.abs(exp).max())
-    bridge.unregister_map(a_d.ptr)
-    bridge.unregister_map(b_d.ptr)
+    for buf in (a_d, b_d) + ((idx_d,) if undefined else ()):
+        bridge.forget(buf.ptr)                 # what the carriers' finalisers do: the addresses are about to be reused
     assert not func.loops
 
 
@@ -356,6 +363,8 @@ def test_dg_ds_subset_loop_through_func():
     func(0, len(sub.indices), idx_d.ptr, L_d.ptr, x_d.ptr, q_d.ptr, u_d.ptr, dt_d.ptr, qin_d.ptr, lf_d.ptr, dq_d.ptr, q1_d.ptr)
     got = L_d.download(np.float64, (nd,))
     assert np.abs(ref).max() > 0 and np.abs(got - ref.reshape(-1)).max() <= 1e-12 * np.abs(ref).max()
+    for buf in (dq_d, q1_d, idx_d):
+        bridge.forget(buf.ptr)
 
 
 @pytest.mark.gpu
@@ -412,6 +421,8 @@ def test_q4_jacobian_and_action_through_func(bcs):
     y = y_d.download(np.float64, (nn,))
     assert np.abs(y - refy).max() <= 1e-11 * np.abs(refy).max()
     dm.free()
+    for buf in (lay_d, q4_d, q1_d):
+        bridge.forget(buf.ptr)
 
 
 @pytest.mark.gpu

@@ -221,8 +221,9 @@ def test_plan_with_empty_and_single_entity_blocks():
 
 @pytest.mark.parametrize("numbering", ["lexicographic", "random"])
 def test_locality_order_matches_numpy_and_drives_the_staged_wrapper(numbering, monkeypatch):
-    """fd_locality_order against helpers.locality_order_ref (identical Morton keys, a permutation of the range), the
-    first-touch row order derived from it, and the un-hinted residual taking the "stagedo" wrapper end to end."""
+    """fd_entity_centroids + fd_kd_order against the numpy restatement (identical order and leaf boundaries), the first-touch
+    row order derived from it with its ranks, and the un-hinted residual / Jacobian taking the "stagedo" / "ocrp" wrappers
+    end to end."""
     from firedrake_amd import _lib, forms, mesh as fmesh
     from firedrake_amd.device import DeviceBuffer
     from helpers import locality_order_ref
@@ -232,22 +233,38 @@ def test_locality_order_matches_numpy_and_drives_the_staged_wrapper(numbering, m
     cm = V.cell_node_map
     n = m.cell_set.size
     pos = np.array(m.coordinates.data_ro)
-    order_ref, keys = locality_order_ref(cm.values_with_halo, 0, n, pos)
-    buf = DeviceBuffer(n * 4)
-    _lib.call("fd_locality_order", cm._dev_values(), 4, 0, n, m.coordinates._dev_ptr(False), 3, buf.ptr, None)
-    order = buf.download(np.int32, (n,))
+    target = 96
+    from firedrake_amd.parloop import kd_order
+    from helpers import kd_order_ref
+    nnod = V.node_set.total_size
+    nbuf, nstarts = kd_order(m.coordinates._dev_ptr(False), 3, nnod, 0, 17)
+    nord_ref, nstarts_ref = kd_order_ref(pos, 17)
+    assert np.array_equal(nstarts, nstarts_ref) and np.array_equal(nbuf.download(np.int32, (nnod,)), nord_ref)   # same keys, stable sorts
+    assert len(nstarts) - 1 == -(-nnod // 17) and np.diff(nstarts).max() - np.diff(nstarts).min() <= 1                 # equal leaves
+    order_ref, starts_ref = locality_order_ref(cm.values_with_halo, 0, n, pos, target=target)
+    monkeypatch.setitem(configuration, "locality_tile_entities", target)
+    pl = forms.PoissonProblem(m, 1, bcs=False).res_loop
+    pl._prepare()
+    lo = pl._locality_order(0, n)
+    order, starts = lo.buf.download(np.int32, (n,)), lo.blocks
     assert sorted(order.tolist()) == list(range(n))
-    assert np.array_equal(keys[order], keys[order_ref])            # same key sequence (ties may be ordered alike or not)
+    assert np.array_equal(starts, starts_ref) and np.array_equal(order, order_ref)
+    buf = lo.buf
+    # a block touches its leaf of nodes plus one layer: far fewer nodes than a run of the caller's order of the same length
+    touched = lambda o: sum(len(np.unique(cm.values_with_halo[o[a:b]])) for a, b in zip(starts[:-1], starts[1:]))      # noqa: E731
+    if numbering == "random":
+        assert touched(order) < 0.5 * touched(np.arange(n))
     # first-touch rows under that order
     nn = V.node_set.size
-    pinv, plist = DeviceBuffer(nn * 4), DeviceBuffer(nn * 4)
-    _lib.call("fd_first_touch_order", cm._dev_values(), 4, buf.ptr, n, nn, pinv.ptr, plist.ptr, None)
-    pl, pi = plist.download(np.int32, (nn,)), pinv.download(np.int32, (nn,))
+    pinv, plist, rank = DeviceBuffer(nn * 4), DeviceBuffer(nn * 4), DeviceBuffer(nn * 4)
+    _lib.call("fd_first_touch_order", cm._dev_values(), 4, buf.ptr, n, nn, pinv.ptr, plist.ptr, rank.ptr, None)
+    pl, pi, rk = plist.download(np.int32, (nn,)), pinv.download(np.int32, (nn,)), rank.download(np.int32, (nn,))
     assert np.array_equal(pi[pl], np.arange(nn)) and sorted(pl.tolist()) == list(range(nn))
     first = np.full(nn, np.iinfo(np.int64).max)
     flat = cm.values_with_halo[order].reshape(-1)
     first[flat[::-1]] = np.arange(len(flat) - 1, -1, -1) // 4
     assert (np.diff(first[pl]) >= 0).all()                          # rows sorted by the rank of the first cell touching them
+    assert np.array_equal(rk, first[pl])                            # and the rank itself is returned per row position
     prob = forms.PoissonProblem(m, 1, bcs=True)
     r = prob.assemble_residual()
     mode = prob.res_loop._staged_geometry(0, n)["cw"].src.mode
@@ -280,7 +297,7 @@ def test_ordered_ocr_plan_matches_numpy_restatement(monkeypatch):
     sp = op2.Sparsity((V.node_set ** 1, V.node_set ** 1), [(cm, cm, None)])
     sp._build()
     n, nrows = m.cell_set.size, V.node_set.size
-    order, _ = locality_order_ref(cm.values_with_halo, 0, n, np.array(m.coordinates.data_ro))
+    order = locality_order_ref(cm.values_with_halo, 0, n, np.array(m.coordinates.data_ro), target=128)[0]
     obuf = DeviceBuffer.from_numpy(order)
     ro = RowOrder(cm, obuf, n, nrows, sp.rowptr)
     plist, pinv = first_touch_ref(cm.values_with_halo, order, nrows)

@@ -35,7 +35,7 @@ def test_sliced_plan_matches_numpy_restatement(ordered, interleave, monkeypatch)
     rp = np.asarray(sp.rowptr)
     ro, pinv, acc_node, acc_pos = None, None, rp, rp
     if ordered:
-        order, _ = locality_order_ref(m.coord_space.cell_node_map.values_with_halo, 0, n, np.array(m.coordinates.data_ro))
+        order = locality_order_ref(m.coord_space.cell_node_map.values_with_halo, 0, n, np.array(m.coordinates.data_ro), target=64)[0]
         ro = RowOrder(cm, DeviceBuffer.from_numpy(order), n, nrows, rp)
         plist, pinv = first_touch_ref(cm.values_with_halo, order, nrows)
         acc_pos = np.concatenate([[0], np.cumsum(np.diff(rp)[:nrows][plist])]).astype(np.int32)

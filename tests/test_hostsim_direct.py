@@ -523,7 +523,7 @@ def test_staged_wrapper_on_extruded_columns_and_subsets_on_host(region):
 
 @pytest.mark.parametrize("numbering", ["lexicographic", "random"])
 def test_staged_wrapper_over_a_locality_order_on_host(numbering):
-    """"stagedo": the staged wrapper over a backend-derived entity order (Morton order of the cell centroids,
+    """"stagedo": the staged wrapper over a backend-derived entity order (the cells around the k-d leaves of the vertices,
     helpers.locality_order_ref = numpy restatement of fd_locality_order) -- plans on the gathered map rows, slot -> entity
     through fd_order_ for the direct argument.  The benchmark's P1 residual plus a direct READ Dat, against the oracle."""
     from firedrake_amd import forms, mesh as fmesh
@@ -532,8 +532,9 @@ def test_staged_wrapper_over_a_locality_order_on_host(numbering):
     mesh = fmesh.UnitCubeMesh(5, degrees=(1,), perturb=0.1, numbering=numbering)
     V = mesh.space(1)
     cm = V.cell_node_map
-    order, keys = locality_order_ref(cm.values_with_halo, 0, mesh.cell_set.size, np.array(mesh.coordinates.data_ro))
-    assert sorted(order.tolist()) == list(range(mesh.cell_set.size)) and (np.diff(keys[order]) >= 0).all()
+    order, starts = locality_order_ref(cm.values_with_halo, 0, mesh.cell_set.size, np.array(mesh.coordinates.data_ro), target=96)
+    assert sorted(order.tolist()) == list(range(mesh.cell_set.size)) and starts[-1] == mesh.cell_set.size
+    assert np.diff(starts).max() <= (3 * 96) // 2
     prob = forms.PoissonProblem(mesh, 1, bcs=False)
     got = run_staged(prob.res_loop, epb=600, order=order)[0]         # > 256 lanes: lanes iterate (index-row prefetch path)
     ref = oracle_run(prob.kres, mesh.cell_set, prob.r(op2.INC, cm), mesh.coordinates(op2.READ, cm), prob.u(op2.READ, cm),
@@ -559,7 +560,7 @@ def test_owner_computes_rows_over_a_row_order_on_host(bcs, numbering):
     from hostsim import run_ocr
     mesh = fmesh.UnitCubeMesh(4, degrees=(1, 2), perturb=0.1, numbering=numbering)
     pos = np.array(mesh.coordinates.data_ro)
-    order, _ = locality_order_ref(mesh.coord_space.cell_node_map.values_with_halo, 0, mesh.cell_set.size, pos)
+    order = locality_order_ref(mesh.coord_space.cell_node_map.values_with_halo, 0, mesh.cell_set.size, pos, target=96)[0]
     for degree, rpb in ((1, 19), (2, 45)):
         prob = forms.PoissonProblem(mesh, degree, bcs=bcs)
         mat, pl = prob.jacobian()
@@ -589,7 +590,7 @@ def test_row_sliced_owner_computes_rows_on_host(bcs, numbering):
     order = None
     if numbering == "random":
         pos = np.array(mesh.coordinates.data_ro)
-        order, _ = locality_order_ref(mesh.coord_space.cell_node_map.values_with_halo, 0, mesh.cell_set.size, pos)
+        order = locality_order_ref(mesh.coord_space.cell_node_map.values_with_halo, 0, mesh.cell_set.size, pos, target=96)[0]
     for degree, cap in ((2, 700), (2, 96), (1, 150)):
         prob = forms.PoissonProblem(mesh, degree, bcs=bcs)
         mat, pl = prob.jacobian()
@@ -628,7 +629,7 @@ def test_row_sliced_vector_valued_blocks_on_host(numbering, bcs):
     assert select_mode(pl.global_kernel) == "ocrs"
     order = None
     if numbering == "random":
-        order, _ = locality_order_ref(cm.values_with_halo, 0, mesh.cell_set.size, np.array(mesh.coordinates.data_ro))
+        order = locality_order_ref(cm.values_with_halo, 0, mesh.cell_set.size, np.array(mesh.coordinates.data_ro), target=96)[0]
     ref = oracle_run(k, mesh.cell_set, mat(op2.INC, (cm, cm), lgmaps=lg), mesh.coordinates(op2.READ, cm))[0]
     for zero_pending in (True, False):
         got = run_ocrs(pl, nnz_per_block=60, zero_pending=zero_pending, order=order)
@@ -675,7 +676,7 @@ static void prism(double *A, const double *x, const double *w, int layer)
     # a backend-derived row order on the virtual space (Morton order of the (column, layer) cells -> first touch): what the
     # Parloop uses for un-hinted extruded maps, whose own row ranges are vertical pencils
     vrows = np.asarray(pl._plan_map(m, staged=True).values_with_halo)
-    order, _ = locality_order_ref(vrows, 0, len(vrows), np.array(x.data_ro))
+    order = locality_order_ref(vrows, 0, len(vrows), np.array(x.data_ro), target=96)[0]
     for got in (run_ocrs(pl, nnz_per_block=150), run_ocr(pl, rows_per_block=9), run_ocrs(pl, nnz_per_block=150, order=order),
                 run_ocr(pl, rows_per_block=9, order=order)):
         assert np.array_equal(got.rowptr, ref.rowptr) and np.array_equal(got.colidx, ref.colidx)
@@ -710,7 +711,7 @@ def test_row_sliced_per_dof_lgmaps_on_host(numbering):
     assert select_mode(pl.global_kernel) == "ocrs"
     order = None
     if numbering == "random":
-        order, _ = locality_order_ref(cm.values_with_halo, 0, mesh.cell_set.size, np.array(mesh.coordinates.data_ro))
+        order = locality_order_ref(cm.values_with_halo, 0, mesh.cell_set.size, np.array(mesh.coordinates.data_ro), target=96)[0]
     ref = oracle_run(k, mesh.cell_set, *args())[0]
     got = run_ocrs(pl, nnz_per_block=60, order=order)
     assert np.abs(got.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()

@@ -1,0 +1,7 @@
+for nb in tiled lexicographic; do for pk in 1 0; do
+echo "== numbering=$nb FDHIP_OCR_PACK=$pk"
+FDHIP_OCR_PACK=$pk python bench.py --steps 20 --warmup 3 --only jacobian --numbering $nb --variants "" --no-secondary --cpu-sample 0 --traffic off 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); r=d['roofline_jacobian']
+print('  kernel_ms %.4f  assemble_ms %.4f  frac %.4f  first_call_s %.3f' % (r['ms'], r['assemble_ms'], r['frac'], d['setup_s']['plans_jacobian_first_call']))"
+done; done
