@@ -706,7 +706,7 @@ __global__ void ocr_lane_order(const int32_t *__restrict__ off, const int32_t *_
     for (int c = threadIdx.x; c < n; c += blockDim.x) out[o + lane_slot_of_entity(c, n, T)] = in[o + c];
 }
 
-// Stencil order: sort the instances of every block by (signature, first owned row), where the signature hashes which
+// Stencil order: sort the instances of every block by (ownership pattern, signature, first owned row), where the signature hashes which
 // of the entity's rows the block owns and the offsets of all its row nodes from the first owned one.  Instances with
 // equal signatures are the "same kind of entity at another place" (a tet type of the structured cube split, in the
 // same position relative to the tile border): consecutive ones touch consecutive rows, so the 16 lanes of an LDS
@@ -734,7 +734,19 @@ __global__ void ocr_stencil_keys(const int32_t *__restrict__ rmap, int ar, const
             h = (h ^ (d >> 16)) * 16777619u;
         }
         h ^= h >> 16;
-        keys[t] = ((uint64_t)(uint32_t)lo << 32) | ((uint64_t)(h & 0xffffu) << 16) | (uint64_t)((uint32_t)(first - n0) & 0xffffu);
+        // the ownership pattern is the MAJOR key inside a block (arity <= 8, < 2^24 blocks): the wrapper skips the LDS atomics
+        // of a row no lane of the wavefront owns (s_cbranch_execz), and 64 consecutive instances are one wavefront's trip --
+        // with the patterns mixed every trip issued all ar*ac atomics (16.1 of 16 measured on C2), grouped it issues the owned
+        // rows' only (12.1).  The full 16-bit signature stays the next key: it is what keeps a conflict window regular
+        // (with 8 bits of it the bank conflicts rose by 43 %, profiles/r3k_pmc_mask_order.txt)
+        if (ar <= 8 && nblocks < (1 << 24)) {
+            uint32_t mask = 0;
+            for (int i = 0; i < ar; ++i) { const int32_t r = row_position(pinv, npos, row[i]); if (r >= n0 && r < n1) mask |= 1u << i; }
+            keys[t] = ((uint64_t)(uint32_t)lo << 40) | ((uint64_t)(mask ^ ((1u << ar) - 1u)) << 32) | ((uint64_t)(h & 0xffffu) << 16)
+                      | (uint64_t)((uint32_t)(first - n0) & 0xffffu);                 // fully owned entities first
+        } else {
+            keys[t] = ((uint64_t)(uint32_t)lo << 32) | ((uint64_t)(h & 0xffffu) << 16) | (uint64_t)((uint32_t)(first - n0) & 0xffffu);
+        }
     }
 }
 
