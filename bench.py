@@ -2,7 +2,8 @@
 """bench.py -- assembled DoFs/s (residual + Jacobian) of the MI355X finite-element assembly path.
 
 Workload (BASELINE.json configs[1], "C2"): Poisson CG1 on UnitCubeMesh(215^3) tets -- 59 630 250
-cells, 10 077 696 DoFs per GPU; one "step" = one Newton-step assembly = assemble(F) + assemble(J):
+cells, 10 077 696 DoFs per GPU, numbered like a DMPlex mesh (cells in plain order, nodes by first touch, no hints to the
+backend); one "step" = one Newton-step assembly = assemble(F) + assemble(J):
 zero the tensors, run the cell kernels (HIP wrapper kernels through the C ABI), exchange halos
 (N > 1), apply the boundary conditions.  Inputs are resident in HBM before the timed region.
 
@@ -648,10 +649,12 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=128, help="cube size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-bcs", action="store_true")
     ap.add_argument("--tile", type=str, default="8,8,4", help="cubes per traversal tile (= plan block)")
-    ap.add_argument("--numbering", choices=["tiled", "lexicographic", "random"], default="tiled",
-                    help="entity numbering of the headline measurement (SURVEY.md 8d)")
-    ap.add_argument("--variants", type=str, default="lexicographic,random",
-                    help="further numberings measured after the headline one at N=1 (no producer hints); '' = none")
+    ap.add_argument("--numbering", choices=["tiled", "lexicographic", "random"], default="lexicographic",
+                    help="entity numbering of the headline measurement (SURVEY.md 8d).  Default: lexicographic cells, first-touch "
+                         "nodes, NO producer hints -- what a DMPlex-produced mesh looks like to the backend (dmcommon.pyx:2688-2712); "
+                         "'tiled' adds the producer's tile boundaries as hints, 'random' is the worst case")
+    ap.add_argument("--variants", type=str, default="tiled,random",
+                    help="further numberings measured after the headline one at N=1; '' = none")
     ap.add_argument("--partition", choices=["slabs", "blocks"], default="slabs",
                     help="N > 1: z-slabs (2 neighbours) or the most cubic process grid (8 -> 2x2x2), SURVEY.md 8e")
     ap.add_argument("--traffic", choices=["auto", "off"], default="auto",

@@ -6,9 +6,16 @@
 #include <cstdlib>
 #include <dlfcn.h>
 #include <unistd.h>
+#include <fcntl.h>
+#include <spawn.h>
+#include <sstream>
+#include <sys/stat.h>
+#include <sys/wait.h>
 #include <map>
 #include <mutex>
 #include <vector>
+
+extern char **environ;
 
 namespace fd {
 static hipStream_t g_default_stream = nullptr;
@@ -129,6 +136,42 @@ static uint64_t fnv1a(const std::string &s, uint64_t h = 1469598103934665603ull)
     return h;
 }
 
+// contents of the device headers a wrapper includes + the compiler's identity (path, size, mtime): part of the cache key, so a
+// header change or a hipcc upgrade never reuses a stale code object (compilation.compile_hip keys its cache the same way)
+static uint64_t toolchain_hash(const std::string &inc, const char *hipcc) {
+    uint64_t h = fnv1a(hipcc);
+    struct stat st;
+    if (stat(hipcc, &st) == 0) h = fnv1a(std::to_string((long long)st.st_size) + ":" + std::to_string((long long)st.st_mtime), h);
+    for (const char *name : {"fd_wrapper.h", "fd_tensor.h", "fd_callables.h"}) {
+        const std::string path = inc + "/" + name;
+        if (FILE *f = fopen(path.c_str(), "rb")) {
+            char buf[4096];
+            size_t n;
+            while ((n = fread(buf, 1, sizeof buf, f)) > 0) h = fnv1a(std::string(buf, n), h);
+            fclose(f);
+        }
+    }
+    return h;
+}
+
+// run `argv` (no shell: nothing in the flags is ever interpreted) with stdout + stderr in `log`; returns the exit status
+static int run_logged(const std::vector<std::string> &argv, const std::string &log) {
+    std::vector<char *> av;
+    for (const auto &a : argv) av.push_back(const_cast<char *>(a.c_str()));
+    av.push_back(nullptr);
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    posix_spawn_file_actions_addopen(&fa, 1, log.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    posix_spawn_file_actions_adddup2(&fa, 1, 2);
+    pid_t pid = 0;
+    const int rc = posix_spawn(&pid, av[0], &fa, nullptr, av.data(), environ);
+    posix_spawn_file_actions_destroy(&fa);
+    if (rc != 0) return -1;
+    int status = 0;
+    if (waitpid(pid, &status, 0) < 0) return -1;
+    return WIFEXITED(status) ? WEXITSTATUS(status) : -1;
+}
+
 int fd_kernel_create(const char *wrapper_src, const char *symbol, const char *cache_dir, const char *extra_flags, fd_kernel_t *out) {
     if (!wrapper_src || !symbol || !cache_dir || !out) FD_FAIL("fd_kernel_create: bad arguments");
     const char *hipcc = getenv("FDHIP_HIPCC");
@@ -143,11 +186,17 @@ int fd_kernel_create(const char *wrapper_src, const char *symbol, const char *ca
         size_t p = lib.find_last_of('/');
         inc = (p == std::string::npos ? std::string(".") : lib.substr(0, p)) + "/csrc";
     }
-    const std::string flags = std::string("--offload-arch=") + arch + " -O3 -std=c++17 --genco -munsafe-fp-atomics -fno-math-errno "
-        "-fno-signed-zeros -fno-honor-nans -fno-honor-infinities -fassociative-math -fno-trapping-math -ffp-contract=fast " +
-        (extra_flags ? extra_flags : "");
+    std::vector<std::string> argv = {hipcc, std::string("--offload-arch=") + arch, "-O3", "-std=c++17", "--genco", "-munsafe-fp-atomics",
+                                     "-fno-math-errno", "-fno-signed-zeros", "-fno-honor-nans", "-fno-honor-infinities",
+                                     "-fassociative-math", "-fno-trapping-math", "-ffp-contract=fast"};
+    if (extra_flags) {                                   // whitespace-separated extra flags, passed as separate arguments
+        std::istringstream ss(extra_flags);
+        for (std::string tok; ss >> tok;) argv.push_back(tok);
+    }
+    std::string flags;
+    for (size_t i = 1; i < argv.size(); ++i) flags += argv[i] + " ";
     char key[32];
-    snprintf(key, sizeof key, "%016llx", (unsigned long long)fnv1a(flags, fnv1a(wrapper_src)));
+    snprintf(key, sizeof key, "%016llx", (unsigned long long)fnv1a(flags, fnv1a(wrapper_src, toolchain_hash(inc, hipcc))));
     const std::string base = std::string(cache_dir) + "/" + symbol + "_c" + key;
     const std::string obj = base + ".hsaco";
     if (access(obj.c_str(), R_OK) != 0) {
@@ -158,10 +207,12 @@ int fd_kernel_create(const char *wrapper_src, const char *symbol, const char *ca
         fputs(wrapper_src, f);
         fclose(f);
         const std::string log = tmp + ".log";
-        const std::string cmd = std::string(hipcc) + " " + flags + " -I'" + inc + "' -o '" + tmp + ".hsaco' '" + src + "' > '" + log + "' 2>&1";
-        const int rc = system(cmd.c_str());
+        argv.push_back("-I" + inc);
+        argv.push_back("-o"); argv.push_back(tmp + ".hsaco");
+        argv.push_back(src);
+        const int rc = run_logged(argv, log);
         if (rc != 0) {
-            std::string msg = "fd_kernel_create: hipcc failed (" + cmd + ")";
+            std::string msg = "fd_kernel_create: hipcc failed (" + std::string(hipcc) + " " + flags + "... exit " + std::to_string(rc) + ")";
             if (FILE *lf = fopen(log.c_str(), "r")) { char buf[2048]; size_t n = fread(buf, 1, sizeof buf - 1, lf); buf[n] = 0; fclose(lf); msg += std::string("\n") + buf; }
             unlink(src.c_str()); unlink(log.c_str()); unlink((tmp + ".hsaco").c_str());
             FD_FAIL(msg);
