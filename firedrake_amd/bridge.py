@@ -406,7 +406,7 @@ def _borrowed_carriers(fd, arglist, start, end):
     for a, la, ptr in zip(fd.arguments, fd.local_kernel.arguments, arg_ptrs):
         if isinstance(a, K.DatKernelArg):
             m = map_of(a.map_)
-            d = _BorrowedDat(int(ptr), a.dim, la.dtype)
+            d = _BorrowedDat(int(ptr), a.dim, la.dtype, None if m is None else m._base()._toset)
             pargs.append(DatParloopArg(d, m))
         elif isinstance(a, K.GlobalKernelArg):
             pargs.append(GlobalParloopArg(_BorrowedDat(int(ptr), a.dim, la.dtype)))
@@ -439,16 +439,21 @@ def _borrowed_carriers(fd, arglist, start, end):
 
 
 class _BorrowedDat:
-    """A Dat/Global whose storage is somebody else's device memory: the wrapper only ever asks for the pointer."""
-
-    def __init__(self, ptr, dim, dtype):
-        self._ptr, self.dim, self.dtype = ptr, tuple(dim), np.dtype(dtype)
-        self.cdim = int(np.prod(dim))
-        self._halo_frozen, self.halo_valid, self.dat_version = False, True, 0
+    """A Dat/Global whose storage is somebody else's device memory: the wrapper only ever asks for the pointer.  ``toset`` =
+    the Set the accessing Map points into when it is known (registered maps): its size is what the backend-derived locality
+    order partitions."""
 
     class _NoHalo:
         halo = None
-    dataset = type("DS", (), {"set": _NoHalo(), "size": 0, "total_size": 0})()
+        size = total_size = None
+
+    def __init__(self, ptr, dim, dtype, toset=None):
+        self._ptr, self.dim, self.dtype = ptr, tuple(dim), np.dtype(dtype)
+        self.cdim = int(np.prod(dim))
+        self._halo_frozen, self.halo_valid, self.dat_version = False, True, 0
+        s = toset if toset is not None else _BorrowedDat._NoHalo()
+        self.dataset = type("DS", (), {"set": s, "size": getattr(s, "size", 0) or 0, "total_size": getattr(s, "total_size", 0) or 0,
+                                       "cdim": self.cdim, "dim": self.dim})()
 
     def _dev_ptr(self, write):
         return self._ptr

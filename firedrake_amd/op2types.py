@@ -496,9 +496,10 @@ class _Mirrored:
     """numpy host array + device mirror with validity flags."""
 
     def _init_storage(self, host: np.ndarray):
-        self._host = np.ascontiguousarray(host)
-        if not self._host.flags.owndata or not self._host.flags.writeable:
-            self._host = np.array(self._host)                 # the ONE buffer every handed-out view aliases
+        # the ONE buffer every handed-out view aliases -- always privately owned: were it the caller's array, the caller's
+        # reference would look like a live view for ever (``_views_alive``) and one ``dat.data`` access would switch the carrier
+        # to eager mirroring for good
+        self._host = np.array(host, order="C", copy=True)
         self._dev: Optional[DeviceBuffer] = None
         self._host_valid = True
         self._dev_valid = False
@@ -512,7 +513,9 @@ class _Mirrored:
     # reference count of ``_host`` says so.  Once a WRITABLE view has been handed out and views are still alive, the
     # host may be written at any moment without this class hearing of it; the Dat is then kept coherent the expensive
     # way: uploaded again before every device use, downloaded again after every device write (Parloop calls
-    # ``_after_device_write``).  When the last view dies the Dat returns to lazy mirroring.
+    # ``_after_device_write``).  When the last view dies the Dat returns to lazy mirroring.  Read-only views (``data_ro``) are
+    # refreshed the same way only while a writable one is alive; a read-only view kept across a device write shows the
+    # values of the moment it was taken until ``data_ro`` is read again.
     def _views_alive(self) -> bool:
         import sys
         return sys.getrefcount(self._host) > 2               # our attribute + getrefcount's argument

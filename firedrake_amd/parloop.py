@@ -588,8 +588,8 @@ class Parloop:
         if not configuration["locality_order"] or n < configuration["locality_min_entities"] or (self._virtual() is not None and not virtual):
             return None
         pa = self._position_arg()
-        if pa is None:
-            return None
+        if pa is None or not getattr(pa.data.dataset.set, "total_size", None):
+            return None                        # (a borrowed carrier whose node count is unknown: function-level seam, unregistered map)
         target = int(target or configuration["locality_tile_entities"])
         pmap = self._plan_map(pa.map_._base(), staged=True) if virtual else pa.map_._base()
         cache = pmap.__dict__.setdefault("_locality_orders", {})
@@ -875,7 +875,8 @@ class Parloop:
             prp = rp[:nrows + 1]
             cap = configuration["ocr_nnz_per_block"]
             rb = None
-            usable = configuration["locality_order"] and pos_ is not None and (end - start) >= configuration["locality_min_entities"]
+            usable = (configuration["locality_order"] and pos_ is not None and (end - start) >= configuration["locality_min_entities"]
+                      and bool(getattr(pos_.data.dataset.set, "total_size", None)))
             if usable and v is None and pos_.map_._base() is pa.maps[0]._base():
                 # the rows ARE the nodes of the position field: partition them by their own coordinates into k-d leaves of
                 # equal row count -- boxes of rows whose accumulators fill the LDS budget exactly
