@@ -1101,11 +1101,12 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
 
 
 def lds_stride(max_nd: int, ocr: bool = False) -> int:
-    """Node stride of a staged LDS array: the block maximum, rounded up to a multiple of FDHIP_LDS_CONST_STRIDE
-    (FDHIP_OCR_CONST_STRIDE for owner-computes-rows loops) when the stride is compiled in; 0 = run-time stride, 1 = exact,
-    64 makes component offsets multiples of 512 bytes so that pairs of accesses fuse into ds_read2st64_b64 -- at the price
-    of a larger LDS footprint, which costs a resident workgroup per CU on the P1 residual (measured: slower)."""
-    g = int(configuration["ocr_const_stride" if ocr else "lds_const_stride"])
+    """Node stride of a staged LDS array: the block maximum, rounded up to a multiple of FDHIP_LDS_CONST_STRIDE when the
+    stride is compiled in (staged loops; owner-computes-rows loops keep run-time strides: compiled in they were 2 % slower,
+    profiles/r1j_ab_lds_const_stride.txt); 0 = run-time stride, 1 = exact, 64 makes component offsets multiples of 512 bytes so
+    that pairs of accesses fuse into ds_read2st64_b64 -- at the price of a larger LDS footprint, which costs a resident
+    workgroup per CU on the P1 residual (measured: slower)."""
+    g = 0 if ocr else int(configuration["lds_const_stride"])
     if g <= 0:
         return int(max_nd)
     return -(-int(max_nd) // g) * g
@@ -1115,7 +1116,7 @@ def mode_variant(base: str, kbytes: int, max_nds) -> str:
     """Name of the wrapper variant for a launch geometry: base mode [+ _k16] [+ _s<strides>]."""
     m = base + ("_k16" if kbytes == 2 else "")
     ocr = base.startswith("ocr")
-    if int(configuration["ocr_const_stride" if ocr else "lds_const_stride"]) > 0 and max_nds:
+    if not ocr and int(configuration["lds_const_stride"]) > 0 and max_nds:
         m += "_s" + "x".join(str(lds_stride(n, ocr)) for n in max_nds)
     return m
 

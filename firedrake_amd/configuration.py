@@ -28,7 +28,6 @@ configuration = {
     # 0 = run-time stride): the LDS offsets of all staged arrays fold into ds_read/ds_add immediates instead of one
     # v_add_u32 per access
     "lds_const_stride": _env("FDHIP_LDS_CONST_STRIDE", 1, int),     # staged loops: P1 residual 0.43 -> 0.41 ms
-    "ocr_const_stride": _env("FDHIP_OCR_CONST_STRIDE", 0, int),     # owner-computes-rows loops: measured 2 % slower
     "lds_soa": _env("FDHIP_LDS_SOA", 1, int),             # component-major LDS layout for staged vector Dats
     "prefetch": _env("FDHIP_PREFETCH", 1, int),          # software-pipeline the packed index rows
     "tensor_wrappers": _env("FDHIP_TENSOR_WRAPPERS", 1, int),   # MFMA matrix / sum-factorised action for TensorProductLocalKernels
@@ -43,13 +42,10 @@ configuration = {
     "ocr_sliced_max_entries": _env("FDHIP_OCR_SLICED_MAX_ENTRIES", 1024, int),
     "ocrs_nnz_per_block": _env("FDHIP_OCRS_NNZ", 4096, int),     # accumulator entries per row block (x8 bytes of LDS)
     "ocrs_block_threads": _env("FDHIP_OCRS_BLOCK_THREADS", 256, int),
-    # cut the row blocks of a sliced plan where the per-row-index instance groups pad least (parloop.balanced_row_cuts; host-side,
-    # needs the map's host values).  Off: measured on C5 it removes 20-40 % of the padding lanes and is 4 % SLOWER (profiles/r2t, run r3e)
-    "ocrs_balanced_cuts": _env("FDHIP_OCRS_BALANCED_CUTS", 0, int),
     "ocrs_interleave": _env("FDHIP_OCRS_INTERLEAVE", 7, int),    # > 1: stride permutation of the instances of every (block, row index) group
     "ocr_block_threads": _env("FDHIP_OCR_BLOCK_THREADS", 0, int),  # 0 = auto: 512 for small element matrices, else block_threads
-    # order of the instances inside an owner-computes-rows block: "lane" (fd_plan_set_lane_order), "stencil"
-    # (sorted by owned-row signature) or "natural" (entity order)
+    # order of the instances inside an owner-computes-rows block: "stencil" (sorted by ownership pattern and owned-row
+    # signature, then bank-packed) or "natural" (entity order: what the numpy restatements of the tests are written in)
     "ocr_order": _env("FDHIP_OCR_ORDER", "stencil"),
     # a wrapper that comes out of hipcc with scratch memory is recompiled with this LLVM -unroll-threshold (0 = never) and the
     # result kept if the scratch shrinks: element tensors must end up in registers (kernel.GlobalKernel._unrolled_variant)

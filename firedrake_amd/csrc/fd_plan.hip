@@ -701,11 +701,6 @@ __global__ void ocr_interleave(const int32_t *__restrict__ off, const int32_t *_
     for (int j = threadIdx.x; j < n; j += blockDim.x) out[o + j] = in[o + (int)((j * pp) % n)];
 }
 
-__global__ void ocr_lane_order(const int32_t *__restrict__ off, const int32_t *__restrict__ in, int32_t *__restrict__ out, int T) {
-    const int o = off[blockIdx.x], n = off[blockIdx.x + 1] - o;
-    for (int c = threadIdx.x; c < n; c += blockDim.x) out[o + lane_slot_of_entity(c, n, T)] = in[o + c];
-}
-
 // Stencil order: sort the instances of every block by (ownership pattern, signature, first owned row), where the signature hashes which
 // of the entity's rows the block owns and the offsets of all its row nodes from the first owned one.  Instances with
 // equal signatures are the "same kind of entity at another place" (a tet type of the structured cube split, in the
@@ -1112,13 +1107,10 @@ static int ocrplan_build(const int32_t *rmap_dev, int ar, int32_t start, int32_t
         p->inst_ent = sorted_ent;
         FD_HIP(hipFree(other)); FD_HIP(hipFree(ka)); FD_HIP(hipFree(kb)); FD_HIP(hipFree(tmp3));
     }
-    if ((interleave > 1 || interleave < 0) && nu > 0) {
+    if (interleave > 1 && nu > 0) {
         int32_t *perm = nullptr;
         FD_HIP(hipMalloc(&perm, (size_t)nu * 4));
-        if (interleave > 1)
-            hipLaunchKernelGGL(ocr_interleave, dim3(nblocks), dim3(256), 0, s, p->inst_off, p->inst_ent, perm, interleave);
-        else
-            hipLaunchKernelGGL(ocr_lane_order, dim3(nblocks), dim3(256), 0, s, p->inst_off, p->inst_ent, perm, -interleave);
+        hipLaunchKernelGGL(ocr_interleave, dim3(nblocks), dim3(256), 0, s, p->inst_off, p->inst_ent, perm, interleave);
         FD_CHECK_LAUNCH();
         FD_HIP(hipStreamSynchronize(s));
         FD_HIP(hipFree(p->inst_ent));

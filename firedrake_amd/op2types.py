@@ -1969,9 +1969,7 @@ class OcrPlan:
             return 1
         if order == "natural":
             return 0
-        if order == "lane":
-            return -int(lane_threads) if lane_threads > 0 else 0
-        raise ValueError("FDHIP_OCR_ORDER must be stencil, lane or natural")
+        raise ValueError("FDHIP_OCR_ORDER must be stencil or natural")
 
     def __del__(self):
         try:

@@ -237,35 +237,6 @@ def _map_kernel_arg(m):
     return mk[1]
 
 
-def balanced_row_cuts(rows, rowptr, cap, lo=0.7, group=64):
-    """Row-block boundaries for a row-sliced plan that waste fewer padding lanes: the instances of a block are grouped by
-    local row index and every group is padded to a multiple of ``group`` slots, so a cut is best placed where the
-    per-index instance counts sit just below such multiples.  Greedy: each block ends at the row in [lo*cap, cap]
-    accumulator entries that minimises padding per real instance.  ``rows`` = the map rows of the entities iterated,
-    ``rowptr`` = accumulator offsets of the rows [0, n] in block order.  Host-side, O(rows x arity) memory in uint16."""
-    n = len(rowptr) - 1
-    ar = rows.shape[1]
-    if n <= 0:
-        return None
-    cnt = np.zeros((n, ar), dtype=np.int64)
-    for i in range(ar):
-        c = rows[:, i]
-        cnt[:, i] = np.bincount(c[(c >= 0) & (c < n)], minlength=n)[:n]
-    rp = np.asarray(rowptr, dtype=np.int64)
-    rb, a = [0], 0
-    while a < n:
-        bmax = max(min(int(np.searchsorted(rp, np.int64(rp[a] + cap), side="right")) - 1, n), a + 1)
-        if bmax >= n:
-            rb.append(n)
-            break
-        bmin = max(min(int(np.searchsorted(rp, np.int64(rp[a] + int(lo * cap)), side="left")), bmax), a + 1)
-        run = np.cumsum(cnt[a:bmax], axis=0)[bmin - a - 1:]
-        pad = ((-run) % group).sum(axis=1)
-        a = bmin + int(np.argmin(pad / np.maximum(run.sum(axis=1), 1)))
-        rb.append(a)
-    return np.asarray(rb, dtype=np.int64)
-
-
 class LocalityOrder:
     """A backend-derived entity order: the nodes of the loop's position field are partitioned into k-d leaves (fd_kd_order)
     and every entity joins the lowest leaf among its nodes (fd_group_entities).  ``buf`` = device int32 list of the entities,
@@ -983,13 +954,9 @@ class Parloop:
         staged = {mi: maps[mi] for mi in src.staged_maps}
         limit = configuration["lds_limit"]
         for attempt in range(8):
-            rb = None
-            if configuration["ocrs_balanced_cuts"] and row_order is None and isinstance(getattr(rmap._base(), "_values", None), np.ndarray):
-                rb = balanced_row_cuts(np.asarray(rmap.values_with_halo)[start:end], prp[:nrows + 1], cap)
-            if rb is None:
-                targets = np.arange(0, int(prp[nrows]) + cap, cap)
-                rb = np.unique(np.concatenate([np.searchsorted(prp[:nrows + 1], targets, side="left"), [0, nrows]]))
-                rb = rb[rb <= nrows]
+            targets = np.arange(0, int(prp[nrows]) + cap, cap)
+            rb = np.unique(np.concatenate([np.searchsorted(prp[:nrows + 1], targets, side="left"), [0, nrows]]))
+            rb = rb[rb <= nrows]
             try:
                 op = SlicedOcrPlan(sp, rmap, cmap, staged, start, end, rb, row_order=row_order)
             except _lib.FDHipError as exc:

@@ -173,15 +173,17 @@ typedef struct fd_ocrplan_s *fd_ocrplan_t;
 int fd_ocrplan_create(const int32_t *rmap_dev, int rarity, int32_t start, int32_t end,
                       const int32_t *row_block_starts_host, int32_t nblocks, int interleave,
                       fd_stream_t s, fd_ocrplan_t *out);   /* interleave == 1: stencil order (instances of a block sorted by
-                                                             * which rows they own + node offsets, then by first owned
+                                                             * ownership pattern -- a wavefront's 64 consecutive instances
+                                                             * then skip the atomics of rows none of them owns --, by the
+                                                             * signature of owned rows + node offsets, then by first owned
                                                              * row: conflict-free LDS atomics on structured pieces);
                                                              * interleave > 1: multiplicative permutation of every instance list;
-                                                             * interleave < 0: lane order for -interleave lanes (see
-                                                             * fd_plan_set_lane_order) */
+                                                             * 0: entity order */
 /* Bank-aware packing of the instance lists (in place; inst_off is unchanged): given the per-instance row-map rows
  * (global node ids), local-map rows and row-offset table built for the CURRENT instance order, a greedy list scheduler
- * reorders the instances of every block so that the 16 consecutive slots of an LDS conflict window touch distinct
- * LDS banks in the wrapper's gathers and ds_add_f64 scatter wherever the block allows it.  The caller rebuilds the
+ * reorders the instances inside chunks of 128 (one wavefront per chunk, all chunks of all blocks in parallel) so that the 16
+ * consecutive slots of an LDS conflict window touch distinct LDS banks in the wrapper's gathers and ds_add_f64 scatter
+ * wherever the chunk allows it.  The caller rebuilds the
  * per-instance tables for the new order afterwards.  No-op for element matrices with ar + ar*ac > 128. */
 /* Row blocks as ranges of row POSITIONS under a backend-derived row order (fd_first_touch_order): pinv[node] = position
  * for node < npos, prowptr[p] = CSR row start of the p-th row in that order (npos + 1 entries).  The CSR itself keeps

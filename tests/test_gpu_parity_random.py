@@ -66,7 +66,7 @@ def test_plan_lane_order_is_the_documented_permutation(T):
             assert np.array_equal(lm1[e0:e1], lm0[e0:e1][ent])
 
 
-@pytest.mark.parametrize("order", ["stencil", "lane", "natural"])
+@pytest.mark.parametrize("order", ["stencil", "natural"])
 def test_ocr_instance_orders_are_permutations(order, monkeypatch):
     """Every instance order of an owner-computes-rows plan lists, per row block, exactly the entities that touch
     the block's rows (once each); only their order differs."""

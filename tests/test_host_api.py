@@ -112,29 +112,3 @@ def test_composed_map_tables():
         assert m.values.tolist() == [[4, 5], [6, 7]] and m.iterset is setC and m.toset is nodesetA
     with pytest.raises(op2.MapValueError):
         op2.ComposedMap(mapA0, mapA0)          # inner maps must have arity 1 / matching sets
-
-
-def test_balanced_row_cuts_for_sliced_plans():
-    """parloop.balanced_row_cuts: valid block boundaries (increasing, covering all rows, at most ``cap`` accumulator entries
-    per block) that pad fewer lanes than uniform cuts, on a P2 mesh."""
-    from firedrake_amd import mesh as fmesh
-    from firedrake_amd.parloop import balanced_row_cuts
-    import oracle
-    m = fmesh.UnitCubeMesh(6, degrees=(2,), perturb=0.0)
-    V = m.space(2)
-    cm = np.asarray(V.cell_node_map.values_with_halo)
-    n = V.node_set.size
-    rp = oracle.build_sparsity(V.node_set.total_size, V.node_set.total_size, [(cm, cm)]).rowptr[:n + 1].astype(np.int64)
-    cap = 1500
-
-    def padding(rb):
-        cnt = np.stack([np.bincount(cm[:, i], minlength=n)[:n] for i in range(10)], axis=1)
-        P = np.concatenate([np.zeros((1, 10), np.int64), np.cumsum(cnt, axis=0)])
-        c = P[rb[1:]] - P[rb[:-1]]
-        return int(((-c) % 64).sum())
-    rb = balanced_row_cuts(cm, rp, cap)
-    assert rb[0] == 0 and rb[-1] == n and (np.diff(rb) > 0).all() and np.diff(rp[rb]).max() <= cap
-    targets = np.arange(0, rp[n] + cap, cap)
-    uni = np.unique(np.concatenate([np.searchsorted(rp, targets, side="left"), [0, n]]))
-    uni = uni[uni <= n]
-    assert padding(rb) < padding(uni)
