@@ -14,7 +14,7 @@ zero the tensors, run the cell kernels (HIP wrapper kernels through the C ABI), 
 Headline line, every N: weak scaling of C2 -- each rank owns a 215^3 block of cubes (z-slabs: a 215 x 215 x 215N grid).
 At N > 1 the same line carries ``strong_c5``: BASELINE.json configs[4] as written -- Poisson CG2 on the 215^3 cube,
 80 062 991 DoFs, split over the N ranks -- and ``multi_gpu``: ranks of the RCCL communicator, exchange time, per-rank
-kernel times, exchange/kernel overlap.  ``--workload c5`` runs configs[4] alone (N = 1: the whole cube on one GPU).
+kernel times, exchange/kernel overlap.  ``--workload c5`` runs configs[4] alone (N >= 2: the whole cube's ~2.3e9 nonzeros exceed the 32-bit CSR index range).
 --gpus N with fewer than N visible devices FAILS.  Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -709,6 +709,12 @@ def main():
         # BASELINE configs[4] as written: ONE cube, split over the ranks -> strong scaling
         n = args.n or 215
         degree = args.degree or 2
+        est_nnz = (degree * n + 1) ** 3 / world * (29 if degree == 2 else 15)
+        if est_nnz > 2.0e9:
+            # the CSR index type is PETSc's default 32-bit IntType (pyop2/datatypes.py:6-10): the whole 80 M-DoF CG2 cube holds
+            # ~2.3e9 nonzeros -- it is a multi-GPU configuration by construction
+            raise SystemExit(f"bench.py: --workload c5 with n={n}, CG{degree} on {world} GPU(s) needs ~{est_nnz:.2e} nonzeros per rank, beyond "
+                             f"the 32-bit CSR index range; run it with --gpus >= 2 (or a smaller --n)")
         out = poisson_line(args, ctx, degree, (n, n, n), "strong", "BASELINE.json configs[4]" + ("" if n == 215 and degree == 2 else ", reduced"),
                            args.numbering, "", False)
     else:
