@@ -694,10 +694,20 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        # the line this program prints is its whole stdout: rendezvous chatter of the backends ("[Gloo] Rank 0 is connected ...")
+        # goes to stderr
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend)
+            dist.barrier()
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
     from firedrake_amd import _lib
     _lib.require_gpu()
     _lib.call("fd_set_device", local_rank)

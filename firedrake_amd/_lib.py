@@ -154,7 +154,13 @@ def check(status):
         raise FDHipError(f"libfdhip status {status}: {msg.decode() if msg else '?'}")
 
 
+_TRACE = os.environ.get("FDHIP_TRACE_CALLS", "0") == "1"
+
+
 def call(name, *args):
+    if _TRACE:        # debugging aid: name every C-ABI call before it runs (with AMD_SERIALIZE_KERNEL=3 the last line is the culprit)
+        import sys
+        print(f"[fdhip r{os.environ.get('RANK', '0')}] {name}", file=sys.stderr, flush=True)
     check(getattr(load(), name)(*args))
 
 

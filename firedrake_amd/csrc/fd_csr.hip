@@ -7,6 +7,8 @@
 // function-space pair, excluded from the DoFs/s metric.
 #include "fd_common.h"
 #include <hipcub/hipcub.hpp>
+#include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -54,9 +56,9 @@ __global__ void emit_keys(const int32_t *__restrict__ rmap, const int32_t *__res
     }
 }
 
-__global__ void emit_diag(int32_t n, uint64_t *__restrict__ keys) {
+__global__ void emit_diag(int32_t first, int32_t n, uint64_t *__restrict__ keys) {
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
-        keys[t] = ((uint64_t)(uint32_t)t << 32) | (uint32_t)t;
+        keys[t] = ((uint64_t)(uint32_t)(first + t) << 32) | (uint32_t)(first + t);
 }
 
 __global__ void keys_to_csr(const uint64_t *__restrict__ keys, int64_t nnz, int32_t nrows,
@@ -95,7 +97,7 @@ __global__ void expand_colidx(int32_t nnode, const int32_t *__restrict__ nrp, co
 __device__ inline int csr_find(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, int r, int c) {
     int lo = rowptr[r], hi = rowptr[r + 1] - 1;
     while (lo <= hi) {
-        int mid = (lo + hi) >> 1;
+        int mid = lo + ((hi - lo) >> 1);
         int v = colidx[mid];
         if (v == c) return mid;
         if (v < c) lo = mid + 1; else hi = mid - 1;
@@ -141,7 +143,7 @@ __global__ void split_counts(int32_t nrows, const int32_t *__restrict__ rowptr, 
     for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
         int lo = rowptr[r], hi = rowptr[r + 1];
         const int b = lo, e = hi;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (colidx[mid] < ncols_owned) lo = mid + 1; else hi = mid; }
+        while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if (colidx[mid] < ncols_owned) lo = mid + 1; else hi = mid; }
         dcnt[r] = lo - b;
         ocnt[r] = e - lo;
     }
@@ -174,7 +176,7 @@ __global__ void get_diag(int32_t nrows, const int32_t *__restrict__ rowptr, cons
     for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
         int lo = rowptr[r], hi = rowptr[r + 1];          // columns are sorted: binary search for the diagonal
         const int end = hi;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (colidx[mid] < (int32_t)r) lo = mid + 1; else hi = mid; }
+        while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if (colidx[mid] < (int32_t)r) lo = mid + 1; else hi = mid; }
         diag[r] = (lo < end && colidx[lo] == (int32_t)r) ? vals[lo] : 0.0;
     }
 }
@@ -236,19 +238,89 @@ int fd_csr_from_maps_ex(int32_t nrows, int32_t ncols, int set_diag, int npairs,
     }
     int32_t ndiag = set_diag ? (nrows < ncols ? nrows : ncols) : 0;
     ncand += ndiag;
-    uint64_t *keys = nullptr, *keys2 = nullptr;
-    FD_HIP(hipMalloc(&keys, (size_t)(ncand + 1) * 8));
-    FD_HIP(hipMalloc(&keys2, (size_t)(ncand + 1) * 8));
-    int64_t off = 0;
-    if (ndiag) { hipLaunchKernelGGL(emit_diag, dim3(grid_for(ndiag)), dim3(256), 0, s, ndiag, keys); FD_CHECK_LAUNCH(); off = ndiag; }
+    // Candidate (row, column) keys are emitted, sorted and made unique in CHUNKS of at most 2^30 keys, the unique keys of
+    // every chunk appended to an accumulator that is itself compacted (sort + unique) whenever it passes 2^30 keys: no
+    // primitive ever sees more items than a 32-bit count holds (the 215^3 CG2 half-cube of BASELINE configs[4] has 3.0e9
+    // candidates for 1.2e9 nonzeros), and the peak footprint is ~4 x 8 GiB instead of 16 bytes per candidate.
+    int64_t CHUNK = 1ll << 30;
+    if (const char *e = getenv("FDHIP_CSR_CHUNK")) { const long long v = atoll(e); if (v > 0 && v < CHUNK) CHUNK = v; }   // (tests: force the chunked path)
+    auto sort_unique = [&](uint64_t *in, uint64_t *alt, int64_t n, void **tmp, size_t *tmp_cap, int64_t *nsel_dev, uint64_t **result,
+                           int64_t *nout) -> int {
+        // sorts `in` (n keys) using `alt` as the second buffer and leaves the unique keys in *result (one of the two)
+        if (n == 0) { *result = in; *nout = 0; return 0; }
+        hipcub::DoubleBuffer<uint64_t> db(in, alt);
+        size_t tb = 0;
+        FD_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, db, (int)n, 0, 64, s));       // (~0 sentinel sorts last: all bits)
+        if (tb > *tmp_cap) { if (*tmp) FD_HIP(hipFree(*tmp)); FD_HIP(hipMalloc(tmp, tb)); *tmp_cap = tb; }
+        FD_HIP(hipcub::DeviceRadixSort::SortKeys(*tmp, tb, db, (int)n, 0, 64, s));
+        uint64_t *sorted = db.Current(), *other = (sorted == in) ? alt : in;
+        size_t tb2 = 0;
+        FD_HIP(hipcub::DeviceSelect::Unique(nullptr, tb2, sorted, other, nsel_dev, (int)n, s));
+        if (tb2 > *tmp_cap) { if (*tmp) FD_HIP(hipFree(*tmp)); FD_HIP(hipMalloc(tmp, tb2)); *tmp_cap = tb2; }
+        FD_HIP(hipcub::DeviceSelect::Unique(*tmp, tb2, sorted, other, nsel_dev, (int)n, s));
+        FD_HIP(hipMemcpyAsync(nout, nsel_dev, 8, hipMemcpyDeviceToHost, s));
+        FD_HIP(hipStreamSynchronize(s));
+        *result = other;
+        return 0;
+    };
+    const int64_t ccap = ncand < CHUNK ? ncand + 1 : CHUNK;
+    uint64_t *ck = nullptr, *ck2 = nullptr;                   // chunk buffers
+    uint64_t *acc = nullptr, *acc2 = nullptr;                 // accumulator (+ its sort partner); grown on demand
+    int64_t acc_n = 0, acc_cap = 0;
+    void *tmp = nullptr;
+    size_t tmp_cap = 0;
+    int64_t *nsel = nullptr;
+    FD_HIP(hipMalloc(&ck, (size_t)ccap * 8));
+    FD_HIP(hipMalloc(&ck2, (size_t)ccap * 8));
+    FD_HIP(hipMalloc(&nsel, 8));
+    auto compact = [&]() -> int {                             // accumulator := its unique keys
+        uint64_t *res = nullptr;
+        int64_t n = 0;
+        if (int rc = sort_unique(acc, acc2, acc_n, &tmp, &tmp_cap, nsel, &res, &n)) return rc;
+        if (res != acc) std::swap(acc, acc2);
+        acc_n = n;
+        return 0;
+    };
+    auto append = [&](const uint64_t *src, int64_t n) -> int {
+        if (acc_n + n > acc_cap) {
+            if (acc_n > CHUNK) { if (int rc = compact()) return rc; }
+            if (acc_n + n > acc_cap) {
+                int64_t want = acc_cap ? acc_cap * 2 : (n + 1);
+                while (want < acc_n + n) want *= 2;
+                if (want > 2147483647ll) want = 2147483647ll;
+                if (acc_n + n > want) { fd::set_error("fd_csr_from_maps: more than 2^31-1 distinct candidate entries (nnz exceeds IntType)"); return -1; }
+                uint64_t *na = nullptr, *na2 = nullptr;
+                FD_HIP(hipMalloc(&na, (size_t)want * 8));
+                FD_HIP(hipMalloc(&na2, (size_t)want * 8));
+                if (acc_n) FD_HIP(hipMemcpyAsync(na, acc, (size_t)acc_n * 8, hipMemcpyDeviceToDevice, s));
+                FD_HIP(hipStreamSynchronize(s));
+                if (acc) FD_HIP(hipFree(acc));
+                if (acc2) FD_HIP(hipFree(acc2));
+                acc = na; acc2 = na2; acc_cap = want;
+            }
+        }
+        if (n) FD_HIP(hipMemcpyAsync(acc + acc_n, src, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+        acc_n += n;
+        return 0;
+    };
+    if (ndiag) {
+        for (int64_t d0 = 0; d0 < ndiag; d0 += ccap) {        // (the diagonal keys are distinct: appended as they are)
+            const int64_t n = std::min<int64_t>(ccap, ndiag - d0);
+            hipLaunchKernelGGL(emit_diag, dim3(grid_for(n)), dim3(256), 0, s, (int32_t)d0, (int32_t)n, ck);
+            FD_CHECK_LAUNCH();
+            if (int rc = append(ck, n)) return rc;
+            FD_HIP(hipStreamSynchronize(s));
+        }
+    }
     for (int k = 0; k < npairs; ++k) {
         int nl = (nlayers && nlayers[k] > 0) ? nlayers[k] : 0, l0, nli, nf;
         pair_layers(nl, region ? region[k] : FD_ALL, periodic ? periodic[k] : 0, &l0, &nli, &nf);
         const int32_t *lay = (layers_dev && layers_dev[k]) ? layers_dev[k] : nullptr;
         if (lay) { l0 = 0; nli = nl; }
         if (nli < 0) nli = 0;
-        int64_t cnt = (int64_t)nent[k] * nli * nf * rarity[k] * nf * carity[k];
-        if (cnt == 0) continue;
+        const int64_t per_ent = (int64_t)nli * nf * rarity[k] * nf * carity[k];
+        if (per_ent == 0 || nent[k] == 0) continue;
+        if (per_ent > ccap) FD_FAIL("fd_csr_from_maps_ex: one entity column emits more than 2^30 candidate entries");
         int32_t *roff = nullptr, *coff = nullptr, *rq = nullptr, *cq = nullptr;
         if (nl) {
             if (!roffs_h || !coffs_h || !roffs_h[k] || !coffs_h[k]) FD_FAIL("fd_csr_from_maps_ex: extruded pairs need the map offsets");
@@ -264,39 +336,28 @@ int fd_csr_from_maps_ex(int32_t nrows, int32_t ncols, int set_diag, int npairs,
                 FD_HIP(hipMemcpyAsync(cq, cquots_h[k], carity[k] * 4, hipMemcpyHostToDevice, s));
             }
         }
-        hipLaunchKernelGGL(emit_keys, dim3(grid_for(cnt)), dim3(256), 0, s, rmaps[k], cmaps[k], nent[k], rarity[k],
-                           carity[k], nl, l0, nli, nf, roff, coff, rq, cq, lay, region ? region[k] : FD_ALL, nrows, ncols,
-                           keys + off);
-        FD_CHECK_LAUNCH();
+        const int64_t epc = std::max<int64_t>(1, ccap / per_ent);              // entities per chunk
+        for (int64_t e0 = 0; e0 < nent[k]; e0 += epc) {
+            const int64_t ne = std::min<int64_t>(epc, (int64_t)nent[k] - e0), cnt = ne * per_ent;
+            hipLaunchKernelGGL(emit_keys, dim3(grid_for(cnt)), dim3(256), 0, s, rmaps[k] + e0 * rarity[k], cmaps[k] + e0 * carity[k],
+                               (int32_t)ne, rarity[k], carity[k], nl, l0, nli, nf, roff, coff, rq, cq, lay ? lay + 2 * e0 : nullptr,
+                               region ? region[k] : FD_ALL, nrows, ncols, ck);
+            FD_CHECK_LAUNCH();
+            uint64_t *res = nullptr;
+            int64_t nu_c = 0;
+            if (int rc = sort_unique(ck, ck2, cnt, &tmp, &tmp_cap, nsel, &res, &nu_c)) return rc;
+            if (int rc = append(res, nu_c)) return rc;
+            FD_HIP(hipStreamSynchronize(s));                   // (the chunk buffers are reused)
+        }
         if (nl) {
             FD_HIP(hipStreamSynchronize(s)); FD_HIP(hipFree(roff)); FD_HIP(hipFree(coff));
             if (rq) FD_HIP(hipFree(rq));
             if (cq) FD_HIP(hipFree(cq));
         }
-        off += cnt;
     }
-    // sort (only the bits that carry information: 32 + ceil(log2(nrows)))
-    int rbits = 1; while ((1ll << rbits) < nrows) ++rbits;
-    int end_bit = 64;   // the ~0 sentinel must sort last: keep all bits
-    (void)rbits;
-    size_t tmp_bytes = 0;
-    hipcub::DoubleBuffer<uint64_t> db(keys, keys2);
-    FD_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, db, (int64_t)ncand, 0, end_bit, s));
-    void *tmp = nullptr;
-    FD_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
-    FD_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, db, (int64_t)ncand, 0, end_bit, s));
-    uint64_t *sorted = db.Current();
-    uint64_t *other = (sorted == keys) ? keys2 : keys;
-    // unique
-    int64_t *nsel = nullptr;
-    FD_HIP(hipMalloc(&nsel, 8));
-    size_t tmp2_bytes = 0;
-    FD_HIP(hipcub::DeviceSelect::Unique(nullptr, tmp2_bytes, sorted, other, nsel, (int64_t)ncand, s));
-    if (tmp2_bytes > tmp_bytes) { FD_HIP(hipFree(tmp)); FD_HIP(hipMalloc(&tmp, tmp2_bytes)); tmp_bytes = tmp2_bytes; }
-    FD_HIP(hipcub::DeviceSelect::Unique(tmp, tmp2_bytes, sorted, other, nsel, (int64_t)ncand, s));
-    int64_t nu = 0;
-    FD_HIP(hipMemcpyAsync(&nu, nsel, 8, hipMemcpyDeviceToHost, s));
-    FD_HIP(hipStreamSynchronize(s));
+    if (acc_n > 0) { if (int rc = compact()) return rc; }
+    int64_t nu = acc_n;
+    uint64_t *other = acc;
     // drop the sentinel (if any candidate was masked it is the last unique key)
     if (nu > 0) {
         uint64_t last;
@@ -310,7 +371,10 @@ int fd_csr_from_maps_ex(int32_t nrows, int32_t ncols, int set_diag, int npairs,
     hipLaunchKernelGGL(keys_to_csr, dim3(grid_for(nu + 1)), dim3(256), 0, s, other, nu, nrows, rowptr, colidx);
     FD_CHECK_LAUNCH();
     FD_HIP(hipStreamSynchronize(s));
-    FD_HIP(hipFree(keys)); FD_HIP(hipFree(keys2)); FD_HIP(hipFree(tmp)); FD_HIP(hipFree(nsel));
+    FD_HIP(hipFree(ck)); FD_HIP(hipFree(ck2)); FD_HIP(hipFree(nsel));
+    if (acc) FD_HIP(hipFree(acc));
+    if (acc2) FD_HIP(hipFree(acc2));
+    if (tmp) FD_HIP(hipFree(tmp));
     *rowptr_out = rowptr; *colidx_out = colidx; *nnz_out = nu;
     return 0;
 }

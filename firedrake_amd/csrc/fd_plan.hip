@@ -132,7 +132,7 @@ __global__ __launch_bounds__(PT) void plan_pass(const int32_t *__restrict__ map,
         int v = src[i];
         int lo = 0, hi = total - 1, r = 0;
         while (lo <= hi) {
-            int mid = (lo + hi) >> 1;
+            int mid = lo + ((hi - lo) >> 1);
             int m = s[mid];
             if (m == v) { r = mid; break; }
             if (m < v) lo = mid + 1; else hi = mid - 1;
@@ -385,7 +385,7 @@ __global__ void mp_block_offsets(const uint64_t *__restrict__ keys, int64_t n, i
 
 __device__ inline int64_t lower_bound_u64(const uint64_t *__restrict__ a, int64_t lo, int64_t hi, uint64_t key) {
     while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
+        int64_t mid = lo + ((hi - lo) >> 1);
         if (a[mid] < key) lo = mid + 1; else hi = mid;
     }
     return lo;
@@ -411,7 +411,7 @@ __global__ void mp_rows_and_gpos(const uint64_t *__restrict__ keys, const int32_
         int r = list_r[r0 + lr], c = list_c[c0 + lc];
         int lo = rowptr[r], hi = rowptr[r + 1] - 1, pos = -1;
         while (lo <= hi) {
-            int mid = (lo + hi) >> 1;
+            int mid = lo + ((hi - lo) >> 1);
             int v = colidx[mid];
             if (v == c) { pos = mid; break; }
             if (v < c) lo = mid + 1; else hi = mid - 1;
@@ -652,7 +652,7 @@ __device__ inline int32_t block_of_node(const int32_t *__restrict__ rblk, int32_
     if (node < rblk[0] || node >= rblk[nblocks]) return -1;
     int lo = 0, hi = nblocks - 1;
     while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
+        int mid = lo + ((hi - lo + 1) >> 1);
         if (rblk[mid] <= node) lo = mid; else hi = mid - 1;
     }
     return lo;
@@ -712,7 +712,7 @@ __global__ void ocr_stencil_keys(const int32_t *__restrict__ rmap, int ar, const
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < ninst; t += (int64_t)gridDim.x * blockDim.x) {
         int lo = 0, hi = nblocks - 1;                      // block of instance t: largest b with inst_off[b] <= t
         while (lo < hi) {
-            int mid = (lo + hi + 1) >> 1;
+            int mid = lo + ((hi - lo + 1) >> 1);
             if (inst_off[mid] <= t) lo = mid; else hi = mid - 1;
         }
         const int32_t n0 = rblk[lo], n1 = rblk[lo + 1];
@@ -863,7 +863,7 @@ __global__ void row_offsets_k(const int32_t *__restrict__ rowptr, const int32_t 
         if (r >= 0 && c >= 0) {
             int lo = rowptr[r], hi = rowptr[r + 1] - 1, pos = -1;
             while (lo <= hi) {
-                int mid = (lo + hi) >> 1;
+                int mid = lo + ((hi - lo) >> 1);
                 int cv = colidx[mid];
                 if (cv == c) { pos = mid; break; }
                 if (cv < c) lo = mid + 1; else hi = mid - 1;
@@ -989,7 +989,7 @@ __global__ void ocrs_tables_k(const int32_t *__restrict__ inst_off, int32_t nblo
             uint16_t sl = 0xffffu;
             if (live) {
                 int lo = 0, hi = nblocks - 1;                  // block of instance t: largest b with inst_off[b] <= t
-                while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (inst_off[mid] <= t) lo = mid; else hi = mid - 1; }
+                while (lo < hi) { int mid = lo + ((hi - lo + 1) >> 1); if (inst_off[mid] <= t) lo = mid; else hi = mid - 1; }
                 const int32_t d = acc_by_node[r] - acc_by_pos[rblk[lo]];
                 if (d < 0 || d >= 0xffff) atomicExch(err, 2); else sl = (uint16_t)d;
             }
@@ -1005,7 +1005,7 @@ __global__ void ocrs_tables_k(const int32_t *__restrict__ inst_off, int32_t nblo
         if (live && c >= 0 && (rmask || !(clg && clg[c] < 0))) {
             int lo = rowptr[r], hi = rowptr[r + 1] - 1, pos = -1;
             while (lo <= hi) {
-                int mid = (lo + hi) >> 1;
+                int mid = lo + ((hi - lo) >> 1);
                 int cv = colidx[mid];
                 if (cv == c) { pos = mid; break; }
                 if (cv < c) lo = mid + 1; else hi = mid - 1;

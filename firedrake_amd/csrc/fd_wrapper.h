@@ -74,7 +74,7 @@ __device__ __forceinline__ int wrap_layer(int a, int nl) { return a % nl; }
 __device__ __forceinline__ int csr_find(const int *__restrict__ rowptr, const int *__restrict__ colidx, int r, int c) {
     int lo = rowptr[r], hi = rowptr[r + 1] - 1;
     while (lo <= hi) {
-        int mid = (lo + hi) >> 1;
+        int mid = lo + ((hi - lo) >> 1);
         int v = colidx[mid];
         if (v == c) return mid;
         if (v < c) lo = mid + 1; else hi = mid - 1;

@@ -213,7 +213,7 @@ static inline void add_scalar(oracle_mat *A, int row, int col, double v, int ins
 {
     int lo = A->rowptr[row], hi = A->rowptr[row + 1] - 1;
     while (lo <= hi) {
-        int mid = (lo + hi) >> 1;
+        int mid = lo + ((hi - lo) >> 1);
         int c = A->colidx[mid];
         if (c == col) {
             if (insert) A->vals[mid] = v;

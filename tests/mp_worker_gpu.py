@@ -14,9 +14,11 @@ def point_key(pts):
     return [tuple(int(v) for v in np.round(p * 1e6)) for p in pts]
 
 
-def main(rank, world, port, n, degree, backend="gloo", partition=None):
+def main(rank, world, port, n, degree, backend="gloo", partition=None, numbering="tiled"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if numbering != "tiled":
+        os.environ["FDHIP_LOCALITY_MIN"] = "64"       # no producer hints: the backend-derived blocks, also on these small meshes
     import torch
     import torch.distributed as dist
     if backend == "nccl":
@@ -30,8 +32,8 @@ def main(rank, world, port, n, degree, backend="gloo", partition=None):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     from firedrake_amd import forms, mesh as fmesh, op2
     serial = forms.PoissonProblem(fmesh.UnitCubeMesh(n, degrees=(degree,), tile=(2, 2, 2), perturb=0.1), degree, bcs=True)
-    part = forms.PoissonProblem(fmesh.UnitCubeMesh(n, degrees=(degree,), tile=(2, 2, 2), perturb=0.1, rank=rank, nranks=world, partition=partition),
-                                degree, bcs=True)
+    part = forms.PoissonProblem(fmesh.UnitCubeMesh(n, degrees=(degree,), tile=(2, 2, 2), perturb=0.1, rank=rank, nranks=world, partition=partition,
+                                                   numbering=numbering), degree, bcs=True)
     rs = np.array(serial.assemble_residual().data_ro)
     As = serial.assemble_jacobian().toscipy().tocsr()
     for rep in range(2):
@@ -66,4 +68,4 @@ def main(rank, world, port, n, degree, backend="gloo", partition=None):
 
 
 if __name__ == "__main__":
-    main(*[int(a) for a in sys.argv[1:6]], *sys.argv[6:8])
+    main(*[int(a) for a in sys.argv[1:6]], *sys.argv[6:9])

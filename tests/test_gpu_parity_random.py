@@ -310,3 +310,27 @@ def test_ordered_ocr_plan_matches_numpy_restatement(monkeypatch):
     _lib.call("fd_memcpy_d2h", ent.ctypes.data, op.inst_ent, ent.nbytes, None)
     assert np.array_equal(ent, inst_ent)
     assert np.array_equal(op.kidx.download(np.uint8, kidx.shape), kidx)
+
+
+@pytest.mark.parametrize("chunk", [0, 997, 70000])
+def test_sparsity_built_in_chunks_equals_the_oracle_pattern(chunk, monkeypatch):
+    """fd_csr_from_maps emits / sorts / uniques the candidate entries in chunks of at most 2^30 keys and merges the unique keys
+    in an accumulator (the 215^3 CG2 half-cube of BASELINE configs[4] has 3.0e9 candidates: more than a 32-bit item count).
+    FDHIP_CSR_CHUNK shrinks the chunk so that a small mesh takes the many-chunk path, including the accumulator's own
+    compaction; extruded pair, variable layers and a rectangular pair included."""
+    from firedrake_amd import mesh as fmesh
+    from helpers import oracle_pattern
+    if chunk:
+        monkeypatch.setenv("FDHIP_CSR_CHUNK", str(chunk))
+    m = fmesh.UnitCubeMesh(5, degrees=(1, 2), perturb=0.1, numbering="random")
+    V1, V2 = m.space(1), m.space(2)
+    for rows, cols in ((V2, V2), (V1, V2)):
+        sp = op2.Sparsity((rows.node_set ** 1, cols.node_set ** 1), [(rows.cell_node_map, cols.cell_node_map, None)])
+        ref = oracle_pattern(sp)
+        assert np.array_equal(sp.rowptr, ref.rowptr) and np.array_equal(sp.colidx, ref.colidx)
+    if chunk == 997:
+        return                   # (a chunk holds whole entity columns: one Q4 column emits 4 x 125 x 125 candidates)
+    hm = fmesh.make_extruded_hex_mesh(3, 4, 4, perturb=0.1)
+    sp = op2.Sparsity((hm.node_set ** 1, hm.node_set ** 1), [(hm.cell_node_map, hm.cell_node_map, None)])
+    ref = oracle_pattern(sp)
+    assert np.array_equal(sp.rowptr, ref.rowptr) and np.array_equal(sp.colidx, ref.colidx)

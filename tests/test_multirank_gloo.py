@@ -42,13 +42,15 @@ def test_partitioned_assembly_protocol(world, n, partition):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,n,degree,partition", [(2, 6, 1, "slabs"), (3, 6, 2, "slabs"), (3, 3, 1, "slabs"), (4, 4, 2, "blocks"),
-                                                      (8, 4, 1, "blocks")])
-def test_partitioned_assembly_on_one_gpu(world, n, degree, partition):
+@pytest.mark.parametrize("world,n,degree,partition,numbering", [(2, 6, 1, "slabs", "tiled"), (3, 6, 2, "slabs", "tiled"), (3, 3, 1, "slabs", "tiled"),
+                                                                (4, 4, 2, "blocks", "tiled"), (8, 4, 1, "blocks", "tiled"),
+                                                                (2, 8, 1, "slabs", "lexicographic"), (4, 6, 1, "blocks", "random"),
+                                                                (2, 6, 2, "slabs", "lexicographic")])
+def test_partitioned_assembly_on_one_gpu(world, n, degree, partition, numbering):
     """Production device path (HIP wrappers, device pack/unpack, owner-computes-rows) with W ranks sharing
     cuda:0; only the wire (gloo instead of RCCL) differs from the multi-GPU run."""
     port = _free_port()
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_worker_gpu.py"), str(r), str(world), str(port), str(n), str(degree), "gloo", partition],
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_worker_gpu.py"), str(r), str(world), str(port), str(n), str(degree), "gloo", partition, numbering],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     for p in procs:
