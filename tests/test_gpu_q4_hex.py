@@ -157,6 +157,67 @@ def test_q4_full_size_sampled_rows_against_oracle():
 
 
 @pytest.mark.gpu
+def test_q4_full_size_shared_rows_against_oracle():
+    """BASELINE.json configs[2] at n = 32: rows of SHARED DoFs -- cell vertices (8 cells), edge and face DoFs (4 / 2 cells),
+    where the atomic scatter of several workgroups collides -- against the sum of the oracle's dense element tensors of every
+    cell touching the DoF, with BCs in place (the cell-interior rows are the test above)."""
+    from test_forms_identities import _element_tensor
+    from firedrake_amd import _lib
+    n = 32
+    m = fmesh.make_extruded_hex_mesh(n, n, 4, perturb=0.1)
+    prob = forms.HelmholtzQ4Problem(m, bcs=True)
+    mat = prob.assemble_jacobian()
+    sp = mat.sparsity
+    rp = sp.rowptr
+    cm, xm = np.asarray(m.cell_node_map.values_with_halo), np.asarray(m.coord_map.values_with_halo)
+    coords = np.array(m.coordinates.data_ro_with_halos)
+    bc = np.zeros(m.node_set.total_size, dtype=bool)
+    bc[prob.bc_nodes] = True
+    # base node (bottom of its vertical line: node - 4*layer lies on a column's bottom cell) -> [(column, local index)]
+    touching = {}
+    for col in range(cm.shape[0]):
+        for i, g in enumerate(cm[col]):
+            touching.setdefault(int(g), []).append((col, i))
+    rng = np.random.default_rng(11)
+    local = {"vertex": [(a * 5 + b) * 5 + c for a in (0, 4) for b in (0, 4) for c in (0, 4)],
+             "edge": [(0 * 5 + 0) * 5 + 2, (4 * 5 + 2) * 5 + 0, (2 * 5 + 4) * 5 + 4],
+             "face": [(0 * 5 + 2) * 5 + 2, (2 * 5 + 2) * 5 + 4, (2 * 5 + 0) * 5 + 1]}
+    tensors = {}
+
+    def tensor(col, lay):
+        if (col, lay) not in tensors:
+            tensors[(col, lay)] = _element_tensor(prob.kjac, 125, coords[xm[col] + lay]).reshape(125, 125)
+        return tensors[(col, lay)]
+
+    worst, seen = 0.0, {1: 0, 2: 0, 4: 0, 8: 0}
+    for kind, idxs in local.items():
+        for _ in range(10):
+            col, lay, i = int(rng.integers(0, cm.shape[0])), int(rng.integers(0, n)), int(rng.choice(idxs))
+            r = int(cm[col, i] + 4 * lay)
+            if bc[r]:
+                continue
+            # every (column', layer', i') with cm[column', i'] + 4*layer' == r
+            cells = [(c2, l2, i2) for l2 in range(max(lay - 1, 0), min(lay + 2, n)) for (c2, i2) in touching.get(r - 4 * l2, [])]
+            assert (col, lay, i) in cells
+            seen[len(cells)] = seen.get(len(cells), 0) + 1
+            expect = {}
+            scale = 0.0
+            for (c2, l2, i2) in cells:
+                Ae = tensor(c2, l2)
+                scale = max(scale, np.abs(Ae).max())
+                for j, g in enumerate(cm[c2] + 4 * l2):
+                    expect[int(g)] = expect.get(int(g), 0.0) + (0.0 if bc[g] else Ae[i2, j])
+            n0, n1 = int(rp[r]), int(rp[r + 1])
+            cidx, vals = np.empty(n1 - n0, dtype=np.int32), np.empty(n1 - n0)
+            _lib.call("fd_memcpy_d2h", cidx.ctypes.data, sp._colidx.ptr + 4 * n0, cidx.nbytes, None)
+            _lib.call("fd_memcpy_d2h", vals.ctypes.data, mat._values_dev().ptr + 8 * n0, vals.nbytes, None)
+            assert np.array_equal(cidx, np.array(sorted(expect), dtype=np.int32))          # the row's pattern = union of its cells' nodes
+            worst = max(worst, np.abs(vals - np.array([expect[g] for g in sorted(expect)])).max() / scale)
+    assert seen.get(8, 0) > 0 and seen.get(4, 0) > 0 and seen.get(2, 0) > 0, seen
+    assert worst <= 1e-11, worst
+
+
+@pytest.mark.gpu
 def test_q4_mfma_properties_at_scale():
     """n=8: 512 cells, 35937 DoFs -- properties instead of the oracle."""
     m = fmesh.make_extruded_hex_mesh(8, 8, 4, perturb=0.1)
