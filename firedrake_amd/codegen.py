@@ -394,6 +394,11 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             P(f"const int *__restrict__ p{mi}_list", ("plan_list", mi))
             P(f"const unsigned short *__restrict__ p{mi}_lmap", ("plan_lmap", mi))
             P(f"long long p{mi}_maxnd", ("plan_maxnd", mi))
+    def srow_table(info):
+        """whole-entity owner-computes-rows, row map = column map: the per-node row words come from a plan-ordered table
+        (fd_ocr_node_words) instead of per-node gathers of a row start and two lgmap entries"""
+        return bool(ocr and info["rm"] == info["cm"] and configuration["ocr_srow_table"])
+
     use_table = {}
     for info in infos:
         if info["kind"] != "mat":
@@ -409,6 +414,8 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             P(f"long long oc{k}_maxnnz", ("ocr_maxnnz", k))
             P(f"long long oc{k}_maxnown", ("ocr_maxnown", k))
             P(f"long long oc{k}_flags", ("ocr_flags", k))
+            if srow_table(info):
+                P(f"const unsigned int *__restrict__ oc{k}_srowtab", ("ocr_srow", k, info["rm"]))
             if ocrp:
                 P(f"const int *__restrict__ oc{k}_prowptr", ("ocr_prowptr", k))
                 P(f"const int *__restrict__ oc{k}_nstart", ("ocr_nstart", k))
@@ -428,7 +435,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         else:
             P(f"const int *__restrict__ rp{k}", ("mat_rowptr", k))
             P(f"const int *__restrict__ ci{k}", ("mat_colidx", k))
-        if info["arg"].lgmaps:
+        if info["arg"].lgmaps and not (ocr and srow_table(info)):
             P(f"const int *__restrict__ rlg{k}", ("mat_row_lgmap", k))
             P(f"const int *__restrict__ clg{k}", ("mat_col_lgmap", k))
 
@@ -577,7 +584,9 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 colmask = bool(lg)
                 rowmask = f" && rlg{k}[g] >= 0" if lg else ""
                 colbit = (f" | ((clg{k}[g] < 0) ? 0x80000000u : 0u)" if (colmask and cm == rm) else "")
-                if ocrp:
+                if srow_table(info):
+                    loads = [f"const unsigned w{k}_U = oc{k}_srowtab[l0_{rm} + I_U];"]
+                elif ocrp:
                     # the accumulator offset of the node's row (by NODE) decides ownership too: the block's rows are exactly
                     # those whose offsets fall into [r0, r0 + nnzb) -- one lookup, no row-position table in the kernel
                     loads = [f"const int p{k}_U = (G_U < (int)oc{k}_npos) ? oc{k}_nstart[G_U] - r0_{k} : -1;",

@@ -1016,9 +1016,44 @@ __global__ void ocrs_tables_k(const int32_t *__restrict__ inst_off, int32_t nblo
     }
 }
 
+// One word per (block, staged node): what the owner-computes-rows wrapper keeps in LDS for a node of its block -- bits 0..29 =
+// 1 + offset of the node's row inside the block's accumulator (0 = row not owned by this block, or masked by the row lgmap),
+// bit 31 = the node's column is masked by the column lgmap.  Precomputed in PLAN order so that the wrapper's staging phase
+// streams it instead of gathering a row start and two lgmap entries per node by node id.
+__global__ void ocr_node_words_k(const int32_t *__restrict__ blkoff, const int32_t *__restrict__ list, int32_t nblocks,
+                                 const int32_t *__restrict__ rblk, const int32_t *__restrict__ base_by_node,
+                                 const int32_t *__restrict__ start_by_pos, int by_offset, int32_t npos, const int32_t *__restrict__ rlg,
+                                 const int32_t *__restrict__ clg, uint32_t *__restrict__ out) {
+    for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        const int32_t n0 = rblk[b], nown = rblk[b + 1] - n0;
+        const int32_t r0 = start_by_pos[n0], nnzb = start_by_pos[n0 + nown] - r0;
+        for (int32_t i = blkoff[b] + threadIdx.x; i < blkoff[b + 1]; i += blockDim.x) {
+            const int32_t g = list[i];
+            int32_t p = -1;
+            if (by_offset) { if (g >= 0 && g < npos) { p = base_by_node[g] - r0; if (p < 0 || p >= nnzb) p = -1; } }
+            else if (g >= n0 && g < n0 + nown) p = base_by_node[g] - r0;
+            uint32_t w = (p >= 0 && !(rlg && rlg[g] < 0)) ? (uint32_t)(p + 1) : 0u;
+            if (clg && clg[g] < 0) w |= 0x80000000u;
+            out[i] = w;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int fd_ocr_node_words(const int32_t *blkoff_dev, const int32_t *list_dev, int32_t nblocks, const int32_t *rblk_dev,
+                      const int32_t *base_by_node_dev, const int32_t *start_by_pos_dev, int by_offset, int32_t npos,
+                      const int32_t *row_lgmap_dev, const int32_t *col_lgmap_dev, uint32_t *out_dev, fd_stream_t s) {
+    if (!blkoff_dev || !list_dev || !rblk_dev || !base_by_node_dev || !start_by_pos_dev || !out_dev || nblocks < 0)
+        FD_FAIL("fd_ocr_node_words: bad arguments");
+    if (nblocks == 0) return 0;
+    hipLaunchKernelGGL(ocr_node_words_k, dim3(nblocks < 65536 ? nblocks : 65536), dim3(256), 0, fd::st(s), blkoff_dev, list_dev, nblocks,
+                       rblk_dev, base_by_node_dev, start_by_pos_dev, by_offset, npos, row_lgmap_dev, col_lgmap_dev, out_dev);
+    FD_CHECK_LAUNCH();
+    return 0;
+}
 
 static int ocrplan_build(const int32_t *rmap_dev, int ar, int32_t start, int32_t end, const int32_t *row_block_starts_host,
                          int32_t nblocks, int interleave, const int32_t *pinv_dev, int32_t npos, const int32_t *prowptr_dev,

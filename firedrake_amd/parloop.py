@@ -1060,6 +1060,8 @@ class Parloop:
                 out.append(geo["row_order"].nstart.ptr)
             elif kind == "ocr_gstart":
                 out.append(geo["row_order"].gstart.ptr)
+            elif kind == "ocr_srow":
+                out.append(self._ocr_node_words(geo, desc[1], desc[2]))
             elif kind == "ocr_gpos":
                 out.append(geo["row_order"].gpos().ptr)
             elif kind == "ocr_npos":
@@ -1071,6 +1073,32 @@ class Parloop:
                 raise AssertionError(kind)
         cw.launch(0, op.ninst, out, block_threads=src.block_threads, ents_per_block=op.max_inst, nblocks=op.nblocks,
                   lds_bytes=geo["lds"])
+
+    def _ocr_node_words(self, geo, k, rm):
+        """Plan-ordered row words of Mat argument ``k`` (fd_ocr_node_words) for its current pair of lgmaps: built on first use
+        per pair and cached by identity -- the reference swaps lgmaps per call (parloop.py:279-314), a set of boundary
+        conditions is assembled many times."""
+        pa = self.arguments[k]
+        lg = pa.lgmaps or (None, None)
+        ident = lambda o: ("dev", o._fd_dev_ptr, getattr(o, "_fd_token", None)) if hasattr(o, "_fd_dev_ptr") else id(o)   # noqa: E731
+        key = (k, ident(lg[0]), ident(lg[1]))
+        cache = geo.setdefault("srow", {})
+        hit = cache.get(key)
+        if hit is None:
+            op, ro = geo["ocr"], geo["row_order"]
+            plan = op.plans[rm]
+            sp = pa.data.sparsity
+            buf = DeviceBuffer(max(plan.list_len, 1) * 4)
+            base = ro.nstart.ptr if ro is not None else sp._node_rowptr.ptr
+            starts = ro.prowptr.ptr if ro is not None else sp._node_rowptr.ptr
+            _lib.call("fd_ocr_node_words", plan.blkoff, plan.list, op.nblocks, op.rblk, base, starts, 1 if ro is not None else 0,
+                      ro.npos if ro is not None else 0, self._lgmap(lg[0]) if lg[0] is not None else None,
+                      self._lgmap(lg[1]) if lg[1] is not None else None, buf.ptr, None)
+            while len(cache) >= 4:
+                cache.pop(next(iter(cache)))
+            hit = (lg, buf)
+            cache[key] = hit
+        return hit[1].ptr
 
     def _nlayers_iterated(self):
         from .op2types import ON_BOTTOM, ON_TOP, ON_INTERIOR_FACETS

@@ -179,6 +179,15 @@ int fd_ocrplan_create(const int32_t *rmap_dev, int rarity, int32_t start, int32_
                                                              * row: conflict-free LDS atomics on structured pieces);
                                                              * interleave > 1: multiplicative permutation of every instance list;
                                                              * 0: entity order */
+/* The per-(block, staged node) words of the whole-entity owner-computes-rows wrapper in PLAN order (blkoff / list of the row
+ * map's block-localisation plan over the instances): bits 0..29 = 1 + offset of the node's row in the block accumulator (0 =
+ * not owned by the block, or dropped by the row lgmap: MatSetValuesLocal semantics, builder.py:573-625), bit 31 = column dropped
+ * by the column lgmap.  base_by_node = CSR row starts by node (by_offset 0: ownership = node in the block's row range) or the
+ * accumulator starts by node of a row order (by_offset 1: ownership = offset inside the block's range; nodes >= npos are not
+ * rows); start_by_pos[rblk[b]] = start of block b.  One table per pair of lgmaps (the reference swaps them per assemble). */
+int fd_ocr_node_words(const int32_t *blkoff_dev, const int32_t *list_dev, int32_t nblocks, const int32_t *rblk_dev,
+                      const int32_t *base_by_node_dev, const int32_t *start_by_pos_dev, int by_offset, int32_t npos,
+                      const int32_t *row_lgmap_dev, const int32_t *col_lgmap_dev, uint32_t *out_dev, fd_stream_t s);
 /* Bank-aware packing of the instance lists (in place; inst_off is unchanged): given the per-instance row-map rows
  * (global node ids), local-map rows and row-offset table built for the CURRENT instance order, a greedy list scheduler
  * reorders the instances inside chunks of 128 (one wavefront per chunk, all chunks of all blocks in parallel) so that the 16

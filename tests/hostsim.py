@@ -244,6 +244,32 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None):
             cargs.append(ptr(ns))
         elif kind == "ocr_gstart":
             cargs.append(ptr(np.ascontiguousarray(csr.rowptr[plist], dtype=np.int32)))
+        elif kind == "ocr_srow":
+            # numpy restatement of fd_ocr_node_words: per (block, staged node) 1 + offset of the node's row in the block
+            # accumulator (0 = not owned / dropped by the row lgmap), bit 31 = column dropped by the column lgmap
+            blk_, lst_ = plans[desc[2]][0], plans[desc[2]][1]
+            lg = mpa.lgmaps or (None, None)
+            nst = None
+            if order is not None:
+                nst = np.zeros(max(nrows, 1), dtype=np.int64)
+                nst[plist] = prowptr[:-1]
+            words = np.zeros(max(len(lst_), 1), dtype=np.uint32)
+            for b in range(len(rb) - 1):
+                n0, n1 = int(rb[b]), int(rb[b + 1])
+                r0 = int(prowptr[n0]) if order is not None else int(csr.rowptr[n0])
+                nnzb = (int(prowptr[n1]) if order is not None else int(csr.rowptr[n1])) - r0
+                for i in range(int(blk_[b]), int(blk_[b + 1])):
+                    g, p_ = int(lst_[i]), -1
+                    if order is not None:
+                        if 0 <= g < nrows and 0 <= nst[g] - r0 < nnzb:
+                            p_ = int(nst[g]) - r0
+                    elif n0 <= g < n1:
+                        p_ = int(csr.rowptr[g]) - r0
+                    w = p_ + 1 if (p_ >= 0 and not (lg[0] is not None and lg[0][g] < 0)) else 0
+                    if lg[1] is not None and lg[1][g] < 0:
+                        w |= 0x80000000
+                    words[i] = w
+            cargs.append(ptr(words))
         elif kind == "ocr_gpos":
             # place of every accumulator entry (rows in position order) in the CSR value array
             cargs.append(ptr(np.concatenate([np.arange(csr.rowptr[r], csr.rowptr[r + 1]) for r in plist] + [np.zeros(0, np.int64)]).astype(np.int32)))
