@@ -363,8 +363,9 @@ def measure(prob, args, world, dist, backend, torch):
         if ev is not None:
             ev[0].record()
         if do_res:
+            prob.u.dat_version += 1            # a Newton step changes u: nothing cached on its values may be reused ...
             if world > 1:
-                prob.u.halo_valid = False      # a Newton step changes u: its ghost copies are refreshed every step
+                prob.u.halo_valid = False      # ... and its ghost copies are refreshed every step
             prob.assemble_residual(events=None if ev is None else (ev[1], ev[2]))
         if ev is not None:
             ev[3].record()

@@ -519,8 +519,13 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 lds_decl.append(f"{ct} *s{k} = ({ct} *)(fd_lds + fd_off); fd_off += (((size_t)p{mi}_maxnd*{c}*sizeof({ct})) + 15) & ~(size_t)15;")
                 if acc == READ:
                     soa = bool(configuration["lds_soa"]) and c > 1
+                    # a READ Dat that has not changed since an earlier call is also kept in PLAN order (one row per (block, staged
+                    # node), Parloop._plan_copy): the staging phase then streams it instead of gathering rows by node id
+                    P(f"const {ct} *__restrict__ pl{k}", ("plan_copy", k, mi))
                     node_actions.setdefault(mi, []).append(
-                        ([f"{ct} v{k}_U[{c}];", f"for (int j = 0; j < {c}; ++j) v{k}_U[j] = arg{k}[(size_t)G_U*{c} + j];"],
+                        ([f"{ct} v{k}_U[{c}];",
+                          f"if (pl{k}) {{ for (int j = 0; j < {c}; ++j) v{k}_U[j] = pl{k}[(size_t)(l0_{mi} + I_U)*{c} + j]; }} "
+                          f"else {{ for (int j = 0; j < {c}; ++j) v{k}_U[j] = arg{k}[(size_t)G_U*{c} + j]; }}"],
                          [f"for (int j = 0; j < {c}; ++j) s{k}[{'j*(int)p%d_maxnd + I_U' % mi if soa else 'I_U*%d + j' % c}] = v{k}_U[j];"]))
                     idx = f"j*(int)p{mi}_maxnd + lm{mi}[{_permi(perm, 'i')}]" if soa else f"lm{mi}[{_permi(perm, 'i')}]*{c} + j"
                     pack.append(f"for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j) t{k}[i*{c}+j] = s{k}[{idx}];")

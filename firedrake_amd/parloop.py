@@ -629,6 +629,8 @@ class Parloop:
                 out.append(geo["plans"][desc[1]].lmap)
             elif kind == "plan_maxnd":
                 out.append(geo["plans"][desc[1]].max_nd)
+            elif kind == "plan_copy":
+                out.append(self._plan_copy(geo, desc[1], geo["plans"][desc[2]]))
             elif kind == "matplan_off":
                 out.append(geo["mplans"][desc[1]].mb_off)
             elif kind == "matplan_gpos":
@@ -1035,6 +1037,8 @@ class Parloop:
                 out.append(op.plans[desc[1]].lmap)
             elif kind == "plan_maxnd":
                 out.append(op.plans[desc[1]].max_nd)
+            elif kind == "plan_copy":
+                out.append(self._plan_copy(geo, desc[1], op.plans[desc[2]]))
             elif kind == "ocr_rblk":
                 out.append(op.rblk)
             elif kind == "ocr_rowptr":
@@ -1073,6 +1077,33 @@ class Parloop:
                 raise AssertionError(kind)
         cw.launch(0, op.ninst, out, block_threads=src.block_threads, ents_per_block=op.max_inst, nblocks=op.nblocks,
                   lds_bytes=geo["lds"])
+
+    def _plan_copy(self, geo, k, plan):
+        """Device pointer of READ Dat ``k`` in PLAN order (row of list entry i at i*cdim), or 0: a field that did not change since
+        the previous call of this loop (coordinates, a forcing term; ``dat_version`` decides) is copied once -- one coalesced
+        gather over the plan's node list -- and streamed by the staging phase from then on; a field that changes between
+        calls (the state of a Newton iteration) keeps the in-kernel gather, and a copy is dropped the moment its Dat changes."""
+        if not configuration["plan_copies"]:
+            return 0
+        d = self.arguments[k].data
+        d = getattr(d, "_parent", d)
+        ver = getattr(d, "dat_version", None)
+        if ver is None or not hasattr(d, "cdim"):
+            return 0
+        cache = geo.setdefault("plan_copies", {})
+        ent = cache.get(k)
+        if ent is not None and ent["version"] == ver and ent["buf"] is not None:
+            return ent["buf"].ptr
+        if ent is None or ent["version"] != ver:
+            cache[k] = {"version": ver, "buf": None}          # first sight of this state of the Dat: gather in the kernel
+            return 0
+        words = d.cdim * np.dtype(d.dtype).itemsize // 4      # unchanged since the last call: make the copy (rows as 32-bit words)
+        if words * 4 != d.cdim * np.dtype(d.dtype).itemsize or plan.list_len == 0:
+            return 0
+        buf = DeviceBuffer(plan.list_len * words * 4)
+        _lib.call("fd_gather_rows", d._dev_ptr(False), words, plan.list, plan.list_len, buf.ptr, None)
+        ent["buf"] = buf
+        return buf.ptr
 
     def _ocr_node_words(self, geo, k, rm):
         """Plan-ordered row words of Mat argument ``k`` (fd_ocr_node_words) for its current pair of lgmaps: built on first use

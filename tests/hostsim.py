@@ -59,6 +59,22 @@ def _compile_mt(source, name):
     return ctypes.CDLL(so)
 
 
+# plan-ordered copies of READ Dats (Parloop._plan_copy): True -> the host-sim hands the wrapper the rows gathered over the plan's
+# node list (the streaming branch of the staging phase), False -> a null pointer (the gather branch).  Tests flip it.
+PLAN_COPIES = False
+
+
+def _plan_copy_arg(pl, desc, plans, ptr):
+    if not PLAN_COPIES:
+        return ctypes.c_void_p(0)
+    d = pl.arguments[desc[1]].data
+    d = getattr(d, "_parent", d)
+    host = d._host if d._host_valid else d._to_host()
+    rows = np.asarray(host).reshape(host.shape[0], -1)
+    return ptr(np.ascontiguousarray(rows[np.asarray(plans[desc[2]][1], dtype=np.int64)]))
+
+
+
 def run_staged(pl, epb=48, order=None):
     """Execute Parloop ``pl`` (Dat / Global arguments only) with the STAGED wrapper on the host: one OS thread per
     lane, workgroups one after the other, real barriers and atomics (tests/hostsim/mt/fd_wrapper.h).  The
@@ -136,6 +152,8 @@ def run_staged(pl, epb=48, order=None):
             cargs.append(ptr(plans[desc[1]][2]))
         elif kind == "plan_maxnd":
             cargs.append(ctypes.c_longlong(plans[desc[1]][3]))
+        elif kind == "plan_copy":
+            cargs.append(_plan_copy_arg(pl, desc, plans, ptr))
         else:
             raise AssertionError(f"hostsim (staged) cannot provide {kind}")
     lib.sim_run(*cargs)
@@ -277,6 +295,8 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None):
             cargs.append(ctypes.c_longlong(nrows))
         elif kind in ("mat_row_lgmap", "mat_col_lgmap"):
             cargs.append(ptr(np.asarray(mpa.lgmaps[0 if kind == "mat_row_lgmap" else 1], dtype=np.int32)))
+        elif kind == "plan_copy":
+            cargs.append(_plan_copy_arg(pl, desc, plans, ptr))
         else:
             raise AssertionError(f"hostsim (ocr) cannot provide {kind}")
     lib.sim_run(*cargs)

@@ -178,3 +178,38 @@ def test_c2_full_size_properties():
     assert np.abs(r0).max() <= 1e-10 * amax
     v2 = prob.assemble_jacobian().csr()[2]
     assert np.abs(v2 - v).max() <= 1e-12 * amax
+
+
+@pytest.mark.parametrize("numbering", ["tiled", "lexicographic"])
+def test_plan_ordered_copies_follow_their_dats(numbering, monkeypatch):
+    """Parloop._plan_copy: a READ Dat that did not change since the previous call is kept in plan order and streamed by the
+    staging phase; the copy must be dropped the moment the Dat changes -- a new state (Newton update), new forcing, a moved
+    mesh -- and rebuilt when the new state repeats.  Residual and Jacobian against the oracle after every change."""
+    monkeypatch.setitem(configuration, "locality_min_entities", 64)
+    m = fmesh.UnitCubeMesh(7, degrees=(1,), perturb=0.1, numbering=numbering)
+    prob = forms.PoissonProblem(m, 1, bcs=True)
+    rng = np.random.default_rng(3)
+
+    def check(tag):
+        ro, Ao = _oracle_problem(prob, True)
+        r = np.array(prob.assemble_residual().data_ro)
+        A = prob.assemble_jacobian().toscipy()
+        assert np.abs(r - ro).max() <= 1e-12 * max(1.0, np.abs(ro).max()), tag
+        assert np.abs(A.data - Ao.data).max() <= 1e-12 * np.abs(Ao.data).max(), tag
+
+    def copies(loop):
+        geos = list(loop._prepared["parts"].values())
+        return sum(1 for g in geos for e in g.get("plan_copies", {}).values() if e["buf"] is not None)
+
+    for rep in range(3):
+        check(f"static {rep}")                                     # from the second repetition on every READ Dat is streamed
+    assert copies(prob.res_loop) >= 3 and copies(prob.jacobian()[1]) >= 1
+    prob.u.data[...] = rng.standard_normal(prob.u.data.shape)       # Newton update: u's copy is stale
+    check("new u")
+    check("new u, again")
+    prob.f.data[...] = rng.standard_normal(prob.f.data.shape)
+    check("new f")
+    xyz = m.coordinates.data
+    xyz[...] = xyz * 1.25 + 0.1                                     # a moved mesh: geometry copies of BOTH loops are stale
+    check("moved mesh")
+    check("moved mesh, again")

@@ -353,9 +353,17 @@ def test_dat_view_in_parloops():
     assert abs(got[0][0] - t.data_ro[:, 1, 0][cells].sum()) < 1e-12
 
 
+@pytest.fixture(params=[False, True], ids=["gathered", "plan-copies"])
+def plan_copies(request, monkeypatch):
+    """READ Dats staged by the in-kernel gather (null plan copy) or streamed from their plan-ordered copy (Parloop._plan_copy)"""
+    import hostsim
+    monkeypatch.setattr(hostsim, "PLAN_COPIES", request.param)
+    return request.param
+
+
 # ---- the STAGED wrapper (LDS staging, lane order, LDS reduction, flush) with one OS thread per lane ---------------------
 @pytest.mark.parametrize("lane_strided", [1, 0])
-def test_staged_wrapper_residuals_on_host(lane_strided, monkeypatch):
+def test_staged_wrapper_residuals_on_host(lane_strided, monkeypatch, plan_copies):
     """The hot residual path: staged wrappers of the P1 right-hand side (golden kernel) and of the benchmark's Poisson
     residuals (P1 and P2, compile-time LDS strides) against the oracle, on a mesh that spans several plan blocks."""
     from firedrake_amd import forms
@@ -401,7 +409,7 @@ def test_staged_wrapper_p2_tets_and_global_reduction_on_host():
 
 
 @pytest.mark.parametrize("bcs", [False, True])
-def test_owner_computes_rows_wrapper_on_host(bcs):
+def test_owner_computes_rows_wrapper_on_host(bcs, plan_copies):
     """The hot Jacobian path: the owner-computes-rows wrapper (instance lists, per-instance row-offset table, LDS row
     accumulators, complete-row flush, BC masking through the lgmaps) of the benchmark's P1 and P2 Poisson Jacobians
     against the oracle's MatSetValuesLocal."""
