@@ -112,6 +112,9 @@ def tensor_eligible(gk: GlobalKernel):
     return None
 
 
+TP_ACTION_CELLS = 5        # fdt::Q4_ACT_CELLS (csrc/fd_tensor.h): cells per workgroup of the action template
+
+
 def generate_tensor_wrapper(gk: GlobalKernel) -> WrapperSource:
     """The wrapper of a tensor-product loop: the reference's positional list for an extruded loop (start, end, layers, one
     pointer per argument, one per distinct Map, builder.py:962-981), then the backend-private tables, around the device

@@ -12,7 +12,7 @@
 // 1-D tables, cell independent), W_q (4 x 4): the point weight the callback computes from the cell geometry.  For the
 // matrix K = 4 per quadrature point is exactly the K of v_mfma_f64_16x16x4_f64: one MFMA updates a 16 x 16 tile of A_e
 // with one quadrature point -- a genuine dense contraction on the fp64 matrix cores.  The action is sum-factorised
-// (O(k^4) per cell) with all intermediates in LDS and is bound by HBM/LDS, not by arithmetic.
+// (O(k^4) per cell), one lane per line of the index cube, intermediates in LDS between the axis passes.
 //
 // Arguments follow the reference's positional order for an extruded loop (builder.py:962-981): start, end, layers, one
 // pointer per Dat/Mat, one per distinct Map; backend-private tables follow.
@@ -173,107 +173,147 @@ __device__ __forceinline__ void hex_q4_matrix(int start, int end, const int *__r
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Q4 operator action y_e += sum_q Phi_q^T W_q (Phi_q u_e), sum-factorised: one 128-lane workgroup per cell, lane t owns
-// the tensor index (a, b, c) = (t/25, t/5 % 5, t%5); every contraction is one 5-term dot product per lane per array
-// with its operands in LDS.  Forward: u -> (d1 u, d2 u, d3 u, u) at the 125 Gauss points; point weights; backward: the
-// transposed contractions; scatter with one fp64 atomic per DoF (extruded addressing map + 4*layer, builder.py:94-124).
+// Q4 operator action y_e += sum_q Phi_q^T W_q (Phi_q u_e), sum-factorised, ONE LANE PER LINE of the 5 x 5 x 5 index cube:
+// a contraction along one axis reads the 5 entries of a line once and produces the line's 5 outputs in registers
+// (25 FMAs per table), so a cell costs 25 lanes per stage and ~100 LDS accesses per lane in total -- against 135 reads per
+// lane and 125 lanes per cell when every lane owns one output (LDS-bound: the first version of this template ran at the
+// ds_read_b64 rate).  A 128-lane workgroup carries Q4_ACT_CELLS = 5 consecutive cells of the (column, layer) space; lane
+// t -> cell slot t / 25, line t % 25 = (p, r).
+//   stage 1  (lines along i1, u straight from the lane's own global loads): V = L_1 u, D1 = DL_1 u        -> A  (q1, i2, i3)
+//   stage 2  (lines along i2):  VV = L_2 V,  D1V = L_2 D1,  D2 = DL_2 V                                    -> B  (q1, q2, i3)
+//   stage 3+4 (lines along i3, all in registers): values and reference gradient at the line's 5 Gauss points, the
+//            point weights (geometry of a trilinear hexahedron is affine along a line: 6 vectors per line, one
+//            interpolation per point), F = W g, then the transposed contraction q3 -> i3                  -> A  (q1, q2, i3)
+//   stage 5  (q2 -> i2), stage 6 (q1 -> i1) and one fp64 atomic per DoF (extruded addressing map + 4*layer, builder.py:94-124).
 // ------------------------------------------------------------------------------------------------------------------
+constexpr int Q4_ACT_CELLS = 5;
+
 template <class WF>
 __device__ __forceinline__ void hex_q4_action(int start, int end, const int *__restrict__ layers, double *__restrict__ y,
                                               const double *__restrict__ coords, const double *__restrict__ u,
                                               const int *__restrict__ map_q4, const int *__restrict__ map_q1,
                                               const double *__restrict__ tables, WF weights) {
-    __shared__ double sL[25], sDL[25], sQP[5], sQW[5], sX[24];
-    __shared__ double b0[125], b1[125], b2[125], b3[125], b4[125];
+    __shared__ double sA[Q4_ACT_CELLS][3][Q4_ND], sB[Q4_ACT_CELLS][3][Q4_ND], sX[Q4_ACT_CELLS][24];
     const int t = threadIdx.x;
     const int nl = layers[1] - 1 - layers[0];
-    const int col = start + (int)(blockIdx.x / nl), lrel = (int)(blockIdx.x % nl);
-    if (col >= end) return;
-    const bool on = t < Q4_ND;
-    const int a = on ? t / 25 : 0, b = on ? (t / 5) % 5 : 0, c = on ? t % 5 : 0;
-    if (t < 25) { sL[t] = tables[t]; sDL[t] = tables[25 + t]; }
-    if (t < 5) { sQP[t] = tables[50 + t]; sQW[t] = tables[55 + t]; }
-    if (t < 24) {
-        const int v = t / 3, cc = t - 3 * v;
-        sX[t] = coords[(size_t)(map_q1[(size_t)col * 8 + v] + lrel) * 3 + cc];
+    const int ncell = (end - start) * nl;
+    const int first = (int)blockIdx.x * Q4_ACT_CELLS;
+    {
+        const int ks = t / 24, e = t - 24 * ks;         // 120 lanes fetch the 5 x 8 vertices
+        const int cs = first + ks;
+        if (ks < Q4_ACT_CELLS && cs < ncell) {
+            const int v = e / 3, cc = e - 3 * v;
+            sX[ks][e] = coords[(size_t)(map_q1[(size_t)(start + cs / nl) * 8 + v] + cs % nl) * 3 + cc];
+        }
     }
-    int node = 0;
-    if (on) { node = map_q4[(size_t)col * Q4_ND + t] + 4 * lrel; b0[t] = u[node]; }
-    __syncthreads();
-    // stage 1: contract the first index with L / DL:  b1 = L_1 u, b2 = DL_1 u   (output index (q1, i2, i3))
-    if (on) {
-        double s0 = 0.0, s1 = 0.0;
+    const int k = t / 25, l = t - 25 * k, p = l / 5, r = l - 5 * p;
+    const bool on = k < Q4_ACT_CELLS && first + k < ncell;
+    const int ka = on ? k : 0;
+    double (*A)[Q4_ND] = sA[ka], (*B)[Q4_ND] = sB[ka];
+    double L[25], DL[25];                               // wavefront-uniform: scalar registers
 #pragma unroll
-        for (int i = 0; i < 5; ++i) { const double v = b0[(i * 5 + b) * 5 + c]; s0 += sL[a * 5 + i] * v; s1 += sDL[a * 5 + i] * v; }
-        b1[t] = s0; b2[t] = s1;
+    for (int i = 0; i < 25; ++i) { L[i] = tables[i]; DL[i] = tables[25 + i]; }
+    int node[5];
+    if (on) {
+        const int cell = first + k;
+        const int *mrow = map_q4 + (size_t)(start + cell / nl) * Q4_ND;
+        const int lrel4 = 4 * (cell % nl);
+        double uv[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { node[i] = mrow[i * 25 + l] + lrel4; uv[i] = u[node[i]]; }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { s0 += L[q * 5 + i] * uv[i]; s1 += DL[q * 5 + i] * uv[i]; }
+            A[0][q * 25 + l] = s0; A[1][q * 25 + l] = s1;
+        }
     }
     __syncthreads();
-    // stage 2: second index:  b0 = L_2 b1, b3 = L_2 b2, b4 = DL_2 b1        (output index (q1, q2, i3))
-    if (on) {
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    if (on) {                                           // stage 2: (p, r) = (q1, i3)
+        double v[5], d[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { v[i] = A[0][p * 25 + i * 5 + r]; d[i] = A[1][p * 25 + i * 5 + r]; }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { s0 += L[q * 5 + i] * v[i]; s1 += L[q * 5 + i] * d[i]; s2 += DL[q * 5 + i] * v[i]; }
+            const int o = (p * 5 + q) * 5 + r;
+            B[0][o] = s0; B[1][o] = s1; B[2][o] = s2;
+        }
+    }
+    __syncthreads();
+    if (on) {                                           // stages 3 + 4: (p, r) = (q1, q2); the line is index l*5 + i3
+        double vv[5], d1[5], d2[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { vv[i] = B[0][l * 5 + i]; d1[i] = B[1][l * 5 + i]; d2[i] = B[2][l * 5 + i]; }
+        // geometry along the line: with (t0, t1) fixed, dx/dt0, dx/dt1 and x are affine in t2 and dx/dt2 is constant
+        const double t0 = tables[50 + p], t1 = tables[50 + r], w01 = tables[55 + p] * tables[55 + r];
+        const double *X8 = sX[ka];
+        double G0[3][2], G1[3][2], P[3][2];             // [component][bottom / top face]
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const double x00 = X8[(0 + f) * 3 + c], x01 = X8[(2 + f) * 3 + c], x10 = X8[(4 + f) * 3 + c], x11 = X8[(6 + f) * 3 + c];
+                G0[c][f] = (1.0 - t1) * (x10 - x00) + t1 * (x11 - x01);
+                G1[c][f] = (1.0 - t0) * (x01 - x00) + t0 * (x11 - x10);
+                P[c][f] = (1.0 - t0) * ((1.0 - t1) * x00 + t1 * x01) + t0 * ((1.0 - t1) * x10 + t1 * x11);
+            }
+        double p0[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, p1[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, sv[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            double g[4] = {0.0, 0.0, 0.0, 0.0};         // d1 u, d2 u, d3 u, u at the Gauss point (p, r, q)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                g[0] += L[q * 5 + i] * d1[i]; g[1] += L[q * 5 + i] * d2[i]; g[2] += DL[q * 5 + i] * vv[i]; g[3] += L[q * 5 + i] * vv[i];
+            }
+            const double t2 = tables[50 + q];
+            double J[3][3], X[3], W[16], F[4];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                J[c][0] = G0[c][0] + t2 * (G0[c][1] - G0[c][0]);
+                J[c][1] = G1[c][0] + t2 * (G1[c][1] - G1[c][0]);
+                J[c][2] = P[c][1] - P[c][0];
+                X[c] = P[c][0] + t2 * (P[c][1] - P[c][0]);
+            }
+            weights(J, X, w01 * tables[55 + q], W);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) F[m] = W[m * 4 + 0] * g[0] + W[m * 4 + 1] * g[1] + W[m * 4 + 2] * g[2] + W[m * 4 + 3] * g[3];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                p0[i] += L[q * 5 + i] * F[0]; p1[i] += L[q * 5 + i] * F[1]; sv[i] += DL[q * 5 + i] * F[2] + L[q * 5 + i] * F[3];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { A[0][l * 5 + i] = p0[i]; A[1][l * 5 + i] = p1[i]; A[2][l * 5 + i] = sv[i]; }
+    }
+    __syncthreads();
+    if (on) {                                           // stage 5: (p, r) = (q1, i3), q2 -> i2
+        double a0[5], a1[5], a2[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { const int o = (p * 5 + q) * 5 + r; a0[q] = A[0][o]; a1[q] = A[1][o]; a2[q] = A[2][o]; }
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-            const double v1 = b1[(a * 5 + i) * 5 + c], v2 = b2[(a * 5 + i) * 5 + c];
-            s0 += sL[b * 5 + i] * v1; s1 += sL[b * 5 + i] * v2; s2 += sDL[b * 5 + i] * v1;
+            double r0 = 0.0, r1 = 0.0;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) { r0 += L[q * 5 + i] * a0[q]; r1 += DL[q * 5 + i] * a1[q] + L[q * 5 + i] * a2[q]; }
+            B[0][p * 25 + i * 5 + r] = r0; B[1][p * 25 + i * 5 + r] = r1;
         }
-        b0[t] = s0; b3[t] = s1; b4[t] = s2;
     }
     __syncthreads();
-    // stage 3: third index -> values at the Gauss point (q1, q2, q3) = (a, b, c); point weights in registers
-    double F[4] = {0.0, 0.0, 0.0, 0.0};
-    if (on) {
-        double g[4] = {0.0, 0.0, 0.0, 0.0};            // d1 u, d2 u, d3 u, u
+    if (on) {                                           // stage 6: line l = (i2, i3), q1 -> i1
+        double r0[5], r1[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { r0[q] = B[0][q * 25 + l]; r1[q] = B[1][q * 25 + l]; }
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-            const double l = sL[c * 5 + i], d = sDL[c * 5 + i];
-            const double v0 = b0[(a * 5 + b) * 5 + i];
-            g[3] += l * v0; g[2] += d * v0; g[0] += l * b3[(a * 5 + b) * 5 + i]; g[1] += l * b4[(a * 5 + b) * 5 + i];
-        }
-        const double tq[3] = {sQP[a], sQP[b], sQP[c]};
-        double J[3][3], X[3], W[16];
-        hex_jacobian(sX, tq, J, X);
-        weights(J, X, sQW[a] * sQW[b] * sQW[c], W);
+            double yv = 0.0;
 #pragma unroll
-        for (int l = 0; l < 4; ++l) F[l] = W[l * 4 + 0] * g[0] + W[l * 4 + 1] * g[1] + W[l * 4 + 2] * g[2] + W[l * 4 + 3] * g[3];
-    }
-    __syncthreads();                                    // all reads of b0/b3/b4 done
-    if (on) { b0[t] = F[0]; b1[t] = F[1]; b2[t] = F[2]; b3[t] = F[3]; }
-    __syncthreads();
-    // stage 4: q3 -> i3:  P0 = L_3^T F0, P1 = L_3^T F1, S = DL_3^T F2 + L_3^T F3     (index (q1, q2, i3))
-    double p0 = 0.0, p1 = 0.0, sv = 0.0;
-    if (on) {
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            const double l = sL[q * 5 + c], d = sDL[q * 5 + c];
-            const int o = (a * 5 + b) * 5 + q;
-            p0 += l * b0[o]; p1 += l * b1[o]; sv += d * b2[o] + l * b3[o];
+            for (int q = 0; q < 5; ++q) yv += DL[q * 5 + i] * r0[q] + L[q * 5 + i] * r1[q];
+            atomicAdd(&y[node[i]], yv);
         }
-    }
-    __syncthreads();
-    if (on) { b0[t] = p0; b1[t] = p1; b2[t] = sv; }
-    __syncthreads();
-    // stage 5: q2 -> i2:  R0 = L_2^T P0, R1 = DL_2^T P1 + L_2^T S                     (index (q1, i2, i3))
-    double r0 = 0.0, r1 = 0.0;
-    if (on) {
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            const double l = sL[q * 5 + b], d = sDL[q * 5 + b];
-            const int o = (a * 5 + q) * 5 + c;
-            r0 += l * b0[o]; r1 += d * b1[o] + l * b2[o];
-        }
-    }
-    __syncthreads();
-    if (on) { b3[t] = r0; b4[t] = r1; }
-    __syncthreads();
-    // stage 6: q1 -> i1:  y = DL_1^T R0 + L_1^T R1
-    if (on) {
-        double yv = 0.0;
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            const int o = (q * 5 + b) * 5 + c;
-            yv += sDL[q * 5 + a] * b3[o] + sL[q * 5 + a] * b4[o];
-        }
-        atomicAdd(&y[node], yv);
     }
 }
 

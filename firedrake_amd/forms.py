@@ -17,6 +17,8 @@ A*u = action(a, u), exactness on polynomial data).
 """
 from __future__ import annotations
 
+import functools
+
 import numpy as np
 
 from . import op2
@@ -62,9 +64,50 @@ def gauss_jacobi_simplex(dim, degree):
     return np.array(pts), np.array(wts)
 
 
+def _orbit_points(dim, orbits):
+    """Points of fully symmetric orbits on the reference simplex, given in barycentric form: ("v", a) = the dim + 1
+    permutations of (1 - dim a, a, ..., a); ("e", b) = the six permutations of (b, b, 1/2 - b, 1/2 - b) (tetrahedron)."""
+    import itertools
+    pts = []
+    for kind, a in orbits:
+        bary = (1.0 - dim * a,) + (a,) * dim if kind == "v" else (a, a, 0.5 - a, 0.5 - a)
+        pts.append(np.array(sorted(set(itertools.permutations(bary))))[:, 1:])
+    return pts
+
+
+@functools.lru_cache(maxsize=None)
+def symmetric_simplex_rule(dim):
+    """Fully symmetric rule with positive weights and interior points: 6 points, degree 4 on the triangle (two vertex
+    orbits); 14 points, degree 5 on the tetrahedron (two vertex orbits and one edge orbit).  The orbit parameters are
+    the solution of the moment equations, refined here to rounding from three-digit starting values and checked."""
+    import math
+    from scipy.optimize import least_squares
+    deg = 4 if dim == 2 else 5
+    kinds = ("v", "v") if dim == 2 else ("v", "v", "e")
+    x0 = (0.0916, 0.055, 0.4459, 0.1117) if dim == 2 else (0.0927, 0.0122, 0.3109, 0.0188, 0.0455, 0.0071)
+    powers = [p for p in np.ndindex(*(deg + 1,) * dim) if sum(p) <= deg]
+    exact = np.array([math.prod(math.factorial(e) for e in p) / math.factorial(sum(p) + dim) for p in powers])
+
+    def rule(x):
+        orbits = _orbit_points(dim, [(k, x[2 * i]) for i, k in enumerate(kinds)])
+        return np.concatenate(orbits), np.concatenate([np.full(len(o), x[2 * i + 1]) for i, o in enumerate(orbits)])
+
+    def residual(x):
+        pts, wts = rule(x)
+        return np.array([(wts * np.prod(pts ** np.array(p), axis=1)).sum() for p in powers]) - exact
+
+    sol = least_squares(residual, x0, xtol=1e-15, ftol=1e-15, gtol=1e-15)
+    pts, wts = rule(sol.x)
+    if np.abs(residual(sol.x)).max() > 1e-15 or wts.min() <= 0 or pts.min() <= 0 or pts.sum(axis=1).max() >= 1:
+        raise RuntimeError("symmetric simplex rule did not converge")
+    return pts, wts
+
+
 def simplex_rule(dim, degree):
     """Quadrature on the reference simplex the way FIAT's default scheme picks it (tsfc/fem.py:330-333 ->
-    FIAT create_quadrature): the minimal symmetric rules for degree <= 2, collapsed Gauss-Jacobi above."""
+    FIAT create_quadrature): small fully symmetric rules with positive weights at low degree, collapsed Gauss-Jacobi
+    above.  (FIAT's own tables are not available offline; degree 4 takes the 6-point triangle rule and degrees 4-5 the 14-point
+    degree-5 tetrahedron rule, which is not fewer points than FIAT's choice for these degrees.)"""
     if degree <= 1:
         return np.full((1, dim), 1.0 / (dim + 1)), np.array([1.0 / (2 if dim == 2 else 6)])
     if degree == 2 and dim == 2:
@@ -72,6 +115,8 @@ def simplex_rule(dim, degree):
     if degree == 2 and dim == 3:
         a, b = 0.5854101966249685, 0.1381966011250105
         return np.array([[b, b, b], [a, b, b], [b, a, b], [b, b, a]]), np.full(4, 1.0 / 24.0)
+    if degree == 4 or (dim == 3 and degree == 5):
+        return symmetric_simplex_rule(dim)
     return gauss_jacobi_simplex(dim, degree)
 
 

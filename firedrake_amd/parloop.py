@@ -796,10 +796,12 @@ class Parloop:
             ps, pe = geo["range"]               # plan coordinates: [start, end), or [0, n) of the derived entity order
             cw.launch(ps, pe, args, block_threads=threads, ents_per_block=geo["epb"], nblocks=nb, lds_bytes=geo["lds"])
         elif src.mode.startswith("tp_"):
-            # one (action) or two (matrix: the halves of the padded 128-row element matrix) workgroups per cell
+            # matrix: two workgroups per cell (the halves of the padded 128-row element matrix); action: one workgroup per
+            # TP_ACTION_CELLS cells of the (column, layer) space
+            from .codegen import TP_ACTION_CELLS
             ncell = size * (self.iterset.layers - 1)
-            cw.launch(start, end, args, block_threads=threads, ents_per_block=1,
-                      nblocks=ncell * (2 if src.mode == "tp_matrix" else 1))
+            nb = ncell * 2 if src.mode == "tp_matrix" else -(-ncell // TP_ACTION_CELLS)
+            cw.launch(start, end, args, block_threads=threads, ents_per_block=1, nblocks=nb)
         else:
             total = size
             if self.iterset._extruded and src.layer_parallel:
