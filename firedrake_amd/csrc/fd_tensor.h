@@ -19,8 +19,6 @@
 #pragma once
 #include "fd_wrapper.h"
 
-typedef double fd_d4 __attribute__((ext_vector_type(4)));
-
 namespace fdt {
 
 constexpr int Q4_ND = 125, Q4_NQ1 = 5;

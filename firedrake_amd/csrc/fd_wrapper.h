@@ -26,6 +26,7 @@ typedef double PetscScalar;
 typedef double PetscReal;
 typedef int PetscInt;
 #define restrict __restrict__   /* C99 keyword used by loopy/TSFC-generated C */
+typedef double fd_d4 __attribute__((ext_vector_type(4)));   /* accumulator tile of v_mfma_f64_16x16x4_f64 (fd_tensor.h) */
 
 namespace fdw {
 

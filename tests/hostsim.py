@@ -33,7 +33,7 @@ def _compile(source, name):
         src = os.path.join(_BUILD, f"{name}_{key}.cpp")
         with open(src, "w") as f:
             f.write(source)
-        cmd = ["g++", "-O1", "-fPIC", "-shared", "-std=gnu++17", "-w", "-I", os.path.join(_HERE, "hostsim"),
+        cmd = ["g++", "-O1", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-std=gnu++17", "-w", "-I", os.path.join(_HERE, "hostsim"),
                "-o", so + ".tmp", src, "-lm"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -50,7 +50,8 @@ def _compile_mt(source, name):
         src = os.path.join(_BUILD, f"{name}_mt_{key}.cpp")
         with open(src, "w") as f:
             f.write(source)
-        cmd = ["g++", "-O1", "-fPIC", "-shared", "-std=gnu++20", "-pthread", "-w", "-I", os.path.join(_HERE, "hostsim", "mt"),
+        # -Bsymbolic: the wrapper's own definition wins over a same-named kernel handle exported by a loaded libfdhip.so
+        cmd = ["g++", "-O1", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-std=gnu++20", "-pthread", "-w", "-I", os.path.join(_HERE, "hostsim", "mt"),
                "-o", so + ".tmp", src, "-lm"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -489,4 +490,89 @@ def run_direct(pl, part=None):
         else:
             raise AssertionError(f"hostsim cannot provide {kind}")
     fn(*cargs)
+    return [outs.get(k) for k in range(len(pl.arguments))]
+
+
+def run_tensor(pl):
+    """Execute a tensor-product Parloop ``pl`` (codegen modes tp_action / tp_matrix) on the host: the generated wrapper and the
+    REAL device templates of firedrake_amd/csrc/fd_tensor.h, compiled against the stand-in header (one OS thread per lane;
+    the fp64 MFMA is restated there from the operand layout the templates rely on).  Returns one entry per argument like
+    run_direct: copies of the Dats after the loop, an OracleCSR for the Mat."""
+    import re
+    from firedrake_amd.codegen import TP_ACTION_CELLS, generate_tensor_wrapper
+    from firedrake_amd.tensor import gll_gauss_tables
+    gk = pl.global_kernel
+    src = generate_tensor_wrapper(gk)
+    csrc = os.path.join(os.path.dirname(_HERE), "firedrake_amd", "csrc")
+    with open(os.path.join(csrc, "fd_tensor.h")) as f:
+        templates = f.read().replace('#include "fd_wrapper.h"', "")
+    text = src.source.replace('#include "fd_tensor.h"', '#include "fd_wrapper.h"\n' + templates)
+    sig = re.search(r'extern "C" __global__[^\n]*void %s\((.*)\)\n' % src.symbol, text).group(1)
+    names = [p.split()[-1].lstrip("*") for p in sig.split(", ")]
+    text += ('\nextern "C" void sim_run(int fd_nblocks, int fd_nthreads, %s)\n{\n  fd_sim::run(fd_nblocks, fd_nthreads, [&] { %s(%s); });\n}\n'
+             % (sig, src.symbol, ", ".join(names)))
+    lib = _compile_mt(text, src.symbol)
+    lib.sim_run.restype = None
+    maps = []
+    for pa in pl.arguments:
+        for m in getattr(pa, "maps", ()):
+            if all(m._base() is not q for q in maps):
+                maps.append(m._base())
+    start, end = 0, pl.iterset.size
+    nl = pl.iterset.layers - 1
+    ncell = (end - start) * nl
+    nblocks = 2 * ncell if src.mode == "tp_matrix" else -(-ncell // TP_ACTION_CELLS)
+    outs, keep = {}, []
+
+    def ptr(a):
+        a = np.ascontiguousarray(a)
+        keep.append(a)
+        return ctypes.c_void_p(a.ctypes.data)
+
+    csr = None
+    cargs = [ctypes.c_int(nblocks), ctypes.c_int(src.block_threads), ctypes.c_int(start), ctypes.c_int(end)]
+    for desc in src.layout:
+        kind = desc[0]
+        if kind == "layers":
+            cargs.append(ptr(np.asarray(pl.iterset.layers_array, dtype=np.int32)))
+        elif kind == "arg":
+            pa = pl.arguments[desc[1]]
+            if isinstance(pa, MatParloopArg):
+                csr = oracle_pattern(pa.data.sparsity)
+                outs[desc[1]] = csr
+                cargs.append(ctypes.c_void_p(csr.values.ctypes.data))
+            else:
+                host = pa.data._host if pa.data._host_valid else pa.data._to_host()
+                a = np.array(host, copy=True)
+                outs[desc[1]] = a
+                cargs.append(ctypes.c_void_p(a.ctypes.data))
+        elif kind == "map":
+            cargs.append(ptr(np.asarray(maps[desc[1]].values_with_halo, dtype=np.int32)))
+        elif kind == "mat_rowptr":
+            cargs.append(ptr(np.asarray(csr.rowptr, dtype=np.int32)))
+        elif kind == "tp_offtab":
+            # Parloop._tp_offtab restated: position of entry (i, j) inside its CSR row for the bottom / an interior / the top cell
+            m = pl.arguments[desc[1]].maps[0]._base()
+            mv, off = np.asarray(m.values_with_halo, dtype=np.int64), np.asarray(m.offset, dtype=np.int64)
+            nd = m.arity
+            tab = np.zeros((mv.shape[0], 3, nd, nd), dtype=np.uint16)
+            for c in range(mv.shape[0]):
+                for v, lay in enumerate((0, min(1, nl - 1), nl - 1)):
+                    nodes = mv[c] + off * lay
+                    for i, rn in enumerate(nodes):
+                        cols = csr.colidx[csr.rowptr[rn]:csr.rowptr[rn + 1]]
+                        pos = np.searchsorted(cols, nodes)
+                        assert (cols[pos] == nodes).all()
+                        tab[c, v, i] = pos
+            cargs.append(ptr(tab))
+        elif kind in ("mat_row_lgmap", "mat_col_lgmap"):
+            pa = pl.arguments[desc[1]]
+            cargs.append(ptr(np.asarray(pa.lgmaps[0 if kind == "mat_row_lgmap" else 1], dtype=np.int32)))
+        elif kind == "tp_tables":
+            tp = gk.local_kernel.tp
+            L, DL, qp, qw = gll_gauss_tables(tp["degree"], tp["nq"])
+            cargs.append(ptr(np.concatenate([L.ravel(), DL.ravel(), qp, qw])))
+        else:
+            raise AssertionError(f"hostsim (tensor) cannot provide {kind}")
+    lib.sim_run(*cargs)
     return [outs.get(k) for k in range(len(pl.arguments))]

@@ -74,6 +74,31 @@ template <class T, class F> inline void cas_update(T *p, F f) {
 }  // namespace fd_sim
 
 static inline void __syncthreads() { fd_sim::bar->arrive_and_wait(); }
+
+// v_mfma_f64_16x16x4_f64 the way csrc/fd_tensor.h uses it: lane l of a wavefront supplies A[l & 15][l >> 4] and
+// B[l >> 4][l & 15] and holds D[(l >> 4) + 4 g][l & 15] in accumulator register g.  Every wavefront of the workgroup must
+// issue it in step (true of the templates: no divergent control flow around the MFMA loop), so two workgroup barriers
+// stand in for the wavefront's lock step.
+struct fd_d4 {
+    double v[4];
+    double &operator[](int i) { return v[i]; }
+    double operator[](int i) const { return v[i]; }
+};
+namespace fd_sim { static double mfma_a[1024], mfma_b[1024]; }
+static inline fd_d4 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, fd_d4 c, int, int, int) {
+    const int t = threadIdx.x, w0 = t & ~63, l = t & 63;
+    fd_sim::mfma_a[t] = a;
+    fd_sim::mfma_b[t] = b;
+    __syncthreads();
+    for (int g = 0; g < 4; ++g) {
+        const int row = (l >> 4) + 4 * g, col = l & 15;
+        double s = c[g];
+        for (int k = 0; k < 4; ++k) s += fd_sim::mfma_a[w0 + k * 16 + row] * fd_sim::mfma_b[w0 + k * 16 + col];
+        c[g] = s;
+    }
+    __syncthreads();
+    return c;
+}
 template <class T> inline T atomicAdd(T *p, T v) { fd_sim::cas_update(p, [v](T o) { return o + v; }); return v; }
 
 namespace fdw {

@@ -1,0 +1,37 @@
+"""Host-sim parity of the tensor-product wrappers (codegen modes tp_action / tp_matrix): the generated wrapper and the device
+templates of firedrake_amd/csrc/fd_tensor.h, compiled against tests/hostsim/mt/fd_wrapper.h (one OS thread per lane, the fp64
+MFMA restated from its operand layout), against the oracle running the dense quadrature kernel through the extruded wrapper
+restatement (builder.py:94-124, 790-831).  Test infrastructure only: the product path has no host route."""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+import hostsim
+from firedrake_amd import forms, mesh as fmesh
+from test_gpu_q4_hex import _oracle_action, _oracle_matrix
+
+
+@pytest.mark.parametrize("n,layers", [(1, 1), (2, 3)])
+def test_q4_action_template_on_the_host(n, layers):
+    """(2, 3): 12 cells = two full workgroups of five cells and one with two -- the idle cell slots and lanes 125..127."""
+    m = fmesh.make_extruded_hex_mesh(n, layers, 4, perturb=0.1)
+    prob = forms.HelmholtzQ4Problem(m)
+    y = hostsim.run_tensor(prob.act_loop)[0]
+    ref = _oracle_action(m, prob.u.data_ro)
+    assert_allclose(y, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("bcs", [False, True])
+def test_q4_mfma_matrix_template_on_the_host(bcs):
+    """One column of two cells (bottom and top variants of the offset table); with BCs every boundary row and column is
+    dropped through the lgmaps, which on a 1 x 1 x 2 mesh leaves the 2 x 9 + 9 interior nodes."""
+    m = fmesh.make_extruded_hex_mesh(1, 2, 4, perturb=0.1)
+    prob = forms.HelmholtzQ4Problem(m, bcs=bcs)
+    csr = hostsim.run_tensor(prob.jac_loop)[0]
+    ref = _oracle_matrix(m, prob.bc_nodes if bcs else None)
+    v = csr.values.copy()
+    if bcs:                                   # the unit diagonal of the BC rows is a separate pass (fd_csr_set_diagonal)
+        rp, ci = csr.rowptr, csr.colidx
+        for b in prob.bc_nodes:
+            v[rp[b] + np.searchsorted(ci[rp[b]:rp[b + 1]], b)] = 1.0
+    assert_allclose(v, ref.values, rtol=0, atol=1e-12 * np.abs(ref.values).max())
