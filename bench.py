@@ -109,6 +109,7 @@ def cpu_baseline(n_sample, degree, reps=10):
 
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD datasheet; tools/microbench.hip measures 77.7 TFLOP/s with v_mfma_f64_16x16x4_f64
+FP64_VECTOR_PEAK_TFLOPS = 78.6 # same datasheet figure for vector fp64 FMA (256 CUs x 64 lanes x 2 flop x 2.4 GHz); microbench: 70 TFLOP/s
 
 
 def measure_c3(n, steps, warmup):
@@ -147,6 +148,7 @@ def measure_c3(n, steps, warmup):
     # action: map (one 125-entry row per COLUMN) + Q1 coordinates + u read + y written (+ zeroing pass at assemble level)
     ncol = m.base_set.size
     act_bytes = ncol * 125 * 4 + ncol * 8 * 4 + m.coord_node_set.size * 24 + ndofs * 8 + ndofs * 8
+    act_flops = ncell * (25 * 450 * 2 + 125 * 200)
     return {"config": {"workload": f"Helmholtz Q4 stiffness+mass on ExtrudedMesh(UnitSquareMesh({n},{n},quadrilateral), {n}) "
                                    f"(BASELINE.json configs[2]), Dirichlet BCs", "cells": ncell, "dofs": ndofs, "nnz": nnz},
             "jacobian_dofs_per_s": ndofs / (a_ms * 1e-3), "action_dofs_per_s": ndofs / (act_a_ms * 1e-3),
@@ -158,7 +160,11 @@ def measure_c3(n, steps, warmup):
                          "note": "assemble = zeroing pass over the CSR values + MFMA kernel incl. its atomic scatter + BC diagonal"},
             "roofline_action": {"kernel": "wrap_helmholtz_q4_hex_action", "bound": "hbm", "achieved": act_bytes / (act_k_ms * 1e-3) / 1e9,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": act_bytes / (act_k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "traffic": None, "ms": act_k_ms, "algorithmic_bytes": act_bytes, "assemble_ms": act_a_ms}}
+                                "traffic": None, "ms": act_k_ms, "algorithmic_bytes": act_bytes, "assemble_ms": act_a_ms,
+                                # the action's floor is fp64 VALU issue, not HBM: 6 axis passes (450 FMAs per line, 25 lines per cell)
+                                # + ~200 flop of geometry / point weights at each of the 125 Gauss points
+                                "valu_flops": act_flops, "valu_floor_ms": act_flops / (FP64_VECTOR_PEAK_TFLOPS * 1e12) * 1e3,
+                                "frac_valu": act_flops / (FP64_VECTOR_PEAK_TFLOPS * 1e12) * 1e3 / act_k_ms}}
 
 
 def run_c3(args):

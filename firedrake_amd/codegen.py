@@ -1098,6 +1098,7 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         src.append("    " + " ".join(f"{n} = nx_{n};" for n, _ in scal) + (" cmask = nx_cmask;" if dofmask else ""))
     src += ["  }", "  __syncthreads();"]
     if ordered:
+        # (a per-entry flush table like the whole-entity wrapper's measured 8 % slower here: rows are ~28 entries long, profiles/r3t)
         src.append(f"  for (int fr = tid >> 4; fr < nown; fr += nthr >> 4) {{ const int fp = n0 + fr; "
                    f"const int fs = (oc{K}_rowptr[fp] - r0)*{B}, fl = (oc{K}_rowptr[fp+1] - oc{K}_rowptr[fp])*{B}; "
                    f"const size_t fd_ = (size_t)oc{K}_gstart[fp]*{B}; "
