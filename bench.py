@@ -293,6 +293,9 @@ def run_calibration():
     _lib.call("fd_device_sync")
 
 
+PMC_PASS_TIMEOUT_S = 240
+
+
 def collect_traffic(argv_tail, kernels):
     """HBM bytes per launch of ``kernels`` from rocprofv3 PMC passes of THIS command, run as child processes after the
     timed region: FETCH_SIZE and WRITE_SIZE in separate passes with --kernel-trace only (MI355X_MICROARCH.md, HBM and PMC
@@ -312,10 +315,24 @@ def collect_traffic(argv_tail, kernels):
         d = tempfile.mkdtemp(prefix=f"fd_pmc_{counter}_", dir="/tmp")
         cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
                sys.executable, os.path.join(ROOT, "bench.py"), "--inner-pmc", *argv_tail]
+        # own session + a hard limit: a profiler pass that wedges is killed with everything it started and the line goes out
+        # with traffic = null (a normal pass takes ~30 s)
         try:
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
-        except (OSError, subprocess.TimeoutExpired) as exc:
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        except OSError as exc:
             return None, {"error": f"{counter} pass: {exc}"}
+        try:
+            out_, err_ = proc.communicate(timeout=PMC_PASS_TIMEOUT_S)
+        except subprocess.TimeoutExpired:
+            import signal
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except OSError:
+                pass
+            proc.wait()
+            shutil.rmtree(d, ignore_errors=True)
+            return None, {"error": f"{counter} pass exceeded {PMC_PASS_TIMEOUT_S} s and was killed"}
+        r = subprocess.CompletedProcess(cmd, proc.returncode, out_, err_)
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         if r.returncode != 0 or not files:
             return None, {"error": f"{counter} pass failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}"}

@@ -55,3 +55,20 @@ def test_cpu_baseline_owner_partition_matches_serial():
         out.append((r, csr.values.copy()))
     assert np.abs(out[0][0] - out[1][0]).max() <= 1e-13 * np.abs(out[0][0]).max()
     assert np.abs(out[0][1] - out[1][1]).max() <= 1e-13 * np.abs(out[0][1]).max()
+
+
+def test_a_wedged_profiler_pass_is_killed_and_reported(tmp_path, monkeypatch):
+    """bench.collect_traffic runs rocprofv3 as a child: a pass that never returns must not hold the bench line back -- it is killed
+    (with whatever it started) after PMC_PASS_TIMEOUT_S and the line carries traffic = null with the reason."""
+    import shutil
+    import time
+    import bench
+    fake = tmp_path / "rocprofv3"
+    fake.write_text("#!/bin/bash\nsleep 600 &\nwait\n")
+    fake.chmod(0o755)
+    monkeypatch.setattr(shutil, "which", lambda name: str(fake))
+    monkeypatch.setattr(bench, "PMC_PASS_TIMEOUT_S", 1)
+    t0 = time.time()
+    traffic, meta = bench.collect_traffic(["--steps", "1"], ["k"])
+    assert traffic is None and "killed" in meta["error"]
+    assert time.time() - t0 < 30

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 3 --warmup 1 --cpu-sample 0 --variants= --traffic off --no-secondary --only jacobian --numbering $NB"
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAVES SQ_WAIT_INST_LDS SQ_INSTS_SMEM" "TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"; do
   name=$(echo $set | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/r3pmc_${NB}_$name -o p -- python $R/bench.py $ARGS > $R/gpurun_out/r3pmc_${NB}_$name.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/r3pmc_${NB}_$name -o p -- python $R/bench.py $ARGS > $R/gpurun_out/r3pmc_${NB}_$name.log 2>&1
 done
 cd $R
 { echo "== wrap_poisson_p1_tet_jacobian, numbering=$NB"; python tools/pmc_summary.py wrap_poisson_p1_tet_jacobian gpurun_out/r3pmc_${NB}_*/;
