@@ -63,6 +63,7 @@ class WrapperSource:
     lane_threads: int = 0                                  # >0: plans must be in lane order for this many lanes
     ocr_lds_limit: int = 0                                 # LDS budget of an OCR row block (0 = configuration["lds_limit"])
     extra_flags: tuple = ()                                # per-kernel hipcc flags chosen at JIT time (kernel.GlobalKernel.compile)
+    tp: dict = field(default_factory=dict)                 # tensor-product wrappers: tensor_geometry() of the element
 
 
 def _distinct_maps(gk: GlobalKernel):
@@ -79,13 +80,14 @@ def _distinct_maps(gk: GlobalKernel):
 
 def tensor_eligible(gk: GlobalKernel):
     """'matrix' / 'action' when the loop can take the tensor-product wrappers of csrc/fd_tensor.h: a
-    TensorProductLocalKernel of degree 4 with 5 Gauss points per axis over an extruded set with constant layers, the
-    whole column (iteration region ALL), no subset, and the argument shapes
-        matrix:  Mat INC (scalar block, both maps the 125-node Q4 map)  +  coordinates READ (dim 3, 8-node Q1 map)
-        action:  Dat INC (scalar, Q4 map)  +  coordinates READ  +  Dat READ (scalar, the same Q4 map)."""
+    TensorProductLocalKernel of degree k = 1..5 with up to 8 Gauss points per axis (tensor_geometry) over an extruded set
+    with constant layers, the whole column (iteration region ALL), no subset, and the argument shapes
+        matrix:  Mat INC (scalar block, both maps the (k+1)^3-node Q_k map, offset k)  +  coordinates READ (dim 3, 8-node Q1 map)
+        action:  Dat INC (scalar, Q_k map)  +  coordinates READ  +  Dat READ (scalar, the same Q_k map)."""
     tp = getattr(gk.local_kernel, "tp", None)
-    if not tp or not configuration["tensor_wrappers"] or (tp["degree"], tp["nq"]) != (4, 5):
+    if not tp or not configuration["tensor_wrappers"] or tensor_geometry(tp["degree"], tp["nq"]) is None:
         return None
+    nd, k = (tp["degree"] + 1) ** 3, tp["degree"]
     if not gk._extruded or not gk._constant_layers or gk._subset or gk._extruded_periodic or gk._iteration_region != ALL or gk._pass_layer_arg:
         return None
     args, las = gk.arguments, gk.local_kernel.arguments
@@ -100,19 +102,30 @@ def tensor_eligible(gk: GlobalKernel):
 
     if tp["kind"] == "matrix" and len(args) == 2:
         a, la = args[0], las[0]
-        if isinstance(a, MatKernelArg) and la.access == INC and not a.unroll and a.maps[0] is a.maps[1] and plain(a.maps[0], 125, 4) \
+        if isinstance(a, MatKernelArg) and la.access == INC and not a.unroll and a.maps[0] is a.maps[1] and plain(a.maps[0], nd, k) \
                 and int(np.prod(a.dims[0])) * int(np.prod(a.dims[1])) == 1 and coords_ok(args[1], las[1]):
             return "matrix"
     if tp["kind"] == "action" and len(args) == 3:
         y, u = args[0], args[2]
         if all(isinstance(d, DatKernelArg) and d.index is None and int(np.prod(d.dim)) == 1 for d in (y, u)) \
                 and las[0].access == INC and las[2].access == READ and las[0].dtype == f64 and las[2].dtype == f64 \
-                and y.map_ is u.map_ and plain(y.map_, 125, 4) and coords_ok(args[1], las[1]):
+                and y.map_ is u.map_ and plain(y.map_, nd, k) and coords_ok(args[1], las[1]):
             return "action"
     return None
 
 
-TP_ACTION_CELLS = 5        # fdt::Q4_ACT_CELLS (csrc/fd_tensor.h): cells per workgroup of the action template
+def tensor_geometry(degree, nq):
+    """Launch shape of the tensor-product templates for Q_degree with nq Gauss points per axis, as csrc/fd_tensor.h derives it
+    (tp_tiles, tp_waves, tp_action_cells), or None outside the instantiated range: ``matrix_threads`` lanes and ``matrix_groups``
+    workgroups per cell (one wavefront per 16-row panel of the padded element matrix), ``action_cells`` cells per 128-lane
+    workgroup of the action."""
+    k1, q1 = int(degree) + 1, int(nq)
+    if not (1 <= degree <= 5 and 1 <= q1 <= 8):
+        return None
+    nt = (k1 ** 3 + 15) // 16
+    wpb = 4 if nt % 4 == 0 else (2 if nt % 2 == 0 else 1)
+    m = max(k1, q1)
+    return {"k1": k1, "q1": q1, "nd": k1 ** 3, "tiles": nt, "matrix_threads": 64 * wpb, "matrix_groups": nt // wpb, "action_cells": 128 // (m * m)}
 
 
 def generate_tensor_wrapper(gk: GlobalKernel) -> WrapperSource:
@@ -121,6 +134,7 @@ def generate_tensor_wrapper(gk: GlobalKernel) -> WrapperSource:
     templates of csrc/fd_tensor.h with the kernel's weight callback inlined."""
     kind = tensor_eligible(gk)
     lk = gk.local_kernel
+    geom = tensor_geometry(lk.tp["degree"], lk.tp["nq"])
     sym = f"wrap_{lk.name}"
     wname = f"{lk.name}_weights"
     layout = [("layers",)]
@@ -138,18 +152,20 @@ def generate_tensor_wrapper(gk: GlobalKernel) -> WrapperSource:
             params += ["const int *__restrict__ rlg0", "const int *__restrict__ clg0"]
         layout.append(("tp_tables",))
         params.append("const double *__restrict__ tptab")
-        body = (f"  fdt::hex_q4_matrix(start, end, layers, arg0, arg1, map0, map1, rp0, tpo0, "
+        body = (f"  fdt::hex_qk_matrix<{geom['k1']}, {geom['q1']}>(start, end, layers, arg0, arg1, map0, map1, rp0, tpo0, "
                 f"{'rlg0, clg0' if lg else 'nullptr, nullptr'}, tptab, {call_w});")
-        threads, bounds = 256, "256, 3"
+        threads = geom["matrix_threads"]
+        # 4 NT accumulator registers per lane: Q4 (NT = 8) fits three wavefronts per SIMD
+        bounds = f"{threads}, 3" if geom["tiles"] <= 8 and threads == 256 else f"{threads}"
     else:
         layout += [("arg", 0), ("arg", 1), ("arg", 2), ("map", 0), ("map", 1), ("tp_tables",)]
         params = ["const int *__restrict__ layers", "double *__restrict__ arg0", "const double *__restrict__ arg1",
                   "const double *__restrict__ arg2", "const int *__restrict__ map0", "const int *__restrict__ map1",
                   "const double *__restrict__ tptab"]
-        body = f"  fdt::hex_q4_action(start, end, layers, arg0, arg1, arg2, map0, map1, tptab, {call_w});"
+        body = f"  fdt::hex_qk_action<{geom['k1']}, {geom['q1']}>(start, end, layers, arg0, arg1, arg2, map0, map1, tptab, {call_w});"
         threads, bounds = 128, "128"
     src = head + [f'extern "C" __global__ __launch_bounds__({bounds}) void {sym}(int start, int end, {", ".join(params)})', "{", body, "}"]
-    return WrapperSource("\n".join(src) + "\n", sym, "tp_" + kind, layout, 2, block_threads=threads)
+    return WrapperSource("\n".join(src) + "\n", sym, "tp_" + kind, layout, 2, block_threads=threads, tp=geom)
 
 
 def select_mode(gk: GlobalKernel) -> str:

@@ -541,20 +541,24 @@ def q4_tables(degree=4, nq=5):
     return gll_gauss_tables(degree, nq)
 
 
-def helmholtz_q4_hex_jacobian_kernel(name="helmholtz_q4_hex_jacobian", alpha=1.0, beta=1.0):
-    """a(u, v) = int alpha grad(u).grad(v) + beta u v dx on a trilinear hexahedron with Q4 basis, 5x5x5 Gauss points
-    (dx(degree=8)); alpha = beta = 1 is the Helmholtz operator of config C3, (0, 1) the mass form.
-    Arguments: A[125*125], coords[8*3] (Q1 vertices, index a*4 + b*2 + c).
+def helmholtz_hex_jacobian_kernel(degree=4, nq=None, name=None, alpha=1.0, beta=1.0):
+    """a(u, v) = int alpha grad(u).grad(v) + beta u v dx on a trilinear hexahedron with the Q_degree basis and nq^3 Gauss points
+    (default nq = degree + 1: dx(degree=2*degree)); alpha = beta = 1 is the Helmholtz operator of config C3,
+    (0, 1) the mass form.  Arguments: A[nd*nd], coords[8*3] (Q1 vertices, index a*4 + b*2 + c), nd = (degree+1)^3.
     Dense formulation (what the MFMA kernel computes); used as the oracle's local kernel."""
-    L, DL, qp, qw = q4_tables()
+    k1 = degree + 1
+    nq = nq or k1
+    nd = k1 ** 3
+    name = name or f"helmholtz_q{degree}_hex_jacobian"
+    L, DL, qp, qw = q4_tables(degree, nq)
     body = f"""
 static void {name}(double *restrict A, const double *restrict x)
 {{
-  static const double L[5][5] = {_c(L)};
-  static const double DL[5][5] = {_c(DL)};
-  static const double QP[5] = {_c(qp)};
-  static const double QW[5] = {_c(qw)};
-  for (int q1 = 0; q1 < 5; ++q1) for (int q2 = 0; q2 < 5; ++q2) for (int q3 = 0; q3 < 5; ++q3) {{
+  static const double L[{nq}][{k1}] = {_c(L)};
+  static const double DL[{nq}][{k1}] = {_c(DL)};
+  static const double QP[{nq}] = {_c(qp)};
+  static const double QW[{nq}] = {_c(qw)};
+  for (int q1 = 0; q1 < {nq}; ++q1) for (int q2 = 0; q2 < {nq}; ++q2) for (int q3 = 0; q3 < {nq}; ++q3) {{
     const double t[3] = {{QP[q1], QP[q2], QP[q3]}};
     double J[3][3] = {{{{0,0,0}},{{0,0,0}},{{0,0,0}}}};
     for (int v = 0; v < 8; ++v) {{
@@ -574,66 +578,78 @@ static void {name}(double *restrict A, const double *restrict x)
     double G[3][3];
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b)
       G[a][b] = w * (K[a][0]*K[b][0] + K[a][1]*K[b][1] + K[a][2]*K[b][2]);
-    double ph[125], dp[125][3];
-    for (int i1 = 0; i1 < 5; ++i1) for (int i2 = 0; i2 < 5; ++i2) for (int i3 = 0; i3 < 5; ++i3) {{
-      const int i = (i1*5 + i2)*5 + i3;
+    double ph[{nd}], dp[{nd}][3];
+    for (int i1 = 0; i1 < {k1}; ++i1) for (int i2 = 0; i2 < {k1}; ++i2) for (int i3 = 0; i3 < {k1}; ++i3) {{
+      const int i = (i1*{k1} + i2)*{k1} + i3;
       ph[i] = L[q1][i1]*L[q2][i2]*L[q3][i3];
       dp[i][0] = DL[q1][i1]*L[q2][i2]*L[q3][i3];
       dp[i][1] = L[q1][i1]*DL[q2][i2]*L[q3][i3];
       dp[i][2] = L[q1][i1]*L[q2][i2]*DL[q3][i3];
     }}
-    for (int i = 0; i < 125; ++i) {{
+    for (int i = 0; i < {nd}; ++i) {{
       const double t0 = G[0][0]*dp[i][0] + G[0][1]*dp[i][1] + G[0][2]*dp[i][2];
       const double t1 = G[1][0]*dp[i][0] + G[1][1]*dp[i][1] + G[1][2]*dp[i][2];
       const double t2 = G[2][0]*dp[i][0] + G[2][1]*dp[i][1] + G[2][2]*dp[i][2];
       const double tm = w * ph[i];
-      for (int j = 0; j < 125; ++j)
-        A[i*125 + j] += {float(alpha)!r}*(t0*dp[j][0] + t1*dp[j][1] + t2*dp[j][2]) + {float(beta)!r}*tm*ph[j];
+      for (int j = 0; j < {nd}; ++j)
+        A[i*{nd} + j] += {float(alpha)!r}*(t0*dp[j][0] + t1*dp[j][1] + t2*dp[j][2]) + {float(beta)!r}*tm*ph[j];
     }}
   }}
 }}
 """
     from .kernel import TensorProductLocalKernel
     from .tensor import second_order_weights
-    return TensorProductLocalKernel(body, name, kind="matrix", degree=4, nq=5, weights_code=second_order_weights(name, alpha, beta))
+    return TensorProductLocalKernel(body, name, kind="matrix", degree=degree, nq=nq, weights_code=second_order_weights(name, alpha, beta))
 
 
-def helmholtz_q4_hex_action_kernel(name="helmholtz_q4_hex_action", alpha=1.0, beta=1.0):
+def helmholtz_hex_action_kernel(degree=4, nq=None, name=None, alpha=1.0, beta=1.0):
     """y += A_e(coords) u: the action of the same bilinear form on a coefficient (the matrix-free operator application of
-    tests/firedrake/regression/test_matrix_free.py, and the Q4 "residual/action" of SURVEY.md 8d).  Arguments: y[125],
-    coords[24], u[125].  The C text is the dense definition (element matrix times element vector) the oracle executes; the
-    backend evaluates it sum-factorised from the descriptor (csrc/fd_tensor.h: hex_q4_action)."""
+    tests/firedrake/regression/test_matrix_free.py, and the Q4 "residual/action" of SURVEY.md 8d).  Arguments: y[nd],
+    coords[24], u[nd].  The C text is the dense definition (element matrix times element vector) the oracle executes; the
+    backend evaluates it sum-factorised from the descriptor (csrc/fd_tensor.h: hex_qk_action)."""
     from .kernel import TensorProductLocalKernel
     from .tensor import second_order_weights
-    jac = helmholtz_q4_hex_jacobian_kernel(name + "_matrix", alpha, beta)
+    nq = nq or degree + 1
+    nd = (degree + 1) ** 3
+    name = name or f"helmholtz_q{degree}_hex_action"
+    jac = helmholtz_hex_jacobian_kernel(degree, nq, name + "_matrix", alpha, beta)
     body = jac.code + f"""
 static void {name}(double *restrict y, const double *restrict x, const double *restrict u)
 {{
-  static double A[125*125];
-  for (int q = 0; q < 125*125; ++q) A[q] = 0.0;
+  static double A[{nd}*{nd}];
+  for (int q = 0; q < {nd}*{nd}; ++q) A[q] = 0.0;
   {name}_matrix(A, x);
-  for (int i = 0; i < 125; ++i) {{
+  for (int i = 0; i < {nd}; ++i) {{
     double s = 0.0;
-    for (int j = 0; j < 125; ++j) s += A[i*125 + j] * u[j];
+    for (int j = 0; j < {nd}; ++j) s += A[i*{nd} + j] * u[j];
     y[i] += s;
   }}
 }}
 """
-    return TensorProductLocalKernel(body, name, kind="action", degree=4, nq=5, weights_code=second_order_weights(name, alpha, beta))
+    return TensorProductLocalKernel(body, name, kind="action", degree=degree, nq=nq, weights_code=second_order_weights(name, alpha, beta))
 
 
-class HelmholtzQ4Problem:
-    """Config C3: the Q4 Helmholtz operator on an extruded hex mesh, assembled and applied through ordinary parloops
+def helmholtz_q4_hex_jacobian_kernel(name="helmholtz_q4_hex_jacobian", alpha=1.0, beta=1.0):
+    """Config C3: Q4, 5 x 5 x 5 Gauss points (dx(degree=8))."""
+    return helmholtz_hex_jacobian_kernel(4, 5, name, alpha, beta)
+
+
+def helmholtz_q4_hex_action_kernel(name="helmholtz_q4_hex_action", alpha=1.0, beta=1.0):
+    return helmholtz_hex_action_kernel(4, 5, name, alpha, beta)
+
+
+class HelmholtzHexProblem:
+    """Config C3 (Q4) and its siblings: the Q_k Helmholtz operator on an extruded hex mesh, assembled and applied through ordinary parloops
     (``op2.LegacyParloop`` with a Mat / Dat argument over the extruded cell set, optional BC lgmaps) whose local kernels
     are TensorProductLocalKernels: ``GlobalKernel.compile`` picks the fp64-MFMA matrix wrapper and the sum-factorised
     action wrapper of csrc/fd_tensor.h.  Plays ExplicitMatrixAssembler / OneFormAssembler like PoissonProblem."""
 
-    FLOPS_PER_CELL = 2.0 * 128 * 128 * 4 * 125          # MFMA work issued (padded 128x128 tiles)
-    ALGO_FLOPS_PER_CELL = 2.0 * 125 * 125 * 125 * 4     # SURVEY.md 8(d): 15.6 MFLOP/cell
-
-    def __init__(self, hexmesh, bcs=False):
+    def __init__(self, hexmesh, bcs=False, nq=None):
         self.mesh = m = hexmesh
-        assert m.degree == 4
+        nd, nqp = (m.degree + 1) ** 3, (nq or m.degree + 1) ** 3
+        pad = -(-nd // 16) * 16
+        self.FLOPS_PER_CELL = 2.0 * pad * pad * 4 * nqp       # MFMA work issued (element matrix padded to 16 x 16 tiles)
+        self.ALGO_FLOPS_PER_CELL = 2.0 * nd * nd * 4 * nqp    # SURVEY.md 8(d): 15.6 MFLOP per Q4 cell
         cm, xm = m.cell_node_map, m.coord_map
         self.sparsity = op2.Sparsity((m.node_set ** 1, m.node_set ** 1), [(cm, cm, None)])
         self.mat = op2.Mat(self.sparsity)
@@ -645,7 +661,7 @@ class HelmholtzQ4Problem:
             rlg = np.arange(m.node_set.total_size, dtype=np.int32)
             rlg[self.bc_nodes] = -1
             lg = (rlg, rlg.copy())
-        self.kjac, self.kact = helmholtz_q4_hex_jacobian_kernel(), helmholtz_q4_hex_action_kernel()
+        self.kjac, self.kact = helmholtz_hex_jacobian_kernel(m.degree, nq), helmholtz_hex_action_kernel(m.degree, nq)
         self.jac_loop = op2.LegacyParloop(self.kjac, m.cell_set, self.mat(op2.INC, (cm, cm), lgmaps=lg), m.coordinates(op2.READ, xm))
         self.u = op2.Dat(m.node_set, np.sin(3 * pts[:, 0]) * np.cos(2 * pts[:, 1]) + 0.3 * pts[:, 2], np.float64, "u")
         self.y = op2.Dat(m.node_set, None, np.float64, "y")
@@ -684,6 +700,14 @@ class HelmholtzQ4Problem:
             if events:
                 events[1].record()
         return self.y
+
+
+class HelmholtzQ4Problem(HelmholtzHexProblem):
+    """BASELINE.json configs[2]: Q4, 5 x 5 x 5 Gauss points."""
+
+    def __init__(self, hexmesh, bcs=False):
+        assert hexmesh.degree == 4
+        super().__init__(hexmesh, bcs, 5)
 
 
 # ------------------------------------------------------------------------------------------

@@ -796,11 +796,10 @@ class Parloop:
             ps, pe = geo["range"]               # plan coordinates: [start, end), or [0, n) of the derived entity order
             cw.launch(ps, pe, args, block_threads=threads, ents_per_block=geo["epb"], nblocks=nb, lds_bytes=geo["lds"])
         elif src.mode.startswith("tp_"):
-            # matrix: two workgroups per cell (the halves of the padded 128-row element matrix); action: one workgroup per
-            # TP_ACTION_CELLS cells of the (column, layer) space
-            from .codegen import TP_ACTION_CELLS
+            # matrix: one wavefront per 16-row panel of the padded element matrix (Q4: two workgroups of four per cell); action:
+            # one workgroup per tp["action_cells"] cells of the (column, layer) space (codegen.tensor_geometry)
             ncell = size * (self.iterset.layers - 1)
-            nb = ncell * 2 if src.mode == "tp_matrix" else -(-ncell // TP_ACTION_CELLS)
+            nb = ncell * src.tp["matrix_groups"] if src.mode == "tp_matrix" else -(-ncell // src.tp["action_cells"])
             cw.launch(start, end, args, block_threads=threads, ents_per_block=1, nblocks=nb)
         else:
             total = size

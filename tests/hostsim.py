@@ -499,7 +499,7 @@ def run_tensor(pl):
     the fp64 MFMA is restated there from the operand layout the templates rely on).  Returns one entry per argument like
     run_direct: copies of the Dats after the loop, an OracleCSR for the Mat."""
     import re
-    from firedrake_amd.codegen import TP_ACTION_CELLS, generate_tensor_wrapper
+    from firedrake_amd.codegen import generate_tensor_wrapper
     from firedrake_amd.tensor import gll_gauss_tables
     gk = pl.global_kernel
     src = generate_tensor_wrapper(gk)
@@ -521,7 +521,7 @@ def run_tensor(pl):
     start, end = 0, pl.iterset.size
     nl = pl.iterset.layers - 1
     ncell = (end - start) * nl
-    nblocks = 2 * ncell if src.mode == "tp_matrix" else -(-ncell // TP_ACTION_CELLS)
+    nblocks = ncell * src.tp["matrix_groups"] if src.mode == "tp_matrix" else -(-ncell // src.tp["action_cells"])
     outs, keep = {}, []
 
     def ptr(a):

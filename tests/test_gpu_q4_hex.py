@@ -9,13 +9,13 @@ from oracle import ODat, OMat, READ, INC
 from firedrake_amd import forms, mesh as fmesh
 
 
-def _oracle_matrix(m, bc_nodes=None):
+def _oracle_matrix(m, bc_nodes=None, k=None):
     """Dense Q4 kernel through the oracle's extruded wrapper; BC rows/columns dropped through the lgmaps and the unit
     diagonal set afterwards, as assemble.py:1501-1507 / 2075-2108 do."""
     cm, xm = m.cell_node_map.values_with_halo, m.coord_map.values_with_halo
     nn = m.node_set.total_size
     csr = oracle.build_sparsity(nn, nn, [(cm, cm, m.layers, m.cell_node_map.offset, m.cell_node_map.offset)])
-    k = forms.helmholtz_q4_hex_jacobian_kernel()
+    k = k or forms.helmholtz_q4_hex_jacobian_kernel()
     lg = None
     if bc_nodes is not None and len(bc_nodes):
         lg = np.arange(nn, dtype=np.int32)
@@ -31,10 +31,10 @@ def _oracle_matrix(m, bc_nodes=None):
     return csr
 
 
-def _oracle_action(m, u):
+def _oracle_action(m, u, k=None):
     cm, xm = m.cell_node_map.values_with_halo, m.coord_map.values_with_halo
     y = np.zeros(m.node_set.total_size)
-    k = forms.helmholtz_q4_hex_action_kernel()
+    k = k or forms.helmholtz_q4_hex_action_kernel()
     oracle.par_loop(k.code, k.name, 0, m.base_set.size,
                     [ODat(y, INC, cm, offset=m.cell_node_map.offset),
                      ODat(np.array(m.coordinates.data_ro_with_halos), READ, xm, offset=m.coord_map.offset),
@@ -251,3 +251,25 @@ def test_q4_mfma_full_size_properties():
     lhs, rhs = float(b @ ta.data_ro), float(a @ tb.data_ro)
     assert abs(lhs - rhs) <= 1e-10 * max(abs(lhs), abs(rhs))
     del xs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("degree,nq,n,layers", [(1, 2, 4, 5), (2, 3, 3, 4), (3, 4, 3, 3), (2, 4, 2, 3), (3, 3, 2, 2), (5, 6, 2, 2)])
+def test_qk_tensor_wrappers_match_the_oracle(degree, nq, n, layers):
+    """The tensor-product templates for other degrees / quadrature sizes (1, 2, 4 and 14 tiles per side of the element matrix;
+    32, 14, 8 and 3 cells per action workgroup): MFMA matrix with BC lgmaps and sum-factorised action against the oracle's dense
+    kernel, and A u == action(u) with the device SpMV."""
+    from firedrake_amd import op2
+    m = fmesh.make_extruded_hex_mesh(n, layers, degree, perturb=0.1)
+    prob = forms.HelmholtzHexProblem(m, bcs=True, nq=nq)
+    assert (prob.jac_loop._prepare()["cw"].src.mode, prob.act_loop._prepare()["cw"].src.mode) == ("tp_matrix", "tp_action")
+    v = prob.assemble_jacobian().csr()[2]
+    ref = _oracle_matrix(m, prob.bc_nodes, prob.kjac)
+    assert_allclose(v, ref.values, rtol=0, atol=1e-11 * np.abs(ref.values).max())
+    y = np.array(prob.assemble_action().data_ro)
+    yref = _oracle_action(m, prob.u.data_ro, prob.kact)
+    assert_allclose(y, yref, rtol=0, atol=1e-11 * np.abs(yref).max())
+    free = forms.HelmholtzHexProblem(m, bcs=False, nq=nq)
+    t = op2.Dat(m.node_set)
+    free.assemble_jacobian().mult(free.u, t)
+    assert_allclose(t.data_ro, y, rtol=0, atol=1e-11 * np.abs(yref).max())

@@ -35,3 +35,30 @@ def test_q4_mfma_matrix_template_on_the_host(bcs):
         for b in prob.bc_nodes:
             v[rp[b] + np.searchsorted(ci[rp[b]:rp[b + 1]], b)] = 1.0
     assert_allclose(v, ref.values, rtol=0, atol=1e-12 * np.abs(ref.values).max())
+
+
+@pytest.mark.parametrize("degree,nq,n,layers", [(1, 2, 3, 3), (2, 3, 2, 3), (3, 4, 2, 2), (2, 4, 2, 2), (3, 3, 1, 2), (5, 6, 1, 1)])
+def test_qk_action_template_on_the_host(degree, nq, n, layers):
+    """The action template for other degrees and quadrature sizes: index cubes of extent max(k+1, nq) (more Gauss points than
+    nodes per axis and fewer), 32 / 14 / 8 / 3 cells per workgroup."""
+    m = fmesh.make_extruded_hex_mesh(n, layers, degree, perturb=0.1)
+    prob = forms.HelmholtzHexProblem(m, nq=nq)
+    y = hostsim.run_tensor(prob.act_loop)[0]
+    ref = _oracle_action(m, prob.u.data_ro, prob.kact)
+    assert_allclose(y, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("degree,nq,bcs", [(1, 2, True), (2, 3, False), (2, 4, True), (3, 4, True)])
+def test_qk_mfma_matrix_template_on_the_host(degree, nq, bcs):
+    """The MFMA template for 1, 2 and 4 tiles per side (one, two and four wavefronts per workgroup), padded and exact.  (Q5 -- 14
+    tiles, seven workgroups of two wavefronts per cell -- takes a minute of barriers per cell here; it runs in the -m gpu suite.)"""
+    m = fmesh.make_extruded_hex_mesh(2 if degree < 3 else 1, 2, degree, perturb=0.1)
+    prob = forms.HelmholtzHexProblem(m, bcs=bcs, nq=nq)
+    csr = hostsim.run_tensor(prob.jac_loop)[0]
+    ref = _oracle_matrix(m, prob.bc_nodes if bcs else None, prob.kjac)
+    v = csr.values.copy()
+    if bcs:
+        rp, ci = csr.rowptr, csr.colidx
+        for b in prob.bc_nodes:
+            v[rp[b] + np.searchsorted(ci[rp[b]:rp[b + 1]], b)] = 1.0
+    assert_allclose(v, ref.values, rtol=0, atol=1e-12 * np.abs(ref.values).max())
