@@ -126,8 +126,9 @@ def tensor_form_info(cell, family, degree, quadrature_degree, terms, kind):
 
     Returns None when the form is not one the tensor wrappers cover (the loop then takes the ordinary wrappers)."""
     nq = int(quadrature_degree) // 2 + 1                   # Gauss-Legendre points per axis exact for that degree
+    from .codegen import tensor_geometry
     ok = (cell in ("hexahedron", "quadrilateral * interval", "TensorProductCell(quadrilateral, interval)") and family in ("Q", "CG", "Lagrange")
-          and int(degree) == 4 and nq == 5 and kind in ("matrix", "action") and set(terms) <= {"stiffness", "mass"})
+          and tensor_geometry(int(degree), nq) is not None and kind in ("matrix", "action") and set(terms) <= {"stiffness", "mass"})
     if not ok:
         return None
     return {"kind": kind, "degree": int(degree), "nq": nq, "alpha": float(terms.get("stiffness", 0.0)), "beta": float(terms.get("mass", 0.0))}
