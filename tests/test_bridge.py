@@ -274,7 +274,9 @@ def test_tensor_form_descriptor_selects_the_matrix_core_wrapper():
     from firedrake_amd.codegen import select_mode
     info = bridge.tensor_form_info("hexahedron", "Q", 4, 8, {"stiffness": 1.0, "mass": 1.0}, "matrix")
     assert info == {"kind": "matrix", "degree": 4, "nq": 5, "alpha": 1.0, "beta": 1.0}
-    assert bridge.tensor_form_info("hexahedron", "Q", 3, 8, {"stiffness": 1.0}, "matrix") is None          # only Q4 / 5 points
+    assert bridge.tensor_form_info("hexahedron", "Q", 3, 6, {"stiffness": 1.0}, "matrix") == \
+        {"kind": "matrix", "degree": 3, "nq": 4, "alpha": 1.0, "beta": 0.0}                                    # Q1..Q5 are instantiated
+    assert bridge.tensor_form_info("hexahedron", "Q", 6, 12, {"stiffness": 1.0}, "matrix") is None         # Q6: ordinary wrappers
     assert bridge.tensor_form_info("tetrahedron", "CG", 4, 8, {"stiffness": 1.0}, "matrix") is None
     assert bridge.tensor_form_info("hexahedron", "Q", 4, 8, {"advection": 1.0}, "matrix") is None
     dense = forms.helmholtz_q4_hex_jacobian_kernel()
