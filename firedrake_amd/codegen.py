@@ -416,7 +416,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
     def srow_table(info):
         """whole-entity owner-computes-rows, row map = column map: the per-node row words come from a plan-ordered table
         (fd_ocr_node_words) instead of per-node gathers of a row start and two lgmap entries"""
-        return bool(ocr and info["rm"] == info["cm"] and configuration["ocr_srow_table"])
+        return bool(ocr and info["rm"] == info["cm"])
 
     use_table = {}
     for info in infos:
@@ -537,7 +537,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 lds_items.append(("dat", mi, c, info["dtype"].itemsize, acc != READ))
                 lds_decl.append(f"{ct} *s{k} = ({ct} *)(fd_lds + fd_off); fd_off += (((size_t)p{mi}_maxnd*{c}*sizeof({ct})) + 15) & ~(size_t)15;")
                 if acc == READ:
-                    soa = bool(configuration["lds_soa"]) and c > 1
+                    soa = c > 1            # component-major LDS layout for vector Dats (conflict-free lane strides)
                     # a READ Dat that has not changed since an earlier call is also kept in PLAN order (one row per (block, staged
                     # node), Parloop._plan_copy): the staging phase then streams it instead of gathering rows by node id
                     P(f"const {ct} *__restrict__ pl{k}", ("plan_copy", k, mi))
@@ -997,7 +997,7 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             call_args.append(f"const_cast<{ct} *>(&arg{k}[(size_t)e*{info['c']}{off}])")
         else:
             c, ar, mi, perm = info["c"], info["ar"], info["m"], info["perm"]
-            soa = bool(configuration["lds_soa"]) and c > 1
+            soa = c > 1            # component-major LDS layout for vector Dats (conflict-free lane strides)
             lds_items.append(("dat", mi, c, info["dtype"].itemsize, False))
             lds_decl.append(f"{ct} *s{k} = ({ct} *)(fd_lds + fd_off); fd_off += (((size_t)p{mi}_maxnd*{c}*sizeof({ct})) + 15) & ~(size_t)15;")
             stage_nodes.setdefault(mi, []).append(
