@@ -205,3 +205,40 @@ def test_q4_hex_element_matrix_is_the_kronecker_product_of_exact_1d_matrices():
     verts = np.array([[x * a, y * b, z * c] for x in (0, 1) for y in (0, 1) for z in (0, 1)], dtype=float)   # v = 4x+2y+z
     A = _element_tensor(forms.helmholtz_q4_hex_jacobian_kernel(), 125, verts)
     assert_allclose(A, exact, atol=1e-12 * np.abs(exact).max())
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_simplex_rules_are_exact_to_their_degree_with_positive_interior_points(dim):
+    """forms.simplex_rule: every rule integrates all monomials up to its degree to rounding, has positive weights and points
+    strictly inside the simplex; the symmetric rules (6 points / degree 4 on the triangle, 14 points / degree 5 on the
+    tetrahedron -- solved from the moment equations at import) are smaller than the collapsed Gauss-Jacobi rules they replace."""
+    import math
+    for degree in range(1, 8):
+        pts, wts = forms.simplex_rule(dim, degree)
+        assert wts.min() > 0 and pts.min() > 0 and pts.sum(axis=1).max() < 1
+        for p in np.ndindex(*(degree + 1,) * dim):
+            if sum(p) <= degree:
+                exact = math.prod(math.factorial(e) for e in p) / math.factorial(sum(p) + dim)
+                assert abs((wts * np.prod(pts ** np.array(p), axis=1)).sum() - exact) < 2e-15
+    assert len(forms.simplex_rule(2, 4)[1]) == 6 and len(forms.simplex_rule(3, 4)[1]) == 14 == len(forms.simplex_rule(3, 5)[1])
+    assert len(forms.gauss_jacobi_simplex(3, 4)[1]) == 27
+
+
+@pytest.mark.parametrize("degree,nq", [(1, 2), (2, 3), (3, 4), (2, 4)])
+def test_qk_hex_element_matrix_rows_sum_to_the_mass_action(degree, nq):
+    """The dense Q_k Helmholtz kernel (the oracle's definition for the tensor wrappers of every degree): constants are in the
+    space, so A_e 1 = M_e 1 and 1^T A_e 1 = |cell|; symmetric."""
+    import oracle
+    from oracle import ODat, OMat, READ, INC
+    from firedrake_amd import mesh as fmesh
+    m = fmesh.make_extruded_hex_mesh(1, 1, degree, perturb=0.0)
+    k = forms.helmholtz_hex_jacobian_kernel(degree, nq)
+    nd = (degree + 1) ** 3
+    cm, xm = m.cell_node_map.values_with_halo, m.coord_map.values_with_halo
+    csr = oracle.build_sparsity(nd, nd, [(cm, cm, m.layers, m.cell_node_map.offset, m.cell_node_map.offset)])
+    oracle.par_loop(k.code, k.name, 0, 1, [OMat(csr, INC, cm, cm, roffset=m.cell_node_map.offset, coffset=m.cell_node_map.offset),
+                                           ODat(np.array(m.coordinates.data_ro_with_halos), READ, xm, offset=m.coord_map.offset)],
+                    layers=(0, m.layers + 1))
+    A = csr.toscipy().toarray()
+    assert abs(A - A.T).max() < 1e-14
+    assert abs(A.sum() - 1.0) < 1e-13
