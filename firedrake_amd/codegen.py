@@ -642,8 +642,17 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                     # nonzero, streamed).  (A row-by-row flush, 16 lanes per row with the row descriptors in LDS, issued 4x the
                     # LDS instructions and 1.5x the scalar ones for the same stores: +12 % LDS-pipe cycles in a kernel bound
                     # by that pipe, profiles/r3f_pmc_jacobian_lexicographic.txt.)
-                    flush.append((rm, f"if (oc{k}_flags & 1) {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)oc{k}_gpos[(size_t)r0_{k} + q]] = sm{k}[q]; }} "
-                                      f"else {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)oc{k}_gpos[(size_t)r0_{k} + q]] += sm{k}[q]; }}"))
+                    FU = max(1, int(configuration["flush_batch"]))
+                    if FU == 1:
+                        flush.append((rm, f"if (oc{k}_flags & 1) {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)oc{k}_gpos[(size_t)r0_{k} + q]] = sm{k}[q]; }} "
+                                          f"else {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)oc{k}_gpos[(size_t)r0_{k} + q]] += sm{k}[q]; }}"))
+                    else:
+                        # the place of an entry is a global load its store depends on: a trip of the loop costs a memory round trip.
+                        # FU places are requested together, then the FU stores go out
+                        flush.append((rm, f"for (int q0 = tid; q0 < nnzb{k}; q0 += {FU}*nthr) {{ int g{k}[{FU}]; "
+                                          f"for (int f = 0; f < {FU}; ++f) {{ const int q = q0 + f*nthr; g{k}[f] = q < nnzb{k} ? oc{k}_gpos[(size_t)r0_{k} + q] : -1; }} "
+                                          f"if (oc{k}_flags & 1) {{ for (int f = 0; f < {FU}; ++f) if (g{k}[f] >= 0) arg{k}[(size_t)g{k}[f]] = sm{k}[q0 + f*nthr]; }} "
+                                          f"else {{ for (int f = 0; f < {FU}; ++f) if (g{k}[f] >= 0) arg{k}[(size_t)g{k}[f]] += sm{k}[q0 + f*nthr]; }} }}"))
                     continue
                 # complete rows, contiguous in the CSR value array: plain coalesced stores
                 flush.append((rm, f"if (oc{k}_flags & 1) {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)r0_{k} + q] = sm{k}[q]; }} "
@@ -1115,11 +1124,22 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     src += ["  }", "  __syncthreads();"]
     if ordered:
         # (a per-entry flush table like the whole-entity wrapper's measured 8 % slower here: rows are ~28 entries long, profiles/r3t)
-        src.append(f"  for (int fr = tid >> 4; fr < nown; fr += nthr >> 4) {{ const int fp = n0 + fr; "
-                   f"const int fs = (oc{K}_rowptr[fp] - r0)*{B}, fl = (oc{K}_rowptr[fp+1] - oc{K}_rowptr[fp])*{B}; "
-                   f"const size_t fd_ = (size_t)oc{K}_gstart[fp]*{B}; "
-                   f"if (oc{K}_flags & 1) {{ for (int q = tid & 15; q < fl; q += 16) arg{K}[fd_ + q] = sm{K}[fs + q]; }} "
-                   f"else {{ for (int q = tid & 15; q < fl; q += 16) arg{K}[fd_ + q] += sm{K}[fs + q]; }} }}")
+        FU = max(1, int(configuration["flush_batch"]))
+        if FU == 1:
+            src.append(f"  for (int fr = tid >> 4; fr < nown; fr += nthr >> 4) {{ const int fp = n0 + fr; "
+                       f"const int fs = (oc{K}_rowptr[fp] - r0)*{B}, fl = (oc{K}_rowptr[fp+1] - oc{K}_rowptr[fp])*{B}; "
+                       f"const size_t fd_ = (size_t)oc{K}_gstart[fp]*{B}; "
+                       f"if (oc{K}_flags & 1) {{ for (int q = tid & 15; q < fl; q += 16) arg{K}[fd_ + q] = sm{K}[fs + q]; }} "
+                       f"else {{ for (int q = tid & 15; q < fl; q += 16) arg{K}[fd_ + q] += sm{K}[fs + q]; }} }}")
+        else:
+            # 16 lanes per row; the row's start / length / place are global loads the stores depend on, so a trip costs a memory
+            # round trip: the tables of FU rows are requested together before any of them is flushed
+            src.append(f"  for (int fr0 = tid >> 4; fr0 < nown; fr0 += {FU}*(nthr >> 4)) {{ int fs[{FU}], fl[{FU}]; size_t fd_[{FU}]; "
+                       f"for (int f = 0; f < {FU}; ++f) {{ const int fr = fr0 + f*(nthr >> 4); const int fp = n0 + (fr < nown ? fr : 0); "
+                       f"const int a = oc{K}_rowptr[fp], b_ = oc{K}_rowptr[fp+1]; fs[f] = (a - r0)*{B}; fl[f] = fr < nown ? (b_ - a)*{B} : 0; "
+                       f"fd_[f] = (size_t)oc{K}_gstart[fp]*{B}; }} "
+                       f"if (oc{K}_flags & 1) {{ for (int f = 0; f < {FU}; ++f) for (int q = tid & 15; q < fl[f]; q += 16) arg{K}[fd_[f] + q] = sm{K}[fs[f] + q]; }} "
+                       f"else {{ for (int f = 0; f < {FU}; ++f) for (int q = tid & 15; q < fl[f]; q += 16) arg{K}[fd_[f] + q] += sm{K}[fs[f] + q]; }} }}")
     else:
         src.append(f"  if (oc{K}_flags & 1) {{ for (int q = tid; q < nnzb; q += nthr) arg{K}[(size_t)r0*{B} + q] = sm{K}[q]; }} "
                    f"else {{ for (int q = tid; q < nnzb; q += nthr) arg{K}[(size_t)r0*{B} + q] += sm{K}[q]; }}")

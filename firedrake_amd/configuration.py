@@ -21,6 +21,7 @@ configuration = {
     "mode": _env("FDHIP_MODE", "auto"),                 # auto | staged | direct
     "block_threads": _env("FDHIP_BLOCK_THREADS", 0, int),
     "ents_per_block": _env("FDHIP_ENTS_PER_BLOCK", 1024, int),
+    "flush_batch": _env("FDHIP_FLUSH_BATCH", 4, int),      # flushes through index tables (derived row orders): table loads requested per trip
     "plan_copies": _env("FDHIP_PLAN_COPIES", 1, int),     # READ Dats unchanged between calls are kept in plan order and streamed
     "ocr_pack": _env("FDHIP_OCR_PACK", 1, int),            # bank-aware greedy packing of the instance lists (fd_ocrplan_pack)
     "ocr_lds_limit": _env("FDHIP_OCR_LDS_LIMIT", 0, int),  # 0 = auto (whole CU for large element matrices)
