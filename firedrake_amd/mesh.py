@@ -200,26 +200,22 @@ def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0,
         (oown, oloc) = node_boxes(p, rc)
         lo = tuple(b[0] for b in oloc)
         L = tuple(b[1] - b[0] for b in oloc)           # local lattice planes per axis
-        # integer (doubled for p=2) coordinates of the 4 vertices of every cell
-        cx = (ii[:, None] + _CORNER[:, 0][None, :])            # (ncube, 8)
-        cy = (jj[:, None] + _CORNER[:, 1][None, :])
-        cz = (kk[:, None] + _CORNER[:, 2][None, :])
-        vx, vy, vz = cx[:, _TETS], cy[:, _TETS], cz[:, _TETS]  # (ncube, 6, 4)
-        if p == 1:
-            nxs, nys, nzs = vx, vy, vz
-        else:
-            ex = vx[..., _TET_EDGES[:, 0]] + vx[..., _TET_EDGES[:, 1]]
-            ey = vy[..., _TET_EDGES[:, 0]] + vy[..., _TET_EDGES[:, 1]]
-            ez = vz[..., _TET_EDGES[:, 0]] + vz[..., _TET_EDGES[:, 1]]
-            nxs = np.concatenate([2 * vx, ex], axis=-1)
-            nys = np.concatenate([2 * vy, ey], axis=-1)
-            nzs = np.concatenate([2 * vz, ez], axis=-1)
-        arity = nxs.shape[-1]
-
+        # index of a lattice point inside the local box is affine in its coordinates, so it is computed once per CUBE CORNER and
+        # carried to the cells through the tetrahedron table: a CG2 vertex node sits at twice the vertex, an edge node at the sum
+        # of its two vertices (coordinates in units of 1/(p n))
         def box_index(x, y, z):
             """index of global lattice point (x, y, z) inside the local lattice box"""
             return ((np.asarray(z, dtype=np.int64) - lo[2]) * L[1] + (y - lo[1])) * L[0] + (x - lo[0])
-        box = box_index(nxs, nys, nzs).reshape(ncube * 6, arity)
+        lin = ((kk.astype(np.int64)[:, None] + _CORNER[:, 2][None, :]) * L[1] + (jj[:, None] + _CORNER[:, 1][None, :])) * L[0] \
+            + (ii[:, None] + _CORNER[:, 0][None, :])                          # (ncube, 8): z L1 L0 + y L0 + x of every corner
+        shift = (lo[2] * L[1] + lo[1]) * L[0] + lo[0]
+        vlin = lin[:, _TETS]                                                    # (ncube, 6, 4)
+        if p == 1:
+            box = vlin - shift
+        else:
+            box = np.concatenate([2 * vlin, vlin[..., _TET_EDGES[:, 0]] + vlin[..., _TET_EDGES[:, 1]]], axis=-1) - shift
+        arity = box.shape[-1]
+        box = box.reshape(ncube * 6, arity)
         # ---- number the lattice nodes of the box: class, then tile traversal order
         zz, yy, xx = np.meshgrid(np.arange(oloc[2][0], oloc[2][1], dtype=np.int32), np.arange(oloc[1][0], oloc[1][1], dtype=np.int32),
                                  np.arange(oloc[0][0], oloc[0][1], dtype=np.int32), indexing="ij")
@@ -241,11 +237,12 @@ def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0,
         if numbering == "lexicographic":
             # first appearance in the cell traversal (vertices of a cell before its edge nodes, as the closure walk
             # of dmcommon.pyx:2688-2712 meets them); lattice points no local cell touches keep the grid order, last
-            first = np.full(len(xx), np.iinfo(np.int64).max, dtype=np.int64)
             flat = box.reshape(-1)
+            ptype = np.int32 if len(flat) < (1 << 31) - 1 else np.int64
+            first = np.full(len(xx), np.iinfo(ptype).max, dtype=ptype)
             # first occurrence of every node: assign positions in REVERSE order, the last write (= earliest position) stays
-            first[flat[::-1]] = np.arange(len(flat) - 1, -1, -1, dtype=np.int64)
-            nkey = ncls.astype(np.int64) * (1 << 50) + np.minimum(first, (1 << 49))
+            first[flat[::-1]] = np.arange(len(flat) - 1, -1, -1, dtype=ptype)
+            nkey = ncls.astype(np.int64) * (1 << 50) + np.where(first == np.iinfo(ptype).max, 1 << 49, first.astype(np.int64))
             nkey = nkey * 2                        # keep "key // 8 // tile volume" below meaningful only for "tiled"
         elif numbering == "random":
             nkey = ncls.astype(np.int64) * (1 << 50) + np.random.default_rng(seed + 7 + 1000 * rank + p).permutation(len(xx))
