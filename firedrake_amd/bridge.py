@@ -121,17 +121,22 @@ def tensor_form_info(cell, family, degree, quadrature_degree, terms, kind):
     ``cell``, ``family``, ``degree``   ``V.ufl_element()``: cellname, family and degree of the (test = trial) space
     ``quadrature_degree``              the integral's ``metadata["quadrature_degree"]`` / TSFC's estimate (tsfc/driver.py)
     ``terms``                          the integrand as a sum of second-order terms with constant coefficients:
-                                       ``{"stiffness": alpha, "mass": beta}`` for alpha*inner(grad u, grad v) + beta*inner(u, v)
+                                       ``{"stiffness": alpha, "mass": beta, "advection": (bx, by, bz)}`` for
+                                       alpha*inner(grad u, grad v) + inner(dot(b, grad u), v) + beta*inner(u, v)
     ``kind``                           "matrix" for a 2-form, "action" for action(a, u) / a 1-form linear in one coefficient
 
     Returns None when the form is not one the tensor wrappers cover (the loop then takes the ordinary wrappers)."""
     nq = int(quadrature_degree) // 2 + 1                   # Gauss-Legendre points per axis exact for that degree
     from .codegen import tensor_geometry
     ok = (cell in ("hexahedron", "quadrilateral * interval", "TensorProductCell(quadrilateral, interval)") and family in ("Q", "CG", "Lagrange")
-          and tensor_geometry(int(degree), nq) is not None and kind in ("matrix", "action") and set(terms) <= {"stiffness", "mass"})
+          and tensor_geometry(int(degree), nq) is not None and kind in ("matrix", "action")
+          and set(terms) <= {"stiffness", "mass", "advection"})
     if not ok:
         return None
-    return {"kind": kind, "degree": int(degree), "nq": nq, "alpha": float(terms.get("stiffness", 0.0)), "beta": float(terms.get("mass", 0.0))}
+    info = {"kind": kind, "degree": int(degree), "nq": nq, "alpha": float(terms.get("stiffness", 0.0)), "beta": float(terms.get("mass", 0.0))}
+    if "advection" in terms:
+        info["velocity"] = tuple(float(v) for v in terms["advection"])
+    return info
 
 
 def tensor_product_local_kernel(code, name, accesses, dtypes, info, **kw):
@@ -140,7 +145,8 @@ def tensor_product_local_kernel(code, name, accesses, dtypes, info, **kw):
     from .tensor import second_order_weights
     kw.setdefault("requires_zeroed_output_arguments", True)
     return K.TensorProductLocalKernel(code, name, accesses, dtypes, kind=info["kind"], degree=info["degree"], nq=info["nq"],
-                                      weights_code=second_order_weights(name, info["alpha"], info["beta"]), **kw)
+                                      weights_code=second_order_weights(name, info["alpha"], info["beta"], info.get("velocity", (0.0, 0.0, 0.0))),
+                                      **kw)
 
 
 def as_fd_global_kernel(gk):

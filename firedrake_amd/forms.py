@@ -529,6 +529,15 @@ def precompile_all():
                         continue
                     src = generate_wrapper(g, mode)
                     out.append(compile_hip(src.source, src.symbol))
+    # config C3: the tensor-product wrappers of the Q4 Helmholtz operator (matrix with and without BC lgmaps, action)
+    from . import mesh as fmesh
+    from .codegen import generate_tensor_wrapper
+    hm = fmesh.make_extruded_hex_mesh(1, 1, 4, perturb=0.0)
+    for bcs in (False, True):
+        prob = HelmholtzQ4Problem(hm, bcs=bcs)
+        for loop in (prob.jac_loop, prob.act_loop):
+            src = generate_tensor_wrapper(loop.global_kernel)
+            out.append(compile_hip(src.source, src.symbol))
     return out
 
 
@@ -541,10 +550,11 @@ def q4_tables(degree=4, nq=5):
     return gll_gauss_tables(degree, nq)
 
 
-def helmholtz_hex_jacobian_kernel(degree=4, nq=None, name=None, alpha=1.0, beta=1.0):
-    """a(u, v) = int alpha grad(u).grad(v) + beta u v dx on a trilinear hexahedron with the Q_degree basis and nq^3 Gauss points
-    (default nq = degree + 1: dx(degree=2*degree)); alpha = beta = 1 is the Helmholtz operator of config C3,
-    (0, 1) the mass form.  Arguments: A[nd*nd], coords[8*3] (Q1 vertices, index a*4 + b*2 + c), nd = (degree+1)^3.
+def helmholtz_hex_jacobian_kernel(degree=4, nq=None, name=None, alpha=1.0, beta=1.0, velocity=(0.0, 0.0, 0.0)):
+    """a(u, v) = int alpha grad(u).grad(v) + (b.grad(u)) v + beta u v dx on a trilinear hexahedron with the Q_degree basis and nq^3
+    Gauss points (default nq = degree + 1: dx(degree=2*degree)); alpha = beta = 1, b = 0 is the Helmholtz operator of
+    config C3, (0, 1) the mass form, a non-zero ``velocity`` b a (non-symmetric) convection-diffusion-reaction operator.
+    Arguments: A[nd*nd] (row = test function), coords[8*3] (Q1 vertices, index a*4 + b*2 + c), nd = (degree+1)^3.
     Dense formulation (what the MFMA kernel computes); used as the oracle's local kernel."""
     k1 = degree + 1
     nq = nq or k1
@@ -578,6 +588,9 @@ static void {name}(double *restrict A, const double *restrict x)
     double G[3][3];
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b)
       G[a][b] = w * (K[a][0]*K[b][0] + K[a][1]*K[b][1] + K[a][2]*K[b][2]);
+    const double bv[3] = {{{float(velocity[0])!r}, {float(velocity[1])!r}, {float(velocity[2])!r}}};
+    double cb[3];                       /* K b: the velocity in reference coordinates */
+    for (int a = 0; a < 3; ++a) cb[a] = K[a][0]*bv[0] + K[a][1]*bv[1] + K[a][2]*bv[2];
     double ph[{nd}], dp[{nd}][3];
     for (int i1 = 0; i1 < {k1}; ++i1) for (int i2 = 0; i2 < {k1}; ++i2) for (int i3 = 0; i3 < {k1}; ++i3) {{
       const int i = (i1*{k1} + i2)*{k1} + i3;
@@ -592,17 +605,18 @@ static void {name}(double *restrict A, const double *restrict x)
       const double t2 = G[2][0]*dp[i][0] + G[2][1]*dp[i][1] + G[2][2]*dp[i][2];
       const double tm = w * ph[i];
       for (int j = 0; j < {nd}; ++j)
-        A[i*{nd} + j] += {float(alpha)!r}*(t0*dp[j][0] + t1*dp[j][1] + t2*dp[j][2]) + {float(beta)!r}*tm*ph[j];
+        A[i*{nd} + j] += {float(alpha)!r}*(t0*dp[j][0] + t1*dp[j][1] + t2*dp[j][2]) + {float(beta)!r}*tm*ph[j]
+                         + tm*(cb[0]*dp[j][0] + cb[1]*dp[j][1] + cb[2]*dp[j][2]);
     }}
   }}
 }}
 """
     from .kernel import TensorProductLocalKernel
     from .tensor import second_order_weights
-    return TensorProductLocalKernel(body, name, kind="matrix", degree=degree, nq=nq, weights_code=second_order_weights(name, alpha, beta))
+    return TensorProductLocalKernel(body, name, kind="matrix", degree=degree, nq=nq, weights_code=second_order_weights(name, alpha, beta, velocity))
 
 
-def helmholtz_hex_action_kernel(degree=4, nq=None, name=None, alpha=1.0, beta=1.0):
+def helmholtz_hex_action_kernel(degree=4, nq=None, name=None, alpha=1.0, beta=1.0, velocity=(0.0, 0.0, 0.0)):
     """y += A_e(coords) u: the action of the same bilinear form on a coefficient (the matrix-free operator application of
     tests/firedrake/regression/test_matrix_free.py, and the Q4 "residual/action" of SURVEY.md 8d).  Arguments: y[nd],
     coords[24], u[nd].  The C text is the dense definition (element matrix times element vector) the oracle executes; the
@@ -612,7 +626,7 @@ def helmholtz_hex_action_kernel(degree=4, nq=None, name=None, alpha=1.0, beta=1.
     nq = nq or degree + 1
     nd = (degree + 1) ** 3
     name = name or f"helmholtz_q{degree}_hex_action"
-    jac = helmholtz_hex_jacobian_kernel(degree, nq, name + "_matrix", alpha, beta)
+    jac = helmholtz_hex_jacobian_kernel(degree, nq, name + "_matrix", alpha, beta, velocity)
     body = jac.code + f"""
 static void {name}(double *restrict y, const double *restrict x, const double *restrict u)
 {{
@@ -626,7 +640,7 @@ static void {name}(double *restrict y, const double *restrict x, const double *r
   }}
 }}
 """
-    return TensorProductLocalKernel(body, name, kind="action", degree=degree, nq=nq, weights_code=second_order_weights(name, alpha, beta))
+    return TensorProductLocalKernel(body, name, kind="action", degree=degree, nq=nq, weights_code=second_order_weights(name, alpha, beta, velocity))
 
 
 def helmholtz_q4_hex_jacobian_kernel(name="helmholtz_q4_hex_jacobian", alpha=1.0, beta=1.0):
@@ -644,7 +658,7 @@ class HelmholtzHexProblem:
     are TensorProductLocalKernels: ``GlobalKernel.compile`` picks the fp64-MFMA matrix wrapper and the sum-factorised
     action wrapper of csrc/fd_tensor.h.  Plays ExplicitMatrixAssembler / OneFormAssembler like PoissonProblem."""
 
-    def __init__(self, hexmesh, bcs=False, nq=None):
+    def __init__(self, hexmesh, bcs=False, nq=None, alpha=1.0, beta=1.0, velocity=(0.0, 0.0, 0.0)):
         self.mesh = m = hexmesh
         nd, nqp = (m.degree + 1) ** 3, (nq or m.degree + 1) ** 3
         pad = -(-nd // 16) * 16
@@ -661,7 +675,8 @@ class HelmholtzHexProblem:
             rlg = np.arange(m.node_set.total_size, dtype=np.int32)
             rlg[self.bc_nodes] = -1
             lg = (rlg, rlg.copy())
-        self.kjac, self.kact = helmholtz_hex_jacobian_kernel(m.degree, nq), helmholtz_hex_action_kernel(m.degree, nq)
+        self.kjac = helmholtz_hex_jacobian_kernel(m.degree, nq, None, alpha, beta, velocity)
+        self.kact = helmholtz_hex_action_kernel(m.degree, nq, None, alpha, beta, velocity)
         self.jac_loop = op2.LegacyParloop(self.kjac, m.cell_set, self.mat(op2.INC, (cm, cm), lgmaps=lg), m.coordinates(op2.READ, xm))
         self.u = op2.Dat(m.node_set, np.sin(3 * pts[:, 0]) * np.cos(2 * pts[:, 1]) + 0.3 * pts[:, 2], np.float64, "u")
         self.y = op2.Dat(m.node_set, None, np.float64, "y")

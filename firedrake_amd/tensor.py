@@ -38,25 +38,31 @@ def gll_gauss_tables(degree=4, nq=5):
     return L, DL, x, w
 
 
-# the Helmholtz point weight: a(u, v) = int grad(u).grad(v) + u v dx  ->  W = [ w|J| K K^T  0 ; 0  w|J| ],  K = J^-1
-HELMHOLTZ_WEIGHTS = """
+# the point weight of a(u, v) = int alpha grad(u).grad(v) + (b.grad(u)) v + beta u v dx with constant alpha, b, beta:
+#     W = w|J| [ alpha K K^T   0 ;  (K b)^T   beta ],   K = J^-1  (K[a][r] = d xi_a / d x_r)
+# row l couples component l of the TEST side (d/dxi_1..3, value), column k component k of the TRIAL side; the advection term makes
+# W non-symmetric (value of v against the reference gradient of u)
+SECOND_ORDER_WEIGHTS = """
 static inline void NAME_weights(const double J[3][3], const double X[3], double wq, double W[16])
 {
   double K[3][3], det;
   fdt::inv3(J, K, det);
   const double w = wq * fabs(det);
+  const double bv[3] = {BX, BY, BZ};
   for (int a = 0; a < 3; ++a) {
-    for (int b = 0; b < 3; ++b) W[a*4 + b] = w * (K[a][0]*K[b][0] + K[a][1]*K[b][1] + K[a][2]*K[b][2]);
-    W[a*4 + 3] = 0.0; W[12 + a] = 0.0;
+    for (int b = 0; b < 3; ++b) W[a*4 + b] = ALPHA * w * (K[a][0]*K[b][0] + K[a][1]*K[b][1] + K[a][2]*K[b][2]);
+    W[a*4 + 3] = 0.0;
+    W[12 + a] = w * (K[a][0]*bv[0] + K[a][1]*bv[1] + K[a][2]*bv[2]);
   }
-  W[15] = w;
+  W[15] = BETA * w;
   (void)X;
 }
 """
 
 
-def second_order_weights(name, alpha=1.0, beta=1.0):
-    """``weights_code`` of a(u, v) = int alpha grad(u).grad(v) + beta u v dx: W = w|J| [ alpha K K^T  0 ; 0  beta ]."""
-    return (HELMHOLTZ_WEIGHTS.replace("NAME", name)
-            .replace("W[a*4 + b] = w * (", f"W[a*4 + b] = {float(alpha)!r} * w * (")
-            .replace("W[15] = w;", f"W[15] = {float(beta)!r} * w;"))
+def second_order_weights(name, alpha=1.0, beta=1.0, velocity=(0.0, 0.0, 0.0)):
+    """``weights_code`` of a(u, v) = int alpha grad(u).grad(v) + (b.grad(u)) v + beta u v dx, b = ``velocity``."""
+    out = SECOND_ORDER_WEIGHTS.replace("NAME", name).replace("ALPHA", repr(float(alpha))).replace("BETA", repr(float(beta)))
+    for tag, v in zip(("BX", "BY", "BZ"), velocity):
+        out = out.replace(tag, repr(float(v)))
+    return out

@@ -278,7 +278,9 @@ def test_tensor_form_descriptor_selects_the_matrix_core_wrapper():
         {"kind": "matrix", "degree": 3, "nq": 4, "alpha": 1.0, "beta": 0.0}                                    # Q1..Q5 are instantiated
     assert bridge.tensor_form_info("hexahedron", "Q", 6, 12, {"stiffness": 1.0}, "matrix") is None         # Q6: ordinary wrappers
     assert bridge.tensor_form_info("tetrahedron", "CG", 4, 8, {"stiffness": 1.0}, "matrix") is None
-    assert bridge.tensor_form_info("hexahedron", "Q", 4, 8, {"advection": 1.0}, "matrix") is None
+    assert bridge.tensor_form_info("hexahedron", "Q", 4, 8, {"curlcurl": 1.0}, "matrix") is None           # not a term of the descriptor
+    adv = bridge.tensor_form_info("hexahedron", "Q", 2, 4, {"stiffness": 0.5, "advection": (1.0, 0.0, -1.0)}, "action")
+    assert adv == {"kind": "action", "degree": 2, "nq": 3, "alpha": 0.5, "beta": 0.0, "velocity": (1.0, 0.0, -1.0)}
     dense = forms.helmholtz_q4_hex_jacobian_kernel()
     q4, q1 = MapKernelArg(arity=125, offset=(4,) * 125), MapKernelArg(arity=8, offset=(1,) * 8)
     lk = CStringLocalKernel(code=dense.code, name=dense.name, accesses=(4, 1), dtypes=(np.float64,) * 2, requires_zeroed_output_arguments=True)

@@ -273,3 +273,23 @@ def test_qk_tensor_wrappers_match_the_oracle(degree, nq, n, layers):
     t = op2.Dat(m.node_set)
     free.assemble_jacobian().mult(free.u, t)
     assert_allclose(t.data_ro, y, rtol=0, atol=1e-11 * np.abs(yref).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("degree,nq", [(2, 3), (4, 5)])
+def test_convection_diffusion_reaction_through_the_tensor_wrappers(degree, nq):
+    """Non-symmetric point weights (alpha grad u . grad v + (b . grad u) v + beta u v) through the MFMA matrix and the
+    sum-factorised action against the oracle's dense kernel."""
+    from firedrake_amd import op2
+    m = fmesh.make_extruded_hex_mesh(3, 3, degree, perturb=0.1)
+    prob = forms.HelmholtzHexProblem(m, nq=nq, alpha=0.7, beta=1.3, velocity=(1.0, -2.0, 0.5))
+    assert (prob.jac_loop._prepare()["cw"].src.mode, prob.act_loop._prepare()["cw"].src.mode) == ("tp_matrix", "tp_action")
+    mat = prob.assemble_jacobian()
+    ref = _oracle_matrix(m, None, prob.kjac)
+    assert_allclose(mat.csr()[2], ref.values, rtol=0, atol=1e-11 * np.abs(ref.values).max())
+    y = np.array(prob.assemble_action().data_ro)
+    yref = _oracle_action(m, prob.u.data_ro, prob.kact)
+    assert_allclose(y, yref, rtol=0, atol=1e-11 * np.abs(yref).max())
+    t = op2.Dat(m.node_set)
+    mat.mult(prob.u, t)
+    assert_allclose(t.data_ro, y, rtol=0, atol=1e-11 * np.abs(yref).max())

@@ -62,3 +62,20 @@ def test_qk_mfma_matrix_template_on_the_host(degree, nq, bcs):
         for b in prob.bc_nodes:
             v[rp[b] + np.searchsorted(ci[rp[b]:rp[b + 1]], b)] = 1.0
     assert_allclose(v, ref.values, rtol=0, atol=1e-12 * np.abs(ref.values).max())
+
+
+@pytest.mark.parametrize("degree,nq", [(2, 3), (3, 4)])
+def test_convection_diffusion_reaction_weights_on_the_host(degree, nq):
+    """A non-symmetric point weight (alpha grad u . grad v + (b . grad u) v + beta u v): the MFMA template's A operand is
+    Phi^T W, the action applies W between the forward and the transposed passes -- both must keep rows and columns apart."""
+    m = fmesh.make_extruded_hex_mesh(1, 2, degree, perturb=0.1)
+    prob = forms.HelmholtzHexProblem(m, nq=nq, alpha=0.7, beta=1.3, velocity=(1.0, -2.0, 0.5))
+    csr = hostsim.run_tensor(prob.jac_loop)[0]
+    ref = _oracle_matrix(m, None, prob.kjac)
+    assert_allclose(csr.values, ref.values, rtol=0, atol=1e-12 * np.abs(ref.values).max())
+    A = ref.toscipy()
+    assert abs(A - A.T).max() > 1e-3 * abs(A).max()              # genuinely non-symmetric
+    y = hostsim.run_tensor(prob.act_loop)[0]
+    yref = _oracle_action(m, prob.u.data_ro, prob.kact)
+    assert_allclose(y, yref, rtol=0, atol=1e-12 * np.abs(yref).max())
+    assert_allclose(y, A @ np.asarray(prob.u.data_ro), rtol=0, atol=1e-11 * np.abs(yref).max())
