@@ -78,11 +78,12 @@ def helmholtz_simplex(backend, dim, degree, n):
     return float(np.sqrt(e @ (_matrix(backend, M) @ e)))
 
 
-def helmholtz_q4_hex(backend, n):
+def helmholtz_hex(backend, degree, n):
     """The extruded-hexahedra Helmholtz problem (test_helmholtz_scalar.py:8-33: ExtrudedMesh(UnitSquareMesh(n, n,
-    quadrilateral=True), n), f and the exact solution interpolated into the space) with the Q4 element of config C3: the
-    operator through the fp64-MFMA matrix wrapper, right-hand side and error norm through the sum-factorised MASS action."""
-    m = fmesh.make_extruded_hex_mesh(n, n, 4, perturb=0.0)
+    quadrilateral=True), n), CG_degree x CG_degree, f and the exact solution interpolated into the space): the operator through
+    the fp64-MFMA matrix wrapper, right-hand side and error norm through the sum-factorised MASS action (degree + 1 Gauss
+    points per axis: exact for the mass form on an affine cell)."""
+    m = fmesh.make_extruded_hex_mesh(n, n, degree, perturb=0.0)
     cm, xm = m.cell_node_map, m.coord_map
     p = m.node_points
     expect = np.cos(2 * np.pi * p[:, 0]) * np.cos(2 * np.pi * p[:, 1]) * np.cos(2 * np.pi * p[:, 2])
@@ -90,14 +91,19 @@ def helmholtz_q4_hex(backend, n):
     b = op2.Dat(m.node_set)
     sp = op2.Sparsity((m.node_set ** 1, m.node_set ** 1), [(cm, cm, None)])
     A = op2.Mat(sp)
-    _run(backend, forms.helmholtz_q4_hex_jacobian_kernel(), m.cell_set, A(op2.INC, (cm, cm)), m.coordinates(op2.READ, xm))
-    kmass = forms.helmholtz_q4_hex_action_kernel("mass_q4_hex_action", 0.0, 1.0)
+    _run(backend, forms.helmholtz_hex_jacobian_kernel(degree), m.cell_set, A(op2.INC, (cm, cm)), m.coordinates(op2.READ, xm))
+    kmass = forms.helmholtz_hex_action_kernel(degree, None, f"mass_q{degree}_hex_action", 0.0, 1.0)
     _run(backend, kmass, m.cell_set, b(op2.INC, cm), m.coordinates(op2.READ, xm), f(op2.READ, cm))
     sol = _solve(backend, A, b)
     e = op2.Dat(m.node_set, sol - expect)
     Me = op2.Dat(m.node_set)
     _run(backend, kmass, m.cell_set, Me(op2.INC, cm), m.coordinates(op2.READ, xm), e(op2.READ, cm))
     return float(np.sqrt(np.array(e.data_ro) @ np.array(Me.data_ro)))
+
+
+def helmholtz_q4_hex(backend, n):
+    """Config C3's element on that problem."""
+    return helmholtz_hex(backend, 4, n)
 
 
 def poisson_strong_bcs(backend, degree, r=2, newton=False):

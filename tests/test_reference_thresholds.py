@@ -54,6 +54,19 @@ def test_helmholtz_tetrahedra(backend, degree):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("degree", [1, 2, 3])
+def test_helmholtz_extruded_hexahedra(backend, degree):
+    """test_helmholtz_scalar.py:8-33 with quadrilateral=True AS WRITTEN: CG_k x CG_k on extruded hexahedra, k = 1, 2, 3, on the
+    reference's refinements and against the reference's orders (1.9 / 2.9 / 3.9) -- through the tensor-product wrappers of every
+    degree (fp64-MFMA matrix with 1, 2 and 4 tiles per side, sum-factorised mass action) on the GPU, through the dense kernels on
+    the oracle."""
+    case = next(c for c in THR["helmholtz_extruded"]["cases"] if c["degree"] == degree)
+    errs = [rp.helmholtz_hex(backend, degree, 2 ** r) for r in case["refinements"]]
+    conv = _orders(errs)
+    assert (conv > case["min_order"]).all(), (errs, conv)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_helmholtz_q4_hexahedra(backend):
     """Config C3's element (Q4 on extruded hexahedra, 5^3 Gauss points) on the problem of test_helmholtz_scalar.py:8-33,
     against the order the reference asserts for degree 4 on tensor-product cells (test_helmholtz.py:73-83: > 4.7 between
