@@ -9,6 +9,7 @@ the passes every LDS instruction of the main loop needs.  It is a design aid for
 compared here before any of them is written as a device kernel.
 
     python tools/lds_sim.py [n] [variant ...]        n = cubes per axis (default 24); variants: natural stencil packed ...
+    python tools/lds_sim.py n layouts                 accumulator-row layouts other than the CSR order (profiles/r3w_lds_sim.txt)
 """
 import os
 import sys
@@ -205,9 +206,6 @@ def main():
               f"model cycles {r['model_cycles'] / 1e6:.2f} M (floor {r['model_cycles_min'] / 1e6:.2f} M)  [{time.time() - t0:.1f} s]")
 
 
-if __name__ == "__main__":
-    main()
-
 
 # ---- experiments with the LDS LAYOUT of the accumulator rows (possible wherever the flush goes through a per-entry table) -------------
 def relayout(p, base_of_row):
@@ -266,3 +264,55 @@ def greedy_residues(p, order, nres=16, window=WINDOW, nthr=NTHR):
                             used.setdefault((w, ii * 4 + j), set()).add((rho + cp[j]) % nres)
         sizes.append(sum(x[1] for x in seq))
     return base, np.array(sizes)
+
+
+def layout_experiments(p):
+    """The layouts of profiles/r3w_lds_sim.txt on the hinted plan (interior tiles are 8 x 8 x 4 nodes in lexicographic order):
+    the rows every kind of fully owned cell can anchor at first; the exact linear residue -(x + 7 y + 49 z) mod 16 reached by
+    padding; the greedy residue assignment."""
+    rb, nn = p["rb"], len(p["rowlen"])
+    blk = np.searchsorted(rb, np.arange(nn), side="right") - 1
+    loc = np.arange(nn) - rb[blk]
+    x, y, z = loc % 8, (loc // 8) % 8, loc // 64
+    full = (rb[blk + 1] - rb[blk]) == 256
+    far = ((x == 7) | (y == 7) | (z == 3)) & full
+    order = stencil(p)
+
+    def show(name, q):
+        for sched, o in (("stencil", order), ("packed", pack_greedy(q, order))):
+            r = simulate(q, o)
+            print(f"{name:28s} {sched:8s} atomics {r['atomic_passes'] / r['atomic_min']:.3f}x  gathers {r['gather_passes'] / r['gather_min']:.3f}x  "
+                  f"model cycles {r['model_cycles'] / 1e6:.3f} M")
+
+    show("CSR layout", p)
+    base = np.zeros(nn, dtype=np.int64)
+    lin = np.zeros(nn, dtype=np.int64)
+    padded = unpadded = 0
+    for b in range(len(rb) - 1):
+        r = np.arange(rb[b], rb[b + 1])
+        o = r[np.argsort(far[r].astype(int), kind="stable")]
+        base[o] = np.concatenate([[0], np.cumsum(p["rowlen"][o])[:-1]])
+        if not full[r[0]]:
+            lin[o] = base[o]
+            continue
+        want = (-(x[o] + 7 * y[o] + 49 * z[o])) % 16
+        cur = 0
+        for k, node in enumerate(o):
+            cur += (want[k] - cur) % 16
+            lin[node] = cur
+            cur += p["rowlen"][node]
+        padded += cur
+        unpadded += p["rowlen"][o].sum()
+    show("anchor rows first", relayout(p, base))
+    print(f"(linear residues: {padded / max(unpadded, 1):.3f}x the LDS of the full tiles)")
+    show("linear residues, padded", relayout(p, lin))
+    gbase, sizes = greedy_residues(p, order)
+    print(f"(greedy residues: {sizes.sum() / p['rowlen'][np.unique(p['rows'][p['own']])].sum():.3f}x the LDS)")
+    show("greedy residues, padded", relayout(p, gbase))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "layouts":
+        layout_experiments(build_plan(int(sys.argv[1])))
+    else:
+        main()
