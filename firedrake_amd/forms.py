@@ -75,31 +75,47 @@ def _orbit_points(dim, orbits):
     return pts
 
 
+# orbit parameters (a, weight) of the symmetric rules below: the solution of the moment equations (solve_symmetric_rule), written out
+# so that every machine generates the same kernel text -- the JIT cache is keyed on it
+_SYMMETRIC_RULES = {
+    2: (("v", "v"), (0.09157621350977267, 0.05497587182766015, 0.44594849091596767, 0.11169079483900653)),
+    3: (("v", "v", "e"), (0.09273525031089183, 0.012248840519393862, 0.31088591926330167, 0.018781320953003302,
+                          0.04550370412564618, 0.0070910034628463275)),
+}
+
+
+def _symmetric_rule_from(dim, x):
+    kinds = _SYMMETRIC_RULES[dim][0]
+    orbits = _orbit_points(dim, [(k, x[2 * i]) for i, k in enumerate(kinds)])
+    return np.concatenate(orbits), np.concatenate([np.full(len(o), x[2 * i + 1]) for i, o in enumerate(orbits)])
+
+
+def _moment_residual(dim, deg, pts, wts):
+    import math
+    powers = [p for p in np.ndindex(*(deg + 1,) * dim) if sum(p) <= deg]
+    exact = np.array([math.prod(math.factorial(e) for e in p) / math.factorial(sum(p) + dim) for p in powers])
+    return np.array([(wts * np.prod(pts ** np.array(p), axis=1)).sum() for p in powers]) - exact
+
+
+def solve_symmetric_rule(dim):
+    """The orbit parameters of ``symmetric_simplex_rule`` from three-digit starting values: Gauss-Newton on the moment equations of
+    degree 4 (triangle) / 5 (tetrahedron).  Kept as the derivation of ``_SYMMETRIC_RULES`` (tests/test_forms_identities.py)."""
+    from scipy.optimize import least_squares
+    deg = 4 if dim == 2 else 5
+    x0 = (0.0916, 0.055, 0.4459, 0.1117) if dim == 2 else (0.0927, 0.0122, 0.3109, 0.0188, 0.0455, 0.0071)
+    sol = least_squares(lambda x: _moment_residual(dim, deg, *_symmetric_rule_from(dim, x)), x0, xtol=1e-15, ftol=1e-15, gtol=1e-15)
+    return sol.x
+
+
 @functools.lru_cache(maxsize=None)
 def symmetric_simplex_rule(dim):
     """Fully symmetric rule with positive weights and interior points: 6 points, degree 4 on the triangle (two vertex
-    orbits); 14 points, degree 5 on the tetrahedron (two vertex orbits and one edge orbit).  The orbit parameters are
-    the solution of the moment equations, refined here to rounding from three-digit starting values and checked."""
-    import math
-    from scipy.optimize import least_squares
+    orbits); 14 points, degree 5 on the tetrahedron (two vertex orbits and one edge orbit).  Checked against the moment
+    equations when first used."""
     deg = 4 if dim == 2 else 5
-    kinds = ("v", "v") if dim == 2 else ("v", "v", "e")
-    x0 = (0.0916, 0.055, 0.4459, 0.1117) if dim == 2 else (0.0927, 0.0122, 0.3109, 0.0188, 0.0455, 0.0071)
-    powers = [p for p in np.ndindex(*(deg + 1,) * dim) if sum(p) <= deg]
-    exact = np.array([math.prod(math.factorial(e) for e in p) / math.factorial(sum(p) + dim) for p in powers])
-
-    def rule(x):
-        orbits = _orbit_points(dim, [(k, x[2 * i]) for i, k in enumerate(kinds)])
-        return np.concatenate(orbits), np.concatenate([np.full(len(o), x[2 * i + 1]) for i, o in enumerate(orbits)])
-
-    def residual(x):
-        pts, wts = rule(x)
-        return np.array([(wts * np.prod(pts ** np.array(p), axis=1)).sum() for p in powers]) - exact
-
-    sol = least_squares(residual, x0, xtol=1e-15, ftol=1e-15, gtol=1e-15)
-    pts, wts = rule(sol.x)
-    if np.abs(residual(sol.x)).max() > 1e-15 or wts.min() <= 0 or pts.min() <= 0 or pts.sum(axis=1).max() >= 1:
-        raise RuntimeError("symmetric simplex rule did not converge")
+    pts, wts = _symmetric_rule_from(dim, _SYMMETRIC_RULES[dim][1])
+    if np.abs(_moment_residual(dim, deg, pts, wts)).max() > 2e-15 or wts.min() <= 0 or pts.min() <= 0 or pts.sum(axis=1).max() >= 1:
+        raise RuntimeError("symmetric simplex rule is not exact")
     return pts, wts
 
 

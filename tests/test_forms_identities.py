@@ -242,3 +242,9 @@ def test_qk_hex_element_matrix_rows_sum_to_the_mass_action(degree, nq):
     A = csr.toscipy().toarray()
     assert abs(A - A.T).max() < 1e-14
     assert abs(A.sum() - 1.0) < 1e-13
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_symmetric_rule_parameters_are_the_solution_of_the_moment_equations(dim):
+    """The literals behind forms.symmetric_simplex_rule against their derivation (Gauss-Newton on the moment equations)."""
+    assert_allclose(forms.solve_symmetric_rule(dim), forms._SYMMETRIC_RULES[dim][1], rtol=0, atol=5e-15)
