@@ -652,7 +652,10 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                         flush.append((rm, f"for (int q0 = tid; q0 < nnzb{k}; q0 += {FU}*nthr) {{ int g{k}[{FU}]; "
                                           f"for (int f = 0; f < {FU}; ++f) {{ const int q = q0 + f*nthr; g{k}[f] = q < nnzb{k} ? oc{k}_gpos[(size_t)r0_{k} + q] : -1; }} "
                                           f"if (oc{k}_flags & 1) {{ for (int f = 0; f < {FU}; ++f) if (g{k}[f] >= 0) arg{k}[(size_t)g{k}[f]] = sm{k}[q0 + f*nthr]; }} "
-                                          f"else {{ for (int f = 0; f < {FU}; ++f) if (g{k}[f] >= 0) arg{k}[(size_t)g{k}[f]] += sm{k}[q0 + f*nthr]; }} }}"))
+                                          # accumulating into existing values (a second integral of the same form): the old values are
+                                          # requested together as well (the places of a block are distinct)
+                                          f"else {{ double o{k}[{FU}]; for (int f = 0; f < {FU}; ++f) o{k}[f] = g{k}[f] >= 0 ? arg{k}[(size_t)g{k}[f]] : 0.0; "
+                                          f"for (int f = 0; f < {FU}; ++f) if (g{k}[f] >= 0) arg{k}[(size_t)g{k}[f]] = o{k}[f] + sm{k}[q0 + f*nthr]; }} }}"))
                     continue
                 # complete rows, contiguous in the CSR value array: plain coalesced stores
                 flush.append((rm, f"if (oc{k}_flags & 1) {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)r0_{k} + q] = sm{k}[q]; }} "
