@@ -823,3 +823,43 @@ static void rnd{seed}(double *A, const double *w, const double *y)
     if rbs * cbs == 1 and not unroll:
         got = run_ocr(pl, rows_per_block=int(rng.integers(3, 40)), zero_pending=zero, order=order)
         assert np.abs(got.values - (ref.values + (0.0 if zero else 1.0))).max() <= tol
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_dat_loops_on_random_maps_through_the_staged_and_direct_wrappers(seed):
+    """Randomised Dat loops against the oracle: two maps of random arity onto different sets (duplicate nodes inside an entity
+    allowed), INC outputs and READ inputs of random widths through either map, a direct read-only argument and a Global
+    reduction, random plan-block sizes; the staged wrapper (LDS staging + LDS reduction + one global atomic per node) and the
+    direct one must both agree with the sequential semantics."""
+    from hostsim import run_direct, run_staged
+    rng = np.random.default_rng(500 + seed)
+    a1, a2 = int(rng.integers(1, 7)), int(rng.integers(1, 6))
+    n1, n2, ne = int(rng.integers(10, 90)), int(rng.integers(8, 70)), int(rng.integers(30, 300))
+    d_out, d_in1, d_in2 = int(rng.integers(1, 4)), int(rng.integers(1, 4)), int(rng.integers(1, 3))
+    s1, s2, ele = op2.Set(n1), op2.Set(n2), op2.Set(ne)
+    m1 = op2.Map(ele, s1, a1, rng.integers(0, n1, (ne, a1)).astype(np.int32))
+    m2 = op2.Map(ele, s2, a2, rng.integers(0, n2, (ne, a2)).astype(np.int32))
+    out1 = op2.Dat(s1 ** d_out if d_out > 1 else s1, rng.standard_normal((n1, d_out)) if d_out > 1 else rng.standard_normal(n1))
+    out2 = op2.Dat(s2, rng.standard_normal(n2))
+    in1 = op2.Dat(s1 ** d_in1 if d_in1 > 1 else s1, rng.standard_normal((n1, d_in1)) if d_in1 > 1 else rng.standard_normal(n1))
+    in2 = op2.Dat(s2 ** d_in2 if d_in2 > 1 else s2, rng.standard_normal((n2, d_in2)) if d_in2 > 1 else rng.standard_normal(n2))
+    w = op2.Dat(ele, rng.uniform(0.5, 1.5, ne))
+    g = op2.Global(1, 0.25, np.float64)
+    k = op2.Kernel(f"""
+static void rdat{seed}(double *o1, double *o2, const double *i1, const double *i2, const double *w, double *g)
+{{
+  double s = 0.0;
+  for (int i = 0; i < {a1 * d_in1}; ++i) s += (1.0 + 0.1*i) * i1[i];
+  for (int i = 0; i < {a2 * d_in2}; ++i) s -= (0.5 + 0.2*i) * i2[i];
+  for (int i = 0; i < {a1 * d_out}; ++i) o1[i] += w[0] * s * (i + 1);
+  for (int i = 0; i < {a2}; ++i) o2[i] += w[0] + 0.01 * s * i;
+  g[0] += w[0] * s;
+}}""", f"rdat{seed}")
+    args = lambda: (out1(op2.INC, m1), out2(op2.INC, m2), in1(op2.READ, m1), in2(op2.READ, m2), w(op2.READ), g(op2.INC))
+    ref = oracle_run(k, ele, *args())
+    tol = lambda r: 1e-11 * (1.0 + np.abs(r).max())
+    for run in (lambda: run_staged(op2.LegacyParloop(k, ele, *args()), epb=int(rng.integers(16, 120))),
+                lambda: run_direct(op2.LegacyParloop(k, ele, *args()))):
+        got = run()
+        for q in (0, 1, 5):
+            assert np.abs(np.asarray(got[q]).reshape(-1) - np.asarray(ref[q]).reshape(-1)).max() <= tol(ref[q]), (seed, q)
