@@ -80,7 +80,7 @@ def _distinct_maps(gk: GlobalKernel):
 
 def tensor_eligible(gk: GlobalKernel):
     """'matrix' / 'action' when the loop can take the tensor-product wrappers of csrc/fd_tensor.h: a
-    TensorProductLocalKernel of degree k = 1..5 with up to 8 Gauss points per axis (tensor_geometry) over an extruded set
+    TensorProductLocalKernel of degree k = 1..5 with up to 7 Gauss points per axis (tensor_geometry) over an extruded set
     with constant layers, the whole column (iteration region ALL), no subset, and the argument shapes
         matrix:  Mat INC (scalar block, both maps the (k+1)^3-node Q_k map, offset k)  +  coordinates READ (dim 3, 8-node Q1 map)
         action:  Dat INC (scalar, Q_k map)  +  coordinates READ  +  Dat READ (scalar, the same Q_k map)."""
@@ -120,7 +120,7 @@ def tensor_geometry(degree, nq):
     workgroups per cell (one wavefront per 16-row panel of the padded element matrix), ``action_cells`` cells per 128-lane
     workgroup of the action."""
     k1, q1 = int(degree) + 1, int(nq)
-    if not (1 <= degree <= 5 and 1 <= q1 <= 8):
+    if not (1 <= degree <= 5 and 1 <= q1 <= 7):        # (8 points per axis: the matrix template's per-point weights alone are 64 KB of LDS)
         return None
     nt = (k1 ** 3 + 15) // 16
     wpb = 4 if nt % 4 == 0 else (2 if nt % 2 == 0 else 1)
