@@ -79,6 +79,11 @@ SIGNATURES = {
     "fd_ocrplan_create_ordered": (c_int, [c_void_p, c_int, c_int32, c_int32, c_void_p, c_int32, c_int, c_void_p, c_int32, c_void_p,
                                           c_void_p, POINTER(c_void_p)]),
     "fd_ocr_node_words": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fd_ocr_node_diag": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fd_ocr_pack_records": (c_int, [c_int64, c_int, POINTER(c_void_p), POINTER(c_int32), POINTER(c_int32), c_void_p, c_int, c_int, c_int,
+                                    c_int, c_int, c_int, c_void_p, c_void_p]),
+    "fd_ocr_row_runs": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, POINTER(c_int32),
+                                POINTER(c_int32), c_void_p]),
     "fd_ocrplan_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "fd_plan_set_lane_order": (c_int, [c_void_p, c_int, c_void_p]),
     "fd_plan_block_starts": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int32)]),

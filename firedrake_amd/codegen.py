@@ -291,7 +291,18 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
     strides = [int(v) for v in sm_.group(1).split("x")] if sm_ else None
     if sm_:
         mode = mode[:sm_.start()]
+    # "_q<L0>x<L1>..k<K>[d]": the per-instance index rows of an owner-computes-rows loop arrive as ONE bit-packed record per
+    # instance (fd_ocr_pack_records): local-map entries of staged map m at L_m bits, row offsets at K bits; "d" = the offsets
+    # of the diagonal entries (i, i) are not stored -- they are a property of the row node and ride in its LDS word
+    rq_ = re.search(r"_q(\d+(?:x\d+)*)k(\d+)(d?)$", mode)
+    rec = None
+    if rq_:
+        rec = {"lbits": [int(v) for v in rq_.group(1).split("x")], "kbits": int(rq_.group(2)), "diag": bool(rq_.group(3))}
+        mode = mode[:rq_.start()]
     ocr = mode.startswith("ocr")
+    # "ocrpr": the flush of a derived row order finds the place of an accumulator entry through RUNS of rows that are consecutive
+    # in the CSR as well (one byte per entry + one word per run in LDS) instead of a 4-byte place per entry (fd_ocr_row_runs)
+    runflush = mode.startswith("ocrpr")
     # "stagedo": staged over a backend-derived entity ORDER (fd_locality_order): slot -> entity through fd_order_, plans on
     # the map rows gathered in that order (Parloop._staged_geometry, un-hinted maps)
     ordered = mode.startswith("stagedo")
@@ -434,12 +445,19 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             P(f"long long oc{k}_maxnown", ("ocr_maxnown", k))
             P(f"long long oc{k}_flags", ("ocr_flags", k))
             if srow_table(info):
-                P(f"const unsigned int *__restrict__ oc{k}_srowtab", ("ocr_srow", k, info["rm"]))
+                P(f"const unsigned int *__restrict__ oc{k}_srowtab", ("ocr_srow", k, info["rm"]) + (("diag",) if (rec and rec["diag"]) else ()))
             if ocrp:
                 P(f"const int *__restrict__ oc{k}_prowptr", ("ocr_prowptr", k))
                 P(f"const int *__restrict__ oc{k}_nstart", ("ocr_nstart", k))
-                P(f"const int *__restrict__ oc{k}_gpos", ("ocr_gpos", k))
+                if runflush:
+                    P(f"const unsigned char *__restrict__ oc{k}_grun", ("ocr_grun", k))
+                    P(f"const int *__restrict__ oc{k}_brun", ("ocr_brun", k))
+                    P(f"const int *__restrict__ oc{k}_rdelta", ("ocr_rdelta", k))
+                else:
+                    P(f"const int *__restrict__ oc{k}_gpos", ("ocr_gpos", k))
                 P(f"long long oc{k}_npos", ("ocr_npos", k))
+            if rec:
+                P(f"const unsigned int *__restrict__ oc{k}_rec", ("ocr_rec", k))
         elif mat_staged[k]:
             P(f"const int *__restrict__ mp{k}_off", ("matplan_off", k))
             P(f"const int *__restrict__ mp{k}_gpos", ("matplan_gpos", k))
@@ -623,10 +641,15 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 if colmask and cm != rm:
                     node_actions.setdefault(cm, []).append(([f"const bool m{k}_U = clg{k}[G_U] < 0;"], [f"smc{k}[I_U] = m{k}_U;"]))
                 lines = [f"unsigned int rw{k}[{ar}];", f"for (int i = 0; i < {ar}; ++i) rw{k}[i] = srow{k}[lm{rm}[i]];"]
+                if rec and rec["diag"]:
+                    # (i, i): the place of a row's diagonal entry belongs to the row node (bits 20..27 of its word)
+                    if not srow_table(info) or ar != ac:
+                        raise ValueError("diagonal-free records need one map on both sides of the Mat")
+                    lines.append(f"for (int i = 0; i < {ar}; ++i) kk{k}[i*{ac} + i] = (int)((rw{k}[i] >> 20) & 0xffu);")
                 if colmask and cm != rm:
                     lines += [f"bool cmk{k}[{ac}];", f"for (int j = 0; j < {ac}; ++j) cmk{k}[j] = smc{k}[lm{cm}[j]];"]
                 lines += [f"for (int i = 0; i < {ar}; ++i) {{",
-                          f"  const int base = (int)(rw{k}[i] & 0x3fffffffu) - 1;",
+                          f"  const int base = (int)(rw{k}[i] & 0xfffffu) - 1;",
                           "  if (base < 0) continue;          /* row owned by another block (or BC-masked) */",
                           f"  for (int j = 0; j < {ac}; ++j) {{"]
                 # a BC-masked column adds 0.0 to its (existing) position instead of branching around the atomic:
@@ -643,7 +666,22 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                     # LDS instructions and 1.5x the scalar ones for the same stores: +12 % LDS-pipe cycles in a kernel bound
                     # by that pipe, profiles/r3f_pmc_jacobian_lexicographic.txt.)
                     FU = max(1, int(configuration["flush_batch"]))
-                    if FU == 1:
+                    if runflush:
+                        # rows that follow one another in the block AND in the CSR form a run with one displacement (place - accumulator
+                        # index): a byte per entry names the run, the block's displacements (<= 256) sit in LDS
+                        lds_items.append(("ocrrun", k))
+                        lds_tail_const.append(f"int *srun{k} = (int *)(fd_lds + fd_off); fd_off += 1024;")
+                        mat_stage_pre.append(f"const int br0_{k} = oc{k}_brun[b], nrun{k} = oc{k}_brun[b+1] - br0_{k};")
+                        stage.append((rm, f"_Pragma(\"clang loop unroll(disable) vectorize(disable)\") "
+                                          f"for (int q = tid; q < nrun{k}; q += nthr) srun{k}[q] = oc{k}_rdelta[br0_{k} + q];"))
+                        # (loads clamped to the block's last entry instead of branched around: FU independent requests per trip)
+                        flush.append((rm, f"for (int q0 = tid; q0 < nnzb{k}; q0 += {FU}*nthr) {{ int g{k}[{FU}]; "
+                                          f"for (int f = 0; f < {FU}; ++f) {{ const int q = q0 + f*nthr; g{k}[f] = (int)oc{k}_grun[(size_t)r0_{k} + (q < nnzb{k} ? q : nnzb{k} - 1)]; }} "
+                                          f"for (int f = 0; f < {FU}; ++f) g{k}[f] = (q0 + f*nthr < nnzb{k}) ? r0_{k} + q0 + f*nthr + srun{k}[g{k}[f]] : -1; "
+                                          f"if (oc{k}_flags & 1) {{ for (int f = 0; f < {FU}; ++f) if (g{k}[f] >= 0) arg{k}[(size_t)g{k}[f]] = sm{k}[q0 + f*nthr]; }} "
+                                          f"else {{ double o{k}[{FU}]; for (int f = 0; f < {FU}; ++f) o{k}[f] = g{k}[f] >= 0 ? arg{k}[(size_t)g{k}[f]] : 0.0; "
+                                          f"for (int f = 0; f < {FU}; ++f) if (g{k}[f] >= 0) arg{k}[(size_t)g{k}[f]] = o{k}[f] + sm{k}[q0 + f*nthr]; }} }}"))
+                    elif FU == 1:
                         flush.append((rm, f"if (oc{k}_flags & 1) {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)oc{k}_gpos[(size_t)r0_{k} + q]] = sm{k}[q]; }} "
                                           f"else {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)oc{k}_gpos[(size_t)r0_{k} + q]] += sm{k}[q]; }}"))
                     else:
@@ -744,7 +782,8 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         # node-major staging: the node-list entry is requested first, then all the rows that depend on it
         for mi, acts in node_actions.items():
             src.append(f"  for (int i_0 = tid; i_0 < nd{mi}; i_0 += nthr) {{")
-            src.append(f"    const int g_0 = p{mi}_list[l0_{mi} + i_0];")
+            if any("G_U" in l for act in acts for part in (0, 1) for l in act[part]):
+                src.append(f"    const int g_0 = p{mi}_list[l0_{mi} + i_0];")
             for part in (0, 1):
                 for act in acts:
                     for l in act[part]:
@@ -769,6 +808,34 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 k, n = info["k"], info["ar"] * info["ac"]
                 idx_loads.append((f"int kk{k}[{n}]", f"int nx_kk{k}[{n}]", f"kk{k}", n,
                                   f"fdw::load_packed<{ktype}, {n}>(oc{k}_k + (size_t)(II - start)*{n}, DST);"))
+        rec_decode = []
+        if rec:
+            # one record per instance replaces every index row above: the words are prefetched, the fields extracted at the top of
+            # the trip that uses them (the prefetched copy is W registers instead of one register per index)
+            (info,) = [i for i in infos if i["kind"] == "mat"]
+            k, ar_, ac_ = info["k"], info["ar"], info["ac"]
+            if len(rec["lbits"]) != len(staged_maps):
+                raise ValueError("one local-index width per staged map")
+            off = 0
+            fields = []
+            for mi, lb in zip(staged_maps, rec["lbits"]):
+                for i in range(maps[mi].arity):
+                    fields.append((f"lm{mi}[{i}]", off, lb))
+                    off += lb
+            for i in range(ar_):
+                for j in range(ac_):
+                    if rec["diag"] and i == j:
+                        continue
+                    fields.append((f"kk{k}[{i * ac_ + j}]", off, rec["kbits"]))
+                    off += rec["kbits"]
+            W = -(-off // 32)
+            for mi in staged_maps:
+                rec_decode.append(f"int lm{mi}[{maps[mi].arity}];")
+            rec_decode.append(f"int kk{k}[{ar_ * ac_}];")
+            for name, o, b in fields:
+                rec_decode.append(f"{name} = fdw::rec_field<{o}, {b}>(rc{k});")
+            idx_loads = [(f"unsigned rc{k}[{W}]", f"unsigned nx_rc{k}[{W}]", f"rc{k}", W,
+                          f"fdw::load_rec<{W}>(oc{k}_rec + (size_t)(II - start)*{W}, DST);")]
         pf = bool(configuration["prefetch"])
         # lane order (fd_plan_set_lane_order): slot k*nthr + t of a block holds the k-th entity of lane t's contiguous
         # run, so the lanes of one trip work on entities that are far apart (no shared nodes -> no serialised LDS
@@ -830,6 +897,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 src.append(f"    const int e = {ent_of('it')};")
             for cur, nxt, name, n, ld in idx_loads:
                 src.append(f"    {cur}; " + ld.replace("II", "it").replace("EE", "e").replace("DST", name))
+        src += ["    " + s for s in rec_decode]
         src += ["    " + s for s in pack]
         src.append(f"    fdk::{lk.name}({', '.join(call_args)});")
         src += ["    " + s for s in unpack]
@@ -1169,9 +1237,22 @@ def lds_stride(max_nd: int, ocr: bool = False) -> int:
     return -(-int(max_nd) // g) * g
 
 
-def mode_variant(base: str, kbytes: int, max_nds) -> str:
-    """Name of the wrapper variant for a launch geometry: base mode [+ _k16] [+ _s<strides>]."""
+def record_layout(arities, max_nds, nr, nc, maxlen, same_map):
+    """Field widths of the bit-packed instance records of a whole-entity owner-computes-rows loop (generate_wrapper, "_q"
+    suffix): (lbits per staged map, kbits, diag, words per instance)."""
+    lbits = [max(int(n - 1).bit_length(), 1) for n in max_nds]
+    kbits = max(int(maxlen - 1).bit_length(), 1)
+    diag = bool(same_map and nr == nc and maxlen <= 256 and configuration["ocr_records_diag"])
+    bits = sum(a * b for a, b in zip(arities, lbits)) + (nr * nc - (nr if diag else 0)) * kbits
+    return lbits, kbits, diag, -(-bits // 32)
+
+
+def mode_variant(base: str, kbytes: int, max_nds, rec=None) -> str:
+    """Name of the wrapper variant for a launch geometry: base mode [+ _k16] [+ _q<record fields>] [+ _s<strides>]."""
     m = base + ("_k16" if kbytes == 2 else "")
+    if rec is not None:
+        lbits, kbits, diag = rec[:3]
+        m += "_q" + "x".join(str(b) for b in lbits) + f"k{kbits}" + ("d" if diag else "")
     ocr = base.startswith("ocr")
     if not ocr and int(configuration["lds_const_stride"]) > 0 and max_nds:
         m += "_s" + "x".join(str(lds_stride(n, ocr)) for n in max_nds)

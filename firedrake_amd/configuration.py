@@ -24,6 +24,11 @@ configuration = {
     "flush_batch": _env("FDHIP_FLUSH_BATCH", 4, int),      # flushes through index tables (derived row orders): table loads requested per trip
     "plan_copies": _env("FDHIP_PLAN_COPIES", 1, int),     # READ Dats unchanged between calls are kept in plan order and streamed
     "ocr_pack": _env("FDHIP_OCR_PACK", 1, int),            # bank-aware greedy packing of the instance lists (fd_ocrplan_pack)
+    # owner-computes-rows index tables: one bit-packed record per instance (fd_ocr_pack_records; 0 = uint16 / uint8 rows), the
+    # diagonal offsets taken from the row node's LDS word, and the flush of a derived row order run-coded (fd_ocr_row_runs)
+    "ocr_records": _env("FDHIP_OCR_RECORDS", 1, int),
+    "ocr_records_diag": _env("FDHIP_OCR_RECORDS_DIAG", 1, int),
+    "ocr_run_flush": _env("FDHIP_OCR_RUN_FLUSH", 1, int),
     "ocr_lds_limit": _env("FDHIP_OCR_LDS_LIMIT", 0, int),  # 0 = auto (whole CU for large element matrices)
     "lane_strided": _env("FDHIP_LANE_STRIDED", 1, int),   # plans in lane order (fd_plan_set_lane_order)
     # staged rows addressed with a COMPILE-TIME node stride (max nodes per block rounded up to a multiple of this value;

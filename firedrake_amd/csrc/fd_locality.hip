@@ -25,6 +25,7 @@
 #include <hipcub/hipcub.hpp>
 #include <cfloat>
 #include <vector>
+#include <algorithm>
 
 namespace {
 
@@ -166,6 +167,45 @@ __global__ void row_entry_positions(int32_t npos, const int32_t *__restrict__ pr
     for (int64_t p = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4; p < npos; p += ((int64_t)gridDim.x * blockDim.x) >> 4) {
         const int32_t a = prowptr[p], len = prowptr[p + 1] - a, g = gstart[p];
         for (int k = sub; k < len; k += 16) gpos[a + k] = g + k;
+    }
+}
+
+// ---- run-coded flush tables of a derived row order (fd_ocr_row_runs)
+// A row position p starts a RUN when it is the first row of its block or when its displacement (CSR start - accumulator start)
+// differs from the previous position's: inside a run, place = accumulator index + one displacement.
+__global__ void rr_flags(int32_t npos, const int32_t *__restrict__ prowptr, const int32_t *__restrict__ gstart,
+                         const int32_t *__restrict__ rblk, int32_t nblocks, int32_t *__restrict__ flag) {
+    const int64_t t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = t0; p < npos; p += st)
+        flag[p] = (p == 0 || gstart[p] - prowptr[p] != gstart[p - 1] - prowptr[p - 1]) ? 1 : 0;
+}
+__global__ void rr_block_starts(const int32_t *__restrict__ rblk, int32_t nblocks, int32_t npos, int32_t *__restrict__ flag) {
+    for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b < nblocks; b += (int64_t)gridDim.x * blockDim.x)
+        if (rblk[b] < npos) flag[rblk[b]] = 1;
+}
+// runidx = inclusive scan of flag (1-based run number of every position)
+__global__ void rr_tables(int32_t npos, const int32_t *__restrict__ prowptr, const int32_t *__restrict__ gstart,
+                          const int32_t *__restrict__ flag, const int32_t *__restrict__ runidx, const int32_t *__restrict__ rblk,
+                          int32_t nblocks, int32_t *__restrict__ brun, int32_t *__restrict__ rdelta) {
+    const int64_t t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = t0; p < npos; p += st)
+        if (flag[p]) rdelta[runidx[p] - 1] = gstart[p] - prowptr[p];
+    for (int64_t b = t0; b <= nblocks; b += st) {
+        const int32_t p = rblk[b];
+        brun[b] = p < npos ? runidx[p] - 1 : (npos > 0 ? runidx[npos - 1] : 0);
+    }
+}
+// one workgroup per block: grun[entry] = run of the entry's row, counted from the block's first run; err |= 1 above 255
+__global__ void rr_entries(const int32_t *__restrict__ rblk, int32_t nblocks, int32_t npos, const int32_t *__restrict__ prowptr,
+                           const int32_t *__restrict__ runidx, const int32_t *__restrict__ brun, uint8_t *__restrict__ grun,
+                           int32_t *__restrict__ err) {
+    for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        const int32_t n0 = rblk[b], n1 = rblk[b + 1] < npos ? rblk[b + 1] : npos, r0 = brun[b];
+        for (int32_t p = n0 + (threadIdx.x >> 4); p < n1; p += blockDim.x >> 4) {
+            const int32_t a = prowptr[p], len = prowptr[p + 1] - a, r = runidx[p] - 1 - r0;
+            if (r > 255 && (threadIdx.x & 15) == 0) atomicOr(err, 1);
+            for (int k = threadIdx.x & 15; k < len; k += 16) grun[a + k] = (uint8_t)r;
+        }
     }
 }
 
@@ -336,6 +376,43 @@ int fd_row_entry_positions(int32_t npos, const int32_t *prowptr_dev, const int32
     if (npos <= 0) return 0;
     hipLaunchKernelGGL(row_entry_positions, dim3(lo_grid((int64_t)npos * 16)), dim3(256), 0, fd::st(s), npos, prowptr_dev, gstart_dev, gpos_dev);
     FD_CHECK_LAUNCH();
+    return 0;
+}
+
+int fd_ocr_row_runs(int32_t npos, const int32_t *prowptr_dev, const int32_t *gstart_dev, const int32_t *rblk_dev, int32_t nblocks,
+                    uint8_t *grun_dev, int32_t *brun_dev, int32_t *rdelta_dev, int32_t *nruns_out, int32_t *max_runs_out, fd_stream_t s_) {
+    if (!prowptr_dev || !gstart_dev || !rblk_dev || !grun_dev || !brun_dev || !rdelta_dev || !nruns_out || !max_runs_out || npos < 0 || nblocks < 0)
+        FD_FAIL("fd_ocr_row_runs: bad arguments");
+    *nruns_out = 0; *max_runs_out = 0;
+    if (npos == 0 || nblocks == 0) return 0;
+    hipStream_t s = fd::st(s_);
+    int32_t *flag = nullptr, *runidx = nullptr, *err = nullptr; void *tmp = nullptr;
+    FD_HIP(hipMalloc(&flag, (size_t)npos * 4));
+    FD_HIP(hipMalloc(&runidx, (size_t)npos * 4));
+    FD_HIP(hipMalloc(&err, 4));
+    FD_HIP(hipMemsetAsync(err, 0, 4, s));
+    hipLaunchKernelGGL(rr_flags, dim3(lo_grid(npos)), dim3(256), 0, s, npos, prowptr_dev, gstart_dev, rblk_dev, nblocks, flag);
+    hipLaunchKernelGGL(rr_block_starts, dim3(lo_grid(nblocks)), dim3(256), 0, s, rblk_dev, nblocks, npos, flag);
+    size_t tb = 0;
+    FD_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tb, flag, runidx, npos, s));
+    FD_HIP(hipMalloc(&tmp, tb ? tb : 8));
+    FD_HIP(hipcub::DeviceScan::InclusiveSum(tmp, tb, flag, runidx, npos, s));
+    hipLaunchKernelGGL(rr_tables, dim3(lo_grid(npos)), dim3(256), 0, s, npos, prowptr_dev, gstart_dev, flag, runidx, rblk_dev, nblocks,
+                       brun_dev, rdelta_dev);
+    hipLaunchKernelGGL(rr_entries, dim3(nblocks < 65536 ? nblocks : 65536), dim3(256), 0, s, rblk_dev, nblocks, npos, prowptr_dev, runidx,
+                       brun_dev, grun_dev, err);
+    FD_CHECK_LAUNCH();
+    std::vector<int32_t> br((size_t)nblocks + 1);
+    int32_t e = 0;
+    FD_HIP(hipMemcpyAsync(br.data(), brun_dev, ((size_t)nblocks + 1) * 4, hipMemcpyDeviceToHost, s));
+    FD_HIP(hipMemcpyAsync(&e, err, 4, hipMemcpyDeviceToHost, s));
+    FD_HIP(hipMemcpyAsync(nruns_out, runidx + (npos - 1), 4, hipMemcpyDeviceToHost, s));
+    FD_HIP(hipStreamSynchronize(s));
+    int32_t mx = 0;
+    for (int32_t b = 0; b < nblocks; ++b) mx = std::max(mx, br[b + 1] - br[b]);
+    // (the last block's runs end at nruns: brun[nblocks] is the run of position npos, i.e. nruns when rblk[nblocks] == npos)
+    *max_runs_out = mx;
+    (void)hipFree(flag); (void)hipFree(runidx); (void)hipFree(err); (void)hipFree(tmp);
     return 0;
 }
 

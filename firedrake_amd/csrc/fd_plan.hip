@@ -1016,6 +1016,50 @@ __global__ void ocrs_tables_k(const int32_t *__restrict__ inst_off, int32_t nblo
     }
 }
 
+// ---- bit-packed instance records of an owner-computes-rows plan (fd_ocr_pack_records; read by fdw::rec_field)
+struct RecDesc {
+    const uint16_t *lmap[8]; int ar[8]; int lbits[8]; int nmaps;
+    const void *kidx; int kbytes, nr, nc, kbits, skipdiag, words;
+};
+__global__ void ocr_pack_records_k(RecDesc d, int64_t ninst, uint32_t *__restrict__ out, int32_t *__restrict__ err) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < ninst; t += (int64_t)gridDim.x * blockDim.x) {
+        uint64_t acc = 0; int nb = 0, wi = 0;
+        uint32_t *o = out + t * d.words;
+        auto put = [&](uint32_t v, int bits) {
+            if (bits < 32 && (v >> bits)) atomicOr(err, 1);
+            acc |= (uint64_t)v << nb; nb += bits;
+            if (nb >= 32) { o[wi++] = (uint32_t)acc; acc >>= 32; nb -= 32; }
+        };
+        for (int m = 0; m < d.nmaps; ++m)
+            for (int i = 0; i < d.ar[m]; ++i) put(d.lmap[m][t * d.ar[m] + i], d.lbits[m]);
+        for (int i = 0; i < d.nr; ++i)
+            for (int j = 0; j < d.nc; ++j) {
+                if (d.skipdiag && i == j) continue;
+                const int64_t q = (t * d.nr + i) * d.nc + j;
+                put(d.kbytes == 1 ? (uint32_t)((const uint8_t *)d.kidx)[q] : (uint32_t)((const uint16_t *)d.kidx)[q], d.kbits);
+            }
+        if (nb > 0) o[wi++] = (uint32_t)acc;
+        while (wi < d.words) o[wi++] = 0;
+    }
+}
+
+// words[i] |= (position of the diagonal entry in the CSR row of node list[i]) << 20  (8 bits; err |= 1 above 255 or without a diagonal)
+__global__ void ocr_node_diag_k(const int32_t *__restrict__ list, int64_t n, int32_t nrows, const int32_t *__restrict__ rowptr,
+                                const int32_t *__restrict__ colidx, uint32_t *__restrict__ words, int32_t *__restrict__ err) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t g = list[i];
+        if (g < 0 || g >= nrows) continue;                    // not a row of this matrix (never owned: its word is 0)
+        int lo = rowptr[g], hi = rowptr[g + 1] - 1, pos = -1;
+        while (lo <= hi) {
+            const int mid = lo + ((hi - lo) >> 1), cv = colidx[mid];
+            if (cv == g) { pos = mid - rowptr[g]; break; }
+            if (cv < g) lo = mid + 1; else hi = mid - 1;
+        }
+        if (pos < 0 || pos > 255) { if (words[i] & 0xfffffu) atomicOr(err, 1); continue; }
+        words[i] |= (uint32_t)pos << 20;
+    }
+}
+
 // One word per (block, staged node): what the owner-computes-rows wrapper keeps in LDS for a node of its block -- bits 0..29 =
 // 1 + offset of the node's row inside the block's accumulator (0 = row not owned by this block, or masked by the row lgmap),
 // bit 31 = the node's column is masked by the column lgmap.  Precomputed in PLAN order so that the wrapper's staging phase
@@ -1052,6 +1096,54 @@ int fd_ocr_node_words(const int32_t *blkoff_dev, const int32_t *list_dev, int32_
     hipLaunchKernelGGL(ocr_node_words_k, dim3(nblocks < 65536 ? nblocks : 65536), dim3(256), 0, fd::st(s), blkoff_dev, list_dev, nblocks,
                        rblk_dev, base_by_node_dev, start_by_pos_dev, by_offset, npos, row_lgmap_dev, col_lgmap_dev, out_dev);
     FD_CHECK_LAUNCH();
+    return 0;
+}
+
+int fd_ocr_pack_records(int64_t ninst, int nmaps, const uint16_t *const *lmaps_dev, const int32_t *arities, const int32_t *lbits,
+                        const void *kidx_dev, int kbytes, int nr, int nc, int kbits, int skipdiag, int words, uint32_t *out_dev,
+                        fd_stream_t s_) {
+    if (ninst < 0 || nmaps < 0 || nmaps > 8 || (nmaps && (!lmaps_dev || !arities || !lbits)) || !kidx_dev || !out_dev ||
+        (kbytes != 1 && kbytes != 2) || nr <= 0 || nc <= 0 || kbits <= 0 || kbits > 16 || words <= 0)
+        FD_FAIL("fd_ocr_pack_records: bad arguments");
+    RecDesc d{};
+    int64_t bits = 0;
+    d.nmaps = nmaps;
+    for (int m = 0; m < nmaps; ++m) {
+        if (!lmaps_dev[m] || arities[m] <= 0 || lbits[m] <= 0 || lbits[m] > 16) FD_FAIL("fd_ocr_pack_records: bad local map");
+        d.lmap[m] = lmaps_dev[m]; d.ar[m] = arities[m]; d.lbits[m] = lbits[m];
+        bits += (int64_t)arities[m] * lbits[m];
+    }
+    bits += (int64_t)(nr * nc - (skipdiag ? (nr < nc ? nr : nc) : 0)) * kbits;
+    if ((bits + 31) / 32 != words) FD_FAIL("fd_ocr_pack_records: the fields do not fill the stated number of words");
+    d.kidx = kidx_dev; d.kbytes = kbytes; d.nr = nr; d.nc = nc; d.kbits = kbits; d.skipdiag = skipdiag; d.words = words;
+    if (ninst == 0) return 0;
+    hipStream_t s = fd::st(s_);
+    int32_t *err = nullptr, e = 0;
+    FD_HIP(hipMalloc(&err, 4));
+    FD_HIP(hipMemsetAsync(err, 0, 4, s));
+    hipLaunchKernelGGL(ocr_pack_records_k, dim3(mp_grid(ninst)), dim3(256), 0, s, d, ninst, out_dev, err);
+    FD_CHECK_LAUNCH();
+    FD_HIP(hipMemcpyAsync(&e, err, 4, hipMemcpyDeviceToHost, s));
+    FD_HIP(hipStreamSynchronize(s));
+    (void)hipFree(err);
+    if (e) FD_FAIL("fd_ocr_pack_records: an index does not fit its field");
+    return 0;
+}
+
+int fd_ocr_node_diag(const int32_t *list_dev, int64_t n, int32_t nrows, const int32_t *rowptr_dev, const int32_t *colidx_dev,
+                     uint32_t *words_dev, fd_stream_t s_) {
+    if (n < 0 || (n && (!list_dev || !rowptr_dev || !colidx_dev || !words_dev))) FD_FAIL("fd_ocr_node_diag: bad arguments");
+    if (n == 0) return 0;
+    hipStream_t s = fd::st(s_);
+    int32_t *err = nullptr, e = 0;
+    FD_HIP(hipMalloc(&err, 4));
+    FD_HIP(hipMemsetAsync(err, 0, 4, s));
+    hipLaunchKernelGGL(ocr_node_diag_k, dim3(mp_grid(n)), dim3(256), 0, s, list_dev, n, nrows, rowptr_dev, colidx_dev, words_dev, err);
+    FD_CHECK_LAUNCH();
+    FD_HIP(hipMemcpyAsync(&e, err, 4, hipMemcpyDeviceToHost, s));
+    FD_HIP(hipStreamSynchronize(s));
+    (void)hipFree(err);
+    if (e) FD_FAIL("fd_ocr_node_diag: an owned row has no diagonal entry within its first 256 columns");
     return 0;
 }
 

@@ -167,6 +167,31 @@ template <int ARITY> __device__ __forceinline__ void load_lmap(const uint16_t *_
     load_packed<uint16_t, ARITY>(p, out);
 }
 
+// ---- bit-packed instance records (fd_ocr_pack_records): W 32-bit words per instance hold every per-instance index of an
+// owner-computes-rows loop back to back -- the local-map entries at ceil(log2(nodes per block)) bits, the row-offset entries
+// at ceil(log2(longest CSR row)) bits -- instead of uint16 / uint8 arrays: P1 tetrahedra 24 -> 12 bytes per instance.
+// Field offsets and widths are compile-time constants, so a field is one v_bfe_u32 (two instructions when it straddles words).
+template <int W> __device__ __forceinline__ void load_rec(const unsigned *__restrict__ p, unsigned (&w)[W]) {
+    if constexpr (W % 4 == 0) {
+        const uint4 *q = reinterpret_cast<const uint4 *>(p);
+#pragma unroll
+        for (int k = 0; k < W / 4; ++k) { const uint4 v = q[k]; w[4*k] = v.x; w[4*k+1] = v.y; w[4*k+2] = v.z; w[4*k+3] = v.w; }
+    } else if constexpr (W % 2 == 0) {
+        const uint2 *q = reinterpret_cast<const uint2 *>(p);
+#pragma unroll
+        for (int k = 0; k < W / 2; ++k) { const uint2 v = q[k]; w[2*k] = v.x; w[2*k+1] = v.y; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < W; ++k) w[k] = p[k];          // (three adjacent words fuse into one global_load_dwordx3)
+    }
+}
+template <int OFF, int BITS, int W> __device__ __forceinline__ int rec_field(const unsigned (&w)[W]) {
+    constexpr int I = OFF >> 5, S = OFF & 31;
+    constexpr unsigned M = BITS >= 32 ? 0xffffffffu : ((1u << BITS) - 1u);
+    if constexpr (S + BITS <= 32) return (int)((w[I] >> S) & M);
+    else return (int)(((w[I] >> S) | (w[I + 1] << (32 - S))) & M);
+}
+
 }  // namespace fdw
 
 #include "fd_callables.h"

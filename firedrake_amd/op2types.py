@@ -1961,6 +1961,23 @@ class OcrPlan:
             _lib.call("fd_csr_elem_row_offsets", sparsity._node_rowptr.ptr, sparsity._node_colidx.ptr, ir.ptr, ic.ptr,
                       int(self.ninst), rmap.arity, cmap.arity, self.kbytes, self.kidx.ptr, None)
 
+    def records(self, staged_keys, lbits, kbits, diag, words, nr, nc):
+        """Bit-packed instance records (fd_ocr_pack_records) for the staged maps ``staged_keys`` in the wrapper's order:
+        device buffer of ``words`` 32-bit words per instance, built once per layout."""
+        key = (tuple(staged_keys), tuple(lbits), kbits, bool(diag), words)
+        cache = self.__dict__.setdefault("_records", {})
+        buf = cache.get(key)
+        if buf is None:
+            n = len(staged_keys)
+            buf = DeviceBuffer(max(self.ninst, 1) * words * 4)
+            lm = (ctypes.c_void_p * max(n, 1))(*[self.plans[k_].lmap for k_ in staged_keys])
+            ar = (ctypes.c_int32 * max(n, 1))(*[self.plans[k_].arity for k_ in staged_keys])
+            lb = (ctypes.c_int32 * max(n, 1))(*[int(b) for b in lbits])
+            _lib.call("fd_ocr_pack_records", int(self.ninst), n, lm, ar, lb, self.kidx.ptr, self.kbytes, int(nr), int(nc), int(kbits),
+                      1 if diag else 0, int(words), buf.ptr, None)
+            cache[key] = buf
+        return buf
+
     @staticmethod
     def _order_code(lane_threads):
         """fd_ocrplan_create's ``interleave`` argument for configuration["ocr_order"]."""
@@ -2109,6 +2126,24 @@ class RowOrder:
             self._gpos = DeviceBuffer(max(int(self.prowptr_host[-1]), 1) * 4)
             _lib.call("fd_row_entry_positions", self.npos, self.prowptr.ptr, self.gstart.ptr, self._gpos.ptr, None)
         return self._gpos
+
+    def runs(self, row_blocks):
+        """Run-coded places of the accumulator entries for the row blocks ``row_blocks`` (host array of nblocks + 1 positions;
+        fd_ocr_row_runs): (grun, brun, rdelta device buffers, most runs in one block), built once per set of blocks."""
+        rb = np.ascontiguousarray(row_blocks, dtype=np.int32)
+        key = rb.tobytes()
+        hit = getattr(self, "_runs", None)
+        if hit is None or hit[0] != key:
+            nb = len(rb) - 1
+            grun = DeviceBuffer(max(int(self.prowptr_host[-1]), 1))
+            brun = DeviceBuffer((nb + 1) * 4)
+            rdelta = DeviceBuffer(max(self.npos, 1) * 4)
+            rblk = DeviceBuffer.from_numpy(rb)
+            nruns, mx = ctypes.c_int32(), ctypes.c_int32()
+            _lib.call("fd_ocr_row_runs", self.npos, self.prowptr.ptr, self.gstart.ptr, rblk.ptr, nb, grun.ptr, brun.ptr, rdelta.ptr,
+                      ctypes.byref(nruns), ctypes.byref(mx), None)
+            hit = self._runs = (key, grun, brun, rdelta, int(mx.value), int(nruns.value))
+        return hit[1:]
 
     def tile_cuts(self, entity_blocks, cap):
         """Row-block boundaries (row positions) at the changes of the entity tile that first touches a row: the rows of one

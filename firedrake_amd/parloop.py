@@ -913,12 +913,30 @@ class Parloop:
         if lds > 160 * 1024 or op.max_inst * maxar > 32768:
             raise PlanDoesNotFit("owner-computes-rows plan does not fit (LDS or instance list)")
         nds = [op.plans[mi].max_nd for mi in src.staged_maps]
-        variant = mode_variant("ocrp" if row_order is not None else "ocr", op.kbytes, nds)
-        geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz,
+        base = "ocrp" if row_order is not None else "ocr"
+        runs = None
+        if row_order is not None and configuration["ocr_run_flush"]:
+            # run-coded flush when no block has more than 256 runs of CSR-consecutive rows (a random numbering has one per row)
+            runs = row_order.runs(op.row_blocks)
+            if runs[3] <= 256:
+                base, lds = "ocrpr", lds + 1024
+            else:
+                runs = None
+        rec = None
+        if configuration["ocr_records"] and len(src.staged_maps) <= 8:
+            from .codegen import record_layout
+            maxlen = int(np.diff(rp).max()) if len(rp) > 1 else 1
+            rec = record_layout([staged[mi].arity for mi in src.staged_maps], nds, rmap.arity, cmap.arity, maxlen,
+                                pa.maps[0]._base() is pa.maps[1]._base())
+            if rec[3] * 4 >= sum(staged[mi].arity for mi in src.staged_maps) * 2 + rmap.arity * cmap.arity * op.kbytes:
+                rec = None                                            # no smaller than the plain rows
+        variant = mode_variant(base, op.kbytes, nds, rec)
+        geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz, "rec": rec, "runs": runs,
                "cw": prep["cw"] if variant == src.mode else self.global_kernel.compile(variant), "row_order": row_order}
         prep["parts"][gkey] = geo
         if configuration["debug"]:
             import sys
+            print(f"[fdhip] {self.global_kernel.name} OCR variant {variant}: record {rec}, runs per block <= {runs[3] if runs else None}", file=sys.stderr)
             print(f"[fdhip] {self.global_kernel.name} OCR [{start},{end}): row blocks={op.nblocks} instances={op.ninst} "
                   f"(x{op.ninst / max(end - start, 1):.2f} entities) max_inst={op.max_inst} max_nnz={op.max_nnz} max_nown={op.max_nown} "
                   f"lds={lds} kbytes={op.kbytes}", file=sys.stderr)
@@ -1066,7 +1084,13 @@ class Parloop:
             elif kind == "ocr_gstart":
                 out.append(geo["row_order"].gstart.ptr)
             elif kind == "ocr_srow":
-                out.append(self._ocr_node_words(geo, desc[1], desc[2]))
+                out.append(self._ocr_node_words(geo, desc[1], desc[2], diag=len(desc) > 3))
+            elif kind == "ocr_rec":
+                lbits, kbits, diag, words = geo["rec"]
+                rm_, cm_ = self.arguments[desc[1]].maps
+                out.append(op.records(src.staged_maps, lbits, kbits, diag, words, rm_.arity, cm_.arity).ptr)
+            elif kind in ("ocr_grun", "ocr_brun", "ocr_rdelta"):
+                out.append(geo["runs"][{"ocr_grun": 0, "ocr_brun": 1, "ocr_rdelta": 2}[kind]].ptr)
             elif kind == "ocr_gpos":
                 out.append(geo["row_order"].gpos().ptr)
             elif kind == "ocr_npos":
@@ -1106,14 +1130,14 @@ class Parloop:
         ent["buf"] = buf
         return buf.ptr
 
-    def _ocr_node_words(self, geo, k, rm):
+    def _ocr_node_words(self, geo, k, rm, diag=False):
         """Plan-ordered row words of Mat argument ``k`` (fd_ocr_node_words) for its current pair of lgmaps: built on first use
         per pair and cached by identity -- the reference swaps lgmaps per call (parloop.py:279-314), a set of boundary
         conditions is assembled many times."""
         pa = self.arguments[k]
         lg = pa.lgmaps or (None, None)
         ident = lambda o: ("dev", o._fd_dev_ptr, getattr(o, "_fd_token", None)) if hasattr(o, "_fd_dev_ptr") else id(o)   # noqa: E731
-        key = (k, ident(lg[0]), ident(lg[1]))
+        key = (k, ident(lg[0]), ident(lg[1]), bool(diag))
         cache = geo.setdefault("srow", {})
         hit = cache.get(key)
         if hit is None:
@@ -1126,6 +1150,10 @@ class Parloop:
             _lib.call("fd_ocr_node_words", plan.blkoff, plan.list, op.nblocks, op.rblk, base, starts, 1 if ro is not None else 0,
                       ro.npos if ro is not None else 0, self._lgmap(lg[0]) if lg[0] is not None else None,
                       self._lgmap(lg[1]) if lg[1] is not None else None, buf.ptr, None)
+            if diag:
+                # the place of a row's diagonal entry rides in the node word (records without the (i, i) offsets)
+                _lib.call("fd_ocr_node_diag", plan.list, plan.list_len, int(sp.dsets[0].set.total_size), sp._node_rowptr.ptr,
+                          sp._node_colidx.ptr, buf.ptr, None)
             while len(cache) >= 4:
                 cache.pop(next(iter(cache)))
             hit = (lg, buf)

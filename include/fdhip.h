@@ -188,6 +188,21 @@ int fd_ocrplan_create(const int32_t *rmap_dev, int rarity, int32_t start, int32_
 int fd_ocr_node_words(const int32_t *blkoff_dev, const int32_t *list_dev, int32_t nblocks, const int32_t *rblk_dev,
                       const int32_t *base_by_node_dev, const int32_t *start_by_pos_dev, int by_offset, int32_t npos,
                       const int32_t *row_lgmap_dev, const int32_t *col_lgmap_dev, uint32_t *out_dev, fd_stream_t s);
+/* words[i] |= (position of the diagonal entry inside the CSR row of node list[i]) << 20 (bits 20..27): with one map on both
+ * sides of the Mat the place of entry (i, i) of an element matrix belongs to the row NODE, so the per-instance records below
+ * need not carry it (the diagonal is always allocated: pyop2/sparsity.pyx:198-203).  Fails when an owned row has no diagonal
+ * entry among its first 256 columns. */
+int fd_ocr_node_diag(const int32_t *list_dev, int64_t n, int32_t nrows, const int32_t *rowptr_dev, const int32_t *colidx_dev,
+                     uint32_t *words_dev, fd_stream_t s);
+/* Bit-packed per-instance records of a whole-entity owner-computes-rows loop: `words` 32-bit words per instance hold, back to
+ * back from bit 0, the local-map rows of the nmaps staged maps (uint16 tables of the node plans, arities[m] entries of
+ * lbits[m] bits) and the nr x nc row-offset entries (kidx, kbytes 1|2 per entry, kbits bits each; the nr diagonal entries
+ * left out when skipdiag).  The wrapper streams ONE record per instance (fdw::load_rec / rec_field) instead of a uint16 row per
+ * map plus a uint8 row of offsets: P1 tetrahedra 24 -> 12 bytes (the reference has no such tables: MatSetValuesLocal searches
+ * every row on every call, builder.py:573-625).  Fails when an index does not fit its field. */
+int fd_ocr_pack_records(int64_t ninst, int nmaps, const uint16_t *const *lmaps_dev, const int32_t *arities, const int32_t *lbits,
+                        const void *kidx_dev, int kbytes, int nr, int nc, int kbits, int skipdiag, int words, uint32_t *out_dev,
+                        fd_stream_t s);
 /* Bank-aware packing of the instance lists (in place; inst_off is unchanged): given the per-instance row-map rows
  * (global node ids), local-map rows and row-offset table built for the CURRENT instance order, a greedy list scheduler
  * reorders the instances inside chunks of 128 (one wavefront per chunk, all chunks of all blocks in parallel) so that the 16
@@ -339,6 +354,12 @@ int fd_invert_permutation(const int32_t *plist_dev, int32_t n, int32_t *pinv_dev
 /* gpos[prowptr[p] + k] = gstart[p] + k for the rows p of a row order (prowptr = accumulator starts by position, gstart = CSR
  * starts by position): the place of every accumulator entry in the CSR value array, streamed by the "ocrp" row flush */
 int fd_row_entry_positions(int32_t npos, const int32_t *prowptr_dev, const int32_t *gstart_dev, int32_t *gpos_dev, fd_stream_t s);
+/* The same places run-coded: rows that follow one another in a block of the row order (rblk: nblocks + 1 block starts in row
+ * positions) AND in the CSR share one displacement (place - accumulator index).  grun[entry] = run of the entry's row counted
+ * from its block's first run (one byte), brun[b] = first run of block b (nblocks + 1), rdelta[run] = displacement (room for
+ * npos).  *max_runs_out = most runs in one block: the "ocrpr" flush keeps a block's displacements in LDS and needs <= 256. */
+int fd_ocr_row_runs(int32_t npos, const int32_t *prowptr_dev, const int32_t *gstart_dev, const int32_t *rblk_dev, int32_t nblocks,
+                    uint8_t *grun_dev, int32_t *brun_dev, int32_t *rdelta_dev, int32_t *nruns_out, int32_t *max_runs_out, fd_stream_t s);
 
 /* ------------------------------------------------- halo exchange + Global reductions over RCCL
  * firedrake/halo.py:87-172 (PetscSF bcast owner->ghost with MPI.REPLACE, reduce ghost->owner with SUM/MIN/MAX behind

@@ -161,7 +161,52 @@ def run_staged(pl, epb=48, order=None):
     return [outs.get(k) for k in range(len(pl.arguments))]
 
 
-def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None):
+def pack_records_ref(lmaps, lbits, kidx, nr, nc, kbits, diag, words):
+    """numpy restatement of fd_ocr_pack_records: per instance the local-map rows of the staged maps (lbits[m] bits per entry)
+    and the nr x nc row offsets (kbits bits, diagonal left out when ``diag``), back to back from bit 0 of ``words`` 32-bit words."""
+    kidx = np.asarray(kidx).reshape(-1, nr * nc)
+    ninst = len(kidx)
+    out = np.zeros((max(ninst, 1), words), dtype=np.uint32)
+    for t in range(ninst):
+        acc, off = 0, 0
+        for lm, lb in zip(lmaps, lbits):
+            for v in np.asarray(lm).reshape(ninst, -1)[t]:
+                assert int(v) < (1 << lb)
+                acc |= int(v) << off
+                off += lb
+        for i in range(nr):
+            for j in range(nc):
+                if diag and i == j:
+                    continue
+                assert int(kidx[t, i * nc + j]) < (1 << kbits)
+                acc |= int(kidx[t, i * nc + j]) << off
+                off += kbits
+        for w in range(words):
+            out[t, w] = (acc >> (32 * w)) & 0xffffffff
+    return out
+
+
+def row_runs_ref(prowptr, gstart, rb):
+    """numpy restatement of fd_ocr_row_runs: (grun per entry, brun per block, rdelta per run, most runs in a block)."""
+    npos = len(gstart)
+    disp = np.asarray(gstart, dtype=np.int64) - np.asarray(prowptr[:npos], dtype=np.int64)
+    flag = np.ones(npos, dtype=np.int64)
+    flag[1:] = disp[1:] != disp[:-1]
+    flag[[int(r) for r in rb[:-1] if r < npos]] = 1
+    runidx = np.cumsum(flag) - 1
+    nruns = int(runidx[-1]) + 1 if npos else 0
+    brun = np.array([int(runidx[r]) if r < npos else nruns for r in rb], dtype=np.int32)
+    rdelta = np.zeros(max(nruns, 1), dtype=np.int32)
+    rdelta[runidx[flag == 1]] = disp[flag == 1]
+    grun = np.zeros(max(int(prowptr[npos]), 1), dtype=np.uint8)
+    for b in range(len(rb) - 1):
+        for p_ in range(int(rb[b]), int(rb[b + 1])):
+            assert runidx[p_] - brun[b] <= 255
+            grun[int(prowptr[p_]):int(prowptr[p_ + 1])] = runidx[p_] - brun[b]
+    return grun, brun, rdelta, int(np.diff(brun).max()) if len(rb) > 1 else 0
+
+
+def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False, run_flush=False):
     """Execute a matrix-assembly Parloop ``pl`` with the OWNER-COMPUTES-ROWS wrapper on the host (one OS thread per
     lane, tests/hostsim/mt/fd_wrapper.h).  The plan tables come from the numpy restatements in helpers.py; the CSR
     pattern from the oracle.  Returns the OracleCSR holding the assembled values."""
@@ -198,7 +243,16 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None):
         blk, lst, lm = plan_ref_blocks(np.asarray(maps[mi].values_with_halo)[inst_ent], inst_off)
         plans[mi] = (blk, lst, np.ascontiguousarray(lm), int(np.diff(blk).max()) if len(blk) > 1 else 0)
     max_nnz = int(np.diff((prowptr if order is not None else csr.rowptr)[rb]).max())
-    src = generate_wrapper(gk, mode_variant("ocrp" if order is not None else "ocr", 1, [plans[mi][3] for mi in base.staged_maps]))
+    rec = None
+    if records:
+        from firedrake_amd.codegen import record_layout
+        rec = record_layout([maps[mi].arity for mi in base.staged_maps], [plans[mi][3] for mi in base.staged_maps], rmap.arity,
+                            cmap.arity, int(np.diff(csr.rowptr).max()), mpa.maps[0]._base() is mpa.maps[1]._base())
+    run_tabs = None
+    if order is not None and run_flush:
+        run_tabs = row_runs_ref(prowptr, csr.rowptr[plist], rb)
+    src = generate_wrapper(gk, mode_variant(("ocrpr" if run_tabs else "ocrp") if order is not None else "ocr", 1,
+                                            [plans[mi][3] for mi in base.staged_maps], rec))
     text = src.source.replace("extern __shared__ __align__(16) unsigned char fd_lds[];", "unsigned char *fd_lds = fd_sim::lds;")
     sig = re.search(r'extern "C" __global__[^\n]*void %s\((.*)\)\n' % src.symbol, text).group(1)
     names = [p.split()[-1].lstrip("*") for p in sig.split(", ")]
@@ -287,8 +341,20 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None):
                     w = p_ + 1 if (p_ >= 0 and not (lg[0] is not None and lg[0][g] < 0)) else 0
                     if lg[1] is not None and lg[1][g] < 0:
                         w |= 0x80000000
+                    if len(desc) > 3 and 0 <= g < len(csr.rowptr) - 1:
+                        # fd_ocr_node_diag: place of the diagonal entry inside the node's CSR row, bits 20..27
+                        row = csr.colidx[csr.rowptr[g]:csr.rowptr[g + 1]]
+                        hit = np.nonzero(row == g)[0]
+                        if len(hit):
+                            w |= int(hit[0]) << 20
                     words[i] = w
             cargs.append(ptr(words))
+        elif kind == "ocr_rec":
+            lbits, kbits, diag, words_ = rec
+            cargs.append(ptr(pack_records_ref([plans[mi][2] for mi in base.staged_maps], lbits, kidx, rmap.arity, cmap.arity,
+                                              kbits, diag, words_)))
+        elif kind in ("ocr_grun", "ocr_brun", "ocr_rdelta"):
+            cargs.append(ptr(run_tabs[{"ocr_grun": 0, "ocr_brun": 1, "ocr_rdelta": 2}[kind]]))
         elif kind == "ocr_gpos":
             # place of every accumulator entry (rows in position order) in the CSR value array
             cargs.append(ptr(np.concatenate([np.arange(csr.rowptr[r], csr.rowptr[r + 1]) for r in plist] + [np.zeros(0, np.int64)]).astype(np.int32)))

@@ -148,6 +148,12 @@ template <class T, int N> inline void load_packed(const T *p, int (&out)[N]) {
     for (int k = 0; k < N; ++k) out[k] = p[k];
 }
 template <int ARITY> inline void load_lmap(const uint16_t *p, int (&out)[ARITY]) { load_packed<uint16_t, ARITY>(p, out); }
+template <int W> inline void load_rec(const unsigned *p, unsigned (&w)[W]) { for (int k = 0; k < W; ++k) w[k] = p[k]; }
+template <int OFF, int BITS, int W> inline int rec_field(const unsigned (&w)[W]) {
+    unsigned long long v = w[OFF >> 5];
+    if ((OFF >> 5) + 1 < W) v |= (unsigned long long)w[(OFF >> 5) + 1] << 32;
+    return (int)((v >> (OFF & 31)) & ((1ull << BITS) - 1ull));
+}
 }  // namespace fdw
 
 #include "../../../oracle/callables.h"

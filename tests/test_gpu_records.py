@@ -1,0 +1,104 @@
+"""GPU: the compact index tables of the whole-entity owner-computes-rows wrapper (round 4) -- bit-packed instance records
+(fd_ocr_pack_records + fd_ocr_node_diag) and the run-coded flush of a derived row order (fd_ocr_row_runs) -- against their
+numpy restatements (tests/hostsim.py) and, end to end, against the oracle's MatSetValuesLocal (builder.py:573-625) with every
+combination of the switches."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from firedrake_amd import _lib, forms, mesh as fmesh, op2
+from firedrake_amd.configuration import configuration
+from firedrake_amd.device import DeviceBuffer
+from helpers import oracle_run
+
+pytestmark = pytest.mark.gpu
+
+
+def _down(ptr, dt, shape):
+    a = np.empty(shape, dtype=dt)
+    if a.nbytes:
+        _lib.call("fd_memcpy_d2h", a.ctypes.data, ptr, a.nbytes, None)
+    return a
+
+
+@pytest.mark.parametrize("diag", [False, True])
+def test_pack_records_matches_numpy_restatement(diag):
+    from hostsim import pack_records_ref
+    rng = np.random.default_rng(3)
+    ninst, nr, nc = 1000, 4, 4
+    lm0 = rng.integers(0, 500, (ninst, 4)).astype(np.uint16)
+    lm1 = rng.integers(0, 37, (ninst, 3)).astype(np.uint16)
+    kidx = rng.integers(0, 27, (ninst, nr * nc)).astype(np.uint8)
+    lbits, kbits = [9, 6], 5
+    bits = 4 * 9 + 3 * 6 + (nr * nc - (nr if diag else 0)) * kbits
+    words = -(-bits // 32)
+    d0, d1, dk = DeviceBuffer.from_numpy(lm0), DeviceBuffer.from_numpy(lm1), DeviceBuffer.from_numpy(kidx)
+    out = DeviceBuffer(ninst * words * 4)
+    lm = (ctypes.c_void_p * 2)(d0.ptr, d1.ptr)
+    ar = (ctypes.c_int32 * 2)(4, 3)
+    lb = (ctypes.c_int32 * 2)(*lbits)
+    _lib.call("fd_ocr_pack_records", ninst, 2, lm, ar, lb, dk.ptr, 1, nr, nc, kbits, int(diag), words, out.ptr, None)
+    got = _down(out.ptr, np.uint32, (ninst, words))
+    ref = pack_records_ref([lm0, lm1], lbits, kidx, nr, nc, kbits, diag, words)
+    assert np.array_equal(got, ref)
+    # an index that does not fit its field is an error, not a truncation
+    with pytest.raises(_lib.FDHipError):
+        _lib.call("fd_ocr_pack_records", ninst, 2, lm, ar, (ctypes.c_int32 * 2)(8, 6), dk.ptr, 1, nr, nc, kbits, int(diag),
+                  -(-(4 * 8 + 3 * 6 + (nr * nc - (nr if diag else 0)) * kbits) // 32), out.ptr, None)
+
+
+def test_row_runs_match_numpy_restatement():
+    from hostsim import row_runs_ref
+    rng = np.random.default_rng(11)
+    npos = 5000
+    rowlen = rng.integers(1, 30, npos)
+    # a row order made of runs of consecutive rows (what a k-d leaf of a lexicographic numbering looks like)
+    starts = np.sort(rng.choice(npos, 400, replace=False))
+    starts[0] = 0
+    pieces = np.split(np.arange(npos), starts[1:])
+    plist = np.concatenate([pieces[i] for i in rng.permutation(len(pieces))])
+    rp = np.concatenate([[0], np.cumsum(rowlen)]).astype(np.int32)
+    prowptr = np.concatenate([[0], np.cumsum(rowlen[plist])]).astype(np.int32)
+    gstart = rp[plist].astype(np.int32)
+    rb = np.unique(np.concatenate([np.sort(rng.choice(npos, 60, replace=False)), [0, npos]])).astype(np.int32)
+    nb = len(rb) - 1
+    dp, dg, dr = DeviceBuffer.from_numpy(prowptr), DeviceBuffer.from_numpy(gstart), DeviceBuffer.from_numpy(rb)
+    grun, brun, rdelta = DeviceBuffer(int(prowptr[-1])), DeviceBuffer((nb + 1) * 4), DeviceBuffer(npos * 4)
+    nruns, mx = ctypes.c_int32(), ctypes.c_int32()
+    _lib.call("fd_ocr_row_runs", npos, dp.ptr, dg.ptr, dr.ptr, nb, grun.ptr, brun.ptr, rdelta.ptr, ctypes.byref(nruns), ctypes.byref(mx), None)
+    g_ref, b_ref, d_ref, mx_ref = row_runs_ref(prowptr, gstart, rb)
+    assert mx.value == mx_ref and nruns.value == b_ref[-1]
+    assert np.array_equal(_down(brun.ptr, np.int32, (nb + 1,)), b_ref)
+    assert np.array_equal(_down(rdelta.ptr, np.int32, (nruns.value,)), d_ref[:nruns.value])
+    assert np.array_equal(_down(grun.ptr, np.uint8, (int(prowptr[-1]),)), g_ref[:int(prowptr[-1])])
+    # the decoded places are exactly the per-entry table of the plain "ocrp" flush
+    gpos = np.concatenate([np.arange(gstart[p], gstart[p] + rowlen[plist[p]]) for p in range(npos)])
+    blk = np.repeat(np.arange(nb), np.diff(prowptr[rb]))
+    assert np.array_equal(np.arange(int(prowptr[-1])) + d_ref[b_ref[blk] + g_ref[:int(prowptr[-1])]], gpos)
+
+
+@pytest.mark.parametrize("numbering", ["tiled", "lexicographic", "random"])
+@pytest.mark.parametrize("records,diag,runs", [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 0, 1), (1, 1, 1)])
+def test_p1_jacobian_with_compact_tables_matches_oracle(numbering, records, diag, runs, monkeypatch):
+    monkeypatch.setitem(configuration, "ocr_records", records)
+    monkeypatch.setitem(configuration, "ocr_records_diag", diag)
+    monkeypatch.setitem(configuration, "ocr_run_flush", runs)
+    monkeypatch.setitem(configuration, "locality_min_entities", 64)
+    m = fmesh.UnitCubeMesh(12, degrees=(1,), perturb=0.1, numbering=numbering)
+    prob = forms.PoissonProblem(m, 1, bcs=True)
+    mat, pl = prob.jacobian()
+    for _ in range(2):                                   # second call: plan-ordered copies, cached tables
+        mat.zero()
+        pl.compute()
+    geo = [g for key, g in pl._prepared["parts"].items() if key[0] == "ocr"][0]
+    assert bool(geo["rec"]) == bool(records) and (geo["rec"][2] if records else False) == bool(diag)
+    if numbering == "tiled":
+        assert geo["cw"].src.mode.startswith("ocr_") or geo["cw"].src.mode == "ocr"
+    elif runs and numbering == "lexicographic":
+        assert geo["cw"].src.mode.startswith("ocrpr")
+    mpa = pl.arguments[0]
+    args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
+    ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
+    _, _, v = mat.csr()
+    assert np.abs(v - ref.values).max() <= 1e-12 * np.abs(ref.values).max()

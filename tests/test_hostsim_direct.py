@@ -428,6 +428,10 @@ def test_owner_computes_rows_wrapper_on_host(bcs, plan_copies):
         if degree == 1:                              # accumulate into existing values (no pending Mat.zero())
             got2 = run_ocr(pl, rows_per_block=17, zero_pending=False)
             assert np.abs(got2.values - (ref.values + 1.0)).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
+        # the same loop with ONE bit-packed record per instance (fd_ocr_pack_records) instead of the uint16 / uint8 index rows;
+        # P1: one map on both sides, so the diagonal offsets come from the row nodes' words
+        got3 = run_ocr(pl, rows_per_block=17 if degree == 1 else 40, records=True)
+        assert np.abs(got3.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
 
 
 def test_staged_wrapper_mixed_and_other_dtypes_on_host():
@@ -580,6 +584,10 @@ def test_owner_computes_rows_over_a_row_order_on_host(bcs, numbering):
         if degree == 1:
             got2 = run_ocr(pl, rows_per_block=rpb, zero_pending=False, order=order)
             assert np.abs(got2.values - (ref.values + 1.0)).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
+        # "ocrpr": run-coded flush (fd_ocr_row_runs) + bit-packed records, fresh and accumulating
+        for zp in (True, False):
+            got3 = run_ocr(pl, rows_per_block=rpb, zero_pending=zp, order=order, records=True, run_flush=True)
+            assert np.abs(got3.values - (ref.values + (0.0 if zp else 1.0))).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
 
 
 @pytest.mark.parametrize("bcs", [False, True])
@@ -822,6 +830,8 @@ static void rnd{seed}(double *A, const double *w, const double *y)
     assert np.abs(got.values - (ref.values + (0.0 if zero else 1.0))).max() <= tol
     if rbs * cbs == 1 and not unroll:
         got = run_ocr(pl, rows_per_block=int(rng.integers(3, 40)), zero_pending=zero, order=order)
+        assert np.abs(got.values - (ref.values + (0.0 if zero else 1.0))).max() <= tol
+        got = run_ocr(pl, rows_per_block=int(rng.integers(3, 40)), zero_pending=zero, order=order, records=True, run_flush=bool(seed % 2))
         assert np.abs(got.values - (ref.values + (0.0 if zero else 1.0))).max() <= tol
 
 
