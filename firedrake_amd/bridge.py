@@ -457,7 +457,9 @@ class _BorrowedDat:
     def __init__(self, ptr, dim, dtype, toset=None):
         self._ptr, self.dim, self.dtype = ptr, tuple(dim), np.dtype(dtype)
         self.cdim = int(np.prod(dim))
-        self._halo_frozen, self.halo_valid, self.dat_version = False, True, 0
+        # dat_version None: the owner (PyOP2 / PETSc / another seam func) may rewrite the buffer between calls without this
+        # carrier hearing of it, so nothing may be cached on its VALUES (Parloop._plan_copy keeps the in-kernel gather)
+        self._halo_frozen, self.halo_valid, self.dat_version = False, True, None
         s = toset if toset is not None else _BorrowedDat._NoHalo()
         self.dataset = type("DS", (), {"set": s, "size": getattr(s, "size", 0) or 0, "total_size": getattr(s, "total_size", 0) or 0,
                                        "cdim": self.cdim, "dim": self.dim})()

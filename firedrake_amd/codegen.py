@@ -1049,6 +1049,11 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     P(f"const int *__restrict__ oc{K}_rowptr", ("ocr_prowptr" if ordered else "ocr_rowptr", K))
     if ordered:
         P(f"const int *__restrict__ oc{K}_gstart", ("ocr_gstart", K))
+    # flush of a derived row order through the per-entry place table of the whole-entity wrapper (4 B per nonzero, FU places
+    # requested per trip) instead of row by row with 16 lanes per row
+    entry_flush = bool(ordered and B == 1 and configuration["ocrs_entry_flush"])
+    if entry_flush:
+        P(f"const int *__restrict__ oc{K}_gpos", ("ocr_gpos", K))
     P(f"const unsigned short *__restrict__ oc{K}_slot", ("ocrs_slot", K))
     if B > 1:
         P(f"const unsigned short *__restrict__ oc{K}_rowlen", ("ocrs_rowlen", K))
@@ -1193,8 +1198,15 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             src.append(f"    for (int q = 0; q < {ln}; ++q) {n}[q] = nx_{n}[q];")
         src.append("    " + " ".join(f"{n} = nx_{n};" for n, _ in scal) + (" cmask = nx_cmask;" if dofmask else ""))
     src += ["  }", "  __syncthreads();"]
-    if ordered:
-        # (a per-entry flush table like the whole-entity wrapper's measured 8 % slower here: rows are ~28 entries long, profiles/r3t)
+    if entry_flush:
+        FU = max(1, int(configuration["flush_batch"]))
+        src.append(f"  for (int q0 = tid; q0 < nnzb; q0 += {FU}*nthr) {{ int g[{FU}]; "
+                   f"for (int f = 0; f < {FU}; ++f) {{ const int q = q0 + f*nthr; g[f] = oc{K}_gpos[(size_t)r0 + (q < nnzb ? q : nnzb - 1)]; }} "
+                   f"if (oc{K}_flags & 1) {{ for (int f = 0; f < {FU}; ++f) if (q0 + f*nthr < nnzb) arg{K}[(size_t)g[f]] = sm{K}[q0 + f*nthr]; }} "
+                   f"else {{ double o[{FU}]; for (int f = 0; f < {FU}; ++f) o[f] = (q0 + f*nthr < nnzb) ? arg{K}[(size_t)g[f]] : 0.0; "
+                   f"for (int f = 0; f < {FU}; ++f) if (q0 + f*nthr < nnzb) arg{K}[(size_t)g[f]] = o[f] + sm{K}[q0 + f*nthr]; }} }}")
+    elif ordered:
+        # (a per-entry flush table like the whole-entity wrapper's measured 8 % slower here before its loads were batched: profiles/r3t)
         FU = max(1, int(configuration["flush_batch"]))
         if FU == 1:
             src.append(f"  for (int fr = tid >> 4; fr < nown; fr += nthr >> 4) {{ const int fp = n0 + fr; "

@@ -152,11 +152,15 @@ __global__ void split_counts(int32_t nrows, const int32_t *__restrict__ rowptr, 
 
 // one wavefront per row: copy the prefix into the diagonal block (local column indices) and the suffix into the
 // off-diagonal block (GLOBAL column indices through col_global, as MatCreateMPIAIJWithSplitArrays expects)
+// The off-diagonal block is a SeqAIJ matrix of its own (MatCreateSeqAIJWithArrays: sorted column indices per row), and the
+// local ghost numbering is not monotone in the global one: WITH_IDX ranks every off-diagonal entry inside its row by global
+// column (rows are short: a quadratic count) and stores the rank; WITH_VALS scatters the values through it.
 template <bool WITH_IDX, bool WITH_VALS>
 __global__ void split_fill(int32_t nrows, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                            const double *__restrict__ vals, const int32_t *__restrict__ col_global,
                            const int32_t *__restrict__ drp, const int32_t *__restrict__ orp,
-                           int32_t *__restrict__ dci, int32_t *__restrict__ oci, double *__restrict__ dv, double *__restrict__ ov) {
+                           int32_t *__restrict__ dci, int32_t *__restrict__ oci, double *__restrict__ dv, double *__restrict__ ov,
+                           int32_t *__restrict__ orank) {
     const int lane = threadIdx.x & 63;
     for (int64_t r = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6; r < nrows; r += ((int64_t)gridDim.x * blockDim.x) >> 6) {
         const int b = rowptr[r], nd = drp[r + 1] - drp[r], no = orp[r + 1] - orp[r];
@@ -165,8 +169,17 @@ __global__ void split_fill(int32_t nrows, const int32_t *__restrict__ rowptr, co
             if (WITH_VALS) dv[drp[r] + q] = vals[b + q];
         }
         for (int q = lane; q < no; q += 64) {
-            if (WITH_IDX) { const int32_t c = colidx[b + nd + q]; oci[orp[r] + q] = col_global ? col_global[c] : c; }
-            if (WITH_VALS) ov[orp[r] + q] = vals[b + nd + q];
+            if (WITH_IDX) {
+                const int32_t c = colidx[b + nd + q], g = col_global ? col_global[c] : c;
+                int rank = 0;
+                for (int p = 0; p < no; ++p) {
+                    const int32_t c2 = colidx[b + nd + p], g2 = col_global ? col_global[c2] : c2;
+                    rank += (g2 < g || (g2 == g && p < q)) ? 1 : 0;
+                }
+                oci[orp[r] + rank] = g;
+                orank[orp[r] + q] = rank;
+            }
+            if (WITH_VALS) ov[orp[r] + (orank ? orank[orp[r] + q] : q)] = vals[b + nd + q];
         }
     }
 }
@@ -444,12 +457,12 @@ int fd_csr_zero_rows(const int32_t *rowptr, const int32_t *colidx, double *vals,
 
 int fd_csr_split_mpiaij(int32_t nrows_owned, const int32_t *rowptr, const int32_t *colidx, int32_t ncols_owned,
                         const int32_t *col_global, int32_t **d_rowptr, int32_t **d_colidx, int64_t *d_nnz,
-                        int32_t **o_rowptr, int32_t **o_colidx, int64_t *o_nnz, fd_stream_t s_) {
-    if (nrows_owned < 0 || !rowptr || !colidx || !d_rowptr || !d_colidx || !o_rowptr || !o_colidx || !d_nnz || !o_nnz)
+                        int32_t **o_rowptr, int32_t **o_colidx, int32_t **o_rank, int64_t *o_nnz, fd_stream_t s_) {
+    if (nrows_owned < 0 || !rowptr || !colidx || !d_rowptr || !d_colidx || !o_rowptr || !o_colidx || !o_rank || !d_nnz || !o_nnz)
         FD_FAIL("fd_csr_split_mpiaij: bad arguments");
     hipStream_t s = fd::st(s_);
     const size_t n1 = (size_t)nrows_owned + 1;
-    int32_t *dc = nullptr, *oc = nullptr, *drp = nullptr, *orp = nullptr, *dci = nullptr, *oci = nullptr;
+    int32_t *dc = nullptr, *oc = nullptr, *drp = nullptr, *orp = nullptr, *dci = nullptr, *oci = nullptr, *ork = nullptr;
     void *tmp = nullptr;
     FD_HIP(hipMalloc(&dc, n1 * 4)); FD_HIP(hipMalloc(&oc, n1 * 4));
     FD_HIP(hipMalloc(&drp, n1 * 4)); FD_HIP(hipMalloc(&orp, n1 * 4));
@@ -467,24 +480,25 @@ int fd_csr_split_mpiaij(int32_t nrows_owned, const int32_t *rowptr, const int32_
     FD_HIP(hipStreamSynchronize(s));
     FD_HIP(hipMalloc(&dci, (size_t)(nd > 0 ? nd : 1) * 4));
     FD_HIP(hipMalloc(&oci, (size_t)(no > 0 ? no : 1) * 4));
+    FD_HIP(hipMalloc(&ork, (size_t)(no > 0 ? no : 1) * 4));
     if (nrows_owned > 0) {
         hipLaunchKernelGGL((split_fill<true, false>), dim3(grid_for((int64_t)nrows_owned * 64)), dim3(256), 0, s, nrows_owned, rowptr, colidx,
-                           (const double *)nullptr, col_global, drp, orp, dci, oci, (double *)nullptr, (double *)nullptr);
+                           (const double *)nullptr, col_global, drp, orp, dci, oci, (double *)nullptr, (double *)nullptr, ork);
         FD_CHECK_LAUNCH();
     }
     FD_HIP(hipStreamSynchronize(s));
     FD_HIP(hipFree(dc)); FD_HIP(hipFree(oc)); FD_HIP(hipFree(tmp));
     *d_rowptr = drp; *d_colidx = dci; *d_nnz = nd;
-    *o_rowptr = orp; *o_colidx = oci; *o_nnz = no;
+    *o_rowptr = orp; *o_colidx = oci; *o_rank = ork; *o_nnz = no;
     return 0;
 }
 
 int fd_csr_split_values(int32_t nrows_owned, const int32_t *rowptr, const double *vals, const int32_t *d_rowptr,
-                        const int32_t *o_rowptr, double *d_vals, double *o_vals, fd_stream_t s) {
+                        const int32_t *o_rowptr, const int32_t *o_rank, double *d_vals, double *o_vals, fd_stream_t s) {
     if (nrows_owned <= 0) return 0;
     hipLaunchKernelGGL((split_fill<false, true>), dim3(grid_for((int64_t)nrows_owned * 64)), dim3(256), 0, fd::st(s), nrows_owned, rowptr,
                        (const int32_t *)nullptr, vals, (const int32_t *)nullptr, d_rowptr, o_rowptr, (int32_t *)nullptr, (int32_t *)nullptr,
-                       d_vals, o_vals);
+                       d_vals, o_vals, const_cast<int32_t *>(o_rank));
     FD_CHECK_LAUNCH();
     return 0;
 }

@@ -164,9 +164,12 @@ static int run_logged(const std::vector<std::string> &argv, const std::string &l
     posix_spawn_file_actions_addopen(&fa, 1, log.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
     posix_spawn_file_actions_adddup2(&fa, 1, 2);
     pid_t pid = 0;
-    const int rc = posix_spawn(&pid, av[0], &fa, nullptr, av.data(), environ);
+    const int rc = posix_spawnp(&pid, av[0], &fa, nullptr, av.data(), environ);      // (searches PATH: FDHIP_HIPCC=hipcc works)
     posix_spawn_file_actions_destroy(&fa);
-    if (rc != 0) return -1;
+    if (rc != 0) {
+        if (FILE *f = fopen(log.c_str(), "w")) { fprintf(f, "cannot start %s: %s\n", av[0], strerror(rc)); fclose(f); }
+        return -1;
+    }
     int status = 0;
     if (waitpid(pid, &status, 0) < 0) return -1;
     return WIFEXITED(status) ? WEXITSTATUS(status) : -1;

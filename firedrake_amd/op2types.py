@@ -535,6 +535,7 @@ class _Mirrored:
         if self._rw_handed and self._host_valid and self._dev_valid:
             if self._views_alive():
                 self._dev_valid = False                       # a live writable view: assume it was written
+                self.dat_version += 1                         # ... so nothing cached on the old values may be reused
             else:
                 self._rw_handed = False
         if not self._dev_valid:
@@ -1836,13 +1837,13 @@ class Sparsity:
     def nnz(self):
         """Non-zeroes per OWNED scalar row in the diagonal portion of the local submatrix: ``d_nnz`` of
         MatMPIAIJSetPreallocation (mat.py:254-262)."""
-        return np.diff(self.mpiaij_split().d_rowptr.download(np.int32, (self._dsets[0].set.size * self._dsets[0].cdim + 1,)))
+        return self.mpiaij_split().row_counts()[0]
 
     @property
     def onnz(self):
         """Non-zeroes per owned scalar row in the off-diagonal portion (columns owned by other ranks): ``o_nnz``
         (mat.py:264-271)."""
-        return np.diff(self.mpiaij_split().o_rowptr.download(np.int32, (self._dsets[0].set.size * self._dsets[0].cdim + 1,)))
+        return self.mpiaij_split().row_counts()[1]
 
     def mpiaij_split(self, col_global=None):
         """The owned rows of the scalar CSR as the two sequential blocks of an MPIAIJ matrix (fd_csr_split_mpiaij): diagonal
@@ -1855,6 +1856,8 @@ class Sparsity:
         hit = cache.get(key)
         if hit is None or hit[0] is not col_global:
             hit = (col_global, MPIAIJSplit(self, col_global))
+            while len(cache) >= 4:                   # a caller handing over a fresh lgmap array per call must not grow device memory
+                cache.pop(next(iter(cache)))
             cache[key] = hit
         return hit[1]
 
@@ -2182,16 +2185,19 @@ class MPIAIJSplit:
         if col_global is not None:
             cg = DeviceBuffer.from_numpy(np.ascontiguousarray(col_global, dtype=np.int32))
         VP = ctypes.c_void_p
-        drp, dci, orp, oci = VP(), VP(), VP(), VP()
+        drp, dci, orp, oci, ork = VP(), VP(), VP(), VP(), VP()
         dn, on = ctypes.c_int64(), ctypes.c_int64()
         _lib.call("fd_csr_split_mpiaij", self.nrows, sp._rowptr.ptr, sp._colidx.ptr, self.ncols_owned, cg.ptr if cg else None,
-                  ctypes.byref(drp), ctypes.byref(dci), ctypes.byref(dn), ctypes.byref(orp), ctypes.byref(oci), ctypes.byref(on), None)
+                  ctypes.byref(drp), ctypes.byref(dci), ctypes.byref(dn), ctypes.byref(orp), ctypes.byref(oci), ctypes.byref(ork),
+                  ctypes.byref(on), None)
         self.d_nnz, self.o_nnz = dn.value, on.value
         self.d_rowptr = DeviceBuffer.wrap(drp.value, (self.nrows + 1) * 4)
         self.d_colidx = DeviceBuffer.wrap(dci.value, max(self.d_nnz, 1) * 4)
         self.o_rowptr = DeviceBuffer.wrap(orp.value, (self.nrows + 1) * 4)
         self.o_colidx = DeviceBuffer.wrap(oci.value, max(self.o_nnz, 1) * 4)
+        self.o_rank = DeviceBuffer.wrap(ork.value, max(self.o_nnz, 1) * 4)     # place of every suffix entry in its SORTED off-diagonal row
         self.d_vals = self.o_vals = None
+        self._nnz_host = self._onnz_host = None
 
     def values(self, mat):
         """(diagonal-block values, off-diagonal-block values) of ``mat`` as assembled now (fd_csr_split_values)."""
@@ -2199,8 +2205,15 @@ class MPIAIJSplit:
             self.d_vals, self.o_vals = DeviceBuffer(max(self.d_nnz, 1) * 8), DeviceBuffer(max(self.o_nnz, 1) * 8)
         sp = mat.sparsity
         _lib.call("fd_csr_split_values", self.nrows, sp._rowptr.ptr, mat._values_dev().ptr, self.d_rowptr.ptr, self.o_rowptr.ptr,
-                  self.d_vals.ptr, self.o_vals.ptr, None)
+                  self.o_rank.ptr, self.d_vals.ptr, self.o_vals.ptr, None)
         return self.d_vals, self.o_vals
+
+    def row_counts(self):
+        """(d_nnz, o_nnz) per owned scalar row on the host, downloaded once."""
+        if self._nnz_host is None:
+            self._nnz_host = np.diff(self.d_rowptr.download(np.int32, (self.nrows + 1,)))
+            self._onnz_host = np.diff(self.o_rowptr.download(np.int32, (self.nrows + 1,)))
+        return self._nnz_host, self._onnz_host
 
 
 class MatPlan:

@@ -447,10 +447,12 @@ class Parloop:
                         if lds_ <= limit:
                             cand = (int(np.diff(bl).max()), p_, mp_, lds_)
                             break
-                    # tiles too large for the LDS budget / the plan builder: bin again with half the target
-                    cand_order = self._locality_order(start, end, target=max(cand_order.target // 2, 32))
+                    # tiles too large for the LDS budget / the plan builder: bin again with half the target (not after the last
+                    # attempt: ``maps`` holds the rows gathered in THIS order, and the kernel is handed this order's table)
+                    if attempt < 3:
+                        cand_order = self._locality_order(start, end, target=max(cand_order.target // 2, 32))
                 if cand is None:
-                    cand = uniform()                    # (blocks of the derived order cut uniformly)
+                    cand = uniform()                    # (blocks of the derived order cut uniformly; maps gathered in cand_order)
                 touched = lambda pl: sum(p.list_len for p in pl.values())          # noqa: E731
                 if touched(cand[1]) < 0.9 * touched(base[1]):
                     order = cand_order

@@ -317,13 +317,16 @@ int fd_csr_get_diagonal(int32_t nrows, const int32_t *rowptr_dev, const int32_t 
  * such a matrix to the device): columns < ncols_owned form the DIAGONAL block (local column indices), the others the
  * OFF-DIAGONAL block with GLOBAL column indices (col_global[local column], NULL = keep local) -- exactly the six arrays of
  * MatCreateMPIAIJWithSplitArrays(comm, m, n, M, N, i, j, a, oi, oj, oa).  Columns are sorted inside a row and owned
- * columns come first, so the diagonal block is a prefix of every row.  fd_csr_split_mpiaij builds the two patterns once
- * (outputs allocated here, release with fd_free); fd_csr_split_values refreshes the two value arrays after an assembly. */
+ * columns come first, so the diagonal block is a prefix of every row.  The off-diagonal block is a sequential AIJ matrix of
+ * its own and needs its rows sorted by (global) column, which the local ghost numbering does not guarantee: o_rank[entry] =
+ * place of the suffix entry inside its sorted row.  fd_csr_split_mpiaij builds the two patterns and the ranks once (outputs
+ * allocated here, release with fd_free); fd_csr_split_values refreshes the two value arrays after an assembly (o_rank_dev
+ * NULL = suffix order). */
 int fd_csr_split_mpiaij(int32_t nrows_owned, const int32_t *rowptr_dev, const int32_t *colidx_dev, int32_t ncols_owned,
                         const int32_t *col_global_dev, int32_t **d_rowptr_dev, int32_t **d_colidx_dev, int64_t *d_nnz,
-                        int32_t **o_rowptr_dev, int32_t **o_colidx_dev, int64_t *o_nnz, fd_stream_t s);
+                        int32_t **o_rowptr_dev, int32_t **o_colidx_dev, int32_t **o_rank_dev, int64_t *o_nnz, fd_stream_t s);
 int fd_csr_split_values(int32_t nrows_owned, const int32_t *rowptr_dev, const double *vals_dev, const int32_t *d_rowptr_dev,
-                        const int32_t *o_rowptr_dev, double *d_vals_dev, double *o_vals_dev, fd_stream_t s);
+                        const int32_t *o_rowptr_dev, const int32_t *o_rank_dev, double *d_vals_dev, double *o_vals_dev, fd_stream_t s);
 
 /* ------------------------------------------------- backend-derived locality orders
  * The reference's locality comes from DMPlex (RCM cell order + first-touch DoF numbering, firedrake/mesh.py:1214-1228,

@@ -476,6 +476,9 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None):
             cargs.append(ptr(np.ascontiguousarray(acc, dtype=np.int32)))
         elif kind == "ocr_gstart":
             cargs.append(ptr(np.ascontiguousarray(ncsr.rowptr[plist], dtype=np.int32)))
+        elif kind == "ocr_gpos":
+            # (scalar matrices only: place of every accumulator entry, rows in position order)
+            cargs.append(ptr(np.concatenate([np.arange(ncsr.rowptr[r], ncsr.rowptr[r + 1]) for r in plist] + [np.zeros(0, np.int64)]).astype(np.int32)))
         elif kind == "ocrs_slot":
             cargs.append(ptr(slot))
         elif kind == "ocrs_rowlen":

@@ -136,6 +136,44 @@ def test_function_level_seam_on_device():
 
 
 @pytest.mark.gpu
+def test_seam_func_sees_buffers_rewritten_between_calls():
+    """The owner of a borrowed buffer (PyOP2, PETSc, another seam func) may rewrite it between calls -- the Newton state fed
+    to a residual: from the third call on nothing cached on the VALUES of a READ argument (plan-ordered copies) may be
+    served.  The same for a native Dat written through a live view without the carrier hearing of it."""
+    from firedrake_amd.device import DeviceBuffer
+    rng = np.random.default_rng(1)
+    nn, ne = 700, 2000
+    cells = rng.integers(0, nn, size=(ne, 3)).astype(np.int32)
+    x = rng.standard_normal((nn, 2))
+    m = MapKernelArg(arity=3)
+    lk = CStringLocalKernel(code=RHS, name="rhs", accesses=(4, 1, 1), dtypes=(np.float64,) * 3)
+    gk = GlobalKernel(local_kernel=lk, arguments=[DatKernelArg(dim=(), map_=m), DatKernelArg(dim=(2,), map_=m),
+                                                  DatKernelArg(dim=(1,), map_=m)])
+    func = bridge.compile_global_kernel_hip(gk)
+    x_d, m_d, f_d, b_d = DeviceBuffer.from_numpy(x), DeviceBuffer.from_numpy(cells), DeviceBuffer(nn * 8), DeviceBuffer(nn * 8)
+    for it in range(5):
+        f = rng.standard_normal(nn)
+        f_d.upload(f)                                   # same pointer, new values
+        b_d.upload(np.zeros(nn))
+        func(0, ne, b_d.ptr, x_d.ptr, f_d.ptr, m_d.ptr)
+        exp = np.zeros(nn)
+        np.add.at(exp, cells.ravel(), (x[:, 0] * f)[cells.ravel()])
+        assert np.abs(b_d.download(np.float64, (nn,)) - exp).max() < 1e-12 * max(1.0, np.abs(exp).max()), it
+    nodes, ele = op2.Set(nn), op2.Set(ne)
+    mm = op2.Map(ele, nodes, 3, cells)
+    xd, fd_, bd = op2.Dat(nodes ** 2, x), op2.Dat(nodes, np.zeros(nn)), op2.Dat(nodes)
+    pl = op2.LegacyParloop(op2.Kernel(RHS, "rhs"), ele, bd(op2.INC, mm), xd(op2.READ, mm), fd_(op2.READ, mm))
+    view = fd_.data                                     # a writable view kept alive across the calls
+    for it in range(5):
+        view[:] = rng.standard_normal(nn)
+        bd.zero()
+        pl.compute()
+        exp = np.zeros(nn)
+        np.add.at(exp, cells.ravel(), (x[:, 0] * view)[cells.ravel()])
+        assert np.abs(bd.data_ro - exp).max() < 1e-12 * max(1.0, np.abs(exp).max()), it
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("bcs", [False, True])
 def test_c1_residual_and_jacobian_through_func_only(bcs):
     """BASELINE.json configs[0] (Poisson CG1 on UnitSquareMesh(64, 64)) assembled through ``func(start, end, *arglist)``

@@ -45,13 +45,17 @@ def test_split_of_the_owned_rows_against_the_oracle(degree, rank, nranks, partit
     dci, oci = split.d_colidx.download(np.int32, (max(split.d_nnz, 1),))[:split.d_nnz], split.o_colidx.download(np.int32, (max(split.o_nnz, 1),))[:split.o_nnz]
     assert np.array_equal(drp, np.concatenate([[0], np.cumsum(d_cnt)])) and np.array_equal(orp, np.concatenate([[0], np.cumsum(o_cnt)]))
     exp_d = np.concatenate([ci[rp[r]:rp[r] + d_cnt[r]] for r in range(nown)])
-    exp_o = np.concatenate([col_global[ci[rp[r] + d_cnt[r]:rp[r + 1]]] for r in range(nown)]) if split.o_nnz else np.zeros(0, np.int32)
-    assert np.array_equal(dci, exp_d) and np.array_equal(oci, exp_o)                 # diagonal block: local columns; off-diagonal: GLOBAL
+    # off-diagonal block: GLOBAL columns, every row SORTED (MatCreateSeqAIJWithArrays needs sorted rows; the local ghost numbering
+    # is not monotone in the global one)
+    perm = [np.argsort(col_global[ci[rp[r] + d_cnt[r]:rp[r + 1]]], kind="stable") for r in range(nown)]
+    exp_o = np.concatenate([col_global[ci[rp[r] + d_cnt[r]:rp[r + 1]]][perm[r]] for r in range(nown)]) if split.o_nnz else np.zeros(0, np.int32)
+    assert np.array_equal(dci, exp_d) and np.array_equal(oci, exp_o)                 # diagonal block: local columns
+    assert all(np.all(np.diff(oci[orp[r]:orp[r + 1]]) > 0) for r in range(nown))
     dval = dv.download(np.float64, (max(split.d_nnz, 1),))[:split.d_nnz]
     oval = ov.download(np.float64, (max(split.o_nnz, 1),))[:split.o_nnz]
     vals = ref.values
     exp_dv = np.concatenate([vals[rp[r]:rp[r] + d_cnt[r]] for r in range(nown)])
-    exp_ov = np.concatenate([vals[rp[r] + d_cnt[r]:rp[r + 1]] for r in range(nown)]) if split.o_nnz else np.zeros(0)
+    exp_ov = np.concatenate([vals[rp[r] + d_cnt[r]:rp[r + 1]][perm[r]] for r in range(nown)]) if split.o_nnz else np.zeros(0)
     tol = 1e-12 * np.abs(vals).max()
     assert np.abs(dval - exp_dv).max() <= tol and (split.o_nnz == 0 or np.abs(oval - exp_ov).max() <= tol)
     assert abs(D.sum() + O.sum() - (dval.sum() + oval.sum())) <= 1e-9 * max(1.0, abs(D.sum()))

@@ -619,6 +619,16 @@ def test_row_sliced_owner_computes_rows_on_host(bcs, numbering):
         if cap == 96:
             got2 = run_ocrs(pl, nnz_per_block=cap, zero_pending=False, order=order)
             assert np.abs(got2.values - (ref.values + 1.0)).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
+            if order is not None:
+                # the same blocks flushed through the per-entry place table (FDHIP_OCRS_ENTRY_FLUSH) instead of row by row
+                from firedrake_amd.configuration import configuration
+                configuration["ocrs_entry_flush"] = 1
+                try:
+                    for zp in (True, False):
+                        got3 = run_ocrs(pl, nnz_per_block=cap, zero_pending=zp, order=order)
+                        assert np.abs(got3.values - (ref.values + (0.0 if zp else 1.0))).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
+                finally:
+                    configuration["ocrs_entry_flush"] = 0
 
 
 @pytest.mark.parametrize("numbering,bcs", [("tiled", False), ("tiled", True), ("random", True)])
