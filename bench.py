@@ -42,15 +42,32 @@ def algorithmic_bytes(ncell, arity, nnode, gdim, ncoeff, nnz=None, zeroing=False
     return ncell * arity * 4 + nnode * gdim * 8 + nnz * 8 + (nnz * 8 if zeroing else 0)      # Jacobian: map + coords + values
 
 
-def cpu_baseline(n_sample, degree, reps=10):
-    """Time the oracle (CPU restatement of the PyOP2 wrapper, compiled with the reference's own flags) on a bounded
-    sample of the same workload: an n_sample^3-cube mesh.  Headline = 1 thread (what one MPI rank of the reference
-    executes).  Beside it: all host threads, node-partitioned (each thread owns a contiguous node range and runs the
-    cells touching it, dropping foreign rows -- the shared-memory analogue of N ranks with a ghost-cell layer)."""
+def host_threads():
+    """(threads to use, affinity count, cgroup CPU quota in cores or None): an OpenMP team larger than the CPU time the container
+    may use only oversubscribes (the GPU box shows 256 logical CPUs under a 16-core quota)."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:          # "max 100000" or "<quota> <period>"
+            q = fh.read().split()
+            quota = None if q[0] == "max" else float(q[0]) / float(q[1])
+    except (OSError, ValueError, IndexError):
+        pass
+    n = aff if quota is None else max(1, min(aff, int(quota)))
+    return n, aff, quota
+
+
+def cpu_baseline(mesh, degree, reps=2, pattern=None, label=None):
+    """Time the oracle (CPU restatement of the PyOP2 wrapper, compiled with the reference's own flags) on ``mesh`` -- by default
+    THE benchmark workload itself, a bounded number of repetitions.  Headline = 1 thread (what one MPI rank of the reference
+    executes).  Beside it: min(affinity, cgroup quota) host threads, node-partitioned (each thread owns a contiguous node range
+    and runs the cells touching it, dropping foreign rows -- the shared-memory analogue of N ranks with a ghost-cell layer).
+    ``pattern`` = (rowptr, colidx) of the matrix when the caller holds it already (the device-built CSR, bit-identical to the
+    oracle's -- tests/test_gpu_fullsize.py); else the oracle builds it."""
     import oracle
     from oracle import ODat, OMat, READ, INC
-    from firedrake_amd import forms, mesh as fmesh
-    m = fmesh.UnitCubeMesh(n_sample, degrees=(degree,))
+    from firedrake_amd import forms
+    m = mesh
     V, X = m.space(degree), m.coord_space
     cm, xm = V.cell_node_map.values_with_halo, X.cell_node_map.values_with_halo
     nn = V.node_set.total_size
@@ -61,15 +78,22 @@ def cpu_baseline(n_sample, degree, reps=10):
     r = np.zeros(nn)
     kr, kj = forms.poisson_residual_kernel(3, degree), forms.poisson_jacobian_kernel(3, degree)
     ncell = m.cell_set.size
-    t0 = time.perf_counter()
-    csr = oracle.build_sparsity(nn, nn, [(cm, cm)])
-    t_sparsity = time.perf_counter() - t0
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    t_sparsity = None
+    if pattern is None:
+        t0 = time.perf_counter()
+        csr = oracle.build_sparsity(nn, nn, [(cm, cm)])
+        t_sparsity = time.perf_counter() - t0
+    else:
+        rp, ci = pattern
+        csr = oracle.OracleCSR(nn, nn, 1, 1, np.ascontiguousarray(rp, dtype=np.int32), np.ascontiguousarray(ci, dtype=np.int32),
+                               np.zeros(len(ci)))
+    cores, aff, quota = host_threads()
 
     def timed(threads, nrep):
         kw = {}
         if threads:
             kw = {"threads": "owner", "owner_partition": oracle.make_owner_partition(cm, ncell, nn, cores)}
+            os.environ["OMP_NUM_THREADS"] = str(cores)
         fn_r, a_r, k1, _ = oracle.par_loop(kr.code, kr.name, 0, ncell, [ODat(r, INC, cm), ODat(coords, READ, xm), ODat(u, READ, cm), ODat(f, READ, cm)],
                                            return_fn=True, **kw)
         fn_j, a_j, k2, cm_ = oracle.par_loop(kj.code, kj.name, 0, ncell, [OMat(csr, INC, cm, cm), ODat(coords, READ, xm)],
@@ -89,21 +113,14 @@ def cpu_baseline(n_sample, degree, reps=10):
 
     tot1, tr1, tj1 = timed(False, reps)
     totN, trN, tjN = timed(True, reps)
-    quota = None
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as fh:          # "max 100000" or "<quota> <period>": CPU time the container may use
-            q = fh.read().split()
-            quota = None if q[0] == "max" else float(q[0]) / float(q[1])
-    except (OSError, ValueError, IndexError):
-        pass
-    multi = {"value": nn / totN, "cores": cores, "cgroup_cpu_quota_cores": quota,
+    multi = {"value": nn / totN, "cores": cores, "affinity_cpus": aff, "cgroup_cpu_quota_cores": quota,
              "residual_dofs_per_s": nn / trN, "jacobian_dofs_per_s": nn / tjN,
-             "note": "OpenMP, one thread per contiguous node range running the cells that touch it (owned + ghost cells), "
-                     "foreign rows dropped: no atomics, no private vectors (shared-memory analogue of N MPI ranks)"}
+             "note": "OpenMP team of min(affinity, cgroup quota) threads, one per contiguous node range running the cells that touch it "
+                     "(owned + ghost cells), foreign rows dropped: no atomics, no private vectors (shared-memory analogue of N MPI ranks)"}
     return {"value": nn / tot1, "unit": "DoFs/s", "cores": 1, "kind": "port",
-            "sample": f"Poisson CG{degree} on UnitCubeMesh({n_sample}) tets: {ncell} cells, {nn} DoFs, residual+Jacobian, "
-                      f"median of {reps} warm repetitions; oracle = CPU restatement of the PyOP2 wrapper (not the reference "
-                      f"binary), gcc -O3 -march=native -ffast-math; 1 thread = what one MPI rank of the reference executes",
+            "sample": f"{label or 'Poisson CG%d on a cube of tets' % degree}: {ncell} cells, {nn} DoFs, residual+Jacobian, "
+                      f"median of {reps} warm repetitions (one more dropped as warm-up); oracle = CPU restatement of the PyOP2 wrapper "
+                      f"(not the reference binary), gcc -O3 -march=native -ffast-math; 1 thread = what one MPI rank of the reference executes",
             "residual_dofs_per_s": nn / tr1, "jacobian_dofs_per_s": nn / tj1,
             "all_host_threads": multi, "sparsity_build_s": t_sparsity}
 
@@ -179,21 +196,20 @@ def run_c3(args):
     print(json.dumps(out))
 
 
-def run_c1(args):
+def measure_c1(steps, warmup):
     """BASELINE.json configs[0]: Poisson CG1 on UnitSquareMesh(64,64) -- launch-bound on a GPU; eager vs hipGraph replay."""
     from firedrake_amd import _lib, forms, mesh as fmesh
     from firedrake_amd.graph import CapturedStep
-    _lib.require_gpu()
     prob = forms.PoissonProblem(fmesh.UnitSquareMesh(64, 64, perturb=0.1), 1, bcs=True)
 
     def step():
         prob.assemble_residual()
         prob.assemble_jacobian()
 
-    for _ in range(max(args.warmup, 2)):
+    for _ in range(max(warmup, 2)):
         step()
     _lib.call("fd_device_sync")
-    n = max(args.steps, 200)
+    n = max(steps, 200)
     t0 = time.perf_counter()
     for _ in range(n):
         step()
@@ -207,30 +223,34 @@ def run_c1(args):
     g.sync()
     graph = (time.perf_counter() - t0) / n
     nd = prob.V.node_set.size
-    print(json.dumps({"metric": "assembled DoFs/sec (residual + Jacobian)", "value": nd / graph, "unit": "DoFs/s", "n_gpus": 1,
-                      "steps": n, "warmup": args.warmup, "ms_per_step": graph * 1e3, "higher_is_better": True, "scaling": "weak",
-                      "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                      "config": {"workload": "Poisson CG1 residual+Jacobian on UnitSquareMesh(64,64) (BASELINE.json configs[0]), hipGraph replay",
-                                 "cells": 8192, "dofs": nd},
-                      "eager_ms_per_step": eager * 1e3, "graph_ms_per_step": graph * 1e3, "roofline": None, "cpu_baseline": None}))
+    return {"metric": "assembled DoFs/sec (residual + Jacobian)", "value": nd / graph, "unit": "DoFs/s", "n_gpus": 1,
+            "steps": n, "warmup": warmup, "ms_per_step": graph * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Poisson CG1 residual+Jacobian on UnitSquareMesh(64,64) (BASELINE.json configs[0]), hipGraph replay",
+                       "cells": 8192, "dofs": nd},
+            "eager_ms_per_step": eager * 1e3, "graph_ms_per_step": graph * 1e3, "roofline": None, "cpu_baseline": None}
 
 
-def run_c4(args):
+def run_c1(args):
+    from firedrake_amd import _lib
+    _lib.require_gpu()
+    print(json.dumps(measure_c1(args.steps, args.warmup)))
+
+
+def measure_c4(n, steps, warmup):
     """BASELINE.json configs[3]: DG_advection demo, DQ1 on quadrilaterals -- the 1-form L1 (cell + exterior-facet +
     interior-facet integrals, upwind flux) assembled matrix-free: three parloops INC-ing one Dat (C4)."""
     from firedrake_amd import _lib, forms, mesh as fmesh
     from firedrake_amd.device import Event
-    _lib.require_gpu()
-    n = args.n if args.n else 2048
     m = fmesh.make_quad_mesh(n, perturb=0.1)
     prob = forms.DGAdvectionProblem(m)
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         prob.assemble_rhs()
     _lib.call("fd_device_sync")
     names = [lp.global_kernel.name for lp in prob.loops]
-    ev = [[Event() for _ in range(len(prob.loops) + 1)] for _ in range(args.steps)]
+    ev = [[Event() for _ in range(len(prob.loops) + 1)] for _ in range(steps)]
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(steps):
         # same sequence as DGAdvectionProblem.assemble_rhs, with an event between the three loops
         prob.L.zero()
         with prob.L.frozen_halo(forms.op2.INC):
@@ -240,7 +260,7 @@ def run_c4(args):
                 ev[k][i + 1].record()
     _lib.call("fd_device_sync")
     elapsed = time.perf_counter() - t0
-    per = [float(np.median([ev[k][i].elapsed_ms(ev[k][i + 1]) for k in range(args.steps)])) for i in range(len(prob.loops))]
+    per = [float(np.median([ev[k][i].elapsed_ms(ev[k][i + 1]) for k in range(steps)])) for i in range(len(prob.loops))]
     ncell, nint, next_ = m.cell_set.size, m.int_facet_set.size, m.ext_facet_set.size
     ndq, nq1 = m.dq_set.size, m.q1_set.size
     # algorithmic bytes per loop: maps + direct facet numbers + every node array once; the INC output is
@@ -254,12 +274,18 @@ def run_c4(args):
         roofs.append({"kernel": name, "bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "ms": ms, "algorithmic_bytes": nbytes})
     dominant = max(roofs, key=lambda r: r["ms"])
-    print(json.dumps({"metric": "assembled DoFs/sec (DG advection RHS action)", "value": ndq / (elapsed / args.steps), "unit": "DoFs/s",
-                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                      "config": {"workload": f"DG_advection demo 1-form L1, DQ1 on {n}x{n} quadrilaterals (BASELINE.json configs[3])",
-                                 "cells": ncell, "dofs": ndq, "interior_facets": nint, "exterior_facets": next_},
-                      "roofline": dominant, "roofline_per_loop": roofs, "cpu_baseline": None}))
+    return {"metric": "assembled DoFs/sec (DG advection RHS action)", "value": ndq / (elapsed / steps), "unit": "DoFs/s",
+            "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"DG_advection demo 1-form L1, DQ1 on {n}x{n} quadrilaterals (BASELINE.json configs[3])",
+                       "cells": ncell, "dofs": ndq, "interior_facets": nint, "exterior_facets": next_},
+            "roofline": dominant, "roofline_per_loop": roofs, "cpu_baseline": None}
+
+
+def run_c4(args):
+    from firedrake_amd import _lib
+    _lib.require_gpu()
+    print(json.dumps(measure_c4(args.n if args.n else 2048, args.steps, args.warmup)))
 
 
 CALIB = (("wrap_fd_calib_read2", 2), ("wrap_fd_calib_read4", 4), ("wrap_fd_calib_read8", 8), ("wrap_fd_calib_read16", 16),
@@ -502,7 +528,7 @@ def check_devices(n):
     return ndev.value
 
 
-def poisson_line(args, ctx, degree, shape, scaling, label, numbering, variants, traffic):
+def poisson_line(args, ctx, degree, shape, scaling, label, numbering, variants, traffic, cpu=False):
     """Measure residual + Jacobian assembly of Poisson CG<degree> on UnitCubeMesh(shape) box-partitioned over the ranks and
     return rank 0's result dict (None on the other ranks)."""
     from firedrake_amd import _lib, forms, mesh as fmesh
@@ -596,6 +622,14 @@ def poisson_line(args, ctx, degree, shape, scaling, label, numbering, variants, 
             "exchange_ms": multi["exchange_ms"] if multi else None,
             "multi_gpu": multi,
         }
+    if cpu and out is not None:
+        # reported baseline (rank 0, N = 1): the oracle on THIS workload -- the same mesh object, the matrix pattern the device built
+        try:
+            sp = prob.jacobian()[0].sparsity
+            out["cpu_baseline"] = cpu_baseline(mesh, degree, reps=args.cpu_reps, pattern=(np.asarray(sp.rowptr), np.asarray(sp.colidx)),
+                                               label=f"Poisson CG{degree} on UnitCubeMesh({shape[0]},{shape[1]},{shape[2]}) tets, the benchmark workload itself")
+        except Exception as exc:                  # (a host without a C compiler, ...): the GPU line still goes out
+            out["cpu_baseline"] = {"error": repr(exc)}
     # further numberings (no producer hints): locality dependence of the same step, N = 1 only
     if world == 1 and variants:
         for nb in [v for v in variants.split(",") if v and v != numbering]:
@@ -675,7 +709,8 @@ def main():
                     help="cubes per axis (c2: per GPU, default 215 -> ~10M CG1 DoF per GPU; c5: of the WHOLE cube, default 215)")
     ap.add_argument("--n5", type=int, default=0, help="cubes per axis of the strong-scaling C5 cube appended at N > 1 (default 215)")
     ap.add_argument("--degree", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=128, help="cube size of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1, help="0 = skip the CPU baseline (the oracle timed on the workload itself)")
+    ap.add_argument("--cpu-reps", type=int, default=2, help="timed repetitions of the CPU baseline (one more is dropped as warm-up)")
     ap.add_argument("--no-bcs", action="store_true")
     ap.add_argument("--tile", type=str, default="8,8,4", help="cubes per traversal tile (= plan block)")
     ap.add_argument("--numbering", choices=["tiled", "lexicographic", "random"], default="lexicographic",
@@ -761,7 +796,7 @@ def main():
         degree = args.degree or 1
         shape = (n * pg[0], n * pg[1], n * pg[2])        # weak scaling: every rank owns an n^3 cube of cubes
         out = poisson_line(args, ctx, degree, shape, "weak", "BASELINE.json configs[1] per GPU" if degree == 1 else f"CG{degree}, weak",
-                           args.numbering, args.variants, args.traffic == "auto")
+                           args.numbering, args.variants, args.traffic == "auto", cpu=(args.cpu_sample > 0 and world == 1))
     if args.inner_pmc:
         run_calibration()
         return
@@ -778,21 +813,24 @@ def main():
                 out["strong_c5"] = {"error": repr(exc)}
             raise
     if rank == 0 and world == 1 and args.secondary and args.workload == "c2" and args.only == "both":
-        # north_star's second numeric target (fp64 MFMA fraction on the Q4 hex config), measured in the same driver run
-        try:
-            out["secondary_c3"] = measure_c3(32, max(3, args.steps // 2), 2)
-        except Exception as exc:                      # the headline line must not die with a secondary measurement
-            out["secondary_c3"] = {"error": repr(exc)}
-    if rank == 0:
-        if args.cpu_sample > 0 and world == 1:       # reported baseline: rank 0 at N = 1 only
-            ns = args.cpu_sample if degree == 1 else min(args.cpu_sample, 64)
+        # the other BASELINE configs in the same driver run (each guarded: the headline line must not die with a secondary one):
+        # C3 = north_star's second numeric target (fp64 MFMA fraction on the Q4 hex config), C4 = the DG advection right-hand side,
+        # C5 share = the CG2 problem one of 8 GPUs holds (n = 107, un-hinted numbering), C1 = the launch-bound 64 x 64 case
+        def guarded(key, fn):
             try:
-                out["cpu_baseline"] = cpu_baseline(ns, degree)
-                out["config"]["cpu_baseline_sample"] = f"{ns}^3 cubes (not the {n}^3 workload), see cpu_baseline.sample"
-            except Exception as exc:                  # (a host without a C compiler, ...): the GPU line still goes out
-                out["cpu_baseline"] = {"error": repr(exc)}
-        else:
-            out["cpu_baseline"] = None
+                out[key] = fn()
+            except Exception as exc:
+                out[key] = {"error": repr(exc)}
+            import gc
+            gc.collect()
+
+        guarded("secondary_c3", lambda: measure_c3(32, max(3, args.steps // 2), 2))
+        guarded("secondary_c4", lambda: measure_c4(2048, max(3, args.steps // 2), 2))
+        guarded("secondary_c5_share", lambda: poisson_line(args, ctx, 2, (107, 107, 107), "weak",
+                                                             "one of the 8 partitions of BASELINE.json configs[4]", "lexicographic", "", False))
+        guarded("secondary_c1", lambda: measure_c1(200, 3))
+    if rank == 0:
+        out.setdefault("cpu_baseline", None)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -43,6 +43,9 @@ SIGNATURES = {
     "fd_event_record": (c_int, [c_void_p, c_void_p]),
     "fd_event_sync": (c_int, [c_void_p]),
     "fd_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
+    "fd_trace_available": (c_int, []),
+    "fd_trace_range_push": (c_int, [c_char_p]),
+    "fd_trace_range_pop": (c_int, []),
     "fd_graph_begin": (c_int, [POINTER(c_void_p)]),
     "fd_graph_end": (c_int, [c_void_p]),
     "fd_graph_launch": (c_int, [c_void_p, c_void_p]),

@@ -16,6 +16,7 @@ configuration = {
     "cflags": _env("FDHIP_CFLAGS", ""),
     "cache_dir": _env("FDHIP_CACHE_DIR", os.path.join(_HERE, "_cache")),
     "debug": _env("FDHIP_DEBUG", 0, int),
+    "trace": _env("FDHIP_TRACE", 0, int),     # roctx range + flop log per parloop (profiling.py; pyop2/parloop.py:219-232)
     "type_check": _env("FDHIP_TYPE_CHECK", 1, int),
     # wrapper generation
     "mode": _env("FDHIP_MODE", "auto"),                 # auto | staged | direct

@@ -267,4 +267,42 @@ int fd_kernel_launch(fd_kernel_t k, int32_t start, int32_t end, const void *cons
     return 0;
 }
 
+// ---- tracing ranges (pyop2/profiling.py timed_region, pyop2/parloop.py:219-232): roctx markers around the launches of a parloop.
+// libroctx64 is bound at run time -- a process that never traces never loads it.
+namespace {
+typedef int (*roctx_push_t)(const char *);
+typedef int (*roctx_pop_t)();
+roctx_push_t roctx_push = nullptr;
+roctx_pop_t roctx_pop = nullptr;
+int roctx_state = 0;      // 0 = not tried, 1 = bound, -1 = unavailable
+bool roctx_bind() {
+    if (roctx_state == 0) {
+        roctx_state = -1;
+        for (const char *lib : {"libroctx64.so.4", "libroctx64.so", "librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so"}) {
+            void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            roctx_push = (roctx_push_t)dlsym(h, "roctxRangePushA");
+            roctx_pop = (roctx_pop_t)dlsym(h, "roctxRangePop");
+            if (roctx_push && roctx_pop) { roctx_state = 1; break; }
+        }
+    }
+    return roctx_state == 1;
+}
+}  // namespace
+
+int fd_trace_available(void) { return roctx_bind() ? 1 : 0; }
+
+int fd_trace_range_push(const char *name) {
+    if (!name) FD_FAIL("fd_trace_range_push: no name");
+    if (!roctx_bind()) FD_FAIL("fd_trace_range_push: libroctx64 is not available");
+    roctx_push(name);
+    return 0;
+}
+
+int fd_trace_range_pop(void) {
+    if (!roctx_bind()) FD_FAIL("fd_trace_range_pop: libroctx64 is not available");
+    roctx_pop();
+    return 0;
+}
+
 }  // extern "C"

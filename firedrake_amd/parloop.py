@@ -753,6 +753,24 @@ class Parloop:
                     print(f"[fdhip] {self.global_kernel.name}: {exc}; falling back to the {nxt} wrapper", file=sys.stderr)
                 self._forced_mode, self._prepared = nxt, None
 
+    def _compute_event(self):            # pyop2/parloop.py:221-222
+        from .profiling import timed_region
+        return timed_region(self._event_name)
+
+    @property
+    def _event_name(self):
+        return f"Parloop_{getattr(self.iterset, 'name', None) or 'set'}_{self.global_kernel.name}"
+
+    @property
+    def num_flops(self):                 # pyop2/global_kernel.py:377-387: flops of ONE entity (x the layers a column iterates)
+        per = self.global_kernel.local_kernel.flop_count or 0
+        return per * (self._nlayers_iterated() if self.iterset._extruded else 1)
+
+    def _log_flops(self, size):          # PETSc.Log.logFlops(part.size * self.num_flops), pyop2/parloop.py:231
+        if configuration["trace"]:
+            from .profiling import log_flops
+            log_flops(self._event_name, size, size * self.num_flops)
+
     def compute(self):
         self._zero_global_temporaries()
         self._ensure_geometry()
@@ -761,7 +779,9 @@ class Parloop:
             # lists, so there is no core/owned split to overlap the halo exchange with
             self.global_to_local_begin()
             self.global_to_local_end()
-            self._compute_ocr()
+            with self._compute_event():
+                self._log_flops(self.iterset.total_size if self.compute_ghost else self.iterset.size)
+                self._compute_ocr()
             self.reduction_begin()
             self.reduction_end()
             return
@@ -784,6 +804,11 @@ class Parloop:
         offset, size = part
         if size <= 0:
             return
+        with self._compute_event():
+            self._log_flops(size)
+            self._compute_part(offset, size)
+
+    def _compute_part(self, offset, size):
         start, end = offset, offset + size
         self._prepare()
         v = self._virtual()

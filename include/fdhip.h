@@ -62,6 +62,13 @@ int fd_event_record(fd_event_t e, fd_stream_t s);
 int fd_event_sync(fd_event_t e);
 int fd_event_elapsed_ms(fd_event_t start, fd_event_t stop, float *ms);
 
+/* Named ranges around the launches of one parloop: the PETSc log event `Parloop_<iterset>_<kernel>` of pyop2/parloop.py:219-232
+ * (pyop2/profiling.py timed_region) as roctx markers (roctxRangePushA / roctxRangePop, libroctx64 bound at run time), shown by
+ * `rocprofv3 --marker-trace` above the wrapper kernels.  fd_trace_available() = 1 when the library could be bound. */
+int fd_trace_available(void);
+int fd_trace_range_push(const char *name);
+int fd_trace_range_pop(void);
+
 /* hipGraph capture of one assembly step.  Between fd_graph_begin and fd_graph_end every entry point called with
  * a NULL stream records into the graph instead of executing; fd_graph_launch then replays the whole step
  * (zeroing, wrapper kernels, BC fix-up) with one host call.  For launch-bound problem sizes (config C1), where

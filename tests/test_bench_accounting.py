@@ -72,3 +72,21 @@ def test_a_wedged_profiler_pass_is_killed_and_reported(tmp_path, monkeypatch):
     traffic, meta = bench.collect_traffic(["--steps", "1"], ["k"])
     assert traffic is None and "killed" in meta["error"]
     assert time.time() - t0 < 30
+
+
+def test_cpu_baseline_runs_on_a_given_mesh_with_a_given_pattern():
+    """bench.cpu_baseline: the oracle timed on the mesh it is handed (the benchmark's own), the matrix pattern taken from the
+    caller (the device-built CSR in bench.py; here the oracle's), the OpenMP team sized by min(affinity, cgroup quota)."""
+    import oracle
+    from firedrake_amd import mesh as fmesh
+    bench = _bench()
+    m = fmesh.UnitCubeMesh(6, degrees=(1,))
+    cm = m.space(1).cell_node_map.values_with_halo
+    nn = m.space(1).node_set.total_size
+    csr = oracle.build_sparsity(nn, nn, [(cm, cm)])
+    out = bench.cpu_baseline(m, 1, reps=1, pattern=(csr.rowptr, csr.colidx), label="test")
+    assert out["cores"] == 1 and out["value"] > 0 and out["sparsity_build_s"] is None and "test" in out["sample"]
+    n, aff, quota = bench.host_threads()
+    assert out["all_host_threads"]["cores"] == n <= aff and (quota is None or n <= max(1, int(quota)))
+    out2 = bench.cpu_baseline(m, 1, reps=1)
+    assert out2["sparsity_build_s"] is not None

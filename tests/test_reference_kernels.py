@@ -24,9 +24,13 @@ M = "test_matrices.py::"
 nelems = 4096
 
 
-@pytest.fixture(params=[pytest.param("gpu", marks=pytest.mark.gpu), "host"])
-def be(request):
-    return GpuBackend() if request.param == "gpu" else HostBackend()
+@pytest.fixture(params=[pytest.param("gpu", marks=pytest.mark.gpu), pytest.param("gpu-direct", marks=pytest.mark.gpu), "host"])
+def be(request, monkeypatch):
+    """gpu: the wrapper shape the backend picks (staged / owner-computes-rows / direct); gpu-direct: the direct wrapper forced"""
+    if request.param == "gpu-direct":
+        from firedrake_amd.configuration import configuration
+        monkeypatch.setitem(configuration, "mode", "direct")
+    return GpuBackend() if request.param.startswith("gpu") else HostBackend()
 
 
 # ---------------------------------------------------------------------------------------- test_matrices.py
