@@ -164,13 +164,35 @@ def check(status):
 
 
 _TRACE = os.environ.get("FDHIP_TRACE_CALLS", "0") == "1"
+_PROFILE = os.environ.get("FDHIP_PROFILE_CALLS", "0") == "1"
+call_times = {}          # FDHIP_PROFILE_CALLS=1: C-ABI entry point -> [calls, seconds incl. the device work it queued]
 
 
 def call(name, *args):
     if _TRACE:        # debugging aid: name every C-ABI call before it runs (with AMD_SERIALIZE_KERNEL=3 the last line is the culprit)
         import sys
         print(f"[fdhip r{os.environ.get('RANK', '0')}] {name}", file=sys.stderr, flush=True)
+    if _PROFILE and name != "fd_device_sync":
+        # setup profiling aid: every call is followed by a device synchronisation, so its time includes the kernels it queued
+        import time
+        lib = load()
+        t0 = time.perf_counter()
+        check(getattr(lib, name)(*args))
+        lib.fd_device_sync()
+        e = call_times.setdefault(name, [0, 0.0])
+        e[0] += 1
+        e[1] += time.perf_counter() - t0
+        return
     check(getattr(load(), name)(*args))
+
+
+def profile_report(reset=True):
+    """FDHIP_PROFILE_CALLS=1: 'name calls seconds' lines, most expensive first."""
+    rows = sorted(call_times.items(), key=lambda kv: -kv[1][1])
+    out = "\n".join(f"{k:<32} {v[0]:>6} {v[1]:9.4f} s" for k, v in rows)
+    if reset:
+        call_times.clear()
+    return out
 
 
 _gpu_ok = None
