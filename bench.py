@@ -129,14 +129,16 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD datasheet; tools/microbench.hip measures 77
 FP64_VECTOR_PEAK_TFLOPS = 78.6 # same datasheet figure for vector fp64 FMA (256 CUs x 64 lanes x 2 flop x 2.4 GHz); microbench: 70 TFLOP/s
 
 
-def measure_c3(n, steps, warmup):
+def measure_c3(n, steps, warmup, coefficients=False):
     """BASELINE.json configs[2]: Helmholtz Q4 on an extruded hex mesh through ordinary parloops -- the stiffness+mass
     matrix on the fp64 matrix cores (tp_matrix wrapper) and the sum-factorised operator action (tp_action).  Reports the
     kernel alone AND the whole assemble (zeroing pass + kernel [+ BC diagonal]) against the fp64 MFMA peak."""
     from firedrake_amd import _lib, forms, mesh as fmesh
     from firedrake_amd.device import Event
     m = fmesh.make_extruded_hex_mesh(n, n, 4, perturb=0.1)
-    prob = forms.HelmholtzQ4Problem(m, bcs=True)
+    # coefficients: the same Q4 operator with a variable diffusivity field and a nonlinear-reaction linearisation point as
+    # coefficient arguments (forms.CoefficientHexProblem) -- the shape of a TSFC Jacobian of a nonlinear problem
+    prob = forms.CoefficientHexProblem(m, bcs=True, nq=5) if coefficients else forms.HelmholtzQ4Problem(m, bcs=True)
     t0 = time.perf_counter()
     prob.assemble_jacobian()
     prob.assemble_action()
@@ -825,6 +827,17 @@ def main():
             gc.collect()
 
         guarded("secondary_c3", lambda: measure_c3(32, max(3, args.steps // 2), 2))
+        if "error" not in out["secondary_c3"]:
+            # the same Q4 operator with two coefficient fields (variable diffusivity, nonlinear-reaction linearisation point)
+            def with_coefficients():
+                r = measure_c3(32, 3, 1, coefficients=True)
+                return {"workload": "a(du, v) = int (1 + w0) grad(du).grad(v) + (1 + u0^2) du v dx, w0 and u0 Q4 fields (coefficient arguments)",
+                        "matrix_kernel_ms": r["roofline"]["ms"], "frac_mfma": r["roofline"]["frac"], "assemble_ms": r["roofline"]["assemble_ms"],
+                        "action_kernel_ms": r["roofline_action"]["ms"], "action_frac_valu": r["roofline_action"]["frac_valu"]}
+            try:
+                out["secondary_c3"]["variable_coefficients"] = with_coefficients()
+            except Exception as exc:
+                out["secondary_c3"]["variable_coefficients"] = {"error": repr(exc)}
         guarded("secondary_c4", lambda: measure_c4(2048, max(3, args.steps // 2), 2))
         guarded("secondary_c5_share", lambda: poisson_line(args, ctx, 2, (107, 107, 107), "weak",
                                                              "one of the 8 partitions of BASELINE.json configs[4]", "lexicographic", "", False))

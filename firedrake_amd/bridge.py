@@ -123,6 +123,12 @@ def tensor_form_info(cell, family, degree, quadrature_degree, terms, kind):
     ``terms``                          the integrand as a sum of second-order terms with constant coefficients:
                                        ``{"stiffness": alpha, "mass": beta, "advection": (bx, by, bz)}`` for
                                        alpha*inner(grad u, grad v) + inner(dot(b, grad u), v) + beta*inner(u, v)
+                                       -- or, for a variable-coefficient / linearised nonlinear form,
+                                       ``{"stiffness": "<C expr>", "mass": "<C expr>", "coefficients": n}``: the two factors as
+                                       C expressions in ``C[0..n)`` -- the values at the point of the form's n coefficient
+                                       Functions on the SAME space, in the order TSFC passes them (``w_0 ...``,
+                                       firedrake_loopy.py:432-522) -- and ``X[0..2]`` (the physical point); what the UFL
+                                       integrand ``kappa(w0)*inner(grad(du), grad(v)) + c(u0)*du*v`` prints as
     ``kind``                           "matrix" for a 2-form, "action" for action(a, u) / a 1-form linear in one coefficient
 
     Returns None when the form is not one the tensor wrappers cover (the loop then takes the ordinary wrappers)."""
@@ -130,9 +136,14 @@ def tensor_form_info(cell, family, degree, quadrature_degree, terms, kind):
     from .codegen import tensor_geometry
     ok = (cell in ("hexahedron", "quadrilateral * interval", "TensorProductCell(quadrilateral, interval)") and family in ("Q", "CG", "Lagrange")
           and tensor_geometry(int(degree), nq) is not None and kind in ("matrix", "action")
-          and set(terms) <= {"stiffness", "mass", "advection"})
+          and set(terms) <= {"stiffness", "mass", "advection", "coefficients"})
     if not ok:
         return None
+    if "coefficients" in terms:
+        if "advection" in terms or int(terms["coefficients"]) < 0:
+            return None
+        return {"kind": kind, "degree": int(degree), "nq": nq, "ncoef": int(terms["coefficients"]),
+                "kappa": str(terms.get("stiffness", "0.0")), "react": str(terms.get("mass", "0.0"))}
     info = {"kind": kind, "degree": int(degree), "nq": nq, "alpha": float(terms.get("stiffness", 0.0)), "beta": float(terms.get("mass", 0.0))}
     if "advection" in terms:
         info["velocity"] = tuple(float(v) for v in terms["advection"])
@@ -142,8 +153,11 @@ def tensor_form_info(cell, family, degree, quadrature_degree, terms, kind):
 def tensor_product_local_kernel(code, name, accesses, dtypes, info, **kw):
     """TensorProductLocalKernel from the TSFC kernel text and a ``tensor_form_info`` descriptor: the per-point weight
     callback of alpha*inner(grad u, grad v) + beta*inner(u, v) is W = w|J| [alpha K K^T, 0; 0, beta] (tensor.py)."""
-    from .tensor import second_order_weights
+    from .tensor import coefficient_weights, second_order_weights
     kw.setdefault("requires_zeroed_output_arguments", True)
+    if "ncoef" in info:
+        return K.TensorProductLocalKernel(code, name, accesses, dtypes, kind=info["kind"], degree=info["degree"], nq=info["nq"],
+                                          ncoef=info["ncoef"], weights_code=coefficient_weights(name, info["kappa"], info["react"]), **kw)
     return K.TensorProductLocalKernel(code, name, accesses, dtypes, kind=info["kind"], degree=info["degree"], nq=info["nq"],
                                       weights_code=second_order_weights(name, info["alpha"], info["beta"], info.get("velocity", (0.0, 0.0, 0.0))),
                                       **kw)

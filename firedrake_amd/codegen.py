@@ -100,16 +100,24 @@ def tensor_eligible(gk: GlobalKernel):
         return isinstance(a, DatKernelArg) and a.index is None and la.access == READ and la.dtype == f64 and tuple(a.dim) == (3,) \
             and plain(a.map_, 8, 1)
 
-    if tp["kind"] == "matrix" and len(args) == 2:
+    nc = int(tp.get("ncoef", 0))
+
+    def coefs_ok(first, qmap):
+        """the descriptor's coefficient arguments: nc scalar fp64 READ Dats on the Q_k map, after the standard arguments"""
+        rest = list(zip(args[first:], las[first:]))
+        return len(rest) == nc and all(isinstance(a, DatKernelArg) and a.index is None and int(np.prod(a.dim)) == 1 and a.map_ is qmap
+                                       and la.access == READ and la.dtype == f64 for a, la in rest)
+
+    if tp["kind"] == "matrix" and len(args) == 2 + nc:
         a, la = args[0], las[0]
         if isinstance(a, MatKernelArg) and la.access == INC and not a.unroll and a.maps[0] is a.maps[1] and plain(a.maps[0], nd, k) \
-                and int(np.prod(a.dims[0])) * int(np.prod(a.dims[1])) == 1 and coords_ok(args[1], las[1]):
+                and int(np.prod(a.dims[0])) * int(np.prod(a.dims[1])) == 1 and coords_ok(args[1], las[1]) and coefs_ok(2, a.maps[0]):
             return "matrix"
-    if tp["kind"] == "action" and len(args) == 3:
+    if tp["kind"] == "action" and len(args) == 3 + nc:
         y, u = args[0], args[2]
         if all(isinstance(d, DatKernelArg) and d.index is None and int(np.prod(d.dim)) == 1 for d in (y, u)) \
                 and las[0].access == INC and las[2].access == READ and las[0].dtype == f64 and las[2].dtype == f64 \
-                and y.map_ is u.map_ and plain(y.map_, nd, k) and coords_ok(args[1], las[1]):
+                and y.map_ is u.map_ and plain(y.map_, nd, k) and coords_ok(args[1], las[1]) and coefs_ok(3, y.map_):
             return "action"
     return None
 
@@ -140,11 +148,18 @@ def generate_tensor_wrapper(gk: GlobalKernel) -> WrapperSource:
     layout = [("layers",)]
     head = ['#include "fd_tensor.h"', "#include <math.h>", "namespace fdk {", "#pragma clang force_cuda_host_device begin",
             lk.tp["weights_code"], "#pragma clang force_cuda_host_device end", "}  // namespace fdk", ""]
-    call_w = f"[](const double J[3][3], const double X[3], double wq, double W[16]) {{ fdk::{wname}(J, X, wq, W); }}"
+    # coefficient arguments (READ Dats on the Q_k map): evaluated at the Gauss points by the templates, handed to the callback as C[]
+    nc = int(lk.tp.get("ncoef", 0))
+    wcall = f"fdk::{wname}(J, X, wq, C, W);" if nc else f"fdk::{wname}(J, X, wq, W); (void)C;"
+    call_w = f"[](const double J[3][3], const double X[3], double wq, const double *C, double W[16]) {{ {wcall} }}"
+    first_c = 2 if kind == "matrix" else 3
+    cparams = [f"const double *__restrict__ arg{first_c + m}" for m in range(nc)]
+    clayout = [("arg", first_c + m) for m in range(nc)]
+    cfdecl = "  const double *const cf[%d] = {%s};" % (max(nc, 1), ", ".join(f"arg{first_c + m}" for m in range(nc)) or "nullptr")
     if kind == "matrix":
         lg = bool(gk.arguments[0].lgmaps)
-        layout += [("arg", 0), ("arg", 1), ("map", 0), ("map", 1), ("mat_rowptr", 0), ("tp_offtab", 0)]
-        params = ["const int *__restrict__ layers", "double *__restrict__ arg0", "const double *__restrict__ arg1",
+        layout += [("arg", 0), ("arg", 1)] + clayout + [("map", 0), ("map", 1), ("mat_rowptr", 0), ("tp_offtab", 0)]
+        params = ["const int *__restrict__ layers", "double *__restrict__ arg0", "const double *__restrict__ arg1"] + cparams + [
                   "const int *__restrict__ map0", "const int *__restrict__ map1", "const int *__restrict__ rp0",
                   "const unsigned short *__restrict__ tpo0"]
         if lg:
@@ -152,17 +167,18 @@ def generate_tensor_wrapper(gk: GlobalKernel) -> WrapperSource:
             params += ["const int *__restrict__ rlg0", "const int *__restrict__ clg0"]
         layout.append(("tp_tables",))
         params.append("const double *__restrict__ tptab")
-        body = (f"  fdt::hex_qk_matrix<{geom['k1']}, {geom['q1']}>(start, end, layers, arg0, arg1, map0, map1, rp0, tpo0, "
+        body = (f"{cfdecl}\n  fdt::hex_qk_matrix<{geom['k1']}, {geom['q1']}, {nc}>(start, end, layers, arg0, arg1, cf, map0, map1, rp0, tpo0, "
                 f"{'rlg0, clg0' if lg else 'nullptr, nullptr'}, tptab, {call_w});")
         threads = geom["matrix_threads"]
         # 4 NT accumulator registers per lane: Q4 (NT = 8) fits three wavefronts per SIMD
         bounds = f"{threads}, 3" if geom["tiles"] <= 8 and threads == 256 else f"{threads}"
     else:
-        layout += [("arg", 0), ("arg", 1), ("arg", 2), ("map", 0), ("map", 1), ("tp_tables",)]
+        layout += [("arg", 0), ("arg", 1), ("arg", 2)] + clayout + [("map", 0), ("map", 1), ("tp_tables",)]
         params = ["const int *__restrict__ layers", "double *__restrict__ arg0", "const double *__restrict__ arg1",
-                  "const double *__restrict__ arg2", "const int *__restrict__ map0", "const int *__restrict__ map1",
+                  "const double *__restrict__ arg2"] + cparams + ["const int *__restrict__ map0", "const int *__restrict__ map1",
                   "const double *__restrict__ tptab"]
-        body = f"  fdt::hex_qk_action<{geom['k1']}, {geom['q1']}>(start, end, layers, arg0, arg1, arg2, map0, map1, tptab, {call_w});"
+        body = (f"{cfdecl}\n  fdt::hex_qk_action<{geom['k1']}, {geom['q1']}, {nc}>(start, end, layers, arg0, arg1, arg2, cf, map0, map1, tptab, "
+                f"{call_w});")
         threads, bounds = 128, "128"
     src = head + [f'extern "C" __global__ __launch_bounds__({bounds}) void {sym}(int start, int end, {", ".join(params)})', "{", body, "}"]
     return WrapperSource("\n".join(src) + "\n", sym, "tp_" + kind, layout, 2, block_threads=threads, tp=geom)

@@ -66,9 +66,51 @@ __device__ __forceinline__ void inv3(const double J[3][3], double K[3][3], doubl
 constexpr int tp_tiles(int k1) { return (k1 * k1 * k1 + 15) / 16; }
 constexpr int tp_waves(int nt) { return nt % 4 == 0 ? 4 : (nt % 2 == 0 ? 2 : 1); }     // wavefronts per workgroup: divides NT
 
-template <int K1, int Q1, class WF>
+// Coefficient arguments (NC > 0): READ Dats on the Q_k map -- what TSFC passes as w_k to a variable-coefficient or linearised
+// nonlinear form (tsfc/kernel_interface/firedrake_loopy.py:432-522; evaluated at the quadrature points in tsfc/fem.py:742-805).
+// Their values at the NQ Gauss points of the cell are computed sum-factorised (three 1-D contractions through LDS, ~2 K1 NQ
+// FMAs per coefficient against 2 ND^2 NQ 4 for the element matrix) and handed to the weight callback as C[0..NC).
+template <int K1, int Q1, int NC, int NTHR>
+__device__ __forceinline__ void hex_qk_coefficients(const double *const (&cf)[NC > 0 ? NC : 1], const int *__restrict__ mrow, int lo,
+                                                    const double *sL, double (*sC)[Q1 * Q1 * Q1]) {
+    constexpr int ND = K1 * K1 * K1, NQ = Q1 * Q1 * Q1;
+    __shared__ double sU[ND], sT1[Q1 * K1 * K1], sT2[Q1 * Q1 * K1];
+    const int tid = threadIdx.x;
+#pragma unroll 1
+    for (int m = 0; m < NC; ++m) {
+        for (int i = tid; i < ND; i += NTHR) sU[i] = cf[m][mrow[i] + lo];
+        __syncthreads();
+        for (int o = tid; o < Q1 * K1 * K1; o += NTHR) {          // (q1, i2, i3) <- sum over i1
+            const int q1 = o / (K1 * K1), r = o - q1 * (K1 * K1);
+            double v = 0.0;
+#pragma unroll
+            for (int i = 0; i < K1; ++i) v += sL[q1 * K1 + i] * sU[i * K1 * K1 + r];
+            sT1[o] = v;
+        }
+        __syncthreads();
+        for (int o = tid; o < Q1 * Q1 * K1; o += NTHR) {          // (q1, q2, i3) <- sum over i2
+            const int q1 = o / (Q1 * K1), q2 = (o / K1) % Q1, i3 = o % K1;
+            double v = 0.0;
+#pragma unroll
+            for (int i = 0; i < K1; ++i) v += sL[q2 * K1 + i] * sT1[(q1 * K1 + i) * K1 + i3];
+            sT2[o] = v;
+        }
+        __syncthreads();
+        for (int q = tid; q < NQ; q += NTHR) {                    // (q1, q2, q3) <- sum over i3
+            const int q12 = q / Q1, q3 = q - q12 * Q1;
+            double v = 0.0;
+#pragma unroll
+            for (int i = 0; i < K1; ++i) v += sL[q3 * K1 + i] * sT2[q12 * K1 + i];
+            sC[m][q] = v;
+        }
+        __syncthreads();
+    }
+}
+
+template <int K1, int Q1, int NC, class WF>
 __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__restrict__ layers, double *__restrict__ vals,
-                                              const double *__restrict__ coords, const int *__restrict__ map_qk,
+                                              const double *__restrict__ coords, const double *const (&cf)[NC > 0 ? NC : 1],
+                                              const int *__restrict__ map_qk,
                                               const int *__restrict__ map_q1, const int *__restrict__ rowptr,
                                               const unsigned short *__restrict__ offtab, const int *__restrict__ rlg,
                                               const int *__restrict__ clg, const double *__restrict__ tables, WF weights) {
@@ -76,6 +118,7 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
     __shared__ double sL[NTAB], sDL[NTAB], sQP[Q1], sQW[Q1];
     __shared__ double sX[24];
     __shared__ double sW[NQ][16];
+    __shared__ double sC[NC > 0 ? NC : 1][NQ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nl = layers[1] - 1 - layers[0];
     const int cellid = blockIdx.x / WGC, part = blockIdx.x - cellid * WGC;
@@ -90,12 +133,16 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
         sX[tid] = coords[(size_t)node * 3 + c];
     }
     __syncthreads();
+    if constexpr (NC > 0)
+        hex_qk_coefficients<K1, Q1, NC, WPB * 64>(cf, map_qk + (size_t)col * ND, (K1 - 1) * lrel, sL, sC);
     for (int q = tid; q < NQ; q += WPB * 64) {
         const int q1 = q / (Q1 * Q1), q2 = (q / Q1) % Q1, q3 = q % Q1;
         const double t[3] = {sQP[q1], sQP[q2], sQP[q3]};
-        double J[3][3], X[3], W[16];
+        double J[3][3], X[3], W[16], C[NC > 0 ? NC : 1];
         hex_jacobian(sX, t, J, X);
-        weights(J, X, sQW[q1] * sQW[q2] * sQW[q3], W);
+#pragma unroll
+        for (int m = 0; m < NC; ++m) C[m] = sC[m][q];
+        weights(J, X, sQW[q1] * sQW[q2] * sQW[q3], C, W);
 #pragma unroll
         for (int k = 0; k < 16; ++k) sW[q][k] = W[k];
     }
@@ -191,15 +238,17 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int tp_action_cells(int k1, int q1) { return 128 / ((k1 > q1 ? k1 : q1) * (k1 > q1 ? k1 : q1)); }
 
-template <int K1, int Q1, class WF>
+template <int K1, int Q1, int NC, class WF>
 __device__ __forceinline__ void hex_qk_action(int start, int end, const int *__restrict__ layers, double *__restrict__ y,
                                               const double *__restrict__ coords, const double *__restrict__ u,
+                                              const double *const (&cf)[NC > 0 ? NC : 1],
                                               const int *__restrict__ map_qk, const int *__restrict__ map_q1,
                                               const double *__restrict__ tables, WF weights) {
     constexpr int M = K1 > Q1 ? K1 : Q1, M2 = M * M, M3 = M2 * M, CPW = tp_action_cells(K1, Q1), ND = K1 * K1 * K1, NTAB = Q1 * K1;
     constexpr int OFF = K1 - 1;
     static_assert(CPW >= 1, "one cell needs at most 128 lines");
-    __shared__ double sA[CPW][3][M3], sB[CPW][3][M3], sX[CPW][24];
+    // (slots 3 .. 3 + NC: the coefficient arguments ride through passes 1 and 2 next to u and are evaluated at the line's points)
+    __shared__ double sA[CPW][3 + NC][M3], sB[CPW][3 + NC][M3], sX[CPW][24];
     const int t = threadIdx.x;
     const int nl = layers[1] - 1 - layers[0];
     const int ncell = (end - start) * nl;
@@ -238,6 +287,19 @@ __device__ __forceinline__ void hex_qk_action(int start, int end, const int *__r
             for (int i = 0; i < K1; ++i) { s0 += L[q * K1 + i] * uv[i]; s1 += DL[q * K1 + i] * uv[i]; }
             A[0][q * M2 + l] = s0; A[1][q * M2 + l] = s1;
         }
+#pragma unroll
+        for (int m = 0; m < NC; ++m) {
+            double cv[K1];
+#pragma unroll
+            for (int i = 0; i < K1; ++i) cv[i] = cf[m][node[i]];
+#pragma unroll
+            for (int q = 0; q < Q1; ++q) {
+                double s0 = 0.0;
+#pragma unroll
+                for (int i = 0; i < K1; ++i) s0 += L[q * K1 + i] * cv[i];
+                A[3 + m][q * M2 + l] = s0;
+            }
+        }
     }
     __syncthreads();
     if (in && p < Q1 && r < K1) {                       // pass 2: (p, r) = (q1, i3), contract i2
@@ -251,6 +313,19 @@ __device__ __forceinline__ void hex_qk_action(int start, int end, const int *__r
             for (int i = 0; i < K1; ++i) { s0 += L[q * K1 + i] * v[i]; s1 += L[q * K1 + i] * d[i]; s2 += DL[q * K1 + i] * v[i]; }
             const int o = (p * M + q) * M + r;
             B[0][o] = s0; B[1][o] = s1; B[2][o] = s2;
+        }
+#pragma unroll
+        for (int m = 0; m < NC; ++m) {
+            double cv[K1];
+#pragma unroll
+            for (int i = 0; i < K1; ++i) cv[i] = A[3 + m][p * M2 + i * M + r];
+#pragma unroll
+            for (int q = 0; q < Q1; ++q) {
+                double s0 = 0.0;
+#pragma unroll
+                for (int i = 0; i < K1; ++i) s0 += L[q * K1 + i] * cv[i];
+                B[3 + m][(p * M + q) * M + r] = s0;
+            }
         }
     }
     __syncthreads();
@@ -282,7 +357,14 @@ __device__ __forceinline__ void hex_qk_action(int start, int end, const int *__r
                 g[0] += L[q * K1 + i] * d1[i]; g[1] += L[q * K1 + i] * d2[i]; g[2] += DL[q * K1 + i] * vv[i]; g[3] += L[q * K1 + i] * vv[i];
             }
             const double t2 = tables[2 * NTAB + q];
-            double J[3][3], X[3], W[16], F[4];
+            double J[3][3], X[3], W[16], F[4], C[NC > 0 ? NC : 1];
+#pragma unroll
+            for (int m = 0; m < NC; ++m) {
+                double cq = 0.0;
+#pragma unroll
+                for (int i = 0; i < K1; ++i) cq += L[q * K1 + i] * B[3 + m][l * M + i];
+                C[m] = cq;
+            }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 J[c][0] = G0[c][0] + t2 * (G0[c][1] - G0[c][0]);
@@ -290,7 +372,7 @@ __device__ __forceinline__ void hex_qk_action(int start, int end, const int *__r
                 J[c][2] = P[c][1] - P[c][0];
                 X[c] = P[c][0] + t2 * (P[c][1] - P[c][0]);
             }
-            weights(J, X, w01 * tables[2 * NTAB + Q1 + q], W);
+            weights(J, X, w01 * tables[2 * NTAB + Q1 + q], C, W);
 #pragma unroll
             for (int m = 0; m < 4; ++m) F[m] = W[m * 4 + 0] * g[0] + W[m * 4 + 1] * g[1] + W[m * 4 + 2] * g[2] + W[m * 4 + 3] * g[3];
 #pragma unroll

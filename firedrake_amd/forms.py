@@ -733,6 +733,126 @@ class HelmholtzHexProblem:
         return self.y
 
 
+def coefficient_hex_jacobian_kernel(degree=4, nq=None, name=None, kappa="1.0 + C[0]", react="1.0 + C[1]*C[1]", ncoef=2):
+    """a(du, v) = int kappa grad(du).grad(v) + react du v dx on a trilinear hexahedron, Q_degree basis, nq^3 Gauss points, with
+    ``kappa`` / ``react`` C expressions in the values C[0..ncoef) of ``ncoef`` coefficient fields at the point and the physical
+    point X[0..2] -- a variable-coefficient operator, or the Jacobian of a residual with a nonlinear reaction term (react = g'(u0)).
+    Arguments in TSFC's order (tsfc/kernel_interface/firedrake_loopy.py:432-522): A[nd*nd], coords[24], w_0[nd] ... w_{ncoef-1}[nd].
+    The C text is the dense definition the oracle and the direct wrapper execute; the descriptor lets the backend evaluate the
+    coefficients sum-factorised and contract on the fp64 matrix cores (csrc/fd_tensor.h)."""
+    from .kernel import TensorProductLocalKernel
+    from .tensor import coefficient_weights
+    k1 = degree + 1
+    nq = nq or k1
+    nd = k1 ** 3
+    name = name or f"coefficient_q{degree}_hex_jacobian"
+    L, DL, qp, qw = q4_tables(degree, nq)
+    wargs = "".join(f", const double *restrict w{m}" for m in range(ncoef))
+    cvals = "\n".join(f"    for (int i = 0; i < {nd}; ++i) C[{m}] += ph[i] * w{m}[i];" for m in range(ncoef))
+    body = f"""
+static void {name}(double *restrict A, const double *restrict x{wargs})
+{{
+  static const double L[{nq}][{k1}] = {_c(L)};
+  static const double DL[{nq}][{k1}] = {_c(DL)};
+  static const double QP[{nq}] = {_c(qp)};
+  static const double QW[{nq}] = {_c(qw)};
+  for (int q1 = 0; q1 < {nq}; ++q1) for (int q2 = 0; q2 < {nq}; ++q2) for (int q3 = 0; q3 < {nq}; ++q3) {{
+    const double t[3] = {{QP[q1], QP[q2], QP[q3]}};
+    double J[3][3] = {{{{0,0,0}},{{0,0,0}},{{0,0,0}}}}, X[3] = {{0,0,0}};
+    for (int v = 0; v < 8; ++v) {{
+      const int a = v >> 2, b = (v >> 1) & 1, c = v & 1;
+      const double Na = a ? t[0] : 1.0 - t[0], Nb = b ? t[1] : 1.0 - t[1], Nc = c ? t[2] : 1.0 - t[2];
+      const double da = a ? 1.0 : -1.0, db = b ? 1.0 : -1.0, dc = c ? 1.0 : -1.0;
+      const double g[3] = {{da*Nb*Nc, Na*db*Nc, Na*Nb*dc}};
+      for (int r = 0; r < 3; ++r) {{ for (int s = 0; s < 3; ++s) J[r][s] += x[3*v + r] * g[s]; X[r] += x[3*v + r] * Na*Nb*Nc; }}
+    }}
+    const double c00 = J[1][1]*J[2][2] - J[1][2]*J[2][1], c01 = J[1][2]*J[2][0] - J[1][0]*J[2][2], c02 = J[1][0]*J[2][1] - J[1][1]*J[2][0];
+    const double det = J[0][0]*c00 + J[0][1]*c01 + J[0][2]*c02, id = 1.0 / det;
+    const double K[3][3] = {{
+      {{ c00*id, (J[0][2]*J[2][1] - J[0][1]*J[2][2])*id, (J[0][1]*J[1][2] - J[0][2]*J[1][1])*id }},
+      {{ c01*id, (J[0][0]*J[2][2] - J[0][2]*J[2][0])*id, (J[0][2]*J[1][0] - J[0][0]*J[1][2])*id }},
+      {{ c02*id, (J[0][1]*J[2][0] - J[0][0]*J[2][1])*id, (J[0][0]*J[1][1] - J[0][1]*J[1][0])*id }} }};
+    const double w = QW[q1]*QW[q2]*QW[q3]*fabs(det);
+    double ph[{nd}], dp[{nd}][3];
+    for (int i1 = 0; i1 < {k1}; ++i1) for (int i2 = 0; i2 < {k1}; ++i2) for (int i3 = 0; i3 < {k1}; ++i3) {{
+      const int i = (i1*{k1} + i2)*{k1} + i3;
+      ph[i] = L[q1][i1]*L[q2][i2]*L[q3][i3];
+      dp[i][0] = DL[q1][i1]*L[q2][i2]*L[q3][i3];
+      dp[i][1] = L[q1][i1]*DL[q2][i2]*L[q3][i3];
+      dp[i][2] = L[q1][i1]*L[q2][i2]*DL[q3][i3];
+    }}
+    double C[{max(ncoef, 1)}] = {{0}};
+{cvals}
+    const double kappa = ({kappa}), react = ({react});
+    double G[3][3];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b)
+      G[a][b] = kappa * w * (K[a][0]*K[b][0] + K[a][1]*K[b][1] + K[a][2]*K[b][2]);
+    for (int i = 0; i < {nd}; ++i) {{
+      const double t0 = G[0][0]*dp[i][0] + G[0][1]*dp[i][1] + G[0][2]*dp[i][2];
+      const double t1 = G[1][0]*dp[i][0] + G[1][1]*dp[i][1] + G[1][2]*dp[i][2];
+      const double t2 = G[2][0]*dp[i][0] + G[2][1]*dp[i][1] + G[2][2]*dp[i][2];
+      const double tm = react * w * ph[i];
+      for (int j = 0; j < {nd}; ++j)
+        A[i*{nd} + j] += t0*dp[j][0] + t1*dp[j][1] + t2*dp[j][2] + tm*ph[j];
+    }}
+    (void)X;
+  }}
+}}
+"""
+    return TensorProductLocalKernel(body, name, kind="matrix", degree=degree, nq=nq, ncoef=ncoef,
+                                    weights_code=coefficient_weights(name, kappa, react))
+
+
+def coefficient_hex_action_kernel(degree=4, nq=None, name=None, kappa="1.0 + C[0]", react="1.0 + C[1]*C[1]", ncoef=2):
+    """y += A_e(coords, w_0 ...) u for the same form.  Arguments: y[nd], coords[24], u[nd], w_0[nd] ...; dense C text for the
+    oracle, sum-factorised on the device (the coefficients ride through the same axis passes as u)."""
+    from .kernel import TensorProductLocalKernel
+    from .tensor import coefficient_weights
+    nq = nq or degree + 1
+    nd = (degree + 1) ** 3
+    name = name or f"coefficient_q{degree}_hex_action"
+    jac = coefficient_hex_jacobian_kernel(degree, nq, name + "_matrix", kappa, react, ncoef)
+    wargs = "".join(f", const double *restrict w{m}" for m in range(ncoef))
+    wpass = "".join(f", w{m}" for m in range(ncoef))
+    body = jac.code + f"""
+static void {name}(double *restrict y, const double *restrict x, const double *restrict u{wargs})
+{{
+  static double A[{nd}*{nd}];
+  for (int q = 0; q < {nd}*{nd}; ++q) A[q] = 0.0;
+  {name}_matrix(A, x{wpass});
+  for (int i = 0; i < {nd}; ++i) {{
+    double s = 0.0;
+    for (int j = 0; j < {nd}; ++j) s += A[i*{nd} + j] * u[j];
+    y[i] += s;
+  }}
+}}
+"""
+    return TensorProductLocalKernel(body, name, kind="action", degree=degree, nq=nq, ncoef=ncoef,
+                                    weights_code=coefficient_weights(name, kappa, react))
+
+
+class CoefficientHexProblem(HelmholtzHexProblem):
+    """a(du, v) = int kappa(w0) grad(du).grad(v) + c(u0) du v dx on extruded Q_k hexahedra: a variable diffusivity field w0 and the
+    linearisation point u0 of a nonlinear reaction term enter the matrix and the action as coefficient arguments -- the shape of
+    the Jacobians TSFC generates for nonlinear / variable-coefficient problems (tsfc/kernel_interface/firedrake_loopy.py:432-522,
+    coefficient evaluation tsfc/fem.py:742-805).  Default: kappa = 1 + w0, c = 1 + u0^2 (the Jacobian of u + u^3/3)."""
+
+    def __init__(self, hexmesh, bcs=False, nq=None, kappa="1.0 + C[0]", react="1.0 + C[1]*C[1]"):
+        super().__init__(hexmesh, bcs, nq)
+        m = hexmesh
+        cm, xm = m.cell_node_map, m.coord_map
+        pts = m.node_points
+        self.w0 = op2.Dat(m.node_set, 0.5 + 0.4 * np.sin(2 * pts[:, 0] + pts[:, 1]) * np.cos(pts[:, 2]), np.float64, "kappa_field")
+        self.u0 = op2.Dat(m.node_set, np.cos(2 * pts[:, 0]) * np.sin(3 * pts[:, 1] + 1.0) + 0.2 * pts[:, 2], np.float64, "u0")
+        lg = self.jac_loop.arguments[0].lgmaps
+        self.kjac = coefficient_hex_jacobian_kernel(m.degree, nq, None, kappa, react, 2)
+        self.kact = coefficient_hex_action_kernel(m.degree, nq, None, kappa, react, 2)
+        self.jac_loop = op2.LegacyParloop(self.kjac, m.cell_set, self.mat(op2.INC, (cm, cm), lgmaps=lg), m.coordinates(op2.READ, xm),
+                                          self.w0(op2.READ, cm), self.u0(op2.READ, cm))
+        self.act_loop = op2.LegacyParloop(self.kact, m.cell_set, self.y(op2.INC, cm), m.coordinates(op2.READ, xm), self.u(op2.READ, cm),
+                                          self.w0(op2.READ, cm), self.u0(op2.READ, cm))
+
+
 class HelmholtzQ4Problem(HelmholtzHexProblem):
     """BASELINE.json configs[2]: Q4, 5 x 5 x 5 Gauss points."""
 

@@ -131,14 +131,19 @@ class TensorProductLocalKernel(CStringLocalKernel):
 
     (J[r][s] = dx_r/dxi_s at the point, X the physical point, wq the quadrature weight; W row-major, W[l*4+k] couples
     component l of the test side with component k of the trial side).  Instantiated for degree 1..5 and up to 7 Gauss points
-    per axis (codegen.tensor_geometry); other descriptors take the ordinary wrappers on the C text."""
+    per axis (codegen.tensor_geometry); other descriptors take the ordinary wrappers on the C text.
 
-    def __init__(self, code, name, accesses=None, dtypes=None, *, kind, degree, nq, weights_code, **kwargs):
+    ``ncoef`` > 0: the form has coefficient arguments -- ``ncoef`` scalar READ Dats on the Q_k map after the standard arguments
+    (A, coords, w_0 ... / y, coords, u, w_0 ...), the ``w_k`` TSFC passes to a variable-coefficient or linearised nonlinear form
+    (tsfc/kernel_interface/firedrake_loopy.py:432-522).  The templates evaluate them at the Gauss points (sum-factorised) and the
+    callback becomes ``<name>_weights(J, X, wq, const double *C, W)`` with C[m] = value of coefficient m at the point."""
+
+    def __init__(self, code, name, accesses=None, dtypes=None, *, kind, degree, nq, weights_code, ncoef=0, **kwargs):
         if kind not in ("matrix", "action"):
             raise ValueError("TensorProductLocalKernel kind must be 'matrix' or 'action'")
         kwargs.setdefault("requires_zeroed_output_arguments", True)
         super().__init__(code, name, accesses, dtypes, **kwargs)
-        self.tp = {"kind": kind, "degree": int(degree), "nq": int(nq), "weights_code": weights_code}
+        self.tp = {"kind": kind, "degree": int(degree), "nq": int(nq), "weights_code": weights_code, "ncoef": int(ncoef)}
 
     @property
     def cache_key(self):

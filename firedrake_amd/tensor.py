@@ -66,3 +66,28 @@ def second_order_weights(name, alpha=1.0, beta=1.0, velocity=(0.0, 0.0, 0.0)):
     for tag, v in zip(("BX", "BY", "BZ"), velocity):
         out = out.replace(tag, repr(float(v)))
     return out
+
+
+# a(u, v) = int kappa grad(u).grad(v) + c u v dx with kappa and c FUNCTIONS of the point and of coefficient fields: the shape of a
+# variable-coefficient operator or of the Jacobian of a nonlinear reaction term (F = ... + g(u0) v  ->  c = g'(u0)).  ``KAPPA`` and
+# ``REACT`` are C expressions in C[0..ncoef) (the coefficient values at the point) and X[0..2] (the physical point).
+COEFFICIENT_WEIGHTS = """
+static inline void NAME_weights(const double J[3][3], const double X[3], double wq, const double *C, double W[16])
+{
+  double K[3][3], det;
+  fdt::inv3(J, K, det);
+  const double w = wq * fabs(det);
+  const double kappa = KAPPA, react = REACT;
+  for (int a = 0; a < 3; ++a) {
+    for (int b = 0; b < 3; ++b) W[a*4 + b] = kappa * w * (K[a][0]*K[b][0] + K[a][1]*K[b][1] + K[a][2]*K[b][2]);
+    W[a*4 + 3] = 0.0;
+    W[12 + a] = 0.0;
+  }
+  W[15] = react * w;
+}
+"""
+
+
+def coefficient_weights(name, kappa="1.0", react="1.0"):
+    """``weights_code`` of a(u, v) = int kappa grad(u).grad(v) + react u v dx, kappa / react C expressions in C[] and X[]."""
+    return COEFFICIENT_WEIGHTS.replace("NAME", name).replace("KAPPA", f"({kappa})").replace("REACT", f"({react})")

@@ -328,6 +328,19 @@ def test_tensor_form_descriptor_selects_the_matrix_core_wrapper():
     lk.fdhip_tensor = info
     fd = bridge.as_fd_global_kernel(plain)
     assert select_mode(fd) == "tp_matrix" and fd.local_kernel.tp["weights_code"] == dense.tp["weights_code"]
+    # a Jacobian with coefficient Functions (variable diffusivity w0, linearisation point u0): the descriptor names their number
+    # and the two factors as C expressions; the loop -- Mat, coordinates, w_0, w_1 in TSFC's order -- still takes tp_matrix
+    cinfo = bridge.tensor_form_info("hexahedron", "Q", 4, 8, {"stiffness": "1.0 + C[0]", "mass": "1.0 + C[1]*C[1]", "coefficients": 2}, "matrix")
+    assert cinfo == {"kind": "matrix", "degree": 4, "nq": 5, "ncoef": 2, "kappa": "1.0 + C[0]", "react": "1.0 + C[1]*C[1]"}
+    cdense = forms.coefficient_hex_jacobian_kernel(4, 5)
+    clk = CStringLocalKernel(code=cdense.code, name=cdense.name, accesses=(4, 1, 1, 1), dtypes=(np.float64,) * 4, requires_zeroed_output_arguments=True)
+    cgk = GlobalKernel(local_kernel=clk, arguments=[MatKernelArg(dims=((1, 1),), maps=(q4, q4)), DatKernelArg(dim=(3,), map_=q1),
+                                                    DatKernelArg(dim=(1,), map_=q4), DatKernelArg(dim=(1,), map_=q4)],
+                       _extruded=True, _constant_layers=True)
+    assert select_mode(bridge.as_fd_global_kernel(cgk)) == "direct"
+    clk.fdhip_tensor = cinfo
+    cfd = bridge.as_fd_global_kernel(cgk)
+    assert select_mode(cfd) == "tp_matrix" and cfd.local_kernel.tp["ncoef"] == 2 and cfd.local_kernel.tp["weights_code"] == cdense.tp["weights_code"]
 
 
 def _dev(*arrays):

@@ -9,7 +9,7 @@ from oracle import ODat, OMat, READ, INC
 from firedrake_amd import forms, mesh as fmesh
 
 
-def _oracle_matrix(m, bc_nodes=None, k=None):
+def _oracle_matrix(m, bc_nodes=None, k=None, coefs=()):
     """Dense Q4 kernel through the oracle's extruded wrapper; BC rows/columns dropped through the lgmaps and the unit
     diagonal set afterwards, as assemble.py:1501-1507 / 2075-2108 do."""
     cm, xm = m.cell_node_map.values_with_halo, m.coord_map.values_with_halo
@@ -22,7 +22,8 @@ def _oracle_matrix(m, bc_nodes=None, k=None):
         lg[bc_nodes] = -1
     oracle.par_loop(k.code, k.name, 0, m.base_set.size,
                     [OMat(csr, INC, cm, cm, roffset=m.cell_node_map.offset, coffset=m.cell_node_map.offset, row_lgmap=lg, col_lgmap=lg),
-                     ODat(np.array(m.coordinates.data_ro_with_halos), READ, xm, offset=m.coord_map.offset)],
+                     ODat(np.array(m.coordinates.data_ro_with_halos), READ, xm, offset=m.coord_map.offset)]
+                    + [ODat(np.array(c), READ, cm, offset=m.cell_node_map.offset) for c in coefs],
                     layers=(0, m.layers + 1))
     if lg is not None:
         rp, ci = csr.rowptr, csr.colidx
@@ -31,14 +32,15 @@ def _oracle_matrix(m, bc_nodes=None, k=None):
     return csr
 
 
-def _oracle_action(m, u, k=None):
+def _oracle_action(m, u, k=None, coefs=()):
     cm, xm = m.cell_node_map.values_with_halo, m.coord_map.values_with_halo
     y = np.zeros(m.node_set.total_size)
     k = k or forms.helmholtz_q4_hex_action_kernel()
     oracle.par_loop(k.code, k.name, 0, m.base_set.size,
                     [ODat(y, INC, cm, offset=m.cell_node_map.offset),
                      ODat(np.array(m.coordinates.data_ro_with_halos), READ, xm, offset=m.coord_map.offset),
-                     ODat(np.array(u), READ, cm, offset=m.cell_node_map.offset)], layers=(0, m.layers + 1))
+                     ODat(np.array(u), READ, cm, offset=m.cell_node_map.offset)]
+                    + [ODat(np.array(c), READ, cm, offset=m.cell_node_map.offset) for c in coefs], layers=(0, m.layers + 1))
     return y
 
 
@@ -293,3 +295,32 @@ def test_convection_diffusion_reaction_through_the_tensor_wrappers(degree, nq):
     t = op2.Dat(m.node_set)
     mat.mult(prob.u, t)
     assert_allclose(t.data_ro, y, rtol=0, atol=1e-11 * np.abs(yref).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("degree,nq,n,layers,bcs", [(4, 5, 2, 3, True), (2, 3, 3, 2, False), (3, 5, 2, 2, True)])
+def test_coefficient_arguments_through_the_tensor_wrappers(degree, nq, n, layers, bcs):
+    """a(du, v) = int kappa(w0) grad(du).grad(v) + c(u0) du v dx on Q_k hexahedra: the coefficient arguments of a TSFC Jacobian
+    (tsfc/kernel_interface/firedrake_loopy.py:432-522) go through the fp64-MFMA matrix wrapper and the sum-factorised action
+    wrapper -- NOT the direct fallback -- and match the oracle's dense kernel to 1e-11; A u == action(a, u)."""
+    m = fmesh.make_extruded_hex_mesh(n, layers, degree, perturb=0.1)
+    prob = forms.CoefficientHexProblem(m, bcs=bcs, nq=nq)
+    mat = prob.assemble_jacobian()
+    assert prob.jac_loop._prepared["cw"].src.mode == "tp_matrix"
+    coefs = (prob.w0.data_ro, prob.u0.data_ro)
+    ref = _oracle_matrix(m, prob.bc_nodes if bcs else None, prob.kjac, coefs)
+    _, _, v = mat.csr()
+    assert_allclose(v, ref.values, rtol=0, atol=1e-11 * np.abs(ref.values).max())
+    y = prob.assemble_action()
+    assert prob.act_loop._prepared["cw"].src.mode == "tp_action"
+    yref = _oracle_action(m, prob.u.data_ro, prob.kact, coefs)
+    assert_allclose(y.data_ro, yref, rtol=0, atol=1e-11 * np.abs(yref).max())
+    if not bcs:
+        assert_allclose(ref.toscipy() @ np.asarray(prob.u.data_ro), yref, rtol=0, atol=1e-10 * np.abs(yref).max())
+    # a coefficient that changes between calls (the Newton state) is seen by the next assembly
+    prob.u0.data[:] = 0.0
+    mat = prob.assemble_jacobian()
+    ref0 = _oracle_matrix(m, prob.bc_nodes if bcs else None, prob.kjac, (prob.w0.data_ro, prob.u0.data_ro))
+    _, _, v0 = mat.csr()
+    assert_allclose(v0, ref0.values, rtol=0, atol=1e-11 * np.abs(ref0.values).max())
+    assert np.abs(v0 - v).max() > 1e-3 * np.abs(v).max()

@@ -79,3 +79,31 @@ def test_convection_diffusion_reaction_weights_on_the_host(degree, nq):
     yref = _oracle_action(m, prob.u.data_ro, prob.kact)
     assert_allclose(y, yref, rtol=0, atol=1e-12 * np.abs(yref).max())
     assert_allclose(y, A @ np.asarray(prob.u.data_ro), rtol=0, atol=1e-11 * np.abs(yref).max())
+
+
+@pytest.mark.parametrize("degree,nq,bcs", [(2, 3, False), (3, 4, True), (4, 5, False)])
+def test_coefficient_arguments_through_the_tensor_templates_on_the_host(degree, nq, bcs):
+    """a(du, v) = int kappa(w0) grad(du).grad(v) + c(u0) du v dx: two coefficient fields on the Q_k map -- a variable diffusivity
+    and the linearisation point of a nonlinear reaction term, the w_k arguments of a TSFC Jacobian
+    (tsfc/kernel_interface/firedrake_loopy.py:432-522) -- evaluated at the Gauss points by the templates (sum-factorised, through
+    LDS in the matrix kernel, through the axis passes in the action) against the oracle's dense kernel that tabulates them
+    point by point."""
+    m = fmesh.make_extruded_hex_mesh(1, 2, degree, perturb=0.1)
+    prob = forms.CoefficientHexProblem(m, bcs=bcs, nq=nq)
+    from firedrake_amd.codegen import tensor_eligible
+    assert tensor_eligible(prob.jac_loop.global_kernel) == "matrix" and tensor_eligible(prob.act_loop.global_kernel) == "action"
+    coefs = (prob.w0.data_ro, prob.u0.data_ro)
+    csr = hostsim.run_tensor(prob.jac_loop)[0]
+    ref = _oracle_matrix(m, prob.bc_nodes if bcs else None, prob.kjac, coefs)
+    v = csr.values.copy()
+    if bcs:
+        rp, ci = csr.rowptr, csr.colidx
+        for b in prob.bc_nodes:
+            v[rp[b] + np.searchsorted(ci[rp[b]:rp[b + 1]], b)] = 1.0
+    assert_allclose(v, ref.values, rtol=0, atol=1e-11 * np.abs(ref.values).max())
+    # the coefficients matter: the constant-coefficient operator differs by O(1)
+    plain = _oracle_matrix(m, prob.bc_nodes if bcs else None, forms.helmholtz_hex_jacobian_kernel(degree, nq))
+    assert np.abs(plain.values - ref.values).max() > 0.05 * np.abs(ref.values).max()
+    y = hostsim.run_tensor(prob.act_loop)[0]
+    yref = _oracle_action(m, prob.u.data_ro, prob.kact, coefs)
+    assert_allclose(y, yref, rtol=0, atol=1e-11 * np.abs(yref).max())
