@@ -209,6 +209,21 @@ __global__ void rr_entries(const int32_t *__restrict__ rblk, int32_t nblocks, in
     }
 }
 
+// ---- tables of a row order (fd_row_order_tables): lengths and CSR starts of the rows in position order, accumulator starts by node
+__global__ void ro_gather(int32_t npos, const int32_t *__restrict__ plist, const int32_t *__restrict__ rowptr,
+                          int32_t *__restrict__ len, int32_t *__restrict__ gstart) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p <= npos; p += (int64_t)gridDim.x * blockDim.x) {
+        if (p == npos) { len[p] = 0; continue; }
+        const int32_t r = plist[p], a = rowptr[r];
+        len[p] = rowptr[r + 1] - a;
+        gstart[p] = a;
+    }
+}
+__global__ void ro_nstart(int32_t npos, const int32_t *__restrict__ plist, const int32_t *__restrict__ prowptr, int32_t *__restrict__ nstart) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npos; p += (int64_t)gridDim.x * blockDim.x)
+        nstart[plist[p]] = prowptr[p];
+}
+
 template <class K, class V> int sort_pairs(K *keys, V *vals, int64_t n, int end_bit, hipStream_t s) {
     K *k2 = nullptr; V *v2 = nullptr; void *tmp = nullptr;
     FD_HIP(hipMalloc(&k2, (size_t)n * sizeof(K)));
@@ -413,6 +428,26 @@ int fd_ocr_row_runs(int32_t npos, const int32_t *prowptr_dev, const int32_t *gst
     // (the last block's runs end at nruns: brun[nblocks] is the run of position npos, i.e. nruns when rblk[nblocks] == npos)
     *max_runs_out = mx;
     (void)hipFree(flag); (void)hipFree(runidx); (void)hipFree(err); (void)hipFree(tmp);
+    return 0;
+}
+
+int fd_row_order_tables(int32_t npos, const int32_t *plist_dev, const int32_t *rowptr_dev, int32_t *prowptr_dev, int32_t *nstart_dev,
+                        int32_t *gstart_dev, fd_stream_t s_) {
+    if (npos < 0 || !prowptr_dev || (npos && (!plist_dev || !rowptr_dev || !nstart_dev || !gstart_dev))) FD_FAIL("fd_row_order_tables: bad arguments");
+    hipStream_t s = fd::st(s_);
+    if (npos == 0) { FD_HIP(hipMemsetAsync(prowptr_dev, 0, 4, s)); return 0; }
+    int32_t *len = nullptr; void *tmp = nullptr;
+    FD_HIP(hipMalloc(&len, ((size_t)npos + 1) * 4));
+    hipLaunchKernelGGL(ro_gather, dim3(lo_grid((int64_t)npos + 1)), dim3(256), 0, s, npos, plist_dev, rowptr_dev, len, gstart_dev);
+    FD_CHECK_LAUNCH();
+    size_t tb = 0;
+    FD_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, len, prowptr_dev, npos + 1, s));
+    FD_HIP(hipMalloc(&tmp, tb ? tb : 8));
+    FD_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, len, prowptr_dev, npos + 1, s));
+    hipLaunchKernelGGL(ro_nstart, dim3(lo_grid(npos)), dim3(256), 0, s, npos, plist_dev, prowptr_dev, nstart_dev);
+    FD_CHECK_LAUNCH();
+    FD_HIP(hipStreamSynchronize(s));
+    (void)hipFree(len); (void)hipFree(tmp);
     return 0;
 }
 

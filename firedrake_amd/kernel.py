@@ -416,10 +416,15 @@ class GlobalKernel:
             cw = GlobalKernel._cache.get(ck)
             if cw is None:
                 src = generate_wrapper(self, mode)
-                path = compile_hip(src.source, self.name)
-                path = self._unrolled_variant(src, path)
-                src, path = self._occupancy_variant(mode, src, path)
-                cw = CompiledWrapper(src, path)
+
+                def build(src=src, mode=mode):
+                    # hipcc runs when the code object is first needed: a wrapper that only lends its argument layout to the
+                    # geometry-specific variant a loop ends up launching (parloop._staged_geometry / _ocr_geometry) is never compiled
+                    path = compile_hip(src.source, self.name)
+                    path = self._unrolled_variant(src, path)
+                    return self._occupancy_variant(mode, src, path)
+
+                cw = CompiledWrapper(src, builder=build)
                 GlobalKernel._cache[ck] = cw
             self._compiled[mode] = cw
         return cw
@@ -480,10 +485,29 @@ class GlobalKernel:
 class CompiledWrapper:
     """A loaded wrapper kernel + the layout of its argument list."""
 
-    def __init__(self, src, hsaco_path):
-        self.src = src
-        self.path = hsaco_path
+    def __init__(self, src, hsaco_path=None, builder=None):
+        """``builder`` () -> (final WrapperSource, code-object path): the compilation, deferred until ``path`` / ``handle`` is first
+        read.  ``src`` before that is the generated wrapper (argument layout, staged maps, LDS items, block size: everything
+        the plan builders read); afterwards the variant that was kept (unroll / occupancy retries change flags and launch
+        bounds only)."""
+        self._src = src
+        self._path = hsaco_path
+        self._builder = builder
         self._handle = None
+
+    def _build(self):
+        if self._path is None:
+            self._src, self._path = self._builder()
+            self._builder = None
+
+    @property
+    def src(self):
+        return self._src
+
+    @property
+    def path(self):
+        self._build()
+        return self._path
 
     @property
     def handle(self):

@@ -2087,40 +2087,41 @@ class RowOrder:
     ``prowptr`` = CSR row starts in that order (device + host copy).  Built from an entity order by the first-touch rule
     (fd_first_touch_order)."""
 
-    def __init__(self, rmap: Map, order: "DeviceBuffer", n, npos, node_rowptr_host):
-        """First-touch row order under the entity order ``order`` (fd_first_touch_order)."""
+    def __init__(self, rmap: Map, order: "DeviceBuffer", n, npos, node_rowptr_host, rowptr_dev=None):
+        """First-touch row order under the entity order ``order`` (fd_first_touch_order).  ``rowptr_dev``: device pointer of the
+        same row starts when the caller holds one (saves an upload)."""
         self.npos = int(npos)
         self.pinv, self.plist = DeviceBuffer(max(npos, 1) * 4), DeviceBuffer(max(npos, 1) * 4)
         rank = DeviceBuffer(max(npos, 1) * 4)
         _lib.call("fd_first_touch_order", rmap._base()._dev_values(), rmap.arity, order.ptr, int(n), self.npos, self.pinv.ptr,
                   self.plist.ptr, rank.ptr, None)
         self.rank_host = rank.download(np.int32, (self.npos,))       # position (in ``order``) of the entity first touching row p
-        self._tables(node_rowptr_host)
+        self._tables(node_rowptr_host, rowptr_dev)
 
     @classmethod
-    def from_plist(cls, plist: "DeviceBuffer", npos, node_rowptr_host):
+    def from_plist(cls, plist: "DeviceBuffer", npos, node_rowptr_host, rowptr_dev=None):
         """A row order given as a device permutation of [0, npos) (a k-d partition of the rows' own positions)."""
         self = cls.__new__(cls)
         self.npos = int(npos)
         self.plist, self.pinv = plist, DeviceBuffer(max(npos, 1) * 4)
         _lib.call("fd_invert_permutation", plist.ptr, self.npos, self.pinv.ptr, None)
         self.rank_host = None
-        self._tables(node_rowptr_host)
+        self._tables(node_rowptr_host, rowptr_dev)
         return self
 
-    def _tables(self, node_rowptr_host):
-        plist = self.plist.download(np.int32, (self.npos,))
-        rp = np.asarray(node_rowptr_host, dtype=np.int64)
-        rowlen = np.diff(rp)[:self.npos]
-        self.prowptr_host = np.concatenate([[0], np.cumsum(rowlen[plist])]).astype(np.int32)
-        self.prowptr = DeviceBuffer.from_numpy(self.prowptr_host)
-        # the two lookups the wrapper needs, flattened so that neither is a dependent chain of loads:
-        # nstart[node] = prowptr[pinv[node]] (accumulator offset of a row, by NODE), gstart[p] = rowptr[plist[p]] (CSR start, by POSITION)
-        nstart = np.zeros(max(self.npos, 1), dtype=np.int32)
-        nstart[plist] = self.prowptr_host[:-1]
-        self.nstart = DeviceBuffer.from_numpy(nstart)
-        self._gstart_host = np.ascontiguousarray(rp[plist], dtype=np.int32) if self.npos else np.zeros(1, np.int32)
-        self.gstart = DeviceBuffer.from_numpy(self._gstart_host)
+    def _tables(self, node_rowptr_host, rowptr_dev=None):
+        """prowptr (accumulator starts by position, also kept on the host: the block cuts are made there) and the two lookups the
+        wrapper needs, flattened so that neither is a dependent chain of loads: nstart[node] = prowptr[pinv[node]] (accumulator
+        offset of a row, by NODE), gstart[p] = rowptr[plist[p]] (CSR start, by POSITION) -- fd_row_order_tables, on the device (the
+        numpy version cost 0.13 s of every first Jacobian call at 10 M rows)."""
+        n1 = max(self.npos, 1)
+        self.prowptr, self.nstart, self.gstart = DeviceBuffer((self.npos + 1) * 4), DeviceBuffer(n1 * 4), DeviceBuffer(n1 * 4)
+        keep = None
+        if rowptr_dev is None:
+            keep = DeviceBuffer.from_numpy(np.ascontiguousarray(node_rowptr_host, dtype=np.int32))
+            rowptr_dev = keep.ptr
+        _lib.call("fd_row_order_tables", self.npos, self.plist.ptr, rowptr_dev, self.prowptr.ptr, self.nstart.ptr, self.gstart.ptr, None)
+        self.prowptr_host = self.prowptr.download(np.int32, (self.npos + 1,))
 
     def gpos(self):
         """int32 per accumulator entry (rows in position order, entries in CSR order inside a row): its place in the CSR value

@@ -471,6 +471,7 @@ class Parloop:
         geo = {"epb": epb, "plans": plans, "mplans": mplans, "lds": lds, "cw": cw, "order": order, "range": (pstart, pend)}
         if configuration["debug"]:
             import sys
+            print(f"[fdhip] {self.global_kernel.name} staged variant {variant}", file=sys.stderr)
             for mi, pl in plans.items():
                 print(f"[fdhip] {self.global_kernel.name} [{start},{end}) epb={epb} map{mi}: blocks={pl.nblocks} "
                       f"max_nd={pl.max_nd} list_len={pl.list_len} lds={lds}", file=sys.stderr)
@@ -884,13 +885,13 @@ class Parloop:
                 cap = configuration["ocr_nnz_per_block_ordered"]
                 rows_per_block = max(cap // max(int(np.ceil(rp[nrows] / max(nrows, 1))), 1), 1)
                 plist, rb = kd_order(pos_.data._dev_ptr(False), pos_.data.cdim, nrows, 0, rows_per_block)
-                row_order = RowOrder.from_plist(plist, nrows, rp)
+                row_order = RowOrder.from_plist(plist, nrows, rp, rowptr_dev=sp._node_rowptr.ptr)
             elif usable:
                 # rows of another space: first touch under the k-d order of the entities, cut where the entity leaf changes
                 # (leaves hold equal numbers of entities, not of rows: 10 % slack before a block is halved)
                 order = self._locality_order(start, end, virtual=v is not None)
                 if order is not None:
-                    row_order = RowOrder(rmap, order, end - start, nrows, rp)
+                    row_order = RowOrder(rmap, order, end - start, nrows, rp, rowptr_dev=sp._node_rowptr.ptr)
                     cap = configuration["ocr_nnz_per_block_ordered"]
                     rb = row_order.tile_cuts(order.blocks, cap + cap // 10)
             if row_order is not None:
@@ -995,7 +996,7 @@ class Parloop:
             # (virtual spaces too: an extruded numbering is column-major, so ranges of ITS rows are vertical pencils)
             order = self._locality_order(start, end, virtual=v is not None)
             if order is not None:
-                row_order = RowOrder(rmap, order, end - start, nrows, rp)
+                row_order = RowOrder(rmap, order, end - start, nrows, rp, rowptr_dev=sp._node_rowptr.ptr)
                 prp = row_order.prowptr_host
         B = int(sp.dsets[0].cdim) * int(sp.dsets[1].cdim)
         cap = max(int(configuration["ocrs_nnz_per_block"]) // B, int(np.diff(prp).max()) if nrows else 1)

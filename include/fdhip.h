@@ -361,6 +361,11 @@ int fd_group_entities(const int32_t *map_dev, int arity, int32_t start, int32_t 
 int fd_first_touch_order(const int32_t *map_dev, int arity, const int32_t *order_dev, int64_t n, int32_t nnodes,
                          int32_t *pinv_dev, int32_t *plist_dev, int32_t *rank_dev, fd_stream_t s);
 int fd_invert_permutation(const int32_t *plist_dev, int32_t n, int32_t *pinv_dev, fd_stream_t s);
+/* The tables of a row order plist (row of every position): prowptr[p] = accumulator start of position p (npos + 1 entries: the
+ * running sum of the row lengths in position order), gstart[p] = CSR start of that row, nstart[row] = prowptr[position of row]
+ * -- the lookups the "ocrp" / "ocrsp" wrappers and the plan builders need, each a flat array */
+int fd_row_order_tables(int32_t npos, const int32_t *plist_dev, const int32_t *rowptr_dev, int32_t *prowptr_dev, int32_t *nstart_dev,
+                        int32_t *gstart_dev, fd_stream_t s);
 /* gpos[prowptr[p] + k] = gstart[p] + k for the rows p of a row order (prowptr = accumulator starts by position, gstart = CSR
  * starts by position): the place of every accumulator entry in the CSR value array, streamed by the "ocrp" row flush */
 int fd_row_entry_positions(int32_t npos, const int32_t *prowptr_dev, const int32_t *gstart_dev, int32_t *gpos_dev, fd_stream_t s);

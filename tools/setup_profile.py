@@ -17,13 +17,23 @@ m = fmesh.UnitCubeMesh(n, degrees=(1,), perturb=0.1, numbering=nb)
 prob = forms.PoissonProblem(m, 1, bcs=True)
 print(f"mesh + problem      {time.perf_counter() - t0:8.3f} s")
 _lib.profile_report()
+import cProfile
+import io
+import pstats
 for label, fn in (("sparsity", lambda: prob.jacobian()[0].sparsity._build()), ("residual first call", prob.assemble_residual),
                   ("jacobian first call", prob.assemble_jacobian), ("residual second call", prob.assemble_residual),
                   ("jacobian second call", prob.assemble_jacobian)):
+    pr = cProfile.Profile()
     t0 = time.perf_counter()
+    pr.enable()
     fn()
+    pr.disable()
     _lib.load().fd_device_sync()
     dt = time.perf_counter() - t0
+    if "first" in label:
+        buf = io.StringIO()
+        pstats.Stats(pr, stream=buf).sort_stats("cumulative").print_stats(28)
+        print("\n".join(l for l in buf.getvalue().splitlines() if l.strip())[:6000])
     print(f"== {label:<22} {dt:8.3f} s (wall, every C-ABI call synchronised)")
     rep = _lib.profile_report()
     tot = sum(float(l.split()[-2]) for l in rep.splitlines()) if rep else 0.0
