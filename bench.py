@@ -706,7 +706,14 @@ def multi_gpu_detail(prob, args, res, ctx):
     wmax = max(r["residual_with_exchange_ms"] or 0.0 for r in allr)
     # bracket = forward exchange + kernels + reverse exchange; exchange_ms = forward + reverse on their own
     hidden = max(0.0, min(emax, kmax + emax - wmax))
-    return {"n_gpus": n_comm, "wire": wire, "communicator": fhalo.communicator_status(), "exchange_ms": emax,
+    # what each partition shape costs for THIS cube and rank count (mesh.partition_overheads): the ghost cube layers every rank
+    # computes again for the owner-computes-rows Jacobian, the halo rows and the neighbours of the worst rank
+    from firedrake_amd.mesh import partition_overheads
+    shape, deg = getattr(prob.mesh, "shape", None), getattr(prob, "degree", 1)
+    overheads = None
+    if shape is not None:
+        overheads = {name: partition_overheads(shape, world, name, deg) for name in ("slabs", "blocks")}
+    return {"n_gpus": n_comm, "wire": wire, "communicator": fhalo.communicator_status(), "exchange_ms": emax, "partition_overheads": overheads,
             "residual_kernel_only_ms": kmax, "residual_with_exchange_ms": wmax, "exchange_hidden_ms": hidden,
             "exchange_hidden_frac": hidden / emax if emax > 0 else None, "per_rank": allr}
 

@@ -113,6 +113,32 @@ template <class T> __global__ void unpack_rows_t(T *__restrict__ dat, int cdim, 
     }
 }
 
+// Reverse combine when owned nodes ARE shared between neighbours, in ONE launch and without atomics: node-major.  comb_node = the
+// distinct owned nodes of the concatenated send lists, comb_pos[comb_ptr[d] .. comb_ptr[d+1]) = the rows of the receive buffer
+// that belong to node d in neighbour order -- so a node's contributions are combined in the same order the per-neighbour
+// launches applied them (bitwise the same sums), by one lane per (node, component).
+template <class T> __global__ void combine_rows_t(T *__restrict__ dat, int cdim, const int32_t *__restrict__ comb_node,
+                                                  const int32_t *__restrict__ comb_ptr, const int32_t *__restrict__ comb_pos, int64_t nd,
+                                                  const T *__restrict__ buf, int op) {
+    const int64_t total = nd * cdim;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t d = t / cdim;
+        const int c = (int)(t - d * cdim);
+        T *p = &dat[(int64_t)comb_node[d] * cdim + c];
+        T acc = *p;
+        for (int32_t q = comb_ptr[d]; q < comb_ptr[d + 1]; ++q) {
+            const T v = buf[(int64_t)comb_pos[q] * cdim + c];
+            switch (op) {
+                case 0: acc = v; break;
+                case 1: acc += v; break;
+                case 2: acc = (v < acc) ? v : acc; break;
+                default: acc = (v > acc) ? v : acc; break;
+            }
+        }
+        *p = acc;
+    }
+}
+
 template <class T> struct Lim;
 template <> struct Lim<double> { static constexpr double hi = 1.7976931348623157e308, lo = -1.7976931348623157e308; };
 template <> struct Lim<float> { static constexpr float hi = 3.402823466e38f, lo = -3.402823466e38f; };
@@ -164,6 +190,8 @@ struct fd_halo_s {
     int32_t *send_idx = nullptr, *recv_idx = nullptr;  // concatenated per-neighbour lists on the device
     int64_t tsend = 0, trecv = 0;
     bool send_disjoint = true;                         // no owned node is sent to two neighbours: one reverse-combine launch
+    int32_t *comb_node = nullptr, *comb_ptr = nullptr, *comb_pos = nullptr;   // node-major combine tables (shared nodes only)
+    int64_t ncomb = 0;
     std::vector<fd_halo_slot> slots;
 };
 
@@ -266,7 +294,14 @@ int exchange_end(fd_halo_t h, void *dat, int cdim, int dtype, int dir, int op, f
                 hipLaunchKernelGGL(unpack_rows_t<T>, dim3(grid_for(nin * cdim)), dim3(256), 0, s, (T *)dat, cdim, iidx, nin, (const T *)sl->rbuf, op);
                 return 0;
             }
-            for (size_t k = 0; k < h->peer.size(); ++k) {       // reverse combine, one neighbour after the other
+            const char *fr = getenv("FDHIP_HALO_FUSED_REVERSE");      // (read per call: the self-neighbour test compares both paths)
+            const bool per_neighbour = fr && atoi(fr) == 0;
+            if (h->comb_node && !per_neighbour) {               // shared owned nodes: node-major combine, one launch
+                hipLaunchKernelGGL(combine_rows_t<T>, dim3(grid_for(h->ncomb * cdim)), dim3(256), 0, s, (T *)dat, cdim, h->comb_node, h->comb_ptr,
+                                   h->comb_pos, h->ncomb, (const T *)sl->rbuf, op);
+                return 0;
+            }
+            for (size_t k = 0; k < h->peer.size(); ++k) {       // (FDHIP_HALO_FUSED_REVERSE=0: one neighbour after the other)
                 const int64_t n = h->nsend[k];
                 if (n > 0)
                     hipLaunchKernelGGL(unpack_rows_t<T>, dim3(grid_for(n * cdim)), dim3(256), 0, s, (T *)dat, cdim, iidx + h->soff[k], n,
@@ -309,7 +344,19 @@ int fd_comm_create(const unsigned char *id128, int rank, int nranks, fd_comm_t *
     auto *c = new fd_comm_s;
     c->rank = rank; c->nranks = nranks;
     ncclResult_t r = R->CommInitRank(&c->comm, nranks, id, rank);
-    if (r != ncclSuccess) { delete c; fd::set_error(std::string("ncclCommInitRank failed: ") + R->GetErrorString(r)); return -2; }
+    if (r != ncclSuccess) {
+        // the first multi-device run must not be wasted on a bare error code: say who, where and what to look at
+        int dev = -1, ndev = 0;
+        (void)hipGetDevice(&dev); (void)hipGetDeviceCount(&ndev);
+        const char *ipc = getenv("HSA_ENABLE_IPC_MODE_LEGACY");
+        fd::set_error(std::string("ncclCommInitRank failed on rank ") + std::to_string(rank) + " of " + std::to_string(nranks) + " (HIP device " +
+                      std::to_string(dev) + " of " + std::to_string(ndev) + " visible): " + R->GetErrorString(r) +
+                      "; HSA_ENABLE_IPC_MODE_LEGACY=" + (ipc ? ipc : "<unset: this driver needs 0>") +
+                      "; every rank must call fd_comm_create with the same 128-byte id and its own device selected (fd_set_device) BEFORE the call"
+                      "; NCCL_DEBUG=INFO prints RCCL's own account");
+        delete c;
+        return -2;
+    }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { R->CommDestroy(c->comm); delete c; FD_HIP(e); }
     *out = c;
@@ -382,11 +429,33 @@ int fd_halo_create(fd_comm_t comm, int nneigh, const int32_t *peers, const int32
         std::sort(t.begin(), t.end());
         h->send_disjoint = std::adjacent_find(t.begin(), t.end()) == t.end();
     }
+    std::vector<int32_t> cnode, cptr, cpos;
+    if (!h->send_disjoint) {
+        // node-major tables of the reverse combine: positions of the concatenated send list grouped by node, neighbour order kept
+        std::vector<int32_t> ord(sall.size());
+        for (size_t i = 0; i < ord.size(); ++i) ord[i] = (int32_t)i;
+        std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) { return sall[a] < sall[b]; });
+        for (size_t i = 0; i < ord.size(); ++i) {
+            if (i == 0 || sall[ord[i]] != sall[ord[i - 1]]) { cnode.push_back(sall[ord[i]]); cptr.push_back((int32_t)i); }
+            cpos.push_back(ord[i]);
+        }
+        cptr.push_back((int32_t)ord.size());
+        h->ncomb = (int64_t)cnode.size();
+    }
     hipError_t e = hipMalloc((void **)&h->send_idx, std::max<size_t>(sall.size() * 4, 8));
     if (e == hipSuccess) e = hipMalloc((void **)&h->recv_idx, std::max<size_t>(rall.size() * 4, 8));
+    if (e == hipSuccess && !cnode.empty()) {
+        e = hipMalloc((void **)&h->comb_node, cnode.size() * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->comb_ptr, cptr.size() * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->comb_pos, cpos.size() * 4);
+        if (e == hipSuccess) e = hipMemcpy(h->comb_node, cnode.data(), cnode.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(h->comb_ptr, cptr.data(), cptr.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(h->comb_pos, cpos.data(), cpos.size() * 4, hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess && !sall.empty()) e = hipMemcpy(h->send_idx, sall.data(), sall.size() * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess && !rall.empty()) e = hipMemcpy(h->recv_idx, rall.data(), rall.size() * 4, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(h->send_idx); (void)hipFree(h->recv_idx); delete h; FD_HIP(e); }
+    if (e != hipSuccess) { (void)hipFree(h->send_idx); (void)hipFree(h->recv_idx); (void)hipFree(h->comb_node); (void)hipFree(h->comb_ptr);
+                           (void)hipFree(h->comb_pos); delete h; FD_HIP(e); }
     *out = h;
     return 0;
 }
@@ -400,6 +469,7 @@ int fd_halo_free(fd_halo_t h) {
         if (s.done) (void)hipEventDestroy(s.done);
     }
     (void)hipFree(h->send_idx); (void)hipFree(h->recv_idx);
+    (void)hipFree(h->comb_node); (void)hipFree(h->comb_ptr); (void)hipFree(h->comb_pos);
     delete h;
     return 0;
 }

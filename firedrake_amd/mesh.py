@@ -122,6 +122,37 @@ def partition_grid(nranks, shape=None):
     return g
 
 
+def partition_overheads(n, nranks, partition=None, degree=1):
+    """What a box partition of the n^3 cube costs, without building any mesh (same rules as UnitCubeMesh): per rank the cubes it
+    owns and the ghost cubes of the low-side layers it computes again for the owner-computes-rows Jacobian, the lattice nodes
+    (CG_degree) it sends / receives per exchange and its neighbours.  Returns the worst rank's figures -- the ones the step time
+    of a bulk-synchronous assembly follows -- and the totals: ``{"grid", "redundant_cell_fraction" (max over ranks of ghost / owned
+    cubes), "redundant_cells_total_fraction", "max_halo_nodes", "max_neighbours"}``."""
+    nx, ny, nz = (int(n),) * 3 if np.isscalar(n) else tuple(int(v) for v in n)
+    ndim = (nx, ny, nz)
+    pgrid = partition_grid(nranks, partition)
+    p = int(degree)
+    worst, own_tot, ghost_tot, halo_max, neigh_max = 0.0, 0, 0, 0, 0
+    for rank in range(nranks):
+        rc = (rank % pgrid[0], (rank // pgrid[0]) % pgrid[1], rank // (pgrid[0] * pgrid[1]))
+        own = tuple(((ndim[d] * rc[d]) // pgrid[d], (ndim[d] * (rc[d] + 1)) // pgrid[d]) for d in range(3))
+        nown = int(np.prod([b - a for a, b in own]))
+        nloc = int(np.prod([b - a + (1 if rc[d] > 0 else 0) for d, (a, b) in enumerate(own)]))
+        own_tot, ghost_tot = own_tot + nown, ghost_tot + (nloc - nown)
+        worst = max(worst, (nloc - nown) / nown)
+        # nodes: owned box [p lo, p hi) (+ the domain's last plane on the last rank of an axis), local box = one more plane on the
+        # high side and the ghost layer's planes on the low side
+        oown = [p * (b - a) + (1 if rc[d] == pgrid[d] - 1 else 0) for d, (a, b) in enumerate(own)]
+        oloc = [p * (b - a + (1 if rc[d] > 0 else 0)) + 1 for d, (a, b) in enumerate(own)]
+        halo_max = max(halo_max, int(np.prod(oloc)) - int(np.prod(oown)))
+        neigh = 1
+        for d in range(3):
+            neigh *= 1 + (1 if rc[d] > 0 else 0) + (1 if rc[d] < pgrid[d] - 1 else 0)
+        neigh_max = max(neigh_max, neigh - 1)
+    return {"grid": pgrid, "redundant_cell_fraction": worst, "redundant_cells_total_fraction": ghost_tot / own_tot,
+            "max_halo_nodes": halo_max, "max_neighbours": neigh_max}
+
+
 def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0, ghost_cells=True, numbering="tiled",
                  seed=0, partition=None):
     """Kuhn-split tetrahedral unit cube, box-partitioned over ``nranks`` ranks (``partition``: "slabs" = z-slabs, the

@@ -93,3 +93,20 @@ def test_partitioned_assembly_over_rccl(world, n, degree, partition):
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n" + "\n=====\n".join(o[-2500:] for o in outs)
         assert f"rank {r}/{world} ok" in out
+
+
+def test_partition_overheads_match_the_meshes_they_describe():
+    """mesh.partition_overheads (the slabs-versus-blocks figures bench.py reports at N > 1) against the meshes themselves."""
+    from firedrake_amd import mesh as fmesh
+    for part, nranks in (("slabs", 4), ("blocks", 8)):
+        ov = fmesh.partition_overheads(8, nranks, part, 1)
+        worst, halo = 0.0, 0
+        for r in range(nranks):
+            m = fmesh.UnitCubeMesh(8, degrees=(1,), rank=r, nranks=nranks, partition=part)
+            own, tot = m.cell_set.size, m.cell_set.total_size
+            worst = max(worst, (tot - own) / own)
+            ns = m.space(1).node_set
+            halo = max(halo, ns.total_size - ns.size)
+        assert abs(ov["redundant_cell_fraction"] - worst) < 1e-12 and ov["max_halo_nodes"] == halo
+    big = fmesh.partition_overheads(215, 8, "blocks", 2)
+    assert big["grid"] == (2, 2, 2) and big["max_neighbours"] == 7 and 0.02 < big["redundant_cell_fraction"] < 0.03
