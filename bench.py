@@ -860,6 +860,9 @@ def main():
         guarded("secondary_c1", lambda: measure_c1(200, 3))
     if rank == 0:
         out.setdefault("cpu_baseline", None)
+        from firedrake_amd import compilation
+        # wrappers this process had to compile (hipcc, ~0.35 s each, inside the first-call times) / found in the disk cache
+        out["jit_compiles"] = dict(compilation.stats)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

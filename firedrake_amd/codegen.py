@@ -999,6 +999,9 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     if sm_:
         mode = mode[:sm_.start()]
     ordered = mode.startswith("ocrsp")
+    # "ocrspr": the flush of a derived row order through run-coded places (one byte per entry + one displacement per run of
+    # CSR-consecutive rows in LDS, fd_ocr_row_runs) instead of row by row
+    runflush = mode.startswith("ocrspr")
     ktype, kbytes = ("unsigned short", 2) if mode.endswith("_k16") else ("unsigned char", 1)
     skip = "0xffffu" if kbytes == 2 else "0xffu"
     threads = configuration["ocrs_block_threads"]
@@ -1067,9 +1070,15 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         P(f"const int *__restrict__ oc{K}_gstart", ("ocr_gstart", K))
     # flush of a derived row order through the per-entry place table of the whole-entity wrapper (4 B per nonzero, FU places
     # requested per trip) instead of row by row with 16 lanes per row
-    entry_flush = bool(ordered and B == 1 and configuration["ocrs_entry_flush"])
+    entry_flush = bool(ordered and B == 1 and configuration["ocrs_entry_flush"] and not runflush)
     if entry_flush:
         P(f"const int *__restrict__ oc{K}_gpos", ("ocr_gpos", K))
+    if runflush:
+        if B != 1:
+            raise ValueError("the run-coded flush serves scalar matrices")
+        P(f"const unsigned char *__restrict__ oc{K}_grun", ("ocr_grun", K))
+        P(f"const int *__restrict__ oc{K}_brun", ("ocr_brun", K))
+        P(f"const int *__restrict__ oc{K}_rdelta", ("ocr_rdelta", K))
     P(f"const unsigned short *__restrict__ oc{K}_slot", ("ocrs_slot", K))
     if B > 1:
         P(f"const unsigned short *__restrict__ oc{K}_rowlen", ("ocrs_rowlen", K))
@@ -1111,6 +1120,8 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     if gk._pass_layer_arg:
         call_args.append("layer")
     lds_items.append(("ocrs", K, B))
+    if runflush:
+        lds_decl.append(f"int *srun{K} = (int *)(fd_lds + fd_off); fd_off += 1024;")
     lds_decl.append(f"double *sm{K} = (double *)(fd_lds + fd_off); fd_off += (((size_t)oc{K}_maxnnz*{B}*8) + 15) & ~(size_t)15;")
 
     includes, body = _hoist_includes(lk.code)
@@ -1129,6 +1140,9 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     src += [f"  const int n0 = oc{K}_rblk[b], nown = oc{K}_rblk[b+1] - n0;",
             f"  const int r0 = oc{K}_rowptr[n0], nnzb = (oc{K}_rowptr[n0 + nown] - r0)*{B};",
             f"  for (int q = tid; q < nnzb; q += nthr) sm{K}[q] = 0;"]
+    if runflush:
+        src += [f"  const int br0 = oc{K}_brun[b], nrun = oc{K}_brun[b+1] - br0;",
+                f'  _Pragma("clang loop unroll(disable) vectorize(disable)") for (int q = tid; q < nrun; q += nthr) srun{K}[q] = oc{K}_rdelta[br0 + q];']
     for mi, acts in stage_nodes.items():
         src.append(f"  for (int i = tid; i < nd{mi}; i += nthr) {{")
         src.append(f"    const int g = p{mi}_list[l0_{mi} + i];")
@@ -1214,7 +1228,15 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             src.append(f"    for (int q = 0; q < {ln}; ++q) {n}[q] = nx_{n}[q];")
         src.append("    " + " ".join(f"{n} = nx_{n};" for n, _ in scal) + (" cmask = nx_cmask;" if dofmask else ""))
     src += ["  }", "  __syncthreads();"]
-    if entry_flush:
+    if runflush:
+        FU = max(1, int(configuration["flush_batch"]))
+        src.append(f"  for (int q0 = tid; q0 < nnzb; q0 += {FU}*nthr) {{ int g[{FU}]; "
+                   f"for (int f = 0; f < {FU}; ++f) {{ const int q = q0 + f*nthr; g[f] = (int)oc{K}_grun[(size_t)r0 + (q < nnzb ? q : nnzb - 1)]; }} "
+                   f"for (int f = 0; f < {FU}; ++f) g[f] = r0 + q0 + f*nthr + srun{K}[g[f]]; "
+                   f"if (oc{K}_flags & 1) {{ for (int f = 0; f < {FU}; ++f) if (q0 + f*nthr < nnzb) arg{K}[(size_t)g[f]] = sm{K}[q0 + f*nthr]; }} "
+                   f"else {{ double o[{FU}]; for (int f = 0; f < {FU}; ++f) o[f] = (q0 + f*nthr < nnzb) ? arg{K}[(size_t)g[f]] : 0.0; "
+                   f"for (int f = 0; f < {FU}; ++f) if (q0 + f*nthr < nnzb) arg{K}[(size_t)g[f]] = o[f] + sm{K}[q0 + f*nthr]; }} }}")
+    elif entry_flush:
         FU = max(1, int(configuration["flush_batch"]))
         src.append(f"  for (int q0 = tid; q0 < nnzb; q0 += {FU}*nthr) {{ int g[{FU}]; "
                    f"for (int f = 0; f < {FU}; ++f) {{ const int q = q0 + f*nthr; g[f] = oc{K}_gpos[(size_t)r0 + (q < nnzb ? q : nnzb - 1)]; }} "

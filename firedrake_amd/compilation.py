@@ -23,6 +23,7 @@ class CompilationError(RuntimeError):
 
 
 _version = None
+stats = {"hipcc_runs": 0, "cache_hits": 0}      # wrappers compiled / found in the disk cache by this process
 
 
 def compiler_version():
@@ -68,7 +69,9 @@ def compile_hip(source: str, name: str, extra_flags=()) -> str:
     key = hashlib.sha1("\0".join([source, " ".join(keyed), compiler_version(), _wrapper_header_hash()]).encode()).hexdigest()[:20]
     out = os.path.join(cache, f"{name}_{key}.hsaco")
     if os.path.exists(out):
+        stats["cache_hits"] += 1
         return out
+    stats["hipcc_runs"] += 1
     # the source goes to a unique temporary name and is renamed into place (pyop2/compilation.py:560-575): ranks that
     # miss the cache together never truncate a file another rank's hipcc is reading
     src = os.path.join(cache, f"{name}_{key}.hip")

@@ -517,13 +517,37 @@ class PoissonProblem:
         return mat
 
 
+# the geometry-specific wrapper variants the benchmark configurations end up launching (bench.py, FDHIP_DEBUG=1 prints them): compiled
+# ahead of time by precompile_all() so that a fresh machine's first assemble does not start with hipcc (0.35 s per wrapper).  A
+# variant missing here is not an error -- it is compiled on first use -- and bench.py reports how many were (``jit_compiles``).
+BENCH_VARIANTS = {
+    ("residual", 2, 1): ("staged_s289",),
+    ("jacobian", 2, 1): ("ocrp_q10k3d", "ocr_q10k3d", "ocrp_q9k3d", "ocr_q9k3d"),
+    ("residual", 3, 1): ("stagedo_s439", "staged_s405"),
+    ("jacobian", 3, 1): ("ocrp_q10k4d", "ocr_q10k4d", "ocrp_q9k4d", "ocr_q9k4d"),
+    ("residual", 3, 2): ("stagedo_s1546x260",),
+    ("jacobian", 3, 2): ("ocrsp", "ocrs"),
+    "dg_advection": ("staged_s2048x561", "staged_s1024x516", "staged_s2332x668"),
+}
+
+
 def precompile_all():
-    """Compile (hipcc, disk-cached) the wrappers of the benchmark forms so the code objects ship with the tree."""
-    from .codegen import generate_wrapper, staged_eligible
-    from .compilation import compile_hip
+    """Compile (hipcc, disk-cached) the wrappers of the benchmark forms so the code objects ship with the tree: the base wrapper
+    shapes and the geometry-specific variants of BENCH_VARIANTS, each through ``GlobalKernel.compile`` (so the unroll / occupancy
+    retries a first call would make are made here)."""
+    from .codegen import ocr_eligible, sliced_eligible, staged_eligible
     from .kernel import DatKernelArg, GlobalKernel, MapKernelArg, MatKernelArg
     from .op2types import INC, READ
     out = []
+
+    def build(g, modes):
+        for mode in modes:
+            try:
+                out.append(g.compile(mode).path)
+            except Exception as exc:                     # (a variant name that no longer fits this kernel's staged maps)
+                import sys
+                print(f"[fdhip] precompile {g.name} {mode}: {exc}", file=sys.stderr)
+
     for dim, degree in ((2, 1), (3, 1), (3, 2)):
         nd = {(2, 1): 3, (3, 1): 4, (3, 2): 10}[(dim, degree)]
         cm = MapKernelArg(nd)
@@ -532,28 +556,25 @@ def precompile_all():
         kres = poisson_residual_kernel(dim, degree).with_signature([INC, READ, READ, READ], [f64] * 4)
         gk = GlobalKernel(kres, [DatKernelArg((1,), cm), DatKernelArg((dim,), xm), DatKernelArg((1,), cm), DatKernelArg((1,), cm)])
         kjac = poisson_jacobian_kernel(dim, degree).with_signature([INC, READ], [f64] * 2)
+        build(gk, [m for m in ("staged", "direct") if m != "staged" or staged_eligible(gk)] + list(BENCH_VARIANTS[("residual", dim, degree)]))
         for lg in (False, True):
             gj = GlobalKernel(kjac, [MatKernelArg(((1,), (1,)), (cm, cm), lgmaps=lg), DatKernelArg((dim,), xm)])
-            for g in (gk, gj):
-                from .codegen import ocr_eligible, sliced_eligible
-                for mode in ("staged", "direct", "ocr", "ocrs"):
-                    if mode == "staged" and not staged_eligible(g):
-                        continue
-                    if mode.startswith("ocr") and not ocr_eligible(g):
-                        continue
-                    if mode == "ocrs" and not sliced_eligible(g):
-                        continue
-                    src = generate_wrapper(g, mode)
-                    out.append(compile_hip(src.source, src.symbol))
-    # config C3: the tensor-product wrappers of the Q4 Helmholtz operator (matrix with and without BC lgmaps, action)
+            modes = ["direct"] + (["staged"] if staged_eligible(gj) else []) + (["ocr"] if ocr_eligible(gj) else []) \
+                + (["ocrs"] if (ocr_eligible(gj) and sliced_eligible(gj)) else [])
+            extra = [v for v in BENCH_VARIANTS[("jacobian", dim, degree)] if v.startswith("ocrs") == (ocr_eligible(gj) and sliced_eligible(gj))]
+            build(gj, modes + (extra if lg else []))
+    # config C3: the tensor-product wrappers of the Q4 Helmholtz operator (matrix with and without BC lgmaps, action), also with
+    # coefficient arguments
     from . import mesh as fmesh
-    from .codegen import generate_tensor_wrapper
     hm = fmesh.make_extruded_hex_mesh(1, 1, 4, perturb=0.0)
     for bcs in (False, True):
-        prob = HelmholtzQ4Problem(hm, bcs=bcs)
-        for loop in (prob.jac_loop, prob.act_loop):
-            src = generate_tensor_wrapper(loop.global_kernel)
-            out.append(compile_hip(src.source, src.symbol))
+        for prob in (HelmholtzQ4Problem(hm, bcs=bcs), CoefficientHexProblem(hm, bcs=bcs, nq=5)):
+            for loop in (prob.jac_loop, prob.act_loop):
+                build(loop.global_kernel, [None])
+    # config C4: the three DG advection loops
+    qm = fmesh.make_quad_mesh(4, perturb=0.1)
+    for loop, variant in zip(DGAdvectionProblem(qm).loops, BENCH_VARIANTS["dg_advection"]):
+        build(loop.global_kernel, [None, variant])
     return out
 
 

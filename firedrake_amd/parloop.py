@@ -1026,8 +1026,15 @@ class Parloop:
         else:
             raise PlanDoesNotFit("row-sliced owner-computes-rows plan does not fit")
         nds = [op.plans[mi].max_nd for mi in src.staged_maps]
-        variant = mode_variant("ocrsp" if row_order is not None else "ocrs", op.kbytes, nds)
-        geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz,
+        base, runs = ("ocrsp" if row_order is not None else "ocrs"), None
+        if row_order is not None and B == 1 and configuration["ocrs_run_flush"]:
+            runs = row_order.runs(op.row_blocks)
+            if runs[3] <= 256 and lds + 1024 <= limit:
+                base, lds = "ocrspr", lds + 1024
+            else:
+                runs = None
+        variant = mode_variant(base, op.kbytes, nds)
+        geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz, "runs": runs,
                "cw": prep["cw"] if variant == src.mode else self.global_kernel.compile(variant), "row_order": row_order}
         prep["parts"][gkey] = geo
         if configuration["debug"]:

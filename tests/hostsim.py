@@ -370,7 +370,7 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False,
     return csr
 
 
-def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None):
+def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None, run_flush=False):
     """Execute a matrix-assembly Parloop ``pl`` with the ROW-SLICED owner-computes-rows wrapper on the host (one OS thread
     per lane).  Plan tables from helpers.ocrs_plan_ref, CSR pattern from the oracle.  Returns the OracleCSR."""
     import re
@@ -423,7 +423,11 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None):
         blk, lst, lm = plan_ref_blocks(np.asarray(maps[mi].values_with_halo)[inst_ent], inst_off)
         plans[mi] = (blk, lst, np.ascontiguousarray(lm), int(np.diff(blk).max()) if len(blk) > 1 else 0)
     max_nnz = int(np.diff(acc[rb]).max())
-    src = generate_wrapper(gk, mode_variant("ocrsp" if order is not None else "ocrs", 1, [plans[mi][3] for mi in base.staged_maps]))
+    run_tabs = None
+    if order is not None and run_flush:
+        run_tabs = row_runs_ref(acc, ncsr.rowptr[plist], rb)
+    src = generate_wrapper(gk, mode_variant(("ocrspr" if run_tabs else "ocrsp") if order is not None else "ocrs", 1,
+                                            [plans[mi][3] for mi in base.staged_maps]))
     text = src.source.replace("extern __shared__ __align__(16) unsigned char fd_lds[];", "unsigned char *fd_lds = fd_sim::lds;")
     sig = re.search(r'extern "C" __global__[^\n]*void %s\((.*)\)\n' % src.symbol, text).group(1)
     names = [p.split()[-1].lstrip("*") for p in sig.split(", ")]
@@ -476,6 +480,8 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None):
             cargs.append(ptr(np.ascontiguousarray(acc, dtype=np.int32)))
         elif kind == "ocr_gstart":
             cargs.append(ptr(np.ascontiguousarray(ncsr.rowptr[plist], dtype=np.int32)))
+        elif kind in ("ocr_grun", "ocr_brun", "ocr_rdelta"):
+            cargs.append(ptr(run_tabs[{"ocr_grun": 0, "ocr_brun": 1, "ocr_rdelta": 2}[kind]]))
         elif kind == "ocr_gpos":
             # (scalar matrices only: place of every accumulator entry, rows in position order)
             cargs.append(ptr(np.concatenate([np.arange(ncsr.rowptr[r], ncsr.rowptr[r + 1]) for r in plist] + [np.zeros(0, np.int64)]).astype(np.int32)))

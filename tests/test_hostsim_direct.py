@@ -629,6 +629,10 @@ def test_row_sliced_owner_computes_rows_on_host(bcs, numbering):
                         assert np.abs(got3.values - (ref.values + (0.0 if zp else 1.0))).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
                 finally:
                     configuration["ocrs_entry_flush"] = 0
+                # ... and through run-coded places ("ocrspr": one byte per entry, the block's displacements in LDS)
+                for zp in (True, False):
+                    got4 = run_ocrs(pl, nnz_per_block=cap, zero_pending=zp, order=order, run_flush=True)
+                    assert np.abs(got4.values - (ref.values + (0.0 if zp else 1.0))).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
 
 
 @pytest.mark.parametrize("numbering,bcs", [("tiled", False), ("tiled", True), ("random", True)])

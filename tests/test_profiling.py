@@ -39,5 +39,6 @@ def test_parloops_log_their_flops_under_the_reference_region_names(monkeypatch):
     for _ in range(3):
         op2.par_loop(k, ele, y(op2.INC, m), x(op2.READ, m))
     s = profiling.summary()
-    assert s["Parloop_cells_ax"] == {"calls": 3, "entities": 120, "flops": 480.0}, s
+    # (the reference's region name: f"Parloop_{iterset.name}_{global_kernel.name}", global_kernel.name = "wrap_" + the local kernel's)
+    assert s["Parloop_cells_wrap_ax"] == {"calls": 3, "entities": 120, "flops": 480.0}, s
     assert np.allclose(y.data_ro.sum(), 3 * 2.0 * 80)
