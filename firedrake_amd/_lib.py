@@ -85,7 +85,7 @@ SIGNATURES = {
     "fd_ocr_node_words": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fd_ocr_node_diag": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fd_ocr_pack_records": (c_int, [c_int64, c_int, POINTER(c_void_p), POINTER(c_int32), POINTER(c_int32), c_void_p, c_int, c_int, c_int,
-                                    c_int, c_int, c_int, c_void_p, c_void_p]),
+                                    c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "fd_ocr_row_runs": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, POINTER(c_int32),
                                 POINTER(c_int32), c_void_p]),
     "fd_ocrplan_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),

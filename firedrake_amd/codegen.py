@@ -998,6 +998,13 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     strides = [int(v) for v in sm_.group(1).split("x")] if sm_ else None
     if sm_:
         mode = mode[:sm_.start()]
+    # "_q<L0>x..k<K>e<S>": one bit-packed record per instance (fd_ocr_pack_records) instead of the uint16 / uint8 index rows and the
+    # uint16 slot: local-map entries at L_m bits, column positions at K bits, the accumulator slot at S bits (dropped = all ones)
+    rq_ = re.search(r"_q(\d+(?:x\d+)*)k(\d+)e(\d+)$", mode)
+    rec = None
+    if rq_:
+        rec = {"lbits": [int(v) for v in rq_.group(1).split("x")], "kbits": int(rq_.group(2)), "sbits": int(rq_.group(3))}
+        mode = mode[:rq_.start()]
     ordered = mode.startswith("ocrsp")
     # "ocrspr": the flush of a derived row order through run-coded places (one byte per entry + one displacement per run of
     # CSR-consecutive rows in LDS, fd_ocr_row_runs) instead of row by row
@@ -1091,6 +1098,12 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     P(f"const {ktype} *__restrict__ oc{K}_k", ("ocrs_kk", K))
     P(f"long long oc{K}_maxnnz", ("ocr_maxnnz", K))
     P(f"long long oc{K}_flags", ("ocr_flags", K))
+    if rec:
+        if B != 1 or dofmask:
+            raise ValueError("instance records serve scalar matrices with node lgmaps")
+        P(f"const unsigned int *__restrict__ oc{K}_rec", ("ocr_rec", K))
+        skip = f"{(1 << rec['kbits']) - 1}u"
+    slot_skip = f"{(1 << rec['sbits']) - 1}" if rec else "0xffff"
 
     lds_decl, lds_items, stage_nodes, pack, call_args = ["size_t fd_off = 0;"], [], {}, [], []
     for info in infos:
@@ -1162,6 +1175,25 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             for mi in staged_maps]
     rows.append(("kk", AC, f"fdw::load_packed<{ktype}, {AC}>(oc{K}_k + (size_t)(II - start)*{AC}, DST);"))
     scal = [("role", "(int)chunk_role_[(II - start) >> 6]"), ("slot", f"(int)oc{K}_slot[II - start]")]
+    rec_decode = []
+    if rec:
+        if len(rec["lbits"]) != len(staged_maps):
+            raise ValueError("one local-index width per staged map")
+        off, fields = 0, []
+        for mi, lb in zip(staged_maps, rec["lbits"]):
+            for i in range(maps[mi].arity):
+                fields.append((f"lm{mi}[{i}]", off, lb))
+                off += lb
+        for j in range(AC):
+            fields.append((f"kk[{j}]", off, rec["kbits"]))
+            off += rec["kbits"]
+        fields.append(("const int slot", off, rec["sbits"]))
+        off += rec["sbits"]
+        W = -(-off // 32)
+        rec_decode = [f"int lm{mi}[{maps[mi].arity}];" for mi in staged_maps] + [f"int kk[{AC}];"]
+        rec_decode += [f"{name} = fdw::rec_field<{o}, {b}>(rc);" for name, o, b in fields]
+        rows = [("rc", W, f"fdw::load_rec<{W}>(oc{K}_rec + (size_t)(II - start)*{W}, DST);")]
+        scal = [("role", "(int)chunk_role_[(II - start) >> 6]")]
     if B > 1:
         scal.append(("rlen", f"(int)oc{K}_rowlen[II - start]"))
     if dofmask:
@@ -1176,7 +1208,8 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         out += [ld.replace("II", ii).replace("DST", prefix + n) for n, _, ld in rows]
         return out
     for n, ln, _ in rows:
-        src.append(f"  int {n}[{ln}];" + (f" int nx_{n}[{ln}];" if pf else ""))
+        ty = "unsigned" if rec else "int"
+        src.append(f"  {ty} {n}[{ln}];" + (f" {ty} nx_{n}[{ln}];" if pf else ""))
     src.append("  int " + ", ".join(f"{n} = 0" + (f", nx_{n} = 0" if pf else "") for n, _ in scal) + ";")
     if dofmask:
         src.append("  unsigned long long cmask = 0" + (", nx_cmask = 0;" if pf else ";"))
@@ -1202,6 +1235,7 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
                     "    const int e = " + ("subset_indices[fd_col];" if gk._subset else "fd_col;")]
         else:
             src.append("    const int e = subset_indices[fd_v];")
+    src += ["    " + s for s in rec_decode]
     src += ["    " + s for s in pack]
     src.append("    switch (fdw::wave_uniform(role)) {")
     NT = AR * RB * AC * CB
@@ -1220,7 +1254,7 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
                 f"      double t{K}[{NT}]; for (int q = 0; q < {NT}; ++q) t{K}[q] = 0;",
                 f"      fdk::{lk.name}({', '.join(call_args)});",
                 # (dropped contributions branch around the ds_add_f64; sending them to per-lane dump words instead measured 5 % slower)
-                "      if (slot != 0xffff) {", *scatter, "      }",
+                f"      if (slot != {slot_skip}) {{", *scatter, "      }",
                 "    } break;"]
     src += ["    default: break;", "    }"]
     if pf:
@@ -1297,10 +1331,23 @@ def record_layout(arities, max_nds, nr, nc, maxlen, same_map):
     return lbits, kbits, diag, -(-bits // 32)
 
 
+def sliced_record_layout(arities, max_nds, nc, maxlen, max_nnz):
+    """Field widths of the bit-packed instance records of a row-sliced loop (generate_sliced_wrapper, "_q...e" suffix): (lbits per
+    staged map, kbits, sbits, words per instance); the all-ones value of the position and slot fields means "dropped"."""
+    lbits = [max(int(n - 1).bit_length(), 1) for n in max_nds]
+    kbits = max(int(maxlen).bit_length(), 1)              # positions 0 .. maxlen-1 and the all-ones marker
+    sbits = max(int(max_nnz).bit_length(), 1)
+    bits = sum(a * b for a, b in zip(arities, lbits)) + nc * kbits + sbits
+    return lbits, kbits, sbits, -(-bits // 32)
+
+
 def mode_variant(base: str, kbytes: int, max_nds, rec=None) -> str:
     """Name of the wrapper variant for a launch geometry: base mode [+ _k16] [+ _q<record fields>] [+ _s<strides>]."""
     m = base + ("_k16" if kbytes == 2 else "")
-    if rec is not None:
+    if rec is not None and base.startswith("ocrs"):
+        lbits, kbits, sbits = rec[:3]
+        m += "_q" + "x".join(str(b) for b in lbits) + f"k{kbits}e{sbits}"
+    elif rec is not None:
         lbits, kbits, diag = rec[:3]
         m += "_q" + "x".join(str(b) for b in lbits) + f"k{kbits}" + ("d" if diag else "")
     ocr = base.startswith("ocr")

@@ -1133,6 +1133,7 @@ __global__ void ocrs_tables_k(const int32_t *__restrict__ inst_off, int32_t nblo
 struct RecDesc {
     const uint16_t *lmap[8]; int ar[8]; int lbits[8]; int nmaps;
     const void *kidx; int kbytes, nr, nc, kbits, skipdiag, words;
+    const uint16_t *extra; int ebits, sentinel;
 };
 __global__ void ocr_pack_records_k(RecDesc d, int64_t ninst, uint32_t *__restrict__ out, int32_t *__restrict__ err) {
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < ninst; t += (int64_t)gridDim.x * blockDim.x) {
@@ -1149,8 +1150,21 @@ __global__ void ocr_pack_records_k(RecDesc d, int64_t ninst, uint32_t *__restric
             for (int j = 0; j < d.nc; ++j) {
                 if (d.skipdiag && i == j) continue;
                 const int64_t q = (t * d.nr + i) * d.nc + j;
-                put(d.kbytes == 1 ? (uint32_t)((const uint8_t *)d.kidx)[q] : (uint32_t)((const uint16_t *)d.kidx)[q], d.kbits);
+                uint32_t v = d.kbytes == 1 ? (uint32_t)((const uint8_t *)d.kidx)[q] : (uint32_t)((const uint16_t *)d.kidx)[q];
+                if (d.sentinel) {                                   // "dropped" (all ones of the source type) -> all ones of the field
+                    const uint32_t all = (1u << d.kbits) - 1u;
+                    if (v == (d.kbytes == 1 ? 0xffu : 0xffffu)) v = all; else if (v >= all) atomicOr(err, 1);
+                }
+                put(v, d.kbits);
             }
+        if (d.extra) {
+            uint32_t v = d.extra[t];
+            if (d.sentinel) {
+                const uint32_t all = (1u << d.ebits) - 1u;
+                if (v == 0xffffu) v = all; else if (v >= all) atomicOr(err, 1);
+            }
+            put(v, d.ebits);
+        }
         if (nb > 0) o[wi++] = (uint32_t)acc;
         while (wi < d.words) o[wi++] = 0;
     }
@@ -1213,10 +1227,10 @@ int fd_ocr_node_words(const int32_t *blkoff_dev, const int32_t *list_dev, int32_
 }
 
 int fd_ocr_pack_records(int64_t ninst, int nmaps, const uint16_t *const *lmaps_dev, const int32_t *arities, const int32_t *lbits,
-                        const void *kidx_dev, int kbytes, int nr, int nc, int kbits, int skipdiag, int words, uint32_t *out_dev,
-                        fd_stream_t s_) {
+                        const void *kidx_dev, int kbytes, int nr, int nc, int kbits, int skipdiag, const uint16_t *extra_dev, int ebits,
+                        int sentinel, int words, uint32_t *out_dev, fd_stream_t s_) {
     if (ninst < 0 || nmaps < 0 || nmaps > 8 || (nmaps && (!lmaps_dev || !arities || !lbits)) || !kidx_dev || !out_dev ||
-        (kbytes != 1 && kbytes != 2) || nr <= 0 || nc <= 0 || kbits <= 0 || kbits > 16 || words <= 0)
+        (kbytes != 1 && kbytes != 2) || nr <= 0 || nc <= 0 || kbits <= 0 || kbits > 16 || words <= 0 || (extra_dev && (ebits <= 0 || ebits > 16)))
         FD_FAIL("fd_ocr_pack_records: bad arguments");
     RecDesc d{};
     int64_t bits = 0;
@@ -1226,7 +1240,8 @@ int fd_ocr_pack_records(int64_t ninst, int nmaps, const uint16_t *const *lmaps_d
         d.lmap[m] = lmaps_dev[m]; d.ar[m] = arities[m]; d.lbits[m] = lbits[m];
         bits += (int64_t)arities[m] * lbits[m];
     }
-    bits += (int64_t)(nr * nc - (skipdiag ? (nr < nc ? nr : nc) : 0)) * kbits;
+    bits += (int64_t)(nr * nc - (skipdiag ? (nr < nc ? nr : nc) : 0)) * kbits + (extra_dev ? ebits : 0);
+    d.extra = extra_dev; d.ebits = ebits; d.sentinel = sentinel;
     if ((bits + 31) / 32 != words) FD_FAIL("fd_ocr_pack_records: the fields do not fill the stated number of words");
     d.kidx = kidx_dev; d.kbytes = kbytes; d.nr = nr; d.nc = nc; d.kbits = kbits; d.skipdiag = skipdiag; d.words = words;
     if (ninst == 0) return 0;

@@ -1977,7 +1977,7 @@ class OcrPlan:
             ar = (ctypes.c_int32 * max(n, 1))(*[self.plans[k_].arity for k_ in staged_keys])
             lb = (ctypes.c_int32 * max(n, 1))(*[int(b) for b in lbits])
             _lib.call("fd_ocr_pack_records", int(self.ninst), n, lm, ar, lb, self.kidx.ptr, self.kbytes, int(nr), int(nc), int(kbits),
-                      1 if diag else 0, int(words), buf.ptr, None)
+                      1 if diag else 0, None, 0, 0, int(words), buf.ptr, None)
             cache[key] = buf
         return buf
 
@@ -2068,11 +2068,30 @@ class SlicedOcrPlan:
                       lgmap_ptr(rlg) if rlg is not None else None, lgmap_ptr(clg) if clg is not None else None,
                       self.kbytes, slot.ptr, rlen.ptr if rlen is not None else None, kk.ptr,
                       int(sp.dsets[0].cdim), int(sp.dsets[1].cdim), rmask.ptr if per_dof else None, cmask.ptr if per_dof else None, None)
-            t = (slot, kk, rlen, rmask, cmask, rlg, clg)
+            t = (slot, kk, rlen, rmask, cmask, rlg, clg, {})
             while len(self._tables) >= self.MAX_TABLE_SETS:
                 self._tables.pop(next(iter(self._tables)))
         self._tables[key] = t                       # most recently used last
         return t[:5]
+
+    def records(self, rlg, clg, lgmap_ptr, staged_keys, lbits, kbits, sbits, words):
+        """Bit-packed instance records for one pair of lgmaps (scalar matrices, node lgmaps): local-map rows of the staged maps,
+        the column positions (dropped = all ones) and the accumulator slot (dropped = all ones) in ``words`` 32-bit words per
+        instance (fd_ocr_pack_records), cached with the table set they are packed from."""
+        self.tables(rlg, clg, lgmap_ptr)
+        t = next(reversed(self._tables.values()))
+        key = (tuple(staged_keys), tuple(lbits), kbits, sbits, words)
+        buf = t[7].get(key)
+        if buf is None:
+            n = len(staged_keys)
+            buf = DeviceBuffer(max(self.ninst, 1) * words * 4)
+            lm = (ctypes.c_void_p * max(n, 1))(*[self.plans[k_].lmap for k_ in staged_keys])
+            ar = (ctypes.c_int32 * max(n, 1))(*[self.plans[k_].arity for k_ in staged_keys])
+            lb = (ctypes.c_int32 * max(n, 1))(*[int(b) for b in lbits])
+            _lib.call("fd_ocr_pack_records", int(self.ninst), n, lm, ar, lb, t[1].ptr, self.kbytes, 1, self._cmap.arity, int(kbits), 0,
+                      t[0].ptr, int(sbits), 1, int(words), buf.ptr, None)
+            t[7][key] = buf
+        return buf
 
     def __del__(self):
         try:

@@ -1033,8 +1033,16 @@ class Parloop:
                 base, lds = "ocrspr", lds + 1024
             else:
                 runs = None
-        variant = mode_variant(base, op.kbytes, nds)
-        geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz, "runs": runs,
+        rec = None
+        per_dof = bool(pa.lgmaps) and bool(self.global_kernel.arguments[k].unroll)
+        if configuration["ocr_records"] and B == 1 and not per_dof and len(src.staged_maps) <= 8 and op.kbytes == 1:
+            from .codegen import sliced_record_layout
+            maxlen = int(np.diff(rp).max()) if len(rp) > 1 else 1
+            rec = sliced_record_layout([staged[mi].arity for mi in src.staged_maps], nds, cmap.arity, maxlen, op.max_nnz)
+            if rec[1] > 8 or rec[2] > 16 or rec[3] * 4 >= sum(staged[mi].arity for mi in src.staged_maps) * 2 + cmap.arity + 2:
+                rec = None
+        variant = mode_variant(base, op.kbytes, nds, rec)
+        geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz, "runs": runs, "rec": rec,
                "cw": prep["cw"] if variant == src.mode else self.global_kernel.compile(variant), "row_order": row_order}
         prep["parts"][gkey] = geo
         if configuration["debug"]:
@@ -1120,6 +1128,10 @@ class Parloop:
                 out.append(geo["row_order"].gstart.ptr)
             elif kind == "ocr_srow":
                 out.append(self._ocr_node_words(geo, desc[1], desc[2], diag=len(desc) > 3))
+            elif kind == "ocr_rec" and src.mode.startswith("ocrs"):
+                lbits, kbits, sbits, words = geo["rec"]
+                lg = self.arguments[desc[1]].lgmaps
+                out.append(op.records(lg[0] if lg else None, lg[1] if lg else None, self._lgmap, src.staged_maps, lbits, kbits, sbits, words).ptr)
             elif kind == "ocr_rec":
                 lbits, kbits, diag, words = geo["rec"]
                 rm_, cm_ = self.arguments[desc[1]].maps

@@ -206,10 +206,12 @@ int fd_ocr_node_diag(const int32_t *list_dev, int64_t n, int32_t nrows, const in
  * lbits[m] bits) and the nr x nc row-offset entries (kidx, kbytes 1|2 per entry, kbits bits each; the nr diagonal entries
  * left out when skipdiag).  The wrapper streams ONE record per instance (fdw::load_rec / rec_field) instead of a uint16 row per
  * map plus a uint8 row of offsets: P1 tetrahedra 24 -> 12 bytes (the reference has no such tables: MatSetValuesLocal searches
- * every row on every call, builder.py:573-625).  Fails when an index does not fit its field. */
+ * every row on every call, builder.py:573-625).  Row-sliced loops (nr = 1) append one uint16 per instance -- the accumulator slot
+ * of the instance's row -- as a last field of ebits bits (extra_dev), and mark dropped rows / columns with the all-ones value of
+ * the source type: `sentinel` maps it to the all-ones value of the field.  Fails when an index does not fit its field. */
 int fd_ocr_pack_records(int64_t ninst, int nmaps, const uint16_t *const *lmaps_dev, const int32_t *arities, const int32_t *lbits,
-                        const void *kidx_dev, int kbytes, int nr, int nc, int kbits, int skipdiag, int words, uint32_t *out_dev,
-                        fd_stream_t s);
+                        const void *kidx_dev, int kbytes, int nr, int nc, int kbits, int skipdiag, const uint16_t *extra_dev, int ebits,
+                        int sentinel, int words, uint32_t *out_dev, fd_stream_t s);
 /* Bank-aware packing of the instance lists (in place; inst_off is unchanged): given the per-instance row-map rows
  * (global node ids), local-map rows and row-offset table built for the CURRENT instance order, a greedy list scheduler
  * reorders the instances inside chunks of 128 (one wavefront per chunk, all chunks of all blocks in parallel) so that the 16

@@ -161,7 +161,7 @@ def run_staged(pl, epb=48, order=None):
     return [outs.get(k) for k in range(len(pl.arguments))]
 
 
-def pack_records_ref(lmaps, lbits, kidx, nr, nc, kbits, diag, words):
+def pack_records_ref(lmaps, lbits, kidx, nr, nc, kbits, diag, words, extra=None, ebits=0, sentinel=False):
     """numpy restatement of fd_ocr_pack_records: per instance the local-map rows of the staged maps (lbits[m] bits per entry)
     and the nr x nc row offsets (kbits bits, diagonal left out when ``diag``), back to back from bit 0 of ``words`` 32-bit words."""
     kidx = np.asarray(kidx).reshape(-1, nr * nc)
@@ -178,9 +178,20 @@ def pack_records_ref(lmaps, lbits, kidx, nr, nc, kbits, diag, words):
             for j in range(nc):
                 if diag and i == j:
                     continue
-                assert int(kidx[t, i * nc + j]) < (1 << kbits)
-                acc |= int(kidx[t, i * nc + j]) << off
+                v = int(kidx[t, i * nc + j])
+                if sentinel:                 # "dropped" (all ones of the source type) -> all ones of the field
+                    v = (1 << kbits) - 1 if v == (1 << (8 * kidx.dtype.itemsize)) - 1 else v
+                    assert v == (1 << kbits) - 1 or v < (1 << kbits) - 1
+                assert v < (1 << kbits)
+                acc |= v << off
                 off += kbits
+        if extra is not None:
+            v = int(extra[t])
+            if sentinel:
+                v = (1 << ebits) - 1 if v == 0xffff else v
+            assert v < (1 << ebits)
+            acc |= v << off
+            off += ebits
         for w in range(words):
             out[t, w] = (acc >> (32 * w)) & 0xffffffff
     return out
@@ -370,7 +381,7 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False,
     return csr
 
 
-def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None, run_flush=False):
+def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None, run_flush=False, records=False):
     """Execute a matrix-assembly Parloop ``pl`` with the ROW-SLICED owner-computes-rows wrapper on the host (one OS thread
     per lane).  Plan tables from helpers.ocrs_plan_ref, CSR pattern from the oracle.  Returns the OracleCSR."""
     import re
@@ -426,8 +437,13 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None, run_flush=Fals
     run_tabs = None
     if order is not None and run_flush:
         run_tabs = row_runs_ref(acc, ncsr.rowptr[plist], rb)
+    rec = None
+    if records:
+        from firedrake_amd.codegen import sliced_record_layout
+        rec = sliced_record_layout([maps[mi].arity for mi in base.staged_maps], [plans[mi][3] for mi in base.staged_maps], cmap.arity,
+                                   int(np.diff(ncsr.rowptr).max()), max_nnz)
     src = generate_wrapper(gk, mode_variant(("ocrspr" if run_tabs else "ocrsp") if order is not None else "ocrs", 1,
-                                            [plans[mi][3] for mi in base.staged_maps]))
+                                            [plans[mi][3] for mi in base.staged_maps], rec))
     text = src.source.replace("extern __shared__ __align__(16) unsigned char fd_lds[];", "unsigned char *fd_lds = fd_sim::lds;")
     sig = re.search(r'extern "C" __global__[^\n]*void %s\((.*)\)\n' % src.symbol, text).group(1)
     names = [p.split()[-1].lstrip("*") for p in sig.split(", ")]
@@ -464,6 +480,10 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None, run_flush=Fals
             cargs.append(ptr(inst_off))
         elif kind == "ocr_inst_ent":
             cargs.append(ptr(inst_ent))
+        elif kind == "ocr_rec":
+            lbits, kbits, sbits, words_ = rec
+            cargs.append(ptr(pack_records_ref([plans[mi][2] for mi in base.staged_maps], lbits, np.asarray(kk), 1, cmap.arity, kbits, False,
+                                              words_, extra=np.asarray(slot), ebits=sbits, sentinel=True)))
         elif kind == "ocrs_chunk_role":
             cargs.append(ptr(chunk_role))
         elif kind == "plan_blkoff":

@@ -38,14 +38,27 @@ def test_pack_records_matches_numpy_restatement(diag):
     lm = (ctypes.c_void_p * 2)(d0.ptr, d1.ptr)
     ar = (ctypes.c_int32 * 2)(4, 3)
     lb = (ctypes.c_int32 * 2)(*lbits)
-    _lib.call("fd_ocr_pack_records", ninst, 2, lm, ar, lb, dk.ptr, 1, nr, nc, kbits, int(diag), words, out.ptr, None)
+    _lib.call("fd_ocr_pack_records", ninst, 2, lm, ar, lb, dk.ptr, 1, nr, nc, kbits, int(diag), None, 0, 0, words, out.ptr, None)
     got = _down(out.ptr, np.uint32, (ninst, words))
     ref = pack_records_ref([lm0, lm1], lbits, kidx, nr, nc, kbits, diag, words)
     assert np.array_equal(got, ref)
     # an index that does not fit its field is an error, not a truncation
     with pytest.raises(_lib.FDHipError):
-        _lib.call("fd_ocr_pack_records", ninst, 2, lm, ar, (ctypes.c_int32 * 2)(8, 6), dk.ptr, 1, nr, nc, kbits, int(diag),
+        _lib.call("fd_ocr_pack_records", ninst, 2, lm, ar, (ctypes.c_int32 * 2)(8, 6), dk.ptr, 1, nr, nc, kbits, int(diag), None, 0, 0,
                   -(-(4 * 8 + 3 * 6 + (nr * nc - (nr if diag else 0)) * kbits) // 32), out.ptr, None)
+    if not diag:
+        # row-sliced form: one row of nc positions + the slot as a last field; 0xff / 0xffff (dropped) become all ones of the field
+        kk = rng.integers(0, 27, (ninst, 10)).astype(np.uint8)
+        kk[rng.random((ninst, 10)) < 0.1] = 0xff
+        slot = rng.integers(0, 4000, ninst).astype(np.uint16)
+        slot[rng.random(ninst) < 0.05] = 0xffff
+        dkk, dsl = DeviceBuffer.from_numpy(kk), DeviceBuffer.from_numpy(slot)
+        w2 = -(-(4 * 9 + 10 * 5 + 12) // 32)
+        out2 = DeviceBuffer(ninst * w2 * 4)
+        _lib.call("fd_ocr_pack_records", ninst, 1, (ctypes.c_void_p * 1)(d0.ptr), (ctypes.c_int32 * 1)(4), (ctypes.c_int32 * 1)(9), dkk.ptr, 1, 1, 10,
+                  5, 0, dsl.ptr, 12, 1, w2, out2.ptr, None)
+        ref2 = pack_records_ref([lm0], [9], kk, 1, 10, 5, False, w2, extra=slot, ebits=12, sentinel=True)
+        assert np.array_equal(_down(out2.ptr, np.uint32, (ninst, w2)), ref2)
 
 
 def test_row_runs_match_numpy_restatement():
@@ -97,6 +110,32 @@ def test_p1_jacobian_with_compact_tables_matches_oracle(numbering, records, diag
         assert geo["cw"].src.mode.startswith("ocr_") or geo["cw"].src.mode == "ocr"
     elif runs and numbering == "lexicographic":
         assert geo["cw"].src.mode.startswith("ocrpr")
+    mpa = pl.arguments[0]
+    args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
+    ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
+    _, _, v = mat.csr()
+    assert np.abs(v - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
+
+
+@pytest.mark.parametrize("numbering", ["tiled", "lexicographic"])
+@pytest.mark.parametrize("records,runs", [(0, 0), (1, 0), (1, 1)])
+def test_p2_jacobian_with_compact_tables_matches_oracle(numbering, records, runs, monkeypatch):
+    """The row-sliced wrapper (CG2) with one record per instance and the run-coded flush of a derived row order, boundary rows and
+    columns dropped (all-ones fields), against the oracle."""
+    monkeypatch.setitem(configuration, "ocr_records", records)
+    monkeypatch.setitem(configuration, "ocrs_run_flush", runs)
+    monkeypatch.setitem(configuration, "locality_min_entities", 64)
+    m = fmesh.UnitCubeMesh(8, degrees=(2,), perturb=0.1, numbering=numbering)
+    prob = forms.PoissonProblem(m, 2, bcs=True)
+    mat, pl = prob.jacobian()
+    for _ in range(2):
+        mat.zero()
+        pl.compute()
+    geo = [g for key, g in pl._prepared["parts"].items() if key[0] == "ocr"][0]
+    mode = geo["cw"].src.mode
+    assert mode.startswith("ocrs") and bool(geo["rec"]) == bool(records) and ("_q" in mode) == bool(records)
+    if numbering == "lexicographic":
+        assert mode.startswith("ocrspr") == bool(runs)
     mpa = pl.arguments[0]
     args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
     ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]

@@ -619,6 +619,9 @@ def test_row_sliced_owner_computes_rows_on_host(bcs, numbering):
         if cap == 96:
             got2 = run_ocrs(pl, nnz_per_block=cap, zero_pending=False, order=order)
             assert np.abs(got2.values - (ref.values + 1.0)).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
+            # one bit-packed record per instance (local map, column positions, slot; dropped = all ones) instead of three arrays
+            got5 = run_ocrs(pl, nnz_per_block=cap, order=order, records=True, run_flush=order is not None)
+            assert np.abs(got5.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
             if order is not None:
                 # the same blocks flushed through the per-entry place table (FDHIP_OCRS_ENTRY_FLUSH) instead of row by row
                 from firedrake_amd.configuration import configuration
