@@ -698,8 +698,8 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                                           f"else {{ double o{k}[{FU}]; for (int f = 0; f < {FU}; ++f) o{k}[f] = g{k}[f] >= 0 ? arg{k}[(size_t)g{k}[f]] : 0.0; "
                                           f"for (int f = 0; f < {FU}; ++f) if (g{k}[f] >= 0) arg{k}[(size_t)g{k}[f]] = o{k}[f] + sm{k}[q0 + f*nthr]; }} }}"))
                     elif FU == 1:
-                        flush.append((rm, f"if (oc{k}_flags & 1) {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)oc{k}_gpos[(size_t)r0_{k} + q]] = sm{k}[q]; }} "
-                                          f"else {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)oc{k}_gpos[(size_t)r0_{k} + q]] += sm{k}[q]; }}"))
+                        flush.append((rm, f"if (oc{k}_flags & 1) {{ for (int q = tid; q < nnzb{k}; q += nthr) {{ const int g = oc{k}_gpos[(size_t)r0_{k} + q]; if (g >= 0) arg{k}[(size_t)g] = sm{k}[q]; }} }} "
+                                          f"else {{ for (int q = tid; q < nnzb{k}; q += nthr) {{ const int g = oc{k}_gpos[(size_t)r0_{k} + q]; if (g >= 0) arg{k}[(size_t)g] += sm{k}[q]; }} }}"))
                     else:
                         # the place of an entry is a global load its store depends on: a trip of the loop costs a memory round trip.
                         # FU places are requested together, then the FU stores go out

@@ -27,13 +27,37 @@ stats = {"hipcc_runs": 0, "cache_hits": 0}      # wrappers compiled / found in t
 
 
 def compiler_version():
+    """First line of ``hipcc --version`` (part of every cache key).  The answer is remembered next to the code objects under the
+    identity of the compiler binary (path, size, mtime), so that a process whose wrappers are all cached starts no subprocess at
+    all (30 ms of every first assemble); a different binary asks again."""
     global _version
     if _version is None:
+        hipcc = configuration["hipcc"]
+        ident, memo = None, os.path.join(configuration["cache_dir"], ".compiler_version.json")
         try:
-            out = subprocess.run([configuration["hipcc"], "--version"], capture_output=True, text=True).stdout
+            st = os.stat(os.path.realpath(hipcc))
+            ident = f"{os.path.realpath(hipcc)}:{st.st_size}:{int(st.st_mtime)}"
+            with open(memo) as fh:
+                known = json.load(fh)
+            if known.get("ident") == ident:
+                _version = known["version"]
+                return _version
+        except (OSError, ValueError, KeyError):
+            pass
+        try:
+            out = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
             _version = out.splitlines()[0] if out else "unknown"
         except OSError:
             _version = "missing"
+        if ident and _version not in ("unknown", "missing"):
+            try:
+                os.makedirs(configuration["cache_dir"], exist_ok=True)
+                fd, tmp = tempfile.mkstemp(dir=configuration["cache_dir"])
+                with os.fdopen(fd, "w") as fh:
+                    json.dump({"ident": ident, "version": _version}, fh)
+                os.replace(tmp, memo)
+            except OSError:
+                pass
     return _version
 
 

@@ -2106,7 +2106,7 @@ class RowOrder:
     ``prowptr`` = CSR row starts in that order (device + host copy).  Built from an entity order by the first-touch rule
     (fd_first_touch_order)."""
 
-    def __init__(self, rmap: Map, order: "DeviceBuffer", n, npos, node_rowptr_host, rowptr_dev=None):
+    def __init__(self, rmap: Map, order: "DeviceBuffer", n, npos, node_rowptr_host, rowptr_dev=None, pad=False):
         """First-touch row order under the entity order ``order`` (fd_first_touch_order).  ``rowptr_dev``: device pointer of the
         same row starts when the caller holds one (saves an upload)."""
         self.npos = int(npos)
@@ -2115,20 +2115,20 @@ class RowOrder:
         _lib.call("fd_first_touch_order", rmap._base()._dev_values(), rmap.arity, order.ptr, int(n), self.npos, self.pinv.ptr,
                   self.plist.ptr, rank.ptr, None)
         self.rank_host = rank.download(np.int32, (self.npos,))       # position (in ``order``) of the entity first touching row p
-        self._tables(node_rowptr_host, rowptr_dev)
+        self._tables(node_rowptr_host, rowptr_dev, pad)
 
     @classmethod
-    def from_plist(cls, plist: "DeviceBuffer", npos, node_rowptr_host, rowptr_dev=None):
+    def from_plist(cls, plist: "DeviceBuffer", npos, node_rowptr_host, rowptr_dev=None, pad=False):
         """A row order given as a device permutation of [0, npos) (a k-d partition of the rows' own positions)."""
         self = cls.__new__(cls)
         self.npos = int(npos)
         self.plist, self.pinv = plist, DeviceBuffer(max(npos, 1) * 4)
         _lib.call("fd_invert_permutation", plist.ptr, self.npos, self.pinv.ptr, None)
         self.rank_host = None
-        self._tables(node_rowptr_host, rowptr_dev)
+        self._tables(node_rowptr_host, rowptr_dev, pad)
         return self
 
-    def _tables(self, node_rowptr_host, rowptr_dev=None):
+    def _tables(self, node_rowptr_host, rowptr_dev=None, pad=False):
         """prowptr (accumulator starts by position, also kept on the host: the block cuts are made there) and the two lookups the
         wrapper needs, flattened so that neither is a dependent chain of loads: nstart[node] = prowptr[pinv[node]] (accumulator
         offset of a row, by NODE), gstart[p] = rowptr[plist[p]] (CSR start, by POSITION) -- fd_row_order_tables, on the device (the
@@ -2139,7 +2139,12 @@ class RowOrder:
         if rowptr_dev is None:
             keep = DeviceBuffer.from_numpy(np.ascontiguousarray(node_rowptr_host, dtype=np.int32))
             rowptr_dev = keep.ptr
-        _lib.call("fd_row_order_tables", self.npos, self.plist.ptr, rowptr_dev, self.prowptr.ptr, self.nstart.ptr, self.gstart.ptr, None)
+        # ``pad``: accumulator starts with one entry of padding after every run of consecutive rows (fd_row_order_tables); plen = the
+        # true row lengths such an order needs wherever prowptr differences used to serve
+        self.padded = bool(pad)
+        self.plen = DeviceBuffer(n1 * 4) if pad else None
+        _lib.call("fd_row_order_tables", self.npos, self.plist.ptr, rowptr_dev, 1 if pad else 0, self.prowptr.ptr, self.nstart.ptr,
+                  self.gstart.ptr, self.plen.ptr if pad else None, None)
         self.prowptr_host = self.prowptr.download(np.int32, (self.npos + 1,))
 
     def gpos(self):
@@ -2147,12 +2152,15 @@ class RowOrder:
         array -- what the whole-entity "ocrp" flush streams (built on first use)."""
         if getattr(self, "_gpos", None) is None:
             self._gpos = DeviceBuffer(max(int(self.prowptr_host[-1]), 1) * 4)
-            _lib.call("fd_row_entry_positions", self.npos, self.prowptr.ptr, self.gstart.ptr, self._gpos.ptr, None)
+            _lib.call("fd_row_entry_positions", self.npos, self.prowptr.ptr, self.gstart.ptr, self.plen.ptr if self.padded else None,
+                      self._gpos.ptr, None)
         return self._gpos
 
     def runs(self, row_blocks):
         """Run-coded places of the accumulator entries for the row blocks ``row_blocks`` (host array of nblocks + 1 positions;
         fd_ocr_row_runs): (grun, brun, rdelta device buffers, most runs in one block), built once per set of blocks."""
+        if self.padded:
+            raise ValueError("the run-coded flush writes every accumulator entry: not for a padded row order")
         rb = np.ascontiguousarray(row_blocks, dtype=np.int32)
         key = rb.tobytes()
         hit = getattr(self, "_runs", None)

@@ -885,13 +885,13 @@ class Parloop:
                 cap = configuration["ocr_nnz_per_block_ordered"]
                 rows_per_block = max(cap // max(int(np.ceil(rp[nrows] / max(nrows, 1))), 1), 1)
                 plist, rb = kd_order(pos_.data._dev_ptr(False), pos_.data.cdim, nrows, 0, rows_per_block)
-                row_order = RowOrder.from_plist(plist, nrows, rp, rowptr_dev=sp._node_rowptr.ptr)
+                row_order = RowOrder.from_plist(plist, nrows, rp, rowptr_dev=sp._node_rowptr.ptr, pad=bool(configuration["ocr_pad_runs"]))
             elif usable:
                 # rows of another space: first touch under the k-d order of the entities, cut where the entity leaf changes
                 # (leaves hold equal numbers of entities, not of rows: 10 % slack before a block is halved)
                 order = self._locality_order(start, end, virtual=v is not None)
                 if order is not None:
-                    row_order = RowOrder(rmap, order, end - start, nrows, rp, rowptr_dev=sp._node_rowptr.ptr)
+                    row_order = RowOrder(rmap, order, end - start, nrows, rp, rowptr_dev=sp._node_rowptr.ptr, pad=bool(configuration["ocr_pad_runs"]))
                     cap = configuration["ocr_nnz_per_block_ordered"]
                     rb = row_order.tile_cuts(order.blocks, cap + cap // 10)
             if row_order is not None:
@@ -943,7 +943,7 @@ class Parloop:
         nds = [op.plans[mi].max_nd for mi in src.staged_maps]
         base = "ocrp" if row_order is not None else "ocr"
         runs = None
-        if row_order is not None and configuration["ocr_run_flush"]:
+        if row_order is not None and configuration["ocr_run_flush"] and not row_order.padded:
             # run-coded flush when no block has more than 256 runs of CSR-consecutive rows (a random numbering has one per row)
             runs = row_order.runs(op.row_blocks)
             if runs[3] <= 256:

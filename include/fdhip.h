@@ -365,12 +365,16 @@ int fd_first_touch_order(const int32_t *map_dev, int arity, const int32_t *order
 int fd_invert_permutation(const int32_t *plist_dev, int32_t n, int32_t *pinv_dev, fd_stream_t s);
 /* The tables of a row order plist (row of every position): prowptr[p] = accumulator start of position p (npos + 1 entries: the
  * running sum of the row lengths in position order), gstart[p] = CSR start of that row, nstart[row] = prowptr[position of row]
- * -- the lookups the "ocrp" / "ocrsp" wrappers and the plan builders need, each a flat array */
-int fd_row_order_tables(int32_t npos, const int32_t *plist_dev, const int32_t *rowptr_dev, int32_t *prowptr_dev, int32_t *nstart_dev,
-                        int32_t *gstart_dev, fd_stream_t s);
+ * -- the lookups the "ocrp" / "ocrsp" wrappers and the plan builders need, each a flat array.  pad = 1 (whole-entity "ocrp" loops,
+ * whose flush goes through a per-entry place table anyway): one accumulator entry of padding after every run of rows that are
+ * consecutive in the caller's numbering, so that the accumulator offsets of same-kind entities along and across the lines of a
+ * box of rows fall into distinct fp64 atomic banks; plen[p] (required then, optional otherwise) = true length of row p */
+int fd_row_order_tables(int32_t npos, const int32_t *plist_dev, const int32_t *rowptr_dev, int pad, int32_t *prowptr_dev, int32_t *nstart_dev,
+                        int32_t *gstart_dev, int32_t *plen_dev, fd_stream_t s);
 /* gpos[prowptr[p] + k] = gstart[p] + k for the rows p of a row order (prowptr = accumulator starts by position, gstart = CSR
  * starts by position): the place of every accumulator entry in the CSR value array, streamed by the "ocrp" row flush */
-int fd_row_entry_positions(int32_t npos, const int32_t *prowptr_dev, const int32_t *gstart_dev, int32_t *gpos_dev, fd_stream_t s);
+int fd_row_entry_positions(int32_t npos, const int32_t *prowptr_dev, const int32_t *gstart_dev, const int32_t *plen_dev, int32_t *gpos_dev,
+                           fd_stream_t s);     /* plen_dev (NULL = prowptr differences): true row lengths; padding entries get -1 */
 /* The same places run-coded: rows that follow one another in a block of the row order (rblk: nblocks + 1 block starts in row
  * positions) AND in the CSR share one displacement (place - accumulator index).  grun[entry] = run of the entry's row counted
  * from its block's first run (one byte), brun[b] = first run of block b (nblocks + 1), rdelta[run] = displacement (room for

@@ -141,3 +141,27 @@ def test_p2_jacobian_with_compact_tables_matches_oracle(numbering, records, runs
     ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
     _, _, v = mat.csr()
     assert np.abs(v - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
+
+
+@pytest.mark.parametrize("numbering", ["lexicographic", "random"])
+@pytest.mark.parametrize("pad", [0, 1])
+def test_p1_jacobian_padded_accumulators(numbering, pad, monkeypatch):
+    """Derived row orders: LDS accumulators padded by one entry per run of consecutive rows (fd_row_order_tables pad = 1; the
+    place table of the flush has holes) -- same matrix, fresh and accumulated on top of existing values."""
+    monkeypatch.setitem(configuration, "ocr_pad_runs", pad)
+    monkeypatch.setitem(configuration, "locality_min_entities", 64)
+    m = fmesh.UnitCubeMesh(12, degrees=(1,), perturb=0.1, numbering=numbering)
+    prob = forms.PoissonProblem(m, 1, bcs=True)
+    mat, pl = prob.jacobian()
+    mat.zero()
+    pl.compute()
+    geo = [g for key, g in pl._prepared["parts"].items() if key[0] == "ocr"][0]
+    assert geo["row_order"].padded == bool(pad)
+    mpa = pl.arguments[0]
+    args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
+    ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
+    _, _, v = mat.csr()
+    assert np.abs(v - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
+    pl.compute()                                             # no pending zero: accumulates
+    _, _, v2 = mat.csr()
+    assert np.abs(v2 - 2.0 * ref.values).max() <= 1e-12 * np.abs(ref.values).max()
