@@ -30,8 +30,10 @@ configuration = {
     "ocr_records": _env("FDHIP_OCR_RECORDS", 1, int),
     "ocr_records_diag": _env("FDHIP_OCR_RECORDS_DIAG", 1, int),
     "ocr_run_flush": _env("FDHIP_OCR_RUN_FLUSH", 0, int),      # measured 2 % slower than the 4-byte places (profiles/r4a): off
-    # whole-entity loops over a derived row order: pad the LDS accumulators by one entry per run of consecutive rows (bank spreading)
-    "ocr_pad_runs": _env("FDHIP_OCR_PAD_RUNS", 1, int),
+    # whole-entity loops over a derived row order: pad the LDS accumulators by one entry per run of consecutive rows (bank spreading
+    # for same-kind entities along and across the lines of a box).  Measured within noise of the unpadded layout (0.921 vs 0.930 ms,
+    # profiles/r4j_ab_pad_runs.txt): the instance order the packer leaves does not form the regular windows the padding serves -- off
+    "ocr_pad_runs": _env("FDHIP_OCR_PAD_RUNS", 0, int),
     "ocr_lds_limit": _env("FDHIP_OCR_LDS_LIMIT", 0, int),  # 0 = auto (whole CU for large element matrices)
     "lane_strided": _env("FDHIP_LANE_STRIDED", 1, int),   # plans in lane order (fd_plan_set_lane_order)
     # staged rows addressed with a COMPILE-TIME node stride (max nodes per block rounded up to a multiple of this value;
