@@ -186,6 +186,29 @@ def measure_c3(n, steps, warmup, coefficients=False):
                                 "frac_valu": act_flops / (FP64_VECTOR_PEAK_TFLOPS * 1e12) * 1e3 / act_k_ms}}
 
 
+def measure_c3_action(n, steps, warmup):
+    """The Q4 operator action on its own at a size whose matrix would not fit the 32-bit CSR index range (n = 64: 262 144 cells,
+    16.97 M DoFs, 3.7e9 nonzeros if assembled): the Krylov inner loop of config 3's matrix-free use."""
+    from firedrake_amd import _lib, forms, mesh as fmesh
+    from firedrake_amd.device import Event
+    m = fmesh.make_extruded_hex_mesh(n, n, 4, perturb=0.1)
+    prob = forms.HelmholtzQ4Problem(m, bcs=False, matrix=False)
+    for _ in range(max(warmup, 1)):
+        prob.assemble_action()
+    _lib.call("fd_device_sync")
+    ev = [(Event(), Event()) for _ in range(steps)]
+    for k in range(steps):
+        prob.assemble_action(events=ev[k])
+    _lib.call("fd_device_sync")
+    k_ms = float(np.median([a.elapsed_ms(b) for a, b in ev]))
+    ncell, ndofs, ncol = m.ncells, m.node_set.size, m.base_set.size
+    act_bytes = ncol * 125 * 4 + ncol * 8 * 4 + m.coord_node_set.size * 24 + ndofs * 8 + ndofs * 8
+    act_flops = ncell * (25 * 450 * 2 + 125 * 200)
+    return {"n": n, "cells": ncell, "dofs": ndofs, "kernel_ms": k_ms, "dofs_per_s": ndofs / (k_ms * 1e-3),
+            "frac_hbm": act_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "valu_flops": act_flops,
+            "frac_valu": act_flops / (FP64_VECTOR_PEAK_TFLOPS * 1e12) * 1e3 / k_ms}
+
+
 def run_c3(args):
     from firedrake_amd import _lib
     _lib.require_gpu()
@@ -854,6 +877,10 @@ def main():
                 out["secondary_c3"]["variable_coefficients"] = with_coefficients()
             except Exception as exc:
                 out["secondary_c3"]["variable_coefficients"] = {"error": repr(exc)}
+            try:
+                out["secondary_c3"]["action_n64"] = measure_c3_action(64, 10, 2)
+            except Exception as exc:
+                out["secondary_c3"]["action_n64"] = {"error": repr(exc)}
         guarded("secondary_c4", lambda: measure_c4(2048, max(3, args.steps // 2), 2))
         guarded("secondary_c5_share", lambda: poisson_line(args, ctx, 2, (107, 107, 107), "weak",
                                                              "one of the 8 partitions of BASELINE.json configs[4]", "lexicographic", "", False))

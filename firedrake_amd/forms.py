@@ -695,15 +695,18 @@ class HelmholtzHexProblem:
     are TensorProductLocalKernels: ``GlobalKernel.compile`` picks the fp64-MFMA matrix wrapper and the sum-factorised
     action wrapper of csrc/fd_tensor.h.  Plays ExplicitMatrixAssembler / OneFormAssembler like PoissonProblem."""
 
-    def __init__(self, hexmesh, bcs=False, nq=None, alpha=1.0, beta=1.0, velocity=(0.0, 0.0, 0.0)):
+    def __init__(self, hexmesh, bcs=False, nq=None, alpha=1.0, beta=1.0, velocity=(0.0, 0.0, 0.0), matrix=True):
+        """``matrix=False``: the matrix-free side only (no Sparsity, no Mat: the action of a mesh whose matrix would not fit the 32-bit
+        CSR index range -- Q4 at n = 64 holds 3.7e9 nonzeros)."""
         self.mesh = m = hexmesh
         nd, nqp = (m.degree + 1) ** 3, (nq or m.degree + 1) ** 3
         pad = -(-nd // 16) * 16
         self.FLOPS_PER_CELL = 2.0 * pad * pad * 4 * nqp       # MFMA work issued (element matrix padded to 16 x 16 tiles)
         self.ALGO_FLOPS_PER_CELL = 2.0 * nd * nd * 4 * nqp    # SURVEY.md 8(d): 15.6 MFLOP per Q4 cell
         cm, xm = m.cell_node_map, m.coord_map
-        self.sparsity = op2.Sparsity((m.node_set ** 1, m.node_set ** 1), [(cm, cm, None)])
-        self.mat = op2.Mat(self.sparsity)
+        if matrix:
+            self.sparsity = op2.Sparsity((m.node_set ** 1, m.node_set ** 1), [(cm, cm, None)])
+            self.mat = op2.Mat(self.sparsity)
         pts = m.node_points
         bnd = np.nonzero(((pts < 1e-12) | (pts > 1 - 1e-12)).any(axis=1))[0].astype(np.int32)
         self.bc_nodes = bnd if bcs else np.zeros(0, dtype=np.int32)
@@ -714,7 +717,8 @@ class HelmholtzHexProblem:
             lg = (rlg, rlg.copy())
         self.kjac = helmholtz_hex_jacobian_kernel(m.degree, nq, None, alpha, beta, velocity)
         self.kact = helmholtz_hex_action_kernel(m.degree, nq, None, alpha, beta, velocity)
-        self.jac_loop = op2.LegacyParloop(self.kjac, m.cell_set, self.mat(op2.INC, (cm, cm), lgmaps=lg), m.coordinates(op2.READ, xm))
+        if matrix:
+            self.jac_loop = op2.LegacyParloop(self.kjac, m.cell_set, self.mat(op2.INC, (cm, cm), lgmaps=lg), m.coordinates(op2.READ, xm))
         self.u = op2.Dat(m.node_set, np.sin(3 * pts[:, 0]) * np.cos(2 * pts[:, 1]) + 0.3 * pts[:, 2], np.float64, "u")
         self.y = op2.Dat(m.node_set, None, np.float64, "y")
         self.act_loop = op2.LegacyParloop(self.kact, m.cell_set, self.y(op2.INC, cm), m.coordinates(op2.READ, xm), self.u(op2.READ, cm))
@@ -877,9 +881,9 @@ class CoefficientHexProblem(HelmholtzHexProblem):
 class HelmholtzQ4Problem(HelmholtzHexProblem):
     """BASELINE.json configs[2]: Q4, 5 x 5 x 5 Gauss points."""
 
-    def __init__(self, hexmesh, bcs=False):
+    def __init__(self, hexmesh, bcs=False, matrix=True):
         assert hexmesh.degree == 4
-        super().__init__(hexmesh, bcs, 5)
+        super().__init__(hexmesh, bcs, 5, matrix=matrix)
 
 
 # ------------------------------------------------------------------------------------------
