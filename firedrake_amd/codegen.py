@@ -1123,8 +1123,11 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             soa = c > 1            # component-major LDS layout for vector Dats (conflict-free lane strides)
             lds_items.append(("dat", mi, c, info["dtype"].itemsize, False))
             lds_decl.append(f"{ct} *s{k} = ({ct} *)(fd_lds + fd_off); fd_off += (((size_t)p{mi}_maxnd*{c}*sizeof({ct})) + 15) & ~(size_t)15;")
+            # (a READ Dat unchanged since an earlier call is also kept in PLAN order and streamed, as in the whole-entity wrappers)
+            P(f"const {ct} *__restrict__ pl{k}", ("plan_copy", k, mi))
             stage_nodes.setdefault(mi, []).append(
-                ([f"{ct} v{k}[{c}];", f"for (int j = 0; j < {c}; ++j) v{k}[j] = arg{k}[(size_t)g*{c} + j];"],
+                ([f"{ct} v{k}[{c}];", f"if (pl{k}) {{ for (int j = 0; j < {c}; ++j) v{k}[j] = pl{k}[(size_t)(l0_{mi} + i)*{c} + j]; }} "
+                                      f"else {{ for (int j = 0; j < {c}; ++j) v{k}[j] = arg{k}[(size_t)g*{c} + j]; }}"],
                  [f"for (int j = 0; j < {c}; ++j) s{k}[{'j*(int)p%d_maxnd + i' % mi if soa else 'i*%d + j' % c}] = v{k}[j];"]))
             idx = f"j*(int)p{mi}_maxnd + lm{mi}[{_permi(perm, 'i')}]" if soa else f"lm{mi}[{_permi(perm, 'i')}]*{c} + j"
             pack.append(f"{ct} t{k}[{ar * c}];")
@@ -1207,10 +1210,13 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         out = [f"{prefix}{n} = {ex.replace('II', ii)};" for n, ex in scal]
         out += [ld.replace("II", ii).replace("DST", prefix + n) for n, _, ld in rows]
         return out
+    # prefetch distance: the index rows of the lane's next instance (1) or of the next two (2: a lane makes ~5 trips per block and a
+    # trip is ~300 instructions -- less than one HBM round trip under load)
+    pf2 = bool(pf and int(configuration["ocrs_prefetch"]) >= 2 and not dofmask)
     for n, ln, _ in rows:
         ty = "unsigned" if rec else "int"
-        src.append(f"  {ty} {n}[{ln}];" + (f" {ty} nx_{n}[{ln}];" if pf else ""))
-    src.append("  int " + ", ".join(f"{n} = 0" + (f", nx_{n} = 0" if pf else "") for n, _ in scal) + ";")
+        src.append(f"  {ty} {n}[{ln}];" + (f" {ty} nx_{n}[{ln}];" if pf else "") + (f" {ty} n2_{n}[{ln}];" if pf2 else ""))
+    src.append("  int " + ", ".join(f"{n} = 0" + (f", nx_{n} = 0" if pf else "") + (f", n2_{n} = 0" if pf2 else "") for n, _ in scal) + ";")
     if dofmask:
         src.append("  unsigned long long cmask = 0" + (", nx_cmask = 0;" if pf else ";"))
     if pf:
@@ -1218,9 +1224,15 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         src += ["    " + l for l in loads("(e0 + tid)", "")]
         if dofmask:
             src.append(f"    cmask = oc{K}_cmask[(e0 + tid) - start];")
+        if pf2:
+            src.append("    const int it1 = (e0 + tid + nthr < e1) ? e0 + tid + nthr : e0 + tid;")
+            src += ["    " + l for l in loads("it1", "nx_")]
         src.append("  }")
     src.append("  for (int it = e0 + tid; it < e1; it += nthr) {")
-    if pf:
+    if pf2:
+        src.append("    const int itn = (it + 2*nthr < e1) ? it + 2*nthr : it;")
+        src += ["    " + l for l in loads("itn", "n2_")]
+    elif pf:
         src.append("    const int itn = (it + nthr < e1) ? it + nthr : it;")
         src += ["    " + l for l in loads("itn", "nx_")]
         if dofmask:
@@ -1260,7 +1272,11 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     if pf:
         for n, ln, _ in rows:
             src.append(f"    for (int q = 0; q < {ln}; ++q) {n}[q] = nx_{n}[q];")
+            if pf2:
+                src.append(f"    for (int q = 0; q < {ln}; ++q) nx_{n}[q] = n2_{n}[q];")
         src.append("    " + " ".join(f"{n} = nx_{n};" for n, _ in scal) + (" cmask = nx_cmask;" if dofmask else ""))
+        if pf2:
+            src.append("    " + " ".join(f"nx_{n} = n2_{n};" for n, _ in scal))
     src += ["  }", "  __syncthreads();"]
     if runflush:
         FU = max(1, int(configuration["flush_batch"]))

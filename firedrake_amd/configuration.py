@@ -51,6 +51,7 @@ configuration = {
     "ocr_sliced_min_arity": _env("FDHIP_OCR_SLICED_MIN_ARITY", 8, int),
     "ocr_sliced_max_arity": _env("FDHIP_OCR_SLICED_MAX_ARITY", 32, int),
     "ocr_sliced_max_entries": _env("FDHIP_OCR_SLICED_MAX_ENTRIES", 1024, int),
+    "ocrs_prefetch": _env("FDHIP_OCRS_PREFETCH", 1, int),         # row-sliced loops: index rows requested 1 or 2 trips ahead
     "ocrs_run_flush": _env("FDHIP_OCRS_RUN_FLUSH", 1, int),       # derived row orders, scalar matrices: run-coded places (1 B per entry)
     "ocrs_entry_flush": _env("FDHIP_OCRS_ENTRY_FLUSH", 0, int),   # derived row orders: per-entry place table instead of the row-by-row flush
     "ocrs_nnz_per_block": _env("FDHIP_OCRS_NNZ", 4096, int),     # accumulator entries per row block (x8 bytes of LDS)

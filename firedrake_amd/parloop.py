@@ -1047,6 +1047,7 @@ class Parloop:
         prep["parts"][gkey] = geo
         if configuration["debug"]:
             import sys
+            print(f"[fdhip] {self.global_kernel.name} OCR row-sliced variant {variant}", file=sys.stderr)
             print(f"[fdhip] {self.global_kernel.name} OCR row-sliced [{start},{end}): row blocks={op.nblocks} instances={op.nreal} "
                   f"(+{op.ninst - op.nreal} padding, x{op.nreal / max((end - start) * rmap.arity, 1):.2f} of the map entries) "
                   f"max_inst={op.max_inst} max_nnz={op.max_nnz} max_nown={op.max_nown} lds={lds} kbytes={op.kbytes}", file=sys.stderr)

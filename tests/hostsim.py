@@ -509,6 +509,8 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None, run_flush=Fals
             cargs.append(ptr(np.ascontiguousarray(ncsr.rowptr[plist], dtype=np.int32)))
         elif kind in ("ocr_grun", "ocr_brun", "ocr_rdelta"):
             cargs.append(ptr(run_tabs[{"ocr_grun": 0, "ocr_brun": 1, "ocr_rdelta": 2}[kind]]))
+        elif kind == "plan_copy":
+            cargs.append(_plan_copy_arg(pl, desc, plans, ptr))
         elif kind == "ocr_gpos":
             # (scalar matrices only: place of every accumulator entry, rows in position order)
             cargs.append(ptr(np.concatenate([np.arange(ncsr.rowptr[r], ncsr.rowptr[r + 1]) for r in plist] + [np.zeros(0, np.int64)]).astype(np.int32)))

@@ -596,7 +596,7 @@ def test_owner_computes_rows_over_a_row_order_on_host(bcs, numbering):
 
 @pytest.mark.parametrize("bcs", [False, True])
 @pytest.mark.parametrize("numbering", ["tiled", "random"])
-def test_row_sliced_owner_computes_rows_on_host(bcs, numbering):
+def test_row_sliced_owner_computes_rows_on_host(bcs, numbering, plan_copies):
     """"ocrs" / "ocrsp": the row-sliced owner-computes-rows wrapper -- instances (entity, local row) grouped by local row and
     padded to whole wavefronts, one instantiation of the local kernel per row index, lgmaps folded into the per-instance
     slot / column-position tables, complete rows flushed contiguously (caller's row order) or row by row (backend-derived
