@@ -1927,17 +1927,40 @@ class OcrPlan:
         maxlen = int(np.diff(rp).max()) if len(rp) > 1 else 0
         self.kbytes = 1 if maxlen <= 254 else 2
         self._build_tables(sparsity, rmap, cmap, staged_maps)
-        if configuration["ocr_pack"] and self.ninst and rmap.arity * (1 + cmap.arity) <= 128:
-            # bank-aware packing needs the tables of the current order; the tables are then rebuilt for the packed order
-            ir, rkey = self._imap_of(rmap, staged_maps)
-            lm = self.plans[rkey].lmap if rkey is not None else Plan(ir.ptr, 0, int(self.ninst), 0, self.inst_off_host,
-                                                                     arity=rmap.arity).lmap
-            _lib.call("fd_ocrplan_pack", self.h, ir.ptr, lm, rmap.arity, self.kidx.ptr, self.kbytes, cmap.arity,
-                      sparsity._node_rowptr.ptr, None)
-            p = [ctypes.c_void_p() for _ in range(4)]
-            _lib.call("fd_ocrplan_arrays", self.h, *[ctypes.byref(x) for x in p])
-            self.inst_ent = p[2].value
-            self._build_tables(sparsity, rmap, cmap, staged_maps)
+        # Bank-aware packing of the instance lists (fd_ocrplan_pack) is worth ~1 % of every later launch and costs ~0.1 s at C2 size
+        # (the packer + a second table build): 10^4 launches to break even.  It is therefore deferred until the plan has proved
+        # to be long-lived -- ``ocr_pack_after`` launches (0 = pack at construction) -- so that a Newton solve of a dozen
+        # assemblies never pays for it (``launched()`` counts; nothing is repacked once a hipGraph may hold the table pointers).
+        self._pack_args = (sparsity, rmap, cmap, staged_maps)
+        self.packed, self._launches = False, 0
+        if configuration["ocr_pack"] and int(configuration["ocr_pack_after"]) <= 0:
+            self.pack()
+
+    def launched(self):
+        """Called by the parloop before every launch; packs the instance lists on the ``ocr_pack_after``-th one."""
+        self._launches += 1
+        if (not self.packed and configuration["ocr_pack"] and self._launches > int(configuration["ocr_pack_after"]) > 0):
+            from . import graph
+            if not graph.captured_any:
+                self.pack()
+
+    def pack(self):
+        sparsity, rmap, cmap, staged_maps = self._pack_args
+        self.packed = True
+        if not (self.ninst and rmap.arity * (1 + cmap.arity) <= 128):
+            return
+        # bank-aware packing needs the tables of the current order; the tables are then rebuilt for the packed order
+        ir, rkey = self._imap_of(rmap, staged_maps)
+        lm = self.plans[rkey].lmap if rkey is not None else Plan(ir.ptr, 0, int(self.ninst), 0, self.inst_off_host,
+                                                                 arity=rmap.arity).lmap
+        _lib.call("fd_ocrplan_pack", self.h, ir.ptr, lm, rmap.arity, self.kidx.ptr, self.kbytes, cmap.arity,
+                  sparsity._node_rowptr.ptr, None)
+        p = [ctypes.c_void_p() for _ in range(4)]
+        _lib.call("fd_ocrplan_arrays", self.h, *[ctypes.byref(x) for x in p])
+        self.inst_ent = p[2].value
+        _lib.call("fd_device_sync")                 # (launches queued on the old tables finish before those are released)
+        self._build_tables(sparsity, rmap, cmap, staged_maps)
+        self.__dict__.pop("_records", None)         # records are packed from the tables of the current order
 
     def _imap_of(self, m, staged_maps):
         """(per-instance copy of Map ``m``, its key among the staged maps or None)."""

@@ -1061,6 +1061,8 @@ class Parloop:
         op = geo["ocr"]
         if op.nblocks == 0 or op.ninst == 0:
             return
+        if hasattr(op, "launched"):
+            op.launched()                  # (deferred bank-aware packing of a plan that turned out to be long-lived)
         out = []
         for desc in src.layout:
             kind = desc[0]

@@ -166,3 +166,25 @@ def test_p1_jacobian_padded_accumulators(numbering, pad, monkeypatch):
     pl.compute()                                             # no pending zero: accumulates
     _, _, v2 = mat.csr()
     assert np.abs(v2 - 2.0 * ref.values).max() <= 1e-12 * np.abs(ref.values).max()
+
+
+def test_deferred_packing_of_a_long_lived_plan(monkeypatch):
+    """The bank-aware packing of the instance lists (fd_ocrplan_pack: ~1 % per launch, ~0.1 s at C2 size) waits until the plan has
+    been launched ``ocr_pack_after`` times; the launches before and after give the same matrix."""
+    monkeypatch.setitem(configuration, "ocr_pack_after", 3)
+    monkeypatch.setitem(configuration, "locality_min_entities", 64)
+    m = fmesh.UnitCubeMesh(10, degrees=(1,), perturb=0.1, numbering="lexicographic")
+    prob = forms.PoissonProblem(m, 1, bcs=True)
+    mat, pl = prob.jacobian()
+    mpa = pl.arguments[0]
+    args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
+    ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
+    states = []
+    for _ in range(6):
+        mat.zero()
+        pl.compute()
+        op = [g for key, g in pl._prepared["parts"].items() if key[0] == "ocr"][0]["ocr"]
+        states.append(op.packed)
+        _, _, v = mat.csr()
+        assert np.abs(v - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
+    assert states == [False, False, False, True, True, True]
