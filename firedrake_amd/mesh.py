@@ -311,6 +311,7 @@ def UnitCubeMesh(n, degrees=(1,), tile=(8, 8, 4), rank=0, nranks=1, perturb=0.0,
                             halo.recv[qrank] = rcv
         node_set = op2.Set(sizes_n, f"cg{p}_nodes")
         m = op2.Map(cell_set, node_set, arity, cmap, f"cell_cg{p}")
+        m._has_negative = False          # (built from lattice arithmetic: spares the Mat loops a scan of the table, Parloop._reject_negative_mat_maps)
         if numbering == "tiled":
             m.preferred_blocks = _split_blocks(cell_blocks, arity)
             # node ranges of the traversal tiles (row blocks for owner-computes-rows matrix assembly)
@@ -377,6 +378,7 @@ def UnitSquareMesh(nx, ny, degrees=(1,), tile=(16, 16), perturb=0.0):
         bnd = np.nonzero((xx[norder] == 0) | (xx[norder] == p * nx) | (yy[norder] == 0) | (yy[norder] == p * ny))[0].astype(np.int32)
         node_set = op2.Set(len(norder), f"cg{p}_nodes")
         m = op2.Map(cell_set, node_set, arity, newnum[box], f"cell_cg{p}")
+        m._has_negative = False          # (built from lattice arithmetic: spares the Mat loops a scan of the table, Parloop._reject_negative_mat_maps)
         m.preferred_blocks = _split_blocks(cell_blocks, arity)
         return FunctionSpaceData(p, node_set, m, pts, HaloLists(), bnd, Lx * Ly)
 
