@@ -125,6 +125,7 @@ SIGNATURES = {
                                     c_void_p, c_void_p]),
     "fd_csr_set_diagonal": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_double, c_void_p]),
     "fd_csr_zero_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_double, c_void_p]),
+    "fd_csr_zero_rows_except": (c_int, [c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
     "fd_csr_spmv": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fd_csr_split_mpiaij": (c_int, [c_int32, c_void_p, c_void_p, c_int32, c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64),
                                     POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_void_p]),

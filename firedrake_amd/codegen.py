@@ -165,10 +165,12 @@ def generate_tensor_wrapper(gk: GlobalKernel) -> WrapperSource:
         if lg:
             layout += [("mat_row_lgmap", 0), ("mat_col_lgmap", 0)]
             params += ["const int *__restrict__ rlg0", "const int *__restrict__ clg0"]
-        layout.append(("tp_tables",))
-        params.append("const double *__restrict__ tptab")
+        # tp_fresh: 1 when the host zeroed only the rows shared between cells for this assembly (Parloop._tp_values): the rows
+        # one cell owns alone are then stored, not accumulated
+        layout += [("tp_tables",), ("tp_fresh", 0)]
+        params += ["const double *__restrict__ tptab", "int fresh0"]
         body = (f"{cfdecl}\n  fdt::hex_qk_matrix<{geom['k1']}, {geom['q1']}, {nc}>(start, end, layers, arg0, arg1, cf, map0, map1, rp0, tpo0, "
-                f"{'rlg0, clg0' if lg else 'nullptr, nullptr'}, tptab, {call_w});")
+                f"{'rlg0, clg0' if lg else 'nullptr, nullptr'}, tptab, fresh0, {call_w});")
         threads = geom["matrix_threads"]
         # 4 NT accumulator registers per lane: Q4 (NT = 8) fits three wavefronts per SIMD
         bounds = f"{threads}, 3" if geom["tiles"] <= 8 and threads == 256 else f"{threads}"

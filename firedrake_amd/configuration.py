@@ -43,6 +43,7 @@ configuration = {
     "lds_const_stride": _env("FDHIP_LDS_CONST_STRIDE", 1, int),     # staged loops: P1 residual 0.43 -> 0.41 ms
     "prefetch": _env("FDHIP_PREFETCH", 1, int),          # software-pipeline the packed index rows
     "tensor_wrappers": _env("FDHIP_TENSOR_WRAPPERS", 1, int),   # MFMA matrix / sum-factorised action for TensorProductLocalKernels
+    "tp_store_single_rows": _env("FDHIP_TP_STORE_SINGLE_ROWS", 1, int),   # a zeroed tensor-product Mat: zero the shared rows only, store the rest
     "mat_ocr": _env("FDHIP_MAT_OCR", 1, int),             # owner-computes-rows matrix assembly (no global atomics)
     "ocr_nnz_per_block_ordered": _env("FDHIP_OCR_NNZ_ORDERED", 3840, int),   # the same under a backend-derived row order
     "ocr_nnz_per_block": _env("FDHIP_OCR_NNZ", 2048, int),  # row-block size (CSR entries) when the producer gives no hint

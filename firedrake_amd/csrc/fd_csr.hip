@@ -216,6 +216,17 @@ inline int grid_for(int64_t n, int block = 256) {
 
 }  // namespace
 
+// zero every row whose length differs from skip_len: one wavefront per row.  The tensor-product matrix wrapper stores the rows a
+// single cell owns (exactly as long as the element matrix is wide) instead of accumulating into them (fd_tensor.h, hex_qk_matrix)
+__global__ __launch_bounds__(256) void zero_rows_except(int32_t nrows, const int32_t *__restrict__ rowptr, double *__restrict__ vals,
+                                                        int32_t skip_len) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    const int32_t a = rowptr[r], b = rowptr[r + 1];
+    if (b - a == skip_len) return;
+    for (int32_t p = a + (threadIdx.x & 63); p < b; p += 64) vals[p] = 0.0;
+}
+
 extern "C" {
 
 // layers visited and stacked cells of one (pair, region): sparsity.pyx:291-305, 331-346
@@ -451,6 +462,14 @@ int fd_csr_zero_rows(const int32_t *rowptr, const int32_t *colidx, double *vals,
                      double v, fd_stream_t s) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(set_diag, dim3(grid_for(n)), dim3(256), 0, fd::st(s), rowptr, colidx, vals, rows, n, v, 1);
+    FD_CHECK_LAUNCH();
+    return 0;
+}
+
+int fd_csr_zero_rows_except(int32_t nrows, const int32_t *rowptr, double *vals, int32_t skip_len, fd_stream_t s) {
+    if (nrows <= 0) return 0;
+    if (!rowptr || !vals) FD_FAIL("fd_csr_zero_rows_except: bad arguments");
+    hipLaunchKernelGGL(zero_rows_except, dim3((nrows + 3) / 4), dim3(256), 0, fd::st(s), nrows, rowptr, vals, skip_len);
     FD_CHECK_LAUNCH();
     return 0;
 }

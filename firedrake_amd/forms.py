@@ -735,7 +735,7 @@ class HelmholtzHexProblem:
         from . import _lib
         self.mat.zero()                       # a13: part of every assemble (the scatter adds into zeroed values)
         if events:
-            self.mat._values_dev()            # perform the memset outside the kernel bracket
+            self.jac_loop.zero_ahead()        # perform the zeroing outside the kernel bracket
             events[0].record()
         self.jac_loop()
         if events:

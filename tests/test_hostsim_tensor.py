@@ -107,3 +107,34 @@ def test_coefficient_arguments_through_the_tensor_templates_on_the_host(degree, 
     y = hostsim.run_tensor(prob.act_loop)[0]
     yref = _oracle_action(m, prob.u.data_ro, prob.kact, coefs)
     assert_allclose(y, yref, rtol=0, atol=1e-11 * np.abs(yref).max())
+
+
+@pytest.mark.parametrize("degree,nq,n,bcs", [(2, 3, 2, False), (2, 3, 2, True), (3, 4, 1, True), (1, 2, 2, False)])
+def test_rows_owned_by_one_cell_are_stored_after_a_zero_and_accumulated_otherwise(degree, nq, n, bcs):
+    """hex_qk_matrix stores the rows exactly as long as the element matrix is wide (the cell-interior nodes; for Q1 the corners of
+    the domain) when the host zeroed only the shared rows (fresh = 1): started from a matrix full of NaNs, every entry must come out
+    as the oracle's -- zeros in the dropped boundary rows and columns included.  fresh = 0 on top of earlier values accumulates
+    (Mat INC without a zero(), mat.py:851-855): the same rows are then read-modify-written."""
+    m = fmesh.make_extruded_hex_mesh(n, 2, degree, perturb=0.1)
+    prob = forms.HelmholtzHexProblem(m, bcs=bcs, nq=nq)
+    ref = _oracle_matrix(m, prob.bc_nodes if bcs else None, prob.kjac)
+    rp, ci = ref.rowptr, ref.colidx
+    rl = np.diff(rp)
+    single = np.repeat(rl == (degree + 1) ** 3, rl)
+    assert single.any() and not single.all()
+
+    def with_diagonal(v):
+        v = v.copy()
+        for b in (prob.bc_nodes if bcs else ()):
+            v[rp[b] + np.searchsorted(ci[rp[b]:rp[b + 1]], b)] = 1.0
+        return v
+
+    tol = 1e-12 * np.abs(ref.values).max()
+    fresh = hostsim.run_tensor(prob.jac_loop, fresh=1, initial=np.full(ref.values.shape, np.nan))[0]
+    assert_allclose(with_diagonal(fresh.values), ref.values, rtol=0, atol=tol)
+    start = np.random.default_rng(5).standard_normal(ref.values.shape)
+    acc = hostsim.run_tensor(prob.jac_loop, fresh=0, initial=start)[0]
+    expect = ref.values.copy()
+    for b in (prob.bc_nodes if bcs else ()):
+        expect[rp[b] + np.searchsorted(ci[rp[b]:rp[b + 1]], b)] = 0.0
+    assert_allclose(acc.values, start + expect, rtol=0, atol=tol)
