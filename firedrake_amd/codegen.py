@@ -181,7 +181,8 @@ def generate_tensor_wrapper(gk: GlobalKernel) -> WrapperSource:
                   "const double *__restrict__ tptab"]
         body = (f"{cfdecl}\n  fdt::hex_qk_action<{geom['k1']}, {geom['q1']}, {nc}>(start, end, layers, arg0, arg1, arg2, cf, map0, map1, tptab, "
                 f"{call_w});")
-        threads, bounds = 128, "128"
+        threads = 128
+        bounds = "128" + (f", {int(configuration['tp_action_waves'])}" if configuration["tp_action_waves"] else "")
     src = head + [f'extern "C" __global__ __launch_bounds__({bounds}) void {sym}(int start, int end, {", ".join(params)})', "{", body, "}"]
     return WrapperSource("\n".join(src) + "\n", sym, "tp_" + kind, layout, 2, block_threads=threads, tp=geom)
 

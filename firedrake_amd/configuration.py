@@ -25,6 +25,7 @@ configuration = {
     "flush_batch": _env("FDHIP_FLUSH_BATCH", 4, int),      # flushes through index tables (derived row orders): table loads requested per trip
     "plan_copies": _env("FDHIP_PLAN_COPIES", 1, int),     # READ Dats unchanged between calls are kept in plan order and streamed
     "ocr_pack": _env("FDHIP_OCR_PACK", 1, int),            # bank-aware greedy packing of the instance lists (fd_ocrplan_pack)
+    "ocr_pad_windows": _env("FDHIP_OCR_PAD_WINDOWS", 0, int),   # dummy instances that keep a 16-lane LDS atomic window on distinct banks
     "ocr_pack_after": _env("FDHIP_OCR_PACK_AFTER", 64, int),   # ... once a plan has been launched this often (0 = when it is built)
     # owner-computes-rows index tables: one bit-packed record per instance (fd_ocr_pack_records; 0 = uint16 / uint8 rows), the
     # diagonal offsets taken from the row node's LDS word, and the flush of a derived row order run-coded (fd_ocr_row_runs)
@@ -43,7 +44,9 @@ configuration = {
     "lds_const_stride": _env("FDHIP_LDS_CONST_STRIDE", 1, int),     # staged loops: P1 residual 0.43 -> 0.41 ms
     "prefetch": _env("FDHIP_PREFETCH", 1, int),          # software-pipeline the packed index rows
     "tensor_wrappers": _env("FDHIP_TENSOR_WRAPPERS", 1, int),   # MFMA matrix / sum-factorised action for TensorProductLocalKernels
-    "tp_store_single_rows": _env("FDHIP_TP_STORE_SINGLE_ROWS", 1, int),   # a zeroed tensor-product Mat: zero the shared rows only, store the rest
+    "tp_action_waves": _env("FDHIP_TP_ACTION_WAVES", 3, int),   # wavefronts per SIMD the action wrapper is compiled for (register cap; 0 = none)
+    "tp_store_single_rows": _env("FDHIP_TP_STORE_SINGLE_ROWS", 0, int),   # a zeroed tensor-product Mat: zero the shared rows only, store the rest
+                                                                        # (measured 1 % slower than fill + atomics: profiles/r4n_c3_single_rows.txt)
     "mat_ocr": _env("FDHIP_MAT_OCR", 1, int),             # owner-computes-rows matrix assembly (no global atomics)
     "ocr_nnz_per_block_ordered": _env("FDHIP_OCR_NNZ_ORDERED", 3840, int),   # the same under a backend-derived row order
     "ocr_nnz_per_block": _env("FDHIP_OCR_NNZ", 2048, int),  # row-block size (CSR entries) when the producer gives no hint

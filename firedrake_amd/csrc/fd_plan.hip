@@ -734,6 +734,7 @@ int fd_matplan_free(fd_matplan_t m) {
 // =====================================================================================
 struct fd_ocrplan_s {
     int32_t nblocks = 0, max_inst = 0;
+    int bygeom = 0;                  // stencil order grouped by shape (interleave = -1)
     int64_t ninst = 0;
     int32_t *inst_off = nullptr;     // nblocks+1 (device)
     int32_t *inst_off_host = nullptr;
@@ -821,7 +822,7 @@ __global__ void ocr_interleave(const int32_t *__restrict__ off, const int32_t *_
 // conflict window add into distinct banks, and no two of them share an accumulator in one instruction.
 __global__ void ocr_stencil_keys(const int32_t *__restrict__ rmap, int ar, const int32_t *__restrict__ inst_off,
                                  const int32_t *__restrict__ inst_ent, const int32_t *__restrict__ rblk, int32_t nblocks,
-                                 int64_t ninst, uint64_t *__restrict__ keys, const int32_t *__restrict__ pinv, int32_t npos) {
+                                 int64_t ninst, uint64_t *__restrict__ keys, const int32_t *__restrict__ pinv, int32_t npos, int bygeom) {
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < ninst; t += (int64_t)gridDim.x * blockDim.x) {
         int lo = 0, hi = nblocks - 1;                      // block of instance t: largest b with inst_off[b] <= t
         while (lo < hi) {
@@ -835,7 +836,7 @@ __global__ void ocr_stencil_keys(const int32_t *__restrict__ rmap, int ar, const
         uint32_t h = 2166136261u;
         for (int i = 0; i < ar; ++i) {
             int32_t r = row_position(pinv, npos, row[i]);
-            uint32_t own = (r >= n0 && r < n1) ? 1u : 0u;
+            uint32_t own = (r >= n0 && r < n1 && !bygeom) ? 1u : 0u;
             uint32_t d = (uint32_t)(r - first);
             h = (h ^ own) * 16777619u;
             h = (h ^ (d & 0xffffu)) * 16777619u;
@@ -847,7 +848,13 @@ __global__ void ocr_stencil_keys(const int32_t *__restrict__ rmap, int ar, const
         // with the patterns mixed every trip issued all ar*ac atomics (16.1 of 16 measured on C2), grouped it issues the owned
         // rows' only (12.1).  The full 16-bit signature stays the next key: it is what keeps a conflict window regular
         // (with 8 bits of it the bank conflicts rose by 43 %, profiles/r3k_pmc_mask_order.txt)
-        if (ar <= 8 && nblocks < (1 << 24)) {
+        // bygeom: groups by the entity's SHAPE alone (offsets of its row nodes from the first owned one, whoever owns them).  With
+        // the rows of a block numbered along the mesh lines every node of the block is the first owned row of exactly one entity of
+        // a kind (the cell it is the low corner of, fully owned or hanging over the block's high faces): sorted by that row, 16
+        // consecutive instances sit on 16 consecutive rows -- distinct accumulator banks in every one of their atomics -- where
+        // the ownership-major order leaves 7 fully owned cells to a line of 8 nodes and a colliding pair in every window
+        // (profiles/r4m_microbench_windows.txt: one pair costs the whole second pass of the LDS atomic unit).
+        if (ar <= 8 && nblocks < (1 << 24) && !bygeom) {
             uint32_t mask = 0;
             for (int i = 0; i < ar; ++i) { const int32_t r = row_position(pinv, npos, row[i]); if (r >= n0 && r < n1) mask |= 1u << i; }
             keys[t] = ((uint64_t)(uint32_t)lo << 40) | ((uint64_t)(mask ^ ((1u << ar) - 1u)) << 32) | ((uint64_t)(h & 0xffffu) << 16)
@@ -858,6 +865,63 @@ __global__ void ocr_stencil_keys(const int32_t *__restrict__ rmap, int ar, const
     }
 }
 
+
+// ---- conflict-free windows ------------------------------------------------------------------------------------------------
+// The fp64 LDS atomic unit takes the 16 lanes of a window in as many passes as lanes share one of its 16 banks (tools/
+// microbench_lds.hip, profiles/r4m_microbench_windows.txt: ONE colliding pair in a window costs the whole second pass -- 4.5 against
+// 8.3 lanes per clock).  Instances of one stencil group are translates, so the 16 of a window hit distinct banks in EVERY one of their
+// ar*ac atomics as soon as the accumulator offsets of their first owned rows differ mod 16.  In the stencil order of an 8-node-wide
+// tile the fully owned cells come 7 to a line (residues 0..6, 8..14, then 0.. again): every window of 16 consecutive ones holds a
+// colliding pair, and only 14 residues exist at all.  ocr_pad_windows walks the sorted list of a block and, where the next instance
+// would collide with one of its own group already in the window and the window is at least FD_PAD_MIN slots full, fills the rest of
+// the window with a DUMMY: an entity none of whose rows the block owns (its atomics are all skipped by the ownership words -- the
+// wrapper needs no change and the dummy's nodes ride in the block's staged list).
+constexpr int FD_PAD_MIN = 12;
+
+__global__ void ocr_pick_dummy(const int32_t *__restrict__ rmap, int ar, int32_t start, int32_t end, const int32_t *__restrict__ rblk,
+                               int32_t nblocks, const int32_t *__restrict__ pinv, int32_t npos, int32_t *__restrict__ dummy) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const int32_t n0 = rblk[b], n1 = rblk[b + 1];
+    int32_t pick = -1;
+    const int64_t span = (int64_t)end - start;
+    for (int c = 0; c < 8 && pick < 0; ++c) {            // a few entities spread over the range: the first that is foreign to the block
+        const int32_t e = start + (int32_t)((span - 1) * c / 7);
+        bool foreign = true;
+        for (int i = 0; i < ar; ++i) { const int32_t r = row_position(pinv, npos, rmap[(int64_t)e * ar + i]); if (r >= n0 && r < n1) foreign = false; }
+        if (foreign) pick = e;
+    }
+    dummy[b] = pick;
+}
+
+// one thread per block; emit == 0: count the padded slots into cnt[b]; emit == 1: write the padded list at off[b]
+__global__ void ocr_pad_windows(const uint64_t *__restrict__ keys, const int32_t *__restrict__ inst_off, const int32_t *__restrict__ inst_ent,
+                                const int32_t *__restrict__ rblk, const int32_t *__restrict__ rowstart, int32_t nblocks,
+                                const int32_t *__restrict__ dummy, int emit, int32_t *__restrict__ cnt,
+                                const int32_t *__restrict__ off, int32_t *__restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const int32_t o0 = inst_off[b], o1 = inst_off[b + 1], n0 = rblk[b], d = dummy[b];
+    const int32_t base = emit ? off[b] : 0, rs0 = rowstart[n0];
+    int32_t pos = 0;
+    uint32_t used = 0;
+    uint64_t prev = ~0ull;
+    for (int32_t j = o0; j < o1; ++j) {
+        const uint64_t key = keys[j], grp = key >> 16;
+        const int res = (rowstart[n0 + (int32_t)(key & 0xffffu)] - rs0) & 15;
+        const int w = pos & 15;
+        if (w == 0 || grp != prev) used = 0;             // (residues of another group say nothing about this one's banks)
+        if (d >= 0 && grp == prev && w >= FD_PAD_MIN && ((used >> res) & 1u)) {
+            for (int q = w; q < 16; ++q, ++pos) if (emit) out[base + pos] = d;
+            used = 0;
+        }
+        if (emit) out[base + pos] = inst_ent[j];
+        ++pos;
+        used |= 1u << res;
+        prev = grp;
+    }
+    if (!emit) cnt[b] = pos;
+}
 
 // ---- bank-aware packing of the instances of a row block --------------------------------------------------------
 // The wrapper's lanes walk the instance slots in order, so the 16 lanes of an LDS conflict window (64-bit LDS
@@ -1340,15 +1404,16 @@ static int ocrplan_build(const int32_t *rmap_dev, int ar, int32_t start, int32_t
     FD_HIP(hipMalloc(&p->inst_ent, (size_t)(nu > 0 ? nu : 1) * 4));
     hipLaunchKernelGGL(ocr_split, dim3(mp_grid(nu + 1)), dim3(256), 0, s, uniq, nu, nblocks, p->inst_off, p->inst_ent);
     FD_CHECK_LAUNCH();
-    if (interleave == 1 && nu > 0) {
-        // stencil order: (block | signature | first owned row) keys, one stable radix sort of (key, entity) pairs
+    p->bygeom = interleave < 0 ? 1 : 0;
+    if ((interleave == 1 || interleave == -1) && nu > 0) {
+        // stencil order (-1: groups by shape, not by ownership pattern): (block | signature | first owned row) keys, one stable radix sort of (key, entity) pairs
         uint64_t *ka = nullptr, *kb = nullptr;
         int32_t *vb = nullptr;
         FD_HIP(hipMalloc(&ka, (size_t)nu * 8));
         FD_HIP(hipMalloc(&kb, (size_t)nu * 8));
         FD_HIP(hipMalloc(&vb, (size_t)nu * 4));
         hipLaunchKernelGGL(ocr_stencil_keys, dim3(mp_grid(nu)), dim3(256), 0, s, rmap_dev, ar, p->inst_off, p->inst_ent, p->rblk,
-                           nblocks, nu, ka, p->pinv, p->npos);
+                           nblocks, nu, ka, p->pinv, p->npos, interleave < 0 ? 1 : 0);
         FD_CHECK_LAUNCH();
         hipcub::DoubleBuffer<uint64_t> dk(ka, kb);
         hipcub::DoubleBuffer<int32_t> dv(p->inst_ent, vb);
@@ -1419,6 +1484,60 @@ int fd_ocrplan_pack(fd_ocrplan_t p, const int32_t *imap_r_dev, const uint16_t *l
     FD_HIP(hipFree(dcb)); FD_HIP(hipFree(dcf)); FD_HIP(hipFree(dcl));
     FD_HIP(hipFree(p->inst_ent));
     p->inst_ent = out;
+    return 0;
+}
+
+int fd_ocrplan_pad_windows(fd_ocrplan_t p, const int32_t *rmap_dev, int ar, int32_t start, int32_t end, const int32_t *rowstart_dev,
+                           int64_t *ndummy, fd_stream_t s_) {
+    if (!p || !rmap_dev || !rowstart_dev || ar <= 0) FD_FAIL("fd_ocrplan_pad_windows: bad arguments");
+    if (ndummy) *ndummy = 0;
+    if (p->ninst <= 0 || p->nblocks <= 0 || end <= start || p->chunk_role) return 0;
+    if (!(ar <= 8 && p->nblocks < (1 << 24))) return 0;          // (the stencil key carries the ownership pattern only then)
+    hipStream_t s = fd::st(s_);
+    const int64_t nu = p->ninst;
+    const int32_t nb = p->nblocks;
+    uint64_t *keys = nullptr;
+    int32_t *dummy = nullptr, *cnt = nullptr, *noff = nullptr, *out = nullptr;
+    void *tmp = nullptr;
+    FD_HIP(hipMalloc(&keys, (size_t)nu * 8));
+    FD_HIP(hipMalloc(&dummy, (size_t)nb * 4));
+    FD_HIP(hipMalloc(&cnt, ((size_t)nb + 1) * 4));
+    FD_HIP(hipMalloc(&noff, ((size_t)nb + 1) * 4));
+    hipLaunchKernelGGL(ocr_stencil_keys, dim3(mp_grid(nu)), dim3(256), 0, s, rmap_dev, ar, p->inst_off, p->inst_ent, p->rblk, nb, nu, keys,
+                       p->pinv, p->npos, p->bygeom);
+    FD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ocr_pick_dummy, dim3((nb + 255) / 256), dim3(256), 0, s, rmap_dev, ar, start, end, p->rblk, nb, p->pinv, p->npos, dummy);
+    FD_CHECK_LAUNCH();
+    FD_HIP(hipMemsetAsync(cnt, 0, ((size_t)nb + 1) * 4, s));
+    hipLaunchKernelGGL(ocr_pad_windows, dim3((nb + 63) / 64), dim3(64), 0, s, keys, p->inst_off, p->inst_ent, p->rblk, rowstart_dev, nb, dummy, 0,
+                       cnt, nullptr, nullptr);
+    FD_CHECK_LAUNCH();
+    size_t tb = 0;
+    FD_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt, noff, nb + 1, s));
+    FD_HIP(hipMalloc(&tmp, tb ? tb : 8));
+    FD_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, cnt, noff, nb + 1, s));
+    int32_t total = 0;
+    FD_HIP(hipMemcpyAsync(&total, noff + nb, 4, hipMemcpyDeviceToHost, s));
+    FD_HIP(hipStreamSynchronize(s));
+    if ((int64_t)total > nu) {
+        FD_HIP(hipMalloc(&out, (size_t)total * 4));
+        hipLaunchKernelGGL(ocr_pad_windows, dim3((nb + 63) / 64), dim3(64), 0, s, keys, p->inst_off, p->inst_ent, p->rblk, rowstart_dev, nb, dummy,
+                           1, nullptr, noff, out);
+        FD_CHECK_LAUNCH();
+        FD_HIP(hipMemcpyAsync(p->inst_off_host, noff, ((size_t)nb + 1) * 4, hipMemcpyDeviceToHost, s));
+        FD_HIP(hipStreamSynchronize(s));
+        FD_HIP(hipFree(p->inst_ent)); FD_HIP(hipFree(p->inst_off));
+        p->inst_ent = out; p->inst_off = noff; noff = nullptr;
+        if (ndummy) *ndummy = (int64_t)total - nu;
+        p->ninst = total;
+        p->max_inst = 0;
+        for (int32_t b = 0; b < nb; ++b) {
+            const int d = p->inst_off_host[b + 1] - p->inst_off_host[b];
+            if (d > p->max_inst) p->max_inst = d;
+        }
+    }
+    FD_HIP(hipFree(keys)); FD_HIP(hipFree(dummy)); FD_HIP(hipFree(cnt)); FD_HIP(hipFree(tmp));
+    if (noff) FD_HIP(hipFree(noff));
     return 0;
 }
 

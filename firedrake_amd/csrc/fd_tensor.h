@@ -210,9 +210,10 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
         if (cok[t] && clg) cok[t] = clg[cn[t]] >= 0;
     }
     // A row as long as the element matrix is wide belongs to this cell alone (the cell-interior nodes, (k-1)^3 of (k+1)^3: 22 % of
-    // the entries of Q4; any row shared with a second cell is longer): nobody else writes it, so it is stored -- or, when the matrix
-    // was not zeroed for this assembly, read-modify-written -- without atomics.  ``fresh`` = the host zeroed only the SHARED rows
-    // (fd_csr_zero_rows_except) and the stores below overwrite the rest, dropped rows and columns (boundary conditions) with zeros.
+    // the entries of Q4; any row shared with a second cell is longer): nobody else writes it.  ``fresh`` = the host zeroed only the
+    // SHARED rows (fd_csr_zero_rows_except) and the stores below overwrite the rest, dropped rows and columns (boundary conditions)
+    // with zeros.  Without it every row takes atomics (a load-add-store of the single-cell rows measured 7 % slower than the
+    // fire-and-forget atomics: profiles/r4m_c3_single_rows.txt).
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int i = itile * 16 + kk + 4 * g;
@@ -226,13 +227,7 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 if (jv[t]) vals[r0 + tab[i * ND + t * 16 + r16]] = (rdrop || !cok[t]) ? 0.0 : acc[t][g];
-        } else if (rdrop) {
-            continue;
-        } else if (single) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (cok[t]) vals[r0 + tab[i * ND + t * 16 + r16]] += acc[t][g];
-        } else {
+        } else if (!rdrop) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 if (cok[t]) atomicAdd(&vals[r0 + tab[i * ND + t * 16 + r16]], acc[t][g]);
@@ -251,8 +246,8 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
 //   pass 2  (lines along i2):  VV = L_2 V,  D1V = L_2 D1,  D2 = DL_2 V                                    -> B  (q1, q2, i3)
 //   pass 3+4 (lines along i3, all in registers): values and reference gradient at the line's Gauss points, the
 //            point weights (geometry of a trilinear hexahedron is affine along a line: 6 vectors per line, one
-//            interpolation per point), F = W g, then the transposed contraction q3 -> i3                  -> A  (q1, q2, i3)
-//   pass 5  (q2 -> i2), pass 6 (q1 -> i1) and one fp64 atomic per DoF (extruded addressing map + k*layer, builder.py:94-124).
+//            interpolation per point), F = W g, then the transposed contraction q3 -> i3                  -> B  (q1, q2, i3), in place
+//   pass 5  (q2 -> i2) -> A, pass 6 (q1 -> i1) and one fp64 atomic per DoF (extruded addressing map + k*layer, builder.py:94-124).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int tp_action_cells(int k1, int q1) { return 128 / ((k1 > q1 ? k1 : q1) * (k1 > q1 ? k1 : q1)); }
 
@@ -265,8 +260,10 @@ __device__ __forceinline__ void hex_qk_action(int start, int end, const int *__r
     constexpr int M = K1 > Q1 ? K1 : Q1, M2 = M * M, M3 = M2 * M, CPW = tp_action_cells(K1, Q1), ND = K1 * K1 * K1, NTAB = Q1 * K1;
     constexpr int OFF = K1 - 1;
     static_assert(CPW >= 1, "one cell needs at most 128 lines");
-    // (slots 3 .. 3 + NC: the coefficient arguments ride through passes 1 and 2 next to u and are evaluated at the line's points)
-    __shared__ double sA[CPW][3 + NC][M3], sB[CPW][3 + NC][M3], sX[CPW][24];
+    // A: two index cubes per cell (passes 1 and 5 write two), B: three (pass 2 writes three; passes 3 + 4 put their three results back
+    // IN PLACE -- a lane reads and writes only its own line) -- 5 cubes of 1000 B per cell for Q4, six workgroups per CU.  The NC
+    // coefficient arguments ride through passes 1 and 2 in further slots (A: 2.., B: 3..) and are evaluated at the line's points.
+    __shared__ double sA[CPW][2 + NC][M3], sB[CPW][3 + NC][M3], sX[CPW][24];
     const int t = threadIdx.x;
     const int nl = layers[1] - 1 - layers[0];
     const int ncell = (end - start) * nl;
@@ -285,9 +282,20 @@ __device__ __forceinline__ void hex_qk_action(int start, int end, const int *__r
     const bool in = k < CPW && first + k < ncell;
     const int ka = in ? k : 0;
     double (*A)[M3] = sA[ka], (*B)[M3] = sB[ka];
-    double L[NTAB], DL[NTAB];                           // wavefront-uniform: scalar registers
+    // The 1-D tables are wavefront-uniform and live in scalar registers -- of which a wavefront has ~100: both tables of Q4 in full
+    // (2 x 25 doubles) overflow them, and the compiler then parks the excess in the lanes of a vector register and fetches every
+    // operand back with v_readlane (768 of the 2400 instructions of the Q4 kernel, a third of its issue slots; Q5: half).  Nodes
+    // and points are symmetric about 1/2, so L[NTAB-1-m] = L[m] and DL[NTAB-1-m] = -DL[m]: only the first halves are kept
+    // (Parloop._tp_tables checks the symmetry), the sign rides on the FMA's source modifier.  Measured at n = 64 (profiles/
+    // r4n_action_variants.txt): on its own the shorter kernel is 10 % SLOWER (0.588 against 0.533 ms -- the kernel waits on its two
+    // dependent rounds of global loads and its barriers, not on issue slots, and this form happens to need 172 registers: two
+    // wavefronts per SIMD); compiled for three wavefronts per SIMD (codegen: __launch_bounds__(128, 3)) it is the fastest, 0.52 ms.
+    constexpr int NH = (NTAB + 1) / 2;
+    double Lh[NH], DLh[NH];
 #pragma unroll
-    for (int i = 0; i < NTAB; ++i) { L[i] = tables[i]; DL[i] = tables[NTAB + i]; }
+    for (int i = 0; i < NH; ++i) { Lh[i] = tables[i]; DLh[i] = tables[NTAB + i]; }
+    auto L = [&](int m) { return m < NH ? Lh[m] : Lh[NTAB - 1 - m]; };
+    auto DL = [&](int m) { return m < NH ? DLh[m] : -DLh[NTAB - 1 - m]; };
     // pass 1: line (i2, i3) = (p, r) of the K1^3 coefficient cube
     const bool on1 = in && p < K1 && r < K1;
     int node[K1];
@@ -302,7 +310,7 @@ __device__ __forceinline__ void hex_qk_action(int start, int end, const int *__r
         for (int q = 0; q < Q1; ++q) {
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-            for (int i = 0; i < K1; ++i) { s0 += L[q * K1 + i] * uv[i]; s1 += DL[q * K1 + i] * uv[i]; }
+            for (int i = 0; i < K1; ++i) { s0 += L(q * K1 + i) * uv[i]; s1 += DL(q * K1 + i) * uv[i]; }
             A[0][q * M2 + l] = s0; A[1][q * M2 + l] = s1;
         }
 #pragma unroll
@@ -314,8 +322,8 @@ __device__ __forceinline__ void hex_qk_action(int start, int end, const int *__r
             for (int q = 0; q < Q1; ++q) {
                 double s0 = 0.0;
 #pragma unroll
-                for (int i = 0; i < K1; ++i) s0 += L[q * K1 + i] * cv[i];
-                A[3 + m][q * M2 + l] = s0;
+                for (int i = 0; i < K1; ++i) s0 += L(q * K1 + i) * cv[i];
+                A[2 + m][q * M2 + l] = s0;
             }
         }
     }
@@ -328,7 +336,7 @@ __device__ __forceinline__ void hex_qk_action(int start, int end, const int *__r
         for (int q = 0; q < Q1; ++q) {
             double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
-            for (int i = 0; i < K1; ++i) { s0 += L[q * K1 + i] * v[i]; s1 += L[q * K1 + i] * d[i]; s2 += DL[q * K1 + i] * v[i]; }
+            for (int i = 0; i < K1; ++i) { s0 += L(q * K1 + i) * v[i]; s1 += L(q * K1 + i) * d[i]; s2 += DL(q * K1 + i) * v[i]; }
             const int o = (p * M + q) * M + r;
             B[0][o] = s0; B[1][o] = s1; B[2][o] = s2;
         }
@@ -336,12 +344,12 @@ __device__ __forceinline__ void hex_qk_action(int start, int end, const int *__r
         for (int m = 0; m < NC; ++m) {
             double cv[K1];
 #pragma unroll
-            for (int i = 0; i < K1; ++i) cv[i] = A[3 + m][p * M2 + i * M + r];
+            for (int i = 0; i < K1; ++i) cv[i] = A[2 + m][p * M2 + i * M + r];
 #pragma unroll
             for (int q = 0; q < Q1; ++q) {
                 double s0 = 0.0;
 #pragma unroll
-                for (int i = 0; i < K1; ++i) s0 += L[q * K1 + i] * cv[i];
+                for (int i = 0; i < K1; ++i) s0 += L(q * K1 + i) * cv[i];
                 B[3 + m][(p * M + q) * M + r] = s0;
             }
         }
@@ -372,7 +380,7 @@ __device__ __forceinline__ void hex_qk_action(int start, int end, const int *__r
             double g[4] = {0.0, 0.0, 0.0, 0.0};         // d1 u, d2 u, d3 u, u at the Gauss point (p, r, q)
 #pragma unroll
             for (int i = 0; i < K1; ++i) {
-                g[0] += L[q * K1 + i] * d1[i]; g[1] += L[q * K1 + i] * d2[i]; g[2] += DL[q * K1 + i] * vv[i]; g[3] += L[q * K1 + i] * vv[i];
+                g[0] += L(q * K1 + i) * d1[i]; g[1] += L(q * K1 + i) * d2[i]; g[2] += DL(q * K1 + i) * vv[i]; g[3] += L(q * K1 + i) * vv[i];
             }
             const double t2 = tables[2 * NTAB + q];
             double J[3][3], X[3], W[16], F[4], C[NC > 0 ? NC : 1];
@@ -380,7 +388,7 @@ __device__ __forceinline__ void hex_qk_action(int start, int end, const int *__r
             for (int m = 0; m < NC; ++m) {
                 double cq = 0.0;
 #pragma unroll
-                for (int i = 0; i < K1; ++i) cq += L[q * K1 + i] * B[3 + m][l * M + i];
+                for (int i = 0; i < K1; ++i) cq += L(q * K1 + i) * B[3 + m][l * M + i];
                 C[m] = cq;
             }
 #pragma unroll
@@ -395,35 +403,35 @@ __device__ __forceinline__ void hex_qk_action(int start, int end, const int *__r
             for (int m = 0; m < 4; ++m) F[m] = W[m * 4 + 0] * g[0] + W[m * 4 + 1] * g[1] + W[m * 4 + 2] * g[2] + W[m * 4 + 3] * g[3];
 #pragma unroll
             for (int i = 0; i < K1; ++i) {
-                p0[i] += L[q * K1 + i] * F[0]; p1[i] += L[q * K1 + i] * F[1]; sv[i] += DL[q * K1 + i] * F[2] + L[q * K1 + i] * F[3];
+                p0[i] += L(q * K1 + i) * F[0]; p1[i] += L(q * K1 + i) * F[1]; sv[i] += DL(q * K1 + i) * F[2] + L(q * K1 + i) * F[3];
             }
         }
 #pragma unroll
-        for (int i = 0; i < K1; ++i) { A[0][l * M + i] = p0[i]; A[1][l * M + i] = p1[i]; A[2][l * M + i] = sv[i]; }
+        for (int i = 0; i < K1; ++i) { B[0][l * M + i] = p0[i]; B[1][l * M + i] = p1[i]; B[2][l * M + i] = sv[i]; }
     }
     __syncthreads();
     if (in && p < Q1 && r < K1) {                       // pass 5: (p, r) = (q1, i3), q2 -> i2
         double a0[Q1], a1[Q1], a2[Q1];
 #pragma unroll
-        for (int q = 0; q < Q1; ++q) { const int o = (p * M + q) * M + r; a0[q] = A[0][o]; a1[q] = A[1][o]; a2[q] = A[2][o]; }
+        for (int q = 0; q < Q1; ++q) { const int o = (p * M + q) * M + r; a0[q] = B[0][o]; a1[q] = B[1][o]; a2[q] = B[2][o]; }
 #pragma unroll
         for (int i = 0; i < K1; ++i) {
             double r0 = 0.0, r1 = 0.0;
 #pragma unroll
-            for (int q = 0; q < Q1; ++q) { r0 += L[q * K1 + i] * a0[q]; r1 += DL[q * K1 + i] * a1[q] + L[q * K1 + i] * a2[q]; }
-            B[0][p * M2 + i * M + r] = r0; B[1][p * M2 + i * M + r] = r1;
+            for (int q = 0; q < Q1; ++q) { r0 += L(q * K1 + i) * a0[q]; r1 += DL(q * K1 + i) * a1[q] + L(q * K1 + i) * a2[q]; }
+            A[0][p * M2 + i * M + r] = r0; A[1][p * M2 + i * M + r] = r1;
         }
     }
     __syncthreads();
     if (on1) {                                          // pass 6: line l = (i2, i3), q1 -> i1
         double r0[Q1], r1[Q1];
 #pragma unroll
-        for (int q = 0; q < Q1; ++q) { r0[q] = B[0][q * M2 + l]; r1[q] = B[1][q * M2 + l]; }
+        for (int q = 0; q < Q1; ++q) { r0[q] = A[0][q * M2 + l]; r1[q] = A[1][q * M2 + l]; }
 #pragma unroll
         for (int i = 0; i < K1; ++i) {
             double yv = 0.0;
 #pragma unroll
-            for (int q = 0; q < Q1; ++q) yv += DL[q * K1 + i] * r0[q] + L[q * K1 + i] * r1[q];
+            for (int q = 0; q < Q1; ++q) yv += DL(q * K1 + i) * r0[q] + L(q * K1 + i) * r1[q];
             atomicAdd(&y[node[i]], yv);
         }
     }

@@ -1908,6 +1908,15 @@ class OcrPlan:
             _lib.call("fd_ocrplan_create", rmap._base()._dev_values(), rmap.arity, int(start), int(end), rb.ctypes.data, nb,
                       self._order_code(lane_threads), None, ctypes.byref(h))
         self.h = h.value
+        # conflict-free LDS atomic windows: dummy instances where the stencil order would put two lanes of a 16-lane window on one
+        # accumulator bank (fd_ocrplan_pad_windows; stencil order only)
+        self.ndummy = 0
+        if configuration["ocr_pad_windows"] and self._order_code(lane_threads) in (1, -1):
+            nd_ = ctypes.c_int64()
+            sparsity._build()
+            _lib.call("fd_ocrplan_pad_windows", self.h, rmap._base()._dev_values(), rmap.arity, int(start), int(end),
+                      row_order.prowptr.ptr if row_order is not None else sparsity._node_rowptr.ptr, ctypes.byref(nd_), None)
+            self.ndummy = nd_.value
         ni, mi = ctypes.c_int64(), ctypes.c_int32()
         _lib.call("fd_ocrplan_info", self.h, ctypes.byref(ni), ctypes.byref(mi))
         self.ninst, self.max_inst, self.nblocks = ni.value, mi.value, nb
@@ -2010,9 +2019,11 @@ class OcrPlan:
         order = str(configuration["ocr_order"])
         if order == "stencil":
             return 1
+        if order == "shape":
+            return -1
         if order == "natural":
             return 0
-        raise ValueError("FDHIP_OCR_ORDER must be stencil or natural")
+        raise ValueError("FDHIP_OCR_ORDER must be stencil, shape or natural")
 
     def __del__(self):
         try:

@@ -679,11 +679,13 @@ class Parloop:
     _tp_fresh = 0
 
     def _tp_values(self, pa, start, end):
-        """Values of the Mat a tensor-product matrix loop assembles into.  A pending Mat.zero() (mat.py:851-855) is carried out here:
-        when this launch covers every cell of the set, only the rows SHARED between cells are zeroed and the wrapper is told to store
+        """Values of the Mat a tensor-product matrix loop assembles into.  A pending Mat.zero() (mat.py:851-855) is carried out here.
+        With FDHIP_TP_STORE_SINGLE_ROWS=1 (off by default: the partial zero + stores measured 1 % slower at C3 size than the plain
+        fill + atomics on every row, profiles/r4n_c3_single_rows.txt -- the fire-and-forget atomics are not what the kernel waits
+        for), when this launch covers every cell of the set, only the rows SHARED between cells are zeroed and the wrapper is told to store
         the rows a single cell owns (``fresh``; the (k-1)^3 cell-interior nodes of Q_k and the corners of the domain: 22 % of the
         entries of a Q4 operator) -- one pass less over those entries and no atomics on them.  Anything else (a partial launch, an
-        accumulating assembly) zeroes the whole matrix as before and the wrapper read-modify-writes those rows."""
+        accumulating assembly) zeroes the whole matrix and the wrapper adds into every row with atomics."""
         mat = pa.data
         self._tp_fresh = 0
         if configuration["tp_store_single_rows"] and start == 0 and end == self.iterset.total_size:
@@ -723,6 +725,11 @@ class Parloop:
             from .tensor import gll_gauss_tables
             tp = self.global_kernel.local_kernel.tp
             L, DL, qp, qw = gll_gauss_tables(tp["degree"], tp["nq"])
+            # the action template keeps half of each table (nodes and points symmetric about 1/2: fd_tensor.h, hex_qk_action)
+            if not (np.allclose(L, L[::-1, ::-1], rtol=0, atol=1e-13 * np.abs(L).max())
+                    and np.allclose(DL, -DL[::-1, ::-1], rtol=0, atol=1e-13 * np.abs(DL).max())):
+                raise ValueError("tensor-product wrappers need 1-D tables symmetric about the midpoint of the interval")
+            L, DL = 0.5 * (L + L[::-1, ::-1]), 0.5 * (DL - DL[::-1, ::-1])
             t = DeviceBuffer.from_numpy(np.concatenate([L.ravel(), DL.ravel(), qp, qw]))
             self._prepared["tp_tables"] = t
         return t
@@ -1007,7 +1014,7 @@ class Parloop:
             import sys
             print(f"[fdhip] {self.global_kernel.name} OCR variant {variant}: record {rec}, runs per block <= {runs[3] if runs else None}", file=sys.stderr)
             print(f"[fdhip] {self.global_kernel.name} OCR [{start},{end}): row blocks={op.nblocks} instances={op.ninst} "
-                  f"(x{op.ninst / max(end - start, 1):.2f} entities) max_inst={op.max_inst} max_nnz={op.max_nnz} max_nown={op.max_nown} "
+                  f"(x{op.ninst / max(end - start, 1):.2f} entities, {op.ndummy} window-padding dummies) max_inst={op.max_inst} max_nnz={op.max_nnz} max_nown={op.max_nown} "
                   f"lds={lds} kbytes={op.kbytes}", file=sys.stderr)
         return geo
 

@@ -184,6 +184,9 @@ int fd_ocrplan_create(const int32_t *rmap_dev, int rarity, int32_t start, int32_
                                                              * then skip the atomics of rows none of them owns --, by the
                                                              * signature of owned rows + node offsets, then by first owned
                                                              * row: conflict-free LDS atomics on structured pieces);
+                                                             * interleave == -1: stencil order grouped by the entity's shape
+                                                             * alone (node offsets from the first owned row, whoever owns
+                                                             * them), then by first owned row;
                                                              * interleave > 1: multiplicative permutation of every instance list;
                                                              * 0: entity order */
 /* The per-(block, staged node) words of the whole-entity owner-computes-rows wrapper in PLAN order (blkoff / list of the row
@@ -227,6 +230,13 @@ int fd_ocrplan_create_ordered(const int32_t *rmap_dev, int rarity, int32_t start
                               fd_stream_t s, fd_ocrplan_t *out);
 int fd_ocrplan_pack(fd_ocrplan_t p, const int32_t *imap_rows_dev, const uint16_t *lmap_dev, int ar,
                     const void *kidx_dev, int kbytes, int ac, const int32_t *node_rowptr_dev, fd_stream_t s);
+/* Conflict-free LDS atomic windows: walks the stencil-ordered instance list of every block and fills the rest of a 16-slot window
+ * with a dummy instance (an entity none of whose rows the block owns: all its contributions are skipped) where the next instance of
+ * the same stencil group would hit an accumulator bank a lane of the window already uses.  rowstart_dev = CSR row starts in the
+ * order the blocks are cut in (node_rowptr, or the prowptr of fd_ocrplan_create_ordered).  Call before fd_ocrplan_info / _arrays;
+ * *ndummy = slots added. */
+int fd_ocrplan_pad_windows(fd_ocrplan_t p, const int32_t *rmap_dev, int rarity, int32_t start, int32_t end,
+                           const int32_t *rowstart_dev, int64_t *ndummy, fd_stream_t s);
 int fd_ocrplan_info(fd_ocrplan_t p, int64_t *ninst, int32_t *max_inst_per_block);
 int fd_ocrplan_arrays(fd_ocrplan_t p, const int32_t **inst_off_dev, const int32_t **inst_off_host,
                       const int32_t **inst_entity_dev, const int32_t **row_block_starts_dev);

@@ -329,11 +329,12 @@ def test_coefficient_arguments_through_the_tensor_wrappers(degree, nq, n, layers
 @pytest.mark.gpu
 @pytest.mark.parametrize("degree,nq,bcs", [(4, 5, True), (2, 3, False), (1, 2, True)])
 def test_single_cell_rows_are_stored_after_zero_and_accumulated_without(degree, nq, bcs, monkeypatch):
-    """After Mat.zero() the tensor-product matrix loop zeroes only the rows shared between cells and stores the others
-    (Parloop._tp_values, fd_csr_zero_rows_except); the values are those of the full-zero route (FDHIP_TP_STORE_SINGLE_ROWS=0) and of
-    the oracle.  Stale contents must not survive, a second loop without zero() adds on top (Mat INC, mat.py:851-855), and a consumer
-    arriving between the partial zero and the loop sees a matrix of zeros."""
+    """FDHIP_TP_STORE_SINGLE_ROWS=1: after Mat.zero() the tensor-product matrix loop zeroes only the rows shared between cells and
+    stores the others (Parloop._tp_values, fd_csr_zero_rows_except); the values are those of the full-zero route and of the oracle.
+    Stale contents must not survive, a second loop without zero() adds on top (Mat INC, mat.py:851-855; atomics on every row), and
+    a consumer arriving between the partial zero and the loop sees a matrix of zeros."""
     from firedrake_amd.configuration import configuration
+    monkeypatch.setitem(configuration, "tp_store_single_rows", 1)      # (off by default: 1 % slower than fill + atomics at C3 size)
     m = fmesh.make_extruded_hex_mesh(3, 3, degree, perturb=0.1)
     prob = forms.HelmholtzHexProblem(m, bcs=bcs, nq=nq)
     ref = _oracle_matrix(m, prob.bc_nodes if bcs else None, prob.kjac)
@@ -346,7 +347,7 @@ def test_single_cell_rows_are_stored_after_zero_and_accumulated_without(degree, 
     assert loop._tp_fresh == 1
     v = mat.csr()[2]
     assert_allclose(v, ref.values, rtol=0, atol=tol)
-    loop()                                    # no zero(): accumulates, the single-cell rows by read-modify-write
+    loop()                                    # no zero(): accumulates
     assert loop._tp_fresh == 0
     twice = mat.csr()[2]
     bcrows = np.zeros(len(v), dtype=bool)

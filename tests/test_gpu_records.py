@@ -188,3 +188,59 @@ def test_deferred_packing_of_a_long_lived_plan(monkeypatch):
         _, _, v = mat.csr()
         assert np.abs(v - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
     assert states == [False, False, False, True, True, True]
+
+
+@pytest.mark.parametrize("numbering", ["lexicographic", "tiled"])
+def test_window_padding_dummies_are_foreign_and_change_nothing(numbering, monkeypatch):
+    """fd_ocrplan_pad_windows: the padded instance lists hold the same real instances in the same order, every dummy is an entity
+    none of whose rows its block owns, no 16-slot window that was padded holds two instances of a stencil group on one accumulator
+    bank -- and the matrix is the oracle's with and without the padding."""
+    monkeypatch.setitem(configuration, "locality_min_entities", 64)
+    m = fmesh.UnitCubeMesh(20, degrees=(1,), perturb=0.1, numbering=numbering)
+    vals, lists = {}, {}
+    for pad in (0, 1):
+        monkeypatch.setitem(configuration, "ocr_pad_windows", pad)
+        prob = forms.PoissonProblem(m, 1, bcs=True)
+        mat, pl = prob.jacobian()
+        for _ in range(2):
+            mat.zero()
+            pl.compute()
+        geo = [g for key, g in pl._prepared["parts"].items() if key[0] == "ocr"][0]
+        op = geo["ocr"]
+        vals[pad] = mat.csr()[2]
+        ent = _down(op.inst_ent, np.int32, (op.ninst,))
+        lists[pad] = (op.inst_off_host.copy(), ent, op.ndummy, op.row_blocks.copy(), geo["row_order"])
+        if pad:
+            mpa = pl.arguments[0]
+            args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
+            ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
+            assert np.abs(vals[1] - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
+            rmap = np.asarray(mpa.maps[0].values_with_halo)
+    assert np.abs(vals[1] - vals[0]).max() <= 1e-13 * np.abs(vals[0]).max()
+    off0, ent0, nd0, rb, ro = lists[0]
+    off1, ent1, nd1, rb1, _ = lists[1]
+    assert nd0 == 0 and nd1 > 0 and len(ent1) == len(ent0) + nd1 and np.array_equal(rb, rb1)
+    pinv = ro.pinv.download(np.int32, (ro.npos,)) if ro is not None else None
+    ndum = 0
+    for b in range(len(off0) - 1):
+        real, padded = ent0[off0[b]:off0[b + 1]], ent1[off1[b]:off1[b + 1]]
+        extra = len(padded) - len(real)
+        if not extra:
+            assert np.array_equal(real, padded)
+            continue
+        # the dummy is the one entity that occurs `extra` times more often than it should (it is foreign: it occurs 0 times in real)
+        cand, counts = np.unique(padded, return_counts=True)
+        d = cand[np.argmax(counts)]
+        assert (real != d).all() and (padded == d).sum() == extra
+        assert np.array_equal(padded[padded != d], real)
+        rows = rmap[d] if pinv is None else pinv[rmap[d]]
+        assert ((rows < rb[b]) | (rows >= rb[b + 1])).all()
+        ndum += extra
+        # dummies only ever fill the tail of a 16-slot window
+        isd = padded == d
+        for w0 in range(0, len(padded), 16):
+            w = isd[w0:w0 + 16]
+            if w.any():
+                first = int(np.argmax(w))
+                assert w[first:].all() and first >= 12
+    assert ndum == nd1

@@ -114,7 +114,7 @@ def test_rows_owned_by_one_cell_are_stored_after_a_zero_and_accumulated_otherwis
     """hex_qk_matrix stores the rows exactly as long as the element matrix is wide (the cell-interior nodes; for Q1 the corners of
     the domain) when the host zeroed only the shared rows (fresh = 1): started from a matrix full of NaNs, every entry must come out
     as the oracle's -- zeros in the dropped boundary rows and columns included.  fresh = 0 on top of earlier values accumulates
-    (Mat INC without a zero(), mat.py:851-855): the same rows are then read-modify-written."""
+    (Mat INC without a zero(), mat.py:851-855), with atomics on every row."""
     m = fmesh.make_extruded_hex_mesh(n, 2, degree, perturb=0.1)
     prob = forms.HelmholtzHexProblem(m, bcs=bcs, nq=nq)
     ref = _oracle_matrix(m, prob.bc_nodes if bcs else None, prob.kjac)

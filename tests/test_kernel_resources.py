@@ -47,7 +47,8 @@ def test_residual_wrappers_stay_within_their_occupancy_step(degree, max_vgprs, m
 
 def test_q4_tensor_wrappers_hold_three_wavefronts_per_simd():
     """C3: the MFMA matrix wrapper (64 accumulator registers per lane) and the action fit 168 registers -- three wavefronts per SIMD,
-    the occupancy the measured 0.66 of the fp64 MFMA peak was taken at."""
+    the occupancy the measured 0.66 of the fp64 MFMA peak was taken at.  The action is COMPILED for three wavefronts (codegen:
+    __launch_bounds__(128, 3), profiles/r4n_action_variants.txt) and may park a few registers in scratch for it."""
     from firedrake_amd import mesh as fmesh
     from firedrake_amd.codegen import generate_tensor_wrapper
     from firedrake_amd.compilation import compile_hip
@@ -55,4 +56,4 @@ def test_q4_tensor_wrappers_hold_three_wavefronts_per_simd():
     for loop in (prob.jac_loop, prob.act_loop):
         src = generate_tensor_wrapper(loop.global_kernel)
         res = kernel_resources(compile_hip(src.source, src.symbol), src.symbol)
-        assert res["scratch"] == 0 and res["occupancy"] >= 3 and res["vgprs"] <= 168, (src.symbol, res)
+        assert res["scratch"] <= (32 if src.mode == "tp_action" else 0) and res["occupancy"] >= 3 and res["vgprs"] <= 168, (src.symbol, res)

@@ -22,6 +22,11 @@ __global__ __launch_bounds__(256) void k(double *out, int iters, int span, int p
                : pat == 4 ? ((threadIdx.x & 15) + 32 * ((threadIdx.x >> 4) + 16 * q)) % span
                : pat == 5 ? ((threadIdx.x & 7) + 32 * ((threadIdx.x >> 3) + 32 * q)) % span
                : pat == 6 ? ((threadIdx.x & 31) + 32 * ((threadIdx.x >> 5) + 8 * q)) % span
+               // 200/201/202: the whole-entity P1 wrapper's windows: rows of 15 doubles at row positions {0..6, 8..14, 16, 17} (two lines of
+               // seven cells of an 8-node-wide box and two cells of a third line: ONE pair of lanes per bank collides twice) / the same
+               // with lanes 14 and 15 of the window idle / 16 consecutive row positions
+               : pat == 200 || pat == 201 ? (15 * ((threadIdx.x & 15) + ((threadIdx.x & 15) >= 7) + ((threadIdx.x & 15) >= 14)) + 1024 * (threadIdx.x >> 4) % 3072 + q) % span
+               : pat == 202 ? (15 * (threadIdx.x & 15) + 1024 * (threadIdx.x >> 4) % 3072 + q) % span
                // 100+s: lane l of every 16-lane window accesses (l & 15) * s (+ window and q offsets that keep the bank): bank function probe
                : (((threadIdx.x & 15) * (pat - 100)) + 1024 * (threadIdx.x >> 4) % 3072 + 32 * q) % span;
     }
@@ -29,7 +34,7 @@ __global__ __launch_bounds__(256) void k(double *out, int iters, int span, int p
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            if (MODE == 0) atomicAdd(&s[idx[q]], 1.0);
+            if (MODE == 0) { if (pat != 201 || (threadIdx.x & 15) < 14) atomicAdd(&s[idx[q]], 1.0); }
             else if (MODE == 1) acc += s[idx[q]];
             else if (MODE == 2) s[idx[q]] += 1.0;
             else if (MODE == 3) atomicAdd(((float *)s) + idx[q], 1.0f);
@@ -75,6 +80,7 @@ int main() {
         run<1>("ds_read_b64 gather", 4096, pat);
         run<2>("plain read+add+write f64", 4096, pat);
     }
+    for (int pat : {200, 201, 202}) run<0>("ds_add_f64 P1 window", 4096, pat);
     for (int st : {1, 2, 3, 4, 8, 16, 32, 64}) {
         run<0>("ds_add_f64 stride", 4096, 100 + st);
         run<1>("ds_read_b64 stride", 4096, 100 + st);
