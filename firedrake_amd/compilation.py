@@ -96,6 +96,7 @@ def compile_hip(source: str, name: str, extra_flags=()) -> str:
         stats["cache_hits"] += 1
         return out
     stats["hipcc_runs"] += 1
+    stats.setdefault("compiled", []).append(f"{name}_{key}")
     # the source goes to a unique temporary name and is renamed into place (pyop2/compilation.py:560-575): ranks that
     # miss the cache together never truncate a file another rank's hipcc is reading
     src = os.path.join(cache, f"{name}_{key}.hip")

@@ -538,15 +538,19 @@ def precompile_all():
     from .codegen import ocr_eligible, sliced_eligible, staged_eligible
     from .kernel import DatKernelArg, GlobalKernel, MapKernelArg, MatKernelArg
     from .op2types import INC, READ
-    out = []
+    jobs = []
 
     def build(g, modes):
-        for mode in modes:
-            try:
-                out.append(g.compile(mode).path)
-            except Exception as exc:                     # (a variant name that no longer fits this kernel's staged maps)
-                import sys
-                print(f"[fdhip] precompile {g.name} {mode}: {exc}", file=sys.stderr)
+        jobs.extend((g, mode) for mode in modes)
+
+    def run(job):
+        g, mode = job
+        try:
+            return g.compile(mode).path
+        except Exception as exc:                         # (a variant name that no longer fits this kernel's staged maps)
+            import sys
+            print(f"[fdhip] precompile {g.name} {mode}: {exc}", file=sys.stderr)
+            return None
 
     for dim, degree in ((2, 1), (3, 1), (3, 2)):
         nd = {(2, 1): 3, (3, 1): 4, (3, 2): 10}[(dim, degree)]
@@ -575,7 +579,11 @@ def precompile_all():
     qm = fmesh.make_quad_mesh(4, perturb=0.1)
     for loop, variant in zip(DGAdvectionProblem(qm).loops, BENCH_VARIANTS["dg_advection"]):
         build(loop.global_kernel, [None, variant])
-    return out
+    # hipcc is a subprocess: the compiles run side by side (a fresh tree: ~70 code objects, seconds each)
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, min(16, len(os.sched_getaffinity(0))))) as pool:
+        return [p for p in pool.map(run, jobs) if p]
 
 
 # ------------------------------------------------------------------------------------------

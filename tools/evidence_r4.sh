@@ -5,6 +5,9 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; mkdir -p gpurun_out
 touch /tmp/r4z_marker
+# the tree ships code objects built by ITS hipcc; this box's compiler (another ROCm point release) hashes differently: build the
+# benchmark wrappers first (parallel, ~20 s) so that the line below times cached first calls, as the next fresh box will
+python -c "from firedrake_amd import forms; print(len(forms.precompile_all()), 'code objects')"
 python bench.py --steps 20 --warmup 5 > gpurun_out/r4z_bench_line.json 2> gpurun_out/r4z_bench_line.err
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r4z_trace -o t -- python $R/bench.py --steps 20 --warmup 5 --cpu-sample 0 --variants "" --traffic off > $R/gpurun_out/r4z_trace.log 2>&1
