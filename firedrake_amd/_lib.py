@@ -100,7 +100,7 @@ SIGNATURES = {
     "fd_matplan_arrays": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
     "fd_matplan_free": (c_int, [c_void_p]),
     "fd_ocrplan_create": (c_int, [c_void_p, c_int, c_int32, c_int32, c_void_p, c_int32, c_int, c_void_p, POINTER(c_void_p)]),
-    "fd_ocrplan_pad_windows": (c_int, [c_void_p, c_void_p, c_int, c_int32, c_int32, c_void_p, POINTER(c_int64), c_void_p]),
+    "fd_ocrplan_pad_windows": (c_int, [c_void_p, c_void_p, c_int, c_int32, c_int32, c_void_p, c_int, POINTER(c_int64), c_void_p]),
     "fd_ocrplan_info": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int32)]),
     "fd_ocrplan_arrays": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
     "fd_ocrplan_free": (c_int, [c_void_p]),

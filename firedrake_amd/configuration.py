@@ -25,7 +25,8 @@ configuration = {
     "flush_batch": _env("FDHIP_FLUSH_BATCH", 4, int),      # flushes through index tables (derived row orders): table loads requested per trip
     "plan_copies": _env("FDHIP_PLAN_COPIES", 1, int),     # READ Dats unchanged between calls are kept in plan order and streamed
     "ocr_pack": _env("FDHIP_OCR_PACK", 1, int),            # bank-aware greedy packing of the instance lists (fd_ocrplan_pack)
-    "ocr_pad_windows": _env("FDHIP_OCR_PAD_WINDOWS", 0, int),   # dummy instances that keep a 16-lane LDS atomic window on distinct banks
+    "ocr_pad_windows": _env("FDHIP_OCR_PAD_WINDOWS", 0, int),   # 16-lane LDS atomic windows on distinct banks: 1 = end a window with dummy instances,
+                                                                 # 2 = with instances from the tail of the block's list (a permutation)
     "ocr_pack_after": _env("FDHIP_OCR_PACK_AFTER", 64, int),   # ... once a plan has been launched this often (0 = when it is built)
     # owner-computes-rows index tables: one bit-packed record per instance (fd_ocr_pack_records; 0 = uint16 / uint8 rows), the
     # diagonal offsets taken from the row node's LDS word, and the flush of a derived row order run-coded (fd_ocr_row_runs)

@@ -894,14 +894,18 @@ __global__ void ocr_pick_dummy(const int32_t *__restrict__ rmap, int ar, int32_t
     dummy[b] = pick;
 }
 
-// one thread per block; emit == 0: count the padded slots into cnt[b]; emit == 1: write the padded list at off[b]
+// one thread per block; emit == 0: count the padded slots into cnt[b]; emit == 1: write the padded list at off[b].
+// fill == 1: instead of dummies the rest of the window is filled with instances from the TAIL of the block's list (the groups that own
+// the fewest rows: they join only the atomics of the rows they own, and their own wavefronts at the end of the list get shorter) --
+// the list is permuted, not lengthened
 __global__ void ocr_pad_windows(const uint64_t *__restrict__ keys, const int32_t *__restrict__ inst_off, const int32_t *__restrict__ inst_ent,
                                 const int32_t *__restrict__ rblk, const int32_t *__restrict__ rowstart, int32_t nblocks,
-                                const int32_t *__restrict__ dummy, int emit, int32_t *__restrict__ cnt,
+                                const int32_t *__restrict__ dummy, int emit, int fill, int32_t *__restrict__ cnt,
                                 const int32_t *__restrict__ off, int32_t *__restrict__ out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblocks) return;
-    const int32_t o0 = inst_off[b], o1 = inst_off[b + 1], n0 = rblk[b], d = dummy[b];
+    const int32_t o0 = inst_off[b], n0 = rblk[b], d = fill ? 0 : dummy[b];
+    int32_t o1 = inst_off[b + 1];                            // (fill: the tail shrinks as instances are taken from it)
     const int32_t base = emit ? off[b] : 0, rs0 = rowstart[n0];
     int32_t pos = 0;
     uint32_t used = 0;
@@ -912,7 +916,11 @@ __global__ void ocr_pad_windows(const uint64_t *__restrict__ keys, const int32_t
         const int w = pos & 15;
         if (w == 0 || grp != prev) used = 0;             // (residues of another group say nothing about this one's banks)
         if (d >= 0 && grp == prev && w >= FD_PAD_MIN && ((used >> res) & 1u)) {
-            for (int q = w; q < 16; ++q, ++pos) if (emit) out[base + pos] = d;
+            for (int q = w; q < 16; ++q) {
+                if (fill) { if (o1 - 1 <= j) break; --o1; if (emit) out[base + pos] = inst_ent[o1]; }
+                else if (emit) out[base + pos] = d;
+                ++pos;
+            }
             used = 0;
         }
         if (emit) out[base + pos] = inst_ent[j];
@@ -1488,7 +1496,7 @@ int fd_ocrplan_pack(fd_ocrplan_t p, const int32_t *imap_r_dev, const uint16_t *l
 }
 
 int fd_ocrplan_pad_windows(fd_ocrplan_t p, const int32_t *rmap_dev, int ar, int32_t start, int32_t end, const int32_t *rowstart_dev,
-                           int64_t *ndummy, fd_stream_t s_) {
+                           int mode, int64_t *ndummy, fd_stream_t s_) {
     if (!p || !rmap_dev || !rowstart_dev || ar <= 0) FD_FAIL("fd_ocrplan_pad_windows: bad arguments");
     if (ndummy) *ndummy = 0;
     if (p->ninst <= 0 || p->nblocks <= 0 || end <= start || p->chunk_role) return 0;
@@ -1508,9 +1516,20 @@ int fd_ocrplan_pad_windows(fd_ocrplan_t p, const int32_t *rmap_dev, int ar, int3
     FD_CHECK_LAUNCH();
     hipLaunchKernelGGL(ocr_pick_dummy, dim3((nb + 255) / 256), dim3(256), 0, s, rmap_dev, ar, start, end, p->rblk, nb, p->pinv, p->npos, dummy);
     FD_CHECK_LAUNCH();
+    if (mode == 2) {                                      // fill from the tail: a permutation of every block's list
+        FD_HIP(hipMalloc(&out, (size_t)nu * 4));
+        hipLaunchKernelGGL(ocr_pad_windows, dim3((nb + 63) / 64), dim3(64), 0, s, keys, p->inst_off, p->inst_ent, p->rblk, rowstart_dev, nb, dummy,
+                           1, 1, nullptr, p->inst_off, out);
+        FD_CHECK_LAUNCH();
+        FD_HIP(hipStreamSynchronize(s));
+        FD_HIP(hipFree(p->inst_ent));
+        p->inst_ent = out;
+        FD_HIP(hipFree(keys)); FD_HIP(hipFree(dummy)); FD_HIP(hipFree(cnt)); FD_HIP(hipFree(noff));
+        return 0;
+    }
     FD_HIP(hipMemsetAsync(cnt, 0, ((size_t)nb + 1) * 4, s));
     hipLaunchKernelGGL(ocr_pad_windows, dim3((nb + 63) / 64), dim3(64), 0, s, keys, p->inst_off, p->inst_ent, p->rblk, rowstart_dev, nb, dummy, 0,
-                       cnt, nullptr, nullptr);
+                       0, cnt, nullptr, nullptr);
     FD_CHECK_LAUNCH();
     size_t tb = 0;
     FD_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt, noff, nb + 1, s));
@@ -1522,7 +1541,7 @@ int fd_ocrplan_pad_windows(fd_ocrplan_t p, const int32_t *rmap_dev, int ar, int3
     if ((int64_t)total > nu) {
         FD_HIP(hipMalloc(&out, (size_t)total * 4));
         hipLaunchKernelGGL(ocr_pad_windows, dim3((nb + 63) / 64), dim3(64), 0, s, keys, p->inst_off, p->inst_ent, p->rblk, rowstart_dev, nb, dummy,
-                           1, nullptr, noff, out);
+                           1, 0, nullptr, noff, out);
         FD_CHECK_LAUNCH();
         FD_HIP(hipMemcpyAsync(p->inst_off_host, noff, ((size_t)nb + 1) * 4, hipMemcpyDeviceToHost, s));
         FD_HIP(hipStreamSynchronize(s));

@@ -1915,7 +1915,8 @@ class OcrPlan:
             nd_ = ctypes.c_int64()
             sparsity._build()
             _lib.call("fd_ocrplan_pad_windows", self.h, rmap._base()._dev_values(), rmap.arity, int(start), int(end),
-                      row_order.prowptr.ptr if row_order is not None else sparsity._node_rowptr.ptr, ctypes.byref(nd_), None)
+                      row_order.prowptr.ptr if row_order is not None else sparsity._node_rowptr.ptr,
+                      int(configuration["ocr_pad_windows"]), ctypes.byref(nd_), None)
             self.ndummy = nd_.value
         ni, mi = ctypes.c_int64(), ctypes.c_int32()
         _lib.call("fd_ocrplan_info", self.h, ctypes.byref(ni), ctypes.byref(mi))

@@ -233,10 +233,11 @@ int fd_ocrplan_pack(fd_ocrplan_t p, const int32_t *imap_rows_dev, const uint16_t
 /* Conflict-free LDS atomic windows: walks the stencil-ordered instance list of every block and fills the rest of a 16-slot window
  * with a dummy instance (an entity none of whose rows the block owns: all its contributions are skipped) where the next instance of
  * the same stencil group would hit an accumulator bank a lane of the window already uses.  rowstart_dev = CSR row starts in the
- * order the blocks are cut in (node_rowptr, or the prowptr of fd_ocrplan_create_ordered).  Call before fd_ocrplan_info / _arrays;
- * *ndummy = slots added. */
+ * order the blocks are cut in (node_rowptr, or the prowptr of fd_ocrplan_create_ordered).  mode 1: dummies (*ndummy = slots added);
+ * mode 2: the window is filled with instances taken from the tail of the block's list instead (the groups owning the fewest rows): a
+ * permutation, nothing added.  Call before fd_ocrplan_info / _arrays. */
 int fd_ocrplan_pad_windows(fd_ocrplan_t p, const int32_t *rmap_dev, int rarity, int32_t start, int32_t end,
-                           const int32_t *rowstart_dev, int64_t *ndummy, fd_stream_t s);
+                           const int32_t *rowstart_dev, int mode, int64_t *ndummy, fd_stream_t s);
 int fd_ocrplan_info(fd_ocrplan_t p, int64_t *ninst, int32_t *max_inst_per_block);
 int fd_ocrplan_arrays(fd_ocrplan_t p, const int32_t **inst_off_dev, const int32_t **inst_off_host,
                       const int32_t **inst_entity_dev, const int32_t **row_block_starts_dev);

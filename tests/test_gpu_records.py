@@ -191,14 +191,16 @@ def test_deferred_packing_of_a_long_lived_plan(monkeypatch):
 
 
 @pytest.mark.parametrize("numbering", ["lexicographic", "tiled"])
-def test_window_padding_dummies_are_foreign_and_change_nothing(numbering, monkeypatch):
-    """fd_ocrplan_pad_windows: the padded instance lists hold the same real instances in the same order, every dummy is an entity
-    none of whose rows its block owns, no 16-slot window that was padded holds two instances of a stencil group on one accumulator
-    bank -- and the matrix is the oracle's with and without the padding."""
+@pytest.mark.parametrize("mode", [1, 2])
+def test_window_padding_dummies_are_foreign_and_change_nothing(numbering, mode, monkeypatch):
+    """fd_ocrplan_pad_windows.  mode 1: the padded instance lists hold the same real instances in the same order, every dummy is an
+    entity none of whose rows its block owns and dummies only fill the tail of a 16-slot window.  mode 2: the windows are filled with
+    instances from the tail of the block's list -- every block's list is a permutation of the unpadded one.  Either way the matrix
+    is the oracle's."""
     monkeypatch.setitem(configuration, "locality_min_entities", 64)
     m = fmesh.UnitCubeMesh(20, degrees=(1,), perturb=0.1, numbering=numbering)
     vals, lists = {}, {}
-    for pad in (0, 1):
+    for pad in (0, mode):
         monkeypatch.setitem(configuration, "ocr_pad_windows", pad)
         prob = forms.PoissonProblem(m, 1, bcs=True)
         mat, pl = prob.jacobian()
@@ -214,12 +216,22 @@ def test_window_padding_dummies_are_foreign_and_change_nothing(numbering, monkey
             mpa = pl.arguments[0]
             args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
             ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
-            assert np.abs(vals[1] - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
+            assert np.abs(vals[pad] - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
             rmap = np.asarray(mpa.maps[0].values_with_halo)
-    assert np.abs(vals[1] - vals[0]).max() <= 1e-13 * np.abs(vals[0]).max()
+    assert np.abs(vals[mode] - vals[0]).max() <= 1e-13 * np.abs(vals[0]).max()
     off0, ent0, nd0, rb, ro = lists[0]
-    off1, ent1, nd1, rb1, _ = lists[1]
-    assert nd0 == 0 and nd1 > 0 and len(ent1) == len(ent0) + nd1 and np.array_equal(rb, rb1)
+    off1, ent1, nd1, rb1, _ = lists[mode]
+    assert nd0 == 0 and np.array_equal(rb, rb1)
+    if mode == 2:
+        assert nd1 == 0 and np.array_equal(off0, off1)
+        moved = 0
+        for b in range(len(off0) - 1):
+            real, perm = ent0[off0[b]:off0[b + 1]], ent1[off1[b]:off1[b + 1]]
+            assert np.array_equal(np.sort(real), np.sort(perm))
+            moved += int((real != perm).any())
+        assert moved > 0
+        return
+    assert nd1 > 0 and len(ent1) == len(ent0) + nd1
     pinv = ro.pinv.download(np.int32, (ro.npos,)) if ro is not None else None
     ndum = 0
     for b in range(len(off0) - 1):

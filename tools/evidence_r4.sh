@@ -34,7 +34,15 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_INSTS_VALU_
 done
 cd $R
 { for k in wrap_helmholtz_q4_hex_jacobian wrap_helmholtz_q4_hex_action; do echo "== $k: bench.py --workload c3 (n = 32)"; python tools/pmc_summary.py $k gpurun_out/r4zpmc_c3_*/; done; } >> gpurun_out/r4z_pmc_summary.txt 2>&1
-rm -rf gpurun_out/r4zpmc_c3_* gpurun_out/r4z_trace
+# the Q4 action at n = 64 (16.97 M DoFs), limiter counters
+cd /tmp
+for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAVES SQ_WAIT_INST_LDS SQ_WAIT_ANY"; do
+  name=$(echo $set | tr ' ' '_' | cut -c1-40)
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/r4zpmc_act64_$name -o p -- python $R/tools/time_action.py 64 > $R/gpurun_out/r4zpmc_act64_$name.log 2>&1
+done
+cd $R
+{ echo "== wrap_helmholtz_q4_hex_action: tools/time_action.py 64 (n = 64)"; python tools/pmc_summary.py wrap_helmholtz_q4_hex_action gpurun_out/r4zpmc_act64_*/; } >> gpurun_out/r4z_pmc_summary.txt 2>&1
+rm -rf gpurun_out/r4zpmc_c3_* gpurun_out/r4zpmc_act64_* gpurun_out/r4z_trace
 timeout 900 python -m pytest tests -q -m gpu 2>&1 | grep -v "Warning\|getlimits\|setattr\|_float_to_str" | tail -12 > gpurun_out/r4z_gputests_tail.txt
 # the code objects this box compiled (tests + bench): back into the tree's cache so the next fresh box starts without hipcc
 mkdir -p gpurun_out/r4z_cache
