@@ -58,6 +58,7 @@ SIGNATURES = {
     "fd_kernel_launch": (c_int, [c_void_p, c_int32, c_int32, POINTER(c_void_p), c_int, c_int, c_int, c_int,
                                  c_size_t, c_void_p]),
     "fd_kd_order": (c_int, [c_void_p, c_int, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int32, POINTER(c_int32), c_void_p]),
+    "fd_leaf_labels": (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
     "fd_group_entities": (c_int, [c_void_p, c_int, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "fd_invert_permutation": (c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
     "fd_row_order_tables": (c_int, [c_int32, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -88,7 +89,8 @@ SIGNATURES = {
                                     c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "fd_ocr_row_runs": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, POINTER(c_int32),
                                 POINTER(c_int32), c_void_p]),
-    "fd_ocrplan_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "fd_ocrplan_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "fd_permute_rows": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p]),
     "fd_plan_set_lane_order": (c_int, [c_void_p, c_int, c_void_p]),
     "fd_plan_block_starts": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int32)]),
     "fd_plan_info": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int64)]),

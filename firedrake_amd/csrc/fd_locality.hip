@@ -249,7 +249,31 @@ template <class K, class V> int sort_pairs(K *keys, V *vals, int64_t n, int end_
 
 }  // namespace
 
+// label[order[i]] = leaf of position i (starts[l] <= i < starts[l + 1]): the node labels fd_group_entities groups entities by
+__global__ void lo_leaf_labels(const int32_t *__restrict__ order, int64_t n, const int32_t *__restrict__ starts, int32_t nleaves,
+                               int32_t *__restrict__ label) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int lo = 0, hi = nleaves - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (starts[mid] <= i) lo = mid; else hi = mid - 1; }
+        label[order[i]] = lo;
+    }
+}
+
 extern "C" {
+
+int fd_leaf_labels(const int32_t *order_dev, int64_t n, const int32_t *leaf_starts_host, int32_t nleaves, int32_t *label_dev, fd_stream_t s_) {
+    if (!order_dev || !leaf_starts_host || !label_dev || n < 0 || nleaves < 1) FD_FAIL("fd_leaf_labels: bad arguments");
+    if (n == 0) return 0;
+    hipStream_t s = fd::st(s_);
+    int32_t *starts = nullptr;
+    FD_HIP(hipMalloc(&starts, ((size_t)nleaves + 1) * 4));
+    FD_HIP(hipMemcpyAsync(starts, leaf_starts_host, ((size_t)nleaves + 1) * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(lo_leaf_labels, dim3(lo_grid(n)), dim3(256), 0, s, order_dev, n, starts, nleaves, label_dev);
+    FD_CHECK_LAUNCH();
+    FD_HIP(hipStreamSynchronize(s));
+    FD_HIP(hipFree(starts));
+    return 0;
+}
 
 int fd_group_entities(const int32_t *map_dev, int arity, int32_t start, int32_t end, const int32_t *label_dev, int32_t nnodes,
                       int32_t nlabels, int32_t *order_dev, int32_t *counts_host, fd_stream_t s_) {

@@ -947,7 +947,7 @@ constexpr int PACK_CHUNK = 128;      // instances per chunk = candidates a slot 
 
 __global__ __launch_bounds__(64) void ocr_pack_k(const int32_t *__restrict__ chunk_block, const int32_t *__restrict__ chunk_first,
                                                  const int32_t *__restrict__ chunk_len, int64_t nchunks,
-                                                 const int32_t *__restrict__ ent_in, int32_t *__restrict__ ent_out,
+                                                 const int32_t *__restrict__ ent_in, int32_t *__restrict__ ent_out, int32_t *__restrict__ perm,
                                                  const int32_t *__restrict__ imap_r, const uint16_t *__restrict__ lmap,
                                                  const unsigned char *__restrict__ kidx8, const unsigned short *__restrict__ kidx16,
                                                  int ar, int ac, const int32_t *__restrict__ rblk, const int32_t *__restrict__ rowptr,
@@ -962,7 +962,7 @@ __global__ __launch_bounds__(64) void ocr_pack_k(const int32_t *__restrict__ chu
     for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const int b = chunk_block[c], o = chunk_first[c], n = chunk_len[c];
         if (n <= window) {                                   // nothing to gain: keep the order
-            for (int q = lane; q < n; q += 64) ent_out[o + q] = ent_in[o + q];
+            for (int q = lane; q < n; q += 64) { ent_out[o + q] = ent_in[o + q]; if (perm) perm[o + q] = o + q; }
             continue;
         }
         const int32_t n0 = rblk[b], n1 = rblk[b + 1];
@@ -1014,12 +1014,162 @@ __global__ __launch_bounds__(64) void ocr_pack_k(const int32_t *__restrict__ chu
             }
             const int chosen = bl;
             if ((chosen & 63) == lane) { if (chosen >= 64) placed1 = true; else placed0 = true; }
-            if (lane == 0) ent_out[o + p] = ent_in[o + chosen];
+            if (lane == 0) { ent_out[o + p] = ent_in[o + chosen]; if (perm) perm[o + p] = o + chosen; }
             __syncthreads();
             const unsigned char *s = sig + (size_t)chosen * ns;
             for (int q = lane; q < ar * ac; q += 64) { const unsigned char bk = s[ar + q]; if (bk != 0xff) amask[q] |= 1u << bk; }
             if (lane < ar) { if (gown[lane * 32 + s[lane]] == 0xffffu) gown[lane * 32 + s[lane]] = gaddr[chosen * ar + lane]; }
         }
+    }
+}
+
+// The same scheduler with the candidates' costs kept in registers (round 4).  The kernel above re-evaluates both candidates of a
+// lane for every slot -- 40 byte reads of LDS each -- although placing one instance changes a candidate's cost only where it sets a
+// bank bit (or takes a free gather bank) that was clear: the lanes that hold the chosen instance's bytes publish exactly those
+// ("newly used bank of atomic q" / "new holder of gather bank i", 0xfe = nothing new) and every candidate adds the bytes of its
+// own signature that match (zero bytes of an XOR, four at a time).  Same costs, same ties, same order out -- the plan of C2 in
+// 12 ms instead of 40.  NSW = 32-bit words of atomic bank bytes per instance (ar * ac <= 32), ar <= 8.
+__device__ __forceinline__ int pk_zero_bytes(uint32_t x) {
+    uint32_t t = (x & 0x7f7f7f7fu) + 0x7f7f7f7fu;
+    t = ~(t | x | 0x7f7f7f7fu);
+    return __popc(t);
+}
+
+template <int NSW>
+__global__ __launch_bounds__(64) void ocr_pack2_k(const int32_t *__restrict__ chunk_block, const int32_t *__restrict__ chunk_first,
+                                                  const int32_t *__restrict__ chunk_len, int64_t nchunks,
+                                                  const int32_t *__restrict__ ent_in, int32_t *__restrict__ ent_out, int32_t *__restrict__ perm,
+                                                  const int32_t *__restrict__ imap_r, const uint16_t *__restrict__ lmap,
+                                                  const unsigned char *__restrict__ kidx8, const unsigned short *__restrict__ kidx16,
+                                                  int ar, int ac, const int32_t *__restrict__ rblk, const int32_t *__restrict__ rowptr,
+                                                  const int32_t *__restrict__ pinv, int32_t npos) {
+    __shared__ uint32_t s_at[PACK_CHUNK][NSW];          // atomic bank bytes of every candidate (0xff = no access)
+    __shared__ uint32_t s_gb[PACK_CHUNK][2];            // gather bank bytes
+    __shared__ uint16_t s_ga[PACK_CHUNK][8];            // gather addresses (local node ids)
+    __shared__ uint32_t s_amask[NSW * 4];               // banks the window already uses, per atomic
+    __shared__ uint16_t s_gown[8][32];                  // address held by a gather bank (0xffff = free)
+    __shared__ uint32_t s_newat[NSW], s_newgb[2];
+    __shared__ uint16_t s_newga[8];
+    const int lane = threadIdx.x, nat = ar * ac;
+    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int b = chunk_block[c], o = chunk_first[c], n = chunk_len[c];
+        if (n <= 16) {                                       // nothing to gain: keep the order
+            for (int q = lane; q < n; q += 64) { ent_out[o + q] = ent_in[o + q]; if (perm) perm[o + q] = o + q; }
+            continue;
+        }
+        const int32_t n0 = rblk[b], n1 = rblk[b + 1];
+        const int32_t r0 = rowptr[n0];
+        uint32_t at[2][NSW], gb[2][2];
+        uint16_t ga[2][8];
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int inst = lane + 64 * h;
+#pragma unroll
+            for (int w = 0; w < NSW; ++w) at[h][w] = 0xffffffffu;
+            gb[h][0] = gb[h][1] = 0xffffffffu;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ga[h][i] = 0;
+            if (inst < n) {
+                const int64_t t = (int64_t)o + inst;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (i >= ar) break;
+                    const unsigned short l = lmap[t * ar + i];
+                    ga[h][i] = l;
+                    gb[h][i >> 2] = (gb[h][i >> 2] & ~(0xffu << (8 * (i & 3)))) | ((uint32_t)(l & 31) << (8 * (i & 3)));
+                    const int32_t g = row_position(pinv, npos, imap_r[t * ar + i]);
+                    if (g >= n0 && g < n1) {
+                        const int base = rowptr[g] - r0;
+                        for (int j = 0; j < ac; ++j) {
+                            const int q = i * ac + j;
+                            const int k = kidx8 ? (int)kidx8[t * nat + q] : (int)kidx16[t * nat + q];
+                            const uint32_t bk = (uint32_t)((base + k) & 15);
+#pragma unroll
+                            for (int w = 0; w < NSW; ++w)
+                                if (w == (q >> 2)) at[h][w] = (at[h][w] & ~(0xffu << (8 * (q & 3)))) | (bk << (8 * (q & 3)));
+                        }
+                    }
+                }
+#pragma unroll
+                for (int w = 0; w < NSW; ++w) s_at[inst][w] = at[h][w];
+                s_gb[inst][0] = gb[h][0]; s_gb[inst][1] = gb[h][1];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s_ga[inst][i] = ga[h][i];
+            }
+        }
+        bool placed[2] = {lane >= n, lane + 64 >= n};
+        int cost[2] = {0, 0};
+        for (int p = 0; p < n; ++p) {
+            if ((p & 15) == 0) {
+                cost[0] = cost[1] = 0;
+                __syncthreads();
+                if (lane < NSW * 4) s_amask[lane] = 0u;
+                for (int q = lane; q < 8 * 32; q += 64) (&s_gown[0][0])[q] = 0xffffu;
+            }
+            __syncthreads();
+            int best = 0x7fffffff, bl = 0x7fffffff;
+            if (!placed[0]) { best = cost[0]; bl = lane; }
+            if (!placed[1] && cost[1] < best) { best = cost[1]; bl = lane + 64; }
+            for (int d = 32; d > 0; d >>= 1) {
+                const int oc = __shfl_xor(best, d, 64), ol = __shfl_xor(bl, d, 64);
+                if (oc < best || (oc == best && ol < bl)) { best = oc; bl = ol; }
+            }
+            const int chosen = bl;
+            if ((chosen & 63) == lane) placed[chosen >> 6] = true;
+            if (lane == 0) { ent_out[o + p] = ent_in[o + chosen]; if (perm) perm[o + p] = o + chosen; }
+            // what the chosen instance adds to the window: one lane per atomic byte, one per gather component
+            if (lane < NSW * 4) {
+                unsigned char nb = 0xfe;
+                if (lane < nat) {
+                    const uint32_t bk = (s_at[chosen][lane >> 2] >> (8 * (lane & 3))) & 0xffu;
+                    if (bk != 0xffu) {
+                        const uint32_t m = s_amask[lane];
+                        if (!((m >> bk) & 1u)) { s_amask[lane] = m | (1u << bk); nb = (unsigned char)bk; }
+                    }
+                }
+                ((unsigned char *)s_newat)[lane] = nb;
+            } else if (lane >= 32 && lane < 40) {
+                const int i = lane - 32;
+                unsigned char nb = 0xfe;
+                if (i < ar) {
+                    const uint32_t gk = (s_gb[chosen][i >> 2] >> (8 * (i & 3))) & 0xffu;
+                    if (s_gown[i][gk] == 0xffffu) { const uint16_t a = s_ga[chosen][i]; s_gown[i][gk] = a; s_newga[i] = a; nb = (unsigned char)gk; }
+                }
+                ((unsigned char *)s_newgb)[i] = nb;
+            }
+            __syncthreads();
+            uint32_t na[NSW];
+#pragma unroll
+            for (int w = 0; w < NSW; ++w) na[w] = s_newat[w];
+            const uint32_t ng0 = s_newgb[0], ng1 = s_newgb[1];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (placed[h]) continue;
+                int add = 0;
+#pragma unroll
+                for (int w = 0; w < NSW; ++w) add += pk_zero_bytes(at[h][w] ^ na[w]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t mine = (gb[h][i >> 2] >> (8 * (i & 3))) & 0xffu, nw = ((i < 4 ? ng0 : ng1) >> (8 * (i & 3))) & 0xffu;
+                    if (mine == nw && ga[h][i] != s_newga[i]) add += 3;       // one extra pass per component
+                }
+                cost[h] += add;
+            }
+        }
+    }
+}
+
+__global__ void iota_k(int32_t *__restrict__ out, int64_t n) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) out[t] = (int32_t)t;
+}
+
+template <class T>
+__global__ void permute_rows_k(const T *__restrict__ src, int units, const int32_t *__restrict__ perm, int64_t n, T *__restrict__ dst) {
+    const int64_t total = n * units;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = t / units;
+        dst[t] = src[(int64_t)perm[k] * units + (t - k * units)];
     }
 }
 
@@ -1456,42 +1606,86 @@ static int ocrplan_build(const int32_t *rmap_dev, int ar, int32_t start, int32_t
 }
 
 int fd_ocrplan_pack(fd_ocrplan_t p, const int32_t *imap_r_dev, const uint16_t *lmap_dev, int ar, const void *kidx_dev, int kbytes,
-                    int ac, const int32_t *node_rowptr_dev, fd_stream_t s_) {
+                    int ac, const int32_t *node_rowptr_dev, int32_t *perm_out_dev, fd_stream_t s_) {
     if (!p || !imap_r_dev || !lmap_dev || !kidx_dev || !node_rowptr_dev || ar <= 0 || ac <= 0 || (kbytes != 1 && kbytes != 2))
         FD_FAIL("fd_ocrplan_pack: bad arguments");
     if (p->nblocks == 0 || p->ninst == 0) return 0;
     const int ns = ar + ar * ac;
-    if (ns > PACK_MAXSIG) return 0;                     // large element matrices: keep the incoming order
     hipStream_t s = fd::st(s_);
+    if (ns > PACK_MAXSIG) {                               // large element matrices: keep the incoming order
+        if (perm_out_dev) { hipLaunchKernelGGL(iota_k, dim3(mp_grid(p->ninst)), dim3(256), 0, s, perm_out_dev, p->ninst); FD_CHECK_LAUNCH(); }
+        return 0;
+    }
     const int window = 16;
     // chunks of PACK_CHUNK consecutive instances, never across a block boundary
-    std::vector<int32_t> cb, cf, cl;
-    for (int32_t b = 0; b < p->nblocks; ++b)
-        for (int32_t o = p->inst_off_host[b]; o < p->inst_off_host[b + 1]; o += PACK_CHUNK) {
-            cb.push_back(b); cf.push_back(o);
-            cl.push_back(std::min<int32_t>(PACK_CHUNK, p->inst_off_host[b + 1] - o));
-        }
-    const int64_t nchunks = (int64_t)cb.size();
+    int64_t nchunks = 0;
+    for (int32_t b = 0; b < p->nblocks; ++b) nchunks += (p->inst_off_host[b + 1] - p->inst_off_host[b] + PACK_CHUNK - 1) / PACK_CHUNK;
     if (nchunks == 0) return 0;
-    int32_t *dcb = nullptr, *dcf = nullptr, *dcl = nullptr, *out = nullptr;
-    FD_HIP(hipMalloc(&dcb, (size_t)nchunks * 4)); FD_HIP(hipMalloc(&dcf, (size_t)nchunks * 4)); FD_HIP(hipMalloc(&dcl, (size_t)nchunks * 4));
-    FD_HIP(hipMemcpyAsync(dcb, cb.data(), (size_t)nchunks * 4, hipMemcpyHostToDevice, s));
-    FD_HIP(hipMemcpyAsync(dcf, cf.data(), (size_t)nchunks * 4, hipMemcpyHostToDevice, s));
-    FD_HIP(hipMemcpyAsync(dcl, cl.data(), (size_t)nchunks * 4, hipMemcpyHostToDevice, s));
-    const size_t lds = (((size_t)PACK_CHUNK * ns + 15) & ~(size_t)15) + (size_t)PACK_CHUNK * ar * 2 + PACK_MAXSIG * 4 + (size_t)ar * 32 * 2 + 64;
-    if (lds > 48 * 1024)
-        FD_HIP(hipFuncSetAttribute((const void *)ocr_pack_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    std::vector<int32_t> ch((size_t)nchunks * 3);
+    int32_t *cb = ch.data(), *cf = cb + nchunks, *cl = cf + nchunks;
+    int64_t c = 0;
+    for (int32_t b = 0; b < p->nblocks; ++b)
+        for (int32_t o = p->inst_off_host[b]; o < p->inst_off_host[b + 1]; o += PACK_CHUNK, ++c) {
+            cb[c] = b; cf[c] = o;
+            cl[c] = std::min<int32_t>(PACK_CHUNK, p->inst_off_host[b + 1] - o);
+        }
+    int32_t *dch = nullptr, *out = nullptr;
+    FD_HIP(hipMalloc(&dch, (size_t)nchunks * 12));
+    FD_HIP(hipMemcpyAsync(dch, ch.data(), (size_t)nchunks * 12, hipMemcpyHostToDevice, s));
+    const int32_t *dcb = dch, *dcf = dch + nchunks, *dcl = dch + 2 * nchunks;
     FD_HIP(hipMalloc(&out, (size_t)p->ninst * 4));
     const int64_t grid = nchunks < 256 * 64 ? nchunks : 256 * 64;
-    hipLaunchKernelGGL(ocr_pack_k, dim3((unsigned)grid), dim3(64), lds, s, dcb, dcf, dcl, nchunks, p->inst_ent, out, imap_r_dev, lmap_dev,
-                       kbytes == 1 ? (const unsigned char *)kidx_dev : nullptr,
-                       kbytes == 2 ? (const unsigned short *)kidx_dev : nullptr, ar, ac, p->rblk,
-                       p->prowptr ? p->prowptr : node_rowptr_dev, window, p->pinv, p->npos);
+    const unsigned char *k8 = kbytes == 1 ? (const unsigned char *)kidx_dev : nullptr;
+    const unsigned short *k16 = kbytes == 2 ? (const unsigned short *)kidx_dev : nullptr;
+    const int32_t *rowstart = p->prowptr ? p->prowptr : node_rowptr_dev;
+    const char *lg = getenv("FDHIP_PACK_LEGACY");             // (read per call: the tests compare the two schedulers in one process)
+    const bool legacy = lg && atoi(lg) != 0;
+    const int nsw = (ar * ac + 3) / 4;
+    if (!legacy && ar <= 8 && nsw <= 8) {
+#define FD_PACK2(N) hipLaunchKernelGGL(ocr_pack2_k<N>, dim3((unsigned)grid), dim3(64), 0, s, dcb, dcf, dcl, nchunks, p->inst_ent, out, perm_out_dev, \
+                                       imap_r_dev, lmap_dev, k8, k16, ar, ac, p->rblk, rowstart, p->pinv, p->npos)
+        switch (nsw) {
+        case 1: FD_PACK2(1); break; case 2: FD_PACK2(2); break; case 3: FD_PACK2(3); break; case 4: FD_PACK2(4); break;
+        case 5: FD_PACK2(5); break; case 6: FD_PACK2(6); break; case 7: FD_PACK2(7); break; default: FD_PACK2(8); break;
+        }
+#undef FD_PACK2
+    } else {
+        const size_t lds = (((size_t)PACK_CHUNK * ns + 15) & ~(size_t)15) + (size_t)PACK_CHUNK * ar * 2 + PACK_MAXSIG * 4 + (size_t)ar * 32 * 2 + 64;
+        if (lds > 48 * 1024)
+            FD_HIP(hipFuncSetAttribute((const void *)ocr_pack_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(ocr_pack_k, dim3((unsigned)grid), dim3(64), lds, s, dcb, dcf, dcl, nchunks, p->inst_ent, out, perm_out_dev, imap_r_dev,
+                           lmap_dev, k8, k16, ar, ac, p->rblk, rowstart, window, p->pinv, p->npos);
+    }
     FD_CHECK_LAUNCH();
     FD_HIP(hipStreamSynchronize(s));
-    FD_HIP(hipFree(dcb)); FD_HIP(hipFree(dcf)); FD_HIP(hipFree(dcl));
+    FD_HIP(hipFree(dch));
     FD_HIP(hipFree(p->inst_ent));
     p->inst_ent = out;
+    return 0;
+}
+
+// rows[t] <- rows[perm[t]] for n rows of rowbytes bytes each (the per-instance tables of a plan after fd_ocrplan_pack: the packer
+// permutes instances inside their blocks, so the block node lists stay and only the rows move)
+int fd_permute_rows(void *rows_dev, int rowbytes, const int32_t *perm_dev, int64_t n, fd_stream_t s_) {
+    if (!rows_dev || !perm_dev || rowbytes <= 0 || n < 0) FD_FAIL("fd_permute_rows: bad arguments");
+    if (n == 0) return 0;
+    hipStream_t s = fd::st(s_);
+    void *tmp = nullptr;
+    const size_t bytes = (size_t)n * rowbytes;
+    FD_HIP(hipMalloc(&tmp, bytes));
+    if (rowbytes % 4 == 0)
+        hipLaunchKernelGGL(permute_rows_k<uint32_t>, dim3(mp_grid(n * (rowbytes / 4))), dim3(256), 0, s, (const uint32_t *)rows_dev, rowbytes / 4,
+                           perm_dev, n, (uint32_t *)tmp);
+    else if (rowbytes % 2 == 0)
+        hipLaunchKernelGGL(permute_rows_k<uint16_t>, dim3(mp_grid(n * (rowbytes / 2))), dim3(256), 0, s, (const uint16_t *)rows_dev, rowbytes / 2,
+                           perm_dev, n, (uint16_t *)tmp);
+    else
+        hipLaunchKernelGGL(permute_rows_k<uint8_t>, dim3(mp_grid(n * rowbytes)), dim3(256), 0, s, (const uint8_t *)rows_dev, rowbytes, perm_dev, n,
+                           (uint8_t *)tmp);
+    FD_CHECK_LAUNCH();
+    FD_HIP(hipMemcpyAsync(rows_dev, tmp, bytes, hipMemcpyDeviceToDevice, s));
+    FD_HIP(hipStreamSynchronize(s));
+    FD_HIP(hipFree(tmp));
     return 0;
 }
 

@@ -1828,6 +1828,25 @@ class Sparsity:
         self._build()
         return self._rowptr.download(np.int32, (self.nrows + 1,))
 
+    def _node_rowptr_host(self):
+        """Host copy of the node-level row starts (read-only; the pattern of a built Sparsity never changes): the plan builders look
+        at it several times per plan (block cuts, accumulator sizes, longest row)."""
+        self._build()
+        h = self.__dict__.get("_node_rowptr_h")
+        if h is None:
+            h = self._node_rowptr.download(np.int32, (self.dsets[0].set.total_size + 1,))
+            h.setflags(write=False)
+            self.__dict__["_node_rowptr_h"] = h
+        return h
+
+    def _max_node_rowlen(self):
+        """Longest node row (cached like the host row starts)."""
+        m = self.__dict__.get("_max_node_rowlen_v")
+        if m is None:
+            rp = self._node_rowptr_host()
+            m = self.__dict__["_max_node_rowlen_v"] = int(np.diff(rp).max()) if len(rp) > 1 else 0
+        return m
+
     @property
     def colidx(self):
         self._build()
@@ -1926,7 +1945,7 @@ class OcrPlan:
         self.inst_off, inst_off_host, self.inst_ent, self.rblk = (x.value for x in p)
         self.inst_off_host = np.ctypeslib.as_array(ctypes.cast(inst_off_host, ctypes.POINTER(ctypes.c_int32)), shape=(nb + 1,)).copy()
         # geometry of the row blocks
-        rp = sparsity._node_rowptr.download(np.int32, (sparsity.dsets[0].set.total_size + 1,))
+        rp = sparsity._node_rowptr_host()
         self.rows_end = int(rb[-1])
         self.vals_end = int(rp[rb[-1]])              # (positions cover exactly the rows [0, npos): same end either way)
         if row_order is not None:
@@ -1934,7 +1953,7 @@ class OcrPlan:
         else:
             self.max_nnz = int(np.diff(rp[rb]).max()) if nb else 0
         self.max_nown = int(np.diff(rb).max()) if nb else 0
-        maxlen = int(np.diff(rp).max()) if len(rp) > 1 else 0
+        maxlen = sparsity._max_node_rowlen()
         self.kbytes = 1 if maxlen <= 254 else 2
         self._build_tables(sparsity, rmap, cmap, staged_maps)
         # Bank-aware packing of the instance lists (fd_ocrplan_pack) is worth ~1 % of every later launch and costs ~0.1 s at C2 size
@@ -1959,17 +1978,23 @@ class OcrPlan:
         self.packed = True
         if not (self.ninst and rmap.arity * (1 + cmap.arity) <= 128):
             return
-        # bank-aware packing needs the tables of the current order; the tables are then rebuilt for the packed order
+        # bank-aware packing needs the tables of the current order.  It moves instances inside their blocks only: the block node
+        # lists of the staged plans stay valid and the per-instance rows (copies of the maps, local maps, row offsets) follow the
+        # permutation -- a second table build cost 5x as much
         ir, rkey = self._imap_of(rmap, staged_maps)
         lm = self.plans[rkey].lmap if rkey is not None else Plan(ir.ptr, 0, int(self.ninst), 0, self.inst_off_host,
                                                                  arity=rmap.arity).lmap
+        perm = DeviceBuffer(int(self.ninst) * 4)
+        _lib.call("fd_device_sync")                 # (launches queued on the current tables finish before the rows move)
         _lib.call("fd_ocrplan_pack", self.h, ir.ptr, lm, rmap.arity, self.kidx.ptr, self.kbytes, cmap.arity,
-                  sparsity._node_rowptr.ptr, None)
+                  sparsity._node_rowptr.ptr, perm.ptr, None)
         p = [ctypes.c_void_p() for _ in range(4)]
         _lib.call("fd_ocrplan_arrays", self.h, *[ctypes.byref(x) for x in p])
         self.inst_ent = p[2].value
-        _lib.call("fd_device_sync")                 # (launches queued on the old tables finish before those are released)
-        self._build_tables(sparsity, rmap, cmap, staged_maps)
+        for key, m in staged_maps.items():
+            _lib.call("fd_permute_rows", self._imaps[key].ptr, m.arity * 4, perm.ptr, int(self.ninst), None)
+            _lib.call("fd_permute_rows", self.plans[key].lmap, m.arity * 2, perm.ptr, int(self.ninst), None)
+        _lib.call("fd_permute_rows", self.kidx.ptr, rmap.arity * cmap.arity * self.kbytes, perm.ptr, int(self.ninst), None)
         self.__dict__.pop("_records", None)         # records are packed from the tables of the current order
 
     def _imap_of(self, m, staged_maps):
@@ -2063,13 +2088,13 @@ class SlicedOcrPlan:
         cr, va, nr = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64()
         _lib.call("fd_ocrplan_sliced_arrays", self.h, ctypes.byref(cr), ctypes.byref(va), ctypes.byref(nr))
         self.chunk_role, self.valid, self.nreal = cr.value, va.value, nr.value
-        rp = sparsity._node_rowptr.download(np.int32, (sparsity.dsets[0].set.total_size + 1,))
+        rp = sparsity._node_rowptr_host()
         self.rows_end = int(rb[-1])
         self.vals_end = int(rp[rb[-1]]) * self.block
         acc = row_order.prowptr_host if row_order is not None else rp
         self.max_nnz = int(np.diff(acc[rb]).max()) if nb else 0
         self.max_nown = int(np.diff(rb).max()) if nb else 0
-        maxlen = int(np.diff(rp).max()) if len(rp) > 1 else 0
+        maxlen = sparsity._max_node_rowlen()
         self.kbytes = 1 if maxlen <= 254 else 2
         self.plans, self._imaps = {}, {}
         for key, m in staged_maps.items():

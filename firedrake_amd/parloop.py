@@ -575,9 +575,9 @@ class Parloop:
             leaf_nodes = max(int(round(target * nnodes / max(n, 1))), 1)
             norder, nstarts = kd_order(pa.data._dev_ptr(False), pdim, nnodes, 0, leaf_nodes)
             nleaves = len(nstarts) - 1
-            label = np.empty(nnodes, dtype=np.int32)
-            label[norder.download(np.int32, (nnodes,))] = np.repeat(np.arange(nleaves, dtype=np.int32), np.diff(nstarts))
-            label_d = DeviceBuffer.from_numpy(label)
+            label_d = DeviceBuffer(max(nnodes, 1) * 4)
+            ns32 = np.ascontiguousarray(nstarts, dtype=np.int32)
+            _lib.call("fd_leaf_labels", norder.ptr, nnodes, ns32.ctypes.data, nleaves, label_d.ptr, None)
             buf = DeviceBuffer(n * 4)
             counts = np.zeros(nleaves, dtype=np.int32)
             _lib.call("fd_group_entities", pmap._dev_values(), pa.map_.arity, int(start), int(end), label_d.ptr, nnodes, nleaves,
@@ -910,7 +910,7 @@ class Parloop:
         sp = pa.data.sparsity
         sp._build()
         nrows = rmap.toset.size                                   # owned rows only
-        rp = sp._node_rowptr.download(np.int32, (rmap.toset.total_size + 1,))
+        rp = sp._node_rowptr_host()
         limit = src.ocr_lds_limit or configuration["lds_limit"]
         hint = getattr(rmap._base(), "preferred_node_blocks", None)
         row_order = None
@@ -1001,7 +1001,7 @@ class Parloop:
         rec = None
         if configuration["ocr_records"] and len(src.staged_maps) <= 8:
             from .codegen import record_layout
-            maxlen = int(np.diff(rp).max()) if len(rp) > 1 else 1
+            maxlen = max(sp._max_node_rowlen(), 1)
             rec = record_layout([staged[mi].arity for mi in src.staged_maps], nds, rmap.arity, cmap.arity, maxlen,
                                 pa.maps[0]._base() is pa.maps[1]._base())
             if rec[3] * 4 >= sum(staged[mi].arity for mi in src.staged_maps) * 2 + rmap.arity * cmap.arity * op.kbytes:
@@ -1036,7 +1036,7 @@ class Parloop:
         sp = pa.data.sparsity
         sp._build()
         nrows = rmap.toset.size
-        rp = sp._node_rowptr.download(np.int32, (rmap.toset.total_size + 1,))
+        rp = sp._node_rowptr_host()
         row_order = None
         prp = rp[:nrows + 1]
         hint = getattr(rmap._base(), "preferred_node_blocks", None)
@@ -1085,7 +1085,7 @@ class Parloop:
         per_dof = bool(pa.lgmaps) and bool(self.global_kernel.arguments[k].unroll)
         if configuration["ocr_records"] and B == 1 and not per_dof and len(src.staged_maps) <= 8 and op.kbytes == 1:
             from .codegen import sliced_record_layout
-            maxlen = int(np.diff(rp).max()) if len(rp) > 1 else 1
+            maxlen = max(sp._max_node_rowlen(), 1)
             rec = sliced_record_layout([staged[mi].arity for mi in src.staged_maps], nds, cmap.arity, maxlen, op.max_nnz)
             if rec[1] > 8 or rec[2] > 16 or rec[3] * 4 >= sum(staged[mi].arity for mi in src.staged_maps) * 2 + cmap.arity + 2:
                 rec = None

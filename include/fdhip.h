@@ -229,7 +229,11 @@ int fd_ocrplan_create_ordered(const int32_t *rmap_dev, int rarity, int32_t start
                               const int32_t *pinv_dev, int32_t npos, const int32_t *prowptr_dev,
                               fd_stream_t s, fd_ocrplan_t *out);
 int fd_ocrplan_pack(fd_ocrplan_t p, const int32_t *imap_rows_dev, const uint16_t *lmap_dev, int ar,
-                    const void *kidx_dev, int kbytes, int ac, const int32_t *node_rowptr_dev, fd_stream_t s);
+                    const void *kidx_dev, int kbytes, int ac, const int32_t *node_rowptr_dev, int32_t *perm_out_dev, fd_stream_t s);
+/* perm_out_dev (nullable, ninst entries): slot t of the packed order holds the instance that was at perm[t] -- the packer moves
+ * instances inside their blocks only, so the per-instance tables (local maps, row offsets) follow with fd_permute_rows and the
+ * block node lists stay as they are */
+int fd_permute_rows(void *rows_dev, int rowbytes, const int32_t *perm_dev, int64_t n, fd_stream_t s);
 /* Conflict-free LDS atomic windows: walks the stencil-ordered instance list of every block and fills the rest of a 16-slot window
  * with a dummy instance (an entity none of whose rows the block owns: all its contributions are skipped) where the next instance of
  * the same stencil group would hit an accumulator bank a lane of the window already uses.  rowstart_dev = CSR row starts in the
@@ -372,6 +376,8 @@ int fd_csr_split_values(int32_t nrows_owned, const int32_t *rowptr_dev, const do
  * Private re-encodings: Dats, Maps and the CSR keep the caller's numbering. */
 int fd_kd_order(const double *pts_dev, int pdim, int64_t n, int32_t base, int32_t leaf_size, int32_t *order_dev,
                 int32_t *leaf_starts_host, int32_t max_leaves, int32_t *nleaves_out, fd_stream_t s);
+/* label_dev[order_dev[i]] = l for leaf_starts_host[l] <= i < leaf_starts_host[l + 1]: the node labels of fd_kd_order's leaves */
+int fd_leaf_labels(const int32_t *order_dev, int64_t n, const int32_t *leaf_starts_host, int32_t nleaves, int32_t *label_dev, fd_stream_t s);
 int fd_group_entities(const int32_t *map_dev, int arity, int32_t start, int32_t end, const int32_t *label_dev, int32_t nnodes,
                       int32_t nlabels, int32_t *order_dev, int32_t *counts_host, fd_stream_t s);
 int fd_first_touch_order(const int32_t *map_dev, int arity, const int32_t *order_dev, int64_t n, int32_t nnodes,

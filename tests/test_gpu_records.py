@@ -256,3 +256,48 @@ def test_window_padding_dummies_are_foreign_and_change_nothing(numbering, mode, 
                 first = int(np.argmax(w))
                 assert w[first:].all() and first >= 12
     assert ndum == nd1
+
+
+@pytest.mark.parametrize("numbering,dim", [("lexicographic", 3), ("tiled", 3), ("lexicographic", 2)])
+def test_incremental_packer_reproduces_the_legacy_schedule_and_permuted_tables_the_rebuilt_ones(numbering, dim, monkeypatch):
+    """fd_ocrplan_pack: the scheduler that keeps the candidates' costs in registers (ocr_pack2_k) emits the instance order of the
+    one that re-evaluates them per slot (FDHIP_PACK_LEGACY=1), and the per-instance tables permuted after it (fd_permute_rows) are
+    the tables a fresh build over the packed order gives; the assembled matrix is the oracle's."""
+    import os
+    monkeypatch.setitem(configuration, "locality_min_entities", 64)
+    monkeypatch.setitem(configuration, "ocr_pack_after", 0)
+    m = (fmesh.UnitCubeMesh(14, degrees=(1,), perturb=0.1, numbering=numbering) if dim == 3
+         else fmesh.UnitSquareMesh(96, 96, perturb=0.1))
+    got = {}
+    for legacy in ("1", "0"):
+        monkeypatch.setenv("FDHIP_PACK_LEGACY", legacy)
+        prob = forms.PoissonProblem(m, 1, bcs=True)
+        mat, pl = prob.jacobian()
+        mat.zero()
+        pl.compute()
+        geo = [g for key, g in pl._prepared["parts"].items() if key[0] == "ocr"][0]
+        op = geo["ocr"]
+        assert op.packed
+        ent = _down(op.inst_ent, np.int32, (op.ninst,))
+        rm = pl.arguments[0].maps[0]
+        key = next(iter(op.plans))
+        ar = op.plans[key].arity
+        lmap = _down(op.plans[key].lmap, np.uint16, (op.ninst, ar))
+        kidx = _down(op.kidx.ptr, np.uint8 if op.kbytes == 1 else np.uint16, (op.ninst, rm.arity ** 2))
+        imap = _down(op._imaps[key].ptr, np.int32, (op.ninst, ar))
+        got[legacy] = (ent, lmap, kidx, imap, mat.csr()[2])
+        if legacy == "0":
+            # the permuted tables against a fresh build over the packed order
+            sparsity, rmap, cmap, staged = op._pack_args
+            op._build_tables(sparsity, rmap, cmap, staged)
+            assert np.array_equal(lmap, _down(op.plans[key].lmap, np.uint16, (op.ninst, ar)))
+            assert np.array_equal(kidx, _down(op.kidx.ptr, kidx.dtype, kidx.shape))
+            assert np.array_equal(imap, _down(op._imaps[key].ptr, np.int32, (op.ninst, ar)))
+            mpa = pl.arguments[0]
+            args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
+            ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
+            assert np.abs(got["0"][4] - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
+    assert np.array_equal(got["1"][0], got["0"][0])
+    for a, b in zip(got["1"][1:4], got["0"][1:4]):
+        assert np.array_equal(a, b)
+    assert np.abs(got["1"][4] - got["0"][4]).max() <= 1e-13 * np.abs(got["0"][4]).max()
