@@ -278,6 +278,30 @@ def kd_order(points_ptr, pdim, n, base, leaf_size):
     return buf, starts[:nl.value + 1].astype(np.int64)
 
 
+def kd_order_of(dat, n, leaf_size):
+    """kd_order of the first ``n`` points of the position field ``dat``, kept on the Dat for its current version: the staged loops
+    (entity groups around leaves of nodes) and the owner-computes-rows loops (row blocks = leaves of nodes) of one mesh ask for the
+    same partition when their leaf sizes agree (``kd_leaf_size`` makes 260 and 256 agree), and a k-d order of 10 M points is 30-40 ms."""
+    if getattr(dat, "dat_version", None) is None:      # a borrowed carrier: no version to tell a moved mesh by
+        return kd_order(dat._dev_ptr(False), dat.cdim, n, 0, leaf_size)
+    cache = dat.__dict__.setdefault("_kd_orders", {})
+    key = (dat.dat_version, int(n), int(leaf_size))
+    hit = cache.get(key)
+    if hit is None:
+        for k in [k for k in cache if k[0] != dat.dat_version]:
+            cache.pop(k)                       # (a moved mesh)
+        while len(cache) >= 2:
+            cache.pop(next(iter(cache)))
+        hit = cache[key] = kd_order(dat._dev_ptr(False), dat.cdim, n, 0, leaf_size)
+    return hit
+
+
+def kd_leaf_size(v):
+    """Leaf sizes within a few percent of each other are the same request: multiples of 32 from 128 points up."""
+    v = max(int(v), 1)
+    return v if v < 128 else max(32 * int(round(v / 32.0)), 32)
+
+
 class PlanDoesNotFit(_lib.FDHipError):
     """A staged / owner-computes-rows plan exceeds the LDS or the plan builder's per-block capacity: the Parloop demotes
     the loop to the next wrapper shape (ocr -> staged -> direct) before anything is launched."""
@@ -572,8 +596,8 @@ class Parloop:
         if lo is None:
             # k-d leaves of the position field's NODES, sized so that the entities around one leaf number ~target
             pdim, nnodes = pa.data.cdim, pa.data.dataset.set.total_size
-            leaf_nodes = max(int(round(target * nnodes / max(n, 1))), 1)
-            norder, nstarts = kd_order(pa.data._dev_ptr(False), pdim, nnodes, 0, leaf_nodes)
+            leaf_nodes = kd_leaf_size(round(target * nnodes / max(n, 1)))
+            norder, nstarts = kd_order_of(pa.data, nnodes, leaf_nodes)
             nleaves = len(nstarts) - 1
             label_d = DeviceBuffer(max(nnodes, 1) * 4)
             ns32 = np.ascontiguousarray(nstarts, dtype=np.int32)
@@ -582,7 +606,7 @@ class Parloop:
             counts = np.zeros(nleaves, dtype=np.int32)
             _lib.call("fd_group_entities", pmap._dev_values(), pa.map_.arity, int(start), int(end), label_d.ptr, nnodes, nleaves,
                       buf.ptr, counts.ctypes.data, None)
-            del label_d, norder
+            del label_d
             starts = LocalityOrder.cut(counts.astype(np.int64), target)
             for k in [k for k in cache if k[:3] == key[:3] and k[3] != key[3]]:
                 cache.pop(k)                   # orders of an earlier state of the position field (a moved mesh)
@@ -932,7 +956,9 @@ class Parloop:
                 # equal row count -- boxes of rows whose accumulators fill the LDS budget exactly
                 cap = configuration["ocr_nnz_per_block_ordered"]
                 rows_per_block = max(cap // max(int(np.ceil(rp[nrows] / max(nrows, 1))), 1), 1)
-                plist, rb = kd_order(pos_.data._dev_ptr(False), pos_.data.cdim, nrows, 0, rows_per_block)
+                if kd_leaf_size(rows_per_block) <= rows_per_block:
+                    rows_per_block = kd_leaf_size(rows_per_block)           # (never above the LDS budget the cap stands for)
+                plist, rb = kd_order_of(pos_.data, nrows, rows_per_block)
                 row_order = RowOrder.from_plist(plist, nrows, rp, rowptr_dev=sp._node_rowptr.ptr, pad=bool(configuration["ocr_pad_runs"]))
             elif usable:
                 # rows of another space: first touch under the k-d order of the entities, cut where the entity leaf changes
