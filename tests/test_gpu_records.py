@@ -171,8 +171,10 @@ def test_p1_jacobian_padded_accumulators(numbering, pad, monkeypatch):
 def test_deferred_packing_of_a_long_lived_plan(monkeypatch):
     """The bank-aware packing of the instance lists (fd_ocrplan_pack: ~1 % per launch, ~0.1 s at C2 size) waits until the plan has
     been launched ``ocr_pack_after`` times; the launches before and after give the same matrix."""
+    from firedrake_amd import graph
     monkeypatch.setitem(configuration, "ocr_pack_after", 3)
     monkeypatch.setitem(configuration, "locality_min_entities", 64)
+    monkeypatch.setattr(graph, "captured_any", False)      # (an earlier test of the session may have captured a hipGraph: no repacking then)
     m = fmesh.UnitCubeMesh(10, degrees=(1,), perturb=0.1, numbering="lexicographic")
     prob = forms.PoissonProblem(m, 1, bcs=True)
     mat, pl = prob.jacobian()
@@ -188,6 +190,16 @@ def test_deferred_packing_of_a_long_lived_plan(monkeypatch):
         _, _, v = mat.csr()
         assert np.abs(v - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
     assert states == [False, False, False, True, True, True]
+    # once a hipGraph has been captured anywhere in the process the tables a replay reads must stay where they are: no packing
+    monkeypatch.setattr(graph, "captured_any", True)
+    prob2 = forms.PoissonProblem(m, 1, bcs=True)
+    mat2, pl2 = prob2.jacobian()
+    for _ in range(5):
+        mat2.zero()
+        pl2.compute()
+    op2_ = [g for key, g in pl2._prepared["parts"].items() if key[0] == "ocr"][0]["ocr"]
+    assert not op2_.packed
+    assert np.abs(mat2.csr()[2] - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
 
 
 @pytest.mark.parametrize("numbering", ["lexicographic", "tiled"])
