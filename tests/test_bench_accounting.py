@@ -90,3 +90,17 @@ def test_cpu_baseline_runs_on_a_given_mesh_with_a_given_pattern():
     assert out["all_host_threads"]["cores"] == n <= aff and (quota is None or n <= max(1, int(quota)))
     out2 = bench.cpu_baseline(m, 1, reps=1)
     assert out2["sparsity_build_s"] is not None
+
+
+def test_kd_leaf_sizes_within_a_few_percent_are_one_request():
+    """parloop.kd_leaf_size: the staged loop asks for leaves of round(1536 * nodes / cells) = 260 nodes at C2 size, the
+    owner-computes-rows loop for 3840 // 15 = 256 rows -- both become 256, so one k-d order of the mesh serves both
+    (parloop.kd_order_of); small leaves are left alone and nothing is ever rounded to zero."""
+    from firedrake_amd.parloop import kd_leaf_size
+    assert kd_leaf_size(260) == kd_leaf_size(256) == 256
+    assert kd_leaf_size(round(1536 * 10077696 / 59630250)) == 256
+    assert kd_leaf_size(100) == 100 and kd_leaf_size(1) == 1 and kd_leaf_size(0) == 1
+    assert kd_leaf_size(128) == 128 and kd_leaf_size(143) == 128 and kd_leaf_size(145) == 160
+    for v in range(128, 5000, 37):
+        w = kd_leaf_size(v)
+        assert w % 32 == 0 and abs(w - v) <= 16
