@@ -272,12 +272,18 @@ int fd_csr_from_maps_ex(int32_t nrows, int32_t ncols, int set_diag, int npairs,
     }
     int32_t ndiag = set_diag ? (nrows < ncols ? nrows : ncols) : 0;
     ncand += ndiag;
-    // Candidate (row, column) keys are emitted, sorted and made unique in CHUNKS of at most 2^30 keys, the unique keys of
+    // Candidate (row, column) keys are emitted, sorted and made unique in CHUNKS of at most CHUNK keys, the unique keys of
     // every chunk appended to an accumulator that is itself compacted (sort + unique) whenever it passes 2^30 keys: no
     // primitive ever sees more items than a 32-bit count holds (the 215^3 CG2 half-cube of BASELINE configs[4] has 3.0e9
     // candidates for 1.2e9 nonzeros), and the peak footprint is ~4 x 8 GiB instead of 16 bytes per candidate.
-    int64_t CHUNK = 1ll << 30;
-    if (const char *e = getenv("FDHIP_CSR_CHUNK")) { const long long v = atoll(e); if (v > 0 && v < CHUNK) CHUNK = v; }   // (tests: force the chunked path)
+    // The chunk buffers are 2 x 8 B per key and most of this function's time at C2 size was spent allocating and releasing them
+    // (954 M candidates in one chunk: 15 GB for 40 ms of kernels): chunks of 2^27 keys by default (2 GB), the accumulator compacted
+    // as before when it passes 2^30.
+    int64_t CHUNK = 1ll << 27, ACC_LIMIT = 1ll << 30;
+    if (const char *e = getenv("FDHIP_CSR_CHUNK")) {          // (tests: force the many-chunk path and the accumulator's own compaction)
+        const long long v = atoll(e);
+        if (v > 0 && v < ACC_LIMIT) { CHUNK = v; ACC_LIMIT = v; }
+    }
     auto sort_unique = [&](uint64_t *in, uint64_t *alt, int64_t n, void **tmp, size_t *tmp_cap, int64_t *nsel_dev, uint64_t **result,
                            int64_t *nout) -> int {
         // sorts `in` (n keys) using `alt` as the second buffer and leaves the unique keys in *result (one of the two)
@@ -301,6 +307,7 @@ int fd_csr_from_maps_ex(int32_t nrows, int32_t ncols, int set_diag, int npairs,
     uint64_t *ck = nullptr, *ck2 = nullptr;                   // chunk buffers
     uint64_t *acc = nullptr, *acc2 = nullptr;                 // accumulator (+ its sort partner); grown on demand
     int64_t acc_n = 0, acc_cap = 0;
+    bool reserved = false;
     void *tmp = nullptr;
     size_t tmp_cap = 0;
     int64_t *nsel = nullptr;
@@ -317,7 +324,7 @@ int fd_csr_from_maps_ex(int32_t nrows, int32_t ncols, int set_diag, int npairs,
     };
     auto append = [&](const uint64_t *src, int64_t n) -> int {
         if (acc_n + n > acc_cap) {
-            if (acc_n > CHUNK) { if (int rc = compact()) return rc; }
+            if (acc_n > ACC_LIMIT) { if (int rc = compact()) return rc; }
             if (acc_n + n > acc_cap) {
                 int64_t want = acc_cap ? acc_cap * 2 : (n + 1);
                 while (want < acc_n + n) want *= 2;
@@ -380,6 +387,24 @@ int fd_csr_from_maps_ex(int32_t nrows, int32_t ncols, int set_diag, int npairs,
             uint64_t *res = nullptr;
             int64_t nu_c = 0;
             if (int rc = sort_unique(ck, ck2, cnt, &tmp, &tmp_cap, nsel, &res, &nu_c)) return rc;
+            if (!reserved && cnt > 0) {
+                // size the accumulator once from the first chunk's share of distinct keys instead of doubling it chunk after chunk
+                reserved = true;
+                const double ratio = (double)nu_c / (double)cnt;
+                double est = (double)acc_n + (double)nu_c + ratio * 1.05 * (double)(ncand - ndiag - cnt) + 4096.0;
+                if (est > 2147483647.0) est = 2147483647.0;
+                const int64_t want = (int64_t)est;
+                if (want > acc_cap) {
+                    uint64_t *na = nullptr, *na2 = nullptr;
+                    FD_HIP(hipMalloc(&na, (size_t)want * 8));
+                    FD_HIP(hipMalloc(&na2, (size_t)want * 8));
+                    if (acc_n) FD_HIP(hipMemcpyAsync(na, acc, (size_t)acc_n * 8, hipMemcpyDeviceToDevice, s));
+                    FD_HIP(hipStreamSynchronize(s));
+                    if (acc) FD_HIP(hipFree(acc));
+                    if (acc2) FD_HIP(hipFree(acc2));
+                    acc = na; acc2 = na2; acc_cap = want;
+                }
+            }
             if (int rc = append(res, nu_c)) return rc;
             FD_HIP(hipStreamSynchronize(s));                   // (the chunk buffers are reused)
         }
