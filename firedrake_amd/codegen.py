@@ -305,6 +305,12 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
     # requires_zeroed_output_arguments: MIN/MAX packs start from zero like INC/WRITE ones (builder.py:276-279, 368-371)
     also_zero = (MIN, MAX) if lk.requires_zeroed_output_arguments else ()
     full_mode = mode
+    # "_x<B>" (experiment, FDHIP_OCR_FIXED_POINT): the LDS accumulators of an owner-computes-rows loop are 64-bit FIXED-POINT sums at
+    # scale 2^B (fdw::fx_add / fx_get) -- integer LDS atomics instead of ds_add_f64; see the end of this function
+    fx_ = re.search(r"_x(\d+)$", mode)
+    fx_bits = int(fx_.group(1)) if fx_ else 0
+    if fx_:
+        mode = mode[:fx_.start()]
     # "<mode>_s<S0>x<S1>...": compile-time node strides of the staged maps (in staged_maps order), see lds_stride()
     sm_ = re.search(r"_s(\d+(?:x\d+)*)$", mode)
     strides = [int(v) for v in sm_.group(1).split("x")] if sm_ else None
@@ -978,6 +984,29 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         for mi, S in zip(staged_maps, strides):
             pat = re.compile(r"\bp%d_maxnd\b" % mi)
             src[sig + 1:] = [pat.sub("((long long)%d)" % S, l) for l in src[sig + 1:]]
+    if fx_bits:
+        # Fixed-point accumulation (experiment).  A contribution x enters as the BIT PATTERN of fma(x, 2^B, 1.5 * 2^52): the pattern is
+        # that of the offset plus round(x 2^B) as a 64-bit integer, so an integer atomic add sums the rounded values exactly and
+        # order-independently, and the n copies of the offset's pattern (0x4338 << 48: its low 48 bits are zero) never reach the low 48
+        # bits -- the flush sign-extends those and scales back.  Valid while |sum| 2^B < 2^47: the scale is the CALLER's promise
+        # (FDHIP_OCR_FIXED_POINT=B), there is no overflow check.  Why: ds_add_u64 runs at 6.2 lanes per clock where ds_add_f64 runs
+        # at 3.3 (profiles/r1i_microbench_lds.txt) and the P1 Jacobian is bound by exactly those atomics.
+        mats = [i_ for i_ in infos if i_["kind"] == "mat"]
+        if not ocr or len(mats) != 1 or int(np.prod(mats[0]["arg"].dims[0])) * int(np.prod(mats[0]["arg"].dims[1])) != 1:
+            raise ValueError("fixed-point accumulation serves scalar owner-computes-rows loops")
+        K_ = mats[0]["k"]
+        S_, IS_ = repr(float(2 ** fx_bits)), repr(float(2.0 ** -fx_bits))
+        add_re = re.compile(r"atomicAdd\(&sm%d\[(.*?)\], (.*)\);" % K_)
+        get_re = re.compile(r"(=|\+) sm%d\[([^\]]+)\]" % K_)
+        out_ = []
+        for line in src:
+            line = add_re.sub(lambda m_: "fdw::fx_add(&sm%d[%s], %s, %s);" % (K_, m_.group(1), m_.group(2), S_), line)
+            line = get_re.sub(lambda m_: "%s fdw::fx_get(sm%d[%s], %s)" % (m_.group(1), K_, m_.group(2), IS_), line)
+            out_.append(line)
+        src = out_
+        for line in "\n".join(src).split("\n"):
+            if ("sm%d[" % K_) in line and "fdw::fx_" not in line and ("sm%d[q] = 0" % K_) not in line:
+                raise ValueError("fixed-point accumulation: an accumulator access of this wrapper shape is not covered: " + line.strip())
     return WrapperSource("\n".join(src) + "\n", sym, full_mode, layout, len(maps), staged_maps, lds_items,
                          layer_parallel, threads, kbytes, mat_staged,
                          (threads if (staged and configuration["lane_strided"]) else 0),

@@ -27,6 +27,8 @@ configuration = {
     "ocr_pack": _env("FDHIP_OCR_PACK", 1, int),            # bank-aware greedy packing of the instance lists (fd_ocrplan_pack)
     "ocr_pad_windows": _env("FDHIP_OCR_PAD_WINDOWS", 0, int),   # 16-lane LDS atomic windows on distinct banks: 1 = end a window with dummy instances,
                                                                  # 2 = with instances from the tail of the block's list (a permutation)
+    "ocr_fixed_point": _env("FDHIP_OCR_FIXED_POINT", 0, int),   # experiment: B > 0 = whole-entity owner-computes-rows loops accumulate 64-bit
+                                                                 # fixed-point sums at scale 2^B in LDS (integer atomics); needs |A| 2^B < 2^47
     "ocr_pack_after": _env("FDHIP_OCR_PACK_AFTER", 64, int),   # ... once a plan has been launched this often (0 = when it is built)
     # owner-computes-rows index tables: one bit-packed record per instance (fd_ocr_pack_records; 0 = uint16 / uint8 rows), the
     # diagonal offsets taken from the row node's LDS word, and the flush of a derived row order run-coded (fd_ocr_row_runs)

@@ -171,6 +171,20 @@ template <int ARITY> __device__ __forceinline__ void load_lmap(const uint16_t *_
 // owner-computes-rows loop back to back -- the local-map entries at ceil(log2(nodes per block)) bits, the row-offset entries
 // at ceil(log2(longest CSR row)) bits -- instead of uint16 / uint8 arrays: P1 tetrahedra 24 -> 12 bytes per instance.
 // Field offsets and widths are compile-time constants, so a field is one v_bfe_u32 (two instructions when it straddles words).
+// Fixed-point accumulation (experiment, codegen mode suffix "_x<B>"): see codegen.generate_wrapper.
+__device__ __forceinline__ void fx_add(double *p, double x, double S) {
+    const double t = __builtin_fma(x, S, 6755399441055744.0);          // 1.5 * 2^52: the sum's unit in the last place is 1
+    unsigned long long b;
+    __builtin_memcpy(&b, &t, 8);
+    atomicAdd((unsigned long long *)p, b);
+}
+__device__ __forceinline__ double fx_get(double acc, double invS) {
+    long long a;
+    __builtin_memcpy(&a, &acc, 8);
+    a = (long long)((unsigned long long)a << 16) >> 16;                   // low 48 bits, sign-extended
+    return (double)a * invS;
+}
+
 template <int W> __device__ __forceinline__ void load_rec(const unsigned *__restrict__ p, unsigned (&w)[W]) {
     if constexpr (W % 4 == 0) {
         const uint4 *q = reinterpret_cast<const uint4 *>(p);

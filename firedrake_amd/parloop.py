@@ -1033,6 +1033,9 @@ class Parloop:
             if rec[3] * 4 >= sum(staged[mi].arity for mi in src.staged_maps) * 2 + rmap.arity * cmap.arity * op.kbytes:
                 rec = None                                            # no smaller than the plain rows
         variant = mode_variant(base, op.kbytes, nds, rec)
+        if int(configuration["ocr_fixed_point"]) > 0 and int(sp.dsets[0].cdim) * int(sp.dsets[1].cdim) == 1:
+            # experiment: 64-bit fixed-point LDS accumulators at scale 2^B (codegen mode suffix "_x<B>"; the caller vouches for B)
+            variant += f"_x{int(configuration['ocr_fixed_point'])}"
         geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz, "rec": rec, "runs": runs,
                "cw": prep["cw"] if variant == src.mode else self.global_kernel.compile(variant), "row_order": row_order}
         prep["parts"][gkey] = geo

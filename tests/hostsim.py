@@ -217,7 +217,7 @@ def row_runs_ref(prowptr, gstart, rb):
     return grun, brun, rdelta, int(np.diff(brun).max()) if len(rb) > 1 else 0
 
 
-def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False, run_flush=False, pad=False):
+def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False, run_flush=False, pad=False, fixed_point=0):
     """Execute a matrix-assembly Parloop ``pl`` with the OWNER-COMPUTES-ROWS wrapper on the host (one OS thread per
     lane, tests/hostsim/mt/fd_wrapper.h).  The plan tables come from the numpy restatements in helpers.py; the CSR
     pattern from the oracle.  Returns the OracleCSR holding the assembled values."""
@@ -267,7 +267,7 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False,
     if order is not None and run_flush:
         run_tabs = row_runs_ref(prowptr, csr.rowptr[plist], rb)
     src = generate_wrapper(gk, mode_variant(("ocrpr" if run_tabs else "ocrp") if order is not None else "ocr", 1,
-                                            [plans[mi][3] for mi in base.staged_maps], rec))
+                                            [plans[mi][3] for mi in base.staged_maps], rec) + (f"_x{int(fixed_point)}" if fixed_point else ""))
     text = src.source.replace("extern __shared__ __align__(16) unsigned char fd_lds[];", "unsigned char *fd_lds = fd_sim::lds;")
     sig = re.search(r'extern "C" __global__[^\n]*void %s\((.*)\)\n' % src.symbol, text).group(1)
     names = [p.split()[-1].lstrip("*") for p in sig.split(", ")]

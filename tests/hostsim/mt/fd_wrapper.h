@@ -148,6 +148,19 @@ template <class T, int N> inline void load_packed(const T *p, int (&out)[N]) {
     for (int k = 0; k < N; ++k) out[k] = p[k];
 }
 template <int ARITY> inline void load_lmap(const uint16_t *p, int (&out)[ARITY]) { load_packed<uint16_t, ARITY>(p, out); }
+// fixed-point accumulation (codegen mode suffix "_x<B>"), as in csrc/fd_wrapper.h
+inline void fx_add(double *p, double x, double S) {
+    const double t = __builtin_fma(x, S, 6755399441055744.0);
+    unsigned long long b;
+    __builtin_memcpy(&b, &t, 8);
+    atomicAdd((unsigned long long *)p, b);
+}
+inline double fx_get(double acc, double invS) {
+    long long a;
+    __builtin_memcpy(&a, &acc, 8);
+    a = (long long)((unsigned long long)a << 16) >> 16;
+    return (double)a * invS;
+}
 template <int W> inline void load_rec(const unsigned *p, unsigned (&w)[W]) { for (int k = 0; k < W; ++k) w[k] = p[k]; }
 template <int OFF, int BITS, int W> inline int rec_field(const unsigned (&w)[W]) {
     unsigned long long v = w[OFF >> 5];

@@ -313,3 +313,35 @@ def test_incremental_packer_reproduces_the_legacy_schedule_and_permuted_tables_t
     for a, b in zip(got["1"][1:4], got["0"][1:4]):
         assert np.array_equal(a, b)
     assert np.abs(got["1"][4] - got["0"][4]).max() <= 1e-13 * np.abs(got["0"][4]).max()
+
+
+@pytest.mark.parametrize("numbering", ["lexicographic", "tiled"])
+def test_fixed_point_accumulators_give_the_oracle_matrix_bit_reproducibly(numbering, monkeypatch):
+    """FDHIP_OCR_FIXED_POINT=B (experiment): 64-bit fixed-point LDS accumulators through integer atomics (codegen mode "_x<B>").
+    With B = 46 - ceil(log2 max|A|) the P1 Jacobian is the oracle's to 1e-12 max|A|, and -- the sums being exact integers -- the
+    same BITS whatever the order of the instances (packed or not)."""
+    monkeypatch.setitem(configuration, "locality_min_entities", 64)
+    m = fmesh.UnitCubeMesh(14, degrees=(1,), perturb=0.1, numbering=numbering)
+    prob = forms.PoissonProblem(m, 1, bcs=True)
+    mat, pl = prob.jacobian()
+    mpa = pl.arguments[0]
+    args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
+    ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
+    vmax = np.abs(ref.values).max()
+    monkeypatch.setitem(configuration, "ocr_fixed_point", 46 - int(np.ceil(np.log2(vmax))))
+    got = []
+    for after in (0, 1000):                                # packed at construction / never packed
+        monkeypatch.setitem(configuration, "ocr_pack_after", after)
+        p2 = forms.PoissonProblem(m, 1, bcs=True)
+        mat2, pl2 = p2.jacobian()
+        for _ in range(2):
+            mat2.zero()
+            pl2.compute()
+        geo = [g for key, g in pl2._prepared["parts"].items() if key[0] == "ocr"][0]
+        assert "_x" in geo["cw"].src.mode
+        v = mat2.csr()[2]
+        assert np.abs(v - ref.values).max() <= 1e-12 * vmax
+        pl2.compute()                                      # accumulates on top
+        assert np.abs(mat2.csr()[2] - 2.0 * ref.values).max() <= 2e-12 * vmax
+        got.append(v)
+    assert np.array_equal(got[0], got[1])

@@ -595,6 +595,36 @@ def test_owner_computes_rows_over_a_row_order_on_host(bcs, numbering):
 
 
 @pytest.mark.parametrize("bcs", [False, True])
+def test_fixed_point_accumulation_on_host(bcs):
+    """Mode suffix "_x<B>" (experiment, FDHIP_OCR_FIXED_POINT): the LDS accumulators hold 64-bit fixed-point sums -- every
+    contribution enters as the bit pattern of fma(x, 2^B, 1.5 * 2^52) through an INTEGER atomic add, the flush sign-extends the low
+    48 bits and scales back (fdw::fx_add / fx_get).  With B = 46 - ceil(log2 max|A|) the result is the oracle's to 1e-12 max|A|, in
+    the caller's row order and in a derived one, fresh and accumulating, with records and the run-coded flush."""
+    from firedrake_amd import forms, mesh as fmesh
+    from helpers import locality_order_ref
+    from hostsim import run_ocr
+    mesh = fmesh.UnitCubeMesh(4, degrees=(1,), perturb=0.1, numbering="lexicographic")
+    order = locality_order_ref(mesh.coord_space.cell_node_map.values_with_halo, 0, mesh.cell_set.size,
+                               np.array(mesh.coordinates.data_ro), target=96)[0]
+    prob = forms.PoissonProblem(mesh, 1, bcs=bcs)
+    mat, pl = prob.jacobian()
+    mpa = pl.arguments[0]
+    args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
+    ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
+    vmax = np.abs(ref.values).max()
+    bits = 46 - int(np.ceil(np.log2(vmax)))
+    for kw in ({}, {"records": True}, {"order": order}, {"order": order, "records": True}, {"order": order, "records": True, "run_flush": True}):
+        got = run_ocr(pl, rows_per_block=19, fixed_point=bits, **kw)
+        assert np.abs(got.values - ref.values).max() <= 1e-12 * vmax, kw
+        got2 = run_ocr(pl, rows_per_block=19, zero_pending=False, fixed_point=bits, **kw)
+        assert np.abs(got2.values - (ref.values + 1.0)).max() <= 1e-12 * (1.0 + vmax), kw
+    # the sums are exact integers: two different instance orders give bitwise the same matrix
+    a = run_ocr(pl, rows_per_block=19, fixed_point=bits).values
+    b = run_ocr(pl, rows_per_block=31, fixed_point=bits, order=order).values
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("bcs", [False, True])
 @pytest.mark.parametrize("numbering", ["tiled", "random"])
 def test_row_sliced_owner_computes_rows_on_host(bcs, numbering, plan_copies):
     """"ocrs" / "ocrsp": the row-sliced owner-computes-rows wrapper -- instances (entity, local row) grouped by local row and
