@@ -1956,8 +1956,8 @@ class OcrPlan:
         maxlen = sparsity._max_node_rowlen()
         self.kbytes = 1 if maxlen <= 254 else 2
         self._build_tables(sparsity, rmap, cmap, staged_maps)
-        # Bank-aware packing of the instance lists (fd_ocrplan_pack) is worth ~1 % of every later launch and costs ~0.1 s at C2 size
-        # (the packer + a second table build): 10^4 launches to break even.  It is therefore deferred until the plan has proved
+        # Bank-aware packing of the instance lists (fd_ocrplan_pack) is worth 1.5-5 % of every later launch and costs ~40 ms at C2 size
+        # (the scheduler kernel + the permutation of the per-instance tables): 10^3 launches to break even.  It is therefore deferred until the plan has proved
         # to be long-lived -- ``ocr_pack_after`` launches (0 = pack at construction) -- so that a Newton solve of a dozen
         # assemblies never pays for it (``launched()`` counts; nothing is repacked once a hipGraph may hold the table pointers).
         self._pack_args = (sparsity, rmap, cmap, staged_maps)
