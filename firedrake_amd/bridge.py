@@ -126,7 +126,8 @@ def tensor_form_info(cell, family, degree, quadrature_degree, terms, kind):
                                        -- or, for a variable-coefficient / linearised nonlinear form,
                                        ``{"stiffness": "<C expr>", "mass": "<C expr>", "coefficients": n}``: the two factors as
                                        C expressions in ``C[0..n)`` -- the values at the point of the form's n coefficient
-                                       Functions on the SAME space, in the order TSFC passes them (``w_0 ...``,
+                                       Functions, each on the SAME space or on the Q1 space of the coordinates (the backend tells
+                                       them apart by the Map of the argument), in the order TSFC passes them (``w_0 ...``,
                                        firedrake_loopy.py:432-522) -- and ``X[0..2]`` (the physical point); what the UFL
                                        integrand ``kappa(w0)*inner(grad(du), grad(v)) + c(u0)*du*v`` prints as
     ``kind``                           "matrix" for a 2-form, "action" for action(a, u) / a 1-form linear in one coefficient

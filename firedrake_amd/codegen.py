@@ -103,9 +103,11 @@ def tensor_eligible(gk: GlobalKernel):
     nc = int(tp.get("ncoef", 0))
 
     def coefs_ok(first, qmap):
-        """the descriptor's coefficient arguments: nc scalar fp64 READ Dats on the Q_k map, after the standard arguments"""
+        """the descriptor's coefficient arguments: nc scalar fp64 READ Dats after the standard arguments, each on the Q_k map or on
+        the Q1 map of the coordinates (tensor_coefficient_spaces)"""
         rest = list(zip(args[first:], las[first:]))
-        return len(rest) == nc and all(isinstance(a, DatKernelArg) and a.index is None and int(np.prod(a.dim)) == 1 and a.map_ is qmap
+        return len(rest) == nc and all(isinstance(a, DatKernelArg) and a.index is None and int(np.prod(a.dim)) == 1
+                                       and (a.map_ is qmap or a.map_ is args[1].map_)
                                        and la.access == READ and la.dtype == f64 for a, la in rest)
 
     if tp["kind"] == "matrix" and len(args) == 2 + nc:
@@ -120,6 +122,13 @@ def tensor_eligible(gk: GlobalKernel):
                 and y.map_ is u.map_ and plain(y.map_, nd, k) and coords_ok(args[1], las[1]) and coefs_ok(3, y.map_):
             return "action"
     return None
+
+
+def tensor_coefficient_spaces(gk: GlobalKernel, kind: str):
+    """'k' / '1' per coefficient argument of a tensor-product loop (in TSFC's order): on the Q_k map of the unknown or on the Q1 map
+    of the coordinates."""
+    first = 2 if kind == "matrix" else 3
+    return ["1" if a.map_ is gk.arguments[1].map_ else "k" for a in gk.arguments[first:]]
 
 
 def tensor_geometry(degree, nq):
@@ -148,14 +157,26 @@ def generate_tensor_wrapper(gk: GlobalKernel) -> WrapperSource:
     layout = [("layers",)]
     head = ['#include "fd_tensor.h"', "#include <math.h>", "namespace fdk {", "#pragma clang force_cuda_host_device begin",
             lk.tp["weights_code"], "#pragma clang force_cuda_host_device end", "}  // namespace fdk", ""]
-    # coefficient arguments (READ Dats on the Q_k map): evaluated at the Gauss points by the templates, handed to the callback as C[]
+    # coefficient arguments (READ Dats on the Q_k map or on the Q1 map of the coordinates): evaluated at the Gauss points by the
+    # templates, which hand the callback C = [Q_k coefficients ..., Q1 coefficients ...]; the lambda restores TSFC's order
     nc = int(lk.tp.get("ncoef", 0))
-    wcall = f"fdk::{wname}(J, X, wq, C, W);" if nc else f"fdk::{wname}(J, X, wq, W); (void)C;"
-    call_w = f"[](const double J[3][3], const double X[3], double wq, const double *C, double W[16]) {{ {wcall} }}"
     first_c = 2 if kind == "matrix" else 3
+    spaces = tensor_coefficient_spaces(gk, kind) if nc else []
+    ck = [m for m in range(nc) if spaces[m] == "k"]
+    c1 = [m for m in range(nc) if spaces[m] == "1"]
+    nck, nc1 = len(ck), len(c1)
+    tpos = {m: p_ for p_, m in enumerate(ck + c1)}            # position of TSFC coefficient m in the templates' C
+    if nc:
+        perm = ", ".join(f"C[{tpos[m]}]" for m in range(nc))
+        wcall = f"const double Cu[{nc}] = {{{perm}}}; fdk::{wname}(J, X, wq, Cu, W);"
+    else:
+        wcall = f"fdk::{wname}(J, X, wq, W); (void)C;"
+    call_w = f"[](const double J[3][3], const double X[3], double wq, const double *C, double W[16]) {{ {wcall} }}"
     cparams = [f"const double *__restrict__ arg{first_c + m}" for m in range(nc)]
     clayout = [("arg", first_c + m) for m in range(nc)]
-    cfdecl = "  const double *const cf[%d] = {%s};" % (max(nc, 1), ", ".join(f"arg{first_c + m}" for m in range(nc)) or "nullptr")
+    cfdecl = ("  const double *const cf[%d] = {%s};\n  const double *const c1[%d] = {%s};"
+              % (max(nck, 1), ", ".join(f"arg{first_c + m}" for m in ck) or "nullptr",
+                 max(nc1, 1), ", ".join(f"arg{first_c + m}" for m in c1) or "nullptr"))
     if kind == "matrix":
         lg = bool(gk.arguments[0].lgmaps)
         layout += [("arg", 0), ("arg", 1)] + clayout + [("map", 0), ("map", 1), ("mat_rowptr", 0), ("tp_offtab", 0)]
@@ -169,7 +190,7 @@ def generate_tensor_wrapper(gk: GlobalKernel) -> WrapperSource:
         # one cell owns alone are then stored, not accumulated
         layout += [("tp_tables",), ("tp_fresh", 0)]
         params += ["const double *__restrict__ tptab", "int fresh0"]
-        body = (f"{cfdecl}\n  fdt::hex_qk_matrix<{geom['k1']}, {geom['q1']}, {nc}>(start, end, layers, arg0, arg1, cf, map0, map1, rp0, tpo0, "
+        body = (f"{cfdecl}\n  fdt::hex_qk_matrix<{geom['k1']}, {geom['q1']}, {nck}, {nc1}>(start, end, layers, arg0, arg1, cf, c1, map0, map1, rp0, tpo0, "
                 f"{'rlg0, clg0' if lg else 'nullptr, nullptr'}, tptab, fresh0, {call_w});")
         threads = geom["matrix_threads"]
         # 4 NT accumulator registers per lane: Q4 (NT = 8) fits three wavefronts per SIMD
@@ -179,7 +200,7 @@ def generate_tensor_wrapper(gk: GlobalKernel) -> WrapperSource:
         params = ["const int *__restrict__ layers", "double *__restrict__ arg0", "const double *__restrict__ arg1",
                   "const double *__restrict__ arg2"] + cparams + ["const int *__restrict__ map0", "const int *__restrict__ map1",
                   "const double *__restrict__ tptab"]
-        body = (f"{cfdecl}\n  fdt::hex_qk_action<{geom['k1']}, {geom['q1']}, {nc}>(start, end, layers, arg0, arg1, arg2, cf, map0, map1, tptab, "
+        body = (f"{cfdecl}\n  fdt::hex_qk_action<{geom['k1']}, {geom['q1']}, {nck}, {nc1}>(start, end, layers, arg0, arg1, arg2, cf, c1, map0, map1, tptab, "
                 f"{call_w});")
         threads = 128
         bounds = "128" + (f", {int(configuration['tp_action_waves'])}" if configuration["tp_action_waves"] else "")

@@ -39,6 +39,15 @@ __device__ __forceinline__ void hex_jacobian(const double *__restrict__ sX, cons
     }
 }
 
+// values of the 8 trilinear vertex functions (index a*4 + b*2 + c) at reference point t: coefficient arguments on the Q1 map
+__device__ __forceinline__ void hex_shape(const double t[3], double N[8]) {
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        const int a = v >> 2, b = (v >> 1) & 1, c = v & 1;
+        N[v] = (a ? t[0] : 1.0 - t[0]) * (b ? t[1] : 1.0 - t[1]) * (c ? t[2] : 1.0 - t[2]);
+    }
+}
+
 // K = J^-1 and det J: helper for weight callbacks
 __device__ __forceinline__ void inv3(const double J[3][3], double K[3][3], double &det) {
     const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
@@ -107,9 +116,12 @@ __device__ __forceinline__ void hex_qk_coefficients(const double *const (&cf)[NC
     }
 }
 
-template <int K1, int Q1, int NC, class WF>
+// N1 further coefficient arguments live on the Q1 map of the coordinates (a piecewise-trilinear diffusivity on a Q4 problem): their 8
+// vertex values per cell are staged next to the coordinates and interpolated at the point; the callback sees C = [Q_k ..., Q1 ...].
+template <int K1, int Q1, int NC, int N1, class WF>
 __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__restrict__ layers, double *__restrict__ vals,
                                               const double *__restrict__ coords, const double *const (&cf)[NC > 0 ? NC : 1],
+                                              const double *const (&c1)[N1 > 0 ? N1 : 1],
                                               const int *__restrict__ map_qk,
                                               const int *__restrict__ map_q1, const int *__restrict__ rowptr,
                                               const unsigned short *__restrict__ offtab, const int *__restrict__ rlg,
@@ -119,6 +131,7 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
     __shared__ double sX[24];
     __shared__ double sW[NQ][16];
     __shared__ double sC[NC > 0 ? NC : 1][NQ];
+    __shared__ double sV1[N1 > 0 ? N1 : 1][8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nl = layers[1] - 1 - layers[0];
     const int cellid = blockIdx.x / WGC, part = blockIdx.x - cellid * WGC;
@@ -132,16 +145,29 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
         const int node = map_q1[(size_t)col * 8 + v] + lrel;       // offset 1 per layer (Q1)
         sX[tid] = coords[(size_t)node * 3 + c];
     }
+    if constexpr (N1 > 0)
+        for (int o = tid; o < 8 * N1; o += WPB * 64) sV1[o >> 3][o & 7] = c1[o >> 3][map_q1[(size_t)col * 8 + (o & 7)] + lrel];
     __syncthreads();
     if constexpr (NC > 0)
         hex_qk_coefficients<K1, Q1, NC, WPB * 64>(cf, map_qk + (size_t)col * ND, (K1 - 1) * lrel, sL, sC);
     for (int q = tid; q < NQ; q += WPB * 64) {
         const int q1 = q / (Q1 * Q1), q2 = (q / Q1) % Q1, q3 = q % Q1;
         const double t[3] = {sQP[q1], sQP[q2], sQP[q3]};
-        double J[3][3], X[3], W[16], C[NC > 0 ? NC : 1];
+        double J[3][3], X[3], W[16], C[NC + N1 > 0 ? NC + N1 : 1];
         hex_jacobian(sX, t, J, X);
 #pragma unroll
         for (int m = 0; m < NC; ++m) C[m] = sC[m][q];
+        if constexpr (N1 > 0) {
+            double N[8];
+            hex_shape(t, N);
+#pragma unroll
+            for (int m = 0; m < N1; ++m) {
+                double v = 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v += N[k] * sV1[m][k];
+                C[NC + m] = v;
+            }
+        }
         weights(J, X, sQW[q1] * sQW[q2] * sQW[q3], C, W);
 #pragma unroll
         for (int k = 0; k < 16; ++k) sW[q][k] = W[k];
@@ -251,10 +277,10 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int tp_action_cells(int k1, int q1) { return 128 / ((k1 > q1 ? k1 : q1) * (k1 > q1 ? k1 : q1)); }
 
-template <int K1, int Q1, int NC, class WF>
+template <int K1, int Q1, int NC, int N1, class WF>
 __device__ __forceinline__ void hex_qk_action(int start, int end, const int *__restrict__ layers, double *__restrict__ y,
                                               const double *__restrict__ coords, const double *__restrict__ u,
-                                              const double *const (&cf)[NC > 0 ? NC : 1],
+                                              const double *const (&cf)[NC > 0 ? NC : 1], const double *const (&c1)[N1 > 0 ? N1 : 1],
                                               const int *__restrict__ map_qk, const int *__restrict__ map_q1,
                                               const double *__restrict__ tables, WF weights) {
     constexpr int M = K1 > Q1 ? K1 : Q1, M2 = M * M, M3 = M2 * M, CPW = tp_action_cells(K1, Q1), ND = K1 * K1 * K1, NTAB = Q1 * K1;
@@ -264,6 +290,7 @@ __device__ __forceinline__ void hex_qk_action(int start, int end, const int *__r
     // IN PLACE -- a lane reads and writes only its own line) -- 5 cubes of 1000 B per cell for Q4, six workgroups per CU.  The NC
     // coefficient arguments ride through passes 1 and 2 in further slots (A: 2.., B: 3..) and are evaluated at the line's points.
     __shared__ double sA[CPW][2 + NC][M3], sB[CPW][3 + NC][M3], sX[CPW][24];
+    __shared__ double sV1[CPW][N1 > 0 ? N1 : 1][8];       // vertex values of the coefficient arguments on the Q1 map
     const int t = threadIdx.x;
     const int nl = layers[1] - 1 - layers[0];
     const int ncell = (end - start) * nl;
@@ -278,6 +305,11 @@ __device__ __forceinline__ void hex_qk_action(int start, int end, const int *__r
             }
         }
     }
+    if constexpr (N1 > 0)
+        for (int o = t; o < CPW * N1 * 8; o += 128) {
+            const int kc = o / (N1 * 8), m = (o / 8) % N1, v = o & 7, cs = first + kc;
+            if (cs < ncell) sV1[kc][m][v] = c1[m][map_q1[(size_t)(start + cs / nl) * 8 + v] + cs % nl];
+        }
     const int k = t / M2, l = t - M2 * k, p = l / M, r = l - M * p;
     const bool in = k < CPW && first + k < ncell;
     const int ka = in ? k : 0;
@@ -372,6 +404,16 @@ __device__ __forceinline__ void hex_qk_action(int start, int end, const int *__r
                 G1[c][f] = (1.0 - t0) * (x01 - x00) + t0 * (x11 - x10);
                 P[c][f] = (1.0 - t0) * ((1.0 - t1) * x00 + t1 * x01) + t0 * ((1.0 - t1) * x10 + t1 * x11);
             }
+        double P1[N1 > 0 ? N1 : 1][2];                  // Q1 coefficients: bilinear in (t0, t1) on the bottom / top face, affine along the line
+        if constexpr (N1 > 0) {
+#pragma unroll
+            for (int m = 0; m < N1; ++m)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const double *V = sV1[ka][m];
+                    P1[m][f] = (1.0 - t0) * ((1.0 - t1) * V[0 + f] + t1 * V[2 + f]) + t0 * ((1.0 - t1) * V[4 + f] + t1 * V[6 + f]);
+                }
+        }
         double p0[K1], p1[K1], sv[K1];
 #pragma unroll
         for (int i = 0; i < K1; ++i) { p0[i] = 0.0; p1[i] = 0.0; sv[i] = 0.0; }
@@ -383,13 +425,17 @@ __device__ __forceinline__ void hex_qk_action(int start, int end, const int *__r
                 g[0] += L(q * K1 + i) * d1[i]; g[1] += L(q * K1 + i) * d2[i]; g[2] += DL(q * K1 + i) * vv[i]; g[3] += L(q * K1 + i) * vv[i];
             }
             const double t2 = tables[2 * NTAB + q];
-            double J[3][3], X[3], W[16], F[4], C[NC > 0 ? NC : 1];
+            double J[3][3], X[3], W[16], F[4], C[NC + N1 > 0 ? NC + N1 : 1];
 #pragma unroll
             for (int m = 0; m < NC; ++m) {
                 double cq = 0.0;
 #pragma unroll
                 for (int i = 0; i < K1; ++i) cq += L(q * K1 + i) * B[3 + m][l * M + i];
                 C[m] = cq;
+            }
+            if constexpr (N1 > 0) {
+#pragma unroll
+                for (int m = 0; m < N1; ++m) C[NC + m] = P1[m][0] + t2 * (P1[m][1] - P1[m][0]);
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {

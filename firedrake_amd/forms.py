@@ -766,11 +766,13 @@ class HelmholtzHexProblem:
         return self.y
 
 
-def coefficient_hex_jacobian_kernel(degree=4, nq=None, name=None, kappa="1.0 + C[0]", react="1.0 + C[1]*C[1]", ncoef=2):
+def coefficient_hex_jacobian_kernel(degree=4, nq=None, name=None, kappa="1.0 + C[0]", react="1.0 + C[1]*C[1]", ncoef=2, spaces=None):
     """a(du, v) = int kappa grad(du).grad(v) + react du v dx on a trilinear hexahedron, Q_degree basis, nq^3 Gauss points, with
     ``kappa`` / ``react`` C expressions in the values C[0..ncoef) of ``ncoef`` coefficient fields at the point and the physical
     point X[0..2] -- a variable-coefficient operator, or the Jacobian of a residual with a nonlinear reaction term (react = g'(u0)).
     Arguments in TSFC's order (tsfc/kernel_interface/firedrake_loopy.py:432-522): A[nd*nd], coords[24], w_0[nd] ... w_{ncoef-1}[nd].
+    ``spaces``: per coefficient "k" (a Q_degree field: nd values per cell, the default) or "1" (a field in the Q1 space of the
+    coordinates: 8 vertex values per cell, interpolated trilinearly).
     The C text is the dense definition the oracle and the direct wrapper execute; the descriptor lets the backend evaluate the
     coefficients sum-factorised and contract on the fp64 matrix cores (csrc/fd_tensor.h)."""
     from .kernel import TensorProductLocalKernel
@@ -780,8 +782,10 @@ def coefficient_hex_jacobian_kernel(degree=4, nq=None, name=None, kappa="1.0 + C
     nd = k1 ** 3
     name = name or f"coefficient_q{degree}_hex_jacobian"
     L, DL, qp, qw = q4_tables(degree, nq)
+    spaces = list(spaces) if spaces is not None else ["k"] * ncoef
     wargs = "".join(f", const double *restrict w{m}" for m in range(ncoef))
-    cvals = "\n".join(f"    for (int i = 0; i < {nd}; ++i) C[{m}] += ph[i] * w{m}[i];" for m in range(ncoef))
+    cvals = "\n".join(f"    for (int i = 0; i < {nd}; ++i) C[{m}] += ph[i] * w{m}[i];" if spaces[m] == "k" else
+                      f"    for (int v = 0; v < 8; ++v) C[{m}] += NV[v] * w{m}[v];" for m in range(ncoef))
     body = f"""
 static void {name}(double *restrict A, const double *restrict x{wargs})
 {{
@@ -791,12 +795,13 @@ static void {name}(double *restrict A, const double *restrict x{wargs})
   static const double QW[{nq}] = {_c(qw)};
   for (int q1 = 0; q1 < {nq}; ++q1) for (int q2 = 0; q2 < {nq}; ++q2) for (int q3 = 0; q3 < {nq}; ++q3) {{
     const double t[3] = {{QP[q1], QP[q2], QP[q3]}};
-    double J[3][3] = {{{{0,0,0}},{{0,0,0}},{{0,0,0}}}}, X[3] = {{0,0,0}};
+    double J[3][3] = {{{{0,0,0}},{{0,0,0}},{{0,0,0}}}}, X[3] = {{0,0,0}}, NV[8];
     for (int v = 0; v < 8; ++v) {{
       const int a = v >> 2, b = (v >> 1) & 1, c = v & 1;
       const double Na = a ? t[0] : 1.0 - t[0], Nb = b ? t[1] : 1.0 - t[1], Nc = c ? t[2] : 1.0 - t[2];
       const double da = a ? 1.0 : -1.0, db = b ? 1.0 : -1.0, dc = c ? 1.0 : -1.0;
       const double g[3] = {{da*Nb*Nc, Na*db*Nc, Na*Nb*dc}};
+      NV[v] = Na*Nb*Nc;
       for (int r = 0; r < 3; ++r) {{ for (int s = 0; s < 3; ++s) J[r][s] += x[3*v + r] * g[s]; X[r] += x[3*v + r] * Na*Nb*Nc; }}
     }}
     const double c00 = J[1][1]*J[2][2] - J[1][2]*J[2][1], c01 = J[1][2]*J[2][0] - J[1][0]*J[2][2], c02 = J[1][0]*J[2][1] - J[1][1]*J[2][0];
@@ -828,7 +833,7 @@ static void {name}(double *restrict A, const double *restrict x{wargs})
       for (int j = 0; j < {nd}; ++j)
         A[i*{nd} + j] += t0*dp[j][0] + t1*dp[j][1] + t2*dp[j][2] + tm*ph[j];
     }}
-    (void)X;
+    (void)X; (void)NV;
   }}
 }}
 """
@@ -836,7 +841,7 @@ static void {name}(double *restrict A, const double *restrict x{wargs})
                                     weights_code=coefficient_weights(name, kappa, react))
 
 
-def coefficient_hex_action_kernel(degree=4, nq=None, name=None, kappa="1.0 + C[0]", react="1.0 + C[1]*C[1]", ncoef=2):
+def coefficient_hex_action_kernel(degree=4, nq=None, name=None, kappa="1.0 + C[0]", react="1.0 + C[1]*C[1]", ncoef=2, spaces=None):
     """y += A_e(coords, w_0 ...) u for the same form.  Arguments: y[nd], coords[24], u[nd], w_0[nd] ...; dense C text for the
     oracle, sum-factorised on the device (the coefficients ride through the same axis passes as u)."""
     from .kernel import TensorProductLocalKernel
@@ -844,7 +849,7 @@ def coefficient_hex_action_kernel(degree=4, nq=None, name=None, kappa="1.0 + C[0
     nq = nq or degree + 1
     nd = (degree + 1) ** 3
     name = name or f"coefficient_q{degree}_hex_action"
-    jac = coefficient_hex_jacobian_kernel(degree, nq, name + "_matrix", kappa, react, ncoef)
+    jac = coefficient_hex_jacobian_kernel(degree, nq, name + "_matrix", kappa, react, ncoef, spaces)
     wargs = "".join(f", const double *restrict w{m}" for m in range(ncoef))
     wpass = "".join(f", w{m}" for m in range(ncoef))
     body = jac.code + f"""
@@ -870,20 +875,29 @@ class CoefficientHexProblem(HelmholtzHexProblem):
     the Jacobians TSFC generates for nonlinear / variable-coefficient problems (tsfc/kernel_interface/firedrake_loopy.py:432-522,
     coefficient evaluation tsfc/fem.py:742-805).  Default: kappa = 1 + w0, c = 1 + u0^2 (the Jacobian of u + u^3/3)."""
 
-    def __init__(self, hexmesh, bcs=False, nq=None, kappa="1.0 + C[0]", react="1.0 + C[1]*C[1]"):
+    def __init__(self, hexmesh, bcs=False, nq=None, kappa="1.0 + C[0]", react="1.0 + C[1]*C[1]", q1_diffusivity=False):
+        """``q1_diffusivity``: w0 lives in the Q1 space of the coordinates (8 vertex values per cell on the coordinate map) instead
+        of the Q_k space of the unknown -- a piecewise-trilinear material field under a high-order discretisation."""
         super().__init__(hexmesh, bcs, nq)
         m = hexmesh
         cm, xm = m.cell_node_map, m.coord_map
         pts = m.node_points
-        self.w0 = op2.Dat(m.node_set, 0.5 + 0.4 * np.sin(2 * pts[:, 0] + pts[:, 1]) * np.cos(pts[:, 2]), np.float64, "kappa_field")
+        if q1_diffusivity:
+            xp = np.asarray(m.coordinates.data_ro_with_halos)
+            self.w0 = op2.Dat(m.coordinates.dataset.set, 0.5 + 0.4 * np.sin(2 * xp[:, 0] + xp[:, 1]) * np.cos(xp[:, 2]), np.float64, "kappa_q1")
+        else:
+            self.w0 = op2.Dat(m.node_set, 0.5 + 0.4 * np.sin(2 * pts[:, 0] + pts[:, 1]) * np.cos(pts[:, 2]), np.float64, "kappa_field")
         self.u0 = op2.Dat(m.node_set, np.cos(2 * pts[:, 0]) * np.sin(3 * pts[:, 1] + 1.0) + 0.2 * pts[:, 2], np.float64, "u0")
         lg = self.jac_loop.arguments[0].lgmaps
-        self.kjac = coefficient_hex_jacobian_kernel(m.degree, nq, None, kappa, react, 2)
-        self.kact = coefficient_hex_action_kernel(m.degree, nq, None, kappa, react, 2)
+        spaces = ("1", "k") if q1_diffusivity else ("k", "k")
+        tag = "q1coef" if q1_diffusivity else "coefficient"
+        self.kjac = coefficient_hex_jacobian_kernel(m.degree, nq, f"{tag}_q{m.degree}_hex_jacobian", kappa, react, 2, spaces)
+        self.kact = coefficient_hex_action_kernel(m.degree, nq, f"{tag}_q{m.degree}_hex_action", kappa, react, 2, spaces)
+        wm = xm if q1_diffusivity else cm
         self.jac_loop = op2.LegacyParloop(self.kjac, m.cell_set, self.mat(op2.INC, (cm, cm), lgmaps=lg), m.coordinates(op2.READ, xm),
-                                          self.w0(op2.READ, cm), self.u0(op2.READ, cm))
+                                          self.w0(op2.READ, wm), self.u0(op2.READ, cm))
         self.act_loop = op2.LegacyParloop(self.kact, m.cell_set, self.y(op2.INC, cm), m.coordinates(op2.READ, xm), self.u(op2.READ, cm),
-                                          self.w0(op2.READ, cm), self.u0(op2.READ, cm))
+                                          self.w0(op2.READ, wm), self.u0(op2.READ, cm))
 
 
 class HelmholtzQ4Problem(HelmholtzHexProblem):

@@ -9,6 +9,18 @@ from oracle import ODat, OMat, READ, INC
 from firedrake_amd import forms, mesh as fmesh
 
 
+def _coef_args(m, coefs):
+    """Oracle arguments of the coefficient fields: an array lives on the Q_k map, a pair (array, "1") on the Q1 map of the coordinates."""
+    cm, xm = m.cell_node_map.values_with_halo, m.coord_map.values_with_halo
+    out = []
+    for c in coefs:
+        if isinstance(c, tuple):
+            out.append(ODat(np.array(c[0]), READ, xm, offset=m.coord_map.offset))
+        else:
+            out.append(ODat(np.array(c), READ, cm, offset=m.cell_node_map.offset))
+    return out
+
+
 def _oracle_matrix(m, bc_nodes=None, k=None, coefs=()):
     """Dense Q4 kernel through the oracle's extruded wrapper; BC rows/columns dropped through the lgmaps and the unit
     diagonal set afterwards, as assemble.py:1501-1507 / 2075-2108 do."""
@@ -23,7 +35,7 @@ def _oracle_matrix(m, bc_nodes=None, k=None, coefs=()):
     oracle.par_loop(k.code, k.name, 0, m.base_set.size,
                     [OMat(csr, INC, cm, cm, roffset=m.cell_node_map.offset, coffset=m.cell_node_map.offset, row_lgmap=lg, col_lgmap=lg),
                      ODat(np.array(m.coordinates.data_ro_with_halos), READ, xm, offset=m.coord_map.offset)]
-                    + [ODat(np.array(c), READ, cm, offset=m.cell_node_map.offset) for c in coefs],
+                    + _coef_args(m, coefs),
                     layers=(0, m.layers + 1))
     if lg is not None:
         rp, ci = csr.rowptr, csr.colidx
@@ -40,7 +52,7 @@ def _oracle_action(m, u, k=None, coefs=()):
                     [ODat(y, INC, cm, offset=m.cell_node_map.offset),
                      ODat(np.array(m.coordinates.data_ro_with_halos), READ, xm, offset=m.coord_map.offset),
                      ODat(np.array(u), READ, cm, offset=m.cell_node_map.offset)]
-                    + [ODat(np.array(c), READ, cm, offset=m.cell_node_map.offset) for c in coefs], layers=(0, m.layers + 1))
+                    + _coef_args(m, coefs), layers=(0, m.layers + 1))
     return y
 
 

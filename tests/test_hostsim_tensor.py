@@ -109,6 +109,36 @@ def test_coefficient_arguments_through_the_tensor_templates_on_the_host(degree, 
     assert_allclose(y, yref, rtol=0, atol=1e-11 * np.abs(yref).max())
 
 
+@pytest.mark.parametrize("degree,nq,bcs", [(2, 3, False), (3, 4, True), (4, 5, True)])
+def test_a_coefficient_on_the_q1_map_through_the_tensor_templates_on_the_host(degree, nq, bcs):
+    """The diffusivity as a field in the Q1 space of the COORDINATES (8 vertex values per cell on the coordinate map: a piecewise-
+    trilinear material under a high-order discretisation) next to a Q_k linearisation point: the templates stage its vertex values
+    beside the coordinates and interpolate them at the Gauss points (trilinear in the matrix kernel, affine along a line in the
+    action), the generated callback restores TSFC's argument order (here: Q1 first, Q_k second, the reverse of the templates')."""
+    m = fmesh.make_extruded_hex_mesh(2, 2, degree, perturb=0.1)
+    prob = forms.CoefficientHexProblem(m, bcs=bcs, nq=nq, q1_diffusivity=True)
+    from firedrake_amd.codegen import tensor_coefficient_spaces, tensor_eligible
+    assert tensor_eligible(prob.jac_loop.global_kernel) == "matrix" and tensor_eligible(prob.act_loop.global_kernel) == "action"
+    assert tensor_coefficient_spaces(prob.jac_loop.global_kernel, "matrix") == ["1", "k"]
+    assert tensor_coefficient_spaces(prob.act_loop.global_kernel, "action") == ["1", "k"]
+    coefs = ((prob.w0.data_ro_with_halos, "1"), prob.u0.data_ro)
+    csr = hostsim.run_tensor(prob.jac_loop)[0]
+    ref = _oracle_matrix(m, prob.bc_nodes if bcs else None, prob.kjac, coefs)
+    v = csr.values.copy()
+    if bcs:
+        rp, ci = csr.rowptr, csr.colidx
+        for b in prob.bc_nodes:
+            v[rp[b] + np.searchsorted(ci[rp[b]:rp[b + 1]], b)] = 1.0
+    assert_allclose(v, ref.values, rtol=0, atol=1e-11 * np.abs(ref.values).max())
+    # the Q1 field is not the Q_k field of the same function: the two operators differ
+    other = forms.CoefficientHexProblem(m, bcs=bcs, nq=nq)
+    ref_k = _oracle_matrix(m, prob.bc_nodes if bcs else None, other.kjac, (other.w0.data_ro, other.u0.data_ro))
+    assert np.abs(ref_k.values - ref.values).max() > 1e-6 * np.abs(ref.values).max()
+    y = hostsim.run_tensor(prob.act_loop)[0]
+    yref = _oracle_action(m, prob.u.data_ro, prob.kact, coefs)
+    assert_allclose(y, yref, rtol=0, atol=1e-11 * np.abs(yref).max())
+
+
 @pytest.mark.parametrize("degree,nq,n,bcs", [(2, 3, 2, False), (2, 3, 2, True), (3, 4, 1, True), (1, 2, 2, False)])
 def test_rows_owned_by_one_cell_are_stored_after_a_zero_and_accumulated_otherwise(degree, nq, n, bcs):
     """hex_qk_matrix stores the rows exactly as long as the element matrix is wide (the cell-interior nodes; for Q1 the corners of
