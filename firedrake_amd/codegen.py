@@ -326,12 +326,12 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
     # requires_zeroed_output_arguments: MIN/MAX packs start from zero like INC/WRITE ones (builder.py:276-279, 368-371)
     also_zero = (MIN, MAX) if lk.requires_zeroed_output_arguments else ()
     full_mode = mode
-    # "_x<B>" (experiment, FDHIP_OCR_FIXED_POINT): the LDS accumulators of an owner-computes-rows loop are 64-bit FIXED-POINT sums at
-    # scale 2^B (fdw::fx_add / fx_get) -- integer LDS atomics instead of ds_add_f64; see the end of this function
-    fx_ = re.search(r"_x(\d+)$", mode)
-    fx_bits = int(fx_.group(1)) if fx_ else 0
-    if fx_:
-        mode = mode[:fx_.start()]
+    # "_fx": the LDS accumulators of a whole-entity owner-computes-rows loop are CHECKED 64-bit fixed-point sums (integer LDS
+    # atomics instead of ds_add_f64; fd_wrapper.h, fx_block_t): every row block keeps its own scale record, and a block whose
+    # largest contribution leaves the window of its scale redoes its rows in fp64 inside the same launch
+    fx = mode.endswith("_fx")
+    if fx:
+        mode = mode[:-3]
     # "<mode>_s<S0>x<S1>...": compile-time node strides of the staged maps (in staged_maps order), see lds_stride()
     sm_ = re.search(r"_s(\d+(?:x\d+)*)$", mode)
     strides = [int(v) for v in sm_.group(1).split("x")] if sm_ else None
@@ -504,6 +504,9 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 P(f"long long oc{k}_npos", ("ocr_npos", k))
             if rec:
                 P(f"const unsigned int *__restrict__ oc{k}_rec", ("ocr_rec", k))
+            if fx:
+                P(f"fdw::fx_block_t *__restrict__ fx{k}_scale", ("fx_scale", k))
+                P(f"unsigned int *__restrict__ fx{k}_stat", ("fx_stat", k))
         elif mat_staged[k]:
             P(f"const int *__restrict__ mp{k}_off", ("matplan_off", k))
             P(f"const int *__restrict__ mp{k}_gpos", ("matplan_gpos", k))
@@ -547,6 +550,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         return e
 
     pre, pack, call_args, unpack, post = [], [], [], [], []
+    unpack_fx = []       # "_fx": the fixed-point trip's unpack of the Mat (everything else in such a loop is READ)
     node_actions = {}    # per staged map: [(load statements, LDS store statements)] templated on I_U / G_U
     lds_decl, stage, flush, mat_stage_pre = [], [], [], []
     # LDS carve-up order: staged Dat rows, then the per-node matrix tables (sizes fixed by the node strides), then the
@@ -665,7 +669,10 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 rp_ = f"oc{k}_prowptr" if ocrp else f"oc{k}_rowptr"       # row starts in the order the blocks are cut in
                 mat_stage_pre.extend([f"const int n0_{k} = oc{k}_rblk[b], nown{k} = oc{k}_rblk[b+1] - n0_{k};",
                                       f"const int r0_{k} = {rp_}[n0_{k}], nnzb{k} = {rp_}[n0_{k} + nown{k}] - r0_{k};"])
-                stage.append((rm, f"for (int q = tid; q < nnzb{k}; q += nthr) sm{k}[q] = 0;"))
+                # (by capacity when the index rows are requested early: the block's row starts -- a second level of dependent scalar
+                # loads -- are then needed by the flush only, and nothing ahead of the main loop waits for them)
+                zcount = f"(int)oc{k}_maxnnz" if configuration["early_loads"] else f"nnzb{k}"
+                stage.append((rm, f"for (int q = tid; q < {zcount}; q += nthr) sm{k}[q] = 0;"))
                 # column masking (BC columns, pyop2/parloop.py:279-302) stays in the loop: a masked contribution adds 0.0.  Moving
                 # it to the row flush (one bit per CSR entry) removes 48 VALU instructions per instance and is NOT faster --
                 # the kernel is bound by the LDS pipe (profiles/r3b_ab_colmask.txt: 0.968 vs 0.952 ms tiled, 1.31 vs 1.19 un-hinted)
@@ -701,8 +708,18 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 # a BC-masked column adds 0.0 to its (existing) position instead of branching around the atomic:
                 # the value array is unchanged either way, and the scatter stays one branch per row
                 val = f"t{k}[i*{ac} + j]"
+                dropped = f"{'cmk%d[j]' % k if cm != rm else '(rw%d[j] >> 31)' % k}"
                 if colmask:
-                    val = f"(({'cmk%d[j]' % k if cm != rm else '(rw%d[j] >> 31)' % k}) ? 0.0 : {val})"
+                    val = f"(({dropped}) ? 0.0 : {val})"
+                if fx:
+                    # fixed-point trip: a BC-masked column scales its contributions by zero (no select per contribution); the
+                    # fp64 trip of a block that fell back tracks the magnitudes as well (the next launch's scale comes from them)
+                    pre_fx = [f"double fdS{k}[{ac}];", f"for (int j = 0; j < {ac}; ++j) fdS{k}[j] = ({dropped}) ? 0.0 : fd_S;"] if colmask else []
+                    sj = f"fdS{k}[j]" if colmask else "fd_S"
+                    at = lines.index(f"for (int i = 0; i < {ar}; ++i) {{")
+                    fixed = lines[:at] + pre_fx + lines[at:] + [f"    fdw::fx_acc(&sm{k}[base + kk{k}[i*{ac} + j]], t{k}[i*{ac} + j], {sj}, fd_mu, fd_mi);", "  }", "}"]
+                    unpack_fx.append("\n    ".join(fixed))
+                    lines += [f"    fdw::fx_track(t{k}[i*{ac} + j], fd_mu, fd_mi);"]
                 lines += [f"    atomicAdd(&sm{k}[base + kk{k}[i*{ac} + j]], {val});", "  }", "}"]
                 unpack.append("\n    ".join(lines))
                 if ocrp:
@@ -814,6 +831,8 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
     need_red = bool(post)
     if need_red:
         src.append("  __shared__ double fd_red[16];")
+    if fx:
+        src.append("  __shared__ unsigned fd_fxmax;")
     layer_parallel = True
     if staged:
         src += ["  extern __shared__ __align__(16) unsigned char fd_lds[];",
@@ -823,20 +842,22 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         src += ["  " + s for s in lds_decl + lds_tail_const + lds_tail_var]
         for mi in staged_maps:
             src.append(f"  const int l0_{mi} = p{mi}_blkoff[b], nd{mi} = p{mi}_blkoff[b+1] - l0_{mi};")
-        src += ["  " + s for s in mat_stage_pre]
-        src += ["  " + s for _, s in stage]
+        stage_src = ["  " + s for s in mat_stage_pre]
+        stage_src += ["  " + s for _, s in stage]
         # node-major staging: the node-list entry is requested first, then all the rows that depend on it
         for mi, acts in node_actions.items():
-            src.append(f"  for (int i_0 = tid; i_0 < nd{mi}; i_0 += nthr) {{")
+            stage_src.append(f"  for (int i_0 = tid; i_0 < nd{mi}; i_0 += nthr) {{")
             if any("G_U" in l for act in acts for part in (0, 1) for l in act[part]):
-                src.append(f"    const int g_0 = p{mi}_list[l0_{mi} + i_0];")
+                stage_src.append(f"    const int g_0 = p{mi}_list[l0_{mi} + i_0];")
             for part in (0, 1):
                 for act in acts:
                     for l in act[part]:
-                        src.append("    " + l.replace("_U", "_0").replace("G_0", "g_0").replace("I_0", "i_0"))
-            src.append("  }")
-        src.append("  __syncthreads();")
-        src += ["  " + s for s in pre]
+                        stage_src.append("    " + l.replace("_U", "_0").replace("G_0", "g_0").replace("I_0", "i_0"))
+            stage_src.append("  }")
+        if fx:
+            stage_src.append("  if (tid == 0) fd_fxmax = 0u;")
+        stage_src.append("  __syncthreads();")
+        stage_src += ["  " + s for s in pre]
         src += ["  const int fd_first = e0 + tid, fd_step = nthr, fd_last = e1;"]
         # software pipeline: the packed index rows of the NEXT entity are requested before the current
         # entity's local kernel runs, so their HBM latency hides under ~10^2 fp64 instructions
@@ -904,17 +925,6 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             ent_of = lambda ii: f"(fd_ebase + ({ii} - e0) / {threads})"
         else:
             ent_of = lambda ii: ii
-        if pf:
-            for cur, nxt, name, n, ld in idx_loads:
-                src.append(f"  {cur}; {nxt};")
-            src.append("  int e_cur = 0, e_nx = 0;")
-            src.append("  if (fd_first < fd_last) {")
-            src.append(f"    e_cur = {ent_of('fd_first')};")
-            for cur, nxt, name, n, ld in idx_loads:
-                src.append("    " + ld.replace("II", "fd_first").replace("EE", "e_cur").replace("DST", name))
-            src.append("  }")
-        src.append("  for (int it = fd_first; it < fd_last; it += fd_step) {")
-
         def decode(v):
             """virtual id (position in the subset x layer) -> base entity ``e`` (+ ``layer``)"""
             out = []
@@ -926,35 +936,103 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             else:
                 out.append(f"    const int e = fd_order_[{v}];")
             return out
-        if pf:
-            if virt:
-                src += decode("e_cur")
-            else:
-                src.append("    const int e = e_cur;")
-            src.append("    const int itn = (it + fd_step < fd_last) ? it + fd_step : it;")
-            src.append(f"    e_nx = {ent_of('itn')};")
+
+        def prologue():
+            """registers of the software pipeline and the index rows of the lane's first entity"""
+            out = []
             for cur, nxt, name, n, ld in idx_loads:
-                src.append("    " + ld.replace("II", "itn").replace("EE", "e_nx").replace("DST", "nx_" + name))
+                out.append(f"  {cur}; {nxt};")
+            out.append("  int e_cur = 0, e_nx = 0;")
+            out.append("  if (fd_first < fd_last) {")
+            out.append(f"    e_cur = {ent_of('fd_first')};")
+            for cur, nxt, name, n, ld in idx_loads:
+                out.append("    " + ld.replace("II", "fd_first").replace("EE", "e_cur").replace("DST", name))
+            out.append("  }")
+            return out
+
+        # the first trip's index rows are requested BEFORE the staging phase (they depend on the block's bounds only), so the
+        # block pays one memory round trip ahead of its main loop -- staging and index rows side by side -- instead of two
+        early = bool(pf and configuration["early_loads"])
+        if early:
+            src += prologue()
+        src += stage_src
+
+        def main_loop(unpack_lines, own_prologue=True):
+            """the entity loop of the block (its own scope: the "_fx" wrappers hold two of them)"""
+            out = ["  {"]
+            if pf and own_prologue:
+                out += prologue()
+            out.append("  for (int it = fd_first; it < fd_last; it += fd_step) {")
+            if pf:
+                if virt:
+                    out.extend(decode("e_cur"))
+                else:
+                    out.append("    const int e = e_cur;")
+                out.append("    const int itn = (it + fd_step < fd_last) ? it + fd_step : it;")
+                out.append(f"    e_nx = {ent_of('itn')};")
+                for cur, nxt, name, n, ld in idx_loads:
+                    out.append("    " + ld.replace("II", "itn").replace("EE", "e_nx").replace("DST", "nx_" + name))
+            else:
+                if virt:
+                    out.append(f"    const int fd_v = {ent_of('it')};")
+                    out.extend(decode("fd_v"))
+                else:
+                    out.append(f"    const int e = {ent_of('it')};")
+                for cur, nxt, name, n, ld in idx_loads:
+                    out.append(f"    {cur}; " + ld.replace("II", "it").replace("EE", "e").replace("DST", name))
+            out += ["    " + s_ for s_ in rec_decode]
+            out += ["    " + s_ for s_ in pack]
+            out.append(f"    fdk::{lk.name}({', '.join(call_args)});")
+            out += ["    " + s_ for s_ in unpack_lines]
+            if pf:
+                for cur, nxt, name, n, ld in idx_loads:
+                    out.append(f"    for (int q = 0; q < {n}; ++q) {name}[q] = nx_{name}[q];")
+                out.append("    e_cur = e_nx;")
+            out += ["  }", "  }"]
+            return out
+
+        if fx:
+            # Checked fixed-point accumulation: a fixed-point pass when the block has a scale; a block whose largest contribution
+            # fell outside the window of that scale (or was not finite) clears its accumulators and redoes its instances with fp64
+            # atomics -- its rows are nobody else's -- and either way leaves the record its next launch uses.
+            mats = [i_ for i_ in infos if i_["kind"] == "mat"]
+            if not ocr or len(mats) != 1 or len(unpack) != 1 or len(unpack_fx) != 1 or post:
+                raise ValueError("fixed-point accumulation serves scalar whole-entity owner-computes-rows loops")
+            K_ = mats[0]["k"]
+            get_re = re.compile(r"(=|\+) sm%d\[([^\]]+)\]" % K_)
+            flush_fx = [get_re.sub(lambda m_: "%s fdw::fx_get(sm%d[%s], fd_iS)" % (m_.group(1), K_, m_.group(2)), s_) for _, s_ in flush]
+            for line in flush_fx:
+                for piece in line.split(";"):
+                    if ("sm%d[" % K_) in piece and "fdw::fx_get" not in piece:
+                        raise ValueError("fixed-point accumulation: an accumulator access of this flush is not covered: " + piece.strip())
+            zcount_ = f"(int)oc{K_}_maxnnz" if configuration["early_loads"] else f"nnzb{K_}"
+            src += [f"  const fdw::fx_block_t fd_rec = fx{K_}_scale[b];",
+                    "  const double fd_S = fd_rec.S, fd_iS = fd_rec.invS;",
+                    "  unsigned fd_mu = 0u; int fd_mi = 0;",
+                    "  bool fd_fixed = fd_S != 0.0, fd_fell = false;",
+                    "  if (fd_fixed) {"]
+            src += main_loop(unpack_fx, own_prologue=not early)
+            src += ["    fdw::fx_block_max(&fd_fxmax, fd_mu, fd_mi);",
+                    "    __syncthreads();",
+                    "    if (fdw::fx_outside(fd_rec, fd_fxmax)) {",
+                    "      fd_fixed = false; fd_fell = true;",
+                    f"      for (int q = tid; q < {zcount_}; q += nthr) sm{K_}[q] = 0;",
+                    "      __syncthreads();",
+                    "    }",
+                    "  }",
+                    "  if (!fd_fixed) {"]
+            src += main_loop(unpack)
+            src += ["    if (!fd_fell) fdw::fx_block_max(&fd_fxmax, fd_mu, fd_mi);",
+                    "    __syncthreads();"]
+            src += ["    " + s_ for _, s_ in flush]
+            src.append("  } else {")
+            src += ["    " + s_ for s_ in flush_fx]
+            src += ["  }", f"  if (tid == 0) fdw::fx_update<{int(configuration['ocr_fx_headroom'])}>(fx{K_}_scale + b, fd_rec, fd_fxmax, fd_fell, fx{K_}_stat);"]
         else:
-            if virt:
-                src.append(f"    const int fd_v = {ent_of('it')};")
-                src += decode("fd_v")
-            else:
-                src.append(f"    const int e = {ent_of('it')};")
-            for cur, nxt, name, n, ld in idx_loads:
-                src.append(f"    {cur}; " + ld.replace("II", "it").replace("EE", "e").replace("DST", name))
-        src += ["    " + s for s in rec_decode]
-        src += ["    " + s for s in pack]
-        src.append(f"    fdk::{lk.name}({', '.join(call_args)});")
-        src += ["    " + s for s in unpack]
-        if pf:
-            for cur, nxt, name, n, ld in idx_loads:
-                src.append(f"    for (int q = 0; q < {n}; ++q) {name}[q] = nx_{name}[q];")
-            src.append("    e_cur = e_nx;")
-        src.append("  }")
-        if flush:
-            src.append("  __syncthreads();")
-            src += ["  " + s for _, s in flush]
+            src += main_loop(unpack, own_prologue=not early)
+            if flush:
+                src.append("  __syncthreads();")
+                src += ["  " + s_ for _, s_ in flush]
         src += ["  " + s for s in post]
     else:
         if extruded:
@@ -1005,29 +1083,6 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         for mi, S in zip(staged_maps, strides):
             pat = re.compile(r"\bp%d_maxnd\b" % mi)
             src[sig + 1:] = [pat.sub("((long long)%d)" % S, l) for l in src[sig + 1:]]
-    if fx_bits:
-        # Fixed-point accumulation (experiment).  A contribution x enters as the BIT PATTERN of fma(x, 2^B, 1.5 * 2^52): the pattern is
-        # that of the offset plus round(x 2^B) as a 64-bit integer, so an integer atomic add sums the rounded values exactly and
-        # order-independently, and the n copies of the offset's pattern (0x4338 << 48: its low 48 bits are zero) never reach the low 48
-        # bits -- the flush sign-extends those and scales back.  Valid while |sum| 2^B < 2^47: the scale is the CALLER's promise
-        # (FDHIP_OCR_FIXED_POINT=B), there is no overflow check.  Why: ds_add_u64 runs at 6.2 lanes per clock where ds_add_f64 runs
-        # at 3.3 (profiles/r1i_microbench_lds.txt) and the P1 Jacobian is bound by exactly those atomics.
-        mats = [i_ for i_ in infos if i_["kind"] == "mat"]
-        if not ocr or len(mats) != 1 or int(np.prod(mats[0]["arg"].dims[0])) * int(np.prod(mats[0]["arg"].dims[1])) != 1:
-            raise ValueError("fixed-point accumulation serves scalar owner-computes-rows loops")
-        K_ = mats[0]["k"]
-        S_, IS_ = repr(float(2 ** fx_bits)), repr(float(2.0 ** -fx_bits))
-        add_re = re.compile(r"atomicAdd\(&sm%d\[(.*?)\], (.*)\);" % K_)
-        get_re = re.compile(r"(=|\+) sm%d\[([^\]]+)\]" % K_)
-        out_ = []
-        for line in src:
-            line = add_re.sub(lambda m_: "fdw::fx_add(&sm%d[%s], %s, %s);" % (K_, m_.group(1), m_.group(2), S_), line)
-            line = get_re.sub(lambda m_: "%s fdw::fx_get(sm%d[%s], %s)" % (m_.group(1), K_, m_.group(2), IS_), line)
-            out_.append(line)
-        src = out_
-        for line in "\n".join(src).split("\n"):
-            if ("sm%d[" % K_) in line and "fdw::fx_" not in line and ("sm%d[q] = 0" % K_) not in line:
-                raise ValueError("fixed-point accumulation: an accumulator access of this wrapper shape is not covered: " + line.strip())
     return WrapperSource("\n".join(src) + "\n", sym, full_mode, layout, len(maps), staged_maps, lds_items,
                          layer_parallel, threads, kbytes, mat_staged,
                          (threads if (staged and configuration["lane_strided"]) else 0),
@@ -1206,20 +1261,29 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     src += ["  " + s for s in lds_decl]
     for mi in staged_maps:
         src.append(f"  const int l0_{mi} = p{mi}_blkoff[b], nd{mi} = p{mi}_blkoff[b+1] - l0_{mi};")
+    # early: the first trip's index rows are requested ahead of the staging phase, the accumulators are zeroed by capacity and the
+    # run displacements are staged after the main loop -- nothing before the main loop waits for the block's row starts or runs
+    # (a second level of dependent scalar loads), and the block pays one memory round trip before its first trip instead of two
+    early = bool(configuration["prefetch"] and configuration["early_loads"])
     src += [f"  const int n0 = oc{K}_rblk[b], nown = oc{K}_rblk[b+1] - n0;",
-            f"  const int r0 = oc{K}_rowptr[n0], nnzb = (oc{K}_rowptr[n0 + nown] - r0)*{B};",
-            f"  for (int q = tid; q < nnzb; q += nthr) sm{K}[q] = 0;"]
+            f"  const int r0 = oc{K}_rowptr[n0], nnzb = (oc{K}_rowptr[n0 + nown] - r0)*{B};"]
     if runflush:
-        src += [f"  const int br0 = oc{K}_brun[b], nrun = oc{K}_brun[b+1] - br0;",
-                f'  _Pragma("clang loop unroll(disable) vectorize(disable)") for (int q = tid; q < nrun; q += nthr) srun{K}[q] = oc{K}_rdelta[br0 + q];']
+        src.append(f"  const int br0 = oc{K}_brun[b], nrun = oc{K}_brun[b+1] - br0;")
+    srun_stage = (f'  _Pragma("clang loop unroll(disable) vectorize(disable)") for (int q = tid; q < nrun; q += nthr) srun{K}[q] = oc{K}_rdelta[br0 + q];'
+                  if runflush else None)
+    stage_src = [f"  for (int q = tid; q < {'(int)oc%d_maxnnz*%d' % (K, B) if early else 'nnzb'}; q += nthr) sm{K}[q] = 0;"]
+    if runflush and not early:
+        stage_src.append(srun_stage)
     for mi, acts in stage_nodes.items():
-        src.append(f"  for (int i = tid; i < nd{mi}; i += nthr) {{")
-        src.append(f"    const int g = p{mi}_list[l0_{mi} + i];")
+        stage_src.append(f"  for (int i = tid; i < nd{mi}; i += nthr) {{")
+        stage_src.append(f"    const int g = p{mi}_list[l0_{mi} + i];")
         for part in (0, 1):
             for act in acts:
-                src += ["    " + l for l in act[part]]
-        src.append("  }")
-    src.append("  __syncthreads();")
+                stage_src += ["    " + l for l in act[part]]
+        stage_src.append("  }")
+    stage_src.append("  __syncthreads();")
+    if not early:
+        src += stage_src
     if extruded:
         lo, hi = {ALL: ("layers[0]", "layers[1]-1"), ON_BOTTOM: ("layers[0]", "layers[0]+1"), ON_TOP: ("layers[1]-2", "layers[1]-1")}[gk._iteration_region]
         src.append(f"  const int fd_llo = {lo}, fd_nlit = ({hi}) - fd_llo;")
@@ -1281,6 +1345,8 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             src.append("    const int it1 = (e0 + tid + nthr < e1) ? e0 + tid + nthr : e0 + tid;")
             src += ["    " + l for l in loads("it1", "nx_")]
         src.append("  }")
+    if early:
+        src += stage_src
     src.append("  for (int it = e0 + tid; it < e1; it += nthr) {")
     if pf2:
         src.append("    const int itn = (it + 2*nthr < e1) ? it + 2*nthr : it;")
@@ -1330,7 +1396,10 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         src.append("    " + " ".join(f"{n} = nx_{n};" for n, _ in scal) + (" cmask = nx_cmask;" if dofmask else ""))
         if pf2:
             src.append("    " + " ".join(f"nx_{n} = n2_{n};" for n, _ in scal))
-    src += ["  }", "  __syncthreads();"]
+    src.append("  }")
+    if runflush and early:
+        src.append(srun_stage)
+    src.append("  __syncthreads();")
     if runflush:
         FU = max(1, int(configuration["flush_batch"]))
         src.append(f"  for (int q0 = tid; q0 < nnzb; q0 += {FU}*nthr) {{ int g[{FU}]; "

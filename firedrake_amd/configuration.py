@@ -27,8 +27,11 @@ configuration = {
     "ocr_pack": _env("FDHIP_OCR_PACK", 1, int),            # bank-aware greedy packing of the instance lists (fd_ocrplan_pack)
     "ocr_pad_windows": _env("FDHIP_OCR_PAD_WINDOWS", 0, int),   # 16-lane LDS atomic windows on distinct banks: 1 = end a window with dummy instances,
                                                                  # 2 = with instances from the tail of the block's list (a permutation)
-    "ocr_fixed_point": _env("FDHIP_OCR_FIXED_POINT", 0, int),   # experiment: B > 0 = whole-entity owner-computes-rows loops accumulate 64-bit
-                                                                 # fixed-point sums at scale 2^B in LDS (integer atomics); needs |A| 2^B < 2^47
+    # whole-entity owner-computes-rows loops (scalar fp64 matrices) reduce their element matrices in LDS as CHECKED 64-bit
+    # fixed-point sums through integer atomics (codegen "_fx"; exact, order-independent; blocks that meet a contribution beyond
+    # the scale's limit redo their rows in fp64 inside the launch); 0 = fp64 atomics (ds_add_f64)
+    "ocr_fixed_point": _env("FDHIP_OCR_FIXED_POINT", 1, int),
+    "ocr_fx_headroom": _env("FDHIP_OCR_FX_HEADROOM", 3, int),   # bits between the largest contribution seen and the limit
     "ocr_pack_after": _env("FDHIP_OCR_PACK_AFTER", 64, int),   # ... once a plan has been launched this often (0 = when it is built)
     # owner-computes-rows index tables: one bit-packed record per instance (fd_ocr_pack_records; 0 = uint16 / uint8 rows), the
     # diagonal offsets taken from the row node's LDS word, and the flush of a derived row order run-coded (fd_ocr_row_runs)
@@ -46,6 +49,8 @@ configuration = {
     # v_add_u32 per access
     "lds_const_stride": _env("FDHIP_LDS_CONST_STRIDE", 1, int),     # staged loops: P1 residual 0.43 -> 0.41 ms
     "prefetch": _env("FDHIP_PREFETCH", 1, int),          # software-pipeline the packed index rows
+    "early_loads": _env("FDHIP_EARLY_LOADS", 1, int),    # first trip's index rows requested ahead of the staging phase; accumulators
+                                                         # zeroed by capacity (no second level of dependent scalar loads before the loop)
     "tensor_wrappers": _env("FDHIP_TENSOR_WRAPPERS", 1, int),   # MFMA matrix / sum-factorised action for TensorProductLocalKernels
     "tp_action_waves": _env("FDHIP_TP_ACTION_WAVES", 3, int),   # wavefronts per SIMD the action wrapper is compiled for (register cap; 0 = none)
     "tp_store_single_rows": _env("FDHIP_TP_STORE_SINGLE_ROWS", 0, int),   # a zeroed tensor-product Mat: zero the shared rows only, store the rest

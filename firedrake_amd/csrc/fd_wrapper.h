@@ -171,18 +171,65 @@ template <int ARITY> __device__ __forceinline__ void load_lmap(const uint16_t *_
 // owner-computes-rows loop back to back -- the local-map entries at ceil(log2(nodes per block)) bits, the row-offset entries
 // at ceil(log2(longest CSR row)) bits -- instead of uint16 / uint8 arrays: P1 tetrahedra 24 -> 12 bytes per instance.
 // Field offsets and widths are compile-time constants, so a field is one v_bfe_u32 (two instructions when it straddles words).
-// Fixed-point accumulation (experiment, codegen mode suffix "_x<B>"): see codegen.generate_wrapper.
-__device__ __forceinline__ void fx_add(double *p, double x, double S) {
-    const double t = __builtin_fma(x, S, 6755399441055744.0);          // 1.5 * 2^52: the sum's unit in the last place is 1
-    unsigned long long b;
+// ---- checked fixed-point accumulation (codegen mode suffix "_fx", whole-entity owner-computes-rows loops).
+// ds_add_u64 runs at ~6 lanes per clock on scattered addresses where ds_add_f64 runs at ~3.3 (profiles/r1i_microbench_lds.txt)
+// and the LDS atomics bind the P1 Jacobian.  A contribution x therefore enters the LDS accumulator as the INTEGER
+// k = round(x S): the bit pattern of fma(x, S, 1.5 * 2^52) is 0x4338 << 48 plus k in two's complement (|k| < 2^51), and the low
+// word of that constant is zero, so removing it costs one 32-bit add on the high word.  The sums are exact and independent of
+// the order of the instances.  Every ROW BLOCK keeps its own scale S = 2^(50 - L) in a 32-byte record next to the window
+// [2^(L-6), 2^L) its largest |contribution| must fall into: below the upper end |x S| < 2^50 (2^12 contributions fit 63 bits),
+// above the lower end the quantum 2^-(50-L) is at most 2^-44 of that contribution (a sum of n is exact to n/2 quanta).  The high
+// words of the contributions are folded into two running maxima per lane (unsigned: the largest negative magnitude, signed: the
+// largest positive one; NaN / Inf land above every limit); a block whose maximum leaves the window -- or that has no scale yet --
+// redoes ITS rows with fp64 atomics inside the same launch (owner-computes-rows: its rows are nobody else's) and rewrites its
+// record for the next launch.  No host round trip, no second kernel.
+struct fx_block_t { double S, invS; unsigned lim_hi, low_hi; int L; unsigned pad; };
+__device__ __forceinline__ void fx_track(double x, unsigned &mu, int &mi) {
+    const int hi = __double2hiint(x);
+    mu = max(mu, (unsigned)hi);
+    mi = max(mi, hi);
+}
+__device__ __forceinline__ void fx_acc(double *p, double x, double S, unsigned &mu, int &mi) {
+    fx_track(x, mu, mi);
+    const double t = __builtin_fma(x, S, 6755399441055744.0);          // 1.5 * 2^52: unit in the last place = 1
+    long long b;
     __builtin_memcpy(&b, &t, 8);
-    atomicAdd((unsigned long long *)p, b);
+    b -= 0x4338000000000000LL;
+    atomicAdd((unsigned long long *)p, (unsigned long long)b);
 }
 __device__ __forceinline__ double fx_get(double acc, double invS) {
     long long a;
     __builtin_memcpy(&a, &acc, 8);
-    a = (long long)((unsigned long long)a << 16) >> 16;                   // low 48 bits, sign-extended
     return (double)a * invS;
+}
+// fold the lanes' maxima into the block's LDS word (one LDS atomic per wavefront); callers put a barrier behind it
+__device__ __forceinline__ void fx_block_max(unsigned *smax, unsigned mu, int mi) {
+    unsigned am = max(mu & 0x7fffffffu, (unsigned)max(mi, 0));
+    for (int d = 32; d > 0; d >>= 1) am = max(am, (unsigned)__shfl_xor((int)am, d, 64));
+    if ((threadIdx.x & 63) == 0 && am) atomicMax(smax, am);
+}
+// true: the block's largest |contribution| (high word bm; 0 = none) lies outside the window of its scale
+__device__ __forceinline__ bool fx_outside(const fx_block_t &r, unsigned bm) { return bm != 0u && (bm >= r.lim_hi || bm < r.low_hi); }
+// one lane, end of the block: the record the NEXT launch of this block uses (kept while the maximum stays in the window's
+// middle, re-derived with H bits of headroom otherwise); stat[0] counts blocks that fell back from a scale, stat[1] blocks that
+// had none
+template <int H> __device__ __forceinline__ void fx_update(fx_block_t *rec, const fx_block_t &r, unsigned bm, bool fell, unsigned *stat) {
+    if (fell) atomicAdd(stat, 1u);
+    if (r.S == 0.0) atomicAdd(stat + 1, 1u);
+    if (bm == 0u || bm >= 0x7ff00000u) return;                         // nothing accumulated, or not finite: keep
+    const int e = (int)((bm >> 20) & 0x7ffu) - 1023 + 1;               // every |contribution| < 2^e
+    if (r.S != 0.0 && e <= r.L - 1 && e >= r.L - 5) return;
+    const int L = e + H;
+    fx_block_t n = {0.0, 0.0, 0u, 0u, 0, 0u};
+    if (L > -900 && L < 900) {
+        const unsigned long long sb = (unsigned long long)(1023 + 50 - L) << 52, ib = (unsigned long long)(1023 - 50 + L) << 52;
+        __builtin_memcpy(&n.S, &sb, 8);
+        __builtin_memcpy(&n.invS, &ib, 8);
+        n.lim_hi = (unsigned)(L + 1023) << 20;
+        n.low_hi = (unsigned)(L - 6 + 1023) << 20;
+        n.L = L;
+    }
+    *rec = n;
 }
 
 template <int W> __device__ __forceinline__ void load_rec(const unsigned *__restrict__ p, unsigned (&w)[W]) {

@@ -1033,10 +1033,16 @@ class Parloop:
             if rec[3] * 4 >= sum(staged[mi].arity for mi in src.staged_maps) * 2 + rmap.arity * cmap.arity * op.kbytes:
                 rec = None                                            # no smaller than the plain rows
         variant = mode_variant(base, op.kbytes, nds, rec)
-        if int(configuration["ocr_fixed_point"]) > 0 and int(sp.dsets[0].cdim) * int(sp.dsets[1].cdim) == 1:
-            # experiment: 64-bit fixed-point LDS accumulators at scale 2^B (codegen mode suffix "_x<B>"; the caller vouches for B)
-            variant += f"_x{int(configuration['ocr_fixed_point'])}"
-        geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz, "rec": rec, "runs": runs,
+        fxbufs = None
+        if int(configuration["ocr_fixed_point"]) > 0 and int(sp.dsets[0].cdim) * int(sp.dsets[1].cdim) == 1 \
+                and np.dtype(pa.data.dtype) == np.dtype("float64"):
+            # checked fixed-point LDS accumulators (codegen mode suffix "_fx"): one 32-byte scale record per row block, written by the
+            # block itself at the end of every launch (zero = no scale yet = an fp64 pass), and two counters
+            variant += "_fx"
+            fxbufs = (DeviceBuffer(max(op.nblocks, 1) * 32), DeviceBuffer(16))
+            for b_ in fxbufs:
+                b_.zero()
+        geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz, "rec": rec, "runs": runs, "fx": fxbufs,
                "cw": prep["cw"] if variant == src.mode else self.global_kernel.compile(variant), "row_order": row_order}
         prep["parts"][gkey] = geo
         if configuration["debug"]:
@@ -1226,10 +1232,30 @@ class Parloop:
             elif kind in ("mat_row_lgmap", "mat_col_lgmap"):
                 pa = self.arguments[desc[1]]
                 out.append(self._lgmap(pa.lgmaps[0 if kind == "mat_row_lgmap" else 1]))
+            elif kind in ("fx_scale", "fx_stat"):
+                out.append(geo["fx"][0 if kind == "fx_scale" else 1].ptr)
             else:
                 raise AssertionError(kind)
         cw.launch(0, op.ninst, out, block_threads=src.block_threads, ents_per_block=op.max_inst, nblocks=op.nblocks,
                   lds_bytes=geo["lds"])
+
+    def fixed_point_state(self):
+        """Diagnostics of the checked fixed-point accumulation of this loop's owner-computes-rows parts (blocks the stream): per
+        part the number of row blocks, how many of them hold a scale, the range of their limit exponents L (a contribution of
+        such a block must stay below 2^L), and the running counts of blocks that fell back from a scale to fp64 / ran without one."""
+        out = []
+        for key, geo in (self._prepared or {}).get("parts", {}).items():
+            if key[0] != "ocr" or not isinstance(geo, dict) or geo.get("fx") is None:
+                continue
+            nb = geo["ocr"].nblocks
+            rec = geo["fx"][0].download(np.uint8, (max(nb, 1) * 32,)).view(np.dtype([("S", "<f8"), ("invS", "<f8"), ("lim", "<u4"), ("low", "<u4"),
+                                                                                      ("L", "<i4"), ("pad", "<u4")]))[:nb]
+            st = geo["fx"][1].download(np.uint32, (4,))
+            have = rec["S"] > 0
+            out.append({"part": key[1:], "blocks": int(nb), "scaled_blocks": int(have.sum()),
+                        "limit_exponents": (int(rec["L"][have].min()), int(rec["L"][have].max())) if have.any() else None,
+                        "fallback_blocks": int(st[0]), "unscaled_blocks": int(st[1])})
+        return out
 
     def _plan_copy(self, geo, k, plan):
         """Device pointer of READ Dat ``k`` in PLAN order (row of list entry i at i*cdim), or 0: a field that did not change since

@@ -30,15 +30,15 @@ def _compile(source, name):
     key = hashlib.sha1(source.encode()).hexdigest()[:16]
     so = os.path.join(_BUILD, f"{name}_{key}.so")
     if not os.path.exists(so):
-        src = os.path.join(_BUILD, f"{name}_{key}.cpp")
+        src = os.path.join(_BUILD, f"{name}_{key}.{os.getpid()}.cpp")
         with open(src, "w") as f:
             f.write(source)
         cmd = ["g++", "-O1", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-std=gnu++17", "-w", "-I", os.path.join(_HERE, "hostsim"),
-               "-o", so + ".tmp", src, "-lm"]
+               "-o", so + f".{os.getpid()}.tmp", src, "-lm"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hostsim compile failed:\n" + r.stderr[-4000:])
-        os.replace(so + ".tmp", so)
+        os.replace(so + f".{os.getpid()}.tmp", so)
     return ctypes.CDLL(so)
 
 
@@ -47,16 +47,16 @@ def _compile_mt(source, name):
     key = hashlib.sha1(source.encode()).hexdigest()[:16]
     so = os.path.join(_BUILD, f"{name}_mt_{key}.so")
     if not os.path.exists(so):
-        src = os.path.join(_BUILD, f"{name}_mt_{key}.cpp")
+        src = os.path.join(_BUILD, f"{name}_mt_{key}.{os.getpid()}.cpp")
         with open(src, "w") as f:
             f.write(source)
         # -Bsymbolic: the wrapper's own definition wins over a same-named kernel handle exported by a loaded libfdhip.so
         cmd = ["g++", "-O1", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-std=gnu++20", "-pthread", "-w", "-I", os.path.join(_HERE, "hostsim", "mt"),
-               "-o", so + ".tmp", src, "-lm"]
+               "-o", so + f".{os.getpid()}.tmp", src, "-lm"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hostsim (mt) compile failed:\n" + r.stderr[-4000:])
-        os.replace(so + ".tmp", so)
+        os.replace(so + f".{os.getpid()}.tmp", so)
     return ctypes.CDLL(so)
 
 
@@ -217,7 +217,7 @@ def row_runs_ref(prowptr, gstart, rb):
     return grun, brun, rdelta, int(np.diff(brun).max()) if len(rb) > 1 else 0
 
 
-def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False, run_flush=False, pad=False, fixed_point=0):
+def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False, run_flush=False, pad=False, fixed_point=None):
     """Execute a matrix-assembly Parloop ``pl`` with the OWNER-COMPUTES-ROWS wrapper on the host (one OS thread per
     lane, tests/hostsim/mt/fd_wrapper.h).  The plan tables come from the numpy restatements in helpers.py; the CSR
     pattern from the oracle.  Returns the OracleCSR holding the assembled values."""
@@ -267,7 +267,7 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False,
     if order is not None and run_flush:
         run_tabs = row_runs_ref(prowptr, csr.rowptr[plist], rb)
     src = generate_wrapper(gk, mode_variant(("ocrpr" if run_tabs else "ocrp") if order is not None else "ocr", 1,
-                                            [plans[mi][3] for mi in base.staged_maps], rec) + (f"_x{int(fixed_point)}" if fixed_point else ""))
+                                            [plans[mi][3] for mi in base.staged_maps], rec) + ("_fx" if fixed_point is not None else ""))
     text = src.source.replace("extern __shared__ __align__(16) unsigned char fd_lds[];", "unsigned char *fd_lds = fd_sim::lds;")
     sig = re.search(r'extern "C" __global__[^\n]*void %s\((.*)\)\n' % src.symbol, text).group(1)
     names = [p.split()[-1].lstrip("*") for p in sig.split(", ")]
@@ -382,6 +382,24 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False,
             cargs.append(ptr(np.asarray(mpa.lgmaps[0 if kind == "mat_row_lgmap" else 1], dtype=np.int32)))
         elif kind == "plan_copy":
             cargs.append(_plan_copy_arg(pl, desc, plans, ptr))
+        elif kind == "fx_scale":
+            # one fx_block_t {S, 1/S, lim_hi, low_hi, L, pad} per row block: ``fixed_point`` = True (no scale yet: every block runs
+            # fp64 and writes its record), a limit exponent L for all blocks (|x| < 2^L, S = 2^(50 - L)), or the record array of an
+            # earlier run
+            dt = np.dtype([("S", "<f8"), ("invS", "<f8"), ("lim", "<u4"), ("low", "<u4"), ("L", "<i4"), ("pad", "<u4")])
+            if isinstance(fixed_point, np.ndarray):
+                rec_ = fixed_point.copy()
+            else:
+                rec_ = np.zeros(len(rb) - 1, dtype=dt)
+                if fixed_point is not True:
+                    L = int(fixed_point)
+                    rec_["S"], rec_["invS"], rec_["L"] = 2.0 ** (50 - L), 2.0 ** (L - 50), L
+                    rec_["lim"], rec_["low"] = (L + 1023) << 20, (L - 6 + 1023) << 20
+            csr.fx_records = rec_
+            cargs.append(ptr(rec_) if False else ctypes.c_void_p(rec_.ctypes.data))
+        elif kind == "fx_stat":
+            csr.fx_stat = np.zeros(4, dtype=np.uint32)
+            cargs.append(ctypes.c_void_p(csr.fx_stat.ctypes.data))
         else:
             raise AssertionError(f"hostsim (ocr) cannot provide {kind}")
     lib.sim_run(*cargs)

@@ -148,18 +148,50 @@ template <class T, int N> inline void load_packed(const T *p, int (&out)[N]) {
     for (int k = 0; k < N; ++k) out[k] = p[k];
 }
 template <int ARITY> inline void load_lmap(const uint16_t *p, int (&out)[ARITY]) { load_packed<uint16_t, ARITY>(p, out); }
-// fixed-point accumulation (codegen mode suffix "_x<B>"), as in csrc/fd_wrapper.h
-inline void fx_add(double *p, double x, double S) {
+// checked fixed-point accumulation (codegen mode suffix "_fx"), as in csrc/fd_wrapper.h
+struct fx_block_t { double S, invS; unsigned lim_hi, low_hi; int L; unsigned pad; };
+inline void fx_track(double x, unsigned &mu, int &mi) {
+    long long b;
+    __builtin_memcpy(&b, &x, 8);
+    const int hi = (int)(b >> 32);
+    if ((unsigned)hi > mu) mu = (unsigned)hi;
+    if (hi > mi) mi = hi;
+}
+inline void fx_acc(double *p, double x, double S, unsigned &mu, int &mi) {
+    fx_track(x, mu, mi);
     const double t = __builtin_fma(x, S, 6755399441055744.0);
-    unsigned long long b;
+    long long b;
     __builtin_memcpy(&b, &t, 8);
-    atomicAdd((unsigned long long *)p, b);
+    b -= 0x4338000000000000LL;
+    atomicAdd((unsigned long long *)p, (unsigned long long)b);
 }
 inline double fx_get(double acc, double invS) {
     long long a;
     __builtin_memcpy(&a, &acc, 8);
-    a = (long long)((unsigned long long)a << 16) >> 16;
     return (double)a * invS;
+}
+inline void fx_block_max(unsigned *smax, unsigned mu, int mi) {
+    unsigned am = mu & 0x7fffffffu;
+    if (mi > 0 && (unsigned)mi > am) am = (unsigned)mi;
+    if (am) fd_sim::cas_update(smax, [am](unsigned o) { return am > o ? am : o; });
+}
+inline bool fx_outside(const fx_block_t &r, unsigned bm) { return bm != 0u && (bm >= r.lim_hi || bm < r.low_hi); }
+template <int H> inline void fx_update(fx_block_t *rec, const fx_block_t &r, unsigned bm, bool fell, unsigned *stat) {
+    if (fell) stat[0] += 1u;                 // (workgroups run one after the other here)
+    if (r.S == 0.0) stat[1] += 1u;
+    if (bm == 0u || bm >= 0x7ff00000u) return;
+    const int e = (int)((bm >> 20) & 0x7ffu) - 1023 + 1;
+    if (r.S != 0.0 && e <= r.L - 1 && e >= r.L - 5) return;
+    const int L = e + H;
+    fx_block_t n = {0.0, 0.0, 0u, 0u, 0, 0u};
+    if (L > -900 && L < 900) {
+        n.S = ldexp(1.0, 50 - L);
+        n.invS = ldexp(1.0, L - 50);
+        n.lim_hi = (unsigned)(L + 1023) << 20;
+        n.low_hi = (unsigned)(L - 6 + 1023) << 20;
+        n.L = L;
+    }
+    *rec = n;
 }
 template <int W> inline void load_rec(const unsigned *p, unsigned (&w)[W]) { for (int k = 0; k < W; ++k) w[k] = p[k]; }
 template <int OFF, int BITS, int W> inline int rec_field(const unsigned (&w)[W]) {

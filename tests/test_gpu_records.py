@@ -317,9 +317,10 @@ def test_incremental_packer_reproduces_the_legacy_schedule_and_permuted_tables_t
 
 @pytest.mark.parametrize("numbering", ["lexicographic", "tiled"])
 def test_fixed_point_accumulators_give_the_oracle_matrix_bit_reproducibly(numbering, monkeypatch):
-    """FDHIP_OCR_FIXED_POINT=B (experiment): 64-bit fixed-point LDS accumulators through integer atomics (codegen mode "_x<B>").
-    With B = 46 - ceil(log2 max|A|) the P1 Jacobian is the oracle's to 1e-12 max|A|, and -- the sums being exact integers -- the
-    same BITS whatever the order of the instances (packed or not)."""
+    """Checked fixed-point accumulation (codegen mode "_fx", the default of whole-entity owner-computes-rows loops): the first
+    launch of a plan has no scales and runs fp64 blocks, each of which leaves the scale record of its next launch; from the second
+    launch on the element matrices are reduced as 64-bit integers.  The P1 Jacobian is the oracle's to 1e-12 max|A| either way, and
+    -- the sums being exact integers -- the same BITS whatever the order of the instances (packed or not)."""
     monkeypatch.setitem(configuration, "locality_min_entities", 64)
     m = fmesh.UnitCubeMesh(14, degrees=(1,), perturb=0.1, numbering=numbering)
     prob = forms.PoissonProblem(m, 1, bcs=True)
@@ -328,20 +329,70 @@ def test_fixed_point_accumulators_give_the_oracle_matrix_bit_reproducibly(number
     args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
     ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
     vmax = np.abs(ref.values).max()
-    monkeypatch.setitem(configuration, "ocr_fixed_point", 46 - int(np.ceil(np.log2(vmax))))
     got = []
     for after in (0, 1000):                                # packed at construction / never packed
         monkeypatch.setitem(configuration, "ocr_pack_after", after)
         p2 = forms.PoissonProblem(m, 1, bcs=True)
         mat2, pl2 = p2.jacobian()
-        for _ in range(2):
-            mat2.zero()
-            pl2.compute()
+        mat2.zero()
+        pl2.compute()                                      # no scales yet: fp64 blocks
+        (st,) = pl2.fixed_point_state()
+        assert st["unscaled_blocks"] == st["blocks"] and st["fallback_blocks"] == 0 and st["scaled_blocks"] >= st["blocks"] - 2
+        assert np.abs(mat2.csr()[2] - ref.values).max() <= 1e-12 * vmax
         geo = [g for key, g in pl2._prepared["parts"].items() if key[0] == "ocr"][0]
-        assert "_x" in geo["cw"].src.mode
+        assert geo["cw"].src.mode.endswith("_fx")
+        mat2.zero()
+        pl2.compute()                                      # fixed-point blocks
+        (st2,) = pl2.fixed_point_state()
+        assert st2["fallback_blocks"] == 0 and st2["unscaled_blocks"] == 2 * st["blocks"] - st["scaled_blocks"]
+        assert st2["limit_exponents"] == st["limit_exponents"]
         v = mat2.csr()[2]
         assert np.abs(v - ref.values).max() <= 1e-12 * vmax
         pl2.compute()                                      # accumulates on top
         assert np.abs(mat2.csr()[2] - 2.0 * ref.values).max() <= 2e-12 * vmax
         got.append(v)
     assert np.array_equal(got[0], got[1])
+
+
+def test_fixed_point_blocks_fall_back_to_fp64_when_the_contributions_leave_the_window_of_their_scale(monkeypatch):
+    """A block's scale comes from its PREVIOUS launch.  When its element matrices outgrow it (here: the mesh is stretched 64-fold
+    between two assemblies, the P1 stiffness entries grow with it) or shrink so far that the scale has become too coarse (4096-fold)
+    the block redoes its rows with fp64 atomics inside the same launch: the matrix is right, the fallbacks are counted, and the next
+    launch runs fixed-point again at the new scales.  Non-finite contributions: the blocks that meet them fall back, NaN lands
+    where fp64 puts it, the rest of the matrix is untouched."""
+    monkeypatch.setitem(configuration, "locality_min_entities", 64)
+    m = fmesh.UnitCubeMesh(12, degrees=(1,), perturb=0.1, numbering="lexicographic")
+    prob = forms.PoissonProblem(m, 1, bcs=True)
+    mat, pl = prob.jacobian()
+    mpa = pl.arguments[0]
+
+    def reference():
+        args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
+        return oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0].values
+
+    def assemble():
+        mat.zero()
+        pl.compute()
+        return mat.csr()[2], pl.fixed_point_state()[0]
+
+    ref = reference()
+    assemble()
+    v, st = assemble()
+    assert st["fallback_blocks"] == 0 and np.abs(v - ref).max() <= 1e-12 * np.abs(ref).max()
+    fell, lim = 0, st["limit_exponents"]
+    for factor, shift in ((64.0, 6), (1.0 / 4096.0, -12)):
+        m.coordinates.data[...] *= factor                   # (bumps dat_version: plan-ordered copies are dropped)
+        ref = reference()
+        v, st = assemble()                                  # launched at the old scales: every block with contributions falls back
+        assert st["fallback_blocks"] - fell >= st["scaled_blocks"] - 2
+        fell = st["fallback_blocks"]
+        assert np.abs(v - ref).max() <= 1e-12 * np.abs(ref).max()
+        assert st["limit_exponents"] == (lim[0] + shift, lim[1] + shift)        # ... and is re-scaled for the next launch
+        lim = st["limit_exponents"]
+        v, st = assemble()
+        assert st["fallback_blocks"] == fell and st["limit_exponents"] == lim
+        assert np.abs(v - ref).max() <= 1e-12 * np.abs(ref).max()
+    x = m.coordinates.data
+    x[5, 0] = np.nan
+    v, st = assemble()
+    assert st["fallback_blocks"] > fell and np.isnan(v).any() and np.isfinite(v).sum() > 0.5 * len(v)

@@ -596,11 +596,14 @@ def test_owner_computes_rows_over_a_row_order_on_host(bcs, numbering):
 
 @pytest.mark.parametrize("bcs", [False, True])
 def test_fixed_point_accumulation_on_host(bcs):
-    """Mode suffix "_x<B>" (experiment, FDHIP_OCR_FIXED_POINT): the LDS accumulators hold 64-bit fixed-point sums -- every
-    contribution enters as the bit pattern of fma(x, 2^B, 1.5 * 2^52) through an INTEGER atomic add, the flush sign-extends the low
-    48 bits and scales back (fdw::fx_add / fx_get).  With B = 46 - ceil(log2 max|A|) the result is the oracle's to 1e-12 max|A|, in
-    the caller's row order and in a derived one, fresh and accumulating, with records and the run-coded flush."""
+    """Mode suffix "_fx": the LDS accumulators hold CHECKED 64-bit fixed-point sums -- every contribution enters as the integer
+    round(x S) through an INTEGER atomic add (fdw::fx_acc), the flush scales back (fdw::fx_get).  Every row block keeps its own
+    scale S = 2^(50 - L) with the window [2^(L-6), 2^L) its largest contribution must fall into; a block without a scale, or whose
+    maximum leaves the window, (re)does its rows with fp64 atomics and writes the record of its next launch.  First run: fp64
+    blocks, records written; with them the result is the oracle's to 1e-12 max|A| in the caller's row order and in a derived one,
+    fresh and accumulating, with records and the run-coded flush -- and bitwise independent of the instance order."""
     from firedrake_amd import forms, mesh as fmesh
+    from firedrake_amd.configuration import configuration
     from helpers import locality_order_ref
     from hostsim import run_ocr
     mesh = fmesh.UnitCubeMesh(4, degrees=(1,), perturb=0.1, numbering="lexicographic")
@@ -612,16 +615,38 @@ def test_fixed_point_accumulation_on_host(bcs):
     args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
     ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
     vmax = np.abs(ref.values).max()
-    bits = 46 - int(np.ceil(np.log2(vmax)))
+    H = int(configuration["ocr_fx_headroom"])
     for kw in ({}, {"records": True}, {"order": order}, {"order": order, "records": True}, {"order": order, "records": True, "run_flush": True}):
-        got = run_ocr(pl, rows_per_block=19, fixed_point=bits, **kw)
+        # no scale yet: fp64 blocks, every block with contributions writes its record
+        cal = run_ocr(pl, rows_per_block=19, fixed_point=True, **kw)
+        nb = len(cal.fx_records)
+        assert np.abs(cal.values - ref.values).max() <= 1e-12 * vmax, kw
+        assert cal.fx_stat[0] == 0 and cal.fx_stat[1] == nb
+        have = cal.fx_records["S"] > 0
+        assert have.sum() >= nb - 2 and np.all(cal.fx_records["S"][have] == 2.0 ** (50 - cal.fx_records["L"][have]))
+        assert 2.0 ** (cal.fx_records["L"][have].max() - H) >= vmax / 32          # (a contribution is of the order of the entries)
+        got = run_ocr(pl, rows_per_block=19, fixed_point=cal.fx_records, **kw)
         assert np.abs(got.values - ref.values).max() <= 1e-12 * vmax, kw
-        got2 = run_ocr(pl, rows_per_block=19, zero_pending=False, fixed_point=bits, **kw)
+        assert got.fx_stat[0] == 0 and got.fx_stat[1] == nb - have.sum(), kw
+        assert np.array_equal(got.fx_records, cal.fx_records)                       # in the window: kept
+        got2 = run_ocr(pl, rows_per_block=19, zero_pending=False, fixed_point=cal.fx_records, **kw)
         assert np.abs(got2.values - (ref.values + 1.0)).max() <= 1e-12 * (1.0 + vmax), kw
-    # the sums are exact integers: two different instance orders give bitwise the same matrix
-    a = run_ocr(pl, rows_per_block=19, fixed_point=bits).values
-    b = run_ocr(pl, rows_per_block=31, fixed_point=bits, order=order).values
+    # the sums are exact integers: two different instance orders give bitwise the same matrix (one scale for all blocks)
+    L = int(cal.fx_records["L"].max())
+    a = run_ocr(pl, rows_per_block=19, fixed_point=L).values
+    b = run_ocr(pl, rows_per_block=31, fixed_point=L, order=order).values
     assert np.array_equal(a, b)
+    # scales the contributions have outgrown / that have become too coarse: the blocks fall back to fp64 -- same matrix, fallbacks
+    # counted, records re-derived
+    for bad in (L - H - 2, L + 12):
+        for kw in ({}, {"order": order, "records": True}):
+            low = run_ocr(pl, rows_per_block=19, fixed_point=bad, **kw)
+            assert low.fx_stat[0] >= len(low.fx_records) - 2 and low.fx_stat[1] == 0
+            assert np.abs(low.values - ref.values).max() <= 1e-12 * vmax, kw
+            Ls = low.fx_records["L"][low.fx_records["S"] > 0]
+            assert np.all((Ls <= L) | (Ls == bad)) and (Ls != bad).sum() >= len(Ls) - 2       # (a block without contributions keeps its record)
+            low2 = run_ocr(pl, rows_per_block=19, zero_pending=False, fixed_point=bad, **kw)
+            assert np.abs(low2.values - (ref.values + 1.0)).max() <= 1e-12 * (1.0 + vmax), kw
 
 
 @pytest.mark.parametrize("bcs", [False, True])
