@@ -525,6 +525,12 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             P(f"const int *__restrict__ rlg{k}", ("mat_row_lgmap", k))
             P(f"const int *__restrict__ clg{k}", ("mat_col_lgmap", k))
 
+    # profiling aid (FDHIP_PHASE_TIMES=1, tools/phase_times.py): lane 0 of every block stores the 100 MHz wall clock at the start, after
+    # the staging barrier, after the main loop's barrier and at the end, plus the hardware id of its wavefront
+    ptimes = bool(ocr and configuration["phase_times"])
+    if ptimes:
+        P("long long *__restrict__ fd_times", ("phase_times",))
+
     # ---- static tables (offsets / permutations)
     decls = []
     for mi, m in enumerate(maps):
@@ -839,6 +845,8 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 "  const int tid = threadIdx.x, nthr = blockDim.x;"]
         src += ["  const int b = fdw::xcd_block(blockIdx.x, gridDim.x);",
                 "  const int e0 = bstart_[b], e1 = bstart_[b+1];"]
+        if ptimes:
+            src.append("  if (tid == 0) { fd_times[5*(size_t)b] = wall_clock64(); fd_times[5*(size_t)b + 4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }")
         src += ["  " + s for s in lds_decl + lds_tail_const + lds_tail_var]
         for mi in staged_maps:
             src.append(f"  const int l0_{mi} = p{mi}_blkoff[b], nd{mi} = p{mi}_blkoff[b+1] - l0_{mi};")
@@ -857,6 +865,8 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         if fx:
             stage_src.append("  if (tid == 0) fd_fxmax = 0u;")
         stage_src.append("  __syncthreads();")
+        if ptimes:
+            stage_src.append("  if (tid == 0) fd_times[5*(size_t)b + 1] = wall_clock64();")
         stage_src += ["  " + s for s in pre]
         src += ["  const int fd_first = e0 + tid, fd_step = nthr, fd_last = e1;"]
         # software pipeline: the packed index rows of the NEXT entity are requested before the current
@@ -1013,7 +1023,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                     "  if (fd_fixed) {"]
             src += main_loop(unpack_fx, own_prologue=not early)
             src += ["    fdw::fx_block_max(&fd_fxmax, fd_mu, fd_mi);",
-                    "    __syncthreads();",
+                    "    __syncthreads();"] + (["    if (tid == 0) fd_times[5*(size_t)b + 2] = wall_clock64();"] if ptimes else []) + [
                     "    if (fdw::fx_outside(fd_rec, fd_fxmax)) {",
                     "      fd_fixed = false; fd_fell = true;",
                     f"      for (int q = tid; q < {zcount_}; q += nthr) sm{K_}[q] = 0;",
@@ -1032,7 +1042,11 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             src += main_loop(unpack, own_prologue=not early)
             if flush:
                 src.append("  __syncthreads();")
+                if ptimes:
+                    src.append("  if (tid == 0) fd_times[5*(size_t)b + 2] = wall_clock64();")
                 src += ["  " + s_ for _, s_ in flush]
+        if ptimes:
+            src.append("  if (tid == 0) fd_times[5*(size_t)b + 3] = wall_clock64();")
         src += ["  " + s for s in post]
     else:
         if extruded:
@@ -1213,6 +1227,9 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         skip = f"{(1 << rec['kbits']) - 1}u"
     slot_skip = f"{(1 << rec['sbits']) - 1}" if rec else "0xffff"
 
+    ptimes = bool(configuration["phase_times"])         # profiling aid, see generate_wrapper
+    if ptimes:
+        P("long long *__restrict__ fd_times", ("phase_times",))
     lds_decl, lds_items, stage_nodes, pack, call_args = ["size_t fd_off = 0;"], [], {}, [], []
     for info in infos:
         k, ct = info["k"], info["ct"]
@@ -1258,6 +1275,8 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
            "  const int tid = threadIdx.x, nthr = blockDim.x;",
            "  const int b = fdw::xcd_block(blockIdx.x, gridDim.x);",
            "  const int e0 = bstart_[b], e1 = bstart_[b+1];"]
+    if ptimes:
+        src.append("  if (tid == 0) { fd_times[5*(size_t)b] = wall_clock64(); fd_times[5*(size_t)b + 4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }")
     src += ["  " + s for s in lds_decl]
     for mi in staged_maps:
         src.append(f"  const int l0_{mi} = p{mi}_blkoff[b], nd{mi} = p{mi}_blkoff[b+1] - l0_{mi};")
@@ -1282,6 +1301,8 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
                 stage_src += ["    " + l for l in act[part]]
         stage_src.append("  }")
     stage_src.append("  __syncthreads();")
+    if ptimes:
+        stage_src.append("  if (tid == 0) fd_times[5*(size_t)b + 1] = wall_clock64();")
     if not early:
         src += stage_src
     if extruded:
@@ -1400,6 +1421,8 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     if runflush and early:
         src.append(srun_stage)
     src.append("  __syncthreads();")
+    if ptimes:
+        src.append("  if (tid == 0) fd_times[5*(size_t)b + 2] = wall_clock64();")
     if runflush:
         FU = max(1, int(configuration["flush_batch"]))
         src.append(f"  for (int q0 = tid; q0 < nnzb; q0 += {FU}*nthr) {{ int g[{FU}]; "
@@ -1436,6 +1459,8 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     else:
         src.append(f"  if (oc{K}_flags & 1) {{ for (int q = tid; q < nnzb; q += nthr) arg{K}[(size_t)r0*{B} + q] = sm{K}[q]; }} "
                    f"else {{ for (int q = tid; q < nnzb; q += nthr) arg{K}[(size_t)r0*{B} + q] += sm{K}[q]; }}")
+    if ptimes:
+        src.append("  if (tid == 0) fd_times[5*(size_t)b + 3] = wall_clock64();")
     src.append("}")
     if strides is not None:
         if len(strides) != len(staged_maps):

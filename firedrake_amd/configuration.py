@@ -18,6 +18,7 @@ configuration = {
     "debug": _env("FDHIP_DEBUG", 0, int),
     "trace": _env("FDHIP_TRACE", 0, int),     # roctx range + flop log per parloop (profiling.py; pyop2/parloop.py:219-232)
     "type_check": _env("FDHIP_TYPE_CHECK", 1, int),
+    "phase_times": _env("FDHIP_PHASE_TIMES", 0, int),   # profiling aid: per-block wall-clock stamps of the staged / owner-computes-rows phases
     # wrapper generation
     "mode": _env("FDHIP_MODE", "auto"),                 # auto | staged | direct
     "block_threads": _env("FDHIP_BLOCK_THREADS", 0, int),

@@ -536,6 +536,7 @@ def precompile_all():
     shapes and the geometry-specific variants of BENCH_VARIANTS, each through ``GlobalKernel.compile`` (so the unroll / occupancy
     retries a first call would make are made here)."""
     from .codegen import ocr_eligible, sliced_eligible, staged_eligible
+    from .configuration import configuration
     from .kernel import DatKernelArg, GlobalKernel, MapKernelArg, MatKernelArg
     from .op2types import INC, READ
     jobs = []
@@ -566,6 +567,8 @@ def precompile_all():
             modes = ["direct"] + (["staged"] if staged_eligible(gj) else []) + (["ocr"] if ocr_eligible(gj) else []) \
                 + (["ocrs"] if (ocr_eligible(gj) and sliced_eligible(gj)) else [])
             extra = [v for v in BENCH_VARIANTS[("jacobian", dim, degree)] if v.startswith("ocrs") == (ocr_eligible(gj) and sliced_eligible(gj))]
+            if not configuration["ocr_fixed_point"]:
+                extra = [v[:-3] if v.endswith("_fx") else v for v in extra]
             build(gj, modes + (extra if lg else []))
     # config C3: the tensor-product wrappers of the Q4 Helmholtz operator (matrix with and without BC lgmaps, action), also with
     # coefficient arguments

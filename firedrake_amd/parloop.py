@@ -1234,6 +1234,10 @@ class Parloop:
                 out.append(self._lgmap(pa.lgmaps[0 if kind == "mat_row_lgmap" else 1]))
             elif kind in ("fx_scale", "fx_stat"):
                 out.append(geo["fx"][0 if kind == "fx_scale" else 1].ptr)
+            elif kind == "phase_times":
+                if geo.get("phase_times") is None:
+                    geo["phase_times"] = DeviceBuffer(max(op.nblocks, 1) * 40)
+                out.append(geo["phase_times"].ptr)
             else:
                 raise AssertionError(kind)
         cw.launch(0, op.ninst, out, block_threads=src.block_threads, ents_per_block=op.max_inst, nblocks=op.nblocks,
