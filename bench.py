@@ -33,13 +33,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def algorithmic_bytes(ncell, arity, nnode, gdim, ncoeff, nnz=None, zeroing=False):
+def algorithmic_bytes(ncell, arity, nnode, gdim, ncoeff, nnz=None, zeroing=False, ncoord=None, coord_arity=0):
     """every input array read once, every output written once.  ``zeroing`` adds the separate zeroing
     pass of a13 -- counted only where a separate pass is actually executed inside the bracket the time comes from
-    (the owner-computes-rows Jacobian has none: it overwrites complete rows)."""
+    (the owner-computes-rows Jacobian has none: it overwrites complete rows).  ``ncoord`` / ``coord_arity``: the coordinate
+    field lives on its own (P1) space -- its nodes and its own cell map are charged instead of the unknown's (CG2: 1.26 M
+    coordinate nodes + a 4-entry map row per cell, not 9.94 M nodes)."""
+    coords = (nnode if ncoord is None else ncoord) * gdim * 8 + ncell * coord_arity * 4
     if nnz is None:   # residual kernel: map + coords + coefficients + output
-        return ncell * arity * 4 + nnode * gdim * 8 + ncoeff * nnode * 8 + nnode * 8 + (nnode * 8 if zeroing else 0)
-    return ncell * arity * 4 + nnode * gdim * 8 + nnz * 8 + (nnz * 8 if zeroing else 0)      # Jacobian: map + coords + values
+        return ncell * arity * 4 + coords + ncoeff * nnode * 8 + nnode * 8 + (nnode * 8 if zeroing else 0)
+    return ncell * arity * 4 + coords + nnz * 8 + (nnz * 8 if zeroing else 0)      # Jacobian: map + coords + values
 
 
 def host_threads():
@@ -57,7 +60,7 @@ def host_threads():
     return n, aff, quota
 
 
-def cpu_baseline(mesh, degree, reps=2, pattern=None, label=None):
+def cpu_baseline(mesh, degree, reps=2, pattern=None, label=None, threads_reps=10):
     """Time the oracle (CPU restatement of the PyOP2 wrapper, compiled with the reference's own flags) on ``mesh`` -- by default
     THE benchmark workload itself, a bounded number of repetitions.  Headline = 1 thread (what one MPI rank of the reference
     executes).  Beside it: min(affinity, cgroup quota) host threads, node-partitioned (each thread owns a contiguous node range
@@ -73,10 +76,10 @@ def cpu_baseline(mesh, degree, reps=2, pattern=None, label=None):
     nn = V.node_set.total_size
     coords = np.array(m.coordinates.data_ro_with_halos)
     pts = V.node_points
-    u = np.sin(3 * pts[:, 0]) * np.cos(2 * pts[:, 1]) + 0.3 * pts[:, 2]
+    u = np.sin(3 * pts[:, 0]) * np.cos(2 * pts[:, 1]) + (0.3 * pts[:, 2] if m.gdim == 3 else 0.0)
     f = (1 + 8 * np.pi ** 2) * np.cos(2 * np.pi * pts[:, 0]) * np.cos(2 * np.pi * pts[:, 1])
     r = np.zeros(nn)
-    kr, kj = forms.poisson_residual_kernel(3, degree), forms.poisson_jacobian_kernel(3, degree)
+    kr, kj = forms.poisson_residual_kernel(m.gdim, degree), forms.poisson_jacobian_kernel(m.gdim, degree)
     ncell = m.cell_set.size
     t_sparsity = None
     if pattern is None:
@@ -112,24 +115,103 @@ def cpu_baseline(mesh, degree, reps=2, pattern=None, label=None):
         return ts[len(ts) // 2]
 
     tot1, tr1, tj1 = timed(False, reps)
-    totN, trN, tjN = timed(True, reps)
-    multi = {"value": nn / totN, "cores": cores, "affinity_cpus": aff, "cgroup_cpu_quota_cores": quota,
+    totN, trN, tjN = timed(True, max(reps, threads_reps))
+    multi = {"value": nn / totN, "cores": cores, "affinity_cpus": aff, "cgroup_cpu_quota_cores": quota, "repetitions": max(reps, threads_reps),
              "residual_dofs_per_s": nn / trN, "jacobian_dofs_per_s": nn / tjN,
              "note": "OpenMP team of min(affinity, cgroup quota) threads, one per contiguous node range running the cells that touch it "
                      "(owned + ghost cells), foreign rows dropped: no atomics, no private vectors (shared-memory analogue of N MPI ranks)"}
     return {"value": nn / tot1, "unit": "DoFs/s", "cores": 1, "kind": "port",
             "sample": f"{label or 'Poisson CG%d on a cube of tets' % degree}: {ncell} cells, {nn} DoFs, residual+Jacobian, "
-                      f"median of {reps} warm repetitions (one more dropped as warm-up); oracle = CPU restatement of the PyOP2 wrapper "
+                      f"median of {reps} warm repetitions (one more dropped as warm-up; SURVEY.md 8d asks for >= 10: the 1-thread leg takes seconds "
+                      f"per repetition at this size and is held to {reps}, the all-threads leg runs {max(reps, threads_reps)}); oracle = CPU restatement of the PyOP2 wrapper "
                       f"(not the reference binary), gcc -O3 -march=native -ffast-math; 1 thread = what one MPI rank of the reference executes",
             "residual_dofs_per_s": nn / tr1, "jacobian_dofs_per_s": nn / tj1,
             "all_host_threads": multi, "sparsity_build_s": t_sparsity}
+
+
+def oracle_step(loops, zero=(), pattern_of=None):
+    """A CPU restatement of ``loops`` (firedrake_amd Parloops) through the oracle, on COPIES of their host data: returns a
+    callable that runs them in order (outputs in ``zero`` -- Dats or Mats -- cleared first, as every assemble does).  Carriers
+    shared between the loops (one coordinate Dat, one output Dat INC'ed by three loops) are shared here too."""
+    import oracle
+    from firedrake_amd.parloop import DatParloopArg, GlobalParloopArg, MatParloopArg
+    arrays = {}
+
+    def host(d):
+        if id(d) not in arrays:
+            arrays[id(d)] = np.array(d.data_ro_with_halos if hasattr(d, "data_ro_with_halos") else d.data_ro, copy=True)
+        return arrays[id(d)]
+
+    def csr_of(mat):
+        if id(mat) not in arrays:
+            sp = mat.sparsity
+            rp, ci = np.ascontiguousarray(sp.rowptr, dtype=np.int32), np.ascontiguousarray(sp.colidx, dtype=np.int32)
+            arrays[id(mat)] = oracle.OracleCSR(sp.nrows, sp.ncols, 1, 1, rp, ci, np.zeros(len(ci)))
+        return arrays[id(mat)]
+
+    calls = []
+    for loop in loops:
+        it = loop.iterset
+        ext = bool(it._extruded)
+        oargs = []
+        for pa, acc in zip(loop.arguments, loop.accesses):
+            if isinstance(pa, MatParloopArg):
+                rm, cm = pa.maps
+                lg = pa.lgmaps or (None, None)
+                oargs.append(oracle.OMat(csr_of(pa.data), int(acc), rm._base().values_with_halo, cm._base().values_with_halo,
+                                         roffset=rm.offset if ext else None, coffset=cm.offset if ext else None,
+                                         row_lgmap=None if lg[0] is None else np.ascontiguousarray(lg[0], dtype=np.int32),
+                                         col_lgmap=None if lg[1] is None else np.ascontiguousarray(lg[1], dtype=np.int32)))
+            elif isinstance(pa, GlobalParloopArg):
+                oargs.append(oracle.OGlobal(host(pa.data), int(acc)))
+            elif isinstance(pa, DatParloopArg):
+                m = pa.map_
+                oargs.append(oracle.ODat(host(pa.data), int(acc), None if m is None else m._base().values_with_halo,
+                                         offset=(m.offset if (ext and m is not None) else None)))
+            else:
+                raise TypeError(f"oracle_step: {type(pa).__name__}")
+        lk = loop.global_kernel.local_kernel
+        layers = None
+        if ext:
+            layers = tuple(int(x) for x in it.layers_array[0])
+        subset = getattr(it, "indices", None) if type(it).__name__ == "Subset" else None
+        fn, cargs, k1, k2 = oracle.par_loop(lk.code, lk.name, 0, it.size, oargs, subset=subset, layers=layers, return_fn=True,
+                                            init_with_zero=bool(getattr(lk, "requires_zeroed_output_arguments", False)))
+        calls.append((fn, cargs, k1, k2))
+
+    def step():
+        for z in zero:
+            a = arrays.get(id(z))
+            if a is not None:
+                (a.values if hasattr(a, "values") else a)[...] = 0
+        for fn, cargs, _, _ in calls:
+            fn(*cargs)
+    return step
+
+
+def cpu_baseline_loops(loops, zero, ndofs, sample, reps=2):
+    """``cpu_baseline`` object for a secondary config: the oracle on a bounded sample, 1 thread, median of ``reps`` warm
+    repetitions (one more dropped as warm-up)."""
+    try:
+        step = oracle_step(loops, zero)
+        ts = []
+        for _ in range(reps + 1):
+            t0 = time.perf_counter()
+            step()
+            ts.append(time.perf_counter() - t0)
+        t = sorted(ts[1:])[len(ts[1:]) // 2]
+        return {"value": ndofs / t, "unit": "DoFs/s", "cores": 1, "kind": "port", "seconds_per_step": t,
+                "sample": sample + f"; oracle = CPU restatement of the PyOP2 wrapper (gcc -O3 -march=native -ffast-math), 1 thread, "
+                                   f"median of {reps} warm repetitions"}
+    except Exception as exc:
+        return {"error": repr(exc)}
 
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD datasheet; tools/microbench.hip measures 77.7 TFLOP/s with v_mfma_f64_16x16x4_f64
 FP64_VECTOR_PEAK_TFLOPS = 78.6 # same datasheet figure for vector fp64 FMA (256 CUs x 64 lanes x 2 flop x 2.4 GHz); microbench: 70 TFLOP/s
 
 
-def measure_c3(n, steps, warmup, coefficients=False):
+def measure_c3(n, steps, warmup, coefficients=False, cpu_sample=0):
     """BASELINE.json configs[2]: Helmholtz Q4 on an extruded hex mesh through ordinary parloops -- the stiffness+mass
     matrix on the fp64 matrix cores (tp_matrix wrapper) and the sum-factorised operator action (tp_action).  Reports the
     kernel alone AND the whole assemble (zeroing pass + kernel [+ BC diagonal]) against the fp64 MFMA peak."""
@@ -168,8 +250,18 @@ def measure_c3(n, steps, warmup, coefficients=False):
     ncol = m.base_set.size
     act_bytes = ncol * 125 * 4 + ncol * 8 * 4 + m.coord_node_set.size * 24 + ndofs * 8 + ndofs * 8
     act_flops = ncell * (25 * 450 * 2 + 125 * 200)
+    cpu = None
+    if cpu_sample:
+        ms_ = fmesh.make_extruded_hex_mesh(cpu_sample, cpu_sample, 4, perturb=0.1)
+        ps_ = forms.CoefficientHexProblem(ms_, bcs=True, nq=5) if coefficients else forms.HelmholtzQ4Problem(ms_, bcs=True)
+        ps_.sparsity._build()
+        cpu = cpu_baseline_loops([ps_.jac_loop, ps_.act_loop], [ps_.mat, ps_.y], ms_.node_set.size,
+                                 f"the same operator (matrix + action) on a {cpu_sample}^3-cell sample of the extruded hex mesh "
+                                 f"({ms_.ncells} cells, {ms_.node_set.size} DoFs; dense 125 x 125 element matrices, MatSetValuesLocal by row search)", reps=1)
+        del ps_, ms_
     return {"config": {"workload": f"Helmholtz Q4 stiffness+mass on ExtrudedMesh(UnitSquareMesh({n},{n},quadrilateral), {n}) "
                                    f"(BASELINE.json configs[2]), Dirichlet BCs", "cells": ncell, "dofs": ndofs, "nnz": nnz},
+            "cpu_baseline": cpu,
             "jacobian_dofs_per_s": ndofs / (a_ms * 1e-3), "action_dofs_per_s": ndofs / (act_a_ms * 1e-3),
             "ms_per_step": elapsed / steps * 1e3, "first_call_s": first,
             "roofline": {"kernel": "wrap_helmholtz_q4_hex_jacobian", "bound": "mfma", "achieved": tf(k_ms), "peak": FP64_MFMA_PEAK_TFLOPS,
@@ -212,16 +304,16 @@ def measure_c3_action(n, steps, warmup):
 def run_c3(args):
     from firedrake_amd import _lib
     _lib.require_gpu()
-    r = measure_c3(args.n if args.n else 32, args.steps, args.warmup)
+    r = measure_c3(args.n if args.n else 32, args.steps, args.warmup, cpu_sample=8 if args.cpu_sample else 0)
     out = {"metric": "assembled DoFs/sec (Jacobian)", "value": r["jacobian_dofs_per_s"], "unit": "DoFs/s", "n_gpus": 1,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": r["config"],
            "action_dofs_per_s": r["action_dofs_per_s"], "roofline": r["roofline"], "roofline_action": r["roofline_action"],
-           "first_call_s": r["first_call_s"], "cpu_baseline": None}
+           "first_call_s": r["first_call_s"], "cpu_baseline": r["cpu_baseline"]}
     print(json.dumps(out))
 
 
-def measure_c1(steps, warmup):
+def measure_c1(steps, warmup, with_cpu=False):
     """BASELINE.json configs[0]: Poisson CG1 on UnitSquareMesh(64,64) -- launch-bound on a GPU; eager vs hipGraph replay."""
     from firedrake_amd import _lib, forms, mesh as fmesh
     from firedrake_amd.graph import CapturedStep
@@ -248,21 +340,29 @@ def measure_c1(steps, warmup):
     g.sync()
     graph = (time.perf_counter() - t0) / n
     nd = prob.V.node_set.size
+    cpu = None
+    if with_cpu:
+        try:
+            sp = prob.jacobian()[0].sparsity
+            cpu = cpu_baseline(prob.mesh, 1, reps=10, pattern=(np.asarray(sp.rowptr), np.asarray(sp.colidx)),
+                               label="Poisson CG1 on UnitSquareMesh(64,64), the workload itself (BASELINE.json configs[0]: the reference's CPU-runnable case)")
+        except Exception as exc:
+            cpu = {"error": repr(exc)}
     return {"metric": "assembled DoFs/sec (residual + Jacobian)", "value": nd / graph, "unit": "DoFs/s", "n_gpus": 1,
             "steps": n, "warmup": warmup, "ms_per_step": graph * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "Poisson CG1 residual+Jacobian on UnitSquareMesh(64,64) (BASELINE.json configs[0]), hipGraph replay",
                        "cells": 8192, "dofs": nd},
-            "eager_ms_per_step": eager * 1e3, "graph_ms_per_step": graph * 1e3, "roofline": None, "cpu_baseline": None}
+            "eager_ms_per_step": eager * 1e3, "graph_ms_per_step": graph * 1e3, "roofline": None, "cpu_baseline": cpu or None}
 
 
 def run_c1(args):
     from firedrake_amd import _lib
     _lib.require_gpu()
-    print(json.dumps(measure_c1(args.steps, args.warmup)))
+    print(json.dumps(measure_c1(args.steps, args.warmup, with_cpu=args.cpu_sample > 0)))
 
 
-def measure_c4(n, steps, warmup):
+def measure_c4(n, steps, warmup, cpu_sample=0):
     """BASELINE.json configs[3]: DG_advection demo, DQ1 on quadrilaterals -- the 1-form L1 (cell + exterior-facet +
     interior-facet integrals, upwind flux) assembled matrix-free: three parloops INC-ing one Dat (C4)."""
     from firedrake_amd import _lib, forms, mesh as fmesh
@@ -299,18 +399,26 @@ def measure_c4(n, steps, warmup):
         roofs.append({"kernel": name, "bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "ms": ms, "algorithmic_bytes": nbytes})
     dominant = max(roofs, key=lambda r: r["ms"])
+    cpu = None
+    if cpu_sample:
+        ms_ = fmesh.make_quad_mesh(cpu_sample, perturb=0.1)
+        ps_ = forms.DGAdvectionProblem(ms_)
+        cpu = cpu_baseline_loops(ps_.loops, [ps_.L], ms_.dq_set.size,
+                                 f"the same 1-form (cell + exterior-facet + interior-facet loops) on a {cpu_sample} x {cpu_sample} sample "
+                                 f"({ms_.cell_set.size} cells, {ms_.dq_set.size} DoFs)", reps=3)
+        del ps_, ms_
     return {"metric": "assembled DoFs/sec (DG advection RHS action)", "value": ndq / (elapsed / steps), "unit": "DoFs/s",
             "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"DG_advection demo 1-form L1, DQ1 on {n}x{n} quadrilaterals (BASELINE.json configs[3])",
                        "cells": ncell, "dofs": ndq, "interior_facets": nint, "exterior_facets": next_},
-            "roofline": dominant, "roofline_per_loop": roofs, "cpu_baseline": None}
+            "roofline": dominant, "roofline_per_loop": roofs, "cpu_baseline": cpu}
 
 
 def run_c4(args):
     from firedrake_amd import _lib
     _lib.require_gpu()
-    print(json.dumps(measure_c4(args.n if args.n else 2048, args.steps, args.warmup)))
+    print(json.dumps(measure_c4(args.n if args.n else 2048, args.steps, args.warmup, cpu_sample=512 if args.cpu_sample else 0)))
 
 
 CALIB = (("wrap_fd_calib_read2", 2), ("wrap_fd_calib_read4", 4), ("wrap_fd_calib_read8", 8), ("wrap_fd_calib_read16", 16),
@@ -553,7 +661,7 @@ def check_devices(n):
     return ndev.value
 
 
-def poisson_line(args, ctx, degree, shape, scaling, label, numbering, variants, traffic, cpu=False):
+def poisson_line(args, ctx, degree, shape, scaling, label, numbering, variants, traffic, cpu=False, cpu_reps=None):
     """Measure residual + Jacobian assembly of Poisson CG<degree> on UnitCubeMesh(shape) box-partitioned over the ranks and
     return rank 0's result dict (None on the other ranks)."""
     from firedrake_amd import _lib, forms, mesh as fmesh
@@ -607,17 +715,19 @@ def poisson_line(args, ctx, degree, shape, scaling, label, numbering, variants, 
             return d
 
         roof_res = roof_jac = None
+        xmap = mesh.coord_space.cell_node_map
+        coord_kw = {} if xmap is V.cell_node_map else {"ncoord": mesh.coord_space.node_set.total_size, "coord_arity": xmap.arity}
         if res["res_kernel_ms"]:
             # the wrapper kernel alone: map + coords + 2 coefficients + the output, against the kernel's own duration
-            b = algorithmic_bytes(ncell_local, arity, nnode_local, 3, 2)
+            b = algorithmic_bytes(ncell_local, arity, nnode_local, 3, 2, **coord_kw)
             roof_res = roof(kres, res["res_kernel_ms"], b, assemble_ms=res["res_assemble_ms"],
                             note="kernel-only bytes and time; assemble_ms adds the zeroing pass (a13) and the BC fix-up (a14)"
                                  + ("; at N > 1 the bracket also holds the forward halo exchange (see multi_gpu.residual_kernel_only_ms)" if world > 1 else ""))
         if res["jac_kernel_ms"]:
             # owner-computes-rows writes complete rows and performs NO zeroing pass: strict bytes = map + coords + values.
             # frac_with_zeroing credits the nnz*8 zeroing traffic SURVEY.md 8(d) lists for the reference's two-pass scheme.
-            b = algorithmic_bytes(ncell_local, arity, nnode_local, 3, 0, nnz, zeroing=not jac_ocr)
-            bz = algorithmic_bytes(ncell_local, arity, nnode_local, 3, 0, nnz, zeroing=True)
+            b = algorithmic_bytes(ncell_local, arity, nnode_local, 3, 0, nnz, zeroing=not jac_ocr, **coord_kw)
+            bz = algorithmic_bytes(ncell_local, arity, nnode_local, 3, 0, nnz, zeroing=True, **coord_kw)
             roof_jac = roof(kjac, res["jac_kernel_ms"], b, assemble_ms=res["jac_assemble_ms"],
                             frac_with_zeroing=bz / (res["jac_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             note="kernel-only; strict bytes (no credit for the zeroing pass the kernel makes unnecessary)")
@@ -645,17 +755,6 @@ def poisson_line(args, ctx, degree, shape, scaling, label, numbering, variants, 
         roofs = [r for r in (roof_res, roof_jac) if r]
         dominant = max(roofs, key=lambda r: r["ms"])
         traffic_meta = None
-        if traffic and world == 1:
-            tail = ["--steps", "3", "--warmup", "1", "--cpu-sample", "0", "--n", str(shape[0]), "--degree", str(degree),
-                    "--tile", args.tile, "--numbering", numbering, "--only", args.only, "--traffic", "off", "--variants", "",
-                    "--no-secondary", "--workload", "c2"]
-            if args.no_bcs:
-                tail.append("--no-bcs")
-            tr, traffic_meta = collect_traffic(tail, [r["kernel"] for r in roofs])
-            for r in roofs:
-                if tr and r["kernel"] in tr:
-                    r["traffic"] = tr[r["kernel"]]["hbm_bytes_per_launch"]
-                    r["traffic_counters_kb"] = {"FETCH_SIZE": tr[r["kernel"]]["FETCH_SIZE_kb"], "WRITE_SIZE": tr[r["kernel"]]["WRITE_SIZE_kb"]}
         n_gpus = multi["n_gpus"] if multi else 1
         out = {
             "metric": "assembled DoFs/sec (residual + Jacobian)",
@@ -681,7 +780,7 @@ def poisson_line(args, ctx, degree, shape, scaling, label, numbering, variants, 
         # reported baseline (rank 0, N = 1): the oracle on THIS workload -- the same mesh object, the matrix pattern the device built
         try:
             sp = prob.jacobian()[0].sparsity
-            out["cpu_baseline"] = cpu_baseline(mesh, degree, reps=args.cpu_reps, pattern=(np.asarray(sp.rowptr), np.asarray(sp.colidx)),
+            out["cpu_baseline"] = cpu_baseline(mesh, degree, reps=cpu_reps or args.cpu_reps, pattern=(np.asarray(sp.rowptr), np.asarray(sp.colidx)),
                                                label=f"Poisson CG{degree} on UnitCubeMesh({shape[0]},{shape[1]},{shape[2]}) tets, the benchmark workload itself")
         except Exception as exc:                  # (a host without a C compiler, ...): the GPU line still goes out
             out["cpu_baseline"] = {"error": repr(exc)}
@@ -860,6 +959,14 @@ def main():
         out = poisson_line(args, ctx, degree, shape, "weak", "BASELINE.json configs[1] per GPU" if degree == 1 else f"CG{degree}, weak",
                            args.numbering, args.variants, args.traffic == "auto", cpu=(args.cpu_sample > 0 and world == 1))
     if args.inner_pmc:
+        # profiled child of collect_traffic(): the secondary configs' kernels in the same pass (a few launches each)
+        if args.secondary and args.workload == "c2" and world == 1:
+            for fn in (lambda: measure_c3(32, 2, 1), lambda: measure_c4(2048, 2, 1),
+                       lambda: poisson_line(args, ctx, 2, (107, 107, 107), "weak", "", "lexicographic", "", False)):
+                try:
+                    fn()
+                except Exception as exc:
+                    print(f"bench.py --inner-pmc: {exc!r}", file=sys.stderr)
         run_calibration()
         return
     if args.secondary and args.workload == "c2" and args.only == "both" and world > 1:
@@ -886,7 +993,8 @@ def main():
             import gc
             gc.collect()
 
-        guarded("secondary_c3", lambda: measure_c3(32, max(3, args.steps // 2), 2))
+        cs = args.cpu_sample > 0
+        guarded("secondary_c3", lambda: measure_c3(32, max(3, args.steps // 2), 2, cpu_sample=8 if cs else 0))
         if "error" not in out["secondary_c3"]:
             # the same Q4 operator with two coefficient fields (variable diffusivity, nonlinear-reaction linearisation point)
             def with_coefficients():
@@ -902,10 +1010,36 @@ def main():
                 out["secondary_c3"]["action_n64"] = measure_c3_action(64, 10, 2)
             except Exception as exc:
                 out["secondary_c3"]["action_n64"] = {"error": repr(exc)}
-        guarded("secondary_c4", lambda: measure_c4(2048, max(3, args.steps // 2), 2))
+        guarded("secondary_c4", lambda: measure_c4(2048, max(3, args.steps // 2), 2, cpu_sample=512 if cs else 0))
         guarded("secondary_c5_share", lambda: poisson_line(args, ctx, 2, (107, 107, 107), "weak",
-                                                             "one of the 8 partitions of BASELINE.json configs[4]", "lexicographic", "", False))
-        guarded("secondary_c1", lambda: measure_c1(200, 3))
+                                                             "one of the 8 partitions of BASELINE.json configs[4]", "lexicographic", "", False,
+                                                             cpu=cs, cpu_reps=1))
+        guarded("secondary_c1", lambda: measure_c1(200, 3, with_cpu=cs))
+    if rank == 0 and world == 1 and args.traffic == "auto" and args.workload == "c2":
+        # HBM bytes per launch of every kernel in the line, from ONE pair of rocprofv3 PMC passes of this command (FETCH_SIZE,
+        # WRITE_SIZE) run as child processes now that nothing is being timed
+        roofs = []
+
+        def gather(d):
+            if isinstance(d, dict):
+                if "kernel" in d and "traffic" in d:
+                    roofs.append(d)
+                for v in d.values():
+                    gather(v)
+            elif isinstance(d, list):
+                for v in d:
+                    gather(v)
+        gather(out)
+        tail = ["--steps", "3", "--warmup", "1", "--cpu-sample", "0", "--n", str(args.n or 215), "--degree", str(args.degree or 1),
+                "--tile", args.tile, "--numbering", args.numbering, "--only", args.only, "--traffic", "off", "--variants", "",
+                "--workload", "c2"] + ([] if (args.secondary and args.only == "both") else ["--no-secondary"]) + (["--no-bcs"] if args.no_bcs else [])
+        tr, out["traffic_meta"] = collect_traffic(tail, sorted({r["kernel"] for r in roofs}))
+        for r in roofs:
+            if tr and r["kernel"] in tr:
+                r["traffic"] = tr[r["kernel"]]["hbm_bytes_per_launch"]
+                r["traffic_counters_kb"] = {"FETCH_SIZE": tr[r["kernel"]]["FETCH_SIZE_kb"], "WRITE_SIZE": tr[r["kernel"]]["WRITE_SIZE_kb"]}
+                if r.get("algorithmic_bytes"):
+                    r["traffic_over_algorithmic"] = r["traffic"] / r["algorithmic_bytes"]
     if rank == 0:
         out.setdefault("cpu_baseline", None)
         from firedrake_amd import compilation

@@ -346,9 +346,6 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         rec = {"lbits": [int(v) for v in rq_.group(1).split("x")], "kbits": int(rq_.group(2)), "diag": bool(rq_.group(3))}
         mode = mode[:rq_.start()]
     ocr = mode.startswith("ocr")
-    # "ocrpr": the flush of a derived row order finds the place of an accumulator entry through RUNS of rows that are consecutive
-    # in the CSR as well (one byte per entry + one word per run in LDS) instead of a 4-byte place per entry (fd_ocr_row_runs)
-    runflush = mode.startswith("ocrpr")
     # "stagedo": staged over a backend-derived entity ORDER (fd_locality_order): slot -> entity through fd_order_, plans on
     # the map rows gathered in that order (Parloop._staged_geometry, un-hinted maps)
     ordered = mode.startswith("stagedo")
@@ -495,12 +492,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             if ocrp:
                 P(f"const int *__restrict__ oc{k}_prowptr", ("ocr_prowptr", k))
                 P(f"const int *__restrict__ oc{k}_nstart", ("ocr_nstart", k))
-                if runflush:
-                    P(f"const unsigned char *__restrict__ oc{k}_grun", ("ocr_grun", k))
-                    P(f"const int *__restrict__ oc{k}_brun", ("ocr_brun", k))
-                    P(f"const int *__restrict__ oc{k}_rdelta", ("ocr_rdelta", k))
-                else:
-                    P(f"const int *__restrict__ oc{k}_gpos", ("ocr_gpos", k))
+                P(f"const int *__restrict__ oc{k}_gpos", ("ocr_gpos", k))
                 P(f"long long oc{k}_npos", ("ocr_npos", k))
             if rec:
                 P(f"const unsigned int *__restrict__ oc{k}_rec", ("ocr_rec", k))
@@ -557,6 +549,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
 
     pre, pack, call_args, unpack, post = [], [], [], [], []
     unpack_fx = []       # "_fx": the fixed-point trip's unpack of the Mat (everything else in such a loop is READ)
+    flush_pre_decl, flush_pre = [], []     # table flushes: registers of the first batch of places, and its loads (ahead of the barrier)
     node_actions = {}    # per staged map: [(load statements, LDS store statements)] templated on I_U / G_U
     lds_decl, stage, flush, mat_stage_pre = [], [], [], []
     # LDS carve-up order: staged Dat rows, then the per-node matrix tables (sizes fixed by the node strides), then the
@@ -734,35 +727,23 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                     # nonzero, streamed).  (A row-by-row flush, 16 lanes per row with the row descriptors in LDS, issued 4x the
                     # LDS instructions and 1.5x the scalar ones for the same stores: +12 % LDS-pipe cycles in a kernel bound
                     # by that pipe, profiles/r3f_pmc_jacobian_lexicographic.txt.)
-                    FU = max(1, int(configuration["flush_batch"]))
-                    if runflush:
-                        # rows that follow one another in the block AND in the CSR form a run with one displacement (place - accumulator
-                        # index): a byte per entry names the run, the block's displacements (<= 256) sit in LDS
-                        lds_items.append(("ocrrun", k))
-                        lds_tail_const.append(f"int *srun{k} = (int *)(fd_lds + fd_off); fd_off += 1024;")
-                        mat_stage_pre.append(f"const int br0_{k} = oc{k}_brun[b], nrun{k} = oc{k}_brun[b+1] - br0_{k};")
-                        stage.append((rm, f"_Pragma(\"clang loop unroll(disable) vectorize(disable)\") "
-                                          f"for (int q = tid; q < nrun{k}; q += nthr) srun{k}[q] = oc{k}_rdelta[br0_{k} + q];"))
-                        # (loads clamped to the block's last entry instead of branched around: FU independent requests per trip)
-                        flush.append((rm, f"for (int q0 = tid; q0 < nnzb{k}; q0 += {FU}*nthr) {{ int g{k}[{FU}]; "
-                                          f"for (int f = 0; f < {FU}; ++f) {{ const int q = q0 + f*nthr; g{k}[f] = (int)oc{k}_grun[(size_t)r0_{k} + (q < nnzb{k} ? q : nnzb{k} - 1)]; }} "
-                                          f"for (int f = 0; f < {FU}; ++f) g{k}[f] = (q0 + f*nthr < nnzb{k}) ? r0_{k} + q0 + f*nthr + srun{k}[g{k}[f]] : -1; "
-                                          f"if (oc{k}_flags & 1) {{ for (int f = 0; f < {FU}; ++f) if (g{k}[f] >= 0) arg{k}[(size_t)g{k}[f]] = sm{k}[q0 + f*nthr]; }} "
-                                          f"else {{ double o{k}[{FU}]; for (int f = 0; f < {FU}; ++f) o{k}[f] = g{k}[f] >= 0 ? arg{k}[(size_t)g{k}[f]] : 0.0; "
-                                          f"for (int f = 0; f < {FU}; ++f) if (g{k}[f] >= 0) arg{k}[(size_t)g{k}[f]] = o{k}[f] + sm{k}[q0 + f*nthr]; }} }}"))
-                    elif FU == 1:
-                        flush.append((rm, f"if (oc{k}_flags & 1) {{ for (int q = tid; q < nnzb{k}; q += nthr) {{ const int g = oc{k}_gpos[(size_t)r0_{k} + q]; if (g >= 0) arg{k}[(size_t)g] = sm{k}[q]; }} }} "
-                                          f"else {{ for (int q = tid; q < nnzb{k}; q += nthr) {{ const int g = oc{k}_gpos[(size_t)r0_{k} + q]; if (g >= 0) arg{k}[(size_t)g] += sm{k}[q]; }} }}"))
-                    else:
-                        # the place of an entry is a global load its store depends on: a trip of the loop costs a memory round trip.
-                        # FU places are requested together, then the FU stores go out
-                        flush.append((rm, f"for (int q0 = tid; q0 < nnzb{k}; q0 += {FU}*nthr) {{ int g{k}[{FU}]; "
-                                          f"for (int f = 0; f < {FU}; ++f) {{ const int q = q0 + f*nthr; g{k}[f] = q < nnzb{k} ? oc{k}_gpos[(size_t)r0_{k} + q] : -1; }} "
-                                          f"if (oc{k}_flags & 1) {{ for (int f = 0; f < {FU}; ++f) if (g{k}[f] >= 0) arg{k}[(size_t)g{k}[f]] = sm{k}[q0 + f*nthr]; }} "
-                                          # accumulating into existing values (a second integral of the same form): the old values are
-                                          # requested together as well (the places of a block are distinct)
-                                          f"else {{ double o{k}[{FU}]; for (int f = 0; f < {FU}; ++f) o{k}[f] = g{k}[f] >= 0 ? arg{k}[(size_t)g{k}[f]] : 0.0; "
-                                          f"for (int f = 0; f < {FU}; ++f) if (g{k}[f] >= 0) arg{k}[(size_t)g{k}[f]] = o{k}[f] + sm{k}[q0 + f*nthr]; }} }}"))
+                    # The place of an entry is a global load its store depends on, so a trip of the flush loop costs a memory round
+                    # trip: FU places are requested together -- and the first trip's (all of them for a block within budget)
+                    # BEFORE the barrier that ends the main loop, so the flush itself waits for no load (profiles/r5a_phase_times.txt:
+                    # the flush was 4.2 of a block's 17.5 microseconds)
+                    preload = bool(configuration["flush_preload"])
+                    FU = 8 if preload else max(1, int(configuration["flush_batch"]))
+                    ld = (f"for (int f = 0; f < {FU}; ++f) {{ const int q = Q0 + f*nthr; g{k}[f] = q < nnzb{k} ? oc{k}_gpos[(size_t)r0_{k} + q] : -1; }}")
+                    if preload:
+                        flush_pre_decl.append(f"int g{k}[{FU}];")
+                        flush_pre.append(ld.replace("Q0", "tid"))
+                    flush.append((rm, f"for (int q0 = tid; q0 < nnzb{k}; q0 += {FU}*nthr) {{ "
+                                      + (f"if (q0 >= {FU}*nthr) {{ {ld.replace('Q0', 'q0')} }} " if preload else f"int g{k}[{FU}]; {ld.replace('Q0', 'q0')} ") +
+                                      f"if (oc{k}_flags & 1) {{ for (int f = 0; f < {FU}; ++f) if (g{k}[f] >= 0) arg{k}[(size_t)g{k}[f]] = sm{k}[q0 + f*nthr]; }} "
+                                      # accumulating into existing values (a second integral of the same form): the old values are
+                                      # requested together as well (the places of a block are distinct)
+                                      f"else {{ double o{k}[{FU}]; for (int f = 0; f < {FU}; ++f) o{k}[f] = g{k}[f] >= 0 ? arg{k}[(size_t)g{k}[f]] : 0.0; "
+                                      f"for (int f = 0; f < {FU}; ++f) if (g{k}[f] >= 0) arg{k}[(size_t)g{k}[f]] = o{k}[f] + sm{k}[q0 + f*nthr]; }} }}"))
                     continue
                 # complete rows, contiguous in the CSR value array: plain coalesced stores
                 flush.append((rm, f"if (oc{k}_flags & 1) {{ for (int q = tid; q < nnzb{k}; q += nthr) arg{k}[(size_t)r0_{k} + q] = sm{k}[q]; }} "
@@ -1016,12 +997,14 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                     if ("sm%d[" % K_) in piece and "fdw::fx_get" not in piece:
                         raise ValueError("fixed-point accumulation: an accumulator access of this flush is not covered: " + piece.strip())
             zcount_ = f"(int)oc{K_}_maxnnz" if configuration["early_loads"] else f"nnzb{K_}"
+            src += ["  " + s_ for s_ in flush_pre_decl]
             src += [f"  const fdw::fx_block_t fd_rec = fx{K_}_scale[b];",
                     "  const double fd_S = fd_rec.S, fd_iS = fd_rec.invS;",
                     "  unsigned fd_mu = 0u; int fd_mi = 0;",
                     "  bool fd_fixed = fd_S != 0.0, fd_fell = false;",
                     "  if (fd_fixed) {"]
             src += main_loop(unpack_fx, own_prologue=not early)
+            src += ["    " + s_ for s_ in flush_pre]
             src += ["    fdw::fx_block_max(&fd_fxmax, fd_mu, fd_mi);",
                     "    __syncthreads();"] + (["    if (tid == 0) fd_times[5*(size_t)b + 2] = wall_clock64();"] if ptimes else []) + [
                     "    if (fdw::fx_outside(fd_rec, fd_fxmax)) {",
@@ -1032,6 +1015,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                     "  }",
                     "  if (!fd_fixed) {"]
             src += main_loop(unpack)
+            src += ["    if (!fd_fell) {"] + ["      " + s_ for s_ in flush_pre] + ["    }"]
             src += ["    if (!fd_fell) fdw::fx_block_max(&fd_fxmax, fd_mu, fd_mi);",
                     "    __syncthreads();"]
             src += ["    " + s_ for _, s_ in flush]
@@ -1039,7 +1023,9 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             src += ["    " + s_ for s_ in flush_fx]
             src += ["  }", f"  if (tid == 0) fdw::fx_update<{int(configuration['ocr_fx_headroom'])}>(fx{K_}_scale + b, fd_rec, fd_fxmax, fd_fell, fx{K_}_stat);"]
         else:
+            src += ["  " + s_ for s_ in flush_pre_decl]
             src += main_loop(unpack, own_prologue=not early)
+            src += ["  " + s_ for s_ in flush_pre]
             if flush:
                 src.append("  __syncthreads();")
                 if ptimes:
@@ -1197,11 +1183,6 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     P(f"const int *__restrict__ oc{K}_rowptr", ("ocr_prowptr" if ordered else "ocr_rowptr", K))
     if ordered:
         P(f"const int *__restrict__ oc{K}_gstart", ("ocr_gstart", K))
-    # flush of a derived row order through the per-entry place table of the whole-entity wrapper (4 B per nonzero, FU places
-    # requested per trip) instead of row by row with 16 lanes per row
-    entry_flush = bool(ordered and B == 1 and configuration["ocrs_entry_flush"] and not runflush)
-    if entry_flush:
-        P(f"const int *__restrict__ oc{K}_gpos", ("ocr_gpos", K))
     if runflush:
         if B != 1:
             raise ValueError("the run-coded flush serves scalar matrices")
@@ -1418,44 +1399,43 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         if pf2:
             src.append("    " + " ".join(f"nx_{n} = n2_{n};" for n, _ in scal))
     src.append("  }")
+    # Flushes through tables (derived row orders): the table entries are global loads the stores depend on, so a trip of the flush
+    # loop costs a memory round trip.  FU entries are requested together, and the first trip's (all of them for a block within
+    # budget) BEFORE the barrier that ends the main loop: the flush itself then waits for no load (profiles/r5a_phase_times.txt:
+    # the flush was 7.0 of a block's 17.7 microseconds on the CG2 share)
+    preload = bool(configuration["flush_preload"])
+    post_flush = []
+    if runflush:
+        FU = 16 if preload else max(1, int(configuration["flush_batch"]))
+        ld = f"for (int f = 0; f < {FU}; ++f) {{ const int q = Q0 + f*nthr; g[f] = (int)oc{K}_grun[(size_t)r0 + (q < nnzb ? q : nnzb - 1)]; }}"
+        if preload:
+            src += [f"  int g[{FU}];", "  " + ld.replace("Q0", "tid")]
+        post_flush.append(f"  for (int q0 = tid; q0 < nnzb; q0 += {FU}*nthr) {{ "
+                          + (f"if (q0 >= {FU}*nthr) {{ {ld.replace('Q0', 'q0')} }} " if preload else f"int g[{FU}]; {ld.replace('Q0', 'q0')} ") +
+                          f"for (int f = 0; f < {FU}; ++f) g[f] = r0 + q0 + f*nthr + srun{K}[g[f]]; "
+                          f"if (oc{K}_flags & 1) {{ for (int f = 0; f < {FU}; ++f) if (q0 + f*nthr < nnzb) arg{K}[(size_t)g[f]] = sm{K}[q0 + f*nthr]; }} "
+                          f"else {{ double o[{FU}]; for (int f = 0; f < {FU}; ++f) o[f] = (q0 + f*nthr < nnzb) ? arg{K}[(size_t)g[f]] : 0.0; "
+                          f"for (int f = 0; f < {FU}; ++f) if (q0 + f*nthr < nnzb) arg{K}[(size_t)g[f]] = o[f] + sm{K}[q0 + f*nthr]; }} }}")
+    elif ordered:
+        # row by row, 16 lanes per row: start / length / place of FU rows per lane group
+        FU = 8 if preload else max(1, int(configuration["flush_batch"]))
+        ld = (f"for (int f = 0; f < {FU}; ++f) {{ const int fr = FR0 + f*(nthr >> 4); const int fp = n0 + (fr < nown ? fr : 0); "
+              f"const int a = oc{K}_rowptr[fp], b_ = oc{K}_rowptr[fp+1]; fs[f] = (a - r0)*{B}; fl[f] = fr < nown ? (b_ - a)*{B} : 0; "
+              f"fd_[f] = (size_t)oc{K}_gstart[fp]*{B}; }}")
+        decl = f"int fs[{FU}], fl[{FU}]; size_t fd_[{FU}];"
+        if preload:
+            src += ["  " + decl, "  " + ld.replace("FR0", "(tid >> 4)")]
+        post_flush.append(f"  for (int fr0 = tid >> 4; fr0 < nown; fr0 += {FU}*(nthr >> 4)) {{ "
+                          + (f"if (fr0 >= {FU}*(nthr >> 4)) {{ {ld.replace('FR0', 'fr0')} }} " if preload else f"{decl} {ld.replace('FR0', 'fr0')} ") +
+                          f"if (oc{K}_flags & 1) {{ for (int f = 0; f < {FU}; ++f) for (int q = tid & 15; q < fl[f]; q += 16) arg{K}[fd_[f] + q] = sm{K}[fs[f] + q]; }} "
+                          f"else {{ for (int f = 0; f < {FU}; ++f) for (int q = tid & 15; q < fl[f]; q += 16) arg{K}[fd_[f] + q] += sm{K}[fs[f] + q]; }} }}")
     if runflush and early:
         src.append(srun_stage)
     src.append("  __syncthreads();")
     if ptimes:
         src.append("  if (tid == 0) fd_times[5*(size_t)b + 2] = wall_clock64();")
-    if runflush:
-        FU = max(1, int(configuration["flush_batch"]))
-        src.append(f"  for (int q0 = tid; q0 < nnzb; q0 += {FU}*nthr) {{ int g[{FU}]; "
-                   f"for (int f = 0; f < {FU}; ++f) {{ const int q = q0 + f*nthr; g[f] = (int)oc{K}_grun[(size_t)r0 + (q < nnzb ? q : nnzb - 1)]; }} "
-                   f"for (int f = 0; f < {FU}; ++f) g[f] = r0 + q0 + f*nthr + srun{K}[g[f]]; "
-                   f"if (oc{K}_flags & 1) {{ for (int f = 0; f < {FU}; ++f) if (q0 + f*nthr < nnzb) arg{K}[(size_t)g[f]] = sm{K}[q0 + f*nthr]; }} "
-                   f"else {{ double o[{FU}]; for (int f = 0; f < {FU}; ++f) o[f] = (q0 + f*nthr < nnzb) ? arg{K}[(size_t)g[f]] : 0.0; "
-                   f"for (int f = 0; f < {FU}; ++f) if (q0 + f*nthr < nnzb) arg{K}[(size_t)g[f]] = o[f] + sm{K}[q0 + f*nthr]; }} }}")
-    elif entry_flush:
-        FU = max(1, int(configuration["flush_batch"]))
-        src.append(f"  for (int q0 = tid; q0 < nnzb; q0 += {FU}*nthr) {{ int g[{FU}]; "
-                   f"for (int f = 0; f < {FU}; ++f) {{ const int q = q0 + f*nthr; g[f] = oc{K}_gpos[(size_t)r0 + (q < nnzb ? q : nnzb - 1)]; }} "
-                   f"if (oc{K}_flags & 1) {{ for (int f = 0; f < {FU}; ++f) if (q0 + f*nthr < nnzb) arg{K}[(size_t)g[f]] = sm{K}[q0 + f*nthr]; }} "
-                   f"else {{ double o[{FU}]; for (int f = 0; f < {FU}; ++f) o[f] = (q0 + f*nthr < nnzb) ? arg{K}[(size_t)g[f]] : 0.0; "
-                   f"for (int f = 0; f < {FU}; ++f) if (q0 + f*nthr < nnzb) arg{K}[(size_t)g[f]] = o[f] + sm{K}[q0 + f*nthr]; }} }}")
-    elif ordered:
-        # (a per-entry flush table like the whole-entity wrapper's measured 8 % slower here before its loads were batched: profiles/r3t)
-        FU = max(1, int(configuration["flush_batch"]))
-        if FU == 1:
-            src.append(f"  for (int fr = tid >> 4; fr < nown; fr += nthr >> 4) {{ const int fp = n0 + fr; "
-                       f"const int fs = (oc{K}_rowptr[fp] - r0)*{B}, fl = (oc{K}_rowptr[fp+1] - oc{K}_rowptr[fp])*{B}; "
-                       f"const size_t fd_ = (size_t)oc{K}_gstart[fp]*{B}; "
-                       f"if (oc{K}_flags & 1) {{ for (int q = tid & 15; q < fl; q += 16) arg{K}[fd_ + q] = sm{K}[fs + q]; }} "
-                       f"else {{ for (int q = tid & 15; q < fl; q += 16) arg{K}[fd_ + q] += sm{K}[fs + q]; }} }}")
-        else:
-            # 16 lanes per row; the row's start / length / place are global loads the stores depend on, so a trip costs a memory
-            # round trip: the tables of FU rows are requested together before any of them is flushed
-            src.append(f"  for (int fr0 = tid >> 4; fr0 < nown; fr0 += {FU}*(nthr >> 4)) {{ int fs[{FU}], fl[{FU}]; size_t fd_[{FU}]; "
-                       f"for (int f = 0; f < {FU}; ++f) {{ const int fr = fr0 + f*(nthr >> 4); const int fp = n0 + (fr < nown ? fr : 0); "
-                       f"const int a = oc{K}_rowptr[fp], b_ = oc{K}_rowptr[fp+1]; fs[f] = (a - r0)*{B}; fl[f] = fr < nown ? (b_ - a)*{B} : 0; "
-                       f"fd_[f] = (size_t)oc{K}_gstart[fp]*{B}; }} "
-                       f"if (oc{K}_flags & 1) {{ for (int f = 0; f < {FU}; ++f) for (int q = tid & 15; q < fl[f]; q += 16) arg{K}[fd_[f] + q] = sm{K}[fs[f] + q]; }} "
-                       f"else {{ for (int f = 0; f < {FU}; ++f) for (int q = tid & 15; q < fl[f]; q += 16) arg{K}[fd_[f] + q] += sm{K}[fs[f] + q]; }} }}")
+    if post_flush:
+        src += post_flush
     else:
         src.append(f"  if (oc{K}_flags & 1) {{ for (int q = tid; q < nnzb; q += nthr) arg{K}[(size_t)r0*{B} + q] = sm{K}[q]; }} "
                    f"else {{ for (int q = tid; q < nnzb; q += nthr) arg{K}[(size_t)r0*{B} + q] += sm{K}[q]; }}")

@@ -24,6 +24,7 @@ configuration = {
     "block_threads": _env("FDHIP_BLOCK_THREADS", 0, int),
     "ents_per_block": _env("FDHIP_ENTS_PER_BLOCK", 1024, int),
     "flush_batch": _env("FDHIP_FLUSH_BATCH", 4, int),      # flushes through index tables (derived row orders): table loads requested per trip
+    "flush_preload": _env("FDHIP_FLUSH_PRELOAD", 1, int),  # ... a block's whole table requested ahead of the barrier that ends its main loop
     "plan_copies": _env("FDHIP_PLAN_COPIES", 1, int),     # READ Dats unchanged between calls are kept in plan order and streamed
     "ocr_pack": _env("FDHIP_OCR_PACK", 1, int),            # bank-aware greedy packing of the instance lists (fd_ocrplan_pack)
     "ocr_pad_windows": _env("FDHIP_OCR_PAD_WINDOWS", 0, int),   # 16-lane LDS atomic windows on distinct banks: 1 = end a window with dummy instances,
@@ -38,7 +39,6 @@ configuration = {
     # diagonal offsets taken from the row node's LDS word, and the flush of a derived row order run-coded (fd_ocr_row_runs)
     "ocr_records": _env("FDHIP_OCR_RECORDS", 1, int),
     "ocr_records_diag": _env("FDHIP_OCR_RECORDS_DIAG", 1, int),
-    "ocr_run_flush": _env("FDHIP_OCR_RUN_FLUSH", 0, int),      # measured 2 % slower than the 4-byte places (profiles/r4a): off
     # whole-entity loops over a derived row order: pad the LDS accumulators by one entry per run of consecutive rows (bank spreading
     # for same-kind entities along and across the lines of a box).  Measured within noise of the unpadded layout (0.921 vs 0.930 ms,
     # profiles/r4j_ab_pad_runs.txt): the instance order the packer leaves does not form the regular windows the padding serves -- off
@@ -67,7 +67,6 @@ configuration = {
     "ocr_sliced_max_entries": _env("FDHIP_OCR_SLICED_MAX_ENTRIES", 1024, int),
     "ocrs_prefetch": _env("FDHIP_OCRS_PREFETCH", 1, int),         # row-sliced loops: index rows requested 1 or 2 trips ahead
     "ocrs_run_flush": _env("FDHIP_OCRS_RUN_FLUSH", 1, int),       # derived row orders, scalar matrices: run-coded places (1 B per entry)
-    "ocrs_entry_flush": _env("FDHIP_OCRS_ENTRY_FLUSH", 0, int),   # derived row orders: per-entry place table instead of the row-by-row flush
     "ocrs_nnz_per_block": _env("FDHIP_OCRS_NNZ", 4096, int),     # accumulator entries per row block (x8 bytes of LDS)
     "ocrs_block_threads": _env("FDHIP_OCRS_BLOCK_THREADS", 256, int),
     "ocrs_interleave": _env("FDHIP_OCRS_INTERLEAVE", 7, int),    # > 1: stride permutation of the instances of every (block, row index) group

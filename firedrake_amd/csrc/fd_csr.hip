@@ -392,17 +392,29 @@ int fd_csr_from_maps_ex(int32_t nrows, int32_t ncols, int set_diag, int npairs,
                 reserved = true;
                 const double ratio = (double)nu_c / (double)cnt;
                 double est = (double)acc_n + (double)nu_c + ratio * 1.05 * (double)(ncand - ndiag - cnt) + 4096.0;
+                // never beyond what one compaction cycle can hold: the first chunk's ratio overstates the global one (a random
+                // numbering has next to no duplicates inside a chunk), and append() compacts once the accumulator passes ACC_LIMIT
+                // -- which it must be allowed to reach before the capacity is
+                const double cap_ = (double)ACC_LIMIT + (double)ccap;
+                if (est > cap_) est = cap_;
                 if (est > 2147483647.0) est = 2147483647.0;
                 const int64_t want = (int64_t)est;
                 if (want > acc_cap) {
+                    // a reservation that does not fit the device is not an error: append() grows the accumulator step by step
                     uint64_t *na = nullptr, *na2 = nullptr;
-                    FD_HIP(hipMalloc(&na, (size_t)want * 8));
-                    FD_HIP(hipMalloc(&na2, (size_t)want * 8));
-                    if (acc_n) FD_HIP(hipMemcpyAsync(na, acc, (size_t)acc_n * 8, hipMemcpyDeviceToDevice, s));
-                    FD_HIP(hipStreamSynchronize(s));
-                    if (acc) FD_HIP(hipFree(acc));
-                    if (acc2) FD_HIP(hipFree(acc2));
-                    acc = na; acc2 = na2; acc_cap = want;
+                    const bool ok = hipMalloc(&na, (size_t)want * 8) == hipSuccess && hipMalloc(&na2, (size_t)want * 8) == hipSuccess;
+                    if (!ok) {
+                        (void)hipGetLastError();
+                        if (na) (void)hipFree(na);
+                        if (na2) (void)hipFree(na2);
+                    } else {
+                        hipError_t ce = acc_n ? hipMemcpyAsync(na, acc, (size_t)acc_n * 8, hipMemcpyDeviceToDevice, s) : hipSuccess;
+                        if (ce == hipSuccess) ce = hipStreamSynchronize(s);
+                        if (ce != hipSuccess) { (void)hipFree(na); (void)hipFree(na2); FD_HIP(ce); }
+                        if (acc) FD_HIP(hipFree(acc));
+                        if (acc2) FD_HIP(hipFree(acc2));
+                        acc = na; acc2 = na2; acc_cap = want;
+                    }
                 }
             }
             if (int rc = append(res, nu_c)) return rc;

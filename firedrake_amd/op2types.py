@@ -1982,8 +1982,10 @@ class OcrPlan:
         # lists of the staged plans stay valid and the per-instance rows (copies of the maps, local maps, row offsets) follow the
         # permutation -- a second table build cost 5x as much
         ir, rkey = self._imap_of(rmap, staged_maps)
-        lm = self.plans[rkey].lmap if rkey is not None else Plan(ir.ptr, 0, int(self.ninst), 0, self.inst_off_host,
-                                                                 arity=rmap.arity).lmap
+        # (a row map that is not among the staged maps gets a plan of its own for the packer: it must outlive the call below --
+        # the local map is a raw pointer into it, and the next allocation could reuse its block)
+        rplan = self.plans[rkey] if rkey is not None else Plan(ir.ptr, 0, int(self.ninst), 0, self.inst_off_host, arity=rmap.arity)
+        lm = rplan.lmap
         perm = DeviceBuffer(int(self.ninst) * 4)
         _lib.call("fd_device_sync")                 # (launches queued on the current tables finish before the rows move)
         _lib.call("fd_ocrplan_pack", self.h, ir.ptr, lm, rmap.arity, self.kidx.ptr, self.kbytes, cmap.arity,
@@ -1995,6 +1997,7 @@ class OcrPlan:
             _lib.call("fd_permute_rows", self._imaps[key].ptr, m.arity * 4, perm.ptr, int(self.ninst), None)
             _lib.call("fd_permute_rows", self.plans[key].lmap, m.arity * 2, perm.ptr, int(self.ninst), None)
         _lib.call("fd_permute_rows", self.kidx.ptr, rmap.arity * cmap.arity * self.kbytes, perm.ptr, int(self.ninst), None)
+        del rplan                                    # (fd_ocrplan_pack and the permutations above have synchronised the stream)
         self.__dict__.pop("_records", None)         # records are packed from the tables of the current order
 
     def _imap_of(self, m, staged_maps):

@@ -1016,14 +1016,6 @@ class Parloop:
             raise PlanDoesNotFit("owner-computes-rows plan does not fit (LDS or instance list)")
         nds = [op.plans[mi].max_nd for mi in src.staged_maps]
         base = "ocrp" if row_order is not None else "ocr"
-        runs = None
-        if row_order is not None and configuration["ocr_run_flush"] and not row_order.padded:
-            # run-coded flush when no block has more than 256 runs of CSR-consecutive rows (a random numbering has one per row)
-            runs = row_order.runs(op.row_blocks)
-            if runs[3] <= 256:
-                base, lds = "ocrpr", lds + 1024
-            else:
-                runs = None
         rec = None
         if configuration["ocr_records"] and len(src.staged_maps) <= 8:
             from .codegen import record_layout
@@ -1042,12 +1034,12 @@ class Parloop:
             fxbufs = (DeviceBuffer(max(op.nblocks, 1) * 32), DeviceBuffer(16))
             for b_ in fxbufs:
                 b_.zero()
-        geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz, "rec": rec, "runs": runs, "fx": fxbufs,
+        geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz, "rec": rec, "fx": fxbufs,
                "cw": prep["cw"] if variant == src.mode else self.global_kernel.compile(variant), "row_order": row_order}
         prep["parts"][gkey] = geo
         if configuration["debug"]:
             import sys
-            print(f"[fdhip] {self.global_kernel.name} OCR variant {variant}: record {rec}, runs per block <= {runs[3] if runs else None}", file=sys.stderr)
+            print(f"[fdhip] {self.global_kernel.name} OCR variant {variant}: record {rec}", file=sys.stderr)
             print(f"[fdhip] {self.global_kernel.name} OCR [{start},{end}): row blocks={op.nblocks} instances={op.ninst} "
                   f"(x{op.ninst / max(end - start, 1):.2f} entities, {op.ndummy} window-padding dummies) max_inst={op.max_inst} max_nnz={op.max_nnz} max_nown={op.max_nown} "
                   f"lds={lds} kbytes={op.kbytes}", file=sys.stderr)

@@ -217,7 +217,7 @@ def row_runs_ref(prowptr, gstart, rb):
     return grun, brun, rdelta, int(np.diff(brun).max()) if len(rb) > 1 else 0
 
 
-def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False, run_flush=False, pad=False, fixed_point=None):
+def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False, pad=False, fixed_point=None):
     """Execute a matrix-assembly Parloop ``pl`` with the OWNER-COMPUTES-ROWS wrapper on the host (one OS thread per
     lane, tests/hostsim/mt/fd_wrapper.h).  The plan tables come from the numpy restatements in helpers.py; the CSR
     pattern from the oracle.  Returns the OracleCSR holding the assembled values."""
@@ -263,10 +263,7 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False,
         from firedrake_amd.codegen import record_layout
         rec = record_layout([maps[mi].arity for mi in base.staged_maps], [plans[mi][3] for mi in base.staged_maps], rmap.arity,
                             cmap.arity, int(np.diff(csr.rowptr).max()), mpa.maps[0]._base() is mpa.maps[1]._base())
-    run_tabs = None
-    if order is not None and run_flush:
-        run_tabs = row_runs_ref(prowptr, csr.rowptr[plist], rb)
-    src = generate_wrapper(gk, mode_variant(("ocrpr" if run_tabs else "ocrp") if order is not None else "ocr", 1,
+    src = generate_wrapper(gk, mode_variant("ocrp" if order is not None else "ocr", 1,
                                             [plans[mi][3] for mi in base.staged_maps], rec) + ("_fx" if fixed_point is not None else ""))
     text = src.source.replace("extern __shared__ __align__(16) unsigned char fd_lds[];", "unsigned char *fd_lds = fd_sim::lds;")
     sig = re.search(r'extern "C" __global__[^\n]*void %s\((.*)\)\n' % src.symbol, text).group(1)
@@ -368,8 +365,6 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False,
             lbits, kbits, diag, words_ = rec
             cargs.append(ptr(pack_records_ref([plans[mi][2] for mi in base.staged_maps], lbits, kidx, rmap.arity, cmap.arity,
                                               kbits, diag, words_)))
-        elif kind in ("ocr_grun", "ocr_brun", "ocr_rdelta"):
-            cargs.append(ptr(run_tabs[{"ocr_grun": 0, "ocr_brun": 1, "ocr_rdelta": 2}[kind]]))
         elif kind == "ocr_gpos":
             # place of every accumulator entry (rows in position order) in the CSR value array
             gp = np.full(max(int(prowptr[-1]), 1), -1, dtype=np.int32)                # (padding entries have no place)

@@ -92,12 +92,10 @@ def test_row_runs_match_numpy_restatement():
 
 
 @pytest.mark.parametrize("numbering", ["tiled", "lexicographic", "random"])
-@pytest.mark.parametrize("records,diag,runs", [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 0, 1), (1, 1, 1)])
-def test_p1_jacobian_with_compact_tables_matches_oracle(numbering, records, diag, runs, monkeypatch):
+@pytest.mark.parametrize("records,diag", [(0, 0), (1, 0), (1, 1)])
+def test_p1_jacobian_with_compact_tables_matches_oracle(numbering, records, diag, monkeypatch):
     monkeypatch.setitem(configuration, "ocr_records", records)
     monkeypatch.setitem(configuration, "ocr_records_diag", diag)
-    monkeypatch.setitem(configuration, "ocr_run_flush", runs)
-    monkeypatch.setitem(configuration, "ocr_pad_runs", 0)          # (a padded order keeps the per-entry place table)
     monkeypatch.setitem(configuration, "locality_min_entities", 64)
     m = fmesh.UnitCubeMesh(12, degrees=(1,), perturb=0.1, numbering=numbering)
     prob = forms.PoissonProblem(m, 1, bcs=True)
@@ -109,8 +107,8 @@ def test_p1_jacobian_with_compact_tables_matches_oracle(numbering, records, diag
     assert bool(geo["rec"]) == bool(records) and (geo["rec"][2] if records else False) == bool(diag)
     if numbering == "tiled":
         assert geo["cw"].src.mode.startswith("ocr_") or geo["cw"].src.mode == "ocr"
-    elif runs and numbering == "lexicographic":
-        assert geo["cw"].src.mode.startswith("ocrpr")
+    elif numbering == "lexicographic":
+        assert geo["cw"].src.mode.startswith("ocrp_")
     mpa = pl.arguments[0]
     args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
     ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]

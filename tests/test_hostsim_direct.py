@@ -588,10 +588,6 @@ def test_owner_computes_rows_over_a_row_order_on_host(bcs, numbering):
         for zp in (True, False):
             got4 = run_ocr(pl, rows_per_block=rpb, zero_pending=zp, order=order, records=True, pad=True)
             assert np.abs(got4.values - (ref.values + (0.0 if zp else 1.0))).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
-        # "ocrpr": run-coded flush (fd_ocr_row_runs) + bit-packed records, fresh and accumulating
-        for zp in (True, False):
-            got3 = run_ocr(pl, rows_per_block=rpb, zero_pending=zp, order=order, records=True, run_flush=True)
-            assert np.abs(got3.values - (ref.values + (0.0 if zp else 1.0))).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
 
 
 @pytest.mark.parametrize("bcs", [False, True])
@@ -616,7 +612,7 @@ def test_fixed_point_accumulation_on_host(bcs):
     ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
     vmax = np.abs(ref.values).max()
     H = int(configuration["ocr_fx_headroom"])
-    for kw in ({}, {"records": True}, {"order": order}, {"order": order, "records": True}, {"order": order, "records": True, "run_flush": True}):
+    for kw in ({}, {"records": True}, {"order": order}, {"order": order, "records": True}):
         # no scale yet: fp64 blocks, every block with contributions writes its record
         cal = run_ocr(pl, rows_per_block=19, fixed_point=True, **kw)
         nb = len(cal.fx_records)
@@ -682,16 +678,8 @@ def test_row_sliced_owner_computes_rows_on_host(bcs, numbering, plan_copies):
             got5 = run_ocrs(pl, nnz_per_block=cap, order=order, records=True, run_flush=order is not None)
             assert np.abs(got5.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
             if order is not None:
-                # the same blocks flushed through the per-entry place table (FDHIP_OCRS_ENTRY_FLUSH) instead of row by row
-                from firedrake_amd.configuration import configuration
-                configuration["ocrs_entry_flush"] = 1
-                try:
-                    for zp in (True, False):
-                        got3 = run_ocrs(pl, nnz_per_block=cap, zero_pending=zp, order=order)
-                        assert np.abs(got3.values - (ref.values + (0.0 if zp else 1.0))).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
-                finally:
-                    configuration["ocrs_entry_flush"] = 0
-                # ... and through run-coded places ("ocrspr": one byte per entry, the block's displacements in LDS)
+                # the same blocks flushed through run-coded places ("ocrspr": one byte per entry, the block's displacements in LDS)
+                # instead of row by row
                 for zp in (True, False):
                     got4 = run_ocrs(pl, nnz_per_block=cap, zero_pending=zp, order=order, run_flush=True)
                     assert np.abs(got4.values - (ref.values + (0.0 if zp else 1.0))).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
@@ -907,7 +895,7 @@ static void rnd{seed}(double *A, const double *w, const double *y)
     if rbs * cbs == 1 and not unroll:
         got = run_ocr(pl, rows_per_block=int(rng.integers(3, 40)), zero_pending=zero, order=order)
         assert np.abs(got.values - (ref.values + (0.0 if zero else 1.0))).max() <= tol
-        got = run_ocr(pl, rows_per_block=int(rng.integers(3, 40)), zero_pending=zero, order=order, records=True, run_flush=bool(seed % 2))
+        got = run_ocr(pl, rows_per_block=int(rng.integers(3, 40)), zero_pending=zero, order=order, records=True)
         assert np.abs(got.values - (ref.values + (0.0 if zero else 1.0))).max() <= tol
 
 
