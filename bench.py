@@ -731,27 +731,6 @@ def poisson_line(args, ctx, degree, shape, scaling, label, numbering, variants, 
             roof_jac = roof(kjac, res["jac_kernel_ms"], b, assemble_ms=res["jac_assemble_ms"],
                             frac_with_zeroing=bz / (res["jac_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             note="kernel-only; strict bytes (no credit for the zeroing pass the kernel makes unnecessary)")
-        if roof_jac and jac_ocr:
-            # the bank-aware packing of the instance lists is deferred until a plan has been launched `ocr_pack_after` (64) times: the
-            # timed region above ran on the unpacked lists.  What a long-lived loop sees afterwards, and what the packing costs:
-            try:
-                from firedrake_amd.device import Event
-                loop = prob.jacobian()[1]
-                op = next(g for key, g in loop._prepared["parts"].items() if key[0] == "ocr")["ocr"]
-                if hasattr(op, "pack") and not op.packed:
-                    t0 = time.perf_counter()
-                    op.pack()
-                    _lib.call("fd_device_sync")
-                    pack_s = time.perf_counter() - t0
-                    evs = [(Event(), Event()) for _ in range(max(args.steps, 6) + 3)]
-                    for a_, b_ in evs:
-                        prob.assemble_jacobian(events=(a_, b_))
-                    _lib.call("fd_device_sync")
-                    ms2 = float(np.median([a_.elapsed_ms(b_) for a_, b_ in evs[3:]]))      # (as many launches as the timed region above)
-                    roof_jac["after_packing"] = {"ms": ms2, "frac": roof_jac["algorithmic_bytes"] / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "pack_s": pack_s,
-                                                 "launches_to_amortise": pack_s / max((roof_jac["ms"] - ms2) * 1e-3, 1e-9) if ms2 < roof_jac["ms"] else None}
-            except Exception as exc:
-                roof_jac["after_packing"] = {"error": repr(exc)}
         roofs = [r for r in (roof_res, roof_jac) if r]
         dominant = max(roofs, key=lambda r: r["ms"])
         traffic_meta = None

@@ -61,8 +61,8 @@ SIGNATURES = {
     "fd_leaf_labels": (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
     "fd_group_entities": (c_int, [c_void_p, c_int, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "fd_invert_permutation": (c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
-    "fd_row_order_tables": (c_int, [c_int32, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "fd_row_entry_positions": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fd_row_order_tables": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fd_row_entry_positions": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fd_first_touch_order": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fd_comm_available": (c_int, []),
     "fd_comm_unique_id": (c_int, [c_void_p]),
@@ -89,8 +89,6 @@ SIGNATURES = {
                                     c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "fd_ocr_row_runs": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, POINTER(c_int32),
                                 POINTER(c_int32), c_void_p]),
-    "fd_ocrplan_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "fd_permute_rows": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p]),
     "fd_plan_set_lane_order": (c_int, [c_void_p, c_int, c_void_p]),
     "fd_plan_block_starts": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int32)]),
     "fd_plan_info": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int64)]),
@@ -102,7 +100,6 @@ SIGNATURES = {
     "fd_matplan_arrays": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
     "fd_matplan_free": (c_int, [c_void_p]),
     "fd_ocrplan_create": (c_int, [c_void_p, c_int, c_int32, c_int32, c_void_p, c_int32, c_int, c_void_p, POINTER(c_void_p)]),
-    "fd_ocrplan_pad_windows": (c_int, [c_void_p, c_void_p, c_int, c_int32, c_int32, c_void_p, c_int, POINTER(c_int64), c_void_p]),
     "fd_ocrplan_info": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int32)]),
     "fd_ocrplan_arrays": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
     "fd_ocrplan_free": (c_int, [c_void_p]),

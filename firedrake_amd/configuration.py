@@ -26,23 +26,15 @@ configuration = {
     "flush_batch": _env("FDHIP_FLUSH_BATCH", 4, int),      # flushes through index tables (derived row orders): table loads requested per trip
     "flush_preload": _env("FDHIP_FLUSH_PRELOAD", 1, int),  # ... a block's whole table requested ahead of the barrier that ends its main loop
     "plan_copies": _env("FDHIP_PLAN_COPIES", 1, int),     # READ Dats unchanged between calls are kept in plan order and streamed
-    "ocr_pack": _env("FDHIP_OCR_PACK", 1, int),            # bank-aware greedy packing of the instance lists (fd_ocrplan_pack)
-    "ocr_pad_windows": _env("FDHIP_OCR_PAD_WINDOWS", 0, int),   # 16-lane LDS atomic windows on distinct banks: 1 = end a window with dummy instances,
-                                                                 # 2 = with instances from the tail of the block's list (a permutation)
     # whole-entity owner-computes-rows loops (scalar fp64 matrices) reduce their element matrices in LDS as CHECKED 64-bit
     # fixed-point sums through integer atomics (codegen "_fx"; exact, order-independent; blocks that meet a contribution beyond
     # the scale's limit redo their rows in fp64 inside the launch); 0 = fp64 atomics (ds_add_f64)
     "ocr_fixed_point": _env("FDHIP_OCR_FIXED_POINT", 1, int),
     "ocr_fx_headroom": _env("FDHIP_OCR_FX_HEADROOM", 3, int),   # bits between the largest contribution seen and the limit
-    "ocr_pack_after": _env("FDHIP_OCR_PACK_AFTER", 64, int),   # ... once a plan has been launched this often (0 = when it is built)
     # owner-computes-rows index tables: one bit-packed record per instance (fd_ocr_pack_records; 0 = uint16 / uint8 rows), the
     # diagonal offsets taken from the row node's LDS word, and the flush of a derived row order run-coded (fd_ocr_row_runs)
     "ocr_records": _env("FDHIP_OCR_RECORDS", 1, int),
     "ocr_records_diag": _env("FDHIP_OCR_RECORDS_DIAG", 1, int),
-    # whole-entity loops over a derived row order: pad the LDS accumulators by one entry per run of consecutive rows (bank spreading
-    # for same-kind entities along and across the lines of a box).  Measured within noise of the unpadded layout (0.921 vs 0.930 ms,
-    # profiles/r4j_ab_pad_runs.txt): the instance order the packer leaves does not form the regular windows the padding serves -- off
-    "ocr_pad_runs": _env("FDHIP_OCR_PAD_RUNS", 0, int),
     "ocr_lds_limit": _env("FDHIP_OCR_LDS_LIMIT", 0, int),  # 0 = auto (whole CU for large element matrices)
     "lane_strided": _env("FDHIP_LANE_STRIDED", 1, int),   # plans in lane order (fd_plan_set_lane_order)
     # staged rows addressed with a COMPILE-TIME node stride (max nodes per block rounded up to a multiple of this value;
@@ -72,7 +64,7 @@ configuration = {
     "ocrs_interleave": _env("FDHIP_OCRS_INTERLEAVE", 7, int),    # > 1: stride permutation of the instances of every (block, row index) group
     "ocr_block_threads": _env("FDHIP_OCR_BLOCK_THREADS", 0, int),  # 0 = auto: 512 for small element matrices, else block_threads
     # order of the instances inside an owner-computes-rows block: "stencil" (sorted by ownership pattern and owned-row
-    # signature, then bank-packed) or "natural" (entity order: what the numpy restatements of the tests are written in)
+    # signature) or "natural" (entity order: what the numpy restatements of the tests are written in)
     "ocr_order": _env("FDHIP_OCR_ORDER", "stencil"),
     # a wrapper that comes out of hipcc with scratch memory is recompiled with this LLVM -unroll-threshold (0 = never) and the
     # result kept if the scratch shrinks: element tensors must end up in registers (kernel.GlobalKernel._unrolled_variant)

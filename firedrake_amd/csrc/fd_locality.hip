@@ -162,11 +162,11 @@ __global__ void ft_invert(const int32_t *__restrict__ plist, int32_t nnodes, int
 
 // gpos[prowptr[p] + k] = gstart[p] + k: 16 lanes per row
 __global__ void row_entry_positions(int32_t npos, const int32_t *__restrict__ prowptr, const int32_t *__restrict__ gstart,
-                                    const int32_t *__restrict__ plen, int32_t *__restrict__ gpos) {
+                                    int32_t *__restrict__ gpos) {
     const int sub = threadIdx.x & 15;
     for (int64_t p = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4; p < npos; p += ((int64_t)gridDim.x * blockDim.x) >> 4) {
-        const int32_t a = prowptr[p], span = prowptr[p + 1] - a, len = plen ? plen[p] : span, g = gstart[p];
-        for (int k = sub; k < span; k += 16) gpos[a + k] = k < len ? g + k : -1;      // (padding entries of a padded order: no place)
+        const int32_t a = prowptr[p], len = prowptr[p + 1] - a, g = gstart[p];
+        for (int k = sub; k < len; k += 16) gpos[a + k] = g + k;
     }
 }
 
@@ -210,18 +210,12 @@ __global__ void rr_entries(const int32_t *__restrict__ rblk, int32_t nblocks, in
 }
 
 // ---- tables of a row order (fd_row_order_tables): lengths and CSR starts of the rows in position order, accumulator starts by node
-// pad: one accumulator entry of padding after every RUN of rows that are consecutive in the caller's numbering -- on a lattice
-// numbering a run is a line of a box of rows, and the pad makes the accumulator offsets of same-kind entities along and across
-// the lines of a box distinct modulo the 16 fp64 atomic banks (offset = 15 p + line(p)  ->  residue (L - 1) line + x).
 __global__ void ro_gather(int32_t npos, const int32_t *__restrict__ plist, const int32_t *__restrict__ rowptr,
-                          int32_t *__restrict__ len, int32_t *__restrict__ gstart, int32_t *__restrict__ plen, int pad) {
+                          int32_t *__restrict__ len, int32_t *__restrict__ gstart) {
     for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p <= npos; p += (int64_t)gridDim.x * blockDim.x) {
         if (p == npos) { len[p] = 0; continue; }
         const int32_t r = plist[p], a = rowptr[r];
-        const int32_t l = rowptr[r + 1] - a;
-        const bool run_ends = pad && (p + 1 == npos || plist[p + 1] != r + 1);
-        len[p] = l + (run_ends ? 1 : 0);
-        if (plen) plen[p] = l;
+        len[p] = rowptr[r + 1] - a;
         gstart[p] = a;
     }
 }
@@ -417,11 +411,9 @@ int fd_first_touch_order(const int32_t *map_dev, int arity, const int32_t *order
     return rc;
 }
 
-int fd_row_entry_positions(int32_t npos, const int32_t *prowptr_dev, const int32_t *gstart_dev, const int32_t *plen_dev, int32_t *gpos_dev,
-                           fd_stream_t s) {
+int fd_row_entry_positions(int32_t npos, const int32_t *prowptr_dev, const int32_t *gstart_dev, int32_t *gpos_dev, fd_stream_t s) {
     if (npos <= 0) return 0;
-    hipLaunchKernelGGL(row_entry_positions, dim3(lo_grid((int64_t)npos * 16)), dim3(256), 0, fd::st(s), npos, prowptr_dev, gstart_dev, plen_dev,
-                       gpos_dev);
+    hipLaunchKernelGGL(row_entry_positions, dim3(lo_grid((int64_t)npos * 16)), dim3(256), 0, fd::st(s), npos, prowptr_dev, gstart_dev, gpos_dev);
     FD_CHECK_LAUNCH();
     return 0;
 }
@@ -463,15 +455,14 @@ int fd_ocr_row_runs(int32_t npos, const int32_t *prowptr_dev, const int32_t *gst
     return 0;
 }
 
-int fd_row_order_tables(int32_t npos, const int32_t *plist_dev, const int32_t *rowptr_dev, int pad, int32_t *prowptr_dev, int32_t *nstart_dev,
-                        int32_t *gstart_dev, int32_t *plen_dev, fd_stream_t s_) {
+int fd_row_order_tables(int32_t npos, const int32_t *plist_dev, const int32_t *rowptr_dev, int32_t *prowptr_dev, int32_t *nstart_dev,
+                        int32_t *gstart_dev, fd_stream_t s_) {
     if (npos < 0 || !prowptr_dev || (npos && (!plist_dev || !rowptr_dev || !nstart_dev || !gstart_dev))) FD_FAIL("fd_row_order_tables: bad arguments");
     hipStream_t s = fd::st(s_);
     if (npos == 0) { FD_HIP(hipMemsetAsync(prowptr_dev, 0, 4, s)); return 0; }
     int32_t *len = nullptr; void *tmp = nullptr;
     FD_HIP(hipMalloc(&len, ((size_t)npos + 1) * 4));
-    if (pad && !plen_dev) FD_FAIL("fd_row_order_tables: a padded order needs the true row lengths (plen_dev)");
-    hipLaunchKernelGGL(ro_gather, dim3(lo_grid((int64_t)npos + 1)), dim3(256), 0, s, npos, plist_dev, rowptr_dev, len, gstart_dev, plen_dev, pad);
+    hipLaunchKernelGGL(ro_gather, dim3(lo_grid((int64_t)npos + 1)), dim3(256), 0, s, npos, plist_dev, rowptr_dev, len, gstart_dev);
     FD_CHECK_LAUNCH();
     size_t tb = 0;
     FD_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, len, prowptr_dev, npos + 1, s));

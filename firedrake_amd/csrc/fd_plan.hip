@@ -734,7 +734,6 @@ int fd_matplan_free(fd_matplan_t m) {
 // =====================================================================================
 struct fd_ocrplan_s {
     int32_t nblocks = 0, max_inst = 0;
-    int bygeom = 0;                  // stencil order grouped by shape (interleave = -1)
     int64_t ninst = 0;
     int32_t *inst_off = nullptr;     // nblocks+1 (device)
     int32_t *inst_off_host = nullptr;
@@ -822,7 +821,7 @@ __global__ void ocr_interleave(const int32_t *__restrict__ off, const int32_t *_
 // conflict window add into distinct banks, and no two of them share an accumulator in one instruction.
 __global__ void ocr_stencil_keys(const int32_t *__restrict__ rmap, int ar, const int32_t *__restrict__ inst_off,
                                  const int32_t *__restrict__ inst_ent, const int32_t *__restrict__ rblk, int32_t nblocks,
-                                 int64_t ninst, uint64_t *__restrict__ keys, const int32_t *__restrict__ pinv, int32_t npos, int bygeom) {
+                                 int64_t ninst, uint64_t *__restrict__ keys, const int32_t *__restrict__ pinv, int32_t npos) {
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < ninst; t += (int64_t)gridDim.x * blockDim.x) {
         int lo = 0, hi = nblocks - 1;                      // block of instance t: largest b with inst_off[b] <= t
         while (lo < hi) {
@@ -836,7 +835,7 @@ __global__ void ocr_stencil_keys(const int32_t *__restrict__ rmap, int ar, const
         uint32_t h = 2166136261u;
         for (int i = 0; i < ar; ++i) {
             int32_t r = row_position(pinv, npos, row[i]);
-            uint32_t own = (r >= n0 && r < n1 && !bygeom) ? 1u : 0u;
+            uint32_t own = (r >= n0 && r < n1) ? 1u : 0u;
             uint32_t d = (uint32_t)(r - first);
             h = (h ^ own) * 16777619u;
             h = (h ^ (d & 0xffffu)) * 16777619u;
@@ -848,13 +847,7 @@ __global__ void ocr_stencil_keys(const int32_t *__restrict__ rmap, int ar, const
         // with the patterns mixed every trip issued all ar*ac atomics (16.1 of 16 measured on C2), grouped it issues the owned
         // rows' only (12.1).  The full 16-bit signature stays the next key: it is what keeps a conflict window regular
         // (with 8 bits of it the bank conflicts rose by 43 %, profiles/r3k_pmc_mask_order.txt)
-        // bygeom: groups by the entity's SHAPE alone (offsets of its row nodes from the first owned one, whoever owns them).  With
-        // the rows of a block numbered along the mesh lines every node of the block is the first owned row of exactly one entity of
-        // a kind (the cell it is the low corner of, fully owned or hanging over the block's high faces): sorted by that row, 16
-        // consecutive instances sit on 16 consecutive rows -- distinct accumulator banks in every one of their atomics -- where
-        // the ownership-major order leaves 7 fully owned cells to a line of 8 nodes and a colliding pair in every window
-        // (profiles/r4m_microbench_windows.txt: one pair costs the whole second pass of the LDS atomic unit).
-        if (ar <= 8 && nblocks < (1 << 24) && !bygeom) {
+        if (ar <= 8 && nblocks < (1 << 24)) {
             uint32_t mask = 0;
             for (int i = 0; i < ar; ++i) { const int32_t r = row_position(pinv, npos, row[i]); if (r >= n0 && r < n1) mask |= 1u << i; }
             keys[t] = ((uint64_t)(uint32_t)lo << 40) | ((uint64_t)(mask ^ ((1u << ar) - 1u)) << 32) | ((uint64_t)(h & 0xffffu) << 16)
@@ -866,311 +859,8 @@ __global__ void ocr_stencil_keys(const int32_t *__restrict__ rmap, int ar, const
 }
 
 
-// ---- conflict-free windows ------------------------------------------------------------------------------------------------
-// The fp64 LDS atomic unit takes the 16 lanes of a window in as many passes as lanes share one of its 16 banks (tools/
-// microbench_lds.hip, profiles/r4m_microbench_windows.txt: ONE colliding pair in a window costs the whole second pass -- 4.5 against
-// 8.3 lanes per clock).  Instances of one stencil group are translates, so the 16 of a window hit distinct banks in EVERY one of their
-// ar*ac atomics as soon as the accumulator offsets of their first owned rows differ mod 16.  In the stencil order of an 8-node-wide
-// tile the fully owned cells come 7 to a line (residues 0..6, 8..14, then 0.. again): every window of 16 consecutive ones holds a
-// colliding pair, and only 14 residues exist at all.  ocr_pad_windows walks the sorted list of a block and, where the next instance
-// would collide with one of its own group already in the window and the window is at least FD_PAD_MIN slots full, fills the rest of
-// the window with a DUMMY: an entity none of whose rows the block owns (its atomics are all skipped by the ownership words -- the
-// wrapper needs no change and the dummy's nodes ride in the block's staged list).
-constexpr int FD_PAD_MIN = 12;
-
-__global__ void ocr_pick_dummy(const int32_t *__restrict__ rmap, int ar, int32_t start, int32_t end, const int32_t *__restrict__ rblk,
-                               int32_t nblocks, const int32_t *__restrict__ pinv, int32_t npos, int32_t *__restrict__ dummy) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nblocks) return;
-    const int32_t n0 = rblk[b], n1 = rblk[b + 1];
-    int32_t pick = -1;
-    const int64_t span = (int64_t)end - start;
-    for (int c = 0; c < 8 && pick < 0; ++c) {            // a few entities spread over the range: the first that is foreign to the block
-        const int32_t e = start + (int32_t)((span - 1) * c / 7);
-        bool foreign = true;
-        for (int i = 0; i < ar; ++i) { const int32_t r = row_position(pinv, npos, rmap[(int64_t)e * ar + i]); if (r >= n0 && r < n1) foreign = false; }
-        if (foreign) pick = e;
-    }
-    dummy[b] = pick;
-}
-
-// one thread per block; emit == 0: count the padded slots into cnt[b]; emit == 1: write the padded list at off[b].
-// fill == 1: instead of dummies the rest of the window is filled with instances from the TAIL of the block's list (the groups that own
-// the fewest rows: they join only the atomics of the rows they own, and their own wavefronts at the end of the list get shorter) --
-// the list is permuted, not lengthened
-__global__ void ocr_pad_windows(const uint64_t *__restrict__ keys, const int32_t *__restrict__ inst_off, const int32_t *__restrict__ inst_ent,
-                                const int32_t *__restrict__ rblk, const int32_t *__restrict__ rowstart, int32_t nblocks,
-                                const int32_t *__restrict__ dummy, int emit, int fill, int32_t *__restrict__ cnt,
-                                const int32_t *__restrict__ off, int32_t *__restrict__ out) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nblocks) return;
-    const int32_t o0 = inst_off[b], n0 = rblk[b], d = fill ? 0 : dummy[b];
-    int32_t o1 = inst_off[b + 1];                            // (fill: the tail shrinks as instances are taken from it)
-    const int32_t base = emit ? off[b] : 0, rs0 = rowstart[n0];
-    int32_t pos = 0;
-    uint32_t used = 0;
-    uint64_t prev = ~0ull;
-    for (int32_t j = o0; j < o1; ++j) {
-        const uint64_t key = keys[j], grp = key >> 16;
-        const int res = (rowstart[n0 + (int32_t)(key & 0xffffu)] - rs0) & 15;
-        const int w = pos & 15;
-        if (w == 0 || grp != prev) used = 0;             // (residues of another group say nothing about this one's banks)
-        if (d >= 0 && grp == prev && w >= FD_PAD_MIN && ((used >> res) & 1u)) {
-            for (int q = w; q < 16; ++q) {
-                if (fill) { if (o1 - 1 <= j) break; --o1; if (emit) out[base + pos] = inst_ent[o1]; }
-                else if (emit) out[base + pos] = d;
-                ++pos;
-            }
-            used = 0;
-        }
-        if (emit) out[base + pos] = inst_ent[j];
-        ++pos;
-        used |= 1u << res;
-        prev = grp;
-    }
-    if (!emit) cnt[b] = pos;
-}
-
-// ---- bank-aware packing of the instances of a row block --------------------------------------------------------
-// The wrapper's lanes walk the instance slots in order, so the 16 lanes of an LDS conflict window (64-bit LDS
-// operations are processed 16 lanes at a time; tools/microbench_lds.hip) are 16 consecutive slots.  Per slot the
-// kernel issues, for each row vertex i, gathers at local node index lm[i] (32 eight-byte banks: bank = lm & 31; equal
-// addresses broadcast) and, for each owned row i and column j, a ds_add_f64 at (row base + position); the fp64 atomic
-// path resolves only 16 banks (measured: stride-2 doubles already halve its rate, profiles/r1i_microbench_lds.txt):
-// bank = that & 15, and equal addresses serialise too.  A greedy list scheduler fills the windows one slot at a time: among
-// the unplaced instances of its CHUNK it takes the one that adds the fewest bank collisions to the current window, ties to
-// the earliest (keeps the incoming stencil order where that is conflict-free).  A chunk is PACK_CHUNK consecutive
-// instances (8 windows) of one block, scheduled by one wavefront on its own: every chunk of every block runs in parallel
-// (round 2 scheduled a whole block -- ~2300 sequential steps -- per wavefront: 0.88 s for the C2 plan; chunked: ~15 ms).
-constexpr int PACK_MAXSIG = 128;     // ar + ar*ac signature bytes per instance at most
-constexpr int PACK_CHUNK = 128;      // instances per chunk = candidates a slot chooses from (2 per lane)
-
-__global__ __launch_bounds__(64) void ocr_pack_k(const int32_t *__restrict__ chunk_block, const int32_t *__restrict__ chunk_first,
-                                                 const int32_t *__restrict__ chunk_len, int64_t nchunks,
-                                                 const int32_t *__restrict__ ent_in, int32_t *__restrict__ ent_out, int32_t *__restrict__ perm,
-                                                 const int32_t *__restrict__ imap_r, const uint16_t *__restrict__ lmap,
-                                                 const unsigned char *__restrict__ kidx8, const unsigned short *__restrict__ kidx16,
-                                                 int ar, int ac, const int32_t *__restrict__ rblk, const int32_t *__restrict__ rowptr,
-                                                 int window, const int32_t *__restrict__ pinv, int32_t npos) {
-    extern __shared__ unsigned char pk_lds[];
-    const int lane = threadIdx.x;
-    const int ns = ar + ar * ac;
-    unsigned char *sig = pk_lds;                                                      // PACK_CHUNK * ns bank bytes (0xff = no access)
-    unsigned short *gaddr = (unsigned short *)(pk_lds + (((size_t)PACK_CHUNK * ns + 15) & ~(size_t)15));   // PACK_CHUNK * ar local node ids
-    unsigned int *amask = (unsigned int *)(gaddr + (size_t)PACK_CHUNK * ar);          // ar*ac bank masks of the current window
-    unsigned short *gown = (unsigned short *)(amask + PACK_MAXSIG);                   // ar * 32: address held by a gather bank
-    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        const int b = chunk_block[c], o = chunk_first[c], n = chunk_len[c];
-        if (n <= window) {                                   // nothing to gain: keep the order
-            for (int q = lane; q < n; q += 64) { ent_out[o + q] = ent_in[o + q]; if (perm) perm[o + q] = o + q; }
-            continue;
-        }
-        const int32_t n0 = rblk[b], n1 = rblk[b + 1];
-        const int32_t r0 = rowptr[n0];
-        __syncthreads();
-        for (int q = lane; q < n; q += 64) {
-            const int64_t t = (int64_t)o + q;
-            for (int i = 0; i < ar; ++i) {
-                const unsigned short l = lmap[t * ar + i];
-                gaddr[q * ar + i] = l;
-                sig[q * ns + i] = (unsigned char)(l & 31);
-                const int32_t g = row_position(pinv, npos, imap_r[t * ar + i]);     // (rowptr = row starts in the same order)
-                const bool own = g >= n0 && g < n1;
-                const int base = own ? rowptr[g] - r0 : 0;
-                for (int j = 0; j < ac; ++j) {
-                    const int k = kidx8 ? (int)kidx8[t * ar * ac + i * ac + j] : (int)kidx16[t * ar * ac + i * ac + j];
-                    sig[q * ns + ar + i * ac + j] = own ? (unsigned char)((base + k) & 15) : (unsigned char)0xff;
-                }
-            }
-        }
-        bool placed0 = false, placed1 = false;               // candidates lane and lane + 64 of this chunk
-        for (int p = 0; p < n; ++p) {
-            if (p % window == 0) {
-                __syncthreads();
-                for (int q = lane; q < ar * ac; q += 64) amask[q] = 0u;
-                for (int q = lane; q < ar * 32; q += 64) gown[q] = 0xffffu;
-            }
-            __syncthreads();
-            int best = 0x7fffffff, bl = 0x7fffffff;          // best (cost, candidate) seen by this lane
-            for (int h = 0; h < 2; ++h) {
-                const int inst = lane + 64 * h;
-                if (inst >= n || (h ? placed1 : placed0)) continue;
-                int cost = 0;
-                const unsigned char *s = sig + (size_t)inst * ns;
-                for (int i = 0; i < ar; ++i) {
-                    const unsigned short held = gown[i * 32 + s[i]];
-                    if (held != 0xffffu && held != gaddr[inst * ar + i]) cost += 3;      // one extra pass per component
-                }
-                for (int q = 0; q < ar * ac; ++q) {
-                    const unsigned char bk = s[ar + q];
-                    if (bk != 0xff && (amask[q] >> bk & 1u)) cost += 1;
-                }
-                if (cost < best) { best = cost; bl = inst; }
-            }
-            // argmin over the wavefront, ties to the earliest candidate (keeps the incoming order where it is conflict-free)
-            for (int d = 32; d > 0; d >>= 1) {
-                const int oc = __shfl_xor(best, d, 64), ol = __shfl_xor(bl, d, 64);
-                if (oc < best || (oc == best && ol < bl)) { best = oc; bl = ol; }
-            }
-            const int chosen = bl;
-            if ((chosen & 63) == lane) { if (chosen >= 64) placed1 = true; else placed0 = true; }
-            if (lane == 0) { ent_out[o + p] = ent_in[o + chosen]; if (perm) perm[o + p] = o + chosen; }
-            __syncthreads();
-            const unsigned char *s = sig + (size_t)chosen * ns;
-            for (int q = lane; q < ar * ac; q += 64) { const unsigned char bk = s[ar + q]; if (bk != 0xff) amask[q] |= 1u << bk; }
-            if (lane < ar) { if (gown[lane * 32 + s[lane]] == 0xffffu) gown[lane * 32 + s[lane]] = gaddr[chosen * ar + lane]; }
-        }
-    }
-}
-
-// The same scheduler with the candidates' costs kept in registers (round 4).  The kernel above re-evaluates both candidates of a
-// lane for every slot -- 40 byte reads of LDS each -- although placing one instance changes a candidate's cost only where it sets a
-// bank bit (or takes a free gather bank) that was clear: the lanes that hold the chosen instance's bytes publish exactly those
-// ("newly used bank of atomic q" / "new holder of gather bank i", 0xfe = nothing new) and every candidate adds the bytes of its
-// own signature that match (zero bytes of an XOR, four at a time).  Same costs, same ties, same order out -- the plan of C2 in
-// 12 ms instead of 40.  NSW = 32-bit words of atomic bank bytes per instance (ar * ac <= 32), ar <= 8.
-__device__ __forceinline__ int pk_zero_bytes(uint32_t x) {
-    uint32_t t = (x & 0x7f7f7f7fu) + 0x7f7f7f7fu;
-    t = ~(t | x | 0x7f7f7f7fu);
-    return __popc(t);
-}
-
-template <int NSW>
-__global__ __launch_bounds__(64) void ocr_pack2_k(const int32_t *__restrict__ chunk_block, const int32_t *__restrict__ chunk_first,
-                                                  const int32_t *__restrict__ chunk_len, int64_t nchunks,
-                                                  const int32_t *__restrict__ ent_in, int32_t *__restrict__ ent_out, int32_t *__restrict__ perm,
-                                                  const int32_t *__restrict__ imap_r, const uint16_t *__restrict__ lmap,
-                                                  const unsigned char *__restrict__ kidx8, const unsigned short *__restrict__ kidx16,
-                                                  int ar, int ac, const int32_t *__restrict__ rblk, const int32_t *__restrict__ rowptr,
-                                                  const int32_t *__restrict__ pinv, int32_t npos) {
-    __shared__ uint32_t s_at[PACK_CHUNK][NSW];          // atomic bank bytes of every candidate (0xff = no access)
-    __shared__ uint32_t s_gb[PACK_CHUNK][2];            // gather bank bytes
-    __shared__ uint16_t s_ga[PACK_CHUNK][8];            // gather addresses (local node ids)
-    __shared__ uint32_t s_amask[NSW * 4];               // banks the window already uses, per atomic
-    __shared__ uint16_t s_gown[8][32];                  // address held by a gather bank (0xffff = free)
-    __shared__ uint32_t s_newat[NSW], s_newgb[2];
-    __shared__ uint16_t s_newga[8];
-    const int lane = threadIdx.x, nat = ar * ac;
-    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        const int b = chunk_block[c], o = chunk_first[c], n = chunk_len[c];
-        if (n <= 16) {                                       // nothing to gain: keep the order
-            for (int q = lane; q < n; q += 64) { ent_out[o + q] = ent_in[o + q]; if (perm) perm[o + q] = o + q; }
-            continue;
-        }
-        const int32_t n0 = rblk[b], n1 = rblk[b + 1];
-        const int32_t r0 = rowptr[n0];
-        uint32_t at[2][NSW], gb[2][2];
-        uint16_t ga[2][8];
-        __syncthreads();
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int inst = lane + 64 * h;
-#pragma unroll
-            for (int w = 0; w < NSW; ++w) at[h][w] = 0xffffffffu;
-            gb[h][0] = gb[h][1] = 0xffffffffu;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) ga[h][i] = 0;
-            if (inst < n) {
-                const int64_t t = (int64_t)o + inst;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    if (i >= ar) break;
-                    const unsigned short l = lmap[t * ar + i];
-                    ga[h][i] = l;
-                    gb[h][i >> 2] = (gb[h][i >> 2] & ~(0xffu << (8 * (i & 3)))) | ((uint32_t)(l & 31) << (8 * (i & 3)));
-                    const int32_t g = row_position(pinv, npos, imap_r[t * ar + i]);
-                    if (g >= n0 && g < n1) {
-                        const int base = rowptr[g] - r0;
-                        for (int j = 0; j < ac; ++j) {
-                            const int q = i * ac + j;
-                            const int k = kidx8 ? (int)kidx8[t * nat + q] : (int)kidx16[t * nat + q];
-                            const uint32_t bk = (uint32_t)((base + k) & 15);
-#pragma unroll
-                            for (int w = 0; w < NSW; ++w)
-                                if (w == (q >> 2)) at[h][w] = (at[h][w] & ~(0xffu << (8 * (q & 3)))) | (bk << (8 * (q & 3)));
-                        }
-                    }
-                }
-#pragma unroll
-                for (int w = 0; w < NSW; ++w) s_at[inst][w] = at[h][w];
-                s_gb[inst][0] = gb[h][0]; s_gb[inst][1] = gb[h][1];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) s_ga[inst][i] = ga[h][i];
-            }
-        }
-        bool placed[2] = {lane >= n, lane + 64 >= n};
-        int cost[2] = {0, 0};
-        for (int p = 0; p < n; ++p) {
-            if ((p & 15) == 0) {
-                cost[0] = cost[1] = 0;
-                __syncthreads();
-                if (lane < NSW * 4) s_amask[lane] = 0u;
-                for (int q = lane; q < 8 * 32; q += 64) (&s_gown[0][0])[q] = 0xffffu;
-            }
-            __syncthreads();
-            int best = 0x7fffffff, bl = 0x7fffffff;
-            if (!placed[0]) { best = cost[0]; bl = lane; }
-            if (!placed[1] && cost[1] < best) { best = cost[1]; bl = lane + 64; }
-            for (int d = 32; d > 0; d >>= 1) {
-                const int oc = __shfl_xor(best, d, 64), ol = __shfl_xor(bl, d, 64);
-                if (oc < best || (oc == best && ol < bl)) { best = oc; bl = ol; }
-            }
-            const int chosen = bl;
-            if ((chosen & 63) == lane) placed[chosen >> 6] = true;
-            if (lane == 0) { ent_out[o + p] = ent_in[o + chosen]; if (perm) perm[o + p] = o + chosen; }
-            // what the chosen instance adds to the window: one lane per atomic byte, one per gather component
-            if (lane < NSW * 4) {
-                unsigned char nb = 0xfe;
-                if (lane < nat) {
-                    const uint32_t bk = (s_at[chosen][lane >> 2] >> (8 * (lane & 3))) & 0xffu;
-                    if (bk != 0xffu) {
-                        const uint32_t m = s_amask[lane];
-                        if (!((m >> bk) & 1u)) { s_amask[lane] = m | (1u << bk); nb = (unsigned char)bk; }
-                    }
-                }
-                ((unsigned char *)s_newat)[lane] = nb;
-            } else if (lane >= 32 && lane < 40) {
-                const int i = lane - 32;
-                unsigned char nb = 0xfe;
-                if (i < ar) {
-                    const uint32_t gk = (s_gb[chosen][i >> 2] >> (8 * (i & 3))) & 0xffu;
-                    if (s_gown[i][gk] == 0xffffu) { const uint16_t a = s_ga[chosen][i]; s_gown[i][gk] = a; s_newga[i] = a; nb = (unsigned char)gk; }
-                }
-                ((unsigned char *)s_newgb)[i] = nb;
-            }
-            __syncthreads();
-            uint32_t na[NSW];
-#pragma unroll
-            for (int w = 0; w < NSW; ++w) na[w] = s_newat[w];
-            const uint32_t ng0 = s_newgb[0], ng1 = s_newgb[1];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (placed[h]) continue;
-                int add = 0;
-#pragma unroll
-                for (int w = 0; w < NSW; ++w) add += pk_zero_bytes(at[h][w] ^ na[w]);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const uint32_t mine = (gb[h][i >> 2] >> (8 * (i & 3))) & 0xffu, nw = ((i < 4 ? ng0 : ng1) >> (8 * (i & 3))) & 0xffu;
-                    if (mine == nw && ga[h][i] != s_newga[i]) add += 3;       // one extra pass per component
-                }
-                cost[h] += add;
-            }
-        }
-    }
-}
-
 __global__ void iota_k(int32_t *__restrict__ out, int64_t n) {
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) out[t] = (int32_t)t;
-}
-
-template <class T>
-__global__ void permute_rows_k(const T *__restrict__ src, int units, const int32_t *__restrict__ perm, int64_t n, T *__restrict__ dst) {
-    const int64_t total = n * units;
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t k = t / units;
-        dst[t] = src[(int64_t)perm[k] * units + (t - k * units)];
-    }
 }
 
 __global__ void gather_rows_k(const int32_t *__restrict__ src, int arity, const int32_t *__restrict__ idx, int64_t n,
@@ -1562,8 +1252,7 @@ static int ocrplan_build(const int32_t *rmap_dev, int ar, int32_t start, int32_t
     FD_HIP(hipMalloc(&p->inst_ent, (size_t)(nu > 0 ? nu : 1) * 4));
     hipLaunchKernelGGL(ocr_split, dim3(mp_grid(nu + 1)), dim3(256), 0, s, uniq, nu, nblocks, p->inst_off, p->inst_ent);
     FD_CHECK_LAUNCH();
-    p->bygeom = interleave < 0 ? 1 : 0;
-    if ((interleave == 1 || interleave == -1) && nu > 0) {
+    if (interleave == 1 && nu > 0) {
         // stencil order (-1: groups by shape, not by ownership pattern): (block | signature | first owned row) keys, one stable radix sort of (key, entity) pairs
         uint64_t *ka = nullptr, *kb = nullptr;
         int32_t *vb = nullptr;
@@ -1571,7 +1260,7 @@ static int ocrplan_build(const int32_t *rmap_dev, int ar, int32_t start, int32_t
         FD_HIP(hipMalloc(&kb, (size_t)nu * 8));
         FD_HIP(hipMalloc(&vb, (size_t)nu * 4));
         hipLaunchKernelGGL(ocr_stencil_keys, dim3(mp_grid(nu)), dim3(256), 0, s, rmap_dev, ar, p->inst_off, p->inst_ent, p->rblk,
-                           nblocks, nu, ka, p->pinv, p->npos, interleave < 0 ? 1 : 0);
+                           nblocks, nu, ka, p->pinv, p->npos);
         FD_CHECK_LAUNCH();
         hipcub::DoubleBuffer<uint64_t> dk(ka, kb);
         hipcub::DoubleBuffer<int32_t> dv(p->inst_ent, vb);
@@ -1602,155 +1291,6 @@ static int ocrplan_build(const int32_t *rmap_dev, int ar, int32_t start, int32_t
     }
     FD_HIP(hipFree(k1)); FD_HIP(hipFree(k2)); FD_HIP(hipFree(tmp)); FD_HIP(hipFree(nsel));
     *out = p;
-    return 0;
-}
-
-int fd_ocrplan_pack(fd_ocrplan_t p, const int32_t *imap_r_dev, const uint16_t *lmap_dev, int ar, const void *kidx_dev, int kbytes,
-                    int ac, const int32_t *node_rowptr_dev, int32_t *perm_out_dev, fd_stream_t s_) {
-    if (!p || !imap_r_dev || !lmap_dev || !kidx_dev || !node_rowptr_dev || ar <= 0 || ac <= 0 || (kbytes != 1 && kbytes != 2))
-        FD_FAIL("fd_ocrplan_pack: bad arguments");
-    if (p->nblocks == 0 || p->ninst == 0) return 0;
-    const int ns = ar + ar * ac;
-    hipStream_t s = fd::st(s_);
-    if (ns > PACK_MAXSIG) {                               // large element matrices: keep the incoming order
-        if (perm_out_dev) { hipLaunchKernelGGL(iota_k, dim3(mp_grid(p->ninst)), dim3(256), 0, s, perm_out_dev, p->ninst); FD_CHECK_LAUNCH(); }
-        return 0;
-    }
-    const int window = 16;
-    // chunks of PACK_CHUNK consecutive instances, never across a block boundary
-    int64_t nchunks = 0;
-    for (int32_t b = 0; b < p->nblocks; ++b) nchunks += (p->inst_off_host[b + 1] - p->inst_off_host[b] + PACK_CHUNK - 1) / PACK_CHUNK;
-    if (nchunks == 0) return 0;
-    std::vector<int32_t> ch((size_t)nchunks * 3);
-    int32_t *cb = ch.data(), *cf = cb + nchunks, *cl = cf + nchunks;
-    int64_t c = 0;
-    for (int32_t b = 0; b < p->nblocks; ++b)
-        for (int32_t o = p->inst_off_host[b]; o < p->inst_off_host[b + 1]; o += PACK_CHUNK, ++c) {
-            cb[c] = b; cf[c] = o;
-            cl[c] = std::min<int32_t>(PACK_CHUNK, p->inst_off_host[b + 1] - o);
-        }
-    int32_t *dch = nullptr, *out = nullptr;
-    FD_HIP(hipMalloc(&dch, (size_t)nchunks * 12));
-    FD_HIP(hipMemcpyAsync(dch, ch.data(), (size_t)nchunks * 12, hipMemcpyHostToDevice, s));
-    const int32_t *dcb = dch, *dcf = dch + nchunks, *dcl = dch + 2 * nchunks;
-    FD_HIP(hipMalloc(&out, (size_t)p->ninst * 4));
-    const int64_t grid = nchunks < 256 * 64 ? nchunks : 256 * 64;
-    const unsigned char *k8 = kbytes == 1 ? (const unsigned char *)kidx_dev : nullptr;
-    const unsigned short *k16 = kbytes == 2 ? (const unsigned short *)kidx_dev : nullptr;
-    const int32_t *rowstart = p->prowptr ? p->prowptr : node_rowptr_dev;
-    const char *lg = getenv("FDHIP_PACK_LEGACY");             // (read per call: the tests compare the two schedulers in one process)
-    const bool legacy = lg && atoi(lg) != 0;
-    const int nsw = (ar * ac + 3) / 4;
-    if (!legacy && ar <= 8 && nsw <= 8) {
-#define FD_PACK2(N) hipLaunchKernelGGL(ocr_pack2_k<N>, dim3((unsigned)grid), dim3(64), 0, s, dcb, dcf, dcl, nchunks, p->inst_ent, out, perm_out_dev, \
-                                       imap_r_dev, lmap_dev, k8, k16, ar, ac, p->rblk, rowstart, p->pinv, p->npos)
-        switch (nsw) {
-        case 1: FD_PACK2(1); break; case 2: FD_PACK2(2); break; case 3: FD_PACK2(3); break; case 4: FD_PACK2(4); break;
-        case 5: FD_PACK2(5); break; case 6: FD_PACK2(6); break; case 7: FD_PACK2(7); break; default: FD_PACK2(8); break;
-        }
-#undef FD_PACK2
-    } else {
-        const size_t lds = (((size_t)PACK_CHUNK * ns + 15) & ~(size_t)15) + (size_t)PACK_CHUNK * ar * 2 + PACK_MAXSIG * 4 + (size_t)ar * 32 * 2 + 64;
-        if (lds > 48 * 1024)
-            FD_HIP(hipFuncSetAttribute((const void *)ocr_pack_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(ocr_pack_k, dim3((unsigned)grid), dim3(64), lds, s, dcb, dcf, dcl, nchunks, p->inst_ent, out, perm_out_dev, imap_r_dev,
-                           lmap_dev, k8, k16, ar, ac, p->rblk, rowstart, window, p->pinv, p->npos);
-    }
-    FD_CHECK_LAUNCH();
-    FD_HIP(hipStreamSynchronize(s));
-    FD_HIP(hipFree(dch));
-    FD_HIP(hipFree(p->inst_ent));
-    p->inst_ent = out;
-    return 0;
-}
-
-// rows[t] <- rows[perm[t]] for n rows of rowbytes bytes each (the per-instance tables of a plan after fd_ocrplan_pack: the packer
-// permutes instances inside their blocks, so the block node lists stay and only the rows move)
-int fd_permute_rows(void *rows_dev, int rowbytes, const int32_t *perm_dev, int64_t n, fd_stream_t s_) {
-    if (!rows_dev || !perm_dev || rowbytes <= 0 || n < 0) FD_FAIL("fd_permute_rows: bad arguments");
-    if (n == 0) return 0;
-    hipStream_t s = fd::st(s_);
-    void *tmp = nullptr;
-    const size_t bytes = (size_t)n * rowbytes;
-    FD_HIP(hipMalloc(&tmp, bytes));
-    if (rowbytes % 4 == 0)
-        hipLaunchKernelGGL(permute_rows_k<uint32_t>, dim3(mp_grid(n * (rowbytes / 4))), dim3(256), 0, s, (const uint32_t *)rows_dev, rowbytes / 4,
-                           perm_dev, n, (uint32_t *)tmp);
-    else if (rowbytes % 2 == 0)
-        hipLaunchKernelGGL(permute_rows_k<uint16_t>, dim3(mp_grid(n * (rowbytes / 2))), dim3(256), 0, s, (const uint16_t *)rows_dev, rowbytes / 2,
-                           perm_dev, n, (uint16_t *)tmp);
-    else
-        hipLaunchKernelGGL(permute_rows_k<uint8_t>, dim3(mp_grid(n * rowbytes)), dim3(256), 0, s, (const uint8_t *)rows_dev, rowbytes, perm_dev, n,
-                           (uint8_t *)tmp);
-    FD_CHECK_LAUNCH();
-    FD_HIP(hipMemcpyAsync(rows_dev, tmp, bytes, hipMemcpyDeviceToDevice, s));
-    FD_HIP(hipStreamSynchronize(s));
-    FD_HIP(hipFree(tmp));
-    return 0;
-}
-
-int fd_ocrplan_pad_windows(fd_ocrplan_t p, const int32_t *rmap_dev, int ar, int32_t start, int32_t end, const int32_t *rowstart_dev,
-                           int mode, int64_t *ndummy, fd_stream_t s_) {
-    if (!p || !rmap_dev || !rowstart_dev || ar <= 0) FD_FAIL("fd_ocrplan_pad_windows: bad arguments");
-    if (ndummy) *ndummy = 0;
-    if (p->ninst <= 0 || p->nblocks <= 0 || end <= start || p->chunk_role) return 0;
-    if (!(ar <= 8 && p->nblocks < (1 << 24))) return 0;          // (the stencil key carries the ownership pattern only then)
-    hipStream_t s = fd::st(s_);
-    const int64_t nu = p->ninst;
-    const int32_t nb = p->nblocks;
-    uint64_t *keys = nullptr;
-    int32_t *dummy = nullptr, *cnt = nullptr, *noff = nullptr, *out = nullptr;
-    void *tmp = nullptr;
-    FD_HIP(hipMalloc(&keys, (size_t)nu * 8));
-    FD_HIP(hipMalloc(&dummy, (size_t)nb * 4));
-    FD_HIP(hipMalloc(&cnt, ((size_t)nb + 1) * 4));
-    FD_HIP(hipMalloc(&noff, ((size_t)nb + 1) * 4));
-    hipLaunchKernelGGL(ocr_stencil_keys, dim3(mp_grid(nu)), dim3(256), 0, s, rmap_dev, ar, p->inst_off, p->inst_ent, p->rblk, nb, nu, keys,
-                       p->pinv, p->npos, p->bygeom);
-    FD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ocr_pick_dummy, dim3((nb + 255) / 256), dim3(256), 0, s, rmap_dev, ar, start, end, p->rblk, nb, p->pinv, p->npos, dummy);
-    FD_CHECK_LAUNCH();
-    if (mode == 2) {                                      // fill from the tail: a permutation of every block's list
-        FD_HIP(hipMalloc(&out, (size_t)nu * 4));
-        hipLaunchKernelGGL(ocr_pad_windows, dim3((nb + 63) / 64), dim3(64), 0, s, keys, p->inst_off, p->inst_ent, p->rblk, rowstart_dev, nb, dummy,
-                           1, 1, nullptr, p->inst_off, out);
-        FD_CHECK_LAUNCH();
-        FD_HIP(hipStreamSynchronize(s));
-        FD_HIP(hipFree(p->inst_ent));
-        p->inst_ent = out;
-        FD_HIP(hipFree(keys)); FD_HIP(hipFree(dummy)); FD_HIP(hipFree(cnt)); FD_HIP(hipFree(noff));
-        return 0;
-    }
-    FD_HIP(hipMemsetAsync(cnt, 0, ((size_t)nb + 1) * 4, s));
-    hipLaunchKernelGGL(ocr_pad_windows, dim3((nb + 63) / 64), dim3(64), 0, s, keys, p->inst_off, p->inst_ent, p->rblk, rowstart_dev, nb, dummy, 0,
-                       0, cnt, nullptr, nullptr);
-    FD_CHECK_LAUNCH();
-    size_t tb = 0;
-    FD_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt, noff, nb + 1, s));
-    FD_HIP(hipMalloc(&tmp, tb ? tb : 8));
-    FD_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, cnt, noff, nb + 1, s));
-    int32_t total = 0;
-    FD_HIP(hipMemcpyAsync(&total, noff + nb, 4, hipMemcpyDeviceToHost, s));
-    FD_HIP(hipStreamSynchronize(s));
-    if ((int64_t)total > nu) {
-        FD_HIP(hipMalloc(&out, (size_t)total * 4));
-        hipLaunchKernelGGL(ocr_pad_windows, dim3((nb + 63) / 64), dim3(64), 0, s, keys, p->inst_off, p->inst_ent, p->rblk, rowstart_dev, nb, dummy,
-                           1, 0, nullptr, noff, out);
-        FD_CHECK_LAUNCH();
-        FD_HIP(hipMemcpyAsync(p->inst_off_host, noff, ((size_t)nb + 1) * 4, hipMemcpyDeviceToHost, s));
-        FD_HIP(hipStreamSynchronize(s));
-        FD_HIP(hipFree(p->inst_ent)); FD_HIP(hipFree(p->inst_off));
-        p->inst_ent = out; p->inst_off = noff; noff = nullptr;
-        if (ndummy) *ndummy = (int64_t)total - nu;
-        p->ninst = total;
-        p->max_inst = 0;
-        for (int32_t b = 0; b < nb; ++b) {
-            const int d = p->inst_off_host[b + 1] - p->inst_off_host[b];
-            if (d > p->max_inst) p->max_inst = d;
-        }
-    }
-    FD_HIP(hipFree(keys)); FD_HIP(hipFree(dummy)); FD_HIP(hipFree(cnt)); FD_HIP(hipFree(tmp));
-    if (noff) FD_HIP(hipFree(noff));
     return 0;
 }
 

@@ -9,14 +9,9 @@ import ctypes
 from . import _lib
 
 
-captured_any = False       # a recorded graph holds raw pointers to plan tables: nothing may rebuild them afterwards (OcrPlan.launched)
-
-
 class CapturedStep:
     def __init__(self, fn, warmup=2):
         """``fn()`` must only enqueue device work once warmed up (no host<->device copies, no allocation)."""
-        global captured_any
-        captured_any = True
         for _ in range(warmup):
             fn()                      # builds plans / tables / uploads data
         _lib.call("fd_device_sync")

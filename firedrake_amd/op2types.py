@@ -1927,16 +1927,6 @@ class OcrPlan:
             _lib.call("fd_ocrplan_create", rmap._base()._dev_values(), rmap.arity, int(start), int(end), rb.ctypes.data, nb,
                       self._order_code(lane_threads), None, ctypes.byref(h))
         self.h = h.value
-        # conflict-free LDS atomic windows: dummy instances where the stencil order would put two lanes of a 16-lane window on one
-        # accumulator bank (fd_ocrplan_pad_windows; stencil order only)
-        self.ndummy = 0
-        if configuration["ocr_pad_windows"] and self._order_code(lane_threads) in (1, -1):
-            nd_ = ctypes.c_int64()
-            sparsity._build()
-            _lib.call("fd_ocrplan_pad_windows", self.h, rmap._base()._dev_values(), rmap.arity, int(start), int(end),
-                      row_order.prowptr.ptr if row_order is not None else sparsity._node_rowptr.ptr,
-                      int(configuration["ocr_pad_windows"]), ctypes.byref(nd_), None)
-            self.ndummy = nd_.value
         ni, mi = ctypes.c_int64(), ctypes.c_int32()
         _lib.call("fd_ocrplan_info", self.h, ctypes.byref(ni), ctypes.byref(mi))
         self.ninst, self.max_inst, self.nblocks = ni.value, mi.value, nb
@@ -1956,49 +1946,6 @@ class OcrPlan:
         maxlen = sparsity._max_node_rowlen()
         self.kbytes = 1 if maxlen <= 254 else 2
         self._build_tables(sparsity, rmap, cmap, staged_maps)
-        # Bank-aware packing of the instance lists (fd_ocrplan_pack) is worth 1.5-5 % of every later launch and costs ~40 ms at C2 size
-        # (the scheduler kernel + the permutation of the per-instance tables): 10^3 launches to break even.  It is therefore deferred until the plan has proved
-        # to be long-lived -- ``ocr_pack_after`` launches (0 = pack at construction) -- so that a Newton solve of a dozen
-        # assemblies never pays for it (``launched()`` counts; nothing is repacked once a hipGraph may hold the table pointers).
-        self._pack_args = (sparsity, rmap, cmap, staged_maps)
-        self.packed, self._launches = False, 0
-        if configuration["ocr_pack"] and int(configuration["ocr_pack_after"]) <= 0:
-            self.pack()
-
-    def launched(self):
-        """Called by the parloop before every launch; packs the instance lists on the ``ocr_pack_after``-th one."""
-        self._launches += 1
-        if (not self.packed and configuration["ocr_pack"] and self._launches > int(configuration["ocr_pack_after"]) > 0):
-            from . import graph
-            if not graph.captured_any:
-                self.pack()
-
-    def pack(self):
-        sparsity, rmap, cmap, staged_maps = self._pack_args
-        self.packed = True
-        if not (self.ninst and rmap.arity * (1 + cmap.arity) <= 128):
-            return
-        # bank-aware packing needs the tables of the current order.  It moves instances inside their blocks only: the block node
-        # lists of the staged plans stay valid and the per-instance rows (copies of the maps, local maps, row offsets) follow the
-        # permutation -- a second table build cost 5x as much
-        ir, rkey = self._imap_of(rmap, staged_maps)
-        # (a row map that is not among the staged maps gets a plan of its own for the packer: it must outlive the call below --
-        # the local map is a raw pointer into it, and the next allocation could reuse its block)
-        rplan = self.plans[rkey] if rkey is not None else Plan(ir.ptr, 0, int(self.ninst), 0, self.inst_off_host, arity=rmap.arity)
-        lm = rplan.lmap
-        perm = DeviceBuffer(int(self.ninst) * 4)
-        _lib.call("fd_device_sync")                 # (launches queued on the current tables finish before the rows move)
-        _lib.call("fd_ocrplan_pack", self.h, ir.ptr, lm, rmap.arity, self.kidx.ptr, self.kbytes, cmap.arity,
-                  sparsity._node_rowptr.ptr, perm.ptr, None)
-        p = [ctypes.c_void_p() for _ in range(4)]
-        _lib.call("fd_ocrplan_arrays", self.h, *[ctypes.byref(x) for x in p])
-        self.inst_ent = p[2].value
-        for key, m in staged_maps.items():
-            _lib.call("fd_permute_rows", self._imaps[key].ptr, m.arity * 4, perm.ptr, int(self.ninst), None)
-            _lib.call("fd_permute_rows", self.plans[key].lmap, m.arity * 2, perm.ptr, int(self.ninst), None)
-        _lib.call("fd_permute_rows", self.kidx.ptr, rmap.arity * cmap.arity * self.kbytes, perm.ptr, int(self.ninst), None)
-        del rplan                                    # (fd_ocrplan_pack and the permutations above have synchronised the stream)
-        self.__dict__.pop("_records", None)         # records are packed from the tables of the current order
 
     def _imap_of(self, m, staged_maps):
         """(per-instance copy of Map ``m``, its key among the staged maps or None)."""
@@ -2048,11 +1995,9 @@ class OcrPlan:
         order = str(configuration["ocr_order"])
         if order == "stencil":
             return 1
-        if order == "shape":
-            return -1
         if order == "natural":
             return 0
-        raise ValueError("FDHIP_OCR_ORDER must be stencil, shape or natural")
+        raise ValueError("FDHIP_OCR_ORDER must be stencil or natural")
 
     def __del__(self):
         try:
@@ -2169,7 +2114,7 @@ class RowOrder:
     ``prowptr`` = CSR row starts in that order (device + host copy).  Built from an entity order by the first-touch rule
     (fd_first_touch_order)."""
 
-    def __init__(self, rmap: Map, order: "DeviceBuffer", n, npos, node_rowptr_host, rowptr_dev=None, pad=False):
+    def __init__(self, rmap: Map, order: "DeviceBuffer", n, npos, node_rowptr_host, rowptr_dev=None):
         """First-touch row order under the entity order ``order`` (fd_first_touch_order).  ``rowptr_dev``: device pointer of the
         same row starts when the caller holds one (saves an upload)."""
         self.npos = int(npos)
@@ -2178,20 +2123,20 @@ class RowOrder:
         _lib.call("fd_first_touch_order", rmap._base()._dev_values(), rmap.arity, order.ptr, int(n), self.npos, self.pinv.ptr,
                   self.plist.ptr, rank.ptr, None)
         self.rank_host = rank.download(np.int32, (self.npos,))       # position (in ``order``) of the entity first touching row p
-        self._tables(node_rowptr_host, rowptr_dev, pad)
+        self._tables(node_rowptr_host, rowptr_dev)
 
     @classmethod
-    def from_plist(cls, plist: "DeviceBuffer", npos, node_rowptr_host, rowptr_dev=None, pad=False):
+    def from_plist(cls, plist: "DeviceBuffer", npos, node_rowptr_host, rowptr_dev=None):
         """A row order given as a device permutation of [0, npos) (a k-d partition of the rows' own positions)."""
         self = cls.__new__(cls)
         self.npos = int(npos)
         self.plist, self.pinv = plist, DeviceBuffer(max(npos, 1) * 4)
         _lib.call("fd_invert_permutation", plist.ptr, self.npos, self.pinv.ptr, None)
         self.rank_host = None
-        self._tables(node_rowptr_host, rowptr_dev, pad)
+        self._tables(node_rowptr_host, rowptr_dev)
         return self
 
-    def _tables(self, node_rowptr_host, rowptr_dev=None, pad=False):
+    def _tables(self, node_rowptr_host, rowptr_dev=None):
         """prowptr (accumulator starts by position, also kept on the host: the block cuts are made there) and the two lookups the
         wrapper needs, flattened so that neither is a dependent chain of loads: nstart[node] = prowptr[pinv[node]] (accumulator
         offset of a row, by NODE), gstart[p] = rowptr[plist[p]] (CSR start, by POSITION) -- fd_row_order_tables, on the device (the
@@ -2202,12 +2147,7 @@ class RowOrder:
         if rowptr_dev is None:
             keep = DeviceBuffer.from_numpy(np.ascontiguousarray(node_rowptr_host, dtype=np.int32))
             rowptr_dev = keep.ptr
-        # ``pad``: accumulator starts with one entry of padding after every run of consecutive rows (fd_row_order_tables); plen = the
-        # true row lengths such an order needs wherever prowptr differences used to serve
-        self.padded = bool(pad)
-        self.plen = DeviceBuffer(n1 * 4) if pad else None
-        _lib.call("fd_row_order_tables", self.npos, self.plist.ptr, rowptr_dev, 1 if pad else 0, self.prowptr.ptr, self.nstart.ptr,
-                  self.gstart.ptr, self.plen.ptr if pad else None, None)
+        _lib.call("fd_row_order_tables", self.npos, self.plist.ptr, rowptr_dev, self.prowptr.ptr, self.nstart.ptr, self.gstart.ptr, None)
         self.prowptr_host = self.prowptr.download(np.int32, (self.npos + 1,))
 
     def gpos(self):
@@ -2215,15 +2155,12 @@ class RowOrder:
         array -- what the whole-entity "ocrp" flush streams (built on first use)."""
         if getattr(self, "_gpos", None) is None:
             self._gpos = DeviceBuffer(max(int(self.prowptr_host[-1]), 1) * 4)
-            _lib.call("fd_row_entry_positions", self.npos, self.prowptr.ptr, self.gstart.ptr, self.plen.ptr if self.padded else None,
-                      self._gpos.ptr, None)
+            _lib.call("fd_row_entry_positions", self.npos, self.prowptr.ptr, self.gstart.ptr, self._gpos.ptr, None)
         return self._gpos
 
     def runs(self, row_blocks):
         """Run-coded places of the accumulator entries for the row blocks ``row_blocks`` (host array of nblocks + 1 positions;
         fd_ocr_row_runs): (grun, brun, rdelta device buffers, most runs in one block), built once per set of blocks."""
-        if self.padded:
-            raise ValueError("the run-coded flush writes every accumulator entry: not for a padded row order")
         rb = np.ascontiguousarray(row_blocks, dtype=np.int32)
         key = rb.tobytes()
         hit = getattr(self, "_runs", None)

@@ -959,13 +959,13 @@ class Parloop:
                 if kd_leaf_size(rows_per_block) <= rows_per_block:
                     rows_per_block = kd_leaf_size(rows_per_block)           # (never above the LDS budget the cap stands for)
                 plist, rb = kd_order_of(pos_.data, nrows, rows_per_block)
-                row_order = RowOrder.from_plist(plist, nrows, rp, rowptr_dev=sp._node_rowptr.ptr, pad=bool(configuration["ocr_pad_runs"]))
+                row_order = RowOrder.from_plist(plist, nrows, rp, rowptr_dev=sp._node_rowptr.ptr)
             elif usable:
                 # rows of another space: first touch under the k-d order of the entities, cut where the entity leaf changes
                 # (leaves hold equal numbers of entities, not of rows: 10 % slack before a block is halved)
                 order = self._locality_order(start, end, virtual=v is not None)
                 if order is not None:
-                    row_order = RowOrder(rmap, order, end - start, nrows, rp, rowptr_dev=sp._node_rowptr.ptr, pad=bool(configuration["ocr_pad_runs"]))
+                    row_order = RowOrder(rmap, order, end - start, nrows, rp, rowptr_dev=sp._node_rowptr.ptr)
                     cap = configuration["ocr_nnz_per_block_ordered"]
                     rb = row_order.tile_cuts(order.blocks, cap + cap // 10)
             if row_order is not None:
@@ -1041,7 +1041,7 @@ class Parloop:
             import sys
             print(f"[fdhip] {self.global_kernel.name} OCR variant {variant}: record {rec}", file=sys.stderr)
             print(f"[fdhip] {self.global_kernel.name} OCR [{start},{end}): row blocks={op.nblocks} instances={op.ninst} "
-                  f"(x{op.ninst / max(end - start, 1):.2f} entities, {op.ndummy} window-padding dummies) max_inst={op.max_inst} max_nnz={op.max_nnz} max_nown={op.max_nown} "
+                  f"(x{op.ninst / max(end - start, 1):.2f} entities) max_inst={op.max_inst} max_nnz={op.max_nnz} max_nown={op.max_nown} "
                   f"lds={lds} kbytes={op.kbytes}", file=sys.stderr)
         return geo
 
@@ -1136,8 +1136,6 @@ class Parloop:
         op = geo["ocr"]
         if op.nblocks == 0 or op.ninst == 0:
             return
-        if hasattr(op, "launched"):
-            op.launched()                  # (deferred bank-aware packing of a plan that turned out to be long-lived)
         out = []
         for desc in src.layout:
             kind = desc[0]

@@ -184,9 +184,6 @@ int fd_ocrplan_create(const int32_t *rmap_dev, int rarity, int32_t start, int32_
                                                              * then skip the atomics of rows none of them owns --, by the
                                                              * signature of owned rows + node offsets, then by first owned
                                                              * row: conflict-free LDS atomics on structured pieces);
-                                                             * interleave == -1: stencil order grouped by the entity's shape
-                                                             * alone (node offsets from the first owned row, whoever owns
-                                                             * them), then by first owned row;
                                                              * interleave > 1: multiplicative permutation of every instance list;
                                                              * 0: entity order */
 /* The per-(block, staged node) words of the whole-entity owner-computes-rows wrapper in PLAN order (blkoff / list of the row
@@ -215,12 +212,6 @@ int fd_ocr_node_diag(const int32_t *list_dev, int64_t n, int32_t nrows, const in
 int fd_ocr_pack_records(int64_t ninst, int nmaps, const uint16_t *const *lmaps_dev, const int32_t *arities, const int32_t *lbits,
                         const void *kidx_dev, int kbytes, int nr, int nc, int kbits, int skipdiag, const uint16_t *extra_dev, int ebits,
                         int sentinel, int words, uint32_t *out_dev, fd_stream_t s);
-/* Bank-aware packing of the instance lists (in place; inst_off is unchanged): given the per-instance row-map rows
- * (global node ids), local-map rows and row-offset table built for the CURRENT instance order, a greedy list scheduler
- * reorders the instances inside chunks of 128 (one wavefront per chunk, all chunks of all blocks in parallel) so that the 16
- * consecutive slots of an LDS conflict window touch distinct LDS banks in the wrapper's gathers and ds_add_f64 scatter
- * wherever the chunk allows it.  The caller rebuilds the
- * per-instance tables for the new order afterwards.  No-op for element matrices with ar + ar*ac > 128. */
 /* Row blocks as ranges of row POSITIONS under a backend-derived row order (fd_first_touch_order): pinv[node] = position
  * for node < npos, prowptr[p] = CSR row start of the p-th row in that order (npos + 1 entries).  The CSR itself keeps
  * the caller's numbering; a block's rows are then a set of CSR rows, flushed row by row.  The tables are borrowed. */
@@ -228,20 +219,6 @@ int fd_ocrplan_create_ordered(const int32_t *rmap_dev, int rarity, int32_t start
                               const int32_t *pos_block_starts_host, int32_t nblocks, int interleave,
                               const int32_t *pinv_dev, int32_t npos, const int32_t *prowptr_dev,
                               fd_stream_t s, fd_ocrplan_t *out);
-int fd_ocrplan_pack(fd_ocrplan_t p, const int32_t *imap_rows_dev, const uint16_t *lmap_dev, int ar,
-                    const void *kidx_dev, int kbytes, int ac, const int32_t *node_rowptr_dev, int32_t *perm_out_dev, fd_stream_t s);
-/* perm_out_dev (nullable, ninst entries): slot t of the packed order holds the instance that was at perm[t] -- the packer moves
- * instances inside their blocks only, so the per-instance tables (local maps, row offsets) follow with fd_permute_rows and the
- * block node lists stay as they are */
-int fd_permute_rows(void *rows_dev, int rowbytes, const int32_t *perm_dev, int64_t n, fd_stream_t s);
-/* Conflict-free LDS atomic windows: walks the stencil-ordered instance list of every block and fills the rest of a 16-slot window
- * with a dummy instance (an entity none of whose rows the block owns: all its contributions are skipped) where the next instance of
- * the same stencil group would hit an accumulator bank a lane of the window already uses.  rowstart_dev = CSR row starts in the
- * order the blocks are cut in (node_rowptr, or the prowptr of fd_ocrplan_create_ordered).  mode 1: dummies (*ndummy = slots added);
- * mode 2: the window is filled with instances taken from the tail of the block's list instead (the groups owning the fewest rows): a
- * permutation, nothing added.  Call before fd_ocrplan_info / _arrays. */
-int fd_ocrplan_pad_windows(fd_ocrplan_t p, const int32_t *rmap_dev, int rarity, int32_t start, int32_t end,
-                           const int32_t *rowstart_dev, int mode, int64_t *ndummy, fd_stream_t s);
 int fd_ocrplan_info(fd_ocrplan_t p, int64_t *ninst, int32_t *max_inst_per_block);
 int fd_ocrplan_arrays(fd_ocrplan_t p, const int32_t **inst_off_dev, const int32_t **inst_off_host,
                       const int32_t **inst_entity_dev, const int32_t **row_block_starts_dev);
@@ -385,20 +362,16 @@ int fd_first_touch_order(const int32_t *map_dev, int arity, const int32_t *order
 int fd_invert_permutation(const int32_t *plist_dev, int32_t n, int32_t *pinv_dev, fd_stream_t s);
 /* The tables of a row order plist (row of every position): prowptr[p] = accumulator start of position p (npos + 1 entries: the
  * running sum of the row lengths in position order), gstart[p] = CSR start of that row, nstart[row] = prowptr[position of row]
- * -- the lookups the "ocrp" / "ocrsp" wrappers and the plan builders need, each a flat array.  pad = 1 (whole-entity "ocrp" loops,
- * whose flush goes through a per-entry place table anyway): one accumulator entry of padding after every run of rows that are
- * consecutive in the caller's numbering, so that the accumulator offsets of same-kind entities along and across the lines of a
- * box of rows fall into distinct fp64 atomic banks; plen[p] (required then, optional otherwise) = true length of row p */
-int fd_row_order_tables(int32_t npos, const int32_t *plist_dev, const int32_t *rowptr_dev, int pad, int32_t *prowptr_dev, int32_t *nstart_dev,
-                        int32_t *gstart_dev, int32_t *plen_dev, fd_stream_t s);
+ * -- the lookups the "ocrp" / "ocrsp" wrappers and the plan builders need, each a flat array */
+int fd_row_order_tables(int32_t npos, const int32_t *plist_dev, const int32_t *rowptr_dev, int32_t *prowptr_dev, int32_t *nstart_dev,
+                        int32_t *gstart_dev, fd_stream_t s);
 /* gpos[prowptr[p] + k] = gstart[p] + k for the rows p of a row order (prowptr = accumulator starts by position, gstart = CSR
  * starts by position): the place of every accumulator entry in the CSR value array, streamed by the "ocrp" row flush */
-int fd_row_entry_positions(int32_t npos, const int32_t *prowptr_dev, const int32_t *gstart_dev, const int32_t *plen_dev, int32_t *gpos_dev,
-                           fd_stream_t s);     /* plen_dev (NULL = prowptr differences): true row lengths; padding entries get -1 */
+int fd_row_entry_positions(int32_t npos, const int32_t *prowptr_dev, const int32_t *gstart_dev, int32_t *gpos_dev, fd_stream_t s);
 /* The same places run-coded: rows that follow one another in a block of the row order (rblk: nblocks + 1 block starts in row
  * positions) AND in the CSR share one displacement (place - accumulator index).  grun[entry] = run of the entry's row counted
  * from its block's first run (one byte), brun[b] = first run of block b (nblocks + 1), rdelta[run] = displacement (room for
- * npos).  *max_runs_out = most runs in one block: the "ocrpr" flush keeps a block's displacements in LDS and needs <= 256. */
+ * npos).  *max_runs_out = most runs in one block: the "ocrspr" flush keeps a block's displacements in LDS and needs <= 256. */
 int fd_ocr_row_runs(int32_t npos, const int32_t *prowptr_dev, const int32_t *gstart_dev, const int32_t *rblk_dev, int32_t nblocks,
                     uint8_t *grun_dev, int32_t *brun_dev, int32_t *rdelta_dev, int32_t *nruns_out, int32_t *max_runs_out, fd_stream_t s);
 

@@ -217,7 +217,7 @@ def row_runs_ref(prowptr, gstart, rb):
     return grun, brun, rdelta, int(np.diff(brun).max()) if len(rb) > 1 else 0
 
 
-def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False, pad=False, fixed_point=None):
+def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False, fixed_point=None):
     """Execute a matrix-assembly Parloop ``pl`` with the OWNER-COMPUTES-ROWS wrapper on the host (one OS thread per
     lane, tests/hostsim/mt/fd_wrapper.h).  The plan tables come from the numpy restatements in helpers.py; the CSR
     pattern from the oracle.  Returns the OracleCSR holding the assembled values."""
@@ -247,10 +247,7 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False,
         # "ocrp": row blocks are ranges of row positions under the first-touch order of the entity order
         plist, pinv = first_touch_ref(np.asarray(rmap.values_with_halo), order, nrows)
         plen = np.diff(csr.rowptr)[:nrows][plist]
-        # fd_row_order_tables(pad=1): one accumulator entry of padding after every run of rows with consecutive ids
-        ends = np.ones(nrows, dtype=np.int64)
-        ends[:-1] = plist[1:] != plist[:-1] + 1
-        prowptr = np.concatenate([[0], np.cumsum(plen + (ends if pad else 0))]).astype(np.int32)
+        prowptr = np.concatenate([[0], np.cumsum(plen)]).astype(np.int32)
     inst_off, inst_ent, kidx = ocr_plan_ref(np.asarray(rmap.values_with_halo), np.asarray(cmap.values_with_halo), nent, rb,
                                             csr.rowptr, csr.colidx, pinv=pinv)
     plans = {}
@@ -367,7 +364,7 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False,
                                               kbits, diag, words_)))
         elif kind == "ocr_gpos":
             # place of every accumulator entry (rows in position order) in the CSR value array
-            gp = np.full(max(int(prowptr[-1]), 1), -1, dtype=np.int32)                # (padding entries have no place)
+            gp = np.full(max(int(prowptr[-1]), 1), -1, dtype=np.int32)
             for p_, r in enumerate(plist):
                 gp[prowptr[p_]:prowptr[p_] + plen[p_]] = np.arange(csr.rowptr[r], csr.rowptr[r + 1])
             cargs.append(ptr(gp))

@@ -98,7 +98,6 @@ def test_ocr_plan_matches_numpy_restatement(monkeypatch):
     from firedrake_amd.op2types import OcrPlan
     from helpers import ocr_plan_ref
     monkeypatch.setitem(configuration, "ocr_order", "natural")
-    monkeypatch.setitem(configuration, "ocr_pack", 0)
     m = fmesh.UnitCubeMesh(5, degrees=(1,), tile=(4, 2, 2), perturb=0.1)
     V = m.space(1)
     cm = V.cell_node_map
@@ -290,7 +289,6 @@ def test_ordered_ocr_plan_matches_numpy_restatement(monkeypatch):
     from firedrake_amd.op2types import OcrPlan, RowOrder
     from helpers import first_touch_ref, locality_order_ref, ocr_plan_ref
     monkeypatch.setitem(configuration, "ocr_order", "natural")
-    monkeypatch.setitem(configuration, "ocr_pack", 0)
     m = fmesh.UnitCubeMesh(6, degrees=(1,), perturb=0.1, numbering="random")
     V = m.space(1)
     cm = V.cell_node_map

@@ -142,183 +142,12 @@ def test_p2_jacobian_with_compact_tables_matches_oracle(numbering, records, runs
     assert np.abs(v - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
 
 
-@pytest.mark.parametrize("numbering", ["lexicographic", "random"])
-@pytest.mark.parametrize("pad", [0, 1])
-def test_p1_jacobian_padded_accumulators(numbering, pad, monkeypatch):
-    """Derived row orders: LDS accumulators padded by one entry per run of consecutive rows (fd_row_order_tables pad = 1; the
-    place table of the flush has holes) -- same matrix, fresh and accumulated on top of existing values."""
-    monkeypatch.setitem(configuration, "ocr_pad_runs", pad)
-    monkeypatch.setitem(configuration, "locality_min_entities", 64)
-    m = fmesh.UnitCubeMesh(12, degrees=(1,), perturb=0.1, numbering=numbering)
-    prob = forms.PoissonProblem(m, 1, bcs=True)
-    mat, pl = prob.jacobian()
-    mat.zero()
-    pl.compute()
-    geo = [g for key, g in pl._prepared["parts"].items() if key[0] == "ocr"][0]
-    assert geo["row_order"].padded == bool(pad)
-    mpa = pl.arguments[0]
-    args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
-    ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
-    _, _, v = mat.csr()
-    assert np.abs(v - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
-    pl.compute()                                             # no pending zero: accumulates
-    _, _, v2 = mat.csr()
-    assert np.abs(v2 - 2.0 * ref.values).max() <= 1e-12 * np.abs(ref.values).max()
-
-
-def test_deferred_packing_of_a_long_lived_plan(monkeypatch):
-    """The bank-aware packing of the instance lists (fd_ocrplan_pack: ~1 % per launch, ~0.1 s at C2 size) waits until the plan has
-    been launched ``ocr_pack_after`` times; the launches before and after give the same matrix."""
-    from firedrake_amd import graph
-    monkeypatch.setitem(configuration, "ocr_pack_after", 3)
-    monkeypatch.setitem(configuration, "locality_min_entities", 64)
-    monkeypatch.setattr(graph, "captured_any", False)      # (an earlier test of the session may have captured a hipGraph: no repacking then)
-    m = fmesh.UnitCubeMesh(10, degrees=(1,), perturb=0.1, numbering="lexicographic")
-    prob = forms.PoissonProblem(m, 1, bcs=True)
-    mat, pl = prob.jacobian()
-    mpa = pl.arguments[0]
-    args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
-    ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
-    states = []
-    for _ in range(6):
-        mat.zero()
-        pl.compute()
-        op = [g for key, g in pl._prepared["parts"].items() if key[0] == "ocr"][0]["ocr"]
-        states.append(op.packed)
-        _, _, v = mat.csr()
-        assert np.abs(v - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
-    assert states == [False, False, False, True, True, True]
-    # once a hipGraph has been captured anywhere in the process the tables a replay reads must stay where they are: no packing
-    monkeypatch.setattr(graph, "captured_any", True)
-    prob2 = forms.PoissonProblem(m, 1, bcs=True)
-    mat2, pl2 = prob2.jacobian()
-    for _ in range(5):
-        mat2.zero()
-        pl2.compute()
-    op2_ = [g for key, g in pl2._prepared["parts"].items() if key[0] == "ocr"][0]["ocr"]
-    assert not op2_.packed
-    assert np.abs(mat2.csr()[2] - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
-
-
-@pytest.mark.parametrize("numbering", ["lexicographic", "tiled"])
-@pytest.mark.parametrize("mode", [1, 2])
-def test_window_padding_dummies_are_foreign_and_change_nothing(numbering, mode, monkeypatch):
-    """fd_ocrplan_pad_windows.  mode 1: the padded instance lists hold the same real instances in the same order, every dummy is an
-    entity none of whose rows its block owns and dummies only fill the tail of a 16-slot window.  mode 2: the windows are filled with
-    instances from the tail of the block's list -- every block's list is a permutation of the unpadded one.  Either way the matrix
-    is the oracle's."""
-    monkeypatch.setitem(configuration, "locality_min_entities", 64)
-    m = fmesh.UnitCubeMesh(20, degrees=(1,), perturb=0.1, numbering=numbering)
-    vals, lists = {}, {}
-    for pad in (0, mode):
-        monkeypatch.setitem(configuration, "ocr_pad_windows", pad)
-        prob = forms.PoissonProblem(m, 1, bcs=True)
-        mat, pl = prob.jacobian()
-        for _ in range(2):
-            mat.zero()
-            pl.compute()
-        geo = [g for key, g in pl._prepared["parts"].items() if key[0] == "ocr"][0]
-        op = geo["ocr"]
-        vals[pad] = mat.csr()[2]
-        ent = _down(op.inst_ent, np.int32, (op.ninst,))
-        lists[pad] = (op.inst_off_host.copy(), ent, op.ndummy, op.row_blocks.copy(), geo["row_order"])
-        if pad:
-            mpa = pl.arguments[0]
-            args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
-            ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
-            assert np.abs(vals[pad] - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
-            rmap = np.asarray(mpa.maps[0].values_with_halo)
-    assert np.abs(vals[mode] - vals[0]).max() <= 1e-13 * np.abs(vals[0]).max()
-    off0, ent0, nd0, rb, ro = lists[0]
-    off1, ent1, nd1, rb1, _ = lists[mode]
-    assert nd0 == 0 and np.array_equal(rb, rb1)
-    if mode == 2:
-        assert nd1 == 0 and np.array_equal(off0, off1)
-        moved = 0
-        for b in range(len(off0) - 1):
-            real, perm = ent0[off0[b]:off0[b + 1]], ent1[off1[b]:off1[b + 1]]
-            assert np.array_equal(np.sort(real), np.sort(perm))
-            moved += int((real != perm).any())
-        assert moved > 0
-        return
-    assert nd1 > 0 and len(ent1) == len(ent0) + nd1
-    pinv = ro.pinv.download(np.int32, (ro.npos,)) if ro is not None else None
-    ndum = 0
-    for b in range(len(off0) - 1):
-        real, padded = ent0[off0[b]:off0[b + 1]], ent1[off1[b]:off1[b + 1]]
-        extra = len(padded) - len(real)
-        if not extra:
-            assert np.array_equal(real, padded)
-            continue
-        # the dummy is the one entity that occurs `extra` times more often than it should (it is foreign: it occurs 0 times in real)
-        cand, counts = np.unique(padded, return_counts=True)
-        d = cand[np.argmax(counts)]
-        assert (real != d).all() and (padded == d).sum() == extra
-        assert np.array_equal(padded[padded != d], real)
-        rows = rmap[d] if pinv is None else pinv[rmap[d]]
-        assert ((rows < rb[b]) | (rows >= rb[b + 1])).all()
-        ndum += extra
-        # dummies only ever fill the tail of a 16-slot window
-        isd = padded == d
-        for w0 in range(0, len(padded), 16):
-            w = isd[w0:w0 + 16]
-            if w.any():
-                first = int(np.argmax(w))
-                assert w[first:].all() and first >= 12
-    assert ndum == nd1
-
-
-@pytest.mark.parametrize("numbering,dim", [("lexicographic", 3), ("tiled", 3), ("lexicographic", 2)])
-def test_incremental_packer_reproduces_the_legacy_schedule_and_permuted_tables_the_rebuilt_ones(numbering, dim, monkeypatch):
-    """fd_ocrplan_pack: the scheduler that keeps the candidates' costs in registers (ocr_pack2_k) emits the instance order of the
-    one that re-evaluates them per slot (FDHIP_PACK_LEGACY=1), and the per-instance tables permuted after it (fd_permute_rows) are
-    the tables a fresh build over the packed order gives; the assembled matrix is the oracle's."""
-    import os
-    monkeypatch.setitem(configuration, "locality_min_entities", 64)
-    monkeypatch.setitem(configuration, "ocr_pack_after", 0)
-    m = (fmesh.UnitCubeMesh(14, degrees=(1,), perturb=0.1, numbering=numbering) if dim == 3
-         else fmesh.UnitSquareMesh(96, 96, perturb=0.1))
-    got = {}
-    for legacy in ("1", "0"):
-        monkeypatch.setenv("FDHIP_PACK_LEGACY", legacy)
-        prob = forms.PoissonProblem(m, 1, bcs=True)
-        mat, pl = prob.jacobian()
-        mat.zero()
-        pl.compute()
-        geo = [g for key, g in pl._prepared["parts"].items() if key[0] == "ocr"][0]
-        op = geo["ocr"]
-        assert op.packed
-        ent = _down(op.inst_ent, np.int32, (op.ninst,))
-        rm = pl.arguments[0].maps[0]
-        key = next(iter(op.plans))
-        ar = op.plans[key].arity
-        lmap = _down(op.plans[key].lmap, np.uint16, (op.ninst, ar))
-        kidx = _down(op.kidx.ptr, np.uint8 if op.kbytes == 1 else np.uint16, (op.ninst, rm.arity ** 2))
-        imap = _down(op._imaps[key].ptr, np.int32, (op.ninst, ar))
-        got[legacy] = (ent, lmap, kidx, imap, mat.csr()[2])
-        if legacy == "0":
-            # the permuted tables against a fresh build over the packed order
-            sparsity, rmap, cmap, staged = op._pack_args
-            op._build_tables(sparsity, rmap, cmap, staged)
-            assert np.array_equal(lmap, _down(op.plans[key].lmap, np.uint16, (op.ninst, ar)))
-            assert np.array_equal(kidx, _down(op.kidx.ptr, kidx.dtype, kidx.shape))
-            assert np.array_equal(imap, _down(op._imaps[key].ptr, np.int32, (op.ninst, ar)))
-            mpa = pl.arguments[0]
-            args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
-            ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
-            assert np.abs(got["0"][4] - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
-    assert np.array_equal(got["1"][0], got["0"][0])
-    for a, b in zip(got["1"][1:4], got["0"][1:4]):
-        assert np.array_equal(a, b)
-    assert np.abs(got["1"][4] - got["0"][4]).max() <= 1e-13 * np.abs(got["0"][4]).max()
-
-
 @pytest.mark.parametrize("numbering", ["lexicographic", "tiled"])
 def test_fixed_point_accumulators_give_the_oracle_matrix_bit_reproducibly(numbering, monkeypatch):
     """Checked fixed-point accumulation (codegen mode "_fx", the default of whole-entity owner-computes-rows loops): the first
     launch of a plan has no scales and runs fp64 blocks, each of which leaves the scale record of its next launch; from the second
     launch on the element matrices are reduced as 64-bit integers.  The P1 Jacobian is the oracle's to 1e-12 max|A| either way, and
-    -- the sums being exact integers -- the same BITS whatever the order of the instances (packed or not)."""
+    -- the sums being exact integers -- the same BITS whatever the order of the instances inside the blocks."""
     monkeypatch.setitem(configuration, "locality_min_entities", 64)
     m = fmesh.UnitCubeMesh(14, degrees=(1,), perturb=0.1, numbering=numbering)
     prob = forms.PoissonProblem(m, 1, bcs=True)
@@ -328,8 +157,8 @@ def test_fixed_point_accumulators_give_the_oracle_matrix_bit_reproducibly(number
     ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
     vmax = np.abs(ref.values).max()
     got = []
-    for after in (0, 1000):                                # packed at construction / never packed
-        monkeypatch.setitem(configuration, "ocr_pack_after", after)
+    for order in ("stencil", "natural"):                   # two different instance orders inside the blocks
+        monkeypatch.setitem(configuration, "ocr_order", order)
         p2 = forms.PoissonProblem(m, 1, bcs=True)
         mat2, pl2 = p2.jacobian()
         mat2.zero()

@@ -584,9 +584,9 @@ def test_owner_computes_rows_over_a_row_order_on_host(bcs, numbering):
         if degree == 1:
             got2 = run_ocr(pl, rows_per_block=rpb, zero_pending=False, order=order)
             assert np.abs(got2.values - (ref.values + 1.0)).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
-        # padded accumulators (one entry per run of consecutive rows: bank spreading), flushed through the place table with holes
+        # bit-packed records, fresh and accumulating
         for zp in (True, False):
-            got4 = run_ocr(pl, rows_per_block=rpb, zero_pending=zp, order=order, records=True, pad=True)
+            got4 = run_ocr(pl, rows_per_block=rpb, zero_pending=zp, order=order, records=True)
             assert np.abs(got4.values - (ref.values + (0.0 if zp else 1.0))).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
 
 

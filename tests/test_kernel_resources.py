@@ -23,9 +23,9 @@ def _poisson(dim, degree):
     return res, jac
 
 
-@pytest.mark.parametrize("degree,mode,max_vgprs", [(1, "ocr", 64), (1, "ocrp", 64), (2, "ocrs", 96), (2, "ocrsp", 96)])
+@pytest.mark.parametrize("degree,mode,max_vgprs", [(1, "ocr", 80), (1, "ocrp", 80), (2, "ocrs", 96), (2, "ocrsp", 96)])
 def test_jacobian_wrappers_keep_their_element_tensor_in_registers(degree, mode, max_vgprs):
-    """C2 / C5 Jacobians, hinted and derived row orders: no scratch, at most ``max_vgprs`` registers (P1: full occupancy; P2 row-sliced: five wavefronts per SIMD, LDS is what limits it)."""
+    """C2 / C5 Jacobians, hinted and derived row orders: no scratch, at most ``max_vgprs`` registers (P1: three 512-lane groups per CU = six wavefronts per SIMD, which 80 registers allow; P2 row-sliced: five wavefronts per SIMD, LDS is what limits it)."""
     _, jac = _poisson(3, degree)
     cw = jac.compile(mode)
     res = kernel_resources(cw.path, cw.src.symbol)
