@@ -1106,6 +1106,12 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     strides = [int(v) for v in sm_.group(1).split("x")] if sm_ else None
     if sm_:
         mode = mode[:sm_.start()]
+    # "_pw<F>": PERSISTENT workgroups (one per CU slot, each walking a contiguous range of row blocks) with the phases of consecutive
+    # blocks software-pipelined -- see the persistent branch below; F = accumulator entries a lane flushes per block
+    pw_ = re.search(r"_pw(\d+)$", mode)
+    pw_fu = int(pw_.group(1)) if pw_ else 0
+    if pw_:
+        mode = mode[:pw_.start()]
     # "_q<L0>x..k<K>e<S>": one bit-packed record per instance (fd_ocr_pack_records) instead of the uint16 / uint8 index rows and the
     # uint16 slot: local-map entries at L_m bits, column positions at K bits, the accumulator slot at S bits (dropped = all ones)
     rq_ = re.search(r"_q(\d+(?:x\d+)*)k(\d+)e(\d+)$", mode)
@@ -1119,7 +1125,7 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     runflush = mode.startswith("ocrspr")
     ktype, kbytes = ("unsigned short", 2) if mode.endswith("_k16") else ("unsigned char", 1)
     skip = "0xffffu" if kbytes == 2 else "0xffu"
-    threads = configuration["ocrs_block_threads"]
+    threads = int(configuration["ocrs_pw_threads"]) if pw_fu else configuration["ocrs_block_threads"]
     params: List[str] = []
     layout: List[tuple] = []
 
@@ -1323,6 +1329,33 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     virt = extruded or bool(gk._subset)
     if need_e:
         scal.append(("fd_v" if virt else "e", "inst_ent_[II - start]"))
+    # the local kernel once per local row index inside a switch on the wavefront's row index (each instantiation keeps just the
+    # arithmetic its row needs)
+    switch_src = ["    switch (fdw::wave_uniform(role)) {"]
+    NT = AR * RB * AC * CB
+    for r in range(AR):
+        # element tensor t[(i*rbs + p)][(j*cbs + q)] (builder.py:573-625); CSR: scalar row (node, p) starts at
+        # node_rowptr[node]*B + p*rowlen*cbs, column (k-th node of the row, q) sits at k*cbs + q
+        rg = "if ((rmask >> p) & 1) " if dofmask else ""
+        cg = f"if ((cmask >> (j*{CB} + q)) & 1ull) " if dofmask else ""
+        if B == 1:
+            scatter = [f"        for (int p = 0; p < 1; ++p) {rg}for (int j = 0; j < {AC}; ++j) if (kk[j] != {skip}) for (int q = 0; q < 1; ++q) {cg}"
+                       f"atomicAdd(&sm{K}[slot + kk[j]], t{K}[{r * AC} + j]);"]
+        else:
+            scatter = [f"        for (int p = 0; p < {RB}; ++p) {rg}for (int j = 0; j < {AC}; ++j) if (kk[j] != {skip}) for (int q = 0; q < {CB}; ++q) {cg}",
+                       f"          atomicAdd(&sm{K}[slot*{B} + (p*rlen + kk[j])*{CB} + q], t{K}[(({r * RB} + p)*{AC} + j)*{CB} + q]);"]
+        switch_src += [f"    case {r}: {{",
+                f"      double t{K}[{NT}]; for (int q = 0; q < {NT}; ++q) t{K}[q] = 0;",
+                f"      fdk::{lk.name}({', '.join(call_args)});",
+                # (dropped contributions branch around the ds_add_f64; sending them to per-lane dump words instead measured 5 % slower)
+                f"      if (slot != {slot_skip}) {{", *scatter, "      }",
+                "    } break;"]
+    switch_src += ["    default: break;", "    }"]
+    if pw_fu:
+        return _sliced_persistent(gk, full_mode, sym_name=f"wrap_{lk.name}", params=params, layout=layout, P=P, infos=infos, maps=maps, staged_maps=staged_maps,
+                                  stage_nodes=stage_nodes, pack=pack, rec=rec, rec_decode=rec_decode, rows=rows, scal=scal, switch_src=switch_src,
+                                  K=K, runflush=runflush, ordered=ordered, threads=threads, FUQ=pw_fu, kbytes=kbytes, need_e=need_e,
+                                  strides=strides, lds_items=lds_items)
     pf = bool(configuration["prefetch"])
 
     def loads(ii, prefix):
@@ -1370,26 +1403,8 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             src.append("    const int e = subset_indices[fd_v];")
     src += ["    " + s for s in rec_decode]
     src += ["    " + s for s in pack]
-    src.append("    switch (fdw::wave_uniform(role)) {")
+    src += switch_src
     NT = AR * RB * AC * CB
-    for r in range(AR):
-        # element tensor t[(i*rbs + p)][(j*cbs + q)] (builder.py:573-625); CSR: scalar row (node, p) starts at
-        # node_rowptr[node]*B + p*rowlen*cbs, column (k-th node of the row, q) sits at k*cbs + q
-        rg = "if ((rmask >> p) & 1) " if dofmask else ""
-        cg = f"if ((cmask >> (j*{CB} + q)) & 1ull) " if dofmask else ""
-        if B == 1:
-            scatter = [f"        for (int p = 0; p < 1; ++p) {rg}for (int j = 0; j < {AC}; ++j) if (kk[j] != {skip}) for (int q = 0; q < 1; ++q) {cg}"
-                       f"atomicAdd(&sm{K}[slot + kk[j]], t{K}[{r * AC} + j]);"]
-        else:
-            scatter = [f"        for (int p = 0; p < {RB}; ++p) {rg}for (int j = 0; j < {AC}; ++j) if (kk[j] != {skip}) for (int q = 0; q < {CB}; ++q) {cg}",
-                       f"          atomicAdd(&sm{K}[slot*{B} + (p*rlen + kk[j])*{CB} + q], t{K}[(({r * RB} + p)*{AC} + j)*{CB} + q]);"]
-        src += [f"    case {r}: {{",
-                f"      double t{K}[{NT}]; for (int q = 0; q < {NT}; ++q) t{K}[q] = 0;",
-                f"      fdk::{lk.name}({', '.join(call_args)});",
-                # (dropped contributions branch around the ds_add_f64; sending them to per-lane dump words instead measured 5 % slower)
-                f"      if (slot != {slot_skip}) {{", *scatter, "      }",
-                "    } break;"]
-    src += ["    default: break;", "    }"]
     if pf:
         for n, ln, _ in rows:
             src.append(f"    for (int q = 0; q < {ln}; ++q) {n}[q] = nx_{n}[q];")
@@ -1450,6 +1465,157 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             pat = re.compile(r"\bp%d_maxnd\b" % mi)
             src[sig + 1:] = [pat.sub("((long long)%d)" % S, l) for l in src[sig + 1:]]
     return WrapperSource("\n".join(src) + "\n", sym, full_mode, layout, len(maps), staged_maps, lds_items, True, threads, kbytes)
+
+
+def _sliced_persistent(gk, full_mode, *, sym_name, params, layout, P, infos, maps, staged_maps, stage_nodes, pack, rec, rec_decode, rows,
+                       scal, switch_src, K, runflush, ordered, threads, FUQ, kbytes, need_e, strides, lds_items):
+    """The row-sliced wrapper with PERSISTENT workgroups ("..._pw<F>").
+
+    profiles/r5b_phase_times.txt: a row block of the CG2 share lives 16.7 microseconds of which its main loop takes 9.7 -- the rest
+    is the staging round trip (block bounds -> index rows / READ rows -> LDS -> barrier), the flush, and the gap until the CU slot is
+    given to the next workgroup; four resident workgroups hide only part of it (VALU, LDS pipe and HBM each ~60 % busy).  Here
+    one workgroup per CU slot walks a contiguous range of row blocks (XCD-aware: a range per XCD, a sub-range per workgroup) and
+    pipelines their phases in software over DOUBLE-BUFFERED LDS:
+      * while block b runs its main loop, the READ rows, the first trip's index record and the descriptor of block b + 1 (b + 2) are
+        in flight -- requested at the top of the iteration, written to the other LDS buffer at its end;
+      * the accumulators of block b - 1 (the other buffer) are flushed at the top of iteration b by the same lanes that then zero
+        them, their places (run indices requested one iteration earlier, displacements in LDS) need no load;
+      * ONE barrier per block.
+    Block bounds come from a descriptor table (ints per block: e0, e1, (l0, nd) per staged map, r0, nnzb, br0, nrun) read with
+    vector loads and made scalar with readfirstlane: they sit on the vmcnt counter, not on the one LDS results share."""
+    lk = gk.local_kernel
+    if not rec or need_e or ordered and not runflush:
+        raise ValueError("persistent row-sliced wrapper: scalar matrices with instance records, no direct arguments, contiguous or run-coded flush")
+    T = int(threads)
+    dats = [i_ for i_ in infos if i_["kind"] == "dat" and "m" in i_]
+    nsm = len(staged_maps)
+    # descriptor layout
+    fields = ["e0", "e1"] + [f"{n}{mi}" for mi in staged_maps for n in ("l0_", "nd")] + ["r0", "nnzb"] + (["br0", "nrun"] if runflush else [])
+    DW = -(-len(fields) // 4) * 4
+    P("const int *__restrict__ binfo_", ("ocrs_binfo", K, tuple(staged_maps), bool(runflush), DW))
+    P("long long fd_nb_", ("ocrs_nblocks", K))
+    includes, body = _hoist_includes(lk.code)
+    W = rows[0][1]
+    src = ['#include "fd_wrapper.h"', "#include <math.h>", *includes, *[f"#include <{h}>" for h in lk.headers],
+           "namespace fdk {", "#pragma clang force_cuda_host_device begin", body,
+           "#pragma clang force_cuda_host_device end", "}  // namespace fdk", "",
+           f'extern "C" __global__ __launch_bounds__({T}) void {sym_name}(int start, int end, {", ".join(params)})', "{",
+           "  extern __shared__ __align__(16) unsigned char fd_lds[];",
+           "  const int tid = threadIdx.x, nthr = blockDim.x;",
+           # blocks of this workgroup: the hardware deals workgroups round robin over the 8 XCDs; XCD x owns one contiguous range of
+           # the blocks (fdw::xcd_block's ranges), its workgroups contiguous sub-ranges
+           "  const int fd_nb = (int)fd_nb_, fd_NX = (int)gridDim.x < 8 ? (int)gridDim.x : 8;",
+           "  const int fd_x = (int)blockIdx.x % fd_NX, fd_j = (int)blockIdx.x / fd_NX, fd_nx = ((int)gridDim.x + fd_NX - 1 - fd_x) / fd_NX;",
+           "  const int fd_q = fd_nb / fd_NX, fd_r = fd_nb % fd_NX;",
+           "  const int fd_xb0 = fd_x*fd_q + (fd_x < fd_r ? fd_x : fd_r), fd_xn = fd_q + (fd_x < fd_r ? 1 : 0);",
+           "  const int wb0 = fd_xb0 + (int)(((long long)fd_xn*fd_j)/fd_nx), wb1 = fd_xb0 + (int)(((long long)fd_xn*(fd_j + 1))/fd_nx);",
+           "  if (wb0 >= wb1) return;",
+           "  size_t fd_off = 0;"]
+    # LDS: two copies of everything
+    for i_ in dats:
+        k, ct, c, mi = i_["k"], i_["ct"], i_["c"], i_["m"]
+        for h in (0, 1):
+            src.append(f"  {ct} *s{k}_{h} = ({ct} *)(fd_lds + fd_off); fd_off += (((size_t)p{mi}_maxnd*{c}*sizeof({ct})) + 15) & ~(size_t)15;")
+    if runflush:
+        for h in (0, 1):
+            src.append(f"  int *srun_{h} = (int *)(fd_lds + fd_off); fd_off += 1024;")
+    for h in (0, 1):
+        src.append(f"  double *sm_{h} = (double *)(fd_lds + fd_off); fd_off += (((size_t)oc{K}_maxnnz*8) + 15) & ~(size_t)15;")
+    # descriptors
+    def desc_load(dst, bexpr):
+        return [f"  int4 {dst}[{DW // 4}]; {{ const int4 *fd_p = reinterpret_cast<const int4 *>(binfo_ + (size_t)(({bexpr}) + fdw::lane_zero())*{DW}); "
+                + " ".join(f"{dst}[{q}] = fd_p[{q}];" for q in range(DW // 4)) + " }"]
+
+    def desc_scalar(prefix, src_):
+        out = []
+        for q, name in enumerate(fields):
+            comp = "xyzw"[q & 3]
+            out.append(f"  {prefix}{name} = fdw::wave_uniform({src_}[{q >> 2}].{comp});")
+        return out
+    decl_c = "  int " + ", ".join(f"{name} = 0, n_{name} = 0" for name in fields) + ";"
+    src.append(decl_c)
+    src += desc_load("fd_d0", "wb0") + desc_load("fd_d1", "(wb0 + 1 < wb1 ? wb0 + 1 : wb0)")
+    src += desc_scalar("", "fd_d0") + desc_scalar("n_", "fd_d1")
+    # prologue: zero both accumulators, stage the first block's READ rows, its first index record
+    src.append(f"  for (int q = tid; q < 2*(int)(((oc{K}_maxnnz*8 + 15) & ~15ll) >> 3); q += nthr) sm_0[q] = 0;")
+    for mi in staged_maps:
+        src.append(f"  if (tid < nd{mi}) {{")
+        src.append(f"    const int i = tid; const int g = p{mi}_list[l0_{mi} + i];")
+        for i_ in [d for d in dats if d["m"] == mi]:
+            k, ct, c = i_["k"], i_["ct"], i_["c"]
+            src.append(f"    {ct} v[{c}]; if (pl{k}) {{ for (int j = 0; j < {c}; ++j) v[j] = pl{k}[(size_t)(l0_{mi} + i)*{c} + j]; }} "
+                       f"else {{ for (int j = 0; j < {c}; ++j) v[j] = arg{k}[(size_t)g*{c} + j]; }}")
+            src.append(f"    for (int j = 0; j < {c}; ++j) s{k}_0[{'j*(int)p%d_maxnd + i' % mi if c > 1 else 'i*%d + j' % c}] = v[j];")
+        src.append("  }")
+    src += [f"  unsigned rc[{W}], nx_rc[{W}], nb_rc[{W}];", "  int role = 0, nx_role = 0, nb_role = 0;",
+            "  if (e0 + tid < e1) {", "    role = (int)chunk_role_[((e0 + tid) - start) >> 6];",
+            f"    fdw::load_rec<{W}>(oc{K}_rec + (size_t)((e0 + tid) - start)*{W}, rc);", "  }",
+            f"  int g[{FUQ}];", "  int p_r0 = 0, p_nnzb = 0, cur = 0;",
+            "  __syncthreads();",
+            "  for (int b = wb0; b < wb1; ++b) {",
+            "    const bool more = b + 1 < wb1;",
+            f"    double *sm{K} = cur ? sm_1 : sm_0, *smp = cur ? sm_0 : sm_1;"]
+    if runflush:
+        src.append("    int *srun = cur ? srun_1 : srun_0, *srunp = cur ? srun_0 : srun_1;")
+    for i_ in dats:
+        k, ct = i_["k"], i_["ct"]
+        src.append(f"    {ct} *s{k} = cur ? s{k}_1 : s{k}_0, *s{k}n = cur ? s{k}_0 : s{k}_1;")
+    # (1) descriptor of block b + 2
+    src += ["  " + l for l in desc_load("fd_d2", "(b + 2 < wb1 ? b + 2 : b)")]
+    # (2) the next block's first index record and READ rows
+    src += ["    if (more && n_e0 + tid < n_e1) {", "      nb_role = (int)chunk_role_[((n_e0 + tid) - start) >> 6];",
+            f"      fdw::load_rec<{W}>(oc{K}_rec + (size_t)((n_e0 + tid) - start)*{W}, nb_rc);", "    }"]
+    for mi in staged_maps:
+        src.append(f"    int gn{mi} = 0; if (more && tid < n_nd{mi}) gn{mi} = p{mi}_list[n_l0_{mi} + tid];")
+        for i_ in [d for d in dats if d["m"] == mi]:
+            k, ct, c = i_["k"], i_["ct"], i_["c"]
+            src.append(f"    {ct} vn{k}[{c}]; if (more && tid < n_nd{mi} && pl{k}) {{ for (int j = 0; j < {c}; ++j) vn{k}[j] = pl{k}[(size_t)(n_l0_{mi} + tid)*{c} + j]; }}")
+    # (3) flush of the previous block out of the other accumulator, zeroed behind the read by the same lane
+    place = "p_r0 + q + srunp[g[f]]" if runflush else "p_r0 + q"
+    src += ["    if (b > wb0) {",
+            f"      if (oc{K}_flags & 1) {{ for (int f = 0; f < {FUQ}; ++f) {{ const int q = tid + f*nthr; if (q < p_nnzb) {{ const double v = smp[q]; smp[q] = 0.0; arg{K}[(size_t)({place})] = v; }} }} }}",
+            f"      else {{ for (int f = 0; f < {FUQ}; ++f) {{ const int q = tid + f*nthr; if (q < p_nnzb) {{ const double v = smp[q]; smp[q] = 0.0; arg{K}[(size_t)({place})] += v; }} }} }}",
+            "    }"]
+    # (4) this block's run indices (for its flush one iteration on) and displacements
+    if runflush:
+        src += [f"    for (int f = 0; f < {FUQ}; ++f) {{ const int q = tid + f*nthr; g[f] = (int)oc{K}_grun[(size_t)r0 + (q < nnzb ? q : nnzb - 1)]; }}",
+                f"    int fd_rd = 0; if (tid < nrun) fd_rd = oc{K}_rdelta[br0 + tid];"]
+    # (5) the block's trips
+    src += ["    for (int it = e0 + tid; it < e1; it += nthr) {",
+            "      const int itn = (it + nthr < e1) ? it + nthr : it;",
+            "      nx_role = (int)chunk_role_[(itn - start) >> 6];",
+            f"      fdw::load_rec<{W}>(oc{K}_rec + (size_t)(itn - start)*{W}, nx_rc);"]
+    src += ["  " + l for l in (["    " + s_ for s_ in rec_decode] + ["    " + s_ for s_ in pack] + switch_src)]
+    src += [f"      for (int q = 0; q < {W}; ++q) rc[q] = nx_rc[q];", "      role = nx_role;", "    }"]
+    # (6) the next block's READ rows into the other buffer, this block's displacements
+    for mi in staged_maps:
+        src.append(f"    if (more && tid < n_nd{mi}) {{")
+        for i_ in [d for d in dats if d["m"] == mi]:
+            k, ct, c = i_["k"], i_["ct"], i_["c"]
+            src.append(f"      if (!pl{k}) {{ for (int j = 0; j < {c}; ++j) vn{k}[j] = arg{k}[(size_t)gn{mi}*{c} + j]; }}")
+            src.append(f"      for (int j = 0; j < {c}; ++j) s{k}n[{'j*(int)p%d_maxnd + tid' % mi if c > 1 else 'tid*%d + j' % c}] = vn{k}[j];")
+        src.append("    }")
+    if runflush:
+        src.append("    if (tid < nrun) srun[tid] = fd_rd;")
+    src += ["    p_r0 = r0; p_nnzb = nnzb;",
+            "    __syncthreads();",
+            f"    for (int q = 0; q < {W}; ++q) rc[q] = nb_rc[q];", "    role = nb_role;"]
+    src += ["  " + " ".join(f"{name} = n_{name};" for name in fields)]
+    src += ["  " + l for l in desc_scalar("n_", "fd_d2")]
+    src += ["    cur ^= 1;", "  }",
+            # epilogue: the last block's accumulators (now the "other" buffer)
+            f"  {{ double *smp = cur ? sm_0 : sm_1;" + (" int *srunp = cur ? srun_0 : srun_1;" if runflush else ""),
+            f"    if (oc{K}_flags & 1) {{ for (int f = 0; f < {FUQ}; ++f) {{ const int q = tid + f*nthr; if (q < p_nnzb) arg{K}[(size_t)({place})] = smp[q]; }} }}",
+            f"    else {{ for (int f = 0; f < {FUQ}; ++f) {{ const int q = tid + f*nthr; if (q < p_nnzb) arg{K}[(size_t)({place})] += smp[q]; }} }}",
+            "  }", "}"]
+    if strides is not None:
+        if len(strides) != len(staged_maps):
+            raise ValueError("one compile-time stride per staged map")
+        sig = next(i for i, l in enumerate(src) if l.startswith('extern "C" __global__'))
+        for mi, S in zip(staged_maps, strides):
+            pat = re.compile(r"\bp%d_maxnd\b" % mi)
+            src[sig + 1:] = [pat.sub("((long long)%d)" % S, l) for l in src[sig + 1:]]
+    return WrapperSource("\n".join(src) + "\n", sym_name, full_mode, layout, len(maps), staged_maps, lds_items, True, T, kbytes)
 
 
 def lds_stride(max_nd: int, ocr: bool = False) -> int:

@@ -47,6 +47,7 @@ int fd_set_device(int device) { FD_HIP(hipSetDevice(device)); return 0; }
 
 int fd_device_info(int device, char *name, size_t name_len, int *cus, size_t *hbm, int *lds) {
     hipDeviceProp_t p;
+    if (device < 0) FD_HIP(hipGetDevice(&device));            // (the calling thread's current device)
     FD_HIP(hipGetDeviceProperties(&p, device));
     if (name && name_len) { std::strncpy(name, p.gcnArchName, name_len - 1); name[name_len - 1] = 0; }
     if (cus) *cus = p.multiProcessorCount;

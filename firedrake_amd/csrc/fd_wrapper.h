@@ -39,6 +39,10 @@ __device__ __forceinline__ int xcd_block(int bid, int nb) {
     return x * q + (x < r ? x : r) + k;
 }
 
+// A zero the compiler cannot see through: added to a wave-uniform index it keeps the load on the vector memory path (vmcnt) where
+// the compiler would otherwise pick a scalar load, whose counter (lgkmcnt) is shared with every LDS result the wavefront waits for.
+__device__ __forceinline__ int lane_zero() { int z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); return z; }
+
 // A value the caller knows to be equal in all lanes of the wavefront (the row index of a sliced instance chunk): moving it
 // to a scalar register turns the switch on it into scalar branches -- no divergence bookkeeping, one instantiation executed.
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -1117,7 +1117,20 @@ class Parloop:
             if rec[1] > 8 or rec[2] > 16 or rec[3] * 4 >= sum(staged[mi].arity for mi in src.staged_maps) * 2 + cmap.arity + 2:
                 rec = None
         variant = mode_variant(base, op.kbytes, nds, rec)
-        geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz, "runs": runs, "rec": rec,
+        # persistent workgroups (codegen._sliced_persistent): scalar matrices with records, READ rows one node per lane, complete
+        # rows flushed contiguously or through run-coded places, no direct arguments; two copies of every LDS array per workgroup
+        pw = None
+        T = int(configuration["ocrs_pw_threads"])
+        per_cu = max(1, int(configuration["ocrs_pw_per_cu"]))
+        direct_args = any(isinstance(a, DatParloopArg) and a.map_ is None for a in self.arguments) or bool(self.global_kernel._pass_layer_arg)
+        if configuration["ocrs_persistent"] and rec is not None and not direct_args and all(n_ <= T for n_ in nds) \
+                and ((base == "ocrspr" and runs is not None) or base == "ocrs"):
+            lds_pw = 2 * lds
+            if lds_pw <= (160 * 1024) // per_cu:
+                fuq = max(1, -(-int(op.max_nnz) // T))
+                variant += f"_pw{fuq}"
+                pw = {"threads": T, "lds": lds_pw, "per_cu": per_cu}
+        geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz, "runs": runs, "rec": rec, "pw": pw,
                "cw": prep["cw"] if variant == src.mode else self.global_kernel.compile(variant), "row_order": row_order}
         prep["parts"][gkey] = geo
         if configuration["debug"]:
@@ -1228,10 +1241,46 @@ class Parloop:
                 if geo.get("phase_times") is None:
                     geo["phase_times"] = DeviceBuffer(max(op.nblocks, 1) * 40)
                 out.append(geo["phase_times"].ptr)
+            elif kind == "ocrs_binfo":
+                out.append(self._ocrs_block_info(geo, desc).ptr)
+            elif kind == "ocrs_nblocks":
+                out.append(op.nblocks)
             else:
                 raise AssertionError(kind)
-        cw.launch(0, op.ninst, out, block_threads=src.block_threads, ents_per_block=op.max_inst, nblocks=op.nblocks,
-                  lds_bytes=geo["lds"])
+        pw = geo.get("pw")
+        if pw:
+            # persistent workgroups: per_cu per compute unit (a multiple of 8: one contiguous block range per XCD), never more than blocks
+            from .device import compute_units
+            grid = max(8, (pw["per_cu"] * compute_units()) // 8 * 8)
+            cw.launch(0, op.ninst, out, block_threads=pw["threads"], ents_per_block=op.max_inst, nblocks=min(grid, max(op.nblocks, 1)),
+                      lds_bytes=pw["lds"])
+        else:
+            cw.launch(0, op.ninst, out, block_threads=src.block_threads, ents_per_block=op.max_inst, nblocks=op.nblocks,
+                      lds_bytes=geo["lds"])
+
+    def _ocrs_block_info(self, geo, desc):
+        """Descriptor table of the persistent row-sliced wrapper: per row block e0, e1, (l0, nd) of every staged map, r0, nnzb
+        [, br0, nrun], padded to a multiple of four ints -- what the one-workgroup-per-block wrapper reads from five arrays."""
+        hit = geo.get("binfo")
+        if hit is None:
+            _, k, smaps, runflush, dw = desc
+            op, ro = geo["ocr"], geo["row_order"]
+            nb = op.nblocks
+            cols = [op.inst_off_host[:-1], op.inst_off_host[1:]]
+            for mi in smaps:
+                blk = DeviceBuffer.wrap(op.plans[mi].blkoff, (nb + 1) * 4, owned=False).download(np.int32, (nb + 1,))
+                cols += [blk[:-1], np.diff(blk)]
+            acc = ro.prowptr_host if ro is not None else self.arguments[k].data.sparsity._node_rowptr_host()
+            starts = np.asarray(acc)[op.row_blocks]
+            cols += [starts[:-1], np.diff(starts)]
+            if runflush:
+                brun = geo["runs"][1].download(np.int32, (nb + 1,))
+                cols += [brun[:-1], np.diff(brun)]
+            tab = np.zeros((max(nb, 1), dw), dtype=np.int32)
+            for q, c_ in enumerate(cols):
+                tab[:nb, q] = c_
+            hit = geo["binfo"] = DeviceBuffer.from_numpy(tab)
+        return hit
 
     def fixed_point_state(self):
         """Diagnostics of the checked fixed-point accumulation of this loop's owner-computes-rows parts (blocks the stream): per

@@ -38,7 +38,7 @@ const char *fd_last_error(void);
 int fd_device_count(int *n);
 int fd_set_device(int device);
 int fd_device_info(int device, char *name, size_t name_len, int *compute_units,
-                   size_t *hbm_bytes, int *lds_bytes_per_block);
+                   size_t *hbm_bytes, int *lds_bytes_per_block);      /* device < 0: the calling thread's current device */
 
 /* Device buffers standing in for the numpy/PETSc buffers whose raw pointers the
  * reference hands to the wrapper: Dat  pyop2/types/dat.py:94-96, Map  map.py:57-59,
