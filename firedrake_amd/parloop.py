@@ -1259,26 +1259,24 @@ class Parloop:
                       lds_bytes=geo["lds"])
 
     def _ocrs_block_info(self, geo, desc):
-        """Descriptor table of the persistent row-sliced wrapper: per row block e0, e1, (l0, nd) of every staged map, r0, nnzb
-        [, br0, nrun], padded to a multiple of four ints -- what the one-workgroup-per-block wrapper reads from five arrays."""
+        """Descriptor table of the persistent row-sliced wrapper: one row of STARTS per row block (+ one closing row) -- first
+        instance, first plan-list entry of every staged map, first accumulator entry [, first run] -- padded to a multiple of four
+        ints; a block's ends are the next row's starts.  What the one-workgroup-per-block wrapper reads from five arrays."""
         hit = geo.get("binfo")
         if hit is None:
             _, k, smaps, runflush, dw = desc
             op, ro = geo["ocr"], geo["row_order"]
             nb = op.nblocks
-            cols = [op.inst_off_host[:-1], op.inst_off_host[1:]]
+            cols = [op.inst_off_host]
             for mi in smaps:
-                blk = DeviceBuffer.wrap(op.plans[mi].blkoff, (nb + 1) * 4, owned=False).download(np.int32, (nb + 1,))
-                cols += [blk[:-1], np.diff(blk)]
+                cols.append(DeviceBuffer.wrap(op.plans[mi].blkoff, (nb + 1) * 4, owned=False).download(np.int32, (nb + 1,)))
             acc = ro.prowptr_host if ro is not None else self.arguments[k].data.sparsity._node_rowptr_host()
-            starts = np.asarray(acc)[op.row_blocks]
-            cols += [starts[:-1], np.diff(starts)]
+            cols.append(np.asarray(acc)[op.row_blocks])
             if runflush:
-                brun = geo["runs"][1].download(np.int32, (nb + 1,))
-                cols += [brun[:-1], np.diff(brun)]
-            tab = np.zeros((max(nb, 1), dw), dtype=np.int32)
+                cols.append(geo["runs"][1].download(np.int32, (nb + 1,)))
+            tab = np.zeros((nb + 1, dw), dtype=np.int32)
             for q, c_ in enumerate(cols):
-                tab[:nb, q] = c_
+                tab[:, q] = c_
             hit = geo["binfo"] = DeviceBuffer.from_numpy(tab)
         return hit
 

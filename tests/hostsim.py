@@ -504,19 +504,13 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None, run_flush=Fals
         elif kind == "ocr_inst_ent":
             cargs.append(ptr(inst_ent))
         elif kind == "ocrs_binfo":
-            # numpy restatement of Parloop._ocrs_block_info
+            # numpy restatement of Parloop._ocrs_block_info: one row of starts per block + the closing row
             _, _, smaps, rf, dw = desc
             nb = len(rb) - 1
-            cols = [inst_off[:-1], inst_off[1:]]
-            for mi in smaps:
-                cols += [plans[mi][0][:-1], np.diff(plans[mi][0])]
-            starts = np.asarray(acc)[rb]
-            cols += [starts[:-1], np.diff(starts)]
-            if rf:
-                cols += [run_tabs[1][:-1], np.diff(run_tabs[1])]
-            tab = np.zeros((max(nb, 1), dw), dtype=np.int32)
+            cols = [inst_off] + [plans[mi][0] for mi in smaps] + [np.asarray(acc)[rb]] + ([run_tabs[1]] if rf else [])
+            tab = np.zeros((nb + 1, dw), dtype=np.int32)
             for q, c_ in enumerate(cols):
-                tab[:nb, q] = c_
+                tab[:, q] = c_
             cargs.append(ptr(tab))
         elif kind == "ocrs_nblocks":
             cargs.append(ctypes.c_longlong(len(rb) - 1))
@@ -540,8 +534,10 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None, run_flush=Fals
             cargs.append(ptr(np.ascontiguousarray(acc, dtype=np.int32)))
         elif kind == "ocr_gstart":
             cargs.append(ptr(np.ascontiguousarray(ncsr.rowptr[plist], dtype=np.int32)))
-        elif kind in ("ocr_grun", "ocr_brun", "ocr_rdelta"):
-            cargs.append(ptr(run_tabs[{"ocr_grun": 0, "ocr_brun": 1, "ocr_rdelta": 2}[kind]]))
+        elif kind == "ocr_grun":
+            cargs.append(ptr(np.concatenate([run_tabs[0], np.zeros(4, dtype=run_tabs[0].dtype)])))     # (+ a word, like RowOrder.runs)
+        elif kind in ("ocr_brun", "ocr_rdelta"):
+            cargs.append(ptr(run_tabs[{"ocr_brun": 1, "ocr_rdelta": 2}[kind]]))
         elif kind == "plan_copy":
             cargs.append(_plan_copy_arg(pl, desc, plans, ptr))
         elif kind == "ocr_gpos":
