@@ -1490,6 +1490,10 @@ def _sliced_persistent(gk, full_mode, *, sym_name, params, layout, P, infos, map
     if not rec or need_e or (ordered and not runflush):
         raise ValueError("persistent row-sliced wrapper: scalar matrices with instance records, no direct arguments, contiguous or run-coded flush")
     T = int(threads)
+    # one accumulator (and one table of run displacements) per workgroup instead of two: the flush of a block follows its trips behind
+    # a second barrier, like in the one-workgroup-per-block wrapper -- half the LDS, twice the resident workgroups; what stays
+    # pipelined is the staging (READ rows, index records, block bounds)
+    single = int(configuration["ocrs_pw_accumulators"]) == 1
     FQ = -(-int(FUQ) // 4)               # 32-bit words of run indices per lane: four consecutive accumulator entries each
     dats = [i_ for i_ in infos if i_["kind"] == "dat" and "m" in i_]
     fields = ["e0"] + [f"l0_{mi}" for mi in staged_maps] + ["r0"] + (["br0"] if runflush else [])
@@ -1520,10 +1524,12 @@ def _sliced_persistent(gk, full_mode, *, sym_name, params, layout, P, infos, map
         for h in (0, 1):
             src.append(f"  {ct} *s{k}_{h} = ({ct} *)(fd_lds + fd_off); fd_off += (((size_t)p{mi}_maxnd*{c}*sizeof({ct})) + 15) & ~(size_t)15;")
     if runflush:
-        for h in (0, 1):
+        for h in ((0,) if single else (0, 1)):
             src.append(f"  int *srun_{h} = (int *)(fd_lds + fd_off); fd_off += 1024;")
-    for h in (0, 1):
+    for h in ((0,) if single else (0, 1)):
         src.append(f"  double *sm_{h} = (double *)(fd_lds + fd_off); fd_off += (((size_t)oc{K}_maxnnz*8) + 15) & ~(size_t)15;")
+    if single:
+        src.append("  double *sm_1 = sm_0;" + (" int *srun_1 = srun_0;" if runflush else ""))
 
     def desc_load(dst, bexpr):
         return (f"int4 {dst}[{DW // 4}]; {{ const int4 *fd_p = reinterpret_cast<const int4 *>(binfo_ + (size_t)(({bexpr}) + fdw::lane_zero())*{DW}); "
@@ -1541,7 +1547,7 @@ def _sliced_persistent(gk, full_mode, *, sym_name, params, layout, P, infos, map
     src += ["  { " + desc_load("fd_d0", "wb0") + " " + desc_load("fd_d1", "wb0 + 1") + " " + desc_load("fd_d2", "(wb0 + 2 < fd_nb ? wb0 + 2 : fd_nb)"),
             "    " + desc_scalar("A_", "fd_d0") + " " + desc_scalar("B_", "fd_d1") + " " + desc_scalar("C_", "fd_d2") + " }"]
     # prologue: zero both accumulators, stage the first block's READ rows, its first index record
-    src.append(f"  for (int q = tid; q < 2*(int)(((oc{K}_maxnnz*8 + 15) & ~15ll) >> 3); q += nthr) sm_0[q] = 0;")
+    src.append(f"  for (int q = tid; q < {1 if single else 2}*(int)(((oc{K}_maxnnz*8 + 15) & ~15ll) >> 3); q += nthr) sm_0[q] = 0;")
     for mi in staged_maps:
         src.append(f"  if (tid < B_l0_{mi} - A_l0_{mi}) {{")
         src.append(f"    const int i = tid; const int g = p{mi}_list[A_l0_{mi} + i];")
@@ -1582,6 +1588,8 @@ def _sliced_persistent(gk, full_mode, *, sym_name, params, layout, P, infos, map
         # padded by a word at its end)
         decl.append("    int fd_rd = 0;")
         req += [f"    if (tid < nrun) fd_rd = oc{K}_rdelta[br0 + tid];"]
+        if single:
+            req.append(f"    for (int f = 0; f < {FQ}; ++f) {{ const int q = 4*(tid + f*nthr); g[f] = fdw::load_u32_unaligned(oc{K}_grun + (size_t)r0 + (q < nnzb ? q : 0)); }}")
     src += decl
     # ... by the lanes without an instance in this block here (with their first record of the next block, into the prefetch
     # registers they never use otherwise), by the others inside their first trip, behind its index-row request: the trips' first
@@ -1618,24 +1626,27 @@ def _sliced_persistent(gk, full_mode, *, sym_name, params, layout, P, infos, map
         src.append("    }")
     if runflush:
         src.append("    if (tid < nrun) srun[tid] = fd_rd;")
-    # (5) flush of the previous block out of the other accumulator, zeroed behind the read by the same lane
+    # (5) flush -- of the previous block out of the other accumulator (two accumulators), or of this block behind a barrier (one) --
+    # zeroed behind the read by the same lane
     place = "p_r0 + q + srunp[(g[f] >> (8*j)) & 0xffu]" if runflush else "p_r0 + q"
-    src += ["    if (b > wb0) {",
+    if single:
+        src += ["    p_r0 = r0; p_nnzb = nnzb;", "    __syncthreads();"]
+    src += ["    if (b > wb0) {" if not single else "    {",
             f"      if (oc{K}_flags & 1) {{ for (int f = 0; f < {FQ}; ++f) for (int j = 0; j < 4; ++j) {{ const int q = 4*(tid + f*nthr) + j; if (q < p_nnzb) {{ const double v = smp[q]; smp[q] = 0.0; arg{K}[(size_t)({place})] = v; }} }} }}",
             f"      else {{ for (int f = 0; f < {FQ}; ++f) for (int j = 0; j < 4; ++j) {{ const int q = 4*(tid + f*nthr) + j; if (q < p_nnzb) {{ const double v = smp[q]; smp[q] = 0.0; arg{K}[(size_t)({place})] += v; }} }} }}",
             "    }"]
-    # (6) requests nobody waits for before the next iteration's explicit wait: this block's run indices (its flush is an iteration
-    # away) and -- a scalar load: it has the barrier and the next requests to land before an LDS result is waited for -- the starts
-    # three blocks ahead
-    if runflush:
+    # (6) requests nobody waits for before the next iteration's explicit wait: this block's run indices (two accumulators: its flush
+    # is an iteration away) and -- a scalar load: it has the barrier and the next requests to land before an LDS result is waited
+    # for -- the starts three blocks ahead
+    if runflush and not single:
         src.append(f"    for (int f = 0; f < {FQ}; ++f) {{ const int q = 4*(tid + f*nthr); g[f] = fdw::load_u32_unaligned(oc{K}_grun + (size_t)r0 + (q < nnzb ? q : 0)); }}")
     src.append("    { const int fd_b3 = (b + 3 < fd_nb ? b + 3 : fd_nb); " + " ".join(f"D_{n} = binfo_[(size_t)fd_b3*{DW} + {q}];" for q, n in enumerate(fields)) + " }")
     src += ["    p_r0 = r0; p_nnzb = nnzb;",
             "    __syncthreads();"] + (["    if (tid == 0) fd_times[5*(size_t)b + 3] = wall_clock64();"] if ptimes else []) + [
             "    " + " ".join(f"A_{n} = B_{n}; B_{n} = C_{n}; C_{n} = D_{n};" for n in fields),
             "    cur ^= 1;", "  }",
-            # epilogue: the last block's accumulators (now the "other" buffer)
-            "  { double *smp = cur ? sm_0 : sm_1;" + (" int *srunp = cur ? srun_0 : srun_1;" if runflush else ""),
+            # epilogue (two accumulators): the last block's accumulators (now the "other" buffer)
+            "  if (%d) { double *smp = cur ? sm_0 : sm_1;" % (0 if single else 1) + (" int *srunp = cur ? srun_0 : srun_1;" if runflush else ""),
             f"    if (oc{K}_flags & 1) {{ for (int f = 0; f < {FQ}; ++f) for (int j = 0; j < 4; ++j) {{ const int q = 4*(tid + f*nthr) + j; if (q < p_nnzb) arg{K}[(size_t)({place})] = smp[q]; }} }}",
             f"    else {{ for (int f = 0; f < {FQ}; ++f) for (int j = 0; j < 4; ++j) {{ const int q = 4*(tid + f*nthr) + j; if (q < p_nnzb) arg{K}[(size_t)({place})] += smp[q]; }} }}",
             "  }", "}"]

@@ -66,6 +66,8 @@ configuration = {
     "ocrs_persistent": _env("FDHIP_OCRS_PERSISTENT", 1, int),
     "ocrs_pw_threads": _env("FDHIP_OCRS_PW_THREADS", 512, int),
     "ocrs_pw_per_cu": _env("FDHIP_OCRS_PW_PER_CU", 2, int),
+    "ocrs_pw_accumulators": _env("FDHIP_OCRS_PW_ACC", 2, int),      # 2: flush of block b - 1 under the trips of block b; 1: one accumulator, two barriers
+    "ocrs_pw_nnz": _env("FDHIP_OCRS_PW_NNZ", 0, int),               # accumulator entries per block of the persistent wrapper (0 = ocrs_nnz_per_block)
     "ocrs_interleave": _env("FDHIP_OCRS_INTERLEAVE", 7, int),    # > 1: stride permutation of the instances of every (block, row index) group
     "ocr_block_threads": _env("FDHIP_OCR_BLOCK_THREADS", 0, int),  # 0 = auto: 512 for small element matrices, else block_threads
     # order of the instances inside an owner-computes-rows block: "stencil" (sorted by ownership pattern and owned-row

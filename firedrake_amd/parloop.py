@@ -1074,7 +1074,9 @@ class Parloop:
                 row_order = RowOrder(rmap, order, end - start, nrows, rp, rowptr_dev=sp._node_rowptr.ptr)
                 prp = row_order.prowptr_host
         B = int(sp.dsets[0].cdim) * int(sp.dsets[1].cdim)
-        cap = max(int(configuration["ocrs_nnz_per_block"]) // B, int(np.diff(prp).max()) if nrows else 1)
+        cap_ = int(configuration["ocrs_pw_nnz"]) if (configuration["ocrs_persistent"] and int(configuration["ocrs_pw_nnz"]) > 0) \
+            else int(configuration["ocrs_nnz_per_block"])
+        cap = max(cap_ // B, int(np.diff(prp).max()) if nrows else 1)
         staged = {mi: maps[mi] for mi in src.staged_maps}
         limit = configuration["lds_limit"]
         for attempt in range(8):
@@ -1125,7 +1127,11 @@ class Parloop:
         direct_args = any(isinstance(a, DatParloopArg) and a.map_ is None for a in self.arguments) or bool(self.global_kernel._pass_layer_arg)
         if configuration["ocrs_persistent"] and rec is not None and not direct_args and all(n_ <= T for n_ in nds) \
                 and ((base == "ocrspr" and runs is not None) or base == "ocrs"):
-            lds_pw = 2 * lds
+            if int(configuration["ocrs_pw_accumulators"]) == 1:
+                acc_ = ((op.max_nnz * B * 8) + 15) // 16 * 16 + (1024 if runs is not None else 0)
+                lds_pw = 2 * (lds - acc_) + acc_
+            else:
+                lds_pw = 2 * lds
             if lds_pw <= (160 * 1024) // per_cu:
                 fuq = max(1, -(-int(op.max_nnz) // T))
                 variant += f"_pw{fuq}"
