@@ -1106,12 +1106,6 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     strides = [int(v) for v in sm_.group(1).split("x")] if sm_ else None
     if sm_:
         mode = mode[:sm_.start()]
-    # "_pw<F>": PERSISTENT workgroups (one per CU slot, each walking a contiguous range of row blocks) with the phases of consecutive
-    # blocks software-pipelined -- see the persistent branch below; F = accumulator entries a lane flushes per block
-    pw_ = re.search(r"_pw(\d+)$", mode)
-    pw_fu = int(pw_.group(1)) if pw_ else 0
-    if pw_:
-        mode = mode[:pw_.start()]
     # "_q<L0>x..k<K>e<S>": one bit-packed record per instance (fd_ocr_pack_records) instead of the uint16 / uint8 index rows and the
     # uint16 slot: local-map entries at L_m bits, column positions at K bits, the accumulator slot at S bits (dropped = all ones)
     rq_ = re.search(r"_q(\d+(?:x\d+)*)k(\d+)e(\d+)$", mode)
@@ -1125,7 +1119,7 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     runflush = mode.startswith("ocrspr")
     ktype, kbytes = ("unsigned short", 2) if mode.endswith("_k16") else ("unsigned char", 1)
     skip = "0xffffu" if kbytes == 2 else "0xffu"
-    threads = int(configuration["ocrs_pw_threads"]) if pw_fu else configuration["ocrs_block_threads"]
+    threads = configuration["ocrs_block_threads"]
     params: List[str] = []
     layout: List[tuple] = []
 
@@ -1351,11 +1345,6 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
                 f"      if (slot != {slot_skip}) {{", *scatter, "      }",
                 "    } break;"]
     switch_src += ["    default: break;", "    }"]
-    if pw_fu:
-        return _sliced_persistent(gk, full_mode, sym_name=f"wrap_{lk.name}", params=params, layout=layout, P=P, infos=infos, maps=maps, staged_maps=staged_maps,
-                                  stage_nodes=stage_nodes, pack=pack, rec=rec, rec_decode=rec_decode, rows=rows, scal=scal, switch_src=switch_src,
-                                  K=K, runflush=runflush, ordered=ordered, threads=threads, FUQ=pw_fu, kbytes=kbytes, need_e=need_e,
-                                  strides=strides, lds_items=lds_items)
     pf = bool(configuration["prefetch"])
 
     def loads(ii, prefix):
@@ -1465,202 +1454,6 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             pat = re.compile(r"\bp%d_maxnd\b" % mi)
             src[sig + 1:] = [pat.sub("((long long)%d)" % S, l) for l in src[sig + 1:]]
     return WrapperSource("\n".join(src) + "\n", sym, full_mode, layout, len(maps), staged_maps, lds_items, True, threads, kbytes)
-
-
-def _sliced_persistent(gk, full_mode, *, sym_name, params, layout, P, infos, maps, staged_maps, stage_nodes, pack, rec, rec_decode, rows,
-                       scal, switch_src, K, runflush, ordered, threads, FUQ, kbytes, need_e, strides, lds_items):
-    """The row-sliced wrapper with PERSISTENT workgroups ("..._pw<F>").
-
-    profiles/r5b_phase_times.txt: a row block of the CG2 share lives 16.7 microseconds of which its main loop takes 9.7 -- the rest
-    is the staging round trip (block bounds -> index rows / READ rows -> LDS -> barrier), the flush, and the gap until the CU slot is
-    given to the next workgroup.  Here one workgroup per CU slot walks a contiguous range of row blocks (XCD-aware: a range per XCD, a
-    sub-range per workgroup) and pipelines their phases in software over DOUBLE-BUFFERED LDS:
-      * while block b runs its trips, the READ rows and the run indices it will be flushed with, the first index record of block
-        b + 1 and the descriptor of block b + 2 are in flight -- requested at the top of the iteration, consumed behind the trips;
-      * the accumulators of block b - 1 (the other buffer) are flushed behind the trips of block b by the lanes that then zero them;
-        their places (run indices requested an iteration earlier, displacements in LDS) need no load;
-      * ONE barrier per block.
-    Vector-memory waits: loads and stores share one counter, and the compiler waits for everything once both kinds are pending.  So
-    the iteration is ordered [requests] [trips] [explicit wait: only old loads are outstanding] [LDS staging] [flush stores] [barrier]:
-    no use of a load ever follows a store it would have to wait for.
-    Block bounds come from a descriptor table -- one row of starts per block (instances, plan list per staged map, accumulator,
-    runs; the ends are the next row's starts) -- read with a vector load (a scalar load would sit on the counter every LDS result is
-    waited on) and made scalar with readfirstlane."""
-    lk = gk.local_kernel
-    if not rec or need_e or (ordered and not runflush):
-        raise ValueError("persistent row-sliced wrapper: scalar matrices with instance records, no direct arguments, contiguous or run-coded flush")
-    T = int(threads)
-    # one accumulator (and one table of run displacements) per workgroup instead of two: the flush of a block follows its trips behind
-    # a second barrier, like in the one-workgroup-per-block wrapper -- half the LDS, twice the resident workgroups; what stays
-    # pipelined is the staging (READ rows, index records, block bounds)
-    single = int(configuration["ocrs_pw_accumulators"]) == 1
-    FQ = -(-int(FUQ) // 4)               # 32-bit words of run indices per lane: four consecutive accumulator entries each
-    dats = [i_ for i_ in infos if i_["kind"] == "dat" and "m" in i_]
-    fields = ["e0"] + [f"l0_{mi}" for mi in staged_maps] + ["r0"] + (["br0"] if runflush else [])
-    DW = -(-len(fields) // 4) * 4
-    P("const int *__restrict__ binfo_", ("ocrs_binfo", K, tuple(staged_maps), bool(runflush), DW))
-    P("long long fd_nb_", ("ocrs_nblocks", K))
-    ptimes = bool(configuration["phase_times"])        # (the parameter was declared by generate_sliced_wrapper)
-    includes, body = _hoist_includes(lk.code)
-    W = rows[0][1]
-    waves = max(1, int(configuration["ocrs_pw_per_cu"]) * T // 256)      # wavefronts per SIMD of the resident workgroups
-    src = ['#include "fd_wrapper.h"', "#include <math.h>", *includes, *[f"#include <{h}>" for h in lk.headers],
-           "namespace fdk {", "#pragma clang force_cuda_host_device begin", body,
-           "#pragma clang force_cuda_host_device end", "}  // namespace fdk", "",
-           f'extern "C" __global__ __launch_bounds__({T}, {waves}) void {sym_name}(int start, int end, {", ".join(params)})', "{",
-           "  extern __shared__ __align__(16) unsigned char fd_lds[];",
-           "  const int tid = threadIdx.x, nthr = blockDim.x;",
-           # blocks of this workgroup: the hardware deals workgroups round robin over the 8 XCDs; XCD x owns one contiguous range of
-           # the blocks (fdw::xcd_block's ranges), its workgroups contiguous sub-ranges
-           "  const int fd_nb = (int)fd_nb_, fd_NX = (int)gridDim.x < 8 ? (int)gridDim.x : 8;",
-           "  const int fd_x = (int)blockIdx.x % fd_NX, fd_j = (int)blockIdx.x / fd_NX, fd_nx = ((int)gridDim.x + fd_NX - 1 - fd_x) / fd_NX;",
-           "  const int fd_q = fd_nb / fd_NX, fd_r = fd_nb % fd_NX;",
-           "  const int fd_xb0 = fd_x*fd_q + (fd_x < fd_r ? fd_x : fd_r), fd_xn = fd_q + (fd_x < fd_r ? 1 : 0);",
-           "  const int wb0 = fd_xb0 + (int)(((long long)fd_xn*fd_j)/fd_nx), wb1 = fd_xb0 + (int)(((long long)fd_xn*(fd_j + 1))/fd_nx);",
-           "  if (wb0 >= wb1) return;",
-           "  size_t fd_off = 0;"]
-    for i_ in dats:                                     # LDS: two copies of everything
-        k, ct, c, mi = i_["k"], i_["ct"], i_["c"], i_["m"]
-        for h in (0, 1):
-            src.append(f"  {ct} *s{k}_{h} = ({ct} *)(fd_lds + fd_off); fd_off += (((size_t)p{mi}_maxnd*{c}*sizeof({ct})) + 15) & ~(size_t)15;")
-    if runflush:
-        for h in ((0,) if single else (0, 1)):
-            src.append(f"  int *srun_{h} = (int *)(fd_lds + fd_off); fd_off += 1024;")
-    for h in ((0,) if single else (0, 1)):
-        src.append(f"  double *sm_{h} = (double *)(fd_lds + fd_off); fd_off += (((size_t)oc{K}_maxnnz*8) + 15) & ~(size_t)15;")
-    if single:
-        src.append("  double *sm_1 = sm_0;" + (" int *srun_1 = srun_0;" if runflush else ""))
-
-    def desc_load(dst, bexpr):
-        return (f"int4 {dst}[{DW // 4}]; {{ const int4 *fd_p = reinterpret_cast<const int4 *>(binfo_ + (size_t)(({bexpr}) + fdw::lane_zero())*{DW}); "
-                + " ".join(f"{dst}[{q}] = fd_p[{q}];" for q in range(DW // 4)) + " }")
-
-    def desc_load_into(dst, bexpr):
-        return (f"{{ const int4 *fd_p = reinterpret_cast<const int4 *>(binfo_ + (size_t)(({bexpr}) + fdw::lane_zero())*{DW}); "
-                + " ".join(f"{dst}[{q}] = fd_p[{q}];" for q in range(DW // 4)) + " }")
-
-    def desc_scalar(prefix, src_):
-        return " ".join(f"{prefix}{name} = fdw::wave_uniform({src_}[{q >> 2}].{'xyzw'[q & 3]});" for q, name in enumerate(fields))
-
-    # A_ = starts of the current block, B_ = of the next one (= the current block's ends), C_ = of the one after
-    src.append("  int " + ", ".join(f"A_{n} = 0, B_{n} = 0, C_{n} = 0" for n in fields) + ";")
-    src += ["  { " + desc_load("fd_d0", "wb0") + " " + desc_load("fd_d1", "wb0 + 1") + " " + desc_load("fd_d2", "(wb0 + 2 < fd_nb ? wb0 + 2 : fd_nb)"),
-            "    " + desc_scalar("A_", "fd_d0") + " " + desc_scalar("B_", "fd_d1") + " " + desc_scalar("C_", "fd_d2") + " }"]
-    # prologue: zero both accumulators, stage the first block's READ rows, its first index record
-    src.append(f"  for (int q = tid; q < {1 if single else 2}*(int)(((oc{K}_maxnnz*8 + 15) & ~15ll) >> 3); q += nthr) sm_0[q] = 0;")
-    for mi in staged_maps:
-        src.append(f"  if (tid < B_l0_{mi} - A_l0_{mi}) {{")
-        src.append(f"    const int i = tid; const int g = p{mi}_list[A_l0_{mi} + i];")
-        for i_ in [d for d in dats if d["m"] == mi]:
-            k, ct, c = i_["k"], i_["ct"], i_["c"]
-            src.append(f"    {ct} v[{c}]; if (pl{k}) {{ for (int j = 0; j < {c}; ++j) v[j] = pl{k}[(size_t)(A_l0_{mi} + i)*{c} + j]; }} "
-                       f"else {{ for (int j = 0; j < {c}; ++j) v[j] = arg{k}[(size_t)g*{c} + j]; }}")
-            src.append(f"    for (int j = 0; j < {c}; ++j) s{k}_0[{'j*(int)p%d_maxnd + i' % mi if c > 1 else 'i*%d + j' % c}] = v[j];")
-        src.append("  }")
-    src += [f"  unsigned rc[{W}], nx_rc[{W}];", "  int role = 0, nx_role = 0;",
-            "  if (A_e0 + tid < B_e0) {", "    role = (int)chunk_role_[((A_e0 + tid) - start) >> 6];",
-            f"    fdw::load_rec<{W}>(oc{K}_rec + (size_t)((A_e0 + tid) - start)*{W}, rc);", "  }",
-            f"  unsigned g[{FQ}];", f"  for (int f = 0; f < {FQ}; ++f) g[f] = 0u;", "  int p_r0 = 0, p_nnzb = 0, cur = 0;",
-            "  __syncthreads();",
-            "  for (int b = wb0; b < wb1; ++b) {",
-            "    const bool more = b + 1 < wb1;",
-            "    const int e0 = A_e0, e1 = B_e0, r0 = A_r0, nnzb = B_r0 - A_r0;",
-            f"    double *sm{K} = cur ? sm_1 : sm_0, *smp = cur ? sm_0 : sm_1;"]
-    if runflush:
-        src.append("    int *srun = cur ? srun_1 : srun_0, *srunp = cur ? srun_0 : srun_1; const int br0 = A_br0, nrun = B_br0 - A_br0;")
-    for i_ in dats:
-        k, ct = i_["k"], i_["ct"]
-        src.append(f"    {ct} *s{k} = cur ? s{k}_1 : s{k}_0, *s{k}n = cur ? s{k}_0 : s{k}_1;")
-    if ptimes:
-        src.append("    if (tid == 0) { fd_times[5*(size_t)b] = wall_clock64(); fd_times[5*(size_t)b + 4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }")
-    req, decl = [], []
-    # (1) requests: the starts of block b + 3 (= the ends of b + 2), the next block's READ rows, this block's run indices / displacements
-    for mi in staged_maps:
-        decl.append(f"    const int n_nd{mi} = more ? C_l0_{mi} - B_l0_{mi} : 0;")
-        decl.append(f"    int gn{mi} = 0;")
-        req.append(f"    if (tid < n_nd{mi}) gn{mi} = p{mi}_list[B_l0_{mi} + tid];")
-        for i_ in [d for d in dats if d["m"] == mi]:
-            k, ct, c = i_["k"], i_["ct"], i_["c"]
-            decl.append(f"    {ct} vn{k}[{c}];")
-            req.append(f"    if (tid < n_nd{mi} && pl{k}) {{ for (int j = 0; j < {c}; ++j) vn{k}[j] = pl{k}[(size_t)(B_l0_{mi} + tid)*{c} + j]; }}")
-    if runflush:
-        # (a lane flushes groups of four consecutive entries: their four run bytes are one unaligned 32-bit load; the table is
-        # padded by a word at its end)
-        decl.append("    int fd_rd = 0;")
-        req += [f"    if (tid < nrun) fd_rd = oc{K}_rdelta[br0 + tid];"]
-        if single:
-            req.append(f"    for (int f = 0; f < {FQ}; ++f) {{ const int q = 4*(tid + f*nthr); g[f] = fdw::load_u32_unaligned(oc{K}_grun + (size_t)r0 + (q < nnzb ? q : 0)); }}")
-    src += decl
-    # ... by the lanes without an instance in this block here (with their first record of the next block, into the prefetch
-    # registers they never use otherwise), by the others inside their first trip, behind its index-row request: the trips' first
-    # wait must not include them
-    src.append("    if (e0 + tid >= e1) {")
-    src += ["  " + l for l in req]
-    src += ["      if (more && B_e0 + tid < C_e0) {", "        nx_role = (int)chunk_role_[((B_e0 + tid) - start) >> 6];",
-            f"        fdw::load_rec<{W}>(oc{K}_rec + (size_t)((B_e0 + tid) - start)*{W}, nx_rc);", "      }", "    }"]
-    if ptimes:
-        src.append("    if (tid == 0) fd_times[5*(size_t)b + 1] = wall_clock64();")
-    # (2) the block's trips
-    src += ["    for (int it = e0 + tid; it < e1; it += nthr) {",
-            "      const int itn = (it + nthr < e1) ? it + nthr : ((more && B_e0 + tid < C_e0) ? B_e0 + tid : it);",
-            "      nx_role = (int)chunk_role_[(itn - start) >> 6];",
-            f"      fdw::load_rec<{W}>(oc{K}_rec + (size_t)(itn - start)*{W}, nx_rc);",
-            "      if (it == e0 + tid) {"] + ["    " + l for l in req] + ["      }"]
-    src += ["  " + l for l in (["    " + s_ for s_ in rec_decode] + ["    " + s_ for s_ in pack] + switch_src)]
-    src += [f"      for (int q = 0; q < {W}; ++q) rc[q] = nx_rc[q];", "      role = nx_role;", "    }"]
-    if ptimes:
-        src.append("    if (tid == 0) fd_times[5*(size_t)b + 2] = wall_clock64();")
-    # (3) everything requested at the top of the iteration is old by now: one explicit wait, so that nothing below -- or behind the
-    # barrier -- waits on the vector-memory counter once the flush stores are in it
-    src.append("    fdw::wait_vector_memory();")
-    src.append(f"    if (e0 + tid >= e1) {{ for (int q = 0; q < {W}; ++q) rc[q] = nx_rc[q]; role = nx_role; }}")
-    # (4) the next block's READ rows into the other buffer (a Dat without a plan-ordered copy is gathered now: one more round trip,
-    # first calls only), this block's displacements
-    for mi in staged_maps:
-        gath = [d for d in dats if d["m"] == mi]
-        src.append(f"    if (tid < n_nd{mi}) {{")
-        for i_ in gath:
-            k, ct, c = i_["k"], i_["ct"], i_["c"]
-            src.append(f"      if (!pl{k}) {{ const int gq = fdw::opaque(gn{mi}); for (int j = 0; j < {c}; ++j) vn{k}[j] = arg{k}[(size_t)gq*{c} + j]; }}")
-            src.append(f"      for (int j = 0; j < {c}; ++j) s{k}n[{'j*(int)p%d_maxnd + tid' % mi if c > 1 else 'tid*%d + j' % c}] = vn{k}[j];")
-        src.append("    }")
-    if runflush:
-        src.append("    if (tid < nrun) srun[tid] = fd_rd;")
-    # (5) flush -- of the previous block out of the other accumulator (two accumulators), or of this block behind a barrier (one) --
-    # zeroed behind the read by the same lane
-    place = "p_r0 + q + srunp[(g[f] >> (8*j)) & 0xffu]" if runflush else "p_r0 + q"
-    if single:
-        src += ["    p_r0 = r0; p_nnzb = nnzb;", "    __syncthreads();"]
-    src += ["    if (b > wb0) {" if not single else "    {",
-            f"      if (oc{K}_flags & 1) {{ for (int f = 0; f < {FQ}; ++f) for (int j = 0; j < 4; ++j) {{ const int q = 4*(tid + f*nthr) + j; if (q < p_nnzb) {{ const double v = smp[q]; smp[q] = 0.0; arg{K}[(size_t)({place})] = v; }} }} }}",
-            f"      else {{ for (int f = 0; f < {FQ}; ++f) for (int j = 0; j < 4; ++j) {{ const int q = 4*(tid + f*nthr) + j; if (q < p_nnzb) {{ const double v = smp[q]; smp[q] = 0.0; arg{K}[(size_t)({place})] += v; }} }} }}",
-            "    }"]
-    # (6) requests nobody waits for before the next iteration's explicit wait: this block's run indices (two accumulators: its flush
-    # is an iteration away) and -- a scalar load: it has the barrier and the next requests to land before an LDS result is waited
-    # for -- the starts three blocks ahead
-    if runflush and not single:
-        src.append(f"    for (int f = 0; f < {FQ}; ++f) {{ const int q = 4*(tid + f*nthr); g[f] = fdw::load_u32_unaligned(oc{K}_grun + (size_t)r0 + (q < nnzb ? q : 0)); }}")
-    src.append("    { const int fd_b3 = (b + 3 < fd_nb ? b + 3 : fd_nb); " + " ".join(f"D_{n} = binfo_[(size_t)fd_b3*{DW} + {q}];" for q, n in enumerate(fields)) + " }")
-    src += ["    p_r0 = r0; p_nnzb = nnzb;",
-            "    __syncthreads();"] + (["    if (tid == 0) fd_times[5*(size_t)b + 3] = wall_clock64();"] if ptimes else []) + [
-            "    " + " ".join(f"A_{n} = B_{n}; B_{n} = C_{n}; C_{n} = D_{n};" for n in fields),
-            "    cur ^= 1;", "  }",
-            # epilogue (two accumulators): the last block's accumulators (now the "other" buffer)
-            "  if (%d) { double *smp = cur ? sm_0 : sm_1;" % (0 if single else 1) + (" int *srunp = cur ? srun_0 : srun_1;" if runflush else ""),
-            f"    if (oc{K}_flags & 1) {{ for (int f = 0; f < {FQ}; ++f) for (int j = 0; j < 4; ++j) {{ const int q = 4*(tid + f*nthr) + j; if (q < p_nnzb) arg{K}[(size_t)({place})] = smp[q]; }} }}",
-            f"    else {{ for (int f = 0; f < {FQ}; ++f) for (int j = 0; j < 4; ++j) {{ const int q = 4*(tid + f*nthr) + j; if (q < p_nnzb) arg{K}[(size_t)({place})] += smp[q]; }} }}",
-            "  }", "}"]
-    # D_ registers of the starts two blocks ahead
-    at = next(i for i, l in enumerate(src) if l.startswith("  int A_e0 = 0"))
-    src.insert(at + 1, "  int " + ", ".join(f"D_{n} = 0" for n in fields) + ";")
-    if strides is not None:
-        if len(strides) != len(staged_maps):
-            raise ValueError("one compile-time stride per staged map")
-        sig = next(i for i, l in enumerate(src) if l.startswith('extern "C" __global__'))
-        for mi, S in zip(staged_maps, strides):
-            pat = re.compile(r"\bp%d_maxnd\b" % mi)
-            src[sig + 1:] = [pat.sub("((long long)%d)" % S, l) for l in src[sig + 1:]]
-    return WrapperSource("\n".join(src) + "\n", sym_name, full_mode, layout, len(maps), staged_maps, lds_items, True, T, kbytes)
 
 
 def lds_stride(max_nd: int, ocr: bool = False) -> int:

@@ -61,13 +61,6 @@ configuration = {
     "ocrs_run_flush": _env("FDHIP_OCRS_RUN_FLUSH", 1, int),       # derived row orders, scalar matrices: run-coded places (1 B per entry)
     "ocrs_nnz_per_block": _env("FDHIP_OCRS_NNZ", 4096, int),     # accumulator entries per row block (x8 bytes of LDS)
     "ocrs_block_threads": _env("FDHIP_OCRS_BLOCK_THREADS", 256, int),
-    # row-sliced loops with persistent workgroups and software-pipelined blocks (codegen._sliced_persistent): 0 = one workgroup
-    # per row block; threads per workgroup; workgroups per CU
-    "ocrs_persistent": _env("FDHIP_OCRS_PERSISTENT", 1, int),
-    "ocrs_pw_threads": _env("FDHIP_OCRS_PW_THREADS", 512, int),
-    "ocrs_pw_per_cu": _env("FDHIP_OCRS_PW_PER_CU", 2, int),
-    "ocrs_pw_accumulators": _env("FDHIP_OCRS_PW_ACC", 2, int),      # 2: flush of block b - 1 under the trips of block b; 1: one accumulator, two barriers
-    "ocrs_pw_nnz": _env("FDHIP_OCRS_PW_NNZ", 0, int),               # accumulator entries per block of the persistent wrapper (0 = ocrs_nnz_per_block)
     "ocrs_interleave": _env("FDHIP_OCRS_INTERLEAVE", 7, int),    # > 1: stride permutation of the instances of every (block, row index) group
     "ocr_block_threads": _env("FDHIP_OCR_BLOCK_THREADS", 0, int),  # 0 = auto: 512 for small element matrices, else block_threads
     # order of the instances inside an owner-computes-rows block: "stencil" (sorted by ownership pattern and owned-row

@@ -39,24 +39,6 @@ __device__ __forceinline__ int xcd_block(int bid, int nb) {
     return x * q + (x < r ? x : r) + k;
 }
 
-// A zero the compiler cannot see through: added to a wave-uniform index it keeps the load on the vector memory path (vmcnt) where
-// the compiler would otherwise pick a scalar load, whose counter (lgkmcnt) is shared with every LDS result the wavefront waits for.
-__device__ __forceinline__ int lane_zero() { int z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); return z; }
-
-// Four bytes of a byte table at any alignment, as one 32-bit load (global memory takes unaligned dword accesses on gfx950)
-__device__ __forceinline__ unsigned load_u32_unaligned(const unsigned char *p) {
-    typedef unsigned __attribute__((aligned(1))) u32_unaligned;
-    return *reinterpret_cast<const u32_unaligned *>(p);
-}
-
-// The value, through a register the compiler cannot see through: a load addressed with it cannot be hoisted above this point.
-__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
-
-// s_waitcnt vmcnt(0): every vector-memory operation the wavefront has issued is complete.  The compiler counts loads and stores on
-// one counter and waits for ALL of them once both kinds are pending; placed where only old loads are outstanding (after the trips of
-// a persistent block, before its flush stores) it is free, and it keeps every later use of those loads from waiting for the stores.
-__device__ __forceinline__ void wait_vector_memory() { __builtin_amdgcn_s_waitcnt(0x0F70); }
-
 // A value the caller knows to be equal in all lanes of the wavefront (the row index of a sliced instance chunk): moving it
 // to a scalar register turns the switch on it into scalar branches -- no divergence bookkeeping, one instantiation executed.
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -86,17 +86,3 @@ class Event:
         except Exception:
             pass
 
-
-_CUS = None
-
-
-def compute_units():
-    """Compute units of the current device (fd_device_info), cached."""
-    global _CUS
-    if _CUS is None:
-        cu, hbm, lds = ctypes.c_int(), ctypes.c_size_t(), ctypes.c_int()
-        name = ctypes.create_string_buffer(128)
-        _lib.call("fd_device_info", -1, name, 128, ctypes.byref(cu), ctypes.byref(hbm), ctypes.byref(lds))
-        _CUS = int(cu.value) or 256
-    return _CUS
-

@@ -526,7 +526,7 @@ BENCH_VARIANTS = {
     ("residual", 3, 1): ("stagedo_s431", "staged_s405"),
     ("jacobian", 3, 1): ("ocrp_q10k4d_fx", "ocr_q10k4d_fx", "ocrp_q9k4d_fx", "ocr_q9k4d_fx"),
     ("residual", 3, 2): ("stagedo_s1508x255",),
-    ("jacobian", 3, 2): ("ocrspr_q8k7e13_pw9", "ocrs_q8k7e13_pw9", "ocrspr_q8k7e13", "ocrspr", "ocrsp", "ocrs"),
+    ("jacobian", 3, 2): ("ocrspr_q8k7e13", "ocrs_q8k7e13", "ocrspr", "ocrsp", "ocrs"),
     "dg_advection": ("staged_s2048x561", "staged_s1024x516", "staged_s2332x668"),
 }
 

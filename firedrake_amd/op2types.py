@@ -2166,7 +2166,7 @@ class RowOrder:
         hit = getattr(self, "_runs", None)
         if hit is None or hit[0] != key:
             nb = len(rb) - 1
-            grun = DeviceBuffer(max(int(self.prowptr_host[-1]), 1) + 4)       # (+ a word: the persistent flush reads four bytes at a time)
+            grun = DeviceBuffer(max(int(self.prowptr_host[-1]), 1))
             brun = DeviceBuffer((nb + 1) * 4)
             rdelta = DeviceBuffer(max(self.npos, 1) * 4)
             rblk = DeviceBuffer.from_numpy(rb)

@@ -1074,9 +1074,7 @@ class Parloop:
                 row_order = RowOrder(rmap, order, end - start, nrows, rp, rowptr_dev=sp._node_rowptr.ptr)
                 prp = row_order.prowptr_host
         B = int(sp.dsets[0].cdim) * int(sp.dsets[1].cdim)
-        cap_ = int(configuration["ocrs_pw_nnz"]) if (configuration["ocrs_persistent"] and int(configuration["ocrs_pw_nnz"]) > 0) \
-            else int(configuration["ocrs_nnz_per_block"])
-        cap = max(cap_ // B, int(np.diff(prp).max()) if nrows else 1)
+        cap = max(int(configuration["ocrs_nnz_per_block"]) // B, int(np.diff(prp).max()) if nrows else 1)
         staged = {mi: maps[mi] for mi in src.staged_maps}
         limit = configuration["lds_limit"]
         for attempt in range(8):
@@ -1119,24 +1117,7 @@ class Parloop:
             if rec[1] > 8 or rec[2] > 16 or rec[3] * 4 >= sum(staged[mi].arity for mi in src.staged_maps) * 2 + cmap.arity + 2:
                 rec = None
         variant = mode_variant(base, op.kbytes, nds, rec)
-        # persistent workgroups (codegen._sliced_persistent): scalar matrices with records, READ rows one node per lane, complete
-        # rows flushed contiguously or through run-coded places, no direct arguments; two copies of every LDS array per workgroup
-        pw = None
-        T = int(configuration["ocrs_pw_threads"])
-        per_cu = max(1, int(configuration["ocrs_pw_per_cu"]))
-        direct_args = any(isinstance(a, DatParloopArg) and a.map_ is None for a in self.arguments) or bool(self.global_kernel._pass_layer_arg)
-        if configuration["ocrs_persistent"] and rec is not None and not direct_args and all(n_ <= T for n_ in nds) \
-                and ((base == "ocrspr" and runs is not None) or base == "ocrs"):
-            if int(configuration["ocrs_pw_accumulators"]) == 1:
-                acc_ = ((op.max_nnz * B * 8) + 15) // 16 * 16 + (1024 if runs is not None else 0)
-                lds_pw = 2 * (lds - acc_) + acc_
-            else:
-                lds_pw = 2 * lds
-            if lds_pw <= (160 * 1024) // per_cu:
-                fuq = max(1, -(-int(op.max_nnz) // T))
-                variant += f"_pw{fuq}"
-                pw = {"threads": T, "lds": lds_pw, "per_cu": per_cu}
-        geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz, "runs": runs, "rec": rec, "pw": pw,
+        geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz, "runs": runs, "rec": rec,
                "cw": prep["cw"] if variant == src.mode else self.global_kernel.compile(variant), "row_order": row_order}
         prep["parts"][gkey] = geo
         if configuration["debug"]:
@@ -1247,44 +1228,10 @@ class Parloop:
                 if geo.get("phase_times") is None:
                     geo["phase_times"] = DeviceBuffer(max(op.nblocks, 1) * 40)
                 out.append(geo["phase_times"].ptr)
-            elif kind == "ocrs_binfo":
-                out.append(self._ocrs_block_info(geo, desc).ptr)
-            elif kind == "ocrs_nblocks":
-                out.append(op.nblocks)
             else:
                 raise AssertionError(kind)
-        pw = geo.get("pw")
-        if pw:
-            # persistent workgroups: per_cu per compute unit (a multiple of 8: one contiguous block range per XCD), never more than blocks
-            from .device import compute_units
-            grid = max(8, (pw["per_cu"] * compute_units()) // 8 * 8)
-            cw.launch(0, op.ninst, out, block_threads=pw["threads"], ents_per_block=op.max_inst, nblocks=min(grid, max(op.nblocks, 1)),
-                      lds_bytes=pw["lds"])
-        else:
-            cw.launch(0, op.ninst, out, block_threads=src.block_threads, ents_per_block=op.max_inst, nblocks=op.nblocks,
-                      lds_bytes=geo["lds"])
-
-    def _ocrs_block_info(self, geo, desc):
-        """Descriptor table of the persistent row-sliced wrapper: one row of STARTS per row block (+ one closing row) -- first
-        instance, first plan-list entry of every staged map, first accumulator entry [, first run] -- padded to a multiple of four
-        ints; a block's ends are the next row's starts.  What the one-workgroup-per-block wrapper reads from five arrays."""
-        hit = geo.get("binfo")
-        if hit is None:
-            _, k, smaps, runflush, dw = desc
-            op, ro = geo["ocr"], geo["row_order"]
-            nb = op.nblocks
-            cols = [op.inst_off_host]
-            for mi in smaps:
-                cols.append(DeviceBuffer.wrap(op.plans[mi].blkoff, (nb + 1) * 4, owned=False).download(np.int32, (nb + 1,)))
-            acc = ro.prowptr_host if ro is not None else self.arguments[k].data.sparsity._node_rowptr_host()
-            cols.append(np.asarray(acc)[op.row_blocks])
-            if runflush:
-                cols.append(geo["runs"][1].download(np.int32, (nb + 1,)))
-            tab = np.zeros((nb + 1, dw), dtype=np.int32)
-            for q, c_ in enumerate(cols):
-                tab[:, q] = c_
-            hit = geo["binfo"] = DeviceBuffer.from_numpy(tab)
-        return hit
+        cw.launch(0, op.ninst, out, block_threads=src.block_threads, ents_per_block=op.max_inst, nblocks=op.nblocks,
+                  lds_bytes=geo["lds"])
 
     def fixed_point_state(self):
         """Diagnostics of the checked fixed-point accumulation of this loop's owner-computes-rows parts (blocks the stream): per

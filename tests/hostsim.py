@@ -398,7 +398,7 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False,
     return csr
 
 
-def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None, run_flush=False, records=False, persistent=0):
+def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None, run_flush=False, records=False):
     """Execute a matrix-assembly Parloop ``pl`` with the ROW-SLICED owner-computes-rows wrapper on the host (one OS thread
     per lane).  Plan tables from helpers.ocrs_plan_ref, CSR pattern from the oracle.  Returns the OracleCSR."""
     import re
@@ -459,14 +459,8 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None, run_flush=Fals
         from firedrake_amd.codegen import sliced_record_layout
         rec = sliced_record_layout([maps[mi].arity for mi in base.staged_maps], [plans[mi][3] for mi in base.staged_maps], cmap.arity,
                                    int(np.diff(ncsr.rowptr).max()), max_nnz)
-    variant = mode_variant(("ocrspr" if run_tabs else "ocrsp") if order is not None else "ocrs", 1, [plans[mi][3] for mi in base.staged_maps], rec)
-    if persistent:
-        # persistent workgroups (codegen._sliced_persistent): ``persistent`` workgroups of configuration["ocrs_pw_threads"] lanes walk
-        # contiguous ranges of the row blocks
-        T = int(configuration["ocrs_pw_threads"])
-        assert all(plans[mi][3] <= T for mi in base.staged_maps)
-        variant += f"_pw{max(1, -(-max_nnz // T))}"
-    src = generate_wrapper(gk, variant)
+    src = generate_wrapper(gk, mode_variant(("ocrspr" if run_tabs else "ocrsp") if order is not None else "ocrs", 1,
+                                            [plans[mi][3] for mi in base.staged_maps], rec))
     text = src.source.replace("extern __shared__ __align__(16) unsigned char fd_lds[];", "unsigned char *fd_lds = fd_sim::lds;")
     sig = re.search(r'extern "C" __global__[^\n]*void %s\((.*)\)\n' % src.symbol, text).group(1)
     names = [p.split()[-1].lstrip("*") for p in sig.split(", ")]
@@ -483,7 +477,7 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None, run_flush=Fals
 
     if not zero_pending:
         csr.values[...] = 1.0
-    cargs = [ctypes.c_int(int(persistent) if persistent else len(rb) - 1), ctypes.c_int(T), ctypes.c_int(0), ctypes.c_int(len(inst_ent))]
+    cargs = [ctypes.c_int(len(rb) - 1), ctypes.c_int(T), ctypes.c_int(0), ctypes.c_int(len(inst_ent))]
     for desc in src.layout:
         kind = desc[0]
         if kind == "layers":
@@ -503,17 +497,6 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None, run_flush=Fals
             cargs.append(ptr(inst_off))
         elif kind == "ocr_inst_ent":
             cargs.append(ptr(inst_ent))
-        elif kind == "ocrs_binfo":
-            # numpy restatement of Parloop._ocrs_block_info: one row of starts per block + the closing row
-            _, _, smaps, rf, dw = desc
-            nb = len(rb) - 1
-            cols = [inst_off] + [plans[mi][0] for mi in smaps] + [np.asarray(acc)[rb]] + ([run_tabs[1]] if rf else [])
-            tab = np.zeros((nb + 1, dw), dtype=np.int32)
-            for q, c_ in enumerate(cols):
-                tab[:, q] = c_
-            cargs.append(ptr(tab))
-        elif kind == "ocrs_nblocks":
-            cargs.append(ctypes.c_longlong(len(rb) - 1))
         elif kind == "ocr_rec":
             lbits, kbits, sbits, words_ = rec
             cargs.append(ptr(pack_records_ref([plans[mi][2] for mi in base.staged_maps], lbits, np.asarray(kk), 1, cmap.arity, kbits, False,
@@ -534,10 +517,8 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None, run_flush=Fals
             cargs.append(ptr(np.ascontiguousarray(acc, dtype=np.int32)))
         elif kind == "ocr_gstart":
             cargs.append(ptr(np.ascontiguousarray(ncsr.rowptr[plist], dtype=np.int32)))
-        elif kind == "ocr_grun":
-            cargs.append(ptr(np.concatenate([run_tabs[0], np.zeros(4, dtype=run_tabs[0].dtype)])))     # (+ a word, like RowOrder.runs)
-        elif kind in ("ocr_brun", "ocr_rdelta"):
-            cargs.append(ptr(run_tabs[{"ocr_brun": 1, "ocr_rdelta": 2}[kind]]))
+        elif kind in ("ocr_grun", "ocr_brun", "ocr_rdelta"):
+            cargs.append(ptr(run_tabs[{"ocr_grun": 0, "ocr_brun": 1, "ocr_rdelta": 2}[kind]]))
         elif kind == "plan_copy":
             cargs.append(_plan_copy_arg(pl, desc, plans, ptr))
         elif kind == "ocr_gpos":

@@ -31,7 +31,6 @@ typedef double PetscReal;
 typedef int PetscInt;
 
 struct fd_sim_dim3 { int x, y, z; };
-struct int4 { int x, y, z, w; };
 static thread_local fd_sim_dim3 threadIdx = {0, 0, 0}, blockIdx = {0, 0, 0};
 static fd_sim_dim3 blockDim = {1, 1, 1}, gridDim = {1, 1, 1};
 
@@ -109,10 +108,6 @@ inline int xcd_block(int bid, int nb) {
     return x * q + (x < r ? x : r) + k;
 }
 inline int wave_uniform(int v) { return v; }
-inline int lane_zero() { return 0; }
-inline void wait_vector_memory() {}
-inline int opaque(int v) { return v; }
-inline unsigned load_u32_unaligned(const unsigned char *p) { unsigned v; __builtin_memcpy(&v, p, 4); return v; }
 template <class T> inline void atomic_add(T *p, T v) { fd_sim::cas_update(p, [v](T o) { return o + v; }); }
 template <class T> inline void atomic_min(T *p, T v) { fd_sim::cas_update(p, [v](T o) { return v < o ? v : o; }); }
 template <class T> inline void atomic_max(T *p, T v) { fd_sim::cas_update(p, [v](T o) { return v > o ? v : o; }); }

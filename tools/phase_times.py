@@ -33,7 +33,6 @@ print(f"{which} n={n}: mode {geo['cw'].src.mode}, {len(t)} blocks, kernel span {
 for name, a, b in (("stage", 0, 1), ("main loop", 1, 2), ("flush", 2, 3), ("lifetime", 0, 3)):
     d = us[:, b] - us[:, a]
     print(f"  {name:10s} mean {d.mean():7.2f} us  median {np.median(d):7.2f}  p10 {np.percentile(d, 10):7.2f}  p90 {np.percentile(d, 90):7.2f}")
-print(f"  (persistent workgroups: phases = top-of-iteration work incl. the previous flush | trips | staging + barrier)") if "_pw" in geo["cw"].src.mode else None
 print(f"  resident blocks per CU (sum of lifetimes / span / 256): {life.sum() / span / 256:.2f}")
 # HW_ID: wave 0..3, simd 4..5, pipe 6..7, cu 8..11, sh 12, se 13..15 (+ XCC by the block's index modulo 8)
 hw = t[:, 4]
