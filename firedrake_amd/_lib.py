@@ -125,7 +125,6 @@ SIGNATURES = {
                                     c_void_p, c_void_p]),
     "fd_csr_set_diagonal": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_double, c_void_p]),
     "fd_csr_zero_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_double, c_void_p]),
-    "fd_csr_zero_rows_except": (c_int, [c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
     "fd_csr_spmv": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fd_csr_split_mpiaij": (c_int, [c_int32, c_void_p, c_void_p, c_int32, c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64),
                                     POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_void_p]),
@@ -165,8 +164,8 @@ def check(status):
         raise FDHipError(f"libfdhip status {status}: {msg.decode() if msg else '?'}")
 
 
-_TRACE = os.environ.get("FDHIP_TRACE_CALLS", "0") == "1"
-_PROFILE = os.environ.get("FDHIP_PROFILE_CALLS", "0") == "1"
+_TRACE = os.environ.get("FDHIP_PROFILE_CALLS", "0") == "2"       # 2: also name every C-ABI call before it runs
+_PROFILE = os.environ.get("FDHIP_PROFILE_CALLS", "0") in ("1", "2")
 call_times = {}          # FDHIP_PROFILE_CALLS=1: C-ABI entry point -> [calls, seconds incl. the device work it queued]
 
 

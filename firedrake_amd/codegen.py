@@ -186,12 +186,10 @@ def generate_tensor_wrapper(gk: GlobalKernel) -> WrapperSource:
         if lg:
             layout += [("mat_row_lgmap", 0), ("mat_col_lgmap", 0)]
             params += ["const int *__restrict__ rlg0", "const int *__restrict__ clg0"]
-        # tp_fresh: 1 when the host zeroed only the rows shared between cells for this assembly (Parloop._tp_values): the rows
-        # one cell owns alone are then stored, not accumulated
-        layout += [("tp_tables",), ("tp_fresh", 0)]
-        params += ["const double *__restrict__ tptab", "int fresh0"]
+        layout += [("tp_tables",)]
+        params += ["const double *__restrict__ tptab"]
         body = (f"{cfdecl}\n  fdt::hex_qk_matrix<{geom['k1']}, {geom['q1']}, {nck}, {nc1}>(start, end, layers, arg0, arg1, cf, c1, map0, map1, rp0, tpo0, "
-                f"{'rlg0, clg0' if lg else 'nullptr, nullptr'}, tptab, fresh0, {call_w});")
+                f"{'rlg0, clg0' if lg else 'nullptr, nullptr'}, tptab, {call_w});")
         threads = geom["matrix_threads"]
         # 4 NT accumulator registers per lane: Q4 (NT = 8) fits three wavefronts per SIMD
         bounds = f"{threads}, 3" if geom["tiles"] <= 8 and threads == 256 else f"{threads}"
@@ -670,7 +668,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                                       f"const int r0_{k} = {rp_}[n0_{k}], nnzb{k} = {rp_}[n0_{k} + nown{k}] - r0_{k};"])
                 # (by capacity when the index rows are requested early: the block's row starts -- a second level of dependent scalar
                 # loads -- are then needed by the flush only, and nothing ahead of the main loop waits for them)
-                zcount = f"(int)oc{k}_maxnnz" if configuration["early_loads"] else f"nnzb{k}"
+                zcount = f"(int)oc{k}_maxnnz" if configuration["prefetch"] else f"nnzb{k}"
                 stage.append((rm, f"for (int q = tid; q < {zcount}; q += nthr) sm{k}[q] = 0;"))
                 # column masking (BC columns, pyop2/parloop.py:279-302) stays in the loop: a masked contribution adds 0.0.  Moving
                 # it to the row flush (one bit per CSR entry) removes 48 VALU instructions per instance and is NOT faster --
@@ -731,8 +729,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                     # trip: FU places are requested together -- and the first trip's (all of them for a block within budget)
                     # BEFORE the barrier that ends the main loop, so the flush itself waits for no load (profiles/r5a_phase_times.txt:
                     # the flush was 4.2 of a block's 17.5 microseconds)
-                    preload = bool(configuration["flush_preload"])
-                    FU = 8 if preload else max(1, int(configuration["flush_batch"]))
+                    preload, FU = True, 8
                     ld = (f"for (int f = 0; f < {FU}; ++f) {{ const int q = Q0 + f*nthr; g{k}[f] = q < nnzb{k} ? oc{k}_gpos[(size_t)r0_{k} + q] : -1; }}")
                     if preload:
                         flush_pre_decl.append(f"int g{k}[{FU}];")
@@ -943,7 +940,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
 
         # the first trip's index rows are requested BEFORE the staging phase (they depend on the block's bounds only), so the
         # block pays one memory round trip ahead of its main loop -- staging and index rows side by side -- instead of two
-        early = bool(pf and configuration["early_loads"])
+        early = pf
         if early:
             src += prologue()
         src += stage_src
@@ -996,7 +993,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 for piece in line.split(";"):
                     if ("sm%d[" % K_) in piece and "fdw::fx_get" not in piece:
                         raise ValueError("fixed-point accumulation: an accumulator access of this flush is not covered: " + piece.strip())
-            zcount_ = f"(int)oc{K_}_maxnnz" if configuration["early_loads"] else f"nnzb{K_}"
+            zcount_ = f"(int)oc{K_}_maxnnz" if configuration["prefetch"] else f"nnzb{K_}"
             src += ["  " + s_ for s_ in flush_pre_decl]
             src += [f"  const fdw::fx_block_t fd_rec = fx{K_}_scale[b];",
                     "  const double fd_S = fd_rec.S, fd_iS = fd_rec.invS;",
@@ -1264,7 +1261,7 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     # early: the first trip's index rows are requested ahead of the staging phase, the accumulators are zeroed by capacity and the
     # run displacements are staged after the main loop -- nothing before the main loop waits for the block's row starts or runs
     # (a second level of dependent scalar loads), and the block pays one memory round trip before its first trip instead of two
-    early = bool(configuration["prefetch"] and configuration["early_loads"])
+    early = bool(configuration["prefetch"])
     src += [f"  const int n0 = oc{K}_rblk[b], nown = oc{K}_rblk[b+1] - n0;",
             f"  const int r0 = oc{K}_rowptr[n0], nnzb = (oc{K}_rowptr[n0 + nown] - r0)*{B};"]
     if runflush:
@@ -1351,13 +1348,11 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         out = [f"{prefix}{n} = {ex.replace('II', ii)};" for n, ex in scal]
         out += [ld.replace("II", ii).replace("DST", prefix + n) for n, _, ld in rows]
         return out
-    # prefetch distance: the index rows of the lane's next instance (1) or of the next two (2: a lane makes ~5 trips per block and a
-    # trip is ~300 instructions -- less than one HBM round trip under load)
-    pf2 = bool(pf and int(configuration["ocrs_prefetch"]) >= 2 and not dofmask)
+    # (prefetch distance one: requesting the index rows two trips ahead measured no faster, profiles/r4k_ab_p2_prefetch_plancopies.txt)
     for n, ln, _ in rows:
         ty = "unsigned" if rec else "int"
-        src.append(f"  {ty} {n}[{ln}];" + (f" {ty} nx_{n}[{ln}];" if pf else "") + (f" {ty} n2_{n}[{ln}];" if pf2 else ""))
-    src.append("  int " + ", ".join(f"{n} = 0" + (f", nx_{n} = 0" if pf else "") + (f", n2_{n} = 0" if pf2 else "") for n, _ in scal) + ";")
+        src.append(f"  {ty} {n}[{ln}];" + (f" {ty} nx_{n}[{ln}];" if pf else ""))
+    src.append("  int " + ", ".join(f"{n} = 0" + (f", nx_{n} = 0" if pf else "") for n, _ in scal) + ";")
     if dofmask:
         src.append("  unsigned long long cmask = 0" + (", nx_cmask = 0;" if pf else ";"))
     if pf:
@@ -1365,17 +1360,11 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         src += ["    " + l for l in loads("(e0 + tid)", "")]
         if dofmask:
             src.append(f"    cmask = oc{K}_cmask[(e0 + tid) - start];")
-        if pf2:
-            src.append("    const int it1 = (e0 + tid + nthr < e1) ? e0 + tid + nthr : e0 + tid;")
-            src += ["    " + l for l in loads("it1", "nx_")]
         src.append("  }")
     if early:
         src += stage_src
     src.append("  for (int it = e0 + tid; it < e1; it += nthr) {")
-    if pf2:
-        src.append("    const int itn = (it + 2*nthr < e1) ? it + 2*nthr : it;")
-        src += ["    " + l for l in loads("itn", "n2_")]
-    elif pf:
+    if pf:
         src.append("    const int itn = (it + nthr < e1) ? it + nthr : it;")
         src += ["    " + l for l in loads("itn", "nx_")]
         if dofmask:
@@ -1397,20 +1386,16 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     if pf:
         for n, ln, _ in rows:
             src.append(f"    for (int q = 0; q < {ln}; ++q) {n}[q] = nx_{n}[q];")
-            if pf2:
-                src.append(f"    for (int q = 0; q < {ln}; ++q) nx_{n}[q] = n2_{n}[q];")
         src.append("    " + " ".join(f"{n} = nx_{n};" for n, _ in scal) + (" cmask = nx_cmask;" if dofmask else ""))
-        if pf2:
-            src.append("    " + " ".join(f"nx_{n} = n2_{n};" for n, _ in scal))
     src.append("  }")
     # Flushes through tables (derived row orders): the table entries are global loads the stores depend on, so a trip of the flush
     # loop costs a memory round trip.  FU entries are requested together, and the first trip's (all of them for a block within
     # budget) BEFORE the barrier that ends the main loop: the flush itself then waits for no load (profiles/r5a_phase_times.txt:
     # the flush was 7.0 of a block's 17.7 microseconds on the CG2 share)
-    preload = bool(configuration["flush_preload"])
+    preload = True
     post_flush = []
     if runflush:
-        FU = 16 if preload else max(1, int(configuration["flush_batch"]))
+        FU = 16
         ld = f"for (int f = 0; f < {FU}; ++f) {{ const int q = Q0 + f*nthr; g[f] = (int)oc{K}_grun[(size_t)r0 + (q < nnzb ? q : nnzb - 1)]; }}"
         if preload:
             src += [f"  int g[{FU}];", "  " + ld.replace("Q0", "tid")]
@@ -1422,7 +1407,7 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
                           f"for (int f = 0; f < {FU}; ++f) if (q0 + f*nthr < nnzb) arg{K}[(size_t)g[f]] = o[f] + sm{K}[q0 + f*nthr]; }} }}")
     elif ordered:
         # row by row, 16 lanes per row: start / length / place of FU rows per lane group
-        FU = 8 if preload else max(1, int(configuration["flush_batch"]))
+        FU = 8
         ld = (f"for (int f = 0; f < {FU}; ++f) {{ const int fr = FR0 + f*(nthr >> 4); const int fp = n0 + (fr < nown ? fr : 0); "
               f"const int a = oc{K}_rowptr[fp], b_ = oc{K}_rowptr[fp+1]; fs[f] = (a - r0)*{B}; fl[f] = fr < nown ? (b_ - a)*{B} : 0; "
               f"fd_[f] = (size_t)oc{K}_gstart[fp]*{B}; }}")
@@ -1457,7 +1442,7 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
 
 
 def lds_stride(max_nd: int, ocr: bool = False) -> int:
-    """Node stride of a staged LDS array: the block maximum, rounded up to a multiple of FDHIP_LDS_CONST_STRIDE when the
+    """Node stride of a staged LDS array: the block maximum, rounded up to a multiple of configuration["lds_const_stride"] when the
     stride is compiled in (staged loops; owner-computes-rows loops keep run-time strides: compiled in they were 2 % slower,
     profiles/r1j_ab_lds_const_stride.txt); 0 = run-time stride, 1 = exact, 64 makes component offsets multiples of 512 bytes so
     that pairs of accesses fuse into ds_read2st64_b64 -- at the price of a larger LDS footprint, which costs a resident

@@ -294,14 +294,12 @@ int exchange_end(fd_halo_t h, void *dat, int cdim, int dtype, int dir, int op, f
                 hipLaunchKernelGGL(unpack_rows_t<T>, dim3(grid_for(nin * cdim)), dim3(256), 0, s, (T *)dat, cdim, iidx, nin, (const T *)sl->rbuf, op);
                 return 0;
             }
-            const char *fr = getenv("FDHIP_HALO_FUSED_REVERSE");      // (read per call: the self-neighbour test compares both paths)
-            const bool per_neighbour = fr && atoi(fr) == 0;
-            if (h->comb_node && !per_neighbour) {               // shared owned nodes: node-major combine, one launch
+            if (h->comb_node) {                                 // shared owned nodes: node-major combine, one launch
                 hipLaunchKernelGGL(combine_rows_t<T>, dim3(grid_for(h->ncomb * cdim)), dim3(256), 0, s, (T *)dat, cdim, h->comb_node, h->comb_ptr,
                                    h->comb_pos, h->ncomb, (const T *)sl->rbuf, op);
                 return 0;
             }
-            for (size_t k = 0; k < h->peer.size(); ++k) {       // (FDHIP_HALO_FUSED_REVERSE=0: one neighbour after the other)
+            for (size_t k = 0; k < h->peer.size(); ++k) {       // (no combine tables: one neighbour after the other)
                 const int64_t n = h->nsend[k];
                 if (n > 0)
                     hipLaunchKernelGGL(unpack_rows_t<T>, dim3(grid_for(n * cdim)), dim3(256), 0, s, (T *)dat, cdim, iidx + h->soff[k], n,

@@ -216,27 +216,6 @@ inline int grid_for(int64_t n, int block = 256) {
 
 }  // namespace
 
-// zero every row whose length differs from skip_len.  The tensor-product matrix wrapper stores the rows a single cell owns (exactly
-// as long as the element matrix is wide) instead of accumulating into them (fd_tensor.h, hex_qk_matrix).  A workgroup takes
-// ZR_ROWS consecutive rows = one contiguous piece of the value array and walks it entry by entry (coalesced stores; the entry's row
-// is found by bisection of the piece's row starts in LDS) -- a wavefront per row left half of every second store instruction empty
-// and ran at 3.7 TB/s against the 6.5 TB/s of a plain fill (profiles/r4m_c3_single_rows.txt).
-constexpr int ZR_ROWS = 32;
-__global__ __launch_bounds__(256) void zero_rows_except(int32_t nrows, const int32_t *__restrict__ rowptr, double *__restrict__ vals,
-                                                        int32_t skip_len) {
-    __shared__ int32_t rp[ZR_ROWS + 1];
-    const int64_t r0 = (int64_t)blockIdx.x * ZR_ROWS;
-    const int nr = (int)((nrows - r0) < ZR_ROWS ? (nrows - r0) : ZR_ROWS);
-    if ((int)threadIdx.x <= nr) rp[threadIdx.x] = rowptr[r0 + threadIdx.x];
-    __syncthreads();
-    const int32_t a = rp[0], b = rp[nr];
-    for (int32_t p = a + (int32_t)threadIdx.x; p < b; p += 256) {
-        int lo = 0, hi = nr - 1;                            // largest row with rp[row] <= p
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (rp[mid] <= p) lo = mid; else hi = mid - 1; }
-        if (rp[lo + 1] - rp[lo] != skip_len) vals[p] = 0.0;
-    }
-}
-
 extern "C" {
 
 // layers visited and stacked cells of one (pair, region): sparsity.pyx:291-305, 331-346
@@ -509,14 +488,6 @@ int fd_csr_zero_rows(const int32_t *rowptr, const int32_t *colidx, double *vals,
                      double v, fd_stream_t s) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(set_diag, dim3(grid_for(n)), dim3(256), 0, fd::st(s), rowptr, colidx, vals, rows, n, v, 1);
-    FD_CHECK_LAUNCH();
-    return 0;
-}
-
-int fd_csr_zero_rows_except(int32_t nrows, const int32_t *rowptr, double *vals, int32_t skip_len, fd_stream_t s) {
-    if (nrows <= 0) return 0;
-    if (!rowptr || !vals) FD_FAIL("fd_csr_zero_rows_except: bad arguments");
-    hipLaunchKernelGGL(zero_rows_except, dim3((nrows + ZR_ROWS - 1) / ZR_ROWS), dim3(256), 0, fd::st(s), nrows, rowptr, vals, skip_len);
     FD_CHECK_LAUNCH();
     return 0;
 }

@@ -308,9 +308,8 @@ static int plan_build(fd_plan_s *p, const int32_t *map_dev, hipStream_t s) {
     const int64_t n = (int64_t)p->end - p->start;
     int n2 = PT;
     while (n2 < p->epb * arity) n2 <<= 1;
-    // hash-set builder when twice the entries of the largest block fit the LDS (FDHIP_PLAN_SORT=1 keeps the two-pass sort)
-    static const bool force_sort = getenv("FDHIP_PLAN_SORT") && atoi(getenv("FDHIP_PLAN_SORT")) != 0;
-    if (!force_sort && 2 * n2 <= PT * MAXCHUNK) return plan_build_hash(p, map_dev, 2 * n2, s);
+    // hash-set builder when twice the entries of the largest block fit the LDS, else the two-pass sort
+    if (2 * n2 <= PT * MAXCHUNK) return plan_build_hash(p, map_dev, 2 * n2, s);
     size_t lds = (size_t)n2 * sizeof(int);
     if (lds > 48 * 1024)
         FD_HIP(hipFuncSetAttribute((const void *)plan_pass, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -125,7 +125,7 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
                                               const int *__restrict__ map_qk,
                                               const int *__restrict__ map_q1, const int *__restrict__ rowptr,
                                               const unsigned short *__restrict__ offtab, const int *__restrict__ rlg,
-                                              const int *__restrict__ clg, const double *__restrict__ tables, int fresh, WF weights) {
+                                              const int *__restrict__ clg, const double *__restrict__ tables, WF weights) {
     constexpr int ND = K1 * K1 * K1, NQ = Q1 * Q1 * Q1, NT = tp_tiles(K1), WPB = tp_waves(NT), WGC = NT / WPB, NTAB = Q1 * K1;
     __shared__ double sL[NTAB], sDL[NTAB], sQP[Q1], sQW[Q1];
     __shared__ double sX[24];
@@ -235,29 +235,18 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
         cn[t] = cok[t] ? mrow[j] + OFF * lrel : 0;
         if (cok[t] && clg) cok[t] = clg[cn[t]] >= 0;
     }
-    // A row as long as the element matrix is wide belongs to this cell alone (the cell-interior nodes, (k-1)^3 of (k+1)^3: 22 % of
-    // the entries of Q4; any row shared with a second cell is longer): nobody else writes it.  ``fresh`` = the host zeroed only the
-    // SHARED rows (fd_csr_zero_rows_except) and the stores below overwrite the rest, dropped rows and columns (boundary conditions)
-    // with zeros.  Without it every row takes atomics (a load-add-store of the single-cell rows measured 7 % slower than the
-    // fire-and-forget atomics: profiles/r4m_c3_single_rows.txt).
+    // every row takes fire-and-forget atomics (storing the rows one cell owns alone -- the cell-interior nodes, 22 % of the entries
+    // of Q4 -- and zeroing only the shared ones was built and measured 1 % slower: profiles/r4m_c3_single_rows.txt, r4n_c3_single_rows.txt)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int i = itile * 16 + kk + 4 * g;
         if (i >= ND) continue;
         const int rn = mrow[i] + OFF * lrel;
-        const bool rdrop = rlg && rlg[rn] < 0;
-        const int r0i = rowptr[rn];
-        const bool single = rowptr[rn + 1] - r0i == ND;
-        const size_t r0 = (size_t)r0i;
-        if (single && fresh) {
+        if (rlg && rlg[rn] < 0) continue;
+        const size_t r0 = (size_t)rowptr[rn];
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (jv[t]) vals[r0 + tab[i * ND + t * 16 + r16]] = (rdrop || !cok[t]) ? 0.0 : acc[t][g];
-        } else if (!rdrop) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (cok[t]) atomicAdd(&vals[r0 + tab[i * ND + t * 16 + r16]], acc[t][g]);
-        }
+        for (int t = 0; t < NT; ++t)
+            if (cok[t]) atomicAdd(&vals[r0 + tab[i * ND + t * 16 + r16]], acc[t][g]);
     }
 }
 

@@ -1997,7 +1997,7 @@ class OcrPlan:
             return 1
         if order == "natural":
             return 0
-        raise ValueError("FDHIP_OCR_ORDER must be stencil or natural")
+        raise ValueError('configuration["ocr_order"] must be "stencil" or "natural"')
 
     def __del__(self):
         try:
@@ -2330,20 +2330,10 @@ class Mat:
     def nblock_cols(self):
         return self._sparsity.dsets[1].set.size
 
-    # > 0: only the rows LONGER or shorter than this were zeroed by the last zero() -- the rows of exactly this length are about to be
-    # overwritten by a tensor-product matrix loop (Parloop._tp_zero_ahead); any other consumer first turns it into a full zero
-    _single_stale = 0
-
-    def _settle_partial_zero(self):
-        if self._single_stale:
-            self._single_stale = 0
-            self._zero_pending = True
-
     def _values_dev(self):
         """Device values; performs a pending zero() first (anything but a fused staged assembly sees
         the zeroed matrix)."""
         v = self._values_raw()
-        self._settle_partial_zero()
         if self._zero_pending:
             v.zero()
             self._zero_pending = False
@@ -2369,7 +2359,6 @@ class Mat:
         fuses the zeroing pass into the assembly kernel.  Any other access flushes it."""
         self._values_raw()
         self._zero_pending = True
-        self._single_stale = 0
         self.dat_version += 1
 
     def assemble(self):             # mat.py:940-954: nothing is stashed off-process here

@@ -639,7 +639,7 @@ class Parloop:
                 acc = self.accesses[desc[1]]
                 if isinstance(pa, MatParloopArg):
                     pa.data.dat_version += 1
-                    out.append(self._tp_values(pa, start, end).ptr if src.mode == "tp_matrix" else pa.data._values_dev().ptr)
+                    out.append(pa.data._values_dev().ptr)
                 else:
                     out.append(pa.data._dev_ptr(write=acc != READ))
             elif kind == "map":
@@ -693,53 +693,16 @@ class Parloop:
                 out.append(self._tp_offtab(desc[1]).ptr)
             elif kind == "tp_tables":
                 out.append(self._tp_tables().ptr)
-            elif kind == "tp_fresh":
-                out.append(self._tp_fresh)
             else:
                 raise AssertionError(kind)
         return out, geo
 
     # -- tensor-product wrappers (csrc/fd_tensor.h) ------------------------------------------------------------------
-    _tp_fresh = 0
-
-    def _tp_values(self, pa, start, end):
-        """Values of the Mat a tensor-product matrix loop assembles into.  A pending Mat.zero() (mat.py:851-855) is carried out here.
-        With FDHIP_TP_STORE_SINGLE_ROWS=1 (off by default: the partial zero + stores measured 1 % slower at C3 size than the plain
-        fill + atomics on every row, profiles/r4n_c3_single_rows.txt -- the fire-and-forget atomics are not what the kernel waits
-        for), when this launch covers every cell of the set, only the rows SHARED between cells are zeroed and the wrapper is told to store
-        the rows a single cell owns (``fresh``; the (k-1)^3 cell-interior nodes of Q_k and the corners of the domain: 22 % of the
-        entries of a Q4 operator) -- one pass less over those entries and no atomics on them.  Anything else (a partial launch, an
-        accumulating assembly) zeroes the whole matrix and the wrapper adds into every row with atomics."""
-        mat = pa.data
-        self._tp_fresh = 0
-        if configuration["tp_store_single_rows"] and start == 0 and end == self.iterset.total_size:
-            nd = pa.maps[0]._base().arity
-            self._tp_zero_ahead(mat, nd)
-            if mat._single_stale == nd:
-                mat._single_stale = 0
-                self._tp_fresh = 1
-                return mat._values_raw()
-        return mat._values_dev()
-
-    @staticmethod
-    def _tp_zero_ahead(mat, nd):
-        """Carry out a pending Mat.zero() on the rows that are not exactly ``nd`` long and mark the others stale
-        (Mat._single_stale: whoever touches the matrix before the loop that overwrites them gets a full zero instead)."""
-        if mat._zero_pending:
-            sp = mat.sparsity
-            _lib.call("fd_csr_zero_rows_except", sp.dsets[0].set.total_size, sp._node_rowptr.ptr, mat._values_raw().ptr, nd, None)
-            mat._zero_pending = False
-            mat._single_stale = nd
-
     def zero_ahead(self):
         """Perform the zeroing this loop would do at its launch now (benchmarks bracket the kernel without it)."""
-        if self._prepare()["cw"].src.mode == "tp_matrix" and configuration["tp_store_single_rows"]:
-            pa = self.arguments[0]
-            self._tp_zero_ahead(pa.data, pa.maps[0]._base().arity)
-        else:
-            for pa in self.arguments:
-                if isinstance(pa, MatParloopArg):
-                    pa.data._values_dev()
+        for pa in self.arguments:
+            if isinstance(pa, MatParloopArg):
+                pa.data._values_dev()
 
     def _tp_tables(self):
         """1-D tabulation of the element (values and derivatives of the CG_k GLL basis at the Gauss points, points,
@@ -1150,7 +1113,6 @@ class Parloop:
                     mat.dat_version += 1
                     vals = mat._values_raw()
                     flag = 0
-                    mat._settle_partial_zero()
                     if mat._zero_pending:
                         # rows outside the blocks (ghost rows) are the only part the loop does not overwrite
                         tail = (geo["nnz"] - op.vals_end) * 8

@@ -303,9 +303,6 @@ int fd_csr_set_diagonal(const int32_t *rowptr_dev, const int32_t *colidx_dev, do
                         const int32_t *rows_dev, int32_t nrows_sel, double value, fd_stream_t s);
 int fd_csr_zero_rows(const int32_t *rowptr_dev, const int32_t *colidx_dev, double *vals_dev,
                      const int32_t *rows_dev, int32_t nrows_sel, double value, fd_stream_t s);
-/* Mat.zero() (mat.py:851-855) ahead of an assembly that STORES the rows of length skip_len (the rows one tensor-product cell owns
- * alone, csrc/fd_tensor.h): every other row is zeroed, those are left for the wrapper to overwrite */
-int fd_csr_zero_rows_except(int32_t nrows, const int32_t *rowptr_dev, double *vals_dev, int32_t skip_len, fd_stream_t s);
 /* y = A x  (parity identity  A*x == action(a, x), tests/firedrake/regression/test_matrix_free.py:97-123) */
 int fd_csr_spmv(int32_t nrows, const int32_t *rowptr_dev, const int32_t *colidx_dev,
                 const double *vals_dev, const double *x_dev, double *y_dev, fd_stream_t s);

@@ -607,13 +607,12 @@ def run_direct(pl, part=None):
     return [outs.get(k) for k in range(len(pl.arguments))]
 
 
-def run_tensor(pl, fresh=0, initial=None):
+def run_tensor(pl, initial=None):
     """Execute a tensor-product Parloop ``pl`` (codegen modes tp_action / tp_matrix) on the host: the generated wrapper and the
     REAL device templates of firedrake_amd/csrc/fd_tensor.h, compiled against the stand-in header (one OS thread per lane;
     the fp64 MFMA is restated there from the operand layout the templates rely on).  Returns one entry per argument like
     run_direct: copies of the Dats after the loop, an OracleCSR for the Mat.  ``initial``: values of the Mat before the loop (default
-    zeros); ``fresh`` = 1 restates Parloop._tp_values: the rows shared between cells are zeroed, the rest are left as they are and the
-    wrapper is told to store them."""
+    zeros)."""
     import re
     from firedrake_amd.codegen import generate_tensor_wrapper
     from firedrake_amd.tensor import gll_gauss_tables
@@ -657,9 +656,6 @@ def run_tensor(pl, fresh=0, initial=None):
                 csr = oracle_pattern(pa.data.sparsity)
                 if initial is not None:
                     csr.values[:] = initial
-                if fresh:                                   # fd_csr_zero_rows_except
-                    rl = np.diff(csr.rowptr)
-                    csr.values[np.repeat(rl != pa.maps[0]._base().arity, rl)] = 0.0
                 outs[desc[1]] = csr
                 cargs.append(ctypes.c_void_p(csr.values.ctypes.data))
             else:
@@ -669,8 +665,6 @@ def run_tensor(pl, fresh=0, initial=None):
                 cargs.append(ctypes.c_void_p(a.ctypes.data))
         elif kind == "map":
             cargs.append(ptr(np.asarray(maps[desc[1]].values_with_halo, dtype=np.int32)))
-        elif kind == "tp_fresh":
-            cargs.append(ctypes.c_int(int(fresh)))
         elif kind == "mat_rowptr":
             cargs.append(ptr(np.asarray(csr.rowptr, dtype=np.int32)))
         elif kind == "tp_offtab":

@@ -340,27 +340,20 @@ def test_coefficient_arguments_through_the_tensor_wrappers(degree, nq, n, layers
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("degree,nq,bcs", [(4, 5, True), (2, 3, False), (1, 2, True)])
-def test_single_cell_rows_are_stored_after_zero_and_accumulated_without(degree, nq, bcs, monkeypatch):
-    """FDHIP_TP_STORE_SINGLE_ROWS=1: after Mat.zero() the tensor-product matrix loop zeroes only the rows shared between cells and
-    stores the others (Parloop._tp_values, fd_csr_zero_rows_except); the values are those of the full-zero route and of the oracle.
-    Stale contents must not survive, a second loop without zero() adds on top (Mat INC, mat.py:851-855; atomics on every row), and
-    a consumer arriving between the partial zero and the loop sees a matrix of zeros."""
-    from firedrake_amd.configuration import configuration
-    monkeypatch.setitem(configuration, "tp_store_single_rows", 1)      # (off by default: 1 % slower than fill + atomics at C3 size)
+def test_matrix_loop_after_zero_and_without(degree, nq, bcs):
+    """The tensor-product matrix loop after Mat.zero() gives the oracle's values whatever the Mat held before; a second loop
+    without zero() adds on top (Mat INC, mat.py:851-855); zeroing ahead of the loop (what the kernel-only timing does) shows a
+    matrix of zeros to whoever looks in between."""
     m = fmesh.make_extruded_hex_mesh(3, 3, degree, perturb=0.1)
     prob = forms.HelmholtzHexProblem(m, bcs=bcs, nq=nq)
     ref = _oracle_matrix(m, prob.bc_nodes if bcs else None, prob.kjac)
     tol = 1e-11 * np.abs(ref.values).max()
     loop, mat = prob.jac_loop, prob.mat
-    rl = np.diff(ref.rowptr)
-    assert ((rl == (degree + 1) ** 3).sum() >= 27 * (degree - 1) ** 3) and (rl != (degree + 1) ** 3).any()
     prob.assemble_jacobian()
     prob.assemble_jacobian()                  # the second time over stale values
-    assert loop._tp_fresh == 1
     v = mat.csr()[2]
     assert_allclose(v, ref.values, rtol=0, atol=tol)
     loop()                                    # no zero(): accumulates
-    assert loop._tp_fresh == 0
     twice = mat.csr()[2]
     bcrows = np.zeros(len(v), dtype=bool)
     if bcs:
@@ -368,22 +361,13 @@ def test_single_cell_rows_are_stored_after_zero_and_accumulated_without(degree, 
         for b in prob.bc_nodes:
             bcrows[rp[b] + np.searchsorted(ci[rp[b]:rp[b + 1]], b)] = True
     assert_allclose(twice[~bcrows], 2 * ref.values[~bcrows], rtol=0, atol=2 * tol)
-    # zero ahead (what the kernel-only timing does), then look at the matrix before the loop runs: all zeros, and the loop still right
     mat.zero()
     loop.zero_ahead()
-    assert mat._single_stale == (degree + 1) ** 3
     assert not mat.csr()[2].any()
-    assert mat._single_stale == 0
     loop()
     got = mat.csr()[2]
     assert_allclose(got[~bcrows], ref.values[~bcrows], rtol=0, atol=tol)
-    # events route of the benchmark
     import torch
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     prob.assemble_jacobian(events=ev)
-    assert loop._tp_fresh == 1
-    assert_allclose(mat.csr()[2], ref.values, rtol=0, atol=tol)
-    monkeypatch.setitem(configuration, "tp_store_single_rows", 0)
-    prob.assemble_jacobian()
-    assert loop._tp_fresh == 0
     assert_allclose(mat.csr()[2], ref.values, rtol=0, atol=tol)

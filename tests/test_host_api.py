@@ -112,3 +112,47 @@ def test_composed_map_tables():
         assert m.values.tolist() == [[4, 5], [6, 7]] and m.iterset is setC and m.toset is nodesetA
     with pytest.raises(op2.MapValueError):
         op2.ComposedMap(mapA0, mapA0)          # inner maps must have arity 1 / matching sets
+
+
+def test_environment_switches_are_few_and_every_one_is_read():
+    """The FDHIP_* switches of the product (pyop2/configuration.py:41-166 has ~25 PYOP2_* ones): at most 30 names under firedrake_amd/,
+    and every environment-backed configuration entry really follows its variable (the module re-read under a changed environment)."""
+    import glob
+    import importlib
+    import os
+    import re
+    import firedrake_amd
+    from firedrake_amd import configuration as cfgmod
+    root = os.path.dirname(firedrake_amd.__file__)
+    names = set()
+    for pat in ("*.py", "csrc/*.hip", "csrc/*.h"):
+        for fn in glob.glob(os.path.join(root, pat)):
+            with open(fn) as fh:
+                names |= set(re.findall(r"FDHIP_[A-Z0-9_]+", fh.read()))
+    expected = {"FDHIP_HIPCC", "FDHIP_ARCH", "FDHIP_CFLAGS", "FDHIP_CACHE_DIR", "FDHIP_DEBUG", "FDHIP_TRACE", "FDHIP_TYPE_CHECK", "FDHIP_PHASE_TIMES",
+                "FDHIP_MODE", "FDHIP_LDS_LIMIT", "FDHIP_PREFETCH", "FDHIP_PLAN_COPIES", "FDHIP_LOCALITY_ORDER", "FDHIP_TENSOR_WRAPPERS", "FDHIP_MAT_OCR",
+                "FDHIP_OCR_SLICED", "FDHIP_OCR_RECORDS", "FDHIP_OCR_FIXED_POINT", "FDHIP_OCR_NNZ", "FDHIP_OCR_NNZ_ORDERED", "FDHIP_OCRS_NNZ",
+                "FDHIP_OCRS_BLOCK_THREADS", "FDHIP_UNROLL_RETRY", "FDHIP_AUTO_OCCUPANCY_SCRATCH",
+                "FDHIP_HALO_WIRE", "FDHIP_PROFILE_CALLS", "FDHIP_SKIP_TORCH", "FDHIP_CSR_CHUNK"}
+    assert names == expected and len(names) <= 30
+    # entries of configuration.py: the integer ones take "7", the string ones "x7"
+    with open(cfgmod.__file__) as fh:
+        entries = re.findall(r'"(\w+)": _env\("(FDHIP_\w+)", [^,)]+(, int)?\)', fh.read())
+    assert len(entries) == 23              # (+ cache_dir, whose default is an expression)
+    saved = {v: os.environ.get(v) for _, v, _ in entries}
+    try:
+        for _, var, is_int in entries:
+            os.environ[var] = "7" if is_int else "x7"
+        fresh = importlib.reload(cfgmod).configuration
+        for key, var, is_int in entries:
+            assert fresh[key] == (7 if is_int else "x7"), (key, var)
+    finally:
+        for var, val in saved.items():
+            if val is None:
+                os.environ.pop(var, None)
+            else:
+                os.environ[var] = val
+        restored = importlib.reload(cfgmod).configuration
+        # (the package's other modules hold the ORIGINAL dictionary object: put the restored values into it)
+        from firedrake_amd.codegen import configuration as live
+        live.update(restored)

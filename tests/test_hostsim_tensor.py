@@ -140,30 +140,16 @@ def test_a_coefficient_on_the_q1_map_through_the_tensor_templates_on_the_host(de
 
 
 @pytest.mark.parametrize("degree,nq,n,bcs", [(2, 3, 2, False), (2, 3, 2, True), (3, 4, 1, True), (1, 2, 2, False)])
-def test_rows_owned_by_one_cell_are_stored_after_a_zero_and_accumulated_otherwise(degree, nq, n, bcs):
-    """hex_qk_matrix stores the rows exactly as long as the element matrix is wide (the cell-interior nodes; for Q1 the corners of
-    the domain) when the host zeroed only the shared rows (fresh = 1): started from a matrix full of NaNs, every entry must come out
-    as the oracle's -- zeros in the dropped boundary rows and columns included.  fresh = 0 on top of earlier values accumulates
-    (Mat INC without a zero(), mat.py:851-855), with atomics on every row."""
+def test_matrix_template_accumulates_on_top_of_existing_values(degree, nq, n, bcs):
+    """hex_qk_matrix adds into every row with atomics: a loop without a zero() accumulates on top of what the Mat holds (Mat INC,
+    mat.py:851-855); dropped boundary rows and columns stay untouched."""
     m = fmesh.make_extruded_hex_mesh(n, 2, degree, perturb=0.1)
     prob = forms.HelmholtzHexProblem(m, bcs=bcs, nq=nq)
     ref = _oracle_matrix(m, prob.bc_nodes if bcs else None, prob.kjac)
     rp, ci = ref.rowptr, ref.colidx
-    rl = np.diff(rp)
-    single = np.repeat(rl == (degree + 1) ** 3, rl)
-    assert single.any() and not single.all()
-
-    def with_diagonal(v):
-        v = v.copy()
-        for b in (prob.bc_nodes if bcs else ()):
-            v[rp[b] + np.searchsorted(ci[rp[b]:rp[b + 1]], b)] = 1.0
-        return v
-
     tol = 1e-12 * np.abs(ref.values).max()
-    fresh = hostsim.run_tensor(prob.jac_loop, fresh=1, initial=np.full(ref.values.shape, np.nan))[0]
-    assert_allclose(with_diagonal(fresh.values), ref.values, rtol=0, atol=tol)
     start = np.random.default_rng(5).standard_normal(ref.values.shape)
-    acc = hostsim.run_tensor(prob.jac_loop, fresh=0, initial=start)[0]
+    acc = hostsim.run_tensor(prob.jac_loop, initial=start)[0]
     expect = ref.values.copy()
     for b in (prob.bc_nodes if bcs else ()):
         expect[rp[b] + np.searchsorted(ci[rp[b]:rp[b + 1]], b)] = 0.0
