@@ -227,14 +227,14 @@ def staged_eligible(gk: GlobalKernel, mats_on_virtual: bool = False, need_indire
     plan is then built on a DERIVED map over the virtual iteration space -- the map rows of the subset's entities, resp.
     one row ``map + offset*layer`` per (column, layer) cell (builder.py:94-124 folded into the table once) -- so the kernel
     itself addresses nothing but local indices; only direct arguments need the base entity.  Restrictions: Dat-only
-    loops, constant layers, no periodic wrap, regions ALL / ON_BOTTOM / ON_TOP, and no direct Dat written on an extruded
-    set (all layers of a column share its row: parloop.py:494-497)."""
+    loops, no periodic wrap, regions ALL / ON_BOTTOM / ON_TOP (constant or variable layers), and no direct Dat written on an
+    extruded set (all layers of a column share its row: parloop.py:494-497)."""
     if gk._extruded or gk._subset:
         if any(isinstance(a, MatKernelArg) for a in gk.arguments) and not mats_on_virtual:
             return False          # (matrix loops over virtual spaces: row-sliced owner-computes-rows only, sliced_eligible)
         if gk._extruded:
-            if not gk._constant_layers or gk._extruded_periodic or gk._iteration_region == ON_INTERIOR_FACETS:
-                return False
+            if gk._extruded_periodic or gk._iteration_region == ON_INTERIOR_FACETS:
+                return False          # (variable layers qualify: the derived map and the cell tables are ragged, set.py:326-337)
             if any(isinstance(a, DatKernelArg) and not a.is_indirect and la.access != READ
                    for a, la in zip(gk.arguments, gk.local_kernel.arguments)):
                 return False
@@ -444,6 +444,12 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         P("const int *__restrict__ inst_ent_", ("ocr_inst_ent",))
     if ordered:
         P("const int *__restrict__ fd_order_", ("order",))
+    # variable layers: (position, layer) of every cell of the virtual iteration space, read where a direct argument or the layer
+    # argument needs them
+    vtab = bool(staged and varlay and (gk._pass_layer_arg or any(i_["kind"] == "dat" and "m" not in i_ for i_ in infos)))
+    if vtab:
+        P("const int *__restrict__ fd_vcol_", ("virt_col",))
+        P("const int *__restrict__ fd_vlay_", ("virt_layer",))
     staged_maps = []
     lds_items = []
     mat_staged = {}
@@ -901,7 +907,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         # direct arguments and the layer argument
         virt = bool(extruded or gk._subset or ordered)
         if virt:
-            if extruded:
+            if extruded and not varlay:
                 lo, hi = {ALL: ("layers[0]", "layers[1]-1"), ON_BOTTOM: ("layers[0]", "layers[0]+1"),
                           ON_TOP: ("layers[1]-2", "layers[1]-1")}[region]
                 src.append(f"  const int fd_llo = {lo}, fd_nlit = ({hi}) - fd_llo;")
@@ -916,7 +922,10 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         def decode(v):
             """virtual id (position in the subset x layer) -> base entity ``e`` (+ ``layer``)"""
             out = []
-            if extruded:
+            if extruded and varlay:
+                out.append(f"    const int fd_col = {'fd_vcol_[%s]' % v if vtab else '0'}; const int layer = {'fd_vlay_[%s]' % v if vtab else '0'};")
+                out.append("    const int e = " + ("subset_indices[fd_col];" if gk._subset else "fd_col;"))
+            elif extruded:
                 out.append(f"    const int fd_col = ({v}) / fd_nlit; const int layer = fd_llo + (({v}) - fd_col*fd_nlit);")
                 out.append("    const int e = " + ("subset_indices[fd_col];" if gk._subset else "fd_col;"))
             elif gk._subset:
@@ -1127,10 +1136,14 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     # virtual iteration spaces (subset / extruded): the instance's entity id is a position in the (subset x layer) space,
     # decoded only for direct arguments and the layer argument (every map row is a row of a derived map)
     extruded = bool(gk._extruded)
+    varlay = bool(extruded and not gk._constant_layers)
     if extruded:
         P("const int *__restrict__ layers", ("layers",))
     if gk._subset:
         P("const int *__restrict__ subset_indices", ("subset",))
+    if varlay and (gk._pass_layer_arg or any(isinstance(a, DatKernelArg) and not a.is_indirect for a in gk.arguments)):
+        P("const int *__restrict__ fd_vcol_", ("virt_col",))          # (position, layer) of every cell of the virtual space
+        P("const int *__restrict__ fd_vlay_", ("virt_layer",))
 
     infos = []
     for k, (a, la) in enumerate(zip(gk.arguments, lk.arguments)):
@@ -1283,7 +1296,7 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         stage_src.append("  if (tid == 0) fd_times[5*(size_t)b + 1] = wall_clock64();")
     if not early:
         src += stage_src
-    if extruded:
+    if extruded and not varlay:
         lo, hi = {ALL: ("layers[0]", "layers[1]-1"), ON_BOTTOM: ("layers[0]", "layers[0]+1"), ON_TOP: ("layers[1]-2", "layers[1]-1")}[gk._iteration_region]
         src.append(f"  const int fd_llo = {lo}, fd_nlit = ({hi}) - fd_llo;")
     # every 64 consecutive slots hold one local row index, and e0 / nthr are multiples of 64: the index is wave-uniform.
@@ -1374,7 +1387,10 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         if dofmask:
             src.append(f"    cmask = oc{K}_cmask[it - start];")
     if need_e and virt:
-        if extruded:
+        if extruded and varlay:
+            src += ["    const int fd_col = fd_vcol_[fd_v]; const int layer = fd_vlay_[fd_v];",
+                    "    const int e = " + ("subset_indices[fd_col];" if gk._subset else "fd_col;")]
+        elif extruded:
             src += ["    const int fd_col = fd_v / fd_nlit; const int layer = fd_llo + (fd_v - fd_col*fd_nlit);",
                     "    const int e = " + ("subset_indices[fd_col];" if gk._subset else "fd_col;")]
         else:

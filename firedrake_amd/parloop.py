@@ -302,6 +302,41 @@ def kd_leaf_size(v):
     return v if v < 128 else max(32 * int(round(v / 32.0)), 32)
 
 
+class VirtualSpace(tuple):
+    """Iteration space of a staged / owner-computes-rows loop over a Subset or an extruded set: the (position, layer) cells in
+    position-major order.  Constant layers: the tuple (cells per entity, first layer), a cell's id is position * cells + layer
+    offset.  Variable layers (``ragged``): ``prefix`` = first cell of every position, ``col`` / ``layer`` = position and absolute
+    layer of every cell -- the tables the wrapper decodes a cell with where it needs the base entity or the layer argument."""
+
+    def __new__(cls, pair, counts=None, first=None, bottom=None):
+        self = super().__new__(cls, pair)
+        self.ragged = counts is not None
+        if self.ragged:
+            counts = np.asarray(counts, dtype=np.int64)
+            self.prefix = np.concatenate([[0], np.cumsum(counts)])
+            self.col = np.repeat(np.arange(len(counts), dtype=np.int64), counts)
+            self.layer = np.asarray(first, dtype=np.int64)[self.col] + (np.arange(int(self.prefix[-1]), dtype=np.int64) - self.prefix[self.col])
+            self.bottom = np.asarray(bottom, dtype=np.int64)
+            self._dev = None
+        return self
+
+    def range(self, start, end):
+        """cells of the positions [start, end)"""
+        if self.ragged:
+            return int(self.prefix[start]), int(self.prefix[end])
+        return int(start) * self[0], int(end) * self[0]
+
+    def size(self, n):
+        return self.range(0, n)[1]
+
+    def tables_dev(self):
+        """(position, layer) of every cell as two int32 device arrays (variable layers)"""
+        if self._dev is None:
+            self._dev = (DeviceBuffer.from_numpy(np.ascontiguousarray(self.col, dtype=np.int32)),
+                         DeviceBuffer.from_numpy(np.ascontiguousarray(self.layer, dtype=np.int32)))
+        return self._dev
+
+
 class PlanDoesNotFit(_lib.FDHipError):
     """A staged / owner-computes-rows plan exceeds the LDS or the plan builder's per-block capacity: the Parloop demotes
     the loop to the next wrapper shape (ocr -> staged -> direct) before anything is launched."""
@@ -525,7 +560,9 @@ class Parloop:
 
     # -- virtual iteration space of staged loops over subsets / extruded sets
     def _virtual(self, staged=None):
-        """(layers per entity iterated, first layer) when the staged wrapper runs over a virtual space, else None."""
+        """The virtual iteration space the staged / owner-computes-rows wrappers run over when the set is a Subset or extruded: a
+        ``VirtualSpace`` -- (cells iterated per entity, first layer) for constant layers (usable as that tuple), a ragged space with
+        per-position tables for variable layers (set.py:326-337) -- else None."""
         gk = self.global_kernel
         if staged is None:
             mode = self._prepared["cw"].src.mode
@@ -533,15 +570,33 @@ class Parloop:
         if not (gk._extruded or gk._subset) or not staged:
             return None
         if not gk._extruded:
-            return (1, 0)
+            return VirtualSpace((1, 0))
         from .op2types import ON_BOTTOM, ON_TOP
-        bottom, top = (int(v) for v in self.iterset.layers_array[0])
         reg = gk._iteration_region
+        it = self.iterset
+        if not gk._constant_layers:
+            hit = self.__dict__.get("_virtual_var")
+            if hit is None:
+                # variable layers: entity e iterates the cells [bottom_e, top_e - 1) of its column (ALL), its first or its last one;
+                # positions of a Subset index the superset's rows (the layers array belongs to the superset, builder.py:744-752)
+                la = np.asarray(it.layers_array, dtype=np.int64)
+                if isinstance(it, Subset):
+                    la = la[np.asarray(it.indices, dtype=np.int64)]
+                ncell = np.maximum(la[:, 1] - 1 - la[:, 0], 0)
+                if reg == ON_BOTTOM:                       # (one trip per entity whatever its column holds: builder.py:790-812)
+                    cnt, first = np.ones_like(ncell), la[:, 0]
+                elif reg == ON_TOP:
+                    cnt, first = np.ones_like(ncell), la[:, 1] - 2
+                else:
+                    cnt, first = ncell, la[:, 0]
+                hit = self.__dict__["_virtual_var"] = VirtualSpace((0, 0), counts=cnt, first=first, bottom=la[:, 0])
+            return hit
+        bottom, top = (int(v) for v in it.layers_array[0])
         if reg == ON_BOTTOM:
-            return (1, bottom)
+            return VirtualSpace((1, bottom))
         if reg == ON_TOP:
-            return (1, top - 2)
-        return (top - 1 - bottom, bottom)
+            return VirtualSpace((1, top - 2))
+        return VirtualSpace((top - 1 - bottom, bottom))
 
     def _plan_map(self, m, staged=None):
         """The Map the block-localisation plans of this loop are built on: ``m`` itself, or its derived map over the
@@ -552,6 +607,17 @@ class Parloop:
         nlit, llo = v
         it = self.iterset
         sub = it.indices if isinstance(it, Subset) else None
+        if v.ragged:
+            key = ("virtual-var", None if sub is None else id(it), int(self.global_kernel._iteration_region))
+
+            def build_var():
+                rows = np.asarray(m.values_with_halo)
+                if sub is not None:
+                    rows = rows[sub]
+                off = np.asarray(m.offset, dtype=np.int64)
+                rel = v.layer - v.bottom[v.col]                    # cells above the entity's own bottom (builder.py:94-124)
+                return (rows[v.col] + off[None, :] * rel[:, None]).astype(rows.dtype)
+            return m.derived(key, build_var)
         bottom = int(it.layers_array[0][0]) if self.global_kernel._extruded else 0
         key = ("virtual", None if sub is None else id(it), nlit, llo)
 
@@ -630,7 +696,9 @@ class Parloop:
         out = []
         for desc in src.layout:
             kind = desc[0]
-            if kind == "layers":
+            if kind in ("virt_col", "virt_layer"):
+                out.append(self._virtual(staged=True).tables_dev()[0 if kind == "virt_col" else 1].ptr)
+            elif kind == "layers":
                 out.append(self.iterset._layers_dev())
             elif kind == "subset":
                 out.append(self.iterset._indices_dev())
@@ -778,8 +846,7 @@ class Parloop:
                 elif mode.startswith("staged"):
                     v = self._virtual()
                     for off, size in self._parts():
-                        k = v[0] if v else 1
-                        self._staged_geometry(off * k, (off + size) * k)
+                        self._staged_geometry(*(v.range(off, off + size) if v else (off, off + size)))
                 return
             except PlanDoesNotFit as exc:
                 from .codegen import staged_eligible
@@ -849,7 +916,7 @@ class Parloop:
         self._prepare()
         v = self._virtual()
         if v is not None:
-            start, end = start * v[0], end * v[0]       # positions in the virtual (entity x layer) space
+            start, end = v.range(start, end)            # positions in the virtual (entity x layer) space
         args, geo = self._arglist(start, end)
         cw = geo["cw"] if geo is not None else self._prepared["cw"]
         src = cw.src
@@ -891,7 +958,7 @@ class Parloop:
         maps = [self._plan_map(m._base(), staged=True) for m in prep["maps"]]
         v = self._virtual(staged=True)
         if v is not None:
-            start, end = start * v[0], end * v[0]
+            start, end = v.range(start, end)
         (k, pa), = [(k, a) for k, a in enumerate(self.arguments) if isinstance(a, MatParloopArg)]
         rmap, cmap = (self._plan_map(m._base(), staged=True) for m in pa.maps)
         sp = pa.data.sparsity
@@ -1020,7 +1087,7 @@ class Parloop:
         maps = {mi: self._plan_map(m._base(), staged=True) for mi, m in enumerate(prep["maps"])}
         v = self._virtual(staged=True)
         if v is not None:
-            start, end = start * v[0], end * v[0]               # positions in the virtual space
+            start, end = v.range(start, end)                    # positions in the virtual space
         (k, pa), = [(k, a) for k, a in enumerate(self.arguments) if isinstance(a, MatParloopArg)]
         rmap, cmap = (self._plan_map(m._base(), staged=True) for m in pa.maps)
         sp = pa.data.sparsity
@@ -1184,6 +1251,8 @@ class Parloop:
             elif kind in ("mat_row_lgmap", "mat_col_lgmap"):
                 pa = self.arguments[desc[1]]
                 out.append(self._lgmap(pa.lgmaps[0 if kind == "mat_row_lgmap" else 1]))
+            elif kind in ("virt_col", "virt_layer"):
+                out.append(self._virtual(staged=True).tables_dev()[0 if kind == "virt_col" else 1].ptr)
             elif kind in ("fx_scale", "fx_stat"):
                 out.append(geo["fx"][0 if kind == "fx_scale" else 1].ptr)
             elif kind == "phase_times":

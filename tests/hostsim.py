@@ -88,7 +88,7 @@ def run_staged(pl, epb=48, order=None):
     assert staged_eligible(gk) and not any(isinstance(pa, MatParloopArg) for pa in pl.arguments)
     # subsets / extruded sets: the plans live on derived maps over the virtual (position x layer) space
     virt = pl._virtual(staged=True)
-    start, end = 0, pl.iterset.size * (virt[0] if virt else 1)
+    start, end = 0, (virt.size(pl.iterset.size) if virt else pl.iterset.size)
     maps, base_maps = [], []
     for pa in pl.arguments:
         for m in getattr(pa, "maps", ()):
@@ -129,7 +129,9 @@ def run_staged(pl, epb=48, order=None):
     cargs = [ctypes.c_int(nblocks), ctypes.c_int(T), ctypes.c_int(start), ctypes.c_int(end)]
     for desc in src.layout:
         kind = desc[0]
-        if kind == "layers":
+        if kind in ("virt_col", "virt_layer"):
+            cargs.append(ptr(np.ascontiguousarray(virt.col if kind == "virt_col" else virt.layer, dtype=np.int32)))
+        elif kind == "layers":
             cargs.append(ptr(np.asarray(pl.iterset.layers_array, dtype=np.int32)))
         elif kind == "subset":
             cargs.append(ptr(np.asarray(pl.iterset.indices, dtype=np.int32)))
@@ -239,7 +241,7 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False,
     T = base.block_threads
     csr = oracle_pattern(mpa.data.sparsity)
     rmap, cmap = (pl._plan_map(m._base(), staged=True) for m in mpa.maps)
-    nent = pl.iterset.size * (virt[0] if virt else 1)
+    nent = virt.size(pl.iterset.size) if virt else pl.iterset.size
     nrows = rmap.toset.size
     rb = np.array(list(range(0, nrows, rows_per_block)) + [nrows], dtype=np.int32)
     plist = pinv = prowptr = None
@@ -281,7 +283,9 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False,
     cargs = [ctypes.c_int(len(rb) - 1), ctypes.c_int(T), ctypes.c_int(0), ctypes.c_int(len(inst_ent))]
     for desc in src.layout:
         kind = desc[0]
-        if kind == "layers":
+        if kind in ("virt_col", "virt_layer"):
+            cargs.append(ptr(np.ascontiguousarray(virt.col if kind == "virt_col" else virt.layer, dtype=np.int32)))
+        elif kind == "layers":
             cargs.append(ptr(np.asarray(pl.iterset.layers_array, dtype=np.int32)))
         elif kind == "subset":
             cargs.append(ptr(np.asarray(pl.iterset.indices, dtype=np.int32)))
@@ -427,7 +431,7 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None, run_flush=Fals
                                      [(r.values_with_halo, c.values_with_halo) for r, c, _ in sp._pairs], set_diag=sp._has_diagonal)
         assert not pl.iterset._extruded
     rmap, cmap = (pl._plan_map(m._base(), staged=True) for m in mpa.maps)
-    nent = pl.iterset.size * (virt[0] if virt else 1)
+    nent = virt.size(pl.iterset.size) if virt else pl.iterset.size
     nrows = rmap.toset.size
     plist = pinv = None
     acc = ncsr.rowptr
@@ -480,7 +484,9 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None, run_flush=Fals
     cargs = [ctypes.c_int(len(rb) - 1), ctypes.c_int(T), ctypes.c_int(0), ctypes.c_int(len(inst_ent))]
     for desc in src.layout:
         kind = desc[0]
-        if kind == "layers":
+        if kind in ("virt_col", "virt_layer"):
+            cargs.append(ptr(np.ascontiguousarray(virt.col if kind == "virt_col" else virt.layer, dtype=np.int32)))
+        elif kind == "layers":
             cargs.append(ptr(np.asarray(pl.iterset.layers_array, dtype=np.int32)))
         elif kind == "subset":
             cargs.append(ptr(np.asarray(pl.iterset.indices, dtype=np.int32)))
@@ -573,7 +579,9 @@ def run_direct(pl, part=None):
     cargs = [ctypes.c_int(offset), ctypes.c_int(offset + size)]
     for desc in src.layout:
         kind = desc[0]
-        if kind == "layers":
+        if kind in ("virt_col", "virt_layer"):
+            cargs.append(ptr(np.ascontiguousarray(virt.col if kind == "virt_col" else virt.layer, dtype=np.int32)))
+        elif kind == "layers":
             cargs.append(ptr(np.asarray(pl.iterset.layers_array, dtype=np.int32)))
         elif kind == "subset":
             cargs.append(ptr(np.asarray(pl.iterset.indices, dtype=np.int32)))
@@ -648,7 +656,9 @@ def run_tensor(pl, initial=None):
     cargs = [ctypes.c_int(nblocks), ctypes.c_int(src.block_threads), ctypes.c_int(start), ctypes.c_int(end)]
     for desc in src.layout:
         kind = desc[0]
-        if kind == "layers":
+        if kind in ("virt_col", "virt_layer"):
+            cargs.append(ptr(np.ascontiguousarray(virt.col if kind == "virt_col" else virt.layer, dtype=np.int32)))
+        elif kind == "layers":
             cargs.append(ptr(np.asarray(pl.iterset.layers_array, dtype=np.int32)))
         elif kind == "arg":
             pa = pl.arguments[desc[1]]

@@ -170,3 +170,52 @@ def test_halo_create_rejects_lists_the_kernels_cannot_handle(comm):
         _halo_multi(comm, [([1, 2], [10, 11]), ([3, 4], [11, 12])])       # a ghost with two owners
     with pytest.raises(_lib.FDHipError, match="repeats a node"):
         _halo_multi(comm, [([1, 1], [10, 11])])
+
+
+@pytest.mark.parametrize("op", [1, 2, 3])
+def test_corner_of_a_block_partition_rccl_wire_equals_host_wire(comm, op):
+    """The interior corner of a 2 x 2 x 2 block partition: SEVEN neighbours (three faces, three edges, one corner), the corner
+    node owned here and held as a ghost by all seven, edge nodes by three, face nodes by one.  The reverse exchange (ghost -> owner
+    SUM / MIN / MAX, firedrake/halo.py:141-172) runs once over the RCCL wire (the rank is its own seven neighbours) and once over the
+    HOST wire -- the path the gloo tests and the one-device rehearsals take: fd_halo_create without a communicator, the packed rows
+    carried from the send to the receive buffer by the caller (fd_halo_wire_buffers) -- and the fused node-major combine must give
+    the same BITS on both, equal to the contributions applied in neighbour order."""
+    m = 12                                              # owned lattice m^3; neighbours on the high side of every axis
+    idx = np.arange(m ** 3).reshape(m, m, m)
+    hi = m - 1
+    # owned nodes each neighbour holds as ghosts: faces x/y/z = hi, edges, the corner
+    sends = [idx[hi, :, :].ravel(), idx[:, hi, :].ravel(), idx[:, :, hi].ravel(),
+             idx[hi, hi, :].ravel(), idx[hi, :, hi].ravel(), idx[:, hi, hi].ravel(), idx[hi, hi, hi].ravel()]
+    n_owned = m ** 3
+    # the ghost copies this rank holds of "their" nodes (as the self-neighbour, the same counts): a private ghost range per neighbour
+    recvs, off = [], n_owned
+    for s_ in sends:
+        recvs.append(np.arange(off, off + len(s_)))
+        off += len(s_)
+    n = off
+    rng = np.random.default_rng(11)
+    a = rng.standard_normal((n, 2))
+    pairs = list(zip(sends, recvs))
+    results = {}
+    for wire in ("rccl", "host"):
+        h = _halo_multi(comm if wire == "rccl" else None, pairs)
+        d = DeviceBuffer.from_numpy(a)
+        _lib.call("fd_halo_l2g_begin", h, d.ptr, 2, 0, op, None)
+        if wire == "host":
+            sb, rb, ns, nr = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64()
+            _lib.call("fd_halo_wire_buffers", h, d.ptr, 1, ctypes.byref(sb), ctypes.byref(ns), ctypes.byref(rb), ctypes.byref(nr))
+            assert ns.value == nr.value == sum(len(s_) for s_ in sends)
+            _lib.call("fd_device_sync")
+            _lib.call("fd_memcpy_d2d", rb.value, sb.value, ns.value * 2 * 8, None)      # what neighbour k sent is what it receives
+            _lib.call("fd_device_sync")
+        _lib.call("fd_halo_l2g_end", h, d.ptr, 2, 0, op, None)
+        results[wire] = d.download(np.float64, a.shape)
+        _lib.call("fd_halo_free", h)
+    f = {1: np.add, 2: np.minimum, 3: np.maximum}[op]
+    seq = a.copy()
+    for s_, r_ in pairs:                                 # contributions in neighbour order
+        seq[s_] = f(seq[s_], a[r_])
+    assert np.array_equal(results["rccl"], results["host"])
+    assert np.array_equal(results["rccl"], seq)
+    corner = idx[hi, hi, hi]
+    assert not np.array_equal(seq[corner], a[corner])     # (seven contributions landed on the corner)

@@ -1,0 +1,84 @@
+"""GPU: loops over extruded sets with VARIABLE layers (set.py:326-337; builder.py:754-831) through the wrappers the backend picks
+since round 5 -- staged (Dat loops) and owner-computes-rows (Mat loops) over the ragged space of existing cells -- and through the
+direct wrapper, against the oracle."""
+import numpy as np
+import pytest
+
+from firedrake_amd import op2
+from firedrake_amd.configuration import configuration
+from helpers import oracle_run
+
+pytestmark = pytest.mark.gpu
+
+
+def _columns(rng, nb, L):
+    bot = rng.integers(0, 3, nb)
+    top = bot + 2 + rng.integers(0, L - 4, nb)
+    return bot, top
+
+
+@pytest.mark.parametrize("mode", ["auto", "direct"])
+@pytest.mark.parametrize("region", [None, op2.ON_BOTTOM, op2.ON_TOP])
+@pytest.mark.parametrize("subset", [False, True])
+def test_dat_loop_over_variable_layers(mode, region, subset, monkeypatch):
+    monkeypatch.setitem(configuration, "mode", mode)
+    rng = np.random.default_rng(4)
+    nbase, L, nv = 3000, 9, 900
+    base = op2.Set(nbase)
+    bot, top = _columns(rng, nbase, L)
+    ext = op2.ExtrudedSet(base, layers=np.stack([bot, top], axis=1))
+    nodes = op2.Set(nv * L)
+    tri = np.array([rng.choice(nv, 3, replace=False) for _ in range(nbase)])
+    cm = op2.Map(ext, nodes, 6, np.concatenate([tri * L + bot[:, None], tri * L + bot[:, None] + 1], axis=1).astype(np.int32), offset=[1] * 6)
+    x = op2.Dat(nodes ** 2, rng.standard_normal((nv * L, 2)))
+    w = op2.Dat(base, rng.standard_normal(nbase))
+    out = op2.Dat(nodes)
+    k = op2.Kernel("static void ksv(double *o, const double *x, const double *w, int layer) "
+                   "{ for (int i = 0; i < 6; ++i) o[i] += (1 + layer) * w[0] * (x[2*i] + 0.5*x[2*i+1]); }", "ksv")
+    it = op2.Subset(ext, rng.choice(nbase, 2000, replace=False)) if subset else ext
+    args = (out(op2.INC, cm), x(op2.READ, cm), w(op2.READ))
+    pl = op2.LegacyParloop(k, it, *args, iteration_region=region, pass_layer_arg=True)
+    for _ in range(2):
+        out.zero()
+        pl()
+    assert pl._prepare()["cw"].src.mode.startswith("staged" if mode == "auto" else "direct")
+    ref = oracle_run(k, it, *args, iteration_region=region, pass_layer_arg=True)[0]
+    assert np.abs(ref).max() > 0 and np.abs(out.data_ro - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("mode", ["auto", "direct"])
+@pytest.mark.parametrize("region", [None, op2.ON_TOP])
+@pytest.mark.parametrize("sliced", [False, True])
+def test_matrix_loop_over_variable_layers(mode, region, sliced, monkeypatch):
+    monkeypatch.setitem(configuration, "mode", mode)
+    monkeypatch.setitem(configuration, "ocr_sliced_min_arity", 4 if sliced else 8)
+    rng = np.random.default_rng(9)
+    nb, L = 600, 10
+    base = op2.Set(nb)
+    bot, top = _columns(rng, nb, L)
+    ext = op2.ExtrudedSet(base, layers=np.stack([bot, top], axis=1))
+    nodes = op2.Set((nb + 2) * L)
+    vm = np.array([[i * L + bot[i], i * L + bot[i] + 1, (i + 1) * L + bot[i], (i + 1) * L + bot[i] + 1, (i + 2) * L + bot[i], (i + 2) * L + bot[i] + 1]
+                   for i in range(nb)], dtype=np.int32)
+    m = op2.Map(ext, nodes, 6, vm, offset=[1] * 6)
+    x = op2.Dat(nodes ** 2, rng.uniform(0, 1, (nodes.total_size, 2)), np.float64)
+    w = op2.Dat(ext, rng.uniform(1, 2, nb), np.float64)
+    mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(m, m, None)]))
+    k = op2.Kernel("""
+static void prismv(double *A, const double *x, const double *w, int layer)
+{
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j)
+      A[i*6 + j] += w[0] * (x[2*i] + 2.0 * x[2*j + 1]) + 0.25 * layer + (i == j ? 1.0 : 0.0);
+}""", "prismv")
+    kw = dict(iteration_region=region, pass_layer_arg=True)
+    pl = op2.LegacyParloop(k, ext, mat(op2.INC, (m, m)), x(op2.READ, m), w(op2.READ), **kw)
+    for _ in range(2):
+        mat.zero()
+        pl()
+    got_mode = pl._prepare()["cw"].src.mode
+    assert got_mode.startswith(("ocrs" if sliced else "ocr") if mode == "auto" else "direct")
+    ref = oracle_run(k, ext, mat(op2.INC, (m, m)), x(op2.READ, m), w(op2.READ), **kw)[0]
+    rp, ci, v = mat.csr()
+    assert np.array_equal(rp, ref.rowptr) and np.array_equal(ci, ref.colidx)
+    assert np.abs(v - ref.values).max() <= 1e-12 * np.abs(ref.values).max()

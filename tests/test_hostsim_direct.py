@@ -520,6 +520,21 @@ def test_staged_wrapper_on_extruded_columns_and_subsets_on_host(region):
         got = run_staged(pl, epb=epb)[0]
         ref = oracle_run(k, iterset, *args, iteration_region=region, pass_layer_arg=True)[0]
         assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    # variable layers (set.py:326-337): every column its own [bottom, top); the map row of a column points at ITS bottom cell.  The
+    # virtual space is ragged -- the derived map has one row per existing cell, the cell tables give the base entity and the layer
+    bot = rng.integers(0, 3, nbase)
+    top = bot + 1 + rng.integers(1, L - 2, nbase)              # node levels [bottom, top): 1 .. L-3 cells per column
+    top[3] = bot[3] + 1                                         # (a column without any cell)
+    extv = op2.ExtrudedSet(base, layers=np.stack([bot, top], axis=1))
+    cmv = op2.Map(extv, nodes, 6, np.concatenate([tri * L + bot[:, None], tri * L + bot[:, None] + 1], axis=1).astype(np.int32), offset=[1] * 6)
+    for iterset, epb in ((extv, 100), (op2.Subset(extv, [5, 1, 3, 6] + list(range(10, 70))), 37)):
+        args = (out(op2.INC, cmv), x(op2.READ, cmv), w(op2.READ))
+        pl = op2.LegacyParloop(k, iterset, *args, iteration_region=region, pass_layer_arg=True)
+        from firedrake_amd.codegen import select_mode
+        assert select_mode(pl.global_kernel) == "staged"
+        got = run_staged(pl, epb=epb)[0]
+        ref = oracle_run(k, iterset, *args, iteration_region=region, pass_layer_arg=True)[0]
+        assert np.abs(ref).max() > 0 and np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
     if region is None:
         it, ind = op2.Set(900), op2.Set(190)
         mp = op2.Map(it, ind, 3, rng.integers(0, 190, size=(900, 3)))
@@ -759,6 +774,47 @@ static void prism(double *A, const double *x, const double *w, int layer)
     order = locality_order_ref(vrows, 0, len(vrows), np.array(x.data_ro), target=96)[0]
     for got in (run_ocrs(pl, nnz_per_block=150), run_ocr(pl, rows_per_block=9), run_ocrs(pl, nnz_per_block=150, order=order),
                 run_ocr(pl, rows_per_block=9, order=order)):
+        assert np.array_equal(got.rowptr, ref.rowptr) and np.array_equal(got.colidx, ref.colidx)
+        assert np.abs(got.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
+
+
+@pytest.mark.parametrize("region", ["all", "bottom", "top"])
+def test_matrix_loops_over_variable_layers_on_host(region):
+    """Variable layers (set.py:326-337: every column its own [bottom, top)) through both owner-computes-rows wrappers: the derived
+    map holds one row per EXISTING cell, the direct argument and the layer argument are decoded through the cell tables.  P1
+    prisms against the oracle (whose sparsity and loop walk the ragged columns, sparsity.pyx:328-371 / builder.py:754-831)."""
+    from firedrake_amd.codegen import select_mode
+    from firedrake_amd.configuration import configuration
+    from hostsim import run_ocr, run_ocrs
+    nb, L = 9, 7
+    rng = np.random.default_rng(18)
+    base = op2.Set(nb)
+    bot = rng.integers(0, 2, nb)
+    top = bot + 2 + rng.integers(0, L - 3, nb)
+    ext = op2.ExtrudedSet(base, layers=np.stack([bot, top], axis=1))
+    nodes = op2.Set((nb + 2) * L)
+    vm = np.array([[i * L + bot[i], i * L + bot[i] + 1, (i + 1) * L + bot[i], (i + 1) * L + bot[i] + 1, (i + 2) * L + bot[i], (i + 2) * L + bot[i] + 1]
+                   for i in range(nb)], dtype=np.int32)
+    m = op2.Map(ext, nodes, 6, vm, offset=[1] * 6)
+    x = op2.Dat(nodes ** 2, rng.uniform(0, 1, (nodes.total_size, 2)), np.float64)
+    w = op2.Dat(ext, rng.uniform(1, 2, nb), np.float64)
+    mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(m, m, None)]))
+    k = op2.Kernel("""
+static void prismv(double *A, const double *x, const double *w, int layer)
+{
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j)
+      A[i*6 + j] += w[0] * (x[2*i] + 2.0 * x[2*j + 1]) + 0.25 * layer + (i == j ? 1.0 : 0.0);
+}""", "prismv")
+    reg = {"all": None, "bottom": op2.ON_BOTTOM, "top": op2.ON_TOP}[region]
+    kw = dict(iteration_region=reg, pass_layer_arg=True)
+    pl = op2.LegacyParloop(k, ext, mat(op2.INC, (m, m)), x(op2.READ, m), w(op2.READ), **kw)
+    assert select_mode(pl.global_kernel) == "ocr"
+    v = pl._virtual(staged=True)
+    assert v.ragged and v.size(nb) == (int((top - 1 - bot).sum()) if region == "all" else nb)
+    ref = oracle_run(k, ext, mat(op2.INC, (m, m)), x(op2.READ, m), w(op2.READ), **kw)[0]
+    for got in (run_ocr(pl, rows_per_block=9), run_ocr(pl, rows_per_block=9, records=True), run_ocrs(pl, nnz_per_block=150),
+                run_ocrs(pl, nnz_per_block=150, records=True)):
         assert np.array_equal(got.rowptr, ref.rowptr) and np.array_equal(got.colidx, ref.colidx)
         assert np.abs(got.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
 
