@@ -301,6 +301,38 @@ def measure_c3_action(n, steps, warmup):
             "frac_valu": act_flops / (FP64_VECTOR_PEAK_TFLOPS * 1e12) * 1e3 / k_ms}
 
 
+def measure_tensor_forms(steps, warmup):
+    """The wider tensor-product descriptors through the same two wrappers: the Newton Jacobian of int (1 + |grad u|^2) grad(u).grad(v) dx
+    on Q3 (a coefficient GRADIENT at the Gauss points) and linear elasticity on (Q2)^3 (a vector-valued space: Mat dims (3, 3), nine
+    scalar MFMA contractions per cell).  Kernel times and the fraction of the fp64 MFMA peak, algorithmic flops = 2 nd^2 4 nq per
+    scalar block."""
+    from firedrake_amd import _lib, forms, mesh as fmesh
+    from firedrake_amd.device import Event
+    out = {}
+    for key, degree, n, make in (("nonlinear_diffusion_q3", 3, 24, lambda m: forms.NonlinearDiffusionHexProblem(m, bcs=True)),
+                                 ("elasticity_q2", 2, 24, lambda m: forms.ElasticityHexProblem(m, bcs=True))):
+        m = fmesh.make_extruded_hex_mesh(n, n, degree, perturb=0.1)
+        prob = make(m)
+        for _ in range(max(warmup, 1)):
+            prob.assemble_jacobian()
+            prob.assemble_action()
+        _lib.call("fd_device_sync")
+        ev = [[Event() for _ in range(4)] for _ in range(steps)]
+        for k in range(steps):
+            prob.assemble_jacobian(events=(ev[k][0], ev[k][1]))
+            prob.assemble_action(events=(ev[k][2], ev[k][3]))
+        _lib.call("fd_device_sync")
+        k_ms = float(np.median([e[0].elapsed_ms(e[1]) for e in ev]))
+        a_ms = float(np.median([e[2].elapsed_ms(e[3]) for e in ev]))
+        flops = prob.ALGO_FLOPS_PER_CELL * m.ncells
+        out[key] = {"workload": f"Q{degree} on ExtrudedMesh(UnitSquareMesh({n},{n},quadrilateral), {n}), Dirichlet BCs", "cells": m.ncells,
+                    "dofs": int(m.node_set.size * (3 if key.startswith("elast") else 1)), "nnz": int(prob.sparsity.nz),
+                    "matrix_kernel": prob.jac_loop.global_kernel.name, "matrix_kernel_ms": k_ms, "frac_mfma": flops / (k_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                    "algorithmic_flops": flops, "action_kernel_ms": a_ms}
+        del prob, m
+    return out
+
+
 def run_c3(args):
     from firedrake_amd import _lib
     _lib.require_gpu()
@@ -989,6 +1021,10 @@ def main():
                 out["secondary_c3"]["action_n64"] = measure_c3_action(64, 10, 2)
             except Exception as exc:
                 out["secondary_c3"]["action_n64"] = {"error": repr(exc)}
+            try:
+                out["secondary_c3"]["wider_descriptors"] = measure_tensor_forms(3, 1)
+            except Exception as exc:
+                out["secondary_c3"]["wider_descriptors"] = {"error": repr(exc)}
         guarded("secondary_c4", lambda: measure_c4(2048, max(3, args.steps // 2), 2, cpu_sample=512 if cs else 0))
         guarded("secondary_c5_share", lambda: poisson_line(args, ctx, 2, (107, 107, 107), "weak",
                                                              "one of the 8 partitions of BASELINE.json configs[4]", "lexicographic", "", False,

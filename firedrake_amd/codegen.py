@@ -82,8 +82,9 @@ def tensor_eligible(gk: GlobalKernel):
     """'matrix' / 'action' when the loop can take the tensor-product wrappers of csrc/fd_tensor.h: a
     TensorProductLocalKernel of degree k = 1..5 with up to 7 Gauss points per axis (tensor_geometry) over an extruded set
     with constant layers, the whole column (iteration region ALL), no subset, and the argument shapes
-        matrix:  Mat INC (scalar block, both maps the (k+1)^3-node Q_k map, offset k)  +  coordinates READ (dim 3, 8-node Q1 map)
-        action:  Dat INC (scalar, Q_k map)  +  coordinates READ  +  Dat READ (scalar, the same Q_k map)."""
+        matrix:  Mat INC (dims (D, D), both maps the (k+1)^3-node Q_k map, offset k)  +  coordinates READ (dim 3, 8-node Q1 map)
+        action:  Dat INC (dim D, Q_k map)  +  coordinates READ  +  Dat READ (dim D, the same Q_k map)
+    with D = the descriptor's ``vdim`` (1: scalar space)."""
     tp = getattr(gk.local_kernel, "tp", None)
     if not tp or not configuration["tensor_wrappers"] or tensor_geometry(tp["degree"], tp["nq"]) is None:
         return None
@@ -100,7 +101,7 @@ def tensor_eligible(gk: GlobalKernel):
         return isinstance(a, DatKernelArg) and a.index is None and la.access == READ and la.dtype == f64 and tuple(a.dim) == (3,) \
             and plain(a.map_, 8, 1)
 
-    nc = int(tp.get("ncoef", 0))
+    nc, D = int(tp.get("ncoef", 0)), int(tp.get("vdim", 1))
 
     def coefs_ok(first, qmap):
         """the descriptor's coefficient arguments: nc scalar fp64 READ Dats after the standard arguments, each on the Q_k map or on
@@ -113,11 +114,11 @@ def tensor_eligible(gk: GlobalKernel):
     if tp["kind"] == "matrix" and len(args) == 2 + nc:
         a, la = args[0], las[0]
         if isinstance(a, MatKernelArg) and la.access == INC and not a.unroll and a.maps[0] is a.maps[1] and plain(a.maps[0], nd, k) \
-                and int(np.prod(a.dims[0])) * int(np.prod(a.dims[1])) == 1 and coords_ok(args[1], las[1]) and coefs_ok(2, a.maps[0]):
+                and int(np.prod(a.dims[0])) == D and int(np.prod(a.dims[1])) == D and coords_ok(args[1], las[1]) and coefs_ok(2, a.maps[0]):
             return "matrix"
     if tp["kind"] == "action" and len(args) == 3 + nc:
         y, u = args[0], args[2]
-        if all(isinstance(d, DatKernelArg) and d.index is None and int(np.prod(d.dim)) == 1 for d in (y, u)) \
+        if all(isinstance(d, DatKernelArg) and d.index is None and int(np.prod(d.dim)) == D for d in (y, u)) \
                 and las[0].access == INC and las[2].access == READ and las[0].dtype == f64 and las[2].dtype == f64 \
                 and y.map_ is u.map_ and plain(y.map_, nd, k) and coords_ok(args[1], las[1]) and coefs_ok(3, y.map_):
             return "action"
@@ -166,12 +167,20 @@ def generate_tensor_wrapper(gk: GlobalKernel) -> WrapperSource:
     c1 = [m for m in range(nc) if spaces[m] == "1"]
     nck, nc1 = len(ck), len(c1)
     tpos = {m: p_ for p_, m in enumerate(ck + c1)}            # position of TSFC coefficient m in the templates' C
+    grad, D = bool(lk.tp.get("coef_gradients")), int(lk.tp.get("vdim", 1))
     if nc:
         perm = ", ".join(f"C[{tpos[m]}]" for m in range(nc))
-        wcall = f"const double Cu[{nc}] = {{{perm}}}; fdk::{wname}(J, X, wq, Cu, W);"
+        wcall = f"const double Cu[{nc}] = {{{perm}}}; "
+        if grad:
+            gperm = ", ".join(f"DC[{3 * tpos[m] + a}]" for m in range(nc) for a in range(3))
+            wcall += f"const double DCu[{3 * nc}] = {{{gperm}}}; fdk::{wname}(J, X, wq, Cu, DCu, W);"
+        else:
+            wcall += f"fdk::{wname}(J, X, wq, Cu, W); (void)DC;"
     else:
-        wcall = f"fdk::{wname}(J, X, wq, W); (void)C;"
-    call_w = f"[](const double J[3][3], const double X[3], double wq, const double *C, double W[16]) {{ {wcall} }}"
+        wcall = f"fdk::{wname}(J, X, wq, W); (void)C; (void)DC;"
+    call_w = (f"[](const double J[3][3], const double X[3], double wq, const double *C, const double *DC, double W[{16 * D * D}]) "
+              f"{{ {wcall} }}")
+    targs = f"{geom['k1']}, {geom['q1']}, {nck}, {nc1}, {'true' if grad else 'false'}, {D}"
     cparams = [f"const double *__restrict__ arg{first_c + m}" for m in range(nc)]
     clayout = [("arg", first_c + m) for m in range(nc)]
     cfdecl = ("  const double *const cf[%d] = {%s};\n  const double *const c1[%d] = {%s};"
@@ -179,7 +188,7 @@ def generate_tensor_wrapper(gk: GlobalKernel) -> WrapperSource:
                  max(nc1, 1), ", ".join(f"arg{first_c + m}" for m in c1) or "nullptr"))
     if kind == "matrix":
         lg = bool(gk.arguments[0].lgmaps)
-        layout += [("arg", 0), ("arg", 1)] + clayout + [("map", 0), ("map", 1), ("mat_rowptr", 0), ("tp_offtab", 0)]
+        layout += [("arg", 0), ("arg", 1)] + clayout + [("map", 0), ("map", 1), ("mat_node_rowptr", 0), ("tp_offtab", 0)]
         params = ["const int *__restrict__ layers", "double *__restrict__ arg0", "const double *__restrict__ arg1"] + cparams + [
                   "const int *__restrict__ map0", "const int *__restrict__ map1", "const int *__restrict__ rp0",
                   "const unsigned short *__restrict__ tpo0"]
@@ -188,7 +197,7 @@ def generate_tensor_wrapper(gk: GlobalKernel) -> WrapperSource:
             params += ["const int *__restrict__ rlg0", "const int *__restrict__ clg0"]
         layout += [("tp_tables",)]
         params += ["const double *__restrict__ tptab"]
-        body = (f"{cfdecl}\n  fdt::hex_qk_matrix<{geom['k1']}, {geom['q1']}, {nck}, {nc1}>(start, end, layers, arg0, arg1, cf, c1, map0, map1, rp0, tpo0, "
+        body = (f"{cfdecl}\n  fdt::hex_qk_matrix<{targs}>(start, end, layers, arg0, arg1, cf, c1, map0, map1, rp0, tpo0, "
                 f"{'rlg0, clg0' if lg else 'nullptr, nullptr'}, tptab, {call_w});")
         threads = geom["matrix_threads"]
         # 4 NT accumulator registers per lane: Q4 (NT = 8) fits three wavefronts per SIMD
@@ -198,10 +207,11 @@ def generate_tensor_wrapper(gk: GlobalKernel) -> WrapperSource:
         params = ["const int *__restrict__ layers", "double *__restrict__ arg0", "const double *__restrict__ arg1",
                   "const double *__restrict__ arg2"] + cparams + ["const int *__restrict__ map0", "const int *__restrict__ map1",
                   "const double *__restrict__ tptab"]
-        body = (f"{cfdecl}\n  fdt::hex_qk_action<{geom['k1']}, {geom['q1']}, {nck}, {nc1}>(start, end, layers, arg0, arg1, arg2, cf, c1, map0, map1, tptab, "
+        body = (f"{cfdecl}\n  fdt::hex_qk_action<{targs}>(start, end, layers, arg0, arg1, arg2, cf, c1, map0, map1, tptab, "
                 f"{call_w});")
         threads = 128
-        bounds = "128" + (f", {int(configuration['tp_action_waves'])}" if configuration["tp_action_waves"] else "")
+        # (a vector-valued unknown or coefficient gradients carry D times / twice the lines in registers: no occupancy floor)
+        bounds = "128" + (f", {int(configuration['tp_action_waves'])}" if configuration["tp_action_waves"] and D == 1 and not grad else "")
     src = head + [f'extern "C" __global__ __launch_bounds__({bounds}) void {sym}(int start, int end, {", ".join(params)})', "{", body, "}"]
     return WrapperSource("\n".join(src) + "\n", sym, "tp_" + kind, layout, 2, block_threads=threads, tp=geom)
 

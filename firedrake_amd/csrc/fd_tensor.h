@@ -48,6 +48,16 @@ __device__ __forceinline__ void hex_shape(const double t[3], double N[8]) {
     }
 }
 
+// ... and their reference gradients dN[v][a] = dN_v / dxi_a (coefficient gradients of Q1 fields)
+__device__ __forceinline__ void hex_shape_grad(const double t[3], double dN[8][3]) {
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        const int a = v >> 2, b = (v >> 1) & 1, c = v & 1;
+        const double Na = a ? t[0] : 1.0 - t[0], Nb = b ? t[1] : 1.0 - t[1], Nc = c ? t[2] : 1.0 - t[2];
+        dN[v][0] = (a ? 1.0 : -1.0) * Nb * Nc; dN[v][1] = Na * (b ? 1.0 : -1.0) * Nc; dN[v][2] = Na * Nb * (c ? 1.0 : -1.0);
+    }
+}
+
 // K = J^-1 and det J: helper for weight callbacks
 __device__ __forceinline__ void inv3(const double J[3][3], double K[3][3], double &det) {
     const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
@@ -79,46 +89,110 @@ constexpr int tp_waves(int nt) { return nt % 4 == 0 ? 4 : (nt % 2 == 0 ? 2 : 1);
 // nonlinear form (tsfc/kernel_interface/firedrake_loopy.py:432-522; evaluated at the quadrature points in tsfc/fem.py:742-805).
 // Their values at the NQ Gauss points of the cell are computed sum-factorised (three 1-D contractions through LDS, ~2 K1 NQ
 // FMAs per coefficient against 2 ND^2 NQ 4 for the element matrix) and handed to the weight callback as C[0..NC).
-template <int K1, int Q1, int NC, int NTHR>
+// GRAD: the REFERENCE GRADIENT of every coefficient at the points as well (the linearisation of a form nonlinear in grad(u0)
+// needs it: tsfc/fem.py:742-805 tabulates the derivative tables for it) -- the derivative table on one axis at a time, three more
+// results out of the same three passes: sC[m*4 + 0] the value, sC[m*4 + 1 + a] d/dxi_a.
+template <int K1, int Q1, int NC, int NTHR, bool GRAD>
 __device__ __forceinline__ void hex_qk_coefficients(const double *const (&cf)[NC > 0 ? NC : 1], const int *__restrict__ mrow, int lo,
-                                                    const double *sL, double (*sC)[Q1 * Q1 * Q1]) {
-    constexpr int ND = K1 * K1 * K1, NQ = Q1 * Q1 * Q1;
-    __shared__ double sU[ND], sT1[Q1 * K1 * K1], sT2[Q1 * Q1 * K1];
+                                                    const double *sL, const double *sDL, double (*sC)[Q1 * Q1 * Q1]) {
+    constexpr int ND = K1 * K1 * K1, NQ = Q1 * Q1 * Q1, G1 = GRAD ? 2 : 1, G2 = GRAD ? 3 : 1, CW = GRAD ? 4 : 1;
+    constexpr int N1 = Q1 * K1 * K1, N2 = Q1 * Q1 * K1;
+    __shared__ double sU[ND], sT1[G1][N1], sT2[G2][N2];
     const int tid = threadIdx.x;
 #pragma unroll 1
     for (int m = 0; m < NC; ++m) {
         for (int i = tid; i < ND; i += NTHR) sU[i] = cf[m][mrow[i] + lo];
         __syncthreads();
-        for (int o = tid; o < Q1 * K1 * K1; o += NTHR) {          // (q1, i2, i3) <- sum over i1
+        for (int o = tid; o < N1; o += NTHR) {                    // (q1, i2, i3) <- sum over i1
             const int q1 = o / (K1 * K1), r = o - q1 * (K1 * K1);
-            double v = 0.0;
+            double v = 0.0, d = 0.0;
 #pragma unroll
-            for (int i = 0; i < K1; ++i) v += sL[q1 * K1 + i] * sU[i * K1 * K1 + r];
-            sT1[o] = v;
+            for (int i = 0; i < K1; ++i) { v += sL[q1 * K1 + i] * sU[i * K1 * K1 + r]; if (GRAD) d += sDL[q1 * K1 + i] * sU[i * K1 * K1 + r]; }
+            sT1[0][o] = v;
+            if (GRAD) sT1[G1 - 1][o] = d;
         }
         __syncthreads();
-        for (int o = tid; o < Q1 * Q1 * K1; o += NTHR) {          // (q1, q2, i3) <- sum over i2
+        for (int o = tid; o < N2; o += NTHR) {                    // (q1, q2, i3) <- sum over i2
             const int q1 = o / (Q1 * K1), q2 = (o / K1) % Q1, i3 = o % K1;
-            double v = 0.0;
+            double v = 0.0, d1 = 0.0, d2 = 0.0;
 #pragma unroll
-            for (int i = 0; i < K1; ++i) v += sL[q2 * K1 + i] * sT1[(q1 * K1 + i) * K1 + i3];
-            sT2[o] = v;
+            for (int i = 0; i < K1; ++i) {
+                const double tv = sT1[0][(q1 * K1 + i) * K1 + i3];
+                v += sL[q2 * K1 + i] * tv;
+                if (GRAD) { d1 += sL[q2 * K1 + i] * sT1[G1 - 1][(q1 * K1 + i) * K1 + i3]; d2 += sDL[q2 * K1 + i] * tv; }
+            }
+            sT2[0][o] = v;
+            if (GRAD) { sT2[G2 > 1 ? 1 : 0][o] = d1; sT2[G2 - 1][o] = d2; }
         }
         __syncthreads();
         for (int q = tid; q < NQ; q += NTHR) {                    // (q1, q2, q3) <- sum over i3
             const int q12 = q / Q1, q3 = q - q12 * Q1;
-            double v = 0.0;
+            double v = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
 #pragma unroll
-            for (int i = 0; i < K1; ++i) v += sL[q3 * K1 + i] * sT2[q12 * K1 + i];
-            sC[m][q] = v;
+            for (int i = 0; i < K1; ++i) {
+                const double tv = sT2[0][q12 * K1 + i];
+                v += sL[q3 * K1 + i] * tv;
+                if (GRAD) { g0 += sL[q3 * K1 + i] * sT2[G2 > 1 ? 1 : 0][q12 * K1 + i]; g1 += sL[q3 * K1 + i] * sT2[G2 - 1][q12 * K1 + i]; g2 += sDL[q3 * K1 + i] * tv; }
+            }
+            sC[m * CW][q] = v;
+            if (GRAD) { sC[m * CW + 1][q] = g0; sC[m * CW + 2][q] = g1; sC[m * CW + 3][q] = g2; }
         }
         __syncthreads();
     }
 }
 
 // N1 further coefficient arguments live on the Q1 map of the coordinates (a piecewise-trilinear diffusivity on a Q4 problem): their 8
-// vertex values per cell are staged next to the coordinates and interpolated at the point; the callback sees C = [Q_k ..., Q1 ...].
-template <int K1, int Q1, int NC, int N1, class WF>
+// vertex values per cell are staged next to the coordinates and interpolated at the point; the callback sees C = [Q_k ..., Q1 ...]
+// and, with GRAD, DC[3*m + a] = d C[m] / d xi_a in the same order.
+//
+// D > 1: a VECTOR-VALUED space (Q_k)^D -- Mat dims (D, D), element tensor t[(i*D + p)][(j*D + r)] (MatSetValuesBlockedLocal,
+// builder.py:573-625).  The callback fills the point's 4D x 4D block weight, W[((p*4 + l) * 4D) + r*4 + k] coupling reference
+// component l of test component p with reference component k of trial component r; the (p, r) blocks are D^2 independent scalar
+// contractions sum_q Phi_q^T W_q^{pr} Phi_q, so a cell takes D^2 times the workgroups (the pair index fastest: the workgroups of a
+// cell run together and share its coordinates in the caches) and each keeps only its own 4 x 4 slice of W per point in LDS.  The
+// slice is picked with COMPILE-TIME indices (one instantiation of the weights phase per pair, selected by a switch), so the
+// callback's other 16 (D^2 - 1) results are dead code in each instantiation and W never has to exist in full.
+// CSR: scalar row (node, p) starts at node_rowptr[node]*D*D + p*rowlen*D, column (k-th node of the row, r) sits at k*D + r.
+template <int K1, int Q1, int NC, int N1, bool GRAD, int D, int P, int R, int NTHR, class WF>
+__device__ __forceinline__ void hex_qk_point_weights(const double *sX, const double *sQP, const double *sQW,
+                                                     const double (*sC)[Q1 * Q1 * Q1], const double (*sV1)[8],
+                                                     double (*sW)[16], WF weights) {
+    constexpr int NQ = Q1 * Q1 * Q1, CW = GRAD ? 4 : 1, NCT = NC + N1 > 0 ? NC + N1 : 1;
+    for (int q = threadIdx.x; q < NQ; q += NTHR) {
+        const int q1 = q / (Q1 * Q1), q2 = (q / Q1) % Q1, q3 = q % Q1;
+        const double t[3] = {sQP[q1], sQP[q2], sQP[q3]};
+        double J[3][3], X[3], W[16 * D * D], C[NCT], DC[3 * NCT];
+        hex_jacobian(sX, t, J, X);
+#pragma unroll
+        for (int m = 0; m < NC; ++m) {
+            C[m] = sC[m * CW][q];
+            if (GRAD) { DC[3 * m] = sC[m * CW + 1][q]; DC[3 * m + 1] = sC[m * CW + 2][q]; DC[3 * m + 2] = sC[m * CW + 3][q]; }
+        }
+        if constexpr (N1 > 0) {
+            double N[8], dN[8][3];
+            hex_shape(t, N);
+            if (GRAD) hex_shape_grad(t, dN);
+#pragma unroll
+            for (int m = 0; m < N1; ++m) {
+                double v = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    v += N[k] * sV1[m][k];
+                    if (GRAD) { g0 += dN[k][0] * sV1[m][k]; g1 += dN[k][1] * sV1[m][k]; g2 += dN[k][2] * sV1[m][k]; }
+                }
+                C[NC + m] = v;
+                if (GRAD) { DC[3 * (NC + m)] = g0; DC[3 * (NC + m) + 1] = g1; DC[3 * (NC + m) + 2] = g2; }
+            }
+        }
+        weights(J, X, sQW[q1] * sQW[q2] * sQW[q3], C, DC, W);
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sW[q][l * 4 + k] = W[((P * 4 + l) * 4 * D) + R * 4 + k];
+    }
+}
+
+template <int K1, int Q1, int NC, int N1, bool GRAD, int D, class WF>
 __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__restrict__ layers, double *__restrict__ vals,
                                               const double *__restrict__ coords, const double *const (&cf)[NC > 0 ? NC : 1],
                                               const double *const (&c1)[N1 > 0 ? N1 : 1],
@@ -127,14 +201,20 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
                                               const unsigned short *__restrict__ offtab, const int *__restrict__ rlg,
                                               const int *__restrict__ clg, const double *__restrict__ tables, WF weights) {
     constexpr int ND = K1 * K1 * K1, NQ = Q1 * Q1 * Q1, NT = tp_tiles(K1), WPB = tp_waves(NT), WGC = NT / WPB, NTAB = Q1 * K1;
+    constexpr int CW = GRAD ? 4 : 1;
+    static_assert(D >= 1 && D <= 3, "vector-valued Q_k spaces of up to three components");
     __shared__ double sL[NTAB], sDL[NTAB], sQP[Q1], sQW[Q1];
     __shared__ double sX[24];
     __shared__ double sW[NQ][16];
-    __shared__ double sC[NC > 0 ? NC : 1][NQ];
+    __shared__ double sC[NC > 0 ? NC * CW : 1][NQ];
     __shared__ double sV1[N1 > 0 ? N1 : 1][8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nl = layers[1] - 1 - layers[0];
-    const int cellid = blockIdx.x / WGC, part = blockIdx.x - cellid * WGC;
+    // (unsigned, like blockIdx: the compiler then knows every index below is non-negative and keeps the table pointers in scalar
+    // registers with 32-bit lane offsets -- with signed ids it fell back to 64-bit address arithmetic per access, 20 % of the kernel)
+    const unsigned wg = blockIdx.x / (unsigned)(D * D), pr = blockIdx.x - wg * (unsigned)(D * D);   // (test, trial) component pair
+    const int cp = pr / (unsigned)D, cr = pr - cp * (unsigned)D;
+    const int cellid = wg / (unsigned)WGC, part = wg - cellid * (unsigned)WGC;
     const int col = start + cellid / nl;
     const int lrel = cellid % nl;                       // layer relative to the bottom
     if (col >= end) return;
@@ -149,29 +229,22 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
         for (int o = tid; o < 8 * N1; o += WPB * 64) sV1[o >> 3][o & 7] = c1[o >> 3][map_q1[(size_t)col * 8 + (o & 7)] + lrel];
     __syncthreads();
     if constexpr (NC > 0)
-        hex_qk_coefficients<K1, Q1, NC, WPB * 64>(cf, map_qk + (size_t)col * ND, (K1 - 1) * lrel, sL, sC);
-    for (int q = tid; q < NQ; q += WPB * 64) {
-        const int q1 = q / (Q1 * Q1), q2 = (q / Q1) % Q1, q3 = q % Q1;
-        const double t[3] = {sQP[q1], sQP[q2], sQP[q3]};
-        double J[3][3], X[3], W[16], C[NC + N1 > 0 ? NC + N1 : 1];
-        hex_jacobian(sX, t, J, X);
-#pragma unroll
-        for (int m = 0; m < NC; ++m) C[m] = sC[m][q];
-        if constexpr (N1 > 0) {
-            double N[8];
-            hex_shape(t, N);
-#pragma unroll
-            for (int m = 0; m < N1; ++m) {
-                double v = 0.0;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v += N[k] * sV1[m][k];
-                C[NC + m] = v;
-            }
+        hex_qk_coefficients<K1, Q1, NC, WPB * 64, GRAD>(cf, map_qk + (size_t)col * ND, (K1 - 1) * lrel, sL, sDL, sC);
+#define FD_TP_PAIR(P, R)                                                                                                            \
+    case (P) * 3 + (R):                                                                                                             \
+        if constexpr ((P) < D && (R) < D)                                                                                           \
+            hex_qk_point_weights<K1, Q1, NC, N1, GRAD, D, (P), (R), WPB * 64>(sX, sQP, sQW, sC, sV1, sW, weights);                  \
+        break;
+    if constexpr (D == 1) {
+        hex_qk_point_weights<K1, Q1, NC, N1, GRAD, 1, 0, 0, WPB * 64>(sX, sQP, sQW, sC, sV1, sW, weights);
+    } else {
+        switch (cp * 3 + cr) {
+            FD_TP_PAIR(0, 0) FD_TP_PAIR(0, 1) FD_TP_PAIR(0, 2) FD_TP_PAIR(1, 0) FD_TP_PAIR(1, 1) FD_TP_PAIR(1, 2)
+            FD_TP_PAIR(2, 0) FD_TP_PAIR(2, 1) FD_TP_PAIR(2, 2)
+        default: break;
         }
-        weights(J, X, sQW[q1] * sQW[q2] * sQW[q3], C, W);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) sW[q][k] = W[k];
     }
+#undef FD_TP_PAIR
     __syncthreads();
     const int r16 = lane & 15, kk = lane >> 4;             // row/col inside a tile, MFMA k index
     const int itile = part * WPB + wave;
@@ -214,6 +287,9 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
                 const double lz = sL[q3 * K1 + i3], dz = sDL[q3 * K1 + i3];
                 // A operand: (Phi^T W)[i][kk] = sum_l Phi[l][i] W[l][kk]
                 const double aop = ax * lz * sW[q][kk] + ay * lz * sW[q][4 + kk] + axy * dz * sW[q][8 + kk] + axy * lz * sW[q][12 + kk];
+                // (requesting the NT table values of the B operands together ahead of the MFMAs instead of one by one between them --
+                // back-to-back MFMAs in the ISA, 16 more registers -- measured the same 9.80 ms at n = 32: three wavefronts per SIMD
+                // already keep the matrix pipe fed; profiles/r5j_ab_c3_tree.txt)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const double bop = bxy[t] * tabz[q3 * K1 + j3[t]];
@@ -243,10 +319,17 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
         if (i >= ND) continue;
         const int rn = mrow[i] + OFF * lrel;
         if (rlg && rlg[rn] < 0) continue;
-        const size_t r0 = (size_t)rowptr[rn];
+        if constexpr (D == 1) {
+            const size_t r0 = (size_t)rowptr[rn];
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-            if (cok[t]) atomicAdd(&vals[r0 + tab[i * ND + t * 16 + r16]], acc[t][g]);
+            for (int t = 0; t < NT; ++t)
+                if (cok[t]) atomicAdd(&vals[r0 + tab[i * ND + t * 16 + r16]], acc[t][g]);
+        } else {
+            const size_t rp = (size_t)rowptr[rn], rlen = (size_t)rowptr[rn + 1] - rp, r0 = rp * (D * D) + (size_t)cp * rlen * D + cr;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (cok[t]) atomicAdd(&vals[r0 + (size_t)tab[i * ND + t * 16 + r16] * D], acc[t][g]);
+        }
     }
 }
 
@@ -266,19 +349,24 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int tp_action_cells(int k1, int q1) { return 128 / ((k1 > q1 ? k1 : q1) * (k1 > q1 ? k1 : q1)); }
 
-template <int K1, int Q1, int NC, int N1, class WF>
+// GRAD / D as in the matrix template: with GRAD every coefficient rides the passes like u itself (value and the derivative-table
+// contractions: A two cubes, B three) and the callback gets DC[3*m + a]; a vector-valued unknown (Dat dim D) takes D times the cubes
+// of u and a 4D x 4D point weight, F[p][l] = sum_{r,k} W[(p*4 + l)*4D + r*4 + k] g[r][k].
+template <int K1, int Q1, int NC, int N1, bool GRAD, int D, class WF>
 __device__ __forceinline__ void hex_qk_action(int start, int end, const int *__restrict__ layers, double *__restrict__ y,
                                               const double *__restrict__ coords, const double *__restrict__ u,
                                               const double *const (&cf)[NC > 0 ? NC : 1], const double *const (&c1)[N1 > 0 ? N1 : 1],
                                               const int *__restrict__ map_qk, const int *__restrict__ map_q1,
                                               const double *__restrict__ tables, WF weights) {
     constexpr int M = K1 > Q1 ? K1 : Q1, M2 = M * M, M3 = M2 * M, CPW = tp_action_cells(K1, Q1), ND = K1 * K1 * K1, NTAB = Q1 * K1;
-    constexpr int OFF = K1 - 1;
+    constexpr int OFF = K1 - 1, CA = GRAD ? 2 : 1, CB = GRAD ? 3 : 1, NCT = NC + N1 > 0 ? NC + N1 : 1;
     static_assert(CPW >= 1, "one cell needs at most 128 lines");
-    // A: two index cubes per cell (passes 1 and 5 write two), B: three (pass 2 writes three; passes 3 + 4 put their three results back
-    // IN PLACE -- a lane reads and writes only its own line) -- 5 cubes of 1000 B per cell for Q4, six workgroups per CU.  The NC
-    // coefficient arguments ride through passes 1 and 2 in further slots (A: 2.., B: 3..) and are evaluated at the line's points.
-    __shared__ double sA[CPW][2 + NC][M3], sB[CPW][3 + NC][M3], sX[CPW][24];
+    static_assert(D >= 1 && D <= 3, "vector-valued Q_k spaces of up to three components");
+    // A: two index cubes per cell and component (passes 1 and 5 write two), B: three (pass 2 writes three; passes 3 + 4 put their three
+    // results back IN PLACE -- a lane reads and writes only its own line) -- 5 cubes of 1000 B per cell for scalar Q4, six workgroups
+    // per CU.  The NC coefficient arguments ride through passes 1 and 2 in further slots (A: 2D.., B: 3D..) and are evaluated at the
+    // line's points.
+    __shared__ double sA[CPW][2 * D + NC * CA][M3], sB[CPW][3 * D + NC * CB][M3], sX[CPW][24];
     __shared__ double sV1[CPW][N1 > 0 ? N1 : 1][8];       // vertex values of the coefficient arguments on the Q1 map
     const int t = threadIdx.x;
     const int nl = layers[1] - 1 - layers[0];
@@ -324,15 +412,20 @@ __device__ __forceinline__ void hex_qk_action(int start, int end, const int *__r
         const int cell = first + k;
         const int *mrow = map_qk + (size_t)(start + cell / nl) * ND;
         const int lrel = OFF * (cell % nl);
-        double uv[K1];
 #pragma unroll
-        for (int i = 0; i < K1; ++i) { node[i] = mrow[(i * K1 + p) * K1 + r] + lrel; uv[i] = u[node[i]]; }
+        for (int i = 0; i < K1; ++i) node[i] = mrow[(i * K1 + p) * K1 + r] + lrel;
 #pragma unroll
-        for (int q = 0; q < Q1; ++q) {
-            double s0 = 0.0, s1 = 0.0;
+        for (int c = 0; c < D; ++c) {
+            double uv[K1];
 #pragma unroll
-            for (int i = 0; i < K1; ++i) { s0 += L(q * K1 + i) * uv[i]; s1 += DL(q * K1 + i) * uv[i]; }
-            A[0][q * M2 + l] = s0; A[1][q * M2 + l] = s1;
+            for (int i = 0; i < K1; ++i) uv[i] = u[(size_t)node[i] * D + c];
+#pragma unroll
+            for (int q = 0; q < Q1; ++q) {
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int i = 0; i < K1; ++i) { s0 += L(q * K1 + i) * uv[i]; s1 += DL(q * K1 + i) * uv[i]; }
+                A[2 * c][q * M2 + l] = s0; A[2 * c + 1][q * M2 + l] = s1;
+            }
         }
 #pragma unroll
         for (int m = 0; m < NC; ++m) {
@@ -341,45 +434,56 @@ __device__ __forceinline__ void hex_qk_action(int start, int end, const int *__r
             for (int i = 0; i < K1; ++i) cv[i] = cf[m][node[i]];
 #pragma unroll
             for (int q = 0; q < Q1; ++q) {
-                double s0 = 0.0;
+                double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-                for (int i = 0; i < K1; ++i) s0 += L(q * K1 + i) * cv[i];
-                A[2 + m][q * M2 + l] = s0;
+                for (int i = 0; i < K1; ++i) { s0 += L(q * K1 + i) * cv[i]; if (GRAD) s1 += DL(q * K1 + i) * cv[i]; }
+                A[2 * D + m * CA][q * M2 + l] = s0;
+                if (GRAD) A[2 * D + m * CA + CA - 1][q * M2 + l] = s1;
             }
         }
     }
     __syncthreads();
     if (in && p < Q1 && r < K1) {                       // pass 2: (p, r) = (q1, i3), contract i2
-        double v[K1], d[K1];
 #pragma unroll
-        for (int i = 0; i < K1; ++i) { v[i] = A[0][p * M2 + i * M + r]; d[i] = A[1][p * M2 + i * M + r]; }
+        for (int c = 0; c < D; ++c) {
+            double v[K1], d[K1];
 #pragma unroll
-        for (int q = 0; q < Q1; ++q) {
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+            for (int i = 0; i < K1; ++i) { v[i] = A[2 * c][p * M2 + i * M + r]; d[i] = A[2 * c + 1][p * M2 + i * M + r]; }
 #pragma unroll
-            for (int i = 0; i < K1; ++i) { s0 += L(q * K1 + i) * v[i]; s1 += L(q * K1 + i) * d[i]; s2 += DL(q * K1 + i) * v[i]; }
-            const int o = (p * M + q) * M + r;
-            B[0][o] = s0; B[1][o] = s1; B[2][o] = s2;
+            for (int q = 0; q < Q1; ++q) {
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int i = 0; i < K1; ++i) { s0 += L(q * K1 + i) * v[i]; s1 += L(q * K1 + i) * d[i]; s2 += DL(q * K1 + i) * v[i]; }
+                const int o = (p * M + q) * M + r;
+                B[3 * c][o] = s0; B[3 * c + 1][o] = s1; B[3 * c + 2][o] = s2;
+            }
         }
 #pragma unroll
         for (int m = 0; m < NC; ++m) {
-            double cv[K1];
+            double cv[K1], cd[K1];
 #pragma unroll
-            for (int i = 0; i < K1; ++i) cv[i] = A[2 + m][p * M2 + i * M + r];
+            for (int i = 0; i < K1; ++i) { cv[i] = A[2 * D + m * CA][p * M2 + i * M + r]; if (GRAD) cd[i] = A[2 * D + m * CA + CA - 1][p * M2 + i * M + r]; }
 #pragma unroll
             for (int q = 0; q < Q1; ++q) {
-                double s0 = 0.0;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
-                for (int i = 0; i < K1; ++i) s0 += L(q * K1 + i) * cv[i];
-                B[3 + m][(p * M + q) * M + r] = s0;
+                for (int i = 0; i < K1; ++i) {
+                    s0 += L(q * K1 + i) * cv[i];
+                    if (GRAD) { s1 += L(q * K1 + i) * cd[i]; s2 += DL(q * K1 + i) * cv[i]; }
+                }
+                const int o = (p * M + q) * M + r;
+                B[3 * D + m * CB][o] = s0;
+                if (GRAD) { B[3 * D + m * CB + (CB > 1 ? 1 : 0)][o] = s1; B[3 * D + m * CB + CB - 1][o] = s2; }
             }
         }
     }
     __syncthreads();
     if (in && p < Q1 && r < Q1) {                       // passes 3 + 4: (p, r) = (q1, q2); the line is index l*M + i3
-        double vv[K1], d1[K1], d2[K1];
+        double vv[D][K1], d1[D][K1], d2[D][K1];
 #pragma unroll
-        for (int i = 0; i < K1; ++i) { vv[i] = B[0][l * M + i]; d1[i] = B[1][l * M + i]; d2[i] = B[2][l * M + i]; }
+        for (int c = 0; c < D; ++c)
+#pragma unroll
+            for (int i = 0; i < K1; ++i) { vv[c][i] = B[3 * c][l * M + i]; d1[c][i] = B[3 * c + 1][l * M + i]; d2[c][i] = B[3 * c + 2][l * M + i]; }
         // geometry along the line: with (t0, t1) fixed, dx/dt0, dx/dt1 and x are affine in t2 and dx/dt2 is constant
         const double t0 = tables[2 * NTAB + p], t1 = tables[2 * NTAB + r], w01 = tables[2 * NTAB + Q1 + p] * tables[2 * NTAB + Q1 + r];
         const double *X8 = sX[ka];
@@ -393,7 +497,8 @@ __device__ __forceinline__ void hex_qk_action(int start, int end, const int *__r
                 G1[c][f] = (1.0 - t0) * (x01 - x00) + t0 * (x11 - x10);
                 P[c][f] = (1.0 - t0) * ((1.0 - t1) * x00 + t1 * x01) + t0 * ((1.0 - t1) * x10 + t1 * x11);
             }
-        double P1[N1 > 0 ? N1 : 1][2];                  // Q1 coefficients: bilinear in (t0, t1) on the bottom / top face, affine along the line
+        // Q1 coefficients: bilinear in (t0, t1) on the bottom / top face, affine along the line -- and so are their t0 / t1 derivatives
+        double P1[N1 > 0 ? N1 : 1][2], P1a[N1 > 0 ? N1 : 1][2], P1b[N1 > 0 ? N1 : 1][2];
         if constexpr (N1 > 0) {
 #pragma unroll
             for (int m = 0; m < N1; ++m)
@@ -401,30 +506,57 @@ __device__ __forceinline__ void hex_qk_action(int start, int end, const int *__r
                 for (int f = 0; f < 2; ++f) {
                     const double *V = sV1[ka][m];
                     P1[m][f] = (1.0 - t0) * ((1.0 - t1) * V[0 + f] + t1 * V[2 + f]) + t0 * ((1.0 - t1) * V[4 + f] + t1 * V[6 + f]);
+                    if (GRAD) {
+                        P1a[m][f] = (1.0 - t1) * (V[4 + f] - V[0 + f]) + t1 * (V[6 + f] - V[2 + f]);
+                        P1b[m][f] = (1.0 - t0) * (V[2 + f] - V[0 + f]) + t0 * (V[6 + f] - V[4 + f]);
+                    }
                 }
         }
-        double p0[K1], p1[K1], sv[K1];
+        double p0[D][K1], p1[D][K1], sv[D][K1];
 #pragma unroll
-        for (int i = 0; i < K1; ++i) { p0[i] = 0.0; p1[i] = 0.0; sv[i] = 0.0; }
+        for (int c = 0; c < D; ++c)
+#pragma unroll
+            for (int i = 0; i < K1; ++i) { p0[c][i] = 0.0; p1[c][i] = 0.0; sv[c][i] = 0.0; }
 #pragma unroll
         for (int q = 0; q < Q1; ++q) {
-            double g[4] = {0.0, 0.0, 0.0, 0.0};         // d1 u, d2 u, d3 u, u at the Gauss point (p, r, q)
+            double g[D][4];                             // d1 u, d2 u, d3 u, u (per component) at the Gauss point (p, r, q)
 #pragma unroll
-            for (int i = 0; i < K1; ++i) {
-                g[0] += L(q * K1 + i) * d1[i]; g[1] += L(q * K1 + i) * d2[i]; g[2] += DL(q * K1 + i) * vv[i]; g[3] += L(q * K1 + i) * vv[i];
+            for (int c = 0; c < D; ++c) {
+                g[c][0] = g[c][1] = g[c][2] = g[c][3] = 0.0;
+#pragma unroll
+                for (int i = 0; i < K1; ++i) {
+                    g[c][0] += L(q * K1 + i) * d1[c][i]; g[c][1] += L(q * K1 + i) * d2[c][i];
+                    g[c][2] += DL(q * K1 + i) * vv[c][i]; g[c][3] += L(q * K1 + i) * vv[c][i];
+                }
             }
             const double t2 = tables[2 * NTAB + q];
-            double J[3][3], X[3], W[16], F[4], C[NC + N1 > 0 ? NC + N1 : 1];
+            double J[3][3], X[3], W[16 * D * D], C[NCT], DC[3 * NCT];
 #pragma unroll
             for (int m = 0; m < NC; ++m) {
-                double cq = 0.0;
+                double cq = 0.0, c0 = 0.0, c1v = 0.0, c2 = 0.0;
 #pragma unroll
-                for (int i = 0; i < K1; ++i) cq += L(q * K1 + i) * B[3 + m][l * M + i];
+                for (int i = 0; i < K1; ++i) {
+                    const double bv = B[3 * D + m * CB][l * M + i];
+                    cq += L(q * K1 + i) * bv;
+                    if (GRAD) {
+                        c0 += L(q * K1 + i) * B[3 * D + m * CB + (CB > 1 ? 1 : 0)][l * M + i];
+                        c1v += L(q * K1 + i) * B[3 * D + m * CB + CB - 1][l * M + i];
+                        c2 += DL(q * K1 + i) * bv;
+                    }
+                }
                 C[m] = cq;
+                if (GRAD) { DC[3 * m] = c0; DC[3 * m + 1] = c1v; DC[3 * m + 2] = c2; }
             }
             if constexpr (N1 > 0) {
 #pragma unroll
-                for (int m = 0; m < N1; ++m) C[NC + m] = P1[m][0] + t2 * (P1[m][1] - P1[m][0]);
+                for (int m = 0; m < N1; ++m) {
+                    C[NC + m] = P1[m][0] + t2 * (P1[m][1] - P1[m][0]);
+                    if (GRAD) {
+                        DC[3 * (NC + m)] = P1a[m][0] + t2 * (P1a[m][1] - P1a[m][0]);
+                        DC[3 * (NC + m) + 1] = P1b[m][0] + t2 * (P1b[m][1] - P1b[m][0]);
+                        DC[3 * (NC + m) + 2] = P1[m][1] - P1[m][0];
+                    }
+                }
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -433,41 +565,60 @@ __device__ __forceinline__ void hex_qk_action(int start, int end, const int *__r
                 J[c][2] = P[c][1] - P[c][0];
                 X[c] = P[c][0] + t2 * (P[c][1] - P[c][0]);
             }
-            weights(J, X, w01 * tables[2 * NTAB + Q1 + q], C, W);
+            weights(J, X, w01 * tables[2 * NTAB + Q1 + q], C, DC, W);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) F[m] = W[m * 4 + 0] * g[0] + W[m * 4 + 1] * g[1] + W[m * 4 + 2] * g[2] + W[m * 4 + 3] * g[3];
+            for (int c = 0; c < D; ++c) {
+                double F[4];
 #pragma unroll
-            for (int i = 0; i < K1; ++i) {
-                p0[i] += L(q * K1 + i) * F[0]; p1[i] += L(q * K1 + i) * F[1]; sv[i] += DL(q * K1 + i) * F[2] + L(q * K1 + i) * F[3];
+                for (int m = 0; m < 4; ++m) {
+                    double f = 0.0;
+#pragma unroll
+                    for (int cr = 0; cr < D; ++cr)
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) f += W[((c * 4 + m) * 4 * D) + cr * 4 + kk] * g[cr][kk];
+                    F[m] = f;
+                }
+#pragma unroll
+                for (int i = 0; i < K1; ++i) {
+                    p0[c][i] += L(q * K1 + i) * F[0]; p1[c][i] += L(q * K1 + i) * F[1]; sv[c][i] += DL(q * K1 + i) * F[2] + L(q * K1 + i) * F[3];
+                }
             }
         }
 #pragma unroll
-        for (int i = 0; i < K1; ++i) { B[0][l * M + i] = p0[i]; B[1][l * M + i] = p1[i]; B[2][l * M + i] = sv[i]; }
+        for (int c = 0; c < D; ++c)
+#pragma unroll
+            for (int i = 0; i < K1; ++i) { B[3 * c][l * M + i] = p0[c][i]; B[3 * c + 1][l * M + i] = p1[c][i]; B[3 * c + 2][l * M + i] = sv[c][i]; }
     }
     __syncthreads();
     if (in && p < Q1 && r < K1) {                       // pass 5: (p, r) = (q1, i3), q2 -> i2
-        double a0[Q1], a1[Q1], a2[Q1];
 #pragma unroll
-        for (int q = 0; q < Q1; ++q) { const int o = (p * M + q) * M + r; a0[q] = B[0][o]; a1[q] = B[1][o]; a2[q] = B[2][o]; }
+        for (int c = 0; c < D; ++c) {
+            double a0[Q1], a1[Q1], a2[Q1];
 #pragma unroll
-        for (int i = 0; i < K1; ++i) {
-            double r0 = 0.0, r1 = 0.0;
+            for (int q = 0; q < Q1; ++q) { const int o = (p * M + q) * M + r; a0[q] = B[3 * c][o]; a1[q] = B[3 * c + 1][o]; a2[q] = B[3 * c + 2][o]; }
 #pragma unroll
-            for (int q = 0; q < Q1; ++q) { r0 += L(q * K1 + i) * a0[q]; r1 += DL(q * K1 + i) * a1[q] + L(q * K1 + i) * a2[q]; }
-            A[0][p * M2 + i * M + r] = r0; A[1][p * M2 + i * M + r] = r1;
+            for (int i = 0; i < K1; ++i) {
+                double r0 = 0.0, r1 = 0.0;
+#pragma unroll
+                for (int q = 0; q < Q1; ++q) { r0 += L(q * K1 + i) * a0[q]; r1 += DL(q * K1 + i) * a1[q] + L(q * K1 + i) * a2[q]; }
+                A[2 * c][p * M2 + i * M + r] = r0; A[2 * c + 1][p * M2 + i * M + r] = r1;
+            }
         }
     }
     __syncthreads();
     if (on1) {                                          // pass 6: line l = (i2, i3), q1 -> i1
-        double r0[Q1], r1[Q1];
 #pragma unroll
-        for (int q = 0; q < Q1; ++q) { r0[q] = A[0][q * M2 + l]; r1[q] = A[1][q * M2 + l]; }
+        for (int c = 0; c < D; ++c) {
+            double r0[Q1], r1[Q1];
 #pragma unroll
-        for (int i = 0; i < K1; ++i) {
-            double yv = 0.0;
+            for (int q = 0; q < Q1; ++q) { r0[q] = A[2 * c][q * M2 + l]; r1[q] = A[2 * c + 1][q * M2 + l]; }
 #pragma unroll
-            for (int q = 0; q < Q1; ++q) yv += DL(q * K1 + i) * r0[q] + L(q * K1 + i) * r1[q];
-            atomicAdd(&y[node[i]], yv);
+            for (int i = 0; i < K1; ++i) {
+                double yv = 0.0;
+#pragma unroll
+                for (int q = 0; q < Q1; ++q) yv += DL(q * K1 + i) * r0[q] + L(q * K1 + i) * r1[q];
+                atomicAdd(&y[(size_t)node[i] * D + c], yv);
+            }
         }
     }
 }

@@ -578,6 +578,11 @@ def precompile_all():
         for prob in (HelmholtzQ4Problem(hm, bcs=bcs), CoefficientHexProblem(hm, bcs=bcs, nq=5)):
             for loop in (prob.jac_loop, prob.act_loop):
                 build(loop.global_kernel, [None])
+    # the wider descriptors of the bench line: a coefficient gradient (Q3) and a vector-valued space ((Q2)^3)
+    for prob in (NonlinearDiffusionHexProblem(fmesh.make_extruded_hex_mesh(1, 1, 3, perturb=0.0), bcs=True),
+                 ElasticityHexProblem(fmesh.make_extruded_hex_mesh(1, 1, 2, perturb=0.0), bcs=True)):
+        for loop in (prob.jac_loop, prob.act_loop):
+            build(loop.global_kernel, [None])
     # config C4: the three DG advection loops
     qm = fmesh.make_quad_mesh(4, perturb=0.1)
     for loop, variant in zip(DGAdvectionProblem(qm).loops, BENCH_VARIANTS["dg_advection"]):
@@ -901,6 +906,217 @@ class CoefficientHexProblem(HelmholtzHexProblem):
                                           self.w0(op2.READ, wm), self.u0(op2.READ, cm))
         self.act_loop = op2.LegacyParloop(self.kact, m.cell_set, self.y(op2.INC, cm), m.coordinates(op2.READ, xm), self.u(op2.READ, cm),
                                           self.w0(op2.READ, wm), self.u0(op2.READ, cm))
+
+
+_HEX_POINT_GEOMETRY = """
+    const double t[3] = {QP[q1], QP[q2], QP[q3]};
+    double J[3][3] = {{0,0,0},{0,0,0},{0,0,0}}, NV[8], DNV[8][3];
+    for (int v = 0; v < 8; ++v) {
+      const int a = v >> 2, b = (v >> 1) & 1, c = v & 1;
+      const double Na = a ? t[0] : 1.0 - t[0], Nb = b ? t[1] : 1.0 - t[1], Nc = c ? t[2] : 1.0 - t[2];
+      const double da = a ? 1.0 : -1.0, db = b ? 1.0 : -1.0, dc = c ? 1.0 : -1.0;
+      NV[v] = Na*Nb*Nc; DNV[v][0] = da*Nb*Nc; DNV[v][1] = Na*db*Nc; DNV[v][2] = Na*Nb*dc;
+      for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) J[r][s] += x[3*v + r] * DNV[v][s];
+    }
+    const double c00 = J[1][1]*J[2][2] - J[1][2]*J[2][1], c01 = J[1][2]*J[2][0] - J[1][0]*J[2][2], c02 = J[1][0]*J[2][1] - J[1][1]*J[2][0];
+    const double det = J[0][0]*c00 + J[0][1]*c01 + J[0][2]*c02, id = 1.0 / det;
+    const double K[3][3] = {
+      { c00*id, (J[0][2]*J[2][1] - J[0][1]*J[2][2])*id, (J[0][1]*J[1][2] - J[0][2]*J[1][1])*id },
+      { c01*id, (J[0][0]*J[2][2] - J[0][2]*J[2][0])*id, (J[0][2]*J[1][0] - J[0][0]*J[1][2])*id },
+      { c02*id, (J[0][1]*J[2][0] - J[0][0]*J[2][1])*id, (J[0][0]*J[1][1] - J[0][1]*J[1][0])*id } };
+    const double w = QW[q1]*QW[q2]*QW[q3]*fabs(det);
+    double ph[ND], dx[ND][3];                     /* basis values and PHYSICAL gradients at the point */
+    for (int i1 = 0; i1 < K1; ++i1) for (int i2 = 0; i2 < K1; ++i2) for (int i3 = 0; i3 < K1; ++i3) {
+      const int i = (i1*K1 + i2)*K1 + i3;
+      const double dr[3] = {DL[q1][i1]*L[q2][i2]*L[q3][i3], L[q1][i1]*DL[q2][i2]*L[q3][i3], L[q1][i1]*L[q2][i2]*DL[q3][i3]};
+      ph[i] = L[q1][i1]*L[q2][i2]*L[q3][i3];
+      for (int s = 0; s < 3; ++s) dx[i][s] = K[0][s]*dr[0] + K[1][s]*dr[1] + K[2][s]*dr[2];
+    }
+"""
+
+
+def _hex_dense_head(name, args, degree, nq):
+    k1 = degree + 1
+    L, DL, qp, qw = q4_tables(degree, nq)
+    return f"""
+static void {name}({args})
+{{
+  enum {{ K1 = {k1}, ND = {k1 ** 3} }};
+  static const double L[{nq}][{k1}] = {_c(L)};
+  static const double DL[{nq}][{k1}] = {_c(DL)};
+  static const double QP[{nq}] = {_c(qp)};
+  static const double QW[{nq}] = {_c(qw)};
+  for (int q1 = 0; q1 < {nq}; ++q1) for (int q2 = 0; q2 < {nq}; ++q2) for (int q3 = 0; q3 < {nq}; ++q3) {{
+{_HEX_POINT_GEOMETRY}"""
+
+
+def _dense_action(name, nrow, extra_params, extra_pass):
+    """y += A_e u on top of the dense matrix kernel ``<name>_matrix``: what the oracle executes for an action descriptor"""
+    return f"""
+static void {name}(double *restrict y, const double *restrict x, const double *restrict u{extra_params})
+{{
+  static double A[{nrow}*{nrow}];
+  for (int q = 0; q < {nrow}*{nrow}; ++q) A[q] = 0.0;
+  {name}_matrix(A, x{extra_pass});
+  for (int i = 0; i < {nrow}; ++i) {{
+    double s = 0.0;
+    for (int j = 0; j < {nrow}; ++j) s += A[i*{nrow} + j] * u[j];
+    y[i] += s;
+  }}
+}}
+"""
+
+
+def nonlinear_diffusion_hex_jacobian_kernel(degree=2, nq=None, name=None, space="k"):
+    """The Newton Jacobian of F(u; v) = int (1 + |grad u|^2) grad(u).grad(v) dx at u0 on a trilinear hexahedron, Q_degree basis:
+        a(du, v) = int (1 + |grad u0|^2) grad(du).grad(v) + 2 (grad u0 . grad du)(grad u0 . grad v) dx
+    -- a form whose point weight needs the GRADIENT of a coefficient at the Gauss points (tsfc/fem.py:742-805).  Arguments in TSFC's
+    order: A[nd*nd], coords[24], u0[nd] (``space`` "k") or u0[8] ("1": a field in the Q1 space of the coordinates).  Dense C text for
+    the oracle and the direct wrapper; descriptor with ``coef_gradients`` for the tensor-product wrappers."""
+    from .kernel import TensorProductLocalKernel
+    from .tensor import nonlinear_diffusion_weights
+    nq = nq or degree + 1
+    name = name or f"nonlinear_diffusion_q{degree}_hex_jacobian"
+    grad = ("for (int i = 0; i < ND; ++i) for (int s = 0; s < 3; ++s) g[s] += dx[i][s] * w0[i];" if space == "k" else
+            "for (int v = 0; v < 8; ++v) for (int s = 0; s < 3; ++s) g[s] += (K[0][s]*DNV[v][0] + K[1][s]*DNV[v][1] + K[2][s]*DNV[v][2]) * w0[v];")
+    body = _hex_dense_head(name, "double *restrict A, const double *restrict x, const double *restrict w0", degree, nq) + f"""
+    double g[3] = {{0, 0, 0}};
+    {grad}
+    const double kappa = 1.0 + g[0]*g[0] + g[1]*g[1] + g[2]*g[2];
+    for (int i = 0; i < ND; ++i) {{
+      const double gi = g[0]*dx[i][0] + g[1]*dx[i][1] + g[2]*dx[i][2];
+      for (int j = 0; j < ND; ++j)
+        A[i*ND + j] += w * (kappa * (dx[i][0]*dx[j][0] + dx[i][1]*dx[j][1] + dx[i][2]*dx[j][2])
+                            + 2.0 * gi * (g[0]*dx[j][0] + g[1]*dx[j][1] + g[2]*dx[j][2]));
+    }}
+    (void)NV; (void)ph;
+  }}
+}}
+"""
+    return TensorProductLocalKernel(body, name, kind="matrix", degree=degree, nq=nq, ncoef=1, coef_gradients=True,
+                                    weights_code=nonlinear_diffusion_weights(name))
+
+
+def nonlinear_diffusion_hex_action_kernel(degree=2, nq=None, name=None, space="k"):
+    """y += A_e(coords, u0) du for the same Jacobian (the matrix-free Newton operator).  Arguments: y[nd], coords[24], du[nd], u0."""
+    from .kernel import TensorProductLocalKernel
+    from .tensor import nonlinear_diffusion_weights
+    nq = nq or degree + 1
+    name = name or f"nonlinear_diffusion_q{degree}_hex_action"
+    jac = nonlinear_diffusion_hex_jacobian_kernel(degree, nq, name + "_matrix", space)
+    body = jac.code + _dense_action(name, (degree + 1) ** 3, ", const double *restrict w0", ", w0")
+    return TensorProductLocalKernel(body, name, kind="action", degree=degree, nq=nq, ncoef=1, coef_gradients=True,
+                                    weights_code=nonlinear_diffusion_weights(name))
+
+
+def elasticity_hex_jacobian_kernel(degree=2, nq=None, name=None, mu=1.0, lam=1.25, rho=0.0):
+    """a(u, v) = int 2 mu eps(u):eps(v) + lam div(u) div(v) + rho u.v dx on (Q_degree)^3 over a trilinear hexahedron: a VECTOR-VALUED
+    space -- Mat dims (3, 3), element tensor A[(i*3 + p)*(3 nd) + j*3 + r] (builder.py:573-625, MatSetValuesBlockedLocal).  Arguments:
+    A[(3 nd)^2], coords[24].  Dense C text for the oracle; descriptor with ``vdim`` = 3 for the tensor-product wrappers."""
+    from .kernel import TensorProductLocalKernel
+    from .tensor import elasticity_weights
+    nq = nq or degree + 1
+    name = name or f"elasticity_q{degree}_hex_jacobian"
+    body = _hex_dense_head(name, "double *restrict A, const double *restrict x", degree, nq) + f"""
+    for (int i = 0; i < ND; ++i) for (int p = 0; p < 3; ++p) for (int j = 0; j < ND; ++j) for (int r = 0; r < 3; ++r) {{
+      double v = {float(mu)!r} * dx[i][r] * dx[j][p] + {float(lam)!r} * dx[i][p] * dx[j][r];
+      if (p == r) v += {float(mu)!r} * (dx[i][0]*dx[j][0] + dx[i][1]*dx[j][1] + dx[i][2]*dx[j][2]) + {float(rho)!r} * ph[i] * ph[j];
+      A[(i*3 + p)*(3*ND) + j*3 + r] += w * v;
+    }}
+    (void)NV;
+  }}
+}}
+"""
+    return TensorProductLocalKernel(body, name, kind="matrix", degree=degree, nq=nq, vdim=3, weights_code=elasticity_weights(name, mu, lam, rho))
+
+
+def elasticity_hex_action_kernel(degree=2, nq=None, name=None, mu=1.0, lam=1.25, rho=0.0):
+    """y += A_e(coords) u for the same form: y, u Dats of dim 3 on the Q_degree map (y[i*3 + p])."""
+    from .kernel import TensorProductLocalKernel
+    from .tensor import elasticity_weights
+    nq = nq or degree + 1
+    name = name or f"elasticity_q{degree}_hex_action"
+    jac = elasticity_hex_jacobian_kernel(degree, nq, name + "_matrix", mu, lam, rho)
+    body = jac.code + _dense_action(name, 3 * (degree + 1) ** 3, "", "")
+    return TensorProductLocalKernel(body, name, kind="action", degree=degree, nq=nq, vdim=3, weights_code=elasticity_weights(name, mu, lam, rho))
+
+
+class NonlinearDiffusionHexProblem(HelmholtzHexProblem):
+    """The Newton Jacobian of int (1 + |grad u|^2) grad(u).grad(v) dx at u0 on extruded Q_k hexahedra, as a matrix and matrix-free: the
+    linearisation point enters through its gradient at the Gauss points (TensorProductLocalKernel ``coef_gradients``).
+    ``q1_state``: u0 in the Q1 space of the coordinates instead of the Q_k space of the unknown."""
+
+    def __init__(self, hexmesh, bcs=False, nq=None, q1_state=False):
+        super().__init__(hexmesh, bcs, nq)
+        m = hexmesh
+        cm, xm = m.cell_node_map, m.coord_map
+        if q1_state:
+            xp = np.asarray(m.coordinates.data_ro_with_halos)
+            self.u0 = op2.Dat(m.coordinates.dataset.set, np.cos(2 * xp[:, 0]) * np.sin(3 * xp[:, 1] + 1.0) + 0.2 * xp[:, 2] ** 2, np.float64, "u0_q1")
+        else:
+            pts = m.node_points
+            self.u0 = op2.Dat(m.node_set, np.cos(2 * pts[:, 0]) * np.sin(3 * pts[:, 1] + 1.0) + 0.2 * pts[:, 2] ** 2, np.float64, "u0")
+        lg = self.jac_loop.arguments[0].lgmaps
+        space, tag = ("1", "q1state_") if q1_state else ("k", "")
+        self.kjac = nonlinear_diffusion_hex_jacobian_kernel(m.degree, nq, f"nonlinear_diffusion_{tag}q{m.degree}_hex_jacobian", space)
+        self.kact = nonlinear_diffusion_hex_action_kernel(m.degree, nq, f"nonlinear_diffusion_{tag}q{m.degree}_hex_action", space)
+        wm = xm if q1_state else cm
+        self.jac_loop = op2.LegacyParloop(self.kjac, m.cell_set, self.mat(op2.INC, (cm, cm), lgmaps=lg), m.coordinates(op2.READ, xm),
+                                          self.u0(op2.READ, wm))
+        self.act_loop = op2.LegacyParloop(self.kact, m.cell_set, self.y(op2.INC, cm), m.coordinates(op2.READ, xm), self.u(op2.READ, cm),
+                                          self.u0(op2.READ, wm))
+
+
+class ElasticityHexProblem:
+    """Linear elasticity on (Q_k)^3 over an extruded hex mesh: a vector-valued tensor-product space -- Mat with dims (3, 3), Dats of dim
+    3 -- through the same two wrappers (fp64-MFMA matrix, one scalar contraction per component pair; sum-factorised action)."""
+
+    def __init__(self, hexmesh, bcs=False, nq=None, mu=1.0, lam=1.25, rho=0.0):
+        self.mesh = m = hexmesh
+        nd, nqp = (m.degree + 1) ** 3, (nq or m.degree + 1) ** 3
+        pad = -(-nd // 16) * 16
+        self.FLOPS_PER_CELL = 9 * 2.0 * pad * pad * 4 * nqp       # MFMA work issued: nine padded scalar blocks
+        self.ALGO_FLOPS_PER_CELL = 9 * 2.0 * nd * nd * 4 * nqp
+        cm, xm = m.cell_node_map, m.coord_map
+        vset = m.node_set ** 3
+        self.sparsity = op2.Sparsity((vset, vset), [(cm, cm, None)])
+        self.mat = op2.Mat(self.sparsity)
+        pts = m.node_points
+        bnd = np.nonzero(((pts < 1e-12) | (pts > 1 - 1e-12)).any(axis=1))[0].astype(np.int32)
+        self.bc_nodes = bnd if bcs else np.zeros(0, dtype=np.int32)
+        lg = None
+        if len(self.bc_nodes):
+            rlg = np.arange(m.node_set.total_size, dtype=np.int32)
+            rlg[self.bc_nodes] = -1
+            lg = (rlg, rlg.copy())
+        self.kjac = elasticity_hex_jacobian_kernel(m.degree, nq, None, mu, lam, rho)
+        self.kact = elasticity_hex_action_kernel(m.degree, nq, None, mu, lam, rho)
+        self.jac_loop = op2.LegacyParloop(self.kjac, m.cell_set, self.mat(op2.INC, (cm, cm), lgmaps=lg), m.coordinates(op2.READ, xm))
+        uv = np.stack([np.sin(3 * pts[:, 0]) * np.cos(2 * pts[:, 1]) + 0.3 * pts[:, 2], pts[:, 0] * pts[:, 1] - 0.5 * pts[:, 2] ** 2,
+                       np.cos(pts[:, 0] + 2 * pts[:, 2])], axis=1)
+        self.u = op2.Dat(vset, uv, np.float64, "u")
+        self.y = op2.Dat(vset, None, np.float64, "y")
+        self.act_loop = op2.LegacyParloop(self.kact, m.cell_set, self.y(op2.INC, cm), m.coordinates(op2.READ, xm), self.u(op2.READ, cm))
+
+    def assemble_jacobian(self, events=None):
+        self.mat.zero()
+        if events:
+            self.jac_loop.zero_ahead()
+            events[0].record()
+        self.jac_loop()
+        if events:
+            events[1].record()
+        return self.mat
+
+    def assemble_action(self, events=None):
+        self.y.zero()
+        with self.y.frozen_halo(op2.INC):
+            if events:
+                events[0].record()
+            self.act_loop()
+            if events:
+                events[1].record()
+        return self.y
 
 
 class HelmholtzQ4Problem(HelmholtzHexProblem):

@@ -136,14 +136,26 @@ class TensorProductLocalKernel(CStringLocalKernel):
     ``ncoef`` > 0: the form has coefficient arguments -- ``ncoef`` scalar READ Dats on the Q_k map after the standard arguments
     (A, coords, w_0 ... / y, coords, u, w_0 ...), the ``w_k`` TSFC passes to a variable-coefficient or linearised nonlinear form
     (tsfc/kernel_interface/firedrake_loopy.py:432-522).  The templates evaluate them at the Gauss points (sum-factorised) and the
-    callback becomes ``<name>_weights(J, X, wq, const double *C, W)`` with C[m] = value of coefficient m at the point."""
+    callback becomes ``<name>_weights(J, X, wq, const double *C, W)`` with C[m] = value of coefficient m at the point.
 
-    def __init__(self, code, name, accesses=None, dtypes=None, *, kind, degree, nq, weights_code, ncoef=0, **kwargs):
+    ``coef_gradients``: the callback also receives the coefficients' REFERENCE gradients, ``<name>_weights(J, X, wq, C, DC, W)`` with
+    DC[3*m + a] = d C[m] / d xi_a (physical gradient = K^T DC, K = J^-1) -- the linearisation of a form nonlinear in grad(u0)
+    (tsfc/fem.py:742-805 tabulates the derivative tables for exactly this).
+
+    ``vdim`` = D > 1: a vector-valued space (Q_k)^D -- the unknown (and y, u of the action) are Dats of dim D, the Mat has dims (D, D)
+    and the element tensor is t[(i*D + p)][(j*D + r)] (MatSetValuesBlockedLocal, builder.py:573-625); the callback fills the 4D x 4D
+    block weight W[((p*4 + l) * 4D) + r*4 + k] (reference component l of test component p against k of trial component r)."""
+
+    def __init__(self, code, name, accesses=None, dtypes=None, *, kind, degree, nq, weights_code, ncoef=0, coef_gradients=False, vdim=1,
+                 **kwargs):
         if kind not in ("matrix", "action"):
             raise ValueError("TensorProductLocalKernel kind must be 'matrix' or 'action'")
         kwargs.setdefault("requires_zeroed_output_arguments", True)
         super().__init__(code, name, accesses, dtypes, **kwargs)
-        self.tp = {"kind": kind, "degree": int(degree), "nq": int(nq), "weights_code": weights_code, "ncoef": int(ncoef)}
+        if not 1 <= int(vdim) <= 3:
+            raise ValueError("TensorProductLocalKernel vdim must be 1, 2 or 3")
+        self.tp = {"kind": kind, "degree": int(degree), "nq": int(nq), "weights_code": weights_code, "ncoef": int(ncoef),
+                   "coef_gradients": bool(coef_gradients) and int(ncoef) > 0, "vdim": int(vdim)}
 
     @property
     def cache_key(self):

@@ -91,3 +91,59 @@ static inline void NAME_weights(const double J[3][3], const double X[3], double 
 def coefficient_weights(name, kappa="1.0", react="1.0"):
     """``weights_code`` of a(u, v) = int kappa grad(u).grad(v) + react u v dx, kappa / react C expressions in C[] and X[]."""
     return COEFFICIENT_WEIGHTS.replace("NAME", name).replace("KAPPA", f"({kappa})").replace("REACT", f"({react})")
+
+
+# The Jacobian of F(u; v) = int (1 + |grad u|^2) grad(u).grad(v) dx at u0 (coefficient 0, with its REFERENCE gradient DC[0..2]):
+#     a(du, v) = int (1 + |g|^2) grad(du).grad(v) + 2 (g.grad(du)) (g.grad(v)) dx,     g = grad(u0) = K^T DC
+# -- the point weight is kappa K K^T + 2 (K g)(K g)^T on the gradient block.
+NONLINEAR_DIFFUSION_WEIGHTS = """
+static inline void NAME_weights(const double J[3][3], const double X[3], double wq, const double *C, const double *DC, double W[16])
+{
+  double K[3][3], det, g[3], Kg[3];
+  fdt::inv3(J, K, det);
+  const double w = wq * fabs(det);
+  for (int r = 0; r < 3; ++r) g[r] = K[0][r]*DC[0] + K[1][r]*DC[1] + K[2][r]*DC[2];
+  for (int a = 0; a < 3; ++a) Kg[a] = K[a][0]*g[0] + K[a][1]*g[1] + K[a][2]*g[2];
+  const double kappa = 1.0 + g[0]*g[0] + g[1]*g[1] + g[2]*g[2];
+  for (int a = 0; a < 3; ++a) {
+    for (int b = 0; b < 3; ++b) W[a*4 + b] = w * (kappa * (K[a][0]*K[b][0] + K[a][1]*K[b][1] + K[a][2]*K[b][2]) + 2.0 * Kg[a] * Kg[b]);
+    W[a*4 + 3] = 0.0;
+    W[12 + a] = 0.0;
+  }
+  W[15] = 0.0;
+  (void)X; (void)C;
+}
+"""
+
+
+def nonlinear_diffusion_weights(name):
+    """``weights_code`` (coef_gradients=True, ncoef=1) of the Newton Jacobian of int (1 + |grad u|^2) grad(u).grad(v) dx at u0."""
+    return NONLINEAR_DIFFUSION_WEIGHTS.replace("NAME", name)
+
+
+# Linear elasticity on (Q_k)^3:  a(u, v) = int 2 mu eps(u):eps(v) + lambda div(u) div(v) + rho u.v dx.  With v = e_p phi_i, u = e_r phi_j:
+#     mu (delta_pr grad(phi_i).grad(phi_j) + d_r phi_i d_p phi_j) + lambda d_p phi_i d_r phi_j + rho delta_pr phi_i phi_j
+# and d_s phi = sum_l K[l][s] dhat_l phi, so the 12 x 12 point weight is, on the gradient components (l of the test side, k of the trial side),
+#     W[(p,l),(r,k)] = w ( mu delta_pr (K K^T)[l][k] + mu K[l][r] K[k][p] + lambda K[l][p] K[k][r] ),     W[(p,3),(r,3)] = w rho delta_pr.
+ELASTICITY_WEIGHTS = """
+static inline void NAME_weights(const double J[3][3], const double X[3], double wq, double W[144])
+{
+  double K[3][3], det;
+  fdt::inv3(J, K, det);
+  const double w = wq * fabs(det);
+  for (int p = 0; p < 3; ++p) for (int l = 0; l < 4; ++l) for (int r = 0; r < 3; ++r) for (int k = 0; k < 4; ++k) {
+    double v = 0.0;
+    if (l < 3 && k < 3)
+      v = MU * ((p == r ? K[l][0]*K[k][0] + K[l][1]*K[k][1] + K[l][2]*K[k][2] : 0.0) + K[l][r]*K[k][p]) + LAMBDA * K[l][p]*K[k][r];
+    else if (l == 3 && k == 3 && p == r)
+      v = RHO;
+    W[(p*4 + l)*12 + r*4 + k] = w * v;
+  }
+  (void)X;
+}
+"""
+
+
+def elasticity_weights(name, mu=1.0, lam=1.0, rho=0.0):
+    """``weights_code`` (vdim=3) of a(u, v) = int 2 mu eps(u):eps(v) + lam div(u) div(v) + rho u.v dx."""
+    return ELASTICITY_WEIGHTS.replace("NAME", name).replace("MU", repr(float(mu))).replace("LAMBDA", repr(float(lam))).replace("RHO", repr(float(rho)))

@@ -644,7 +644,8 @@ def run_tensor(pl, initial=None):
     start, end = 0, pl.iterset.size
     nl = pl.iterset.layers - 1
     ncell = (end - start) * nl
-    nblocks = ncell * src.tp["matrix_groups"] if src.mode == "tp_matrix" else -(-ncell // src.tp["action_cells"])
+    vd = int(gk.local_kernel.tp.get("vdim", 1))
+    nblocks = ncell * src.tp["matrix_groups"] * vd * vd if src.mode == "tp_matrix" else -(-ncell // src.tp["action_cells"])
     outs, keep = {}, []
 
     def ptr(a):
@@ -675,8 +676,11 @@ def run_tensor(pl, initial=None):
                 cargs.append(ctypes.c_void_p(a.ctypes.data))
         elif kind == "map":
             cargs.append(ptr(np.asarray(maps[desc[1]].values_with_halo, dtype=np.int32)))
-        elif kind == "mat_rowptr":
-            cargs.append(ptr(np.asarray(csr.rowptr, dtype=np.int32)))
+        elif kind == "mat_node_rowptr":
+            # node-level row starts: scalar row (node, p) of a (D, D)-blocked Mat starts at node_rowptr[node]*D*D + p*rowlen*D
+            node_rp = np.asarray(csr.rowptr[::vd] // (vd * vd), dtype=np.int32)
+            node_ci = [np.asarray(csr.colidx[csr.rowptr[n * vd]:csr.rowptr[n * vd + 1]][::vd] // vd) for n in range(len(node_rp) - 1)]
+            cargs.append(ptr(node_rp))
         elif kind == "tp_offtab":
             # Parloop._tp_offtab restated: position of entry (i, j) inside its CSR row for the bottom / an interior / the top cell
             m = pl.arguments[desc[1]].maps[0]._base()
@@ -687,7 +691,7 @@ def run_tensor(pl, initial=None):
                 for v, lay in enumerate((0, min(1, nl - 1), nl - 1)):
                     nodes = mv[c] + off * lay
                     for i, rn in enumerate(nodes):
-                        cols = csr.colidx[csr.rowptr[rn]:csr.rowptr[rn + 1]]
+                        cols = node_ci[rn]
                         pos = np.searchsorted(cols, nodes)
                         assert (cols[pos] == nodes).all()
                         tab[c, v, i] = pos

@@ -7,7 +7,7 @@ import pytest
 from numpy.testing import assert_allclose
 
 import hostsim
-from firedrake_amd import forms, mesh as fmesh
+from firedrake_amd import forms, mesh as fmesh, op2
 from test_gpu_q4_hex import _oracle_action, _oracle_matrix
 
 
@@ -154,3 +154,71 @@ def test_matrix_template_accumulates_on_top_of_existing_values(degree, nq, n, bc
     for b in (prob.bc_nodes if bcs else ()):
         expect[rp[b] + np.searchsorted(ci[rp[b]:rp[b + 1]], b)] = 0.0
     assert_allclose(acc.values, start + expect, rtol=0, atol=tol)
+
+
+def _oracle_loop(pl):
+    """the loop's own arguments through the oracle (generic adapter: blocked Mats, coefficient arguments on either map)"""
+    from firedrake_amd.parloop import MatParloopArg
+    from helpers import oracle_run
+    args = [pa.data(acc, pa.maps, lgmaps=pa.lgmaps) if isinstance(pa, MatParloopArg) else pa.data(acc, pa.map_)
+            for pa, acc in zip(pl.arguments, pl.accesses)]
+    for pa, acc in zip(pl.arguments, pl.accesses):
+        if int(acc) != int(op2.READ) and not isinstance(pa, MatParloopArg):
+            pa.data.zero()                                     # (the oracle starts from the carrier's values)
+    return oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
+
+
+@pytest.mark.parametrize("degree,nq,bcs,q1_state", [(2, 3, False, False), (3, 4, True, False), (2, 4, True, True), (1, 2, False, False)])
+def test_coefficient_gradients_through_the_tensor_templates_on_the_host(degree, nq, bcs, q1_state):
+    """The Newton Jacobian of int (1 + |grad u|^2) grad(u).grad(v) dx at u0: the point weight needs grad(u0) at the Gauss points
+    (tsfc/fem.py:742-805 tabulates the derivative tables for coefficients exactly like for arguments).  The templates evaluate the
+    reference gradient sum-factorised next to the value (matrix: three more results of the same LDS passes; action: the coefficient
+    rides the axis passes like u itself) -- or, for a state in the Q1 space of the coordinates, from the staged vertex values --
+    and hand it to the callback as DC; against the oracle's dense kernel that sums grad(phi_i) u0_i point by point."""
+    m = fmesh.make_extruded_hex_mesh(2 if degree < 3 else 1, 2, degree, perturb=0.1)
+    prob = forms.NonlinearDiffusionHexProblem(m, bcs=bcs, nq=nq, q1_state=q1_state)
+    from firedrake_amd.codegen import tensor_eligible
+    assert tensor_eligible(prob.jac_loop.global_kernel) == "matrix" and tensor_eligible(prob.act_loop.global_kernel) == "action"
+    csr = hostsim.run_tensor(prob.jac_loop)[0]
+    ref = _oracle_loop(prob.jac_loop)
+    assert np.array_equal(csr.rowptr, ref.rowptr) and np.array_equal(csr.colidx, ref.colidx)
+    assert_allclose(csr.values, ref.values, rtol=0, atol=1e-11 * np.abs(ref.values).max())
+    # the state matters: the Laplacian (u0 = 0) differs by O(1), and the rank-one term makes it more than a rescaling
+    lap = _oracle_matrix(m, prob.bc_nodes if bcs else None, forms.helmholtz_hex_jacobian_kernel(degree, nq, alpha=1.0, beta=0.0))
+    if bcs:
+        rp, ci = lap.rowptr, lap.colidx
+        for b in prob.bc_nodes:
+            lap.values[rp[b] + np.searchsorted(ci[rp[b]:rp[b + 1]], b)] = 0.0
+    assert np.abs(lap.values - ref.values).max() > 0.05 * np.abs(ref.values).max()
+    y = hostsim.run_tensor(prob.act_loop)[0]
+    yref = _oracle_loop(prob.act_loop)
+    assert_allclose(y, yref, rtol=0, atol=1e-11 * np.abs(yref).max())
+
+
+@pytest.mark.parametrize("degree,nq,bcs", [(2, 3, False), (1, 2, True), (3, 4, True)])
+def test_a_vector_valued_space_through_the_tensor_templates_on_the_host(degree, nq, bcs):
+    """Linear elasticity on (Q_k)^3: Mat dims (3, 3) -- element tensor t[(i*3 + p)][(j*3 + r)], MatSetValuesBlockedLocal
+    (builder.py:573-625) -- and Dats of dim 3.  The matrix template runs one scalar MFMA contraction per (test, trial) component pair
+    on its 4 x 4 slice of the 12 x 12 point weight and scatters into the blocked CSR; the action carries three components of u
+    through the axis passes.  Against the oracle's dense 3 nd x 3 nd kernel; the operator is symmetric and annihilates the rigid
+    translations (rho = 0)."""
+    m = fmesh.make_extruded_hex_mesh(1 if degree > 2 else 2, 2, degree, perturb=0.1)
+    prob = forms.ElasticityHexProblem(m, bcs=bcs, nq=nq)
+    from firedrake_amd.codegen import tensor_eligible
+    assert tensor_eligible(prob.jac_loop.global_kernel) == "matrix" and tensor_eligible(prob.act_loop.global_kernel) == "action"
+    csr = hostsim.run_tensor(prob.jac_loop)[0]
+    ref = _oracle_loop(prob.jac_loop)
+    assert np.array_equal(csr.rowptr, ref.rowptr) and np.array_equal(csr.colidx, ref.colidx)
+    assert_allclose(csr.values, ref.values, rtol=0, atol=1e-11 * np.abs(ref.values).max())
+    A = ref.toscipy()
+    assert abs(A - A.T).max() <= 1e-12 * abs(A).max()
+    if not bcs:
+        for c in range(3):
+            t = np.zeros((m.node_set.total_size, 3))
+            t[:, c] = 1.0
+            assert np.abs(A @ t.ravel()).max() <= 1e-11 * abs(A).max()
+    y = hostsim.run_tensor(prob.act_loop)[0]
+    yref = _oracle_loop(prob.act_loop)
+    assert_allclose(y, yref, rtol=0, atol=1e-11 * np.abs(yref).max())
+    if not bcs:
+        assert_allclose(y.ravel(), A @ np.asarray(prob.u.data_ro).ravel(), rtol=0, atol=1e-10 * np.abs(yref).max())
