@@ -146,6 +146,13 @@ def tensor_geometry(degree, nq):
     return {"k1": k1, "q1": q1, "nd": k1 ** 3, "tiles": nt, "matrix_threads": 64 * wpb, "matrix_groups": nt // wpb, "action_cells": 128 // (m * m)}
 
 
+def tensor_matrix_groups(geom, vdim):
+    """workgroups per cell of the matrix template: one per (panel group, component pair) of a (Q_k)^vdim space, or -- small elements,
+    fd_tensor.h tp_fused -- all vdim^2 pairs of a panel group in one"""
+    fused = vdim > 1 and 4 * geom["tiles"] * vdim * vdim <= 96
+    return geom["matrix_groups"] * (1 if fused else vdim * vdim)
+
+
 def generate_tensor_wrapper(gk: GlobalKernel) -> WrapperSource:
     """The wrapper of a tensor-product loop: the reference's positional list for an extruded loop (start, end, layers, one
     pointer per argument, one per distinct Map, builder.py:962-981), then the backend-private tables, around the device
@@ -202,6 +209,9 @@ def generate_tensor_wrapper(gk: GlobalKernel) -> WrapperSource:
         threads = geom["matrix_threads"]
         # 4 NT accumulator registers per lane: Q4 (NT = 8) fits three wavefronts per SIMD
         bounds = f"{threads}, 3" if geom["tiles"] <= 8 and threads == 256 else f"{threads}"
+        if D > 1 and tensor_matrix_groups(geom, D) == geom["matrix_groups"]:
+            # all D^2 blocks in one workgroup (8 NT D^2 accumulator registers, (Q2)^3: 144): two wavefronts per SIMD = 256 registers
+            bounds = f"{threads}, 2"
     else:
         layout += [("arg", 0), ("arg", 1), ("arg", 2)] + clayout + [("map", 0), ("map", 1), ("tp_tables",)]
         params = ["const int *__restrict__ layers", "double *__restrict__ arg0", "const double *__restrict__ arg1",

@@ -84,6 +84,7 @@ __device__ __forceinline__ void inv3(const double J[3][3], double K[3][3], doubl
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int tp_tiles(int k1) { return (k1 * k1 * k1 + 15) / 16; }
 constexpr int tp_waves(int nt) { return nt % 4 == 0 ? 4 : (nt % 2 == 0 ? 2 : 1); }     // wavefronts per workgroup: divides NT
+constexpr bool tp_fused(int nt, int d) { return d > 1 && 4 * nt * d * d <= 96; }         // all D^2 component pairs in one workgroup
 
 // Coefficient arguments (NC > 0): READ Dats on the Q_k map -- what TSFC passes as w_k to a variable-coefficient or linearised
 // nonlinear form (tsfc/kernel_interface/firedrake_loopy.py:432-522; evaluated at the quadrature points in tsfc/fem.py:742-805).
@@ -153,10 +154,15 @@ __device__ __forceinline__ void hex_qk_coefficients(const double *const (&cf)[NC
 // slice is picked with COMPILE-TIME indices (one instantiation of the weights phase per pair, selected by a switch), so the
 // callback's other 16 (D^2 - 1) results are dead code in each instantiation and W never has to exist in full.
 // CSR: scalar row (node, p) starts at node_rowptr[node]*D*D + p*rowlen*D, column (k-th node of the row, r) sits at k*D + r.
-template <int K1, int Q1, int NC, int N1, bool GRAD, int D, int P, int R, int NTHR, class WF>
+// Small elements (tp_fused: 4 NT D^2 <= 96 accumulator registers -- (Q1)^3, (Q2)^3, (Q3)^2) keep ALL D^2 blocks in one workgroup
+// instead: the geometry, the point weights and the B operands are computed once per cell and every Gauss point feeds D^2 NT MFMAs
+// instead of NT.  (Measured on the (Q2)^3 elasticity matrix, n = 24: 2.10 ms either way, 0.12 of the fp64 MFMA peak -- that kernel
+// is bound by its 90.7 M scattered fp64 atomics, whose entries sit D doubles apart so that one wavefront instruction touches ~3x
+// the cache lines of the scalar case; profiles/r5k_tensor_forms.txt.)
+template <int K1, int Q1, int NC, int N1, bool GRAD, int D, int P, int R, int NTHR, int SWW, class WF>
 __device__ __forceinline__ void hex_qk_point_weights(const double *sX, const double *sQP, const double *sQW,
                                                      const double (*sC)[Q1 * Q1 * Q1], const double (*sV1)[8],
-                                                     double (*sW)[16], WF weights) {
+                                                     double (*sW)[SWW], WF weights) {
     constexpr int NQ = Q1 * Q1 * Q1, CW = GRAD ? 4 : 1, NCT = NC + N1 > 0 ? NC + N1 : 1;
     for (int q = threadIdx.x; q < NQ; q += NTHR) {
         const int q1 = q / (Q1 * Q1), q2 = (q / Q1) % Q1, q3 = q % Q1;
@@ -188,7 +194,7 @@ __device__ __forceinline__ void hex_qk_point_weights(const double *sX, const dou
 #pragma unroll
         for (int l = 0; l < 4; ++l)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) sW[q][l * 4 + k] = W[((P * 4 + l) * 4 * D) + R * 4 + k];
+            for (int k = 0; k < 4; ++k) sW[q][(SWW > 16 ? (P * D + R) * 16 : 0) + l * 4 + k] = W[((P * 4 + l) * 4 * D) + R * 4 + k];
     }
 }
 
@@ -202,17 +208,19 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
                                               const int *__restrict__ clg, const double *__restrict__ tables, WF weights) {
     constexpr int ND = K1 * K1 * K1, NQ = Q1 * Q1 * Q1, NT = tp_tiles(K1), WPB = tp_waves(NT), WGC = NT / WPB, NTAB = Q1 * K1;
     constexpr int CW = GRAD ? 4 : 1;
+    constexpr bool FUSED = tp_fused(NT, D);
+    constexpr int NP = FUSED ? D * D : 1, DG = FUSED ? 1 : D * D;      // pairs per workgroup, workgroups per (cell, panel group)
     static_assert(D >= 1 && D <= 3, "vector-valued Q_k spaces of up to three components");
     __shared__ double sL[NTAB], sDL[NTAB], sQP[Q1], sQW[Q1];
     __shared__ double sX[24];
-    __shared__ double sW[NQ][16];
+    __shared__ double sW[NQ][16 * NP];
     __shared__ double sC[NC > 0 ? NC * CW : 1][NQ];
     __shared__ double sV1[N1 > 0 ? N1 : 1][8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nl = layers[1] - 1 - layers[0];
     // (unsigned, like blockIdx: the compiler then knows every index below is non-negative and keeps the table pointers in scalar
     // registers with 32-bit lane offsets -- with signed ids it fell back to 64-bit address arithmetic per access, 20 % of the kernel)
-    const unsigned wg = blockIdx.x / (unsigned)(D * D), pr = blockIdx.x - wg * (unsigned)(D * D);   // (test, trial) component pair
+    const unsigned wg = blockIdx.x / (unsigned)DG, pr = blockIdx.x - wg * (unsigned)DG;   // (test, trial) component pair
     const int cp = pr / (unsigned)D, cr = pr - cp * (unsigned)D;
     const int cellid = wg / (unsigned)WGC, part = wg - cellid * (unsigned)WGC;
     const int col = start + cellid / nl;
@@ -232,11 +240,20 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
         hex_qk_coefficients<K1, Q1, NC, WPB * 64, GRAD>(cf, map_qk + (size_t)col * ND, (K1 - 1) * lrel, sL, sDL, sC);
 #define FD_TP_PAIR(P, R)                                                                                                            \
     case (P) * 3 + (R):                                                                                                             \
-        if constexpr ((P) < D && (R) < D)                                                                                           \
-            hex_qk_point_weights<K1, Q1, NC, N1, GRAD, D, (P), (R), WPB * 64>(sX, sQP, sQW, sC, sV1, sW, weights);                  \
+        if constexpr ((P) < D && (R) < D && !FUSED)                                                                                 \
+            hex_qk_point_weights<K1, Q1, NC, N1, GRAD, D, (P), (R), WPB * 64, 16>(sX, sQP, sQW, sC, sV1, sW, weights);              \
         break;
     if constexpr (D == 1) {
-        hex_qk_point_weights<K1, Q1, NC, N1, GRAD, 1, 0, 0, WPB * 64>(sX, sQP, sQW, sC, sV1, sW, weights);
+        hex_qk_point_weights<K1, Q1, NC, N1, GRAD, 1, 0, 0, WPB * 64, 16>(sX, sQP, sQW, sC, sV1, sW, weights);
+    } else if constexpr (FUSED) {
+        // (one pass per pair, each with its own compile-time slice: filling all D^2 slices from one callback evaluation keeps the
+        // whole 4D x 4D weight live -- 288 registers for D = 3)
+#define FD_TP_SLICE(P, R)                                                                                                           \
+        if constexpr ((P) < D && (R) < D)                                                                                           \
+            hex_qk_point_weights<K1, Q1, NC, N1, GRAD, D, (P), (R), WPB * 64, 16 * NP>(sX, sQP, sQW, sC, sV1, sW, weights);
+        FD_TP_SLICE(0, 0) FD_TP_SLICE(0, 1) FD_TP_SLICE(0, 2) FD_TP_SLICE(1, 0) FD_TP_SLICE(1, 1) FD_TP_SLICE(1, 2)
+        FD_TP_SLICE(2, 0) FD_TP_SLICE(2, 1) FD_TP_SLICE(2, 2)
+#undef FD_TP_SLICE
     } else {
         switch (cp * 3 + cr) {
             FD_TP_PAIR(0, 0) FD_TP_PAIR(0, 1) FD_TP_PAIR(0, 2) FD_TP_PAIR(1, 0) FD_TP_PAIR(1, 1) FD_TP_PAIR(1, 2)
@@ -265,9 +282,11 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
     }
     // B operand of lane (kk, j): Phi[kk][j] = X[q1][j1] * Y[q2][j2] * Z[q3][j3], derivative table on axis kk (kk = 3: value)
     const double *tabx = kk == 0 ? sDL : sL, *taby = kk == 1 ? sDL : sL, *tabz = kk == 2 ? sDL : sL;
-    fd_d4 acc[NT];
+    fd_d4 acc[NP][NT];
 #pragma unroll
-    for (int b = 0; b < NT; ++b) acc[b] = fd_d4{0.0, 0.0, 0.0, 0.0};
+    for (int a = 0; a < NP; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = fd_d4{0.0, 0.0, 0.0, 0.0};
 
 #pragma unroll 1
     for (int q1 = 0; q1 < Q1; ++q1) {
@@ -286,14 +305,28 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
                 const int q = (q1 * Q1 + q2) * Q1 + q3;
                 const double lz = sL[q3 * K1 + i3], dz = sDL[q3 * K1 + i3];
                 // A operand: (Phi^T W)[i][kk] = sum_l Phi[l][i] W[l][kk]
-                const double aop = ax * lz * sW[q][kk] + ay * lz * sW[q][4 + kk] + axy * dz * sW[q][8 + kk] + axy * lz * sW[q][12 + kk];
+                const double a0 = ax * lz, a1 = ay * lz, a2 = axy * dz, a3 = axy * lz;
                 // (requesting the NT table values of the B operands together ahead of the MFMAs instead of one by one between them --
                 // back-to-back MFMAs in the ISA, 16 more registers -- measured the same 9.80 ms at n = 32: three wavefronts per SIMD
                 // already keep the matrix pipe fed; profiles/r5j_ab_c3_tree.txt)
+                if constexpr (NP == 1) {
+                    const double aop = a0 * sW[q][kk] + a1 * sW[q][4 + kk] + a2 * sW[q][8 + kk] + a3 * sW[q][12 + kk];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const double bop = bxy[t] * tabz[q3 * K1 + j3[t]];
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc[t], 0, 0, 0);
+                    for (int t = 0; t < NT; ++t) {
+                        const double bop = bxy[t] * tabz[q3 * K1 + j3[t]];
+                        acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc[0][t], 0, 0, 0);
+                    }
+                } else {
+                    double bop[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) bop[t] = bxy[t] * tabz[q3 * K1 + j3[t]];
+#pragma unroll
+                    for (int a = 0; a < NP; ++a) {
+                        const double *w = &sW[q][a * 16];
+                        const double aop = a0 * w[kk] + a1 * w[4 + kk] + a2 * w[8 + kk] + a3 * w[12 + kk];
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc[a][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop[t], acc[a][t], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -308,27 +341,61 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
     for (int t = 0; t < NT; ++t) {
         const int j = t * 16 + r16;
         cok[t] = j < ND;
-        cn[t] = cok[t] ? mrow[j] + OFF * lrel : 0;
-        if (cok[t] && clg) cok[t] = clg[cn[t]] >= 0;
+        cn[t] = mrow[cok[t] ? j : 0] + OFF * lrel;
+    }
+    if (clg) {
+        int cl[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) cl[t] = clg[cn[t]];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) cok[t] = cok[t] && cl[t] >= 0;
     }
     // every row takes fire-and-forget atomics (storing the rows one cell owns alone -- the cell-interior nodes, 22 % of the entries
-    // of Q4 -- and zeroing only the shared ones was built and measured 1 % slower: profiles/r4m_c3_single_rows.txt, r4n_c3_single_rows.txt)
+    // of Q4 -- and zeroing only the shared ones was built and measured 1 % slower: profiles/r4m_c3_single_rows.txt, r4n_c3_single_rows.txt).
+    // ALL the index reads of the lane's 4 NT entries (row node -> lgmap -> row start, entry positions) are requested before the
+    // first atomic: on gfx9 atomics and loads share one counter, so a position read issued between two atomics waits for every
+    // atomic before it -- 4 NT serialised round trips per lane, during which the wavefront feeds no MFMA either.
+    int rn[4]; bool rok[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int i = itile * 16 + kk + 4 * g;
-        if (i >= ND) continue;
-        const int rn = mrow[i] + OFF * lrel;
-        if (rlg && rlg[rn] < 0) continue;
+        rok[g] = i < ND;
+        rn[g] = mrow[rok[g] ? i : 0] + OFF * lrel;
+    }
+    if (rlg) {
+        int rl[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) rl[g] = rlg[rn[g]];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) rok[g] = rok[g] && rl[g] >= 0;
+    }
+    int rp[4], rlen[4];
+    unsigned short pos[4][NT];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        rp[g] = rowptr[rn[g]];                             // (unconditional reads of clamped indices: no branch, no wait in between)
+        rlen[g] = D > 1 ? rowptr[rn[g] + 1] - rp[g] : 0;
+        const int i = itile * 16 + kk + 4 * g;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) pos[g][t] = tab[(i < ND && t * 16 + r16 < ND) ? i * ND + t * 16 + r16 : 0];
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (!rok[g]) continue;
         if constexpr (D == 1) {
-            const size_t r0 = (size_t)rowptr[rn];
+            const size_t r0 = (size_t)rp[g];
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                if (cok[t]) atomicAdd(&vals[r0 + tab[i * ND + t * 16 + r16]], acc[t][g]);
+                if (cok[t]) atomicAdd(&vals[r0 + pos[g][t]], acc[0][t][g]);
         } else {
-            const size_t rp = (size_t)rowptr[rn], rlen = (size_t)rowptr[rn + 1] - rp, r0 = rp * (D * D) + (size_t)cp * rlen * D + cr;
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (cok[t]) atomicAdd(&vals[r0 + (size_t)tab[i * ND + t * 16 + r16] * D], acc[t][g]);
+            for (int a = 0; a < NP; ++a) {
+                const int p = FUSED ? a / D : cp, r = FUSED ? a % D : cr;
+                const size_t r0 = (size_t)rp[g] * (D * D) + (size_t)p * rlen[g] * D + r;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (cok[t]) atomicAdd(&vals[r0 + (unsigned)pos[g][t] * D], acc[a][t][g]);
+            }
         }
     }
 }

@@ -929,8 +929,9 @@ class Parloop:
             # matrix: one wavefront per 16-row panel of the padded element matrix (Q4: two workgroups of four per cell); action:
             # one workgroup per tp["action_cells"] cells of the (column, layer) space (codegen.tensor_geometry)
             ncell = size * (self.iterset.layers - 1)
+            from .codegen import tensor_matrix_groups
             vd = int(self.global_kernel.local_kernel.tp.get("vdim", 1))         # (Q_k)^D: D^2 scalar blocks per element matrix
-            nb = ncell * src.tp["matrix_groups"] * vd * vd if src.mode == "tp_matrix" else -(-ncell // src.tp["action_cells"])
+            nb = ncell * tensor_matrix_groups(src.tp, vd) if src.mode == "tp_matrix" else -(-ncell // src.tp["action_cells"])
             cw.launch(start, end, args, block_threads=threads, ents_per_block=1, nblocks=nb)
         else:
             total = size

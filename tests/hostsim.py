@@ -645,7 +645,8 @@ def run_tensor(pl, initial=None):
     nl = pl.iterset.layers - 1
     ncell = (end - start) * nl
     vd = int(gk.local_kernel.tp.get("vdim", 1))
-    nblocks = ncell * src.tp["matrix_groups"] * vd * vd if src.mode == "tp_matrix" else -(-ncell // src.tp["action_cells"])
+    from firedrake_amd.codegen import tensor_matrix_groups
+    nblocks = ncell * tensor_matrix_groups(src.tp, vd) if src.mode == "tp_matrix" else -(-ncell // src.tp["action_cells"])
     outs, keep = {}, []
 
     def ptr(a):

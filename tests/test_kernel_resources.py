@@ -57,3 +57,25 @@ def test_q4_tensor_wrappers_hold_three_wavefronts_per_simd():
         src = generate_tensor_wrapper(loop.global_kernel)
         res = kernel_resources(compile_hip(src.source, src.symbol), src.symbol)
         assert res["scratch"] <= (32 if src.mode == "tp_action" else 0) and res["occupancy"] >= 3 and res["vgprs"] <= 168, (src.symbol, res)
+
+
+def test_wider_tensor_descriptors_compile_without_scratch():
+    """The Q3 Newton Jacobian with a coefficient gradient and the (Q2)^3 elasticity matrix -- nine scalar blocks in one workgroup, 144
+    accumulator registers, compiled for two wavefronts per SIMD -- stay out of scratch memory; so does the scalar Q4 matrix kernel
+    whose index arithmetic the widening touched (unsigned workgroup ids: signed ones cost 20 %, profiles/r5j_ab_c3_tree.txt)."""
+    from firedrake_amd import mesh as fmesh
+    from firedrake_amd.codegen import generate_tensor_wrapper, tensor_matrix_groups
+    from firedrake_amd.compilation import compile_hip
+    el = forms.ElasticityHexProblem(fmesh.make_extruded_hex_mesh(1, 1, 2, perturb=0.0), bcs=True)
+    nd = forms.NonlinearDiffusionHexProblem(fmesh.make_extruded_hex_mesh(1, 1, 3, perturb=0.0), bcs=True)
+    src = generate_tensor_wrapper(el.jac_loop.global_kernel)
+    assert tensor_matrix_groups(src.tp, 3) == src.tp["matrix_groups"]                  # fused pairs
+    res = kernel_resources(compile_hip(src.source, src.symbol), src.symbol)
+    assert res["scratch"] == 0 and res["occupancy"] >= 2 and res["vgprs"] + res.get("agprs", 0) <= 256, res
+    src = generate_tensor_wrapper(nd.jac_loop.global_kernel)
+    res = kernel_resources(compile_hip(src.source, src.symbol), src.symbol)
+    assert res["scratch"] == 0 and res["occupancy"] >= 3, res
+    for loop in (el.act_loop, nd.act_loop):
+        src = generate_tensor_wrapper(loop.global_kernel)
+        res = kernel_resources(compile_hip(src.source, src.symbol), src.symbol)
+        assert res["scratch"] == 0, (src.symbol, res)
