@@ -113,7 +113,7 @@ def as_fd_local_kernel(lk):
     return K.LoopyLocalKernel(lk.code, lk.name, accesses, dtypes, **kw)      # lowered with lp.generate_code_v2
 
 
-def tensor_form_info(cell, family, degree, quadrature_degree, terms, kind):
+def tensor_form_info(cell, family, degree, quadrature_degree, terms, kind, value_size=1):
     """The descriptor a Firedrake-side patch attaches to the pyop2 local kernel of a tensor-product form
     (``kernel.fdhip_tensor = tensor_form_info(...)``).  Everything in it is form data Firedrake holds
     when it builds the kernel (firedrake/tsfc_interface.py:84-140):
@@ -130,15 +130,42 @@ def tensor_form_info(cell, family, degree, quadrature_degree, terms, kind):
                                        them apart by the Map of the argument), in the order TSFC passes them (``w_0 ...``,
                                        firedrake_loopy.py:432-522) -- and ``X[0..2]`` (the physical point); what the UFL
                                        integrand ``kappa(w0)*inner(grad(du), grad(v)) + c(u0)*du*v`` prints as
+                                       -- or a form family the backend holds the point weight of:
+                                       ``{"elasticity": (mu, lam), "mass": rho}`` for 2 mu eps(u):eps(v) + lam div(u) div(v) + rho u.v on a
+                                       VectorFunctionSpace (``value_size`` 3), ``{"nonlinear_diffusion": 1}`` for the Newton Jacobian of
+                                       (1 + |grad u|^2) grad(u).grad(v) at the form's one coefficient (its GRADIENT at the points)
+                                       -- or, in general, ``{"weights_code": "<C>", "coefficients": n, "coefficient_gradients": bool}``:
+                                       the C text of ``<NAME>_weights`` (kernel.TensorProductLocalKernel documents its signatures; the
+                                       literal NAME is replaced by the kernel's name) filling the 4 value_size x 4 value_size point weight
     ``kind``                           "matrix" for a 2-form, "action" for action(a, u) / a 1-form linear in one coefficient
+    ``value_size``                     ``V.value_size``: 1 for a scalar space, 2 or 3 for a VectorFunctionSpace on the same element
 
     Returns None when the form is not one the tensor wrappers cover (the loop then takes the ordinary wrappers)."""
     nq = int(quadrature_degree) // 2 + 1                   # Gauss-Legendre points per axis exact for that degree
     from .codegen import tensor_geometry
     ok = (cell in ("hexahedron", "quadrilateral * interval", "TensorProductCell(quadrilateral, interval)") and family in ("Q", "CG", "Lagrange")
           and tensor_geometry(int(degree), nq) is not None and kind in ("matrix", "action")
-          and set(terms) <= {"stiffness", "mass", "advection", "coefficients"})
+          and set(terms) <= {"stiffness", "mass", "advection", "coefficients", "elasticity", "nonlinear_diffusion", "weights_code",
+                             "coefficient_gradients"}
+          and int(value_size) in (1, 2, 3))
     if not ok:
+        return None
+    base = {"kind": kind, "degree": int(degree), "nq": nq}
+    if "weights_code" in terms:
+        if set(terms) - {"weights_code", "coefficients", "coefficient_gradients"}:
+            return None
+        return dict(base, weights_code=str(terms["weights_code"]), ncoef=int(terms.get("coefficients", 0)),
+                    coef_gradients=bool(terms.get("coefficient_gradients", False)), vdim=int(value_size))
+    if "elasticity" in terms:
+        if set(terms) - {"elasticity", "mass"} or int(value_size) != 3:
+            return None
+        mu, lam = terms["elasticity"]
+        return dict(base, family="elasticity", mu=float(mu), lam=float(lam), rho=float(terms.get("mass", 0.0)), vdim=3)
+    if "nonlinear_diffusion" in terms:
+        if set(terms) - {"nonlinear_diffusion"} or int(value_size) != 1:
+            return None
+        return dict(base, family="nonlinear_diffusion", ncoef=1, coef_gradients=True)
+    if int(value_size) != 1:
         return None
     if "coefficients" in terms:
         if "advection" in terms or int(terms["coefficients"]) < 0:
@@ -154,8 +181,18 @@ def tensor_form_info(cell, family, degree, quadrature_degree, terms, kind):
 def tensor_product_local_kernel(code, name, accesses, dtypes, info, **kw):
     """TensorProductLocalKernel from the TSFC kernel text and a ``tensor_form_info`` descriptor: the per-point weight
     callback of alpha*inner(grad u, grad v) + beta*inner(u, v) is W = w|J| [alpha K K^T, 0; 0, beta] (tensor.py)."""
-    from .tensor import coefficient_weights, second_order_weights
+    from .tensor import coefficient_weights, elasticity_weights, nonlinear_diffusion_weights, second_order_weights
     kw.setdefault("requires_zeroed_output_arguments", True)
+    common = dict(kind=info["kind"], degree=info["degree"], nq=info["nq"])
+    if "weights_code" in info:
+        return K.TensorProductLocalKernel(code, name, accesses, dtypes, ncoef=info["ncoef"], coef_gradients=info["coef_gradients"],
+                                          vdim=info["vdim"], weights_code=info["weights_code"].replace("NAME", name), **common, **kw)
+    if info.get("family") == "elasticity":
+        return K.TensorProductLocalKernel(code, name, accesses, dtypes, vdim=3,
+                                          weights_code=elasticity_weights(name, info["mu"], info["lam"], info["rho"]), **common, **kw)
+    if info.get("family") == "nonlinear_diffusion":
+        return K.TensorProductLocalKernel(code, name, accesses, dtypes, ncoef=1, coef_gradients=True,
+                                          weights_code=nonlinear_diffusion_weights(name), **common, **kw)
     if "ncoef" in info:
         return K.TensorProductLocalKernel(code, name, accesses, dtypes, kind=info["kind"], degree=info["degree"], nq=info["nq"],
                                           ncoef=info["ncoef"], weights_code=coefficient_weights(name, info["kappa"], info["react"]), **kw)

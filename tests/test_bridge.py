@@ -343,6 +343,43 @@ def test_tensor_form_descriptor_selects_the_matrix_core_wrapper():
     assert select_mode(cfd) == "tp_matrix" and cfd.local_kernel.tp["ncoef"] == 2 and cfd.local_kernel.tp["weights_code"] == cdense.tp["weights_code"]
 
 
+def test_tensor_form_descriptor_for_vector_spaces_and_coefficient_gradients():
+    """The wider descriptors through the seam: elasticity on a VectorFunctionSpace (``value_size`` 3: Mat dims (3, 3), blocked element
+    tensor), the Newton Jacobian of a form nonlinear in grad(u) (the coefficient's gradient at the points), and the general form -- the
+    Firedrake-side patch hands the point-weight callback itself."""
+    from firedrake_amd import forms, tensor
+    from firedrake_amd.codegen import select_mode
+    q2, q1 = MapKernelArg(arity=27, offset=(2,) * 27), MapKernelArg(arity=8, offset=(1,) * 8)
+    einfo = bridge.tensor_form_info("hexahedron", "Q", 2, 4, {"elasticity": (1.0, 1.25)}, "matrix", value_size=3)
+    assert einfo == {"kind": "matrix", "degree": 2, "nq": 3, "family": "elasticity", "mu": 1.0, "lam": 1.25, "rho": 0.0, "vdim": 3}
+    assert bridge.tensor_form_info("hexahedron", "Q", 2, 4, {"elasticity": (1.0, 1.25)}, "matrix") is None           # a scalar space
+    assert bridge.tensor_form_info("hexahedron", "Q", 2, 4, {"stiffness": 1.0}, "matrix", value_size=3) is None      # not a vector form
+    dense = forms.elasticity_hex_jacobian_kernel(2, 3)
+    lk = CStringLocalKernel(code=dense.code, name=dense.name, accesses=(4, 1), dtypes=(np.float64,) * 2, requires_zeroed_output_arguments=True)
+    gk = GlobalKernel(local_kernel=lk, arguments=[MatKernelArg(dims=((3,), (3,)), maps=(q2, q2)), DatKernelArg(dim=(3,), map_=q1)],
+                      _extruded=True, _constant_layers=True)
+    assert select_mode(bridge.as_fd_global_kernel(gk)) != "tp_matrix"
+    lk.fdhip_tensor = einfo
+    fd = bridge.as_fd_global_kernel(gk)
+    assert select_mode(fd) == "tp_matrix" and fd.local_kernel.tp["vdim"] == 3 and fd.local_kernel.tp["weights_code"] == dense.tp["weights_code"]
+    ninfo = bridge.tensor_form_info("hexahedron", "Q", 3, 6, {"nonlinear_diffusion": 1}, "action")
+    assert ninfo == {"kind": "action", "degree": 3, "nq": 4, "family": "nonlinear_diffusion", "ncoef": 1, "coef_gradients": True}
+    q3 = MapKernelArg(arity=64, offset=(3,) * 64)
+    adense = forms.nonlinear_diffusion_hex_action_kernel(3, 4)
+    alk = CStringLocalKernel(code=adense.code, name=adense.name, accesses=(4, 1, 1, 1), dtypes=(np.float64,) * 4, requires_zeroed_output_arguments=True)
+    agk = GlobalKernel(local_kernel=alk, arguments=[DatKernelArg(dim=(1,), map_=q3), DatKernelArg(dim=(3,), map_=q1), DatKernelArg(dim=(1,), map_=q3),
+                                                    DatKernelArg(dim=(1,), map_=q3)], _extruded=True, _constant_layers=True)
+    alk.fdhip_tensor = ninfo
+    afd = bridge.as_fd_global_kernel(agk)
+    assert select_mode(afd) == "tp_action" and afd.local_kernel.tp["coef_gradients"] and afd.local_kernel.tp["weights_code"] == adense.tp["weights_code"]
+    # the general road: the callback text itself (NAME stands for the kernel's name)
+    ginfo = bridge.tensor_form_info("hexahedron", "Q", 3, 6, {"weights_code": tensor.NONLINEAR_DIFFUSION_WEIGHTS, "coefficients": 1,
+                                                             "coefficient_gradients": True}, "action")
+    alk.fdhip_tensor = ginfo
+    gfd = bridge.as_fd_global_kernel(agk)
+    assert select_mode(gfd) == "tp_action" and gfd.local_kernel.tp["weights_code"] == adense.tp["weights_code"]
+
+
 def _dev(*arrays):
     from firedrake_amd.device import DeviceBuffer
     return [DeviceBuffer.from_numpy(np.ascontiguousarray(a)) for a in arrays]
