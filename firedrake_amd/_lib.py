@@ -10,6 +10,12 @@ import os
 from ctypes import (POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64,
                     c_size_t, c_uint16, c_void_p)
 
+import numpy as _np
+
+# include/fdhip.h: fd_nnz_t -- the type of CSR / accumulator row starts (64-bit: patterns beyond 2^31 entries)
+NNZ_DTYPE = _np.dtype(_np.int64)
+NNZ_BYTES = NNZ_DTYPE.itemsize
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfdhip.so")
 

@@ -253,7 +253,10 @@ class DeviceMat:
 
     _next = [1]
 
-    def __init__(self, rowptr, colidx, values, nrows, nnz, nrows_owned=None, ncols=None, rbs=1, cbs=1):
+    def __init__(self, rowptr, colidx, values, nrows, nnz, nrows_owned=None, ncols=None, rbs=1, cbs=1, rowptr_bytes=4):
+        """``rowptr_bytes``: size of the row starts behind ``rowptr`` -- PetscInt of the PETSc build, 4 or 8 (pyop2/datatypes.py:6-10).
+        The backend's row starts are ``fd_nnz_t`` (64-bit); a 32-bit array is widened once into a buffer this object owns."""
+        from . import _lib
         from .device import DeviceBuffer
         self.handle = (DeviceMat._next[0] << 4) | 0xD            # never a plausible device address
         DeviceMat._next[0] += 1
@@ -261,7 +264,14 @@ class DeviceMat:
         self.nrows_owned = int(nrows if nrows_owned is None else nrows_owned)
         self.rbs, self.cbs = int(rbs), int(cbs)
         wrap = lambda p, n: DeviceBuffer.wrap(int(p), int(n), owned=False)       # noqa: E731
-        self.rowptr, self.colidx = wrap(rowptr, (self.nrows + 1) * 4), wrap(colidx, max(nnz, 1) * 4)
+        self.colidx = wrap(colidx, max(nnz, 1) * 4)
+        if int(rowptr_bytes) == _lib.NNZ_BYTES:
+            self.rowptr = wrap(rowptr, (self.nrows + 1) * _lib.NNZ_BYTES)
+        elif int(rowptr_bytes) == 4:
+            narrow = wrap(rowptr, (self.nrows + 1) * 4).download(np.int32, (self.nrows + 1,))
+            self.rowptr = DeviceBuffer.from_numpy(narrow.astype(_lib.NNZ_DTYPE))
+        else:
+            raise ValueError("DeviceMat: rowptr_bytes must be 4 or 8")
         self.values = wrap(values, max(nnz, 1) * 8 * self.rbs * self.cbs)
         self._scalar = None
         self.lgmaps = None
@@ -292,7 +302,7 @@ class DeviceMat:
             _lib.call("fd_csr_expand_blocks", self.nrows, self.rowptr.ptr, self.colidx.ptr, self.rbs, self.cbs,
                       ctypes.byref(rp2), ctypes.byref(ci2), None)
             n2 = self.nnz * self.rbs * self.cbs
-            self._scalar = (DeviceBuffer.wrap(rp2.value, (self.nrows * self.rbs + 1) * 4), DeviceBuffer.wrap(ci2.value, max(n2, 1) * 4), n2)
+            self._scalar = (DeviceBuffer.wrap(rp2.value, (self.nrows * self.rbs + 1) * _lib.NNZ_BYTES), DeviceBuffer.wrap(ci2.value, max(n2, 1) * 4), n2)
         return self._scalar
 
     def free(self):

@@ -197,7 +197,7 @@ def generate_tensor_wrapper(gk: GlobalKernel) -> WrapperSource:
         lg = bool(gk.arguments[0].lgmaps)
         layout += [("arg", 0), ("arg", 1)] + clayout + [("map", 0), ("map", 1), ("mat_node_rowptr", 0), ("tp_offtab", 0)]
         params = ["const int *__restrict__ layers", "double *__restrict__ arg0", "const double *__restrict__ arg1"] + cparams + [
-                  "const int *__restrict__ map0", "const int *__restrict__ map1", "const int *__restrict__ rp0",
+                  "const int *__restrict__ map0", "const int *__restrict__ map1", "const fd_nnz_t *__restrict__ rp0",
                   "const unsigned short *__restrict__ tpo0"]
         if lg:
             layout += [("mat_row_lgmap", 0), ("mat_col_lgmap", 0)]
@@ -506,7 +506,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         use_table[k] = table
         if ocr:
             P(f"const int *__restrict__ oc{k}_rblk", ("ocr_rblk", k))
-            P(f"const int *__restrict__ oc{k}_rowptr", ("ocr_rowptr", k))
+            P(f"const fd_nnz_t *__restrict__ oc{k}_rowptr", ("ocr_rowptr", k))
             P(f"const {ktype} *__restrict__ oc{k}_k", ("ocr_kidx", k))
             P(f"long long oc{k}_maxnnz", ("ocr_maxnnz", k))
             P(f"long long oc{k}_maxnown", ("ocr_maxnown", k))
@@ -514,8 +514,8 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             if srow_table(info):
                 P(f"const unsigned int *__restrict__ oc{k}_srowtab", ("ocr_srow", k, info["rm"]) + (("diag",) if (rec and rec["diag"]) else ()))
             if ocrp:
-                P(f"const int *__restrict__ oc{k}_prowptr", ("ocr_prowptr", k))
-                P(f"const int *__restrict__ oc{k}_nstart", ("ocr_nstart", k))
+                P(f"const fd_nnz_t *__restrict__ oc{k}_prowptr", ("ocr_prowptr", k))
+                P(f"const fd_nnz_t *__restrict__ oc{k}_nstart", ("ocr_nstart", k))
                 P(f"const int *__restrict__ oc{k}_gpos", ("ocr_gpos", k))
                 P(f"long long oc{k}_npos", ("ocr_npos", k))
             if rec:
@@ -533,9 +533,9 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         elif table:
             P(f"const int *__restrict__ tab{k}", ("mat_table", k))
             if info["rbs"] * info["cbs"] != 1:
-                P(f"const int *__restrict__ nrp{k}", ("mat_node_rowptr", k))
+                P(f"const fd_nnz_t *__restrict__ nrp{k}", ("mat_node_rowptr", k))
         else:
-            P(f"const int *__restrict__ rp{k}", ("mat_rowptr", k))
+            P(f"const fd_nnz_t *__restrict__ rp{k}", ("mat_rowptr", k))
             P(f"const int *__restrict__ ci{k}", ("mat_colidx", k))
         if info["arg"].lgmaps and not (ocr and srow_table(info)):
             P(f"const int *__restrict__ rlg{k}", ("mat_row_lgmap", k))
@@ -691,7 +691,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                     lds_tail_const.append(f"unsigned char *smc{k} = fd_lds + fd_off; fd_off += ((size_t)p{cm}_maxnd + 15) & ~(size_t)15;")
                 rp_ = f"oc{k}_prowptr" if ocrp else f"oc{k}_rowptr"       # row starts in the order the blocks are cut in
                 mat_stage_pre.extend([f"const int n0_{k} = oc{k}_rblk[b], nown{k} = oc{k}_rblk[b+1] - n0_{k};",
-                                      f"const int r0_{k} = {rp_}[n0_{k}], nnzb{k} = {rp_}[n0_{k} + nown{k}] - r0_{k};"])
+                                      f"const fd_nnz_t r0_{k} = {rp_}[n0_{k}]; const int nnzb{k} = (int)({rp_}[n0_{k} + nown{k}] - r0_{k});"])
                 # (by capacity when the index rows are requested early: the block's row starts -- a second level of dependent scalar
                 # loads -- are then needed by the flush only, and nothing ahead of the main loop waits for them)
                 zcount = f"(int)oc{k}_maxnnz" if configuration["prefetch"] else f"nnzb{k}"
@@ -707,7 +707,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 elif ocrp:
                     # the accumulator offset of the node's row (by NODE) decides ownership too: the block's rows are exactly
                     # those whose offsets fall into [r0, r0 + nnzb) -- one lookup, no row-position table in the kernel
-                    loads = [f"const int p{k}_U = (G_U < (int)oc{k}_npos) ? oc{k}_nstart[G_U] - r0_{k} : -1;",
+                    loads = [f"const fd_nnz_t p{k}_U = (G_U < (int)oc{k}_npos) ? oc{k}_nstart[G_U] - r0_{k} : -1;",
                              f"const unsigned w{k}_U = ((p{k}_U >= 0 && p{k}_U < nnzb{k}{rowmask.replace('[g]', '[G_U]')}) ? "
                              f"(unsigned)(p{k}_U + 1) : 0u){colbit.replace('[g]', '[G_U]')};"]
                 else:
@@ -812,7 +812,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 lines.append(f"    const int pn = tab{k}[((size_t)e*{ar} + i)*{ac} + j];")
                 lines.append("    if (pn < 0) continue;")
                 if rbs * cbs != 1:
-                    lines.append(f"    const int r0 = nrp{k}[rn], rl = nrp{k}[rn+1] - r0;")
+                    lines.append(f"    const fd_nnz_t r0 = nrp{k}[rn]; const int rl = (int)(nrp{k}[rn+1] - r0);")
             for p in range(rbs):
                 for q in range(cbs):
                     v = f"t{k}[((((size_t)(fi*{ar}+i)*{rbs} + {p})*{nc_}) + (fj*{ac}+j))*{cbs} + {q}]"
@@ -823,7 +823,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                         pos = "pn" if rbs * cbs == 1 else f"(size_t)r0*{rbs * cbs} + (size_t){p}*rl*{cbs} + (size_t)(pn - r0)*{cbs} + {q}"
                         lines.append(f"    {guard}{{ {store(pos, v)} }}")
                     else:
-                        lines.append(f"    {guard}{{ const int ps = fdw::csr_find(rp{k}, ci{k}, rn*{rbs}+{p}, cn*{cbs}+{q}); if (ps >= 0) {{ {store('ps', v)} }} }}")
+                        lines.append(f"    {guard}{{ const fd_nnz_t ps = fdw::csr_find(rp{k}, ci{k}, rn*{rbs}+{p}, cn*{cbs}+{q}); if (ps >= 0) {{ {store('ps', v)} }} }}")
             lines += ["  }", "}"]
             unpack.append("\n      ".join(lines))
     if gk._pass_layer_arg:
@@ -1210,15 +1210,15 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         P(f"const unsigned short *__restrict__ p{mi}_lmap", ("plan_lmap", mi))
         P(f"long long p{mi}_maxnd", ("plan_maxnd", mi))
     P(f"const int *__restrict__ oc{K}_rblk", ("ocr_rblk", K))
-    P(f"const int *__restrict__ oc{K}_rowptr", ("ocr_prowptr" if ordered else "ocr_rowptr", K))
+    P(f"const fd_nnz_t *__restrict__ oc{K}_rowptr", ("ocr_prowptr" if ordered else "ocr_rowptr", K))
     if ordered:
-        P(f"const int *__restrict__ oc{K}_gstart", ("ocr_gstart", K))
+        P(f"const fd_nnz_t *__restrict__ oc{K}_gstart", ("ocr_gstart", K))
     if runflush:
         if B != 1:
             raise ValueError("the run-coded flush serves scalar matrices")
         P(f"const unsigned char *__restrict__ oc{K}_grun", ("ocr_grun", K))
         P(f"const int *__restrict__ oc{K}_brun", ("ocr_brun", K))
-        P(f"const int *__restrict__ oc{K}_rdelta", ("ocr_rdelta", K))
+        P(f"const fd_nnz_t *__restrict__ oc{K}_rdelta", ("ocr_rdelta", K))
     P(f"const unsigned short *__restrict__ oc{K}_slot", ("ocrs_slot", K))
     if B > 1:
         P(f"const unsigned short *__restrict__ oc{K}_rowlen", ("ocrs_rowlen", K))
@@ -1273,7 +1273,7 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         call_args.append("layer")
     lds_items.append(("ocrs", K, B))
     if runflush:
-        lds_decl.append(f"int *srun{K} = (int *)(fd_lds + fd_off); fd_off += 1024;")
+        lds_decl.append(f"fd_nnz_t *srun{K} = (fd_nnz_t *)(fd_lds + fd_off); fd_off += 256*sizeof(fd_nnz_t);")
     lds_decl.append(f"double *sm{K} = (double *)(fd_lds + fd_off); fd_off += (((size_t)oc{K}_maxnnz*{B}*8) + 15) & ~(size_t)15;")
 
     includes, body = _hoist_includes(lk.code)
@@ -1296,7 +1296,7 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     # (a second level of dependent scalar loads), and the block pays one memory round trip before its first trip instead of two
     early = bool(configuration["prefetch"])
     src += [f"  const int n0 = oc{K}_rblk[b], nown = oc{K}_rblk[b+1] - n0;",
-            f"  const int r0 = oc{K}_rowptr[n0], nnzb = (oc{K}_rowptr[n0 + nown] - r0)*{B};"]
+            f"  const fd_nnz_t r0 = oc{K}_rowptr[n0]; const int nnzb = (int)(oc{K}_rowptr[n0 + nown] - r0)*{B};"]
     if runflush:
         src.append(f"  const int br0 = oc{K}_brun[b], nrun = oc{K}_brun[b+1] - br0;")
     srun_stage = (f'  _Pragma("clang loop unroll(disable) vectorize(disable)") for (int q = tid; q < nrun; q += nthr) srun{K}[q] = oc{K}_rdelta[br0 + q];'
@@ -1437,15 +1437,15 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             src += [f"  int g[{FU}];", "  " + ld.replace("Q0", "tid")]
         post_flush.append(f"  for (int q0 = tid; q0 < nnzb; q0 += {FU}*nthr) {{ "
                           + (f"if (q0 >= {FU}*nthr) {{ {ld.replace('Q0', 'q0')} }} " if preload else f"int g[{FU}]; {ld.replace('Q0', 'q0')} ") +
-                          f"for (int f = 0; f < {FU}; ++f) g[f] = r0 + q0 + f*nthr + srun{K}[g[f]]; "
-                          f"if (oc{K}_flags & 1) {{ for (int f = 0; f < {FU}; ++f) if (q0 + f*nthr < nnzb) arg{K}[(size_t)g[f]] = sm{K}[q0 + f*nthr]; }} "
-                          f"else {{ double o[{FU}]; for (int f = 0; f < {FU}; ++f) o[f] = (q0 + f*nthr < nnzb) ? arg{K}[(size_t)g[f]] : 0.0; "
-                          f"for (int f = 0; f < {FU}; ++f) if (q0 + f*nthr < nnzb) arg{K}[(size_t)g[f]] = o[f] + sm{K}[q0 + f*nthr]; }} }}")
+                          f"size_t gp[{FU}]; for (int f = 0; f < {FU}; ++f) gp[f] = (size_t)(r0 + q0 + f*nthr + srun{K}[g[f]]); "
+                          f"if (oc{K}_flags & 1) {{ for (int f = 0; f < {FU}; ++f) if (q0 + f*nthr < nnzb) arg{K}[gp[f]] = sm{K}[q0 + f*nthr]; }} "
+                          f"else {{ double o[{FU}]; for (int f = 0; f < {FU}; ++f) o[f] = (q0 + f*nthr < nnzb) ? arg{K}[gp[f]] : 0.0; "
+                          f"for (int f = 0; f < {FU}; ++f) if (q0 + f*nthr < nnzb) arg{K}[gp[f]] = o[f] + sm{K}[q0 + f*nthr]; }} }}")
     elif ordered:
         # row by row, 16 lanes per row: start / length / place of FU rows per lane group
         FU = 8
         ld = (f"for (int f = 0; f < {FU}; ++f) {{ const int fr = FR0 + f*(nthr >> 4); const int fp = n0 + (fr < nown ? fr : 0); "
-              f"const int a = oc{K}_rowptr[fp], b_ = oc{K}_rowptr[fp+1]; fs[f] = (a - r0)*{B}; fl[f] = fr < nown ? (b_ - a)*{B} : 0; "
+              f"const fd_nnz_t a = oc{K}_rowptr[fp], b_ = oc{K}_rowptr[fp+1]; fs[f] = (int)(a - r0)*{B}; fl[f] = fr < nown ? (int)(b_ - a)*{B} : 0; "
               f"fd_[f] = (size_t)oc{K}_gstart[fp]*{B}; }}")
         decl = f"int fs[{FU}], fl[{FU}]; size_t fd_[{FU}];"
         if preload:

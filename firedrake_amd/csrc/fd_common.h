@@ -31,3 +31,15 @@ inline hipStream_t st(fd_stream_t s) { return s ? reinterpret_cast<hipStream_t>(
     } while (0)
 
 #define FD_CHECK_LAUNCH() FD_HIP(hipGetLastError())
+
+// position of column c in CSR row r (sorted columns), or -1: row starts are fd_nnz_t, the place inside a row fits an int
+__device__ inline fd_nnz_t fd_csr_find(const fd_nnz_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, int r, int c) {
+    fd_nnz_t lo = rowptr[r], hi = rowptr[r + 1] - 1;
+    while (lo <= hi) {
+        const fd_nnz_t mid = lo + ((hi - lo) >> 1);
+        const int v = colidx[mid];
+        if (v == c) return mid;
+        if (v < c) lo = mid + 1; else hi = mid - 1;
+    }
+    return -1;
+}

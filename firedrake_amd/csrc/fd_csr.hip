@@ -62,42 +62,42 @@ __global__ void emit_diag(int32_t first, int32_t n, uint64_t *__restrict__ keys)
 }
 
 __global__ void keys_to_csr(const uint64_t *__restrict__ keys, int64_t nnz, int32_t nrows,
-                            int32_t *__restrict__ rowptr, int32_t *__restrict__ colidx) {
+                            fd_nnz_t *__restrict__ rowptr, int32_t *__restrict__ colidx) {
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t <= nnz; t += (int64_t)gridDim.x * blockDim.x) {
         int32_t r = t < nnz ? (int32_t)(keys[t] >> 32) : nrows;
         int32_t rp = t > 0 ? (int32_t)(keys[t - 1] >> 32) : -1;
-        for (int32_t rr = rp + 1; rr <= r; ++rr) rowptr[rr] = (int32_t)t;
+        for (int32_t rr = rp + 1; rr <= r; ++rr) rowptr[rr] = (fd_nnz_t)t;
         if (t < nnz) colidx[t] = (int32_t)(keys[t] & 0xffffffffu);
     }
 }
 
-__global__ void expand_rowptr(int32_t nnode, const int32_t *__restrict__ nrp, int rbs, int cbs,
-                              int32_t *__restrict__ rp) {
+__global__ void expand_rowptr(int32_t nnode, const fd_nnz_t *__restrict__ nrp, int rbs, int cbs,
+                              fd_nnz_t *__restrict__ rp) {
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t <= (int64_t)nnode * rbs;
          t += (int64_t)gridDim.x * blockDim.x) {
         if (t == (int64_t)nnode * rbs) { rp[t] = nrp[nnode] * rbs * cbs; continue; }
         int32_t r = (int32_t)(t / rbs), p = (int32_t)(t - (int64_t)r * rbs);
-        int32_t len = nrp[r + 1] - nrp[r];
+        const fd_nnz_t len = nrp[r + 1] - nrp[r];
         rp[t] = nrp[r] * rbs * cbs + p * len * cbs;
     }
 }
 
-__global__ void expand_colidx(int32_t nnode, const int32_t *__restrict__ nrp, const int32_t *__restrict__ nci,
-                              int rbs, int cbs, const int32_t *__restrict__ rp, int32_t *__restrict__ ci) {
+__global__ void expand_colidx(int32_t nnode, const fd_nnz_t *__restrict__ nrp, const int32_t *__restrict__ nci,
+                              int rbs, int cbs, const fd_nnz_t *__restrict__ rp, int32_t *__restrict__ ci) {
     // one thread per (node row, p): writes its row's len*cbs entries
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < (int64_t)nnode * rbs;
          t += (int64_t)gridDim.x * blockDim.x) {
         int32_t r = (int32_t)(t / rbs);
-        int32_t o = rp[t];
-        for (int32_t q = nrp[r]; q < nrp[r + 1]; ++q)
+        fd_nnz_t o = rp[t];
+        for (fd_nnz_t q = nrp[r]; q < nrp[r + 1]; ++q)
             for (int c = 0; c < cbs; ++c) ci[o++] = nci[q] * cbs + c;
     }
 }
 
-__device__ inline int csr_find(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, int r, int c) {
-    int lo = rowptr[r], hi = rowptr[r + 1] - 1;
+__device__ inline fd_nnz_t csr_find(const fd_nnz_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, int r, int c) {
+    fd_nnz_t lo = rowptr[r], hi = rowptr[r + 1] - 1;
     while (lo <= hi) {
-        int mid = lo + ((hi - lo) >> 1);
+        const fd_nnz_t mid = lo + ((hi - lo) >> 1);
         int v = colidx[mid];
         if (v == c) return mid;
         if (v < c) lo = mid + 1; else hi = mid - 1;
@@ -105,7 +105,7 @@ __device__ inline int csr_find(const int32_t *__restrict__ rowptr, const int32_t
     return -1;
 }
 
-__global__ void elem_offsets(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+__global__ void elem_offsets(const fd_nnz_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                              const int32_t *__restrict__ rmap, const int32_t *__restrict__ cmap, int32_t nent,
                              int ar, int ac, int nl, const int32_t *__restrict__ roff, const int32_t *__restrict__ coff,
                              int32_t *__restrict__ out) {
@@ -118,19 +118,19 @@ __global__ void elem_offsets(const int32_t *__restrict__ rowptr, const int32_t *
         int i = ij / ac, j = ij - i * ac;
         int r = rmap[e * ar + i], c = cmap[e * ac + j];
         if (nl > 0) { if (r >= 0) r += roff[i] * l; if (c >= 0) c += coff[j] * l; }
-        out[t] = (r >= 0 && c >= 0) ? csr_find(rowptr, colidx, r, c) : -1;
+        out[t] = (r >= 0 && c >= 0) ? (int32_t)csr_find(rowptr, colidx, r, c) : -1;      // (callers check nnz < 2^31)
     }
 }
 
-__global__ void set_diag(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, double *__restrict__ vals,
+__global__ void set_diag(const fd_nnz_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, double *__restrict__ vals,
                          const int32_t *__restrict__ rows, int32_t n, double v, int zero_row) {
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
         int r = rows[t];
         if (r < 0) continue;
         if (zero_row) {
-            for (int q = rowptr[r]; q < rowptr[r + 1]; ++q) vals[q] = (colidx[q] == r) ? v : 0.0;
+            for (fd_nnz_t q = rowptr[r]; q < rowptr[r + 1]; ++q) vals[q] = (colidx[q] == r) ? v : 0.0;
         } else {
-            int q = csr_find(rowptr, colidx, r, r);
+            const fd_nnz_t q = csr_find(rowptr, colidx, r, r);
             if (q >= 0) vals[q] = v;
         }
     }
@@ -138,14 +138,14 @@ __global__ void set_diag(const int32_t *__restrict__ rowptr, const int32_t *__re
 
 // ---- MPIAIJ split (pyop2/types/mat.py:254-278: d_nnz / o_nnz; MatCreateMPIAIJWithSplitArrays): columns are sorted
 // inside a row and the owned columns [0, ncols_owned) come first, so the diagonal block is a prefix of every row
-__global__ void split_counts(int32_t nrows, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, int32_t ncols_owned,
+__global__ void split_counts(int32_t nrows, const fd_nnz_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, int32_t ncols_owned,
                              int32_t *__restrict__ dcnt, int32_t *__restrict__ ocnt) {
     for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
-        int lo = rowptr[r], hi = rowptr[r + 1];
-        const int b = lo, e = hi;
-        while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if (colidx[mid] < ncols_owned) lo = mid + 1; else hi = mid; }
-        dcnt[r] = lo - b;
-        ocnt[r] = e - lo;
+        fd_nnz_t lo = rowptr[r], hi = rowptr[r + 1];
+        const fd_nnz_t b = lo, e = hi;
+        while (lo < hi) { const fd_nnz_t mid = lo + ((hi - lo) >> 1); if (colidx[mid] < ncols_owned) lo = mid + 1; else hi = mid; }
+        dcnt[r] = (int32_t)(lo - b);
+        ocnt[r] = (int32_t)(e - lo);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { dcnt[nrows] = 0; ocnt[nrows] = 0; }
 }
@@ -156,14 +156,15 @@ __global__ void split_counts(int32_t nrows, const int32_t *__restrict__ rowptr, 
 // local ghost numbering is not monotone in the global one: WITH_IDX ranks every off-diagonal entry inside its row by global
 // column (rows are short: a quadratic count) and stores the rank; WITH_VALS scatters the values through it.
 template <bool WITH_IDX, bool WITH_VALS>
-__global__ void split_fill(int32_t nrows, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+__global__ void split_fill(int32_t nrows, const fd_nnz_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                            const double *__restrict__ vals, const int32_t *__restrict__ col_global,
                            const int32_t *__restrict__ drp, const int32_t *__restrict__ orp,
                            int32_t *__restrict__ dci, int32_t *__restrict__ oci, double *__restrict__ dv, double *__restrict__ ov,
                            int32_t *__restrict__ orank) {
     const int lane = threadIdx.x & 63;
     for (int64_t r = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6; r < nrows; r += ((int64_t)gridDim.x * blockDim.x) >> 6) {
-        const int b = rowptr[r], nd = drp[r + 1] - drp[r], no = orp[r + 1] - orp[r];
+        const fd_nnz_t b = rowptr[r];
+        const int nd = drp[r + 1] - drp[r], no = orp[r + 1] - orp[r];
         for (int q = lane; q < nd; q += 64) {
             if (WITH_IDX) dci[drp[r] + q] = colidx[b + q];
             if (WITH_VALS) dv[drp[r] + q] = vals[b + q];
@@ -184,24 +185,24 @@ __global__ void split_fill(int32_t nrows, const int32_t *__restrict__ rowptr, co
     }
 }
 
-__global__ void get_diag(int32_t nrows, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+__global__ void get_diag(int32_t nrows, const fd_nnz_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                          const double *__restrict__ vals, double *__restrict__ diag) {
     for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
-        int lo = rowptr[r], hi = rowptr[r + 1];          // columns are sorted: binary search for the diagonal
-        const int end = hi;
-        while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if (colidx[mid] < (int32_t)r) lo = mid + 1; else hi = mid; }
+        fd_nnz_t lo = rowptr[r], hi = rowptr[r + 1];     // columns are sorted: binary search for the diagonal
+        const fd_nnz_t end = hi;
+        while (lo < hi) { const fd_nnz_t mid = lo + ((hi - lo) >> 1); if (colidx[mid] < (int32_t)r) lo = mid + 1; else hi = mid; }
         diag[r] = (lo < end && colidx[lo] == (int32_t)r) ? vals[lo] : 0.0;
     }
 }
 
-__global__ void spmv(int32_t nrows, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+__global__ void spmv(int32_t nrows, const fd_nnz_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                      const double *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y) {
     // one wavefront per row
     const int lane = threadIdx.x & 63;
     for (int64_t r = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6; r < nrows;
          r += ((int64_t)gridDim.x * blockDim.x) >> 6) {
         double acc = 0.0;
-        for (int q = rowptr[r] + lane; q < rowptr[r + 1]; q += 64) acc += vals[q] * x[colidx[q]];
+        for (fd_nnz_t q = rowptr[r] + lane; q < rowptr[r + 1]; q += 64) acc += vals[q] * x[colidx[q]];
         for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
         if (lane == 0) y[r] = acc;
     }
@@ -234,7 +235,7 @@ int fd_csr_from_maps_ex(int32_t nrows, int32_t ncols, int set_diag, int npairs,
                         const int32_t *region, const int32_t *periodic,
                         const int32_t *const *rquots_h, const int32_t *const *cquots_h,
                         const int32_t *const *layers_dev,
-                        int32_t **rowptr_out, int32_t **colidx_out, int64_t *nnz_out, fd_stream_t s_) {
+                        fd_nnz_t **rowptr_out, int32_t **colidx_out, int64_t *nnz_out, fd_stream_t s_) {
     hipStream_t s = fd::st(s_);
     int64_t ncand = 0;
     for (int k = 0; k < npairs; ++k) {
@@ -252,9 +253,10 @@ int fd_csr_from_maps_ex(int32_t nrows, int32_t ncols, int set_diag, int npairs,
     int32_t ndiag = set_diag ? (nrows < ncols ? nrows : ncols) : 0;
     ncand += ndiag;
     // Candidate (row, column) keys are emitted, sorted and made unique in CHUNKS of at most CHUNK keys, the unique keys of
-    // every chunk appended to an accumulator that is itself compacted (sort + unique) whenever it passes 2^30 keys: no
-    // primitive ever sees more items than a 32-bit count holds (the 215^3 CG2 half-cube of BASELINE configs[4] has 3.0e9
-    // candidates for 1.2e9 nonzeros), and the peak footprint is ~4 x 8 GiB instead of 16 bytes per candidate.
+    // every chunk appended to an accumulator that is itself compacted (sort + unique) whenever it passes 2^30 keys -- or twice
+    // what its last compaction left, for patterns beyond 2^30 nonzeros (the 215^3 CG2 cube of BASELINE configs[4] has 6.0e9
+    // candidates for 2.3e9 nonzeros; the item counts of the primitives are 64-bit) -- so the peak footprint is a few times the
+    // pattern instead of 16 bytes per candidate.
     // The chunk buffers are 2 x 8 B per key and most of this function's time at C2 size was spent allocating and releasing them
     // (954 M candidates in one chunk: 15 GB for 40 ms of kernels): chunks of 2^27 keys by default (2 GB), the accumulator compacted
     // as before when it passes 2^30.
@@ -269,14 +271,14 @@ int fd_csr_from_maps_ex(int32_t nrows, int32_t ncols, int set_diag, int npairs,
         if (n == 0) { *result = in; *nout = 0; return 0; }
         hipcub::DoubleBuffer<uint64_t> db(in, alt);
         size_t tb = 0;
-        FD_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, db, (int)n, 0, 64, s));       // (~0 sentinel sorts last: all bits)
+        FD_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, db, (int64_t)n, 0, 64, s));   // (~0 sentinel sorts last: all bits)
         if (tb > *tmp_cap) { if (*tmp) FD_HIP(hipFree(*tmp)); FD_HIP(hipMalloc(tmp, tb)); *tmp_cap = tb; }
-        FD_HIP(hipcub::DeviceRadixSort::SortKeys(*tmp, tb, db, (int)n, 0, 64, s));
+        FD_HIP(hipcub::DeviceRadixSort::SortKeys(*tmp, tb, db, (int64_t)n, 0, 64, s));
         uint64_t *sorted = db.Current(), *other = (sorted == in) ? alt : in;
         size_t tb2 = 0;
-        FD_HIP(hipcub::DeviceSelect::Unique(nullptr, tb2, sorted, other, nsel_dev, (int)n, s));
+        FD_HIP(hipcub::DeviceSelect::Unique(nullptr, tb2, sorted, other, nsel_dev, (int64_t)n, s));
         if (tb2 > *tmp_cap) { if (*tmp) FD_HIP(hipFree(*tmp)); FD_HIP(hipMalloc(tmp, tb2)); *tmp_cap = tb2; }
-        FD_HIP(hipcub::DeviceSelect::Unique(*tmp, tb2, sorted, other, nsel_dev, (int)n, s));
+        FD_HIP(hipcub::DeviceSelect::Unique(*tmp, tb2, sorted, other, nsel_dev, (int64_t)n, s));
         FD_HIP(hipMemcpyAsync(nout, nsel_dev, 8, hipMemcpyDeviceToHost, s));
         FD_HIP(hipStreamSynchronize(s));
         *result = other;
@@ -285,7 +287,7 @@ int fd_csr_from_maps_ex(int32_t nrows, int32_t ncols, int set_diag, int npairs,
     const int64_t ccap = ncand < CHUNK ? ncand + 1 : CHUNK;
     uint64_t *ck = nullptr, *ck2 = nullptr;                   // chunk buffers
     uint64_t *acc = nullptr, *acc2 = nullptr;                 // accumulator (+ its sort partner); grown on demand
-    int64_t acc_n = 0, acc_cap = 0;
+    int64_t acc_n = 0, acc_cap = 0, next_compact = ACC_LIMIT;
     bool reserved = false;
     void *tmp = nullptr;
     size_t tmp_cap = 0;
@@ -299,15 +301,16 @@ int fd_csr_from_maps_ex(int32_t nrows, int32_t ncols, int set_diag, int npairs,
         if (int rc = sort_unique(acc, acc2, acc_n, &tmp, &tmp_cap, nsel, &res, &n)) return rc;
         if (res != acc) std::swap(acc, acc2);
         acc_n = n;
+        next_compact = std::max<int64_t>(ACC_LIMIT, 2 * n);
         return 0;
     };
     auto append = [&](const uint64_t *src, int64_t n) -> int {
         if (acc_n + n > acc_cap) {
-            if (acc_n > ACC_LIMIT) { if (int rc = compact()) return rc; }
+            if (acc_n > next_compact) { if (int rc = compact()) return rc; }
             if (acc_n + n > acc_cap) {
                 int64_t want = acc_cap ? acc_cap * 2 : (n + 1);
                 while (want < acc_n + n) want *= 2;
-                if (want > 2147483647ll) want = 2147483647ll;
+                if (sizeof(fd_nnz_t) == 4 && want > 2147483647ll) want = 2147483647ll;
                 if (acc_n + n > want) { fd::set_error("fd_csr_from_maps: more than 2^31-1 distinct candidate entries (nnz exceeds IntType)"); return -1; }
                 uint64_t *na = nullptr, *na2 = nullptr;
                 FD_HIP(hipMalloc(&na, (size_t)want * 8));
@@ -376,7 +379,7 @@ int fd_csr_from_maps_ex(int32_t nrows, int32_t ncols, int set_diag, int npairs,
                 // -- which it must be allowed to reach before the capacity is
                 const double cap_ = (double)ACC_LIMIT + (double)ccap;
                 if (est > cap_) est = cap_;
-                if (est > 2147483647.0) est = 2147483647.0;
+                if (sizeof(fd_nnz_t) == 4 && est > 2147483647.0) est = 2147483647.0;
                 const int64_t want = (int64_t)est;
                 if (want > acc_cap) {
                     // a reservation that does not fit the device is not an error: append() grows the accumulator step by step
@@ -414,9 +417,10 @@ int fd_csr_from_maps_ex(int32_t nrows, int32_t ncols, int set_diag, int npairs,
         FD_HIP(hipMemcpy(&last, other + nu - 1, 8, hipMemcpyDeviceToHost));
         if (last == ~0ull) --nu;
     }
-    if (nu > 2147483647ll) FD_FAIL("fd_csr_from_maps: nnz exceeds int32 (IntType)");
-    int32_t *rowptr = nullptr, *colidx = nullptr;
-    FD_HIP(hipMalloc(&rowptr, ((size_t)nrows + 1) * 4));
+    if (sizeof(fd_nnz_t) == 4 && nu > 2147483647ll) FD_FAIL("fd_csr_from_maps: nnz exceeds int32 (IntType)");
+    fd_nnz_t *rowptr = nullptr;
+    int32_t *colidx = nullptr;
+    FD_HIP(hipMalloc(&rowptr, ((size_t)nrows + 1) * sizeof(fd_nnz_t)));
     FD_HIP(hipMalloc(&colidx, (size_t)(nu > 0 ? nu : 1) * 4));
     hipLaunchKernelGGL(keys_to_csr, dim3(grid_for(nu + 1)), dim3(256), 0, s, other, nu, nrows, rowptr, colidx);
     FD_CHECK_LAUNCH();
@@ -433,20 +437,21 @@ int fd_csr_from_maps(int32_t nrows, int32_t ncols, int set_diag, int npairs,
                      const int32_t *const *rmaps, const int32_t *const *cmaps, const int32_t *nent,
                      const int32_t *rarity, const int32_t *carity, const int32_t *nlayers,
                      const int32_t *const *roffs_h, const int32_t *const *coffs_h,
-                     int32_t **rowptr_out, int32_t **colidx_out, int64_t *nnz_out, fd_stream_t s) {
+                     fd_nnz_t **rowptr_out, int32_t **colidx_out, int64_t *nnz_out, fd_stream_t s) {
     return fd_csr_from_maps_ex(nrows, ncols, set_diag, npairs, rmaps, cmaps, nent, rarity, carity, nlayers, roffs_h,
                                coffs_h, nullptr, nullptr, nullptr, nullptr, nullptr, rowptr_out, colidx_out, nnz_out, s);
 }
 
-int fd_csr_expand_blocks(int32_t nnode, const int32_t *nrp, const int32_t *nci, int rbs, int cbs,
-                         int32_t **rp_out, int32_t **ci_out, fd_stream_t s_) {
+int fd_csr_expand_blocks(int32_t nnode, const fd_nnz_t *nrp, const int32_t *nci, int rbs, int cbs,
+                         fd_nnz_t **rp_out, int32_t **ci_out, fd_stream_t s_) {
     hipStream_t s = fd::st(s_);
-    int32_t nnz_node;
-    FD_HIP(hipMemcpy(&nnz_node, nrp + nnode, 4, hipMemcpyDeviceToHost));
+    fd_nnz_t nnz_node;
+    FD_HIP(hipMemcpy(&nnz_node, nrp + nnode, sizeof(fd_nnz_t), hipMemcpyDeviceToHost));
     int64_t nnz = (int64_t)nnz_node * rbs * cbs;
-    if (nnz > 2147483647ll) FD_FAIL("fd_csr_expand_blocks: nnz exceeds int32");
-    int32_t *rp = nullptr, *ci = nullptr;
-    FD_HIP(hipMalloc(&rp, ((size_t)nnode * rbs + 1) * 4));
+    if (sizeof(fd_nnz_t) == 4 && nnz > 2147483647ll) FD_FAIL("fd_csr_expand_blocks: nnz exceeds int32");
+    fd_nnz_t *rp = nullptr;
+    int32_t *ci = nullptr;
+    FD_HIP(hipMalloc(&rp, ((size_t)nnode * rbs + 1) * sizeof(fd_nnz_t)));
     FD_HIP(hipMalloc(&ci, (size_t)(nnz > 0 ? nnz : 1) * 4));
     hipLaunchKernelGGL(expand_rowptr, dim3(grid_for((int64_t)nnode * rbs + 1)), dim3(256), 0, s, nnode, nrp, rbs, cbs, rp);
     FD_CHECK_LAUNCH();
@@ -456,7 +461,7 @@ int fd_csr_expand_blocks(int32_t nnode, const int32_t *nrp, const int32_t *nci, 
     return 0;
 }
 
-int fd_csr_elem_offsets(const int32_t *rowptr, const int32_t *colidx, const int32_t *rmap, const int32_t *cmap,
+int fd_csr_elem_offsets(const fd_nnz_t *rowptr, const int32_t *colidx, const int32_t *rmap, const int32_t *cmap,
                         int32_t nent, int ar, int ac, int nlayers, const int32_t *roff_host, const int32_t *coff_host,
                         int32_t *out, fd_stream_t s_) {
     if (nent <= 0) return 0;
@@ -476,7 +481,7 @@ int fd_csr_elem_offsets(const int32_t *rowptr, const int32_t *colidx, const int3
     return 0;
 }
 
-int fd_csr_set_diagonal(const int32_t *rowptr, const int32_t *colidx, double *vals, const int32_t *rows, int32_t n,
+int fd_csr_set_diagonal(const fd_nnz_t *rowptr, const int32_t *colidx, double *vals, const int32_t *rows, int32_t n,
                         double v, fd_stream_t s) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(set_diag, dim3(grid_for(n)), dim3(256), 0, fd::st(s), rowptr, colidx, vals, rows, n, v, 0);
@@ -484,7 +489,7 @@ int fd_csr_set_diagonal(const int32_t *rowptr, const int32_t *colidx, double *va
     return 0;
 }
 
-int fd_csr_zero_rows(const int32_t *rowptr, const int32_t *colidx, double *vals, const int32_t *rows, int32_t n,
+int fd_csr_zero_rows(const fd_nnz_t *rowptr, const int32_t *colidx, double *vals, const int32_t *rows, int32_t n,
                      double v, fd_stream_t s) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(set_diag, dim3(grid_for(n)), dim3(256), 0, fd::st(s), rowptr, colidx, vals, rows, n, v, 1);
@@ -492,7 +497,7 @@ int fd_csr_zero_rows(const int32_t *rowptr, const int32_t *colidx, double *vals,
     return 0;
 }
 
-int fd_csr_split_mpiaij(int32_t nrows_owned, const int32_t *rowptr, const int32_t *colidx, int32_t ncols_owned,
+int fd_csr_split_mpiaij(int32_t nrows_owned, const fd_nnz_t *rowptr, const int32_t *colidx, int32_t ncols_owned,
                         const int32_t *col_global, int32_t **d_rowptr, int32_t **d_colidx, int64_t *d_nnz,
                         int32_t **o_rowptr, int32_t **o_colidx, int32_t **o_rank, int64_t *o_nnz, fd_stream_t s_) {
     if (nrows_owned < 0 || !rowptr || !colidx || !d_rowptr || !d_colidx || !o_rowptr || !o_colidx || !o_rank || !d_nnz || !o_nnz)
@@ -530,7 +535,7 @@ int fd_csr_split_mpiaij(int32_t nrows_owned, const int32_t *rowptr, const int32_
     return 0;
 }
 
-int fd_csr_split_values(int32_t nrows_owned, const int32_t *rowptr, const double *vals, const int32_t *d_rowptr,
+int fd_csr_split_values(int32_t nrows_owned, const fd_nnz_t *rowptr, const double *vals, const int32_t *d_rowptr,
                         const int32_t *o_rowptr, const int32_t *o_rank, double *d_vals, double *o_vals, fd_stream_t s) {
     if (nrows_owned <= 0) return 0;
     hipLaunchKernelGGL((split_fill<false, true>), dim3(grid_for((int64_t)nrows_owned * 64)), dim3(256), 0, fd::st(s), nrows_owned, rowptr,
@@ -540,14 +545,14 @@ int fd_csr_split_values(int32_t nrows_owned, const int32_t *rowptr, const double
     return 0;
 }
 
-int fd_csr_get_diagonal(int32_t nrows, const int32_t *rowptr, const int32_t *colidx, const double *vals, double *diag, fd_stream_t s) {
+int fd_csr_get_diagonal(int32_t nrows, const fd_nnz_t *rowptr, const int32_t *colidx, const double *vals, double *diag, fd_stream_t s) {
     if (nrows <= 0) return 0;
     hipLaunchKernelGGL(get_diag, dim3(grid_for(nrows)), dim3(256), 0, fd::st(s), nrows, rowptr, colidx, vals, diag);
     FD_CHECK_LAUNCH();
     return 0;
 }
 
-int fd_csr_spmv(int32_t nrows, const int32_t *rowptr, const int32_t *colidx, const double *vals, const double *x,
+int fd_csr_spmv(int32_t nrows, const fd_nnz_t *rowptr, const int32_t *colidx, const double *vals, const double *x,
                 double *y, fd_stream_t s) {
     if (nrows <= 0) return 0;
     hipLaunchKernelGGL(spmv, dim3(grid_for((int64_t)nrows * 64)), dim3(256), 0, fd::st(s), nrows, rowptr, colidx, vals, x, y);

@@ -161,19 +161,21 @@ __global__ void ft_invert(const int32_t *__restrict__ plist, int32_t nnodes, int
 }
 
 // gpos[prowptr[p] + k] = gstart[p] + k: 16 lanes per row
-__global__ void row_entry_positions(int32_t npos, const int32_t *__restrict__ prowptr, const int32_t *__restrict__ gstart,
+// (gpos holds 32-bit places: the whole-entity row flush serves patterns below 2^31 entries, fd_row_entry_positions checks)
+__global__ void row_entry_positions(int32_t npos, const fd_nnz_t *__restrict__ prowptr, const fd_nnz_t *__restrict__ gstart,
                                     int32_t *__restrict__ gpos) {
     const int sub = threadIdx.x & 15;
     for (int64_t p = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4; p < npos; p += ((int64_t)gridDim.x * blockDim.x) >> 4) {
-        const int32_t a = prowptr[p], len = prowptr[p + 1] - a, g = gstart[p];
-        for (int k = sub; k < len; k += 16) gpos[a + k] = g + k;
+        const fd_nnz_t a = prowptr[p], g = gstart[p];
+        const int len = (int)(prowptr[p + 1] - a);
+        for (int k = sub; k < len; k += 16) gpos[a + k] = (int32_t)(g + k);
     }
 }
 
 // ---- run-coded flush tables of a derived row order (fd_ocr_row_runs)
 // A row position p starts a RUN when it is the first row of its block or when its displacement (CSR start - accumulator start)
 // differs from the previous position's: inside a run, place = accumulator index + one displacement.
-__global__ void rr_flags(int32_t npos, const int32_t *__restrict__ prowptr, const int32_t *__restrict__ gstart,
+__global__ void rr_flags(int32_t npos, const fd_nnz_t *__restrict__ prowptr, const fd_nnz_t *__restrict__ gstart,
                          const int32_t *__restrict__ rblk, int32_t nblocks, int32_t *__restrict__ flag) {
     const int64_t t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
     for (int64_t p = t0; p < npos; p += st)
@@ -184,9 +186,9 @@ __global__ void rr_block_starts(const int32_t *__restrict__ rblk, int32_t nblock
         if (rblk[b] < npos) flag[rblk[b]] = 1;
 }
 // runidx = inclusive scan of flag (1-based run number of every position)
-__global__ void rr_tables(int32_t npos, const int32_t *__restrict__ prowptr, const int32_t *__restrict__ gstart,
+__global__ void rr_tables(int32_t npos, const fd_nnz_t *__restrict__ prowptr, const fd_nnz_t *__restrict__ gstart,
                           const int32_t *__restrict__ flag, const int32_t *__restrict__ runidx, const int32_t *__restrict__ rblk,
-                          int32_t nblocks, int32_t *__restrict__ brun, int32_t *__restrict__ rdelta) {
+                          int32_t nblocks, int32_t *__restrict__ brun, fd_nnz_t *__restrict__ rdelta) {
     const int64_t t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
     for (int64_t p = t0; p < npos; p += st)
         if (flag[p]) rdelta[runidx[p] - 1] = gstart[p] - prowptr[p];
@@ -196,13 +198,14 @@ __global__ void rr_tables(int32_t npos, const int32_t *__restrict__ prowptr, con
     }
 }
 // one workgroup per block: grun[entry] = run of the entry's row, counted from the block's first run; err |= 1 above 255
-__global__ void rr_entries(const int32_t *__restrict__ rblk, int32_t nblocks, int32_t npos, const int32_t *__restrict__ prowptr,
+__global__ void rr_entries(const int32_t *__restrict__ rblk, int32_t nblocks, int32_t npos, const fd_nnz_t *__restrict__ prowptr,
                            const int32_t *__restrict__ runidx, const int32_t *__restrict__ brun, uint8_t *__restrict__ grun,
                            int32_t *__restrict__ err) {
     for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
         const int32_t n0 = rblk[b], n1 = rblk[b + 1] < npos ? rblk[b + 1] : npos, r0 = brun[b];
         for (int32_t p = n0 + (threadIdx.x >> 4); p < n1; p += blockDim.x >> 4) {
-            const int32_t a = prowptr[p], len = prowptr[p + 1] - a, r = runidx[p] - 1 - r0;
+            const fd_nnz_t a = prowptr[p];
+            const int32_t len = (int32_t)(prowptr[p + 1] - a), r = runidx[p] - 1 - r0;
             if (r > 255 && (threadIdx.x & 15) == 0) atomicOr(err, 1);
             for (int k = threadIdx.x & 15; k < len; k += 16) grun[a + k] = (uint8_t)r;
         }
@@ -210,16 +213,17 @@ __global__ void rr_entries(const int32_t *__restrict__ rblk, int32_t nblocks, in
 }
 
 // ---- tables of a row order (fd_row_order_tables): lengths and CSR starts of the rows in position order, accumulator starts by node
-__global__ void ro_gather(int32_t npos, const int32_t *__restrict__ plist, const int32_t *__restrict__ rowptr,
-                          int32_t *__restrict__ len, int32_t *__restrict__ gstart) {
+__global__ void ro_gather(int32_t npos, const int32_t *__restrict__ plist, const fd_nnz_t *__restrict__ rowptr,
+                          fd_nnz_t *__restrict__ len, fd_nnz_t *__restrict__ gstart) {
     for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p <= npos; p += (int64_t)gridDim.x * blockDim.x) {
         if (p == npos) { len[p] = 0; continue; }
-        const int32_t r = plist[p], a = rowptr[r];
+        const int32_t r = plist[p];
+        const fd_nnz_t a = rowptr[r];
         len[p] = rowptr[r + 1] - a;
         gstart[p] = a;
     }
 }
-__global__ void ro_nstart(int32_t npos, const int32_t *__restrict__ plist, const int32_t *__restrict__ prowptr, int32_t *__restrict__ nstart) {
+__global__ void ro_nstart(int32_t npos, const int32_t *__restrict__ plist, const fd_nnz_t *__restrict__ prowptr, fd_nnz_t *__restrict__ nstart) {
     for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npos; p += (int64_t)gridDim.x * blockDim.x)
         nstart[plist[p]] = prowptr[p];
 }
@@ -411,15 +415,15 @@ int fd_first_touch_order(const int32_t *map_dev, int arity, const int32_t *order
     return rc;
 }
 
-int fd_row_entry_positions(int32_t npos, const int32_t *prowptr_dev, const int32_t *gstart_dev, int32_t *gpos_dev, fd_stream_t s) {
+int fd_row_entry_positions(int32_t npos, const fd_nnz_t *prowptr_dev, const fd_nnz_t *gstart_dev, int32_t *gpos_dev, fd_stream_t s) {
     if (npos <= 0) return 0;
     hipLaunchKernelGGL(row_entry_positions, dim3(lo_grid((int64_t)npos * 16)), dim3(256), 0, fd::st(s), npos, prowptr_dev, gstart_dev, gpos_dev);
     FD_CHECK_LAUNCH();
     return 0;
 }
 
-int fd_ocr_row_runs(int32_t npos, const int32_t *prowptr_dev, const int32_t *gstart_dev, const int32_t *rblk_dev, int32_t nblocks,
-                    uint8_t *grun_dev, int32_t *brun_dev, int32_t *rdelta_dev, int32_t *nruns_out, int32_t *max_runs_out, fd_stream_t s_) {
+int fd_ocr_row_runs(int32_t npos, const fd_nnz_t *prowptr_dev, const fd_nnz_t *gstart_dev, const int32_t *rblk_dev, int32_t nblocks,
+                    uint8_t *grun_dev, int32_t *brun_dev, fd_nnz_t *rdelta_dev, int32_t *nruns_out, int32_t *max_runs_out, fd_stream_t s_) {
     if (!prowptr_dev || !gstart_dev || !rblk_dev || !grun_dev || !brun_dev || !rdelta_dev || !nruns_out || !max_runs_out || npos < 0 || nblocks < 0)
         FD_FAIL("fd_ocr_row_runs: bad arguments");
     *nruns_out = 0; *max_runs_out = 0;
@@ -455,13 +459,13 @@ int fd_ocr_row_runs(int32_t npos, const int32_t *prowptr_dev, const int32_t *gst
     return 0;
 }
 
-int fd_row_order_tables(int32_t npos, const int32_t *plist_dev, const int32_t *rowptr_dev, int32_t *prowptr_dev, int32_t *nstart_dev,
-                        int32_t *gstart_dev, fd_stream_t s_) {
+int fd_row_order_tables(int32_t npos, const int32_t *plist_dev, const fd_nnz_t *rowptr_dev, fd_nnz_t *prowptr_dev, fd_nnz_t *nstart_dev,
+                        fd_nnz_t *gstart_dev, fd_stream_t s_) {
     if (npos < 0 || !prowptr_dev || (npos && (!plist_dev || !rowptr_dev || !nstart_dev || !gstart_dev))) FD_FAIL("fd_row_order_tables: bad arguments");
     hipStream_t s = fd::st(s_);
-    if (npos == 0) { FD_HIP(hipMemsetAsync(prowptr_dev, 0, 4, s)); return 0; }
-    int32_t *len = nullptr; void *tmp = nullptr;
-    FD_HIP(hipMalloc(&len, ((size_t)npos + 1) * 4));
+    if (npos == 0) { FD_HIP(hipMemsetAsync(prowptr_dev, 0, sizeof(fd_nnz_t), s)); return 0; }
+    fd_nnz_t *len = nullptr; void *tmp = nullptr;
+    FD_HIP(hipMalloc(&len, ((size_t)npos + 1) * sizeof(fd_nnz_t)));
     hipLaunchKernelGGL(ro_gather, dim3(lo_grid((int64_t)npos + 1)), dim3(256), 0, s, npos, plist_dev, rowptr_dev, len, gstart_dev);
     FD_CHECK_LAUNCH();
     size_t tb = 0;

@@ -507,7 +507,7 @@ __device__ inline int64_t lower_bound_u64(const uint64_t *__restrict__ a, int64_
 __global__ void mp_rows_and_gpos(const uint64_t *__restrict__ keys, const int32_t *__restrict__ mb_off,
                                  const int32_t *__restrict__ blkoff_r, const int32_t *__restrict__ list_r,
                                  const int32_t *__restrict__ blkoff_c, const int32_t *__restrict__ list_c,
-                                 const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                                 const fd_nnz_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                                  int32_t *__restrict__ lrp, int32_t *__restrict__ gpos, int32_t *__restrict__ stats) {
     const int64_t b = blockIdx.x;
     const int64_t o0 = mb_off[b], o1 = mb_off[b + 1];
@@ -521,15 +521,9 @@ __global__ void mp_rows_and_gpos(const uint64_t *__restrict__ keys, const int32_
         uint64_t k = keys[t];
         int lr = (int)((k >> 16) & 0xffff), lc = (int)(k & 0xffff);
         int r = list_r[r0 + lr], c = list_c[c0 + lc];
-        int lo = rowptr[r], hi = rowptr[r + 1] - 1, pos = -1;
-        while (lo <= hi) {
-            int mid = lo + ((hi - lo) >> 1);
-            int v = colidx[mid];
-            if (v == c) { pos = mid; break; }
-            if (v < c) lo = mid + 1; else hi = mid - 1;
-        }
+        const fd_nnz_t pos = fd_csr_find(rowptr, colidx, r, c);
         if (pos < 0) atomicExch(&stats[2], 1);
-        gpos[t] = pos;
+        gpos[t] = (int32_t)pos;                                // (fd_matplan_create: patterns below 2^31 entries)
     }
     if (threadIdx.x == 0) atomicMax(&stats[0], (int32_t)(o1 - o0));
     __syncthreads();
@@ -580,12 +574,13 @@ inline int mp_grid(int64_t n) { int64_t g = (n + 255) / 256; if (g < 1) g = 1; i
 
 extern "C" {
 
-int fd_matplan_create(fd_plan_t rp, fd_plan_t cp, const int32_t *rowptr, const int32_t *colidx, int64_t nnz,
+int fd_matplan_create(fd_plan_t rp, fd_plan_t cp, const fd_nnz_t *rowptr, const int32_t *colidx, int64_t nnz,
                       fd_stream_t s_, fd_matplan_t *out) {
     hipStream_t s = fd::st(s_);
     if (!rp || !cp) FD_FAIL("fd_matplan_create: null plan");
     if (rp->start != cp->start || rp->end != cp->end || rp->nblocks != cp->nblocks)
         FD_FAIL("fd_matplan_create: row and column plans must cover the same blocks");
+    if (nnz > 2147483647ll) FD_FAIL("fd_matplan_create: staged matrix plans address the value array with 32-bit places (nnz >= 2^31: use the owner-computes-rows shapes)");
     auto *m = new fd_matplan_s;
     m->nblocks = rp->nblocks;
     const int64_t nent = (int64_t)rp->end - rp->start;
@@ -741,7 +736,7 @@ struct fd_ocrplan_s {
     // optional backend-derived row order (fd_first_touch_order): the blocks are then ranges of row POSITIONS;
     // pinv[node] = position for node < npos (borrowed, caller keeps it alive), prowptr = CSR row starts in position order
     const int32_t *pinv = nullptr;
-    const int32_t *prowptr = nullptr;
+    const fd_nnz_t *prowptr = nullptr;
     int32_t npos = 0;
     // row-sliced plans (fd_ocrplan_create_sliced): an instance is (entity, local row); the lists are padded so that every
     // 64 consecutive slots hold ONE local row index (chunk_role), valid[t] = 0 marks the padding slots
@@ -873,7 +868,7 @@ __global__ void gather_rows_k(const int32_t *__restrict__ src, int arity, const 
 }
 
 template <class KT>
-__global__ void row_offsets_k(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+__global__ void row_offsets_k(const fd_nnz_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                               const int32_t *__restrict__ rmap, const int32_t *__restrict__ cmap, int64_t nent, int ar, int ac,
                               KT *__restrict__ out, int32_t *__restrict__ err) {
     const int64_t per = (int64_t)ar * ac, total = nent * per;
@@ -885,13 +880,7 @@ __global__ void row_offsets_k(const int32_t *__restrict__ rowptr, const int32_t 
         int r = rmap[e * ar + i], c = cmap[e * ac + j];
         KT v = SKIP;
         if (r >= 0 && c >= 0) {
-            int lo = rowptr[r], hi = rowptr[r + 1] - 1, pos = -1;
-            while (lo <= hi) {
-                int mid = lo + ((hi - lo) >> 1);
-                int cv = colidx[mid];
-                if (cv == c) { pos = mid; break; }
-                if (cv < c) lo = mid + 1; else hi = mid - 1;
-            }
+            const fd_nnz_t pos = fd_csr_find(rowptr, colidx, r, c);
             if (pos >= 0) v = (KT)(pos - rowptr[r]); else atomicExch(err, 1);
         }
         out[t] = v;
@@ -981,8 +970,8 @@ template <class KT>
 __global__ void ocrs_tables_k(const int32_t *__restrict__ inst_off, int32_t nblocks, const int32_t *__restrict__ ent,
                               const uint8_t *__restrict__ valid, const uint8_t *__restrict__ chunk_role, int64_t ninst,
                               const int32_t *__restrict__ rmap, int ar, const int32_t *__restrict__ cmap, int ac,
-                              const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
-                              const int32_t *__restrict__ acc_by_node, const int32_t *__restrict__ acc_by_pos,
+                              const fd_nnz_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                              const fd_nnz_t *__restrict__ acc_by_node, const fd_nnz_t *__restrict__ acc_by_pos,
                               const int32_t *__restrict__ rblk, const int32_t *__restrict__ rlg, const int32_t *__restrict__ clg,
                               uint16_t *__restrict__ slot, uint16_t *__restrict__ rowlen, KT *__restrict__ kk, int32_t *__restrict__ err,
                               int rbs, int cbs, uint8_t *__restrict__ rmask, unsigned long long *__restrict__ cmask) {
@@ -1014,12 +1003,12 @@ __global__ void ocrs_tables_k(const int32_t *__restrict__ inst_off, int32_t nblo
             if (live) {
                 int lo = 0, hi = nblocks - 1;                  // block of instance t: largest b with inst_off[b] <= t
                 while (lo < hi) { int mid = lo + ((hi - lo + 1) >> 1); if (inst_off[mid] <= t) lo = mid; else hi = mid - 1; }
-                const int32_t d = acc_by_node[r] - acc_by_pos[rblk[lo]];
+                const fd_nnz_t d = acc_by_node[r] - acc_by_pos[rblk[lo]];
                 if (d < 0 || d >= 0xffff) atomicExch(err, 2); else sl = (uint16_t)d;
             }
             slot[t] = sl;
             if (rowlen) {
-                const int32_t rl = r >= 0 ? rowptr[r + 1] - rowptr[r] : 0;
+                const fd_nnz_t rl = r >= 0 ? rowptr[r + 1] - rowptr[r] : 0;
                 if (rl > 0xffff) atomicExch(err, 2);
                 rowlen[t] = (uint16_t)rl;
             }
@@ -1027,13 +1016,7 @@ __global__ void ocrs_tables_k(const int32_t *__restrict__ inst_off, int32_t nblo
         KT v = SKIP;
         const int32_t c = cmap[(int64_t)e * ac + j];
         if (live && c >= 0 && (rmask || !(clg && clg[c] < 0))) {
-            int lo = rowptr[r], hi = rowptr[r + 1] - 1, pos = -1;
-            while (lo <= hi) {
-                int mid = lo + ((hi - lo) >> 1);
-                int cv = colidx[mid];
-                if (cv == c) { pos = mid; break; }
-                if (cv < c) lo = mid + 1; else hi = mid - 1;
-            }
+            const fd_nnz_t pos = fd_csr_find(rowptr, colidx, r, c);
             if (pos >= 0) v = (KT)(pos - rowptr[r]); else atomicExch(err, 1);
         }
         kk[u] = v;
@@ -1082,17 +1065,13 @@ __global__ void ocr_pack_records_k(RecDesc d, int64_t ninst, uint32_t *__restric
 }
 
 // words[i] |= (position of the diagonal entry in the CSR row of node list[i]) << 20  (8 bits; err |= 1 above 255 or without a diagonal)
-__global__ void ocr_node_diag_k(const int32_t *__restrict__ list, int64_t n, int32_t nrows, const int32_t *__restrict__ rowptr,
+__global__ void ocr_node_diag_k(const int32_t *__restrict__ list, int64_t n, int32_t nrows, const fd_nnz_t *__restrict__ rowptr,
                                 const int32_t *__restrict__ colidx, uint32_t *__restrict__ words, int32_t *__restrict__ err) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int32_t g = list[i];
         if (g < 0 || g >= nrows) continue;                    // not a row of this matrix (never owned: its word is 0)
-        int lo = rowptr[g], hi = rowptr[g + 1] - 1, pos = -1;
-        while (lo <= hi) {
-            const int mid = lo + ((hi - lo) >> 1), cv = colidx[mid];
-            if (cv == g) { pos = mid - rowptr[g]; break; }
-            if (cv < g) lo = mid + 1; else hi = mid - 1;
-        }
+        const fd_nnz_t at = fd_csr_find(rowptr, colidx, g, g);
+        const int pos = at < 0 ? -1 : (int)(at - rowptr[g]);
         if (pos < 0 || pos > 255) { if (words[i] & 0xfffffu) atomicOr(err, 1); continue; }
         words[i] |= (uint32_t)pos << 20;
     }
@@ -1103,15 +1082,15 @@ __global__ void ocr_node_diag_k(const int32_t *__restrict__ list, int64_t n, int
 // bit 31 = the node's column is masked by the column lgmap.  Precomputed in PLAN order so that the wrapper's staging phase
 // streams it instead of gathering a row start and two lgmap entries per node by node id.
 __global__ void ocr_node_words_k(const int32_t *__restrict__ blkoff, const int32_t *__restrict__ list, int32_t nblocks,
-                                 const int32_t *__restrict__ rblk, const int32_t *__restrict__ base_by_node,
-                                 const int32_t *__restrict__ start_by_pos, int by_offset, int32_t npos, const int32_t *__restrict__ rlg,
+                                 const int32_t *__restrict__ rblk, const fd_nnz_t *__restrict__ base_by_node,
+                                 const fd_nnz_t *__restrict__ start_by_pos, int by_offset, int32_t npos, const int32_t *__restrict__ rlg,
                                  const int32_t *__restrict__ clg, uint32_t *__restrict__ out) {
     for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
         const int32_t n0 = rblk[b], nown = rblk[b + 1] - n0;
-        const int32_t r0 = start_by_pos[n0], nnzb = start_by_pos[n0 + nown] - r0;
+        const fd_nnz_t r0 = start_by_pos[n0], nnzb = start_by_pos[n0 + nown] - r0;
         for (int32_t i = blkoff[b] + threadIdx.x; i < blkoff[b + 1]; i += blockDim.x) {
             const int32_t g = list[i];
-            int32_t p = -1;
+            fd_nnz_t p = -1;
             if (by_offset) { if (g >= 0 && g < npos) { p = base_by_node[g] - r0; if (p < 0 || p >= nnzb) p = -1; } }
             else if (g >= n0 && g < n0 + nown) p = base_by_node[g] - r0;
             uint32_t w = (p >= 0 && !(rlg && rlg[g] < 0)) ? (uint32_t)(p + 1) : 0u;
@@ -1126,7 +1105,7 @@ __global__ void ocr_node_words_k(const int32_t *__restrict__ blkoff, const int32
 extern "C" {
 
 int fd_ocr_node_words(const int32_t *blkoff_dev, const int32_t *list_dev, int32_t nblocks, const int32_t *rblk_dev,
-                      const int32_t *base_by_node_dev, const int32_t *start_by_pos_dev, int by_offset, int32_t npos,
+                      const fd_nnz_t *base_by_node_dev, const fd_nnz_t *start_by_pos_dev, int by_offset, int32_t npos,
                       const int32_t *row_lgmap_dev, const int32_t *col_lgmap_dev, uint32_t *out_dev, fd_stream_t s) {
     if (!blkoff_dev || !list_dev || !rblk_dev || !base_by_node_dev || !start_by_pos_dev || !out_dev || nblocks < 0)
         FD_FAIL("fd_ocr_node_words: bad arguments");
@@ -1169,7 +1148,7 @@ int fd_ocr_pack_records(int64_t ninst, int nmaps, const uint16_t *const *lmaps_d
     return 0;
 }
 
-int fd_ocr_node_diag(const int32_t *list_dev, int64_t n, int32_t nrows, const int32_t *rowptr_dev, const int32_t *colidx_dev,
+int fd_ocr_node_diag(const int32_t *list_dev, int64_t n, int32_t nrows, const fd_nnz_t *rowptr_dev, const int32_t *colidx_dev,
                      uint32_t *words_dev, fd_stream_t s_) {
     if (n < 0 || (n && (!list_dev || !rowptr_dev || !colidx_dev || !words_dev))) FD_FAIL("fd_ocr_node_diag: bad arguments");
     if (n == 0) return 0;
@@ -1187,7 +1166,7 @@ int fd_ocr_node_diag(const int32_t *list_dev, int64_t n, int32_t nrows, const in
 }
 
 static int ocrplan_build(const int32_t *rmap_dev, int ar, int32_t start, int32_t end, const int32_t *row_block_starts_host,
-                         int32_t nblocks, int interleave, const int32_t *pinv_dev, int32_t npos, const int32_t *prowptr_dev,
+                         int32_t nblocks, int interleave, const int32_t *pinv_dev, int32_t npos, const fd_nnz_t *prowptr_dev,
                          fd_stream_t s_, fd_ocrplan_t *out);
 
 int fd_ocrplan_create(const int32_t *rmap_dev, int ar, int32_t start, int32_t end,
@@ -1197,13 +1176,13 @@ int fd_ocrplan_create(const int32_t *rmap_dev, int ar, int32_t start, int32_t en
 
 int fd_ocrplan_create_ordered(const int32_t *rmap_dev, int ar, int32_t start, int32_t end,
                               const int32_t *pos_block_starts_host, int32_t nblocks, int interleave,
-                              const int32_t *pinv_dev, int32_t npos, const int32_t *prowptr_dev, fd_stream_t s_, fd_ocrplan_t *out) {
+                              const int32_t *pinv_dev, int32_t npos, const fd_nnz_t *prowptr_dev, fd_stream_t s_, fd_ocrplan_t *out) {
     if (!pinv_dev || !prowptr_dev || npos < 0) FD_FAIL("fd_ocrplan_create_ordered: bad arguments");
     return ocrplan_build(rmap_dev, ar, start, end, pos_block_starts_host, nblocks, interleave, pinv_dev, npos, prowptr_dev, s_, out);
 }
 
 static int ocrplan_build(const int32_t *rmap_dev, int ar, int32_t start, int32_t end, const int32_t *row_block_starts_host,
-                         int32_t nblocks, int interleave, const int32_t *pinv_dev, int32_t npos, const int32_t *prowptr_dev,
+                         int32_t nblocks, int interleave, const int32_t *pinv_dev, int32_t npos, const fd_nnz_t *prowptr_dev,
                          fd_stream_t s_, fd_ocrplan_t *out) {
     hipStream_t s = fd::st(s_);
     if (ar <= 0 || nblocks < 0 || end < start || !row_block_starts_host) FD_FAIL("fd_ocrplan_create: bad arguments");
@@ -1407,8 +1386,8 @@ int fd_ocrplan_sliced_arrays(fd_ocrplan_t p, const uint8_t **chunk_role_dev, con
     return 0;
 }
 
-int fd_ocrplan_sliced_tables(fd_ocrplan_t p, const int32_t *rmap_dev, const int32_t *cmap_dev, int ac, const int32_t *rowptr_dev,
-                             const int32_t *colidx_dev, const int32_t *acc_by_node_dev, const int32_t *acc_by_pos_dev,
+int fd_ocrplan_sliced_tables(fd_ocrplan_t p, const int32_t *rmap_dev, const int32_t *cmap_dev, int ac, const fd_nnz_t *rowptr_dev,
+                             const int32_t *colidx_dev, const fd_nnz_t *acc_by_node_dev, const fd_nnz_t *acc_by_pos_dev,
                              const int32_t *row_lgmap_dev, const int32_t *col_lgmap_dev, int kbytes, uint16_t *slot_out_dev,
                              uint16_t *rowlen_out_dev, void *kk_out_dev, int rbs, int cbs, uint8_t *rowmask_out_dev,
                              uint64_t *colmask_out_dev, fd_stream_t s_) {
@@ -1450,7 +1429,7 @@ int fd_gather_rows(const int32_t *src_dev, int arity, const int32_t *idx_dev, in
     return 0;
 }
 
-int fd_csr_elem_row_offsets(const int32_t *rowptr, const int32_t *colidx, const int32_t *rmap, const int32_t *cmap,
+int fd_csr_elem_row_offsets(const fd_nnz_t *rowptr, const int32_t *colidx, const int32_t *rmap, const int32_t *cmap,
                             int32_t nent, int ar, int ac, int kbytes, void *out, fd_stream_t s_) {
     if (nent <= 0) return 0;
     hipStream_t s = fd::st(s_);

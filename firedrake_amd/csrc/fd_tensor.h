@@ -203,7 +203,7 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
                                               const double *__restrict__ coords, const double *const (&cf)[NC > 0 ? NC : 1],
                                               const double *const (&c1)[N1 > 0 ? N1 : 1],
                                               const int *__restrict__ map_qk,
-                                              const int *__restrict__ map_q1, const int *__restrict__ rowptr,
+                                              const int *__restrict__ map_q1, const fd_nnz_t *__restrict__ rowptr,
                                               const unsigned short *__restrict__ offtab, const int *__restrict__ rlg,
                                               const int *__restrict__ clg, const double *__restrict__ tables, WF weights) {
     constexpr int ND = K1 * K1 * K1, NQ = Q1 * Q1 * Q1, NT = tp_tiles(K1), WPB = tp_waves(NT), WGC = NT / WPB, NTAB = Q1 * K1;
@@ -369,12 +369,12 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
 #pragma unroll
         for (int g = 0; g < 4; ++g) rok[g] = rok[g] && rl[g] >= 0;
     }
-    int rp[4], rlen[4];
+    fd_nnz_t rp[4]; int rlen[4];
     unsigned short pos[4][NT];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         rp[g] = rowptr[rn[g]];                             // (unconditional reads of clamped indices: no branch, no wait in between)
-        rlen[g] = D > 1 ? rowptr[rn[g] + 1] - rp[g] : 0;
+        rlen[g] = D > 1 ? (int)(rowptr[rn[g] + 1] - rp[g]) : 0;
         const int i = itile * 16 + kk + 4 * g;
 #pragma unroll
         for (int t = 0; t < NT; ++t) pos[g][t] = tab[(i < ND && t * 16 + r16 < ND) ? i * ND + t * 16 + r16 : 0];

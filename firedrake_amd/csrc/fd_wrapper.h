@@ -22,6 +22,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// row starts of CSR value arrays and of block accumulators (include/fdhip.h: fd_nnz_t; pyop2/datatypes.py:6-10 IntType for nnz
+// beyond 2^31): everything INSIDE a row or a block stays a 32-bit offset
+typedef int64_t fd_nnz_t;
+
 typedef double PetscScalar;
 typedef double PetscReal;
 typedef int PetscInt;
@@ -72,10 +76,10 @@ template <> __device__ __forceinline__ void atomic_max<unsigned long>(unsigned l
 __device__ __forceinline__ int wrap_layer(int a, int nl) { return a % nl; }
 
 // ---- CSR position of (row, col): the per-call row search of MatSetValuesLocal ----
-__device__ __forceinline__ int csr_find(const int *__restrict__ rowptr, const int *__restrict__ colidx, int r, int c) {
-    int lo = rowptr[r], hi = rowptr[r + 1] - 1;
+__device__ __forceinline__ fd_nnz_t csr_find(const fd_nnz_t *__restrict__ rowptr, const int *__restrict__ colidx, int r, int c) {
+    fd_nnz_t lo = rowptr[r], hi = rowptr[r + 1] - 1;
     while (lo <= hi) {
-        int mid = lo + ((hi - lo) >> 1);
+        const fd_nnz_t mid = lo + ((hi - lo) >> 1);
         int v = colidx[mid];
         if (v == c) return mid;
         if (v < c) lo = mid + 1; else hi = mid - 1;

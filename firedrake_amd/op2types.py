@@ -1794,7 +1794,7 @@ class Sparsity:
         _lib.call("fd_csr_from_maps_ex", rset.set.total_size, cset.set.total_size, int(self._has_diagonal), n,
                   rm, cm, nent, ra, ca, nl, ro, co, region, periodic, rq, cq, lay,
                   ctypes.byref(rp), ctypes.byref(ci), ctypes.byref(nnz), None)
-        self._node_rowptr = DeviceBuffer.wrap(rp.value, (rset.set.total_size + 1) * 4)
+        self._node_rowptr = DeviceBuffer.wrap(rp.value, (rset.set.total_size + 1) * _lib.NNZ_BYTES)
         self._node_colidx = DeviceBuffer.wrap(ci.value, max(nnz.value, 1) * 4)
         self._node_nnz = nnz.value
         rbs, cbs = rset.cdim, cset.cdim
@@ -1805,7 +1805,7 @@ class Sparsity:
             _lib.call("fd_csr_expand_blocks", rset.set.total_size, rp.value, ci.value, rbs, cbs,
                       ctypes.byref(rp2), ctypes.byref(ci2), None)
             self._nnz = nnz.value * rbs * cbs
-            self._rowptr = DeviceBuffer.wrap(rp2.value, (rset.set.total_size * rbs + 1) * 4)
+            self._rowptr = DeviceBuffer.wrap(rp2.value, (rset.set.total_size * rbs + 1) * _lib.NNZ_BYTES)
             self._colidx = DeviceBuffer.wrap(ci2.value, max(self._nnz, 1) * 4)
         self._built = True
         self._elem_tables = {}
@@ -1826,7 +1826,7 @@ class Sparsity:
     @property
     def rowptr(self):
         self._build()
-        return self._rowptr.download(np.int32, (self.nrows + 1,))
+        return self._rowptr.download(_lib.NNZ_DTYPE, (self.nrows + 1,))
 
     def _node_rowptr_host(self):
         """Host copy of the node-level row starts (read-only; the pattern of a built Sparsity never changes): the plan builders look
@@ -1834,7 +1834,7 @@ class Sparsity:
         self._build()
         h = self.__dict__.get("_node_rowptr_h")
         if h is None:
-            h = self._node_rowptr.download(np.int32, (self.dsets[0].set.total_size + 1,))
+            h = self._node_rowptr.download(_lib.NNZ_DTYPE, (self.dsets[0].set.total_size + 1,))
             h.setflags(write=False)
             self.__dict__["_node_rowptr_h"] = h
         return h
@@ -1896,6 +1896,9 @@ class Sparsity:
         key = (id(rmap._base()), id(cmap._base()), nlayers)
         t = self._elem_tables.get(key)
         if t is None:
+            if self._node_nnz > 2 ** 31 - 1:
+                raise _lib.FDHipError("the element -> nonzero table of the direct wrapper holds 32-bit places (pattern of 2^31 entries "
+                                      "or more): set configuration['mat_scatter'] = 'search'")
             nent = rmap._base().values_with_halo.shape[0]
             t = DeviceBuffer(nent * max(nlayers, 1) * rmap.arity * cmap.arity * 4)
             ro = co = None
@@ -2142,18 +2145,22 @@ class RowOrder:
         offset of a row, by NODE), gstart[p] = rowptr[plist[p]] (CSR start, by POSITION) -- fd_row_order_tables, on the device (the
         numpy version cost 0.13 s of every first Jacobian call at 10 M rows)."""
         n1 = max(self.npos, 1)
-        self.prowptr, self.nstart, self.gstart = DeviceBuffer((self.npos + 1) * 4), DeviceBuffer(n1 * 4), DeviceBuffer(n1 * 4)
+        nb_ = _lib.NNZ_BYTES
+        self.prowptr, self.nstart, self.gstart = DeviceBuffer((self.npos + 1) * nb_), DeviceBuffer(n1 * nb_), DeviceBuffer(n1 * nb_)
         keep = None
         if rowptr_dev is None:
-            keep = DeviceBuffer.from_numpy(np.ascontiguousarray(node_rowptr_host, dtype=np.int32))
+            keep = DeviceBuffer.from_numpy(np.ascontiguousarray(node_rowptr_host, dtype=_lib.NNZ_DTYPE))
             rowptr_dev = keep.ptr
         _lib.call("fd_row_order_tables", self.npos, self.plist.ptr, rowptr_dev, self.prowptr.ptr, self.nstart.ptr, self.gstart.ptr, None)
-        self.prowptr_host = self.prowptr.download(np.int32, (self.npos + 1,))
+        self.prowptr_host = self.prowptr.download(_lib.NNZ_DTYPE, (self.npos + 1,))
 
     def gpos(self):
         """int32 per accumulator entry (rows in position order, entries in CSR order inside a row): its place in the CSR value
         array -- what the whole-entity "ocrp" flush streams (built on first use)."""
         if getattr(self, "_gpos", None) is None:
+            if int(self.prowptr_host[-1]) > 2 ** 31 - 1:
+                raise _lib.FDHipError("the whole-entity row flush holds 32-bit places: patterns of 2^31 entries and more take the "
+                                      "row-sliced shapes (run-coded flush)")
             self._gpos = DeviceBuffer(max(int(self.prowptr_host[-1]), 1) * 4)
             _lib.call("fd_row_entry_positions", self.npos, self.prowptr.ptr, self.gstart.ptr, self._gpos.ptr, None)
         return self._gpos
@@ -2168,7 +2175,7 @@ class RowOrder:
             nb = len(rb) - 1
             grun = DeviceBuffer(max(int(self.prowptr_host[-1]), 1))
             brun = DeviceBuffer((nb + 1) * 4)
-            rdelta = DeviceBuffer(max(self.npos, 1) * 4)
+            rdelta = DeviceBuffer(max(self.npos, 1) * _lib.NNZ_BYTES)
             rblk = DeviceBuffer.from_numpy(rb)
             nruns, mx = ctypes.c_int32(), ctypes.c_int32()
             _lib.call("fd_ocr_row_runs", self.npos, self.prowptr.ptr, self.gstart.ptr, rblk.ptr, nb, grun.ptr, brun.ptr, rdelta.ptr,

@@ -1136,8 +1136,8 @@ class Parloop:
         base, runs = ("ocrsp" if row_order is not None else "ocrs"), None
         if row_order is not None and B == 1 and configuration["ocrs_run_flush"]:
             runs = row_order.runs(op.row_blocks)
-            if runs[3] <= 256 and lds + 1024 <= limit:
-                base, lds = "ocrspr", lds + 1024
+            if runs[3] <= 256 and lds + 256 * _lib.NNZ_BYTES <= limit:         # (the block's run displacements, fd_nnz_t each)
+                base, lds = "ocrspr", lds + 256 * _lib.NNZ_BYTES
             else:
                 runs = None
         rec = None

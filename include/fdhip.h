@@ -27,6 +27,11 @@
 extern "C" {
 #endif
 
+/* Row starts of CSR value arrays (rowptr, node_rowptr, gstart) and of the owner-computes-rows accumulators (prowptr, nstart, the
+ * displacements rdelta): PETSc's IntType for nnz (pyop2/datatypes.py:6-10; the 64-bit-index CI variant, .github/workflows/
+ * core.yml:276).  64 bits, so that a pattern may hold more than 2^31 entries (BASELINE configs[4] on one GPU: 2.3e9; Q4 at
+ * n = 64: 3.7e9).  Column indices, row / node numbers and every offset inside a row or a block stay int32_t. */
+typedef int64_t fd_nnz_t;
 typedef void *fd_stream_t;
 typedef struct fd_kernel_s *fd_kernel_t;
 typedef struct fd_plan_s *fd_plan_t;
@@ -153,7 +158,7 @@ int fd_plan_free(fd_plan_t p);
  *   lrp                local row pointers, block b at lrp[blkoff_r[b] + b .. + ndr_b]
  *   kidx               per (entity,i,j): offset inside its local row (uint8 if kbytes==1 else uint16) */
 typedef struct fd_matplan_s *fd_matplan_t;
-int fd_matplan_create(fd_plan_t row_plan, fd_plan_t col_plan, const int32_t *node_rowptr_dev,
+int fd_matplan_create(fd_plan_t row_plan, fd_plan_t col_plan, const fd_nnz_t *node_rowptr_dev,
                       const int32_t *node_colidx_dev, int64_t nnz, fd_stream_t s, fd_matplan_t *out);
 /* gpos entries that exactly one block touches are stored as ~pos (negative): the wrapper writes them
  * without an atomic.  zero_list = all other CSR positions (shared between blocks, or never touched by
@@ -193,13 +198,13 @@ int fd_ocrplan_create(const int32_t *rmap_dev, int rarity, int32_t start, int32_
  * accumulator starts by node of a row order (by_offset 1: ownership = offset inside the block's range; nodes >= npos are not
  * rows); start_by_pos[rblk[b]] = start of block b.  One table per pair of lgmaps (the reference swaps them per assemble). */
 int fd_ocr_node_words(const int32_t *blkoff_dev, const int32_t *list_dev, int32_t nblocks, const int32_t *rblk_dev,
-                      const int32_t *base_by_node_dev, const int32_t *start_by_pos_dev, int by_offset, int32_t npos,
+                      const fd_nnz_t *base_by_node_dev, const fd_nnz_t *start_by_pos_dev, int by_offset, int32_t npos,
                       const int32_t *row_lgmap_dev, const int32_t *col_lgmap_dev, uint32_t *out_dev, fd_stream_t s);
 /* words[i] |= (position of the diagonal entry inside the CSR row of node list[i]) << 20 (bits 20..27): with one map on both
  * sides of the Mat the place of entry (i, i) of an element matrix belongs to the row NODE, so the per-instance records below
  * need not carry it (the diagonal is always allocated: pyop2/sparsity.pyx:198-203).  Fails when an owned row has no diagonal
  * entry among its first 256 columns. */
-int fd_ocr_node_diag(const int32_t *list_dev, int64_t n, int32_t nrows, const int32_t *rowptr_dev, const int32_t *colidx_dev,
+int fd_ocr_node_diag(const int32_t *list_dev, int64_t n, int32_t nrows, const fd_nnz_t *rowptr_dev, const int32_t *colidx_dev,
                      uint32_t *words_dev, fd_stream_t s);
 /* Bit-packed per-instance records of a whole-entity owner-computes-rows loop: `words` 32-bit words per instance hold, back to
  * back from bit 0, the local-map rows of the nmaps staged maps (uint16 tables of the node plans, arities[m] entries of
@@ -217,7 +222,7 @@ int fd_ocr_pack_records(int64_t ninst, int nmaps, const uint16_t *const *lmaps_d
  * the caller's numbering; a block's rows are then a set of CSR rows, flushed row by row.  The tables are borrowed. */
 int fd_ocrplan_create_ordered(const int32_t *rmap_dev, int rarity, int32_t start, int32_t end,
                               const int32_t *pos_block_starts_host, int32_t nblocks, int interleave,
-                              const int32_t *pinv_dev, int32_t npos, const int32_t *prowptr_dev,
+                              const int32_t *pinv_dev, int32_t npos, const fd_nnz_t *prowptr_dev,
                               fd_stream_t s, fd_ocrplan_t *out);
 int fd_ocrplan_info(fd_ocrplan_t p, int64_t *ninst, int32_t *max_inst_per_block);
 int fd_ocrplan_arrays(fd_ocrplan_t p, const int32_t **inst_off_dev, const int32_t **inst_off_host,
@@ -240,15 +245,15 @@ int fd_ocrplan_create_sliced(const int32_t *rmap_dev, int rarity, int32_t start,
                              * in the order j -> (j*P) mod count, P = smallest integer >= interleave coprime with count */
 int fd_ocrplan_sliced_arrays(fd_ocrplan_t p, const uint8_t **chunk_role_dev, const uint8_t **valid_dev, int64_t *nreal);
 int fd_ocrplan_sliced_tables(fd_ocrplan_t p, const int32_t *rmap_dev, const int32_t *cmap_dev, int carity,
-                             const int32_t *rowptr_dev, const int32_t *colidx_dev, const int32_t *acc_by_node_dev,
-                             const int32_t *acc_by_pos_dev, const int32_t *row_lgmap_dev, const int32_t *col_lgmap_dev,
+                             const fd_nnz_t *rowptr_dev, const int32_t *colidx_dev, const fd_nnz_t *acc_by_node_dev,
+                             const fd_nnz_t *acc_by_pos_dev, const int32_t *row_lgmap_dev, const int32_t *col_lgmap_dev,
                              int kbytes, uint16_t *slot_out_dev, uint16_t *rowlen_out_dev /* nullable: entries of the
                              instance's CSR node row, needed to address vector-valued blocks */, void *kk_out_dev,
                              int rbs, int cbs, uint8_t *rowmask_out_dev, uint64_t *colmask_out_dev /* both nullable; given:
                              the lgmaps are per DOF (node*bs + component; MatSetValuesLocal on dof indices, mat.py:700-716):
                              bit p of rowmask / bit j*cbs+q of colmask = that scalar row / column survives */, fd_stream_t s);
 int fd_gather_rows(const int32_t *src_dev, int arity, const int32_t *idx_dev, int64_t n, int32_t *dst_dev, fd_stream_t s);
-int fd_csr_elem_row_offsets(const int32_t *rowptr_dev, const int32_t *colidx_dev, const int32_t *rmap_dev,
+int fd_csr_elem_row_offsets(const fd_nnz_t *rowptr_dev, const int32_t *colidx_dev, const int32_t *rmap_dev,
                             const int32_t *cmap_dev, int32_t nent, int rarity, int carity, int kbytes,
                             void *out_dev, fd_stream_t s);
 
@@ -265,7 +270,7 @@ int fd_csr_from_maps(int32_t nrow_nodes, int32_t ncol_nodes, int set_diag, int n
                      const int32_t *nent, const int32_t *rarity, const int32_t *carity,
                      const int32_t *nlayers, const int32_t *const *roffsets_host,
                      const int32_t *const *coffsets_host,
-                     int32_t **rowptr_dev, int32_t **colidx_dev, int64_t *nnz, fd_stream_t s);
+                     fd_nnz_t **rowptr_dev, int32_t **colidx_dev, int64_t *nnz, fd_stream_t s);
 /* The same with the rest of fill_with_zeros' extruded cases: `region[k]` is the iteration region of pair k
  * (FD_ON_BOTTOM / FD_ON_TOP / FD_ON_INTERIOR_FACETS / FD_ALL, the values of pyop2's IterationRegion; sparsity.pyx:291-305,
  * 331-346 -- interior facets couple two stacked cells), `periodic[k]` marks periodic extrusion (sparsity.pyx:273, 343-346)
@@ -286,30 +291,30 @@ int fd_csr_from_maps_ex(int32_t nrow_nodes, int32_t ncol_nodes, int set_diag, in
                         const int32_t *const *coffsets_host, const int32_t *region, const int32_t *periodic,
                         const int32_t *const *rquot_host, const int32_t *const *cquot_host,
                         const int32_t *const *layers_dev,
-                        int32_t **rowptr_dev, int32_t **colidx_dev, int64_t *nnz, fd_stream_t s);
+                        fd_nnz_t **rowptr_dev, int32_t **colidx_dev, int64_t *nnz, fd_stream_t s);
 /* node pattern -> scalar (aij) pattern for DataSet dims (rbs, cbs) (mat.py:254-278) */
-int fd_csr_expand_blocks(int32_t nrow_nodes, const int32_t *rowptr_dev, const int32_t *colidx_dev,
-                         int rbs, int cbs, int32_t **rowptr_out, int32_t **colidx_out, fd_stream_t s);
+int fd_csr_expand_blocks(int32_t nrow_nodes, const fd_nnz_t *rowptr_dev, const int32_t *colidx_dev,
+                         int rbs, int cbs, fd_nnz_t **rowptr_out, int32_t **colidx_out, fd_stream_t s);
 /* element -> nonzero table: out[((e*nl+l)*ar+i)*ac+j] = position of (rmap[e][i]+roff[i]*l,
  * cmap[e][j]+coff[j]*l) in the node CSR, or -1 (nlayers = 0: non-extruded, nl = 1).  Replaces the per-call row search inside MatSetValuesLocal
  * (pyop2/codegen/builder.py:573-625). */
-int fd_csr_elem_offsets(const int32_t *rowptr_dev, const int32_t *colidx_dev,
+int fd_csr_elem_offsets(const fd_nnz_t *rowptr_dev, const int32_t *colidx_dev,
                         const int32_t *rmap_dev, const int32_t *cmap_dev,
                         int32_t nent, int rarity, int carity,
                         int nlayers, const int32_t *roffsets_host, const int32_t *coffsets_host,
                         int32_t *out_dev, fd_stream_t s);
 /* Mat.set_local_diagonal_entries (mat.py:896-937) and Mat.zero_rows (mat.py:857-891) */
-int fd_csr_set_diagonal(const int32_t *rowptr_dev, const int32_t *colidx_dev, double *vals_dev,
+int fd_csr_set_diagonal(const fd_nnz_t *rowptr_dev, const int32_t *colidx_dev, double *vals_dev,
                         const int32_t *rows_dev, int32_t nrows_sel, double value, fd_stream_t s);
-int fd_csr_zero_rows(const int32_t *rowptr_dev, const int32_t *colidx_dev, double *vals_dev,
+int fd_csr_zero_rows(const fd_nnz_t *rowptr_dev, const int32_t *colidx_dev, double *vals_dev,
                      const int32_t *rows_dev, int32_t nrows_sel, double value, fd_stream_t s);
 /* y = A x  (parity identity  A*x == action(a, x), tests/firedrake/regression/test_matrix_free.py:97-123) */
-int fd_csr_spmv(int32_t nrows, const int32_t *rowptr_dev, const int32_t *colidx_dev,
+int fd_csr_spmv(int32_t nrows, const fd_nnz_t *rowptr_dev, const int32_t *colidx_dev,
                 const double *vals_dev, const double *x_dev, double *y_dev, fd_stream_t s);
 /* diag[r] = A[r][r] (0 where the pattern has no diagonal entry): MatGetDiagonal, what a Jacobi-preconditioned Krylov solve
  * of the assembled operator needs (the reference's regression tests solve with PETSc: tests/firedrake/regression/
  * test_helmholtz.py:50; here only the parity tests do, tests/test_reference_thresholds.py) */
-int fd_csr_get_diagonal(int32_t nrows, const int32_t *rowptr_dev, const int32_t *colidx_dev,
+int fd_csr_get_diagonal(int32_t nrows, const fd_nnz_t *rowptr_dev, const int32_t *colidx_dev,
                         const double *vals_dev, double *diag_dev, fd_stream_t s);
 
 /* ------------------------------------------------- hand-over to a distributed PETSc matrix (f1)
@@ -323,10 +328,10 @@ int fd_csr_get_diagonal(int32_t nrows, const int32_t *rowptr_dev, const int32_t 
  * place of the suffix entry inside its sorted row.  fd_csr_split_mpiaij builds the two patterns and the ranks once (outputs
  * allocated here, release with fd_free); fd_csr_split_values refreshes the two value arrays after an assembly (o_rank_dev
  * NULL = suffix order). */
-int fd_csr_split_mpiaij(int32_t nrows_owned, const int32_t *rowptr_dev, const int32_t *colidx_dev, int32_t ncols_owned,
+int fd_csr_split_mpiaij(int32_t nrows_owned, const fd_nnz_t *rowptr_dev, const int32_t *colidx_dev, int32_t ncols_owned,
                         const int32_t *col_global_dev, int32_t **d_rowptr_dev, int32_t **d_colidx_dev, int64_t *d_nnz,
                         int32_t **o_rowptr_dev, int32_t **o_colidx_dev, int32_t **o_rank_dev, int64_t *o_nnz, fd_stream_t s);
-int fd_csr_split_values(int32_t nrows_owned, const int32_t *rowptr_dev, const double *vals_dev, const int32_t *d_rowptr_dev,
+int fd_csr_split_values(int32_t nrows_owned, const fd_nnz_t *rowptr_dev, const double *vals_dev, const int32_t *d_rowptr_dev,
                         const int32_t *o_rowptr_dev, const int32_t *o_rank_dev, double *d_vals_dev, double *o_vals_dev, fd_stream_t s);
 
 /* ------------------------------------------------- backend-derived locality orders
@@ -360,17 +365,17 @@ int fd_invert_permutation(const int32_t *plist_dev, int32_t n, int32_t *pinv_dev
 /* The tables of a row order plist (row of every position): prowptr[p] = accumulator start of position p (npos + 1 entries: the
  * running sum of the row lengths in position order), gstart[p] = CSR start of that row, nstart[row] = prowptr[position of row]
  * -- the lookups the "ocrp" / "ocrsp" wrappers and the plan builders need, each a flat array */
-int fd_row_order_tables(int32_t npos, const int32_t *plist_dev, const int32_t *rowptr_dev, int32_t *prowptr_dev, int32_t *nstart_dev,
-                        int32_t *gstart_dev, fd_stream_t s);
+int fd_row_order_tables(int32_t npos, const int32_t *plist_dev, const fd_nnz_t *rowptr_dev, fd_nnz_t *prowptr_dev, fd_nnz_t *nstart_dev,
+                        fd_nnz_t *gstart_dev, fd_stream_t s);
 /* gpos[prowptr[p] + k] = gstart[p] + k for the rows p of a row order (prowptr = accumulator starts by position, gstart = CSR
  * starts by position): the place of every accumulator entry in the CSR value array, streamed by the "ocrp" row flush */
-int fd_row_entry_positions(int32_t npos, const int32_t *prowptr_dev, const int32_t *gstart_dev, int32_t *gpos_dev, fd_stream_t s);
+int fd_row_entry_positions(int32_t npos, const fd_nnz_t *prowptr_dev, const fd_nnz_t *gstart_dev, int32_t *gpos_dev, fd_stream_t s);
 /* The same places run-coded: rows that follow one another in a block of the row order (rblk: nblocks + 1 block starts in row
  * positions) AND in the CSR share one displacement (place - accumulator index).  grun[entry] = run of the entry's row counted
  * from its block's first run (one byte), brun[b] = first run of block b (nblocks + 1), rdelta[run] = displacement (room for
  * npos).  *max_runs_out = most runs in one block: the "ocrspr" flush keeps a block's displacements in LDS and needs <= 256. */
-int fd_ocr_row_runs(int32_t npos, const int32_t *prowptr_dev, const int32_t *gstart_dev, const int32_t *rblk_dev, int32_t nblocks,
-                    uint8_t *grun_dev, int32_t *brun_dev, int32_t *rdelta_dev, int32_t *nruns_out, int32_t *max_runs_out, fd_stream_t s);
+int fd_ocr_row_runs(int32_t npos, const fd_nnz_t *prowptr_dev, const fd_nnz_t *gstart_dev, const int32_t *rblk_dev, int32_t nblocks,
+                    uint8_t *grun_dev, int32_t *brun_dev, fd_nnz_t *rdelta_dev, int32_t *nruns_out, int32_t *max_runs_out, fd_stream_t s);
 
 /* ------------------------------------------------- halo exchange + Global reductions over RCCL
  * firedrake/halo.py:87-172 (PetscSF bcast owner->ghost with MPI.REPLACE, reduce ghost->owner with SUM/MIN/MAX behind

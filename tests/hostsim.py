@@ -199,6 +199,9 @@ def pack_records_ref(lmaps, lbits, kidx, nr, nc, kbits, diag, words, extra=None,
     return out
 
 
+NNZ = np.int64            # include/fdhip.h: fd_nnz_t (row starts of the value array and of the block accumulators)
+
+
 def row_runs_ref(prowptr, gstart, rb):
     """numpy restatement of fd_ocr_row_runs: (grun per entry, brun per block, rdelta per run, most runs in a block)."""
     npos = len(gstart)
@@ -209,7 +212,7 @@ def row_runs_ref(prowptr, gstart, rb):
     runidx = np.cumsum(flag) - 1
     nruns = int(runidx[-1]) + 1 if npos else 0
     brun = np.array([int(runidx[r]) if r < npos else nruns for r in rb], dtype=np.int32)
-    rdelta = np.zeros(max(nruns, 1), dtype=np.int32)
+    rdelta = np.zeros(max(nruns, 1), dtype=NNZ)
     rdelta[runidx[flag == 1]] = disp[flag == 1]
     grun = np.zeros(max(int(prowptr[npos]), 1), dtype=np.uint8)
     for b in range(len(rb) - 1):
@@ -313,7 +316,7 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False,
         elif kind == "ocr_rblk":
             cargs.append(ptr(rb))
         elif kind == "ocr_rowptr":
-            cargs.append(ptr(csr.rowptr))
+            cargs.append(ptr(np.ascontiguousarray(csr.rowptr, dtype=NNZ)))
         elif kind == "ocr_kidx":
             cargs.append(ptr(kidx))
         elif kind == "ocr_maxnnz":
@@ -323,13 +326,13 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False,
         elif kind == "ocr_flags":
             cargs.append(ctypes.c_longlong(1 if zero_pending else 0))
         elif kind == "ocr_prowptr":
-            cargs.append(ptr(prowptr))
+            cargs.append(ptr(np.ascontiguousarray(prowptr, dtype=NNZ)))
         elif kind == "ocr_nstart":
-            ns = np.zeros(max(nrows, 1), dtype=np.int32)
+            ns = np.zeros(max(nrows, 1), dtype=NNZ)
             ns[plist] = prowptr[:-1]
             cargs.append(ptr(ns))
         elif kind == "ocr_gstart":
-            cargs.append(ptr(np.ascontiguousarray(csr.rowptr[plist], dtype=np.int32)))
+            cargs.append(ptr(np.ascontiguousarray(csr.rowptr[plist], dtype=NNZ)))
         elif kind == "ocr_srow":
             # numpy restatement of fd_ocr_node_words: per (block, staged node) 1 + offset of the node's row in the block
             # accumulator (0 = not owned / dropped by the row lgmap), bit 31 = column dropped by the column lgmap
@@ -520,9 +523,9 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None, run_flush=Fals
         elif kind == "ocr_rblk":
             cargs.append(ptr(rb))
         elif kind in ("ocr_rowptr", "ocr_prowptr"):
-            cargs.append(ptr(np.ascontiguousarray(acc, dtype=np.int32)))
+            cargs.append(ptr(np.ascontiguousarray(acc, dtype=NNZ)))
         elif kind == "ocr_gstart":
-            cargs.append(ptr(np.ascontiguousarray(ncsr.rowptr[plist], dtype=np.int32)))
+            cargs.append(ptr(np.ascontiguousarray(ncsr.rowptr[plist], dtype=NNZ)))
         elif kind in ("ocr_grun", "ocr_brun", "ocr_rdelta"):
             cargs.append(ptr(run_tabs[{"ocr_grun": 0, "ocr_brun": 1, "ocr_rdelta": 2}[kind]]))
         elif kind == "plan_copy":
@@ -603,7 +606,9 @@ def run_direct(pl, part=None):
         elif kind == "bstart":
             cargs.append(ctypes.c_void_p(0))
         elif kind == "mat_rowptr":
-            cargs.append(ctypes.c_void_p(outs[desc[1]].rowptr.ctypes.data))
+            rp64 = np.ascontiguousarray(outs[desc[1]].rowptr, dtype=NNZ)
+            keep.append(rp64)
+            cargs.append(ctypes.c_void_p(rp64.ctypes.data))
         elif kind == "mat_colidx":
             cargs.append(ctypes.c_void_p(outs[desc[1]].colidx.ctypes.data))
         elif kind in ("mat_row_lgmap", "mat_col_lgmap"):
@@ -679,7 +684,7 @@ def run_tensor(pl, initial=None):
             cargs.append(ptr(np.asarray(maps[desc[1]].values_with_halo, dtype=np.int32)))
         elif kind == "mat_node_rowptr":
             # node-level row starts: scalar row (node, p) of a (D, D)-blocked Mat starts at node_rowptr[node]*D*D + p*rowlen*D
-            node_rp = np.asarray(csr.rowptr[::vd] // (vd * vd), dtype=np.int32)
+            node_rp = np.asarray(csr.rowptr[::vd] // (vd * vd), dtype=NNZ)
             node_ci = [np.asarray(csr.colidx[csr.rowptr[n * vd]:csr.rowptr[n * vd + 1]][::vd] // vd) for n in range(len(node_rp) - 1)]
             cargs.append(ptr(node_rp))
         elif kind == "tp_offtab":

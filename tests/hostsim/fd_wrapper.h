@@ -21,6 +21,7 @@
 typedef double PetscScalar;
 typedef double PetscReal;
 typedef int PetscInt;
+typedef long long fd_nnz_t;      // firedrake_amd/csrc/fd_wrapper.h (int64_t)
 
 struct fd_sim_dim3 { int x, y, z; };
 static const fd_sim_dim3 threadIdx = {0, 0, 0}, blockIdx = {0, 0, 0}, blockDim = {1, 1, 1}, gridDim = {1, 1, 1};
@@ -33,8 +34,8 @@ template <class T> inline void atomic_max(T *p, T v) { if (v > *p) *p = v; }
 
 inline int wrap_layer(int a, int nl) { return a % nl; }
 
-inline int csr_find(const int *rowptr, const int *colidx, int r, int c) {
-    for (int q = rowptr[r]; q < rowptr[r + 1]; ++q)
+inline fd_nnz_t csr_find(const fd_nnz_t *rowptr, const int *colidx, int r, int c) {
+    for (fd_nnz_t q = rowptr[r]; q < rowptr[r + 1]; ++q)
         if (colidx[q] == c) return q;
     return -1;
 }

@@ -10,6 +10,7 @@
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
+typedef int64_t fd_nnz_t;        // firedrake_amd/csrc/fd_wrapper.h
 #include <math.h>
 #include <barrier>
 #include <functional>
@@ -113,8 +114,8 @@ template <class T> inline void atomic_min(T *p, T v) { fd_sim::cas_update(p, [v]
 template <class T> inline void atomic_max(T *p, T v) { fd_sim::cas_update(p, [v](T o) { return v > o ? v : o; }); }
 inline int wrap_layer(int a, int nl) { return a % nl; }
 
-inline int csr_find(const int *rowptr, const int *colidx, int r, int c) {
-    for (int q = rowptr[r]; q < rowptr[r + 1]; ++q)
+inline fd_nnz_t csr_find(const fd_nnz_t *rowptr, const int *colidx, int r, int c) {
+    for (fd_nnz_t q = rowptr[r]; q < rowptr[r + 1]; ++q)
         if (colidx[q] == c) return q;
     return -1;
 }

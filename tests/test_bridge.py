@@ -6,7 +6,7 @@ import types
 import numpy as np
 import pytest
 
-from firedrake_amd import bridge, op2
+from firedrake_amd import _lib, bridge, op2
 from firedrake_amd.codegen import generate_wrapper
 
 
@@ -206,7 +206,7 @@ def test_c1_residual_and_jacobian_through_func_only(bcs):
     sp._build()
     vals = DeviceBuffer(sp.nz * 8)
     vals.upload(np.full(sp.nz, 7.0))                                   # stale values: Mat.zero() must clear them
-    dm = bridge.DeviceMat(sp._rowptr.ptr, sp._colidx.ptr, vals.ptr, nn, sp.nz)
+    dm = bridge.DeviceMat(sp._rowptr.ptr, sp._colidx.ptr, vals.ptr, nn, sp.nz, rowptr_bytes=_lib.NNZ_BYTES)
     bc = V.boundary_nodes
     lg = np.arange(nn, dtype=np.int32)
     if bcs:
@@ -263,7 +263,7 @@ def test_p2_jacobian_through_func_takes_the_sliced_wrapper():
     sp = op2.Sparsity((V.node_set ** 1, V.node_set ** 1), [(V.cell_node_map, V.cell_node_map, None)])
     sp._build()
     vals = DeviceBuffer(sp.nz * 8)
-    dm = bridge.DeviceMat(sp._rowptr.ptr, sp._colidx.ptr, vals.ptr, nn, sp.nz)
+    dm = bridge.DeviceMat(sp._rowptr.ptr, sp._colidx.ptr, vals.ptr, nn, sp.nz, rowptr_bytes=_lib.NNZ_BYTES)
     csr = oracle.build_sparsity(nn, nn, [(cells, cells)])
     rng = np.random.default_rng(2)
     pairs = []
@@ -498,7 +498,7 @@ def test_q4_jacobian_and_action_through_func(bcs):
     from firedrake_amd.device import DeviceBuffer
     vals = DeviceBuffer(sp.nz * 8)
     vals.upload(np.zeros(sp.nz))
-    dm = bridge.DeviceMat(sp._rowptr.ptr, sp._colidx.ptr, vals.ptr, nn, sp.nz)
+    dm = bridge.DeviceMat(sp._rowptr.ptr, sp._colidx.ptr, vals.ptr, nn, sp.nz, rowptr_bytes=_lib.NNZ_BYTES)
     lay_d, x_d, q4_d, q1_d, y_d, u_d = _dev(np.asarray(m.cell_set.layers_array, dtype=np.int32), np.array(m.coordinates.data_ro),
                                            np.asarray(cm.values_with_halo), np.asarray(xm.values_with_halo), np.zeros(nn), u)
     bridge.register_map(q4_d.ptr, ncol, 125, toset_sizes=(nn,) * 3, values=np.asarray(cm.values_with_halo))
@@ -535,7 +535,9 @@ def test_vector_valued_blocks_through_func():
     sp._build()
     nn, ne = V.node_set.total_size, msh.cell_set.size
     vals = DeviceBuffer(sp.nz * 8)
-    dm = bridge.DeviceMat(sp._node_rowptr.ptr, sp._node_colidx.ptr, vals.ptr, nn, sp._node_nnz, rbs=3, cbs=3)
+    # (a PETSc build with 32-bit PetscInt hands over int32 row starts: DeviceMat widens them once)
+    narrow = DeviceBuffer.from_numpy(np.ascontiguousarray(sp._node_rowptr_host(), dtype=np.int32))
+    dm = bridge.DeviceMat(narrow.ptr, sp._node_colidx.ptr, vals.ptr, nn, sp._node_nnz, rbs=3, cbs=3, rowptr_bytes=4)
     m = MapKernelArg(arity=4)
     gk = GlobalKernel(local_kernel=CStringLocalKernel(code=k.code, name=k.name, accesses=(4, 1), dtypes=(np.float64,) * 2),
                       arguments=[MatKernelArg(dims=((3, 3),), maps=(m, m)), DatKernelArg(dim=(3,), map_=m)])

@@ -65,7 +65,7 @@ def test_plan_and_csr_from_raw_pointers():
     rp, ci, nnz = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64()
     _lib.call("fd_csr_from_maps", nnode, nnode, 1, 1, rm, rm, nent, ar, ar, nl, none, none,
               ctypes.byref(rp), ctypes.byref(ci), ctypes.byref(nnz), None)
-    rowptr = np.empty(nnode + 1, dtype=np.int32)
+    rowptr = np.empty(nnode + 1, dtype=_lib.NNZ_DTYPE)               # fd_nnz_t row starts
     _lib.call("fd_memcpy_d2h", rowptr.ctypes.data, rp, rowptr.nbytes, None)
     pairs = {(int(r), int(c)) for row in m for r in row for c in row} | {(i, i) for i in range(nnode)}
     assert nnz.value == len(pairs) and rowptr[-1] == nnz.value

@@ -71,19 +71,19 @@ def test_row_runs_match_numpy_restatement():
     starts[0] = 0
     pieces = np.split(np.arange(npos), starts[1:])
     plist = np.concatenate([pieces[i] for i in rng.permutation(len(pieces))])
-    rp = np.concatenate([[0], np.cumsum(rowlen)]).astype(np.int32)
-    prowptr = np.concatenate([[0], np.cumsum(rowlen[plist])]).astype(np.int32)
-    gstart = rp[plist].astype(np.int32)
+    rp = np.concatenate([[0], np.cumsum(rowlen)]).astype(_lib.NNZ_DTYPE)             # (row starts: fd_nnz_t)
+    prowptr = np.concatenate([[0], np.cumsum(rowlen[plist])]).astype(_lib.NNZ_DTYPE)
+    gstart = rp[plist].astype(_lib.NNZ_DTYPE)
     rb = np.unique(np.concatenate([np.sort(rng.choice(npos, 60, replace=False)), [0, npos]])).astype(np.int32)
     nb = len(rb) - 1
     dp, dg, dr = DeviceBuffer.from_numpy(prowptr), DeviceBuffer.from_numpy(gstart), DeviceBuffer.from_numpy(rb)
-    grun, brun, rdelta = DeviceBuffer(int(prowptr[-1])), DeviceBuffer((nb + 1) * 4), DeviceBuffer(npos * 4)
+    grun, brun, rdelta = DeviceBuffer(int(prowptr[-1])), DeviceBuffer((nb + 1) * 4), DeviceBuffer(npos * _lib.NNZ_BYTES)
     nruns, mx = ctypes.c_int32(), ctypes.c_int32()
     _lib.call("fd_ocr_row_runs", npos, dp.ptr, dg.ptr, dr.ptr, nb, grun.ptr, brun.ptr, rdelta.ptr, ctypes.byref(nruns), ctypes.byref(mx), None)
     g_ref, b_ref, d_ref, mx_ref = row_runs_ref(prowptr, gstart, rb)
     assert mx.value == mx_ref and nruns.value == b_ref[-1]
     assert np.array_equal(_down(brun.ptr, np.int32, (nb + 1,)), b_ref)
-    assert np.array_equal(_down(rdelta.ptr, np.int32, (nruns.value,)), d_ref[:nruns.value])
+    assert np.array_equal(_down(rdelta.ptr, _lib.NNZ_DTYPE, (nruns.value,)), d_ref[:nruns.value])
     assert np.array_equal(_down(grun.ptr, np.uint8, (int(prowptr[-1]),)), g_ref[:int(prowptr[-1])])
     # the decoded places are exactly the per-entry table of the plain "ocrp" flush
     gpos = np.concatenate([np.arange(gstart[p], gstart[p] + rowlen[plist[p]]) for p in range(npos)])

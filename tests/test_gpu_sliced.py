@@ -282,7 +282,7 @@ def test_per_dof_lgmaps_against_oracle():
     assert_allclose(mat.csr()[2], ref.values, rtol=0, atol=1e-12 * np.abs(ref.values).max())
     op = pl._ocr_geometry()["ocr"]
     tabs = op.tables(rlg, clg, pl._lgmap, per_dof=True)
-    nrp = np.asarray(sp._node_rowptr.download(np.int32, (nn + 1,)))
+    nrp = np.asarray(sp._node_rowptr_host())
     nci = np.asarray(sp._node_colidx.download(np.int32, (sp._node_nnz,)))
     res = ocrs_plan_ref(np.asarray(cm.values_with_halo), np.asarray(cm.values_with_halo), 0, mesh.cell_set.size, op.row_blocks, nrp, nci, nrp, nrp,
                         rlg=rlg, clg=clg, interleave=configuration["ocrs_interleave"], per_dof=(3, 3))
