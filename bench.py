@@ -955,12 +955,7 @@ def main():
         # BASELINE configs[4] as written: ONE cube, split over the ranks -> strong scaling
         n = args.n or 215
         degree = args.degree or 2
-        est_nnz = (degree * n + 1) ** 3 / world * (29 if degree == 2 else 15)
-        if est_nnz > 2.0e9:
-            # the CSR index type is PETSc's default 32-bit IntType (pyop2/datatypes.py:6-10): the whole 80 M-DoF CG2 cube holds
-            # ~2.3e9 nonzeros -- it is a multi-GPU configuration by construction
-            raise SystemExit(f"bench.py: --workload c5 with n={n}, CG{degree} on {world} GPU(s) needs ~{est_nnz:.2e} nonzeros per rank, beyond "
-                             f"the 32-bit CSR index range; run it with --gpus >= 2 (or a smaller --n)")
+        # (the whole 80 M-DoF CG2 cube holds ~2.3e9 nonzeros: row starts are 64-bit, include/fdhip.h fd_nnz_t, so N = 1 anchors the curve)
         out = poisson_line(args, ctx, degree, (n, n, n), "strong", "BASELINE.json configs[4]" + ("" if n == 215 and degree == 2 else ", reduced"),
                            args.numbering, "", False)
     else:
@@ -1030,6 +1025,11 @@ def main():
                                                              "one of the 8 partitions of BASELINE.json configs[4]", "lexicographic", "", False,
                                                              cpu=cs, cpu_reps=1))
         guarded("secondary_c1", lambda: measure_c1(200, 3, with_cpu=cs))
+        # BASELINE configs[4] as written -- the whole 215^3 CG2 cube, 2.29e9 nonzeros -- on this one device: the N = 1 anchor of the
+        # strong-scaling curve the N > 1 lines append as "strong_c5" (row starts are 64-bit, include/fdhip.h fd_nnz_t)
+        n5 = args.n5 or 215
+        guarded("strong_c5", lambda: poisson_line(args, ctx, 2, (n5, n5, n5), "strong",
+                                                  "BASELINE.json configs[4]" + ("" if n5 == 215 else ", reduced"), args.numbering, "", False))
     if rank == 0 and world == 1 and args.traffic == "auto" and args.workload == "c2":
         # HBM bytes per launch of every kernel in the line, from ONE pair of rocprofv3 PMC passes of this command (FETCH_SIZE,
         # WRITE_SIZE) run as child processes now that nothing is being timed
