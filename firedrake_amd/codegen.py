@@ -247,14 +247,15 @@ def staged_eligible(gk: GlobalKernel, mats_on_virtual: bool = False, need_indire
     plan is then built on a DERIVED map over the virtual iteration space -- the map rows of the subset's entities, resp.
     one row ``map + offset*layer`` per (column, layer) cell (builder.py:94-124 folded into the table once) -- so the kernel
     itself addresses nothing but local indices; only direct arguments need the base entity.  Restrictions: Dat-only
-    loops, no periodic wrap, regions ALL / ON_BOTTOM / ON_TOP (constant or variable layers), and no direct Dat written on an
+    loops, regions ALL / ON_BOTTOM / ON_TOP (constant, variable or periodic layers), and no direct Dat written on an
     extruded set (all layers of a column share its row: parloop.py:494-497)."""
     if gk._extruded or gk._subset:
         if any(isinstance(a, MatKernelArg) for a in gk.arguments) and not mats_on_virtual:
             return False          # (matrix loops over virtual spaces: row-sliced owner-computes-rows only, sliced_eligible)
         if gk._extruded:
-            if gk._extruded_periodic or gk._iteration_region == ON_INTERIOR_FACETS:
-                return False          # (variable layers qualify: the derived map and the cell tables are ragged, set.py:326-337)
+            if gk._iteration_region == ON_INTERIOR_FACETS:
+                return False          # (variable layers qualify: the derived map and the cell tables are ragged, set.py:326-337;
+                                      #  periodic columns too: the wrap of builder.py:101-123 is folded into the derived map's rows)
             if any(isinstance(a, DatKernelArg) and not a.is_indirect and la.access != READ
                    for a, la in zip(gk.arguments, gk.local_kernel.arguments)):
                 return False

@@ -619,7 +619,8 @@ class Parloop:
                 return (rows[v.col] + off[None, :] * rel[:, None]).astype(rows.dtype)
             return m.derived(key, build_var)
         bottom = int(it.layers_array[0][0]) if self.global_kernel._extruded else 0
-        key = ("virtual", None if sub is None else id(it), nlit, llo)
+        periodic = bool(self.global_kernel._extruded and self.global_kernel._extruded_periodic)
+        key = ("virtual", None if sub is None else id(it), nlit, llo, periodic)
 
         def build():
             rows = np.asarray(m.values_with_halo)
@@ -628,7 +629,15 @@ class Parloop:
             if self.global_kernel._extruded:
                 off = np.asarray(m.offset, dtype=np.int64)
                 lay = np.arange(llo - bottom, llo - bottom + nlit, dtype=np.int64)
-                rows = (rows[:, None, :] + off[None, None, :] * lay[None, :, None]).reshape(-1, m.arity)
+                if periodic:
+                    # builder.py:101-123: the layer offset wraps around the column's nl cell layers -- entry i of layer l sits
+                    # offset_i * ((l + quotient_i) mod nl - quotient_i mod nl) above its bottom value (quotient 0 without one)
+                    nl = int(it.layers_array[0][1]) - 1 - bottom
+                    quot = np.zeros(m.arity, dtype=np.int64) if m.offset_quotient is None else np.asarray(m.offset_quotient, dtype=np.int64)
+                    rel = (lay[:, None] + quot[None, :]) % nl - (quot % nl)[None, :]
+                    rows = (rows[:, None, :] + off[None, None, :] * rel[None, :, :]).reshape(-1, m.arity)
+                else:
+                    rows = (rows[:, None, :] + off[None, None, :] * lay[None, :, None]).reshape(-1, m.arity)
             return rows
         return m.derived(key, build)
 

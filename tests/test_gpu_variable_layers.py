@@ -84,3 +84,43 @@ static void prismv(double *A, const double *x, const double *w, int layer)
     rp, ci, v = mat.csr()
     assert np.array_equal(rp, ref.rowptr) and np.array_equal(ci, ref.colidx)
     assert np.abs(v - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
+
+
+@pytest.mark.parametrize("mode", ["auto", "direct"])
+@pytest.mark.parametrize("region", [None, op2.ON_TOP])
+def test_periodic_columns_through_the_fast_shapes(mode, region, monkeypatch):
+    """Periodic extrusion (builder.py:101-123): the wrap folded into the derived map of the (column, layer) cells -- staged Dat loop and
+    owner-computes-rows Mat loop -- and through the direct wrapper, against the oracle."""
+    from mixed_cases import periodic_column_mesh
+    monkeypatch.setitem(configuration, "mode", mode)
+    rng = np.random.default_rng(31)
+    base, ext, nodes, cm = periodic_column_mesh(rng, nbase=2500, ncl=6, nv=900)
+    x = op2.Dat(nodes ** 2, rng.standard_normal((nodes.size, 2)))
+    w = op2.Dat(base, rng.standard_normal(base.size))
+    out = op2.Dat(nodes)
+    k = op2.Kernel("static void kpw(double *o, const double *x, const double *w, int layer) { for (int i = 0; i < 6; ++i) "
+                   "o[i] += (1 + layer) * w[0] * ((i+1)*x[2*i] + 0.5*x[2*i+1]); }", "kpw")
+    kw = dict(iteration_region=region, pass_layer_arg=True)
+    args = (out(op2.INC, cm), x(op2.READ, cm), w(op2.READ))
+    pl = op2.LegacyParloop(k, ext, *args, **kw)
+    for _ in range(2):
+        out.zero()
+        pl()
+    assert pl._prepare()["cw"].src.mode.startswith("staged" if mode == "auto" else "direct")
+    got = np.array(out.data_ro)
+    out.zero()
+    ref = oracle_run(k, ext, *args, **kw)[0]
+    assert np.abs(ref).max() > 0 and np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(cm, cm, [region] if region is not None else None)]))
+    km = op2.Kernel("static void kpm2(double *A, const double *x, const double *w) { for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) "
+                    "A[i*6+j] += w[0]*x[2*i]*x[2*j+1] + (i == j); }", "kpm2")
+    margs = (mat(op2.INC, (cm, cm)), x(op2.READ, cm), w(op2.READ))
+    plm = op2.LegacyParloop(km, ext, *margs, iteration_region=region)
+    for _ in range(2):
+        mat.zero()
+        plm()
+    assert plm._prepare()["cw"].src.mode.startswith("ocr" if mode == "auto" else "direct")
+    mref = oracle_run(km, ext, *margs, iteration_region=region)[0]
+    rp, ci, v = mat.csr()
+    assert np.array_equal(rp, mref.rowptr) and np.array_equal(ci, mref.colidx)
+    assert np.abs(v - mref.values).max() <= 1e-12 * np.abs(mref.values).max()

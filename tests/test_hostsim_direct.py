@@ -993,3 +993,50 @@ static void rdat{seed}(double *o1, double *o2, const double *i1, const double *i
         got = run()
         for q in (0, 1, 5):
             assert np.abs(np.asarray(got[q]).reshape(-1) - np.asarray(ref[q]).reshape(-1)).max() <= tol(ref[q]), (seed, q)
+
+
+@pytest.mark.parametrize("region", [None, op2.ON_BOTTOM, op2.ON_TOP])
+@pytest.mark.parametrize("quotient", [True, False])
+def test_periodic_columns_through_the_staged_and_owner_computes_rows_wrappers_on_host(region, quotient):
+    """Periodic extrusion (builder.py:101-123: the layer offset wraps around the column) through the fast shapes: the wrap is
+    folded into the rows of the derived map over the (column, layer) cells, so the staged wrapper (Dat loop, with the layer
+    argument and a direct READ argument) and both owner-computes-rows wrappers (Mat loop) run it unchanged.  With the quotient
+    table of a vertex-based space (the top cell's upper vertices are the column's level-0 vertices) and without one (a DG-like
+    space: every entry wraps with the layer), against the oracle."""
+    from firedrake_amd.codegen import select_mode
+    from hostsim import run_ocr, run_ocrs, run_staged
+    rng = np.random.default_rng(31)
+    ncl = 5
+    if quotient:
+        base, ext, nodes, cm = periodic_column_mesh(rng, nbase=40, ncl=ncl, nv=23)
+        ar = 6
+    else:
+        base = op2.Set(40)
+        ext = op2.ExtrudedSet(base, layers=ncl + 1, extruded_periodic=True)
+        nodes = op2.Set(47 * ncl)
+        pick = np.array([rng.choice(47, 3, replace=False) for _ in range(40)])
+        cm = op2.Map(ext, nodes, 3, (pick * ncl).astype(np.int32), offset=[1, 2, 1])
+        ar = 3
+    x = op2.Dat(nodes ** 2, rng.standard_normal((nodes.size, 2)))
+    w = op2.Dat(base, rng.standard_normal(base.size))
+    out = op2.Dat(nodes)
+    k = op2.Kernel("static void kpw(double *o, const double *x, const double *w, int layer) { for (int i = 0; i < %d; ++i) "
+                   "o[i] += (1 + layer) * w[0] * ((i+1)*x[2*i] + 0.5*x[2*i+1]); }" % ar, "kpw")
+    kw = dict(iteration_region=region, pass_layer_arg=True)
+    args = (out(op2.INC, cm), x(op2.READ, cm), w(op2.READ))
+    pl = op2.LegacyParloop(k, ext, *args, **kw)
+    assert select_mode(pl.global_kernel) == "staged"
+    ref = oracle_run(k, ext, *args, **kw)[0]
+    for epb in (64, 300):
+        got = run_staged(pl, epb=epb)[0]
+        assert np.abs(ref).max() > 0 and np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(cm, cm, [region] if region is not None else None)]))
+    km = op2.Kernel("static void kpm2(double *A, const double *x, const double *w) { for (int i = 0; i < %d; ++i) for (int j = 0; j < %d; ++j) "
+                    "A[i*%d+j] += w[0]*x[2*i]*x[2*j+1] + (i == j); }" % (ar, ar, ar), "kpm2")
+    margs = (mat(op2.INC, (cm, cm)), x(op2.READ, cm), w(op2.READ))
+    plm = op2.LegacyParloop(km, ext, *margs, iteration_region=region)
+    assert select_mode(plm.global_kernel).startswith("ocr")
+    mref = oracle_run(km, ext, *margs, iteration_region=region)[0]
+    for got in (run_ocr(plm, rows_per_block=17), run_ocrs(plm, nnz_per_block=200), run_ocrs(plm, nnz_per_block=200, records=True)):
+        assert np.array_equal(got.rowptr, mref.rowptr) and np.array_equal(got.colidx, mref.colidx)
+        assert np.abs(got.values - mref.values).max() <= 1e-12 * np.abs(mref.values).max()
