@@ -47,6 +47,13 @@ CTYPE = {np.dtype("float64"): "double", np.dtype("float32"): "float", np.dtype("
 STAGEABLE_INC = {np.dtype("float64"), np.dtype("float32"), np.dtype("int32"), np.dtype("uint32")}
 
 
+def stages_in_lds(access, dtype) -> bool:
+    """An indirect Dat argument the staged wrapper keeps in LDS: READ rows are gathered once per block, INC rows reduced there.
+    WRITE / RW / MIN / MAX (and INC of a type without an LDS atomic) go straight to global memory from the lane, as in the
+    direct wrapper -- beside the staged arguments of the same loop."""
+    return access == READ or (access == INC and np.dtype(dtype) in STAGEABLE_INC)
+
+
 @dataclass
 class WrapperSource:
     source: str
@@ -264,14 +271,16 @@ def staged_eligible(gk: GlobalKernel, mats_on_virtual: bool = False, need_indire
         if isinstance(a, MatKernelArg) and any(isinstance(m, PermutedMapKernelArg) for m in a.maps):
             return False          # matrix plans / row-offset tables are built on the base maps
         if isinstance(a, DatKernelArg) and a.is_indirect:
-            n_ind += 1
             if a.index is not None:
                 return False
-            if la.access == READ:
+            if stages_in_lds(la.access, la.dtype):
+                n_ind += 1
                 continue
-            if la.access == INC and la.dtype in STAGEABLE_INC:
-                continue
-            return False
+            # WRITE / RW / MIN / MAX through a map (an interpolation's output, a limiter's bounds): the lane reads and writes global
+            # memory itself while the READ / INC arguments of the loop are staged -- on plain sets and subsets (an extruded loop
+            # addresses such an argument through the layer arithmetic of the direct wrapper), and not in matrix loops
+            if gk._extruded or any(isinstance(b, MatKernelArg) for b in gk.arguments):
+                return False
     return n_ind > 0 or not need_indirect_dat
 
 
@@ -481,7 +490,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                                          and info["ar"] * info["ac"] <= configuration["ocr_sliced_max_entries"])
     if staged:
         for info in infos:
-            if info["kind"] == "dat" and "m" in info and info["m"] not in staged_maps:
+            if info["kind"] == "dat" and "m" in info and stages_in_lds(info["acc"], info["dtype"]) and info["m"] not in staged_maps:
                 staged_maps.append(info["m"])
             if info["kind"] == "mat" and (mat_staged[info["k"]] or ocr):
                 for mi in (info["rm"], info["cm"]):
@@ -625,7 +634,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             perm, off = info["perm"], info["off"]
             size = nf * ar * c
             pack.append(f"{ct} t{k}[{size}];")
-            if staged:
+            if staged and stages_in_lds(acc, info["dtype"]):
                 lds_items.append(("dat", mi, c, info["dtype"].itemsize, acc != READ))
                 lds_decl.append(f"{ct} *s{k} = ({ct} *)(fd_lds + fd_off); fd_off += (((size_t)p{mi}_maxnd*{c}*sizeof({ct})) + 15) & ~(size_t)15;")
                 if acc == READ:

@@ -12,7 +12,8 @@ TSFC/FInAT cannot run here, so this module restates that kernel for expressions 
 target node k it computes the physical point ``X = sum_v coords[v] * N_v(xi_k)`` (``N`` = coordinate-element basis
 tabulated at the node's reference point, a static table like TSFC's), the coefficient values
 ``w<j> = sum_i w_j[i] * P^j_i(xi_k)`` and assigns ``A[k] = expr(X, w0, ..., c0, ...)``.  The parloop then runs through
-the same wrapper generator as every other loop (indirect WRITE: direct wrapper; a node shared by several cells is
+the same wrapper generator as every other loop (indirect WRITE beside staged READ arguments since round 5: the coordinates and
+coefficients are gathered through LDS, the lane writes the target in global memory; a node shared by several cells is
 written with the same value by each of them, exactly as in the reference's sequential loop).  Keeping these loops on
 the device means initial conditions and coefficient updates never round-trip through the host between assemblies.
 """

@@ -1,0 +1,41 @@
+"""GPU: WRITE / MIN / MAX through a map in loops whose READ arguments are staged (builder.py:405-429: the DatPack of every access
+mode): the backend-picked staged wrapper -- READ rows through LDS, the lane addressing the WRITE / MIN / MAX argument in global
+memory -- and the direct wrapper, against the oracle."""
+import numpy as np
+import pytest
+
+from firedrake_amd import op2
+from firedrake_amd.configuration import configuration
+from helpers import oracle_run
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("mode", ["auto", "direct"])
+@pytest.mark.parametrize("subset", [False, True])
+def test_write_min_max_through_maps(mode, subset, monkeypatch):
+    monkeypatch.setitem(configuration, "mode", mode)
+    rng = np.random.default_rng(41)
+    nc, nn = 60000, 21000
+    cells, nodes = op2.Set(nc), op2.Set(nn)
+    cm = op2.Map(cells, nodes, 3, np.array([rng.choice(nn, 3, replace=False) for _ in range(nc)], dtype=np.int32))
+    x = op2.Dat(nodes ** 2, rng.standard_normal((nn, 2)))
+    cv = op2.Dat(cells, rng.standard_normal(nc))
+    it = op2.Subset(cells, rng.choice(nc, 45000, replace=False)) if subset else cells
+    out = op2.Dat(nodes, np.full(nn, -7.0))
+    kw = op2.Kernel("static void interp(double *o, const double *x) { for (int i = 0; i < 3; ++i) o[i] = 2.0*x[2*i] - x[2*i+1]*x[2*i+1]; }", "interp")
+    ref = oracle_run(kw, it, out(op2.WRITE, cm), x(op2.READ, cm))[0]
+    pl = op2.LegacyParloop(kw, it, out(op2.WRITE, cm), x(op2.READ, cm))
+    pl()
+    assert pl._prepare()["cw"].src.mode.startswith("staged" if mode == "auto" else "direct")
+    assert np.allclose(out.data_ro, ref, rtol=1e-14, atol=0) and (ref != -7.0).sum() > 1000
+    lo, hi = op2.Dat(nodes, np.full(nn, 1e30)), op2.Dat(nodes, np.full(nn, -1e30))
+    km = op2.Kernel("static void bounds(double *lo, double *hi, const double *c, const double *x) { for (int i = 0; i < 3; ++i) { "
+                    "const double v = c[0] + 0.1*x[2*i]; if (v < lo[i]) lo[i] = v; if (v > hi[i]) hi[i] = v; } }", "bounds")
+    args = (lo(op2.MIN, cm), hi(op2.MAX, cm), cv(op2.READ), x(op2.READ, cm))
+    refs = oracle_run(km, it, *args)
+    plm = op2.LegacyParloop(km, it, *args)
+    plm()
+    assert plm._prepare()["cw"].src.mode.startswith("staged" if mode == "auto" else "direct")
+    assert np.allclose(lo.data_ro, refs[0], rtol=1e-14, atol=0) and np.allclose(hi.data_ro, refs[1], rtol=1e-14, atol=0)
+    assert (refs[0] < 1e29).sum() > 1000

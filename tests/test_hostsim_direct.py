@@ -1040,3 +1040,37 @@ def test_periodic_columns_through_the_staged_and_owner_computes_rows_wrappers_on
     for got in (run_ocr(plm, rows_per_block=17), run_ocrs(plm, nnz_per_block=200), run_ocrs(plm, nnz_per_block=200, records=True)):
         assert np.array_equal(got.rowptr, mref.rowptr) and np.array_equal(got.colidx, mref.colidx)
         assert np.abs(got.values - mref.values).max() <= 1e-12 * np.abs(mref.values).max()
+
+
+@pytest.mark.parametrize("subset", [False, True])
+def test_write_min_max_through_maps_beside_staged_arguments_on_host(subset):
+    """WRITE / MIN / MAX through a map in a loop whose READ arguments are staged: an interpolation writes its target through the
+    cell-node map (every cell touching a node writes the same value: pyop2 WRITE semantics leave the winner open, builder.py:405-429),
+    a limiter takes the minimum / maximum of cell values into its vertices.  The staged wrapper gathers the READ rows into LDS and lets
+    the lane address the WRITE / MIN / MAX arguments in global memory as the direct wrapper does."""
+    from firedrake_amd.codegen import select_mode
+    from hostsim import run_staged
+    rng = np.random.default_rng(41)
+    nc, nn = 700, 260
+    cells, nodes = op2.Set(nc), op2.Set(nn)
+    cm = op2.Map(cells, nodes, 3, np.array([rng.choice(nn, 3, replace=False) for _ in range(nc)], dtype=np.int32))
+    x = op2.Dat(nodes ** 2, rng.standard_normal((nn, 2)))
+    cv = op2.Dat(cells, rng.standard_normal(nc))
+    it = op2.Subset(cells, rng.choice(nc, 500, replace=False)) if subset else cells
+    out = op2.Dat(nodes, np.full(nn, -7.0))
+    kw = op2.Kernel("static void interp(double *o, const double *x) { for (int i = 0; i < 3; ++i) o[i] = 2.0*x[2*i] - x[2*i+1]*x[2*i+1]; }", "interp")
+    pl = op2.LegacyParloop(kw, it, out(op2.WRITE, cm), x(op2.READ, cm))
+    assert select_mode(pl.global_kernel) == "staged"
+    got = run_staged(pl, epb=300)[0]
+    ref = oracle_run(kw, it, out(op2.WRITE, cm), x(op2.READ, cm))[0]
+    assert np.allclose(got, ref, rtol=1e-14, atol=0) and (ref != -7.0).sum() > 100
+    lo, hi = op2.Dat(nodes, np.full(nn, 1e30)), op2.Dat(nodes, np.full(nn, -1e30))
+    km = op2.Kernel("static void bounds(double *lo, double *hi, const double *c, const double *x) { for (int i = 0; i < 3; ++i) { "
+                    "const double v = c[0] + 0.1*x[2*i]; if (v < lo[i]) lo[i] = v; if (v > hi[i]) hi[i] = v; } }", "bounds")
+    args = (lo(op2.MIN, cm), hi(op2.MAX, cm), cv(op2.READ), x(op2.READ, cm))
+    plm = op2.LegacyParloop(km, it, *args)
+    assert select_mode(plm.global_kernel) == "staged"
+    res = run_staged(plm, epb=200)
+    refs = oracle_run(km, it, *args)
+    # (to rounding: the oracle's compiler contracts c + 0.1 x into an FMA, the host-sim's does not)
+    assert np.allclose(res[0], refs[0], rtol=1e-14, atol=0) and np.allclose(res[1], refs[1], rtol=1e-14, atol=0) and (refs[0] < 1e29).sum() > 100
