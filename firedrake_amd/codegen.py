@@ -260,9 +260,10 @@ def staged_eligible(gk: GlobalKernel, mats_on_virtual: bool = False, need_indire
         if any(isinstance(a, MatKernelArg) for a in gk.arguments) and not mats_on_virtual:
             return False          # (matrix loops over virtual spaces: row-sliced owner-computes-rows only, sliced_eligible)
         if gk._extruded:
-            if gk._iteration_region == ON_INTERIOR_FACETS:
+            if gk._iteration_region == ON_INTERIOR_FACETS and (not gk._constant_layers or any(isinstance(a, MatKernelArg) for a in gk.arguments)):
                 return False          # (variable layers qualify: the derived map and the cell tables are ragged, set.py:326-337;
-                                      #  periodic columns too: the wrap of builder.py:101-123 is folded into the derived map's rows)
+                                      #  periodic columns too: the wrap of builder.py:101-123 is folded into the derived map's rows;
+                                      #  interior facets of constant-layer columns in Dat loops: a derived row holds both stacked cells)
             if any(isinstance(a, DatKernelArg) and not a.is_indirect and la.access != READ
                    for a, la in zip(gk.arguments, gk.local_kernel.arguments)):
                 return False
@@ -647,13 +648,23 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                           f"if (pl{k}) {{ for (int j = 0; j < {c}; ++j) v{k}_U[j] = pl{k}[(size_t)(l0_{mi} + I_U)*{c} + j]; }} "
                           f"else {{ for (int j = 0; j < {c}; ++j) v{k}_U[j] = arg{k}[(size_t)G_U*{c} + j]; }}"],
                          [f"for (int j = 0; j < {c}; ++j) s{k}[{'j*(int)p%d_maxnd + I_U' % mi if soa else 'I_U*%d + j' % c}] = v{k}_U[j];"]))
-                    idx = f"j*(int)p{mi}_maxnd + lm{mi}[{_permi(perm, 'i')}]" if soa else f"lm{mi}[{_permi(perm, 'i')}]*{c} + j"
-                    pack.append(f"for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j) t{k}[i*{c}+j] = s{k}[{idx}];")
+                    if nf == 1:
+                        idx = f"j*(int)p{mi}_maxnd + lm{mi}[{_permi(perm, 'i')}]" if soa else f"lm{mi}[{_permi(perm, 'i')}]*{c} + j"
+                        pack.append(f"for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j) t{k}[i*{c}+j] = s{k}[{idx}];")
+                    else:
+                        li = f"lm{mi}[f*{ar} + {_permi(perm, 'i')}]"
+                        idx = f"j*(int)p{mi}_maxnd + {li}" if soa else f"{li}*{c} + j"
+                        pack.append(f"for (int f = 0; f < {nf}; ++f) for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j) "
+                                    f"t{k}[(f*{ar}+i)*{c}+j] = s{k}[{idx}];")
                 else:  # INC
                     stage.append((mi, f"for (int q = tid; q < nd{mi}*{c}; q += nthr) s{k}[q] = 0;"))
                     pack.append(f"for (int q = 0; q < {size}; ++q) t{k}[q] = 0;")
-                    unpack.append(f"for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j) "
-                                  f"atomicAdd(&s{k}[lm{mi}[{_permi(perm, 'i')}]*{c} + j], t{k}[i*{c}+j]);")
+                    if nf == 1:
+                        unpack.append(f"for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j) "
+                                      f"atomicAdd(&s{k}[lm{mi}[{_permi(perm, 'i')}]*{c} + j], t{k}[i*{c}+j]);")
+                    else:
+                        unpack.append(f"for (int f = 0; f < {nf}; ++f) for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j) "
+                                      f"atomicAdd(&s{k}[lm{mi}[f*{ar} + {_permi(perm, 'i')}]*{c} + j], t{k}[(f*{ar}+i)*{c}+j]);")
                     flush.append((mi, f"for (int q = tid; q < nd{mi}*{c}; q += nthr) {{ const int i = q / {c}; "
                                       f"fdw::atomic_add<{ct}>(&arg{k}[(size_t)p{mi}_list[l0_{mi} + i]*{c} + (q - i*{c})], "
                                       f"s{k}[q]); }}"))
@@ -887,7 +898,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         # entity's local kernel runs, so their HBM latency hides under ~10^2 fp64 instructions
         idx_loads = []      # (register row, its prefetch twin, name, length, load template: II = iteration index, EE = entity)
         for mi in staged_maps:
-            ar = maps[mi].arity
+            ar = maps[mi].arity * (nf if staged and not ocr else 1)       # (interior facets: the derived row holds both stacked cells)
             idx_loads.append((f"int lm{mi}[{ar}]", f"int nx_lm{mi}[{ar}]", f"lm{mi}", ar,
                               f"fdw::load_lmap<{ar}>(p{mi}_lmap + (size_t)(II - start)*{ar}, DST);"))
         for info in infos:
@@ -939,7 +950,8 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         if virt:
             if extruded and not varlay:
                 lo, hi = {ALL: ("layers[0]", "layers[1]-1"), ON_BOTTOM: ("layers[0]", "layers[0]+1"),
-                          ON_TOP: ("layers[1]-2", "layers[1]-1")}[region]
+                          ON_TOP: ("layers[1]-2", "layers[1]-1"),
+                          ON_INTERIOR_FACETS: ("layers[0]", "layers[1]-1" if periodic else "layers[1]-2")}[region]
                 src.append(f"  const int fd_llo = {lo}, fd_nlit = ({hi}) - fd_llo;")
         if ocr:
             ent_of = lambda ii: f"inst_ent_[{ii}]"

@@ -1442,7 +1442,9 @@ class Map:
             if not hasattr(self, "_derived"):
                 self._derived = {}
             vals = np.ascontiguousarray(build(), dtype=IntType)
-            d = Map(Set(len(vals), "virtual_" + self.iterset.name), self.toset, self.arity, vals, self.name + "_derived")
+            # (interior facets of an extruded set: a row holds the nodes of BOTH stacked cells, twice the arity)
+            d = Map(Set(len(vals), "virtual_" + self.iterset.name), self.toset, vals.shape[1] if vals.ndim == 2 else self.arity, vals,
+                    self.name + "_derived")
             self._derived[key] = d
         return d
 

@@ -571,7 +571,7 @@ class Parloop:
             return None
         if not gk._extruded:
             return VirtualSpace((1, 0))
-        from .op2types import ON_BOTTOM, ON_TOP
+        from .op2types import ON_BOTTOM, ON_INTERIOR_FACETS, ON_TOP
         reg = gk._iteration_region
         it = self.iterset
         if not gk._constant_layers:
@@ -596,6 +596,8 @@ class Parloop:
             return VirtualSpace((1, bottom))
         if reg == ON_TOP:
             return VirtualSpace((1, top - 2))
+        if reg == ON_INTERIOR_FACETS:                  # one trip per pair of stacked cells (builder.py:806-809; periodic: top/bottom too)
+            return VirtualSpace((top - 1 - bottom if gk._extruded_periodic else max(top - 2 - bottom, 0), bottom))
         return VirtualSpace((top - 1 - bottom, bottom))
 
     def _plan_map(self, m, staged=None):
@@ -620,7 +622,9 @@ class Parloop:
             return m.derived(key, build_var)
         bottom = int(it.layers_array[0][0]) if self.global_kernel._extruded else 0
         periodic = bool(self.global_kernel._extruded and self.global_kernel._extruded_periodic)
-        key = ("virtual", None if sub is None else id(it), nlit, llo, periodic)
+        from .op2types import ON_INTERIOR_FACETS
+        facets = bool(self.global_kernel._extruded and self.global_kernel._iteration_region == ON_INTERIOR_FACETS)
+        key = ("virtual", None if sub is None else id(it), nlit, llo, periodic, facets)
 
         def build():
             rows = np.asarray(m.values_with_halo)
@@ -629,15 +633,19 @@ class Parloop:
             if self.global_kernel._extruded:
                 off = np.asarray(m.offset, dtype=np.int64)
                 lay = np.arange(llo - bottom, llo - bottom + nlit, dtype=np.int64)
-                if periodic:
-                    # builder.py:101-123: the layer offset wraps around the column's nl cell layers -- entry i of layer l sits
-                    # offset_i * ((l + quotient_i) mod nl - quotient_i mod nl) above its bottom value (quotient 0 without one)
-                    nl = int(it.layers_array[0][1]) - 1 - bottom
-                    quot = np.zeros(m.arity, dtype=np.int64) if m.offset_quotient is None else np.asarray(m.offset_quotient, dtype=np.int64)
-                    rel = (lay[:, None] + quot[None, :]) % nl - (quot % nl)[None, :]
-                    rows = (rows[:, None, :] + off[None, None, :] * rel[None, :, :]).reshape(-1, m.arity)
+                def cells(lay_):
+                    if periodic:
+                        # builder.py:101-123: the layer offset wraps around the column's nl cell layers -- entry i of layer l sits
+                        # offset_i * ((l + quotient_i) mod nl - quotient_i mod nl) above its bottom value (quotient 0 without one)
+                        nl = int(it.layers_array[0][1]) - 1 - bottom
+                        quot = np.zeros(m.arity, dtype=np.int64) if m.offset_quotient is None else np.asarray(m.offset_quotient, dtype=np.int64)
+                        rel = (lay_[:, None] + quot[None, :]) % nl - (quot % nl)[None, :]
+                        return rows[:, None, :] + off[None, None, :] * rel[None, :, :]
+                    return rows[:, None, :] + off[None, None, :] * lay_[None, :, None]
+                if facets:       # an interior facet sees the cell below and the cell above it: a row of 2 x arity nodes (builder.py:94-124, f = 0, 1)
+                    rows = np.concatenate([cells(lay), cells(lay + 1)], axis=2).reshape(-1, 2 * m.arity)
                 else:
-                    rows = (rows[:, None, :] + off[None, None, :] * lay[None, :, None]).reshape(-1, m.arity)
+                    rows = cells(lay).reshape(-1, m.arity)
             return rows
         return m.derived(key, build)
 

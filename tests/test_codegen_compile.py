@@ -83,7 +83,7 @@ def test_extruded_wrappers():
         assert _compile(pl) == ["staged", "direct"]        # staged over the (column, layer) cells through a derived map
     k2 = op2.Kernel("static void volf(double A[1], const double x[24]) { A[0] += x[12]; }", "volf")
     pl = op2.LegacyParloop(k2, ext, g(op2.INC), x(op2.READ, cm), iteration_region=op2.ON_INTERIOR_FACETS)
-    assert _compile(pl) == ["direct"]
+    assert _compile(pl) == ["staged", "direct"]            # (a derived row holds the nodes of both stacked cells)
     d = op2.Dat(base)
     pl = op2.LegacyParloop(op2.Kernel("static void k1(double *x) { *x += 1.0; }", "k1"), ext, d(op2.INC))
     assert _compile(pl) == ["direct"]
@@ -123,8 +123,8 @@ def test_periodic_extruded_wrappers_compile():
         k = op2.Kernel("static void kp(double *o, const double *x) { for (int i = 0; i < %d; ++i) o[i] += x[2*i]; }" % (6 * nf), "kp")
         pl = op2.LegacyParloop(k, ext, out(op2.INC, cm), x(op2.READ, cm), iteration_region=region)
         assert pl.global_kernel._extruded_periodic
-        # (cell regions: the wrap is folded into the derived map, the staged wrapper runs them; interior facets stay direct)
-        assert _compile(pl) == (["staged", "direct"] if region is None else ["direct"])
+        # (the wrap is folded into the derived map: the staged wrapper runs cell regions and interior facets alike)
+        assert _compile(pl) == ["staged", "direct"]
 
 
 def test_row_sliced_wrappers():

@@ -124,3 +124,38 @@ def test_periodic_columns_through_the_fast_shapes(mode, region, monkeypatch):
     rp, ci, v = mat.csr()
     assert np.array_equal(rp, mref.rowptr) and np.array_equal(ci, mref.colidx)
     assert np.abs(v - mref.values).max() <= 1e-12 * np.abs(mref.values).max()
+
+
+@pytest.mark.parametrize("mode", ["auto", "direct"])
+@pytest.mark.parametrize("periodic", [False, True])
+def test_interior_facets_of_extruded_columns(mode, periodic, monkeypatch):
+    """ON_INTERIOR_FACETS (dS_h): the kernel sees the cell below and the cell above a horizontal facet (builder.py:94-124, 806-809);
+    the staged wrapper takes both cells' nodes from one row of the derived map, also across the seam of a periodic column."""
+    from mixed_cases import periodic_column_mesh
+    monkeypatch.setitem(configuration, "mode", mode)
+    rng = np.random.default_rng(51)
+    ncl, nb, nv = 7, 2500, 900
+    if periodic:
+        base, ext, nodes, cm = periodic_column_mesh(rng, nbase=nb, ncl=ncl, nv=nv)
+    else:
+        base = op2.Set(nb)
+        ext = op2.ExtrudedSet(base, layers=ncl + 1)
+        nodes = op2.Set(nv * (ncl + 1))
+        tri = np.array([rng.choice(nv, 3, replace=False) for _ in range(nb)])
+        cm = op2.Map(ext, nodes, 6, np.concatenate([tri * (ncl + 1), tri * (ncl + 1) + 1], axis=1).astype(np.int32), offset=[1] * 6)
+    x = op2.Dat(nodes ** 2, rng.standard_normal((nodes.size, 2)))
+    w = op2.Dat(base, rng.standard_normal(base.size))
+    out = op2.Dat(nodes)
+    k = op2.Kernel("static void kfac(double *o, const double *x, const double *w, int layer) { for (int i = 0; i < 12; ++i) "
+                   "o[i] += (1 + layer) * w[0] * ((i+1)*x[2*i] + 0.5*x[2*((i+5)%12)+1]); }", "kfac")
+    kw = dict(iteration_region=op2.ON_INTERIOR_FACETS, pass_layer_arg=True)
+    for it in (ext, op2.Subset(ext, rng.choice(nb, 1800, replace=False))):
+        args = (out(op2.INC, cm), x(op2.READ, cm), w(op2.READ))
+        out.zero()
+        ref = oracle_run(k, it, *args, **kw)[0]
+        pl = op2.LegacyParloop(k, it, *args, **kw)
+        for _ in range(2):
+            out.zero()
+            pl()
+        assert pl._prepare()["cw"].src.mode.startswith("staged" if mode == "auto" else "direct")
+        assert np.abs(ref).max() > 0 and np.abs(out.data_ro - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())

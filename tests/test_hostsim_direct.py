@@ -1074,3 +1074,43 @@ def test_write_min_max_through_maps_beside_staged_arguments_on_host(subset):
     refs = oracle_run(km, it, *args)
     # (to rounding: the oracle's compiler contracts c + 0.1 x into an FMA, the host-sim's does not)
     assert np.allclose(res[0], refs[0], rtol=1e-14, atol=0) and np.allclose(res[1], refs[1], rtol=1e-14, atol=0) and (refs[0] < 1e29).sum() > 100
+
+
+@pytest.mark.parametrize("periodic", [False, True])
+def test_interior_facets_of_extruded_columns_through_the_staged_wrapper_on_host(periodic):
+    """ON_INTERIOR_FACETS on an extruded set (the horizontal facets between stacked cells: dS_h): the local kernel sees the nodes
+    of the cell below and of the cell above (builder.py:94-124, f = 0, 1).  In the staged wrapper a row of the derived map holds
+    both cells' nodes -- 2 x arity local indices per trip -- also across the seam of a periodic column."""
+    from firedrake_amd.codegen import select_mode
+    from hostsim import run_staged
+    rng = np.random.default_rng(51)
+    ncl = 5
+    if periodic:
+        base, ext, nodes, cm = periodic_column_mesh(rng, nbase=40, ncl=ncl, nv=23)
+    else:
+        nv = 23
+        base = op2.Set(40)
+        ext = op2.ExtrudedSet(base, layers=ncl + 1)
+        nodes = op2.Set(nv * (ncl + 1))
+        tri = np.array([rng.choice(nv, 3, replace=False) for _ in range(40)])
+        cm = op2.Map(ext, nodes, 6, np.concatenate([tri * (ncl + 1), tri * (ncl + 1) + 1], axis=1).astype(np.int32), offset=[1] * 6)
+    x = op2.Dat(nodes ** 2, rng.standard_normal((nodes.size, 2)))
+    w = op2.Dat(base, rng.standard_normal(base.size))
+    out = op2.Dat(nodes)
+    k = op2.Kernel("static void kfac(double *o, const double *x, const double *w, int layer) { for (int i = 0; i < 12; ++i) "
+                   "o[i] += (1 + layer) * w[0] * ((i+1)*x[2*i] + 0.5*x[2*((i+5)%12)+1]); }", "kfac")
+    kw = dict(iteration_region=op2.ON_INTERIOR_FACETS, pass_layer_arg=True)
+    args = (out(op2.INC, cm), x(op2.READ, cm), w(op2.READ))
+    pl = op2.LegacyParloop(k, ext, *args, **kw)
+    assert select_mode(pl.global_kernel) == "staged"
+    v = pl._virtual(staged=True)
+    assert v[0] == (ncl if periodic else ncl - 1)
+    ref = oracle_run(k, ext, *args, **kw)[0]
+    for epb in (37, 300):
+        got = run_staged(pl, epb=epb)[0]
+        assert np.abs(ref).max() > 0 and np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    sub = op2.Subset(ext, [5, 1, 3, 6] + list(range(10, 40)))
+    pls = op2.LegacyParloop(k, sub, *args, **kw)
+    refs = oracle_run(k, sub, *args, **kw)[0]
+    gots = run_staged(pls, epb=64)[0]
+    assert np.abs(gots - refs).max() <= 1e-12 * max(1.0, np.abs(refs).max())
