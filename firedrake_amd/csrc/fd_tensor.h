@@ -156,9 +156,9 @@ __device__ __forceinline__ void hex_qk_coefficients(const double *const (&cf)[NC
 // CSR: scalar row (node, p) starts at node_rowptr[node]*D*D + p*rowlen*D, column (k-th node of the row, r) sits at k*D + r.
 // Small elements (tp_fused: 4 NT D^2 <= 96 accumulator registers -- (Q1)^3, (Q2)^3, (Q3)^2) keep ALL D^2 blocks in one workgroup
 // instead: the geometry, the point weights and the B operands are computed once per cell and every Gauss point feeds D^2 NT MFMAs
-// instead of NT.  (Measured on the (Q2)^3 elasticity matrix, n = 24: 2.10 ms either way, 0.12 of the fp64 MFMA peak -- that kernel
-// is bound by its 90.7 M scattered fp64 atomics, whose entries sit D doubles apart so that one wavefront instruction touches ~3x
-// the cache lines of the scalar case; profiles/r5k_tensor_forms.txt.)
+// instead of NT -- and the whole element matrix can leave through LDS transposed (below: the scatter of the accumulator layout is what
+// bounds a vector-valued matrix -- entries D doubles apart, ~3x the cache lines per wavefront instruction of the scalar case:
+// (Q2)^3 elasticity, n = 24, 2.10 ms = 0.12 of the fp64 MFMA peak, fused or not; profiles/r5k_tensor_forms.txt).
 template <int K1, int Q1, int NC, int N1, bool GRAD, int D, int P, int R, int NTHR, int SWW, class WF>
 __device__ __forceinline__ void hex_qk_point_weights(const double *sX, const double *sQP, const double *sQW,
                                                      const double (*sC)[Q1 * Q1 * Q1], const double (*sV1)[8],
@@ -336,6 +336,70 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
     const int variant = (lrel == 0) ? 0 : ((lrel == nl - 1) ? 2 : 1);
     const unsigned short *tab = offtab + ((size_t)(col - start) * 3 + variant) * (ND * ND);
     const int *mrow = map_qk + (size_t)col * ND;
+    if constexpr (FUSED) {
+        // All D^2 blocks of the cell are in this workgroup's registers: the element matrix goes through LDS a few node rows at a time
+        // (the buffer of the point weights, free now) and leaves it TRANSPOSED -- consecutive lanes hold consecutive column nodes of
+        // one scalar row, each with its D trial components, i.e. contiguous runs of the CSR row.  In the accumulator layout a
+        // wavefront instruction touched 4 rows x 16 column nodes D doubles apart (~3x the cache lines of the scalar case); here it
+        // touches one row's runs.  Measured on (Q2)^3 elasticity, n = 24: 2.10 -> 2.00 ms -- the kernel runs at the rate of its 90.7 M
+        // fp64 atomics (45 G/s; the scalar Q4 matrix kernel, MFMA-bound, issues 52 G/s) whatever lines they fall on
+        // (profiles/r5q_tensor_forms.txt).
+        constexpr int RL = ND * D, CAP = NQ * 16 * NP, NR = (CAP / (D * RL)) < ND ? (CAP / (D * RL)) : ND, NTH = WPB * 64, U = 4;
+        static_assert(NR >= 1, "the weight buffer holds at least one node row of the element matrix");
+        __shared__ fd_nnz_t sRowP[ND];
+        __shared__ int sRowL[ND];
+        __shared__ unsigned char sRowOk[ND], sColOk[ND];
+        double *sE = &sW[0][0];
+        if (tid < ND) {
+            const int nd_ = mrow[tid] + OFF * lrel;
+            sRowOk[tid] = !(rlg && rlg[nd_] < 0);
+            sColOk[tid] = !(clg && clg[nd_] < 0);
+            const fd_nnz_t a_ = rowptr[nd_];
+            sRowP[tid] = a_;
+            sRowL[tid] = (int)(rowptr[nd_ + 1] - a_);
+        }
+#pragma unroll 1
+        for (int i0 = 0; i0 < ND; i0 += NR) {
+            const int i1 = i0 + NR < ND ? i0 + NR : ND;
+            __syncthreads();                            // (the MFMA loop's reads of sW / the previous round's reads of sE are done)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int i = itile * 16 + kk + 4 * g;
+                if (i < i0 || i >= i1) continue;
+#pragma unroll
+                for (int a = 0; a < NP; ++a)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int j = t * 16 + r16;
+                        if (j < ND) sE[((i - i0) * D + a / D) * RL + j * D + a % D] = acc[a][t][g];
+                    }
+            }
+            __syncthreads();
+            const int items = (i1 - i0) * D * ND;       // (node row, test component, column node): D contiguous entries each
+#pragma unroll 1
+            for (int o0 = tid; o0 < items; o0 += U * NTH) {
+                unsigned short ps[U];
+#pragma unroll
+                for (int q = 0; q < U; ++q) {           // the places first (loads and atomics share one counter), then the atomics
+                    const int o = o0 + q * NTH, oc = o < items ? o : 0;
+                    const int il = oc / (D * ND), j = oc % ND;
+                    ps[q] = tab[(i0 + il) * ND + j];
+                }
+#pragma unroll
+                for (int q = 0; q < U; ++q) {
+                    const int o = o0 + q * NTH;
+                    if (o >= items) continue;
+                    const int il = o / (D * ND), rem = o - il * (D * ND), pc = rem / ND, j = rem - pc * ND, i = i0 + il;
+                    if (!sRowOk[i] || !sColOk[j]) continue;
+                    const size_t base = (size_t)sRowP[i] * (D * D) + (size_t)pc * sRowL[i] * D + (size_t)ps[q] * D;
+                    const double *src = sE + (il * D + pc) * RL + j * D;
+#pragma unroll
+                    for (int c = 0; c < D; ++c) atomicAdd(&vals[base + c], src[c]);
+                }
+            }
+        }
+        return;
+    }
     int cn[NT]; bool cok[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
