@@ -101,9 +101,9 @@ def test_cg2_cube_of_configs4_on_one_gpu():
     rng = np.random.default_rng(3)
     beyond = np.nonzero((rp[:-1] > 2 ** 31) & ~bc)[0]                       # (the last 6 % of the rows)
     assert len(beyond) > 1000000
-    cand = np.concatenate([rng.choice(beyond, 14, replace=False), [beyond[0], beyond[-1]], rng.integers(0, nn, 40)])
-    rows = [int(r) for r in cand if not bc[r]][:36]
-    assert sum(int(rp[r]) > 2 ** 31 for r in rows) >= 16
+    cand = np.concatenate([rng.choice(beyond, 10, replace=False), [beyond[0], beyond[-1]], rng.integers(0, nn, 30)])
+    rows = [int(r) for r in cand if not bc[r]][:22]
+    assert sum(int(rp[r]) > 2 ** 31 for r in rows) >= 12
     worst = 0.0
     for r in rows:
         cells = np.nonzero((cm == r).any(axis=1))[0]
