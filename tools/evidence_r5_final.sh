@@ -11,7 +11,7 @@ python -c "from firedrake_amd import forms; print(len(forms.precompile_all()), '
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v "Warning\|amdgpu" | tail -2 | tee gpurun_out/r5zz_smoke.txt
 timeout 1800 python -m pytest tests -q -m gpu 2>&1 | grep -v "Warning\|getlimits\|setattr\|_float_to_str" | tail -12 > gpurun_out/r5zz_gputests_tail.txt
 tail -4 gpurun_out/r5zz_gputests_tail.txt
-/usr/bin/time -f "bench.py wall %e s" python bench.py --steps 20 --warmup 5 > gpurun_out/r5zz_bench_line.json 2> gpurun_out/r5zz_bench_line.err
+S=$(date +%s); python bench.py --steps 20 --warmup 5 > gpurun_out/r5zz_bench_line.json 2> gpurun_out/r5zz_bench_line.err; echo "bench.py wall $(( $(date +%s) - S )) s" >> gpurun_out/r5zz_bench_line.err
 tail -2 gpurun_out/r5zz_bench_line.err; head -c 600 gpurun_out/r5zz_bench_line.json; echo
 for part in slabs blocks; do
   FDHIP_FORCE_DEVICE=0 FDHIP_DIST_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
