@@ -525,7 +525,7 @@ BENCH_VARIANTS = {
     ("jacobian", 2, 1): ("ocrp_q10k3d_fx", "ocr_q10k3d_fx", "ocrp_q9k3d_fx", "ocr_q9k3d_fx"),
     ("residual", 3, 1): ("stagedo_s431", "staged_s405"),
     ("jacobian", 3, 1): ("ocrp_q10k4d_fx", "ocr_q10k4d_fx", "ocrp_q9k4d_fx", "ocr_q9k4d_fx"),
-    ("residual", 3, 2): ("stagedo_s1508x255",),
+    ("residual", 3, 2): ("stagedo_s1508x255", "stagedo_s1502x256"),       # n = 107 (one GPU's share), n = 215 (the whole cube of configs[4])
     ("jacobian", 3, 2): ("ocrspr_q8k7e13", "ocrs_q8k7e13", "ocrspr", "ocrsp", "ocrs"),
     "dg_advection": ("staged_s2048x561", "staged_s1024x516", "staged_s2332x668"),
 }
