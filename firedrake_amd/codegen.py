@@ -260,7 +260,9 @@ def staged_eligible(gk: GlobalKernel, mats_on_virtual: bool = False, need_indire
         if any(isinstance(a, MatKernelArg) for a in gk.arguments) and not mats_on_virtual:
             return False          # (matrix loops over virtual spaces: row-sliced owner-computes-rows only, sliced_eligible)
         if gk._extruded:
-            if gk._iteration_region == ON_INTERIOR_FACETS and (not gk._constant_layers or any(isinstance(a, MatKernelArg) for a in gk.arguments)):
+            if gk._iteration_region == ON_INTERIOR_FACETS and (
+                    not gk._constant_layers or (not mats_on_virtual and any(isinstance(a, MatKernelArg) for a in gk.arguments))
+                    or any(isinstance(m, PermutedMapKernelArg) for a in gk.arguments for m in (getattr(a, "maps", None) or ()))):
                 return False          # (variable layers qualify: the derived map and the cell tables are ragged, set.py:326-337;
                                       #  periodic columns too: the wrap of builder.py:101-123 is folded into the derived map's rows;
                                       #  interior facets of constant-layer columns in Dat loops: a derived row holds both stacked cells)
@@ -306,6 +308,8 @@ def ocr_eligible(gk: GlobalKernel) -> bool:
     """Owner-computes-rows matrix assembly with whole-entity instances: scalar blocks, per-node lgmaps; also over subsets and
     extruded sets (constant layers, regions ALL / ON_BOTTOM / ON_TOP: the plans are built on derived maps)."""
     a = _ocr_shape(gk, mats_on_virtual=True)
+    if gk._extruded and gk._iteration_region == ON_INTERIOR_FACETS:
+        return False              # (two stacked cells per trip: the row-sliced wrapper takes them as maps of twice the arity)
     # (the element tensor and its row-offset table live in registers: bounded element matrices only)
     return a is not None and int(np.prod(a.dims[0])) * int(np.prod(a.dims[1])) == 1 \
         and a.maps[0].arity * a.maps[1].arity <= configuration["ocr_sliced_max_entries"]
@@ -327,10 +331,11 @@ def sliced_eligible(gk: GlobalKernel) -> bool:
         return False          # per-dof lgmaps (MatSetValuesLocal on dof indices) travel as an 8-bit row and a 64-bit column mask
     # the local kernel is inlined once per row-map entry and must unroll completely in each copy: bounded element matrices
     # only (Q2 hexahedra 27x27 and vector P2 tetrahedra 30x30 qualify; the 125x125 of Q4 has its own wrapper, else direct)
-    entries = a.maps[0].arity * a.maps[1].arity * int(np.prod(a.dims[0])) * int(np.prod(a.dims[1]))
-    if a.maps[0].arity > configuration["ocr_sliced_max_arity"] or entries > configuration["ocr_sliced_max_entries"]:
+    nf = 2 if (gk._extruded and gk._iteration_region == ON_INTERIOR_FACETS) else 1      # (a facet sees two stacked cells)
+    entries = nf * a.maps[0].arity * nf * a.maps[1].arity * int(np.prod(a.dims[0])) * int(np.prod(a.dims[1]))
+    if nf * a.maps[0].arity > configuration["ocr_sliced_max_arity"] or entries > configuration["ocr_sliced_max_entries"]:
         return False
-    if not ocr_eligible(gk):
+    if nf > 1 or not ocr_eligible(gk):
         # vector-valued blocks, per-dof lgmaps: whole-entity instances do not cover them, and the only other path scatters
         # every entry with a global atomic -- sliced whatever the size of the element matrix
         return True
@@ -1179,6 +1184,10 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     # decoded only for direct arguments and the layer argument (every map row is a row of a derived map)
     extruded = bool(gk._extruded)
     varlay = bool(extruded and not gk._constant_layers)
+    # interior facets of an extruded set: the loop runs on derived maps whose rows hold the nodes of BOTH stacked cells (Parloop.
+    # _plan_map), in the order of the local kernel's packs (cell below, cell above: builder.py:94-124) -- to this wrapper simply maps
+    # of twice the arity
+    nf = 2 if (extruded and gk._iteration_region == ON_INTERIOR_FACETS) else 1
     if extruded:
         P("const int *__restrict__ layers", ("layers",))
     if gk._subset:
@@ -1192,7 +1201,7 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         info = {"k": k, "arg": a, "acc": la.access, "ct": CTYPE[np.dtype(la.dtype)], "dtype": np.dtype(la.dtype)}
         if isinstance(a, MatKernelArg):
             info["kind"] = "mat"
-            info["ar"], info["ac"] = a.maps[0].arity, a.maps[1].arity
+            info["ar"], info["ac"] = a.maps[0].arity * nf, a.maps[1].arity * nf
             info["rbs"], info["cbs"] = int(np.prod(a.dims[0])), int(np.prod(a.dims[1]))
         elif isinstance(a, DatKernelArg):
             info["kind"] = "dat"
@@ -1200,8 +1209,10 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             if a.is_indirect:
                 m = a.map_
                 base = m.base_map if isinstance(m, PermutedMapKernelArg) else m
-                info["m"], info["ar"] = map_index[id(base)], base.arity
+                info["m"], info["ar"] = map_index[id(base)], base.arity * nf
                 info["perm"] = tuple(m.permutation) if isinstance(m, PermutedMapKernelArg) else None
+                if nf > 1 and info["perm"] is not None:
+                    raise ValueError("interior-facet matrix loops through PermutedMaps take the direct wrapper")
         elif isinstance(a, GlobalKernelArg):
             info["kind"] = "global"
         elif isinstance(a, PassthroughKernelArg):
@@ -1339,13 +1350,14 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     if not early:
         src += stage_src
     if extruded and not varlay:
-        lo, hi = {ALL: ("layers[0]", "layers[1]-1"), ON_BOTTOM: ("layers[0]", "layers[0]+1"), ON_TOP: ("layers[1]-2", "layers[1]-1")}[gk._iteration_region]
+        lo, hi = {ALL: ("layers[0]", "layers[1]-1"), ON_BOTTOM: ("layers[0]", "layers[0]+1"), ON_TOP: ("layers[1]-2", "layers[1]-1"),
+                  ON_INTERIOR_FACETS: ("layers[0]", "layers[1]-1" if gk._extruded_periodic else "layers[1]-2")}[gk._iteration_region]
         src.append(f"  const int fd_llo = {lo}, fd_nlit = ({hi}) - fd_llo;")
     # every 64 consecutive slots hold one local row index, and e0 / nthr are multiples of 64: the index is wave-uniform.
     # Software pipeline like the unsliced wrappers: the index rows of the lane's NEXT instance are requested before the
     # current one's local kernel runs (a trip is only ~300 instructions, far less than an HBM round trip).
     need_e = any(i["kind"] == "dat" and "m" not in i for i in infos) or bool(gk._pass_layer_arg)
-    rows = [(f"lm{mi}", maps[mi].arity, f"fdw::load_lmap<{maps[mi].arity}>(p{mi}_lmap + (size_t)(II - start)*{maps[mi].arity}, DST);")
+    rows = [(f"lm{mi}", maps[mi].arity * nf, f"fdw::load_lmap<{maps[mi].arity * nf}>(p{mi}_lmap + (size_t)(II - start)*{maps[mi].arity * nf}, DST);")
             for mi in staged_maps]
     rows.append(("kk", AC, f"fdw::load_packed<{ktype}, {AC}>(oc{K}_k + (size_t)(II - start)*{AC}, DST);"))
     scal = [("role", "(int)chunk_role_[(II - start) >> 6]"), ("slot", f"(int)oc{K}_slot[II - start]")]
@@ -1355,7 +1367,7 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             raise ValueError("one local-index width per staged map")
         off, fields = 0, []
         for mi, lb in zip(staged_maps, rec["lbits"]):
-            for i in range(maps[mi].arity):
+            for i in range(maps[mi].arity * nf):
                 fields.append((f"lm{mi}[{i}]", off, lb))
                 off += lb
         for j in range(AC):
@@ -1364,7 +1376,7 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
         fields.append(("const int slot", off, rec["sbits"]))
         off += rec["sbits"]
         W = -(-off // 32)
-        rec_decode = [f"int lm{mi}[{maps[mi].arity}];" for mi in staged_maps] + [f"int kk[{AC}];"]
+        rec_decode = [f"int lm{mi}[{maps[mi].arity * nf}];" for mi in staged_maps] + [f"int kk[{AC}];"]
         rec_decode += [f"{name} = fdw::rec_field<{o}, {b}>(rc);" for name, o, b in fields]
         rows = [("rc", W, f"fdw::load_rec<{W}>(oc{K}_rec + (size_t)(II - start)*{W}, DST);")]
         scal = [("role", "(int)chunk_role_[(II - start) >> 6]")]

@@ -210,8 +210,8 @@ def test_row_sliced_variants_for_blocks_dof_masks_and_virtual_spaces():
 def test_wrapper_shape_selection_table():
     """Which wrapper a matrix loop gets (codegen.select_mode): whole-entity owner-computes-rows for small scalar element
     matrices, row-sliced from 8 scalar rows and for every vector-valued / per-dof-lgmap matrix, both also over subsets and
-    extruded sets; the direct wrapper for what neither covers (periodic or interior-facet extrusion, oversized element
-    matrices, a second output)."""
+    extruded sets (interior facets: row-sliced on maps of twice the arity); the direct or the staged wrapper for what neither covers
+    (oversized element matrices, a second output)."""
     from firedrake_amd.codegen import select_mode
     from firedrake_amd.configuration import configuration
     assert configuration["ocr_sliced_min_arity"] == 8
@@ -236,7 +236,7 @@ def test_wrapper_shape_selection_table():
     #                                                                   wrapper then scatters the matrix entry by entry)
     ext = op2.ExtrudedSet(op2.Set(2), layers=4)
     assert mode(6, iterset=ext) == "ocr" and mode(8, iterset=ext) == "ocrs"
-    assert mode(6, iterset=ext, iteration_region=op2.ON_INTERIOR_FACETS) == "direct"
+    assert mode(6, iterset=ext, iteration_region=op2.ON_INTERIOR_FACETS) == "ocrs"   # two stacked cells: maps of twice the arity
     assert mode(6, iterset=op2.Subset(ele, [1])) == "ocr"
     out = op2.Dat(nodes)
     m4 = op2.Map(ele, nodes, 4, np.arange(8))

@@ -159,3 +159,38 @@ def test_interior_facets_of_extruded_columns(mode, periodic, monkeypatch):
             pl()
         assert pl._prepare()["cw"].src.mode.startswith("staged" if mode == "auto" else "direct")
         assert np.abs(ref).max() > 0 and np.abs(out.data_ro - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("mode", ["auto", "direct"])
+@pytest.mark.parametrize("periodic", [False, True])
+def test_interior_facet_matrix_loop(mode, periodic, monkeypatch):
+    """The matrix of an interior-facet integral on an extruded set (dS_h: 2a x 2a element tensors coupling the cells below and above
+    a horizontal facet): row-sliced owner-computes-rows on the derived facet maps (twice the arity), and the direct wrapper."""
+    from mixed_cases import periodic_column_mesh
+    monkeypatch.setitem(configuration, "mode", mode)
+    rng = np.random.default_rng(61)
+    ncl, nb, nv = 6, 2000, 700
+    if periodic:
+        base, ext, nodes, cm = periodic_column_mesh(rng, nbase=nb, ncl=ncl, nv=nv)
+    else:
+        base = op2.Set(nb)
+        ext = op2.ExtrudedSet(base, layers=ncl + 1)
+        nodes = op2.Set(nv * (ncl + 1))
+        tri = np.array([rng.choice(nv, 3, replace=False) for _ in range(nb)])
+        cm = op2.Map(ext, nodes, 6, np.concatenate([tri * (ncl + 1), tri * (ncl + 1) + 1], axis=1).astype(np.int32), offset=[1] * 6)
+    x = op2.Dat(nodes ** 2, rng.standard_normal((nodes.size, 2)))
+    w = op2.Dat(base, rng.uniform(1, 2, base.size))
+    mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(cm, cm, [op2.ON_INTERIOR_FACETS])]))
+    k = op2.Kernel("static void kfm(double *A, const double *x, const double *w, int layer) { for (int i = 0; i < 12; ++i) "
+                   "for (int j = 0; j < 12; ++j) A[i*12 + j] += w[0] * (x[2*i] * x[2*j+1] + 0.125 * layer) + (i == j ? 1.0 : 0.0) + (i < 6 && j >= 6 ? 0.5 : 0.0); }", "kfm")
+    kw = dict(iteration_region=op2.ON_INTERIOR_FACETS, pass_layer_arg=True)
+    args = (mat(op2.INC, (cm, cm)), x(op2.READ, cm), w(op2.READ))
+    pl = op2.LegacyParloop(k, ext, *args, **kw)
+    for _ in range(2):
+        mat.zero()
+        pl()
+    assert pl._prepare()["cw"].src.mode.startswith("ocrs" if mode == "auto" else "direct")
+    ref = oracle_run(k, ext, *args, **kw)[0]
+    rp, ci, v = mat.csr()
+    assert np.array_equal(rp, ref.rowptr) and np.array_equal(ci, ref.colidx)
+    assert np.abs(v - ref.values).max() <= 1e-12 * np.abs(ref.values).max()

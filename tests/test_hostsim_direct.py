@@ -1114,3 +1114,36 @@ def test_interior_facets_of_extruded_columns_through_the_staged_wrapper_on_host(
     refs = oracle_run(k, sub, *args, **kw)[0]
     gots = run_staged(pls, epb=64)[0]
     assert np.abs(gots - refs).max() <= 1e-12 * max(1.0, np.abs(refs).max())
+
+
+@pytest.mark.parametrize("periodic", [False, True])
+def test_interior_facet_matrix_loop_through_the_row_sliced_wrapper_on_host(periodic):
+    """The MATRIX of an interior-facet integral on an extruded set (dS_h: a 2a x 2a element tensor coupling the cell below and the
+    cell above a horizontal facet, builder.py:573-625 with both maps doubled): the row-sliced owner-computes-rows wrapper sees the
+    derived maps of the facets -- rows of 2 x arity nodes in the order of the kernel's packs -- as ordinary maps of twice the arity."""
+    from firedrake_amd.codegen import select_mode
+    from hostsim import run_ocrs
+    rng = np.random.default_rng(61)
+    ncl = 5
+    if periodic:
+        base, ext, nodes, cm = periodic_column_mesh(rng, nbase=30, ncl=ncl, nv=19)
+    else:
+        nv = 19
+        base = op2.Set(30)
+        ext = op2.ExtrudedSet(base, layers=ncl + 1)
+        nodes = op2.Set(nv * (ncl + 1))
+        tri = np.array([rng.choice(nv, 3, replace=False) for _ in range(30)])
+        cm = op2.Map(ext, nodes, 6, np.concatenate([tri * (ncl + 1), tri * (ncl + 1) + 1], axis=1).astype(np.int32), offset=[1] * 6)
+    x = op2.Dat(nodes ** 2, rng.standard_normal((nodes.size, 2)))
+    w = op2.Dat(base, rng.uniform(1, 2, base.size))
+    mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(cm, cm, [op2.ON_INTERIOR_FACETS])]))
+    k = op2.Kernel("static void kfm(double *A, const double *x, const double *w, int layer) { for (int i = 0; i < 12; ++i) "
+                   "for (int j = 0; j < 12; ++j) A[i*12 + j] += w[0] * (x[2*i] * x[2*j+1] + 0.125 * layer) + (i == j ? 1.0 : 0.0) + (i < 6 && j >= 6 ? 0.5 : 0.0); }", "kfm")
+    kw = dict(iteration_region=op2.ON_INTERIOR_FACETS, pass_layer_arg=True)
+    args = (mat(op2.INC, (cm, cm)), x(op2.READ, cm), w(op2.READ))
+    pl = op2.LegacyParloop(k, ext, *args, **kw)
+    assert select_mode(pl.global_kernel).startswith("ocrs")
+    ref = oracle_run(k, ext, *args, **kw)[0]
+    for got in (run_ocrs(pl, nnz_per_block=260), run_ocrs(pl, nnz_per_block=260, records=True)):
+        assert np.array_equal(got.rowptr, ref.rowptr) and np.array_equal(got.colidx, ref.colidx)
+        assert np.abs(got.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
