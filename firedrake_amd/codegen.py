@@ -280,9 +280,11 @@ def staged_eligible(gk: GlobalKernel, mats_on_virtual: bool = False, need_indire
                 n_ind += 1
                 continue
             # WRITE / RW / MIN / MAX through a map (an interpolation's output, a limiter's bounds): the lane reads and writes global
-            # memory itself while the READ / INC arguments of the loop are staged -- on plain sets and subsets (an extruded loop
-            # addresses such an argument through the layer arithmetic of the direct wrapper), and not in matrix loops
-            if gk._extruded or any(isinstance(b, MatKernelArg) for b in gk.arguments):
+            # memory itself while the READ / INC arguments of the loop are staged -- on plain sets, subsets and constant-layer
+            # extruded sets (cell regions; the lane applies the layer arithmetic of builder.py:94-124 to the base entity's map row as
+            # the direct wrapper does), and not in matrix loops
+            if any(isinstance(b, MatKernelArg) for b in gk.arguments) or (
+                    gk._extruded and (not gk._constant_layers or gk._iteration_region == ON_INTERIOR_FACETS)):
                 return False
     return n_ind > 0 or not need_indirect_dat
 
@@ -958,6 +960,11 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                           ON_TOP: ("layers[1]-2", "layers[1]-1"),
                           ON_INTERIOR_FACETS: ("layers[0]", "layers[1]-1" if periodic else "layers[1]-2")}[region]
                 src.append(f"  const int fd_llo = {lo}, fd_nlit = ({hi}) - fd_llo;")
+                if any(i_["kind"] == "dat" and "m" in i_ and not stages_in_lds(i_["acc"], i_["dtype"]) for i_ in infos):
+                    # (WRITE / RW / MIN / MAX arguments addressed from the lane: base map row + offset * layer, builder.py:94-124)
+                    src.append("  const int *__restrict__ lay = layers;")
+                    if periodic:
+                        src.append("  const int fd_nl = lay[1] - 1 - lay[0];")
         if ocr:
             ent_of = lambda ii: f"inst_ent_[{ii}]"
         elif lane_threads:

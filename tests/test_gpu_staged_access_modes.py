@@ -39,3 +39,36 @@ def test_write_min_max_through_maps(mode, subset, monkeypatch):
     assert plm._prepare()["cw"].src.mode.startswith("staged" if mode == "auto" else "direct")
     assert np.allclose(lo.data_ro, refs[0], rtol=1e-14, atol=0) and np.allclose(hi.data_ro, refs[1], rtol=1e-14, atol=0)
     assert (refs[0] < 1e29).sum() > 1000
+
+
+@pytest.mark.parametrize("mode", ["auto", "direct"])
+@pytest.mark.parametrize("periodic", [False, True])
+def test_write_and_max_through_maps_on_extruded_columns(mode, periodic, monkeypatch):
+    """WRITE / MAX through the (column, layer) addressing of an extruded set (builder.py:94-124), beside staged READ arguments: the
+    lane applies map + offset * layer (with the periodic wrap) to the base entity's map row."""
+    from mixed_cases import periodic_column_mesh
+    monkeypatch.setitem(configuration, "mode", mode)
+    rng = np.random.default_rng(71)
+    ncl, nb, nv = 6, 3000, 1000
+    if periodic:
+        base, ext, nodes, cm = periodic_column_mesh(rng, nbase=nb, ncl=ncl, nv=nv)
+    else:
+        base = op2.Set(nb)
+        ext = op2.ExtrudedSet(base, layers=ncl + 1)
+        nodes = op2.Set(nv * (ncl + 1))
+        tri = np.array([rng.choice(nv, 3, replace=False) for _ in range(nb)])
+        cm = op2.Map(ext, nodes, 6, np.concatenate([tri * (ncl + 1), tri * (ncl + 1) + 1], axis=1).astype(np.int32), offset=[1] * 6)
+    x = op2.Dat(nodes ** 2, rng.standard_normal((nodes.size, 2)))
+    cv = op2.Dat(base, rng.standard_normal(base.size))
+    k = op2.Kernel("static void interp_max(double *o, double *hi, const double *x, const double *c) { for (int i = 0; i < 6; ++i) { "
+                   "o[i] = 2.0*x[2*i] - x[2*i+1]*x[2*i+1]; const double v = c[0] + x[2*i]; if (v > hi[i]) hi[i] = v; } }", "interp_max")
+    for region in (None, op2.ON_TOP):
+        out = op2.Dat(nodes, np.full(nodes.size, -7.0))
+        hi = op2.Dat(nodes, np.full(nodes.size, -1e30))
+        args = (out(op2.WRITE, cm), hi(op2.MAX, cm), x(op2.READ, cm), cv(op2.READ))
+        refs = oracle_run(k, ext, *args, iteration_region=region)
+        pl = op2.LegacyParloop(k, ext, *args, iteration_region=region)
+        pl()
+        assert pl._prepare()["cw"].src.mode.startswith("staged" if mode == "auto" else "direct")
+        assert np.allclose(out.data_ro, refs[0], rtol=1e-14, atol=0) and np.allclose(hi.data_ro, refs[1], rtol=1e-14, atol=0)
+        assert (refs[0] != -7.0).sum() > 1000

@@ -1147,3 +1147,38 @@ def test_interior_facet_matrix_loop_through_the_row_sliced_wrapper_on_host(perio
     for got in (run_ocrs(pl, nnz_per_block=260), run_ocrs(pl, nnz_per_block=260, records=True)):
         assert np.array_equal(got.rowptr, ref.rowptr) and np.array_equal(got.colidx, ref.colidx)
         assert np.abs(got.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
+
+
+@pytest.mark.parametrize("region", [None, op2.ON_TOP])
+@pytest.mark.parametrize("periodic", [False, True])
+def test_write_and_max_through_maps_on_extruded_columns_on_host(region, periodic):
+    """An interpolation on an extruded mesh writes its target through the (column, layer) addressing of builder.py:94-124: in the staged
+    wrapper the READ arguments come from LDS (plans on the derived map) and the lane applies map + offset * layer -- with the periodic
+    wrap -- to the BASE entity's map row for the WRITE / MAX arguments."""
+    from firedrake_amd.codegen import select_mode
+    from hostsim import run_staged
+    rng = np.random.default_rng(71)
+    ncl = 5
+    if periodic:
+        base, ext, nodes, cm = periodic_column_mesh(rng, nbase=40, ncl=ncl, nv=23)
+    else:
+        nv = 23
+        base = op2.Set(40)
+        ext = op2.ExtrudedSet(base, layers=ncl + 1)
+        nodes = op2.Set(nv * (ncl + 1))
+        tri = np.array([rng.choice(nv, 3, replace=False) for _ in range(40)])
+        cm = op2.Map(ext, nodes, 6, np.concatenate([tri * (ncl + 1), tri * (ncl + 1) + 1], axis=1).astype(np.int32), offset=[1] * 6)
+    x = op2.Dat(nodes ** 2, rng.standard_normal((nodes.size, 2)))
+    out = op2.Dat(nodes, np.full(nodes.size, -7.0))
+    hi = op2.Dat(nodes, np.full(nodes.size, -1e30))
+    cv = op2.Dat(base, rng.standard_normal(base.size))
+    k = op2.Kernel("static void interp_max(double *o, double *hi, const double *x, const double *c) { for (int i = 0; i < 6; ++i) { "
+                   "o[i] = 2.0*x[2*i] - x[2*i+1]*x[2*i+1]; const double v = c[0] + x[2*i]; if (v > hi[i]) hi[i] = v; } }", "interp_max")
+    for it in (ext, op2.Subset(ext, [5, 1, 3, 6] + list(range(10, 40)))):
+        args = (out(op2.WRITE, cm), hi(op2.MAX, cm), x(op2.READ, cm), cv(op2.READ))
+        pl = op2.LegacyParloop(k, it, *args, iteration_region=region)
+        assert select_mode(pl.global_kernel) == "staged"
+        res = run_staged(pl, epb=90)
+        refs = oracle_run(k, it, *args, iteration_region=region)
+        assert np.allclose(res[0], refs[0], rtol=1e-14, atol=0) and np.allclose(res[1], refs[1], rtol=1e-14, atol=0)
+        assert (refs[0] != -7.0).sum() > 20 and (refs[1] > -1e29).sum() > 20
