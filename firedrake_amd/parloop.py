@@ -863,7 +863,9 @@ class Parloop:
                 elif mode.startswith("staged"):
                     v = self._virtual()
                     for off, size in self._parts():
-                        self._staged_geometry(*(v.range(off, off + size) if v else (off, off + size)))
+                        rng_ = v.range(off, off + size) if v else (off, off + size)
+                        if rng_[1] > rng_[0]:
+                            self._staged_geometry(*rng_)
                 return
             except PlanDoesNotFit as exc:
                 from .codegen import staged_eligible
@@ -934,6 +936,8 @@ class Parloop:
         v = self._virtual()
         if v is not None:
             start, end = v.range(start, end)            # positions in the virtual (entity x layer) space
+            if end <= start:
+                return                                  # (no cell to visit: one-layer columns under ON_INTERIOR_FACETS, empty columns)
         args, geo = self._arglist(start, end)
         cw = geo["cw"] if geo is not None else self._prepared["cw"]
         src = cw.src

@@ -194,3 +194,20 @@ def test_interior_facet_matrix_loop(mode, periodic, monkeypatch):
     rp, ci, v = mat.csr()
     assert np.array_equal(rp, ref.rowptr) and np.array_equal(ci, ref.colidx)
     assert np.abs(v - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
+
+
+def test_loops_without_any_cell_are_no_ops():
+    """One cell layer has no interior facet: the staged wrapper's virtual space is empty and nothing is launched (the reference's
+    wrapper loop runs zero trips, builder.py:806-809)."""
+    rng = np.random.default_rng(5)
+    base = op2.Set(50)
+    ext = op2.ExtrudedSet(base, layers=2)
+    nodes = op2.Set(40 * 2)
+    tri = np.array([rng.choice(40, 3, replace=False) for _ in range(50)])
+    cm = op2.Map(ext, nodes, 6, np.concatenate([tri * 2, tri * 2 + 1], axis=1).astype(np.int32), offset=[1] * 6)
+    x = op2.Dat(nodes ** 2, rng.standard_normal((nodes.size, 2)))
+    out = op2.Dat(nodes)
+    k = op2.Kernel("static void kf0(double *o, const double *x) { for (int i = 0; i < 12; ++i) o[i] += x[2*i]; }", "kf0")
+    pl = op2.LegacyParloop(k, ext, out(op2.INC, cm), x(op2.READ, cm), iteration_region=op2.ON_INTERIOR_FACETS)
+    pl()
+    assert pl._prepare()["cw"].src.mode.startswith("staged") and not np.asarray(out.data_ro).any()
