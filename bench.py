@@ -211,6 +211,12 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD datasheet; tools/microbench.hip measures 77
 FP64_VECTOR_PEAK_TFLOPS = 78.6 # same datasheet figure for vector fp64 FMA (256 CUs x 64 lanes x 2 flop x 2.4 GHz); microbench: 70 TFLOP/s
 
 
+def _grid_of(loop):
+    """Work-items of the most recent launch of ``loop``'s wrapper (firedrake_amd.kernel.last_launch), or None."""
+    from firedrake_amd.kernel import last_launch
+    return last_launch.get(loop.global_kernel.name, (None,))[0]
+
+
 def measure_c3(n, steps, warmup, coefficients=False, cpu_sample=0):
     """BASELINE.json configs[2]: Helmholtz Q4 on an extruded hex mesh through ordinary parloops -- the stiffness+mass
     matrix on the fp64 matrix cores (tp_matrix wrapper) and the sum-factorised operator action (tp_action).  Reports the
@@ -264,12 +270,12 @@ def measure_c3(n, steps, warmup, coefficients=False, cpu_sample=0):
             "cpu_baseline": cpu,
             "jacobian_dofs_per_s": ndofs / (a_ms * 1e-3), "action_dofs_per_s": ndofs / (act_a_ms * 1e-3),
             "ms_per_step": elapsed / steps * 1e3, "first_call_s": first,
-            "roofline": {"kernel": "wrap_helmholtz_q4_hex_jacobian", "bound": "mfma", "achieved": tf(k_ms), "peak": FP64_MFMA_PEAK_TFLOPS,
+            "roofline": {"kernel": "wrap_helmholtz_q4_hex_jacobian", "grid": _grid_of(prob.jac_loop), "bound": "mfma", "achieved": tf(k_ms), "peak": FP64_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": tf(k_ms) / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "ms": k_ms,
                          "algorithmic_flops": flops, "issued_mfma_flops": prob.FLOPS_PER_CELL * ncell,
                          "assemble_ms": a_ms, "frac_assemble": tf(a_ms) / FP64_MFMA_PEAK_TFLOPS,
                          "note": "assemble = zeroing pass over the CSR values + MFMA kernel incl. its atomic scatter + BC diagonal"},
-            "roofline_action": {"kernel": "wrap_helmholtz_q4_hex_action", "bound": "hbm", "achieved": act_bytes / (act_k_ms * 1e-3) / 1e9,
+            "roofline_action": {"kernel": "wrap_helmholtz_q4_hex_action", "grid": _grid_of(prob.act_loop), "bound": "hbm", "achieved": act_bytes / (act_k_ms * 1e-3) / 1e9,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": act_bytes / (act_k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "traffic": None, "ms": act_k_ms, "algorithmic_bytes": act_bytes, "assemble_ms": act_a_ms,
                                 # the action's floor is fp64 VALU issue, not HBM: 6 axis passes (450 FMAs per line, 25 lines per cell)
@@ -427,8 +433,8 @@ def measure_c4(n, steps, warmup, cpu_sample=0):
     b_ext = next_ * ((4 + 4) * 4 + 4 + 4 * (16 + 16) + 4 * (8 + 16))     # boundary cells only: per-facet rows, no reuse
     b_int = nint * ((8 + 8) * 4 + 8) + node_in + ndq * 16
     roofs = []
-    for name, ms, nbytes in zip(names, per, (b_cell, b_ext, b_int)):
-        roofs.append({"kernel": name, "bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    for loop, name, ms, nbytes in zip(prob.loops, names, per, (b_cell, b_ext, b_int)):
+        roofs.append({"kernel": name, "grid": _grid_of(loop), "bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "ms": ms, "algorithmic_bytes": nbytes})
     dominant = max(roofs, key=lambda r: r["ms"])
     cpu = None
@@ -532,14 +538,23 @@ def collect_traffic(argv_tail, kernels):
             with open(fcsv) as fh:
                 for row in csv.DictReader(fh):
                     if row.get("Counter_Name") == counter:
-                        acc.setdefault(row["Kernel_Name"].split("(")[0].strip(), []).append(float(row["Counter_Value"]))
+                        # keyed by (kernel, work-items of the dispatch): one wrapper launched on two problem sizes (the CG2 share and
+                        # the whole configs[4] cube) must not be averaged together, nor lend its counters by name
+                        try:
+                            grid = int(float(row.get("Grid_Size") or 0))
+                        except ValueError:
+                            grid = 0
+                        acc.setdefault((row["Kernel_Name"].split("(")[0].strip(), grid), []).append(float(row["Counter_Value"]))
         for k, v in acc.items():
             mean.setdefault(k, {})[counter] = sum(v) / len(v)
         shutil.rmtree(d, ignore_errors=True)
     calib = {}
     gib = float(1 << 30)
+    by_name = {}
+    for (name, grid), c in mean.items():
+        by_name.setdefault(name, {})[grid] = c
     for name, width in CALIB:
-        c = mean.get(name)
+        c = next(iter(by_name.get(name, {}).values()), None)
         if c:
             moved = gib * (1.5 if name.endswith("gather8") else 1.0)        # the gather also streams its 4-byte index array
             calib[name[len("wrap_fd_calib_"):]] = {
@@ -548,12 +563,24 @@ def collect_traffic(argv_tail, kernels):
                 "FETCH_SIZE_kb": c.get("FETCH_SIZE"), "WRITE_SIZE_kb": c.get("WRITE_SIZE")}
     out = {}
     for k in kernels:
-        c = mean.get(k)
-        if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            # guide formula: FETCH_SIZE counts 64 B per 128-B request on gfx950 -> doubled; WRITE_SIZE as reported
-            out[k] = {"hbm_bytes_per_launch": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0,
-                      "FETCH_SIZE_kb": c["FETCH_SIZE"], "WRITE_SIZE_kb": c["WRITE_SIZE"]}
-    return out, {"calibration": calib, "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes of this command"}
+        for grid, c in by_name.get(k, {}).items():
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                # guide formula: FETCH_SIZE counts 64 B per 128-B request on gfx950 -> doubled; WRITE_SIZE as reported
+                out.setdefault(k, {})[grid] = {"hbm_bytes_per_launch": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0,
+                                               "FETCH_SIZE_kb": c["FETCH_SIZE"], "WRITE_SIZE_kb": c["WRITE_SIZE"]}
+    return out, {"calibration": calib, "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes of this command",
+                 "keyed_by": "(kernel name, work-items of the dispatch): a roofline whose launch size the profiled child did not run keeps traffic = null"}
+
+
+def match_traffic(tr, roof):
+    """Counters of the profiled child for THIS roofline's launch: same kernel name and the same number of work-items (``grid``);
+    a roofline that does not know its grid takes the kernel's counters only when the child ran a single launch size of it."""
+    sizes = (tr or {}).get(roof.get("kernel"))
+    if not sizes:
+        return None
+    if roof.get("grid") is not None:
+        return sizes.get(int(roof["grid"]))
+    return next(iter(sizes.values())) if len(sizes) == 1 else None
 
 
 def measure(prob, args, world, dist, backend, torch):
@@ -693,7 +720,47 @@ def check_devices(n):
     return ndev.value
 
 
-def poisson_line(args, ctx, degree, shape, scaling, label, numbering, variants, traffic, cpu=False, cpu_reps=None):
+def jacobian_accumulation(prob, args, ab):
+    """{"accumulation": ...} of ``prob``'s Jacobian loop as it just ran, plus (``ab``) the kernel time of the same loop rebuilt with
+    the other setting of FDHIP_OCR_FIXED_POINT on the same mesh."""
+    from firedrake_amd import _lib, forms
+    from firedrake_amd.configuration import configuration
+    from firedrake_amd.device import Event
+
+    def mode_of(p):
+        loop = p.jacobian()[1]
+        geos = [g for key, g in (loop._prepared or {}).get("parts", {}).items() if key[0] == "ocr" and isinstance(g, dict)]
+        fx = any(g["cw"].src.mode.endswith("_fx") for g in geos)
+        return ("fixed-point, quantum 2^-44..2^-47 of the row block's largest contribution (opt-in, normwise only)" if fx
+                else "fp64 (ds_add_f64 in LDS; global_atomic_add_f64 off the owner-computes-rows path)"), fx, bool(geos)
+
+    name, fx, ocr = mode_of(prob)
+    out = {"accumulation": name}
+    whole = ocr and not prob.jacobian()[1]._prepared["cw"].src.mode.startswith("ocrs")
+    if not (ab and whole):
+        return out
+    saved = configuration["ocr_fixed_point"]
+    try:
+        configuration["ocr_fixed_point"] = 0 if fx else 1
+        p2 = forms.PoissonProblem(prob.mesh, prob.degree, bcs=len(prob.bc_nodes) > 0)
+        for _ in range(3):
+            p2.assemble_jacobian()
+        ev = [(Event(), Event()) for _ in range(max(min(args.steps, 10), 3))]
+        for e in ev:
+            p2.assemble_jacobian(events=e)
+        _lib.call("fd_device_sync")
+        name2, fx2, _ = mode_of(p2)
+        out["other_accumulation"] = {"accumulation": name2, "kernel_ms": float(np.median([a.elapsed_ms(b) for a, b in ev])),
+                                     "switch": f"FDHIP_OCR_FIXED_POINT={0 if fx else 1}"}
+        del p2
+    except Exception as exc:
+        out["other_accumulation"] = {"error": repr(exc)}
+    finally:
+        configuration["ocr_fixed_point"] = saved
+    return out
+
+
+def poisson_line(args, ctx, degree, shape, scaling, label, numbering, variants, traffic, cpu=False, cpu_reps=None, accum_ab=False):
     """Measure residual + Jacobian assembly of Poisson CG<degree> on UnitCubeMesh(shape) box-partitioned over the ranks and
     return rank 0's result dict (None on the other ranks)."""
     from firedrake_amd import _lib, forms, mesh as fmesh
@@ -741,8 +808,10 @@ def poisson_line(args, ctx, degree, shape, scaling, label, numbering, variants, 
         jac_ocr = prob.jacobian()[1]._prepared["cw"].src.mode.startswith("ocr") if prob.jacobian()[1]._prepared else False
 
         def roof(kernel, ms, nbytes, **extra):
+            from firedrake_amd.kernel import last_launch
             d = {"kernel": kernel, "bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "ms": ms, "algorithmic_bytes": nbytes}
+                 "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "ms": ms, "algorithmic_bytes": nbytes,
+                 "grid": last_launch.get(kernel, (None,))[0]}
             d.update(extra)
             return d
 
@@ -763,6 +832,9 @@ def poisson_line(args, ctx, degree, shape, scaling, label, numbering, variants, 
             roof_jac = roof(kjac, res["jac_kernel_ms"], b, assemble_ms=res["jac_assemble_ms"],
                             frac_with_zeroing=bz / (res["jac_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             note="kernel-only; strict bytes (no credit for the zeroing pass the kernel makes unnecessary)")
+            # how the element matrices were ADDED in the timed launches (the reference: fp64, MatSetValuesLocal ADD_VALUES,
+            # builder.py:573-625), and -- whole-entity owner-computes-rows loops at N = 1 -- the other mode's kernel time beside it
+            roof_jac.update(jacobian_accumulation(prob, args, accum_ab and world == 1))
         roofs = [r for r in (roof_res, roof_jac) if r]
         dominant = max(roofs, key=lambda r: r["ms"])
         traffic_meta = None
@@ -882,7 +954,7 @@ def main():
     ap.add_argument("--n5", type=int, default=0, help="cubes per axis of the strong-scaling C5 cube appended at N > 1 (default 215)")
     ap.add_argument("--degree", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=1, help="0 = skip the CPU baseline (the oracle timed on the workload itself)")
-    ap.add_argument("--cpu-reps", type=int, default=2, help="timed repetitions of the CPU baseline (one more is dropped as warm-up)")
+    ap.add_argument("--cpu-reps", type=int, default=3, help="timed repetitions of the CPU baseline (one more is dropped as warm-up)")
     ap.add_argument("--no-bcs", action="store_true")
     ap.add_argument("--tile", type=str, default="8,8,4", help="cubes per traversal tile (= plan block)")
     ap.add_argument("--numbering", choices=["tiled", "lexicographic", "random"], default="lexicographic",
@@ -963,7 +1035,8 @@ def main():
         degree = args.degree or 1
         shape = (n * pg[0], n * pg[1], n * pg[2])        # weak scaling: every rank owns an n^3 cube of cubes
         out = poisson_line(args, ctx, degree, shape, "weak", "BASELINE.json configs[1] per GPU" if degree == 1 else f"CG{degree}, weak",
-                           args.numbering, args.variants, args.traffic == "auto", cpu=(args.cpu_sample > 0 and world == 1))
+                           args.numbering, args.variants, args.traffic == "auto", cpu=(args.cpu_sample > 0 and world == 1),
+                           accum_ab=not args.inner_pmc)
     if args.inner_pmc:
         # profiled child of collect_traffic(): the secondary configs' kernels in the same pass (a few launches each)
         if args.secondary and args.workload == "c2" and world == 1:
@@ -1023,7 +1096,7 @@ def main():
         guarded("secondary_c4", lambda: measure_c4(2048, max(3, args.steps // 2), 2, cpu_sample=512 if cs else 0))
         guarded("secondary_c5_share", lambda: poisson_line(args, ctx, 2, (107, 107, 107), "weak",
                                                              "one of the 8 partitions of BASELINE.json configs[4]", "lexicographic", "", False,
-                                                             cpu=cs, cpu_reps=1))
+                                                             cpu=cs, cpu_reps=3))
         guarded("secondary_c1", lambda: measure_c1(200, 3, with_cpu=cs))
         # BASELINE configs[4] as written -- the whole 215^3 CG2 cube, 2.29e9 nonzeros -- on this one device: the N = 1 anchor of the
         # strong-scaling curve the N > 1 lines append as "strong_c5" (row starts are 64-bit, include/fdhip.h fd_nnz_t)
@@ -1050,9 +1123,10 @@ def main():
                 "--workload", "c2"] + ([] if (args.secondary and args.only == "both") else ["--no-secondary"]) + (["--no-bcs"] if args.no_bcs else [])
         tr, out["traffic_meta"] = collect_traffic(tail, sorted({r["kernel"] for r in roofs}))
         for r in roofs:
-            if tr and r["kernel"] in tr:
-                r["traffic"] = tr[r["kernel"]]["hbm_bytes_per_launch"]
-                r["traffic_counters_kb"] = {"FETCH_SIZE": tr[r["kernel"]]["FETCH_SIZE_kb"], "WRITE_SIZE": tr[r["kernel"]]["WRITE_SIZE_kb"]}
+            c = match_traffic(tr, r)
+            if c:
+                r["traffic"] = c["hbm_bytes_per_launch"]
+                r["traffic_counters_kb"] = {"FETCH_SIZE": c["FETCH_SIZE_kb"], "WRITE_SIZE": c["WRITE_SIZE_kb"]}
                 if r.get("algorithmic_bytes"):
                     r["traffic_over_algorithmic"] = r["traffic"] / r["algorithmic_bytes"]
     if rank == 0:

@@ -94,6 +94,10 @@ def compile_hip(source: str, name: str, extra_flags=()) -> str:
     out = os.path.join(cache, f"{name}_{key}.hsaco")
     if os.path.exists(out):
         stats["cache_hits"] += 1
+        try:
+            os.utime(out)                 # "used now": evict_unused() removes code objects nothing has asked for in a while
+        except OSError:
+            pass
         return out
     stats["hipcc_runs"] += 1
     stats.setdefault("compiled", []).append(f"{name}_{key}")
@@ -152,3 +156,39 @@ def kernel_resources(path: str, symbol: str):
             return json.load(fh).get(symbol)
     except (OSError, ValueError):
         return None
+
+
+def evict_unused(max_age_hours=36.0, cache=None):
+    """Remove the code objects (with their sources and resource sidecars) that no process has asked for within ``max_age_hours``:
+    every change of fd_wrapper.h / fd_tensor.h / the compiler starts a new generation of keys, and the old generation can never be
+    hit again.  The reference leaves its cache to the user (pyop2/compilation.py:424-455, ``firedrake-clean``); here the cache ships
+    with the tree, so ``__graft_entry__.build()`` prunes it.  Returns (kept, removed) counts of code objects."""
+    import time
+    cache = cache or configuration["cache_dir"]
+    try:
+        names = os.listdir(cache)
+    except OSError:
+        return 0, 0
+    limit = time.time() - max_age_hours * 3600.0
+    live = {n[:-len(".hsaco")] for n in names if n.endswith(".hsaco") and os.path.getmtime(os.path.join(cache, n)) >= limit}
+    kept = removed = 0
+    for n in names:
+        stem = n
+        for suffix in (".hsaco.res.json", ".hsaco", ".hip"):
+            if n.endswith(suffix):
+                stem = n[:-len(suffix)]
+                break
+        else:
+            continue
+        if stem in live:
+            kept += n.endswith(".hsaco")
+            continue
+        path = os.path.join(cache, n)
+        if n.endswith(".hip") and os.path.getmtime(path) >= limit:
+            continue                      # a compile in flight (source written, code object not yet renamed into place)
+        try:
+            os.unlink(path)
+            removed += n.endswith(".hsaco")
+        except OSError:
+            pass
+    return kept, removed

@@ -504,6 +504,14 @@ int fd_csr_split_mpiaij(int32_t nrows_owned, const fd_nnz_t *rowptr, const int32
         FD_FAIL("fd_csr_split_mpiaij: bad arguments");
     hipStream_t s = fd::st(s_);
     const size_t n1 = (size_t)nrows_owned + 1;
+    {
+        // the two parts keep PETSc's 32-bit row starts (PetscInt without --with-64-bit-indices, pyop2/datatypes.py:6-10): a local
+        // pattern of 2^31 entries or more would overflow the scans below -- refused like the other 32-bit consumers of a pattern
+        fd_nnz_t last = 0;
+        FD_HIP(hipMemcpyAsync(&last, rowptr + nrows_owned, sizeof(fd_nnz_t), hipMemcpyDeviceToHost, s));
+        FD_HIP(hipStreamSynchronize(s));
+        if (last > (fd_nnz_t)INT32_MAX) FD_FAIL("fd_csr_split_mpiaij: the owned rows hold 2^31 entries or more; the MPIAIJ parts have 32-bit row starts");
+    }
     int32_t *dc = nullptr, *oc = nullptr, *drp = nullptr, *orp = nullptr, *dci = nullptr, *oci = nullptr, *ork = nullptr;
     void *tmp = nullptr;
     FD_HIP(hipMalloc(&dc, n1 * 4)); FD_HIP(hipMalloc(&oc, n1 * 4));

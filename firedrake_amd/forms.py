@@ -567,8 +567,8 @@ def precompile_all():
             modes = ["direct"] + (["staged"] if staged_eligible(gj) else []) + (["ocr"] if ocr_eligible(gj) else []) \
                 + (["ocrs"] if (ocr_eligible(gj) and sliced_eligible(gj)) else [])
             extra = [v for v in BENCH_VARIANTS[("jacobian", dim, degree)] if v.startswith("ocrs") == (ocr_eligible(gj) and sliced_eligible(gj))]
-            if not configuration["ocr_fixed_point"]:
-                extra = [v[:-3] if v.endswith("_fx") else v for v in extra]
+            # the default accumulates in fp64; the opt-in fixed-point variants ("_fx") are built too: bench.py times them beside
+            extra = extra + [v[:-3] for v in extra if v.endswith("_fx")]
             build(gj, modes + (extra if lg else []))
     # config C3: the tensor-product wrappers of the Q4 Helmholtz operator (matrix with and without BC lgmaps, action), also with
     # coefficient arguments

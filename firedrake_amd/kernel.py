@@ -494,6 +494,10 @@ class GlobalKernel:
         cw.launch(start, end, args, **launch)
 
 
+
+# symbol -> (work-items, workgroup size) of the most recent launch of a wrapper of that name (diagnostics; see CompiledWrapper.launch)
+last_launch = {}
+
 class CompiledWrapper:
     """A loaded wrapper kernel + the layout of its argument list."""
 
@@ -532,6 +536,11 @@ class CompiledWrapper:
 
     def launch(self, start, end, args, *, block_threads=256, ents_per_block=256, nblocks=-1, lds_bytes=0, stream=None):
         n = len(args)
+        if int(end) > int(start):
+            # work-items of this launch (what a profiler reports as the dispatch's grid size): lets a measurement script tell the
+            # launches of one wrapper on different problem sizes apart (bench.py keys its PMC results by (kernel, grid))
+            nb_ = int(nblocks) if int(nblocks) > 0 else -(-(int(end) - int(start)) // int(ents_per_block))
+            last_launch[self.src.symbol] = (nb_ * int(block_threads), int(block_threads))
         arr = (ctypes.c_void_p * max(n, 1))(*[ctypes.c_void_p(int(a) if a is not None else 0) for a in args])
         _lib.call("fd_kernel_launch", self.handle, int(start), int(end), arr, n, int(block_threads),
                   int(ents_per_block), int(nblocks), int(lds_bytes), stream)

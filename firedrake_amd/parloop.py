@@ -687,7 +687,8 @@ class Parloop:
             _lib.call("fd_leaf_labels", norder.ptr, nnodes, ns32.ctypes.data, nleaves, label_d.ptr, None)
             buf = DeviceBuffer(n * 4)
             counts = np.zeros(nleaves, dtype=np.int32)
-            _lib.call("fd_group_entities", pmap._dev_values(), pa.map_.arity, int(start), int(end), label_d.ptr, nnodes, nleaves,
+            # (the DERIVED map's arity: interior-facet rows of a virtual space hold both stacked cells)
+            _lib.call("fd_group_entities", pmap._dev_values(), pmap.arity, int(start), int(end), label_d.ptr, nnodes, nleaves,
                       buf.ptr, counts.ctypes.data, None)
             del label_d
             starts = LocalityOrder.cut(counts.astype(np.int64), target)
@@ -1022,6 +1023,11 @@ class Parloop:
                     cap = configuration["ocr_nnz_per_block_ordered"]
                     rb = row_order.tile_cuts(order.blocks, cap + cap // 10)
             if row_order is not None:
+                if int(row_order.prowptr_host[-1]) > 2 ** 31 - 1:
+                    # the whole-entity flush of a derived row order streams 32-bit places (RowOrder.gpos): refused HERE, where
+                    # _prepare still can demote the loop to the row-sliced / staged / direct shapes, not at launch time
+                    raise PlanDoesNotFit("whole-entity owner-computes-rows under a derived row order holds 32-bit places: "
+                                         "the pattern has 2^31 entries or more")
                 prp = row_order.prowptr_host
             if rb is None:
                 targets = np.arange(0, int(prp[nrows]) + cap, cap)
@@ -1083,10 +1089,14 @@ class Parloop:
                 and np.dtype(pa.data.dtype) == np.dtype("float64"):
             # checked fixed-point LDS accumulators (codegen mode suffix "_fx"): one 32-byte scale record per row block, written by the
             # block itself at the end of every launch (zero = no scale yet = an fp64 pass), and two counters
-            variant += "_fx"
-            fxbufs = (DeviceBuffer(max(op.nblocks, 1) * 32), DeviceBuffer(16))
-            for b_ in fxbufs:
-                b_.zero()
+            # The 63-bit sums hold 2^12 contributions of |x S| < 2^50 per entry: an entry (r, c) collects at most one contribution per
+            # entity around row node r, so the bound is the largest entity valence of a row node; maps that exceed it (degenerate or
+            # star-shaped meshes) keep the fp64 atomics
+            if self._max_row_valence(rmap, start, end) < 4096:
+                variant += "_fx"
+                fxbufs = (DeviceBuffer(max(op.nblocks, 1) * 32), DeviceBuffer(16))
+                for b_ in fxbufs:
+                    b_.zero()
         geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz, "rec": rec, "fx": fxbufs,
                "cw": prep["cw"] if variant == src.mode else self.global_kernel.compile(variant), "row_order": row_order}
         prep["parts"][gkey] = geo
@@ -1286,6 +1296,13 @@ class Parloop:
                 raise AssertionError(kind)
         cw.launch(0, op.ninst, out, block_threads=src.block_threads, ents_per_block=op.max_inst, nblocks=op.nblocks,
                   lds_bytes=geo["lds"])
+
+    @staticmethod
+    def _max_row_valence(rmap, start, end):
+        """Largest number of entities of [start, end) around one node of ``rmap`` (host pass, opt-in fixed-point mode only)."""
+        vals = np.asarray(rmap.values_with_halo if hasattr(rmap, "values_with_halo") else rmap.values)[start:end].ravel()
+        vals = vals[vals >= 0]
+        return int(np.bincount(vals).max()) if len(vals) else 0
 
     def fixed_point_state(self):
         """Diagnostics of the checked fixed-point accumulation of this loop's owner-computes-rows parts (blocks the stream): per

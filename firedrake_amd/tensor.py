@@ -6,6 +6,8 @@ CG_k with GLL nodes, Gauss-Legendre quadrature from ``dx(degree=...)``, tsfc/fem
 available here, so the 1-D Lagrange tabulation is computed directly."""
 from __future__ import annotations
 
+import re
+
 import numpy as np
 
 
@@ -62,10 +64,10 @@ static inline void NAME_weights(const double J[3][3], const double X[3], double 
 
 def second_order_weights(name, alpha=1.0, beta=1.0, velocity=(0.0, 0.0, 0.0)):
     """``weights_code`` of a(u, v) = int alpha grad(u).grad(v) + (b.grad(u)) v + beta u v dx, b = ``velocity``."""
-    out = SECOND_ORDER_WEIGHTS.replace("NAME", name).replace("ALPHA", repr(float(alpha))).replace("BETA", repr(float(beta)))
+    out = SECOND_ORDER_WEIGHTS.replace("ALPHA", repr(float(alpha))).replace("BETA", repr(float(beta)))
     for tag, v in zip(("BX", "BY", "BZ"), velocity):
         out = out.replace(tag, repr(float(v)))
-    return out
+    return out.replace("NAME_weights", name + "_weights")          # the name LAST: it may contain the parameter tokens
 
 
 # a(u, v) = int kappa grad(u).grad(v) + c u v dx with kappa and c FUNCTIONS of the point and of coefficient fields: the shape of a
@@ -90,7 +92,7 @@ static inline void NAME_weights(const double J[3][3], const double X[3], double 
 
 def coefficient_weights(name, kappa="1.0", react="1.0"):
     """``weights_code`` of a(u, v) = int kappa grad(u).grad(v) + react u v dx, kappa / react C expressions in C[] and X[]."""
-    return COEFFICIENT_WEIGHTS.replace("NAME", name).replace("KAPPA", f"({kappa})").replace("REACT", f"({react})")
+    return COEFFICIENT_WEIGHTS.replace("KAPPA", f"({kappa})").replace("REACT", f"({react})").replace("NAME_weights", name + "_weights")
 
 
 # The Jacobian of F(u; v) = int (1 + |grad u|^2) grad(u).grad(v) dx at u0 (coefficient 0, with its REFERENCE gradient DC[0..2]):
@@ -118,7 +120,7 @@ static inline void NAME_weights(const double J[3][3], const double X[3], double 
 
 def nonlinear_diffusion_weights(name):
     """``weights_code`` (coef_gradients=True, ncoef=1) of the Newton Jacobian of int (1 + |grad u|^2) grad(u).grad(v) dx at u0."""
-    return NONLINEAR_DIFFUSION_WEIGHTS.replace("NAME", name)
+    return NONLINEAR_DIFFUSION_WEIGHTS.replace("NAME_weights", name + "_weights")
 
 
 # Linear elasticity on (Q_k)^3:  a(u, v) = int 2 mu eps(u):eps(v) + lambda div(u) div(v) + rho u.v dx.  With v = e_p phi_i, u = e_r phi_j:
@@ -146,4 +148,9 @@ static inline void NAME_weights(const double J[3][3], const double X[3], double 
 
 def elasticity_weights(name, mu=1.0, lam=1.0, rho=0.0):
     """``weights_code`` (vdim=3) of a(u, v) = int 2 mu eps(u):eps(v) + lam div(u) div(v) + rho u.v dx."""
-    return ELASTICITY_WEIGHTS.replace("NAME", name).replace("MU", repr(float(mu))).replace("LAMBDA", repr(float(lam))).replace("RHO", repr(float(rho)))
+    # parameters first, the name LAST: a kernel name containing "MU" / "LAMBDA" / "RHO" (Firedrake's kernel names are arbitrary
+    # identifiers) must not have its letters replaced by a float literal
+    text = ELASTICITY_WEIGHTS
+    for token, value in (("LAMBDA", lam), ("MU", mu), ("RHO", rho)):
+        text = re.sub(r"\b%s\b" % token, repr(float(value)), text)
+    return text.replace("NAME_weights", name + "_weights")

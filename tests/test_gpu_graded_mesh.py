@@ -1,0 +1,136 @@
+"""GPU: row-relative accuracy of the matrix path on a geometrically GRADED tetrahedral mesh.
+
+The reference adds element matrices in fp64 (``MatSetValuesLocal(..., ADD_VALUES)``, pyop2/codegen/builder.py:573-625), so every
+assembled row is accurate relative to ITS OWN entries however small they are beside the rest of the matrix.  A parity statement
+of the form ``1e-12 * max|A|`` cannot see a backend that is only normwise accurate: on a mesh whose cells shrink by a factor 4 per
+layer towards the origin, one row block of the owner-computes-rows plan mixes cells whose sizes differ by > 10^3 (stiffness
+entries scale with h, mass entries with h^3: > 10^9 inside a block), and the rows of the small cells sit far below the block's and
+the matrix's largest entry.  These tests hold the DEFAULT accumulation to ``1e-13 * max|row|`` per row, and check that no entry the
+oracle holds as non-zero comes back as zero.  The opt-in fixed-point accumulation (``FDHIP_OCR_FIXED_POINT=1``) is held to what
+it promises -- the normwise bound -- and is shown NOT to meet the row-relative one on the mass matrix of this mesh, which is why
+it is not the default."""
+import numpy as np
+import pytest
+
+from firedrake_amd import forms, mesh as fmesh, op2
+from firedrake_amd.configuration import configuration
+from helpers import oracle_run
+
+pytestmark = pytest.mark.gpu
+
+RATIO = 4.0           # size ratio of consecutive cell layers
+N = 12
+
+
+def graded_mesh(numbering, degree=1):
+    m = fmesh.UnitCubeMesh(N, degrees=(degree,), perturb=0.0, numbering=numbering)
+    x = m.coordinates.data                                # (bumps dat_version)
+    i = np.rint(np.asarray(x) * N)                        # lattice index of every vertex
+    x[...] = (RATIO ** i - 1.0) / (RATIO ** N - 1.0)
+    return m
+
+
+def matrix_loop(m, kernel, degree=1, bcs=False):
+    V = m.space(degree)
+    cm, xm = V.cell_node_map, m.coord_space.cell_node_map
+    sp = op2.Sparsity((V.node_set ** 1, V.node_set ** 1), [(cm, cm, None)])
+    mat = op2.Mat(sp)
+    lg = None
+    if bcs:
+        rlg = np.arange(V.node_set.total_size, dtype=np.int32)
+        rlg[V.boundary_nodes] = -1
+        lg = (rlg, rlg.copy())
+    loop = op2.LegacyParloop(kernel, m.cell_set, mat(op2.INC, (cm, cm), lgmaps=lg), m.coordinates(op2.READ, xm))
+    return mat, loop, (cm, lg, xm)
+
+
+def assemble_and_reference(m, kernel, degree=1, bcs=False, launches=2):
+    mat, loop, (cm, lg, xm) = matrix_loop(m, kernel, degree, bcs)
+    for _ in range(launches):                              # (the second launch is the one a fixed-point plan runs on its scales)
+        mat.zero()
+        loop.compute()
+    ref = oracle_run(kernel, m.cell_set, mat(op2.INC, (cm, cm), lgmaps=lg), m.coordinates(op2.READ, xm))[0]
+    rowptr, _, v = mat.csr()
+    return np.asarray(rowptr), np.asarray(v), np.asarray(ref.values), loop
+
+
+def row_relative_error(rowptr, v, ref):
+    """max over rows of max_j |v_rj - ref_rj| / max_j |ref_rj| (rows without entries or all-zero rows are skipped)."""
+    starts = rowptr[:-1]
+    live = np.diff(rowptr) > 0
+    rmax = np.zeros(len(starts))
+    emax = np.zeros(len(starts))
+    rmax[live] = np.maximum.reduceat(np.abs(ref), starts[live])
+    emax[live] = np.maximum.reduceat(np.abs(v - ref), starts[live])
+    ok = rmax > 0
+    return (emax[ok] / rmax[ok]).max(), rmax[ok].max() / rmax[ok].min()
+
+
+@pytest.mark.parametrize("numbering", ["tiled", "lexicographic"])
+@pytest.mark.parametrize("form", ["stiffness", "mass", "helmholtz"])
+def test_default_accumulation_is_accurate_relative_to_every_row(form, numbering, monkeypatch):
+    monkeypatch.setitem(configuration, "locality_min_entities", 64)
+    assert int(configuration["ocr_fixed_point"]) == 0          # the default adds in fp64
+    m = graded_mesh(numbering)
+    kernel = {"stiffness": forms.poisson_jacobian_kernel, "mass": forms.mass_kernel, "helmholtz": forms.helmholtz_kernel}[form](3, 1)
+    rowptr, v, ref, loop = assemble_and_reference(m, kernel, bcs=(form == "stiffness"))
+    geo = [g for key, g in loop._prepared["parts"].items() if key[0] == "ocr"][0]
+    assert not geo["cw"].src.mode.endswith("_fx")
+    err, spread = row_relative_error(rowptr, v, ref)
+    # the rows span > 9 decades (stiffness ~ h: 4^11; mass ~ h^3: 4^33): a normwise statement says nothing about most of them
+    assert spread > (1e6 if form != "mass" else 1e18)
+    assert err <= 1e-13, err
+    assert not np.any((ref != 0.0) & (v == 0.0))
+    assert np.abs(v - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_row_sliced_p2_matrix_is_accurate_relative_to_every_row(monkeypatch):
+    """The row-sliced wrapper (CG2) adds in fp64 in every mode."""
+    monkeypatch.setitem(configuration, "locality_min_entities", 64)
+    m = graded_mesh("lexicographic", degree=2)
+    rowptr, v, ref, loop = assemble_and_reference(m, forms.poisson_jacobian_kernel(3, 2), degree=2)
+    geo = [g for key, g in loop._prepared["parts"].items() if key[0] == "ocr"][0]
+    assert geo["cw"].src.mode.startswith("ocrs")
+    err, spread = row_relative_error(rowptr, v, ref)
+    assert spread > 1e6 and err <= 1e-13, (err, spread)
+    assert not np.any((ref != 0.0) & (v == 0.0))
+
+
+def test_opt_in_fixed_point_is_normwise_only_on_a_graded_mesh(monkeypatch):
+    """What the opt-in promises and what it does not: the mass matrix of the graded mesh stays within the normwise bound (and within
+    2^-44 of every row BLOCK's largest contribution), but rows of the small cells lose their relative accuracy -- entries below the
+    block's quantum come back as zero.  The test documents the reason for the default."""
+    monkeypatch.setitem(configuration, "ocr_fixed_point", 1)
+    monkeypatch.setitem(configuration, "locality_min_entities", 64)
+    m = graded_mesh("lexicographic")
+    rowptr, v, ref, loop = assemble_and_reference(m, forms.mass_kernel(3, 1))
+    geo = [g for key, g in loop._prepared["parts"].items() if key[0] == "ocr"][0]
+    assert geo["cw"].src.mode.endswith("_fx")
+    (st,) = loop.fixed_point_state()
+    assert st["scaled_blocks"] > 0
+    assert np.abs(v - ref).max() <= 1e-12 * np.abs(ref).max()
+    err, _ = row_relative_error(rowptr, v, ref)
+    assert err > 1e-13                                         # not row-relative: this is the hole the default closes
+
+
+def test_fixed_point_refuses_maps_with_too_many_contributions_per_entry(monkeypatch):
+    """The 63-bit sums hold 2^12 contributions per entry; a star of 5000 triangles around one vertex exceeds that, and the loop keeps
+    the fp64 atomics although fixed point was asked for."""
+    monkeypatch.setitem(configuration, "ocr_fixed_point", 1)
+    nt = 5000
+    ang = np.linspace(0.0, 2 * np.pi, nt, endpoint=False)
+    coords = np.concatenate([[[0.0, 0.0]], np.stack([np.cos(ang), np.sin(ang)], axis=1)])
+    cells = np.stack([np.zeros(nt, dtype=np.int32), 1 + np.arange(nt, dtype=np.int32), 1 + (np.arange(nt, dtype=np.int32) + 1) % nt], axis=1)
+    nodes, ele = op2.Set(len(coords)), op2.Set(nt)
+    cm = op2.Map(ele, nodes, 3, cells)
+    x = op2.Dat(nodes ** 2, coords)
+    mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(cm, cm, None)]))
+    kernel = forms.mass_kernel(2, 1)
+    loop = op2.LegacyParloop(kernel, ele, mat(op2.INC, (cm, cm)), x(op2.READ, cm))
+    loop.compute()
+    ocr = [g for key, g in loop._prepared["parts"].items() if key[0] == "ocr"]
+    if ocr:                                                    # (a plan that does not fit takes another wrapper altogether)
+        assert not ocr[0]["cw"].src.mode.endswith("_fx")
+    ref = oracle_run(kernel, ele, mat(op2.INC, (cm, cm)), x(op2.READ, cm))[0]
+    v = np.asarray(mat.csr()[2])
+    assert np.abs(v - ref.values).max() <= 1e-12 * np.abs(ref.values).max()

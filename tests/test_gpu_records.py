@@ -144,10 +144,11 @@ def test_p2_jacobian_with_compact_tables_matches_oracle(numbering, records, runs
 
 @pytest.mark.parametrize("numbering", ["lexicographic", "tiled"])
 def test_fixed_point_accumulators_give_the_oracle_matrix_bit_reproducibly(numbering, monkeypatch):
-    """Checked fixed-point accumulation (codegen mode "_fx", the default of whole-entity owner-computes-rows loops): the first
+    """Checked fixed-point accumulation (codegen mode "_fx", FDHIP_OCR_FIXED_POINT=1: opt-in for whole-entity owner-computes-rows loops): the first
     launch of a plan has no scales and runs fp64 blocks, each of which leaves the scale record of its next launch; from the second
     launch on the element matrices are reduced as 64-bit integers.  The P1 Jacobian is the oracle's to 1e-12 max|A| either way, and
     -- the sums being exact integers -- the same BITS whatever the order of the instances inside the blocks."""
+    monkeypatch.setitem(configuration, "ocr_fixed_point", 1)          # opt-in since round 6 (normwise guarantee only)
     monkeypatch.setitem(configuration, "locality_min_entities", 64)
     m = fmesh.UnitCubeMesh(14, degrees=(1,), perturb=0.1, numbering=numbering)
     prob = forms.PoissonProblem(m, 1, bcs=True)
@@ -187,6 +188,7 @@ def test_fixed_point_blocks_fall_back_to_fp64_when_the_contributions_leave_the_w
     the block redoes its rows with fp64 atomics inside the same launch: the matrix is right, the fallbacks are counted, and the next
     launch runs fixed-point again at the new scales.  Non-finite contributions: the blocks that meet them fall back, NaN lands
     where fp64 puts it, the rest of the matrix is untouched."""
+    monkeypatch.setitem(configuration, "ocr_fixed_point", 1)
     monkeypatch.setitem(configuration, "locality_min_entities", 64)
     m = fmesh.UnitCubeMesh(12, degrees=(1,), perturb=0.1, numbering="lexicographic")
     prob = forms.PoissonProblem(m, 1, bcs=True)
