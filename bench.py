@@ -889,6 +889,32 @@ def poisson_line(args, ctx, degree, shape, scaling, label, numbering, variants, 
     return out
 
 
+def redundant_instances_frac(prob):
+    """Share of this rank's owner-computes-rows Jacobian instances that sit on GHOST cells -- cells another rank owns and this one
+    evaluates again so that its own rows are complete without a matrix exchange (SURVEY.md 8e option 1; the reference ships the
+    foreign rows in MatAssemblyBegin/End instead, mat.py:776, 940-954).  None when the loop took another wrapper."""
+    try:
+        loop = prob.jacobian()[1]
+        ncell_owned = prob.mesh.cell_set.size
+        tot = red = 0
+        for key, geo in (loop._prepared or {}).get("parts", {}).items():
+            if key[0] != "ocr" or not isinstance(geo, dict):
+                continue
+            op = geo["ocr"]
+            if op.ninst == 0:
+                continue
+            from firedrake_amd.device import DeviceBuffer
+            ent = DeviceBuffer.wrap(op.inst_ent, int(op.ninst) * 4, owned=False).download(np.int32, (int(op.ninst),))
+            live = np.ones(len(ent), dtype=bool)
+            if getattr(op, "valid", None):
+                live = DeviceBuffer.wrap(op.valid, int(op.ninst), owned=False).download(np.uint8, (int(op.ninst),)) != 0
+            tot += int(live.sum())
+            red += int((live & (ent >= ncell_owned)).sum())
+        return red / tot if tot else None
+    except Exception:
+        return None
+
+
 def multi_gpu_detail(prob, args, res, ctx):
     """N > 1 (SURVEY.md 8e deliverables): ranks of the library's own communicator, the wire in use, the halo traffic of one
     step on its own, per-rank kernel times, and how much of the exchange the core-entity kernel hides (parloop.py:250-253)."""
@@ -921,6 +947,7 @@ def multi_gpu_detail(prob, args, res, ctx):
     k_only = float(np.median([a.elapsed_ms(b) for a, b in ev]))
     mine = {"rank": rank, "residual_kernel_only_ms": k_only, "residual_with_exchange_ms": res["res_kernel_ms"],
             "jacobian_kernel_ms": res["jac_kernel_ms"], "exchange_ms": exch,
+            "jacobian_redundant_instances_frac": redundant_instances_frac(prob),
             "halo_rows": {"send": int(sum(len(v) for v in h.lists.send.values())), "recv": int(sum(len(v) for v in h.lists.recv.values())),
                           "neighbours": len(set(h.lists.send) | set(h.lists.recv))} if h is not None else None}
     allr = [None] * world
@@ -941,7 +968,8 @@ def multi_gpu_detail(prob, args, res, ctx):
         overheads = {name: partition_overheads(shape, world, name, deg) for name in ("slabs", "blocks")}
     return {"n_gpus": n_comm, "wire": wire, "communicator": fhalo.communicator_status(), "exchange_ms": emax, "partition_overheads": overheads,
             "residual_kernel_only_ms": kmax, "residual_with_exchange_ms": wmax, "exchange_hidden_ms": hidden,
-            "exchange_hidden_frac": hidden / emax if emax > 0 else None, "per_rank": allr}
+            "exchange_hidden_frac": hidden / emax if emax > 0 else None,
+            "jacobian_redundant_instances_frac": max((r.get("jacobian_redundant_instances_frac") or 0.0) for r in allr), "per_rank": allr}
 
 
 def main():

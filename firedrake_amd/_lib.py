@@ -111,6 +111,11 @@ SIGNATURES = {
     "fd_ocrplan_free": (c_int, [c_void_p]),
     "fd_ocrplan_create_sliced": (c_int, [c_void_p, c_int, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int, c_void_p,
                                          POINTER(c_void_p)]),
+    "fd_ocrplan_create_paired": (c_int, [c_void_p, c_int, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int, c_int, c_void_p,
+                                         c_void_p, POINTER(c_void_p)]),
+    "fd_ocrplan_pair_counts": (c_int, [c_void_p, c_int, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
+    "fd_ocr_pack_records_rows": (c_int, [c_int64, c_int, POINTER(c_void_p), POINTER(c_int32), POINTER(c_int32), c_void_p, c_int, c_int, c_int,
+                                         c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "fd_ocrplan_sliced_arrays": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64)]),
     "fd_ocrplan_sliced_tables": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -1173,6 +1173,15 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     if rq_:
         rec = {"lbits": [int(v) for v in rq_.group(1).split("x")], "kbits": int(rq_.group(2)), "sbits": int(rq_.group(3))}
         mode = mode[:rq_.start()]
+    # "_g<pairs>": two rows per instance (fd_ocrplan_create_paired) -- the local rows in groups of two (one), two characters per group
+    # (group_code); the chunk role is the group, one evaluation of the local kernel feeds both rows' accumulators
+    gq_ = re.search(r"_g([0-9a-vz]+)$", mode)
+    groups = None
+    if gq_:
+        groups = decode_groups(gq_.group(1))
+        mode = mode[:gq_.start()]
+        if rec is None:
+            raise ValueError("paired instances come with instance records")
     ordered = mode.startswith("ocrsp")
     # "ocrspr": the flush of a derived row order through run-coded places (one byte per entry + one displacement per run of
     # CSR-consecutive rows in LDS, fd_ocr_row_runs) instead of row by row
@@ -1377,13 +1386,17 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
             for i in range(maps[mi].arity * nf):
                 fields.append((f"lm{mi}[{i}]", off, lb))
                 off += lb
-        for j in range(AC):
-            fields.append((f"kk[{j}]", off, rec["kbits"]))
-            off += rec["kbits"]
-        fields.append(("const int slot", off, rec["sbits"]))
-        off += rec["sbits"]
+        NRI = 2 if groups else 1                          # rows per instance: kk / slot of row s carry the suffix s
+        for s_ in range(NRI):
+            for j in range(AC):
+                fields.append((f"kk{s_ if groups else ''}[{j}]", off, rec["kbits"]))
+                off += rec["kbits"]
+        for s_ in range(NRI):
+            fields.append((f"const int slot{s_ if groups else ''}", off, rec["sbits"]))
+            off += rec["sbits"]
         W = -(-off // 32)
-        rec_decode = [f"int lm{mi}[{maps[mi].arity * nf}];" for mi in staged_maps] + [f"int kk[{AC}];"]
+        rec_decode = [f"int lm{mi}[{maps[mi].arity * nf}];" for mi in staged_maps] + \
+            ([f"int kk0[{AC}], kk1[{AC}];"] if groups else [f"int kk[{AC}];"])
         rec_decode += [f"{name} = fdw::rec_field<{o}, {b}>(rc);" for name, o, b in fields]
         rows = [("rc", W, f"fdw::load_rec<{W}>(oc{K}_rec + (size_t)(II - start)*{W}, DST);")]
         scal = [("role", "(int)chunk_role_[(II - start) >> 6]")]
@@ -1398,7 +1411,31 @@ def generate_sliced_wrapper(gk: GlobalKernel, mode: str) -> WrapperSource:
     # arithmetic its row needs)
     switch_src = ["    switch (fdw::wave_uniform(role)) {"]
     NT = AR * RB * AC * CB
-    for r in range(AR):
+    if groups:
+        if B != 1 or dofmask or sorted(r for g in groups for r in g if r is not None) != list(range(AR)):
+            raise ValueError("paired instances: scalar matrices, node lgmaps, the groups a partition of the local rows")
+        def inst_(rows_):
+            # one instantiation of the local kernel that keeps the rows ``rows_`` = [(s, local row), ...] of its output
+            out_ = [f"        double t{K}[{NT}]; for (int q = 0; q < {NT}; ++q) t{K}[q] = 0;",
+                    f"        fdk::{lk.name}({', '.join(call_args)});"]
+            for s__, lr in rows_:
+                out_.append(f"        if (slot{s__} != {slot_skip}) {{ for (int j = 0; j < {AC}; ++j) if (kk{s__}[j] != {skip}) "
+                            f"atomicAdd(&sm{K}[slot{s__} + kk{s__}[j]], t{K}[{lr * AC} + j]); }}")
+            return out_
+        for gi, (ra, rb_) in enumerate(groups):
+            if rb_ is None:
+                switch_src += [f"    case {gi}: {{", "      {", *inst_([(0, ra)]), "      }", "    } break;"]
+                continue
+            # the instances of a group are sorted by ownership class (both rows / the first / the second only: fd_ocrplan_create_paired),
+            # so nearly every wavefront needs ONE of three instantiations -- and the one-row instantiations carry no arithmetic of
+            # the row nobody in the wavefront owns
+            switch_src += [f"    case {gi}: {{",
+                           f"      const bool fd_w0 = fdw::wave_any(slot0 != {slot_skip}), fd_w1 = fdw::wave_any(slot1 != {slot_skip});",
+                           "      if (fd_w0 && fd_w1) {", *inst_([(0, ra), (1, rb_)]),
+                           "      } else if (fd_w0) {", *inst_([(0, ra)]),
+                           "      } else if (fd_w1) {", *inst_([(1, rb_)]),
+                           "      }", "    } break;"]
+    for r in ([] if groups else range(AR)):
         # element tensor t[(i*rbs + p)][(j*cbs + q)] (builder.py:573-625); CSR: scalar row (node, p) starts at
         # node_rowptr[node]*B + p*rowlen*cbs, column (k-th node of the row, q) sits at k*cbs + q
         rg = "if ((rmask >> p) & 1) " if dofmask else ""
@@ -1540,19 +1577,36 @@ def record_layout(arities, max_nds, nr, nc, maxlen, same_map):
     return lbits, kbits, diag, -(-bits // 32)
 
 
-def sliced_record_layout(arities, max_nds, nc, maxlen, max_nnz):
+def sliced_record_layout(arities, max_nds, nc, maxlen, max_nnz, rows=1):
     """Field widths of the bit-packed instance records of a row-sliced loop (generate_sliced_wrapper, "_q...e" suffix): (lbits per
-    staged map, kbits, sbits, words per instance); the all-ones value of the position and slot fields means "dropped"."""
+    staged map, kbits, sbits, words per instance); the all-ones value of the position and slot fields means "dropped".  ``rows``
+    = rows per instance (2: paired instances -- two rows of positions, two slots)."""
     lbits = [max(int(n - 1).bit_length(), 1) for n in max_nds]
     kbits = max(int(maxlen).bit_length(), 1)              # positions 0 .. maxlen-1 and the all-ones marker
     sbits = max(int(max_nnz).bit_length(), 1)
-    bits = sum(a * b for a, b in zip(arities, lbits)) + nc * kbits + sbits
+    bits = sum(a * b for a, b in zip(arities, lbits)) + rows * (nc * kbits + sbits)
     return lbits, kbits, sbits, -(-bits // 32)
 
 
-def mode_variant(base: str, kbytes: int, max_nds, rec=None) -> str:
-    """Name of the wrapper variant for a launch geometry: base mode [+ _k16] [+ _q<record fields>] [+ _s<strides>]."""
+_GROUP_CHARS = "0123456789abcdefghijklmnopqrstuv"
+
+
+def group_code(groups) -> str:
+    """Two characters per group of local rows (rows 0..31 as one base-32 digit, 'z' = no second row)."""
+    return "".join(_GROUP_CHARS[a] + ("z" if b is None else _GROUP_CHARS[b]) for a, b in groups)
+
+
+def decode_groups(code: str):
+    if len(code) % 2:
+        raise ValueError(f"bad group code {code!r}")
+    return tuple((_GROUP_CHARS.index(code[i]), None if code[i + 1] == "z" else _GROUP_CHARS.index(code[i + 1])) for i in range(0, len(code), 2))
+
+
+def mode_variant(base: str, kbytes: int, max_nds, rec=None, groups=None) -> str:
+    """Name of the wrapper variant for a launch geometry: base mode [+ _k16] [+ _g<row groups>] [+ _q<record fields>] [+ _s<strides>]."""
     m = base + ("_k16" if kbytes == 2 else "")
+    if groups is not None:
+        m += "_g" + group_code(groups)
     if rec is not None and base.startswith("ocrs"):
         lbits, kbits, sbits = rec[:3]
         m += "_q" + "x".join(str(b) for b in lbits) + f"k{kbits}e{sbits}"

@@ -32,6 +32,9 @@ configuration = {
     "tensor_wrappers": _env("FDHIP_TENSOR_WRAPPERS", 1, int),   # MFMA matrix / sum-factorised action for TensorProductLocalKernels
     "mat_ocr": _env("FDHIP_MAT_OCR", 1, int),             # owner-computes-rows matrix assembly (no global atomics)
     "ocr_sliced": _env("FDHIP_OCR_SLICED", 1, int),       # row-sliced instances (entity, local row) for large element matrices
+    # row-sliced loops on scalar matrices: TWO local rows per instance sharing one evaluation of the local kernel and one index
+    # record (fd_ocrplan_create_paired; the pairs are picked from the rows' co-ownership counts), 0 = one row per instance
+    "ocrs_pairs": _env("FDHIP_OCRS_PAIRS", 1, int),
     "ocr_records": _env("FDHIP_OCR_RECORDS", 1, int),     # one bit-packed record per instance (0 = uint16 / uint8 index rows)
     # 1 = whole-entity owner-computes-rows loops (scalar fp64 matrices) reduce their element matrices in LDS as CHECKED 64-bit
     # fixed-point sums through integer atomics (codegen "_fx": exact, order-independent sums of contributions ROUNDED to a quantum of

@@ -744,6 +744,11 @@ struct fd_ocrplan_s {
     uint8_t *valid = nullptr;
     int64_t nreal = 0;
     int sliced_ar = 0;
+    // row GROUPS of a sliced plan: an instance is (entity, group); a group names one local row (fd_ocrplan_create_sliced: group i =
+    // row i) or two (fd_ocrplan_create_paired: both rows share one evaluation of the local kernel).  groles[2g], groles[2g+1]
+    // (device; 255 = none); rows_per_inst = 1 or 2 = rows of the per-instance tables
+    int ngroups = 0, rows_per_inst = 1;
+    uint8_t *groles = nullptr;
 };
 
 namespace {
@@ -908,16 +913,61 @@ __global__ void ocrs_emit(const int32_t *__restrict__ rmap, int ar, int32_t star
     }
 }
 
+// paired groups: one thread per (entity, group) writes TWO key slots -- the instance of the block that owns the group's first row,
+// and a second instance when the other row belongs to a different block (a row that no block owns gives none)
+__global__ void ocrs_emit_pairs(const int32_t *__restrict__ rmap, int ar, int32_t start, int32_t end, const int32_t *__restrict__ rblk,
+                                int32_t nblocks, uint64_t *__restrict__ keys, const int32_t *__restrict__ pinv, int32_t npos,
+                                const uint8_t *__restrict__ groles, int ng) {
+    const int64_t total = ((int64_t)end - start) * ng;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = start + t / ng;
+        const int g = (int)(t % ng);
+        const int ra = groles[2 * g], rb = groles[2 * g + 1];
+        int32_t ba = -1, bb = -1;
+        { const int32_t r = row_position(pinv, npos, rmap[e * ar + ra]); if (r >= 0) ba = block_of_node(rblk, nblocks, r); }
+        if (rb != 255) { const int32_t r = row_position(pinv, npos, rmap[e * ar + rb]); if (r >= 0) bb = block_of_node(rblk, nblocks, r); }
+        // ownership class of an instance (bits 31..32, between group and entity): 0 = the block owns both rows, 1 = the first only,
+        // 2 = the second only.  Sorting by it makes the wavefronts of a group (nearly) uniform in what they have to compute.
+        uint64_t ca = 1, cb = 2;
+        if (ba >= 0 && bb == ba) { ca = 0; bb = -1; }
+        else if (ba < 0) { ba = bb; bb = -1; ca = 2; }
+        keys[2 * t] = ba >= 0 ? (((uint64_t)ba << 39) | ((uint64_t)g << 33) | (ca << 31) | (uint64_t)(uint32_t)e) : ~0ull;
+        keys[2 * t + 1] = bb >= 0 ? (((uint64_t)bb << 39) | ((uint64_t)g << 33) | (cb << 31) | (uint64_t)(uint32_t)e) : ~0ull;
+    }
+}
+
+// co-ownership counts of the local rows: cnt[a*ar + b] = entities whose rows a and b (a < b) fall into the same row block
+__global__ void ocrs_pair_counts_k(const int32_t *__restrict__ rmap, int ar, int32_t start, int32_t end, const int32_t *__restrict__ rblk,
+                                   int32_t nblocks, const int32_t *__restrict__ pinv, int32_t npos, unsigned long long *__restrict__ cnt) {
+    __shared__ unsigned int sc[32 * 32];
+    for (int q = threadIdx.x; q < ar * ar; q += blockDim.x) sc[q] = 0;
+    __syncthreads();
+    for (int64_t e = start + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < end; e += (int64_t)gridDim.x * blockDim.x) {
+        int32_t blk[32];
+        for (int i = 0; i < ar; ++i) {
+            const int32_t r = row_position(pinv, npos, rmap[e * ar + i]);
+            blk[i] = r >= 0 ? block_of_node(rblk, nblocks, r) : -1;
+        }
+        for (int a = 0; a < ar; ++a)
+            for (int b = a + 1; b < ar; ++b)
+                if (blk[a] >= 0 && blk[a] == blk[b]) atomicAdd(&sc[a * ar + b], 1u);
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < ar * ar; q += blockDim.x) if (sc[q]) atomicAdd(&cnt[q], (unsigned long long)sc[q]);
+}
+
 // segment (block, role) boundaries of the sorted keys: sstart/send per dense segment id b*ar + role; nvalid = number of real keys
+// (shift = first bit of the role / group field: 31 for (entity, row) keys, 33 for paired keys whose bits 31..32 hold the ownership class)
 __global__ void ocrs_bounds(const uint64_t *__restrict__ keys, int64_t n, int ar, int32_t *__restrict__ sstart, int32_t *__restrict__ send,
-                            int64_t *__restrict__ nvalid) {
+                            int64_t *__restrict__ nvalid, int shift) {
+    const uint64_t gmask = (1ull << (39 - shift)) - 1ull;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t k = keys[t];
         if (k == ~0ull) continue;
-        const uint64_t seg = k >> 31;
-        const int64_t id = (int64_t)(seg >> 8) * ar + (int64_t)(seg & 255u);
-        if (t == 0 || (keys[t - 1] >> 31) != seg) sstart[id] = (int32_t)t;
-        if (t + 1 == n || keys[t + 1] == ~0ull || (keys[t + 1] >> 31) != seg) send[id] = (int32_t)(t + 1);
+        const uint64_t seg = k >> shift;
+        const int64_t id = (int64_t)(seg >> (39 - shift)) * ar + (int64_t)(seg & gmask);
+        if (t == 0 || (keys[t - 1] >> shift) != seg) sstart[id] = (int32_t)t;
+        if (t + 1 == n || keys[t + 1] == ~0ull || (keys[t + 1] >> shift) != seg) send[id] = (int32_t)(t + 1);
         if (t + 1 == n || keys[t + 1] == ~0ull) *nvalid = t + 1;
     }
 }
@@ -931,9 +981,21 @@ __global__ void ocrs_padded_counts(const int32_t *__restrict__ sstart, const int
 // interleave > 1: the real instances of a group are stored in the order j -> (j*P) mod cnt, P = the smallest integer >= interleave
 // coprime with cnt -- neighbouring entities share rows and columns, and lanes that add into the SAME accumulator in one
 // ds_add_f64 are serialised
+__device__ inline long long ocrs_stride(int interleave, int32_t cnt) {
+    long long P = 1;
+    if (interleave > 1 && cnt > 1) {
+        for (P = interleave;; ++P) {
+            long long a = P, c = cnt;
+            while (c) { long long t = a % c; a = c; c = t; }
+            if (a == 1) break;
+        }
+    }
+    return P;
+}
+
 __global__ void ocrs_fill(const uint64_t *__restrict__ keys, const int32_t *__restrict__ sstart, const int32_t *__restrict__ send,
                           const int64_t *__restrict__ pstart, int64_t nseg, int ar, int32_t *__restrict__ ent, uint8_t *__restrict__ valid,
-                          uint8_t *__restrict__ chunk_role, int interleave) {
+                          uint8_t *__restrict__ chunk_role, int interleave, int classes) {
     // 64 lanes per segment
     const int lane = threadIdx.x & 63;
     for (int64_t q = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6; q < nseg; q += ((int64_t)gridDim.x * blockDim.x) >> 6) {
@@ -942,14 +1004,24 @@ __global__ void ocrs_fill(const uint64_t *__restrict__ keys, const int32_t *__re
         const int64_t o = pstart[q];
         const int32_t pc = (cnt + 63) & ~63;
         const int32_t last = (int32_t)(keys[s0 + cnt - 1] & 0x7fffffffu);
-        long long P = 1;
-        if (interleave > 1 && cnt > 1) {
-            for (P = interleave;; ++P) {
-                long long a = P, c = cnt;
-                while (c) { long long t = a % c; a = c; c = t; }
-                if (a == 1) break;
+        if (classes) {
+            // paired keys: the segment is sorted by ownership class (bits 31..32) first; the stride permutation stays inside a class
+            int32_t c1 = cnt, c2 = cnt;                    // first instance of class >= 1 / >= 2
+            { int32_t lo = 0, hi = cnt; while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (((keys[s0 + mid] >> 31) & 3u) >= 1u) hi = mid; else lo = mid + 1; } c1 = lo; }
+            { int32_t lo = c1, hi = cnt; while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (((keys[s0 + mid] >> 31) & 3u) >= 2u) hi = mid; else lo = mid + 1; } c2 = lo; }
+            const long long P0 = ocrs_stride(interleave, c1), P1 = ocrs_stride(interleave, c2 - c1), P2 = ocrs_stride(interleave, cnt - c2);
+            for (int32_t j = lane; j < pc; j += 64) {
+                int32_t src = 0;
+                if (j < c1) src = (int32_t)((j * P0) % c1);
+                else if (j < c2) src = c1 + (int32_t)(((j - c1) * P1) % (c2 - c1));
+                else if (j < cnt) src = c2 + (int32_t)(((j - c2) * P2) % (cnt - c2));
+                ent[o + j] = j < cnt ? (int32_t)(keys[s0 + src] & 0x7fffffffu) : last;
+                valid[o + j] = j < cnt ? 1 : 0;
+                if ((j & 63) == 0) chunk_role[(o + j) >> 6] = (uint8_t)(q % ar);
             }
+            continue;
         }
+        const long long P = ocrs_stride(interleave, cnt);
         for (int32_t j = lane; j < pc; j += 64) {
             ent[o + j] = j < cnt ? (int32_t)(keys[s0 + (int32_t)((j * P) % cnt)] & 0x7fffffffu) : last;
             valid[o + j] = j < cnt ? 1 : 0;
@@ -974,20 +1046,34 @@ __global__ void ocrs_tables_k(const int32_t *__restrict__ inst_off, int32_t nblo
                               const fd_nnz_t *__restrict__ acc_by_node, const fd_nnz_t *__restrict__ acc_by_pos,
                               const int32_t *__restrict__ rblk, const int32_t *__restrict__ rlg, const int32_t *__restrict__ clg,
                               uint16_t *__restrict__ slot, uint16_t *__restrict__ rowlen, KT *__restrict__ kk, int32_t *__restrict__ err,
-                              int rbs, int cbs, uint8_t *__restrict__ rmask, unsigned long long *__restrict__ cmask) {
+                              int rbs, int cbs, uint8_t *__restrict__ rmask, unsigned long long *__restrict__ cmask,
+                              const uint8_t *__restrict__ groles, int NR, const int32_t *__restrict__ pinv, int32_t npos) {
     // rmask != nullptr: per-DOF lgmaps (``unroll``): rlg / clg are indexed by node*bs + component; a node row (column) is
     // dropped as a whole only when all its components are, the per-component bits go to rmask[t] / cmask[t]
+    // NR = rows per instance (fd_ocrplan_create_paired: 2): the tables hold NR rows per instance, (t, s) at t*NR + s; a row of the
+    // group that another block owns (or that the group does not have) is a dropped row of THIS instance
     const KT SKIP = (KT)~(KT)0;
-    const int64_t total = ninst * ac;
+    const int64_t total = ninst * NR * ac;
     for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u < total; u += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t t = u / ac;
-        const int j = (int)(u - t * ac);
-        const int role = chunk_role[t >> 6];
+        const int64_t ts = u / ac;                    // table row (t, s)
+        const int j = (int)(u - ts * ac);
+        const int64_t t = ts / NR;
+        const int sidx = (int)(ts - t * NR);
+        const int role = groles[2 * chunk_role[t >> 6] + sidx];
         const int32_t e = ent[t];
-        const int32_t r = rmap[(int64_t)e * ar + role];
+        const int32_t r = role != 255 ? rmap[(int64_t)e * ar + role] : -1;
         unsigned rm = 0;
         if (rmask && r >= 0) { for (int p = 0; p < rbs; ++p) if (!rlg || rlg[(int64_t)r * rbs + p] >= 0) rm |= 1u << p; }
-        const bool live = valid[t] && r >= 0 && (rmask ? rm != 0 : !(rlg && rlg[r] < 0));
+        bool live = valid[t] && r >= 0 && (rmask ? rm != 0 : !(rlg && rlg[r] < 0));
+        int lo = 0;
+        if (live && (j == 0 || NR > 1)) {
+            int hi = nblocks - 1;                      // block of instance t: largest b with inst_off[b] <= t
+            while (lo < hi) { int mid = lo + ((hi - lo + 1) >> 1); if (inst_off[mid] <= t) lo = mid; else hi = mid - 1; }
+            if (NR > 1) {
+                const int32_t pos = row_position(pinv, npos, r);
+                live = pos >= rblk[lo] && pos < rblk[lo + 1];
+            }
+        }
         if (rmask && j == 0) {
             rmask[t] = live ? (uint8_t)rm : (uint8_t)0;
             unsigned long long cmk = 0;
@@ -1001,16 +1087,14 @@ __global__ void ocrs_tables_k(const int32_t *__restrict__ inst_off, int32_t nblo
         if (j == 0) {
             uint16_t sl = 0xffffu;
             if (live) {
-                int lo = 0, hi = nblocks - 1;                  // block of instance t: largest b with inst_off[b] <= t
-                while (lo < hi) { int mid = lo + ((hi - lo + 1) >> 1); if (inst_off[mid] <= t) lo = mid; else hi = mid - 1; }
                 const fd_nnz_t d = acc_by_node[r] - acc_by_pos[rblk[lo]];
                 if (d < 0 || d >= 0xffff) atomicExch(err, 2); else sl = (uint16_t)d;
             }
-            slot[t] = sl;
+            slot[ts] = sl;
             if (rowlen) {
                 const fd_nnz_t rl = r >= 0 ? rowptr[r + 1] - rowptr[r] : 0;
                 if (rl > 0xffff) atomicExch(err, 2);
-                rowlen[t] = (uint16_t)rl;
+                rowlen[ts] = (uint16_t)rl;
             }
         }
         KT v = SKIP;
@@ -1027,7 +1111,7 @@ __global__ void ocrs_tables_k(const int32_t *__restrict__ inst_off, int32_t nblo
 struct RecDesc {
     const uint16_t *lmap[8]; int ar[8]; int lbits[8]; int nmaps;
     const void *kidx; int kbytes, nr, nc, kbits, skipdiag, words;
-    const uint16_t *extra; int ebits, sentinel;
+    const uint16_t *extra; int ebits, sentinel, nextra;
 };
 __global__ void ocr_pack_records_k(RecDesc d, int64_t ninst, uint32_t *__restrict__ out, int32_t *__restrict__ err) {
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < ninst; t += (int64_t)gridDim.x * blockDim.x) {
@@ -1051,8 +1135,8 @@ __global__ void ocr_pack_records_k(RecDesc d, int64_t ninst, uint32_t *__restric
                 }
                 put(v, d.kbits);
             }
-        if (d.extra) {
-            uint32_t v = d.extra[t];
+        for (int x = 0; d.extra && x < d.nextra; ++x) {
+            uint32_t v = d.extra[t * d.nextra + x];
             if (d.sentinel) {
                 const uint32_t all = (1u << d.ebits) - 1u;
                 if (v == 0xffffu) v = all; else if (v >= all) atomicOr(err, 1);
@@ -1116,10 +1200,28 @@ int fd_ocr_node_words(const int32_t *blkoff_dev, const int32_t *list_dev, int32_
     return 0;
 }
 
+static int pack_records(int64_t ninst, int nmaps, const uint16_t *const *lmaps_dev, const int32_t *arities, const int32_t *lbits,
+                        const void *kidx_dev, int kbytes, int nr, int nc, int kbits, int skipdiag, const uint16_t *extra_dev, int ebits,
+                        int nextra, int sentinel, int words, uint32_t *out_dev, fd_stream_t s_);
+
 int fd_ocr_pack_records(int64_t ninst, int nmaps, const uint16_t *const *lmaps_dev, const int32_t *arities, const int32_t *lbits,
                         const void *kidx_dev, int kbytes, int nr, int nc, int kbits, int skipdiag, const uint16_t *extra_dev, int ebits,
                         int sentinel, int words, uint32_t *out_dev, fd_stream_t s_) {
-    if (ninst < 0 || nmaps < 0 || nmaps > 8 || (nmaps && (!lmaps_dev || !arities || !lbits)) || !kidx_dev || !out_dev ||
+    return pack_records(ninst, nmaps, lmaps_dev, arities, lbits, kidx_dev, kbytes, nr, nc, kbits, skipdiag, extra_dev, ebits, 1, sentinel,
+                        words, out_dev, s_);
+}
+
+int fd_ocr_pack_records_rows(int64_t ninst, int nmaps, const uint16_t *const *lmaps_dev, const int32_t *arities, const int32_t *lbits,
+                             const void *kidx_dev, int kbytes, int nr, int nc, int kbits, const uint16_t *extra_dev, int ebits,
+                             int words, uint32_t *out_dev, fd_stream_t s_) {
+    if (!extra_dev) FD_FAIL("fd_ocr_pack_records_rows: the per-row slots are required");
+    return pack_records(ninst, nmaps, lmaps_dev, arities, lbits, kidx_dev, kbytes, nr, nc, kbits, 0, extra_dev, ebits, nr, 1, words, out_dev, s_);
+}
+
+static int pack_records(int64_t ninst, int nmaps, const uint16_t *const *lmaps_dev, const int32_t *arities, const int32_t *lbits,
+                        const void *kidx_dev, int kbytes, int nr, int nc, int kbits, int skipdiag, const uint16_t *extra_dev, int ebits,
+                        int nextra, int sentinel, int words, uint32_t *out_dev, fd_stream_t s_) {
+    if (ninst < 0 || nextra < 1 || nmaps < 0 || nmaps > 8 || (nmaps && (!lmaps_dev || !arities || !lbits)) || !kidx_dev || !out_dev ||
         (kbytes != 1 && kbytes != 2) || nr <= 0 || nc <= 0 || kbits <= 0 || kbits > 16 || words <= 0 || (extra_dev && (ebits <= 0 || ebits > 16)))
         FD_FAIL("fd_ocr_pack_records: bad arguments");
     RecDesc d{};
@@ -1130,8 +1232,8 @@ int fd_ocr_pack_records(int64_t ninst, int nmaps, const uint16_t *const *lmaps_d
         d.lmap[m] = lmaps_dev[m]; d.ar[m] = arities[m]; d.lbits[m] = lbits[m];
         bits += (int64_t)arities[m] * lbits[m];
     }
-    bits += (int64_t)(nr * nc - (skipdiag ? (nr < nc ? nr : nc) : 0)) * kbits + (extra_dev ? ebits : 0);
-    d.extra = extra_dev; d.ebits = ebits; d.sentinel = sentinel;
+    bits += (int64_t)(nr * nc - (skipdiag ? (nr < nc ? nr : nc) : 0)) * kbits + (extra_dev ? ebits * nextra : 0);
+    d.extra = extra_dev; d.ebits = ebits; d.sentinel = sentinel; d.nextra = nextra;
     if ((bits + 31) / 32 != words) FD_FAIL("fd_ocr_pack_records: the fields do not fill the stated number of words");
     d.kidx = kidx_dev; d.kbytes = kbytes; d.nr = nr; d.nc = nc; d.kbits = kbits; d.skipdiag = skipdiag; d.words = words;
     if (ninst == 0) return 0;
@@ -1295,34 +1397,99 @@ int fd_ocrplan_free(fd_ocrplan_t p) {
     if (p->inst_ent) FD_HIP(hipFree(p->inst_ent));
     if (p->rblk) FD_HIP(hipFree(p->rblk));
     if (p->chunk_role) FD_HIP(hipFree(p->chunk_role));
+    if (p->groles) FD_HIP(hipFree(p->groles));
     if (p->valid) FD_HIP(hipFree(p->valid));
     free(p->inst_off_host);
     delete p;
     return 0;
 }
 
+static int create_sliced(const int32_t *rmap_dev, int ar, int32_t start, int32_t end, const int32_t *block_starts_host,
+                         int32_t nblocks, const int32_t *pinv_dev, int32_t npos, int interleave, int ngroups, const uint8_t *groles_host,
+                         fd_stream_t s_, fd_ocrplan_t *out);
+
 int fd_ocrplan_create_sliced(const int32_t *rmap_dev, int ar, int32_t start, int32_t end, const int32_t *block_starts_host,
                              int32_t nblocks, const int32_t *pinv_dev, int32_t npos, int interleave, fd_stream_t s_, fd_ocrplan_t *out) {
+    if (ar <= 0 || ar > 255) FD_FAIL("fd_ocrplan_create_sliced: bad arguments");
+    return create_sliced(rmap_dev, ar, start, end, block_starts_host, nblocks, pinv_dev, npos, interleave, 0, nullptr, s_, out);
+}
+
+int fd_ocrplan_create_paired(const int32_t *rmap_dev, int ar, int32_t start, int32_t end, const int32_t *block_starts_host,
+                             int32_t nblocks, const int32_t *pinv_dev, int32_t npos, int interleave, int ngroups,
+                             const uint8_t *group_rows_host, fd_stream_t s_, fd_ocrplan_t *out) {
+    if (ar <= 0 || ar > 254 || ngroups <= 0 || ngroups > ar || ngroups > 63 || !group_rows_host)
+        FD_FAIL("fd_ocrplan_create_paired: bad arguments (at most 63 groups)");
+    // every local row in exactly one group, first row of a group present
+    int seen[256] = {0};
+    for (int g = 0; g < ngroups; ++g)
+        for (int x = 0; x < 2; ++x) {
+            const int r = group_rows_host[2 * g + x];
+            if (r == 255 && x == 1) continue;
+            if (r >= ar || seen[r]++) FD_FAIL("fd_ocrplan_create_paired: the groups are not a partition of the local rows");
+        }
+    for (int r = 0; r < ar; ++r) if (!seen[r]) FD_FAIL("fd_ocrplan_create_paired: the groups are not a partition of the local rows");
+    return create_sliced(rmap_dev, ar, start, end, block_starts_host, nblocks, pinv_dev, npos, interleave, ngroups, group_rows_host, s_, out);
+}
+
+int fd_ocrplan_pair_counts(const int32_t *rmap_dev, int ar, int32_t start, int32_t end, const int32_t *block_starts_host, int32_t nblocks,
+                           const int32_t *pinv_dev, int32_t npos, int64_t *counts_host, fd_stream_t s_) {
+    if (!rmap_dev || ar <= 0 || ar > 32 || nblocks < 0 || end < start || !block_starts_host || !counts_host)
+        FD_FAIL("fd_ocrplan_pair_counts: bad arguments (at most 32 local rows)");
+    for (int q = 0; q < ar * ar; ++q) counts_host[q] = 0;
+    if (nblocks == 0 || end == start) return 0;
+    hipStream_t s = fd::st(s_);
+    int32_t *rblk = nullptr;
+    unsigned long long *cnt = nullptr;
+    FD_HIP(hipMalloc(&rblk, ((size_t)nblocks + 1) * 4));
+    FD_HIP(hipMalloc(&cnt, (size_t)ar * ar * 8));
+    FD_HIP(hipMemcpyAsync(rblk, block_starts_host, ((size_t)nblocks + 1) * 4, hipMemcpyHostToDevice, s));
+    FD_HIP(hipMemsetAsync(cnt, 0, (size_t)ar * ar * 8, s));
+    hipLaunchKernelGGL(ocrs_pair_counts_k, dim3(mp_grid((int64_t)end - start)), dim3(256), 0, s, rmap_dev, ar, start, end, rblk, nblocks,
+                       pinv_dev, npos, cnt);
+    FD_CHECK_LAUNCH();
+    FD_HIP(hipMemcpyAsync(counts_host, cnt, (size_t)ar * ar * 8, hipMemcpyDeviceToHost, s));
+    FD_HIP(hipStreamSynchronize(s));
+    FD_HIP(hipFree(rblk)); FD_HIP(hipFree(cnt));
+    return 0;
+}
+
+static int create_sliced(const int32_t *rmap_dev, int ar, int32_t start, int32_t end, const int32_t *block_starts_host,
+                         int32_t nblocks, const int32_t *pinv_dev, int32_t npos, int interleave, int ngroups, const uint8_t *groles_host,
+                         fd_stream_t s_, fd_ocrplan_t *out) {
     hipStream_t s = fd::st(s_);
     if (!rmap_dev || !out || ar <= 0 || ar > 255 || nblocks < 0 || nblocks >= (1 << 24) || end < start || !block_starts_host)
         FD_FAIL("fd_ocrplan_create_sliced: bad arguments");
+    const bool paired = groles_host != nullptr;
+    const int ng = paired ? ngroups : ar;
     auto *p = new fd_ocrplan_s;
     p->nblocks = nblocks;
     p->pinv = pinv_dev; p->npos = npos; p->sliced_ar = ar;
+    p->ngroups = ng; p->rows_per_inst = paired ? 2 : 1;
+    {
+        uint8_t roles[512];
+        for (int g = 0; g < ng; ++g) { roles[2 * g] = paired ? groles_host[2 * g] : (uint8_t)g; roles[2 * g + 1] = paired ? groles_host[2 * g + 1] : (uint8_t)255; }
+        FD_HIP(hipMalloc(&p->groles, (size_t)2 * ng));
+        FD_HIP(hipMemcpyAsync(p->groles, roles, (size_t)2 * ng, hipMemcpyHostToDevice, s));
+        FD_HIP(hipStreamSynchronize(s));            // (the host copy is a local)
+    }
     FD_HIP(hipMalloc(&p->rblk, ((size_t)nblocks + 1) * 4));
     FD_HIP(hipMemcpyAsync(p->rblk, block_starts_host, ((size_t)nblocks + 1) * 4, hipMemcpyHostToDevice, s));
     FD_HIP(hipMalloc(&p->inst_off, ((size_t)nblocks + 1) * 4));
     p->inst_off_host = (int32_t *)calloc((size_t)nblocks + 1, 4);
-    const int64_t nkeys = ((int64_t)end - start) * ar;
+    const int64_t nkeys = ((int64_t)end - start) * (paired ? 2 * ng : ar);
     if (nblocks == 0 || nkeys == 0) {
         FD_HIP(hipMemsetAsync(p->inst_off, 0, ((size_t)nblocks + 1) * 4, s));
         *out = p; return 0;
     }
-    if (nkeys > 2147483647ll || (int64_t)nblocks * ar >= 2147483647ll) FD_FAIL("fd_ocrplan_create_sliced: too many (entity, row) pairs");
+    if (nkeys > 2147483647ll || (int64_t)nblocks * ng >= 2147483647ll) FD_FAIL("fd_ocrplan_create_sliced: too many (entity, row) pairs");
     uint64_t *k1 = nullptr, *k2 = nullptr;
     FD_HIP(hipMalloc(&k1, (size_t)nkeys * 8));
     FD_HIP(hipMalloc(&k2, (size_t)nkeys * 8));
-    hipLaunchKernelGGL(ocrs_emit, dim3(mp_grid(nkeys)), dim3(256), 0, s, rmap_dev, ar, start, end, p->rblk, nblocks, k1, p->pinv, p->npos);
+    if (paired)
+        hipLaunchKernelGGL(ocrs_emit_pairs, dim3(mp_grid(nkeys / 2)), dim3(256), 0, s, rmap_dev, ar, start, end, p->rblk, nblocks, k1, p->pinv,
+                           p->npos, p->groles, ng);
+    else
+        hipLaunchKernelGGL(ocrs_emit, dim3(mp_grid(nkeys)), dim3(256), 0, s, rmap_dev, ar, start, end, p->rblk, nblocks, k1, p->pinv, p->npos);
     FD_CHECK_LAUNCH();
     size_t tb = 0;
     hipcub::DoubleBuffer<uint64_t> db(k1, k2);
@@ -1331,7 +1498,7 @@ int fd_ocrplan_create_sliced(const int32_t *rmap_dev, int ar, int32_t start, int
     FD_HIP(hipMalloc(&tmp, tb ? tb : 8));
     FD_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, tb, db, nkeys, 0, 64, s));
     const uint64_t *sorted = db.Current();
-    const int64_t nseg = (int64_t)nblocks * ar;
+    const int64_t nseg = (int64_t)nblocks * ng;
     int32_t *sstart = nullptr, *send = nullptr;
     int64_t *pc = nullptr, *pstart = nullptr, *nvalid = nullptr;
     FD_HIP(hipMalloc(&sstart, (size_t)nseg * 4));
@@ -1342,7 +1509,7 @@ int fd_ocrplan_create_sliced(const int32_t *rmap_dev, int ar, int32_t start, int
     FD_HIP(hipMemsetAsync(sstart, 0, (size_t)nseg * 4, s));
     FD_HIP(hipMemsetAsync(send, 0, (size_t)nseg * 4, s));
     FD_HIP(hipMemsetAsync(nvalid, 0, 8, s));
-    hipLaunchKernelGGL(ocrs_bounds, dim3(mp_grid(nkeys)), dim3(256), 0, s, sorted, nkeys, ar, sstart, send, nvalid);
+    hipLaunchKernelGGL(ocrs_bounds, dim3(mp_grid(nkeys)), dim3(256), 0, s, sorted, nkeys, ng, sstart, send, nvalid, paired ? 33 : 31);
     FD_CHECK_LAUNCH();
     hipLaunchKernelGGL(ocrs_padded_counts, dim3(mp_grid(nseg + 1)), dim3(256), 0, s, sstart, send, nseg, pc);
     FD_CHECK_LAUNCH();
@@ -1360,11 +1527,11 @@ int fd_ocrplan_create_sliced(const int32_t *rmap_dev, int ar, int32_t start, int
     FD_HIP(hipMalloc(&p->valid, (size_t)(np_ > 0 ? np_ : 1)));
     FD_HIP(hipMalloc(&p->chunk_role, (size_t)(np_ / 64 + 1)));
     if (np_ > 0) {
-        hipLaunchKernelGGL(ocrs_fill, dim3(mp_grid(nseg * 64)), dim3(256), 0, s, sorted, sstart, send, pstart, nseg, ar, p->inst_ent,
-                           p->valid, p->chunk_role, interleave);
+        hipLaunchKernelGGL(ocrs_fill, dim3(mp_grid(nseg * 64)), dim3(256), 0, s, sorted, sstart, send, pstart, nseg, ng, p->inst_ent,
+                           p->valid, p->chunk_role, interleave, paired ? 1 : 0);
         FD_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(ocrs_block_offsets, dim3(mp_grid((int64_t)nblocks + 1)), dim3(256), 0, s, pstart, nblocks, ar, p->inst_off);
+    hipLaunchKernelGGL(ocrs_block_offsets, dim3(mp_grid((int64_t)nblocks + 1)), dim3(256), 0, s, pstart, nblocks, ng, p->inst_off);
     FD_CHECK_LAUNCH();
     FD_HIP(hipMemcpyAsync(p->inst_off_host, p->inst_off, ((size_t)nblocks + 1) * 4, hipMemcpyDeviceToHost, s));
     FD_HIP(hipStreamSynchronize(s));
@@ -1401,17 +1568,19 @@ int fd_ocrplan_sliced_tables(fd_ocrplan_t p, const int32_t *rmap_dev, const int3
     int32_t *err = nullptr;
     FD_HIP(hipMalloc(&err, 4));
     FD_HIP(hipMemsetAsync(err, 0, 4, s));
-    const int64_t total = p->ninst * ac;
+    const int NR = p->rows_per_inst;
+    if (NR > 1 && (rowlen_out_dev || rowmask_out_dev)) FD_FAIL("fd_ocrplan_sliced_tables: paired plans serve scalar matrices with node lgmaps");
+    const int64_t total = p->ninst * NR * ac;
     if (kbytes == 1)
         hipLaunchKernelGGL(ocrs_tables_k<uint8_t>, dim3(mp_grid(total)), dim3(256), 0, s, p->inst_off, p->nblocks, p->inst_ent, p->valid,
                            p->chunk_role, p->ninst, rmap_dev, p->sliced_ar, cmap_dev, ac, rowptr_dev, colidx_dev, acc_by_node_dev,
                            acc_by_pos_dev, p->rblk, row_lgmap_dev, col_lgmap_dev, slot_out_dev, rowlen_out_dev, (uint8_t *)kk_out_dev, err,
-                           rbs, cbs, rowmask_out_dev, (unsigned long long *)colmask_out_dev);
+                           rbs, cbs, rowmask_out_dev, (unsigned long long *)colmask_out_dev, p->groles, NR, p->pinv, p->npos);
     else
         hipLaunchKernelGGL(ocrs_tables_k<uint16_t>, dim3(mp_grid(total)), dim3(256), 0, s, p->inst_off, p->nblocks, p->inst_ent, p->valid,
                            p->chunk_role, p->ninst, rmap_dev, p->sliced_ar, cmap_dev, ac, rowptr_dev, colidx_dev, acc_by_node_dev,
                            acc_by_pos_dev, p->rblk, row_lgmap_dev, col_lgmap_dev, slot_out_dev, rowlen_out_dev, (uint16_t *)kk_out_dev, err,
-                           rbs, cbs, rowmask_out_dev, (unsigned long long *)colmask_out_dev);
+                           rbs, cbs, rowmask_out_dev, (unsigned long long *)colmask_out_dev, p->groles, NR, p->pinv, p->npos);
     FD_CHECK_LAUNCH();
     int32_t h = 0;
     FD_HIP(hipMemcpyAsync(&h, err, 4, hipMemcpyDeviceToHost, s));

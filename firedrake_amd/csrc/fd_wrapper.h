@@ -46,6 +46,9 @@ __device__ __forceinline__ int xcd_block(int bid, int nb) {
 // A value the caller knows to be equal in all lanes of the wavefront (the row index of a sliced instance chunk): moving it
 // to a scalar register turns the switch on it into scalar branches -- no divergence bookkeeping, one instantiation executed.
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// true when the predicate holds in SOME lane of the wavefront: a scalar condition (paired row-sliced instances pick, per wavefront,
+// the instantiation of the local kernel that computes only the rows some lane owns)
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
 // ---- global atomics (compiled with -munsafe-fp-atomics => global_atomic_add_f64) ----
 template <class T> __device__ __forceinline__ void atomic_add(T *p, T v) { atomicAdd(p, v); }

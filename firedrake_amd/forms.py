@@ -140,9 +140,26 @@ _TET_EDGES = [(2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1)]
 _TRI_EDGES = [(1, 2), (0, 2), (0, 1)]
 
 
+def ffc_rounding(table, epsilon=float(np.finfo(np.float64).resolution)):
+    """TSFC's treatment of every tabulated table before it becomes kernel text (tsfc/fem.py:726, 758: ``ffc_rounding(table,
+    ctx.epsilon)``, epsilon = finfo(scalar_type).resolution = 1e-15, tsfc/fem.py:87-88; the function itself lives in
+    gem.optimise, FInAT's repository, not vendored with the reference): entries within epsilon of a one-decimal number (0, +-0.1,
+    ..., +-1, ...) are snapped to it, minus zeros cleared.  A generated kernel therefore holds EXACT zeros where the tabulation
+    leaves 1e-17, and the C compiler folds the terms they multiply."""
+    table = np.asarray(table, dtype=np.float64)
+    one_decimal = np.asarray(np.round(table, 1))
+    one_decimal[np.logical_not(one_decimal)] = 0.0
+    return np.where(np.abs(table - one_decimal) < epsilon, one_decimal, table)
+
+
 def tabulate_lagrange(dim, degree, pts):
     """(phi[q][i], dphi[q][i][b]) of P1/P2 on the reference simplex; node order = vertices, then edges
-    in the UFC/FIAT edge order (matches mesh.py's cell-node maps)."""
+    in the UFC/FIAT edge order (matches mesh.py's cell-node maps); rounded like TSFC rounds its tables (ffc_rounding)."""
+    phi, dphi = _tabulate_lagrange(dim, degree, pts)
+    return ffc_rounding(phi), ffc_rounding(dphi)
+
+
+def _tabulate_lagrange(dim, degree, pts):
     pts = np.asarray(pts)
     lam = np.concatenate([1 - pts.sum(axis=1, keepdims=True), pts], axis=1)        # (nq, dim+1)
     dlam = np.concatenate([-np.ones((1, dim)), np.eye(dim)], axis=0)               # (dim+1, dim)
@@ -526,7 +543,8 @@ BENCH_VARIANTS = {
     ("residual", 3, 1): ("stagedo_s431", "staged_s405"),
     ("jacobian", 3, 1): ("ocrp_q10k4d_fx", "ocr_q10k4d_fx", "ocrp_q9k4d_fx", "ocr_q9k4d_fx"),
     ("residual", 3, 2): ("stagedo_s1508x255", "stagedo_s1502x256"),       # n = 107 (one GPU's share), n = 215 (the whole cube of configs[4])
-    ("jacobian", 3, 2): ("ocrspr_q8k7e13", "ocrs_q8k7e13", "ocrspr", "ocrsp", "ocrs"),
+    # (two rows per instance since round 6: "_g" + the row pairs Parloop._ocrs_geometry picks on the benchmark meshes)
+    ("jacobian", 3, 2): ("ocrspr_g0619283745_q8k7e13", "ocrspr_q8k7e13", "ocrs_q8k7e13", "ocrspr", "ocrsp", "ocrs"),
     "dg_advection": ("staged_s2048x561", "staged_s1024x516", "staged_s2332x668"),
 }
 

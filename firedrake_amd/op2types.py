@@ -2020,16 +2020,28 @@ class SlicedOcrPlan:
 
     MAX_TABLE_SETS = 3
 
-    def __init__(self, sparsity, rmap: Map, cmap: Map, staged_maps, start, end, row_blocks, row_order=None):
+    def __init__(self, sparsity, rmap: Map, cmap: Map, staged_maps, start, end, row_blocks, row_order=None, groups=None):
+        """``groups``: a partition of the local rows into groups of one or two, [(a, b) | (a, None), ...] -- two rows per instance
+        sharing one evaluation of the local kernel (fd_ocrplan_create_paired); None = one row per instance."""
         self.row_blocks = rb = np.ascontiguousarray(row_blocks, dtype=np.int32)
         nb = len(rb) - 1
         self.row_order = row_order
         self._sp, self._rmap, self._cmap = sparsity, rmap._base(), cmap._base()
         self.block = int(sparsity.dsets[0].cdim) * int(sparsity.dsets[1].cdim)     # scalars per (row node, column node) pair
+        self.groups = None if groups is None else tuple((int(a), None if b is None else int(b)) for a, b in groups)
+        self.rows_per_inst = 1 if groups is None else 2
         h = ctypes.c_void_p()
-        _lib.call("fd_ocrplan_create_sliced", self._rmap._dev_values(), rmap.arity, int(start), int(end), rb.ctypes.data, nb,
-                  row_order.pinv.ptr if row_order is not None else None, row_order.npos if row_order is not None else 0,
-                  int(configuration["ocrs_interleave"]), None, ctypes.byref(h))
+        pinv_ = row_order.pinv.ptr if row_order is not None else None
+        npos_ = row_order.npos if row_order is not None else 0
+        if groups is None:
+            _lib.call("fd_ocrplan_create_sliced", self._rmap._dev_values(), rmap.arity, int(start), int(end), rb.ctypes.data, nb,
+                      pinv_, npos_, int(configuration["ocrs_interleave"]), None, ctypes.byref(h))
+        else:
+            if self.block != 1:
+                raise ValueError("paired instances serve scalar matrices")
+            gr = np.array([[a, 255 if b is None else b] for a, b in self.groups], dtype=np.uint8)
+            _lib.call("fd_ocrplan_create_paired", self._rmap._dev_values(), rmap.arity, int(start), int(end), rb.ctypes.data, nb,
+                      pinv_, npos_, int(configuration["ocrs_interleave"]), len(gr), gr.ctypes.data, None, ctypes.byref(h))
         self.h = h.value
         ni, mi = ctypes.c_int64(), ctypes.c_int32()
         _lib.call("fd_ocrplan_info", self.h, ctypes.byref(ni), ctypes.byref(mi))
@@ -2069,8 +2081,10 @@ class SlicedOcrPlan:
         key = (ident(rlg), ident(clg), bool(per_dof))
         t = self._tables.pop(key, None)
         if t is None:
-            slot = DeviceBuffer(max(self.ninst, 1) * 2)
-            kk = DeviceBuffer(max(self.ninst, 1) * self._cmap.arity * self.kbytes)
+            if self.rows_per_inst > 1 and (per_dof or self.block > 1):
+                raise ValueError("paired instances serve scalar matrices with node lgmaps")
+            slot = DeviceBuffer(max(self.ninst, 1) * self.rows_per_inst * 2)
+            kk = DeviceBuffer(max(self.ninst, 1) * self.rows_per_inst * self._cmap.arity * self.kbytes)
             rlen = DeviceBuffer(max(self.ninst, 1) * 2) if self.block > 1 else None
             rmask = DeviceBuffer(max(self.ninst, 1)) if per_dof else None
             cmask = DeviceBuffer(max(self.ninst, 1) * 8) if per_dof else None
@@ -2087,6 +2101,30 @@ class SlicedOcrPlan:
         self._tables[key] = t                       # most recently used last
         return t[:5]
 
+    @staticmethod
+    def choose_groups(rmap, start, end, row_blocks, row_order=None):
+        """A partition of the local rows into pairs (and one single row when their number is odd) for two-rows-per-instance plans:
+        greedy maximum-weight matching on the co-ownership counts (fd_ocrplan_pair_counts: entities whose rows a and b fall into one
+        row block).  Deterministic for a given mesh and block cut; ties go to the lower rows."""
+        ar = rmap.arity
+        if ar > 32:
+            return None
+        rb = np.ascontiguousarray(row_blocks, dtype=np.int32)
+        cnt = np.zeros(ar * ar, dtype=np.int64)
+        _lib.call("fd_ocrplan_pair_counts", rmap._base()._dev_values(), ar, int(start), int(end), rb.ctypes.data, len(rb) - 1,
+                  row_order.pinv.ptr if row_order is not None else None, row_order.npos if row_order is not None else 0,
+                  cnt.ctypes.data, None)
+        cnt = cnt.reshape(ar, ar)
+        pairs = sorted(((int(cnt[a, b]), -a, -b) for a in range(ar) for b in range(a + 1, ar)), reverse=True)
+        free, groups = set(range(ar)), []
+        for _, na, nb_ in pairs:
+            a, b = -na, -nb_
+            if a in free and b in free:
+                groups.append((a, b))
+                free -= {a, b}
+        groups += [(a, None) for a in sorted(free)]
+        return tuple(sorted(groups))
+
     def records(self, rlg, clg, lgmap_ptr, staged_keys, lbits, kbits, sbits, words):
         """Bit-packed instance records for one pair of lgmaps (scalar matrices, node lgmaps): local-map rows of the staged maps,
         the column positions (dropped = all ones) and the accumulator slot (dropped = all ones) in ``words`` 32-bit words per
@@ -2101,8 +2139,12 @@ class SlicedOcrPlan:
             lm = (ctypes.c_void_p * max(n, 1))(*[self.plans[k_].lmap for k_ in staged_keys])
             ar = (ctypes.c_int32 * max(n, 1))(*[self.plans[k_].arity for k_ in staged_keys])
             lb = (ctypes.c_int32 * max(n, 1))(*[int(b) for b in lbits])
-            _lib.call("fd_ocr_pack_records", int(self.ninst), n, lm, ar, lb, t[1].ptr, self.kbytes, 1, self._cmap.arity, int(kbits), 0,
-                      t[0].ptr, int(sbits), 1, int(words), buf.ptr, None)
+            if self.rows_per_inst > 1:
+                _lib.call("fd_ocr_pack_records_rows", int(self.ninst), n, lm, ar, lb, t[1].ptr, self.kbytes, self.rows_per_inst, self._cmap.arity,
+                          int(kbits), t[0].ptr, int(sbits), int(words), buf.ptr, None)
+            else:
+                _lib.call("fd_ocr_pack_records", int(self.ninst), n, lm, ar, lb, t[1].ptr, self.kbytes, 1, self._cmap.arity, int(kbits), 0,
+                          t[0].ptr, int(sbits), 1, int(words), buf.ptr, None)
             t[7][key] = buf
         return buf
 

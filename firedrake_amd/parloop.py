@@ -1116,6 +1116,7 @@ class Parloop:
         from .codegen import lds_stride, mode_variant
         prep = self._prepared
         src = prep["cw"].src
+        start0, end0 = start, end
         # subsets / extruded sets: every map is replaced by its derived map over the virtual (position x layer) space
         maps = {mi: self._plan_map(m._base(), staged=True) for mi, m in enumerate(prep["maps"])}
         v = self._virtual(staged=True)
@@ -1140,12 +1141,20 @@ class Parloop:
         cap = max(int(configuration["ocrs_nnz_per_block"]) // B, int(np.diff(prp).max()) if nrows else 1)
         staged = {mi: maps[mi] for mi in src.staged_maps}
         limit = configuration["lds_limit"]
+        per_dof = bool(pa.lgmaps) and bool(self.global_kernel.arguments[k].unroll)
+        # two rows per instance (one evaluation of the local kernel, one index record for both): scalar matrices with node lgmaps whose
+        # element matrix has enough rows for the shared part to matter; the pairs are chosen once, from the first block cut
+        want_pairs = (int(configuration["ocrs_pairs"]) > 0 and B == 1 and not per_dof and configuration["ocr_records"]
+                      and 4 <= rmap.arity <= 32 and len(src.staged_maps) <= 8 and sp._max_node_rowlen() <= 254)
+        groups = None
         for attempt in range(8):
             targets = np.arange(0, int(prp[nrows]) + cap, cap)
             rb = np.unique(np.concatenate([np.searchsorted(prp[:nrows + 1], targets, side="left"), [0, nrows]]))
             rb = rb[rb <= nrows]
+            if want_pairs and groups is None:
+                groups = SlicedOcrPlan.choose_groups(rmap, start, end, rb, row_order)
             try:
-                op = SlicedOcrPlan(sp, rmap, cmap, staged, start, end, rb, row_order=row_order)
+                op = SlicedOcrPlan(sp, rmap, cmap, staged, start, end, rb, row_order=row_order, groups=groups)
             except _lib.FDHipError as exc:
                 if "too many" in str(exc):
                     raise PlanDoesNotFit(str(exc))          # 32-bit instance indices: the loop falls back (staged / direct)
@@ -1172,22 +1181,31 @@ class Parloop:
             else:
                 runs = None
         rec = None
-        per_dof = bool(pa.lgmaps) and bool(self.global_kernel.arguments[k].unroll)
         if configuration["ocr_records"] and B == 1 and not per_dof and len(src.staged_maps) <= 8 and op.kbytes == 1:
             from .codegen import sliced_record_layout
             maxlen = max(sp._max_node_rowlen(), 1)
-            rec = sliced_record_layout([staged[mi].arity for mi in src.staged_maps], nds, cmap.arity, maxlen, op.max_nnz)
-            if rec[1] > 8 or rec[2] > 16 or rec[3] * 4 >= sum(staged[mi].arity for mi in src.staged_maps) * 2 + cmap.arity + 2:
+            nri = op.rows_per_inst
+            rec = sliced_record_layout([staged[mi].arity for mi in src.staged_maps], nds, cmap.arity, maxlen, op.max_nnz, rows=nri)
+            if rec[1] > 8 or rec[2] > 16 or rec[3] * 4 >= sum(staged[mi].arity for mi in src.staged_maps) * 2 + nri * (cmap.arity + 2):
                 rec = None
-        variant = mode_variant(base, op.kbytes, nds, rec)
-        geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz, "runs": runs, "rec": rec,
+        if groups is not None and rec is None:
+            # (paired instances read everything from their record; fields that do not fit: back to one row per instance)
+            configuration_pairs = configuration["ocrs_pairs"]
+            configuration["ocrs_pairs"] = 0
+            try:
+                return self._ocrs_geometry(start0, end0, gkey)
+            finally:
+                configuration["ocrs_pairs"] = configuration_pairs
+        variant = mode_variant(base, op.kbytes, nds, rec, groups=groups)
+        geo = {"ocr": op, "lds": lds, "k": k, "nnz": sp._nnz, "runs": runs, "rec": rec, "groups": groups,
                "cw": prep["cw"] if variant == src.mode else self.global_kernel.compile(variant), "row_order": row_order}
         prep["parts"][gkey] = geo
         if configuration["debug"]:
             import sys
             print(f"[fdhip] {self.global_kernel.name} OCR row-sliced variant {variant}", file=sys.stderr)
             print(f"[fdhip] {self.global_kernel.name} OCR row-sliced [{start},{end}): row blocks={op.nblocks} instances={op.nreal} "
-                  f"(+{op.ninst - op.nreal} padding, x{op.nreal / max((end - start) * rmap.arity, 1):.2f} of the map entries) "
+                  f"(+{op.ninst - op.nreal} padding, x{op.nreal / max((end - start) * rmap.arity, 1):.2f} of the map entries"
+                  f"{'' if groups is None else ', row groups ' + str(groups)}) "
                   f"max_inst={op.max_inst} max_nnz={op.max_nnz} max_nown={op.max_nown} lds={lds} kbytes={op.kbytes}", file=sys.stderr)
         return geo
 

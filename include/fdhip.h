@@ -217,6 +217,11 @@ int fd_ocr_node_diag(const int32_t *list_dev, int64_t n, int32_t nrows, const fd
 int fd_ocr_pack_records(int64_t ninst, int nmaps, const uint16_t *const *lmaps_dev, const int32_t *arities, const int32_t *lbits,
                         const void *kidx_dev, int kbytes, int nr, int nc, int kbits, int skipdiag, const uint16_t *extra_dev, int ebits,
                         int sentinel, int words, uint32_t *out_dev, fd_stream_t s);
+/* The records of a paired row-sliced plan (fd_ocrplan_create_paired): kidx holds nr rows of nc positions per instance and
+ * extra_dev nr slots per instance (all-ones source values = dropped, mapped to the all-ones value of the field). */
+int fd_ocr_pack_records_rows(int64_t ninst, int nmaps, const uint16_t *const *lmaps_dev, const int32_t *arities, const int32_t *lbits,
+                             const void *kidx_dev, int kbytes, int nr, int nc, int kbits, const uint16_t *extra_dev, int ebits,
+                             int words, uint32_t *out_dev, fd_stream_t s);
 /* Row blocks as ranges of row POSITIONS under a backend-derived row order (fd_first_touch_order): pinv[node] = position
  * for node < npos, prowptr[p] = CSR row start of the p-th row in that order (npos + 1 entries).  The CSR itself keeps
  * the caller's numbering; a block's rows are then a set of CSR rows, flushed row by row.  The tables are borrowed. */
@@ -243,6 +248,20 @@ int fd_ocrplan_create_sliced(const int32_t *rmap_dev, int rarity, int32_t start,
                              const int32_t *block_starts_host, int32_t nblocks, const int32_t *pinv_dev, int32_t npos,
                              int interleave, fd_stream_t s, fd_ocrplan_t *out);   /* interleave > 1: the instances of a group
                              * in the order j -> (j*P) mod count, P = smallest integer >= interleave coprime with count */
+/* Two rows per instance: the local rows are partitioned into ngroups GROUPS of one or two rows (group_rows_host[2g], [2g+1];
+ * 255 = no second row) and an instance is (entity, group) -- the wrapper evaluates the local kernel ONCE per instance and keeps
+ * both rows of its output, so the geometry and the instance's index record are shared by the two rows.  The block that owns the
+ * group's first row gets the instance; when another block owns the second row it gets an instance of its own, and each of the
+ * two drops the row it does not own (its slot reads 0xffff).  The chunk role of fd_ocrplan_sliced_arrays is then the GROUP index,
+ * and fd_ocrplan_sliced_tables writes two table rows per instance ((t, s) at t*2 + s: slot[2*ninst], kk[2*ninst*carity]; scalar
+ * matrices with node lgmaps only).  fd_ocrplan_pair_counts gives the statistic the caller picks the groups from: counts_host[a*rarity
+ * + b] (a < b) = entities whose local rows a and b fall into the same row block.  The reference has no counterpart: MatSetValuesLocal
+ * is called with whole element matrices (builder.py:573-625). */
+int fd_ocrplan_create_paired(const int32_t *rmap_dev, int rarity, int32_t start, int32_t end,
+                             const int32_t *block_starts_host, int32_t nblocks, const int32_t *pinv_dev, int32_t npos,
+                             int interleave, int ngroups, const uint8_t *group_rows_host, fd_stream_t s, fd_ocrplan_t *out);
+int fd_ocrplan_pair_counts(const int32_t *rmap_dev, int rarity, int32_t start, int32_t end, const int32_t *block_starts_host,
+                           int32_t nblocks, const int32_t *pinv_dev, int32_t npos, int64_t *counts_host, fd_stream_t s);
 int fd_ocrplan_sliced_arrays(fd_ocrplan_t p, const uint8_t **chunk_role_dev, const uint8_t **valid_dev, int64_t *nreal);
 int fd_ocrplan_sliced_tables(fd_ocrplan_t p, const int32_t *rmap_dev, const int32_t *cmap_dev, int carity,
                              const fd_nnz_t *rowptr_dev, const int32_t *colidx_dev, const fd_nnz_t *acc_by_node_dev,

@@ -170,6 +170,99 @@ def ocr_plan_ref(rmapv, cmapv, nent, row_blocks, rowptr, colidx, pinv=None):
     return np.array(inst_off, np.int32), inst_ent, kidx
 
 
+def ocrs_pair_counts_ref(rmapv, start, end, row_blocks, pinv=None):
+    """numpy restatement of fd_ocrplan_pair_counts: cnt[a, b] (a < b) = entities whose local rows a and b fall into one row block."""
+    rows = np.asarray(rmapv)[start:end]
+    pos = rows
+    if pinv is not None:
+        pos = np.where((rows >= 0) & (rows < len(pinv)), np.asarray(pinv)[np.clip(rows, 0, len(pinv) - 1)], -1)
+    rb = np.asarray(row_blocks)
+    blk = np.where((pos >= rb[0]) & (pos < rb[-1]), np.searchsorted(rb, pos, side="right") - 1, -1)
+    ar = rows.shape[1]
+    cnt = np.zeros((ar, ar), dtype=np.int64)
+    for a in range(ar):
+        for b in range(a + 1, ar):
+            cnt[a, b] = int(((blk[:, a] >= 0) & (blk[:, a] == blk[:, b])).sum())
+    return cnt
+
+
+def choose_groups_ref(cnt):
+    """numpy restatement of SlicedOcrPlan.choose_groups: greedy matching on the co-ownership counts, ties to the lower rows."""
+    ar = cnt.shape[0]
+    pairs = sorted(((int(cnt[a, b]), -a, -b) for a in range(ar) for b in range(a + 1, ar)), reverse=True)
+    free, groups = set(range(ar)), []
+    for _, na, nb in pairs:
+        if -na in free and -nb in free:
+            groups.append((-na, -nb))
+            free -= {-na, -nb}
+    return tuple(sorted(groups + [(a, None) for a in sorted(free)]))
+
+
+def ocrs_paired_plan_ref(rmapv, cmapv, start, end, row_blocks, rowptr, colidx, acc_by_node, acc_by_pos, groups, pinv=None, rlg=None, clg=None,
+                         interleave=0):
+    """numpy restatement of the PAIRED row-sliced plan (include/fdhip.h: fd_ocrplan_create_paired + fd_ocrplan_sliced_tables): instances
+    (entity, group of one or two local rows) for every group with a row inside the row block, per block grouped by group (entity
+    order inside a group), every group padded to a multiple of 64 slots with copies of its last entity; two table rows per instance --
+    a row of the group that is absent, dropped, or owned by ANOTHER block reads slot 0xffff.  Returns (padded inst_off, inst_ent,
+    chunk_role = group index, valid, slot (n, 2), kk (n, 2, ac))."""
+    ar, ac = rmapv.shape[1], cmapv.shape[1]
+    rows = np.asarray(rmapv)[start:end]
+    pos = rows
+    if pinv is not None:
+        pos = np.where((rows >= 0) & (rows < len(pinv)), np.asarray(pinv)[np.clip(rows, 0, len(pinv) - 1)], -1)
+    inst_off, ent, role, valid = [0], [], [], []
+    for b in range(len(row_blocks) - 1):
+        n = 0
+        inb = (pos >= row_blocks[b]) & (pos < row_blocks[b + 1])
+        for g, (ra, rb_) in enumerate(groups):
+            ina = inb[:, ra]
+            inb2 = np.zeros_like(ina) if rb_ is None else inb[:, rb_]
+            # sorted by ownership class (both rows / the first only / the second only), entity order inside a class; the stride
+            # permutation stays inside a class
+            parts = []
+            for sel in (ina & inb2, ina & ~inb2, ~ina & inb2):
+                ec = start + np.nonzero(sel)[0]
+                if interleave > 1 and len(ec) > 1:
+                    P = next(q for q in range(interleave, interleave + len(ec) + 2) if np.gcd(q, len(ec)) == 1)
+                    ec = ec[(np.arange(len(ec)) * P) % len(ec)]
+                parts.append((ec, start + np.nonzero(sel)[0]))
+            es = np.concatenate([pp[0] for pp in parts])
+            if len(es) == 0:
+                continue
+            last = [pp[1][-1] for pp in parts if len(pp[1])][-1]       # the padding repeats the last entity of the sorted segment
+            pad = -len(es) % 64
+            ent += [es, np.full(pad, last)]
+            valid += [np.ones(len(es), np.uint8), np.zeros(pad, np.uint8)]
+            role += [np.full((len(es) + pad) // 64, g, np.uint8)]
+            n += len(es) + pad
+        inst_off.append(inst_off[-1] + n)
+    cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)
+    ent, role, valid = cat(ent, np.int32), cat(role, np.uint8), cat(valid, np.uint8)
+    slot = np.full((len(ent), 2), 0xffff, dtype=np.uint16)
+    kk = np.full((len(ent), 2, ac), 0xff, dtype=np.uint8)
+    blk = np.searchsorted(np.asarray(inst_off), np.arange(len(ent)), side="right") - 1
+    for t, e in enumerate(ent):
+        for s_, lr in enumerate(groups[role[t // 64]]):
+            if lr is None or not valid[t]:
+                continue
+            r = rmapv[e, lr]
+            if r < 0 or (rlg is not None and rlg[r] < 0):
+                continue
+            p_ = r if pinv is None else (pinv[r] if r < len(pinv) else -1)
+            if not (row_blocks[blk[t]] <= p_ < row_blocks[blk[t] + 1]):
+                continue
+            slot[t, s_] = acc_by_node[r] - acc_by_pos[row_blocks[blk[t]]]
+            row = colidx[rowptr[r]:rowptr[r + 1]]
+            for j in range(ac):
+                c = cmapv[e, j]
+                if c < 0 or (clg is not None and clg[c] < 0):
+                    continue
+                q = int(np.searchsorted(row, c))
+                assert q < len(row) and row[q] == c and q < 255
+                kk[t, s_, j] = q
+    return np.array(inst_off, np.int32), ent, role, valid, slot, kk
+
+
 def ocrs_plan_ref(rmapv, cmapv, start, end, row_blocks, rowptr, colidx, acc_by_node, acc_by_pos, pinv=None, rlg=None, clg=None,
                   interleave=0, per_dof=None):
     """numpy restatement of the row-sliced plan (include/fdhip.h: fd_ocrplan_create_sliced + fd_ocrplan_sliced_tables):

@@ -187,8 +187,8 @@ def pack_records_ref(lmaps, lbits, kidx, nr, nc, kbits, diag, words, extra=None,
                 assert v < (1 << kbits)
                 acc |= v << off
                 off += kbits
-        if extra is not None:
-            v = int(extra[t])
+        for v in ([] if extra is None else np.atleast_1d(np.asarray(extra)[t])):      # (one slot per row of a paired instance)
+            v = int(v)
             if sentinel:
                 v = (1 << ebits) - 1 if v == 0xffff else v
             assert v < (1 << ebits)
@@ -405,12 +405,12 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False,
     return csr
 
 
-def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None, run_flush=False, records=False):
+def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None, run_flush=False, records=False, pairs=False):
     """Execute a matrix-assembly Parloop ``pl`` with the ROW-SLICED owner-computes-rows wrapper on the host (one OS thread
     per lane).  Plan tables from helpers.ocrs_plan_ref, CSR pattern from the oracle.  Returns the OracleCSR."""
     import re
     from firedrake_amd.codegen import _ocr_shape, mode_variant
-    from helpers import first_touch_ref, ocrs_plan_ref, plan_ref_blocks
+    from helpers import choose_groups_ref, first_touch_ref, ocrs_pair_counts_ref, ocrs_paired_plan_ref, ocrs_plan_ref, plan_ref_blocks
     gk = pl.global_kernel
     assert _ocr_shape(gk, mats_on_virtual=True, allow_unroll=True) is not None
     (k, mpa), = [(k, pa) for k, pa in enumerate(pl.arguments) if isinstance(pa, MatParloopArg)]
@@ -449,9 +449,19 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None, run_flush=Fals
     rb = rb[rb <= nrows].astype(np.int32)
     lg = mpa.lgmaps
     per_dof = (sp.dsets[0].cdim, sp.dsets[1].cdim) if (lg is not None and gk.arguments[k].unroll) else None
-    res = ocrs_plan_ref(
-        np.asarray(rmap.values_with_halo), np.asarray(cmap.values_with_halo), 0, nent, rb, ncsr.rowptr, ncsr.colidx, acc_by_node, acc,
-        pinv=pinv, rlg=None if lg is None else np.asarray(lg[0]), clg=None if lg is None else np.asarray(lg[1]), per_dof=per_dof)
+    groups = None
+    if pairs:
+        # two rows per instance ("_g" variants): the groups from the rows' co-ownership counts, as Parloop._ocrs_geometry picks them
+        assert B == 1 and per_dof is None and records
+        groups = choose_groups_ref(ocrs_pair_counts_ref(np.asarray(rmap.values_with_halo), 0, nent, rb, pinv=pinv))
+        res = ocrs_paired_plan_ref(
+            np.asarray(rmap.values_with_halo), np.asarray(cmap.values_with_halo), 0, nent, rb, ncsr.rowptr, ncsr.colidx, acc_by_node, acc,
+            groups, pinv=pinv, rlg=None if lg is None else np.asarray(lg[0]), clg=None if lg is None else np.asarray(lg[1]))
+        res = res + (None,)
+    else:
+        res = ocrs_plan_ref(
+            np.asarray(rmap.values_with_halo), np.asarray(cmap.values_with_halo), 0, nent, rb, ncsr.rowptr, ncsr.colidx, acc_by_node, acc,
+            pinv=pinv, rlg=None if lg is None else np.asarray(lg[0]), clg=None if lg is None else np.asarray(lg[1]), per_dof=per_dof)
     inst_off, inst_ent, chunk_role, valid, slot, kk, rowlen = res[:7]
     plans = {}
     for mi in base.staged_maps:
@@ -465,9 +475,9 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None, run_flush=Fals
     if records:
         from firedrake_amd.codegen import sliced_record_layout
         rec = sliced_record_layout([maps[mi].arity for mi in base.staged_maps], [plans[mi][3] for mi in base.staged_maps], cmap.arity,
-                                   int(np.diff(ncsr.rowptr).max()), max_nnz)
+                                   int(np.diff(ncsr.rowptr).max()), max_nnz, rows=2 if groups else 1)
     src = generate_wrapper(gk, mode_variant(("ocrspr" if run_tabs else "ocrsp") if order is not None else "ocrs", 1,
-                                            [plans[mi][3] for mi in base.staged_maps], rec))
+                                            [plans[mi][3] for mi in base.staged_maps], rec, groups=groups))
     text = src.source.replace("extern __shared__ __align__(16) unsigned char fd_lds[];", "unsigned char *fd_lds = fd_sim::lds;")
     sig = re.search(r'extern "C" __global__[^\n]*void %s\((.*)\)\n' % src.symbol, text).group(1)
     names = [p.split()[-1].lstrip("*") for p in sig.split(", ")]
@@ -508,7 +518,8 @@ def run_ocrs(pl, nnz_per_block=96, zero_pending=True, order=None, run_flush=Fals
             cargs.append(ptr(inst_ent))
         elif kind == "ocr_rec":
             lbits, kbits, sbits, words_ = rec
-            cargs.append(ptr(pack_records_ref([plans[mi][2] for mi in base.staged_maps], lbits, np.asarray(kk), 1, cmap.arity, kbits, False,
+            cargs.append(ptr(pack_records_ref([plans[mi][2] for mi in base.staged_maps], lbits, np.asarray(kk).reshape(len(inst_ent), -1),
+                                              2 if groups else 1, cmap.arity, kbits, False,
                                               words_, extra=np.asarray(slot), ebits=sbits, sentinel=True)))
         elif kind == "ocrs_chunk_role":
             cargs.append(ptr(chunk_role))

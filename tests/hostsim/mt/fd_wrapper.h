@@ -109,6 +109,8 @@ inline int xcd_block(int bid, int nb) {
     return x * q + (x < r ? x : r) + k;
 }
 inline int wave_uniform(int v) { return v; }
+// (one OS thread per lane: "some lane of the wavefront" is answered conservatively -- the per-lane guards decide)
+inline bool wave_any(bool) { return true; }
 template <class T> inline void atomic_add(T *p, T v) { fd_sim::cas_update(p, [v](T o) { return o + v; }); }
 template <class T> inline void atomic_min(T *p, T v) { fd_sim::cas_update(p, [v](T o) { return v < o ? v : o; }); }
 template <class T> inline void atomic_max(T *p, T v) { fd_sim::cas_update(p, [v](T o) { return v > o ? v : o; }); }

@@ -66,6 +66,14 @@ def row_relative_error(rowptr, v, ref):
     return (emax[ok] / rmax[ok]).max(), rmax[ok].max() / rmax[ok].min()
 
 
+def lost_entries(rowptr, v, ref):
+    """Entries the oracle holds above the rounding noise of their row (1e-12 of the row's largest entry: structured meshes have
+    entries that are analytically zero and come out as +-1e-25 or as 0 depending on the order of a cancelling sum) that came back
+    as exactly zero."""
+    rmax = np.repeat(np.maximum.reduceat(np.abs(ref), rowptr[:-1][np.diff(rowptr) > 0]), np.diff(rowptr)[np.diff(rowptr) > 0])
+    return int(((np.abs(ref) > 1e-12 * rmax) & (v == 0.0)).sum())
+
+
 @pytest.mark.parametrize("numbering", ["tiled", "lexicographic"])
 @pytest.mark.parametrize("form", ["stiffness", "mass", "helmholtz"])
 def test_default_accumulation_is_accurate_relative_to_every_row(form, numbering, monkeypatch):
@@ -80,7 +88,7 @@ def test_default_accumulation_is_accurate_relative_to_every_row(form, numbering,
     # the rows span > 9 decades (stiffness ~ h: 4^11; mass ~ h^3: 4^33): a normwise statement says nothing about most of them
     assert spread > (1e6 if form != "mass" else 1e18)
     assert err <= 1e-13, err
-    assert not np.any((ref != 0.0) & (v == 0.0))
+    assert not lost_entries(rowptr, v, ref)
     assert np.abs(v - ref).max() <= 1e-12 * np.abs(ref).max()
 
 
@@ -93,7 +101,7 @@ def test_row_sliced_p2_matrix_is_accurate_relative_to_every_row(monkeypatch):
     assert geo["cw"].src.mode.startswith("ocrs")
     err, spread = row_relative_error(rowptr, v, ref)
     assert spread > 1e6 and err <= 1e-13, (err, spread)
-    assert not np.any((ref != 0.0) & (v == 0.0))
+    assert not lost_entries(rowptr, v, ref)
 
 
 def test_opt_in_fixed_point_is_normwise_only_on_a_graded_mesh(monkeypatch):

@@ -67,6 +67,110 @@ def test_sliced_plan_matches_numpy_restatement(ordered, interleave, monkeypatch)
         assert np.array_equal(k_.download(np.uint8, kk.shape), kk)
 
 
+@pytest.mark.parametrize("ordered,interleave", [(False, 0), (True, 0), (True, 7)])
+def test_paired_plan_matches_numpy_restatement(ordered, interleave, monkeypatch):
+    """Two rows per instance (fd_ocrplan_create_paired, fd_ocrplan_pair_counts, two table rows per instance, fd_ocr_pack_records_rows)
+    against the numpy restatements; every (entity, owned row) pair is served by exactly one live table row."""
+    from firedrake_amd import _lib
+    from firedrake_amd.codegen import sliced_record_layout
+    from firedrake_amd.device import DeviceBuffer
+    from firedrake_amd.op2types import RowOrder, SlicedOcrPlan
+    from helpers import choose_groups_ref, first_touch_ref, locality_order_ref, ocrs_pair_counts_ref, ocrs_paired_plan_ref, plan_ref_blocks
+    from hostsim import pack_records_ref
+    monkeypatch.setitem(configuration, "ocrs_interleave", interleave)
+    m = fmesh.UnitCubeMesh(4, degrees=(2,), perturb=0.1, numbering="random" if ordered else "tiled")
+    V = m.space(2)
+    cm, xm = V.cell_node_map, m.coord_space.cell_node_map
+    sp = op2.Sparsity((V.node_set ** 1, V.node_set ** 1), [(cm, cm, None)])
+    sp._build()
+    n, nrows = m.cell_set.size, V.node_set.size
+    rp = np.asarray(sp.rowptr)
+    ro, pinv, acc_node, acc_pos = None, None, rp, rp
+    if ordered:
+        order = locality_order_ref(xm.values_with_halo, 0, n, np.array(m.coordinates.data_ro), target=64)[0]
+        ro = RowOrder(cm, DeviceBuffer.from_numpy(order), n, nrows, rp)
+        plist, pinv = first_touch_ref(cm.values_with_halo, order, nrows)
+        acc_pos = np.concatenate([[0], np.cumsum(np.diff(rp)[:nrows][plist])]).astype(np.int32)
+        acc_node = np.zeros(nrows, dtype=np.int32)
+        acc_node[plist] = acc_pos[:-1]
+    rb = np.unique(np.concatenate([np.arange(0, nrows, 37), [nrows]])).astype(np.int32)
+    cmv = np.asarray(cm.values_with_halo)
+    cnt = ocrs_pair_counts_ref(cmv, 0, n, rb, pinv=pinv)
+    groups = SlicedOcrPlan.choose_groups(cm, 0, n, rb, ro)
+    assert groups == choose_groups_ref(cnt) and len(groups) == 5 and all(b is not None for _, b in groups)
+    op = SlicedOcrPlan(sp, cm, cm, {0: xm}, 0, n, rb, row_order=ro, groups=groups)
+    rng = np.random.default_rng(5)
+    rlg = np.arange(V.node_set.total_size, dtype=np.int32)
+    rlg[rng.choice(nrows, nrows // 7, replace=False)] = -1
+    clg = np.arange(V.node_set.total_size, dtype=np.int32)
+    clg[rng.choice(nrows, nrows // 5, replace=False)] = -1
+
+    def down(ptr, dt, shape):
+        a = np.empty(shape, dtype=dt)
+        _lib.call("fd_memcpy_d2h", a.ctypes.data, ptr, a.nbytes, None)
+        return a
+
+    for lgs in ((None, None), (rlg, clg)):
+        inst_off, ent, role, valid, slot, kk = ocrs_paired_plan_ref(cmv, cmv, 0, n, rb, rp, np.asarray(sp.colidx), acc_node, acc_pos, groups,
+                                                                   pinv=pinv, rlg=lgs[0], clg=lgs[1], interleave=interleave)
+        assert np.array_equal(op.inst_off_host, inst_off) and op.ninst == len(ent) and op.nreal == int(valid.sum())
+        assert op.nreal < int((cmv[:n] < nrows).sum())                  # fewer instances than (entity, row) pairs
+        assert np.array_equal(down(op.inst_ent, np.int32, (op.ninst,)), ent)
+        assert np.array_equal(down(op.chunk_role, np.uint8, (op.ninst // 64,)), role)
+        assert np.array_equal(down(op.valid, np.uint8, (op.ninst,)), valid)
+        keep = []
+        s_, k_, *_ = op.tables(lgs[0], lgs[1], lambda a: keep.append(DeviceBuffer.from_numpy(a)) or keep[-1].ptr)
+        assert np.array_equal(s_.download(np.uint16, slot.shape), slot)
+        assert np.array_equal(k_.download(np.uint8, kk.shape), kk)
+        if lgs[0] is None:
+            # every (entity, owned row) pair has exactly ONE live table row
+            live = slot != 0xffff
+            rows_of = np.array([[(-1 if r is None else r) for r in g] for g in groups])[np.repeat(role, 64)]
+            served = np.zeros(cmv[:n].shape, dtype=np.int32)
+            for s2 in range(2):
+                sel = live[:, s2]
+                np.add.at(served, (ent[sel], rows_of[sel, s2]), 1)
+            assert np.array_equal(served, (cmv[:n] < nrows).astype(np.int32))
+        # records: the coordinate map's local rows + two rows of positions + two slots
+        lm = plan_ref_blocks(np.asarray(xm.values_with_halo)[ent], inst_off)[2]
+        nd = op.plans[0].max_nd
+        lbits, kbits, sbits, words = sliced_record_layout([xm.arity], [nd], cm.arity, int(np.diff(rp).max()), op.max_nnz, rows=2)
+        rec = op.records(lgs[0], lgs[1], lambda a: keep.append(DeviceBuffer.from_numpy(a)) or keep[-1].ptr, [0], lbits, kbits, sbits, words)
+        ref = pack_records_ref([lm], lbits, kk.reshape(len(ent), -1), 2, cm.arity, kbits, False, words, extra=slot, ebits=sbits, sentinel=True)
+        assert np.array_equal(rec.download(np.uint32, (op.ninst, words)), ref)
+
+
+@pytest.mark.parametrize("numbering", ["tiled", "lexicographic", "random"])
+@pytest.mark.parametrize("pairs", [0, 1])
+def test_p2_jacobian_paired_instances_against_oracle(numbering, pairs, monkeypatch):
+    """The default of scalar row-sliced loops since round 6: two rows per instance ("_g" variants).  Same matrix as one row per
+    instance and as the oracle, with BCs (dropped rows and columns), accumulation on top, and lgmaps swapped between calls."""
+    monkeypatch.setitem(configuration, "locality_min_entities", 0)
+    monkeypatch.setitem(configuration, "ocrs_pairs", pairs)
+    m = fmesh.UnitCubeMesh(7, degrees=(2,), tile=(4, 4, 2), perturb=0.1, numbering=numbering)
+    prob = forms.PoissonProblem(m, 2, bcs=True)
+    mat, pl = prob.jacobian()
+    mat.zero()
+    pl()
+    geo = pl._ocr_geometry()
+    assert ("_g" in geo["cw"].src.mode) == bool(pairs) and (geo["groups"] is not None) == bool(pairs)
+    if pairs and numbering != "random":
+        assert geo["ocr"].nreal < m.cell_set.size * 10 * 0.75          # most rows found a partner in their block
+    ref = _oracle_jac(prob, pl, mat)
+    assert_allclose(mat.csr()[2], ref.values, rtol=0, atol=1e-12 * np.abs(ref.values).max())
+    pl()
+    assert_allclose(mat.csr()[2], 2.0 * ref.values, rtol=0, atol=2e-12 * np.abs(ref.values).max())
+    mpa = pl.arguments[0]
+    nn = prob.V.node_set.total_size
+    lg = np.arange(nn, dtype=np.int32)
+    lg[np.random.default_rng(3).choice(nn, nn // 6, replace=False)] = -1
+    mpa.lgmaps = (lg, np.arange(nn, dtype=np.int32))
+    mat.zero()
+    pl()
+    ref2 = _oracle_jac(prob, pl, mat)
+    assert_allclose(mat.csr()[2], ref2.values, rtol=0, atol=1e-12 * np.abs(ref2.values).max())
+
+
 @pytest.mark.parametrize("numbering", ["tiled", "lexicographic", "random"])
 @pytest.mark.parametrize("bcs", [False, True])
 def test_p2_jacobian_sliced_against_oracle_and_unsliced(numbering, bcs, monkeypatch):

@@ -692,6 +692,12 @@ def test_row_sliced_owner_computes_rows_on_host(bcs, numbering, plan_copies):
             # one bit-packed record per instance (local map, column positions, slot; dropped = all ones) instead of three arrays
             got5 = run_ocrs(pl, nnz_per_block=cap, order=order, records=True, run_flush=order is not None)
             assert np.abs(got5.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
+        if degree == 2:
+            # two rows per instance ("_g" variants, fd_ocrplan_create_paired): one evaluation of the local kernel and one record for both
+            # rows of a pair; a row another block owns is dropped by the instance (and added by that block's own instance)
+            for zp in (True, False):
+                got6 = run_ocrs(pl, nnz_per_block=cap, zero_pending=zp, order=order, records=True, run_flush=order is not None, pairs=True)
+                assert np.abs(got6.values - (ref.values + (0.0 if zp else 1.0))).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
             if order is not None:
                 # the same blocks flushed through run-coded places ("ocrspr": one byte per entry, the block's displacements in LDS)
                 # instead of row by row
