@@ -69,6 +69,7 @@ SIGNATURES = {
     "fd_invert_permutation": (c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
     "fd_row_order_tables": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fd_row_entry_positions": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fd_row_entry_positions_masked": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fd_first_touch_order": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fd_comm_available": (c_int, []),
     "fd_comm_unique_id": (c_int, [c_void_p]),

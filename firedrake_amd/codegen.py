@@ -373,6 +373,16 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
     strides = [int(v) for v in sm_.group(1).split("x")] if sm_ else None
     if sm_:
         mode = mode[:sm_.start()]
+    # "_d<m0>x<m1>...": maps whose staged rows would see NO reuse inside a block (every node touched by one entity: cell loops of
+    # discontinuous spaces) -- their READ / INC arguments are gathered and scattered from the lane through the map row, like the
+    # WRITE / RW / MIN / MAX arguments beside staged ones, instead of passing through LDS (Parloop._staged_geometry decides)
+    dm_ = re.search(r"_d(\d+(?:x\d+)*)$", mode) if mode.startswith("staged") else None
+    direct_maps = set(int(v) for v in dm_.group(1).split("x")) if dm_ else set()
+    if dm_:
+        mode = mode[:dm_.start()]
+
+    def in_lds(info):
+        return stages_in_lds(info["acc"], info["dtype"]) and info.get("m") not in direct_maps
     # "_q<L0>x<L1>..k<K>[d]": the per-instance index rows of an owner-computes-rows loop arrive as ONE bit-packed record per
     # instance (fd_ocr_pack_records): local-map entries of staged map m at L_m bits, row offsets at K bits; "d" = the offsets
     # of the diagonal entries (i, i) are not stored -- they are a property of the row node and ride in its LDS word
@@ -388,6 +398,9 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
     # "ocrp": owner-computes-rows over row POSITIONS of a backend-derived row order (fd_first_touch_order): a block's rows
     # are a set of CSR rows -- accumulated contiguously in LDS, flushed row by row
     ocrp = mode.startswith("ocrp")
+    # "ocrpm": the column lgmap of the Mat is folded into the flush's place table (fd_row_entry_positions_masked) instead of a select
+    # per contribution in the main loop
+    ocrpm = mode.startswith("ocrpm")
     staged = mode.startswith("staged") or ocr
     ktype, kbytes = ("unsigned short", 2) if mode.endswith("_k16") else ("unsigned char", 1)
     extruded = gk._extruded
@@ -498,7 +511,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                                          and info["ar"] * info["ac"] <= configuration["ocr_sliced_max_entries"])
     if staged:
         for info in infos:
-            if info["kind"] == "dat" and "m" in info and stages_in_lds(info["acc"], info["dtype"]) and info["m"] not in staged_maps:
+            if info["kind"] == "dat" and "m" in info and in_lds(info) and info["m"] not in staged_maps:
                 staged_maps.append(info["m"])
             if info["kind"] == "mat" and (mat_staged[info["k"]] or ocr):
                 for mi in (info["rm"], info["cm"]):
@@ -576,6 +589,10 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
     def node(mi, ar, i, off, perm=None, f="0", ent="e"):
         ii = _permi(perm, i)
         e = f"map{mi}[(size_t){ent}*{ar} + {ii}]"
+        if mi in direct_maps:
+            # "_d" maps are AFFINE (Parloop._staged_geometry checked map[e][i] == arity*e + i): no index load at all, and the rows of
+            # an entity are contiguous -- one wide load / a run of adjacent atomics per lane
+            e = f"({ent}*{ar} + {ii})"
         if extruded and off is not None:
             # a permuted map permutes its offsets (and quotients) with its values (builder.py:160-169)
             rel = f"(layer - lay[0] + {f})"
@@ -590,6 +607,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         return e
 
     pre, pack, call_args, unpack, post = [], [], [], [], []
+    direct_prefetch = []       # (argument, C type, values per entity) of READ arguments on affine "_d" maps
     unpack_fx = []       # "_fx": the fixed-point trip's unpack of the Mat (everything else in such a loop is READ)
     flush_pre_decl, flush_pre = [], []     # table flushes: registers of the first batch of places, and its loads (ahead of the barrier)
     node_actions = {}    # per staged map: [(load statements, LDS store statements)] templated on I_U / G_U
@@ -642,7 +660,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             perm, off = info["perm"], info["off"]
             size = nf * ar * c
             pack.append(f"{ct} t{k}[{size}];")
-            if staged and stages_in_lds(acc, info["dtype"]):
+            if staged and in_lds(info):
                 lds_items.append(("dat", mi, c, info["dtype"].itemsize, acc != READ))
                 lds_decl.append(f"{ct} *s{k} = ({ct} *)(fd_lds + fd_off); fd_off += (((size_t)p{mi}_maxnd*{c}*sizeof({ct})) + 15) & ~(size_t)15;")
                 if acc == READ:
@@ -691,10 +709,20 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 vsize = size
             if acc in (INC, WRITE) + also_zero:
                 pack.append(f"for (int q = 0; q < {vsize}; ++q) t{k}[q] = 0;")
+            elif (mi in direct_maps and acc == READ and info["vi"] is None and nf == 1 and staged and configuration["prefetch"]
+                  and not (extruded or gk._subset or mode.startswith("stagedo"))):
+                # rows of an affine map ride in the software pipeline like the index rows: the NEXT entity's values are requested
+                # before the current entity's local kernel runs (direct_prefetch: consumed below, once idx_loads exists)
+                direct_prefetch.append((k, ct, ar * c))
+                pack.append(f"for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j) t{k}[i*{c}+j] = dv{k}[{_permi(perm, 'i')}*{c} + j];")
             else:
                 pack.append(f"{loop} {rhs} = {lhs};")
             call_args.append(f"t{k}")
-            if acc == INC:
+            if acc == INC and mi in direct_maps:
+                # an affine map is injective: no other entity of this launch touches these rows, so += is a plain read-modify-write of
+                # the entity's contiguous rows (wide loads and stores) instead of one atomic per scalar
+                unpack.append(f"{loop} {lhs} += {rhs};")
+            elif acc == INC:
                 unpack.append(f"{loop} fdw::atomic_add<{ct}>(&{lhs}, {rhs});")
             elif acc == MIN:
                 unpack.append(f"{loop} fdw::atomic_min<{ct}>(&{lhs}, {rhs});")
@@ -727,7 +755,9 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 # column masking (BC columns, pyop2/parloop.py:279-302) stays in the loop: a masked contribution adds 0.0.  Moving
                 # it to the row flush (one bit per CSR entry) removes 48 VALU instructions per instance and is NOT faster --
                 # the kernel is bound by the LDS pipe (profiles/r3b_ab_colmask.txt: 0.968 vs 0.952 ms tiled, 1.31 vs 1.19 un-hinted)
-                colmask = bool(lg)
+                colmask = bool(lg) and not ocrpm
+                if ocrpm and (fx or not lg or cm != rm):
+                    raise ValueError('"ocrpm" serves fp64 accumulation of a Mat with lgmaps and one map on both sides')
                 rowmask = f" && rlg{k}[g] >= 0" if lg else ""
                 colbit = (f" | ((clg{k}[g] < 0) ? 0x80000000u : 0u)" if (colmask and cm == rm) else "")
                 if srow_table(info):
@@ -789,8 +819,11 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                         flush_pre_decl.append(f"int g{k}[{FU}];")
                         flush_pre.append(ld.replace("Q0", "tid"))
                     flush.append((rm, f"for (int q0 = tid; q0 < nnzb{k}; q0 += {FU}*nthr) {{ "
-                                      + (f"if (q0 >= {FU}*nthr) {{ {ld.replace('Q0', 'q0')} }} " if preload else f"int g{k}[{FU}]; {ld.replace('Q0', 'q0')} ") +
-                                      f"if (oc{k}_flags & 1) {{ for (int f = 0; f < {FU}; ++f) if (g{k}[f] >= 0) arg{k}[(size_t)g{k}[f]] = sm{k}[q0 + f*nthr]; }} "
+                                      + (f"if (q0 >= {FU}*nthr) {{ {ld.replace('Q0', 'q0')} }} " if preload else f"int g{k}[{FU}]; {ld.replace('Q0', 'q0')} ")
+                                      # ("ocrpm": -2 - place = an entry in a masked column -- zero when the rows are overwritten, untouched otherwise)
+                                      + (f"if (oc{k}_flags & 1) {{ for (int f = 0; f < {FU}; ++f) {{ const int gq = g{k}[f]; "
+                                         f"if (gq >= 0) arg{k}[(size_t)gq] = sm{k}[q0 + f*nthr]; else if (gq < -1) arg{k}[(size_t)(-2 - gq)] = 0.0; }} }} " if ocrpm else
+                                         f"if (oc{k}_flags & 1) {{ for (int f = 0; f < {FU}; ++f) if (g{k}[f] >= 0) arg{k}[(size_t)g{k}[f]] = sm{k}[q0 + f*nthr]; }} ") +
                                       # accumulating into existing values (a second integral of the same form): the old values are
                                       # requested together as well (the places of a block are distinct)
                                       f"else {{ double o{k}[{FU}]; for (int f = 0; f < {FU}; ++f) o{k}[f] = g{k}[f] >= 0 ? arg{k}[(size_t)g{k}[f]] : 0.0; "
@@ -917,6 +950,9 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                 k, n = info["k"], info["ar"] * info["ac"]
                 idx_loads.append((f"int kk{k}[{n}]", f"int nx_kk{k}[{n}]", f"kk{k}", n,
                                   f"fdw::load_packed<{ktype}, {n}>(oc{k}_k + (size_t)(II - start)*{n}, DST);"))
+        for k_, ct_, n_ in direct_prefetch:
+            idx_loads.append((f"{ct_} dv{k_}[{n_}]", f"{ct_} nx_dv{k_}[{n_}]", f"dv{k_}", n_,
+                              f"for (int q = 0; q < {n_}; ++q) DST[q] = arg{k_}[(size_t)EE*{n_} + q];"))
         rec_decode = []
         if rec:
             # one record per instance replaces every index row above: the words are prefetched, the fields extracted at the top of
@@ -949,7 +985,8 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         # lane order (fd_plan_set_lane_order): slot k*nthr + t of a block holds the k-th entity of lane t's contiguous
         # run, so the lanes of one trip work on entities that are far apart (no shared nodes -> no serialised LDS
         # atomics) while their index rows stay coalesced.  OCR instance lists are stored in that order already.
-        lane_threads = threads if configuration["lane_strided"] else 0
+        # ("_d" variants keep the entity order: consecutive lanes then read and write consecutive rows of the affine maps)
+        lane_threads = threads if (configuration["lane_strided"] and not direct_maps) else 0
         # virtual iteration spaces: positions in a subset / (column, layer) cells / a derived entity order; the staged and the
         # owner-computes-rows wrappers address everything through plans built on derived maps and decode the position only for
         # direct arguments and the layer argument
@@ -960,7 +997,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                           ON_TOP: ("layers[1]-2", "layers[1]-1"),
                           ON_INTERIOR_FACETS: ("layers[0]", "layers[1]-1" if periodic else "layers[1]-2")}[region]
                 src.append(f"  const int fd_llo = {lo}, fd_nlit = ({hi}) - fd_llo;")
-                if any(i_["kind"] == "dat" and "m" in i_ and not stages_in_lds(i_["acc"], i_["dtype"]) for i_ in infos):
+                if any(i_["kind"] == "dat" and "m" in i_ and not in_lds(i_) for i_ in infos):
                     # (WRITE / RW / MIN / MAX arguments addressed from the lane: base map row + offset * layer, builder.py:94-124)
                     src.append("  const int *__restrict__ lay = layers;")
                     if periodic:
@@ -1145,7 +1182,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             src[sig + 1:] = [pat.sub("((long long)%d)" % S, l) for l in src[sig + 1:]]
     return WrapperSource("\n".join(src) + "\n", sym, full_mode, layout, len(maps), staged_maps, lds_items,
                          layer_parallel, threads, kbytes, mat_staged,
-                         (threads if (staged and configuration["lane_strided"]) else 0),
+                         (threads if (staged and configuration["lane_strided"] and not direct_maps) else 0),
                          ocr_lds_limit if ocr else 0)
 
 
@@ -1602,8 +1639,9 @@ def decode_groups(code: str):
     return tuple((_GROUP_CHARS.index(code[i]), None if code[i + 1] == "z" else _GROUP_CHARS.index(code[i + 1])) for i in range(0, len(code), 2))
 
 
-def mode_variant(base: str, kbytes: int, max_nds, rec=None, groups=None) -> str:
-    """Name of the wrapper variant for a launch geometry: base mode [+ _k16] [+ _g<row groups>] [+ _q<record fields>] [+ _s<strides>]."""
+def mode_variant(base: str, kbytes: int, max_nds, rec=None, groups=None, direct_maps=()) -> str:
+    """Name of the wrapper variant for a launch geometry: base mode [+ _k16] [+ _g<row groups>] [+ _q<record fields>] [+ _d<direct
+    maps>] [+ _s<strides>] (``max_nds``: the maps that stay staged)."""
     m = base + ("_k16" if kbytes == 2 else "")
     if groups is not None:
         m += "_g" + group_code(groups)
@@ -1614,6 +1652,8 @@ def mode_variant(base: str, kbytes: int, max_nds, rec=None, groups=None) -> str:
         lbits, kbits, diag = rec[:3]
         m += "_q" + "x".join(str(b) for b in lbits) + f"k{kbits}" + ("d" if diag else "")
     ocr = base.startswith("ocr")
+    if direct_maps:
+        m += "_d" + "x".join(str(int(v)) for v in sorted(direct_maps))
     if not ocr and int(configuration["lds_const_stride"]) > 0 and max_nds:
         m += "_s" + "x".join(str(lds_stride(n, ocr)) for n in max_nds)
     return m

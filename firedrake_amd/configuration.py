@@ -44,6 +44,9 @@ configuration = {
     # reference's MatSetValuesLocal(..., ADD_VALUES) (pyop2/codegen/builder.py:573-625), and keeps every row accurate relative to ITS
     # OWN entries (tests/test_gpu_graded_mesh.py).  Measured gain of the opt-in: 0-3 % of the P1 Jacobian
     "ocr_fixed_point": _env("FDHIP_OCR_FIXED_POINT", 0, int),
+    # whole-entity loops over a derived row order: the column lgmap (BC columns) is folded into the flush's place table ("ocrpm",
+    # fd_row_entry_positions_masked) instead of a select per contribution in the main loop; 0 = select in the loop ("ocrp")
+    "ocr_flush_colmask": _env("FDHIP_OCR_FLUSH_COLMASK", 1, int),
     "ocr_nnz_per_block": _env("FDHIP_OCR_NNZ", 2048, int),  # whole-entity row-block size (CSR entries) when the producer gives no hint
     "ocr_nnz_per_block_ordered": _env("FDHIP_OCR_NNZ_ORDERED", 3840, int),   # the same under a backend-derived row order
     "ocrs_nnz_per_block": _env("FDHIP_OCRS_NNZ", 4096, int),     # row-sliced loops: accumulator entries per row block (x8 bytes of LDS)
@@ -62,6 +65,7 @@ configuration = {
     "ocr_lds_limit": 0,                 # 0 = lds_limit (the whole CU for element matrices above 32 entries kept whole)
     "ocr_fx_headroom": 3,               # fixed-point scales: bits between a block's largest contribution and the limit of its scale
     "ocr_records_diag": 1,              # records without the diagonal offsets (they ride in the row node's LDS word)
+    "staged_direct_noreuse": 1,         # staged loops: Dat arguments on maps without reuse inside a block bypass LDS ("_d" variants)
     "lane_strided": 1,                  # plans in lane order (fd_plan_set_lane_order)
     "lds_const_stride": 1,              # staged loops: node stride of the LDS arrays compiled in (P1 residual 0.43 -> 0.41 ms)
     "tp_action_waves": 3,               # wavefronts per SIMD the tensor-product action wrapper is compiled for

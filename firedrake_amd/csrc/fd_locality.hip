@@ -172,6 +172,21 @@ __global__ void row_entry_positions(int32_t npos, const fd_nnz_t *__restrict__ p
     }
 }
 
+// the same table with the COLUMN lgmap folded in: an entry whose column is masked (clg[col] < 0: MatSetValuesLocal drops it,
+// builder.py:573-625) reads -2 - place -- the flush leaves it alone when it accumulates and stores 0.0 when it overwrites its rows
+__global__ void row_entry_positions_masked(int32_t npos, const fd_nnz_t *__restrict__ prowptr, const fd_nnz_t *__restrict__ gstart,
+                                           const int32_t *__restrict__ colidx, const int32_t *__restrict__ clg, int32_t *__restrict__ gpos) {
+    const int sub = threadIdx.x & 15;
+    for (int64_t p = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4; p < npos; p += ((int64_t)gridDim.x * blockDim.x) >> 4) {
+        const fd_nnz_t a = prowptr[p], g = gstart[p];
+        const int len = (int)(prowptr[p + 1] - a);
+        for (int k = sub; k < len; k += 16) {
+            const int32_t place = (int32_t)(g + k);
+            gpos[a + k] = clg[colidx[g + k]] < 0 ? -2 - place : place;
+        }
+    }
+}
+
 // ---- run-coded flush tables of a derived row order (fd_ocr_row_runs)
 // A row position p starts a RUN when it is the first row of its block or when its displacement (CSR start - accumulator start)
 // differs from the previous position's: inside a run, place = accumulator index + one displacement.
@@ -418,6 +433,16 @@ int fd_first_touch_order(const int32_t *map_dev, int arity, const int32_t *order
 int fd_row_entry_positions(int32_t npos, const fd_nnz_t *prowptr_dev, const fd_nnz_t *gstart_dev, int32_t *gpos_dev, fd_stream_t s) {
     if (npos <= 0) return 0;
     hipLaunchKernelGGL(row_entry_positions, dim3(lo_grid((int64_t)npos * 16)), dim3(256), 0, fd::st(s), npos, prowptr_dev, gstart_dev, gpos_dev);
+    FD_CHECK_LAUNCH();
+    return 0;
+}
+
+int fd_row_entry_positions_masked(int32_t npos, const fd_nnz_t *prowptr_dev, const fd_nnz_t *gstart_dev, const int32_t *colidx_dev,
+                                  const int32_t *col_lgmap_dev, int32_t *gpos_dev, fd_stream_t s) {
+    if (npos <= 0) return 0;
+    if (!prowptr_dev || !gstart_dev || !colidx_dev || !col_lgmap_dev || !gpos_dev) FD_FAIL("fd_row_entry_positions_masked: bad arguments");
+    hipLaunchKernelGGL(row_entry_positions_masked, dim3(lo_grid((int64_t)npos * 16)), dim3(256), 0, fd::st(s), npos, prowptr_dev, gstart_dev,
+                       colidx_dev, col_lgmap_dev, gpos_dev);
     FD_CHECK_LAUNCH();
     return 0;
 }

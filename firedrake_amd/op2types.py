@@ -2209,6 +2209,24 @@ class RowOrder:
             _lib.call("fd_row_entry_positions", self.npos, self.prowptr.ptr, self.gstart.ptr, self._gpos.ptr, None)
         return self._gpos
 
+    def gpos_masked(self, sparsity, clg, lgmap_ptr):
+        """``gpos()`` with the column lgmap ``clg`` folded in (fd_row_entry_positions_masked: -2 - place for entries in masked
+        columns), kept for the last few lgmaps by identity like the tables of a row-sliced plan."""
+        if int(self.prowptr_host[-1]) > 2 ** 31 - 1:
+            raise _lib.FDHipError("the whole-entity row flush holds 32-bit places")
+        key = ("dev", clg._fd_dev_ptr, getattr(clg, "_fd_token", None)) if hasattr(clg, "_fd_dev_ptr") else id(clg)
+        cache = self.__dict__.setdefault("_gpos_masked", {})
+        hit = cache.pop(key, None)
+        if hit is None:
+            buf = DeviceBuffer(max(int(self.prowptr_host[-1]), 1) * 4)
+            _lib.call("fd_row_entry_positions_masked", self.npos, self.prowptr.ptr, self.gstart.ptr, sparsity._node_colidx.ptr,
+                      lgmap_ptr(clg), buf.ptr, None)
+            hit = (buf, clg)                          # (the entry keeps the lgmap alive: its id cannot be recycled)
+            while len(cache) >= 3:
+                cache.pop(next(iter(cache)))
+        cache[key] = hit
+        return hit[0]
+
     def runs(self, row_blocks):
         """Run-coded places of the accumulator entries for the row blocks ``row_blocks`` (host array of nblocks + 1 positions;
         fd_ocr_row_runs): (grun, brun, rdelta device buffers, most runs in one block), built once per set of blocks."""

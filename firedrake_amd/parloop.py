@@ -474,6 +474,8 @@ class Parloop:
             if lds > limit:
                 plans = None
         if plans is None:
+            blocks = None
+
             def uniform():
                 # uniform blocks, halved until the staged rows fit the LDS budget
                 epb = configuration["ents_per_block"]
@@ -522,11 +524,29 @@ class Parloop:
         if lds > 160 * 1024:
             raise PlanDoesNotFit("staged wrapper does not fit LDS even at 32 entities per block")
         kb = 2 if any(mp.kbytes == 2 for mp in mplans.values()) else 1
-        variant = mode_variant("stagedo" if order is not None else "staged", kb, [plans[mi].max_nd for mi in src.staged_maps])
-        # geometry-specific variant (16-bit matrix offsets, compile-time LDS strides, entity order); same parameter layout
-        # up to the order table
+        # maps whose staged rows see no reuse inside any block (every node list entry belongs to one map entry: the cell loop of a
+        # discontinuous space): LDS staging buys nothing there -- no gather is saved, no reduction happens -- and costs a dependent
+        # load chain, LDS capacity and a flush phase.  Their Dat arguments go straight from / to global memory ("_d" variants); maps
+        # a matrix plan hangs on, and the last staged map, stay
+        direct_maps = []
+        if configuration["staged_direct_noreuse"] and not mplans:
+            n_ent = pend - pstart
+            for mi in src.staged_maps:
+                if plans[mi].list_len == n_ent * maps[mi].arity and len(direct_maps) + 1 < len(src.staged_maps) \
+                        and order is None and self._affine_map(prep["maps"][mi], start, end):
+                    direct_maps.append(mi)
+        kept = [mi for mi in src.staged_maps if mi not in direct_maps]
+        variant = mode_variant("stagedo" if order is not None else "staged", kb, [plans[mi].max_nd for mi in kept], direct_maps=direct_maps)
+        # geometry-specific variant (16-bit matrix offsets, compile-time LDS strides, entity order, direct maps); the argument list
+        # is built from the VARIANT's layout (_arglist)
         cw = prep["cw"] if variant == src.mode else self.global_kernel.compile(variant)
-        assert [d for d in cw.src.layout if d[0] != "order"] == [d for d in src.layout if d[0] != "order"]
+        if direct_maps:
+            # ("_d" variants run in entity order: the kept plans are rebuilt without the lane order)
+            plans = {mi: maps[mi].plan(pstart, pend, epb if blocks is None else 0, blocks, lane_threads=cw.src.lane_threads) for mi in kept}
+            nd_ = {mi: lds_stride(p.max_nd) for mi, p in plans.items()}
+            lds = sum(((nd_[item[1]] * item[2] * item[3]) + 15) // 16 * 16 for item in cw.src.lds_items if item[0] == "dat")
+        else:
+            assert [d for d in cw.src.layout if d[0] != "order"] == [d for d in src.layout if d[0] != "order"]
         geo = {"epb": epb, "plans": plans, "mplans": mplans, "lds": lds, "cw": cw, "order": order, "range": (pstart, pend)}
         if configuration["debug"]:
             import sys
@@ -539,6 +559,22 @@ class Parloop:
                       f"kbytes={mp.kbytes} exclusive={mp.n_exclusive} zero_list={mp.n_zero}", file=sys.stderr)
         prep["parts"][key] = geo
         return geo
+
+    @staticmethod
+    def _affine_map(m, start, end):
+        """map[e][i] == arity*e + i for every entity of [start, end): the cell-node map of a discontinuous space (Firedrake numbers
+        DG nodes cell by cell).  Checked once per map and range on the host values; maps known only by a device pointer are not."""
+        b = m._base()
+        cache = b.__dict__.setdefault("_affine_ranges", {})
+        hit = cache.get((start, end))
+        if hit is None:
+            v = getattr(b, "_values", None)
+            hit = False
+            if isinstance(v, np.ndarray) and v.ndim == 2 and end <= len(v):
+                ar = v.shape[1]
+                hit = bool(np.array_equal(v[start:end], (np.arange(start, end, dtype=np.int64)[:, None] * ar + np.arange(ar)[None, :])))
+            cache[(start, end)] = hit
+        return hit
 
     def _reject_negative_mat_maps(self):
         """MatSetValuesLocal ignores negative indices (builder.py:573-625), so the maps of a Mat argument may hold -1 entries
@@ -1075,6 +1111,11 @@ class Parloop:
             raise PlanDoesNotFit("owner-computes-rows plan does not fit (LDS or instance list)")
         nds = [op.plans[mi].max_nd for mi in src.staged_maps]
         base = "ocrp" if row_order is not None else "ocr"
+        fx_wanted = (int(configuration["ocr_fixed_point"]) > 0 and int(sp.dsets[0].cdim) * int(sp.dsets[1].cdim) == 1
+                     and np.dtype(pa.data.dtype) == np.dtype("float64"))
+        if (base == "ocrp" and configuration["ocr_flush_colmask"] and bool(pa.lgmaps) and pa.maps[0]._base() is pa.maps[1]._base()
+                and not fx_wanted):
+            base = "ocrpm"          # BC columns masked by the flush's place table, not by a select per contribution
         rec = None
         if configuration["ocr_records"] and len(src.staged_maps) <= 8:
             from .codegen import record_layout
@@ -1296,7 +1337,11 @@ class Parloop:
             elif kind in ("ocr_grun", "ocr_brun", "ocr_rdelta"):
                 out.append(geo["runs"][{"ocr_grun": 0, "ocr_brun": 1, "ocr_rdelta": 2}[kind]].ptr)
             elif kind == "ocr_gpos":
-                out.append(geo["row_order"].gpos().ptr)
+                if src.mode.startswith("ocrpm"):
+                    pa_ = self.arguments[desc[1]]
+                    out.append(geo["row_order"].gpos_masked(pa_.data.sparsity, pa_.lgmaps[1], self._lgmap).ptr)
+                else:
+                    out.append(geo["row_order"].gpos().ptr)
             elif kind == "ocr_npos":
                 out.append(geo["row_order"].npos)
             elif kind in ("mat_row_lgmap", "mat_col_lgmap"):

@@ -389,6 +389,12 @@ int fd_row_order_tables(int32_t npos, const int32_t *plist_dev, const fd_nnz_t *
 /* gpos[prowptr[p] + k] = gstart[p] + k for the rows p of a row order (prowptr = accumulator starts by position, gstart = CSR
  * starts by position): the place of every accumulator entry in the CSR value array, streamed by the "ocrp" row flush */
 int fd_row_entry_positions(int32_t npos, const fd_nnz_t *prowptr_dev, const fd_nnz_t *gstart_dev, int32_t *gpos_dev, fd_stream_t s);
+/* The same places with a COLUMN lgmap folded in (what the reference's MatSetValuesLocal does with negative column indices,
+ * pyop2/codegen/builder.py:573-625, pyop2/parloop.py:279-302): an entry in a masked column reads -2 - place.  The whole-entity
+ * wrapper over a derived row order ("ocrpm") then adds every contribution unconditionally in LDS and lets the flush skip those
+ * entries (accumulating) or store 0.0 there (overwriting its rows): no select per contribution in the main loop. */
+int fd_row_entry_positions_masked(int32_t npos, const fd_nnz_t *prowptr_dev, const fd_nnz_t *gstart_dev, const int32_t *colidx_dev,
+                                  const int32_t *col_lgmap_dev, int32_t *gpos_dev, fd_stream_t s);
 /* The same places run-coded: rows that follow one another in a block of the row order (rblk: nblocks + 1 block starts in row
  * positions) AND in the CSR share one displacement (place - accumulator index).  grun[entry] = run of the entry's row counted
  * from its block's first run (one byte), brun[b] = first run of block b (nblocks + 1), rdelta[run] = displacement (room for

@@ -76,7 +76,7 @@ def _plan_copy_arg(pl, desc, plans, ptr):
 
 
 
-def run_staged(pl, epb=48, order=None):
+def run_staged(pl, epb=48, order=None, direct_noreuse=False):
     """Execute Parloop ``pl`` (Dat / Global arguments only) with the STAGED wrapper on the host: one OS thread per
     lane, workgroups one after the other, real barriers and atomics (tests/hostsim/mt/fd_wrapper.h).  The
     block-localisation plans come from the numpy restatement in helpers.py (itself checked against the device's
@@ -110,7 +110,18 @@ def run_staged(pl, epb=48, order=None):
         plans[mi] = (blk, lst, np.ascontiguousarray(lm), int(np.diff(blk).max()) if len(blk) > 1 else 0)
     bstart = np.array(list(range(start, end, epb)) + [end], dtype=np.int32)
     nblocks = len(bstart) - 1
-    src = generate_wrapper(gk, mode_variant("stagedo" if order is not None else "staged", 1, [plans[mi][3] for mi in base.staged_maps]))
+    # direct_noreuse: maps whose node lists show no reuse inside any block go straight from / to global memory ("_d" variants), the
+    # choice Parloop._staged_geometry makes from the device plans
+    direct = []
+    if direct_noreuse:
+        def affine(mi):                                     # map[e][i] == arity*e + i (what "_d" variants rely on)
+            v = np.asarray(maps[mi].values_with_halo)[start:end]
+            return np.array_equal(v, np.arange(start, end)[:, None] * v.shape[1] + np.arange(v.shape[1])[None, :])
+        direct = [mi for mi in base.staged_maps if len(plans[mi][1]) == (end - start) * maps[mi].arity and order is None and affine(mi)]
+        direct = direct[:max(len(base.staged_maps) - 1, 0)]
+    kept = [mi for mi in base.staged_maps if mi not in direct]
+    src = generate_wrapper(gk, mode_variant("stagedo" if order is not None else "staged", 1, [plans[mi][3] for mi in kept], direct_maps=direct))
+    assert src.staged_maps == kept and (not direct or "_d" in src.mode)
     text = src.source.replace("extern __shared__ __align__(16) unsigned char fd_lds[];", "unsigned char *fd_lds = fd_sim::lds;")
     # driver: the kernel's own parameter list, run as nblocks workgroups of T lanes
     sig = re.search(r'extern "C" __global__[^\n]*void %s\((.*)\)\n' % src.symbol, text).group(1)
@@ -147,6 +158,8 @@ def run_staged(pl, epb=48, order=None):
             cargs.append(ptr(bstart))
         elif kind == "order":
             cargs.append(ptr(np.asarray(order, dtype=np.int32)))
+        elif kind.startswith("plan_") and kind != "plan_copy" and desc[1] in direct:
+            raise AssertionError("a direct map has no plan parameters")
         elif kind == "plan_blkoff":
             cargs.append(ptr(plans[desc[1]][0]))
         elif kind == "plan_list":
@@ -202,6 +215,16 @@ def pack_records_ref(lmaps, lbits, kidx, nr, nc, kbits, diag, words, extra=None,
 NNZ = np.int64            # include/fdhip.h: fd_nnz_t (row starts of the value array and of the block accumulators)
 
 
+def row_entry_positions_masked_ref(gpos, colidx, clg):
+    """numpy restatement of fd_row_entry_positions_masked: places of entries in masked columns (clg[col] < 0) read -2 - place."""
+    gpos = np.asarray(gpos, dtype=np.int32).copy()
+    live = gpos >= 0
+    masked = np.zeros(len(gpos), dtype=bool)
+    masked[live] = np.asarray(clg)[np.asarray(colidx)[gpos[live]]] < 0
+    gpos[masked] = -2 - gpos[masked]
+    return gpos
+
+
 def row_runs_ref(prowptr, gstart, rb):
     """numpy restatement of fd_ocr_row_runs: (grun per entry, brun per block, rdelta per run, most runs in a block)."""
     npos = len(gstart)
@@ -222,7 +245,7 @@ def row_runs_ref(prowptr, gstart, rb):
     return grun, brun, rdelta, int(np.diff(brun).max()) if len(rb) > 1 else 0
 
 
-def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False, fixed_point=None):
+def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False, fixed_point=None, flush_colmask=False):
     """Execute a matrix-assembly Parloop ``pl`` with the OWNER-COMPUTES-ROWS wrapper on the host (one OS thread per
     lane, tests/hostsim/mt/fd_wrapper.h).  The plan tables come from the numpy restatements in helpers.py; the CSR
     pattern from the oracle.  Returns the OracleCSR holding the assembled values."""
@@ -265,7 +288,9 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False,
         from firedrake_amd.codegen import record_layout
         rec = record_layout([maps[mi].arity for mi in base.staged_maps], [plans[mi][3] for mi in base.staged_maps], rmap.arity,
                             cmap.arity, int(np.diff(csr.rowptr).max()), mpa.maps[0]._base() is mpa.maps[1]._base())
-    src = generate_wrapper(gk, mode_variant("ocrp" if order is not None else "ocr", 1,
+    # flush_colmask: "ocrpm" -- the column lgmap folded into the flush's place table (fd_row_entry_positions_masked)
+    assert not flush_colmask or (order is not None and mpa.lgmaps and fixed_point is None)
+    src = generate_wrapper(gk, mode_variant(("ocrpm" if flush_colmask else "ocrp") if order is not None else "ocr", 1,
                                             [plans[mi][3] for mi in base.staged_maps], rec) + ("_fx" if fixed_point is not None else ""))
     text = src.source.replace("extern __shared__ __align__(16) unsigned char fd_lds[];", "unsigned char *fd_lds = fd_sim::lds;")
     sig = re.search(r'extern "C" __global__[^\n]*void %s\((.*)\)\n' % src.symbol, text).group(1)
@@ -283,6 +308,8 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False,
 
     if not zero_pending:
         csr.values[...] = 1.0                     # accumulate on top of existing values
+    elif flush_colmask:
+        csr.values[...] = 7.0                     # a pending zero() is no memset: the loop overwrites every entry of its rows
     cargs = [ctypes.c_int(len(rb) - 1), ctypes.c_int(T), ctypes.c_int(0), ctypes.c_int(len(inst_ent))]
     for desc in src.layout:
         kind = desc[0]
@@ -374,6 +401,8 @@ def run_ocr(pl, rows_per_block=24, zero_pending=True, order=None, records=False,
             gp = np.full(max(int(prowptr[-1]), 1), -1, dtype=np.int32)
             for p_, r in enumerate(plist):
                 gp[prowptr[p_]:prowptr[p_] + plen[p_]] = np.arange(csr.rowptr[r], csr.rowptr[r + 1])
+            if flush_colmask:
+                gp = row_entry_positions_masked_ref(gp, csr.colidx, np.asarray(mpa.lgmaps[1]))
             cargs.append(ptr(gp))
         elif kind == "ocr_npos":
             cargs.append(ctypes.c_longlong(nrows))

@@ -105,8 +105,8 @@ def test_dg_advection_time_loop_conserves_mass_and_is_l2_stable():
     assert_allclose(st.dq.data_ro, dq, rtol=0, atol=1e-11 * np.abs(dq).max())
 
 
-@pytest.mark.parametrize("lane_strided", [1, 0])
-def test_dg_rhs_staged_wrappers_on_host(lane_strided, monkeypatch):
+@pytest.mark.parametrize("lane_strided,direct_noreuse", [(1, False), (0, False), (1, True)])
+def test_dg_rhs_staged_wrappers_on_host(lane_strided, direct_noreuse, monkeypatch):
     """The three staged wrappers of the demo's RHS (cell, exterior-facet and interior-facet loops: arity-8 maps, a
     direct uint32 facet-number Dat addressed through the lane-order entity formula, READ Globals) executed by the
     multi-threaded host-sim, chained like assemble_rhs, against the oracle."""
@@ -117,7 +117,9 @@ def test_dg_rhs_staged_wrappers_on_host(lane_strided, monkeypatch):
     L = np.zeros(m.dq_set.total_size)
     for loop, epb in zip(prob.loops, (30, 16, 70)):
         prob.L._host_rw()[...] = L                       # the loops accumulate into the same Dat
-        L = run_staged(loop, epb=epb)[0]
+        # direct_noreuse: the DQ1 map of the CELL loop has no reuse inside a block (every node belongs to one cell), so its READ and
+        # INC arguments bypass LDS ("_d" variant) beside the staged Q1 fields; the facet loops keep every map staged
+        L = run_staged(loop, epb=epb, direct_noreuse=direct_noreuse)[0]
     ref = _oracle_rhs(prob)
     assert np.abs(L - ref).max() <= 1e-12 * np.abs(ref).max()
 

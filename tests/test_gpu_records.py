@@ -91,6 +91,62 @@ def test_row_runs_match_numpy_restatement():
     assert np.array_equal(np.arange(int(prowptr[-1])) + d_ref[b_ref[blk] + g_ref[:int(prowptr[-1])]], gpos)
 
 
+def test_masked_entry_positions_match_numpy_restatement():
+    from hostsim import row_entry_positions_masked_ref
+    rng = np.random.default_rng(2)
+    npos, ncol = 3000, 3500
+    rowlen = rng.integers(1, 25, npos)
+    plist = rng.permutation(npos)
+    rp = np.concatenate([[0], np.cumsum(rowlen)]).astype(_lib.NNZ_DTYPE)
+    colidx = rng.integers(0, ncol, int(rp[-1])).astype(np.int32)
+    prowptr = np.concatenate([[0], np.cumsum(rowlen[plist])]).astype(_lib.NNZ_DTYPE)
+    gstart = rp[plist].astype(_lib.NNZ_DTYPE)
+    clg = np.arange(ncol, dtype=np.int32)
+    clg[rng.choice(ncol, ncol // 6, replace=False)] = -1
+    bufs = [DeviceBuffer.from_numpy(a) for a in (prowptr, gstart, colidx, clg)]
+    out, plain = DeviceBuffer(int(rp[-1]) * 4), DeviceBuffer(int(rp[-1]) * 4)
+    _lib.call("fd_row_entry_positions", npos, bufs[0].ptr, bufs[1].ptr, plain.ptr, None)
+    _lib.call("fd_row_entry_positions_masked", npos, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, out.ptr, None)
+    gp = _down(plain.ptr, np.int32, (int(rp[-1]),))
+    assert np.array_equal(gp, np.concatenate([np.arange(gstart[p], gstart[p] + rowlen[plist[p]]) for p in range(npos)]))
+    got = _down(out.ptr, np.int32, (int(rp[-1]),))
+    assert np.array_equal(got, row_entry_positions_masked_ref(gp, colidx, clg)) and (got < -1).sum() > 0
+
+
+@pytest.mark.parametrize("flush_colmask", [0, 1])
+def test_p1_jacobian_column_mask_in_the_flush_matches_oracle(flush_colmask, monkeypatch):
+    """"ocrpm": BC columns masked by the flush's place table.  Fresh assembly (the value array holds garbage: a pending zero() is no
+    memset), accumulation on top (masked entries untouched), and a swap of the lgmaps between calls (a new masked table)."""
+    monkeypatch.setitem(configuration, "ocr_flush_colmask", flush_colmask)
+    monkeypatch.setitem(configuration, "locality_min_entities", 64)
+    m = fmesh.UnitCubeMesh(12, degrees=(1,), perturb=0.1, numbering="lexicographic")
+    prob = forms.PoissonProblem(m, 1, bcs=True)
+    mat, pl = prob.jacobian()
+    mpa = pl.arguments[0]
+
+    def oracle():
+        args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
+        return oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0].values
+
+    mat._values_dev().upload(np.full(mat.sparsity.nz, 7.0))          # garbage under a pending zero()
+    mat.zero()
+    pl.compute()
+    geo = [g for key, g in pl._prepared["parts"].items() if key[0] == "ocr"][0]
+    assert geo["cw"].src.mode.startswith("ocrpm") == bool(flush_colmask)
+    ref = oracle()
+    assert np.abs(mat.csr()[2] - ref).max() <= 1e-12 * np.abs(ref).max()
+    pl.compute()                                                       # ADD_VALUES on top
+    assert np.abs(mat.csr()[2] - 2.0 * ref).max() <= 2e-12 * np.abs(ref).max()
+    nn = prob.V.node_set.total_size
+    lg = np.arange(nn, dtype=np.int32)
+    lg[np.random.default_rng(4).choice(nn, nn // 5, replace=False)] = -1
+    mpa.lgmaps = (lg, lg.copy())
+    mat.zero()
+    pl.compute()
+    ref2 = oracle()
+    assert np.abs(mat.csr()[2] - ref2).max() <= 1e-12 * np.abs(ref2).max()
+
+
 @pytest.mark.parametrize("numbering", ["tiled", "lexicographic", "random"])
 @pytest.mark.parametrize("records,diag", [(0, 0), (1, 0), (1, 1)])
 def test_p1_jacobian_with_compact_tables_matches_oracle(numbering, records, diag, monkeypatch):
@@ -108,7 +164,7 @@ def test_p1_jacobian_with_compact_tables_matches_oracle(numbering, records, diag
     if numbering == "tiled":
         assert geo["cw"].src.mode.startswith("ocr_") or geo["cw"].src.mode == "ocr"
     elif numbering == "lexicographic":
-        assert geo["cw"].src.mode.startswith("ocrp_")
+        assert geo["cw"].src.mode.startswith("ocrpm_" if records else "ocrpm")      # (BCs: column mask in the flush's place table)
     mpa = pl.arguments[0]
     args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
     ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]

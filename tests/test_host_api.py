@@ -131,14 +131,14 @@ def test_environment_switches_are_few_and_every_one_is_read():
                 names |= set(re.findall(r"FDHIP_[A-Z0-9_]+", fh.read()))
     expected = {"FDHIP_HIPCC", "FDHIP_ARCH", "FDHIP_CFLAGS", "FDHIP_CACHE_DIR", "FDHIP_DEBUG", "FDHIP_TRACE", "FDHIP_TYPE_CHECK", "FDHIP_PHASE_TIMES",
                 "FDHIP_MODE", "FDHIP_LDS_LIMIT", "FDHIP_PREFETCH", "FDHIP_PLAN_COPIES", "FDHIP_LOCALITY_ORDER", "FDHIP_TENSOR_WRAPPERS", "FDHIP_MAT_OCR",
-                "FDHIP_OCR_SLICED", "FDHIP_OCR_RECORDS", "FDHIP_OCR_FIXED_POINT", "FDHIP_OCR_NNZ", "FDHIP_OCR_NNZ_ORDERED", "FDHIP_OCRS_NNZ",
+                "FDHIP_OCR_SLICED", "FDHIP_OCR_RECORDS", "FDHIP_OCR_FIXED_POINT", "FDHIP_OCR_FLUSH_COLMASK", "FDHIP_OCR_NNZ", "FDHIP_OCR_NNZ_ORDERED", "FDHIP_OCRS_NNZ",
                 "FDHIP_OCRS_BLOCK_THREADS", "FDHIP_OCRS_PAIRS", "FDHIP_UNROLL_RETRY", "FDHIP_AUTO_OCCUPANCY_SCRATCH",
                 "FDHIP_HALO_WIRE", "FDHIP_PROFILE_CALLS", "FDHIP_SKIP_TORCH", "FDHIP_CSR_CHUNK"}
     assert names == expected and len(names) <= 30
     # entries of configuration.py: the integer ones take "7", the string ones "x7"
     with open(cfgmod.__file__) as fh:
         entries = re.findall(r'"(\w+)": _env\("(FDHIP_\w+)", [^,)]+(, int)?\)', fh.read())
-    assert len(entries) == 24              # (+ cache_dir, whose default is an expression)
+    assert len(entries) == 25              # (+ cache_dir, whose default is an expression)
     saved = {v: os.environ.get(v) for _, v, _ in entries}
     try:
         for _, var, is_int in entries:

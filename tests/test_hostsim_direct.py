@@ -603,6 +603,13 @@ def test_owner_computes_rows_over_a_row_order_on_host(bcs, numbering):
         for zp in (True, False):
             got4 = run_ocr(pl, rows_per_block=rpb, zero_pending=zp, order=order, records=True)
             assert np.abs(got4.values - (ref.values + (0.0 if zp else 1.0))).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
+        if bcs and degree == 1:
+            # "ocrpm": the BC columns masked by the flush's place table (-2 - place) instead of a select per contribution -- entries in
+            # masked columns are stored as 0.0 when the loop overwrites its rows (the value array starts as garbage) and left
+            # alone when it accumulates
+            for zp in (True, False):
+                got5 = run_ocr(pl, rows_per_block=rpb, zero_pending=zp, order=order, records=True, flush_colmask=True)
+                assert np.abs(got5.values - (ref.values + (0.0 if zp else 1.0))).max() <= 1e-12 * (1.0 + np.abs(ref.values).max())
 
 
 @pytest.mark.parametrize("bcs", [False, True])
