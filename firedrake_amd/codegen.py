@@ -261,11 +261,12 @@ def staged_eligible(gk: GlobalKernel, mats_on_virtual: bool = False, need_indire
             return False          # (matrix loops over virtual spaces: row-sliced owner-computes-rows only, sliced_eligible)
         if gk._extruded:
             if gk._iteration_region == ON_INTERIOR_FACETS and (
-                    not gk._constant_layers or (not mats_on_virtual and any(isinstance(a, MatKernelArg) for a in gk.arguments))
+                    (not mats_on_virtual and any(isinstance(a, MatKernelArg) for a in gk.arguments))
                     or any(isinstance(m, PermutedMapKernelArg) for a in gk.arguments for m in (getattr(a, "maps", None) or ()))):
                 return False          # (variable layers qualify: the derived map and the cell tables are ragged, set.py:326-337;
                                       #  periodic columns too: the wrap of builder.py:101-123 is folded into the derived map's rows;
-                                      #  interior facets of constant-layer columns in Dat loops: a derived row holds both stacked cells)
+                                      #  interior facets -- of constant- and, since round 6, variable-layer columns -- in Dat loops: a
+                                      #  derived row holds both stacked cells)
             if any(isinstance(a, DatKernelArg) and not a.is_indirect and la.access != READ
                    for a, la in zip(gk.arguments, gk.local_kernel.arguments)):
                 return False

@@ -623,6 +623,10 @@ class Parloop:
                     cnt, first = np.ones_like(ncell), la[:, 0]
                 elif reg == ON_TOP:
                     cnt, first = np.ones_like(ncell), la[:, 1] - 2
+                elif reg == ON_INTERIOR_FACETS:
+                    # one trip per pair of stacked cells of the entity's own column: layers [bottom_e, top_e - 2) (builder.py:806-809
+                    # with per-entity bounds, :754-776); a one-cell column has none
+                    cnt, first = np.maximum(ncell - 1, 0), la[:, 0]
                 else:
                     cnt, first = ncell, la[:, 0]
                 hit = self.__dict__["_virtual_var"] = VirtualSpace((0, 0), counts=cnt, first=first, bottom=la[:, 0])
@@ -654,7 +658,12 @@ class Parloop:
                     rows = rows[sub]
                 off = np.asarray(m.offset, dtype=np.int64)
                 rel = v.layer - v.bottom[v.col]                    # cells above the entity's own bottom (builder.py:94-124)
-                return (rows[v.col] + off[None, :] * rel[:, None]).astype(rows.dtype)
+                below = rows[v.col] + off[None, :] * rel[:, None]
+                from .op2types import ON_INTERIOR_FACETS as facets_
+                if self.global_kernel._iteration_region == facets_:
+                    # an interior facet sees the cell below and the cell above it: a row of 2 x arity nodes (f = 0, 1)
+                    return np.concatenate([below, below + off[None, :]], axis=1).astype(rows.dtype)
+                return below.astype(rows.dtype)
             return m.derived(key, build_var)
         bottom = int(it.layers_array[0][0]) if self.global_kernel._extruded else 0
         periodic = bool(self.global_kernel._extruded and self.global_kernel._extruded_periodic)

@@ -196,6 +196,55 @@ def test_interior_facet_matrix_loop(mode, periodic, monkeypatch):
     assert np.abs(v - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
 
 
+@pytest.mark.parametrize("mode", ["auto", "direct"])
+@pytest.mark.parametrize("subset", [False, True])
+def test_interior_facets_of_variable_layer_columns(mode, subset, monkeypatch):
+    """Round 6: ON_INTERIOR_FACETS on columns of DIFFERENT heights (builder.py:754-776 bounds per entity, :806-809 one trip per pair of
+    stacked cells) through the staged wrapper (Dat loop) and the row-sliced owner-computes-rows wrapper (Mat loop) -- the ragged
+    virtual space holds top_e - bottom_e - 2 facets per column, a derived row both cells' nodes -- and through the direct wrapper."""
+    monkeypatch.setitem(configuration, "mode", mode)
+    rng = np.random.default_rng(77)
+    nb, L, nv = 2500, 9, 800
+    base = op2.Set(nb)
+    bot, top = _columns(rng, nb, L)
+    top[:40] = bot[:40] + 2                                   # one-cell columns: no interior facet
+    ext = op2.ExtrudedSet(base, layers=np.stack([bot, top], axis=1))
+    nodes = op2.Set(nv * L)
+    tri = np.array([rng.choice(nv, 3, replace=False) for _ in range(nb)])
+    cm = op2.Map(ext, nodes, 6, np.concatenate([tri * L + bot[:, None], tri * L + bot[:, None] + 1], axis=1).astype(np.int32), offset=[1] * 6)
+    x = op2.Dat(nodes ** 2, rng.standard_normal((nv * L, 2)))
+    w = op2.Dat(base, rng.uniform(1, 2, nb))
+    out = op2.Dat(nodes)
+    it = op2.Subset(ext, rng.choice(nb, 1700, replace=False)) if subset else ext
+    kw = dict(iteration_region=op2.ON_INTERIOR_FACETS, pass_layer_arg=True)
+    k = op2.Kernel("static void kfv(double *o, const double *x, const double *w, int layer) { for (int i = 0; i < 12; ++i) "
+                   "o[i] += (1 + layer) * w[0] * ((i+1)*x[2*i] + 0.5*x[2*((i+5)%12)+1]); }", "kfv")
+    args = (out(op2.INC, cm), x(op2.READ, cm), w(op2.READ))
+    out.zero()
+    ref = oracle_run(k, it, *args, **kw)[0]
+    pl = op2.LegacyParloop(k, it, *args, **kw)
+    for _ in range(2):
+        out.zero()
+        pl()
+    assert pl._prepare()["cw"].src.mode.startswith("staged" if mode == "auto" else "direct")
+    assert np.abs(ref).max() > 0 and np.abs(out.data_ro - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    if subset:
+        return
+    mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(cm, cm, [op2.ON_INTERIOR_FACETS])]))
+    km = op2.Kernel("static void kfvm(double *A, const double *x, const double *w, int layer) { for (int i = 0; i < 12; ++i) "
+                    "for (int j = 0; j < 12; ++j) A[i*12 + j] += w[0] * (x[2*i] * x[2*j+1] + 0.125 * layer) + (i == j ? 1.0 : 0.0) + (i < 6 && j >= 6 ? 0.5 : 0.0); }", "kfvm")
+    margs = (mat(op2.INC, (cm, cm)), x(op2.READ, cm), w(op2.READ))
+    plm = op2.LegacyParloop(km, ext, *margs, **kw)
+    for _ in range(2):
+        mat.zero()
+        plm()
+    assert plm._prepare()["cw"].src.mode.startswith("ocrs" if mode == "auto" else "direct")
+    mref = oracle_run(km, ext, *margs, **kw)[0]
+    rp, ci, v = mat.csr()
+    assert np.array_equal(rp, mref.rowptr) and np.array_equal(ci, mref.colidx)
+    assert np.abs(v - mref.values).max() <= 1e-12 * np.abs(mref.values).max()
+
+
 def test_loops_without_any_cell_are_no_ops():
     """One cell layer has no interior facet: the staged wrapper's virtual space is empty and nothing is launched (the reference's
     wrapper loop runs zero trips, builder.py:806-809)."""

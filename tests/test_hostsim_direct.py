@@ -1195,3 +1195,46 @@ def test_write_and_max_through_maps_on_extruded_columns_on_host(region, periodic
         refs = oracle_run(k, it, *args, iteration_region=region)
         assert np.allclose(res[0], refs[0], rtol=1e-14, atol=0) and np.allclose(res[1], refs[1], rtol=1e-14, atol=0)
         assert (refs[0] != -7.0).sum() > 20 and (refs[1] > -1e29).sum() > 20
+
+
+def test_interior_facets_of_variable_layer_columns_on_host():
+    """Round 6: ON_INTERIOR_FACETS over columns of different heights through the staged wrapper (Dat loop) and the row-sliced
+    owner-computes-rows wrapper (Mat loop): the ragged virtual space holds top_e - bottom_e - 2 facets per column (a one-cell column
+    none), every derived map row the nodes of the cell below and of the cell above (builder.py:94-124, 754-776, 806-809)."""
+    from firedrake_amd.codegen import select_mode
+    from hostsim import run_ocrs, run_staged
+    rng = np.random.default_rng(33)
+    nbase, L, nv = 60, 7, 25
+    base = op2.Set(nbase)
+    bot = rng.integers(0, 3, nbase)
+    top = bot + 2 + rng.integers(0, L - 3, nbase)
+    top[:5] = bot[:5] + 2                                        # one cell: no interior facet
+    ext = op2.ExtrudedSet(base, layers=np.stack([bot, top], axis=1))
+    nodes = op2.Set(nv * (L + 2))
+    tri = np.array([rng.choice(nv, 3, replace=False) for _ in range(nbase)])
+    cm = op2.Map(ext, nodes, 6, np.concatenate([tri * (L + 2) + bot[:, None], tri * (L + 2) + bot[:, None] + 1], axis=1).astype(np.int32), offset=[1] * 6)
+    x = op2.Dat(nodes ** 2, rng.standard_normal((nodes.size, 2)))
+    w = op2.Dat(base, rng.uniform(1, 2, nbase))
+    out = op2.Dat(nodes)
+    kw = dict(iteration_region=op2.ON_INTERIOR_FACETS, pass_layer_arg=True)
+    k = op2.Kernel("static void kfvh(double *o, const double *x, const double *w, int layer) { for (int i = 0; i < 12; ++i) "
+                   "o[i] += (1 + layer) * w[0] * ((i+1)*x[2*i] + 0.5*x[2*((i+5)%12)+1]); }", "kfvh")
+    for it, epb in ((ext, 64), (op2.Subset(ext, [7, 2, 3] + list(range(12, 55))), 37)):
+        args = (out(op2.INC, cm), x(op2.READ, cm), w(op2.READ))
+        pl = op2.LegacyParloop(k, it, *args, **kw)
+        assert select_mode(pl.global_kernel) == "staged"
+        v = pl._virtual(staged=True)
+        assert v.ragged and (it is not ext or v.size(nbase) == int(np.maximum(top - bot - 2, 0).sum()))
+        got = run_staged(pl, epb=epb)[0]
+        ref = oracle_run(k, it, *args, **kw)[0]
+        assert np.abs(ref).max() > 0 and np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    mat = op2.Mat(op2.Sparsity((nodes ** 1, nodes ** 1), [(cm, cm, [op2.ON_INTERIOR_FACETS])]))
+    km = op2.Kernel("static void kfvhm(double *A, const double *x, const double *w, int layer) { for (int i = 0; i < 12; ++i) "
+                    "for (int j = 0; j < 12; ++j) A[i*12 + j] += w[0] * (x[2*i] * x[2*j+1] + 0.125 * layer) + (i == j ? 1.0 : 0.0) + (i < 6 && j >= 6 ? 0.5 : 0.0); }", "kfvhm")
+    margs = (mat(op2.INC, (cm, cm)), x(op2.READ, cm), w(op2.READ))
+    plm = op2.LegacyParloop(km, ext, *margs, **kw)
+    assert select_mode(plm.global_kernel) == "ocrs"
+    ref = oracle_run(km, ext, *margs, **kw)[0]
+    for got in (run_ocrs(plm, nnz_per_block=300), run_ocrs(plm, nnz_per_block=300, records=True)):
+        assert np.array_equal(got.rowptr, ref.rowptr) and np.array_equal(got.colidx, ref.colidx)
+        assert np.abs(got.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()

@@ -1,4 +1,4 @@
-"""tools/bench_extruded.py [n] [layers] [--variable] -- loops over an extruded set: Q1 Helmholtz matrix (8x8 element matrices) and
+"""tools/bench_extruded.py [n] [layers] [--variable] [--interior] [--check] -- loops over an extruded set: Q1 Helmholtz matrix (8x8 element matrices) and
 a Q1 nodal accumulation (Dat INC) on make_extruded_hex_mesh(n, layers, degree=1), map + offset*layer addressing
 (builder.py:94-124).  --variable: a bathymetry -- every column its own [bottom, top) (set.py:326-337), the map row of a column
 pointing at its own bottom cell -- i.e. VARIABLE layers.  Compare FDHIP_MODE=direct (one lane per column walking its layers,
@@ -32,13 +32,30 @@ if variable:
     xm = op2.Map(cells, m.coord_node_set, xm.arity, (np.asarray(xm.values_with_halo) + np.asarray(xm.offset)[None, :] * bot[:, None]).astype(np.int32),
                  offset=list(xm.offset))
     ncells = int((la[:, 1] - 1 - la[:, 0]).sum())
-sp = op2.Sparsity((m.node_set ** 1, m.node_set ** 1), [(cm, cm, None)])
-mat = op2.Mat(sp)
-pl = op2.LegacyParloop(q1_hex_helmholtz_kernel(), cells, mat(op2.INC, (cm, cm)), m.coordinates(op2.READ, xm))
+interior = "--interior" in sys.argv
 y = op2.Dat(m.node_set)
-kd = op2.Kernel("static void q1_acc(double *y, const double *x) { for (int i = 0; i < 8; ++i) { double s = 0.0; "
-                "for (int j = 0; j < 8; ++j) s += x[3*j] * x[3*((i + j) & 7) + 1] + x[3*j + 2]; y[i] += s; } }", "q1_acc")
-pd = op2.LegacyParloop(kd, cells, y(op2.INC, cm), m.coordinates(op2.READ, xm))
+if interior:
+    # --interior: the horizontal interior facets of the columns (dS_h, ON_INTERIOR_FACETS: the kernel sees the cell below and the cell
+    # above, 16 nodes; builder.py:806-809) -- a jump-penalty-like 16 x 16 matrix and a 16-node accumulation
+    sp = op2.Sparsity((m.node_set ** 1, m.node_set ** 1), [(cm, cm, [op2.ON_INTERIOR_FACETS])])
+    mat = op2.Mat(sp)
+    kf = op2.Kernel("static void q1_face(double *A, const double *x) { double h = 0.0; for (int i = 0; i < 8; ++i) h += x[3*(8 + i) + 2] - x[3*i + 2]; "
+                    "for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) A[i*16 + j] += 0.125 * h * ((i < 8) == (j < 8) ? 1.0 : -1.0) * (1.0 + x[3*i] * x[3*j + 1]); }",
+                    "q1_face")
+    kw = dict(iteration_region=op2.ON_INTERIOR_FACETS)
+    pl = op2.LegacyParloop(kf, cells, mat(op2.INC, (cm, cm)), m.coordinates(op2.READ, xm), **kw)
+    kd = op2.Kernel("static void q1_jump(double *y, const double *x) { for (int i = 0; i < 16; ++i) { double s = 0.0; "
+                    "for (int j = 0; j < 16; ++j) s += x[3*j] * x[3*((i + j) & 15) + 1] + x[3*j + 2]; y[i] += s; } }", "q1_jump")
+    pd = op2.LegacyParloop(kd, cells, y(op2.INC, cm), m.coordinates(op2.READ, xm), **kw)
+    ncells = int(np.maximum(la[:, 1] - 2 - la[:, 0], 0).sum()) if variable else m.base_set.size * (layers - 1)
+else:
+    kw = {}
+    sp = op2.Sparsity((m.node_set ** 1, m.node_set ** 1), [(cm, cm, None)])
+    mat = op2.Mat(sp)
+    pl = op2.LegacyParloop(q1_hex_helmholtz_kernel(), cells, mat(op2.INC, (cm, cm)), m.coordinates(op2.READ, xm))
+    kd = op2.Kernel("static void q1_acc(double *y, const double *x) { for (int i = 0; i < 8; ++i) { double s = 0.0; "
+                    "for (int j = 0; j < 8; ++j) s += x[3*j] * x[3*((i + j) & 7) + 1] + x[3*j + 2]; y[i] += s; } }", "q1_acc")
+    pd = op2.LegacyParloop(kd, cells, y(op2.INC, cm), m.coordinates(op2.READ, xm))
 
 
 def timed(zero, loop):
@@ -58,14 +75,14 @@ def timed(zero, loop):
 
 f1, t1 = timed(mat.zero, pl)
 f2, t2 = timed(y.zero, pd)
-print(f"n={n} layers={layers} variable={variable} cells={ncells} nnz={sp.nz} FDHIP_MODE={os.environ.get('FDHIP_MODE', 'auto')}: "
+print(f"n={n} layers={layers} variable={variable} interior_facets={interior} cells={ncells} nnz={sp.nz} FDHIP_MODE={os.environ.get('FDHIP_MODE', 'auto')}: "
       f"matrix mode={pl._prepare()['cw'].src.mode} first_call_s={f1:.2f} assemble_ms={1e3 * t1:.3f} ({sp.nz * 8 / t1 / 1e9:.0f} GB/s of values); "
       f"Dat loop mode={pd._prepare()['cw'].src.mode} first_call_s={f2:.2f} ms={1e3 * t2:.3f} ({ncells / t2 / 1e9:.2f} Gcells/s)")
 if "--check" in sys.argv:
     from helpers import oracle_run
-    ref = oracle_run(pl.global_kernel.local_kernel, cells, mat(op2.INC, (cm, cm)), m.coordinates(op2.READ, xm))[0]
+    ref = oracle_run(pl.global_kernel.local_kernel, cells, mat(op2.INC, (cm, cm)), m.coordinates(op2.READ, xm), **kw)[0]
     got = mat.csr()
     assert np.array_equal(got[0], ref.rowptr) and np.array_equal(got[1], ref.colidx)
     print("  matrix vs oracle: max |diff| / max |A| = %.2e" % (np.abs(got[2] - ref.values).max() / np.abs(ref.values).max()))
-    yr = oracle_run(kd, cells, op2.Dat(m.node_set)(op2.INC, cm), m.coordinates(op2.READ, xm))[0]
+    yr = oracle_run(kd, cells, op2.Dat(m.node_set)(op2.INC, cm), m.coordinates(op2.READ, xm), **kw)[0]
     print("  Dat loop vs oracle: max |diff| / max |y| = %.2e" % (np.abs(y.data_ro - yr[:, None] if y.data_ro.ndim > 1 else y.data_ro - yr).max() / np.abs(yr).max()))
