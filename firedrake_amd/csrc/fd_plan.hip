@@ -749,6 +749,7 @@ struct fd_ocrplan_s {
     // (device; 255 = none); rows_per_inst = 1 or 2 = rows of the per-instance tables
     int ngroups = 0, rows_per_inst = 1;
     uint8_t *groles = nullptr;
+    int32_t *chunk_block = nullptr;  // row block of every 64-slot chunk (the table builders look a block up per chunk, not per entry)
 };
 
 namespace {
@@ -1030,6 +1031,13 @@ __global__ void ocrs_fill(const uint64_t *__restrict__ keys, const int32_t *__re
     }
 }
 
+__global__ void ocrs_chunk_blocks(const int32_t *__restrict__ inst_off, int32_t nblocks, int32_t *__restrict__ chunk_block) {
+    // 64 lanes per block: its chunks [inst_off[b] / 64, inst_off[b+1] / 64)
+    const int lane = threadIdx.x & 63;
+    for (int64_t b = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6; b < nblocks; b += ((int64_t)gridDim.x * blockDim.x) >> 6)
+        for (int32_t c = (inst_off[b] >> 6) + lane; c < (inst_off[b + 1] >> 6); c += 64) chunk_block[c] = (int32_t)b;
+}
+
 __global__ void ocrs_block_offsets(const int64_t *__restrict__ pstart, int32_t nblocks, int ar, int32_t *__restrict__ off) {
     for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b <= nblocks; b += (int64_t)gridDim.x * blockDim.x)
         off[b] = (int32_t)pstart[b * ar];
@@ -1047,7 +1055,8 @@ __global__ void ocrs_tables_k(const int32_t *__restrict__ inst_off, int32_t nblo
                               const int32_t *__restrict__ rblk, const int32_t *__restrict__ rlg, const int32_t *__restrict__ clg,
                               uint16_t *__restrict__ slot, uint16_t *__restrict__ rowlen, KT *__restrict__ kk, int32_t *__restrict__ err,
                               int rbs, int cbs, uint8_t *__restrict__ rmask, unsigned long long *__restrict__ cmask,
-                              const uint8_t *__restrict__ groles, int NR, const int32_t *__restrict__ pinv, int32_t npos) {
+                              const uint8_t *__restrict__ groles, int NR, const int32_t *__restrict__ pinv, int32_t npos,
+                              const int32_t *__restrict__ chunk_block) {
     // rmask != nullptr: per-DOF lgmaps (``unroll``): rlg / clg are indexed by node*bs + component; a node row (column) is
     // dropped as a whole only when all its components are, the per-component bits go to rmask[t] / cmask[t]
     // NR = rows per instance (fd_ocrplan_create_paired: 2): the tables hold NR rows per instance, (t, s) at t*NR + s; a row of the
@@ -1067,8 +1076,7 @@ __global__ void ocrs_tables_k(const int32_t *__restrict__ inst_off, int32_t nblo
         bool live = valid[t] && r >= 0 && (rmask ? rm != 0 : !(rlg && rlg[r] < 0));
         int lo = 0;
         if (live && (j == 0 || NR > 1)) {
-            int hi = nblocks - 1;                      // block of instance t: largest b with inst_off[b] <= t
-            while (lo < hi) { int mid = lo + ((hi - lo + 1) >> 1); if (inst_off[mid] <= t) lo = mid; else hi = mid - 1; }
+            lo = chunk_block[t >> 6];                  // block of instance t
             if (NR > 1) {
                 const int32_t pos = row_position(pinv, npos, r);
                 live = pos >= rblk[lo] && pos < rblk[lo + 1];
@@ -1398,6 +1406,7 @@ int fd_ocrplan_free(fd_ocrplan_t p) {
     if (p->rblk) FD_HIP(hipFree(p->rblk));
     if (p->chunk_role) FD_HIP(hipFree(p->chunk_role));
     if (p->groles) FD_HIP(hipFree(p->groles));
+    if (p->chunk_block) FD_HIP(hipFree(p->chunk_block));
     if (p->valid) FD_HIP(hipFree(p->valid));
     free(p->inst_off_host);
     delete p;
@@ -1533,6 +1542,9 @@ static int create_sliced(const int32_t *rmap_dev, int ar, int32_t start, int32_t
     }
     hipLaunchKernelGGL(ocrs_block_offsets, dim3(mp_grid((int64_t)nblocks + 1)), dim3(256), 0, s, pstart, nblocks, ng, p->inst_off);
     FD_CHECK_LAUNCH();
+    FD_HIP(hipMalloc(&p->chunk_block, (size_t)(np_ / 64 + 1) * 4));
+    hipLaunchKernelGGL(ocrs_chunk_blocks, dim3(mp_grid((int64_t)nblocks * 64)), dim3(256), 0, s, p->inst_off, nblocks, p->chunk_block);
+    FD_CHECK_LAUNCH();
     FD_HIP(hipMemcpyAsync(p->inst_off_host, p->inst_off, ((size_t)nblocks + 1) * 4, hipMemcpyDeviceToHost, s));
     FD_HIP(hipStreamSynchronize(s));
     for (int32_t b = 0; b < nblocks; ++b) {
@@ -1575,12 +1587,12 @@ int fd_ocrplan_sliced_tables(fd_ocrplan_t p, const int32_t *rmap_dev, const int3
         hipLaunchKernelGGL(ocrs_tables_k<uint8_t>, dim3(mp_grid(total)), dim3(256), 0, s, p->inst_off, p->nblocks, p->inst_ent, p->valid,
                            p->chunk_role, p->ninst, rmap_dev, p->sliced_ar, cmap_dev, ac, rowptr_dev, colidx_dev, acc_by_node_dev,
                            acc_by_pos_dev, p->rblk, row_lgmap_dev, col_lgmap_dev, slot_out_dev, rowlen_out_dev, (uint8_t *)kk_out_dev, err,
-                           rbs, cbs, rowmask_out_dev, (unsigned long long *)colmask_out_dev, p->groles, NR, p->pinv, p->npos);
+                           rbs, cbs, rowmask_out_dev, (unsigned long long *)colmask_out_dev, p->groles, NR, p->pinv, p->npos, p->chunk_block);
     else
         hipLaunchKernelGGL(ocrs_tables_k<uint16_t>, dim3(mp_grid(total)), dim3(256), 0, s, p->inst_off, p->nblocks, p->inst_ent, p->valid,
                            p->chunk_role, p->ninst, rmap_dev, p->sliced_ar, cmap_dev, ac, rowptr_dev, colidx_dev, acc_by_node_dev,
                            acc_by_pos_dev, p->rblk, row_lgmap_dev, col_lgmap_dev, slot_out_dev, rowlen_out_dev, (uint16_t *)kk_out_dev, err,
-                           rbs, cbs, rowmask_out_dev, (unsigned long long *)colmask_out_dev, p->groles, NR, p->pinv, p->npos);
+                           rbs, cbs, rowmask_out_dev, (unsigned long long *)colmask_out_dev, p->groles, NR, p->pinv, p->npos, p->chunk_block);
     FD_CHECK_LAUNCH();
     int32_t h = 0;
     FD_HIP(hipMemcpyAsync(&h, err, 4, hipMemcpyDeviceToHost, s));

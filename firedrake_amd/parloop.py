@@ -337,6 +337,10 @@ class VirtualSpace(tuple):
         return self._dev
 
 
+# most entries a per-entry place table of 32-bit places can address (RowOrder.gpos; a module constant so that a test can lower it)
+WIDE_PLACES = 2 ** 31 - 1
+
+
 class PlanDoesNotFit(_lib.FDHipError):
     """A staged / owner-computes-rows plan exceeds the LDS or the plan builder's per-block capacity: the Parloop demotes
     the loop to the next wrapper shape (ocr -> staged -> direct) before anything is launched."""
@@ -914,8 +918,11 @@ class Parloop:
                             self._staged_geometry(*rng_)
                 return
             except PlanDoesNotFit as exc:
-                from .codegen import staged_eligible
+                from .codegen import _ocr_shape, staged_eligible
                 nxt = "staged" if (mode.startswith("ocr") and staged_eligible(self.global_kernel)) else "direct"
+                if getattr(exc, "retry_mode", None) == "ocrs" and not mode.startswith("ocrs") \
+                        and _ocr_shape(self.global_kernel, mats_on_virtual=True, allow_unroll=True) is not None:
+                    nxt = "ocrs"
                 if configuration["debug"]:
                     import sys
                     print(f"[fdhip] {self.global_kernel.name}: {exc}; falling back to the {nxt} wrapper", file=sys.stderr)
@@ -1068,11 +1075,15 @@ class Parloop:
                     cap = configuration["ocr_nnz_per_block_ordered"]
                     rb = row_order.tile_cuts(order.blocks, cap + cap // 10)
             if row_order is not None:
-                if int(row_order.prowptr_host[-1]) > 2 ** 31 - 1:
+                if int(row_order.prowptr_host[-1]) > WIDE_PLACES:
                     # the whole-entity flush of a derived row order streams 32-bit places (RowOrder.gpos): refused HERE, where
-                    # _prepare still can demote the loop to the row-sliced / staged / direct shapes, not at launch time
-                    raise PlanDoesNotFit("whole-entity owner-computes-rows under a derived row order holds 32-bit places: "
+                    # _ensure_geometry still can move the loop to another shape, not at launch time -- and the shape that serves
+                    # such patterns is the row-sliced one (run-coded flush: 64-bit row starts, one byte per entry), whatever the
+                    # size of the element matrix
+                    exc = PlanDoesNotFit("whole-entity owner-computes-rows under a derived row order holds 32-bit places: "
                                          "the pattern has 2^31 entries or more")
+                    exc.retry_mode = "ocrs"
+                    raise exc
                 prp = row_order.prowptr_host
             if rb is None:
                 targets = np.arange(0, int(prp[nrows]) + cap, cap)

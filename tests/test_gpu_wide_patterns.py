@@ -142,3 +142,27 @@ def test_cg2_cube_of_configs4_on_one_gpu():
     ya, yb = np.array(ta.data_ro), np.array(tb.data_ro)
     assert np.abs(np.array(t1.data_ro)).max() <= 1e-10 * np.abs(ya).max()
     assert abs(b @ ya - a @ yb) <= 1e-10 * (np.abs(b) @ np.abs(ya))
+
+
+def test_whole_entity_loops_on_wide_patterns_take_the_row_sliced_shape(monkeypatch):
+    """A P1-like (whole-entity) matrix loop over a derived row order flushes through 32-bit places; a pattern of 2^31 entries or more
+    used to end on the slow path.  It now moves to the row-sliced shape -- 64-bit row starts, run-coded flush --
+    whatever the size of its element matrix.  Exercised by lowering the limit: the P1 Jacobian takes "ocrs" and matches the oracle."""
+    from firedrake_amd import forms, mesh as fmesh, parloop
+    from firedrake_amd.configuration import configuration
+    from helpers import oracle_run
+    monkeypatch.setitem(configuration, "locality_min_entities", 64)
+    monkeypatch.setattr(parloop, "WIDE_PLACES", 1000)
+    m = fmesh.UnitCubeMesh(10, degrees=(1,), perturb=0.1, numbering="lexicographic")
+    prob = forms.PoissonProblem(m, 1, bcs=True)
+    mat, pl = prob.jacobian()
+    for _ in range(2):
+        mat.zero()
+        pl.compute()
+    assert pl._prepared["cw"].src.mode.startswith("ocrs")
+    geo = [g for key, g in pl._prepared["parts"].items() if key[0] == "ocr"][0]
+    assert geo["cw"].src.mode.startswith("ocrs") and geo["groups"] is not None and len(geo["groups"]) == 2       # two pairs of the four rows
+    mpa = pl.arguments[0]
+    args = [mat(op2.INC, mpa.maps, lgmaps=mpa.lgmaps)] + [pa.data(op2.READ, pa.map_) for pa in pl.arguments[1:]]
+    ref = oracle_run(pl.global_kernel.local_kernel, pl.iterset, *args)[0]
+    assert np.abs(mat.csr()[2] - ref.values).max() <= 1e-12 * np.abs(ref.values).max()

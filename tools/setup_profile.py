@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""tools/setup_profile.py [n] [numbering] -- where the time to first assemble goes at C2 size: wall time per phase and, with
+"""tools/setup_profile.py [n] [numbering] [degree] -- where the time to first assemble goes at C2 size: wall time per phase and, with
 FDHIP_PROFILE_CALLS=1 (set here), per C-ABI entry point including the device work each call queued."""
 import os
 import sys
@@ -13,8 +13,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 215
 nb = sys.argv[2] if len(sys.argv) > 2 else "lexicographic"
 _lib.require_gpu()
 t0 = time.perf_counter()
-m = fmesh.UnitCubeMesh(n, degrees=(1,), perturb=0.1, numbering=nb)
-prob = forms.PoissonProblem(m, 1, bcs=True)
+degree = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+m = fmesh.UnitCubeMesh(n, degrees=(degree,), perturb=0.1, numbering=nb)
+prob = forms.PoissonProblem(m, degree, bcs=True)
 print(f"mesh + problem      {time.perf_counter() - t0:8.3f} s")
 _lib.profile_report()
 import cProfile
