@@ -284,8 +284,10 @@ def staged_eligible(gk: GlobalKernel, mats_on_virtual: bool = False, need_indire
             # memory itself while the READ / INC arguments of the loop are staged -- on plain sets, subsets and constant-layer
             # extruded sets (cell regions; the lane applies the layer arithmetic of builder.py:94-124 to the base entity's map row as
             # the direct wrapper does), and not in matrix loops
+            # (round 6: variable layers and interior facets too -- the lane takes the column's own bottom from the layers array and
+            # walks both stacked cells of a facet; periodic columns of variable height stay direct)
             if any(isinstance(b, MatKernelArg) for b in gk.arguments) or (
-                    gk._extruded and (not gk._constant_layers or gk._iteration_region == ON_INTERIOR_FACETS)):
+                    gk._extruded and not gk._constant_layers and gk._extruded_periodic):
                 return False
     return n_ind > 0 or not need_indirect_dat
 
@@ -498,7 +500,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         P("const int *__restrict__ fd_order_", ("order",))
     # variable layers: (position, layer) of every cell of the virtual iteration space, read where a direct argument or the layer
     # argument needs them
-    vtab = bool(staged and varlay and (gk._pass_layer_arg or any(i_["kind"] == "dat" and "m" not in i_ for i_ in infos)))
+    vtab = bool(staged and varlay and (gk._pass_layer_arg or any(i_["kind"] == "dat" and ("m" not in i_ or not in_lds(i_)) for i_ in infos)))
     if vtab:
         P("const int *__restrict__ fd_vcol_", ("virt_col",))
         P("const int *__restrict__ fd_vlay_", ("virt_layer",))
@@ -1017,6 +1019,10 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             if extruded and varlay:
                 out.append(f"    const int fd_col = {'fd_vcol_[%s]' % v if vtab else '0'}; const int layer = {'fd_vlay_[%s]' % v if vtab else '0'};")
                 out.append("    const int e = " + ("subset_indices[fd_col];" if gk._subset else "fd_col;"))
+                if any(i_["kind"] == "dat" and "m" in i_ and not in_lds(i_) for i_ in infos):
+                    # WRITE / RW / MIN / MAX arguments addressed from the lane: the column's own [bottom, top) row (the layers array
+                    # belongs to the superset: indexed by the entity, builder.py:754-776)
+                    out.append("    const int *__restrict__ lay = layers + 2*(size_t)e;")
             elif extruded:
                 out.append(f"    const int fd_col = ({v}) / fd_nlit; const int layer = fd_llo + (({v}) - fd_col*fd_nlit);")
                 out.append("    const int e = " + ("subset_indices[fd_col];" if gk._subset else "fd_col;"))

@@ -72,3 +72,43 @@ def test_write_and_max_through_maps_on_extruded_columns(mode, periodic, monkeypa
         assert pl._prepare()["cw"].src.mode.startswith("staged" if mode == "auto" else "direct")
         assert np.allclose(out.data_ro, refs[0], rtol=1e-14, atol=0) and np.allclose(hi.data_ro, refs[1], rtol=1e-14, atol=0)
         assert (refs[0] != -7.0).sum() > 1000
+
+
+@pytest.mark.parametrize("mode", ["auto", "direct"])
+@pytest.mark.parametrize("shape", ["variable", "facets", "variable-facets"])
+def test_write_and_max_through_maps_on_variable_layers_and_interior_facets(mode, shape, monkeypatch):
+    """Round 6: the last two extruded shapes on which a WRITE / MAX argument through a map demoted the loop to the direct wrapper --
+    columns of variable height and interior facets -- now keep the staged wrapper: the READ arguments come from LDS, the lane
+    addresses the others itself from the column's own bottom (builder.py:754-776) and over both stacked cells (builder.py:94-124)."""
+    monkeypatch.setitem(configuration, "mode", mode)
+    rng = np.random.default_rng(83)
+    nb, L, nv = 3000, 8, 900
+    base = op2.Set(nb)
+    if shape.startswith("variable"):
+        bot = rng.integers(0, 3, nb)
+        top = bot + 2 + rng.integers(0, L - 3, nb)
+        layers = np.stack([bot, top], axis=1)
+    else:
+        bot = np.zeros(nb, dtype=np.int64)
+        layers = L
+    ext = op2.ExtrudedSet(base, layers=layers)
+    nodes = op2.Set(nv * (L + 2))
+    tri = np.array([rng.choice(nv, 3, replace=False) for _ in range(nb)])
+    cm = op2.Map(ext, nodes, 6, np.concatenate([tri * (L + 2) + bot[:, None], tri * (L + 2) + bot[:, None] + 1], axis=1).astype(np.int32), offset=[1] * 6)
+    x = op2.Dat(nodes ** 2, rng.standard_normal((nodes.size, 2)))
+    cv = op2.Dat(base, rng.standard_normal(nb))
+    facets = shape.endswith("facets")
+    n = 12 if facets else 6
+    k = op2.Kernel(f"static void interp_max_v(double *o, double *hi, const double *x, const double *c) {{ for (int i = 0; i < {n}; ++i) {{ "
+                   "o[i] = 2.0*x[2*i] - x[2*i+1]*x[2*i+1]; const double v = c[0] + x[2*i]; if (v > hi[i]) hi[i] = v; } }", "interp_max_v")
+    region = op2.ON_INTERIOR_FACETS if facets else None
+    for it in (ext, op2.Subset(ext, rng.choice(nb, 2000, replace=False))):
+        out = op2.Dat(nodes, np.full(nodes.size, -7.0))
+        hi = op2.Dat(nodes, np.full(nodes.size, -1e30))
+        args = (out(op2.WRITE, cm), hi(op2.MAX, cm), x(op2.READ, cm), cv(op2.READ))
+        refs = oracle_run(k, it, *args, iteration_region=region)
+        pl = op2.LegacyParloop(k, it, *args, iteration_region=region)
+        pl()
+        assert pl._prepare()["cw"].src.mode.startswith("staged" if mode == "auto" else "direct")
+        assert np.allclose(out.data_ro, refs[0], rtol=1e-14, atol=0) and np.allclose(hi.data_ro, refs[1], rtol=1e-14, atol=0)
+        assert (refs[0] != -7.0).sum() > 1000

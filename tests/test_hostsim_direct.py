@@ -1238,3 +1238,43 @@ def test_interior_facets_of_variable_layer_columns_on_host():
     for got in (run_ocrs(plm, nnz_per_block=300), run_ocrs(plm, nnz_per_block=300, records=True)):
         assert np.array_equal(got.rowptr, ref.rowptr) and np.array_equal(got.colidx, ref.colidx)
         assert np.abs(got.values - ref.values).max() <= 1e-12 * np.abs(ref.values).max()
+
+
+@pytest.mark.parametrize("shape", ["variable", "facets", "variable-facets"])
+def test_write_and_max_through_maps_on_variable_layers_and_interior_facets_on_host(shape):
+    """Round 6: WRITE / MAX arguments through maps beside staged READ arguments on the last two extruded shapes that demoted such a
+    loop to the direct wrapper -- columns of VARIABLE height (the lane takes the column's own bottom from the layers array,
+    builder.py:754-776) and INTERIOR FACETS (the lane walks both stacked cells of the facet, builder.py:94-124 with f = 0, 1)."""
+    from firedrake_amd.codegen import select_mode
+    from hostsim import run_staged
+    rng = np.random.default_rng(83)
+    nbase, L, nv = 50, 7, 21
+    base = op2.Set(nbase)
+    if shape.startswith("variable"):
+        bot = rng.integers(0, 3, nbase)
+        top = bot + 2 + rng.integers(0, L - 3, nbase)
+        layers = np.stack([bot, top], axis=1)
+    else:
+        bot = np.zeros(nbase, dtype=np.int64)
+        layers = L
+    ext = op2.ExtrudedSet(base, layers=layers)
+    nodes = op2.Set(nv * (L + 2))
+    tri = np.array([rng.choice(nv, 3, replace=False) for _ in range(nbase)])
+    cm = op2.Map(ext, nodes, 6, np.concatenate([tri * (L + 2) + bot[:, None], tri * (L + 2) + bot[:, None] + 1], axis=1).astype(np.int32), offset=[1] * 6)
+    x = op2.Dat(nodes ** 2, rng.standard_normal((nodes.size, 2)))
+    cv = op2.Dat(base, rng.standard_normal(nbase))
+    facets = shape.endswith("facets")
+    n = 12 if facets else 6
+    k = op2.Kernel(f"static void interp_max_v(double *o, double *hi, const double *x, const double *c) {{ for (int i = 0; i < {n}; ++i) {{ "
+                   "o[i] = 2.0*x[2*i] - x[2*i+1]*x[2*i+1]; const double v = c[0] + x[2*i]; if (v > hi[i]) hi[i] = v; } }", "interp_max_v")
+    region = op2.ON_INTERIOR_FACETS if facets else None
+    for it in (ext, op2.Subset(ext, [5, 1, 3, 6] + list(range(10, 45)))):
+        out = op2.Dat(nodes, np.full(nodes.size, -7.0))
+        hi = op2.Dat(nodes, np.full(nodes.size, -1e30))
+        args = (out(op2.WRITE, cm), hi(op2.MAX, cm), x(op2.READ, cm), cv(op2.READ))
+        pl = op2.LegacyParloop(k, it, *args, iteration_region=region)
+        assert select_mode(pl.global_kernel) == "staged"
+        res = run_staged(pl, epb=64)
+        refs = oracle_run(k, it, *args, iteration_region=region)
+        assert np.allclose(res[0], refs[0], rtol=1e-14, atol=0) and np.allclose(res[1], refs[1], rtol=1e-14, atol=0)
+        assert (refs[0] != -7.0).sum() > 20 and (refs[1] > -1e29).sum() > 20
