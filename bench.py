@@ -1064,7 +1064,7 @@ def main():
         shape = (n * pg[0], n * pg[1], n * pg[2])        # weak scaling: every rank owns an n^3 cube of cubes
         out = poisson_line(args, ctx, degree, shape, "weak", "BASELINE.json configs[1] per GPU" if degree == 1 else f"CG{degree}, weak",
                            args.numbering, args.variants, args.traffic == "auto", cpu=(args.cpu_sample > 0 and world == 1),
-                           accum_ab=not args.inner_pmc)
+                           accum_ab=(not args.inner_pmc and args.traffic == "auto"))      # (profiled / traced runs: one mode per kernel name)
     if args.inner_pmc:
         # profiled child of collect_traffic(): the secondary configs' kernels in the same pass (a few launches each)
         if args.secondary and args.workload == "c2" and world == 1:
