@@ -178,7 +178,9 @@ template <int ARITY> __device__ __forceinline__ void load_lmap(const uint16_t *_
 // owner-computes-rows loop back to back -- the local-map entries at ceil(log2(nodes per block)) bits, the row-offset entries
 // at ceil(log2(longest CSR row)) bits -- instead of uint16 / uint8 arrays: P1 tetrahedra 24 -> 12 bytes per instance.
 // Field offsets and widths are compile-time constants, so a field is one v_bfe_u32 (two instructions when it straddles words).
-// ---- checked fixed-point accumulation (codegen mode suffix "_fx", whole-entity owner-computes-rows loops).
+// ---- checked fixed-point accumulation (codegen mode suffix "_fx", whole-entity owner-computes-rows loops; OPT-IN since round 6:
+// FDHIP_OCR_FIXED_POINT=1 -- the sums below are exact sums of contributions ROUNDED to a quantum of the row block's scale, accurate
+// relative to the block's largest contribution, not to each row's own entries; the default adds in fp64 like the reference).
 // ds_add_u64 runs at ~6 lanes per clock on scattered addresses where ds_add_f64 runs at ~3.3 (profiles/r1i_microbench_lds.txt)
 // and the LDS atomics bind the P1 Jacobian.  A contribution x therefore enters the LDS accumulator as the INTEGER
 // k = round(x S): the bit pattern of fma(x, S, 1.5 * 2^52) is 0x4338 << 48 plus k in two's complement (|k| < 2^51), and the low
