@@ -533,7 +533,7 @@ class Parloop:
         # load chain, LDS capacity and a flush phase.  Their Dat arguments go straight from / to global memory ("_d" variants); maps
         # a matrix plan hangs on, and the last staged map, stay
         direct_maps = []
-        if configuration["staged_direct_noreuse"] and not mplans:
+        if configuration["staged_direct_noreuse"] and not mplans and self._virtual() is None:        # (plain sets: [start, end) are entity ids)
             n_ent = pend - pstart
             for mi in src.staged_maps:
                 if plans[mi].list_len == n_ent * maps[mi].arity and len(direct_maps) + 1 < len(src.staged_maps) \
