@@ -600,18 +600,21 @@ def measure(prob, args, world, dist, backend, torch):
     first = {}
     do_res, do_jac = args.only != "jacobian", args.only != "residual"
 
-    def step(ev=None):
+    def step(ev=None, dom=None):
+        """``ev``: the full set of 7 events (assemble-level and kernel-level brackets of both forms); ``dom``: the two events that
+        bracket the DOMINANT kernel only -- what the timed region carries (an event is a barrier packet between two dependent
+        kernels: 7 per step cost 20 us of a 1.3 ms step, profiles/r6p_overlap_probe_c2.txt)."""
         if ev is not None:
             ev[0].record()
         if do_res:
             prob.u.dat_version += 1            # a Newton step changes u: nothing cached on its values may be reused ...
             if world > 1:
                 prob.u.halo_valid = False      # ... and its ghost copies are refreshed every step
-            prob.assemble_residual(events=None if ev is None else (ev[1], ev[2]))
+            prob.assemble_residual(events=(ev[1], ev[2]) if ev is not None else (dom if (dom is not None and not do_jac) else None))
         if ev is not None:
             ev[3].record()
         if do_jac:
-            prob.assemble_jacobian(events=None if ev is None else (ev[4], ev[5]))
+            prob.assemble_jacobian(events=(ev[4], ev[5]) if ev is not None else dom)
         if ev is not None:
             ev[6].record()
 
@@ -629,20 +632,30 @@ def measure(prob, args, world, dist, backend, torch):
     first["plans_jacobian_first_call"] = time.perf_counter() - t0
     for _ in range(max(args.warmup - 1, 0)):
         step()
-    ev = [[Event() for _ in range(7)] for _ in range(args.steps)]
+    # the timed region: EXACTLY args.steps steps, each carrying the HIP-event bracket of the dominant kernel (the Jacobian wrapper
+    # when both forms run: 2/3 of the step in every configuration of this file) on the stream it is launched on
+    dom = [(Event(), Event()) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(ev[k])
+        step(dom=dom[k])
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    med = lambda i, j: float(np.median([ev[k][i].elapsed_ms(ev[k][j]) for k in range(args.steps)]))
+    dom_ms = float(np.median([a.elapsed_ms(b) for a, b in dom]))
+    # the breakdown (the other kernel, the assemble-level brackets): the same steps once more with all 7 events, after the clock stopped
+    nd = max(min(args.steps, 10), 3)
+    ev = [[Event() for _ in range(7)] for _ in range(nd)]
+    for k in range(nd):
+        step(ev[k])
+    barrier()
+    med = lambda i, j: float(np.median([ev[k][i].elapsed_ms(ev[k][j]) for k in range(nd)]))
     return {"ms_per_step": elapsed / args.steps * 1e3, "first": first,
-            "res_kernel_ms": med(1, 2) if do_res else None, "jac_kernel_ms": med(4, 5) if do_jac else None,
+            "res_kernel_ms": (med(1, 2) if do_jac else dom_ms) if do_res else None, "jac_kernel_ms": dom_ms if do_jac else None,
+            "jac_kernel_ms_detail_pass": med(4, 5) if do_jac else None, "detail_steps": nd,
             "res_assemble_ms": med(0, 3), "jac_assemble_ms": med(3, 6)}
 
 
@@ -822,6 +835,9 @@ def poisson_line(args, ctx, degree, shape, scaling, label, numbering, variants, 
             # the wrapper kernel alone: map + coords + 2 coefficients + the output, against the kernel's own duration
             b = algorithmic_bytes(ncell_local, arity, nnode_local, 3, 2, **coord_kw)
             roof_res = roof(kres, res["res_kernel_ms"], b, assemble_ms=res["res_assemble_ms"],
+                            events=("HIP events around this kernel in every step of the timed region" if not res["jac_kernel_ms"] else
+                                    f"HIP events in a pass of {res['detail_steps']} further steps after the timed region (the timed steps "
+                                    "carry the dominant kernel's bracket only); assemble_ms from the same pass"),
                             note="kernel-only bytes and time; assemble_ms adds the zeroing pass (a13) and the BC fix-up (a14)"
                                  + ("; at N > 1 the bracket also holds the forward halo exchange (see multi_gpu.residual_kernel_only_ms)" if world > 1 else ""))
         if res["jac_kernel_ms"]:
@@ -830,6 +846,9 @@ def poisson_line(args, ctx, degree, shape, scaling, label, numbering, variants, 
             b = algorithmic_bytes(ncell_local, arity, nnode_local, 3, 0, nnz, zeroing=not jac_ocr, **coord_kw)
             bz = algorithmic_bytes(ncell_local, arity, nnode_local, 3, 0, nnz, zeroing=True, **coord_kw)
             roof_jac = roof(kjac, res["jac_kernel_ms"], b, assemble_ms=res["jac_assemble_ms"],
+                            events="HIP events around this kernel in every step of the timed region, median; assemble_ms and "
+                                   f"ms_detail_pass from a pass of {res['detail_steps']} further steps with all 7 events per step",
+                            ms_detail_pass=res["jac_kernel_ms_detail_pass"],
                             frac_with_zeroing=bz / (res["jac_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             note="kernel-only; strict bytes (no credit for the zeroing pass the kernel makes unnecessary)")
             # how the element matrices were ADDED in the timed launches (the reference: fp64, MatSetValuesLocal ADD_VALUES,

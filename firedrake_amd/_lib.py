@@ -43,6 +43,8 @@ SIGNATURES = {
     "fd_stream_create": (c_int, [POINTER(c_void_p)]),
     "fd_stream_destroy": (c_int, [c_void_p]),
     "fd_stream_sync": (c_int, [c_void_p]),
+    "fd_stream_set_default": (c_int, [c_void_p]),
+    "fd_stream_wait_event": (c_int, [c_void_p, c_void_p]),
     "fd_device_sync": (c_int, []),
     "fd_event_create": (c_int, [POINTER(c_void_p)]),
     "fd_event_destroy": (c_int, [c_void_p]),
@@ -135,6 +137,8 @@ SIGNATURES = {
                                      POINTER(c_void_p), c_void_p]),
     "fd_csr_elem_offsets": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int, c_int, c_int, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
+    "fd_csr_diag_positions": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
+    "fd_csr_set_at": (c_int, [c_void_p, c_void_p, c_int32, c_double, c_void_p]),
     "fd_csr_set_diagonal": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_double, c_void_p]),
     "fd_csr_zero_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_double, c_void_p]),
     "fd_csr_spmv": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -136,6 +136,22 @@ __global__ void set_diag(const fd_nnz_t *__restrict__ rowptr, const int32_t *__r
     }
 }
 
+// places of the diagonal entries of the selected rows (-1: row not selected / no diagonal entry), found once; set_at then is one
+// coalesced read of the places and one scattered store per row instead of rows -> rowptr -> log2(row length) dependent colidx loads
+__global__ void diag_positions(const fd_nnz_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const int32_t *__restrict__ rows,
+                               int32_t n, fd_nnz_t *__restrict__ pos) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const int r = rows[t];
+        pos[t] = r < 0 ? (fd_nnz_t)-1 : csr_find(rowptr, colidx, r, r);
+    }
+}
+__global__ void set_at(double *__restrict__ vals, const fd_nnz_t *__restrict__ pos, int32_t n, double v) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const fd_nnz_t q = pos[t];
+        if (q >= 0) vals[q] = v;
+    }
+}
+
 // ---- MPIAIJ split (pyop2/types/mat.py:254-278: d_nnz / o_nnz; MatCreateMPIAIJWithSplitArrays): columns are sorted
 // inside a row and the owned columns [0, ncols_owned) come first, so the diagonal block is a prefix of every row
 __global__ void split_counts(int32_t nrows, const fd_nnz_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, int32_t ncols_owned,
@@ -485,6 +501,20 @@ int fd_csr_set_diagonal(const fd_nnz_t *rowptr, const int32_t *colidx, double *v
                         double v, fd_stream_t s) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(set_diag, dim3(grid_for(n)), dim3(256), 0, fd::st(s), rowptr, colidx, vals, rows, n, v, 0);
+    FD_CHECK_LAUNCH();
+    return 0;
+}
+
+int fd_csr_diag_positions(const fd_nnz_t *rowptr, const int32_t *colidx, const int32_t *rows, int32_t n, fd_nnz_t *pos, fd_stream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(diag_positions, dim3(grid_for(n)), dim3(256), 0, fd::st(s), rowptr, colidx, rows, n, pos);
+    FD_CHECK_LAUNCH();
+    return 0;
+}
+
+int fd_csr_set_at(double *vals, const fd_nnz_t *pos, int32_t n, double v, fd_stream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(set_at, dim3(grid_for(n)), dim3(256), 0, fd::st(s), vals, pos, n, v);
     FD_CHECK_LAUNCH();
     return 0;
 }

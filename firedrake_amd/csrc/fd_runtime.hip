@@ -19,6 +19,7 @@ extern char **environ;
 
 namespace fd {
 static hipStream_t g_default_stream = nullptr;
+static hipStream_t g_saved_stream = nullptr;      // the default stream a graph capture displaced (fd_graph_begin .. fd_graph_end)
 hipStream_t default_stream() { return g_default_stream; }
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
@@ -69,6 +70,10 @@ int fd_stream_create(fd_stream_t *s) { hipStream_t h; FD_HIP(hipStreamCreateWith
 int fd_stream_destroy(fd_stream_t s) { FD_HIP(hipStreamDestroy(fd::st(s))); return 0; }
 int fd_stream_sync(fd_stream_t s) { FD_HIP(hipStreamSynchronize(fd::st(s))); return 0; }
 int fd_device_sync(void) { FD_HIP(hipDeviceSynchronize()); return 0; }
+// The stream every call with a NULL stream argument uses from now on (NULL: back to the HIP null stream).  Two independent
+// parloops -- the residual and the Jacobian of one Newton step -- are put on two streams this way and share the device.
+int fd_stream_set_default(fd_stream_t s) { fd::g_default_stream = reinterpret_cast<hipStream_t>(s); return 0; }
+int fd_stream_wait_event(fd_stream_t s, fd_event_t e) { if (!e) FD_FAIL("fd_stream_wait_event: null event"); FD_HIP(hipStreamWaitEvent(fd::st(s), e->ev, 0)); return 0; }
 
 int fd_event_create(fd_event_t *e) { auto *p = new fd_event_s; hipError_t r = hipEventCreate(&p->ev); if (r != hipSuccess) { delete p; FD_HIP(r); } *e = p; return 0; }
 int fd_event_destroy(fd_event_t e) { if (e) { FD_HIP(hipEventDestroy(e->ev)); delete e; } return 0; }
@@ -85,13 +90,15 @@ int fd_graph_begin(fd_graph_t *out) {
     if (r != hipSuccess) { delete g; FD_HIP(r); }
     r = hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal);
     if (r != hipSuccess) { (void)hipStreamDestroy(g->stream); delete g; FD_HIP(r); }
+    fd::g_saved_stream = fd::g_default_stream;
     fd::g_default_stream = g->stream;
     *out = g;
     return 0;
 }
 
 int fd_graph_end(fd_graph_t g) {
-    fd::g_default_stream = nullptr;
+    fd::g_default_stream = fd::g_saved_stream;
+    fd::g_saved_stream = nullptr;
     if (!g) FD_FAIL("fd_graph_end: null graph");
     FD_HIP(hipStreamEndCapture(g->stream, &g->graph));
     FD_HIP(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0));

@@ -86,3 +86,62 @@ class Event:
         except Exception:
             pass
 
+
+
+class Stream:
+    """A non-blocking HIP stream of the library (fd_stream_create).  The reference runs its parloops one after another on the host
+    (pyop2/parloop.py:243-260); here a parloop is stream-ordered device work, and two loops that write different tensors and only
+    READ what they share -- ``assemble(F)`` and ``assemble(J)`` of one Newton step -- can be put on two streams and share the
+    device: the latency-bound staged residual fills the issue slots the LDS-bound Jacobian leaves idle.  ``with side.fork(): ...``
+    runs the enclosed launches on ``side`` after everything enqueued so far; ``side.join()`` makes the launching stream wait for
+    them.  Nothing here synchronises the host."""
+
+    _current = None      # the stream NULL-stream calls of the library resolve to (None = the HIP null stream)
+
+    def __init__(self):
+        p = ctypes.c_void_p()
+        _lib.call("fd_stream_create", ctypes.byref(p))
+        self.h = p.value
+        self._fork, self._done = Event(), Event()
+
+    def sync(self):
+        _lib.call("fd_stream_sync", self.h)
+
+    def wait(self, event: "Event"):
+        _lib.call("fd_stream_wait_event", self.h, event.h)
+
+    def fork(self):
+        return _Forked(self)
+
+    def join(self):
+        """The launching stream waits for the work enqueued inside the last ``fork()`` block."""
+        _lib.call("fd_stream_wait_event", Stream._current.h if Stream._current is not None else None, self._done.h)
+
+    def __del__(self):
+        try:
+            if self.h:
+                _lib.load().fd_stream_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class _Forked:
+    def __init__(self, side):
+        self.side = side
+
+    def __enter__(self):
+        s = self.side
+        self.prev = Stream._current
+        s._fork.record()                     # on the launching stream: everything enqueued so far ...
+        s.wait(s._fork)                      # ... precedes the side stream's work
+        _lib.call("fd_stream_set_default", s.h)
+        Stream._current = s
+        return s
+
+    def __exit__(self, *exc):
+        s = self.side
+        s._done.record()                     # (on the side stream: it is still the default)
+        _lib.call("fd_stream_set_default", self.prev.h if self.prev is not None else None)
+        Stream._current = self.prev
+        return False

@@ -528,9 +528,7 @@ class PoissonProblem:
         if events:
             events[1].record()
         if len(self.bc_nodes):
-            sp = mat.sparsity
-            _lib.call("fd_csr_set_diagonal", sp._rowptr.ptr, sp._colidx.ptr, mat._values_dev().ptr, self._bc_rows().ptr,
-                      len(self.bc_nodes), ctypes.c_double(1.0), None)
+            mat.set_diagonal_rows(self._bc_rows(), len(self.bc_nodes), 1.0)
         return mat
 
 
@@ -775,9 +773,7 @@ class HelmholtzHexProblem:
         if events:
             events[1].record()
         if len(self.bc_nodes):
-            sp = self.sparsity
-            _lib.call("fd_csr_set_diagonal", sp._rowptr.ptr, sp._colidx.ptr, self.mat._values_dev().ptr, self._bc_rows().ptr,
-                      len(self.bc_nodes), ctypes.c_double(1.0), None)
+            self.mat.set_diagonal_rows(self._bc_rows(), len(self.bc_nodes), 1.0)
         return self.mat
 
     def assemble_action(self, events=None):

@@ -2355,6 +2355,7 @@ class Mat:
         self._vals = None
         self._zero_pending = False
         self.dat_version = 0
+        self._diag_lists, self._diag_pos = {}, {}      # set_local_diagonal_entries: row lists / diagonal places kept on the device
         # mixed spaces: one Mat per block of the nested sparsity (MATNEST, mat.py:741-768)
         self._blocks = ([[Mat(sparsity[i, j], dtype, f"{self.name}_{i}_{j}") for j in range(sparsity.shape[1])]
                          for i in range(sparsity.shape[0])] if sparsity.nested else [[self]])
@@ -2475,12 +2476,34 @@ class Mat:
         if rbs > 1:
             comps = range(rbs) if idx is None else [idx]
             r = np.concatenate([r * rbs + c for c in comps]).astype(np.int32)
-        d = DeviceBuffer.from_numpy(r)
+        # a Newton / time loop applies the same row list after every assembly: the list and the places of its diagonal entries
+        # stay on the device, keyed by the list's content (a handful of lists per matrix: one per set of boundary conditions)
+        key = (len(r), hash(r.tobytes()))
+        hit = self._diag_lists.get(key)
+        if hit is None:
+            if len(self._diag_lists) >= 8:
+                self._diag_lists.pop(next(iter(self._diag_lists)))
+            hit = self._diag_lists[key] = DeviceBuffer.from_numpy(r)
+        self.set_diagonal_rows(hit, len(r), diag_val)
+        _lib.call("fd_device_sync")
+
+    def set_diagonal_rows(self, rows_dev, n, diag_val=1.0):
+        """``set_local_diagonal_entries`` for a row list that already lives on the device (int32 scalar rows, negative = skip): the
+        places of the diagonal entries are searched once per (list, pattern) -- ``fd_csr_diag_positions`` -- and every later call is
+        one store per row through them, stream-ordered, no host synchronisation."""
+        if n <= 0:
+            return
         sp = self._sparsity
         sp._build()
-        _lib.call("fd_csr_set_diagonal", sp._rowptr.ptr, sp._colidx.ptr,
-                  self._values_dev().ptr, d.ptr, len(r), float(diag_val), None)
-        _lib.call("fd_device_sync")
+        key = (rows_dev.ptr, int(n))
+        pos = self._diag_pos.get(key)
+        if pos is None:
+            if len(self._diag_pos) >= 8:
+                self._diag_pos.pop(next(iter(self._diag_pos)))
+            buf = DeviceBuffer(int(n) * 8)
+            _lib.call("fd_csr_diag_positions", sp._rowptr.ptr, sp._colidx.ptr, rows_dev.ptr, int(n), buf.ptr, None)
+            pos = self._diag_pos[key] = (buf, rows_dev)          # (the list is kept alive with its places: the key is its address)
+        _lib.call("fd_csr_set_at", self._values_dev().ptr, pos[0].ptr, int(n), float(diag_val), None)
         self.dat_version += 1
 
     def zero_rows(self, rows, diag_val=1.0):                               # mat.py:857-891

@@ -58,6 +58,12 @@ int fd_stream_create(fd_stream_t *s);
 int fd_stream_destroy(fd_stream_t s);
 int fd_stream_sync(fd_stream_t s);
 int fd_device_sync(void);
+/* Stream every later call with a NULL stream argument runs on (NULL = the HIP null stream again), and the
+ * event edge between two streams.  The reference runs its parloops one after another on the host
+ * (pyop2/parloop.py:243-260); on the device two loops that share no written argument -- assemble(F) and
+ * assemble(J) of one Newton step -- may be put on two streams and overlap (firedrake_amd/op2types.py: stream()). */
+int fd_stream_set_default(fd_stream_t s);
+int fd_stream_wait_event(fd_stream_t s, fd_event_t e);
 
 /* HIP events recorded on the launch stream (PETSc Log.Event analogue of
  * pyop2/parloop.py:221-232; used by bench.py for per-kernel durations). */
@@ -327,6 +333,13 @@ int fd_csr_set_diagonal(const fd_nnz_t *rowptr_dev, const int32_t *colidx_dev, d
                         const int32_t *rows_dev, int32_t nrows_sel, double value, fd_stream_t s);
 int fd_csr_zero_rows(const fd_nnz_t *rowptr_dev, const int32_t *colidx_dev, double *vals_dev,
                      const int32_t *rows_dev, int32_t nrows_sel, double value, fd_stream_t s);
+/* The same diagonal fix-up for a row list that is applied at every assembly (Dirichlet rows of a Newton loop: the reference
+ * calls set_local_diagonal_entries after every assemble(J), firedrake/assemble.py -> mat.py:896-937, and PETSc searches each row
+ * each time): the places of the diagonal entries are found once (-1: negative row id or no diagonal entry in the pattern) and
+ * fd_csr_set_at stores through them. */
+int fd_csr_diag_positions(const fd_nnz_t *rowptr_dev, const int32_t *colidx_dev, const int32_t *rows_dev, int32_t nrows_sel,
+                          fd_nnz_t *pos_out_dev, fd_stream_t s);
+int fd_csr_set_at(double *vals_dev, const fd_nnz_t *pos_dev, int32_t n, double value, fd_stream_t s);
 /* y = A x  (parity identity  A*x == action(a, x), tests/firedrake/regression/test_matrix_free.py:97-123) */
 int fd_csr_spmv(int32_t nrows, const fd_nnz_t *rowptr_dev, const int32_t *colidx_dev,
                 const double *vals_dev, const double *x_dev, double *y_dev, fd_stream_t s);
