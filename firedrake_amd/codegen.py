@@ -525,6 +525,19 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             P(f"const int *__restrict__ p{mi}_list", ("plan_list", mi))
             P(f"const unsigned short *__restrict__ p{mi}_lmap", ("plan_lmap", mi))
             P(f"long long p{mi}_maxnd", ("plan_maxnd", mi))
+    def stage_unroll(mi):
+        """nodes a lane stages (and flushes) per batch: ceil(nodes per block / lanes), from the compile-time node stride of the map;
+        owner-computes-rows blocks (run-time strides, 600-1000 nodes for 512 lanes) take 2; 1 = the one-node-per-trip loops"""
+        if not configuration["stage_batch"]:
+            return 1
+        if ocr:
+            # owner-computes-rows blocks keep one node per trip: their staging depends on no node id (plan-ordered tables and
+            # copies), and two nodes per lane measured 1-4 % SLOWER on the P1 Jacobian (profiles/r6q_ab_stage_batch.txt)
+            return 1
+        if strides is None or mi not in staged_maps or len(strides) != len(staged_maps):
+            return 1
+        return max(1, min(int(configuration["stage_batch"]), -(-strides[staged_maps.index(mi)] // threads)))
+
     def srow_table(info):
         """whole-entity owner-computes-rows, row map = column map: the per-node row words come from a plan-ordered table
         (fd_ocr_node_words) instead of per-node gathers of a row start and two lgmap entries"""
@@ -673,8 +686,10 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                     P(f"const {ct} *__restrict__ pl{k}", ("plan_copy", k, mi))
                     node_actions.setdefault(mi, []).append(
                         ([f"{ct} v{k}_U[{c}];",
-                          f"if (pl{k}) {{ for (int j = 0; j < {c}; ++j) v{k}_U[j] = pl{k}[(size_t)(l0_{mi} + I_U)*{c} + j]; }} "
-                          f"else {{ for (int j = 0; j < {c}; ++j) v{k}_U[j] = arg{k}[(size_t)G_U*{c} + j]; }}"],
+                          # (uniform condition, streaming branch, gathering branch): a batched staging loop hoists the condition
+                          # over the batch, so the streamed rows are requested without waiting for the node ids
+                          ("IF", f"pl{k}", f"for (int j = 0; j < {c}; ++j) v{k}_U[j] = pl{k}[(size_t)(l0_{mi} + I_U)*{c} + j];",
+                           f"for (int j = 0; j < {c}; ++j) v{k}_U[j] = arg{k}[(size_t)G_U*{c} + j];")],
                          [f"for (int j = 0; j < {c}; ++j) s{k}[{'j*(int)p%d_maxnd + I_U' % mi if soa else 'I_U*%d + j' % c}] = v{k}_U[j];"]))
                     if nf == 1:
                         idx = f"j*(int)p{mi}_maxnd + lm{mi}[{_permi(perm, 'i')}]" if soa else f"lm{mi}[{_permi(perm, 'i')}]*{c} + j"
@@ -693,9 +708,22 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                     else:
                         unpack.append(f"for (int f = 0; f < {nf}; ++f) for (int i = 0; i < {ar}; ++i) for (int j = 0; j < {c}; ++j) "
                                       f"atomicAdd(&s{k}[lm{mi}[f*{ar} + {_permi(perm, 'i')}]*{c} + j], t{k}[(f*{ar}+i)*{c}+j]);")
-                    flush.append((mi, f"for (int q = tid; q < nd{mi}*{c}; q += nthr) {{ const int i = q / {c}; "
-                                      f"fdw::atomic_add<{ct}>(&arg{k}[(size_t)p{mi}_list[l0_{mi} + i]*{c} + (q - i*{c})], "
-                                      f"s{k}[q]); }}"))
+                    fu = stage_unroll(mi)
+                    if fu == 1:
+                        flush.append((mi, f"for (int q = tid; q < nd{mi}*{c}; q += nthr) {{ const int i = q / {c}; "
+                                          f"fdw::atomic_add<{ct}>(&arg{k}[(size_t)p{mi}_list[l0_{mi} + i]*{c} + (q - i*{c})], "
+                                          f"s{k}[q]); }}"))
+                    else:
+                        # the node ids the flush scatters through are requested BEFORE the barrier that ends the main loop (a batch
+                        # per lane, like the places of the owner-computes-rows flush): the flush itself waits for no load
+                        ld = (f"for (int f = 0; f < {fu}; ++f) {{ const int q = Q0 + f*nthr; "
+                              f"fl{k}[f] = q < nd{mi}*{c} ? p{mi}_list[l0_{mi} + q / {c}] : 0; }}")
+                        flush_pre_decl.append(f"int fl{k}[{fu}];")
+                        flush_pre.append(ld.replace("Q0", "tid"))
+                        flush.append((mi, f"for (int q0 = tid; q0 < nd{mi}*{c}; q0 += {fu}*nthr) {{ "
+                                          f"if (q0 >= {fu}*nthr) {{ {ld.replace('Q0', 'q0')} }} "
+                                          f"for (int f = 0; f < {fu}; ++f) {{ const int q = q0 + f*nthr; if (q < nd{mi}*{c}) "
+                                          f"fdw::atomic_add<{ct}>(&arg{k}[(size_t)fl{k}[f]*{c} + (q - (q / {c})*{c})], s{k}[q]); }} }}"))
                 call_args.append(f"t{k}")
                 continue
             nexpr = node(mi, ar, "i", off, perm, "f")
@@ -922,13 +950,46 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         stage_src += ["  " + s for _, s in stage]
         # node-major staging: the node-list entry is requested first, then all the rows that depend on it
         for mi, acts in node_actions.items():
-            stage_src.append(f"  for (int i_0 = tid; i_0 < nd{mi}; i_0 += nthr) {{")
-            if any("G_U" in l for act in acts for part in (0, 1) for l in act[part]):
-                stage_src.append(f"    const int g_0 = p{mi}_list[l0_{mi} + i_0];")
-            for part in (0, 1):
+            fu = stage_unroll(mi)
+            flat = lambda l: l if isinstance(l, str) else f"if ({l[1]}) {{ {l[2]} }} else {{ {l[3]} }}"
+            needs_g = any("G_U" in flat(l) for act in acts for part in (0, 1) for l in act[part])
+            if fu == 1:
+                stage_src.append(f"  for (int i_0 = tid; i_0 < nd{mi}; i_0 += nthr) {{")
+                if needs_g:
+                    stage_src.append(f"    const int g_0 = p{mi}_list[l0_{mi} + i_0];")
+                for part in (0, 1):
+                    for act in acts:
+                        for l in act[part]:
+                            stage_src.append("    " + flat(l).replace("_U", "_0").replace("G_0", "g_0").replace("I_0", "i_0"))
+                stage_src.append("  }")
+                continue
+            # A lane stages several nodes (nodes per block / lanes per block, known from the compile-time stride).  One node per trip
+            # made every trip a chain of dependent memory round trips -- node id, then the rows gathered through it -- and the trips
+            # followed one another: 4 round trips for the 405 nodes of a P1 block before its main loop could start.  All node ids
+            # of a lane's batch are requested first, then the rows of the whole batch argument by argument (plan-ordered copies
+            # do not wait for the node ids: their uniform null test is hoisted over the batch), then LDS is written: two round
+            # trips whatever the batch.  Indices are clamped to the block's last node and the stores are unconditional too (a lane
+            # beyond the end rewrites the last node's row with the same values): any guard makes the compiler sink the loads of
+            # the later nodes behind it, one round trip each again
+            sub = lambda l, f: l.replace("_U", f"_{f}").replace(f"G_{f}", f"g_{f}").replace(f"I_{f}", f"i_{f}")
+            stage_src.append(f"  for (int i_b = tid; i_b < nd{mi}; i_b += {fu}*nthr) {{")
+            for f in range(fu):
+                stage_src.append(f"    const int i_{f} = min(i_b + {f}*nthr, nd{mi} - 1);")
+            if needs_g:
+                for f in range(fu):
+                    stage_src.append(f"    const int g_{f} = p{mi}_list[l0_{mi} + i_{f}];")
+            for act in acts:
+                for l in act[0]:
+                    if isinstance(l, str):
+                        for f in range(fu):
+                            stage_src.append("    " + sub(l, f))
+                    else:
+                        stage_src.append(f"    if ({l[1]}) {{ " + " ".join(sub(l[2], f) for f in range(fu)) + " } else { "
+                                         + " ".join(sub(l[3], f) for f in range(fu)) + " }")
+            for f in range(fu):
                 for act in acts:
-                    for l in act[part]:
-                        stage_src.append("    " + l.replace("_U", "_0").replace("G_0", "g_0").replace("I_0", "i_0"))
+                    for l in act[1]:
+                        stage_src.append("    " + sub(flat(l), f))
             stage_src.append("  }")
         if fx:
             stage_src.append("  if (tid == 0) fd_fxmax = 0u;")
@@ -940,10 +1001,19 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
         # software pipeline: the packed index rows of the NEXT entity are requested before the current
         # entity's local kernel runs, so their HBM latency hides under ~10^2 fp64 instructions
         idx_loads = []      # (register row, its prefetch twin, name, length, load template: II = iteration index, EE = entity)
+        raw_decode = []     # unpacking of index rows that travel as raw words (top of the trip)
         for mi in staged_maps:
             ar = maps[mi].arity * (nf if staged and not ocr else 1)       # (interior facets: the derived row holds both stacked cells)
-            idx_loads.append((f"int lm{mi}[{ar}]", f"int nx_lm{mi}[{ar}]", f"lm{mi}", ar,
-                              f"fdw::load_lmap<{ar}>(p{mi}_lmap + (size_t)(II - start)*{ar}, DST);"))
+            if configuration["stage_batch"] and ar % 2 == 0 and not ocr:
+                # the packed row travels through the software pipeline as RAW words and is unpacked at the top of the trip that
+                # uses it: load_lmap's shifts follow its loads directly, which made the request of the first trip's row -- issued
+                # ahead of the staging phase on purpose -- a wait of one memory round trip at the head of every block
+                idx_loads.append((f"unsigned lw{mi}[{ar // 2}]", f"unsigned nx_lw{mi}[{ar // 2}]", f"lw{mi}", ar // 2,
+                                  f"fdw::load_rec<{ar // 2}>((const unsigned *)(p{mi}_lmap + (size_t)(II - start)*{ar}), DST);"))
+                raw_decode += [f"int lm{mi}[{ar}];", f"fdw::unpack_lmap<{ar}>(lw{mi}, lm{mi});"]
+            else:
+                idx_loads.append((f"int lm{mi}[{ar}]", f"int nx_lm{mi}[{ar}]", f"lm{mi}", ar,
+                                  f"fdw::load_lmap<{ar}>(p{mi}_lmap + (size_t)(II - start)*{ar}, DST);"))
         for info in infos:
             if info["kind"] == "mat" and mat_staged[info["k"]]:
                 k, n = info["k"], info["ar"] * info["ac"]
@@ -1075,7 +1145,7 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
                     out.append(f"    const int e = {ent_of('it')};")
                 for cur, nxt, name, n, ld in idx_loads:
                     out.append(f"    {cur}; " + ld.replace("II", "it").replace("EE", "e").replace("DST", name))
-            out += ["    " + s_ for s_ in rec_decode]
+            out += ["    " + s_ for s_ in (rec_decode or raw_decode)]
             out += ["    " + s_ for s_ in pack]
             out.append(f"    fdk::{lk.name}({', '.join(call_args)});")
             out += ["    " + s_ for s_ in unpack_lines]

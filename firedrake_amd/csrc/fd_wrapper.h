@@ -255,6 +255,11 @@ template <int W> __device__ __forceinline__ void load_rec(const unsigned *__rest
         for (int k = 0; k < W; ++k) w[k] = p[k];          // (three adjacent words fuse into one global_load_dwordx3)
     }
 }
+// uint16 index row carried as raw words (load_rec<ARITY / 2>): entry 2k in the low half of word k
+template <int ARITY> __device__ __forceinline__ void unpack_lmap(const unsigned (&w)[ARITY / 2], int (&out)[ARITY]) {
+#pragma unroll
+    for (int k = 0; k < ARITY / 2; ++k) { out[2 * k] = (int)(w[k] & 0xffffu); out[2 * k + 1] = (int)(w[k] >> 16); }
+}
 template <int OFF, int BITS, int W> __device__ __forceinline__ int rec_field(const unsigned (&w)[W]) {
     constexpr int I = OFF >> 5, S = OFF & 31;
     constexpr unsigned M = BITS >= 32 ? 0xffffffffu : ((1u << BITS) - 1u);

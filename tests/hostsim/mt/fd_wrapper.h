@@ -197,11 +197,15 @@ template <int H> inline void fx_update(fx_block_t *rec, const fx_block_t &r, uns
     *rec = n;
 }
 template <int W> inline void load_rec(const unsigned *p, unsigned (&w)[W]) { for (int k = 0; k < W; ++k) w[k] = p[k]; }
+template <int ARITY> inline void unpack_lmap(const unsigned (&w)[ARITY / 2], int (&out)[ARITY]) {
+    for (int k = 0; k < ARITY / 2; ++k) { out[2 * k] = (int)(w[k] & 0xffffu); out[2 * k + 1] = (int)(w[k] >> 16); }
+}
 template <int OFF, int BITS, int W> inline int rec_field(const unsigned (&w)[W]) {
     unsigned long long v = w[OFF >> 5];
     if ((OFF >> 5) + 1 < W) v |= (unsigned long long)w[(OFF >> 5) + 1] << 32;
     return (int)((v >> (OFF & 31)) & ((1ull << BITS) - 1ull));
 }
 }  // namespace fdw
+static inline int min(int a, int b) { return a < b ? a : b; }      // (HIP's device-side integer min, used by the generated staging loops)
 
 #include "../../../oracle/callables.h"

@@ -156,6 +156,7 @@ def test_environment_switches_are_few_and_every_one_is_read():
         # (the package's other modules hold the ORIGINAL dictionary object: put the restored values into it)
         from firedrake_amd.codegen import configuration as live
         live.update(restored)
+        cfgmod.configuration = live           # ... and later importers of the module see that object again
 
 
 def test_weight_templates_keep_kernel_names_that_contain_parameter_tokens():

@@ -1278,3 +1278,43 @@ def test_write_and_max_through_maps_on_variable_layers_and_interior_facets_on_ho
         refs = oracle_run(k, it, *args, iteration_region=region)
         assert np.allclose(res[0], refs[0], rtol=1e-14, atol=0) and np.allclose(res[1], refs[1], rtol=1e-14, atol=0)
         assert (refs[0] != -7.0).sum() > 20 and (refs[1] > -1e29).sum() > 20
+
+
+@pytest.mark.parametrize("stage_batch", [4, 2, 0])
+def test_staged_wrapper_batched_staging_and_flush_on_host(stage_batch, monkeypatch, plan_copies):
+    """Blocks with MORE nodes than lanes: a lane stages a batch of nodes (all node ids, then all rows, then LDS: clamped indices,
+    unconditional stores) and preloads the node ids of the flush ahead of the main loop's last barrier; the index rows travel as raw
+    words.  P1 residual (scalar INC) and a vector-valued INC Dat (cdim 2: the flush walks (node, component) pairs) against the
+    oracle, with blocks whose node counts are not multiples of the lane count and a last block that is nearly empty."""
+    import re
+    from firedrake_amd import forms
+    from firedrake_amd.codegen import generate_wrapper, mode_variant
+    from firedrake_amd.configuration import configuration
+    from hostsim import run_staged
+    monkeypatch.setitem(configuration, "stage_batch", stage_batch)
+    coords, cells = structured_tri_mesh(37, 29, perturb=0.2)
+    nodes, ele = op2.Set(len(coords)), op2.Set(len(cells))
+    m = op2.Map(ele, nodes, 3, cells)
+    x = op2.Dat(nodes ** 2, coords)
+    rng = np.random.default_rng(5)
+    f = op2.Dat(nodes, rng.standard_normal(len(coords)))
+    u = op2.Dat(nodes, rng.standard_normal(len(coords)))
+    kr = forms.poisson_residual_kernel(2, 1)
+    args = (op2.Dat(nodes)(op2.INC, m), x(op2.READ, m), u(op2.READ, m), f(op2.READ, m))
+    pl = op2.LegacyParloop(kr, ele, *args)
+    src = generate_wrapper(pl.global_kernel, mode_variant("staged", 1, [700])).source
+    assert ("i_b += 3*nthr" in src) == (stage_batch == 4) and ("i_b += 2*nthr" in src) == (stage_batch == 2)
+    for epb in (1100, 2000):                      # ~600 / ~1050 nodes per block for 256 lanes
+        got = run_staged(pl, epb=epb)[0]
+        ref = oracle_run(kr, ele, *args)[0]
+        assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    # even arity (raw index rows) and a vector-valued INC argument
+    it = op2.Set(2500)
+    mp = op2.Map(it, nodes, 4, rng.integers(0, len(coords), size=(2500, 4)))
+    o2, d2 = op2.Dat(nodes ** 2), op2.Dat(nodes ** 2, rng.standard_normal((len(coords), 2)))
+    k2 = op2.Kernel("static void k2v(double *o, const double *d) { for (int i = 0; i < 4; ++i) for (int c = 0; c < 2; ++c) "
+                    "o[2*i + c] += d[2*((i+1)%4) + c] - 0.5*d[2*i + 1 - c]; }", "k2v")
+    pl2 = op2.LegacyParloop(k2, it, o2(op2.INC, mp), d2(op2.READ, mp))
+    got = run_staged(pl2, epb=1300)[0]
+    ref = oracle_run(k2, it, o2(op2.INC, mp), d2(op2.READ, mp))[0]
+    assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
