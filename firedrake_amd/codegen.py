@@ -87,7 +87,7 @@ def _distinct_maps(gk: GlobalKernel):
 
 def tensor_eligible(gk: GlobalKernel):
     """'matrix' / 'action' when the loop can take the tensor-product wrappers of csrc/fd_tensor.h: a
-    TensorProductLocalKernel of degree k = 1..5 with up to 7 Gauss points per axis (tensor_geometry) over an extruded set
+    TensorProductLocalKernel of degree k = 1..8 with up to 11 Gauss points per axis (tensor_geometry) over an extruded set
     with constant layers, the whole column (iteration region ALL), no subset, and the argument shapes
         matrix:  Mat INC (dims (D, D), both maps the (k+1)^3-node Q_k map, offset k)  +  coordinates READ (dim 3, 8-node Q1 map)
         action:  Dat INC (dim D, Q_k map)  +  coordinates READ  +  Dat READ (dim D, the same Q_k map)
@@ -145,18 +145,26 @@ def tensor_geometry(degree, nq):
     workgroups per cell (one wavefront per 16-row panel of the padded element matrix), ``action_cells`` cells per 128-lane
     workgroup of the action."""
     k1, q1 = int(degree) + 1, int(nq)
-    if not (1 <= degree <= 5 and 1 <= q1 <= 7):        # (8 points per axis: the matrix template's per-point weights alone are 64 KB of LDS)
+    # degree <= 8 and max(k + 1, nq) <= 11: one cell's line set (max^2 lanes) fits the action's 128-lane workgroup.  The matrix template
+    # keeps the per-point weights of a whole cell in LDS up to 48 KB and computes them plane by plane beyond (fd_tensor.h tp_weight_slabs)
+    if not (1 <= degree <= 8 and 1 <= q1 <= 11):
         return None
     nt = (k1 ** 3 + 15) // 16
-    wpb = 4 if nt % 4 == 0 else (2 if nt % 2 == 0 else 1)
+    # Q6+ (more than 14 tiles per side): a 16-row panel is cut into column chunks of <= 8 tiles, one wavefront per (panel, chunk)
+    ct = int(configuration["tp_chunk_tiles"])
+    ncs = 1 if nt <= int(configuration["tp_max_panel_tiles"]) else (nt + ct - 1) // ct
+    items = nt * ncs
+    wpb = 4 if items % 4 == 0 else (2 if items % 2 == 0 else 1)
     m = max(k1, q1)
-    return {"k1": k1, "q1": q1, "nd": k1 ** 3, "tiles": nt, "matrix_threads": 64 * wpb, "matrix_groups": nt // wpb, "action_cells": 128 // (m * m)}
+    return {"k1": k1, "q1": q1, "nd": k1 ** 3, "tiles": nt, "col_splits": ncs, "col_tiles": -(-nt // ncs), "matrix_threads": 64 * wpb,
+            "matrix_groups": items // wpb, "action_cells": 128 // (m * m)}
 
 
 def tensor_matrix_groups(geom, vdim):
     """workgroups per cell of the matrix template: one per (panel group, component pair) of a (Q_k)^vdim space, or -- small elements,
     fd_tensor.h tp_fused -- all vdim^2 pairs of a panel group in one"""
-    fused = vdim > 1 and 4 * geom["tiles"] * vdim * vdim <= 96
+    fused = (vdim > 1 and 4 * geom["tiles"] * vdim * vdim <= 96 and geom["col_splits"] == 1
+             and geom["q1"] ** 3 * 16 * vdim * vdim * 8 <= int(configuration["tp_weight_lds"]))
     return geom["matrix_groups"] * (1 if fused else vdim * vdim)
 
 
@@ -170,7 +178,10 @@ def generate_tensor_wrapper(gk: GlobalKernel) -> WrapperSource:
     sym = f"wrap_{lk.name}"
     wname = f"{lk.name}_weights"
     layout = [("layers",)]
-    head = ['#include "fd_tensor.h"', "#include <math.h>", "namespace fdk {", "#pragma clang force_cuda_host_device begin",
+    tune = [f"#define {macro} {int(configuration[key])}" for macro, key, default in
+            (("FD_TP_MAX_PANEL_TILES", "tp_max_panel_tiles", 14), ("FD_TP_CHUNK_TILES", "tp_chunk_tiles", 8), ("FD_TP_WEIGHT_LDS", "tp_weight_lds", 48 * 1024))
+            if int(configuration[key]) != default]
+    head = tune + ['#include "fd_tensor.h"', "#include <math.h>", "namespace fdk {", "#pragma clang force_cuda_host_device begin",
             lk.tp["weights_code"], "#pragma clang force_cuda_host_device end", "}  // namespace fdk", ""]
     # coefficient arguments (READ Dats on the Q_k map or on the Q1 map of the coordinates): evaluated at the Gauss points by the
     # templates, which hand the callback C = [Q_k coefficients ..., Q1 coefficients ...]; the lambda restores TSFC's order
@@ -228,7 +239,8 @@ def generate_tensor_wrapper(gk: GlobalKernel) -> WrapperSource:
                 f"{call_w});")
         threads = 128
         # (a vector-valued unknown or coefficient gradients carry D times / twice the lines in registers: no occupancy floor)
-        bounds = "128" + (f", {int(configuration['tp_action_waves'])}" if configuration["tp_action_waves"] and D == 1 and not grad else "")
+        # (... and from Q6 on the lines themselves are 7+ doubles per array)
+        bounds = "128" + (f", {int(configuration['tp_action_waves'])}" if configuration["tp_action_waves"] and D == 1 and not grad and geom["k1"] <= 6 else "")
     src = head + [f'extern "C" __global__ __launch_bounds__({bounds}) void {sym}(int start, int end, {", ".join(params)})', "{", body, "}"]
     return WrapperSource("\n".join(src) + "\n", sym, "tp_" + kind, layout, 2, block_threads=threads, tp=geom)
 

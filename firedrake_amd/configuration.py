@@ -72,7 +72,13 @@ configuration = {
     "stage_batch": 4,
     "lane_strided": 1,                  # plans in lane order (fd_plan_set_lane_order)
     "lds_const_stride": 1,              # staged loops: node stride of the LDS arrays compiled in (P1 residual 0.43 -> 0.41 ms)
-    "tp_action_waves": 3,               # wavefronts per SIMD the tensor-product action wrapper is compiled for
+    "tp_action_waves": 3,
+    # MFMA matrix template (csrc/fd_tensor.h): a 16-row panel of more than tp_max_panel_tiles column tiles is cut into chunks of
+    # tp_chunk_tiles (Q6: 22 tiles -> 3 chunks of 8; 4 accumulator registers per tile); per-point weights beyond tp_weight_lds bytes
+    # are computed one q1 plane at a time
+    "tp_max_panel_tiles": 14,
+    "tp_chunk_tiles": 8,
+    "tp_weight_lds": 48 * 1024,               # wavefronts per SIMD the tensor-product action wrapper is compiled for
     "ocr_sliced_min_arity": 8,          # scalar rows of the element matrix from which row-sliced instances pay (P1: 4, whole; P2: 10, sliced)
     "ocr_sliced_max_arity": 32,
     "ocr_sliced_max_entries": 1024,

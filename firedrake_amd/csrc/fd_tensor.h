@@ -84,6 +84,27 @@ __device__ __forceinline__ void inv3(const double J[3][3], double K[3][3], doubl
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int tp_tiles(int k1) { return (k1 * k1 * k1 + 15) / 16; }
 constexpr int tp_waves(int nt) { return nt % 4 == 0 ? 4 : (nt % 2 == 0 ? 2 : 1); }     // wavefronts per workgroup: divides NT
+// Q6 and beyond (NT = 22, 32, 46 tiles per side): a full 16-row panel is 4 NT accumulator registers -- more than a lane has -- so
+// the panel is cut into tp_col_splits(NT) column chunks of tp_col_tiles(NT) <= 8 tiles (the 64 accumulator registers of Q4) and a
+// wavefront owns one (panel, chunk): NT * splits wavefront items per cell, tp_waves(items) of them per workgroup.  A chunk's
+// wavefront builds the panel's A operand again (one of NT + 1 operands per point, as for Q4).
+// (the three thresholds are tuning constants of firedrake_amd/configuration.py -- tp_max_panel_tiles, tp_chunk_tiles, tp_weight_lds --
+// that codegen.generate_tensor_wrapper defines ahead of this header when they differ from the defaults below; the host-sim tests
+// lower them to run both mechanisms on small elements)
+#ifndef FD_TP_MAX_PANEL_TILES
+#define FD_TP_MAX_PANEL_TILES 14
+#endif
+#ifndef FD_TP_CHUNK_TILES
+#define FD_TP_CHUNK_TILES 8
+#endif
+#ifndef FD_TP_WEIGHT_LDS
+#define FD_TP_WEIGHT_LDS (48 * 1024)
+#endif
+constexpr int tp_col_splits(int nt) { return nt <= FD_TP_MAX_PANEL_TILES ? 1 : (nt + FD_TP_CHUNK_TILES - 1) / FD_TP_CHUNK_TILES; }
+constexpr int tp_col_tiles(int nt) { return (nt + tp_col_splits(nt) - 1) / tp_col_splits(nt); }
+// the per-point weights of ALL Gauss points of a cell stay in LDS up to 48 KB (Q5 with 7 points per axis: 43 KB); beyond, the
+// matrix template computes them one q1-slab at a time (Q1^2 points, two more barriers per slab)
+constexpr bool tp_weight_slabs(int q1, int np_) { return q1 * q1 * q1 * 16 * np_ * 8 > FD_TP_WEIGHT_LDS; }
 constexpr bool tp_fused(int nt, int d) { return d > 1 && 4 * nt * d * d <= 96; }         // all D^2 component pairs in one workgroup
 
 // Coefficient arguments (NC > 0): READ Dats on the Q_k map -- what TSFC passes as w_k to a variable-coefficient or linearised
@@ -162,9 +183,9 @@ __device__ __forceinline__ void hex_qk_coefficients(const double *const (&cf)[NC
 template <int K1, int Q1, int NC, int N1, bool GRAD, int D, int P, int R, int NTHR, int SWW, class WF>
 __device__ __forceinline__ void hex_qk_point_weights(const double *sX, const double *sQP, const double *sQW,
                                                      const double (*sC)[Q1 * Q1 * Q1], const double (*sV1)[8],
-                                                     double (*sW)[SWW], WF weights) {
-    constexpr int NQ = Q1 * Q1 * Q1, CW = GRAD ? 4 : 1, NCT = NC + N1 > 0 ? NC + N1 : 1;
-    for (int q = threadIdx.x; q < NQ; q += NTHR) {
+                                                     double (*sW)[SWW], WF weights, int q_begin = 0, int q_count = Q1 * Q1 * Q1) {
+    constexpr int CW = GRAD ? 4 : 1, NCT = NC + N1 > 0 ? NC + N1 : 1;
+    for (int q = q_begin + (int)threadIdx.x; q < q_begin + q_count; q += NTHR) {
         const int q1 = q / (Q1 * Q1), q2 = (q / Q1) % Q1, q3 = q % Q1;
         const double t[3] = {sQP[q1], sQP[q2], sQP[q3]};
         double J[3][3], X[3], W[16 * D * D], C[NCT], DC[3 * NCT];
@@ -194,7 +215,7 @@ __device__ __forceinline__ void hex_qk_point_weights(const double *sX, const dou
 #pragma unroll
         for (int l = 0; l < 4; ++l)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) sW[q][(SWW > 16 ? (P * D + R) * 16 : 0) + l * 4 + k] = W[((P * 4 + l) * 4 * D) + R * 4 + k];
+            for (int k = 0; k < 4; ++k) sW[q - q_begin][(SWW > 16 ? (P * D + R) * 16 : 0) + l * 4 + k] = W[((P * 4 + l) * 4 * D) + R * 4 + k];
     }
 }
 
@@ -206,14 +227,17 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
                                               const int *__restrict__ map_q1, const fd_nnz_t *__restrict__ rowptr,
                                               const unsigned short *__restrict__ offtab, const int *__restrict__ rlg,
                                               const int *__restrict__ clg, const double *__restrict__ tables, WF weights) {
-    constexpr int ND = K1 * K1 * K1, NQ = Q1 * Q1 * Q1, NT = tp_tiles(K1), WPB = tp_waves(NT), WGC = NT / WPB, NTAB = Q1 * K1;
+    constexpr int ND = K1 * K1 * K1, NQ = Q1 * Q1 * Q1, NT = tp_tiles(K1), NCS = tp_col_splits(NT), NTC = tp_col_tiles(NT);
+    constexpr int NI = NT * NCS, WPB = tp_waves(NI), WGC = NI / WPB, NTAB = Q1 * K1;     // wavefront items (panel, column chunk) per cell
     constexpr int CW = GRAD ? 4 : 1;
-    constexpr bool FUSED = tp_fused(NT, D);
+    constexpr bool FUSED = tp_fused(NT, D) && NCS == 1 && !tp_weight_slabs(Q1, D * D);     // (small elements, all their weights in LDS)
     constexpr int NP = FUSED ? D * D : 1, DG = FUSED ? 1 : D * D;      // pairs per workgroup, workgroups per (cell, panel group)
+    constexpr bool SLAB = tp_weight_slabs(Q1, NP);                     // point weights one q1-slab at a time
+    constexpr int NQW = SLAB ? Q1 * Q1 : NQ;
     static_assert(D >= 1 && D <= 3, "vector-valued Q_k spaces of up to three components");
     __shared__ double sL[NTAB], sDL[NTAB], sQP[Q1], sQW[Q1];
     __shared__ double sX[24];
-    __shared__ double sW[NQ][16 * NP];
+    __shared__ double sW[NQW][16 * NP];
     __shared__ double sC[NC > 0 ? NC * CW : 1][NQ];
     __shared__ double sV1[N1 > 0 ? N1 : 1][8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -238,33 +262,42 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
     __syncthreads();
     if constexpr (NC > 0)
         hex_qk_coefficients<K1, Q1, NC, WPB * 64, GRAD>(cf, map_qk + (size_t)col * ND, (K1 - 1) * lrel, sL, sDL, sC);
+    // the point weights of the Gauss points [qb, qb + qc) into sW[0 .. qc): every point of the cell at once, or -- SLAB -- the
+    // Q1^2 points of one q1 plane ahead of that plane's MFMAs
+    auto fill_weights = [&](int qb, int qc) {
 #define FD_TP_PAIR(P, R)                                                                                                            \
     case (P) * 3 + (R):                                                                                                             \
         if constexpr ((P) < D && (R) < D && !FUSED)                                                                                 \
-            hex_qk_point_weights<K1, Q1, NC, N1, GRAD, D, (P), (R), WPB * 64, 16>(sX, sQP, sQW, sC, sV1, sW, weights);              \
+            hex_qk_point_weights<K1, Q1, NC, N1, GRAD, D, (P), (R), WPB * 64, 16>(sX, sQP, sQW, sC, sV1, sW, weights, qb, qc);      \
         break;
-    if constexpr (D == 1) {
-        hex_qk_point_weights<K1, Q1, NC, N1, GRAD, 1, 0, 0, WPB * 64, 16>(sX, sQP, sQW, sC, sV1, sW, weights);
-    } else if constexpr (FUSED) {
-        // (one pass per pair, each with its own compile-time slice: filling all D^2 slices from one callback evaluation keeps the
-        // whole 4D x 4D weight live -- 288 registers for D = 3)
+        if constexpr (D == 1) {
+            hex_qk_point_weights<K1, Q1, NC, N1, GRAD, 1, 0, 0, WPB * 64, 16>(sX, sQP, sQW, sC, sV1, sW, weights, qb, qc);
+        } else if constexpr (FUSED) {
+            // (one pass per pair, each with its own compile-time slice: filling all D^2 slices from one callback evaluation keeps the
+            // whole 4D x 4D weight live -- 288 registers for D = 3)
 #define FD_TP_SLICE(P, R)                                                                                                           \
-        if constexpr ((P) < D && (R) < D)                                                                                           \
-            hex_qk_point_weights<K1, Q1, NC, N1, GRAD, D, (P), (R), WPB * 64, 16 * NP>(sX, sQP, sQW, sC, sV1, sW, weights);
-        FD_TP_SLICE(0, 0) FD_TP_SLICE(0, 1) FD_TP_SLICE(0, 2) FD_TP_SLICE(1, 0) FD_TP_SLICE(1, 1) FD_TP_SLICE(1, 2)
-        FD_TP_SLICE(2, 0) FD_TP_SLICE(2, 1) FD_TP_SLICE(2, 2)
+            if constexpr ((P) < D && (R) < D)                                                                                       \
+                hex_qk_point_weights<K1, Q1, NC, N1, GRAD, D, (P), (R), WPB * 64, 16 * NP>(sX, sQP, sQW, sC, sV1, sW, weights, qb, qc);
+            FD_TP_SLICE(0, 0) FD_TP_SLICE(0, 1) FD_TP_SLICE(0, 2) FD_TP_SLICE(1, 0) FD_TP_SLICE(1, 1) FD_TP_SLICE(1, 2)
+            FD_TP_SLICE(2, 0) FD_TP_SLICE(2, 1) FD_TP_SLICE(2, 2)
 #undef FD_TP_SLICE
-    } else {
-        switch (cp * 3 + cr) {
-            FD_TP_PAIR(0, 0) FD_TP_PAIR(0, 1) FD_TP_PAIR(0, 2) FD_TP_PAIR(1, 0) FD_TP_PAIR(1, 1) FD_TP_PAIR(1, 2)
-            FD_TP_PAIR(2, 0) FD_TP_PAIR(2, 1) FD_TP_PAIR(2, 2)
-        default: break;
+        } else {
+            switch (cp * 3 + cr) {
+                FD_TP_PAIR(0, 0) FD_TP_PAIR(0, 1) FD_TP_PAIR(0, 2) FD_TP_PAIR(1, 0) FD_TP_PAIR(1, 1) FD_TP_PAIR(1, 2)
+                FD_TP_PAIR(2, 0) FD_TP_PAIR(2, 1) FD_TP_PAIR(2, 2)
+            default: break;
+            }
         }
-    }
 #undef FD_TP_PAIR
-    __syncthreads();
+    };
+    if constexpr (!SLAB) {
+        fill_weights(0, NQ);
+        __syncthreads();
+    }
     const int r16 = lane & 15, kk = lane >> 4;             // row/col inside a tile, MFMA k index
-    const int itile = part * WPB + wave;
+    const int item = part * WPB + wave;
+    const int itile = NCS == 1 ? item : item / NCS;        // 16-row panel
+    const int tc0 = NCS == 1 ? 0 : (item - itile * NCS) * NTC;   // first column tile of the wavefront's chunk
     int i1, i2, i3; bool iv;
     {
         const int i = itile * 16 + r16;
@@ -272,29 +305,34 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
         const int ic = iv ? i : 0;
         i1 = ic / (K1 * K1); i2 = (ic / K1) % K1; i3 = ic % K1;
     }
-    int j1[NT], j2[NT], j3[NT]; bool jv[NT];
+    int j1[NTC], j2[NTC], j3[NTC]; bool jv[NTC];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int j = t * 16 + r16;
+    for (int t = 0; t < NTC; ++t) {
+        const int j = (tc0 + t) * 16 + r16;
         jv[t] = j < ND;
         const int jc = jv[t] ? j : 0;
         j1[t] = jc / (K1 * K1); j2[t] = (jc / K1) % K1; j3[t] = jc % K1;
     }
     // B operand of lane (kk, j): Phi[kk][j] = X[q1][j1] * Y[q2][j2] * Z[q3][j3], derivative table on axis kk (kk = 3: value)
     const double *tabx = kk == 0 ? sDL : sL, *taby = kk == 1 ? sDL : sL, *tabz = kk == 2 ? sDL : sL;
-    fd_d4 acc[NP][NT];
+    fd_d4 acc[NP][NTC];
 #pragma unroll
     for (int a = 0; a < NP; ++a)
 #pragma unroll
-        for (int b = 0; b < NT; ++b) acc[a][b] = fd_d4{0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < NTC; ++b) acc[a][b] = fd_d4{0.0, 0.0, 0.0, 0.0};
 
 #pragma unroll 1
     for (int q1 = 0; q1 < Q1; ++q1) {
+        if constexpr (SLAB) {
+            __syncthreads();                                // (the previous plane's MFMAs have read their weights)
+            fill_weights(q1 * Q1 * Q1, Q1 * Q1);
+            __syncthreads();
+        }
 #pragma unroll 1
         for (int q2 = 0; q2 < Q1; ++q2) {
-            double bxy[NT];
+            double bxy[NTC];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) bxy[t] = jv[t] ? tabx[q1 * K1 + j1[t]] * taby[q2 * K1 + j2[t]] : 0.0;
+            for (int t = 0; t < NTC; ++t) bxy[t] = jv[t] ? tabx[q1 * K1 + j1[t]] * taby[q2 * K1 + j2[t]] : 0.0;
             const double lx = sL[q1 * K1 + i1], dx = sDL[q1 * K1 + i1];
             const double ly = sL[q2 * K1 + i2], dy = sDL[q2 * K1 + i2];
             const double ax = iv ? dx * ly : 0.0;      // d/dxi1 part
@@ -302,7 +340,7 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
             const double axy = iv ? lx * ly : 0.0;     // value in (xi1, xi2)
 #pragma unroll 1
             for (int q3 = 0; q3 < Q1; ++q3) {
-                const int q = (q1 * Q1 + q2) * Q1 + q3;
+                const int q = SLAB ? q2 * Q1 + q3 : (q1 * Q1 + q2) * Q1 + q3;       // the point's slot in sW
                 const double lz = sL[q3 * K1 + i3], dz = sDL[q3 * K1 + i3];
                 // A operand: (Phi^T W)[i][kk] = sum_l Phi[l][i] W[l][kk]
                 const double a0 = ax * lz, a1 = ay * lz, a2 = axy * dz, a3 = axy * lz;
@@ -312,20 +350,20 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
                 if constexpr (NP == 1) {
                     const double aop = a0 * sW[q][kk] + a1 * sW[q][4 + kk] + a2 * sW[q][8 + kk] + a3 * sW[q][12 + kk];
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
+                    for (int t = 0; t < NTC; ++t) {
                         const double bop = bxy[t] * tabz[q3 * K1 + j3[t]];
                         acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc[0][t], 0, 0, 0);
                     }
                 } else {
-                    double bop[NT];
+                    double bop[NTC];
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) bop[t] = bxy[t] * tabz[q3 * K1 + j3[t]];
+                    for (int t = 0; t < NTC; ++t) bop[t] = bxy[t] * tabz[q3 * K1 + j3[t]];
 #pragma unroll
                     for (int a = 0; a < NP; ++a) {
                         const double *w = &sW[q][a * 16];
                         const double aop = a0 * w[kk] + a1 * w[4 + kk] + a2 * w[8 + kk] + a3 * w[12 + kk];
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) acc[a][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop[t], acc[a][t], 0, 0, 0);
+                        for (int t = 0; t < NTC; ++t) acc[a][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop[t], acc[a][t], 0, 0, 0);
                     }
                 }
             }
@@ -400,19 +438,19 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
         }
         return;
     }
-    int cn[NT]; bool cok[NT];
+    int cn[NTC]; bool cok[NTC];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int j = t * 16 + r16;
+    for (int t = 0; t < NTC; ++t) {
+        const int j = (tc0 + t) * 16 + r16;
         cok[t] = j < ND;
         cn[t] = mrow[cok[t] ? j : 0] + OFF * lrel;
     }
     if (clg) {
-        int cl[NT];
+        int cl[NTC];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) cl[t] = clg[cn[t]];
+        for (int t = 0; t < NTC; ++t) cl[t] = clg[cn[t]];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) cok[t] = cok[t] && cl[t] >= 0;
+        for (int t = 0; t < NTC; ++t) cok[t] = cok[t] && cl[t] >= 0;
     }
     // every row takes fire-and-forget atomics (storing the rows one cell owns alone -- the cell-interior nodes, 22 % of the entries
     // of Q4 -- and zeroing only the shared ones was built and measured 1 % slower: profiles/r4m_c3_single_rows.txt, r4n_c3_single_rows.txt).
@@ -434,14 +472,14 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
         for (int g = 0; g < 4; ++g) rok[g] = rok[g] && rl[g] >= 0;
     }
     fd_nnz_t rp[4]; int rlen[4];
-    unsigned short pos[4][NT];
+    unsigned short pos[4][NTC];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         rp[g] = rowptr[rn[g]];                             // (unconditional reads of clamped indices: no branch, no wait in between)
         rlen[g] = D > 1 ? (int)(rowptr[rn[g] + 1] - rp[g]) : 0;
         const int i = itile * 16 + kk + 4 * g;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) pos[g][t] = tab[(i < ND && t * 16 + r16 < ND) ? i * ND + t * 16 + r16 : 0];
+        for (int t = 0; t < NTC; ++t) pos[g][t] = tab[(i < ND && (tc0 + t) * 16 + r16 < ND) ? i * ND + (tc0 + t) * 16 + r16 : 0];
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -449,7 +487,7 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
         if constexpr (D == 1) {
             const size_t r0 = (size_t)rp[g];
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NTC; ++t)
                 if (cok[t]) atomicAdd(&vals[r0 + pos[g][t]], acc[0][t][g]);
         } else {
 #pragma unroll
@@ -457,7 +495,7 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
                 const int p = FUSED ? a / D : cp, r = FUSED ? a % D : cr;
                 const size_t r0 = (size_t)rp[g] * (D * D) + (size_t)p * rlen[g] * D + r;
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
+                for (int t = 0; t < NTC; ++t)
                     if (cok[t]) atomicAdd(&vals[r0 + (unsigned)pos[g][t] * D], acc[a][t][g]);
             }
         }

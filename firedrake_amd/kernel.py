@@ -130,7 +130,7 @@ class TensorProductLocalKernel(CStringLocalKernel):
         static inline void <name>_weights(const double J[3][3], const double X[3], double wq, double W[16])
 
     (J[r][s] = dx_r/dxi_s at the point, X the physical point, wq the quadrature weight; W row-major, W[l*4+k] couples
-    component l of the test side with component k of the trial side).  Instantiated for degree 1..5 and up to 7 Gauss points
+    component l of the test side with component k of the trial side).  Instantiated for degree 1..8 and up to 11 Gauss points
     per axis (codegen.tensor_geometry); other descriptors take the ordinary wrappers on the C text.
 
     ``ncoef`` > 0: the form has coefficient arguments -- ``ncoef`` scalar READ Dats on the Q_k map after the standard arguments

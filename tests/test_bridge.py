@@ -313,8 +313,10 @@ def test_tensor_form_descriptor_selects_the_matrix_core_wrapper():
     info = bridge.tensor_form_info("hexahedron", "Q", 4, 8, {"stiffness": 1.0, "mass": 1.0}, "matrix")
     assert info == {"kind": "matrix", "degree": 4, "nq": 5, "alpha": 1.0, "beta": 1.0}
     assert bridge.tensor_form_info("hexahedron", "Q", 3, 6, {"stiffness": 1.0}, "matrix") == \
-        {"kind": "matrix", "degree": 3, "nq": 4, "alpha": 1.0, "beta": 0.0}                                    # Q1..Q5 are instantiated
-    assert bridge.tensor_form_info("hexahedron", "Q", 6, 12, {"stiffness": 1.0}, "matrix") is None         # Q6: ordinary wrappers
+        {"kind": "matrix", "degree": 3, "nq": 4, "alpha": 1.0, "beta": 0.0}                                    # Q1..Q5: whole panels
+    assert bridge.tensor_form_info("hexahedron", "Q", 6, 12, {"stiffness": 1.0}, "matrix") == \
+        {"kind": "matrix", "degree": 6, "nq": 7, "alpha": 1.0, "beta": 0.0}                                    # ... and Q6..Q8 since round 6
+    assert bridge.tensor_form_info("hexahedron", "Q", 9, 18, {"stiffness": 1.0}, "matrix") is None         # Q9: ordinary wrappers
     assert bridge.tensor_form_info("tetrahedron", "CG", 4, 8, {"stiffness": 1.0}, "matrix") is None
     assert bridge.tensor_form_info("hexahedron", "Q", 4, 8, {"curlcurl": 1.0}, "matrix") is None           # not a term of the descriptor
     adv = bridge.tensor_form_info("hexahedron", "Q", 2, 4, {"stiffness": 0.5, "advection": (1.0, 0.0, -1.0)}, "action")

@@ -268,11 +268,13 @@ def test_q4_mfma_full_size_properties():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("degree,nq,n,layers", [(1, 2, 4, 5), (2, 3, 3, 4), (3, 4, 3, 3), (2, 4, 2, 3), (3, 3, 2, 2), (5, 6, 2, 2)])
+@pytest.mark.parametrize("degree,nq,n,layers", [(1, 2, 4, 5), (2, 3, 3, 4), (3, 4, 3, 3), (2, 4, 2, 3), (3, 3, 2, 2), (5, 6, 2, 2),
+                                                (6, 7, 2, 2), (6, 8, 1, 3), (7, 9, 1, 2), (8, 10, 1, 2)])
 def test_qk_tensor_wrappers_match_the_oracle(degree, nq, n, layers):
     """The tensor-product templates for other degrees / quadrature sizes (1, 2, 4 and 14 tiles per side of the element matrix;
     32, 14, 8 and 3 cells per action workgroup): MFMA matrix with BC lgmaps and sum-factorised action against the oracle's dense
-    kernel, and A u == action(u) with the device SpMV."""
+    kernel, and A u == action(u) with the device SpMV.  Q6, Q7, Q8 (22, 32, 46 tiles per side): 16-row panels cut into column
+    chunks of 8 tiles, one wavefront per (panel, chunk); with 8+ points per axis the point weights are computed plane by plane."""
     from firedrake_amd import op2
     m = fmesh.make_extruded_hex_mesh(n, layers, degree, perturb=0.1)
     prob = forms.HelmholtzHexProblem(m, bcs=True, nq=nq)

@@ -222,3 +222,38 @@ def test_a_vector_valued_space_through_the_tensor_templates_on_the_host(degree, 
     assert_allclose(y, yref, rtol=0, atol=1e-11 * np.abs(yref).max())
     if not bcs:
         assert_allclose(y.ravel(), A @ np.asarray(prob.u.data_ro).ravel(), rtol=0, atol=1e-10 * np.abs(yref).max())
+
+
+@pytest.mark.parametrize("degree,nq,bcs,panel,chunk,wlds", [(3, 4, True, 3, 2, 1024), (2, 3, False, 1, 1, 1 << 20), (3, 5, False, 14, 8, 4096)])
+def test_qk_mfma_matrix_column_chunks_and_weight_slabs_on_the_host(degree, nq, bcs, panel, chunk, wlds, monkeypatch):
+    """Q6 and beyond (22+ tiles per side) cut a 16-row panel into column chunks -- one wavefront per (panel, chunk) -- and compute the
+    point weights one q1 plane at a time once a cell's weights pass 48 KB of LDS (fd_tensor.h tp_col_splits / tp_weight_slabs).  On the
+    host the REAL Q6 template takes seven minutes per cell, so the two mechanisms are run on small elements with the thresholds
+    lowered: Q3 (4 tiles) as 2 chunks of 2 with plane-wise weights, Q2 (2 tiles) as 2 chunks of 1, Q3 with 5 points plane-wise only;
+    Q6 / Q7 themselves run in the -m gpu suite (tests/test_gpu_q4_hex.py)."""
+    from firedrake_amd.codegen import configuration, tensor_geometry
+    monkeypatch.setitem(configuration, "tp_max_panel_tiles", panel)
+    monkeypatch.setitem(configuration, "tp_chunk_tiles", chunk)
+    monkeypatch.setitem(configuration, "tp_weight_lds", wlds)
+    g = tensor_geometry(degree, nq)
+    assert g["col_splits"] == (1 if g["tiles"] <= panel else -(-g["tiles"] // chunk)) and g["matrix_groups"] * g["matrix_threads"] == 64 * g["tiles"] * g["col_splits"]
+    m = fmesh.make_extruded_hex_mesh(1, 2, degree, perturb=0.1)
+    prob = forms.HelmholtzHexProblem(m, bcs=bcs, nq=nq, alpha=0.7, beta=1.3, velocity=(1.0, -2.0, 0.5))
+    csr = hostsim.run_tensor(prob.jac_loop)[0]
+    ref = _oracle_matrix(m, prob.bc_nodes if bcs else None, prob.kjac)
+    v = csr.values.copy()
+    if bcs:
+        rp, ci = csr.rowptr, csr.colidx
+        for b in prob.bc_nodes:
+            v[rp[b] + np.searchsorted(ci[rp[b]:rp[b + 1]], b)] = 1.0
+    assert_allclose(v, ref.values, rtol=0, atol=1e-12 * np.abs(ref.values).max())
+
+
+@pytest.mark.parametrize("degree,nq", [(6, 8), (7, 9), (8, 10)])
+def test_high_order_action_template_on_the_host(degree, nq):
+    """Q6, Q7, Q8: 64 / 81 / 100 lanes per cell (one or two cells per workgroup), lines of 7 to 9 nodes and 8 to 10 points."""
+    m = fmesh.make_extruded_hex_mesh(1, 2, degree, perturb=0.1)
+    prob = forms.HelmholtzHexProblem(m, nq=nq, alpha=0.7, beta=1.3, velocity=(1.0, -2.0, 0.5))
+    y = hostsim.run_tensor(prob.act_loop)[0]
+    ref = _oracle_action(m, prob.u.data_ro, prob.kact)
+    assert_allclose(y, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
