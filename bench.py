@@ -315,10 +315,11 @@ def measure_tensor_forms(steps, warmup):
     from firedrake_amd import _lib, forms, mesh as fmesh
     from firedrake_amd.device import Event
     out = {}
-    # ... and the Helmholtz operator of config C3 beyond Q5 (round 6): 16-row panels of 22 / 32 tiles cut into column chunks of 8, one
+    # ... and the Helmholtz operator of config C3 beyond Q4 (round 6): 16-row panels of 14 / 22 / 32 tiles cut into column chunks of <= 8, one
     # wavefront per (panel, chunk); 8+ Gauss points per axis take their point weights plane by plane
     for key, degree, n, make in (("nonlinear_diffusion_q3", 3, 24, lambda m: forms.NonlinearDiffusionHexProblem(m, bcs=True)),
                                  ("elasticity_q2", 2, 24, lambda m: forms.ElasticityHexProblem(m, bcs=True)),
+                                 ("helmholtz_q5", 5, 16, lambda m: forms.HelmholtzHexProblem(m, bcs=True, nq=6)),
                                  ("helmholtz_q6", 6, 12, lambda m: forms.HelmholtzHexProblem(m, bcs=True, nq=8)),
                                  ("helmholtz_q7", 7, 8, lambda m: forms.HelmholtzHexProblem(m, bcs=True, nq=9))):
         m = fmesh.make_extruded_hex_mesh(n, n, degree, perturb=0.1)

@@ -150,7 +150,7 @@ def tensor_geometry(degree, nq):
     if not (1 <= degree <= 8 and 1 <= q1 <= 11):
         return None
     nt = (k1 ** 3 + 15) // 16
-    # Q6+ (more than 14 tiles per side): a 16-row panel is cut into column chunks of <= 8 tiles, one wavefront per (panel, chunk)
+    # Q5+ (more than 8 tiles per side): a 16-row panel is cut into column chunks of <= 8 tiles, one wavefront per (panel, chunk)
     ct = int(configuration["tp_chunk_tiles"])
     ncs = 1 if nt <= int(configuration["tp_max_panel_tiles"]) else (nt + ct - 1) // ct
     items = nt * ncs
@@ -179,7 +179,7 @@ def generate_tensor_wrapper(gk: GlobalKernel) -> WrapperSource:
     wname = f"{lk.name}_weights"
     layout = [("layers",)]
     tune = [f"#define {macro} {int(configuration[key])}" for macro, key, default in
-            (("FD_TP_MAX_PANEL_TILES", "tp_max_panel_tiles", 14), ("FD_TP_CHUNK_TILES", "tp_chunk_tiles", 8), ("FD_TP_WEIGHT_LDS", "tp_weight_lds", 48 * 1024))
+            (("FD_TP_MAX_PANEL_TILES", "tp_max_panel_tiles", 8), ("FD_TP_CHUNK_TILES", "tp_chunk_tiles", 8), ("FD_TP_WEIGHT_LDS", "tp_weight_lds", 48 * 1024))
             if int(configuration[key]) != default]
     head = tune + ['#include "fd_tensor.h"', "#include <math.h>", "namespace fdk {", "#pragma clang force_cuda_host_device begin",
             lk.tp["weights_code"], "#pragma clang force_cuda_host_device end", "}  // namespace fdk", ""]

@@ -74,9 +74,9 @@ configuration = {
     "lds_const_stride": 1,              # staged loops: node stride of the LDS arrays compiled in (P1 residual 0.43 -> 0.41 ms)
     "tp_action_waves": 3,
     # MFMA matrix template (csrc/fd_tensor.h): a 16-row panel of more than tp_max_panel_tiles column tiles is cut into chunks of
-    # tp_chunk_tiles (Q6: 22 tiles -> 3 chunks of 8; 4 accumulator registers per tile); per-point weights beyond tp_weight_lds bytes
+    # tp_chunk_tiles (Q5: 14 tiles -> 2 chunks of 7, Q6: 22 -> 3 of 8; 4 accumulator registers per tile); per-point weights beyond tp_weight_lds bytes
     # are computed one q1 plane at a time
-    "tp_max_panel_tiles": 14,
+    "tp_max_panel_tiles": 8,
     "tp_chunk_tiles": 8,
     "tp_weight_lds": 48 * 1024,               # wavefronts per SIMD the tensor-product action wrapper is compiled for
     "ocr_sliced_min_arity": 8,          # scalar rows of the element matrix from which row-sliced instances pay (P1: 4, whole; P2: 10, sliced)

@@ -84,15 +84,18 @@ __device__ __forceinline__ void inv3(const double J[3][3], double K[3][3], doubl
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int tp_tiles(int k1) { return (k1 * k1 * k1 + 15) / 16; }
 constexpr int tp_waves(int nt) { return nt % 4 == 0 ? 4 : (nt % 2 == 0 ? 2 : 1); }     // wavefronts per workgroup: divides NT
-// Q6 and beyond (NT = 22, 32, 46 tiles per side): a full 16-row panel is 4 NT accumulator registers -- more than a lane has -- so
-// the panel is cut into tp_col_splits(NT) column chunks of tp_col_tiles(NT) <= 8 tiles (the 64 accumulator registers of Q4) and a
-// wavefront owns one (panel, chunk): NT * splits wavefront items per cell, tp_waves(items) of them per workgroup.  A chunk's
-// wavefront builds the panel's A operand again (one of NT + 1 operands per point, as for Q4).
+// Q5 and beyond (NT = 14, 22, 32, 46 tiles per side): a full 16-row panel is 4 NT accumulator registers -- one wavefront per SIMD for
+// Q5, more than a lane has from Q6 on -- so the panel is cut into tp_col_splits(NT) column chunks of tp_col_tiles(NT) <= 8 tiles (the
+// 64 accumulator registers of Q4) and a wavefront owns one (panel, chunk): NT * splits wavefront items per cell, tp_waves(items) of
+// them per workgroup.  A chunk's wavefront builds the panel's A operand again (one of NTC + 1 operands per point, as for Q4); the
+// tiles of the last chunk that lie beyond NT (Q6: 22 = 8 + 8 + 6) run on zero operands -- a wavefront-uniform guard around their
+// MFMAs costs the accumulators their static register indices (Q6 18.4 -> 21.8 ms, Q5 6.5 -> 7.3 ms).  Measured (profiles/r6s_ab_tensor_panels.txt): Q5
+// whole panels 9.09 ms = 0.46 of the MFMA peak, 2 x 7 tiles 6.52 ms = 0.64; Q4 (8 tiles) whole 0.685, 2 x 4 0.638: whole up to 8.
 // (the three thresholds are tuning constants of firedrake_amd/configuration.py -- tp_max_panel_tiles, tp_chunk_tiles, tp_weight_lds --
 // that codegen.generate_tensor_wrapper defines ahead of this header when they differ from the defaults below; the host-sim tests
 // lower them to run both mechanisms on small elements)
 #ifndef FD_TP_MAX_PANEL_TILES
-#define FD_TP_MAX_PANEL_TILES 14
+#define FD_TP_MAX_PANEL_TILES 8
 #endif
 #ifndef FD_TP_CHUNK_TILES
 #define FD_TP_CHUNK_TILES 8

@@ -224,12 +224,14 @@ def test_a_vector_valued_space_through_the_tensor_templates_on_the_host(degree, 
         assert_allclose(y.ravel(), A @ np.asarray(prob.u.data_ro).ravel(), rtol=0, atol=1e-10 * np.abs(yref).max())
 
 
-@pytest.mark.parametrize("degree,nq,bcs,panel,chunk,wlds", [(3, 4, True, 3, 2, 1024), (2, 3, False, 1, 1, 1 << 20), (3, 5, False, 14, 8, 4096)])
+@pytest.mark.parametrize("degree,nq,bcs,panel,chunk,wlds", [(3, 4, True, 3, 2, 1024), (2, 3, False, 1, 1, 1 << 20), (3, 5, False, 14, 8, 4096),
+                                                             (4, 5, True, 7, 3, 1 << 20)])
 def test_qk_mfma_matrix_column_chunks_and_weight_slabs_on_the_host(degree, nq, bcs, panel, chunk, wlds, monkeypatch):
     """Q6 and beyond (22+ tiles per side) cut a 16-row panel into column chunks -- one wavefront per (panel, chunk) -- and compute the
     point weights one q1 plane at a time once a cell's weights pass 48 KB of LDS (fd_tensor.h tp_col_splits / tp_weight_slabs).  On the
     host the REAL Q6 template takes seven minutes per cell, so the two mechanisms are run on small elements with the thresholds
-    lowered: Q3 (4 tiles) as 2 chunks of 2 with plane-wise weights, Q2 (2 tiles) as 2 chunks of 1, Q3 with 5 points plane-wise only;
+    lowered: Q3 (4 tiles) as 2 chunks of 2 with plane-wise weights, Q2 (2 tiles) as 2 chunks of 1, Q3 with 5 points plane-wise only,
+    Q4 (8 tiles) as 3 chunks of 3 -- the last chunk's third tile lies beyond the matrix;
     Q6 / Q7 themselves run in the -m gpu suite (tests/test_gpu_q4_hex.py)."""
     from firedrake_amd.codegen import configuration, tensor_geometry
     monkeypatch.setitem(configuration, "tp_max_panel_tiles", panel)
