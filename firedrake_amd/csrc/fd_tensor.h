@@ -18,6 +18,7 @@
 // pointer per Dat/Mat, one per distinct Map; backend-private tables follow.
 #pragma once
 #include "fd_wrapper.h"
+#include <type_traits>
 
 namespace fdt {
 
@@ -87,10 +88,11 @@ constexpr int tp_waves(int nt) { return nt % 4 == 0 ? 4 : (nt % 2 == 0 ? 2 : 1);
 // Q5 and beyond (NT = 14, 22, 32, 46 tiles per side): a full 16-row panel is 4 NT accumulator registers -- one wavefront per SIMD for
 // Q5, more than a lane has from Q6 on -- so the panel is cut into tp_col_splits(NT) column chunks of tp_col_tiles(NT) <= 8 tiles (the
 // 64 accumulator registers of Q4) and a wavefront owns one (panel, chunk): NT * splits wavefront items per cell, tp_waves(items) of
-// them per workgroup.  A chunk's wavefront builds the panel's A operand again (one of NTC + 1 operands per point, as for Q4); the
-// tiles of the last chunk that lie beyond NT (Q6: 22 = 8 + 8 + 6) run on zero operands -- a wavefront-uniform guard around their
-// MFMAs costs the accumulators their static register indices (Q6 18.4 -> 21.8 ms, Q5 6.5 -> 7.3 ms).  Measured (profiles/r6s_ab_tensor_panels.txt): Q5
-// whole panels 9.09 ms = 0.46 of the MFMA peak, 2 x 7 tiles 6.52 ms = 0.64; Q4 (8 tiles) whole 0.685, 2 x 4 0.638: whole up to 8.
+// them per workgroup.  A chunk's wavefront builds the panel's A operand again (one of NTC + 1 operands per point, as for Q4).  When
+// the chunk count does not divide NT the first NT % splits chunks hold one tile more (Q6: 22 = 8 + 7 + 7): the chunk body of
+// hex_qk_matrix is instantiated for both sizes and picked per wavefront -- no MFMA on padding tiles (a run-time guard inside one
+// instantiation cost the accumulators their static register indices: Q6 18.4 -> 21.8 ms).  Measured (profiles/r6s_ab_tensor_panels.txt):
+// Q5 whole panels 9.09 ms = 0.46 of the MFMA peak, 2 x 7 tiles 6.52 ms = 0.64; Q4 (8 tiles) whole 0.685, 2 x 4 0.638: whole up to 8.
 // (the three thresholds are tuning constants of firedrake_amd/configuration.py -- tp_max_panel_tiles, tp_chunk_tiles, tp_weight_lds --
 // that codegen.generate_tensor_wrapper defines ahead of this header when they differ from the defaults below; the host-sim tests
 // lower them to run both mechanisms on small elements)
@@ -230,7 +232,7 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
                                               const int *__restrict__ map_q1, const fd_nnz_t *__restrict__ rowptr,
                                               const unsigned short *__restrict__ offtab, const int *__restrict__ rlg,
                                               const int *__restrict__ clg, const double *__restrict__ tables, WF weights) {
-    constexpr int ND = K1 * K1 * K1, NQ = Q1 * Q1 * Q1, NT = tp_tiles(K1), NCS = tp_col_splits(NT), NTC = tp_col_tiles(NT);
+    constexpr int ND = K1 * K1 * K1, NQ = Q1 * Q1 * Q1, NT = tp_tiles(K1), NCS = tp_col_splits(NT);
     constexpr int NI = NT * NCS, WPB = tp_waves(NI), WGC = NI / WPB, NTAB = Q1 * K1;     // wavefront items (panel, column chunk) per cell
     constexpr int CW = GRAD ? 4 : 1;
     constexpr bool FUSED = tp_fused(NT, D) && NCS == 1 && !tp_weight_slabs(Q1, D * D);     // (small elements, all their weights in LDS)
@@ -300,7 +302,12 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
     const int r16 = lane & 15, kk = lane >> 4;             // row/col inside a tile, MFMA k index
     const int item = part * WPB + wave;
     const int itile = NCS == 1 ? item : item / NCS;        // 16-row panel
-    const int tc0 = NCS == 1 ? 0 : (item - itile * NCS) * NTC;   // first column tile of the wavefront's chunk
+    // column chunks of unequal size when NCS does not divide NT (Q6: 22 = 8 + 7 + 7, Q8: 46 = 4 x 8 + 2 x 7): the first NT % NCS chunks
+    // hold one tile more -- two instantiations of the chunk body, picked per wavefront, and no MFMA is issued on a padding tile
+    constexpr int CB = NT / NCS, CR = NT % NCS;
+    const int csplit = NCS == 1 ? 0 : fdw::wave_uniform(item - itile * NCS);
+    auto chunk = [&](auto ntc_c, const int tc0) {
+    constexpr int NTC = decltype(ntc_c)::value;
     int i1, i2, i3; bool iv;
     {
         const int i = itile * 16 + r16;
@@ -502,6 +509,13 @@ __device__ __forceinline__ void hex_qk_matrix(int start, int end, const int *__r
                     if (cok[t]) atomicAdd(&vals[r0 + (unsigned)pos[g][t] * D], acc[a][t][g]);
             }
         }
+    }
+    };
+    if constexpr (CR == 0) {
+        chunk(std::integral_constant<int, CB>{}, csplit * CB);
+    } else {
+        if (csplit < CR) chunk(std::integral_constant<int, CB + 1>{}, csplit * (CB + 1));
+        else chunk(std::integral_constant<int, CB>{}, CR * (CB + 1) + (csplit - CR) * CB);
     }
 }
 

@@ -213,3 +213,40 @@ def test_plan_ordered_copies_follow_their_dats(numbering, monkeypatch):
     xyz[...] = xyz * 1.25 + 0.1                                     # a moved mesh: geometry copies of BOTH loops are stale
     check("moved mesh")
     check("moved mesh, again")
+
+
+def test_two_parloops_on_two_streams_and_the_cached_diagonal_places():
+    """``device.Stream``: the Jacobian of a Newton step forked onto a side stream while the residual runs on the launching one (two
+    loops that write different tensors and only read what they share), joined by an event -- no host synchronisation in between --
+    gives the tensors of the serial order; and ``Mat.set_diagonal_rows`` (places of the BC diagonal entries searched once, stored
+    through at every assembly) equals ``set_local_diagonal_entries`` of the same rows."""
+    from firedrake_amd import _lib
+    from firedrake_amd.device import Stream
+    m = fmesh.UnitCubeMesh((14, 14, 14), degrees=(1,), perturb=0.1, numbering="lexicographic")
+    prob = forms.PoissonProblem(m, 1, bcs=True)
+    r0 = np.array(prob.assemble_residual().data_ro)
+    v0 = prob.assemble_jacobian().csr()[2].copy()
+    side = Stream()
+    for _ in range(3):
+        prob.u.dat_version += 1
+        with side.fork():
+            prob.assemble_jacobian()
+        prob.assemble_residual()
+        side.join()
+    _lib.call("fd_device_sync")
+    assert_allclose(np.array(prob.r.data_ro), r0, rtol=0, atol=1e-13 * np.abs(r0).max())
+    mat = prob.jacobian()[0]
+    assert_allclose(mat.csr()[2], v0, rtol=0, atol=1e-13 * np.abs(v0).max())
+    # the diagonal fix-up through the API that takes host rows: same places, other value
+    rp, ci, vb = mat.csr()
+    vb = vb.copy()
+    mat.set_local_diagonal_entries(prob.bc_nodes, 3.5)
+    v1 = mat.csr()[2]
+    diag = np.array([rp[b] + np.searchsorted(ci[rp[b]:rp[b + 1]], b) for b in prob.bc_nodes])
+    assert np.all(v1[diag] == 3.5)
+    rest = np.ones(len(v1), dtype=bool)
+    rest[diag] = False
+    assert np.array_equal(v1[rest], vb[rest])
+    mat.set_local_diagonal_entries(prob.bc_nodes[::2], 1.0)          # another list: its own places
+    v2 = mat.csr()[2]
+    assert np.all(v2[diag[::2]] == 1.0) and np.all(v2[diag[1::2]] == 3.5)
