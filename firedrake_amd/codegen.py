@@ -548,7 +548,9 @@ def generate_wrapper(gk: GlobalKernel, mode: str, min_waves: int = 0) -> Wrapper
             return 1
         if strides is None or mi not in staged_maps or len(strides) != len(staged_maps):
             return 1
-        return max(1, min(int(configuration["stage_batch"]), -(-strides[staged_maps.index(mi)] // threads)))
+        # (a batch keeps its rows in registers between the loads and the LDS stores: at most ~32 doubles per lane)
+        words = 1 + sum(i_["c"] for i_ in infos if i_["kind"] == "dat" and i_.get("m") == mi and i_["acc"] == READ and in_lds(i_))
+        return max(1, min(int(configuration["stage_batch"]), 32 // words, -(-strides[staged_maps.index(mi)] // threads)))
 
     def srow_table(info):
         """whole-entity owner-computes-rows, row map = column map: the per-node row words come from a plan-ordered table

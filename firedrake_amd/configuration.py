@@ -66,10 +66,10 @@ configuration = {
     "ocr_fx_headroom": 3,               # fixed-point scales: bits between a block's largest contribution and the limit of its scale
     "ocr_records_diag": 1,              # records without the diagonal offsets (they ride in the row node's LDS word)
     "staged_direct_noreuse": 1,         # staged loops: Dat arguments on maps without reuse inside a block bypass LDS ("_d" variants)
-    # staged / owner-computes-rows blocks: a lane stages up to this many nodes per batch -- all node ids, then all rows, then LDS --
+    # staged blocks: a lane stages up to this many nodes per batch (and at most ~32 doubles) -- all node ids, then all rows, then LDS --
     # and preloads the node ids of the flush ahead of the main loop's last barrier; index rows travel as raw words (0 = one node
     # per trip, decode at the load: the wrappers of rounds 1-5)
-    "stage_batch": 4,
+    "stage_batch": 8,
     "lane_strided": 1,                  # plans in lane order (fd_plan_set_lane_order)
     "lds_const_stride": 1,              # staged loops: node stride of the LDS arrays compiled in (P1 residual 0.43 -> 0.41 ms)
     "tp_action_waves": 3,
