@@ -55,7 +55,7 @@ timeout 1800 python -m pytest tests -q -m gpu 2>&1 | grep -v "Warning\|getlimits
 tail -3 gpurun_out/${T}_gputests_tail.txt
 for part in slabs blocks; do
   FDHIP_FORCE_DEVICE=0 FDHIP_DIST_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-    --master-port 29517 bench.py --gpus 8 --steps 3 --warmup 1 --partition $part > gpurun_out/${T}_rehearsal_8ranks_${part}_one_device.json \
+    --master-port 29517 bench.py --gpus 8 --steps 3 --warmup 2 --partition $part > gpurun_out/${T}_rehearsal_8ranks_${part}_one_device.json \
     2> gpurun_out/${T}_rehearsal_${part}.err
   head -c 300 gpurun_out/${T}_rehearsal_8ranks_${part}_one_device.json; echo
 done
