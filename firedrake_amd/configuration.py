@@ -48,7 +48,9 @@ configuration = {
     # fd_row_entry_positions_masked) instead of a select per contribution in the main loop; 0 = select in the loop ("ocrp")
     "ocr_flush_colmask": _env("FDHIP_OCR_FLUSH_COLMASK", 1, int),
     "ocr_nnz_per_block": _env("FDHIP_OCR_NNZ", 2048, int),  # whole-entity row-block size (CSR entries) when the producer gives no hint
-    "ocr_nnz_per_block_ordered": _env("FDHIP_OCR_NNZ_ORDERED", 3840, int),   # the same under a backend-derived row order
+    # the same under a backend-derived row order: the largest leaves whose blocks still fit three to a CU (4416 entries of P1 rows on
+    # tetrahedra = 288 rows = 52.9 KB of LDS; a plan that comes out above 53 KB is rebuilt on smaller leaves, parloop._ocr_geometry)
+    "ocr_nnz_per_block_ordered": _env("FDHIP_OCR_NNZ_ORDERED", 4416, int),
     "ocrs_nnz_per_block": _env("FDHIP_OCRS_NNZ", 4096, int),     # row-sliced loops: accumulator entries per row block (x8 bytes of LDS)
     "ocrs_block_threads": _env("FDHIP_OCRS_BLOCK_THREADS", 256, int),
     # a wrapper that comes out of hipcc with scratch memory is recompiled with this LLVM -unroll-threshold (0 = never) and the

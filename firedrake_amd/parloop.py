@@ -1029,6 +1029,7 @@ class Parloop:
         src = prep["cw"].src
         if src.mode.startswith("ocrs"):
             return self._ocrs_geometry(start, end, gkey)
+        start0, end0, kd_rows = start, end, None
         self._reject_negative_mat_maps()
         # subsets / extruded sets: every map is replaced by its derived map over the virtual (position x layer) space
         maps = [self._plan_map(m._base(), staged=True) for m in prep["maps"]]
@@ -1064,6 +1065,7 @@ class Parloop:
                 rows_per_block = max(cap // max(int(np.ceil(rp[nrows] / max(nrows, 1))), 1), 1)
                 if kd_leaf_size(rows_per_block) <= rows_per_block:
                     rows_per_block = kd_leaf_size(rows_per_block)           # (never above the LDS budget the cap stands for)
+                rows_per_block = kd_rows = prep.get("ocr_leaf_rows", {}).get(gkey, rows_per_block)    # (a leaf shrunk below: see the end)
                 plist, rb = kd_order_of(pos_.data, nrows, rows_per_block)
                 row_order = RowOrder.from_plist(plist, nrows, rp, rowptr_dev=sp._node_rowptr.ptr)
             elif usable:
@@ -1129,6 +1131,16 @@ class Parloop:
             rb = np.unique(np.concatenate([rb, (rb[:-1] + d // 2)[big]]))
         if lds > 160 * 1024 or op.max_inst * maxar > 32768:
             raise PlanDoesNotFit("owner-computes-rows plan does not fit (LDS or instance list)")
+        three = (160 * 1024) // 3
+        if kd_rows and not src.ocr_lds_limit and three < lds <= three + three // 4 and kd_rows >= 64 \
+                and len(prep.setdefault("ocr_leaf_tries", {}).setdefault(gkey, [])) < 2:
+            # The LDS footprint of a row block decides how many 512-lane groups a CU holds, and small element matrices want three
+            # (3 x 53 KB).  The leaf size comes from an AVERAGE row length; a leaf a few percent too large leaves two groups per CU
+            # (P1 on the 215^3 cube, profiles/r6y2_sweep_ocr_nnz_fp64*.txt: 288 rows = 52.9 KB run at 0.921 ms, 307 rows = 56.1 KB
+            # at 0.98 ms): such a plan is rebuilt once or twice on leaves scaled to fit
+            prep["ocr_leaf_tries"][gkey].append((kd_rows, lds))
+            prep.setdefault("ocr_leaf_rows", {})[gkey] = max(32, int(kd_rows * three / lds * 0.98) // 32 * 32)
+            return self._ocr_geometry(start0, end0)
         nds = [op.plans[mi].max_nd for mi in src.staged_maps]
         base = "ocrp" if row_order is not None else "ocr"
         fx_wanted = (int(configuration["ocr_fixed_point"]) > 0 and int(sp.dsets[0].cdim) * int(sp.dsets[1].cdim) == 1
