@@ -81,6 +81,7 @@ configuration = {
     "tp_max_panel_tiles": 8,
     "tp_chunk_tiles": 8,
     "tp_weight_lds": 48 * 1024,               # wavefronts per SIMD the tensor-product action wrapper is compiled for
+    "ocrs_lds_limit": 0,                # row-sliced blocks: their own LDS budget (0 = lds_limit)
     "ocr_sliced_min_arity": 8,          # scalar rows of the element matrix from which row-sliced instances pay (P1: 4, whole; P2: 10, sliced)
     "ocr_sliced_max_arity": 32,
     "ocr_sliced_max_entries": 1024,

@@ -1213,7 +1213,7 @@ class Parloop:
         B = int(sp.dsets[0].cdim) * int(sp.dsets[1].cdim)
         cap = max(int(configuration["ocrs_nnz_per_block"]) // B, int(np.diff(prp).max()) if nrows else 1)
         staged = {mi: maps[mi] for mi in src.staged_maps}
-        limit = configuration["lds_limit"]
+        limit = configuration["ocrs_lds_limit"] or configuration["lds_limit"]
         per_dof = bool(pa.lgmaps) and bool(self.global_kernel.arguments[k].unroll)
         # two rows per instance (one evaluation of the local kernel, one index record for both): scalar matrices with node lgmaps whose
         # element matrix has enough rows for the shared part to matter; the pairs are chosen once, from the first block cut
