@@ -599,6 +599,11 @@ def precompile_all():
                  ElasticityHexProblem(fmesh.make_extruded_hex_mesh(1, 1, 2, perturb=0.0), bcs=True)):
         for loop in (prob.jac_loop, prob.act_loop):
             build(loop.global_kernel, [None])
+    # ... and the Helmholtz operator on Q5, Q6, Q7 (column-chunked MFMA panels; the bench line's high-order entries)
+    for degree, nq in ((5, 6), (6, 8), (7, 9)):
+        prob = HelmholtzHexProblem(fmesh.make_extruded_hex_mesh(1, 1, degree, perturb=0.0), bcs=True, nq=nq)
+        for loop in (prob.jac_loop, prob.act_loop):
+            build(loop.global_kernel, [None])
     # config C4: the three DG advection loops
     qm = fmesh.make_quad_mesh(4, perturb=0.1)
     for loop, variant in zip(DGAdvectionProblem(qm).loops, BENCH_VARIANTS["dg_advection"]):
