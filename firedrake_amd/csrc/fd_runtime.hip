@@ -38,6 +38,14 @@ struct fd_kernel_s {
 struct fd_event_s { hipEvent_t ev; };
 struct fd_graph_s { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; hipStream_t stream = nullptr; };
 
+namespace {
+// zero-fill of a small 8-byte-aligned range in ONE launch: hipMemsetAsync splits a range whose size is not a multiple of its block
+// into two fill kernels (bulk + tail: 2 x 2.5 us of a 22 us step of config C1, where a residual vector is 33 800 bytes)
+__global__ void zero_words_k(unsigned long long *__restrict__ p, size_t nwords) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) p[i] = 0ull;
+}
+}  // namespace
+
 extern "C" {
 
 int fd_version(void) { return 100; }
@@ -59,7 +67,18 @@ int fd_device_info(int device, char *name, size_t name_len, int *cus, size_t *hb
 
 int fd_malloc(void **ptr, size_t bytes) { FD_HIP(hipMalloc(ptr, bytes ? bytes : 8)); return 0; }
 int fd_free(void *ptr) { if (ptr) FD_HIP(hipFree(ptr)); return 0; }
-int fd_memset(void *p, int b, size_t n, fd_stream_t s) { if (n) FD_HIP(hipMemsetAsync(p, b, n, fd::st(s))); return 0; }
+int fd_memset(void *p, int b, size_t n, fd_stream_t s) {
+    if (!n) return 0;
+    if (b == 0 && n <= (size_t)(4u << 20) && n % 8 == 0 && (reinterpret_cast<uintptr_t>(p) & 7u) == 0) {
+        const size_t nw = n / 8;
+        const unsigned grid = (unsigned)((nw + 255) / 256 < 2048 ? (nw + 255) / 256 : 2048);
+        hipLaunchKernelGGL(zero_words_k, dim3(grid), dim3(256), 0, fd::st(s), static_cast<unsigned long long *>(p), nw);
+        FD_CHECK_LAUNCH();
+        return 0;
+    }
+    FD_HIP(hipMemsetAsync(p, b, n, fd::st(s)));
+    return 0;
+}
 int fd_memcpy_h2d(void *d, const void *s_, size_t n, fd_stream_t s) { if (n) FD_HIP(hipMemcpyAsync(d, s_, n, hipMemcpyHostToDevice, fd::st(s))); return 0; }
 int fd_memcpy_d2h(void *d, const void *s_, size_t n, fd_stream_t s) {
     if (n) { FD_HIP(hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToHost, fd::st(s))); FD_HIP(hipStreamSynchronize(fd::st(s))); }

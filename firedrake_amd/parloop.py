@@ -720,7 +720,8 @@ class Parloop:
         pa = self._position_arg()
         if pa is None or not getattr(pa.data.dataset.set, "total_size", None):
             return None                        # (a borrowed carrier whose node count is unknown: function-level seam, unregistered map)
-        target = int(target or configuration["locality_tile_entities"])
+        # (small loops: leaves sized to give the device ~2 blocks per CU -- 8192 cells in leaves of 1536 are 6 workgroups on 256 CUs)
+        target = int(target or min(int(configuration["locality_tile_entities"]), max(256, (end - start) // 512)))
         pmap = self._plan_map(pa.map_._base(), staged=True) if virtual else pa.map_._base()
         cache = pmap.__dict__.setdefault("_locality_orders", {})
         key = (start, end, id(pa.data), pa.data.dat_version, target)
@@ -1063,6 +1064,7 @@ class Parloop:
                 # equal row count -- boxes of rows whose accumulators fill the LDS budget exactly
                 cap = configuration["ocr_nnz_per_block_ordered"]
                 rows_per_block = max(cap // max(int(np.ceil(rp[nrows] / max(nrows, 1))), 1), 1)
+                rows_per_block = min(rows_per_block, max(32, nrows // 512))       # (small loops: ~2 row blocks per CU)
                 if kd_leaf_size(rows_per_block) <= rows_per_block:
                     rows_per_block = kd_leaf_size(rows_per_block)           # (never above the LDS budget the cap stands for)
                 rows_per_block = kd_rows = prep.get("ocr_leaf_rows", {}).get(gkey, rows_per_block)    # (a leaf shrunk below: see the end)
