@@ -94,6 +94,11 @@ configuration = {
     "min_waves": 0,                     # 2nd __launch_bounds__ argument (waves per SIMD), 0 = unset
     "locality_min_entities": 8192,      # loops below this size keep the caller's order
     "locality_tile_entities": 1536,     # entities per leaf of the derived order
+    # loops too small to fill the device with leaves of that size get smaller ones: at least this many blocks (4 per CU), leaves of
+    # no less than 256 entities / 32 rows (0 = off).  tools/size_sweep.py, profiles/r6s3_size_sweep*.txt: the C2 step on cubes of
+    # 16..48 per axis -27..-8 % (n = 48: 0.0433 -> 0.0398 ms at 1024 blocks, 0.0425 at 2048, 0.0455 at 4096), C1 0.0231 -> 0.0187 ms;
+    # from 1.5 M cells on the leaves have their full size
+    "small_loop_blocks": 1024,
     "use_preferred_blocks": 1,          # plan blocks = the producer's traversal tiles when a Map carries them
     "mat_scatter": "table",             # direct wrapper: element->nonzero table | "search" (row search, what hostsim runs)
     "mat_staged": 1,                    # staged wrapper: reduce element matrices in LDS (matrix plans)

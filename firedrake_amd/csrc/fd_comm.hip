@@ -461,13 +461,13 @@ int fd_halo_create(fd_comm_t comm, int nneigh, const int32_t *peers, const int32
 int fd_halo_free(fd_halo_t h) {
     if (!h) return 0;
     for (auto &s : h->slots) {
-        if (s.sbuf) (void)hipFree(s.sbuf);
-        if (s.rbuf) (void)hipFree(s.rbuf);
+        if (s.sbuf) (void)fd::release(s.sbuf);
+        if (s.rbuf) (void)fd::release(s.rbuf);
         if (s.packed) (void)hipEventDestroy(s.packed);
         if (s.done) (void)hipEventDestroy(s.done);
     }
-    (void)hipFree(h->send_idx); (void)hipFree(h->recv_idx);
-    (void)hipFree(h->comb_node); (void)hipFree(h->comb_ptr); (void)hipFree(h->comb_pos);
+    (void)fd::release(h->send_idx); (void)fd::release(h->recv_idx);
+    (void)fd::release(h->comb_node); (void)fd::release(h->comb_ptr); (void)fd::release(h->comb_pos);
     delete h;
     return 0;
 }

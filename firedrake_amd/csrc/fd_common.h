@@ -12,6 +12,9 @@ void set_error(const std::string &msg);
 // stream while a hipGraph of an assembly step is being recorded (fd_graph_begin).
 hipStream_t default_stream();
 inline hipStream_t st(fd_stream_t s) { return s ? reinterpret_cast<hipStream_t>(s) : default_stream(); }
+// hipFree for the release entry points (fd_free, fd_*_free): carried out at fd_graph_end when it arrives while a step is being
+// captured -- hipFree synchronises the device, which invalidates the capture, and a finaliser can run at any moment
+hipError_t release(void *p);
 }  // namespace fd
 
 #define FD_HIP(call)                                                                   \

@@ -343,10 +343,10 @@ static int plan_build(fd_plan_s *p, const int32_t *map_dev, hipStream_t s) {
 }
 
 static void plan_release(fd_plan_s *p) {
-    if (p->blkoff) (void)hipFree(p->blkoff);
-    if (p->list) (void)hipFree(p->list);
-    if (p->lmap) (void)hipFree(p->lmap);
-    if (p->bstart) (void)hipFree(p->bstart);
+    if (p->blkoff) (void)fd::release(p->blkoff);
+    if (p->list) (void)fd::release(p->list);
+    if (p->lmap) (void)fd::release(p->lmap);
+    if (p->bstart) (void)fd::release(p->bstart);
     delete p;
 }
 
@@ -704,11 +704,11 @@ int fd_matplan_arrays(fd_matplan_t m, const int32_t **mb_off, const int32_t **gp
 
 int fd_matplan_free(fd_matplan_t m) {
     if (!m) return 0;
-    if (m->mb_off) FD_HIP(hipFree(m->mb_off));
-    if (m->gpos) FD_HIP(hipFree(m->gpos));
-    if (m->lrp) FD_HIP(hipFree(m->lrp));
-    if (m->kidx) FD_HIP(hipFree(m->kidx));
-    if (m->zero_list) FD_HIP(hipFree(m->zero_list));
+    if (m->mb_off) FD_HIP(fd::release(m->mb_off));
+    if (m->gpos) FD_HIP(fd::release(m->gpos));
+    if (m->lrp) FD_HIP(fd::release(m->lrp));
+    if (m->kidx) FD_HIP(fd::release(m->kidx));
+    if (m->zero_list) FD_HIP(fd::release(m->zero_list));
     delete m;
     return 0;
 }
@@ -1401,13 +1401,13 @@ int fd_ocrplan_arrays(fd_ocrplan_t p, const int32_t **inst_off_dev, const int32_
 
 int fd_ocrplan_free(fd_ocrplan_t p) {
     if (!p) return 0;
-    if (p->inst_off) FD_HIP(hipFree(p->inst_off));
-    if (p->inst_ent) FD_HIP(hipFree(p->inst_ent));
-    if (p->rblk) FD_HIP(hipFree(p->rblk));
-    if (p->chunk_role) FD_HIP(hipFree(p->chunk_role));
-    if (p->groles) FD_HIP(hipFree(p->groles));
-    if (p->chunk_block) FD_HIP(hipFree(p->chunk_block));
-    if (p->valid) FD_HIP(hipFree(p->valid));
+    if (p->inst_off) FD_HIP(fd::release(p->inst_off));
+    if (p->inst_ent) FD_HIP(fd::release(p->inst_ent));
+    if (p->rblk) FD_HIP(fd::release(p->rblk));
+    if (p->chunk_role) FD_HIP(fd::release(p->chunk_role));
+    if (p->groles) FD_HIP(fd::release(p->groles));
+    if (p->chunk_block) FD_HIP(fd::release(p->chunk_block));
+    if (p->valid) FD_HIP(fd::release(p->valid));
     free(p->inst_off_host);
     delete p;
     return 0;

@@ -20,6 +20,19 @@ extern char **environ;
 namespace fd {
 static hipStream_t g_default_stream = nullptr;
 static hipStream_t g_saved_stream = nullptr;      // the default stream a graph capture displaced (fd_graph_begin .. fd_graph_end)
+// hipFree synchronises the device and is illegal while this thread captures a stream: the capture is invalidated and every later
+// launch fails with "a previous error during capture".  A release can arrive at any moment (a finaliser of the host language's
+// garbage collector running inside the captured step), so releases between fd_graph_begin and fd_graph_end are parked here and
+// carried out by fd_graph_end.
+static bool g_capturing = false;
+static std::vector<void *> g_deferred_free;
+static std::vector<fd_kernel_t> g_deferred_kernels;            // (hipModuleUnload and the destruction of another graph's stream: the same)
+static std::vector<fd_graph_t> g_deferred_graphs;
+hipError_t release(void *p) {
+    if (!p) return hipSuccess;
+    if (g_capturing) { g_deferred_free.push_back(p); return hipSuccess; }
+    return hipFree(p);
+}
 hipStream_t default_stream() { return g_default_stream; }
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
@@ -65,8 +78,15 @@ int fd_device_info(int device, char *name, size_t name_len, int *cus, size_t *hb
     return 0;
 }
 
-int fd_malloc(void **ptr, size_t bytes) { FD_HIP(hipMalloc(ptr, bytes ? bytes : 8)); return 0; }
-int fd_free(void *ptr) { if (ptr) FD_HIP(hipFree(ptr)); return 0; }
+int fd_malloc(void **ptr, size_t bytes) {
+    if (fd::g_capturing) FD_FAIL("fd_malloc inside fd_graph_begin .. fd_graph_end: a captured step may only enqueue work -- run it once before the capture so that its plans and buffers exist");
+    FD_HIP(hipMalloc(ptr, bytes ? bytes : 8));
+    return 0;
+}
+int fd_free(void *ptr) {
+    FD_HIP(fd::release(ptr));
+    return 0;
+}
 int fd_memset(void *p, int b, size_t n, fd_stream_t s) {
     if (!n) return 0;
     if (b == 0 && n <= (size_t)(4u << 20) && n % 8 == 0 && (reinterpret_cast<uintptr_t>(p) & 7u) == 0) {
@@ -104,6 +124,7 @@ int fd_event_elapsed_ms(fd_event_t a, fd_event_t b, float *ms) { FD_HIP(hipEvent
 // SURVEY.md 7 hard part (f)).  Between begin and end every libfdhip call that takes a NULL stream records
 // into the graph instead of executing.
 int fd_graph_begin(fd_graph_t *out) {
+    if (fd::g_capturing) FD_FAIL("fd_graph_begin: a capture is already open (captures do not nest)");
     auto *g = new fd_graph_s;
     hipError_t r = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
     if (r != hipSuccess) { delete g; FD_HIP(r); }
@@ -111,6 +132,7 @@ int fd_graph_begin(fd_graph_t *out) {
     if (r != hipSuccess) { (void)hipStreamDestroy(g->stream); delete g; FD_HIP(r); }
     fd::g_saved_stream = fd::g_default_stream;
     fd::g_default_stream = g->stream;
+    fd::g_capturing = true;
     *out = g;
     return 0;
 }
@@ -118,8 +140,16 @@ int fd_graph_begin(fd_graph_t *out) {
 int fd_graph_end(fd_graph_t g) {
     fd::g_default_stream = fd::g_saved_stream;
     fd::g_saved_stream = nullptr;
+    fd::g_capturing = false;
     if (!g) FD_FAIL("fd_graph_end: null graph");
-    FD_HIP(hipStreamEndCapture(g->stream, &g->graph));
+    const hipError_t ended = hipStreamEndCapture(g->stream, &g->graph);
+    for (void *p : fd::g_deferred_free) (void)hipFree(p);           // (releases parked during the capture)
+    fd::g_deferred_free.clear();
+    for (fd_kernel_t k : fd::g_deferred_kernels) (void)fd_kernel_free(k);
+    fd::g_deferred_kernels.clear();
+    for (fd_graph_t d : fd::g_deferred_graphs) (void)fd_graph_free(d);
+    fd::g_deferred_graphs.clear();
+    FD_HIP(ended);
     FD_HIP(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0));
     return 0;
 }
@@ -138,6 +168,7 @@ int fd_graph_sync(fd_graph_t g) {
 
 int fd_graph_free(fd_graph_t g) {
     if (!g) return 0;
+    if (fd::g_capturing) { fd::g_deferred_graphs.push_back(g); return 0; }
     if (g->exec) FD_HIP(hipGraphExecDestroy(g->exec));
     if (g->graph) FD_HIP(hipGraphDestroy(g->graph));
     if (g->stream) FD_HIP(hipStreamDestroy(g->stream));
@@ -261,6 +292,7 @@ int fd_kernel_builtin(const char *symbol, fd_kernel_t *out) {
 
 int fd_kernel_free(fd_kernel_t k) {
     if (!k) return 0;
+    if (fd::g_capturing) { fd::g_deferred_kernels.push_back(k); return 0; }
     if (k->mod) FD_HIP(hipModuleUnload(k->mod));
     delete k;
     return 0;

@@ -5,6 +5,7 @@ and ctypes overhead (pyop2/parloop.py:203-232).  A step who
 are already built consists only of stream-ordered work (memsets, wrapper kernels, BC kernels), so it can be
 recorded once and replayed with a single host call."""
 import ctypes
+import gc
 
 from . import _lib
 
@@ -14,7 +15,8 @@ class CapturedStep:
         """``fn()`` must only enqueue device work once warmed up (no host<->device copies, no allocation)."""
         for _ in range(warmup):
             fn()                      # builds plans / tables / uploads data
-        _lib.call("fd_device_sync")
+        gc.collect()                  # (finalisers that release device memory run now rather than inside the capture; one that does
+        _lib.call("fd_device_sync")   #  arrive there is parked by the library until fd_graph_end: hipFree would invalidate the capture)
         h = ctypes.c_void_p()
         _lib.call("fd_graph_begin", ctypes.byref(h))
         try:

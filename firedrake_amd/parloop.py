@@ -720,8 +720,9 @@ class Parloop:
         pa = self._position_arg()
         if pa is None or not getattr(pa.data.dataset.set, "total_size", None):
             return None                        # (a borrowed carrier whose node count is unknown: function-level seam, unregistered map)
-        # (small loops: leaves sized to give the device ~2 blocks per CU -- 8192 cells in leaves of 1536 are 6 workgroups on 256 CUs)
-        target = int(target or min(int(configuration["locality_tile_entities"]), max(256, (end - start) // 512)))
+        # (small loops: leaves sized to give the device ~4 blocks per CU -- 8192 cells in leaves of 1536 are 6 workgroups on 256 CUs)
+        sb = int(configuration["small_loop_blocks"])
+        target = int(target or min(int(configuration["locality_tile_entities"]), max(256, (end - start) // sb) if sb else 1 << 30))
         pmap = self._plan_map(pa.map_._base(), staged=True) if virtual else pa.map_._base()
         cache = pmap.__dict__.setdefault("_locality_orders", {})
         key = (start, end, id(pa.data), pa.data.dat_version, target)
@@ -1064,7 +1065,8 @@ class Parloop:
                 # equal row count -- boxes of rows whose accumulators fill the LDS budget exactly
                 cap = configuration["ocr_nnz_per_block_ordered"]
                 rows_per_block = max(cap // max(int(np.ceil(rp[nrows] / max(nrows, 1))), 1), 1)
-                rows_per_block = min(rows_per_block, max(32, nrows // 512))       # (small loops: ~2 row blocks per CU)
+                sb = int(configuration["small_loop_blocks"])
+                rows_per_block = min(rows_per_block, max(32, nrows // sb) if sb else rows_per_block)     # (small loops: ~4 row blocks per CU)
                 if kd_leaf_size(rows_per_block) <= rows_per_block:
                     rows_per_block = kd_leaf_size(rows_per_block)           # (never above the LDS budget the cap stands for)
                 rows_per_block = kd_rows = prep.get("ocr_leaf_rows", {}).get(gkey, rows_per_block)    # (a leaf shrunk below: see the end)

@@ -143,6 +143,47 @@ def test_c1_step_as_hipgraph():
     assert_allclose(prob.jacobian()[0].toscipy().data, Ao.data, rtol=0, atol=1e-12 * np.abs(Ao.data).max())
 
 
+def test_release_of_device_memory_inside_a_capture_is_parked():
+    """A finaliser can run at any moment of a captured step (the garbage collector), and hipFree there would invalidate the capture
+    ("operation failed due to a previous error during capture" at the next launch).  The library parks releases that arrive between
+    fd_graph_begin and fd_graph_end and carries them out at the end; an ALLOCATION inside a capture is refused with a message, and
+    the capture survives it; captures do not nest."""
+    import ctypes
+    from firedrake_amd import _lib
+    from firedrake_amd.device import DeviceBuffer
+    from firedrake_amd.graph import CapturedStep
+    m = fmesh.UnitSquareMesh(16, 16, perturb=0.1)
+    prob = forms.PoissonProblem(m, 1, bcs=True)
+    ro, Ao = _oracle_problem(prob, True)
+    state = {"garbage": None, "old": None}
+
+    def step():
+        prob.assemble_residual()
+        if state["garbage"] is not None:         # (only the captured call finds something to drop)
+            state["garbage"] = None              # four buffers released inside the capture (DeviceBuffer.__del__ -> fd_free)
+            state["old"] = None                  # and a whole graph: exec, graph, stream (fd_graph_free)
+            with pytest.raises(_lib.FDHipError, match="fd_malloc inside"):
+                DeviceBuffer(64)
+            h = ctypes.c_void_p()
+            with pytest.raises(_lib.FDHipError, match="do not nest"):
+                _lib.call("fd_graph_begin", ctypes.byref(h))
+        prob.assemble_jacobian()
+
+    step(); step()                               # warm: plans exist
+    state["garbage"] = [DeviceBuffer(1 << 20) for _ in range(4)]
+    state["old"] = CapturedStep(lambda: prob.assemble_residual())
+    g = CapturedStep(step, warmup=0)
+    assert state["garbage"] is None and state["old"] is None
+    prob.r.zero()
+    for _ in range(2):
+        g()
+    g.sync()
+    prob.r._host_valid = False
+    assert_allclose(prob.r.data_ro, ro, rtol=0, atol=1e-12 * np.abs(ro).max())
+    assert_allclose(prob.jacobian()[0].toscipy().data, Ao.data, rtol=0, atol=1e-12 * np.abs(Ao.data).max())
+    DeviceBuffer(64)                             # (allocation works again after the capture)
+
+
 def test_c2_full_size_properties():
     """BASELINE.json configs[1] at full size (59.6 M tets, 10.08 M DoFs, nnz 150 M): size-independent properties of the
     assembled tensors instead of the oracle -- constants in the null space, symmetry (x'Ay = y'Ax), residual of a
