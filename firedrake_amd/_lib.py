@@ -44,6 +44,7 @@ SIGNATURES = {
     "fd_stream_destroy": (c_int, [c_void_p]),
     "fd_stream_sync": (c_int, [c_void_p]),
     "fd_stream_set_default": (c_int, [c_void_p]),
+    "fd_stream_get_default": (c_int, [POINTER(c_void_p)]),
     "fd_stream_wait_event": (c_int, [c_void_p, c_void_p]),
     "fd_device_sync": (c_int, []),
     "fd_event_create": (c_int, [POINTER(c_void_p)]),

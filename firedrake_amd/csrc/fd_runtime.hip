@@ -112,6 +112,7 @@ int fd_device_sync(void) { FD_HIP(hipDeviceSynchronize()); return 0; }
 // The stream every call with a NULL stream argument uses from now on (NULL: back to the HIP null stream).  Two independent
 // parloops -- the residual and the Jacobian of one Newton step -- are put on two streams this way and share the device.
 int fd_stream_set_default(fd_stream_t s) { fd::g_default_stream = reinterpret_cast<hipStream_t>(s); return 0; }
+int fd_stream_get_default(fd_stream_t *s) { if (!s) FD_FAIL("fd_stream_get_default: null result"); *s = reinterpret_cast<fd_stream_t>(fd::g_default_stream); return 0; }
 int fd_stream_wait_event(fd_stream_t s, fd_event_t e) { if (!e) FD_FAIL("fd_stream_wait_event: null event"); FD_HIP(hipStreamWaitEvent(fd::st(s), e->ev, 0)); return 0; }
 
 int fd_event_create(fd_event_t *e) { auto *p = new fd_event_s; hipError_t r = hipEventCreate(&p->ev); if (r != hipSuccess) { delete p; FD_HIP(r); } *e = p; return 0; }

@@ -94,7 +94,8 @@ class Stream:
     READ what they share -- ``assemble(F)`` and ``assemble(J)`` of one Newton step -- can be put on two streams and share the
     device: the latency-bound staged residual fills the issue slots the LDS-bound Jacobian leaves idle.  ``with side.fork(): ...``
     runs the enclosed launches on ``side`` after everything enqueued so far; ``side.join()`` makes the launching stream wait for
-    them.  Nothing here synchronises the host."""
+    them.  Nothing here synchronises the host.  Inside a captured step (graph.CapturedStep) a fork becomes a second branch of the
+    graph: at launch-bound sizes (config C1) the two assemblies' kernel chains run side by side."""
 
     _current = None      # the stream NULL-stream calls of the library resolve to (None = the HIP null stream)
 
@@ -115,7 +116,7 @@ class Stream:
 
     def join(self):
         """The launching stream waits for the work enqueued inside the last ``fork()`` block."""
-        _lib.call("fd_stream_wait_event", Stream._current.h if Stream._current is not None else None, self._done.h)
+        _lib.call("fd_stream_wait_event", None, self._done.h)           # (NULL = the stream launches go to right now)
 
     def __del__(self):
         try:
@@ -133,6 +134,9 @@ class _Forked:
     def __enter__(self):
         s = self.side
         self.prev = Stream._current
+        p = ctypes.c_void_p()
+        _lib.call("fd_stream_get_default", ctypes.byref(p))
+        self.prev_handle = p.value           # (not always prev.h: inside a capture the launching stream is the capturing one)
         s._fork.record()                     # on the launching stream: everything enqueued so far ...
         s.wait(s._fork)                      # ... precedes the side stream's work
         _lib.call("fd_stream_set_default", s.h)
@@ -142,6 +146,6 @@ class _Forked:
     def __exit__(self, *exc):
         s = self.side
         s._done.record()                     # (on the side stream: it is still the default)
-        _lib.call("fd_stream_set_default", self.prev.h if self.prev is not None else None)
+        _lib.call("fd_stream_set_default", self.prev_handle)
         Stream._current = self.prev
         return False

@@ -63,6 +63,10 @@ int fd_device_sync(void);
  * (pyop2/parloop.py:243-260); on the device two loops that share no written argument -- assemble(F) and
  * assemble(J) of one Newton step -- may be put on two streams and overlap (firedrake_amd/op2types.py: stream()). */
 int fd_stream_set_default(fd_stream_t s);
+/* the stream NULL-stream calls run on right now (NULL = the HIP null stream; the capturing stream between fd_graph_begin and
+ * fd_graph_end): what a fork onto a side stream hands back to fd_stream_set_default when it ends, so that forks work inside a
+ * captured step too (two branches of the graph: pyop2/parloop.py:243-260 has no counterpart, its loops are host-serial) */
+int fd_stream_get_default(fd_stream_t *s);
 int fd_stream_wait_event(fd_stream_t s, fd_event_t e);
 
 /* HIP events recorded on the launch stream (PETSc Log.Event analogue of

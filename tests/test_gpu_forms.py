@@ -278,6 +278,28 @@ def test_two_parloops_on_two_streams_and_the_cached_diagonal_places():
     assert_allclose(np.array(prob.r.data_ro), r0, rtol=0, atol=1e-13 * np.abs(r0).max())
     mat = prob.jacobian()[0]
     assert_allclose(mat.csr()[2], v0, rtol=0, atol=1e-13 * np.abs(v0).max())
+    # the same fork inside a captured step: two branches of one hipGraph (the fork hands the CAPTURING stream back when it ends)
+    from firedrake_amd.graph import CapturedStep
+
+    def step():
+        with side.fork():
+            prob.assemble_jacobian()
+        prob.assemble_residual()
+        side.join()
+
+    g = CapturedStep(step)
+    prob.r.zero()
+    mat.zero()
+    mat._values_dev()                           # flush the pending zero: the tensors really are cleared now
+    for _ in range(3):
+        g()
+    g.sync()
+    prob.r._host_valid = False                  # device copy is authoritative after the replay
+    assert_allclose(np.array(prob.r.data_ro), r0, rtol=0, atol=1e-13 * np.abs(r0).max())
+    assert_allclose(mat.csr()[2], v0, rtol=0, atol=1e-13 * np.abs(v0).max())
+    prob.assemble_residual()                    # eager launches after the capture go to the null stream again
+    _lib.call("fd_device_sync")
+    assert_allclose(np.array(prob.r.data_ro), r0, rtol=0, atol=1e-13 * np.abs(r0).max())
     # the diagonal fix-up through the API that takes host rows: same places, other value
     rp, ci, vb = mat.csr()
     vb = vb.copy()
