@@ -12,6 +12,7 @@ overlaps MPI with ``_compute(core_part)``.
 """
 from __future__ import annotations
 
+import contextlib
 from dataclasses import dataclass
 from typing import Any, Optional, Tuple
 
@@ -24,6 +25,8 @@ from .kernel import (CStringLocalKernel, DatKernelArg, GlobalKernel, GlobalKerne
                      MixedDatKernelArg, MixedMatKernelArg, PermutedMapKernelArg)
 from .op2types import (INC, MAX, MIN, READ, WRITE, Access, Dat, ExtrudedSet, Global, Map, MapValueError,
                        Mat, MixedDat, MixedMap, PermutedMap, Set, SetTypeError, Subset)
+
+_NO_EVENT = contextlib.nullcontext()          # (tracing off: no generator-based context manager per launch)
 
 
 # ---- parloop arguments (pyop2/parloop.py:36-165) ----------------------------------------------
@@ -931,6 +934,8 @@ class Parloop:
                 self._forced_mode, self._prepared = nxt, None
 
     def _compute_event(self):            # pyop2/parloop.py:221-222
+        if not configuration["trace"]:
+            return _NO_EVENT
         from .profiling import timed_region
         return timed_region(self._event_name)
 
@@ -949,6 +954,13 @@ class Parloop:
             log_flops(self._event_name, size, size * self.num_flops)
 
     def compute(self):
+        self._halos_now = self._halos_present()
+        try:
+            self._compute_all()
+        finally:
+            self._halos_now = None
+
+    def _compute_all(self):
         self._zero_global_temporaries()
         self._ensure_geometry()
         if self._prepare()["cw"].src.mode.startswith("ocr"):
@@ -1491,32 +1503,55 @@ class Parloop:
     # -- halo protocol (parloop.py:320-409)
     def _indirect_dats(self):
         """(Dat, access) of the indirectly accessed Dats, each data carrier once (the reference's ``seen`` sets,
-        pyop2/parloop.py:343-352, 393-403): one exchange per distinct Dat and direction."""
-        seen = set()
-        for pa, acc in zip(self.arguments, self.accesses):
-            if isinstance(pa, DatParloopArg) and pa.map_ is not None:
-                d = getattr(pa.data, "_parent", pa.data)          # a DatView exchanges its parent's storage
-                if id(d) in seen:
-                    continue
-                seen.add(id(d))
-                yield pa.data, acc
+        pyop2/parloop.py:343-352, 393-403): one exchange per distinct Dat and direction.  (The arguments of a Parloop are fixed:
+        the list is made once -- a launch-bound step walks it four times per loop.)"""
+        lst = self.__dict__.get("_indirect_list")
+        if lst is None:
+            lst, seen = [], set()
+            for pa, acc in zip(self.arguments, self.accesses):
+                if isinstance(pa, DatParloopArg) and pa.map_ is not None:
+                    d = getattr(pa.data, "_parent", pa.data)          # a DatView exchanges its parent's storage
+                    if id(d) in seen:
+                        continue
+                    seen.add(id(d))
+                    lst.append((pa.data, acc))
+            self._indirect_list = lst
+        return lst
+
+    def _halos_present(self):
+        """Does any Dat argument live on a Set with a halo right now?  (One rank: no -- the four exchange phases and the
+        ``halo_valid`` bookkeeping are then skipped as a whole; every one of them returns at once for such a Dat anyway.)"""
+        for pa in self.arguments:
+            if isinstance(pa, DatParloopArg) and pa.data.dataset.set.halo is not None:
+                return True
+        return False
+
+    _halos_now = None         # set by compute() for the duration of one call; None = look at every Dat (calls from outside)
 
     def global_to_local_begin(self):
+        if self._halos_now is False:
+            return
         for d, acc in self._indirect_dats():
             if acc != WRITE:
                 d.global_to_local_begin(acc)
 
     def global_to_local_end(self):
+        if self._halos_now is False:
+            return
         for d, acc in self._indirect_dats():
             if acc != WRITE:
                 d.global_to_local_end(acc)
 
     def local_to_global_begin(self):
+        if self._halos_now is False:
+            return
         for d, acc in self._indirect_dats():
             if acc in (INC, MIN, MAX):
                 d.local_to_global_begin(acc)
 
     def local_to_global_end(self):
+        if self._halos_now is False:
+            return
         for d, acc in self._indirect_dats():
             if acc in (INC, MIN, MAX):
                 d.local_to_global_end(acc)
@@ -1525,15 +1560,24 @@ class Parloop:
                 if pa.data.dataset.set.halo is not None:
                     pa.data.halo_valid = False
 
+    def _global_reductions(self):
+        lst = self.__dict__.get("_reduction_list")
+        if lst is None:
+            lst = self._reduction_list = [(k, pa, acc) for k, (pa, acc) in enumerate(zip(self.arguments, self.accesses))
+                                          if isinstance(pa, GlobalParloopArg) and acc in (INC, MIN, MAX)]
+        return lst
+
     def _zero_global_temporaries(self):
         """pyop2/parloop.py:274-277, 516-532: with more than one rank an INC Global accumulates this loop's
         contributions in a zeroed temporary; the all-reduced temporary is then added to the Global."""
-        from .halo import world_size
         self._glob_saved = {}
+        if not self._global_reductions():
+            return
+        from .halo import world_size
         if world_size() == 1:
             return
-        for k, (pa, acc) in enumerate(zip(self.arguments, self.accesses)):
-            if isinstance(pa, GlobalParloopArg) and acc == INC:
+        for k, pa, acc in self._global_reductions():
+            if acc == INC:
                 self._glob_saved[k] = np.array(pa.data.data_ro, copy=True)
                 pa.data.data[...] = 0
 
@@ -1541,12 +1585,14 @@ class Parloop:
         pass
 
     def reduction_end(self):
+        red = self._global_reductions()
+        if not red:
+            return
         from .halo import allreduce_global
-        for k, (pa, acc) in enumerate(zip(self.arguments, self.accesses)):
-            if isinstance(pa, GlobalParloopArg) and acc in (INC, MIN, MAX):
-                allreduce_global(pa.data, acc, self.iterset.comm)
-                if k in self._glob_saved:
-                    pa.data.data[...] += self._glob_saved[k]
+        for k, pa, acc in red:
+            allreduce_global(pa.data, acc, self.iterset.comm)
+            if k in self._glob_saved:
+                pa.data.data[...] += self._glob_saved[k]
 
     def finalize_assembly(self):
         pass
