@@ -537,7 +537,7 @@ class PoissonProblem:
 # variant missing here is not an error -- it is compiled on first use -- and bench.py reports how many were (``jit_compiles``).
 BENCH_VARIANTS = {
     ("residual", 2, 1): ("staged_s289",),
-    ("jacobian", 2, 1): ("ocrpm_q10k3d", "ocrpm_q9k3d", "ocrp_q10k3d_fx", "ocr_q10k3d_fx", "ocrp_q9k3d_fx", "ocr_q9k3d_fx"),
+    ("jacobian", 2, 1): ("ocrpm_q10k3d", "ocrpm_q9k3d", "ocrpm_q8k3d", "ocrpm_q7k3d", "ocrpm_q6k3d", "ocrp_q10k3d_fx", "ocr_q10k3d_fx", "ocrp_q9k3d_fx", "ocr_q9k3d_fx"),
     ("residual", 3, 1): ("stagedo_s431", "staged_s405"),
     ("jacobian", 3, 1): ("ocrpm_q10k4d", "ocrpm_q9k4d", "ocrp_q10k4d_fx", "ocr_q10k4d_fx", "ocrp_q9k4d_fx", "ocr_q9k4d_fx"),
     ("residual", 3, 2): ("stagedo_s1508x255", "stagedo_s1502x256"),       # n = 107 (one GPU's share), n = 215 (the whole cube of configs[4])
