@@ -29,6 +29,17 @@ from .op2types import (INC, MAX, MIN, READ, WRITE, Access, Dat, ExtrudedSet, Glo
 _NO_EVENT = contextlib.nullcontext()          # (tracing off: no generator-based context manager per launch)
 
 
+def small_loop_leaf(n: int, leaf: int, floor: int) -> int:
+    """Leaf size (entities or rows per block of a derived order) for a loop over ``n`` of them: the configured ``leaf``, unless that
+    leaves the device short of ``configuration["small_loop_blocks"]`` blocks (4 per CU) -- then ``n // blocks``, but not below
+    ``floor`` (a block of fewer entities than lanes idles most of its workgroup) and never above ``leaf`` (the LDS budget it stands
+    for).  0 blocks = off.  tools/size_sweep.py, profiles/r6s3_size_sweep*.txt."""
+    sb = int(configuration["small_loop_blocks"])
+    if sb <= 0:
+        return int(leaf)
+    return int(min(leaf, max(floor, n // sb)))
+
+
 # ---- parloop arguments (pyop2/parloop.py:36-165) ----------------------------------------------
 @dataclass
 class GlobalParloopArg:
@@ -724,8 +735,7 @@ class Parloop:
         if pa is None or not getattr(pa.data.dataset.set, "total_size", None):
             return None                        # (a borrowed carrier whose node count is unknown: function-level seam, unregistered map)
         # (small loops: leaves sized to give the device ~4 blocks per CU -- 8192 cells in leaves of 1536 are 6 workgroups on 256 CUs)
-        sb = int(configuration["small_loop_blocks"])
-        target = int(target or min(int(configuration["locality_tile_entities"]), max(256, (end - start) // sb) if sb else 1 << 30))
+        target = int(target or small_loop_leaf(end - start, int(configuration["locality_tile_entities"]), 256))
         pmap = self._plan_map(pa.map_._base(), staged=True) if virtual else pa.map_._base()
         cache = pmap.__dict__.setdefault("_locality_orders", {})
         key = (start, end, id(pa.data), pa.data.dat_version, target)
@@ -1077,8 +1087,7 @@ class Parloop:
                 # equal row count -- boxes of rows whose accumulators fill the LDS budget exactly
                 cap = configuration["ocr_nnz_per_block_ordered"]
                 rows_per_block = max(cap // max(int(np.ceil(rp[nrows] / max(nrows, 1))), 1), 1)
-                sb = int(configuration["small_loop_blocks"])
-                rows_per_block = min(rows_per_block, max(32, nrows // sb) if sb else rows_per_block)     # (small loops: ~4 row blocks per CU)
+                rows_per_block = small_loop_leaf(nrows, rows_per_block, 32)     # (small loops: ~4 row blocks per CU)
                 if kd_leaf_size(rows_per_block) <= rows_per_block:
                     rows_per_block = kd_leaf_size(rows_per_block)           # (never above the LDS budget the cap stands for)
                 rows_per_block = kd_rows = prep.get("ocr_leaf_rows", {}).get(gkey, rows_per_block)    # (a leaf shrunk below: see the end)

@@ -186,3 +186,21 @@ def test_wrapper_cache_evicts_code_objects_nothing_has_used(tmp_path):
     (tmp_path / ".compiler_version.json").write_text("{}")
     assert compilation.evict_unused(36.0, str(tmp_path)) == (1, 1)
     assert sorted(os.listdir(tmp_path)) == [".compiler_version.json", "wrap_a_0123.hip", "wrap_a_0123.hsaco", "wrap_a_0123.hsaco.res.json"]
+
+
+def test_small_loops_get_smaller_leaves(monkeypatch):
+    """Leaves of a derived order are sized for the benchmark (1536 cells, 288 rows); a loop too small to give the device 1024 blocks of
+    that size gets smaller ones -- not below the floor, never above the configured size (a test or a user that asks for 96 gets 96),
+    0 blocks switches it off (tools/size_sweep.py: the C2 step on cubes of 16..48 per axis -8..-27 %)."""
+    from firedrake_amd.configuration import configuration
+    from firedrake_amd.parloop import small_loop_leaf
+    assert configuration["small_loop_blocks"] == 1024
+    assert small_loop_leaf(8192, 1536, 256) == 256                  # C1: 64 x 64 triangles
+    assert small_loop_leaf(196608, 1536, 256) == 256                # 32^3 cubes of six tetrahedra
+    assert small_loop_leaf(663552, 1536, 256) == 648                # 48^3
+    assert small_loop_leaf(1572864, 1536, 256) == 1536              # 64^3: full size from here on
+    assert small_loop_leaf(59630250, 1536, 256) == 1536             # C2
+    assert small_loop_leaf(4374, 96, 256) == 96                     # a configured leaf below the floor stays
+    assert small_loop_leaf(4225, 288, 32) == 32 and small_loop_leaf(117649, 288, 32) == 114 and small_loop_leaf(10077696, 288, 32) == 288
+    monkeypatch.setitem(configuration, "small_loop_blocks", 0)
+    assert small_loop_leaf(8192, 1536, 256) == 1536
