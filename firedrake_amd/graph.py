@@ -19,10 +19,15 @@ class CapturedStep:
         _lib.call("fd_device_sync")   #  arrive there is parked by the library until fd_graph_end: hipFree would invalidate the capture)
         h = ctypes.c_void_p()
         _lib.call("fd_graph_begin", ctypes.byref(h))
+        self.h = None
         try:
             fn()
         finally:
-            _lib.call("fd_graph_end", h)
+            try:
+                _lib.call("fd_graph_end", h)
+            except _lib.FDHipError:
+                _lib.load().fd_graph_free(h)      # (a capture that did not end in a graph: its stream goes with it)
+                raise
         self.h = h.value
 
     def __call__(self):
