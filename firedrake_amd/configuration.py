@@ -73,7 +73,11 @@ configuration = {
     # per trip, decode at the load: the wrappers of rounds 1-5)
     "stage_batch": 8,
     "lane_strided": 1,                  # plans in lane order (fd_plan_set_lane_order)
-    "lds_const_stride": 1,              # staged loops: node stride of the LDS arrays compiled in (P1 residual 0.43 -> 0.41 ms)
+    # staged loops: node stride of the LDS arrays compiled in (P1 residual 0.43 -> 0.41 ms), rounded up to a multiple of this: the
+    # stride is part of the variant's name, so an exact stride (1) sends every mesh whose blocks hold a few nodes more or less
+    # through hipcc again (0.35 s per loop); 16 shares a code object between meshes of alike blocks at < 1 KB of LDS and no measurable
+    # time (profiles/r6s3_ab_lds_stride_quantum.txt); 0 = run-time stride
+    "lds_const_stride": 16,
     "tp_action_waves": 3,
     # MFMA matrix template (csrc/fd_tensor.h): a 16-row panel of more than tp_max_panel_tiles column tiles is cut into chunks of
     # tp_chunk_tiles (Q5: 14 tiles -> 2 chunks of 7, Q6: 22 -> 3 of 8; 4 accumulator registers per tile); per-point weights beyond tp_weight_lds bytes

@@ -536,14 +536,14 @@ class PoissonProblem:
 # ahead of time by precompile_all() so that a fresh machine's first assemble does not start with hipcc (0.35 s per wrapper).  A
 # variant missing here is not an error -- it is compiled on first use -- and bench.py reports how many were (``jit_compiles``).
 BENCH_VARIANTS = {
-    ("residual", 2, 1): ("staged_s289",),
+    ("residual", 2, 1): ("staged_s304",),
     ("jacobian", 2, 1): ("ocrpm_q10k3d", "ocrpm_q9k3d", "ocrpm_q8k3d", "ocrpm_q7k3d", "ocrpm_q6k3d", "ocrp_q10k3d_fx", "ocr_q10k3d_fx", "ocrp_q9k3d_fx", "ocr_q9k3d_fx"),
-    ("residual", 3, 1): ("stagedo_s431", "staged_s405"),
+    ("residual", 3, 1): ("stagedo_s432", "staged_s416"),
     ("jacobian", 3, 1): ("ocrpm_q10k4d", "ocrpm_q9k4d", "ocrp_q10k4d_fx", "ocr_q10k4d_fx", "ocrp_q9k4d_fx", "ocr_q9k4d_fx"),
-    ("residual", 3, 2): ("stagedo_s1508x255", "stagedo_s1502x256"),       # n = 107 (one GPU's share), n = 215 (the whole cube of configs[4])
+    ("residual", 3, 2): ("stagedo_s1520x256", "stagedo_s1504x256"),       # n = 107 (one GPU's share), n = 215 (the whole cube of configs[4])
     # (two rows per instance since round 6: "_g" + the row pairs Parloop._ocrs_geometry picks on the benchmark meshes)
     ("jacobian", 3, 2): ("ocrspr_g0619283745_q8k7e13", "ocrspr_q8k7e13", "ocrs_q8k7e13", "ocrspr", "ocrsp", "ocrs"),
-    "dg_advection": ("staged_d0_s561", "staged_s1024x516", "staged_s2332x668"),
+    "dg_advection": ("staged_d0_s576", "staged_s1024x528", "staged_s2336x672"),
 }
 
 
