@@ -230,9 +230,6 @@ class MixedMatLegacyArg:             # pyop2/parloop.py:679-706
         return MixedMatParloopArg(self.data, self.maps, self.lgmaps)
 
 
-_mka_cache = {}
-
-
 def _tuple_or_none(x):
     return None if x is None else tuple(int(v) for v in x)
 
@@ -242,13 +239,14 @@ def _map_kernel_arg(m):
     if m is None:
         return None
     base = m._base()
-    mk = _mka_cache.get(id(base))
-    if mk is None or mk[0] is not base:
-        mk = (base, MapKernelArg(base.arity, base.offset, _tuple_or_none(base.offset_quotient)))
-        _mka_cache[id(base)] = mk
+    # (kept ON the Map: a module-level table keyed by id() with the Map as its value kept every Map ever used in a parloop alive --
+    #  its device values, the plans and derived orders cached on it: 26 MB per problem of 384 k cells, profiles/r6s3_leak_probe.txt)
+    mk = base.__dict__.get("_map_kernel_arg")
+    if mk is None:
+        mk = base.__dict__["_map_kernel_arg"] = MapKernelArg(base.arity, base.offset, _tuple_or_none(base.offset_quotient))
     if isinstance(m, PermutedMap):
-        return PermutedMapKernelArg(mk[1], tuple(int(p) for p in m.permutation))
-    return mk[1]
+        return PermutedMapKernelArg(mk, tuple(int(p) for p in m.permutation))
+    return mk
 
 
 class LocalityOrder:

@@ -1,0 +1,58 @@
+"""Device memory comes back when a problem goes: meshes, maps, plans, derived orders, sparsities, matrices, code objects' tables.
+(Round 6, third session: a module-level table keyed by ``id(map)`` with the Map as its value kept every Map ever used in a parloop
+alive -- 26 MB per problem of 384 k cells, found by building twelve problems in a row, profiles/r6s3_leak_probe.txt.  The reference's
+caches hang on the objects they describe -- ``ObjectCached``, pyop2/caching.py:60-120 -- for the same reason.)"""
+import ctypes
+import gc
+
+import numpy as np
+import pytest
+
+from firedrake_amd import _lib, forms, mesh as fmesh
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_bytes():
+    _lib.call("fd_device_sync")
+    hip = ctypes.CDLL("libamdhip64.so")
+    f, t = ctypes.c_size_t(), ctypes.c_size_t()
+    assert hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+    return f.value
+
+
+def _poisson(degree, n):
+    def run():
+        prob = forms.PoissonProblem(fmesh.UnitCubeMesh((n, n, n), degrees=(degree,), perturb=0.1, numbering="lexicographic"), degree, bcs=True)
+        for _ in range(2):
+            prob.assemble_residual()
+            prob.assemble_jacobian()
+        return float(np.abs(prob.r.data_ro).max())
+    return run
+
+
+def _dg():
+    prob = forms.DGAdvectionProblem(fmesh.make_quad_mesh(96, tile=(4, 4), perturb=0.1))
+    for _ in range(2):
+        prob.assemble_rhs()
+    return float(np.abs(prob.L.data_ro).max())
+
+
+def _q2_hex():
+    prob = forms.HelmholtzHexProblem(fmesh.make_extruded_hex_mesh(10, 10, 2, perturb=0.1), bcs=True)
+    for _ in range(2):
+        prob.assemble_jacobian()
+        prob.assemble_action()
+    return float(np.abs(prob.y.data_ro).max())
+
+
+@pytest.mark.parametrize("kind", ["p1", "p2", "dg", "q2_hex"])
+def test_device_memory_returns_when_a_problem_goes(kind):
+    run = {"p1": _poisson(1, 24), "p2": _poisson(2, 12), "dg": _dg, "q2_hex": _q2_hex}[kind]
+    free = []
+    for _ in range(4):
+        assert run() > 0.0
+        gc.collect()
+        free.append(_free_bytes())
+    # the first pass loads code objects and fills the kernel caches (per kernel, not per mesh); from then on nothing may stay behind
+    assert min(free[1:]) >= free[1] - (1 << 20) and free[3] >= free[1] - (1 << 20), [f >> 20 for f in free]
