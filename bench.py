@@ -382,6 +382,18 @@ def measure_c1(steps, warmup, with_cpu=False):
         g()
     g.sync()
     graph = (time.perf_counter() - t0) / n
+    own = None
+    try:                                 # (replays on the graph's own stream instead of the stream eager launches go to)
+        go = CapturedStep(step, ordered=False)
+        go(); go.sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            go()
+        go.sync()
+        own = (time.perf_counter() - t0) / n
+        del go
+    except Exception as exc:
+        own = repr(exc)
     # the two assemblies write different tensors: forked onto a side stream inside the capture they become two branches of the
     # graph and their kernel chains (zero, residual, BC rows | Jacobian, BC diagonal) run side by side on the mostly idle device
     two = None
@@ -419,6 +431,7 @@ def measure_c1(steps, warmup, with_cpu=False):
             "config": {"workload": "Poisson CG1 residual+Jacobian on UnitSquareMesh(64,64) (BASELINE.json configs[0]), hipGraph replay",
                        "cells": 8192, "dofs": nd},
             "eager_ms_per_step": eager * 1e3, "graph_ms_per_step": graph * 1e3,
+            "graph_own_stream_ms_per_step": own * 1e3 if isinstance(own, float) else own,
             "graph_two_branches_ms_per_step": two * 1e3 if isinstance(two, float) else two, "roofline": None, "cpu_baseline": cpu or None}
 
 

@@ -58,6 +58,7 @@ SIGNATURES = {
     "fd_graph_begin": (c_int, [POINTER(c_void_p)]),
     "fd_graph_end": (c_int, [c_void_p]),
     "fd_graph_launch": (c_int, [c_void_p, c_void_p]),
+    "fd_graph_launch_default": (c_int, [c_void_p]),
     "fd_graph_sync": (c_int, [c_void_p]),
     "fd_graph_free": (c_int, [c_void_p]),
     "fd_kernel_load": (c_int, [c_char_p, c_char_p, POINTER(c_void_p)]),

@@ -49,7 +49,8 @@ struct fd_kernel_s {
     size_t max_lds_set = 0;
 };
 struct fd_event_s { hipEvent_t ev; };
-struct fd_graph_s { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; hipStream_t stream = nullptr; };
+struct fd_graph_s { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; hipStream_t stream = nullptr;
+                    hipStream_t last = nullptr; bool last_is_default = false; };      // (the stream of the last launch: what fd_graph_sync waits for)
 
 namespace {
 // zero-fill of a small 8-byte-aligned range in ONE launch: hipMemsetAsync splits a range whose size is not a multiple of its block
@@ -157,13 +158,24 @@ int fd_graph_end(fd_graph_t g) {
 
 int fd_graph_launch(fd_graph_t g, fd_stream_t s) {
     if (!g || !g->exec) FD_FAIL("fd_graph_launch: graph not instantiated");
-    FD_HIP(hipGraphLaunch(g->exec, s ? fd::st(s) : g->stream));
+    g->last = s ? fd::st(s) : g->stream;
+    g->last_is_default = false;
+    FD_HIP(hipGraphLaunch(g->exec, g->last));
+    return 0;
+}
+
+int fd_graph_launch_default(fd_graph_t g) {
+    if (!g || !g->exec) FD_FAIL("fd_graph_launch_default: graph not instantiated");
+    if (fd::g_capturing) FD_FAIL("fd_graph_launch_default: a capture is open");
+    g->last = fd::default_stream();
+    g->last_is_default = true;
+    FD_HIP(hipGraphLaunch(g->exec, g->last));
     return 0;
 }
 
 int fd_graph_sync(fd_graph_t g) {
     if (!g) FD_FAIL("fd_graph_sync: null graph");
-    FD_HIP(hipStreamSynchronize(g->stream));
+    FD_HIP(hipStreamSynchronize(g->last_is_default || g->last ? g->last : g->stream));
     return 0;
 }
 

@@ -7,6 +7,18 @@ import numpy as np
 from . import _lib
 
 
+_pending_graph = [None]        # the graph.CapturedStep whose last replay nobody has waited for yet
+
+
+def wait_pending_graph():
+    """A replayed step runs on the graph's own (non-blocking) stream, which the synchronous copies of the NULL stream do not wait
+    for: every host read of device memory (``DeviceBuffer.download``, the Dats' ``data_ro``) waits for the last replay first."""
+    g = _pending_graph[0]
+    if g is not None:
+        _pending_graph[0] = None
+        g.sync()
+
+
 class DeviceBuffer:
     """An owned hipMalloc allocation (fd_malloc / fd_free)."""
 
@@ -42,6 +54,7 @@ class DeviceBuffer:
 
     def download(self, dtype, shape):
         out = np.empty(shape, dtype=dtype)
+        wait_pending_graph()
         if out.nbytes:
             _lib.call("fd_memcpy_d2h", out.ctypes.data, self.ptr, out.nbytes, None)
         return out

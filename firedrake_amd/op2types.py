@@ -492,6 +492,12 @@ class MixedDataSet:
 
 
 # ---- host/device mirrored array ---------------------------------------------------------
+# graph.CapturedStep sets this to (read, written) dictionaries {id: carrier} while it records a step: the bookkeeping below runs at
+# capture time only, so the replay has to redo what it would have done -- bring the device copy of a carrier the step READS up to
+# date when the host wrote it in between, and declare the host copy of every carrier the step WRITES stale
+_capture_log = None
+
+
 class _Mirrored:
     """numpy host array + device mirror with validity flags."""
 
@@ -522,6 +528,8 @@ class _Mirrored:
 
     def _to_host(self):
         if not self._host_valid:
+            from .device import wait_pending_graph
+            wait_pending_graph()           # (a replayed graph writes on its own stream)
             if self._host.nbytes:
                 _lib.call("fd_memcpy_d2h", self._host.ctypes.data, self._dev.ptr, self._host.nbytes, None)
             self._host_valid = True
@@ -529,6 +537,8 @@ class _Mirrored:
 
     def _dev_ptr(self, write: bool) -> int:
         """Device pointer for a kernel; uploads if the host copy is newer (or may be: see above)."""
+        if _capture_log is not None:                          # (graph.CapturedStep: the carriers a recorded step reads and writes)
+            _capture_log[1 if write else 0][id(self)] = self
         if self._dev is None:
             self._dev = DeviceBuffer(self._host.nbytes)
             self._dev_valid = False
@@ -686,6 +696,8 @@ class Dat(_Mirrored):
             par_loop(self._kernel("zero"), subset, self(WRITE))
             return
         if self._dev is not None:
+            if _capture_log is not None:
+                _capture_log[1][id(self)] = self
             self._dev.zero()
             self._dev_valid = True
             self._host_valid = False

@@ -1447,6 +1447,9 @@ class Parloop:
         calls (the state of a Newton iteration) keeps the in-kernel gather, and a copy is dropped the moment its Dat changes."""
         if not configuration["plan_copies"]:
             return 0
+        from . import op2types
+        if op2types._capture_log is not None:
+            return 0          # (a recorded step gathers from the Dat itself: a copy baked into the graph would never see the Dat change)
         d = self.arguments[k].data
         d = getattr(d, "_parent", d)
         ver = getattr(d, "dat_version", None)

@@ -92,6 +92,9 @@ typedef struct fd_graph_s *fd_graph_t;
 int fd_graph_begin(fd_graph_t *out);
 int fd_graph_end(fd_graph_t g);
 int fd_graph_launch(fd_graph_t g, fd_stream_t s);   /* s = NULL: the graph's own stream */
+/* replay on the stream NULL-stream calls run on (the HIP null stream unless fd_stream_set_default changed it): ordered with the
+ * eager launches and the synchronous copies before and after it, like the host-serial parloops of pyop2/parloop.py:243-260 */
+int fd_graph_launch_default(fd_graph_t g);
 int fd_graph_sync(fd_graph_t g);
 int fd_graph_free(fd_graph_t g);
 

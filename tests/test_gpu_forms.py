@@ -137,10 +137,17 @@ def test_c1_step_as_hipgraph():
     prob.jacobian()[0]._values_dev()            # flush the pending zero: the tensors really are cleared now
     for _ in range(3):
         g()
-    g.sync()
-    prob.r._host_valid = False                  # device copy is authoritative after the replay
+    # no sync, no invalidation by hand: a replay declares the host copies of what the step writes stale, and the download waits for it
     assert_allclose(prob.r.data_ro, ro, rtol=0, atol=1e-12 * np.abs(ro).max())
     assert_allclose(prob.jacobian()[0].toscipy().data, Ao.data, rtol=0, atol=1e-12 * np.abs(Ao.data).max())
+    # the state rewritten ON THE HOST between two replays reaches the device (the replay uploads what the step reads when it is stale)
+    u0 = np.array(prob.u.data_ro)
+    prob.u.data[...] = 0.0
+    prob.f.data[...] = 0.0
+    g()
+    assert np.abs(prob.r.data_ro).max() <= 1e-13 * np.abs(ro).max()
+    prob.u.data[...] = u0
+    del u0
 
 
 def test_release_of_device_memory_inside_a_capture_is_parked():
@@ -178,7 +185,6 @@ def test_release_of_device_memory_inside_a_capture_is_parked():
     for _ in range(2):
         g()
     g.sync()
-    prob.r._host_valid = False
     assert_allclose(prob.r.data_ro, ro, rtol=0, atol=1e-12 * np.abs(ro).max())
     assert_allclose(prob.jacobian()[0].toscipy().data, Ao.data, rtol=0, atol=1e-12 * np.abs(Ao.data).max())
     DeviceBuffer(64)                             # (allocation works again after the capture)
@@ -294,7 +300,6 @@ def test_two_parloops_on_two_streams_and_the_cached_diagonal_places():
     for _ in range(3):
         g()
     g.sync()
-    prob.r._host_valid = False                  # device copy is authoritative after the replay
     assert_allclose(np.array(prob.r.data_ro), r0, rtol=0, atol=1e-13 * np.abs(r0).max())
     assert_allclose(mat.csr()[2], v0, rtol=0, atol=1e-13 * np.abs(v0).max())
     prob.assemble_residual()                    # eager launches after the capture go to the null stream again
