@@ -31,6 +31,20 @@ def _poisson(degree, n):
     return run
 
 
+def _poisson_graph():
+    from firedrake_amd.graph import CapturedStep
+    prob = forms.PoissonProblem(fmesh.UnitCubeMesh((20, 20, 20), degrees=(1,), perturb=0.1, numbering="lexicographic"), 1, bcs=True)
+
+    def step():
+        prob.assemble_residual()
+        prob.assemble_jacobian()
+
+    g = CapturedStep(step)
+    for _ in range(3):
+        g()
+    return float(np.abs(prob.r.data_ro).max())        # (the download waits for the replays)
+
+
 def _dg():
     prob = forms.DGAdvectionProblem(fmesh.make_quad_mesh(96, tile=(4, 4), perturb=0.1))
     for _ in range(2):
@@ -46,9 +60,9 @@ def _q2_hex():
     return float(np.abs(prob.y.data_ro).max())
 
 
-@pytest.mark.parametrize("kind", ["p1", "p2", "dg", "q2_hex"])
+@pytest.mark.parametrize("kind", ["p1", "p2", "dg", "q2_hex", "p1_graph"])
 def test_device_memory_returns_when_a_problem_goes(kind):
-    run = {"p1": _poisson(1, 24), "p2": _poisson(2, 12), "dg": _dg, "q2_hex": _q2_hex}[kind]
+    run = {"p1": _poisson(1, 24), "p2": _poisson(2, 12), "dg": _dg, "q2_hex": _q2_hex, "p1_graph": _poisson_graph}[kind]
     free = []
     for _ in range(4):
         assert run() > 0.0
