@@ -27,6 +27,23 @@ from .op2types import (INC, MAX, MIN, READ, WRITE, Access, Dat, ExtrudedSet, Glo
                        Mat, MixedDat, MixedMap, PermutedMap, Set, SetTypeError, Subset)
 
 _NO_EVENT = contextlib.nullcontext()          # (tracing off: no generator-based context manager per launch)
+_CHECK_ARGLISTS = False                       # tests: build every argument list both ways and compare (tests/conftest.py, FD_TEST_ARGLISTS)
+
+
+def _same_arglists(layout, out, ref):
+    """tests (``_CHECK_ARGLISTS``): the pre-dispatched argument list equals the branch-per-entry one.  ``plan_copy`` entries are
+    left out: asking twice in one call is itself a state change there (a Dat seen unchanged a second time gets its copy)."""
+    a = [int(v) if v is not None else 0 for d, v in zip(layout, out) if d[0] != "plan_copy"]
+    b = [int(v) if v is not None else 0 for d, v in zip(layout, ref) if d[0] != "plan_copy"]
+    assert len(out) == len(ref) == len(layout) and a == b, (layout, out, ref)
+
+
+def _restore_versions(vers):
+    for d, v in vers:
+        try:
+            d.dat_version = v
+        except AttributeError:            # (a view or a mixed carrier: its version is its parts')
+            pass
 
 
 def small_loop_leaf(n: int, leaf: int, floor: int) -> int:
@@ -773,6 +790,21 @@ class Parloop:
         geo = self._staged_geometry(start, end) if src.mode.startswith("staged") else None
         if geo is not None:
             src = geo["cw"].src
+        holder = geo if geo is not None else prep
+        got = holder.get("_arg_getters")
+        if got is None or got[0] is not src:
+            got = holder["_arg_getters"] = (src, self._arg_getters(prep, src, geo))
+        out = [g() for g in got[1]]
+        if _CHECK_ARGLISTS:               # (tests: the branch-per-entry statement of the same list; version counters as one call leaves them)
+            vers = [(pa.data, pa.data.dat_version) for pa in self.arguments if hasattr(pa.data, "dat_version")]
+            ref = self._args_chain(prep, src, geo)
+            _restore_versions(vers)
+            _same_arglists(src.layout, out, ref)
+        return out, geo
+
+    def _args_chain(self, prep, src, geo):
+        """The argument list of a staged / direct / tensor-product launch, one branch per layout entry (what ``_arg_getters``
+        pre-dispatches; tests run both and compare)."""
         out = []
         for desc in src.layout:
             kind = desc[0]
@@ -843,7 +875,74 @@ class Parloop:
                 out.append(self._tp_tables().ptr)
             else:
                 raise AssertionError(kind)
-        return out, geo
+        return out
+
+    def _arg_getters(self, prep, src, geo):
+        """One zero-argument callable per layout entry, built once per (geometry, wrapper source): see ``_ocr_arg_getters``."""
+        args, accs = self.arguments, self.accesses
+        g = []
+        for desc in src.layout:
+            kind = desc[0]
+            if kind in ("virt_col", "virt_layer"):
+                g.append(lambda w=0 if kind == "virt_col" else 1: self._virtual(staged=True).tables_dev()[w].ptr)
+            elif kind == "layers":
+                g.append(self.iterset._layers_dev)
+            elif kind == "subset":
+                g.append(self.iterset._indices_dev)
+            elif kind == "arg":
+                pa = args[desc[1]]
+                if isinstance(pa, MatParloopArg):
+                    def mat_arg(mat=pa.data):
+                        mat.dat_version += 1
+                        return mat._values_dev().ptr
+                    g.append(mat_arg)
+                else:
+                    g.append(lambda d=pa.data, w=accs[desc[1]] != READ: d._dev_ptr(write=w))
+            elif kind == "map":
+                g.append(lambda k=desc[1]: prep["maps"][k]._dev_values())
+            elif kind == "bstart":
+                g.append((lambda: next(iter(geo["plans"].values())).bstart) if geo else (lambda: 0))
+            elif kind == "order":
+                g.append(lambda: geo["order"].ptr)
+            elif kind == "plan_blkoff":
+                g.append(lambda k=desc[1]: geo["plans"][k].blkoff)
+            elif kind == "plan_list":
+                g.append(lambda k=desc[1]: geo["plans"][k].list)
+            elif kind == "plan_lmap":
+                g.append(lambda k=desc[1]: geo["plans"][k].lmap)
+            elif kind == "plan_maxnd":
+                g.append(lambda k=desc[1]: geo["plans"][k].max_nd)
+            elif kind == "plan_copy":
+                g.append(lambda k=desc[1], m=desc[2]: self._plan_copy(geo, k, geo["plans"][m]))
+            elif kind == "matplan_off":
+                g.append(lambda k=desc[1]: geo["mplans"][k].mb_off)
+            elif kind == "matplan_gpos":
+                g.append(lambda k=desc[1]: geo["mplans"][k].gpos)
+            elif kind == "matplan_lrp":
+                g.append(lambda k=desc[1]: geo["mplans"][k].lrp)
+            elif kind == "matplan_kidx":
+                g.append(lambda k=desc[1]: geo["mplans"][k].kidx)
+            elif kind == "matplan_maxnnz":
+                g.append(lambda k=desc[1]: geo["mplans"][k].max_nnz)
+            elif kind == "matplan_flags":
+                g.append(lambda: 0)
+            elif kind == "mat_table":
+                g.append(lambda pa=args[desc[1]]: pa.data.sparsity.elem_table(*pa.maps).ptr)
+            elif kind in ("mat_node_rowptr", "mat_rowptr", "mat_colidx"):
+                def sparsity_array(pa=args[desc[1]], name={"mat_node_rowptr": "_node_rowptr", "mat_rowptr": "_rowptr", "mat_colidx": "_colidx"}[kind]):
+                    sp = pa.data.sparsity
+                    sp._build()
+                    return getattr(sp, name).ptr
+                g.append(sparsity_array)
+            elif kind in ("mat_row_lgmap", "mat_col_lgmap"):
+                g.append(lambda pa=args[desc[1]], w=0 if kind == "mat_row_lgmap" else 1: self._lgmap(pa.lgmaps[w]))
+            elif kind == "tp_offtab":
+                g.append(lambda k=desc[1]: self._tp_offtab(k).ptr)
+            elif kind == "tp_tables":
+                g.append(lambda: self._tp_tables().ptr)
+            else:
+                raise AssertionError(kind)
+        return g
 
     # -- tensor-product wrappers (csrc/fd_tensor.h) ------------------------------------------------------------------
     def zero_ahead(self):
@@ -1307,12 +1406,33 @@ class Parloop:
 
     def _compute_ocr(self, start=0, end=None):
         geo = self._ocr_geometry(start, end)
-        prep = self._prepared
         cw = geo["cw"]
         src = cw.src
         op = geo["ocr"]
         if op.nblocks == 0 or op.ninst == 0:
             return
+        got = geo.get("_arg_getters")
+        if got is None or got[0] is not cw:
+            got = geo["_arg_getters"] = (cw, self._ocr_arg_getters(geo, cw))
+        if _CHECK_ARGLISTS:
+            pending = [(pa.data, pa.data._zero_pending) for pa in self.arguments if isinstance(pa, MatParloopArg)]
+        out = [g() for g in got[1]]
+        if _CHECK_ARGLISTS:               # (tests: the branch-per-entry statement of the same list, from the same state)
+            for mat, was in pending:
+                mat._zero_pending = was
+            vers = [(pa.data, pa.data.dat_version) for pa in self.arguments if hasattr(pa.data, "dat_version")]
+            ref = self._ocr_args_chain(geo, cw)
+            _restore_versions(vers)
+            _same_arglists(src.layout, out, ref)
+        cw.launch(0, op.ninst, out, block_threads=src.block_threads, ents_per_block=op.max_inst, nblocks=op.nblocks,
+                  lds_bytes=geo["lds"])
+
+    def _ocr_args_chain(self, geo, cw):
+        """The argument list of an owner-computes-rows launch, one branch per layout entry: what ``_ocr_arg_getters`` pre-dispatches
+        (kept as the statement of what each entry is; tests run both and compare: ``parloop._CHECK_ARGLISTS``)."""
+        prep = self._prepared
+        src = cw.src
+        op = geo["ocr"]
         out = []
         for desc in src.layout:
             kind = desc[0]
@@ -1412,8 +1532,126 @@ class Parloop:
                 out.append(geo["phase_times"].ptr)
             else:
                 raise AssertionError(kind)
-        cw.launch(0, op.ninst, out, block_threads=src.block_threads, ents_per_block=op.max_inst, nblocks=op.nblocks,
-                  lds_bytes=geo["lds"])
+        return out
+
+    def _ocr_arg_getters(self, geo, cw):
+        """One zero-argument callable per layout entry of the launch, built once per (geometry, wrapper): the per-call marshalling of
+        SURVEY.md 7 hard part (f) was a chain of string comparisons per entry and call.  Entries whose value depends on the state of
+        a carrier (a Mat's pending zero, a Dat's device pointer, a plan copy, the lgmap tables) stay calls; everything is looked up
+        through ``geo`` at call time, so tables replaced inside a geometry are seen."""
+        prep = self._prepared
+        src = cw.src
+        args = self.arguments
+        g = []
+        K = lambda v: (lambda: v)                        # noqa: E731
+        for desc in src.layout:
+            kind = desc[0]
+            if kind == "layers":
+                g.append(self.iterset._layers_dev)
+            elif kind == "subset":
+                g.append(self.iterset._indices_dev)
+            elif kind == "arg":
+                pa = args[desc[1]]
+                if isinstance(pa, MatParloopArg):
+                    def mat_arg(mat=pa.data):
+                        mat.dat_version += 1
+                        vals = mat._values_raw()
+                        flag = 0
+                        if mat._zero_pending:
+                            # rows outside the blocks (ghost rows) are the only part the loop does not overwrite
+                            op = geo["ocr"]
+                            tail = (geo["nnz"] - op.vals_end) * 8
+                            if tail > 0:
+                                _lib.call("fd_memset", vals.ptr + op.vals_end * 8, 0, tail, None)
+                            mat._zero_pending = False
+                            flag = 1
+                        self._ocr_flag = flag
+                        return vals.ptr
+                    g.append(mat_arg)
+                else:
+                    g.append(lambda d=pa.data: d._dev_ptr(write=False))
+            elif kind == "map":
+                g.append(lambda k=desc[1]: prep["maps"][k]._dev_values())
+            elif kind == "bstart":
+                g.append(lambda: geo["ocr"].inst_off)
+            elif kind == "ocr_inst_ent":
+                g.append(lambda: geo["ocr"].inst_ent)
+            elif kind == "plan_blkoff":
+                g.append(lambda k=desc[1]: geo["ocr"].plans[k].blkoff)
+            elif kind == "plan_list":
+                g.append(lambda k=desc[1]: geo["ocr"].plans[k].list)
+            elif kind == "plan_lmap":
+                g.append(lambda k=desc[1]: geo["ocr"].plans[k].lmap)
+            elif kind == "plan_maxnd":
+                g.append(lambda k=desc[1]: geo["ocr"].plans[k].max_nd)
+            elif kind == "plan_copy":
+                g.append(lambda k=desc[1], m=desc[2]: self._plan_copy(geo, k, geo["ocr"].plans[m]))
+            elif kind == "ocr_rblk":
+                g.append(lambda: geo["ocr"].rblk)
+            elif kind == "ocr_rowptr":
+                g.append(lambda k=desc[1]: args[k].data.sparsity._node_rowptr.ptr)
+            elif kind == "ocr_kidx":
+                g.append(lambda: geo["ocr"].kidx.ptr)
+            elif kind == "ocrs_chunk_role":
+                g.append(lambda: geo["ocr"].chunk_role)
+            elif kind in ("ocrs_slot", "ocrs_kk", "ocrs_rowlen", "ocrs_rmask", "ocrs_cmask"):
+                which = {"ocrs_slot": 0, "ocrs_kk": 1, "ocrs_rowlen": 2, "ocrs_rmask": 3, "ocrs_cmask": 4}[kind]
+
+                def ocrs_table(k=desc[1], which=which):
+                    lg = args[k].lgmaps
+                    per_dof = bool(lg) and bool(self.global_kernel.arguments[k].unroll)
+                    return geo["ocr"].tables(lg[0] if lg else None, lg[1] if lg else None, self._lgmap, per_dof=per_dof)[which].ptr
+                g.append(ocrs_table)
+            elif kind == "ocr_maxnnz":
+                g.append(lambda: geo["ocr"].max_nnz)
+            elif kind == "ocr_maxnown":
+                g.append(lambda: geo["ocr"].max_nown)
+            elif kind == "ocr_flags":
+                g.append(lambda: self._ocr_flag)
+            elif kind == "ocr_prowptr":
+                g.append(lambda: geo["row_order"].prowptr.ptr)
+            elif kind == "ocr_nstart":
+                g.append(lambda: geo["row_order"].nstart.ptr)
+            elif kind == "ocr_gstart":
+                g.append(lambda: geo["row_order"].gstart.ptr)
+            elif kind == "ocr_srow":
+                g.append(lambda k=desc[1], m=desc[2], dg=len(desc) > 3: self._ocr_node_words(geo, k, m, diag=dg))
+            elif kind == "ocr_rec" and src.mode.startswith("ocrs"):
+                def rec_sliced(k=desc[1]):
+                    lbits, kbits, sbits, words = geo["rec"]
+                    lg = args[k].lgmaps
+                    return geo["ocr"].records(lg[0] if lg else None, lg[1] if lg else None, self._lgmap, src.staged_maps, lbits, kbits, sbits, words).ptr
+                g.append(rec_sliced)
+            elif kind == "ocr_rec":
+                def rec_whole(k=desc[1]):
+                    lbits, kbits, diag, words = geo["rec"]
+                    rm_, cm_ = args[k].maps
+                    return geo["ocr"].records(src.staged_maps, lbits, kbits, diag, words, rm_.arity, cm_.arity).ptr
+                g.append(rec_whole)
+            elif kind in ("ocr_grun", "ocr_brun", "ocr_rdelta"):
+                g.append(lambda w={"ocr_grun": 0, "ocr_brun": 1, "ocr_rdelta": 2}[kind]: geo["runs"][w].ptr)
+            elif kind == "ocr_gpos":
+                if src.mode.startswith("ocrpm"):
+                    g.append(lambda pa_=args[desc[1]]: geo["row_order"].gpos_masked(pa_.data.sparsity, pa_.lgmaps[1], self._lgmap).ptr)
+                else:
+                    g.append(lambda: geo["row_order"].gpos().ptr)
+            elif kind == "ocr_npos":
+                g.append(lambda: geo["row_order"].npos)
+            elif kind in ("mat_row_lgmap", "mat_col_lgmap"):
+                g.append(lambda pa=args[desc[1]], w=0 if kind == "mat_row_lgmap" else 1: self._lgmap(pa.lgmaps[w]))
+            elif kind in ("virt_col", "virt_layer"):
+                g.append(lambda w=0 if kind == "virt_col" else 1: self._virtual(staged=True).tables_dev()[w].ptr)
+            elif kind in ("fx_scale", "fx_stat"):
+                g.append(lambda w=0 if kind == "fx_scale" else 1: geo["fx"][w].ptr)
+            elif kind == "phase_times":
+                def phase_times():
+                    if geo.get("phase_times") is None:
+                        geo["phase_times"] = DeviceBuffer(max(geo["ocr"].nblocks, 1) * 40)
+                    return geo["phase_times"].ptr
+                g.append(phase_times)
+            else:
+                raise AssertionError(kind)
+        return g
 
     @staticmethod
     def _max_row_valence(rmap, start, end):

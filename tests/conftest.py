@@ -11,6 +11,11 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # every launch of the suite builds its argument list both ways -- the pre-dispatched getters the product uses and the
+    # branch-per-entry statement of the same list -- and compares them (FD_TEST_ARGLISTS=0 switches the cross-check off)
+    if os.environ.get("FD_TEST_ARGLISTS", "1") != "0":
+        from firedrake_amd import parloop
+        parloop._CHECK_ARGLISTS = True
 
 
 def pytest_collection_modifyitems(config, items):
