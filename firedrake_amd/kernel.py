@@ -541,6 +541,6 @@ class CompiledWrapper:
             # launches of one wrapper on different problem sizes apart (bench.py keys its PMC results by (kernel, grid))
             nb_ = int(nblocks) if int(nblocks) > 0 else -(-(int(end) - int(start)) // int(ents_per_block))
             last_launch[self.src.symbol] = (nb_ * int(block_threads), int(block_threads))
-        arr = (ctypes.c_void_p * max(n, 1))(*[ctypes.c_void_p(int(a) if a is not None else 0) for a in args])
+        arr = (ctypes.c_void_p * max(n, 1))(*[int(a) if a is not None else None for a in args])       # (plain ints: no c_void_p object per slot)
         _lib.call("fd_kernel_launch", self.handle, int(start), int(end), arr, n, int(block_threads),
                   int(ents_per_block), int(nblocks), int(lds_bytes), stream)
