@@ -28,6 +28,7 @@ static bool g_capturing = false;
 static std::vector<void *> g_deferred_free;
 static std::vector<fd_kernel_t> g_deferred_kernels;            // (hipModuleUnload and the destruction of another graph's stream: the same)
 static std::vector<fd_graph_t> g_deferred_graphs;
+static std::vector<hipStream_t> g_deferred_streams;
 hipError_t release(void *p) {
     if (!p) return hipSuccess;
     if (g_capturing) { g_deferred_free.push_back(p); return hipSuccess; }
@@ -107,7 +108,12 @@ int fd_memcpy_d2h(void *d, const void *s_, size_t n, fd_stream_t s) {
 }
 int fd_memcpy_d2d(void *d, const void *s_, size_t n, fd_stream_t s) { if (n) FD_HIP(hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, fd::st(s))); return 0; }
 int fd_stream_create(fd_stream_t *s) { hipStream_t h; FD_HIP(hipStreamCreateWithFlags(&h, hipStreamNonBlocking)); *s = h; return 0; }
-int fd_stream_destroy(fd_stream_t s) { FD_HIP(hipStreamDestroy(fd::st(s))); return 0; }
+int fd_stream_destroy(fd_stream_t s) {
+    if (!s) return 0;
+    if (fd::g_capturing) { fd::g_deferred_streams.push_back(reinterpret_cast<hipStream_t>(s)); return 0; }
+    FD_HIP(hipStreamDestroy(reinterpret_cast<hipStream_t>(s)));
+    return 0;
+}
 int fd_stream_sync(fd_stream_t s) { FD_HIP(hipStreamSynchronize(fd::st(s))); return 0; }
 int fd_device_sync(void) { FD_HIP(hipDeviceSynchronize()); return 0; }
 // The stream every call with a NULL stream argument uses from now on (NULL: back to the HIP null stream).  Two independent
@@ -151,6 +157,8 @@ int fd_graph_end(fd_graph_t g) {
     fd::g_deferred_kernels.clear();
     for (fd_graph_t d : fd::g_deferred_graphs) (void)fd_graph_free(d);
     fd::g_deferred_graphs.clear();
+    for (hipStream_t q : fd::g_deferred_streams) (void)hipStreamDestroy(q);
+    fd::g_deferred_streams.clear();
     FD_HIP(ended);
     FD_HIP(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0));
     return 0;
