@@ -892,12 +892,13 @@ class Parloop:
             elif kind == "arg":
                 pa = args[desc[1]]
                 if isinstance(pa, MatParloopArg):
-                    def mat_arg(mat=pa.data):
+                    def mat_arg(pa=pa):
+                        mat = pa.data                        # (read at every call: see _ocr_arg_getters)
                         mat.dat_version += 1
                         return mat._values_dev().ptr
                     g.append(mat_arg)
                 else:
-                    g.append(lambda d=pa.data, w=accs[desc[1]] != READ: d._dev_ptr(write=w))
+                    g.append(lambda pa=pa, w=accs[desc[1]] != READ: pa.data._dev_ptr(write=w))
             elif kind == "map":
                 g.append(lambda k=desc[1]: prep["maps"][k]._dev_values())
             elif kind == "bstart":
@@ -1553,8 +1554,9 @@ class Parloop:
             elif kind == "arg":
                 pa = args[desc[1]]
                 if isinstance(pa, MatParloopArg):
-                    def mat_arg(mat=pa.data):
-                        mat.dat_version += 1
+                    def mat_arg(pa=pa):
+                        mat = pa.data                        # (read at every call: the reference's assemblers swap the output tensor
+                        mat.dat_version += 1                 #  of a cached Parloop -- parloop.arguments[0].data = ..., assemble.py:1073-1077)
                         vals = mat._values_raw()
                         flag = 0
                         if mat._zero_pending:
@@ -1569,7 +1571,7 @@ class Parloop:
                         return vals.ptr
                     g.append(mat_arg)
                 else:
-                    g.append(lambda d=pa.data: d._dev_ptr(write=False))
+                    g.append(lambda pa=pa: pa.data._dev_ptr(write=False))
             elif kind == "map":
                 g.append(lambda k=desc[1]: prep["maps"][k]._dev_values())
             elif kind == "bstart":
@@ -1695,10 +1697,12 @@ class Parloop:
             return 0
         cache = geo.setdefault("plan_copies", {})
         ent = cache.get(k)
+        if ent is not None and ent["of"] is not d:
+            ent = None                                        # (another Dat in this slot: nothing kept of the old one)
         if ent is not None and ent["version"] == ver and ent["buf"] is not None:
             return ent["buf"].ptr
         if ent is None or ent["version"] != ver:
-            cache[k] = {"version": ver, "buf": None}          # first sight of this state of the Dat: gather in the kernel
+            cache[k] = {"version": ver, "buf": None, "of": d}          # first sight of this state of the Dat: gather in the kernel
             return 0
         words = d.cdim * np.dtype(d.dtype).itemsize // 4      # unchanged since the last call: make the copy (rows as 32-bit words)
         if words * 4 != d.cdim * np.dtype(d.dtype).itemsize or plan.list_len == 0:
@@ -1751,19 +1755,20 @@ class Parloop:
     # -- halo protocol (parloop.py:320-409)
     def _indirect_dats(self):
         """(Dat, access) of the indirectly accessed Dats, each data carrier once (the reference's ``seen`` sets,
-        pyop2/parloop.py:343-352, 393-403): one exchange per distinct Dat and direction.  (The arguments of a Parloop are fixed:
-        the list is made once -- a launch-bound step walks it four times per loop.)"""
-        lst = self.__dict__.get("_indirect_list")
-        if lst is None:
-            lst, seen = [], set()
-            for pa, acc in zip(self.arguments, self.accesses):
-                if isinstance(pa, DatParloopArg) and pa.map_ is not None:
-                    d = getattr(pa.data, "_parent", pa.data)          # a DatView exchanges its parent's storage
-                    if id(d) in seen:
-                        continue
-                    seen.add(id(d))
-                    lst.append((pa.data, acc))
-            self._indirect_list = lst
+        pyop2/parloop.py:343-352, 393-403): one exchange per distinct Dat and direction.  The ARGUMENTS of a Parloop are fixed and
+        looked up once; their ``data`` is read at every call (the reference's assemblers swap the output tensor of a cached Parloop,
+        firedrake/assemble.py:1073-1077)."""
+        pas = self.__dict__.get("_indirect_args")
+        if pas is None:
+            pas = self._indirect_args = [(pa, acc) for pa, acc in zip(self.arguments, self.accesses)
+                                         if isinstance(pa, DatParloopArg) and pa.map_ is not None]
+        lst, seen = [], set()
+        for pa, acc in pas:
+            d = getattr(pa.data, "_parent", pa.data)          # a DatView exchanges its parent's storage
+            if id(d) in seen:
+                continue
+            seen.add(id(d))
+            lst.append((pa.data, acc))
         return lst
 
     def _halos_present(self):

@@ -318,3 +318,48 @@ def test_two_parloops_on_two_streams_and_the_cached_diagonal_places():
     mat.set_local_diagonal_entries(prob.bc_nodes[::2], 1.0)          # another list: its own places
     v2 = mat.csr()[2]
     assert np.all(v2[diag[::2]] == 1.0) and np.all(v2[diag[1::2]] == 3.5)
+
+
+@pytest.mark.parametrize("degree,n", [(1, 10), (2, 5)])
+def test_output_tensor_of_a_cached_parloop_is_swapped(degree, n):
+    """Firedrake's assemblers build their parloops once and swap the output tensor per call -- ``parloop.arguments[0].data = data``
+    (firedrake/assemble.py:1073-1077).  Nothing a Parloop caches may hang on the tensor it was built with: the swapped-in Dat / Mat
+    receives the result, the old one is left alone (whole-entity and row-sliced matrix loops, staged vector loops)."""
+    m = fmesh.UnitCubeMesh(n, degrees=(degree,), perturb=0.1)
+    prob = forms.PoissonProblem(m, degree, bcs=True)
+    loop = prob.res_loop
+    r1 = prob.r
+    for _ in range(2):                                   # (twice: plans, plan copies and argument getters exist)
+        r1.zero()
+        loop()
+    ref = np.array(r1.data_ro)
+    assert np.abs(ref).max() > 0
+    r2 = prob.V.dat(1, None, "r2")
+    loop.arguments[0].data = r2
+    r1.data[...] = -7.0
+    r2.zero()
+    loop()
+    assert_allclose(r2.data_ro, ref, rtol=0, atol=1e-13 * np.abs(ref).max())
+    assert np.all(r1.data_ro == -7.0)
+    loop.arguments[0].data = r1
+    r1.zero()
+    loop()
+    assert_allclose(r1.data_ro, ref, rtol=0, atol=1e-13 * np.abs(ref).max())
+    mat, jloop = prob.jacobian()
+    for _ in range(2):
+        mat.zero()
+        jloop()
+    v1 = mat.csr()[2].copy()
+    assert np.abs(v1).max() > 0
+    mat2 = op2.Mat(mat.sparsity)
+    jloop.arguments[0].data = mat2
+    mat2.zero()
+    jloop()
+    assert_allclose(mat2.csr()[2], v1, rtol=0, atol=1e-13 * np.abs(v1).max())
+    assert np.array_equal(mat.csr()[2], v1)              # the first matrix is left alone
+    jloop()                                              # ADD_VALUES on top of the swapped-in matrix
+    assert_allclose(mat2.csr()[2], 2.0 * v1, rtol=0, atol=1e-13 * np.abs(v1).max())
+    jloop.arguments[0].data = mat
+    mat.zero()
+    jloop()
+    assert_allclose(mat.csr()[2], v1, rtol=0, atol=1e-13 * np.abs(v1).max())
