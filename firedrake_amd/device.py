@@ -25,7 +25,15 @@ class DeviceBuffer:
     def __init__(self, nbytes: int):
         _lib.require_gpu()
         p = ctypes.c_void_p()
-        _lib.call("fd_malloc", ctypes.byref(p), max(int(nbytes), 8))
+        try:
+            _lib.call("fd_malloc", ctypes.byref(p), max(int(nbytes), 8))
+        except _lib.FDHipError as exc:
+            if "out of memory" not in str(exc).lower():
+                raise
+            # device memory held by unreachable objects that sit in reference cycles comes back with a collection: once, then again
+            import gc
+            gc.collect()
+            _lib.call("fd_malloc", ctypes.byref(p), max(int(nbytes), 8))
         self.ptr = p.value
         self.nbytes = int(nbytes)
         self._owned = True

@@ -1651,6 +1651,19 @@ class Sparsity:
     the CSR pattern is built natively on the device (fd_csr_from_maps) instead of walking a
     PETSc MATPREALLOCATOR (pyop2/sparsity.pyx:105-159)."""
 
+    # non-nested: "one block, itself" (mat.py:87-99, 741-768) WITHOUT storing the list -- ``self._blocks = [[self]]`` is a reference cycle,
+    # and a Sparsity / Mat in a cycle keeps its device arrays (and, through its maps, their plans and derived orders) until the cycle
+    # collector runs instead of until the last reference goes (tests/test_gpu_leaks.py)
+    _nested_blocks = None
+
+    @property
+    def _blocks(self):
+        return self._nested_blocks if self._nested_blocks is not None else [[self]]
+
+    @_blocks.setter
+    def _blocks(self, rows):
+        self._nested_blocks = None if (len(rows) == 1 and len(rows[0]) == 1 and rows[0][0] is self) else rows
+
     def __init__(self, dsets, maps_and_regions, name=None, nest=None, block_sparse=None, diagonal_block=True):
         if isinstance(dsets, (Set, DataSet, MixedSet, MixedDataSet)):
             dsets = (dsets, dsets)
@@ -2354,6 +2367,19 @@ class MatPlan:
 
 class Mat:
     """pyop2/types/mat.py:607-985, as a device-resident scalar CSR ("aij")."""
+
+    # non-nested: "one block, itself" (mat.py:87-99, 741-768) WITHOUT storing the list -- ``self._blocks = [[self]]`` is a reference cycle,
+    # and a Sparsity / Mat in a cycle keeps its device arrays (and, through its maps, their plans and derived orders) until the cycle
+    # collector runs instead of until the last reference goes (tests/test_gpu_leaks.py)
+    _nested_blocks = None
+
+    @property
+    def _blocks(self):
+        return self._nested_blocks if self._nested_blocks is not None else [[self]]
+
+    @_blocks.setter
+    def _blocks(self, rows):
+        self._nested_blocks = None if (len(rows) == 1 and len(rows[0]) == 1 and rows[0][0] is self) else rows
 
     def __init__(self, sparsity, dtype=None, name=None):
         if not isinstance(sparsity, Sparsity):

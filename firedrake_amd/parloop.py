@@ -790,17 +790,25 @@ class Parloop:
         geo = self._staged_geometry(start, end) if src.mode.startswith("staged") else None
         if geo is not None:
             src = geo["cw"].src
-        holder = geo if geo is not None else prep
-        got = holder.get("_arg_getters")
-        if got is None or got[0] is not src:
-            got = holder["_arg_getters"] = (src, self._arg_getters(prep, src, geo))
-        out = [g() for g in got[1]]
+        out = [g(self) for g in self._getters_of(geo if geo is not None else prep, src, lambda: self._arg_getters(prep, src, geo))]
         if _CHECK_ARGLISTS:               # (tests: the branch-per-entry statement of the same list; version counters as one call leaves them)
             vers = [(pa.data, pa.data.dat_version) for pa in self.arguments if hasattr(pa.data, "dat_version")]
             ref = self._args_chain(prep, src, geo)
             _restore_versions(vers)
             _same_arglists(src.layout, out, ref)
         return out, geo
+
+    def _getters_of(self, holder, wrapper, build):
+        """The argument getters of (geometry or prepared state ``holder``, wrapper): kept on the Parloop, a few entries, identity-checked."""
+        store = self.__dict__.get("_getter_store")
+        if store is None:
+            store = self._getter_store = {}
+        ent = store.get(id(holder))
+        if ent is None or ent[0] is not holder or ent[1] is not wrapper:
+            while len(store) >= 8:
+                store.pop(next(iter(store)))
+            ent = store[id(holder)] = (holder, wrapper, build())
+        return ent[2]
 
     def _args_chain(self, prep, src, geo):
         """The argument list of a staged / direct / tensor-product launch, one branch per layout entry (what ``_arg_getters``
@@ -878,69 +886,69 @@ class Parloop:
         return out
 
     def _arg_getters(self, prep, src, geo):
-        """One zero-argument callable per layout entry, built once per (geometry, wrapper source): see ``_ocr_arg_getters``."""
+        """One callable ``f(parloop)`` per layout entry, built once per (geometry, wrapper source): see ``_ocr_arg_getters``."""
         args, accs = self.arguments, self.accesses
         g = []
         for desc in src.layout:
             kind = desc[0]
             if kind in ("virt_col", "virt_layer"):
-                g.append(lambda w=0 if kind == "virt_col" else 1: self._virtual(staged=True).tables_dev()[w].ptr)
+                g.append(lambda pl, w=0 if kind == "virt_col" else 1: pl._virtual(staged=True).tables_dev()[w].ptr)
             elif kind == "layers":
-                g.append(self.iterset._layers_dev)
+                g.append(lambda pl: pl.iterset._layers_dev())
             elif kind == "subset":
-                g.append(self.iterset._indices_dev)
+                g.append(lambda pl: pl.iterset._indices_dev())
             elif kind == "arg":
                 pa = args[desc[1]]
                 if isinstance(pa, MatParloopArg):
-                    def mat_arg(pa=pa):
+                    def mat_arg(pl, pa=pa):
                         mat = pa.data                        # (read at every call: see _ocr_arg_getters)
                         mat.dat_version += 1
                         return mat._values_dev().ptr
                     g.append(mat_arg)
                 else:
-                    g.append(lambda pa=pa, w=accs[desc[1]] != READ: pa.data._dev_ptr(write=w))
+                    g.append(lambda pl, pa=pa, w=accs[desc[1]] != READ: pa.data._dev_ptr(write=w))
             elif kind == "map":
-                g.append(lambda k=desc[1]: prep["maps"][k]._dev_values())
+                g.append(lambda pl, k=desc[1]: prep["maps"][k]._dev_values())
             elif kind == "bstart":
-                g.append((lambda: next(iter(geo["plans"].values())).bstart) if geo else (lambda: 0))
+                g.append((lambda pl: next(iter(geo["plans"].values())).bstart) if geo else (lambda pl: 0))
             elif kind == "order":
-                g.append(lambda: geo["order"].ptr)
+                g.append(lambda pl: geo["order"].ptr)
             elif kind == "plan_blkoff":
-                g.append(lambda k=desc[1]: geo["plans"][k].blkoff)
+                g.append(lambda pl, k=desc[1]: geo["plans"][k].blkoff)
             elif kind == "plan_list":
-                g.append(lambda k=desc[1]: geo["plans"][k].list)
+                g.append(lambda pl, k=desc[1]: geo["plans"][k].list)
             elif kind == "plan_lmap":
-                g.append(lambda k=desc[1]: geo["plans"][k].lmap)
+                g.append(lambda pl, k=desc[1]: geo["plans"][k].lmap)
             elif kind == "plan_maxnd":
-                g.append(lambda k=desc[1]: geo["plans"][k].max_nd)
+                g.append(lambda pl, k=desc[1]: geo["plans"][k].max_nd)
             elif kind == "plan_copy":
-                g.append(lambda k=desc[1], m=desc[2]: self._plan_copy(geo, k, geo["plans"][m]))
+                g.append(lambda pl, k=desc[1], m=desc[2]: pl._plan_copy(geo, k, geo["plans"][m]))
             elif kind == "matplan_off":
-                g.append(lambda k=desc[1]: geo["mplans"][k].mb_off)
+                g.append(lambda pl, k=desc[1]: geo["mplans"][k].mb_off)
             elif kind == "matplan_gpos":
-                g.append(lambda k=desc[1]: geo["mplans"][k].gpos)
+                g.append(lambda pl, k=desc[1]: geo["mplans"][k].gpos)
             elif kind == "matplan_lrp":
-                g.append(lambda k=desc[1]: geo["mplans"][k].lrp)
+                g.append(lambda pl, k=desc[1]: geo["mplans"][k].lrp)
             elif kind == "matplan_kidx":
-                g.append(lambda k=desc[1]: geo["mplans"][k].kidx)
+                g.append(lambda pl, k=desc[1]: geo["mplans"][k].kidx)
             elif kind == "matplan_maxnnz":
-                g.append(lambda k=desc[1]: geo["mplans"][k].max_nnz)
+                g.append(lambda pl, k=desc[1]: geo["mplans"][k].max_nnz)
             elif kind == "matplan_flags":
-                g.append(lambda: 0)
+                g.append(lambda pl: 0)
             elif kind == "mat_table":
-                g.append(lambda pa=args[desc[1]]: pa.data.sparsity.elem_table(*pa.maps).ptr)
+                g.append(lambda pl, pa=args[desc[1]]: pa.data.sparsity.elem_table(*pa.maps).ptr)
             elif kind in ("mat_node_rowptr", "mat_rowptr", "mat_colidx"):
-                def sparsity_array(pa=args[desc[1]], name={"mat_node_rowptr": "_node_rowptr", "mat_rowptr": "_rowptr", "mat_colidx": "_colidx"}[kind]):
+                def sparsity_array(pl, pa=args[desc[1]], name={"mat_node_rowptr": "_node_rowptr", "mat_rowptr": "_rowptr", "mat_colidx": "_colidx"}[kind]):
                     sp = pa.data.sparsity
                     sp._build()
                     return getattr(sp, name).ptr
                 g.append(sparsity_array)
             elif kind in ("mat_row_lgmap", "mat_col_lgmap"):
-                g.append(lambda pa=args[desc[1]], w=0 if kind == "mat_row_lgmap" else 1: self._lgmap(pa.lgmaps[w]))
+                g.append(lambda pl, pa=args[desc[1]], w=0 if kind == "mat_row_lgmap" else 1: pl._lgmap(pa.lgmaps[w]))
             elif kind == "tp_offtab":
-                g.append(lambda k=desc[1]: self._tp_offtab(k).ptr)
+                g.append(lambda pl, k=desc[1]: pl._tp_offtab(k).ptr)
             elif kind == "tp_tables":
-                g.append(lambda: self._tp_tables().ptr)
+                g.append(lambda pl: pl._tp_tables().ptr)
             else:
                 raise AssertionError(kind)
         return g
@@ -1412,12 +1420,10 @@ class Parloop:
         op = geo["ocr"]
         if op.nblocks == 0 or op.ninst == 0:
             return
-        got = geo.get("_arg_getters")
-        if got is None or got[0] is not cw:
-            got = geo["_arg_getters"] = (cw, self._ocr_arg_getters(geo, cw))
+        getters = self._getters_of(geo, cw, lambda: self._ocr_arg_getters(geo, cw))
         if _CHECK_ARGLISTS:
             pending = [(pa.data, pa.data._zero_pending) for pa in self.arguments if isinstance(pa, MatParloopArg)]
-        out = [g() for g in got[1]]
+        out = [g(self) for g in getters]
         if _CHECK_ARGLISTS:               # (tests: the branch-per-entry statement of the same list, from the same state)
             for mat, was in pending:
                 mat._zero_pending = was
@@ -1536,25 +1542,26 @@ class Parloop:
         return out
 
     def _ocr_arg_getters(self, geo, cw):
-        """One zero-argument callable per layout entry of the launch, built once per (geometry, wrapper): the per-call marshalling of
+        """One callable ``f(parloop)`` per layout entry of the launch, built once per (geometry, wrapper): the per-call marshalling of
         SURVEY.md 7 hard part (f) was a chain of string comparisons per entry and call.  Entries whose value depends on the state of
         a carrier (a Mat's pending zero, a Dat's device pointer, a plan copy, the lgmap tables) stay calls; everything is looked up
-        through ``geo`` at call time, so tables replaced inside a geometry are seen."""
+        through ``geo`` at call time, so tables replaced inside a geometry are seen.  The callables take the Parloop as their argument and
+        are kept on it (``_getters_of``), not in ``geo``: closures over ``self`` stored in ``geo`` would tie Parloop, geometry and
+        plans into a reference cycle, and the device memory of a dropped problem would wait for the cycle collector."""
         prep = self._prepared
         src = cw.src
         args = self.arguments
         g = []
-        K = lambda v: (lambda: v)                        # noqa: E731
         for desc in src.layout:
             kind = desc[0]
             if kind == "layers":
-                g.append(self.iterset._layers_dev)
+                g.append(lambda pl: pl.iterset._layers_dev())
             elif kind == "subset":
-                g.append(self.iterset._indices_dev)
+                g.append(lambda pl: pl.iterset._indices_dev())
             elif kind == "arg":
                 pa = args[desc[1]]
                 if isinstance(pa, MatParloopArg):
-                    def mat_arg(pa=pa):
+                    def mat_arg(pl, pa=pa):
                         mat = pa.data                        # (read at every call: the reference's assemblers swap the output tensor
                         mat.dat_version += 1                 #  of a cached Parloop -- parloop.arguments[0].data = ..., assemble.py:1073-1077)
                         vals = mat._values_raw()
@@ -1567,86 +1574,86 @@ class Parloop:
                                 _lib.call("fd_memset", vals.ptr + op.vals_end * 8, 0, tail, None)
                             mat._zero_pending = False
                             flag = 1
-                        self._ocr_flag = flag
+                        pl._ocr_flag = flag
                         return vals.ptr
                     g.append(mat_arg)
                 else:
-                    g.append(lambda pa=pa: pa.data._dev_ptr(write=False))
+                    g.append(lambda pl, pa=pa: pa.data._dev_ptr(write=False))
             elif kind == "map":
-                g.append(lambda k=desc[1]: prep["maps"][k]._dev_values())
+                g.append(lambda pl, k=desc[1]: prep["maps"][k]._dev_values())
             elif kind == "bstart":
-                g.append(lambda: geo["ocr"].inst_off)
+                g.append(lambda pl: geo["ocr"].inst_off)
             elif kind == "ocr_inst_ent":
-                g.append(lambda: geo["ocr"].inst_ent)
+                g.append(lambda pl: geo["ocr"].inst_ent)
             elif kind == "plan_blkoff":
-                g.append(lambda k=desc[1]: geo["ocr"].plans[k].blkoff)
+                g.append(lambda pl, k=desc[1]: geo["ocr"].plans[k].blkoff)
             elif kind == "plan_list":
-                g.append(lambda k=desc[1]: geo["ocr"].plans[k].list)
+                g.append(lambda pl, k=desc[1]: geo["ocr"].plans[k].list)
             elif kind == "plan_lmap":
-                g.append(lambda k=desc[1]: geo["ocr"].plans[k].lmap)
+                g.append(lambda pl, k=desc[1]: geo["ocr"].plans[k].lmap)
             elif kind == "plan_maxnd":
-                g.append(lambda k=desc[1]: geo["ocr"].plans[k].max_nd)
+                g.append(lambda pl, k=desc[1]: geo["ocr"].plans[k].max_nd)
             elif kind == "plan_copy":
-                g.append(lambda k=desc[1], m=desc[2]: self._plan_copy(geo, k, geo["ocr"].plans[m]))
+                g.append(lambda pl, k=desc[1], m=desc[2]: pl._plan_copy(geo, k, geo["ocr"].plans[m]))
             elif kind == "ocr_rblk":
-                g.append(lambda: geo["ocr"].rblk)
+                g.append(lambda pl: geo["ocr"].rblk)
             elif kind == "ocr_rowptr":
-                g.append(lambda k=desc[1]: args[k].data.sparsity._node_rowptr.ptr)
+                g.append(lambda pl, k=desc[1]: args[k].data.sparsity._node_rowptr.ptr)
             elif kind == "ocr_kidx":
-                g.append(lambda: geo["ocr"].kidx.ptr)
+                g.append(lambda pl: geo["ocr"].kidx.ptr)
             elif kind == "ocrs_chunk_role":
-                g.append(lambda: geo["ocr"].chunk_role)
+                g.append(lambda pl: geo["ocr"].chunk_role)
             elif kind in ("ocrs_slot", "ocrs_kk", "ocrs_rowlen", "ocrs_rmask", "ocrs_cmask"):
                 which = {"ocrs_slot": 0, "ocrs_kk": 1, "ocrs_rowlen": 2, "ocrs_rmask": 3, "ocrs_cmask": 4}[kind]
 
-                def ocrs_table(k=desc[1], which=which):
+                def ocrs_table(pl, k=desc[1], which=which):
                     lg = args[k].lgmaps
-                    per_dof = bool(lg) and bool(self.global_kernel.arguments[k].unroll)
-                    return geo["ocr"].tables(lg[0] if lg else None, lg[1] if lg else None, self._lgmap, per_dof=per_dof)[which].ptr
+                    per_dof = bool(lg) and bool(pl.global_kernel.arguments[k].unroll)
+                    return geo["ocr"].tables(lg[0] if lg else None, lg[1] if lg else None, pl._lgmap, per_dof=per_dof)[which].ptr
                 g.append(ocrs_table)
             elif kind == "ocr_maxnnz":
-                g.append(lambda: geo["ocr"].max_nnz)
+                g.append(lambda pl: geo["ocr"].max_nnz)
             elif kind == "ocr_maxnown":
-                g.append(lambda: geo["ocr"].max_nown)
+                g.append(lambda pl: geo["ocr"].max_nown)
             elif kind == "ocr_flags":
-                g.append(lambda: self._ocr_flag)
+                g.append(lambda pl: pl._ocr_flag)
             elif kind == "ocr_prowptr":
-                g.append(lambda: geo["row_order"].prowptr.ptr)
+                g.append(lambda pl: geo["row_order"].prowptr.ptr)
             elif kind == "ocr_nstart":
-                g.append(lambda: geo["row_order"].nstart.ptr)
+                g.append(lambda pl: geo["row_order"].nstart.ptr)
             elif kind == "ocr_gstart":
-                g.append(lambda: geo["row_order"].gstart.ptr)
+                g.append(lambda pl: geo["row_order"].gstart.ptr)
             elif kind == "ocr_srow":
-                g.append(lambda k=desc[1], m=desc[2], dg=len(desc) > 3: self._ocr_node_words(geo, k, m, diag=dg))
+                g.append(lambda pl, k=desc[1], m=desc[2], dg=len(desc) > 3: pl._ocr_node_words(geo, k, m, diag=dg))
             elif kind == "ocr_rec" and src.mode.startswith("ocrs"):
-                def rec_sliced(k=desc[1]):
+                def rec_sliced(pl, k=desc[1]):
                     lbits, kbits, sbits, words = geo["rec"]
                     lg = args[k].lgmaps
-                    return geo["ocr"].records(lg[0] if lg else None, lg[1] if lg else None, self._lgmap, src.staged_maps, lbits, kbits, sbits, words).ptr
+                    return geo["ocr"].records(lg[0] if lg else None, lg[1] if lg else None, pl._lgmap, src.staged_maps, lbits, kbits, sbits, words).ptr
                 g.append(rec_sliced)
             elif kind == "ocr_rec":
-                def rec_whole(k=desc[1]):
+                def rec_whole(pl, k=desc[1]):
                     lbits, kbits, diag, words = geo["rec"]
                     rm_, cm_ = args[k].maps
                     return geo["ocr"].records(src.staged_maps, lbits, kbits, diag, words, rm_.arity, cm_.arity).ptr
                 g.append(rec_whole)
             elif kind in ("ocr_grun", "ocr_brun", "ocr_rdelta"):
-                g.append(lambda w={"ocr_grun": 0, "ocr_brun": 1, "ocr_rdelta": 2}[kind]: geo["runs"][w].ptr)
+                g.append(lambda pl, w={"ocr_grun": 0, "ocr_brun": 1, "ocr_rdelta": 2}[kind]: geo["runs"][w].ptr)
             elif kind == "ocr_gpos":
                 if src.mode.startswith("ocrpm"):
-                    g.append(lambda pa_=args[desc[1]]: geo["row_order"].gpos_masked(pa_.data.sparsity, pa_.lgmaps[1], self._lgmap).ptr)
+                    g.append(lambda pl, pa_=args[desc[1]]: geo["row_order"].gpos_masked(pa_.data.sparsity, pa_.lgmaps[1], pl._lgmap).ptr)
                 else:
-                    g.append(lambda: geo["row_order"].gpos().ptr)
+                    g.append(lambda pl: geo["row_order"].gpos().ptr)
             elif kind == "ocr_npos":
-                g.append(lambda: geo["row_order"].npos)
+                g.append(lambda pl: geo["row_order"].npos)
             elif kind in ("mat_row_lgmap", "mat_col_lgmap"):
-                g.append(lambda pa=args[desc[1]], w=0 if kind == "mat_row_lgmap" else 1: self._lgmap(pa.lgmaps[w]))
+                g.append(lambda pl, pa=args[desc[1]], w=0 if kind == "mat_row_lgmap" else 1: pl._lgmap(pa.lgmaps[w]))
             elif kind in ("virt_col", "virt_layer"):
-                g.append(lambda w=0 if kind == "virt_col" else 1: self._virtual(staged=True).tables_dev()[w].ptr)
+                g.append(lambda pl, w=0 if kind == "virt_col" else 1: pl._virtual(staged=True).tables_dev()[w].ptr)
             elif kind in ("fx_scale", "fx_stat"):
-                g.append(lambda w=0 if kind == "fx_scale" else 1: geo["fx"][w].ptr)
+                g.append(lambda pl, w=0 if kind == "fx_scale" else 1: geo["fx"][w].ptr)
             elif kind == "phase_times":
-                def phase_times():
+                def phase_times(pl):
                     if geo.get("phase_times") is None:
                         geo["phase_times"] = DeviceBuffer(max(geo["ocr"].nblocks, 1) * 40)
                     return geo["phase_times"].ptr

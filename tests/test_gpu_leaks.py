@@ -70,3 +70,22 @@ def test_device_memory_returns_when_a_problem_goes(kind):
         free.append(_free_bytes())
     # the first pass loads code objects and fills the kernel caches (per kernel, not per mesh); from then on nothing may stay behind
     assert min(free[1:]) >= free[1] - (1 << 20) and free[3] >= free[1] - (1 << 20), [f >> 20 for f in free]
+
+
+def test_plans_and_tensors_go_with_the_last_reference():
+    """No reference cycle ties a Parloop to its geometry: with the cycle collector OFF, dropping a problem returns the device memory of
+    its plans, derived orders, instance tables and tensors at once (the argument getters take the Parloop as an argument and are kept
+    on it; closures over ``self`` stored in the geometry would make the memory wait for a full collection)."""
+    gc.collect()
+    run = _poisson(1, 24)
+    run()                                                # code objects, kernel caches
+    gc.collect()
+    before = _free_bytes()
+    gc.disable()
+    try:
+        for _ in range(3):
+            run()
+        after = _free_bytes()
+    finally:
+        gc.enable()
+    assert after >= before - (1 << 20), ((before - after) >> 20, "MB held by garbage the reference counts did not free")
