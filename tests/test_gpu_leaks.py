@@ -72,12 +72,13 @@ def test_device_memory_returns_when_a_problem_goes(kind):
     assert min(free[1:]) >= free[1] - (1 << 20) and free[3] >= free[1] - (1 << 20), [f >> 20 for f in free]
 
 
-def test_plans_and_tensors_go_with_the_last_reference():
+@pytest.mark.parametrize("kind", ["p1", "p2", "dg", "q2_hex"])
+def test_plans_and_tensors_go_with_the_last_reference(kind):
     """No reference cycle ties a Parloop to its geometry: with the cycle collector OFF, dropping a problem returns the device memory of
     its plans, derived orders, instance tables and tensors at once (the argument getters take the Parloop as an argument and are kept
     on it; closures over ``self`` stored in the geometry would make the memory wait for a full collection)."""
     gc.collect()
-    run = _poisson(1, 24)
+    run = {"p1": _poisson(1, 24), "p2": _poisson(2, 12), "dg": _dg, "q2_hex": _q2_hex}[kind]
     run()                                                # code objects, kernel caches
     gc.collect()
     before = _free_bytes()
